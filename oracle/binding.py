@@ -1,0 +1,393 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY. ctypes binding over oracle/liboracle.so.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module. It is the
+checker, never the product: rucene_amd/ must not import it (tests/test_layout.py enforces that).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+# shared 32-byte layout: BlockTermState (oracle/postings.hpp) == rgpu_term_state (include/rucene_gpu.h)
+TERM_STATE_DTYPE = np.dtype(
+    [("doc_start_fp", "<i8"), ("skip_offset", "<i8"), ("total_term_freq", "<i8"), ("doc_freq", "<i4"),
+     ("singleton_doc_id", "<i4")], align=True)
+assert TERM_STATE_DTYPE.itemsize == 32
+
+OP_TERM, OP_AND, OP_OR = 0, 1, 2
+TIE_RUST_HEAP, TIE_CANONICAL = 0, 1
+FLAG_FREQS = 1 << 3
+NO_MORE_DOCS = 2**31 - 1
+
+
+def build(force=False):
+    """Compile oracle/liboracle.so with g++ (make)."""
+    if force or not os.path.exists(_LIB_PATH) or any(
+            os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
+            for f in ("oracle_capi.cpp", "store.hpp", "packed.hpp", "postings.hpp", "search.hpp")):
+        subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        _lib = C.CDLL(_LIB_PATH)
+        _declare(_lib)
+    return _lib
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t)) if a is not None else None
+
+
+def _declare(L):
+    L.orc_last_error.restype = C.c_char_p
+    u8p, u32p, i32p, i64p, f32p, u64p = (C.POINTER(t) for t in (C.c_uint8, C.c_uint32, C.c_int32, C.c_int64, C.c_float, C.c_uint64))
+    vp = C.c_void_p
+    sig = {
+        "orc_bp128_pack": (C.c_int, [u32p, u8p, C.c_int]),
+        "orc_bp128_unpack": (C.c_int, [u8p, u32p, C.c_int]),
+        "orc_bp128_delta_pack": (C.c_int, [u32p, u8p, C.c_uint32, C.c_int]),
+        "orc_bp128_delta_unpack": (C.c_int, [u8p, u32p, C.c_uint32, C.c_int]),
+        "orc_max_bits_num": (C.c_int, [u32p, C.c_int]),
+        "orc_simd_block_advance": (C.c_int, [i32p, C.c_int32]),
+        "orc_max_data_size": (C.c_int, []),
+        "orc_format_fastest": (C.c_int, [C.c_int, C.c_int, C.c_float, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+        "orc_format_byte_count": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
+        "orc_legacy_decode": (C.c_int, [C.c_int, C.c_int, u8p, i32p, C.c_int]),
+        "orc_legacy_encode": (C.c_int, [C.c_int, C.c_int, i32p, u8p, C.c_int]),
+        "orc_legacy_counts": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+        "orc_write_vint": (C.c_int, [C.c_int32, u8p]),
+        "orc_write_vlong": (C.c_int, [C.c_int64, u8p]),
+        "orc_read_vint": (C.c_int, [u8p, C.c_int, i32p]),
+        "orc_read_vlong": (C.c_int, [u8p, C.c_int, i64p]),
+        "orc_crc32": (C.c_uint32, [u8p, C.c_int64]),
+        "orc_float_to_byte315": (C.c_uint8, [C.c_float]),
+        "orc_byte315_to_float": (C.c_float, [C.c_uint8]),
+        "orc_origin_float_to_byte": (C.c_uint8, [C.c_float]),
+        "orc_origin_byte_to_float": (C.c_float, [C.c_uint8]),
+        "orc_norm_table": (C.c_float, [C.c_int]),
+        "orc_bm25_encode_norm": (C.c_uint8, [C.c_float, C.c_int32]),
+        "orc_bm25_idf": (C.c_float, [C.c_int64, C.c_int64, C.c_int64]),
+        "orc_bm25_avgdl": (C.c_float, [C.c_int64, C.c_int64, C.c_int64]),
+        "orc_bm25_weight": (C.c_float, [C.c_float, C.c_float, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_float, f32p]),
+        "orc_bm25_score": (C.c_float, [C.c_float, C.c_float, C.c_float, C.c_int, C.c_float]),
+        "orc_writer_new": (vp, [C.c_int32, C.c_int32, C.c_int, u8p, C.c_char_p]),
+        "orc_writer_free": (None, [vp]),
+        "orc_writer_start_term": (C.c_int, [vp]),
+        "orc_writer_add_docs": (C.c_int, [vp, i32p, i32p, C.c_int64]),
+        "orc_writer_finish_term": (C.c_int, [vp, C.c_int32, C.c_int64, vp]),
+        "orc_writer_close": (C.c_int64, [vp]),
+        "orc_writer_size": (C.c_int64, [vp]),
+        "orc_writer_copy": (C.c_int, [vp, u8p]),
+        "orc_segment_new": (vp, [u8p, C.c_int64, u8p, u64p, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int64, vp, C.c_int64]),
+        "orc_segment_free": (None, [vp]),
+        "orc_segment_version": (C.c_int, [vp]),
+        "orc_postings_new": (vp, [vp, vp, C.c_int]),
+        "orc_postings_free": (None, [vp]),
+        "orc_postings_next": (C.c_int, [vp, i32p]),
+        "orc_postings_advance": (C.c_int, [vp, C.c_int32, i32p]),
+        "orc_postings_freq": (C.c_int32, [vp]),
+        "orc_postings_doc": (C.c_int32, [vp]),
+        "orc_decode_term": (C.c_int64, [vp, vp, i32p, i32p]),
+        "orc_decode_terms": (C.c_double, [vp, vp, C.c_int64, i32p, i32p, C.c_int]),
+        "orc_searcher_new": (vp, [C.POINTER(vp), C.c_int, C.c_float, C.c_float]),
+        "orc_searcher_free": (None, [vp]),
+        "orc_searcher_stats_leaf": (C.c_int, [vp]),
+        "orc_searcher_term_weight": (C.c_float, [vp, C.c_int64, C.c_float, f32p]),
+        "orc_search": (C.c_int, [vp, C.c_int, i64p, C.c_int, f32p, C.c_int, C.c_int, C.c_int, C.c_int, i32p, f32p, i32p, i64p]),
+        "orc_search_batch": (C.c_double, [vp, C.c_int, i32p, i32p, i64p, C.c_int, C.c_int, C.c_int, i32p, f32p, i32p, i64p, u64p]),
+        "orc_mock_conjunction": (C.c_int, [i32p, i32p, C.c_int, C.c_int32, i32p, f32p, C.c_int]),
+        "orc_mock_conjunction_initial_score": (C.c_float, [i32p, i32p, C.c_int]),
+        "orc_mock_disjunction": (C.c_int, [i32p, i32p, C.c_int, C.c_int, i32p, f32p, C.c_int]),
+        "orc_mock_topk": (C.c_int, [i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, i32p, f32p, i64p]),
+        "orc_topk_stream": (C.c_int, [i32p, f32p, C.c_int64, C.c_int, C.c_int, i32p, f32p]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+
+
+class OracleError(RuntimeError):
+    pass
+
+
+def _check(rc):
+    if rc < 0:
+        raise OracleError("oracle error %d: %s" % (rc, lib().orc_last_error().decode()))
+    return rc
+
+
+# ---- packed helpers ------------------------------------------------------------------------------------------------
+def bp128_pack(values, bits):
+    v = np.ascontiguousarray(values, dtype=np.uint32)
+    assert v.size == 128
+    out = np.zeros(512, dtype=np.uint8)
+    _check(lib().orc_bp128_pack(_p(v, C.c_uint32), _p(out, C.c_uint8), bits))
+    return out[:16 * bits].copy()
+
+
+def bp128_unpack(encoded, bits):
+    enc = np.zeros(512 + 16, dtype=np.uint8)
+    enc[:len(encoded)] = encoded
+    out = np.zeros(128, dtype=np.uint32)
+    _check(lib().orc_bp128_unpack(_p(enc, C.c_uint8), _p(out, C.c_uint32), bits))
+    return out
+
+
+def bp128_delta_pack(values, base, bits):
+    v = np.ascontiguousarray(values, dtype=np.uint32)
+    out = np.zeros(512, dtype=np.uint8)
+    _check(lib().orc_bp128_delta_pack(_p(v, C.c_uint32), _p(out, C.c_uint8), base, bits))
+    return out[:16 * bits].copy()
+
+
+def bp128_delta_unpack(encoded, base, bits):
+    enc = np.zeros(512 + 16, dtype=np.uint8)
+    enc[:len(encoded)] = encoded
+    out = np.zeros(128, dtype=np.uint32)
+    _check(lib().orc_bp128_delta_unpack(_p(enc, C.c_uint8), _p(out, C.c_uint32), base, bits))
+    return out
+
+
+def legacy_counts(fmt, bpv):
+    a, b = C.c_int(), C.c_int()
+    lib().orc_legacy_counts(fmt, bpv, C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
+def legacy_decode(fmt, bpv, blocks, iterations):
+    bbc, bvc = legacy_counts(fmt, bpv)
+    enc = np.zeros(max(len(blocks), iterations * bbc) + 8, dtype=np.uint8)
+    enc[:len(blocks)] = blocks
+    out = np.zeros(iterations * bvc + 8, dtype=np.int32)
+    _check(lib().orc_legacy_decode(fmt, bpv, _p(enc, C.c_uint8), _p(out, C.c_int32), iterations))
+    return out[:iterations * bvc]
+
+
+def legacy_encode(fmt, bpv, values, iterations):
+    bbc, bvc = legacy_counts(fmt, bpv)
+    v = np.zeros(iterations * bvc + 8, dtype=np.int32)
+    v[:len(values)] = values
+    out = np.zeros(iterations * bbc + 8, dtype=np.uint8)
+    _check(lib().orc_legacy_encode(fmt, bpv, _p(v, C.c_int32), _p(out, C.c_uint8), iterations))
+    return out[:iterations * bbc]
+
+
+def format_fastest(value_count, bpv, ratio=0.0):
+    f, b = C.c_int(), C.c_int()
+    lib().orc_format_fastest(value_count, bpv, ratio, C.byref(f), C.byref(b))
+    return f.value, b.value
+
+
+# ---- writer ----------------------------------------------------------------------------------------------------------
+class Writer:
+    """Line-faithful Lucene50PostingsWriter (docs+freqs). write_term(docs, freqs) -> term-state record."""
+
+    def __init__(self, max_doc, version=1, write_freqs=True, segment_id=None, suffix="Lucene50_0"):
+        sid = np.frombuffer(segment_id or bytes(range(16)), dtype=np.uint8).copy()
+        self._h = lib().orc_writer_new(max_doc, version, int(write_freqs), _p(sid, C.c_uint8), suffix.encode())
+        if not self._h:
+            raise OracleError(lib().orc_last_error().decode())
+        self.write_freqs = write_freqs
+
+    def write_term(self, docs, freqs):
+        docs = np.ascontiguousarray(docs, dtype=np.int32)
+        freqs = np.ascontiguousarray(freqs, dtype=np.int32)
+        L = lib()
+        _check(L.orc_writer_start_term(self._h))
+        _check(L.orc_writer_add_docs(self._h, _p(docs, C.c_int32), _p(freqs, C.c_int32) if self.write_freqs else None, docs.size))
+        st = np.zeros(1, dtype=TERM_STATE_DTYPE)
+        _check(L.orc_writer_finish_term(self._h, docs.size, int(freqs.sum()), st.ctypes.data))
+        return st[0]
+
+    def close(self):
+        n = _check(lib().orc_writer_close(self._h))
+        out = np.zeros(n, dtype=np.uint8)
+        lib().orc_writer_copy(self._h, _p(out, C.c_uint8))
+        return out
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_writer_free(self._h)
+            self._h = None
+
+
+# ---- segment / searcher --------------------------------------------------------------------------------------------
+class Segment:
+    def __init__(self, doc_bytes, norms, max_doc, terms, doc_base=0, live_docs=None, doc_count=None,
+                 sum_total_term_freq=0, sum_doc_freq=0):
+        self.doc_bytes = np.ascontiguousarray(doc_bytes, dtype=np.uint8)
+        self.norms = None if norms is None else np.ascontiguousarray(norms, dtype=np.uint8)
+        self.live_docs = None if live_docs is None else np.ascontiguousarray(live_docs, dtype=np.uint64)
+        self.terms = np.ascontiguousarray(terms, dtype=TERM_STATE_DTYPE)
+        self.max_doc, self.doc_base = int(max_doc), int(doc_base)
+        self.doc_count = int(max_doc if doc_count is None else doc_count)
+        self.sum_total_term_freq = int(sum_total_term_freq)
+        self._h = lib().orc_segment_new(
+            _p(self.doc_bytes, C.c_uint8), self.doc_bytes.size, _p(self.norms, C.c_uint8), _p(self.live_docs, C.c_uint64),
+            self.max_doc, self.doc_base, self.doc_count, self.sum_total_term_freq, int(sum_doc_freq),
+            self.terms.ctypes.data, self.terms.size)
+        if not self._h:
+            raise OracleError(lib().orc_last_error().decode())
+
+    @property
+    def version(self):
+        return lib().orc_segment_version(self._h)
+
+    def decode_term(self, state):
+        st = np.array([state], dtype=TERM_STATE_DTYPE)
+        n = int(st[0]["doc_freq"])
+        docs = np.zeros(n + 1, dtype=np.int32)
+        freqs = np.zeros(n + 1, dtype=np.int32)
+        got = _check(lib().orc_decode_term(self._h, st.ctypes.data, _p(docs, C.c_int32), _p(freqs, C.c_int32)))
+        assert got == n, (got, n)
+        return docs[:n], freqs[:n]
+
+    def decode_terms(self, states, threads=1):
+        sts = np.ascontiguousarray(states, dtype=TERM_STATE_DTYPE)
+        total = int(sts["doc_freq"].sum())
+        docs = np.zeros(total + 1, dtype=np.int32)
+        freqs = np.zeros(total + 1, dtype=np.int32)
+        secs = lib().orc_decode_terms(self._h, sts.ctypes.data, sts.size, _p(docs, C.c_int32), _p(freqs, C.c_int32), threads)
+        return docs[:total], freqs[:total], secs
+
+    def postings(self, state, flags=FLAG_FREQS):
+        return Postings(self, state, flags)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_segment_free(self._h)
+            self._h = None
+
+
+class Postings:
+    def __init__(self, seg, state, flags):
+        self._seg = seg
+        self._st = np.array([state], dtype=TERM_STATE_DTYPE)
+        self._h = lib().orc_postings_new(seg._h, self._st.ctypes.data, flags)
+
+    def next(self):
+        d = C.c_int32()
+        _check(lib().orc_postings_next(self._h, C.byref(d)))
+        return d.value
+
+    def advance(self, target):
+        d = C.c_int32()
+        _check(lib().orc_postings_advance(self._h, target, C.byref(d)))
+        return d.value
+
+    def freq(self):
+        return lib().orc_postings_freq(self._h)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_postings_free(self._h)
+            self._h = None
+
+
+class Searcher:
+    def __init__(self, segments, k1=1.2, b=0.75):
+        self.segments = list(segments)
+        arr = (C.c_void_p * len(self.segments))(*[s._h for s in self.segments])
+        self._h = lib().orc_searcher_new(arr, len(self.segments), k1, b)
+        if not self._h:
+            raise OracleError(lib().orc_last_error().decode())
+
+    def term_weight(self, term_id, boost=1.0):
+        cache = np.zeros(256, dtype=np.float32)
+        w = lib().orc_searcher_term_weight(self._h, term_id, boost, _p(cache, C.c_float))
+        return w, cache
+
+    def search(self, op, term_ids, k, tie_mode=TIE_CANONICAL, boosts=None, min_should_match=0, max_collect_per_leaf=0):
+        t = np.ascontiguousarray(term_ids, dtype=np.int64)
+        b = None if boosts is None else np.ascontiguousarray(boosts, dtype=np.float32)
+        docs = np.zeros(max(k, 1), dtype=np.int32)
+        scores = np.zeros(max(k, 1), dtype=np.float32)
+        n, total = C.c_int32(), C.c_int64()
+        _check(lib().orc_search(self._h, op, _p(t, C.c_int64), t.size, _p(b, C.c_float), min_should_match, k, tie_mode,
+                                max_collect_per_leaf, _p(docs, C.c_int32), _p(scores, C.c_float), C.byref(n), C.byref(total)))
+        return docs[:n.value].copy(), scores[:n.value].copy(), total.value
+
+    def search_batch(self, ops, term_offsets, term_ids, k, tie_mode=TIE_CANONICAL, threads=1):
+        ops = np.ascontiguousarray(ops, dtype=np.int32)
+        offs = np.ascontiguousarray(term_offsets, dtype=np.int32)
+        tids = np.ascontiguousarray(term_ids, dtype=np.int64)
+        nq = ops.size
+        docs = np.full((nq, k), -1, dtype=np.int32)
+        scores = np.zeros((nq, k), dtype=np.float32)
+        counts = np.zeros(nq, dtype=np.int32)
+        totals = np.zeros(nq, dtype=np.int64)
+        visited = np.zeros(nq, dtype=np.uint64)
+        secs = lib().orc_search_batch(self._h, nq, _p(ops, C.c_int32), _p(offs, C.c_int32), _p(tids, C.c_int64), k, tie_mode,
+                                      threads, _p(docs, C.c_int32), _p(scores, C.c_float), _p(counts, C.c_int32),
+                                      _p(totals, C.c_int64), _p(visited, C.c_uint64))
+        if secs < 0:
+            raise OracleError(lib().orc_last_error().decode())
+        return docs, scores, counts, totals, visited, secs
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_searcher_free(self._h)
+            self._h = None
+
+
+# ---- mock KAT probes -----------------------------------------------------------------------------------------------
+def _lists(lists):
+    flat = np.concatenate([np.asarray(l, dtype=np.int32) for l in lists]) if lists else np.zeros(0, np.int32)
+    offs = np.zeros(len(lists) + 1, dtype=np.int32)
+    offs[1:] = np.cumsum([len(l) for l in lists])
+    return np.ascontiguousarray(flat), offs
+
+
+def mock_conjunction(lists, advance_first=-1):
+    flat, offs = _lists(lists)
+    docs = np.zeros(flat.size + 1, np.int32)
+    scores = np.zeros(flat.size + 1, np.float32)
+    n = _check(lib().orc_mock_conjunction(_p(flat, C.c_int32), _p(offs, C.c_int32), len(lists), advance_first,
+                                          _p(docs, C.c_int32), _p(scores, C.c_float), docs.size))
+    return docs[:n].tolist(), scores[:n].tolist()
+
+
+def mock_conjunction_initial_score(lists):
+    flat, offs = _lists(lists)
+    return lib().orc_mock_conjunction_initial_score(_p(flat, C.c_int32), _p(offs, C.c_int32), len(lists))
+
+
+def mock_disjunction(lists, min_should_match=1):
+    flat, offs = _lists(lists)
+    docs = np.zeros(flat.size + 1, np.int32)
+    scores = np.zeros(flat.size + 1, np.float32)
+    n = _check(lib().orc_mock_disjunction(_p(flat, C.c_int32), _p(offs, C.c_int32), len(lists), min_should_match,
+                                          _p(docs, C.c_int32), _p(scores, C.c_float), docs.size))
+    return docs[:n].tolist(), scores[:n].tolist()
+
+
+def mock_topk(docs, k, n_leaves=1, max_collect_per_leaf=0, tie_mode=TIE_RUST_HEAP, use_bulk_scorer=False):
+    d = np.ascontiguousarray(docs, dtype=np.int32)
+    od = np.zeros(k + 1, np.int32)
+    os_ = np.zeros(k + 1, np.float32)
+    total = C.c_int64()
+    n = _check(lib().orc_mock_topk(_p(d, C.c_int32), d.size, n_leaves, max_collect_per_leaf, k, tie_mode, int(use_bulk_scorer),
+                                   _p(od, C.c_int32), _p(os_, C.c_float), C.byref(total)))
+    return od[:n].tolist(), os_[:n].tolist(), total.value
+
+
+def topk_stream(docs, scores, k, tie_mode):
+    d = np.ascontiguousarray(docs, dtype=np.int32)
+    s = np.ascontiguousarray(scores, dtype=np.float32)
+    od = np.zeros(k + 1, np.int32)
+    os_ = np.zeros(k + 1, np.float32)
+    n = _check(lib().orc_topk_stream(_p(d, C.c_int32), _p(s, C.c_float), d.size, k, tie_mode, _p(od, C.c_int32), _p(os_, C.c_float)))
+    return od[:n].copy(), os_[:n].copy()

@@ -1,0 +1,342 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY. Not shipped, not on the product path.
+// extern "C" surface over the oracle headers so tests/ (ctypes), __graft_entry__.smoke() and bench.py's
+// cpu_baseline leg can drive the CPU restatement of Rucene's query path. Nothing in rucene_amd/ may link or
+// load this library.
+#include <atomic>
+#include <chrono>
+#include <string>
+#include <thread>
+
+#include "packed.hpp"
+#include "postings.hpp"
+#include "search.hpp"
+#include "store.hpp"
+
+using namespace orc;
+
+static thread_local std::string g_err;
+#define ORC_TRY try {
+#define ORC_CATCH                                                        \
+  }                                                                      \
+  catch (const OracleError& e) { g_err = e.what(); return -e.kind; }     \
+  catch (const std::exception& e) { g_err = e.what(); return -100; }
+
+extern "C" {
+
+const char* orc_last_error() { return g_err.c_str(); }
+
+// ---- packed KAT surface --------------------------------------------------------------------------------------
+int orc_bp128_pack(const uint32_t* data, uint8_t* out, int bits) { ORC_TRY Simd128Packer::pack(data, out, bits); return 0; ORC_CATCH }
+int orc_bp128_unpack(const uint8_t* in, uint32_t* out, int bits) { ORC_TRY Simd128Packer::unpack(in, out, bits); return 0; ORC_CATCH }
+int orc_bp128_delta_pack(const uint32_t* data, uint8_t* out, uint32_t base, int bits) {
+  ORC_TRY Simd128Packer p; p.delta_pack(data, out, base, bits); return 0; ORC_CATCH
+}
+int orc_bp128_delta_unpack(const uint8_t* in, uint32_t* out, uint32_t base, int bits) {
+  ORC_TRY Simd128Packer p; p.delta_unpack(in, out, base, bits); return 0; ORC_CATCH
+}
+int orc_max_bits_num(const uint32_t* data, int n) { return Simd128Packer::max_bits_num(data, n); }
+int orc_simd_block_advance(const int32_t* block, int32_t target) { return simd_block_advance(block, target); }
+int orc_max_data_size() { return max_data_size(); }
+int orc_format_fastest(int value_count, int bpv, float ratio, int* out_format, int* out_bpv) {
+  FormatAndBits fb = format_fastest(value_count, bpv, ratio);
+  *out_format = fb.format; *out_bpv = fb.bits_per_value;
+  return 0;
+}
+int64_t orc_format_byte_count(int format, int value_count, int bpv) { return format_byte_count(format, value_count, bpv); }
+// legacy decoders/encoders: `n_bytes`/`n_values` are derived by the caller from iterations
+int orc_legacy_decode(int format, int bpv, const uint8_t* blocks, int32_t* values, int iterations) {
+  ORC_TRY
+  if (format == FMT_PACKED) BulkOperationPacked(bpv).decode_byte_to_int(blocks, values, iterations);
+  else BulkOperationPackedSingleBlock(bpv).decode_byte_to_int(blocks, values, iterations);
+  return 0;
+  ORC_CATCH
+}
+int orc_legacy_encode(int format, int bpv, const int32_t* values, uint8_t* blocks, int iterations) {
+  ORC_TRY
+  if (format == FMT_PACKED) BulkOperationPacked(bpv).encode_int_to_byte(values, blocks, iterations);
+  else BulkOperationPackedSingleBlock(bpv).encode_int_to_byte(values, blocks, iterations);
+  return 0;
+  ORC_CATCH
+}
+int orc_legacy_counts(int format, int bpv, int* byte_block_count, int* byte_value_count) {
+  if (format == FMT_PACKED) { BulkOperationPacked p(bpv); *byte_block_count = p.byte_block_count; *byte_value_count = p.byte_value_count; }
+  else { BulkOperationPackedSingleBlock p(bpv); *byte_block_count = p.byte_block_count(); *byte_value_count = p.byte_value_count(); }
+  return 0;
+}
+
+// ---- vint grammar --------------------------------------------------------------------------------------------
+int orc_write_vint(int32_t v, uint8_t* out) { ByteOut o; o.write_vint(v); std::memcpy(out, o.buf.data(), o.buf.size()); return (int)o.buf.size(); }
+int orc_write_vlong(int64_t v, uint8_t* out) {
+  ORC_TRY ByteOut o; o.write_vlong(v); std::memcpy(out, o.buf.data(), o.buf.size()); return (int)o.buf.size(); ORC_CATCH
+}
+int orc_read_vint(const uint8_t* in, int len, int32_t* v) { ORC_TRY ByteIn i(in, len); *v = i.read_vint(); return (int)i.pos; ORC_CATCH }
+int orc_read_vlong(const uint8_t* in, int len, int64_t* v) { ORC_TRY ByteIn i(in, len); *v = i.read_vlong(); return (int)i.pos; ORC_CATCH }
+uint32_t orc_crc32(const uint8_t* p, int64_t n) { return crc32_ieee(p, (size_t)n); }
+
+// ---- small float / BM25 --------------------------------------------------------------------------------------
+uint8_t orc_float_to_byte315(float f) { return float_to_byte315(f); }
+float orc_byte315_to_float(uint8_t b) { return byte315_to_float(b); }
+uint8_t orc_origin_float_to_byte(float f) { return origin_float_to_byte(f); }
+float orc_origin_byte_to_float(uint8_t b) { return origin_byte_to_float(b); }
+float orc_norm_table(int i) { return norm_table()[i & 255]; }
+uint8_t orc_bm25_encode_norm(float boost, int32_t field_length) { return bm25_encode_norm_value(boost, field_length); }
+float orc_bm25_idf(int64_t doc_freq, int64_t max_doc, int64_t doc_count) {
+  CollectionStatistics cs; cs.max_doc = max_doc; cs.doc_count = doc_count;
+  TermStatistics ts; ts.doc_freq = doc_freq;
+  return bm25_idf(&ts, 1, cs);
+}
+float orc_bm25_avgdl(int64_t max_doc, int64_t doc_count, int64_t sum_ttf) {
+  CollectionStatistics cs; cs.max_doc = max_doc; cs.doc_count = doc_count; cs.sum_total_term_freq = sum_ttf;
+  return bm25_avg_field_length(cs);
+}
+// compute_weight for one term: returns weight (= idf*boost), fills cache[256]
+float orc_bm25_weight(float k1, float b, int64_t max_doc, int64_t doc_count, int64_t sum_ttf, int64_t doc_freq,
+                      float boost, float* cache_out) {
+  CollectionStatistics cs; cs.max_doc = max_doc; cs.doc_count = doc_count; cs.sum_total_term_freq = sum_ttf;
+  TermStatistics ts; ts.doc_freq = doc_freq;
+  BM25Weight w = bm25_compute_weight(k1, b, cs, &ts, 1, boost);
+  if (cache_out) std::memcpy(cache_out, w.cache, sizeof(w.cache));
+  return w.weight;
+}
+float orc_bm25_score(float weight, float k1, float freq, int has_norms, float norm_cache) {
+  return bm25_compute_score(weight, k1, freq, has_norms != 0, norm_cache);
+}
+
+// ---- writer ----------------------------------------------------------------------------------------------------
+struct orc_writer { PostingsWriter w; };
+orc_writer* orc_writer_new(int32_t max_doc, int32_t version, int write_freqs, const uint8_t* segment_id16, const char* suffix) {
+  try { return new orc_writer{PostingsWriter(max_doc, version, write_freqs != 0, segment_id16, suffix ? suffix : "")}; }
+  catch (const std::exception& e) { g_err = e.what(); return nullptr; }
+}
+void orc_writer_free(orc_writer* w) { delete w; }
+int orc_writer_start_term(orc_writer* w) { ORC_TRY w->w.start_term(); return 0; ORC_CATCH }
+// start_doc + finish_doc for a batch of postings of the current term
+int orc_writer_add_docs(orc_writer* w, const int32_t* docs, const int32_t* freqs, int64_t n) {
+  ORC_TRY
+  for (int64_t i = 0; i < n; i++) { w->w.start_doc(docs[i], freqs ? freqs[i] : -1); w->w.finish_doc(); }
+  return 0;
+  ORC_CATCH
+}
+int orc_writer_finish_term(orc_writer* w, int32_t doc_freq, int64_t total_term_freq, BlockTermState* out) {
+  ORC_TRY
+  BlockTermState st; st.doc_freq = doc_freq; st.total_term_freq = total_term_freq;
+  w->w.finish_term(st);
+  *out = st;
+  return 0;
+  ORC_CATCH
+}
+int64_t orc_writer_close(orc_writer* w) { ORC_TRY w->w.close(); return w->w.doc_out.file_pointer(); ORC_CATCH }
+int64_t orc_writer_size(orc_writer* w) { return w->w.doc_out.file_pointer(); }
+int orc_writer_copy(orc_writer* w, uint8_t* out) { std::memcpy(out, w->w.doc_out.buf.data(), w->w.doc_out.buf.size()); return 0; }
+
+// ---- segment / postings iterator -------------------------------------------------------------------------------
+struct orc_segment { Segment s; };
+orc_segment* orc_segment_new(const uint8_t* doc_bytes, int64_t doc_len, const uint8_t* norms, const uint64_t* live_docs,
+                             int32_t max_doc, int32_t doc_base, int64_t doc_count, int64_t sum_ttf, int64_t sum_df,
+                             const BlockTermState* terms, int64_t n_terms) {
+  try {
+    orc_segment* seg = new orc_segment();
+    seg->s.reader.reset(new PostingsReader(doc_bytes, doc_len));
+    seg->s.norms = norms; seg->s.live_docs = live_docs; seg->s.max_doc = max_doc; seg->s.doc_base = doc_base;
+    seg->s.doc_count = doc_count; seg->s.sum_total_term_freq = sum_ttf; seg->s.sum_doc_freq = sum_df;
+    seg->s.terms = terms; seg->s.n_terms = n_terms;
+    return seg;
+  } catch (const std::exception& e) { g_err = e.what(); return nullptr; }
+}
+void orc_segment_free(orc_segment* s) { delete s; }
+int orc_segment_version(orc_segment* s) { return s->s.reader->version; }
+
+struct orc_postings { BlockDocIterator it; };
+orc_postings* orc_postings_new(orc_segment* seg, const BlockTermState* st, int flags) {
+  try { return new orc_postings{BlockDocIterator(seg->s.reader.get(), true, *st, (uint16_t)flags)}; }
+  catch (const std::exception& e) { g_err = e.what(); return nullptr; }
+}
+void orc_postings_free(orc_postings* p) { delete p; }
+int orc_postings_next(orc_postings* p, int32_t* doc) { ORC_TRY *doc = p->it.next(); return 0; ORC_CATCH }
+int orc_postings_advance(orc_postings* p, int32_t target, int32_t* doc) { ORC_TRY *doc = p->it.advance(target); return 0; ORC_CATCH }
+int32_t orc_postings_freq(orc_postings* p) { return p->it.freq(); }
+int32_t orc_postings_doc(orc_postings* p) { return p->it.doc_id(); }
+// full sequential decode of one term through BlockDocIterator::next
+int64_t orc_decode_term(orc_segment* seg, const BlockTermState* st, int32_t* docs_out, int32_t* freqs_out) {
+  ORC_TRY
+  BlockDocIterator it(seg->s.reader.get(), true, *st, FLAG_FREQS);
+  int64_t n = 0;
+  while (true) {
+    int32_t d = it.next();
+    if (d == NO_MORE_DOCS) break;
+    docs_out[n] = d; freqs_out[n] = it.freq(); n++;
+  }
+  return n;
+  ORC_CATCH
+}
+// decode many terms back-to-back into concatenated outputs; returns seconds spent (for the CPU baseline leg)
+double orc_decode_terms(orc_segment* seg, const BlockTermState* sts, int64_t n_terms, int32_t* docs_out, int32_t* freqs_out,
+                        int threads) {
+  std::vector<int64_t> offs((size_t)n_terms + 1, 0);
+  for (int64_t i = 0; i < n_terms; i++) offs[(size_t)i + 1] = offs[(size_t)i] + sts[i].doc_freq;
+  std::atomic<int64_t> next_term{0};
+  auto t0 = std::chrono::steady_clock::now();
+  auto work = [&]() {
+    while (true) {
+      int64_t i = next_term.fetch_add(1);
+      if (i >= n_terms) break;
+      try {
+        BlockDocIterator it(seg->s.reader.get(), true, sts[i], FLAG_FREQS);
+        int64_t n = offs[(size_t)i];
+        while (true) {
+          int32_t d = it.next();
+          if (d == NO_MORE_DOCS) break;
+          docs_out[n] = d; freqs_out[n] = it.freq(); n++;
+        }
+      } catch (...) {}
+    }
+  };
+  std::vector<std::thread> th;
+  for (int t = 1; t < threads; t++) th.emplace_back(work);
+  work();
+  for (auto& t : th) t.join();
+  return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+// ---- searcher ----------------------------------------------------------------------------------------------------
+struct orc_searcher { IndexSearcher s; };
+orc_searcher* orc_searcher_new(orc_segment** segs, int n, float k1, float b) {
+  try {
+    std::vector<Segment*> leaves;
+    for (int i = 0; i < n; i++) leaves.push_back(&segs[i]->s);
+    orc_searcher* s = new orc_searcher{IndexSearcher(leaves)};
+    s->s.k1 = k1; s->s.b = b;
+    return s;
+  } catch (const std::exception& e) { g_err = e.what(); return nullptr; }
+}
+void orc_searcher_free(orc_searcher* s) { delete s; }
+int orc_searcher_stats_leaf(orc_searcher* s) { return s->s.stats_leaf; }
+float orc_searcher_term_weight(orc_searcher* s, int64_t term_id, float boost, float* cache_out) {
+  BM25Weight w = s->s.term_weight(term_id, boost);
+  if (cache_out) std::memcpy(cache_out, w.cache, sizeof(w.cache));
+  return w.weight;
+}
+
+static Query make_query(int op, const int64_t* term_ids, int n_terms, const float* boosts, int msm) {
+  Query q; q.op = op; q.min_should_match = msm;
+  q.term_ids.assign(term_ids, term_ids + n_terms);
+  if (boosts) q.boosts.assign(boosts, boosts + n_terms);
+  return q;
+}
+
+int orc_search(orc_searcher* s, int op, const int64_t* term_ids, int n_terms, const float* boosts, int msm, int k,
+               int tie_mode, int max_collect_per_leaf, int32_t* out_docs, float* out_scores, int32_t* out_n,
+               int64_t* out_total) {
+  ORC_TRY
+  SearchResult r = s->s.search(make_query(op, term_ids, n_terms, boosts, msm), (size_t)k, tie_mode, max_collect_per_leaf);
+  *out_n = (int32_t)r.hits.size();
+  *out_total = r.total_hits;
+  for (size_t i = 0; i < r.hits.size(); i++) { out_docs[i] = r.hits[i].doc; out_scores[i] = r.hits[i].score; }
+  return 0;
+  ORC_CATCH
+}
+
+// Batch: one query per task, `threads` worker threads pulling from a shared counter (Rucene: one core per
+// query per segment, searcher shared across threads — searcher.rs:527-630 falls back to sequential search
+// for a single large segment). Returns elapsed seconds; fills per-query outputs.
+double orc_search_batch(orc_searcher* s, int n_queries, const int32_t* ops, const int32_t* term_offsets,
+                        const int64_t* term_ids, int k, int tie_mode, int threads, int32_t* out_docs, float* out_scores,
+                        int32_t* out_counts, int64_t* out_totals, uint64_t* out_visited) {
+  std::atomic<int> next_q{0};
+  std::atomic<int> failed{0};
+  auto t0 = std::chrono::steady_clock::now();
+  auto work = [&]() {
+    while (true) {
+      int qi = next_q.fetch_add(1);
+      if (qi >= n_queries) break;
+      try {
+        int n_terms = term_offsets[qi + 1] - term_offsets[qi];
+        SearchResult r = s->s.search(make_query(ops[qi], term_ids + term_offsets[qi], n_terms, nullptr, 0), (size_t)k, tie_mode);
+        out_counts[qi] = (int32_t)r.hits.size();
+        out_totals[qi] = r.total_hits;
+        if (out_visited) out_visited[qi] = r.postings_visited;
+        for (size_t i = 0; i < r.hits.size(); i++) {
+          out_docs[(size_t)qi * (size_t)k + i] = r.hits[i].doc;
+          out_scores[(size_t)qi * (size_t)k + i] = r.hits[i].score;
+        }
+      } catch (const std::exception& e) { failed++; }
+    }
+  };
+  std::vector<std::thread> th;
+  for (int t = 1; t < threads; t++) th.emplace_back(work);
+  work();
+  for (auto& t : th) t.join();
+  double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  if (failed.load() > 0) { g_err = "search failed for some queries"; return -1.0; }
+  return el;
+}
+
+// ---- mock-scorer KATs (reference unit tests restated as callable probes) ---------------------------------------
+// conjunction_scorer.rs:162-222: children given as concatenated doc lists; emits (doc, score) via next() until end.
+int orc_mock_conjunction(const int32_t* docs, const int32_t* list_offsets, int n_lists, int32_t advance_first,
+                         int32_t* out_docs, float* out_scores, int max_out) {
+  ORC_TRY
+  std::vector<ScorerBox> ch;
+  for (int i = 0; i < n_lists; i++)
+    ch.emplace_back(new MockScorer(std::vector<int32_t>(docs + list_offsets[i], docs + list_offsets[i + 1])));
+  ConjunctionScorer c(std::move(ch));
+  int n = 0;
+  int32_t d = advance_first >= 0 ? c.advance(advance_first) : c.next();
+  while (d != NO_MORE_DOCS && n < max_out) { out_docs[n] = d; out_scores[n] = c.score(); n++; d = c.next(); }
+  return n;
+  ORC_CATCH
+}
+float orc_mock_conjunction_initial_score(const int32_t* docs, const int32_t* list_offsets, int n_lists) {
+  std::vector<ScorerBox> ch;
+  for (int i = 0; i < n_lists; i++)
+    ch.emplace_back(new MockScorer(std::vector<int32_t>(docs + list_offsets[i], docs + list_offsets[i + 1])));
+  ConjunctionScorer c(std::move(ch));
+  return c.score();  // doc_id == -1 for every child -> -1 * n
+}
+int orc_mock_disjunction(const int32_t* docs, const int32_t* list_offsets, int n_lists, int msm, int32_t* out_docs,
+                         float* out_scores, int max_out) {
+  ORC_TRY
+  std::vector<ScorerBox> ch;
+  for (int i = 0; i < n_lists; i++)
+    ch.emplace_back(new MockScorer(std::vector<int32_t>(docs + list_offsets[i], docs + list_offsets[i + 1])));
+  DisjunctionSumScorer c(std::move(ch), true, msm);
+  int n = 0;
+  int32_t d = c.next();
+  while (d != NO_MORE_DOCS && n < max_out) { out_docs[n] = d; out_scores[n] = c.score(); n++; d = c.next(); }
+  return n;
+  ORC_CATCH
+}
+// top_docs.rs:235-264 / bulk_scorer.rs:167-200 / searcher.rs:916-952: `n_leaves` leaves with doc bases
+// 0,10,20,..., the same mock doc list in each, optional per-leaf early termination.
+int orc_mock_topk(const int32_t* docs, int n_docs, int n_leaves, int max_collect_per_leaf, int k, int tie_mode,
+                  int use_bulk_scorer, int32_t* out_docs, float* out_scores, int64_t* out_total) {
+  ORC_TRY
+  TopDocsCollector collector((size_t)k, tie_mode);
+  for (int l = 0; l < n_leaves; l++) {
+    MockScorer sc(std::vector<int32_t>(docs, docs + n_docs));
+    collector.cur_doc_base = l * 10;
+    if (use_bulk_scorer) {
+      bulk_score(&sc, &collector, nullptr, 0, NO_MORE_DOCS, max_collect_per_leaf);
+    } else {
+      while (true) { int32_t d = sc.next(); if (d == NO_MORE_DOCS) break; collector.collect(d, &sc); }
+    }
+  }
+  *out_total = (int64_t)collector.total_hits;
+  std::vector<ScoreDoc> r = collector.top_docs();
+  for (size_t i = 0; i < r.size(); i++) { out_docs[i] = r[i].doc; out_scores[i] = r[i].score; }
+  return (int)r.size();
+  ORC_CATCH
+}
+// feed an explicit (doc, score) stream to the collector (tie-behaviour probes)
+int orc_topk_stream(const int32_t* docs, const float* scores, int64_t n, int k, int tie_mode, int32_t* out_docs,
+                    float* out_scores) {
+  ORC_TRY
+  TopDocsCollector collector((size_t)k, tie_mode);
+  for (int64_t i = 0; i < n; i++) { collector.add_doc(docs[i], scores[i]); collector.total_hits++; }
+  std::vector<ScoreDoc> r = collector.top_docs();
+  for (size_t i = 0; i < r.size(); i++) { out_docs[i] = r[i].doc; out_scores[i] = r[i].score; }
+  return (int)r.size();
+  ORC_CATCH
+}
+
+}  // extern "C"

@@ -1,0 +1,292 @@
+"""Known-answer tests that pin the oracle against every golden vector the reference's own unit tests hold for
+the hot path. Each test cites the reference test it restates
+(paths relative to /root/reference/src/core). CPU only."""
+import math
+import struct
+
+import numpy as np
+import pytest
+
+
+# ---- util/packed/packed_simd.rs ------------------------------------------------------------------------------------
+def test_max_bits_num(oracle):
+    # packed_simd.rs:404-422 test_max_bits_num
+    import ctypes as C
+    L = oracle.lib()
+
+    def mbn(vals):
+        a = np.asarray(vals, dtype=np.uint32)
+        return L.orc_max_bits_num(a.ctypes.data_as(C.POINTER(C.c_uint32)), a.size)
+
+    assert mbn([5, 8, 7]) == 4
+    assert mbn([0b10101, 0b111, 0b11101]) == 5
+    assert mbn([0b10101, 0b1000000111, 0b11101]) == 10
+    data = np.arange(128, dtype=np.uint32) * 5
+    assert mbn(data) == int(data.max()).bit_length()
+
+
+def test_pack_unpack_bits(oracle):
+    # packed_simd.rs:470-505 test_pack_unpack_bits
+    d1 = np.zeros(128, np.uint32)
+    d5 = np.zeros(128, np.uint32)
+    d31 = np.zeros(128, np.uint32)
+    for i in range(0, 128, 5):
+        d1[i] = 1
+        d5[i] = 0b10000 | (i & 0b1111)
+        d31[i] = 0x40000000 | i
+    dec = oracle.bp128_unpack(oracle.bp128_pack(d1, 1), 1)
+    assert (dec == d1).all()
+    assert [dec[i] for i in (0, 1, 4, 5, 6, 34, 35, 36)] == [1, 0, 0, 1, 0, 0, 1, 0]
+    dec = oracle.bp128_unpack(oracle.bp128_pack(d5, 5), 5)
+    assert (dec == d5).all() and dec[35] == (0b10000 | (35 & 0b1111))
+    dec = oracle.bp128_unpack(oracle.bp128_pack(d31, 31), 31)
+    assert (dec == d31).all() and dec[40] == (0x40000000 | 40)
+
+
+def test_direct_copy_32_bits(oracle):
+    # packed_simd.rs:424-443 test_direct_copy
+    data = np.array([i % 9 * (i + 1) for i in range(128)], dtype=np.uint32)
+    enc = oracle.bp128_pack(data, 32)
+    assert enc.size == 512 and enc.tobytes() == data.tobytes()
+    dec = oracle.bp128_unpack(enc, 32)
+    assert dec[0] == 0 and dec[1] == 2 and dec[9] == 0 and dec[10] == 11
+    assert (dec == data).all()
+
+
+def test_delta_pack_unpack(oracle):
+    # packed_simd.rs:507-525 test_delta_pack_unpack
+    data = (np.arange(1, 129, dtype=np.uint32)) * 128
+    assert data[127] == 128 * 128
+    assert (oracle.bp128_unpack(oracle.bp128_pack(data, 15), 15) == data).all()
+    assert (oracle.bp128_delta_unpack(oracle.bp128_delta_pack(data, 128, 14), 128, 14) == data).all()
+
+
+def _bp128_layout_formula(values, b):
+    """value i=4r+l occupies bits [r*b,(r+1)*b) of lane l's LE bitstream whose 32-bit word w
+    sits at output dword 4w+l. Independent restatement used to cross-check the macro restatement."""
+    out = np.zeros(4 * b, dtype=np.uint32)
+    for i, v in enumerate(values):
+        r, l = divmod(i, 4)
+        p = r * b
+        w, s = divmod(p, 32)
+        out[4 * w + l] |= np.uint32((int(v) << s) & 0xFFFFFFFF)
+        if s + b > 32:
+            out[4 * (w + 1) + l] |= np.uint32(int(v) >> (32 - s))
+    return out.view(np.uint8)
+
+
+@pytest.mark.parametrize("b", list(range(1, 33)))
+def test_bp128_layout_all_widths(oracle, b):
+    rng = np.random.default_rng(1000 + b)
+    vals = rng.integers(0, 2**b, size=128, dtype=np.uint64).astype(np.uint32)
+    vals[rng.integers(0, 128)] = (2**b - 1)
+    enc = oracle.bp128_pack(vals, b)
+    assert enc.size == 16 * b
+    assert enc.tobytes() == _bp128_layout_formula(vals, b).tobytes()
+    assert (oracle.bp128_unpack(enc, b) == vals).all()
+
+
+# ---- codec/postings/simd_block_decoder.rs --------------------------------------------------------------------------
+def test_simd_advance(oracle):
+    # simd_block_decoder.rs:168-196 test_simd_advance / test_binary_search: data = 128*(i+1)
+    import ctypes as C
+    data = (np.arange(1, 129, dtype=np.int32)) * 128
+
+    def adv(t):
+        pos = oracle.lib().orc_simd_block_advance(data.ctypes.data_as(C.POINTER(C.c_int32)), t)
+        return int(data[pos]), pos
+
+    assert adv(1) == (128, 0)
+    assert adv(129) == (256, 1)
+    assert adv(130)[0] == 256 and adv(255)[0] == 256 and adv(256)[0] == 256
+    assert adv(257)[0] == 384
+    assert adv(512) == (512, 3)
+    assert adv(16283)[0] == 16384
+
+
+# ---- codec/postings/partial_block_decoder.rs (legacy bit order) ----------------------------------------------------
+def test_legacy_packed_bit_order(oracle):
+    # partial_block_decoder.rs:128-141: bytes FF FF 00 FF @4 bits -> F F F F 0 0 F F
+    out = oracle.legacy_decode(0, 4, np.array([0xFF, 0xFF, 0, 0xFF], np.uint8), 4)
+    assert out[:8].tolist() == [0xF, 0xF, 0xF, 0xF, 0, 0, 0xF, 0xF]
+
+
+def test_legacy_psb_bit_order(oracle):
+    # partial_block_decoder.rs:143-152, 166-180: 16-byte PackedSingleBlock vector @6 bits
+    data = np.array([0xFF, 0xF, 0, 0, 0, 0, 0xFF, 0, 0x8F, 0xFF, 0x8F, 0x8F, 0x8F, 0x8F, 0x8F, 0x8F], np.uint8)
+    out = oracle.legacy_decode(1, 6, data, 2)  # 2 blocks x 10 values
+    assert out[0] == 0 and out[1] == 0x3C and out[2] == 0xF and out[3] == 0
+    assert out[9] == 0x3C and out[10] == 0xF and out[11] == 0x3E
+
+
+@pytest.mark.parametrize("b", list(range(1, 33)))
+def test_legacy_roundtrip_and_fastest(oracle, b):
+    # packed_misc.rs:474-531 with COMPACT: PackedSingleBlock for 1,2,4; Packed otherwise; size 16*b either way
+    fmt, bits = oracle.format_fastest(128, b, 0.0)
+    assert bits == b
+    assert fmt == (1 if b in (1, 2, 4) else 0)
+    assert oracle.lib().orc_format_byte_count(fmt, 128, b) == 16 * b
+    rng = np.random.default_rng(2000 + b)
+    vals = rng.integers(0, 2**b, size=128, dtype=np.uint64).astype(np.uint32).view(np.int32)
+    bbc, bvc = oracle.legacy_counts(fmt, b)
+    iters = math.ceil(128 / bvc)
+    enc = oracle.legacy_encode(fmt, b, vals, iters)
+    dec = oracle.legacy_decode(fmt, b, enc, iters)
+    assert (dec[:128] == vals).all()
+    if fmt == 0:
+        # independent statement: contiguous MSB-first bitstream
+        bits_str = "".join(format(int(v) & (2**b - 1), "0%db" % b) for v in vals.view(np.uint32))
+        ref = bytes(int(bits_str[i:i + 8], 2) for i in range(0, 128 * b, 8))
+        assert enc[:16 * b].tobytes() == ref
+
+
+def test_max_data_size(oracle):
+    # for_util.rs:42,53-56 test_max_data_size
+    assert oracle.lib().orc_max_data_size() == 147
+
+
+# ---- util/small_float.rs ---------------------------------------------------------------------------------------------
+def test_float_to_byte315(oracle):
+    # small_float.rs:76-107
+    L = oracle.lib()
+    min_value = struct.unpack("<f", struct.pack("<I", 1))[0]
+    max_value = 3.4028235e38
+    assert L.orc_origin_float_to_byte(5.8123817e-10) == 1
+    assert L.orc_float_to_byte315(5.8123817e-10) == 1
+    assert L.orc_float_to_byte315(0.0) == 0
+    assert L.orc_float_to_byte315(min_value) == 1
+    assert L.orc_float_to_byte315(max_value) == 255
+    assert L.orc_float_to_byte315(float("inf")) == 255
+    assert L.orc_float_to_byte315(-min_value) == 0
+    assert L.orc_float_to_byte315(-max_value) == 0
+    assert L.orc_float_to_byte315(float("-inf")) == 0
+    rng = np.random.default_rng(7)
+    bits = rng.integers(0, 2**32, size=100_000, dtype=np.uint64).astype(np.uint32)
+    for f in bits.view(np.float32):
+        if np.isnan(f):
+            continue
+        assert L.orc_origin_float_to_byte(float(f)) == L.orc_float_to_byte315(float(f))
+
+
+def test_byte315_to_float(oracle):
+    # small_float.rs:109-115
+    L = oracle.lib()
+    for i in range(256):
+        assert L.orc_origin_byte_to_float(i) == L.orc_byte315_to_float(i)
+
+
+# ---- search/similarity/bm25_similarity.rs ----------------------------------------------------------------------------
+def test_sane_norm_values(oracle):
+    # bm25_similarity.rs:400-411
+    L = oracle.lib()
+    prev = None
+    for i in range(256):
+        v = L.orc_norm_table(i)
+        assert v >= 0 and math.isfinite(v)
+        if prev is not None:
+            assert v < prev
+        prev = v
+
+
+def test_idf(oracle):
+    # bm25_similarity.rs:413-428: idf(df=1, maxDoc=11, docCount=-1) = ln 8; idf(df=1, docCount=32) = ln 22
+    L = oracle.lib()
+    assert abs(L.orc_bm25_idf(1, 11, -1) - np.float32(math.log(8))) < np.finfo(np.float32).eps
+    assert abs(L.orc_bm25_idf(1, 35, 32) - np.float32(math.log(22))) < np.finfo(np.float32).eps
+
+
+def test_avg_field_length(oracle):
+    # bm25_similarity.rs:430-440
+    L = oracle.lib()
+    assert L.orc_bm25_avgdl(11, 5, 0) == 1.0
+    assert L.orc_bm25_avgdl(3, 2, 8) == 4.0
+    assert L.orc_bm25_avgdl(3, -1, 9) == 3.0
+
+
+def test_bm25_similarity(oracle):
+    # bm25_similarity.rs:442-465: N=32, docCount=32, sumTTF=120, df=1 -> weight^2 = 9.5545435
+    import ctypes as C
+    L = oracle.lib()
+    cache = np.zeros(256, np.float32)
+    w = L.orc_bm25_weight(1.2, 0.75, 32, 32, 120, 1, 1.0, cache.ctypes.data_as(C.POINTER(C.c_float)))
+    assert abs(np.float32(w) * np.float32(w) - np.float32(9.5545435)) < 1e-6
+    # MockLeafReader norms (index/mod.rs): doc 1 -> length 120, doc 2 -> length 1000
+    n1 = L.orc_bm25_encode_norm(1.0, 120)
+    n2 = L.orc_bm25_encode_norm(1.0, 1000)
+    s = lambda freq, n: L.orc_bm25_score(w, 1.2, freq, 1, float(cache[n]))
+    assert s(100.0, n1) > s(20.0, n1)   # monotone in freq
+    assert s(10.0, n1) > s(10.0, n2)    # shorter doc scores higher
+    # op order of compute_score: ((w*(k1+1))*f)/(f+norm) in f32
+    f32 = np.float32
+    expect = (f32(w) * (f32(1.2) + f32(1.0)) * f32(10.0)) / (f32(10.0) + cache[n1])
+    assert f32(s(10.0, n1)) == expect
+
+
+# ---- search/scorer/conjunction_scorer.rs -----------------------------------------------------------------------------
+LISTS = [[1, 2, 3, 4, 5], [2, 5], [2, 3, 4, 5]]
+
+
+def test_conjunction_next(oracle):
+    # conjunction_scorer.rs:162-174, 201-215: docs 2, 5 ; scores 6, 15 ; initial score -3
+    docs, scores = oracle.mock_conjunction(LISTS)
+    assert docs == [2, 5] and scores == [6.0, 15.0]
+    assert oracle.mock_conjunction_initial_score(LISTS) == -3.0
+
+
+def test_conjunction_advance(oracle):
+    # conjunction_scorer.rs:176-199
+    assert oracle.mock_conjunction(LISTS, advance_first=1)[0] == [2, 5]
+    assert oracle.mock_conjunction(LISTS, advance_first=2)[0] == [2, 5]
+    assert oracle.mock_conjunction(LISTS, advance_first=5)[0] == [5]
+    assert oracle.mock_conjunction(LISTS, advance_first=7)[0] == []
+
+
+# ---- search/collector/top_docs.rs, scorer/bulk_scorer.rs, searcher.rs ------------------------------------------------
+@pytest.mark.parametrize("mode", [0, 1])
+def test_topdocs_collect(oracle, mode):
+    # top_docs.rs:235-264: k=3 of [1,2,3,3,5] -> 5,3,3 ; total_hits 5
+    docs, scores, total = oracle.mock_topk([1, 2, 3, 3, 5], 3, tie_mode=mode)
+    assert total == 5 and docs == [5, 3, 3] and scores == [5.0, 3.0, 3.0]
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_bulk_scorer_score(oracle, mode):
+    # bulk_scorer.rs:167-200: [1..5] k=3 -> 5,4,3
+    docs, _, total = oracle.mock_topk([1, 2, 3, 4, 5], 3, tie_mode=mode, use_bulk_scorer=True)
+    assert total == 5 and docs == [5, 4, 3]
+
+
+def test_early_terminating_search(oracle):
+    # searcher.rs:916-952: 3 leaves (doc bases 0/10/20) x docs [1,5,3,4,2], 3 collected per leaf ->
+    # total_hits 9, top-3 scores all 5
+    docs, scores, total = oracle.mock_topk([1, 5, 3, 4, 2], 3, n_leaves=3, max_collect_per_leaf=3, use_bulk_scorer=True)
+    assert total == 9 and scores == [5.0, 5.0, 5.0]
+    assert sorted(docs) == [5, 15, 25]
+
+
+# ---- DisjunctionSumScorer (parity-unpinned in the reference; self-consistency only) ---------------------------------
+def test_disjunction_simple_queue_and_dpq_agree(oracle):
+    rng = np.random.default_rng(3)
+    for n_lists in (3, 9, 10, 12):
+        lists = [sorted(set(rng.integers(0, 200, size=rng.integers(1, 80)).tolist())) for _ in range(n_lists)]
+        docs, scores = oracle.mock_disjunction(lists)
+        union = sorted(set().union(*lists))
+        assert docs == union
+        for d, s in zip(docs, scores):
+            assert s == float(d) * sum(1 for l in lists if d in l)  # mock score == doc id, exact in f32 here
+
+
+def test_rust_heap_vs_canonical_only_differ_on_ties(oracle):
+    rng = np.random.default_rng(5)
+    docs = np.arange(1000, dtype=np.int32)
+    scores = rng.integers(0, 20, size=1000).astype(np.float32)
+    k = 10
+    d0, s0 = oracle.topk_stream(docs, scores, k, 0)
+    d1, s1 = oracle.topk_stream(docs, scores, k, 1)
+    assert (np.sort(s0)[::-1] == s0).all() and (s0 == s1).all()  # identical score multiset, sorted desc
+    kth = s1[-1]
+    assert set(d0[s0 > kth]) == set(d1[s1 > kth])
+    assert all(scores[d] == kth for d in d0[s0 == kth])
+    # canonical = score desc, doc asc
+    order = np.lexsort((docs, -scores))[:k]
+    assert (d1 == docs[order]).all()
