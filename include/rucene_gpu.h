@@ -1,0 +1,181 @@
+/*
+ * rucene_gpu.h — C ABI of the MI355X (gfx950) query-evaluation path for Rucene.
+ *
+ * This is the drop-in boundary: a Rust shim inside Rucene binds exactly these symbols over `extern "C"`
+ *  to replace, for Lucene50 docs+freqs postings,
+ *   core::codec::postings::{ForUtil, Lucene50PostingsReader (BlockDocIterator), Lucene50SkipReader}
+ *   core::search::{TermScorer, ConjunctionScorer, DisjunctionSumScorer, BM25 SimScorer, TopDocsCollector}.
+ * The reference has no FFI of its own; each entry point cites the reference interface it
+ * stands in for. Paths are relative to /root/reference/src/core.
+ *
+ * Conventions (mirroring src/error.rs and the trait surface):
+ *   - plain C, opaque handles, caller-owned output buffers, no exceptions/panics across the boundary;
+ *   - every fallible call returns 0 or a negative rgpu_status that maps 1:1 onto error.rs ErrorKind;
+ *   - doc ids are int32 per segment (DocId), NO_MORE_DOCS = INT32_MAX; hits carry doc + doc_base;
+ *   - one rgpu_ctx per process per GPU; calls on one ctx are serialised internally (safe from many
+ *     threads, like &self methods of IndexSearcher);
+ *   - there is NO CPU fallback: if no gfx950 device is present rgpu_init fails with RGPU_ERR_RUNTIME.
+ */
+#ifndef RUCENE_GPU_H
+#define RUCENE_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RGPU_ABI_VERSION 1
+#define RGPU_NO_MORE_DOCS 0x7fffffff /* search/mod.rs:59 */
+#define RGPU_BLOCK_SIZE 128          /* codec/postings/posting_format.rs:36 */
+#define RGPU_MAX_QUERY_TERMS 16
+#define RGPU_MAX_K 128
+
+/* error.rs:24-91 ErrorKind */
+typedef enum rgpu_status {
+  RGPU_OK = 0,
+  RGPU_ERR_ILLEGAL_STATE = -1,     /* ErrorKind::IllegalState */
+  RGPU_ERR_ILLEGAL_ARGUMENT = -2,  /* ErrorKind::IllegalArgument */
+  RGPU_ERR_UNEXPECTED_EOF = -3,    /* ErrorKind::UnexpectedEOF */
+  RGPU_ERR_CORRUPT_INDEX = -4,     /* ErrorKind::CorruptIndex */
+  RGPU_ERR_UNSUPPORTED = -5,       /* ErrorKind::UnsupportedOperation (EF/BITSET blocks, k > RGPU_MAX_K ...) */
+  RGPU_ERR_IO = -6,                /* ErrorKind::IOError */
+  RGPU_ERR_RUNTIME = -7            /* ErrorKind::RuntimeError (HIP failure, no device, out of HBM) */
+} rgpu_status;
+
+typedef struct rgpu_ctx rgpu_ctx;
+typedef struct rgpu_segment rgpu_segment;
+
+/* Knobs (the reference has plain config structs only: SURVEY.md §5). Zero-initialise for defaults. */
+typedef struct rgpu_config {
+  int32_t abi_version;        /* must be RGPU_ABI_VERSION */
+  int32_t blocks_per_item;    /* 128-posting blocks per wave work item in the TERM kernel (0 = default 32) */
+  int32_t window_docs;        /* doc-id window of the AND/OR accumulate kernel (0 = default 8192) */
+  int32_t profile_kernels;    /* 1 = bracket every kernel with HIP events (see rgpu_kernel_stats) */
+  int32_t reserved[12];
+} rgpu_config;
+
+/* blocktree/mod.rs:33-59 BlockTermState, as filled by posting_reader.rs:264-306 lucene50_decode_term.
+ * doc_freq == 0 means "term absent from this segment" (TermWeight::create_scorer -> None). */
+typedef struct rgpu_term_state {
+  int64_t doc_start_fp;      /* where this term's postings start in .doc */
+  int64_t skip_offset;       /* skip data at doc_start_fp + skip_offset, -1 unless doc_freq > 128 */
+  int64_t total_term_freq;   /* freq of the singleton posting when doc_freq == 1 */
+  int32_t doc_freq;
+  int32_t singleton_doc_id;  /* -1 unless doc_freq == 1 */
+} rgpu_term_state;
+
+/* One scored clause: TermQuery -> TermWeight (term_query.rs:58-95). `weight` and the 256-entry norm
+ * cache are computed on the host exactly as bm25_similarity.rs:151-177 (idf in f64 -> f32, weight =
+ * idf * boost) so the device never re-derives idf. `sim_table` is a handle from rgpu_sim_table_upload. */
+typedef struct rgpu_query_term {
+  rgpu_term_state state;
+  float weight;
+  int32_t sim_table;
+} rgpu_query_term;
+
+typedef enum rgpu_query_op {
+  RGPU_OP_TERM = 0, /* TermQuery                      -> TermScorer (term_scorer.rs:43-67) */
+  RGPU_OP_AND = 1,  /* BooleanQuery, all MUST         -> ConjunctionScorer (conjunction_scorer.rs:26-128) */
+  RGPU_OP_OR = 2    /* BooleanQuery, all SHOULD, msm 1 -> DisjunctionSumScorer (disjunction_scorer.rs:24-104) */
+} rgpu_query_op;
+
+typedef struct rgpu_query {
+  int32_t op;          /* rgpu_query_op */
+  int32_t n_terms;     /* 1 for TERM, 2..RGPU_MAX_QUERY_TERMS otherwise */
+  int32_t first_term;  /* index of this query's first clause in the `terms` array */
+  int32_t reserved;
+} rgpu_query;
+
+/* sort_field/collapse_top_docs.rs:22-36 ScoreDoc */
+typedef struct rgpu_hit {
+  int32_t doc;  /* doc + doc_base (collector/top_docs.rs:89); -1 pads unused slots */
+  float score;
+} rgpu_hit;
+
+/* ---- context ---------------------------------------------------------------------------------------------- */
+/* No reference counterpart (Rucene is single-process CPU); created once by the shim. */
+int32_t rgpu_init(int32_t device_ordinal, const rgpu_config* cfg_or_null, rgpu_ctx** out_ctx);
+void rgpu_shutdown(rgpu_ctx* ctx);
+const char* rgpu_last_error(rgpu_ctx* ctx_or_null); /* message of the last failing call on this thread */
+int32_t rgpu_abi_version(void);
+int32_t rgpu_device_name(rgpu_ctx* ctx, char* buf, size_t buf_len);
+
+/* ---- segment (per-leaf, immutable) ------------------------------------------------------------------------ */
+/* Stands in for Lucene50PostingsReader::open (posting_reader.rs:85-158): validates the IndexHeader
+ * ("Lucene50PostingsWriterDoc", version 0..1), parses the ForUtil table (for_util.rs:120-148), checks the
+ * footer magic, then copies the raw .doc bytes, the 1-byte-per-doc norms (norms_producer.rs:146-154) and
+ * the optional live-docs bitset (util/bit_set.rs:453-460: bit doc&63 of word doc>>6; NULL = MatchAllBits)
+ * into HBM. Version 1 selects the SIMD-BP128 block layout, version 0 the legacy PackedInts layout. */
+int32_t rgpu_segment_upload(rgpu_ctx* ctx, const uint8_t* doc_file, size_t doc_len, const uint8_t* norms_or_null,
+                            int32_t max_doc, int32_t doc_base, const uint64_t* live_docs_or_null,
+                            rgpu_segment** out_seg);
+void rgpu_segment_free(rgpu_segment* seg);
+int32_t rgpu_segment_version(const rgpu_segment* seg); /* .doc format version (0 legacy, 1 BP128) */
+
+/* Skip-list decode (Lucene50SkipReader::init/load_skip_levels/read_skip_data, skip_reader.rs:315-511):
+ * decodes each term's level-0 skip entries on the GPU into a flat per-term block directory
+ * {last doc id, file offset, header bytes} cached in HBM for the life of the segment — the GPU analogue
+ * of opening a term's skipper. Called implicitly by every entry point below for terms it has not seen;
+ * exposed so a caller can pay it at segment-open time. */
+int32_t rgpu_segment_prepare_terms(rgpu_segment* seg, const rgpu_term_state* terms, int64_t n_terms);
+
+/* BlockDocIterator over whole terms (posting_reader.rs:501-647: refill_docs + next, i.e. ForUtil
+ * read_block for docs and freqs, VInt tail, singleton) — decodes every posting of every given term into
+ * caller-owned HOST buffers, terms concatenated in order (sum of doc_freq entries each). The parity and
+ * micro-benchmark surface for block decode. */
+int32_t rgpu_decode_terms(rgpu_segment* seg, const rgpu_term_state* terms, int64_t n_terms, int32_t* docs_out,
+                          int32_t* freqs_out);
+/* Same, results left in device memory (docs_dev / freqs_dev are hipMalloc'd by the caller or a torch
+ * tensor's data_ptr); asynchronous on `hip_stream` (a hipStream_t, NULL = the ctx stream). */
+int32_t rgpu_decode_terms_device(rgpu_segment* seg, const rgpu_term_state* terms, int64_t n_terms, void* docs_dev,
+                                 void* freqs_dev, void* hip_stream);
+
+/* BlockDocIterator::advance (posting_reader.rs:649-789) for a batch of independent probes on one term:
+ * out_docs[i] = first doc >= targets[i] (RGPU_NO_MORE_DOCS if none), out_freqs[i] its freq. */
+int32_t rgpu_advance_batch(rgpu_segment* seg, const rgpu_term_state* term, const int32_t* targets, int64_t n_targets,
+                           int32_t* out_docs, int32_t* out_freqs);
+
+/* ---- similarity tables ------------------------------------------------------------------------------------ */
+/* BM25SimWeight::cache (bm25_similarity.rs:158-165): 256 f32 = k1*((1-b) + b*NORM_TABLE[i]/avgdl),
+ * plus k1 for the final formula and the no-norms case. Returns a handle >= 0 or a negative status. */
+int32_t rgpu_sim_table_upload(rgpu_ctx* ctx, const float cache[256], float k1);
+
+/* ---- search ----------------------------------------------------------------------------------------------- */
+/* One leaf of IndexSearcher::search (searcher.rs:487-525): for each query, create_scorer + BulkScorer::score
+ * (bulk_scorer.rs:57-154) into a TopDocsCollector(k) (collector/top_docs.rs:28-95) — all on the GPU.
+ *   hits_out        n_queries x k, best first; order = score desc, then doc asc (the canonical tie rule of
+ *                   SURVEY.md §8(c)); unused slots {-1, 0}
+ *   total_hits_out  n_queries, TopDocs::total_hits (every collected live doc)
+ * Scores are f32 computed in the reference's operation order: TERM and AND bit-exact with the CPU scorers,
+ * OR with >= 10 clauses within 1e-5 relative (heap-order-dependent summation in the reference). */
+int32_t rgpu_search_batch(rgpu_segment* seg, const rgpu_query* queries, int32_t n_queries, const rgpu_query_term* terms,
+                          int32_t n_terms_total, int32_t k, rgpu_hit* hits_out, int64_t* total_hits_out);
+/* Same with device-resident outputs (for the RCCL all-gather of per-shard top-k), async on hip_stream. */
+int32_t rgpu_search_batch_device(rgpu_segment* seg, const rgpu_query* queries, int32_t n_queries,
+                                 const rgpu_query_term* terms, int32_t n_terms_total, int32_t k, void* hits_dev,
+                                 void* total_hits_dev, void* hip_stream);
+
+/* TopDocsCollector::finish_parallel (collector/top_docs.rs:157-172): merge n_lists per-leaf / per-shard
+ * top-k lists (layout [list][query][k], device memory) into [query][k] under the canonical order and sum
+ * the hit counts ([list][query] -> [query]). */
+int32_t rgpu_merge_topk_device(rgpu_ctx* ctx, const void* hits_dev, const void* totals_dev, int32_t n_lists,
+                               int32_t n_queries, int32_t k, void* hits_out_dev, void* totals_out_dev, void* hip_stream);
+
+/* ---- measurement ------------------------------------------------------------------------------------------ */
+typedef struct rgpu_kernel_stat {
+  char name[48];
+  int64_t launches;
+  double total_ms;          /* HIP-event time summed over launches (needs cfg.profile_kernels = 1) */
+  int64_t algorithmic_bytes; /* encoded postings bytes + norm bytes + output bytes the launches covered */
+  int64_t postings;          /* postings decoded by the launches */
+} rgpu_kernel_stat;
+int32_t rgpu_kernel_stats(rgpu_ctx* ctx, rgpu_kernel_stat* out, int32_t max_out); /* returns count */
+void rgpu_kernel_stats_reset(rgpu_ctx* ctx);
+int32_t rgpu_synchronize(rgpu_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RUCENE_GPU_H */

@@ -1,0 +1,113 @@
+"""ctypes binding over librucene_indexgen.so — the deterministic synthetic Lucene50 segment generator
+(rucene_amd/csrc/indexgen/indexgen.cpp). Host-only; produces the inputs of tests and bench.py
+(SURVEY.md §8(d) corpus): raw ".doc" bytes, 1-byte norms and a flat BlockTermState table."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "librucene_indexgen.so")
+
+TERM_STATE_DTYPE = np.dtype(
+    [("doc_start_fp", "<i8"), ("skip_offset", "<i8"), ("total_term_freq", "<i8"), ("doc_freq", "<i4"),
+     ("singleton_doc_id", "<i4")], align=True)
+
+DEFAULT_SEED = 0x527563656E65  # "Rucene"
+
+
+class _Config(C.Structure):
+    _fields_ = [("max_doc", C.c_int32), ("version", C.c_int32), ("n_terms", C.c_int64), ("zipf_scale", C.c_double),
+                ("seed", C.c_uint64), ("shard", C.c_int32), ("reserved", C.c_int32)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise RuntimeError("%s is missing — run `python -c 'import __graft_entry__ as g; g.build()'`" % _LIB_PATH)
+        L = C.CDLL(_LIB_PATH)
+        vp = C.c_void_p
+        L.rgen_build_zipf.restype = vp
+        L.rgen_build_zipf.argtypes = [C.POINTER(_Config)]
+        L.rgen_build_explicit.restype = vp
+        L.rgen_build_explicit.argtypes = [C.c_int32, C.c_int32, C.c_int64, vp, vp, vp, vp, vp]
+        L.rgen_free.argtypes = [vp]
+        L.rgen_doc_len.restype = C.c_int64
+        L.rgen_doc_len.argtypes = [vp]
+        for n in ("rgen_doc_bytes", "rgen_norms", "rgen_terms"):
+            getattr(L, n).restype = vp
+            getattr(L, n).argtypes = [vp]
+        L.rgen_n_terms.restype = C.c_int64
+        L.rgen_n_terms.argtypes = [vp]
+        L.rgen_max_doc.restype = C.c_int32
+        L.rgen_max_doc.argtypes = [vp]
+        L.rgen_stats.argtypes = [vp, vp]
+        _lib = L
+    return _lib
+
+
+class SyntheticSegment:
+    """One generated segment. Arrays are numpy copies (the native object is freed in the constructor)."""
+
+    def __init__(self, handle, doc_base=0):
+        L = lib()
+        n = L.rgen_doc_len(handle)
+        self.max_doc = L.rgen_max_doc(handle)
+        self.doc_bytes = np.ctypeslib.as_array(C.cast(L.rgen_doc_bytes(handle), C.POINTER(C.c_uint8)), shape=(n,)).copy()
+        self.norms = np.ctypeslib.as_array(C.cast(L.rgen_norms(handle), C.POINTER(C.c_uint8)), shape=(self.max_doc,)).copy()
+        nt = L.rgen_n_terms(handle)
+        raw = np.ctypeslib.as_array(C.cast(L.rgen_terms(handle), C.POINTER(C.c_uint8)), shape=(nt * 32,)).copy()
+        self.terms = raw.view(TERM_STATE_DTYPE)
+        st = np.zeros(8, dtype=np.int64)
+        L.rgen_stats(handle, st.ctypes.data)
+        (self.sum_total_term_freq, self.sum_doc_freq, self.total_postings, self.full_blocks, self.block_bytes,
+         self.tail_bytes, self.skip_bytes, _) = [int(x) for x in st]
+        self.doc_count = self.max_doc
+        self.doc_base = doc_base
+        self.live_docs = None
+        L.rgen_free(handle)
+
+
+def build_zipf(max_doc, n_terms, zipf_scale=0.2, version=1, seed=DEFAULT_SEED, shard=0, doc_base=0):
+    cfg = _Config(max_doc, version, n_terms, zipf_scale, seed, shard, 0)
+    h = lib().rgen_build_zipf(C.byref(cfg))
+    return SyntheticSegment(h, doc_base)
+
+
+def build_explicit(max_doc, postings, norms=None, version=1, segment_id=None, doc_base=0):
+    """postings: list of (docs, freqs) per term (empty docs -> absent term)."""
+    offs = np.zeros(len(postings) + 1, dtype=np.int64)
+    offs[1:] = np.cumsum([len(p[0]) for p in postings])
+    docs = np.concatenate([np.asarray(p[0], dtype=np.int32) for p in postings]) if postings else np.zeros(0, np.int32)
+    freqs = np.concatenate([np.asarray(p[1], dtype=np.int32) for p in postings]) if postings else np.zeros(0, np.int32)
+    docs = np.ascontiguousarray(docs, dtype=np.int32)
+    freqs = np.ascontiguousarray(freqs, dtype=np.int32)
+    nb = None if norms is None else np.ascontiguousarray(norms, dtype=np.uint8)
+    sid = None if segment_id is None else np.frombuffer(segment_id, dtype=np.uint8).copy()
+    h = lib().rgen_build_explicit(max_doc, version, len(postings), offs.ctypes.data, docs.ctypes.data, freqs.ctypes.data,
+                                  None if nb is None else nb.ctypes.data, None if sid is None else sid.ctypes.data)
+    seg = SyntheticSegment(h, doc_base)
+    if norms is None:
+        seg.norms = None
+    return seg
+
+
+def log_uniform_ranks(n, lo, hi, seed):
+    """Query term ranks drawn log-uniform in [lo, hi], deterministic (splitmix64)."""
+    out = np.zeros(n, dtype=np.int64)
+    s = np.uint64(seed)
+    mask = (1 << 64) - 1
+    x = int(s)
+    for i in range(n):
+        x = (x + 0x9E3779B97F4A7C15) & mask
+        z = x
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & mask
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & mask
+        z ^= z >> 31
+        u = (z >> 11) / float(1 << 53)
+        out[i] = min(hi, max(lo, int(np.floor(np.exp(np.log(lo) + u * (np.log(hi + 1) - np.log(lo)))))))
+    return out
