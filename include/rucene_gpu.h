@@ -163,13 +163,23 @@ int32_t rgpu_search_batch_device(rgpu_segment* seg, const rgpu_query* queries, i
 int32_t rgpu_merge_topk_device(rgpu_ctx* ctx, const void* hits_dev, const void* totals_dev, int32_t n_lists,
                                int32_t n_queries, int32_t k, void* hits_out_dev, void* totals_out_dev, void* hip_stream);
 
+/* ---- host helpers (no GPU work) ----------------------------------------------------------------------------- */
+/* BM25Similarity::compute_weight (bm25_similarity.rs:151-177) for one TermQuery (n_terms = 1) or a multi-term
+ * weight: idf summed over `doc_freqs` (idf() :99-114, f64 log -> f32), avgdl = sumTTF / docCount
+ * (avg_field_length :72-83; doc_count == -1 -> max_doc; sumTTF <= 0 -> 1), cache[i] = k1*((1-b) + b*NORM_TABLE[i]/avgdl),
+ * weight = idf * boost. Outputs may be NULL. */
+int32_t rgpu_bm25_compute_weight(float k1, float b, int64_t max_doc, int64_t doc_count, int64_t sum_total_term_freq,
+                                 const int64_t* doc_freqs, int32_t n_terms, float boost, float* weight_out, float* idf_out,
+                                 float* cache_out /* 256 floats */);
+/* BM25Similarity::encode_norm_value (bm25_similarity.rs:90-92): float_to_byte315(boost / sqrt(field_length)). */
+uint8_t rgpu_bm25_encode_norm(float boost, int32_t field_length);
+
 /* ---- measurement ------------------------------------------------------------------------------------------ */
 typedef struct rgpu_kernel_stat {
   char name[48];
   int64_t launches;
   double total_ms;          /* HIP-event time summed over launches (needs cfg.profile_kernels = 1) */
-  int64_t algorithmic_bytes; /* encoded postings bytes + norm bytes + output bytes the launches covered */
-  int64_t postings;          /* postings decoded by the launches */
+  int64_t postings;          /* sum of doc_freq over the terms the launches covered */
 } rgpu_kernel_stat;
 int32_t rgpu_kernel_stats(rgpu_ctx* ctx, rgpu_kernel_stat* out, int32_t max_out); /* returns count */
 void rgpu_kernel_stats_reset(rgpu_ctx* ctx);

@@ -1,0 +1,11 @@
+"""rucene_amd — MI355X-native query evaluation for Rucene (Lucene50 postings -> BM25 -> top-k on gfx950).
+
+The product is the C-ABI shared library `librucene_gpu.so` (include/rucene_gpu.h); this package is the thin
+Python host layer over it (ctypes) used by tests and bench.py, plus the synthetic index generator binding.
+There is NO CPU fallback: importing works anywhere, but every compute call needs the HIP library and a GPU
+and fails loudly otherwise.
+"""
+from ._lib import (OP_AND, OP_OR, OP_TERM, Context, RgpuError, Segment, bm25_compute_weight, bm25_encode_norm,  # noqa: F401
+                   lib, lib_path, QUERY_DTYPE, QUERY_TERM_DTYPE, TERM_STATE_DTYPE, HIT_DTYPE)
+from .searcher import (BM25Similarity, BooleanQuery, CollectionStatistics, GpuIndexSearcher, LeafReader,  # noqa: F401
+                       TermQuery, TopDocs, TopDocsCollector)

@@ -1,0 +1,266 @@
+"""ctypes binding of include/rucene_gpu.h (librucene_gpu.so). No torch types cross this boundary: numpy arrays
+for host buffers, raw integers for device pointers / hipStream_t handles."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_NAME = "librucene_gpu.so"
+
+OP_TERM, OP_AND, OP_OR = 0, 1, 2
+MAX_K = 128
+MAX_QUERY_TERMS = 16
+NO_MORE_DOCS = 0x7FFFFFFF
+
+TERM_STATE_DTYPE = np.dtype(
+    [("doc_start_fp", "<i8"), ("skip_offset", "<i8"), ("total_term_freq", "<i8"), ("doc_freq", "<i4"),
+     ("singleton_doc_id", "<i4")], align=True)
+QUERY_TERM_DTYPE = np.dtype([("state", TERM_STATE_DTYPE), ("weight", "<f4"), ("sim_table", "<i4")], align=True)
+QUERY_DTYPE = np.dtype([("op", "<i4"), ("n_terms", "<i4"), ("first_term", "<i4"), ("reserved", "<i4")], align=True)
+HIT_DTYPE = np.dtype([("doc", "<i4"), ("score", "<f4")], align=True)
+assert TERM_STATE_DTYPE.itemsize == 32 and QUERY_TERM_DTYPE.itemsize == 40 and QUERY_DTYPE.itemsize == 16 and HIT_DTYPE.itemsize == 8
+
+STATUS_NAMES = {0: "OK", -1: "IllegalState", -2: "IllegalArgument", -3: "UnexpectedEOF", -4: "CorruptIndex",
+                -5: "UnsupportedOperation", -6: "IOError", -7: "RuntimeError"}
+
+# every symbol include/rucene_gpu.h declares (tests/test_abi.py checks the header and this list agree)
+EXPORTS = [
+    "rgpu_init", "rgpu_shutdown", "rgpu_last_error", "rgpu_abi_version", "rgpu_device_name", "rgpu_segment_upload",
+    "rgpu_segment_free", "rgpu_segment_version", "rgpu_segment_prepare_terms", "rgpu_decode_terms",
+    "rgpu_decode_terms_device", "rgpu_advance_batch", "rgpu_sim_table_upload", "rgpu_search_batch",
+    "rgpu_search_batch_device", "rgpu_merge_topk_device", "rgpu_bm25_compute_weight", "rgpu_bm25_encode_norm",
+    "rgpu_kernel_stats", "rgpu_kernel_stats_reset", "rgpu_synchronize",
+]
+
+
+class RgpuError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("%s (%d): %s" % (STATUS_NAMES.get(status, "?"), status, message))
+        self.status = status
+
+
+class _Config(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("blocks_per_item", C.c_int32), ("window_docs", C.c_int32),
+                ("profile_kernels", C.c_int32), ("reserved", C.c_int32 * 12)]
+
+
+class _KernelStat(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_int64), ("total_ms", C.c_double), ("postings", C.c_int64)]
+
+
+def lib_path():
+    return os.path.join(_HERE, _LIB_NAME)
+
+
+_lib = None
+
+
+def _share_torch_hip_runtime():
+    """One HIP/HSA runtime per process. The PyTorch-ROCm wheel bundles its own libamdhip64.so /
+    libhsa-runtime64.so (same SONAMEs as /opt/rocm's); if librucene_gpu.so pulled in the system copies first, a
+    later `import torch` would bring up a second runtime that cannot see the GPU. Loading torch's copies first
+    (by path, without importing torch) makes our NEEDED entries resolve to them, whatever the import order."""
+    import importlib.util
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.origin:
+        return
+    libdir = os.path.join(os.path.dirname(spec.origin), "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        p = os.path.join(libdir, name)
+        if os.path.exists(p):
+            C.CDLL(p, mode=C.RTLD_GLOBAL)
+
+
+def lib():
+    """Load librucene_gpu.so. Fails loudly when the HIP extension has not been built — there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise RuntimeError("%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(hipcc --offload-arch=gfx950). rucene_amd has no CPU fallback." % path)
+    _share_torch_hip_runtime()
+    L = C.CDLL(path)
+    vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+    sig = {
+        "rgpu_init": (i32, [i32, C.POINTER(_Config), C.POINTER(vp)]),
+        "rgpu_shutdown": (None, [vp]),
+        "rgpu_last_error": (C.c_char_p, [vp]),
+        "rgpu_abi_version": (i32, []),
+        "rgpu_device_name": (i32, [vp, C.c_char_p, C.c_size_t]),
+        "rgpu_segment_upload": (i32, [vp, vp, C.c_size_t, vp, i32, i32, vp, C.POINTER(vp)]),
+        "rgpu_segment_free": (None, [vp]),
+        "rgpu_segment_version": (i32, [vp]),
+        "rgpu_segment_prepare_terms": (i32, [vp, vp, i64]),
+        "rgpu_decode_terms": (i32, [vp, vp, i64, vp, vp]),
+        "rgpu_decode_terms_device": (i32, [vp, vp, i64, vp, vp, vp]),
+        "rgpu_advance_batch": (i32, [vp, vp, vp, i64, vp, vp]),
+        "rgpu_sim_table_upload": (i32, [vp, vp, f32]),
+        "rgpu_search_batch": (i32, [vp, vp, i32, vp, i32, i32, vp, vp]),
+        "rgpu_search_batch_device": (i32, [vp, vp, i32, vp, i32, i32, vp, vp, vp]),
+        "rgpu_merge_topk_device": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp]),
+        "rgpu_bm25_compute_weight": (i32, [f32, f32, i64, i64, i64, vp, i32, f32, vp, vp, vp]),
+        "rgpu_bm25_encode_norm": (C.c_uint8, [f32, i32]),
+        "rgpu_kernel_stats": (i32, [vp, C.POINTER(_KernelStat), i32]),
+        "rgpu_kernel_stats_reset": (None, [vp]),
+        "rgpu_synchronize": (i32, [vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype, fn.argtypes = res, args
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc < 0:
+        raise RgpuError(rc, lib().rgpu_last_error(None).decode(errors="replace"))
+    return rc
+
+
+def bm25_compute_weight(k1, b, max_doc, doc_count, sum_total_term_freq, doc_freqs, boost=1.0):
+    """BM25Similarity::compute_weight -> (weight, idf, cache[256])."""
+    dfs = np.ascontiguousarray(np.atleast_1d(doc_freqs), dtype=np.int64)
+    w, idf = C.c_float(), C.c_float()
+    cache = np.zeros(256, dtype=np.float32)
+    _check(lib().rgpu_bm25_compute_weight(k1, b, max_doc, doc_count, sum_total_term_freq, dfs.ctypes.data, dfs.size, boost,
+                                          C.addressof(w), C.addressof(idf), cache.ctypes.data))
+    return w.value, idf.value, cache
+
+
+def bm25_encode_norm(boost, field_length):
+    return int(lib().rgpu_bm25_encode_norm(boost, field_length))
+
+
+class Context:
+    """rgpu_ctx: one per process per GPU."""
+
+    def __init__(self, device=0, profile_kernels=False, blocks_per_item=0, window_docs=0):
+        cfg = _Config()
+        cfg.abi_version = 1
+        cfg.blocks_per_item = blocks_per_item
+        cfg.window_docs = window_docs
+        cfg.profile_kernels = int(profile_kernels)
+        h = C.c_void_p()
+        _check(lib().rgpu_init(device, C.byref(cfg), C.byref(h)))
+        self._h = h
+        self._tables = {}
+        self._segments = []  # weakrefs: segments must be freed before the ctx they belong to
+
+    @property
+    def device_name(self):
+        buf = C.create_string_buffer(128)
+        _check(lib().rgpu_device_name(self._h, buf, 128))
+        return buf.value.decode()
+
+    def sim_table(self, cache, k1):
+        """Upload (or reuse) a BM25 norm cache; returns the handle for rgpu_query_term.sim_table."""
+        cache = np.ascontiguousarray(cache, dtype=np.float32)
+        key = (cache.tobytes(), float(np.float32(k1)))
+        if key not in self._tables:
+            self._tables[key] = _check(lib().rgpu_sim_table_upload(self._h, cache.ctypes.data, k1))
+        return self._tables[key]
+
+    def synchronize(self):
+        _check(lib().rgpu_synchronize(self._h))
+
+    def kernel_stats(self):
+        arr = (_KernelStat * 32)()
+        n = _check(lib().rgpu_kernel_stats(self._h, arr, 32))
+        return {arr[i].name.decode(): {"launches": arr[i].launches, "total_ms": arr[i].total_ms, "postings": arr[i].postings}
+                for i in range(n)}
+
+    def kernel_stats_reset(self):
+        lib().rgpu_kernel_stats_reset(self._h)
+
+    def merge_topk_device(self, hits_ptr, totals_ptr, n_lists, n_queries, k, out_hits_ptr, out_totals_ptr, stream=0):
+        _check(lib().rgpu_merge_topk_device(self._h, hits_ptr, totals_ptr, n_lists, n_queries, k, out_hits_ptr, out_totals_ptr,
+                                            stream or None))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            for ref in self._segments:
+                seg = ref()
+                if seg is not None:
+                    seg.close()
+            self._segments = []
+            lib().rgpu_shutdown(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Segment:
+    """rgpu_segment: one uploaded leaf (.doc bytes, norms, live docs in HBM)."""
+
+    def __init__(self, ctx, doc_bytes, norms, max_doc, doc_base=0, live_docs=None):
+        self.ctx = ctx
+        doc = np.ascontiguousarray(doc_bytes, dtype=np.uint8)
+        nb = None if norms is None else np.ascontiguousarray(norms, dtype=np.uint8)
+        lv = None if live_docs is None else np.ascontiguousarray(live_docs, dtype=np.uint64)
+        h = C.c_void_p()
+        _check(lib().rgpu_segment_upload(ctx._h, doc.ctypes.data, doc.size, None if nb is None else nb.ctypes.data, max_doc,
+                                         doc_base, None if lv is None else lv.ctypes.data, C.byref(h)))
+        self._h = h
+        self.max_doc, self.doc_base = max_doc, doc_base
+        import weakref
+        ctx._segments.append(weakref.ref(self))
+
+    @property
+    def version(self):
+        return lib().rgpu_segment_version(self._h)
+
+    def prepare_terms(self, states):
+        st = np.ascontiguousarray(states, dtype=TERM_STATE_DTYPE)
+        _check(lib().rgpu_segment_prepare_terms(self._h, st.ctypes.data, st.size))
+
+    def decode_terms(self, states):
+        st = np.ascontiguousarray(np.atleast_1d(states), dtype=TERM_STATE_DTYPE)
+        total = int(st["doc_freq"].sum())
+        docs = np.zeros(max(total, 1), dtype=np.int32)
+        freqs = np.zeros(max(total, 1), dtype=np.int32)
+        _check(lib().rgpu_decode_terms(self._h, st.ctypes.data, st.size, docs.ctypes.data, freqs.ctypes.data))
+        return docs[:total], freqs[:total]
+
+    def decode_terms_device(self, states, docs_ptr, freqs_ptr, stream=0):
+        st = np.ascontiguousarray(np.atleast_1d(states), dtype=TERM_STATE_DTYPE)
+        _check(lib().rgpu_decode_terms_device(self._h, st.ctypes.data, st.size, docs_ptr, freqs_ptr, stream or None))
+
+    def advance(self, state, targets):
+        st = np.ascontiguousarray(np.atleast_1d(state), dtype=TERM_STATE_DTYPE)
+        t = np.ascontiguousarray(targets, dtype=np.int32)
+        docs = np.zeros(t.size, dtype=np.int32)
+        freqs = np.zeros(t.size, dtype=np.int32)
+        _check(lib().rgpu_advance_batch(self._h, st.ctypes.data, t.ctypes.data, t.size, docs.ctypes.data, freqs.ctypes.data))
+        return docs, freqs
+
+    def search_batch(self, queries, terms, k):
+        q = np.ascontiguousarray(queries, dtype=QUERY_DTYPE)
+        t = np.ascontiguousarray(terms, dtype=QUERY_TERM_DTYPE)
+        hits = np.zeros((q.size, max(k, 1)), dtype=HIT_DTYPE)
+        totals = np.zeros(q.size, dtype=np.int64)
+        _check(lib().rgpu_search_batch(self._h, q.ctypes.data, q.size, t.ctypes.data, t.size, k, hits.ctypes.data, totals.ctypes.data))
+        return hits, totals
+
+    def search_batch_device(self, queries, terms, k, hits_ptr, totals_ptr, stream=0):
+        q = np.ascontiguousarray(queries, dtype=QUERY_DTYPE)
+        t = np.ascontiguousarray(terms, dtype=QUERY_TERM_DTYPE)
+        _check(lib().rgpu_search_batch_device(self._h, q.ctypes.data, q.size, t.ctypes.data, t.size, k, hits_ptr, totals_ptr,
+                                              stream or None))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().rgpu_segment_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,248 @@
+// Device-side decoders for one 128-posting FullBlock (doc deltas + freqs) and for a VInt tail, one wavefront
+// per block. Replaces, for the GPU path (paths relative to /root/reference/src/core):
+//   codec/postings/for_util.rs:187-243            ForUtilInstance::read_block (header byte, all-equal, payload)
+//   util/packed/packed_simd.rs:126-163            SIMD128Packer::unpack   (.doc version 1, BP128 vertical layout)
+//   util/packed/packed_misc.rs:2655-2680,2829-2841 BulkOperationPacked / PackedSingleBlock::decode_byte_to_int (v0)
+//   codec/postings/posting_reader.rs:308-333      read_vint_block (tail)
+//   codec/postings/posting_reader.rs:622-646      the sequential `accum + delta` prefix sum in next()
+//
+// Lane mapping: lane t owns postings 2t and 2t+1 of the block. In the BP128 layout value i = 4r + l lives at
+// bits [r*b, (r+1)*b) of stream l, stream word w at dword 4w + l, so postings (2t, 2t+1) share row r = t/2 and
+// sit in adjacent streams l = 2(t&1), l+1: one ds_read_b64 fetches both low words, one more the straddle words.
+// Payload rows (16 B each) are pulled from HBM with one unaligned global_load_dwordx4 per row — lanes 0..31
+// take doc rows, lanes 32..63 freq rows — and staged in a wave-private LDS slab.
+#pragma once
+#include "wave.hpp"
+
+namespace rgpu {
+
+// wave-private LDS slab (bytes): two 528-byte stream areas, reused as byte / value scratch by the tail decoder
+constexpr int SLAB_STREAM = 528;
+constexpr int SLAB_BYTES = 2432;  // >= 1296 tail bytes + 1024 value words, multiple of 16
+constexpr int TAIL_MAX_BYTES = 1280;
+constexpr int DIR_SENTINEL_DOC = 0x7ffffffe;
+
+// per-block directory header word: b_doc(6) | vint_len_doc(3) << 6 | b_freq(6) << 9
+__device__ __host__ __forceinline__ int hdr_bdoc(uint32_t h) { return (int)(h & 63); }
+__device__ __host__ __forceinline__ int hdr_vlen(uint32_t h) { return (int)((h >> 6) & 7); }
+__device__ __host__ __forceinline__ int hdr_bfreq(uint32_t h) { return (int)((h >> 9) & 63); }
+
+struct __attribute__((packed, aligned(1))) UnalignedU4 { uint32_t x, y, z, w; };
+struct __attribute__((packed, aligned(1))) UnalignedU32 { uint32_t v; };
+
+__device__ __forceinline__ uint4 load16_unaligned(const uint8_t* p) {
+  UnalignedU4 v = *reinterpret_cast<const UnalignedU4*>(p);
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ uint32_t load4_unaligned(const uint8_t* p) {
+  return reinterpret_cast<const UnalignedU32*>(p)->v;
+}
+
+// data_input.rs:78-111 read_vint, all lanes on the same address (broadcast load); *len receives the byte count
+__device__ __forceinline__ uint32_t read_vint_uniform(const uint8_t* p, int* len) {
+  uint32_t v = 0;
+  int i = 0;
+  for (; i < 5; ++i) {
+    uint32_t b = p[i];
+    v |= (b & 0x7f) << (7 * i);
+    if (!(b & 0x80)) { ++i; break; }
+  }
+  *len = i;
+  return v;
+}
+
+// ---- BP128 (version 1) ----------------------------------------------------------------------------------------
+__device__ __forceinline__ void extract_pair_bp128(const uint32_t* stream_words, int b, int lane, uint32_t& v0, uint32_t& v1) {
+  const int r = lane >> 1;
+  const int l = (lane & 1) << 1;
+  const int p = r * b;
+  const int w = p >> 5;
+  const int s = p & 31;
+  const uint2 lo = *reinterpret_cast<const uint2*>(stream_words + 4 * w + l);
+  const uint2 hi = *reinterpret_cast<const uint2*>(stream_words + 4 * w + 4 + l);
+  const uint32_t mask = b >= 32 ? 0xffffffffu : ((1u << b) - 1u);
+  v0 = (uint32_t)((((uint64_t)hi.x << 32) | lo.x) >> s) & mask;
+  v1 = (uint32_t)((((uint64_t)hi.y << 32) | lo.y) >> s) & mask;
+}
+
+// ---- legacy PackedInts (version 0) ----------------------------------------------------------------------------
+// Packed: value i at bits [i*b, (i+1)*b) of one MSB-first big-endian stream; PackedSingleBlock (b in 1,2,4):
+// big-endian u64 blocks holding 64/b values each, value j of a block at bits [j*b, (j+1)*b) from the LSB.
+__device__ __forceinline__ uint32_t bswap32(uint32_t x) { return __builtin_bswap32(x); }
+__device__ __forceinline__ uint32_t extract_packed_be(const uint32_t* stream_words, int b, int i) {
+  const int p = i * b;
+  const int w = p >> 5;
+  const int s = p & 31;
+  const uint64_t hi = bswap32(stream_words[w]);
+  const uint64_t lo = bswap32(stream_words[w + 1]);
+  const uint64_t win = (hi << 32) | lo;  // bits p.. start at the top
+  const uint32_t mask = b >= 32 ? 0xffffffffu : ((1u << b) - 1u);
+  return (uint32_t)(win >> (64 - s - b)) & mask;
+}
+__device__ __forceinline__ uint32_t extract_psb(const uint32_t* stream_words, int b, int i) {
+  const int per = 64 / b;
+  const int blk = i / per;
+  const int j = i - blk * per;
+  const uint64_t w = ((uint64_t)bswap32(stream_words[2 * blk]) << 32) | bswap32(stream_words[2 * blk + 1]);
+  return (uint32_t)(w >> (j * b)) & ((1u << b) - 1u);
+}
+__device__ __forceinline__ void extract_pair_legacy(const uint32_t* stream_words, int b, int lane, uint32_t& v0, uint32_t& v1) {
+  if (b == 1 || b == 2 || b == 4) {  // FormatAndBits::fastest with COMPACT (packed_misc.rs:474-531)
+    v0 = extract_psb(stream_words, b, 2 * lane);
+    v1 = extract_psb(stream_words, b, 2 * lane + 1);
+  } else {
+    v0 = extract_packed_be(stream_words, b, 2 * lane);
+    v1 = extract_packed_be(stream_words, b, 2 * lane + 1);
+  }
+}
+
+struct BlockPair {
+  uint32_t d0, d1;  // doc deltas of postings 2*lane, 2*lane+1
+  uint32_t f0, f1;  // freqs
+};
+
+// Decode one FullBlock starting at `blk` (header byte of the doc-delta block). `hdr` comes from the block
+// directory. `slab` is this wave's LDS slab. Wave-uniform control flow.
+template <bool LEGACY>
+__device__ __forceinline__ BlockPair decode_block(const uint8_t* __restrict__ blk, uint32_t hdr, uint8_t* slab, int lane) {
+  const int bd = hdr_bdoc(hdr);
+  const int bf = hdr_bfreq(hdr);
+  const int doc_sz = bd ? 16 * bd : hdr_vlen(hdr);
+  const uint8_t* doc_payload = blk + 1;
+  const uint8_t* freq_payload = blk + 1 + doc_sz + 1;
+  // stage payload rows: lanes 0..31 -> doc rows, lanes 32..63 -> freq rows
+  {
+    const int half = lane >> 5;
+    const int row = lane & 31;
+    const int rows = half ? bf : bd;
+    if (row < rows) {
+      const uint8_t* src = (half ? freq_payload : doc_payload) + 16 * row;
+      uint4 v = load16_unaligned(src);
+      *reinterpret_cast<uint4*>(slab + half * SLAB_STREAM + 16 * row) = v;
+    }
+  }
+  wave_sync();
+  BlockPair out;
+  if (bd) {
+    const uint32_t* words = reinterpret_cast<const uint32_t*>(slab);
+    if (LEGACY) extract_pair_legacy(words, bd, lane, out.d0, out.d1);
+    else extract_pair_bp128(words, bd, lane, out.d0, out.d1);
+  } else {
+    int n;
+    out.d0 = out.d1 = read_vint_uniform(doc_payload, &n);
+  }
+  if (bf) {
+    const uint32_t* words = reinterpret_cast<const uint32_t*>(slab + SLAB_STREAM);
+    if (LEGACY) extract_pair_legacy(words, bf, lane, out.f0, out.f1);
+    else extract_pair_bp128(words, bf, lane, out.f0, out.f1);
+  } else {
+    int n;
+    out.f0 = out.f1 = read_vint_uniform(freq_payload, &n);
+  }
+  wave_sync();  // slab is free for the next block
+  return out;
+}
+
+// deltas -> absolute doc ids (the `accum + delta` chain of posting_reader.rs:622-646, as a wave scan)
+__device__ __forceinline__ void deltas_to_docs(uint32_t d0, uint32_t d1, int32_t base, int32_t& doc0, int32_t& doc1) {
+  const int pair = (int)(d0 + d1);
+  const int incl = wave_incl_scan(pair);
+  doc0 = base + (incl - pair) + (int)d0;
+  doc1 = doc0 + (int)d1;
+}
+
+// ---- VInt tail (< 128 postings) -------------------------------------------------------------------------------
+// posting i: code = vint; delta = code >>> 1; freq = (code & 1) ? 1 : vint        (posting_reader.rs:316-325)
+// Parallel formulation: (1) every lane scans 20 bytes for VInt terminators, a wave scan turns terminator counts
+// into value indices and each terminator lane assembles its value by looking back over continuation bytes;
+// (2) "is this value a code or a freq" is the recurrence s[k+1] = !(s[k] && even(v[k])), a scan over the
+// 4-element function monoid {const0, const1, id, not}; (3) a wave scan over the code deltas gives doc ids.
+// Returns postings 2*lane, 2*lane+1 (valid while index < n).
+__device__ __forceinline__ uint32_t compose_fn(uint32_t first, uint32_t then) {
+  // a function {0,1}->{0,1} is 2 bits: bit0 = f(0), bit1 = f(1); result = then o first
+  const uint32_t r0 = (then >> (first & 1)) & 1;
+  const uint32_t r1 = (then >> ((first >> 1) & 1)) & 1;
+  return r0 | (r1 << 1);
+}
+
+__device__ __forceinline__ void decode_tail(const uint8_t* __restrict__ tail, int n, int32_t base, uint8_t* slab, int lane,
+                                            int32_t& doc0, int32_t& doc1, uint32_t& f0, uint32_t& f1) {
+  uint8_t* bytes = slab;                                              // [0, 1296)
+  uint32_t* vals = reinterpret_cast<uint32_t*>(slab + 1296);         // 256 values (+ 8 pad words)
+  // (0) stage TAIL_MAX_BYTES: 80 x 16 B
+  for (int c = lane; c < TAIL_MAX_BYTES / 16; c += WAVE)
+    *reinterpret_cast<uint4*>(bytes + 16 * c) = load16_unaligned(tail + 16 * c);
+  for (int i = lane; i < 264; i += WAVE) vals[i] = 1;  // unwritten values read as odd codes (harmless)
+  wave_sync();
+  // (1) terminators in my 20-byte span
+  const int span = 20 * lane;
+  uint32_t w[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) w[j] = *reinterpret_cast<const uint32_t*>(bytes + span + 4 * j);
+  uint32_t term = 0;
+#pragma unroll
+  for (int j = 0; j < 20; ++j) term |= (((w[j >> 2] >> (8 * (j & 3) + 7)) & 1u) ^ 1u) << j;
+  const int cnt = __popc(term);
+  int vi = wave_incl_scan(cnt) - cnt;
+  while (term) {
+    const int j = __builtin_ctz(term);
+    term &= term - 1;
+    int p = span + j;
+    uint32_t v = bytes[p];
+    for (int back = 0; back < 4 && p > 0 && (bytes[p - 1] & 0x80); ++back) {
+      --p;
+      v = (v << 7) | (bytes[p] & 0x7f);
+    }
+    if (vi < 256) vals[vi] = v;
+    ++vi;
+  }
+  wave_sync();
+  // (2) classify 4 values per lane: code / freq
+  uint32_t v4[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v4[j] = vals[4 * lane + j];
+  uint32_t F = 2;  // identity
+#pragma unroll
+  for (int j = 0; j < 4; ++j) F = compose_fn(F, (v4[j] & 1) ? 3u /*const 1*/ : 1u /*not*/);
+  // inclusive scan of F under composition (Hillis-Steele over lanes)
+  uint32_t S = F;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t prev = (uint32_t)__shfl_up((int)S, d);
+    if (lane >= d) S = compose_fn(prev, S);
+  }
+  uint32_t before = (uint32_t)__shfl_up((int)S, 1);  // composition of all earlier lanes
+  uint32_t state = lane == 0 ? 1u : ((before >> 1) & 1u);  // apply to s[0] = 1 (first value is a code)
+  uint32_t is_code[4];
+  int ncodes = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    is_code[j] = state;
+    ncodes += (int)state;
+    state = ((state & 1u) && !(v4[j] & 1u)) ? 0u : 1u;
+  }
+  int pi = wave_incl_scan(ncodes) - ncodes;
+  wave_sync();
+  uint32_t* pd = reinterpret_cast<uint32_t*>(slab);        // posting deltas [128]  (byte area is dead now)
+  uint32_t* pf = reinterpret_cast<uint32_t*>(slab + 512);  // posting freqs  [128]
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (is_code[j]) {
+      if (pi < 128) {
+        pd[pi] = v4[j] >> 1;
+        pf[pi] = (v4[j] & 1) ? 1u : vals[4 * lane + j + 1];
+      }
+      ++pi;
+    }
+  }
+  wave_sync();
+  // (3) two postings per lane + prefix sum
+  const uint32_t d0 = (2 * lane < n) ? pd[2 * lane] : 0u;
+  const uint32_t d1 = (2 * lane + 1 < n) ? pd[2 * lane + 1] : 0u;
+  f0 = pf[2 * lane];
+  f1 = pf[2 * lane + 1];
+  deltas_to_docs(d0, d1, base, doc0, doc1);
+  wave_sync();
+}
+
+}  // namespace rgpu

@@ -1,0 +1,127 @@
+// Materialising decode of whole terms: one wavefront per 128-posting block (or per VInt tail / singleton),
+// docs and freqs written to HBM. GPU counterpart of BlockDocIterator::{refill_docs, next}
+// (codec/postings/posting_reader.rs:501-561, 612-647) driven to exhaustion, and the block-decode microbenchmark.
+// Also k_advance: BlockDocIterator::advance (posting_reader.rs:649-789) for independent probes.
+#pragma once
+#include "decode.hpp"
+#include "types.hpp"
+
+namespace rgpu {
+
+constexpr int WG_THREADS = 256;
+constexpr int WG_WAVES = WG_THREADS / 64;
+
+// largest t in [0, n) with prefix[t] <= x   (prefix[0] == 0, prefix is non-decreasing, x < prefix[n])
+__device__ __forceinline__ int upper_slot(const int64_t* __restrict__ prefix, int n, int64_t x) {
+  int lo = 0, hi = n;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (prefix[mid] <= x) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+template <bool LEGACY>
+__global__ __launch_bounds__(WG_THREADS) void k_decode_terms(SegView seg, const DevTerm* __restrict__ terms,
+                                                             const int64_t* __restrict__ item_prefix,
+                                                             const int64_t* __restrict__ out_prefix, int n_terms,
+                                                             int64_t n_items, int32_t* __restrict__ docs_out,
+                                                             int32_t* __restrict__ freqs_out) {
+  __shared__ __attribute__((aligned(16))) uint8_t slabs[WG_WAVES][SLAB_BYTES];
+  const int lane = lane_id();
+  const int wave = (int)(threadIdx.x >> 6);
+  const int64_t item = (int64_t)blockIdx.x * WG_WAVES + wave;
+  if (item >= n_items) return;
+  const int t = upper_slot(item_prefix, n_terms, item);
+  const int local = (int)(item - item_prefix[t]);
+  const DevTerm T = terms[t];
+  const int64_t out = out_prefix[t];
+  uint8_t* slab = slabs[wave];
+  if (local < T.nblocks) {
+    const int32_t base = local == 0 ? 0 : seg.dir_last[T.dir_base + local - 1];
+    const uint32_t off = seg.dir_off[T.dir_base + local];
+    const uint32_t hdr = seg.dir_hdr[T.dir_base + local];
+    const BlockPair bp = decode_block<LEGACY>(seg.doc + T.start_fp + off, hdr, slab, lane);
+    int32_t d0, d1;
+    deltas_to_docs(bp.d0, bp.d1, base, d0, d1);
+    const int64_t o = out + 128 * (int64_t)local + 2 * lane;
+    docs_out[o] = d0;
+    docs_out[o + 1] = d1;
+    freqs_out[o] = (int32_t)bp.f0;
+    freqs_out[o + 1] = (int32_t)bp.f1;
+  } else if (T.df == 1) {
+    if (lane == 0) { docs_out[out] = T.singleton_doc; freqs_out[out] = T.singleton_freq; }
+  } else {
+    const uint32_t toff = T.nblocks ? seg.dir_off[T.dir_base + T.nblocks] : 0u;
+    const int32_t base = T.nblocks ? seg.dir_last[T.dir_base + T.nblocks - 1] : 0;
+    int32_t d0, d1;
+    uint32_t f0, f1;
+    decode_tail(seg.doc + T.start_fp + toff, T.tail_n, base, slab, lane, d0, d1, f0, f1);
+    const int64_t o = out + 128 * (int64_t)T.nblocks + 2 * lane;
+    if (2 * lane < T.tail_n) { docs_out[o] = d0; freqs_out[o] = (int32_t)f0; }
+    if (2 * lane + 1 < T.tail_n) { docs_out[o + 1] = d1; freqs_out[o + 1] = (int32_t)f1; }
+  }
+}
+
+// first directory slot whose last doc >= target, in [0, nblocks]; nblocks == "the tail (or nothing)"
+__device__ __forceinline__ int find_block(const int32_t* __restrict__ dir_last, uint32_t dir_base, int nblocks, int32_t target) {
+  int lo = 0, hi = nblocks;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (dir_last[dir_base + mid] >= target) hi = mid; else lo = mid + 1;
+  }
+  return lo;
+}
+
+// One wavefront per probe: binary search over the block directory (what skip_to + seek achieve, skip_reader.rs:
+// 554-584), decode that block, then the in-block position of the first doc >= target as a count-of-less-than
+// over the 128 docs (simd_block_decoder.rs:100-128) via ballot.
+template <bool LEGACY>
+__global__ __launch_bounds__(WG_THREADS) void k_advance(SegView seg, DevTerm T, const int32_t* __restrict__ targets,
+                                                        int64_t n_targets, int32_t* __restrict__ out_docs,
+                                                        int32_t* __restrict__ out_freqs) {
+  __shared__ __attribute__((aligned(16))) uint8_t slabs[WG_WAVES][SLAB_BYTES];
+  const int lane = lane_id();
+  const int wave = (int)(threadIdx.x >> 6);
+  const int64_t probe = (int64_t)blockIdx.x * WG_WAVES + wave;
+  if (probe >= n_targets) return;
+  const int32_t target = targets[probe];
+  uint8_t* slab = slabs[wave];
+  int32_t res_doc = 0x7fffffff, res_freq = 0;
+  if (T.df == 1) {
+    if (T.singleton_doc >= target) { res_doc = T.singleton_doc; res_freq = T.singleton_freq; }
+  } else {
+    int blk = find_block(seg.dir_last, T.dir_base, T.nblocks, target);
+    // a block whose directory entry is the sentinel (df % 128 == 0) may turn out not to hold the target
+    for (; blk <= T.nblocks; ++blk) {
+      int32_t d0, d1;
+      uint32_t f0, f1;
+      int n;
+      if (blk < T.nblocks) {
+        const int32_t base = blk == 0 ? 0 : seg.dir_last[T.dir_base + blk - 1];
+        const BlockPair bp = decode_block<LEGACY>(seg.doc + T.start_fp + seg.dir_off[T.dir_base + blk],
+                                                   seg.dir_hdr[T.dir_base + blk], slab, lane);
+        deltas_to_docs(bp.d0, bp.d1, base, d0, d1);
+        f0 = bp.f0; f1 = bp.f1; n = 128;
+      } else {
+        if (T.tail_n == 0) break;
+        const uint32_t toff = T.nblocks ? seg.dir_off[T.dir_base + T.nblocks] : 0u;
+        const int32_t base = T.nblocks ? seg.dir_last[T.dir_base + T.nblocks - 1] : 0;
+        decode_tail(seg.doc + T.start_fp + toff, T.tail_n, base, slab, lane, d0, d1, f0, f1);
+        n = T.tail_n;
+      }
+      const bool lt0 = 2 * lane < n && d0 < target;
+      const bool lt1 = 2 * lane + 1 < n && d1 < target;
+      const int pos = __popcll(__ballot(lt0)) + __popcll(__ballot(lt1));  // docs are sorted: count == index
+      if (pos < n) {
+        const int src = pos >> 1;
+        res_doc = (pos & 1) ? readlane(d1, src) : readlane(d0, src);
+        res_freq = (pos & 1) ? readlane((int)f1, src) : readlane((int)f0, src);
+        break;
+      }
+    }
+  }
+  if (lane == 0) { out_docs[probe] = res_doc; out_freqs[probe] = res_freq; }
+}
+
+}  // namespace rgpu

@@ -1,0 +1,159 @@
+// Skip-list decode on the GPU: one workgroup per term turns the term's level-0 skip entries into a flat block
+// directory {last doc id, byte offset, header word} in HBM. GPU counterpart of (paths relative to
+// /root/reference/src/core):
+//   codec/postings/skip_reader.rs:460-511   load_skip_levels  (vlong length + bytes for levels L-1..1, then level 0)
+//   codec/postings/skip_reader.rs:431-453   read_skip_data    (vint docDelta, vlong docFpDelta per entry)
+//   codec/postings/skip_reader.rs:513-539   load_next_skip    (the running sums skip_doc / doc_pointer)
+//   codec/postings/for_util.rs:196-223      block header byte (encode type, num_bits, all-equal vint)
+// The higher skip levels are subsampled copies of level 0 with child pointers; a flat level-0 directory plus
+// binary search gives the same `advance` answers, so only their byte lengths are parsed (to find level 0).
+//
+// VInt streams are decoded data-parallel: each thread inspects 4 bytes, a workgroup scan over terminator
+// counts yields each value's index, and the thread owning a terminator assembles the value by looking back
+// over its continuation bytes.
+#pragma once
+#include "decode.hpp"
+#include "types.hpp"
+
+namespace rgpu {
+
+constexpr int PREP_THREADS = 256;
+
+// workgroup exclusive scan for PREP_THREADS threads; `total` is uniform on return
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* wave_sums, uint32_t& total) {
+  const int lane = lane_id();
+  const int wave = (int)(threadIdx.x >> 6);
+  const uint32_t incl = (uint32_t)wave_incl_scan((int)v);
+  __syncthreads();  // protect wave_sums reuse
+  if (lane == 63) wave_sums[wave] = incl;
+  __syncthreads();
+  uint32_t off = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < PREP_THREADS / 64; ++w) {
+    const uint32_t s = wave_sums[w];
+    if (w < wave) off += s;
+    tot += s;
+  }
+  total = tot;
+  return off + incl - v;
+}
+
+__device__ __forceinline__ uint64_t read_vlong_serial(const uint8_t* p, int* len) {
+  uint64_t v = 0;
+  int i = 0;
+  for (; i < 9; ++i) {
+    uint64_t b = p[i];
+    v |= (b & 0x7f) << (7 * i);
+    if (!(b & 0x80)) { ++i; break; }
+  }
+  *len = i;
+  return v;
+}
+
+__device__ __forceinline__ int vint_len_serial(const uint8_t* p) {
+  int i = 0;
+  while (i < 4 && (p[i] & 0x80)) ++i;
+  return i + 1;
+}
+
+__global__ __launch_bounds__(PREP_THREADS) void k_prepare_terms(const uint8_t* __restrict__ doc, int64_t doc_len,
+                                                                 const PrepTerm* __restrict__ terms, int32_t* dir_last,
+                                                                 uint32_t* dir_off, uint16_t* dir_hdr, int* err) {
+  const PrepTerm t = terms[blockIdx.x];
+  const int tid = (int)threadIdx.x;
+  __shared__ uint32_t s_ws[PREP_THREADS / 64];
+  __shared__ int64_t s_l0;
+
+  if (t.n_entries > 0) {
+    // ---- where does level 0 start? (skip_reader.rs:481-509)
+    if (tid == 0) {
+      int64_t p = t.skip_fp;
+      for (int lvl = t.n_levels - 1; lvl >= 1; --lvl) {
+        int n;
+        uint64_t len = read_vlong_serial(doc + p, &n);
+        p += n + (int64_t)len;
+        if (p >= doc_len) { atomicMin(err, -4); p = t.skip_fp; break; }
+      }
+      s_l0 = p;
+    }
+    __syncthreads();
+    const uint8_t* l0 = doc + s_l0;
+    // ---- parallel VInt decode of 2 * n_entries values: even = docDelta (vint), odd = docFpDelta (vlong)
+    const uint32_t need = 2u * (uint32_t)t.n_entries;
+    uint32_t done = 0;
+    int64_t chunk = 0;
+    while (done < need) {
+      const int64_t my = chunk + 4 * tid;
+      const uint32_t w = load4_unaligned(l0 + my);
+      uint32_t term = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) term |= (((w >> (8 * j + 7)) & 1u) ^ 1u) << j;
+      uint32_t total;
+      uint32_t vi = done + block_excl_scan((uint32_t)__popc(term), s_ws, total);
+      while (term) {
+        const int j = __builtin_ctz(term);
+        term &= term - 1;
+        int64_t p = my + j;
+        uint64_t v = l0[p];
+        for (int back = 0; back < 9 && p > 0 && (l0[p - 1] & 0x80); ++back) {
+          --p;
+          v = (v << 7) | (uint64_t)(l0[p] & 0x7f);
+        }
+        if (vi < need) {
+          const uint32_t e = vi >> 1;
+          if (vi & 1) dir_off[t.dir_base + e + 1] = (uint32_t)v;
+          else dir_last[t.dir_base + e] = (int32_t)v;
+        }
+        ++vi;
+      }
+      if (total == 0) { if (tid == 0) atomicMin(err, -4); break; }  // 1 KiB without a terminator: corrupt
+      done += total;
+      chunk += 4 * PREP_THREADS;
+    }
+    __syncthreads();
+    // ---- deltas -> running sums (skip_doc[0] += delta ; doc_pointer[0] += delta, skip_reader.rs:530, 434)
+    uint32_t carry_doc = 0, carry_off = 0;
+    for (int e0 = 0; e0 < t.n_entries; e0 += PREP_THREADS) {
+      const int e = e0 + tid;
+      const bool ok = e < t.n_entries;
+      const uint32_t dd = ok ? (uint32_t)dir_last[t.dir_base + e] : 0u;
+      const uint32_t fo = ok ? dir_off[t.dir_base + e + 1] : 0u;
+      uint32_t tot_d, tot_o;
+      const uint32_t sd = block_excl_scan(dd, s_ws, tot_d) + dd + carry_doc;
+      const uint32_t so = block_excl_scan(fo, s_ws, tot_o) + fo + carry_off;
+      if (ok) {
+        dir_last[t.dir_base + e] = (int32_t)sd;
+        dir_off[t.dir_base + e + 1] = so;
+      }
+      carry_doc += tot_d;
+      carry_off += tot_o;
+    }
+  }
+  if (tid == 0) {
+    dir_off[t.dir_base] = 0;
+    if (t.nblocks > t.n_entries) dir_last[t.dir_base + t.nblocks - 1] = DIR_SENTINEL_DOC;  // df % 128 == 0
+  }
+  __syncthreads();
+  // ---- block headers (for_util.rs:196-223) + consistency of every skip pointer with the block sizes
+  for (int i = tid; i < t.nblocks; i += PREP_THREADS) {
+    const uint32_t off = dir_off[t.dir_base + i];
+    const uint8_t* p = doc + t.start_fp + off;
+    const uint32_t h = p[0];
+    const int bd = (int)(h & 63);
+    int vlen = 0;
+    if ((h >> 6) != 0) atomicMin(err, -5);  // EF / BITSET / FULL doc blocks: never written by Rucene
+    if (bd > 32) atomicMin(err, -4);
+    int doc_sz = 16 * bd;
+    if (bd == 0) { vlen = vint_len_serial(p + 1); doc_sz = vlen; }
+    const uint32_t h2 = p[1 + doc_sz];
+    const int bf = (int)(h2 & 63);
+    if (bf > 32) atomicMin(err, -4);
+    const int freq_sz = bf ? 16 * bf : vint_len_serial(p + 1 + doc_sz + 1);
+    const uint32_t end = off + 1u + (uint32_t)doc_sz + 1u + (uint32_t)freq_sz;
+    if (i < t.n_entries && end != dir_off[t.dir_base + i + 1]) atomicMin(err, -4);
+    if (i > 0 && i < t.n_entries && dir_last[t.dir_base + i] <= dir_last[t.dir_base + i - 1]) atomicMin(err, -4);
+    dir_hdr[t.dir_base + i] = (uint16_t)((uint32_t)bd | ((uint32_t)vlen << 6) | ((uint32_t)bf << 9));
+  }
+}
+
+}  // namespace rgpu

@@ -1,0 +1,52 @@
+// Device-visible plain structs shared by the host side of the C ABI and the kernels.
+#pragma once
+#include <stdint.h>
+
+namespace rgpu {
+
+// One segment's device-resident data (passed by value to kernels).
+struct SegView {
+  const uint8_t* doc;        // raw .doc bytes (+ zero padding so speculative 16-byte row loads never fault)
+  const uint8_t* norms;      // 1 byte per doc, or null (compute_score falls back to k1)
+  const uint64_t* live;      // FixedBitSet words or null (MatchAllBits)
+  const int32_t* dir_last;   // block directory: last doc id of block i            (skip level 0 docs, summed)
+  const uint32_t* dir_off;   // block directory: byte offset of block i from the term's doc_start_fp
+  const uint16_t* dir_hdr;   // block directory: b_doc | vint_len << 6 | b_freq << 9
+  const float* sim_tables;   // n x 257 floats: cache[256] then k1
+  int32_t max_doc;
+  int32_t doc_base;
+};
+
+// One term as the kernels see it (built on the host from rgpu_term_state + the directory cache).
+struct DevTerm {
+  uint64_t start_fp;      // doc_start_fp
+  uint32_t dir_base;      // first directory slot (nblocks + 1 slots)
+  int32_t nblocks;        // full 128-posting blocks
+  int32_t df;
+  int32_t tail_n;         // df % 128 when df > 1, else 0
+  int32_t singleton_doc;  // df == 1
+  int32_t singleton_freq;
+  float weight;           // idf * boost
+  int32_t sim_table;
+};
+
+// Work description of one term for the skip-decode ("prepare") kernel.
+struct PrepTerm {
+  uint64_t start_fp;
+  int64_t skip_fp;     // absolute, -1 when df <= 128
+  uint32_t dir_base;
+  int32_t nblocks;
+  int32_t n_entries;   // level-0 skip entries = ceil(df / 128) - 1
+  int32_t n_levels;    // 1 + floor(log8(trim(df) / 128)), capped at 10
+  int32_t df;
+  int32_t pad;
+};
+
+struct DevQuery {
+  int32_t op;
+  int32_t n_terms;
+  int32_t first_term;
+  int32_t pad;
+};
+
+}  // namespace rgpu

@@ -1,0 +1,118 @@
+// gfx950 wavefront primitives (wave64): DPP prefix scans, readlane helpers, monotone score keys.
+// Everything here assumes a full 64-lane wavefront executing convergently.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rgpu {
+
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+// Wave-synchronous LDS hand-off between lanes of one wavefront: LDS operations of a wave complete in issue
+// order, so only the compiler has to be kept from moving accesses across the hand-off point.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// DPP controls (CDNA ISA, DPP_CTRL): row_shr:n = 0x110+n, row_bcast:15 = 0x142, row_bcast:31 = 0x143,
+// wave_shr:1 = 0x138.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_or0(int v) {
+  // lanes whose source is out of range (or masked off by ROW_MASK) receive `old` = 0
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false);
+}
+
+// Inclusive +scan over the 64 lanes: 4 row_shr steps inside each 16-lane row, then two row broadcasts.
+__device__ __forceinline__ int wave_incl_scan(int v) {
+  v += dpp_or0<0x111, 0xf>(v);
+  v += dpp_or0<0x112, 0xf>(v);
+  v += dpp_or0<0x114, 0xf>(v);
+  v += dpp_or0<0x118, 0xf>(v);
+  v += dpp_or0<0x142, 0xa>(v);  // lane 15 of rows 0,2 -> rows 1,3
+  v += dpp_or0<0x143, 0xc>(v);  // lane 31 -> rows 2,3
+  return v;
+}
+
+__device__ __forceinline__ int readlane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, int l) {
+  uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
+  uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
+  return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ int readfirstlane(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// whole-wave shift towards higher lanes by one (lane 0 receives `fill`)
+__device__ __forceinline__ uint64_t wave_shr1_64(uint64_t v, uint64_t fill) {
+  int lo = __builtin_amdgcn_update_dpp((int)(uint32_t)fill, (int)(uint32_t)v, 0x138, 0xf, 0xf, false);
+  int hi = __builtin_amdgcn_update_dpp((int)(uint32_t)(fill >> 32), (int)(uint32_t)(v >> 32), 0x138, 0xf, 0xf, false);
+  return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
+}
+
+__device__ __forceinline__ int wave_reduce_add(int v) {
+  return readlane(wave_incl_scan(v), 63);
+}
+
+// number of set bits of `mask` below this lane
+__device__ __forceinline__ int mbcnt(uint64_t mask) {
+  return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// ---- (score, doc) -> one sortable u64; larger == better under "score desc, then doc asc" ----------------------
+__device__ __forceinline__ uint32_t float_order_bits(float f) {
+  uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float order_bits_float(uint32_t o) {
+  uint32_t u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+  return __uint_as_float(u);
+}
+__device__ __forceinline__ uint64_t make_key(float score, int32_t doc) {
+  return ((uint64_t)float_order_bits(score) << 32) | (uint32_t)(~(uint32_t)doc);
+}
+__device__ __forceinline__ int32_t key_doc(uint64_t k) { return (int32_t)(~(uint32_t)k); }
+__device__ __forceinline__ float key_score(uint64_t k) { return order_bits_float((uint32_t)(k >> 32)); }
+
+// ---- wave-resident top-k (k <= 128): rank r lives in lane r of `a` (r < 64) or lane r-64 of `b` ----------------
+struct WaveTopK {
+  uint64_t a = 0, b = 0;  // 0 == empty slot (every real key has a nonzero high word)
+};
+
+template <bool WIDE>  // WIDE: k > 64
+__device__ __forceinline__ void topk_insert(WaveTopK& t, uint64_t key, int lane) {
+  int pa = __popcll(__ballot(t.a > key));
+  if (pa < 64) {
+    uint64_t carry = readlane64(t.a, 63);
+    uint64_t up = wave_shr1_64(t.a, 0);
+    t.a = lane < pa ? t.a : (lane == pa ? key : up);
+    if (WIDE) t.b = wave_shr1_64(t.b, carry);
+  } else if (WIDE) {
+    int pb = __popcll(__ballot(t.b > key));
+    uint64_t up = wave_shr1_64(t.b, 0);
+    t.b = lane < pb ? t.b : (lane == pb ? key : up);
+  }
+}
+template <bool WIDE>
+__device__ __forceinline__ uint64_t topk_threshold(const WaveTopK& t, int k) {
+  if (WIDE && k > 64) return readlane64(t.b, k - 65);
+  return readlane64(t.a, k - 1);
+}
+
+// Offer one key per lane (invalid lanes pass 0); keeps `tau` (the current k-th best) up to date.
+template <bool WIDE>
+__device__ __forceinline__ void topk_offer(WaveTopK& t, uint64_t key, uint64_t& tau, int k, int lane) {
+  uint64_t m = __ballot(key > tau);
+  while (m) {
+    int src = __builtin_ctzll(m);
+    uint64_t x = readlane64(key, src);
+    topk_insert<WIDE>(t, x, lane);
+    tau = topk_threshold<WIDE>(t, k);
+    m &= m - 1;
+    m &= __ballot(key > tau);
+  }
+}
+
+}  // namespace rgpu

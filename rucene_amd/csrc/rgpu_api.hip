@@ -1,0 +1,831 @@
+// C ABI of the MI355X query-evaluation path (include/rucene_gpu.h): host-side orchestration around the
+// gfx950 kernels in kernels/*.hpp. HIP runtime only — no torch types, no CPU fallback: every entry point
+// either runs on the GPU or fails with a negative rgpu_status.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/rucene_gpu.h"
+#include "host/doc_format.hpp"
+#include "kernels/prepare.hpp"
+#include "kernels/search.hpp"
+
+using namespace rgpu;
+
+static_assert(sizeof(HitOut) == sizeof(rgpu_hit), "hit layout");
+
+static thread_local std::string g_last_error;
+
+static int32_t fail(int32_t code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+#define HIP_TRY(expr)                                                                                      \
+  do {                                                                                                     \
+    hipError_t _e = (expr);                                                                                \
+    if (_e != hipSuccess) return fail(RGPU_ERR_RUNTIME, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+
+namespace {
+
+// growable device array (copy-on-grow); sizes are element counts
+template <typename T>
+struct DevVec {
+  T* p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t n, size_t keep, hipStream_t s) {
+    if (n <= cap) return hipSuccess;
+    size_t ncap = std::max(n, cap * 2);
+    ncap = std::max<size_t>(ncap, 1024);
+    T* np = nullptr;
+    hipError_t e = hipMalloc(&np, ncap * sizeof(T));
+    if (e != hipSuccess) return e;
+    if (p && keep) {
+      e = hipMemcpyAsync(np, p, keep * sizeof(T), hipMemcpyDeviceToDevice, s);
+      if (e != hipSuccess) return e;
+      e = hipStreamSynchronize(s);
+      if (e != hipSuccess) return e;
+    }
+    if (p) (void)hipFree(p);
+    p = np;
+    cap = ncap;
+    return hipSuccess;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct HostPinned {
+  uint8_t* p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t n) {
+    if (n <= cap) return hipSuccess;
+    if (p) (void)hipHostFree(p);
+    cap = std::max(n, cap * 2);
+    return hipHostMalloc((void**)&p, cap, hipHostMallocDefault);
+  }
+  void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
+struct StatSlot {
+  std::string name;
+  int64_t launches = 0;
+  double total_ms = 0;
+  int64_t postings = 0;
+};
+struct PendingEvent { int slot; hipEvent_t start, stop; };
+
+}  // namespace
+
+struct rgpu_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  rgpu_config cfg{};
+  std::mutex mu;
+  DevVec<float> sim_tables;
+  int n_sim_tables = 0;
+  // per-call scratch
+  HostPinned h_stage;
+  DevVec<uint8_t> d_stage;
+  DevVec<uint64_t> d_partial_keys;
+  DevVec<int32_t> d_partial_counts;
+  DevVec<HitOut> d_hits;
+  DevVec<int64_t> d_totals;
+  int* d_err = nullptr;
+  // profiling
+  std::vector<StatSlot> stats;
+  std::vector<PendingEvent> pending;
+  std::vector<hipEvent_t> free_events;
+  char name[128] = {0};
+};
+
+struct TermInfo { uint32_t dir_base; int32_t nblocks; int32_t df; };
+
+struct rgpu_segment {
+  rgpu_ctx* ctx = nullptr;
+  uint8_t* d_doc = nullptr;
+  size_t doc_len = 0;
+  uint8_t* d_norms = nullptr;
+  uint64_t* d_live = nullptr;
+  int32_t max_doc = 0, doc_base = 0, version = 1;
+  DevVec<int32_t> dir_last;
+  DevVec<uint32_t> dir_off;
+  DevVec<uint16_t> dir_hdr;
+  size_t dir_used = 0;
+  std::unordered_map<int64_t, TermInfo> prepared;
+};
+
+// ---- profiling helpers -----------------------------------------------------------------------------------------
+static int stat_slot(rgpu_ctx* c, const char* name) {
+  for (size_t i = 0; i < c->stats.size(); ++i) if (c->stats[i].name == name) return (int)i;
+  c->stats.push_back(StatSlot{name, 0, 0.0, 0});
+  return (int)c->stats.size() - 1;
+}
+static hipEvent_t take_event(rgpu_ctx* c) {
+  if (!c->free_events.empty()) { hipEvent_t e = c->free_events.back(); c->free_events.pop_back(); return e; }
+  hipEvent_t e;
+  (void)hipEventCreate(&e);
+  return e;
+}
+struct TimedLaunch {
+  rgpu_ctx* c;
+  hipStream_t s;
+  int slot;
+  hipEvent_t stop = nullptr;
+  bool on;
+  TimedLaunch(rgpu_ctx* c_, hipStream_t s_, const char* name, int64_t postings) : c(c_), s(s_), on(c_->cfg.profile_kernels != 0) {
+    slot = stat_slot(c, name);
+    c->stats[(size_t)slot].launches++;
+    c->stats[(size_t)slot].postings += postings;
+    if (on) {
+      hipEvent_t start = take_event(c);
+      stop = take_event(c);
+      (void)hipEventRecord(start, s);
+      c->pending.push_back(PendingEvent{slot, start, stop});
+    }
+  }
+  ~TimedLaunch() { if (on) (void)hipEventRecord(stop, s); }
+};
+static void drain_events(rgpu_ctx* c) {
+  for (auto& pe : c->pending) {
+    (void)hipEventSynchronize(pe.stop);
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, pe.start, pe.stop) == hipSuccess) c->stats[(size_t)pe.slot].total_ms += ms;
+    c->free_events.push_back(pe.start);
+    c->free_events.push_back(pe.stop);
+  }
+  c->pending.clear();
+}
+
+// ---- staging: pack several host arrays into one pinned buffer, one H2D copy ---------------------------------
+struct Stager {
+  rgpu_ctx* c;
+  size_t used = 0;
+  std::vector<std::pair<size_t, size_t>> parts;  // offset, bytes
+  explicit Stager(rgpu_ctx* c_) : c(c_) {}
+  size_t add(size_t bytes) {
+    used = (used + 255) & ~size_t(255);
+    size_t off = used;
+    used += bytes;
+    return off;
+  }
+};
+
+static SegView seg_view(const rgpu_segment* s) {
+  SegView v;
+  v.doc = s->d_doc;
+  v.norms = s->d_norms;
+  v.live = s->d_live;
+  v.dir_last = s->dir_last.p;
+  v.dir_off = s->dir_off.p;
+  v.dir_hdr = s->dir_hdr.p;
+  v.sim_tables = s->ctx->sim_tables.p;
+  v.max_doc = s->max_doc;
+  v.doc_base = s->doc_base;
+  return v;
+}
+
+static int ilog8_levels(int32_t df) {  // skip_reader.rs:307-313 trim + :461-472
+  int32_t t = (df % 128 == 0) ? df - 1 : df;
+  if (t <= 128) return 1;
+  int levels = 1;
+  for (int64_t x = t / 128; x >= 8; x /= 8) levels++;
+  return std::min(levels, 10);
+}
+
+static int32_t validate_state(const rgpu_segment* seg, const rgpu_term_state& st) {
+  if (st.doc_freq < 0) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "negative doc_freq");
+  if (st.doc_freq <= 1) return RGPU_OK;
+  if (st.doc_start_fp < 0 || (size_t)st.doc_start_fp >= seg->doc_len)
+    return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "doc_start_fp outside the .doc file");
+  if (st.doc_freq > 128) {
+    if (st.skip_offset <= 0 || (size_t)(st.doc_start_fp + st.skip_offset) >= seg->doc_len)
+      return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "skip_offset outside the .doc file");
+    if (st.skip_offset > (int64_t)0xffffffffLL) return fail(RGPU_ERR_UNSUPPORTED, "a single term's postings exceed 4 GiB");
+  }
+  return RGPU_OK;
+}
+
+// Build block directories for every not-yet-seen term with df >= 128 (ctx mutex held by the caller).
+static int32_t prepare_terms_locked(rgpu_segment* seg, const rgpu_term_state* const* sts, size_t n) {
+  rgpu_ctx* c = seg->ctx;
+  std::vector<PrepTerm> work;
+  size_t need_slots = seg->dir_used;
+  std::vector<std::pair<int64_t, TermInfo>> added;
+  std::unordered_map<int64_t, int> in_batch;
+  for (size_t i = 0; i < n; ++i) {
+    const rgpu_term_state& st = *sts[i];
+    int32_t rc = validate_state(seg, st);
+    if (rc != RGPU_OK) return rc;
+    if (st.doc_freq < 128) continue;
+    auto it = seg->prepared.find(st.doc_start_fp);
+    if (it != seg->prepared.end()) {
+      if (it->second.df != st.doc_freq) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "term state changed doc_freq for a known doc_start_fp");
+      continue;
+    }
+    if (in_batch.count(st.doc_start_fp)) continue;
+    in_batch[st.doc_start_fp] = 1;
+    PrepTerm p;
+    p.start_fp = (uint64_t)st.doc_start_fp;
+    p.df = st.doc_freq;
+    p.nblocks = st.doc_freq / 128;
+    p.n_entries = (st.doc_freq + 127) / 128 - 1;
+    p.n_levels = ilog8_levels(st.doc_freq);
+    p.skip_fp = st.doc_freq > 128 ? st.doc_start_fp + st.skip_offset : -1;
+    p.dir_base = (uint32_t)need_slots;
+    p.pad = 0;
+    need_slots += (size_t)p.nblocks + 1;
+    if (need_slots > 0xfffffff0ull) return fail(RGPU_ERR_UNSUPPORTED, "block directory exceeds 2^32 slots");
+    work.push_back(p);
+    added.push_back({st.doc_start_fp, TermInfo{p.dir_base, p.nblocks, p.df}});
+  }
+  if (work.empty()) return RGPU_OK;
+  HIP_TRY(seg->dir_last.reserve(need_slots, seg->dir_used, c->stream));
+  HIP_TRY(seg->dir_off.reserve(need_slots, seg->dir_used, c->stream));
+  HIP_TRY(seg->dir_hdr.reserve(need_slots, seg->dir_used, c->stream));
+  const size_t bytes = work.size() * sizeof(PrepTerm);
+  HIP_TRY(c->h_stage.reserve(bytes));
+  HIP_TRY(c->d_stage.reserve(bytes, 0, c->stream));
+  std::memcpy(c->h_stage.p, work.data(), bytes);
+  HIP_TRY(hipMemcpyAsync(c->d_stage.p, c->h_stage.p, bytes, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream));
+  {
+    int64_t postings = 0;
+    for (auto& w : work) postings += w.df;
+    TimedLaunch tl(c, c->stream, "k_prepare_terms", postings);
+    hipLaunchKernelGGL(k_prepare_terms, dim3((unsigned)work.size()), dim3(PREP_THREADS), 0, c->stream, seg->d_doc,
+                       (int64_t)seg->doc_len, reinterpret_cast<const PrepTerm*>(c->d_stage.p), seg->dir_last.p,
+                       seg->dir_off.p, seg->dir_hdr.p, c->d_err);
+  }
+  int err = 0;
+  HIP_TRY(hipMemcpyAsync(&err, c->d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(hipGetLastError());
+  if (err != 0) {
+    return fail(err, err == RGPU_ERR_UNSUPPORTED ? "EF/BITSET/FULL encoded doc block (never written by Rucene) is not supported"
+                                                 : "corrupt skip data or block framing in .doc");
+  }
+  seg->dir_used = need_slots;
+  for (auto& a : added) seg->prepared[a.first] = a.second;
+  return RGPU_OK;
+}
+
+static int32_t make_dev_term(const rgpu_segment* seg, const rgpu_term_state& st, float weight, int32_t sim_table, DevTerm* out) {
+  DevTerm t;
+  std::memset(&t, 0, sizeof t);
+  t.start_fp = (uint64_t)std::max<int64_t>(0, st.doc_start_fp);
+  t.df = st.doc_freq;
+  t.weight = weight;
+  t.sim_table = sim_table;
+  t.singleton_doc = st.singleton_doc_id;
+  t.singleton_freq = (int32_t)st.total_term_freq;
+  if (st.doc_freq == 1 && (st.singleton_doc_id < 0 || st.singleton_doc_id >= seg->max_doc))
+    return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "singleton_doc_id out of range");
+  if (st.doc_freq >= 128) {
+    auto it = seg->prepared.find(st.doc_start_fp);
+    if (it == seg->prepared.end()) return fail(RGPU_ERR_ILLEGAL_STATE, "term not prepared");
+    t.dir_base = it->second.dir_base;
+    t.nblocks = it->second.nblocks;
+  }
+  t.tail_n = st.doc_freq > 1 ? st.doc_freq % 128 : 0;
+  *out = t;
+  return RGPU_OK;
+}
+
+// ---- context ---------------------------------------------------------------------------------------------------
+extern "C" int32_t rgpu_abi_version(void) { return RGPU_ABI_VERSION; }
+
+extern "C" const char* rgpu_last_error(rgpu_ctx*) { return g_last_error.c_str(); }
+
+extern "C" int32_t rgpu_init(int32_t device_ordinal, const rgpu_config* cfg, rgpu_ctx** out_ctx) {
+  if (!out_ctx) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "out_ctx is null");
+  *out_ctx = nullptr;
+  if (cfg && cfg->abi_version != RGPU_ABI_VERSION) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "rgpu_config.abi_version mismatch");
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+    return fail(RGPU_ERR_RUNTIME, "no HIP device present: this library has no CPU fallback");
+  if (device_ordinal < 0 || device_ordinal >= count) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "device ordinal out of range");
+  HIP_TRY(hipSetDevice(device_ordinal));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device_ordinal));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(RGPU_ERR_RUNTIME, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+  rgpu_ctx* c = new rgpu_ctx();
+  c->device = device_ordinal;
+  if (cfg) c->cfg = *cfg;
+  c->cfg.abi_version = RGPU_ABI_VERSION;
+  if (c->cfg.blocks_per_item <= 0) c->cfg.blocks_per_item = 32;
+  if (c->cfg.window_docs <= 0) c->cfg.window_docs = 4096;
+  c->cfg.window_docs = std::min(24576, std::max(1024, (c->cfg.window_docs + 1023) / 1024 * 1024));
+  std::snprintf(c->name, sizeof c->name, "%s (%s)", prop.name, prop.gcnArchName);
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipMalloc(&c->d_err, sizeof(int)) != hipSuccess) {
+    delete c;
+    return fail(RGPU_ERR_RUNTIME, "failed to create stream / error word");
+  }
+  *out_ctx = c;
+  return RGPU_OK;
+}
+
+extern "C" void rgpu_shutdown(rgpu_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  drain_events(c);
+  for (auto e : c->free_events) (void)hipEventDestroy(e);
+  c->sim_tables.release(); c->d_stage.release(); c->d_partial_keys.release(); c->d_partial_counts.release();
+  c->d_hits.release(); c->d_totals.release(); c->h_stage.release();
+  if (c->d_err) (void)hipFree(c->d_err);
+  (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+extern "C" int32_t rgpu_device_name(rgpu_ctx* c, char* buf, size_t len) {
+  if (!c || !buf || len == 0) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "bad arguments");
+  std::snprintf(buf, len, "%s", c->name);
+  return RGPU_OK;
+}
+
+extern "C" int32_t rgpu_synchronize(rgpu_ctx* c) {
+  if (!c) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "ctx is null");
+  std::lock_guard<std::mutex> g(c->mu);
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return RGPU_OK;
+}
+
+extern "C" int32_t rgpu_kernel_stats(rgpu_ctx* c, rgpu_kernel_stat* out, int32_t max_out) {
+  if (!c) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "ctx is null");
+  std::lock_guard<std::mutex> g(c->mu);
+  (void)hipSetDevice(c->device);
+  drain_events(c);
+  int32_t n = 0;
+  for (auto& s : c->stats) {
+    if (n >= max_out) break;
+    std::memset(&out[n], 0, sizeof(rgpu_kernel_stat));
+    std::snprintf(out[n].name, sizeof out[n].name, "%s", s.name.c_str());
+    out[n].launches = s.launches;
+    out[n].total_ms = s.total_ms;
+    out[n].postings = s.postings;
+    ++n;
+  }
+  return n;
+}
+
+extern "C" void rgpu_kernel_stats_reset(rgpu_ctx* c) {
+  if (!c) return;
+  std::lock_guard<std::mutex> g(c->mu);
+  (void)hipSetDevice(c->device);
+  drain_events(c);
+  c->stats.clear();
+}
+
+// ---- similarity tables ---------------------------------------------------------------------------------------
+extern "C" int32_t rgpu_sim_table_upload(rgpu_ctx* c, const float cache[256], float k1) {
+  if (!c || !cache) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "bad arguments");
+  std::lock_guard<std::mutex> g(c->mu);
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(c->sim_tables.reserve((size_t)(c->n_sim_tables + 1) * 257, (size_t)c->n_sim_tables * 257, c->stream));
+  float tmp[257];
+  std::memcpy(tmp, cache, 256 * sizeof(float));
+  tmp[256] = k1;
+  HIP_TRY(hipMemcpyAsync(c->sim_tables.p + (size_t)c->n_sim_tables * 257, tmp, sizeof tmp, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return c->n_sim_tables++;
+}
+
+// ---- segment ---------------------------------------------------------------------------------------------------
+extern "C" int32_t rgpu_segment_upload(rgpu_ctx* c, const uint8_t* doc_file, size_t doc_len, const uint8_t* norms,
+                                       int32_t max_doc, int32_t doc_base, const uint64_t* live_docs, rgpu_segment** out_seg) {
+  if (!c || !doc_file || !out_seg) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "bad arguments");
+  *out_seg = nullptr;
+  if (max_doc < 0) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "negative max_doc");
+  rucene::DocFileInfo info;
+  std::string why;
+  int rc = rucene::parse_doc_file(doc_file, doc_len, &info, &why);
+  if (rc != 0) return fail(rc, why);
+  std::lock_guard<std::mutex> g(c->mu);
+  HIP_TRY(hipSetDevice(c->device));
+  rgpu_segment* s = new rgpu_segment();
+  s->ctx = c;
+  s->doc_len = doc_len;
+  s->max_doc = max_doc;
+  s->doc_base = doc_base;
+  s->version = info.version;
+  const size_t pad = 8192;  // speculative row / tail loads may run past the last posting byte
+  auto bail = [&](hipError_t e, const char* what) { rgpu_segment_free(s); return fail(RGPU_ERR_RUNTIME, std::string(what) + ": " + hipGetErrorString(e)); };
+  hipError_t e;
+  if ((e = hipMalloc(&s->d_doc, doc_len + pad)) != hipSuccess) return bail(e, "hipMalloc(.doc)");
+  if ((e = hipMemsetAsync(s->d_doc + doc_len, 0, pad, c->stream)) != hipSuccess) return bail(e, "memset");
+  if ((e = hipMemcpyAsync(s->d_doc, doc_file, doc_len, hipMemcpyHostToDevice, c->stream)) != hipSuccess) return bail(e, "copy .doc");
+  if (norms && max_doc > 0) {
+    if ((e = hipMalloc(&s->d_norms, (size_t)max_doc + 64)) != hipSuccess) return bail(e, "hipMalloc(norms)");
+    if ((e = hipMemcpyAsync(s->d_norms, norms, (size_t)max_doc, hipMemcpyHostToDevice, c->stream)) != hipSuccess) return bail(e, "copy norms");
+  }
+  if (live_docs && max_doc > 0) {
+    const size_t words = ((size_t)max_doc + 63) / 64;
+    if ((e = hipMalloc(&s->d_live, words * 8)) != hipSuccess) return bail(e, "hipMalloc(live docs)");
+    if ((e = hipMemcpyAsync(s->d_live, live_docs, words * 8, hipMemcpyHostToDevice, c->stream)) != hipSuccess) return bail(e, "copy live docs");
+  }
+  if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return bail(e, "sync");
+  *out_seg = s;
+  return RGPU_OK;
+}
+
+extern "C" void rgpu_segment_free(rgpu_segment* s) {
+  if (!s) return;
+  (void)hipSetDevice(s->ctx->device);
+  (void)hipStreamSynchronize(s->ctx->stream);
+  if (s->d_doc) (void)hipFree(s->d_doc);
+  if (s->d_norms) (void)hipFree(s->d_norms);
+  if (s->d_live) (void)hipFree(s->d_live);
+  s->dir_last.release(); s->dir_off.release(); s->dir_hdr.release();
+  delete s;
+}
+
+extern "C" int32_t rgpu_segment_version(const rgpu_segment* s) { return s ? s->version : RGPU_ERR_ILLEGAL_ARGUMENT; }
+
+extern "C" int32_t rgpu_segment_prepare_terms(rgpu_segment* seg, const rgpu_term_state* terms, int64_t n_terms) {
+  if (!seg || (!terms && n_terms > 0) || n_terms < 0) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "bad arguments");
+  std::lock_guard<std::mutex> g(seg->ctx->mu);
+  HIP_TRY(hipSetDevice(seg->ctx->device));
+  std::vector<const rgpu_term_state*> ptrs((size_t)n_terms);
+  for (int64_t i = 0; i < n_terms; ++i) ptrs[(size_t)i] = &terms[i];
+  return prepare_terms_locked(seg, ptrs.data(), ptrs.size());
+}
+
+// ---- decode ----------------------------------------------------------------------------------------------------
+static int32_t decode_terms_impl(rgpu_segment* seg, const rgpu_term_state* terms, int64_t n_terms, int32_t* docs_dev,
+                                 int32_t* freqs_dev, hipStream_t stream, int64_t* total_out) {
+  rgpu_ctx* c = seg->ctx;
+  std::vector<const rgpu_term_state*> ptrs((size_t)n_terms);
+  for (int64_t i = 0; i < n_terms; ++i) ptrs[(size_t)i] = &terms[i];
+  int32_t rc = prepare_terms_locked(seg, ptrs.data(), ptrs.size());
+  if (rc != RGPU_OK) return rc;
+  Stager st(c);
+  const size_t o_terms = st.add((size_t)n_terms * sizeof(DevTerm));
+  const size_t o_items = st.add((size_t)(n_terms + 1) * 8);
+  const size_t o_out = st.add((size_t)(n_terms + 1) * 8);
+  HIP_TRY(c->h_stage.reserve(st.used));
+  HIP_TRY(c->d_stage.reserve(st.used, 0, c->stream));
+  DevTerm* ht = reinterpret_cast<DevTerm*>(c->h_stage.p + o_terms);
+  int64_t* hitems = reinterpret_cast<int64_t*>(c->h_stage.p + o_items);
+  int64_t* hout = reinterpret_cast<int64_t*>(c->h_stage.p + o_out);
+  int64_t items = 0, out = 0;
+  for (int64_t i = 0; i < n_terms; ++i) {
+    rc = make_dev_term(seg, terms[i], 0.f, 0, &ht[i]);
+    if (rc != RGPU_OK) return rc;
+    hitems[i] = items;
+    hout[i] = out;
+    items += ht[i].nblocks + ((ht[i].tail_n > 0 || ht[i].df == 1) ? 1 : 0);
+    out += terms[i].doc_freq;
+  }
+  hitems[n_terms] = items;
+  hout[n_terms] = out;
+  if (total_out) *total_out = out;
+  if (items == 0) return RGPU_OK;
+  HIP_TRY(hipMemcpyAsync(c->d_stage.p, c->h_stage.p, st.used, hipMemcpyHostToDevice, stream));
+  const unsigned grid = (unsigned)((items + WG_WAVES - 1) / WG_WAVES);
+  {
+    TimedLaunch tl(c, stream, "k_decode_terms", out);
+    auto args = [&](auto kern) {
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(WG_THREADS), 0, stream, seg_view(seg),
+                         reinterpret_cast<const DevTerm*>(c->d_stage.p + o_terms),
+                         reinterpret_cast<const int64_t*>(c->d_stage.p + o_items),
+                         reinterpret_cast<const int64_t*>(c->d_stage.p + o_out), (int)n_terms, items, docs_dev, freqs_dev);
+    };
+    if (seg->version >= 1) args(k_decode_terms<false>); else args(k_decode_terms<true>);
+  }
+  HIP_TRY(hipGetLastError());
+  return RGPU_OK;
+}
+
+extern "C" int32_t rgpu_decode_terms_device(rgpu_segment* seg, const rgpu_term_state* terms, int64_t n_terms, void* docs_dev,
+                                            void* freqs_dev, void* hip_stream) {
+  if (!seg || !terms || n_terms <= 0 || !docs_dev || !freqs_dev) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "bad arguments");
+  std::lock_guard<std::mutex> g(seg->ctx->mu);
+  HIP_TRY(hipSetDevice(seg->ctx->device));
+  hipStream_t s = hip_stream ? (hipStream_t)hip_stream : seg->ctx->stream;
+  // the staging buffer is reused by the next call: finish this launch's H2D before returning control
+  int32_t rc = decode_terms_impl(seg, terms, n_terms, (int32_t*)docs_dev, (int32_t*)freqs_dev, s, nullptr);
+  if (rc != RGPU_OK) return rc;
+  HIP_TRY(hipStreamSynchronize(s));
+  return RGPU_OK;
+}
+
+extern "C" int32_t rgpu_decode_terms(rgpu_segment* seg, const rgpu_term_state* terms, int64_t n_terms, int32_t* docs_out,
+                                     int32_t* freqs_out) {
+  if (!seg || !terms || n_terms <= 0 || !docs_out || !freqs_out) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "bad arguments");
+  rgpu_ctx* c = seg->ctx;
+  std::lock_guard<std::mutex> g(c->mu);
+  HIP_TRY(hipSetDevice(c->device));
+  int64_t total = 0;
+  for (int64_t i = 0; i < n_terms; ++i) { if (terms[i].doc_freq < 0) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "negative doc_freq"); total += terms[i].doc_freq; }
+  if (total == 0) return RGPU_OK;
+  int32_t *d_docs = nullptr, *d_freqs = nullptr;
+  HIP_TRY(hipMalloc(&d_docs, (size_t)total * 4));
+  if (hipMalloc(&d_freqs, (size_t)total * 4) != hipSuccess) { (void)hipFree(d_docs); return fail(RGPU_ERR_RUNTIME, "out of device memory"); }
+  int32_t rc = decode_terms_impl(seg, terms, n_terms, d_docs, d_freqs, c->stream, nullptr);
+  if (rc == RGPU_OK) {
+    hipError_t e1 = hipMemcpyAsync(docs_out, d_docs, (size_t)total * 4, hipMemcpyDeviceToHost, c->stream);
+    hipError_t e2 = hipMemcpyAsync(freqs_out, d_freqs, (size_t)total * 4, hipMemcpyDeviceToHost, c->stream);
+    hipError_t e3 = hipStreamSynchronize(c->stream);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) rc = fail(RGPU_ERR_RUNTIME, "device to host copy failed");
+  }
+  (void)hipFree(d_docs);
+  (void)hipFree(d_freqs);
+  return rc;
+}
+
+extern "C" int32_t rgpu_advance_batch(rgpu_segment* seg, const rgpu_term_state* term, const int32_t* targets, int64_t n,
+                                      int32_t* out_docs, int32_t* out_freqs) {
+  if (!seg || !term || !targets || n <= 0 || !out_docs || !out_freqs) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "bad arguments");
+  rgpu_ctx* c = seg->ctx;
+  std::lock_guard<std::mutex> g(c->mu);
+  HIP_TRY(hipSetDevice(c->device));
+  if (term->doc_freq <= 0) { for (int64_t i = 0; i < n; ++i) { out_docs[i] = RGPU_NO_MORE_DOCS; out_freqs[i] = 0; } return RGPU_OK; }
+  const rgpu_term_state* p = term;
+  int32_t rc = prepare_terms_locked(seg, &p, 1);
+  if (rc != RGPU_OK) return rc;
+  DevTerm T;
+  rc = make_dev_term(seg, *term, 0.f, 0, &T);
+  if (rc != RGPU_OK) return rc;
+  int32_t* d = nullptr;
+  HIP_TRY(hipMalloc(&d, (size_t)n * 12));
+  hipError_t e = hipMemcpyAsync(d, targets, (size_t)n * 4, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) {
+    TimedLaunch tl(c, c->stream, "k_advance", n);
+    const unsigned grid = (unsigned)((n + WG_WAVES - 1) / WG_WAVES);
+    if (seg->version >= 1)
+      hipLaunchKernelGGL(k_advance<false>, dim3(grid), dim3(WG_THREADS), 0, c->stream, seg_view(seg), T, d, n, d + n, d + 2 * n);
+    else
+      hipLaunchKernelGGL(k_advance<true>, dim3(grid), dim3(WG_THREADS), 0, c->stream, seg_view(seg), T, d, n, d + n, d + 2 * n);
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(out_docs, d + n, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(out_freqs, d + 2 * n, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(d);
+  if (e != hipSuccess) return fail(RGPU_ERR_RUNTIME, hipGetErrorString(e));
+  return RGPU_OK;
+}
+
+// ---- search ----------------------------------------------------------------------------------------------------
+namespace {
+struct Group {  // queries of one op, in their original order
+  std::vector<int32_t> qmap;    // original query index
+  std::vector<DevQuery> queries;
+  std::vector<DevTerm> terms;
+  std::vector<int64_t> item_prefix;
+  int64_t postings = 0;
+};
+}  // namespace
+
+template <bool WIDE>
+static void launch_merge(rgpu_ctx* c, hipStream_t s, int n_queries, int k, const int64_t* d_prefix, int32_t doc_base, HitOut* hits,
+                         int64_t* totals) {
+  TimedLaunch tl(c, s, "k_merge_items", 0);
+  const unsigned grid = (unsigned)((n_queries + WG_WAVES - 1) / WG_WAVES);
+  hipLaunchKernelGGL(k_merge_items<WIDE>, dim3(grid), dim3(WG_THREADS), 0, s, d_prefix, n_queries, k, c->d_partial_keys.p,
+                     c->d_partial_counts.p, doc_base, hits, totals);
+}
+
+static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t n_queries, const rgpu_query_term* terms,
+                           int32_t n_terms_total, int32_t k, HitOut* hits_dev, int64_t* totals_dev, hipStream_t stream) {
+  rgpu_ctx* c = seg->ctx;
+  if (k <= 0 || k > RGPU_MAX_K) return fail(k <= 0 ? RGPU_ERR_ILLEGAL_ARGUMENT : RGPU_ERR_UNSUPPORTED, "k must be in 1..RGPU_MAX_K");
+  // validate + prepare
+  std::vector<const rgpu_term_state*> ptrs;
+  for (int32_t q = 0; q < n_queries; ++q) {
+    const rgpu_query& Q = queries[q];
+    if (Q.op < RGPU_OP_TERM || Q.op > RGPU_OP_OR) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "unknown query op");
+    if (Q.n_terms < 1 || Q.n_terms > RGPU_MAX_QUERY_TERMS || (Q.op == RGPU_OP_TERM && Q.n_terms != 1))
+      return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "bad clause count");
+    if (Q.first_term < 0 || Q.first_term + Q.n_terms > n_terms_total) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "clause range outside terms[]");
+    for (int i = 0; i < Q.n_terms; ++i) {
+      const rgpu_query_term& t = terms[Q.first_term + i];
+      if (t.sim_table < 0 || t.sim_table >= c->n_sim_tables) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "unknown sim_table handle");
+      if (t.state.doc_freq > 0) ptrs.push_back(&t.state);
+    }
+  }
+  int32_t rc = prepare_terms_locked(seg, ptrs.data(), ptrs.size());
+  if (rc != RGPU_OK) return rc;
+
+  Group groups[3];
+  for (int32_t q = 0; q < n_queries; ++q) {
+    const rgpu_query& Q = queries[q];
+    Group& G = groups[Q.op];
+    DevQuery dq;
+    dq.op = Q.op;
+    dq.first_term = (int32_t)G.terms.size();
+    dq.n_terms = 0;
+    dq.pad = 0;
+    std::vector<DevTerm> mine;
+    bool dead = false;
+    for (int i = 0; i < Q.n_terms; ++i) {
+      const rgpu_query_term& t = terms[Q.first_term + i];
+      if (t.state.doc_freq <= 0) {  // TermWeight::create_scorer -> None for this leaf
+        if (Q.op != RGPU_OP_OR) dead = true;  // a missing MUST clause kills the conjunction (boolean_query.rs:201-207)
+        continue;
+      }
+      DevTerm dt;
+      rc = make_dev_term(seg, t.state, t.weight, t.sim_table, &dt);
+      if (rc != RGPU_OK) return rc;
+      mine.push_back(dt);
+    }
+    if (dead) mine.clear();
+    if (Q.op == RGPU_OP_AND)  // ConjunctionScorer::new: stable sort by cost() = doc_freq (conjunction_scorer.rs:30)
+      std::stable_sort(mine.begin(), mine.end(), [](const DevTerm& a, const DevTerm& b) { return a.df < b.df; });
+    dq.n_terms = (int32_t)mine.size();
+    for (auto& m : mine) { G.terms.push_back(m); G.postings += m.df; }
+    G.qmap.push_back(q);
+    G.queries.push_back(dq);
+  }
+
+  // defaults for every query (groups overwrite their own rows)
+  HIP_TRY(hipMemsetAsync(totals_dev, 0, (size_t)n_queries * 8, stream));
+  hipLaunchKernelGGL(k_init_hits, dim3((unsigned)(((size_t)n_queries * k + 255) / 256)), dim3(256), 0, stream, hits_dev,
+                     (int64_t)n_queries * k);
+
+  const bool wide = k > 64;
+  const bool legacy = seg->version < 1;
+  for (int op = 0; op < 3; ++op) {
+    Group& G = groups[op];
+    const int nq = (int)G.queries.size();
+    if (nq == 0) continue;
+    int blocks_per_item = c->cfg.blocks_per_item;
+    int W = c->cfg.window_docs, wpq = 0, wpi = 1, ipq = 0;
+    int64_t items = 0;
+    G.item_prefix.assign((size_t)nq + 1, 0);
+    if (op == RGPU_OP_TERM) {
+      while (true) {
+        items = 0;
+        for (int q = 0; q < nq; ++q) {
+          G.item_prefix[(size_t)q] = items;
+          if (G.queries[(size_t)q].n_terms == 1) {
+            const DevTerm& t = G.terms[(size_t)G.queries[(size_t)q].first_term];
+            items += t.nblocks == 0 ? 1 : (t.nblocks + blocks_per_item - 1) / blocks_per_item;
+          }
+        }
+        G.item_prefix[(size_t)nq] = items;
+        if (items <= 262144 || blocks_per_item >= (1 << 20)) break;
+        blocks_per_item *= 2;
+      }
+    } else {
+      wpq = (seg->max_doc + W - 1) / W;
+      if (wpq < 1) wpq = 1;
+      wpi = (int)std::max<int64_t>(1, ((int64_t)nq * wpq + 65535) / 65536);
+      ipq = (wpq + wpi - 1) / wpi;
+      items = (int64_t)nq * ipq;
+      for (int q = 0; q <= nq; ++q) G.item_prefix[(size_t)q] = (int64_t)q * ipq;
+    }
+    if (items == 0) continue;
+    // group-local outputs, scattered to the caller's rows afterwards
+    Stager st(c);
+    const size_t o_q = st.add((size_t)nq * sizeof(DevQuery));
+    const size_t o_t = st.add(std::max<size_t>(1, G.terms.size()) * sizeof(DevTerm));
+    const size_t o_p = st.add((size_t)(nq + 1) * 8);
+    const size_t o_m = st.add((size_t)nq * 4);
+    HIP_TRY(c->h_stage.reserve(st.used));
+    HIP_TRY(c->d_stage.reserve(st.used, 0, stream));
+    std::memcpy(c->h_stage.p + o_q, G.queries.data(), (size_t)nq * sizeof(DevQuery));
+    if (!G.terms.empty()) std::memcpy(c->h_stage.p + o_t, G.terms.data(), G.terms.size() * sizeof(DevTerm));
+    std::memcpy(c->h_stage.p + o_p, G.item_prefix.data(), (size_t)(nq + 1) * 8);
+    std::memcpy(c->h_stage.p + o_m, G.qmap.data(), (size_t)nq * 4);
+    HIP_TRY(hipMemcpyAsync(c->d_stage.p, c->h_stage.p, st.used, hipMemcpyHostToDevice, stream));
+    HIP_TRY(c->d_partial_keys.reserve((size_t)items * (size_t)k, 0, stream));
+    HIP_TRY(c->d_partial_counts.reserve((size_t)items, 0, stream));
+    HIP_TRY(c->d_hits.reserve((size_t)nq * (size_t)k, 0, stream));
+    HIP_TRY(c->d_totals.reserve((size_t)nq, 0, stream));
+    const DevQuery* dq = reinterpret_cast<const DevQuery*>(c->d_stage.p + o_q);
+    const DevTerm* dt = reinterpret_cast<const DevTerm*>(c->d_stage.p + o_t);
+    const int64_t* dp = reinterpret_cast<const int64_t*>(c->d_stage.p + o_p);
+    const int32_t* dm = reinterpret_cast<const int32_t*>(c->d_stage.p + o_m);
+    const SegView sv = seg_view(seg);
+    if (op == RGPU_OP_TERM) {
+      TimedLaunch tl(c, stream, "k_search_term", G.postings);
+      const unsigned grid = (unsigned)((items + WG_WAVES - 1) / WG_WAVES);
+      auto go = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(WG_THREADS), 0, stream, sv, dq, dt, dp, nq, items, blocks_per_item, (int)k,
+                           c->d_partial_keys.p, c->d_partial_counts.p);
+      };
+      if (legacy) { if (wide) go(k_search_term<true, true>); else go(k_search_term<true, false>); }
+      else { if (wide) go(k_search_term<false, true>); else go(k_search_term<false, false>); }
+    } else {
+      TimedLaunch tl(c, stream, op == RGPU_OP_AND ? "k_search_window_and" : "k_search_window_or", G.postings);
+      const size_t lds = (size_t)WINDOW_LDS_FIXED + (size_t)W * 5;
+      auto go = [&](auto kern) -> hipError_t {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3((unsigned)items), dim3(WG_THREADS), lds, stream, sv, dq, dt, nq, wpq, wpi, ipq, W, (int)k,
+                           c->d_partial_keys.p, c->d_partial_counts.p);
+        return hipSuccess;
+      };
+      hipError_t e;
+      if (op == RGPU_OP_AND) {
+        if (legacy) e = wide ? go(k_search_window<true, true, true>) : go(k_search_window<true, false, true>);
+        else e = wide ? go(k_search_window<false, true, true>) : go(k_search_window<false, false, true>);
+      } else {
+        if (legacy) e = wide ? go(k_search_window<true, true, false>) : go(k_search_window<true, false, false>);
+        else e = wide ? go(k_search_window<false, true, false>) : go(k_search_window<false, false, false>);
+      }
+      HIP_TRY(e);
+    }
+    if (wide) launch_merge<true>(c, stream, nq, k, dp, seg->doc_base, c->d_hits.p, c->d_totals.p);
+    else launch_merge<false>(c, stream, nq, k, dp, seg->doc_base, c->d_hits.p, c->d_totals.p);
+    // scatter group rows to the caller's rows
+    hipLaunchKernelGGL(k_scatter_rows, dim3((unsigned)nq), dim3(128), 0, stream, c->d_hits.p, c->d_totals.p, dm, (int)k, hits_dev, totals_dev);
+    HIP_TRY(hipGetLastError());
+    // d_stage / d_hits are reused by the next group
+    HIP_TRY(hipStreamSynchronize(stream));
+  }
+  return RGPU_OK;
+}
+
+extern "C" int32_t rgpu_search_batch_device(rgpu_segment* seg, const rgpu_query* queries, int32_t n_queries,
+                                            const rgpu_query_term* terms, int32_t n_terms_total, int32_t k, void* hits_dev,
+                                            void* totals_dev, void* hip_stream) {
+  if (!seg || !queries || n_queries <= 0 || !terms || n_terms_total <= 0 || !hits_dev || !totals_dev)
+    return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "bad arguments");
+  std::lock_guard<std::mutex> g(seg->ctx->mu);
+  HIP_TRY(hipSetDevice(seg->ctx->device));
+  hipStream_t s = hip_stream ? (hipStream_t)hip_stream : seg->ctx->stream;
+  int32_t rc = search_impl(seg, queries, n_queries, terms, n_terms_total, k, (HitOut*)hits_dev, (int64_t*)totals_dev, s);
+  if (rc != RGPU_OK) return rc;
+  HIP_TRY(hipStreamSynchronize(s));
+  return RGPU_OK;
+}
+
+extern "C" int32_t rgpu_search_batch(rgpu_segment* seg, const rgpu_query* queries, int32_t n_queries, const rgpu_query_term* terms,
+                                     int32_t n_terms_total, int32_t k, rgpu_hit* hits_out, int64_t* total_hits_out) {
+  if (!seg || !queries || n_queries <= 0 || !terms || n_terms_total <= 0 || !hits_out || !total_hits_out)
+    return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "bad arguments");
+  if (k <= 0 || k > RGPU_MAX_K) return fail(k <= 0 ? RGPU_ERR_ILLEGAL_ARGUMENT : RGPU_ERR_UNSUPPORTED, "k must be in 1..RGPU_MAX_K");
+  rgpu_ctx* c = seg->ctx;
+  std::lock_guard<std::mutex> g(c->mu);
+  HIP_TRY(hipSetDevice(c->device));
+  HitOut* d_hits = nullptr;
+  int64_t* d_tot = nullptr;
+  HIP_TRY(hipMalloc(&d_hits, (size_t)n_queries * (size_t)k * sizeof(HitOut)));
+  if (hipMalloc(&d_tot, (size_t)n_queries * 8) != hipSuccess) { (void)hipFree(d_hits); return fail(RGPU_ERR_RUNTIME, "out of device memory"); }
+  int32_t rc = search_impl(seg, queries, n_queries, terms, n_terms_total, k, d_hits, d_tot, c->stream);
+  if (rc == RGPU_OK) {
+    hipError_t e1 = hipMemcpyAsync(hits_out, d_hits, (size_t)n_queries * (size_t)k * sizeof(HitOut), hipMemcpyDeviceToHost, c->stream);
+    hipError_t e2 = hipMemcpyAsync(total_hits_out, d_tot, (size_t)n_queries * 8, hipMemcpyDeviceToHost, c->stream);
+    hipError_t e3 = hipStreamSynchronize(c->stream);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) rc = fail(RGPU_ERR_RUNTIME, "device to host copy failed");
+  }
+  (void)hipFree(d_hits);
+  (void)hipFree(d_tot);
+  return rc;
+}
+
+extern "C" int32_t rgpu_merge_topk_device(rgpu_ctx* c, const void* hits_dev, const void* totals_dev, int32_t n_lists, int32_t n_queries,
+                                          int32_t k, void* hits_out_dev, void* totals_out_dev, void* hip_stream) {
+  if (!c || !hits_dev || !totals_dev || !hits_out_dev || !totals_out_dev || n_lists <= 0 || n_queries <= 0)
+    return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "bad arguments");
+  if (k <= 0 || k > RGPU_MAX_K) return fail(k <= 0 ? RGPU_ERR_ILLEGAL_ARGUMENT : RGPU_ERR_UNSUPPORTED, "k must be in 1..RGPU_MAX_K");
+  std::lock_guard<std::mutex> g(c->mu);
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+  {
+    TimedLaunch tl(c, s, "k_merge_lists", 0);
+    const unsigned grid = (unsigned)((n_queries + WG_WAVES - 1) / WG_WAVES);
+    if (k > 64)
+      hipLaunchKernelGGL(k_merge_lists<true>, dim3(grid), dim3(WG_THREADS), 0, s, (const HitOut*)hits_dev, (const int64_t*)totals_dev,
+                         n_lists, n_queries, k, (HitOut*)hits_out_dev, (int64_t*)totals_out_dev);
+    else
+      hipLaunchKernelGGL(k_merge_lists<false>, dim3(grid), dim3(WG_THREADS), 0, s, (const HitOut*)hits_dev, (const int64_t*)totals_dev,
+                         n_lists, n_queries, k, (HitOut*)hits_out_dev, (int64_t*)totals_out_dev);
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(s));
+  return RGPU_OK;
+}
+
+// ---- host helpers: BM25Similarity (no GPU involved) ------------------------------------------------------------
+#include "host/bm25_similarity.hpp"
+
+extern "C" int32_t rgpu_bm25_compute_weight(float k1, float b, int64_t max_doc, int64_t doc_count, int64_t sum_total_term_freq,
+                                            const int64_t* doc_freqs, int32_t n_terms, float boost, float* weight_out,
+                                            float* idf_out, float* cache_out) {
+  if (!doc_freqs || n_terms <= 0 || n_terms > 64) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "bad arguments");
+  rucene::CollectionStatistics cs;
+  cs.max_doc = max_doc;
+  cs.doc_count = doc_count;
+  cs.sum_total_term_freq = sum_total_term_freq;
+  rucene::TermStatistics ts[64];
+  for (int i = 0; i < n_terms; ++i) ts[i].doc_freq = doc_freqs[i];
+  rucene::BM25SimWeight w = rucene::BM25Similarity(k1, b).compute_weight(cs, ts, (size_t)n_terms, boost);
+  if (weight_out) *weight_out = w.weight;
+  if (idf_out) *idf_out = w.idf;
+  if (cache_out) std::memcpy(cache_out, w.cache.data(), 256 * sizeof(float));
+  return RGPU_OK;
+}
+
+extern "C" uint8_t rgpu_bm25_encode_norm(float boost, int32_t field_length) {
+  return rucene::BM25Similarity::encode_norm_value(boost, field_length);
+}

@@ -1,0 +1,234 @@
+"""Host-side mirror of the slice of Rucene's search API that the GPU path serves, with the reference's names,
+argument meaning and error behaviour so tests read like the reference's own (paths relative to
+/root/reference/src/core):
+
+    search/searcher.rs:205-249, 306-363, 487-525, 732-767   IndexSearcher::search, statistics quirk
+    search/query/term_query.rs:45-95                         TermQuery::new(term, boost) / create_weight
+    search/query/boolean_query.rs:40-86                      BooleanQuery::build(musts, shoulds, ...)
+    search/similarity/bm25_similarity.rs:45-177              BM25Similarity::new(k1, b) / compute_weight
+    search/collector/top_docs.rs:97-183                      TopDocsCollector::new(k) / top_docs()
+    search/statistics.rs                                     CollectionStatistics / TermStatistics
+
+The term dictionary (block-tree) is out of scope: a LeafReader carries a flat table of
+BlockTermState records indexed by term id. All scoring work happens in librucene_gpu.so; this module only
+resolves terms, computes BM25 weights (via the C ABI's host helper) and packs query structs.
+"""
+import numpy as np
+
+from . import _lib
+from ._lib import OP_AND, OP_OR, OP_TERM, QUERY_DTYPE, QUERY_TERM_DTYPE, TERM_STATE_DTYPE, RgpuError
+
+
+class CollectionStatistics:
+    """search/statistics.rs CollectionStatistics (field-level)."""
+
+    def __init__(self, field, doc_base, max_doc, doc_count, sum_total_term_freq, sum_doc_freq=-1):
+        self.field, self.doc_base, self.max_doc = field, doc_base, max_doc
+        self.doc_count, self.sum_total_term_freq, self.sum_doc_freq = doc_count, sum_total_term_freq, sum_doc_freq
+
+
+class BM25Similarity:
+    """bm25_similarity.rs:45-63. compute_weight returns (weight, cache[256]) == BM25SimWeight{weight, cache}."""
+    DEFAULT_BM25_K1 = 1.2
+    DEFAULT_BM25_B = 0.75
+
+    def __init__(self, k1=DEFAULT_BM25_K1, b=DEFAULT_BM25_B):
+        self.k1, self.b = float(np.float32(k1)), float(np.float32(b))
+
+    def compute_weight(self, collection_stats, doc_freqs, boost=1.0):
+        w, _idf, cache = _lib.bm25_compute_weight(self.k1, self.b, collection_stats.max_doc, collection_stats.doc_count,
+                                                  collection_stats.sum_total_term_freq, doc_freqs, boost)
+        return w, cache
+
+    @staticmethod
+    def encode_norm_value(boost, field_length):
+        return _lib.bm25_encode_norm(boost, field_length)
+
+    def __str__(self):
+        return "BM25Similarity(k1: %s, b: %s)" % (self.k1, self.b)
+
+
+class LeafReader:
+    """One segment as the searcher sees it (index/reader/leaf_reader.rs:62-182, reduced to what BM25 term and
+    boolean queries read): postings file, norms, live docs, FieldReader statistics, flat term table."""
+
+    def __init__(self, doc_bytes, norms, max_doc, terms, doc_base=0, live_docs=None, doc_count=None,
+                 sum_total_term_freq=0, sum_doc_freq=-1, field="body"):
+        self.doc_bytes, self.norms, self.max_doc, self.doc_base = doc_bytes, norms, int(max_doc), int(doc_base)
+        self.terms = np.ascontiguousarray(terms, dtype=TERM_STATE_DTYPE)
+        self.live_docs = live_docs
+        self.doc_count = int(max_doc if doc_count is None else doc_count)
+        self.sum_total_term_freq, self.sum_doc_freq, self.field = int(sum_total_term_freq), int(sum_doc_freq), field
+        self.segment = None  # rgpu_segment, created by the searcher
+
+    @classmethod
+    def from_synthetic(cls, seg, doc_base=None):
+        return cls(seg.doc_bytes, seg.norms, seg.max_doc, seg.terms, seg.doc_base if doc_base is None else doc_base,
+                   seg.live_docs, seg.doc_count, seg.sum_total_term_freq, seg.sum_doc_freq)
+
+    def term_state(self, term_id):
+        """TermIterator::seek_exact + term_state(); None when the term is absent from this leaf."""
+        if term_id < 0 or term_id >= self.terms.size or self.terms[term_id]["doc_freq"] <= 0:
+            return None
+        return self.terms[term_id]
+
+
+class TermQuery:
+    def __init__(self, term, boost=1.0):
+        self.term, self.boost = int(term), float(boost)
+
+    def extract_terms(self):
+        return [self]
+
+    def __str__(self):
+        return "TermQuery(field: body, term: %d, boost: %s)" % (self.term, self.boost)
+
+
+class BooleanQuery:
+    """Only the trees the GPU path serves: all-MUST (AND) or all-SHOULD with min_should_match 1 (OR)."""
+
+    def __init__(self, must_queries, should_queries, min_should_match):
+        self.must_queries, self.should_queries, self.min_should_match = must_queries, should_queries, min_should_match
+
+    @staticmethod
+    def build(musts, shoulds, filters=(), must_nots=(), min_should_match=0):
+        # boolean_query.rs:40-86
+        msm = min_should_match if min_should_match > 0 else (1 if len(musts) == 0 else 0)
+        if len(musts) + len(shoulds) + len(filters) + len(must_nots) == 0:
+            raise RgpuError(-2, "boolean query should at least contain one inner query!")
+        if len(must_nots) == 0 and len(musts) + len(shoulds) + len(filters) == 1 and len(filters) == 0:
+            return (list(musts) + list(shoulds))[0]
+        if filters or must_nots or (musts and shoulds) or msm > 1:
+            raise RgpuError(-5, "only pure-MUST and pure-SHOULD (min_should_match 1) term trees run on the GPU path")
+        if any(not isinstance(q, TermQuery) for q in list(musts) + list(shoulds)):
+            raise RgpuError(-5, "nested boolean clauses are not supported on the GPU path")
+        return BooleanQuery(list(musts), list(shoulds), msm)
+
+    def extract_terms(self):
+        return list(self.must_queries) + list(self.should_queries)
+
+
+class TopDocs:
+    def __init__(self, total_hits, score_docs):
+        self._total, self._docs = int(total_hits), score_docs
+
+    def total_hits(self):
+        return self._total
+
+    def score_docs(self):
+        """[(doc, score)] best first: score desc, then doc asc (the canonical tie rule)."""
+        return self._docs
+
+
+class TopDocsCollector:
+    def __init__(self, estimated_hits):
+        self.estimated_hits = int(estimated_hits)
+        self._result = TopDocs(0, [])
+
+    def needs_scores(self):
+        return True
+
+    def top_docs(self):
+        return self._result
+
+
+class GpuIndexSearcher:
+    """IndexSearcher over GPU-resident leaves. `search(query, collector)` mirrors searcher.rs:487-525;
+    `search_batch` is the batched form the hardware wants (one launch set per leaf for many queries)."""
+
+    def __init__(self, leaves, ctx=None, similarity=None):
+        self.leaves = list(leaves)
+        self.ctx = ctx or _lib.Context()
+        self.similarity = similarity or BM25Similarity()
+        for leaf in self.leaves:
+            if leaf.segment is None:
+                leaf.segment = _lib.Segment(self.ctx, leaf.doc_bytes, leaf.norms, leaf.max_doc, leaf.doc_base, leaf.live_docs)
+        # searcher.rs:306-363: statistics of the first leaf with the largest max_doc stand in for the index
+        self._stats_leaf = 0
+        for i, leaf in enumerate(self.leaves):
+            if leaf.max_doc > self.leaves[self._stats_leaf].max_doc:
+                self._stats_leaf = i
+        sl = self.leaves[self._stats_leaf]
+        self.collection_statistics = CollectionStatistics(sl.field, sl.doc_base, self.max_doc(), sl.doc_count,
+                                                          sl.sum_total_term_freq, sl.sum_doc_freq)
+        self._weights = {}
+
+    def max_doc(self):
+        return sum(leaf.max_doc for leaf in self.leaves)
+
+    def term_statistics(self, term_id):
+        """searcher.rs:732-767: df of the term in the statistics leaf only (0 when absent there)."""
+        st = self.leaves[self._stats_leaf].term_state(term_id)
+        return 0 if st is None else int(st["doc_freq"])
+
+    def _weight(self, term_id, boost):
+        key = (term_id, boost)
+        if key not in self._weights:
+            w, cache = self.similarity.compute_weight(self.collection_statistics, [self.term_statistics(term_id)], boost)
+            self._weights[key] = (w, self.ctx.sim_table(cache, self.similarity.k1))
+        return self._weights[key]
+
+    @staticmethod
+    def _flatten(query):
+        if isinstance(query, TermQuery):
+            return OP_TERM, [query]
+        if isinstance(query, BooleanQuery):
+            if query.must_queries:
+                return OP_AND, query.must_queries
+            return OP_OR, query.should_queries
+        raise RgpuError(-5, "query type not served by the GPU path: %r" % (query,))
+
+    def pack(self, queries, leaf):
+        """queries -> (rgpu_query[], rgpu_query_term[]) for one leaf."""
+        flat = [self._flatten(q) for q in queries]
+        n_terms = sum(len(t) for _, t in flat)
+        qs = np.zeros(len(flat), dtype=QUERY_DTYPE)
+        ts = np.zeros(max(n_terms, 1), dtype=QUERY_TERM_DTYPE)
+        pos = 0
+        for i, (op, clauses) in enumerate(flat):
+            if len(clauses) > _lib.MAX_QUERY_TERMS:
+                raise RgpuError(-5, "more than %d clauses" % _lib.MAX_QUERY_TERMS)
+            qs[i] = (op, len(clauses), pos, 0)
+            for c in clauses:
+                w, table = self._weight(c.term, c.boost)
+                st = leaf.term_state(c.term)
+                if st is not None:
+                    ts[pos]["state"] = st
+                else:
+                    ts[pos]["state"]["doc_freq"] = 0
+                    ts[pos]["state"]["skip_offset"] = -1
+                    ts[pos]["state"]["singleton_doc_id"] = -1
+                ts[pos]["weight"] = w
+                ts[pos]["sim_table"] = table
+                pos += 1
+        return qs, ts
+
+    def search_batch(self, queries, k):
+        """-> (hits[n][k] structured {doc, score}, total_hits[n]) merged over all leaves."""
+        per_leaf = []
+        for leaf in self.leaves:
+            qs, ts = self.pack(queries, leaf)
+            per_leaf.append(leaf.segment.search_batch(qs, ts, k))
+        if len(per_leaf) == 1:
+            return per_leaf[0]
+        return self._merge_leaves(per_leaf, len(queries), k)
+
+    def _merge_leaves(self, per_leaf, n_queries, k):
+        # TopDocsCollector::finish_parallel (top_docs.rs:157-172) on the device: [leaf][query][k] -> [query][k]
+        import torch
+        hits = torch.from_numpy(np.stack([h.view(np.int64).reshape(n_queries, k) for h, _ in per_leaf])).cuda()
+        totals = torch.from_numpy(np.stack([t for _, t in per_leaf])).cuda()
+        out_h = torch.empty((n_queries, k), dtype=torch.int64, device="cuda")
+        out_t = torch.empty((n_queries,), dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        self.ctx.merge_topk_device(hits.data_ptr(), totals.data_ptr(), len(per_leaf), n_queries, k, out_h.data_ptr(), out_t.data_ptr())
+        return out_h.cpu().numpy().view(_lib.HIT_DTYPE).reshape(n_queries, k), out_t.cpu().numpy()
+
+    def search(self, query, collector):
+        """IndexSearcher::search(query, collector) for a TopDocsCollector."""
+        if not isinstance(collector, TopDocsCollector):
+            raise RgpuError(-5, "only TopDocsCollector is served by the GPU path")
+        hits, totals = self.search_batch([query], collector.estimated_hits)
+        row = hits[0]
+        docs = [(int(d), float(s)) for d, s in zip(row["doc"], row["score"]) if d >= 0]
+        collector._result = TopDocs(int(totals[0]), docs)

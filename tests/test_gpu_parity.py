@@ -1,0 +1,299 @@
+"""GPU parity tests proper (`-m gpu`, run on an MI355X through gpurun): every C-ABI entry point against the CPU
+oracle on the same seeded inputs. Integer/byte/index work must be bit-exact; BM25 scores are bit-exact for TERM,
+AND and OR with < 10 clauses, and within 1e-5 relative for OR with >= 10 clauses (the reference's own summation
+order there depends on heap topology — SURVEY.md §3.5)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+EDGE_DFS = [1, 2, 3, 64, 127, 128, 129, 255, 256, 257, 383, 384, 1023, 1024, 1025, 1152, 1153, 8192, 8193, 9000, 70_000]
+
+
+def _postings(rng, df, max_doc, max_freq=10):
+    docs = np.sort(rng.choice(max_doc, size=df, replace=False)).astype(np.int32)
+    freqs = np.minimum(max_freq, rng.geometric(0.5, size=df)).astype(np.int32)
+    return docs, freqs
+
+
+def _edge_lists(seed, max_doc):
+    rng = np.random.default_rng(seed)
+    out = [_postings(rng, df, max_doc) for df in EDGE_DFS]
+    out.append((np.arange(0, 300 * 3, 3, dtype=np.int32) + 5, np.ones(300, np.int32)))       # b == 0 doc + freq blocks
+    out.append((np.arange(260, dtype=np.int32), np.full(260, 7, np.int32)))                   # delta 1, freq const
+    wide = np.sort(rng.choice(max_doc, size=200, replace=False)).astype(np.int32)
+    out.append((wide, rng.integers(1, 2**20, size=200).astype(np.int32)))                     # wide freq bits + big vints
+    big = np.sort(rng.choice(max_doc, size=1300, replace=False)).astype(np.int32)
+    out.append((big, rng.integers(1, 2**31 - 1, size=1300).astype(np.int32)))                 # 31-bit freq blocks
+    return out
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import rucene_amd
+    c = rucene_amd.Context(profile_kernels=True)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module", params=[1, 0], ids=["bp128", "legacy"])
+def edge_index(request, ctx, oracle):
+    import rucene_amd
+    from rucene_amd import indexgen
+    max_doc = 600_000
+    lists = _edge_lists(41, max_doc)
+    rng = np.random.default_rng(2)
+    norms = rng.integers(90, 130, size=max_doc).astype(np.uint8)
+    seg = indexgen.build_explicit(max_doc, lists, norms=norms, version=request.param)
+    seg.sum_total_term_freq = 100 * max_doc
+    oseg = oracle.Segment(seg.doc_bytes, seg.norms, max_doc, seg.terms, sum_total_term_freq=seg.sum_total_term_freq)
+    gseg = rucene_amd.Segment(ctx, seg.doc_bytes, seg.norms, max_doc)
+    return seg, lists, oseg, gseg
+
+
+def test_decode_terms_bit_exact(edge_index):
+    seg, lists, oseg, gseg = edge_index
+    docs, freqs = gseg.decode_terms(seg.terms)
+    want_d = np.concatenate([d for d, _ in lists])
+    want_f = np.concatenate([f for _, f in lists])
+    assert docs.size == want_d.size
+    assert (docs == want_d).all()
+    assert (freqs == want_f).all()
+    # and against the oracle's BlockDocIterator, term by term
+    o = 0
+    for st in seg.terms:
+        d, f = oseg.decode_term(st)
+        assert (docs[o:o + d.size] == d).all() and (freqs[o:o + d.size] == f).all()
+        o += d.size
+
+
+def test_decode_single_terms_and_reordering(edge_index):
+    seg, lists, _, gseg = edge_index
+    order = np.random.default_rng(3).permutation(len(lists))
+    docs, freqs = gseg.decode_terms(seg.terms[order])
+    o = 0
+    for t in order:
+        d, f = lists[t]
+        assert (docs[o:o + d.size] == d).all() and (freqs[o:o + d.size] == f).all()
+        o += d.size
+
+
+def test_advance_matches_oracle(edge_index, oracle):
+    seg, lists, oseg, gseg = edge_index
+    rng = np.random.default_rng(9)
+    for t, (docs, freqs) in enumerate(lists):
+        targets = np.unique(np.concatenate([
+            rng.integers(0, seg.max_doc, size=200), docs[rng.integers(0, docs.size, size=50)],
+            docs[rng.integers(0, docs.size, size=50)] + 1, [0, int(docs[0]), int(docs[-1]), int(docs[-1]) + 1, seg.max_doc - 1]
+        ])).astype(np.int32)
+        got_d, got_f = gseg.advance(seg.terms[t], targets)
+        idx = np.searchsorted(docs, targets, side="left")
+        ok = idx < docs.size
+        assert (got_d[~ok] == oracle.NO_MORE_DOCS).all()
+        assert (got_d[ok] == docs[idx[ok]]).all() and (got_f[ok] == freqs[idx[ok]]).all()
+        # spot-check against the oracle iterator itself (fresh iterator per probe: advance from the start)
+        for tg in targets[:: max(1, targets.size // 12)]:
+            it = oseg.postings(seg.terms[t])
+            want = it.advance(int(tg))
+            i = int(np.where(targets == tg)[0][0])
+            assert got_d[i] == want
+            if want != oracle.NO_MORE_DOCS:
+                assert got_f[i] == it.freq()
+
+
+# ---- search ----------------------------------------------------------------------------------------------------------
+def _oracle_many(osearcher, oracle, specs, k, tie):
+    ops = [op for op, _ in specs]
+    offs = np.zeros(len(specs) + 1, np.int32)
+    offs[1:] = np.cumsum([len(t) for _, t in specs])
+    tids = np.concatenate([np.asarray(t, np.int64) for _, t in specs])
+    return osearcher.search_batch(ops, offs, tids, k, tie_mode=tie, threads=4)
+
+
+def _check_against_oracle(oracle, osearcher, gsearcher, specs, k, exact=True):
+    import rucene_amd
+    queries = []
+    for op, tids in specs:
+        if op == oracle.OP_TERM:
+            queries.append(rucene_amd.TermQuery(tids[0]))
+        elif op == oracle.OP_AND:
+            queries.append(rucene_amd.BooleanQuery.build([rucene_amd.TermQuery(t) for t in tids], []))
+        else:
+            queries.append(rucene_amd.BooleanQuery.build([], [rucene_amd.TermQuery(t) for t in tids]))
+    hits, totals = gsearcher.search_batch(queries, k)
+    cd, cs, cc, ct, _, _ = _oracle_many(osearcher, oracle, specs, k, oracle.TIE_CANONICAL)
+    rd, rs, rc, rt, _, _ = _oracle_many(osearcher, oracle, specs, k, oracle.TIE_RUST_HEAP)
+    for i in range(len(specs)):
+        n = int(cc[i])
+        gd, gs = hits[i]["doc"], hits[i]["score"]
+        assert totals[i] == ct[i] == rt[i], (i, specs[i])
+        assert (gd[n:] == -1).all()
+        if exact:
+            assert (gd[:n] == cd[i, :n]).all(), (i, specs[i], gd[:n], cd[i, :n])
+            assert (gs[:n].view(np.int32) == cs[i, :n].view(np.int32)).all(), (i, specs[i])
+        else:
+            np.testing.assert_allclose(gs[:n], cs[i, :n], rtol=1e-5, atol=0)
+            # doc ids may only differ where scores tie within the tolerance
+            diff = gd[:n] != cd[i, :n]
+            if diff.any():
+                assert np.allclose(gs[:n][diff], cs[i, :n][diff], rtol=1e-5)
+        # SURVEY §8(c) rule against the Rust-heap emulation: same score multiset, same docs above the k-th score,
+        # ties at the k-th score drawn from docs that really have that score (here: present in canonical order
+        # or not at all — checked via score equality)
+        m = int(rc[i])
+        assert m == n
+        if exact and n:
+            assert (np.sort(rs[i, :m]) == np.sort(gs[:n])).all()
+            kth = gs[n - 1]
+            assert set(rd[i, :m][rs[i, :m] > kth]) == set(gd[:n][gs[:n] > kth])
+
+
+@pytest.fixture(scope="module")
+def zipf(ctx, oracle):
+    import rucene_amd
+    from rucene_amd import indexgen
+    seg = indexgen.build_zipf(300_000, 50_000)
+    oseg = oracle.Segment(seg.doc_bytes, seg.norms, seg.max_doc, seg.terms, sum_total_term_freq=seg.sum_total_term_freq)
+    osearcher = oracle.Searcher([oseg])
+    gsearcher = rucene_amd.GpuIndexSearcher([rucene_amd.LeafReader.from_synthetic(seg)], ctx=ctx)
+    return seg, osearcher, gsearcher
+
+
+def test_bm25_weight_matches_oracle(zipf, oracle):
+    seg, osearcher, gsearcher = zipf
+    for t in (0, 5, 100, 4000, 49_999):
+        w, table = gsearcher._weight(t, 1.0)
+        ow, ocache = osearcher.term_weight(t)
+        assert np.float32(w).view(np.int32) == np.float32(ow).view(np.int32)
+    w, _, cache = __import__("rucene_amd").bm25_compute_weight(1.2, 0.75, seg.max_doc, seg.max_doc, seg.sum_total_term_freq, [int(seg.terms[7]["doc_freq"])])
+    ow, ocache = osearcher.term_weight(7)
+    assert (cache.view(np.int32) == ocache.view(np.int32)).all()
+
+
+@pytest.mark.parametrize("k", [10, 100])
+def test_single_term_queries(zipf, oracle, k):
+    seg, osearcher, gsearcher = zipf
+    from rucene_amd import indexgen
+    ranks = indexgen.log_uniform_ranks(96, 1, 20_000, seed=11 + k)
+    specs = [(oracle.OP_TERM, [int(r - 1)]) for r in ranks] + [(oracle.OP_TERM, [t]) for t in (0, 1, 468, 469, 470, 49_999)]
+    _check_against_oracle(oracle, osearcher, gsearcher, specs, k)
+
+
+@pytest.mark.parametrize("k", [10, 100])
+def test_conjunctions(zipf, oracle, k):
+    seg, osearcher, gsearcher = zipf
+    from rucene_amd import indexgen
+    ranks = indexgen.log_uniform_ranks(3 * 64, 1, 1000, seed=5 + k).reshape(-1, 3)
+    specs = [(oracle.OP_AND, [int(r - 1) for r in row]) for row in ranks]
+    specs += [(oracle.OP_AND, [0, 1]), (oracle.OP_AND, [0, 1, 2, 3, 4]), (oracle.OP_AND, [2, 2]), (oracle.OP_AND, [10, 40_000])]
+    _check_against_oracle(oracle, osearcher, gsearcher, specs, k)
+
+
+@pytest.mark.parametrize("n_clauses", [2, 5, 9])
+def test_disjunctions_exact_below_ten_clauses(zipf, oracle, n_clauses):
+    seg, osearcher, gsearcher = zipf
+    from rucene_amd import indexgen
+    ranks = indexgen.log_uniform_ranks(n_clauses * 24, 1, 10_000, seed=17 + n_clauses).reshape(-1, n_clauses)
+    specs = [(oracle.OP_OR, [int(r - 1) for r in row]) for row in ranks]
+    _check_against_oracle(oracle, osearcher, gsearcher, specs, 100)
+
+
+def test_disjunctions_ten_clauses_within_tolerance(zipf, oracle):
+    seg, osearcher, gsearcher = zipf
+    from rucene_amd import indexgen
+    ranks = indexgen.log_uniform_ranks(10 * 24, 1, 10_000, seed=23).reshape(-1, 10)
+    specs = [(oracle.OP_OR, [int(r - 1) for r in row]) for row in ranks]
+    _check_against_oracle(oracle, osearcher, gsearcher, specs, 100, exact=False)
+
+
+def test_mixed_batch_and_edge_terms(edge_index, ctx, oracle):
+    import rucene_amd
+    seg, lists, oseg, gseg = edge_index
+    osearcher = oracle.Searcher([oseg])
+    leaf = rucene_amd.LeafReader(seg.doc_bytes, seg.norms, seg.max_doc, seg.terms, sum_total_term_freq=seg.sum_total_term_freq)
+    leaf.segment = gseg
+    gsearcher = rucene_amd.GpuIndexSearcher([leaf], ctx=ctx)
+    n = len(lists)
+    specs = [(oracle.OP_TERM, [t]) for t in range(n)]
+    specs += [(oracle.OP_AND, [n - 5, t]) for t in range(n - 6)] + [(oracle.OP_AND, [20, 18, 19]), (oracle.OP_AND, [0, 20])]
+    specs += [(oracle.OP_OR, [t, (t + 7) % n, (t + 13) % n]) for t in range(n)]
+    _check_against_oracle(oracle, osearcher, gsearcher, specs, 10)
+    _check_against_oracle(oracle, osearcher, gsearcher, specs[: n + 4], 128)
+
+
+def test_live_docs_no_norms_absent_terms(ctx, oracle):
+    import rucene_amd
+    from rucene_amd import indexgen
+    max_doc = 50_000
+    rng = np.random.default_rng(77)
+    lists = [_postings(rng, df, max_doc) for df in (5, 300, 3000, 20_000)] + [(np.zeros(0, np.int32), np.zeros(0, np.int32))]
+    live = rng.integers(0, 2**63, size=(max_doc + 63) // 64, dtype=np.uint64) | rng.integers(0, 2**63, size=(max_doc + 63) // 64, dtype=np.uint64)
+    for norms in (rng.integers(95, 125, size=max_doc).astype(np.uint8), None):
+        seg = indexgen.build_explicit(max_doc, lists, norms=norms)
+        oseg = oracle.Segment(seg.doc_bytes, seg.norms, max_doc, seg.terms, live_docs=live, sum_total_term_freq=70 * max_doc)
+        leaf = rucene_amd.LeafReader(seg.doc_bytes, seg.norms, max_doc, seg.terms, live_docs=live, sum_total_term_freq=70 * max_doc)
+        osearcher = oracle.Searcher([oseg])
+        gsearcher = rucene_amd.GpuIndexSearcher([leaf], ctx=ctx)
+        specs = [(oracle.OP_TERM, [t]) for t in range(5)]
+        specs += [(oracle.OP_AND, [1, 3]), (oracle.OP_AND, [2, 3, 1]), (oracle.OP_AND, [3, 4]), (oracle.OP_OR, [0, 4, 2]), (oracle.OP_OR, [4, 4])]
+        _check_against_oracle(oracle, osearcher, gsearcher, specs, 10)
+
+
+def test_multi_leaf_statistics_quirk_and_doc_base(ctx, oracle):
+    """BM25 statistics come from the largest leaf only (searcher.rs:311-351); hits carry doc + doc_base."""
+    import rucene_amd
+    from rucene_amd import indexgen
+    segs = [indexgen.build_zipf(40_000, 5_000, shard=0), indexgen.build_zipf(90_000, 5_000, shard=1), indexgen.build_zipf(90_000, 5_000, shard=2)]
+    bases = [0, 40_000, 130_000]
+    osegs = [oracle.Segment(s.doc_bytes, s.norms, s.max_doc, s.terms, doc_base=b, sum_total_term_freq=s.sum_total_term_freq) for s, b in zip(segs, bases)]
+    osearcher = oracle.Searcher(osegs)
+    assert oracle.lib().orc_searcher_stats_leaf(osearcher._h) == 1
+    leaves = [rucene_amd.LeafReader.from_synthetic(s, doc_base=b) for s, b in zip(segs, bases)]
+    gsearcher = rucene_amd.GpuIndexSearcher(leaves, ctx=ctx)
+    specs = [(oracle.OP_TERM, [t]) for t in (0, 3, 50, 700, 4_999)] + [(oracle.OP_AND, [0, 2, 5]), (oracle.OP_OR, [1, 30, 200, 900])]
+    _check_against_oracle(oracle, osearcher, gsearcher, specs, 20)
+
+
+def test_search_api_reads_like_the_reference(zipf):
+    import rucene_amd
+    _, _, searcher = zipf
+    collector = rucene_amd.TopDocsCollector(3)
+    searcher.search(rucene_amd.TermQuery(7, 1.0), collector)
+    top = collector.top_docs()
+    assert top.total_hits() > 0 and len(top.score_docs()) == 3
+    scores = [s for _, s in top.score_docs()]
+    assert scores == sorted(scores, reverse=True)
+
+
+def test_error_codes(ctx):
+    import rucene_amd
+    from rucene_amd import indexgen
+    seg = indexgen.build_explicit(1000, [(np.arange(0, 900, 3, dtype=np.int32), np.ones(300, np.int32))])
+    bad = seg.doc_bytes.copy()
+    bad[0] ^= 0xFF
+    with pytest.raises(rucene_amd.RgpuError) as e:
+        rucene_amd.Segment(ctx, bad, seg.norms, 1000)
+    assert e.value.status == -4  # CorruptIndex
+    g = rucene_amd.Segment(ctx, seg.doc_bytes, seg.norms, 1000)
+    qs = np.zeros(1, rucene_amd.QUERY_DTYPE)
+    ts = np.zeros(1, rucene_amd.QUERY_TERM_DTYPE)
+    qs[0] = (0, 1, 0, 0)
+    ts[0]["state"] = seg.terms[0]
+    ts[0]["sim_table"] = 9999
+    with pytest.raises(rucene_amd.RgpuError) as e:
+        g.search_batch(qs, ts, 10)  # unknown sim_table handle
+    assert e.value.status == -2  # IllegalArgument
+    with pytest.raises(rucene_amd.RgpuError) as e:
+        g.search_batch(qs, ts, 1000)
+    assert e.value.status == -5  # k > RGPU_MAX_K -> UnsupportedOperation
+    # corrupt skip pointer -> CorruptIndex from the skip-decode kernel
+    corrupt = seg.doc_bytes.copy()
+    st = seg.terms[0]
+    p = int(st["doc_start_fp"] + st["skip_offset"])
+    while corrupt[p] & 0x80:  # skip the first entry's docDelta vint ...
+        p += 1
+    corrupt[p + 1] ^= 0x01      # ... and damage its docFpDelta
+    g2 = rucene_amd.Segment(ctx, corrupt, seg.norms, 1000)
+    with pytest.raises(rucene_amd.RgpuError) as e:
+        g2.decode_terms(seg.terms[:1])
+    assert e.value.status == -4
