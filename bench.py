@@ -1,0 +1,291 @@
+#!/usr/bin/env python3
+"""bench.py — the hot path on BASELINE.json's metric: queries/sec + postings decoded/sec, BM25, 10M-doc Zipfian.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch: 1024 single-term BM25 queries (BASELINE.json configs[1],
+SURVEY.md §8(d)) evaluated on the GPU against a 10M-doc Zipfian segment that is already resident in HBM
+(decode -> BM25 -> top-10). With N GPUs the index is segment-sharded (one 10M-doc shard per rank, shard = rank),
+the query batch is replicated, every rank evaluates it against its shard, per-shard top-k is all-gathered over
+RCCL and merged on the GPU — weak scaling: the unit is one query evaluated against one 10M-doc segment.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+SEED_QUERIES = 0x527563656E65 ^ 0x51  # "Rucene" ^ purpose tag
+
+
+def term_encoded_bytes(terms, doc_len_end):
+    """Encoded postings bytes per term (blocks + VInt tail, no skip data), from the term table alone:
+    df > 128 -> skip_offset (the skip data starts right after the postings); otherwise next term's start."""
+    start = terms["doc_start_fp"].astype(np.int64)
+    nxt = np.empty_like(start)
+    nxt[:-1] = start[1:]
+    nxt[-1] = doc_len_end
+    out = np.where(terms["doc_freq"] > 128, terms["skip_offset"], nxt - start)
+    out[terms["doc_freq"] <= 1] = 0
+    return out.astype(np.int64)
+
+
+def build_queries(n_queries, kind, seed):
+    from rucene_amd import indexgen
+    if kind == "term":
+        ranks = indexgen.log_uniform_ranks(n_queries, 1, 10_000, seed).reshape(-1, 1)
+    elif kind == "and3":
+        ranks = indexgen.log_uniform_ranks(3 * n_queries, 1, 1000, seed ^ 0xA3).reshape(-1, 3)
+    else:
+        ranks = indexgen.log_uniform_ranks(10 * n_queries, 1, 10_000, seed ^ 0x0A).reshape(-1, 10)
+    return ranks - 1  # term ids
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--docs", type=int, default=10_000_000)
+    ap.add_argument("--vocab", type=int, default=1_000_000)
+    ap.add_argument("--queries", type=int, default=1024)
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--workload", choices=["term", "and3", "or10"], default="term")
+    ap.add_argument("--extra", action="store_true", help="also time the AND / OR workloads and the block-decode microbench")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N > 1)" % (args.gpus, world))
+
+    import torch
+    import torch.distributed as dist
+    import rucene_amd
+    from rucene_amd import indexgen
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: rucene_amd has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    # ---- inputs: one 10M-doc shard per rank, resident in HBM before anything is timed -------------------------
+    t0 = time.time()
+    seg = indexgen.build_zipf(args.docs, args.vocab, shard=rank, doc_base=rank * args.docs)
+    gen_s = time.time() - t0
+    ctx = rucene_amd.Context(device=local_rank, profile_kernels=True)
+    leaf = rucene_amd.LeafReader.from_synthetic(seg)
+    searcher = rucene_amd.GpuIndexSearcher([leaf], ctx=ctx)
+    # BM25 statistics are those of the largest leaf = shard 0 (searcher.rs:311-351; all shards are equal-sized,
+    # the first wins). Shard 0's table is regenerated on other ranks only for its doc_freqs.
+    stats_seg = seg if rank == 0 else indexgen.build_zipf(args.docs, args.vocab, shard=0)
+    searcher.collection_statistics = rucene_amd.CollectionStatistics("body", 0, args.docs * world, stats_seg.doc_count,
+                                                                     stats_seg.sum_total_term_freq)
+    stats_df = stats_seg.terms["doc_freq"].astype(np.int64)
+    searcher.term_statistics = lambda t: int(stats_df[t])
+
+    def make_batch(kind):
+        tids = build_queries(args.queries, kind, SEED_QUERIES)
+        T, B = rucene_amd.TermQuery, rucene_amd.BooleanQuery
+        if kind == "term":
+            qs = [T(int(t[0])) for t in tids]
+        elif kind == "and3":
+            qs = [B.build([T(int(x)) for x in t], []) for t in tids]
+        else:
+            qs = [B.build([], [T(int(x)) for x in t]) for t in tids]
+        packed = searcher.pack(qs, leaf)
+        enc = term_encoded_bytes(seg.terms, seg.doc_bytes.size - 16)
+        flat = tids.reshape(-1)
+        postings = int(seg.terms["doc_freq"][flat].sum())
+        algo_bytes = int(enc[flat].sum()) + postings + 8 * args.k * args.queries  # encoded + 1 B norm/posting + output
+        return tids, packed, postings, algo_bytes
+
+    k, nq = args.k, args.queries
+    hits_local = torch.empty((nq, k), dtype=torch.int64, device="cuda")      # rgpu_hit {i32 doc, f32 score}
+    totals_local = torch.empty((nq,), dtype=torch.int64, device="cuda")
+    if world > 1:
+        hits_all = torch.empty((world, nq, k), dtype=torch.int64, device="cuda")
+        totals_all = torch.empty((world, nq), dtype=torch.int64, device="cuda")
+        hits_merged = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+        totals_merged = torch.empty((nq,), dtype=torch.int64, device="cuda")
+
+    def step(packed):
+        stream = torch.cuda.current_stream().cuda_stream
+        leaf.segment.search_batch_device(packed[0], packed[1], k, hits_local.data_ptr(), totals_local.data_ptr(), stream)
+        if world > 1:
+            dist.all_gather_into_tensor(hits_all, hits_local)
+            dist.all_gather_into_tensor(totals_all, totals_local)
+            ctx.merge_topk_device(hits_all.data_ptr(), totals_all.data_ptr(), world, nq, k, hits_merged.data_ptr(),
+                                  totals_merged.data_ptr(), stream)
+
+    def timed(packed, steps, warmup):
+        for _ in range(warmup):
+            step(packed)
+        torch.cuda.synchronize()
+        ctx.kernel_stats_reset()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(steps):
+            step(packed)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t
+        if world > 1:
+            tt = torch.tensor([el], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        return el, ctx.kernel_stats()
+
+    tids, packed, postings, algo_bytes = make_batch(args.workload)
+    elapsed, kstats = timed(packed, args.steps, args.warmup)
+    ms_per_step = 1e3 * elapsed / args.steps
+    g_hits = hits_local.cpu().numpy().view(rucene_amd.HIT_DTYPE).reshape(nq, k).copy()
+    g_totals = totals_local.cpu().numpy().copy()
+    seg_queries_per_s = world * nq * args.steps / elapsed
+    dom_name = {"term": "k_search_term", "and3": "k_search_window_and", "or10": "k_search_window_or"}[args.workload]
+    dom = kstats.get(dom_name, {"launches": 0, "total_ms": 0.0})
+    dom_ms = dom["total_ms"] / max(1, dom["launches"])
+    achieved = algo_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+
+    out = {
+        "metric": "queries/sec + postings decoded/sec, BM25 10M-doc synthetic",
+        "value": seg_queries_per_s,
+        "unit": "queries/s (one query evaluated against one %dM-doc segment; x n_gpus shards)" % (args.docs // 1_000_000),
+        "queries_per_sec": nq * args.steps / elapsed,
+        "postings_per_sec": world * postings * args.steps / elapsed,
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 decode + f32 BM25",
+        "data": "synthetic",
+        "config": {
+            "workload": {"term": "1024 single-term BM25 queries top-10, ranks log-uniform 1..10000 (BASELINE configs[1])",
+                         "and3": "1024 x 3-term AND top-10, ranks log-uniform 1..1000 (BASELINE configs[2])",
+                         "or10": "1024 x 10-term OR top-%d, ranks log-uniform 1..10000 (BASELINE configs[3])" % k}[args.workload],
+            "docs_per_shard": args.docs, "vocab": args.vocab, "n_queries": nq, "k": k, "doc_format": ".doc v1 (SIMD-BP128)",
+            "parallelism": "segment-sharded x%d, RCCL all-gather of per-shard top-k" % world,
+            "postings_per_step_per_shard": postings, "index_build_s": round(gen_s, 2), "device": ctx.device_name,
+        },
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "kernel": dom_name, "kernel_ms": dom_ms, "algorithmic_bytes_per_launch": algo_bytes,
+                     "frac_vs_measured_copy_6290": achieved / 6290.0},
+        "kernels_ms_per_step": {n: s["total_ms"] / args.steps for n, s in kstats.items()},
+    }
+
+    if args.extra and rank == 0:
+        extra = {}
+        # block-decode microbench: every term with df >= 128 of the shard, docs+freqs materialised in HBM
+        sel = seg.terms[seg.terms["doc_freq"] >= 128]
+        total = int(sel["doc_freq"].sum())
+        d_docs = torch.empty((total,), dtype=torch.int32, device="cuda")
+        d_freqs = torch.empty((total,), dtype=torch.int32, device="cuda")
+        enc = term_encoded_bytes(seg.terms, seg.doc_bytes.size - 16)[seg.terms["doc_freq"] >= 128]
+        for _ in range(2):
+            leaf.segment.decode_terms_device(sel, d_docs.data_ptr(), d_freqs.data_ptr())
+        ctx.kernel_stats_reset()
+        reps = 5
+        for _ in range(reps):
+            leaf.segment.decode_terms_device(sel, d_docs.data_ptr(), d_freqs.data_ptr())
+        st = ctx.kernel_stats()["k_decode_terms"]
+        ms = st["total_ms"] / st["launches"]
+        b = int(enc.sum()) + 8 * total
+        extra["block_decode"] = {"postings": total, "kernel_ms": ms, "postings_per_sec": total / (ms * 1e-3),
+                                 "algorithmic_bytes": b, "achieved_GBs": b / (ms * 1e-3) / 1e9,
+                                 "frac_of_8TBs": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        del d_docs, d_freqs
+        for kind, kk in (("and3", 10), ("or10", 100)):
+            if kind == args.workload:
+                continue
+            k_saved = k
+            try:
+                _, pk, post, ab = make_batch(kind)
+                hits_x = torch.empty((nq, kk), dtype=torch.int64, device="cuda")
+                totals_x = torch.empty((nq,), dtype=torch.int64, device="cuda")
+                for _ in range(1):
+                    leaf.segment.search_batch_device(pk[0], pk[1], kk, hits_x.data_ptr(), totals_x.data_ptr())
+                ctx.kernel_stats_reset()
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                reps = 3
+                for _ in range(reps):
+                    leaf.segment.search_batch_device(pk[0], pk[1], kk, hits_x.data_ptr(), totals_x.data_ptr())
+                torch.cuda.synchronize()
+                el = time.perf_counter() - t
+                extra[kind] = {"queries_per_sec": nq * reps / el, "postings_per_sec": post * reps / el, "ms_per_step": 1e3 * el / reps,
+                               "k": kk, "kernels_ms_per_step": {n: s["total_ms"] / reps for n, s in ctx.kernel_stats().items()}}
+                if not args.no_cpu_baseline:
+                    from oracle import binding as orc
+                    x_tids = build_queries(nq, kind, SEED_QUERIES)
+                    oseg_x = orc.Segment(seg.doc_bytes, seg.norms, seg.max_doc, seg.terms, sum_total_term_freq=seg.sum_total_term_freq)
+                    osr_x = orc.Searcher([oseg_x])
+                    xop = np.full(nq, orc.OP_AND if kind == "and3" else orc.OP_OR, np.int32)
+                    xoffs = (np.arange(nq + 1) * x_tids.shape[1]).astype(np.int32)
+                    xd, xs, xc, xt, xv, xsecs = osr_x.search_batch(xop, xoffs, x_tids.reshape(-1), kk, tie_mode=orc.TIE_CANONICAL,
+                                                                   threads=os.cpu_count() or 1)
+                    gx = hits_x.cpu().numpy().view(rucene_amd.HIT_DTYPE).reshape(nq, kk)
+                    extra[kind]["cpu_baseline_queries_per_sec"] = nq / xsecs
+                    extra[kind]["cpu_cores"] = os.cpu_count()
+                    extra[kind]["gpu_over_cpu"] = extra[kind]["queries_per_sec"] / (nq / xsecs)
+                    extra[kind]["totals_match"] = bool((totals_x.cpu().numpy() == xt).all())
+                    extra[kind]["parity"] = bool(np.allclose(gx["score"], xs, rtol=1e-5 if kind == "or10" else 0, atol=0)
+                                                 and (kind == "or10" or (gx["doc"] == xd).all()))
+            finally:
+                k = k_saved
+        out["extra"] = extra
+
+    # ---- CPU baseline: the oracle (a C++ port of Rucene's CPU IndexSearcher), rank 0, N = 1 only -------------
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import binding as orc
+        cores = os.cpu_count() or 1
+        oseg = orc.Segment(seg.doc_bytes, seg.norms, seg.max_doc, seg.terms, sum_total_term_freq=seg.sum_total_term_freq)
+        osearcher = orc.Searcher([oseg])
+        op = {"term": orc.OP_TERM, "and3": orc.OP_AND, "or10": orc.OP_OR}[args.workload]
+        ops = np.full(nq, op, np.int32)
+        offs = (np.arange(nq + 1) * tids.shape[1]).astype(np.int32)
+        spent, done_q, reps = 0.0, 0, 0
+        parity = None
+        while spent < 10.0 and reps < 50:
+            cd, cs, cc, ct, vis, secs = osearcher.search_batch(ops, offs, tids.reshape(-1), k, tie_mode=orc.TIE_RUST_HEAP, threads=cores)
+            spent += secs
+            done_q += nq
+            reps += 1
+        # parity of the timed GPU output against the oracle on the full batch (canonical tie rule)
+        cd, cs, cc, ct, _, _ = osearcher.search_batch(ops, offs, tids.reshape(-1), k, tie_mode=orc.TIE_CANONICAL, threads=cores)
+        if args.workload == "or10":  # >= 10 clauses: the reference's own sum order is heap-dependent -> 1e-5 relative
+            parity = bool(np.allclose(g_hits["score"], cs, rtol=1e-5, atol=0) and (g_totals == ct).all())
+        else:
+            parity = bool((g_hits["doc"] == cd).all() and (g_hits["score"].view(np.int32) == cs.view(np.int32)).all()
+                          and (g_totals == ct).all())
+        out["cpu_baseline"] = {"value": done_q / spent, "unit": "queries/s", "cores": cores, "kind": "port",
+                               "postings_per_sec": float(postings) * reps / spent,
+                               "sample": "the same 1024-query batch x %d repetitions (%.1f s), one query per thread, %d threads, "
+                                         "oracle = C++ restatement of Rucene's CPU IndexSearcher (the Rust original cannot be built here)"
+                                         % (reps, spent, cores)}
+        out["gpu_over_cpu"] = out["queries_per_sec"] / out["cpu_baseline"]["value"]
+        out["parity_vs_oracle_full_batch"] = parity
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
