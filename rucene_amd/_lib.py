@@ -137,12 +137,15 @@ def bm25_encode_norm(boost, field_length):
 class Context:
     """rgpu_ctx: one per process per GPU."""
 
-    def __init__(self, device=0, profile_kernels=False, blocks_per_item=0, window_docs=0):
+    def __init__(self, device=0, profile_kernels=False, blocks_per_item=0, window_docs=0, and_blocks_per_item=0,
+                 and_via_windows=False):
         cfg = _Config()
         cfg.abi_version = 1
         cfg.blocks_per_item = blocks_per_item
         cfg.window_docs = window_docs
         cfg.profile_kernels = int(profile_kernels)
+        cfg.reserved[0] = and_blocks_per_item
+        cfg.reserved[1] = int(and_via_windows)
         h = C.c_void_p()
         _check(lib().rgpu_init(device, C.byref(cfg), C.byref(h)))
         self._h = h

@@ -101,25 +101,31 @@ struct BlockPair {
   uint32_t f0, f1;  // freqs
 };
 
-// Decode one FullBlock starting at `blk` (header byte of the doc-delta block). `hdr` comes from the block
-// directory. `slab` is this wave's LDS slab. Wave-uniform control flow.
-template <bool LEGACY>
-__device__ __forceinline__ BlockPair decode_block(const uint8_t* __restrict__ blk, uint32_t hdr, uint8_t* slab, int lane) {
+// Phase 1 of a FullBlock decode: issue this lane's 16-byte payload row load (lanes 0..31 -> doc rows, lanes
+// 32..63 -> freq rows). Split from phase 2 so callers can issue block i+1's load before decoding block i.
+__device__ __forceinline__ uint4 block_rows_load(const uint8_t* __restrict__ blk, uint32_t hdr, int lane) {
   const int bd = hdr_bdoc(hdr);
   const int bf = hdr_bfreq(hdr);
   const int doc_sz = bd ? 16 * bd : hdr_vlen(hdr);
-  const uint8_t* doc_payload = blk + 1;
-  const uint8_t* freq_payload = blk + 1 + doc_sz + 1;
-  // stage payload rows: lanes 0..31 -> doc rows, lanes 32..63 -> freq rows
+  const int half = lane >> 5;
+  const int row = lane & 31;
+  const int rows = half ? bf : bd;
+  uint4 v = make_uint4(0u, 0u, 0u, 0u);
+  if (row < rows) v = load16_unaligned(blk + 1 + (half ? doc_sz + 1 : 0) + 16 * row);
+  return v;
+}
+
+// Phase 2: stage the rows in the wave's LDS slab and extract postings 2*lane, 2*lane+1. `blk` = header byte of
+// the doc-delta block, `hdr` from the block directory. Wave-uniform control flow.
+template <bool LEGACY>
+__device__ __forceinline__ BlockPair block_rows_decode(uint4 rows, const uint8_t* __restrict__ blk, uint32_t hdr, uint8_t* slab, int lane) {
+  const int bd = hdr_bdoc(hdr);
+  const int bf = hdr_bfreq(hdr);
+  const int doc_sz = bd ? 16 * bd : hdr_vlen(hdr);
   {
     const int half = lane >> 5;
     const int row = lane & 31;
-    const int rows = half ? bf : bd;
-    if (row < rows) {
-      const uint8_t* src = (half ? freq_payload : doc_payload) + 16 * row;
-      uint4 v = load16_unaligned(src);
-      *reinterpret_cast<uint4*>(slab + half * SLAB_STREAM + 16 * row) = v;
-    }
+    if (row < (half ? bf : bd)) *reinterpret_cast<uint4*>(slab + half * SLAB_STREAM + 16 * row) = rows;
   }
   wave_sync();
   BlockPair out;
@@ -129,7 +135,7 @@ __device__ __forceinline__ BlockPair decode_block(const uint8_t* __restrict__ bl
     else extract_pair_bp128(words, bd, lane, out.d0, out.d1);
   } else {
     int n;
-    out.d0 = out.d1 = read_vint_uniform(doc_payload, &n);
+    out.d0 = out.d1 = read_vint_uniform(blk + 1, &n);
   }
   if (bf) {
     const uint32_t* words = reinterpret_cast<const uint32_t*>(slab + SLAB_STREAM);
@@ -137,11 +143,30 @@ __device__ __forceinline__ BlockPair decode_block(const uint8_t* __restrict__ bl
     else extract_pair_bp128(words, bf, lane, out.f0, out.f1);
   } else {
     int n;
-    out.f0 = out.f1 = read_vint_uniform(freq_payload, &n);
+    out.f0 = out.f1 = read_vint_uniform(blk + 1 + doc_sz + 1, &n);
   }
   wave_sync();  // slab is free for the next block
   return out;
 }
+
+template <bool LEGACY>
+__device__ __forceinline__ BlockPair decode_block(const uint8_t* __restrict__ blk, uint32_t hdr, uint8_t* slab, int lane) {
+  return block_rows_decode<LEGACY>(block_rows_load(blk, hdr, lane), blk, hdr, slab, lane);
+}
+
+// A wave's view of up to 64 consecutive directory entries (one coalesced load), read back with readlane so
+// the per-block loop carries no dependent directory loads.
+struct DirChunk {
+  uint32_t off, hdr;
+  __device__ __forceinline__ void load(const uint32_t* __restrict__ dir_off, const uint16_t* __restrict__ dir_hdr, uint32_t base, int first,
+                                       int count, int lane) {
+    const bool ok = lane < count;
+    off = ok ? dir_off[base + first + lane] : 0u;
+    hdr = ok ? (uint32_t)dir_hdr[base + first + lane] : 0u;
+  }
+  __device__ __forceinline__ uint32_t off_at(int i) const { return (uint32_t)readlane((int)off, i); }
+  __device__ __forceinline__ uint32_t hdr_at(int i) const { return (uint32_t)readlane((int)hdr, i); }
+};
 
 // deltas -> absolute doc ids (the `accum + delta` chain of posting_reader.rs:622-646, as a wave scan)
 __device__ __forceinline__ void deltas_to_docs(uint32_t d0, uint32_t d1, int32_t base, int32_t& doc0, int32_t& doc1) {

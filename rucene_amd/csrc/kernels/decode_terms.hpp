@@ -1,4 +1,4 @@
-// Materialising decode of whole terms: one wavefront per 128-posting block (or per VInt tail / singleton),
+// Materialising decode of whole terms: one wavefront per chunk of 128-posting blocks (+ VInt tail / singleton),
 // docs and freqs written to HBM. GPU counterpart of BlockDocIterator::{refill_docs, next}
 // (codec/postings/posting_reader.rs:501-561, 612-647) driven to exhaustion, and the block-decode microbenchmark.
 // Also k_advance: BlockDocIterator::advance (posting_reader.rs:649-789) for independent probes.
@@ -21,11 +21,15 @@ __device__ __forceinline__ int upper_slot(const int64_t* __restrict__ prefix, in
   return lo;
 }
 
+// Items = (term, chunk of `blocks_per_item` blocks); the last chunk of a term also decodes its VInt tail or
+// singleton. Directory entries of a chunk come in with one coalesced load and block i+1's payload rows are in
+// flight while block i is unpacked and stored.
 template <bool LEGACY>
 __global__ __launch_bounds__(WG_THREADS) void k_decode_terms(SegView seg, const DevTerm* __restrict__ terms,
                                                              const int64_t* __restrict__ item_prefix,
                                                              const int64_t* __restrict__ out_prefix, int n_terms,
-                                                             int64_t n_items, int32_t* __restrict__ docs_out,
+                                                             int64_t n_items, int blocks_per_item,
+                                                             int32_t* __restrict__ docs_out,
                                                              int32_t* __restrict__ freqs_out) {
   __shared__ __attribute__((aligned(16))) uint8_t slabs[WG_WAVES][SLAB_BYTES];
   const int lane = lane_id();
@@ -33,33 +37,51 @@ __global__ __launch_bounds__(WG_THREADS) void k_decode_terms(SegView seg, const 
   const int64_t item = (int64_t)blockIdx.x * WG_WAVES + wave;
   if (item >= n_items) return;
   const int t = upper_slot(item_prefix, n_terms, item);
-  const int local = (int)(item - item_prefix[t]);
+  const int chunk = (int)(item - item_prefix[t]);
   const DevTerm T = terms[t];
   const int64_t out = out_prefix[t];
   uint8_t* slab = slabs[wave];
-  if (local < T.nblocks) {
-    const int32_t base = local == 0 ? 0 : seg.dir_last[T.dir_base + local - 1];
-    const uint32_t off = seg.dir_off[T.dir_base + local];
-    const uint32_t hdr = seg.dir_hdr[T.dir_base + local];
-    const BlockPair bp = decode_block<LEGACY>(seg.doc + T.start_fp + off, hdr, slab, lane);
-    int32_t d0, d1;
-    deltas_to_docs(bp.d0, bp.d1, base, d0, d1);
-    const int64_t o = out + 128 * (int64_t)local + 2 * lane;
-    docs_out[o] = d0;
-    docs_out[o + 1] = d1;
-    freqs_out[o] = (int32_t)bp.f0;
-    freqs_out[o + 1] = (int32_t)bp.f1;
-  } else if (T.df == 1) {
-    if (lane == 0) { docs_out[out] = T.singleton_doc; freqs_out[out] = T.singleton_freq; }
-  } else {
-    const uint32_t toff = T.nblocks ? seg.dir_off[T.dir_base + T.nblocks] : 0u;
-    const int32_t base = T.nblocks ? seg.dir_last[T.dir_base + T.nblocks - 1] : 0;
-    int32_t d0, d1;
-    uint32_t f0, f1;
-    decode_tail(seg.doc + T.start_fp + toff, T.tail_n, base, slab, lane, d0, d1, f0, f1);
-    const int64_t o = out + 128 * (int64_t)T.nblocks + 2 * lane;
-    if (2 * lane < T.tail_n) { docs_out[o] = d0; freqs_out[o] = (int32_t)f0; }
-    if (2 * lane + 1 < T.tail_n) { docs_out[o + 1] = d1; freqs_out[o + 1] = (int32_t)f1; }
+  const int b0 = chunk * blocks_per_item;
+  const int b1 = min(T.nblocks, b0 + blocks_per_item);
+  int32_t base = b0 == 0 ? 0 : seg.dir_last[T.dir_base + b0 - 1];
+  const uint8_t* tbase = seg.doc + T.start_fp;
+  for (int c0 = b0; c0 < b1; c0 += 64) {
+    const int nb = min(64, b1 - c0);
+    DirChunk dir;
+    dir.load(seg.dir_off, seg.dir_hdr, T.dir_base, c0, nb, lane);
+    uint32_t off_n = dir.off_at(0), hdr_n = dir.hdr_at(0);
+    uint4 rows_n = block_rows_load(tbase + off_n, hdr_n, lane);
+    for (int i = 0; i < nb; ++i) {
+      const uint32_t off = off_n, hdr = hdr_n;
+      const uint4 rows = rows_n;
+      if (i + 1 < nb) {
+        off_n = dir.off_at(i + 1);
+        hdr_n = dir.hdr_at(i + 1);
+        rows_n = block_rows_load(tbase + off_n, hdr_n, lane);
+      }
+      const BlockPair bp = block_rows_decode<LEGACY>(rows, tbase + off, hdr, slab, lane);
+      int32_t d0, d1;
+      deltas_to_docs(bp.d0, bp.d1, base, d0, d1);
+      base = readlane(d1, 63);
+      const int64_t o = out + 128 * (int64_t)(c0 + i) + 2 * lane;
+      docs_out[o] = d0;
+      docs_out[o + 1] = d1;
+      freqs_out[o] = (int32_t)bp.f0;
+      freqs_out[o + 1] = (int32_t)bp.f1;
+    }
+  }
+  if (b1 == T.nblocks) {
+    if (T.df == 1) {
+      if (lane == 0) { docs_out[out] = T.singleton_doc; freqs_out[out] = T.singleton_freq; }
+    } else if (T.tail_n > 0) {
+      const uint32_t toff = T.nblocks ? seg.dir_off[T.dir_base + T.nblocks] : 0u;
+      int32_t d0, d1;
+      uint32_t f0, f1;
+      decode_tail(seg.doc + T.start_fp + toff, T.tail_n, base, slab, lane, d0, d1, f0, f1);
+      const int64_t o = out + 128 * (int64_t)T.nblocks + 2 * lane;
+      if (2 * lane < T.tail_n) { docs_out[o] = d0; freqs_out[o] = (int32_t)f0; }
+      if (2 * lane + 1 < T.tail_n) { docs_out[o + 1] = d1; freqs_out[o + 1] = (int32_t)f1; }
+    }
   }
 }
 

@@ -64,40 +64,56 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_term(SegView seg, const D
   WaveTopK top;
   uint64_t tau = 0;
   int count = 0;
-  auto collect = [&](int32_t doc, uint32_t freq, bool valid) {
-    valid = valid && doc_is_live(seg.live, doc);
-    uint64_t key = 0;
-    if (valid) {
-      const float nrm = has_norms ? cache[seg.norms[doc]] : k1;
-      key = make_key(bm25_score(wk, (float)(int32_t)freq, nrm), doc);
+  // two postings per lane: both norm gathers are issued before either score is formed
+  auto collect2 = [&](int32_t d0, int32_t d1, uint32_t f0, uint32_t f1, bool v0, bool v1) {
+    v0 = v0 && doc_is_live(seg.live, d0);
+    v1 = v1 && doc_is_live(seg.live, d1);
+    uint32_t nb0 = 0, nb1 = 0;
+    if (has_norms) {
+      if (v0) nb0 = seg.norms[d0];
+      if (v1) nb1 = seg.norms[d1];
     }
-    count += __popcll(__ballot(valid));
-    topk_offer<WIDE>(top, key, tau, k, lane);
+    const float s0 = bm25_score(wk, (float)(int32_t)f0, has_norms ? cache[nb0] : k1);
+    const float s1 = bm25_score(wk, (float)(int32_t)f1, has_norms ? cache[nb1] : k1);
+    count += __popcll(__ballot(v0)) + __popcll(__ballot(v1));
+    topk_offer<WIDE>(top, v0 ? make_key(s0, d0) : 0ull, tau, k, lane);
+    topk_offer<WIDE>(top, v1 ? make_key(s1, d1) : 0ull, tau, k, lane);
   };
 
   const int b0 = chunk * blocks_per_item;
   const int b1 = min(T.nblocks, b0 + blocks_per_item);
   int32_t base = b0 == 0 ? 0 : seg.dir_last[T.dir_base + b0 - 1];
-  for (int blk = b0; blk < b1; ++blk) {
-    const uint32_t off = seg.dir_off[T.dir_base + blk];
-    const uint32_t hdr = seg.dir_hdr[T.dir_base + blk];
-    const BlockPair bp = decode_block<LEGACY>(seg.doc + T.start_fp + off, hdr, slab, lane);
-    int32_t d0, d1;
-    deltas_to_docs(bp.d0, bp.d1, base, d0, d1);
-    base = readlane(d1, 63);
-    collect(d0, bp.f0, true);
-    collect(d1, bp.f1, true);
+  const uint8_t* tbase = seg.doc + T.start_fp;
+  for (int c0 = b0; c0 < b1; c0 += 64) {
+    const int nb = min(64, b1 - c0);
+    DirChunk dir;
+    dir.load(seg.dir_off, seg.dir_hdr, T.dir_base, c0, nb, lane);
+    uint32_t off_n = dir.off_at(0), hdr_n = dir.hdr_at(0);
+    uint4 rows_n = block_rows_load(tbase + off_n, hdr_n, lane);
+    for (int i = 0; i < nb; ++i) {
+      const uint32_t off = off_n, hdr = hdr_n;
+      const uint4 rows = rows_n;
+      if (i + 1 < nb) {  // next block's payload is in flight while this one is decoded and scored
+        off_n = dir.off_at(i + 1);
+        hdr_n = dir.hdr_at(i + 1);
+        rows_n = block_rows_load(tbase + off_n, hdr_n, lane);
+      }
+      const BlockPair bp = block_rows_decode<LEGACY>(rows, tbase + off, hdr, slab, lane);
+      int32_t d0, d1;
+      deltas_to_docs(bp.d0, bp.d1, base, d0, d1);
+      base = readlane(d1, 63);
+      collect2(d0, d1, bp.f0, bp.f1, true, true);
+    }
   }
   if (b1 == T.nblocks) {
     if (T.df == 1) {
-      collect(T.singleton_doc, (uint32_t)T.singleton_freq, lane == 0);
+      collect2(T.singleton_doc, 0, (uint32_t)T.singleton_freq, 0u, lane == 0, false);
     } else if (T.tail_n > 0) {
       const uint32_t toff = T.nblocks ? seg.dir_off[T.dir_base + T.nblocks] : 0u;
       int32_t d0, d1;
       uint32_t f0, f1;
       decode_tail(seg.doc + T.start_fp + toff, T.tail_n, base, slab, lane, d0, d1, f0, f1);
-      collect(d0, f0, 2 * lane < T.tail_n);
-      collect(d1, f1, 2 * lane + 1 < T.tail_n);
+      collect2(d0, d1, f0, f1, 2 * lane < T.tail_n, 2 * lane + 1 < T.tail_n);
     }
   }
   uint64_t* pk = partial_keys + (size_t)item * (size_t)k;
@@ -244,11 +260,22 @@ __global__ __launch_bounds__(WG_THREADS) void k_merge_items(const int64_t* __res
   uint64_t tau = 0;
   int64_t total = 0;
   const int64_t i0 = item_prefix[q], i1 = item_prefix[q + 1];
-  for (int64_t it = i0; it < i1; ++it) {
-    const uint64_t* pk = partial_keys + (size_t)it * (size_t)k;
-    topk_offer<WIDE>(top, lane < k ? pk[lane] : 0ull, tau, k, lane);
-    if (WIDE) topk_offer<WIDE>(top, lane + 64 < k ? pk[lane + 64] : 0ull, tau, k, lane);
-    total += partial_counts[it];
+  for (int64_t g0 = i0; g0 < i1; g0 += 64) {
+    // each lane looks at one item's best key (lists are sorted best-first): an item whose head cannot
+    // enter the current top-k is skipped without reading the rest of its list
+    const int64_t mine = g0 + lane;
+    const bool ok = mine < i1;
+    const uint64_t head = ok ? partial_keys[(size_t)mine * (size_t)k] : 0ull;
+    total += wave_reduce_add(ok ? partial_counts[mine] : 0);
+    uint64_t m = __ballot(head > tau);
+    while (m) {
+      const int src = __builtin_ctzll(m);
+      const uint64_t* pk = partial_keys + (size_t)(g0 + src) * (size_t)k;
+      topk_offer<WIDE>(top, lane < k ? pk[lane] : 0ull, tau, k, lane);
+      if (WIDE) topk_offer<WIDE>(top, lane + 64 < k ? pk[lane + 64] : 0ull, tau, k, lane);
+      m &= m - 1;
+      m &= __ballot(head > tau);
+    }
   }
   HitOut* out = hits_out + (size_t)q * (size_t)k;
   if (lane < k) out[lane] = top.a ? HitOut{key_doc(top.a) + doc_base, key_score(top.a)} : HitOut{-1, 0.f};

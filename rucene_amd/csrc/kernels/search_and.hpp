@@ -1,0 +1,171 @@
+// Conjunction (AND) on the GPU, lead-driven: the data-parallel form of ConjunctionScorer's leapfrog
+// (search/scorer/conjunction_scorer.rs:44-83). One wavefront owns a chunk of the cheapest clause's blocks; each
+// decoded lead block yields 128 sorted candidates, two per lane. For every other clause, in cost order, the wave
+//   1. brackets the candidates in that clause's block directory (two wave-uniform binary searches, then a short
+//      per-lane one) — what Lucene50SkipReader::skip_to does per probe (skip_reader.rs:554-584);
+//   2. visits only the distinct blocks that hold at least one live candidate, decoding each once into LDS;
+//   3. lets every lane whose candidate maps to that block binary-search the 128 decoded docs — the in-block
+//      scan of BlockDocIterator::advance (posting_reader.rs:714-731).
+// A candidate dies at the first clause that misses it, so later clauses touch fewer blocks. Scores are summed
+// lead1, lead2, others... in f32 exactly as conjunction_scorer.rs:87-95 (the host sorts clauses by doc_freq).
+#pragma once
+#include "search.hpp"
+
+namespace rgpu {
+
+// first slot in [lo, hi] whose last doc >= target; slot `hi` is returned without being read
+__device__ __forceinline__ int find_block_in(const int32_t* __restrict__ dir_last, uint32_t dir_base, int lo, int hi, int32_t target) {
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (dir_last[dir_base + mid] >= target) hi = mid; else lo = mid + 1;
+  }
+  return lo;
+}
+
+__device__ __forceinline__ int lds_lower_bound(const int32_t* a, int n, int32_t x) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (a[mid] < x) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+template <bool LEGACY, bool WIDE>
+__global__ __launch_bounds__(WG_THREADS) void k_search_and(SegView seg, const DevQuery* __restrict__ queries,
+                                                           const DevTerm* __restrict__ terms,
+                                                           const int64_t* __restrict__ item_prefix, int n_queries,
+                                                           int64_t n_items, int blocks_per_item, int k,
+                                                           uint64_t* __restrict__ partial_keys,
+                                                           int32_t* __restrict__ partial_counts) {
+  __shared__ __attribute__((aligned(16))) uint8_t slabs[WG_WAVES][SLAB_BYTES];
+  __shared__ float caches[WG_WAVES][256];
+  __shared__ int32_t bdocs[WG_WAVES][128];
+  __shared__ uint32_t bfreqs[WG_WAVES][128];
+  const int lane = lane_id();
+  const int wave = (int)(threadIdx.x >> 6);
+  const int64_t item = (int64_t)blockIdx.x * WG_WAVES + wave;
+  if (item >= n_items) return;
+  const int q = upper_slot(item_prefix, n_queries, item);
+  const int chunk = (int)(item - item_prefix[q]);
+  const DevQuery Q = queries[q];
+  const DevTerm L = terms[Q.first_term];
+  uint8_t* slab = slabs[wave];
+  float* cache = caches[wave];
+  int32_t* bd = bdocs[wave];
+  uint32_t* bf = bfreqs[wave];
+  const bool has_norms = seg.norms != nullptr;
+  int cur_table = -1;
+  float k1 = 0.f;
+  auto use_table = [&](int id) {
+    if (id != cur_table) { load_sim_table(seg.sim_tables, id, cache, lane, k1); cur_table = id; }
+  };
+
+  WaveTopK top;
+  uint64_t tau = 0;
+  int count = 0;
+
+  auto intersect = [&](int32_t d0, int32_t d1, uint32_t f0, uint32_t f1, bool a0, bool a1) {
+    a0 = a0 && doc_is_live(seg.live, d0);
+    a1 = a1 && doc_is_live(seg.live, d1);
+    const uint32_t nb0 = (has_norms && a0) ? seg.norms[d0] : 0u;
+    const uint32_t nb1 = (has_norms && a1) ? seg.norms[d1] : 0u;
+    use_table(L.sim_table);
+    float wk = L.weight * (k1 + 1.0f);
+    float s0 = bm25_score(wk, (float)(int32_t)f0, has_norms ? cache[nb0] : k1);
+    float s1 = bm25_score(wk, (float)(int32_t)f1, has_norms ? cache[nb1] : k1);
+    for (int ti = 1; ti < Q.n_terms; ++ti) {
+      const uint64_t m0 = __ballot(a0), m1 = __ballot(a1);
+      if (!(m0 | m1)) break;
+      const DevTerm T = terms[Q.first_term + ti];
+      use_table(T.sim_table);
+      wk = T.weight * (k1 + 1.0f);
+      const float n0 = has_norms ? cache[nb0] : k1;
+      const float n1 = has_norms ? cache[nb1] : k1;
+      if (T.df == 1) {
+        if (a0) { if (d0 == T.singleton_doc) s0 += bm25_score(wk, (float)T.singleton_freq, n0); else a0 = false; }
+        if (a1) { if (d1 == T.singleton_doc) s1 += bm25_score(wk, (float)T.singleton_freq, n1); else a1 = false; }
+        continue;
+      }
+      // candidates are sorted across (lane, slot): first / last live candidate bracket the directory range
+      const int fl0 = m0 ? __builtin_ctzll(m0) : 64, fl1 = m1 ? __builtin_ctzll(m1) : 64;
+      const int32_t dmin = fl0 <= fl1 ? readlane(d0, fl0 & 63) : readlane(d1, fl1 & 63);
+      const int ll0 = m0 ? 63 - __builtin_clzll(m0) : -1, ll1 = m1 ? 63 - __builtin_clzll(m1) : -1;
+      const int32_t dmax = ll1 >= ll0 ? readlane(d1, ll1 & 63) : readlane(d0, ll0 & 63);
+      const int lo = find_block_in(seg.dir_last, T.dir_base, 0, T.nblocks, dmin);
+      const int hi = find_block_in(seg.dir_last, T.dir_base, lo, T.nblocks, dmax);
+      int blk0 = a0 ? find_block_in(seg.dir_last, T.dir_base, lo, hi, d0) : 0x7fffffff;
+      int blk1 = a1 ? find_block_in(seg.dir_last, T.dir_base, lo, hi, d1) : 0x7fffffff;
+      bool p0 = a0, p1 = a1;
+      while (true) {
+        const uint64_t q0 = __ballot(p0), q1 = __ballot(p1);
+        if (!(q0 | q1)) break;
+        const int l0 = q0 ? __builtin_ctzll(q0) : 64, l1 = q1 ? __builtin_ctzll(q1) : 64;
+        const int cur = l0 <= l1 ? readlane(blk0, l0 & 63) : readlane(blk1, l1 & 63);
+        int n_in = 0;
+        if (cur < T.nblocks) {
+          const int32_t base = cur == 0 ? 0 : seg.dir_last[T.dir_base + cur - 1];
+          const BlockPair bp = decode_block<LEGACY>(seg.doc + T.start_fp + seg.dir_off[T.dir_base + cur],
+                                                     seg.dir_hdr[T.dir_base + cur], slab, lane);
+          int32_t e0, e1;
+          deltas_to_docs(bp.d0, bp.d1, base, e0, e1);
+          bd[2 * lane] = e0; bd[2 * lane + 1] = e1;
+          bf[2 * lane] = bp.f0; bf[2 * lane + 1] = bp.f1;
+          n_in = 128;
+        } else if (T.tail_n > 0) {
+          const uint32_t toff = T.nblocks ? seg.dir_off[T.dir_base + T.nblocks] : 0u;
+          const int32_t base = T.nblocks ? seg.dir_last[T.dir_base + T.nblocks - 1] : 0;
+          int32_t e0, e1;
+          uint32_t g0, g1;
+          decode_tail(seg.doc + T.start_fp + toff, T.tail_n, base, slab, lane, e0, e1, g0, g1);
+          bd[2 * lane] = e0; bd[2 * lane + 1] = e1;
+          bf[2 * lane] = g0; bf[2 * lane + 1] = g1;
+          n_in = T.tail_n;
+        }
+        wave_sync();
+        if (p0 && blk0 == cur) {
+          const int pos = lds_lower_bound(bd, n_in, d0);
+          if (pos < n_in && bd[pos] == d0) s0 += bm25_score(wk, (float)(int32_t)bf[pos], n0); else a0 = false;
+          p0 = false;
+        }
+        if (p1 && blk1 == cur) {
+          const int pos = lds_lower_bound(bd, n_in, d1);
+          if (pos < n_in && bd[pos] == d1) s1 += bm25_score(wk, (float)(int32_t)bf[pos], n1); else a1 = false;
+          p1 = false;
+        }
+        wave_sync();
+      }
+    }
+    count += __popcll(__ballot(a0)) + __popcll(__ballot(a1));
+    topk_offer<WIDE>(top, a0 ? make_key(s0, d0) : 0ull, tau, k, lane);
+    topk_offer<WIDE>(top, a1 ? make_key(s1, d1) : 0ull, tau, k, lane);
+  };
+
+  const int b0 = chunk * blocks_per_item;
+  const int b1 = min(L.nblocks, b0 + blocks_per_item);
+  int32_t base = b0 == 0 ? 0 : seg.dir_last[L.dir_base + b0 - 1];
+  for (int blk = b0; blk < b1; ++blk) {
+    const BlockPair bp = decode_block<LEGACY>(seg.doc + L.start_fp + seg.dir_off[L.dir_base + blk], seg.dir_hdr[L.dir_base + blk], slab, lane);
+    int32_t d0, d1;
+    deltas_to_docs(bp.d0, bp.d1, base, d0, d1);
+    base = readlane(d1, 63);
+    intersect(d0, d1, bp.f0, bp.f1, true, true);
+  }
+  if (b1 == L.nblocks) {
+    if (L.df == 1) {
+      intersect(L.singleton_doc, L.singleton_doc, (uint32_t)L.singleton_freq, 0u, lane == 0, false);
+    } else if (L.tail_n > 0) {
+      const uint32_t toff = L.nblocks ? seg.dir_off[L.dir_base + L.nblocks] : 0u;
+      int32_t d0, d1;
+      uint32_t f0, f1;
+      decode_tail(seg.doc + L.start_fp + toff, L.tail_n, base, slab, lane, d0, d1, f0, f1);
+      intersect(d0, d1, f0, f1, 2 * lane < L.tail_n, 2 * lane + 1 < L.tail_n);
+    }
+  }
+  uint64_t* pk = partial_keys + (size_t)item * (size_t)k;
+  if (lane < k) pk[lane] = top.a;
+  if (WIDE && lane + 64 < k) pk[lane + 64] = top.b;
+  if (lane == 0) partial_counts[item] = count;
+}
+
+}  // namespace rgpu

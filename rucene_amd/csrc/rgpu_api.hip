@@ -15,6 +15,7 @@
 #include "host/doc_format.hpp"
 #include "kernels/prepare.hpp"
 #include "kernels/search.hpp"
+#include "kernels/search_and.hpp"
 
 using namespace rgpu;
 
@@ -320,6 +321,7 @@ extern "C" int32_t rgpu_init(int32_t device_ordinal, const rgpu_config* cfg, rgp
   if (cfg) c->cfg = *cfg;
   c->cfg.abi_version = RGPU_ABI_VERSION;
   if (c->cfg.blocks_per_item <= 0) c->cfg.blocks_per_item = 32;
+  if (c->cfg.reserved[0] <= 0) c->cfg.reserved[0] = 4;  // and_blocks_per_item
   if (c->cfg.window_docs <= 0) c->cfg.window_docs = 4096;
   c->cfg.window_docs = std::min(24576, std::max(1024, (c->cfg.window_docs + 1023) / 1024 * 1024));
   std::snprintf(c->name, sizeof c->name, "%s (%s)", prop.name, prop.gcnArchName);
@@ -476,12 +478,13 @@ static int32_t decode_terms_impl(rgpu_segment* seg, const rgpu_term_state* terms
   int64_t* hitems = reinterpret_cast<int64_t*>(c->h_stage.p + o_items);
   int64_t* hout = reinterpret_cast<int64_t*>(c->h_stage.p + o_out);
   int64_t items = 0, out = 0;
+  const int dec_blocks_per_item = 16;
   for (int64_t i = 0; i < n_terms; ++i) {
     rc = make_dev_term(seg, terms[i], 0.f, 0, &ht[i]);
     if (rc != RGPU_OK) return rc;
     hitems[i] = items;
     hout[i] = out;
-    items += ht[i].nblocks + ((ht[i].tail_n > 0 || ht[i].df == 1) ? 1 : 0);
+    if (ht[i].df > 0) items += ht[i].nblocks == 0 ? 1 : (ht[i].nblocks + dec_blocks_per_item - 1) / dec_blocks_per_item;
     out += terms[i].doc_freq;
   }
   hitems[n_terms] = items;
@@ -496,7 +499,8 @@ static int32_t decode_terms_impl(rgpu_segment* seg, const rgpu_term_state* terms
       hipLaunchKernelGGL(kern, dim3(grid), dim3(WG_THREADS), 0, stream, seg_view(seg),
                          reinterpret_cast<const DevTerm*>(c->d_stage.p + o_terms),
                          reinterpret_cast<const int64_t*>(c->d_stage.p + o_items),
-                         reinterpret_cast<const int64_t*>(c->d_stage.p + o_out), (int)n_terms, items, docs_dev, freqs_dev);
+                         reinterpret_cast<const int64_t*>(c->d_stage.p + o_out), (int)n_terms, items, dec_blocks_per_item, docs_dev,
+                         freqs_dev);
     };
     if (seg->version >= 1) args(k_decode_terms<false>); else args(k_decode_terms<true>);
   }
@@ -656,22 +660,23 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
     Group& G = groups[op];
     const int nq = (int)G.queries.size();
     if (nq == 0) continue;
-    int blocks_per_item = c->cfg.blocks_per_item;
+    const bool lead_driven = op == RGPU_OP_TERM || (op == RGPU_OP_AND && !c->cfg.reserved[1]);
+    int blocks_per_item = op == RGPU_OP_TERM ? c->cfg.blocks_per_item : c->cfg.reserved[0];
     int W = c->cfg.window_docs, wpq = 0, wpi = 1, ipq = 0;
     int64_t items = 0;
     G.item_prefix.assign((size_t)nq + 1, 0);
-    if (op == RGPU_OP_TERM) {
+    if (lead_driven) {  // items = chunks of the (lead) term's blocks; the last chunk also takes its tail
       while (true) {
         items = 0;
         for (int q = 0; q < nq; ++q) {
           G.item_prefix[(size_t)q] = items;
-          if (G.queries[(size_t)q].n_terms == 1) {
+          if (G.queries[(size_t)q].n_terms >= 1) {
             const DevTerm& t = G.terms[(size_t)G.queries[(size_t)q].first_term];
             items += t.nblocks == 0 ? 1 : (t.nblocks + blocks_per_item - 1) / blocks_per_item;
           }
         }
         G.item_prefix[(size_t)nq] = items;
-        if (items <= 262144 || blocks_per_item >= (1 << 20)) break;
+        if (items <= 262144 || blocks_per_item >= (1 << 17)) break;
         blocks_per_item *= 2;
       }
     } else {
@@ -705,7 +710,16 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
     const int64_t* dp = reinterpret_cast<const int64_t*>(c->d_stage.p + o_p);
     const int32_t* dm = reinterpret_cast<const int32_t*>(c->d_stage.p + o_m);
     const SegView sv = seg_view(seg);
-    if (op == RGPU_OP_TERM) {
+    if (op == RGPU_OP_AND && lead_driven) {
+      TimedLaunch tl(c, stream, "k_search_and", G.postings);
+      const unsigned grid = (unsigned)((items + WG_WAVES - 1) / WG_WAVES);
+      auto go = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(WG_THREADS), 0, stream, sv, dq, dt, dp, nq, items, blocks_per_item, (int)k,
+                           c->d_partial_keys.p, c->d_partial_counts.p);
+      };
+      if (legacy) { if (wide) go(k_search_and<true, true>); else go(k_search_and<true, false>); }
+      else { if (wide) go(k_search_and<false, true>); else go(k_search_and<false, false>); }
+    } else if (op == RGPU_OP_TERM) {
       TimedLaunch tl(c, stream, "k_search_term", G.postings);
       const unsigned grid = (unsigned)((items + WG_WAVES - 1) / WG_WAVES);
       auto go = [&](auto kern) {

@@ -297,3 +297,21 @@ def test_error_codes(ctx):
     with pytest.raises(rucene_amd.RgpuError) as e:
         g2.decode_terms(seg.terms[:1])
     assert e.value.status == -4
+
+
+def test_conjunctions_through_the_window_kernel(oracle):
+    """The doc-window accumulate kernel (shared with OR) must give the same AND answers as the lead-driven one."""
+    import rucene_amd
+    from rucene_amd import indexgen
+    ctx2 = rucene_amd.Context(and_via_windows=True, window_docs=2048, blocks_per_item=3)
+    try:
+        seg = indexgen.build_zipf(120_000, 20_000)
+        oseg = oracle.Segment(seg.doc_bytes, seg.norms, seg.max_doc, seg.terms, sum_total_term_freq=seg.sum_total_term_freq)
+        osearcher = oracle.Searcher([oseg])
+        gsearcher = rucene_amd.GpuIndexSearcher([rucene_amd.LeafReader.from_synthetic(seg)], ctx=ctx2)
+        ranks = indexgen.log_uniform_ranks(3 * 48, 1, 2000, seed=99).reshape(-1, 3)
+        specs = [(oracle.OP_AND, [int(r - 1) for r in row]) for row in ranks]
+        specs += [(oracle.OP_TERM, [int(r - 1)]) for r in ranks[:16, 0]]
+        _check_against_oracle(oracle, osearcher, gsearcher, specs, 10)
+    finally:
+        ctx2.close()
