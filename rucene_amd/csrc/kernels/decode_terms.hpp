@@ -33,7 +33,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_decode_terms(SegView seg, const 
                                                              int32_t* __restrict__ freqs_out) {
   __shared__ __attribute__((aligned(16))) uint8_t slabs[WG_WAVES][SLAB_BYTES];
   const int lane = lane_id();
-  const int wave = (int)(threadIdx.x >> 6);
+  const int wave = wave_id();
   const int64_t item = (int64_t)blockIdx.x * WG_WAVES + wave;
   if (item >= n_items) return;
   const int t = upper_slot(item_prefix, n_terms, item);
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_advance(SegView seg, DevTerm T, 
                                                         int32_t* __restrict__ out_freqs) {
   __shared__ __attribute__((aligned(16))) uint8_t slabs[WG_WAVES][SLAB_BYTES];
   const int lane = lane_id();
-  const int wave = (int)(threadIdx.x >> 6);
+  const int wave = wave_id();
   const int64_t probe = (int64_t)blockIdx.x * WG_WAVES + wave;
   if (probe >= n_targets) return;
   const int32_t target = targets[probe];

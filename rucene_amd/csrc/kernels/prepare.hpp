@@ -22,7 +22,7 @@ constexpr int PREP_THREADS = 256;
 // workgroup exclusive scan for PREP_THREADS threads; `total` is uniform on return
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* wave_sums, uint32_t& total) {
   const int lane = lane_id();
-  const int wave = (int)(threadIdx.x >> 6);
+  const int wave = wave_id();
   const uint32_t incl = (uint32_t)wave_incl_scan((int)v);
   __syncthreads();  // protect wave_sums reuse
   if (lane == 63) wave_sums[wave] = incl;

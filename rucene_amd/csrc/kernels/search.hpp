@@ -11,6 +11,8 @@
 // "score desc, doc asc" is one integer compare; lists are merged by k_merge_items. Results do not depend on
 // scheduling: the key order is total and every collected doc is offered exactly once.
 #pragma once
+#include <type_traits>
+
 #include "decode_terms.hpp"
 
 namespace rgpu {
@@ -48,7 +50,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_term(SegView seg, const D
   __shared__ __attribute__((aligned(16))) uint8_t slabs[WG_WAVES][SLAB_BYTES];
   __shared__ float caches[WG_WAVES][256];
   const int lane = lane_id();
-  const int wave = (int)(threadIdx.x >> 6);
+  const int wave = wave_id();
   const int64_t item = (int64_t)blockIdx.x * WG_WAVES + wave;
   if (item >= n_items) return;
   const int q = upper_slot(item_prefix, n_queries, item);
@@ -64,20 +66,38 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_term(SegView seg, const D
   WaveTopK top;
   uint64_t tau = 0;
   int count = 0;
-  // two postings per lane: both norm gathers are issued before either score is formed
-  auto collect2 = [&](int32_t d0, int32_t d1, uint32_t f0, uint32_t f1, bool v0, bool v1) {
-    v0 = v0 && doc_is_live(seg.live, d0);
-    v1 = v1 && doc_is_live(seg.live, d1);
-    uint32_t nb0 = 0, nb1 = 0;
-    if (has_norms) {
-      if (v0) nb0 = seg.norms[d0];
-      if (v1) nb1 = seg.norms[d1];
+  // two postings per lane: both norm gathers are issued before either score is formed. `full` (a
+  // std::true_type) marks a FullBlock, where every lane holds two real postings and no validity masks exist.
+  const bool has_live = seg.live != nullptr;
+  auto collect2 = [&](auto full, int32_t d0, int32_t d1, uint32_t f0, uint32_t f1, bool v0, bool v1) {
+    constexpr bool FULL = decltype(full)::value;
+    if (FULL) { v0 = true; v1 = true; }
+    if (has_live) {
+      v0 = v0 && doc_is_live(seg.live, d0);
+      v1 = v1 && doc_is_live(seg.live, d1);
     }
-    const float s0 = bm25_score(wk, (float)(int32_t)f0, has_norms ? cache[nb0] : k1);
-    const float s1 = bm25_score(wk, (float)(int32_t)f1, has_norms ? cache[nb1] : k1);
-    count += __popcll(__ballot(v0)) + __popcll(__ballot(v1));
-    topk_offer<WIDE>(top, v0 ? make_key(s0, d0) : 0ull, tau, k, lane);
-    topk_offer<WIDE>(top, v1 ? make_key(s1, d1) : 0ull, tau, k, lane);
+    float n0 = k1, n1 = k1;
+    if (has_norms) {
+      const uint32_t nb0 = (FULL && !has_live) ? seg.norms[d0] : (v0 ? seg.norms[d0] : 0u);
+      const uint32_t nb1 = (FULL && !has_live) ? seg.norms[d1] : (v1 ? seg.norms[d1] : 0u);
+      n0 = cache[nb0];
+      n1 = cache[nb1];
+    }
+    const float s0 = bm25_score(wk, (float)(int32_t)f0, n0);
+    const float s1 = bm25_score(wk, (float)(int32_t)f1, n1);
+    uint64_t key0 = make_key(s0, d0), key1 = make_key(s1, d1);
+    if (FULL && !has_live) {
+      count += 128;
+    } else {
+      count += __popcll(__ballot(v0)) + __popcll(__ballot(v1));
+      key0 = v0 ? key0 : 0ull;
+      key1 = v1 ? key1 : 0ull;
+    }
+    // one ballot covers both postings in the common case where neither can enter the current top-k
+    if (__ballot((key0 > key1 ? key0 : key1) > tau)) {
+      topk_offer<WIDE>(top, key0, tau, k, lane);
+      topk_offer<WIDE>(top, key1, tau, k, lane);
+    }
   };
 
   const int b0 = chunk * blocks_per_item;
@@ -102,18 +122,18 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_term(SegView seg, const D
       int32_t d0, d1;
       deltas_to_docs(bp.d0, bp.d1, base, d0, d1);
       base = readlane(d1, 63);
-      collect2(d0, d1, bp.f0, bp.f1, true, true);
+      collect2(std::true_type{}, d0, d1, bp.f0, bp.f1, true, true);
     }
   }
   if (b1 == T.nblocks) {
     if (T.df == 1) {
-      collect2(T.singleton_doc, 0, (uint32_t)T.singleton_freq, 0u, lane == 0, false);
+      collect2(std::false_type{}, T.singleton_doc, 0, (uint32_t)T.singleton_freq, 0u, lane == 0, false);
     } else if (T.tail_n > 0) {
       const uint32_t toff = T.nblocks ? seg.dir_off[T.dir_base + T.nblocks] : 0u;
       int32_t d0, d1;
       uint32_t f0, f1;
       decode_tail(seg.doc + T.start_fp + toff, T.tail_n, base, slab, lane, d0, d1, f0, f1);
-      collect2(d0, d1, f0, f1, 2 * lane < T.tail_n, 2 * lane + 1 < T.tail_n);
+      collect2(std::false_type{}, d0, d1, f0, f1, 2 * lane < T.tail_n, 2 * lane + 1 < T.tail_n);
     }
   }
   uint64_t* pk = partial_keys + (size_t)item * (size_t)k;
@@ -137,15 +157,15 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_window(SegView seg, const
                                                               int32_t* __restrict__ partial_counts) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   // carve: slabs | caches | merge area | wave counts | acc[W] | cnt[W]
-  uint8_t* slab = smem + (threadIdx.x >> 6) * SLAB_BYTES;
-  float* cache = reinterpret_cast<float*>(smem + WG_WAVES * SLAB_BYTES) + (threadIdx.x >> 6) * 256;
+  uint8_t* slab = smem + wave_id() * SLAB_BYTES;
+  float* cache = reinterpret_cast<float*>(smem + WG_WAVES * SLAB_BYTES) + wave_id() * 256;
   uint64_t* merge = reinterpret_cast<uint64_t*>(smem + WG_WAVES * SLAB_BYTES + WG_WAVES * 1024);  // [WG_WAVES][128]
   int* s_counts = reinterpret_cast<int*>(smem + WG_WAVES * SLAB_BYTES + WG_WAVES * 1024 + WG_WAVES * 128 * 8);
   float* acc = reinterpret_cast<float*>(smem + WINDOW_LDS_FIXED);
   uint8_t* cnt = reinterpret_cast<uint8_t*>(acc + W);
 
   const int lane = lane_id();
-  const int wave = (int)(threadIdx.x >> 6);
+  const int wave = wave_id();
   const int tid = (int)threadIdx.x;
   const int64_t item = blockIdx.x;
   const int q = (int)(item / items_per_query);
@@ -254,7 +274,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_merge_items(const int64_t* __res
                                                             const int32_t* __restrict__ partial_counts, int32_t doc_base,
                                                             HitOut* __restrict__ hits_out, int64_t* __restrict__ totals_out) {
   const int lane = lane_id();
-  const int q = (int)(blockIdx.x * WG_WAVES + (threadIdx.x >> 6));
+  const int q = (int)(blockIdx.x * WG_WAVES) + wave_id();
   if (q >= n_queries) return;
   WaveTopK top;
   uint64_t tau = 0;
@@ -290,7 +310,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_merge_lists(const HitOut* __rest
                                                             int n_lists, int n_queries, int k, HitOut* __restrict__ hits_out,
                                                             int64_t* __restrict__ totals_out) {
   const int lane = lane_id();
-  const int q = (int)(blockIdx.x * WG_WAVES + (threadIdx.x >> 6));
+  const int q = (int)(blockIdx.x * WG_WAVES) + wave_id();
   if (q >= n_queries) return;
   WaveTopK top;
   uint64_t tau = 0;

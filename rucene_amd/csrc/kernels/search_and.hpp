@@ -43,7 +43,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_and(SegView seg, const De
   __shared__ int32_t bdocs[WG_WAVES][128];
   __shared__ uint32_t bfreqs[WG_WAVES][128];
   const int lane = lane_id();
-  const int wave = (int)(threadIdx.x >> 6);
+  const int wave = wave_id();
   const int64_t item = (int64_t)blockIdx.x * WG_WAVES + wave;
   if (item >= n_items) return;
   const int q = upper_slot(item_prefix, n_queries, item);

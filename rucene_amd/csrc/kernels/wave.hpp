@@ -9,6 +9,9 @@ namespace rgpu {
 constexpr int WAVE = 64;
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+// Wave index inside the workgroup, as a scalar: everything derived from it (work item, term descriptor,
+// block counts, header words) then lives in SGPRs and control flow on it is branch-, not exec-mask-based.
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
 // Wave-synchronous LDS hand-off between lanes of one wavefront: LDS operations of a wave complete in issue
 // order, so only the compiler has to be kept from moving accesses across the hand-off point.

@@ -1,0 +1,40 @@
+"""Minimal driver for profiling: build the 10M-doc shard, run one workload a few times through the C ABI.
+usage: run_workload.py [term|and3|or10|decode] [reps]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import rucene_amd
+from rucene_amd import indexgen
+kind = sys.argv[1] if len(sys.argv) > 1 else "term"
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+docs = int(os.environ.get("DOCS", "10000000"))
+seg = indexgen.build_zipf(docs, 1_000_000)
+ctx = rucene_amd.Context(profile_kernels=True)
+leaf = rucene_amd.LeafReader.from_synthetic(seg)
+s = rucene_amd.GpuIndexSearcher([leaf], ctx=ctx)
+T, B = rucene_amd.TermQuery, rucene_amd.BooleanQuery
+SEED = 0x527563656E65 ^ 0x51
+if kind == "decode":
+    sel = seg.terms[seg.terms["doc_freq"] >= 128]
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    total = int(sel["doc_freq"].sum())
+    pd, pf = ctypes.c_void_p(), ctypes.c_void_p()
+    hip.hipMalloc(ctypes.byref(pd), ctypes.c_size_t(total * 4)); hip.hipMalloc(ctypes.byref(pf), ctypes.c_size_t(total * 4))
+    for _ in range(reps + 2):
+        leaf.segment.decode_terms_device(sel, pd.value, pf.value)
+else:
+    if kind == "term":
+        tids = indexgen.log_uniform_ranks(1024, 1, 10_000, SEED).reshape(-1, 1) - 1
+        qs, k = [T(int(t[0])) for t in tids], 10
+    elif kind == "and3":
+        tids = indexgen.log_uniform_ranks(3 * 1024, 1, 1000, SEED ^ 0xA3).reshape(-1, 3) - 1
+        qs, k = [B.build([T(int(x)) for x in t], []) for t in tids], 10
+    else:
+        tids = indexgen.log_uniform_ranks(10 * 1024, 1, 10_000, SEED ^ 0x0A).reshape(-1, 10) - 1
+        qs, k = [B.build([], [T(int(x)) for x in t]) for t in tids], 100
+    packed = s.pack(qs, leaf)
+    for _ in range(reps + 2):
+        hits, totals = leaf.segment.search_batch(packed[0], packed[1], k)
+print({n: (v["launches"], round(v["total_ms"] / v["launches"], 4)) for n, v in ctx.kernel_stats().items()})
+ctx.close()
