@@ -66,26 +66,43 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_term(SegView seg, const D
   WaveTopK top;
   uint64_t tau = 0;
   int count = 0;
-  // two postings per lane: both norm gathers are issued before either score is formed. `full` (a
-  // std::true_type) marks a FullBlock, where every lane holds two real postings and no validity masks exist.
+  // Scoring runs one block behind decoding: the norm (and live-docs) gathers of block i are issued right after
+  // its doc ids exist and consumed while block i+1 is being decoded, so no wave ever sits on its own gather.
+  // `full` (std::true_type) marks a FullBlock: every lane holds two real postings, no validity masks.
   const bool has_live = seg.live != nullptr;
-  auto collect2 = [&](auto full, int32_t d0, int32_t d1, uint32_t f0, uint32_t f1, bool v0, bool v1) {
+  struct Pending {
+    int32_t d0, d1;
+    uint32_t f0, f1, nb0, nb1;
+    uint64_t lw0, lw1;
+  };
+  auto issue = [&](auto full, int32_t d0, int32_t d1, uint32_t f0, uint32_t f1, bool v0, bool v1) {
+    constexpr bool FULL = decltype(full)::value;
+    Pending p;
+    p.d0 = d0; p.d1 = d1; p.f0 = f0; p.f1 = f1;
+    p.nb0 = p.nb1 = 0u;
+    p.lw0 = p.lw1 = ~0ull;
+    if (has_norms) {
+      if (FULL || v0) p.nb0 = seg.norms[d0];
+      if (FULL || v1) p.nb1 = seg.norms[d1];
+    }
+    if (has_live) {
+      if (FULL || v0) p.lw0 = seg.live[d0 >> 6];
+      if (FULL || v1) p.lw1 = seg.live[d1 >> 6];
+    }
+    return p;
+  };
+  auto finish = [&](auto full, const Pending& p, bool v0, bool v1) {
     constexpr bool FULL = decltype(full)::value;
     if (FULL) { v0 = true; v1 = true; }
     if (has_live) {
-      v0 = v0 && doc_is_live(seg.live, d0);
-      v1 = v1 && doc_is_live(seg.live, d1);
+      v0 = v0 && ((p.lw0 >> (p.d0 & 63)) & 1ull);
+      v1 = v1 && ((p.lw1 >> (p.d1 & 63)) & 1ull);
     }
-    float n0 = k1, n1 = k1;
-    if (has_norms) {
-      const uint32_t nb0 = (FULL && !has_live) ? seg.norms[d0] : (v0 ? seg.norms[d0] : 0u);
-      const uint32_t nb1 = (FULL && !has_live) ? seg.norms[d1] : (v1 ? seg.norms[d1] : 0u);
-      n0 = cache[nb0];
-      n1 = cache[nb1];
-    }
-    const float s0 = bm25_score(wk, (float)(int32_t)f0, n0);
-    const float s1 = bm25_score(wk, (float)(int32_t)f1, n1);
-    uint64_t key0 = make_key(s0, d0), key1 = make_key(s1, d1);
+    const float n0 = has_norms ? cache[p.nb0] : k1;
+    const float n1 = has_norms ? cache[p.nb1] : k1;
+    const float s0 = bm25_score(wk, (float)(int32_t)p.f0, n0);
+    const float s1 = bm25_score(wk, (float)(int32_t)p.f1, n1);
+    uint64_t key0 = make_key(s0, p.d0), key1 = make_key(s1, p.d1);
     if (FULL && !has_live) {
       count += 128;
     } else {
@@ -104,6 +121,8 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_term(SegView seg, const D
   const int b1 = min(T.nblocks, b0 + blocks_per_item);
   int32_t base = b0 == 0 ? 0 : seg.dir_last[T.dir_base + b0 - 1];
   const uint8_t* tbase = seg.doc + T.start_fp;
+  Pending pend;
+  bool have = false;
   for (int c0 = b0; c0 < b1; c0 += 64) {
     const int nb = min(64, b1 - c0);
     DirChunk dir;
@@ -113,7 +132,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_term(SegView seg, const D
     for (int i = 0; i < nb; ++i) {
       const uint32_t off = off_n, hdr = hdr_n;
       const uint4 rows = rows_n;
-      if (i + 1 < nb) {  // next block's payload is in flight while this one is decoded and scored
+      if (i + 1 < nb) {  // next block's payload is in flight while this one is decoded
         off_n = dir.off_at(i + 1);
         hdr_n = dir.hdr_at(i + 1);
         rows_n = block_rows_load(tbase + off_n, hdr_n, lane);
@@ -122,18 +141,25 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_term(SegView seg, const D
       int32_t d0, d1;
       deltas_to_docs(bp.d0, bp.d1, base, d0, d1);
       base = readlane(d1, 63);
-      collect2(std::true_type{}, d0, d1, bp.f0, bp.f1, true, true);
+      const Pending cur = issue(std::true_type{}, d0, d1, bp.f0, bp.f1, true, true);
+      if (have) finish(std::true_type{}, pend, true, true);
+      pend = cur;
+      have = true;
     }
   }
+  if (have) finish(std::true_type{}, pend, true, true);
   if (b1 == T.nblocks) {
     if (T.df == 1) {
-      collect2(std::false_type{}, T.singleton_doc, 0, (uint32_t)T.singleton_freq, 0u, lane == 0, false);
+      const Pending p = issue(std::false_type{}, T.singleton_doc, 0, (uint32_t)T.singleton_freq, 0u, lane == 0, false);
+      finish(std::false_type{}, p, lane == 0, false);
     } else if (T.tail_n > 0) {
       const uint32_t toff = T.nblocks ? seg.dir_off[T.dir_base + T.nblocks] : 0u;
       int32_t d0, d1;
       uint32_t f0, f1;
       decode_tail(seg.doc + T.start_fp + toff, T.tail_n, base, slab, lane, d0, d1, f0, f1);
-      collect2(std::false_type{}, d0, d1, f0, f1, 2 * lane < T.tail_n, 2 * lane + 1 < T.tail_n);
+      const bool v0 = 2 * lane < T.tail_n, v1 = 2 * lane + 1 < T.tail_n;
+      const Pending p = issue(std::false_type{}, d0, d1, f0, f1, v0, v1);
+      finish(std::false_type{}, p, v0, v1);
     }
   }
   uint64_t* pk = partial_keys + (size_t)item * (size_t)k;

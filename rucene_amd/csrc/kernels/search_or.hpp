@@ -1,0 +1,201 @@
+// Disjunction (OR) on the GPU in two launches, nothing shared between wavefronts inside either:
+//   1. k_score_terms   every clause's postings are decoded and BM25-scored exactly once (the TermScorer work of
+//                      each sub-scorer, term_scorer.rs:43-67) into a {doc, score} run per clause in HBM;
+//   2. k_or_windows    each wavefront owns a range of small doc-id windows. Per window it walks every clause's
+//                      run from a cursor, adds the scores into an LDS accumulator *in clause order* — the
+//                      summation order of SubScorers::score_sum over a SimpleQueue
+//                      (search/scorer/disjunction_scorer.rs:213-225) — then scans the window: every touched doc
+//                      is one collected hit (bulk_scorer.rs:114-120) offered to the wave's top-k.
+// This is DisjunctionSumScorer's doc-at-a-time merge (disjunction_scorer.rs:24-104, util/disi.rs) turned
+// term-at-a-time per window; for >= 10 clauses the reference sums in heap order, so only 1e-5 relative holds
+// there. No block is decoded twice and no posting is scored twice, whatever the clause density.
+#pragma once
+#include "search.hpp"
+
+namespace rgpu {
+
+struct ScoredPosting {
+  int32_t doc;
+  float score;
+};
+
+// items = (flat clause index, chunk of blocks); out_prefix[j] = first slot of clause j's run
+template <bool LEGACY>
+__global__ __launch_bounds__(WG_THREADS) void k_score_terms(SegView seg, const DevTerm* __restrict__ terms,
+                                                            const int64_t* __restrict__ item_prefix,
+                                                            const int64_t* __restrict__ out_prefix, int n_terms,
+                                                            int64_t n_items, int blocks_per_item,
+                                                            ScoredPosting* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) uint8_t slabs[WG_WAVES][SLAB_BYTES];
+  __shared__ float caches[WG_WAVES][256];
+  const int lane = lane_id();
+  const int wave = wave_id();
+  const int64_t item = (int64_t)blockIdx.x * WG_WAVES + wave;
+  if (item >= n_items) return;
+  const int t = upper_slot(item_prefix, n_terms, item);
+  const int chunk = (int)(item - item_prefix[t]);
+  const DevTerm T = terms[t];
+  uint8_t* slab = slabs[wave];
+  float* cache = caches[wave];
+  float k1;
+  load_sim_table(seg.sim_tables, T.sim_table, cache, lane, k1);
+  const float wk = T.weight * (k1 + 1.0f);
+  const bool has_norms = seg.norms != nullptr;
+  ScoredPosting* run = out + out_prefix[t];
+
+  struct Pending { int32_t d0, d1; uint32_t f0, f1, nb0, nb1; int64_t slot; };
+  auto issue = [&](int32_t d0, int32_t d1, uint32_t f0, uint32_t f1, bool v0, bool v1, int64_t slot) {
+    Pending p{d0, d1, f0, f1, 0u, 0u, slot};
+    if (has_norms) {
+      if (v0) p.nb0 = seg.norms[d0];
+      if (v1) p.nb1 = seg.norms[d1];
+    }
+    return p;
+  };
+  auto finish = [&](const Pending& p, bool v0, bool v1) {
+    const float s0 = bm25_score(wk, (float)(int32_t)p.f0, has_norms ? cache[p.nb0] : k1);
+    const float s1 = bm25_score(wk, (float)(int32_t)p.f1, has_norms ? cache[p.nb1] : k1);
+    if (v0) run[p.slot] = ScoredPosting{p.d0, s0};
+    if (v1) run[p.slot + 1] = ScoredPosting{p.d1, s1};
+  };
+
+  const int b0 = chunk * blocks_per_item;
+  const int b1 = min(T.nblocks, b0 + blocks_per_item);
+  int32_t base = b0 == 0 ? 0 : seg.dir_last[T.dir_base + b0 - 1];
+  const uint8_t* tbase = seg.doc + T.start_fp;
+  Pending pend{};
+  bool have = false;
+  for (int c0 = b0; c0 < b1; c0 += 64) {
+    const int nb = min(64, b1 - c0);
+    DirChunk dir;
+    dir.load(seg.dir_off, seg.dir_hdr, T.dir_base, c0, nb, lane);
+    uint32_t off_n = dir.off_at(0), hdr_n = dir.hdr_at(0);
+    uint4 rows_n = block_rows_load(tbase + off_n, hdr_n, lane);
+    for (int i = 0; i < nb; ++i) {
+      const uint32_t off = off_n, hdr = hdr_n;
+      const uint4 rows = rows_n;
+      if (i + 1 < nb) {
+        off_n = dir.off_at(i + 1);
+        hdr_n = dir.hdr_at(i + 1);
+        rows_n = block_rows_load(tbase + off_n, hdr_n, lane);
+      }
+      const BlockPair bp = block_rows_decode<LEGACY>(rows, tbase + off, hdr, slab, lane);
+      int32_t d0, d1;
+      deltas_to_docs(bp.d0, bp.d1, base, d0, d1);
+      base = readlane(d1, 63);
+      const Pending cur = issue(d0, d1, bp.f0, bp.f1, true, true, 128 * (int64_t)(c0 + i) + 2 * lane);
+      if (have) finish(pend, true, true);
+      pend = cur;
+      have = true;
+    }
+  }
+  if (have) finish(pend, true, true);
+  if (b1 == T.nblocks) {
+    if (T.df == 1) {
+      const Pending p = issue(T.singleton_doc, 0, (uint32_t)T.singleton_freq, 0u, lane == 0, false, 0);
+      finish(p, lane == 0, false);
+    } else if (T.tail_n > 0) {
+      const uint32_t toff = T.nblocks ? seg.dir_off[T.dir_base + T.nblocks] : 0u;
+      int32_t d0, d1;
+      uint32_t f0, f1;
+      decode_tail(seg.doc + T.start_fp + toff, T.tail_n, base, slab, lane, d0, d1, f0, f1);
+      const bool v0 = 2 * lane < T.tail_n, v1 = 2 * lane + 1 < T.tail_n;
+      const Pending p = issue(d0, d1, f0, f1, v0, v1, 128 * (int64_t)T.nblocks + 2 * lane);
+      finish(p, v0, v1);
+    }
+  }
+}
+
+constexpr int OR_MAX_TERMS = 16;
+
+// items = (query, group of `windows_per_item` windows of `W` docs), one per wavefront
+template <bool WIDE>
+__global__ __launch_bounds__(WG_THREADS) void k_or_windows(SegView seg, const DevQuery* __restrict__ queries,
+                                                           const DevTerm* __restrict__ terms,
+                                                           const int64_t* __restrict__ run_prefix,
+                                                           const ScoredPosting* __restrict__ runs, int n_queries,
+                                                           int windows_per_query, int windows_per_item,
+                                                           int items_per_query, int W, int k,
+                                                           uint64_t* __restrict__ partial_keys,
+                                                           int32_t* __restrict__ partial_counts) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int lane = lane_id();
+  const int wave = wave_id();
+  float* acc = reinterpret_cast<float*>(smem + (size_t)wave * (size_t)W * 5);
+  uint8_t* flag = reinterpret_cast<uint8_t*>(acc + W);
+  const int64_t item = (int64_t)blockIdx.x * WG_WAVES + wave;
+  if (item >= (int64_t)n_queries * items_per_query) return;
+  const int q = (int)(item / items_per_query);
+  const int g = (int)(item - (int64_t)q * items_per_query);
+  const DevQuery Q = queries[q];
+  const bool has_live = seg.live != nullptr;
+
+  WaveTopK top;
+  uint64_t tau = 0;
+  int count = 0;
+  const int win0 = g * windows_per_item;
+  const int win1 = Q.n_terms > 0 ? min(windows_per_query, win0 + windows_per_item) : win0;
+
+  // lane t (< n_terms) owns clause t's cursor: run base, length, and the first entry with doc >= this item's
+  // first window — one lane-parallel binary search over all clauses at once
+  const bool mine = lane < Q.n_terms;
+  const int64_t my_base = mine ? run_prefix[Q.first_term + lane] : 0;
+  const int my_len = mine ? terms[Q.first_term + lane].df : 0;
+  int my_cur = 0;
+  {
+    const int32_t first_doc = win0 * W;
+    int lo = 0, hi = my_len;
+    while (__ballot(lo < hi)) {
+      if (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (runs[my_base + mid].doc < first_doc) lo = mid + 1; else hi = mid;
+      }
+    }
+    my_cur = lo;
+  }
+
+  for (int win = win0; win < win1; ++win) {
+    const int32_t w0 = win * W;
+    const int32_t w1 = min(seg.max_doc, w0 + W);
+    for (int i = lane * 4; i < W; i += 256) {
+      *reinterpret_cast<float4*>(acc + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<uint32_t*>(flag + i) = 0u;
+    }
+    wave_sync();
+    for (int t = 0; t < Q.n_terms; ++t) {  // clause order == summation order
+      const int64_t rb = ((int64_t)readlane((int)(uint32_t)(my_base >> 32), t) << 32) | (uint32_t)readlane((int)(uint32_t)my_base, t);
+      const int len = readlane(my_len, t);
+      int cur = readlane(my_cur, t);
+      while (true) {
+        const int idx = cur + lane;
+        ScoredPosting e{0x7fffffff, 0.f};
+        if (idx < len) e = runs[rb + idx];
+        bool in = e.doc < w1;
+        const int n = __popcll(__ballot(in));  // runs are doc-sorted: the in-window entries are a prefix
+        if (in && has_live) in = doc_is_live(seg.live, e.doc);
+        if (in) {
+          const int o = e.doc - w0;
+          acc[o] += e.score;
+          flag[o] = 1;
+        }
+        cur += n;
+        if (n < 64) break;
+      }
+      my_cur = lane == t ? cur : my_cur;
+      wave_sync();
+    }
+    for (int i = lane; i < W; i += 64) {
+      const bool hit = flag[i] != 0;
+      const uint64_t key = hit ? make_key(acc[i], w0 + i) : 0ull;
+      count += __popcll(__ballot(hit));
+      if (__ballot(key > tau)) topk_offer<WIDE>(top, key, tau, k, lane);
+    }
+    wave_sync();
+  }
+  uint64_t* pk = partial_keys + (size_t)item * (size_t)k;
+  if (lane < k) pk[lane] = top.a;
+  if (WIDE && lane + 64 < k) pk[lane + 64] = top.b;
+  if (lane == 0) partial_counts[item] = count;
+}
+
+}  // namespace rgpu

@@ -16,6 +16,7 @@
 #include "kernels/prepare.hpp"
 #include "kernels/search.hpp"
 #include "kernels/search_and.hpp"
+#include "kernels/search_or.hpp"
 
 using namespace rgpu;
 
@@ -97,6 +98,7 @@ struct rgpu_ctx {
   DevVec<int32_t> d_partial_counts;
   DevVec<HitOut> d_hits;
   DevVec<int64_t> d_totals;
+  DevVec<ScoredPosting> d_runs;  // OR: per-clause {doc, score} runs
   int* d_err = nullptr;
   // profiling
   std::vector<StatSlot> stats;
@@ -340,7 +342,7 @@ extern "C" void rgpu_shutdown(rgpu_ctx* c) {
   drain_events(c);
   for (auto e : c->free_events) (void)hipEventDestroy(e);
   c->sim_tables.release(); c->d_stage.release(); c->d_partial_keys.release(); c->d_partial_counts.release();
-  c->d_hits.release(); c->d_totals.release(); c->h_stage.release();
+  c->d_hits.release(); c->d_totals.release(); c->d_runs.release(); c->h_stage.release();
   if (c->d_err) (void)hipFree(c->d_err);
   (void)hipStreamDestroy(c->stream);
   delete c;
@@ -580,6 +582,7 @@ extern "C" int32_t rgpu_advance_batch(rgpu_segment* seg, const rgpu_term_state* 
 // ---- search ----------------------------------------------------------------------------------------------------
 namespace {
 struct Group {  // queries of one op, in their original order
+  int op = 0;
   std::vector<int32_t> qmap;    // original query index
   std::vector<DevQuery> queries;
   std::vector<DevTerm> terms;
@@ -595,6 +598,97 @@ static void launch_merge(rgpu_ctx* c, hipStream_t s, int n_queries, int k, const
   const unsigned grid = (unsigned)((n_queries + WG_WAVES - 1) / WG_WAVES);
   hipLaunchKernelGGL(k_merge_items<WIDE>, dim3(grid), dim3(WG_THREADS), 0, s, d_prefix, n_queries, k, c->d_partial_keys.p,
                      c->d_partial_counts.p, doc_base, hits, totals);
+}
+
+// OR: score every clause once into {doc, score} runs, then accumulate per doc-id window (kernels/search_or.hpp)
+static int32_t search_or_group(rgpu_segment* seg, Group& G, int32_t k, HitOut* hits_dev, int64_t* totals_dev, hipStream_t stream) {
+  rgpu_ctx* c = seg->ctx;
+  const int nq = (int)G.queries.size();
+  const int nt = (int)G.terms.size();
+  const bool wide = k > 64;
+  const bool legacy = seg->version < 1;
+  if (nt == 0) return RGPU_OK;  // every clause absent from this leaf: rows keep their {-1, 0} / 0 defaults
+  // phase 1 plan: items = (clause, chunk of blocks)
+  int blocks_per_item = c->cfg.blocks_per_item;
+  std::vector<int64_t> item_prefix((size_t)nt + 1), run_prefix((size_t)nt + 1);
+  int64_t items1 = 0, postings = 0;
+  while (true) {
+    items1 = 0;
+    for (int j = 0; j < nt; ++j) {
+      item_prefix[(size_t)j] = items1;
+      const DevTerm& t = G.terms[(size_t)j];
+      items1 += t.nblocks == 0 ? 1 : (t.nblocks + blocks_per_item - 1) / blocks_per_item;
+    }
+    item_prefix[(size_t)nt] = items1;
+    if (items1 <= 1048576 || blocks_per_item >= (1 << 17)) break;
+    blocks_per_item *= 2;
+  }
+  for (int j = 0; j < nt; ++j) { run_prefix[(size_t)j] = postings; postings += G.terms[(size_t)j].df; }
+  run_prefix[(size_t)nt] = postings;
+  // phase 2 plan: items = (query, group of windows), one per wavefront
+  int W = std::min(4096, std::max(1024, c->cfg.reserved[3] > 0 ? (c->cfg.reserved[3] + 1023) / 1024 * 1024 : 2048));
+  const int wpq = std::max(1, (seg->max_doc + W - 1) / W);
+  const int wpi = (int)std::max<int64_t>(1, ((int64_t)nq * wpq + 131071) / 131072);
+  const int ipq = (wpq + wpi - 1) / wpi;
+  const int64_t items2 = (int64_t)nq * ipq;
+  std::vector<int64_t> merge_prefix((size_t)nq + 1);
+  for (int q = 0; q <= nq; ++q) merge_prefix[(size_t)q] = (int64_t)q * ipq;
+
+  Stager st(c);
+  const size_t o_q = st.add((size_t)nq * sizeof(DevQuery));
+  const size_t o_t = st.add((size_t)nt * sizeof(DevTerm));
+  const size_t o_ip = st.add((size_t)(nt + 1) * 8);
+  const size_t o_rp = st.add((size_t)(nt + 1) * 8);
+  const size_t o_mp = st.add((size_t)(nq + 1) * 8);
+  const size_t o_m = st.add((size_t)nq * 4);
+  HIP_TRY(c->h_stage.reserve(st.used));
+  HIP_TRY(c->d_stage.reserve(st.used, 0, stream));
+  std::memcpy(c->h_stage.p + o_q, G.queries.data(), (size_t)nq * sizeof(DevQuery));
+  std::memcpy(c->h_stage.p + o_t, G.terms.data(), (size_t)nt * sizeof(DevTerm));
+  std::memcpy(c->h_stage.p + o_ip, item_prefix.data(), (size_t)(nt + 1) * 8);
+  std::memcpy(c->h_stage.p + o_rp, run_prefix.data(), (size_t)(nt + 1) * 8);
+  std::memcpy(c->h_stage.p + o_mp, merge_prefix.data(), (size_t)(nq + 1) * 8);
+  std::memcpy(c->h_stage.p + o_m, G.qmap.data(), (size_t)nq * 4);
+  HIP_TRY(hipMemcpyAsync(c->d_stage.p, c->h_stage.p, st.used, hipMemcpyHostToDevice, stream));
+  HIP_TRY(c->d_runs.reserve((size_t)postings + 64, 0, stream));
+  HIP_TRY(c->d_partial_keys.reserve((size_t)items2 * (size_t)k, 0, stream));
+  HIP_TRY(c->d_partial_counts.reserve((size_t)items2, 0, stream));
+  HIP_TRY(c->d_hits.reserve((size_t)nq * (size_t)k, 0, stream));
+  HIP_TRY(c->d_totals.reserve((size_t)nq, 0, stream));
+  const DevQuery* dq = reinterpret_cast<const DevQuery*>(c->d_stage.p + o_q);
+  const DevTerm* dt = reinterpret_cast<const DevTerm*>(c->d_stage.p + o_t);
+  const int64_t* dip = reinterpret_cast<const int64_t*>(c->d_stage.p + o_ip);
+  const int64_t* drp = reinterpret_cast<const int64_t*>(c->d_stage.p + o_rp);
+  const int64_t* dmp = reinterpret_cast<const int64_t*>(c->d_stage.p + o_mp);
+  const int32_t* dm = reinterpret_cast<const int32_t*>(c->d_stage.p + o_m);
+  const SegView sv = seg_view(seg);
+  {
+    TimedLaunch tl(c, stream, "k_score_terms", G.postings);
+    const unsigned grid = (unsigned)((items1 + WG_WAVES - 1) / WG_WAVES);
+    if (legacy)
+      hipLaunchKernelGGL(k_score_terms<true>, dim3(grid), dim3(WG_THREADS), 0, stream, sv, dt, dip, drp, nt, items1, blocks_per_item, c->d_runs.p);
+    else
+      hipLaunchKernelGGL(k_score_terms<false>, dim3(grid), dim3(WG_THREADS), 0, stream, sv, dt, dip, drp, nt, items1, blocks_per_item, c->d_runs.p);
+  }
+  {
+    TimedLaunch tl(c, stream, "k_or_windows", G.postings);
+    const size_t lds = (size_t)WG_WAVES * (size_t)W * 5;
+    const unsigned grid = (unsigned)((items2 + WG_WAVES - 1) / WG_WAVES);
+    auto go = [&](auto kern) -> hipError_t {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(WG_THREADS), lds, stream, sv, dq, dt, drp, c->d_runs.p, nq, wpq, wpi, ipq, W, (int)k,
+                         c->d_partial_keys.p, c->d_partial_counts.p);
+      return hipSuccess;
+    };
+    HIP_TRY(wide ? go(k_or_windows<true>) : go(k_or_windows<false>));
+  }
+  if (wide) launch_merge<true>(c, stream, nq, k, dmp, seg->doc_base, c->d_hits.p, c->d_totals.p);
+  else launch_merge<false>(c, stream, nq, k, dmp, seg->doc_base, c->d_hits.p, c->d_totals.p);
+  hipLaunchKernelGGL(k_scatter_rows, dim3((unsigned)nq), dim3(128), 0, stream, c->d_hits.p, c->d_totals.p, dm, (int)k, hits_dev, totals_dev);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(stream));  // staging / scratch buffers are reused by the next group
+  return RGPU_OK;
 }
 
 static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t n_queries, const rgpu_query_term* terms,
@@ -618,10 +712,19 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
   int32_t rc = prepare_terms_locked(seg, ptrs.data(), ptrs.size());
   if (rc != RGPU_OK) return rc;
 
-  Group groups[3];
+  // one group per op; OR groups are cut so that a group's scored runs stay below ~12 GiB of HBM scratch
+  const int64_t or_postings_cap = 1500000000LL;
+  std::vector<Group> groups(3);
+  int cur_group[3] = {0, 1, 2};
+  for (int i = 0; i < 3; ++i) groups[(size_t)i].op = i;
   for (int32_t q = 0; q < n_queries; ++q) {
     const rgpu_query& Q = queries[q];
-    Group& G = groups[Q.op];
+    if (Q.op == RGPU_OP_OR && groups[(size_t)cur_group[2]].postings > or_postings_cap) {
+      groups.emplace_back();
+      groups.back().op = RGPU_OP_OR;
+      cur_group[2] = (int)groups.size() - 1;
+    }
+    Group& G = groups[(size_t)cur_group[Q.op]];
     DevQuery dq;
     dq.op = Q.op;
     dq.first_term = (int32_t)G.terms.size();
@@ -656,10 +759,16 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
 
   const bool wide = k > 64;
   const bool legacy = seg->version < 1;
-  for (int op = 0; op < 3; ++op) {
-    Group& G = groups[op];
+  for (size_t gi = 0; gi < groups.size(); ++gi) {
+    Group& G = groups[gi];
+    const int op = G.op;
     const int nq = (int)G.queries.size();
     if (nq == 0) continue;
+    if (op == RGPU_OP_OR && !c->cfg.reserved[2]) {
+      int32_t rc_or = search_or_group(seg, G, k, hits_dev, totals_dev, stream);
+      if (rc_or != RGPU_OK) return rc_or;
+      continue;
+    }
     const bool lead_driven = op == RGPU_OP_TERM || (op == RGPU_OP_AND && !c->cfg.reserved[1]);
     int blocks_per_item = op == RGPU_OP_TERM ? c->cfg.blocks_per_item : c->cfg.reserved[0];
     int W = c->cfg.window_docs, wpq = 0, wpi = 1, ipq = 0;

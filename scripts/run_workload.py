@@ -11,6 +11,8 @@ docs = int(os.environ.get("DOCS", "10000000"))
 seg = indexgen.build_zipf(docs, 1_000_000)
 ctx = rucene_amd.Context(profile_kernels=True)
 leaf = rucene_amd.LeafReader.from_synthetic(seg)
+if os.environ.get('NONORMS'):
+    leaf.norms = None
 s = rucene_amd.GpuIndexSearcher([leaf], ctx=ctx)
 T, B = rucene_amd.TermQuery, rucene_amd.BooleanQuery
 SEED = 0x527563656E65 ^ 0x51

@@ -303,7 +303,7 @@ def test_conjunctions_through_the_window_kernel(oracle):
     """The doc-window accumulate kernel (shared with OR) must give the same AND answers as the lead-driven one."""
     import rucene_amd
     from rucene_amd import indexgen
-    ctx2 = rucene_amd.Context(and_via_windows=True, window_docs=2048, blocks_per_item=3)
+    ctx2 = rucene_amd.Context(and_via_windows=True, or_via_windows=True, window_docs=2048, blocks_per_item=3)
     try:
         seg = indexgen.build_zipf(120_000, 20_000)
         oseg = oracle.Segment(seg.doc_bytes, seg.norms, seg.max_doc, seg.terms, sum_total_term_freq=seg.sum_total_term_freq)
@@ -312,6 +312,7 @@ def test_conjunctions_through_the_window_kernel(oracle):
         ranks = indexgen.log_uniform_ranks(3 * 48, 1, 2000, seed=99).reshape(-1, 3)
         specs = [(oracle.OP_AND, [int(r - 1) for r in row]) for row in ranks]
         specs += [(oracle.OP_TERM, [int(r - 1)]) for r in ranks[:16, 0]]
+        specs += [(oracle.OP_OR, [int(r - 1) for r in row]) for row in ranks[:16]]
         _check_against_oracle(oracle, osearcher, gsearcher, specs, 10)
     finally:
         ctx2.close()
