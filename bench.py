@@ -190,11 +190,13 @@ def main():
     if args.extra and rank == 0:
         extra = {}
         # block-decode microbench: every term with df >= 128 of the shard, docs+freqs materialised in HBM
-        sel = seg.terms[seg.terms["doc_freq"] >= 128]
+        # (the term list is repeated so that one launch carries enough blocks to fill 256 CUs several times over)
+        rep = 16
+        sel = np.tile(seg.terms[seg.terms["doc_freq"] >= 128], rep)
         total = int(sel["doc_freq"].sum())
         d_docs = torch.empty((total,), dtype=torch.int32, device="cuda")
         d_freqs = torch.empty((total,), dtype=torch.int32, device="cuda")
-        enc = term_encoded_bytes(seg.terms, seg.doc_bytes.size - 16)[seg.terms["doc_freq"] >= 128]
+        enc = np.tile(term_encoded_bytes(seg.terms, seg.doc_bytes.size - 16)[seg.terms["doc_freq"] >= 128], rep)
         for _ in range(2):
             leaf.segment.decode_terms_device(sel, d_docs.data_ptr(), d_freqs.data_ptr())
         ctx.kernel_stats_reset()

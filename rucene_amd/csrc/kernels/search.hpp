@@ -46,16 +46,36 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_term(SegView seg, const D
                                                             const int64_t* __restrict__ item_prefix, int n_queries,
                                                             int64_t n_items, int blocks_per_item, int k,
                                                             uint64_t* __restrict__ partial_keys,
-                                                            int32_t* __restrict__ partial_counts) {
+                                                            int32_t* __restrict__ partial_counts,
+                                                            unsigned long long* __restrict__ tau_slots) {
   __shared__ __attribute__((aligned(16))) uint8_t slabs[WG_WAVES][SLAB_BYTES];
   __shared__ float caches[WG_WAVES][256];
   const int lane = lane_id();
   const int wave = wave_id();
   const int64_t item = (int64_t)blockIdx.x * WG_WAVES + wave;
   if (item >= n_items) return;
-  const int q = upper_slot(item_prefix, n_queries, item);
-  const int chunk = (int)(item - item_prefix[q]);
+  // Item order: the first chunk of every query comes first (items 0..n_queries-1), the remaining chunks follow
+  // query-major. Workgroups start in order, so by the time most chunks begin, their query's first chunk has
+  // already published a top-k threshold (SharedTau) and they skip nearly all list insertions.
+  int q, chunk;
+  if (item < n_queries) {
+    q = (int)item;
+    chunk = 0;
+  } else {
+    q = upper_slot(item_prefix, n_queries, item - n_queries);
+    chunk = (int)(item - n_queries - item_prefix[q]) + 1;
+  }
+  if (queries[q].n_terms < 1) {  // clause absent from this leaf: nothing to collect
+    if (lane == 0) partial_counts[item] = 0;
+    for (int i = lane; i < k; i += 64) partial_keys[(size_t)item * (size_t)k + i] = 0ull;
+    return;
+  }
   const DevTerm T = terms[queries[q].first_term];
+  // one look at what earlier wavefronts of this query already achieved (per-block exchanges cost far more in
+  // same-address atomics than they save in insertions), one publication when this item is done
+  SharedTau shared{tau_slots + q};
+  uint64_t floor = 0;
+  const uint64_t seen = shared.peek();
   uint8_t* slab = slabs[wave];
   float* cache = caches[wave];
   float k1;
@@ -66,6 +86,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_term(SegView seg, const D
   WaveTopK top;
   uint64_t tau = 0;
   int count = 0;
+  shared.fold(seen, tau, floor);
   // Scoring runs one block behind decoding: the norm (and live-docs) gathers of block i are issued right after
   // its doc ids exist and consumed while block i+1 is being decoded, so no wave ever sits on its own gather.
   // `full` (std::true_type) marks a FullBlock: every lane holds two real postings, no validity masks.
@@ -112,8 +133,8 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_term(SegView seg, const D
     }
     // one ballot covers both postings in the common case where neither can enter the current top-k
     if (__ballot((key0 > key1 ? key0 : key1) > tau)) {
-      topk_offer<WIDE>(top, key0, tau, k, lane);
-      topk_offer<WIDE>(top, key1, tau, k, lane);
+      topk_offer<WIDE>(top, key0, tau, k, lane, floor);
+      topk_offer<WIDE>(top, key1, tau, k, lane, floor);
     }
   };
 
@@ -162,6 +183,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_term(SegView seg, const D
       finish(std::false_type{}, p, v0, v1);
     }
   }
+  shared.publish<WIDE>(top, k, lane);
   uint64_t* pk = partial_keys + (size_t)item * (size_t)k;
   if (lane < k) pk[lane] = top.a;
   if (WIDE && lane + 64 < k) pk[lane + 64] = top.b;
@@ -294,11 +316,14 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_window(SegView seg, const
 }
 
 // ---- fold the per-item lists of each query: one wavefront per query --------------------------------------------
+// `head_items` > 0 selects the TERM kernel's item layout: item q is query q's first chunk and the query's other
+// chunks are items head_items + [item_prefix[q], item_prefix[q+1]); 0 = plain contiguous ranges.
 template <bool WIDE>
 __global__ __launch_bounds__(WG_THREADS) void k_merge_items(const int64_t* __restrict__ item_prefix, int n_queries, int k,
                                                             const uint64_t* __restrict__ partial_keys,
                                                             const int32_t* __restrict__ partial_counts, int32_t doc_base,
-                                                            HitOut* __restrict__ hits_out, int64_t* __restrict__ totals_out) {
+                                                            int head_items, HitOut* __restrict__ hits_out,
+                                                            int64_t* __restrict__ totals_out) {
   const int lane = lane_id();
   const int q = (int)(blockIdx.x * WG_WAVES) + wave_id();
   if (q >= n_queries) return;
@@ -306,17 +331,22 @@ __global__ __launch_bounds__(WG_THREADS) void k_merge_items(const int64_t* __res
   uint64_t tau = 0;
   int64_t total = 0;
   const int64_t i0 = item_prefix[q], i1 = item_prefix[q + 1];
-  for (int64_t g0 = i0; g0 < i1; g0 += 64) {
+  const int64_t n_mine = (i1 - i0) + (head_items > 0 ? 1 : 0);
+  auto item_at = [&](int64_t j) -> int64_t {  // j-th item of this query
+    if (head_items > 0) return j == 0 ? (int64_t)q : (int64_t)head_items + i0 + j - 1;
+    return i0 + j;
+  };
+  for (int64_t g0 = 0; g0 < n_mine; g0 += 64) {
     // each lane looks at one item's best key (lists are sorted best-first): an item whose head cannot
     // enter the current top-k is skipped without reading the rest of its list
-    const int64_t mine = g0 + lane;
-    const bool ok = mine < i1;
+    const bool ok = g0 + lane < n_mine;
+    const int64_t mine = ok ? item_at(g0 + lane) : 0;
     const uint64_t head = ok ? partial_keys[(size_t)mine * (size_t)k] : 0ull;
     total += wave_reduce_add(ok ? partial_counts[mine] : 0);
     uint64_t m = __ballot(head > tau);
     while (m) {
       const int src = __builtin_ctzll(m);
-      const uint64_t* pk = partial_keys + (size_t)(g0 + src) * (size_t)k;
+      const uint64_t* pk = partial_keys + (size_t)item_at(g0 + src) * (size_t)k;
       topk_offer<WIDE>(top, lane < k ? pk[lane] : 0ull, tau, k, lane);
       if (WIDE) topk_offer<WIDE>(top, lane + 64 < k ? pk[lane + 64] : 0ull, tau, k, lane);
       m &= m - 1;

@@ -37,7 +37,8 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_and(SegView seg, const De
                                                            const int64_t* __restrict__ item_prefix, int n_queries,
                                                            int64_t n_items, int blocks_per_item, int k,
                                                            uint64_t* __restrict__ partial_keys,
-                                                           int32_t* __restrict__ partial_counts) {
+                                                           int32_t* __restrict__ partial_counts,
+                                                           unsigned long long* __restrict__ tau_slots) {
   __shared__ __attribute__((aligned(16))) uint8_t slabs[WG_WAVES][SLAB_BYTES];
   __shared__ float caches[WG_WAVES][256];
   __shared__ int32_t bdocs[WG_WAVES][128];
@@ -62,8 +63,10 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_and(SegView seg, const De
   };
 
   WaveTopK top;
-  uint64_t tau = 0;
+  uint64_t tau = 0, floor = 0;
   int count = 0;
+  SharedTau shared{tau_slots + q};
+  shared.fold(shared.peek(), tau, floor);
 
   auto intersect = [&](int32_t d0, int32_t d1, uint32_t f0, uint32_t f1, bool a0, bool a1) {
     a0 = a0 && doc_is_live(seg.live, d0);
@@ -137,8 +140,8 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_and(SegView seg, const De
       }
     }
     count += __popcll(__ballot(a0)) + __popcll(__ballot(a1));
-    topk_offer<WIDE>(top, a0 ? make_key(s0, d0) : 0ull, tau, k, lane);
-    topk_offer<WIDE>(top, a1 ? make_key(s1, d1) : 0ull, tau, k, lane);
+    topk_offer<WIDE>(top, a0 ? make_key(s0, d0) : 0ull, tau, k, lane, floor);
+    topk_offer<WIDE>(top, a1 ? make_key(s1, d1) : 0ull, tau, k, lane, floor);
   };
 
   const int b0 = chunk * blocks_per_item;
@@ -162,6 +165,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_and(SegView seg, const De
       intersect(d0, d1, f0, f1, 2 * lane < L.tail_n, 2 * lane + 1 < L.tail_n);
     }
   }
+  shared.publish<WIDE>(top, k, lane);
   uint64_t* pk = partial_keys + (size_t)item * (size_t)k;
   if (lane < k) pk[lane] = top.a;
   if (WIDE && lane + 64 < k) pk[lane + 64] = top.b;

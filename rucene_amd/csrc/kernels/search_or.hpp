@@ -117,7 +117,8 @@ __global__ __launch_bounds__(WG_THREADS) void k_or_windows(SegView seg, const De
                                                            int windows_per_query, int windows_per_item,
                                                            int items_per_query, int W, int k,
                                                            uint64_t* __restrict__ partial_keys,
-                                                           int32_t* __restrict__ partial_counts) {
+                                                           int32_t* __restrict__ partial_counts,
+                                                           unsigned long long* __restrict__ tau_slots) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int lane = lane_id();
   const int wave = wave_id();
@@ -131,8 +132,10 @@ __global__ __launch_bounds__(WG_THREADS) void k_or_windows(SegView seg, const De
   const bool has_live = seg.live != nullptr;
 
   WaveTopK top;
-  uint64_t tau = 0;
+  uint64_t tau = 0, floor = 0;
   int count = 0;
+  SharedTau shared{tau_slots + q};
+  shared.fold(shared.peek(), tau, floor);
   const int win0 = g * windows_per_item;
   const int win1 = Q.n_terms > 0 ? min(windows_per_query, win0 + windows_per_item) : win0;
 
@@ -188,10 +191,11 @@ __global__ __launch_bounds__(WG_THREADS) void k_or_windows(SegView seg, const De
       const bool hit = flag[i] != 0;
       const uint64_t key = hit ? make_key(acc[i], w0 + i) : 0ull;
       count += __popcll(__ballot(hit));
-      if (__ballot(key > tau)) topk_offer<WIDE>(top, key, tau, k, lane);
+      if (__ballot(key > tau)) topk_offer<WIDE>(top, key, tau, k, lane, floor);
     }
     wave_sync();
   }
+  shared.publish<WIDE>(top, k, lane);
   uint64_t* pk = partial_keys + (size_t)item * (size_t)k;
   if (lane < k) pk[lane] = top.a;
   if (WIDE && lane + 64 < k) pk[lane + 64] = top.b;

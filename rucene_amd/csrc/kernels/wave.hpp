@@ -104,18 +104,45 @@ __device__ __forceinline__ uint64_t topk_threshold(const WaveTopK& t, int k) {
   return readlane64(t.a, k - 1);
 }
 
-// Offer one key per lane (invalid lanes pass 0); keeps `tau` (the current k-th best) up to date.
+// Offer one key per lane (invalid lanes pass 0); keeps `tau` (the current entry threshold) up to date.
+// `floor` is a lower bound on the query's global k-th best learnt from other wavefronts (0 if none): a key
+// at or below it can never be in the final top-k, so it is not worth an insertion here either.
 template <bool WIDE>
-__device__ __forceinline__ void topk_offer(WaveTopK& t, uint64_t key, uint64_t& tau, int k, int lane) {
+__device__ __forceinline__ void topk_offer(WaveTopK& t, uint64_t key, uint64_t& tau, int k, int lane, uint64_t floor = 0) {
   uint64_t m = __ballot(key > tau);
   while (m) {
     int src = __builtin_ctzll(m);
     uint64_t x = readlane64(key, src);
     topk_insert<WIDE>(t, x, lane);
-    tau = topk_threshold<WIDE>(t, k);
+    const uint64_t kth = topk_threshold<WIDE>(t, k);
+    tau = kth > floor ? kth : floor;
     m &= m - 1;
     m &= __ballot(key > tau);
   }
 }
+
+// Per-query threshold shared between the wavefronts working on one query (one u64 per query in HBM, zeroed
+// per launch). A wave whose list is full publishes its k-th best with an atomic max; every wave folds the
+// published value into its own entry threshold. Only keys that provably cannot reach the final top-k are
+// dropped, so results stay exact and independent of timing.
+struct SharedTau {
+  unsigned long long* slot;
+  uint64_t published = 0;
+  // issue the (L1-bypassing) read early, fold() it later: the latency hides behind the work in between
+  __device__ __forceinline__ uint64_t peek() const { return __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  __device__ __forceinline__ void fold(uint64_t g, uint64_t& tau, uint64_t& floor) const {
+    const uint64_t gu = ((uint64_t)(uint32_t)readfirstlane((int)(uint32_t)(g >> 32)) << 32) | (uint32_t)readfirstlane((int)(uint32_t)g);
+    if (gu > floor) floor = gu;
+    if (floor > tau) tau = floor;
+  }
+  template <bool WIDE>
+  __device__ __forceinline__ void publish(const WaveTopK& t, int k, int lane) {
+    const uint64_t kth = topk_threshold<WIDE>(t, k);  // 0 until the list holds k keys
+    if (kth > published) {
+      if (lane == 0) atomicMax(slot, (unsigned long long)kth);
+      published = kth;
+    }
+  }
+};
 
 }  // namespace rgpu

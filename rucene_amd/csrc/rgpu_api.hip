@@ -88,6 +88,7 @@ struct rgpu_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   rgpu_config cfg{};
+  bool blocks_per_item_auto = false;
   std::mutex mu;
   DevVec<float> sim_tables;
   int n_sim_tables = 0;
@@ -99,6 +100,7 @@ struct rgpu_ctx {
   DevVec<HitOut> d_hits;
   DevVec<int64_t> d_totals;
   DevVec<ScoredPosting> d_runs;  // OR: per-clause {doc, score} runs
+  DevVec<unsigned long long> d_tau;  // per-query shared top-k thresholds
   int* d_err = nullptr;
   // profiling
   std::vector<StatSlot> stats;
@@ -322,7 +324,7 @@ extern "C" int32_t rgpu_init(int32_t device_ordinal, const rgpu_config* cfg, rgp
   c->device = device_ordinal;
   if (cfg) c->cfg = *cfg;
   c->cfg.abi_version = RGPU_ABI_VERSION;
-  if (c->cfg.blocks_per_item <= 0) c->cfg.blocks_per_item = 32;
+  if (c->cfg.blocks_per_item <= 0) { c->cfg.blocks_per_item = 32; c->blocks_per_item_auto = true; }
   if (c->cfg.reserved[0] <= 0) c->cfg.reserved[0] = 4;  // and_blocks_per_item
   if (c->cfg.window_docs <= 0) c->cfg.window_docs = 4096;
   c->cfg.window_docs = std::min(24576, std::max(1024, (c->cfg.window_docs + 1023) / 1024 * 1024));
@@ -342,7 +344,7 @@ extern "C" void rgpu_shutdown(rgpu_ctx* c) {
   drain_events(c);
   for (auto e : c->free_events) (void)hipEventDestroy(e);
   c->sim_tables.release(); c->d_stage.release(); c->d_partial_keys.release(); c->d_partial_counts.release();
-  c->d_hits.release(); c->d_totals.release(); c->d_runs.release(); c->h_stage.release();
+  c->d_hits.release(); c->d_totals.release(); c->d_runs.release(); c->d_tau.release(); c->h_stage.release();
   if (c->d_err) (void)hipFree(c->d_err);
   (void)hipStreamDestroy(c->stream);
   delete c;
@@ -593,11 +595,11 @@ struct Group {  // queries of one op, in their original order
 
 template <bool WIDE>
 static void launch_merge(rgpu_ctx* c, hipStream_t s, int n_queries, int k, const int64_t* d_prefix, int32_t doc_base, HitOut* hits,
-                         int64_t* totals) {
+                         int64_t* totals, int head_items = 0) {
   TimedLaunch tl(c, s, "k_merge_items", 0);
   const unsigned grid = (unsigned)((n_queries + WG_WAVES - 1) / WG_WAVES);
   hipLaunchKernelGGL(k_merge_items<WIDE>, dim3(grid), dim3(WG_THREADS), 0, s, d_prefix, n_queries, k, c->d_partial_keys.p,
-                     c->d_partial_counts.p, doc_base, hits, totals);
+                     c->d_partial_counts.p, doc_base, head_items, hits, totals);
 }
 
 // OR: score every clause once into {doc, score} runs, then accumulate per doc-id window (kernels/search_or.hpp)
@@ -626,7 +628,7 @@ static int32_t search_or_group(rgpu_segment* seg, Group& G, int32_t k, HitOut* h
   for (int j = 0; j < nt; ++j) { run_prefix[(size_t)j] = postings; postings += G.terms[(size_t)j].df; }
   run_prefix[(size_t)nt] = postings;
   // phase 2 plan: items = (query, group of windows), one per wavefront
-  int W = std::min(4096, std::max(1024, c->cfg.reserved[3] > 0 ? (c->cfg.reserved[3] + 1023) / 1024 * 1024 : 2048));
+  int W = std::min(4096, std::max(256, c->cfg.reserved[3] > 0 ? (c->cfg.reserved[3] + 255) / 256 * 256 : 1024));
   const int wpq = std::max(1, (seg->max_doc + W - 1) / W);
   const int wpi = (int)std::max<int64_t>(1, ((int64_t)nq * wpq + 131071) / 131072);
   const int ipq = (wpq + wpi - 1) / wpi;
@@ -651,6 +653,8 @@ static int32_t search_or_group(rgpu_segment* seg, Group& G, int32_t k, HitOut* h
   std::memcpy(c->h_stage.p + o_m, G.qmap.data(), (size_t)nq * 4);
   HIP_TRY(hipMemcpyAsync(c->d_stage.p, c->h_stage.p, st.used, hipMemcpyHostToDevice, stream));
   HIP_TRY(c->d_runs.reserve((size_t)postings + 64, 0, stream));
+  HIP_TRY(c->d_tau.reserve((size_t)nq, 0, stream));
+  HIP_TRY(hipMemsetAsync(c->d_tau.p, 0, (size_t)nq * 8, stream));
   HIP_TRY(c->d_partial_keys.reserve((size_t)items2 * (size_t)k, 0, stream));
   HIP_TRY(c->d_partial_counts.reserve((size_t)items2, 0, stream));
   HIP_TRY(c->d_hits.reserve((size_t)nq * (size_t)k, 0, stream));
@@ -678,7 +682,7 @@ static int32_t search_or_group(rgpu_segment* seg, Group& G, int32_t k, HitOut* h
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
       hipLaunchKernelGGL(kern, dim3(grid), dim3(WG_THREADS), lds, stream, sv, dq, dt, drp, c->d_runs.p, nq, wpq, wpi, ipq, W, (int)k,
-                         c->d_partial_keys.p, c->d_partial_counts.p);
+                         c->d_partial_keys.p, c->d_partial_counts.p, c->d_tau.p);
       return hipSuccess;
     };
     HIP_TRY(wide ? go(k_or_windows<true>) : go(k_or_windows<false>));
@@ -774,20 +778,29 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
     int W = c->cfg.window_docs, wpq = 0, wpi = 1, ipq = 0;
     int64_t items = 0;
     G.item_prefix.assign((size_t)nq + 1, 0);
+    const int head_items = op == RGPU_OP_TERM ? nq : 0;  // TERM: every query's first chunk is scheduled first
     if (lead_driven) {  // items = chunks of the (lead) term's blocks; the last chunk also takes its tail
+      if (op == RGPU_OP_TERM && c->blocks_per_item_auto) {  // fewer, longer items when there are plenty of blocks
+        int64_t total_blocks = 0;
+        for (auto& t : G.terms) total_blocks += t.nblocks;
+        blocks_per_item = 8;
+        while (blocks_per_item < 128 && total_blocks / blocks_per_item > 40000) blocks_per_item *= 2;
+      }
       while (true) {
         items = 0;
         for (int q = 0; q < nq; ++q) {
           G.item_prefix[(size_t)q] = items;
           if (G.queries[(size_t)q].n_terms >= 1) {
             const DevTerm& t = G.terms[(size_t)G.queries[(size_t)q].first_term];
-            items += t.nblocks == 0 ? 1 : (t.nblocks + blocks_per_item - 1) / blocks_per_item;
+            const int64_t mine = t.nblocks == 0 ? 1 : (t.nblocks + blocks_per_item - 1) / blocks_per_item;
+            items += head_items ? mine - 1 : mine;
           }
         }
         G.item_prefix[(size_t)nq] = items;
         if (items <= 262144 || blocks_per_item >= (1 << 17)) break;
         blocks_per_item *= 2;
       }
+      items += head_items;
     } else {
       wpq = (seg->max_doc + W - 1) / W;
       if (wpq < 1) wpq = 1;
@@ -814,6 +827,8 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
     HIP_TRY(c->d_partial_counts.reserve((size_t)items, 0, stream));
     HIP_TRY(c->d_hits.reserve((size_t)nq * (size_t)k, 0, stream));
     HIP_TRY(c->d_totals.reserve((size_t)nq, 0, stream));
+    HIP_TRY(c->d_tau.reserve((size_t)nq, 0, stream));
+    HIP_TRY(hipMemsetAsync(c->d_tau.p, 0, (size_t)nq * 8, stream));
     const DevQuery* dq = reinterpret_cast<const DevQuery*>(c->d_stage.p + o_q);
     const DevTerm* dt = reinterpret_cast<const DevTerm*>(c->d_stage.p + o_t);
     const int64_t* dp = reinterpret_cast<const int64_t*>(c->d_stage.p + o_p);
@@ -824,7 +839,7 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
       const unsigned grid = (unsigned)((items + WG_WAVES - 1) / WG_WAVES);
       auto go = [&](auto kern) {
         hipLaunchKernelGGL(kern, dim3(grid), dim3(WG_THREADS), 0, stream, sv, dq, dt, dp, nq, items, blocks_per_item, (int)k,
-                           c->d_partial_keys.p, c->d_partial_counts.p);
+                           c->d_partial_keys.p, c->d_partial_counts.p, c->d_tau.p);
       };
       if (legacy) { if (wide) go(k_search_and<true, true>); else go(k_search_and<true, false>); }
       else { if (wide) go(k_search_and<false, true>); else go(k_search_and<false, false>); }
@@ -833,7 +848,7 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
       const unsigned grid = (unsigned)((items + WG_WAVES - 1) / WG_WAVES);
       auto go = [&](auto kern) {
         hipLaunchKernelGGL(kern, dim3(grid), dim3(WG_THREADS), 0, stream, sv, dq, dt, dp, nq, items, blocks_per_item, (int)k,
-                           c->d_partial_keys.p, c->d_partial_counts.p);
+                           c->d_partial_keys.p, c->d_partial_counts.p, c->d_tau.p);
       };
       if (legacy) { if (wide) go(k_search_term<true, true>); else go(k_search_term<true, false>); }
       else { if (wide) go(k_search_term<false, true>); else go(k_search_term<false, false>); }
@@ -857,8 +872,8 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
       }
       HIP_TRY(e);
     }
-    if (wide) launch_merge<true>(c, stream, nq, k, dp, seg->doc_base, c->d_hits.p, c->d_totals.p);
-    else launch_merge<false>(c, stream, nq, k, dp, seg->doc_base, c->d_hits.p, c->d_totals.p);
+    if (wide) launch_merge<true>(c, stream, nq, k, dp, seg->doc_base, c->d_hits.p, c->d_totals.p, head_items);
+    else launch_merge<false>(c, stream, nq, k, dp, seg->doc_base, c->d_hits.p, c->d_totals.p, head_items);
     // scatter group rows to the caller's rows
     hipLaunchKernelGGL(k_scatter_rows, dim3((unsigned)nq), dim3(128), 0, stream, c->d_hits.p, c->d_totals.p, dm, (int)k, hits_dev, totals_dev);
     HIP_TRY(hipGetLastError());
