@@ -39,6 +39,29 @@ def term_encoded_bytes(terms, doc_len_end):
     return out.astype(np.int64)
 
 
+def profiled_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary under profiles/
+    (FETCH_SIZE + WRITE_SIZE, KiB -> bytes, uncorrected: MI355X_MICROARCH.md notes gfx950's FETCH_SIZE can read 1/2
+    for wide streams). None when no profile of this kernel is committed — bench.py itself never runs rocprof."""
+    import glob
+    import re
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_rocprofv3_summary.txt"))):
+        fetch = write = None
+        for line in open(path):
+            if kernel not in line:
+                continue
+            m = re.search(r"FETCH_SIZE=([0-9.e+]+)", line)
+            if m:
+                fetch = float(m.group(1))
+            m = re.search(r"WRITE_SIZE=([0-9.e+]+)", line)
+            if m:
+                write = float(m.group(1))
+        if fetch is not None and write is not None:
+            best = {"bytes": (fetch + write) * 1024.0, "source": os.path.relpath(path, ROOT)}
+    return best
+
+
 def build_queries(n_queries, kind, seed):
     from rucene_amd import indexgen
     if kind == "term":
@@ -116,20 +139,23 @@ def main():
     k, nq = args.k, args.queries
     hits_local = torch.empty((nq, k), dtype=torch.int64, device="cuda")      # rgpu_hit {i32 doc, f32 score}
     totals_local = torch.empty((nq,), dtype=torch.int64, device="cuda")
-    if world > 1:
-        hits_all = torch.empty((world, nq, k), dtype=torch.int64, device="cuda")
-        totals_all = torch.empty((world, nq), dtype=torch.int64, device="cuda")
-        hits_merged = torch.empty((nq, k), dtype=torch.int64, device="cuda")
-        totals_merged = torch.empty((nq,), dtype=torch.int64, device="cuda")
+
+    from rucene_amd import dist as rdist
+    merge = rdist.hip_merge(ctx)
+
+    def local_search(packed):
+        # the ctx runs its kernels on its own stream and returns when they are done, so the collective that
+        # follows (torch's stream) always sees complete per-shard results
+        leaf.segment.search_batch_device(packed[0], packed[1], k, hits_local.data_ptr(), totals_local.data_ptr())
+        return hits_local, totals_local
+
+    merged = {}
 
     def step(packed):
-        stream = torch.cuda.current_stream().cuda_stream
-        leaf.segment.search_batch_device(packed[0], packed[1], k, hits_local.data_ptr(), totals_local.data_ptr(), stream)
         if world > 1:
-            dist.all_gather_into_tensor(hits_all, hits_local)
-            dist.all_gather_into_tensor(totals_all, totals_local)
-            ctx.merge_topk_device(hits_all.data_ptr(), totals_all.data_ptr(), world, nq, k, hits_merged.data_ptr(),
-                                  totals_merged.data_ptr(), stream)
+            merged["hits"], merged["totals"] = rdist.sharded_search(lambda: local_search(packed), merge)
+        else:
+            local_search(packed)
 
     def timed(packed, steps, warmup):
         for _ in range(warmup):
@@ -182,7 +208,8 @@ def main():
             "postings_per_step_per_shard": postings, "index_build_s": round(gen_s, 2), "device": ctx.device_name,
         },
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "kernel": dom_name, "kernel_ms": dom_ms, "algorithmic_bytes_per_launch": algo_bytes,
+                     "traffic": (profiled_traffic(dom_name) or {}).get("bytes"),
+                     "traffic_source": (profiled_traffic(dom_name) or {}).get("source"), "kernel": dom_name, "kernel_ms": dom_ms, "algorithmic_bytes_per_launch": algo_bytes,
                      "frac_vs_measured_copy_6290": achieved / 6290.0},
         "kernels_ms_per_step": {n: s["total_ms"] / args.steps for n, s in kstats.items()},
     }

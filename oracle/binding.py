@@ -104,6 +104,7 @@ def _declare(L):
         "orc_searcher_new": (vp, [C.POINTER(vp), C.c_int, C.c_float, C.c_float]),
         "orc_searcher_free": (None, [vp]),
         "orc_searcher_stats_leaf": (C.c_int, [vp]),
+        "orc_searcher_override_stats": (None, [vp, vp, C.c_int64]),
         "orc_searcher_term_weight": (C.c_float, [vp, C.c_int64, C.c_float, f32p]),
         "orc_search": (C.c_int, [vp, C.c_int, i64p, C.c_int, f32p, C.c_int, C.c_int, C.c_int, C.c_int, i32p, f32p, i32p, i64p]),
         "orc_search_batch": (C.c_double, [vp, C.c_int, i32p, i32p, i64p, C.c_int, C.c_int, C.c_int, i32p, f32p, i32p, i64p, u64p]),
@@ -304,6 +305,11 @@ class Searcher:
         self._h = lib().orc_searcher_new(arr, len(self.segments), k1, b)
         if not self._h:
             raise OracleError(lib().orc_last_error().decode())
+
+    def override_statistics(self, stats_segment, total_max_doc):
+        """Score with another leaf's statistics (the index-wide largest leaf living on another shard)."""
+        self._stats_segment = stats_segment  # keep alive
+        lib().orc_searcher_override_stats(self._h, stats_segment._h, int(total_max_doc))
 
     def term_weight(self, term_id, boost=1.0):
         cache = np.zeros(256, dtype=np.float32)

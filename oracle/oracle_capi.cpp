@@ -211,6 +211,7 @@ orc_searcher* orc_searcher_new(orc_segment** segs, int n, float k1, float b) {
 }
 void orc_searcher_free(orc_searcher* s) { delete s; }
 int orc_searcher_stats_leaf(orc_searcher* s) { return s->s.stats_leaf; }
+void orc_searcher_override_stats(orc_searcher* s, orc_segment* stats_seg, int64_t total_max_doc) { s->s.override_statistics(&stats_seg->s, total_max_doc); }
 float orc_searcher_term_weight(orc_searcher* s, int64_t term_id, float boost, float* cache_out) {
   BM25Weight w = s->s.term_weight(term_id, boost);
   if (cache_out) std::memcpy(cache_out, w.cache, sizeof(w.cache));

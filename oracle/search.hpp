@@ -594,10 +594,21 @@ struct IndexSearcher {
     field_stats.sum_total_term_freq = s->sum_total_term_freq;
     field_stats.sum_doc_freq = s->sum_doc_freq;
   }
+  // Sharded deployment: every shard scores with the statistics of the index-wide largest
+  // leaf, which may live on another rank; the host ships that leaf's statistics instead of recomputing idf.
+  const Segment* stats_override = nullptr;
+  void override_statistics(const Segment* s, int64_t total_max_doc) {
+    stats_override = s;
+    field_stats.doc_base = s->doc_base;
+    field_stats.max_doc = total_max_doc;
+    field_stats.doc_count = s->doc_count;
+    field_stats.sum_total_term_freq = s->sum_total_term_freq;
+    field_stats.sum_doc_freq = s->sum_doc_freq;
+  }
   // searcher.rs:732-767 — df/ttf of the term in the statistics leaf only
   TermStatistics term_statistics(int64_t term_id) const {
     TermStatistics ts;
-    const Segment* s = leaves[(size_t)stats_leaf];
+    const Segment* s = stats_override ? stats_override : leaves[(size_t)stats_leaf];
     ts.doc_freq = 0;
     ts.total_term_freq = 0;
     if (term_id >= 0 && term_id < s->n_terms && s->terms[term_id].doc_freq > 0) {

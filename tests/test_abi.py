@@ -1,0 +1,101 @@
+"""CPU-only checks of the drop-in boundary: the C-ABI library loads without a GPU and exports every symbol that
+include/rucene_gpu.h declares; struct layouts match the ctypes/numpy mirrors; host-side helpers (no GPU work) agree
+with the oracle bit for bit; compute entry points fail loudly — never fall back — when no device is present."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def gpu_lib():
+    import __graft_entry__ as g
+    g.build()
+    from rucene_amd import _lib
+    return _lib
+
+
+def _header_functions():
+    text = open(os.path.join(ROOT, "include", "rucene_gpu.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rgpu_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported(gpu_lib):
+    declared = _header_functions()
+    assert declared, "no prototypes parsed from the header"
+    L = C.CDLL(gpu_lib.lib_path())
+    for name in declared:
+        assert hasattr(L, name), "header declares %s but librucene_gpu.so does not export it" % name
+    assert sorted(gpu_lib.EXPORTS) == declared, "rucene_amd/_lib.py EXPORTS drifted from include/rucene_gpu.h"
+
+
+def test_struct_layouts_match_the_header(gpu_lib):
+    assert gpu_lib.TERM_STATE_DTYPE.itemsize == 32
+    assert gpu_lib.TERM_STATE_DTYPE.fields["doc_freq"][1] == 24 and gpu_lib.TERM_STATE_DTYPE.fields["singleton_doc_id"][1] == 28
+    assert gpu_lib.QUERY_TERM_DTYPE.itemsize == 40 and gpu_lib.QUERY_TERM_DTYPE.fields["weight"][1] == 32
+    assert gpu_lib.QUERY_DTYPE.itemsize == 16 and gpu_lib.HIT_DTYPE.itemsize == 8
+    assert C.sizeof(gpu_lib._Config) == 64
+    assert gpu_lib.lib().rgpu_abi_version() == 1
+
+
+def test_bm25_host_helper_is_bit_exact_with_the_oracle(gpu_lib, oracle):
+    rng = np.random.default_rng(4)
+    for _ in range(50):
+        max_doc = int(rng.integers(10, 10**8))
+        doc_count = int(rng.integers(1, max_doc + 1)) if rng.random() < 0.8 else -1
+        sum_ttf = int(rng.integers(-1, 10**11))
+        df = int(rng.integers(0, max_doc))
+        boost = float(np.float32(rng.uniform(0.1, 3.0)))
+        k1, b = float(np.float32(rng.uniform(0.5, 2.0))), float(np.float32(rng.uniform(0.0, 1.0)))
+        w, idf, cache = gpu_lib.bm25_compute_weight(k1, b, max_doc, doc_count, sum_ttf, [df], boost)
+        ocache = np.zeros(256, np.float32)
+        ow = oracle.lib().orc_bm25_weight(k1, b, max_doc, doc_count, sum_ttf, df, boost, ocache.ctypes.data_as(C.POINTER(C.c_float)))
+        assert np.float32(w).view(np.int32) == np.float32(ow).view(np.int32)
+        assert (cache.view(np.int32) == ocache.view(np.int32)).all()
+    for length in (1, 2, 99, 100, 120, 1000, 10_000, 2**31 - 1):
+        assert gpu_lib.bm25_encode_norm(1.0, length) == oracle.lib().orc_bm25_encode_norm(1.0, length)
+
+
+def test_no_cpu_fallback(gpu_lib):
+    """Without a HIP device rgpu_init must fail with RuntimeError (-7); nothing computes on the host."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(gpu_lib.RgpuError) as e:
+        gpu_lib.Context()
+    assert e.value.status == -7
+
+
+def test_boolean_query_build_rules():
+    # search/query/boolean_query.rs:40-86
+    import rucene_amd
+    T, B = rucene_amd.TermQuery, rucene_amd.BooleanQuery
+    assert isinstance(B.build([T(1)], []), T)            # single clause collapses to the clause
+    assert isinstance(B.build([], [T(2)]), T)
+    q = B.build([T(1), T(2)], [])
+    assert q.min_should_match == 0 and len(q.must_queries) == 2
+    q = B.build([], [T(1), T(2), T(3)])
+    assert q.min_should_match == 1 and len(q.should_queries) == 3
+    with pytest.raises(rucene_amd.RgpuError) as e:
+        B.build([], [])
+    assert e.value.status == -2                          # IllegalArgument, like the reference's bail!
+    for bad in (lambda: B.build([T(1)], [T(2)]), lambda: B.build([], [T(1), T(2)], min_should_match=2),
+                lambda: B.build([T(1), T(2)], [], must_nots=[T(3)])):
+        with pytest.raises(rucene_amd.RgpuError) as e:
+            bad()
+        assert e.value.status == -5                      # UnsupportedOperation: caller keeps those on the CPU path
+
+
+def test_doc_file_validation_needs_no_gpu(gpu_lib):
+    """Header/footer/ForUtil-table validation is host code; it is exercised through upload on the GPU box
+    (tests/test_gpu_parity.py::test_error_codes). Here: the generator's files carry what open() checks."""
+    from rucene_amd import indexgen
+    seg = indexgen.build_explicit(1000, [(np.arange(0, 900, 3, dtype=np.int32), np.ones(300, np.int32))])
+    raw = seg.doc_bytes.tobytes()
+    assert raw[:4] == bytes.fromhex("3FD76C17") and b"Lucene50PostingsWriterDoc" in raw[:40]
+    assert raw[-16:-12] == bytes.fromhex("C02893E8")  # ~CODEC_MAGIC
