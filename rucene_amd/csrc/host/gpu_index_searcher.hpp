@@ -1,0 +1,235 @@
+// C++ host-side mirror of the slice of Rucene's search API served by the GPU path, header-only over the C ABI
+// (include/rucene_gpu.h). The reference is compiled Rust and this image has no Rust toolchain, so the layer a
+// Rucene maintainer would write as a Rust shim is provided in C++ with the reference's names,
+// argument meaning and error behaviour (paths relative to /root/reference/src/core):
+//
+//   search/searcher.rs:205-249, 306-363, 487-525, 732-767   IndexSearcher::search + the largest-leaf statistics
+//   search/query/term_query.rs:45-95                         TermQuery::new(term, boost), create_weight
+//   search/query/boolean_query.rs:40-86                      BooleanQuery::build
+//   search/collector/top_docs.rs:97-183                      TopDocsCollector::new(k), top_docs()
+//   search/sort_field/collapse_top_docs.rs:22-36             ScoreDoc
+//   error.rs:24-91                                           ErrorKind -> rucene::Error{kind}
+//
+// The block-tree term dictionary is out of scope: a LeafReader carries a flat table of
+// BlockTermState records indexed by term id.
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../../include/rucene_gpu.h"
+#include "bm25_similarity.hpp"
+
+namespace rucene {
+
+struct Error : std::runtime_error {
+  int kind;  // rgpu_status == error.rs ErrorKind
+  Error(int k, const std::string& m) : std::runtime_error(m), kind(k) {}
+};
+inline void check(int32_t rc) {
+  if (rc < 0) throw Error(rc, rgpu_last_error(nullptr));
+}
+
+struct ScoreDoc {
+  int32_t doc;
+  float score;
+};
+
+class TopDocs {
+ public:
+  TopDocs() = default;
+  TopDocs(int64_t total, std::vector<ScoreDoc> docs) : total_(total), docs_(std::move(docs)) {}
+  int64_t total_hits() const { return total_; }
+  const std::vector<ScoreDoc>& score_docs() const { return docs_; }  // score desc, then doc asc
+
+ private:
+  int64_t total_ = 0;
+  std::vector<ScoreDoc> docs_;
+};
+
+class TopDocsCollector {
+ public:
+  explicit TopDocsCollector(size_t estimated_hits) : estimated_hits_(estimated_hits) {}
+  bool needs_scores() const { return true; }
+  size_t estimated_hits() const { return estimated_hits_; }
+  TopDocs top_docs() const { return result_; }
+  void set_result(TopDocs r) { result_ = std::move(r); }
+
+ private:
+  size_t estimated_hits_;
+  TopDocs result_;
+};
+
+struct Query {
+  virtual ~Query() {}
+};
+struct TermQuery : Query {
+  int64_t term;
+  float boost;
+  explicit TermQuery(int64_t t, float b = 1.0f) : term(t), boost(b) {}
+};
+struct BooleanQuery : Query {
+  std::vector<TermQuery> must_queries, should_queries;
+  int32_t min_should_match = 0;
+  // boolean_query.rs:40-86 restricted to what the GPU path serves; a single clause collapses to that clause
+  static std::unique_ptr<Query> build(std::vector<TermQuery> musts, std::vector<TermQuery> shoulds, int32_t min_should_match = 0) {
+    const int32_t msm = min_should_match > 0 ? min_should_match : (musts.empty() ? 1 : 0);
+    if (musts.empty() && shoulds.empty())
+      throw Error(RGPU_ERR_ILLEGAL_ARGUMENT, "boolean query should at least contain one inner query!");
+    if (musts.size() + shoulds.size() == 1) return std::unique_ptr<Query>(new TermQuery(musts.empty() ? shoulds[0] : musts[0]));
+    if ((!musts.empty() && !shoulds.empty()) || msm > 1)
+      throw Error(RGPU_ERR_UNSUPPORTED, "only pure-MUST and pure-SHOULD (min_should_match 1) term trees run on the GPU path");
+    auto q = std::unique_ptr<BooleanQuery>(new BooleanQuery());
+    q->must_queries = std::move(musts);
+    q->should_queries = std::move(shoulds);
+    q->min_should_match = msm;
+    return std::unique_ptr<Query>(q.release());
+  }
+};
+
+// One segment: postings file, norms, live docs, FieldReader statistics, flat term table.
+struct LeafReader {
+  const uint8_t* doc_bytes = nullptr;
+  size_t doc_len = 0;
+  const uint8_t* norms = nullptr;
+  const uint64_t* live_docs = nullptr;
+  int32_t max_doc = 0, doc_base = 0;
+  int64_t doc_count = 0, sum_total_term_freq = 0, sum_doc_freq = -1;
+  const rgpu_term_state* terms = nullptr;
+  int64_t n_terms = 0;
+  rgpu_segment* segment = nullptr;  // filled by the searcher
+  const rgpu_term_state* term_state(int64_t t) const { return (t >= 0 && t < n_terms && terms[t].doc_freq > 0) ? &terms[t] : nullptr; }
+};
+
+class GpuIndexSearcher {
+ public:
+  GpuIndexSearcher(std::vector<LeafReader> leaves, const BM25Similarity& sim = BM25Similarity(), int device = 0)
+      : leaves_(std::move(leaves)), sim_(sim) {
+    rgpu_config cfg{};
+    cfg.abi_version = RGPU_ABI_VERSION;
+    check(rgpu_init(device, &cfg, &ctx_));
+    for (auto& l : leaves_)
+      check(rgpu_segment_upload(ctx_, l.doc_bytes, l.doc_len, l.norms, l.max_doc, l.doc_base, l.live_docs, &l.segment));
+    // searcher.rs:306-363: the first leaf with the largest max_doc provides the collection statistics
+    for (size_t i = 1; i < leaves_.size(); ++i)
+      if (leaves_[i].max_doc > leaves_[stats_leaf_].max_doc) stats_leaf_ = i;
+    const LeafReader& s = leaves_[stats_leaf_];
+    stats_.doc_base = s.doc_base;
+    stats_.max_doc = max_doc();
+    stats_.doc_count = s.doc_count;
+    stats_.sum_total_term_freq = s.sum_total_term_freq;
+    stats_.sum_doc_freq = s.sum_doc_freq;
+  }
+  ~GpuIndexSearcher() {
+    for (auto& l : leaves_) rgpu_segment_free(l.segment);
+    rgpu_shutdown(ctx_);
+  }
+  GpuIndexSearcher(const GpuIndexSearcher&) = delete;
+  GpuIndexSearcher& operator=(const GpuIndexSearcher&) = delete;
+
+  int64_t max_doc() const {
+    int64_t n = 0;
+    for (auto& l : leaves_) n += l.max_doc;
+    return n;
+  }
+  // searcher.rs:732-767: doc_freq of the term in the statistics leaf only
+  TermStatistics term_statistics(int64_t term) const {
+    TermStatistics ts;
+    const rgpu_term_state* st = leaves_[stats_leaf_].term_state(term);
+    ts.doc_freq = st ? st->doc_freq : 0;
+    ts.total_term_freq = st ? st->total_term_freq : 0;
+    return ts;
+  }
+  const CollectionStatistics& collection_statistics() const { return stats_; }
+
+  // IndexSearcher::search(query, collector) for a TopDocsCollector
+  void search(const Query& query, TopDocsCollector& collector) {
+    std::vector<const Query*> one{&query};
+    std::vector<TopDocs> r = search_many(one, collector.estimated_hits());
+    collector.set_result(std::move(r[0]));
+  }
+
+  // the batched form the hardware wants: one launch set per leaf for many queries
+  std::vector<TopDocs> search_many(const std::vector<const Query*>& queries, size_t k) {
+    const int32_t nq = static_cast<int32_t>(queries.size());
+    std::vector<std::vector<rgpu_hit>> leaf_hits(leaves_.size());
+    std::vector<std::vector<int64_t>> leaf_totals(leaves_.size());
+    for (size_t li = 0; li < leaves_.size(); ++li) {
+      std::vector<rgpu_query> qs;
+      std::vector<rgpu_query_term> ts;
+      for (const Query* q : queries) pack(*q, leaves_[li], &qs, &ts);
+      leaf_hits[li].assign(static_cast<size_t>(nq) * k, rgpu_hit{-1, 0.f});
+      leaf_totals[li].assign(static_cast<size_t>(nq), 0);
+      check(rgpu_search_batch(leaves_[li].segment, qs.data(), nq, ts.data(), static_cast<int32_t>(ts.size()), static_cast<int32_t>(k),
+                              leaf_hits[li].data(), leaf_totals[li].data()));
+    }
+    // TopDocsCollector::finish_parallel (top_docs.rs:157-172) over a handful of leaves: canonical order
+    std::vector<TopDocs> out;
+    for (int32_t q = 0; q < nq; ++q) {
+      std::vector<ScoreDoc> all;
+      int64_t total = 0;
+      for (size_t li = 0; li < leaves_.size(); ++li) {
+        total += leaf_totals[li][static_cast<size_t>(q)];
+        for (size_t i = 0; i < k; ++i) {
+          const rgpu_hit& h = leaf_hits[li][static_cast<size_t>(q) * k + i];
+          if (h.doc >= 0) all.push_back(ScoreDoc{h.doc, h.score});
+        }
+      }
+      std::stable_sort(all.begin(), all.end(), [](const ScoreDoc& a, const ScoreDoc& b) {
+        return a.score > b.score || (a.score == b.score && a.doc < b.doc);
+      });
+      if (all.size() > k) all.resize(k);
+      out.emplace_back(total, std::move(all));
+    }
+    return out;
+  }
+
+ private:
+  std::pair<float, int32_t> weight_of(const TermQuery& tq) {
+    // TermQuery::create_weight (term_query.rs:58-95) -> BM25Similarity::compute_weight
+    const TermStatistics ts = term_statistics(tq.term);
+    const BM25SimWeight w = sim_.compute_weight(stats_, &ts, 1, tq.boost);
+    if (sim_table_ < 0) check(sim_table_ = rgpu_sim_table_upload(ctx_, w.cache.data(), w.k1));  // one field -> one cache
+    return {w.weight, sim_table_};
+  }
+  void pack(const Query& q, const LeafReader& leaf, std::vector<rgpu_query>* qs, std::vector<rgpu_query_term>* ts) {
+    const std::vector<TermQuery>* clauses = nullptr;
+    std::vector<TermQuery> single;
+    int32_t op = RGPU_OP_TERM;
+    if (auto* t = dynamic_cast<const TermQuery*>(&q)) {
+      single.push_back(*t);
+      clauses = &single;
+    } else if (auto* b = dynamic_cast<const BooleanQuery*>(&q)) {
+      op = b->must_queries.empty() ? RGPU_OP_OR : RGPU_OP_AND;
+      clauses = b->must_queries.empty() ? &b->should_queries : &b->must_queries;
+    } else {
+      throw Error(RGPU_ERR_UNSUPPORTED, "query type not served by the GPU path");
+    }
+    rgpu_query rq{op, static_cast<int32_t>(clauses->size()), static_cast<int32_t>(ts->size()), 0};
+    for (const TermQuery& c : *clauses) {
+      rgpu_query_term qt{};
+      const rgpu_term_state* st = leaf.term_state(c.term);
+      if (st) qt.state = *st;
+      else { qt.state.doc_freq = 0; qt.state.skip_offset = -1; qt.state.singleton_doc_id = -1; }
+      auto w = weight_of(c);
+      qt.weight = w.first;
+      qt.sim_table = w.second;
+      ts->push_back(qt);
+    }
+    qs->push_back(rq);
+  }
+
+  std::vector<LeafReader> leaves_;
+  BM25Similarity sim_;
+  rgpu_ctx* ctx_ = nullptr;
+  size_t stats_leaf_ = 0;
+  CollectionStatistics stats_;
+  int32_t sim_table_ = -1;
+};
+
+}  // namespace rucene

@@ -1,0 +1,71 @@
+// Exercises the C++ host mirror (rucene_amd/csrc/host/gpu_index_searcher.hpp) the way the reference's own
+// example drives Rucene (examples/example.rs: build docs -> TermQuery -> TopDocsCollector -> search): builds a
+// synthetic segment with the generator, runs a few queries on the GPU and prints
+//   <query-index> <total_hits> <doc>:<score-bits> ...
+// tests/test_gpu_parity.py::test_cpp_host_mirror compares the lines with the oracle.
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "../../rucene_amd/csrc/host/gpu_index_searcher.hpp"
+
+extern "C" {
+struct rgen_config { int32_t max_doc; int32_t version; int64_t n_terms; double zipf_scale; uint64_t seed; int32_t shard; int32_t reserved; };
+struct rgen_index;
+rgen_index* rgen_build_zipf(const rgen_config*);
+void rgen_free(rgen_index*);
+int64_t rgen_doc_len(const rgen_index*);
+const uint8_t* rgen_doc_bytes(const rgen_index*);
+const uint8_t* rgen_norms(const rgen_index*);
+const rgpu_term_state* rgen_terms(const rgen_index*);
+int64_t rgen_n_terms(const rgen_index*);
+void rgen_stats(const rgen_index*, int64_t*);
+}
+
+int main() {
+  using namespace rucene;
+  try {
+    rgen_config cfg{150000, 1, 20000, 0.2, 0, 0, 0};
+    rgen_index* ix = rgen_build_zipf(&cfg);
+    int64_t st[8];
+    rgen_stats(ix, st);
+    LeafReader leaf;
+    leaf.doc_bytes = rgen_doc_bytes(ix);
+    leaf.doc_len = (size_t)rgen_doc_len(ix);
+    leaf.norms = rgen_norms(ix);
+    leaf.max_doc = cfg.max_doc;
+    leaf.doc_count = cfg.max_doc;
+    leaf.sum_total_term_freq = st[0];
+    leaf.terms = rgen_terms(ix);
+    leaf.n_terms = rgen_n_terms(ix);
+    GpuIndexSearcher searcher({leaf});
+
+    std::vector<std::unique_ptr<Query>> queries;
+    queries.emplace_back(new TermQuery(7));
+    queries.emplace_back(new TermQuery(4321, 2.0f));
+    queries.push_back(BooleanQuery::build({TermQuery(1), TermQuery(12), TermQuery(40)}, {}));
+    queries.push_back(BooleanQuery::build({}, {TermQuery(3), TermQuery(77), TermQuery(900), TermQuery(15000)}));
+    queries.push_back(BooleanQuery::build({TermQuery(5)}, {}));  // collapses to a TermQuery
+    for (size_t i = 0; i < queries.size(); ++i) {
+      TopDocsCollector collector(10);
+      searcher.search(*queries[i], collector);
+      TopDocs top = collector.top_docs();
+      std::printf("%zu %lld", i, (long long)top.total_hits());
+      for (const ScoreDoc& d : top.score_docs()) {
+        uint32_t bits;
+        std::memcpy(&bits, &d.score, 4);
+        std::printf(" %d:%08x", d.doc, bits);
+      }
+      std::printf("\n");
+    }
+    bool threw = false;
+    try { BooleanQuery::build({}, {}); } catch (const Error& e) { threw = e.kind == RGPU_ERR_ILLEGAL_ARGUMENT; }
+    std::printf("empty-boolean-is-illegal-argument %d\n", threw ? 1 : 0);
+    rgen_free(ix);
+  } catch (const rucene::Error& e) {
+    std::fprintf(stderr, "rucene::Error kind=%d: %s\n", e.kind, e.what());
+    return 2;
+  }
+  return 0;
+}

@@ -2,6 +2,8 @@
 oracle on the same seeded inputs. Integer/byte/index work must be bit-exact; BM25 scores are bit-exact for TERM,
 AND and OR with < 10 clauses, and within 1e-5 relative for OR with >= 10 clauses (the reference's own summation
 order there depends on heap topology — SURVEY.md §3.5)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -316,3 +318,30 @@ def test_conjunctions_through_the_window_kernel(oracle):
         _check_against_oracle(oracle, osearcher, gsearcher, specs, 10)
     finally:
         ctx2.close()
+
+
+def test_cpp_host_mirror(oracle, tmp_path):
+    """The C++ host layer (csrc/host/gpu_index_searcher.hpp) over the C ABI, driven like the reference's example."""
+    import subprocess
+    import rucene_amd
+    from rucene_amd import indexgen
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "host_demo")
+    libdir = os.path.join(root, "rucene_amd")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(root, "tests", "cpp", "host_searcher_demo.cpp"),
+                           "-L" + libdir, "-lrucene_gpu", "-lrucene_indexgen", "-Wl,-rpath," + libdir, "-L/opt/rocm/lib",
+                           "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.check_output([exe], text=True).strip().splitlines()
+    seg = indexgen.build_zipf(150_000, 20_000)
+    oseg = oracle.Segment(seg.doc_bytes, seg.norms, seg.max_doc, seg.terms, sum_total_term_freq=seg.sum_total_term_freq)
+    osr = oracle.Searcher([oseg])
+    specs = [(oracle.OP_TERM, [7], None), (oracle.OP_TERM, [4321], [2.0]), (oracle.OP_AND, [1, 12, 40], None),
+             (oracle.OP_OR, [3, 77, 900, 15000], None), (oracle.OP_TERM, [5], None)]
+    for line, (op, tids, boosts) in zip(out, specs):
+        parts = line.split()
+        d, s, total = osr.search(op, tids, 10, tie_mode=oracle.TIE_CANONICAL, boosts=boosts)
+        assert int(parts[1]) == total
+        got = [(int(p.split(":")[0]), int(p.split(":")[1], 16)) for p in parts[2:]]
+        assert [g[0] for g in got] == d.tolist()
+        assert [g[1] for g in got] == s.view(np.uint32).tolist()
+    assert out[len(specs)].endswith(" 1")
