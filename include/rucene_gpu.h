@@ -56,7 +56,9 @@ typedef struct rgpu_config {
   int32_t reserved[12];       /* [0] = lead blocks per work item of the AND kernel (0 = default 4);
                                  [1] = 1 forces AND through the doc-window kernel (A/B testing);
                                  [2] = 1 forces OR through the doc-window kernel (A/B testing);
-                                 [3] = docs per wave window of the OR kernel (0 = default 1024, 256..4096) */
+                                 [3] = docs per wave window of the OR kernel (0 = default 1024, 256..4096);
+                                 [4] = 1 keeps raw norm bytes in HBM even when <= 64 distinct values exist
+                                       (disables the per-clause LDS score table; A/B testing) */
 } rgpu_config;
 
 /* blocktree/mod.rs:33-59 BlockTermState, as filled by posting_reader.rs:264-306 lucene50_decode_term.

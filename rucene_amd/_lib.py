@@ -138,7 +138,7 @@ class Context:
     """rgpu_ctx: one per process per GPU."""
 
     def __init__(self, device=0, profile_kernels=False, blocks_per_item=0, window_docs=0, and_blocks_per_item=0,
-                 and_via_windows=False, or_via_windows=False, or_window_docs=0):
+                 and_via_windows=False, or_via_windows=False, or_window_docs=0, raw_norms=False):
         cfg = _Config()
         cfg.abi_version = 1
         cfg.blocks_per_item = blocks_per_item
@@ -148,6 +148,7 @@ class Context:
         cfg.reserved[1] = int(and_via_windows)
         cfg.reserved[2] = int(or_via_windows)
         cfg.reserved[3] = or_window_docs
+        cfg.reserved[4] = int(raw_norms)
         h = C.c_void_p()
         _check(lib().rgpu_init(device, C.byref(cfg), C.byref(h)))
         self._h = h

@@ -31,12 +31,34 @@ __device__ __forceinline__ bool doc_is_live(const uint64_t* __restrict__ live, i
   return live == nullptr || ((live[doc >> 6] >> (doc & 63)) & 1ull);  // util/bit_set.rs:453-460
 }
 
-__device__ __forceinline__ void load_sim_table(const float* __restrict__ tables, int id, float* cache, int lane, float& k1) {
-  const float* src = tables + (size_t)id * 257;
+// cache[] is indexed by whatever seg.norms holds: raw norm bytes (256 entries) or norm ranks (<= 64 entries)
+__device__ __forceinline__ void load_sim_table(const SegView& seg, int id, float* cache, int lane, float& k1) {
+  const float* src = seg.sim_tables + (size_t)id * 257;
+  if (seg.n_norm_ranks > 0) {
+    cache[lane] = src[seg.rank_to_norm[lane]];
+  } else {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) cache[lane + 64 * i] = src[lane + 64 * i];
+    for (int i = 0; i < 4; ++i) cache[lane + 64 * i] = src[lane + 64 * i];
+  }
   k1 = src[256];
   wave_sync();
+}
+
+// Per-clause score table over (norm rank, freq 1..SCORE_TABLE_FREQS): Rucene clamps term freqs to 10 at write
+// time (codec/postings/mod.rs:82), so for its own indexes every posting's BM25 score is one LDS read; each entry
+// is produced by the same f32 expression as bm25_score, i.e. bit-identical. Lives right after the 64 cache
+// entries of the wave's LDS slice; lane r fills row r.
+constexpr int SCORE_TABLE_FREQS = 10;
+constexpr int WAVE_CACHE_FLOATS = 64 + 64 * SCORE_TABLE_FREQS;  // >= 256 (raw-norm mode uses the first 256)
+__device__ __forceinline__ void build_score_table(float* cache, float wk, int lane) {
+  const float nrm = cache[lane];
+  float* row = cache + 64 + lane * SCORE_TABLE_FREQS;
+#pragma unroll
+  for (int f = 1; f <= SCORE_TABLE_FREQS; ++f) row[f - 1] = bm25_score(wk, (float)f, nrm);
+  wave_sync();
+}
+__device__ __forceinline__ float table_score(const float* cache, uint32_t rank, uint32_t freq) {
+  return cache[64 + rank * SCORE_TABLE_FREQS + freq - 1];
 }
 
 // ---- single term: items = (query, chunk of `blocks_per_item` blocks); the last chunk also takes the tail -------
@@ -49,7 +71,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_term(SegView seg, const D
                                                             int32_t* __restrict__ partial_counts,
                                                             unsigned long long* __restrict__ tau_slots) {
   __shared__ __attribute__((aligned(16))) uint8_t slabs[WG_WAVES][SLAB_BYTES];
-  __shared__ float caches[WG_WAVES][256];
+  __shared__ float caches[WG_WAVES][WAVE_CACHE_FLOATS];
   const int lane = lane_id();
   const int wave = wave_id();
   const int64_t item = (int64_t)blockIdx.x * WG_WAVES + wave;
@@ -79,9 +101,11 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_term(SegView seg, const D
   uint8_t* slab = slabs[wave];
   float* cache = caches[wave];
   float k1;
-  load_sim_table(seg.sim_tables, T.sim_table, cache, lane, k1);
+  load_sim_table(seg, T.sim_table, cache, lane, k1);
   const float wk = T.weight * (k1 + 1.0f);
   const bool has_norms = seg.norms != nullptr;
+  const bool tabled = has_norms && seg.n_norm_ranks > 0;
+  if (tabled) build_score_table(cache, wk, lane);
 
   WaveTopK top;
   uint64_t tau = 0;
@@ -91,6 +115,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_term(SegView seg, const D
   // its doc ids exist and consumed while block i+1 is being decoded, so no wave ever sits on its own gather.
   // `full` (std::true_type) marks a FullBlock: every lane holds two real postings, no validity masks.
   const bool has_live = seg.live != nullptr;
+  const bool nonneg = T.weight >= 0.0f;  // idf * boost; negative only with a negative boost
   struct Pending {
     int32_t d0, d1;
     uint32_t f0, f1, nb0, nb1;
@@ -119,10 +144,29 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_term(SegView seg, const D
       v0 = v0 && ((p.lw0 >> (p.d0 & 63)) & 1ull);
       v1 = v1 && ((p.lw1 >> (p.d1 & 63)) & 1ull);
     }
-    const float n0 = has_norms ? cache[p.nb0] : k1;
-    const float n1 = has_norms ? cache[p.nb1] : k1;
-    const float s0 = bm25_score(wk, (float)(int32_t)p.f0, n0);
-    const float s1 = bm25_score(wk, (float)(int32_t)p.f1, n1);
+    float s0, s1;
+    const uint32_t fmax = p.f0 > p.f1 ? p.f0 : p.f1, fmin = p.f0 < p.f1 ? p.f0 : p.f1;
+    if (tabled && !__ballot(fmax > (uint32_t)SCORE_TABLE_FREQS || fmin == 0u)) {
+      s0 = table_score(cache, p.nb0, p.f0);
+      s1 = table_score(cache, p.nb1, p.f1);
+    } else {
+      s0 = bm25_score(wk, (float)(int32_t)p.f0, has_norms ? cache[p.nb0] : k1);
+      s1 = bm25_score(wk, (float)(int32_t)p.f1, has_norms ? cache[p.nb1] : k1);
+    }
+    if (FULL && !has_live && nonneg) {
+      // Common case, cheap entry test: scores of a non-negative weight are >= +0, so their raw IEEE bits
+      // order like the key's score field; a posting whose score bits are below the threshold's cannot
+      // enter, and only a wave holding a candidate (>=: ties are settled on doc id) builds the 64-bit keys.
+      count += 128;
+      const uint32_t thi = (uint32_t)(tau >> 32);
+      const uint32_t thr = (thi & 0x80000000u) ? (thi & 0x7fffffffu) : 0u;
+      const uint32_t r0 = __float_as_uint(s0), r1 = __float_as_uint(s1);
+      if (__ballot((r0 > r1 ? r0 : r1) >= thr)) {
+        topk_offer<WIDE>(top, make_key(s0, p.d0), tau, k, lane, floor);
+        topk_offer<WIDE>(top, make_key(s1, p.d1), tau, k, lane, floor);
+      }
+      return;
+    }
     uint64_t key0 = make_key(s0, p.d0), key1 = make_key(s1, p.d1);
     if (FULL && !has_live) {
       count += 128;
@@ -241,7 +285,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_window(SegView seg, const
     for (int ti = 0; ti < Q.n_terms && alive; ++ti) {
       const DevTerm T = terms[Q.first_term + ti];
       if (T.sim_table != cur_table) {
-        load_sim_table(seg.sim_tables, T.sim_table, cache, lane, k1);
+        load_sim_table(seg, T.sim_table, cache, lane, k1);
         cur_table = T.sim_table;
       }
       const float wk = T.weight * (k1 + 1.0f);

@@ -59,7 +59,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_and(SegView seg, const De
   int cur_table = -1;
   float k1 = 0.f;
   auto use_table = [&](int id) {
-    if (id != cur_table) { load_sim_table(seg.sim_tables, id, cache, lane, k1); cur_table = id; }
+    if (id != cur_table) { load_sim_table(seg, id, cache, lane, k1); cur_table = id; }
   };
 
   WaveTopK top;

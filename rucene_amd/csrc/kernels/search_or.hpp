@@ -27,7 +27,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_score_terms(SegView seg, const D
                                                             int64_t n_items, int blocks_per_item,
                                                             ScoredPosting* __restrict__ out) {
   __shared__ __attribute__((aligned(16))) uint8_t slabs[WG_WAVES][SLAB_BYTES];
-  __shared__ float caches[WG_WAVES][256];
+  __shared__ float caches[WG_WAVES][WAVE_CACHE_FLOATS];
   const int lane = lane_id();
   const int wave = wave_id();
   const int64_t item = (int64_t)blockIdx.x * WG_WAVES + wave;
@@ -38,9 +38,11 @@ __global__ __launch_bounds__(WG_THREADS) void k_score_terms(SegView seg, const D
   uint8_t* slab = slabs[wave];
   float* cache = caches[wave];
   float k1;
-  load_sim_table(seg.sim_tables, T.sim_table, cache, lane, k1);
+  load_sim_table(seg, T.sim_table, cache, lane, k1);
   const float wk = T.weight * (k1 + 1.0f);
   const bool has_norms = seg.norms != nullptr;
+  const bool tabled = has_norms && seg.n_norm_ranks > 0;
+  if (tabled) build_score_table(cache, wk, lane);
   ScoredPosting* run = out + out_prefix[t];
 
   struct Pending { int32_t d0, d1; uint32_t f0, f1, nb0, nb1; int64_t slot; };
@@ -53,8 +55,15 @@ __global__ __launch_bounds__(WG_THREADS) void k_score_terms(SegView seg, const D
     return p;
   };
   auto finish = [&](const Pending& p, bool v0, bool v1) {
-    const float s0 = bm25_score(wk, (float)(int32_t)p.f0, has_norms ? cache[p.nb0] : k1);
-    const float s1 = bm25_score(wk, (float)(int32_t)p.f1, has_norms ? cache[p.nb1] : k1);
+    float s0, s1;
+    const uint32_t fmax = p.f0 > p.f1 ? p.f0 : p.f1, fmin = p.f0 < p.f1 ? p.f0 : p.f1;
+    if (tabled && !__ballot((v0 || v1) && (fmax > (uint32_t)SCORE_TABLE_FREQS || fmin == 0u))) {
+      s0 = table_score(cache, p.nb0, v0 ? p.f0 : 1u);
+      s1 = table_score(cache, p.nb1, v1 ? p.f1 : 1u);
+    } else {
+      s0 = bm25_score(wk, (float)(int32_t)p.f0, has_norms ? cache[p.nb0] : k1);
+      s1 = bm25_score(wk, (float)(int32_t)p.f1, has_norms ? cache[p.nb1] : k1);
+    }
     if (v0) run[p.slot] = ScoredPosting{p.d0, s0};
     if (v1) run[p.slot + 1] = ScoredPosting{p.d1, s1};
   };

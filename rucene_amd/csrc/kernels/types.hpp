@@ -13,6 +13,11 @@ struct SegView {
   const uint32_t* dir_off;   // block directory: byte offset of block i from the term's doc_start_fp
   const uint16_t* dir_hdr;   // block directory: b_doc | vint_len << 6 | b_freq << 9
   const float* sim_tables;   // n x 257 floats: cache[256] then k1
+  // Norm ranks: when a segment uses <= 64 distinct norm bytes (SmallFloat lengths: the usual case) the HBM copy of
+  // the norms holds each byte's RANK among the used values and rank_to_norm maps back, so a clause's whole
+  // (norm, freq <= 10) score table fits in a wave's LDS slice. n_norm_ranks == 0 means raw norm bytes.
+  const uint8_t* rank_to_norm;
+  int32_t n_norm_ranks;
   int32_t max_doc;
   int32_t doc_base;
 };

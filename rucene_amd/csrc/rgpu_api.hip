@@ -115,7 +115,9 @@ struct rgpu_segment {
   rgpu_ctx* ctx = nullptr;
   uint8_t* d_doc = nullptr;
   size_t doc_len = 0;
-  uint8_t* d_norms = nullptr;
+  uint8_t* d_norms = nullptr;       // raw norm bytes, or norm ranks when n_norm_ranks > 0
+  uint8_t* d_rank_to_norm = nullptr;
+  int32_t n_norm_ranks = 0;
   uint64_t* d_live = nullptr;
   int32_t max_doc = 0, doc_base = 0, version = 1;
   DevVec<int32_t> dir_last;
@@ -185,6 +187,8 @@ static SegView seg_view(const rgpu_segment* s) {
   SegView v;
   v.doc = s->d_doc;
   v.norms = s->d_norms;
+  v.rank_to_norm = s->d_rank_to_norm;
+  v.n_norm_ranks = s->n_norm_ranks;
   v.live = s->d_live;
   v.dir_last = s->dir_last.p;
   v.dir_off = s->dir_off.p;
@@ -430,7 +434,21 @@ extern "C" int32_t rgpu_segment_upload(rgpu_ctx* c, const uint8_t* doc_file, siz
   if ((e = hipMemcpyAsync(s->d_doc, doc_file, doc_len, hipMemcpyHostToDevice, c->stream)) != hipSuccess) return bail(e, "copy .doc");
   if (norms && max_doc > 0) {
     if ((e = hipMalloc(&s->d_norms, (size_t)max_doc + 64)) != hipSuccess) return bail(e, "hipMalloc(norms)");
-    if ((e = hipMemcpyAsync(s->d_norms, norms, (size_t)max_doc, hipMemcpyHostToDevice, c->stream)) != hipSuccess) return bail(e, "copy norms");
+    // <= 64 distinct norm bytes (the usual SmallFloat length spectrum): store ranks so that a clause's whole
+    // (norm, freq) score table fits in LDS; otherwise keep the raw bytes
+    size_t hist[256] = {0};
+    for (int32_t d = 0; d < max_doc; ++d) hist[norms[d]]++;
+    uint8_t rank_of[256] = {0}, rank_to_norm[64] = {0};
+    int used = 0;
+    for (int b = 0; b < 256; ++b) if (hist[b]) { if (used < 64) { rank_of[b] = (uint8_t)used; rank_to_norm[used] = (uint8_t)b; } ++used; }
+    if (used <= 64 && !c->cfg.reserved[4]) {
+      std::vector<uint8_t> ranks((size_t)max_doc);
+      for (int32_t d = 0; d < max_doc; ++d) ranks[(size_t)d] = rank_of[norms[d]];
+      if ((e = hipMalloc(&s->d_rank_to_norm, 64)) != hipSuccess) return bail(e, "hipMalloc(rank_to_norm)");
+      if ((e = hipMemcpy(s->d_norms, ranks.data(), (size_t)max_doc, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "copy norm ranks");
+      if ((e = hipMemcpy(s->d_rank_to_norm, rank_to_norm, 64, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "copy rank_to_norm");
+      s->n_norm_ranks = used;
+    } else if ((e = hipMemcpyAsync(s->d_norms, norms, (size_t)max_doc, hipMemcpyHostToDevice, c->stream)) != hipSuccess) return bail(e, "copy norms");
   }
   if (live_docs && max_doc > 0) {
     const size_t words = ((size_t)max_doc + 63) / 64;
@@ -448,6 +466,7 @@ extern "C" void rgpu_segment_free(rgpu_segment* s) {
   (void)hipStreamSynchronize(s->ctx->stream);
   if (s->d_doc) (void)hipFree(s->d_doc);
   if (s->d_norms) (void)hipFree(s->d_norms);
+  if (s->d_rank_to_norm) (void)hipFree(s->d_rank_to_norm);
   if (s->d_live) (void)hipFree(s->d_live);
   s->dir_last.release(); s->dir_off.release(); s->dir_hdr.release();
   delete s;

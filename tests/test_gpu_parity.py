@@ -345,3 +345,29 @@ def test_cpp_host_mirror(oracle, tmp_path):
         assert [g[0] for g in got] == d.tolist()
         assert [g[1] for g in got] == s.view(np.uint32).tolist()
     assert out[len(specs)].endswith(" 1")
+
+
+def test_negative_boost_and_raw_norm_mode(oracle):
+    """Negative weights take the generic key path; raw_norms=True disables the LDS score table (256-entry cache)."""
+    import rucene_amd
+    from rucene_amd import indexgen
+    seg = indexgen.build_zipf(100_000, 10_000)
+    oseg = oracle.Segment(seg.doc_bytes, seg.norms, seg.max_doc, seg.terms, sum_total_term_freq=seg.sum_total_term_freq)
+    osr = oracle.Searcher([oseg])
+    for raw in (False, True):
+        c = rucene_amd.Context(raw_norms=raw)
+        try:
+            gs = rucene_amd.GpuIndexSearcher([rucene_amd.LeafReader.from_synthetic(seg)], ctx=c)
+            T, B = rucene_amd.TermQuery, rucene_amd.BooleanQuery
+            cases = [(T(3, -1.5), oracle.OP_TERM, [3], [-1.5]), (T(40, 2.5), oracle.OP_TERM, [40], [2.5]),
+                     (B.build([T(1, -1.0), T(7, 3.0)], []), oracle.OP_AND, [1, 7], [-1.0, 3.0]),
+                     (B.build([], [T(2, 0.5), T(9, -2.0), T(300, 1.0)]), oracle.OP_OR, [2, 9, 300], [0.5, -2.0, 1.0]),
+                     (T(0), oracle.OP_TERM, [0], None)]
+            hits, totals = gs.search_batch([q for q, _, _, _ in cases], 10)
+            for i, (_, op, tids, boosts) in enumerate(cases):
+                d, s, total = osr.search(op, tids, 10, tie_mode=oracle.TIE_CANONICAL, boosts=boosts)
+                assert totals[i] == total
+                assert (hits[i]["doc"][:d.size] == d).all(), (raw, i, hits[i]["doc"], d)
+                assert (hits[i]["score"][:d.size].view(np.int32) == s.view(np.int32)).all(), (raw, i)
+        finally:
+            c.close()
