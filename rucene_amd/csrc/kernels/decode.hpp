@@ -102,26 +102,40 @@ struct BlockPair {
 };
 
 // Phase 1 of a FullBlock decode: issue this lane's 16-byte payload row load (lanes 0..31 -> doc rows, lanes
-// 32..63 -> freq rows). Split from phase 2 so callers can issue block i+1's load before decoding block i.
+// 32..63 -> freq rows). Split from phase 2 so callers can issue later blocks' loads before decoding block i.
+// The load is unconditional (every lane reads 16 bytes at its row position, rows past the payload read the
+// bytes that follow — the file is padded) so that it never sits behind a branch: the waitcnt pass can then keep
+// several blocks in flight. Row 0 of an all-equal stream (b == 0) holds the stream's VInt.
 __device__ __forceinline__ uint4 block_rows_load(const uint8_t* __restrict__ blk, uint32_t hdr, int lane) {
   const int bd = hdr_bdoc(hdr);
-  const int bf = hdr_bfreq(hdr);
   const int doc_sz = bd ? 16 * bd : hdr_vlen(hdr);
   const int half = lane >> 5;
   const int row = lane & 31;
-  const int rows = half ? bf : bd;
-  uint4 v = make_uint4(0u, 0u, 0u, 0u);
-  if (row < rows) v = load16_unaligned(blk + 1 + (half ? doc_sz + 1 : 0) + 16 * row);
+  return load16_unaligned(blk + 1 + (half ? doc_sz + 1 : 0) + 16 * row);
+}
+
+// VInt (data_input.rs:78-111) out of the first 8 bytes of a row held in registers
+__device__ __forceinline__ uint32_t vint_from_words(uint32_t w0, uint32_t w1) {
+  uint32_t v = w0 & 0x7fu;
+  if (w0 & 0x80u) {
+    v |= ((w0 >> 8) & 0x7fu) << 7;
+    if (w0 & 0x8000u) {
+      v |= ((w0 >> 16) & 0x7fu) << 14;
+      if (w0 & 0x800000u) {
+        v |= ((w0 >> 24) & 0x7fu) << 21;
+        if (w0 & 0x80000000u) v |= (w1 & 0x0fu) << 28;
+      }
+    }
+  }
   return v;
 }
 
-// Phase 2: stage the rows in the wave's LDS slab and extract postings 2*lane, 2*lane+1. `blk` = header byte of
-// the doc-delta block, `hdr` from the block directory. Wave-uniform control flow.
+// Phase 2: stage the rows in the wave's LDS slab and extract postings 2*lane, 2*lane+1. `hdr` from the block
+// directory. Wave-uniform control flow, no global loads.
 template <bool LEGACY>
-__device__ __forceinline__ BlockPair block_rows_decode(uint4 rows, const uint8_t* __restrict__ blk, uint32_t hdr, uint8_t* slab, int lane) {
+__device__ __forceinline__ BlockPair block_rows_decode(uint4 rows, uint32_t hdr, uint8_t* slab, int lane) {
   const int bd = hdr_bdoc(hdr);
   const int bf = hdr_bfreq(hdr);
-  const int doc_sz = bd ? 16 * bd : hdr_vlen(hdr);
   {
     const int half = lane >> 5;
     const int row = lane & 31;
@@ -134,16 +148,14 @@ __device__ __forceinline__ BlockPair block_rows_decode(uint4 rows, const uint8_t
     if (LEGACY) extract_pair_legacy(words, bd, lane, out.d0, out.d1);
     else extract_pair_bp128(words, bd, lane, out.d0, out.d1);
   } else {
-    int n;
-    out.d0 = out.d1 = read_vint_uniform(blk + 1, &n);
+    out.d0 = out.d1 = vint_from_words((uint32_t)readlane((int)rows.x, 0), (uint32_t)readlane((int)rows.y, 0));
   }
   if (bf) {
     const uint32_t* words = reinterpret_cast<const uint32_t*>(slab + SLAB_STREAM);
     if (LEGACY) extract_pair_legacy(words, bf, lane, out.f0, out.f1);
     else extract_pair_bp128(words, bf, lane, out.f0, out.f1);
   } else {
-    int n;
-    out.f0 = out.f1 = read_vint_uniform(blk + 1 + doc_sz + 1, &n);
+    out.f0 = out.f1 = vint_from_words((uint32_t)readlane((int)rows.x, 32), (uint32_t)readlane((int)rows.y, 32));
   }
   wave_sync();  // slab is free for the next block
   return out;
@@ -151,7 +163,7 @@ __device__ __forceinline__ BlockPair block_rows_decode(uint4 rows, const uint8_t
 
 template <bool LEGACY>
 __device__ __forceinline__ BlockPair decode_block(const uint8_t* __restrict__ blk, uint32_t hdr, uint8_t* slab, int lane) {
-  return block_rows_decode<LEGACY>(block_rows_load(blk, hdr, lane), blk, hdr, slab, lane);
+  return block_rows_decode<LEGACY>(block_rows_load(blk, hdr, lane), hdr, slab, lane);
 }
 
 // A wave's view of up to 64 consecutive directory entries (one coalesced load), read back with readlane so
@@ -174,6 +186,63 @@ __device__ __forceinline__ void deltas_to_docs(uint32_t d0, uint32_t d1, int32_t
   const int incl = wave_incl_scan(pair);
   doc0 = base + (incl - pair) + (int)d0;
   doc1 = doc0 + (int)d1;
+}
+
+// Streams the FullBlocks [b0, b1) of one term through `body(block_index, doc0, doc1, freq0, freq1)`, keeping
+// PREFETCH_DEPTH blocks' payload rows in flight per wavefront. One row load per block in flight is latency bound
+// (Little: 7 waves/SIMD x ~150 B / ~0.7 us ~ 1.5 TB/s chip-wide — what a depth-1 pipeline measured); four deep
+// covers the HBM/Infinity-Cache latency with the decode work of the blocks in between. `base` carries the
+// running doc id (last doc of the previous block) in and out.
+constexpr int PREFETCH_DEPTH = 4;
+// HAS_PN: also stream the term's posting-order norms (2 bytes per lane per block, SegView::pnorm) through the
+// same ring; body(block_index, doc0, doc1, freq0, freq1, norm0, norm1) — norms are 0 without HAS_PN.
+template <bool LEGACY, bool HAS_PN, typename Body>
+__device__ __forceinline__ void stream_blocks(const uint8_t* __restrict__ tbase, const uint32_t* __restrict__ dir_off,
+                                              const uint16_t* __restrict__ dir_hdr, uint32_t dir_base,
+                                              const uint8_t* __restrict__ pn, int b0, int b1, uint8_t* slab, int lane,
+                                              int32_t& base, Body body) {
+  for (int c0 = b0; c0 < b1; c0 += 64) {
+    const int nb = min(64, b1 - c0);
+    DirChunk dir;
+    dir.load(dir_off, dir_hdr, dir_base, c0, nb, lane);
+    auto step = [&](int idx, const uint4& rows, uint32_t nn) {
+      const BlockPair bp = block_rows_decode<LEGACY>(rows, dir.hdr_at(idx), slab, lane);
+      int32_t d0, d1;
+      deltas_to_docs(bp.d0, bp.d1, base, d0, d1);
+      base = readlane(d1, 63);
+      body(c0 + idx, d0, d1, bp.f0, bp.f1, nn & 0xffu, nn >> 8);
+    };
+    auto norms_of = [&](int idx) -> uint32_t {
+      if (!HAS_PN) return 0u;
+      return *reinterpret_cast<const uint16_t*>(pn + 128 * (size_t)(c0 + idx) + 2 * lane);
+    };
+    // prefetch indices are clamped to the chunk's last block instead of being guarded: a redundant reload of
+    // that block near the end is cheaper than a load behind a branch
+    const int last = nb - 1;
+    uint4 ring[PREFETCH_DEPTH];
+    uint32_t nring[PREFETCH_DEPTH];
+#pragma unroll
+    for (int j = 0; j < PREFETCH_DEPTH; ++j) {
+      const int pj = min(j, last);
+      ring[j] = block_rows_load(tbase + dir.off_at(pj), dir.hdr_at(pj), lane);
+      nring[j] = norms_of(pj);
+    }
+    int i = 0;
+    for (; i + PREFETCH_DEPTH <= nb; i += PREFETCH_DEPTH) {
+#pragma unroll
+      for (int j = 0; j < PREFETCH_DEPTH; ++j) {  // static ring slot j <-> block i + j
+        const uint4 rows = ring[j];
+        const uint32_t nn = nring[j];
+        const int pj = min(i + j + PREFETCH_DEPTH, last);
+        ring[j] = block_rows_load(tbase + dir.off_at(pj), dir.hdr_at(pj), lane);
+        nring[j] = norms_of(pj);
+        step(i + j, rows, nn);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < PREFETCH_DEPTH - 1; ++j)
+      if (i + j < nb) step(i + j, ring[j], nring[j]);
+  }
 }
 
 // ---- VInt tail (< 128 postings) -------------------------------------------------------------------------------

@@ -45,31 +45,14 @@ __global__ __launch_bounds__(WG_THREADS) void k_decode_terms(SegView seg, const 
   const int b1 = min(T.nblocks, b0 + blocks_per_item);
   int32_t base = b0 == 0 ? 0 : seg.dir_last[T.dir_base + b0 - 1];
   const uint8_t* tbase = seg.doc + T.start_fp;
-  for (int c0 = b0; c0 < b1; c0 += 64) {
-    const int nb = min(64, b1 - c0);
-    DirChunk dir;
-    dir.load(seg.dir_off, seg.dir_hdr, T.dir_base, c0, nb, lane);
-    uint32_t off_n = dir.off_at(0), hdr_n = dir.hdr_at(0);
-    uint4 rows_n = block_rows_load(tbase + off_n, hdr_n, lane);
-    for (int i = 0; i < nb; ++i) {
-      const uint32_t off = off_n, hdr = hdr_n;
-      const uint4 rows = rows_n;
-      if (i + 1 < nb) {
-        off_n = dir.off_at(i + 1);
-        hdr_n = dir.hdr_at(i + 1);
-        rows_n = block_rows_load(tbase + off_n, hdr_n, lane);
-      }
-      const BlockPair bp = block_rows_decode<LEGACY>(rows, tbase + off, hdr, slab, lane);
-      int32_t d0, d1;
-      deltas_to_docs(bp.d0, bp.d1, base, d0, d1);
-      base = readlane(d1, 63);
-      const int64_t o = out + 128 * (int64_t)(c0 + i) + 2 * lane;
-      docs_out[o] = d0;
-      docs_out[o + 1] = d1;
-      freqs_out[o] = (int32_t)bp.f0;
-      freqs_out[o + 1] = (int32_t)bp.f1;
-    }
-  }
+  stream_blocks<LEGACY, false>(tbase, seg.dir_off, seg.dir_hdr, T.dir_base, nullptr, b0, b1, slab, lane, base,
+                        [&](int blk, int32_t d0, int32_t d1, uint32_t f0, uint32_t f1, uint32_t, uint32_t) {
+                          const int64_t o = out + 128 * (int64_t)blk + 2 * lane;
+                          docs_out[o] = d0;
+                          docs_out[o + 1] = d1;
+                          freqs_out[o] = (int32_t)f0;
+                          freqs_out[o + 1] = (int32_t)f1;
+                        });
   if (b1 == T.nblocks) {
     if (T.df == 1) {
       if (lane == 0) { docs_out[out] = T.singleton_doc; freqs_out[out] = T.singleton_freq; }

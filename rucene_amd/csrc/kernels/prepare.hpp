@@ -56,13 +56,16 @@ __device__ __forceinline__ int vint_len_serial(const uint8_t* p) {
   return i + 1;
 }
 
+template <bool LEGACY>
 __global__ __launch_bounds__(PREP_THREADS) void k_prepare_terms(const uint8_t* __restrict__ doc, int64_t doc_len,
                                                                  const PrepTerm* __restrict__ terms, int32_t* dir_last,
-                                                                 uint32_t* dir_off, uint16_t* dir_hdr, int* err) {
+                                                                 uint32_t* dir_off, uint16_t* dir_hdr,
+                                                                 const uint8_t* __restrict__ norms, uint8_t* pnorm, int* err) {
   const PrepTerm t = terms[blockIdx.x];
   const int tid = (int)threadIdx.x;
   __shared__ uint32_t s_ws[PREP_THREADS / 64];
   __shared__ int64_t s_l0;
+  __shared__ __attribute__((aligned(16))) uint8_t slabs[PREP_THREADS / 64][SLAB_BYTES];
 
   if (t.n_entries > 0) {
     // ---- where does level 0 start? (skip_reader.rs:481-509)
@@ -153,6 +156,21 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_terms(const uint8_t* _
     if (i < t.n_entries && end != dir_off[t.dir_base + i + 1]) atomicMin(err, -4);
     if (i > 0 && i < t.n_entries && dir_last[t.dir_base + i] <= dir_last[t.dir_base + i - 1]) atomicMin(err, -4);
     dir_hdr[t.dir_base + i] = (uint16_t)((uint32_t)bd | ((uint32_t)vlen << 6) | ((uint32_t)bf << 9));
+  }
+  // ---- posting-order norms: decode every block once and gather its docs' norm bytes (SegView::pnorm)
+  if (norms != nullptr && *reinterpret_cast<volatile int*>(err) == 0) {
+    __syncthreads();
+    const int lane = lane_id();
+    const int wave = wave_id();
+    for (int blk = wave; blk < t.nblocks; blk += PREP_THREADS / 64) {
+      const int32_t base = blk == 0 ? 0 : dir_last[t.dir_base + blk - 1];
+      const BlockPair bp = decode_block<LEGACY>(doc + t.start_fp + dir_off[t.dir_base + blk], dir_hdr[t.dir_base + blk], slabs[wave], lane);
+      int32_t d0, d1;
+      deltas_to_docs(bp.d0, bp.d1, base, d0, d1);
+      // a corrupt block must not turn into a wild gather
+      const uint32_t n0 = d0 >= 0 ? norms[d0] : 0u, n1 = d1 >= 0 ? norms[d1] : 0u;
+      *reinterpret_cast<uint16_t*>(pnorm + t.pn_base + 128 * (uint64_t)blk + 2 * lane) = (uint16_t)(n0 | (n1 << 8));
+    }
   }
 }
 

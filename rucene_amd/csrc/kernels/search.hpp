@@ -111,47 +111,26 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_term(SegView seg, const D
   uint64_t tau = 0;
   int count = 0;
   shared.fold(seen, tau, floor);
-  // Scoring runs one block behind decoding: the norm (and live-docs) gathers of block i are issued right after
-  // its doc ids exist and consumed while block i+1 is being decoded, so no wave ever sits on its own gather.
-  // `full` (std::true_type) marks a FullBlock: every lane holds two real postings, no validity masks.
+  // Norms of FullBlock postings arrive in posting order with the payload rows (SegView::pnorm), so scoring a
+  // block needs no gather at all; only the VInt tail / singleton (< 128 postings per term) and the optional
+  // live-docs test still gather. `full` (std::true_type) marks a FullBlock: two real postings per lane.
   const bool has_live = seg.live != nullptr;
   const bool nonneg = T.weight >= 0.0f;  // idf * boost; negative only with a negative boost
-  struct Pending {
-    int32_t d0, d1;
-    uint32_t f0, f1, nb0, nb1;
-    uint64_t lw0, lw1;
-  };
-  auto issue = [&](auto full, int32_t d0, int32_t d1, uint32_t f0, uint32_t f1, bool v0, bool v1) {
-    constexpr bool FULL = decltype(full)::value;
-    Pending p;
-    p.d0 = d0; p.d1 = d1; p.f0 = f0; p.f1 = f1;
-    p.nb0 = p.nb1 = 0u;
-    p.lw0 = p.lw1 = ~0ull;
-    if (has_norms) {
-      if (FULL || v0) p.nb0 = seg.norms[d0];
-      if (FULL || v1) p.nb1 = seg.norms[d1];
-    }
-    if (has_live) {
-      if (FULL || v0) p.lw0 = seg.live[d0 >> 6];
-      if (FULL || v1) p.lw1 = seg.live[d1 >> 6];
-    }
-    return p;
-  };
-  auto finish = [&](auto full, const Pending& p, bool v0, bool v1) {
+  auto collect = [&](auto full, int32_t d0, int32_t d1, uint32_t f0, uint32_t f1, uint32_t nb0, uint32_t nb1, bool v0, bool v1) {
     constexpr bool FULL = decltype(full)::value;
     if (FULL) { v0 = true; v1 = true; }
     if (has_live) {
-      v0 = v0 && ((p.lw0 >> (p.d0 & 63)) & 1ull);
-      v1 = v1 && ((p.lw1 >> (p.d1 & 63)) & 1ull);
+      v0 = v0 && doc_is_live(seg.live, d0);
+      v1 = v1 && doc_is_live(seg.live, d1);
     }
     float s0, s1;
-    const uint32_t fmax = p.f0 > p.f1 ? p.f0 : p.f1, fmin = p.f0 < p.f1 ? p.f0 : p.f1;
-    if (tabled && !__ballot(fmax > (uint32_t)SCORE_TABLE_FREQS || fmin == 0u)) {
-      s0 = table_score(cache, p.nb0, p.f0);
-      s1 = table_score(cache, p.nb1, p.f1);
+    const uint32_t fmax = f0 > f1 ? f0 : f1, fmin = f0 < f1 ? f0 : f1;
+    if (tabled && !__ballot((v0 || v1) && (fmax > (uint32_t)SCORE_TABLE_FREQS || fmin == 0u))) {
+      s0 = table_score(cache, nb0, v0 ? f0 : 1u);
+      s1 = table_score(cache, nb1, v1 ? f1 : 1u);
     } else {
-      s0 = bm25_score(wk, (float)(int32_t)p.f0, has_norms ? cache[p.nb0] : k1);
-      s1 = bm25_score(wk, (float)(int32_t)p.f1, has_norms ? cache[p.nb1] : k1);
+      s0 = bm25_score(wk, (float)(int32_t)f0, has_norms ? cache[nb0] : k1);
+      s1 = bm25_score(wk, (float)(int32_t)f1, has_norms ? cache[nb1] : k1);
     }
     if (FULL && !has_live && nonneg) {
       // Common case, cheap entry test: scores of a non-negative weight are >= +0, so their raw IEEE bits
@@ -162,20 +141,13 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_term(SegView seg, const D
       const uint32_t thr = (thi & 0x80000000u) ? (thi & 0x7fffffffu) : 0u;
       const uint32_t r0 = __float_as_uint(s0), r1 = __float_as_uint(s1);
       if (__ballot((r0 > r1 ? r0 : r1) >= thr)) {
-        topk_offer<WIDE>(top, make_key(s0, p.d0), tau, k, lane, floor);
-        topk_offer<WIDE>(top, make_key(s1, p.d1), tau, k, lane, floor);
+        topk_offer<WIDE>(top, make_key(s0, d0), tau, k, lane, floor);
+        topk_offer<WIDE>(top, make_key(s1, d1), tau, k, lane, floor);
       }
       return;
     }
-    uint64_t key0 = make_key(s0, p.d0), key1 = make_key(s1, p.d1);
-    if (FULL && !has_live) {
-      count += 128;
-    } else {
-      count += __popcll(__ballot(v0)) + __popcll(__ballot(v1));
-      key0 = v0 ? key0 : 0ull;
-      key1 = v1 ? key1 : 0ull;
-    }
-    // one ballot covers both postings in the common case where neither can enter the current top-k
+    count += __popcll(__ballot(v0)) + __popcll(__ballot(v1));
+    const uint64_t key0 = v0 ? make_key(s0, d0) : 0ull, key1 = v1 ? make_key(s1, d1) : 0ull;
     if (__ballot((key0 > key1 ? key0 : key1) > tau)) {
       topk_offer<WIDE>(top, key0, tau, k, lane, floor);
       topk_offer<WIDE>(top, key1, tau, k, lane, floor);
@@ -186,45 +158,26 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_term(SegView seg, const D
   const int b1 = min(T.nblocks, b0 + blocks_per_item);
   int32_t base = b0 == 0 ? 0 : seg.dir_last[T.dir_base + b0 - 1];
   const uint8_t* tbase = seg.doc + T.start_fp;
-  Pending pend;
-  bool have = false;
-  for (int c0 = b0; c0 < b1; c0 += 64) {
-    const int nb = min(64, b1 - c0);
-    DirChunk dir;
-    dir.load(seg.dir_off, seg.dir_hdr, T.dir_base, c0, nb, lane);
-    uint32_t off_n = dir.off_at(0), hdr_n = dir.hdr_at(0);
-    uint4 rows_n = block_rows_load(tbase + off_n, hdr_n, lane);
-    for (int i = 0; i < nb; ++i) {
-      const uint32_t off = off_n, hdr = hdr_n;
-      const uint4 rows = rows_n;
-      if (i + 1 < nb) {  // next block's payload is in flight while this one is decoded
-        off_n = dir.off_at(i + 1);
-        hdr_n = dir.hdr_at(i + 1);
-        rows_n = block_rows_load(tbase + off_n, hdr_n, lane);
-      }
-      const BlockPair bp = block_rows_decode<LEGACY>(rows, tbase + off, hdr, slab, lane);
-      int32_t d0, d1;
-      deltas_to_docs(bp.d0, bp.d1, base, d0, d1);
-      base = readlane(d1, 63);
-      const Pending cur = issue(std::true_type{}, d0, d1, bp.f0, bp.f1, true, true);
-      if (have) finish(std::true_type{}, pend, true, true);
-      pend = cur;
-      have = true;
-    }
-  }
-  if (have) finish(std::true_type{}, pend, true, true);
+  auto on_block = [&](int, int32_t d0, int32_t d1, uint32_t f0, uint32_t f1, uint32_t nb0, uint32_t nb1) {
+    collect(std::true_type{}, d0, d1, f0, f1, nb0, nb1, true, true);
+  };
+  if (has_norms)
+    stream_blocks<LEGACY, true>(tbase, seg.dir_off, seg.dir_hdr, T.dir_base, seg.pnorm + T.pn_base, b0, b1, slab, lane, base, on_block);
+  else
+    stream_blocks<LEGACY, false>(tbase, seg.dir_off, seg.dir_hdr, T.dir_base, nullptr, b0, b1, slab, lane, base, on_block);
   if (b1 == T.nblocks) {
     if (T.df == 1) {
-      const Pending p = issue(std::false_type{}, T.singleton_doc, 0, (uint32_t)T.singleton_freq, 0u, lane == 0, false);
-      finish(std::false_type{}, p, lane == 0, false);
+      const bool v0 = lane == 0;
+      const uint32_t nb0 = (has_norms && v0) ? seg.norms[T.singleton_doc] : 0u;
+      collect(std::false_type{}, T.singleton_doc, 0, (uint32_t)T.singleton_freq, 1u, nb0, 0u, v0, false);
     } else if (T.tail_n > 0) {
       const uint32_t toff = T.nblocks ? seg.dir_off[T.dir_base + T.nblocks] : 0u;
       int32_t d0, d1;
       uint32_t f0, f1;
       decode_tail(seg.doc + T.start_fp + toff, T.tail_n, base, slab, lane, d0, d1, f0, f1);
       const bool v0 = 2 * lane < T.tail_n, v1 = 2 * lane + 1 < T.tail_n;
-      const Pending p = issue(std::false_type{}, d0, d1, f0, f1, v0, v1);
-      finish(std::false_type{}, p, v0, v1);
+      const uint32_t nb0 = (has_norms && v0) ? seg.norms[d0] : 0u, nb1 = (has_norms && v1) ? seg.norms[d1] : 0u;
+      collect(std::false_type{}, d0, d1, f0, f1, nb0, nb1, v0, v1);
     }
   }
   shared.publish<WIDE>(top, k, lane);

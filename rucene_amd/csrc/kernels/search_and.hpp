@@ -68,11 +68,11 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_and(SegView seg, const De
   SharedTau shared{tau_slots + q};
   shared.fold(shared.peek(), tau, floor);
 
-  auto intersect = [&](int32_t d0, int32_t d1, uint32_t f0, uint32_t f1, bool a0, bool a1) {
+  // nb0 / nb1: the candidates' norm bytes — from the lead's posting-order norms for FullBlocks, gathered for
+  // its tail; every other clause scores the same docs, so no clause ever gathers norms again
+  auto intersect = [&](int32_t d0, int32_t d1, uint32_t f0, uint32_t f1, uint32_t nb0, uint32_t nb1, bool a0, bool a1) {
     a0 = a0 && doc_is_live(seg.live, d0);
     a1 = a1 && doc_is_live(seg.live, d1);
-    const uint32_t nb0 = (has_norms && a0) ? seg.norms[d0] : 0u;
-    const uint32_t nb1 = (has_norms && a1) ? seg.norms[d1] : 0u;
     use_table(L.sim_table);
     float wk = L.weight * (k1 + 1.0f);
     float s0 = bm25_score(wk, (float)(int32_t)f0, has_norms ? cache[nb0] : k1);
@@ -148,21 +148,26 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_and(SegView seg, const De
   const int b1 = min(L.nblocks, b0 + blocks_per_item);
   int32_t base = b0 == 0 ? 0 : seg.dir_last[L.dir_base + b0 - 1];
   for (int blk = b0; blk < b1; ++blk) {
+    uint32_t nn = 0;
+    if (has_norms) nn = *reinterpret_cast<const uint16_t*>(seg.pnorm + L.pn_base + 128 * (size_t)blk + 2 * lane);
     const BlockPair bp = decode_block<LEGACY>(seg.doc + L.start_fp + seg.dir_off[L.dir_base + blk], seg.dir_hdr[L.dir_base + blk], slab, lane);
     int32_t d0, d1;
     deltas_to_docs(bp.d0, bp.d1, base, d0, d1);
     base = readlane(d1, 63);
-    intersect(d0, d1, bp.f0, bp.f1, true, true);
+    intersect(d0, d1, bp.f0, bp.f1, nn & 0xffu, nn >> 8, true, true);
   }
   if (b1 == L.nblocks) {
     if (L.df == 1) {
-      intersect(L.singleton_doc, L.singleton_doc, (uint32_t)L.singleton_freq, 0u, lane == 0, false);
+      const bool a0 = lane == 0;
+      intersect(L.singleton_doc, L.singleton_doc, (uint32_t)L.singleton_freq, 0u, (has_norms && a0) ? seg.norms[L.singleton_doc] : 0u, 0u,
+                a0, false);
     } else if (L.tail_n > 0) {
       const uint32_t toff = L.nblocks ? seg.dir_off[L.dir_base + L.nblocks] : 0u;
       int32_t d0, d1;
       uint32_t f0, f1;
       decode_tail(seg.doc + L.start_fp + toff, L.tail_n, base, slab, lane, d0, d1, f0, f1);
-      intersect(d0, d1, f0, f1, 2 * lane < L.tail_n, 2 * lane + 1 < L.tail_n);
+      const bool a0 = 2 * lane < L.tail_n, a1 = 2 * lane + 1 < L.tail_n;
+      intersect(d0, d1, f0, f1, (has_norms && a0) ? seg.norms[d0] : 0u, (has_norms && a1) ? seg.norms[d1] : 0u, a0, a1);
     }
   }
   shared.publish<WIDE>(top, k, lane);

@@ -45,72 +45,44 @@ __global__ __launch_bounds__(WG_THREADS) void k_score_terms(SegView seg, const D
   if (tabled) build_score_table(cache, wk, lane);
   ScoredPosting* run = out + out_prefix[t];
 
-  struct Pending { int32_t d0, d1; uint32_t f0, f1, nb0, nb1; int64_t slot; };
-  auto issue = [&](int32_t d0, int32_t d1, uint32_t f0, uint32_t f1, bool v0, bool v1, int64_t slot) {
-    Pending p{d0, d1, f0, f1, 0u, 0u, slot};
-    if (has_norms) {
-      if (v0) p.nb0 = seg.norms[d0];
-      if (v1) p.nb1 = seg.norms[d1];
-    }
-    return p;
-  };
-  auto finish = [&](const Pending& p, bool v0, bool v1) {
+  auto emit = [&](int32_t d0, int32_t d1, uint32_t f0, uint32_t f1, uint32_t nb0, uint32_t nb1, bool v0, bool v1, int64_t slot) {
     float s0, s1;
-    const uint32_t fmax = p.f0 > p.f1 ? p.f0 : p.f1, fmin = p.f0 < p.f1 ? p.f0 : p.f1;
+    const uint32_t fmax = f0 > f1 ? f0 : f1, fmin = f0 < f1 ? f0 : f1;
     if (tabled && !__ballot((v0 || v1) && (fmax > (uint32_t)SCORE_TABLE_FREQS || fmin == 0u))) {
-      s0 = table_score(cache, p.nb0, v0 ? p.f0 : 1u);
-      s1 = table_score(cache, p.nb1, v1 ? p.f1 : 1u);
+      s0 = table_score(cache, nb0, v0 ? f0 : 1u);
+      s1 = table_score(cache, nb1, v1 ? f1 : 1u);
     } else {
-      s0 = bm25_score(wk, (float)(int32_t)p.f0, has_norms ? cache[p.nb0] : k1);
-      s1 = bm25_score(wk, (float)(int32_t)p.f1, has_norms ? cache[p.nb1] : k1);
+      s0 = bm25_score(wk, (float)(int32_t)f0, has_norms ? cache[nb0] : k1);
+      s1 = bm25_score(wk, (float)(int32_t)f1, has_norms ? cache[nb1] : k1);
     }
-    if (v0) run[p.slot] = ScoredPosting{p.d0, s0};
-    if (v1) run[p.slot + 1] = ScoredPosting{p.d1, s1};
+    if (v0) run[slot] = ScoredPosting{d0, s0};
+    if (v1) run[slot + 1] = ScoredPosting{d1, s1};
   };
 
   const int b0 = chunk * blocks_per_item;
   const int b1 = min(T.nblocks, b0 + blocks_per_item);
   int32_t base = b0 == 0 ? 0 : seg.dir_last[T.dir_base + b0 - 1];
   const uint8_t* tbase = seg.doc + T.start_fp;
-  Pending pend{};
-  bool have = false;
-  for (int c0 = b0; c0 < b1; c0 += 64) {
-    const int nb = min(64, b1 - c0);
-    DirChunk dir;
-    dir.load(seg.dir_off, seg.dir_hdr, T.dir_base, c0, nb, lane);
-    uint32_t off_n = dir.off_at(0), hdr_n = dir.hdr_at(0);
-    uint4 rows_n = block_rows_load(tbase + off_n, hdr_n, lane);
-    for (int i = 0; i < nb; ++i) {
-      const uint32_t off = off_n, hdr = hdr_n;
-      const uint4 rows = rows_n;
-      if (i + 1 < nb) {
-        off_n = dir.off_at(i + 1);
-        hdr_n = dir.hdr_at(i + 1);
-        rows_n = block_rows_load(tbase + off_n, hdr_n, lane);
-      }
-      const BlockPair bp = block_rows_decode<LEGACY>(rows, tbase + off, hdr, slab, lane);
-      int32_t d0, d1;
-      deltas_to_docs(bp.d0, bp.d1, base, d0, d1);
-      base = readlane(d1, 63);
-      const Pending cur = issue(d0, d1, bp.f0, bp.f1, true, true, 128 * (int64_t)(c0 + i) + 2 * lane);
-      if (have) finish(pend, true, true);
-      pend = cur;
-      have = true;
-    }
-  }
-  if (have) finish(pend, true, true);
+  auto on_block = [&](int blk, int32_t d0, int32_t d1, uint32_t f0, uint32_t f1, uint32_t nb0, uint32_t nb1) {
+    emit(d0, d1, f0, f1, nb0, nb1, true, true, 128 * (int64_t)blk + 2 * lane);
+  };
+  if (has_norms)
+    stream_blocks<LEGACY, true>(tbase, seg.dir_off, seg.dir_hdr, T.dir_base, seg.pnorm + T.pn_base, b0, b1, slab, lane, base, on_block);
+  else
+    stream_blocks<LEGACY, false>(tbase, seg.dir_off, seg.dir_hdr, T.dir_base, nullptr, b0, b1, slab, lane, base, on_block);
   if (b1 == T.nblocks) {
     if (T.df == 1) {
-      const Pending p = issue(T.singleton_doc, 0, (uint32_t)T.singleton_freq, 0u, lane == 0, false, 0);
-      finish(p, lane == 0, false);
+      const bool v0 = lane == 0;
+      const uint32_t nb0 = (has_norms && v0) ? seg.norms[T.singleton_doc] : 0u;
+      emit(T.singleton_doc, 0, (uint32_t)T.singleton_freq, 1u, nb0, 0u, v0, false, 0);
     } else if (T.tail_n > 0) {
       const uint32_t toff = T.nblocks ? seg.dir_off[T.dir_base + T.nblocks] : 0u;
       int32_t d0, d1;
       uint32_t f0, f1;
       decode_tail(seg.doc + T.start_fp + toff, T.tail_n, base, slab, lane, d0, d1, f0, f1);
       const bool v0 = 2 * lane < T.tail_n, v1 = 2 * lane + 1 < T.tail_n;
-      const Pending p = issue(d0, d1, f0, f1, v0, v1, 128 * (int64_t)T.nblocks + 2 * lane);
-      finish(p, v0, v1);
+      const uint32_t nb0 = (has_norms && v0) ? seg.norms[d0] : 0u, nb1 = (has_norms && v1) ? seg.norms[d1] : 0u;
+      emit(d0, d1, f0, f1, nb0, nb1, v0, v1, 128 * (int64_t)T.nblocks + 2 * lane);
     }
   }
 }

@@ -17,6 +17,11 @@ struct SegView {
   // the norms holds each byte's RANK among the used values and rank_to_norm maps back, so a clause's whole
   // (norm, freq <= 10) score table fits in a wave's LDS slice. n_norm_ranks == 0 means raw norm bytes.
   const uint8_t* rank_to_norm;
+  // Posting-order norms: for every FullBlock posting of a prepared term, the norm byte (or rank) of its doc, laid
+  // out in posting order (built once per term by k_prepare_terms). Turns the per-posting norm gather — 128
+  // cache-line lookups per block, the measured bottleneck of the scoring kernels — into one coalesced 128-byte
+  // read per block. Null when the segment has no norms.
+  const uint8_t* pnorm;
   int32_t n_norm_ranks;
   int32_t max_doc;
   int32_t doc_base;
@@ -25,6 +30,7 @@ struct SegView {
 // One term as the kernels see it (built on the host from rgpu_term_state + the directory cache).
 struct DevTerm {
   uint64_t start_fp;      // doc_start_fp
+  uint64_t pn_base;       // first byte of this term's posting-order norms in SegView::pnorm
   uint32_t dir_base;      // first directory slot (nblocks + 1 slots)
   int32_t nblocks;        // full 128-posting blocks
   int32_t df;
@@ -38,6 +44,7 @@ struct DevTerm {
 // Work description of one term for the skip-decode ("prepare") kernel.
 struct PrepTerm {
   uint64_t start_fp;
+  uint64_t pn_base;    // where this term's posting-order norms go
   int64_t skip_fp;     // absolute, -1 when df <= 128
   uint32_t dir_base;
   int32_t nblocks;

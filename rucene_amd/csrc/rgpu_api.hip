@@ -109,7 +109,7 @@ struct rgpu_ctx {
   char name[128] = {0};
 };
 
-struct TermInfo { uint32_t dir_base; int32_t nblocks; int32_t df; };
+struct TermInfo { uint32_t dir_base; int32_t nblocks; int32_t df; uint64_t pn_base; };
 
 struct rgpu_segment {
   rgpu_ctx* ctx = nullptr;
@@ -124,6 +124,8 @@ struct rgpu_segment {
   DevVec<uint32_t> dir_off;
   DevVec<uint16_t> dir_hdr;
   size_t dir_used = 0;
+  DevVec<uint8_t> pnorm;  // posting-order norms of every prepared term's FullBlocks
+  size_t pnorm_used = 0;
   std::unordered_map<int64_t, TermInfo> prepared;
 };
 
@@ -188,6 +190,7 @@ static SegView seg_view(const rgpu_segment* s) {
   v.doc = s->d_doc;
   v.norms = s->d_norms;
   v.rank_to_norm = s->d_rank_to_norm;
+  v.pnorm = s->d_norms ? s->pnorm.p : nullptr;
   v.n_norm_ranks = s->n_norm_ranks;
   v.live = s->d_live;
   v.dir_last = s->dir_last.p;
@@ -225,6 +228,7 @@ static int32_t prepare_terms_locked(rgpu_segment* seg, const rgpu_term_state* co
   rgpu_ctx* c = seg->ctx;
   std::vector<PrepTerm> work;
   size_t need_slots = seg->dir_used;
+  size_t need_pn = seg->pnorm_used;
   std::vector<std::pair<int64_t, TermInfo>> added;
   std::unordered_map<int64_t, int> in_batch;
   for (size_t i = 0; i < n; ++i) {
@@ -248,15 +252,18 @@ static int32_t prepare_terms_locked(rgpu_segment* seg, const rgpu_term_state* co
     p.skip_fp = st.doc_freq > 128 ? st.doc_start_fp + st.skip_offset : -1;
     p.dir_base = (uint32_t)need_slots;
     p.pad = 0;
+    p.pn_base = (uint64_t)need_pn;
     need_slots += (size_t)p.nblocks + 1;
+    need_pn += (size_t)p.nblocks * 128;
     if (need_slots > 0xfffffff0ull) return fail(RGPU_ERR_UNSUPPORTED, "block directory exceeds 2^32 slots");
     work.push_back(p);
-    added.push_back({st.doc_start_fp, TermInfo{p.dir_base, p.nblocks, p.df}});
+    added.push_back({st.doc_start_fp, TermInfo{p.dir_base, p.nblocks, p.df, p.pn_base}});
   }
   if (work.empty()) return RGPU_OK;
   HIP_TRY(seg->dir_last.reserve(need_slots, seg->dir_used, c->stream));
   HIP_TRY(seg->dir_off.reserve(need_slots, seg->dir_used, c->stream));
   HIP_TRY(seg->dir_hdr.reserve(need_slots, seg->dir_used, c->stream));
+  if (seg->d_norms) HIP_TRY(seg->pnorm.reserve(need_pn + 64, seg->pnorm_used, c->stream));
   const size_t bytes = work.size() * sizeof(PrepTerm);
   HIP_TRY(c->h_stage.reserve(bytes));
   HIP_TRY(c->d_stage.reserve(bytes, 0, c->stream));
@@ -267,9 +274,14 @@ static int32_t prepare_terms_locked(rgpu_segment* seg, const rgpu_term_state* co
     int64_t postings = 0;
     for (auto& w : work) postings += w.df;
     TimedLaunch tl(c, c->stream, "k_prepare_terms", postings);
-    hipLaunchKernelGGL(k_prepare_terms, dim3((unsigned)work.size()), dim3(PREP_THREADS), 0, c->stream, seg->d_doc,
-                       (int64_t)seg->doc_len, reinterpret_cast<const PrepTerm*>(c->d_stage.p), seg->dir_last.p,
-                       seg->dir_off.p, seg->dir_hdr.p, c->d_err);
+    if (seg->version >= 1)
+      hipLaunchKernelGGL(k_prepare_terms<false>, dim3((unsigned)work.size()), dim3(PREP_THREADS), 0, c->stream, seg->d_doc,
+                         (int64_t)seg->doc_len, reinterpret_cast<const PrepTerm*>(c->d_stage.p), seg->dir_last.p,
+                         seg->dir_off.p, seg->dir_hdr.p, seg->d_norms, seg->pnorm.p, c->d_err);
+    else
+      hipLaunchKernelGGL(k_prepare_terms<true>, dim3((unsigned)work.size()), dim3(PREP_THREADS), 0, c->stream, seg->d_doc,
+                         (int64_t)seg->doc_len, reinterpret_cast<const PrepTerm*>(c->d_stage.p), seg->dir_last.p,
+                         seg->dir_off.p, seg->dir_hdr.p, seg->d_norms, seg->pnorm.p, c->d_err);
   }
   int err = 0;
   HIP_TRY(hipMemcpyAsync(&err, c->d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -280,6 +292,7 @@ static int32_t prepare_terms_locked(rgpu_segment* seg, const rgpu_term_state* co
                                                  : "corrupt skip data or block framing in .doc");
   }
   seg->dir_used = need_slots;
+  seg->pnorm_used = need_pn;
   for (auto& a : added) seg->prepared[a.first] = a.second;
   return RGPU_OK;
 }
@@ -300,6 +313,7 @@ static int32_t make_dev_term(const rgpu_segment* seg, const rgpu_term_state& st,
     if (it == seg->prepared.end()) return fail(RGPU_ERR_ILLEGAL_STATE, "term not prepared");
     t.dir_base = it->second.dir_base;
     t.nblocks = it->second.nblocks;
+    t.pn_base = it->second.pn_base;
   }
   t.tail_n = st.doc_freq > 1 ? st.doc_freq % 128 : 0;
   *out = t;
@@ -468,7 +482,7 @@ extern "C" void rgpu_segment_free(rgpu_segment* s) {
   if (s->d_norms) (void)hipFree(s->d_norms);
   if (s->d_rank_to_norm) (void)hipFree(s->d_rank_to_norm);
   if (s->d_live) (void)hipFree(s->d_live);
-  s->dir_last.release(); s->dir_off.release(); s->dir_hdr.release();
+  s->dir_last.release(); s->dir_off.release(); s->dir_hdr.release(); s->pnorm.release();
   delete s;
 }
 
