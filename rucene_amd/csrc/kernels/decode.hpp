@@ -193,10 +193,13 @@ __device__ __forceinline__ void deltas_to_docs(uint32_t d0, uint32_t d1, int32_t
 // (Little: 7 waves/SIMD x ~150 B / ~0.7 us ~ 1.5 TB/s chip-wide — what a depth-1 pipeline measured); four deep
 // covers the HBM/Infinity-Cache latency with the decode work of the blocks in between. `base` carries the
 // running doc id (last doc of the previous block) in and out.
-constexpr int PREFETCH_DEPTH = 4;
+#ifndef RGPU_PREFETCH_DEPTH
+#define RGPU_PREFETCH_DEPTH 4
+#endif
+constexpr int PREFETCH_DEPTH = RGPU_PREFETCH_DEPTH;  // default; the store-bound materialising decode runs shallower (see k_decode_terms)
 // HAS_PN: also stream the term's posting-order norms (2 bytes per lane per block, SegView::pnorm) through the
 // same ring; body(block_index, doc0, doc1, freq0, freq1, norm0, norm1) — norms are 0 without HAS_PN.
-template <bool LEGACY, bool HAS_PN, typename Body>
+template <bool LEGACY, bool HAS_PN, int DEPTH = PREFETCH_DEPTH, typename Body>
 __device__ __forceinline__ void stream_blocks(const uint8_t* __restrict__ tbase, const uint32_t* __restrict__ dir_off,
                                               const uint16_t* __restrict__ dir_hdr, uint32_t dir_base,
                                               const uint8_t* __restrict__ pn, int b0, int b1, uint8_t* slab, int lane,
@@ -219,28 +222,28 @@ __device__ __forceinline__ void stream_blocks(const uint8_t* __restrict__ tbase,
     // prefetch indices are clamped to the chunk's last block instead of being guarded: a redundant reload of
     // that block near the end is cheaper than a load behind a branch
     const int last = nb - 1;
-    uint4 ring[PREFETCH_DEPTH];
-    uint32_t nring[PREFETCH_DEPTH];
+    uint4 ring[DEPTH];
+    uint32_t nring[DEPTH];
 #pragma unroll
-    for (int j = 0; j < PREFETCH_DEPTH; ++j) {
+    for (int j = 0; j < DEPTH; ++j) {
       const int pj = min(j, last);
       ring[j] = block_rows_load(tbase + dir.off_at(pj), dir.hdr_at(pj), lane);
       nring[j] = norms_of(pj);
     }
     int i = 0;
-    for (; i + PREFETCH_DEPTH <= nb; i += PREFETCH_DEPTH) {
+    for (; i + DEPTH <= nb; i += DEPTH) {
 #pragma unroll
-      for (int j = 0; j < PREFETCH_DEPTH; ++j) {  // static ring slot j <-> block i + j
+      for (int j = 0; j < DEPTH; ++j) {  // static ring slot j <-> block i + j
         const uint4 rows = ring[j];
         const uint32_t nn = nring[j];
-        const int pj = min(i + j + PREFETCH_DEPTH, last);
+        const int pj = min(i + j + DEPTH, last);
         ring[j] = block_rows_load(tbase + dir.off_at(pj), dir.hdr_at(pj), lane);
         nring[j] = norms_of(pj);
         step(i + j, rows, nn);
       }
     }
 #pragma unroll
-    for (int j = 0; j < PREFETCH_DEPTH - 1; ++j)
+    for (int j = 0; j < DEPTH - 1; ++j)
       if (i + j < nb) step(i + j, ring[j], nring[j]);
   }
 }

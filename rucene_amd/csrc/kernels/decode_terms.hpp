@@ -8,6 +8,10 @@
 
 namespace rgpu {
 
+#ifndef RGPU_DECODE_DEPTH
+#define RGPU_DECODE_DEPTH 3
+#endif
+constexpr int DECODE_PREFETCH_DEPTH = RGPU_DECODE_DEPTH;
 constexpr int WG_THREADS = 256;
 constexpr int WG_WAVES = WG_THREADS / 64;
 
@@ -45,7 +49,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_decode_terms(SegView seg, const 
   const int b1 = min(T.nblocks, b0 + blocks_per_item);
   int32_t base = b0 == 0 ? 0 : seg.dir_last[T.dir_base + b0 - 1];
   const uint8_t* tbase = seg.doc + T.start_fp;
-  stream_blocks<LEGACY, false>(tbase, seg.dir_off, seg.dir_hdr, T.dir_base, nullptr, b0, b1, slab, lane, base,
+  stream_blocks<LEGACY, false, DECODE_PREFETCH_DEPTH>(tbase, seg.dir_off, seg.dir_hdr, T.dir_base, nullptr, b0, b1, slab, lane, base,
                         [&](int blk, int32_t d0, int32_t d1, uint32_t f0, uint32_t f1, uint32_t, uint32_t) {
                           const int64_t o = out + 128 * (int64_t)blk + 2 * lane;
                           docs_out[o] = d0;

@@ -103,8 +103,11 @@ __global__ __launch_bounds__(WG_THREADS) void k_or_windows(SegView seg, const De
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int lane = lane_id();
   const int wave = wave_id();
-  float* acc = reinterpret_cast<float*>(smem + (size_t)wave * (size_t)W * 5);
-  uint8_t* flag = reinterpret_cast<uint8_t*>(acc + W);
+  // per-wave LDS slice: acc[W] f32 | hits[W] u16 (window offsets of touched docs, in first-touch order) |
+  // gen[W] u8 (a doc's accumulator is live in this window iff gen[o] == the window's generation)
+  float* acc = reinterpret_cast<float*>(smem + (size_t)wave * (size_t)W * 7);
+  uint16_t* hits = reinterpret_cast<uint16_t*>(acc + W);
+  uint8_t* gen = reinterpret_cast<uint8_t*>(hits + W);
   const int64_t item = (int64_t)blockIdx.x * WG_WAVES + wave;
   if (item >= (int64_t)n_queries * items_per_query) return;
   const int q = (int)(item / items_per_query);
@@ -137,19 +140,29 @@ __global__ __launch_bounds__(WG_THREADS) void k_or_windows(SegView seg, const De
     }
     my_cur = lo;
   }
+  int32_t my_next = (mine && my_cur < my_len) ? runs[my_base + my_cur].doc : 0x7fffffff;  // doc under the cursor
 
+  for (int i = lane * 4; i < W; i += 256) *reinterpret_cast<uint32_t*>(gen + i) = 0u;
+  uint32_t generation = 0;
+  wave_sync();
   for (int win = win0; win < win1; ++win) {
     const int32_t w0 = win * W;
     const int32_t w1 = min(seg.max_doc, w0 + W);
-    for (int i = lane * 4; i < W; i += 256) {
-      *reinterpret_cast<float4*>(acc + i) = make_float4(0.f, 0.f, 0.f, 0.f);
-      *reinterpret_cast<uint32_t*>(flag + i) = 0u;
+    if (++generation == 256u) {  // 8-bit generations: recycle every 255 windows
+      for (int i = lane * 4; i < W; i += 256) *reinterpret_cast<uint32_t*>(gen + i) = 0u;
+      generation = 1;
+      wave_sync();
     }
-    wave_sync();
-    for (int t = 0; t < Q.n_terms; ++t) {  // clause order == summation order
+    int nhits = 0;
+    // only clauses with a posting inside this window are visited, in clause order == summation order
+    uint64_t active = __ballot(my_next < w1);
+    while (active) {
+      const int t = __builtin_ctzll(active);
+      active &= active - 1;
       const int64_t rb = ((int64_t)readlane((int)(uint32_t)(my_base >> 32), t) << 32) | (uint32_t)readlane((int)(uint32_t)my_base, t);
       const int len = readlane(my_len, t);
       int cur = readlane(my_cur, t);
+      int32_t next;
       while (true) {
         const int idx = cur + lane;
         ScoredPosting e{0x7fffffff, 0.f};
@@ -157,21 +170,29 @@ __global__ __launch_bounds__(WG_THREADS) void k_or_windows(SegView seg, const De
         bool in = e.doc < w1;
         const int n = __popcll(__ballot(in));  // runs are doc-sorted: the in-window entries are a prefix
         if (in && has_live) in = doc_is_live(seg.live, e.doc);
+        bool first = false;
         if (in) {
           const int o = e.doc - w0;
-          acc[o] += e.score;
-          flag[o] = 1;
+          first = gen[o] != (uint8_t)generation;
+          acc[o] = (first ? 0.0f : acc[o]) + e.score;  // 0.0f + s: the reference's `score = 0; score += s`
+          gen[o] = (uint8_t)generation;
         }
+        const uint64_t fm = __ballot(first);
+        if (first) hits[nhits + mbcnt(fm)] = (uint16_t)(e.doc - w0);
+        nhits += __popcll(fm);
         cur += n;
-        if (n < 64) break;
+        if (n < 64) { next = readlane(e.doc, n); break; }  // the entry now under the cursor (or "none")
       }
       my_cur = lane == t ? cur : my_cur;
+      my_next = lane == t ? next : my_next;
       wave_sync();
     }
-    for (int i = lane; i < W; i += 64) {
-      const bool hit = flag[i] != 0;
-      const uint64_t key = hit ? make_key(acc[i], w0 + i) : 0ull;
-      count += __popcll(__ballot(hit));
+    // every touched doc is one collected hit
+    count += nhits;
+    for (int i0 = 0; i0 < nhits; i0 += 64) {  // uniform trip count: the offer is a wave-wide operation
+      const bool valid = i0 + lane < nhits;
+      const int o = valid ? hits[i0 + lane] : 0;
+      const uint64_t key = valid ? make_key(acc[o], w0 + o) : 0ull;
       if (__ballot(key > tau)) topk_offer<WIDE>(top, key, tau, k, lane, floor);
     }
     wave_sync();

@@ -343,7 +343,7 @@ extern "C" int32_t rgpu_init(int32_t device_ordinal, const rgpu_config* cfg, rgp
   if (cfg) c->cfg = *cfg;
   c->cfg.abi_version = RGPU_ABI_VERSION;
   if (c->cfg.blocks_per_item <= 0) { c->cfg.blocks_per_item = 32; c->blocks_per_item_auto = true; }
-  if (c->cfg.reserved[0] <= 0) c->cfg.reserved[0] = 4;  // and_blocks_per_item
+  if (c->cfg.reserved[0] <= 0) c->cfg.reserved[0] = 2;  // and_blocks_per_item
   if (c->cfg.window_docs <= 0) c->cfg.window_docs = 4096;
   c->cfg.window_docs = std::min(24576, std::max(1024, (c->cfg.window_docs + 1023) / 1024 * 1024));
   std::snprintf(c->name, sizeof c->name, "%s (%s)", prop.name, prop.gcnArchName);
@@ -709,7 +709,7 @@ static int32_t search_or_group(rgpu_segment* seg, Group& G, int32_t k, HitOut* h
   }
   {
     TimedLaunch tl(c, stream, "k_or_windows", G.postings);
-    const size_t lds = (size_t)WG_WAVES * (size_t)W * 5;
+    const size_t lds = (size_t)WG_WAVES * (size_t)W * 7;
     const unsigned grid = (unsigned)((items2 + WG_WAVES - 1) / WG_WAVES);
     auto go = [&](auto kern) -> hipError_t {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
