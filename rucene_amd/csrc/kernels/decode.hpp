@@ -111,7 +111,9 @@ __device__ __forceinline__ uint4 block_rows_load(const uint8_t* __restrict__ blk
   const int doc_sz = bd ? 16 * bd : hdr_vlen(hdr);
   const int half = lane >> 5;
   const int row = lane & 31;
-  return load16_unaligned(blk + 1 + (half ? doc_sz + 1 : 0) + 16 * row);
+  // uniform base + one 32-bit lane offset: selects the SGPR-base addressing form (no 64-bit VALU adds)
+  const uint32_t voff = 1u + 16u * (uint32_t)row + __umul24((uint32_t)half, (uint32_t)doc_sz + 1u);
+  return load16_unaligned(blk + voff);
 }
 
 // VInt (data_input.rs:78-111) out of the first 8 bytes of a row held in registers
@@ -136,11 +138,10 @@ template <bool LEGACY>
 __device__ __forceinline__ BlockPair block_rows_decode(uint4 rows, uint32_t hdr, uint8_t* slab, int lane) {
   const int bd = hdr_bdoc(hdr);
   const int bf = hdr_bfreq(hdr);
-  {
-    const int half = lane >> 5;
-    const int row = lane & 31;
-    if (row < (half ? bf : bd)) *reinterpret_cast<uint4*>(slab + half * SLAB_STREAM + 16 * row) = rows;
-  }
+  // every lane stores its row: rows past a stream's payload hold over-read bytes that extraction never uses
+  // (a value's straddle word lies in the next row only when that row is still payload), and an unconditional
+  // 1 KB wave store costs less issue time than the per-lane `row < b` test
+  *reinterpret_cast<uint4*>(slab + (lane >> 5) * SLAB_STREAM + 16 * (lane & 31)) = rows;
   wave_sync();
   BlockPair out;
   if (bd) {
@@ -217,7 +218,8 @@ __device__ __forceinline__ void stream_blocks(const uint8_t* __restrict__ tbase,
     };
     auto norms_of = [&](int idx) -> uint32_t {
       if (!HAS_PN) return 0u;
-      return *reinterpret_cast<const uint16_t*>(pn + 128 * (size_t)(c0 + idx) + 2 * lane);
+      // uniform term base + one 32-bit offset (a term's posting-order norms span < 2^31 bytes)
+      return *reinterpret_cast<const uint16_t*>(pn + (128u * (uint32_t)(c0 + idx) + 2u * (uint32_t)lane));
     };
     // prefetch indices are clamped to the chunk's last block instead of being guarded: a redundant reload of
     // that block near the end is cheaper than a load behind a branch

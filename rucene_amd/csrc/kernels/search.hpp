@@ -44,21 +44,135 @@ __device__ __forceinline__ void load_sim_table(const SegView& seg, int id, float
   wave_sync();
 }
 
-// Per-clause score table over (norm rank, freq 1..SCORE_TABLE_FREQS): Rucene clamps term freqs to 10 at write
+// Per-clause score table over (norm rank, freq 0..SCORE_TABLE_FREQS): Rucene clamps term freqs to 10 at write
 // time (codec/postings/mod.rs:82), so for its own indexes every posting's BM25 score is one LDS read; each entry
-// is produced by the same f32 expression as bm25_score, i.e. bit-identical. Lives right after the 64 cache
-// entries of the wave's LDS slice; lane r fills row r.
+// is produced by the same f32 expression as bm25_score, i.e. bit-identical (the freq-0 column only exists so
+// that a block whose freq width is <= 3 bits needs no per-posting range test at all). Lives right after the
+// 64 cache entries of the wave's LDS slice; lane r fills row r.
 constexpr int SCORE_TABLE_FREQS = 10;
-constexpr int WAVE_CACHE_FLOATS = 64 + 64 * SCORE_TABLE_FREQS;  // >= 256 (raw-norm mode uses the first 256)
+constexpr int SCORE_TABLE_COLS = SCORE_TABLE_FREQS + 1;
+constexpr int WAVE_CACHE_FLOATS = 64 + 64 * SCORE_TABLE_COLS;  // >= 256 (raw-norm mode uses the first 256)
 __device__ __forceinline__ void build_score_table(float* cache, float wk, int lane) {
   const float nrm = cache[lane];
-  float* row = cache + 64 + lane * SCORE_TABLE_FREQS;
+  float* row = cache + 64 + lane * SCORE_TABLE_COLS;
 #pragma unroll
-  for (int f = 1; f <= SCORE_TABLE_FREQS; ++f) row[f - 1] = bm25_score(wk, (float)f, nrm);
+  for (int f = 0; f <= SCORE_TABLE_FREQS; ++f) row[f] = bm25_score(wk, (float)f, nrm);
   wave_sync();
 }
 __device__ __forceinline__ float table_score(const float* cache, uint32_t rank, uint32_t freq) {
-  return cache[64 + rank * SCORE_TABLE_FREQS + freq - 1];
+  return cache[64 + rank * SCORE_TABLE_COLS + freq];
+}
+
+// TermScorer fast path: FullBlocks of a term whose scores come from the LDS table (norm ranks, weight >= 0, no
+// deleted docs). The kernel is VALU-issue bound (rocprofv3: ~77 VALU/block at 86% VALU busy before this path
+// existed), so a block only does what its outcome can depend on: stage the rows, unpack the FREQ stream, two
+// table reads, one compare of the raw score bits against the threshold's. The doc-delta stream is unpacked
+// and prefix-summed only when some posting can still enter the top-k — its base doc then comes from the block
+// directory (dir_last), not from a running scan — which after the first few blocks of a query is rare.
+// Every posting is still counted (TopDocsCollector::total_hits) and every candidate offered, so results are
+// those of the plain loop.
+template <bool LEGACY, bool WIDE>
+__device__ __forceinline__ void term_blocks_fast(const SegView& seg, const DevTerm& T, int b0, int b1, uint8_t* slab,
+                                                 const float* cache, float wk, int lane, WaveTopK& top, uint64_t& tau,
+                                                 uint64_t floor, int k, int& count) {
+  constexpr int DEPTH = PREFETCH_DEPTH;
+  const uint8_t* tbase = seg.doc + T.start_fp;
+  const uint8_t* pn = seg.pnorm + T.pn_base;
+  // Entry test on raw score bits: a posting can enter iff its key exceeds tau = (S, D), i.e. score > S, or
+  // score == S and doc < D. Postings arrive in doc order, so once every remaining doc is known to lie above D
+  // (seen_doc >= D) a tie can no longer win and the test becomes strict — BM25 scores of one term take few
+  // distinct values (freq <= 10 x norm rank), so ties with the threshold are the common case, not the corner.
+  int32_t seen_doc = b0 == 0 ? -1 : seg.dir_last[T.dir_base + b0 - 1];  // every posting from b0 on has doc > seen_doc
+  auto thr_of = [&](uint64_t t) -> uint32_t {
+    const uint32_t thi = (uint32_t)(t >> 32);
+    if (!(thi & 0x80000000u)) return 0u;  // no threshold yet (or a negative one): everything is a candidate
+    const uint32_t bits = thi & 0x7fffffffu;
+    return key_doc(t) <= seen_doc ? bits + 1u : bits;
+  };
+  uint32_t thr = thr_of(tau);
+  const int half = lane >> 5;
+  const int row = lane & 31;
+  uint8_t* stage_at = slab + half * SLAB_STREAM + 16 * row;
+  const uint32_t* dwords = reinterpret_cast<const uint32_t*>(slab);
+  const uint32_t* fwords = reinterpret_cast<const uint32_t*>(slab + SLAB_STREAM);
+  for (int c0 = b0; c0 < b1; c0 += 64) {
+    const int nb = min(64, b1 - c0);
+    DirChunk dir;
+    dir.load(seg.dir_off, seg.dir_hdr, T.dir_base, c0, nb, lane);
+    auto step = [&](int idx, const uint4& rows, uint32_t nn) {
+      const uint32_t hdr = dir.hdr_at(idx);
+      const int bd = hdr_bdoc(hdr);
+      const int bf = hdr_bfreq(hdr);
+      *reinterpret_cast<uint4*>(stage_at) = rows;  // unconditional, see block_rows_decode
+      wave_sync();
+      uint32_t f0, f1;
+      bool in_table;  // wave-uniform
+      if (bf) {
+        if (LEGACY) extract_pair_legacy(fwords, bf, lane, f0, f1);
+        else extract_pair_bp128(fwords, bf, lane, f0, f1);
+        in_table = bf <= 3 || !__ballot((f0 > f1 ? f0 : f1) > (uint32_t)SCORE_TABLE_FREQS);
+      } else {
+        f0 = f1 = vint_from_words((uint32_t)readlane((int)rows.x, 32), (uint32_t)readlane((int)rows.y, 32));
+        in_table = (uint32_t)readfirstlane((int)f0) <= (uint32_t)SCORE_TABLE_FREQS;
+      }
+      const uint32_t nb0 = nn & 0xffu, nb1 = nn >> 8;
+      float s0, s1;
+      if (in_table) {
+        s0 = table_score(cache, nb0, f0);
+        s1 = table_score(cache, nb1, f1);
+      } else {
+        s0 = bm25_score(wk, (float)(int32_t)f0, cache[nb0]);
+        s1 = bm25_score(wk, (float)(int32_t)f1, cache[nb1]);
+      }
+      count += 128;
+      const uint32_t r0 = __float_as_uint(s0), r1 = __float_as_uint(s1);
+      if (__ballot((r0 > r1 ? r0 : r1) >= thr)) {
+        uint32_t e0, e1;
+        if (bd) {
+          if (LEGACY) extract_pair_legacy(dwords, bd, lane, e0, e1);
+          else extract_pair_bp128(dwords, bd, lane, e0, e1);
+        } else {
+          e0 = e1 = vint_from_words((uint32_t)readlane((int)rows.x, 0), (uint32_t)readlane((int)rows.y, 0));
+        }
+        const int blk = c0 + idx;
+        const int32_t base = blk == 0 ? 0 : seg.dir_last[T.dir_base + blk - 1];
+        int32_t d0, d1;
+        deltas_to_docs(e0, e1, base, d0, d1);
+        topk_offer<WIDE>(top, make_key(s0, d0), tau, k, lane, floor);
+        topk_offer<WIDE>(top, make_key(s1, d1), tau, k, lane, floor);
+        seen_doc = readlane(d1, 63);
+        thr = thr_of(tau);
+      }
+      wave_sync();  // slab is free for the next block
+    };
+    auto norms_of = [&](int idx) -> uint32_t {
+      return *reinterpret_cast<const uint16_t*>(pn + (128u * (uint32_t)(c0 + idx) + 2u * (uint32_t)lane));
+    };
+    const int last = nb - 1;
+    uint4 ring[DEPTH];
+    uint32_t nring[DEPTH];
+#pragma unroll
+    for (int j = 0; j < DEPTH; ++j) {
+      const int pj = min(j, last);
+      ring[j] = block_rows_load(tbase + dir.off_at(pj), dir.hdr_at(pj), lane);
+      nring[j] = norms_of(pj);
+    }
+    int i = 0;
+    for (; i + DEPTH <= nb; i += DEPTH) {
+#pragma unroll
+      for (int j = 0; j < DEPTH; ++j) {
+        const uint4 rows = ring[j];
+        const uint32_t nn = nring[j];
+        const int pj = min(i + j + DEPTH, last);
+        ring[j] = block_rows_load(tbase + dir.off_at(pj), dir.hdr_at(pj), lane);
+        nring[j] = norms_of(pj);
+        step(i + j, rows, nn);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < DEPTH - 1; ++j)
+      if (i + j < nb) step(i + j, ring[j], nring[j]);
+  }
 }
 
 // ---- single term: items = (query, chunk of `blocks_per_item` blocks); the last chunk also takes the tail -------
@@ -124,8 +238,8 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_term(SegView seg, const D
       v1 = v1 && doc_is_live(seg.live, d1);
     }
     float s0, s1;
-    const uint32_t fmax = f0 > f1 ? f0 : f1, fmin = f0 < f1 ? f0 : f1;
-    if (tabled && !__ballot((v0 || v1) && (fmax > (uint32_t)SCORE_TABLE_FREQS || fmin == 0u))) {
+    const uint32_t fmax = f0 > f1 ? f0 : f1;
+    if (tabled && !__ballot((v0 || v1) && fmax > (uint32_t)SCORE_TABLE_FREQS)) {
       s0 = table_score(cache, nb0, v0 ? f0 : 1u);
       s1 = table_score(cache, nb1, v1 ? f1 : 1u);
     } else {
@@ -161,10 +275,14 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_term(SegView seg, const D
   auto on_block = [&](int, int32_t d0, int32_t d1, uint32_t f0, uint32_t f1, uint32_t nb0, uint32_t nb1) {
     collect(std::true_type{}, d0, d1, f0, f1, nb0, nb1, true, true);
   };
-  if (has_norms)
+  if (tabled && !has_live && nonneg) {
+    term_blocks_fast<LEGACY, WIDE>(seg, T, b0, b1, slab, cache, wk, lane, top, tau, floor, k, count);
+    if (b1 > b0) base = seg.dir_last[T.dir_base + b1 - 1];
+  } else if (has_norms) {
     stream_blocks<LEGACY, true>(tbase, seg.dir_off, seg.dir_hdr, T.dir_base, seg.pnorm + T.pn_base, b0, b1, slab, lane, base, on_block);
-  else
+  } else {
     stream_blocks<LEGACY, false>(tbase, seg.dir_off, seg.dir_hdr, T.dir_base, nullptr, b0, b1, slab, lane, base, on_block);
+  }
   if (b1 == T.nblocks) {
     if (T.df == 1) {
       const bool v0 = lane == 0;

@@ -47,8 +47,8 @@ __global__ __launch_bounds__(WG_THREADS) void k_score_terms(SegView seg, const D
 
   auto emit = [&](int32_t d0, int32_t d1, uint32_t f0, uint32_t f1, uint32_t nb0, uint32_t nb1, bool v0, bool v1, int64_t slot) {
     float s0, s1;
-    const uint32_t fmax = f0 > f1 ? f0 : f1, fmin = f0 < f1 ? f0 : f1;
-    if (tabled && !__ballot((v0 || v1) && (fmax > (uint32_t)SCORE_TABLE_FREQS || fmin == 0u))) {
+    const uint32_t fmax = f0 > f1 ? f0 : f1;
+    if (tabled && !__ballot((v0 || v1) && fmax > (uint32_t)SCORE_TABLE_FREQS)) {
       s0 = table_score(cache, nb0, v0 ? f0 : 1u);
       s1 = table_score(cache, nb1, v1 ? f1 : 1u);
     } else {
