@@ -50,7 +50,8 @@ class _KernelStat(C.Structure):
 
 
 def lib_path():
-    return os.path.join(_HERE, _LIB_NAME)
+    # RUCENE_GPU_LIB: developer knob for A/B-ing kernel build variants (same C ABI, same exports)
+    return os.environ.get("RUCENE_GPU_LIB") or os.path.join(_HERE, _LIB_NAME)
 
 
 _lib = None

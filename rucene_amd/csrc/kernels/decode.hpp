@@ -9,8 +9,12 @@
 // Lane mapping: lane t owns postings 2t and 2t+1 of the block. In the BP128 layout value i = 4r + l lives at
 // bits [r*b, (r+1)*b) of stream l, stream word w at dword 4w + l, so postings (2t, 2t+1) share row r = t/2 and
 // sit in adjacent streams l = 2(t&1), l+1: one ds_read_b64 fetches both low words, one more the straddle words.
-// Payload rows (16 B each) are pulled from HBM with one unaligned global_load_dwordx4 per row — lanes 0..31
-// take doc rows, lanes 32..63 freq rows — and staged in a wave-private LDS slab.
+// Payload rows (16 B each) come from the block store (SegView::bstore, 16-byte aligned copies made once per term by
+// k_prepare_terms): one aligned global_load_dwordx4 per lane — lanes 0..31 take the doc stream, lanes 32..63 the
+// freq stream — staged in a wave-private LDS slab. In the file itself a stream starts right after a 1-byte header,
+// and byte-misaligned dwordx4 loads run at 1/3 of the aligned rate on gfx950 (scripts/microbench/unaligned_rows.hip:
+// 34.6 vs 11.5 ns per block per CU), which bounded every scoring kernel; shifting the bytes into place in
+// registers (v_alignbyte) or through misaligned LDS reads was measured too and costs more than it saves.
 #pragma once
 #include "wave.hpp"
 
@@ -51,15 +55,20 @@ __device__ __forceinline__ uint32_t read_vint_uniform(const uint8_t* p, int* len
   return v;
 }
 
+// staged streams are dword streams (16-byte aligned in the slab)
+__device__ __forceinline__ uint32_t lds_u32(const uint8_t* p) { return *reinterpret_cast<const uint32_t*>(p); }
+__device__ __forceinline__ uint2 lds_u2(const uint8_t* p) { return *reinterpret_cast<const uint2*>(p); }
+
 // ---- BP128 (version 1) ----------------------------------------------------------------------------------------
-__device__ __forceinline__ void extract_pair_bp128(const uint32_t* stream_words, int b, int lane, uint32_t& v0, uint32_t& v1) {
+__device__ __forceinline__ void extract_pair_bp128(const uint8_t* stream, int b, int lane, uint32_t& v0, uint32_t& v1) {
   const int r = lane >> 1;
   const int l = (lane & 1) << 1;
   const int p = r * b;
   const int w = p >> 5;
   const int s = p & 31;
-  const uint2 lo = *reinterpret_cast<const uint2*>(stream_words + 4 * w + l);
-  const uint2 hi = *reinterpret_cast<const uint2*>(stream_words + 4 * w + 4 + l);
+  const uint8_t* at = stream + 4 * l + 16 * w;  // one address: the pair of reads becomes one ds_read2_b64
+  const uint2 lo = lds_u2(at);
+  const uint2 hi = lds_u2(at + 16);
   const uint32_t mask = b >= 32 ? 0xffffffffu : ((1u << b) - 1u);
   v0 = (uint32_t)((((uint64_t)hi.x << 32) | lo.x) >> s) & mask;
   v1 = (uint32_t)((((uint64_t)hi.y << 32) | lo.y) >> s) & mask;
@@ -69,31 +78,36 @@ __device__ __forceinline__ void extract_pair_bp128(const uint32_t* stream_words,
 // Packed: value i at bits [i*b, (i+1)*b) of one MSB-first big-endian stream; PackedSingleBlock (b in 1,2,4):
 // big-endian u64 blocks holding 64/b values each, value j of a block at bits [j*b, (j+1)*b) from the LSB.
 __device__ __forceinline__ uint32_t bswap32(uint32_t x) { return __builtin_bswap32(x); }
-__device__ __forceinline__ uint32_t extract_packed_be(const uint32_t* stream_words, int b, int i) {
+__device__ __forceinline__ uint32_t extract_packed_be(const uint8_t* stream, int b, int i) {
   const int p = i * b;
   const int w = p >> 5;
   const int s = p & 31;
-  const uint64_t hi = bswap32(stream_words[w]);
-  const uint64_t lo = bswap32(stream_words[w + 1]);
+  const uint64_t hi = bswap32(lds_u32(stream + 4 * w));
+  const uint64_t lo = bswap32(lds_u32(stream + 4 * w + 4));
   const uint64_t win = (hi << 32) | lo;  // bits p.. start at the top
   const uint32_t mask = b >= 32 ? 0xffffffffu : ((1u << b) - 1u);
   return (uint32_t)(win >> (64 - s - b)) & mask;
 }
-__device__ __forceinline__ uint32_t extract_psb(const uint32_t* stream_words, int b, int i) {
+__device__ __forceinline__ uint32_t extract_psb(const uint8_t* stream, int b, int i) {
   const int per = 64 / b;
   const int blk = i / per;
   const int j = i - blk * per;
-  const uint64_t w = ((uint64_t)bswap32(stream_words[2 * blk]) << 32) | bswap32(stream_words[2 * blk + 1]);
+  const uint64_t w = ((uint64_t)bswap32(lds_u32(stream + 8 * blk)) << 32) | bswap32(lds_u32(stream + 8 * blk + 4));
   return (uint32_t)(w >> (j * b)) & ((1u << b) - 1u);
 }
-__device__ __forceinline__ void extract_pair_legacy(const uint32_t* stream_words, int b, int lane, uint32_t& v0, uint32_t& v1) {
+__device__ __forceinline__ void extract_pair_legacy(const uint8_t* stream, int b, int lane, uint32_t& v0, uint32_t& v1) {
   if (b == 1 || b == 2 || b == 4) {  // FormatAndBits::fastest with COMPACT (packed_misc.rs:474-531)
-    v0 = extract_psb(stream_words, b, 2 * lane);
-    v1 = extract_psb(stream_words, b, 2 * lane + 1);
+    v0 = extract_psb(stream, b, 2 * lane);
+    v1 = extract_psb(stream, b, 2 * lane + 1);
   } else {
-    v0 = extract_packed_be(stream_words, b, 2 * lane);
-    v1 = extract_packed_be(stream_words, b, 2 * lane + 1);
+    v0 = extract_packed_be(stream, b, 2 * lane);
+    v1 = extract_packed_be(stream, b, 2 * lane + 1);
   }
+}
+template <bool LEGACY>
+__device__ __forceinline__ void extract_pair(const uint8_t* stream, int b, int lane, uint32_t& v0, uint32_t& v1) {
+  if (LEGACY) extract_pair_legacy(stream, b, lane, v0, v1);
+  else extract_pair_bp128(stream, b, lane, v0, v1);
 }
 
 struct BlockPair {
@@ -101,22 +115,17 @@ struct BlockPair {
   uint32_t f0, f1;  // freqs
 };
 
-// Phase 1 of a FullBlock decode: issue this lane's 16-byte payload row load (lanes 0..31 -> doc rows, lanes
-// 32..63 -> freq rows). Split from phase 2 so callers can issue later blocks' loads before decoding block i.
-// The load is unconditional (every lane reads 16 bytes at its row position, rows past the payload read the
-// bytes that follow — the file is padded) so that it never sits behind a branch: the waitcnt pass can then keep
-// several blocks in flight. Row 0 of an all-equal stream (b == 0) holds the stream's VInt.
-__device__ __forceinline__ uint4 block_rows_load(const uint8_t* __restrict__ blk, uint32_t hdr, int lane) {
+// ---- the .doc file's own framing (prepare time only) ------------------------------------------------------------
+// [hdr byte][doc payload 16*b | vint][hdr byte][freq payload 16*b | vint]; this lane's 16-byte row of its stream,
+// fetched byte-exact (the slow TA path — once per block per term lifetime). Row 0 of an all-equal stream (b == 0)
+// starts with the stream's VInt.
+__device__ __forceinline__ uint4 file_rows_load(const uint8_t* __restrict__ blk, uint32_t hdr, int lane) {
   const int bd = hdr_bdoc(hdr);
   const int doc_sz = bd ? 16 * bd : hdr_vlen(hdr);
-  const int half = lane >> 5;
-  const int row = lane & 31;
-  // uniform base + one 32-bit lane offset: selects the SGPR-base addressing form (no 64-bit VALU adds)
-  const uint32_t voff = 1u + 16u * (uint32_t)row + __umul24((uint32_t)half, (uint32_t)doc_sz + 1u);
+  const uint32_t voff = 1u + 16u * (uint32_t)(lane & 31) + __umul24((uint32_t)(lane >> 5), (uint32_t)doc_sz + 1u);
   return load16_unaligned(blk + voff);
 }
-
-// VInt (data_input.rs:78-111) out of the first 8 bytes of a row held in registers
+// VInt (data_input.rs:78-111) out of two dwords holding its first 8 bytes
 __device__ __forceinline__ uint32_t vint_from_words(uint32_t w0, uint32_t w1) {
   uint32_t v = w0 & 0x7fu;
   if (w0 & 0x80u) {
@@ -131,53 +140,78 @@ __device__ __forceinline__ uint32_t vint_from_words(uint32_t w0, uint32_t w1) {
   }
   return v;
 }
+// file rows -> block-store rows: the VInt of an all-equal stream becomes its plain u32 value (for_util.rs:203-207)
+__device__ __forceinline__ uint4 store_rows_from_file(uint4 rows, uint32_t hdr, int lane) {
+  const int b = (lane >> 5) ? hdr_bfreq(hdr) : hdr_bdoc(hdr);
+  if (b == 0) rows = make_uint4(vint_from_words(rows.x, rows.y), 0u, 0u, 0u);
+  return rows;
+}
+__device__ __host__ __forceinline__ int store_doc_rows(uint32_t hdr) { return hdr_bdoc(hdr) ? hdr_bdoc(hdr) : 1; }
+__device__ __host__ __forceinline__ int store_freq_rows(uint32_t hdr) { return hdr_bfreq(hdr) ? hdr_bfreq(hdr) : 1; }
+
+// ---- the block store (query time) -------------------------------------------------------------------------------
+// Phase 1 of a FullBlock decode: issue this lane's aligned 16-byte row load (lanes 0..31 -> doc rows, lanes 32..63
+// -> freq rows) of the block whose rows start at `rows0`. Split from phase 2 so callers can issue later blocks'
+// loads before decoding block i. The load is unconditional (rows past a stream read what follows — the store is
+// padded) so that it never sits behind a branch: the waitcnt pass can then keep several blocks in flight.
+// Address = uniform base + one 32-bit lane offset (SGPR-base form).
+__device__ __forceinline__ uint4 block_rows_load(const uint8_t* __restrict__ rows0, uint32_t hdr, int lane) {
+  const uint32_t voff = 16u * ((uint32_t)(lane & 31) + __umul24((uint32_t)(lane >> 5), (uint32_t)store_doc_rows(hdr)));
+  return *reinterpret_cast<const uint4*>(rows0 + voff);
+}
+__device__ __forceinline__ const uint8_t* block_rows_at(const uint8_t* __restrict__ term_rows, uint32_t row) {
+  return term_rows + 16 * (size_t)row;
+}
+
+// Staging: every lane stores its row — rows past a stream's payload hold over-read bytes that extraction never
+// uses (a value's straddle word lies in the next row only when that row is still payload), and an unconditional
+// 1 KB wave store costs less issue time than a per-lane `row < b` test.
+__device__ __forceinline__ void stage_rows(const uint4& rows, uint8_t* slab, int lane) {
+  *reinterpret_cast<uint4*>(slab + (lane >> 5) * SLAB_STREAM + 16 * (lane & 31)) = rows;
+}
+template <bool LEGACY>
+__device__ __forceinline__ void staged_doc_deltas(const uint8_t* slab, const uint4& rows, uint32_t hdr, int lane, uint32_t& d0, uint32_t& d1) {
+  const int bd = hdr_bdoc(hdr);
+  if (bd) extract_pair<LEGACY>(slab, bd, lane, d0, d1);
+  else d0 = d1 = (uint32_t)readlane((int)rows.x, 0);
+}
+template <bool LEGACY>
+__device__ __forceinline__ void staged_freqs(const uint8_t* slab, const uint4& rows, uint32_t hdr, int lane, uint32_t& f0, uint32_t& f1) {
+  const int bf = hdr_bfreq(hdr);
+  if (bf) extract_pair<LEGACY>(slab + SLAB_STREAM, bf, lane, f0, f1);
+  else f0 = f1 = (uint32_t)readlane((int)rows.x, 32);
+}
 
 // Phase 2: stage the rows in the wave's LDS slab and extract postings 2*lane, 2*lane+1. `hdr` from the block
 // directory. Wave-uniform control flow, no global loads.
 template <bool LEGACY>
-__device__ __forceinline__ BlockPair block_rows_decode(uint4 rows, uint32_t hdr, uint8_t* slab, int lane) {
-  const int bd = hdr_bdoc(hdr);
-  const int bf = hdr_bfreq(hdr);
-  // every lane stores its row: rows past a stream's payload hold over-read bytes that extraction never uses
-  // (a value's straddle word lies in the next row only when that row is still payload), and an unconditional
-  // 1 KB wave store costs less issue time than the per-lane `row < b` test
-  *reinterpret_cast<uint4*>(slab + (lane >> 5) * SLAB_STREAM + 16 * (lane & 31)) = rows;
+__device__ __forceinline__ BlockPair block_rows_decode(const uint4& rows, uint32_t hdr, uint8_t* slab, int lane) {
+  stage_rows(rows, slab, lane);
   wave_sync();
   BlockPair out;
-  if (bd) {
-    const uint32_t* words = reinterpret_cast<const uint32_t*>(slab);
-    if (LEGACY) extract_pair_legacy(words, bd, lane, out.d0, out.d1);
-    else extract_pair_bp128(words, bd, lane, out.d0, out.d1);
-  } else {
-    out.d0 = out.d1 = vint_from_words((uint32_t)readlane((int)rows.x, 0), (uint32_t)readlane((int)rows.y, 0));
-  }
-  if (bf) {
-    const uint32_t* words = reinterpret_cast<const uint32_t*>(slab + SLAB_STREAM);
-    if (LEGACY) extract_pair_legacy(words, bf, lane, out.f0, out.f1);
-    else extract_pair_bp128(words, bf, lane, out.f0, out.f1);
-  } else {
-    out.f0 = out.f1 = vint_from_words((uint32_t)readlane((int)rows.x, 32), (uint32_t)readlane((int)rows.y, 32));
-  }
+  staged_doc_deltas<LEGACY>(slab, rows, hdr, lane, out.d0, out.d1);
+  staged_freqs<LEGACY>(slab, rows, hdr, lane, out.f0, out.f1);
   wave_sync();  // slab is free for the next block
   return out;
 }
 
+// one block of a term: `term_rows` = SegView::bstore + DevTerm::bs_base, `row` = SegView::dir_row of the block
 template <bool LEGACY>
-__device__ __forceinline__ BlockPair decode_block(const uint8_t* __restrict__ blk, uint32_t hdr, uint8_t* slab, int lane) {
-  return block_rows_decode<LEGACY>(block_rows_load(blk, hdr, lane), hdr, slab, lane);
+__device__ __forceinline__ BlockPair decode_block(const uint8_t* __restrict__ term_rows, uint32_t row, uint32_t hdr, uint8_t* slab, int lane) {
+  return block_rows_decode<LEGACY>(block_rows_load(block_rows_at(term_rows, row), hdr, lane), hdr, slab, lane);
 }
 
 // A wave's view of up to 64 consecutive directory entries (one coalesced load), read back with readlane so
 // the per-block loop carries no dependent directory loads.
 struct DirChunk {
-  uint32_t off, hdr;
-  __device__ __forceinline__ void load(const uint32_t* __restrict__ dir_off, const uint16_t* __restrict__ dir_hdr, uint32_t base, int first,
+  uint32_t row, hdr;
+  __device__ __forceinline__ void load(const uint32_t* __restrict__ dir_row, const uint16_t* __restrict__ dir_hdr, uint32_t base, int first,
                                        int count, int lane) {
     const bool ok = lane < count;
-    off = ok ? dir_off[base + first + lane] : 0u;
+    row = ok ? dir_row[base + first + lane] : 0u;
     hdr = ok ? (uint32_t)dir_hdr[base + first + lane] : 0u;
   }
-  __device__ __forceinline__ uint32_t off_at(int i) const { return (uint32_t)readlane((int)off, i); }
+  __device__ __forceinline__ uint32_t row_at(int i) const { return (uint32_t)readlane((int)row, i); }
   __device__ __forceinline__ uint32_t hdr_at(int i) const { return (uint32_t)readlane((int)hdr, i); }
 };
 
@@ -201,14 +235,14 @@ constexpr int PREFETCH_DEPTH = RGPU_PREFETCH_DEPTH;  // default; the store-bound
 // HAS_PN: also stream the term's posting-order norms (2 bytes per lane per block, SegView::pnorm) through the
 // same ring; body(block_index, doc0, doc1, freq0, freq1, norm0, norm1) — norms are 0 without HAS_PN.
 template <bool LEGACY, bool HAS_PN, int DEPTH = PREFETCH_DEPTH, typename Body>
-__device__ __forceinline__ void stream_blocks(const uint8_t* __restrict__ tbase, const uint32_t* __restrict__ dir_off,
+__device__ __forceinline__ void stream_blocks(const uint8_t* __restrict__ term_rows, const uint32_t* __restrict__ dir_row,
                                               const uint16_t* __restrict__ dir_hdr, uint32_t dir_base,
                                               const uint8_t* __restrict__ pn, int b0, int b1, uint8_t* slab, int lane,
                                               int32_t& base, Body body) {
   for (int c0 = b0; c0 < b1; c0 += 64) {
     const int nb = min(64, b1 - c0);
     DirChunk dir;
-    dir.load(dir_off, dir_hdr, dir_base, c0, nb, lane);
+    dir.load(dir_row, dir_hdr, dir_base, c0, nb, lane);
     auto step = [&](int idx, const uint4& rows, uint32_t nn) {
       const BlockPair bp = block_rows_decode<LEGACY>(rows, dir.hdr_at(idx), slab, lane);
       int32_t d0, d1;
@@ -229,7 +263,7 @@ __device__ __forceinline__ void stream_blocks(const uint8_t* __restrict__ tbase,
 #pragma unroll
     for (int j = 0; j < DEPTH; ++j) {
       const int pj = min(j, last);
-      ring[j] = block_rows_load(tbase + dir.off_at(pj), dir.hdr_at(pj), lane);
+      ring[j] = block_rows_load(block_rows_at(term_rows, dir.row_at(pj)), dir.hdr_at(pj), lane);
       nring[j] = norms_of(pj);
     }
     int i = 0;
@@ -239,7 +273,7 @@ __device__ __forceinline__ void stream_blocks(const uint8_t* __restrict__ tbase,
         const uint4 rows = ring[j];
         const uint32_t nn = nring[j];
         const int pj = min(i + j + DEPTH, last);
-        ring[j] = block_rows_load(tbase + dir.off_at(pj), dir.hdr_at(pj), lane);
+        ring[j] = block_rows_load(block_rows_at(term_rows, dir.row_at(pj)), dir.hdr_at(pj), lane);
         nring[j] = norms_of(pj);
         step(i + j, rows, nn);
       }

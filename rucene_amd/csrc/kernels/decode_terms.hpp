@@ -48,8 +48,8 @@ __global__ __launch_bounds__(WG_THREADS) void k_decode_terms(SegView seg, const 
   const int b0 = chunk * blocks_per_item;
   const int b1 = min(T.nblocks, b0 + blocks_per_item);
   int32_t base = b0 == 0 ? 0 : seg.dir_last[T.dir_base + b0 - 1];
-  const uint8_t* tbase = seg.doc + T.start_fp;
-  stream_blocks<LEGACY, false, DECODE_PREFETCH_DEPTH>(tbase, seg.dir_off, seg.dir_hdr, T.dir_base, nullptr, b0, b1, slab, lane, base,
+  const uint8_t* term_rows = seg.bstore + T.bs_base;
+  stream_blocks<LEGACY, false, DECODE_PREFETCH_DEPTH>(term_rows, seg.dir_row, seg.dir_hdr, T.dir_base, nullptr, b0, b1, slab, lane, base,
                         [&](int blk, int32_t d0, int32_t d1, uint32_t f0, uint32_t f1, uint32_t, uint32_t) {
                           const int64_t o = out + 128 * (int64_t)blk + 2 * lane;
                           docs_out[o] = d0;
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_advance(SegView seg, DevTerm T, 
       int n;
       if (blk < T.nblocks) {
         const int32_t base = blk == 0 ? 0 : seg.dir_last[T.dir_base + blk - 1];
-        const BlockPair bp = decode_block<LEGACY>(seg.doc + T.start_fp + seg.dir_off[T.dir_base + blk],
+        const BlockPair bp = decode_block<LEGACY>(seg.bstore + T.bs_base, seg.dir_row[T.dir_base + blk],
                                                    seg.dir_hdr[T.dir_base + blk], slab, lane);
         deltas_to_docs(bp.d0, bp.d1, base, d0, d1);
         f0 = bp.f0; f1 = bp.f1; n = 128;

@@ -1,5 +1,6 @@
 // Skip-list decode on the GPU: one workgroup per term turns the term's level-0 skip entries into a flat block
-// directory {last doc id, byte offset, header word} in HBM. GPU counterpart of (paths relative to
+// directory {last doc id, byte offset, header word, store row} in HBM, copies the term's FullBlock payloads into
+// the 16-byte aligned block store and lays the docs' norms out in posting order. GPU counterpart of (paths relative to
 // /root/reference/src/core):
 //   codec/postings/skip_reader.rs:460-511   load_skip_levels  (vlong length + bytes for levels L-1..1, then level 0)
 //   codec/postings/skip_reader.rs:431-453   read_skip_data    (vint docDelta, vlong docFpDelta per entry)
@@ -59,8 +60,9 @@ __device__ __forceinline__ int vint_len_serial(const uint8_t* p) {
 template <bool LEGACY>
 __global__ __launch_bounds__(PREP_THREADS) void k_prepare_terms(const uint8_t* __restrict__ doc, int64_t doc_len,
                                                                  const PrepTerm* __restrict__ terms, int32_t* dir_last,
-                                                                 uint32_t* dir_off, uint16_t* dir_hdr,
-                                                                 const uint8_t* __restrict__ norms, uint8_t* pnorm, int* err) {
+                                                                 uint32_t* dir_off, uint32_t* dir_row, uint16_t* dir_hdr,
+                                                                 uint8_t* bstore, const uint8_t* __restrict__ norms,
+                                                                 uint8_t* pnorm, int* err) {
   const PrepTerm t = terms[blockIdx.x];
   const int tid = (int)threadIdx.x;
   __shared__ uint32_t s_ws[PREP_THREADS / 64];
@@ -157,19 +159,48 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_terms(const uint8_t* _
     if (i > 0 && i < t.n_entries && dir_last[t.dir_base + i] <= dir_last[t.dir_base + i - 1]) atomicMin(err, -4);
     dir_hdr[t.dir_base + i] = (uint16_t)((uint32_t)bd | ((uint32_t)vlen << 6) | ((uint32_t)bf << 9));
   }
-  // ---- posting-order norms: decode every block once and gather its docs' norm bytes (SegView::pnorm)
-  if (norms != nullptr && *reinterpret_cast<volatile int*>(err) == 0) {
-    __syncthreads();
+  __syncthreads();
+  // ---- block store rows: block i takes max(b_doc,1) + max(b_freq,1) rows; exclusive prefix sum over the blocks
+  uint32_t carry_rows = 0;
+  for (int i0 = 0; i0 < t.nblocks; i0 += PREP_THREADS) {
+    const int i = i0 + tid;
+    const bool ok = i < t.nblocks;
+    const uint32_t h = ok ? (uint32_t)dir_hdr[t.dir_base + i] : 0u;
+    const uint32_t r = ok ? (uint32_t)(store_doc_rows(h) + store_freq_rows(h)) : 0u;
+    uint32_t tot;
+    const uint32_t at = block_excl_scan(r, s_ws, tot) + carry_rows;
+    if (ok) dir_row[t.dir_base + i] = at;
+    carry_rows += tot;
+  }
+  if (tid == 0) dir_row[t.dir_base + t.nblocks] = carry_rows;
+  if (carry_rows > t.bs_rows) {  // more rows than the framing the host sized the store from: corrupt
+    if (tid == 0) atomicMin(err, -4);
+    return;
+  }
+  __syncthreads();
+  // ---- one pass over the blocks (one wavefront per block): copy the payload rows into the block store, then —
+  // with norms — decode the block from those rows and gather its docs' norm bytes in posting order (SegView::pnorm)
+  if (*reinterpret_cast<volatile int*>(err) == 0) {
     const int lane = lane_id();
     const int wave = wave_id();
+    uint8_t* term_rows = bstore + t.bs_base;
     for (int blk = wave; blk < t.nblocks; blk += PREP_THREADS / 64) {
-      const int32_t base = blk == 0 ? 0 : dir_last[t.dir_base + blk - 1];
-      const BlockPair bp = decode_block<LEGACY>(doc + t.start_fp + dir_off[t.dir_base + blk], dir_hdr[t.dir_base + blk], slabs[wave], lane);
-      int32_t d0, d1;
-      deltas_to_docs(bp.d0, bp.d1, base, d0, d1);
-      // a corrupt block must not turn into a wild gather
-      const uint32_t n0 = d0 >= 0 ? norms[d0] : 0u, n1 = d1 >= 0 ? norms[d1] : 0u;
-      *reinterpret_cast<uint16_t*>(pnorm + t.pn_base + 128 * (uint64_t)blk + 2 * lane) = (uint16_t)(n0 | (n1 << 8));
+      const uint32_t hdr = dir_hdr[t.dir_base + blk];
+      const uint32_t row0 = dir_row[t.dir_base + blk];
+      const uint4 rows = store_rows_from_file(file_rows_load(doc + t.start_fp + dir_off[t.dir_base + blk], hdr, lane), hdr, lane);
+      const int half = lane >> 5, row = lane & 31;
+      const int rd = store_doc_rows(hdr);
+      if (row < (half ? store_freq_rows(hdr) : rd))
+        *reinterpret_cast<uint4*>(term_rows + 16 * (size_t)(row0 + (uint32_t)(half ? rd : 0) + (uint32_t)row)) = rows;
+      if (norms != nullptr) {
+        const int32_t base = blk == 0 ? 0 : dir_last[t.dir_base + blk - 1];
+        const BlockPair bp = block_rows_decode<LEGACY>(rows, hdr, slabs[wave], lane);
+        int32_t d0, d1;
+        deltas_to_docs(bp.d0, bp.d1, base, d0, d1);
+        // a corrupt block must not turn into a wild gather
+        const uint32_t n0 = d0 >= 0 ? norms[d0] : 0u, n1 = d1 >= 0 ? norms[d1] : 0u;
+        *reinterpret_cast<uint16_t*>(pnorm + t.pn_base + 128 * (uint64_t)blk + 2 * lane) = (uint16_t)(n0 | (n1 << 8));
+      }
     }
   }
 }

@@ -63,248 +63,6 @@ __device__ __forceinline__ float table_score(const float* cache, uint32_t rank, 
   return cache[64 + rank * SCORE_TABLE_COLS + freq];
 }
 
-// TermScorer fast path: FullBlocks of a term whose scores come from the LDS table (norm ranks, weight >= 0, no
-// deleted docs). The kernel is VALU-issue bound (rocprofv3: ~77 VALU/block at 86% VALU busy before this path
-// existed), so a block only does what its outcome can depend on: stage the rows, unpack the FREQ stream, two
-// table reads, one compare of the raw score bits against the threshold's. The doc-delta stream is unpacked
-// and prefix-summed only when some posting can still enter the top-k — its base doc then comes from the block
-// directory (dir_last), not from a running scan — which after the first few blocks of a query is rare.
-// Every posting is still counted (TopDocsCollector::total_hits) and every candidate offered, so results are
-// those of the plain loop.
-template <bool LEGACY, bool WIDE>
-__device__ __forceinline__ void term_blocks_fast(const SegView& seg, const DevTerm& T, int b0, int b1, uint8_t* slab,
-                                                 const float* cache, float wk, int lane, WaveTopK& top, uint64_t& tau,
-                                                 uint64_t floor, int k, int& count) {
-  constexpr int DEPTH = PREFETCH_DEPTH;
-  const uint8_t* tbase = seg.doc + T.start_fp;
-  const uint8_t* pn = seg.pnorm + T.pn_base;
-  // Entry test on raw score bits: a posting can enter iff its key exceeds tau = (S, D), i.e. score > S, or
-  // score == S and doc < D. Postings arrive in doc order, so once every remaining doc is known to lie above D
-  // (seen_doc >= D) a tie can no longer win and the test becomes strict — BM25 scores of one term take few
-  // distinct values (freq <= 10 x norm rank), so ties with the threshold are the common case, not the corner.
-  int32_t seen_doc = b0 == 0 ? -1 : seg.dir_last[T.dir_base + b0 - 1];  // every posting from b0 on has doc > seen_doc
-  auto thr_of = [&](uint64_t t) -> uint32_t {
-    const uint32_t thi = (uint32_t)(t >> 32);
-    if (!(thi & 0x80000000u)) return 0u;  // no threshold yet (or a negative one): everything is a candidate
-    const uint32_t bits = thi & 0x7fffffffu;
-    return key_doc(t) <= seen_doc ? bits + 1u : bits;
-  };
-  uint32_t thr = thr_of(tau);
-  const int half = lane >> 5;
-  const int row = lane & 31;
-  uint8_t* stage_at = slab + half * SLAB_STREAM + 16 * row;
-  const uint32_t* dwords = reinterpret_cast<const uint32_t*>(slab);
-  const uint32_t* fwords = reinterpret_cast<const uint32_t*>(slab + SLAB_STREAM);
-  for (int c0 = b0; c0 < b1; c0 += 64) {
-    const int nb = min(64, b1 - c0);
-    DirChunk dir;
-    dir.load(seg.dir_off, seg.dir_hdr, T.dir_base, c0, nb, lane);
-    auto step = [&](int idx, const uint4& rows, uint32_t nn) {
-      const uint32_t hdr = dir.hdr_at(idx);
-      const int bd = hdr_bdoc(hdr);
-      const int bf = hdr_bfreq(hdr);
-      *reinterpret_cast<uint4*>(stage_at) = rows;  // unconditional, see block_rows_decode
-      wave_sync();
-      uint32_t f0, f1;
-      bool in_table;  // wave-uniform
-      if (bf) {
-        if (LEGACY) extract_pair_legacy(fwords, bf, lane, f0, f1);
-        else extract_pair_bp128(fwords, bf, lane, f0, f1);
-        in_table = bf <= 3 || !__ballot((f0 > f1 ? f0 : f1) > (uint32_t)SCORE_TABLE_FREQS);
-      } else {
-        f0 = f1 = vint_from_words((uint32_t)readlane((int)rows.x, 32), (uint32_t)readlane((int)rows.y, 32));
-        in_table = (uint32_t)readfirstlane((int)f0) <= (uint32_t)SCORE_TABLE_FREQS;
-      }
-      const uint32_t nb0 = nn & 0xffu, nb1 = nn >> 8;
-      float s0, s1;
-      if (in_table) {
-        s0 = table_score(cache, nb0, f0);
-        s1 = table_score(cache, nb1, f1);
-      } else {
-        s0 = bm25_score(wk, (float)(int32_t)f0, cache[nb0]);
-        s1 = bm25_score(wk, (float)(int32_t)f1, cache[nb1]);
-      }
-      count += 128;
-      const uint32_t r0 = __float_as_uint(s0), r1 = __float_as_uint(s1);
-      if (__ballot((r0 > r1 ? r0 : r1) >= thr)) {
-        uint32_t e0, e1;
-        if (bd) {
-          if (LEGACY) extract_pair_legacy(dwords, bd, lane, e0, e1);
-          else extract_pair_bp128(dwords, bd, lane, e0, e1);
-        } else {
-          e0 = e1 = vint_from_words((uint32_t)readlane((int)rows.x, 0), (uint32_t)readlane((int)rows.y, 0));
-        }
-        const int blk = c0 + idx;
-        const int32_t base = blk == 0 ? 0 : seg.dir_last[T.dir_base + blk - 1];
-        int32_t d0, d1;
-        deltas_to_docs(e0, e1, base, d0, d1);
-        topk_offer<WIDE>(top, make_key(s0, d0), tau, k, lane, floor);
-        topk_offer<WIDE>(top, make_key(s1, d1), tau, k, lane, floor);
-        seen_doc = readlane(d1, 63);
-        thr = thr_of(tau);
-      }
-      wave_sync();  // slab is free for the next block
-    };
-    auto norms_of = [&](int idx) -> uint32_t {
-      return *reinterpret_cast<const uint16_t*>(pn + (128u * (uint32_t)(c0 + idx) + 2u * (uint32_t)lane));
-    };
-    const int last = nb - 1;
-    uint4 ring[DEPTH];
-    uint32_t nring[DEPTH];
-#pragma unroll
-    for (int j = 0; j < DEPTH; ++j) {
-      const int pj = min(j, last);
-      ring[j] = block_rows_load(tbase + dir.off_at(pj), dir.hdr_at(pj), lane);
-      nring[j] = norms_of(pj);
-    }
-    int i = 0;
-    for (; i + DEPTH <= nb; i += DEPTH) {
-#pragma unroll
-      for (int j = 0; j < DEPTH; ++j) {
-        const uint4 rows = ring[j];
-        const uint32_t nn = nring[j];
-        const int pj = min(i + j + DEPTH, last);
-        ring[j] = block_rows_load(tbase + dir.off_at(pj), dir.hdr_at(pj), lane);
-        nring[j] = norms_of(pj);
-        step(i + j, rows, nn);
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < DEPTH - 1; ++j)
-      if (i + j < nb) step(i + j, ring[j], nring[j]);
-  }
-}
-
-// ---- single term: items = (query, chunk of `blocks_per_item` blocks); the last chunk also takes the tail -------
-template <bool LEGACY, bool WIDE>
-__global__ __launch_bounds__(WG_THREADS) void k_search_term(SegView seg, const DevQuery* __restrict__ queries,
-                                                            const DevTerm* __restrict__ terms,
-                                                            const int64_t* __restrict__ item_prefix, int n_queries,
-                                                            int64_t n_items, int blocks_per_item, int k,
-                                                            uint64_t* __restrict__ partial_keys,
-                                                            int32_t* __restrict__ partial_counts,
-                                                            unsigned long long* __restrict__ tau_slots) {
-  __shared__ __attribute__((aligned(16))) uint8_t slabs[WG_WAVES][SLAB_BYTES];
-  __shared__ float caches[WG_WAVES][WAVE_CACHE_FLOATS];
-  const int lane = lane_id();
-  const int wave = wave_id();
-  const int64_t item = (int64_t)blockIdx.x * WG_WAVES + wave;
-  if (item >= n_items) return;
-  // Item order: the first chunk of every query comes first (items 0..n_queries-1), the remaining chunks follow
-  // query-major. Workgroups start in order, so by the time most chunks begin, their query's first chunk has
-  // already published a top-k threshold (SharedTau) and they skip nearly all list insertions.
-  int q, chunk;
-  if (item < n_queries) {
-    q = (int)item;
-    chunk = 0;
-  } else {
-    q = upper_slot(item_prefix, n_queries, item - n_queries);
-    chunk = (int)(item - n_queries - item_prefix[q]) + 1;
-  }
-  if (queries[q].n_terms < 1) {  // clause absent from this leaf: nothing to collect
-    if (lane == 0) partial_counts[item] = 0;
-    for (int i = lane; i < k; i += 64) partial_keys[(size_t)item * (size_t)k + i] = 0ull;
-    return;
-  }
-  const DevTerm T = terms[queries[q].first_term];
-  // one look at what earlier wavefronts of this query already achieved (per-block exchanges cost far more in
-  // same-address atomics than they save in insertions), one publication when this item is done
-  SharedTau shared{tau_slots + q};
-  uint64_t floor = 0;
-  const uint64_t seen = shared.peek();
-  uint8_t* slab = slabs[wave];
-  float* cache = caches[wave];
-  float k1;
-  load_sim_table(seg, T.sim_table, cache, lane, k1);
-  const float wk = T.weight * (k1 + 1.0f);
-  const bool has_norms = seg.norms != nullptr;
-  const bool tabled = has_norms && seg.n_norm_ranks > 0;
-  if (tabled) build_score_table(cache, wk, lane);
-
-  WaveTopK top;
-  uint64_t tau = 0;
-  int count = 0;
-  shared.fold(seen, tau, floor);
-  // Norms of FullBlock postings arrive in posting order with the payload rows (SegView::pnorm), so scoring a
-  // block needs no gather at all; only the VInt tail / singleton (< 128 postings per term) and the optional
-  // live-docs test still gather. `full` (std::true_type) marks a FullBlock: two real postings per lane.
-  const bool has_live = seg.live != nullptr;
-  const bool nonneg = T.weight >= 0.0f;  // idf * boost; negative only with a negative boost
-  auto collect = [&](auto full, int32_t d0, int32_t d1, uint32_t f0, uint32_t f1, uint32_t nb0, uint32_t nb1, bool v0, bool v1) {
-    constexpr bool FULL = decltype(full)::value;
-    if (FULL) { v0 = true; v1 = true; }
-    if (has_live) {
-      v0 = v0 && doc_is_live(seg.live, d0);
-      v1 = v1 && doc_is_live(seg.live, d1);
-    }
-    float s0, s1;
-    const uint32_t fmax = f0 > f1 ? f0 : f1;
-    if (tabled && !__ballot((v0 || v1) && fmax > (uint32_t)SCORE_TABLE_FREQS)) {
-      s0 = table_score(cache, nb0, v0 ? f0 : 1u);
-      s1 = table_score(cache, nb1, v1 ? f1 : 1u);
-    } else {
-      s0 = bm25_score(wk, (float)(int32_t)f0, has_norms ? cache[nb0] : k1);
-      s1 = bm25_score(wk, (float)(int32_t)f1, has_norms ? cache[nb1] : k1);
-    }
-    if (FULL && !has_live && nonneg) {
-      // Common case, cheap entry test: scores of a non-negative weight are >= +0, so their raw IEEE bits
-      // order like the key's score field; a posting whose score bits are below the threshold's cannot
-      // enter, and only a wave holding a candidate (>=: ties are settled on doc id) builds the 64-bit keys.
-      count += 128;
-      const uint32_t thi = (uint32_t)(tau >> 32);
-      const uint32_t thr = (thi & 0x80000000u) ? (thi & 0x7fffffffu) : 0u;
-      const uint32_t r0 = __float_as_uint(s0), r1 = __float_as_uint(s1);
-      if (__ballot((r0 > r1 ? r0 : r1) >= thr)) {
-        topk_offer<WIDE>(top, make_key(s0, d0), tau, k, lane, floor);
-        topk_offer<WIDE>(top, make_key(s1, d1), tau, k, lane, floor);
-      }
-      return;
-    }
-    count += __popcll(__ballot(v0)) + __popcll(__ballot(v1));
-    const uint64_t key0 = v0 ? make_key(s0, d0) : 0ull, key1 = v1 ? make_key(s1, d1) : 0ull;
-    if (__ballot((key0 > key1 ? key0 : key1) > tau)) {
-      topk_offer<WIDE>(top, key0, tau, k, lane, floor);
-      topk_offer<WIDE>(top, key1, tau, k, lane, floor);
-    }
-  };
-
-  const int b0 = chunk * blocks_per_item;
-  const int b1 = min(T.nblocks, b0 + blocks_per_item);
-  int32_t base = b0 == 0 ? 0 : seg.dir_last[T.dir_base + b0 - 1];
-  const uint8_t* tbase = seg.doc + T.start_fp;
-  auto on_block = [&](int, int32_t d0, int32_t d1, uint32_t f0, uint32_t f1, uint32_t nb0, uint32_t nb1) {
-    collect(std::true_type{}, d0, d1, f0, f1, nb0, nb1, true, true);
-  };
-  if (tabled && !has_live && nonneg) {
-    term_blocks_fast<LEGACY, WIDE>(seg, T, b0, b1, slab, cache, wk, lane, top, tau, floor, k, count);
-    if (b1 > b0) base = seg.dir_last[T.dir_base + b1 - 1];
-  } else if (has_norms) {
-    stream_blocks<LEGACY, true>(tbase, seg.dir_off, seg.dir_hdr, T.dir_base, seg.pnorm + T.pn_base, b0, b1, slab, lane, base, on_block);
-  } else {
-    stream_blocks<LEGACY, false>(tbase, seg.dir_off, seg.dir_hdr, T.dir_base, nullptr, b0, b1, slab, lane, base, on_block);
-  }
-  if (b1 == T.nblocks) {
-    if (T.df == 1) {
-      const bool v0 = lane == 0;
-      const uint32_t nb0 = (has_norms && v0) ? seg.norms[T.singleton_doc] : 0u;
-      collect(std::false_type{}, T.singleton_doc, 0, (uint32_t)T.singleton_freq, 1u, nb0, 0u, v0, false);
-    } else if (T.tail_n > 0) {
-      const uint32_t toff = T.nblocks ? seg.dir_off[T.dir_base + T.nblocks] : 0u;
-      int32_t d0, d1;
-      uint32_t f0, f1;
-      decode_tail(seg.doc + T.start_fp + toff, T.tail_n, base, slab, lane, d0, d1, f0, f1);
-      const bool v0 = 2 * lane < T.tail_n, v1 = 2 * lane + 1 < T.tail_n;
-      const uint32_t nb0 = (has_norms && v0) ? seg.norms[d0] : 0u, nb1 = (has_norms && v1) ? seg.norms[d1] : 0u;
-      collect(std::false_type{}, d0, d1, f0, f1, nb0, nb1, v0, v1);
-    }
-  }
-  shared.publish<WIDE>(top, k, lane);
-  uint64_t* pk = partial_keys + (size_t)item * (size_t)k;
-  if (lane < k) pk[lane] = top.a;
-  if (WIDE && lane + 64 < k) pk[lane + 64] = top.b;
-  if (lane == 0) partial_counts[item] = count;
-}
-
 constexpr int WINDOW_LDS_FIXED = WG_WAVES * SLAB_BYTES + WG_WAVES * 1024 + WG_WAVES * 128 * 8 + 16;  // bytes before acc[]
 
 // ---- AND / OR: items = (query, group of doc-id windows); one workgroup accumulates a window in LDS ------------
@@ -382,7 +140,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_window(SegView seg, const
         const int bhi = find_block(seg.dir_last, T.dir_base, T.nblocks, w1 - 1);
         for (int blk = blo + wave; blk <= bhi && blk < T.nblocks; blk += WG_WAVES) {
           const int32_t base = blk == 0 ? 0 : seg.dir_last[T.dir_base + blk - 1];
-          const BlockPair bp = decode_block<LEGACY>(seg.doc + T.start_fp + seg.dir_off[T.dir_base + blk],
+          const BlockPair bp = decode_block<LEGACY>(seg.bstore + T.bs_base, seg.dir_row[T.dir_base + blk],
                                                      seg.dir_hdr[T.dir_base + blk], slab, lane);
           int32_t d0, d1;
           deltas_to_docs(bp.d0, bp.d1, base, d0, d1);

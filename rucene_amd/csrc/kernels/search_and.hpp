@@ -147,7 +147,7 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
         int n_in = 0;
         if (cur < T.nblocks) {
           const int32_t base = cur == 0 ? 0 : seg.dir_last[T.dir_base + cur - 1];
-          const BlockPair bp = decode_block<LEGACY>(seg.doc + T.start_fp + seg.dir_off[T.dir_base + cur],
+          const BlockPair bp = decode_block<LEGACY>(seg.bstore + T.bs_base, seg.dir_row[T.dir_base + cur],
                                                      seg.dir_hdr[T.dir_base + cur], slab, lane);
           int32_t e0, e1;
           deltas_to_docs(bp.d0, bp.d1, base, e0, e1);
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
   for (int blk = b0; blk < b1; ++blk) {
     uint32_t nn = 0;
     if (has_norms) nn = *reinterpret_cast<const uint16_t*>(seg.pnorm + L.pn_base + 128 * (size_t)blk + 2 * lane);
-    const BlockPair bp = decode_block<LEGACY>(seg.doc + L.start_fp + seg.dir_off[L.dir_base + blk], seg.dir_hdr[L.dir_base + blk], slab, lane);
+    const BlockPair bp = decode_block<LEGACY>(seg.bstore + L.bs_base, seg.dir_row[L.dir_base + blk], seg.dir_hdr[L.dir_base + blk], slab, lane);
     int32_t d0, d1;
     deltas_to_docs(bp.d0, bp.d1, base, d0, d1);
     base = readlane(d1, 63);

@@ -62,14 +62,14 @@ __global__ __launch_bounds__(WG_THREADS) void k_score_terms(SegView seg, const D
   const int b0 = chunk * blocks_per_item;
   const int b1 = min(T.nblocks, b0 + blocks_per_item);
   int32_t base = b0 == 0 ? 0 : seg.dir_last[T.dir_base + b0 - 1];
-  const uint8_t* tbase = seg.doc + T.start_fp;
+  const uint8_t* term_rows = seg.bstore + T.bs_base;
   auto on_block = [&](int blk, int32_t d0, int32_t d1, uint32_t f0, uint32_t f1, uint32_t nb0, uint32_t nb1) {
     emit(d0, d1, f0, f1, nb0, nb1, true, true, 128 * (int64_t)blk + 2 * lane);
   };
   if (has_norms)
-    stream_blocks<LEGACY, true>(tbase, seg.dir_off, seg.dir_hdr, T.dir_base, seg.pnorm + T.pn_base, b0, b1, slab, lane, base, on_block);
+    stream_blocks<LEGACY, true>(term_rows, seg.dir_row, seg.dir_hdr, T.dir_base, seg.pnorm + T.pn_base, b0, b1, slab, lane, base, on_block);
   else
-    stream_blocks<LEGACY, false>(tbase, seg.dir_off, seg.dir_hdr, T.dir_base, nullptr, b0, b1, slab, lane, base, on_block);
+    stream_blocks<LEGACY, false>(term_rows, seg.dir_row, seg.dir_hdr, T.dir_base, nullptr, b0, b1, slab, lane, base, on_block);
   if (b1 == T.nblocks) {
     if (T.df == 1) {
       const bool v0 = lane == 0;

@@ -1,0 +1,335 @@
+// Single-term queries (TermScorer + TopDocsCollector) on the GPU. Replaces, per leaf:
+//   search/scorer/term_scorer.rs:43-67              TermScorer (postings iteration + BM25SimScorer::score)
+//   search/scorer/bulk_scorer.rs:114-120            the collect loop
+//   search/collector/top_docs.rs:67-94,157-172      TopDocsCollector::{collect, add_doc}
+//
+// Work items = (query, chunk of `blocks_per_item` FullBlocks), one wavefront each; the last chunk of a term also
+// takes its VInt tail. A workgroup is TERM_WAVES consecutive items, and the waves of a workgroup that work on
+// the SAME query share ONE top-k list in LDS (a "group", led by the lowest such wave): k-th best of 8 x 128
+// blocks instead of 64 rises ~3x faster, and what a block costs depends on whether it can still contribute —
+// see term_blocks_fast. The list is checked out into the registers of whichever wave has candidates (WaveTopK,
+// under an LDS spin lock) and written back; the wave of a group that finishes last emits the list as the
+// group's partial result (the other items emit empty lists), k_merge_items merges groups.
+#pragma once
+#include "search.hpp"
+
+namespace rgpu {
+
+#ifdef RGPU_EXP_COUNT  // developer instrumentation (variant builds only): [0] blocks, [1] blocks that took the doc-id path
+__device__ unsigned long long g_term_dbg[4];
+#endif
+
+#ifndef RGPU_TERM_WAVES
+#define RGPU_TERM_WAVES 8
+#endif
+constexpr int TERM_WAVES = RGPU_TERM_WAVES;
+constexpr int TERM_THREADS = 64 * TERM_WAVES;
+// per-wave LDS slice: [norm cache 64 f32 | score table 64 x 11 f32 | FullBlock staging slab 2 x 528 B] (raw-norm
+// mode: a 256-entry norm cache and no table); the VInt tail decoder (once per term, after the last FullBlock)
+// takes everything past the first 256 floats as its scratch
+constexpr int TERM_BLOCK_SLAB = 2 * SLAB_STREAM;
+constexpr int TERM_WAVE_LDS = WAVE_CACHE_FLOATS * 4 + TERM_BLOCK_SLAB;
+static_assert((WAVE_CACHE_FLOATS - 256) * 4 + TERM_BLOCK_SLAB >= SLAB_BYTES, "tail scratch");
+static_assert(TERM_WAVE_LDS % 16 == 0, "16-byte aligned slices");
+__host__ __device__ constexpr size_t term_lds_bytes(bool wide) {
+  return (size_t)TERM_WAVES * TERM_WAVE_LDS + (size_t)TERM_WAVES * (wide ? 128 : 64) * 8 + (size_t)TERM_WAVES * 8;
+}
+
+// ---- a top-k list shared by the wavefronts of one group -------------------------------------------------------
+struct GroupList {
+  uint64_t* keys;  // LDS: 64 (128 when WIDE) keys, sorted descending, 0 == empty — WaveTopK's registers at rest
+  uint32_t* lock;  // LDS
+};
+__device__ __forceinline__ void group_lock(uint32_t* lock, int lane) {
+  while (true) {
+    uint32_t old = 1u;
+    if (lane == 0) old = atomicCAS(lock, 0u, 1u);
+    if ((uint32_t)readfirstlane((int)old) == 0u) break;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ __forceinline__ void group_unlock(uint32_t* lock, int lane) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if (lane == 0) __hip_atomic_store(lock, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// the group's current k-th best (0 while the list holds fewer than k keys); a stale value is only conservative
+template <bool WIDE>
+__device__ __forceinline__ uint64_t group_kth(const GroupList& g, int k) {
+  const uint64_t v = __hip_atomic_load(g.keys + (k - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  return ((uint64_t)(uint32_t)readfirstlane((int)(uint32_t)(v >> 32)) << 32) | (uint32_t)readfirstlane((int)(uint32_t)v);
+}
+// Offer two keys per lane (0 == none) to the group's list; `tau` returns the entry threshold afterwards.
+template <bool WIDE>
+__device__ __forceinline__ void group_offer2(const GroupList& g, uint64_t key0, uint64_t key1, uint64_t& tau, int k, int lane,
+                                             uint64_t floor) {
+  group_lock(g.lock, lane);
+  WaveTopK top;
+  top.a = g.keys[lane];
+  if (WIDE) top.b = g.keys[64 + lane];
+  const uint64_t kth = topk_threshold<WIDE>(top, k);
+  tau = kth > floor ? kth : floor;
+  topk_offer<WIDE>(top, key0, tau, k, lane, floor);
+  topk_offer<WIDE>(top, key1, tau, k, lane, floor);
+  g.keys[lane] = top.a;
+  if (WIDE) g.keys[64 + lane] = top.b;
+  group_unlock(g.lock, lane);
+}
+
+// TermScorer fast path: FullBlocks of a term whose scores come from the LDS table (norm ranks, weight >= 0, no
+// deleted docs). The kernel is VALU-issue bound (rocprofv3: ~77 VALU/block at 86% VALU busy before this path
+// existed), so a block only does what its outcome can depend on: stage the rows, unpack the FREQ stream, two
+// table reads, one compare of the raw score bits against the threshold's. The doc-delta stream is unpacked
+// and prefix-summed only when some posting can still enter the top-k — its base doc then comes from the block
+// directory (dir_last), not from a running scan. Every posting is still counted (TopDocsCollector::total_hits)
+// and every candidate offered, so results are those of the plain loop.
+template <bool LEGACY, bool WIDE>
+__device__ __forceinline__ void term_blocks_fast(const SegView& seg, const DevTerm& T, int b0, int b1, uint8_t* slab,
+                                                 const float* cache, float wk, int lane, const GroupList& group,
+                                                 uint64_t floor, int k, int& count) {
+  constexpr int DEPTH = PREFETCH_DEPTH;
+  const uint8_t* term_rows = seg.bstore + T.bs_base;
+  const uint8_t* pn = seg.pnorm + T.pn_base;
+  // Entry test on raw score bits: a posting can enter iff its key exceeds tau = (S, D), i.e. score > S, or
+  // score == S and doc < D. Postings arrive in doc order, so once every remaining doc is known to lie above D
+  // (seen_doc >= D) a tie can no longer win and the test becomes strict — BM25 scores of one term take few
+  // distinct values (freq <= 10 x norm rank), so ties with the threshold are the common case, not the corner.
+  int32_t seen_doc = b0 == 0 ? -1 : seg.dir_last[T.dir_base + b0 - 1];  // every posting from b0 on has doc > seen_doc
+  auto thr_of = [&](uint64_t t) -> uint32_t {
+    const uint32_t thi = (uint32_t)(t >> 32);
+    if (!(thi & 0x80000000u)) return 0u;  // no threshold yet (or a negative one): everything is a candidate
+    const uint32_t bits = thi & 0x7fffffffu;
+    return key_doc(t) <= seen_doc ? bits + 1u : bits;
+  };
+  auto fresh_tau = [&]() -> uint64_t {
+    const uint64_t kth = group_kth<WIDE>(group, k);
+    return kth > floor ? kth : floor;
+  };
+  uint64_t tau = fresh_tau();
+  uint32_t thr = thr_of(tau);
+#ifdef RGPU_EXP_COUNT
+  int dbg_slow = 0;
+#endif
+  for (int c0 = b0; c0 < b1; c0 += 64) {
+    const int nb = min(64, b1 - c0);
+    DirChunk dir;
+    dir.load(seg.dir_row, seg.dir_hdr, T.dir_base, c0, nb, lane);
+    auto step = [&](int idx, const uint4& rows, uint32_t nn) {
+      const uint32_t hdr = dir.hdr_at(idx);
+      const int bf = hdr_bfreq(hdr);
+      stage_rows(rows, slab, lane);
+      wave_sync();
+      uint32_t f0, f1;
+      staged_freqs<LEGACY>(slab, rows, hdr, lane, f0, f1);
+      bool in_table;  // wave-uniform
+      if (bf > 3) in_table = !__ballot((f0 > f1 ? f0 : f1) > (uint32_t)SCORE_TABLE_FREQS);
+      else in_table = bf != 0 || (uint32_t)readfirstlane((int)f0) <= (uint32_t)SCORE_TABLE_FREQS;
+      const uint32_t nb0 = nn & 0xffu, nb1 = nn >> 8;
+      float s0, s1;
+      if (in_table) {
+        s0 = table_score(cache, nb0, f0);
+        s1 = table_score(cache, nb1, f1);
+      } else {
+        s0 = bm25_score(wk, (float)(int32_t)f0, cache[nb0]);
+        s1 = bm25_score(wk, (float)(int32_t)f1, cache[nb1]);
+      }
+      count += 128;
+      const uint32_t r0 = __float_as_uint(s0), r1 = __float_as_uint(s1);
+#ifdef RGPU_EXP_NOSLOW
+      if (false) {
+#else
+      if (__ballot((r0 > r1 ? r0 : r1) >= thr)) {
+#endif
+#ifdef RGPU_EXP_COUNT
+        ++dbg_slow;
+#endif
+        uint32_t e0, e1;
+        staged_doc_deltas<LEGACY>(slab, rows, hdr, lane, e0, e1);
+        const int blk = c0 + idx;
+        const int32_t base = blk == 0 ? 0 : seg.dir_last[T.dir_base + blk - 1];
+        int32_t d0, d1;
+        deltas_to_docs(e0, e1, base, d0, d1);
+        group_offer2<WIDE>(group, make_key(s0, d0), make_key(s1, d1), tau, k, lane, floor);
+        seen_doc = readlane(d1, 63);
+        thr = thr_of(tau);
+      }
+      wave_sync();  // slab is free for the next block
+    };
+    auto norms_of = [&](int idx) -> uint32_t {
+      return *reinterpret_cast<const uint16_t*>(pn + (128u * (uint32_t)(c0 + idx) + 2u * (uint32_t)lane));
+    };
+    const int last = nb - 1;
+    uint4 ring[DEPTH];
+    uint32_t nring[DEPTH];
+#pragma unroll
+    for (int j = 0; j < DEPTH; ++j) {
+      const int pj = min(j, last);
+      ring[j] = block_rows_load(block_rows_at(term_rows, dir.row_at(pj)), dir.hdr_at(pj), lane);
+      nring[j] = norms_of(pj);
+    }
+    int i = 0;
+    for (; i + DEPTH <= nb; i += DEPTH) {
+      // what the group's other wavefronts achieved meanwhile: one LDS read per DEPTH blocks
+      tau = fresh_tau();
+      thr = thr_of(tau);
+#pragma unroll
+      for (int j = 0; j < DEPTH; ++j) {
+        const uint4 rows = ring[j];
+        const uint32_t nn = nring[j];
+        const int pj = min(i + j + DEPTH, last);
+        ring[j] = block_rows_load(block_rows_at(term_rows, dir.row_at(pj)), dir.hdr_at(pj), lane);
+        nring[j] = norms_of(pj);
+        step(i + j, rows, nn);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < DEPTH - 1; ++j)
+      if (i + j < nb) step(i + j, ring[j], nring[j]);
+  }
+#ifdef RGPU_EXP_COUNT
+  if (lane == 0) { atomicAdd(&g_term_dbg[0], (unsigned long long)(b1 - b0)); atomicAdd(&g_term_dbg[1], (unsigned long long)dbg_slow); }
+#endif
+}
+
+template <bool LEGACY, bool WIDE>
+__global__ __launch_bounds__(TERM_THREADS, 8) void k_search_term(SegView seg, const DevQuery* __restrict__ queries,
+                                                              const DevTerm* __restrict__ terms,
+                                                              const int64_t* __restrict__ item_prefix, int n_queries,
+                                                              int64_t n_items, int blocks_per_item, int k,
+                                                              uint64_t* __restrict__ partial_keys,
+                                                              int32_t* __restrict__ partial_counts,
+                                                              unsigned long long* __restrict__ tau_slots) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  constexpr int LIST_N = WIDE ? 128 : 64;
+  const int lane = lane_id();
+  const int wave = wave_id();
+  float* cache = reinterpret_cast<float*>(smem + wave * TERM_WAVE_LDS);
+  uint8_t* tail_scratch = reinterpret_cast<uint8_t*>(cache + 256);  // rest of the score table + slab
+  uint8_t* slab = smem + wave * TERM_WAVE_LDS + WAVE_CACHE_FLOATS * 4;
+  uint64_t* lists = reinterpret_cast<uint64_t*>(smem + TERM_WAVES * TERM_WAVE_LDS);
+  uint32_t* locks = reinterpret_cast<uint32_t*>(lists + TERM_WAVES * LIST_N);
+  uint32_t* remaining = locks + TERM_WAVES;
+
+  // Item order: the first chunk of every query comes first (items 0..n_queries-1), the remaining chunks follow
+  // query-major — consecutive items, i.e. the waves of a workgroup, mostly belong to one query. Workgroups
+  // start in order, so by the time most chunks begin, their query's first chunk has already published a
+  // threshold (SharedTau). Lane i resolves item i of this workgroup; every wave then knows all the groups.
+  const int64_t item0 = (int64_t)blockIdx.x * TERM_WAVES;
+  int qv = -1, cv = 0;
+  if (lane < TERM_WAVES && item0 + lane < n_items) {
+    const int64_t it = item0 + lane;
+    if (it < n_queries) {
+      qv = (int)it;
+    } else {
+      qv = upper_slot(item_prefix, n_queries, it - n_queries);
+      cv = (int)(it - n_queries - item_prefix[qv]) + 1;
+    }
+  }
+  const int q = readlane(qv, wave);
+  const int chunk = readlane(cv, wave);
+  const uint64_t same = __ballot(lane < TERM_WAVES && qv == q);
+  const int leader = __builtin_ctzll(same);
+  lists[wave * LIST_N + lane] = 0ull;
+  if (WIDE) lists[wave * LIST_N + 64 + lane] = 0ull;
+  if (lane == 0) {
+    locks[wave] = 0u;
+    remaining[wave] = leader == wave ? (uint32_t)__popcll(same) : 0u;
+  }
+  __syncthreads();
+  if (q < 0) return;  // past the last item
+  const int64_t item = item0 + wave;
+  const GroupList group{lists + leader * LIST_N, locks + leader};
+  SharedTau shared{tau_slots + q};
+  int count = 0;
+
+  if (queries[q].n_terms >= 1) {  // else: clause absent from this leaf, nothing to collect
+    const DevTerm T = terms[queries[q].first_term];
+    // one look at what earlier workgroups of this query already achieved (per-block exchanges through HBM cost
+    // far more in same-address atomics than they save in insertions), one publication when the group is done
+    uint64_t floor = 0, tau = 0;
+    const uint64_t seen = shared.peek();
+    float k1;
+    load_sim_table(seg, T.sim_table, cache, lane, k1);
+    const float wk = T.weight * (k1 + 1.0f);
+    const bool has_norms = seg.norms != nullptr;
+    bool tabled = has_norms && seg.n_norm_ranks > 0;
+    if (tabled) build_score_table(cache, wk, lane);
+    shared.fold(seen, tau, floor);
+    // Norms of FullBlock postings arrive in posting order with the payload rows (SegView::pnorm), so scoring a
+    // block needs no gather at all; only the VInt tail / singleton (< 128 postings per term) and the optional
+    // live-docs test still gather. `full` (std::true_type) marks a FullBlock: two real postings per lane.
+    const bool has_live = seg.live != nullptr;
+    const bool nonneg = T.weight >= 0.0f;  // idf * boost; negative only with a negative boost
+    auto collect = [&](auto full, int32_t d0, int32_t d1, uint32_t f0, uint32_t f1, uint32_t nb0, uint32_t nb1, bool v0, bool v1) {
+      constexpr bool FULL = decltype(full)::value;
+      if (FULL) { v0 = true; v1 = true; }
+      if (has_live) {
+        v0 = v0 && doc_is_live(seg.live, d0);
+        v1 = v1 && doc_is_live(seg.live, d1);
+      }
+      float s0, s1;
+      const uint32_t fmax = f0 > f1 ? f0 : f1;
+      if (tabled && !__ballot((v0 || v1) && fmax > (uint32_t)SCORE_TABLE_FREQS)) {
+        s0 = table_score(cache, nb0, v0 ? f0 : 1u);
+        s1 = table_score(cache, nb1, v1 ? f1 : 1u);
+      } else {
+        s0 = bm25_score(wk, (float)(int32_t)f0, has_norms ? cache[nb0] : k1);
+        s1 = bm25_score(wk, (float)(int32_t)f1, has_norms ? cache[nb1] : k1);
+      }
+      count += __popcll(__ballot(v0)) + __popcll(__ballot(v1));
+      const uint64_t key0 = v0 ? make_key(s0, d0) : 0ull, key1 = v1 ? make_key(s1, d1) : 0ull;
+      // `tau` may lag behind the group's list: a stale threshold only lets more keys through to the locked offer
+      if (__ballot((key0 > key1 ? key0 : key1) > tau)) group_offer2<WIDE>(group, key0, key1, tau, k, lane, floor);
+    };
+
+    const int b0 = chunk * blocks_per_item;
+    const int b1 = min(T.nblocks, b0 + blocks_per_item);
+    int32_t base = b0 == 0 ? 0 : seg.dir_last[T.dir_base + b0 - 1];
+    const uint8_t* term_rows = seg.bstore + T.bs_base;
+    auto on_block = [&](int, int32_t d0, int32_t d1, uint32_t f0, uint32_t f1, uint32_t nb0, uint32_t nb1) {
+      collect(std::true_type{}, d0, d1, f0, f1, nb0, nb1, true, true);
+    };
+    if (tabled && !has_live && nonneg) {
+      term_blocks_fast<LEGACY, WIDE>(seg, T, b0, b1, slab, cache, wk, lane, group, floor, k, count);
+      if (b1 > b0) base = seg.dir_last[T.dir_base + b1 - 1];
+    } else if (has_norms) {
+      stream_blocks<LEGACY, true>(term_rows, seg.dir_row, seg.dir_hdr, T.dir_base, seg.pnorm + T.pn_base, b0, b1, slab, lane, base, on_block);
+    } else {
+      stream_blocks<LEGACY, false>(term_rows, seg.dir_row, seg.dir_hdr, T.dir_base, nullptr, b0, b1, slab, lane, base, on_block);
+    }
+    if (b1 == T.nblocks) {
+      if (T.df == 1) {
+        const bool v0 = lane == 0;
+        const uint32_t nb0 = (has_norms && v0) ? seg.norms[T.singleton_doc] : 0u;
+        collect(std::false_type{}, T.singleton_doc, 0, (uint32_t)T.singleton_freq, 1u, nb0, 0u, v0, false);
+      } else if (T.tail_n > 0) {
+        const uint32_t toff = T.nblocks ? seg.dir_off[T.dir_base + T.nblocks] : 0u;
+        int32_t d0, d1;
+        uint32_t f0, f1;
+        decode_tail(seg.doc + T.start_fp + toff, T.tail_n, base, tail_scratch, lane, d0, d1, f0, f1);
+        tabled = false;  // the tail decoder's scratch overlaid the score table: score by the formula it memoises
+        const bool v0 = 2 * lane < T.tail_n, v1 = 2 * lane + 1 < T.tail_n;
+        const uint32_t nb0 = (has_norms && v0) ? seg.norms[d0] : 0u, nb1 = (has_norms && v1) ? seg.norms[d1] : 0u;
+        collect(std::false_type{}, d0, d1, f0, f1, nb0, nb1, v0, v1);
+      }
+    }
+  }
+
+  // the wave of a group that finishes last emits the group's list; the other items emit empty lists
+  if (lane == 0) partial_counts[item] = count;
+  uint32_t left = 0;
+  if (lane == 0) left = __hip_atomic_fetch_sub(remaining + leader, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+  left = (uint32_t)readfirstlane((int)left);
+  WaveTopK top;
+  if (left == 1u) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    top.a = group.keys[lane];
+    if (WIDE) top.b = group.keys[64 + lane];
+    shared.publish<WIDE>(top, k, lane);
+  }
+  uint64_t* pk = partial_keys + (size_t)item * (size_t)k;
+  if (lane < k) pk[lane] = top.a;
+  if (WIDE && lane + 64 < k) pk[lane + 64] = top.b;
+}
+
+}  // namespace rgpu

@@ -10,8 +10,15 @@ struct SegView {
   const uint8_t* norms;      // 1 byte per doc, or null (compute_score falls back to k1)
   const uint64_t* live;      // FixedBitSet words or null (MatchAllBits)
   const int32_t* dir_last;   // block directory: last doc id of block i            (skip level 0 docs, summed)
-  const uint32_t* dir_off;   // block directory: byte offset of block i from the term's doc_start_fp
+  const uint32_t* dir_off;   // block directory: byte offset of block i from the term's doc_start_fp (slot nblocks: the tail)
+  const uint32_t* dir_row;   // block directory: first 16-byte row of block i in the block store, from the term's bs_base
   const uint16_t* dir_hdr;   // block directory: b_doc | vint_len << 6 | b_freq << 9
+  // Block store: the FullBlock payloads of every prepared term, copied once (k_prepare_terms) to 16-byte aligned
+  // rows: block i = [max(b_doc,1) doc rows][max(b_freq,1) freq rows]; a row is 16 bytes of the BP128 / packed
+  // stream exactly as in the .doc file, an all-equal stream (b == 0) is one row holding its value as a u32.
+  // In the file a payload starts right after a 1-byte header, and byte-misaligned 16-byte loads run at a third
+  // of the aligned rate on gfx950 (scripts/microbench/unaligned_rows.hip) — the scoring kernels were bound by it.
+  const uint8_t* bstore;
   const float* sim_tables;   // n x 257 floats: cache[256] then k1
   // Norm ranks: when a segment uses <= 64 distinct norm bytes (SmallFloat lengths: the usual case) the HBM copy of
   // the norms holds each byte's RANK among the used values and rank_to_norm maps back, so a clause's whole
@@ -31,6 +38,7 @@ struct SegView {
 struct DevTerm {
   uint64_t start_fp;      // doc_start_fp
   uint64_t pn_base;       // first byte of this term's posting-order norms in SegView::pnorm
+  uint64_t bs_base;       // first byte of this term's rows in SegView::bstore (16-byte aligned)
   uint32_t dir_base;      // first directory slot (nblocks + 1 slots)
   int32_t nblocks;        // full 128-posting blocks
   int32_t df;
@@ -45,13 +53,14 @@ struct DevTerm {
 struct PrepTerm {
   uint64_t start_fp;
   uint64_t pn_base;    // where this term's posting-order norms go
+  uint64_t bs_base;    // where this term's block-store rows go (bytes, 16-byte aligned)
   int64_t skip_fp;     // absolute, -1 when df <= 128
   uint32_t dir_base;
   int32_t nblocks;
   int32_t n_entries;   // level-0 skip entries = ceil(df / 128) - 1
   int32_t n_levels;    // 1 + floor(log8(trim(df) / 128)), capped at 10
   int32_t df;
-  int32_t pad;
+  uint32_t bs_rows;    // rows reserved for this term in the block store
 };
 
 struct DevQuery {

@@ -17,6 +17,7 @@
 #include "kernels/search.hpp"
 #include "kernels/search_and.hpp"
 #include "kernels/search_or.hpp"
+#include "kernels/search_term.hpp"
 
 using namespace rgpu;
 
@@ -109,7 +110,7 @@ struct rgpu_ctx {
   char name[128] = {0};
 };
 
-struct TermInfo { uint32_t dir_base; int32_t nblocks; int32_t df; uint64_t pn_base; };
+struct TermInfo { uint32_t dir_base; int32_t nblocks; int32_t df; uint64_t pn_base; uint64_t bs_base; };
 
 struct rgpu_segment {
   rgpu_ctx* ctx = nullptr;
@@ -122,8 +123,11 @@ struct rgpu_segment {
   int32_t max_doc = 0, doc_base = 0, version = 1;
   DevVec<int32_t> dir_last;
   DevVec<uint32_t> dir_off;
+  DevVec<uint32_t> dir_row;
   DevVec<uint16_t> dir_hdr;
   size_t dir_used = 0;
+  DevVec<uint8_t> bstore;  // 16-byte aligned FullBlock payload rows of every prepared term (SegView::bstore)
+  size_t bstore_used = 0;
   DevVec<uint8_t> pnorm;  // posting-order norms of every prepared term's FullBlocks
   size_t pnorm_used = 0;
   std::unordered_map<int64_t, TermInfo> prepared;
@@ -195,6 +199,8 @@ static SegView seg_view(const rgpu_segment* s) {
   v.live = s->d_live;
   v.dir_last = s->dir_last.p;
   v.dir_off = s->dir_off.p;
+  v.dir_row = s->dir_row.p;
+  v.bstore = s->bstore.p;
   v.dir_hdr = s->dir_hdr.p;
   v.sim_tables = s->ctx->sim_tables.p;
   v.max_doc = s->max_doc;
@@ -229,6 +235,7 @@ static int32_t prepare_terms_locked(rgpu_segment* seg, const rgpu_term_state* co
   std::vector<PrepTerm> work;
   size_t need_slots = seg->dir_used;
   size_t need_pn = seg->pnorm_used;
+  size_t need_bs = seg->bstore_used;
   std::vector<std::pair<int64_t, TermInfo>> added;
   std::unordered_map<int64_t, int> in_batch;
   for (size_t i = 0; i < n; ++i) {
@@ -251,17 +258,26 @@ static int32_t prepare_terms_locked(rgpu_segment* seg, const rgpu_term_state* co
     p.n_levels = ilog8_levels(st.doc_freq);
     p.skip_fp = st.doc_freq > 128 ? st.doc_start_fp + st.skip_offset : -1;
     p.dir_base = (uint32_t)need_slots;
-    p.pad = 0;
     p.pn_base = (uint64_t)need_pn;
+    // block store rows: a block's aligned copy is at most 28 bytes longer than its framing in the file (two
+    // header bytes dropped, each all-equal VInt padded to a 16-byte row); the FullBlocks end before the skip data
+    const uint64_t span = st.doc_freq > 128 ? (uint64_t)st.skip_offset : 1026u;
+    const uint64_t rows = (span + 28u * (uint64_t)p.nblocks + 15u) / 16u;
+    if (rows > 0xffffffffull) return fail(RGPU_ERR_UNSUPPORTED, "a single term's postings exceed 64 GiB");
+    p.bs_base = (uint64_t)need_bs;
+    p.bs_rows = (uint32_t)rows;
     need_slots += (size_t)p.nblocks + 1;
     need_pn += (size_t)p.nblocks * 128;
+    need_bs += (size_t)rows * 16;
     if (need_slots > 0xfffffff0ull) return fail(RGPU_ERR_UNSUPPORTED, "block directory exceeds 2^32 slots");
     work.push_back(p);
-    added.push_back({st.doc_start_fp, TermInfo{p.dir_base, p.nblocks, p.df, p.pn_base}});
+    added.push_back({st.doc_start_fp, TermInfo{p.dir_base, p.nblocks, p.df, p.pn_base, p.bs_base}});
   }
   if (work.empty()) return RGPU_OK;
   HIP_TRY(seg->dir_last.reserve(need_slots, seg->dir_used, c->stream));
   HIP_TRY(seg->dir_off.reserve(need_slots, seg->dir_used, c->stream));
+  HIP_TRY(seg->dir_row.reserve(need_slots, seg->dir_used, c->stream));
+  HIP_TRY(seg->bstore.reserve(need_bs + 1024, seg->bstore_used, c->stream));  // + over-read padding of the row loads
   HIP_TRY(seg->dir_hdr.reserve(need_slots, seg->dir_used, c->stream));
   if (seg->d_norms) HIP_TRY(seg->pnorm.reserve(need_pn + 64, seg->pnorm_used, c->stream));
   const size_t bytes = work.size() * sizeof(PrepTerm);
@@ -277,11 +293,11 @@ static int32_t prepare_terms_locked(rgpu_segment* seg, const rgpu_term_state* co
     if (seg->version >= 1)
       hipLaunchKernelGGL(k_prepare_terms<false>, dim3((unsigned)work.size()), dim3(PREP_THREADS), 0, c->stream, seg->d_doc,
                          (int64_t)seg->doc_len, reinterpret_cast<const PrepTerm*>(c->d_stage.p), seg->dir_last.p,
-                         seg->dir_off.p, seg->dir_hdr.p, seg->d_norms, seg->pnorm.p, c->d_err);
+                         seg->dir_off.p, seg->dir_row.p, seg->dir_hdr.p, seg->bstore.p, seg->d_norms, seg->pnorm.p, c->d_err);
     else
       hipLaunchKernelGGL(k_prepare_terms<true>, dim3((unsigned)work.size()), dim3(PREP_THREADS), 0, c->stream, seg->d_doc,
                          (int64_t)seg->doc_len, reinterpret_cast<const PrepTerm*>(c->d_stage.p), seg->dir_last.p,
-                         seg->dir_off.p, seg->dir_hdr.p, seg->d_norms, seg->pnorm.p, c->d_err);
+                         seg->dir_off.p, seg->dir_row.p, seg->dir_hdr.p, seg->bstore.p, seg->d_norms, seg->pnorm.p, c->d_err);
   }
   int err = 0;
   HIP_TRY(hipMemcpyAsync(&err, c->d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -293,6 +309,7 @@ static int32_t prepare_terms_locked(rgpu_segment* seg, const rgpu_term_state* co
   }
   seg->dir_used = need_slots;
   seg->pnorm_used = need_pn;
+  seg->bstore_used = need_bs;
   for (auto& a : added) seg->prepared[a.first] = a.second;
   return RGPU_OK;
 }
@@ -314,6 +331,7 @@ static int32_t make_dev_term(const rgpu_segment* seg, const rgpu_term_state& st,
     t.dir_base = it->second.dir_base;
     t.nblocks = it->second.nblocks;
     t.pn_base = it->second.pn_base;
+    t.bs_base = it->second.bs_base;
   }
   t.tail_n = st.doc_freq > 1 ? st.doc_freq % 128 : 0;
   *out = t;
@@ -482,7 +500,7 @@ extern "C" void rgpu_segment_free(rgpu_segment* s) {
   if (s->d_norms) (void)hipFree(s->d_norms);
   if (s->d_rank_to_norm) (void)hipFree(s->d_rank_to_norm);
   if (s->d_live) (void)hipFree(s->d_live);
-  s->dir_last.release(); s->dir_off.release(); s->dir_hdr.release(); s->pnorm.release();
+  s->dir_last.release(); s->dir_off.release(); s->dir_row.release(); s->dir_hdr.release(); s->pnorm.release(); s->bstore.release();
   delete s;
 }
 
@@ -817,7 +835,7 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
         int64_t total_blocks = 0;
         for (auto& t : G.terms) total_blocks += t.nblocks;
         blocks_per_item = 8;
-        while (blocks_per_item < 128 && total_blocks / blocks_per_item > 40000) blocks_per_item *= 2;
+        while (blocks_per_item < 128 && total_blocks / blocks_per_item > 20000) blocks_per_item *= 2;
       }
       while (true) {
         items = 0;
@@ -878,13 +896,19 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
       else { if (wide) go(k_search_and<false, true>); else go(k_search_and<false, false>); }
     } else if (op == RGPU_OP_TERM) {
       TimedLaunch tl(c, stream, "k_search_term", G.postings);
-      const unsigned grid = (unsigned)((items + WG_WAVES - 1) / WG_WAVES);
-      auto go = [&](auto kern) {
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(WG_THREADS), 0, stream, sv, dq, dt, dp, nq, items, blocks_per_item, (int)k,
+      const unsigned grid = (unsigned)((items + TERM_WAVES - 1) / TERM_WAVES);
+      const size_t lds = term_lds_bytes(wide);
+      auto go = [&](auto kern) -> hipError_t {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(TERM_THREADS), lds, stream, sv, dq, dt, dp, nq, items, blocks_per_item, (int)k,
                            c->d_partial_keys.p, c->d_partial_counts.p, c->d_tau.p);
+        return hipSuccess;
       };
-      if (legacy) { if (wide) go(k_search_term<true, true>); else go(k_search_term<true, false>); }
-      else { if (wide) go(k_search_term<false, true>); else go(k_search_term<false, false>); }
+      hipError_t e;
+      if (legacy) e = wide ? go(k_search_term<true, true>) : go(k_search_term<true, false>);
+      else e = wide ? go(k_search_term<false, true>) : go(k_search_term<false, false>);
+      HIP_TRY(e);
     } else {
       TimedLaunch tl(c, stream, op == RGPU_OP_AND ? "k_search_window_and" : "k_search_window_or", G.postings);
       const size_t lds = (size_t)WINDOW_LDS_FIXED + (size_t)W * 5;
@@ -1000,3 +1024,11 @@ extern "C" int32_t rgpu_bm25_compute_weight(float k1, float b, int64_t max_doc, 
 extern "C" uint8_t rgpu_bm25_encode_norm(float boost, int32_t field_length) {
   return rucene::BM25Similarity::encode_norm_value(boost, field_length);
 }
+
+#ifdef RGPU_EXP_COUNT
+extern "C" int32_t rgpu_debug_counters(unsigned long long* out4, int32_t reset) {
+  if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_term_dbg), 32) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[4] = {0, 0, 0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_term_dbg), z, 32) != hipSuccess) return -1; }
+  return 0;
+}
+#endif

@@ -18,11 +18,13 @@ T, B = rucene_amd.TermQuery, rucene_amd.BooleanQuery
 SEED = 0x527563656E65 ^ 0x51
 if kind == "decode":
     sel = seg.terms[seg.terms["doc_freq"] >= 128]
-    import ctypes
-    hip = ctypes.CDLL("libamdhip64.so")
+    import torch  # device buffers only
     total = int(sel["doc_freq"].sum())
-    pd, pf = ctypes.c_void_p(), ctypes.c_void_p()
-    hip.hipMalloc(ctypes.byref(pd), ctypes.c_size_t(total * 4)); hip.hipMalloc(ctypes.byref(pf), ctypes.c_size_t(total * 4))
+    td = torch.empty(total, dtype=torch.int32, device="cuda")
+    tf = torch.empty(total, dtype=torch.int32, device="cuda")
+    class _P:  # .value like a ctypes pointer
+        def __init__(self, v): self.value = v
+    pd, pf = _P(td.data_ptr()), _P(tf.data_ptr())
     for _ in range(reps + 2):
         leaf.segment.decode_terms_device(sel, pd.value, pf.value)
 else:
@@ -38,5 +40,11 @@ else:
     packed = s.pack(qs, leaf)
     for _ in range(reps + 2):
         hits, totals = leaf.segment.search_batch(packed[0], packed[1], k)
+import ctypes as _C
+_L = _C.CDLL(rucene_amd._lib.lib_path())
+if hasattr(_L, "rgpu_debug_counters"):
+    _o = (_C.c_ulonglong * 4)()
+    _L.rgpu_debug_counters(_o, 0)
+    print("dbg counters", list(_o), "slow frac", _o[1] / max(1, _o[0]))
 print({n: (v["launches"], round(v["total_ms"] / v["launches"], 4)) for n, v in ctx.kernel_stats().items()})
 ctx.close()
