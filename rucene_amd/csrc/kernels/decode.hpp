@@ -69,7 +69,7 @@ __device__ __forceinline__ void extract_pair_bp128(const uint8_t* stream, int b,
   const uint8_t* at = stream + 4 * l + 16 * w;  // one address: the pair of reads becomes one ds_read2_b64
   const uint2 lo = lds_u2(at);
   const uint2 hi = lds_u2(at + 16);
-  const uint32_t mask = b >= 32 ? 0xffffffffu : ((1u << b) - 1u);
+  const uint32_t mask = 0xffffffffu >> (32 - b);  // callers pass 1 <= b <= 32 (b == 0 is the all-equal form)
   v0 = (uint32_t)((((uint64_t)hi.x << 32) | lo.x) >> s) & mask;
   v1 = (uint32_t)((((uint64_t)hi.y << 32) | lo.y) >> s) & mask;
 }
@@ -156,7 +156,7 @@ __device__ __host__ __forceinline__ int store_freq_rows(uint32_t hdr) { return h
 // padded) so that it never sits behind a branch: the waitcnt pass can then keep several blocks in flight.
 // Address = uniform base + one 32-bit lane offset (SGPR-base form).
 __device__ __forceinline__ uint4 block_rows_load(const uint8_t* __restrict__ rows0, uint32_t hdr, int lane) {
-  const uint32_t voff = 16u * ((uint32_t)(lane & 31) + __umul24((uint32_t)(lane >> 5), (uint32_t)store_doc_rows(hdr)));
+  const uint32_t voff = 16u * (uint32_t)(lane & 31) + __umul24(16u * (uint32_t)(lane >> 5), (uint32_t)store_doc_rows(hdr));  // one v_mad_u32_u24
   return *reinterpret_cast<const uint4*>(rows0 + voff);
 }
 __device__ __forceinline__ const uint8_t* block_rows_at(const uint8_t* __restrict__ term_rows, uint32_t row) {

@@ -24,15 +24,33 @@ __device__ unsigned long long g_term_dbg[4];
 #endif
 constexpr int TERM_WAVES = RGPU_TERM_WAVES;
 constexpr int TERM_THREADS = 64 * TERM_WAVES;
-// per-wave LDS slice: [norm cache 64 f32 | score table 64 x 11 f32 | FullBlock staging slab 2 x 528 B] (raw-norm
-// mode: a 256-entry norm cache and no table); the VInt tail decoder (once per term, after the last FullBlock)
-// takes everything past the first 256 floats as its scratch
+// per-wave LDS slice: [FullBlock staging slab 2 x 528 B | norm cache 64 f32 | score table 64 x 11 f32]; the slab
+// comes first so that the extraction's ds_read2_b64 offsets stay immediates. Raw-norm mode (no ranks, no table)
+// keeps its 256-entry norm cache in the last 1 KB instead. The VInt tail decoder (once per term, after the last
+// FullBlock) takes the table as its scratch, or in raw-norm mode everything before the cache.
 constexpr int TERM_BLOCK_SLAB = 2 * SLAB_STREAM;
-constexpr int TERM_WAVE_LDS = WAVE_CACHE_FLOATS * 4 + TERM_BLOCK_SLAB;
-static_assert((WAVE_CACHE_FLOATS - 256) * 4 + TERM_BLOCK_SLAB >= SLAB_BYTES, "tail scratch");
-static_assert(TERM_WAVE_LDS % 16 == 0, "16-byte aligned slices");
+constexpr int TERM_WAVE_LDS = TERM_BLOCK_SLAB + WAVE_CACHE_FLOATS * 4;
+constexpr int TERM_RAW_CACHE_AT = TERM_WAVE_LDS - 256 * 4;
+static_assert((WAVE_CACHE_FLOATS - 64) * 4 >= SLAB_BYTES, "tail scratch (rank mode: the score table)");
+static_assert(TERM_RAW_CACHE_AT >= SLAB_BYTES, "tail scratch (raw-norm mode: slab + unused table)");
+static_assert(TERM_WAVE_LDS % 16 == 0 && TERM_BLOCK_SLAB % 16 == 0, "16-byte aligned slices");
 __host__ __device__ constexpr size_t term_lds_bytes(bool wide) {
-  return (size_t)TERM_WAVES * TERM_WAVE_LDS + (size_t)TERM_WAVES * (wide ? 128 : 64) * 8 + (size_t)TERM_WAVES * 8;
+  return (size_t)TERM_WAVES * TERM_WAVE_LDS + (size_t)TERM_WAVES * (wide ? 128 : 64) * 8 + (size_t)TERM_WAVES * 12;
+}
+
+// largest t in [0, n) with prefix[t] <= x, searched by the whole wavefront: 64 probes per step (two dependent
+// loads for 1024 queries instead of ten)
+__device__ __forceinline__ int upper_slot_wave(const int64_t* __restrict__ prefix, int n, int64_t x, int lane) {
+  int lo = 0, hi = n;
+  while (hi - lo > 1) {
+    const int step = (hi - lo + 63) >> 6;
+    const int idx = lo + lane * step;
+    const bool ok = idx < hi && prefix[idx] <= x;  // true on a prefix of the lanes, lane 0 included
+    const int cnt = __popcll(__ballot(ok));
+    lo += (cnt - 1) * step;
+    hi = min(hi, lo + step);
+  }
+  return lo;
 }
 
 // ---- a top-k list shared by the wavefronts of one group -------------------------------------------------------
@@ -105,8 +123,11 @@ __device__ __forceinline__ void term_blocks_fast(const SegView& seg, const DevTe
     const uint64_t kth = group_kth<WIDE>(group, k);
     return kth > floor ? kth : floor;
   };
+  // `thr` lives in one scalar register between updates (kept opaque: the compiler would otherwise recompute it
+  // from tau / seen_doc — eight scalar instructions — in front of every block's compare)
+  auto pin = [](uint32_t v) -> uint32_t { asm volatile("" : "+s"(v)); return v; };
   uint64_t tau = fresh_tau();
-  uint32_t thr = thr_of(tau);
+  uint32_t thr = pin(thr_of(tau));
 #ifdef RGPU_EXP_COUNT
   int dbg_slow = 0;
 #endif
@@ -114,16 +135,25 @@ __device__ __forceinline__ void term_blocks_fast(const SegView& seg, const DevTe
     const int nb = min(64, b1 - c0);
     DirChunk dir;
     dir.load(seg.dir_row, seg.dir_hdr, T.dir_base, c0, nb, lane);
+    if (c0 > b0) {  // blocks skipped on the cheap path moved the position too
+      const int32_t upto = seg.dir_last[T.dir_base + c0 - 1];
+      seen_doc = upto > seen_doc ? upto : seen_doc;
+    }
     auto step = [&](int idx, const uint4& rows, uint32_t nn) {
       const uint32_t hdr = dir.hdr_at(idx);
       const int bf = hdr_bfreq(hdr);
       stage_rows(rows, slab, lane);
       wave_sync();
       uint32_t f0, f1;
-      staged_freqs<LEGACY>(slab, rows, hdr, lane, f0, f1);
-      bool in_table;  // wave-uniform
-      if (bf > 3) in_table = !__ballot((f0 > f1 ? f0 : f1) > (uint32_t)SCORE_TABLE_FREQS);
-      else in_table = bf != 0 || (uint32_t)readfirstlane((int)f0) <= (uint32_t)SCORE_TABLE_FREQS;
+      bool in_table = true;  // wave-uniform: every freq of the block has a table column
+      if (bf) {
+        extract_pair<LEGACY>(slab + SLAB_STREAM, bf, lane, f0, f1);
+        if (bf > 3) in_table = !__ballot((f0 > f1 ? f0 : f1) > (uint32_t)SCORE_TABLE_FREQS);
+      } else {
+        const uint32_t f = (uint32_t)readlane((int)rows.x, 32);  // all-equal stream: its value
+        f0 = f1 = f;
+        in_table = f <= (uint32_t)SCORE_TABLE_FREQS;
+      }
       const uint32_t nb0 = nn & 0xffu, nb1 = nn >> 8;
       float s0, s1;
       if (in_table) {
@@ -135,8 +165,8 @@ __device__ __forceinline__ void term_blocks_fast(const SegView& seg, const DevTe
       }
       count += 128;
       const uint32_t r0 = __float_as_uint(s0), r1 = __float_as_uint(s1);
-#ifdef RGPU_EXP_NOSLOW
-      if (false) {
+#ifdef RGPU_EXP_NOSLOW  // timing experiment (wrong results): the doc-id path is never taken, scoring stays live
+      if (__ballot((r0 > r1 ? r0 : r1) >= 0xffffffffu - ((uint32_t)k >> 30))) {
 #else
       if (__ballot((r0 > r1 ? r0 : r1) >= thr)) {
 #endif
@@ -149,9 +179,13 @@ __device__ __forceinline__ void term_blocks_fast(const SegView& seg, const DevTe
         const int32_t base = blk == 0 ? 0 : seg.dir_last[T.dir_base + blk - 1];
         int32_t d0, d1;
         deltas_to_docs(e0, e1, base, d0, d1);
-        group_offer2<WIDE>(group, make_key(s0, d0), make_key(s1, d1), tau, k, lane, floor);
+        const uint64_t key0 = make_key(s0, d0), key1 = make_key(s1, d1);
+        // most blocks that get here only tie with the threshold or trail a fresher one: look at the group's
+        // current k-th best (one LDS read) before paying for the lock and the list check-out
+        tau = fresh_tau();
+        if (__ballot((key0 > key1 ? key0 : key1) > tau)) group_offer2<WIDE>(group, key0, key1, tau, k, lane, floor);
         seen_doc = readlane(d1, 63);
-        thr = thr_of(tau);
+        thr = pin(thr_of(tau));
       }
       wave_sync();  // slab is free for the next block
     };
@@ -171,7 +205,7 @@ __device__ __forceinline__ void term_blocks_fast(const SegView& seg, const DevTe
     for (; i + DEPTH <= nb; i += DEPTH) {
       // what the group's other wavefronts achieved meanwhile: one LDS read per DEPTH blocks
       tau = fresh_tau();
-      thr = thr_of(tau);
+      thr = pin(thr_of(tau));
 #pragma unroll
       for (int j = 0; j < DEPTH; ++j) {
         const uint4 rows = ring[j];
@@ -203,41 +237,42 @@ __global__ __launch_bounds__(TERM_THREADS, 8) void k_search_term(SegView seg, co
   constexpr int LIST_N = WIDE ? 128 : 64;
   const int lane = lane_id();
   const int wave = wave_id();
-  float* cache = reinterpret_cast<float*>(smem + wave * TERM_WAVE_LDS);
-  uint8_t* tail_scratch = reinterpret_cast<uint8_t*>(cache + 256);  // rest of the score table + slab
-  uint8_t* slab = smem + wave * TERM_WAVE_LDS + WAVE_CACHE_FLOATS * 4;
+  uint8_t* slice = smem + wave * TERM_WAVE_LDS;
+  uint8_t* slab = slice;
+  const bool ranked = seg.n_norm_ranks > 0;
+  float* cache = reinterpret_cast<float*>(slice + (ranked ? TERM_BLOCK_SLAB : TERM_RAW_CACHE_AT));
+  uint8_t* tail_scratch = ranked ? reinterpret_cast<uint8_t*>(cache + 64) : slice;
   uint64_t* lists = reinterpret_cast<uint64_t*>(smem + TERM_WAVES * TERM_WAVE_LDS);
   uint32_t* locks = reinterpret_cast<uint32_t*>(lists + TERM_WAVES * LIST_N);
-  uint32_t* remaining = locks + TERM_WAVES;
+  uint32_t* remaining = locks + TERM_WAVES;  // waves of a group that have finished, counted at the leader's slot
+  int32_t* wave_query = reinterpret_cast<int32_t*>(remaining + TERM_WAVES);
 
   // Item order: the first chunk of every query comes first (items 0..n_queries-1), the remaining chunks follow
   // query-major — consecutive items, i.e. the waves of a workgroup, mostly belong to one query. Workgroups
   // start in order, so by the time most chunks begin, their query's first chunk has already published a
-  // threshold (SharedTau). Lane i resolves item i of this workgroup; every wave then knows all the groups.
-  const int64_t item0 = (int64_t)blockIdx.x * TERM_WAVES;
-  int qv = -1, cv = 0;
-  if (lane < TERM_WAVES && item0 + lane < n_items) {
-    const int64_t it = item0 + lane;
-    if (it < n_queries) {
-      qv = (int)it;
+  // threshold (SharedTau). Every wave resolves its own item and posts the query in LDS for the others.
+  const int64_t item = (int64_t)blockIdx.x * TERM_WAVES + wave;
+  int q = -1, chunk = 0;
+  if (item < n_items) {
+    if (item < n_queries) {
+      q = (int)item;
     } else {
-      qv = upper_slot(item_prefix, n_queries, it - n_queries);
-      cv = (int)(it - n_queries - item_prefix[qv]) + 1;
+      q = upper_slot_wave(item_prefix, n_queries, item - n_queries, lane);
+      chunk = (int)(item - n_queries - item_prefix[q]) + 1;
     }
   }
-  const int q = readlane(qv, wave);
-  const int chunk = readlane(cv, wave);
-  const uint64_t same = __ballot(lane < TERM_WAVES && qv == q);
-  const int leader = __builtin_ctzll(same);
   lists[wave * LIST_N + lane] = 0ull;
   if (WIDE) lists[wave * LIST_N + 64 + lane] = 0ull;
   if (lane == 0) {
     locks[wave] = 0u;
-    remaining[wave] = leader == wave ? (uint32_t)__popcll(same) : 0u;
+    remaining[wave] = 0u;
+    wave_query[wave] = q;
   }
   __syncthreads();
   if (q < 0) return;  // past the last item
-  const int64_t item = item0 + wave;
+  const uint64_t same = __ballot(lane < TERM_WAVES && wave_query[lane < TERM_WAVES ? lane : 0] == q);
+  const int leader = __builtin_ctzll(same);
+  const int members = __popcll(same);
   const GroupList group{lists + leader * LIST_N, locks + leader};
   SharedTau shared{tau_slots + q};
   int count = 0;
@@ -317,11 +352,11 @@ __global__ __launch_bounds__(TERM_THREADS, 8) void k_search_term(SegView seg, co
 
   // the wave of a group that finishes last emits the group's list; the other items emit empty lists
   if (lane == 0) partial_counts[item] = count;
-  uint32_t left = 0;
-  if (lane == 0) left = __hip_atomic_fetch_sub(remaining + leader, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-  left = (uint32_t)readfirstlane((int)left);
+  uint32_t done = 0;
+  if (lane == 0) done = __hip_atomic_fetch_add(remaining + leader, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+  done = (uint32_t)readfirstlane((int)done) + 1u;
   WaveTopK top;
-  if (left == 1u) {
+  if (done == (uint32_t)members) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     top.a = group.keys[lane];
     if (WIDE) top.b = group.keys[64 + lane];
