@@ -143,17 +143,22 @@ def main():
     from rucene_amd import dist as rdist
     merge = rdist.hip_merge(ctx)
 
+    # rgpu_search_batch_device only enqueues (staging copy + kernels): back-to-back steps overlap the host-side
+    # planning of batch i+1 with the kernels of batch i; the timed region ends with a device-wide synchronize.
+    # N > 1: search, all-gather and merge are all enqueued on one torch side stream, in order, without host syncs.
+    side = torch.cuda.Stream() if world > 1 else None
+    sid = side.cuda_stream if side is not None else 0
+
     def local_search(packed):
-        # the ctx runs its kernels on its own stream and returns when they are done, so the collective that
-        # follows (torch's stream) always sees complete per-shard results
-        leaf.segment.search_batch_device(packed[0], packed[1], k, hits_local.data_ptr(), totals_local.data_ptr())
+        leaf.segment.search_batch_device(packed[0], packed[1], k, hits_local.data_ptr(), totals_local.data_ptr(), sid)
         return hits_local, totals_local
 
     merged = {}
 
     def step(packed):
         if world > 1:
-            merged["hits"], merged["totals"] = rdist.sharded_search(lambda: local_search(packed), merge)
+            with torch.cuda.stream(side):
+                merged["hits"], merged["totals"] = rdist.sharded_search(lambda: local_search(packed), merge)
         else:
             local_search(packed)
 

@@ -157,14 +157,18 @@ int32_t rgpu_sim_table_upload(rgpu_ctx* ctx, const float cache[256], float k1);
  * OR with >= 10 clauses within 1e-5 relative (heap-order-dependent summation in the reference). */
 int32_t rgpu_search_batch(rgpu_segment* seg, const rgpu_query* queries, int32_t n_queries, const rgpu_query_term* terms,
                           int32_t n_terms_total, int32_t k, rgpu_hit* hits_out, int64_t* total_hits_out);
-/* Same with device-resident outputs (for the RCCL all-gather of per-shard top-k), async on hip_stream. */
+/* Same with device-resident outputs (for the RCCL all-gather of per-shard top-k). Enqueue-only for TERM / AND
+ * batches: the call stages its inputs, launches on hip_stream (NULL = the context's own stream) and returns; the
+ * outputs are complete when the stream reaches that point (hipStreamSynchronize, or rgpu_synchronize for the
+ * context's stream). Back-to-back calls therefore overlap the host-side planning of batch i+1 with the kernels of
+ * batch i. `queries` / `terms` are copied before the call returns. */
 int32_t rgpu_search_batch_device(rgpu_segment* seg, const rgpu_query* queries, int32_t n_queries,
                                  const rgpu_query_term* terms, int32_t n_terms_total, int32_t k, void* hits_dev,
                                  void* total_hits_dev, void* hip_stream);
 
 /* TopDocsCollector::finish_parallel (collector/top_docs.rs:157-172): merge n_lists per-leaf / per-shard
  * top-k lists (layout [list][query][k], device memory) into [query][k] under the canonical order and sum
- * the hit counts ([list][query] -> [query]). */
+ * the hit counts ([list][query] -> [query]). Enqueue-only on hip_stream, like rgpu_search_batch_device. */
 int32_t rgpu_merge_topk_device(rgpu_ctx* ctx, const void* hits_dev, const void* totals_dev, int32_t n_lists,
                                int32_t n_queries, int32_t k, void* hits_out_dev, void* totals_out_dev, void* hip_stream);
 

@@ -85,6 +85,25 @@ struct PendingEvent { int slot; hipEvent_t start, stop; };
 
 }  // namespace
 
+constexpr int N_SCRATCH = 4;
+struct Scratch {
+  HostPinned h_stage;
+  DevVec<uint8_t> d_stage;
+  DevVec<uint64_t> d_partial_keys;
+  DevVec<int32_t> d_partial_counts;
+  DevVec<HitOut> d_hits;
+  DevVec<int64_t> d_totals;
+  DevVec<unsigned long long> d_tau;  // per-query shared top-k thresholds
+  hipEvent_t done = nullptr;
+  bool busy = false;
+  void release() {
+    h_stage.release(); d_stage.release(); d_partial_keys.release(); d_partial_counts.release(); d_hits.release();
+    d_totals.release(); d_tau.release();
+    if (done) (void)hipEventDestroy(done);
+    done = nullptr;
+  }
+};
+
 struct rgpu_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -93,15 +112,13 @@ struct rgpu_ctx {
   std::mutex mu;
   DevVec<float> sim_tables;
   int n_sim_tables = 0;
-  // per-call scratch
-  HostPinned h_stage;
-  DevVec<uint8_t> d_stage;
-  DevVec<uint64_t> d_partial_keys;
-  DevVec<int32_t> d_partial_counts;
-  DevVec<HitOut> d_hits;
-  DevVec<int64_t> d_totals;
-  DevVec<ScoredPosting> d_runs;  // OR: per-clause {doc, score} runs
-  DevVec<unsigned long long> d_tau;  // per-query shared top-k thresholds
+  // Per-call scratch, in rotating slots: a search call only enqueues work (staging copy + kernels) on its stream
+  // and marks its slot with an event; the slot is waited for when its turn comes again, so the host prepares batch
+  // i+1 while the GPU runs batch i and a caller synchronizes the stream once, when it wants the results.
+  Scratch scr[N_SCRATCH];
+  Scratch* S = &scr[0];
+  int scr_next = 0;
+  DevVec<ScoredPosting> d_runs;  // OR: per-clause {doc, score} runs (one instance: OR groups end with a stream sync)
   int* d_err = nullptr;
   // profiling
   std::vector<StatSlot> stats;
@@ -173,6 +190,31 @@ static void drain_events(rgpu_ctx* c) {
     c->free_events.push_back(pe.stop);
   }
   c->pending.clear();
+}
+
+// ---- scratch slots -------------------------------------------------------------------------------------------------
+// take the next slot (waiting for the work that used it N_SCRATCH calls ago) ...
+static hipError_t scratch_take(rgpu_ctx* c) {
+  Scratch* sc = &c->scr[c->scr_next];
+  c->scr_next = (c->scr_next + 1) % N_SCRATCH;
+  if (sc->busy) {
+    hipError_t e = hipEventSynchronize(sc->done);
+    if (e != hipSuccess) return e;
+    sc->busy = false;
+  }
+  c->S = sc;
+  return hipSuccess;
+}
+// ... and mark it in flight once everything that reads it has been enqueued on `s`
+static hipError_t scratch_mark(rgpu_ctx* c, hipStream_t s) {
+  Scratch* sc = c->S;
+  if (!sc->done) {
+    hipError_t e = hipEventCreateWithFlags(&sc->done, hipEventDisableTiming);
+    if (e != hipSuccess) return e;
+  }
+  hipError_t e = hipEventRecord(sc->done, s);
+  if (e == hipSuccess) sc->busy = true;
+  return e;
 }
 
 // ---- staging: pack several host arrays into one pinned buffer, one H2D copy ---------------------------------
@@ -274,6 +316,7 @@ static int32_t prepare_terms_locked(rgpu_segment* seg, const rgpu_term_state* co
     added.push_back({st.doc_start_fp, TermInfo{p.dir_base, p.nblocks, p.df, p.pn_base, p.bs_base}});
   }
   if (work.empty()) return RGPU_OK;
+  HIP_TRY(scratch_take(c));  // staging below; this function ends with a stream sync, so the slot is free again on return
   HIP_TRY(seg->dir_last.reserve(need_slots, seg->dir_used, c->stream));
   HIP_TRY(seg->dir_off.reserve(need_slots, seg->dir_used, c->stream));
   HIP_TRY(seg->dir_row.reserve(need_slots, seg->dir_used, c->stream));
@@ -281,10 +324,10 @@ static int32_t prepare_terms_locked(rgpu_segment* seg, const rgpu_term_state* co
   HIP_TRY(seg->dir_hdr.reserve(need_slots, seg->dir_used, c->stream));
   if (seg->d_norms) HIP_TRY(seg->pnorm.reserve(need_pn + 64, seg->pnorm_used, c->stream));
   const size_t bytes = work.size() * sizeof(PrepTerm);
-  HIP_TRY(c->h_stage.reserve(bytes));
-  HIP_TRY(c->d_stage.reserve(bytes, 0, c->stream));
-  std::memcpy(c->h_stage.p, work.data(), bytes);
-  HIP_TRY(hipMemcpyAsync(c->d_stage.p, c->h_stage.p, bytes, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c->S->h_stage.reserve(bytes));
+  HIP_TRY(c->S->d_stage.reserve(bytes, 0, c->stream));
+  std::memcpy(c->S->h_stage.p, work.data(), bytes);
+  HIP_TRY(hipMemcpyAsync(c->S->d_stage.p, c->S->h_stage.p, bytes, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream));
   {
     int64_t postings = 0;
@@ -292,11 +335,11 @@ static int32_t prepare_terms_locked(rgpu_segment* seg, const rgpu_term_state* co
     TimedLaunch tl(c, c->stream, "k_prepare_terms", postings);
     if (seg->version >= 1)
       hipLaunchKernelGGL(k_prepare_terms<false>, dim3((unsigned)work.size()), dim3(PREP_THREADS), 0, c->stream, seg->d_doc,
-                         (int64_t)seg->doc_len, reinterpret_cast<const PrepTerm*>(c->d_stage.p), seg->dir_last.p,
+                         (int64_t)seg->doc_len, reinterpret_cast<const PrepTerm*>(c->S->d_stage.p), seg->dir_last.p,
                          seg->dir_off.p, seg->dir_row.p, seg->dir_hdr.p, seg->bstore.p, seg->d_norms, seg->pnorm.p, c->d_err);
     else
       hipLaunchKernelGGL(k_prepare_terms<true>, dim3((unsigned)work.size()), dim3(PREP_THREADS), 0, c->stream, seg->d_doc,
-                         (int64_t)seg->doc_len, reinterpret_cast<const PrepTerm*>(c->d_stage.p), seg->dir_last.p,
+                         (int64_t)seg->doc_len, reinterpret_cast<const PrepTerm*>(c->S->d_stage.p), seg->dir_last.p,
                          seg->dir_off.p, seg->dir_row.p, seg->dir_hdr.p, seg->bstore.p, seg->d_norms, seg->pnorm.p, c->d_err);
   }
   int err = 0;
@@ -379,8 +422,8 @@ extern "C" void rgpu_shutdown(rgpu_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   drain_events(c);
   for (auto e : c->free_events) (void)hipEventDestroy(e);
-  c->sim_tables.release(); c->d_stage.release(); c->d_partial_keys.release(); c->d_partial_counts.release();
-  c->d_hits.release(); c->d_totals.release(); c->d_runs.release(); c->d_tau.release(); c->h_stage.release();
+  c->sim_tables.release(); c->d_runs.release();
+  for (auto& sc : c->scr) sc.release();
   if (c->d_err) (void)hipFree(c->d_err);
   (void)hipStreamDestroy(c->stream);
   delete c;
@@ -523,15 +566,16 @@ static int32_t decode_terms_impl(rgpu_segment* seg, const rgpu_term_state* terms
   for (int64_t i = 0; i < n_terms; ++i) ptrs[(size_t)i] = &terms[i];
   int32_t rc = prepare_terms_locked(seg, ptrs.data(), ptrs.size());
   if (rc != RGPU_OK) return rc;
+  HIP_TRY(scratch_take(c));  // callers synchronize the stream before they return
   Stager st(c);
   const size_t o_terms = st.add((size_t)n_terms * sizeof(DevTerm));
   const size_t o_items = st.add((size_t)(n_terms + 1) * 8);
   const size_t o_out = st.add((size_t)(n_terms + 1) * 8);
-  HIP_TRY(c->h_stage.reserve(st.used));
-  HIP_TRY(c->d_stage.reserve(st.used, 0, c->stream));
-  DevTerm* ht = reinterpret_cast<DevTerm*>(c->h_stage.p + o_terms);
-  int64_t* hitems = reinterpret_cast<int64_t*>(c->h_stage.p + o_items);
-  int64_t* hout = reinterpret_cast<int64_t*>(c->h_stage.p + o_out);
+  HIP_TRY(c->S->h_stage.reserve(st.used));
+  HIP_TRY(c->S->d_stage.reserve(st.used, 0, c->stream));
+  DevTerm* ht = reinterpret_cast<DevTerm*>(c->S->h_stage.p + o_terms);
+  int64_t* hitems = reinterpret_cast<int64_t*>(c->S->h_stage.p + o_items);
+  int64_t* hout = reinterpret_cast<int64_t*>(c->S->h_stage.p + o_out);
   int64_t items = 0, out = 0;
   const int dec_blocks_per_item = 16;
   for (int64_t i = 0; i < n_terms; ++i) {
@@ -546,15 +590,15 @@ static int32_t decode_terms_impl(rgpu_segment* seg, const rgpu_term_state* terms
   hout[n_terms] = out;
   if (total_out) *total_out = out;
   if (items == 0) return RGPU_OK;
-  HIP_TRY(hipMemcpyAsync(c->d_stage.p, c->h_stage.p, st.used, hipMemcpyHostToDevice, stream));
+  HIP_TRY(hipMemcpyAsync(c->S->d_stage.p, c->S->h_stage.p, st.used, hipMemcpyHostToDevice, stream));
   const unsigned grid = (unsigned)((items + WG_WAVES - 1) / WG_WAVES);
   {
     TimedLaunch tl(c, stream, "k_decode_terms", out);
     auto args = [&](auto kern) {
       hipLaunchKernelGGL(kern, dim3(grid), dim3(WG_THREADS), 0, stream, seg_view(seg),
-                         reinterpret_cast<const DevTerm*>(c->d_stage.p + o_terms),
-                         reinterpret_cast<const int64_t*>(c->d_stage.p + o_items),
-                         reinterpret_cast<const int64_t*>(c->d_stage.p + o_out), (int)n_terms, items, dec_blocks_per_item, docs_dev,
+                         reinterpret_cast<const DevTerm*>(c->S->d_stage.p + o_terms),
+                         reinterpret_cast<const int64_t*>(c->S->d_stage.p + o_items),
+                         reinterpret_cast<const int64_t*>(c->S->d_stage.p + o_out), (int)n_terms, items, dec_blocks_per_item, docs_dev,
                          freqs_dev);
     };
     if (seg->version >= 1) args(k_decode_terms<false>); else args(k_decode_terms<true>);
@@ -649,8 +693,8 @@ static void launch_merge(rgpu_ctx* c, hipStream_t s, int n_queries, int k, const
                          int64_t* totals, int head_items = 0) {
   TimedLaunch tl(c, s, "k_merge_items", 0);
   const unsigned grid = (unsigned)((n_queries + WG_WAVES - 1) / WG_WAVES);
-  hipLaunchKernelGGL(k_merge_items<WIDE>, dim3(grid), dim3(WG_THREADS), 0, s, d_prefix, n_queries, k, c->d_partial_keys.p,
-                     c->d_partial_counts.p, doc_base, head_items, hits, totals);
+  hipLaunchKernelGGL(k_merge_items<WIDE>, dim3(grid), dim3(WG_THREADS), 0, s, d_prefix, n_queries, k, c->S->d_partial_keys.p,
+                     c->S->d_partial_counts.p, doc_base, head_items, hits, totals);
 }
 
 // OR: score every clause once into {doc, score} runs, then accumulate per doc-id window (kernels/search_or.hpp)
@@ -661,6 +705,7 @@ static int32_t search_or_group(rgpu_segment* seg, Group& G, int32_t k, HitOut* h
   const bool wide = k > 64;
   const bool legacy = seg->version < 1;
   if (nt == 0) return RGPU_OK;  // every clause absent from this leaf: rows keep their {-1, 0} / 0 defaults
+  HIP_TRY(scratch_take(c));
   // phase 1 plan: items = (clause, chunk of blocks)
   int blocks_per_item = c->cfg.blocks_per_item;
   std::vector<int64_t> item_prefix((size_t)nt + 1), run_prefix((size_t)nt + 1);
@@ -694,28 +739,28 @@ static int32_t search_or_group(rgpu_segment* seg, Group& G, int32_t k, HitOut* h
   const size_t o_rp = st.add((size_t)(nt + 1) * 8);
   const size_t o_mp = st.add((size_t)(nq + 1) * 8);
   const size_t o_m = st.add((size_t)nq * 4);
-  HIP_TRY(c->h_stage.reserve(st.used));
-  HIP_TRY(c->d_stage.reserve(st.used, 0, stream));
-  std::memcpy(c->h_stage.p + o_q, G.queries.data(), (size_t)nq * sizeof(DevQuery));
-  std::memcpy(c->h_stage.p + o_t, G.terms.data(), (size_t)nt * sizeof(DevTerm));
-  std::memcpy(c->h_stage.p + o_ip, item_prefix.data(), (size_t)(nt + 1) * 8);
-  std::memcpy(c->h_stage.p + o_rp, run_prefix.data(), (size_t)(nt + 1) * 8);
-  std::memcpy(c->h_stage.p + o_mp, merge_prefix.data(), (size_t)(nq + 1) * 8);
-  std::memcpy(c->h_stage.p + o_m, G.qmap.data(), (size_t)nq * 4);
-  HIP_TRY(hipMemcpyAsync(c->d_stage.p, c->h_stage.p, st.used, hipMemcpyHostToDevice, stream));
+  HIP_TRY(c->S->h_stage.reserve(st.used));
+  HIP_TRY(c->S->d_stage.reserve(st.used, 0, stream));
+  std::memcpy(c->S->h_stage.p + o_q, G.queries.data(), (size_t)nq * sizeof(DevQuery));
+  std::memcpy(c->S->h_stage.p + o_t, G.terms.data(), (size_t)nt * sizeof(DevTerm));
+  std::memcpy(c->S->h_stage.p + o_ip, item_prefix.data(), (size_t)(nt + 1) * 8);
+  std::memcpy(c->S->h_stage.p + o_rp, run_prefix.data(), (size_t)(nt + 1) * 8);
+  std::memcpy(c->S->h_stage.p + o_mp, merge_prefix.data(), (size_t)(nq + 1) * 8);
+  std::memcpy(c->S->h_stage.p + o_m, G.qmap.data(), (size_t)nq * 4);
+  HIP_TRY(hipMemcpyAsync(c->S->d_stage.p, c->S->h_stage.p, st.used, hipMemcpyHostToDevice, stream));
   HIP_TRY(c->d_runs.reserve((size_t)postings + 64, 0, stream));
-  HIP_TRY(c->d_tau.reserve((size_t)nq, 0, stream));
-  HIP_TRY(hipMemsetAsync(c->d_tau.p, 0, (size_t)nq * 8, stream));
-  HIP_TRY(c->d_partial_keys.reserve((size_t)items2 * (size_t)k, 0, stream));
-  HIP_TRY(c->d_partial_counts.reserve((size_t)items2, 0, stream));
-  HIP_TRY(c->d_hits.reserve((size_t)nq * (size_t)k, 0, stream));
-  HIP_TRY(c->d_totals.reserve((size_t)nq, 0, stream));
-  const DevQuery* dq = reinterpret_cast<const DevQuery*>(c->d_stage.p + o_q);
-  const DevTerm* dt = reinterpret_cast<const DevTerm*>(c->d_stage.p + o_t);
-  const int64_t* dip = reinterpret_cast<const int64_t*>(c->d_stage.p + o_ip);
-  const int64_t* drp = reinterpret_cast<const int64_t*>(c->d_stage.p + o_rp);
-  const int64_t* dmp = reinterpret_cast<const int64_t*>(c->d_stage.p + o_mp);
-  const int32_t* dm = reinterpret_cast<const int32_t*>(c->d_stage.p + o_m);
+  HIP_TRY(c->S->d_tau.reserve((size_t)nq, 0, stream));
+  HIP_TRY(hipMemsetAsync(c->S->d_tau.p, 0, (size_t)nq * 8, stream));
+  HIP_TRY(c->S->d_partial_keys.reserve((size_t)items2 * (size_t)k, 0, stream));
+  HIP_TRY(c->S->d_partial_counts.reserve((size_t)items2, 0, stream));
+  HIP_TRY(c->S->d_hits.reserve((size_t)nq * (size_t)k, 0, stream));
+  HIP_TRY(c->S->d_totals.reserve((size_t)nq, 0, stream));
+  const DevQuery* dq = reinterpret_cast<const DevQuery*>(c->S->d_stage.p + o_q);
+  const DevTerm* dt = reinterpret_cast<const DevTerm*>(c->S->d_stage.p + o_t);
+  const int64_t* dip = reinterpret_cast<const int64_t*>(c->S->d_stage.p + o_ip);
+  const int64_t* drp = reinterpret_cast<const int64_t*>(c->S->d_stage.p + o_rp);
+  const int64_t* dmp = reinterpret_cast<const int64_t*>(c->S->d_stage.p + o_mp);
+  const int32_t* dm = reinterpret_cast<const int32_t*>(c->S->d_stage.p + o_m);
   const SegView sv = seg_view(seg);
   {
     TimedLaunch tl(c, stream, "k_score_terms", G.postings);
@@ -733,14 +778,14 @@ static int32_t search_or_group(rgpu_segment* seg, Group& G, int32_t k, HitOut* h
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
       hipLaunchKernelGGL(kern, dim3(grid), dim3(WG_THREADS), lds, stream, sv, dq, dt, drp, c->d_runs.p, nq, wpq, wpi, ipq, W, (int)k,
-                         c->d_partial_keys.p, c->d_partial_counts.p, c->d_tau.p);
+                         c->S->d_partial_keys.p, c->S->d_partial_counts.p, c->S->d_tau.p);
       return hipSuccess;
     };
     HIP_TRY(wide ? go(k_or_windows<true>) : go(k_or_windows<false>));
   }
-  if (wide) launch_merge<true>(c, stream, nq, k, dmp, seg->doc_base, c->d_hits.p, c->d_totals.p);
-  else launch_merge<false>(c, stream, nq, k, dmp, seg->doc_base, c->d_hits.p, c->d_totals.p);
-  hipLaunchKernelGGL(k_scatter_rows, dim3((unsigned)nq), dim3(128), 0, stream, c->d_hits.p, c->d_totals.p, dm, (int)k, hits_dev, totals_dev);
+  if (wide) launch_merge<true>(c, stream, nq, k, dmp, seg->doc_base, c->S->d_hits.p, c->S->d_totals.p);
+  else launch_merge<false>(c, stream, nq, k, dmp, seg->doc_base, c->S->d_hits.p, c->S->d_totals.p);
+  hipLaunchKernelGGL(k_scatter_rows, dim3((unsigned)nq), dim3(128), 0, stream, c->S->d_hits.p, c->S->d_totals.p, dm, (int)k, hits_dev, totals_dev);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(stream));  // staging / scratch buffers are reused by the next group
   return RGPU_OK;
@@ -772,6 +817,7 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
   std::vector<Group> groups(3);
   int cur_group[3] = {0, 1, 2};
   for (int i = 0; i < 3; ++i) groups[(size_t)i].op = i;
+  std::vector<DevTerm> mine;
   for (int32_t q = 0; q < n_queries; ++q) {
     const rgpu_query& Q = queries[q];
     if (Q.op == RGPU_OP_OR && groups[(size_t)cur_group[2]].postings > or_postings_cap) {
@@ -785,7 +831,7 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
     dq.first_term = (int32_t)G.terms.size();
     dq.n_terms = 0;
     dq.pad = 0;
-    std::vector<DevTerm> mine;
+    mine.clear();
     bool dead = false;
     for (int i = 0; i < Q.n_terms; ++i) {
       const rgpu_query_term& t = terms[Q.first_term + i];
@@ -824,6 +870,7 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
       if (rc_or != RGPU_OK) return rc_or;
       continue;
     }
+    HIP_TRY(scratch_take(c));
     const bool lead_driven = op == RGPU_OP_TERM || (op == RGPU_OP_AND && !c->cfg.reserved[1]);
     int blocks_per_item = op == RGPU_OP_TERM ? c->cfg.blocks_per_item : c->cfg.reserved[0];
     int W = c->cfg.window_docs, wpq = 0, wpi = 1, ipq = 0;
@@ -867,30 +914,30 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
     const size_t o_t = st.add(std::max<size_t>(1, G.terms.size()) * sizeof(DevTerm));
     const size_t o_p = st.add((size_t)(nq + 1) * 8);
     const size_t o_m = st.add((size_t)nq * 4);
-    HIP_TRY(c->h_stage.reserve(st.used));
-    HIP_TRY(c->d_stage.reserve(st.used, 0, stream));
-    std::memcpy(c->h_stage.p + o_q, G.queries.data(), (size_t)nq * sizeof(DevQuery));
-    if (!G.terms.empty()) std::memcpy(c->h_stage.p + o_t, G.terms.data(), G.terms.size() * sizeof(DevTerm));
-    std::memcpy(c->h_stage.p + o_p, G.item_prefix.data(), (size_t)(nq + 1) * 8);
-    std::memcpy(c->h_stage.p + o_m, G.qmap.data(), (size_t)nq * 4);
-    HIP_TRY(hipMemcpyAsync(c->d_stage.p, c->h_stage.p, st.used, hipMemcpyHostToDevice, stream));
-    HIP_TRY(c->d_partial_keys.reserve((size_t)items * (size_t)k, 0, stream));
-    HIP_TRY(c->d_partial_counts.reserve((size_t)items, 0, stream));
-    HIP_TRY(c->d_hits.reserve((size_t)nq * (size_t)k, 0, stream));
-    HIP_TRY(c->d_totals.reserve((size_t)nq, 0, stream));
-    HIP_TRY(c->d_tau.reserve((size_t)nq, 0, stream));
-    HIP_TRY(hipMemsetAsync(c->d_tau.p, 0, (size_t)nq * 8, stream));
-    const DevQuery* dq = reinterpret_cast<const DevQuery*>(c->d_stage.p + o_q);
-    const DevTerm* dt = reinterpret_cast<const DevTerm*>(c->d_stage.p + o_t);
-    const int64_t* dp = reinterpret_cast<const int64_t*>(c->d_stage.p + o_p);
-    const int32_t* dm = reinterpret_cast<const int32_t*>(c->d_stage.p + o_m);
+    HIP_TRY(c->S->h_stage.reserve(st.used));
+    HIP_TRY(c->S->d_stage.reserve(st.used, 0, stream));
+    std::memcpy(c->S->h_stage.p + o_q, G.queries.data(), (size_t)nq * sizeof(DevQuery));
+    if (!G.terms.empty()) std::memcpy(c->S->h_stage.p + o_t, G.terms.data(), G.terms.size() * sizeof(DevTerm));
+    std::memcpy(c->S->h_stage.p + o_p, G.item_prefix.data(), (size_t)(nq + 1) * 8);
+    std::memcpy(c->S->h_stage.p + o_m, G.qmap.data(), (size_t)nq * 4);
+    HIP_TRY(hipMemcpyAsync(c->S->d_stage.p, c->S->h_stage.p, st.used, hipMemcpyHostToDevice, stream));
+    HIP_TRY(c->S->d_partial_keys.reserve((size_t)items * (size_t)k, 0, stream));
+    HIP_TRY(c->S->d_partial_counts.reserve((size_t)items, 0, stream));
+    HIP_TRY(c->S->d_hits.reserve((size_t)nq * (size_t)k, 0, stream));
+    HIP_TRY(c->S->d_totals.reserve((size_t)nq, 0, stream));
+    HIP_TRY(c->S->d_tau.reserve((size_t)nq, 0, stream));
+    HIP_TRY(hipMemsetAsync(c->S->d_tau.p, 0, (size_t)nq * 8, stream));
+    const DevQuery* dq = reinterpret_cast<const DevQuery*>(c->S->d_stage.p + o_q);
+    const DevTerm* dt = reinterpret_cast<const DevTerm*>(c->S->d_stage.p + o_t);
+    const int64_t* dp = reinterpret_cast<const int64_t*>(c->S->d_stage.p + o_p);
+    const int32_t* dm = reinterpret_cast<const int32_t*>(c->S->d_stage.p + o_m);
     const SegView sv = seg_view(seg);
     if (op == RGPU_OP_AND && lead_driven) {
       TimedLaunch tl(c, stream, "k_search_and", G.postings);
       const unsigned grid = (unsigned)((items + WG_WAVES - 1) / WG_WAVES);
       auto go = [&](auto kern) {
         hipLaunchKernelGGL(kern, dim3(grid), dim3(WG_THREADS), 0, stream, sv, dq, dt, dp, nq, items, blocks_per_item, (int)k,
-                           c->d_partial_keys.p, c->d_partial_counts.p, c->d_tau.p);
+                           c->S->d_partial_keys.p, c->S->d_partial_counts.p, c->S->d_tau.p);
       };
       if (legacy) { if (wide) go(k_search_and<true, true>); else go(k_search_and<true, false>); }
       else { if (wide) go(k_search_and<false, true>); else go(k_search_and<false, false>); }
@@ -902,7 +949,7 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(TERM_THREADS), lds, stream, sv, dq, dt, dp, nq, items, blocks_per_item, (int)k,
-                           c->d_partial_keys.p, c->d_partial_counts.p, c->d_tau.p);
+                           c->S->d_partial_keys.p, c->S->d_partial_counts.p, c->S->d_tau.p);
         return hipSuccess;
       };
       hipError_t e;
@@ -916,7 +963,7 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3((unsigned)items), dim3(WG_THREADS), lds, stream, sv, dq, dt, nq, wpq, wpi, ipq, W, (int)k,
-                           c->d_partial_keys.p, c->d_partial_counts.p);
+                           c->S->d_partial_keys.p, c->S->d_partial_counts.p);
         return hipSuccess;
       };
       hipError_t e;
@@ -929,13 +976,12 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
       }
       HIP_TRY(e);
     }
-    if (wide) launch_merge<true>(c, stream, nq, k, dp, seg->doc_base, c->d_hits.p, c->d_totals.p, head_items);
-    else launch_merge<false>(c, stream, nq, k, dp, seg->doc_base, c->d_hits.p, c->d_totals.p, head_items);
+    if (wide) launch_merge<true>(c, stream, nq, k, dp, seg->doc_base, c->S->d_hits.p, c->S->d_totals.p, head_items);
+    else launch_merge<false>(c, stream, nq, k, dp, seg->doc_base, c->S->d_hits.p, c->S->d_totals.p, head_items);
     // scatter group rows to the caller's rows
-    hipLaunchKernelGGL(k_scatter_rows, dim3((unsigned)nq), dim3(128), 0, stream, c->d_hits.p, c->d_totals.p, dm, (int)k, hits_dev, totals_dev);
+    hipLaunchKernelGGL(k_scatter_rows, dim3((unsigned)nq), dim3(128), 0, stream, c->S->d_hits.p, c->S->d_totals.p, dm, (int)k, hits_dev, totals_dev);
     HIP_TRY(hipGetLastError());
-    // d_stage / d_hits are reused by the next group
-    HIP_TRY(hipStreamSynchronize(stream));
+    HIP_TRY(scratch_mark(c, stream));  // no stream sync: the slot is waited for when it is taken again
   }
   return RGPU_OK;
 }
@@ -948,10 +994,9 @@ extern "C" int32_t rgpu_search_batch_device(rgpu_segment* seg, const rgpu_query*
   std::lock_guard<std::mutex> g(seg->ctx->mu);
   HIP_TRY(hipSetDevice(seg->ctx->device));
   hipStream_t s = hip_stream ? (hipStream_t)hip_stream : seg->ctx->stream;
-  int32_t rc = search_impl(seg, queries, n_queries, terms, n_terms_total, k, (HitOut*)hits_dev, (int64_t*)totals_dev, s);
-  if (rc != RGPU_OK) return rc;
-  HIP_TRY(hipStreamSynchronize(s));
-  return RGPU_OK;
+  // enqueue only: TERM / AND batches return without waiting for the GPU (the caller synchronizes the stream, or
+  // calls rgpu_synchronize for the context's own, before it reads the outputs)
+  return search_impl(seg, queries, n_queries, terms, n_terms_total, k, (HitOut*)hits_dev, (int64_t*)totals_dev, s);
 }
 
 extern "C" int32_t rgpu_search_batch(rgpu_segment* seg, const rgpu_query* queries, int32_t n_queries, const rgpu_query_term* terms,
@@ -997,8 +1042,7 @@ extern "C" int32_t rgpu_merge_topk_device(rgpu_ctx* c, const void* hits_dev, con
                          n_lists, n_queries, k, (HitOut*)hits_out_dev, (int64_t*)totals_out_dev);
   }
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(s));
-  return RGPU_OK;
+  return RGPU_OK;  // enqueue only, like rgpu_search_batch_device
 }
 
 // ---- host helpers: BM25Similarity (no GPU involved) ------------------------------------------------------------

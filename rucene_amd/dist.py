@@ -39,7 +39,12 @@ def hip_merge(ctx):
         world, nq, k = hits_all.shape
         out_h = torch.empty((nq, k), dtype=torch.int64, device=hits_all.device)
         out_t = torch.empty((nq,), dtype=torch.int64, device=hits_all.device)
-        torch.cuda.current_stream().synchronize()  # the collective's output must be complete before our stream reads it
-        ctx.merge_topk_device(hits_all.data_ptr(), totals_all.data_ptr(), world, nq, k, out_h.data_ptr(), out_t.data_ptr())
+        stream = torch.cuda.current_stream().cuda_stream
+        if stream:  # a real (non-default) torch stream: the merge is simply enqueued behind the collective
+            ctx.merge_topk_device(hits_all.data_ptr(), totals_all.data_ptr(), world, nq, k, out_h.data_ptr(), out_t.data_ptr(), stream)
+        else:       # default stream: the ctx has its own, so fence on both sides
+            torch.cuda.current_stream().synchronize()
+            ctx.merge_topk_device(hits_all.data_ptr(), totals_all.data_ptr(), world, nq, k, out_h.data_ptr(), out_t.data_ptr())
+            ctx.synchronize()
         return out_h, out_t
     return merge

@@ -222,6 +222,7 @@ class GpuIndexSearcher:
         out_t = torch.empty((n_queries,), dtype=torch.int64, device="cuda")
         torch.cuda.synchronize()
         self.ctx.merge_topk_device(hits.data_ptr(), totals.data_ptr(), len(per_leaf), n_queries, k, out_h.data_ptr(), out_t.data_ptr())
+        self.ctx.synchronize()  # the merge is only enqueued (on the ctx's stream)
         return out_h.cpu().numpy().view(_lib.HIT_DTYPE).reshape(n_queries, k), out_t.cpu().numpy()
 
     def search(self, query, collector):
