@@ -88,6 +88,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_score_terms(SegView seg, const D
 }
 
 constexpr int OR_MAX_TERMS = 16;
+constexpr uint32_t OR_UNTOUCHED = 0xffffffffu;
 
 // items = (query, group of `windows_per_item` windows of `W` docs), one per wavefront
 template <bool WIDE>
@@ -103,11 +104,11 @@ __global__ __launch_bounds__(WG_THREADS) void k_or_windows(SegView seg, const De
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int lane = lane_id();
   const int wave = wave_id();
-  // per-wave LDS slice: acc[W] f32 | hits[W] u16 (window offsets of touched docs, in first-touch order) |
-  // gen[W] u8 (a doc's accumulator is live in this window iff gen[o] == the window's generation)
-  float* acc = reinterpret_cast<float*>(smem + (size_t)wave * (size_t)W * 7);
+  // per-wave LDS slice: acc[W] f32 | hits[W] u16 (window offsets of touched docs, in first-touch order). An
+  // untouched accumulator holds OR_UNTOUCHED, a NaN pattern no sum of scores produces; the hit scan at the end
+  // of a window puts it back, so no per-doc flag array and no clearing pass are needed.
+  float* acc = reinterpret_cast<float*>(smem + (size_t)wave * (size_t)W * 6);
   uint16_t* hits = reinterpret_cast<uint16_t*>(acc + W);
-  uint8_t* gen = reinterpret_cast<uint8_t*>(hits + W);
   const int64_t item = (int64_t)blockIdx.x * WG_WAVES + wave;
   if (item >= (int64_t)n_queries * items_per_query) return;
   const int q = (int)(item / items_per_query);
@@ -142,46 +143,53 @@ __global__ __launch_bounds__(WG_THREADS) void k_or_windows(SegView seg, const De
   }
   int32_t my_next = (mine && my_cur < my_len) ? runs[my_base + my_cur].doc : 0x7fffffff;  // doc under the cursor
 
-  for (int i = lane * 4; i < W; i += 256) *reinterpret_cast<uint32_t*>(gen + i) = 0u;
-  uint32_t generation = 0;
+  for (int i = lane; i < W; i += 64) acc[i] = __uint_as_float(OR_UNTOUCHED);
   wave_sync();
   for (int win = win0; win < win1; ++win) {
     const int32_t w0 = win * W;
     const int32_t w1 = min(seg.max_doc, w0 + W);
-    if (++generation == 256u) {  // 8-bit generations: recycle every 255 windows
-      for (int i = lane * 4; i < W; i += 256) *reinterpret_cast<uint32_t*>(gen + i) = 0u;
-      generation = 1;
-      wave_sync();
-    }
     int nhits = 0;
-    // only clauses with a posting inside this window are visited, in clause order == summation order
-    uint64_t active = __ballot(my_next < w1);
-    while (active) {
-      const int t = __builtin_ctzll(active);
-      active &= active - 1;
+    // only clauses with a posting inside this window are visited, in clause order == summation order. The first
+    // 64 run entries of EVERY such clause are requested up front (one exposed load latency per window instead of
+    // one per clause: the window walk was latency bound), the rare longer stretches are fetched as they come.
+    const uint64_t active0 = __ballot(my_next < w1);
+    ScoredPosting pre[OR_MAX_TERMS];
+#pragma unroll
+    for (int t = 0; t < OR_MAX_TERMS; ++t) {
+      pre[t] = ScoredPosting{0x7fffffff, 0.f};
+      if ((active0 >> t) & 1ull) {  // wave-uniform
+        const int64_t rb = ((int64_t)readlane((int)(uint32_t)(my_base >> 32), t) << 32) | (uint32_t)readlane((int)(uint32_t)my_base, t);
+        const int idx = readlane(my_cur, t) + lane;
+        if (idx < readlane(my_len, t)) pre[t] = runs[rb + idx];
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < OR_MAX_TERMS; ++t) {
+      if (!((active0 >> t) & 1ull)) continue;
       const int64_t rb = ((int64_t)readlane((int)(uint32_t)(my_base >> 32), t) << 32) | (uint32_t)readlane((int)(uint32_t)my_base, t);
       const int len = readlane(my_len, t);
       int cur = readlane(my_cur, t);
       int32_t next;
+      ScoredPosting e = pre[t];
       while (true) {
-        const int idx = cur + lane;
-        ScoredPosting e{0x7fffffff, 0.f};
-        if (idx < len) e = runs[rb + idx];
         bool in = e.doc < w1;
         const int n = __popcll(__ballot(in));  // runs are doc-sorted: the in-window entries are a prefix
         if (in && has_live) in = doc_is_live(seg.live, e.doc);
         bool first = false;
         if (in) {
           const int o = e.doc - w0;
-          first = gen[o] != (uint8_t)generation;
-          acc[o] = (first ? 0.0f : acc[o]) + e.score;  // 0.0f + s: the reference's `score = 0; score += s`
-          gen[o] = (uint8_t)generation;
+          const float a = acc[o];
+          first = __float_as_uint(a) == OR_UNTOUCHED;
+          acc[o] = (first ? 0.0f : a) + e.score;  // 0.0f + s: the reference's `score = 0; score += s`
         }
         const uint64_t fm = __ballot(first);
         if (first) hits[nhits + mbcnt(fm)] = (uint16_t)(e.doc - w0);
         nhits += __popcll(fm);
         cur += n;
         if (n < 64) { next = readlane(e.doc, n); break; }  // the entry now under the cursor (or "none")
+        const int idx = cur + lane;
+        e = ScoredPosting{0x7fffffff, 0.f};
+        if (idx < len) e = runs[rb + idx];
       }
       my_cur = lane == t ? cur : my_cur;
       my_next = lane == t ? next : my_next;
@@ -193,6 +201,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_or_windows(SegView seg, const De
       const bool valid = i0 + lane < nhits;
       const int o = valid ? hits[i0 + lane] : 0;
       const uint64_t key = valid ? make_key(acc[o], w0 + o) : 0ull;
+      if (valid) acc[o] = __uint_as_float(OR_UNTOUCHED);
       if (__ballot(key > tau)) topk_offer<WIDE>(top, key, tau, k, lane, floor);
     }
     wave_sync();

@@ -772,7 +772,7 @@ static int32_t search_or_group(rgpu_segment* seg, Group& G, int32_t k, HitOut* h
   }
   {
     TimedLaunch tl(c, stream, "k_or_windows", G.postings);
-    const size_t lds = (size_t)WG_WAVES * (size_t)W * 7;
+    const size_t lds = (size_t)WG_WAVES * (size_t)W * 6;
     const unsigned grid = (unsigned)((items2 + WG_WAVES - 1) / WG_WAVES);
     auto go = [&](auto kern) -> hipError_t {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
