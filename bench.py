@@ -40,9 +40,10 @@ def term_encoded_bytes(terms, doc_len_end):
 
 
 def profiled_traffic(kernel):
-    """HBM-side bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary under profiles/
-    (FETCH_SIZE + WRITE_SIZE, KiB -> bytes, uncorrected: MI355X_MICROARCH.md notes gfx950's FETCH_SIZE can read 1/2
-    for wide streams). None when no profile of this kernel is committed — bench.py itself never runs rocprof."""
+    """HBM-side bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary under profiles/:
+    2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes. The factor 2 is MI355X_MICROARCH.md's gfx950 correction (FETCH_SIZE
+    tallies the 128-byte requests of wide 16-byte-per-lane streaming reads at 64 bytes — this kernel's row loads);
+    WRITE_SIZE is taken as reported. None when no profile of this kernel is committed — bench.py never runs rocprof."""
     import glob
     import re
     best = None
@@ -58,7 +59,7 @@ def profiled_traffic(kernel):
             if m:
                 write = float(m.group(1))
         if fetch is not None and write is not None:
-            best = {"bytes": (fetch + write) * 1024.0, "source": os.path.relpath(path, ROOT)}
+            best = {"bytes": (2.0 * fetch + write) * 1024.0, "source": os.path.relpath(path, ROOT)}
     return best
 
 

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_score_terms(SegView seg, const D
       s0 = bm25_score(wk, (float)(int32_t)f0, has_norms ? cache[nb0] : k1);
       s1 = bm25_score(wk, (float)(int32_t)f1, has_norms ? cache[nb1] : k1);
     }
-    if (v0) run[slot] = ScoredPosting{d0, s0};
+    if (v0) run[slot] = ScoredPosting{d0, s0};  // (nontemporal stores were tried here: 8% slower — the runs are re-read next)
     if (v1) run[slot + 1] = ScoredPosting{d1, s1};
   };
 

@@ -1,8 +1,13 @@
 #!/bin/bash
+# developer sweep: k_decode_terms prefetch depth (builds variants next to the product library, never replaces it)
 cd $GRAFT_REPO_ROOT
+mkdir -p build_variants
 for d in 1 2 3 4; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -DRGPU_DECODE_DEPTH=$d -o rucene_amd/librucene_gpu.so rucene_amd/csrc/rgpu_api.hip 2>/dev/null
-  echo DEPTH=$d; python - <<'PY'
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -DRGPU_DECODE_DEPTH=$d -o build_variants/dec$d.so rucene_amd/csrc/rgpu_api.hip 2>/dev/null &
+done
+wait
+for d in 1 2 3 4; do
+  echo DEPTH=$d; RUCENE_GPU_LIB=$GRAFT_REPO_ROOT/build_variants/dec$d.so python - <<'PY'
 import os, sys, numpy as np
 sys.path.insert(0, os.getcwd())
 import torch, rucene_amd
@@ -17,7 +22,7 @@ d = torch.empty((total,), dtype=torch.int32, device="cuda"); f = torch.empty((to
 for _ in range(2): leaf.segment.decode_terms_device(sel, d.data_ptr(), f.data_ptr())
 ctx.kernel_stats_reset()
 for _ in range(5): leaf.segment.decode_terms_device(sel, d.data_ptr(), f.data_ptr())
-st = ctx.kernel_stats()["k_decode_terms"]; print(st["total_ms"]/st["launches"])
+st = ctx.kernel_stats()["k_decode_terms"]; print(st["total_ms"]/st["launches"], len(sel), total)
 ctx.close()
 PY
 done
