@@ -1,0 +1,3 @@
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/g9
+timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/g9/pytest.log 2>&1; echo "pytest rc=$?"; tail -25 gpurun_out/g9/pytest.log | cut -c1-300

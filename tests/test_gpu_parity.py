@@ -371,3 +371,67 @@ def test_negative_boost_and_raw_norm_mode(oracle):
                 assert (hits[i]["score"][:d.size].view(np.int32) == s.view(np.int32)).all(), (raw, i)
         finally:
             c.close()
+
+
+def test_tie_heavy_postings_prefer_low_doc_ids(ctx, oracle):
+    """Scores that tie en masse (constant freq x constant norm, or two levels): the canonical order must come out
+    exactly — this is what the TERM kernel's tie-aware entry threshold and its workgroup-shared top-k have to get
+    right across many work items, workgroups and the final merge."""
+    import rucene_amd
+    from rucene_amd import indexgen
+    max_doc = 400_000
+    rng = np.random.default_rng(123)
+    all_docs = np.arange(max_doc, dtype=np.int32)
+    lists = [
+        (all_docs[::2].copy(), np.ones(max_doc // 2, np.int32)),                       # 200k postings, one score
+        (all_docs[1::3].copy(), np.full(len(all_docs[1::3]), 3, np.int32)),            # one score
+        (np.sort(rng.choice(max_doc, 150_000, replace=False)).astype(np.int32), None),  # two score levels
+    ]
+    two = lists[2][0]
+    lists[2] = (two, np.where(rng.random(two.size) < 0.0005, 9, 2).astype(np.int32))
+    norms = np.full(max_doc, 110, np.uint8)
+    seg = indexgen.build_explicit(max_doc, lists, norms=norms)
+    stf = 30 * max_doc
+    oseg = oracle.Segment(seg.doc_bytes, seg.norms, max_doc, seg.terms, sum_total_term_freq=stf)
+    leaf = rucene_amd.LeafReader(seg.doc_bytes, seg.norms, max_doc, seg.terms, sum_total_term_freq=stf)
+    osearcher = oracle.Searcher([oseg])
+    gsearcher = rucene_amd.GpuIndexSearcher([leaf], ctx=ctx)
+    specs = [(oracle.OP_TERM, [t]) for t in range(3)] * 3
+    specs += [(oracle.OP_AND, [0, 2]), (oracle.OP_AND, [1, 2, 0]), (oracle.OP_OR, [0, 1]), (oracle.OP_OR, [2, 1, 0])]
+    for k in (1, 10, 64, 65, 128):
+        _check_against_oracle(oracle, osearcher, gsearcher, specs, k)
+
+
+def test_enqueue_only_device_search_rotates_scratch(zipf, oracle):
+    """rgpu_search_batch_device only enqueues: many back-to-back calls (more than the context has scratch slots)
+    with different batches and output buffers, one synchronize at the end, every batch equal to the blocking API."""
+    import torch
+    import rucene_amd
+    from rucene_amd import indexgen
+    seg, osearcher, gsearcher = zipf
+    leaf = gsearcher.leaves[0]
+    T, B = rucene_amd.TermQuery, rucene_amd.BooleanQuery
+    k = 10
+    batches = []
+    for i in range(11):
+        ranks = indexgen.log_uniform_ranks(3 * 40, 1, 5_000, seed=900 + i).reshape(-1, 3)
+        if i % 3 == 2:
+            qs = [B.build([T(int(r - 1)) for r in row], []) for row in ranks]
+        else:
+            qs = [T(int(row[0] - 1)) for row in ranks] + [T(int(row[1] - 1)) for row in ranks[: 7 * (i + 1)]]
+        batches.append(gsearcher.pack(qs, leaf))
+    outs = []
+    for qp, tp in batches:
+        h = torch.zeros((len(qp), k), dtype=torch.int64, device="cuda")
+        t = torch.zeros((len(qp),), dtype=torch.int64, device="cuda")
+        outs.append((h, t))
+    torch.cuda.synchronize()
+    for (qp, tp), (h, t) in zip(batches, outs):
+        leaf.segment.search_batch_device(qp, tp, k, h.data_ptr(), t.data_ptr())
+    gsearcher.ctx.synchronize()
+    for (qp, tp), (h, t) in zip(batches, outs):
+        want_h, want_t = leaf.segment.search_batch(qp, tp, k)
+        got_h = h.cpu().numpy().view(rucene_amd.HIT_DTYPE).reshape(len(qp), k)
+        assert (got_h["doc"] == want_h["doc"]).all()
+        assert (got_h["score"].view(np.int32) == want_h["score"].view(np.int32)).all()
+        assert (t.cpu().numpy() == want_t).all()
