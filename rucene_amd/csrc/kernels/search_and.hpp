@@ -14,7 +14,10 @@
 namespace rgpu {
 
 // The kernel is latency bound (dependent directory probes and block decodes): occupancy buys more than registers.
-constexpr int AND_WAVES_PER_SIMD = 8;
+#ifndef RGPU_AND_WAVES
+#define RGPU_AND_WAVES 8
+#endif
+constexpr int AND_WAVES_PER_SIMD = RGPU_AND_WAVES;
 
 // first slot in [lo, hi] whose last doc >= target; slot `hi` is returned without being read
 __device__ __forceinline__ int find_block_in(const int32_t* __restrict__ dir_last, uint32_t dir_base, int lo, int hi, int32_t target) {
@@ -139,22 +142,60 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
       int blk0 = a0 ? find_block_in(seg.dir_last, T.dir_base, lo, hi, d0) : 0x7fffffff;
       int blk1 = a1 ? find_block_in(seg.dir_last, T.dir_base, lo, hi, d1) : 0x7fffffff;
       bool p0 = a0, p1 = a1;
-      while (true) {
+      // first pending candidate's block (candidates are sorted across (lane, slot)); INT_MAX when none is pending
+      auto first_pending = [&]() -> int {
         const uint64_t q0 = __ballot(p0), q1 = __ballot(p1);
-        if (!(q0 | q1)) break;
+        if (!(q0 | q1)) return 0x7fffffff;
         const int l0 = q0 ? __builtin_ctzll(q0) : 64, l1 = q1 ? __builtin_ctzll(q1) : 64;
-        const int cur = l0 <= l1 ? readlane(blk0, l0 & 63) : readlane(blk1, l1 & 63);
-        int n_in = 0;
-        if (cur < T.nblocks) {
-          const int32_t base = cur == 0 ? 0 : seg.dir_last[T.dir_base + cur - 1];
-          const BlockPair bp = decode_block<LEGACY>(seg.bstore + T.bs_base, seg.dir_row[T.dir_base + cur],
-                                                     seg.dir_hdr[T.dir_base + cur], slab, lane);
+        return l0 <= l1 ? readlane(blk0, l0 & 63) : readlane(blk1, l1 & 63);
+      };
+      auto probe = [&](bool c0, bool c1, int n_in) {  // lanes whose candidate maps to the block now in bd / bf
+        if (c0) {
+          const int pos = lds_lower_bound(bd, n_in, d0);
+          if (pos < n_in && bd[pos] == d0) s0 += bm25_score(wk, (float)(int32_t)bf[pos], n0); else a0 = false;
+        }
+        if (c1) {
+          const int pos = lds_lower_bound(bd, n_in, d1);
+          if (pos < n_in && bd[pos] == d1) s1 += bm25_score(wk, (float)(int32_t)bf[pos], n1); else a1 = false;
+        }
+      };
+      int cur = first_pending();
+      // FullBlocks, software-pipelined: the rows (and directory words) of the NEXT distinct block are requested
+      // before the current one is decoded and probed — the kernel is bound by this dependent-load chain
+      if (cur < T.nblocks) {
+        const uint8_t* term_rows = seg.bstore + T.bs_base;
+        struct Fetched { uint4 rows; uint32_t hdr; int32_t base; };
+        auto fetch = [&](int b) -> Fetched {
+          Fetched f;
+          f.hdr = seg.dir_hdr[T.dir_base + b];
+          f.base = b == 0 ? 0 : seg.dir_last[T.dir_base + b - 1];
+          f.rows = block_rows_load(block_rows_at(term_rows, seg.dir_row[T.dir_base + b]), f.hdr, lane);
+          return f;
+        };
+        Fetched A = fetch(cur);
+        while (true) {
+          const bool c0 = p0 && blk0 == cur, c1 = p1 && blk1 == cur;
+          p0 = p0 && !c0;
+          p1 = p1 && !c1;
+          const int nxt = first_pending();
+          const bool more = nxt < T.nblocks;
+          const Fetched B = fetch(more ? nxt : cur);  // unconditional: a load behind a branch would serialise the two
+          const BlockPair bp = block_rows_decode<LEGACY>(A.rows, A.hdr, slab, lane);
           int32_t e0, e1;
-          deltas_to_docs(bp.d0, bp.d1, base, e0, e1);
+          deltas_to_docs(bp.d0, bp.d1, A.base, e0, e1);
           bd[2 * lane] = e0; bd[2 * lane + 1] = e1;
           bf[2 * lane] = bp.f0; bf[2 * lane + 1] = bp.f1;
-          n_in = 128;
-        } else if (T.tail_n > 0) {
+          wave_sync();
+          probe(c0, c1, 128);
+          wave_sync();
+          cur = nxt;
+          if (!more) break;
+          A = B;
+        }
+      }
+      if (cur != 0x7fffffff) {  // candidates past the last FullBlock: the VInt tail, or nothing
+        int n_in = 0;
+        if (T.tail_n > 0) {
           const uint32_t toff = T.nblocks ? seg.dir_off[T.dir_base + T.nblocks] : 0u;
           const int32_t base = T.nblocks ? seg.dir_last[T.dir_base + T.nblocks - 1] : 0;
           int32_t e0, e1;
@@ -165,16 +206,7 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
           n_in = T.tail_n;
         }
         wave_sync();
-        if (p0 && blk0 == cur) {
-          const int pos = lds_lower_bound(bd, n_in, d0);
-          if (pos < n_in && bd[pos] == d0) s0 += bm25_score(wk, (float)(int32_t)bf[pos], n0); else a0 = false;
-          p0 = false;
-        }
-        if (p1 && blk1 == cur) {
-          const int pos = lds_lower_bound(bd, n_in, d1);
-          if (pos < n_in && bd[pos] == d1) s1 += bm25_score(wk, (float)(int32_t)bf[pos], n1); else a1 = false;
-          p1 = false;
-        }
+        probe(p0, p1, n_in);
         wave_sync();
       }
     }
