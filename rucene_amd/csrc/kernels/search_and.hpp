@@ -13,11 +13,22 @@
 
 namespace rgpu {
 
+#ifdef RGPU_EXP_COUNT  // developer instrumentation (variant builds only): [0] lead blocks, [1] other-clause block decodes,
+__device__ unsigned long long g_and_dbg[4];  // [2] probed candidates, [3] (lead block, clause) visits
+#define AND_DBG(i, n) do { if (lane == 0) atomicAdd(&g_and_dbg[i], (unsigned long long)(n)); } while (0)
+#else
+#define AND_DBG(i, n) do {} while (0)
+#endif
+
 // The kernel is latency bound (dependent directory probes and block decodes): occupancy buys more than registers.
 #ifndef RGPU_AND_WAVES
 #define RGPU_AND_WAVES 8
 #endif
 constexpr int AND_WAVES_PER_SIMD = RGPU_AND_WAVES;
+#ifndef RGPU_AND_SERIAL
+#define RGPU_AND_SERIAL 8
+#endif
+constexpr int AND_SERIAL_PROBES = RGPU_AND_SERIAL;  // up to this many candidates per block are probed by broadcast
 
 // first slot in [lo, hi] whose last doc >= target; slot `hi` is returned without being read
 __device__ __forceinline__ int find_block_in(const int32_t* __restrict__ dir_last, uint32_t dir_base, int lo, int hi, int32_t target) {
@@ -135,12 +146,34 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
       const int32_t dmin = fl0 <= fl1 ? readlane(d0, fl0 & 63) : readlane(d1, fl1 & 63);
       const int ll0 = m0 ? 63 - __builtin_clzll(m0) : -1, ll1 = m1 ? 63 - __builtin_clzll(m1) : -1;
       const int32_t dmax = ll1 >= ll0 ? readlane(d1, ll1 & 63) : readlane(d0, ll0 & 63);
-      // this clause's cursor only moves forward: lead blocks of an item arrive in doc order
-      const int lo = find_block_wave(seg.dir_last, T.dir_base, readlane(cursor, ti), T.nblocks, dmin, lane);
-      const int hi = find_block_wave(seg.dir_last, T.dir_base, lo, T.nblocks, dmax, lane);
+      // This clause's cursor only moves forward: lead blocks of an item arrive in doc order. Usual case: the 64
+      // directory entries after the cursor (ONE coalesced load) bracket all candidates — they give lo, hi and,
+      // parked in LDS, the per-candidate block search without any further trip to memory. Otherwise the general
+      // wave-cooperative searches and a per-lane search in the directory itself.
+      int lo, hi, blk0, blk1;
+      AND_DBG(3, 1);
+      {
+        const int from = readlane(cursor, ti);
+        const int p = from + lane;
+        const int32_t v = p < T.nblocks ? seg.dir_last[T.dir_base + p] : 0x7fffffff;  // the virtual end slot bounds every doc
+        const uint64_t mlo = __ballot(v >= dmin), mhi = __ballot(v >= dmax);
+        if (from < T.nblocks && mhi) {  // mhi != 0 implies mlo != 0 (dmin <= dmax)
+          lo = from + (int)__builtin_ctzll(mlo);
+          hi = from + (int)__builtin_ctzll(mhi);
+          const int span = hi - lo;  // slots lo .. hi-1 are real and < dmax's slot; slot hi is the answer for the rest
+          if (p >= lo && p < hi) bd[p - lo] = v;
+          wave_sync();
+          blk0 = a0 ? lo + lds_lower_bound(bd, span, d0) : 0x7fffffff;
+          blk1 = a1 ? lo + lds_lower_bound(bd, span, d1) : 0x7fffffff;
+          wave_sync();
+        } else {
+          lo = find_block_wave(seg.dir_last, T.dir_base, from, T.nblocks, dmin, lane);
+          hi = find_block_wave(seg.dir_last, T.dir_base, lo, T.nblocks, dmax, lane);
+          blk0 = a0 ? find_block_in(seg.dir_last, T.dir_base, lo, hi, d0) : 0x7fffffff;
+          blk1 = a1 ? find_block_in(seg.dir_last, T.dir_base, lo, hi, d1) : 0x7fffffff;
+        }
+      }
       cursor = lane == ti ? lo : cursor;
-      int blk0 = a0 ? find_block_in(seg.dir_last, T.dir_base, lo, hi, d0) : 0x7fffffff;
-      int blk1 = a1 ? find_block_in(seg.dir_last, T.dir_base, lo, hi, d1) : 0x7fffffff;
       bool p0 = a0, p1 = a1;
       // first pending candidate's block (candidates are sorted across (lane, slot)); INT_MAX when none is pending
       auto first_pending = [&]() -> int {
@@ -181,13 +214,37 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
           const bool more = nxt < T.nblocks;
           const Fetched B = fetch(more ? nxt : cur);  // unconditional: a load behind a branch would serialise the two
           const BlockPair bp = block_rows_decode<LEGACY>(A.rows, A.hdr, slab, lane);
+          AND_DBG(1, 1);
           int32_t e0, e1;
           deltas_to_docs(bp.d0, bp.d1, A.base, e0, e1);
-          bd[2 * lane] = e0; bd[2 * lane + 1] = e1;
-          bf[2 * lane] = bp.f0; bf[2 * lane + 1] = bp.f1;
-          wave_sync();
-          probe(c0, c1, 128);
-          wave_sync();
+          const uint64_t k0 = __ballot(c0), k1m = __ballot(c1);
+          AND_DBG(2, __popcll(k0) + __popcll(k1m));
+          if (__popcll(k0) + __popcll(k1m) <= AND_SERIAL_PROBES) {
+            // a few candidates (the usual case from the second clause on): broadcast each one and let the 128
+            // decoded docs, still in registers, answer with two compares — no LDS round trips, no per-lane search
+            auto serial = [&](uint64_t km, const int32_t dcand, float& s, bool& alive, float nrm) {
+              while (km) {
+                const int j = __builtin_ctzll(km);
+                km &= km - 1;
+                const int32_t d = readlane(dcand, j);
+                const uint64_t h0 = __ballot(e0 == d), h1 = __ballot(e1 == d);
+                if (h0 | h1) {
+                  const uint32_t fq = h0 ? (uint32_t)readlane((int)bp.f0, __builtin_ctzll(h0)) : (uint32_t)readlane((int)bp.f1, __builtin_ctzll(h1));
+                  if (lane == j) s += bm25_score(wk, (float)(int32_t)fq, nrm);
+                } else if (lane == j) {
+                  alive = false;
+                }
+              }
+            };
+            serial(k0, d0, s0, a0, n0);
+            serial(k1m, d1, s1, a1, n1);
+          } else {
+            bd[2 * lane] = e0; bd[2 * lane + 1] = e1;
+            bf[2 * lane] = bp.f0; bf[2 * lane + 1] = bp.f1;
+            wave_sync();
+            probe(c0, c1, 128);
+            wave_sync();
+          }
           cur = nxt;
           if (!more) break;
           A = B;
@@ -225,6 +282,7 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
     int32_t d0, d1;
     deltas_to_docs(bp.d0, bp.d1, base, d0, d1);
     base = readlane(d1, 63);
+    AND_DBG(0, 1);
     intersect(d0, d1, bp.f0, bp.f1, nn & 0xffu, nn >> 8, true, true);
   }
   if (b1 == L.nblocks) {

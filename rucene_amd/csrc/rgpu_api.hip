@@ -1070,9 +1070,13 @@ extern "C" uint8_t rgpu_bm25_encode_norm(float boost, int32_t field_length) {
 }
 
 #ifdef RGPU_EXP_COUNT
-extern "C" int32_t rgpu_debug_counters(unsigned long long* out4, int32_t reset) {
-  if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_term_dbg), 32) != hipSuccess) return -1;
-  if (reset) { unsigned long long z[4] = {0, 0, 0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_term_dbg), z, 32) != hipSuccess) return -1; }
+extern "C" int32_t rgpu_debug_counters(unsigned long long* out8, int32_t reset) {  // [0..3] TERM, [4..7] AND
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_term_dbg), 32) != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(out8 + 4, HIP_SYMBOL(g_and_dbg), 32) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[4] = {0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_term_dbg), z, 32) != hipSuccess || hipMemcpyToSymbol(HIP_SYMBOL(g_and_dbg), z, 32) != hipSuccess) return -1;
+  }
   return 0;
 }
 #endif

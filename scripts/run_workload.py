@@ -43,8 +43,8 @@ else:
 import ctypes as _C
 _L = _C.CDLL(rucene_amd._lib.lib_path())
 if hasattr(_L, "rgpu_debug_counters"):
-    _o = (_C.c_ulonglong * 4)()
+    _o = (_C.c_ulonglong * 8)()
     _L.rgpu_debug_counters(_o, 0)
-    print("dbg counters", list(_o), "slow frac", _o[1] / max(1, _o[0]))
+    print("dbg counters (whole run, %d launches)" % (reps + 2), list(_o))
 print({n: (v["launches"], round(v["total_ms"] / v["launches"], 4)) for n, v in ctx.kernel_stats().items()})
 ctx.close()
