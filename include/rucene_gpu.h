@@ -88,9 +88,12 @@ typedef enum rgpu_query_op {
 
 typedef struct rgpu_query {
   int32_t op;          /* rgpu_query_op */
-  int32_t n_terms;     /* 1 for TERM, 2..RGPU_MAX_QUERY_TERMS otherwise */
+  int32_t n_terms;     /* positive clauses: 1 for TERM, 1..RGPU_MAX_QUERY_TERMS MUST (AND) / SHOULD (OR) clauses */
   int32_t first_term;  /* index of this query's first clause in the `terms` array */
-  int32_t reserved;
+  int32_t n_must_not;  /* MUST_NOT TermQuery clauses, stored right after the positive ones (weight / sim_table unused):
+                          BooleanWeight::create_scorer wraps the positive scorer in a ReqNotScorer over their union
+                          (query/boolean_query.rs:235-273, scorer/req_not_scorer.rs:20-120). 0 = none;
+                          n_terms + n_must_not <= RGPU_MAX_QUERY_TERMS */
 } rgpu_query;
 
 /* sort_field/collapse_top_docs.rs:22-36 ScoreDoc */

@@ -108,6 +108,10 @@ def _declare(L):
         "orc_searcher_term_weight": (C.c_float, [vp, C.c_int64, C.c_float, f32p]),
         "orc_search": (C.c_int, [vp, C.c_int, i64p, C.c_int, f32p, C.c_int, C.c_int, C.c_int, C.c_int, i32p, f32p, i32p, i64p]),
         "orc_search_batch": (C.c_double, [vp, C.c_int, i32p, i32p, i64p, C.c_int, C.c_int, C.c_int, i32p, f32p, i32p, i64p, u64p]),
+        "orc_search_batch_not": (C.c_double, [vp, C.c_int, i32p, i32p, i64p, i32p, i64p, C.c_int, C.c_int, C.c_int, i32p, f32p, i32p,
+                                              i64p, u64p]),
+        "orc_search_not": (C.c_int, [vp, C.c_int, i64p, C.c_int, i64p, C.c_int, C.c_int, C.c_int, i32p, f32p, i32p, i64p]),
+        "orc_mock_req_not": (C.c_int, [i32p, i32p, C.c_int, i32p, i32p, C.c_int, i32p, C.c_int, i32p, C.c_int]),
         "orc_mock_conjunction": (C.c_int, [i32p, i32p, C.c_int, C.c_int32, i32p, f32p, C.c_int]),
         "orc_mock_conjunction_initial_score": (C.c_float, [i32p, i32p, C.c_int]),
         "orc_mock_disjunction": (C.c_int, [i32p, i32p, C.c_int, C.c_int, i32p, f32p, C.c_int]),
@@ -326,11 +330,37 @@ class Searcher:
                                 max_collect_per_leaf, _p(docs, C.c_int32), _p(scores, C.c_float), C.byref(n), C.byref(total)))
         return docs[:n.value].copy(), scores[:n.value].copy(), total.value
 
-    def search_batch(self, ops, term_offsets, term_ids, k, tie_mode=TIE_CANONICAL, threads=1):
+    def search_not(self, op, term_ids, must_not_ids, k, tie_mode=TIE_CANONICAL):
+        """BooleanQuery with MUST_NOT TermQuery clauses (ReqNotScorer)."""
+        t = np.ascontiguousarray(term_ids, dtype=np.int64)
+        nn = np.ascontiguousarray(must_not_ids, dtype=np.int64)
+        docs = np.zeros(max(k, 1), dtype=np.int32)
+        scores = np.zeros(max(k, 1), dtype=np.float32)
+        n, total = C.c_int32(), C.c_int64()
+        _check(lib().orc_search_not(self._h, op, _p(t, C.c_int64), t.size, _p(nn, C.c_int64), nn.size, k, tie_mode,
+                                    _p(docs, C.c_int32), _p(scores, C.c_float), C.byref(n), C.byref(total)))
+        return docs[:n.value].copy(), scores[:n.value].copy(), total.value
+
+    def search_batch(self, ops, term_offsets, term_ids, k, tie_mode=TIE_CANONICAL, threads=1, not_offsets=None, not_ids=None):
         ops = np.ascontiguousarray(ops, dtype=np.int32)
         offs = np.ascontiguousarray(term_offsets, dtype=np.int32)
         tids = np.ascontiguousarray(term_ids, dtype=np.int64)
         nq = ops.size
+        if not_offsets is not None:
+            noffs = np.ascontiguousarray(not_offsets, dtype=np.int32)
+            nids = np.ascontiguousarray(not_ids, dtype=np.int64)
+            docs = np.full((nq, k), -1, dtype=np.int32)
+            scores = np.zeros((nq, k), dtype=np.float32)
+            counts = np.zeros(nq, dtype=np.int32)
+            totals = np.zeros(nq, dtype=np.int64)
+            visited = np.zeros(nq, dtype=np.uint64)
+            secs = lib().orc_search_batch_not(self._h, nq, _p(ops, C.c_int32), _p(offs, C.c_int32), _p(tids, C.c_int64),
+                                              _p(noffs, C.c_int32), _p(nids, C.c_int64), k, tie_mode, threads, _p(docs, C.c_int32),
+                                              _p(scores, C.c_float), _p(counts, C.c_int32), _p(totals, C.c_int64),
+                                              _p(visited, C.c_uint64))
+            if secs < 0:
+                raise OracleError(lib().orc_last_error().decode())
+            return docs, scores, counts, totals, visited, secs
         docs = np.full((nq, k), -1, dtype=np.int32)
         scores = np.zeros((nq, k), dtype=np.float32)
         counts = np.zeros(nq, dtype=np.int32)
@@ -378,6 +408,18 @@ def mock_disjunction(lists, min_should_match=1):
     n = _check(lib().orc_mock_disjunction(_p(flat, C.c_int32), _p(offs, C.c_int32), len(lists), min_should_match,
                                           _p(docs, C.c_int32), _p(scores, C.c_float), docs.size))
     return docs[:n].tolist(), scores[:n].tolist()
+
+
+def mock_req_not(req_lists, not_lists, targets=()):
+    """ReqNotScorer(Conjunction(req_lists) | the single list, Disjunction(not_lists) | the single list):
+    next() to exhaustion, or advance(t) for each target."""
+    rf, ro = _lists(req_lists)
+    nf, no = _lists(not_lists)
+    tg = np.ascontiguousarray(targets, dtype=np.int32)
+    out = np.zeros(max(1, rf.size + tg.size), dtype=np.int32)
+    n = _check(lib().orc_mock_req_not(_p(rf, C.c_int32), _p(ro, C.c_int32), len(req_lists), _p(nf, C.c_int32), _p(no, C.c_int32),
+                                      len(not_lists), _p(tg, C.c_int32), tg.size, _p(out, C.c_int32), out.size))
+    return out[:n].copy()
 
 
 def mock_topk(docs, k, n_leaves=1, max_collect_per_leaf=0, tie_mode=TIE_RUST_HEAP, use_bulk_scorer=False):

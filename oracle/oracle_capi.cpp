@@ -237,12 +237,38 @@ int orc_search(orc_searcher* s, int op, const int64_t* term_ids, int n_terms, co
   ORC_CATCH
 }
 
+// same with MUST_NOT TermQuery clauses (boolean_query.rs:235-273 -> ReqNotScorer)
+int orc_search_not(orc_searcher* s, int op, const int64_t* term_ids, int n_terms, const int64_t* not_ids, int n_not, int k,
+                   int tie_mode, int32_t* out_docs, float* out_scores, int32_t* out_n, int64_t* out_total) {
+  ORC_TRY
+  Query q = make_query(op, term_ids, n_terms, nullptr, 0);
+  q.must_not_ids.assign(not_ids, not_ids + n_not);
+  SearchResult r = s->s.search(q, (size_t)k, tie_mode);
+  *out_n = (int32_t)r.hits.size();
+  *out_total = r.total_hits;
+  for (size_t i = 0; i < r.hits.size(); i++) { out_docs[i] = r.hits[i].doc; out_scores[i] = r.hits[i].score; }
+  return 0;
+  ORC_CATCH
+}
+
 // Batch: one query per task, `threads` worker threads pulling from a shared counter (Rucene: one core per
 // query per segment, searcher shared across threads — searcher.rs:527-630 falls back to sequential search
 // for a single large segment). Returns elapsed seconds; fills per-query outputs.
+double orc_search_batch_not(orc_searcher* s, int n_queries, const int32_t* ops, const int32_t* term_offsets,
+                            const int64_t* term_ids, const int32_t* not_offsets, const int64_t* not_ids, int k, int tie_mode,
+                            int threads, int32_t* out_docs, float* out_scores, int32_t* out_counts, int64_t* out_totals,
+                            uint64_t* out_visited);
 double orc_search_batch(orc_searcher* s, int n_queries, const int32_t* ops, const int32_t* term_offsets,
                         const int64_t* term_ids, int k, int tie_mode, int threads, int32_t* out_docs, float* out_scores,
                         int32_t* out_counts, int64_t* out_totals, uint64_t* out_visited) {
+  return orc_search_batch_not(s, n_queries, ops, term_offsets, term_ids, nullptr, nullptr, k, tie_mode, threads, out_docs,
+                              out_scores, out_counts, out_totals, out_visited);
+}
+// not_offsets / not_ids: per-query MUST_NOT term ids (null = none)
+double orc_search_batch_not(orc_searcher* s, int n_queries, const int32_t* ops, const int32_t* term_offsets,
+                            const int64_t* term_ids, const int32_t* not_offsets, const int64_t* not_ids, int k, int tie_mode,
+                            int threads, int32_t* out_docs, float* out_scores, int32_t* out_counts, int64_t* out_totals,
+                            uint64_t* out_visited) {
   std::atomic<int> next_q{0};
   std::atomic<int> failed{0};
   auto t0 = std::chrono::steady_clock::now();
@@ -252,7 +278,9 @@ double orc_search_batch(orc_searcher* s, int n_queries, const int32_t* ops, cons
       if (qi >= n_queries) break;
       try {
         int n_terms = term_offsets[qi + 1] - term_offsets[qi];
-        SearchResult r = s->s.search(make_query(ops[qi], term_ids + term_offsets[qi], n_terms, nullptr, 0), (size_t)k, tie_mode);
+        Query q = make_query(ops[qi], term_ids + term_offsets[qi], n_terms, nullptr, 0);
+        if (not_offsets) q.must_not_ids.assign(not_ids + not_offsets[qi], not_ids + not_offsets[qi + 1]);
+        SearchResult r = s->s.search(q, (size_t)k, tie_mode);
         out_counts[qi] = (int32_t)r.hits.size();
         out_totals[qi] = r.total_hits;
         if (out_visited) out_visited[qi] = r.postings_visited;
@@ -304,6 +332,30 @@ int orc_mock_disjunction(const int32_t* docs, const int32_t* list_offsets, int n
   int n = 0;
   int32_t d = c.next();
   while (d != NO_MORE_DOCS && n < max_out) { out_docs[n] = d; out_scores[n] = c.score(); n++; d = c.next(); }
+  return n;
+  ORC_CATCH
+}
+// req_not_scorer.rs:126-165: ReqNotScorer(ConjunctionScorer(req lists), DisjunctionSumScorer(not lists, true, 0)).
+// n_targets == 0: emits next() until the end; else emits advance(target) for each target in turn.
+int orc_mock_req_not(const int32_t* req_docs, const int32_t* req_offsets, int n_req, const int32_t* not_docs,
+                     const int32_t* not_offsets, int n_not, const int32_t* targets, int n_targets, int32_t* out_docs,
+                     int max_out) {
+  ORC_TRY
+  std::vector<ScorerBox> rq, nt;
+  for (int i = 0; i < n_req; i++)
+    rq.emplace_back(new MockScorer(std::vector<int32_t>(req_docs + req_offsets[i], req_docs + req_offsets[i + 1])));
+  for (int i = 0; i < n_not; i++)
+    nt.emplace_back(new MockScorer(std::vector<int32_t>(not_docs + not_offsets[i], not_docs + not_offsets[i + 1])));
+  ScorerBox req = rq.size() == 1 ? std::move(rq[0]) : ScorerBox(new ConjunctionScorer(std::move(rq)));
+  ScorerBox nots = nt.size() == 1 ? std::move(nt[0]) : ScorerBox(new DisjunctionSumScorer(std::move(nt), true, 0));
+  ReqNotScorer sc(std::move(req), std::move(nots));
+  if (sc.doc_id() != -1) throw OracleError(E_ILLEGAL_STATE, "ReqNotScorer must start unpositioned");
+  int n = 0;
+  if (n_targets == 0) {
+    for (int32_t d = sc.next(); d != NO_MORE_DOCS && n < max_out; d = sc.next()) out_docs[n++] = d;
+  } else {
+    for (int i = 0; i < n_targets && n < max_out; i++) out_docs[n++] = sc.advance(targets[i]);
+  }
   return n;
   ORC_CATCH
 }

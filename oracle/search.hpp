@@ -415,6 +415,61 @@ struct DisjunctionSumScorer : Scorer {
   }
 };
 
+// scorer/req_not_scorer.rs:20-120 — required scorer minus the docs of a prohibited one; scores are the required
+// scorer's. PINNED by the reference's own tests (req_not_scorer.rs:126-165, tests/test_oracle_kat.py).
+struct ReqNotScorer : Scorer {
+  ScorerBox req_scorer, not_scorer;
+  ReqNotScorer(ScorerBox req, ScorerBox nots) : req_scorer(std::move(req)), not_scorer(std::move(nots)) {}
+  float score() override { return req_scorer->score(); }  // :36-40
+  int32_t doc_id() const override { return req_scorer->doc_id(); }
+  int32_t next() override {  // :47-63
+    while (true) {
+      const int32_t doc = req_scorer->next();
+      if (doc == NO_MORE_DOCS) break;
+      if (doc == not_scorer->doc_id()) continue;
+      else if (doc < not_scorer->doc_id()) return doc;
+      const int32_t not_doc = not_scorer->advance(doc);
+      if (doc < not_doc) return doc;
+    }
+    return NO_MORE_DOCS;
+  }
+  int32_t advance(int32_t target) override {  // :65-78
+    const int32_t doc = req_scorer->advance(target);
+    if (doc < NO_MORE_DOCS) {
+      while (true) {
+        if (doc == not_scorer->doc_id()) return next();
+        else if (doc < not_scorer->doc_id()) return doc;
+        not_scorer->advance(doc);
+      }
+    }
+    return NO_MORE_DOCS;
+  }
+  size_t cost() const override { return req_scorer->cost(); }
+  int32_t approximate_next() override {  // :88-104
+    while (true) {
+      const int32_t doc = req_scorer->approximate_next();
+      if (doc == NO_MORE_DOCS) break;
+      if (doc == not_scorer->doc_id()) continue;
+      else if (doc < not_scorer->doc_id()) return doc;
+      const int32_t not_doc = not_scorer->approximate_advance(doc);
+      if (doc < not_doc) return doc;
+    }
+    return NO_MORE_DOCS;
+  }
+  int32_t approximate_advance(int32_t target) override {  // :106-119
+    const int32_t doc = req_scorer->approximate_advance(target);
+    if (doc < NO_MORE_DOCS) {
+      while (true) {
+        if (doc == not_scorer->doc_id()) return approximate_next();
+        else if (doc < not_scorer->doc_id()) return doc;
+        not_scorer->approximate_advance(doc);
+      }
+    }
+    return NO_MORE_DOCS;
+  }
+  uint64_t postings_visited() const override { return req_scorer->postings_visited() + not_scorer->postings_visited(); }
+};
+
 // ---- TopDocsCollector --------------------------------------------------------------------------------------------
 
 struct ScoreDoc { int32_t doc; float score; };
@@ -566,6 +621,7 @@ struct Query {
   std::vector<int64_t> term_ids;
   std::vector<float> boosts;
   int32_t min_should_match = 0;
+  std::vector<int64_t> must_not_ids;  // MUST_NOT TermQuery clauses (boolean_query.rs:33), scored with needs_scores = false
 };
 
 struct SearchResult {
@@ -627,8 +683,9 @@ struct IndexSearcher {
     if (term_id < 0 || term_id >= seg->n_terms || seg->terms[term_id].doc_freq <= 0) return nullptr;
     return ScorerBox(new TermScorer(seg->reader.get(), seg->terms[term_id], w, seg->norms));
   }
-  // boolean_query.rs:195-279 restricted to pure-MUST and pure-SHOULD trees of TermQuery
-  ScorerBox create_scorer(const Segment* seg, const Query& q, const std::vector<BM25Weight>& weights) const {
+  // boolean_query.rs:195-279 restricted to trees of TermQuery clauses: MUST only, SHOULD only, each optionally
+  // with MUST_NOT clauses (MUST + SHOULD -> ReqOptScorer is not restated: its score() carries sequential state)
+  ScorerBox positive_scorer(const Segment* seg, const Query& q, const std::vector<BM25Weight>& weights) const {
     if (q.op == OP_TERM) return term_scorer(seg, q.term_ids[0], &weights[0]);
     std::vector<ScorerBox> scorers;
     for (size_t i = 0; i < q.term_ids.size(); i++) {
@@ -637,7 +694,8 @@ struct IndexSearcher {
       else if (q.op == OP_AND) return nullptr;
     }
     if (q.op == OP_AND) {
-      // BooleanQuery::build collapses a single-clause query to the clause itself (boolean_query.rs:66-75)
+      // BooleanQuery::build collapses a single-clause query to the clause itself (boolean_query.rs:66-75);
+      // with MUST_NOT clauses the single MUST scorer is used as is (boolean_query.rs:209-213)
       if (scorers.size() == 1) return std::move(scorers[0]);
       return ScorerBox(new ConjunctionScorer(std::move(scorers)));
     }
@@ -645,11 +703,32 @@ struct IndexSearcher {
     int32_t msm = q.min_should_match > 0 ? q.min_should_match : 1;  // boolean_query.rs:47-55
     return ScorerBox(new DisjunctionSumScorer(std::move(scorers), true, msm));
   }
+  ScorerBox create_scorer(const Segment* seg, const Query& q, const std::vector<BM25Weight>& weights) const {
+    ScorerBox positive = positive_scorer(seg, q, weights);
+    if (!positive || q.must_not_ids.empty()) return positive;
+    // boolean_query.rs:235-252: absent terms drop out; one scorer is used directly, several are united by a
+    // DisjunctionSumScorer(needs_scores = false, the query's min_should_match: 0 with MUST clauses, else 1)
+    std::vector<ScorerBox> nots;
+    for (size_t i = 0; i < q.must_not_ids.size(); i++) {
+      ScorerBox s = term_scorer(seg, q.must_not_ids[i], &weights[q.term_ids.size() + i]);
+      if (s) nots.push_back(std::move(s));
+    }
+    if (nots.empty()) return positive;
+    ScorerBox prohibited;
+    if (nots.size() == 1) {
+      prohibited = std::move(nots[0]);
+    } else {
+      const int32_t msm = q.min_should_match > 0 ? q.min_should_match : (q.op == OP_OR ? 1 : 0);
+      prohibited.reset(new DisjunctionSumScorer(std::move(nots), false, msm));
+    }
+    return ScorerBox(new ReqNotScorer(std::move(positive), std::move(prohibited)));  // boolean_query.rs:264-273
+  }
   // searcher.rs:487-525
   SearchResult search(const Query& q, size_t k, int tie_mode, int max_collect_per_leaf = 0) const {
     std::vector<BM25Weight> weights;
     for (size_t i = 0; i < q.term_ids.size(); i++)
       weights.push_back(term_weight(q.term_ids[i], q.boosts.empty() ? 1.0f : q.boosts[i]));
+    for (size_t i = 0; i < q.must_not_ids.size(); i++) weights.push_back(term_weight(q.must_not_ids[i], 1.0f));
     TopDocsCollector collector(k, tie_mode);
     SearchResult r;
     for (auto* seg : leaves) {

@@ -17,7 +17,7 @@ TERM_STATE_DTYPE = np.dtype(
     [("doc_start_fp", "<i8"), ("skip_offset", "<i8"), ("total_term_freq", "<i8"), ("doc_freq", "<i4"),
      ("singleton_doc_id", "<i4")], align=True)
 QUERY_TERM_DTYPE = np.dtype([("state", TERM_STATE_DTYPE), ("weight", "<f4"), ("sim_table", "<i4")], align=True)
-QUERY_DTYPE = np.dtype([("op", "<i4"), ("n_terms", "<i4"), ("first_term", "<i4"), ("reserved", "<i4")], align=True)
+QUERY_DTYPE = np.dtype([("op", "<i4"), ("n_terms", "<i4"), ("first_term", "<i4"), ("n_must_not", "<i4")], align=True)
 HIT_DTYPE = np.dtype([("doc", "<i4"), ("score", "<f4")], align=True)
 assert TERM_STATE_DTYPE.itemsize == 32 and QUERY_TERM_DTYPE.itemsize == 40 and QUERY_DTYPE.itemsize == 16 and HIT_DTYPE.itemsize == 8
 

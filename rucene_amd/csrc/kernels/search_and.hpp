@@ -81,7 +81,8 @@ __device__ __forceinline__ int lds_lower_bound(const int32_t* a, int n, int32_t 
   return lo;
 }
 
-template <bool LEGACY, bool WIDE>
+// HAS_NOT: some query of the launch carries MUST_NOT clauses (a second instantiation keeps the common kernel lean)
+template <bool LEGACY, bool WIDE, bool HAS_NOT>
 __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(SegView seg, const DevQuery* __restrict__ queries,
                                                            const DevTerm* __restrict__ terms,
                                                            const int64_t* __restrict__ item_prefix, int n_queries,
@@ -128,17 +129,28 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
     float wk = L.weight * (k1 + 1.0f);
     float s0 = bm25_score(wk, (float)(int32_t)f0, has_norms ? cache[nb0] : k1);
     float s1 = bm25_score(wk, (float)(int32_t)f1, has_norms ? cache[nb1] : k1);
-    for (int ti = 1; ti < Q.n_terms; ++ti) {
+    // clauses 1 .. n_terms-1 are required (MUST), the n_not after them prohibited (MUST_NOT: ReqNotScorer,
+    // req_not_scorer.rs:47-63 — a candidate found there dies, nothing is scored)
+    const int n_clauses = HAS_NOT ? Q.n_terms + Q.pad : Q.n_terms;
+    for (int ti = 1; ti < n_clauses; ++ti) {
       const uint64_t m0 = __ballot(a0), m1 = __ballot(a1);
       if (!(m0 | m1)) break;
+      const bool excl = HAS_NOT && ti >= Q.n_terms;  // wave-uniform
       const DevTerm T = terms[Q.first_term + ti];
-      use_table(T.sim_table);
-      wk = T.weight * (k1 + 1.0f);
+      if (!excl) {
+        use_table(T.sim_table);
+        wk = T.weight * (k1 + 1.0f);
+      }
       const float n0 = has_norms ? cache[nb0] : k1;
       const float n1 = has_norms ? cache[nb1] : k1;
+      // what finding / missing a candidate in this clause means
+      auto found = [&](bool& alive, float& s, uint32_t fq, float nrm) {
+        if (excl) alive = false; else s += bm25_score(wk, (float)(int32_t)fq, nrm);
+      };
+      auto missed = [&](bool& alive) { if (!excl) alive = false; };
       if (T.df == 1) {
-        if (a0) { if (d0 == T.singleton_doc) s0 += bm25_score(wk, (float)T.singleton_freq, n0); else a0 = false; }
-        if (a1) { if (d1 == T.singleton_doc) s1 += bm25_score(wk, (float)T.singleton_freq, n1); else a1 = false; }
+        if (a0) { if (d0 == T.singleton_doc) found(a0, s0, (uint32_t)T.singleton_freq, n0); else missed(a0); }
+        if (a1) { if (d1 == T.singleton_doc) found(a1, s1, (uint32_t)T.singleton_freq, n1); else missed(a1); }
         continue;
       }
       // candidates are sorted across (lane, slot): first / last live candidate bracket the directory range
@@ -185,11 +197,11 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
       auto probe = [&](bool c0, bool c1, int n_in) {  // lanes whose candidate maps to the block now in bd / bf
         if (c0) {
           const int pos = lds_lower_bound(bd, n_in, d0);
-          if (pos < n_in && bd[pos] == d0) s0 += bm25_score(wk, (float)(int32_t)bf[pos], n0); else a0 = false;
+          if (pos < n_in && bd[pos] == d0) found(a0, s0, bf[pos], n0); else missed(a0);
         }
         if (c1) {
           const int pos = lds_lower_bound(bd, n_in, d1);
-          if (pos < n_in && bd[pos] == d1) s1 += bm25_score(wk, (float)(int32_t)bf[pos], n1); else a1 = false;
+          if (pos < n_in && bd[pos] == d1) found(a1, s1, bf[pos], n1); else missed(a1);
         }
       };
       int cur = first_pending();
@@ -230,9 +242,9 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
                 const uint64_t h0 = __ballot(e0 == d), h1 = __ballot(e1 == d);
                 if (h0 | h1) {
                   const uint32_t fq = h0 ? (uint32_t)readlane((int)bp.f0, __builtin_ctzll(h0)) : (uint32_t)readlane((int)bp.f1, __builtin_ctzll(h1));
-                  if (lane == j) s += bm25_score(wk, (float)(int32_t)fq, nrm);
+                  if (lane == j) found(alive, s, fq, nrm);
                 } else if (lane == j) {
-                  alive = false;
+                  missed(alive);
                 }
               }
             };

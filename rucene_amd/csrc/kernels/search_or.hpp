@@ -88,10 +88,12 @@ __global__ __launch_bounds__(WG_THREADS) void k_score_terms(SegView seg, const D
 }
 
 constexpr int OR_MAX_TERMS = 16;
-constexpr uint32_t OR_UNTOUCHED = 0xffffffffu;
+constexpr uint32_t OR_UNTOUCHED = 0xffffffffu;  // accumulator patterns no sum of scores produces (negative quiet NaNs)
+constexpr uint32_t OR_EXCLUDED = 0xfffffffeu;
 
 // items = (query, group of `windows_per_item` windows of `W` docs), one per wavefront
-template <bool WIDE>
+// HAS_NOT: some query of the launch carries MUST_NOT clauses (a second instantiation keeps the common kernel lean)
+template <bool WIDE, bool HAS_NOT>
 __global__ __launch_bounds__(WG_THREADS) void k_or_windows(SegView seg, const DevQuery* __restrict__ queries,
                                                            const DevTerm* __restrict__ terms,
                                                            const int64_t* __restrict__ run_prefix,
@@ -124,11 +126,15 @@ __global__ __launch_bounds__(WG_THREADS) void k_or_windows(SegView seg, const De
   const int win0 = g * windows_per_item;
   const int win1 = Q.n_terms > 0 ? min(windows_per_query, win0 + windows_per_item) : win0;
 
-  // lane t (< n_terms) owns clause t's cursor: run base, length, and the first entry with doc >= this item's
-  // first window — one lane-parallel binary search over all clauses at once
-  const bool mine = lane < Q.n_terms;
-  const int64_t my_base = mine ? run_prefix[Q.first_term + lane] : 0;
-  const int my_len = mine ? terms[Q.first_term + lane].df : 0;
+  // Lane t owns one clause's cursor: run base, length, and the first entry with doc >= this item's first window —
+  // one lane-parallel binary search over all clauses at once. The n_not MUST_NOT clauses (stored after the n_terms
+  // SHOULD clauses) take lanes 0 .. n_not-1 so that a window meets them first: ReqNotScorer over the disjunction
+  // (boolean_query.rs:271-273, req_not_scorer.rs:47-63) — their docs are marked excluded before anything is summed.
+  const int n_not = HAS_NOT ? Q.pad : 0;
+  const bool mine = lane < Q.n_terms + n_not;
+  const int my_clause = lane < n_not ? Q.n_terms + lane : lane - n_not;
+  const int64_t my_base = mine ? run_prefix[Q.first_term + my_clause] : 0;
+  const int my_len = mine ? terms[Q.first_term + my_clause].df : 0;
   int my_cur = 0;
   {
     const int32_t first_doc = win0 * W;
@@ -180,7 +186,11 @@ __global__ __launch_bounds__(WG_THREADS) void k_or_windows(SegView seg, const De
           const int o = e.doc - w0;
           const float a = acc[o];
           first = __float_as_uint(a) == OR_UNTOUCHED;
-          acc[o] = (first ? 0.0f : a) + e.score;  // 0.0f + s: the reference's `score = 0; score += s`
+          if (t < n_not) {  // wave-uniform: a prohibited clause only marks
+            if (first) acc[o] = __uint_as_float(OR_EXCLUDED);
+          } else if (!HAS_NOT || __float_as_uint(a) != OR_EXCLUDED) {
+            acc[o] = (first ? 0.0f : a) + e.score;  // 0.0f + s: the reference's `score = 0; score += s`
+          }
         }
         const uint64_t fm = __ballot(first);
         if (first) hits[nhits + mbcnt(fm)] = (uint16_t)(e.doc - w0);
@@ -195,12 +205,15 @@ __global__ __launch_bounds__(WG_THREADS) void k_or_windows(SegView seg, const De
       my_next = lane == t ? next : my_next;
       wave_sync();
     }
-    // every touched doc is one collected hit
-    count += nhits;
+    // every touched doc that no prohibited clause claimed is one collected hit
+    if (!HAS_NOT) count += nhits;
     for (int i0 = 0; i0 < nhits; i0 += 64) {  // uniform trip count: the offer is a wave-wide operation
       const bool valid = i0 + lane < nhits;
       const int o = valid ? hits[i0 + lane] : 0;
-      const uint64_t key = valid ? make_key(acc[o], w0 + o) : 0ull;
+      const float a = valid ? acc[o] : 0.0f;
+      const bool hit = valid && (!HAS_NOT || __float_as_uint(a) != OR_EXCLUDED);
+      if (HAS_NOT) count += __popcll(__ballot(hit));
+      const uint64_t key = hit ? make_key(a, w0 + o) : 0ull;
       if (valid) acc[o] = __uint_as_float(OR_UNTOUCHED);
       if (__ballot(key > tau)) topk_offer<WIDE>(top, key, tau, k, lane, floor);
     }

@@ -65,9 +65,9 @@ struct PrepTerm {
 
 struct DevQuery {
   int32_t op;
-  int32_t n_terms;
+  int32_t n_terms;     // positive clauses (MUST or SHOULD) that exist in this leaf
   int32_t first_term;
-  int32_t pad;
+  int32_t pad;         // n_not: MUST_NOT clauses, stored right after the positive ones
 };
 
 }  // namespace rgpu

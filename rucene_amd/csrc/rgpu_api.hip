@@ -22,6 +22,7 @@
 using namespace rgpu;
 
 static_assert(sizeof(HitOut) == sizeof(rgpu_hit), "hit layout");
+static_assert(OR_MAX_TERMS >= RGPU_MAX_QUERY_TERMS, "k_or_windows keeps one cursor per clause in a lane / register slot");
 
 static thread_local std::string g_last_error;
 
@@ -781,7 +782,10 @@ static int32_t search_or_group(rgpu_segment* seg, Group& G, int32_t k, HitOut* h
                          c->S->d_partial_keys.p, c->S->d_partial_counts.p, c->S->d_tau.p);
       return hipSuccess;
     };
-    HIP_TRY(wide ? go(k_or_windows<true>) : go(k_or_windows<false>));
+    bool has_not = false;
+    for (const DevQuery& dq : G.queries) has_not = has_not || dq.pad != 0;
+    if (has_not) HIP_TRY(wide ? go(k_or_windows<true, true>) : go(k_or_windows<false, true>));
+    else HIP_TRY(wide ? go(k_or_windows<true, false>) : go(k_or_windows<false, false>));
   }
   if (wide) launch_merge<true>(c, stream, nq, k, dmp, seg->doc_base, c->S->d_hits.p, c->S->d_totals.p);
   else launch_merge<false>(c, stream, nq, k, dmp, seg->doc_base, c->S->d_hits.p, c->S->d_totals.p);
@@ -800,12 +804,13 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
   for (int32_t q = 0; q < n_queries; ++q) {
     const rgpu_query& Q = queries[q];
     if (Q.op < RGPU_OP_TERM || Q.op > RGPU_OP_OR) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "unknown query op");
-    if (Q.n_terms < 1 || Q.n_terms > RGPU_MAX_QUERY_TERMS || (Q.op == RGPU_OP_TERM && Q.n_terms != 1))
+    if (Q.n_terms < 1 || Q.n_must_not < 0 || Q.n_terms + Q.n_must_not > RGPU_MAX_QUERY_TERMS || (Q.op == RGPU_OP_TERM && Q.n_terms != 1))
       return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "bad clause count");
-    if (Q.first_term < 0 || Q.first_term + Q.n_terms > n_terms_total) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "clause range outside terms[]");
-    for (int i = 0; i < Q.n_terms; ++i) {
+    if (Q.first_term < 0 || Q.first_term + Q.n_terms + Q.n_must_not > n_terms_total)
+      return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "clause range outside terms[]");
+    for (int i = 0; i < Q.n_terms + Q.n_must_not; ++i) {
       const rgpu_query_term& t = terms[Q.first_term + i];
-      if (t.sim_table < 0 || t.sim_table >= c->n_sim_tables) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "unknown sim_table handle");
+      if (i < Q.n_terms && (t.sim_table < 0 || t.sim_table >= c->n_sim_tables)) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "unknown sim_table handle");
       if (t.state.doc_freq > 0) ptrs.push_back(&t.state);
     }
   }
@@ -817,21 +822,11 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
   std::vector<Group> groups(3);
   int cur_group[3] = {0, 1, 2};
   for (int i = 0; i < 3; ++i) groups[(size_t)i].op = i;
-  std::vector<DevTerm> mine;
+  std::vector<DevTerm> mine, mine_not;
   for (int32_t q = 0; q < n_queries; ++q) {
     const rgpu_query& Q = queries[q];
-    if (Q.op == RGPU_OP_OR && groups[(size_t)cur_group[2]].postings > or_postings_cap) {
-      groups.emplace_back();
-      groups.back().op = RGPU_OP_OR;
-      cur_group[2] = (int)groups.size() - 1;
-    }
-    Group& G = groups[(size_t)cur_group[Q.op]];
-    DevQuery dq;
-    dq.op = Q.op;
-    dq.first_term = (int32_t)G.terms.size();
-    dq.n_terms = 0;
-    dq.pad = 0;
     mine.clear();
+    mine_not.clear();
     bool dead = false;
     for (int i = 0; i < Q.n_terms; ++i) {
       const rgpu_query_term& t = terms[Q.first_term + i];
@@ -845,10 +840,34 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
       mine.push_back(dt);
     }
     if (dead) mine.clear();
+    // MUST_NOT clauses (boolean_query.rs:235-252): absent terms drop out; without a positive scorer there is none
+    if (!mine.empty()) {
+      for (int i = 0; i < Q.n_must_not; ++i) {
+        const rgpu_query_term& t = terms[Q.first_term + Q.n_terms + i];
+        if (t.state.doc_freq <= 0) continue;
+        DevTerm dt;
+        rc = make_dev_term(seg, t.state, 0.0f, 0, &dt);  // needs_scores = false: weight and table are never read
+        if (rc != RGPU_OK) return rc;
+        mine_not.push_back(dt);
+      }
+    }
     if (Q.op == RGPU_OP_AND)  // ConjunctionScorer::new: stable sort by cost() = doc_freq (conjunction_scorer.rs:30)
       std::stable_sort(mine.begin(), mine.end(), [](const DevTerm& a, const DevTerm& b) { return a.df < b.df; });
+    // a term with prohibited clauses runs as a one-clause conjunction (the lead-driven kernel probes them)
+    const int gop = (Q.op == RGPU_OP_TERM && !mine_not.empty()) ? (int)RGPU_OP_AND : Q.op;
+    if (gop == RGPU_OP_OR && groups[(size_t)cur_group[2]].postings > or_postings_cap) {
+      groups.emplace_back();
+      groups.back().op = RGPU_OP_OR;
+      cur_group[2] = (int)groups.size() - 1;
+    }
+    Group& G = groups[(size_t)cur_group[gop]];
+    DevQuery dq;
+    dq.op = gop;
+    dq.first_term = (int32_t)G.terms.size();
     dq.n_terms = (int32_t)mine.size();
+    dq.pad = (int32_t)mine_not.size();
     for (auto& m : mine) { G.terms.push_back(m); G.postings += m.df; }
+    for (auto& m : mine_not) { G.terms.push_back(m); G.postings += m.df; }
     G.qmap.push_back(q);
     G.queries.push_back(dq);
   }
@@ -872,6 +891,9 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
     }
     HIP_TRY(scratch_take(c));
     const bool lead_driven = op == RGPU_OP_TERM || (op == RGPU_OP_AND && !c->cfg.reserved[1]);
+    if (!lead_driven)  // the doc-window kernel (A/B knobs reserved[1], [2]) predates MUST_NOT clauses
+      for (const DevQuery& dq : G.queries)
+        if (dq.pad) return fail(RGPU_ERR_UNSUPPORTED, "MUST_NOT clauses are not served by the doc-window kernel");
     int blocks_per_item = op == RGPU_OP_TERM ? c->cfg.blocks_per_item : c->cfg.reserved[0];
     int W = c->cfg.window_docs, wpq = 0, wpi = 1, ipq = 0;
     int64_t items = 0;
@@ -939,8 +961,15 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
         hipLaunchKernelGGL(kern, dim3(grid), dim3(WG_THREADS), 0, stream, sv, dq, dt, dp, nq, items, blocks_per_item, (int)k,
                            c->S->d_partial_keys.p, c->S->d_partial_counts.p, c->S->d_tau.p);
       };
-      if (legacy) { if (wide) go(k_search_and<true, true>); else go(k_search_and<true, false>); }
-      else { if (wide) go(k_search_and<false, true>); else go(k_search_and<false, false>); }
+      bool has_not = false;
+      for (const DevQuery& q : G.queries) has_not = has_not || q.pad != 0;
+      if (has_not) {
+        if (legacy) { if (wide) go(k_search_and<true, true, true>); else go(k_search_and<true, false, true>); }
+        else { if (wide) go(k_search_and<false, true, true>); else go(k_search_and<false, false, true>); }
+      } else {
+        if (legacy) { if (wide) go(k_search_and<true, true, false>); else go(k_search_and<true, false, false>); }
+        else { if (wide) go(k_search_and<false, true, false>); else go(k_search_and<false, false, false>); }
+      }
     } else if (op == RGPU_OP_TERM) {
       TimedLaunch tl(c, stream, "k_search_term", G.postings);
       const unsigned grid = (unsigned)((items + TERM_WAVES - 1) / TERM_WAVES);

@@ -85,10 +85,12 @@ class TermQuery:
 
 
 class BooleanQuery:
-    """Only the trees the GPU path serves: all-MUST (AND) or all-SHOULD with min_should_match 1 (OR)."""
+    """Only the trees the GPU path serves: all-MUST (AND) or all-SHOULD with min_should_match 1 (OR), each
+    optionally with MUST_NOT TermQuery clauses (ReqNotScorer, boolean_query.rs:235-273)."""
 
-    def __init__(self, must_queries, should_queries, min_should_match):
+    def __init__(self, must_queries, should_queries, min_should_match, must_not_queries=()):
         self.must_queries, self.should_queries, self.min_should_match = must_queries, should_queries, min_should_match
+        self.must_not_queries = list(must_not_queries)
 
     @staticmethod
     def build(musts, shoulds, filters=(), must_nots=(), min_should_match=0):
@@ -98,13 +100,15 @@ class BooleanQuery:
             raise RgpuError(-2, "boolean query should at least contain one inner query!")
         if len(must_nots) == 0 and len(musts) + len(shoulds) + len(filters) == 1 and len(filters) == 0:
             return (list(musts) + list(shoulds))[0]
-        if filters or must_nots or (musts and shoulds) or msm > 1:
-            raise RgpuError(-5, "only pure-MUST and pure-SHOULD (min_should_match 1) term trees run on the GPU path")
-        if any(not isinstance(q, TermQuery) for q in list(musts) + list(shoulds)):
+        if filters or (musts and shoulds) or msm > 1:
+            raise RgpuError(-5, "only MUST (+MUST_NOT) and SHOULD (+MUST_NOT, min_should_match 1) term trees run on the GPU path")
+        if len(musts) + len(shoulds) == 0:
+            raise RgpuError(-5, "a MUST_NOT-only query (MatchAllDocsQuery minus ...) is not served by the GPU path")
+        if any(not isinstance(q, TermQuery) for q in list(musts) + list(shoulds) + list(must_nots)):
             raise RgpuError(-5, "nested boolean clauses are not supported on the GPU path")
-        return BooleanQuery(list(musts), list(shoulds), msm)
+        return BooleanQuery(list(musts), list(shoulds), msm, list(must_nots))
 
-    def extract_terms(self):
+    def extract_terms(self):  # boolean_query.rs:124-145: MUST, SHOULD and FILTER clauses only
         return list(self.must_queries) + list(self.should_queries)
 
 
@@ -171,25 +175,25 @@ class GpuIndexSearcher:
     @staticmethod
     def _flatten(query):
         if isinstance(query, TermQuery):
-            return OP_TERM, [query]
+            return OP_TERM, [query], []
         if isinstance(query, BooleanQuery):
             if query.must_queries:
-                return OP_AND, query.must_queries
-            return OP_OR, query.should_queries
+                return OP_AND, query.must_queries, query.must_not_queries
+            return OP_OR, query.should_queries, query.must_not_queries
         raise RgpuError(-5, "query type not served by the GPU path: %r" % (query,))
 
     def pack(self, queries, leaf):
         """queries -> (rgpu_query[], rgpu_query_term[]) for one leaf."""
         flat = [self._flatten(q) for q in queries]
-        n_terms = sum(len(t) for _, t in flat)
+        n_terms = sum(len(t) + len(n) for _, t, n in flat)
         qs = np.zeros(len(flat), dtype=QUERY_DTYPE)
         ts = np.zeros(max(n_terms, 1), dtype=QUERY_TERM_DTYPE)
         pos = 0
-        for i, (op, clauses) in enumerate(flat):
-            if len(clauses) > _lib.MAX_QUERY_TERMS:
+        for i, (op, clauses, nots) in enumerate(flat):
+            if len(clauses) + len(nots) > _lib.MAX_QUERY_TERMS:
                 raise RgpuError(-5, "more than %d clauses" % _lib.MAX_QUERY_TERMS)
-            qs[i] = (op, len(clauses), pos, 0)
-            for c in clauses:
+            qs[i] = (op, len(clauses), pos, len(nots))   # MUST_NOT clauses follow the positive ones
+            for c in list(clauses) + list(nots):
                 w, table = self._weight(c.term, c.boost)
                 st = leaf.term_state(c.term)
                 if st is not None:

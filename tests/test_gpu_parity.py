@@ -435,3 +435,75 @@ def test_enqueue_only_device_search_rotates_scratch(zipf, oracle):
         assert (got_h["doc"] == want_h["doc"]).all()
         assert (got_h["score"].view(np.int32) == want_h["score"].view(np.int32)).all()
         assert (t.cpu().numpy() == want_t).all()
+
+
+def _check_not_queries(oracle, osearcher, gsearcher, specs, k):
+    """specs: (op, positive term ids, MUST_NOT term ids). Exact docs, scores (bitwise) and hit counts."""
+    import rucene_amd
+    T, B = rucene_amd.TermQuery, rucene_amd.BooleanQuery
+    queries = []
+    for op, pos, nots in specs:
+        if op == oracle.OP_OR:
+            queries.append(B.build([], [T(t) for t in pos], must_nots=[T(t) for t in nots]))
+        else:  # a single MUST clause with MUST_NOT clauses stays a BooleanQuery (boolean_query.rs:66)
+            queries.append(B.build([T(t) for t in pos], [], must_nots=[T(t) for t in nots]))
+    hits, totals = gsearcher.search_batch(queries, k)
+    ops = [oracle.OP_AND if (op == oracle.OP_TERM) else op for op, _, _ in specs]
+    offs = np.zeros(len(specs) + 1, np.int32)
+    offs[1:] = np.cumsum([len(p) for _, p, _ in specs])
+    noffs = np.zeros(len(specs) + 1, np.int32)
+    noffs[1:] = np.cumsum([len(n) for _, _, n in specs])
+    tids = np.concatenate([np.asarray(p, np.int64) for _, p, _ in specs])
+    nids = np.concatenate([np.asarray(n, np.int64) for _, _, n in specs] + [np.zeros(0, np.int64)])
+    cd, cs, cc, ct, _, _ = osearcher.search_batch(ops, offs, tids, k, tie_mode=oracle.TIE_CANONICAL, threads=4, not_offsets=noffs, not_ids=nids)
+    for i in range(len(specs)):
+        n = int(cc[i])
+        assert totals[i] == ct[i], (i, specs[i], totals[i], ct[i])
+        assert (hits[i]["doc"][n:] == -1).all()
+        assert (hits[i]["doc"][:n] == cd[i, :n]).all(), (i, specs[i], hits[i]["doc"][:n], cd[i, :n])
+        assert (hits[i]["score"][:n].view(np.int32) == cs[i, :n].view(np.int32)).all(), (i, specs[i])
+
+
+def test_must_not_clauses_zipf(zipf, oracle):
+    """ReqNotScorer (req_not_scorer.rs): MUST / SHOULD trees minus the union of MUST_NOT term clauses."""
+    seg, osearcher, gsearcher = zipf
+    from rucene_amd import indexgen
+    r = indexgen.log_uniform_ranks(6 * 48, 1, 3000, seed=77).reshape(-1, 6) - 1
+    specs = []
+    for i, row in enumerate(r):
+        row = [int(x) for x in row]
+        specs.append((oracle.OP_TERM, row[:1], row[1:2 + i % 3]))
+        specs.append((oracle.OP_AND, row[:2 + i % 2], row[3:4 + i % 3]))
+        specs.append((oracle.OP_OR, row[:1 + i % 4], row[4:5 + i % 2]))
+    specs += [(oracle.OP_TERM, [0], [1]), (oracle.OP_TERM, [5], [5]), (oracle.OP_AND, [0, 1], [2, 3, 4]), (oracle.OP_OR, [0, 7, 9], [1]),
+              (oracle.OP_OR, [3], [0]), (oracle.OP_TERM, [2], [49_999, 40_000]), (oracle.OP_AND, [10, 12], [10])]
+    for k in (10, 100):
+        _check_not_queries(oracle, osearcher, gsearcher, specs, k)
+
+
+def test_must_not_clauses_edge_terms_and_live_docs(ctx, oracle):
+    import rucene_amd
+    from rucene_amd import indexgen
+    max_doc = 60_000
+    rng = np.random.default_rng(5150)
+    dfs = [1, 1, 2, 127, 128, 129, 300, 1000, 5000, 30_000, 45_000]
+    lists = [_postings(rng, df, max_doc) for df in dfs] + [(np.zeros(0, np.int32), np.zeros(0, np.int32))]
+    lists[1] = (lists[3][0][5:6].copy(), np.array([4], np.int32))  # a singleton that sits inside term 3
+    live = rng.integers(0, 2**63, size=(max_doc + 63) // 64, dtype=np.uint64) | rng.integers(0, 2**63, size=(max_doc + 63) // 64, dtype=np.uint64)
+    norms = rng.integers(95, 125, size=max_doc).astype(np.uint8)
+    for lv in (None, live):
+        seg = indexgen.build_explicit(max_doc, lists, norms=norms)
+        oseg = oracle.Segment(seg.doc_bytes, seg.norms, max_doc, seg.terms, live_docs=lv, sum_total_term_freq=60 * max_doc)
+        leaf = rucene_amd.LeafReader(seg.doc_bytes, seg.norms, max_doc, seg.terms, live_docs=lv, sum_total_term_freq=60 * max_doc)
+        osearcher = oracle.Searcher([oseg])
+        gsearcher = rucene_amd.GpuIndexSearcher([leaf], ctx=ctx)
+        n = len(lists)
+        specs = []
+        for a in range(n - 1):
+            for b in range(n):
+                if a != b:
+                    specs.append((oracle.OP_TERM, [a], [b]))
+        specs += [(oracle.OP_AND, [9, 10], [8]), (oracle.OP_AND, [8, 9, 10], [7, 6, 0]), (oracle.OP_AND, [3, 9], [1]), (oracle.OP_AND, [9, 10], [11]),
+                  (oracle.OP_AND, [11, 9], [8]), (oracle.OP_OR, [7, 8], [9]), (oracle.OP_OR, [0, 1, 2, 3], [4, 5]), (oracle.OP_OR, [11, 6], [10, 9]),
+                  (oracle.OP_OR, [11], [9]), (oracle.OP_OR, [9, 10, 8, 7, 6], [3, 1, 11])]
+        _check_not_queries(oracle, osearcher, gsearcher, specs, 10)

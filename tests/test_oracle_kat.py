@@ -241,6 +241,30 @@ def test_conjunction_advance(oracle):
     assert oracle.mock_conjunction(LISTS, advance_first=7)[0] == []
 
 
+# ---- search/scorer/req_not_scorer.rs ------------------------------------------------------------------------------------
+REQ = [[1, 2, 3, 4, 5, 6, 7, 8, 9], [2, 3, 5, 7, 9, 10]]   # ConjunctionScorer(s1, s2)   -> 2, 3, 5, 7, 9
+NOT = [[2, 5], [1, 4, 5]]                                   # DisjunctionSumScorer(s3, s4) -> 1, 2, 4, 5
+
+
+def test_req_not_next(oracle):
+    # req_not_scorer.rs:126-145: doc_id() starts at -1 (checked inside the probe); next() -> 3, 7, 9, NO_MORE_DOCS
+    assert list(oracle.mock_req_not(REQ, NOT)) == [3, 7, 9]
+
+
+def test_req_not_advance(oracle):
+    # req_not_scorer.rs:147-165: advance(1) = 3, advance(4) = 7, advance(8) = 9, advance(10) = NO_MORE_DOCS
+    assert list(oracle.mock_req_not(REQ, NOT, [1, 4, 8, 10])) == [3, 7, 9, oracle.NO_MORE_DOCS]
+
+
+def test_req_not_single_children_and_brute_force(oracle):
+    rng = np.random.default_rng(31)
+    for _ in range(20):
+        req = [sorted(rng.choice(300, size=int(rng.integers(1, 200)), replace=False).tolist()) for _ in range(int(rng.integers(1, 4)))]
+        nots = [sorted(rng.choice(300, size=int(rng.integers(1, 150)), replace=False).tolist()) for _ in range(int(rng.integers(1, 4)))]
+        want = sorted(set.intersection(*map(set, req)) - set.union(*map(set, nots)))
+        assert list(oracle.mock_req_not(req, nots)) == want
+
+
 # ---- search/collector/top_docs.rs, scorer/bulk_scorer.rs, searcher.rs ------------------------------------------------
 @pytest.mark.parametrize("mode", [0, 1])
 def test_topdocs_collect(oracle, mode):
