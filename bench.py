@@ -69,6 +69,8 @@ def build_queries(n_queries, kind, seed):
         ranks = indexgen.log_uniform_ranks(n_queries, 1, 10_000, seed).reshape(-1, 1)
     elif kind == "and3":
         ranks = indexgen.log_uniform_ranks(3 * n_queries, 1, 1000, seed ^ 0xA3).reshape(-1, 3)
+    elif kind == "and3not1":  # 3 MUST + 1 MUST_NOT term (ReqNotScorer over the conjunction)
+        ranks = indexgen.log_uniform_ranks(4 * n_queries, 1, 1000, seed ^ 0xA4).reshape(-1, 4)
     else:
         ranks = indexgen.log_uniform_ranks(10 * n_queries, 1, 10_000, seed ^ 0x0A).reshape(-1, 10)
     return ranks - 1  # term ids
@@ -132,6 +134,8 @@ def main():
             qs = [T(int(t[0])) for t in tids]
         elif kind == "and3":
             qs = [B.build([T(int(x)) for x in t], []) for t in tids]
+        elif kind == "and3not1":
+            qs = [B.build([T(int(x)) for x in t[:3]], [], must_nots=[T(int(t[3]))]) for t in tids]
         else:
             qs = [B.build([], [T(int(x)) for x in t]) for t in tids]
         packed = searcher.pack(qs, leaf)
@@ -282,7 +286,7 @@ def main():
                                  "algorithmic_bytes": b, "achieved_GBs": b / (ms * 1e-3) / 1e9,
                                  "frac_of_8TBs": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
         del d_docs, d_freqs
-        for kind, kk in (("and3", 10), ("or10", 100)):
+        for kind, kk in (("and3", 10), ("and3not1", 10), ("or10", 100)):
             if kind == args.workload:
                 continue
             k_saved = k
@@ -307,10 +311,17 @@ def main():
                     x_tids = build_queries(nq, kind, SEED_QUERIES)
                     oseg_x = orc.Segment(seg.doc_bytes, seg.norms, seg.max_doc, seg.terms, sum_total_term_freq=seg.sum_total_term_freq)
                     osr_x = orc.Searcher([oseg_x])
-                    xop = np.full(nq, orc.OP_AND if kind == "and3" else orc.OP_OR, np.int32)
-                    xoffs = (np.arange(nq + 1) * x_tids.shape[1]).astype(np.int32)
-                    xd, xs, xc, xt, xv, xsecs = osr_x.search_batch(xop, xoffs, x_tids.reshape(-1), kk, tie_mode=orc.TIE_CANONICAL,
-                                                                   threads=os.cpu_count() or 1)
+                    xop = np.full(nq, orc.OP_OR if kind == "or10" else orc.OP_AND, np.int32)
+                    if kind == "and3not1":
+                        pos_t, not_t = x_tids[:, :3], x_tids[:, 3:]
+                        xd, xs, xc, xt, xv, xsecs = osr_x.search_batch(
+                            xop, (np.arange(nq + 1) * 3).astype(np.int32), np.ascontiguousarray(pos_t).reshape(-1), kk,
+                            tie_mode=orc.TIE_CANONICAL, threads=os.cpu_count() or 1,
+                            not_offsets=np.arange(nq + 1).astype(np.int32), not_ids=np.ascontiguousarray(not_t).reshape(-1))
+                    else:
+                        xoffs = (np.arange(nq + 1) * x_tids.shape[1]).astype(np.int32)
+                        xd, xs, xc, xt, xv, xsecs = osr_x.search_batch(xop, xoffs, x_tids.reshape(-1), kk, tie_mode=orc.TIE_CANONICAL,
+                                                                       threads=os.cpu_count() or 1)
                     gx = hits_x.cpu().numpy().view(rucene_amd.HIT_DTYPE).reshape(nq, kk)
                     extra[kind]["cpu_baseline_queries_per_sec"] = nq / xsecs
                     extra[kind]["cpu_cores"] = os.cpu_count()

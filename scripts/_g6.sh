@@ -1,4 +1,5 @@
 set -u
 cd $GRAFT_REPO_ROOT
-for w in term and3 or10 decode; do bash scripts/prof.sh $w prof_r01_$w > gpurun_out/prof_$w.log 2>&1; tail -3 gpurun_out/prof_$w.log | cut -c1-200; done
-timeout 1200 python bench.py --steps 50 --warmup 5 --extra > gpurun_out/bench11.json 2> gpurun_out/bench11.err; echo "bench rc=$?"; tail -2 gpurun_out/bench11.err
+timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_final.log 2>&1; echo "pytest rc=$?"; tail -2 gpurun_out/pytest_final.log | cut -c1-200
+for w in term and3 or10 decode; do bash scripts/prof.sh $w prof_r01_$w > gpurun_out/prof_$w.log 2>&1; done
+timeout 1200 python bench.py --steps 50 --warmup 5 --extra > gpurun_out/bench12.json 2> gpurun_out/bench12.err; echo "bench rc=$?"; tail -2 gpurun_out/bench12.err
