@@ -74,19 +74,23 @@ struct TermQuery : Query {
   explicit TermQuery(int64_t t, float b = 1.0f) : term(t), boost(b) {}
 };
 struct BooleanQuery : Query {
-  std::vector<TermQuery> must_queries, should_queries;
+  std::vector<TermQuery> must_queries, should_queries, must_not_queries;
   int32_t min_should_match = 0;
-  // boolean_query.rs:40-86 restricted to what the GPU path serves; a single clause collapses to that clause
-  static std::unique_ptr<Query> build(std::vector<TermQuery> musts, std::vector<TermQuery> shoulds, int32_t min_should_match = 0) {
+  // boolean_query.rs:40-86 restricted to what the GPU path serves: MUST-only or SHOULD-only term trees, each
+  // optionally with MUST_NOT term clauses (ReqNotScorer); a single clause without MUST_NOTs collapses to that clause
+  static std::unique_ptr<Query> build(std::vector<TermQuery> musts, std::vector<TermQuery> shoulds, int32_t min_should_match = 0,
+                                      std::vector<TermQuery> must_nots = {}) {
     const int32_t msm = min_should_match > 0 ? min_should_match : (musts.empty() ? 1 : 0);
-    if (musts.empty() && shoulds.empty())
+    if (musts.empty() && shoulds.empty() && must_nots.empty())
       throw Error(RGPU_ERR_ILLEGAL_ARGUMENT, "boolean query should at least contain one inner query!");
-    if (musts.size() + shoulds.size() == 1) return std::unique_ptr<Query>(new TermQuery(musts.empty() ? shoulds[0] : musts[0]));
-    if ((!musts.empty() && !shoulds.empty()) || msm > 1)
-      throw Error(RGPU_ERR_UNSUPPORTED, "only pure-MUST and pure-SHOULD (min_should_match 1) term trees run on the GPU path");
+    if (must_nots.empty() && musts.size() + shoulds.size() == 1)
+      return std::unique_ptr<Query>(new TermQuery(musts.empty() ? shoulds[0] : musts[0]));
+    if ((!musts.empty() && !shoulds.empty()) || msm > 1 || (musts.empty() && shoulds.empty()))
+      throw Error(RGPU_ERR_UNSUPPORTED, "only MUST (+MUST_NOT) and SHOULD (+MUST_NOT, min_should_match 1) term trees run on the GPU path");
     auto q = std::unique_ptr<BooleanQuery>(new BooleanQuery());
     q->must_queries = std::move(musts);
     q->should_queries = std::move(shoulds);
+    q->must_not_queries = std::move(must_nots);
     q->min_should_match = msm;
     return std::unique_ptr<Query>(q.release());
   }
@@ -199,6 +203,7 @@ class GpuIndexSearcher {
   }
   void pack(const Query& q, const LeafReader& leaf, std::vector<rgpu_query>* qs, std::vector<rgpu_query_term>* ts) {
     const std::vector<TermQuery>* clauses = nullptr;
+    const std::vector<TermQuery>* nots = nullptr;
     std::vector<TermQuery> single;
     int32_t op = RGPU_OP_TERM;
     if (auto* t = dynamic_cast<const TermQuery*>(&q)) {
@@ -207,11 +212,15 @@ class GpuIndexSearcher {
     } else if (auto* b = dynamic_cast<const BooleanQuery*>(&q)) {
       op = b->must_queries.empty() ? RGPU_OP_OR : RGPU_OP_AND;
       clauses = b->must_queries.empty() ? &b->should_queries : &b->must_queries;
+      nots = &b->must_not_queries;
     } else {
       throw Error(RGPU_ERR_UNSUPPORTED, "query type not served by the GPU path");
     }
-    rgpu_query rq{op, static_cast<int32_t>(clauses->size()), static_cast<int32_t>(ts->size()), 0};
-    for (const TermQuery& c : *clauses) {
+    std::vector<TermQuery> all(*clauses);  // MUST_NOT clauses follow the positive ones
+    if (nots) all.insert(all.end(), nots->begin(), nots->end());
+    rgpu_query rq{op, static_cast<int32_t>(clauses->size()), static_cast<int32_t>(ts->size()),
+                  static_cast<int32_t>(nots ? nots->size() : 0)};
+    for (const TermQuery& c : all) {
       rgpu_query_term qt{};
       const rgpu_term_state* st = leaf.term_state(c.term);
       if (st) qt.state = *st;

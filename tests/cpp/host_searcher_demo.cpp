@@ -47,6 +47,9 @@ int main() {
     queries.push_back(BooleanQuery::build({TermQuery(1), TermQuery(12), TermQuery(40)}, {}));
     queries.push_back(BooleanQuery::build({}, {TermQuery(3), TermQuery(77), TermQuery(900), TermQuery(15000)}));
     queries.push_back(BooleanQuery::build({TermQuery(5)}, {}));  // collapses to a TermQuery
+    queries.push_back(BooleanQuery::build({TermQuery(2), TermQuery(9)}, {}, 0, {TermQuery(1), TermQuery(30)}));  // MUST + MUST_NOT
+    queries.push_back(BooleanQuery::build({}, {TermQuery(6), TermQuery(60)}, 0, {TermQuery(0)}));                // SHOULD + MUST_NOT
+    queries.push_back(BooleanQuery::build({TermQuery(4)}, {}, 0, {TermQuery(8)}));                               // one MUST + MUST_NOT
     for (size_t i = 0; i < queries.size(); ++i) {
       TopDocsCollector collector(10);
       searcher.search(*queries[i], collector);

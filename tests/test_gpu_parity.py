@@ -336,10 +336,14 @@ def test_cpp_host_mirror(oracle, tmp_path):
     oseg = oracle.Segment(seg.doc_bytes, seg.norms, seg.max_doc, seg.terms, sum_total_term_freq=seg.sum_total_term_freq)
     osr = oracle.Searcher([oseg])
     specs = [(oracle.OP_TERM, [7], None), (oracle.OP_TERM, [4321], [2.0]), (oracle.OP_AND, [1, 12, 40], None),
-             (oracle.OP_OR, [3, 77, 900, 15000], None), (oracle.OP_TERM, [5], None)]
+             (oracle.OP_OR, [3, 77, 900, 15000], None), (oracle.OP_TERM, [5], None),
+             (oracle.OP_AND, [2, 9], ("not", [1, 30])), (oracle.OP_OR, [6, 60], ("not", [0])), (oracle.OP_AND, [4], ("not", [8]))]
     for line, (op, tids, boosts) in zip(out, specs):
         parts = line.split()
-        d, s, total = osr.search(op, tids, 10, tie_mode=oracle.TIE_CANONICAL, boosts=boosts)
+        if isinstance(boosts, tuple):
+            d, s, total = osr.search_not(op, tids, boosts[1], 10, tie_mode=oracle.TIE_CANONICAL)
+        else:
+            d, s, total = osr.search(op, tids, 10, tie_mode=oracle.TIE_CANONICAL, boosts=boosts)
         assert int(parts[1]) == total
         got = [(int(p.split(":")[0]), int(p.split(":")[1], 16)) for p in parts[2:]]
         assert [g[0] for g in got] == d.tolist()
