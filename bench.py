@@ -306,6 +306,11 @@ def main():
                 el = time.perf_counter() - t
                 extra[kind] = {"queries_per_sec": nq * reps / el, "postings_per_sec": post * reps / el, "ms_per_step": 1e3 * el / reps,
                                "k": kk, "kernels_ms_per_step": {n: s["total_ms"] / reps for n, s in ctx.kernel_stats().items()}}
+                # "scan bytes" = every clause's list read fully (encoded blocks + tails + 1 B norm per
+                # posting + output): the upper bound a scan-intersect kernel would move. The lead-driven AND kernel
+                # touches only blocks that overlap a live candidate (DESIGN.md 4 gives the measured touched fraction).
+                extra[kind]["scan_bytes"] = ab
+                extra[kind]["scan_equivalent_GBs"] = ab / (1e-3 * 1e3 * el / reps) / 1e9
                 if not args.no_cpu_baseline:
                     from oracle import binding as orc
                     x_tids = build_queries(nq, kind, SEED_QUERIES)

@@ -71,6 +71,8 @@ __global__ __launch_bounds__(WG_THREADS) void k_score_terms(SegView seg, const D
   else
     stream_blocks<LEGACY, false>(term_rows, seg.dir_row, seg.dir_hdr, T.dir_base, nullptr, b0, b1, slab, lane, base, on_block);
   if (b1 == T.nblocks) {
+    // 64 sentinel entries close every run: k_or_windows reads 64 entries from a cursor without knowing the length
+    run[(int64_t)T.df + lane] = ScoredPosting{0x7fffffff, 0.0f};
     if (T.df == 1) {
       const bool v0 = lane == 0;
       const uint32_t nb0 = (has_norms && v0) ? seg.norms[T.singleton_doc] : 0u;
@@ -88,6 +90,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_score_terms(SegView seg, const D
 }
 
 constexpr int OR_MAX_TERMS = 16;
+constexpr int OR_RUN_PAD = 64;  // sentinel entries {doc = INT_MAX} after every clause's run (written by k_score_terms)
 constexpr uint32_t OR_UNTOUCHED = 0xffffffffu;  // accumulator patterns no sum of scores produces (negative quiet NaNs)
 constexpr uint32_t OR_EXCLUDED = 0xfffffffeu;
 
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_or_windows(SegView seg, const De
   const int my_clause = lane < n_not ? Q.n_terms + lane : lane - n_not;
   const int64_t my_base = mine ? run_prefix[Q.first_term + my_clause] : 0;
   const int my_len = mine ? terms[Q.first_term + my_clause].df : 0;
-  int my_cur = 0;
+  int64_t my_at = my_base;  // absolute index of the entry under this clause's cursor (every run ends in sentinels)
   {
     const int32_t first_doc = win0 * W;
     int lo = 0, hi = my_len;
@@ -145,9 +148,9 @@ __global__ __launch_bounds__(WG_THREADS) void k_or_windows(SegView seg, const De
         if (runs[my_base + mid].doc < first_doc) lo = mid + 1; else hi = mid;
       }
     }
-    my_cur = lo;
+    my_at += lo;
   }
-  int32_t my_next = (mine && my_cur < my_len) ? runs[my_base + my_cur].doc : 0x7fffffff;  // doc under the cursor
+  int32_t my_next = mine ? runs[my_at].doc : 0x7fffffff;  // doc under the cursor (INT_MAX: the run is exhausted)
 
   for (int i = lane; i < W; i += 64) acc[i] = __uint_as_float(OR_UNTOUCHED);
   wave_sync();
@@ -163,18 +166,12 @@ __global__ __launch_bounds__(WG_THREADS) void k_or_windows(SegView seg, const De
 #pragma unroll
     for (int t = 0; t < OR_MAX_TERMS; ++t) {
       pre[t] = ScoredPosting{0x7fffffff, 0.f};
-      if ((active0 >> t) & 1ull) {  // wave-uniform
-        const int64_t rb = ((int64_t)readlane((int)(uint32_t)(my_base >> 32), t) << 32) | (uint32_t)readlane((int)(uint32_t)my_base, t);
-        const int idx = readlane(my_cur, t) + lane;
-        if (idx < readlane(my_len, t)) pre[t] = runs[rb + idx];
-      }
+      if ((active0 >> t) & 1ull) pre[t] = runs[(int64_t)readlane64((uint64_t)my_at, t) + lane];  // wave-uniform branch
     }
 #pragma unroll
     for (int t = 0; t < OR_MAX_TERMS; ++t) {
       if (!((active0 >> t) & 1ull)) continue;
-      const int64_t rb = ((int64_t)readlane((int)(uint32_t)(my_base >> 32), t) << 32) | (uint32_t)readlane((int)(uint32_t)my_base, t);
-      const int len = readlane(my_len, t);
-      int cur = readlane(my_cur, t);
+      int taken = 0;
       int32_t next;
       ScoredPosting e = pre[t];
       while (true) {
@@ -195,14 +192,11 @@ __global__ __launch_bounds__(WG_THREADS) void k_or_windows(SegView seg, const De
         const uint64_t fm = __ballot(first);
         if (first) hits[nhits + mbcnt(fm)] = (uint16_t)(e.doc - w0);
         nhits += __popcll(fm);
-        cur += n;
-        if (n < 64) { next = readlane(e.doc, n); break; }  // the entry now under the cursor (or "none")
-        const int idx = cur + lane;
-        e = ScoredPosting{0x7fffffff, 0.f};
-        if (idx < len) e = runs[rb + idx];
+        taken += n;
+        if (n < 64) { next = readlane(e.doc, n); break; }  // the entry now under the cursor (or the sentinel)
+        e = runs[(int64_t)readlane64((uint64_t)my_at, t) + taken + lane];  // a stretch longer than 64: the rare case
       }
-      my_cur = lane == t ? cur : my_cur;
-      my_next = lane == t ? next : my_next;
+      if (lane == t) { my_at += taken; my_next = next; }
       wave_sync();
     }
     // every touched doc that no prohibited clause claimed is one collected hit

@@ -722,8 +722,8 @@ static int32_t search_or_group(rgpu_segment* seg, Group& G, int32_t k, HitOut* h
     if (items1 <= 1048576 || blocks_per_item >= (1 << 17)) break;
     blocks_per_item *= 2;
   }
-  for (int j = 0; j < nt; ++j) { run_prefix[(size_t)j] = postings; postings += G.terms[(size_t)j].df; }
-  run_prefix[(size_t)nt] = postings;
+  for (int j = 0; j < nt; ++j) { run_prefix[(size_t)j] = postings; postings += (int64_t)G.terms[(size_t)j].df + OR_RUN_PAD; }
+  run_prefix[(size_t)nt] = postings;  // run lengths include the sentinel padding
   // phase 2 plan: items = (query, group of windows), one per wavefront
   int W = std::min(4096, std::max(256, c->cfg.reserved[3] > 0 ? (c->cfg.reserved[3] + 255) / 256 * 256 : 1024));
   const int wpq = std::max(1, (seg->max_doc + W - 1) / W);
