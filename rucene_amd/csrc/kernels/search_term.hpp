@@ -165,11 +165,7 @@ __device__ __forceinline__ void term_blocks_fast(const SegView& seg, const DevTe
       }
       count += 128;
       const uint32_t r0 = __float_as_uint(s0), r1 = __float_as_uint(s1);
-#ifdef RGPU_EXP_NOSLOW  // timing experiment (wrong results): the doc-id path is never taken, scoring stays live
-      if (__ballot((r0 > r1 ? r0 : r1) >= 0xffffffffu - ((uint32_t)k >> 30))) {
-#else
       if (__ballot((r0 > r1 ? r0 : r1) >= thr)) {
-#endif
 #ifdef RGPU_EXP_COUNT
         ++dbg_slow;
 #endif
