@@ -120,6 +120,8 @@ struct rgpu_ctx {
   Scratch* S = &scr[0];
   int scr_next = 0;
   DevVec<ScoredPosting> d_runs;  // OR: per-clause {doc, score} runs (one instance: OR groups end with a stream sync)
+  DevVec<HitOut> host_api_hits;  // rgpu_search_batch (blocking, host outputs): device-side result rows
+  DevVec<int64_t> host_api_totals;
   int* d_err = nullptr;
   // profiling
   std::vector<StatSlot> stats;
@@ -423,7 +425,7 @@ extern "C" void rgpu_shutdown(rgpu_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   drain_events(c);
   for (auto e : c->free_events) (void)hipEventDestroy(e);
-  c->sim_tables.release(); c->d_runs.release();
+  c->sim_tables.release(); c->d_runs.release(); c->host_api_hits.release(); c->host_api_totals.release();
   for (auto& sc : c->scr) sc.release();
   if (c->d_err) (void)hipFree(c->d_err);
   (void)hipStreamDestroy(c->stream);
@@ -1036,10 +1038,12 @@ extern "C" int32_t rgpu_search_batch(rgpu_segment* seg, const rgpu_query* querie
   rgpu_ctx* c = seg->ctx;
   std::lock_guard<std::mutex> g(c->mu);
   HIP_TRY(hipSetDevice(c->device));
-  HitOut* d_hits = nullptr;
-  int64_t* d_tot = nullptr;
-  HIP_TRY(hipMalloc(&d_hits, (size_t)n_queries * (size_t)k * sizeof(HitOut)));
-  if (hipMalloc(&d_tot, (size_t)n_queries * 8) != hipSuccess) { (void)hipFree(d_hits); return fail(RGPU_ERR_RUNTIME, "out of device memory"); }
+  // device-side result rows of the blocking variant live in the context (grow-only): the call ends with a stream
+  // sync, so they are free again when it returns
+  HIP_TRY(c->host_api_hits.reserve((size_t)n_queries * (size_t)k, 0, c->stream));
+  HIP_TRY(c->host_api_totals.reserve((size_t)n_queries, 0, c->stream));
+  HitOut* d_hits = c->host_api_hits.p;
+  int64_t* d_tot = c->host_api_totals.p;
   int32_t rc = search_impl(seg, queries, n_queries, terms, n_terms_total, k, d_hits, d_tot, c->stream);
   if (rc == RGPU_OK) {
     hipError_t e1 = hipMemcpyAsync(hits_out, d_hits, (size_t)n_queries * (size_t)k * sizeof(HitOut), hipMemcpyDeviceToHost, c->stream);
@@ -1047,8 +1051,6 @@ extern "C" int32_t rgpu_search_batch(rgpu_segment* seg, const rgpu_query* querie
     hipError_t e3 = hipStreamSynchronize(c->stream);
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) rc = fail(RGPU_ERR_RUNTIME, "device to host copy failed");
   }
-  (void)hipFree(d_hits);
-  (void)hipFree(d_tot);
   return rc;
 }
 
