@@ -185,6 +185,13 @@ int32_t rgpu_bm25_compute_weight(float k1, float b, int64_t max_doc, int64_t doc
                                  float* cache_out /* 256 floats */);
 /* BM25Similarity::encode_norm_value (bm25_similarity.rs:90-92): float_to_byte315(boost / sqrt(field_length)). */
 uint8_t rgpu_bm25_encode_norm(float boost, int32_t field_length);
+/* Lucene53NormsProducer (codec/norms/norms_producer.rs:40-189; format constants codec/norms/norms.rs:23-28): the
+ * 1-byte-per-doc norms array rgpu_segment_upload takes, read from a segment's ".nvm" (metadata) and ".nvd" (data)
+ * files: norms_out[doc] = norms(field_number).get(doc) & 0xFF (what BM25 reads, bm25_similarity.rs:205) for
+ * doc in [0, max_doc). Validates both index headers (same segment id / suffix / version), the metadata checksum
+ * (check_footer) and the data footer (retrieve_checksum). */
+int32_t rgpu_norms_from_lucene53(const uint8_t* nvm, size_t nvm_len, const uint8_t* nvd, size_t nvd_len, int32_t field_number,
+                                 int32_t max_doc, uint8_t* norms_out);
 
 /* ---- measurement ------------------------------------------------------------------------------------------ */
 typedef struct rgpu_kernel_stat {

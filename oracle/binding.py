@@ -112,6 +112,8 @@ def _declare(L):
                                               i64p, u64p]),
         "orc_search_not": (C.c_int, [vp, C.c_int, i64p, C.c_int, i64p, C.c_int, C.c_int, C.c_int, i32p, f32p, i32p, i64p]),
         "orc_mock_req_not": (C.c_int, [i32p, i32p, C.c_int, i32p, i32p, C.c_int, i32p, C.c_int, i32p, C.c_int]),
+        "orc_norms_write": (C.c_int, [i64p, C.c_int32, C.c_int32, u8p, C.c_char_p, u8p, i64p, u8p, i64p]),
+        "orc_norms_read": (C.c_int, [u8p, C.c_int64, u8p, C.c_int64, C.c_int32, C.c_int32, i64p]),
         "orc_mock_conjunction": (C.c_int, [i32p, i32p, C.c_int, C.c_int32, i32p, f32p, C.c_int]),
         "orc_mock_conjunction_initial_score": (C.c_float, [i32p, i32p, C.c_int]),
         "orc_mock_disjunction": (C.c_int, [i32p, i32p, C.c_int, C.c_int, i32p, f32p, C.c_int]),
@@ -408,6 +410,29 @@ def mock_disjunction(lists, min_should_match=1):
     n = _check(lib().orc_mock_disjunction(_p(flat, C.c_int32), _p(offs, C.c_int32), len(lists), min_should_match,
                                           _p(docs, C.c_int32), _p(scores, C.c_float), docs.size))
     return docs[:n].tolist(), scores[:n].tolist()
+
+
+def norms_write(values, field_number=0, segment_id=None, suffix=""):
+    """Lucene53NormsConsumer for one field: i64 norm values (one per doc) -> (nvm bytes, nvd bytes)."""
+    v = np.ascontiguousarray(values, dtype=np.int64)
+    sid = np.frombuffer(segment_id if segment_id is not None else bytes(range(16)), dtype=np.uint8).copy()
+    ml, dl = C.c_int64(0), C.c_int64(0)
+    _check(lib().orc_norms_write(_p(v, C.c_int64), v.size, field_number, _p(sid, C.c_uint8), suffix.encode(), None, C.byref(ml),
+                                 None, C.byref(dl)))
+    m = np.zeros(ml.value, dtype=np.uint8)
+    d = np.zeros(dl.value, dtype=np.uint8)
+    _check(lib().orc_norms_write(_p(v, C.c_int64), v.size, field_number, _p(sid, C.c_uint8), suffix.encode(), _p(m, C.c_uint8),
+                                 C.byref(ml), _p(d, C.c_uint8), C.byref(dl)))
+    return m.tobytes(), d.tobytes()
+
+
+def norms_read(nvm, nvd, field_number, max_doc):
+    """Lucene53NormsProducer: norms(field).get(doc) for every doc."""
+    m = np.frombuffer(nvm, dtype=np.uint8).copy()
+    d = np.frombuffer(nvd, dtype=np.uint8).copy()
+    out = np.zeros(max_doc, dtype=np.int64)
+    _check(lib().orc_norms_read(_p(m, C.c_uint8), m.size, _p(d, C.c_uint8), d.size, field_number, max_doc, _p(out, C.c_int64)))
+    return out
 
 
 def mock_req_not(req_lists, not_lists, targets=()):

@@ -10,6 +10,7 @@
 #include "packed.hpp"
 #include "postings.hpp"
 #include "search.hpp"
+#include "norms.hpp"
 #include "store.hpp"
 
 using namespace orc;
@@ -298,6 +299,31 @@ double orc_search_batch_not(orc_searcher* s, int n_queries, const int32_t* ops, 
   double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   if (failed.load() > 0) { g_err = "search failed for some queries"; return -1.0; }
   return el;
+}
+
+// ---- Lucene53 norms files (oracle/norms.hpp) -------------------------------------------------------------------------
+// Writes one field's norms the way Lucene53NormsConsumer does. Two-call protocol: sizes first (bufs null), then fill.
+int orc_norms_write(const int64_t* values, int32_t max_doc, int32_t field_number, const uint8_t* segment_id16, const char* suffix,
+                    uint8_t* nvm_out, int64_t* nvm_len, uint8_t* nvd_out, int64_t* nvd_len) {
+  ORC_TRY
+  NormsConsumer c(max_doc, segment_id16, suffix ? suffix : "");
+  c.add_norms_field(field_number, std::vector<int64_t>(values, values + max_doc));
+  c.finish();
+  if (nvm_out && *nvm_len >= (int64_t)c.meta.buf.size()) std::memcpy(nvm_out, c.meta.buf.data(), c.meta.buf.size());
+  if (nvd_out && *nvd_len >= (int64_t)c.data.buf.size()) std::memcpy(nvd_out, c.data.buf.data(), c.data.buf.size());
+  *nvm_len = (int64_t)c.meta.buf.size();
+  *nvd_len = (int64_t)c.data.buf.size();
+  return 0;
+  ORC_CATCH
+}
+// Lucene53NormsProducer: values_out[doc] = norms(field).get(doc)
+int orc_norms_read(const uint8_t* nvm, int64_t nvm_len, const uint8_t* nvd, int64_t nvd_len, int32_t field_number, int32_t max_doc,
+                   int64_t* values_out) {
+  ORC_TRY
+  NormsProducer p(nvm, (size_t)nvm_len, nvd, (size_t)nvd_len, max_doc);
+  for (int32_t d = 0; d < max_doc; d++) values_out[d] = p.get(field_number, d);
+  return 0;
+  ORC_CATCH
 }
 
 // ---- mock-scorer KATs (reference unit tests restated as callable probes) ---------------------------------------

@@ -58,6 +58,11 @@ struct ByteOut {
     uint8_t b[4] = {(uint8_t)(u >> 24), (uint8_t)(u >> 16), (uint8_t)(u >> 8), (uint8_t)u};
     write_bytes(b, 4);
   }
+  // data_output.rs:39-43
+  void write_short(int16_t i) {
+    write_byte((uint8_t)((uint16_t)i >> 8));
+    write_byte((uint8_t)(uint16_t)i);
+  }
   // data_output.rs:64-68
   void write_long(int64_t i) {
     write_int((int32_t)((uint64_t)i >> 32));
@@ -113,6 +118,10 @@ struct ByteIn {
   int32_t read_int() {  // data_input.rs:66-76 (big-endian)
     const uint8_t* p = get_and_advance(4);
     return (int32_t)(((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]);
+  }
+  int16_t read_short() {  // data_input.rs:59-64 (big-endian)
+    const uint8_t* p = get_and_advance(2);
+    return (int16_t)(uint16_t)(((uint16_t)p[0] << 8) | p[1]);
   }
   int64_t read_long() {
     int64_t hi = (uint32_t)read_int();

@@ -30,7 +30,7 @@ EXPORTS = [
     "rgpu_segment_free", "rgpu_segment_version", "rgpu_segment_prepare_terms", "rgpu_decode_terms",
     "rgpu_decode_terms_device", "rgpu_advance_batch", "rgpu_sim_table_upload", "rgpu_search_batch",
     "rgpu_search_batch_device", "rgpu_merge_topk_device", "rgpu_bm25_compute_weight", "rgpu_bm25_encode_norm",
-    "rgpu_kernel_stats", "rgpu_kernel_stats_reset", "rgpu_synchronize",
+    "rgpu_norms_from_lucene53", "rgpu_kernel_stats", "rgpu_kernel_stats_reset", "rgpu_synchronize",
 ]
 
 
@@ -104,6 +104,7 @@ def lib():
         "rgpu_merge_topk_device": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp]),
         "rgpu_bm25_compute_weight": (i32, [f32, f32, i64, i64, i64, vp, i32, f32, vp, vp, vp]),
         "rgpu_bm25_encode_norm": (C.c_uint8, [f32, i32]),
+        "rgpu_norms_from_lucene53": (i32, [vp, C.c_size_t, vp, C.c_size_t, i32, i32, vp]),
         "rgpu_kernel_stats": (i32, [vp, C.POINTER(_KernelStat), i32]),
         "rgpu_kernel_stats_reset": (None, [vp]),
         "rgpu_synchronize": (i32, [vp]),
@@ -133,6 +134,17 @@ def bm25_compute_weight(k1, b, max_doc, doc_count, sum_total_term_freq, doc_freq
 
 def bm25_encode_norm(boost, field_length):
     return int(lib().rgpu_bm25_encode_norm(boost, field_length))
+
+
+def norms_from_lucene53(nvm, nvd, field_number, max_doc):
+    """Lucene53NormsProducer: a segment's ".nvm" + ".nvd" bytes -> the u8[max_doc] norms array of one field
+    (norms.get(doc) & 0xFF, what BM25 reads). Host-side parse, no GPU involved."""
+    m = np.frombuffer(bytes(nvm), dtype=np.uint8)
+    d = np.frombuffer(bytes(nvd), dtype=np.uint8)
+    out = np.zeros(max(int(max_doc), 0), dtype=np.uint8)
+    _check(lib().rgpu_norms_from_lucene53(m.ctypes.data, m.size, d.ctypes.data, d.size, int(field_number), int(max_doc),
+                                          out.ctypes.data if out.size else None))
+    return out
 
 
 class Context:

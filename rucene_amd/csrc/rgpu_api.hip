@@ -13,6 +13,7 @@
 
 #include "../../include/rucene_gpu.h"
 #include "host/doc_format.hpp"
+#include "host/norms_format.hpp"
 #include "kernels/prepare.hpp"
 #include "kernels/search.hpp"
 #include "kernels/search_and.hpp"
@@ -1094,6 +1095,13 @@ extern "C" int32_t rgpu_bm25_compute_weight(float k1, float b, int64_t max_doc, 
   if (idf_out) *idf_out = w.idf;
   if (cache_out) std::memcpy(cache_out, w.cache.data(), 256 * sizeof(float));
   return RGPU_OK;
+}
+
+extern "C" int32_t rgpu_norms_from_lucene53(const uint8_t* nvm, size_t nvm_len, const uint8_t* nvd, size_t nvd_len,
+                                            int32_t field_number, int32_t max_doc, uint8_t* norms_out) {
+  std::string why;
+  const int rc = rucene::read_lucene53_norms(nvm, nvm_len, nvd, nvd_len, field_number, max_doc, norms_out, &why);
+  return rc == 0 ? RGPU_OK : fail(rc, why);
 }
 
 extern "C" uint8_t rgpu_bm25_encode_norm(float boost, int32_t field_length) {
