@@ -192,6 +192,10 @@ uint8_t rgpu_bm25_encode_norm(float boost, int32_t field_length);
  * (check_footer) and the data footer (retrieve_checksum). */
 int32_t rgpu_norms_from_lucene53(const uint8_t* nvm, size_t nvm_len, const uint8_t* nvd, size_t nvd_len, int32_t field_number,
                                  int32_t max_doc, uint8_t* norms_out);
+/* Lucene50LiveDocsFormat::read_live_docs (codec/live_docs.rs:81-121): a segment's ".liv" file -> the FixedBitSet words
+ * rgpu_segment_upload takes (ceil(max_doc / 64) words; bit doc&63 of word doc>>6 set = live). Validates the index
+ * header, the checksum, clear ghost bits and, when del_count >= 0, max_doc - cardinality == del_count. */
+int32_t rgpu_live_docs_from_lucene50(const uint8_t* liv, size_t liv_len, int32_t max_doc, int32_t del_count, uint64_t* words_out);
 
 /* ---- measurement ------------------------------------------------------------------------------------------ */
 typedef struct rgpu_kernel_stat {

@@ -114,6 +114,8 @@ def _declare(L):
         "orc_mock_req_not": (C.c_int, [i32p, i32p, C.c_int, i32p, i32p, C.c_int, i32p, C.c_int, i32p, C.c_int]),
         "orc_norms_write": (C.c_int, [i64p, C.c_int32, C.c_int32, u8p, C.c_char_p, u8p, i64p, u8p, i64p]),
         "orc_norms_read": (C.c_int, [u8p, C.c_int64, u8p, C.c_int64, C.c_int32, C.c_int32, i64p]),
+        "orc_live_docs_write": (C.c_int, [i64p, C.c_int32, C.c_int32, C.c_int32, u8p, C.c_int64, u8p, i64p]),
+        "orc_live_docs_read": (C.c_int, [u8p, C.c_int64, C.c_int32, C.c_int32, i64p]),
         "orc_mock_conjunction": (C.c_int, [i32p, i32p, C.c_int, C.c_int32, i32p, f32p, C.c_int]),
         "orc_mock_conjunction_initial_score": (C.c_float, [i32p, i32p, C.c_int]),
         "orc_mock_disjunction": (C.c_int, [i32p, i32p, C.c_int, C.c_int, i32p, f32p, C.c_int]),
@@ -433,6 +435,24 @@ def norms_read(nvm, nvd, field_number, max_doc):
     out = np.zeros(max_doc, dtype=np.int64)
     _check(lib().orc_norms_read(_p(m, C.c_uint8), m.size, _p(d, C.c_uint8), d.size, field_number, max_doc, _p(out, C.c_int64)))
     return out
+
+
+def live_docs_write(words, max_doc, del_count, segment_id=None, gen=1):
+    """Lucene50LiveDocsFormat::write_live_docs: FixedBitSet words -> ".liv" bytes."""
+    w = np.ascontiguousarray(words).view(np.int64)
+    sid = np.frombuffer(segment_id if segment_id is not None else bytes(range(16)), dtype=np.uint8).copy()
+    n = C.c_int64(0)
+    _check(lib().orc_live_docs_write(_p(w, C.c_int64), w.size, max_doc, del_count, _p(sid, C.c_uint8), gen, None, C.byref(n)))
+    out = np.zeros(n.value, dtype=np.uint8)
+    _check(lib().orc_live_docs_write(_p(w, C.c_int64), w.size, max_doc, del_count, _p(sid, C.c_uint8), gen, _p(out, C.c_uint8), C.byref(n)))
+    return out.tobytes()
+
+
+def live_docs_read(liv, max_doc, del_count):
+    b = np.frombuffer(liv, dtype=np.uint8).copy()
+    out = np.zeros((max_doc + 63) // 64, dtype=np.int64)
+    _check(lib().orc_live_docs_read(_p(b, C.c_uint8), b.size, max_doc, del_count, _p(out, C.c_int64)))
+    return out.view(np.uint64)
 
 
 def mock_req_not(req_lists, not_lists, targets=()):

@@ -106,4 +106,45 @@ struct NormsProducer {
   }
 };
 
+// ---- Lucene50LiveDocsFormat (codec/live_docs.rs:63-161) ----------------------------------------------------------
+// PARITY UNPINNED as well (no reference test). write_live_docs :123-150, read_live_docs :81-121; to_base36
+// util/numeric.rs:148-161; bits2words util/bit_set.rs:480-484.
+inline std::string to_base36(uint64_t val) {
+  static const char digits[] = "0123456789abcdefghijklmnopqrstuvwxyz";
+  std::string r;
+  while (true) {
+    r.push_back(digits[val % 36]);
+    val /= 36;
+    if (val == 0) break;
+  }
+  return std::string(r.rbegin(), r.rend());
+}
+inline std::vector<uint8_t> write_live_docs(const std::vector<int64_t>& words, int32_t max_doc, int32_t del_count_total,
+                                            const uint8_t id[ID_LENGTH], uint64_t gen) {
+  int64_t live = 0;
+  for (int64_t w : words) live += __builtin_popcountll((uint64_t)w);
+  if ((int64_t)max_doc - live != del_count_total) throw OracleError(E_CORRUPT_INDEX, "bits.deleted != del_count + new_del_count");
+  ByteOut out;
+  write_index_header(out, "Lucene50LiveDocs", 0, id, to_base36(gen));
+  for (int64_t w : words) out.write_long(w);
+  write_footer(out);
+  return out.buf;
+}
+inline std::vector<int64_t> read_live_docs(const uint8_t* liv, size_t len, int32_t max_doc, int32_t del_count) {
+  ByteIn in(liv, (int64_t)len);
+  check_index_header(in, "Lucene50LiveDocs", 0, 0);
+  const size_t num_words = (size_t)(((max_doc - 1) >> 6) + 1);
+  std::vector<int64_t> bits;
+  for (size_t i = 0; i < num_words; i++) bits.push_back(in.read_long());
+  if (len < 16 || in.pos != (int64_t)len - 16) throw OracleError(E_CORRUPT_INDEX, "misplaced codec footer");
+  if (in.read_int() != FOOTER_MAGIC || in.read_int() != 0) throw OracleError(E_CORRUPT_INDEX, "codec footer mismatch");
+  const int64_t expected = in.read_long();
+  if ((int64_t)crc32_ieee(liv, len - 8) != expected) throw OracleError(E_CORRUPT_INDEX, "checksum failed");
+  int64_t live = 0;
+  for (int64_t w : bits) live += __builtin_popcountll((uint64_t)w);
+  if ((max_doc & 63) != 0 && ((uint64_t)bits.back() >> (max_doc & 63)) != 0) throw OracleError(E_ILLEGAL_STATE, "ghost bits");
+  if ((int64_t)max_doc - live != del_count) throw OracleError(E_CORRUPT_INDEX, "bits.deleted != info.delcount");
+  return bits;
+}
+
 }  // namespace orc

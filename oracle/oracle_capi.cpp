@@ -326,6 +326,24 @@ int orc_norms_read(const uint8_t* nvm, int64_t nvm_len, const uint8_t* nvd, int6
   ORC_CATCH
 }
 
+// Lucene50LiveDocsFormat: words (i64 FixedBitSet) -> ".liv" bytes (two-call protocol) and back
+int orc_live_docs_write(const int64_t* words, int32_t n_words, int32_t max_doc, int32_t del_count, const uint8_t* segment_id16,
+                        int64_t gen, uint8_t* out, int64_t* out_len) {
+  ORC_TRY
+  std::vector<uint8_t> b = write_live_docs(std::vector<int64_t>(words, words + n_words), max_doc, del_count, segment_id16, (uint64_t)gen);
+  if (out && *out_len >= (int64_t)b.size()) std::memcpy(out, b.data(), b.size());
+  *out_len = (int64_t)b.size();
+  return 0;
+  ORC_CATCH
+}
+int orc_live_docs_read(const uint8_t* liv, int64_t len, int32_t max_doc, int32_t del_count, int64_t* words_out) {
+  ORC_TRY
+  std::vector<int64_t> w = read_live_docs(liv, (size_t)len, max_doc, del_count);
+  std::memcpy(words_out, w.data(), w.size() * 8);
+  return 0;
+  ORC_CATCH
+}
+
 // ---- mock-scorer KATs (reference unit tests restated as callable probes) ---------------------------------------
 // conjunction_scorer.rs:162-222: children given as concatenated doc lists; emits (doc, score) via next() until end.
 int orc_mock_conjunction(const int32_t* docs, const int32_t* list_offsets, int n_lists, int32_t advance_first,

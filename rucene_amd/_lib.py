@@ -30,7 +30,7 @@ EXPORTS = [
     "rgpu_segment_free", "rgpu_segment_version", "rgpu_segment_prepare_terms", "rgpu_decode_terms",
     "rgpu_decode_terms_device", "rgpu_advance_batch", "rgpu_sim_table_upload", "rgpu_search_batch",
     "rgpu_search_batch_device", "rgpu_merge_topk_device", "rgpu_bm25_compute_weight", "rgpu_bm25_encode_norm",
-    "rgpu_norms_from_lucene53", "rgpu_kernel_stats", "rgpu_kernel_stats_reset", "rgpu_synchronize",
+    "rgpu_norms_from_lucene53", "rgpu_live_docs_from_lucene50", "rgpu_kernel_stats", "rgpu_kernel_stats_reset", "rgpu_synchronize",
 ]
 
 
@@ -105,6 +105,7 @@ def lib():
         "rgpu_bm25_compute_weight": (i32, [f32, f32, i64, i64, i64, vp, i32, f32, vp, vp, vp]),
         "rgpu_bm25_encode_norm": (C.c_uint8, [f32, i32]),
         "rgpu_norms_from_lucene53": (i32, [vp, C.c_size_t, vp, C.c_size_t, i32, i32, vp]),
+        "rgpu_live_docs_from_lucene50": (i32, [vp, C.c_size_t, i32, i32, vp]),
         "rgpu_kernel_stats": (i32, [vp, C.POINTER(_KernelStat), i32]),
         "rgpu_kernel_stats_reset": (None, [vp]),
         "rgpu_synchronize": (i32, [vp]),
@@ -144,6 +145,15 @@ def norms_from_lucene53(nvm, nvd, field_number, max_doc):
     out = np.zeros(max(int(max_doc), 0), dtype=np.uint8)
     _check(lib().rgpu_norms_from_lucene53(m.ctypes.data, m.size, d.ctypes.data, d.size, int(field_number), int(max_doc),
                                           out.ctypes.data if out.size else None))
+    return out
+
+
+def live_docs_from_lucene50(liv, max_doc, del_count=-1):
+    """Lucene50LiveDocsFormat::read_live_docs: a segment's ".liv" bytes -> u64[ceil(max_doc / 64)] FixedBitSet words.
+    Host-side parse, no GPU involved."""
+    b = np.frombuffer(bytes(liv), dtype=np.uint8)
+    out = np.zeros((max(int(max_doc), 1) + 63) // 64, dtype=np.uint64)
+    _check(lib().rgpu_live_docs_from_lucene50(b.ctypes.data, b.size, int(max_doc), int(del_count), out.ctypes.data))
     return out
 
 

@@ -128,3 +128,43 @@ inline int read_lucene53_norms(const uint8_t* nvm, size_t nvm_len, const uint8_t
 }
 
 }  // namespace rucene
+
+namespace rucene {
+
+// Lucene50LiveDocsFormat::read_live_docs (codec/live_docs.rs:81-121): ".liv" -> FixedBitSet words (bit doc&63 of word
+// doc>>6 set = live, util/bit_set.rs:453-460) as rgpu_segment_upload takes them. Checks the index header (codec
+// "Lucene50LiveDocs", version 0; the suffix is base36(del_gen), which only the caller's SegmentCommitInfo could
+// confirm), the footer checksum, clear ghost bits (FixedBitSet::copy_from, bit_set.rs:155-171) and — when
+// del_count >= 0 — `max_doc - cardinality == del_count`.
+inline int read_lucene50_live_docs(const uint8_t* liv, size_t liv_len, int32_t max_doc, int32_t del_count, uint64_t* words_out,
+                                   std::string* why) {
+  const int ERR_ARG = -2, ERR_EOF = -3, ERR_CORRUPT = -4;
+  if (!liv || !words_out || max_doc <= 0) { *why = "bad arguments"; return ERR_ARG; }
+  detail::Cursor c{liv, liv_len};
+  int32_t version = 0;
+  const uint8_t* id = nullptr;
+  std::string suffix;
+  int rc = detail::read_index_header(c, "Lucene50LiveDocs", 0, 0, &version, &id, &suffix, why);
+  if (rc) return rc;
+  const size_t num_words = (size_t)(((max_doc - 1) >> 6) + 1);  // bits2words, bit_set.rs:480-484
+  if (c.pos + 8 * num_words + 16 > liv_len) { *why = "live docs file shorter than max_doc needs"; return ERR_EOF; }
+  int64_t live = 0;
+  for (size_t w = 0; w < num_words; ++w) {
+    const uint64_t v = detail::be64_at(liv + c.pos + 8 * w);
+    words_out[w] = v;
+    live += __builtin_popcountll(v);
+  }
+  c.pos += 8 * num_words;
+  uint64_t stored = 0;
+  rc = detail::read_footer(liv, liv_len, c.pos, &stored, why);
+  if (rc) return rc;
+  if ((uint64_t)detail::crc32_ieee(liv, liv_len - 8) != stored) { *why = "checksum failed (hardware problems?) in live docs"; return ERR_CORRUPT; }
+  if ((max_doc & 63) != 0 && (words_out[num_words - 1] >> (max_doc & 63)) != 0) { *why = "ghost bits set past max_doc"; return ERR_CORRUPT; }
+  if (del_count >= 0 && (int64_t)max_doc - live != (int64_t)del_count) {
+    *why = "bits.deleted= " + std::to_string((int64_t)max_doc - live) + " info.delcount= " + std::to_string(del_count);
+    return ERR_CORRUPT;
+  }
+  return 0;
+}
+
+}  // namespace rucene

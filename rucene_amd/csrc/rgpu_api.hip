@@ -1104,6 +1104,13 @@ extern "C" int32_t rgpu_norms_from_lucene53(const uint8_t* nvm, size_t nvm_len, 
   return rc == 0 ? RGPU_OK : fail(rc, why);
 }
 
+extern "C" int32_t rgpu_live_docs_from_lucene50(const uint8_t* liv, size_t liv_len, int32_t max_doc, int32_t del_count,
+                                                uint64_t* words_out) {
+  std::string why;
+  const int rc = rucene::read_lucene50_live_docs(liv, liv_len, max_doc, del_count, words_out, &why);
+  return rc == 0 ? RGPU_OK : fail(rc, why);
+}
+
 extern "C" uint8_t rgpu_bm25_encode_norm(float boost, int32_t field_length) {
   return rucene::BM25Similarity::encode_norm_value(boost, field_length);
 }

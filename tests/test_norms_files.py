@@ -94,3 +94,46 @@ def test_corrupt_files_are_rejected(rgpu, oracle):
     head = _header(b"Lucene53NormsMetadata")
     bad = _footer(head + bytes([2, 3]) + struct.pack(">q", 41) + b"\xff\xff\xff\xff\x0f")
     assert status(bad, nvd) == -4
+
+
+# ---- Lucene50LiveDocsFormat (".liv") ----------------------------------------------------------------------------------------
+def test_live_docs_file_round_trip_and_hand_assembled(rgpu, oracle):
+    rng = np.random.default_rng(12)
+    for max_doc in (1, 63, 64, 65, 1000, 4096, 50_001):
+        bits = rng.random(max_doc) < 0.9
+        words = np.zeros((max_doc + 63) // 64, dtype=np.uint64)
+        idx = np.nonzero(bits)[0]
+        np.bitwise_or.at(words, idx >> 6, np.uint64(1) << (idx & 63).astype(np.uint64))
+        dels = int(max_doc - bits.sum())
+        liv = oracle.live_docs_write(words, max_doc, dels, gen=37)
+        # header: codec Lucene50LiveDocs, version 0, suffix = base36(gen) = "11"; then big-endian words; then the footer
+        head = _header(b"Lucene50LiveDocs", suffix=b"11")
+        assert liv == _footer(head + b"".join(struct.pack(">Q", int(w)) for w in words))
+        assert (rgpu.live_docs_from_lucene50(liv, max_doc, dels) == words).all()
+        assert (rgpu.live_docs_from_lucene50(liv, max_doc) == words).all()        # del_count unknown: not checked
+        assert (oracle.live_docs_read(liv, max_doc, dels) == words).all()
+
+
+def test_live_docs_file_corruption(rgpu, oracle):
+    max_doc = 200
+    words = np.full(4, 0xFFFFFFFFFFFFFFFF, dtype=np.uint64)
+    words[3] = np.uint64((1 << (200 - 192)) - 1)
+    words[1] &= ~np.uint64(0b1011)
+    liv = oracle.live_docs_write(words, max_doc, 3)
+
+    def status(b, n=max_doc, dc=3):
+        with pytest.raises(rgpu.RgpuError) as e:
+            rgpu.live_docs_from_lucene50(b, n, dc)
+        return e.value.status
+
+    assert status(liv, dc=2) == -4                                   # bits.deleted != info.delcount
+    assert status(liv[:-1]) in (-3, -4)
+    assert status(liv[:5] + b"X" + liv[6:]) == -4                    # codec name
+    body = bytearray(liv)
+    body[len(_header(b"Lucene50LiveDocs", suffix=b"1")) + 3] ^= 1    # a payload bit: checksum fails
+    assert status(bytes(body)) == -4
+    assert status(liv, n=500) == -3                                  # file too short for that many docs
+    ghost = words.copy()
+    ghost[3] |= np.uint64(1 << 20)                                   # a bit past max_doc
+    head = _header(b"Lucene50LiveDocs", suffix=b"1")
+    assert status(_footer(head + b"".join(struct.pack(">Q", int(w)) for w in ghost)), dc=-1) == -4
