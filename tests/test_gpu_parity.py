@@ -511,3 +511,27 @@ def test_must_not_clauses_edge_terms_and_live_docs(ctx, oracle):
                   (oracle.OP_AND, [11, 9], [8]), (oracle.OP_OR, [7, 8], [9]), (oracle.OP_OR, [0, 1, 2, 3], [4, 5]), (oracle.OP_OR, [11, 6], [10, 9]),
                   (oracle.OP_OR, [11], [9]), (oracle.OP_OR, [9, 10, 8, 7, 6], [3, 1, 11])]
         _check_not_queries(oracle, osearcher, gsearcher, specs, 10)
+
+
+def test_segment_ingested_from_index_files(ctx, oracle):
+    """A segment uploaded from what a Rucene directory holds — ".doc", ".nvm" + ".nvd", ".liv" — answers exactly like
+    one built from the in-memory arrays (the file readers are host code behind the C ABI)."""
+    import rucene_amd
+    from rucene_amd import indexgen
+    max_doc = 120_000
+    seg = indexgen.build_zipf(max_doc, 8_000)
+    rng = np.random.default_rng(404)
+    bits = rng.random(max_doc) < 0.93
+    live = np.zeros((max_doc + 63) // 64, dtype=np.uint64)
+    idx = np.nonzero(bits)[0]
+    np.bitwise_or.at(live, idx >> 6, np.uint64(1) << (idx & 63).astype(np.uint64))
+    nvm, nvd = oracle.norms_write(seg.norms.astype(np.int64), field_number=1)
+    liv = oracle.live_docs_write(live, max_doc, int(max_doc - bits.sum()), gen=2)
+    norms_f = rucene_amd.norms_from_lucene53(nvm, nvd, 1, max_doc)
+    live_f = rucene_amd.live_docs_from_lucene50(liv, max_doc, int(max_doc - bits.sum()))
+    leaf = rucene_amd.LeafReader(seg.doc_bytes, norms_f, max_doc, seg.terms, live_docs=live_f, sum_total_term_freq=seg.sum_total_term_freq)
+    oseg = oracle.Segment(seg.doc_bytes, seg.norms, max_doc, seg.terms, live_docs=live, sum_total_term_freq=seg.sum_total_term_freq)
+    gsearcher = rucene_amd.GpuIndexSearcher([leaf], ctx=ctx)
+    osearcher = oracle.Searcher([oseg])
+    specs = [(oracle.OP_TERM, [t]) for t in (0, 3, 50, 700, 7_999)] + [(oracle.OP_AND, [1, 4]), (oracle.OP_AND, [0, 2, 9]), (oracle.OP_OR, [5, 60, 600])]
+    _check_against_oracle(oracle, osearcher, gsearcher, specs, 10)
