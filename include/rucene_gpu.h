@@ -83,11 +83,16 @@ typedef struct rgpu_query_term {
 typedef enum rgpu_query_op {
   RGPU_OP_TERM = 0, /* TermQuery                      -> TermScorer (term_scorer.rs:43-67) */
   RGPU_OP_AND = 1,  /* BooleanQuery, all MUST         -> ConjunctionScorer (conjunction_scorer.rs:26-128) */
-  RGPU_OP_OR = 2    /* BooleanQuery, all SHOULD, msm 1 -> DisjunctionSumScorer (disjunction_scorer.rs:24-104) */
+  RGPU_OP_OR = 2    /* BooleanQuery, all SHOULD         -> DisjunctionSumScorer (disjunction_scorer.rs:24-104) */
 } rgpu_query_op;
+/* rgpu_query.op for an OR query may carry BooleanQuery's min_should_match in its second byte:
+ * RGPU_OP_OR | (msm << 8). 0 and 1 are the default (any clause matches); msm >= 2 collects only docs held by at least
+ * that many SHOULD clauses (disjunction_scorer.rs:317-329) and, as in the reference, sums in clause order whatever
+ * the clause count (SimpleQueue is forced, :41), so those scores are bit-exact. */
+#define RGPU_OP_OR_MSM(msm) ((int32_t)RGPU_OP_OR | ((int32_t)(msm) << 8))
 
 typedef struct rgpu_query {
-  int32_t op;          /* rgpu_query_op */
+  int32_t op;          /* rgpu_query_op (OR: optionally RGPU_OP_OR_MSM(msm)) */
   int32_t n_terms;     /* positive clauses: 1 for TERM, 1..RGPU_MAX_QUERY_TERMS MUST (AND) / SHOULD (OR) clauses */
   int32_t first_term;  /* index of this query's first clause in the `terms` array */
   int32_t n_must_not;  /* MUST_NOT TermQuery clauses, stored right after the positive ones (weight / sim_table unused):

@@ -108,8 +108,8 @@ def _declare(L):
         "orc_searcher_term_weight": (C.c_float, [vp, C.c_int64, C.c_float, f32p]),
         "orc_search": (C.c_int, [vp, C.c_int, i64p, C.c_int, f32p, C.c_int, C.c_int, C.c_int, C.c_int, i32p, f32p, i32p, i64p]),
         "orc_search_batch": (C.c_double, [vp, C.c_int, i32p, i32p, i64p, C.c_int, C.c_int, C.c_int, i32p, f32p, i32p, i64p, u64p]),
-        "orc_search_batch_not": (C.c_double, [vp, C.c_int, i32p, i32p, i64p, i32p, i64p, C.c_int, C.c_int, C.c_int, i32p, f32p, i32p,
-                                              i64p, u64p]),
+        "orc_search_batch_not": (C.c_double, [vp, C.c_int, i32p, i32p, i64p, i32p, i64p, i32p, C.c_int, C.c_int, C.c_int, i32p, f32p,
+                                              i32p, i64p, u64p]),
         "orc_search_not": (C.c_int, [vp, C.c_int, i64p, C.c_int, i64p, C.c_int, C.c_int, C.c_int, i32p, f32p, i32p, i64p]),
         "orc_mock_req_not": (C.c_int, [i32p, i32p, C.c_int, i32p, i32p, C.c_int, i32p, C.c_int, i32p, C.c_int]),
         "orc_norms_write": (C.c_int, [i64p, C.c_int32, C.c_int32, u8p, C.c_char_p, u8p, i64p, u8p, i64p]),
@@ -345,21 +345,26 @@ class Searcher:
                                     _p(docs, C.c_int32), _p(scores, C.c_float), C.byref(n), C.byref(total)))
         return docs[:n.value].copy(), scores[:n.value].copy(), total.value
 
-    def search_batch(self, ops, term_offsets, term_ids, k, tie_mode=TIE_CANONICAL, threads=1, not_offsets=None, not_ids=None):
+    def search_batch(self, ops, term_offsets, term_ids, k, tie_mode=TIE_CANONICAL, threads=1, not_offsets=None, not_ids=None,
+                     min_should_match=None):
         ops = np.ascontiguousarray(ops, dtype=np.int32)
         offs = np.ascontiguousarray(term_offsets, dtype=np.int32)
         tids = np.ascontiguousarray(term_ids, dtype=np.int64)
         nq = ops.size
-        if not_offsets is not None:
+        if not_offsets is not None or min_should_match is not None:
+            if not_offsets is None:
+                not_offsets, not_ids = np.zeros(nq + 1, np.int32), np.zeros(0, np.int64)
             noffs = np.ascontiguousarray(not_offsets, dtype=np.int32)
             nids = np.ascontiguousarray(not_ids, dtype=np.int64)
+            msms = None if min_should_match is None else np.ascontiguousarray(min_should_match, dtype=np.int32)
             docs = np.full((nq, k), -1, dtype=np.int32)
             scores = np.zeros((nq, k), dtype=np.float32)
             counts = np.zeros(nq, dtype=np.int32)
             totals = np.zeros(nq, dtype=np.int64)
             visited = np.zeros(nq, dtype=np.uint64)
             secs = lib().orc_search_batch_not(self._h, nq, _p(ops, C.c_int32), _p(offs, C.c_int32), _p(tids, C.c_int64),
-                                              _p(noffs, C.c_int32), _p(nids, C.c_int64), k, tie_mode, threads, _p(docs, C.c_int32),
+                                              _p(noffs, C.c_int32), _p(nids, C.c_int64), _p(msms, C.c_int32), k, tie_mode, threads,
+                                              _p(docs, C.c_int32),
                                               _p(scores, C.c_float), _p(counts, C.c_int32), _p(totals, C.c_int64),
                                               _p(visited, C.c_uint64))
             if secs < 0:

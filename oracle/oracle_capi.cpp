@@ -256,20 +256,20 @@ int orc_search_not(orc_searcher* s, int op, const int64_t* term_ids, int n_terms
 // query per segment, searcher shared across threads — searcher.rs:527-630 falls back to sequential search
 // for a single large segment). Returns elapsed seconds; fills per-query outputs.
 double orc_search_batch_not(orc_searcher* s, int n_queries, const int32_t* ops, const int32_t* term_offsets,
-                            const int64_t* term_ids, const int32_t* not_offsets, const int64_t* not_ids, int k, int tie_mode,
-                            int threads, int32_t* out_docs, float* out_scores, int32_t* out_counts, int64_t* out_totals,
-                            uint64_t* out_visited);
+                            const int64_t* term_ids, const int32_t* not_offsets, const int64_t* not_ids, const int32_t* msms,
+                            int k, int tie_mode, int threads, int32_t* out_docs, float* out_scores, int32_t* out_counts,
+                            int64_t* out_totals, uint64_t* out_visited);
 double orc_search_batch(orc_searcher* s, int n_queries, const int32_t* ops, const int32_t* term_offsets,
                         const int64_t* term_ids, int k, int tie_mode, int threads, int32_t* out_docs, float* out_scores,
                         int32_t* out_counts, int64_t* out_totals, uint64_t* out_visited) {
-  return orc_search_batch_not(s, n_queries, ops, term_offsets, term_ids, nullptr, nullptr, k, tie_mode, threads, out_docs,
-                              out_scores, out_counts, out_totals, out_visited);
+  return orc_search_batch_not(s, n_queries, ops, term_offsets, term_ids, nullptr, nullptr, nullptr, k, tie_mode, threads,
+                              out_docs, out_scores, out_counts, out_totals, out_visited);
 }
-// not_offsets / not_ids: per-query MUST_NOT term ids (null = none)
+// not_offsets / not_ids: per-query MUST_NOT term ids (null = none); msms: per-query min_should_match (null = default)
 double orc_search_batch_not(orc_searcher* s, int n_queries, const int32_t* ops, const int32_t* term_offsets,
-                            const int64_t* term_ids, const int32_t* not_offsets, const int64_t* not_ids, int k, int tie_mode,
-                            int threads, int32_t* out_docs, float* out_scores, int32_t* out_counts, int64_t* out_totals,
-                            uint64_t* out_visited) {
+                            const int64_t* term_ids, const int32_t* not_offsets, const int64_t* not_ids, const int32_t* msms,
+                            int k, int tie_mode, int threads, int32_t* out_docs, float* out_scores, int32_t* out_counts,
+                            int64_t* out_totals, uint64_t* out_visited) {
   std::atomic<int> next_q{0};
   std::atomic<int> failed{0};
   auto t0 = std::chrono::steady_clock::now();
@@ -279,7 +279,7 @@ double orc_search_batch_not(orc_searcher* s, int n_queries, const int32_t* ops, 
       if (qi >= n_queries) break;
       try {
         int n_terms = term_offsets[qi + 1] - term_offsets[qi];
-        Query q = make_query(ops[qi], term_ids + term_offsets[qi], n_terms, nullptr, 0);
+        Query q = make_query(ops[qi], term_ids + term_offsets[qi], n_terms, nullptr, msms ? msms[qi] : 0);
         if (not_offsets) q.must_not_ids.assign(not_ids + not_offsets[qi], not_ids + not_offsets[qi + 1]);
         SearchResult r = s->s.search(q, (size_t)k, tie_mode);
         out_counts[qi] = (int32_t)r.hits.size();

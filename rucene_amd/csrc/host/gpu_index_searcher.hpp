@@ -85,8 +85,8 @@ struct BooleanQuery : Query {
       throw Error(RGPU_ERR_ILLEGAL_ARGUMENT, "boolean query should at least contain one inner query!");
     if (must_nots.empty() && musts.size() + shoulds.size() == 1)
       return std::unique_ptr<Query>(new TermQuery(musts.empty() ? shoulds[0] : musts[0]));
-    if ((!musts.empty() && !shoulds.empty()) || msm > 1 || (musts.empty() && shoulds.empty()))
-      throw Error(RGPU_ERR_UNSUPPORTED, "only MUST (+MUST_NOT) and SHOULD (+MUST_NOT, min_should_match 1) term trees run on the GPU path");
+    if ((!musts.empty() && !shoulds.empty()) || (msm > 1 && !musts.empty()) || msm > 255 || (musts.empty() && shoulds.empty()))
+      throw Error(RGPU_ERR_UNSUPPORTED, "only MUST (+MUST_NOT) and SHOULD (+MUST_NOT, min_should_match) term trees run on the GPU path");
     auto q = std::unique_ptr<BooleanQuery>(new BooleanQuery());
     q->must_queries = std::move(musts);
     q->should_queries = std::move(shoulds);
@@ -210,7 +210,7 @@ class GpuIndexSearcher {
       single.push_back(*t);
       clauses = &single;
     } else if (auto* b = dynamic_cast<const BooleanQuery*>(&q)) {
-      op = b->must_queries.empty() ? RGPU_OP_OR : RGPU_OP_AND;
+      op = b->must_queries.empty() ? (b->min_should_match > 1 ? RGPU_OP_OR_MSM(b->min_should_match) : (int32_t)RGPU_OP_OR) : (int32_t)RGPU_OP_AND;
       clauses = b->must_queries.empty() ? &b->should_queries : &b->must_queries;
       nots = &b->must_not_queries;
     } else {

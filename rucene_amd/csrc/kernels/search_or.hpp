@@ -95,8 +95,10 @@ constexpr uint32_t OR_UNTOUCHED = 0xffffffffu;  // accumulator patterns no sum o
 constexpr uint32_t OR_EXCLUDED = 0xfffffffeu;
 
 // items = (query, group of `windows_per_item` windows of `W` docs), one per wavefront
-// HAS_NOT: some query of the launch carries MUST_NOT clauses (a second instantiation keeps the common kernel lean)
-template <bool WIDE, bool HAS_NOT>
+// HAS_NOT: some query of the launch carries MUST_NOT clauses; HAS_MSM: some query asks for min_should_match > 1
+// (disjunction_scorer.rs:317-329: a doc is a hit only if that many SHOULD clauses hold it — a per-doc clause counter
+// next to the accumulator). Separate instantiations keep the common kernel lean.
+template <bool WIDE, bool HAS_NOT, bool HAS_MSM>
 __global__ __launch_bounds__(WG_THREADS) void k_or_windows(SegView seg, const DevQuery* __restrict__ queries,
                                                            const DevTerm* __restrict__ terms,
                                                            const int64_t* __restrict__ run_prefix,
@@ -112,8 +114,9 @@ __global__ __launch_bounds__(WG_THREADS) void k_or_windows(SegView seg, const De
   // per-wave LDS slice: acc[W] f32 | hits[W] u16 (window offsets of touched docs, in first-touch order). An
   // untouched accumulator holds OR_UNTOUCHED, a NaN pattern no sum of scores produces; the hit scan at the end
   // of a window puts it back, so no per-doc flag array and no clearing pass are needed.
-  float* acc = reinterpret_cast<float*>(smem + (size_t)wave * (size_t)W * 6);
+  float* acc = reinterpret_cast<float*>(smem + (size_t)wave * (size_t)W * (HAS_MSM ? 7 : 6));
   uint16_t* hits = reinterpret_cast<uint16_t*>(acc + W);
+  uint8_t* cnt = reinterpret_cast<uint8_t*>(hits + W);  // HAS_MSM only: SHOULD clauses that hold the doc
   const int64_t item = (int64_t)blockIdx.x * WG_WAVES + wave;
   if (item >= (int64_t)n_queries * items_per_query) return;
   const int q = (int)(item / items_per_query);
@@ -134,6 +137,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_or_windows(SegView seg, const De
   // SHOULD clauses) take lanes 0 .. n_not-1 so that a window meets them first: ReqNotScorer over the disjunction
   // (boolean_query.rs:271-273, req_not_scorer.rs:47-63) — their docs are marked excluded before anything is summed.
   const int n_not = HAS_NOT ? Q.pad : 0;
+  const int msm = HAS_MSM ? (Q.op >> 8) : 1;
   const bool mine = lane < Q.n_terms + n_not;
   const int my_clause = lane < n_not ? Q.n_terms + lane : lane - n_not;
   const int64_t my_base = mine ? run_prefix[Q.first_term + my_clause] : 0;
@@ -187,6 +191,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_or_windows(SegView seg, const De
             if (first) acc[o] = __uint_as_float(OR_EXCLUDED);
           } else if (!HAS_NOT || __float_as_uint(a) != OR_EXCLUDED) {
             acc[o] = (first ? 0.0f : a) + e.score;  // 0.0f + s: the reference's `score = 0; score += s`
+            if (HAS_MSM) cnt[o] = first ? (uint8_t)1 : (uint8_t)(cnt[o] + 1);
           }
         }
         const uint64_t fm = __ballot(first);
@@ -200,13 +205,13 @@ __global__ __launch_bounds__(WG_THREADS) void k_or_windows(SegView seg, const De
       wave_sync();
     }
     // every touched doc that no prohibited clause claimed is one collected hit
-    if (!HAS_NOT) count += nhits;
+    if (!HAS_NOT && !HAS_MSM) count += nhits;
     for (int i0 = 0; i0 < nhits; i0 += 64) {  // uniform trip count: the offer is a wave-wide operation
       const bool valid = i0 + lane < nhits;
       const int o = valid ? hits[i0 + lane] : 0;
       const float a = valid ? acc[o] : 0.0f;
-      const bool hit = valid && (!HAS_NOT || __float_as_uint(a) != OR_EXCLUDED);
-      if (HAS_NOT) count += __popcll(__ballot(hit));
+      const bool hit = valid && (!HAS_NOT || __float_as_uint(a) != OR_EXCLUDED) && (!HAS_MSM || (int)cnt[o] >= msm);
+      if (HAS_NOT || HAS_MSM) count += __popcll(__ballot(hit));
       const uint64_t key = hit ? make_key(a, w0 + o) : 0ull;
       if (valid) acc[o] = __uint_as_float(OR_UNTOUCHED);
       if (__ballot(key > tau)) topk_offer<WIDE>(top, key, tau, k, lane, floor);

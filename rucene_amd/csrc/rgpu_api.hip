@@ -776,7 +776,9 @@ static int32_t search_or_group(rgpu_segment* seg, Group& G, int32_t k, HitOut* h
   }
   {
     TimedLaunch tl(c, stream, "k_or_windows", G.postings);
-    const size_t lds = (size_t)WG_WAVES * (size_t)W * 6;
+    bool has_not = false, has_msm = false;
+    for (const DevQuery& dq : G.queries) { has_not = has_not || dq.pad != 0; has_msm = has_msm || (dq.op >> 8) > 1; }
+    const size_t lds = (size_t)WG_WAVES * (size_t)W * (has_msm ? 7 : 6);
     const unsigned grid = (unsigned)((items2 + WG_WAVES - 1) / WG_WAVES);
     auto go = [&](auto kern) -> hipError_t {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -785,10 +787,13 @@ static int32_t search_or_group(rgpu_segment* seg, Group& G, int32_t k, HitOut* h
                          c->S->d_partial_keys.p, c->S->d_partial_counts.p, c->S->d_tau.p);
       return hipSuccess;
     };
-    bool has_not = false;
-    for (const DevQuery& dq : G.queries) has_not = has_not || dq.pad != 0;
-    if (has_not) HIP_TRY(wide ? go(k_or_windows<true, true>) : go(k_or_windows<false, true>));
-    else HIP_TRY(wide ? go(k_or_windows<true, false>) : go(k_or_windows<false, false>));
+    if (has_msm) {  // min_should_match > 1 somewhere: the general instantiation (it also handles MUST_NOT clauses)
+      HIP_TRY(wide ? go(k_or_windows<true, true, true>) : go(k_or_windows<false, true, true>));
+    } else if (has_not) {
+      HIP_TRY(wide ? go(k_or_windows<true, true, false>) : go(k_or_windows<false, true, false>));
+    } else {
+      HIP_TRY(wide ? go(k_or_windows<true, false, false>) : go(k_or_windows<false, false, false>));
+    }
   }
   if (wide) launch_merge<true>(c, stream, nq, k, dmp, seg->doc_base, c->S->d_hits.p, c->S->d_totals.p);
   else launch_merge<false>(c, stream, nq, k, dmp, seg->doc_base, c->S->d_hits.p, c->S->d_totals.p);
@@ -806,8 +811,10 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
   std::vector<const rgpu_term_state*> ptrs;
   for (int32_t q = 0; q < n_queries; ++q) {
     const rgpu_query& Q = queries[q];
-    if (Q.op < RGPU_OP_TERM || Q.op > RGPU_OP_OR) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "unknown query op");
-    if (Q.n_terms < 1 || Q.n_must_not < 0 || Q.n_terms + Q.n_must_not > RGPU_MAX_QUERY_TERMS || (Q.op == RGPU_OP_TERM && Q.n_terms != 1))
+    const int qop = Q.op & 0xff, qmsm = (Q.op >> 8) & 0xff;
+    if (qop < RGPU_OP_TERM || qop > RGPU_OP_OR || (Q.op >> 16) != 0) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "unknown query op");
+    if (qmsm > 1 && qop != RGPU_OP_OR) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "min_should_match applies to SHOULD clauses (op OR) only");
+    if (Q.n_terms < 1 || Q.n_must_not < 0 || Q.n_terms + Q.n_must_not > RGPU_MAX_QUERY_TERMS || (qop == RGPU_OP_TERM && Q.n_terms != 1))
       return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "bad clause count");
     if (Q.first_term < 0 || Q.first_term + Q.n_terms + Q.n_must_not > n_terms_total)
       return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "clause range outside terms[]");
@@ -828,13 +835,14 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
   std::vector<DevTerm> mine, mine_not;
   for (int32_t q = 0; q < n_queries; ++q) {
     const rgpu_query& Q = queries[q];
+    const int qop = Q.op & 0xff, qmsm = (Q.op >> 8) & 0xff;  // low byte: rgpu_query_op; next byte: min_should_match (OR)
     mine.clear();
     mine_not.clear();
     bool dead = false;
     for (int i = 0; i < Q.n_terms; ++i) {
       const rgpu_query_term& t = terms[Q.first_term + i];
       if (t.state.doc_freq <= 0) {  // TermWeight::create_scorer -> None for this leaf
-        if (Q.op != RGPU_OP_OR) dead = true;  // a missing MUST clause kills the conjunction (boolean_query.rs:201-207)
+        if (qop != RGPU_OP_OR) dead = true;  // a missing MUST clause kills the conjunction (boolean_query.rs:201-207)
         continue;
       }
       DevTerm dt;
@@ -854,10 +862,10 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
         mine_not.push_back(dt);
       }
     }
-    if (Q.op == RGPU_OP_AND)  // ConjunctionScorer::new: stable sort by cost() = doc_freq (conjunction_scorer.rs:30)
+    if (qop == RGPU_OP_AND)  // ConjunctionScorer::new: stable sort by cost() = doc_freq (conjunction_scorer.rs:30)
       std::stable_sort(mine.begin(), mine.end(), [](const DevTerm& a, const DevTerm& b) { return a.df < b.df; });
     // a term with prohibited clauses runs as a one-clause conjunction (the lead-driven kernel probes them)
-    const int gop = (Q.op == RGPU_OP_TERM && !mine_not.empty()) ? (int)RGPU_OP_AND : Q.op;
+    const int gop = (qop == RGPU_OP_TERM && !mine_not.empty()) ? (int)RGPU_OP_AND : qop;
     if (gop == RGPU_OP_OR && groups[(size_t)cur_group[2]].postings > or_postings_cap) {
       groups.emplace_back();
       groups.back().op = RGPU_OP_OR;
@@ -865,7 +873,7 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
     }
     Group& G = groups[(size_t)cur_group[gop]];
     DevQuery dq;
-    dq.op = gop;
+    dq.op = gop | (qmsm > 1 ? qmsm << 8 : 0);  // the window kernel reads min_should_match from the second byte
     dq.first_term = (int32_t)G.terms.size();
     dq.n_terms = (int32_t)mine.size();
     dq.pad = (int32_t)mine_not.size();
@@ -896,7 +904,8 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
     const bool lead_driven = op == RGPU_OP_TERM || (op == RGPU_OP_AND && !c->cfg.reserved[1]);
     if (!lead_driven)  // the doc-window kernel (A/B knobs reserved[1], [2]) predates MUST_NOT clauses
       for (const DevQuery& dq : G.queries)
-        if (dq.pad) return fail(RGPU_ERR_UNSUPPORTED, "MUST_NOT clauses are not served by the doc-window kernel");
+        if (dq.pad || (dq.op >> 8) > 1)
+          return fail(RGPU_ERR_UNSUPPORTED, "MUST_NOT clauses / min_should_match > 1 are not served by the doc-window kernel");
     int blocks_per_item = op == RGPU_OP_TERM ? c->cfg.blocks_per_item : c->cfg.reserved[0];
     int W = c->cfg.window_docs, wpq = 0, wpi = 1, ipq = 0;
     int64_t items = 0;

@@ -85,7 +85,7 @@ class TermQuery:
 
 
 class BooleanQuery:
-    """Only the trees the GPU path serves: all-MUST (AND) or all-SHOULD with min_should_match 1 (OR), each
+    """Only the trees the GPU path serves: all-MUST (AND) or all-SHOULD with any min_should_match (OR), each
     optionally with MUST_NOT TermQuery clauses (ReqNotScorer, boolean_query.rs:235-273)."""
 
     def __init__(self, must_queries, should_queries, min_should_match, must_not_queries=()):
@@ -100,8 +100,8 @@ class BooleanQuery:
             raise RgpuError(-2, "boolean query should at least contain one inner query!")
         if len(must_nots) == 0 and len(musts) + len(shoulds) + len(filters) == 1 and len(filters) == 0:
             return (list(musts) + list(shoulds))[0]
-        if filters or (musts and shoulds) or msm > 1:
-            raise RgpuError(-5, "only MUST (+MUST_NOT) and SHOULD (+MUST_NOT, min_should_match 1) term trees run on the GPU path")
+        if filters or (musts and shoulds) or (msm > 1 and musts) or msm > 255:
+            raise RgpuError(-5, "only MUST (+MUST_NOT) and SHOULD (+MUST_NOT, min_should_match) term trees run on the GPU path")
         if len(musts) + len(shoulds) == 0:
             raise RgpuError(-5, "a MUST_NOT-only query (MatchAllDocsQuery minus ...) is not served by the GPU path")
         if any(not isinstance(q, TermQuery) for q in list(musts) + list(shoulds) + list(must_nots)):
@@ -179,7 +179,8 @@ class GpuIndexSearcher:
         if isinstance(query, BooleanQuery):
             if query.must_queries:
                 return OP_AND, query.must_queries, query.must_not_queries
-            return OP_OR, query.should_queries, query.must_not_queries
+            msm = query.min_should_match
+            return (OP_OR | (msm << 8) if msm > 1 else OP_OR), query.should_queries, query.must_not_queries
         raise RgpuError(-5, "query type not served by the GPU path: %r" % (query,))
 
     def pack(self, queries, leaf):

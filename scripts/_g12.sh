@@ -1,2 +1,4 @@
 cd $GRAFT_REPO_ROOT
-for i in 1 2 3 4; do timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -1 | cut -c1-200; done
+mkdir -p gpurun_out/g12
+timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/g12/pytest.log 2>&1; echo "pytest rc=$?"; tail -30 gpurun_out/g12/pytest.log | cut -c1-300
+python scripts/run_workload.py or10 5 | tail -1

@@ -535,3 +535,41 @@ def test_segment_ingested_from_index_files(ctx, oracle):
     osearcher = oracle.Searcher([oseg])
     specs = [(oracle.OP_TERM, [t]) for t in (0, 3, 50, 700, 7_999)] + [(oracle.OP_AND, [1, 4]), (oracle.OP_AND, [0, 2, 9]), (oracle.OP_OR, [5, 60, 600])]
     _check_against_oracle(oracle, osearcher, gsearcher, specs, 10)
+
+
+def test_min_should_match(zipf, oracle):
+    """DisjunctionSumScorer with min_should_match > 1 (disjunction_scorer.rs:41, 317-329): only docs held by that many
+    SHOULD clauses are collected, and the clause-order sum (SimpleQueue is forced) is bit-exact even past 10 clauses.
+    With MUST_NOT clauses the prohibited union ignores the count (ReqNotScorer only ever calls advance())."""
+    import rucene_amd
+    from rucene_amd import indexgen
+    seg, osearcher, gsearcher = zipf
+    T, B = rucene_amd.TermQuery, rucene_amd.BooleanQuery
+    rows = indexgen.log_uniform_ranks(14 * 40, 1, 400, seed=4242).reshape(-1, 14) - 1
+    specs = []
+    for i, row in enumerate(rows):
+        row = [int(x) for x in row]
+        n = 2 + i % 11                       # 2 .. 12 SHOULD clauses
+        msm = 2 + i % min(3, n - 1)          # 2 .. 4, never more than the clause count
+        nots = row[12:12 + i % 3]
+        specs.append((row[:n], msm, nots))
+    specs += [([0, 1], 2, []), ([0, 0, 1], 2, []), ([0, 1, 2], 3, [3]), ([5, 6], 3, []), ([0, 49_999, 1], 2, [])]
+    queries = [B.build([], [T(t) for t in pos], must_nots=[T(t) for t in nots], min_should_match=msm) for pos, msm, nots in specs]
+    offs = np.zeros(len(specs) + 1, np.int32)
+    offs[1:] = np.cumsum([len(p) for p, _, _ in specs])
+    noffs = np.zeros(len(specs) + 1, np.int32)
+    noffs[1:] = np.cumsum([len(n) for _, _, n in specs])
+    tids = np.concatenate([np.asarray(p, np.int64) for p, _, _ in specs])
+    nids = np.concatenate([np.asarray(n, np.int64) for _, _, n in specs] + [np.zeros(0, np.int64)])
+    msms = np.asarray([m for _, m, _ in specs], np.int32)
+    ops = np.full(len(specs), oracle.OP_OR, np.int32)
+    for k in (10, 100):
+        hits, totals = gsearcher.search_batch(queries, k)
+        cd, cs, cc, ct, _, _ = osearcher.search_batch(ops, offs, tids, k, tie_mode=oracle.TIE_CANONICAL, threads=4, not_offsets=noffs,
+                                                      not_ids=nids, min_should_match=msms)
+        for i in range(len(specs)):
+            n = int(cc[i])
+            assert totals[i] == ct[i], (i, specs[i], totals[i], ct[i])
+            assert (hits[i]["doc"][n:] == -1).all()
+            assert (hits[i]["doc"][:n] == cd[i, :n]).all(), (i, specs[i])
+            assert (hits[i]["score"][:n].view(np.int32) == cs[i, :n].view(np.int32)).all(), (i, specs[i])
