@@ -107,6 +107,11 @@ def main():
         raise SystemExit("bench.py needs an MI355X: rucene_amd has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist_mode = world > 1 or args.force_dist
+    # RCCL prints a start-up banner on fd 1; the contract is ONE JSON line on stdout, so everything native goes to
+    # stderr until that line is written
+    sys.stdout.flush()
+    stdout_fd = os.dup(1)
+    os.dup2(2, 1)
     if dist_mode:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
@@ -369,8 +374,12 @@ def main():
         out["gpu_over_cpu"] = out["queries_per_sec"] / out["cpu_baseline"]["value"]
         out["parity_vs_oracle_full_batch"] = parity
 
+    sys.stdout.flush()
+    os.dup2(stdout_fd, 1)
+    os.close(stdout_fd)
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    os.dup2(2, 1)  # anything native libraries print while shutting down stays off stdout too
     if args.force_dist and world == 1:  # with one shard the all-gathered + merged rows must equal the local ones
         same = bool(torch.equal(merged["hits"], merged["local_hits"])) and bool(torch.equal(merged["totals"], merged["local_totals"]))
         print("force-dist: merged == local: %s" % same, file=sys.stderr)
