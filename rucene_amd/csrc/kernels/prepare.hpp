@@ -1,6 +1,7 @@
-// Skip-list decode on the GPU: one workgroup per term turns the term's level-0 skip entries into a flat block
-// directory {last doc id, byte offset, header word, store row} in HBM, copies the term's FullBlock payloads into
-// the 16-byte aligned block store and lays the docs' norms out in posting order. GPU counterpart of (paths relative to
+// Term preparation on the GPU, two launches: k_prepare_terms — one workgroup per term turns the term's level-0 skip
+// entries into a flat block directory {last doc id, byte offset, header word, store row} in HBM; k_prepare_blocks —
+// one wavefront per chunk of blocks copies the FullBlock payloads into the 16-byte aligned block store and lays the
+// docs' norms out in posting order. GPU counterpart of (paths relative to
 // /root/reference/src/core):
 //   codec/postings/skip_reader.rs:460-511   load_skip_levels  (vlong length + bytes for levels L-1..1, then level 0)
 //   codec/postings/skip_reader.rs:431-453   read_skip_data    (vint docDelta, vlong docFpDelta per entry)
@@ -61,13 +62,11 @@ template <bool LEGACY>
 __global__ __launch_bounds__(PREP_THREADS) void k_prepare_terms(const uint8_t* __restrict__ doc, int64_t doc_len,
                                                                  const PrepTerm* __restrict__ terms, int32_t* dir_last,
                                                                  uint32_t* dir_off, uint32_t* dir_row, uint16_t* dir_hdr,
-                                                                 uint8_t* bstore, const uint8_t* __restrict__ norms,
-                                                                 uint8_t* pnorm, int* err) {
+                                                                 int* err) {
   const PrepTerm t = terms[blockIdx.x];
   const int tid = (int)threadIdx.x;
   __shared__ uint32_t s_ws[PREP_THREADS / 64];
   __shared__ int64_t s_l0;
-  __shared__ __attribute__((aligned(16))) uint8_t slabs[PREP_THREADS / 64][SLAB_BYTES];
 
   if (t.n_entries > 0) {
     // ---- where does level 0 start? (skip_reader.rs:481-509)
@@ -177,30 +176,57 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_terms(const uint8_t* _
     if (tid == 0) atomicMin(err, -4);
     return;
   }
-  __syncthreads();
-  // ---- one pass over the blocks (one wavefront per block): copy the payload rows into the block store, then —
-  // with norms — decode the block from those rows and gather its docs' norm bytes in posting order (SegView::pnorm)
-  if (*reinterpret_cast<volatile int*>(err) == 0) {
-    const int lane = lane_id();
-    const int wave = wave_id();
-    uint8_t* term_rows = bstore + t.bs_base;
-    for (int blk = wave; blk < t.nblocks; blk += PREP_THREADS / 64) {
-      const uint32_t hdr = dir_hdr[t.dir_base + blk];
-      const uint32_t row0 = dir_row[t.dir_base + blk];
-      const uint4 rows = store_rows_from_file(file_rows_load(doc + t.start_fp + dir_off[t.dir_base + blk], hdr, lane), hdr, lane);
-      const int half = lane >> 5, row = lane & 31;
-      const int rd = store_doc_rows(hdr);
-      if (row < (half ? store_freq_rows(hdr) : rd))
-        *reinterpret_cast<uint4*>(term_rows + 16 * (size_t)(row0 + (uint32_t)(half ? rd : 0) + (uint32_t)row)) = rows;
-      if (norms != nullptr) {
-        const int32_t base = blk == 0 ? 0 : dir_last[t.dir_base + blk - 1];
-        const BlockPair bp = block_rows_decode<LEGACY>(rows, hdr, slabs[wave], lane);
-        int32_t d0, d1;
-        deltas_to_docs(bp.d0, bp.d1, base, d0, d1);
-        // a corrupt block must not turn into a wild gather
-        const uint32_t n0 = d0 >= 0 ? norms[d0] : 0u, n1 = d1 >= 0 ? norms[d1] : 0u;
-        *reinterpret_cast<uint16_t*>(pnorm + t.pn_base + 128 * (uint64_t)blk + 2 * lane) = (uint16_t)(n0 | (n1 << 8));
-      }
+}
+
+// Second half of term preparation, spread over the whole GPU (a 2 M-posting term has 15 k blocks: far too many for the
+// four wavefronts of its directory workgroup). Items = (term, chunk of PREP_BLOCKS_PER_ITEM blocks), one wavefront
+// each: copy the payload rows into the block store, then — with norms — decode the block from those rows and gather
+// its docs' norm bytes in posting order (SegView::pnorm).
+constexpr int PREP_BLOCKS_PER_ITEM = 32;
+
+template <bool LEGACY>
+__global__ __launch_bounds__(PREP_THREADS) void k_prepare_blocks(const uint8_t* __restrict__ doc, const PrepTerm* __restrict__ terms,
+                                                                  const int64_t* __restrict__ item_prefix, int n_terms,
+                                                                  int64_t n_items, const int32_t* __restrict__ dir_last,
+                                                                  const uint32_t* __restrict__ dir_off,
+                                                                  const uint32_t* __restrict__ dir_row,
+                                                                  const uint16_t* __restrict__ dir_hdr, uint8_t* bstore,
+                                                                  const uint8_t* __restrict__ norms, uint8_t* pnorm,
+                                                                  const int* __restrict__ err) {
+  __shared__ __attribute__((aligned(16))) uint8_t slabs[PREP_THREADS / 64][SLAB_BYTES];
+  const int lane = lane_id();
+  const int wave = wave_id();
+  const int64_t item = (int64_t)blockIdx.x * (PREP_THREADS / 64) + wave;
+  if (item >= n_items || *err != 0) return;  // a term whose framing did not check out must not be walked
+  int ti = 0;
+  {
+    int lo = 0, hi = n_terms;  // largest t with item_prefix[t] <= item
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (item_prefix[mid] <= item) lo = mid; else hi = mid;
+    }
+    ti = lo;
+  }
+  const PrepTerm t = terms[ti];
+  const int b0 = (int)(item - item_prefix[ti]) * PREP_BLOCKS_PER_ITEM;
+  const int b1 = min(t.nblocks, b0 + PREP_BLOCKS_PER_ITEM);
+  uint8_t* term_rows = bstore + t.bs_base;
+  for (int blk = b0; blk < b1; ++blk) {
+    const uint32_t hdr = dir_hdr[t.dir_base + blk];
+    const uint32_t row0 = dir_row[t.dir_base + blk];
+    const uint4 rows = store_rows_from_file(file_rows_load(doc + t.start_fp + dir_off[t.dir_base + blk], hdr, lane), hdr, lane);
+    const int half = lane >> 5, row = lane & 31;
+    const int rd = store_doc_rows(hdr);
+    if (row < (half ? store_freq_rows(hdr) : rd))
+      *reinterpret_cast<uint4*>(term_rows + 16 * (size_t)(row0 + (uint32_t)(half ? rd : 0) + (uint32_t)row)) = rows;
+    if (norms != nullptr) {
+      const int32_t base = blk == 0 ? 0 : dir_last[t.dir_base + blk - 1];
+      const BlockPair bp = block_rows_decode<LEGACY>(rows, hdr, slabs[wave], lane);
+      int32_t d0, d1;
+      deltas_to_docs(bp.d0, bp.d1, base, d0, d1);
+      // a corrupt block must not turn into a wild gather
+      const uint32_t n0 = d0 >= 0 ? norms[d0] : 0u, n1 = d1 >= 0 ? norms[d1] : 0u;
+      *reinterpret_cast<uint16_t*>(pnorm + t.pn_base + 128 * (uint64_t)blk + 2 * lane) = (uint16_t)(n0 | (n1 << 8));
     }
   }
 }

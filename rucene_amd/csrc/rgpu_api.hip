@@ -327,24 +327,46 @@ static int32_t prepare_terms_locked(rgpu_segment* seg, const rgpu_term_state* co
   HIP_TRY(seg->bstore.reserve(need_bs + 1024, seg->bstore_used, c->stream));  // + over-read padding of the row loads
   HIP_TRY(seg->dir_hdr.reserve(need_slots, seg->dir_used, c->stream));
   if (seg->d_norms) HIP_TRY(seg->pnorm.reserve(need_pn + 64, seg->pnorm_used, c->stream));
+  // staging: the PrepTerm records + the (term, chunk of blocks) item prefix of the second launch
+  std::vector<int64_t> item_prefix(work.size() + 1);
+  int64_t n_items = 0, postings = 0;
+  for (size_t i = 0; i < work.size(); ++i) {
+    item_prefix[i] = n_items;
+    n_items += (work[i].nblocks + PREP_BLOCKS_PER_ITEM - 1) / PREP_BLOCKS_PER_ITEM;
+    postings += work[i].df;
+  }
+  item_prefix[work.size()] = n_items;
   const size_t bytes = work.size() * sizeof(PrepTerm);
-  HIP_TRY(c->S->h_stage.reserve(bytes));
-  HIP_TRY(c->S->d_stage.reserve(bytes, 0, c->stream));
+  const size_t o_items = (bytes + 255) & ~size_t(255);
+  const size_t staged = o_items + item_prefix.size() * 8;
+  HIP_TRY(c->S->h_stage.reserve(staged));
+  HIP_TRY(c->S->d_stage.reserve(staged, 0, c->stream));
   std::memcpy(c->S->h_stage.p, work.data(), bytes);
-  HIP_TRY(hipMemcpyAsync(c->S->d_stage.p, c->S->h_stage.p, bytes, hipMemcpyHostToDevice, c->stream));
+  std::memcpy(c->S->h_stage.p + o_items, item_prefix.data(), item_prefix.size() * 8);
+  HIP_TRY(hipMemcpyAsync(c->S->d_stage.p, c->S->h_stage.p, staged, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream));
+  const PrepTerm* d_work = reinterpret_cast<const PrepTerm*>(c->S->d_stage.p);
+  const int64_t* d_items = reinterpret_cast<const int64_t*>(c->S->d_stage.p + o_items);
   {
-    int64_t postings = 0;
-    for (auto& w : work) postings += w.df;
     TimedLaunch tl(c, c->stream, "k_prepare_terms", postings);
     if (seg->version >= 1)
       hipLaunchKernelGGL(k_prepare_terms<false>, dim3((unsigned)work.size()), dim3(PREP_THREADS), 0, c->stream, seg->d_doc,
-                         (int64_t)seg->doc_len, reinterpret_cast<const PrepTerm*>(c->S->d_stage.p), seg->dir_last.p,
-                         seg->dir_off.p, seg->dir_row.p, seg->dir_hdr.p, seg->bstore.p, seg->d_norms, seg->pnorm.p, c->d_err);
+                         (int64_t)seg->doc_len, d_work, seg->dir_last.p, seg->dir_off.p, seg->dir_row.p, seg->dir_hdr.p, c->d_err);
     else
       hipLaunchKernelGGL(k_prepare_terms<true>, dim3((unsigned)work.size()), dim3(PREP_THREADS), 0, c->stream, seg->d_doc,
-                         (int64_t)seg->doc_len, reinterpret_cast<const PrepTerm*>(c->S->d_stage.p), seg->dir_last.p,
-                         seg->dir_off.p, seg->dir_row.p, seg->dir_hdr.p, seg->bstore.p, seg->d_norms, seg->pnorm.p, c->d_err);
+                         (int64_t)seg->doc_len, d_work, seg->dir_last.p, seg->dir_off.p, seg->dir_row.p, seg->dir_hdr.p, c->d_err);
+  }
+  if (n_items > 0) {
+    TimedLaunch tl(c, c->stream, "k_prepare_blocks", postings);
+    const unsigned grid = (unsigned)((n_items + PREP_THREADS / 64 - 1) / (PREP_THREADS / 64));
+    if (seg->version >= 1)
+      hipLaunchKernelGGL(k_prepare_blocks<false>, dim3(grid), dim3(PREP_THREADS), 0, c->stream, seg->d_doc, d_work, d_items,
+                         (int)work.size(), n_items, seg->dir_last.p, seg->dir_off.p, seg->dir_row.p, seg->dir_hdr.p, seg->bstore.p,
+                         seg->d_norms, seg->pnorm.p, c->d_err);
+    else
+      hipLaunchKernelGGL(k_prepare_blocks<true>, dim3(grid), dim3(PREP_THREADS), 0, c->stream, seg->d_doc, d_work, d_items,
+                         (int)work.size(), n_items, seg->dir_last.p, seg->dir_off.p, seg->dir_row.p, seg->dir_hdr.p, seg->bstore.p,
+                         seg->d_norms, seg->pnorm.p, c->d_err);
   }
   int err = 0;
   HIP_TRY(hipMemcpyAsync(&err, c->d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
