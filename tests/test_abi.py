@@ -105,3 +105,15 @@ def test_doc_file_validation_needs_no_gpu(gpu_lib):
     raw = seg.doc_bytes.tobytes()
     assert raw[:4] == bytes.fromhex("3FD76C17") and b"Lucene50PostingsWriterDoc" in raw[:40]
     assert raw[-16:-12] == bytes.fromhex("C02893E8")  # ~CODEC_MAGIC
+
+
+def test_cpp_host_mirror_compiles_without_a_gpu(gpu_lib, tmp_path):
+    """csrc/host/gpu_index_searcher.hpp + the demo that drives it link against the C ABI on a CPU-only box
+    (running it needs a GPU: tests/test_gpu_parity.py::test_cpp_host_mirror)."""
+    import subprocess
+    libdir = os.path.join(ROOT, "rucene_amd")
+    exe = str(tmp_path / "host_demo")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-Wextra", "-o", exe, os.path.join(ROOT, "tests", "cpp", "host_searcher_demo.cpp"),
+                           "-L" + libdir, "-lrucene_gpu", "-lrucene_indexgen", "-Wl,-rpath," + libdir, "-L/opt/rocm/lib",
+                           "-Wl,-rpath,/opt/rocm/lib"])
+    assert os.path.exists(exe)
