@@ -51,11 +51,10 @@ typedef struct rgpu_segment rgpu_segment;
 typedef struct rgpu_config {
   int32_t abi_version;        /* must be RGPU_ABI_VERSION */
   int32_t blocks_per_item;    /* 128-posting blocks per wave work item in the TERM kernel (0 = auto: 8..128 by batch size) */
-  int32_t window_docs;        /* doc-id window of the legacy doc-window AND/OR kernel, see reserved[1], [2] (0 = default 4096) */
+  int32_t window_docs;        /* unused (kept for layout compatibility) */
   int32_t profile_kernels;    /* 1 = bracket every kernel with HIP events (see rgpu_kernel_stats) */
   int32_t reserved[12];       /* [0] = lead blocks per work item of the AND kernel (0 = default 2);
-                                 [1] = 1 forces AND through the doc-window kernel (A/B testing);
-                                 [2] = 1 forces OR through the doc-window kernel (A/B testing);
+                                 [1], [2] unused;
                                  [3] = docs per wave window of the OR kernel (0 = default 1024, 256..4096);
                                  [4] = 1 keeps raw norm bytes in HBM even when <= 64 distinct values exist
                                        (disables the per-clause LDS score table; A/B testing) */

@@ -160,16 +160,13 @@ def live_docs_from_lucene50(liv, max_doc, del_count=-1):
 class Context:
     """rgpu_ctx: one per process per GPU."""
 
-    def __init__(self, device=0, profile_kernels=False, blocks_per_item=0, window_docs=0, and_blocks_per_item=0,
-                 and_via_windows=False, or_via_windows=False, or_window_docs=0, raw_norms=False):
+    def __init__(self, device=0, profile_kernels=False, blocks_per_item=0, and_blocks_per_item=0, or_window_docs=0,
+                 raw_norms=False):
         cfg = _Config()
         cfg.abi_version = 1
         cfg.blocks_per_item = blocks_per_item
-        cfg.window_docs = window_docs
         cfg.profile_kernels = int(profile_kernels)
         cfg.reserved[0] = and_blocks_per_item
-        cfg.reserved[1] = int(and_via_windows)
-        cfg.reserved[2] = int(or_via_windows)
         cfg.reserved[3] = or_window_docs
         cfg.reserved[4] = int(raw_norms)
         h = C.c_void_p()

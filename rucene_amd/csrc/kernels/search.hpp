@@ -1,8 +1,8 @@
 // Fused query-evaluation kernels: block decode -> doc ids -> BM25 -> top-k, nothing materialised in HBM.
 // GPU counterparts of (paths relative to /root/reference/src/core):
-//   search/scorer/term_scorer.rs:43-67              TermScorer            -> k_search_term
-//   search/scorer/conjunction_scorer.rs:26-128      ConjunctionScorer     -> k_search_window<AND>
-//   search/scorer/disjunction_scorer.rs:24-104      DisjunctionSumScorer  -> k_search_window<OR>
+//   search/scorer/term_scorer.rs:43-67              TermScorer            -> search_term.hpp (k_search_term)
+//   search/scorer/conjunction_scorer.rs:26-128      ConjunctionScorer     -> search_and.hpp (k_search_and)
+//   search/scorer/disjunction_scorer.rs:24-104      DisjunctionSumScorer  -> search_or.hpp (k_score_terms, k_or_windows)
 //   search/similarity/bm25_similarity.rs:203-212    BM25SimScorer::compute_score (f32, left to right)
 //   search/scorer/bulk_scorer.rs:114-120            the per-leaf collect loop incl. the live-docs test
 //   search/collector/top_docs.rs:67-94,157-172      TopDocsCollector::{add_doc, collect, finish_parallel}
@@ -61,131 +61,6 @@ __device__ __forceinline__ void build_score_table(float* cache, float wk, int la
 }
 __device__ __forceinline__ float table_score(const float* cache, uint32_t rank, uint32_t freq) {
   return cache[64 + rank * SCORE_TABLE_COLS + freq];
-}
-
-constexpr int WINDOW_LDS_FIXED = WG_WAVES * SLAB_BYTES + WG_WAVES * 1024 + WG_WAVES * 128 * 8 + 16;  // bytes before acc[]
-
-// ---- AND / OR: items = (query, group of doc-id windows); one workgroup accumulates a window in LDS ------------
-// Term-at-a-time inside the window keeps the reference's f32 summation order: AND = cost-sorted
-// lead1, lead2, others (conjunction_scorer.rs:87-95, the host sorts clauses by df), OR = clause order
-// (SimpleQueue score_sum, disjunction_scorer.rs:213-225). A doc matches AND when every clause touched it.
-template <bool LEGACY, bool WIDE, bool IS_AND>
-__global__ __launch_bounds__(WG_THREADS) void k_search_window(SegView seg, const DevQuery* __restrict__ queries,
-                                                              const DevTerm* __restrict__ terms, int n_queries,
-                                                              int windows_per_query, int windows_per_item,
-                                                              int items_per_query, int W, int k,
-                                                              uint64_t* __restrict__ partial_keys,
-                                                              int32_t* __restrict__ partial_counts) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  // carve: slabs | caches | merge area | wave counts | acc[W] | cnt[W]
-  uint8_t* slab = smem + wave_id() * SLAB_BYTES;
-  float* cache = reinterpret_cast<float*>(smem + WG_WAVES * SLAB_BYTES) + wave_id() * 256;
-  uint64_t* merge = reinterpret_cast<uint64_t*>(smem + WG_WAVES * SLAB_BYTES + WG_WAVES * 1024);  // [WG_WAVES][128]
-  int* s_counts = reinterpret_cast<int*>(smem + WG_WAVES * SLAB_BYTES + WG_WAVES * 1024 + WG_WAVES * 128 * 8);
-  float* acc = reinterpret_cast<float*>(smem + WINDOW_LDS_FIXED);
-  uint8_t* cnt = reinterpret_cast<uint8_t*>(acc + W);
-
-  const int lane = lane_id();
-  const int wave = wave_id();
-  const int tid = (int)threadIdx.x;
-  const int64_t item = blockIdx.x;
-  const int q = (int)(item / items_per_query);
-  const int g = (int)(item - (int64_t)q * items_per_query);
-  const DevQuery Q = queries[q];
-  const bool has_norms = seg.norms != nullptr;
-
-  WaveTopK top;
-  uint64_t tau = 0;
-  int count = 0;
-  int cur_table = -1;
-  float k1 = 0.f;
-
-  const int win0 = g * windows_per_item;
-  const int win1 = Q.n_terms > 0 ? min(windows_per_query, win0 + windows_per_item) : win0;
-  for (int win = win0; win < win1; ++win) {
-    const int32_t w0 = win * W;
-    const int32_t w1 = min(seg.max_doc, w0 + W);
-    for (int i = tid * 4; i < W; i += WG_THREADS * 4) {
-      *reinterpret_cast<float4*>(acc + i) = make_float4(0.f, 0.f, 0.f, 0.f);
-      *reinterpret_cast<uint32_t*>(cnt + i) = 0u;
-    }
-    __syncthreads();
-    bool alive = true;  // AND: some doc of this window still matches every clause so far
-    for (int ti = 0; ti < Q.n_terms && alive; ++ti) {
-      const DevTerm T = terms[Q.first_term + ti];
-      if (T.sim_table != cur_table) {
-        load_sim_table(seg, T.sim_table, cache, lane, k1);
-        cur_table = T.sim_table;
-      }
-      const float wk = T.weight * (k1 + 1.0f);
-      bool touched = false;
-      auto visit = [&](int32_t doc, uint32_t freq, bool valid) {
-        valid = valid && doc >= w0 && doc < w1 && doc_is_live(seg.live, doc);
-        if (valid) {
-          const int o = doc - w0;
-          const float nrm = has_norms ? cache[seg.norms[doc]] : k1;
-          const float s = bm25_score(wk, (float)(int32_t)freq, nrm);
-          if (IS_AND) {
-            if (cnt[o] == (uint8_t)ti) { acc[o] += s; cnt[o] = (uint8_t)(ti + 1); touched = true; }
-          } else {
-            acc[o] += s;
-            cnt[o] = 1;
-          }
-        }
-      };
-      if (T.df == 1) {
-        if (tid == 0) visit(T.singleton_doc, (uint32_t)T.singleton_freq, true);
-      } else if (T.df > 1) {
-        const int blo = find_block(seg.dir_last, T.dir_base, T.nblocks, w0);
-        const int bhi = find_block(seg.dir_last, T.dir_base, T.nblocks, w1 - 1);
-        for (int blk = blo + wave; blk <= bhi && blk < T.nblocks; blk += WG_WAVES) {
-          const int32_t base = blk == 0 ? 0 : seg.dir_last[T.dir_base + blk - 1];
-          const BlockPair bp = decode_block<LEGACY>(seg.bstore + T.bs_base, seg.dir_row[T.dir_base + blk],
-                                                     seg.dir_hdr[T.dir_base + blk], slab, lane);
-          int32_t d0, d1;
-          deltas_to_docs(bp.d0, bp.d1, base, d0, d1);
-          visit(d0, bp.f0, true);
-          visit(d1, bp.f1, true);
-        }
-        if (bhi == T.nblocks && T.tail_n > 0 && wave == (T.nblocks & (WG_WAVES - 1))) {
-          const uint32_t toff = T.nblocks ? seg.dir_off[T.dir_base + T.nblocks] : 0u;
-          const int32_t base = T.nblocks ? seg.dir_last[T.dir_base + T.nblocks - 1] : 0;
-          int32_t d0, d1;
-          uint32_t f0, f1;
-          decode_tail(seg.doc + T.start_fp + toff, T.tail_n, base, slab, lane, d0, d1, f0, f1);
-          visit(d0, f0, 2 * lane < T.tail_n);
-          visit(d1, f1, 2 * lane + 1 < T.tail_n);
-        }
-      }
-      if (IS_AND) alive = __syncthreads_or(touched ? 1 : 0) != 0;
-      else __syncthreads();
-    }
-    if (alive) {
-      const uint8_t want = IS_AND ? (uint8_t)Q.n_terms : (uint8_t)1;
-      for (int i = tid; i < W; i += WG_THREADS) {
-        const bool hit = cnt[i] == want;
-        const uint64_t key = hit ? make_key(acc[i], w0 + i) : 0ull;
-        count += __popcll(__ballot(hit));
-        topk_offer<WIDE>(top, key, tau, k, lane);
-      }
-    }
-    __syncthreads();
-  }
-  // fold the four wave lists into wave 0's
-  if (lane < 64) { merge[wave * 128 + lane] = top.a; merge[wave * 128 + 64 + lane] = WIDE ? top.b : 0ull; }
-  if (lane == 0) s_counts[wave] = count;
-  __syncthreads();
-  if (wave == 0) {
-    for (int w = 1; w < WG_WAVES; ++w) {
-      topk_offer<WIDE>(top, merge[w * 128 + lane], tau, k, lane);
-      if (WIDE) topk_offer<WIDE>(top, merge[w * 128 + 64 + lane], tau, k, lane);
-      count += s_counts[w];
-    }
-    uint64_t* pk = partial_keys + (size_t)item * (size_t)k;
-    if (lane < k) pk[lane] = top.a;
-    if (WIDE && lane + 64 < k) pk[lane + 64] = top.b;
-    if (lane == 0) partial_counts[item] = count;
-  }
 }
 
 // ---- fold the per-item lists of each query: one wavefront per query --------------------------------------------

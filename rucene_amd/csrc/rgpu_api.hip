@@ -431,8 +431,6 @@ extern "C" int32_t rgpu_init(int32_t device_ordinal, const rgpu_config* cfg, rgp
   c->cfg.abi_version = RGPU_ABI_VERSION;
   if (c->cfg.blocks_per_item <= 0) { c->cfg.blocks_per_item = 32; c->blocks_per_item_auto = true; }
   if (c->cfg.reserved[0] <= 0) c->cfg.reserved[0] = 2;  // and_blocks_per_item
-  if (c->cfg.window_docs <= 0) c->cfg.window_docs = 4096;
-  c->cfg.window_docs = std::min(24576, std::max(1024, (c->cfg.window_docs + 1023) / 1024 * 1024));
   std::snprintf(c->name, sizeof c->name, "%s (%s)", prop.name, prop.gcnArchName);
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipMalloc(&c->d_err, sizeof(int)) != hipSuccess) {
     delete c;
@@ -917,23 +915,17 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
     const int op = G.op;
     const int nq = (int)G.queries.size();
     if (nq == 0) continue;
-    if (op == RGPU_OP_OR && !c->cfg.reserved[2]) {
+    if (op == RGPU_OP_OR) {
       int32_t rc_or = search_or_group(seg, G, k, hits_dev, totals_dev, stream);
       if (rc_or != RGPU_OK) return rc_or;
       continue;
     }
     HIP_TRY(scratch_take(c));
-    const bool lead_driven = op == RGPU_OP_TERM || (op == RGPU_OP_AND && !c->cfg.reserved[1]);
-    if (!lead_driven)  // the doc-window kernel (A/B knobs reserved[1], [2]) predates MUST_NOT clauses
-      for (const DevQuery& dq : G.queries)
-        if (dq.pad || (dq.op >> 8) > 1)
-          return fail(RGPU_ERR_UNSUPPORTED, "MUST_NOT clauses / min_should_match > 1 are not served by the doc-window kernel");
     int blocks_per_item = op == RGPU_OP_TERM ? c->cfg.blocks_per_item : c->cfg.reserved[0];
-    int W = c->cfg.window_docs, wpq = 0, wpi = 1, ipq = 0;
     int64_t items = 0;
     G.item_prefix.assign((size_t)nq + 1, 0);
     const int head_items = op == RGPU_OP_TERM ? nq : 0;  // TERM: every query's first chunk is scheduled first
-    if (lead_driven) {  // items = chunks of the (lead) term's blocks; the last chunk also takes its tail
+    {  // items = chunks of the (lead) term's blocks; the last chunk also takes its tail
       if (op == RGPU_OP_TERM && c->blocks_per_item_auto) {  // fewer, longer items when there are plenty of blocks
         int64_t total_blocks = 0;
         for (auto& t : G.terms) total_blocks += t.nblocks;
@@ -955,13 +947,6 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
         blocks_per_item *= 2;
       }
       items += head_items;
-    } else {
-      wpq = (seg->max_doc + W - 1) / W;
-      if (wpq < 1) wpq = 1;
-      wpi = (int)std::max<int64_t>(1, ((int64_t)nq * wpq + 65535) / 65536);
-      ipq = (wpq + wpi - 1) / wpi;
-      items = (int64_t)nq * ipq;
-      for (int q = 0; q <= nq; ++q) G.item_prefix[(size_t)q] = (int64_t)q * ipq;
     }
     if (items == 0) continue;
     // group-local outputs, scattered to the caller's rows afterwards
@@ -988,7 +973,7 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
     const int64_t* dp = reinterpret_cast<const int64_t*>(c->S->d_stage.p + o_p);
     const int32_t* dm = reinterpret_cast<const int32_t*>(c->S->d_stage.p + o_m);
     const SegView sv = seg_view(seg);
-    if (op == RGPU_OP_AND && lead_driven) {
+    if (op == RGPU_OP_AND) {
       TimedLaunch tl(c, stream, "k_search_and", G.postings);
       const unsigned grid = (unsigned)((items + WG_WAVES - 1) / WG_WAVES);
       auto go = [&](auto kern) {
@@ -1018,25 +1003,6 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
       hipError_t e;
       if (legacy) e = wide ? go(k_search_term<true, true>) : go(k_search_term<true, false>);
       else e = wide ? go(k_search_term<false, true>) : go(k_search_term<false, false>);
-      HIP_TRY(e);
-    } else {
-      TimedLaunch tl(c, stream, op == RGPU_OP_AND ? "k_search_window_and" : "k_search_window_or", G.postings);
-      const size_t lds = (size_t)WINDOW_LDS_FIXED + (size_t)W * 5;
-      auto go = [&](auto kern) -> hipError_t {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3((unsigned)items), dim3(WG_THREADS), lds, stream, sv, dq, dt, nq, wpq, wpi, ipq, W, (int)k,
-                           c->S->d_partial_keys.p, c->S->d_partial_counts.p);
-        return hipSuccess;
-      };
-      hipError_t e;
-      if (op == RGPU_OP_AND) {
-        if (legacy) e = wide ? go(k_search_window<true, true, true>) : go(k_search_window<true, false, true>);
-        else e = wide ? go(k_search_window<false, true, true>) : go(k_search_window<false, false, true>);
-      } else {
-        if (legacy) e = wide ? go(k_search_window<true, true, false>) : go(k_search_window<true, false, false>);
-        else e = wide ? go(k_search_window<false, true, false>) : go(k_search_window<false, false, false>);
-      }
       HIP_TRY(e);
     }
     if (wide) launch_merge<true>(c, stream, nq, k, dp, seg->doc_base, c->S->d_hits.p, c->S->d_totals.p, head_items);

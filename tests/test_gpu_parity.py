@@ -301,11 +301,13 @@ def test_error_codes(ctx):
     assert e.value.status == -4
 
 
-def test_conjunctions_through_the_window_kernel(oracle):
-    """The doc-window accumulate kernel (shared with OR) must give the same AND answers as the lead-driven one."""
+@pytest.mark.parametrize("knobs", [dict(blocks_per_item=3, and_blocks_per_item=1, or_window_docs=256),
+                                   dict(blocks_per_item=64, and_blocks_per_item=7, or_window_docs=4096)])
+def test_work_partitioning_knobs_do_not_change_answers(oracle, knobs):
+    """Items per query / lead blocks per item / docs per OR window only change how the work is cut up."""
     import rucene_amd
     from rucene_amd import indexgen
-    ctx2 = rucene_amd.Context(and_via_windows=True, or_via_windows=True, window_docs=2048, blocks_per_item=3)
+    ctx2 = rucene_amd.Context(**knobs)
     try:
         seg = indexgen.build_zipf(120_000, 20_000)
         oseg = oracle.Segment(seg.doc_bytes, seg.norms, seg.max_doc, seg.terms, sum_total_term_freq=seg.sum_total_term_freq)
