@@ -201,6 +201,40 @@ int32_t rgpu_norms_from_lucene53(const uint8_t* nvm, size_t nvm_len, const uint8
  * header, the checksum, clear ghost bits and, when del_count >= 0, max_doc - cardinality == del_count. */
 int32_t rgpu_live_docs_from_lucene50(const uint8_t* liv, size_t liv_len, int32_t max_doc, int32_t del_count, uint64_t* words_out);
 
+/* ---- term dictionary (host; no GPU work) ---------------------------------------------------------------------- */
+/* A segment's block-tree term dictionary: ".tim" (BlockTreeTermsDict, term blocks) + ".tip" (BlockTreeTermsIndex, one
+ * FST per field). Replaces BlockTreeTermsReader::new (codec/postings/blocktree/blocktree_reader.rs:132-304),
+ * FieldReader's Terms statistics (:390-548) and, for exact lookups, SegmentTermIterator::seek_exact + term_state
+ * (:1364-1550, :1805; blocktree/term_iter_frame.rs:176-402; posting_reader.rs:264-306 lucene50_decode_term).
+ * rgpu_terms_open enumerates every term block once and hashes term bytes -> rgpu_term_state, so a lookup costs one
+ * hash probe instead of an FST walk + block scan. Format versions 0 and 3 (what Rucene writes);
+ * auto-prefix versions 1-2 -> RGPU_ERR_UNSUPPORTED. The handle is immutable: lookups may run from any thread. */
+typedef struct rgpu_terms rgpu_terms;
+typedef struct rgpu_field_info {   /* the slice of FieldInfo (codec/field_infos/mod.rs) the dictionary needs */
+  int32_t number;                  /* FieldInfo::number */
+  int32_t index_options;           /* doc::IndexOptions ordinal: 1 Docs, 2 DocsAndFreqs, 3 +Positions, 4 +Offsets */
+  int32_t has_payloads;            /* FieldInfo::has_store_payloads */
+  int32_t reserved;
+} rgpu_field_info;
+typedef struct rgpu_field_stats {  /* Terms::{size, sum_total_term_freq, sum_doc_freq, doc_count} (blocktree_reader.rs:502-516) */
+  int64_t num_terms;
+  int64_t sum_total_term_freq;     /* -1 for IndexOptions::Docs */
+  int64_t sum_doc_freq;
+  int32_t doc_count;
+  int32_t longs_size;
+} rgpu_field_stats;
+int32_t rgpu_terms_open(const uint8_t* tim, size_t tim_len, const uint8_t* tip, size_t tip_len, const rgpu_field_info* infos,
+                        int32_t n_infos, int32_t max_doc, rgpu_terms** out_terms);
+void rgpu_terms_close(rgpu_terms* terms);
+/* RGPU_ERR_ILLEGAL_ARGUMENT when the segment has no such indexed field (Fields::terms -> None). */
+int32_t rgpu_terms_field_stats(const rgpu_terms* terms, int32_t field_number, rgpu_field_stats* out);
+/* seek_exact + term_state for n_terms terms of one field; term i = term_bytes[term_offsets[i] .. term_offsets[i+1]).
+ * found_out[i] = 1/0; an absent term yields the "absent" state (doc_freq 0, skip_offset -1, singleton_doc_id -1),
+ * which rgpu_search_batch treats as TermWeight::create_scorer -> None. found_out may be NULL. Only the docs+freqs
+ * pointers are returned: positions / payloads pointers are decoded and dropped (positions are not served). */
+int32_t rgpu_terms_lookup(const rgpu_terms* terms, int32_t field_number, const uint8_t* term_bytes, const int64_t* term_offsets,
+                          int32_t n_terms, rgpu_term_state* states_out, uint8_t* found_out);
+
 /* ---- measurement ------------------------------------------------------------------------------------------ */
 typedef struct rgpu_kernel_stat {
   char name[48];

@@ -28,7 +28,8 @@ def build(force=False):
     """Compile oracle/liboracle.so with g++ (make)."""
     if force or not os.path.exists(_LIB_PATH) or any(
             os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
-            for f in ("oracle_capi.cpp", "store.hpp", "packed.hpp", "postings.hpp", "search.hpp")):
+            for f in ("oracle_capi.cpp", "store.hpp", "packed.hpp", "postings.hpp", "search.hpp", "norms.hpp", "fst.hpp",
+                      "blocktree.hpp")):
         subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
@@ -116,6 +117,16 @@ def _declare(L):
         "orc_norms_read": (C.c_int, [u8p, C.c_int64, u8p, C.c_int64, C.c_int32, C.c_int32, i64p]),
         "orc_live_docs_write": (C.c_int, [i64p, C.c_int32, C.c_int32, C.c_int32, u8p, C.c_int64, u8p, i64p]),
         "orc_live_docs_read": (C.c_int, [u8p, C.c_int64, C.c_int32, C.c_int32, i64p]),
+        "orc_fst_build": (C.c_int, [u8p, i64p, u8p, i64p, C.c_int64, C.c_int, u8p, i64p]),
+        "orc_fst_get": (C.c_int, [u8p, C.c_int64, u8p, C.c_int32, u8p, C.c_int32]),
+        "orc_fst_enumerate": (C.c_int64, [u8p, C.c_int64, u8p, C.c_int64, i64p]),
+        "orc_fst_reverse_read": (C.c_int, [u8p, C.c_int64, C.c_int64, C.c_int32, u8p, C.c_int32]),
+        "orc_blocktree_write": (C.c_int, [C.c_int32, i32p, i32p, u8p, i32p, i64p, u8p, i64p, vp, C.c_int32, C.c_int32, u8p,
+                                          C.c_char_p, u8p, i64p, u8p, i64p]),
+        "orc_blocktree_open": (vp, [u8p, C.c_int64, u8p, C.c_int64, C.c_int32, i32p, i32p, u8p, C.c_int32]),
+        "orc_blocktree_close": (None, [vp]),
+        "orc_blocktree_field_stats": (C.c_int, [vp, C.c_int32, i64p]),
+        "orc_blocktree_seek_exact": (C.c_int, [vp, C.c_int32, u8p, i64p, C.c_int64, vp, u8p]),
         "orc_mock_conjunction": (C.c_int, [i32p, i32p, C.c_int, C.c_int32, i32p, f32p, C.c_int]),
         "orc_mock_conjunction_initial_score": (C.c_float, [i32p, i32p, C.c_int]),
         "orc_mock_disjunction": (C.c_int, [i32p, i32p, C.c_int, C.c_int, i32p, f32p, C.c_int]),
@@ -489,3 +500,133 @@ def topk_stream(docs, scores, k, tie_mode):
     os_ = np.zeros(k + 1, np.float32)
     n = _check(lib().orc_topk_stream(_p(d, C.c_int32), _p(s, C.c_float), d.size, k, tie_mode, _p(od, C.c_int32), _p(os_, C.c_float)))
     return od[:n].copy(), os_[:n].copy()
+
+
+# ---- FST + block-tree term dictionary --------------------------------------------------------------------------------
+
+# FullTermState (oracle/blocktree.hpp): the shared 32-byte term state + the position/payload pointers
+FULL_TERM_STATE_DTYPE = np.dtype(
+    [("base", TERM_STATE_DTYPE), ("pos_start_fp", "<i8"), ("pay_start_fp", "<i8"), ("last_pos_block_offset", "<i8")], align=True)
+assert FULL_TERM_STATE_DTYPE.itemsize == 56
+IO_DOCS, IO_DOCS_FREQS, IO_DOCS_FREQS_POS, IO_DOCS_FREQS_POS_OFFS = 1, 2, 3, 4
+
+
+def _flatten_bytes(items):
+    offs = np.zeros(len(items) + 1, dtype=np.int64)
+    for i, b in enumerate(items):
+        offs[i + 1] = offs[i] + len(b)
+    flat = np.frombuffer(b"".join(items), dtype=np.uint8).copy() if offs[-1] else np.zeros(1, dtype=np.uint8)
+    return flat, offs
+
+
+def fst_build(pairs, share_non_singleton=True):
+    """FstBuilder over sorted (input bytes, output bytes) pairs -> saved FST bytes (b"" when the builder yields None)."""
+    fi, oi = _flatten_bytes([p[0] for p in pairs])
+    fo, oo = _flatten_bytes([p[1] for p in pairs])
+    n = C.c_int64(0)
+    _check(lib().orc_fst_build(_p(fi, C.c_uint8), _p(oi, C.c_int64), _p(fo, C.c_uint8), _p(oo, C.c_int64), len(pairs),
+                               int(share_non_singleton), None, C.byref(n)))
+    out = np.zeros(max(1, n.value), dtype=np.uint8)
+    _check(lib().orc_fst_build(_p(fi, C.c_uint8), _p(oi, C.c_int64), _p(fo, C.c_uint8), _p(oo, C.c_int64), len(pairs),
+                               int(share_non_singleton), _p(out, C.c_uint8), C.byref(n)))
+    return out[:n.value].tobytes()
+
+
+def fst_get(fst_bytes, key):
+    """FST::get -> output bytes, or None when `key` is not accepted."""
+    b = np.frombuffer(fst_bytes, dtype=np.uint8).copy()
+    k = np.frombuffer(key, dtype=np.uint8).copy() if key else np.zeros(1, dtype=np.uint8)
+    out = np.zeros(4096, dtype=np.uint8)
+    r = lib().orc_fst_get(_p(b, C.c_uint8), b.size, _p(k, C.c_uint8), len(key), _p(out, C.c_uint8), out.size)
+    if r == -1000:
+        return None
+    return out[:_check(r)].tobytes()
+
+
+def fst_enumerate(fst_bytes):
+    """BytesRefFSTIterator: [(input, output)] in input byte order (inputs/outputs < 256 bytes)."""
+    b = np.frombuffer(fst_bytes, dtype=np.uint8).copy()
+    n = C.c_int64(0)
+    _check(lib().orc_fst_enumerate(_p(b, C.c_uint8), b.size, None, 0, C.byref(n)))
+    flat = np.zeros(max(1, n.value), dtype=np.uint8)
+    count = _check(lib().orc_fst_enumerate(_p(b, C.c_uint8), b.size, _p(flat, C.c_uint8), flat.size, C.byref(n)))
+    raw, pos, out = flat.tobytes(), 0, []
+    for _ in range(count):
+        li = raw[pos]; inp = raw[pos + 1:pos + 1 + li]; pos += 1 + li
+        lo = raw[pos]; outp = raw[pos + 1:pos + 1 + lo]; pos += 1 + lo
+        out.append((inp, outp))
+    return out
+
+
+def fst_reverse_read(data, pos, skip_after_first, n):
+    """Reverse bytes reader: one byte at `pos`, skip, then n-1 more; -> (bytes read, final position)."""
+    b = np.frombuffer(bytes(data), dtype=np.uint8).copy()
+    out = np.zeros(n, dtype=np.uint8)
+    end = _check(lib().orc_fst_reverse_read(_p(b, C.c_uint8), b.size, pos, skip_after_first, _p(out, C.c_uint8), n))
+    return out.tolist(), end - 1
+
+
+def blocktree_write(fields, min_items=25, max_items=48, segment_id=None, suffix=""):
+    """BlockTreeTermsWriter. fields = [{number, index_options, has_payloads, doc_count, terms: [bytes] sorted,
+    states: FULL_TERM_STATE_DTYPE[len(terms)]}] in field-name order -> (tim bytes, tip bytes)."""
+    numbers = np.array([f["number"] for f in fields], dtype=np.int32)
+    opts = np.array([f.get("index_options", IO_DOCS_FREQS) for f in fields], dtype=np.int32)
+    pay = np.array([1 if f.get("has_payloads") else 0 for f in fields], dtype=np.uint8)
+    dcs = np.array([f["doc_count"] for f in fields], dtype=np.int32)
+    foffs = np.zeros(len(fields) + 1, dtype=np.int64)
+    all_terms, all_states = [], []
+    for i, f in enumerate(fields):
+        foffs[i + 1] = foffs[i] + len(f["terms"])
+        all_terms += list(f["terms"])
+        all_states.append(np.ascontiguousarray(f["states"], dtype=FULL_TERM_STATE_DTYPE))
+    flat, toffs = _flatten_bytes(all_terms)
+    states = np.concatenate(all_states) if all_states else np.zeros(0, dtype=FULL_TERM_STATE_DTYPE)
+    sid = np.frombuffer(segment_id if segment_id is not None else bytes(range(16)), dtype=np.uint8).copy()
+    tl, il = C.c_int64(0), C.c_int64(0)
+    args = (len(fields), _p(numbers, C.c_int32), _p(opts, C.c_int32), _p(pay, C.c_uint8), _p(dcs, C.c_int32), _p(foffs, C.c_int64),
+            _p(flat, C.c_uint8), _p(toffs, C.c_int64), states.ctypes.data_as(C.c_void_p), min_items, max_items, _p(sid, C.c_uint8),
+            suffix.encode())
+    _check(lib().orc_blocktree_write(*args, None, C.byref(tl), None, C.byref(il)))
+    tim = np.zeros(tl.value, dtype=np.uint8)
+    tip = np.zeros(il.value, dtype=np.uint8)
+    _check(lib().orc_blocktree_write(*args, _p(tim, C.c_uint8), C.byref(tl), _p(tip, C.c_uint8), C.byref(il)))
+    return tim.tobytes(), tip.tobytes()
+
+
+class BlockTreeReader:
+    """BlockTreeTermsReader + SegmentTermIterator::seek_exact / term_state."""
+
+    def __init__(self, tim, tip, field_infos, max_doc):
+        self._tim = np.frombuffer(tim, dtype=np.uint8).copy()
+        self._tip = np.frombuffer(tip, dtype=np.uint8).copy()
+        numbers = np.array([f["number"] for f in field_infos], dtype=np.int32)
+        opts = np.array([f.get("index_options", IO_DOCS_FREQS) for f in field_infos], dtype=np.int32)
+        pay = np.array([1 if f.get("has_payloads") else 0 for f in field_infos], dtype=np.uint8)
+        self._h = lib().orc_blocktree_open(_p(self._tim, C.c_uint8), self._tim.size, _p(self._tip, C.c_uint8), self._tip.size,
+                                           len(field_infos), _p(numbers, C.c_int32), _p(opts, C.c_int32), _p(pay, C.c_uint8), max_doc)
+        if not self._h:
+            raise OracleError(lib().orc_last_error().decode())
+
+    def field_stats(self, field):
+        out = np.zeros(6, dtype=np.int64)
+        r = _check(lib().orc_blocktree_field_stats(self._h, field, _p(out, C.c_int64)))
+        if r == 1:
+            return None
+        return dict(zip(("num_terms", "sum_total_term_freq", "sum_doc_freq", "doc_count", "longs_size", "root_block_fp"),
+                        out.tolist()))
+
+    def seek_exact(self, field, terms):
+        flat, offs = _flatten_bytes(list(terms))
+        states = np.zeros(len(terms), dtype=FULL_TERM_STATE_DTYPE)
+        found = np.zeros(max(1, len(terms)), dtype=np.uint8)
+        _check(lib().orc_blocktree_seek_exact(self._h, field, _p(flat, C.c_uint8), _p(offs, C.c_int64), len(terms),
+                                              states.ctypes.data_as(C.c_void_p), _p(found, C.c_uint8)))
+        return states, found[:len(terms)].astype(bool)
+
+    def close(self):
+        if self._h:
+            lib().orc_blocktree_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()

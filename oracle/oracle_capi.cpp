@@ -11,6 +11,8 @@
 #include "postings.hpp"
 #include "search.hpp"
 #include "norms.hpp"
+#include "fst.hpp"
+#include "blocktree.hpp"
 #include "store.hpp"
 
 using namespace orc;
@@ -433,6 +435,140 @@ int orc_topk_stream(const int32_t* docs, const float* scores, int64_t n, int k, 
   std::vector<ScoreDoc> r = collector.top_docs();
   for (size_t i = 0; i < r.size(); i++) { out_docs[i] = r[i].doc; out_scores[i] = r[i].score; }
   return (int)r.size();
+  ORC_CATCH
+}
+
+// ---- FST<ByteSequenceOutput> (oracle/fst.hpp) -----------------------------------------------------------------------
+// Builds an FST from sorted (input, output) byte strings and saves it; two-call protocol (out null -> size only).
+int orc_fst_build(const uint8_t* inputs, const int64_t* in_offs, const uint8_t* outputs, const int64_t* out_offs, int64_t n,
+                  int share_non_singleton, uint8_t* out, int64_t* out_len) {
+  ORC_TRY
+  FstBuilder b(true, share_non_singleton != 0);
+  for (int64_t i = 0; i < n; i++)
+    b.add(Bytes(inputs + in_offs[i], inputs + in_offs[i + 1]), Bytes(outputs + out_offs[i], outputs + out_offs[i + 1]));
+  if (!b.finish()) { *out_len = 0; return 0; }
+  ByteOut o;
+  b.fst.save(o);
+  if (out && *out_len >= (int64_t)o.buf.size()) std::memcpy(out, o.buf.data(), o.buf.size());
+  *out_len = (int64_t)o.buf.size();
+  return 0;
+  ORC_CATCH
+}
+// FST::get: returns the output length (>= 0) or -1000 when the key is not accepted
+int orc_fst_get(const uint8_t* fst_bytes, int64_t len, const uint8_t* key, int32_t key_len, uint8_t* out, int32_t cap) {
+  ORC_TRY
+  ByteIn in(fst_bytes, len);
+  Fst f = Fst::from_input(in);
+  Bytes r;
+  if (!f.get(Bytes(key, key + key_len), r)) return -1000;
+  if ((int32_t)r.size() <= cap) std::memcpy(out, r.data(), r.size());
+  return (int)r.size();
+  ORC_CATCH
+}
+// BytesRefFSTIterator: number of accepted inputs; when `flat` is non-null every "input\0output-length-byte output" is
+// appended (inputs in byte order) so the test can check order and content
+int64_t orc_fst_enumerate(const uint8_t* fst_bytes, int64_t len, uint8_t* flat, int64_t cap, int64_t* flat_len) {
+  ORC_TRY
+  ByteIn in(fst_bytes, len);
+  Fst f = Fst::from_input(in);
+  int64_t count = 0;
+  Bytes acc;
+  f.enumerate([&](const Bytes& input, const Bytes& output) {
+    count++;
+    acc.push_back((uint8_t)input.size());
+    acc.insert(acc.end(), input.begin(), input.end());
+    acc.push_back((uint8_t)output.size());
+    acc.insert(acc.end(), output.begin(), output.end());
+  });
+  if (flat && (int64_t)acc.size() <= cap) std::memcpy(flat, acc.data(), acc.size());
+  if (flat_len) *flat_len = (int64_t)acc.size();
+  return count;
+  ORC_CATCH
+}
+// reverse bytes reader (bytes_store.rs:654-670 KAT surface): reads `n` bytes starting at `pos` going down; returns
+// the final position + 1
+int orc_fst_reverse_read(const uint8_t* bytes, int64_t len, int64_t pos, int32_t skip_after_first, uint8_t* out, int32_t n) {
+  ORC_TRY
+  RevReader r{bytes, len, pos};
+  out[0] = r.read_byte();
+  r.skip_bytes(skip_after_first);
+  for (int32_t i = 1; i < n; i++) out[i] = r.read_byte();
+  return (int)r.pos + 1;
+  ORC_CATCH
+}
+
+// ---- block-tree term dictionary (oracle/blocktree.hpp) --------------------------------------------------------------
+// states: n_terms x FullTermState (56 bytes: rgpu_term_state layout + pos_start_fp, pay_start_fp, last_pos_block_offset).
+// Fields are given in field-name order with their sorted terms; field f owns terms [field_term_offs[f], field_term_offs[f+1]).
+int orc_blocktree_write(int32_t n_fields, const int32_t* numbers, const int32_t* index_options, const uint8_t* has_payloads,
+                        const int32_t* doc_counts, const int64_t* field_term_offs, const uint8_t* term_bytes,
+                        const int64_t* term_offs, const FullTermState* states, int32_t min_items, int32_t max_items,
+                        const uint8_t* segment_id16, const char* suffix, uint8_t* tim_out, int64_t* tim_len, uint8_t* tip_out,
+                        int64_t* tip_len) {
+  ORC_TRY
+  BlockTreeTermsWriter w(segment_id16, suffix ? suffix : "", min_items, max_items);
+  for (int32_t f = 0; f < n_fields; f++) {
+    BtFieldInfo info;
+    info.number = numbers[f];
+    info.index_options = index_options[f];
+    info.has_payloads = has_payloads[f] != 0;
+    w.start_field(info);
+    for (int64_t t = field_term_offs[f]; t < field_term_offs[f + 1]; t++)
+      w.write_term(Bytes(term_bytes + term_offs[t], term_bytes + term_offs[t + 1]), states[t]);
+    w.finish_field(doc_counts[f]);
+  }
+  w.close();
+  if (tim_out && *tim_len >= (int64_t)w.terms_out.buf.size()) std::memcpy(tim_out, w.terms_out.buf.data(), w.terms_out.buf.size());
+  if (tip_out && *tip_len >= (int64_t)w.index_out.buf.size()) std::memcpy(tip_out, w.index_out.buf.data(), w.index_out.buf.size());
+  *tim_len = (int64_t)w.terms_out.buf.size();
+  *tip_len = (int64_t)w.index_out.buf.size();
+  return 0;
+  ORC_CATCH
+}
+
+struct orc_blocktree {
+  std::vector<uint8_t> tim, tip;
+  std::unique_ptr<BlockTreeTermsReader> reader;
+};
+orc_blocktree* orc_blocktree_open(const uint8_t* tim, int64_t tim_len, const uint8_t* tip, int64_t tip_len, int32_t n_infos,
+                                  const int32_t* numbers, const int32_t* index_options, const uint8_t* has_payloads,
+                                  int32_t max_doc) {
+  try {
+    auto h = std::make_unique<orc_blocktree>();
+    h->tim.assign(tim, tim + tim_len);
+    h->tip.assign(tip, tip + tip_len);
+    std::vector<BtFieldInfo> infos((size_t)n_infos);
+    for (int32_t i = 0; i < n_infos; i++) {
+      infos[i].number = numbers[i];
+      infos[i].index_options = index_options[i];
+      infos[i].has_payloads = has_payloads[i] != 0;
+    }
+    h->reader = std::make_unique<BlockTreeTermsReader>(h->tim.data(), h->tim.size(), h->tip.data(), h->tip.size(), infos, max_doc);
+    return h.release();
+  } catch (const std::exception& e) { g_err = e.what(); return nullptr; }
+}
+void orc_blocktree_close(orc_blocktree* h) { delete h; }
+// stats_out: num_terms, sum_total_term_freq, sum_doc_freq, doc_count, longs_size, root_block_fp; returns 0, or 1 if no such field
+int orc_blocktree_field_stats(orc_blocktree* h, int32_t field, int64_t* stats_out) {
+  ORC_TRY
+  auto it = h->reader->fields.find(field);
+  if (it == h->reader->fields.end()) return 1;
+  const auto& fr = it->second;
+  stats_out[0] = fr.num_terms; stats_out[1] = fr.sum_total_term_freq; stats_out[2] = fr.sum_doc_freq;
+  stats_out[3] = fr.doc_count; stats_out[4] = fr.longs_size; stats_out[5] = fr.root_block_fp;
+  return 0;
+  ORC_CATCH
+}
+// TermIterator::seek_exact + term_state for n terms of one field
+int orc_blocktree_seek_exact(orc_blocktree* h, int32_t field, const uint8_t* term_bytes, const int64_t* term_offs, int64_t n,
+                             FullTermState* states_out, uint8_t* found_out) {
+  ORC_TRY
+  for (int64_t i = 0; i < n; i++) {
+    FullTermState st;
+    found_out[i] = h->reader->seek_exact(field, Bytes(term_bytes + term_offs[i], term_bytes + term_offs[i + 1]), st) ? 1 : 0;
+    states_out[i] = found_out[i] ? st : FullTermState();
+  }
+  return 0;
   ORC_CATCH
 }
 

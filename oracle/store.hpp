@@ -201,4 +201,19 @@ inline int32_t check_index_header(ByteIn& in, const std::string& codec, int32_t 
   return version;
 }
 
+// codec_util.rs footer_length(): magic + algorithm id + i64 CRC
+constexpr int FOOTER_LENGTH = 16;
+
+// codec_util.rs:340-353 retrieve_checksum (+ validate_footer :275-305, read_crc): locates and sanity-checks the
+// footer without hashing the file; returns the stored CRC.
+inline int64_t retrieve_checksum(const uint8_t* data, size_t len) {
+  if (len < (size_t)FOOTER_LENGTH) throw OracleError(E_CORRUPT_INDEX, "misplaced codec footer (file truncated?)");
+  ByteIn f(data + len - FOOTER_LENGTH, FOOTER_LENGTH);
+  if (f.read_int() != FOOTER_MAGIC) throw OracleError(E_CORRUPT_INDEX, "codec footer mismatch");
+  if (f.read_int() != 0) throw OracleError(E_CORRUPT_INDEX, "codec footer mismatch: unknown algorithm_id");
+  const int64_t crc = f.read_long();
+  if ((uint64_t)crc & 0xFFFFFFFF00000000ull) throw OracleError(E_CORRUPT_INDEX, "Illegal CRC-32 checksum");
+  return crc;
+}
+
 }  // namespace orc

@@ -19,6 +19,11 @@ TERM_STATE_DTYPE = np.dtype(
 QUERY_TERM_DTYPE = np.dtype([("state", TERM_STATE_DTYPE), ("weight", "<f4"), ("sim_table", "<i4")], align=True)
 QUERY_DTYPE = np.dtype([("op", "<i4"), ("n_terms", "<i4"), ("first_term", "<i4"), ("n_must_not", "<i4")], align=True)
 HIT_DTYPE = np.dtype([("doc", "<i4"), ("score", "<f4")], align=True)
+FIELD_INFO_DTYPE = np.dtype([("number", "<i4"), ("index_options", "<i4"), ("has_payloads", "<i4"), ("reserved", "<i4")], align=True)
+FIELD_STATS_DTYPE = np.dtype([("num_terms", "<i8"), ("sum_total_term_freq", "<i8"), ("sum_doc_freq", "<i8"), ("doc_count", "<i4"),
+                              ("longs_size", "<i4")], align=True)
+INDEX_OPTIONS_DOCS, INDEX_OPTIONS_DOCS_AND_FREQS, INDEX_OPTIONS_POSITIONS, INDEX_OPTIONS_OFFSETS = 1, 2, 3, 4
+assert FIELD_INFO_DTYPE.itemsize == 16 and FIELD_STATS_DTYPE.itemsize == 32
 assert TERM_STATE_DTYPE.itemsize == 32 and QUERY_TERM_DTYPE.itemsize == 40 and QUERY_DTYPE.itemsize == 16 and HIT_DTYPE.itemsize == 8
 
 STATUS_NAMES = {0: "OK", -1: "IllegalState", -2: "IllegalArgument", -3: "UnexpectedEOF", -4: "CorruptIndex",
@@ -30,7 +35,8 @@ EXPORTS = [
     "rgpu_segment_free", "rgpu_segment_version", "rgpu_segment_prepare_terms", "rgpu_decode_terms",
     "rgpu_decode_terms_device", "rgpu_advance_batch", "rgpu_sim_table_upload", "rgpu_search_batch",
     "rgpu_search_batch_device", "rgpu_merge_topk_device", "rgpu_bm25_compute_weight", "rgpu_bm25_encode_norm",
-    "rgpu_norms_from_lucene53", "rgpu_live_docs_from_lucene50", "rgpu_kernel_stats", "rgpu_kernel_stats_reset", "rgpu_synchronize",
+    "rgpu_norms_from_lucene53", "rgpu_live_docs_from_lucene50", "rgpu_terms_open", "rgpu_terms_close", "rgpu_terms_field_stats",
+    "rgpu_terms_lookup", "rgpu_kernel_stats", "rgpu_kernel_stats_reset", "rgpu_synchronize",
 ]
 
 
@@ -106,6 +112,10 @@ def lib():
         "rgpu_bm25_encode_norm": (C.c_uint8, [f32, i32]),
         "rgpu_norms_from_lucene53": (i32, [vp, C.c_size_t, vp, C.c_size_t, i32, i32, vp]),
         "rgpu_live_docs_from_lucene50": (i32, [vp, C.c_size_t, i32, i32, vp]),
+        "rgpu_terms_open": (i32, [vp, C.c_size_t, vp, C.c_size_t, vp, i32, i32, C.POINTER(vp)]),
+        "rgpu_terms_close": (None, [vp]),
+        "rgpu_terms_field_stats": (i32, [vp, i32, vp]),
+        "rgpu_terms_lookup": (i32, [vp, i32, vp, vp, i32, vp, vp]),
         "rgpu_kernel_stats": (i32, [vp, C.POINTER(_KernelStat), i32]),
         "rgpu_kernel_stats_reset": (None, [vp]),
         "rgpu_synchronize": (i32, [vp]),
@@ -155,6 +165,55 @@ def live_docs_from_lucene50(liv, max_doc, del_count=-1):
     out = np.zeros((max(int(max_doc), 1) + 63) // 64, dtype=np.uint64)
     _check(lib().rgpu_live_docs_from_lucene50(b.ctypes.data, b.size, int(max_doc), int(del_count), out.ctypes.data))
     return out
+
+
+class TermDictionary:
+    """rgpu_terms: a segment's block-tree term dictionary (.tim + .tip), resolved term bytes -> rgpu_term_state on the
+    host. `field_infos`: iterable of (number, index_options[, has_payloads]) for the segment's indexed fields."""
+
+    def __init__(self, tim, tip, field_infos, max_doc):
+        self._tim = np.frombuffer(bytes(tim), dtype=np.uint8)
+        self._tip = np.frombuffer(bytes(tip), dtype=np.uint8)
+        infos = np.zeros(len(field_infos), dtype=FIELD_INFO_DTYPE)
+        for i, fi in enumerate(field_infos):
+            infos[i]["number"], infos[i]["index_options"] = int(fi[0]), int(fi[1])
+            infos[i]["has_payloads"] = int(fi[2]) if len(fi) > 2 else 0
+        h = C.c_void_p()
+        _check(lib().rgpu_terms_open(self._tim.ctypes.data, self._tim.size, self._tip.ctypes.data, self._tip.size,
+                                     infos.ctypes.data if infos.size else None, infos.size, int(max_doc), C.byref(h)))
+        self._h = h
+
+    def field_stats(self, field_number):
+        """Terms::{size, sum_total_term_freq, sum_doc_freq, doc_count}; None when the field is not in this segment."""
+        out = np.zeros(1, dtype=FIELD_STATS_DTYPE)
+        rc = lib().rgpu_terms_field_stats(self._h, int(field_number), out.ctypes.data)
+        if rc == -2:
+            return None
+        _check(rc)
+        return {k: int(out[0][k]) for k in FIELD_STATS_DTYPE.names}
+
+    def lookup(self, field_number, terms):
+        """seek_exact + term_state for each of `terms` (bytes) -> (TERM_STATE_DTYPE[n], found bool[n])."""
+        terms = [bytes(t) for t in terms]
+        offs = np.zeros(len(terms) + 1, dtype=np.int64)
+        np.cumsum([len(t) for t in terms], out=offs[1:])
+        flat = np.frombuffer(b"".join(terms) or b"\0", dtype=np.uint8)
+        states = np.zeros(len(terms), dtype=TERM_STATE_DTYPE)
+        found = np.zeros(max(len(terms), 1), dtype=np.uint8)
+        _check(lib().rgpu_terms_lookup(self._h, int(field_number), flat.ctypes.data, offs.ctypes.data, len(terms),
+                                       states.ctypes.data if len(terms) else None, found.ctypes.data))
+        return states, found[:len(terms)].astype(bool)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().rgpu_terms_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Context:

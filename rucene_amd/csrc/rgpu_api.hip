@@ -14,6 +14,7 @@
 #include "../../include/rucene_gpu.h"
 #include "host/doc_format.hpp"
 #include "host/norms_format.hpp"
+#include "host/term_dict.hpp"
 #include "kernels/prepare.hpp"
 #include "kernels/search.hpp"
 #include "kernels/search_and.hpp"
@@ -1106,6 +1107,60 @@ extern "C" int32_t rgpu_live_docs_from_lucene50(const uint8_t* liv, size_t liv_l
   std::string why;
   const int rc = rucene::read_lucene50_live_docs(liv, liv_len, max_doc, del_count, words_out, &why);
   return rc == 0 ? RGPU_OK : fail(rc, why);
+}
+
+// ---- term dictionary (host) --------------------------------------------------------------------------------------------
+struct rgpu_terms {
+  std::unique_ptr<rucene::TermDictionary> dict;
+};
+static_assert(sizeof(rucene::TermState) == sizeof(rgpu_term_state) && offsetof(rucene::TermState, doc_freq) == offsetof(rgpu_term_state, doc_freq) &&
+                  offsetof(rucene::TermState, skip_offset) == offsetof(rgpu_term_state, skip_offset),
+              "rucene::TermState must mirror rgpu_term_state");
+static_assert(sizeof(rucene::TermFieldStats) == sizeof(rgpu_field_stats), "rucene::TermFieldStats must mirror rgpu_field_stats");
+
+extern "C" int32_t rgpu_terms_open(const uint8_t* tim, size_t tim_len, const uint8_t* tip, size_t tip_len, const rgpu_field_info* infos,
+                                   int32_t n_infos, int32_t max_doc, rgpu_terms** out_terms) {
+  if (!out_terms) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "out_terms is null");
+  *out_terms = nullptr;
+  if (n_infos < 0 || (n_infos > 0 && !infos)) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "bad field infos");
+  std::vector<rucene::TermFieldInfo> fi((size_t)n_infos);
+  for (int32_t i = 0; i < n_infos; ++i) fi[i] = rucene::TermFieldInfo{infos[i].number, infos[i].index_options, infos[i].has_payloads};
+  std::string why;
+  auto h = std::make_unique<rgpu_terms>();
+  int rc;
+  try {
+    rc = rucene::TermDictionary::open(tim, tim_len, tip, tip_len, fi.data(), n_infos, max_doc, &h->dict, &why);
+  } catch (const std::bad_alloc&) {
+    return fail(RGPU_ERR_RUNTIME, "out of host memory while building the term dictionary");
+  }
+  if (rc != 0) return fail(rc, why);
+  *out_terms = h.release();
+  return RGPU_OK;
+}
+
+extern "C" void rgpu_terms_close(rgpu_terms* terms) { delete terms; }
+
+extern "C" int32_t rgpu_terms_field_stats(const rgpu_terms* terms, int32_t field_number, rgpu_field_stats* out) {
+  if (!terms || !out) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "null argument");
+  const rucene::TermFieldStats* st = terms->dict->field_stats(field_number);
+  if (!st) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "no such indexed field in this segment");
+  std::memcpy(out, st, sizeof(*out));
+  return RGPU_OK;
+}
+
+extern "C" int32_t rgpu_terms_lookup(const rgpu_terms* terms, int32_t field_number, const uint8_t* term_bytes, const int64_t* term_offsets,
+                                     int32_t n_terms, rgpu_term_state* states_out, uint8_t* found_out) {
+  if (!terms || n_terms < 0 || (n_terms > 0 && (!term_offsets || !states_out))) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "null argument");
+  static const uint8_t kEmpty = 0;
+  for (int32_t i = 0; i < n_terms; ++i) {
+    const int64_t a = term_offsets[i], b = term_offsets[i + 1];
+    if (a < 0 || b < a || (b > a && !term_bytes)) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "term_offsets must be non-decreasing");
+    rucene::TermState st;
+    const bool found = terms->dict->lookup(field_number, b > a ? term_bytes + a : &kEmpty, (size_t)(b - a), &st);
+    std::memcpy(&states_out[i], &st, sizeof(st));
+    if (found_out) found_out[i] = found ? 1 : 0;
+  }
+  return RGPU_OK;
 }
 
 extern "C" uint8_t rgpu_bm25_encode_norm(float boost, int32_t field_length) {

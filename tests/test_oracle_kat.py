@@ -314,3 +314,63 @@ def test_rust_heap_vs_canonical_only_differ_on_ties(oracle):
     # canonical = score desc, doc asc
     order = np.lexsort((docs, -scores))[:k]
     assert (d1 == docs[order]).all()
+
+
+# ---- FST<ByteSequenceOutput> (terms index of the block-tree dictionary) ---------------------------------------------
+@pytest.mark.parametrize("share_non_singleton", [True, False])
+def test_fst_cat_to_dogs(oracle, share_non_singleton):
+    # util/fst/fst_reader.rs:1079-1109 test_fst: FstBuilder::new (share_non_singleton = true); the block-tree writer
+    # builds with false (blocktree_writer.rs:947-957) — same mapping either way
+    inputs = [b"cat", b"dag", b"dbg", b"dcg", b"ddg", b"deg", b"dog", b"dogs"]
+    outputs = [bytes([v]) for v in (5, 7, 12, 13, 14, 15, 16, 17)]
+    fst = oracle.fst_build(list(zip(inputs, outputs)), share_non_singleton)
+    for k, v in zip(inputs, outputs):
+        assert oracle.fst_get(fst, k) == v
+    for absent in (b"", b"c", b"ca", b"cats", b"do", b"dogsx", b"e"):
+        assert oracle.fst_get(fst, absent) is None
+    assert oracle.fst_enumerate(fst) == list(zip(inputs, outputs))
+
+
+def test_fst_reverse_bytes_reader(oracle):
+    # util/fst/bytes_store.rs:654-670 test_reverse_reader over bytes 1..10: position 7 -> 8, skip 1, 6, then 5 4 3 2 1
+    got, _ = oracle.fst_reverse_read(bytes(range(1, 11)), 7, 1, 7)
+    assert got == [8, 6, 5, 4, 3, 2, 1]
+
+
+def test_fst_byte_sequence_output_wire_format(oracle):
+    # util/fst/bytes_output.rs:298-308 test_read_write: output [1,2,3,4,5] is written as 5,1,2,3,4,5. A one-entry FST
+    # whose only (empty) input carries that output stores it as the reversed "final output" blob right after the header.
+    fst = oracle.fst_build([(b"", bytes([1, 2, 3, 4, 5]))])
+    head = b"\x3f\xd7\x6c\x17\x03FST\x00\x00\x00\x06"
+    assert fst.startswith(head + b"\x01\x06" + bytes([5, 1, 2, 3, 4, 5])[::-1])
+    assert oracle.fst_get(fst, b"") == bytes([1, 2, 3, 4, 5])
+
+
+def test_fst_output_algebra_through_the_builder(oracle):
+    # bytes_output.rs:250-296 (prefix / cat / subtract) drive output pushing in FstBuilder::add: shared output prefixes
+    # move towards the root, the remainders stay on the diverging arcs, and get() must re-assemble every output
+    pairs = [(b"ab", bytes([1, 2, 3, 4, 5])), (b"abc", bytes([1, 2, 4, 5, 6])), (b"abd", bytes([1, 2])), (b"b", b""),
+             (b"ba", bytes([9]))]
+    fst = oracle.fst_build(pairs)
+    assert oracle.fst_enumerate(fst) == pairs
+    for k, v in pairs:
+        assert oracle.fst_get(fst, k) == v
+
+
+def test_fst_random_maps_round_trip(oracle):
+    import random
+    rng = random.Random(5)
+    for trial in range(60):
+        n = rng.randint(1, 300)
+        width = rng.choice([2, 5, 255])          # 255: wide nodes -> ARCS_AS_FIXED_ARRAY + binary search in find_target_arc
+        maxlen = 6 if trial % 3 else 3
+        n = min(n, (width ** maxlen) // 2)
+        keys = set()
+        while len(keys) < n:
+            keys.add(bytes(rng.randint(1, width) for _ in range(rng.randint(0, maxlen))))
+        pairs = [(k, bytes(rng.randint(0, 255) for _ in range(rng.randint(0, 5)))) for k in sorted(keys)]
+        for share in (True, False):
+            fst = oracle.fst_build(pairs, share)
+            assert oracle.fst_enumerate(fst) == pairs
+            for k, v in pairs[::7]:
+                assert oracle.fst_get(fst, k) == v
