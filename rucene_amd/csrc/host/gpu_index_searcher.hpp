@@ -10,8 +10,9 @@
 //   search/sort_field/collapse_top_docs.rs:22-36             ScoreDoc
 //   error.rs:24-91                                           ErrorKind -> rucene::Error{kind}
 //
-// The block-tree term dictionary is out of scope: a LeafReader carries a flat table of
-// BlockTermState records indexed by term id.
+// Terms are named either by bytes — resolved per leaf through its block-tree dictionary (rgpu_terms_*, the
+// TermIterator::seek_exact + term_state step of TermWeight::create_scorer, term_query.rs:150-180) — or, for synthetic
+// indexes, by an id into a flat table of BlockTermState records.
 #pragma once
 #include <algorithm>
 #include <cstdint>
@@ -69,9 +70,12 @@ struct Query {
   virtual ~Query() {}
 };
 struct TermQuery : Query {
-  int64_t term;
+  int64_t term = -1;   // id into LeafReader::terms, or -1 when the term is named by bytes
+  std::string text;    // Term::bytes
   float boost;
   explicit TermQuery(int64_t t, float b = 1.0f) : term(t), boost(b) {}
+  explicit TermQuery(std::string bytes, float b = 1.0f) : text(std::move(bytes)), boost(b) {}
+  bool by_text() const { return term < 0; }
 };
 struct BooleanQuery : Query {
   std::vector<TermQuery> must_queries, should_queries, must_not_queries;
@@ -96,7 +100,8 @@ struct BooleanQuery : Query {
   }
 };
 
-// One segment: postings file, norms, live docs, FieldReader statistics, flat term table.
+// One segment: postings file, norms, live docs, FieldReader statistics, and the terms: a block-tree dictionary
+// (rgpu_terms_open over the segment's .tim/.tip) and/or a flat term table.
 struct LeafReader {
   const uint8_t* doc_bytes = nullptr;
   size_t doc_len = 0;
@@ -106,8 +111,22 @@ struct LeafReader {
   int64_t doc_count = 0, sum_total_term_freq = 0, sum_doc_freq = -1;
   const rgpu_term_state* terms = nullptr;
   int64_t n_terms = 0;
+  const rgpu_terms* dictionary = nullptr;  // not owned
+  int32_t field_number = 0;
   rgpu_segment* segment = nullptr;  // filled by the searcher
-  const rgpu_term_state* term_state(int64_t t) const { return (t >= 0 && t < n_terms && terms[t].doc_freq > 0) ? &terms[t] : nullptr; }
+  // TermIterator::seek_exact + term_state(); false when the term is absent from this leaf
+  bool term_state(const TermQuery& q, rgpu_term_state* out) const {
+    if (q.by_text()) {
+      if (!dictionary) throw Error(RGPU_ERR_ILLEGAL_ARGUMENT, "this leaf has no term dictionary: query it by term id");
+      const int64_t offs[2] = {0, static_cast<int64_t>(q.text.size())};
+      uint8_t found = 0;
+      check(rgpu_terms_lookup(dictionary, field_number, reinterpret_cast<const uint8_t*>(q.text.data()), offs, 1, out, &found));
+      return found != 0;
+    }
+    if (q.term >= n_terms || terms[q.term].doc_freq <= 0) return false;
+    *out = terms[q.term];
+    return true;
+  }
 };
 
 class GpuIndexSearcher {
@@ -142,11 +161,12 @@ class GpuIndexSearcher {
     return n;
   }
   // searcher.rs:732-767: doc_freq of the term in the statistics leaf only
-  TermStatistics term_statistics(int64_t term) const {
+  TermStatistics term_statistics(const TermQuery& term) const {
     TermStatistics ts;
-    const rgpu_term_state* st = leaves_[stats_leaf_].term_state(term);
-    ts.doc_freq = st ? st->doc_freq : 0;
-    ts.total_term_freq = st ? st->total_term_freq : 0;
+    rgpu_term_state st;
+    const bool have = leaves_[stats_leaf_].term_state(term, &st);
+    ts.doc_freq = have ? st.doc_freq : 0;
+    ts.total_term_freq = have ? st.total_term_freq : 0;
     return ts;
   }
   const CollectionStatistics& collection_statistics() const { return stats_; }
@@ -196,7 +216,7 @@ class GpuIndexSearcher {
  private:
   std::pair<float, int32_t> weight_of(const TermQuery& tq) {
     // TermQuery::create_weight (term_query.rs:58-95) -> BM25Similarity::compute_weight
-    const TermStatistics ts = term_statistics(tq.term);
+    const TermStatistics ts = term_statistics(tq);
     const BM25SimWeight w = sim_.compute_weight(stats_, &ts, 1, tq.boost);
     if (sim_table_ < 0) check(sim_table_ = rgpu_sim_table_upload(ctx_, w.cache.data(), w.k1));  // one field -> one cache
     return {w.weight, sim_table_};
@@ -222,9 +242,7 @@ class GpuIndexSearcher {
                   static_cast<int32_t>(nots ? nots->size() : 0)};
     for (const TermQuery& c : all) {
       rgpu_query_term qt{};
-      const rgpu_term_state* st = leaf.term_state(c.term);
-      if (st) qt.state = *st;
-      else { qt.state.doc_freq = 0; qt.state.skip_offset = -1; qt.state.singleton_doc_id = -1; }
+      if (!leaf.term_state(c, &qt.state)) { qt.state = rgpu_term_state{}; qt.state.skip_offset = -1; qt.state.singleton_doc_id = -1; }
       auto w = weight_of(c);
       qt.weight = w.first;
       qt.sim_table = w.second;

@@ -32,6 +32,7 @@
 //
 // Error codes are rgpu_status values (include/rucene_gpu.h). No GPU involved.
 #pragma once
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
 #include <memory>
@@ -164,18 +165,48 @@ class TermDictionary {
 
   // seek_exact + term_state. Absent term (or field): returns false and *out is the "absent" state (doc_freq 0).
   bool lookup(int32_t field_number, const uint8_t* term, size_t len, TermState* out) const {
-    *out = TermState{0, -1, 0, 0, -1};
     const Field* f = find_field(field_number);
-    if (!f || f->slots.empty()) return false;
-    const uint64_t h = hash_bytes(term, len);
+    if (!f || f->slots.empty()) { *out = TermState{0, -1, 0, 0, -1}; return false; }
+    return probe(*f, hash_bytes(term, len), term, len, out);
+  }
+
+  // n lookups in one field; term i = bytes[offsets[i], offsets[i+1]). A resident dictionary is bound by cache misses
+  // (slot -> entry -> term bytes), so the batch is software-pipelined: hash a window ahead and prefetch its slots while
+  // the current window is probed.
+  void lookup_batch(int32_t field_number, const uint8_t* bytes, const int64_t* offsets, int64_t n, TermState* out, uint8_t* found) const {
+    const Field* f = find_field(field_number);
+    if (!f || f->slots.empty()) {
+      for (int64_t i = 0; i < n; ++i) { out[i] = TermState{0, -1, 0, 0, -1}; if (found) found[i] = 0; }
+      return;
+    }
+    // three stages, W lookups apart: (A) hash + prefetch the slot, (B) read the slot, prefetch the entry it names,
+    // (C) probe for real (slot and entry now in cache; only the term bytes may still miss)
+    constexpr int W = 16;
+    uint64_t h[3][W];
     const size_t mask = f->slots.size() - 1;
-    const uint32_t tag = (uint32_t)(h >> 32) | 1u;
-    for (size_t i = (size_t)h & mask;; i = (i + 1) & mask) {
-      const Slot& s = f->slots[i];
-      if (s.tag == 0) return false;
-      if (s.tag == tag) {
-        const Entry& e = f->entries[s.entry];
-        if (e.len == len && std::memcmp(f->pool.data() + e.offset, term, len) == 0) { *out = e.state; return true; }
+    auto count = [&](int64_t base) { return base < n ? std::min<int64_t>(W, n - base) : 0; };
+    auto stage_a = [&](int64_t base, uint64_t* hs) {
+      for (int64_t j = 0; j < count(base); ++j) {
+        hs[j] = hash_bytes(bytes + offsets[base + j], (size_t)(offsets[base + j + 1] - offsets[base + j]));
+        __builtin_prefetch(&f->slots[(size_t)hs[j] & mask]);
+      }
+    };
+    auto stage_b = [&](int64_t base, const uint64_t* hs) {
+      for (int64_t j = 0; j < count(base); ++j) {
+        const Slot& s = f->slots[(size_t)hs[j] & mask];
+        if (s.tag != 0) __builtin_prefetch(&f->entries[s.entry]);
+      }
+    };
+    stage_a(0, h[0]);
+    stage_a(W, h[1]);
+    stage_b(0, h[0]);
+    for (int64_t base = 0, w = 0; base < n; base += W, w = (w + 1) % 3) {
+      stage_a(base + 2 * W, h[(w + 2) % 3]);
+      stage_b(base + W, h[(w + 1) % 3]);
+      for (int64_t j = 0; j < count(base); ++j) {
+        const int64_t i = base + j;
+        const bool ok = probe(*f, h[w][j], bytes + offsets[i], (size_t)(offsets[i + 1] - offsets[i]), &out[i]);
+        if (found) found[i] = ok ? 1 : 0;
       }
     }
   }
@@ -197,6 +228,19 @@ class TermDictionary {
     std::vector<Slot> slots;
   };
   std::vector<Field> fields_;
+
+  static bool probe(const Field& f, uint64_t h, const uint8_t* term, size_t len, TermState* out) {
+    const size_t mask = f.slots.size() - 1;
+    const uint32_t tag = (uint32_t)(h >> 32) | 1u;
+    for (size_t i = (size_t)h & mask;; i = (i + 1) & mask) {
+      const Slot& s = f.slots[i];
+      if (s.tag == 0) { *out = TermState{0, -1, 0, 0, -1}; return false; }
+      if (s.tag == tag) {
+        const Entry& e = f.entries[s.entry];
+        if (e.len == len && std::memcmp(f.pool.data() + e.offset, term, len) == 0) { *out = e.state; return true; }
+      }
+    }
+  }
 
   const Field* find_field(int32_t number) const {
     for (const Field& f : fields_) if (f.info.number == number) return &f;

@@ -1151,15 +1151,13 @@ extern "C" int32_t rgpu_terms_field_stats(const rgpu_terms* terms, int32_t field
 extern "C" int32_t rgpu_terms_lookup(const rgpu_terms* terms, int32_t field_number, const uint8_t* term_bytes, const int64_t* term_offsets,
                                      int32_t n_terms, rgpu_term_state* states_out, uint8_t* found_out) {
   if (!terms || n_terms < 0 || (n_terms > 0 && (!term_offsets || !states_out))) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "null argument");
+  for (int32_t i = 0; i < n_terms; ++i)
+    if (term_offsets[i] < 0 || term_offsets[i + 1] < term_offsets[i]) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "term_offsets must be non-decreasing");
   static const uint8_t kEmpty = 0;
-  for (int32_t i = 0; i < n_terms; ++i) {
-    const int64_t a = term_offsets[i], b = term_offsets[i + 1];
-    if (a < 0 || b < a || (b > a && !term_bytes)) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "term_offsets must be non-decreasing");
-    rucene::TermState st;
-    const bool found = terms->dict->lookup(field_number, b > a ? term_bytes + a : &kEmpty, (size_t)(b - a), &st);
-    std::memcpy(&states_out[i], &st, sizeof(st));
-    if (found_out) found_out[i] = found ? 1 : 0;
-  }
+  if (n_terms > 0 && term_offsets[n_terms] > term_offsets[0] && !term_bytes) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "term_bytes is null");
+  static_assert(sizeof(rucene::TermState) == sizeof(rgpu_term_state), "layout");
+  terms->dict->lookup_batch(field_number, term_bytes ? term_bytes : &kEmpty, term_offsets, n_terms,
+                            reinterpret_cast<rucene::TermState*>(states_out), found_out);
   return RGPU_OK;
 }
 

@@ -50,15 +50,19 @@ class BM25Similarity:
 
 class LeafReader:
     """One segment as the searcher sees it (index/reader/leaf_reader.rs:62-182, reduced to what BM25 term and
-    boolean queries read): postings file, norms, live docs, FieldReader statistics, flat term table."""
+    boolean queries read): postings file, norms, live docs, FieldReader statistics, and the term dictionary — either a
+    flat table of term states indexed by term id (synthetic indexes) or a block-tree dictionary (`.tim`/`.tip`) keyed
+    by term bytes."""
 
     def __init__(self, doc_bytes, norms, max_doc, terms, doc_base=0, live_docs=None, doc_count=None,
-                 sum_total_term_freq=0, sum_doc_freq=-1, field="body"):
+                 sum_total_term_freq=0, sum_doc_freq=-1, field="body", term_dictionary=None, field_number=0):
         self.doc_bytes, self.norms, self.max_doc, self.doc_base = doc_bytes, norms, int(max_doc), int(doc_base)
-        self.terms = np.ascontiguousarray(terms, dtype=TERM_STATE_DTYPE)
+        self.terms = np.ascontiguousarray(terms if terms is not None else [], dtype=TERM_STATE_DTYPE)
         self.live_docs = live_docs
         self.doc_count = int(max_doc if doc_count is None else doc_count)
         self.sum_total_term_freq, self.sum_doc_freq, self.field = int(sum_total_term_freq), int(sum_doc_freq), field
+        self.term_dictionary, self.field_number = term_dictionary, int(field_number)
+        self._resolved = {}  # term bytes -> state or None
         self.segment = None  # rgpu_segment, created by the searcher
 
     @classmethod
@@ -66,22 +70,58 @@ class LeafReader:
         return cls(seg.doc_bytes, seg.norms, seg.max_doc, seg.terms, seg.doc_base if doc_base is None else doc_base,
                    seg.live_docs, seg.doc_count, seg.sum_total_term_freq, seg.sum_doc_freq)
 
-    def term_state(self, term_id):
+    @classmethod
+    def from_index_files(cls, doc, tim, tip, nvm, nvd, max_doc, field_number=0, index_options=2, liv=None, del_count=-1,
+                         doc_base=0, field="body", other_fields=()):
+        """A segment as Rucene wrote it (SegmentReader::open -> the per-format producers): `.doc` postings, `.tim`/`.tip`
+        block-tree term dictionary, `.nvm`/`.nvd` norms, optional `.liv` live docs. `other_fields`: (number,
+        index_options[, has_payloads]) of the segment's other indexed fields (the `.tim` summary lists them all).
+        Only a docs+freqs field can be searched (positions fields carry a different skip-entry layout)."""
+        if index_options != _lib.INDEX_OPTIONS_DOCS_AND_FREQS:
+            raise RgpuError(-5, "the searched field must be indexed with IndexOptions::DocsAndFreqs")
+        td = _lib.TermDictionary(tim, tip, [(field_number, index_options)] + list(other_fields), max_doc)
+        stats = td.field_stats(field_number)
+        if stats is None:
+            raise RgpuError(-2, "field %d has no postings in this segment" % field_number)
+        norms = _lib.norms_from_lucene53(nvm, nvd, field_number, max_doc)
+        live = _lib.live_docs_from_lucene50(liv, max_doc, del_count) if liv is not None else None
+        return cls(doc, norms, max_doc, None, doc_base, live, stats["doc_count"], stats["sum_total_term_freq"],
+                   stats["sum_doc_freq"], field, td, field_number)
+
+    def resolve(self, terms):
+        """One batched dictionary lookup for the byte terms not seen before (seek_exact + term_state each)."""
+        new = [t for t in dict.fromkeys(terms) if isinstance(t, bytes) and t not in self._resolved]
+        if not new:
+            return
+        if self.term_dictionary is None:
+            raise RgpuError(-2, "this leaf has no term dictionary: query it by term id")
+        states, found = self.term_dictionary.lookup(self.field_number, new)
+        for t, st, ok in zip(new, states, found):
+            self._resolved[t] = st if ok else None
+
+    def term_state(self, term):
         """TermIterator::seek_exact + term_state(); None when the term is absent from this leaf."""
-        if term_id < 0 or term_id >= self.terms.size or self.terms[term_id]["doc_freq"] <= 0:
+        if isinstance(term, bytes):
+            if term not in self._resolved:
+                self.resolve([term])
+            return self._resolved[term]
+        if term < 0 or term >= self.terms.size or self.terms[term]["doc_freq"] <= 0:
             return None
-        return self.terms[term_id]
+        return self.terms[term]
 
 
 class TermQuery:
+    """term: bytes (resolved through each leaf's term dictionary) or an int term id (synthetic flat term table)."""
+
     def __init__(self, term, boost=1.0):
-        self.term, self.boost = int(term), float(boost)
+        self.term = bytes(term) if isinstance(term, (bytes, bytearray, memoryview)) else int(term)
+        self.boost = float(boost)
 
     def extract_terms(self):
         return [self]
 
     def __str__(self):
-        return "TermQuery(field: body, term: %d, boost: %s)" % (self.term, self.boost)
+        return "TermQuery(field: body, term: %r, boost: %s)" % (self.term, self.boost)
 
 
 class BooleanQuery:
@@ -186,6 +226,10 @@ class GpuIndexSearcher:
     def pack(self, queries, leaf):
         """queries -> (rgpu_query[], rgpu_query_term[]) for one leaf."""
         flat = [self._flatten(q) for q in queries]
+        byte_terms = [c.term for _, t, n in flat for c in list(t) + list(n) if isinstance(c.term, bytes)]
+        if byte_terms:
+            leaf.resolve(byte_terms)
+            self.leaves[self._stats_leaf].resolve(byte_terms)
         n_terms = sum(len(t) + len(n) for _, t, n in flat)
         qs = np.zeros(len(flat), dtype=QUERY_DTYPE)
         ts = np.zeros(max(n_terms, 1), dtype=QUERY_TERM_DTYPE)

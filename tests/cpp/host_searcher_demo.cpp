@@ -2,9 +2,13 @@
 // example drives Rucene (examples/example.rs: build docs -> TermQuery -> TopDocsCollector -> search): builds a
 // synthetic segment with the generator, runs a few queries on the GPU and prints
 //   <query-index> <total_hits> <doc>:<score-bits> ...
-// tests/test_gpu_parity.py::test_cpp_host_mirror compares the lines with the oracle.
+// tests/test_gpu_parity.py::test_cpp_host_mirror compares the lines with the oracle. With two arguments (paths of a
+// .tim and a .tip file naming term id N "t%07d") the same queries are run again with their terms given as bytes and
+// resolved through the block-tree dictionary (rgpu_terms_*); the test expects identical lines.
 #include <cstdio>
 #include <cstring>
+#include <fstream>
+#include <iterator>
 #include <memory>
 #include <vector>
 
@@ -23,7 +27,17 @@ int64_t rgen_n_terms(const rgen_index*);
 void rgen_stats(const rgen_index*, int64_t*);
 }
 
-int main() {
+static std::vector<uint8_t> slurp(const char* path) {
+  std::ifstream f(path, std::ios::binary);
+  return std::vector<uint8_t>(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+}
+static rucene::TermQuery named(int64_t id, float boost = 1.0f) {
+  char buf[16];
+  std::snprintf(buf, sizeof buf, "t%07lld", (long long)id);
+  return rucene::TermQuery(std::string(buf), boost);
+}
+
+int main(int argc, char** argv) {
   using namespace rucene;
   try {
     rgen_config cfg{150000, 1, 20000, 0.2, 0, 0, 0};
@@ -39,6 +53,15 @@ int main() {
     leaf.sum_total_term_freq = st[0];
     leaf.terms = rgen_terms(ix);
     leaf.n_terms = rgen_n_terms(ix);
+    rgpu_terms* dict = nullptr;
+    std::vector<uint8_t> tim, tip;
+    if (argc == 3) {
+      tim = slurp(argv[1]);
+      tip = slurp(argv[2]);
+      const rgpu_field_info fi{0, 2, 0, 0};
+      check(rgpu_terms_open(tim.data(), tim.size(), tip.data(), tip.size(), &fi, 1, cfg.max_doc, &dict));
+      leaf.dictionary = dict;
+    }
     GpuIndexSearcher searcher({leaf});
 
     std::vector<std::unique_ptr<Query>> queries;
@@ -62,9 +85,34 @@ int main() {
       }
       std::printf("\n");
     }
+    if (dict) {  // the same trees, terms named by bytes
+      std::vector<std::unique_ptr<Query>> by_text;
+      by_text.emplace_back(new TermQuery(named(7)));
+      by_text.emplace_back(new TermQuery(named(4321, 2.0f)));
+      by_text.push_back(BooleanQuery::build({named(1), named(12), named(40)}, {}));
+      by_text.push_back(BooleanQuery::build({}, {named(3), named(77), named(900), named(15000)}));
+      by_text.push_back(BooleanQuery::build({named(5)}, {}));
+      by_text.push_back(BooleanQuery::build({named(2), named(9)}, {}, 0, {named(1), named(30)}));
+      by_text.push_back(BooleanQuery::build({}, {named(6), named(60)}, 0, {named(0)}));
+      by_text.push_back(BooleanQuery::build({named(4)}, {}, 0, {named(8)}));
+      by_text.emplace_back(new TermQuery(std::string("no-such-term")));
+      for (size_t i = 0; i < by_text.size(); ++i) {
+        TopDocsCollector collector(10);
+        searcher.search(*by_text[i], collector);
+        TopDocs top = collector.top_docs();
+        std::printf("text %zu %lld", i, (long long)top.total_hits());
+        for (const ScoreDoc& d : top.score_docs()) {
+          uint32_t bits;
+          std::memcpy(&bits, &d.score, 4);
+          std::printf(" %d:%08x", d.doc, bits);
+        }
+        std::printf("\n");
+      }
+    }
     bool threw = false;
     try { BooleanQuery::build({}, {}); } catch (const Error& e) { threw = e.kind == RGPU_ERR_ILLEGAL_ARGUMENT; }
     std::printf("empty-boolean-is-illegal-argument %d\n", threw ? 1 : 0);
+    rgpu_terms_close(dict);
     rgen_free(ix);
   } catch (const rucene::Error& e) {
     std::fprintf(stderr, "rucene::Error kind=%d: %s\n", e.kind, e.what());

@@ -112,16 +112,17 @@ def _oracle_many(osearcher, oracle, specs, k, tie):
     return osearcher.search_batch(ops, offs, tids, k, tie_mode=tie, threads=4)
 
 
-def _check_against_oracle(oracle, osearcher, gsearcher, specs, k, exact=True):
+def _check_against_oracle(oracle, osearcher, gsearcher, specs, k, exact=True, name=lambda t: t):
+    """`name` maps the oracle's term id to what the product is asked for (the id itself, or the term's bytes)."""
     import rucene_amd
     queries = []
     for op, tids in specs:
         if op == oracle.OP_TERM:
-            queries.append(rucene_amd.TermQuery(tids[0]))
+            queries.append(rucene_amd.TermQuery(name(tids[0])))
         elif op == oracle.OP_AND:
-            queries.append(rucene_amd.BooleanQuery.build([rucene_amd.TermQuery(t) for t in tids], []))
+            queries.append(rucene_amd.BooleanQuery.build([rucene_amd.TermQuery(name(t)) for t in tids], []))
         else:
-            queries.append(rucene_amd.BooleanQuery.build([], [rucene_amd.TermQuery(t) for t in tids]))
+            queries.append(rucene_amd.BooleanQuery.build([], [rucene_amd.TermQuery(name(t)) for t in tids]))
     hits, totals = gsearcher.search_batch(queries, k)
     cd, cs, cc, ct, _, _ = _oracle_many(osearcher, oracle, specs, k, oracle.TIE_CANONICAL)
     rd, rs, rc, rt, _, _ = _oracle_many(osearcher, oracle, specs, k, oracle.TIE_RUST_HEAP)
@@ -333,8 +334,14 @@ def test_cpp_host_mirror(oracle, tmp_path):
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(root, "tests", "cpp", "host_searcher_demo.cpp"),
                            "-L" + libdir, "-lrucene_gpu", "-lrucene_indexgen", "-Wl,-rpath," + libdir, "-L/opt/rocm/lib",
                            "-Wl,-rpath,/opt/rocm/lib"])
-    out = subprocess.check_output([exe], text=True).strip().splitlines()
     seg = indexgen.build_zipf(150_000, 20_000)
+    st = np.zeros(seg.terms.size, dtype=oracle.FULL_TERM_STATE_DTYPE)
+    st["base"] = seg.terms
+    st["last_pos_block_offset"] = -1
+    tim, tip = oracle.blocktree_write([dict(number=0, doc_count=seg.doc_count, terms=[b"t%07d" % t for t in range(seg.terms.size)], states=st)])
+    (tmp_path / "seg.tim").write_bytes(tim)
+    (tmp_path / "seg.tip").write_bytes(tip)
+    out = subprocess.check_output([exe, str(tmp_path / "seg.tim"), str(tmp_path / "seg.tip")], text=True).strip().splitlines()
     oseg = oracle.Segment(seg.doc_bytes, seg.norms, seg.max_doc, seg.terms, sum_total_term_freq=seg.sum_total_term_freq)
     osr = oracle.Searcher([oseg])
     specs = [(oracle.OP_TERM, [7], None), (oracle.OP_TERM, [4321], [2.0]), (oracle.OP_AND, [1, 12, 40], None),
@@ -350,7 +357,11 @@ def test_cpp_host_mirror(oracle, tmp_path):
         got = [(int(p.split(":")[0]), int(p.split(":")[1], 16)) for p in parts[2:]]
         assert [g[0] for g in got] == d.tolist()
         assert [g[1] for g in got] == s.view(np.uint32).tolist()
-    assert out[len(specs)].endswith(" 1")
+    # the same trees with their terms named by bytes (resolved through rgpu_terms_lookup) give the same lines
+    for i in range(len(specs)):
+        assert out[len(specs) + i] == "text " + out[i]
+    assert out[2 * len(specs)] == "text %d 0" % len(specs)      # a term the dictionary does not hold
+    assert out[2 * len(specs) + 1].endswith(" 1")
 
 
 def test_negative_boost_and_raw_norm_mode(oracle):
@@ -537,6 +548,46 @@ def test_segment_ingested_from_index_files(ctx, oracle):
     osearcher = oracle.Searcher([oseg])
     specs = [(oracle.OP_TERM, [t]) for t in (0, 3, 50, 700, 7_999)] + [(oracle.OP_AND, [1, 4]), (oracle.OP_AND, [0, 2, 9]), (oracle.OP_OR, [5, 60, 600])]
     _check_against_oracle(oracle, osearcher, gsearcher, specs, 10)
+
+
+def test_segment_opened_from_a_full_index_directory(ctx, oracle):
+    """Everything a Rucene segment directory holds for one docs+freqs field — ".doc", ".tim" + ".tip", ".nvm" + ".nvd",
+    ".liv" — goes in as files; queries name their terms by bytes and are resolved through the block-tree dictionary
+    (rgpu_terms_lookup). Answers must equal the oracle's, which is handed the term states directly."""
+    import rucene_amd
+    from rucene_amd import indexgen
+    max_doc = 150_000
+    seg = indexgen.build_zipf(max_doc, 6_000, seed=77)
+    word = lambda t: b"w%05d" % t   # Rucene writes postings in term order: .doc pointers must grow with the term bytes
+    ids = sorted(range(seg.terms.size), key=word)
+    st = np.zeros(len(ids), dtype=oracle.FULL_TERM_STATE_DTYPE)
+    st["base"] = seg.terms[ids]
+    st["last_pos_block_offset"] = -1
+    tim, tip = oracle.blocktree_write([dict(number=0, doc_count=seg.doc_count, terms=[word(t) for t in ids], states=st),
+                                       dict(number=4, index_options=oracle.IO_DOCS, doc_count=1, terms=[b"id1"], states=st[:1])])
+    rng = np.random.default_rng(9)
+    bits = rng.random(max_doc) < 0.9
+    live = np.zeros((max_doc + 63) // 64, dtype=np.uint64)
+    idx = np.nonzero(bits)[0]
+    np.bitwise_or.at(live, idx >> 6, np.uint64(1) << (idx & 63).astype(np.uint64))
+    nvm, nvd = oracle.norms_write(seg.norms.astype(np.int64), field_number=0)
+    liv = oracle.live_docs_write(live, max_doc, int(max_doc - bits.sum()), gen=1)
+    leaf = rucene_amd.LeafReader.from_index_files(seg.doc_bytes, tim, tip, nvm, nvd, max_doc, field_number=0, liv=liv,
+                                                  del_count=int(max_doc - bits.sum()), other_fields=[(4, 1)])
+    assert leaf.sum_total_term_freq == int(seg.terms["total_term_freq"].sum()) and leaf.doc_count == seg.doc_count
+    oseg = oracle.Segment(seg.doc_bytes, seg.norms, max_doc, seg.terms, live_docs=live, doc_count=seg.doc_count,
+                          sum_total_term_freq=leaf.sum_total_term_freq)
+    gsearcher = rucene_amd.GpuIndexSearcher([leaf], ctx=ctx)
+    osearcher = oracle.Searcher([oseg])
+    specs = ([(oracle.OP_TERM, [t]) for t in (0, 1, 17, 400, 5_999)] +
+             [(oracle.OP_AND, [0, 3]), (oracle.OP_AND, [2, 5, 11]), (oracle.OP_OR, [4, 40, 400, 4_000]), (oracle.OP_OR, [0, 1])])
+    _check_against_oracle(oracle, osearcher, gsearcher, specs, 10, name=word)
+    # a term the dictionary does not hold: TermWeight::create_scorer -> None
+    T, B = rucene_amd.TermQuery, rucene_amd.BooleanQuery
+    hits, totals = gsearcher.search_batch([T(b"nope"), B.build([T(word(0)), T(b"nope")], []), B.build([], [T(word(9)), T(b"nope")]),
+                                           T(word(9))], 10)
+    assert totals[0] == 0 and totals[1] == 0 and totals[2] == totals[3] > 0
+    assert (hits[2]["doc"] == hits[3]["doc"]).all()
 
 
 def test_min_should_match(zipf, oracle):

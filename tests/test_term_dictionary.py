@@ -270,3 +270,55 @@ def test_oracle_reader_rejects_what_the_reference_rejects(oracle):
         oracle.blocktree_write([dict(number=1, doc_count=1, terms=[b"a"], states=np.zeros(1, oracle.FULL_TERM_STATE_DTYPE))], 1, 48)
     with pytest.raises(oracle.OracleError):
         oracle.blocktree_write([dict(number=1, doc_count=1, terms=[b"a"], states=np.zeros(1, oracle.FULL_TERM_STATE_DTYPE))], 10, 12)
+
+
+def test_lookup_throughput_against_the_reference_algorithm(rgpu, oracle, capsys):
+    """Measurement (host CPU, one thread; DESIGN.md §2b quotes it): batched hash lookups of the product against the
+    reference's per-term algorithm — FST walk, floor-block choice, block scan, metadata decode — as restated by the
+    oracle. Same files, same probes, identical answers; the product must be clearly faster (it is ~20x here)."""
+    import ctypes as C
+    import time
+    n = 300_000
+    terms = [b"t%07d" % i for i in range(n)]
+    st = _full_states(oracle, n)
+    df = np.maximum(1, 600_000 // (np.arange(n) + 1)).astype(np.int32)
+    st["base"]["doc_freq"] = df
+    st["base"]["total_term_freq"] = df.astype(np.int64) * 2
+    sizes = np.where(df > 1, df.astype(np.int64) * 2, 0)
+    st["base"]["doc_start_fp"] = np.cumsum(sizes) - sizes + 100
+    st["base"]["singleton_doc_id"] = np.where(df == 1, 5, -1)
+    st["base"]["skip_offset"] = np.where(df > 128, 1000, -1)
+    st["last_pos_block_offset"] = -1
+    tim, tip = oracle.blocktree_write([dict(number=0, doc_count=1000, terms=terms, states=st)])
+    t0 = time.perf_counter()
+    d = rgpu.TermDictionary(tim, tip, [(0, 2)], max_doc=10**7)
+    open_s = time.perf_counter() - t0
+    r = oracle.BlockTreeReader(tim, tip, [dict(number=0)], max_doc=10**7)
+    rng = np.random.default_rng(1)
+    probes = [terms[i] for i in rng.integers(0, n, 100_000)]
+    offs = np.zeros(len(probes) + 1, dtype=np.int64)
+    np.cumsum([len(p) for p in probes], out=offs[1:])
+    flat = np.frombuffer(b"".join(probes), dtype=np.uint8)
+    pst = np.zeros(len(probes), dtype=rgpu.TERM_STATE_DTYPE)
+    ost = np.zeros(len(probes), dtype=oracle.FULL_TERM_STATE_DTYPE)
+    found = np.zeros(len(probes), dtype=np.uint8)
+
+    def best(fn, reps):
+        times = []
+        for _ in range(reps):
+            t = time.perf_counter()
+            fn()
+            times.append(time.perf_counter() - t)
+        return min(times)
+    tp = best(lambda: rgpu.lib().rgpu_terms_lookup(d._h, 0, flat.ctypes.data, offs.ctypes.data, len(probes), pst.ctypes.data,
+                                                   found.ctypes.data), 5)
+    assert found.all()
+    to = best(lambda: oracle.lib().orc_blocktree_seek_exact(r._h, 0, flat.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                                            offs.ctypes.data_as(C.POINTER(C.c_int64)), len(probes),
+                                                            ost.ctypes.data_as(C.c_void_p),
+                                                            found.ctypes.data_as(C.POINTER(C.c_uint8))), 2)
+    assert found.all() and pst.tobytes() == np.ascontiguousarray(ost["base"]).tobytes()
+    with capsys.disabled():
+        print("\n[term dictionary] %d terms: open %.0f ms (%.1f M terms/s); lookups: product %.1f M/s, reference algorithm %.2f M/s (%.0fx)"
+              % (n, open_s * 1e3, n / open_s / 1e6, len(probes) / tp / 1e6, len(probes) / to / 1e6, to / tp))
+    assert to > 3 * tp
