@@ -214,7 +214,8 @@ typedef struct rgpu_field_info {   /* the slice of FieldInfo (codec/field_infos/
   int32_t number;                  /* FieldInfo::number */
   int32_t index_options;           /* doc::IndexOptions ordinal: 1 Docs, 2 DocsAndFreqs, 3 +Positions, 4 +Offsets */
   int32_t has_payloads;            /* FieldInfo::has_store_payloads */
-  int32_t reserved;
+  int32_t flags;                   /* filled by rgpu_field_infos_from_lucene60, ignored by rgpu_terms_open:
+                                      bit 0 omit_norms, bit 1 has_store_term_vector, bits 8..15 DocValuesType ordinal */
 } rgpu_field_info;
 typedef struct rgpu_field_stats {  /* Terms::{size, sum_total_term_freq, sum_doc_freq, doc_count} (blocktree_reader.rs:502-516) */
   int64_t num_terms;
@@ -223,6 +224,13 @@ typedef struct rgpu_field_stats {  /* Terms::{size, sum_total_term_freq, sum_doc
   int32_t doc_count;
   int32_t longs_size;
 } rgpu_field_stats;
+/* Lucene60FieldInfosFormat::read (codec/field_infos/field_infos_format.rs:55-128, 186-212): a segment's ".fnm" file ->
+ * one rgpu_field_info per field (ascending as stored) and the field names as consecutive NUL-terminated UTF-8 strings
+ * in names_out. Returns the number of fields in the file (>= 0) or a negative status; at most `cap` infos and
+ * `names_cap` name bytes are written (call with cap = 0 to size). Verifies the index header, FieldInfo consistency,
+ * duplicate numbers / names and the checksum. */
+int32_t rgpu_field_infos_from_lucene60(const uint8_t* fnm, size_t fnm_len, rgpu_field_info* infos_out, int32_t cap, char* names_out,
+                                       size_t names_cap, size_t* names_len_out);
 int32_t rgpu_terms_open(const uint8_t* tim, size_t tim_len, const uint8_t* tip, size_t tip_len, const rgpu_field_info* infos,
                         int32_t n_infos, int32_t max_doc, rgpu_terms** out_terms);
 void rgpu_terms_close(rgpu_terms* terms);

@@ -29,7 +29,7 @@ def build(force=False):
     if force or not os.path.exists(_LIB_PATH) or any(
             os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
             for f in ("oracle_capi.cpp", "store.hpp", "packed.hpp", "postings.hpp", "search.hpp", "norms.hpp", "fst.hpp",
-                      "blocktree.hpp")):
+                      "blocktree.hpp", "field_infos.hpp")):
         subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
@@ -117,6 +117,8 @@ def _declare(L):
         "orc_norms_read": (C.c_int, [u8p, C.c_int64, u8p, C.c_int64, C.c_int32, C.c_int32, i64p]),
         "orc_live_docs_write": (C.c_int, [i64p, C.c_int32, C.c_int32, C.c_int32, u8p, C.c_int64, u8p, i64p]),
         "orc_live_docs_read": (C.c_int, [u8p, C.c_int64, C.c_int32, C.c_int32, i64p]),
+        "orc_field_infos_write": (C.c_int, [C.c_int32, i32p, i64p, u8p, u8p, C.c_char_p, u8p, i64p]),
+        "orc_field_infos_read": (C.c_int, [u8p, C.c_int64, C.c_int32, i32p, i64p, u8p, C.c_int64, i64p]),
         "orc_fst_build": (C.c_int, [u8p, i64p, u8p, i64p, C.c_int64, C.c_int, u8p, i64p]),
         "orc_fst_get": (C.c_int, [u8p, C.c_int64, u8p, C.c_int32, u8p, C.c_int32]),
         "orc_fst_enumerate": (C.c_int64, [u8p, C.c_int64, u8p, C.c_int64, i64p]),
@@ -630,3 +632,67 @@ class BlockTreeReader:
 
     def __del__(self):
         self.close()
+
+
+# ---- Lucene60 field infos (".fnm") ----------------------------------------------------------------------------------
+_FI_DEFAULTS = dict(index_options=0, doc_values_type=0, store_term_vector=False, omit_norms=False, store_payloads=False,
+                    dv_gen=-1, attributes=None, point_dimension_count=0, point_num_bytes=0)
+
+
+def _lp(s):
+    b = s.encode("utf-8")
+    return len(b).to_bytes(4, "little") + b
+
+
+def field_infos_write(fields, segment_id=None, suffix=""):
+    """Lucene60FieldInfosFormat::write. fields: [dict(name, number, index_options, ...)] (see _FI_DEFAULTS) -> ".fnm" bytes."""
+    fields = [dict(_FI_DEFAULTS, **f) for f in fields]
+    recs = np.zeros((max(len(fields), 1), 6), dtype=np.int32)
+    gens = np.zeros(max(len(fields), 1), dtype=np.int64)
+    flat = b""
+    for i, f in enumerate(fields):
+        bits = (1 if f["store_term_vector"] else 0) | (2 if f["omit_norms"] else 0) | (4 if f["store_payloads"] else 0)
+        recs[i] = (f["number"], f["index_options"], f["doc_values_type"], bits, f["point_dimension_count"], f["point_num_bytes"])
+        gens[i] = f["dv_gen"]
+        attrs = f["attributes"] or {}
+        flat += _lp(f["name"]) + len(attrs).to_bytes(4, "little") + b"".join(_lp(k) + _lp(v) for k, v in attrs.items())
+    strings = np.frombuffer(flat + b"\0", dtype=np.uint8).copy()
+    sid = np.frombuffer(segment_id if segment_id is not None else bytes(range(16)), dtype=np.uint8).copy()
+    n = C.c_int64(0)
+    args = (len(fields), _p(recs, C.c_int32), _p(gens, C.c_int64), _p(strings, C.c_uint8), _p(sid, C.c_uint8), suffix.encode())
+    _check(lib().orc_field_infos_write(*args, None, C.byref(n)))
+    out = np.zeros(n.value, dtype=np.uint8)
+    _check(lib().orc_field_infos_write(*args, _p(out, C.c_uint8), C.byref(n)))
+    return out.tobytes()
+
+
+def field_infos_read(fnm):
+    """Lucene60FieldInfosFormat::read -> [dict] with every FieldInfo member."""
+    b = np.frombuffer(fnm, dtype=np.uint8).copy()
+    n = C.c_int64(0)
+    count = _check(lib().orc_field_infos_read(_p(b, C.c_uint8), b.size, 0, None, None, None, 0, C.byref(n)))
+    recs = np.zeros((max(count, 1), 6), dtype=np.int32)
+    gens = np.zeros(max(count, 1), dtype=np.int64)
+    buf = np.zeros(max(n.value, 1), dtype=np.uint8)
+    _check(lib().orc_field_infos_read(_p(b, C.c_uint8), b.size, count, _p(recs, C.c_int32), _p(gens, C.c_int64), _p(buf, C.c_uint8),
+                                      buf.size, C.byref(n)))
+    raw, pos, out = buf.tobytes(), 0, []
+
+    def take():
+        nonlocal pos
+        ln = int.from_bytes(raw[pos:pos + 4], "little")
+        s = raw[pos + 4:pos + 4 + ln].decode("utf-8")
+        pos += 4 + ln
+        return s
+    for i in range(count):
+        name = take()
+        n_attr = int.from_bytes(raw[pos:pos + 4], "little")
+        pos += 4
+        attrs = {}
+        for _ in range(n_attr):
+            k = take()
+            attrs[k] = take()
+        out.append(dict(name=name, number=int(recs[i, 0]), index_options=int(recs[i, 1]), doc_values_type=int(recs[i, 2]),
+                        store_term_vector=bool(recs[i, 3] & 1), omit_norms=bool(recs[i, 3] & 2), store_payloads=bool(recs[i, 3] & 4),
+                        dv_gen=int(gens[i]), attributes=attrs, point_dimension_count=int(recs[i, 4]), point_num_bytes=int(recs[i, 5])))
+    return out

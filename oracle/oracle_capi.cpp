@@ -13,6 +13,7 @@
 #include "norms.hpp"
 #include "fst.hpp"
 #include "blocktree.hpp"
+#include "field_infos.hpp"
 #include "store.hpp"
 
 using namespace orc;
@@ -569,6 +570,73 @@ int orc_blocktree_seek_exact(orc_blocktree* h, int32_t field, const uint8_t* ter
     states_out[i] = found_out[i] ? st : FullTermState();
   }
   return 0;
+  ORC_CATCH
+}
+
+// ---- Lucene60 field infos (oracle/field_infos.hpp) ------------------------------------------------------------------
+// Flat record per field: number, index_options, doc_values_type, bits (1 term vectors, 2 omit norms, 4 payloads),
+// point_dimension_count, point_num_bytes, + dv_gen; strings travel length-prefixed (u32 LE + bytes): per field the
+// name, a u32 attribute count, then key / value pairs.
+static std::string take_string(const uint8_t*& p) {
+  uint32_t n;
+  std::memcpy(&n, p, 4);
+  std::string s((const char*)p + 4, n);
+  p += 4 + n;
+  return s;
+}
+static void put_string(std::string& out, const std::string& s) {
+  uint32_t n = (uint32_t)s.size();
+  out.append((const char*)&n, 4);
+  out += s;
+}
+static std::vector<FieldInfoRec> unflatten_field_infos(int32_t n, const int32_t* recs6, const int64_t* dv_gens, const uint8_t* strings) {
+  std::vector<FieldInfoRec> infos((size_t)n);
+  const uint8_t* p = strings;
+  for (int32_t i = 0; i < n; i++) {
+    FieldInfoRec& fi = infos[i];
+    fi.number = recs6[6 * i]; fi.index_options = recs6[6 * i + 1]; fi.doc_values_type = recs6[6 * i + 2];
+    fi.store_term_vector = recs6[6 * i + 3] & 1; fi.omit_norms = recs6[6 * i + 3] & 2; fi.store_payloads = recs6[6 * i + 3] & 4;
+    fi.point_dimension_count = recs6[6 * i + 4]; fi.point_num_bytes = recs6[6 * i + 5];
+    fi.dv_gen = dv_gens[i];
+    fi.name = take_string(p);
+    uint32_t n_attr;
+    std::memcpy(&n_attr, p, 4);
+    p += 4;
+    for (uint32_t k = 0; k < n_attr; k++) { std::string key = take_string(p); fi.attributes[key] = take_string(p); }
+  }
+  return infos;
+}
+int orc_field_infos_write(int32_t n, const int32_t* recs6, const int64_t* dv_gens, const uint8_t* strings, const uint8_t* segment_id16,
+                          const char* suffix, uint8_t* out, int64_t* out_len) {
+  ORC_TRY
+  std::vector<uint8_t> b = write_field_infos(unflatten_field_infos(n, recs6, dv_gens, strings), segment_id16, suffix ? suffix : "");
+  if (out && *out_len >= (int64_t)b.size()) std::memcpy(out, b.data(), b.size());
+  *out_len = (int64_t)b.size();
+  return 0;
+  ORC_CATCH
+}
+// returns the field count; recs6 / dv_gens sized by the caller (cap fields); strings_out as above
+int orc_field_infos_read(const uint8_t* fnm, int64_t len, int32_t cap, int32_t* recs6, int64_t* dv_gens, uint8_t* strings_out,
+                         int64_t strings_cap, int64_t* strings_len) {
+  ORC_TRY
+  std::vector<FieldInfoRec> infos = read_field_infos(fnm, (size_t)len);
+  std::string flat;
+  for (size_t i = 0; i < infos.size(); i++) {
+    const FieldInfoRec& fi = infos[i];
+    if ((int32_t)i < cap) {
+      recs6[6 * i] = fi.number; recs6[6 * i + 1] = fi.index_options; recs6[6 * i + 2] = fi.doc_values_type;
+      recs6[6 * i + 3] = (fi.store_term_vector ? 1 : 0) | (fi.omit_norms ? 2 : 0) | (fi.store_payloads ? 4 : 0);
+      recs6[6 * i + 4] = fi.point_dimension_count; recs6[6 * i + 5] = fi.point_num_bytes;
+      dv_gens[i] = fi.dv_gen;
+    }
+    put_string(flat, fi.name);
+    uint32_t n_attr = (uint32_t)fi.attributes.size();
+    flat.append((const char*)&n_attr, 4);
+    for (const auto& kv : fi.attributes) { put_string(flat, kv.first); put_string(flat, kv.second); }
+  }
+  if (strings_out && (int64_t)flat.size() <= strings_cap) std::memcpy(strings_out, flat.data(), flat.size());
+  *strings_len = (int64_t)flat.size();
+  return (int)infos.size();
   ORC_CATCH
 }
 

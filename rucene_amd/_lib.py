@@ -19,7 +19,7 @@ TERM_STATE_DTYPE = np.dtype(
 QUERY_TERM_DTYPE = np.dtype([("state", TERM_STATE_DTYPE), ("weight", "<f4"), ("sim_table", "<i4")], align=True)
 QUERY_DTYPE = np.dtype([("op", "<i4"), ("n_terms", "<i4"), ("first_term", "<i4"), ("n_must_not", "<i4")], align=True)
 HIT_DTYPE = np.dtype([("doc", "<i4"), ("score", "<f4")], align=True)
-FIELD_INFO_DTYPE = np.dtype([("number", "<i4"), ("index_options", "<i4"), ("has_payloads", "<i4"), ("reserved", "<i4")], align=True)
+FIELD_INFO_DTYPE = np.dtype([("number", "<i4"), ("index_options", "<i4"), ("has_payloads", "<i4"), ("flags", "<i4")], align=True)
 FIELD_STATS_DTYPE = np.dtype([("num_terms", "<i8"), ("sum_total_term_freq", "<i8"), ("sum_doc_freq", "<i8"), ("doc_count", "<i4"),
                               ("longs_size", "<i4")], align=True)
 INDEX_OPTIONS_DOCS, INDEX_OPTIONS_DOCS_AND_FREQS, INDEX_OPTIONS_POSITIONS, INDEX_OPTIONS_OFFSETS = 1, 2, 3, 4
@@ -35,7 +35,7 @@ EXPORTS = [
     "rgpu_segment_free", "rgpu_segment_version", "rgpu_segment_prepare_terms", "rgpu_decode_terms",
     "rgpu_decode_terms_device", "rgpu_advance_batch", "rgpu_sim_table_upload", "rgpu_search_batch",
     "rgpu_search_batch_device", "rgpu_merge_topk_device", "rgpu_bm25_compute_weight", "rgpu_bm25_encode_norm",
-    "rgpu_norms_from_lucene53", "rgpu_live_docs_from_lucene50", "rgpu_terms_open", "rgpu_terms_close", "rgpu_terms_field_stats",
+    "rgpu_norms_from_lucene53", "rgpu_live_docs_from_lucene50", "rgpu_field_infos_from_lucene60", "rgpu_terms_open", "rgpu_terms_close", "rgpu_terms_field_stats",
     "rgpu_terms_lookup", "rgpu_kernel_stats", "rgpu_kernel_stats_reset", "rgpu_synchronize",
 ]
 
@@ -112,6 +112,7 @@ def lib():
         "rgpu_bm25_encode_norm": (C.c_uint8, [f32, i32]),
         "rgpu_norms_from_lucene53": (i32, [vp, C.c_size_t, vp, C.c_size_t, i32, i32, vp]),
         "rgpu_live_docs_from_lucene50": (i32, [vp, C.c_size_t, i32, i32, vp]),
+        "rgpu_field_infos_from_lucene60": (i32, [vp, C.c_size_t, vp, i32, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
         "rgpu_terms_open": (i32, [vp, C.c_size_t, vp, C.c_size_t, vp, i32, i32, C.POINTER(vp)]),
         "rgpu_terms_close": (None, [vp]),
         "rgpu_terms_field_stats": (i32, [vp, i32, vp]),
@@ -164,6 +165,24 @@ def live_docs_from_lucene50(liv, max_doc, del_count=-1):
     b = np.frombuffer(bytes(liv), dtype=np.uint8)
     out = np.zeros((max(int(max_doc), 1) + 63) // 64, dtype=np.uint64)
     _check(lib().rgpu_live_docs_from_lucene50(b.ctypes.data, b.size, int(max_doc), int(del_count), out.ctypes.data))
+    return out
+
+
+def field_infos_from_lucene60(fnm):
+    """Lucene60FieldInfosFormat::read: ".fnm" bytes -> [dict(name, number, index_options, has_payloads, omit_norms,
+    store_term_vector, doc_values_type)] in file order (ascending field number). Host-side parse."""
+    b = np.frombuffer(bytes(fnm), dtype=np.uint8)
+    names_len = C.c_size_t(0)
+    n = _check(lib().rgpu_field_infos_from_lucene60(b.ctypes.data, b.size, None, 0, None, 0, C.byref(names_len)))
+    infos = np.zeros(max(n, 1), dtype=FIELD_INFO_DTYPE)
+    names = C.create_string_buffer(max(names_len.value, 1))
+    _check(lib().rgpu_field_infos_from_lucene60(b.ctypes.data, b.size, infos.ctypes.data, n, names, names_len.value, C.byref(names_len)))
+    out = []
+    for rec, name in zip(infos[:n], names.raw[:names_len.value].split(b"\0")):
+        flags = int(rec["flags"])
+        out.append(dict(name=name.decode("utf-8"), number=int(rec["number"]), index_options=int(rec["index_options"]),
+                        has_payloads=bool(rec["has_payloads"]), omit_norms=bool(flags & 1), store_term_vector=bool(flags & 2),
+                        doc_values_type=(flags >> 8) & 0xFF))
     return out
 
 

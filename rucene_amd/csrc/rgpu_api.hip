@@ -15,6 +15,7 @@
 #include "host/doc_format.hpp"
 #include "host/norms_format.hpp"
 #include "host/term_dict.hpp"
+#include "host/field_infos_format.hpp"
 #include "kernels/prepare.hpp"
 #include "kernels/search.hpp"
 #include "kernels/search_and.hpp"
@@ -1124,7 +1125,7 @@ extern "C" int32_t rgpu_terms_open(const uint8_t* tim, size_t tim_len, const uin
   *out_terms = nullptr;
   if (n_infos < 0 || (n_infos > 0 && !infos)) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "bad field infos");
   std::vector<rucene::TermFieldInfo> fi((size_t)n_infos);
-  for (int32_t i = 0; i < n_infos; ++i) fi[i] = rucene::TermFieldInfo{infos[i].number, infos[i].index_options, infos[i].has_payloads};
+  for (int32_t i = 0; i < n_infos; ++i) fi[i] = rucene::TermFieldInfo{infos[i].number, infos[i].index_options, infos[i].has_payloads};  // .flags is informational
   std::string why;
   auto h = std::make_unique<rgpu_terms>();
   int rc;
@@ -1139,6 +1140,25 @@ extern "C" int32_t rgpu_terms_open(const uint8_t* tim, size_t tim_len, const uin
 }
 
 extern "C" void rgpu_terms_close(rgpu_terms* terms) { delete terms; }
+
+extern "C" int32_t rgpu_field_infos_from_lucene60(const uint8_t* fnm, size_t fnm_len, rgpu_field_info* infos_out, int32_t cap, char* names_out,
+                                                  size_t names_cap, size_t* names_len_out) {
+  std::vector<rucene::FieldInfoEntry> infos;
+  std::string why;
+  const int rc = rucene::read_lucene60_field_infos(fnm, fnm_len, &infos, &why);
+  if (rc != 0) return fail(rc, why);
+  size_t names_len = 0;
+  for (size_t i = 0; i < infos.size(); ++i) {
+    const rucene::FieldInfoEntry& fi = infos[i];
+    if (infos_out && (int64_t)i < cap)
+      infos_out[i] = rgpu_field_info{fi.number, fi.index_options, fi.store_payloads ? 1 : 0,
+                                     (fi.omit_norms ? 1 : 0) | (fi.store_term_vector ? 2 : 0) | (fi.doc_values_type << 8)};
+    if (names_out && names_len + fi.name.size() + 1 <= names_cap) std::memcpy(names_out + names_len, fi.name.c_str(), fi.name.size() + 1);
+    names_len += fi.name.size() + 1;
+  }
+  if (names_len_out) *names_len_out = names_len;
+  return (int32_t)infos.size();
+}
 
 extern "C" int32_t rgpu_terms_field_stats(const rgpu_terms* terms, int32_t field_number, rgpu_field_stats* out) {
   if (!terms || !out) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "null argument");

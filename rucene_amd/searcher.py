@@ -72,11 +72,21 @@ class LeafReader:
 
     @classmethod
     def from_index_files(cls, doc, tim, tip, nvm, nvd, max_doc, field_number=0, index_options=2, liv=None, del_count=-1,
-                         doc_base=0, field="body", other_fields=()):
+                         doc_base=0, field="body", other_fields=(), fnm=None):
         """A segment as Rucene wrote it (SegmentReader::open -> the per-format producers): `.doc` postings, `.tim`/`.tip`
-        block-tree term dictionary, `.nvm`/`.nvd` norms, optional `.liv` live docs. `other_fields`: (number,
-        index_options[, has_payloads]) of the segment's other indexed fields (the `.tim` summary lists them all).
+        block-tree term dictionary, `.nvm`/`.nvd` norms, optional `.liv` live docs. With `fnm` (the segment's field infos
+        file) the searched field is found by its name `field` and every other indexed field is declared from the file;
+        otherwise pass `field_number`/`index_options` and `other_fields`: (number, index_options[, has_payloads]) of the
+        segment's other indexed fields (the `.tim` summary lists them all).
         Only a docs+freqs field can be searched (positions fields carry a different skip-entry layout)."""
+        if fnm is not None:
+            infos = _lib.field_infos_from_lucene60(fnm)
+            mine = [fi for fi in infos if fi["name"] == field]
+            if not mine:
+                raise RgpuError(-2, "no field named %r in this segment" % field)
+            field_number, index_options = mine[0]["number"], mine[0]["index_options"]
+            other_fields = [(fi["number"], fi["index_options"], int(fi["has_payloads"])) for fi in infos
+                            if fi["index_options"] != 0 and fi["name"] != field]
         if index_options != _lib.INDEX_OPTIONS_DOCS_AND_FREQS:
             raise RgpuError(-5, "the searched field must be indexed with IndexOptions::DocsAndFreqs")
         td = _lib.TermDictionary(tim, tip, [(field_number, index_options)] + list(other_fields), max_doc)

@@ -551,8 +551,8 @@ def test_segment_ingested_from_index_files(ctx, oracle):
 
 
 def test_segment_opened_from_a_full_index_directory(ctx, oracle):
-    """Everything a Rucene segment directory holds for one docs+freqs field — ".doc", ".tim" + ".tip", ".nvm" + ".nvd",
-    ".liv" — goes in as files; queries name their terms by bytes and are resolved through the block-tree dictionary
+    """Everything a Rucene segment directory holds for one docs+freqs field — ".fnm", ".doc", ".tim" + ".tip", ".nvm" +
+    ".nvd", ".liv" — goes in as files; queries name their terms by bytes and are resolved through the block-tree dictionary
     (rgpu_terms_lookup). Answers must equal the oracle's, which is handed the term states directly."""
     import rucene_amd
     from rucene_amd import indexgen
@@ -572,8 +572,11 @@ def test_segment_opened_from_a_full_index_directory(ctx, oracle):
     np.bitwise_or.at(live, idx >> 6, np.uint64(1) << (idx & 63).astype(np.uint64))
     nvm, nvd = oracle.norms_write(seg.norms.astype(np.int64), field_number=0)
     liv = oracle.live_docs_write(live, max_doc, int(max_doc - bits.sum()), gen=1)
-    leaf = rucene_amd.LeafReader.from_index_files(seg.doc_bytes, tim, tip, nvm, nvd, max_doc, field_number=0, liv=liv,
-                                                  del_count=int(max_doc - bits.sum()), other_fields=[(4, 1)])
+    fnm = oracle.field_infos_write([dict(name="body", number=0, index_options=2), dict(name="id", number=4, index_options=1, omit_norms=True),
+                                    dict(name="stored", number=2)])
+    leaf = rucene_amd.LeafReader.from_index_files(seg.doc_bytes, tim, tip, nvm, nvd, max_doc, field="body", fnm=fnm, liv=liv,
+                                                  del_count=int(max_doc - bits.sum()))
+    assert leaf.field_number == 0
     assert leaf.sum_total_term_freq == int(seg.terms["total_term_freq"].sum()) and leaf.doc_count == seg.doc_count
     oseg = oracle.Segment(seg.doc_bytes, seg.norms, max_doc, seg.terms, live_docs=live, doc_count=seg.doc_count,
                           sum_total_term_freq=leaf.sum_total_term_freq)
