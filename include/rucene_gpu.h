@@ -89,15 +89,25 @@ typedef enum rgpu_query_op {
  * that many SHOULD clauses (disjunction_scorer.rs:317-329) and, as in the reference, sums in clause order whatever
  * the clause count (SimpleQueue is forced, :41), so those scores are bit-exact. */
 #define RGPU_OP_OR_MSM(msm) ((int32_t)RGPU_OP_OR | ((int32_t)(msm) << 8))
+/* A TERM / AND query may carry optional SHOULD TermQuery clauses in its third byte: RGPU_OP_WITH_SHOULD(op, n). They are
+ * stored between the MUST clauses and the MUST_NOT ones. BooleanWeight::create_scorer builds ReqOptScorer(must,
+ * DisjunctionSumScorer(should)) for such a tree (query/boolean_query.rs:217-233, 253-262; scorer/req_opt_scorer.rs): the
+ * SHOULD clauses never change which docs match, each one found on a matching doc adds its score (summed on their own in
+ * clause order, then added to the MUST sum). DEVIATION, by design: the reference's ReqOptScorer::score skips the optional
+ * clauses for a doc whose MUST score is under half the running mean of earlier docs' MUST scores once 100 docs were
+ * scored (:46-50) — state carried from doc to doc in iteration order. This library always adds them: doc ids and hit
+ * counts equal the reference's, scores are >= the reference's and equal wherever the reference did not skip. */
+#define RGPU_OP_WITH_SHOULD(op, n_should) ((int32_t)(op) | ((int32_t)(n_should) << 16))
 
 typedef struct rgpu_query {
-  int32_t op;          /* rgpu_query_op (OR: optionally RGPU_OP_OR_MSM(msm)) */
-  int32_t n_terms;     /* positive clauses: 1 for TERM, 1..RGPU_MAX_QUERY_TERMS MUST (AND) / SHOULD (OR) clauses */
+  int32_t op;          /* rgpu_query_op (OR: optionally RGPU_OP_OR_MSM(msm); TERM / AND: optionally RGPU_OP_WITH_SHOULD(op, n)) */
+  int32_t n_terms;     /* required / scored clauses: 1 for TERM, 1..RGPU_MAX_QUERY_TERMS MUST (AND) / SHOULD (OR) clauses;
+                          the n optional SHOULD clauses of RGPU_OP_WITH_SHOULD follow them and are not counted here */
   int32_t first_term;  /* index of this query's first clause in the `terms` array */
   int32_t n_must_not;  /* MUST_NOT TermQuery clauses, stored right after the positive ones (weight / sim_table unused):
                           BooleanWeight::create_scorer wraps the positive scorer in a ReqNotScorer over their union
                           (query/boolean_query.rs:235-273, scorer/req_not_scorer.rs:20-120). 0 = none;
-                          n_terms + n_must_not <= RGPU_MAX_QUERY_TERMS */
+                          n_terms + n_should + n_must_not <= RGPU_MAX_QUERY_TERMS */
 } rgpu_query;
 
 /* sort_field/collapse_top_docs.rs:22-36 ScoreDoc */

@@ -117,6 +117,9 @@ def _declare(L):
         "orc_norms_read": (C.c_int, [u8p, C.c_int64, u8p, C.c_int64, C.c_int32, C.c_int32, i64p]),
         "orc_live_docs_write": (C.c_int, [i64p, C.c_int32, C.c_int32, C.c_int32, u8p, C.c_int64, u8p, i64p]),
         "orc_live_docs_read": (C.c_int, [u8p, C.c_int64, C.c_int32, C.c_int32, i64p]),
+        "orc_mock_req_opt": (C.c_int, [i32p, i32p, C.c_int, i32p, i32p, C.c_int, i32p, f32p, C.c_int]),
+        "orc_search_opt": (C.c_int, [vp, C.c_int, i64p, C.c_int, i64p, C.c_int, i64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, i32p,
+                                     f32p, i32p, i64p]),
         "orc_field_infos_write": (C.c_int, [C.c_int32, i32p, i64p, u8p, u8p, C.c_char_p, u8p, i64p]),
         "orc_field_infos_read": (C.c_int, [u8p, C.c_int64, C.c_int32, i32p, i64p, u8p, C.c_int64, i64p]),
         "orc_fst_build": (C.c_int, [u8p, i64p, u8p, i64p, C.c_int64, C.c_int, u8p, i64p]),
@@ -358,6 +361,20 @@ class Searcher:
                                     _p(docs, C.c_int32), _p(scores, C.c_float), C.byref(n), C.byref(total)))
         return docs[:n.value].copy(), scores[:n.value].copy(), total.value
 
+    def search_opt(self, op, term_ids, should_ids, k, must_not_ids=(), min_should_match=0, tie_mode=TIE_CANONICAL, exact=False):
+        """BooleanQuery with MUST (op AND / TERM) + SHOULD [+ MUST_NOT] TermQuery clauses: ReqOptScorer, with its sequential
+        skip-the-optional-clause rule (req_opt_scorer.rs:41-66); exact=True turns that rule off (full sums everywhere)."""
+        t = np.ascontiguousarray(term_ids, dtype=np.int64)
+        oo = np.ascontiguousarray(should_ids, dtype=np.int64)
+        nn = np.ascontiguousarray(must_not_ids, dtype=np.int64)
+        docs = np.zeros(max(k, 1), dtype=np.int32)
+        scores = np.zeros(max(k, 1), dtype=np.float32)
+        n, total = C.c_int32(), C.c_int64()
+        _check(lib().orc_search_opt(self._h, op, _p(t, C.c_int64), t.size, _p(oo, C.c_int64), oo.size,
+                                    _p(nn, C.c_int64) if nn.size else None, nn.size, min_should_match, int(exact), k, tie_mode,
+                                    _p(docs, C.c_int32), _p(scores, C.c_float), C.byref(n), C.byref(total)))
+        return docs[:n.value].copy(), scores[:n.value].copy(), total.value
+
     def search_batch(self, ops, term_offsets, term_ids, k, tie_mode=TIE_CANONICAL, threads=1, not_offsets=None, not_ids=None,
                      min_should_match=None):
         ops = np.ascontiguousarray(ops, dtype=np.int32)
@@ -471,6 +488,18 @@ def live_docs_read(liv, max_doc, del_count):
     out = np.zeros((max_doc + 63) // 64, dtype=np.int64)
     _check(lib().orc_live_docs_read(_p(b, C.c_uint8), b.size, max_doc, del_count, _p(out, C.c_int64)))
     return out.view(np.uint64)
+
+
+def mock_req_opt(req_lists, opt_lists):
+    """ReqOptScorer(Conjunction(req_lists) | the single list, DisjunctionSumScorer(opt_lists)): next() to exhaustion
+    -> (docs, scores)."""
+    rf, ro = _lists(req_lists)
+    of, oo = _lists(opt_lists)
+    docs = np.zeros(max(1, rf.size), dtype=np.int32)
+    scores = np.zeros(max(1, rf.size), dtype=np.float32)
+    n = _check(lib().orc_mock_req_opt(_p(rf, C.c_int32), _p(ro, C.c_int32), len(req_lists), _p(of, C.c_int32), _p(oo, C.c_int32),
+                                      len(opt_lists), _p(docs, C.c_int32), _p(scores, C.c_float), docs.size))
+    return docs[:n].tolist(), scores[:n].tolist()
 
 
 def mock_req_not(req_lists, not_lists, targets=()):

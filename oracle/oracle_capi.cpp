@@ -255,6 +255,26 @@ int orc_search_not(orc_searcher* s, int op, const int64_t* term_ids, int n_terms
   ORC_CATCH
 }
 
+// MUST (op = AND / TERM) + SHOULD + MUST_NOT trees: boolean_query.rs:253-262 -> ReqOptScorer (inside ReqNotScorer when
+// MUST_NOT clauses exist). min_should_match applies to the SHOULD disjunction. exact != 0 turns the reference's
+// skip-the-optional-clause rule off (every score is the full sum).
+int orc_search_opt(orc_searcher* s, int op, const int64_t* term_ids, int n_terms, const int64_t* opt_ids, int n_opt,
+                   const int64_t* not_ids, int n_not, int min_should_match, int exact, int k, int tie_mode, int32_t* out_docs,
+                   float* out_scores, int32_t* out_n, int64_t* out_total) {
+  ORC_TRY
+  Query q = make_query(op, term_ids, n_terms, nullptr, 0);
+  q.opt_ids.assign(opt_ids, opt_ids + n_opt);
+  q.opt_exact = exact != 0;
+  if (n_not > 0) q.must_not_ids.assign(not_ids, not_ids + n_not);
+  q.min_should_match = min_should_match;
+  SearchResult r = s->s.search(q, (size_t)k, tie_mode);
+  *out_n = (int32_t)r.hits.size();
+  *out_total = r.total_hits;
+  for (size_t i = 0; i < r.hits.size(); i++) { out_docs[i] = r.hits[i].doc; out_scores[i] = r.hits[i].score; }
+  return 0;
+  ORC_CATCH
+}
+
 // Batch: one query per task, `threads` worker threads pulling from a shared counter (Rucene: one core per
 // query per segment, searcher shared across threads — searcher.rs:527-630 falls back to sequential search
 // for a single large segment). Returns elapsed seconds; fills per-query outputs.
@@ -403,6 +423,24 @@ int orc_mock_req_not(const int32_t* req_docs, const int32_t* req_offsets, int n_
   } else {
     for (int i = 0; i < n_targets && n < max_out; i++) out_docs[n++] = sc.advance(targets[i]);
   }
+  return n;
+  ORC_CATCH
+}
+// req_opt_scorer.rs:104-134: ReqOptScorer(ConjunctionScorer(req lists), DisjunctionSumScorer(opt lists, true, 0)):
+// next() to exhaustion, emitting (doc, score()).
+int orc_mock_req_opt(const int32_t* req_docs, const int32_t* req_offsets, int n_req, const int32_t* opt_docs,
+                     const int32_t* opt_offsets, int n_opt, int32_t* out_docs, float* out_scores, int max_out) {
+  ORC_TRY
+  std::vector<ScorerBox> rq, op;
+  for (int i = 0; i < n_req; i++)
+    rq.emplace_back(new MockScorer(std::vector<int32_t>(req_docs + req_offsets[i], req_docs + req_offsets[i + 1])));
+  for (int i = 0; i < n_opt; i++)
+    op.emplace_back(new MockScorer(std::vector<int32_t>(opt_docs + opt_offsets[i], opt_docs + opt_offsets[i + 1])));
+  ScorerBox req = rq.size() == 1 ? std::move(rq[0]) : ScorerBox(new ConjunctionScorer(std::move(rq)));
+  ReqOptScorer sc(std::move(req), ScorerBox(new DisjunctionSumScorer(std::move(op), true, 0)));
+  if (sc.doc_id() != -1) throw OracleError(E_ILLEGAL_STATE, "ReqOptScorer must start unpositioned");
+  int n = 0;
+  for (int32_t d = sc.next(); d != NO_MORE_DOCS && n < max_out; d = sc.next()) { out_docs[n] = d; out_scores[n++] = sc.score(); }
   return n;
   ORC_CATCH
 }

@@ -470,6 +470,43 @@ struct ReqNotScorer : Scorer {
   uint64_t postings_visited() const override { return req_scorer->postings_visited() + not_scorer->postings_visited(); }
 };
 
+// scorer/req_opt_scorer.rs:19-100 — a required scorer whose score is topped up by an optional one positioned on the
+// same doc. score() carries SEQUENTIAL state: once more than OPT_SCORE_THRESHOLD docs took the optional path, a doc
+// whose required score is under half the running mean of those docs' required scores skips the optional clause
+// (:46-50). Iteration is the required scorer's. PINNED by the reference's own test (req_opt_scorer.rs:104-134: scores
+// 6, 9, 20 — tests/test_oracle_kat.py); the skipping rule itself is exercised by no reference test (parity unpinned).
+constexpr size_t OPT_SCORE_THRESHOLD = 100;
+struct ReqOptScorer : Scorer {
+  ScorerBox req_scorer, opt_scorer;
+  float scores_sum = 0.0f;
+  size_t scores_num = 0;
+  // threshold: OPT_SCORE_THRESHOLD is the reference; SIZE_MAX turns the skipping rule off ("exact sums": what the GPU
+  // path computes, see include/rucene_gpu.h RGPU_OP_WITH_SHOULD) so that tests can pin that path bit for bit
+  size_t threshold;
+  ReqOptScorer(ScorerBox req, ScorerBox opt, size_t threshold_ = OPT_SCORE_THRESHOLD)
+      : req_scorer(std::move(req)), opt_scorer(std::move(opt)), threshold(threshold_) {}
+  float score() override {  // :41-66
+    const int32_t current_doc = req_scorer->doc_id();
+    float score = req_scorer->score();
+    if (scores_num > threshold) {
+      if (2.0f * score < scores_sum / (float)scores_num) return score;
+    }
+    scores_sum += score;
+    scores_num += 1;
+    int32_t opt_doc = opt_scorer->doc_id();
+    if (opt_doc < current_doc) opt_doc = opt_scorer->advance(current_doc);
+    if (opt_doc == current_doc) score += opt_scorer->score();
+    return score;
+  }
+  int32_t doc_id() const override { return req_scorer->doc_id(); }
+  int32_t next() override { return req_scorer->next(); }
+  int32_t advance(int32_t target) override { return req_scorer->advance(target); }
+  size_t cost() const override { return req_scorer->cost(); }
+  int32_t approximate_next() override { return req_scorer->approximate_next(); }
+  int32_t approximate_advance(int32_t target) override { return req_scorer->approximate_advance(target); }
+  uint64_t postings_visited() const override { return req_scorer->postings_visited() + opt_scorer->postings_visited(); }
+};
+
 // ---- TopDocsCollector --------------------------------------------------------------------------------------------
 
 struct ScoreDoc { int32_t doc; float score; };
@@ -622,6 +659,8 @@ struct Query {
   std::vector<float> boosts;
   int32_t min_should_match = 0;
   std::vector<int64_t> must_not_ids;  // MUST_NOT TermQuery clauses (boolean_query.rs:33), scored with needs_scores = false
+  std::vector<int64_t> opt_ids;       // SHOULD TermQuery clauses next to MUST ones (op == OP_AND / OP_TERM): ReqOptScorer
+  bool opt_exact = false;             // true: never skip the optional clauses (not the reference's behaviour)
 };
 
 struct SearchResult {
@@ -705,6 +744,19 @@ struct IndexSearcher {
   }
   ScorerBox create_scorer(const Segment* seg, const Query& q, const std::vector<BM25Weight>& weights) const {
     ScorerBox positive = positive_scorer(seg, q, weights);
+    if (positive && !q.opt_ids.empty()) {
+      // boolean_query.rs:217-233, 253-262: the SHOULD clauses that exist in this leaf always go through a
+      // DisjunctionSumScorer (even a single one), with the query's min_should_match (0 next to MUST clauses unless set)
+      std::vector<ScorerBox> opts;
+      const size_t base = q.term_ids.size() + q.must_not_ids.size();
+      for (size_t i = 0; i < q.opt_ids.size(); i++) {
+        ScorerBox s = term_scorer(seg, q.opt_ids[i], &weights[base + i]);
+        if (s) opts.push_back(std::move(s));
+      }
+      if (!opts.empty())
+        positive.reset(new ReqOptScorer(std::move(positive), ScorerBox(new DisjunctionSumScorer(std::move(opts), true, q.min_should_match)),
+                                        q.opt_exact ? SIZE_MAX : OPT_SCORE_THRESHOLD));
+    }
     if (!positive || q.must_not_ids.empty()) return positive;
     // boolean_query.rs:235-252: absent terms drop out; one scorer is used directly, several are united by a
     // DisjunctionSumScorer(needs_scores = false, the query's min_should_match: 0 with MUST clauses, else 1)
@@ -729,6 +781,7 @@ struct IndexSearcher {
     for (size_t i = 0; i < q.term_ids.size(); i++)
       weights.push_back(term_weight(q.term_ids[i], q.boosts.empty() ? 1.0f : q.boosts[i]));
     for (size_t i = 0; i < q.must_not_ids.size(); i++) weights.push_back(term_weight(q.must_not_ids[i], 1.0f));
+    for (size_t i = 0; i < q.opt_ids.size(); i++) weights.push_back(term_weight(q.opt_ids[i], 1.0f));
     TopDocsCollector collector(k, tie_mode);
     SearchResult r;
     for (auto* seg : leaves) {

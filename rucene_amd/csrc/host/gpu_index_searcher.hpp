@@ -80,8 +80,10 @@ struct TermQuery : Query {
 struct BooleanQuery : Query {
   std::vector<TermQuery> must_queries, should_queries, must_not_queries;
   int32_t min_should_match = 0;
-  // boolean_query.rs:40-86 restricted to what the GPU path serves: MUST-only or SHOULD-only term trees, each
-  // optionally with MUST_NOT term clauses (ReqNotScorer); a single clause without MUST_NOTs collapses to that clause
+  // boolean_query.rs:40-86 restricted to what the GPU path serves: SHOULD-only term trees, or MUST clauses with optional
+  // SHOULD clauses beside them (ReqOptScorer, scored without the reference's sequential skipping rule: see
+  // RGPU_OP_WITH_SHOULD), each optionally with MUST_NOT term clauses (ReqNotScorer); a single clause without MUST_NOTs
+  // collapses to that clause
   static std::unique_ptr<Query> build(std::vector<TermQuery> musts, std::vector<TermQuery> shoulds, int32_t min_should_match = 0,
                                       std::vector<TermQuery> must_nots = {}) {
     const int32_t msm = min_should_match > 0 ? min_should_match : (musts.empty() ? 1 : 0);
@@ -89,8 +91,8 @@ struct BooleanQuery : Query {
       throw Error(RGPU_ERR_ILLEGAL_ARGUMENT, "boolean query should at least contain one inner query!");
     if (must_nots.empty() && musts.size() + shoulds.size() == 1)
       return std::unique_ptr<Query>(new TermQuery(musts.empty() ? shoulds[0] : musts[0]));
-    if ((!musts.empty() && !shoulds.empty()) || (msm > 1 && !musts.empty()) || msm > 255 || (musts.empty() && shoulds.empty()))
-      throw Error(RGPU_ERR_UNSUPPORTED, "only MUST (+MUST_NOT) and SHOULD (+MUST_NOT, min_should_match) term trees run on the GPU path");
+    if ((msm > 1 && !musts.empty()) || msm > 255 || (musts.empty() && shoulds.empty()))
+      throw Error(RGPU_ERR_UNSUPPORTED, "only MUST (+SHOULD, +MUST_NOT) and SHOULD (+MUST_NOT, min_should_match) term trees run on the GPU path");
     auto q = std::unique_ptr<BooleanQuery>(new BooleanQuery());
     q->must_queries = std::move(musts);
     q->should_queries = std::move(shoulds);
@@ -223,6 +225,7 @@ class GpuIndexSearcher {
   }
   void pack(const Query& q, const LeafReader& leaf, std::vector<rgpu_query>* qs, std::vector<rgpu_query_term>* ts) {
     const std::vector<TermQuery>* clauses = nullptr;
+    const std::vector<TermQuery>* opts = nullptr;  // SHOULD clauses beside MUST ones
     const std::vector<TermQuery>* nots = nullptr;
     std::vector<TermQuery> single;
     int32_t op = RGPU_OP_TERM;
@@ -230,13 +233,16 @@ class GpuIndexSearcher {
       single.push_back(*t);
       clauses = &single;
     } else if (auto* b = dynamic_cast<const BooleanQuery*>(&q)) {
-      op = b->must_queries.empty() ? (b->min_should_match > 1 ? RGPU_OP_OR_MSM(b->min_should_match) : (int32_t)RGPU_OP_OR) : (int32_t)RGPU_OP_AND;
+      op = b->must_queries.empty() ? (b->min_should_match > 1 ? RGPU_OP_OR_MSM(b->min_should_match) : (int32_t)RGPU_OP_OR)
+                                   : RGPU_OP_WITH_SHOULD(RGPU_OP_AND, b->should_queries.size());
       clauses = b->must_queries.empty() ? &b->should_queries : &b->must_queries;
+      if (!b->must_queries.empty()) opts = &b->should_queries;
       nots = &b->must_not_queries;
     } else {
       throw Error(RGPU_ERR_UNSUPPORTED, "query type not served by the GPU path");
     }
-    std::vector<TermQuery> all(*clauses);  // MUST_NOT clauses follow the positive ones
+    std::vector<TermQuery> all(*clauses);  // clause order: MUST / scored, optional SHOULD, MUST_NOT
+    if (opts) all.insert(all.end(), opts->begin(), opts->end());
     if (nots) all.insert(all.end(), nots->begin(), nots->end());
     rgpu_query rq{op, static_cast<int32_t>(clauses->size()), static_cast<int32_t>(ts->size()),
                   static_cast<int32_t>(nots ? nots->size() : 0)};

@@ -81,8 +81,9 @@ __device__ __forceinline__ int lds_lower_bound(const int32_t* a, int n, int32_t 
   return lo;
 }
 
-// HAS_NOT: some query of the launch carries MUST_NOT clauses (a second instantiation keeps the common kernel lean)
-template <bool LEGACY, bool WIDE, bool HAS_NOT>
+// HAS_NOT / HAS_OPT: some query of the launch carries MUST_NOT / optional SHOULD clauses (separate instantiations keep the
+// common kernel lean). Clause order on the device: [MUST x n_terms][MUST_NOT x pad][SHOULD x (op >> 16)].
+template <bool LEGACY, bool WIDE, bool HAS_NOT, bool HAS_OPT>
 __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(SegView seg, const DevQuery* __restrict__ queries,
                                                            const DevTerm* __restrict__ terms,
                                                            const int64_t* __restrict__ item_prefix, int n_queries,
@@ -130,12 +131,21 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
     float s0 = bm25_score(wk, (float)(int32_t)f0, has_norms ? cache[nb0] : k1);
     float s1 = bm25_score(wk, (float)(int32_t)f1, has_norms ? cache[nb1] : k1);
     // clauses 1 .. n_terms-1 are required (MUST), the n_not after them prohibited (MUST_NOT: ReqNotScorer,
-    // req_not_scorer.rs:47-63 — a candidate found there dies, nothing is scored)
-    const int n_clauses = HAS_NOT ? Q.n_terms + Q.pad : Q.n_terms;
+    // req_not_scorer.rs:47-63 — a candidate found there dies, nothing is scored), the n_opt after those optional
+    // (SHOULD next to MUST: ReqOptScorer, req_opt_scorer.rs:41-66 — a candidate found there adds that clause's score to
+    // a separate sum, as DisjunctionSumScorer does, which is added to the required sum at the end; a miss costs nothing.
+    // The reference's sequential "skip the optional clause for low scorers after 100 docs" rule is NOT applied:
+    // scores are the exact sums, >= the reference's)
+    const int n_req_not = HAS_NOT ? Q.n_terms + Q.pad : Q.n_terms;
+    const int n_clauses = HAS_OPT ? n_req_not + ((Q.op >> 16) & 0xff) : n_req_not;
+    float r0 = 0.f, r1 = 0.f;  // required sums, parked while s0 / s1 collect the optional sum
+    bool in_opt = false;
     for (int ti = 1; ti < n_clauses; ++ti) {
       const uint64_t m0 = __ballot(a0), m1 = __ballot(a1);
       if (!(m0 | m1)) break;
-      const bool excl = HAS_NOT && ti >= Q.n_terms;  // wave-uniform
+      const bool excl = HAS_NOT && ti >= Q.n_terms && ti < n_req_not;  // wave-uniform
+      const bool opt = HAS_OPT && ti >= n_req_not;                      // wave-uniform
+      if (HAS_OPT && opt && !in_opt) { r0 = s0; r1 = s1; s0 = 0.f; s1 = 0.f; in_opt = true; }
       const DevTerm T = terms[Q.first_term + ti];
       if (!excl) {
         use_table(T.sim_table);
@@ -147,7 +157,7 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
       auto found = [&](bool& alive, float& s, uint32_t fq, float nrm) {
         if (excl) alive = false; else s += bm25_score(wk, (float)(int32_t)fq, nrm);
       };
-      auto missed = [&](bool& alive) { if (!excl) alive = false; };
+      auto missed = [&](bool& alive) { if (!excl && !opt) alive = false; };
       if (T.df == 1) {
         if (a0) { if (d0 == T.singleton_doc) found(a0, s0, (uint32_t)T.singleton_freq, n0); else missed(a0); }
         if (a1) { if (d1 == T.singleton_doc) found(a1, s1, (uint32_t)T.singleton_freq, n1); else missed(a1); }
@@ -279,6 +289,7 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
         wave_sync();
       }
     }
+    if (HAS_OPT && in_opt) { s0 = r0 + s0; s1 = r1 + s1; }
     count += __popcll(__ballot(a0)) + __popcll(__ballot(a1));
     topk_offer<WIDE>(top, a0 ? make_key(s0, d0) : 0ull, tau, k, lane, floor);
     topk_offer<WIDE>(top, a1 ? make_key(s1, d1) : 0ull, tau, k, lane, floor);

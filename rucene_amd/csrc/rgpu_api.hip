@@ -833,16 +833,17 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
   std::vector<const rgpu_term_state*> ptrs;
   for (int32_t q = 0; q < n_queries; ++q) {
     const rgpu_query& Q = queries[q];
-    const int qop = Q.op & 0xff, qmsm = (Q.op >> 8) & 0xff;
-    if (qop < RGPU_OP_TERM || qop > RGPU_OP_OR || (Q.op >> 16) != 0) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "unknown query op");
+    const int qop = Q.op & 0xff, qmsm = (Q.op >> 8) & 0xff, qopt = (Q.op >> 16) & 0xff;
+    if (qop < RGPU_OP_TERM || qop > RGPU_OP_OR || (Q.op >> 24) != 0) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "unknown query op");
     if (qmsm > 1 && qop != RGPU_OP_OR) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "min_should_match applies to SHOULD clauses (op OR) only");
-    if (Q.n_terms < 1 || Q.n_must_not < 0 || Q.n_terms + Q.n_must_not > RGPU_MAX_QUERY_TERMS || (qop == RGPU_OP_TERM && Q.n_terms != 1))
+    if (qopt > 0 && qop == RGPU_OP_OR) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "optional SHOULD clauses go with MUST clauses (op TERM / AND); an OR query's clauses are its n_terms");
+    if (Q.n_terms < 1 || Q.n_must_not < 0 || Q.n_terms + qopt + Q.n_must_not > RGPU_MAX_QUERY_TERMS || (qop == RGPU_OP_TERM && Q.n_terms != 1))
       return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "bad clause count");
-    if (Q.first_term < 0 || Q.first_term + Q.n_terms + Q.n_must_not > n_terms_total)
+    if (Q.first_term < 0 || Q.first_term + Q.n_terms + qopt + Q.n_must_not > n_terms_total)
       return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "clause range outside terms[]");
-    for (int i = 0; i < Q.n_terms + Q.n_must_not; ++i) {
+    for (int i = 0; i < Q.n_terms + qopt + Q.n_must_not; ++i) {
       const rgpu_query_term& t = terms[Q.first_term + i];
-      if (i < Q.n_terms && (t.sim_table < 0 || t.sim_table >= c->n_sim_tables)) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "unknown sim_table handle");
+      if (i < Q.n_terms + qopt && (t.sim_table < 0 || t.sim_table >= c->n_sim_tables)) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "unknown sim_table handle");
       if (t.state.doc_freq > 0) ptrs.push_back(&t.state);
     }
   }
@@ -854,12 +855,14 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
   std::vector<Group> groups(3);
   int cur_group[3] = {0, 1, 2};
   for (int i = 0; i < 3; ++i) groups[(size_t)i].op = i;
-  std::vector<DevTerm> mine, mine_not;
+  std::vector<DevTerm> mine, mine_not, mine_opt;
   for (int32_t q = 0; q < n_queries; ++q) {
     const rgpu_query& Q = queries[q];
-    const int qop = Q.op & 0xff, qmsm = (Q.op >> 8) & 0xff;  // low byte: rgpu_query_op; next byte: min_should_match (OR)
+    // low byte: rgpu_query_op; next byte: min_should_match (OR); third byte: optional SHOULD clauses (TERM / AND)
+    const int qop = Q.op & 0xff, qmsm = (Q.op >> 8) & 0xff, qopt = (Q.op >> 16) & 0xff;
     mine.clear();
     mine_not.clear();
+    mine_opt.clear();
     bool dead = false;
     for (int i = 0; i < Q.n_terms; ++i) {
       const rgpu_query_term& t = terms[Q.first_term + i];
@@ -875,8 +878,16 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
     if (dead) mine.clear();
     // MUST_NOT clauses (boolean_query.rs:235-252): absent terms drop out; without a positive scorer there is none
     if (!mine.empty()) {
-      for (int i = 0; i < Q.n_must_not; ++i) {
+      for (int i = 0; i < qopt; ++i) {  // SHOULD next to MUST (boolean_query.rs:217-233): absent terms drop out
         const rgpu_query_term& t = terms[Q.first_term + Q.n_terms + i];
+        if (t.state.doc_freq <= 0) continue;
+        DevTerm dt;
+        rc = make_dev_term(seg, t.state, t.weight, t.sim_table, &dt);
+        if (rc != RGPU_OK) return rc;
+        mine_opt.push_back(dt);
+      }
+      for (int i = 0; i < Q.n_must_not; ++i) {
+        const rgpu_query_term& t = terms[Q.first_term + Q.n_terms + qopt + i];
         if (t.state.doc_freq <= 0) continue;
         DevTerm dt;
         rc = make_dev_term(seg, t.state, 0.0f, 0, &dt);  // needs_scores = false: weight and table are never read
@@ -886,8 +897,8 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
     }
     if (qop == RGPU_OP_AND)  // ConjunctionScorer::new: stable sort by cost() = doc_freq (conjunction_scorer.rs:30)
       std::stable_sort(mine.begin(), mine.end(), [](const DevTerm& a, const DevTerm& b) { return a.df < b.df; });
-    // a term with prohibited clauses runs as a one-clause conjunction (the lead-driven kernel probes them)
-    const int gop = (qop == RGPU_OP_TERM && !mine_not.empty()) ? (int)RGPU_OP_AND : qop;
+    // a term with prohibited / optional clauses runs as a one-clause conjunction (the lead-driven kernel probes them)
+    const int gop = (qop == RGPU_OP_TERM && (!mine_not.empty() || !mine_opt.empty())) ? (int)RGPU_OP_AND : qop;
     if (gop == RGPU_OP_OR && groups[(size_t)cur_group[2]].postings > or_postings_cap) {
       groups.emplace_back();
       groups.back().op = RGPU_OP_OR;
@@ -895,12 +906,15 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
     }
     Group& G = groups[(size_t)cur_group[gop]];
     DevQuery dq;
-    dq.op = gop | (qmsm > 1 ? qmsm << 8 : 0);  // the window kernel reads min_should_match from the second byte
+    // the window kernel reads min_should_match from the second byte, the conjunction kernel its optional clause count
+    // from the third; device clause order: MUST, MUST_NOT, SHOULD
+    dq.op = gop | (qmsm > 1 ? qmsm << 8 : 0) | ((int32_t)mine_opt.size() << 16);
     dq.first_term = (int32_t)G.terms.size();
     dq.n_terms = (int32_t)mine.size();
     dq.pad = (int32_t)mine_not.size();
     for (auto& m : mine) { G.terms.push_back(m); G.postings += m.df; }
     for (auto& m : mine_not) { G.terms.push_back(m); G.postings += m.df; }
+    for (auto& m : mine_opt) { G.terms.push_back(m); G.postings += m.df; }
     G.qmap.push_back(q);
     G.queries.push_back(dq);
   }
@@ -982,14 +996,17 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
         hipLaunchKernelGGL(kern, dim3(grid), dim3(WG_THREADS), 0, stream, sv, dq, dt, dp, nq, items, blocks_per_item, (int)k,
                            c->S->d_partial_keys.p, c->S->d_partial_counts.p, c->S->d_tau.p);
       };
-      bool has_not = false;
-      for (const DevQuery& q : G.queries) has_not = has_not || q.pad != 0;
-      if (has_not) {
-        if (legacy) { if (wide) go(k_search_and<true, true, true>); else go(k_search_and<true, false, true>); }
-        else { if (wide) go(k_search_and<false, true, true>); else go(k_search_and<false, false, true>); }
+      bool has_not = false, has_opt = false;
+      for (const DevQuery& q : G.queries) { has_not = has_not || q.pad != 0; has_opt = has_opt || (q.op >> 16) != 0; }
+      if (has_opt) {  // one instantiation serves MUST_NOT too (rare trees: keep the instantiation count down)
+        if (legacy) { if (wide) go(k_search_and<true, true, true, true>); else go(k_search_and<true, false, true, true>); }
+        else { if (wide) go(k_search_and<false, true, true, true>); else go(k_search_and<false, false, true, true>); }
+      } else if (has_not) {
+        if (legacy) { if (wide) go(k_search_and<true, true, true, false>); else go(k_search_and<true, false, true, false>); }
+        else { if (wide) go(k_search_and<false, true, true, false>); else go(k_search_and<false, false, true, false>); }
       } else {
-        if (legacy) { if (wide) go(k_search_and<true, true, false>); else go(k_search_and<true, false, false>); }
-        else { if (wide) go(k_search_and<false, true, false>); else go(k_search_and<false, false, false>); }
+        if (legacy) { if (wide) go(k_search_and<true, true, false, false>); else go(k_search_and<true, false, false, false>); }
+        else { if (wide) go(k_search_and<false, true, false, false>); else go(k_search_and<false, false, false, false>); }
       }
     } else if (op == RGPU_OP_TERM) {
       TimedLaunch tl(c, stream, "k_search_term", G.postings);

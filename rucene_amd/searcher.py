@@ -135,8 +135,10 @@ class TermQuery:
 
 
 class BooleanQuery:
-    """Only the trees the GPU path serves: all-MUST (AND) or all-SHOULD with any min_should_match (OR), each
-    optionally with MUST_NOT TermQuery clauses (ReqNotScorer, boolean_query.rs:235-273)."""
+    """Only the trees the GPU path serves: all-SHOULD with any min_should_match (OR), or MUST clauses (AND) with optional
+    SHOULD clauses beside them (ReqOptScorer, boolean_query.rs:253-262 — scored without the reference's sequential
+    skipping rule, see RGPU_OP_WITH_SHOULD in include/rucene_gpu.h); each optionally with MUST_NOT TermQuery clauses
+    (ReqNotScorer, boolean_query.rs:235-273)."""
 
     def __init__(self, must_queries, should_queries, min_should_match, must_not_queries=()):
         self.must_queries, self.should_queries, self.min_should_match = must_queries, should_queries, min_should_match
@@ -150,8 +152,8 @@ class BooleanQuery:
             raise RgpuError(-2, "boolean query should at least contain one inner query!")
         if len(must_nots) == 0 and len(musts) + len(shoulds) + len(filters) == 1 and len(filters) == 0:
             return (list(musts) + list(shoulds))[0]
-        if filters or (musts and shoulds) or (msm > 1 and musts) or msm > 255:
-            raise RgpuError(-5, "only MUST (+MUST_NOT) and SHOULD (+MUST_NOT, min_should_match) term trees run on the GPU path")
+        if filters or (msm > 1 and musts) or msm > 255:
+            raise RgpuError(-5, "only MUST (+SHOULD, +MUST_NOT) and SHOULD (+MUST_NOT, min_should_match) term trees run on the GPU path")
         if len(musts) + len(shoulds) == 0:
             raise RgpuError(-5, "a MUST_NOT-only query (MatchAllDocsQuery minus ...) is not served by the GPU path")
         if any(not isinstance(q, TermQuery) for q in list(musts) + list(shoulds) + list(must_nots)):
@@ -224,31 +226,33 @@ class GpuIndexSearcher:
 
     @staticmethod
     def _flatten(query):
+        """-> (op, required / scored clauses, optional SHOULD clauses beside MUST ones, MUST_NOT clauses)"""
         if isinstance(query, TermQuery):
-            return OP_TERM, [query], []
+            return OP_TERM, [query], [], []
         if isinstance(query, BooleanQuery):
             if query.must_queries:
-                return OP_AND, query.must_queries, query.must_not_queries
+                opts = query.should_queries
+                return OP_AND | (len(opts) << 16), query.must_queries, opts, query.must_not_queries   # RGPU_OP_WITH_SHOULD
             msm = query.min_should_match
-            return (OP_OR | (msm << 8) if msm > 1 else OP_OR), query.should_queries, query.must_not_queries
+            return (OP_OR | (msm << 8) if msm > 1 else OP_OR), query.should_queries, [], query.must_not_queries
         raise RgpuError(-5, "query type not served by the GPU path: %r" % (query,))
 
     def pack(self, queries, leaf):
         """queries -> (rgpu_query[], rgpu_query_term[]) for one leaf."""
         flat = [self._flatten(q) for q in queries]
-        byte_terms = [c.term for _, t, n in flat for c in list(t) + list(n) if isinstance(c.term, bytes)]
+        byte_terms = [c.term for _, t, o, n in flat for c in list(t) + list(o) + list(n) if isinstance(c.term, bytes)]
         if byte_terms:
             leaf.resolve(byte_terms)
             self.leaves[self._stats_leaf].resolve(byte_terms)
-        n_terms = sum(len(t) + len(n) for _, t, n in flat)
+        n_terms = sum(len(t) + len(o) + len(n) for _, t, o, n in flat)
         qs = np.zeros(len(flat), dtype=QUERY_DTYPE)
         ts = np.zeros(max(n_terms, 1), dtype=QUERY_TERM_DTYPE)
         pos = 0
-        for i, (op, clauses, nots) in enumerate(flat):
-            if len(clauses) + len(nots) > _lib.MAX_QUERY_TERMS:
+        for i, (op, clauses, opts, nots) in enumerate(flat):
+            if len(clauses) + len(opts) + len(nots) > _lib.MAX_QUERY_TERMS:
                 raise RgpuError(-5, "more than %d clauses" % _lib.MAX_QUERY_TERMS)
-            qs[i] = (op, len(clauses), pos, len(nots))   # MUST_NOT clauses follow the positive ones
-            for c in list(clauses) + list(nots):
+            qs[i] = (op, len(clauses), pos, len(nots))   # clause order: MUST / scored, optional SHOULD, MUST_NOT
+            for c in list(clauses) + list(opts) + list(nots):
                 w, table = self._weight(c.term, c.boost)
                 st = leaf.term_state(c.term)
                 if st is not None:

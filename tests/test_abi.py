@@ -90,7 +90,9 @@ def test_boolean_query_build_rules():
     assert isinstance(q, B) and len(q.must_queries) == 1
     q = B.build([], [T(1), T(2), T(3)], min_should_match=2)   # DisjunctionSumScorer with min_should_match
     assert q.min_should_match == 2 and len(q.should_queries) == 3
-    for bad in (lambda: B.build([T(1)], [T(2)]), lambda: B.build([T(1), T(2)], [], min_should_match=2),
+    q = B.build([T(1)], [T(2), T(3)])                      # MUST + SHOULD: ReqOptScorer tree, the SHOULD clauses are optional
+    assert isinstance(q, B) and len(q.must_queries) == 1 and len(q.should_queries) == 2 and q.min_should_match == 0
+    for bad in (lambda: B.build([T(1)], [T(2)], min_should_match=2), lambda: B.build([T(1), T(2)], [], min_should_match=2),
                 lambda: B.build([], [], must_nots=[T(3)]), lambda: B.build([T(1)], [], filters=[T(2)])):
         with pytest.raises(rucene_amd.RgpuError) as e:
             bad()

@@ -593,6 +593,40 @@ def test_segment_opened_from_a_full_index_directory(ctx, oracle):
     assert (hits[2]["doc"] == hits[3]["doc"]).all()
 
 
+def test_must_with_optional_should_clauses(zipf, oracle):
+    """MUST + SHOULD trees (ReqOptScorer, boolean_query.rs:253-262), also under MUST_NOT (ReqNotScorer around it). The GPU
+    always adds the optional clauses' scores; the reference skips them for some low scorers once 100 docs were scored
+    (req_opt_scorer.rs:46-50, sequential state). So: bit-exact against the oracle with that rule switched off, and
+    against the rule-following oracle the same hit counts with every common doc scored >= the reference."""
+    import rucene_amd
+    seg, osearcher, gsearcher = zipf
+    T, B = rucene_amd.TermQuery, rucene_amd.BooleanQuery
+    specs = [([0, 1], [2, 7], []), ([3], [1], []), ([900, 5], [0, 1, 2], []), ([2000, 2500], [0], []), ([40], [0], [9]),
+             ([1, 4], [2], [3, 6]), ([10], [49_999], []), ([6, 2, 30], [1, 0, 3, 4, 5, 7, 8, 9, 11], []), ([0], [1], [2]),
+             ([12, 7], [7, 12], []), ([49_998], [0, 1], []), ([5], [6], [5])]
+    queries = [B.build([T(t) for t in m], [T(t) for t in s], must_nots=[T(t) for t in n]) for m, s, n in specs]
+    skipped_somewhere = 0
+    for k in (10, 100):
+        hits, totals = gsearcher.search_batch(queries, k)
+        for i, (m, s, n) in enumerate(specs):
+            ed, es, et = osearcher.search_opt(oracle.OP_AND, m, s, k, must_not_ids=n, exact=True)
+            rd, rs, rt = osearcher.search_opt(oracle.OP_AND, m, s, k, must_not_ids=n)
+            cnt = len(ed)
+            gd, gs = hits[i]["doc"], hits[i]["score"]
+            assert totals[i] == et == rt, (i, specs[i])
+            assert (gd[cnt:] == -1).all()
+            assert (gd[:cnt] == ed).all(), (i, specs[i], gd[:cnt], ed)
+            assert (gs[:cnt].view(np.int32) == es.view(np.int32)).all(), (i, specs[i])
+            ref = dict(zip(rd.tolist(), rs.tolist()))
+            for d, sc in zip(gd[:cnt].tolist(), gs[:cnt].tolist()):
+                if d in ref:
+                    assert sc >= ref[d]
+                    skipped_somewhere += sc > ref[d]
+    # without SHOULD clauses present in the leaf the tree degenerates to the plain conjunction
+    plain, pt = gsearcher.search_batch([B.build([T(0), T(1)], []), B.build([T(0), T(1)], [T(-1)])], 10)
+    assert pt[0] == pt[1] and plain[0].tobytes() == plain[1].tobytes()
+
+
 def test_min_should_match(zipf, oracle):
     """DisjunctionSumScorer with min_should_match > 1 (disjunction_scorer.rs:41, 317-329): only docs held by that many
     SHOULD clauses are collected, and the clause-order sum (SimpleQueue is forced) is bit-exact even past 10 clauses.

@@ -374,3 +374,50 @@ def test_fst_random_maps_round_trip(oracle):
             assert oracle.fst_enumerate(fst) == pairs
             for k, v in pairs[::7]:
                 assert oracle.fst_get(fst, k) == v
+
+
+# ---- ReqOptScorer (MUST + SHOULD) -------------------------------------------------------------------------------------
+def test_req_opt_scorer_known_answers(oracle):
+    # scorer/req_opt_scorer.rs:104-134 test_score: Conjunction([1..5], [2,3,5]) required, Disjunction([2,5], [3,4,5])
+    # optional; mock score == doc id -> doc 2: 2+2 + 2 = 6, doc 3: 3+3 + 3 = 9, doc 5: 5+5 + 5+5 = 20
+    docs, scores = oracle.mock_req_opt([[1, 2, 3, 4, 5], [2, 3, 5]], [[2, 5], [3, 4, 5]])
+    assert docs == [2, 3, 5] and scores == [6.0, 9.0, 20.0]
+
+
+def test_req_opt_scorer_on_postings(oracle):
+    """The optional clause never changes which docs match or how many; it only adds to scores, and — the sequential
+    rule of req_opt_scorer.rs:46-50 — may be skipped once more than 100 docs have been scored, so every score lies between
+    the MUST-only score and MUST + all SHOULD scores. With <= 100 matches nothing is skipped: the sum is exact."""
+    from rucene_amd import indexgen
+    seg = indexgen.build_zipf(60_000, 4_000)
+    oseg = oracle.Segment(seg.doc_bytes, seg.norms, seg.max_doc, seg.terms, sum_total_term_freq=seg.sum_total_term_freq)
+    sr = oracle.Searcher([oseg])
+    k = 60_000
+
+    def by_doc(res):
+        return dict(zip(res[0].tolist(), res[1].tolist()))
+    total_skipped = 0
+    for musts, shoulds in (([0, 1], [2, 7]), ([3], [1]), ([900, 5], [0, 1, 2]), ([2000, 2500], [0])):
+        op = oracle.OP_AND if len(musts) > 1 else oracle.OP_TERM
+        base = sr.search(op, musts, k, tie_mode=oracle.TIE_CANONICAL)
+        got = sr.search_opt(op, musts, shoulds, k)
+        assert got[2] == base[2] and set(got[0].tolist()) == set(base[0].tolist())
+        must_score, opt_scores = by_doc(base), [by_doc(sr.search(oracle.OP_TERM, [t], k, tie_mode=oracle.TIE_CANONICAL)) for t in shoulds]
+        skipped = 0
+        for doc, score in by_doc(got).items():
+            full = np.float32(must_score[doc])
+            extra = np.float32(0)
+            for o in opt_scores:                       # DisjunctionSumScorer sums its positioned children in clause order
+                if doc in o:
+                    extra = np.float32(extra + np.float32(o[doc]))
+            full = np.float32(full + extra)
+            assert np.float32(score) in (np.float32(must_score[doc]), full), (musts, shoulds, doc)
+            skipped += np.float32(score) != full
+        if base[2] <= 100:
+            assert skipped == 0
+        total_skipped += skipped
+    assert total_skipped > 0        # the rule does fire on this data (TermQuery(3) + SHOULD 1 skips a couple of docs)
+    # MUST_NOT on top: ReqNotScorer(ReqOptScorer(..), ..) removes docs, nothing else
+    with_not = sr.search_opt(oracle.OP_AND, [0, 1], [2], k, must_not_ids=[3])
+    plain_not = sr.search_not(oracle.OP_AND, [0, 1], [3], k)
+    assert with_not[2] == plain_not[2] and set(with_not[0].tolist()) == set(plain_not[0].tolist())
