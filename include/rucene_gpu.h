@@ -241,6 +241,33 @@ typedef struct rgpu_field_stats {  /* Terms::{size, sum_total_term_freq, sum_doc
  * duplicate numbers / names and the checksum. */
 int32_t rgpu_field_infos_from_lucene60(const uint8_t* fnm, size_t fnm_len, rgpu_field_info* infos_out, int32_t cap, char* names_out,
                                        size_t names_cap, size_t* names_len_out);
+/* Lucene62SegmentInfoFormat::read (codec/segment_infos/segment_infos_format.rs:43-247): a segment's ".si" file.
+ * expected_id16: the id the commit point holds for the segment (check_index_header_id), or NULL. */
+typedef struct rgpu_segment_info {
+  int32_t max_doc;
+  int32_t is_compound_file;  /* 1: the segment's files live inside .cfs / .cfe (not readable through this library) */
+  int32_t version[3];        /* major, minor, bugfix of the writer */
+  int32_t n_files;
+  int32_t n_sort_fields;     /* > 0: the segment is index-sorted */
+  int32_t reserved;
+  uint8_t id[16];
+} rgpu_segment_info;
+int32_t rgpu_segment_info_from_lucene62(const uint8_t* si, size_t si_len, const uint8_t* expected_id16_or_null, rgpu_segment_info* out);
+/* SegmentInfos::read_commit (codec/segment_infos/segment_infos.rs:443-569): the commit point "segments_N". generation = N
+ * (the header suffix must be its base-36 form; < 0 skips that check). Returns the number of segments in the commit
+ * (>= 0) or a negative status and fills at most `cap` records. The reference also bounds del_count by the segment's
+ * max_doc while it reads; here that is the caller's job once it has the ".si" (rgpu_live_docs_from_lucene50 re-checks). */
+typedef struct rgpu_commit_segment {
+  char name[48];             /* "_0", "_1", ...: files are <name>.si, <name>.fnm, <name>_Lucene50_0.doc ..., <name>_<delgen36>.liv */
+  char codec[16];            /* "Lucene62" */
+  uint8_t id[16];
+  int64_t del_gen;           /* -1: no deletions file */
+  int64_t field_infos_gen;
+  int64_t dv_gen;
+  int32_t del_count;
+  int32_t reserved;
+} rgpu_commit_segment;
+int32_t rgpu_commit_from_segments_file(const uint8_t* data, size_t len, int64_t generation, rgpu_commit_segment* out, int32_t cap);
 int32_t rgpu_terms_open(const uint8_t* tim, size_t tim_len, const uint8_t* tip, size_t tip_len, const rgpu_field_info* infos,
                         int32_t n_infos, int32_t max_doc, rgpu_terms** out_terms);
 void rgpu_terms_close(rgpu_terms* terms);

@@ -29,7 +29,7 @@ def build(force=False):
     if force or not os.path.exists(_LIB_PATH) or any(
             os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
             for f in ("oracle_capi.cpp", "store.hpp", "packed.hpp", "postings.hpp", "search.hpp", "norms.hpp", "fst.hpp",
-                      "blocktree.hpp", "field_infos.hpp")):
+                      "blocktree.hpp", "field_infos.hpp", "segment_infos.hpp")):
         subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
@@ -120,6 +120,10 @@ def _declare(L):
         "orc_mock_req_opt": (C.c_int, [i32p, i32p, C.c_int, i32p, i32p, C.c_int, i32p, f32p, C.c_int]),
         "orc_search_opt": (C.c_int, [vp, C.c_int, i64p, C.c_int, i64p, C.c_int, i64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, i32p,
                                      f32p, i32p, i64p]),
+        "orc_segment_info_write": (C.c_int, [u8p, u8p, i32p, C.c_int32, C.c_int, u8p, i64p]),
+        "orc_segment_info_read": (C.c_int, [u8p, C.c_int64, u8p, i32p, i32p, u8p]),
+        "orc_segments_file_write": (C.c_int, [C.c_int64, u8p, C.c_int64, C.c_int32, C.c_int32, u8p, u8p, i64p, i32p, u8p, i64p]),
+        "orc_segments_file_read": (C.c_int, [u8p, C.c_int64, C.c_int64, i32p, C.c_int32, C.c_int32, u8p, C.c_int64, i64p, u8p, i64p, i32p]),
         "orc_field_infos_write": (C.c_int, [C.c_int32, i32p, i64p, u8p, u8p, C.c_char_p, u8p, i64p]),
         "orc_field_infos_read": (C.c_int, [u8p, C.c_int64, C.c_int32, i32p, i64p, u8p, C.c_int64, i64p]),
         "orc_fst_build": (C.c_int, [u8p, i64p, u8p, i64p, C.c_int64, C.c_int, u8p, i64p]),
@@ -724,4 +728,79 @@ def field_infos_read(fnm):
         out.append(dict(name=name, number=int(recs[i, 0]), index_options=int(recs[i, 1]), doc_values_type=int(recs[i, 2]),
                         store_term_vector=bool(recs[i, 3] & 1), omit_norms=bool(recs[i, 3] & 2), store_payloads=bool(recs[i, 3] & 4),
                         dv_gen=int(gens[i]), attributes=attrs, point_dimension_count=int(recs[i, 4]), point_num_bytes=int(recs[i, 5])))
+    return out
+
+
+# ---- ".si" and "segments_N" ------------------------------------------------------------------------------------------
+def _u8(b):
+    return np.frombuffer(bytes(b) + b"\0", dtype=np.uint8).copy()
+
+
+def segment_info_write(name, max_doc, segment_id=None, files=(), is_compound_file=False, version=(6, 4, 18), diagnostics=None,
+                       attributes=None):
+    """Lucene62SegmentInfoFormat::write (no index sort) -> ".si" bytes."""
+    diagnostics, attributes = diagnostics or {}, attributes or {}
+    flat = (_lp(name) + len(diagnostics).to_bytes(4, "little") + b"".join(_lp(k) + _lp(v) for k, v in diagnostics.items()) +
+            len(files).to_bytes(4, "little") + b"".join(_lp(f) for f in files) +
+            len(attributes).to_bytes(4, "little") + b"".join(_lp(k) + _lp(v) for k, v in attributes.items()))
+    sid = _u8(segment_id if segment_id is not None else bytes(range(16)))
+    ver = np.asarray(version, dtype=np.int32)
+    strings = _u8(flat)
+    n = C.c_int64(0)
+    args = (_p(strings, C.c_uint8), _p(sid, C.c_uint8), _p(ver, C.c_int32), int(max_doc), int(is_compound_file))
+    _check(lib().orc_segment_info_write(*args, None, C.byref(n)))
+    out = np.zeros(n.value, dtype=np.uint8)
+    _check(lib().orc_segment_info_write(*args, _p(out, C.c_uint8), C.byref(n)))
+    return out.tobytes()
+
+
+def segment_info_read(si, expected_id=None):
+    b = np.frombuffer(si, dtype=np.uint8).copy()
+    out6, counts2, sid = np.zeros(6, np.int32), np.zeros(2, np.int32), np.zeros(16, np.uint8)
+    eid = _u8(expected_id) if expected_id is not None else None
+    _check(lib().orc_segment_info_read(_p(b, C.c_uint8), b.size, _p(eid, C.c_uint8), _p(out6, C.c_int32), _p(counts2, C.c_int32), _p(sid, C.c_uint8)))
+    return dict(max_doc=int(out6[0]), is_compound_file=bool(out6[1]), version=tuple(int(v) for v in out6[2:5]), n_files=int(out6[5]),
+                n_diagnostics=int(counts2[0]), n_attributes=int(counts2[1]), id=sid.tobytes())
+
+
+def segments_file_write(segments, generation=1, commit_id=None, version=1, counter=None):
+    """SegmentInfos::write_output. segments: [dict(name, id, max_doc, del_gen=-1, del_count=0, field_infos_gen=-1, dv_gen=-1,
+    version=(6, 4, 18))] -> "segments_N" bytes."""
+    n = len(segments)
+    names = _u8(b"".join(_lp(s["name"]) for s in segments))
+    ids = _u8(b"".join(bytes(s["id"]) for s in segments))
+    longs = np.zeros((max(n, 1), 4), np.int64)
+    ints = np.zeros((max(n, 1), 5), np.int32)
+    for i, s in enumerate(segments):
+        longs[i, :3] = (s.get("del_gen", -1), s.get("field_infos_gen", -1), s.get("dv_gen", -1))
+        ints[i] = (s.get("del_count", 0), s["max_doc"]) + tuple(s.get("version", (6, 4, 18)))
+    cid = _u8(commit_id if commit_id is not None else bytes(range(100, 116)))
+    ln = C.c_int64(0)
+    args = (int(generation), _p(cid, C.c_uint8), int(version), int(n if counter is None else counter), n, _p(names, C.c_uint8),
+            _p(ids, C.c_uint8), _p(longs, C.c_int64), _p(ints, C.c_int32))
+    _check(lib().orc_segments_file_write(*args, None, C.byref(ln)))
+    out = np.zeros(ln.value, dtype=np.uint8)
+    _check(lib().orc_segments_file_write(*args, _p(out, C.c_uint8), C.byref(ln)))
+    return out.tobytes()
+
+
+def segments_file_read(data, generation, max_docs=None):
+    b = np.frombuffer(data, dtype=np.uint8).copy()
+    md = np.asarray(max_docs, dtype=np.int32) if max_docs is not None else None
+    ln = C.c_int64(0)
+    count = _check(lib().orc_segments_file_read(_p(b, C.c_uint8), b.size, int(generation), _p(md, C.c_int32), 0 if md is None else md.size,
+                                                0, None, 0, C.byref(ln), None, None, None))
+    names = np.zeros(max(ln.value, 1), np.uint8)
+    ids = np.zeros(max(count, 1) * 16, np.uint8)
+    longs = np.zeros((max(count, 1), 3), np.int64)
+    dels = np.zeros(max(count, 1), np.int32)
+    _check(lib().orc_segments_file_read(_p(b, C.c_uint8), b.size, int(generation), _p(md, C.c_int32), 0 if md is None else md.size, count,
+                                        _p(names, C.c_uint8), names.size, C.byref(ln), _p(ids, C.c_uint8), _p(longs, C.c_int64),
+                                        _p(dels, C.c_int32)))
+    raw, pos, out = names.tobytes(), 0, []
+    for i in range(count):
+        n = int.from_bytes(raw[pos:pos + 4], "little")
+        out.append(dict(name=raw[pos + 4:pos + 4 + n].decode(), id=ids[16 * i:16 * i + 16].tobytes(), del_gen=int(longs[i, 0]),
+                        field_infos_gen=int(longs[i, 1]), dv_gen=int(longs[i, 2]), del_count=int(dels[i])))
+        pos += 4 + n
     return out

@@ -14,6 +14,7 @@
 #include "fst.hpp"
 #include "blocktree.hpp"
 #include "field_infos.hpp"
+#include "segment_infos.hpp"
 #include "store.hpp"
 
 using namespace orc;
@@ -675,6 +676,88 @@ int orc_field_infos_read(const uint8_t* fnm, int64_t len, int32_t cap, int32_t* 
   if (strings_out && (int64_t)flat.size() <= strings_cap) std::memcpy(strings_out, flat.data(), flat.size());
   *strings_len = (int64_t)flat.size();
   return (int)infos.size();
+  ORC_CATCH
+}
+
+// ---- .si and segments_N (oracle/segment_infos.hpp) ------------------------------------------------------------------
+// strings: length-prefixed (u32 LE + bytes): name, then u32 n + pairs (diagnostics), u32 n + strings (files), u32 n + pairs
+// (attributes)
+int orc_segment_info_write(const uint8_t* strings, const uint8_t* id16, const int32_t* version3, int32_t max_doc, int is_compound,
+                           uint8_t* out, int64_t* out_len) {
+  ORC_TRY
+  const uint8_t* p = strings;
+  SegmentInfoRec si;
+  si.name = take_string(p);
+  auto take_u32 = [&]() { uint32_t n; std::memcpy(&n, p, 4); p += 4; return n; };
+  for (uint32_t n = take_u32(); n > 0; n--) { std::string k = take_string(p); si.diagnostics[k] = take_string(p); }
+  for (uint32_t n = take_u32(); n > 0; n--) si.files.insert(take_string(p));
+  for (uint32_t n = take_u32(); n > 0; n--) { std::string k = take_string(p); si.attributes[k] = take_string(p); }
+  std::memcpy(si.id, id16, ID_LENGTH);
+  si.version.major = version3[0]; si.version.minor = version3[1]; si.version.bugfix = version3[2];
+  si.max_doc = max_doc;
+  si.is_compound_file = is_compound != 0;
+  std::vector<uint8_t> b = write_segment_info(si);
+  if (out && *out_len >= (int64_t)b.size()) std::memcpy(out, b.data(), b.size());
+  *out_len = (int64_t)b.size();
+  return 0;
+  ORC_CATCH
+}
+// out6: max_doc, is_compound, major, minor, bugfix, n_files; counts2: #diagnostics, #attributes; id_out: 16 bytes
+int orc_segment_info_read(const uint8_t* si, int64_t len, const uint8_t* expected_id16, int32_t* out6, int32_t* counts2, uint8_t* id_out) {
+  ORC_TRY
+  SegmentInfoRec r = read_segment_info(si, (size_t)len, "", expected_id16);
+  out6[0] = r.max_doc; out6[1] = r.is_compound_file ? 1 : 0; out6[2] = r.version.major; out6[3] = r.version.minor;
+  out6[4] = r.version.bugfix; out6[5] = (int32_t)r.files.size();
+  counts2[0] = (int32_t)r.diagnostics.size(); counts2[1] = (int32_t)r.attributes.size();
+  std::memcpy(id_out, r.id, ID_LENGTH);
+  return 0;
+  ORC_CATCH
+}
+// per segment: names (length-prefixed strings, one per segment), ids (16 bytes each), i64 x4 {del_gen, field_infos_gen,
+// dv_gen, spare}, i32 x5 {del_count, max_doc, major, minor, bugfix}
+int orc_segments_file_write(int64_t generation, const uint8_t* commit_id16, int64_t version, int32_t counter, int32_t n,
+                            const uint8_t* names, const uint8_t* ids, const int64_t* longs4, const int32_t* ints5, uint8_t* out,
+                            int64_t* out_len) {
+  ORC_TRY
+  CommitRec c;
+  c.generation = generation;
+  std::memcpy(c.id, commit_id16, ID_LENGTH);
+  c.version = version;
+  c.counter = counter;
+  const uint8_t* p = names;
+  for (int32_t i = 0; i < n; i++) {
+    CommitSegmentRec s;
+    s.name = take_string(p);
+    std::memcpy(s.id, ids + 16 * i, ID_LENGTH);
+    s.del_gen = longs4[4 * i]; s.field_infos_gen = longs4[4 * i + 1]; s.dv_gen = longs4[4 * i + 2];
+    s.del_count = ints5[5 * i]; s.max_doc = ints5[5 * i + 1];
+    s.version.major = ints5[5 * i + 2]; s.version.minor = ints5[5 * i + 3]; s.version.bugfix = ints5[5 * i + 4];
+    c.segments.push_back(std::move(s));
+  }
+  std::vector<uint8_t> b = write_segments_file(c);
+  if (out && *out_len >= (int64_t)b.size()) std::memcpy(out, b.data(), b.size());
+  *out_len = (int64_t)b.size();
+  return 0;
+  ORC_CATCH
+}
+// returns the segment count; names_out length-prefixed; ids 16 bytes each; longs3 {del_gen, field_infos_gen, dv_gen}; del_counts
+int orc_segments_file_read(const uint8_t* data, int64_t len, int64_t generation, const int32_t* max_docs, int32_t n_max_docs, int32_t cap,
+                           uint8_t* names_out, int64_t names_cap, int64_t* names_len, uint8_t* ids_out, int64_t* longs3, int32_t* del_counts) {
+  ORC_TRY
+  CommitRec c = read_segments_file(data, (size_t)len, generation, max_docs, (size_t)n_max_docs);
+  std::string flat;
+  for (size_t i = 0; i < c.segments.size(); i++) {
+    const CommitSegmentRec& s = c.segments[i];
+    put_string(flat, s.name);
+    if ((int32_t)i < cap) {
+      std::memcpy(ids_out + 16 * i, s.id, ID_LENGTH);
+      longs3[3 * i] = s.del_gen; longs3[3 * i + 1] = s.field_infos_gen; longs3[3 * i + 2] = s.dv_gen;
+      del_counts[i] = s.del_count;
+    }
+  }
+  if (names_out && (int64_t)flat.size() <= names_cap) std::memcpy(names_out, flat.data(), flat.size());
+  *names_len = (int64_t)flat.size();
+  return (int)c.segments.size();
   ORC_CATCH
 }
 

@@ -23,7 +23,12 @@ FIELD_INFO_DTYPE = np.dtype([("number", "<i4"), ("index_options", "<i4"), ("has_
 FIELD_STATS_DTYPE = np.dtype([("num_terms", "<i8"), ("sum_total_term_freq", "<i8"), ("sum_doc_freq", "<i8"), ("doc_count", "<i4"),
                               ("longs_size", "<i4")], align=True)
 INDEX_OPTIONS_DOCS, INDEX_OPTIONS_DOCS_AND_FREQS, INDEX_OPTIONS_POSITIONS, INDEX_OPTIONS_OFFSETS = 1, 2, 3, 4
+SEGMENT_INFO_DTYPE = np.dtype([("max_doc", "<i4"), ("is_compound_file", "<i4"), ("version", "<i4", (3,)), ("n_files", "<i4"),
+                               ("n_sort_fields", "<i4"), ("reserved", "<i4"), ("id", "u1", (16,))], align=True)
+COMMIT_SEGMENT_DTYPE = np.dtype([("name", "S48"), ("codec", "S16"), ("id", "u1", (16,)), ("del_gen", "<i8"), ("field_infos_gen", "<i8"),
+                                 ("dv_gen", "<i8"), ("del_count", "<i4"), ("reserved", "<i4")], align=True)
 assert FIELD_INFO_DTYPE.itemsize == 16 and FIELD_STATS_DTYPE.itemsize == 32
+assert SEGMENT_INFO_DTYPE.itemsize == 48 and COMMIT_SEGMENT_DTYPE.itemsize == 112
 assert TERM_STATE_DTYPE.itemsize == 32 and QUERY_TERM_DTYPE.itemsize == 40 and QUERY_DTYPE.itemsize == 16 and HIT_DTYPE.itemsize == 8
 
 STATUS_NAMES = {0: "OK", -1: "IllegalState", -2: "IllegalArgument", -3: "UnexpectedEOF", -4: "CorruptIndex",
@@ -35,7 +40,7 @@ EXPORTS = [
     "rgpu_segment_free", "rgpu_segment_version", "rgpu_segment_prepare_terms", "rgpu_decode_terms",
     "rgpu_decode_terms_device", "rgpu_advance_batch", "rgpu_sim_table_upload", "rgpu_search_batch",
     "rgpu_search_batch_device", "rgpu_merge_topk_device", "rgpu_bm25_compute_weight", "rgpu_bm25_encode_norm",
-    "rgpu_norms_from_lucene53", "rgpu_live_docs_from_lucene50", "rgpu_field_infos_from_lucene60", "rgpu_terms_open", "rgpu_terms_close", "rgpu_terms_field_stats",
+    "rgpu_norms_from_lucene53", "rgpu_live_docs_from_lucene50", "rgpu_field_infos_from_lucene60", "rgpu_segment_info_from_lucene62", "rgpu_commit_from_segments_file", "rgpu_terms_open", "rgpu_terms_close", "rgpu_terms_field_stats",
     "rgpu_terms_lookup", "rgpu_kernel_stats", "rgpu_kernel_stats_reset", "rgpu_synchronize",
 ]
 
@@ -112,6 +117,8 @@ def lib():
         "rgpu_bm25_encode_norm": (C.c_uint8, [f32, i32]),
         "rgpu_norms_from_lucene53": (i32, [vp, C.c_size_t, vp, C.c_size_t, i32, i32, vp]),
         "rgpu_live_docs_from_lucene50": (i32, [vp, C.c_size_t, i32, i32, vp]),
+        "rgpu_segment_info_from_lucene62": (i32, [vp, C.c_size_t, vp, vp]),
+        "rgpu_commit_from_segments_file": (i32, [vp, C.c_size_t, i64, vp, i32]),
         "rgpu_field_infos_from_lucene60": (i32, [vp, C.c_size_t, vp, i32, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
         "rgpu_terms_open": (i32, [vp, C.c_size_t, vp, C.c_size_t, vp, i32, i32, C.POINTER(vp)]),
         "rgpu_terms_close": (None, [vp]),
@@ -166,6 +173,27 @@ def live_docs_from_lucene50(liv, max_doc, del_count=-1):
     out = np.zeros((max(int(max_doc), 1) + 63) // 64, dtype=np.uint64)
     _check(lib().rgpu_live_docs_from_lucene50(b.ctypes.data, b.size, int(max_doc), int(del_count), out.ctypes.data))
     return out
+
+
+def segment_info_from_lucene62(si, expected_id=None):
+    """Lucene62SegmentInfoFormat::read: ".si" bytes -> dict(max_doc, is_compound_file, version, n_files, n_sort_fields, id)."""
+    b = np.frombuffer(bytes(si), dtype=np.uint8)
+    out = np.zeros(1, dtype=SEGMENT_INFO_DTYPE)
+    eid = np.frombuffer(bytes(expected_id), dtype=np.uint8) if expected_id is not None else None
+    _check(lib().rgpu_segment_info_from_lucene62(b.ctypes.data, b.size, eid.ctypes.data if eid is not None else None, out.ctypes.data))
+    r = out[0]
+    return dict(max_doc=int(r["max_doc"]), is_compound_file=bool(r["is_compound_file"]), version=tuple(int(v) for v in r["version"]),
+                n_files=int(r["n_files"]), n_sort_fields=int(r["n_sort_fields"]), id=r["id"].tobytes())
+
+
+def commit_from_segments_file(data, generation=-1):
+    """SegmentInfos::read_commit: "segments_N" bytes -> [dict(name, codec, id, del_gen, del_count, field_infos_gen, dv_gen)]."""
+    b = np.frombuffer(bytes(data), dtype=np.uint8)
+    n = _check(lib().rgpu_commit_from_segments_file(b.ctypes.data, b.size, int(generation), None, 0))
+    out = np.zeros(max(n, 1), dtype=COMMIT_SEGMENT_DTYPE)
+    _check(lib().rgpu_commit_from_segments_file(b.ctypes.data, b.size, int(generation), out.ctypes.data, n))
+    return [dict(name=r["name"].decode(), codec=r["codec"].decode(), id=r["id"].tobytes(), del_gen=int(r["del_gen"]),
+                 del_count=int(r["del_count"]), field_infos_gen=int(r["field_infos_gen"]), dv_gen=int(r["dv_gen"])) for r in out[:n]]
 
 
 def field_infos_from_lucene60(fnm):

@@ -16,6 +16,7 @@
 #include "host/norms_format.hpp"
 #include "host/term_dict.hpp"
 #include "host/field_infos_format.hpp"
+#include "host/segment_infos_format.hpp"
 #include "kernels/prepare.hpp"
 #include "kernels/search.hpp"
 #include "kernels/search_and.hpp"
@@ -1157,6 +1158,42 @@ extern "C" int32_t rgpu_terms_open(const uint8_t* tim, size_t tim_len, const uin
 }
 
 extern "C" void rgpu_terms_close(rgpu_terms* terms) { delete terms; }
+
+extern "C" int32_t rgpu_segment_info_from_lucene62(const uint8_t* si, size_t si_len, const uint8_t* expected_id16_or_null, rgpu_segment_info* out) {
+  if (!out) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "out is null");
+  rucene::SegmentInfoEntry e;
+  std::string why;
+  const int rc = rucene::read_lucene62_segment_info(si, si_len, expected_id16_or_null, &e, &why);
+  if (rc != 0) return fail(rc, why);
+  *out = rgpu_segment_info{};
+  out->max_doc = e.max_doc;
+  out->is_compound_file = e.is_compound_file ? 1 : 0;
+  for (int i = 0; i < 3; ++i) out->version[i] = e.version[i];
+  out->n_files = e.n_files;
+  out->n_sort_fields = e.n_sort_fields;
+  std::memcpy(out->id, e.id, 16);
+  return RGPU_OK;
+}
+
+extern "C" int32_t rgpu_commit_from_segments_file(const uint8_t* data, size_t len, int64_t generation, rgpu_commit_segment* out, int32_t cap) {
+  std::vector<rucene::CommitSegmentEntry> segs;
+  std::string why;
+  const int rc = rucene::read_segments_file(data, len, generation, &segs, &why);
+  if (rc != 0) return fail(rc, why);
+  for (size_t i = 0; i < segs.size() && out && (int64_t)i < cap; ++i) {
+    const rucene::CommitSegmentEntry& s = segs[i];
+    if (s.name.size() >= sizeof(out[i].name) || s.codec.size() >= sizeof(out[i].codec)) return fail(RGPU_ERR_UNSUPPORTED, "segment or codec name too long");
+    out[i] = rgpu_commit_segment{};
+    std::memcpy(out[i].name, s.name.c_str(), s.name.size());
+    std::memcpy(out[i].codec, s.codec.c_str(), s.codec.size());
+    std::memcpy(out[i].id, s.id, 16);
+    out[i].del_gen = s.del_gen;
+    out[i].field_infos_gen = s.field_infos_gen;
+    out[i].dv_gen = s.dv_gen;
+    out[i].del_count = s.del_count;
+  }
+  return (int32_t)segs.size();
+}
 
 extern "C" int32_t rgpu_field_infos_from_lucene60(const uint8_t* fnm, size_t fnm_len, rgpu_field_info* infos_out, int32_t cap, char* names_out,
                                                   size_t names_cap, size_t* names_len_out) {

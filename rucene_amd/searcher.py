@@ -120,6 +120,49 @@ class LeafReader:
         return self.terms[term]
 
 
+def _base36(v):
+    digits, out = "0123456789abcdefghijklmnopqrstuvwxyz", ""
+    while True:
+        out = digits[v % 36] + out
+        v //= 36
+        if v == 0:
+            return out
+
+
+def open_directory(path, field="body"):
+    """StandardDirectoryReader::open for the slice this path needs: the newest commit point `segments_N` names the
+    segments; per segment `.si` gives max_doc, `.fnm` the field's number and index options, `_Lucene50_0.{doc,tim,tip}` the
+    postings and term dictionary, `.nvm/.nvd` the norms, `_<delgen>.liv` the live docs (index/reader/directory_reader.rs:
+    90-140; segment_reader.rs open; file names per codec/segment_infos/mod.rs:60-114). Returns the LeafReaders with
+    cumulative doc bases, ready for GpuIndexSearcher. Compound-file segments are refused (UnsupportedOperation)."""
+    import os
+    gens = [int(f[len("segments_"):], 36) for f in os.listdir(path) if f.startswith("segments_")]
+    if not gens:
+        raise RgpuError(-6, "no segments_N file found in %s" % path)   # IndexNotFound
+    gen = max(gens)
+
+    def read(name):
+        with open(os.path.join(path, name), "rb") as fh:
+            return fh.read()
+    leaves, doc_base = [], 0
+    for seg in _lib.commit_from_segments_file(read("segments_" + _base36(gen)), gen):
+        name = seg["name"]
+        info = _lib.segment_info_from_lucene62(read(name + ".si"), expected_id=seg["id"])
+        if info["is_compound_file"]:
+            raise RgpuError(-5, "segment %s uses a compound file (.cfs); only plain segment files can be opened" % name)
+        if seg["del_count"] > info["max_doc"]:
+            raise RgpuError(-4, "invalid deletion count: %d vs maxDoc=%d" % (seg["del_count"], info["max_doc"]))
+        postings = name + "_Lucene50_0"      # PerFieldPostingsFormat: format "Lucene50", suffix "0" (field_infos/mod.rs:441-447)
+        liv = read("%s_%s.liv" % (name, _base36(seg["del_gen"]))) if seg["del_gen"] >= 0 and seg["del_count"] > 0 else None
+        leaf = LeafReader.from_index_files(np.frombuffer(read(postings + ".doc"), dtype=np.uint8), read(postings + ".tim"),
+                                           read(postings + ".tip"), read(name + ".nvm"), read(name + ".nvd"), info["max_doc"],
+                                           liv=liv, del_count=seg["del_count"] if liv is not None else -1, doc_base=doc_base,
+                                           field=field, fnm=read(name + ".fnm"))
+        leaves.append(leaf)
+        doc_base += info["max_doc"]
+    return leaves
+
+
 class TermQuery:
     """term: bytes (resolved through each leaf's term dictionary) or an int term id (synthetic flat term table)."""
 

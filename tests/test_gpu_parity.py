@@ -593,6 +593,26 @@ def test_segment_opened_from_a_full_index_directory(ctx, oracle):
     assert (hits[2]["doc"] == hits[3]["doc"]).all()
 
 
+def test_index_directory_opened_and_searched(ctx, oracle, tmp_path):
+    """rucene_amd.open_directory over a directory laid out like Rucene's (segments_N, .si, .fnm, _Lucene50_0.doc/.tim/.tip,
+    .nvm/.nvd, .liv; two segments, deletions in the first) -> GpuIndexSearcher; byte-named queries over both leaves must
+    equal the oracle searching the same two segments (doc bases, live docs, largest-leaf statistics)."""
+    import rucene_amd
+    from test_index_directory import build_directory
+    segs, lives = build_directory(oracle, str(tmp_path))
+    leaves = rucene_amd.open_directory(str(tmp_path), field="body")
+    gsearcher = rucene_amd.GpuIndexSearcher(leaves, ctx=ctx)
+    osegs, base = [], 0
+    for seg, live, leaf in zip(segs, lives, leaves):
+        osegs.append(oracle.Segment(seg.doc_bytes, seg.norms, seg.max_doc, seg.terms, doc_base=base, live_docs=live,
+                                    doc_count=leaf.doc_count, sum_total_term_freq=leaf.sum_total_term_freq))
+        base += seg.max_doc
+    osearcher = oracle.Searcher(osegs)
+    specs = ([(oracle.OP_TERM, [t]) for t in (0, 2, 33, 850)] + [(oracle.OP_AND, [0, 1]), (oracle.OP_AND, [0, 1, 2]), (oracle.OP_AND, [3, 4, 20]),
+             (oracle.OP_OR, [5, 50, 500]), (oracle.OP_OR, [0, 899, 1500])])   # 1500: only the first segment has that term
+    _check_against_oracle(oracle, osearcher, gsearcher, specs, 10, name=lambda t: b"w%05d" % t)
+
+
 def test_must_with_optional_should_clauses(zipf, oracle):
     """MUST + SHOULD trees (ReqOptScorer, boolean_query.rs:253-262), also under MUST_NOT (ReqNotScorer around it). The GPU
     always adds the optional clauses' scores; the reference skips them for some low scorers once 100 docs were scored

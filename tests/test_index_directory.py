@@ -1,0 +1,183 @@
+"""The files that say what a Rucene index directory holds — the commit point "segments_N" and each segment's ".si" —
+and opening a whole directory through them. Host-only code on both sides: the product readers are
+rgpu_commit_from_segments_file / rgpu_segment_info_from_lucene62 (rucene_amd/csrc/host/segment_infos_format.hpp through the
+C ABI), the checker is the oracle's restatement of SegmentInfos::{write_output, read_commit} and
+Lucene62SegmentInfoFormat::{write, read} (oracle/segment_infos.hpp). No reference test pins these formats (parity
+unpinned: the source text is the only authority); the two are checked against each other and hand-assembled bytes."""
+import os
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def rgpu():
+    import __graft_entry__ as g
+    g.build()
+    import rucene_amd
+    return rucene_amd
+
+
+SID = bytes(range(16))
+CID = bytes(range(100, 116))
+
+
+def _header(codec, version, sid, suffix=b""):
+    return struct.pack(">I", 0x3FD76C17) + bytes([len(codec)]) + codec + struct.pack(">i", version) + sid + bytes([len(suffix)]) + suffix
+
+
+def _footer(body):
+    f = body + struct.pack(">Ii", 0xC02893E8, 0)
+    return f + struct.pack(">q", zlib.crc32(f) & 0xFFFFFFFF)
+
+
+def test_hand_assembled_segment_info(rgpu, oracle):
+    # segment_infos_format.rs:249-380: version triple (i32 x3), i32 max_doc, u8 compound, diagnostics, files, attributes, sort
+    si = _footer(_header(b"Lucene62SegmentInfo", 1, SID) + struct.pack(">iiii", 6, 4, 18, 1234) + b"\xff" +
+                 bytes([1]) + b"\x06source" + b"\x05flush" +
+                 bytes([2]) + b"\x06_0.fnm" + b"\x05_0.si" +
+                 bytes([0]) + bytes([0]))
+    assert oracle.segment_info_write("_0", 1234, segment_id=SID, files=["_0.si", "_0.fnm"], diagnostics={"source": "flush"}) == si
+    want = dict(max_doc=1234, is_compound_file=False, version=(6, 4, 18), n_files=2, id=SID)
+    got = rgpu.segment_info_from_lucene62(si, expected_id=SID)
+    assert {k: got[k] for k in want} == want and got["n_sort_fields"] == 0
+    assert {k: oracle.segment_info_read(si, SID)[k] for k in want} == want
+    with pytest.raises(rgpu.RgpuError) as e:
+        rgpu.segment_info_from_lucene62(si, expected_id=CID)             # check_index_header_id
+    assert e.value.status == -4
+    with pytest.raises(oracle.OracleError):
+        oracle.segment_info_read(si, CID)
+    with pytest.raises(oracle.OracleError):                                 # a file of another segment
+        oracle.segment_info_write("_0", 1, files=["_1.si"])
+
+
+def test_index_sorted_and_compound_segment_info(rgpu, oracle):
+    # the index-sort grammar (segment_infos_format.rs:65-200) is parsed to reach the footer: Long with a missing value, a
+    # SortedNumeric (Float, Max) and a reversed String
+    body = (_header(b"Lucene62SegmentInfo", 1, SID) + struct.pack(">iiii", 6, 4, 18, 77) + b"\x01" + bytes([0, 0, 0]) + bytes([3]) +
+            b"\x01a" + bytes([1]) + bytes([1]) + bytes([1]) + struct.pack(">q", -5) +
+            b"\x01b" + bytes([6, 3, 1]) + bytes([0]) + bytes([1]) + struct.pack(">i", 7) +
+            b"\x01c" + bytes([0]) + bytes([0]) + bytes([0]))
+    si = _footer(body)
+    got = rgpu.segment_info_from_lucene62(si)
+    assert got["is_compound_file"] and got["n_sort_fields"] == 3 and got["max_doc"] == 77
+    assert oracle.segment_info_read(si)["is_compound_file"]
+    bad = bytearray(body)
+    bad[-3] = 9                                                            # sort type id of "c"
+    with pytest.raises(rgpu.RgpuError) as e:
+        rgpu.segment_info_from_lucene62(_footer(bytes(bad)))
+    assert e.value.status == -4
+    with pytest.raises(oracle.OracleError):
+        oracle.segment_info_read(_footer(bytes(bad)))
+
+
+def test_hand_assembled_segments_file(rgpu, oracle):
+    # segment_infos.rs:243-300, generation 37 -> suffix "11"
+    seg = (b"\x02_0" + b"\x01" + SID + b"\x08Lucene62" + struct.pack(">qiqq", 3, 12, -1, -1) + bytes([0]) + struct.pack(">i", 0))
+    data = _footer(_header(b"segments", 6, CID, b"11") + bytes([6, 4, 18]) + struct.pack(">qii", 9, 5, 1) + bytes([6, 4, 18]) + seg + bytes([0]))
+    segs = [dict(name="_0", id=SID, max_doc=100, del_gen=3, del_count=12)]
+    assert oracle.segments_file_write(segs, generation=37, commit_id=CID, version=9, counter=5) == data
+    want = [dict(name="_0", id=SID, del_gen=3, del_count=12, field_infos_gen=-1, dv_gen=-1)]
+    assert oracle.segments_file_read(data, 37, max_docs=[100]) == want
+    got = rgpu.commit_from_segments_file(data, 37)
+    assert [{k: g[k] for k in want[0]} for g in got] == want and got[0]["codec"] == "Lucene62"
+    for call in (lambda: rgpu.commit_from_segments_file(data, 36), lambda: oracle.segments_file_read(data, 36)):   # wrong generation
+        with pytest.raises((rgpu.RgpuError, oracle.OracleError)):
+            call()
+    with pytest.raises(oracle.OracleError):
+        oracle.segments_file_read(data, 37, max_docs=[11])                  # del_count > max_doc
+    with pytest.raises(rgpu.RgpuError) as e:
+        rgpu.commit_from_segments_file(data[:-1], 37)
+    assert e.value.status == -4
+    other_codec = data.replace(b"Lucene62", b"Lucene70")
+    with pytest.raises(rgpu.RgpuError) as e:
+        rgpu.commit_from_segments_file(_footer(other_codec[:-16]), 37)
+    assert e.value.status == -2                                             # IllegalArgument: Invalid codec name
+    assert rgpu.commit_from_segments_file(oracle.segments_file_write([], generation=1), 1) == []
+
+
+def test_product_matches_oracle_on_many_segments(rgpu, oracle):
+    rng = np.random.default_rng(8)
+    segs = [dict(name="_%s" % np.base_repr(i, 36).lower(), id=bytes(rng.integers(0, 256, 16, dtype=np.uint8)), max_doc=int(rng.integers(1, 10**6)),
+                 del_gen=int(rng.integers(-1, 50)), field_infos_gen=int(rng.integers(-1, 3)), dv_gen=-1) for i in range(70)]
+    for s in segs:
+        s["del_count"] = int(rng.integers(0, s["max_doc"] + 1)) if s["del_gen"] >= 0 else 0
+    data = oracle.segments_file_write(segs, generation=1295)
+    want = oracle.segments_file_read(data, 1295, max_docs=[s["max_doc"] for s in segs])
+    got = rgpu.commit_from_segments_file(data, 1295)
+    assert [{k: g[k] for k in want[0]} for g in got] == want
+    assert [w["name"] for w in want] == [s["name"] for s in segs]
+
+
+def _write_segment(oracle, path, name, sid, seg, live=None, del_gen=-1):
+    """Lay one synthetic segment out as the files a Rucene directory would hold for it."""
+    present = [t for t in range(seg.terms.size) if seg.terms[t]["doc_freq"] > 0]
+    st = np.zeros(len(present), dtype=oracle.FULL_TERM_STATE_DTYPE)
+    st["base"] = seg.terms[present]
+    st["last_pos_block_offset"] = -1
+    tim, tip = oracle.blocktree_write([dict(number=1, doc_count=seg.doc_count, terms=[b"w%05d" % t for t in present], states=st)],
+                                      segment_id=sid, suffix="Lucene50_0")
+    nvm, nvd = oracle.norms_write(seg.norms.astype(np.int64), field_number=1, segment_id=sid)
+    files = {name + ".fnm": oracle.field_infos_write([dict(name="title", number=0), dict(name="body", number=1, index_options=2)], segment_id=sid),
+             name + "_Lucene50_0.doc": seg.doc_bytes.tobytes(), name + "_Lucene50_0.tim": tim, name + "_Lucene50_0.tip": tip,
+             name + ".nvm": nvm, name + ".nvd": nvd}
+    del_count = 0
+    if live is not None:
+        bits = np.unpackbits(live.view(np.uint8), bitorder="little")[:seg.max_doc]
+        del_count = int(seg.max_doc - bits.sum())
+        files["%s_%s.liv" % (name, np.base_repr(del_gen, 36).lower())] = oracle.live_docs_write(live, seg.max_doc, del_count, segment_id=sid, gen=del_gen)
+    files[name + ".si"] = oracle.segment_info_write(name, seg.max_doc, segment_id=sid, files=sorted(files) + [name + ".si"])
+    for fname, data in files.items():
+        with open(os.path.join(path, fname), "wb") as fh:
+            fh.write(data)
+    return dict(name=name, id=sid, max_doc=seg.max_doc, del_gen=del_gen if live is not None else -1, del_count=del_count)
+
+
+def build_directory(oracle, path, sizes=((30_000, 2_000), (12_000, 900)), deletions=True):
+    """Two synthetic segments + an older commit point. -> (synthetic segments, live-doc words per segment)"""
+    from rucene_amd import indexgen
+    rng = np.random.default_rng(77)
+    segs, lives, commit = [], [], []
+    for i, (max_doc, n_terms) in enumerate(sizes):
+        seg = indexgen.build_zipf(max_doc, n_terms, seed=500 + i)
+        live = None
+        if deletions and i == 0:
+            bits = rng.random(max_doc) < 0.9
+            live = np.zeros((max_doc + 63) // 64, dtype=np.uint64)
+            idx = np.nonzero(bits)[0]
+            np.bitwise_or.at(live, idx >> 6, np.uint64(1) << (idx & 63).astype(np.uint64))
+        sid = bytes(rng.integers(0, 256, 16, dtype=np.uint8))
+        commit.append(_write_segment(oracle, path, "_%d" % i, sid, seg, live, del_gen=2))
+        segs.append(seg)
+        lives.append(live)
+    with open(os.path.join(path, "segments_1"), "wb") as fh:                # an older commit: only the first segment
+        fh.write(oracle.segments_file_write(commit[:1], generation=1))
+    with open(os.path.join(path, "segments_2"), "wb") as fh:
+        fh.write(oracle.segments_file_write(commit, generation=2))
+    return segs, lives
+
+
+def test_open_directory_host_side(rgpu, oracle, tmp_path):
+    segs, lives = build_directory(oracle, str(tmp_path))
+    leaves = rgpu.open_directory(str(tmp_path), field="body")
+    assert [l.max_doc for l in leaves] == [30_000, 12_000] and [l.doc_base for l in leaves] == [0, 30_000]
+    assert leaves[0].field_number == 1 and leaves[0].live_docs is not None and leaves[1].live_docs is None
+    assert (leaves[0].live_docs == lives[0]).all() and (leaves[0].norms == segs[0].norms).all()
+    for leaf, seg in zip(leaves, segs):
+        for t in (0, 1, 57, seg.terms.size - 1):
+            assert leaf.term_state(b"w%05d" % t).tobytes() == seg.terms[t].tobytes()
+        assert leaf.term_state(b"nope") is None
+        assert leaf.sum_total_term_freq == int(seg.terms["total_term_freq"].sum())
+    with pytest.raises(rgpu.RgpuError) as e:
+        rgpu.open_directory(str(tmp_path), field="title")                  # not indexed
+    assert e.value.status == -5
+    with pytest.raises(rgpu.RgpuError) as e:
+        rgpu.open_directory(str(tmp_path), field="missing")
+    assert e.value.status == -2
+    os.remove(str(tmp_path / "segments_2"))
+    assert len(rgpu.open_directory(str(tmp_path), field="body")) == 1    # falls back to the older commit point
+    os.remove(str(tmp_path / "segments_1"))
+    with pytest.raises(rgpu.RgpuError):
+        rgpu.open_directory(str(tmp_path))
