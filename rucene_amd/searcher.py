@@ -9,8 +9,10 @@ argument meaning and error behaviour so tests read like the reference's own (pat
     search/collector/top_docs.rs:97-183                      TopDocsCollector::new(k) / top_docs()
     search/statistics.rs                                     CollectionStatistics / TermStatistics
 
-The term dictionary (block-tree) is out of scope: a LeafReader carries a flat table of
-BlockTermState records indexed by term id. All scoring work happens in librucene_gpu.so; this module only
+    index/reader/directory_reader.rs, segment_reader.rs      open_directory: commit point -> segments -> per-format readers
+
+Terms are named by bytes and resolved through each leaf's block-tree dictionary (rgpu_terms_*), or — synthetic indexes —
+by an id into a flat table of BlockTermState records. All scoring work happens in librucene_gpu.so; this module only
 resolves terms, computes BM25 weights (via the C ABI's host helper) and packs query structs.
 """
 import numpy as np
