@@ -332,10 +332,16 @@ class TermDictionary {
           // a term: stats + metadata (decode_metadata + lucene50_decode_term), cumulative within the block
           TermState st;
           st.doc_freq = (int32_t)stats.vint();
-          st.total_term_freq = has_freqs ? (int64_t)st.doc_freq + (int64_t)vlong(stats) : -1;
+          // vlong() yields < 2^63; sums are formed unsigned and must stay below 2^62 (a file pointer / count a real
+          // index can hold), so no signed overflow whatever the bytes say
+          const uint64_t kMax = 1ull << 62;
+          const uint64_t ttf_extra = has_freqs ? vlong(stats) : 0;
           uint64_t longs[3] = {0, 0, 0};
           for (int k = 0; k < longs_size; ++k) longs[k] = vlong(meta);
-          doc_fp = (first_term ? 0 : doc_fp) + (int64_t)longs[0];
+          const uint64_t fp = (first_term ? 0ull : (uint64_t)doc_fp) + longs[0];
+          if (ttf_extra >= kMax || longs[0] >= kMax || fp >= kMax) { *why = "term statistics / file pointer out of range in a term block"; return ERR_CORRUPT; }
+          st.total_term_freq = has_freqs ? (int64_t)((uint64_t)(uint32_t)st.doc_freq + ttf_extra) : -1;
+          doc_fp = (int64_t)fp;
           first_term = false;
           st.doc_start_fp = doc_fp;
           st.singleton_doc_id = st.doc_freq == 1 ? (int32_t)meta.vint() : -1;
