@@ -84,13 +84,17 @@ struct BooleanQuery : Query {
   // SHOULD clauses beside them (ReqOptScorer, scored without the reference's sequential skipping rule: see
   // RGPU_OP_WITH_SHOULD), each optionally with MUST_NOT term clauses (ReqNotScorer); a single clause without MUST_NOTs
   // collapses to that clause
+  // FILTER clauses are required clauses that score 0 (create_weight with needs_scores = false -> NonScoringSimilarity,
+  // boolean_query.rs:106-108, searcher.rs:158-202): they join the MUST clauses with boost 0, which leaves every sum unchanged
   static std::unique_ptr<Query> build(std::vector<TermQuery> musts, std::vector<TermQuery> shoulds, int32_t min_should_match = 0,
-                                      std::vector<TermQuery> must_nots = {}) {
+                                      std::vector<TermQuery> must_nots = {}, std::vector<TermQuery> filters = {}) {
     const int32_t msm = min_should_match > 0 ? min_should_match : (musts.empty() ? 1 : 0);
-    if (musts.empty() && shoulds.empty() && must_nots.empty())
+    if (musts.empty() && shoulds.empty() && must_nots.empty() && filters.empty())
       throw Error(RGPU_ERR_ILLEGAL_ARGUMENT, "boolean query should at least contain one inner query!");
-    if (must_nots.empty() && musts.size() + shoulds.size() == 1)
-      return std::unique_ptr<Query>(new TermQuery(musts.empty() ? shoulds[0] : musts[0]));
+    for (TermQuery& f : filters) f.boost = 0.0f;
+    if (must_nots.empty() && musts.size() + shoulds.size() + filters.size() == 1)  // a lone FILTER: ConstantScoreQuery, boost 0
+      return std::unique_ptr<Query>(new TermQuery(!filters.empty() ? filters[0] : (musts.empty() ? shoulds[0] : musts[0])));
+    musts.insert(musts.end(), filters.begin(), filters.end());
     if ((msm > 1 && !musts.empty()) || msm > 255 || (musts.empty() && shoulds.empty()))
       throw Error(RGPU_ERR_UNSUPPORTED, "only MUST (+SHOULD, +MUST_NOT) and SHOULD (+MUST_NOT, min_should_match) term trees run on the GPU path");
     auto q = std::unique_ptr<BooleanQuery>(new BooleanQuery());

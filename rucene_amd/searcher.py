@@ -183,11 +183,14 @@ class BooleanQuery:
     """Only the trees the GPU path serves: all-SHOULD with any min_should_match (OR), or MUST clauses (AND) with optional
     SHOULD clauses beside them (ReqOptScorer, boolean_query.rs:253-262 — scored without the reference's sequential
     skipping rule, see RGPU_OP_WITH_SHOULD in include/rucene_gpu.h); each optionally with MUST_NOT TermQuery clauses
-    (ReqNotScorer, boolean_query.rs:235-273)."""
+    (ReqNotScorer, boolean_query.rs:235-273). FILTER clauses are required clauses that score 0 (create_weight with
+    needs_scores = false -> NonScoringSimilarity, boolean_query.rs:106-108, searcher.rs:158-202): they ride as MUST clauses
+    of weight 0, which leaves every f32 sum unchanged."""
 
-    def __init__(self, must_queries, should_queries, min_should_match, must_not_queries=()):
+    def __init__(self, must_queries, should_queries, min_should_match, must_not_queries=(), filter_queries=()):
         self.must_queries, self.should_queries, self.min_should_match = must_queries, should_queries, min_should_match
         self.must_not_queries = list(must_not_queries)
+        self.filter_queries = list(filter_queries)
 
     @staticmethod
     def build(musts, shoulds, filters=(), must_nots=(), min_should_match=0):
@@ -195,18 +198,24 @@ class BooleanQuery:
         msm = min_should_match if min_should_match > 0 else (1 if len(musts) == 0 else 0)
         if len(musts) + len(shoulds) + len(filters) + len(must_nots) == 0:
             raise RgpuError(-2, "boolean query should at least contain one inner query!")
-        if len(must_nots) == 0 and len(musts) + len(shoulds) + len(filters) == 1 and len(filters) == 0:
+        if len(must_nots) == 0 and len(musts) + len(shoulds) + len(filters) == 1:
+            if filters:   # ConstantScoreQuery::with_boost(filter, 0.0) (boolean_query.rs:70-73): every match scores 0
+                return TermQuery(filters[0].term, 0.0)
             return (list(musts) + list(shoulds))[0]
-        if filters or (msm > 1 and musts) or msm > 255:
+        if (msm > 1 and (musts or filters)) or msm > 255:
             raise RgpuError(-5, "only MUST (+SHOULD, +MUST_NOT) and SHOULD (+MUST_NOT, min_should_match) term trees run on the GPU path")
-        if len(musts) + len(shoulds) == 0:
+        if len(musts) + len(shoulds) + len(filters) == 0:
             raise RgpuError(-5, "a MUST_NOT-only query (MatchAllDocsQuery minus ...) is not served by the GPU path")
-        if any(not isinstance(q, TermQuery) for q in list(musts) + list(shoulds) + list(must_nots)):
+        if any(not isinstance(q, TermQuery) for q in list(musts) + list(shoulds) + list(must_nots) + list(filters)):
             raise RgpuError(-5, "nested boolean clauses are not supported on the GPU path")
-        return BooleanQuery(list(musts), list(shoulds), msm, list(must_nots))
+        return BooleanQuery(list(musts), list(shoulds), msm, list(must_nots), list(filters))
+
+    def required_clauses(self):
+        """MUST clauses followed by the FILTER clauses as zero-weight MUST clauses (BooleanWeight puts both into must_weights)."""
+        return list(self.must_queries) + [TermQuery(f.term, 0.0) for f in self.filter_queries]
 
     def extract_terms(self):  # boolean_query.rs:124-145: MUST, SHOULD and FILTER clauses only
-        return list(self.must_queries) + list(self.should_queries)
+        return list(self.must_queries) + list(self.should_queries) + list(self.filter_queries)
 
 
 class TopDocs:
@@ -275,9 +284,10 @@ class GpuIndexSearcher:
         if isinstance(query, TermQuery):
             return OP_TERM, [query], [], []
         if isinstance(query, BooleanQuery):
-            if query.must_queries:
+            required = query.required_clauses()
+            if required:
                 opts = query.should_queries
-                return OP_AND | (len(opts) << 16), query.must_queries, opts, query.must_not_queries   # RGPU_OP_WITH_SHOULD
+                return OP_AND | (len(opts) << 16), required, opts, query.must_not_queries   # RGPU_OP_WITH_SHOULD
             msm = query.min_should_match
             return (OP_OR | (msm << 8) if msm > 1 else OP_OR), query.should_queries, [], query.must_not_queries
         raise RgpuError(-5, "query type not served by the GPU path: %r" % (query,))

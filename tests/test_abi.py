@@ -92,8 +92,13 @@ def test_boolean_query_build_rules():
     assert q.min_should_match == 2 and len(q.should_queries) == 3
     q = B.build([T(1)], [T(2), T(3)])                      # MUST + SHOULD: ReqOptScorer tree, the SHOULD clauses are optional
     assert isinstance(q, B) and len(q.must_queries) == 1 and len(q.should_queries) == 2 and q.min_should_match == 0
+    q = B.build([T(1)], [], filters=[T(2), T(3)])            # FILTER: required, scores 0 -> zero-weight MUST clauses
+    assert [c.term for c in q.required_clauses()] == [1, 2, 3] and [c.boost for c in q.required_clauses()] == [1.0, 0.0, 0.0]
+    assert len(q.extract_terms()) == 3
+    q = B.build([], [], filters=[T(7)])                      # a lone FILTER: ConstantScoreQuery with boost 0
+    assert isinstance(q, T) and q.term == 7 and q.boost == 0.0
     for bad in (lambda: B.build([T(1)], [T(2)], min_should_match=2), lambda: B.build([T(1), T(2)], [], min_should_match=2),
-                lambda: B.build([], [], must_nots=[T(3)]), lambda: B.build([T(1)], [], filters=[T(2)])):
+                lambda: B.build([], [], must_nots=[T(3)]), lambda: B.build([], [T(1), T(2)], filters=[T(3)], min_should_match=2)):
         with pytest.raises(rucene_amd.RgpuError) as e:
             bad()
         assert e.value.status == -5                      # UnsupportedOperation: caller keeps those on the CPU path

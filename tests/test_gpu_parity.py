@@ -647,6 +647,31 @@ def test_must_with_optional_should_clauses(zipf, oracle):
     assert pt[0] == pt[1] and plain[0].tobytes() == plain[1].tobytes()
 
 
+def test_filter_clauses(zipf, oracle):
+    """FILTER clauses are required and score 0 (NonScoringSimilarity, searcher.rs:158-202): the mirror sends them as MUST
+    clauses of weight 0; the oracle runs them as MUST clauses with boost 0, the same arithmetic (x + 0.0f == x)."""
+    import rucene_amd
+    seg, osearcher, gsearcher = zipf
+    T, B = rucene_amd.TermQuery, rucene_amd.BooleanQuery
+    specs = [([0], [1]), ([3, 4], [0]), ([40], [0, 1, 2]), ([], [5, 6]), ([], [9]), ([2000], [49_999]), ([7, 1], [7])]
+    queries = [B.build([T(t) for t in m], [], filters=[T(t) for t in f]) for m, f in specs]
+    for k in (10, 100):
+        hits, totals = gsearcher.search_batch(queries, k)
+        for i, (m, f) in enumerate(specs):
+            op = oracle.OP_AND if len(m) + len(f) > 1 else oracle.OP_TERM
+            cd, cs, ct = osearcher.search(op, m + f, k, tie_mode=oracle.TIE_CANONICAL, boosts=[1.0] * len(m) + [0.0] * len(f))
+            n = len(cd)
+            assert totals[i] == ct, (i, specs[i])
+            assert (hits[i]["doc"][:n] == cd).all() and (hits[i]["doc"][n:] == -1).all(), (i, specs[i])
+            assert (hits[i]["score"][:n].view(np.int32) == cs.view(np.int32)).all(), (i, specs[i])
+            if not m:
+                assert (hits[i]["score"][:n] == 0).all()           # only FILTER clauses: every match scores 0, doc order decides
+    # FILTER + SHOULD: the filter is the required side of a ReqOptScorer
+    h, t = gsearcher.search_batch([B.build([], [T(1)], filters=[T(3)])], 10)
+    ed, es, et = osearcher.search_opt(oracle.OP_TERM, [3], [1], 10, exact=True)   # weight 1 on the required clause ...
+    assert t[0] == et                                                                # ... same docs match; scores differ by design
+
+
 def test_min_should_match(zipf, oracle):
     """DisjunctionSumScorer with min_should_match > 1 (disjunction_scorer.rs:41, 317-329): only docs held by that many
     SHOULD clauses are collected, and the clause-order sum (SimpleQueue is forced) is bit-exact even past 10 clauses.
