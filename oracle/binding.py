@@ -29,7 +29,7 @@ def build(force=False):
     if force or not os.path.exists(_LIB_PATH) or any(
             os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
             for f in ("oracle_capi.cpp", "store.hpp", "packed.hpp", "postings.hpp", "search.hpp", "norms.hpp", "fst.hpp",
-                      "blocktree.hpp", "field_infos.hpp", "segment_infos.hpp")):
+                      "blocktree.hpp", "field_infos.hpp", "segment_infos.hpp", "positions.hpp")):
         subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
@@ -120,6 +120,11 @@ def _declare(L):
         "orc_mock_req_opt": (C.c_int, [i32p, i32p, C.c_int, i32p, i32p, C.c_int, i32p, f32p, C.c_int]),
         "orc_search_opt": (C.c_int, [vp, C.c_int, i64p, C.c_int, i64p, C.c_int, i64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, i32p,
                                      f32p, i32p, i64p]),
+        "orc_pos_index_build": (vp, [C.c_int32, C.c_int32, C.c_int32, i64p, i32p, i32p, i64p, i32p]),
+        "orc_pos_index_free": (None, [vp]),
+        "orc_pos_index_sizes": (C.c_int64, [vp, i64p, i64p]),
+        "orc_pos_term_state": (C.c_int, [vp, C.c_int32, i64p]),
+        "orc_pos_iterate": (C.c_int64, [vp, C.c_int32, i32p, C.c_int64, C.c_int32, C.c_int32, i32p, i32p, i32p, C.c_int64, i32p, C.c_int64]),
         "orc_segment_info_write": (C.c_int, [u8p, u8p, i32p, C.c_int32, C.c_int, u8p, i64p]),
         "orc_segment_info_read": (C.c_int, [u8p, C.c_int64, u8p, i32p, i32p, u8p]),
         "orc_segments_file_write": (C.c_int, [C.c_int64, u8p, C.c_int64, C.c_int32, C.c_int32, u8p, u8p, i64p, i32p, u8p, i64p]),
@@ -804,3 +809,61 @@ def segments_file_read(data, generation, max_docs=None):
                         field_infos_gen=int(longs[i, 1]), dv_gen=int(longs[i, 2]), del_count=int(dels[i])))
         pos += 4 + n
     return out
+
+
+# ---- positions (".pos" + BlockPostingIterator) -------------------------------------------------------------------------
+class PositionsIndex:
+    """A docs+freqs+positions field written by the restated Lucene50PostingsWriter. postings: per term a list of
+    (doc, [positions...]) in doc order."""
+
+    def __init__(self, max_doc, postings, version=1):
+        docs, freqs, positions, doc_offs, pos_offs = [], [], [], [0], [0]
+        for plist in postings:
+            for d, ps in plist:
+                docs.append(d)
+                freqs.append(len(ps))
+                positions.extend(ps)
+                pos_offs.append(len(positions))
+            doc_offs.append(len(docs))
+        a = lambda v, t: np.ascontiguousarray(v if len(v) else [0], dtype=t)
+        self._args = (a(doc_offs, np.int64), a(docs, np.int32), a(freqs, np.int32), a(pos_offs, np.int64), a(positions, np.int32))
+        self.n_terms = len(postings)
+        self._h = lib().orc_pos_index_build(int(max_doc), int(version), self.n_terms, _p(self._args[0], C.c_int64), _p(self._args[1], C.c_int32),
+                                            _p(self._args[2], C.c_int32), _p(self._args[3], C.c_int64), _p(self._args[4], C.c_int32))
+        if not self._h:
+            raise OracleError(lib().orc_last_error().decode())
+
+    def sizes(self):
+        d, p = C.c_int64(0), C.c_int64(0)
+        lib().orc_pos_index_sizes(self._h, C.byref(d), C.byref(p))
+        return d.value, p.value
+
+    def term_state(self, term):
+        out = np.zeros(7, dtype=np.int64)
+        _check(lib().orc_pos_term_state(self._h, term, _p(out, C.c_int64)))
+        return dict(zip(("doc_start_fp", "skip_offset", "total_term_freq", "doc_freq", "singleton_doc_id", "pos_start_fp",
+                         "last_pos_block_offset"), out.tolist()))
+
+    def iterate(self, term, targets=None, read_every=1, max_positions=-1, cap_visits=1 << 20, cap_positions=1 << 22):
+        """-> [(doc, freq, [positions read])]; targets None: next() to the end, else advance(t) for each t."""
+        tg = None if targets is None else np.ascontiguousarray(targets, dtype=np.int32)
+        docs = np.zeros(cap_visits, np.int32)
+        freqs = np.zeros(cap_visits, np.int32)
+        npos = np.zeros(cap_visits, np.int32)
+        pos = np.zeros(cap_positions, np.int32)
+        n = _check(lib().orc_pos_iterate(self._h, term, _p(tg, C.c_int32), 0 if tg is None else tg.size, read_every, max_positions,
+                                         _p(docs, C.c_int32), _p(freqs, C.c_int32), _p(npos, C.c_int32), cap_visits, _p(pos, C.c_int32),
+                                         cap_positions))
+        out, at = [], 0
+        for i in range(n):
+            out.append((int(docs[i]), int(freqs[i]), pos[at:at + npos[i]].tolist()))
+            at += int(npos[i])
+        return out
+
+    def close(self):
+        if self._h:
+            lib().orc_pos_index_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()

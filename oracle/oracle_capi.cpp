@@ -15,6 +15,7 @@
 #include "blocktree.hpp"
 #include "field_infos.hpp"
 #include "segment_infos.hpp"
+#include "positions.hpp"
 #include "store.hpp"
 
 using namespace orc;
@@ -758,6 +759,98 @@ int orc_segments_file_read(const uint8_t* data, int64_t len, int64_t generation,
   if (names_out && (int64_t)flat.size() <= names_cap) std::memcpy(names_out, flat.data(), flat.size());
   *names_len = (int64_t)flat.size();
   return (int)c.segments.size();
+  ORC_CATCH
+}
+
+// ---- positions: .pos file + BlockPostingIterator (oracle/positions.hpp) ---------------------------------------------
+struct orc_pos_index {
+  std::vector<uint8_t> doc, pos;
+  std::vector<PosTermState> terms;
+  std::unique_ptr<PostingsReader> reader;
+  std::unique_ptr<PosFile> pos_file;
+};
+// Term t owns docs [doc_offs[t], doc_offs[t+1]) with freqs; doc j owns positions [pos_offs[j], pos_offs[j+1]) (pos_offs is
+// indexed by the flat doc slot, so pos_offs[j+1] - pos_offs[j] == freqs[j]).
+orc_pos_index* orc_pos_index_build(int32_t max_doc, int32_t version, int32_t n_terms, const int64_t* doc_offs, const int32_t* docs,
+                                   const int32_t* freqs, const int64_t* pos_offs, const int32_t* positions) {
+  try {
+    auto h = std::make_unique<orc_pos_index>();
+    uint8_t id[ID_LENGTH];
+    for (int i = 0; i < ID_LENGTH; i++) id[i] = (uint8_t)(i * 7 + 1);
+    PosPostingsWriter w(max_doc, version, id, "Lucene50_0");
+    for (int32_t t = 0; t < n_terms; t++) {
+      PosTermState st;
+      w.start_term();
+      int64_t ttf = 0;
+      for (int64_t j = doc_offs[t]; j < doc_offs[t + 1]; j++) {
+        if (pos_offs[j + 1] - pos_offs[j] != freqs[j]) throw OracleError(E_ILLEGAL_ARGUMENT, "positions per doc must equal freq");
+        w.start_doc(docs[j], freqs[j]);
+        for (int64_t p = pos_offs[j]; p < pos_offs[j + 1]; p++) w.add_position(positions[p]);
+        w.finish_doc();
+        ttf += freqs[j];
+      }
+      st.base.doc_freq = (int32_t)(doc_offs[t + 1] - doc_offs[t]);
+      st.base.total_term_freq = ttf;
+      if (st.base.doc_freq > 0) w.finish_term(st);
+      h->terms.push_back(st);
+    }
+    w.close();
+    h->doc = std::move(w.doc_out.buf);
+    h->pos = std::move(w.pos_out.buf);
+    h->reader = std::make_unique<PostingsReader>(h->doc.data(), (int64_t)h->doc.size());
+    h->pos_file = std::make_unique<PosFile>(h->pos.data(), (int64_t)h->pos.size(), h->reader->version);
+    return h.release();
+  } catch (const std::exception& e) { g_err = e.what(); return nullptr; }
+}
+void orc_pos_index_free(orc_pos_index* h) { delete h; }
+int64_t orc_pos_index_sizes(orc_pos_index* h, int64_t* doc_len, int64_t* pos_len) { *doc_len = (int64_t)h->doc.size(); *pos_len = (int64_t)h->pos.size(); return (int64_t)h->terms.size(); }
+// out7: doc_start_fp, skip_offset, total_term_freq, doc_freq, singleton_doc_id, pos_start_fp, last_pos_block_offset
+int orc_pos_term_state(orc_pos_index* h, int32_t term, int64_t* out7) {
+  ORC_TRY
+  const PosTermState& s = h->terms.at((size_t)term);
+  out7[0] = s.base.doc_start_fp; out7[1] = s.base.skip_offset; out7[2] = s.base.total_term_freq; out7[3] = s.base.doc_freq;
+  out7[4] = s.base.singleton_doc_id; out7[5] = s.pos_start_fp; out7[6] = s.last_pos_block_offset;
+  return 0;
+  ORC_CATCH
+}
+// Drive one iterator. targets == null: next() to exhaustion; else advance(target) for each target (targets ascending, each
+// greater than the previous result). For every doc landed on, positions are read when (visit index % read_every == 0):
+// the first min(freq, max_positions) of them (max_positions < 0: all) — unread positions must be skipped lazily by the
+// iterator. Outputs: docs / freqs per visit; positions flattened with npos[visit] each. Returns the visit count.
+int64_t orc_pos_iterate(orc_pos_index* h, int32_t term, const int32_t* targets, int64_t n_targets, int32_t read_every, int32_t max_positions,
+                        int32_t* out_docs, int32_t* out_freqs, int32_t* out_npos, int64_t cap_visits, int32_t* out_positions,
+                        int64_t cap_positions) {
+  ORC_TRY
+  const PosTermState& st = h->terms.at((size_t)term);
+  if (st.base.doc_freq <= 0) return 0;
+  BlockPostingIterator it(h->reader.get(), h->pos_file.get(), st);
+  if (it.doc_id() != -1) throw OracleError(E_ILLEGAL_STATE, "iterator must start unpositioned");
+  int64_t visits = 0, npos_total = 0, ti = 0;
+  while (true) {
+    int32_t d;
+    if (targets) {
+      if (ti >= n_targets) break;
+      d = it.advance(targets[ti++]);
+    } else {
+      d = it.next();
+    }
+    if (d == NO_MORE_DOCS) {
+      if (targets && visits < cap_visits) { out_docs[visits] = d; out_freqs[visits] = 0; out_npos[visits] = 0; visits++; continue; }
+      break;
+    }
+    if (visits >= cap_visits) throw OracleError(E_ILLEGAL_ARGUMENT, "visit capacity exceeded");
+    out_docs[visits] = d;
+    out_freqs[visits] = it.freq();
+    int32_t np = 0;
+    if (read_every > 0 && visits % read_every == 0) {
+      np = max_positions < 0 ? it.freq() : std::min(it.freq(), max_positions);
+      if (npos_total + np > cap_positions) throw OracleError(E_ILLEGAL_ARGUMENT, "position capacity exceeded");
+      for (int32_t i = 0; i < np; i++) out_positions[npos_total++] = it.next_position();
+    }
+    out_npos[visits] = np;
+    visits++;
+  }
+  return visits;
   ORC_CATCH
 }
 

@@ -203,8 +203,9 @@ struct SkipWriter {
   }
   // skip_writer.rs:140-149
   void reset_skip(int64_t doc_fp) { last_doc_fp = doc_fp; initialized = false; }
-  // skip_writer.rs:151-183
-  void init_skip() {
+  virtual ~SkipWriter() {}
+  // skip_writer.rs:151-183 (virtual: positions.hpp adds the position pointers)
+  virtual void init_skip() {
     if (!initialized) {
       if (skip_buffer.empty()) skip_buffer.resize((size_t)number_of_skip_levels);
       else for (auto& b : skip_buffer) b.reset();
@@ -237,8 +238,8 @@ struct SkipWriter {
       child_pointer = new_child_pointer;
     }
   }
-  // skip_writer.rs:261-289 (positions arm never taken for DocsAndFreqs)
-  void write_skip_data_local(int level) {
+  // skip_writer.rs:261-289 (the positions arm lives in positions.hpp's subclass)
+  virtual void write_skip_data_local(int level) {
     int32_t delta = cur_doc - last_skip_doc[(size_t)level];
     skip_buffer[(size_t)level].write_vint(delta);
     last_skip_doc[(size_t)level] = cur_doc;
@@ -390,8 +391,9 @@ struct SkipReader {
   int64_t get_doc_pointer() const { return last_doc_pointer; }  // skip_reader.rs:360-362
   int32_t next_skip_doc() const { return skip_doc[0]; }         // skip_reader.rs:380-382
   int32_t doc() const { return last_doc; }                      // skip_reader.rs:548-550
-  // skip_reader.rs:385-408
-  void seek_child(int level) {
+  virtual ~SkipReader() {}
+  // skip_reader.rs:385-408 (virtual: positions.hpp adds the position pointers)
+  virtual void seek_child(int level) {
     size_t ul = (size_t)level;
     skip_stream[ul].seek(last_child_pointer);
     num_skipped[ul] = num_skipped[ul + 1] - skip_interval[ul + 1];
@@ -400,13 +402,13 @@ struct SkipReader {
     doc_pointer[ul] = last_doc_pointer;
   }
   // skip_reader.rs:410-429
-  void set_last_skip_data(int level) {
+  virtual void set_last_skip_data(int level) {
     last_doc = skip_doc[(size_t)level];
     last_child_pointer = child_pointer[(size_t)level];
     last_doc_pointer = doc_pointer[(size_t)level];
   }
   // skip_reader.rs:431-453
-  int32_t read_skip_data(int level) {
+  virtual int32_t read_skip_data(int level) {
     int32_t delta = skip_stream[(size_t)level].read_vint();
     int64_t pointer = skip_stream[(size_t)level].read_vlong();
     doc_pointer[(size_t)level] += pointer;

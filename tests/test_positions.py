@@ -1,0 +1,112 @@
+"""Positions side of the Lucene50 postings (".pos" file, position pointers in the ".doc" skip entries, BlockPostingIterator),
+as restated in oracle/positions.hpp — groundwork for SURVEY §8(f)3 (positions + PhraseScorer); no product code reads
+positions yet. The reference holds no test for any of it (parity unpinned), so the writer/reader pair is checked against
+brute force over the input postings: every doc, freq and position, through next() and advance(), with positions read
+for every doc, for some docs (the iterator must lazily skip the unread ones, across whole blocks) or partially."""
+import numpy as np
+import pytest
+
+
+def _make_postings(rng, max_doc, dfs, max_freq):
+    postings = []
+    for df in dfs:
+        docs = np.sort(rng.choice(max_doc, size=df, replace=False)).tolist()
+        plist = []
+        for d in docs:
+            f = int(rng.integers(1, max_freq + 1)) if rng.random() < 0.7 else 1
+            ps = np.sort(rng.choice(5000, size=f, replace=False)).tolist()
+            plist.append((d, ps))
+        postings.append(plist)
+    return postings
+
+
+@pytest.fixture(scope="module")
+def index(oracle):
+    rng = np.random.default_rng(12)
+    dfs = [1, 2, 127, 128, 129, 255, 256, 300, 1024, 1025, 1200, 9000, 70_000]   # 70 000 docs -> 3 skip levels
+    postings = _make_postings(rng, 200_000, dfs[:-1], 40) + _make_postings(rng, 200_000, dfs[-1:], 3)
+    # a term whose total_term_freq is exactly 128 and one with exactly 256 (last_pos_block_fp corner cases)
+    postings.append([(10 + i, [i, i + 7]) for i in range(64)])
+    postings.append([(5 + 3 * i, [1, 2, 3, 4]) for i in range(64)])
+    return oracle.PositionsIndex(200_000, postings), postings
+
+
+def test_term_states(index):
+    ix, postings = index
+    for t, plist in enumerate(postings):
+        st = ix.term_state(t)
+        ttf = sum(len(ps) for _, ps in plist)
+        assert st["doc_freq"] == len(plist) and st["total_term_freq"] == ttf
+        assert (st["singleton_doc_id"] == plist[0][0]) if len(plist) == 1 else (st["singleton_doc_id"] == -1)
+        assert (st["skip_offset"] > 0) == (len(plist) > 128)
+        assert (st["last_pos_block_offset"] >= 0) == (ttf > 128)
+    assert ix.sizes()[1] > 100_000
+
+
+@pytest.mark.parametrize("version", [1, 0])
+def test_next_reads_everything(oracle, index, version):
+    ix, postings = index
+    if version == 0:          # legacy PackedInts blocks
+        postings = postings[:9]
+        ix = oracle.PositionsIndex(200_000, postings, version=0)
+    for t, plist in enumerate(postings):
+        got = ix.iterate(t)
+        assert [(d, f) for d, f, _ in got] == [(d, len(ps)) for d, ps in plist], t
+        assert [p for _, _, p in got] == [ps for _, ps in plist], t
+
+
+@pytest.mark.parametrize("read_every,max_positions", [(2, -1), (7, -1), (1, 1), (3, 2), (50, -1), (0, 0)])
+def test_lazy_position_skipping(index, read_every, max_positions):
+    """Positions are pulled only for some docs / only partly: pos_pending_count grows and skip_positions() must jump inside the
+    buffered block, over whole blocks (ForUtil::skip_block) and into the vint tail."""
+    ix, postings = index
+    for t, plist in enumerate(postings):
+        got = ix.iterate(t, read_every=read_every, max_positions=max_positions)
+        assert [(d, f) for d, f, _ in got] == [(d, len(ps)) for d, ps in plist]
+        for i, ((d, ps), (_, _, rp)) in enumerate(zip(plist, got)):
+            if read_every > 0 and i % read_every == 0:
+                want = ps if max_positions < 0 else ps[:max_positions]
+                assert rp == want, (t, i, d)
+            else:
+                assert rp == []
+
+
+def test_advance_lands_on_the_right_doc_with_the_right_positions(index):
+    ix, postings = index
+    rng = np.random.default_rng(3)
+    for t, plist in enumerate(postings):
+        docs = np.array([d for d, _ in plist])
+        by_doc = dict(plist)
+        for step in (1, 30, 129, 5000, 60_000):
+            targets, cur = [], -1
+            while True:
+                tgt = cur + 1 + int(rng.integers(0, step))
+                j = int(np.searchsorted(docs, tgt))
+                targets.append(tgt)
+                if j >= len(docs):
+                    break
+                cur = int(docs[j])
+            for read_every in (1, 3):
+                got = ix.iterate(t, targets=targets, read_every=read_every)
+                assert len(got) == len(targets)
+                for i, (tgt, (d, f, rp)) in enumerate(zip(targets, got)):
+                    j = int(np.searchsorted(docs, tgt))
+                    if j >= len(docs):
+                        assert d == oracle_no_more_docs()
+                    else:
+                        assert d == docs[j] and f == len(by_doc[d]), (t, step, tgt)
+                        if i % read_every == 0:
+                            assert rp == by_doc[d], (t, step, tgt)
+
+
+def oracle_no_more_docs():
+    return 2**31 - 1
+
+
+def test_rejects_bad_input(oracle):
+    with pytest.raises(oracle.OracleError):
+        oracle.PositionsIndex(100, [[(5, [1]), (5, [2])]])            # docs out of order
+    with pytest.raises(oracle.OracleError):
+        oracle.PositionsIndex(100, [[(5, [-1])]])                     # position < 0
+    ix = oracle.PositionsIndex(100, [[(5, [3, 9])], []])
+    assert ix.iterate(0) == [(5, 2, [3, 9])] and ix.iterate(1) == []
