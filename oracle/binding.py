@@ -29,7 +29,7 @@ def build(force=False):
     if force or not os.path.exists(_LIB_PATH) or any(
             os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
             for f in ("oracle_capi.cpp", "store.hpp", "packed.hpp", "postings.hpp", "search.hpp", "norms.hpp", "fst.hpp",
-                      "blocktree.hpp", "field_infos.hpp", "segment_infos.hpp", "positions.hpp")):
+                      "blocktree.hpp", "field_infos.hpp", "segment_infos.hpp", "positions.hpp", "phrase.hpp")):
         subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
@@ -125,6 +125,9 @@ def _declare(L):
         "orc_pos_index_sizes": (C.c_int64, [vp, i64p, i64p]),
         "orc_pos_term_state": (C.c_int, [vp, C.c_int32, i64p]),
         "orc_pos_iterate": (C.c_int64, [vp, C.c_int32, i32p, C.c_int64, C.c_int32, C.c_int32, i32p, i32p, i32p, C.c_int64, i32p, C.c_int64]),
+        "orc_pos_phrase_freqs": (C.c_int64, [vp, i32p, i32p, C.c_int, i32p, i32p, C.c_int64]),
+        "orc_pos_phrase_search": (C.c_int, [vp, i32p, i32p, C.c_int, u8p, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, i32p, f32p,
+                                            i32p, i64p]),
         "orc_segment_info_write": (C.c_int, [u8p, u8p, i32p, C.c_int32, C.c_int, u8p, i64p]),
         "orc_segment_info_read": (C.c_int, [u8p, C.c_int64, u8p, i32p, i32p, u8p]),
         "orc_segments_file_write": (C.c_int, [C.c_int64, u8p, C.c_int64, C.c_int32, C.c_int32, u8p, u8p, i64p, i32p, u8p, i64p]),
@@ -859,6 +862,26 @@ class PositionsIndex:
             out.append((int(docs[i]), int(freqs[i]), pos[at:at + npos[i]].tolist()))
             at += int(npos[i])
         return out
+
+    def phrase_freqs(self, term_ids, offsets=None, cap=1 << 20):
+        """ExactPhraseScorer over the phrase term_ids (positions 0, 1, 2, ... unless `offsets`): [(doc, phrase freq)]."""
+        t = np.ascontiguousarray(term_ids, dtype=np.int32)
+        o = np.ascontiguousarray(range(t.size) if offsets is None else offsets, dtype=np.int32)
+        docs, freqs = np.zeros(cap, np.int32), np.zeros(cap, np.int32)
+        n = _check(lib().orc_pos_phrase_freqs(self._h, _p(t, C.c_int32), _p(o, C.c_int32), t.size, _p(docs, C.c_int32), _p(freqs, C.c_int32), cap))
+        return list(zip(docs[:n].tolist(), freqs[:n].tolist()))
+
+    def phrase_search(self, term_ids, k, norms, max_doc, doc_count, sum_total_term_freq, offsets=None, tie_mode=TIE_CANONICAL):
+        """IndexSearcher::search(PhraseQuery(slop 0), TopDocsCollector(k)) -> (docs, scores, total_hits)."""
+        t = np.ascontiguousarray(term_ids, dtype=np.int32)
+        o = np.ascontiguousarray(range(t.size) if offsets is None else offsets, dtype=np.int32)
+        nm = None if norms is None else np.ascontiguousarray(norms, dtype=np.uint8)
+        docs, scores = np.zeros(max(k, 1), np.int32), np.zeros(max(k, 1), np.float32)
+        n, total = C.c_int32(), C.c_int64()
+        _check(lib().orc_pos_phrase_search(self._h, _p(t, C.c_int32), _p(o, C.c_int32), t.size, _p(nm, C.c_uint8), int(max_doc), int(doc_count),
+                                           int(sum_total_term_freq), k, tie_mode, _p(docs, C.c_int32), _p(scores, C.c_float), C.byref(n),
+                                           C.byref(total)))
+        return docs[:n.value].copy(), scores[:n.value].copy(), total.value
 
     def close(self):
         if self._h:

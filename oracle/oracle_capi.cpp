@@ -16,6 +16,7 @@
 #include "field_infos.hpp"
 #include "segment_infos.hpp"
 #include "positions.hpp"
+#include "phrase.hpp"
 #include "store.hpp"
 
 using namespace orc;
@@ -851,6 +852,70 @@ int64_t orc_pos_iterate(orc_pos_index* h, int32_t term, const int32_t* targets, 
     visits++;
   }
   return visits;
+  ORC_CATCH
+}
+
+// ---- exact PhraseQuery (oracle/phrase.hpp) ---------------------------------------------------------------------------
+// PhraseWeight::create_scorer for term_ids at phrase positions `offsets` (PhraseQuery::build: 0, 1, 2, ...): null when a
+// term is absent. The scorer owns its iterators; `w` must outlive it.
+static std::unique_ptr<ExactPhraseScorer> make_phrase_scorer(orc_pos_index* h, const int32_t* term_ids, const int32_t* offsets, int n,
+                                                             const BM25Weight* w, const uint8_t* norms, bool needs_scores) {
+  if (n < 2) throw OracleError(E_ILLEGAL_ARGUMENT, "PhraseWeight does not support less than 2 terms");
+  if (offsets[0] != 0) throw OracleError(E_ILLEGAL_ARGUMENT, "PhraseWeight requires that the first position is 0");
+  std::vector<int> order((size_t)n);
+  for (int i = 0; i < n; i++) order[(size_t)i] = i;
+  // postings_freqs.sort(): by position, then (one term each) by term bytes — stood in for by the term id
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+    return offsets[a] != offsets[b] ? offsets[a] < offsets[b] : term_ids[a] < term_ids[b];
+  });
+  std::vector<std::unique_ptr<BlockPostingIterator>> its;
+  std::vector<int32_t> offs;
+  for (int i : order) {
+    const PosTermState& st = h->terms.at((size_t)term_ids[i]);
+    if (st.base.doc_freq <= 0) return nullptr;
+    its.emplace_back(new BlockPostingIterator(h->reader.get(), h->pos_file.get(), st));
+    offs.push_back(offsets[i]);
+  }
+  return std::make_unique<ExactPhraseScorer>(std::move(its), offs, w, norms, needs_scores);
+}
+// every matching doc with its phrase frequency (scorer.next() to exhaustion, needs_scores = true)
+int64_t orc_pos_phrase_freqs(orc_pos_index* h, const int32_t* term_ids, const int32_t* offsets, int n, int32_t* out_docs, int32_t* out_freqs,
+                             int64_t cap) {
+  ORC_TRY
+  BM25Weight w{};
+  auto sc = make_phrase_scorer(h, term_ids, offsets, n, &w, nullptr, true);
+  if (!sc) return 0;
+  int64_t m = 0;
+  for (int32_t d = sc->next(); d != NO_MORE_DOCS; d = sc->next()) {
+    if (m >= cap) throw OracleError(E_ILLEGAL_ARGUMENT, "capacity exceeded");
+    out_docs[m] = d;
+    out_freqs[m++] = sc->freq();
+  }
+  return m;
+  ORC_CATCH
+}
+// IndexSearcher::search(PhraseQuery, TopDocsCollector(k)) over this one segment: BM25 with idf summed over the terms
+int orc_pos_phrase_search(orc_pos_index* h, const int32_t* term_ids, const int32_t* offsets, int n, const uint8_t* norms, int64_t max_doc,
+                          int64_t doc_count, int64_t sum_total_term_freq, int k, int tie_mode, int32_t* out_docs, float* out_scores,
+                          int32_t* out_n, int64_t* out_total) {
+  ORC_TRY
+  CollectionStatistics cs;
+  cs.max_doc = max_doc; cs.doc_count = doc_count; cs.sum_total_term_freq = sum_total_term_freq;
+  std::vector<TermStatistics> ts((size_t)n);
+  for (int i = 0; i < n; i++) {
+    const PosTermState& st = h->terms.at((size_t)term_ids[i]);
+    ts[(size_t)i].doc_freq = st.base.doc_freq;
+    ts[(size_t)i].total_term_freq = st.base.total_term_freq;
+  }
+  BM25Weight w = bm25_compute_weight(1.2f, 0.75f, cs, ts.data(), n, 1.0f);
+  TopDocsCollector collector((size_t)k, tie_mode);
+  auto sc = make_phrase_scorer(h, term_ids, offsets, n, &w, norms, true);
+  if (sc) bulk_score(sc.get(), &collector, nullptr, 0, NO_MORE_DOCS, 0);
+  std::vector<ScoreDoc> r = collector.top_docs();
+  *out_n = (int32_t)r.size();
+  *out_total = (int64_t)collector.total_hits;
+  for (size_t i = 0; i < r.size(); i++) { out_docs[i] = r[i].doc; out_scores[i] = r[i].score; }
+  return 0;
   ORC_CATCH
 }
 

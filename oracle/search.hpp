@@ -723,7 +723,7 @@ struct IndexSearcher {
     return ScorerBox(new TermScorer(seg->reader.get(), seg->terms[term_id], w, seg->norms));
   }
   // boolean_query.rs:195-279 restricted to trees of TermQuery clauses: MUST only, SHOULD only, each optionally
-  // with MUST_NOT clauses (MUST + SHOULD -> ReqOptScorer is not restated: its score() carries sequential state)
+  // with MUST_NOT clauses; MUST + SHOULD -> ReqOptScorer is added by create_scorer below
   ScorerBox positive_scorer(const Segment* seg, const Query& q, const std::vector<BM25Weight>& weights) const {
     if (q.op == OP_TERM) return term_scorer(seg, q.term_ids[0], &weights[0]);
     std::vector<ScorerBox> scorers;

@@ -110,3 +110,81 @@ def test_rejects_bad_input(oracle):
         oracle.PositionsIndex(100, [[(5, [-1])]])                     # position < 0
     ix = oracle.PositionsIndex(100, [[(5, [3, 9])], []])
     assert ix.iterate(0) == [(5, 2, [3, 9])] and ix.iterate(1) == []
+
+
+# ---- exact PhraseQuery (oracle/phrase.hpp) ------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def corpus(oracle):
+    """Random token streams over a small vocabulary (so that phrases really occur and terms repeat inside a doc)."""
+    rng = np.random.default_rng(21)
+    max_doc, vocab = 6000, 12
+    docs = [rng.integers(0, vocab, size=int(rng.integers(1, 60))).tolist() if rng.random() < 0.9 else [] for _ in range(max_doc)]
+    postings = [[] for _ in range(vocab + 1)]            # the last term never occurs
+    for d, toks in enumerate(docs):
+        where = {}
+        for p, t in enumerate(toks):
+            where.setdefault(t, []).append(p)
+        for t, ps in where.items():
+            postings[t].append((d, ps))
+    return oracle.PositionsIndex(max_doc, postings), docs, postings
+
+
+def _brute_phrase(docs, terms, offsets):
+    out = []
+    for d, toks in enumerate(docs):
+        n = 0
+        for start in range(-max(offsets), len(toks)):
+            if all(0 <= start + o < len(toks) and toks[start + o] == t for t, o in zip(terms, offsets)):
+                n += 1
+        if n:
+            out.append((d, n))
+    return out
+
+
+def test_exact_phrase_freq_matches_brute_force(corpus):
+    ix, docs, postings = corpus
+    rng = np.random.default_rng(5)
+    phrases = [[0, 1], [1, 0], [3, 3], [2, 2, 2], [4, 5, 6], [7, 7, 8, 7], [0, 1, 2, 3], [9, 10, 11, 0, 1], [5, 12], [12, 5]]
+    phrases += [rng.integers(0, 12, size=int(rng.integers(2, 5))).tolist() for _ in range(40)]
+    for terms in phrases:
+        offsets = list(range(len(terms)))
+        assert ix.phrase_freqs(terms) == _brute_phrase(docs, terms, offsets), terms
+    # phrases with position gaps ("a ? b"), as PhraseQuery::new(terms, positions) allows
+    for terms, offsets in (([0, 1], [0, 2]), ([3, 4, 5], [0, 1, 3]), ([2, 2], [0, 5])):
+        assert ix.phrase_freqs(terms, offsets) == _brute_phrase(docs, terms, offsets), (terms, offsets)
+
+
+def test_exact_phrase_scores_and_topk(oracle, corpus):
+    """score = BM25(phrase freq) with idf summed over the phrase's terms (phrase_query.rs:136-186, bm25_similarity.rs:99-114,
+    203-212): recomputed here in numpy float32 in the reference's evaluation order."""
+    ix, docs, postings = corpus
+    max_doc = len(docs)
+    lens = np.array([max(len(t), 1) for t in docs])
+    L = oracle.lib()
+    norms = np.array([L.orc_bm25_encode_norm(1.0, int(l)) for l in lens], dtype=np.uint8)
+    sum_ttf = int(sum(len(t) for t in docs))
+    doc_count = int(sum(1 for t in docs if t))
+    k1, b = np.float32(1.2), np.float32(0.75)
+    avgdl = np.float32(np.float64(sum_ttf) / np.float64(doc_count))
+    table = np.array([L.orc_norm_table(i) for i in range(256)], dtype=np.float32)
+    cache = (k1 * ((np.float32(1) - b) + b * (table / avgdl))).astype(np.float32)
+    for terms in ([0, 1], [4, 5, 6], [2, 2, 2], [7, 8]):
+        dfs = [len(postings[t]) for t in terms]
+        idf = np.float32(0)
+        for df in dfs:
+            idf = np.float32(idf + np.float32(np.log(1.0 + (np.float64(doc_count) - df + 0.5) / (df + 0.5))))
+        want = []
+        for d, f in _brute_phrase(docs, terms, list(range(len(terms)))):
+            freq = np.float32(f)
+            score = np.float32(np.float32(np.float32(idf * (k1 + np.float32(1))) * freq) / np.float32(freq + cache[norms[d]]))
+            want.append((float(score), d))
+        want.sort(key=lambda x: (-x[0], x[1]))
+        gd, gs, total = ix.phrase_search(terms, 10, norms, max_doc, doc_count, sum_ttf)
+        assert total == len(want)
+        assert gd.tolist() == [d for _, d in want[:10]]
+        assert gs.tolist() == [s for s, _ in want[:10]]
+    # a phrase with an absent term matches nothing (PhraseWeight::create_scorer -> None)
+    gd, gs, total = ix.phrase_search([0, 12], 10, norms, max_doc, doc_count, sum_ttf)
+    assert total == 0 and len(gd) == 0
+    with pytest.raises(oracle.OracleError):
+        ix.phrase_freqs([3])                       # fewer than 2 terms
