@@ -275,10 +275,20 @@ void rgpu_terms_close(rgpu_terms* terms);
 int32_t rgpu_terms_field_stats(const rgpu_terms* terms, int32_t field_number, rgpu_field_stats* out);
 /* seek_exact + term_state for n_terms terms of one field; term i = term_bytes[term_offsets[i] .. term_offsets[i+1]).
  * found_out[i] = 1/0; an absent term yields the "absent" state (doc_freq 0, skip_offset -1, singleton_doc_id -1),
- * which rgpu_search_batch treats as TermWeight::create_scorer -> None. found_out may be NULL. Only the docs+freqs
- * pointers are returned: positions / payloads pointers are decoded and dropped (positions are not served). */
+ * which rgpu_search_batch treats as TermWeight::create_scorer -> None. found_out may be NULL. */
 int32_t rgpu_terms_lookup(const rgpu_terms* terms, int32_t field_number, const uint8_t* term_bytes, const int64_t* term_offsets,
                           int32_t n_terms, rgpu_term_state* states_out, uint8_t* found_out);
+/* The rest of BlockTermState for a field indexed with positions (blocktree/mod.rs:33-59; lucene50_decode_term): where the
+ * term's positions start in ".pos", its payloads / offsets in ".pay", and the offset of its last (vint) position block.
+ * Same lookup as rgpu_terms_lookup plus positions_out[i] (zeros / -1 for an absent term or a field without positions).
+ * No search entry point reads positions yet; this is the term-resolution half of that row. */
+typedef struct rgpu_term_positions {
+  int64_t pos_start_fp;
+  int64_t pay_start_fp;           /* 0 unless the field stores payloads or offsets */
+  int64_t last_pos_block_offset;  /* -1 unless total_term_freq > 128 */
+} rgpu_term_positions;
+int32_t rgpu_terms_lookup_positions(const rgpu_terms* terms, int32_t field_number, const uint8_t* term_bytes, const int64_t* term_offsets,
+                                    int32_t n_terms, rgpu_term_state* states_out, rgpu_term_positions* positions_out, uint8_t* found_out);
 
 /* ---- measurement ------------------------------------------------------------------------------------------ */
 typedef struct rgpu_kernel_stat {

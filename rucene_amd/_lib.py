@@ -23,6 +23,7 @@ FIELD_INFO_DTYPE = np.dtype([("number", "<i4"), ("index_options", "<i4"), ("has_
 FIELD_STATS_DTYPE = np.dtype([("num_terms", "<i8"), ("sum_total_term_freq", "<i8"), ("sum_doc_freq", "<i8"), ("doc_count", "<i4"),
                               ("longs_size", "<i4")], align=True)
 INDEX_OPTIONS_DOCS, INDEX_OPTIONS_DOCS_AND_FREQS, INDEX_OPTIONS_POSITIONS, INDEX_OPTIONS_OFFSETS = 1, 2, 3, 4
+TERM_POSITIONS_DTYPE = np.dtype([("pos_start_fp", "<i8"), ("pay_start_fp", "<i8"), ("last_pos_block_offset", "<i8")], align=True)
 SEGMENT_INFO_DTYPE = np.dtype([("max_doc", "<i4"), ("is_compound_file", "<i4"), ("version", "<i4", (3,)), ("n_files", "<i4"),
                                ("n_sort_fields", "<i4"), ("reserved", "<i4"), ("id", "u1", (16,))], align=True)
 COMMIT_SEGMENT_DTYPE = np.dtype([("name", "S48"), ("codec", "S16"), ("id", "u1", (16,)), ("del_gen", "<i8"), ("field_infos_gen", "<i8"),
@@ -41,7 +42,7 @@ EXPORTS = [
     "rgpu_decode_terms_device", "rgpu_advance_batch", "rgpu_sim_table_upload", "rgpu_search_batch",
     "rgpu_search_batch_device", "rgpu_merge_topk_device", "rgpu_bm25_compute_weight", "rgpu_bm25_encode_norm",
     "rgpu_norms_from_lucene53", "rgpu_live_docs_from_lucene50", "rgpu_field_infos_from_lucene60", "rgpu_segment_info_from_lucene62", "rgpu_commit_from_segments_file", "rgpu_terms_open", "rgpu_terms_close", "rgpu_terms_field_stats",
-    "rgpu_terms_lookup", "rgpu_kernel_stats", "rgpu_kernel_stats_reset", "rgpu_synchronize",
+    "rgpu_terms_lookup", "rgpu_terms_lookup_positions", "rgpu_kernel_stats", "rgpu_kernel_stats_reset", "rgpu_synchronize",
 ]
 
 
@@ -124,6 +125,7 @@ def lib():
         "rgpu_terms_close": (None, [vp]),
         "rgpu_terms_field_stats": (i32, [vp, i32, vp]),
         "rgpu_terms_lookup": (i32, [vp, i32, vp, vp, i32, vp, vp]),
+        "rgpu_terms_lookup_positions": (i32, [vp, i32, vp, vp, i32, vp, vp, vp]),
         "rgpu_kernel_stats": (i32, [vp, C.POINTER(_KernelStat), i32]),
         "rgpu_kernel_stats_reset": (None, [vp]),
         "rgpu_synchronize": (i32, [vp]),
@@ -239,14 +241,20 @@ class TermDictionary:
         _check(rc)
         return {k: int(out[0][k]) for k in FIELD_STATS_DTYPE.names}
 
-    def lookup(self, field_number, terms):
-        """seek_exact + term_state for each of `terms` (bytes) -> (TERM_STATE_DTYPE[n], found bool[n])."""
+    def lookup(self, field_number, terms, with_positions=False):
+        """seek_exact + term_state for each of `terms` (bytes) -> (TERM_STATE_DTYPE[n], found bool[n]); with_positions adds
+        the TERM_POSITIONS_DTYPE[n] pointers of a positions field in between."""
         terms = [bytes(t) for t in terms]
         offs = np.zeros(len(terms) + 1, dtype=np.int64)
         np.cumsum([len(t) for t in terms], out=offs[1:])
         flat = np.frombuffer(b"".join(terms) or b"\0", dtype=np.uint8)
         states = np.zeros(len(terms), dtype=TERM_STATE_DTYPE)
         found = np.zeros(max(len(terms), 1), dtype=np.uint8)
+        if with_positions:
+            pos = np.zeros(max(len(terms), 1), dtype=TERM_POSITIONS_DTYPE)
+            _check(lib().rgpu_terms_lookup_positions(self._h, int(field_number), flat.ctypes.data, offs.ctypes.data, len(terms),
+                                                     states.ctypes.data if len(terms) else None, pos.ctypes.data, found.ctypes.data))
+            return states, pos[:len(terms)], found[:len(terms)].astype(bool)
         _check(lib().rgpu_terms_lookup(self._h, int(field_number), flat.ctypes.data, offs.ctypes.data, len(terms),
                                        states.ctypes.data if len(terms) else None, found.ctypes.data))
         return states, found[:len(terms)].astype(bool)

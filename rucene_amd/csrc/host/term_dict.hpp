@@ -57,6 +57,12 @@ struct TermState {          // == rgpu_term_state
   int32_t singleton_doc_id;
 };
 
+struct TermPositions {      // == rgpu_term_positions: the pointers a positions field adds to BlockTermState
+  int64_t pos_start_fp;           // where the term's positions start in .pos (0 for fields without positions)
+  int64_t pay_start_fp;           // ... its payloads / offsets in .pay (0 unless the field stores them)
+  int64_t last_pos_block_offset;  // -1 unless total_term_freq > 128
+};
+
 struct TermFieldStats {     // == rgpu_field_stats; Terms::{size, sum_total_term_freq, sum_doc_freq, doc_count}
   int64_t num_terms;
   int64_t sum_total_term_freq;  // -1 for IndexOptions::Docs
@@ -164,17 +170,22 @@ class TermDictionary {
   }
 
   // seek_exact + term_state. Absent term (or field): returns false and *out is the "absent" state (doc_freq 0).
-  bool lookup(int32_t field_number, const uint8_t* term, size_t len, TermState* out) const {
+  bool lookup(int32_t field_number, const uint8_t* term, size_t len, TermState* out, TermPositions* pos_out = nullptr) const {
     const Field* f = find_field(field_number);
+    if (pos_out) *pos_out = TermPositions{0, 0, -1};
     if (!f || f->slots.empty()) { *out = TermState{0, -1, 0, 0, -1}; return false; }
-    return probe(*f, hash_bytes(term, len), term, len, out);
+    const int64_t e = probe(*f, hash_bytes(term, len), term, len, out);
+    if (e >= 0 && pos_out && !f->positions.empty()) *pos_out = f->positions[(size_t)e];
+    return e >= 0;
   }
 
   // n lookups in one field; term i = bytes[offsets[i], offsets[i+1]). A resident dictionary is bound by cache misses
   // (slot -> entry -> term bytes), so the batch is software-pipelined: hash a window ahead and prefetch its slots while
   // the current window is probed.
-  void lookup_batch(int32_t field_number, const uint8_t* bytes, const int64_t* offsets, int64_t n, TermState* out, uint8_t* found) const {
+  void lookup_batch(int32_t field_number, const uint8_t* bytes, const int64_t* offsets, int64_t n, TermState* out, uint8_t* found,
+                    TermPositions* pos_out = nullptr) const {
     const Field* f = find_field(field_number);
+    if (pos_out) for (int64_t i = 0; i < n; ++i) pos_out[i] = TermPositions{0, 0, -1};
     if (!f || f->slots.empty()) {
       for (int64_t i = 0; i < n; ++i) { out[i] = TermState{0, -1, 0, 0, -1}; if (found) found[i] = 0; }
       return;
@@ -205,15 +216,17 @@ class TermDictionary {
       stage_b(base + W, h[(w + 1) % 3]);
       for (int64_t j = 0; j < count(base); ++j) {
         const int64_t i = base + j;
-        const bool ok = probe(*f, h[w][j], bytes + offsets[i], (size_t)(offsets[i + 1] - offsets[i]), &out[i]);
-        if (found) found[i] = ok ? 1 : 0;
+        const int64_t e = probe(*f, h[w][j], bytes + offsets[i], (size_t)(offsets[i + 1] - offsets[i]), &out[i]);
+        if (found) found[i] = e >= 0 ? 1 : 0;
+        if (e >= 0 && pos_out && !f->positions.empty()) pos_out[i] = f->positions[(size_t)e];
       }
     }
   }
 
   size_t memory_bytes() const {
     size_t n = 0;
-    for (const Field& f : fields_) n += f.pool.size() + f.entries.size() * sizeof(Entry) + f.slots.size() * sizeof(Slot);
+    for (const Field& f : fields_)
+      n += f.pool.size() + f.entries.size() * sizeof(Entry) + f.positions.size() * sizeof(TermPositions) + f.slots.size() * sizeof(Slot);
     return n;
   }
 
@@ -225,19 +238,21 @@ class TermDictionary {
     TermFieldStats stats{};
     std::vector<uint8_t> pool;
     std::vector<Entry> entries;
+    std::vector<TermPositions> positions;  // parallel to `entries`; only for fields indexed with positions
     std::vector<Slot> slots;
   };
   std::vector<Field> fields_;
 
-  static bool probe(const Field& f, uint64_t h, const uint8_t* term, size_t len, TermState* out) {
+  // -> index of the term's entry, or -1 (then *out is the "absent" state)
+  static int64_t probe(const Field& f, uint64_t h, const uint8_t* term, size_t len, TermState* out) {
     const size_t mask = f.slots.size() - 1;
     const uint32_t tag = (uint32_t)(h >> 32) | 1u;
     for (size_t i = (size_t)h & mask;; i = (i + 1) & mask) {
       const Slot& s = f.slots[i];
-      if (s.tag == 0) { *out = TermState{0, -1, 0, 0, -1}; return false; }
+      if (s.tag == 0) { *out = TermState{0, -1, 0, 0, -1}; return -1; }
       if (s.tag == tag) {
         const Entry& e = f.entries[s.entry];
-        if (e.len == len && std::memcmp(f.pool.data() + e.offset, term, len) == 0) { *out = e.state; return true; }
+        if (e.len == len && std::memcmp(f.pool.data() + e.offset, term, len) == 0) { *out = e.state; return (int64_t)s.entry; }
       }
     }
   }
@@ -312,6 +327,7 @@ class TermDictionary {
         const uint64_t fp_end = c.pos;
 
         int64_t doc_fp = 0;
+        uint64_t pos_fp = 0, pay_fp = 0;
         bool first_term = true;
         for (uint32_t e = 0; e < ent_count; ++e) {
           const uint32_t scode = sfx.vint();
@@ -339,14 +355,19 @@ class TermDictionary {
           uint64_t longs[3] = {0, 0, 0};
           for (int k = 0; k < longs_size; ++k) longs[k] = vlong(meta);
           const uint64_t fp = (first_term ? 0ull : (uint64_t)doc_fp) + longs[0];
-          if (ttf_extra >= kMax || longs[0] >= kMax || fp >= kMax) { *why = "term statistics / file pointer out of range in a term block"; return ERR_CORRUPT; }
+          if (ttf_extra >= kMax || longs[0] >= kMax || longs[1] >= kMax || longs[2] >= kMax || fp >= kMax) { *why = "term statistics / file pointer out of range in a term block"; return ERR_CORRUPT; }
           st.total_term_freq = has_freqs ? (int64_t)((uint64_t)(uint32_t)st.doc_freq + ttf_extra) : -1;
           doc_fp = (int64_t)fp;
+          if (has_pos) {  // lucene50_decode_term: longs[1] -> pos_start_fp, longs[2] -> pay_start_fp (payloads / offsets only)
+            pos_fp = (first_term ? 0ull : pos_fp) + longs[1];
+            pay_fp = has_pay ? (first_term ? 0ull : pay_fp) + longs[2] : 0ull;
+            if (pos_fp >= kMax || pay_fp >= kMax) { *why = "position file pointer out of range in a term block"; return ERR_CORRUPT; }
+          }
           first_term = false;
           st.doc_start_fp = doc_fp;
           st.singleton_doc_id = st.doc_freq == 1 ? (int32_t)meta.vint() : -1;
-          if (has_pos && st.total_term_freq > 128) vlong(meta);  // last_pos_block_offset: positions are not served
-          (void)has_pay;
+          const uint64_t last_pos_block = (has_pos && st.total_term_freq > 128) ? vlong(meta) : 0ull;
+          if (last_pos_block >= kMax) { *why = "last position block offset out of range in a term block"; return ERR_CORRUPT; }
           st.skip_offset = st.doc_freq > 128 ? (int64_t)vlong(meta) : -1;
           if (!stats.ok || !meta.ok) { *why = "truncated stats/metadata blob in a term block"; return ERR_EOF; }
           if (st.doc_freq <= 0 || (has_freqs && st.total_term_freq < st.doc_freq)) { *why = "invalid term statistics in a term block"; return ERR_CORRUPT; }
@@ -356,6 +377,7 @@ class TermDictionary {
           f->pool.insert(f->pool.end(), prefix.begin(), prefix.end());
           f->pool.insert(f->pool.end(), sbytes, sbytes + slen);
           f->entries.push_back(ent);
+          if (has_pos) f->positions.push_back(TermPositions{(int64_t)pos_fp, (int64_t)pay_fp, st.total_term_freq > 128 ? (int64_t)last_pos_block : -1});
         }
         if (sfx.pos != sfx.len || stats.pos != stats.len || meta.pos != meta.len) { *why = "term block blobs longer than their entries"; return ERR_CORRUPT; }
         if (is_last_in_floor) break;

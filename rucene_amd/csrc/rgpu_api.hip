@@ -1222,17 +1222,31 @@ extern "C" int32_t rgpu_terms_field_stats(const rgpu_terms* terms, int32_t field
   return RGPU_OK;
 }
 
-extern "C" int32_t rgpu_terms_lookup(const rgpu_terms* terms, int32_t field_number, const uint8_t* term_bytes, const int64_t* term_offsets,
-                                     int32_t n_terms, rgpu_term_state* states_out, uint8_t* found_out) {
+static int32_t terms_lookup_impl(const rgpu_terms* terms, int32_t field_number, const uint8_t* term_bytes, const int64_t* term_offsets,
+                                 int32_t n_terms, rgpu_term_state* states_out, rgpu_term_positions* positions_out, uint8_t* found_out) {
   if (!terms || n_terms < 0 || (n_terms > 0 && (!term_offsets || !states_out))) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "null argument");
   for (int32_t i = 0; i < n_terms; ++i)
     if (term_offsets[i] < 0 || term_offsets[i + 1] < term_offsets[i]) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "term_offsets must be non-decreasing");
   static const uint8_t kEmpty = 0;
   if (n_terms > 0 && term_offsets[n_terms] > term_offsets[0] && !term_bytes) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "term_bytes is null");
   static_assert(sizeof(rucene::TermState) == sizeof(rgpu_term_state), "layout");
+  static_assert(sizeof(rucene::TermPositions) == sizeof(rgpu_term_positions), "layout");
   terms->dict->lookup_batch(field_number, term_bytes ? term_bytes : &kEmpty, term_offsets, n_terms,
-                            reinterpret_cast<rucene::TermState*>(states_out), found_out);
+                            reinterpret_cast<rucene::TermState*>(states_out), found_out,
+                            reinterpret_cast<rucene::TermPositions*>(positions_out));
   return RGPU_OK;
+}
+
+extern "C" int32_t rgpu_terms_lookup(const rgpu_terms* terms, int32_t field_number, const uint8_t* term_bytes, const int64_t* term_offsets,
+                                     int32_t n_terms, rgpu_term_state* states_out, uint8_t* found_out) {
+  return terms_lookup_impl(terms, field_number, term_bytes, term_offsets, n_terms, states_out, nullptr, found_out);
+}
+
+extern "C" int32_t rgpu_terms_lookup_positions(const rgpu_terms* terms, int32_t field_number, const uint8_t* term_bytes,
+                                               const int64_t* term_offsets, int32_t n_terms, rgpu_term_state* states_out,
+                                               rgpu_term_positions* positions_out, uint8_t* found_out) {
+  if (n_terms > 0 && !positions_out) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "positions_out is null");
+  return terms_lookup_impl(terms, field_number, term_bytes, term_offsets, n_terms, states_out, positions_out, found_out);
 }
 
 extern "C" uint8_t rgpu_bm25_encode_norm(float boost, int32_t field_length) {

@@ -87,6 +87,9 @@ int main(int argc, char** argv) {
         rucene::TermState sts[2];
         uint8_t found[2];
         dict->lookup_batch(1, probe, offs, 2, sts, found);
+        rucene::TermPositions pos[2];
+        dict->lookup_batch(1, probe, offs, 2, sts, found, pos);
+        dict->lookup(1, probe, 6, &st, pos);
       }
     }
     std::vector<uint8_t> norms((size_t)max_doc);

@@ -151,9 +151,16 @@ def test_product_matches_oracle_lookup(rgpu, oracle, alphabet, blocks):
                 assert (pstates[name][:n] == st["base"][name]).all(), name
                 assert (ostates["base"][name][:n] == st["base"][name]).all(), name
             assert (pstates["doc_freq"][n:] == 0).all()
-            # the oracle also returns the pointers the product drops (positions are not served)
+            # the rest of BlockTermState for positions fields: rgpu_terms_lookup_positions
+            pstates2, ppos, pfound2 = d.lookup(3, probes, with_positions=True)
+            assert pstates2.tobytes() == pstates.tobytes() and (pfound2 == pfound).all()
             for name in ("pos_start_fp", "pay_start_fp", "last_pos_block_offset"):
                 assert (ostates[name][:n] == st[name]).all(), name
+                if opts >= oracle.IO_DOCS_FREQS_POS:
+                    assert (ppos[name][:n] == st[name]).all(), name
+            if opts < oracle.IO_DOCS_FREQS_POS:
+                assert (ppos["pos_start_fp"] == 0).all() and (ppos["last_pos_block_offset"] == -1).all()
+            assert (ppos["last_pos_block_offset"][n:] == -1).all() and (ppos["pos_start_fp"][n:] == 0).all()
             stats = d.field_stats(3)
             assert stats["num_terms"] == n and stats["sum_doc_freq"] == int(st["base"]["doc_freq"].sum())
             assert stats == {k: v for k, v in r.field_stats(3).items() if k != "root_block_fp"}
