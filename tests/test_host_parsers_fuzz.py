@@ -23,6 +23,25 @@ def test_parsers_survive_mutated_files(oracle, tmp_path):
     d = str(tmp_path)
     files = [os.path.join(d, f) for f in ("_0_Lucene50_0.doc", "_0_Lucene50_0.tim", "_0_Lucene50_0.tip", "_0.nvm", "_0.nvd", "_0_2.liv",
                                            "_0.fnm", "_0.si", "segments_2")]
+    # a second dictionary whose field is indexed with positions + offsets + payloads (three file pointers per term)
+    rng = np.random.default_rng(4)
+    n = 1200
+    st = np.zeros(n, dtype=oracle.FULL_TERM_STATE_DTYPE)
+    df = rng.choice([1, 2, 100, 129, 4000], size=n)
+    st["base"]["doc_freq"] = df
+    st["base"]["total_term_freq"] = df + rng.integers(0, 300, n)
+    st["base"]["doc_start_fp"] = 40 + np.cumsum(rng.integers(0, 900, n))
+    st["base"]["singleton_doc_id"] = np.where(df == 1, 77, -1)
+    st["base"]["skip_offset"] = np.where(df > 128, 999, -1)
+    st["pos_start_fp"] = np.cumsum(rng.integers(0, 5000, n))
+    st["pay_start_fp"] = np.cumsum(rng.integers(0, 300, n))
+    st["last_pos_block_offset"] = np.where(st["base"]["total_term_freq"] > 128, 12345, -1)
+    ptim, ptip = oracle.blocktree_write([dict(number=1, index_options=4, has_payloads=True, doc_count=1, terms=[b"w%05d" % i for i in range(n)],
+                                              states=st)], 5, 10)
+    for name, data in (("pos.tim", ptim), ("pos.tip", ptip)):
+        with open(os.path.join(d, name), "wb") as fh:
+            fh.write(data)
+    files += [os.path.join(d, "pos.tim"), os.path.join(d, "pos.tip")]
     assert all(os.path.exists(f) for f in files)
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
     for seed in (1, 2):
