@@ -122,6 +122,7 @@ def _declare(L):
                                      f32p, i32p, i64p]),
         "orc_pos_index_build": (vp, [C.c_int32, C.c_int32, C.c_int32, i64p, i32p, i32p, i64p, i32p]),
         "orc_pos_index_free": (None, [vp]),
+        "orc_pos_index_copy": (None, [vp, u8p, u8p]),
         "orc_pos_index_sizes": (C.c_int64, [vp, i64p, i64p]),
         "orc_pos_term_state": (C.c_int, [vp, C.c_int32, i64p]),
         "orc_pos_iterate": (C.c_int64, [vp, C.c_int32, i32p, C.c_int64, C.c_int32, C.c_int32, i32p, i32p, i32p, C.c_int64, i32p, C.c_int64]),
@@ -840,6 +841,13 @@ class PositionsIndex:
         d, p = C.c_int64(0), C.c_int64(0)
         lib().orc_pos_index_sizes(self._h, C.byref(d), C.byref(p))
         return d.value, p.value
+
+    def files(self):
+        """-> (.doc bytes, .pos bytes)"""
+        dl, pl = self.sizes()
+        d, p = np.zeros(dl, np.uint8), np.zeros(pl, np.uint8)
+        lib().orc_pos_index_copy(self._h, _p(d, C.c_uint8), _p(p, C.c_uint8))
+        return d.tobytes(), p.tobytes()
 
     def term_state(self, term):
         out = np.zeros(7, dtype=np.int64)

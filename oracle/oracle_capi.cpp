@@ -777,7 +777,7 @@ orc_pos_index* orc_pos_index_build(int32_t max_doc, int32_t version, int32_t n_t
   try {
     auto h = std::make_unique<orc_pos_index>();
     uint8_t id[ID_LENGTH];
-    for (int i = 0; i < ID_LENGTH; i++) id[i] = (uint8_t)(i * 7 + 1);
+    for (int i = 0; i < ID_LENGTH; i++) id[i] = (uint8_t)i;  // the synthetic index writer's default segment id
     PosPostingsWriter w(max_doc, version, id, "Lucene50_0");
     for (int32_t t = 0; t < n_terms; t++) {
       PosTermState st;
@@ -804,6 +804,10 @@ orc_pos_index* orc_pos_index_build(int32_t max_doc, int32_t version, int32_t n_t
   } catch (const std::exception& e) { g_err = e.what(); return nullptr; }
 }
 void orc_pos_index_free(orc_pos_index* h) { delete h; }
+void orc_pos_index_copy(orc_pos_index* h, uint8_t* doc_out, uint8_t* pos_out) {
+  std::memcpy(doc_out, h->doc.data(), h->doc.size());
+  std::memcpy(pos_out, h->pos.data(), h->pos.size());
+}
 int64_t orc_pos_index_sizes(orc_pos_index* h, int64_t* doc_len, int64_t* pos_len) { *doc_len = (int64_t)h->doc.size(); *pos_len = (int64_t)h->pos.size(); return (int64_t)h->terms.size(); }
 // out7: doc_start_fp, skip_offset, total_term_freq, doc_freq, singleton_doc_id, pos_start_fp, last_pos_block_offset
 int orc_pos_term_state(orc_pos_index* h, int32_t term, int64_t* out7) {

@@ -254,6 +254,134 @@ struct rgen_index {
     doc.be32(~0x3FD76C17u);
     doc.be32(0);
     doc.be64((uint64_t)crc32_of(doc.b.data(), doc.size()));
+    if (has_positions) {
+      pos.be32(~0x3FD76C17u);
+      pos.be32(0);
+      pos.be64((uint64_t)crc32_of(pos.b.data(), pos.size()));
+    }
+  }
+
+  // ---- positions (IndexOptions::DocsAndFreqsAndPositions, no payloads / offsets) ---------------------------------------
+  // ".pos" = index header "Lucene50PostingsWriterPos" + per term: floor(ttf / 128) ForUtil blocks of position deltas (the
+  // delta restarts at every doc) + (ttf % 128) vints (posting_writer.rs:363-455, 505-560). The ".doc" skip entries of such a
+  // field carry two more values: the .pos pointer and the number of buffered positions at the block boundary
+  // (skip_writer.rs:261-289). Synthetic data for the positions / phrase row.
+  Bytes pos;
+  bool has_positions = false;
+  std::vector<int64_t> term_pos_start, term_last_pos_block_offset;
+
+  void begin_positions(const uint8_t seg_id[16]) {
+    has_positions = true;
+    pos.be32(0x3FD76C17u);
+    const char* name = "Lucene50PostingsWriterPos";
+    pos.vint((uint32_t)std::strlen(name));
+    pos.raw(name, std::strlen(name));
+    pos.be32((uint32_t)version);
+    pos.raw(seg_id, 16);
+    const char* suffix = "Lucene50_0";
+    pos.u8((uint8_t)std::strlen(suffix));
+    pos.raw(suffix, std::strlen(suffix));
+  }
+
+  // positions: flat, doc j of the term owns freqs[j] of them (ascending within a doc)
+  rgpu_term_state add_term_positions(const int32_t* docs, const int32_t* freqs, const int32_t* positions, int64_t df) {
+    rgpu_term_state st;
+    st.doc_start_fp = (int64_t)doc.size();
+    st.skip_offset = -1;
+    st.singleton_doc_id = -1;
+    st.doc_freq = (int32_t)df;
+    const int64_t pos_start = (int64_t)pos.size();
+    int64_t ttf = 0;
+    for (int64_t i = 0; i < df; i++) ttf += freqs[i];
+    st.total_term_freq = ttf;
+    total_postings += df;
+    sum_doc_freq += df;
+    // .pos first: deltas of the whole term, cut into 128-blocks; remember where each block ends
+    std::vector<uint32_t> deltas((size_t)ttf);
+    {
+      int64_t at = 0;
+      for (int64_t j = 0; j < df; j++) {
+        int32_t last = 0;
+        for (int32_t q = 0; q < freqs[j]; q++, at++) { deltas[(size_t)at] = (uint32_t)(positions[at] - last); last = positions[at]; }
+      }
+    }
+    const int64_t n_pos_blocks = ttf / 128;
+    std::vector<int64_t> pos_fp_after((size_t)n_pos_blocks + 1, pos_start);  // [b] = .pos pointer once b blocks are written
+    for (int64_t b = 0; b < n_pos_blocks; b++) {
+      codec.put_block(deltas.data() + b * 128, pos);
+      pos_fp_after[(size_t)b + 1] = (int64_t)pos.size();
+    }
+    term_pos_start.push_back(pos_start);
+    term_last_pos_block_offset.push_back(ttf > 128 ? (int64_t)pos.size() - pos_start : -1);
+    for (int64_t i = n_pos_blocks * 128; i < ttf; i++) pos.vint(deltas[(size_t)i]);
+    if (df == 1) { st.singleton_doc_id = docs[0]; return st; }
+
+    struct Level { Bytes buf; int32_t last_doc = 0; int64_t last_fp = 0, last_pos_fp = 0; };
+    std::vector<Level> levels;
+    const int64_t nfull = df / 128;
+    int64_t freq_sum = 0;  // positions of the docs written so far
+    auto boundary = [&](int64_t blocks_done) {  // the first doc after `blocks_done` full doc blocks is about to be written
+      if (levels.empty()) { levels.resize((size_t)writer_skip_levels); for (auto& L : levels) { L.last_fp = st.doc_start_fp; L.last_pos_fp = pos_start; } }
+      const int32_t boundary_doc = docs[blocks_done * 128 - 1];
+      const int64_t boundary_fp = (int64_t)doc.size();
+      const int64_t boundary_pos_fp = pos_fp_after[(size_t)(freq_sum / 128)];
+      const uint32_t pos_buffer_upto = (uint32_t)(freq_sum % 128);
+      int nlev = 1;
+      for (int64_t e = blocks_done; e % 8 == 0 && nlev < writer_skip_levels; e /= 8) nlev++;
+      int64_t child = 0;
+      for (int lv = 0; lv < nlev; lv++) {
+        Level& L = levels[(size_t)lv];
+        L.buf.vint((uint32_t)(boundary_doc - L.last_doc));
+        L.buf.vlong((uint64_t)(boundary_fp - L.last_fp));
+        L.buf.vlong((uint64_t)(boundary_pos_fp - L.last_pos_fp));
+        L.buf.vint(pos_buffer_upto);
+        L.last_doc = boundary_doc;
+        L.last_fp = boundary_fp;
+        L.last_pos_fp = boundary_pos_fp;
+        const int64_t here = (int64_t)L.buf.size();
+        if (lv > 0) L.buf.vlong((uint64_t)child);
+        child = here;
+      }
+    };
+    int32_t prev = 0;
+    uint32_t dbuf[128], fbuf[128];
+    for (int64_t blk = 0; blk < nfull; blk++) {
+      if (blk > 0) boundary(blk);
+      for (int i = 0; i < 128; i++) {
+        const int32_t d = docs[blk * 128 + i];
+        dbuf[i] = (uint32_t)(d - prev);
+        prev = d;
+        fbuf[i] = (uint32_t)freqs[blk * 128 + i];
+        freq_sum += freqs[blk * 128 + i];
+      }
+      const size_t before = doc.size();
+      codec.put_block(dbuf, doc);
+      codec.put_block(fbuf, doc);
+      block_payload_bytes += (int64_t)(doc.size() - before);
+      full_blocks++;
+    }
+    if (df - nfull * 128 > 0 && nfull > 0) boundary(nfull);
+    const size_t tail_start = doc.size();
+    for (int64_t i = nfull * 128; i < df; i++) {
+      const uint32_t delta = (uint32_t)(docs[i] - prev);
+      prev = docs[i];
+      if (freqs[i] == 1) doc.vint(delta << 1 | 1);
+      else { doc.vint(delta << 1); doc.vint((uint32_t)freqs[i]); }
+    }
+    tail_bytes += (int64_t)(doc.size() - tail_start);
+    if (df > 128) {
+      st.skip_offset = (int64_t)doc.size() - st.doc_start_fp;
+      const size_t skip_start = doc.size();
+      for (int lv = (int)levels.size() - 1; lv >= 1; lv--) {
+        if (levels[(size_t)lv].buf.size() > 0) {
+          doc.vlong(levels[(size_t)lv].buf.size());
+          doc.raw(levels[(size_t)lv].buf.b.data(), levels[(size_t)lv].buf.size());
+        }
+      }
+      if (!levels.empty()) doc.raw(levels[0].buf.b.data(), levels[0].buf.size());
+      skip_bytes += (int64_t)(doc.size() - skip_start);
+    }
+    return st;
   }
 };
 
@@ -345,6 +473,45 @@ rgen_index* rgen_build_explicit(int32_t max_doc, int32_t version, int64_t n_term
   ix->finish();
   return ix;
 }
+
+// Explicit postings WITH positions (a DocsAndFreqsAndPositions field): doc slot j (flat over all terms) owns positions
+// [pos_offsets[j], pos_offsets[j+1]) and freqs[j] must equal that count. Produces ".doc" (skip entries with position pointers)
+// and ".pos"; rgen_pos_* below expose the extra bytes and per-term pointers.
+rgen_index* rgen_build_explicit_positions(int32_t max_doc, int32_t version, int64_t n_terms, const int64_t* offsets, const int32_t* docs,
+                                          const int32_t* freqs, const int64_t* pos_offsets, const int32_t* positions,
+                                          const uint8_t* norms_or_null, const uint8_t* seg_id16_or_null) {
+  rgen_index* ix = new rgen_index();
+  uint8_t seg_id[16];
+  for (int i = 0; i < 16; i++) seg_id[i] = seg_id16_or_null ? seg_id16_or_null[i] : (uint8_t)i;
+  ix->begin(max_doc, version, seg_id);
+  ix->begin_positions(seg_id);
+  ix->norms.assign((size_t)max_doc, 0);
+  if (norms_or_null) std::memcpy(ix->norms.data(), norms_or_null, (size_t)max_doc);
+  ix->terms.resize((size_t)n_terms);
+  for (int64_t t = 0; t < n_terms; t++) {
+    const int64_t df = offsets[t + 1] - offsets[t];
+    if (df <= 0) {
+      rgpu_term_state z;
+      std::memset(&z, 0, sizeof z);
+      z.skip_offset = -1;
+      z.singleton_doc_id = -1;
+      ix->terms[(size_t)t] = z;
+      ix->term_pos_start.push_back((int64_t)ix->pos.size());
+      ix->term_last_pos_block_offset.push_back(-1);
+      continue;
+    }
+    for (int64_t j = offsets[t]; j < offsets[t + 1]; j++)
+      if (pos_offsets[j + 1] - pos_offsets[j] != freqs[j]) { ix->error = "positions per doc must equal freq"; return ix; }
+    ix->terms[(size_t)t] = ix->add_term_positions(docs + offsets[t], freqs + offsets[t], positions + pos_offsets[offsets[t]], df);
+  }
+  ix->finish();
+  return ix;
+}
+int64_t rgen_pos_len(const rgen_index* ix) { return (int64_t)ix->pos.size(); }
+const uint8_t* rgen_pos_bytes(const rgen_index* ix) { return ix->pos.b.data(); }
+const int64_t* rgen_pos_start_fps(const rgen_index* ix) { return ix->term_pos_start.data(); }
+const int64_t* rgen_last_pos_block_offsets(const rgen_index* ix) { return ix->term_last_pos_block_offset.data(); }
+const char* rgen_error(const rgen_index* ix) { return ix->error.c_str(); }
 
 void rgen_free(rgen_index* ix) { delete ix; }
 int64_t rgen_doc_len(const rgen_index* ix) { return (int64_t)ix->doc.size(); }

@@ -46,6 +46,15 @@ def lib():
         L.rgen_max_doc.restype = C.c_int32
         L.rgen_max_doc.argtypes = [vp]
         L.rgen_stats.argtypes = [vp, vp]
+        L.rgen_build_explicit_positions.restype = vp
+        L.rgen_build_explicit_positions.argtypes = [C.c_int32, C.c_int32, C.c_int64, vp, vp, vp, vp, vp, vp, vp]
+        L.rgen_pos_len.restype = C.c_int64
+        L.rgen_pos_len.argtypes = [vp]
+        for n in ("rgen_pos_bytes", "rgen_pos_start_fps", "rgen_last_pos_block_offsets"):
+            getattr(L, n).restype = vp
+            getattr(L, n).argtypes = [vp]
+        L.rgen_error.restype = C.c_char_p
+        L.rgen_error.argtypes = [vp]
         _lib = L
     return _lib
 
@@ -69,7 +78,17 @@ class SyntheticSegment:
         self.doc_count = self.max_doc
         self.doc_base = doc_base
         self.live_docs = None
+        npos = L.rgen_pos_len(handle)
+        self.pos_bytes = self.pos_start_fp = self.last_pos_block_offset = None
+        if npos > 0:   # a positions field: the ".pos" file and the two extra BlockTermState pointers per term
+            self.pos_bytes = np.ctypeslib.as_array(C.cast(L.rgen_pos_bytes(handle), C.POINTER(C.c_uint8)), shape=(npos,)).copy()
+            self.pos_start_fp = np.ctypeslib.as_array(C.cast(L.rgen_pos_start_fps(handle), C.POINTER(C.c_int64)), shape=(nt,)).copy()
+            self.last_pos_block_offset = np.ctypeslib.as_array(C.cast(L.rgen_last_pos_block_offsets(handle), C.POINTER(C.c_int64)),
+                                                               shape=(nt,)).copy()
+        err = L.rgen_error(handle).decode()
         L.rgen_free(handle)
+        if err:
+            raise ValueError(err)
 
 
 def build_zipf(max_doc, n_terms, zipf_scale=0.2, version=1, seed=DEFAULT_SEED, shard=0, doc_base=0):
@@ -90,6 +109,28 @@ def build_explicit(max_doc, postings, norms=None, version=1, segment_id=None, do
     sid = None if segment_id is None else np.frombuffer(segment_id, dtype=np.uint8).copy()
     h = lib().rgen_build_explicit(max_doc, version, len(postings), offs.ctypes.data, docs.ctypes.data, freqs.ctypes.data,
                                   None if nb is None else nb.ctypes.data, None if sid is None else sid.ctypes.data)
+    seg = SyntheticSegment(h, doc_base)
+    if norms is None:
+        seg.norms = None
+    return seg
+
+
+def build_explicit_positions(max_doc, postings, norms=None, version=1, segment_id=None, doc_base=0):
+    """A DocsAndFreqsAndPositions field. postings: per term a list of (doc, [positions ascending]) in doc order (an empty
+    list -> absent term). The segment carries .doc bytes (skip entries with position pointers), .pos bytes and, per term,
+    pos_start_fp / last_pos_block_offset next to the usual term states."""
+    offs = np.zeros(len(postings) + 1, dtype=np.int64)
+    offs[1:] = np.cumsum([len(p) for p in postings])
+    docs = np.ascontiguousarray([d for p in postings for d, _ in p] or [0], dtype=np.int32)
+    freqs = np.ascontiguousarray([len(ps) for p in postings for _, ps in p] or [0], dtype=np.int32)
+    pos_offs = np.zeros(int(offs[-1]) + 1, dtype=np.int64)
+    pos_offs[1:] = np.cumsum([len(ps) for p in postings for _, ps in p]) if offs[-1] else 0
+    positions = np.ascontiguousarray([x for p in postings for _, ps in p for x in ps] or [0], dtype=np.int32)
+    nb = None if norms is None else np.ascontiguousarray(norms, dtype=np.uint8)
+    sid = None if segment_id is None else np.frombuffer(segment_id, dtype=np.uint8).copy()
+    h = lib().rgen_build_explicit_positions(max_doc, version, len(postings), offs.ctypes.data, docs.ctypes.data, freqs.ctypes.data,
+                                            pos_offs.ctypes.data, positions.ctypes.data, None if nb is None else nb.ctypes.data,
+                                            None if sid is None else sid.ctypes.data)
     seg = SyntheticSegment(h, doc_base)
     if norms is None:
         seg.norms = None

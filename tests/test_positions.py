@@ -188,3 +188,26 @@ def test_exact_phrase_scores_and_topk(oracle, corpus):
     assert total == 0 and len(gd) == 0
     with pytest.raises(oracle.OracleError):
         ix.phrase_freqs([3])                       # fewer than 2 terms
+
+
+# ---- the synthetic index writer's positions output vs the restated Lucene50PostingsWriter --------------------------------
+@pytest.mark.parametrize("version", [1, 0])
+def test_synthetic_positions_writer_is_byte_identical_to_the_restated_writer(oracle, index, version):
+    """Two independent implementations of the same format — rucene_amd/csrc/indexgen (bulk: whole term at a time) and
+    oracle/positions.hpp (line-faithful: doc by doc, position by position) — must produce the same .doc and .pos bytes
+    and the same term pointers."""
+    import __graft_entry__ as g
+    g.build()
+    from rucene_amd import indexgen
+    _, postings = index
+    postings = postings if version == 1 else postings[:9]
+    ix = oracle.PositionsIndex(200_000, postings, version=version)
+    seg = indexgen.build_explicit_positions(200_000, postings, version=version)
+    odoc, opos = ix.files()
+    assert seg.pos_bytes.tobytes() == opos
+    assert seg.doc_bytes.tobytes() == odoc
+    for t in range(len(postings)):
+        st = ix.term_state(t)
+        for name in ("doc_start_fp", "skip_offset", "total_term_freq", "doc_freq", "singleton_doc_id"):
+            assert int(seg.terms[t][name]) == st[name], (t, name)
+        assert int(seg.pos_start_fp[t]) == st["pos_start_fp"] and int(seg.last_pos_block_offset[t]) == st["last_pos_block_offset"], t
