@@ -4,6 +4,7 @@ with the oracle bit for bit; compute entry points fail loudly — never fall bac
 import ctypes as C
 import os
 import re
+import subprocess
 
 import numpy as np
 import pytest
@@ -34,8 +35,46 @@ def test_every_declared_symbol_is_exported(gpu_lib):
     assert sorted(gpu_lib.EXPORTS) == declared, "rucene_amd/_lib.py EXPORTS drifted from include/rucene_gpu.h"
 
 
+def test_header_is_plain_c_and_layouts_match_the_bindings(gpu_lib, tmp_path):
+    """include/rucene_gpu.h must compile as C (it is the drop-in boundary: no C++-isms, no torch types), and what the C compiler
+    lays out must be what the ctypes / numpy mirrors assume."""
+    src = tmp_path / "layout.c"
+    structs = {"rgpu_term_state": gpu_lib.TERM_STATE_DTYPE, "rgpu_query_term": gpu_lib.QUERY_TERM_DTYPE, "rgpu_query": gpu_lib.QUERY_DTYPE,
+               "rgpu_hit": gpu_lib.HIT_DTYPE, "rgpu_field_info": gpu_lib.FIELD_INFO_DTYPE, "rgpu_field_stats": gpu_lib.FIELD_STATS_DTYPE,
+               "rgpu_term_positions": gpu_lib.TERM_POSITIONS_DTYPE, "rgpu_segment_info": gpu_lib.SEGMENT_INFO_DTYPE,
+               "rgpu_commit_segment": gpu_lib.COMMIT_SEGMENT_DTYPE}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "%s"' % os.path.join(ROOT, "include", "rucene_gpu.h"), "int main(void) {"]
+    for name, dt in structs.items():
+        lines.append('  printf("%s %%zu", sizeof(%s));' % (name, name))
+        for field in dt.names:
+            lines.append('  printf(" %s=%%zu", offsetof(%s, %s));' % (field, name, field))
+        lines.append('  printf("\\n");')
+    lines += ['  printf("rgpu_config %zu rgpu_kernel_stat %zu\\n", sizeof(rgpu_config), sizeof(rgpu_kernel_stat));', "  return 0;", "}"]
+    src.write_text("\n".join(lines))
+    exe = str(tmp_path / "layout")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-o", exe, str(src)])
+    out = subprocess.check_output([exe], text=True).strip().splitlines()
+    for line, (name, dt) in zip(out, structs.items()):
+        parts = line.split()
+        assert parts[0] == name and int(parts[1]) == dt.itemsize, line
+        for field, spec in zip(dt.names, parts[2:]):
+            fname, off = spec.split("=")
+            assert fname == field and int(off) == dt.fields[field][1], (name, spec)
+    assert out[-1] == "rgpu_config %d rgpu_kernel_stat %d" % (C.sizeof(gpu_lib._Config), C.sizeof(gpu_lib._KernelStat))
+
+
+def test_integration_guide_binds_every_entry_point():
+    """INTEGRATION.md shows the reference-side binding (Rust FFI block): it must name every function the header declares."""
+    guide = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    missing = [name for name in _header_functions() if ("pub fn %s(" % name) not in guide]
+    assert not missing, "INTEGRATION.md's FFI block lacks: %s" % missing
+
+
 def test_struct_layouts_match_the_header(gpu_lib):
     assert gpu_lib.TERM_STATE_DTYPE.itemsize == 32
+    assert gpu_lib.TERM_POSITIONS_DTYPE.itemsize == 24 and gpu_lib.FIELD_INFO_DTYPE.itemsize == 16 and gpu_lib.FIELD_STATS_DTYPE.itemsize == 32
+    assert gpu_lib.SEGMENT_INFO_DTYPE.itemsize == 48 and gpu_lib.SEGMENT_INFO_DTYPE.fields["id"][1] == 32
+    assert gpu_lib.COMMIT_SEGMENT_DTYPE.itemsize == 112 and gpu_lib.COMMIT_SEGMENT_DTYPE.fields["del_gen"][1] == 80
     assert gpu_lib.TERM_STATE_DTYPE.fields["doc_freq"][1] == 24 and gpu_lib.TERM_STATE_DTYPE.fields["singleton_doc_id"][1] == 28
     assert gpu_lib.QUERY_TERM_DTYPE.itemsize == 40 and gpu_lib.QUERY_TERM_DTYPE.fields["weight"][1] == 32
     assert gpu_lib.QUERY_DTYPE.itemsize == 16 and gpu_lib.HIT_DTYPE.itemsize == 8
