@@ -56,6 +56,8 @@ class LeafReader:
     flat table of term states indexed by term id (synthetic indexes) or a block-tree dictionary (`.tim`/`.tip`) keyed
     by term bytes."""
 
+    RESOLVED_CACHE_TERMS = 1 << 20   # bound of the per-leaf memo of resolved byte terms
+
     def __init__(self, doc_bytes, norms, max_doc, terms, doc_base=0, live_docs=None, doc_count=None,
                  sum_total_term_freq=0, sum_doc_freq=-1, field="body", term_dictionary=None, field_number=0):
         self.doc_bytes, self.norms, self.max_doc, self.doc_base = doc_bytes, norms, int(max_doc), int(doc_base)
@@ -108,6 +110,8 @@ class LeafReader:
         if self.term_dictionary is None:
             raise RgpuError(-2, "this leaf has no term dictionary: query it by term id")
         states, found = self.term_dictionary.lookup(self.field_number, new)
+        if len(self._resolved) + len(new) > self.RESOLVED_CACHE_TERMS:   # a memo, not an index: start over rather than grow forever
+            self._resolved.clear()
         for t, st, ok in zip(new, states, found):
             self._resolved[t] = st if ok else None
 
@@ -273,6 +277,8 @@ class GpuIndexSearcher:
 
     def _weight(self, term_id, boost):
         key = (term_id, boost)
+        if key not in self._weights and len(self._weights) >= (1 << 20):
+            self._weights.clear()
         if key not in self._weights:
             w, cache = self.similarity.compute_weight(self.collection_statistics, [self.term_statistics(term_id)], boost)
             self._weights[key] = (w, self.ctx.sim_table(cache, self.similarity.k1))
