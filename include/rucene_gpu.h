@@ -268,6 +268,18 @@ typedef struct rgpu_commit_segment {
   int32_t reserved;
 } rgpu_commit_segment;
 int32_t rgpu_commit_from_segments_file(const uint8_t* data, size_t len, int64_t generation, rgpu_commit_segment* out, int32_t cap);
+/* Lucene50CompoundReader (codec/compound.rs:116-195): a compound segment's ".cfe" entry table -> where each of the segment's
+ * files lies inside ".cfs" (each is copied there whole: header, body, footer). Entry ids are file names without the segment
+ * name (".fnm", "_Lucene50_0.doc", ...: strip_segment_name, codec/segment_infos/mod.rs:64-79). cfs may be NULL; when given its
+ * header, footer and total length are checked as the reference does. Returns the number of entries (>= 0) or a negative
+ * status; fills at most `cap` records. */
+typedef struct rgpu_compound_entry {
+  char id[112];
+  int64_t offset;   /* from the start of the .cfs file */
+  int64_t length;
+} rgpu_compound_entry;
+int32_t rgpu_compound_entries_from_lucene50(const uint8_t* cfe, size_t cfe_len, const uint8_t* cfs_or_null, size_t cfs_len,
+                                            const uint8_t* expected_id16_or_null, rgpu_compound_entry* out, int32_t cap);
 int32_t rgpu_terms_open(const uint8_t* tim, size_t tim_len, const uint8_t* tip, size_t tip_len, const rgpu_field_info* infos,
                         int32_t n_infos, int32_t max_doc, rgpu_terms** out_terms);
 void rgpu_terms_close(rgpu_terms* terms);

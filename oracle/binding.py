@@ -29,7 +29,7 @@ def build(force=False):
     if force or not os.path.exists(_LIB_PATH) or any(
             os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
             for f in ("oracle_capi.cpp", "store.hpp", "packed.hpp", "postings.hpp", "search.hpp", "norms.hpp", "fst.hpp",
-                      "blocktree.hpp", "field_infos.hpp", "segment_infos.hpp", "positions.hpp", "phrase.hpp")):
+                      "blocktree.hpp", "field_infos.hpp", "segment_infos.hpp", "positions.hpp", "phrase.hpp", "compound.hpp")):
         subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
@@ -129,6 +129,8 @@ def _declare(L):
         "orc_pos_phrase_freqs": (C.c_int64, [vp, i32p, i32p, C.c_int, i32p, i32p, C.c_int64]),
         "orc_pos_phrase_search": (C.c_int, [vp, i32p, i32p, C.c_int, u8p, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, i32p, f32p,
                                             i32p, i64p]),
+        "orc_compound_write": (C.c_int, [C.c_int32, u8p, u8p, i64p, u8p, u8p, i64p, u8p, i64p]),
+        "orc_compound_read": (C.c_int, [u8p, C.c_int64, u8p, C.c_int64, u8p, C.c_int32, u8p, C.c_int64, i64p, i64p, i64p]),
         "orc_segment_info_write": (C.c_int, [u8p, u8p, i32p, C.c_int32, C.c_int, u8p, i64p]),
         "orc_segment_info_read": (C.c_int, [u8p, C.c_int64, u8p, i32p, i32p, u8p]),
         "orc_segments_file_write": (C.c_int, [C.c_int64, u8p, C.c_int64, C.c_int32, C.c_int32, u8p, u8p, i64p, i32p, u8p, i64p]),
@@ -898,3 +900,38 @@ class PositionsIndex:
 
     def __del__(self):
         self.close()
+
+
+# ---- compound files (".cfs" + ".cfe") ----------------------------------------------------------------------------------
+def compound_write(files, segment_id):
+    """Lucene50CompoundFormat::write. files: {file name: bytes} (every file must carry segment_id in its header) -> (cfs, cfe)."""
+    names = sorted(files)
+    flat_names = _u8(b"".join(_lp(n) for n in names))
+    blob = _u8(b"".join(files[n] for n in names))
+    offs = np.zeros(len(names) + 1, np.int64)
+    np.cumsum([len(files[n]) for n in names], out=offs[1:])
+    sid = _u8(segment_id)
+    sl, el = C.c_int64(0), C.c_int64(0)
+    args = (len(names), _p(flat_names, C.c_uint8), _p(blob, C.c_uint8), _p(offs, C.c_int64), _p(sid, C.c_uint8))
+    _check(lib().orc_compound_write(*args, None, C.byref(sl), None, C.byref(el)))
+    cfs, cfe = np.zeros(sl.value, np.uint8), np.zeros(el.value, np.uint8)
+    _check(lib().orc_compound_write(*args, _p(cfs, C.c_uint8), C.byref(sl), _p(cfe, C.c_uint8), C.byref(el)))
+    return cfs.tobytes(), cfe.tobytes()
+
+
+def compound_read(cfe, cfs, expected_id=None):
+    """Lucene50CompoundReader -> {entry id: (offset, length)}"""
+    e, d = _u8(cfe)[:-1], _u8(cfs)[:-1]
+    eid = _u8(expected_id) if expected_id is not None else None
+    ln = C.c_int64(0)
+    n = _check(lib().orc_compound_read(_p(e, C.c_uint8), e.size, _p(d, C.c_uint8), d.size, _p(eid, C.c_uint8), 0, None, 0, C.byref(ln), None, None))
+    ids = np.zeros(max(ln.value, 1), np.uint8)
+    offs, lens = np.zeros(max(n, 1), np.int64), np.zeros(max(n, 1), np.int64)
+    _check(lib().orc_compound_read(_p(e, C.c_uint8), e.size, _p(d, C.c_uint8), d.size, _p(eid, C.c_uint8), n, _p(ids, C.c_uint8), ids.size,
+                                   C.byref(ln), _p(offs, C.c_int64), _p(lens, C.c_int64)))
+    raw, pos, out = ids.tobytes(), 0, {}
+    for i in range(n):
+        k = int.from_bytes(raw[pos:pos + 4], "little")
+        out[raw[pos + 4:pos + 4 + k].decode()] = (int(offs[i]), int(lens[i]))
+        pos += 4 + k
+    return out

@@ -17,6 +17,7 @@
 #include "segment_infos.hpp"
 #include "positions.hpp"
 #include "phrase.hpp"
+#include "compound.hpp"
 #include "store.hpp"
 
 using namespace orc;
@@ -920,6 +921,40 @@ int orc_pos_phrase_search(orc_pos_index* h, const int32_t* term_ids, const int32
   *out_total = (int64_t)collector.total_hits;
   for (size_t i = 0; i < r.size(); i++) { out_docs[i] = r[i].doc; out_scores[i] = r[i].score; }
   return 0;
+  ORC_CATCH
+}
+
+// ---- compound files (oracle/compound.hpp) ------------------------------------------------------------------------------
+// names: length-prefixed strings; file i = blob[offs[i], offs[i+1]). Two-call protocol on both outputs.
+int orc_compound_write(int32_t n, const uint8_t* names, const uint8_t* blob, const int64_t* offs, const uint8_t* id16, uint8_t* cfs_out,
+                       int64_t* cfs_len, uint8_t* cfe_out, int64_t* cfe_len) {
+  ORC_TRY
+  std::map<std::string, std::vector<uint8_t>> files;
+  const uint8_t* p = names;
+  for (int32_t i = 0; i < n; i++) files[take_string(p)] = std::vector<uint8_t>(blob + offs[i], blob + offs[i + 1]);
+  auto r = write_compound(files, id16);
+  if (cfs_out && *cfs_len >= (int64_t)r.first.size()) std::memcpy(cfs_out, r.first.data(), r.first.size());
+  if (cfe_out && *cfe_len >= (int64_t)r.second.size()) std::memcpy(cfe_out, r.second.data(), r.second.size());
+  *cfs_len = (int64_t)r.first.size();
+  *cfe_len = (int64_t)r.second.size();
+  return 0;
+  ORC_CATCH
+}
+// returns the entry count; ids length-prefixed in ids_out; offsets/lengths per entry (map order = sorted ids)
+int orc_compound_read(const uint8_t* cfe, int64_t cfe_len, const uint8_t* cfs, int64_t cfs_len, const uint8_t* expected_id16, int32_t cap,
+                      uint8_t* ids_out, int64_t ids_cap, int64_t* ids_len, int64_t* offsets, int64_t* lengths) {
+  ORC_TRY
+  auto m = read_compound(cfe, (size_t)cfe_len, cfs, (size_t)cfs_len, expected_id16);
+  std::string flat;
+  int32_t i = 0;
+  for (const auto& kv : m) {
+    put_string(flat, kv.first);
+    if (i < cap) { offsets[i] = kv.second.offset; lengths[i] = kv.second.length; }
+    i++;
+  }
+  if (ids_out && (int64_t)flat.size() <= ids_cap) std::memcpy(ids_out, flat.data(), flat.size());
+  *ids_len = (int64_t)flat.size();
+  return (int)m.size();
   ORC_CATCH
 }
 

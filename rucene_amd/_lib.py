@@ -29,7 +29,8 @@ SEGMENT_INFO_DTYPE = np.dtype([("max_doc", "<i4"), ("is_compound_file", "<i4"), 
 COMMIT_SEGMENT_DTYPE = np.dtype([("name", "S48"), ("codec", "S16"), ("id", "u1", (16,)), ("del_gen", "<i8"), ("field_infos_gen", "<i8"),
                                  ("dv_gen", "<i8"), ("del_count", "<i4"), ("reserved", "<i4")], align=True)
 assert FIELD_INFO_DTYPE.itemsize == 16 and FIELD_STATS_DTYPE.itemsize == 32
-assert SEGMENT_INFO_DTYPE.itemsize == 48 and COMMIT_SEGMENT_DTYPE.itemsize == 112
+COMPOUND_ENTRY_DTYPE = np.dtype([("id", "S112"), ("offset", "<i8"), ("length", "<i8")], align=True)
+assert SEGMENT_INFO_DTYPE.itemsize == 48 and COMMIT_SEGMENT_DTYPE.itemsize == 112 and COMPOUND_ENTRY_DTYPE.itemsize == 128
 assert TERM_STATE_DTYPE.itemsize == 32 and QUERY_TERM_DTYPE.itemsize == 40 and QUERY_DTYPE.itemsize == 16 and HIT_DTYPE.itemsize == 8
 
 STATUS_NAMES = {0: "OK", -1: "IllegalState", -2: "IllegalArgument", -3: "UnexpectedEOF", -4: "CorruptIndex",
@@ -41,7 +42,7 @@ EXPORTS = [
     "rgpu_segment_free", "rgpu_segment_version", "rgpu_segment_prepare_terms", "rgpu_decode_terms",
     "rgpu_decode_terms_device", "rgpu_advance_batch", "rgpu_sim_table_upload", "rgpu_search_batch",
     "rgpu_search_batch_device", "rgpu_merge_topk_device", "rgpu_bm25_compute_weight", "rgpu_bm25_encode_norm",
-    "rgpu_norms_from_lucene53", "rgpu_live_docs_from_lucene50", "rgpu_field_infos_from_lucene60", "rgpu_segment_info_from_lucene62", "rgpu_commit_from_segments_file", "rgpu_terms_open", "rgpu_terms_close", "rgpu_terms_field_stats",
+    "rgpu_norms_from_lucene53", "rgpu_live_docs_from_lucene50", "rgpu_field_infos_from_lucene60", "rgpu_segment_info_from_lucene62", "rgpu_commit_from_segments_file", "rgpu_compound_entries_from_lucene50", "rgpu_terms_open", "rgpu_terms_close", "rgpu_terms_field_stats",
     "rgpu_terms_lookup", "rgpu_terms_lookup_positions", "rgpu_kernel_stats", "rgpu_kernel_stats_reset", "rgpu_synchronize",
 ]
 
@@ -120,6 +121,7 @@ def lib():
         "rgpu_live_docs_from_lucene50": (i32, [vp, C.c_size_t, i32, i32, vp]),
         "rgpu_segment_info_from_lucene62": (i32, [vp, C.c_size_t, vp, vp]),
         "rgpu_commit_from_segments_file": (i32, [vp, C.c_size_t, i64, vp, i32]),
+        "rgpu_compound_entries_from_lucene50": (i32, [vp, C.c_size_t, vp, C.c_size_t, vp, vp, i32]),
         "rgpu_field_infos_from_lucene60": (i32, [vp, C.c_size_t, vp, i32, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
         "rgpu_terms_open": (i32, [vp, C.c_size_t, vp, C.c_size_t, vp, i32, i32, C.POINTER(vp)]),
         "rgpu_terms_close": (None, [vp]),
@@ -196,6 +198,20 @@ def commit_from_segments_file(data, generation=-1):
     _check(lib().rgpu_commit_from_segments_file(b.ctypes.data, b.size, int(generation), out.ctypes.data, n))
     return [dict(name=r["name"].decode(), codec=r["codec"].decode(), id=r["id"].tobytes(), del_gen=int(r["del_gen"]),
                  del_count=int(r["del_count"]), field_infos_gen=int(r["field_infos_gen"]), dv_gen=int(r["dv_gen"])) for r in out[:n]]
+
+
+def compound_files_from_lucene50(cfe, cfs, expected_id=None):
+    """Lucene50CompoundReader: the ".cfe" + ".cfs" pair of a compound segment -> {entry id: bytes of that file}, ids being
+    file names without the segment name (".fnm", "_Lucene50_0.doc", ...)."""
+    e = np.frombuffer(bytes(cfe), dtype=np.uint8)
+    raw = bytes(cfs)
+    d = np.frombuffer(raw, dtype=np.uint8)
+    eid = np.frombuffer(bytes(expected_id), dtype=np.uint8) if expected_id is not None else None
+    args = (e.ctypes.data, e.size, d.ctypes.data, d.size, eid.ctypes.data if eid is not None else None)
+    n = _check(lib().rgpu_compound_entries_from_lucene50(*args, None, 0))
+    out = np.zeros(max(n, 1), dtype=COMPOUND_ENTRY_DTYPE)
+    _check(lib().rgpu_compound_entries_from_lucene50(*args, out.ctypes.data, n))
+    return {r["id"].decode(): raw[int(r["offset"]):int(r["offset"]) + int(r["length"])] for r in out[:n]}
 
 
 def field_infos_from_lucene60(fnm):

@@ -17,6 +17,7 @@
 #include "host/term_dict.hpp"
 #include "host/field_infos_format.hpp"
 #include "host/segment_infos_format.hpp"
+#include "host/compound_format.hpp"
 #include "kernels/prepare.hpp"
 #include "kernels/search.hpp"
 #include "kernels/search_and.hpp"
@@ -1193,6 +1194,22 @@ extern "C" int32_t rgpu_commit_from_segments_file(const uint8_t* data, size_t le
     out[i].del_count = s.del_count;
   }
   return (int32_t)segs.size();
+}
+
+extern "C" int32_t rgpu_compound_entries_from_lucene50(const uint8_t* cfe, size_t cfe_len, const uint8_t* cfs_or_null, size_t cfs_len,
+                                                       const uint8_t* expected_id16_or_null, rgpu_compound_entry* out, int32_t cap) {
+  std::vector<rucene::CompoundEntry> entries;
+  std::string why;
+  const int rc = rucene::read_lucene50_compound_entries(cfe, cfe_len, cfs_or_null, cfs_len, expected_id16_or_null, &entries, &why);
+  if (rc != 0) return fail(rc, why);
+  for (size_t i = 0; i < entries.size() && out && (int64_t)i < cap; ++i) {
+    if (entries[i].id.size() >= sizeof(out[i].id)) return fail(RGPU_ERR_UNSUPPORTED, "compound entry name too long");
+    out[i] = rgpu_compound_entry{};
+    std::memcpy(out[i].id, entries[i].id.c_str(), entries[i].id.size());
+    out[i].offset = entries[i].offset;
+    out[i].length = entries[i].length;
+  }
+  return (int32_t)entries.size();
 }
 
 extern "C" int32_t rgpu_field_infos_from_lucene60(const uint8_t* fnm, size_t fnm_len, rgpu_field_info* infos_out, int32_t cap, char* names_out,

@@ -140,7 +140,8 @@ def open_directory(path, field="body"):
     segments; per segment `.si` gives max_doc, `.fnm` the field's number and index options, `_Lucene50_0.{doc,tim,tip}` the
     postings and term dictionary, `.nvm/.nvd` the norms, `_<delgen>.liv` the live docs (index/reader/directory_reader.rs:
     90-140; segment_reader.rs open; file names per codec/segment_infos/mod.rs:60-114). Returns the LeafReaders with
-    cumulative doc bases, ready for GpuIndexSearcher. Compound-file segments are refused (UnsupportedOperation)."""
+    cumulative doc bases, ready for GpuIndexSearcher. A compound segment's files are taken out of its `.cfs` through the
+    `.cfe` entry table (codec/compound.rs); its `.si` and `.liv` stay outside, as Rucene writes them."""
     import os
     gens = [int(f[len("segments_"):], 36) for f in os.listdir(path) if f.startswith("segments_")]
     if not gens:
@@ -154,16 +155,24 @@ def open_directory(path, field="body"):
     for seg in _lib.commit_from_segments_file(read("segments_" + _base36(gen)), gen):
         name = seg["name"]
         info = _lib.segment_info_from_lucene62(read(name + ".si"), expected_id=seg["id"])
+        inner = None
         if info["is_compound_file"]:
-            raise RgpuError(-5, "segment %s uses a compound file (.cfs); only plain segment files can be opened" % name)
+            inner = _lib.compound_files_from_lucene50(read(name + ".cfe"), read(name + ".cfs"), expected_id=seg["id"])
+
+        def part(suffix, _inner=inner, _name=name):   # a file of this segment, from the directory or from inside its .cfs
+            if _inner is None:
+                return read(_name + suffix)
+            if suffix not in _inner:
+                raise RgpuError(-6, "%s%s is not in the compound file" % (_name, suffix))
+            return _inner[suffix]
         if seg["del_count"] > info["max_doc"]:
             raise RgpuError(-4, "invalid deletion count: %d vs maxDoc=%d" % (seg["del_count"], info["max_doc"]))
-        postings = name + "_Lucene50_0"      # PerFieldPostingsFormat: format "Lucene50", suffix "0" (field_infos/mod.rs:441-447)
+        # postings files carry PerFieldPostingsFormat's suffix: format "Lucene50", suffix "0" (field_infos/mod.rs:441-447)
         liv = read("%s_%s.liv" % (name, _base36(seg["del_gen"]))) if seg["del_gen"] >= 0 and seg["del_count"] > 0 else None
-        leaf = LeafReader.from_index_files(np.frombuffer(read(postings + ".doc"), dtype=np.uint8), read(postings + ".tim"),
-                                           read(postings + ".tip"), read(name + ".nvm"), read(name + ".nvd"), info["max_doc"],
+        leaf = LeafReader.from_index_files(np.frombuffer(part("_Lucene50_0.doc"), dtype=np.uint8), part("_Lucene50_0.tim"),
+                                           part("_Lucene50_0.tip"), part(".nvm"), part(".nvd"), info["max_doc"],
                                            liv=liv, del_count=seg["del_count"] if liv is not None else -1, doc_base=doc_base,
-                                           field=field, fnm=read(name + ".fnm"))
+                                           field=field, fnm=part(".fnm"))
         leaves.append(leaf)
         doc_base += info["max_doc"]
     return leaves

@@ -1,7 +1,7 @@
 // Mutation fuzzer for the host-side file parsers (header-only, no HIP): every reader that takes bytes from an index
 // directory must reject damaged input with a status — never read out of bounds, overflow, loop or crash. Built with
 // -fsanitize=address,undefined by tests/test_host_parsers_fuzz.py, which hands it valid files written by the oracle:
-//   argv: iterations seed doc tim tip nvm nvd liv fnm si segments [tim_pos tip_pos]
+//   argv: iterations seed doc tim tip nvm nvd liv fnm si segments [tim_pos tip_pos [cfe cfs]]
 // (tim_pos / tip_pos: a second dictionary whose field 1 is indexed with positions, offsets and payloads: longs_size 3)
 // Each iteration takes one valid file set, damages one or more files (bit flips, byte overwrites, truncation, insertion,
 // block duplication) and runs every parser. Prints a tally; exit code 0 unless a sanitizer aborts the process.
@@ -13,6 +13,7 @@
 #include <string>
 #include <vector>
 
+#include "../../rucene_amd/csrc/host/compound_format.hpp"
 #include "../../rucene_amd/csrc/host/doc_format.hpp"
 #include "../../rucene_amd/csrc/host/field_infos_format.hpp"
 #include "../../rucene_amd/csrc/host/norms_format.hpp"
@@ -55,14 +56,15 @@ static void mutate(Bytes& b, Rng& r) {
 }
 
 int main(int argc, char** argv) {
-  if (argc != 12 && argc != 14) { std::fprintf(stderr, "usage: %s iterations seed doc tim tip nvm nvd liv fnm si segments [tim_pos tip_pos]\n", argv[0]); return 2; }
+  if (argc != 12 && argc != 14 && argc != 16) { std::fprintf(stderr, "usage: %s iterations seed doc tim tip nvm nvd liv fnm si segments [tim_pos tip_pos]\n", argv[0]); return 2; }
   const long iterations = std::atol(argv[1]);
   Rng rng{(uint64_t)std::atoll(argv[2])};
   const Bytes doc0 = slurp(argv[3]), tim0 = slurp(argv[4]), tip0 = slurp(argv[5]), nvm0 = slurp(argv[6]), nvd0 = slurp(argv[7]),
               liv0 = slurp(argv[8]), fnm0 = slurp(argv[9]), si0 = slurp(argv[10]), seg0 = slurp(argv[11]);
-  const Bytes ptim0 = argc == 14 ? slurp(argv[12]) : Bytes(), ptip0 = argc == 14 ? slurp(argv[13]) : Bytes();
+  const Bytes ptim0 = argc >= 14 ? slurp(argv[12]) : Bytes(), ptip0 = argc >= 14 ? slurp(argv[13]) : Bytes();
+  const Bytes cfe0 = argc == 16 ? slurp(argv[14]) : Bytes(), cfs0 = argc == 16 ? slurp(argv[15]) : Bytes();
   const int32_t max_doc = 20000;
-  long ok[8] = {0}, bad[8] = {0};
+  long ok[9] = {0}, bad[9] = {0};
   auto tally = [&](int which, int rc) { (rc == 0 ? ok : bad)[which]++; };
   std::string why;
   for (long it = 0; it <= iterations; ++it) {
@@ -108,6 +110,12 @@ int main(int argc, char** argv) {
         dict->lookup(1, probe, 6, &st, &pos);
       }
     }
+    if (!cfe0.empty()) {
+      Bytes cfe = cfe0, cfs = cfs0;
+      if (it > 0) { mutate(cfe, rng); if (rng.below(3) == 0) mutate(cfs, rng); }
+      std::vector<rucene::CompoundEntry> entries;
+      tally(8, rucene::read_lucene50_compound_entries(cfe.data(), cfe.size(), cfs.data(), cfs.size(), nullptr, &entries, &why));
+    }
     std::vector<uint8_t> norms((size_t)max_doc);
     tally(2, rucene::read_lucene53_norms(nvm.data(), nvm.size(), nvd.data(), nvd.size(), 1, max_doc, norms.data(), &why));
     std::vector<uint64_t> words((size_t)(max_doc + 63) / 64);
@@ -118,9 +126,9 @@ int main(int argc, char** argv) {
     tally(5, rucene::read_lucene62_segment_info(si.data(), si.size(), nullptr, &sie, &why));
     std::vector<rucene::CommitSegmentEntry> segs;
     tally(6, rucene::read_segments_file(seg.data(), seg.size(), 2, &segs, &why));
-    if (it == 0) for (int i = 0; i < 8; ++i) if (bad[i]) { std::fprintf(stderr, "parser %d rejects the undamaged file: %s\n", i, why.c_str()); return 3; }
+    if (it == 0) for (int i = 0; i < 9; ++i) if (bad[i]) { std::fprintf(stderr, "parser %d rejects the undamaged file: %s\n", i, why.c_str()); return 3; }
   }
-  const char* names[8] = {"doc", "tim/tip", "nvm/nvd", "liv", "fnm", "si", "segments_N", "tim/tip+pos"};
-  for (int i = 0; i < (ptim0.empty() ? 7 : 8); ++i) std::printf("%-10s accepted %ld rejected %ld\n", names[i], ok[i], bad[i]);
+  const char* names[9] = {"doc", "tim/tip", "nvm/nvd", "liv", "fnm", "si", "segments_N", "tim/tip+pos", "cfe/cfs"};
+  for (int i = 0; i < (ptim0.empty() ? 7 : cfe0.empty() ? 8 : 9); ++i) std::printf("%-10s accepted %ld rejected %ld\n", names[i], ok[i], bad[i]);
   return 0;
 }

@@ -42,7 +42,7 @@ def test_header_is_plain_c_and_layouts_match_the_bindings(gpu_lib, tmp_path):
     structs = {"rgpu_term_state": gpu_lib.TERM_STATE_DTYPE, "rgpu_query_term": gpu_lib.QUERY_TERM_DTYPE, "rgpu_query": gpu_lib.QUERY_DTYPE,
                "rgpu_hit": gpu_lib.HIT_DTYPE, "rgpu_field_info": gpu_lib.FIELD_INFO_DTYPE, "rgpu_field_stats": gpu_lib.FIELD_STATS_DTYPE,
                "rgpu_term_positions": gpu_lib.TERM_POSITIONS_DTYPE, "rgpu_segment_info": gpu_lib.SEGMENT_INFO_DTYPE,
-               "rgpu_commit_segment": gpu_lib.COMMIT_SEGMENT_DTYPE}
+               "rgpu_commit_segment": gpu_lib.COMMIT_SEGMENT_DTYPE, "rgpu_compound_entry": gpu_lib.COMPOUND_ENTRY_DTYPE}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "%s"' % os.path.join(ROOT, "include", "rucene_gpu.h"), "int main(void) {"]
     for name, dt in structs.items():
         lines.append('  printf("%s %%zu", sizeof(%s));' % (name, name))

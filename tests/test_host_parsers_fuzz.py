@@ -42,6 +42,13 @@ def test_parsers_survive_mutated_files(oracle, tmp_path):
         with open(os.path.join(d, name), "wb") as fh:
             fh.write(data)
     files += [os.path.join(d, "pos.tim"), os.path.join(d, "pos.tip")]
+    # a compound file holding the small files of the segment
+    sid = open(os.path.join(d, "_0.fnm"), "rb").read()[4 + 1 + len("Lucene60FieldInfos") + 4:][:16]
+    cfs, cfe = oracle.compound_write({n: open(os.path.join(d, n), "rb").read() for n in ("_0.fnm", "_0.nvm", "_0.nvd", "_0_Lucene50_0.tip")}, sid)
+    for name, data in (("_0.cfe", cfe), ("_0.cfs", cfs)):
+        with open(os.path.join(d, name), "wb") as fh:
+            fh.write(data)
+    files += [os.path.join(d, "_0.cfe"), os.path.join(d, "_0.cfs")]
     assert all(os.path.exists(f) for f in files)
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
     for seed in (1, 2):

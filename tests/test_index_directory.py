@@ -120,8 +120,13 @@ def _write_segment(oracle, path, name, sid, seg, live=None, del_gen=-1):
     tim, tip = oracle.blocktree_write([dict(number=1, doc_count=seg.doc_count, terms=[b"w%05d" % t for t in present], states=st)],
                                       segment_id=sid, suffix="Lucene50_0")
     nvm, nvd = oracle.norms_write(seg.norms.astype(np.int64), field_number=1, segment_id=sid)
+    # every file of a segment carries the segment's id: re-stamp the synthetic .doc (its generator picked its own) and re-seal it
+    doc = bytearray(seg.doc_bytes.tobytes())
+    at = 4 + 1 + len("Lucene50PostingsWriterDoc") + 4
+    doc[at:at + 16] = sid
+    doc[-8:] = struct.pack(">q", zlib.crc32(bytes(doc[:-8])) & 0xFFFFFFFF)
     files = {name + ".fnm": oracle.field_infos_write([dict(name="title", number=0), dict(name="body", number=1, index_options=2)], segment_id=sid),
-             name + "_Lucene50_0.doc": seg.doc_bytes.tobytes(), name + "_Lucene50_0.tim": tim, name + "_Lucene50_0.tip": tip,
+             name + "_Lucene50_0.doc": bytes(doc), name + "_Lucene50_0.tim": tim, name + "_Lucene50_0.tip": tip,
              name + ".nvm": nvm, name + ".nvd": nvd}
     del_count = 0
     if live is not None:
@@ -181,3 +186,52 @@ def test_open_directory_host_side(rgpu, oracle, tmp_path):
     os.remove(str(tmp_path / "segments_1"))
     with pytest.raises(rgpu.RgpuError):
         rgpu.open_directory(str(tmp_path))
+
+
+# ---- compound segments (".cfs" + ".cfe") ---------------------------------------------------------------------------------
+def _compound_directory(oracle, path):
+    """The two-segment directory again, with the second segment packed into a compound file the way IndexWriter does after a
+    flush or merge: .si (is_compound_file = yes, files = .cfs/.cfe/.si) and .liv stay outside."""
+    segs, lives = build_directory(oracle, path)
+    name = "_1"
+    inner = {f: open(os.path.join(path, f), "rb").read() for f in os.listdir(path) if f.startswith(name + ".") or f.startswith(name + "_")}
+    si = inner.pop(name + ".si")
+    sid = si[4 + 1 + len("Lucene62SegmentInfo") + 4:][:16]
+    cfs, cfe = oracle.compound_write(inner, sid)
+    for f in inner:
+        os.remove(os.path.join(path, f))
+    with open(os.path.join(path, name + ".cfs"), "wb") as fh:
+        fh.write(cfs)
+    with open(os.path.join(path, name + ".cfe"), "wb") as fh:
+        fh.write(cfe)
+    with open(os.path.join(path, name + ".si"), "wb") as fh:
+        fh.write(oracle.segment_info_write(name, segs[1].max_doc, segment_id=sid, files=[name + ".cfs", name + ".cfe", name + ".si"],
+                                           is_compound_file=True))
+    return segs, lives, inner, sid, cfs, cfe
+
+
+def test_compound_files(rgpu, oracle, tmp_path):
+    segs, lives, inner, sid, cfs, cfe = _compound_directory(oracle, str(tmp_path))
+    want = oracle.compound_read(cfe, cfs, sid)
+    got = rgpu.compound_files_from_lucene50(cfe, cfs, expected_id=sid)
+    assert sorted(got) == sorted(want) == sorted(n[2:] for n in inner)          # "_1.fnm" -> ".fnm", "_1_Lucene50_0.doc" -> "_Lucene50_0.doc"
+    for n, data in inner.items():
+        off, ln = want[n[2:]]
+        assert cfs[off:off + ln] == data and got[n[2:]] == data                    # each file is inside, whole
+    # the directory opens as before: the compound segment's files come out of its .cfs
+    leaves = rgpu.open_directory(str(tmp_path), field="body")
+    assert [l.max_doc for l in leaves] == [30_000, 12_000]
+    for t in (0, 5, 899):
+        assert leaves[1].term_state(b"w%05d" % t).tobytes() == segs[1].terms[t].tobytes()
+    assert (leaves[1].norms == segs[1].norms).all()
+    # rejections
+    for bad_cfe, bad_cfs in ((cfe[:-1], cfs), (cfe, cfs[:-1]), (cfe, cfs + b"\\0"), (cfe[:-8] + bytes(8), cfs)):
+        with pytest.raises(rgpu.RgpuError) as e:
+            rgpu.compound_files_from_lucene50(bad_cfe, bad_cfs, expected_id=sid)
+        assert e.value.status == -4
+        with pytest.raises(oracle.OracleError):
+            oracle.compound_read(bad_cfe, bad_cfs, sid)
+    with pytest.raises(rgpu.RgpuError):
+        rgpu.compound_files_from_lucene50(cfe, cfs, expected_id=bytes(16))
+    with pytest.raises(oracle.OracleError):                                        # a file of another segment cannot be packed
+        oracle.compound_write({"_1.fnm": oracle.field_infos_write([], segment_id=bytes(range(16)))}, sid)
