@@ -165,6 +165,9 @@ def open_directory(path, field="body"):
             if suffix not in _inner:
                 raise RgpuError(-6, "%s%s is not in the compound file" % (_name, suffix))
             return _inner[suffix]
+        # field infos rewritten by a doc-values update live outside the compound file under a generation suffix
+        # (SegmentCommitInfo::field_infos_gen; file_name_from_generation, codec/segment_infos/mod.rs:100-114)
+        fnm = read("%s_%s.fnm" % (name, _base36(seg["field_infos_gen"]))) if seg["field_infos_gen"] > 0 else part(".fnm")
         if seg["del_count"] > info["max_doc"]:
             raise RgpuError(-4, "invalid deletion count: %d vs maxDoc=%d" % (seg["del_count"], info["max_doc"]))
         # postings files carry PerFieldPostingsFormat's suffix: format "Lucene50", suffix "0" (field_infos/mod.rs:441-447)
@@ -172,7 +175,7 @@ def open_directory(path, field="body"):
         leaf = LeafReader.from_index_files(np.frombuffer(part("_Lucene50_0.doc"), dtype=np.uint8), part("_Lucene50_0.tim"),
                                            part("_Lucene50_0.tip"), part(".nvm"), part(".nvd"), info["max_doc"],
                                            liv=liv, del_count=seg["del_count"] if liv is not None else -1, doc_base=doc_base,
-                                           field=field, fnm=part(".fnm"))
+                                           field=field, fnm=fnm)
         leaves.append(leaf)
         doc_base += info["max_doc"]
     return leaves

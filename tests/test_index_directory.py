@@ -181,6 +181,22 @@ def test_open_directory_host_side(rgpu, oracle, tmp_path):
     with pytest.raises(rgpu.RgpuError) as e:
         rgpu.open_directory(str(tmp_path), field="missing")
     assert e.value.status == -2
+    # a later commit whose field infos were rewritten (doc-values update): _0_3.fnm replaces _0.fnm for that commit
+    commit = oracle.segments_file_read(open(str(tmp_path / "segments_2"), "rb").read(), 2)
+    fnm = open(str(tmp_path / "_0.fnm"), "rb").read()
+    sid0 = commit[0]["id"]
+    renumbered = oracle.field_infos_write([dict(name="title", number=0), dict(name="body", number=1, index_options=2),
+                                           dict(name="views", number=2, doc_values_type=1, dv_gen=3)], segment_id=sid0)
+    with open(str(tmp_path / "_0_3.fnm"), "wb") as fh:
+        fh.write(renumbered)
+    with open(str(tmp_path / "segments_3"), "wb") as fh:
+        fh.write(oracle.segments_file_write([dict(commit[0], max_doc=30_000, field_infos_gen=3, dv_gen=3), dict(commit[1], max_doc=12_000)],
+                                            generation=3))
+    os.remove(str(tmp_path / "_0.fnm"))                                    # only the generation file is left for segment _0
+    assert [l.field_number for l in rgpu.open_directory(str(tmp_path), field="body")] == [1, 1]
+    with open(str(tmp_path / "_0.fnm"), "wb") as fh:
+        fh.write(fnm)
+    os.remove(str(tmp_path / "segments_3"))
     os.remove(str(tmp_path / "segments_2"))
     assert len(rgpu.open_directory(str(tmp_path), field="body")) == 1    # falls back to the older commit point
     os.remove(str(tmp_path / "segments_1"))
