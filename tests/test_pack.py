@@ -1,0 +1,91 @@
+"""The mirror -> C ABI contract, checked without a GPU: what GpuIndexSearcher.pack puts into rgpu_query / rgpu_query_term for
+every tree shape the GPU path serves (include/rucene_gpu.h: op byte, min_should_match byte, optional-SHOULD byte, clause
+order MUST / SHOULD / MUST_NOT, absent terms, FILTER clauses as zero-weight MUST clauses, byte-named terms resolved through
+the block-tree dictionary)."""
+import numpy as np
+import pytest
+
+
+class _FakeCtx:
+    def __init__(self):
+        self.tables = []
+
+    def sim_table(self, cache, k1):
+        self.tables.append((np.asarray(cache).copy(), k1))
+        return 7
+
+
+@pytest.fixture(scope="module")
+def world(oracle):
+    import __graft_entry__ as g
+    g.build()
+    import rucene_amd
+    from rucene_amd import indexgen
+    seg = indexgen.build_zipf(20_000, 500, seed=3)
+    leaf = rucene_amd.LeafReader.from_synthetic(seg)
+    s = object.__new__(rucene_amd.GpuIndexSearcher)     # no Context: pack() is host-only
+    s.leaves, s.ctx, s.similarity, s._stats_leaf, s._weights = [leaf], _FakeCtx(), rucene_amd.BM25Similarity(), 0, {}
+    s.collection_statistics = rucene_amd.CollectionStatistics("body", 0, seg.max_doc, seg.doc_count, seg.sum_total_term_freq)
+    return rucene_amd, seg, leaf, s
+
+
+def test_ops_counts_and_clause_order(world):
+    ra, seg, leaf, s = world
+    T, B = ra.TermQuery, ra.BooleanQuery
+    queries = [T(3),
+               B.build([T(1), T(2), T(3)], []),
+               B.build([], [T(4), T(5)]),
+               B.build([], [T(4), T(5), T(6)], min_should_match=2),
+               B.build([T(1), T(2)], [], must_nots=[T(7), T(8)]),
+               B.build([T(1)], [T(9), T(10)], must_nots=[T(11)]),
+               B.build([T(1)], [], filters=[T(12)]),
+               B.build([], [], filters=[T(13)]),
+               B.build([T(1), T(499)], [T(-1)])]
+    q, t = s.pack(queries, leaf)
+    assert q["op"].tolist() == [0, 1, 2, 2 | 2 << 8, 1, 1 | 2 << 16, 1, 0, 1 | 1 << 16]
+    assert q["n_terms"].tolist() == [1, 3, 2, 3, 2, 1, 2, 1, 2]
+    assert q["n_must_not"].tolist() == [0, 0, 0, 0, 2, 1, 0, 0, 0]
+    assert q["first_term"].tolist() == [0, 1, 4, 6, 9, 13, 17, 19, 20]
+    ids = lambda lo, n: [int(np.flatnonzero(seg.terms["doc_start_fp"] == fp)[0]) if df else None
+                         for fp, df in zip(t["state"]["doc_start_fp"][lo:lo + n], t["state"]["doc_freq"][lo:lo + n])]
+    assert ids(9, 4) == [1, 2, 7, 8]                      # MUST, MUST, then the MUST_NOT clauses
+    assert ids(13, 4) == [1, 9, 10, 11]                   # MUST, the optional SHOULD clauses, then MUST_NOT
+    assert ids(17, 2) == [1, 12] and t["weight"][18] == 0.0 and t["weight"][17] > 0     # FILTER = zero-weight MUST
+    assert t["weight"][19] == 0.0                         # a lone FILTER: ConstantScoreQuery with boost 0
+    assert ids(20, 3) == [1, 499, None]                   # an absent term keeps its slot with doc_freq 0
+    assert t["state"]["skip_offset"][22] == -1 and t["state"]["singleton_doc_id"][22] == -1
+    assert (t["sim_table"][:23] == 7).all()
+    # weights are BM25 idf * boost with the statistics of the (only) leaf
+    w, _, _ = ra.bm25_compute_weight(1.2, 0.75, seg.max_doc, seg.doc_count, seg.sum_total_term_freq, [int(seg.terms[3]["doc_freq"])])
+    assert t["weight"][0] == np.float32(w)
+
+
+def test_clause_limit_and_unsupported_trees(world):
+    ra, seg, leaf, s = world
+    T, B = ra.TermQuery, ra.BooleanQuery
+    with pytest.raises(ra.RgpuError) as e:
+        s.pack([B.build([T(i) for i in range(9)], [T(i) for i in range(9, 17)])], leaf)     # 17 clauses > RGPU_MAX_QUERY_TERMS
+    assert e.value.status == -5
+    with pytest.raises(ra.RgpuError):
+        s.pack(["not a query"], leaf)
+
+
+def test_byte_terms_go_through_the_dictionary(world, oracle):
+    ra, seg, leaf, s = world
+    st = np.zeros(seg.terms.size, dtype=oracle.FULL_TERM_STATE_DTYPE)
+    st["base"] = seg.terms
+    st["last_pos_block_offset"] = -1
+    tim, tip = oracle.blocktree_write([dict(number=0, doc_count=seg.doc_count, terms=[b"t%04d" % i for i in range(seg.terms.size)], states=st)])
+    dleaf = ra.LeafReader(seg.doc_bytes, seg.norms, seg.max_doc, None, sum_total_term_freq=seg.sum_total_term_freq,
+                          term_dictionary=ra.TermDictionary(tim, tip, [(0, 2)], seg.max_doc), field_number=0)
+    s2 = object.__new__(ra.GpuIndexSearcher)
+    s2.leaves, s2.ctx, s2.similarity, s2._stats_leaf, s2._weights = [dleaf], _FakeCtx(), ra.BM25Similarity(), 0, {}
+    s2.collection_statistics = s.collection_statistics
+    T, B = ra.TermQuery, ra.BooleanQuery
+    by_id = s.pack([T(3), B.build([T(1), T(2)], [T(9)], must_nots=[T(4)])], leaf)
+    by_text = s2.pack([T(b"t0003"), B.build([T(b"t0001"), T(b"t0002")], [T(b"t0009")], must_nots=[T(b"t0004")])], dleaf)
+    assert by_id[0].tobytes() == by_text[0].tobytes() and by_id[1].tobytes() == by_text[1].tobytes()
+    q, t = s2.pack([T(b"nope")], dleaf)
+    assert t["state"]["doc_freq"][0] == 0
+    with pytest.raises(ra.RgpuError):
+        s.pack([T(b"t0003")], leaf)                      # a leaf without a dictionary cannot resolve bytes
