@@ -1,5 +1,6 @@
+"""Developer check (run by hand on a GPU box): decode and search parity against the ORACLE at a chosen corpus size. Uses the oracle,\nhence lives under tests/."""
 import sys, os, numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import rucene_amd
 from rucene_amd import indexgen
 from oracle import binding as orc
