@@ -28,6 +28,10 @@ def test_only_allowed_callers_use_the_oracle():
     for m in re.finditer(r"from oracle import binding", bench):
         before = bench[:m.start()]
         assert "cpu_baseline" in before[-2500:] or "no_cpu_baseline" in before[-2500:], "oracle import outside a cpu_baseline leg"
+    # developer scripts are not allowed callers: anything that needs the oracle lives under tests/ (tests/analysis)
+    for path in _files("scripts", (".py", ".sh")):
+        text = open(path, errors="replace").read()
+        assert not re.search(r"(from|import)\s+oracle\b", text) and "liboracle" not in text, path
 
 
 def test_nothing_reads_the_reference_at_run_time():
