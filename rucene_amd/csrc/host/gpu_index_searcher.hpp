@@ -14,8 +14,13 @@
 // TermIterator::seek_exact + term_state step of TermWeight::create_scorer, term_query.rs:150-180) — or, for synthetic
 // indexes, by an id into a flat table of BlockTermState records.
 #pragma once
+#include <dirent.h>
+
 #include <algorithm>
 #include <cstdint>
+#include <cstring>
+#include <fstream>
+#include <iterator>
 #include <map>
 #include <memory>
 #include <stdexcept>
@@ -132,6 +137,124 @@ struct LeafReader {
     if (q.term >= n_terms || terms[q.term].doc_freq <= 0) return false;
     *out = terms[q.term];
     return true;
+  }
+};
+
+// StandardDirectoryReader::open for the slice this path needs (index/reader/directory_reader.rs:90-140, segment_reader.rs):
+// the newest commit point segments_N names the segments; per segment .si gives max_doc, .fnm the field's number, then
+// _Lucene50_0.{doc,tim,tip}, .nvm/.nvd and _<delgen>.liv — taken out of .cfs for a compound segment. Owns every buffer the
+// LeafReaders point into; hand `leaves()` to a GpuIndexSearcher and keep this object alive as long as that searcher.
+class IndexDirectory {
+ public:
+  static std::unique_ptr<IndexDirectory> open(const std::string& path, const std::string& field) {
+    std::unique_ptr<IndexDirectory> dir(new IndexDirectory());
+    int64_t gen = -1;
+    {  // find_segment_file: the highest generation present
+      DIR* d = opendir(path.c_str());
+      if (!d) throw Error(RGPU_ERR_IO, "cannot list " + path);
+      while (dirent* e = readdir(d)) {
+        const std::string name = e->d_name;
+        if (name.compare(0, 9, "segments_") == 0 && name.size() > 9) gen = std::max<int64_t>(gen, (int64_t)std::stoll(name.substr(9), nullptr, 36));
+      }
+      closedir(d);
+    }
+    if (gen < 0) throw Error(RGPU_ERR_IO, "no segments_N file found in " + path);
+    const std::vector<uint8_t> commit_bytes = slurp(path + "/segments_" + base36((uint64_t)gen));
+    int32_t n = rgpu_commit_from_segments_file(commit_bytes.data(), commit_bytes.size(), gen, nullptr, 0);
+    check(n);
+    std::vector<rgpu_commit_segment> commit((size_t)n);
+    check(rgpu_commit_from_segments_file(commit_bytes.data(), commit_bytes.size(), gen, commit.data(), n));
+    int32_t doc_base = 0;
+    for (const rgpu_commit_segment& seg : commit) {
+      dir->segments_.emplace_back(new Segment());
+      Segment& s = *dir->segments_.back();
+      const std::string name = seg.name, stem = path + "/" + name;
+      const std::vector<uint8_t> si = slurp(stem + ".si");
+      rgpu_segment_info info;
+      check(rgpu_segment_info_from_lucene62(si.data(), si.size(), seg.id, &info));
+      if (seg.del_count > info.max_doc) throw Error(RGPU_ERR_CORRUPT_INDEX, "invalid deletion count");
+      std::vector<uint8_t> cfs;
+      std::vector<rgpu_compound_entry> entries;
+      if (info.is_compound_file) {
+        cfs = slurp(stem + ".cfs");
+        const std::vector<uint8_t> cfe = slurp(stem + ".cfe");
+        int32_t ne = rgpu_compound_entries_from_lucene50(cfe.data(), cfe.size(), cfs.data(), cfs.size(), seg.id, nullptr, 0);
+        check(ne);
+        entries.resize((size_t)ne);
+        check(rgpu_compound_entries_from_lucene50(cfe.data(), cfe.size(), cfs.data(), cfs.size(), seg.id, entries.data(), ne));
+      }
+      auto part = [&](const std::string& suffix) -> std::vector<uint8_t> {
+        if (!info.is_compound_file) return slurp(stem + suffix);
+        for (const rgpu_compound_entry& e : entries)
+          if (suffix == e.id) return std::vector<uint8_t>(cfs.begin() + e.offset, cfs.begin() + e.offset + e.length);
+        throw Error(RGPU_ERR_IO, name + suffix + " is not in the compound file");
+      };
+      const std::vector<uint8_t> fnm = seg.field_infos_gen > 0 ? slurp(stem + "_" + base36((uint64_t)seg.field_infos_gen) + ".fnm") : part(".fnm");
+      size_t names_len = 0;
+      int32_t nf = rgpu_field_infos_from_lucene60(fnm.data(), fnm.size(), nullptr, 0, nullptr, 0, &names_len);
+      check(nf);
+      std::vector<rgpu_field_info> infos((size_t)nf);
+      std::vector<char> names(names_len + 1);
+      check(rgpu_field_infos_from_lucene60(fnm.data(), fnm.size(), infos.data(), nf, names.data(), names_len, &names_len));
+      int32_t field_number = -1, index_options = 0;
+      std::vector<rgpu_field_info> indexed;
+      const char* p = names.data();
+      for (int32_t i = 0; i < nf; ++i, p += std::strlen(p) + 1) {
+        if (infos[(size_t)i].index_options != 0) indexed.push_back(infos[(size_t)i]);
+        if (field == p) { field_number = infos[(size_t)i].number; index_options = infos[(size_t)i].index_options; }
+      }
+      if (field_number < 0) throw Error(RGPU_ERR_ILLEGAL_ARGUMENT, "no field named " + field + " in segment " + name);
+      if (index_options != 2) throw Error(RGPU_ERR_UNSUPPORTED, "the searched field must be indexed with IndexOptions::DocsAndFreqs");
+      s.doc = part("_Lucene50_0.doc");
+      const std::vector<uint8_t> tim = part("_Lucene50_0.tim"), tip = part("_Lucene50_0.tip"), nvm = part(".nvm"), nvd = part(".nvd");
+      check(rgpu_terms_open(tim.data(), tim.size(), tip.data(), tip.size(), indexed.data(), (int32_t)indexed.size(), info.max_doc, &s.terms));
+      s.norms.resize((size_t)info.max_doc);
+      check(rgpu_norms_from_lucene53(nvm.data(), nvm.size(), nvd.data(), nvd.size(), field_number, info.max_doc, s.norms.data()));
+      if (seg.del_gen >= 0 && seg.del_count > 0) {
+        const std::vector<uint8_t> liv = slurp(stem + "_" + base36((uint64_t)seg.del_gen) + ".liv");
+        s.live.resize((size_t)((info.max_doc + 63) / 64));
+        check(rgpu_live_docs_from_lucene50(liv.data(), liv.size(), info.max_doc, seg.del_count, s.live.data()));
+      }
+      rgpu_field_stats stats;
+      check(rgpu_terms_field_stats(s.terms, field_number, &stats));
+      LeafReader leaf;
+      leaf.doc_bytes = s.doc.data();
+      leaf.doc_len = s.doc.size();
+      leaf.norms = s.norms.data();
+      leaf.live_docs = s.live.empty() ? nullptr : s.live.data();
+      leaf.max_doc = info.max_doc;
+      leaf.doc_base = doc_base;
+      leaf.doc_count = stats.doc_count;
+      leaf.sum_total_term_freq = stats.sum_total_term_freq;
+      leaf.sum_doc_freq = stats.sum_doc_freq;
+      leaf.dictionary = s.terms;
+      leaf.field_number = field_number;
+      dir->leaves_.push_back(leaf);
+      doc_base += info.max_doc;
+    }
+    return dir;
+  }
+  const std::vector<LeafReader>& leaves() const { return leaves_; }
+
+ private:
+  struct Segment {
+    std::vector<uint8_t> doc, norms;
+    std::vector<uint64_t> live;
+    rgpu_terms* terms = nullptr;
+    ~Segment() { rgpu_terms_close(terms); }
+  };
+  std::vector<std::unique_ptr<Segment>> segments_;
+  std::vector<LeafReader> leaves_;
+
+  static std::vector<uint8_t> slurp(const std::string& file) {
+    std::ifstream f(file, std::ios::binary);
+    if (!f) throw Error(RGPU_ERR_IO, "cannot open " + file);
+    return std::vector<uint8_t>(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+  }
+  static std::string base36(uint64_t v) {  // util/numeric.rs:148-160
+    std::string r;
+    do { r.insert(r.begin(), "0123456789abcdefghijklmnopqrstuvwxyz"[v % 36]); v /= 36; } while (v);
+    return r;
   }
 };
 

@@ -251,3 +251,32 @@ def test_compound_files(rgpu, oracle, tmp_path):
         rgpu.compound_files_from_lucene50(cfe, cfs, expected_id=bytes(16))
     with pytest.raises(oracle.OracleError):                                        # a file of another segment cannot be packed
         oracle.compound_write({"_1.fnm": oracle.field_infos_write([], segment_id=bytes(range(16)))}, sid)
+
+
+def test_cpp_mirror_opens_directories(rgpu, oracle, tmp_path):
+    """rucene::IndexDirectory::open (the C++ host mirror, header-only over the C ABI) reads the same directories as the Python
+    mirror: plain and compound segments, deletions, term resolution by bytes. Host-only: no GPU is touched."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "rucene_amd")
+    exe = str(tmp_path / "open_dir")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-Wextra", "-o", exe, os.path.join(root, "tests", "cpp", "open_directory_demo.cpp"),
+                           "-L" + libdir, "-lrucene_gpu", "-Wl,-rpath," + libdir, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
+    d = tmp_path / "idx"
+    d.mkdir()
+    segs, lives, inner, sid, cfs, cfe = _compound_directory(oracle, str(d))
+    out = subprocess.check_output([exe, str(d), "body", "w00000", "w00007", "w00899", "w01500", "nope"], text=True).strip().splitlines()
+    leaves = rgpu.open_directory(str(d), field="body")
+    assert len(out) == 2
+    for line, leaf, seg in zip(out, leaves, segs):
+        parts = line.split()
+        assert [int(x) for x in parts[1:8]] == [leaf.max_doc, leaf.doc_base, leaf.doc_count, leaf.sum_total_term_freq, leaf.sum_doc_freq,
+                                                 leaf.field_number, int(leaf.live_docs is not None)]
+        for tok, t in zip(parts[8:], (0, 7, 899, 1500, None)):
+            st = None if t is None or t >= seg.terms.size else seg.terms[t]
+            assert tok == ("-" if st is None else "%d@%d" % (st["doc_freq"], st["doc_start_fp"]))
+    golden = os.path.join(root, "tests", "golden", "dir")
+    line = subprocess.check_output([exe, golden, "body", "w000", "w039", "w040"], text=True).split()
+    assert line[1:4] == ["3000", "0", "3000"] and line[-1] == "-" and line[7] == "1"
+    bad = subprocess.run([exe, golden, "stored"], capture_output=True, text=True)
+    assert bad.returncode == 1 and bad.stdout.startswith("error -5")
