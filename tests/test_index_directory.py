@@ -280,3 +280,61 @@ def test_cpp_mirror_opens_directories(rgpu, oracle, tmp_path):
     assert line[1:4] == ["3000", "0", "3000"] and line[-1] == "-" and line[7] == "1"
     bad = subprocess.run([exe, golden, "stored"], capture_output=True, text=True)
     assert bad.returncode == 1 and bad.stdout.startswith("error -5")
+
+
+def test_randomised_metadata_files_product_vs_oracle(rgpu, oracle):
+    """Differential check on many VALID files of random shape: names of 0..300 bytes (vint lengths of 1 and 2 bytes), non-ASCII
+    names, attribute maps, many fields / segments, every flag combination the writers allow."""
+    import random
+    rng = random.Random(99)
+
+    def name(lo=1):
+        n = rng.choice([lo, 1, 5, 127, 128, 300])
+        return "".join(rng.choice("abcXYZ_09-é中") for _ in range(max(n, lo)))
+    for _ in range(60):
+        # .fnm
+        fields, used = [], set()
+        for number in sorted(rng.sample(range(0, 5000), rng.randint(0, 25))):
+            nm = name()
+            while nm in used:
+                nm = name()
+            used.add(nm)
+            opts = rng.choice([0, 1, 2, 3, 4])
+            dvt = rng.choice([0, 0, 1, 2, 3, 4, 5])
+            fields.append(dict(name=nm, number=number, index_options=opts, store_term_vector=opts > 0 and rng.random() < 0.3,
+                               omit_norms=rng.random() < 0.3, store_payloads=opts >= 3 and rng.random() < 0.5, doc_values_type=dvt,
+                               dv_gen=rng.choice([-1, 7]) if dvt else -1,
+                               attributes={name(0): name(0) for _ in range(rng.randint(0, 3))},
+                               point_dimension_count=rng.choice([0, 0, 2]), point_num_bytes=0))
+            if fields[-1]["point_dimension_count"]:
+                fields[-1]["point_num_bytes"] = rng.choice([4, 8])
+        sid = bytes(rng.randrange(256) for _ in range(16))
+        fnm = oracle.field_infos_write(fields, segment_id=sid, suffix=rng.choice(["", "x"]))
+        want = oracle.field_infos_read(fnm)
+        got = rgpu.field_infos_from_lucene60(fnm)
+        assert [(g["name"], g["number"], g["index_options"], g["has_payloads"], g["omit_norms"], g["store_term_vector"], g["doc_values_type"])
+                for g in got] == [(w["name"], w["number"], w["index_options"], w["store_payloads"], w["omit_norms"], w["store_term_vector"],
+                                   w["doc_values_type"]) for w in want]
+        # .si
+        seg_name = "_" + np.base_repr(rng.randrange(36 ** 3), 36).lower()
+        files = sorted({seg_name + rng.choice([".fnm", ".nvd", "_Lucene50_0.doc", ".cfs", "_1.liv", ".si"]) for _ in range(rng.randint(0, 6))})
+        si = oracle.segment_info_write(seg_name, rng.randrange(0, 2 ** 31 - 1), segment_id=sid, files=files, is_compound_file=rng.random() < 0.5,
+                                       version=(rng.randint(5, 9), rng.randint(0, 255), rng.randint(0, 255)),
+                                       diagnostics={name(0): name(0) for _ in range(rng.randint(0, 4))},
+                                       attributes={name(0): name(0) for _ in range(rng.randint(0, 2))})
+        w = oracle.segment_info_read(si, sid)
+        g = rgpu.segment_info_from_lucene62(si, expected_id=sid)
+        assert {k: g[k] for k in ("max_doc", "is_compound_file", "version", "n_files", "id")} == {k: w[k] for k in ("max_doc", "is_compound_file", "version", "n_files", "id")}
+        # segments_N
+        gen = rng.choice([1, 35, 36, 1295, 1296, 10 ** 9])
+        segs = []
+        for i in range(rng.randint(0, 40)):
+            md = rng.randrange(1, 10 ** 7)
+            dg = rng.choice([-1, -1, 1, 40])
+            segs.append(dict(name="_" + np.base_repr(i, 36).lower(), id=bytes(rng.randrange(256) for _ in range(16)), max_doc=md, del_gen=dg,
+                             del_count=rng.randrange(0, md + 1) if dg > 0 else 0, field_infos_gen=rng.choice([-1, 2]), dv_gen=rng.choice([-1, 2]),
+                             version=(rng.randint(5, 6), rng.randint(0, 9), 0)))
+        data = oracle.segments_file_write(segs, generation=gen, version=rng.randrange(2 ** 40), counter=len(segs))
+        w = oracle.segments_file_read(data, gen, max_docs=[s["max_doc"] for s in segs])
+        g = rgpu.commit_from_segments_file(data, gen)
+        assert [{k: x[k] for k in w[0]} for x in g] == w if w else g == []
