@@ -1,8 +1,9 @@
 """Executable specification of the block-max pruning planned for k_search_term — a numpy model, no GPU
-code. Per FullBlock one 64-bit word: for every freq value 1..10 the largest norm rank (6 bits, 0 = no such posting) among the
-block's postings with that freq — the block's Pareto frontier in (freq, rank), which carries its exact maximum score under ANY
-similarity table. Per query the score table's prefix maximum over ranks; a block's bound is the largest of the ten entries
-`pmax[rank_f][f]`; the skip test is "bound bits < threshold bits" with the kernel's tie rule (strict once every remaining doc
+code. Per FullBlock one 64-bit word: bits 0..3 the largest freq (15 = some freq > 10: no bound), then for every freq value
+1..10 six bits with the largest norm rank among the block's postings with that freq (0 when there is none) — the block's Pareto
+frontier in (freq, rank), which carries its exact maximum score under ANY similarity table. Per query the score table's 2-D
+prefix maximum (over ranks, then freqs: robust to rounding and to the rank-0 filler of absent freqs); a block's bound is the
+largest of the entries `pmax[rank_f][f]`, f = 1..largest freq; the skip test is "bound bits < threshold bits" with the kernel's tie rule (strict once every remaining doc
 lies after the threshold's doc). A first design with two bytes per block (largest freq, largest rank) was modelled here too: it
 prunes only ~20 % of the blocks the exact bound prunes, because the posting with both extremes rarely exists. The model must return exactly what the oracle's TermScorer + TopDocsCollector return (canonical order) and count every
 posting, whatever the order in which independent work items run and share their lists. It also reports how many blocks it
@@ -53,19 +54,31 @@ def _thr(tau, seen_doc):
     return bits + 1 if doc <= seen_doc else bits
 
 
+def frontier_words(freqs, ranks):
+    """The per-block directory word k_prepare_blocks would build (n_blocks x 128 freqs / ranks -> uint64[n_blocks])."""
+    assert ranks.max() < 64
+    words = np.zeros(freqs.shape[0], dtype=np.uint64)
+    fmax = freqs.max(axis=1)
+    words |= np.where(fmax > 10, 15, fmax).astype(np.uint64)
+    for fv in range(1, 11):
+        best = np.where(freqs == fv, ranks, 0).max(axis=1).astype(np.uint64)
+        words |= best << np.uint64(4 + 6 * (fv - 1))
+    return words
+
+
 def model_search(docs, freqs, ranks, table, k, items, order):
     """docs/freqs/ranks: the term's FullBlock postings (n_blocks x 128). items: list of (first block, last block + 1); order: the
     sequence in which (item index) steps run one block each — any interleaving. All items share ONE list (a workgroup group)."""
-    pmax = np.maximum.accumulate(table, axis=0)                                     # prefix max over ranks (robust to any cache[] order)
+    pmax = np.maximum.accumulate(np.maximum.accumulate(table, axis=0), axis=1)      # 2-D prefix max: ranks, then freqs
     nb = docs.shape[0]
-    frontier = np.full((nb, 11), -1, dtype=np.int64)                                # [block][freq] = largest rank, -1 = none
-    usable_block = freqs.max(axis=1) <= 10
-    for fv in range(1, 11):
-        frontier[:, fv] = np.where(freqs == fv, ranks, -1).max(axis=1)
+    words = frontier_words(freqs, ranks)
+    usable_block = (words & np.uint64(15)) != np.uint64(15)
     bound_bits = np.zeros(nb, dtype=np.uint32)
     for b in range(nb):
-        vals = [pmax[frontier[b, fv], fv] for fv in range(1, 11) if frontier[b, fv] >= 0]
-        bound_bits[b] = np.max(np.asarray(vals, dtype=np.float32)).view(np.uint32) if vals else 0
+        w = int(words[b])
+        fmax = w & 15
+        if fmax != 15:
+            bound_bits[b] = max(pmax[(w >> (4 + 6 * (fv - 1))) & 63, fv] for fv in range(1, fmax + 1)).view(np.uint32)
     top, skipped, count = _TopK(k), 0, 0
     cursor = [a for a, _ in items]
     seen = [(-1 if a == 0 else int(docs[a - 1, -1])) for a, _ in items]
