@@ -69,6 +69,29 @@ def main(n_docs=10_000_000, n_terms=1_000_000, n_queries=96, k=10):
                             else:
                                 feed(heap, g[bi])
         print("group-local threshold, %3d blocks per item: %.1f%% skippable" % (blocks_per_item, 100.0 * skipped / total))
+    # the same, but every group starts from the threshold its query's HEAD item (the first `blocks_per_item` blocks, run in an
+    # earlier wave of workgroups) has published — what SharedTau already transports today
+    for blocks_per_item in (8, 32, 128):
+        skipped = 0
+        for g in per_term:
+            nb, gmax = g.shape[0], g.max(axis=1)
+            head = []
+            for bi in range(min(nb, blocks_per_item)):
+                feed(head, g[bi])
+            floor = head[0] if len(head) == k else -1.0
+            for g0 in range(0, nb, 8 * blocks_per_item):
+                heap = []
+                items = [range(g0 + i * blocks_per_item, min(nb, g0 + (i + 1) * blocks_per_item)) for i in range(8)]
+                for step in range(blocks_per_item):
+                    for it in items:
+                        if step < len(it):
+                            bi = it[step]
+                            thr = max(floor, heap[0]) if len(heap) == k else floor
+                            if gmax[bi] <= thr:
+                                skipped += 1
+                            else:
+                                feed(heap, g[bi])
+        print("head item's threshold + group-local, %3d blocks per item: %.1f%% skippable" % (blocks_per_item, 100.0 * skipped / total))
 
 
 if __name__ == "__main__":
