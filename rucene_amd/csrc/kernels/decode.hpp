@@ -285,6 +285,9 @@ __device__ __forceinline__ void stream_blocks(const uint8_t* __restrict__ term_r
 }
 
 // ---- VInt tail (< 128 postings) -------------------------------------------------------------------------------
+#ifndef RGPU_TAIL_INLINE
+#define RGPU_TAIL_INLINE __forceinline__
+#endif
 // posting i: code = vint; delta = code >>> 1; freq = (code & 1) ? 1 : vint        (posting_reader.rs:316-325)
 // Parallel formulation: (1) every lane scans 20 bytes for VInt terminators, a wave scan turns terminator counts
 // into value indices and each terminator lane assembles its value by looking back over continuation bytes;
@@ -298,7 +301,7 @@ __device__ __forceinline__ uint32_t compose_fn(uint32_t first, uint32_t then) {
   return r0 | (r1 << 1);
 }
 
-__device__ __forceinline__ void decode_tail(const uint8_t* __restrict__ tail, int n, int32_t base, uint8_t* slab, int lane,
+__device__ RGPU_TAIL_INLINE void decode_tail(const uint8_t* __restrict__ tail, int n, int32_t base, uint8_t* slab, int lane,
                                             int32_t& doc0, int32_t& doc1, uint32_t& f0, uint32_t& f1) {
   uint8_t* bytes = slab;                                              // [0, 1296)
   uint32_t* vals = reinterpret_cast<uint32_t*>(slab + 1296);         // 256 values (+ 8 pad words)

@@ -193,6 +193,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_blocks(const uint8_t* 
                                                                   const uint32_t* __restrict__ dir_row,
                                                                   const uint16_t* __restrict__ dir_hdr, uint8_t* bstore,
                                                                   const uint8_t* __restrict__ norms, uint8_t* pnorm,
+                                                                  uint64_t* __restrict__ dir_bmax, int ranked,
                                                                   const int* __restrict__ err) {
   __shared__ __attribute__((aligned(16))) uint8_t slabs[PREP_THREADS / 64][SLAB_BYTES];
   const int lane = lane_id();
@@ -228,6 +229,20 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_blocks(const uint8_t* 
       // a corrupt block must not turn into a wild gather
       const uint32_t n0 = d0 >= 0 ? norms[d0] : 0u, n1 = d1 >= 0 ? norms[d1] : 0u;
       *reinterpret_cast<uint16_t*>(pnorm + t.pn_base + 128 * (uint64_t)blk + 2 * lane) = (uint16_t)(n0 | (n1 << 8));
+      // the block's (freq, norm rank) frontier word (SegView::dir_bmax)
+      uint64_t w = 15ull;
+      const uint32_t fmax = wave_reduce_max_u32(bp.f0 > bp.f1 ? bp.f0 : bp.f1);
+      if (ranked && fmax <= 10u) {
+        w = fmax;
+#pragma unroll
+        for (uint32_t f = 1; f <= 10; ++f) {
+          const uint32_t r0 = bp.f0 == f ? n0 : 0u, r1 = bp.f1 == f ? n1 : 0u;
+          w |= (uint64_t)(wave_reduce_max_u32(r0 > r1 ? r0 : r1) & 63u) << (4 + 6 * (f - 1));
+        }
+      }
+      if (lane == 0) dir_bmax[t.dir_base + blk] = w;
+    } else if (lane == 0) {
+      dir_bmax[t.dir_base + blk] = 15ull;
     }
   }
 }

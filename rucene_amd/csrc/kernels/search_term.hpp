@@ -15,10 +15,13 @@
 
 namespace rgpu {
 
-#ifdef RGPU_EXP_COUNT  // developer instrumentation (variant builds only): [0] blocks, [1] blocks that took the doc-id path
+#ifdef RGPU_EXP_COUNT  // developer instrumentation (variant builds only): [0] blocks, [1] blocks that took the doc-id path, [2] blocks looked at (not pruned)
 __device__ unsigned long long g_term_dbg[4];
 #endif
 
+#ifndef RGPU_TERM_PRUNE  // 0: variant builds that measure the unpruned kernel
+#define RGPU_TERM_PRUNE 1
+#endif
 #ifndef RGPU_TERM_WAVES
 #define RGPU_TERM_WAVES 8
 #endif
@@ -95,16 +98,25 @@ __device__ __forceinline__ void group_offer2(const GroupList& g, uint64_t key0, 
 }
 
 // TermScorer fast path: FullBlocks of a term whose scores come from the LDS table (norm ranks, weight >= 0, no
-// deleted docs). The kernel is VALU-issue bound (rocprofv3: ~77 VALU/block at 86% VALU busy before this path
-// existed), so a block only does what its outcome can depend on: stage the rows, unpack the FREQ stream, two
-// table reads, one compare of the raw score bits against the threshold's. The doc-delta stream is unpacked
-// and prefix-summed only when some posting can still enter the top-k — its base doc then comes from the block
-// directory (dir_last), not from a running scan. Every posting is still counted (TopDocsCollector::total_hits)
-// and every candidate offered, so results are those of the plain loop.
+// deleted docs). The kernel is VALU-issue bound (rocprofv3: 38 VALU + 29 SALU per block at ~80 % VALU busy), so a
+// block only does what its outcome can depend on:
+//   0. (PRUNE) nothing at all when its frontier word (SegView::dir_bmax: largest norm rank per freq) bounds every
+//      posting's score below the entry threshold — 64 blocks are tested at once, one lane each, ten table reads;
+//   1. otherwise stage the rows, unpack the FREQ stream, two table reads, one compare of the raw score bits;
+//   2. the doc-delta stream is unpacked and prefix-summed only when some posting can still enter the top-k — its
+//      base doc then comes from the block directory (dir_last), not from a running scan.
+// Every posting is still counted (TopDocsCollector::total_hits: no deletions on this path, so a block is 128 hits
+// whether it is looked at or not) and every candidate offered, so results are those of the plain loop; the reference
+// itself has no such pruning (term_scorer.rs:43-67 scores every posting) — exactness is the constraint here.
+// The bound is exact in f32: table[r][f] is produced by the very expression that scores a posting, and it does not
+// fall as the rank r grows when the sim table's cache does not rise with the norm byte (checked on the host,
+// TERM_FLAG_MONOTONE) and the weight is >= 0 — x / y with x >= 0 fixed and y = f + cache[r] > 0 shrinking, correctly
+// rounded. Absent freqs carry rank 0, whose entry the bound of the block's largest freq dominates up to rounding;
+// either way the maximum is taken over a superset of the block's (rank, freq) pairs.
 template <bool LEGACY, bool WIDE>
 __device__ __forceinline__ void term_blocks_fast(const SegView& seg, const DevTerm& T, int b0, int b1, uint8_t* slab,
                                                  const float* cache, float wk, int lane, const GroupList& group,
-                                                 uint64_t floor, int k, int& count) {
+                                                 uint64_t floor, int k, int& count, bool prune) {
   constexpr int DEPTH = PREFETCH_DEPTH;
   const uint8_t* term_rows = seg.bstore + T.bs_base;
   const uint8_t* pn = seg.pnorm + T.pn_base;
@@ -129,16 +141,42 @@ __device__ __forceinline__ void term_blocks_fast(const SegView& seg, const DevTe
   uint64_t tau = fresh_tau();
   uint32_t thr = pin(thr_of(tau));
 #ifdef RGPU_EXP_COUNT
-  int dbg_slow = 0;
+  int dbg_slow = 0, dbg_looked = 0;
 #endif
+  // a chunk's directory entries (and frontier words) arrive one chunk ahead of their use
+  struct Chunk { DirChunk dir; uint64_t bmax; };
+  auto load_chunk = [&](int c0) -> Chunk {
+    Chunk c;
+    const int nb = min(64, b1 - c0);
+    c.dir.load(seg.dir_row, seg.dir_hdr, T.dir_base, c0, nb, lane);
+    c.bmax = (prune && lane < nb) ? seg.dir_bmax[T.dir_base + c0 + lane] : 0ull;
+    return c;
+  };
+  Chunk next = load_chunk(b0);
   for (int c0 = b0; c0 < b1; c0 += 64) {
     const int nb = min(64, b1 - c0);
-    DirChunk dir;
-    dir.load(seg.dir_row, seg.dir_hdr, T.dir_base, c0, nb, lane);
+    const Chunk cur = next;
+    if (c0 + 64 < b1) next = load_chunk(c0 + 64);
+    const DirChunk& dir = cur.dir;
     if (c0 > b0) {  // blocks skipped on the cheap path moved the position too
       const int32_t upto = seg.dir_last[T.dir_base + c0 - 1];
       seen_doc = upto > seen_doc ? upto : seen_doc;
     }
+    count += 128 * nb;
+    // lane j: the best score any posting of block c0 + j can have (raw bits; scores are >= 0 here)
+    uint32_t best = 0xffffffffu;
+    if (prune) {
+      const uint32_t fmax = (uint32_t)cur.bmax & 15u;
+      uint32_t bb = 0u;
+#pragma unroll
+      for (int f = 1; f <= SCORE_TABLE_FREQS; ++f) {
+        const uint32_t r = (uint32_t)(cur.bmax >> (4 + 6 * (f - 1))) & 63u;
+        const uint32_t sc = __float_as_uint(table_score(cache, r, (uint32_t)f));
+        bb = ((uint32_t)f <= fmax && sc > bb) ? sc : bb;
+      }
+      best = fmax > (uint32_t)SCORE_TABLE_FREQS ? 0xffffffffu : bb;
+    }
+    const uint64_t in_chunk = nb == 64 ? ~0ull : ((1ull << nb) - 1ull);
     auto step = [&](int idx, const uint4& rows, uint32_t nn) {
       const uint32_t hdr = dir.hdr_at(idx);
       const int bf = hdr_bfreq(hdr);
@@ -163,7 +201,9 @@ __device__ __forceinline__ void term_blocks_fast(const SegView& seg, const DevTe
         s0 = bm25_score(wk, (float)(int32_t)f0, cache[nb0]);
         s1 = bm25_score(wk, (float)(int32_t)f1, cache[nb1]);
       }
-      count += 128;
+#ifdef RGPU_EXP_COUNT
+      ++dbg_looked;
+#endif
       const uint32_t r0 = __float_as_uint(s0), r1 = __float_as_uint(s1);
       if (__ballot((r0 > r1 ? r0 : r1) >= thr)) {
 #ifdef RGPU_EXP_COUNT
@@ -188,36 +228,51 @@ __device__ __forceinline__ void term_blocks_fast(const SegView& seg, const DevTe
     auto norms_of = [&](int idx) -> uint32_t {
       return *reinterpret_cast<const uint16_t*>(pn + (128u * (uint32_t)(c0 + idx) + 2u * (uint32_t)lane));
     };
-    const int last = nb - 1;
+    // Blocks that may still matter, streamed through a DEPTH-deep ring of row (and norm) loads. `todo` is re-filtered
+    // with the threshold of the moment before every round: the threshold only rises, so a stale test is merely
+    // conservative. Ring slots without a block (slot[j] < 0) reload the chunk's first block instead of being guarded:
+    // a redundant load is cheaper than a load behind a branch.
+    uint64_t todo = in_chunk & __ballot(best >= thr);
+    int slot[DEPTH];
     uint4 ring[DEPTH];
     uint32_t nring[DEPTH];
+    auto take = [&]() -> int {
+      if (!todo) return -1;
+      const int i = (int)__builtin_ctzll(todo);
+      todo &= todo - 1;
+      return i;
+    };
 #pragma unroll
     for (int j = 0; j < DEPTH; ++j) {
-      const int pj = min(j, last);
+      slot[j] = take();
+      const int pj = slot[j] < 0 ? 0 : slot[j];
       ring[j] = block_rows_load(block_rows_at(term_rows, dir.row_at(pj)), dir.hdr_at(pj), lane);
       nring[j] = norms_of(pj);
     }
-    int i = 0;
-    for (; i + DEPTH <= nb; i += DEPTH) {
+    while (slot[0] >= 0) {  // slots fill in order, so an empty slot 0 means an empty ring
       // what the group's other wavefronts achieved meanwhile: one LDS read per DEPTH blocks
       tau = fresh_tau();
       thr = pin(thr_of(tau));
+      if (prune) todo &= __ballot(best >= thr);
 #pragma unroll
-      for (int j = 0; j < DEPTH; ++j) {
+      for (int j = 0; j < DEPTH; ++j) {  // static ring slot j
         const uint4 rows = ring[j];
         const uint32_t nn = nring[j];
-        const int pj = min(i + j + DEPTH, last);
+        const int idx = slot[j];
+        slot[j] = take();
+        const int pj = slot[j] < 0 ? 0 : slot[j];
         ring[j] = block_rows_load(block_rows_at(term_rows, dir.row_at(pj)), dir.hdr_at(pj), lane);
         nring[j] = norms_of(pj);
-        step(i + j, rows, nn);
+        if (idx >= 0) step(idx, rows, nn);
       }
     }
-#pragma unroll
-    for (int j = 0; j < DEPTH - 1; ++j)
-      if (i + j < nb) step(i + j, ring[j], nring[j]);
   }
 #ifdef RGPU_EXP_COUNT
-  if (lane == 0) { atomicAdd(&g_term_dbg[0], (unsigned long long)(b1 - b0)); atomicAdd(&g_term_dbg[1], (unsigned long long)dbg_slow); }
+  if (lane == 0) {
+    atomicAdd(&g_term_dbg[0], (unsigned long long)(b1 - b0));
+    atomicAdd(&g_term_dbg[1], (unsigned long long)dbg_slow);
+    atomicAdd(&g_term_dbg[2], (unsigned long long)dbg_looked);
+  }
 #endif
 }
 
@@ -321,7 +376,8 @@ __global__ __launch_bounds__(TERM_THREADS, 8) void k_search_term(SegView seg, co
       collect(std::true_type{}, d0, d1, f0, f1, nb0, nb1, true, true);
     };
     if (tabled && !has_live && nonneg) {
-      term_blocks_fast<LEGACY, WIDE>(seg, T, b0, b1, slab, cache, wk, lane, group, floor, k, count);
+      term_blocks_fast<LEGACY, WIDE>(seg, T, b0, b1, slab, cache, wk, lane, group, floor, k, count,
+                                     RGPU_TERM_PRUNE && (T.flags & TERM_FLAG_MONOTONE) != 0u);
       if (b1 > b0) base = seg.dir_last[T.dir_base + b1 - 1];
     } else if (has_norms) {
       stream_blocks<LEGACY, true>(term_rows, seg.dir_row, seg.dir_hdr, T.dir_base, seg.pnorm + T.pn_base, b0, b1, slab, lane, base, on_block);

@@ -13,6 +13,12 @@ struct SegView {
   const uint32_t* dir_off;   // block directory: byte offset of block i from the term's doc_start_fp (slot nblocks: the tail)
   const uint32_t* dir_row;   // block directory: first 16-byte row of block i in the block store, from the term's bs_base
   const uint16_t* dir_hdr;   // block directory: b_doc | vint_len << 6 | b_freq << 9
+  // Block directory: the block's (freq, norm rank) frontier — bits 0..3 = its largest freq (15: some freq > 10, "no
+  // bound"), then for freq f = 1..10 six bits with the largest norm RANK among the block's postings of that freq (0 when
+  // there is none). With a similarity whose score grows with the norm rank (BM25: shorter doc, larger norm byte) the
+  // block's best possible score under ANY clause weight is max over f <= largest freq of table[rank_f][f]: the TERM
+  // kernel skips a block outright when that bound cannot enter the top-k (search_term.hpp). Built by k_prepare_blocks.
+  const uint64_t* dir_bmax;
   // Block store: the FullBlock payloads of every prepared term, copied once (k_prepare_terms) to 16-byte aligned
   // rows: block i = [max(b_doc,1) doc rows][max(b_freq,1) freq rows]; a row is 16 bytes of the BP128 / packed
   // stream exactly as in the .doc file, an all-equal stream (b == 0) is one row holding its value as a u32.
@@ -47,7 +53,10 @@ struct DevTerm {
   int32_t singleton_freq;
   float weight;           // idf * boost
   int32_t sim_table;
+  uint32_t flags;         // bit 0: the sim table's norm cache is non-increasing in the norm byte (block-max bounds hold)
+  uint32_t pad;
 };
+constexpr uint32_t TERM_FLAG_MONOTONE = 1u;
 
 // Work description of one term for the skip-decode ("prepare") kernel.
 struct PrepTerm {

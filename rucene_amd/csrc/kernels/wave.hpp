@@ -59,6 +59,18 @@ __device__ __forceinline__ int wave_reduce_add(int v) {
   return readlane(wave_incl_scan(v), 63);
 }
 
+// max over the 64 lanes (unsigned), returned as a scalar; out-of-range DPP sources read 0
+__device__ __forceinline__ uint32_t wave_reduce_max_u32(uint32_t v) {
+  auto mx = [](uint32_t a, int b) { return a > (uint32_t)b ? a : (uint32_t)b; };
+  v = mx(v, dpp_or0<0x111, 0xf>((int)v));
+  v = mx(v, dpp_or0<0x112, 0xf>((int)v));
+  v = mx(v, dpp_or0<0x114, 0xf>((int)v));
+  v = mx(v, dpp_or0<0x118, 0xf>((int)v));
+  v = mx(v, dpp_or0<0x142, 0xa>((int)v));
+  v = mx(v, dpp_or0<0x143, 0xc>((int)v));
+  return (uint32_t)readlane((int)v, 63);
+}
+
 // number of set bits of `mask` below this lane
 __device__ __forceinline__ int mbcnt(uint64_t mask) {
   return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));

@@ -118,6 +118,7 @@ struct rgpu_ctx {
   std::mutex mu;
   DevVec<float> sim_tables;
   int n_sim_tables = 0;
+  std::vector<uint8_t> sim_monotone;  // per table: cache[] finite, >= 0 and non-increasing in the norm byte
   // Per-call scratch, in rotating slots: a search call only enqueues work (staging copy + kernels) on its stream
   // and marks its slot with an event; the slot is waited for when its turn comes again, so the host prepares batch
   // i+1 while the GPU runs batch i and a caller synchronizes the stream once, when it wants the results.
@@ -150,6 +151,7 @@ struct rgpu_segment {
   DevVec<uint32_t> dir_off;
   DevVec<uint32_t> dir_row;
   DevVec<uint16_t> dir_hdr;
+  DevVec<uint64_t> dir_bmax;  // per block: (freq, norm rank) frontier word (SegView::dir_bmax)
   size_t dir_used = 0;
   DevVec<uint8_t> bstore;  // 16-byte aligned FullBlock payload rows of every prepared term (SegView::bstore)
   size_t bstore_used = 0;
@@ -252,6 +254,7 @@ static SegView seg_view(const rgpu_segment* s) {
   v.dir_row = s->dir_row.p;
   v.bstore = s->bstore.p;
   v.dir_hdr = s->dir_hdr.p;
+  v.dir_bmax = s->dir_bmax.p;
   v.sim_tables = s->ctx->sim_tables.p;
   v.max_doc = s->max_doc;
   v.doc_base = s->doc_base;
@@ -330,6 +333,7 @@ static int32_t prepare_terms_locked(rgpu_segment* seg, const rgpu_term_state* co
   HIP_TRY(seg->dir_row.reserve(need_slots, seg->dir_used, c->stream));
   HIP_TRY(seg->bstore.reserve(need_bs + 1024, seg->bstore_used, c->stream));  // + over-read padding of the row loads
   HIP_TRY(seg->dir_hdr.reserve(need_slots, seg->dir_used, c->stream));
+  HIP_TRY(seg->dir_bmax.reserve(need_slots, seg->dir_used, c->stream));
   if (seg->d_norms) HIP_TRY(seg->pnorm.reserve(need_pn + 64, seg->pnorm_used, c->stream));
   // staging: the PrepTerm records + the (term, chunk of blocks) item prefix of the second launch
   std::vector<int64_t> item_prefix(work.size() + 1);
@@ -366,11 +370,11 @@ static int32_t prepare_terms_locked(rgpu_segment* seg, const rgpu_term_state* co
     if (seg->version >= 1)
       hipLaunchKernelGGL(k_prepare_blocks<false>, dim3(grid), dim3(PREP_THREADS), 0, c->stream, seg->d_doc, d_work, d_items,
                          (int)work.size(), n_items, seg->dir_last.p, seg->dir_off.p, seg->dir_row.p, seg->dir_hdr.p, seg->bstore.p,
-                         seg->d_norms, seg->pnorm.p, c->d_err);
+                         seg->d_norms, seg->pnorm.p, seg->dir_bmax.p, seg->n_norm_ranks > 0 ? 1 : 0, c->d_err);
     else
       hipLaunchKernelGGL(k_prepare_blocks<true>, dim3(grid), dim3(PREP_THREADS), 0, c->stream, seg->d_doc, d_work, d_items,
                          (int)work.size(), n_items, seg->dir_last.p, seg->dir_off.p, seg->dir_row.p, seg->dir_hdr.p, seg->bstore.p,
-                         seg->d_norms, seg->pnorm.p, c->d_err);
+                         seg->d_norms, seg->pnorm.p, seg->dir_bmax.p, seg->n_norm_ranks > 0 ? 1 : 0, c->d_err);
   }
   int err = 0;
   HIP_TRY(hipMemcpyAsync(&err, c->d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -394,6 +398,7 @@ static int32_t make_dev_term(const rgpu_segment* seg, const rgpu_term_state& st,
   t.df = st.doc_freq;
   t.weight = weight;
   t.sim_table = sim_table;
+  t.flags = (sim_table >= 0 && (size_t)sim_table < seg->ctx->sim_monotone.size() && seg->ctx->sim_monotone[(size_t)sim_table]) ? TERM_FLAG_MONOTONE : 0u;
   t.singleton_doc = st.singleton_doc_id;
   t.singleton_freq = (int32_t)st.total_term_freq;
   if (st.doc_freq == 1 && (st.singleton_doc_id < 0 || st.singleton_doc_id >= seg->max_doc))
@@ -508,6 +513,11 @@ extern "C" int32_t rgpu_sim_table_upload(rgpu_ctx* c, const float cache[256], fl
   tmp[256] = k1;
   HIP_TRY(hipMemcpyAsync(c->sim_tables.p + (size_t)c->n_sim_tables * 257, tmp, sizeof tmp, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
+  // BM25's cache falls as the norm byte grows (shorter doc): then a score never falls as the norm rank grows, which is
+  // what the per-block (freq, rank) frontier bound of the TERM kernel relies on. Any other table simply runs unpruned.
+  bool mono = k1 >= 0.0f;
+  for (int i = 0; i < 256 && mono; ++i) mono = cache[i] >= 0.0f && cache[i] <= 3.0e38f && (i == 0 || cache[i] <= cache[i - 1]);
+  c->sim_monotone.push_back(mono ? 1 : 0);
   return c->n_sim_tables++;
 }
 
@@ -571,7 +581,7 @@ extern "C" void rgpu_segment_free(rgpu_segment* s) {
   if (s->d_norms) (void)hipFree(s->d_norms);
   if (s->d_rank_to_norm) (void)hipFree(s->d_rank_to_norm);
   if (s->d_live) (void)hipFree(s->d_live);
-  s->dir_last.release(); s->dir_off.release(); s->dir_row.release(); s->dir_hdr.release(); s->pnorm.release(); s->bstore.release();
+  s->dir_last.release(); s->dir_off.release(); s->dir_row.release(); s->dir_hdr.release(); s->dir_bmax.release(); s->pnorm.release(); s->bstore.release();
   delete s;
 }
 
