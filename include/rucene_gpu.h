@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RGPU_ABI_VERSION 1
+#define RGPU_ABI_VERSION 2
 #define RGPU_NO_MORE_DOCS 0x7fffffff /* search/mod.rs:59 */
 #define RGPU_BLOCK_SIZE 128          /* codec/postings/posting_format.rs:36 */
 #define RGPU_MAX_QUERY_TERMS 16
@@ -47,17 +47,19 @@ typedef enum rgpu_status {
 typedef struct rgpu_ctx rgpu_ctx;
 typedef struct rgpu_segment rgpu_segment;
 
-/* Knobs (the reference has plain config structs only: SURVEY.md §5). Zero-initialise for defaults. */
+/* Knobs (the reference has plain config structs only: SURVEY.md §5). Zero-initialise for defaults. Results never
+ * depend on any of them (tests/test_gpu_parity.py::test_work_partitioning_knobs_do_not_change_answers). */
 typedef struct rgpu_config {
-  int32_t abi_version;        /* must be RGPU_ABI_VERSION */
-  int32_t blocks_per_item;    /* 128-posting blocks per wave work item in the TERM kernel (0 = auto: 8..128 by batch size) */
-  int32_t window_docs;        /* unused (kept for layout compatibility) */
-  int32_t profile_kernels;    /* 1 = bracket every kernel with HIP events (see rgpu_kernel_stats) */
-  int32_t reserved[12];       /* [0] = lead blocks per work item of the AND kernel (0 = default 2);
-                                 [1], [2] unused;
-                                 [3] = docs per wave window of the OR kernel (0 = default 1024, 256..4096);
-                                 [4] = 1 keeps raw norm bytes in HBM even when <= 64 distinct values exist
-                                       (disables the per-clause LDS score table; A/B testing) */
+  int32_t abi_version;          /* must be RGPU_ABI_VERSION */
+  int32_t blocks_per_item;      /* 128-posting blocks per wave work item in the TERM kernel (0 = auto: 8..512 by batch size) */
+  int32_t and_blocks_per_item;  /* lead blocks per wave work item of the AND kernel (0 = default 2) */
+  int32_t profile_kernels;      /* 1 = bracket every kernel with HIP events from the start (see rgpu_set_profiling) */
+  int32_t or_window_docs;       /* docs per wave window of the OR kernel (0 = default 2048; 256..4096, rounded to 256) */
+  int32_t or_dense_clauses;     /* OR: clauses decoded inside the window kernel instead of through a scored run
+                                   (0 = default 4, -1 = none; at most 4) */
+  int32_t raw_norms;            /* 1 keeps raw norm bytes in HBM even when <= 64 distinct values exist (disables the
+                                   per-clause LDS score table and everything built on it; A/B testing) */
+  int32_t reserved[9];          /* must be zero */
 } rgpu_config;
 
 /* blocktree/mod.rs:33-59 BlockTermState, as filled by posting_reader.rs:264-306 lucene50_decode_term.
@@ -245,7 +247,7 @@ int32_t rgpu_field_infos_from_lucene60(const uint8_t* fnm, size_t fnm_len, rgpu_
  * expected_id16: the id the commit point holds for the segment (check_index_header_id), or NULL. */
 typedef struct rgpu_segment_info {
   int32_t max_doc;
-  int32_t is_compound_file;  /* 1: the segment's files live inside .cfs / .cfe (not readable through this library) */
+  int32_t is_compound_file;  /* 1: the segment's files live inside .cfs / .cfe (rgpu_compound_entries_from_lucene50) */
   int32_t version[3];        /* major, minor, bugfix of the writer */
   int32_t n_files;
   int32_t n_sort_fields;     /* > 0: the segment is index-sorted */
@@ -310,6 +312,13 @@ typedef struct rgpu_kernel_stat {
   int64_t postings;          /* sum of doc_freq over the terms the launches covered */
 } rgpu_kernel_stat;
 int32_t rgpu_kernel_stats(rgpu_ctx* ctx, rgpu_kernel_stat* out, int32_t max_out); /* returns count */
+/* Switch the HIP-event bracketing of kernels on / off (rgpu_config.profile_kernels sets the initial state): a timed
+ * region runs without it, the per-kernel pass that follows with it. */
+int32_t rgpu_set_profiling(rgpu_ctx* ctx, int32_t on);
+/* SURVEY.md 8(d) "touched bytes" of the most recent AND launch on this context: the encoded bytes (two header bytes +
+ * doc and freq payload) of every FullBlock the conjunction kernel decoded — lead blocks and the blocks of the other
+ * clauses that held a pending candidate. Waits for that launch. */
+int32_t rgpu_and_touched_bytes(rgpu_ctx* ctx, int64_t* bytes_out);
 void rgpu_kernel_stats_reset(rgpu_ctx* ctx);
 int32_t rgpu_synchronize(rgpu_ctx* ctx);
 

@@ -8,6 +8,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_NAME = "librucene_gpu.so"
 
+ABI_VERSION = 2
 OP_TERM, OP_AND, OP_OR = 0, 1, 2
 MAX_K = 128
 MAX_QUERY_TERMS = 16
@@ -44,6 +45,7 @@ EXPORTS = [
     "rgpu_search_batch_device", "rgpu_merge_topk_device", "rgpu_bm25_compute_weight", "rgpu_bm25_encode_norm",
     "rgpu_norms_from_lucene53", "rgpu_live_docs_from_lucene50", "rgpu_field_infos_from_lucene60", "rgpu_segment_info_from_lucene62", "rgpu_commit_from_segments_file", "rgpu_compound_entries_from_lucene50", "rgpu_terms_open", "rgpu_terms_close", "rgpu_terms_field_stats",
     "rgpu_terms_lookup", "rgpu_terms_lookup_positions", "rgpu_kernel_stats", "rgpu_kernel_stats_reset", "rgpu_synchronize",
+    "rgpu_set_profiling", "rgpu_and_touched_bytes",
 ]
 
 
@@ -54,8 +56,9 @@ class RgpuError(RuntimeError):
 
 
 class _Config(C.Structure):
-    _fields_ = [("abi_version", C.c_int32), ("blocks_per_item", C.c_int32), ("window_docs", C.c_int32),
-                ("profile_kernels", C.c_int32), ("reserved", C.c_int32 * 12)]
+    _fields_ = [("abi_version", C.c_int32), ("blocks_per_item", C.c_int32), ("and_blocks_per_item", C.c_int32),
+                ("profile_kernels", C.c_int32), ("or_window_docs", C.c_int32), ("or_dense_clauses", C.c_int32),
+                ("raw_norms", C.c_int32), ("reserved", C.c_int32 * 9)]
 
 
 class _KernelStat(C.Structure):
@@ -131,6 +134,8 @@ def lib():
         "rgpu_kernel_stats": (i32, [vp, C.POINTER(_KernelStat), i32]),
         "rgpu_kernel_stats_reset": (None, [vp]),
         "rgpu_synchronize": (i32, [vp]),
+        "rgpu_set_profiling": (i32, [vp, i32]),
+        "rgpu_and_touched_bytes": (i32, [vp, C.POINTER(i64)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -291,14 +296,15 @@ class Context:
     """rgpu_ctx: one per process per GPU."""
 
     def __init__(self, device=0, profile_kernels=False, blocks_per_item=0, and_blocks_per_item=0, or_window_docs=0,
-                 raw_norms=False):
+                 raw_norms=False, or_dense_clauses=0):
         cfg = _Config()
-        cfg.abi_version = 1
+        cfg.abi_version = ABI_VERSION
         cfg.blocks_per_item = blocks_per_item
         cfg.profile_kernels = int(profile_kernels)
-        cfg.reserved[0] = and_blocks_per_item
-        cfg.reserved[3] = or_window_docs
-        cfg.reserved[4] = int(raw_norms)
+        cfg.and_blocks_per_item = and_blocks_per_item
+        cfg.or_window_docs = or_window_docs
+        cfg.or_dense_clauses = or_dense_clauses
+        cfg.raw_norms = int(raw_norms)
         h = C.c_void_p()
         _check(lib().rgpu_init(device, C.byref(cfg), C.byref(h)))
         self._h = h
@@ -321,6 +327,14 @@ class Context:
 
     def synchronize(self):
         _check(lib().rgpu_synchronize(self._h))
+
+    def set_profiling(self, on):
+        _check(lib().rgpu_set_profiling(self._h, int(bool(on))))
+
+    def and_touched_bytes(self):
+        out = C.c_int64(0)
+        _check(lib().rgpu_and_touched_bytes(self._h, C.byref(out)))
+        return int(out.value)
 
     def kernel_stats(self):
         arr = (_KernelStat * 32)()

@@ -188,7 +188,7 @@ constexpr int PREP_BLOCKS_PER_ITEM = 32;
 template <bool LEGACY>
 __global__ __launch_bounds__(PREP_THREADS) void k_prepare_blocks(const uint8_t* __restrict__ doc, const PrepTerm* __restrict__ terms,
                                                                   const int64_t* __restrict__ item_prefix, int n_terms,
-                                                                  int64_t n_items, const int32_t* __restrict__ dir_last,
+                                                                  int64_t n_items, int32_t* dir_last,
                                                                   const uint32_t* __restrict__ dir_off,
                                                                   const uint32_t* __restrict__ dir_row,
                                                                   const uint16_t* __restrict__ dir_hdr, uint8_t* bstore,
@@ -226,6 +226,9 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_blocks(const uint8_t* 
       const BlockPair bp = block_rows_decode<LEGACY>(rows, hdr, slabs[wave], lane);
       int32_t d0, d1;
       deltas_to_docs(bp.d0, bp.d1, base, d0, d1);
+      // df % 128 == 0: no skip entry names the final block's last doc (k_prepare_terms left a sentinel there); the
+      // decode does — windowed consumers (the OR kernel) can then tell that the term has ended
+      if (blk == t.nblocks - 1 && t.nblocks > t.n_entries && lane == 63) dir_last[t.dir_base + blk] = d1;
       // a corrupt block must not turn into a wild gather
       const uint32_t n0 = d0 >= 0 ? norms[d0] : 0u, n1 = d1 >= 0 ? norms[d1] : 0u;
       *reinterpret_cast<uint16_t*>(pnorm + t.pn_base + 128 * (uint64_t)blk + 2 * lane) = (uint16_t)(n0 | (n1 << 8));

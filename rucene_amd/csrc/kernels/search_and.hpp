@@ -21,7 +21,7 @@ namespace rgpu {
 
 #ifdef RGPU_EXP_COUNT  // developer instrumentation (variant builds only): [0] lead blocks, [1] other-clause block decodes,
 __device__ unsigned long long g_and_dbg[4];  // [2] probed candidates, [3] (lead block, clause) visits
-#define AND_DBG(i, n) do { if (lane == 0) atomicAdd(&g_and_dbg[i], (unsigned long long)(n)); } while (0)
+#define AND_DBG(i, n) do { const unsigned long long n_ = (unsigned long long)(n); if (lane == 0) atomicAdd(&g_and_dbg[i], n_); } while (0)
 #else
 #define AND_DBG(i, n) do {} while (0)
 #endif
@@ -32,6 +32,9 @@ __device__ unsigned long long g_and_dbg[4];  // [2] probed candidates, [3] (lead
 #define RGPU_AND_WAVES 6
 #endif
 constexpr int AND_WAVES_PER_SIMD = RGPU_AND_WAVES;
+#ifndef RGPU_AND_ABL  // developer ablations (variant builds only; results are wrong): 1 lead decode only, 2 + clause setup
+#define RGPU_AND_ABL 0  // and directory window, 3 + block decodes without the membership probe
+#endif
 
 // Wave-cooperative search (target is wave-uniform): first a coalesced look at the 64 directory entries right
 // after `from` — consecutive lead blocks probe monotonically, so the answer is usually there (one load instead of
@@ -93,7 +96,8 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
                                                            int64_t n_items, int blocks_per_item, int k,
                                                            uint64_t* __restrict__ partial_keys,
                                                            int32_t* __restrict__ partial_counts,
-                                                           unsigned long long* __restrict__ tau_slots) {
+                                                           unsigned long long* __restrict__ tau_slots,
+                                                           unsigned long long* __restrict__ touched_slots) {
   __shared__ __attribute__((aligned(16))) uint8_t slabs[WG_WAVES][SLAB_BYTES];
   __shared__ float caches[WG_WAVES][256];
   __shared__ uint32_t filters[WG_WAVES][AND_FILTER_WORDS];
@@ -118,6 +122,10 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
   WaveTopK top;
   uint64_t tau = 0, floor = 0;
   int count = 0;
+  uint32_t touched = 0;  // encoded bytes of the FullBlocks this item decoded (SURVEY 8(d) "touched bytes"; scalar)
+  auto block_bytes = [](uint32_t hdr) -> uint32_t {
+    return 2u + (hdr_bdoc(hdr) ? 16u * (uint32_t)hdr_bdoc(hdr) : (uint32_t)hdr_vlen(hdr)) + (hdr_bfreq(hdr) ? 16u * (uint32_t)hdr_bfreq(hdr) : 1u);
+  };
   int cursor = 0;  // lane ti holds clause ti's directory cursor (a register array indexed by ti would spill)
   SharedTau shared{tau_slots + q};
   shared.fold(shared.peek(), tau, floor);
@@ -164,6 +172,13 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
         continue;
       }
       AND_DBG(3, 1);
+      if (RGPU_AND_ABL == 2) {
+        DirWindow W2;
+        W2.load(seg, T.dir_base, T.nblocks, min(readlane(cursor, ti), T.nblocks), lane);
+        if (W2.last == 12345 && W2.row == 7 && W2.hdr == 9) count++;
+        a0 = a1 = false;
+        continue;
+      }
       bool p0 = a0, p1 = a1;  // candidates this clause has not answered yet (sorted across (lane, slot))
       // doc of the first pending candidate; `any` = false when none is pending
       auto first_pending = [&](bool& any) -> int32_t {
@@ -190,22 +205,28 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
         if (k0 | k1m) {  // the filter has no false negatives; a hit is confirmed against the docs themselves
           uint32_t g0, g1;
           freqs(g0, g1);
-          auto verify = [&](uint64_t km, const int32_t dcand, float& s, bool& alive, uint32_t nrm) {
+          // One broadcast compare per hit only FETCHES the freq into the candidate's lane; the scoring (an IEEE
+          // division) then runs once for all confirmed hits of the block together — doing it per hit, one lane at a
+          // time, cost 100 VALU issue slots per block on the 3-term workload (rocprofv3, round 2).
+          uint32_t fq0 = 0u, fq1 = 0u;
+          auto collect = [&](uint64_t km, const int32_t dcand, uint32_t& fq) -> uint64_t {
+            uint64_t got = 0;
             while (km) {
               const int j = __builtin_ctzll(km);
               km &= km - 1;
               const int32_t d = readlane(dcand, j);
               const uint64_t m0 = __ballot(ev0 && e0 == d), m1 = __ballot(ev1 && e1 == d);
               if (m0 | m1) {
-                const uint32_t fq = m0 ? (uint32_t)readlane((int)g0, __builtin_ctzll(m0)) : (uint32_t)readlane((int)g1, __builtin_ctzll(m1));
-                if (lane == j) found(alive, s, fq, nrm);
-              } else if (lane == j) {
-                missed(alive);
+                const uint32_t f = m0 ? (uint32_t)readlane((int)g0, __builtin_ctzll(m0)) : (uint32_t)readlane((int)g1, __builtin_ctzll(m1));
+                fq = lane == j ? f : fq;
+                got |= 1ull << j;
               }
             }
+            return got;
           };
-          verify(k0, d0, s0, a0, n0);
-          verify(k1m, d1, s1, a1, n1);
+          const uint64_t got0 = collect(k0, d0, fq0), got1 = collect(k1m, d1, fq1);
+          if (h0) { if ((got0 >> lane) & 1ull) found(a0, s0, fq0, n0); else missed(a0); }
+          if (h1) { if ((got1 >> lane) & 1ull) found(a1, s1, fq1, n1); else missed(a1); }
         }
         wave_sync();  // the filter is rewritten by the next block
       };
@@ -278,11 +299,14 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
           const Fetched B = fetch(more ? jn : j);  // unconditional: a load behind a branch would serialise the two
           stage_rows(A.rows, slab, lane);
           wave_sync();
+          touched += block_bytes(A.hdr);
           AND_DBG(1, 1);
           uint32_t x0, x1;
           staged_doc_deltas<LEGACY>(slab, A.rows, A.hdr, lane, x0, x1);
           int32_t e0, e1;
           deltas_to_docs(x0, x1, vbase, e0, e1);
+          if (RGPU_AND_ABL == 3) { if (c0 && e0 == d0) count++; if (c0) a0 = false; if (c1) a1 = false; wave_sync(); }
+          else
           probe(e0, e1, true, true, c0, c1, [&](uint32_t& g0, uint32_t& g1) { staged_freqs<LEGACY>(slab, A.rows, A.hdr, lane, g0, g1); });
           if (!more) break;
           j = jn;
@@ -308,7 +332,9 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
     bool a0, a1;
     if (blk < L.nblocks) {
       if (has_norms) nn = *reinterpret_cast<const uint16_t*>(seg.pnorm + L.pn_base + 128 * (size_t)blk + 2 * lane);
-      const BlockPair bp = decode_block<LEGACY>(seg.bstore + L.bs_base, seg.dir_row[L.dir_base + blk], seg.dir_hdr[L.dir_base + blk], slab, lane);
+      const uint32_t lhdr = seg.dir_hdr[L.dir_base + blk];
+      const BlockPair bp = decode_block<LEGACY>(seg.bstore + L.bs_base, seg.dir_row[L.dir_base + blk], lhdr, slab, lane);
+      touched += block_bytes(lhdr);
       deltas_to_docs(bp.d0, bp.d1, base, d0, d1);
       base = readlane(d1, 63);
       f0 = bp.f0; f1 = bp.f1;
@@ -326,13 +352,17 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
       if (has_norms && a0) nn = seg.norms[d0];
       if (has_norms && a1) nn |= (uint32_t)seg.norms[d1] << 8;
     }
+    if (RGPU_AND_ABL == 1) { if (a0 && d0 == 12345 && f0 == 77 && nn == 3) count++; continue; }
     intersect(d0, d1, f0, f1, nn, a0, a1);
   }
   shared.publish<WIDE>(top, k, lane);
   uint64_t* pk = partial_keys + (size_t)item * (size_t)k;
   if (lane < k) pk[lane] = top.a;
   if (WIDE && lane + 64 < k) pk[lane + 64] = top.b;
-  if (lane == 0) partial_counts[item] = count;
+  if (lane == 0) {
+    partial_counts[item] = count;
+    atomicAdd(touched_slots + q, (unsigned long long)touched);  // ~160 items per query word: no contention to speak of
+  }
 }
 
 }  // namespace rgpu

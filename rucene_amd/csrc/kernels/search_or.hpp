@@ -1,16 +1,22 @@
 // Disjunction (OR) on the GPU in two launches, nothing shared between wavefronts inside either:
-//   1. k_score_terms   every clause's postings are decoded and BM25-scored exactly once (the TermScorer work of
-//                      each sub-scorer, term_scorer.rs:43-67) into a {doc, score} run per clause in HBM;
-//   2. k_or_windows    each wavefront owns a range of small doc-id windows. Per window it walks every clause's
-//                      run from a cursor, adds the scores into an LDS accumulator *in clause order* — the
-//                      summation order of SubScorers::score_sum over a SimpleQueue
-//                      (search/scorer/disjunction_scorer.rs:213-225) — then scans the window: every touched doc
-//                      is one collected hit (bulk_scorer.rs:114-120) offered to the wave's top-k.
+//   1. k_score_terms   the SPARSE clauses' postings (and the VInt tails of the dense ones) are decoded and BM25-scored
+//                      exactly once (the TermScorer work of each sub-scorer, term_scorer.rs:43-67) into a {doc, score}
+//                      run per clause in HBM;
+//   2. k_or_windows    each wavefront owns a range of doc-id windows. Per window it goes through the clauses *in clause
+//                      order* — the summation order of SubScorers::score_sum over a SimpleQueue
+//                      (search/scorer/disjunction_scorer.rs:213-225) — and adds each one's scores into an LDS
+//                      accumulator: a sparse clause's from its run (walked from a cursor), a DENSE clause's (up to
+//                      OR_DENSE_MAX per query: the lists that hold ~90 % of a Zipfian query's postings) straight from
+//                      the block store — its FullBlocks overlapping the window are unpacked, scored through the
+//                      clause's LDS score table and added, nothing materialised. Then the window is scanned: every
+//                      touched doc is one collected hit (bulk_scorer.rs:114-120) offered to the wave's top-k.
+// Round 1 sent every clause through a run: 8 B per posting written and read back (22 GB per 1024-query batch against
+// 6 GB of postings) and 2.6 VALU instructions per posting; the dense path costs 0.6.
 // This is DisjunctionSumScorer's doc-at-a-time merge (disjunction_scorer.rs:24-104, util/disi.rs) turned
 // term-at-a-time per window; for >= 10 clauses the reference sums in heap order, so only 1e-5 relative holds
 // there. No block is decoded twice and no posting is scored twice, whatever the clause density.
 #pragma once
-#include "search.hpp"
+#include "search_and.hpp"
 
 namespace rgpu {
 
@@ -59,8 +65,12 @@ __global__ __launch_bounds__(WG_THREADS) void k_score_terms(SegView seg, const D
     if (v1) run[slot + 1] = ScoredPosting{d1, s1};
   };
 
-  const int b0 = chunk * blocks_per_item;
-  const int b1 = min(T.nblocks, b0 + blocks_per_item);
+  // a clause whose FullBlocks the window kernel decodes itself (TERM_FLAG_OR_DENSE) only sends its VInt tail through
+  // a run: one item, no blocks, the tail at the run's start
+  const bool dense = (T.flags & TERM_FLAG_OR_DENSE) != 0u;
+  const int b0 = dense ? T.nblocks : chunk * blocks_per_item;
+  const int b1 = dense ? T.nblocks : min(T.nblocks, b0 + blocks_per_item);
+  const int64_t run_len = dense ? (int64_t)T.tail_n : (int64_t)T.df;
   int32_t base = b0 == 0 ? 0 : seg.dir_last[T.dir_base + b0 - 1];
   const uint8_t* term_rows = seg.bstore + T.bs_base;
   auto on_block = [&](int blk, int32_t d0, int32_t d1, uint32_t f0, uint32_t f1, uint32_t nb0, uint32_t nb1) {
@@ -72,7 +82,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_score_terms(SegView seg, const D
     stream_blocks<LEGACY, false>(term_rows, seg.dir_row, seg.dir_hdr, T.dir_base, nullptr, b0, b1, slab, lane, base, on_block);
   if (b1 == T.nblocks) {
     // 64 sentinel entries close every run: k_or_windows reads 64 entries from a cursor without knowing the length
-    run[(int64_t)T.df + lane] = ScoredPosting{0x7fffffff, 0.0f};
+    run[run_len + lane] = ScoredPosting{0x7fffffff, 0.0f};
     if (T.df == 1) {
       const bool v0 = lane == 0;
       const uint32_t nb0 = (has_norms && v0) ? seg.norms[T.singleton_doc] : 0u;
@@ -84,67 +94,95 @@ __global__ __launch_bounds__(WG_THREADS) void k_score_terms(SegView seg, const D
       decode_tail(seg.doc + T.start_fp + toff, T.tail_n, base, slab, lane, d0, d1, f0, f1);
       const bool v0 = 2 * lane < T.tail_n, v1 = 2 * lane + 1 < T.tail_n;
       const uint32_t nb0 = (has_norms && v0) ? seg.norms[d0] : 0u, nb1 = (has_norms && v1) ? seg.norms[d1] : 0u;
-      emit(d0, d1, f0, f1, nb0, nb1, v0, v1, 128 * (int64_t)T.nblocks + 2 * lane);
+      emit(d0, d1, f0, f1, nb0, nb1, v0, v1, (dense ? 0 : 128 * (int64_t)T.nblocks) + 2 * lane);
     }
   }
 }
 
 constexpr int OR_MAX_TERMS = 16;
 constexpr int OR_RUN_PAD = 64;  // sentinel entries {doc = INT_MAX} after every clause's run (written by k_score_terms)
+constexpr int OR_DENSE_MAX = 4;  // clauses per query decoded inside the window kernel (score tables: one per wave of a workgroup)
 constexpr uint32_t OR_UNTOUCHED = 0xffffffffu;  // accumulator patterns no sum of scores produces (negative quiet NaNs)
 constexpr uint32_t OR_EXCLUDED = 0xfffffffeu;
+static_assert(OR_DENSE_MAX <= WG_WAVES, "wave w of a workgroup builds dense clause w's score table");
 
-// items = (query, group of `windows_per_item` windows of `W` docs), one per wavefront
+__host__ __device__ constexpr size_t or_wave_lds_bytes(int W, bool msm) { return (size_t)(2 * SLAB_STREAM) + (size_t)W * (msm ? 5 : 4); }
+__host__ __device__ constexpr size_t or_lds_bytes(int W, bool msm) {
+  return (size_t)OR_DENSE_MAX * WAVE_CACHE_FLOATS * 4 + (size_t)WG_WAVES * or_wave_lds_bytes(W, msm);
+}
+
+// items = (query, group of `windows_per_item` windows of `W` docs), one per wavefront; items_per_query is a multiple
+// of WG_WAVES, so the wavefronts of a workgroup always work on the same query and share its dense clauses' score
+// tables. DevQuery::op carries the query's dense-clause mask in bits 16.. (bit i = SHOULD clause i).
 // HAS_NOT: some query of the launch carries MUST_NOT clauses; HAS_MSM: some query asks for min_should_match > 1
 // (disjunction_scorer.rs:317-329: a doc is a hit only if that many SHOULD clauses hold it — a per-doc clause counter
 // next to the accumulator). Separate instantiations keep the common kernel lean.
-template <bool WIDE, bool HAS_NOT, bool HAS_MSM>
-__global__ __launch_bounds__(WG_THREADS) void k_or_windows(SegView seg, const DevQuery* __restrict__ queries,
-                                                           const DevTerm* __restrict__ terms,
-                                                           const int64_t* __restrict__ run_prefix,
-                                                           const ScoredPosting* __restrict__ runs, int n_queries,
-                                                           int windows_per_query, int windows_per_item,
-                                                           int items_per_query, int W, int k,
-                                                           uint64_t* __restrict__ partial_keys,
-                                                           int32_t* __restrict__ partial_counts,
-                                                           unsigned long long* __restrict__ tau_slots) {
+template <bool LEGACY, bool WIDE, bool HAS_NOT, bool HAS_MSM>
+__global__ __launch_bounds__(WG_THREADS, 3) void k_or_windows(SegView seg, const DevQuery* __restrict__ queries,
+                                                              const DevTerm* __restrict__ terms,
+                                                              const int64_t* __restrict__ run_prefix,
+                                                              const ScoredPosting* __restrict__ runs, int n_queries,
+                                                              int windows_per_query, int windows_per_item,
+                                                              int items_per_query, int W, int k,
+                                                              uint64_t* __restrict__ partial_keys,
+                                                              int32_t* __restrict__ partial_counts,
+                                                              unsigned long long* __restrict__ tau_slots) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int lane = lane_id();
   const int wave = wave_id();
-  // per-wave LDS slice: acc[W] f32 | hits[W] u16 (window offsets of touched docs, in first-touch order). An
-  // untouched accumulator holds OR_UNTOUCHED, a NaN pattern no sum of scores produces; the hit scan at the end
-  // of a window puts it back, so no per-doc flag array and no clearing pass are needed.
-  float* acc = reinterpret_cast<float*>(smem + (size_t)wave * (size_t)W * (HAS_MSM ? 7 : 6));
-  uint16_t* hits = reinterpret_cast<uint16_t*>(acc + W);
-  uint8_t* cnt = reinterpret_cast<uint8_t*>(hits + W);  // HAS_MSM only: SHOULD clauses that hold the doc
-  const int64_t item = (int64_t)blockIdx.x * WG_WAVES + wave;
-  if (item >= (int64_t)n_queries * items_per_query) return;
+  // LDS: [OR_DENSE_MAX score tables (norm cache 64 f32 + 64 x 11 scores)] then per wave [block staging slab | acc[W] f32
+  // | cnt[W] u8 (HAS_MSM)]. An untouched accumulator holds OR_UNTOUCHED, a NaN pattern no sum of scores produces; the
+  // scan at the end of a window puts it back, so there is no per-doc flag array and no clearing pass.
+  float* tables = reinterpret_cast<float*>(smem);
+  uint8_t* slice = smem + (size_t)OR_DENSE_MAX * WAVE_CACHE_FLOATS * 4 + (size_t)wave * or_wave_lds_bytes(W, HAS_MSM);
+  uint8_t* slab = slice;
+  float* acc = reinterpret_cast<float*>(slice + 2 * SLAB_STREAM);
+  uint8_t* cnt = reinterpret_cast<uint8_t*>(acc + W);  // HAS_MSM only: SHOULD clauses that hold the doc
+  const int64_t item = (int64_t)blockIdx.x * WG_WAVES + wave;  // the grid is exactly n_queries * items_per_query / WG_WAVES
   const int q = (int)(item / items_per_query);
   const int g = (int)(item - (int64_t)q * items_per_query);
   const DevQuery Q = queries[q];
   const bool has_live = seg.live != nullptr;
+  const uint32_t dense_mask = ((uint32_t)Q.op >> 16) & 0xffffu;
+  const int nd = __popc(dense_mask);
+  auto nth_bit = [](uint32_t m, int n) -> int {  // index of the n-th set bit (n < popcount)
+    for (int i = 0; i < n; ++i) m &= m - 1;
+    return (int)__builtin_ctz(m);
+  };
+  // wave w builds dense clause w's score table (the same f32 expression as bm25_score per entry: bit-identical)
+  if (wave < nd) {
+    const DevTerm T = terms[Q.first_term + nth_bit(dense_mask, wave)];
+    float* tbl = tables + wave * WAVE_CACHE_FLOATS;
+    float k1;
+    load_sim_table(seg, T.sim_table, tbl, lane, k1);
+    build_score_table(tbl, T.weight * (k1 + 1.0f), lane);
+  }
+  __syncthreads();
 
   WaveTopK top;
   uint64_t tau = 0, floor = 0;
-  int count = 0;
+  int hits_lane = 0;  // collected docs this lane saw (summed over the wave at the end: TopDocs::total_hits)
   SharedTau shared{tau_slots + q};
   shared.fold(shared.peek(), tau, floor);
   const int win0 = g * windows_per_item;
   const int win1 = Q.n_terms > 0 ? min(windows_per_query, win0 + windows_per_item) : win0;
+  const int32_t first_doc = win0 * W;
 
-  // Lane t owns one clause's cursor: run base, length, and the first entry with doc >= this item's first window —
-  // one lane-parallel binary search over all clauses at once. The n_not MUST_NOT clauses (stored after the n_terms
-  // SHOULD clauses) take lanes 0 .. n_not-1 so that a window meets them first: ReqNotScorer over the disjunction
+  // ---- runs: lane t owns one clause's cursor: run base, length, and the first entry with doc >= this item's first
+  // window — one lane-parallel binary search over all clauses at once. The n_not MUST_NOT clauses (stored after the
+  // n_terms SHOULD clauses) take lanes 0 .. n_not-1 so that a window meets them first: ReqNotScorer over the disjunction
   // (boolean_query.rs:271-273, req_not_scorer.rs:47-63) — their docs are marked excluded before anything is summed.
   const int n_not = HAS_NOT ? Q.pad : 0;
-  const int msm = HAS_MSM ? (Q.op >> 8) : 1;
-  const bool mine = lane < Q.n_terms + n_not;
+  const int msm = HAS_MSM ? ((Q.op >> 8) & 0xff) : 1;
+  const int n_pos = Q.n_terms + n_not;  // clause positions of a window, in summation order
+  const bool mine = lane < n_pos;
   const int my_clause = lane < n_not ? Q.n_terms + lane : lane - n_not;
+  const bool my_dense = mine && lane >= n_not && ((dense_mask >> my_clause) & 1u);
   const int64_t my_base = mine ? run_prefix[Q.first_term + my_clause] : 0;
-  const int my_len = mine ? terms[Q.first_term + my_clause].df : 0;
+  int my_len = 0;
+  if (mine) { const DevTerm* Tm = terms + Q.first_term + my_clause; my_len = my_dense ? Tm->tail_n : Tm->df; }
   int64_t my_at = my_base;  // absolute index of the entry under this clause's cursor (every run ends in sentinels)
   {
-    const int32_t first_doc = win0 * W;
     int lo = 0, hi = my_len;
     while (__ballot(lo < hi)) {
       if (lo < hi) {
@@ -156,15 +194,58 @@ __global__ __launch_bounds__(WG_THREADS) void k_or_windows(SegView seg, const De
   }
   int32_t my_next = mine ? runs[my_at].doc : 0x7fffffff;  // doc under the cursor (INT_MAX: the run is exhausted)
 
+  // ---- dense clauses: lane s (< nd) holds slot s's term fields and cursor; every slot keeps a 64-entry window of its
+  // block directory in registers (DirWindow, search_and.hpp)
+  uint64_t d_bs = 0, d_pn = 0;
+  uint32_t d_dir = 0;
+  int32_t d_nb = 0, d_cb = 0, d_from = 0;
+  float d_wk = 0.f;
+  if (lane < nd) {
+    const DevTerm* Td = terms + Q.first_term + nth_bit(dense_mask, lane);
+    d_bs = Td->bs_base; d_pn = Td->pn_base; d_dir = Td->dir_base; d_nb = Td->nblocks;
+    d_wk = Td->weight * (seg.sim_tables[(size_t)Td->sim_table * 257 + 256] + 1.0f);
+  }
+  // four named windows, selected with scalar-condition moves: an array indexed by the (wave-uniform but dynamic) slot
+  // number is put in scratch memory by the compiler, one load and one store per dense visit
+  DirWindow Wd0, Wd1, Wd2, Wd3;
+  auto init_window = [&](DirWindow& Wx, int s) {
+    Wx.last = 0x7fffffff; Wx.row = 0u; Wx.hdr = 0u;
+    if (s < nd) {
+      const uint32_t dir = (uint32_t)readlane((int)d_dir, s);
+      const int nb = readlane(d_nb, s);
+      const int cb = find_block_wave(seg.dir_last, dir, 0, nb, first_doc, lane);  // first block that reaches this item's docs
+      d_cb = lane == s ? cb : d_cb;
+      d_from = lane == s ? cb : d_from;
+      Wx.load(seg, dir, nb, cb, lane);
+    }
+  };
+  init_window(Wd0, 0); init_window(Wd1, 1); init_window(Wd2, 2); init_window(Wd3, 3);
+  auto sel = [](int s, uint32_t a, uint32_t b, uint32_t c, uint32_t d) -> uint32_t { return s == 0 ? a : (s == 1 ? b : (s == 2 ? c : d)); };
+  auto pick_window = [&](int s) -> DirWindow {
+    DirWindow r;
+    r.last = (int32_t)sel(s, (uint32_t)Wd0.last, (uint32_t)Wd1.last, (uint32_t)Wd2.last, (uint32_t)Wd3.last);
+    r.row = sel(s, Wd0.row, Wd1.row, Wd2.row, Wd3.row);
+    r.hdr = sel(s, Wd0.hdr, Wd1.hdr, Wd2.hdr, Wd3.hdr);
+    return r;
+  };
+  auto put_window = [&](int s, const DirWindow& w) {
+    // field by field: a ternary over whole structs becomes a pointer select, which forces all four into memory
+    Wd0.last = s == 0 ? w.last : Wd0.last; Wd0.row = s == 0 ? w.row : Wd0.row; Wd0.hdr = s == 0 ? w.hdr : Wd0.hdr;
+    Wd1.last = s == 1 ? w.last : Wd1.last; Wd1.row = s == 1 ? w.row : Wd1.row; Wd1.hdr = s == 1 ? w.hdr : Wd1.hdr;
+    Wd2.last = s == 2 ? w.last : Wd2.last; Wd2.row = s == 2 ? w.row : Wd2.row; Wd2.hdr = s == 2 ? w.hdr : Wd2.hdr;
+    Wd3.last = s == 3 ? w.last : Wd3.last; Wd3.row = s == 3 ? w.row : Wd3.row; Wd3.hdr = s == 3 ? w.hdr : Wd3.hdr;
+  };
+
   for (int i = lane; i < W; i += 64) acc[i] = __uint_as_float(OR_UNTOUCHED);
   wave_sync();
   for (int win = win0; win < win1; ++win) {
     const int32_t w0 = win * W;
     const int32_t w1 = min(seg.max_doc, w0 + W);
-    int nhits = 0;
-    // only clauses with a posting inside this window are visited, in clause order == summation order. The first
-    // 64 run entries of EVERY such clause are requested up front (one exposed load latency per window instead of
-    // one per clause: the window walk was latency bound), the rare longer stretches are fetched as they come.
+    const uint32_t wlen = (uint32_t)(w1 - w0);
+    const bool exchange = ((win - win0) & 7) == 7;  // thresholds travel between the wavefronts of a query every 8 windows
+    const uint64_t seen = exchange ? shared.peek() : 0ull;
+    // ---- loads first: the first 64 run entries of EVERY clause with a posting in this window (one exposed load latency
+    // per window instead of one per clause: the window walk is latency bound), and the first block of every dense clause
     const uint64_t active0 = __ballot(my_next < w1);
     ScoredPosting pre[OR_MAX_TERMS];
 #pragma unroll
@@ -172,56 +253,195 @@ __global__ __launch_bounds__(WG_THREADS) void k_or_windows(SegView seg, const De
       pre[t] = ScoredPosting{0x7fffffff, 0.f};
       if ((active0 >> t) & 1ull) pre[t] = runs[(int64_t)readlane64((uint64_t)my_at, t) + lane];  // wave-uniform branch
     }
-#pragma unroll
-    for (int t = 0; t < OR_MAX_TERMS; ++t) {
-      if (!((active0 >> t) & 1ull)) continue;
-      int taken = 0;
-      int32_t next;
-      ScoredPosting e = pre[t];
-      while (true) {
-        bool in = e.doc < w1;
-        const int n = __popcll(__ballot(in));  // runs are doc-sorted: the in-window entries are a prefix
-        if (in && has_live) in = doc_is_live(seg.live, e.doc);
-        bool first = false;
-        if (in) {
-          const int o = e.doc - w0;
-          const float a = acc[o];
-          first = __float_as_uint(a) == OR_UNTOUCHED;
-          if (t < n_not) {  // wave-uniform: a prohibited clause only marks
-            if (first) acc[o] = __uint_as_float(OR_EXCLUDED);
-          } else if (!HAS_NOT || __float_as_uint(a) != OR_EXCLUDED) {
-            acc[o] = (first ? 0.0f : a) + e.score;  // 0.0f + s: the reference's `score = 0; score += s`
-            if (HAS_MSM) cnt[o] = first ? (uint8_t)1 : (uint8_t)(cnt[o] + 1);
+    uint4 hrows0 = make_uint4(0u, 0u, 0u, 0u), hrows1 = hrows0, hrows2 = hrows0, hrows3 = hrows0;
+    uint32_t hnorm0 = 0u, hnorm1 = 0u, hnorm2 = 0u, hnorm3 = 0u;
+    uint32_t hmask = 0;  // dense slots whose first block of this window is in flight
+    auto head = [&](DirWindow& Wx, uint4& hrows, uint32_t& hnorm, int s) {
+      if (s < nd) {
+        const int cb = readlane(d_cb, s), nb = readlane(d_nb, s);
+        int from = readlane(d_from, s);
+        if (cb < nb) {
+          if (cb - from + 1 > 63) {  // the cursor left the register window: move it
+            from = cb;
+            Wx.load(seg, (uint32_t)readlane((int)d_dir, s), nb, from, lane);
+            d_from = lane == s ? from : d_from;
+          }
+          const int jj = cb - from + 1;
+          if (readlane(Wx.last, jj - 1) < w1 - 1) {  // the block starts before the window ends
+            const uint32_t hdr = (uint32_t)readlane((int)Wx.hdr, jj);
+            hrows = block_rows_load(block_rows_at(seg.bstore + readlane64(d_bs, s), (uint32_t)readlane((int)Wx.row, jj)), hdr, lane);
+            hnorm = *reinterpret_cast<const uint16_t*>(seg.pnorm + readlane64(d_pn, s) + (128u * (uint32_t)cb + 2u * (uint32_t)lane));
+            hmask |= 1u << s;
           }
         }
-        const uint64_t fm = __ballot(first);
-        if (first) hits[nhits + mbcnt(fm)] = (uint16_t)(e.doc - w0);
-        nhits += __popcll(fm);
-        taken += n;
-        if (n < 64) { next = readlane(e.doc, n); break; }  // the entry now under the cursor (or the sentinel)
-        e = runs[(int64_t)readlane64((uint64_t)my_at, t) + taken + lane];  // a stretch longer than 64: the rare case
       }
-      if (lane == t) { my_at += taken; my_next = next; }
+    };
+    head(Wd0, hrows0, hnorm0, 0); head(Wd1, hrows1, hnorm1, 1); head(Wd2, hrows2, hnorm2, 2); head(Wd3, hrows3, hnorm3, 3);
+    bool touched_any = false;  // wave-uniform: some accumulator of this window was written
+
+    // one posting into the window's accumulator (all docs of one clause are distinct: no two lanes meet)
+    auto add = [&](int32_t doc, float sc, bool valid, bool prohibited) {
+      const uint32_t o = (uint32_t)(doc - w0);
+      bool in = valid && o < wlen;
+      if (in && has_live) in = doc_is_live(seg.live, doc);
+      if (in) {
+        const float a = acc[o];
+        const uint32_t ab = __float_as_uint(a);
+        const bool first = ab == OR_UNTOUCHED;
+        if (prohibited) {  // wave-uniform: a prohibited clause only marks
+          if (first) acc[o] = __uint_as_float(OR_EXCLUDED);
+        } else if (!HAS_NOT || ab != OR_EXCLUDED) {
+          acc[o] = (first ? 0.0f : a) + sc;  // 0.0f + s: the reference's `score = 0; score += s`
+          if (HAS_MSM) cnt[o] = first ? (uint8_t)1 : (uint8_t)(cnt[o] + 1);
+        }
+      }
+    };
+
+    for (int t = 0; t < n_pos; ++t) {
+      // ---- the clause's run (a sparse clause's postings, a dense clause's VInt tail)
+      if ((active0 >> t) & 1ull) {
+        ScoredPosting e;
+        switch (t) {  // register select behind scalar branches: the loop body exists once, not sixteen times
+          case 0: e = pre[0]; break; case 1: e = pre[1]; break; case 2: e = pre[2]; break; case 3: e = pre[3]; break;
+          case 4: e = pre[4]; break; case 5: e = pre[5]; break; case 6: e = pre[6]; break; case 7: e = pre[7]; break;
+          case 8: e = pre[8]; break; case 9: e = pre[9]; break; case 10: e = pre[10]; break; case 11: e = pre[11]; break;
+          case 12: e = pre[12]; break; case 13: e = pre[13]; break; case 14: e = pre[14]; break; default: e = pre[15]; break;
+        }
+        int taken = 0;
+        int32_t next;
+        while (true) {
+          const bool in = e.doc < w1;
+          const int n = __popcll(__ballot(in));  // runs are doc-sorted: the in-window entries are a prefix
+          add(e.doc, e.score, in, t < n_not);
+          taken += n;
+          if (n < 64) { next = readlane(e.doc, n); break; }  // the entry now under the cursor (or the sentinel)
+          e = runs[(int64_t)readlane64((uint64_t)my_at, t) + taken + lane];  // a stretch longer than 64: the rare case
+        }
+        if (lane == t) { my_at += taken; my_next = next; }
+        touched_any = true;
+        wave_sync();
+      }
+      // ---- the clause's FullBlocks, when it is a dense one
+      const int ci = t - n_not;
+      if (ci >= 0 && ((dense_mask >> ci) & 1u)) {
+        const int s = __popc(dense_mask & ((1u << ci) - 1u));
+        DirWindow Wn = pick_window(s);
+        uint4 rows = make_uint4(sel(s, hrows0.x, hrows1.x, hrows2.x, hrows3.x), sel(s, hrows0.y, hrows1.y, hrows2.y, hrows3.y),
+                                sel(s, hrows0.z, hrows1.z, hrows2.z, hrows3.z), sel(s, hrows0.w, hrows1.w, hrows2.w, hrows3.w));
+        uint32_t nn = sel(s, hnorm0, hnorm1, hnorm2, hnorm3);
+        bool have = (hmask >> s) & 1u;
+        int cb = readlane(d_cb, s), from = readlane(d_from, s);
+        const int nb = readlane(d_nb, s);
+        const uint32_t dir = (uint32_t)readlane((int)d_dir, s);
+        const uint8_t* term_rows = seg.bstore + readlane64(d_bs, s);
+        const uint8_t* pn = seg.pnorm + readlane64(d_pn, s);
+        const float* tbl = tables + s * WAVE_CACHE_FLOATS;
+        const float wk = __int_as_float(readlane(__float_as_int(d_wk), s));
+        while (cb < nb) {
+          int jj = cb - from + 1;
+          if (jj > 63) {
+            from = cb;
+            Wn.load(seg, dir, nb, from, lane);
+            jj = 1;
+          }
+          const int32_t base = readlane(Wn.last, jj - 1);
+          if (base >= w1 - 1) break;  // the block's docs lie beyond this window
+          const int32_t last = readlane(Wn.last, jj);
+          const uint32_t hdr = (uint32_t)readlane((int)Wn.hdr, jj);
+          if (!have) {
+            rows = block_rows_load(block_rows_at(term_rows, (uint32_t)readlane((int)Wn.row, jj)), hdr, lane);
+            nn = *reinterpret_cast<const uint16_t*>(pn + (128u * (uint32_t)cb + 2u * (uint32_t)lane));
+          }
+          // the clause's next block also belongs to this window: request it before this one is unpacked
+          const bool more = last < w1 - 1 && cb + 1 < nb && jj + 1 <= 63;
+          uint4 rows2 = rows;
+          uint32_t nn2 = nn;
+          if (more) {
+            const uint32_t hdr2 = (uint32_t)readlane((int)Wn.hdr, jj + 1);
+            rows2 = block_rows_load(block_rows_at(term_rows, (uint32_t)readlane((int)Wn.row, jj + 1)), hdr2, lane);
+            nn2 = *reinterpret_cast<const uint16_t*>(pn + (128u * (uint32_t)(cb + 1) + 2u * (uint32_t)lane));
+          }
+          stage_rows(rows, slab, lane);
+          wave_sync();
+          uint32_t x0, x1, f0, f1;
+          staged_doc_deltas<LEGACY>(slab, rows, hdr, lane, x0, x1);
+          staged_freqs<LEGACY>(slab, rows, hdr, lane, f0, f1);
+          wave_sync();  // slab is free for the next block
+          int32_t e0, e1;
+          deltas_to_docs(x0, x1, base, e0, e1);
+          const uint32_t nb0 = nn & 0xffu, nb1 = nn >> 8;
+          float s0, s1;
+          if (hdr_bfreq(hdr) <= 3 || !__ballot((f0 > f1 ? f0 : f1) > (uint32_t)SCORE_TABLE_FREQS)) {
+            s0 = table_score(tbl, nb0, f0);
+            s1 = table_score(tbl, nb1, f1);
+          } else {  // a freq beyond the table's columns: the formula the table memoises (tbl[0..63] = the norm cache by rank)
+            s0 = bm25_score(wk, (float)(int32_t)f0, tbl[nb0]);
+            s1 = bm25_score(wk, (float)(int32_t)f1, tbl[nb1]);
+          }
+          add(e0, s0, true, false);
+          add(e1, s1, true, false);
+          touched_any = true;
+          wave_sync();
+          if (last >= w1) break;  // the block reaches into the next window: the cursor stays on it
+          ++cb;
+          have = more;
+          rows = rows2;
+          nn = nn2;
+        }
+        d_cb = lane == s ? cb : d_cb;
+        d_from = lane == s ? from : d_from;
+        put_window(s, Wn);
+      }
+    }
+
+    // ---- scan the window: every touched doc that no prohibited clause claimed (and that enough SHOULD clauses hold)
+    // is one collected hit; four docs per lane per step (one ds_read_b128), accumulators go back to "untouched"
+    if (touched_any) {
+      for (uint32_t i0 = 0; i0 < wlen; i0 += 256) {  // uniform trip count: the offer is a wave-wide operation
+        float4* cell = reinterpret_cast<float4*>(acc + i0 + 4 * lane);
+        const float4 v = *cell;
+        const uint32_t r0 = __float_as_uint(v.x), r1 = __float_as_uint(v.y), r2 = __float_as_uint(v.z), r3 = __float_as_uint(v.w);
+        if (__ballot((r0 & r1 & r2 & r3) != OR_UNTOUCHED)) {
+          // >= OR_EXCLUDED: untouched or excluded — no hit
+          bool h0 = r0 < OR_EXCLUDED, h1 = r1 < OR_EXCLUDED, h2 = r2 < OR_EXCLUDED, h3 = r3 < OR_EXCLUDED;
+          if (HAS_MSM) {
+            const uint32_t c4 = *reinterpret_cast<const uint32_t*>(cnt + i0 + 4 * lane);
+            h0 = h0 && (int)(c4 & 0xffu) >= msm;
+            h1 = h1 && (int)((c4 >> 8) & 0xffu) >= msm;
+            h2 = h2 && (int)((c4 >> 16) & 0xffu) >= msm;
+            h3 = h3 && (int)(c4 >> 24) >= msm;
+          }
+          hits_lane += (int)h0 + (int)h1 + (int)h2 + (int)h3;
+          *cell = make_float4(__uint_as_float(OR_UNTOUCHED), __uint_as_float(OR_UNTOUCHED), __uint_as_float(OR_UNTOUCHED), __uint_as_float(OR_UNTOUCHED));
+          // candidates: score order bits against the entry threshold's before any key is built
+          const uint32_t thi = (uint32_t)(tau >> 32);
+          const uint32_t o0 = float_order_bits(v.x), o1 = float_order_bits(v.y), o2 = float_order_bits(v.z), o3 = float_order_bits(v.w);
+          const bool c0 = h0 && o0 >= thi, c1 = h1 && o1 >= thi, c2 = h2 && o2 >= thi, c3 = h3 && o3 >= thi;
+          if (__ballot(c0 || c1 || c2 || c3)) {
+            const int32_t d = w0 + (int32_t)i0 + 4 * lane;
+            uint64_t key = c0 ? make_key(v.x, d) : 0ull;
+            if (__ballot(key > tau)) topk_offer<WIDE>(top, key, tau, k, lane, floor);
+            key = c1 ? make_key(v.y, d + 1) : 0ull;
+            if (__ballot(key > tau)) topk_offer<WIDE>(top, key, tau, k, lane, floor);
+            key = c2 ? make_key(v.z, d + 2) : 0ull;
+            if (__ballot(key > tau)) topk_offer<WIDE>(top, key, tau, k, lane, floor);
+            key = c3 ? make_key(v.w, d + 3) : 0ull;
+            if (__ballot(key > tau)) topk_offer<WIDE>(top, key, tau, k, lane, floor);
+          }
+        }
+      }
       wave_sync();
     }
-    // every touched doc that no prohibited clause claimed is one collected hit
-    if (!HAS_NOT && !HAS_MSM) count += nhits;
-    for (int i0 = 0; i0 < nhits; i0 += 64) {  // uniform trip count: the offer is a wave-wide operation
-      const bool valid = i0 + lane < nhits;
-      const int o = valid ? hits[i0 + lane] : 0;
-      const float a = valid ? acc[o] : 0.0f;
-      const bool hit = valid && (!HAS_NOT || __float_as_uint(a) != OR_EXCLUDED) && (!HAS_MSM || (int)cnt[o] >= msm);
-      if (HAS_NOT || HAS_MSM) count += __popcll(__ballot(hit));
-      const uint64_t key = hit ? make_key(a, w0 + o) : 0ull;
-      if (valid) acc[o] = __uint_as_float(OR_UNTOUCHED);
-      if (__ballot(key > tau)) topk_offer<WIDE>(top, key, tau, k, lane, floor);
+    if (exchange) {
+      shared.publish<WIDE>(top, k, lane);
+      shared.fold(seen, tau, floor);
     }
-    wave_sync();
   }
   shared.publish<WIDE>(top, k, lane);
   uint64_t* pk = partial_keys + (size_t)item * (size_t)k;
   if (lane < k) pk[lane] = top.a;
   if (WIDE && lane + 64 < k) pk[lane + 64] = top.b;
+  const int count = wave_reduce_add(hits_lane);
   if (lane == 0) partial_counts[item] = count;
 }
 

@@ -116,7 +116,7 @@ __device__ __forceinline__ void group_offer2(const GroupList& g, uint64_t key0, 
 template <bool LEGACY, bool WIDE>
 __device__ __forceinline__ void term_blocks_fast(const SegView& seg, const DevTerm& T, int b0, int b1, uint8_t* slab,
                                                  const float* cache, float wk, int lane, const GroupList& group,
-                                                 uint64_t floor, int k, int& count, bool prune) {
+                                                 SharedTau& shared, uint64_t& floor, int k, int& count, bool prune) {
   constexpr int DEPTH = PREFETCH_DEPTH;
   const uint8_t* term_rows = seg.bstore + T.bs_base;
   const uint8_t* pn = seg.pnorm + T.pn_base;
@@ -232,6 +232,8 @@ __device__ __forceinline__ void term_blocks_fast(const SegView& seg, const DevTe
     // with the threshold of the moment before every round: the threshold only rises, so a stale test is merely
     // conservative. Ring slots without a block (slot[j] < 0) reload the chunk's first block instead of being guarded:
     // a redundant load is cheaper than a load behind a branch.
+    tau = fresh_tau();
+    thr = pin(thr_of(tau));
     uint64_t todo = in_chunk & __ballot(best >= thr);
     int slot[DEPTH];
     uint4 ring[DEPTH];
@@ -376,7 +378,7 @@ __global__ __launch_bounds__(TERM_THREADS, 8) void k_search_term(SegView seg, co
       collect(std::true_type{}, d0, d1, f0, f1, nb0, nb1, true, true);
     };
     if (tabled && !has_live && nonneg) {
-      term_blocks_fast<LEGACY, WIDE>(seg, T, b0, b1, slab, cache, wk, lane, group, floor, k, count,
+      term_blocks_fast<LEGACY, WIDE>(seg, T, b0, b1, slab, cache, wk, lane, group, shared, floor, k, count,
                                      RGPU_TERM_PRUNE && (T.flags & TERM_FLAG_MONOTONE) != 0u);
       if (b1 > b0) base = seg.dir_last[T.dir_base + b1 - 1];
     } else if (has_norms) {

@@ -57,6 +57,7 @@ struct DevTerm {
   uint32_t pad;
 };
 constexpr uint32_t TERM_FLAG_MONOTONE = 1u;
+constexpr uint32_t TERM_FLAG_OR_DENSE = 2u;  // OR: this clause's FullBlocks are decoded inside the window kernel; only its tail runs through k_score_terms
 
 // Work description of one term for the skip-decode ("prepare") kernel.
 struct PrepTerm {

@@ -147,13 +147,15 @@ struct SharedTau {
     if (gu > floor) floor = gu;
     if (floor > tau) tau = floor;
   }
-  template <bool WIDE>
-  __device__ __forceinline__ void publish(const WaveTopK& t, int k, int lane) {
-    const uint64_t kth = topk_threshold<WIDE>(t, k);  // 0 until the list holds k keys
+  __device__ __forceinline__ void publish_key(uint64_t kth, int lane) {  // kth: wave-uniform, 0 = nothing to say yet
     if (kth > published) {
       if (lane == 0) atomicMax(slot, (unsigned long long)kth);
       published = kth;
     }
+  }
+  template <bool WIDE>
+  __device__ __forceinline__ void publish(const WaveTopK& t, int k, int lane) {
+    publish_key(topk_threshold<WIDE>(t, k), lane);  // 0 until the list holds k keys
   }
 };
 

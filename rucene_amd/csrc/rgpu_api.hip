@@ -100,11 +100,12 @@ struct Scratch {
   DevVec<HitOut> d_hits;
   DevVec<int64_t> d_totals;
   DevVec<unsigned long long> d_tau;  // per-query shared top-k thresholds
+  DevVec<unsigned long long> d_touched;  // AND: per-query encoded bytes of the blocks the kernel decoded
   hipEvent_t done = nullptr;
   bool busy = false;
   void release() {
     h_stage.release(); d_stage.release(); d_partial_keys.release(); d_partial_counts.release(); d_hits.release();
-    d_totals.release(); d_tau.release();
+    d_totals.release(); d_tau.release(); d_touched.release();
     if (done) (void)hipEventDestroy(done);
     done = nullptr;
   }
@@ -129,6 +130,8 @@ struct rgpu_ctx {
   DevVec<HitOut> host_api_hits;  // rgpu_search_batch (blocking, host outputs): device-side result rows
   DevVec<int64_t> host_api_totals;
   int* d_err = nullptr;
+  Scratch* last_and = nullptr;  // the slot whose d_touched the most recent AND launch filled
+  int last_and_queries = 0;
   // profiling
   std::vector<StatSlot> stats;
   std::vector<PendingEvent> pending;
@@ -425,6 +428,7 @@ extern "C" int32_t rgpu_init(int32_t device_ordinal, const rgpu_config* cfg, rgp
   if (!out_ctx) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "out_ctx is null");
   *out_ctx = nullptr;
   if (cfg && cfg->abi_version != RGPU_ABI_VERSION) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "rgpu_config.abi_version mismatch");
+  if (cfg) for (int32_t r : cfg->reserved) if (r != 0) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "rgpu_config.reserved must be zero");
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
     return fail(RGPU_ERR_RUNTIME, "no HIP device present: this library has no CPU fallback");
@@ -439,7 +443,7 @@ extern "C" int32_t rgpu_init(int32_t device_ordinal, const rgpu_config* cfg, rgp
   if (cfg) c->cfg = *cfg;
   c->cfg.abi_version = RGPU_ABI_VERSION;
   if (c->cfg.blocks_per_item <= 0) { c->cfg.blocks_per_item = 32; c->blocks_per_item_auto = true; }
-  if (c->cfg.reserved[0] <= 0) c->cfg.reserved[0] = 2;  // and_blocks_per_item
+  if (c->cfg.and_blocks_per_item <= 0) c->cfg.and_blocks_per_item = 2;
   std::snprintf(c->name, sizeof c->name, "%s (%s)", prop.name, prop.gcnArchName);
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipMalloc(&c->d_err, sizeof(int)) != hipSuccess) {
     delete c;
@@ -492,6 +496,30 @@ extern "C" int32_t rgpu_kernel_stats(rgpu_ctx* c, rgpu_kernel_stat* out, int32_t
     ++n;
   }
   return n;
+}
+
+extern "C" int32_t rgpu_set_profiling(rgpu_ctx* c, int32_t on) {
+  if (!c) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "ctx is null");
+  std::lock_guard<std::mutex> g(c->mu);
+  (void)hipSetDevice(c->device);
+  drain_events(c);
+  c->cfg.profile_kernels = on ? 1 : 0;
+  return RGPU_OK;
+}
+
+extern "C" int32_t rgpu_and_touched_bytes(rgpu_ctx* c, int64_t* bytes_out) {
+  if (!c || !bytes_out) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "null argument");
+  std::lock_guard<std::mutex> g(c->mu);
+  HIP_TRY(hipSetDevice(c->device));
+  *bytes_out = 0;
+  if (!c->last_and || c->last_and_queries <= 0) return RGPU_OK;
+  if (c->last_and->busy) { HIP_TRY(hipEventSynchronize(c->last_and->done)); c->last_and->busy = false; }
+  std::vector<unsigned long long> h((size_t)c->last_and_queries);
+  HIP_TRY(hipMemcpy(h.data(), c->last_and->d_touched.p, h.size() * 8, hipMemcpyDeviceToHost));
+  unsigned long long sum = 0;
+  for (auto v : h) sum += v;
+  *bytes_out = (int64_t)sum;
+  return RGPU_OK;
 }
 
 extern "C" void rgpu_kernel_stats_reset(rgpu_ctx* c) {
@@ -554,7 +582,7 @@ extern "C" int32_t rgpu_segment_upload(rgpu_ctx* c, const uint8_t* doc_file, siz
     uint8_t rank_of[256] = {0}, rank_to_norm[64] = {0};
     int used = 0;
     for (int b = 0; b < 256; ++b) if (hist[b]) { if (used < 64) { rank_of[b] = (uint8_t)used; rank_to_norm[used] = (uint8_t)b; } ++used; }
-    if (used <= 64 && !c->cfg.reserved[4]) {
+    if (used <= 64 && !c->cfg.raw_norms) {
       std::vector<uint8_t> ranks((size_t)max_doc);
       for (int32_t d = 0; d < max_doc; ++d) ranks[(size_t)d] = rank_of[norms[d]];
       if ((e = hipMalloc(&s->d_rank_to_norm, 64)) != hipSuccess) return bail(e, "hipMalloc(rank_to_norm)");
@@ -744,8 +772,30 @@ static int32_t search_or_group(rgpu_segment* seg, Group& G, int32_t k, HitOut* h
   const bool legacy = seg->version < 1;
   if (nt == 0) return RGPU_OK;  // every clause absent from this leaf: rows keep their {-1, 0} / 0 defaults
   HIP_TRY(scratch_take(c));
-  // phase 1 plan: items = (clause, chunk of blocks)
-  int blocks_per_item = c->cfg.blocks_per_item;
+  // Which clauses does the window kernel decode itself? Per query the (up to) `or_dense_clauses` longest SHOULD lists
+  // whose blocks are narrower than ~4 windows: df * 64 >= max_doc, i.e. a 128-posting block spans <= 8192 docs. On a
+  // Zipfian query those few lists hold ~90 % of the postings; every other clause (and every tail) goes through a run.
+  // Needs the per-clause LDS score table, i.e. norms held as ranks.
+  const int dense_max = c->cfg.or_dense_clauses < 0 ? 0 : (c->cfg.or_dense_clauses == 0 ? OR_DENSE_MAX : std::min(c->cfg.or_dense_clauses, OR_DENSE_MAX));
+  if (dense_max > 0 && seg->d_norms && seg->n_norm_ranks > 0) {
+    for (DevQuery& dq : G.queries) {
+      uint32_t mask = 0;
+      for (int pick = 0; pick < dense_max; ++pick) {
+        int best = -1;
+        for (int i = 0; i < dq.n_terms; ++i) {
+          const DevTerm& t = G.terms[(size_t)(dq.first_term + i)];
+          if (((mask >> i) & 1u) || t.nblocks < 1 || (int64_t)t.df * 64 < (int64_t)seg->max_doc) continue;
+          if (best < 0 || t.df > G.terms[(size_t)(dq.first_term + best)].df) best = i;
+        }
+        if (best < 0) break;
+        mask |= 1u << best;
+        G.terms[(size_t)(dq.first_term + best)].flags |= TERM_FLAG_OR_DENSE;
+      }
+      dq.op = (dq.op & 0xffff) | (int32_t)(mask << 16);
+    }
+  }
+  // phase 1 plan: items = (clause, chunk of blocks); a dense clause is one item (its tail)
+  int blocks_per_item = 32;
   std::vector<int64_t> item_prefix((size_t)nt + 1), run_prefix((size_t)nt + 1);
   int64_t items1 = 0, postings = 0;
   while (true) {
@@ -753,19 +803,24 @@ static int32_t search_or_group(rgpu_segment* seg, Group& G, int32_t k, HitOut* h
     for (int j = 0; j < nt; ++j) {
       item_prefix[(size_t)j] = items1;
       const DevTerm& t = G.terms[(size_t)j];
-      items1 += t.nblocks == 0 ? 1 : (t.nblocks + blocks_per_item - 1) / blocks_per_item;
+      const bool dense = (t.flags & TERM_FLAG_OR_DENSE) != 0u;
+      items1 += (t.nblocks == 0 || dense) ? 1 : (t.nblocks + blocks_per_item - 1) / blocks_per_item;
     }
     item_prefix[(size_t)nt] = items1;
     if (items1 <= 1048576 || blocks_per_item >= (1 << 17)) break;
     blocks_per_item *= 2;
   }
-  for (int j = 0; j < nt; ++j) { run_prefix[(size_t)j] = postings; postings += (int64_t)G.terms[(size_t)j].df + OR_RUN_PAD; }
+  for (int j = 0; j < nt; ++j) {
+    const DevTerm& t = G.terms[(size_t)j];
+    run_prefix[(size_t)j] = postings;
+    postings += (int64_t)((t.flags & TERM_FLAG_OR_DENSE) ? t.tail_n : t.df) + OR_RUN_PAD;
+  }
   run_prefix[(size_t)nt] = postings;  // run lengths include the sentinel padding
-  // phase 2 plan: items = (query, group of windows), one per wavefront
-  int W = std::min(4096, std::max(256, c->cfg.reserved[3] > 0 ? (c->cfg.reserved[3] + 255) / 256 * 256 : 1024));
+  // phase 2 plan: items = (query, group of windows), one per wavefront; a workgroup's wavefronts share one query
+  int W = std::min(4096, std::max(256, c->cfg.or_window_docs > 0 ? (c->cfg.or_window_docs + 255) / 256 * 256 : 2048));
   const int wpq = std::max(1, (seg->max_doc + W - 1) / W);
   const int wpi = (int)std::max<int64_t>(1, ((int64_t)nq * wpq + 131071) / 131072);
-  const int ipq = (wpq + wpi - 1) / wpi;
+  const int ipq = ((wpq + wpi - 1) / wpi + WG_WAVES - 1) / WG_WAVES * WG_WAVES;
   const int64_t items2 = (int64_t)nq * ipq;
   std::vector<int64_t> merge_prefix((size_t)nq + 1);
   for (int q = 0; q <= nq; ++q) merge_prefix[(size_t)q] = (int64_t)q * ipq;
@@ -811,9 +866,9 @@ static int32_t search_or_group(rgpu_segment* seg, Group& G, int32_t k, HitOut* h
   {
     TimedLaunch tl(c, stream, "k_or_windows", G.postings);
     bool has_not = false, has_msm = false;
-    for (const DevQuery& dq : G.queries) { has_not = has_not || dq.pad != 0; has_msm = has_msm || (dq.op >> 8) > 1; }
-    const size_t lds = (size_t)WG_WAVES * (size_t)W * (has_msm ? 7 : 6);
-    const unsigned grid = (unsigned)((items2 + WG_WAVES - 1) / WG_WAVES);
+    for (const DevQuery& dq : G.queries) { has_not = has_not || dq.pad != 0; has_msm = has_msm || ((dq.op >> 8) & 0xff) > 1; }
+    const size_t lds = or_lds_bytes(W, has_msm);
+    const unsigned grid = (unsigned)(items2 / WG_WAVES);  // exact: items_per_query is a multiple of WG_WAVES
     auto go = [&](auto kern) -> hipError_t {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
@@ -821,13 +876,14 @@ static int32_t search_or_group(rgpu_segment* seg, Group& G, int32_t k, HitOut* h
                          c->S->d_partial_keys.p, c->S->d_partial_counts.p, c->S->d_tau.p);
       return hipSuccess;
     };
-    if (has_msm) {  // min_should_match > 1 somewhere: the general instantiation (it also handles MUST_NOT clauses)
-      HIP_TRY(wide ? go(k_or_windows<true, true, true>) : go(k_or_windows<false, true, true>));
-    } else if (has_not) {
-      HIP_TRY(wide ? go(k_or_windows<true, true, false>) : go(k_or_windows<false, true, false>));
-    } else {
-      HIP_TRY(wide ? go(k_or_windows<true, false, false>) : go(k_or_windows<false, false, false>));
-    }
+    auto pick = [&](auto legacy_tag) -> hipError_t {
+      constexpr bool LG = decltype(legacy_tag)::value;
+      if (has_msm)  // min_should_match > 1 somewhere: the general instantiation (it also handles MUST_NOT clauses)
+        return wide ? go(k_or_windows<LG, true, true, true>) : go(k_or_windows<LG, false, true, true>);
+      if (has_not) return wide ? go(k_or_windows<LG, true, true, false>) : go(k_or_windows<LG, false, true, false>);
+      return wide ? go(k_or_windows<LG, true, false, false>) : go(k_or_windows<LG, false, false, false>);
+    };
+    HIP_TRY(legacy ? pick(std::true_type{}) : pick(std::false_type{}));
   }
   if (wide) launch_merge<true>(c, stream, nq, k, dmp, seg->doc_base, c->S->d_hits.p, c->S->d_totals.p);
   else launch_merge<false>(c, stream, nq, k, dmp, seg->doc_base, c->S->d_hits.p, c->S->d_totals.p);
@@ -949,7 +1005,7 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
       continue;
     }
     HIP_TRY(scratch_take(c));
-    int blocks_per_item = op == RGPU_OP_TERM ? c->cfg.blocks_per_item : c->cfg.reserved[0];
+    int blocks_per_item = op == RGPU_OP_TERM ? c->cfg.blocks_per_item : c->cfg.and_blocks_per_item;
     int64_t items = 0;
     G.item_prefix.assign((size_t)nq + 1, 0);
     const int head_items = op == RGPU_OP_TERM ? nq : 0;  // TERM: every query's first chunk is scheduled first
@@ -957,8 +1013,10 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
       if (op == RGPU_OP_TERM && c->blocks_per_item_auto) {  // fewer, longer items when there are plenty of blocks
         int64_t total_blocks = 0;
         for (auto& t : G.terms) total_blocks += t.nblocks;
+        // with block-max pruning most blocks cost a directory word, so an item's fixed cost (term descriptor, score
+        // table, one threshold look-up) is spread over up to 512 of them while the launch still fills the chip
         blocks_per_item = 8;
-        while (blocks_per_item < 128 && total_blocks / blocks_per_item > 20000) blocks_per_item *= 2;
+        while (blocks_per_item < 512 && total_blocks / blocks_per_item > 6000) blocks_per_item *= 2;
       }
       while (true) {
         items = 0;
@@ -1002,11 +1060,15 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
     const int32_t* dm = reinterpret_cast<const int32_t*>(c->S->d_stage.p + o_m);
     const SegView sv = seg_view(seg);
     if (op == RGPU_OP_AND) {
+      HIP_TRY(c->S->d_touched.reserve((size_t)nq, 0, stream));
+      HIP_TRY(hipMemsetAsync(c->S->d_touched.p, 0, (size_t)nq * 8, stream));
+      c->last_and = c->S;
+      c->last_and_queries = nq;
       TimedLaunch tl(c, stream, "k_search_and", G.postings);
       const unsigned grid = (unsigned)((items + WG_WAVES - 1) / WG_WAVES);
       auto go = [&](auto kern) {
         hipLaunchKernelGGL(kern, dim3(grid), dim3(WG_THREADS), 0, stream, sv, dq, dt, dp, nq, items, blocks_per_item, (int)k,
-                           c->S->d_partial_keys.p, c->S->d_partial_counts.p, c->S->d_tau.p);
+                           c->S->d_partial_keys.p, c->S->d_partial_counts.p, c->S->d_tau.p, c->S->d_touched.p);
       };
       bool has_not = false, has_opt = false;
       for (const DevQuery& q : G.queries) { has_not = has_not || q.pad != 0; has_opt = has_opt || (q.op >> 16) != 0; }
