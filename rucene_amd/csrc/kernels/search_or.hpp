@@ -102,23 +102,30 @@ __global__ __launch_bounds__(WG_THREADS) void k_score_terms(SegView seg, const D
 constexpr int OR_MAX_TERMS = 16;
 constexpr int OR_RUN_PAD = 64;  // sentinel entries {doc = INT_MAX} after every clause's run (written by k_score_terms)
 constexpr int OR_DENSE_MAX = 4;  // clauses per query decoded inside the window kernel (score tables: one per wave of a workgroup)
+// The window walk is a chain of dependent steps per clause (LDS read-modify-write of the accumulator, cursor hand-over),
+// so the kernel lives on occupancy: eight wavefronts per workgroup share the dense clauses' score tables (12 KB), and
+// the per-wave state is kept under 80 VGPRs — a first version that held directory windows and prefetched block heads in
+// registers (135 VGPRs, 3 waves/SIMD) ran 2.2x slower than the run-only kernel it replaced.
+constexpr int OR_PREFETCH = 8;  // run heads requested at the start of a window (two VGPRs each)
+constexpr int OR_WAVES = 8;
+constexpr int OR_THREADS = 64 * OR_WAVES;
 constexpr uint32_t OR_UNTOUCHED = 0xffffffffu;  // accumulator patterns no sum of scores produces (negative quiet NaNs)
 constexpr uint32_t OR_EXCLUDED = 0xfffffffeu;
-static_assert(OR_DENSE_MAX <= WG_WAVES, "wave w of a workgroup builds dense clause w's score table");
+static_assert(OR_DENSE_MAX <= OR_WAVES, "wave w of a workgroup builds dense clause w's score table");
 
 __host__ __device__ constexpr size_t or_wave_lds_bytes(int W, bool msm) { return (size_t)(2 * SLAB_STREAM) + (size_t)W * (msm ? 5 : 4); }
 __host__ __device__ constexpr size_t or_lds_bytes(int W, bool msm) {
-  return (size_t)OR_DENSE_MAX * WAVE_CACHE_FLOATS * 4 + (size_t)WG_WAVES * or_wave_lds_bytes(W, msm);
+  return (size_t)OR_DENSE_MAX * WAVE_CACHE_FLOATS * 4 + (size_t)OR_WAVES * or_wave_lds_bytes(W, msm);
 }
 
 // items = (query, group of `windows_per_item` windows of `W` docs), one per wavefront; items_per_query is a multiple
-// of WG_WAVES, so the wavefronts of a workgroup always work on the same query and share its dense clauses' score
+// of OR_WAVES, so the wavefronts of a workgroup always work on the same query and share its dense clauses' score
 // tables. DevQuery::op carries the query's dense-clause mask in bits 16.. (bit i = SHOULD clause i).
 // HAS_NOT: some query of the launch carries MUST_NOT clauses; HAS_MSM: some query asks for min_should_match > 1
 // (disjunction_scorer.rs:317-329: a doc is a hit only if that many SHOULD clauses hold it — a per-doc clause counter
 // next to the accumulator). Separate instantiations keep the common kernel lean.
 template <bool LEGACY, bool WIDE, bool HAS_NOT, bool HAS_MSM>
-__global__ __launch_bounds__(WG_THREADS, 3) void k_or_windows(SegView seg, const DevQuery* __restrict__ queries,
+__global__ __launch_bounds__(OR_THREADS, 6) void k_or_windows(SegView seg, const DevQuery* __restrict__ queries,
                                                               const DevTerm* __restrict__ terms,
                                                               const int64_t* __restrict__ run_prefix,
                                                               const ScoredPosting* __restrict__ runs, int n_queries,
@@ -138,9 +145,13 @@ __global__ __launch_bounds__(WG_THREADS, 3) void k_or_windows(SegView seg, const
   uint8_t* slab = slice;
   float* acc = reinterpret_cast<float*>(slice + 2 * SLAB_STREAM);
   uint8_t* cnt = reinterpret_cast<uint8_t*>(acc + W);  // HAS_MSM only: SHOULD clauses that hold the doc
-  const int64_t item = (int64_t)blockIdx.x * WG_WAVES + wave;  // the grid is exactly n_queries * items_per_query / WG_WAVES
-  const int q = (int)(item / items_per_query);
-  const int g = (int)(item - (int64_t)q * items_per_query);
+  // Workgroup b works on query b % n_queries: a query's workgroups are spread over the whole launch instead of running
+  // side by side, so all but the first one or two start from the thresholds the earlier ones published (SharedTau) —
+  // query-major order made every wavefront build its own top-k from nothing, ~460 insertions each, which was over half
+  // of the kernel's time. The grid is exactly n_queries * items_per_query / OR_WAVES workgroups.
+  const int q = (int)(blockIdx.x % (unsigned)n_queries);
+  const int g = (int)(blockIdx.x / (unsigned)n_queries) * OR_WAVES + wave;
+  const int64_t item = (int64_t)q * items_per_query + g;
   const DevQuery Q = queries[q];
   const bool has_live = seg.live != nullptr;
   const uint32_t dense_mask = ((uint32_t)Q.op >> 16) & 0xffffu;
@@ -194,47 +205,21 @@ __global__ __launch_bounds__(WG_THREADS, 3) void k_or_windows(SegView seg, const
   }
   int32_t my_next = mine ? runs[my_at].doc : 0x7fffffff;  // doc under the cursor (INT_MAX: the run is exhausted)
 
-  // ---- dense clauses: lane s (< nd) holds slot s's term fields and cursor; every slot keeps a 64-entry window of its
-  // block directory in registers (DirWindow, search_and.hpp)
+  // ---- dense clauses: lane s (< nd) holds slot s's term fields and its cursor (the first block that may still hold a doc
+  // of the current window); directory entries are read through the scalar cache (wave-uniform addresses)
   uint64_t d_bs = 0, d_pn = 0;
   uint32_t d_dir = 0;
-  int32_t d_nb = 0, d_cb = 0, d_from = 0;
+  int32_t d_nb = 0, d_cb = 0;
   float d_wk = 0.f;
   if (lane < nd) {
     const DevTerm* Td = terms + Q.first_term + nth_bit(dense_mask, lane);
     d_bs = Td->bs_base; d_pn = Td->pn_base; d_dir = Td->dir_base; d_nb = Td->nblocks;
     d_wk = Td->weight * (seg.sim_tables[(size_t)Td->sim_table * 257 + 256] + 1.0f);
   }
-  // four named windows, selected with scalar-condition moves: an array indexed by the (wave-uniform but dynamic) slot
-  // number is put in scratch memory by the compiler, one load and one store per dense visit
-  DirWindow Wd0, Wd1, Wd2, Wd3;
-  auto init_window = [&](DirWindow& Wx, int s) {
-    Wx.last = 0x7fffffff; Wx.row = 0u; Wx.hdr = 0u;
-    if (s < nd) {
-      const uint32_t dir = (uint32_t)readlane((int)d_dir, s);
-      const int nb = readlane(d_nb, s);
-      const int cb = find_block_wave(seg.dir_last, dir, 0, nb, first_doc, lane);  // first block that reaches this item's docs
-      d_cb = lane == s ? cb : d_cb;
-      d_from = lane == s ? cb : d_from;
-      Wx.load(seg, dir, nb, cb, lane);
-    }
-  };
-  init_window(Wd0, 0); init_window(Wd1, 1); init_window(Wd2, 2); init_window(Wd3, 3);
-  auto sel = [](int s, uint32_t a, uint32_t b, uint32_t c, uint32_t d) -> uint32_t { return s == 0 ? a : (s == 1 ? b : (s == 2 ? c : d)); };
-  auto pick_window = [&](int s) -> DirWindow {
-    DirWindow r;
-    r.last = (int32_t)sel(s, (uint32_t)Wd0.last, (uint32_t)Wd1.last, (uint32_t)Wd2.last, (uint32_t)Wd3.last);
-    r.row = sel(s, Wd0.row, Wd1.row, Wd2.row, Wd3.row);
-    r.hdr = sel(s, Wd0.hdr, Wd1.hdr, Wd2.hdr, Wd3.hdr);
-    return r;
-  };
-  auto put_window = [&](int s, const DirWindow& w) {
-    // field by field: a ternary over whole structs becomes a pointer select, which forces all four into memory
-    Wd0.last = s == 0 ? w.last : Wd0.last; Wd0.row = s == 0 ? w.row : Wd0.row; Wd0.hdr = s == 0 ? w.hdr : Wd0.hdr;
-    Wd1.last = s == 1 ? w.last : Wd1.last; Wd1.row = s == 1 ? w.row : Wd1.row; Wd1.hdr = s == 1 ? w.hdr : Wd1.hdr;
-    Wd2.last = s == 2 ? w.last : Wd2.last; Wd2.row = s == 2 ? w.row : Wd2.row; Wd2.hdr = s == 2 ? w.hdr : Wd2.hdr;
-    Wd3.last = s == 3 ? w.last : Wd3.last; Wd3.row = s == 3 ? w.row : Wd3.row; Wd3.hdr = s == 3 ? w.hdr : Wd3.hdr;
-  };
+  for (int s = 0; s < nd; ++s) {
+    const int cb = find_block_wave(seg.dir_last, (uint32_t)readlane((int)d_dir, s), 0, readlane(d_nb, s), first_doc, lane);
+    d_cb = lane == s ? cb : d_cb;
+  }
 
   for (int i = lane; i < W; i += 64) acc[i] = __uint_as_float(OR_UNTOUCHED);
   wave_sync();
@@ -242,41 +227,15 @@ __global__ __launch_bounds__(WG_THREADS, 3) void k_or_windows(SegView seg, const
     const int32_t w0 = win * W;
     const int32_t w1 = min(seg.max_doc, w0 + W);
     const uint32_t wlen = (uint32_t)(w1 - w0);
-    const bool exchange = ((win - win0) & 7) == 7;  // thresholds travel between the wavefronts of a query every 8 windows
-    const uint64_t seen = exchange ? shared.peek() : 0ull;
     // ---- loads first: the first 64 run entries of EVERY clause with a posting in this window (one exposed load latency
     // per window instead of one per clause: the window walk is latency bound), and the first block of every dense clause
     const uint64_t active0 = __ballot(my_next < w1);
-    ScoredPosting pre[OR_MAX_TERMS];
+    ScoredPosting pre[OR_PREFETCH];  // clause positions beyond OR_PREFETCH load when their turn comes
 #pragma unroll
-    for (int t = 0; t < OR_MAX_TERMS; ++t) {
+    for (int t = 0; t < OR_PREFETCH; ++t) {
       pre[t] = ScoredPosting{0x7fffffff, 0.f};
       if ((active0 >> t) & 1ull) pre[t] = runs[(int64_t)readlane64((uint64_t)my_at, t) + lane];  // wave-uniform branch
     }
-    uint4 hrows0 = make_uint4(0u, 0u, 0u, 0u), hrows1 = hrows0, hrows2 = hrows0, hrows3 = hrows0;
-    uint32_t hnorm0 = 0u, hnorm1 = 0u, hnorm2 = 0u, hnorm3 = 0u;
-    uint32_t hmask = 0;  // dense slots whose first block of this window is in flight
-    auto head = [&](DirWindow& Wx, uint4& hrows, uint32_t& hnorm, int s) {
-      if (s < nd) {
-        const int cb = readlane(d_cb, s), nb = readlane(d_nb, s);
-        int from = readlane(d_from, s);
-        if (cb < nb) {
-          if (cb - from + 1 > 63) {  // the cursor left the register window: move it
-            from = cb;
-            Wx.load(seg, (uint32_t)readlane((int)d_dir, s), nb, from, lane);
-            d_from = lane == s ? from : d_from;
-          }
-          const int jj = cb - from + 1;
-          if (readlane(Wx.last, jj - 1) < w1 - 1) {  // the block starts before the window ends
-            const uint32_t hdr = (uint32_t)readlane((int)Wx.hdr, jj);
-            hrows = block_rows_load(block_rows_at(seg.bstore + readlane64(d_bs, s), (uint32_t)readlane((int)Wx.row, jj)), hdr, lane);
-            hnorm = *reinterpret_cast<const uint16_t*>(seg.pnorm + readlane64(d_pn, s) + (128u * (uint32_t)cb + 2u * (uint32_t)lane));
-            hmask |= 1u << s;
-          }
-        }
-      }
-    };
-    head(Wd0, hrows0, hnorm0, 0); head(Wd1, hrows1, hnorm1, 1); head(Wd2, hrows2, hnorm2, 2); head(Wd3, hrows3, hnorm3, 3);
     bool touched_any = false;  // wave-uniform: some accumulator of this window was written
 
     // one posting into the window's accumulator (all docs of one clause are distinct: no two lanes meet)
@@ -301,11 +260,10 @@ __global__ __launch_bounds__(WG_THREADS, 3) void k_or_windows(SegView seg, const
       // ---- the clause's run (a sparse clause's postings, a dense clause's VInt tail)
       if ((active0 >> t) & 1ull) {
         ScoredPosting e;
-        switch (t) {  // register select behind scalar branches: the loop body exists once, not sixteen times
+        switch (t) {  // register select behind scalar branches: the loop body exists once, not once per clause position
           case 0: e = pre[0]; break; case 1: e = pre[1]; break; case 2: e = pre[2]; break; case 3: e = pre[3]; break;
           case 4: e = pre[4]; break; case 5: e = pre[5]; break; case 6: e = pre[6]; break; case 7: e = pre[7]; break;
-          case 8: e = pre[8]; break; case 9: e = pre[9]; break; case 10: e = pre[10]; break; case 11: e = pre[11]; break;
-          case 12: e = pre[12]; break; case 13: e = pre[13]; break; case 14: e = pre[14]; break; default: e = pre[15]; break;
+          default: e = runs[(int64_t)readlane64((uint64_t)my_at, t) + lane]; break;
         }
         int taken = 0;
         int32_t next;
@@ -325,12 +283,7 @@ __global__ __launch_bounds__(WG_THREADS, 3) void k_or_windows(SegView seg, const
       const int ci = t - n_not;
       if (ci >= 0 && ((dense_mask >> ci) & 1u)) {
         const int s = __popc(dense_mask & ((1u << ci) - 1u));
-        DirWindow Wn = pick_window(s);
-        uint4 rows = make_uint4(sel(s, hrows0.x, hrows1.x, hrows2.x, hrows3.x), sel(s, hrows0.y, hrows1.y, hrows2.y, hrows3.y),
-                                sel(s, hrows0.z, hrows1.z, hrows2.z, hrows3.z), sel(s, hrows0.w, hrows1.w, hrows2.w, hrows3.w));
-        uint32_t nn = sel(s, hnorm0, hnorm1, hnorm2, hnorm3);
-        bool have = (hmask >> s) & 1u;
-        int cb = readlane(d_cb, s), from = readlane(d_from, s);
+        int cb = readlane(d_cb, s);
         const int nb = readlane(d_nb, s);
         const uint32_t dir = (uint32_t)readlane((int)d_dir, s);
         const uint8_t* term_rows = seg.bstore + readlane64(d_bs, s);
@@ -338,29 +291,12 @@ __global__ __launch_bounds__(WG_THREADS, 3) void k_or_windows(SegView seg, const
         const float* tbl = tables + s * WAVE_CACHE_FLOATS;
         const float wk = __int_as_float(readlane(__float_as_int(d_wk), s));
         while (cb < nb) {
-          int jj = cb - from + 1;
-          if (jj > 63) {
-            from = cb;
-            Wn.load(seg, dir, nb, from, lane);
-            jj = 1;
-          }
-          const int32_t base = readlane(Wn.last, jj - 1);
+          const int32_t base = cb == 0 ? 0 : seg.dir_last[dir + cb - 1];
           if (base >= w1 - 1) break;  // the block's docs lie beyond this window
-          const int32_t last = readlane(Wn.last, jj);
-          const uint32_t hdr = (uint32_t)readlane((int)Wn.hdr, jj);
-          if (!have) {
-            rows = block_rows_load(block_rows_at(term_rows, (uint32_t)readlane((int)Wn.row, jj)), hdr, lane);
-            nn = *reinterpret_cast<const uint16_t*>(pn + (128u * (uint32_t)cb + 2u * (uint32_t)lane));
-          }
-          // the clause's next block also belongs to this window: request it before this one is unpacked
-          const bool more = last < w1 - 1 && cb + 1 < nb && jj + 1 <= 63;
-          uint4 rows2 = rows;
-          uint32_t nn2 = nn;
-          if (more) {
-            const uint32_t hdr2 = (uint32_t)readlane((int)Wn.hdr, jj + 1);
-            rows2 = block_rows_load(block_rows_at(term_rows, (uint32_t)readlane((int)Wn.row, jj + 1)), hdr2, lane);
-            nn2 = *reinterpret_cast<const uint16_t*>(pn + (128u * (uint32_t)(cb + 1) + 2u * (uint32_t)lane));
-          }
+          const int32_t last = seg.dir_last[dir + cb];
+          const uint32_t hdr = seg.dir_hdr[dir + cb];
+          const uint4 rows = block_rows_load(block_rows_at(term_rows, seg.dir_row[dir + cb]), hdr, lane);
+          const uint32_t nn = *reinterpret_cast<const uint16_t*>(pn + (128u * (uint32_t)cb + 2u * (uint32_t)lane));
           stage_rows(rows, slab, lane);
           wave_sync();
           uint32_t x0, x1, f0, f1;
@@ -384,19 +320,17 @@ __global__ __launch_bounds__(WG_THREADS, 3) void k_or_windows(SegView seg, const
           wave_sync();
           if (last >= w1) break;  // the block reaches into the next window: the cursor stays on it
           ++cb;
-          have = more;
-          rows = rows2;
-          nn = nn2;
         }
         d_cb = lane == s ? cb : d_cb;
-        d_from = lane == s ? from : d_from;
-        put_window(s, Wn);
       }
     }
 
     // ---- scan the window: every touched doc that no prohibited clause claimed (and that enough SHOULD clauses hold)
     // is one collected hit; four docs per lane per step (one ds_read_b128), accumulators go back to "untouched"
-    if (touched_any) {
+#ifndef RGPU_OR_ABL  // developer ablations (variant builds only; results are wrong)
+#define RGPU_OR_ABL 0
+#endif
+    if (touched_any && RGPU_OR_ABL != 2) {
       for (uint32_t i0 = 0; i0 < wlen; i0 += 256) {  // uniform trip count: the offer is a wave-wide operation
         float4* cell = reinterpret_cast<float4*>(acc + i0 + 4 * lane);
         const float4 v = *cell;
@@ -417,7 +351,7 @@ __global__ __launch_bounds__(WG_THREADS, 3) void k_or_windows(SegView seg, const
           const uint32_t thi = (uint32_t)(tau >> 32);
           const uint32_t o0 = float_order_bits(v.x), o1 = float_order_bits(v.y), o2 = float_order_bits(v.z), o3 = float_order_bits(v.w);
           const bool c0 = h0 && o0 >= thi, c1 = h1 && o1 >= thi, c2 = h2 && o2 >= thi, c3 = h3 && o3 >= thi;
-          if (__ballot(c0 || c1 || c2 || c3)) {
+          if (RGPU_OR_ABL != 1 && __ballot(c0 || c1 || c2 || c3)) {
             const int32_t d = w0 + (int32_t)i0 + 4 * lane;
             uint64_t key = c0 ? make_key(v.x, d) : 0ull;
             if (__ballot(key > tau)) topk_offer<WIDE>(top, key, tau, k, lane, floor);
@@ -431,10 +365,6 @@ __global__ __launch_bounds__(WG_THREADS, 3) void k_or_windows(SegView seg, const
         }
       }
       wave_sync();
-    }
-    if (exchange) {
-      shared.publish<WIDE>(top, k, lane);
-      shared.fold(seen, tau, floor);
     }
   }
   shared.publish<WIDE>(top, k, lane);

@@ -773,9 +773,11 @@ static int32_t search_or_group(rgpu_segment* seg, Group& G, int32_t k, HitOut* h
   if (nt == 0) return RGPU_OK;  // every clause absent from this leaf: rows keep their {-1, 0} / 0 defaults
   HIP_TRY(scratch_take(c));
   // Which clauses does the window kernel decode itself? Per query the (up to) `or_dense_clauses` longest SHOULD lists
-  // whose blocks are narrower than ~4 windows: df * 64 >= max_doc, i.e. a 128-posting block spans <= 8192 docs. On a
-  // Zipfian query those few lists hold ~90 % of the postings; every other clause (and every tail) goes through a run.
-  // Needs the per-clause LDS score table, i.e. norms held as ranks.
+  // whose 128-posting blocks span at most two windows on average (df * W >= 64 * max_doc): a block is unpacked again
+  // in every window it reaches into, so a sparser list is cheaper through a run. On a Zipfian query those few lists
+  // hold most of the postings; every other clause (and every tail) goes through a run. Needs the per-clause LDS score
+  // table, i.e. norms held as ranks.
+  const int W = std::min(4096, std::max(256, c->cfg.or_window_docs > 0 ? (c->cfg.or_window_docs + 255) / 256 * 256 : 1024));
   const int dense_max = c->cfg.or_dense_clauses < 0 ? 0 : (c->cfg.or_dense_clauses == 0 ? OR_DENSE_MAX : std::min(c->cfg.or_dense_clauses, OR_DENSE_MAX));
   if (dense_max > 0 && seg->d_norms && seg->n_norm_ranks > 0) {
     for (DevQuery& dq : G.queries) {
@@ -784,7 +786,7 @@ static int32_t search_or_group(rgpu_segment* seg, Group& G, int32_t k, HitOut* h
         int best = -1;
         for (int i = 0; i < dq.n_terms; ++i) {
           const DevTerm& t = G.terms[(size_t)(dq.first_term + i)];
-          if (((mask >> i) & 1u) || t.nblocks < 1 || (int64_t)t.df * 64 < (int64_t)seg->max_doc) continue;
+          if (((mask >> i) & 1u) || t.nblocks < 1 || (int64_t)t.df * W < 64 * (int64_t)seg->max_doc) continue;
           if (best < 0 || t.df > G.terms[(size_t)(dq.first_term + best)].df) best = i;
         }
         if (best < 0) break;
@@ -817,10 +819,9 @@ static int32_t search_or_group(rgpu_segment* seg, Group& G, int32_t k, HitOut* h
   }
   run_prefix[(size_t)nt] = postings;  // run lengths include the sentinel padding
   // phase 2 plan: items = (query, group of windows), one per wavefront; a workgroup's wavefronts share one query
-  int W = std::min(4096, std::max(256, c->cfg.or_window_docs > 0 ? (c->cfg.or_window_docs + 255) / 256 * 256 : 2048));
   const int wpq = std::max(1, (seg->max_doc + W - 1) / W);
   const int wpi = (int)std::max<int64_t>(1, ((int64_t)nq * wpq + 131071) / 131072);
-  const int ipq = ((wpq + wpi - 1) / wpi + WG_WAVES - 1) / WG_WAVES * WG_WAVES;
+  const int ipq = ((wpq + wpi - 1) / wpi + OR_WAVES - 1) / OR_WAVES * OR_WAVES;
   const int64_t items2 = (int64_t)nq * ipq;
   std::vector<int64_t> merge_prefix((size_t)nq + 1);
   for (int q = 0; q <= nq; ++q) merge_prefix[(size_t)q] = (int64_t)q * ipq;
@@ -868,11 +869,11 @@ static int32_t search_or_group(rgpu_segment* seg, Group& G, int32_t k, HitOut* h
     bool has_not = false, has_msm = false;
     for (const DevQuery& dq : G.queries) { has_not = has_not || dq.pad != 0; has_msm = has_msm || ((dq.op >> 8) & 0xff) > 1; }
     const size_t lds = or_lds_bytes(W, has_msm);
-    const unsigned grid = (unsigned)(items2 / WG_WAVES);  // exact: items_per_query is a multiple of WG_WAVES
+    const unsigned grid = (unsigned)(items2 / OR_WAVES);  // exact: items_per_query is a multiple of OR_WAVES
     auto go = [&](auto kern) -> hipError_t {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
-      hipLaunchKernelGGL(kern, dim3(grid), dim3(WG_THREADS), lds, stream, sv, dq, dt, drp, c->d_runs.p, nq, wpq, wpi, ipq, W, (int)k,
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(OR_THREADS), lds, stream, sv, dq, dt, drp, c->d_runs.p, nq, wpq, wpi, ipq, W, (int)k,
                          c->S->d_partial_keys.p, c->S->d_partial_counts.p, c->S->d_tau.p);
       return hipSuccess;
     };
@@ -918,8 +919,9 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
   int32_t rc = prepare_terms_locked(seg, ptrs.data(), ptrs.size());
   if (rc != RGPU_OK) return rc;
 
-  // one group per op; OR groups are cut so that a group's scored runs stay below ~12 GiB of HBM scratch
-  const int64_t or_postings_cap = 1500000000LL;
+  // one group per op; OR groups are cut so that a group's scored runs stay below ~24 GiB of HBM scratch (288 GB per GPU; with the
+  // dense clauses decoded inside the window kernel only about a third of a Zipfian batch's postings go through a run at all)
+  const int64_t or_postings_cap = 3000000000LL;
   std::vector<Group> groups(3);
   int cur_group[3] = {0, 1, 2};
   for (int i = 0; i < 3; ++i) groups[(size_t)i].op = i;
