@@ -127,13 +127,17 @@ def main():
     if dist_mode:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        # torch.distributed is job plumbing here (communicator id, barriers, max of the time): gloo. The data path's
+        # collective is the library's own RCCL all-gather (rgpu_search_batch_sharded).
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     cores = os.cpu_count() or 1
     nq = args.queries
     T, B = rucene_amd.TermQuery, rucene_amd.BooleanQuery
     ctx = rucene_amd.Context(device=local_rank, profile_kernels=False)
     from rucene_amd import dist as rdist
-    merge = rdist.hip_merge(ctx)
+    # N > 1: the collective lives behind the C ABI (rgpu_comm_*: RCCL linked into librucene_gpu.so); torch.distributed only
+    # carries the 128-byte communicator id, the barriers around the timed region and the max-over-ranks of the time
+    comm = rdist.create_comm(ctx) if dist_mode else None
 
     class Shard:
         """One segment resident in HBM + the searcher over it (statistics of shard 0, the first largest leaf)."""
@@ -175,12 +179,15 @@ def main():
             self.stream = torch.cuda.Stream()
             self.hits = torch.empty((nq, k), dtype=torch.int64, device="cuda")      # rgpu_hit {i32 doc, f32 score}
             self.totals = torch.empty((nq,), dtype=torch.int64, device="cuda")
+            self.local_hits = torch.empty((nq, k), dtype=torch.int64, device="cuda")  # this rank's shard alone (parity checks)
+            self.local_totals = torch.empty((nq,), dtype=torch.int64, device="cuda")
 
     def measure(shard, kind, k, steps, warmup, two_streams, with_planning=True):
         """Times `steps` passes of one batch. rgpu_search_batch_device only enqueues (staging copy + kernels): back-to-back
         steps overlap the host-side planning of batch i+1 with the kernels of batch i; the timed region is bracketed by a
-        barrier + device-wide synchronize on both sides and runs WITHOUT per-kernel events. N > 1: a step = search ->
-        RCCL all-gather of the per-shard top-k -> device merge, enqueued in order on one stream without host syncs.
+        barrier + device-wide synchronize on both sides and runs WITHOUT per-kernel events. N > 1: a step =
+        rgpu_search_batch_sharded: search -> ONE RCCL all-gather of the per-shard {top-k, count} records -> device merge,
+        enqueued in order on one stream without host syncs.
         Returns wall figures for one stream, for two alternating streams (the small merge / scatter kernels and the tail
         of step i then run under step i+1's search kernel), for one stream with the query planning (pack: term
         resolution, BM25 weights, sim table) redone every step, and the isolated per-kernel durations (HIP events on one
@@ -193,16 +200,11 @@ def main():
         def step(pk, n_lanes):
             lane = lanes[state["n"] % n_lanes]
             state["n"] += 1
-            merged["local_hits"], merged["local_totals"] = lane.hits, lane.totals
-
-            def local():
-                shard.leaf.segment.search_batch_device(pk[0], pk[1], k, lane.hits.data_ptr(), lane.totals.data_ptr(), lane.stream.cuda_stream)
-                return lane.hits, lane.totals
+            merged["hits"], merged["totals"] = lane.hits, lane.totals
             if dist_mode:
-                with torch.cuda.stream(lane.stream):
-                    merged["hits"], merged["totals"] = rdist.sharded_search(local, merge)
+                comm.search_batch_sharded(shard.leaf.segment, pk[0], pk[1], k, lane.hits.data_ptr(), lane.totals.data_ptr(), lane.stream.cuda_stream)
             else:
-                local()
+                shard.leaf.segment.search_batch_device(pk[0], pk[1], k, lane.hits.data_ptr(), lane.totals.data_ptr(), lane.stream.cuda_stream)
 
         def timed(n_lanes, replan):
             for _ in range(warmup):
@@ -220,7 +222,7 @@ def main():
             torch.cuda.synchronize()
             el = time.perf_counter() - t
             if dist_mode:
-                tt = torch.tensor([el], dtype=torch.float64, device="cuda")
+                tt = torch.tensor([el], dtype=torch.float64)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 el = float(tt.item())
             return 1e3 * el / steps
@@ -238,10 +240,13 @@ def main():
         res["kernels_ms"] = {n: s["total_ms"] / max(1, s["launches"]) for n, s in ctx.kernel_stats().items()}
         ctx.set_profiling(False)
         ctx.kernel_stats_reset()
-        res["g_hits"] = merged["local_hits"].cpu().numpy().view(rucene_amd.HIT_DTYPE).reshape(nq, k).copy()
-        res["g_totals"] = merged["local_totals"].cpu().numpy().copy()
-        if args.force_dist and world == 1:
-            res["force_dist_same"] = bool(torch.equal(merged["hits"], merged["local_hits"])) and bool(torch.equal(merged["totals"], merged["local_totals"]))
+        res["g_hits"] = merged["hits"].cpu().numpy().view(rucene_amd.HIT_DTYPE).reshape(nq, k).copy()
+        res["g_totals"] = merged["totals"].cpu().numpy().copy()
+        if args.force_dist and world == 1:  # a world of one: the gathered + merged rows must equal the plain local search
+            lane = lanes[0]
+            shard.leaf.segment.search_batch_device(packed[0], packed[1], k, lane.local_hits.data_ptr(), lane.local_totals.data_ptr(), lane.stream.cuda_stream)
+            torch.cuda.synchronize()
+            res["force_dist_same"] = bool(torch.equal(merged["hits"], lane.local_hits)) and bool(torch.equal(merged["totals"], lane.local_totals))
         return res
 
     def cpu_baseline_leg(shard, kind, k, res, budget_s, sample_queries):
@@ -424,6 +429,7 @@ def main():
     os.dup2(2, 1)  # anything native libraries print while shutting down stays off stdout too
     if dist_mode:
         dist.barrier()
+        comm.close()
         dist.destroy_process_group()
     ctx.close()
 

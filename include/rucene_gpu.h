@@ -191,6 +191,28 @@ int32_t rgpu_search_batch_device(rgpu_segment* seg, const rgpu_query* queries, i
 int32_t rgpu_merge_topk_device(rgpu_ctx* ctx, const void* hits_dev, const void* totals_dev, int32_t n_lists,
                                int32_t n_queries, int32_t k, void* hits_out_dev, void* totals_out_dev, void* hip_stream);
 
+/* ---- segment-sharded search across GPUs (one process per GPU, RCCL over xGMI) ------------------------------------ */
+/* Rucene's search_parallel sends every leaf's heap over a channel and merges them in finish_parallel
+ * (search/searcher.rs:527-630, collector/top_docs.rs:157-172, 201-214). Here the leaves of an index live on different
+ * GPUs (segment s -> rank s, doc_base = cumulative max_doc), the query batch is replicated, and the channel is ONE
+ * ncclAllGather per batch of each rank's {k hits per query, hit count per query} record (n_queries * (k + 1) * 8
+ * bytes), followed on every rank by the canonical k-way merge (k_merge_lists) and the sum of the counts. BM25
+ * statistics must already be those of the whole index (the largest leaf's, searcher.rs:311-351): they travel inside
+ * the query terms' weights, so no rank re-derives idf. */
+typedef struct rgpu_comm rgpu_comm;
+#define RGPU_COMM_ID_BYTES 128  /* = NCCL_UNIQUE_ID_BYTES */
+/* ncclGetUniqueId: called on one rank; the caller hands the bytes to the other ranks over whatever channel it has. */
+int32_t rgpu_comm_unique_id(uint8_t id_out[RGPU_COMM_ID_BYTES]);
+/* ncclCommInitRank on the context's device; collective: every rank of the job calls it with the same id. */
+int32_t rgpu_comm_init(rgpu_ctx* ctx, int32_t n_ranks, int32_t rank, const uint8_t id[RGPU_COMM_ID_BYTES], rgpu_comm** out_comm);
+void rgpu_comm_destroy(rgpu_comm* comm);
+/* rgpu_search_batch_device on this rank's segment -> all-gather -> merge, all enqueued in that order on hip_stream
+ * (NULL = the context's stream); enqueue-only, collective (every rank calls it with the same batch shape).
+ * hits_dev / total_hits_dev (device memory, n_queries x k and n_queries) receive the merged result on every rank. */
+int32_t rgpu_search_batch_sharded(rgpu_comm* comm, rgpu_segment* seg, const rgpu_query* queries, int32_t n_queries,
+                                  const rgpu_query_term* terms, int32_t n_terms_total, int32_t k, void* hits_dev,
+                                  void* total_hits_dev, void* hip_stream);
+
 /* ---- host helpers (no GPU work) ----------------------------------------------------------------------------- */
 /* BM25Similarity::compute_weight (bm25_similarity.rs:151-177) for one TermQuery (n_terms = 1) or a multi-term
  * weight: idf summed over `doc_freqs` (idf() :99-114, f64 log -> f32), avgdl = sumTTF / docCount

@@ -45,7 +45,8 @@ EXPORTS = [
     "rgpu_search_batch_device", "rgpu_merge_topk_device", "rgpu_bm25_compute_weight", "rgpu_bm25_encode_norm",
     "rgpu_norms_from_lucene53", "rgpu_live_docs_from_lucene50", "rgpu_field_infos_from_lucene60", "rgpu_segment_info_from_lucene62", "rgpu_commit_from_segments_file", "rgpu_compound_entries_from_lucene50", "rgpu_terms_open", "rgpu_terms_close", "rgpu_terms_field_stats",
     "rgpu_terms_lookup", "rgpu_terms_lookup_positions", "rgpu_kernel_stats", "rgpu_kernel_stats_reset", "rgpu_synchronize",
-    "rgpu_set_profiling", "rgpu_and_touched_bytes",
+    "rgpu_set_profiling", "rgpu_and_touched_bytes", "rgpu_comm_unique_id", "rgpu_comm_init", "rgpu_comm_destroy",
+    "rgpu_search_batch_sharded",
 ]
 
 
@@ -136,6 +137,10 @@ def lib():
         "rgpu_synchronize": (i32, [vp]),
         "rgpu_set_profiling": (i32, [vp, i32]),
         "rgpu_and_touched_bytes": (i32, [vp, C.POINTER(i64)]),
+        "rgpu_comm_unique_id": (i32, [vp]),
+        "rgpu_comm_init": (i32, [vp, i32, i32, vp, C.POINTER(vp)]),
+        "rgpu_comm_destroy": (None, [vp]),
+        "rgpu_search_batch_sharded": (i32, [vp, vp, vp, i32, vp, i32, i32, vp, vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -357,6 +362,44 @@ class Context:
                     seg.close()
             self._segments = []
             lib().rgpu_shutdown(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def comm_unique_id():
+    """ncclGetUniqueId through the C ABI: 128 bytes for rgpu_comm_init, created on one rank and handed to the others."""
+    buf = np.zeros(128, np.uint8)
+    _check(lib().rgpu_comm_unique_id(buf.ctypes.data))
+    return buf
+
+
+class Comm:
+    """rgpu_comm: this rank's end of the RCCL communicator over which per-shard top-k is all-gathered."""
+
+    def __init__(self, ctx, n_ranks, rank, unique_id):
+        uid = np.ascontiguousarray(unique_id, dtype=np.uint8)
+        if uid.size != 128:
+            raise ValueError("unique_id must hold 128 bytes")
+        h = C.c_void_p()
+        _check(lib().rgpu_comm_init(ctx._h, n_ranks, rank, uid.ctypes.data, C.byref(h)))
+        self._h = h
+        self.ctx, self.n_ranks, self.rank = ctx, n_ranks, rank
+
+    def search_batch_sharded(self, segment, queries, terms, k, hits_ptr, totals_ptr, stream=0):
+        """local search -> one all-gather of {hits, counts} records -> canonical merge; enqueue-only, collective."""
+        q = np.ascontiguousarray(queries, dtype=QUERY_DTYPE)
+        t = np.ascontiguousarray(terms, dtype=QUERY_TERM_DTYPE)
+        _check(lib().rgpu_search_batch_sharded(self._h, segment._h, q.ctypes.data, q.size, t.ctypes.data, t.size, k, hits_ptr, totals_ptr,
+                                               stream or None))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().rgpu_comm_destroy(self._h)
             self._h = None
 
     def __del__(self):

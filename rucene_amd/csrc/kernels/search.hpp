@@ -107,10 +107,12 @@ __global__ __launch_bounds__(WG_THREADS) void k_merge_items(const int64_t* __res
   if (lane == 0) totals_out[q] = total;
 }
 
-// TopDocsCollector::finish_parallel across leaves / shards: lists laid out [list][query][k] (already in global
-// doc ids), one wavefront per query.
+// TopDocsCollector::finish_parallel across leaves / shards: list l's rows start at hits_in + l * hits_stride
+// ([query][k], already in global doc ids) and its hit counts at totals_in + l * totals_stride — [list][query][k] and
+// [list][query] arrays, or the records of one all-gather ([list][hits | totals]). One wavefront per query.
 template <bool WIDE>
 __global__ __launch_bounds__(WG_THREADS) void k_merge_lists(const HitOut* __restrict__ hits_in, const int64_t* __restrict__ totals_in,
+                                                            int64_t hits_stride, int64_t totals_stride,
                                                             int n_lists, int n_queries, int k, HitOut* __restrict__ hits_out,
                                                             int64_t* __restrict__ totals_out) {
   const int lane = lane_id();
@@ -120,13 +122,13 @@ __global__ __launch_bounds__(WG_THREADS) void k_merge_lists(const HitOut* __rest
   uint64_t tau = 0;
   int64_t total = 0;
   for (int l = 0; l < n_lists; ++l) {
-    const HitOut* in = hits_in + ((size_t)l * n_queries + q) * (size_t)k;
+    const HitOut* in = hits_in + (size_t)l * (size_t)hits_stride + (size_t)q * (size_t)k;
     for (int r = 0; r < k; r += 64) {
       uint64_t key = 0;
       if (r + lane < k) { const HitOut h = in[r + lane]; if (h.doc >= 0) key = make_key(h.score, h.doc); }
       topk_offer<WIDE>(top, key, tau, k, lane);
     }
-    total += totals_in[(size_t)l * n_queries + q];
+    total += totals_in[(size_t)l * (size_t)totals_stride + q];
   }
   HitOut* out = hits_out + (size_t)q * (size_t)k;
   if (lane < k) out[lane] = top.a ? HitOut{key_doc(top.a), key_score(top.a)} : HitOut{-1, 0.f};

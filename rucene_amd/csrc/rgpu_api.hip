@@ -2,6 +2,7 @@
 // gfx950 kernels in kernels/*.hpp. HIP runtime only — no torch types, no CPU fallback: every entry point
 // either runs on the GPU or fails with a negative rgpu_status.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <cstdio>
@@ -1160,13 +1161,110 @@ extern "C" int32_t rgpu_merge_topk_device(rgpu_ctx* c, const void* hits_dev, con
     const unsigned grid = (unsigned)((n_queries + WG_WAVES - 1) / WG_WAVES);
     if (k > 64)
       hipLaunchKernelGGL(k_merge_lists<true>, dim3(grid), dim3(WG_THREADS), 0, s, (const HitOut*)hits_dev, (const int64_t*)totals_dev,
-                         n_lists, n_queries, k, (HitOut*)hits_out_dev, (int64_t*)totals_out_dev);
+                         (int64_t)n_queries * k, (int64_t)n_queries, n_lists, n_queries, k, (HitOut*)hits_out_dev, (int64_t*)totals_out_dev);
     else
       hipLaunchKernelGGL(k_merge_lists<false>, dim3(grid), dim3(WG_THREADS), 0, s, (const HitOut*)hits_dev, (const int64_t*)totals_dev,
-                         n_lists, n_queries, k, (HitOut*)hits_out_dev, (int64_t*)totals_out_dev);
+                         (int64_t)n_queries * k, (int64_t)n_queries, n_lists, n_queries, k, (HitOut*)hits_out_dev, (int64_t*)totals_out_dev);
   }
   HIP_TRY(hipGetLastError());
   return RGPU_OK;  // enqueue only, like rgpu_search_batch_device
+}
+
+// ---- segment-sharded search: RCCL all-gather of per-shard top-k + device merge -------------------------------------------
+constexpr int N_COMM_SLOTS = 4;
+struct CommSlot {
+  DevVec<uint8_t> send, recv;  // send: [n_queries x k hits][n_queries counts]; recv: the same record from every rank
+  hipEvent_t done = nullptr;
+  bool busy = false;
+};
+struct rgpu_comm {
+  rgpu_ctx* ctx = nullptr;
+  ncclComm_t nccl = nullptr;
+  int n_ranks = 1, rank = 0;
+  CommSlot slots[N_COMM_SLOTS];
+  int next = 0;
+};
+#define NCCL_TRY(expr)                                                                                          \
+  do {                                                                                                          \
+    ncclResult_t _r = (expr);                                                                                   \
+    if (_r != ncclSuccess) return fail(RGPU_ERR_RUNTIME, std::string(#expr) + ": " + ncclGetErrorString(_r)); \
+  } while (0)
+static_assert(RGPU_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "rgpu_comm ids are ncclUniqueIds");
+
+extern "C" int32_t rgpu_comm_unique_id(uint8_t* id_out) {
+  if (!id_out) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "id_out is null");
+  ncclUniqueId id;
+  NCCL_TRY(ncclGetUniqueId(&id));
+  std::memcpy(id_out, id.internal, RGPU_COMM_ID_BYTES);
+  return RGPU_OK;
+}
+
+extern "C" int32_t rgpu_comm_init(rgpu_ctx* c, int32_t n_ranks, int32_t rank, const uint8_t* id_bytes, rgpu_comm** out) {
+  if (!out) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "out_comm is null");
+  *out = nullptr;
+  if (!c || !id_bytes) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "null argument");
+  if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "rank outside [0, n_ranks)");
+  std::lock_guard<std::mutex> g(c->mu);
+  HIP_TRY(hipSetDevice(c->device));
+  ncclUniqueId id;
+  std::memcpy(id.internal, id_bytes, RGPU_COMM_ID_BYTES);
+  auto comm = std::make_unique<rgpu_comm>();
+  comm->ctx = c;
+  comm->n_ranks = n_ranks;
+  comm->rank = rank;
+  NCCL_TRY(ncclCommInitRank(&comm->nccl, n_ranks, id, rank));
+  *out = comm.release();
+  return RGPU_OK;
+}
+
+extern "C" void rgpu_comm_destroy(rgpu_comm* comm) {
+  if (!comm) return;
+  (void)hipSetDevice(comm->ctx->device);
+  for (auto& sl : comm->slots) {
+    if (sl.busy) (void)hipEventSynchronize(sl.done);
+    if (sl.done) (void)hipEventDestroy(sl.done);
+    sl.send.release();
+    sl.recv.release();
+  }
+  if (comm->nccl) (void)ncclCommDestroy(comm->nccl);
+  delete comm;
+}
+
+extern "C" int32_t rgpu_search_batch_sharded(rgpu_comm* comm, rgpu_segment* seg, const rgpu_query* queries, int32_t n_queries,
+                                             const rgpu_query_term* terms, int32_t n_terms_total, int32_t k, void* hits_dev,
+                                             void* totals_dev, void* hip_stream) {
+  if (!comm || !seg || !queries || n_queries <= 0 || !terms || n_terms_total <= 0 || !hits_dev || !totals_dev)
+    return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "bad arguments");
+  if (seg->ctx != comm->ctx) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "segment and communicator belong to different contexts");
+  if (k <= 0 || k > RGPU_MAX_K) return fail(k <= 0 ? RGPU_ERR_ILLEGAL_ARGUMENT : RGPU_ERR_UNSUPPORTED, "k must be in 1..RGPU_MAX_K");
+  rgpu_ctx* c = comm->ctx;
+  std::lock_guard<std::mutex> g(c->mu);
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+  CommSlot& sl = comm->slots[comm->next];
+  comm->next = (comm->next + 1) % N_COMM_SLOTS;
+  if (sl.busy) { HIP_TRY(hipEventSynchronize(sl.done)); sl.busy = false; }
+  const size_t hits_bytes = (size_t)n_queries * (size_t)k * sizeof(HitOut), record = hits_bytes + (size_t)n_queries * 8;
+  HIP_TRY(sl.send.reserve(record, 0, s));
+  HIP_TRY(sl.recv.reserve(record * (size_t)comm->n_ranks, 0, s));
+  int32_t rc = search_impl(seg, queries, n_queries, terms, n_terms_total, k, (HitOut*)sl.send.p, (int64_t*)(sl.send.p + hits_bytes), s);
+  if (rc != RGPU_OK) return rc;
+  NCCL_TRY(ncclAllGather(sl.send.p, sl.recv.p, record, ncclInt8, comm->nccl, s));
+  {
+    TimedLaunch tl(c, s, "k_merge_lists", 0);
+    const unsigned grid = (unsigned)((n_queries + WG_WAVES - 1) / WG_WAVES);
+    auto go = [&](auto kern) {
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(WG_THREADS), 0, s, (const HitOut*)sl.recv.p, (const int64_t*)(sl.recv.p + hits_bytes),
+                         (int64_t)(record / sizeof(HitOut)), (int64_t)(record / 8), comm->n_ranks, n_queries, (int)k, (HitOut*)hits_dev,
+                         (int64_t*)totals_dev);
+    };
+    if (k > 64) go(k_merge_lists<true>); else go(k_merge_lists<false>);
+  }
+  HIP_TRY(hipGetLastError());
+  if (!sl.done) HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(sl.done, s));
+  sl.busy = true;
+  return RGPU_OK;
 }
 
 // ---- host helpers: BM25Similarity (no GPU involved) ------------------------------------------------------------

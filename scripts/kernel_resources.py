@@ -15,7 +15,7 @@ if "-o" in args:
     del args[i:i + 2]
 cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
        "-Wno-unused-function", "-Rpass-analysis=kernel-resource-usage", "-o", out,
-       os.path.join(ROOT, "rucene_amd", "csrc", "rgpu_api.hip")] + args
+       os.path.join(ROOT, "rucene_amd", "csrc", "rgpu_api.hip"), "-L/opt/rocm/lib", "-lrccl"] + args
 p = subprocess.run(cmd, stderr=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
 if p.returncode != 0:
     sys.stderr.write(p.stderr)

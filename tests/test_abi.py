@@ -163,3 +163,15 @@ def test_cpp_host_mirror_compiles_without_a_gpu(gpu_lib, tmp_path):
                            "-L" + libdir, "-lrucene_gpu", "-lrucene_indexgen", "-Wl,-rpath," + libdir, "-L/opt/rocm/lib",
                            "-Wl,-rpath,/opt/rocm/lib"])
     assert os.path.exists(exe)
+
+
+def test_comm_entry_points_check_their_arguments(gpu_lib):
+    """rgpu_comm_*: argument errors are reported as codes, never crashes; no GPU (and no peer) is needed for that."""
+    L = gpu_lib.lib()
+    out = C.c_void_p()
+    uid = np.zeros(128, np.uint8)
+    assert L.rgpu_comm_init(None, 1, 0, uid.ctypes.data, C.byref(out)) == -2 and not out.value   # no context
+    assert L.rgpu_comm_init(None, 1, 0, uid.ctypes.data, None) == -2
+    assert L.rgpu_comm_unique_id(None) == -2
+    assert L.rgpu_search_batch_sharded(None, None, None, 0, None, 0, 10, None, None, None) == -2
+    L.rgpu_comm_destroy(None)

@@ -708,3 +708,29 @@ def test_min_should_match(zipf, oracle):
             assert (hits[i]["doc"][n:] == -1).all()
             assert (hits[i]["doc"][:n] == cd[i, :n]).all(), (i, specs[i])
             assert (hits[i]["score"][:n].view(np.int32) == cs[i, :n].view(np.int32)).all(), (i, specs[i])
+
+
+def test_sharded_search_through_the_c_abi_with_a_world_of_one(zipf, oracle):
+    """rgpu_comm_* + rgpu_search_batch_sharded (RCCL all-gather of {hits, counts} records + k_merge_lists): with one rank the
+    gathered and merged rows must be the local search's rows, for every op and both list widths. The N > 1 layout is
+    covered on CPU by tests/test_dist_gloo.py; real multi-GPU runs are the driver's (bench.py --gpus N)."""
+    import torch
+    import rucene_amd
+    from rucene_amd import _lib as gpu
+    seg, osearcher, searcher = zipf
+    leaf = searcher.leaves[0]
+    comm = gpu.Comm(searcher.ctx, 1, 0, gpu.comm_unique_id())
+    T, B = rucene_amd.TermQuery, rucene_amd.BooleanQuery
+    queries = [T(3), T(700), B.build([T(1), T(4), T(20)], []), B.build([], [T(2), T(50), T(700), T(9000)]), T(123456789 % seg.terms.size)]
+    packed = searcher.pack(queries, leaf)
+    for k in (10, 100):
+        want_h, want_t = leaf.segment.search_batch(packed[0], packed[1], k)
+        hits = torch.zeros((len(queries), k), dtype=torch.int64, device="cuda")
+        totals = torch.zeros((len(queries),), dtype=torch.int64, device="cuda")
+        for _ in range(6):  # more calls than the communicator has buffer slots
+            comm.search_batch_sharded(leaf.segment, packed[0], packed[1], k, hits.data_ptr(), totals.data_ptr())
+        searcher.ctx.synchronize()
+        got = hits.cpu().numpy().view(gpu.HIT_DTYPE).reshape(len(queries), k)
+        assert (got["doc"] == want_h["doc"]).all() and (got["score"].view(np.int32) == want_h["score"].view(np.int32)).all()
+        assert (totals.cpu().numpy() == want_t).all()
+    comm.close()
