@@ -135,6 +135,13 @@ int32_t rgpu_device_name(rgpu_ctx* ctx, char* buf, size_t buf_len);
 int32_t rgpu_segment_upload(rgpu_ctx* ctx, const uint8_t* doc_file, size_t doc_len, const uint8_t* norms_or_null,
                             int32_t max_doc, int32_t doc_base, const uint64_t* live_docs_or_null,
                             rgpu_segment** out_seg);
+/* The same for a field of the given doc::IndexOptions ordinal: 1 = Docs (no freq block follows a doc block, the VInt
+ * tail holds plain deltas, every freq reads as 1 and a FREQS-less iterator's skip_block has nothing to skip:
+ * posting_reader.rs:532-557, for_util.rs:263-272), 2 = DocsAndFreqs (what rgpu_segment_upload assumes).
+ * Positions fields (3, 4) -> RGPU_ERR_UNSUPPORTED. For a Docs field rgpu_term_state.total_term_freq is ignored. */
+int32_t rgpu_segment_upload_field(rgpu_ctx* ctx, const uint8_t* doc_file, size_t doc_len, const uint8_t* norms_or_null,
+                                  int32_t max_doc, int32_t doc_base, const uint64_t* live_docs_or_null, int32_t index_options,
+                                  rgpu_segment** out_seg);
 void rgpu_segment_free(rgpu_segment* seg);
 int32_t rgpu_segment_version(const rgpu_segment* seg); /* .doc format version (0 legacy, 1 BP128) */
 

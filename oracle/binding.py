@@ -94,6 +94,7 @@ def _declare(L):
         "orc_segment_new": (vp, [u8p, C.c_int64, u8p, u64p, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int64, vp, C.c_int64]),
         "orc_segment_free": (None, [vp]),
         "orc_segment_version": (C.c_int, [vp]),
+        "orc_segment_set_index_has_freq": (None, [vp, C.c_int]),
         "orc_postings_new": (vp, [vp, vp, C.c_int]),
         "orc_postings_free": (None, [vp]),
         "orc_postings_next": (C.c_int, [vp, i32p]),
@@ -267,7 +268,7 @@ class Writer:
 # ---- segment / searcher --------------------------------------------------------------------------------------------
 class Segment:
     def __init__(self, doc_bytes, norms, max_doc, terms, doc_base=0, live_docs=None, doc_count=None,
-                 sum_total_term_freq=0, sum_doc_freq=0):
+                 sum_total_term_freq=0, sum_doc_freq=0, has_freqs=True):
         self.doc_bytes = np.ascontiguousarray(doc_bytes, dtype=np.uint8)
         self.norms = None if norms is None else np.ascontiguousarray(norms, dtype=np.uint8)
         self.live_docs = None if live_docs is None else np.ascontiguousarray(live_docs, dtype=np.uint64)
@@ -281,6 +282,8 @@ class Segment:
             self.terms.ctypes.data, self.terms.size)
         if not self._h:
             raise OracleError(lib().orc_last_error().decode())
+        if not has_freqs:  # the field was indexed with IndexOptions::Docs
+            lib().orc_segment_set_index_has_freq(self._h, 0)
 
     @property
     def version(self):

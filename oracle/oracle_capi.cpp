@@ -151,12 +151,13 @@ orc_segment* orc_segment_new(const uint8_t* doc_bytes, int64_t doc_len, const ui
     return seg;
   } catch (const std::exception& e) { g_err = e.what(); return nullptr; }
 }
+void orc_segment_set_index_has_freq(orc_segment* s, int has_freq) { s->s.index_has_freq = has_freq != 0; }
 void orc_segment_free(orc_segment* s) { delete s; }
 int orc_segment_version(orc_segment* s) { return s->s.reader->version; }
 
 struct orc_postings { BlockDocIterator it; };
 orc_postings* orc_postings_new(orc_segment* seg, const BlockTermState* st, int flags) {
-  try { return new orc_postings{BlockDocIterator(seg->s.reader.get(), true, *st, (uint16_t)flags)}; }
+  try { return new orc_postings{BlockDocIterator(seg->s.reader.get(), seg->s.index_has_freq, *st, (uint16_t)flags)}; }
   catch (const std::exception& e) { g_err = e.what(); return nullptr; }
 }
 void orc_postings_free(orc_postings* p) { delete p; }
@@ -167,7 +168,7 @@ int32_t orc_postings_doc(orc_postings* p) { return p->it.doc_id(); }
 // full sequential decode of one term through BlockDocIterator::next
 int64_t orc_decode_term(orc_segment* seg, const BlockTermState* st, int32_t* docs_out, int32_t* freqs_out) {
   ORC_TRY
-  BlockDocIterator it(seg->s.reader.get(), true, *st, FLAG_FREQS);
+  BlockDocIterator it(seg->s.reader.get(), seg->s.index_has_freq, *st, FLAG_FREQS);
   int64_t n = 0;
   while (true) {
     int32_t d = it.next();
@@ -189,7 +190,7 @@ double orc_decode_terms(orc_segment* seg, const BlockTermState* sts, int64_t n_t
       int64_t i = next_term.fetch_add(1);
       if (i >= n_terms) break;
       try {
-        BlockDocIterator it(seg->s.reader.get(), true, sts[i], FLAG_FREQS);
+        BlockDocIterator it(seg->s.reader.get(), seg->s.index_has_freq, sts[i], FLAG_FREQS);
         int64_t n = offs[(size_t)i];
         while (true) {
           int32_t d = it.next();

@@ -186,8 +186,9 @@ struct TermScorer : Scorer {
   const float* cache;   // BM25Weight::cache (Arc<[f32;256]>)
   const uint8_t* norms;  // 1 byte per doc (norms_producer.rs:146-154) or null
   uint64_t visited = 0;
-  TermScorer(const PostingsReader* r, const BlockTermState& st, const BM25Weight* w, const uint8_t* norms_)
-      : it(r, true, st, FLAG_FREQS), weight(w->weight), k1(w->k1), cache(w->cache), norms(norms_) {}
+  // index_has_freq: FieldInfo::index_options >= DocsAndFreqs (posting_reader.rs:189-212); a Docs field's freq() is 1
+  TermScorer(const PostingsReader* r, const BlockTermState& st, const BM25Weight* w, const uint8_t* norms_, bool index_has_freq = true)
+      : it(r, index_has_freq, st, FLAG_FREQS), weight(w->weight), k1(w->k1), cache(w->cache), norms(norms_) {}
   int32_t doc_id() const override { return it.doc_id(); }
   int32_t next() override { visited++; return it.next(); }
   int32_t advance(int32_t t) override { visited++; return it.advance(t); }
@@ -650,6 +651,7 @@ struct Segment {
   int64_t sum_doc_freq = 0;
   const BlockTermState* terms = nullptr;  // indexed by term id; doc_freq == 0 -> term absent in this segment
   int64_t n_terms = 0;
+  bool index_has_freq = true;        // the field's IndexOptions >= DocsAndFreqs
 };
 
 enum QueryOp { OP_TERM = 0, OP_AND = 1, OP_OR = 2 };
@@ -720,7 +722,7 @@ struct IndexSearcher {
   // term_query.rs:145-163 — None when the term is absent from the leaf
   ScorerBox term_scorer(const Segment* seg, int64_t term_id, const BM25Weight* w) const {
     if (term_id < 0 || term_id >= seg->n_terms || seg->terms[term_id].doc_freq <= 0) return nullptr;
-    return ScorerBox(new TermScorer(seg->reader.get(), seg->terms[term_id], w, seg->norms));
+    return ScorerBox(new TermScorer(seg->reader.get(), seg->terms[term_id], w, seg->norms, seg->index_has_freq));
   }
   // boolean_query.rs:195-279 restricted to trees of TermQuery clauses: MUST only, SHOULD only, each optionally
   // with MUST_NOT clauses; MUST + SHOULD -> ReqOptScorer is added by create_scorer below

@@ -40,6 +40,7 @@ STATUS_NAMES = {0: "OK", -1: "IllegalState", -2: "IllegalArgument", -3: "Unexpec
 # every symbol include/rucene_gpu.h declares (tests/test_abi.py checks the header and this list agree)
 EXPORTS = [
     "rgpu_init", "rgpu_shutdown", "rgpu_last_error", "rgpu_abi_version", "rgpu_device_name", "rgpu_segment_upload",
+    "rgpu_segment_upload_field",
     "rgpu_segment_free", "rgpu_segment_version", "rgpu_segment_prepare_terms", "rgpu_decode_terms",
     "rgpu_decode_terms_device", "rgpu_advance_batch", "rgpu_sim_table_upload", "rgpu_search_batch",
     "rgpu_search_batch_device", "rgpu_merge_topk_device", "rgpu_bm25_compute_weight", "rgpu_bm25_encode_norm",
@@ -109,6 +110,7 @@ def lib():
         "rgpu_abi_version": (i32, []),
         "rgpu_device_name": (i32, [vp, C.c_char_p, C.c_size_t]),
         "rgpu_segment_upload": (i32, [vp, vp, C.c_size_t, vp, i32, i32, vp, C.POINTER(vp)]),
+        "rgpu_segment_upload_field": (i32, [vp, vp, C.c_size_t, vp, i32, i32, vp, i32, C.POINTER(vp)]),
         "rgpu_segment_free": (None, [vp]),
         "rgpu_segment_version": (i32, [vp]),
         "rgpu_segment_prepare_terms": (i32, [vp, vp, i64]),
@@ -412,14 +414,14 @@ class Comm:
 class Segment:
     """rgpu_segment: one uploaded leaf (.doc bytes, norms, live docs in HBM)."""
 
-    def __init__(self, ctx, doc_bytes, norms, max_doc, doc_base=0, live_docs=None):
+    def __init__(self, ctx, doc_bytes, norms, max_doc, doc_base=0, live_docs=None, index_options=INDEX_OPTIONS_DOCS_AND_FREQS):
         self.ctx = ctx
         doc = np.ascontiguousarray(doc_bytes, dtype=np.uint8)
         nb = None if norms is None else np.ascontiguousarray(norms, dtype=np.uint8)
         lv = None if live_docs is None else np.ascontiguousarray(live_docs, dtype=np.uint64)
         h = C.c_void_p()
-        _check(lib().rgpu_segment_upload(ctx._h, doc.ctypes.data, doc.size, None if nb is None else nb.ctypes.data, max_doc,
-                                         doc_base, None if lv is None else lv.ctypes.data, C.byref(h)))
+        _check(lib().rgpu_segment_upload_field(ctx._h, doc.ctypes.data, doc.size, None if nb is None else nb.ctypes.data, max_doc,
+                                               doc_base, None if lv is None else lv.ctypes.data, index_options, C.byref(h)))
         self._h = h
         self.max_doc, self.doc_base = max_doc, doc_base
         import weakref

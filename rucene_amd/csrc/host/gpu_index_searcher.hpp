@@ -114,6 +114,7 @@ struct BooleanQuery : Query {
 // One segment: postings file, norms, live docs, FieldReader statistics, and the terms: a block-tree dictionary
 // (rgpu_terms_open over the segment's .tim/.tip) and/or a flat term table.
 struct LeafReader {
+  int32_t index_options = 2;  // doc::IndexOptions ordinal of the searched field: 1 Docs, 2 DocsAndFreqs
   const uint8_t* doc_bytes = nullptr;
   size_t doc_len = 0;
   const uint8_t* norms = nullptr;
@@ -204,7 +205,8 @@ class IndexDirectory {
         if (field == p) { field_number = infos[(size_t)i].number; index_options = infos[(size_t)i].index_options; }
       }
       if (field_number < 0) throw Error(RGPU_ERR_ILLEGAL_ARGUMENT, "no field named " + field + " in segment " + name);
-      if (index_options != 2) throw Error(RGPU_ERR_UNSUPPORTED, "the searched field must be indexed with IndexOptions::DocsAndFreqs");
+      if (index_options != 1 && index_options != 2)
+        throw Error(RGPU_ERR_UNSUPPORTED, "the searched field must be indexed with IndexOptions::Docs or ::DocsAndFreqs");
       s.doc = part("_Lucene50_0.doc");
       const std::vector<uint8_t> tim = part("_Lucene50_0.tim"), tip = part("_Lucene50_0.tip"), nvm = part(".nvm"), nvd = part(".nvd");
       check(rgpu_terms_open(tim.data(), tim.size(), tip.data(), tip.size(), indexed.data(), (int32_t)indexed.size(), info.max_doc, &s.terms));
@@ -229,6 +231,7 @@ class IndexDirectory {
       leaf.sum_doc_freq = stats.sum_doc_freq;
       leaf.dictionary = s.terms;
       leaf.field_number = field_number;
+      leaf.index_options = index_options;
       dir->leaves_.push_back(leaf);
       doc_base += info.max_doc;
     }
@@ -266,7 +269,7 @@ class GpuIndexSearcher {
     cfg.abi_version = RGPU_ABI_VERSION;
     check(rgpu_init(device, &cfg, &ctx_));
     for (auto& l : leaves_)
-      check(rgpu_segment_upload(ctx_, l.doc_bytes, l.doc_len, l.norms, l.max_doc, l.doc_base, l.live_docs, &l.segment));
+      check(rgpu_segment_upload_field(ctx_, l.doc_bytes, l.doc_len, l.norms, l.max_doc, l.doc_base, l.live_docs, l.index_options, &l.segment));
     // searcher.rs:306-363: the first leaf with the largest max_doc provides the collection statistics
     for (size_t i = 1; i < leaves_.size(); ++i)
       if (leaves_[i].max_doc > leaves_[stats_leaf_].max_doc) stats_leaf_ = i;

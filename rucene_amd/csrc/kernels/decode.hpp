@@ -119,6 +119,7 @@ struct BlockPair {
 // [hdr byte][doc payload 16*b | vint][hdr byte][freq payload 16*b | vint]; this lane's 16-byte row of its stream,
 // fetched byte-exact (the slow TA path — once per block per term lifetime). Row 0 of an all-equal stream (b == 0)
 // starts with the stream's VInt.
+// (a docs-only field has no freq stream: its freq half reads bytes past the block, replaced by store_rows_from_file)
 __device__ __forceinline__ uint4 file_rows_load(const uint8_t* __restrict__ blk, uint32_t hdr, int lane) {
   const int bd = hdr_bdoc(hdr);
   const int doc_sz = bd ? 16 * bd : hdr_vlen(hdr);
@@ -141,9 +142,10 @@ __device__ __forceinline__ uint32_t vint_from_words(uint32_t w0, uint32_t w1) {
   return v;
 }
 // file rows -> block-store rows: the VInt of an all-equal stream becomes its plain u32 value (for_util.rs:203-207)
-__device__ __forceinline__ uint4 store_rows_from_file(uint4 rows, uint32_t hdr, int lane) {
+__device__ __forceinline__ uint4 store_rows_from_file(uint4 rows, uint32_t hdr, int lane, bool has_freqs = true) {
   const int b = (lane >> 5) ? hdr_bfreq(hdr) : hdr_bdoc(hdr);
   if (b == 0) rows = make_uint4(vint_from_words(rows.x, rows.y), 0u, 0u, 0u);
+  if (!has_freqs && (lane >> 5)) rows = make_uint4(1u, 0u, 0u, 0u);  // IndexOptions::Docs: "all freqs equal 1"
   return rows;
 }
 __device__ __host__ __forceinline__ int store_doc_rows(uint32_t hdr) { return hdr_bdoc(hdr) ? hdr_bdoc(hdr) : 1; }
@@ -301,8 +303,9 @@ __device__ __forceinline__ uint32_t compose_fn(uint32_t first, uint32_t then) {
   return r0 | (r1 << 1);
 }
 
+// has_freqs == false (IndexOptions::Docs, posting_reader.rs:326-331): every value is a doc delta, every freq is 1.
 __device__ RGPU_TAIL_INLINE void decode_tail(const uint8_t* __restrict__ tail, int n, int32_t base, uint8_t* slab, int lane,
-                                            int32_t& doc0, int32_t& doc1, uint32_t& f0, uint32_t& f1) {
+                                            int32_t& doc0, int32_t& doc1, uint32_t& f0, uint32_t& f1, bool has_freqs = true) {
   uint8_t* bytes = slab;                                              // [0, 1296)
   uint32_t* vals = reinterpret_cast<uint32_t*>(slab + 1296);         // 256 values (+ 8 pad words)
   // (0) stage TAIL_MAX_BYTES: 80 x 16 B
@@ -333,6 +336,14 @@ __device__ RGPU_TAIL_INLINE void decode_tail(const uint8_t* __restrict__ tail, i
     ++vi;
   }
   wave_sync();
+  if (!has_freqs) {  // wave-uniform: value i is posting i's delta
+    const uint32_t d0 = (2 * lane < n) ? vals[2 * lane] : 0u;
+    const uint32_t d1 = (2 * lane + 1 < n) ? vals[2 * lane + 1] : 0u;
+    f0 = f1 = 1u;
+    deltas_to_docs(d0, d1, base, doc0, doc1);
+    wave_sync();
+    return;
+  }
   // (2) classify 4 values per lane: code / freq
   uint32_t v4[4];
 #pragma unroll

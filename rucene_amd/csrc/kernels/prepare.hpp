@@ -62,7 +62,7 @@ template <bool LEGACY>
 __global__ __launch_bounds__(PREP_THREADS) void k_prepare_terms(const uint8_t* __restrict__ doc, int64_t doc_len,
                                                                  const PrepTerm* __restrict__ terms, int32_t* dir_last,
                                                                  uint32_t* dir_off, uint32_t* dir_row, uint16_t* dir_hdr,
-                                                                 int* err) {
+                                                                 int has_freqs, int* err) {
   const PrepTerm t = terms[blockIdx.x];
   const int tid = (int)threadIdx.x;
   __shared__ uint32_t s_ws[PREP_THREADS / 64];
@@ -150,11 +150,17 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_terms(const uint8_t* _
     if (bd > 32) atomicMin(err, -4);
     int doc_sz = 16 * bd;
     if (bd == 0) { vlen = vint_len_serial(p + 1); doc_sz = vlen; }
-    const uint32_t h2 = p[1 + doc_sz];
-    const int bf = (int)(h2 & 63);
-    if (bf > 32) atomicMin(err, -4);
-    const int freq_sz = bf ? 16 * bf : vint_len_serial(p + 1 + doc_sz + 1);
-    const uint32_t end = off + 1u + (uint32_t)doc_sz + 1u + (uint32_t)freq_sz;
+    // the freq block (absent for IndexOptions::Docs: posting_writer.rs:334-351 writes it only when the field has freqs;
+    // the directory then says "all-equal freq stream" and the block store supplies the value 1)
+    int bf = 0;
+    uint32_t end = off + 1u + (uint32_t)doc_sz;
+    if (has_freqs) {
+      const uint32_t h2 = p[1 + doc_sz];
+      bf = (int)(h2 & 63);
+      if (bf > 32) atomicMin(err, -4);
+      const int freq_sz = bf ? 16 * bf : vint_len_serial(p + 1 + doc_sz + 1);
+      end += 1u + (uint32_t)freq_sz;
+    }
     if (i < t.n_entries && end != dir_off[t.dir_base + i + 1]) atomicMin(err, -4);
     if (i > 0 && i < t.n_entries && dir_last[t.dir_base + i] <= dir_last[t.dir_base + i - 1]) atomicMin(err, -4);
     dir_hdr[t.dir_base + i] = (uint16_t)((uint32_t)bd | ((uint32_t)vlen << 6) | ((uint32_t)bf << 9));
@@ -193,7 +199,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_blocks(const uint8_t* 
                                                                   const uint32_t* __restrict__ dir_row,
                                                                   const uint16_t* __restrict__ dir_hdr, uint8_t* bstore,
                                                                   const uint8_t* __restrict__ norms, uint8_t* pnorm,
-                                                                  uint64_t* __restrict__ dir_bmax, int ranked,
+                                                                  uint64_t* __restrict__ dir_bmax, int ranked, int has_freqs,
                                                                   const int* __restrict__ err) {
   __shared__ __attribute__((aligned(16))) uint8_t slabs[PREP_THREADS / 64][SLAB_BYTES];
   const int lane = lane_id();
@@ -216,7 +222,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_blocks(const uint8_t* 
   for (int blk = b0; blk < b1; ++blk) {
     const uint32_t hdr = dir_hdr[t.dir_base + blk];
     const uint32_t row0 = dir_row[t.dir_base + blk];
-    const uint4 rows = store_rows_from_file(file_rows_load(doc + t.start_fp + dir_off[t.dir_base + blk], hdr, lane), hdr, lane);
+    const uint4 rows = store_rows_from_file(file_rows_load(doc + t.start_fp + dir_off[t.dir_base + blk], hdr, lane), hdr, lane, has_freqs != 0);
     const int half = lane >> 5, row = lane & 31;
     const int rd = store_doc_rows(hdr);
     if (row < (half ? store_freq_rows(hdr) : rd))

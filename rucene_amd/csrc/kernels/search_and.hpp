@@ -262,7 +262,7 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
             const int32_t tbase = T.nblocks ? seg.dir_last[T.dir_base + T.nblocks - 1] : 0;
             int32_t e0, e1;
             uint32_t g0, g1;
-            decode_tail(seg.doc + T.start_fp + toff, T.tail_n, tbase, slab, lane, e0, e1, g0, g1);
+            decode_tail(seg.doc + T.start_fp + toff, T.tail_n, tbase, slab, lane, e0, e1, g0, g1, seg.has_freqs != 0);
             probe(e0, e1, 2 * lane < T.tail_n, 2 * lane + 1 < T.tail_n, p0, p1, [&](uint32_t& x0, uint32_t& x1) { x0 = g0; x1 = g1; });
           } else {
             if (p0) missed(a0);
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
       if (has_norms && a0) nn = seg.norms[d0];
     } else {
       const uint32_t toff = L.nblocks ? seg.dir_off[L.dir_base + L.nblocks] : 0u;
-      decode_tail(seg.doc + L.start_fp + toff, L.tail_n, base, slab, lane, d0, d1, f0, f1);
+      decode_tail(seg.doc + L.start_fp + toff, L.tail_n, base, slab, lane, d0, d1, f0, f1, seg.has_freqs != 0);
       a0 = 2 * lane < L.tail_n; a1 = 2 * lane + 1 < L.tail_n;
       if (has_norms && a0) nn = seg.norms[d0];
       if (has_norms && a1) nn |= (uint32_t)seg.norms[d1] << 8;

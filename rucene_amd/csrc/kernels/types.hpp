@@ -38,6 +38,10 @@ struct SegView {
   int32_t n_norm_ranks;
   int32_t max_doc;
   int32_t doc_base;
+  // 0: the field was indexed with IndexOptions::Docs — no freq block follows a doc block and tail VInts are plain
+  // deltas; every freq is 1 (posting_reader.rs:532-557: the freq buffer is filled with 1). The block store then carries
+  // one synthetic all-equal freq row (value 1) per block, so every block decoder works unchanged.
+  int32_t has_freqs;
 };
 
 // One term as the kernels see it (built on the host from rgpu_term_state + the directory cache).

@@ -151,6 +151,7 @@ struct rgpu_segment {
   int32_t n_norm_ranks = 0;
   uint64_t* d_live = nullptr;
   int32_t max_doc = 0, doc_base = 0, version = 1;
+  bool has_freqs = true;  // false: IndexOptions::Docs (no freq blocks, plain-delta tails, every freq 1)
   DevVec<int32_t> dir_last;
   DevVec<uint32_t> dir_off;
   DevVec<uint32_t> dir_row;
@@ -262,6 +263,7 @@ static SegView seg_view(const rgpu_segment* s) {
   v.sim_tables = s->ctx->sim_tables.p;
   v.max_doc = s->max_doc;
   v.doc_base = s->doc_base;
+  v.has_freqs = s->has_freqs ? 1 : 0;
   return v;
 }
 
@@ -319,7 +321,8 @@ static int32_t prepare_terms_locked(rgpu_segment* seg, const rgpu_term_state* co
     // block store rows: a block's aligned copy is at most 28 bytes longer than its framing in the file (two
     // header bytes dropped, each all-equal VInt padded to a 16-byte row); the FullBlocks end before the skip data
     const uint64_t span = st.doc_freq > 128 ? (uint64_t)st.skip_offset : 1026u;
-    const uint64_t rows = (span + 28u * (uint64_t)p.nblocks + 15u) / 16u;
+    // (a docs-only field: one header byte dropped, a synthetic 16-byte freq row added per block)
+    const uint64_t rows = (span + (seg->has_freqs ? 28u : 32u) * (uint64_t)p.nblocks + 15u) / 16u;
     if (rows > 0xffffffffull) return fail(RGPU_ERR_UNSUPPORTED, "a single term's postings exceed 64 GiB");
     p.bs_base = (uint64_t)need_bs;
     p.bs_rows = (uint32_t)rows;
@@ -363,10 +366,10 @@ static int32_t prepare_terms_locked(rgpu_segment* seg, const rgpu_term_state* co
     TimedLaunch tl(c, c->stream, "k_prepare_terms", postings);
     if (seg->version >= 1)
       hipLaunchKernelGGL(k_prepare_terms<false>, dim3((unsigned)work.size()), dim3(PREP_THREADS), 0, c->stream, seg->d_doc,
-                         (int64_t)seg->doc_len, d_work, seg->dir_last.p, seg->dir_off.p, seg->dir_row.p, seg->dir_hdr.p, c->d_err);
+                         (int64_t)seg->doc_len, d_work, seg->dir_last.p, seg->dir_off.p, seg->dir_row.p, seg->dir_hdr.p, seg->has_freqs ? 1 : 0, c->d_err);
     else
       hipLaunchKernelGGL(k_prepare_terms<true>, dim3((unsigned)work.size()), dim3(PREP_THREADS), 0, c->stream, seg->d_doc,
-                         (int64_t)seg->doc_len, d_work, seg->dir_last.p, seg->dir_off.p, seg->dir_row.p, seg->dir_hdr.p, c->d_err);
+                         (int64_t)seg->doc_len, d_work, seg->dir_last.p, seg->dir_off.p, seg->dir_row.p, seg->dir_hdr.p, seg->has_freqs ? 1 : 0, c->d_err);
   }
   if (n_items > 0) {
     TimedLaunch tl(c, c->stream, "k_prepare_blocks", postings);
@@ -374,11 +377,11 @@ static int32_t prepare_terms_locked(rgpu_segment* seg, const rgpu_term_state* co
     if (seg->version >= 1)
       hipLaunchKernelGGL(k_prepare_blocks<false>, dim3(grid), dim3(PREP_THREADS), 0, c->stream, seg->d_doc, d_work, d_items,
                          (int)work.size(), n_items, seg->dir_last.p, seg->dir_off.p, seg->dir_row.p, seg->dir_hdr.p, seg->bstore.p,
-                         seg->d_norms, seg->pnorm.p, seg->dir_bmax.p, seg->n_norm_ranks > 0 ? 1 : 0, c->d_err);
+                         seg->d_norms, seg->pnorm.p, seg->dir_bmax.p, seg->n_norm_ranks > 0 ? 1 : 0, seg->has_freqs ? 1 : 0, c->d_err);
     else
       hipLaunchKernelGGL(k_prepare_blocks<true>, dim3(grid), dim3(PREP_THREADS), 0, c->stream, seg->d_doc, d_work, d_items,
                          (int)work.size(), n_items, seg->dir_last.p, seg->dir_off.p, seg->dir_row.p, seg->dir_hdr.p, seg->bstore.p,
-                         seg->d_norms, seg->pnorm.p, seg->dir_bmax.p, seg->n_norm_ranks > 0 ? 1 : 0, c->d_err);
+                         seg->d_norms, seg->pnorm.p, seg->dir_bmax.p, seg->n_norm_ranks > 0 ? 1 : 0, seg->has_freqs ? 1 : 0, c->d_err);
   }
   int err = 0;
   HIP_TRY(hipMemcpyAsync(&err, c->d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -404,7 +407,7 @@ static int32_t make_dev_term(const rgpu_segment* seg, const rgpu_term_state& st,
   t.sim_table = sim_table;
   t.flags = (sim_table >= 0 && (size_t)sim_table < seg->ctx->sim_monotone.size() && seg->ctx->sim_monotone[(size_t)sim_table]) ? TERM_FLAG_MONOTONE : 0u;
   t.singleton_doc = st.singleton_doc_id;
-  t.singleton_freq = (int32_t)st.total_term_freq;
+  t.singleton_freq = seg->has_freqs ? (int32_t)st.total_term_freq : 1;  // posting_reader.rs:483: total_term_freq = doc_freq without freqs
   if (st.doc_freq == 1 && (st.singleton_doc_id < 0 || st.singleton_doc_id >= seg->max_doc))
     return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "singleton_doc_id out of range");
   if (st.doc_freq >= 128) {
@@ -553,8 +556,17 @@ extern "C" int32_t rgpu_sim_table_upload(rgpu_ctx* c, const float cache[256], fl
 // ---- segment ---------------------------------------------------------------------------------------------------
 extern "C" int32_t rgpu_segment_upload(rgpu_ctx* c, const uint8_t* doc_file, size_t doc_len, const uint8_t* norms,
                                        int32_t max_doc, int32_t doc_base, const uint64_t* live_docs, rgpu_segment** out_seg) {
+  return rgpu_segment_upload_field(c, doc_file, doc_len, norms, max_doc, doc_base, live_docs, 2 /* DocsAndFreqs */, out_seg);
+}
+
+extern "C" int32_t rgpu_segment_upload_field(rgpu_ctx* c, const uint8_t* doc_file, size_t doc_len, const uint8_t* norms,
+                                             int32_t max_doc, int32_t doc_base, const uint64_t* live_docs, int32_t index_options,
+                                             rgpu_segment** out_seg) {
   if (!c || !doc_file || !out_seg) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "bad arguments");
   *out_seg = nullptr;
+  if (index_options != 1 && index_options != 2)
+    return fail(index_options >= 3 && index_options <= 4 ? RGPU_ERR_UNSUPPORTED : RGPU_ERR_ILLEGAL_ARGUMENT,
+                "index_options must be 1 (Docs) or 2 (DocsAndFreqs): a positions field's skip entries carry extra pointers");
   if (max_doc < 0) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "negative max_doc");
   rucene::DocFileInfo info;
   std::string why;
@@ -568,6 +580,7 @@ extern "C" int32_t rgpu_segment_upload(rgpu_ctx* c, const uint8_t* doc_file, siz
   s->max_doc = max_doc;
   s->doc_base = doc_base;
   s->version = info.version;
+  s->has_freqs = index_options >= 2;
   const size_t pad = 8192;  // speculative row / tail loads may run past the last posting byte
   auto bail = [&](hipError_t e, const char* what) { rgpu_segment_free(s); return fail(RGPU_ERR_RUNTIME, std::string(what) + ": " + hipGetErrorString(e)); };
   hipError_t e;

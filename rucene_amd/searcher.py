@@ -59,13 +59,15 @@ class LeafReader:
     RESOLVED_CACHE_TERMS = 1 << 20   # bound of the per-leaf memo of resolved byte terms
 
     def __init__(self, doc_bytes, norms, max_doc, terms, doc_base=0, live_docs=None, doc_count=None,
-                 sum_total_term_freq=0, sum_doc_freq=-1, field="body", term_dictionary=None, field_number=0):
+                 sum_total_term_freq=0, sum_doc_freq=-1, field="body", term_dictionary=None, field_number=0,
+                 index_options=_lib.INDEX_OPTIONS_DOCS_AND_FREQS):
         self.doc_bytes, self.norms, self.max_doc, self.doc_base = doc_bytes, norms, int(max_doc), int(doc_base)
         self.terms = np.ascontiguousarray(terms if terms is not None else [], dtype=TERM_STATE_DTYPE)
         self.live_docs = live_docs
         self.doc_count = int(max_doc if doc_count is None else doc_count)
         self.sum_total_term_freq, self.sum_doc_freq, self.field = int(sum_total_term_freq), int(sum_doc_freq), field
         self.term_dictionary, self.field_number = term_dictionary, int(field_number)
+        self.index_options = int(index_options)  # doc::IndexOptions ordinal of the searched field: 1 Docs, 2 DocsAndFreqs
         self._resolved = {}  # term bytes -> state or None
         self.segment = None  # rgpu_segment, created by the searcher
 
@@ -82,7 +84,7 @@ class LeafReader:
         file) the searched field is found by its name `field` and every other indexed field is declared from the file;
         otherwise pass `field_number`/`index_options` and `other_fields`: (number, index_options[, has_payloads]) of the
         segment's other indexed fields (the `.tim` summary lists them all).
-        Only a docs+freqs field can be searched (positions fields carry a different skip-entry layout)."""
+        A Docs or a DocsAndFreqs field can be searched (positions fields carry a different skip-entry layout)."""
         if fnm is not None:
             infos = _lib.field_infos_from_lucene60(fnm)
             mine = [fi for fi in infos if fi["name"] == field]
@@ -91,8 +93,8 @@ class LeafReader:
             field_number, index_options = mine[0]["number"], mine[0]["index_options"]
             other_fields = [(fi["number"], fi["index_options"], int(fi["has_payloads"])) for fi in infos
                             if fi["index_options"] != 0 and fi["name"] != field]
-        if index_options != _lib.INDEX_OPTIONS_DOCS_AND_FREQS:
-            raise RgpuError(-5, "the searched field must be indexed with IndexOptions::DocsAndFreqs")
+        if index_options not in (_lib.INDEX_OPTIONS_DOCS, _lib.INDEX_OPTIONS_DOCS_AND_FREQS):
+            raise RgpuError(-5, "the searched field must be indexed with IndexOptions::Docs or ::DocsAndFreqs")
         td = _lib.TermDictionary(tim, tip, [(field_number, index_options)] + list(other_fields), max_doc)
         stats = td.field_stats(field_number)
         if stats is None:
@@ -100,7 +102,7 @@ class LeafReader:
         norms = _lib.norms_from_lucene53(nvm, nvd, field_number, max_doc)
         live = _lib.live_docs_from_lucene50(liv, max_doc, del_count) if liv is not None else None
         return cls(doc, norms, max_doc, None, doc_base, live, stats["doc_count"], stats["sum_total_term_freq"],
-                   stats["sum_doc_freq"], field, td, field_number)
+                   stats["sum_doc_freq"], field, td, field_number, index_options)
 
     def resolve(self, terms):
         """One batched dictionary lookup for the byte terms not seen before (seek_exact + term_state each)."""
@@ -268,7 +270,7 @@ class GpuIndexSearcher:
         self.similarity = similarity or BM25Similarity()
         for leaf in self.leaves:
             if leaf.segment is None:
-                leaf.segment = _lib.Segment(self.ctx, leaf.doc_bytes, leaf.norms, leaf.max_doc, leaf.doc_base, leaf.live_docs)
+                leaf.segment = _lib.Segment(self.ctx, leaf.doc_bytes, leaf.norms, leaf.max_doc, leaf.doc_base, leaf.live_docs, leaf.index_options)
         # searcher.rs:306-363: statistics of the first leaf with the largest max_doc stand in for the index
         self._stats_leaf = 0
         for i, leaf in enumerate(self.leaves):

@@ -734,3 +734,44 @@ def test_sharded_search_through_the_c_abi_with_a_world_of_one(zipf, oracle):
         assert (got["doc"] == want_h["doc"]).all() and (got["score"].view(np.int32) == want_h["score"].view(np.int32)).all()
         assert (totals.cpu().numpy() == want_t).all()
     comm.close()
+
+
+@pytest.mark.parametrize("version", [1, 0], ids=["bp128", "legacy"])
+def test_docs_only_field(ctx, oracle, version):
+    """IndexOptions::Docs (SURVEY 8(a) a4: no freq block after a doc block, plain-delta VInt tails, every freq 1 —
+    posting_reader.rs:532-557, skip_block for_util.rs:263-272): the .doc bytes come from the restated
+    Lucene50PostingsWriter with write_freqs = false; decode, advance and TERM / AND / OR / MUST_NOT search must equal
+    the oracle's BlockDocIterator / scorers over the same bytes, bit for bit."""
+    import rucene_amd
+    max_doc = 400_000
+    lists = _edge_lists(43, max_doc // 2)
+    rng = np.random.default_rng(3)
+    norms = rng.integers(95, 125, size=max_doc).astype(np.uint8)
+    w = oracle.Writer(max_doc, version=version, write_freqs=False)
+    terms = np.array([w.write_term(d, np.ones_like(d)) for d, _ in lists], dtype=oracle.TERM_STATE_DTYPE)
+    doc_bytes = w.close()
+    # Lucene's term dictionary keeps no total_term_freq for such a field (blocktree: -1): the product must not read it
+    terms["total_term_freq"] = -1
+    sum_ttf = -1  # Terms::sum_total_term_freq of a Docs field -> avgdl = 1 (bm25_similarity.rs:72-83)
+    oseg = oracle.Segment(doc_bytes, norms, max_doc, terms, sum_total_term_freq=sum_ttf, has_freqs=False)
+    gseg = rucene_amd.Segment(ctx, doc_bytes, norms, max_doc, index_options=1)
+    docs, freqs = gseg.decode_terms(terms)
+    want = [oseg.decode_term(t) for t in terms]
+    assert (docs == np.concatenate([x[0] for x in want])).all()
+    assert (freqs == 1).all() and (np.concatenate([x[1] for x in want]) == 1).all()
+    big = int(np.argmax(terms["doc_freq"]))
+    targets = np.concatenate([lists[big][0][::97], lists[big][0][::89] + 1, [0, max_doc - 1]]).astype(np.int32)
+    gd, gf = gseg.advance(terms[big], targets)
+    all_docs = lists[big][0]
+    pos = np.searchsorted(all_docs, targets)
+    assert (gd == np.where(pos < all_docs.size, all_docs[np.minimum(pos, all_docs.size - 1)], 0x7FFFFFFF)).all()
+    assert (gf[gd != 0x7FFFFFFF] == 1).all()
+    leaf = rucene_amd.LeafReader(doc_bytes, norms, max_doc, terms, sum_total_term_freq=sum_ttf, index_options=1)
+    gsearcher = rucene_amd.GpuIndexSearcher([leaf], ctx=ctx)
+    osearcher = oracle.Searcher([oseg])
+    n = len(lists)
+    specs = [(oracle.OP_TERM, [t]) for t in range(n)]
+    specs += [(oracle.OP_AND, [n - 5, n - 6]), (oracle.OP_AND, [n - 5, n - 7, n - 8]), (oracle.OP_OR, [0, 3, n - 5, n - 6]),
+              (oracle.OP_OR, list(range(n - 9, n)))]
+    for k in (10, 100):
+        _check_against_oracle(oracle, osearcher, gsearcher, specs, k)
