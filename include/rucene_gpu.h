@@ -151,6 +151,12 @@ int32_t rgpu_segment_version(const rgpu_segment* seg); /* .doc format version (0
  * of opening a term's skipper. Called implicitly by every entry point below for terms it has not seen;
  * exposed so a caller can pay it at segment-open time. */
 int32_t rgpu_segment_prepare_terms(rgpu_segment* seg, const rgpu_term_state* terms, int64_t n_terms);
+/* The per-term structures (directory, 16-byte aligned block copies, posting-order norms: about the term's share of the
+ * .doc file again plus 1 byte per posting) are kept for every distinct term ever queried, for the life of the segment;
+ * HBM use therefore grows towards ~2x the .doc size as the query vocabulary widens, and running out surfaces as
+ * RGPU_ERR_RUNTIME from the call that needed the space. This drops them all (after waiting for work in flight); terms
+ * are prepared again the next time they are used. */
+int32_t rgpu_segment_release_prepared_terms(rgpu_segment* seg);
 
 /* BlockDocIterator over whole terms (posting_reader.rs:501-647: refill_docs + next, i.e. ForUtil
  * read_block for docs and freqs, VInt tail, singleton) — decodes every posting of every given term into
@@ -180,7 +186,10 @@ int32_t rgpu_sim_table_upload(rgpu_ctx* ctx, const float cache[256], float k1);
  *                   SURVEY.md §8(c)); unused slots {-1, 0}
  *   total_hits_out  n_queries, TopDocs::total_hits (every collected live doc)
  * Scores are f32 computed in the reference's operation order: TERM and AND bit-exact with the CPU scorers,
- * OR with >= 10 clauses within 1e-5 relative (heap-order-dependent summation in the reference). */
+ * OR with >= 10 clauses within 1e-5 relative (heap-order-dependent summation in the reference). ONE exception, by
+ * design: queries carrying RGPU_OP_WITH_SHOULD clauses always add the optional scores, where the reference's
+ * ReqOptScorer skips them for low scorers after 100 docs (see the macro above) — doc ids and hit counts equal the
+ * reference's, scores are >= its. */
 int32_t rgpu_search_batch(rgpu_segment* seg, const rgpu_query* queries, int32_t n_queries, const rgpu_query_term* terms,
                           int32_t n_terms_total, int32_t k, rgpu_hit* hits_out, int64_t* total_hits_out);
 /* Same with device-resident outputs (for the RCCL all-gather of per-shard top-k). Enqueue-only for TERM / AND

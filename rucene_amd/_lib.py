@@ -40,7 +40,7 @@ STATUS_NAMES = {0: "OK", -1: "IllegalState", -2: "IllegalArgument", -3: "Unexpec
 # every symbol include/rucene_gpu.h declares (tests/test_abi.py checks the header and this list agree)
 EXPORTS = [
     "rgpu_init", "rgpu_shutdown", "rgpu_last_error", "rgpu_abi_version", "rgpu_device_name", "rgpu_segment_upload",
-    "rgpu_segment_upload_field",
+    "rgpu_segment_upload_field", "rgpu_segment_release_prepared_terms",
     "rgpu_segment_free", "rgpu_segment_version", "rgpu_segment_prepare_terms", "rgpu_decode_terms",
     "rgpu_decode_terms_device", "rgpu_advance_batch", "rgpu_sim_table_upload", "rgpu_search_batch",
     "rgpu_search_batch_device", "rgpu_merge_topk_device", "rgpu_bm25_compute_weight", "rgpu_bm25_encode_norm",
@@ -114,6 +114,7 @@ def lib():
         "rgpu_segment_free": (None, [vp]),
         "rgpu_segment_version": (i32, [vp]),
         "rgpu_segment_prepare_terms": (i32, [vp, vp, i64]),
+        "rgpu_segment_release_prepared_terms": (i32, [vp]),
         "rgpu_decode_terms": (i32, [vp, vp, i64, vp, vp]),
         "rgpu_decode_terms_device": (i32, [vp, vp, i64, vp, vp, vp]),
         "rgpu_advance_batch": (i32, [vp, vp, vp, i64, vp, vp]),
@@ -434,6 +435,9 @@ class Segment:
     def prepare_terms(self, states):
         st = np.ascontiguousarray(states, dtype=TERM_STATE_DTYPE)
         _check(lib().rgpu_segment_prepare_terms(self._h, st.ctypes.data, st.size))
+
+    def release_prepared_terms(self):
+        _check(lib().rgpu_segment_release_prepared_terms(self._h))
 
     def decode_terms(self, states):
         st = np.ascontiguousarray(np.atleast_1d(states), dtype=TERM_STATE_DTYPE)

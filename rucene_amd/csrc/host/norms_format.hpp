@@ -20,16 +20,18 @@ namespace rucene {
 
 namespace detail {
 inline uint32_t crc32_ieee(const uint8_t* p, size_t n) {  // zlib polynomial, as store/io/fs_index_output.rs (crc32fast)
-  static uint32_t table[256];
-  static bool init = false;
-  if (!init) {
-    for (uint32_t i = 0; i < 256; i++) {
-      uint32_t c = i;
-      for (int k = 0; k < 8; k++) c = (c & 1) ? (0xEDB88320u ^ (c >> 1)) : (c >> 1);
-      table[i] = c;
+  struct Table {  // built by a function-local static's initialiser: thread-safe since C++11 (the parsers run from any thread)
+    uint32_t v[256];
+    Table() {
+      for (uint32_t i = 0; i < 256; i++) {
+        uint32_t c = i;
+        for (int k = 0; k < 8; k++) c = (c & 1) ? (0xEDB88320u ^ (c >> 1)) : (c >> 1);
+        v[i] = c;
+      }
     }
-    init = true;
-  }
+  };
+  static const Table tbl;
+  const uint32_t* table = tbl.v;
   uint32_t c = 0xFFFFFFFFu;
   for (size_t i = 0; i < n; i++) c = table[(c ^ p[i]) & 0xFF] ^ (c >> 8);
   return c ^ 0xFFFFFFFFu;

@@ -82,12 +82,14 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_terms(const uint8_t* _
     }
     __syncthreads();
     const uint8_t* l0 = doc + s_l0;
+    const int64_t l0_room = doc_len - s_l0;  // bytes of the file from level 0 on (the device copy is padded by 8 KiB of zeros)
     // ---- parallel VInt decode of 2 * n_entries values: even = docDelta (vint), odd = docFpDelta (vlong)
     const uint32_t need = 2u * (uint32_t)t.n_entries;
     uint32_t done = 0;
     int64_t chunk = 0;
     while (done < need) {
       const int64_t my = chunk + 16 * tid;  // 16 bytes per thread, 4 KiB per round (a 2 M-posting term has ~80 KB of level 0)
+      if (chunk >= l0_room) { if (tid == 0) atomicMin(err, -4); break; }  // ran off the file looking for skip entries (uniform)
       const uint4 w4 = load16_unaligned(l0 + my);
       const uint32_t ws[4] = {w4.x, w4.y, w4.z, w4.w};
       uint32_t term = 0;
@@ -142,6 +144,8 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_terms(const uint8_t* _
   // ---- block headers (for_util.rs:196-223) + consistency of every skip pointer with the block sizes
   for (int i = tid; i < t.nblocks; i += PREP_THREADS) {
     const uint32_t off = dir_off[t.dir_base + i];
+    // offsets are running sums of deltas nobody has checked yet: a block (<= 2 + 2 * 512 bytes) must start inside the file
+    if ((uint64_t)t.start_fp + (uint64_t)off + 1030u > (uint64_t)doc_len + 4096u) { atomicMin(err, -4); dir_hdr[t.dir_base + i] = 0; continue; }
     const uint8_t* p = doc + t.start_fp + off;
     const uint32_t h = p[0];
     const int bd = (int)(h & 63);
@@ -200,7 +204,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_blocks(const uint8_t* 
                                                                   const uint16_t* __restrict__ dir_hdr, uint8_t* bstore,
                                                                   const uint8_t* __restrict__ norms, uint8_t* pnorm,
                                                                   uint64_t* __restrict__ dir_bmax, int ranked, int has_freqs,
-                                                                  const int* __restrict__ err) {
+                                                                  int32_t max_doc, int* err) {
   __shared__ __attribute__((aligned(16))) uint8_t slabs[PREP_THREADS / 64][SLAB_BYTES];
   const int lane = lane_id();
   const int wave = wave_id();
@@ -227,16 +231,24 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_blocks(const uint8_t* 
     const int rd = store_doc_rows(hdr);
     if (row < (half ? store_freq_rows(hdr) : rd))
       *reinterpret_cast<uint4*>(term_rows + 16 * (size_t)(row0 + (uint32_t)(half ? rd : 0) + (uint32_t)row)) = rows;
+    // Every FullBlock is decoded and validated here, once: doc ids inside the segment and strictly increasing (a zero
+    // delta or a 32-bit wrap shows up as d1 <= d0 or d0 <= the previous lane's d1), and the block ending on the doc its
+    // skip entry names. The query kernels then gather norms / live bits and index windows with these docs unchecked.
+    const int32_t base = blk == 0 ? 0 : dir_last[t.dir_base + blk - 1];
+    const BlockPair bp = block_rows_decode<LEGACY>(rows, hdr, slabs[wave], lane);
+    int32_t d0, d1;
+    deltas_to_docs(bp.d0, bp.d1, base, d0, d1);
+    // df % 128 == 0: no skip entry names the final block's last doc (k_prepare_terms left a sentinel there); the
+    // decode does — windowed consumers (the OR kernel) can then tell that the term has ended
+    if (blk == t.nblocks - 1 && t.nblocks > t.n_entries && lane == 63) dir_last[t.dir_base + blk] = d1;
+    const int32_t prev = __builtin_amdgcn_update_dpp(base, d1, 0x138, 0xf, 0xf, false);  // wave_shr:1; lane 0 <- the block's base doc
+    // (a term's very first delta is relative to doc 0 and may be 0: posting_writer.rs:298)
+    const bool bad_first = (blk == 0 && lane == 0) ? d0 < 0 : d0 <= prev;
+    const bool bad = bad_first || d1 <= d0 || d1 >= max_doc;
+    const bool bad_last = blk < t.n_entries && lane == 63 && d1 != dir_last[t.dir_base + blk];
+    if (__ballot(bad || bad_last)) { if (lane == 0) atomicMin(err, -4); return; }
     if (norms != nullptr) {
-      const int32_t base = blk == 0 ? 0 : dir_last[t.dir_base + blk - 1];
-      const BlockPair bp = block_rows_decode<LEGACY>(rows, hdr, slabs[wave], lane);
-      int32_t d0, d1;
-      deltas_to_docs(bp.d0, bp.d1, base, d0, d1);
-      // df % 128 == 0: no skip entry names the final block's last doc (k_prepare_terms left a sentinel there); the
-      // decode does — windowed consumers (the OR kernel) can then tell that the term has ended
-      if (blk == t.nblocks - 1 && t.nblocks > t.n_entries && lane == 63) dir_last[t.dir_base + blk] = d1;
-      // a corrupt block must not turn into a wild gather
-      const uint32_t n0 = d0 >= 0 ? norms[d0] : 0u, n1 = d1 >= 0 ? norms[d1] : 0u;
+      const uint32_t n0 = norms[d0], n1 = norms[d1];
       *reinterpret_cast<uint16_t*>(pnorm + t.pn_base + 128 * (uint64_t)blk + 2 * lane) = (uint16_t)(n0 | (n1 << 8));
       // the block's (freq, norm rank) frontier word (SegView::dir_bmax)
       uint64_t w = 15ull;

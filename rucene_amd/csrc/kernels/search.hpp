@@ -30,6 +30,11 @@ __device__ __forceinline__ float bm25_score(float weight_k1p1, float freq, float
 __device__ __forceinline__ bool doc_is_live(const uint64_t* __restrict__ live, int32_t doc) {
   return live == nullptr || ((live[doc >> 6] >> (doc & 63)) & 1ull);  // util/bit_set.rs:453-460
 }
+// A VInt tail or a singleton is decoded at query time from bytes nobody validated (FullBlocks are checked once by
+// k_prepare_blocks): a doc id outside [0, max_doc) from a corrupt file must not turn into a wild gather. Such a posting
+// simply is not collected (the reference would fail its bounds check; garbage in a corrupt index is not parity).
+__device__ __forceinline__ bool doc_in_segment(const SegView& seg, int32_t doc) { return (uint32_t)doc < (uint32_t)seg.max_doc; }
+__device__ __forceinline__ uint32_t norm_at(const SegView& seg, int32_t doc) { return doc_in_segment(seg, doc) ? seg.norms[doc] : 0u; }
 
 // cache[] is indexed by whatever seg.norms holds: raw norm bytes (256 entries) or norm ranks (<= 64 entries)
 __device__ __forceinline__ void load_sim_table(const SegView& seg, int id, float* cache, int lane, float& k1) {

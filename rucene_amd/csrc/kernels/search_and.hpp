@@ -133,8 +133,8 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
   // nn: the candidates' norm bytes — from the lead's posting-order norms for FullBlocks, gathered for
   // its tail; every other clause scores the same docs, so no clause ever gathers norms again
   auto intersect = [&](int32_t d0, int32_t d1, uint32_t f0, uint32_t f1, uint32_t nn, bool a0, bool a1) {  // nn = norm byte 0 | norm byte 1 << 8
-    a0 = a0 && doc_is_live(seg.live, d0);
-    a1 = a1 && doc_is_live(seg.live, d1);
+    a0 = a0 && doc_in_segment(seg, d0) && doc_is_live(seg.live, d0);
+    a1 = a1 && doc_in_segment(seg, d1) && doc_is_live(seg.live, d1);
     use_table(L.sim_table);
     float wk = L.weight * (k1 + 1.0f);
     float s0 = bm25_score(wk, (float)(int32_t)f0, has_norms ? cache[nn & 0xffu] : k1);
@@ -344,13 +344,13 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
       d0 = d1 = L.singleton_doc;
       f0 = (uint32_t)L.singleton_freq; f1 = 0u;
       a0 = lane == 0; a1 = false;
-      if (has_norms && a0) nn = seg.norms[d0];
+      if (has_norms && a0) nn = norm_at(seg, d0);
     } else {
       const uint32_t toff = L.nblocks ? seg.dir_off[L.dir_base + L.nblocks] : 0u;
       decode_tail(seg.doc + L.start_fp + toff, L.tail_n, base, slab, lane, d0, d1, f0, f1, seg.has_freqs != 0);
       a0 = 2 * lane < L.tail_n; a1 = 2 * lane + 1 < L.tail_n;
-      if (has_norms && a0) nn = seg.norms[d0];
-      if (has_norms && a1) nn |= (uint32_t)seg.norms[d1] << 8;
+      if (has_norms && a0) nn = norm_at(seg, d0);
+      if (has_norms && a1) nn |= norm_at(seg, d1) << 8;
     }
     if (RGPU_AND_ABL == 1) { if (a0 && d0 == 12345 && f0 == 77 && nn == 3) count++; continue; }
     intersect(d0, d1, f0, f1, nn, a0, a1);

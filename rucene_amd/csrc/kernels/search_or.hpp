@@ -85,7 +85,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_score_terms(SegView seg, const D
     run[run_len + lane] = ScoredPosting{0x7fffffff, 0.0f};
     if (T.df == 1) {
       const bool v0 = lane == 0;
-      const uint32_t nb0 = (has_norms && v0) ? seg.norms[T.singleton_doc] : 0u;
+      const uint32_t nb0 = (has_norms && v0) ? norm_at(seg, T.singleton_doc) : 0u;
       emit(T.singleton_doc, 0, (uint32_t)T.singleton_freq, 1u, nb0, 0u, v0, false, 0);
     } else if (T.tail_n > 0) {
       const uint32_t toff = T.nblocks ? seg.dir_off[T.dir_base + T.nblocks] : 0u;
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_score_terms(SegView seg, const D
       uint32_t f0, f1;
       decode_tail(seg.doc + T.start_fp + toff, T.tail_n, base, slab, lane, d0, d1, f0, f1, seg.has_freqs != 0);
       const bool v0 = 2 * lane < T.tail_n, v1 = 2 * lane + 1 < T.tail_n;
-      const uint32_t nb0 = (has_norms && v0) ? seg.norms[d0] : 0u, nb1 = (has_norms && v1) ? seg.norms[d1] : 0u;
+      const uint32_t nb0 = (has_norms && v0) ? norm_at(seg, d0) : 0u, nb1 = (has_norms && v1) ? norm_at(seg, d1) : 0u;
       emit(d0, d1, f0, f1, nb0, nb1, v0, v1, (dense ? 0 : 128 * (int64_t)T.nblocks) + 2 * lane);
     }
   }
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(OR_THREADS, 6) void k_or_windows(SegView seg, const
     auto add = [&](int32_t doc, float sc, bool valid, bool prohibited) {
       const uint32_t o = (uint32_t)(doc - w0);
       bool in = valid && o < wlen;
-      if (in && has_live) in = doc_is_live(seg.live, doc);
+      if (in && has_live) in = doc_is_live(seg.live, doc);  // doc < w1 <= max_doc here
       if (in) {
         const float a = acc[o];
         const uint32_t ab = __float_as_uint(a);

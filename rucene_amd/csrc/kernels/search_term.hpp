@@ -352,8 +352,8 @@ __global__ __launch_bounds__(TERM_THREADS, 8) void k_search_term(SegView seg, co
       constexpr bool FULL = decltype(full)::value;
       if (FULL) { v0 = true; v1 = true; }
       if (has_live) {
-        v0 = v0 && doc_is_live(seg.live, d0);
-        v1 = v1 && doc_is_live(seg.live, d1);
+        v0 = v0 && doc_in_segment(seg, d0) && doc_is_live(seg.live, d0);
+        v1 = v1 && doc_in_segment(seg, d1) && doc_is_live(seg.live, d1);
       }
       float s0, s1;
       const uint32_t fmax = f0 > f1 ? f0 : f1;
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(TERM_THREADS, 8) void k_search_term(SegView seg, co
     if (b1 == T.nblocks) {
       if (T.df == 1) {
         const bool v0 = lane == 0;
-        const uint32_t nb0 = (has_norms && v0) ? seg.norms[T.singleton_doc] : 0u;
+        const uint32_t nb0 = (has_norms && v0) ? norm_at(seg, T.singleton_doc) : 0u;
         collect(std::false_type{}, T.singleton_doc, 0, (uint32_t)T.singleton_freq, 1u, nb0, 0u, v0, false);
       } else if (T.tail_n > 0) {
         const uint32_t toff = T.nblocks ? seg.dir_off[T.dir_base + T.nblocks] : 0u;
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(TERM_THREADS, 8) void k_search_term(SegView seg, co
         uint32_t f0, f1;
         decode_tail(seg.doc + T.start_fp + toff, T.tail_n, base, tail_scratch, lane, d0, d1, f0, f1, seg.has_freqs != 0);
         tabled = false;  // the tail decoder's scratch overlaid the score table: score by the formula it memoises
-        const bool v0 = 2 * lane < T.tail_n, v1 = 2 * lane + 1 < T.tail_n;
+        const bool v0 = 2 * lane < T.tail_n && doc_in_segment(seg, d0), v1 = 2 * lane + 1 < T.tail_n && doc_in_segment(seg, d1);
         const uint32_t nb0 = (has_norms && v0) ? seg.norms[d0] : 0u, nb1 = (has_norms && v1) ? seg.norms[d1] : 0u;
         collect(std::false_type{}, d0, d1, f0, f1, nb0, nb1, v0, v1);
       }

@@ -58,9 +58,8 @@ struct DevVec {
     if (e != hipSuccess) return e;
     if (p && keep) {
       e = hipMemcpyAsync(np, p, keep * sizeof(T), hipMemcpyDeviceToDevice, s);
-      if (e != hipSuccess) return e;
-      e = hipStreamSynchronize(s);
-      if (e != hipSuccess) return e;
+      if (e == hipSuccess) e = hipStreamSynchronize(s);
+      if (e != hipSuccess) { (void)hipFree(np); return e; }
     }
     if (p) (void)hipFree(p);
     p = np;
@@ -75,9 +74,14 @@ struct HostPinned {
   size_t cap = 0;
   hipError_t reserve(size_t n) {
     if (n <= cap) return hipSuccess;
+    const size_t ncap = std::max(n, cap * 2);
+    uint8_t* np = nullptr;
+    hipError_t e = hipHostMalloc((void**)&np, ncap, hipHostMallocDefault);
+    if (e != hipSuccess) return e;  // the old buffer stays valid
     if (p) (void)hipHostFree(p);
-    cap = std::max(n, cap * 2);
-    return hipHostMalloc((void**)&p, cap, hipHostMallocDefault);
+    p = np;
+    cap = ncap;
+    return hipSuccess;
   }
   void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
 };
@@ -377,11 +381,11 @@ static int32_t prepare_terms_locked(rgpu_segment* seg, const rgpu_term_state* co
     if (seg->version >= 1)
       hipLaunchKernelGGL(k_prepare_blocks<false>, dim3(grid), dim3(PREP_THREADS), 0, c->stream, seg->d_doc, d_work, d_items,
                          (int)work.size(), n_items, seg->dir_last.p, seg->dir_off.p, seg->dir_row.p, seg->dir_hdr.p, seg->bstore.p,
-                         seg->d_norms, seg->pnorm.p, seg->dir_bmax.p, seg->n_norm_ranks > 0 ? 1 : 0, seg->has_freqs ? 1 : 0, c->d_err);
+                         seg->d_norms, seg->pnorm.p, seg->dir_bmax.p, seg->n_norm_ranks > 0 ? 1 : 0, seg->has_freqs ? 1 : 0, seg->max_doc, c->d_err);
     else
       hipLaunchKernelGGL(k_prepare_blocks<true>, dim3(grid), dim3(PREP_THREADS), 0, c->stream, seg->d_doc, d_work, d_items,
                          (int)work.size(), n_items, seg->dir_last.p, seg->dir_off.p, seg->dir_row.p, seg->dir_hdr.p, seg->bstore.p,
-                         seg->d_norms, seg->pnorm.p, seg->dir_bmax.p, seg->n_norm_ranks > 0 ? 1 : 0, seg->has_freqs ? 1 : 0, c->d_err);
+                         seg->d_norms, seg->pnorm.p, seg->dir_bmax.p, seg->n_norm_ranks > 0 ? 1 : 0, seg->has_freqs ? 1 : 0, seg->max_doc, c->d_err);
   }
   int err = 0;
   HIP_TRY(hipMemcpyAsync(&err, c->d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -628,6 +632,18 @@ extern "C" void rgpu_segment_free(rgpu_segment* s) {
 }
 
 extern "C" int32_t rgpu_segment_version(const rgpu_segment* s) { return s ? s->version : RGPU_ERR_ILLEGAL_ARGUMENT; }
+
+extern "C" int32_t rgpu_segment_release_prepared_terms(rgpu_segment* seg) {
+  if (!seg) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "seg is null");
+  rgpu_ctx* c = seg->ctx;
+  std::lock_guard<std::mutex> g(c->mu);
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipDeviceSynchronize());  // batches in flight on any stream still read the directories
+  for (auto& sc : c->scr) sc.busy = false;
+  seg->prepared.clear();
+  seg->dir_used = seg->bstore_used = seg->pnorm_used = 0;  // the arrays keep their capacity and are refilled from the start
+  return RGPU_OK;
+}
 
 extern "C" int32_t rgpu_segment_prepare_terms(rgpu_segment* seg, const rgpu_term_state* terms, int64_t n_terms) {
   if (!seg || (!terms && n_terms > 0) || n_terms < 0) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "bad arguments");
@@ -920,9 +936,10 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
     if (qop < RGPU_OP_TERM || qop > RGPU_OP_OR || (Q.op >> 24) != 0) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "unknown query op");
     if (qmsm > 1 && qop != RGPU_OP_OR) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "min_should_match applies to SHOULD clauses (op OR) only");
     if (qopt > 0 && qop == RGPU_OP_OR) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "optional SHOULD clauses go with MUST clauses (op TERM / AND); an OR query's clauses are its n_terms");
-    if (Q.n_terms < 1 || Q.n_must_not < 0 || Q.n_terms + qopt + Q.n_must_not > RGPU_MAX_QUERY_TERMS || (qop == RGPU_OP_TERM && Q.n_terms != 1))
+    if (Q.n_terms < 1 || Q.n_terms > RGPU_MAX_QUERY_TERMS || Q.n_must_not < 0 || Q.n_must_not > RGPU_MAX_QUERY_TERMS ||
+        Q.n_terms + qopt + Q.n_must_not > RGPU_MAX_QUERY_TERMS || (qop == RGPU_OP_TERM && Q.n_terms != 1))
       return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "bad clause count");
-    if (Q.first_term < 0 || Q.first_term + Q.n_terms + qopt + Q.n_must_not > n_terms_total)
+    if (Q.first_term < 0 || (int64_t)Q.first_term + Q.n_terms + qopt + Q.n_must_not > (int64_t)n_terms_total)
       return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "clause range outside terms[]");
     for (int i = 0; i < Q.n_terms + qopt + Q.n_must_not; ++i) {
       const rgpu_query_term& t = terms[Q.first_term + i];

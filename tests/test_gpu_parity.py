@@ -775,3 +775,46 @@ def test_docs_only_field(ctx, oracle, version):
               (oracle.OP_OR, list(range(n - 9, n)))]
     for k in (10, 100):
         _check_against_oracle(oracle, osearcher, gsearcher, specs, k)
+
+
+def test_corrupt_doc_files_fail_safely(ctx, oracle):
+    """offsets and doc ids taken from the .doc file are validated on the GPU before use. Mutated
+    files (random byte flips in block payloads, headers, skip data and tails) must either search without a fault or be
+    refused with a status code (CorruptIndex / IllegalArgument / UnexpectedEOF / Unsupported) — never crash the process."""
+    import rucene_amd
+    from rucene_amd import indexgen
+    max_doc = 200_000
+    rng = np.random.default_rng(77)
+    lists = [_postings(rng, df, max_doc) for df in (1, 5, 127, 128, 129, 700, 1152, 5000, 40_000)]
+    norms = rng.integers(95, 125, size=max_doc).astype(np.uint8)
+    seg = indexgen.build_explicit(max_doc, lists, norms=norms)
+    pristine = np.array(seg.doc_bytes, dtype=np.uint8)
+    T, B = rucene_amd.TermQuery, rucene_amd.BooleanQuery
+    n = len(lists)
+    queries = [T(t) for t in range(n)] + [B.build([T(n - 1), T(n - 2)], []), B.build([T(n - 1), T(n - 3), T(n - 4)], []),
+                                           B.build([], [T(t) for t in range(n)]), B.build([T(n - 1)], [], must_nots=[T(n - 2)])]
+    body0 = 60  # past the index header and the ForUtil table
+    refused = searched = 0
+    for trial in range(48):
+        data = pristine.copy()
+        for _ in range(int(rng.integers(1, 4))):
+            at = int(rng.integers(body0, data.size - 16))
+            data[at] = np.uint8(rng.integers(0, 256)) if trial % 3 else np.uint8(data[at] ^ (1 << int(rng.integers(0, 8))))
+        try:
+            leaf = rucene_amd.LeafReader(data, norms, max_doc, seg.terms, sum_total_term_freq=100 * max_doc)
+            s = rucene_amd.GpuIndexSearcher([leaf], ctx=ctx)
+            hits, totals = s.search_batch(queries, 10)
+            docs, freqs = leaf.segment.decode_terms(seg.terms)
+            assert docs.size == int(seg.terms["doc_freq"].sum())
+            searched += 1
+        except rucene_amd.RgpuError as e:
+            assert e.status in (-2, -3, -4, -5), e
+            refused += 1
+    assert refused + searched == 48 and refused > 0
+    # the context is still healthy afterwards
+    leaf = rucene_amd.LeafReader(pristine, norms, max_doc, seg.terms, sum_total_term_freq=100 * max_doc)
+    hits, totals = rucene_amd.GpuIndexSearcher([leaf], ctx=ctx).search_batch(queries[:n], 10)
+    assert (totals == seg.terms["doc_freq"]).all()
+    leaf.segment.release_prepared_terms()
+    hits2, totals2 = rucene_amd.GpuIndexSearcher([leaf], ctx=ctx).search_batch(queries[:n], 10)
+    assert (totals2 == totals).all() and (hits2["doc"] == hits["doc"]).all()
