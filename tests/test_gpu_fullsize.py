@@ -1,8 +1,10 @@
-"""GPU path at BASELINE.json's full size (10 M docs, 1 M terms — far beyond what the per-doc CPU oracle covers in test
-time): size-independent properties through the C ABI. Decoded postings against the term table's own invariants
-(counts, strictly increasing doc ids, per-term freq checksums, idempotence) and TERM / AND / OR top-k against a numpy
-re-derivation from those postings (tests/fullsize_checks.py; the checkers themselves are validated against the
-oracle on a small index in tests/test_fullsize_checks_cpu.py)."""
+"""GPU path at BASELINE.json's full size (10 M docs, 1 M terms): (1) the ORACLE itself on sampled subsets of the bench's
+own query batches — the multithreaded oracle does 1024 single-term queries in a fraction of a second, 64 conjunctions /
+16 ten-clause disjunctions in a few seconds — and (2) size-independent properties through the C ABI: decoded postings
+against the term table's own invariants (counts, strictly increasing doc ids, per-term freq checksums, idempotence) and
+TERM / AND / OR top-k against a numpy re-derivation from those postings (tests/fullsize_checks.py; the checkers
+themselves are validated against the oracle on a small index in tests/test_fullsize_checks_cpu.py)."""
+import os
 import numpy as np
 import pytest
 
@@ -44,3 +46,45 @@ def test_conjunction_topk_against_numpy(full):
 def test_disjunction_topk_against_numpy(full):
     rucene_amd, seg, decode, search = full
     fc.check_or_queries(rucene_amd, seg, decode, search, [[0, 5], [1, 30, 400, 5_000, 70_000], [2, 3, 4, 6, 8, 9, 11, 13, 15]], 100)
+
+
+# ---- the oracle at full size, on samples of bench.py's batches (same seeds, same rank distributions) --------------------
+def _bench_queries(kind, n):
+    import bench
+    return bench.build_queries(1024, kind, bench.SEED_QUERIES)[:n]
+
+
+def _against_oracle(full, oracle, kind, n, k):
+    rucene_amd, seg, decode, search = full
+    tids = _bench_queries(kind, n)
+    T, B = rucene_amd.TermQuery, rucene_amd.BooleanQuery
+    if kind == "term":
+        qs, op = [T(int(t[0])) for t in tids], oracle.OP_TERM
+    elif kind == "and3":
+        qs, op = [B.build([T(int(x)) for x in t], []) for t in tids], oracle.OP_AND
+    else:
+        qs, op = [B.build([], [T(int(x)) for x in t]) for t in tids], oracle.OP_OR
+    hits, totals = search(qs, k)
+    osearcher = oracle.Searcher([oracle.Segment(seg.doc_bytes, seg.norms, seg.max_doc, seg.terms, sum_total_term_freq=seg.sum_total_term_freq)])
+    ops = np.full(len(qs), op, np.int32)
+    offs = (np.arange(len(qs) + 1) * tids.shape[1]).astype(np.int32)
+    cd, cs, cc, ct, _, _ = osearcher.search_batch(ops, offs, np.ascontiguousarray(tids).reshape(-1), k, tie_mode=oracle.TIE_CANONICAL,
+                                                  threads=os.cpu_count() or 1)
+    assert (totals == ct).all()
+    if kind == "or10":  # >= 10 clauses: the reference sums in heap order -> 1e-5 relative (north_star's tolerance)
+        np.testing.assert_allclose(hits["score"], cs, rtol=1e-5, atol=0)
+    else:
+        assert (hits["doc"] == cd).all()
+        assert (hits["score"].view(np.int32) == cs.view(np.int32)).all()
+
+
+def test_single_term_batch_equals_the_oracle_at_full_size(full, oracle):
+    _against_oracle(full, oracle, "term", 1024, 10)
+
+
+def test_conjunction_sample_equals_the_oracle_at_full_size(full, oracle):
+    _against_oracle(full, oracle, "and3", 64, 10)
+
+
+def test_disjunction_sample_matches_the_oracle_at_full_size(full, oracle):
+    _against_oracle(full, oracle, "or10", 16, 100)
