@@ -63,10 +63,9 @@ __global__ __launch_bounds__(WG_THREADS) void k_decode_terms(SegView seg, const 
     if (T.df == 1) {
       if (lane == 0) { docs_out[out] = T.singleton_doc; freqs_out[out] = T.singleton_freq; }
     } else if (T.tail_n > 0) {
-      const uint32_t toff = T.nblocks ? seg.dir_off[T.dir_base + T.nblocks] : 0u;
       int32_t d0, d1;
       uint32_t f0, f1;
-      decode_tail(seg.doc + T.start_fp + toff, T.tail_n, base, slab, lane, d0, d1, f0, f1, seg.has_freqs != 0);
+      tail_load(term_rows, seg.dir_row[T.dir_base + T.nblocks], lane, d0, d1, f0, f1);  // decoded and validated at prepare time
       const int64_t o = out + 128 * (int64_t)T.nblocks + 2 * lane;
       if (2 * lane < T.tail_n) { docs_out[o] = d0; freqs_out[o] = (int32_t)f0; }
       if (2 * lane + 1 < T.tail_n) { docs_out[o + 1] = d1; freqs_out[o + 1] = (int32_t)f1; }
@@ -116,9 +115,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_advance(SegView seg, DevTerm T, 
         f0 = bp.f0; f1 = bp.f1; n = 128;
       } else {
         if (T.tail_n == 0) break;
-        const uint32_t toff = T.nblocks ? seg.dir_off[T.dir_base + T.nblocks] : 0u;
-        const int32_t base = T.nblocks ? seg.dir_last[T.dir_base + T.nblocks - 1] : 0;
-        decode_tail(seg.doc + T.start_fp + toff, T.tail_n, base, slab, lane, d0, d1, f0, f1, seg.has_freqs != 0);
+        tail_load(seg.bstore + T.bs_base, seg.dir_row[T.dir_base + T.nblocks], lane, d0, d1, f0, f1);
         n = T.tail_n;
       }
       const bool lt0 = 2 * lane < n && d0 < target;

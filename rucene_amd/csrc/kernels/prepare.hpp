@@ -182,8 +182,9 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_terms(const uint8_t* _
     if (ok) dir_row[t.dir_base + i] = at;
     carry_rows += tot;
   }
-  if (tid == 0) dir_row[t.dir_base + t.nblocks] = carry_rows;
-  if (carry_rows > t.bs_rows) {  // more rows than the framing the host sized the store from: corrupt
+  if (tid == 0) dir_row[t.dir_base + t.nblocks] = carry_rows;  // where the term's decoded tail goes (k_prepare_blocks)
+  const uint32_t tail_rows = (t.df > 1 && t.df % 128 != 0) ? (uint32_t)TAIL_STORE_ROWS : 0u;
+  if (carry_rows + tail_rows > t.bs_rows) {  // more rows than the framing the host sized the store from: corrupt
     if (tid == 0) atomicMin(err, -4);
     return;
   }
@@ -223,6 +224,24 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_blocks(const uint8_t* 
   const int b0 = (int)(item - item_prefix[ti]) * PREP_BLOCKS_PER_ITEM;
   const int b1 = min(t.nblocks, b0 + PREP_BLOCKS_PER_ITEM);
   uint8_t* term_rows = bstore + t.bs_base;
+  // the term's last item also takes its VInt tail (posting_reader.rs:308-333): decoded here once, checked like the blocks
+  // (doc ids strictly increasing from the last FullBlock's last doc, inside the segment) and stored as plain arrays
+  const int tail_n = t.df > 1 ? t.df % 128 : 0;
+  if (tail_n > 0 && b0 + PREP_BLOCKS_PER_ITEM >= t.nblocks) {
+    const uint32_t toff = t.nblocks ? dir_off[t.dir_base + t.nblocks] : 0u;
+    const int32_t tbase = t.nblocks ? dir_last[t.dir_base + t.nblocks - 1] : 0;
+    int32_t d0, d1;
+    uint32_t f0, f1;
+    decode_tail(doc + t.start_fp + toff, tail_n, tbase, slabs[wave], lane, d0, d1, f0, f1, has_freqs != 0);
+    const bool v0 = 2 * lane < tail_n, v1 = 2 * lane + 1 < tail_n;
+    const int32_t prev = __builtin_amdgcn_update_dpp(tbase, d1, 0x138, 0xf, 0xf, false);  // wave_shr:1; lane 0 <- the base doc
+    const bool first_ok = (t.nblocks == 0 && lane == 0) ? d0 >= 0 : d0 > prev;  // a term's very first doc may be doc 0
+    const bool bad = (v0 && (!first_ok || d0 >= max_doc)) || (v1 && (d1 <= d0 || d1 >= max_doc));
+    if (__ballot(bad)) { if (lane == 0) atomicMin(err, -4); return; }
+    uint8_t* tp = term_rows + 16 * (size_t)dir_row[t.dir_base + t.nblocks];
+    *reinterpret_cast<uint2*>(tp + 8 * lane) = make_uint2(v0 ? (uint32_t)d0 : 0x7fffffffu, v1 ? (uint32_t)d1 : 0x7fffffffu);
+    *reinterpret_cast<uint2*>(tp + 512 + 8 * lane) = make_uint2(v0 ? f0 : 0u, v1 ? f1 : 0u);
+  }
   for (int blk = b0; blk < b1; ++blk) {
     const uint32_t hdr = dir_hdr[t.dir_base + blk];
     const uint32_t row0 = dir_row[t.dir_base + blk];

@@ -27,11 +27,17 @@ __device__ unsigned long long g_and_dbg[4];  // [2] probed candidates, [3] (lead
 #endif
 
 // Occupancy against registers: at 8 waves/SIMD (64 VGPRs, 80 SGPRs) the kernel spilled 90-120 bytes per lane to
-// scratch (551 MB of writes per launch of the 3-term workload); 6 waves/SIMD hold everything in registers.
+// scratch (551 MB of writes per launch of the 3-term workload, round 1). With the VInt tail decoder moved to prepare
+// time (tail_load) the kernel needs 85-94 VGPRs: 5 waves/SIMD hold every instantiation without scratch
+// (scripts/kernel_resources.py); measured 1.58-1.61 ms at 5 against 1.52-1.58 ms at 8 with spills (VALU-bound, not
+// latency-bound: 86 % VALU busy).
 #ifndef RGPU_AND_WAVES
-#define RGPU_AND_WAVES 6
+#define RGPU_AND_WAVES 5
 #endif
 constexpr int AND_WAVES_PER_SIMD = RGPU_AND_WAVES;
+#ifndef RGPU_AND_PREFETCH  // 1: the next block's rows are requested before the current one is unpacked (five more VGPRs)
+#define RGPU_AND_PREFETCH 1
+#endif
 #ifndef RGPU_AND_ABL  // developer ablations (variant builds only; results are wrong): 1 lead decode only, 2 + clause setup
 #define RGPU_AND_ABL 0  // and directory window, 3 + block decodes without the membership probe
 #endif
@@ -98,7 +104,7 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
                                                            int32_t* __restrict__ partial_counts,
                                                            unsigned long long* __restrict__ tau_slots,
                                                            unsigned long long* __restrict__ touched_slots) {
-  __shared__ __attribute__((aligned(16))) uint8_t slabs[WG_WAVES][SLAB_BYTES];
+  __shared__ __attribute__((aligned(16))) uint8_t slabs[WG_WAVES][2 * SLAB_STREAM];  // FullBlock staging only: tails arrive decoded
   __shared__ float caches[WG_WAVES][256];
   __shared__ uint32_t filters[WG_WAVES][AND_FILTER_WORDS];
   const int lane = lane_id();
@@ -258,11 +264,9 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
         }
         if (from + j - 1 >= T.nblocks) {  // candidates past the last FullBlock: the VInt tail, or nothing
           if (T.tail_n > 0) {
-            const uint32_t toff = T.nblocks ? seg.dir_off[T.dir_base + T.nblocks] : 0u;
-            const int32_t tbase = T.nblocks ? seg.dir_last[T.dir_base + T.nblocks - 1] : 0;
             int32_t e0, e1;
             uint32_t g0, g1;
-            decode_tail(seg.doc + T.start_fp + toff, T.tail_n, tbase, slab, lane, e0, e1, g0, g1, seg.has_freqs != 0);
+            tail_load(term_rows, seg.dir_row[T.dir_base + T.nblocks], lane, e0, e1, g0, g1);  // decoded and validated at prepare time
             probe(e0, e1, 2 * lane < T.tail_n, 2 * lane + 1 < T.tail_n, p0, p1, [&](uint32_t& x0, uint32_t& x1) { x0 = g0; x1 = g1; });
           } else {
             if (p0) missed(a0);
@@ -296,7 +300,9 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
             }
           }
           const bool more = jn > 0;
+#if RGPU_AND_PREFETCH
           const Fetched B = fetch(more ? jn : j);  // unconditional: a load behind a branch would serialise the two
+#endif
           stage_rows(A.rows, slab, lane);
           wave_sync();
           touched += block_bytes(A.hdr);
@@ -310,7 +316,11 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
           probe(e0, e1, true, true, c0, c1, [&](uint32_t& g0, uint32_t& g1) { staged_freqs<LEGACY>(slab, A.rows, A.hdr, lane, g0, g1); });
           if (!more) break;
           j = jn;
+#if RGPU_AND_PREFETCH
           A = B;
+#else
+          A = fetch(j);
+#endif
         }
       }
     }
@@ -346,8 +356,7 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
       a0 = lane == 0; a1 = false;
       if (has_norms && a0) nn = norm_at(seg, d0);
     } else {
-      const uint32_t toff = L.nblocks ? seg.dir_off[L.dir_base + L.nblocks] : 0u;
-      decode_tail(seg.doc + L.start_fp + toff, L.tail_n, base, slab, lane, d0, d1, f0, f1, seg.has_freqs != 0);
+      tail_load(seg.bstore + L.bs_base, seg.dir_row[L.dir_base + L.nblocks], lane, d0, d1, f0, f1);
       a0 = 2 * lane < L.tail_n; a1 = 2 * lane + 1 < L.tail_n;
       if (has_norms && a0) nn = norm_at(seg, d0);
       if (has_norms && a1) nn |= norm_at(seg, d1) << 8;

@@ -88,10 +88,9 @@ __global__ __launch_bounds__(WG_THREADS) void k_score_terms(SegView seg, const D
       const uint32_t nb0 = (has_norms && v0) ? norm_at(seg, T.singleton_doc) : 0u;
       emit(T.singleton_doc, 0, (uint32_t)T.singleton_freq, 1u, nb0, 0u, v0, false, 0);
     } else if (T.tail_n > 0) {
-      const uint32_t toff = T.nblocks ? seg.dir_off[T.dir_base + T.nblocks] : 0u;
       int32_t d0, d1;
       uint32_t f0, f1;
-      decode_tail(seg.doc + T.start_fp + toff, T.tail_n, base, slab, lane, d0, d1, f0, f1, seg.has_freqs != 0);
+      tail_load(term_rows, seg.dir_row[T.dir_base + T.nblocks], lane, d0, d1, f0, f1);  // decoded and validated at prepare time
       const bool v0 = 2 * lane < T.tail_n, v1 = 2 * lane + 1 < T.tail_n;
       const uint32_t nb0 = (has_norms && v0) ? norm_at(seg, d0) : 0u, nb1 = (has_norms && v1) ? norm_at(seg, d1) : 0u;
       emit(d0, d1, f0, f1, nb0, nb1, v0, v1, (dense ? 0 : 128 * (int64_t)T.nblocks) + 2 * lane);

@@ -29,13 +29,11 @@ constexpr int TERM_WAVES = RGPU_TERM_WAVES;
 constexpr int TERM_THREADS = 64 * TERM_WAVES;
 // per-wave LDS slice: [FullBlock staging slab 2 x 528 B | norm cache 64 f32 | score table 64 x 11 f32]; the slab
 // comes first so that the extraction's ds_read2_b64 offsets stay immediates. Raw-norm mode (no ranks, no table)
-// keeps its 256-entry norm cache in the last 1 KB instead. The VInt tail decoder (once per term, after the last
-// FullBlock) takes the table as its scratch, or in raw-norm mode everything before the cache.
+// keeps its 256-entry norm cache in the last 1 KB instead.
 constexpr int TERM_BLOCK_SLAB = 2 * SLAB_STREAM;
 constexpr int TERM_WAVE_LDS = TERM_BLOCK_SLAB + WAVE_CACHE_FLOATS * 4;
 constexpr int TERM_RAW_CACHE_AT = TERM_WAVE_LDS - 256 * 4;
-static_assert((WAVE_CACHE_FLOATS - 64) * 4 >= SLAB_BYTES, "tail scratch (rank mode: the score table)");
-static_assert(TERM_RAW_CACHE_AT >= SLAB_BYTES, "tail scratch (raw-norm mode: slab + unused table)");
+static_assert(TERM_RAW_CACHE_AT >= TERM_BLOCK_SLAB, "raw-norm mode: the 256-entry cache sits behind the slab");
 static_assert(TERM_WAVE_LDS % 16 == 0 && TERM_BLOCK_SLAB % 16 == 0, "16-byte aligned slices");
 __host__ __device__ constexpr size_t term_lds_bytes(bool wide) {
   return (size_t)TERM_WAVES * TERM_WAVE_LDS + (size_t)TERM_WAVES * (wide ? 128 : 64) * 8 + (size_t)TERM_WAVES * 12;
@@ -294,7 +292,6 @@ __global__ __launch_bounds__(TERM_THREADS, 8) void k_search_term(SegView seg, co
   uint8_t* slab = slice;
   const bool ranked = seg.n_norm_ranks > 0;
   float* cache = reinterpret_cast<float*>(slice + (ranked ? TERM_BLOCK_SLAB : TERM_RAW_CACHE_AT));
-  uint8_t* tail_scratch = ranked ? reinterpret_cast<uint8_t*>(cache + 64) : slice;
   uint64_t* lists = reinterpret_cast<uint64_t*>(smem + TERM_WAVES * TERM_WAVE_LDS);
   uint32_t* locks = reinterpret_cast<uint32_t*>(lists + TERM_WAVES * LIST_N);
   uint32_t* remaining = locks + TERM_WAVES;  // waves of a group that have finished, counted at the leader's slot
@@ -392,12 +389,10 @@ __global__ __launch_bounds__(TERM_THREADS, 8) void k_search_term(SegView seg, co
         const uint32_t nb0 = (has_norms && v0) ? norm_at(seg, T.singleton_doc) : 0u;
         collect(std::false_type{}, T.singleton_doc, 0, (uint32_t)T.singleton_freq, 1u, nb0, 0u, v0, false);
       } else if (T.tail_n > 0) {
-        const uint32_t toff = T.nblocks ? seg.dir_off[T.dir_base + T.nblocks] : 0u;
         int32_t d0, d1;
         uint32_t f0, f1;
-        decode_tail(seg.doc + T.start_fp + toff, T.tail_n, base, tail_scratch, lane, d0, d1, f0, f1, seg.has_freqs != 0);
-        tabled = false;  // the tail decoder's scratch overlaid the score table: score by the formula it memoises
-        const bool v0 = 2 * lane < T.tail_n && doc_in_segment(seg, d0), v1 = 2 * lane + 1 < T.tail_n && doc_in_segment(seg, d1);
+        tail_load(term_rows, seg.dir_row[T.dir_base + T.nblocks], lane, d0, d1, f0, f1);  // decoded and validated at prepare time
+        const bool v0 = 2 * lane < T.tail_n, v1 = 2 * lane + 1 < T.tail_n;
         const uint32_t nb0 = (has_norms && v0) ? seg.norms[d0] : 0u, nb1 = (has_norms && v1) ? seg.norms[d1] : 0u;
         collect(std::false_type{}, d0, d1, f0, f1, nb0, nb1, v0, v1);
       }
