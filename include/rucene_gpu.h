@@ -138,7 +138,9 @@ int32_t rgpu_segment_upload(rgpu_ctx* ctx, const uint8_t* doc_file, size_t doc_l
 /* The same for a field of the given doc::IndexOptions ordinal: 1 = Docs (no freq block follows a doc block, the VInt
  * tail holds plain deltas, every freq reads as 1 and a FREQS-less iterator's skip_block has nothing to skip:
  * posting_reader.rs:532-557, for_util.rs:263-272), 2 = DocsAndFreqs (what rgpu_segment_upload assumes).
- * Positions fields (3, 4) -> RGPU_ERR_UNSUPPORTED. For a Docs field rgpu_term_state.total_term_freq is ignored. */
+ * 3 = DocsAndFreqsAndPositions without payloads (skip entries carry position pointers; see
+ * rgpu_segment_attach_positions / rgpu_search_phrase_batch). Offsets (4) -> RGPU_ERR_UNSUPPORTED. For a Docs field
+ * rgpu_term_state.total_term_freq is ignored. */
 int32_t rgpu_segment_upload_field(rgpu_ctx* ctx, const uint8_t* doc_file, size_t doc_len, const uint8_t* norms_or_null,
                                   int32_t max_doc, int32_t doc_base, const uint64_t* live_docs_or_null, int32_t index_options,
                                   rgpu_segment** out_seg);
@@ -341,6 +343,35 @@ typedef struct rgpu_term_positions {
 } rgpu_term_positions;
 int32_t rgpu_terms_lookup_positions(const rgpu_terms* terms, int32_t field_number, const uint8_t* term_bytes, const int64_t* term_offsets,
                                     int32_t n_terms, rgpu_term_state* states_out, rgpu_term_positions* positions_out, uint8_t* found_out);
+
+/* ---- exact phrases (positions fields) ----------------------------------------------------------------------------- */
+/* The ".pos" file of a segment uploaded with index_options = 3 (Lucene50PostingsReader::open, posting_reader.rs:112-158:
+ * header "Lucene50PostingsWriterPos", the .doc file's version, segment id and suffix; footer). Needed before
+ * rgpu_search_phrase_batch; TERM / AND / OR search of a positions field works without it. */
+int32_t rgpu_segment_attach_positions(rgpu_segment* seg, const uint8_t* pos_file, size_t pos_len);
+/* One term of a phrase: its postings (BlockTermState), its position-stream pointers (rgpu_terms_lookup_positions) and
+ * its position inside the phrase (PhraseQuery::build numbers them 0, 1, 2, ...; query/phrase_query.rs:60-110). */
+typedef struct rgpu_phrase_term {
+  rgpu_term_state state;
+  rgpu_term_positions positions;
+  int32_t position;
+  int32_t reserved;
+} rgpu_phrase_term;
+/* PhraseQuery with slop 0. `weight` = idf summed over the phrase's terms x boost (PhraseQuery::create_weight,
+ * phrase_query.rs:136-186 -> rgpu_bm25_compute_weight with every term's doc_freq), `sim_table` as for rgpu_query_term. */
+typedef struct rgpu_phrase_query {
+  int32_t n_terms;     /* 2..RGPU_MAX_QUERY_TERMS (the reference turns a one-term phrase into a TermQuery) */
+  int32_t first_term;  /* index of the query's first term in `terms` */
+  float weight;
+  int32_t sim_table;
+} rgpu_phrase_query;
+/* One leaf of IndexSearcher::search(PhraseQuery, TopDocsCollector(k)): PhraseWeight::create_scorer (None when a term is
+ * absent from the leaf) -> ExactPhraseScorer (scorer/phrase_scorer.rs:122-294) — a doc matches when the terms occur at
+ * their phrase offsets, its score is BM25(phrase frequency, norm). Outputs as rgpu_search_batch; scores are bit-exact
+ * with the CPU scorer. A doc holding one of the phrase's terms more than 1024 times -> RGPU_ERR_UNSUPPORTED. */
+int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase_query* queries, int32_t n_queries,
+                                 const rgpu_phrase_term* terms, int32_t n_terms_total, int32_t k, rgpu_hit* hits_out,
+                                 int64_t* total_hits_out);
 
 /* ---- measurement ------------------------------------------------------------------------------------------ */
 typedef struct rgpu_kernel_stat {

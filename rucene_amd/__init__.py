@@ -8,4 +8,4 @@ and fails loudly otherwise.
 from ._lib import (OP_AND, OP_OR, OP_TERM, Context, RgpuError, Segment, bm25_compute_weight, bm25_encode_norm,  # noqa: F401
                    norms_from_lucene53, live_docs_from_lucene50, field_infos_from_lucene60, segment_info_from_lucene62, commit_from_segments_file, compound_files_from_lucene50, TermDictionary, lib, lib_path, QUERY_DTYPE, QUERY_TERM_DTYPE, TERM_STATE_DTYPE, HIT_DTYPE)
 from .searcher import (BM25Similarity, BooleanQuery, CollectionStatistics, GpuIndexSearcher, LeafReader,  # noqa: F401
-                       TermQuery, TopDocs, TopDocsCollector, open_directory)
+                       PhraseQuery, TermQuery, TopDocs, TopDocsCollector, open_directory)

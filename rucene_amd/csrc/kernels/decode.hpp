@@ -318,9 +318,9 @@ __device__ __forceinline__ uint32_t compose_fn(uint32_t first, uint32_t then) {
   return r0 | (r1 << 1);
 }
 
-// has_freqs == false (IndexOptions::Docs, posting_reader.rs:326-331): every value is a doc delta, every freq is 1.
-__device__ RGPU_TAIL_INLINE void decode_tail(const uint8_t* __restrict__ tail, int n, int32_t base, uint8_t* slab, int lane,
-                                            int32_t& doc0, int32_t& doc1, uint32_t& f0, uint32_t& f1, bool has_freqs = true) {
+// Stages (0) + (1) of the tail decoder: TAIL_MAX_BYTES of the stream are parsed as VInts in parallel and the first 256
+// values are left, in order, in `slab` + 1296 (u32 each; unwritten slots read 1).
+__device__ __forceinline__ uint32_t* stage_vints(const uint8_t* __restrict__ tail, uint8_t* slab, int lane) {
   uint8_t* bytes = slab;                                              // [0, 1296)
   uint32_t* vals = reinterpret_cast<uint32_t*>(slab + 1296);         // 256 values (+ 8 pad words)
   // (0) stage TAIL_MAX_BYTES: 80 x 16 B
@@ -351,6 +351,21 @@ __device__ RGPU_TAIL_INLINE void decode_tail(const uint8_t* __restrict__ tail, i
     ++vi;
   }
   wave_sync();
+  return vals;
+}
+// A block of up to 128 plain VInts (the trailing position block of a term, posting_reader.rs:1285-1324 without payloads
+// or offsets): values 2*lane, 2*lane+1, as stored.
+__device__ __forceinline__ void decode_vint_block(const uint8_t* __restrict__ src, uint8_t* slab, int lane, uint32_t& v0, uint32_t& v1) {
+  const uint32_t* vals = stage_vints(src, slab, lane);
+  v0 = vals[2 * lane];
+  v1 = vals[2 * lane + 1];
+  wave_sync();
+}
+
+// has_freqs == false (IndexOptions::Docs, posting_reader.rs:326-331): every value is a doc delta, every freq is 1.
+__device__ RGPU_TAIL_INLINE void decode_tail(const uint8_t* __restrict__ tail, int n, int32_t base, uint8_t* slab, int lane,
+                                            int32_t& doc0, int32_t& doc1, uint32_t& f0, uint32_t& f1, bool has_freqs = true) {
+  uint32_t* vals = stage_vints(tail, slab, lane);
   if (!has_freqs) {  // wave-uniform: value i is posting i's delta
     const uint32_t d0 = (2 * lane < n) ? vals[2 * lane] : 0u;
     const uint32_t d1 = (2 * lane + 1 < n) ? vals[2 * lane + 1] : 0u;

@@ -62,7 +62,7 @@ template <bool LEGACY>
 __global__ __launch_bounds__(PREP_THREADS) void k_prepare_terms(const uint8_t* __restrict__ doc, int64_t doc_len,
                                                                  const PrepTerm* __restrict__ terms, int32_t* dir_last,
                                                                  uint32_t* dir_off, uint32_t* dir_row, uint16_t* dir_hdr,
-                                                                 int has_freqs, int* err) {
+                                                                 uint64_t* dir_pos, int has_freqs, int* err) {
   const PrepTerm t = terms[blockIdx.x];
   const int tid = (int)threadIdx.x;
   __shared__ uint32_t s_ws[PREP_THREADS / 64];
@@ -83,8 +83,10 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_terms(const uint8_t* _
     __syncthreads();
     const uint8_t* l0 = doc + s_l0;
     const int64_t l0_room = doc_len - s_l0;  // bytes of the file from level 0 on (the device copy is padded by 8 KiB of zeros)
-    // ---- parallel VInt decode of 2 * n_entries values: even = docDelta (vint), odd = docFpDelta (vlong)
-    const uint32_t need = 2u * (uint32_t)t.n_entries;
+    // ---- parallel VInt decode of the level-0 entries: docDelta (vint), docFpDelta (vlong) and, for a positions field
+    // (dir_pos != null; skip_writer.rs:261-289), posFpDelta (vlong), posBufferUpto (vint)
+    const uint32_t vals = dir_pos ? 4u : 2u;
+    const uint32_t need = vals * (uint32_t)t.n_entries;
     uint32_t done = 0;
     int64_t chunk = 0;
     while (done < need) {
@@ -107,9 +109,10 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_terms(const uint8_t* _
           v = (v << 7) | (uint64_t)(l0[p] & 0x7f);
         }
         if (vi < need) {
-          const uint32_t e = vi >> 1;
-          if (vi & 1) dir_off[t.dir_base + e + 1] = (uint32_t)v;
-          else dir_last[t.dir_base + e] = (int32_t)v;
+          const uint32_t e = vi / vals, f = vi % vals;
+          if (f == 0) dir_last[t.dir_base + e] = (int32_t)v;
+          else if (f == 1) dir_off[t.dir_base + e + 1] = (uint32_t)v;
+          else reinterpret_cast<uint32_t*>(dir_pos + t.dir_base + e + 1)[f - 2] = (uint32_t)v;  // [0] posFpDelta, [1] upto
         }
         ++vi;
       }
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_terms(const uint8_t* _
     }
     __syncthreads();
     // ---- deltas -> running sums (skip_doc[0] += delta ; doc_pointer[0] += delta, skip_reader.rs:530, 434)
-    uint32_t carry_doc = 0, carry_off = 0;
+    uint32_t carry_doc = 0, carry_off = 0, carry_pos = 0;
     for (int e0 = 0; e0 < t.n_entries; e0 += PREP_THREADS) {
       const int e = e0 + tid;
       const bool ok = e < t.n_entries;
@@ -134,9 +137,18 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_terms(const uint8_t* _
       }
       carry_doc += tot_d;
       carry_off += tot_o;
+      if (dir_pos) {  // uniform: the position pointer is a running sum too, the buffered count is absolute
+        uint32_t* pp = reinterpret_cast<uint32_t*>(dir_pos + t.dir_base + e + 1);
+        const uint32_t po = ok ? pp[0] : 0u;
+        uint32_t tot_p;
+        const uint32_t sp = block_excl_scan(po, s_ws, tot_p) + po + carry_pos;
+        if (ok) { pp[0] = sp; if (pp[1] >= 128u) atomicMin(err, -4); }
+        carry_pos += tot_p;
+      }
     }
   }
   if (tid == 0) {
+    if (dir_pos) dir_pos[t.dir_base] = 0ull;
     dir_off[t.dir_base] = 0;
     if (t.nblocks > t.n_entries) dir_last[t.dir_base + t.nblocks - 1] = DIR_SENTINEL_DOC;  // df % 128 == 0
   }

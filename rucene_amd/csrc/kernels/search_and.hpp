@@ -103,7 +103,10 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
                                                            uint64_t* __restrict__ partial_keys,
                                                            int32_t* __restrict__ partial_counts,
                                                            unsigned long long* __restrict__ tau_slots,
-                                                           unsigned long long* __restrict__ touched_slots) {
+                                                           unsigned long long* __restrict__ touched_slots,
+                                                           const int64_t* __restrict__ emit_prefix,
+                                                           unsigned long long* __restrict__ emit_count,
+                                                           int32_t* __restrict__ emit_docs) {
   __shared__ __attribute__((aligned(16))) uint8_t slabs[WG_WAVES][2 * SLAB_STREAM];  // FullBlock staging only: tails arrive decoded
   __shared__ float caches[WG_WAVES][256];
   __shared__ uint32_t filters[WG_WAVES][AND_FILTER_WORDS];
@@ -325,6 +328,20 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
       }
     }
     if (HAS_OPT && in_opt) { s0 = r0 + s0; s1 = r1 + s1; }
+    if (emit_docs != nullptr) {
+      // Phrase queries (search_phrase.hpp): the conjunction's matches are not collected but handed on, every one of them,
+      // to the position check — appended to the query's candidate list in any order (the phrase kernels are order-free).
+      const uint64_t m0 = __ballot(a0), m1 = __ballot(a1);
+      const int n0c = __popcll(m0), nc = n0c + __popcll(m1);
+      if (nc) {
+        unsigned long long at = 0;
+        if (lane == 0) at = atomicAdd(emit_count + q, (unsigned long long)nc);
+        const int64_t base_at = emit_prefix[q] + (int64_t)readlane64(at, 0);
+        if (a0) emit_docs[base_at + mbcnt(m0)] = d0;
+        if (a1) emit_docs[base_at + n0c + mbcnt(m1)] = d1;
+      }
+      return;
+    }
     count += __popcll(__ballot(a0)) + __popcll(__ballot(a1));
     topk_offer<WIDE>(top, a0 ? make_key(s0, d0) : 0ull, tau, k, lane, floor);
     topk_offer<WIDE>(top, a1 ? make_key(s1, d1) : 0ull, tau, k, lane, floor);

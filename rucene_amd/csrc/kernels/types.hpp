@@ -42,6 +42,12 @@ struct SegView {
   // deltas; every freq is 1 (posting_reader.rs:532-557: the freq buffer is filled with 1). The block store then carries
   // one synthetic all-equal freq row (value 1) per block, so every block decoder works unchanged.
   int32_t has_freqs;
+  // Positions fields (IndexOptions::DocsAndFreqsAndPositions): the raw .pos bytes and, per directory slot i (block i of
+  // a term), where the position stream stands when block i starts — low word: byte offset from the term's
+  // pos_start_fp of the position block that holds the block's first position, high word: positions of EARLIER docs
+  // buffered in that block (the skip entry's posFP / posBufferUpto, skip_writer.rs:187-205; slot 0 = {0, 0}).
+  const uint8_t* pos;
+  const uint64_t* dir_pos;
 };
 
 // One term as the kernels see it (built on the host from rgpu_term_state + the directory cache).
@@ -75,6 +81,15 @@ struct PrepTerm {
   int32_t n_levels;    // 1 + floor(log8(trim(df) / 128)), capped at 10
   int32_t df;
   uint32_t bs_rows;    // rows reserved for this term in the block store
+};
+
+// One phrase clause's position-stream pointers (parallel to the DevTerm array of a phrase launch).
+struct PosTerm {
+  uint64_t pos_start_fp;       // where the term's positions start in .pos
+  int64_t last_pos_block_fp;   // absolute fp of the trailing VInt block; -1: none (total_term_freq == 128)
+  int64_t total_term_freq;
+  int32_t phrase_pos;          // the term's position inside the phrase (PhraseQuery::build: 0, 1, 2, ...)
+  int32_t pad;
 };
 
 struct DevQuery {

@@ -23,6 +23,7 @@
 #include "kernels/search.hpp"
 #include "kernels/search_and.hpp"
 #include "kernels/search_or.hpp"
+#include "kernels/search_phrase.hpp"
 #include "kernels/search_term.hpp"
 
 using namespace rgpu;
@@ -132,6 +133,9 @@ struct rgpu_ctx {
   Scratch* S = &scr[0];
   int scr_next = 0;
   DevVec<ScoredPosting> d_runs;  // OR: per-clause {doc, score} runs (one instance: OR groups end with a stream sync)
+  DevVec<int32_t> phrase_docs;             // phrase search: the conjunctions' matches (candidates), per query
+  DevVec<uint64_t> phrase_keys;            // ... and their keys (0 = phrase freq 0)
+  DevVec<unsigned long long> phrase_count;  // ... how many each query's conjunction produced
   DevVec<HitOut> host_api_hits;  // rgpu_search_batch (blocking, host outputs): device-side result rows
   DevVec<int64_t> host_api_totals;
   int* d_err = nullptr;
@@ -161,6 +165,10 @@ struct rgpu_segment {
   DevVec<uint32_t> dir_row;
   DevVec<uint16_t> dir_hdr;
   DevVec<uint64_t> dir_bmax;  // per block: (freq, norm rank) frontier word (SegView::dir_bmax)
+  bool has_positions = false;  // IndexOptions::DocsAndFreqsAndPositions: skip entries carry position pointers
+  DevVec<uint64_t> dir_pos;    // per block: position-stream state at the block's start (SegView::dir_pos)
+  uint8_t* d_pos = nullptr;    // raw .pos bytes (rgpu_segment_attach_positions)
+  size_t pos_len = 0;
   size_t dir_used = 0;
   DevVec<uint8_t> bstore;  // 16-byte aligned FullBlock payload rows of every prepared term (SegView::bstore)
   size_t bstore_used = 0;
@@ -264,6 +272,8 @@ static SegView seg_view(const rgpu_segment* s) {
   v.bstore = s->bstore.p;
   v.dir_hdr = s->dir_hdr.p;
   v.dir_bmax = s->dir_bmax.p;
+  v.pos = s->d_pos;
+  v.dir_pos = s->has_positions ? s->dir_pos.p : nullptr;
   v.sim_tables = s->ctx->sim_tables.p;
   v.max_doc = s->max_doc;
   v.doc_base = s->doc_base;
@@ -347,6 +357,7 @@ static int32_t prepare_terms_locked(rgpu_segment* seg, const rgpu_term_state* co
   HIP_TRY(seg->bstore.reserve(need_bs + 1024, seg->bstore_used, c->stream));  // + over-read padding of the row loads
   HIP_TRY(seg->dir_hdr.reserve(need_slots, seg->dir_used, c->stream));
   HIP_TRY(seg->dir_bmax.reserve(need_slots, seg->dir_used, c->stream));
+  if (seg->has_positions) HIP_TRY(seg->dir_pos.reserve(need_slots, seg->dir_used, c->stream));
   if (seg->d_norms) HIP_TRY(seg->pnorm.reserve(need_pn + 64, seg->pnorm_used, c->stream));
   // staging: the PrepTerm records + the (term, chunk of blocks) item prefix of the second launch
   std::vector<int64_t> item_prefix(work.size() + 1);
@@ -372,10 +383,12 @@ static int32_t prepare_terms_locked(rgpu_segment* seg, const rgpu_term_state* co
     TimedLaunch tl(c, c->stream, "k_prepare_terms", postings);
     if (seg->version >= 1)
       hipLaunchKernelGGL(k_prepare_terms<false>, dim3((unsigned)work.size()), dim3(PREP_THREADS), 0, c->stream, seg->d_doc,
-                         (int64_t)seg->doc_len, d_work, seg->dir_last.p, seg->dir_off.p, seg->dir_row.p, seg->dir_hdr.p, seg->has_freqs ? 1 : 0, c->d_err);
+                         (int64_t)seg->doc_len, d_work, seg->dir_last.p, seg->dir_off.p, seg->dir_row.p, seg->dir_hdr.p, seg->has_positions ? seg->dir_pos.p : nullptr,
+                         seg->has_freqs ? 1 : 0, c->d_err);
     else
       hipLaunchKernelGGL(k_prepare_terms<true>, dim3((unsigned)work.size()), dim3(PREP_THREADS), 0, c->stream, seg->d_doc,
-                         (int64_t)seg->doc_len, d_work, seg->dir_last.p, seg->dir_off.p, seg->dir_row.p, seg->dir_hdr.p, seg->has_freqs ? 1 : 0, c->d_err);
+                         (int64_t)seg->doc_len, d_work, seg->dir_last.p, seg->dir_off.p, seg->dir_row.p, seg->dir_hdr.p, seg->has_positions ? seg->dir_pos.p : nullptr,
+                         seg->has_freqs ? 1 : 0, c->d_err);
   }
   if (n_items > 0) {
     TimedLaunch tl(c, c->stream, "k_prepare_blocks", postings);
@@ -469,7 +482,7 @@ extern "C" void rgpu_shutdown(rgpu_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   drain_events(c);
   for (auto e : c->free_events) (void)hipEventDestroy(e);
-  c->sim_tables.release(); c->d_runs.release(); c->host_api_hits.release(); c->host_api_totals.release();
+  c->sim_tables.release(); c->d_runs.release(); c->phrase_docs.release(); c->phrase_keys.release(); c->phrase_count.release(); c->host_api_hits.release(); c->host_api_totals.release();
   for (auto& sc : c->scr) sc.release();
   if (c->d_err) (void)hipFree(c->d_err);
   (void)hipStreamDestroy(c->stream);
@@ -570,9 +583,9 @@ extern "C" int32_t rgpu_segment_upload_field(rgpu_ctx* c, const uint8_t* doc_fil
                                              rgpu_segment** out_seg) {
   if (!c || !doc_file || !out_seg) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "bad arguments");
   *out_seg = nullptr;
-  if (index_options != 1 && index_options != 2)
-    return fail(index_options >= 3 && index_options <= 4 ? RGPU_ERR_UNSUPPORTED : RGPU_ERR_ILLEGAL_ARGUMENT,
-                "index_options must be 1 (Docs) or 2 (DocsAndFreqs): a positions field's skip entries carry extra pointers");
+  if (index_options < 1 || index_options > 3)
+    return fail(index_options == 4 ? RGPU_ERR_UNSUPPORTED : RGPU_ERR_ILLEGAL_ARGUMENT,
+                "index_options must be 1 (Docs), 2 (DocsAndFreqs) or 3 (DocsAndFreqsAndPositions); offsets / payloads are not supported");
   if (max_doc < 0) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "negative max_doc");
   rucene::DocFileInfo info;
   std::string why;
@@ -587,6 +600,7 @@ extern "C" int32_t rgpu_segment_upload_field(rgpu_ctx* c, const uint8_t* doc_fil
   s->doc_base = doc_base;
   s->version = info.version;
   s->has_freqs = index_options >= 2;
+  s->has_positions = index_options >= 3;
   const size_t pad = 8192;  // speculative row / tail loads may run past the last posting byte
   auto bail = [&](hipError_t e, const char* what) { rgpu_segment_free(s); return fail(RGPU_ERR_RUNTIME, std::string(what) + ": " + hipGetErrorString(e)); };
   hipError_t e;
@@ -629,7 +643,8 @@ extern "C" void rgpu_segment_free(rgpu_segment* s) {
   if (s->d_norms) (void)hipFree(s->d_norms);
   if (s->d_rank_to_norm) (void)hipFree(s->d_rank_to_norm);
   if (s->d_live) (void)hipFree(s->d_live);
-  s->dir_last.release(); s->dir_off.release(); s->dir_row.release(); s->dir_hdr.release(); s->dir_bmax.release(); s->pnorm.release(); s->bstore.release();
+  if (s->d_pos) (void)hipFree(s->d_pos);
+  s->dir_last.release(); s->dir_off.release(); s->dir_row.release(); s->dir_hdr.release(); s->dir_bmax.release(); s->dir_pos.release(); s->pnorm.release(); s->bstore.release();
   delete s;
 }
 
@@ -1103,7 +1118,8 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
       const unsigned grid = (unsigned)((items + WG_WAVES - 1) / WG_WAVES);
       auto go = [&](auto kern) {
         hipLaunchKernelGGL(kern, dim3(grid), dim3(WG_THREADS), 0, stream, sv, dq, dt, dp, nq, items, blocks_per_item, (int)k,
-                           c->S->d_partial_keys.p, c->S->d_partial_counts.p, c->S->d_tau.p, c->S->d_touched.p);
+                           c->S->d_partial_keys.p, c->S->d_partial_counts.p, c->S->d_tau.p, c->S->d_touched.p,
+                           (const int64_t*)nullptr, (unsigned long long*)nullptr, (int32_t*)nullptr);
       };
       bool has_not = false, has_opt = false;
       for (const DevQuery& q : G.queries) { has_not = has_not || q.pad != 0; has_opt = has_opt || (q.op >> 16) != 0; }
@@ -1200,6 +1216,179 @@ extern "C" int32_t rgpu_merge_topk_device(rgpu_ctx* c, const void* hits_dev, con
   }
   HIP_TRY(hipGetLastError());
   return RGPU_OK;  // enqueue only, like rgpu_search_batch_device
+}
+
+// ---- exact phrases -----------------------------------------------------------------------------------------------------------
+extern "C" int32_t rgpu_segment_attach_positions(rgpu_segment* seg, const uint8_t* pos_file, size_t pos_len) {
+  if (!seg || !pos_file) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "bad arguments");
+  if (!seg->has_positions) return fail(RGPU_ERR_ILLEGAL_STATE, "the segment was not uploaded as a positions field (index_options 3)");
+  rgpu_ctx* c = seg->ctx;
+  std::lock_guard<std::mutex> g(c->mu);
+  HIP_TRY(hipSetDevice(c->device));
+  std::vector<uint8_t> head(128);
+  const size_t head_n = std::min(seg->doc_len, head.size());
+  HIP_TRY(hipMemcpy(head.data(), seg->d_doc, head_n, hipMemcpyDeviceToHost));  // the .doc header: id + suffix to compare with
+  int64_t start = 0;
+  std::string why;
+  const int rc = rucene::parse_pos_file(pos_file, pos_len, head.data(), seg->version, &start, &why);
+  if (rc != 0) return fail(rc, why);
+  if (seg->d_pos) { HIP_TRY(hipDeviceSynchronize()); (void)hipFree(seg->d_pos); seg->d_pos = nullptr; }
+  const size_t pad = 8192;  // speculative row / VInt-block loads may run past the last position byte
+  HIP_TRY(hipMalloc(&seg->d_pos, pos_len + pad));
+  HIP_TRY(hipMemcpy(seg->d_pos, pos_file, pos_len, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemset(seg->d_pos + pos_len, 0, pad));
+  seg->pos_len = pos_len;
+  return RGPU_OK;
+}
+
+extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase_query* queries, int32_t n_queries,
+                                            const rgpu_phrase_term* terms, int32_t n_terms_total, int32_t k, rgpu_hit* hits_out,
+                                            int64_t* total_hits_out) {
+  if (!seg || !queries || n_queries <= 0 || !terms || n_terms_total <= 0 || !hits_out || !total_hits_out)
+    return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "bad arguments");
+  if (k <= 0 || k > RGPU_MAX_K) return fail(k <= 0 ? RGPU_ERR_ILLEGAL_ARGUMENT : RGPU_ERR_UNSUPPORTED, "k must be in 1..RGPU_MAX_K");
+  if (!seg->has_positions || !seg->d_pos) return fail(RGPU_ERR_ILLEGAL_STATE, "phrase search needs a positions field with its .pos file attached");
+  rgpu_ctx* c = seg->ctx;
+  std::lock_guard<std::mutex> g(c->mu);
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t stream = c->stream;
+  // ---- validate, resolve, plan
+  std::vector<const rgpu_term_state*> ptrs;
+  for (int32_t q = 0; q < n_queries; ++q) {
+    const rgpu_phrase_query& Q = queries[q];
+    if (Q.n_terms < 2 || Q.n_terms > RGPU_MAX_QUERY_TERMS) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "a phrase has 2..RGPU_MAX_QUERY_TERMS terms");
+    if (Q.first_term < 0 || (int64_t)Q.first_term + Q.n_terms > (int64_t)n_terms_total) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "term range outside terms[]");
+    if (Q.sim_table < 0 || Q.sim_table >= c->n_sim_tables) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "unknown sim_table handle");
+    for (int i = 0; i < Q.n_terms; ++i) {
+      const rgpu_phrase_term& t = terms[Q.first_term + i];
+      if (t.state.doc_freq > 0) {
+        if (t.positions.pos_start_fp < 0 || (size_t)t.positions.pos_start_fp >= seg->pos_len) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "pos_start_fp outside the .pos file");
+        if (t.state.total_term_freq < t.state.doc_freq) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "total_term_freq below doc_freq");
+        ptrs.push_back(&t.state);
+      }
+    }
+  }
+  int32_t rc = prepare_terms_locked(seg, ptrs.data(), ptrs.size());
+  if (rc != RGPU_OK) return rc;
+  std::vector<DevQuery> dq((size_t)n_queries);
+  std::vector<DevTerm> dt;
+  std::vector<PosTerm> pt;
+  std::vector<int64_t> item_prefix((size_t)n_queries + 1), emit_prefix((size_t)n_queries + 1);
+  const int blocks_per_item = c->cfg.and_blocks_per_item;
+  int64_t items = 0, slots = 0;
+  for (int32_t q = 0; q < n_queries; ++q) {
+    const rgpu_phrase_query& Q = queries[q];
+    item_prefix[(size_t)q] = items;
+    emit_prefix[(size_t)q] = slots;
+    dq[(size_t)q] = DevQuery{RGPU_OP_AND, 0, (int32_t)dt.size(), 0};
+    bool dead = false;
+    for (int i = 0; i < Q.n_terms; ++i) dead = dead || terms[Q.first_term + i].state.doc_freq <= 0;
+    if (dead) continue;  // PhraseWeight::create_scorer -> None (phrase_query.rs:275-283)
+    std::vector<int> order((size_t)Q.n_terms);
+    for (int i = 0; i < Q.n_terms; ++i) order[(size_t)i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return terms[Q.first_term + a].state.doc_freq < terms[Q.first_term + b].state.doc_freq; });
+    for (int i : order) {  // the conjunction is driven by the rarest term (conjunction_scorer.rs:30)
+      const rgpu_phrase_term& t = terms[Q.first_term + i];
+      DevTerm d;
+      rc = make_dev_term(seg, t.state, Q.weight, Q.sim_table, &d);
+      if (rc != RGPU_OK) return rc;
+      dt.push_back(d);
+      PosTerm p{};
+      p.pos_start_fp = (uint64_t)t.positions.pos_start_fp;
+      p.total_term_freq = t.state.total_term_freq;
+      // posting_reader.rs:1195-1203: fewer than 128 positions -> all VInts; exactly 128 -> one packed block, no trailing one
+      p.last_pos_block_fp = t.state.total_term_freq < 128 ? t.positions.pos_start_fp
+                            : (t.state.total_term_freq == 128 ? -1 : t.positions.pos_start_fp + t.positions.last_pos_block_offset);
+      p.phrase_pos = t.position;
+      pt.push_back(p);
+    }
+    dq[(size_t)q].n_terms = Q.n_terms;
+    const DevTerm& lead = dt[(size_t)dq[(size_t)q].first_term];
+    items += lead.nblocks == 0 ? 1 : (lead.nblocks + blocks_per_item - 1) / blocks_per_item;
+    slots += lead.df;
+  }
+  item_prefix[(size_t)n_queries] = items;
+  emit_prefix[(size_t)n_queries] = slots;
+  HIP_TRY(c->host_api_hits.reserve((size_t)n_queries * (size_t)k, 0, stream));
+  HIP_TRY(c->host_api_totals.reserve((size_t)n_queries, 0, stream));
+  HIP_TRY(hipMemsetAsync(c->host_api_totals.p, 0, (size_t)n_queries * 8, stream));
+  hipLaunchKernelGGL(k_init_hits, dim3((unsigned)(((size_t)n_queries * k + 255) / 256)), dim3(256), 0, stream, c->host_api_hits.p, (int64_t)n_queries * k);
+  if (items > 0) {
+    HIP_TRY(scratch_take(c));
+    Stager st(c);
+    const size_t o_q = st.add((size_t)n_queries * sizeof(DevQuery));
+    const size_t o_t = st.add(dt.size() * sizeof(DevTerm));
+    const size_t o_pt = st.add(pt.size() * sizeof(PosTerm));
+    const size_t o_ip = st.add((size_t)(n_queries + 1) * 8);
+    const size_t o_ep = st.add((size_t)(n_queries + 1) * 8);
+    HIP_TRY(c->S->h_stage.reserve(st.used));
+    HIP_TRY(c->S->d_stage.reserve(st.used, 0, stream));
+    std::memcpy(c->S->h_stage.p + o_q, dq.data(), (size_t)n_queries * sizeof(DevQuery));
+    std::memcpy(c->S->h_stage.p + o_t, dt.data(), dt.size() * sizeof(DevTerm));
+    std::memcpy(c->S->h_stage.p + o_pt, pt.data(), pt.size() * sizeof(PosTerm));
+    std::memcpy(c->S->h_stage.p + o_ip, item_prefix.data(), (size_t)(n_queries + 1) * 8);
+    std::memcpy(c->S->h_stage.p + o_ep, emit_prefix.data(), (size_t)(n_queries + 1) * 8);
+    HIP_TRY(hipMemcpyAsync(c->S->d_stage.p, c->S->h_stage.p, st.used, hipMemcpyHostToDevice, stream));
+    HIP_TRY(c->phrase_docs.reserve((size_t)slots + 64, 0, stream));
+    HIP_TRY(c->phrase_keys.reserve((size_t)slots + 64, 0, stream));
+    HIP_TRY(c->phrase_count.reserve((size_t)n_queries, 0, stream));
+    HIP_TRY(hipMemsetAsync(c->phrase_count.p, 0, (size_t)n_queries * 8, stream));
+    HIP_TRY(c->S->d_partial_keys.reserve((size_t)items * (size_t)k, 0, stream));
+    HIP_TRY(c->S->d_partial_counts.reserve((size_t)items, 0, stream));
+    HIP_TRY(c->S->d_tau.reserve((size_t)n_queries, 0, stream));
+    HIP_TRY(c->S->d_touched.reserve((size_t)n_queries, 0, stream));
+    HIP_TRY(hipMemsetAsync(c->S->d_tau.p, 0, (size_t)n_queries * 8, stream));
+    HIP_TRY(hipMemsetAsync(c->S->d_touched.p, 0, (size_t)n_queries * 8, stream));
+    HIP_TRY(hipMemsetAsync(c->d_err, 0, sizeof(int), stream));
+    const DevQuery* d_q = reinterpret_cast<const DevQuery*>(c->S->d_stage.p + o_q);
+    const DevTerm* d_t = reinterpret_cast<const DevTerm*>(c->S->d_stage.p + o_t);
+    const PosTerm* d_pt = reinterpret_cast<const PosTerm*>(c->S->d_stage.p + o_pt);
+    const int64_t* d_ip = reinterpret_cast<const int64_t*>(c->S->d_stage.p + o_ip);
+    const int64_t* d_ep = reinterpret_cast<const int64_t*>(c->S->d_stage.p + o_ep);
+    const SegView sv = seg_view(seg);
+    const bool legacy = seg->version < 1;
+    {
+      TimedLaunch tl(c, stream, "k_search_and(phrase candidates)", 0);
+      const unsigned grid = (unsigned)((items + WG_WAVES - 1) / WG_WAVES);
+      auto go = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(WG_THREADS), 0, stream, sv, d_q, d_t, d_ip, (int)n_queries, items, blocks_per_item, (int)k,
+                           c->S->d_partial_keys.p, c->S->d_partial_counts.p, c->S->d_tau.p, c->S->d_touched.p, d_ep, c->phrase_count.p,
+                           c->phrase_docs.p);
+      };
+      if (legacy) go(k_search_and<true, false, false, false>); else go(k_search_and<false, false, false, false>);
+    }
+    if (slots > 0) {
+      TimedLaunch tl(c, stream, "k_phrase_match", 0);
+      const unsigned grid = (unsigned)((slots + WG_WAVES - 1) / WG_WAVES);
+      if (legacy)
+        hipLaunchKernelGGL(k_phrase_match<true>, dim3(grid), dim3(WG_THREADS), 0, stream, sv, d_q, d_t, d_pt, d_ep, c->phrase_count.p,
+                           c->phrase_docs.p, (int)n_queries, slots, (int64_t)seg->pos_len, c->phrase_keys.p, c->d_err);
+      else
+        hipLaunchKernelGGL(k_phrase_match<false>, dim3(grid), dim3(WG_THREADS), 0, stream, sv, d_q, d_t, d_pt, d_ep, c->phrase_count.p,
+                           c->phrase_docs.p, (int)n_queries, slots, (int64_t)seg->pos_len, c->phrase_keys.p, c->d_err);
+    }
+    {
+      TimedLaunch tl(c, stream, "k_phrase_collect", 0);
+      const unsigned grid = (unsigned)((n_queries + WG_WAVES - 1) / WG_WAVES);
+      if (k > 64)
+        hipLaunchKernelGGL(k_phrase_collect<true>, dim3(grid), dim3(WG_THREADS), 0, stream, d_ep, c->phrase_count.p, c->phrase_keys.p, (int)n_queries,
+                           (int)k, seg->doc_base, c->host_api_hits.p, c->host_api_totals.p);
+      else
+        hipLaunchKernelGGL(k_phrase_collect<false>, dim3(grid), dim3(WG_THREADS), 0, stream, d_ep, c->phrase_count.p, c->phrase_keys.p, (int)n_queries,
+                           (int)k, seg->doc_base, c->host_api_hits.p, c->host_api_totals.p);
+    }
+    HIP_TRY(hipGetLastError());
+  }
+  int err = 0;
+  hipError_t e0 = items > 0 ? hipMemcpyAsync(&err, c->d_err, sizeof(int), hipMemcpyDeviceToHost, stream) : hipSuccess;
+  hipError_t e1 = hipMemcpyAsync(hits_out, c->host_api_hits.p, (size_t)n_queries * (size_t)k * sizeof(HitOut), hipMemcpyDeviceToHost, stream);
+  hipError_t e2 = hipMemcpyAsync(total_hits_out, c->host_api_totals.p, (size_t)n_queries * 8, hipMemcpyDeviceToHost, stream);
+  hipError_t e3 = hipStreamSynchronize(stream);
+  if (e0 != hipSuccess || e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return fail(RGPU_ERR_RUNTIME, "device to host copy failed");
+  if (err != 0)
+    return fail(err, err == RGPU_ERR_UNSUPPORTED ? "a doc holds one of the phrase's terms more than 1024 times"
+                                                 : (err == RGPU_ERR_ILLEGAL_STATE ? "internal: a conjunction match was not found again" : "corrupt position data in .pos"));
+  return RGPU_OK;
 }
 
 // ---- segment-sharded search: RCCL all-gather of per-shard top-k + device merge -------------------------------------------

@@ -67,7 +67,9 @@ class LeafReader:
         self.doc_count = int(max_doc if doc_count is None else doc_count)
         self.sum_total_term_freq, self.sum_doc_freq, self.field = int(sum_total_term_freq), int(sum_doc_freq), field
         self.term_dictionary, self.field_number = term_dictionary, int(field_number)
-        self.index_options = int(index_options)  # doc::IndexOptions ordinal of the searched field: 1 Docs, 2 DocsAndFreqs
+        self.index_options = int(index_options)  # doc::IndexOptions ordinal: 1 Docs, 2 DocsAndFreqs, 3 DocsAndFreqsAndPositions
+        self.pos_bytes = None      # the ".pos" file of a positions field
+        self.term_positions = None  # per flat term id: TERM_POSITIONS_DTYPE records (synthetic segments)
         self._resolved = {}  # term bytes -> state or None
         self.segment = None  # rgpu_segment, created by the searcher
 
@@ -75,6 +77,29 @@ class LeafReader:
     def from_synthetic(cls, seg, doc_base=None):
         return cls(seg.doc_bytes, seg.norms, seg.max_doc, seg.terms, seg.doc_base if doc_base is None else doc_base,
                    seg.live_docs, seg.doc_count, seg.sum_total_term_freq, seg.sum_doc_freq)
+
+    @classmethod
+    def from_synthetic_positions(cls, seg, doc_base=None):
+        """A synthetic DocsAndFreqsAndPositions field (indexgen.build_explicit_positions): .doc + .pos + per-term pointers."""
+        leaf = cls(seg.doc_bytes, seg.norms, seg.max_doc, seg.terms, seg.doc_base if doc_base is None else doc_base,
+                   seg.live_docs, seg.doc_count, seg.sum_total_term_freq, seg.sum_doc_freq, index_options=_lib.INDEX_OPTIONS_POSITIONS)
+        leaf.pos_bytes = seg.pos_bytes
+        tp = np.zeros(seg.terms.size, dtype=_lib.TERM_POSITIONS_DTYPE)
+        tp["pos_start_fp"], tp["last_pos_block_offset"] = seg.pos_start_fp, seg.last_pos_block_offset
+        leaf.term_positions = tp
+        return leaf
+
+    def positions_state(self, term):
+        """The position-stream pointers of BlockTermState for `term` (None when the term is absent)."""
+        if isinstance(term, bytes):
+            if self.term_dictionary is None:
+                raise RgpuError(-2, "this leaf has no term dictionary: query it by term id")
+            states, pos, found = self.term_dictionary.lookup_positions(self.field_number, [term])
+            return (states[0], pos[0]) if found[0] else None
+        st = self.term_state(term)
+        if st is None or self.term_positions is None:
+            return None
+        return st, self.term_positions[term]
 
     @classmethod
     def from_index_files(cls, doc, tim, tip, nvm, nvd, max_doc, field_number=0, index_options=2, liv=None, del_count=-1,
@@ -93,8 +118,8 @@ class LeafReader:
             field_number, index_options = mine[0]["number"], mine[0]["index_options"]
             other_fields = [(fi["number"], fi["index_options"], int(fi["has_payloads"])) for fi in infos
                             if fi["index_options"] != 0 and fi["name"] != field]
-        if index_options not in (_lib.INDEX_OPTIONS_DOCS, _lib.INDEX_OPTIONS_DOCS_AND_FREQS):
-            raise RgpuError(-5, "the searched field must be indexed with IndexOptions::Docs or ::DocsAndFreqs")
+        if index_options not in (_lib.INDEX_OPTIONS_DOCS, _lib.INDEX_OPTIONS_DOCS_AND_FREQS, _lib.INDEX_OPTIONS_POSITIONS):
+            raise RgpuError(-5, "the searched field must be indexed with IndexOptions::Docs, ::DocsAndFreqs or ::DocsAndFreqsAndPositions")
         td = _lib.TermDictionary(tim, tip, [(field_number, index_options)] + list(other_fields), max_doc)
         stats = td.field_stats(field_number)
         if stats is None:
@@ -195,6 +220,19 @@ class TermQuery:
 
     def __str__(self):
         return "TermQuery(field: body, term: %r, boost: %s)" % (self.term, self.boost)
+
+
+class PhraseQuery:
+    """PhraseQuery::build (query/phrase_query.rs:60-110) with slop 0: terms at positions 0, 1, 2, ... (or `positions`)."""
+
+    def __init__(self, terms, positions=None, boost=1.0):
+        self.terms = [bytes(t) if isinstance(t, (bytes, bytearray, memoryview)) else int(t) for t in terms]
+        self.positions = list(range(len(self.terms))) if positions is None else [int(p) for p in positions]
+        self.boost = float(boost)
+        if len(self.terms) < 2:
+            raise RgpuError(-2, "PhraseWeight does not support less than 2 terms, call rewrite first")
+        if len(self.positions) != len(self.terms):
+            raise RgpuError(-2, "Must have as many terms as positions")
 
 
 class BooleanQuery:
@@ -340,6 +378,35 @@ class GpuIndexSearcher:
                 ts[pos]["sim_table"] = table
                 pos += 1
         return qs, ts
+
+    def search_phrase_batch(self, queries, k):
+        """IndexSearcher::search(PhraseQuery, TopDocsCollector(k)) for a batch of exact phrases -> (hits, total_hits).
+        PhraseQuery::create_weight (phrase_query.rs:136-186): one BM25 weight from the statistics of ALL the phrase's terms."""
+        per_leaf = []
+        for leaf in self.leaves:
+            if leaf.pos_bytes is None:
+                raise RgpuError(-1, "phrase search needs a positions field (LeafReader.pos_bytes)")
+            if not getattr(leaf, "_pos_attached", False):
+                leaf.segment.attach_positions(leaf.pos_bytes)
+                leaf._pos_attached = True
+            qs = np.zeros(len(queries), dtype=_lib.PHRASE_QUERY_DTYPE)
+            ts = np.zeros(sum(len(q.terms) for q in queries), dtype=_lib.PHRASE_TERM_DTYPE)
+            at = 0
+            for i, q in enumerate(queries):
+                w, cache = self.similarity.compute_weight(self.collection_statistics, [self.term_statistics(t) for t in q.terms], q.boost)
+                qs[i] = (len(q.terms), at, w, self.ctx.sim_table(cache, self.similarity.k1))
+                for t, p in zip(q.terms, q.positions):
+                    sp = leaf.positions_state(t)
+                    if sp is not None:
+                        ts[at]["state"], ts[at]["positions"] = sp
+                    else:
+                        ts[at]["state"]["doc_freq"] = 0
+                    ts[at]["position"] = p
+                    at += 1
+            per_leaf.append(leaf.segment.search_phrase_batch(qs, ts, k))
+        if len(per_leaf) == 1:
+            return per_leaf[0]
+        return self._merge_leaves(per_leaf, len(queries), k)
 
     def search_batch(self, queries, k):
         """-> (hits[n][k] structured {doc, score}, total_hits[n]) merged over all leaves."""

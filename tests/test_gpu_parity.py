@@ -818,3 +818,58 @@ def test_corrupt_doc_files_fail_safely(ctx, oracle):
     leaf.segment.release_prepared_terms()
     hits2, totals2 = rucene_amd.GpuIndexSearcher([leaf], ctx=ctx).search_batch(queries[:n], 10)
     assert (totals2 == totals).all() and (hits2["doc"] == hits["doc"]).all()
+
+
+@pytest.mark.parametrize("version,max_doc", [(1, 6000), (0, 6000), (1, 90_000)], ids=["bp128", "legacy", "bp128-4-skip-levels"])
+def test_exact_phrases(ctx, oracle, version, max_doc):
+    """PhraseQuery (slop 0) on the GPU — conjunction candidates, position decode from the .pos blocks (packed
+    blocks, the trailing VInt block, positions buffered across doc-block boundaries through the skip entries' position
+    pointers), phrase frequency and BM25(phrase freq) — against the oracle's PhraseWeight + ExactPhraseScorer over files
+    written by the restated Lucene50PostingsWriter: doc ids, scores (bit-exact) and hit counts."""
+    import rucene_amd
+    from rucene_amd import _lib as gpu
+    rng = np.random.default_rng(21 + version)
+    vocab = 12
+    docs = [rng.integers(0, vocab, size=int(rng.integers(1, 60))).tolist() if rng.random() < 0.9 else [] for _ in range(max_doc)]
+    postings = [[] for _ in range(vocab + 3)]
+    for d, toks in enumerate(docs):
+        where = {}
+        for p, t in enumerate(toks):
+            where.setdefault(t, []).append(p)
+        for t, ps in where.items():
+            postings[t].append((d, ps))
+    postings[vocab] = [(17, [3, 4, 900])]                                 # a singleton
+    postings[vocab + 1] = [(d, [0]) for d in range(5, 5 + 3 * 100, 3)]     # a short list (VInt tail only), 100 positions in all
+    ix = oracle.PositionsIndex(max_doc, postings, version=version)      # postings[vocab + 2] never occurs
+    doc_bytes, pos_bytes = ix.files()
+    n = len(postings)
+    terms = np.zeros(n, dtype=gpu.TERM_STATE_DTYPE)
+    tpos = np.zeros(n, dtype=gpu.TERM_POSITIONS_DTYPE)
+    for t in range(n):
+        st = ix.term_state(t)
+        terms[t] = (st["doc_start_fp"], st["skip_offset"], st["total_term_freq"], st["doc_freq"], st["singleton_doc_id"])
+        tpos[t]["pos_start_fp"], tpos[t]["last_pos_block_offset"] = st["pos_start_fp"], st["last_pos_block_offset"]
+    norms = rng.integers(95, 125, size=max_doc).astype(np.uint8)
+    doc_count = sum(1 for toks in docs if toks)
+    sum_ttf = sum(len(toks) for toks in docs)
+    leaf = rucene_amd.LeafReader(np.frombuffer(doc_bytes, np.uint8), norms, max_doc, terms, doc_count=doc_count, sum_total_term_freq=sum_ttf,
+                                 index_options=3)
+    leaf.pos_bytes, leaf.term_positions = np.frombuffer(pos_bytes, np.uint8), tpos
+    searcher = rucene_amd.GpuIndexSearcher([leaf], ctx=ctx)
+    phrases = [[0, 1], [1, 0], [3, 3], [2, 2, 2], [4, 5, 6], [7, 7, 8, 7], [0, 1, 2, 3], [9, 10, 11, 0, 1], [5, vocab + 2], [vocab + 2, 5],
+               [vocab, 3], [vocab + 1, 0], [0, vocab + 1]]
+    phrases += [rng.integers(0, vocab, size=int(rng.integers(2, 5))).tolist() for _ in range(30)]
+    gapped = [([0, 1], [0, 2]), ([3, 4, 5], [0, 1, 3]), ([2, 2], [0, 5])]
+    queries = [rucene_amd.PhraseQuery(p) for p in phrases] + [rucene_amd.PhraseQuery(t, o) for t, o in gapped]
+    for k in (10, 100):
+        hits, totals = searcher.search_phrase_batch(queries, k)
+        for i, q in enumerate(queries):
+            d, s, total = ix.phrase_search(q.terms, k, norms, max_doc, doc_count, sum_ttf, offsets=q.positions)
+            assert totals[i] == total, (i, q.terms, totals[i], total)
+            assert (hits[i]["doc"][:d.size] == d).all() and (hits[i]["doc"][d.size:] == -1).all(), (i, q.terms)
+            assert (hits[i]["score"][:d.size].view(np.int32) == s.view(np.int32)).all(), (i, q.terms)
+    # the same field answers plain term / boolean queries (its .doc skip entries carry position pointers)
+    T, B = rucene_amd.TermQuery, rucene_amd.BooleanQuery
+    hits, totals = searcher.search_batch([T(0), B.build([T(1), T(2)], []), B.build([], [T(3), T(vocab + 1)])], 10)
+    assert totals[0] == len(postings[0]) and totals[1] == len(set(d for d, _ in postings[1]) & set(d for d, _ in postings[2]))
+    assert totals[2] == len(set(d for d, _ in postings[3]) | set(d for d, _ in postings[vocab + 1]))
