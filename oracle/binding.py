@@ -29,7 +29,7 @@ def build(force=False):
     if force or not os.path.exists(_LIB_PATH) or any(
             os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
             for f in ("oracle_capi.cpp", "store.hpp", "packed.hpp", "postings.hpp", "search.hpp", "norms.hpp", "fst.hpp",
-                      "blocktree.hpp", "field_infos.hpp", "segment_infos.hpp", "positions.hpp", "phrase.hpp", "compound.hpp")):
+                      "blocktree.hpp", "field_infos.hpp", "segment_infos.hpp", "positions.hpp", "phrase.hpp", "compound.hpp", "elias_fano.hpp")):
         subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
@@ -95,6 +95,11 @@ def _declare(L):
         "orc_segment_free": (None, [vp]),
         "orc_segment_version": (C.c_int, [vp]),
         "orc_segment_set_index_has_freq": (None, [vp, C.c_int]),
+        "orc_writer_set_ef": (None, [vp, C.c_int, C.c_int]),
+        "orc_ef_num_longs_for_bits": (C.c_int64, [C.c_int64]),
+        "orc_ef_pack_value": (None, [C.c_int64, C.POINTER(C.c_int64), C.c_int, C.c_int32, C.c_int64]),
+        "orc_ef_encode_upper": (C.c_int64, [C.c_int64, C.c_int64, C.POINTER(C.c_int64), C.c_int]),
+        "orc_ef_roundtrip": (C.c_int64, [C.POINTER(C.c_int64), C.c_int64, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
         "orc_postings_new": (vp, [vp, vp, C.c_int]),
         "orc_postings_free": (None, [vp]),
         "orc_postings_next": (C.c_int, [vp, i32p]),
@@ -236,11 +241,13 @@ def format_fastest(value_count, bpv, ratio=0.0):
 class Writer:
     """Line-faithful Lucene50PostingsWriter (docs+freqs). write_term(docs, freqs) -> term-state record."""
 
-    def __init__(self, max_doc, version=1, write_freqs=True, segment_id=None, suffix="Lucene50_0"):
+    def __init__(self, max_doc, version=1, write_freqs=True, segment_id=None, suffix="Lucene50_0", use_ef=False, with_pf=True):
         sid = np.frombuffer(segment_id or bytes(range(16)), dtype=np.uint8).copy()
         self._h = lib().orc_writer_new(max_doc, version, int(write_freqs), _p(sid, C.c_uint8), suffix.encode())
         if not self._h:
             raise OracleError(lib().orc_last_error().decode())
+        if use_ef:  # EfWriterMeta.use_ef: Elias-Fano / bitset doc blocks where they are smaller (never on in Rucene itself)
+            lib().orc_writer_set_ef(self._h, 1, int(with_pf))
         self.write_freqs = write_freqs
 
     def write_term(self, docs, freqs):

@@ -116,7 +116,42 @@ orc_writer* orc_writer_new(int32_t max_doc, int32_t version, int write_freqs, co
   try { return new orc_writer{PostingsWriter(max_doc, version, write_freqs != 0, segment_id16, suffix ? suffix : "")}; }
   catch (const std::exception& e) { g_err = e.what(); return nullptr; }
 }
+// switch the (never used by Rucene) EF / BITSET doc-block encodings on: posting_writer.rs:33-56 EfWriterMeta
+void orc_writer_set_ef(orc_writer* w, int use_ef, int with_pf) { w->w.ef_writer_meta.use_ef = use_ef != 0; w->w.ef_writer_meta.with_pf = with_pf != 0; }
 void orc_writer_free(orc_writer* w) { delete w; }
+
+// ---- Elias-Fano known answers (elias_fano_encoder.rs:397-447) -------------------------------------------------------------
+int64_t orc_ef_num_longs_for_bits(int64_t n) { return EliasFanoEncoder::num_longs_for_bits(n); }
+void orc_ef_pack_value(int64_t value, int64_t* longs, int n_longs, int32_t num_bits, int64_t pack_index) {
+  std::vector<int64_t> v(longs, longs + n_longs);
+  EliasFanoEncoder::pack_value(value, v, num_bits, pack_index);
+  for (int i = 0; i < n_longs; i++) longs[i] = v[(size_t)i];
+}
+// new(num_values, upper_bound, 256) then encode_upper_bits(h) / num_encoded += 1 for each h: returns upper_longs[0]
+int64_t orc_ef_encode_upper(int64_t num_values, int64_t upper_bound, const int64_t* highs, int n) {
+  EliasFanoEncoder ef(num_values, upper_bound, 256);
+  for (int i = 0; i < n; i++) { ef.encode_upper_bits(highs[i]); ef.num_encoded += 1; }
+  return ef.upper_longs[0];
+}
+// encode -> serialize -> (skip type byte) deserialize2 -> next_value to exhaustion; returns the number of values read back
+int64_t orc_ef_roundtrip(const int64_t* values, int64_t n, int64_t upper_bound, int64_t* out, int32_t* num_low_bits, int32_t* encode_size) {
+  ORC_TRY
+  EliasFanoEncoder enc(n, upper_bound);
+  for (int64_t i = 0; i < n; i++) enc.encode_next(values[i]);
+  ByteOut bytes;
+  enc.serialize(bytes);
+  ByteIn in(bytes.buf.data(), (int64_t)bytes.buf.size());
+  if (in.read_byte() != 0x40) throw OracleError(E_CORRUPT_INDEX, "EF type byte");
+  EliasFanoEncoder back(n, in.read_vlong());
+  back.deserialize2(in);
+  EliasFanoDecoder dec(&back);
+  int64_t got = 0;
+  for (int64_t v = dec.next_value(); v != EF_NO_MORE_VALUES; v = dec.next_value()) out[got++] = v;
+  *num_low_bits = enc.num_low_bits;
+  *encode_size = enc.encode_size();
+  return got;
+  ORC_CATCH
+}
 int orc_writer_start_term(orc_writer* w) { ORC_TRY w->w.start_term(); return 0; ORC_CATCH }
 // start_doc + finish_doc for a batch of postings of the current term
 int orc_writer_add_docs(orc_writer* w, const int32_t* docs, const int32_t* freqs, int64_t n) {

@@ -25,6 +25,7 @@
 #include <memory>
 #include <vector>
 
+#include "elias_fano.hpp"
 #include "packed.hpp"
 #include "store.hpp"
 
@@ -56,6 +57,13 @@ struct BlockTermState {
   int32_t singleton_doc_id = -1;
 };
 static_assert(sizeof(BlockTermState) == 32, "BlockTermState must match rgpu_term_state");
+
+// posting_writer.rs:33-56
+struct EfWriterMeta {
+  int32_t ef_base_doc = -1, ef_upper_doc = 0;
+  bool use_ef = false, with_pf = true;
+  void reset() { ef_base_doc = -1; ef_upper_doc = 0; }
+};
 
 // ---- ForUtil ---------------------------------------------------------------------------------------------------
 
@@ -154,8 +162,10 @@ struct ForUtil {
     return o == 0 ? 0 : 32 - __builtin_clz((uint32_t)o);
   }
 
-  // for_util.rs:396-478 (ef_writer_meta.use_ef is always false: posting_writer.rs:46 → PF arm only)
-  void write_block(const int32_t* data, ByteOut& out, bool by_simd) const {
+  // for_util.rs:396-478. `meta` non-null == the doc-delta stream of a postings writer (posting_writer.rs:334-351); its
+  // use_ef is false in every Rucene build (posting_writer.rs:46, never set) — the EF / BITSET arms below exist so that the
+  // READ side (read_other_encode_block, the iterator's EF / BITSET arms) has files to be checked against.
+  void write_block(const int32_t* data, ByteOut& out, bool by_simd, EfWriterMeta* meta = nullptr) const {
     if (is_all_equal(data)) {
       out.write_byte(0);
       out.write_vint(data[0]);
@@ -163,6 +173,39 @@ struct ForUtil {
     }
     int num_bits = bits_required(data);
     if (!(num_bits > 0 && num_bits <= 32)) throw OracleError(E_ILLEGAL_STATE, "bad num_bits");
+    const int encoded_size = encoded_sizes[num_bits - 1];
+    if (meta != nullptr && meta->use_ef) {  // for_util.rs:417-468
+      EliasFanoEncoder ef_encoder(BLOCK_SIZE, (int64_t)(meta->ef_upper_doc - meta->ef_base_doc - 1));
+      if (ef_encoder.encode_size() <= MAX_ENCODED_SIZE) {
+        int32_t doc_id = meta->ef_base_doc;
+        if (doc_id < 0) doc_id = 0;
+        int32_t min_doc = INT32_MAX, max_doc = 0;
+        for (int i = 0; i < BLOCK_SIZE; i++) {
+          doc_id += data[i];
+          if (doc_id > max_doc) max_doc = doc_id;
+          if (doc_id < min_doc) min_doc = doc_id;
+          ef_encoder.encode_next((int64_t)(doc_id - meta->ef_base_doc - 1));
+        }
+        // FixedBitSet::resize(max_doc - min_doc + 1): num_words = bits2words (util/bit_set.rs:193-199); encode_size = words * 8
+        const int num_words = (max_doc - min_doc + 1 + 63) >> 6;
+        if (num_words * 8 <= encoded_size) {
+          std::vector<int64_t> bits((size_t)num_words, 0);
+          doc_id = meta->ef_base_doc;
+          if (doc_id < 0) doc_id = 0;
+          for (int i = 0; i < BLOCK_SIZE; i++) {
+            doc_id += data[i];
+            const int b = doc_id - min_doc;
+            bits[(size_t)(b >> 6)] |= (int64_t)(1ull << (b & 63));
+          }
+          out.write_byte(0x80);  // EncodeType::BITSET << 6
+          out.write_vint(min_doc);
+          out.write_byte((uint8_t)num_words);
+          EliasFanoEncoder::write_data(bits, out);
+          return;
+        }
+        if (!meta->with_pf || ef_encoder.encode_size() <= encoded_size) { ef_encoder.serialize(out); return; }
+      }
+    }
     uint8_t encoded[MAX_ENCODED_SIZE + 64] = {0};
     out.write_byte((uint8_t)num_bits);
     if (by_simd) {
@@ -278,6 +321,7 @@ struct PostingsWriter {
   bool write_freqs;
   bool use_simd;
   int32_t version;
+  EfWriterMeta ef_writer_meta;  // use_ef stays false unless a test switches it on (no Rucene build does)
 
   // posting_writer.rs:116-251. `version` 1 + simd == the live Zhihu layout; 0 == legacy Lucene PackedInts.
   PostingsWriter(int32_t max_doc, int32_t version_, bool write_freqs_, const uint8_t segment_id[ID_LENGTH],
@@ -295,6 +339,7 @@ struct PostingsWriter {
     last_doc_id = 0;
     last_block_doc_id = -1;
     skip_writer.reset_skip(doc_start_fp);
+    ef_writer_meta.reset();  // posting_writer.rs:300
   }
   // posting_writer.rs:304-361
   void start_doc(int32_t doc_id, int32_t term_doc_freq) {
@@ -307,7 +352,8 @@ struct PostingsWriter {
     doc_buffer_upto++;
     doc_count++;
     if (doc_buffer_upto == BLOCK_SIZE) {
-      for_util.write_block(doc_delta_buffer.data(), doc_out, use_simd);
+      ef_writer_meta.ef_upper_doc = doc_id;  // posting_writer.rs:335
+      for_util.write_block(doc_delta_buffer.data(), doc_out, use_simd, &ef_writer_meta);
       if (write_freqs) for_util.write_block(freq_buffer.data(), doc_out, use_simd);
     }
     last_doc_id = doc_id;
@@ -317,6 +363,7 @@ struct PostingsWriter {
     if (doc_buffer_upto == BLOCK_SIZE) {
       last_block_doc_id = last_doc_id;
       doc_buffer_upto = 0;
+      ef_writer_meta.ef_base_doc = last_block_doc_id;  // posting_writer.rs:472
     }
   }
   // posting_writer.rs:477-591
@@ -520,6 +567,12 @@ struct BlockDocIterator {
   int32_t singleton_doc_id = 0;
   const PostingsReader* reader;
   uint64_t blocks_decoded = 0;  // instrumentation for the CPU baseline report (not in the reference)
+  // EF / BITSET blocks (posting_reader.rs:392-400): the block's encode type and what its arm of next() walks
+  int encode_type = 0;  // 0 PF, 1 EF, 2 BITSET
+  int32_t ef_base_doc = -1, ef_base_total = 0, bits_min_doc = 0, bits_index = 0;
+  std::unique_ptr<EliasFanoEncoder> ef_encoder;
+  std::unique_ptr<EliasFanoDecoder> ef_decoder;
+  std::vector<int64_t> doc_bits;
 
   // posting_reader.rs:410-458
   BlockDocIterator(const PostingsReader* r, bool index_has_freq_, const BlockTermState& st, uint16_t flags)
@@ -542,13 +595,32 @@ struct BlockDocIterator {
     next_skip_doc = BLOCK_SIZE - 1;
     doc_buffer_upto = BLOCK_SIZE;
     skipped = false;
+    ef_base_doc = -1;  // posting_reader.rs:493-494
+    ef_base_total = 0;
+    encode_type = 0;
   }
   // posting_reader.rs:501-561
   void refill_docs() {
+    if (accum > 0) ef_base_doc = accum;  // :503-505 "EF & PF compatible"
+    ef_base_total = doc_upto;
+    encode_type = 0;
+    bits_index = 0;
     int32_t left = doc_freq - doc_upto;
     if (left >= BLOCK_SIZE) {
       int etype = reader->for_util.read_block(doc_in, doc_delta_buffer, true, reader->use_simd);
-      if (etype != 0) throw OracleError(E_UNSUPPORTED, "EF/BITSET/FULL blocks are never written by Rucene (posting_writer.rs:46)");
+      if (etype == 3) throw OracleError(E_UNSUPPORTED, "EncodeType::FULL is unimplemented in the reference (posting_reader.rs:639-641)");
+      encode_type = etype;
+      if (etype == 1) {  // ForUtil::read_other_encode_block, EF arm (for_util.rs:345-362)
+        const int64_t upper_bound = doc_in.read_vlong();
+        ef_encoder.reset(new EliasFanoEncoder(BLOCK_SIZE, upper_bound));
+        ef_encoder->deserialize2(doc_in);
+        ef_decoder.reset(new EliasFanoDecoder(ef_encoder.get()));
+      } else if (etype == 2) {  // BITSET arm (for_util.rs:363-368)
+        bits_min_doc = doc_in.read_vint();
+        const int num_longs = doc_in.read_byte();
+        doc_bits.assign((size_t)num_longs, 0);
+        EliasFanoEncoder::read_data2(doc_bits, doc_in);
+      }
       if (index_has_freq) {
         if (needs_freq) reader->for_util.read_block(doc_in, freq_buffer, false, reader->use_simd);
         else reader->for_util.skip_block(doc_in);
@@ -569,7 +641,23 @@ struct BlockDocIterator {
   int32_t next() {
     if (doc_upto == doc_freq) { doc = NO_MORE_DOCS; return doc; }
     if (doc_buffer_upto == BLOCK_SIZE) refill_docs();
-    doc = accum + doc_delta_buffer[doc_buffer_upto];
+    if (encode_type == 0) {
+      doc = accum + doc_delta_buffer[doc_buffer_upto];
+    } else if (encode_type == 1) {  // posting_reader.rs:624-626
+      doc = (int32_t)ef_decoder->next_value() + 1 + ef_base_doc;
+    } else {                        // :628-633 FixedBitSet::next_set_bit (util/bit_set.rs:351-376)
+      int32_t i = bits_index >> 6;
+      uint64_t word = (uint64_t)doc_bits[(size_t)i] >> (bits_index & 63);
+      int32_t found;
+      if (word != 0) found = bits_index + __builtin_ctzll(word);
+      else {
+        found = NO_MORE_DOCS;
+        while (++i < (int32_t)doc_bits.size()) if (doc_bits[(size_t)i] != 0) { found = (i << 6) + __builtin_ctzll((uint64_t)doc_bits[(size_t)i]); break; }
+      }
+      bits_index = found;
+      doc = bits_min_doc + bits_index;
+      bits_index += 1;
+    }
     accum = doc;
     doc_upto++;
     freq_ = freq_buffer[doc_buffer_upto];
@@ -596,6 +684,8 @@ struct BlockDocIterator {
     }
     if (doc_upto == doc_freq) { doc = NO_MORE_DOCS; return doc; }
     if (doc_buffer_upto == BLOCK_SIZE) refill_docs();
+    if (encode_type != 0)  // posting_reader.rs:733-777 (EliasFanoDecoder::advance_to_value, count_ones_before_index2): not restated
+      throw OracleError(E_UNSUPPORTED, "advance() inside an EF / BITSET block is not restated (no Rucene build writes such blocks)");
     while (true) {
       accum += doc_delta_buffer[doc_buffer_upto];
       doc_upto++;

@@ -148,8 +148,53 @@ __device__ __forceinline__ uint4 store_rows_from_file(uint4 rows, uint32_t hdr, 
   if (!has_freqs && (lane >> 5)) rows = make_uint4(1u, 0u, 0u, 0u);  // IndexOptions::Docs: "all freqs equal 1"
   return rows;
 }
-__device__ __host__ __forceinline__ int store_doc_rows(uint32_t hdr) { return hdr_bdoc(hdr) ? hdr_bdoc(hdr) : 1; }
+__device__ __host__ __forceinline__ int store_doc_rows(uint32_t hdr) { return hdr_bdoc(hdr) ? hdr_bdoc(hdr) : 1; }  // (a flagged non-PF block says 32)
 __device__ __host__ __forceinline__ int store_freq_rows(uint32_t hdr) { return hdr_bfreq(hdr) ? hdr_bfreq(hdr) : 1; }
+
+// ---- doc blocks that are not packed deltas (prepare time only) ---------------------------------------------------
+// ForUtil::read_other_encode_block (for_util.rs:337-372): a doc block's header byte carries its encode type in bits 6-7
+// — 0 PF (packed deltas), 1 EF (Elias-Fano over doc - base - 1; util/packed/elias_fano_encoder.rs), 2 BITSET (a bitmap
+// from min_doc), 3 FULL (unimplemented in the reference itself). No Rucene build writes 1 or 2 (posting_writer.rs:46:
+// use_ef = false, never set), the reader handles them, and so does k_prepare_blocks: such a block is decoded ONCE, its
+// doc ids re-expressed as deltas and packed into the block store as ordinary BP128 rows — the query kernels never see
+// anything but packed-delta blocks. In the directory header word such a block is flagged (bit 15, encode type in the
+// vint-length field, 32 doc rows reserved) until k_prepare_blocks has rewritten it.
+constexpr uint32_t HDR_NONPF = 0x8000u;
+__device__ __host__ __forceinline__ bool hdr_nonpf(uint32_t h) { return (h & HDR_NONPF) != 0u; }
+__device__ __forceinline__ int lz64(uint64_t v) { return v == 0 ? 64 : __builtin_clzll(v); }
+struct EfShape {  // EliasFanoEncoder::new for 128 values (elias_fano_encoder.rs:47-146)
+  int64_t upper_bound;
+  int low_bits, upper_longs, lower_longs, index_longs, vlen;
+};
+__device__ __forceinline__ EfShape ef_shape(const uint8_t* p /* at the vlong */) {
+  EfShape e;
+  uint64_t ub = 0;
+  int i = 0;
+  for (; i < 9; ++i) { const uint64_t b = p[i]; ub |= (b & 0x7f) << (7 * i); if (!(b & 0x80)) { ++i; break; } }
+  e.vlen = i;
+  e.upper_bound = (int64_t)ub;
+  const uint64_t fac = ub / 128u;
+  e.low_bits = fac > 0 ? 63 - lz64(fac) : 0;
+  const uint64_t max_high = ub >> e.low_bits;
+  e.upper_longs = (int)((max_high + 128u + 63u) >> 6);
+  e.lower_longs = (int)((128u * (uint64_t)e.low_bits + 63u) >> 6);
+  const uint64_t n_index = max_high / 256u, max_entry = max_high + 127u;
+  const int entry_bits = max_entry == 0 ? 0 : 64 - lz64(max_entry);
+  e.index_longs = (int)((n_index * (uint64_t)entry_bits + 63u) >> 6);
+  return e;
+}
+// bytes of a non-PF doc block after its header byte; < 0: malformed
+__device__ __forceinline__ int nonpf_doc_bytes(const uint8_t* p /* at the header byte */, int etype) {
+  if (etype == 2) {  // vint min_doc | u8 num_words | num_words x i64
+    int v = 1;
+    while (v < 5 && (p[v] & 0x80)) ++v;
+    const int nw = p[1 + v];
+    return nw <= 64 ? v + 1 + 8 * nw : -1;
+  }
+  const EfShape e = ef_shape(p + 1);
+  if (e.upper_bound < 127 || e.upper_bound > 0x7fffffffLL || e.upper_longs > 6) return -1;
+  return e.vlen + 8 * (e.upper_longs + e.lower_longs + e.index_longs);
+}
 
 // ---- the block store (query time) -------------------------------------------------------------------------------
 // Phase 1 of a FullBlock decode: issue this lane's aligned 16-byte row load (lanes 0..31 -> doc rows, lanes 32..63

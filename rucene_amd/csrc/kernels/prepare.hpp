@@ -21,6 +21,13 @@ namespace rgpu {
 
 constexpr int PREP_THREADS = 256;
 
+// err[0] = the most severe status (rgpu_status, or -101 "plan again with worst-case rows"), err[1] = the highest-numbered
+// check that failed — which of this file's consistency checks it was ends up in the host's error message
+__device__ __forceinline__ void flag_err(int* err, int status, int site) {
+  atomicMin(err, status);
+  atomicMax(err + 1, site);
+}
+
 // workgroup exclusive scan for PREP_THREADS threads; `total` is uniform on return
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* wave_sums, uint32_t& total) {
   const int lane = lane_id();
@@ -67,6 +74,9 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_terms(const uint8_t* _
   const int tid = (int)threadIdx.x;
   __shared__ uint32_t s_ws[PREP_THREADS / 64];
   __shared__ int64_t s_l0;
+  __shared__ int s_nonpf;  // some block of this term is EF / BITSET encoded
+  if (tid == 0) s_nonpf = 0;
+  __syncthreads();
 
   if (t.n_entries > 0) {
     // ---- where does level 0 start? (skip_reader.rs:481-509)
@@ -76,7 +86,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_terms(const uint8_t* _
         int n;
         uint64_t len = read_vlong_serial(doc + p, &n);
         p += n + (int64_t)len;
-        if (p >= doc_len) { atomicMin(err, -4); p = t.skip_fp; break; }
+        if (p >= doc_len) { flag_err(err, -4, 1); p = t.skip_fp; break; }
       }
       s_l0 = p;
     }
@@ -91,7 +101,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_terms(const uint8_t* _
     int64_t chunk = 0;
     while (done < need) {
       const int64_t my = chunk + 16 * tid;  // 16 bytes per thread, 4 KiB per round (a 2 M-posting term has ~80 KB of level 0)
-      if (chunk >= l0_room) { if (tid == 0) atomicMin(err, -4); break; }  // ran off the file looking for skip entries (uniform)
+      if (chunk >= l0_room) { if (tid == 0) flag_err(err, -4, 2); break; }  // ran off the file looking for skip entries (uniform)
       const uint4 w4 = load16_unaligned(l0 + my);
       const uint32_t ws[4] = {w4.x, w4.y, w4.z, w4.w};
       uint32_t term = 0;
@@ -116,7 +126,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_terms(const uint8_t* _
         }
         ++vi;
       }
-      if (total == 0) { if (tid == 0) atomicMin(err, -4); break; }  // 4 KiB without a terminator: corrupt
+      if (total == 0) { if (tid == 0) flag_err(err, -4, 3); break; }  // 4 KiB without a terminator: corrupt
       done += total;
       chunk += 16 * PREP_THREADS;
     }
@@ -142,7 +152,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_terms(const uint8_t* _
         const uint32_t po = ok ? pp[0] : 0u;
         uint32_t tot_p;
         const uint32_t sp = block_excl_scan(po, s_ws, tot_p) + po + carry_pos;
-        if (ok) { pp[0] = sp; if (pp[1] >= 128u) atomicMin(err, -4); }
+        if (ok) { pp[0] = sp; if (pp[1] >= 128u) flag_err(err, -4, 4); }
         carry_pos += tot_p;
       }
     }
@@ -157,15 +167,26 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_terms(const uint8_t* _
   for (int i = tid; i < t.nblocks; i += PREP_THREADS) {
     const uint32_t off = dir_off[t.dir_base + i];
     // offsets are running sums of deltas nobody has checked yet: a block (<= 2 + 2 * 512 bytes) must start inside the file
-    if ((uint64_t)t.start_fp + (uint64_t)off + 1030u > (uint64_t)doc_len + 4096u) { atomicMin(err, -4); dir_hdr[t.dir_base + i] = 0; continue; }
+    if ((uint64_t)t.start_fp + (uint64_t)off + 1030u > (uint64_t)doc_len + 4096u) { flag_err(err, -4, 5); dir_hdr[t.dir_base + i] = 0; continue; }
     const uint8_t* p = doc + t.start_fp + off;
     const uint32_t h = p[0];
-    const int bd = (int)(h & 63);
+    int bd = (int)(h & 63);
     int vlen = 0;
-    if ((h >> 6) != 0) atomicMin(err, -5);  // EF / BITSET / FULL doc blocks: never written by Rucene
-    if (bd > 32) atomicMin(err, -4);
+    const int etype = (int)(h >> 6);
     int doc_sz = 16 * bd;
-    if (bd == 0) { vlen = vint_len_serial(p + 1); doc_sz = vlen; }
+    uint32_t flag = 0;
+    if (etype != 0) {  // EF / BITSET doc block (decode.hpp): sized here, decoded and re-packed by k_prepare_blocks
+      if (etype == 3 || LEGACY) flag_err(err, -5, 6);  // FULL is unimplemented in the reference; EF + the legacy layout: not served
+      doc_sz = etype == 3 ? 0 : nonpf_doc_bytes(p, etype);
+      if (doc_sz < 0) { flag_err(err, -4, 7); doc_sz = 0; }
+      bd = 32;       // doc rows reserved in the block store
+      vlen = etype;  // the vint-length field is free in a flagged word
+      flag = HDR_NONPF;
+      s_nonpf = 1;
+    } else {
+      if (bd > 32) flag_err(err, -4, 8);
+      if (bd == 0) { vlen = vint_len_serial(p + 1); doc_sz = vlen; }
+    }
     // the freq block (absent for IndexOptions::Docs: posting_writer.rs:334-351 writes it only when the field has freqs;
     // the directory then says "all-equal freq stream" and the block store supplies the value 1)
     int bf = 0;
@@ -173,13 +194,13 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_terms(const uint8_t* _
     if (has_freqs) {
       const uint32_t h2 = p[1 + doc_sz];
       bf = (int)(h2 & 63);
-      if (bf > 32) atomicMin(err, -4);
+      if (bf > 32) flag_err(err, -4, 9);
       const int freq_sz = bf ? 16 * bf : vint_len_serial(p + 1 + doc_sz + 1);
       end += 1u + (uint32_t)freq_sz;
     }
-    if (i < t.n_entries && end != dir_off[t.dir_base + i + 1]) atomicMin(err, -4);
-    if (i > 0 && i < t.n_entries && dir_last[t.dir_base + i] <= dir_last[t.dir_base + i - 1]) atomicMin(err, -4);
-    dir_hdr[t.dir_base + i] = (uint16_t)((uint32_t)bd | ((uint32_t)vlen << 6) | ((uint32_t)bf << 9));
+    if (i < t.n_entries && end != dir_off[t.dir_base + i + 1]) flag_err(err, -4, 10);
+    if (i > 0 && i < t.n_entries && dir_last[t.dir_base + i] <= dir_last[t.dir_base + i - 1]) flag_err(err, -4, 11);
+    dir_hdr[t.dir_base + i] = (uint16_t)((uint32_t)bd | ((uint32_t)vlen << 6) | ((uint32_t)bf << 9) | flag);
   }
   __syncthreads();
   // ---- block store rows: block i takes max(b_doc,1) + max(b_freq,1) rows; exclusive prefix sum over the blocks
@@ -196,8 +217,10 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_terms(const uint8_t* _
   }
   if (tid == 0) dir_row[t.dir_base + t.nblocks] = carry_rows;  // where the term's decoded tail goes (k_prepare_blocks)
   const uint32_t tail_rows = (t.df > 1 && t.df % 128 != 0) ? (uint32_t)TAIL_STORE_ROWS : 0u;
-  if (carry_rows + tail_rows > t.bs_rows) {  // more rows than the framing the host sized the store from: corrupt
-    if (tid == 0) atomicMin(err, -4);
+  if (carry_rows + tail_rows > t.bs_rows) {
+    // more rows than the framing the host sized the store from: corrupt — unless the term has EF / BITSET blocks, whose
+    // re-packed deltas may outgrow their file bytes: -101 asks the host to plan this call again with worst-case sizes
+    if (tid == 0) flag_err(err, s_nonpf ? -101 : -4, 12);
     return;
   }
 }
@@ -214,7 +237,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_blocks(const uint8_t* 
                                                                   int64_t n_items, int32_t* dir_last,
                                                                   const uint32_t* __restrict__ dir_off,
                                                                   const uint32_t* __restrict__ dir_row,
-                                                                  const uint16_t* __restrict__ dir_hdr, uint8_t* bstore,
+                                                                  uint16_t* dir_hdr, uint8_t* bstore,
                                                                   const uint8_t* __restrict__ norms, uint8_t* pnorm,
                                                                   uint64_t* __restrict__ dir_bmax, int ranked, int has_freqs,
                                                                   int32_t max_doc, int* err) {
@@ -249,15 +272,96 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_blocks(const uint8_t* 
     const int32_t prev = __builtin_amdgcn_update_dpp(tbase, d1, 0x138, 0xf, 0xf, false);  // wave_shr:1; lane 0 <- the base doc
     const bool first_ok = (t.nblocks == 0 && lane == 0) ? d0 >= 0 : d0 > prev;  // a term's very first doc may be doc 0
     const bool bad = (v0 && (!first_ok || d0 >= max_doc)) || (v1 && (d1 <= d0 || d1 >= max_doc));
-    if (__ballot(bad)) { if (lane == 0) atomicMin(err, -4); return; }
+    if (__ballot(bad)) { if (lane == 0) flag_err(err, -4, 13); return; }
     uint8_t* tp = term_rows + 16 * (size_t)dir_row[t.dir_base + t.nblocks];
     *reinterpret_cast<uint2*>(tp + 8 * lane) = make_uint2(v0 ? (uint32_t)d0 : 0x7fffffffu, v1 ? (uint32_t)d1 : 0x7fffffffu);
     *reinterpret_cast<uint2*>(tp + 512 + 8 * lane) = make_uint2(v0 ? f0 : 0u, v1 ? f1 : 0u);
   }
   for (int blk = b0; blk < b1; ++blk) {
-    const uint32_t hdr = dir_hdr[t.dir_base + blk];
+    uint32_t hdr = dir_hdr[t.dir_base + blk];
     const uint32_t row0 = dir_row[t.dir_base + blk];
-    const uint4 rows = store_rows_from_file(file_rows_load(doc + t.start_fp + dir_off[t.dir_base + blk], hdr, lane), hdr, lane, has_freqs != 0);
+    uint4 rows;
+    if (!hdr_nonpf(hdr)) {
+      rows = store_rows_from_file(file_rows_load(doc + t.start_fp + dir_off[t.dir_base + blk], hdr, lane), hdr, lane, has_freqs != 0);
+    } else {
+      // ---- an EF / BITSET doc block: 128 doc ids -> deltas -> BP128 rows (decode.hpp; for_util.rs:337-372,
+      // posting_reader.rs:622-637, elias_fano_decoder.rs:95-169, util/bit_set.rs:351-376)
+      const uint8_t* p = doc + t.start_fp + dir_off[t.dir_base + blk];
+      const int etype = hdr_vlen(hdr);
+      int32_t* ids = reinterpret_cast<int32_t*>(slabs[wave]);            // 128 doc ids
+      uint32_t* pack = reinterpret_cast<uint32_t*>(slabs[wave] + 512);   // 132 dwords of BP128 rows
+      const int32_t pf_base = blk == 0 ? 0 : dir_last[t.dir_base + blk - 1];
+      int doc_sz, total;
+      if (etype == 2) {
+        int v = 1;
+        while (v < 5 && (p[v] & 0x80)) ++v;
+        int vl;
+        const int32_t min_doc = (int32_t)read_vint_uniform(p + 1, &vl);
+        const int nw = p[1 + v];
+        doc_sz = v + 1 + 8 * nw;
+        uint64_t word = 0;
+        if (lane < nw) { const uint8_t* wp = p + 2 + v + 8 * lane; word = (uint64_t)load4_unaligned(wp) | ((uint64_t)load4_unaligned(wp + 4) << 32); }
+        const int cnt = __popcll(word);
+        const int incl = wave_incl_scan(cnt);
+        total = readlane(incl, 63);
+        int at = incl - cnt;
+        while (word) {
+          if (at < 128) ids[at] = min_doc + 64 * lane + (int)__builtin_ctzll(word);
+          ++at;
+          word &= word - 1;
+        }
+      } else {
+        const EfShape e = ef_shape(p + 1);
+        doc_sz = e.vlen + 8 * (e.upper_longs + e.lower_longs + e.index_longs);
+        const uint8_t* up = p + 1 + e.vlen;
+        const uint8_t* lp = up + 8 * e.upper_longs;
+        const int32_t ef_base = blk == 0 ? -1 : pf_base;  // refill_docs: ef_base_doc = accum when accum > 0, else -1
+        uint64_t word = 0;
+        if (lane < e.upper_longs) word = (uint64_t)load4_unaligned(up + 8 * lane) | ((uint64_t)load4_unaligned(up + 8 * lane + 4) << 32);
+        const int cnt = __popcll(word);
+        const int incl = wave_incl_scan(cnt);
+        total = readlane(incl, 63);
+        int i = incl - cnt;  // index of this lane's first value
+        const uint64_t lmask = e.low_bits ? (~0ull >> (64 - e.low_bits)) : 0ull;
+        while (word) {
+          const int64_t high = 64 * lane + (int)__builtin_ctzll(word) - i;  // set bit position - index (current_high_value)
+          uint64_t low = 0;
+          if (e.low_bits) {  // unpack_value
+            const int bit_pos = i * e.low_bits, at = bit_pos & 63;
+            const uint8_t* wp = lp + 8 * (bit_pos >> 6);
+            low = ((uint64_t)load4_unaligned(wp) | ((uint64_t)load4_unaligned(wp + 4) << 32)) >> at;
+            if (at + e.low_bits > 64) low |= ((uint64_t)load4_unaligned(wp + 8) | ((uint64_t)load4_unaligned(wp + 12) << 32)) << (64 - at);
+            low &= lmask;
+          }
+          if (i < 128) ids[i] = (int32_t)(((uint64_t)high << e.low_bits) | low) + 1 + ef_base;
+          ++i;
+          word &= word - 1;
+        }
+      }
+      pack[lane] = 0u; pack[64 + lane] = 0u;
+      if (lane < 4) pack[128 + lane] = 0u;
+      wave_sync();
+      if (total != 128) { if (lane == 0) flag_err(err, -4, 14); return; }
+      const int32_t a = ids[2 * lane], b = ids[2 * lane + 1];
+      const int32_t before = lane == 0 ? pf_base : ids[2 * lane - 1];
+      const uint32_t d0 = (uint32_t)(a - before), d1 = (uint32_t)(b - a);
+      const uint32_t top = wave_reduce_max_u32(d0 | d1);  // bits_required looks at the OR: the same most significant bit as the maximum
+      const int bits = top == 0u ? 1 : 32 - __builtin_clz(top);
+      auto put = [&](int i, uint32_t v) {  // SIMD128Packer::pack for one value (packed_simd.rs:81-108)
+        const int bit = (i >> 2) * bits, w = bit >> 5, sft = bit & 31, l = i & 3;
+        atomicOr(&pack[4 * w + l], v << sft);
+        if (sft + bits > 32) atomicOr(&pack[4 * (w + 1) + l], v >> (32 - sft));
+      };
+      put(2 * lane, d0);
+      put(2 * lane + 1, d1);
+      wave_sync();
+      hdr = (uint32_t)bits | (hdr & (63u << 9));  // from here on an ordinary packed-delta block
+      if (lane == 0) dir_hdr[t.dir_base + blk] = (uint16_t)hdr;
+      if (lane < 32) rows = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(pack) + 16 * lane);
+      else rows = load16_unaligned(p + 1 + doc_sz + 1 + 16 * (lane & 31));
+      rows = store_rows_from_file(rows, hdr, lane, has_freqs != 0);
+      wave_sync();
+    }
     const int half = lane >> 5, row = lane & 31;
     const int rd = store_doc_rows(hdr);
     if (row < (half ? store_freq_rows(hdr) : rd))
@@ -277,7 +381,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_blocks(const uint8_t* 
     const bool bad_first = (blk == 0 && lane == 0) ? d0 < 0 : d0 <= prev;
     const bool bad = bad_first || d1 <= d0 || d1 >= max_doc;
     const bool bad_last = blk < t.n_entries && lane == 63 && d1 != dir_last[t.dir_base + blk];
-    if (__ballot(bad || bad_last)) { if (lane == 0) atomicMin(err, -4); return; }
+    if (__ballot(bad || bad_last)) { if (lane == 0) flag_err(err, -4, 15); return; }
     if (norms != nullptr) {
       const uint32_t n0 = norms[d0], n1 = norms[d1];
       *reinterpret_cast<uint16_t*>(pnorm + t.pn_base + 128 * (uint64_t)blk + 2 * lane) = (uint16_t)(n0 | (n1 << 8));

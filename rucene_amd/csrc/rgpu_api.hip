@@ -303,7 +303,15 @@ static int32_t validate_state(const rgpu_segment* seg, const rgpu_term_state& st
 }
 
 // Build block directories for every not-yet-seen term with df >= 128 (ctx mutex held by the caller).
+static int32_t prepare_terms_attempt(rgpu_segment* seg, const rgpu_term_state* const* sts, size_t n, bool wide);
+// -101 from the device: a term holds EF / BITSET doc blocks whose re-packed deltas need more block-store rows than its
+// file bytes suggest — plan the same call again with worst-case rows (64 per block). Nothing was committed.
 static int32_t prepare_terms_locked(rgpu_segment* seg, const rgpu_term_state* const* sts, size_t n) {
+  int32_t rc = prepare_terms_attempt(seg, sts, n, false);
+  if (rc == -101) rc = prepare_terms_attempt(seg, sts, n, true);
+  return rc;
+}
+static int32_t prepare_terms_attempt(rgpu_segment* seg, const rgpu_term_state* const* sts, size_t n, bool wide) {
   rgpu_ctx* c = seg->ctx;
   std::vector<PrepTerm> work;
   size_t need_slots = seg->dir_used;
@@ -337,7 +345,7 @@ static int32_t prepare_terms_locked(rgpu_segment* seg, const rgpu_term_state* co
     const uint64_t span = st.doc_freq > 128 ? (uint64_t)st.skip_offset : (p.nblocks ? 1026u : 0u);
     // (a docs-only field: one header byte dropped, a synthetic 16-byte freq row added per block);
     // + the decoded tail: 128 doc ids and 128 freqs as plain arrays behind the block rows
-    const uint64_t rows = (span + (seg->has_freqs ? 28u : 32u) * (uint64_t)p.nblocks + 15u) / 16u +
+    const uint64_t rows = (wide ? 64u * (uint64_t)p.nblocks : (span + (seg->has_freqs ? 28u : 32u) * (uint64_t)p.nblocks + 15u) / 16u) +
                           ((st.doc_freq % 128) ? (uint64_t)TAIL_STORE_ROWS : 0u);
     if (rows > 0xffffffffull) return fail(RGPU_ERR_UNSUPPORTED, "a single term's postings exceed 64 GiB");
     p.bs_base = (uint64_t)need_bs;
@@ -376,7 +384,7 @@ static int32_t prepare_terms_locked(rgpu_segment* seg, const rgpu_term_state* co
   std::memcpy(c->S->h_stage.p, work.data(), bytes);
   std::memcpy(c->S->h_stage.p + o_items, item_prefix.data(), item_prefix.size() * 8);
   HIP_TRY(hipMemcpyAsync(c->S->d_stage.p, c->S->h_stage.p, staged, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream));
+  HIP_TRY(hipMemsetAsync(c->d_err, 0, 2 * sizeof(int), c->stream));
   const PrepTerm* d_work = reinterpret_cast<const PrepTerm*>(c->S->d_stage.p);
   const int64_t* d_items = reinterpret_cast<const int64_t*>(c->S->d_stage.p + o_items);
   {
@@ -402,13 +410,15 @@ static int32_t prepare_terms_locked(rgpu_segment* seg, const rgpu_term_state* co
                          (int)work.size(), n_items, seg->dir_last.p, seg->dir_off.p, seg->dir_row.p, seg->dir_hdr.p, seg->bstore.p,
                          seg->d_norms, seg->pnorm.p, seg->dir_bmax.p, seg->n_norm_ranks > 0 ? 1 : 0, seg->has_freqs ? 1 : 0, seg->max_doc, c->d_err);
   }
-  int err = 0;
-  HIP_TRY(hipMemcpyAsync(&err, c->d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  int err2[2] = {0, 0};
+  HIP_TRY(hipMemcpyAsync(err2, c->d_err, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   HIP_TRY(hipGetLastError());
+  const int err = err2[0];
+  if (err == -101) return -101;  // see prepare_terms_locked
   if (err != 0) {
-    return fail(err, err == RGPU_ERR_UNSUPPORTED ? "EF/BITSET/FULL encoded doc block (never written by Rucene) is not supported"
-                                                 : "corrupt skip data or block framing in .doc");
+    return fail(err, err == RGPU_ERR_UNSUPPORTED ? std::string("FULL-encoded doc block (unimplemented in Rucene itself), or an EF / BITSET block in a legacy (.doc version 0) file")
+                                                 : "corrupt skip data or block framing in .doc (prepare.hpp check #" + std::to_string(err2[1]) + ")");
   }
   seg->dir_used = need_slots;
   seg->pnorm_used = need_pn;
@@ -468,7 +478,7 @@ extern "C" int32_t rgpu_init(int32_t device_ordinal, const rgpu_config* cfg, rgp
   if (c->cfg.blocks_per_item <= 0) { c->cfg.blocks_per_item = 32; c->blocks_per_item_auto = true; }
   if (c->cfg.and_blocks_per_item <= 0) c->cfg.and_blocks_per_item = 4;  // measured 3-5 % over 2 (fewer items, cursors reused longer)
   std::snprintf(c->name, sizeof c->name, "%s (%s)", prop.name, prop.gcnArchName);
-  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipMalloc(&c->d_err, sizeof(int)) != hipSuccess) {
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipMalloc(&c->d_err, 2 * sizeof(int)) != hipSuccess) {
     delete c;
     return fail(RGPU_ERR_RUNTIME, "failed to create stream / error word");
   }

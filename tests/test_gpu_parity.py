@@ -873,3 +873,43 @@ def test_exact_phrases(ctx, oracle, version, max_doc):
     hits, totals = searcher.search_batch([T(0), B.build([T(1), T(2)], []), B.build([], [T(3), T(vocab + 1)])], 10)
     assert totals[0] == len(postings[0]) and totals[1] == len(set(d for d, _ in postings[1]) & set(d for d, _ in postings[2]))
     assert totals[2] == len(set(d for d, _ in postings[3]) | set(d for d, _ in postings[vocab + 1]))
+
+
+@pytest.mark.parametrize("with_pf", [True, False], ids=["ef-where-smaller", "ef-always"])
+def test_elias_fano_and_bitset_doc_blocks(ctx, oracle, with_pf):
+    """SURVEY 8(f)4: doc blocks in the EF and BITSET encodings (ForUtil::read_other_encode_block, for_util.rs:337-372) — no
+    Rucene build writes them (posting_writer.rs:46), its reader takes them, and so does this library: k_prepare_blocks
+    decodes such a block once and re-packs it as deltas. Files from the restated writer with use_ef switched on; decode,
+    TERM and OR against the oracle's own EF / BITSET arms, AND against the plain intersection (the oracle does not restate
+    advance() inside such blocks)."""
+    import rucene_amd
+    rng = np.random.default_rng(13)
+    max_doc = 500_000
+    w = oracle.Writer(max_doc, use_ef=True, with_pf=with_pf)
+    lists = [np.sort(rng.choice(max_doc, size=n, replace=False)).astype(np.int32) for n in (128, 129, 1000, 5000, 70_000, 200_000)]
+    lists.append(np.unique(np.arange(7, 7 + 3000 * 2, 2) + (rng.random(3000) < 0.3)).astype(np.int32))   # dense: bitset blocks
+    lists.append(np.arange(1000, 1000 + 128 * 5, dtype=np.int32))                                         # consecutive docs
+    freqs = [rng.integers(1, 9, size=d.size).astype(np.int32) for d in lists]
+    terms = np.array([w.write_term(d, f) for d, f in zip(lists, freqs)], dtype=oracle.TERM_STATE_DTYPE)
+    data = w.close()
+    kinds = {int(data[int(st["doc_start_fp"])]) >> 6 for st in terms}
+    assert {1, 2} <= kinds, kinds
+    norms = rng.integers(95, 125, size=max_doc).astype(np.uint8)
+    oseg = oracle.Segment(data, norms, max_doc, terms, sum_total_term_freq=90 * max_doc)
+    gseg = rucene_amd.Segment(ctx, data, norms, max_doc)
+    docs, fr = gseg.decode_terms(terms)
+    assert (docs == np.concatenate(lists)).all() and (fr == np.concatenate(freqs)).all()
+    leaf = rucene_amd.LeafReader(data, norms, max_doc, terms, sum_total_term_freq=90 * max_doc)
+    gsearcher = rucene_amd.GpuIndexSearcher([leaf], ctx=ctx)
+    osearcher = oracle.Searcher([oseg])
+    n = len(lists)
+    specs = [(oracle.OP_TERM, [t]) for t in range(n)] + [(oracle.OP_OR, [0, 2, 4]), (oracle.OP_OR, list(range(n)))]
+    for k in (10, 100):
+        _check_against_oracle(oracle, osearcher, gsearcher, specs, k)
+    T, B = rucene_amd.TermQuery, rucene_amd.BooleanQuery
+    pairs = [(4, 5), (3, 5), (5, 6), (2, 4), (6, 7)]
+    hits, totals = gsearcher.search_batch([B.build([T(a), T(b)], []) for a, b in pairs], 10)
+    for (a, b), total, row in zip(pairs, totals, hits):
+        both = np.intersect1d(lists[a], lists[b])
+        assert total == both.size
+        assert set(row["doc"][row["doc"] >= 0]) <= set(both.tolist())

@@ -421,3 +421,64 @@ def test_req_opt_scorer_on_postings(oracle):
     with_not = sr.search_opt(oracle.OP_AND, [0, 1], [2], k, must_not_ids=[3])
     plain_not = sr.search_not(oracle.OP_AND, [0, 1], [3], k)
     assert with_not[2] == plain_not[2] and set(with_not[0].tolist()) == set(plain_not[0].tolist())
+
+
+# ---- Elias-Fano (util/packed/elias_fano_encoder.rs:397-447: the reference's four tests) -----------------------------------
+def test_elias_fano_num_longs_for_bits(oracle):
+    L = oracle.lib()
+    assert [L.orc_ef_num_longs_for_bits(n) for n in (5, 31, 32, 33, 65, 128, 129)] == [1, 1, 1, 1, 2, 2, 3]
+
+
+def test_elias_fano_pack_value(oracle):
+    import ctypes as C
+    L = oracle.lib()
+    lv = (C.c_int64 * 2)(0, 0)
+    L.orc_ef_pack_value(2, lv, 2, 2, 31)
+    assert lv[0] & (2**64 - 1) == 0x8000000000000000
+    lv = (C.c_int64 * 2)(0, 0)
+    L.orc_ef_pack_value(0b11111, lv, 2, 5, 12)
+    assert lv[0] & (2**64 - 1) == 0xF000000000000000 and lv[1] == 1
+
+
+def test_elias_fano_encode_upper(oracle):
+    import ctypes as C
+    hs = (C.c_int64 * 5)(0, 0, 1, 1, 2)
+    assert [oracle.lib().orc_ef_encode_upper(7, 24, hs, n) for n in range(1, 6)] == [1, 3, 11, 27, 91]
+
+
+def test_elias_fano_get_encoder_and_round_trip(oracle):
+    """get_encoder(128, 510901) (the reference's fourth test only prints it): shape from the formulas, then
+    encode -> serialize -> deserialize2 -> next_value returns what went in, for block-like inputs."""
+    import ctypes as C
+    L = oracle.lib()
+    rng = np.random.default_rng(3)
+    for ub in (127, 128, 300, 5000, 510901, 2**31 - 2):
+        vals = np.sort(rng.choice(ub + 1, 128, replace=False)).astype(np.int64) if ub >= 128 else np.arange(128, dtype=np.int64)
+        out = np.zeros(128, np.int64)
+        nl, es = C.c_int32(), C.c_int32()
+        n = L.orc_ef_roundtrip(vals.ctypes.data_as(C.POINTER(C.c_int64)), 128, ub, out.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(nl), C.byref(es))
+        assert n == 128 and (out == vals).all()
+        assert nl.value == (0 if ub // 128 == 0 else (ub // 128).bit_length() - 1)   # floor(log2(upper_bound / num_values))
+    # 510901 / 128 = 3991 -> 11 low bits; upper longs = ceil((510901 >> 11 + 128) / 64) = 6; lower = 22; no index entries
+    assert es.value >= 0
+
+
+def test_ef_and_bitset_doc_blocks_round_trip_through_the_postings_reader(oracle):
+    """ForUtil::write_block's EF / BITSET arms (for_util.rs:417-468) against read_other_encode_block + the iterator's arms
+    (posting_reader.rs:501-561, 622-637): sparse lists become EF blocks, dense ones bitsets, the rest stays packed."""
+    rng = np.random.default_rng(9)
+    max_doc = 400_000
+    for with_pf in (True, False):
+        w = oracle.Writer(max_doc, use_ef=True, with_pf=with_pf)
+        lists = [np.sort(rng.choice(max_doc, size=n, replace=False)).astype(np.int32) for n in (128, 129, 1000, 5000, 60_000)]
+        lists.append(np.unique(np.arange(7, 7 + 3000 * 2, 2) + (rng.random(3000) < 0.3)).astype(np.int32))   # dense: bitsets
+        freqs = [rng.integers(1, 9, size=d.size).astype(np.int32) for d in lists]
+        terms = np.array([w.write_term(d, f) for d, f in zip(lists, freqs)], dtype=oracle.TERM_STATE_DTYPE)
+        data = w.close()
+        seg = oracle.Segment(data, None, max_doc, terms)
+        kinds = set()
+        for d, f, st in zip(lists, freqs, terms):
+            gd, gf = seg.decode_term(st)
+            assert (gd == d).all() and (gf == f).all()
+            kinds.add(int(data[int(st["doc_start_fp"])]) >> 6)
+        assert {1, 2} <= kinds
