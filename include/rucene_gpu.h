@@ -373,6 +373,29 @@ int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase_query* que
                                  const rgpu_phrase_term* terms, int32_t n_terms_total, int32_t k, rgpu_hit* hits_out,
                                  int64_t* total_hits_out);
 
+/* ---- second-pass scoring (QueryRescorer) ------------------------------------------------------------------------------ */
+/* search/scorer/rescorer.rs: QueryRescorer re-ranks the top `window_size` hits of a first pass with a second query —
+ * per hit the second query's scorer is advanced to the doc and the two scores are combined (combine_score :337-352:
+ * mode.combine(first * query_weight, second * rescore_weight), or first * query_weight when the second query does not
+ * match), the window is sorted again (score desc, doc asc) and hits past the window take the query weight
+ * (combine_docs :356-374). Rucene scores the window one doc at a time, or all at once through a Weight's BatchScorer
+ * (:32-36, batch_rescore :133-229); this entry point IS the batched form: every hit of every row is scored by its
+ * own wavefront. Rescore queries: TERM, all-MUST (AND) or all-SHOULD (OR) term queries. */
+typedef enum rgpu_rescore_mode { RGPU_RESCORE_AVG = 0, RGPU_RESCORE_MAX = 1, RGPU_RESCORE_MIN = 2, RGPU_RESCORE_TOTAL = 3,
+                                 RGPU_RESCORE_MULTIPLY = 4 } rgpu_rescore_mode;  /* RescoreMode (rescorer.rs:96-116) */
+typedef struct rgpu_rescore_request {  /* RescoreRequest (rescorer.rs:67-93), one per row */
+  float query_weight;
+  float rescore_weight;
+  int32_t mode;         /* rgpu_rescore_mode */
+  int32_t window_size;  /* <= RGPU_MAX_K */
+} rgpu_rescore_request;
+/* hits_inout: n_queries rows of k rgpu_hit (host memory), best first, unused slots {-1, 0} — a first pass's output; on
+ * return the rescored rows. Docs carry doc_base; hits of other leaves are left alone, so a multi-leaf caller runs one
+ * call per leaf with finish = 0 and finish = 1 on the last: only then is the window sorted and the tail re-weighted. */
+int32_t rgpu_rescore_batch(rgpu_segment* seg, const rgpu_query* queries, int32_t n_queries, const rgpu_query_term* terms,
+                           int32_t n_terms_total, const rgpu_rescore_request* requests, int32_t k, rgpu_hit* hits_inout,
+                           int32_t finish);
+
 /* ---- measurement ------------------------------------------------------------------------------------------ */
 typedef struct rgpu_kernel_stat {
   char name[48];

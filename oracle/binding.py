@@ -96,6 +96,8 @@ def _declare(L):
         "orc_segment_version": (C.c_int, [vp]),
         "orc_segment_set_index_has_freq": (None, [vp, C.c_int]),
         "orc_writer_set_ef": (None, [vp, C.c_int, C.c_int]),
+        "orc_searcher_rescore": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int64), C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.c_int, C.c_int,
+                                         C.c_float, C.c_float, C.c_int]),
         "orc_ef_num_longs_for_bits": (C.c_int64, [C.c_int64]),
         "orc_ef_pack_value": (None, [C.c_int64, C.POINTER(C.c_int64), C.c_int, C.c_int32, C.c_int64]),
         "orc_ef_encode_upper": (C.c_int64, [C.c_int64, C.c_int64, C.POINTER(C.c_int64), C.c_int]),
@@ -354,6 +356,16 @@ class Searcher:
         self._h = lib().orc_searcher_new(arr, len(self.segments), k1, b)
         if not self._h:
             raise OracleError(lib().orc_last_error().decode())
+
+    def rescore(self, op, term_ids, docs, scores, window_size, query_weight, rescore_weight, mode):
+        """QueryRescorer::rescore (rescorer.rs:376-390) of one first-pass row (best first) with a TERM / AND / OR term query;
+        mode: 0 Avg, 1 Max, 2 Min, 3 Total, 4 Multiply. Returns the new (docs, scores)."""
+        t = np.ascontiguousarray(term_ids, dtype=np.int64)
+        d = np.ascontiguousarray(docs, dtype=np.int32).copy()
+        sc = np.ascontiguousarray(scores, dtype=np.float32).copy()
+        _check(lib().orc_searcher_rescore(self._h, op, _p(t, C.c_int64), t.size, _p(d, C.c_int32), _p(sc, C.c_float), d.size, int(window_size),
+                                          float(query_weight), float(rescore_weight), int(mode)))
+        return d, sc
 
     def override_statistics(self, stats_segment, total_max_doc):
         """Score with another leaf's statistics (the index-wide largest leaf living on another shard)."""

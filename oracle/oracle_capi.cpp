@@ -896,6 +896,21 @@ int64_t orc_pos_iterate(orc_pos_index* h, int32_t term, const int32_t* targets, 
   ORC_CATCH
 }
 
+// QueryRescorer::rescore of one first-pass row (docs / scores in place, best first) with a TERM / AND / OR term query
+int orc_searcher_rescore(orc_searcher* h, int op, const int64_t* term_ids, int n_terms, int32_t* docs, float* scores, int n_hits,
+                         int window_size, float query_weight, float rescore_weight, int mode) {
+  ORC_TRY
+  Query q;
+  q.op = op;
+  q.term_ids.assign(term_ids, term_ids + n_terms);
+  std::vector<ScoreDoc> hits((size_t)n_hits);
+  for (int i = 0; i < n_hits; i++) { hits[(size_t)i].doc = docs[i]; hits[(size_t)i].score = scores[i]; }
+  h->s.rescore(q, hits, (size_t)window_size, query_weight, rescore_weight, mode);
+  for (int i = 0; i < n_hits; i++) { docs[i] = hits[(size_t)i].doc; scores[i] = hits[(size_t)i].score; }
+  return 0;
+  ORC_CATCH
+}
+
 // ---- exact PhraseQuery (oracle/phrase.hpp) ---------------------------------------------------------------------------
 // PhraseWeight::create_scorer for term_ids at phrase positions `offsets` (PhraseQuery::build: 0, 1, 2, ...): null when a
 // term is absent. The scorer owns its iterators; `w` must outlive it.

@@ -797,6 +797,64 @@ struct IndexSearcher {
     r.hits = collector.top_docs();
     return r;
   }
+
+  // ---- QueryRescorer (search/scorer/rescorer.rs:129-374) ---------------------------------------------------------------
+  // RescoreMode::combine (:97-116): 0 Avg, 1 Max, 2 Min, 3 Total, 4 Multiply
+  static float rescore_mode_combine(int mode, float primary, float secondary) {
+    switch (mode) {
+      case 0: return (primary + secondary) / 2.0f;
+      case 1: return primary >= secondary ? primary : secondary;  // f32::max (no NaNs here)
+      case 2: return primary <= secondary ? primary : secondary;
+      case 3: return primary + secondary;
+      default: return primary * secondary;
+    }
+  }
+  // combine_score (:337-352)
+  static float rescore_combine_score(int mode, float query_weight, float rescore_weight, float last_score, bool is_match, float new_score) {
+    if (is_match) return rescore_mode_combine(mode, last_score * query_weight, new_score * rescore_weight);
+    return last_score * query_weight;
+  }
+  // rescore (:376-390) = query_rescore (:279-335: the window's hits sorted by doc, iterative_rescore :231-277 — one scorer
+  // per leaf advanced from hit to hit — then hits.sort(): score desc, doc asc) + combine_docs (:354-374: the rescored
+  // window goes back on top, hits past it take the query weight). `hits` is the first pass's list, best first.
+  void rescore(const Query& q, std::vector<ScoreDoc>& hits, size_t window_size, float query_weight, float rescore_weight, int mode) const {
+    std::vector<BM25Weight> weights;
+    for (size_t i = 0; i < q.term_ids.size(); i++) weights.push_back(term_weight(q.term_ids[i], q.boosts.empty() ? 1.0f : q.boosts[i]));
+    for (size_t i = 0; i < q.must_not_ids.size(); i++) weights.push_back(term_weight(q.must_not_ids[i], 1.0f));
+    for (size_t i = 0; i < q.opt_ids.size(); i++) weights.push_back(term_weight(q.opt_ids[i], 1.0f));
+    std::vector<ScoreDoc> window(hits.begin(), hits.begin() + (ptrdiff_t)std::min(window_size, hits.size()));
+    std::sort(window.begin(), window.end(), [](const ScoreDoc& a, const ScoreDoc& b) { return a.doc < b.doc; });
+    size_t hit_upto = 0;
+    int32_t end_doc = 0, doc_base = 0;
+    int reader_idx = -1, current_reader_idx = -1;
+    ScorerBox scorer;
+    while (hit_upto < window.size()) {
+      const int32_t doc_id = window[hit_upto].doc;
+      const float current_score = window[hit_upto].score;
+      while (doc_id >= end_doc && reader_idx < (int)leaves.size() - 1) {
+        reader_idx += 1;
+        end_doc = leaves[(size_t)reader_idx]->doc_base + leaves[(size_t)reader_idx]->max_doc;
+      }
+      if (reader_idx != current_reader_idx) {
+        doc_base = leaves[(size_t)reader_idx]->doc_base;
+        scorer = create_scorer(leaves[(size_t)reader_idx], q, weights);
+        current_reader_idx = reader_idx;
+      }
+      if (scorer) {
+        const int32_t target_doc = doc_id - doc_base;
+        int32_t actual_doc = scorer->doc_id();
+        if (actual_doc < target_doc) actual_doc = scorer->advance(target_doc);
+        if (actual_doc == target_doc) window[hit_upto].score = rescore_combine_score(mode, query_weight, rescore_weight, current_score, true, scorer->score());
+        else window[hit_upto].score = rescore_combine_score(mode, query_weight, rescore_weight, current_score, false, 0.0f);
+      } else {
+        window[hit_upto].score = rescore_combine_score(mode, query_weight, rescore_weight, current_score, false, 0.0f);
+      }
+      hit_upto += 1;
+    }
+    std::sort(window.begin(), window.end(), [](const ScoreDoc& a, const ScoreDoc& b) { return a.score != b.score ? a.score > b.score : a.doc < b.doc; });
+    for (size_t i = 0; i < window.size(); i++) hits[i] = window[i];
+    for (size_t i = window.size(); i < hits.size(); i++) hits[i].score = hits[i].score * query_weight;
+  }
 };
 
 }  // namespace orc

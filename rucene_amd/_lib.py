@@ -22,6 +22,8 @@ QUERY_DTYPE = np.dtype([("op", "<i4"), ("n_terms", "<i4"), ("first_term", "<i4")
 HIT_DTYPE = np.dtype([("doc", "<i4"), ("score", "<f4")], align=True)
 TERM_POSITIONS_DTYPE_ = np.dtype([("pos_start_fp", "<i8"), ("pay_start_fp", "<i8"), ("last_pos_block_offset", "<i8")], align=True)
 PHRASE_TERM_DTYPE = np.dtype([("state", TERM_STATE_DTYPE), ("positions", TERM_POSITIONS_DTYPE_), ("position", "<i4"), ("reserved", "<i4")], align=True)
+RESCORE_REQUEST_DTYPE = np.dtype([("query_weight", "<f4"), ("rescore_weight", "<f4"), ("mode", "<i4"), ("window_size", "<i4")], align=True)
+RESCORE_AVG, RESCORE_MAX, RESCORE_MIN, RESCORE_TOTAL, RESCORE_MULTIPLY = range(5)
 PHRASE_QUERY_DTYPE = np.dtype([("n_terms", "<i4"), ("first_term", "<i4"), ("weight", "<f4"), ("sim_table", "<i4")], align=True)
 assert PHRASE_TERM_DTYPE.itemsize == 64 and PHRASE_QUERY_DTYPE.itemsize == 16
 FIELD_INFO_DTYPE = np.dtype([("number", "<i4"), ("index_options", "<i4"), ("has_payloads", "<i4"), ("flags", "<i4")], align=True)
@@ -44,7 +46,7 @@ STATUS_NAMES = {0: "OK", -1: "IllegalState", -2: "IllegalArgument", -3: "Unexpec
 # every symbol include/rucene_gpu.h declares (tests/test_abi.py checks the header and this list agree)
 EXPORTS = [
     "rgpu_init", "rgpu_shutdown", "rgpu_last_error", "rgpu_abi_version", "rgpu_device_name", "rgpu_segment_upload",
-    "rgpu_segment_upload_field", "rgpu_segment_release_prepared_terms", "rgpu_segment_attach_positions", "rgpu_search_phrase_batch",
+    "rgpu_segment_upload_field", "rgpu_segment_release_prepared_terms", "rgpu_segment_attach_positions", "rgpu_search_phrase_batch", "rgpu_rescore_batch",
     "rgpu_segment_free", "rgpu_segment_version", "rgpu_segment_prepare_terms", "rgpu_decode_terms",
     "rgpu_decode_terms_device", "rgpu_advance_batch", "rgpu_sim_table_upload", "rgpu_search_batch",
     "rgpu_search_batch_device", "rgpu_merge_topk_device", "rgpu_bm25_compute_weight", "rgpu_bm25_encode_norm",
@@ -121,6 +123,7 @@ def lib():
         "rgpu_segment_release_prepared_terms": (i32, [vp]),
         "rgpu_segment_attach_positions": (i32, [vp, vp, C.c_size_t]),
         "rgpu_search_phrase_batch": (i32, [vp, vp, i32, vp, i32, i32, vp, vp]),
+        "rgpu_rescore_batch": (i32, [vp, vp, i32, vp, i32, vp, i32, vp, i32]),
         "rgpu_decode_terms": (i32, [vp, vp, i64, vp, vp]),
         "rgpu_decode_terms_device": (i32, [vp, vp, i64, vp, vp, vp]),
         "rgpu_advance_batch": (i32, [vp, vp, vp, i64, vp, vp]),
@@ -454,6 +457,15 @@ class Segment:
         totals = np.zeros(q.size, dtype=np.int64)
         _check(lib().rgpu_search_phrase_batch(self._h, q.ctypes.data, q.size, t.ctypes.data, t.size, k, hits.ctypes.data, totals.ctypes.data))
         return hits, totals
+
+    def rescore_batch(self, queries, terms, requests, hits, finish=True):
+        """QueryRescorer over first-pass rows `hits` [n][k] (modified copy returned): rgpu_rescore_batch."""
+        q = np.ascontiguousarray(queries, dtype=QUERY_DTYPE)
+        t = np.ascontiguousarray(terms, dtype=QUERY_TERM_DTYPE)
+        r = np.ascontiguousarray(requests, dtype=RESCORE_REQUEST_DTYPE)
+        h = np.ascontiguousarray(hits, dtype=HIT_DTYPE).copy()
+        _check(lib().rgpu_rescore_batch(self._h, q.ctypes.data, q.size, t.ctypes.data, t.size, r.ctypes.data, h.shape[1], h.ctypes.data, int(finish)))
+        return h
 
     def release_prepared_terms(self):
         _check(lib().rgpu_segment_release_prepared_terms(self._h))

@@ -21,6 +21,7 @@
 
 namespace rgpu {
 
+constexpr int RGPU_MAX_K_DEV = 128;  // = RGPU_MAX_K: the widest list a wavefront's registers hold
 constexpr int PHRASE_LIST_CAP = 1024;  // positions of one term inside one doc that the LDS lists hold
 constexpr int32_t PHRASE_DEAD = (int32_t)0x80000000;
 
@@ -202,6 +203,114 @@ __global__ __launch_bounds__(WG_THREADS) void k_phrase_collect(const int64_t* __
   if (lane < k) out[lane] = top.a ? HitOut{key_doc(top.a) + doc_base, key_score(top.a)} : HitOut{-1, 0.f};
   if (WIDE && lane + 64 < k) out[lane + 64] = top.b ? HitOut{key_doc(top.b) + doc_base, key_score(top.b)} : HitOut{-1, 0.f};
   if (lane == 0) totals_out[q] = total;
+}
+
+// ---- QueryRescorer (search/scorer/rescorer.rs:129-374) with a batched second-pass scorer (the BatchScorer hook, :32-36) ----
+// One wavefront per first-pass hit: the rescore query's scorer is "advanced" to the hit's doc in every clause (block
+// directory -> block -> index: BlockDocIterator::advance) and, where the query matches the doc, its score is combined
+// with the first-pass score: combine_score(:337-352) = mode.combine(first * query_weight, second * rescore_weight),
+// first * query_weight when the query does not match. TERM / all-MUST / all-SHOULD term queries; clause sums in the
+// order their scorers use (conjunction: cost order, the host sorts; disjunction: clause order).
+struct RescoreParams {
+  float query_weight, rescore_weight;
+  int32_t mode;    // RescoreMode: 0 Avg, 1 Max, 2 Min, 3 Total, 4 Multiply (rescorer.rs:97-116)
+  int32_t window;  // hits of the row that are rescored
+};
+
+__device__ __forceinline__ float rescore_combine(int mode, float primary, float secondary) {
+  switch (mode) {
+    case 0: return (primary + secondary) / 2.0f;
+    case 1: return fmaxf(primary, secondary);  // f32::max
+    case 2: return fminf(primary, secondary);
+    case 3: return primary + secondary;
+    default: return primary * secondary;
+  }
+}
+
+template <bool LEGACY>
+__global__ __launch_bounds__(WG_THREADS) void k_rescore(SegView seg, const DevQuery* __restrict__ queries, const DevTerm* __restrict__ terms,
+                                                        const RescoreParams* __restrict__ params, int n_queries, int k,
+                                                        HitOut* __restrict__ hits, int finish) {
+  __shared__ __attribute__((aligned(16))) uint8_t slabs[WG_WAVES][2 * SLAB_STREAM];
+  __shared__ float caches[WG_WAVES][256];
+  const int lane = lane_id();
+  const int wave = wave_id();
+  const int64_t slot = (int64_t)blockIdx.x * WG_WAVES + wave;
+  if (slot >= (int64_t)n_queries * k) return;
+  const int q = (int)(slot / k), i = (int)(slot - (int64_t)q * k);
+  const RescoreParams R = params[q];
+  HitOut* hit = hits + slot;
+  const HitOut h = *hit;
+  if (h.doc < 0) return;
+  const float first = h.score * R.query_weight;
+  if (i >= R.window) {  // combine_docs (:356-374): hits past the window only take the query weight — once, in the finishing call
+    if (lane == 0 && finish) hit->score = first;
+    return;
+  }
+  const int32_t doc = h.doc - seg.doc_base;
+  if (doc < 0 || doc >= seg.max_doc) return;  // another leaf's doc: that leaf's call handles it
+  const DevQuery Q = queries[q];
+  const bool conj = (Q.op & 0xff) != 2;  // TERM / AND: every clause must hold the doc; OR: any
+  uint8_t* slab = slabs[wave];
+  float sum = 0.0f;
+  bool any = false, all = Q.n_terms > 0;
+  int cur_table = -1;
+  float k1 = 0.f;
+  for (int c = 0; c < Q.n_terms; ++c) {
+    const DevTerm T = terms[Q.first_term + c];
+    uint32_t freq = 0;
+    if (T.df == 1) {
+      if (T.singleton_doc == doc) freq = (uint32_t)T.singleton_freq;
+    } else {
+      const int blk = find_block(seg.dir_last, T.dir_base, T.nblocks, doc);
+      int32_t e0, e1;
+      uint32_t g0, g1;
+      bool v0 = true, v1 = true;
+      bool have = true;
+      if (blk < T.nblocks) {
+        const int32_t base = blk == 0 ? 0 : seg.dir_last[T.dir_base + blk - 1];
+        const BlockPair bp = decode_block<LEGACY>(seg.bstore + T.bs_base, seg.dir_row[T.dir_base + blk], seg.dir_hdr[T.dir_base + blk], slab, lane);
+        deltas_to_docs(bp.d0, bp.d1, base, e0, e1);
+        g0 = bp.f0; g1 = bp.f1;
+      } else if (T.tail_n > 0) {
+        tail_load(seg.bstore + T.bs_base, seg.dir_row[T.dir_base + T.nblocks], lane, e0, e1, g0, g1);
+        v0 = 2 * lane < T.tail_n; v1 = 2 * lane + 1 < T.tail_n;
+      } else {
+        have = false; e0 = e1 = 0; g0 = g1 = 0u; v0 = v1 = false;
+      }
+      const uint64_t m0 = __ballot(have && v0 && e0 == doc), m1 = __ballot(have && v1 && e1 == doc);
+      if (m0) freq = (uint32_t)readlane((int)g0, (int)__builtin_ctzll(m0));
+      else if (m1) freq = (uint32_t)readlane((int)g1, (int)__builtin_ctzll(m1));
+    }
+    if (freq == 0u) { all = false; if (conj) break; continue; }
+    any = true;
+    if (T.sim_table != cur_table) { load_sim_table(seg, T.sim_table, caches[wave], lane, k1); cur_table = T.sim_table; }
+    const float nrm = seg.norms != nullptr ? caches[wave][seg.norms[doc]] : k1;
+    sum += bm25_score(T.weight * (k1 + 1.0f), (float)(int32_t)freq, nrm);  // 0.0f + s for the first clause
+  }
+  const bool match = conj ? all : any;
+  if (lane == 0) hit->score = match ? rescore_combine(R.mode, first, sum * R.rescore_weight) : first;
+}
+
+// hits.sort() over the rescored window (rescorer.rs:330: score desc, then doc asc — ScoreDocHit's order,
+// sort_field/collapse_top_docs.rs:186-202), written back to the top of the row: one wavefront per query.
+__global__ __launch_bounds__(WG_THREADS) void k_rescore_sort(const RescoreParams* __restrict__ params, int n_queries, int k, HitOut* __restrict__ hits) {
+  const int lane = lane_id();
+  const int q = (int)(blockIdx.x * WG_WAVES) + wave_id();
+  if (q >= n_queries) return;
+  HitOut* row = hits + (size_t)q * (size_t)k;
+  const int window = min(params[q].window, k);
+  WaveTopK top;
+  uint64_t tau = 0;
+  int n = 0;
+  for (int r = 0; r < window; r += 64) {
+    uint64_t key = 0;
+    if (r + lane < window) { const HitOut h = row[r + lane]; if (h.doc >= 0) key = make_key(h.score, h.doc); }
+    n += __popcll(__ballot(key != 0ull));
+    topk_offer<true>(top, key, tau, RGPU_MAX_K_DEV, lane);
+  }
+  if (lane < n) row[lane] = HitOut{key_doc(top.a), key_score(top.a)};
+  if (lane + 64 < n) row[lane + 64] = HitOut{key_doc(top.b), key_score(top.b)};
 }
 
 }  // namespace rgpu

@@ -1401,6 +1401,92 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
   return RGPU_OK;
 }
 
+// ---- QueryRescorer ------------------------------------------------------------------------------------------------------------
+static_assert(sizeof(RescoreParams) == sizeof(rgpu_rescore_request), "RescoreParams mirrors rgpu_rescore_request");
+extern "C" int32_t rgpu_rescore_batch(rgpu_segment* seg, const rgpu_query* queries, int32_t n_queries, const rgpu_query_term* terms,
+                                      int32_t n_terms_total, const rgpu_rescore_request* requests, int32_t k, rgpu_hit* hits_inout,
+                                      int32_t finish) {
+  if (!seg || !queries || n_queries <= 0 || !terms || n_terms_total <= 0 || !requests || !hits_inout)
+    return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "bad arguments");
+  if (k <= 0 || k > RGPU_MAX_K) return fail(k <= 0 ? RGPU_ERR_ILLEGAL_ARGUMENT : RGPU_ERR_UNSUPPORTED, "k must be in 1..RGPU_MAX_K");
+  rgpu_ctx* c = seg->ctx;
+  std::lock_guard<std::mutex> g(c->mu);
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t stream = c->stream;
+  std::vector<const rgpu_term_state*> ptrs;
+  std::vector<RescoreParams> rp((size_t)n_queries);
+  for (int32_t q = 0; q < n_queries; ++q) {
+    const rgpu_query& Q = queries[q];
+    const int qop = Q.op & 0xff;
+    if (qop < RGPU_OP_TERM || qop > RGPU_OP_OR || (Q.op >> 8) > 1 || Q.n_must_not != 0)
+      return fail(RGPU_ERR_UNSUPPORTED, "rescore queries are TERM, all-MUST or all-SHOULD term queries");
+    if (Q.n_terms < 1 || Q.n_terms > RGPU_MAX_QUERY_TERMS || (qop == RGPU_OP_TERM && Q.n_terms != 1)) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "bad clause count");
+    if (Q.first_term < 0 || (int64_t)Q.first_term + Q.n_terms > (int64_t)n_terms_total) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "clause range outside terms[]");
+    const rgpu_rescore_request& r = requests[q];
+    if (r.mode < RGPU_RESCORE_AVG || r.mode > RGPU_RESCORE_MULTIPLY || r.window_size < 0) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "bad rescore request");
+    rp[(size_t)q] = RescoreParams{r.query_weight, r.rescore_weight, r.mode, std::min(std::min(r.window_size, k), RGPU_MAX_K)};
+    for (int i = 0; i < Q.n_terms; ++i) {
+      const rgpu_query_term& t = terms[Q.first_term + i];
+      if (t.sim_table < 0 || t.sim_table >= c->n_sim_tables) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "unknown sim_table handle");
+      if (t.state.doc_freq > 0) ptrs.push_back(&t.state);
+    }
+  }
+  int32_t rc = prepare_terms_locked(seg, ptrs.data(), ptrs.size());
+  if (rc != RGPU_OK) return rc;
+  std::vector<DevQuery> dq((size_t)n_queries);
+  std::vector<DevTerm> dt;
+  std::vector<DevTerm> mine;
+  for (int32_t q = 0; q < n_queries; ++q) {
+    const rgpu_query& Q = queries[q];
+    const int qop = Q.op & 0xff;
+    mine.clear();
+    bool dead = false;
+    for (int i = 0; i < Q.n_terms; ++i) {
+      const rgpu_query_term& t = terms[Q.first_term + i];
+      if (t.state.doc_freq <= 0) { if (qop != RGPU_OP_OR) dead = true; continue; }  // create_scorer -> None: the query matches nothing here
+      DevTerm d;
+      rc = make_dev_term(seg, t.state, t.weight, t.sim_table, &d);
+      if (rc != RGPU_OK) return rc;
+      mine.push_back(d);
+    }
+    if (dead) mine.clear();
+    if (qop == RGPU_OP_AND) std::stable_sort(mine.begin(), mine.end(), [](const DevTerm& a, const DevTerm& b) { return a.df < b.df; });
+    dq[(size_t)q] = DevQuery{qop, (int32_t)mine.size(), (int32_t)dt.size(), 0};
+    for (auto& m : mine) dt.push_back(m);
+  }
+  HIP_TRY(scratch_take(c));
+  Stager st(c);
+  const size_t o_q = st.add((size_t)n_queries * sizeof(DevQuery));
+  const size_t o_t = st.add(std::max<size_t>(1, dt.size()) * sizeof(DevTerm));
+  const size_t o_r = st.add((size_t)n_queries * sizeof(RescoreParams));
+  HIP_TRY(c->S->h_stage.reserve(st.used));
+  HIP_TRY(c->S->d_stage.reserve(st.used, 0, stream));
+  std::memcpy(c->S->h_stage.p + o_q, dq.data(), (size_t)n_queries * sizeof(DevQuery));
+  if (!dt.empty()) std::memcpy(c->S->h_stage.p + o_t, dt.data(), dt.size() * sizeof(DevTerm));
+  std::memcpy(c->S->h_stage.p + o_r, rp.data(), (size_t)n_queries * sizeof(RescoreParams));
+  HIP_TRY(hipMemcpyAsync(c->S->d_stage.p, c->S->h_stage.p, st.used, hipMemcpyHostToDevice, stream));
+  const size_t n_hits = (size_t)n_queries * (size_t)k;
+  HIP_TRY(c->host_api_hits.reserve(n_hits, 0, stream));
+  HIP_TRY(hipMemcpyAsync(c->host_api_hits.p, hits_inout, n_hits * sizeof(HitOut), hipMemcpyHostToDevice, stream));
+  const DevQuery* d_q = reinterpret_cast<const DevQuery*>(c->S->d_stage.p + o_q);
+  const DevTerm* d_t = reinterpret_cast<const DevTerm*>(c->S->d_stage.p + o_t);
+  RescoreParams* d_r = reinterpret_cast<RescoreParams*>(c->S->d_stage.p + o_r);
+  {
+    TimedLaunch tl(c, stream, "k_rescore", 0);
+    const unsigned grid = (unsigned)((n_hits + WG_WAVES - 1) / WG_WAVES);
+    if (seg->version < 1) hipLaunchKernelGGL(k_rescore<true>, dim3(grid), dim3(WG_THREADS), 0, stream, seg_view(seg), d_q, d_t, d_r, (int)n_queries, (int)k, c->host_api_hits.p, finish ? 1 : 0);
+    else hipLaunchKernelGGL(k_rescore<false>, dim3(grid), dim3(WG_THREADS), 0, stream, seg_view(seg), d_q, d_t, d_r, (int)n_queries, (int)k, c->host_api_hits.p, finish ? 1 : 0);
+  }
+  if (finish) {
+    TimedLaunch tl(c, stream, "k_rescore_sort", 0);
+    hipLaunchKernelGGL(k_rescore_sort, dim3((unsigned)((n_queries + WG_WAVES - 1) / WG_WAVES)), dim3(WG_THREADS), 0, stream, d_r, (int)n_queries, (int)k, c->host_api_hits.p);
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(hits_inout, c->host_api_hits.p, n_hits * sizeof(HitOut), hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipStreamSynchronize(stream));
+  return RGPU_OK;
+}
+
 // ---- segment-sharded search: RCCL all-gather of per-shard top-k + device merge -------------------------------------------
 constexpr int N_COMM_SLOTS = 4;
 struct CommSlot {

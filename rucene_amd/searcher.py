@@ -408,6 +408,20 @@ class GpuIndexSearcher:
             return per_leaf[0]
         return self._merge_leaves(per_leaf, len(queries), k)
 
+    def rescore_batch(self, hits, rescore_queries, query_weight=1.0, rescore_weight=1.0, mode=_lib.RESCORE_TOTAL, window_size=None):
+        """QueryRescorer::rescore (search/scorer/rescorer.rs:376-390) for a batch: row i of `hits` (a first pass's output) is
+        re-ranked by rescore_queries[i] — TermQuery or an all-MUST / all-SHOULD BooleanQuery. One call per leaf, the last
+        one sorts the windows and re-weights the tails."""
+        k = hits.shape[1]
+        req = np.zeros(len(rescore_queries), dtype=_lib.RESCORE_REQUEST_DTYPE)
+        req["query_weight"], req["rescore_weight"], req["mode"] = query_weight, rescore_weight, mode
+        req["window_size"] = k if window_size is None else window_size
+        out = hits
+        for i, leaf in enumerate(self.leaves):
+            qs, ts = self.pack(rescore_queries, leaf)
+            out = leaf.segment.rescore_batch(qs, ts, req, out, finish=(i == len(self.leaves) - 1))
+        return out
+
     def search_batch(self, queries, k):
         """-> (hits[n][k] structured {doc, score}, total_hits[n]) merged over all leaves."""
         per_leaf = []

@@ -913,3 +913,29 @@ def test_elias_fano_and_bitset_doc_blocks(ctx, oracle, with_pf):
         both = np.intersect1d(lists[a], lists[b])
         assert total == both.size
         assert set(row["doc"][row["doc"] >= 0]) <= set(both.tolist())
+
+
+def test_query_rescorer(zipf, oracle):
+    """SURVEY 8(f)4, the BatchScorer / rescorer hook: QueryRescorer::rescore (search/scorer/rescorer.rs) — the top window of a
+    first pass re-scored by a second query, every RescoreMode, windows shorter than the row, second queries that match all,
+    some or none of the hits — against the oracle's restatement (iterative_rescore + combine_docs), bit for bit."""
+    import rucene_amd
+    from rucene_amd import _lib as gpu
+    seg, osearcher, gsearcher = zipf
+    T, B = rucene_amd.TermQuery, rucene_amd.BooleanQuery
+    first = [T(0), T(3), B.build([], [T(1), T(7), T(40)]), B.build([T(2), T(5)], []), T(11), T(49_999)]
+    k = 100
+    hits, totals = gsearcher.search_batch(first, k)
+    seconds = [(oracle.OP_TERM, [1]), (oracle.OP_AND, [0, 2]), (oracle.OP_OR, [3, 9, 200]), (oracle.OP_TERM, [48_000]), (oracle.OP_OR, [0, 1]),
+               (oracle.OP_AND, [0, 1, 2])]
+    gq = [T(t[0]) if op == oracle.OP_TERM else (B.build([T(x) for x in t], []) if op == oracle.OP_AND else B.build([], [T(x) for x in t]))
+          for op, t in seconds]
+    for mode in range(5):
+        for window, qw, rw in ((k, 1.0, 1.0), (10, 0.7, 2.5), (37, 1.3, 0.25)):
+            got = gsearcher.rescore_batch(hits, gq, query_weight=qw, rescore_weight=rw, mode=mode, window_size=window)
+            for i, (op, tids) in enumerate(seconds):
+                n = int((hits[i]["doc"] >= 0).sum())
+                wd, ws = osearcher.rescore(op, tids, hits[i]["doc"][:n], hits[i]["score"][:n], window, qw, rw, mode)
+                assert (got[i]["doc"][:n] == wd).all(), (mode, window, i)
+                assert (got[i]["score"][:n].view(np.int32) == ws.view(np.int32)).all(), (mode, window, i)
+                assert (got[i]["doc"][n:] == -1).all()
