@@ -50,6 +50,11 @@ def profiled_traffic(kernel, tag):
     2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes. The factor 2 is MI355X_MICROARCH.md's gfx950 correction (FETCH_SIZE
     tallies the 128-byte requests of wide 16-byte-per-lane streaming reads at 64 bytes — these kernels' row loads);
     WRITE_SIZE is taken as reported. None when no such profile is committed — bench.py never runs rocprof."""
+    if " + " in kernel:  # several kernels per batch (OR): their per-launch traffic summed
+        parts = [profiled_traffic(x, tag) for x in kernel.split(" + ")]
+        if any(x is None for x in parts):
+            return None
+        return {"bytes": sum(x["bytes"] for x in parts), "source": parts[0]["source"]}
     best = None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "%s_rocprofv3_summary.txt" % tag))):
         fetch = write = None
@@ -237,7 +242,10 @@ def main():
         for _ in range(steps):
             step(packed, 1)
         torch.cuda.synchronize()
-        res["kernels_ms"] = {n: s["total_ms"] / max(1, s["launches"]) for n, s in ctx.kernel_stats().items()}
+        stats = ctx.kernel_stats()
+        res["kernels_ms"] = {n: s["total_ms"] / max(1, s["launches"]) for n, s in stats.items()}  # average per launch
+        res["kernels_ms_per_step"] = {n: s["total_ms"] / steps for n, s in stats.items()}
+        res["launches_per_step"] = {n: s["launches"] / steps for n, s in stats.items()}
         ctx.set_profiling(False)
         ctx.kernel_stats_reset()
         res["g_hits"] = merged["hits"].cpu().numpy().view(rucene_amd.HIT_DTYPE).reshape(nq, k).copy()
@@ -388,7 +396,9 @@ def main():
             c["roofline"]["note"] = "achieved = touched bytes / kernel_ms; scan_equivalent_frac = scan bytes / kernel_ms"
         else:
             c["algorithmic_bytes"] = r["algo_bytes"]
-            kms = sum(v for n, v in r["kernels_ms"].items() if n in ("k_score_terms", "k_or_windows"))
+            c["kernels_ms_per_step"] = r["kernels_ms_per_step"]
+            c["launches_per_step"] = r["launches_per_step"]
+            kms = sum(v for n, v in r["kernels_ms_per_step"].items() if n in ("k_score_terms", "k_or_windows"))
             c["roofline"] = roofline("k_score_terms + k_or_windows", kms, r["algo_bytes"], PROFILE_TAG[kind])
             c["roofline"]["note"] = "achieved = scan bytes (all ten lists + norms) / summed duration of the OR kernels per batch"
         if not args.no_cpu_baseline:
