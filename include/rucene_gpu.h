@@ -54,12 +54,15 @@ typedef struct rgpu_config {
   int32_t blocks_per_item;      /* 128-posting blocks per wave work item in the TERM kernel (0 = auto: 8..512 by batch size) */
   int32_t and_blocks_per_item;  /* lead blocks per wave work item of the AND kernel (0 = default 4) */
   int32_t profile_kernels;      /* 1 = bracket every kernel with HIP events from the start (see rgpu_set_profiling) */
-  int32_t or_window_docs;       /* docs per wave window of the OR kernel (0 = default 2048; 256..4096, rounded to 256) */
+  int32_t or_window_docs;       /* docs per wave window of the ordered OR kernel (0 = default 1024; 256..4096, rounded to 256) */
   int32_t or_dense_clauses;     /* OR: clauses decoded inside the window kernel instead of through a scored run
                                    (0 = default 4, -1 = none; at most 4) */
   int32_t raw_norms;            /* 1 keeps raw norm bytes in HBM even when <= 64 distinct values exist (disables the
                                    per-clause LDS score table and everything built on it; A/B testing) */
-  int32_t reserved[9];          /* must be zero */
+  int32_t or_wide;              /* disjunctions of >= 10 SHOULD clauses (where the reference itself sums in heap order) through the
+                                   order-free workgroup-window kernel: 0 = yes (default), -1 = no (clause-order kernel for all) */
+  int32_t or_wide_window_docs;  /* docs per workgroup window of that kernel (0 = default 12288; 2048..14336, rounded to 2048) */
+  int32_t reserved[7];          /* must be zero */
 } rgpu_config;
 
 /* blocktree/mod.rs:33-59 BlockTermState, as filled by posting_reader.rs:264-306 lucene50_decode_term.

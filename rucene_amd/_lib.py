@@ -66,7 +66,8 @@ class RgpuError(RuntimeError):
 class _Config(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("blocks_per_item", C.c_int32), ("and_blocks_per_item", C.c_int32),
                 ("profile_kernels", C.c_int32), ("or_window_docs", C.c_int32), ("or_dense_clauses", C.c_int32),
-                ("raw_norms", C.c_int32), ("reserved", C.c_int32 * 9)]
+                ("raw_norms", C.c_int32), ("or_wide", C.c_int32), ("or_wide_window_docs", C.c_int32),
+                ("reserved", C.c_int32 * 7)]
 
 
 class _KernelStat(C.Structure):
@@ -313,7 +314,7 @@ class Context:
     """rgpu_ctx: one per process per GPU."""
 
     def __init__(self, device=0, profile_kernels=False, blocks_per_item=0, and_blocks_per_item=0, or_window_docs=0,
-                 raw_norms=False, or_dense_clauses=0):
+                 raw_norms=False, or_dense_clauses=0, or_wide=0, or_wide_window_docs=0):
         cfg = _Config()
         cfg.abi_version = ABI_VERSION
         cfg.blocks_per_item = blocks_per_item
@@ -322,6 +323,8 @@ class Context:
         cfg.or_window_docs = or_window_docs
         cfg.or_dense_clauses = or_dense_clauses
         cfg.raw_norms = int(raw_norms)
+        cfg.or_wide = or_wide
+        cfg.or_wide_window_docs = or_wide_window_docs
         h = C.c_void_p()
         _check(lib().rgpu_init(device, C.byref(cfg), C.byref(h)))
         self._h = h

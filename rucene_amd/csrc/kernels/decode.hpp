@@ -333,17 +333,16 @@ __device__ __forceinline__ void stream_blocks(const uint8_t* __restrict__ term_r
 
 // ---- a term's tail as the query kernels see it -------------------------------------------------------------------
 // k_prepare_blocks decodes every term's VInt tail ONCE (decode_tail below), validates it and leaves it in the block
-// store behind the term's FullBlock rows as plain arrays — 128 absolute doc ids, then 128 freqs (TAIL_STORE_ROWS rows;
-// the tail starts at row dir_row[nblocks] of the term). Query kernels read postings 2*lane, 2*lane+1 with two 8-byte
-// loads: no byte-serial VInt parsing and none of its ~15 registers in any scoring kernel.
-constexpr int TAIL_STORE_ROWS = 64;  // 2 x 128 x 4 bytes
+// store behind the term's FullBlock rows as 64 cells of 16 bytes — cell `lane` = {doc 2*lane, doc 2*lane+1, freq 2*lane,
+// freq 2*lane+1}, absolute doc ids, INT_MAX / 0 past the tail's end (TAIL_STORE_ROWS rows; the tail starts at row
+// dir_row[nblocks] of the term). Query kernels read their two postings with one 16-byte load: no byte-serial VInt
+// parsing and none of its ~15 registers in any scoring kernel.
+constexpr int TAIL_STORE_ROWS = 64;  // 64 lanes x 16 bytes
 __device__ __forceinline__ void tail_load(const uint8_t* __restrict__ term_rows, uint32_t tail_row, int lane, int32_t& doc0, int32_t& doc1,
                                           uint32_t& f0, uint32_t& f1) {
-  const uint8_t* p = term_rows + 16 * (size_t)tail_row;
-  const uint2 d = *reinterpret_cast<const uint2*>(p + 8 * lane);
-  const uint2 f = *reinterpret_cast<const uint2*>(p + 512 + 8 * lane);
-  doc0 = (int32_t)d.x; doc1 = (int32_t)d.y;
-  f0 = f.x; f1 = f.y;
+  const uint4 c = *reinterpret_cast<const uint4*>(term_rows + 16 * (size_t)tail_row + 16 * lane);
+  doc0 = (int32_t)c.x; doc1 = (int32_t)c.y;
+  f0 = c.z; f1 = c.w;
 }
 
 // ---- VInt tail (< 128 postings) -------------------------------------------------------------------------------

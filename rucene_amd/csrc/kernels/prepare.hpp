@@ -260,7 +260,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_blocks(const uint8_t* 
   const int b1 = min(t.nblocks, b0 + PREP_BLOCKS_PER_ITEM);
   uint8_t* term_rows = bstore + t.bs_base;
   // the term's last item also takes its VInt tail (posting_reader.rs:308-333): decoded here once, checked like the blocks
-  // (doc ids strictly increasing from the last FullBlock's last doc, inside the segment) and stored as plain arrays
+  // (doc ids strictly increasing from the last FullBlock's last doc, inside the segment) and stored as 16-byte cells (tail_load)
   const int tail_n = t.df > 1 ? t.df % 128 : 0;
   if (tail_n > 0 && b0 + PREP_BLOCKS_PER_ITEM >= t.nblocks) {
     const uint32_t toff = t.nblocks ? dir_off[t.dir_base + t.nblocks] : 0u;
@@ -274,8 +274,14 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_blocks(const uint8_t* 
     const bool bad = (v0 && (!first_ok || d0 >= max_doc)) || (v1 && (d1 <= d0 || d1 >= max_doc));
     if (__ballot(bad)) { if (lane == 0) flag_err(err, -4, 13); return; }
     uint8_t* tp = term_rows + 16 * (size_t)dir_row[t.dir_base + t.nblocks];
-    *reinterpret_cast<uint2*>(tp + 8 * lane) = make_uint2(v0 ? (uint32_t)d0 : 0x7fffffffu, v1 ? (uint32_t)d1 : 0x7fffffffu);
-    *reinterpret_cast<uint2*>(tp + 512 + 8 * lane) = make_uint2(v0 ? f0 : 0u, v1 ? f1 : 0u);
+    *reinterpret_cast<uint4*>(tp + 16 * lane) = make_uint4(v0 ? (uint32_t)d0 : 0x7fffffffu, v1 ? (uint32_t)d1 : 0x7fffffffu, v0 ? f0 : 0u, v1 ? f1 : 0u);
+    // the tail's directory slot gets its last doc, like a FullBlock's: the wide OR kernel walks tails as one more block
+    const int32_t tail_last = readlane(((tail_n - 1) & 1) ? d1 : d0, (tail_n - 1) >> 1);
+    if (lane == 0) dir_last[t.dir_base + t.nblocks] = tail_last;
+    if (norms != nullptr) {  // ... and its posting-order norms continue the FullBlocks'
+      const uint32_t n0 = v0 ? norms[d0] : 0u, n1 = v1 ? norms[d1] : 0u;
+      *reinterpret_cast<uint16_t*>(pnorm + t.pn_base + 128 * (uint64_t)t.nblocks + 2 * lane) = (uint16_t)(n0 | (n1 << 8));
+    }
   }
   for (int blk = b0; blk < b1; ++blk) {
     uint32_t hdr = dir_hdr[t.dir_base + blk];

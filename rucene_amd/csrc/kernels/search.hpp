@@ -76,7 +76,9 @@ __global__ __launch_bounds__(WG_THREADS) void k_merge_items(const int64_t* __res
                                                             const uint64_t* __restrict__ partial_keys,
                                                             const int32_t* __restrict__ partial_counts, int32_t doc_base,
                                                             int head_items, HitOut* __restrict__ hits_out,
-                                                            int64_t* __restrict__ totals_out) {
+                                                            int64_t* __restrict__ totals_out,
+                                                            const int2* __restrict__ fixed_info = nullptr,
+                                                            int32_t* __restrict__ low_flags = nullptr) {
   const int lane = lane_id();
   const int q = (int)(blockIdx.x * WG_WAVES) + wave_id();
   if (q >= n_queries) return;
@@ -107,6 +109,19 @@ __global__ __launch_bounds__(WG_THREADS) void k_merge_items(const int64_t* __res
     }
   }
   HitOut* out = hits_out + (size_t)q * (size_t)k;
+  if (fixed_info != nullptr) {
+    // k_or_wide's keys: the high word is a fixed-point total (search_or_wide.hpp). score = total * 2^-e, rounded to f32
+    // once; a hit whose total is below the query's floor asks for the f32 path (low_flags)
+    const int2 info = fixed_info[q];
+    auto score_of = [&](uint64_t key) { return (float)ldexp((double)(uint32_t)(key >> 32), -info.x); };
+    if (lane < k) out[lane] = top.a ? HitOut{key_doc(top.a) + doc_base, score_of(top.a)} : HitOut{-1, 0.f};
+    if (WIDE && lane + 64 < k) out[lane + 64] = top.b ? HitOut{key_doc(top.b) + doc_base, score_of(top.b)} : HitOut{-1, 0.f};
+    const bool low = (lane < k && top.a != 0 && (uint32_t)(top.a >> 32) < (uint32_t)info.y) ||
+                     (WIDE && lane + 64 < k && top.b != 0 && (uint32_t)(top.b >> 32) < (uint32_t)info.y);
+    const uint64_t any_low = __ballot(low);
+    if (lane == 0) { totals_out[q] = total; low_flags[q] = any_low ? 1 : 0; }
+    return;
+  }
   if (lane < k) out[lane] = top.a ? HitOut{key_doc(top.a) + doc_base, key_score(top.a)} : HitOut{-1, 0.f};
   if (WIDE && lane + 64 < k) out[lane + 64] = top.b ? HitOut{key_doc(top.b) + doc_base, key_score(top.b)} : HitOut{-1, 0.f};
   if (lane == 0) totals_out[q] = total;

@@ -23,6 +23,7 @@
 #include "kernels/search.hpp"
 #include "kernels/search_and.hpp"
 #include "kernels/search_or.hpp"
+#include "kernels/search_or_wide.hpp"
 #include "kernels/search_phrase.hpp"
 #include "kernels/search_term.hpp"
 
@@ -126,6 +127,9 @@ struct rgpu_ctx {
   DevVec<float> sim_tables;
   int n_sim_tables = 0;
   std::vector<uint8_t> sim_monotone;  // per table: cache[] finite, >= 0 and non-increasing in the norm byte
+  int64_t or_wide_redone = 0;         // queries k_or_wide handed back to the f32 kernel (fixed-point floor); tests read it
+  std::vector<float> sim_k1;          // per table: k1
+  std::vector<uint8_t> sim_nonneg;    // per table: k1 and every cache[] entry finite and >= 0 (a score is then within [0, weight * (k1 + 1)])
   // Per-call scratch, in rotating slots: a search call only enqueues work (staging copy + kernels) on its stream
   // and marks its slot with an event; the slot is waited for when its turn comes again, so the host prepares batch
   // i+1 while the GPU runs batch i and a caller synchronizes the stream once, when it wants the results.
@@ -172,7 +176,7 @@ struct rgpu_segment {
   size_t dir_used = 0;
   DevVec<uint8_t> bstore;  // 16-byte aligned FullBlock payload rows of every prepared term (SegView::bstore)
   size_t bstore_used = 0;
-  DevVec<uint8_t> pnorm;  // posting-order norms of every prepared term's FullBlocks
+  DevVec<uint8_t> pnorm;  // posting-order norms of every prepared term's FullBlocks and tail
   size_t pnorm_used = 0;
   std::unordered_map<int64_t, TermInfo> prepared;
 };
@@ -344,14 +348,14 @@ static int32_t prepare_terms_attempt(rgpu_segment* seg, const rgpu_term_state* c
     // header bytes dropped, each all-equal VInt padded to a 16-byte row); the FullBlocks end before the skip data
     const uint64_t span = st.doc_freq > 128 ? (uint64_t)st.skip_offset : (p.nblocks ? 1026u : 0u);
     // (a docs-only field: one header byte dropped, a synthetic 16-byte freq row added per block);
-    // + the decoded tail: 128 doc ids and 128 freqs as plain arrays behind the block rows
+    // + the decoded tail: 64 cells {doc, doc, freq, freq} behind the block rows
     const uint64_t rows = (wide ? 64u * (uint64_t)p.nblocks : (span + (seg->has_freqs ? 28u : 32u) * (uint64_t)p.nblocks + 15u) / 16u) +
                           ((st.doc_freq % 128) ? (uint64_t)TAIL_STORE_ROWS : 0u);
     if (rows > 0xffffffffull) return fail(RGPU_ERR_UNSUPPORTED, "a single term's postings exceed 64 GiB");
     p.bs_base = (uint64_t)need_bs;
     p.bs_rows = (uint32_t)rows;
     need_slots += (size_t)p.nblocks + 1;
-    need_pn += (size_t)p.nblocks * 128;
+    need_pn += ((size_t)p.nblocks + ((st.doc_freq % 128) ? 1u : 0u)) * 128;  // the tail's norms follow the FullBlocks' 
     need_bs += (size_t)rows * 16;
     if (need_slots > 0xfffffff0ull) return fail(RGPU_ERR_UNSUPPORTED, "block directory exceeds 2^32 slots");
     work.push_back(p);
@@ -579,6 +583,10 @@ extern "C" int32_t rgpu_sim_table_upload(rgpu_ctx* c, const float cache[256], fl
   bool mono = k1 >= 0.0f;
   for (int i = 0; i < 256 && mono; ++i) mono = cache[i] >= 0.0f && cache[i] <= 3.0e38f && (i == 0 || cache[i] <= cache[i - 1]);
   c->sim_monotone.push_back(mono ? 1 : 0);
+  bool nonneg = k1 >= 0.0f && k1 <= 3.0e38f;
+  for (int i = 0; i < 256 && nonneg; ++i) nonneg = cache[i] >= 0.0f && cache[i] <= 3.0e38f;
+  c->sim_k1.push_back(k1);
+  c->sim_nonneg.push_back(nonneg ? 1 : 0);
   return c->n_sim_tables++;
 }
 
@@ -803,6 +811,7 @@ extern "C" int32_t rgpu_advance_batch(rgpu_segment* seg, const rgpu_term_state* 
 namespace {
 struct Group {  // queries of one op, in their original order
   int op = 0;
+  bool or_wide = false;         // OR queries of >= 10 clauses: the order-free workgroup-window kernel
   std::vector<int32_t> qmap;    // original query index
   std::vector<DevQuery> queries;
   std::vector<DevTerm> terms;
@@ -813,11 +822,11 @@ struct Group {  // queries of one op, in their original order
 
 template <bool WIDE>
 static void launch_merge(rgpu_ctx* c, hipStream_t s, int n_queries, int k, const int64_t* d_prefix, int32_t doc_base, HitOut* hits,
-                         int64_t* totals, int head_items = 0) {
+                         int64_t* totals, int head_items = 0, const int2* fixed_info = nullptr, int32_t* low_flags = nullptr) {
   TimedLaunch tl(c, s, "k_merge_items", 0);
   const unsigned grid = (unsigned)((n_queries + WG_WAVES - 1) / WG_WAVES);
   hipLaunchKernelGGL(k_merge_items<WIDE>, dim3(grid), dim3(WG_THREADS), 0, s, d_prefix, n_queries, k, c->S->d_partial_keys.p,
-                     c->S->d_partial_counts.p, doc_base, head_items, hits, totals);
+                     c->S->d_partial_counts.p, doc_base, head_items, hits, totals, fixed_info, low_flags);
 }
 
 // OR: score every clause once into {doc, score} runs, then accumulate per doc-id window (kernels/search_or.hpp)
@@ -951,6 +960,131 @@ static int32_t search_or_group(rgpu_segment* seg, Group& G, int32_t k, HitOut* h
   return RGPU_OK;
 }
 
+// OR with >= 10 SHOULD clauses (the reference sums those in heap order: any order is within its own spec): one launch of
+// k_or_wide (kernels/search_or_wide.hpp), nothing materialised in HBM
+static int32_t search_or_wide_group(rgpu_segment* seg, Group& G, int32_t k, HitOut* hits_dev, int64_t* totals_dev, hipStream_t stream) {
+  rgpu_ctx* c = seg->ctx;
+  const int nq = (int)G.queries.size();
+  const int nt = (int)G.terms.size();
+  const bool wide = k > 64;
+  const bool legacy = seg->version < 1;
+  if (nt == 0) return RGPU_OK;
+  HIP_TRY(scratch_take(c));
+  int WS = c->cfg.or_wide_window_docs > 0 ? (c->cfg.or_wide_window_docs + 2047) / 2048 * 2048 : 12288;
+  WS = std::min(14336, std::max(2048, WS));
+  static_assert(14336 <= ORX_MAX_WINDOW, "a window's blocks of one clause fit the directory look-ahead");
+  // score tables for the (up to) ORX_TABLES longest lists of each query
+  for (DevQuery& dq : G.queries) {
+    uint32_t mask = 0;
+    for (int pick = 0; pick < ORX_TABLES; ++pick) {
+      int best = -1;
+      for (int i = 0; i < dq.n_terms; ++i) {
+        const DevTerm& t = G.terms[(size_t)(dq.first_term + i)];
+        if (((mask >> i) & 1u) || t.nblocks < 1) continue;
+        if (best < 0 || t.df > G.terms[(size_t)(dq.first_term + best)].df) best = i;
+      }
+      if (best < 0) break;
+      mask |= 1u << best;
+    }
+    dq.op = (dq.op & 0xffff) | (int32_t)(mask << 16);
+  }
+  // fixed point: a posting's score is at most weight * (k1 + 1) (times f32 rounding): 2^e times the sum of those bounds
+  // stays below 2^31 - 64; a returned total below n * ORX_FLOOR_PER_CLAUSE steps sends the query through the f32 kernel
+  std::vector<int32_t> fixed_info((size_t)nq * 2);
+  for (int q = 0; q < nq; ++q) {
+    DevQuery& dq = G.queries[(size_t)q];
+    double bound = 0.0;
+    for (int i = 0; i < dq.n_terms; ++i) {
+      const DevTerm& t = G.terms[(size_t)(dq.first_term + i)];
+      bound += (double)t.weight * ((double)c->sim_k1[(size_t)t.sim_table] + 1.0) * 1.000001;
+    }
+    int e = 100;
+    if (bound > 0.0) e = std::min(100, (int)std::floor(std::log2((2147483648.0 - 64.0) / bound)));
+    dq.pad = e;
+    fixed_info[(size_t)q * 2] = e;
+    fixed_info[(size_t)q * 2 + 1] = (int32_t)(dq.n_terms * (int)ORX_FLOOR_PER_CLAUSE);
+  }
+  // items = (query, group of windows), one per workgroup: enough of them to fill the chip a few times over
+  const int wpq = std::max(1, (int)(((int64_t)seg->max_doc + WS - 1) / WS));
+  int ipq = std::min(wpq, std::max(1, (4096 + nq - 1) / nq));
+  const int wpi = (wpq + ipq - 1) / ipq;
+  ipq = (wpq + wpi - 1) / wpi;
+  const int64_t lists = (int64_t)nq * ipq * ORX_WAVES;  // one top-k list per wavefront
+  std::vector<int64_t> merge_prefix((size_t)nq + 1);
+  for (int q = 0; q <= nq; ++q) merge_prefix[(size_t)q] = (int64_t)q * ipq * ORX_WAVES;
+
+  Stager st(c);
+  const size_t o_q = st.add((size_t)nq * sizeof(DevQuery));
+  const size_t o_t = st.add((size_t)nt * sizeof(DevTerm));
+  const size_t o_mp = st.add((size_t)(nq + 1) * 8);
+  const size_t o_m = st.add((size_t)nq * 4);
+  const size_t o_fi = st.add((size_t)nq * 8);
+  const size_t o_fl = st.add((size_t)nq * 4);  // written by k_merge_items, read back below
+  HIP_TRY(c->S->h_stage.reserve(st.used));
+  HIP_TRY(c->S->d_stage.reserve(st.used, 0, stream));
+  std::memcpy(c->S->h_stage.p + o_q, G.queries.data(), (size_t)nq * sizeof(DevQuery));
+  std::memcpy(c->S->h_stage.p + o_t, G.terms.data(), (size_t)nt * sizeof(DevTerm));
+  std::memcpy(c->S->h_stage.p + o_mp, merge_prefix.data(), (size_t)(nq + 1) * 8);
+  std::memcpy(c->S->h_stage.p + o_m, G.qmap.data(), (size_t)nq * 4);
+  std::memcpy(c->S->h_stage.p + o_fi, fixed_info.data(), (size_t)nq * 8);
+  std::memset(c->S->h_stage.p + o_fl, 0, (size_t)nq * 4);
+  HIP_TRY(hipMemcpyAsync(c->S->d_stage.p, c->S->h_stage.p, st.used, hipMemcpyHostToDevice, stream));
+  HIP_TRY(c->S->d_tau.reserve((size_t)nq, 0, stream));
+  HIP_TRY(hipMemsetAsync(c->S->d_tau.p, 0, (size_t)nq * 8, stream));
+  HIP_TRY(c->S->d_partial_keys.reserve((size_t)lists * (size_t)k, 0, stream));
+  HIP_TRY(c->S->d_partial_counts.reserve((size_t)lists, 0, stream));
+  HIP_TRY(c->S->d_hits.reserve((size_t)nq * (size_t)k, 0, stream));
+  HIP_TRY(c->S->d_totals.reserve((size_t)nq, 0, stream));
+  const DevQuery* dq = reinterpret_cast<const DevQuery*>(c->S->d_stage.p + o_q);
+  const DevTerm* dt = reinterpret_cast<const DevTerm*>(c->S->d_stage.p + o_t);
+  const int64_t* dmp = reinterpret_cast<const int64_t*>(c->S->d_stage.p + o_mp);
+  const int32_t* dm = reinterpret_cast<const int32_t*>(c->S->d_stage.p + o_m);
+  const SegView sv = seg_view(seg);
+  {
+    TimedLaunch tl(c, stream, "k_or_wide", G.postings);
+    const size_t lds = orx_lds_bytes(WS);
+    const unsigned grid = (unsigned)((int64_t)nq * ipq);
+    auto go = [&](auto kern) -> hipError_t {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(ORX_THREADS), lds, stream, sv, dq, dt, nq, wpq, wpi, ipq, WS, (int)k,
+                         c->S->d_partial_keys.p, c->S->d_partial_counts.p, c->S->d_tau.p);
+      return hipSuccess;
+    };
+    if (legacy) HIP_TRY(wide ? go(k_or_wide<true, true>) : go(k_or_wide<true, false>));
+    else HIP_TRY(wide ? go(k_or_wide<false, true>) : go(k_or_wide<false, false>));
+  }
+  const int2* dfi = reinterpret_cast<const int2*>(c->S->d_stage.p + o_fi);
+  int32_t* dfl = reinterpret_cast<int32_t*>(c->S->d_stage.p + o_fl);
+  if (wide) launch_merge<true>(c, stream, nq, k, dmp, seg->doc_base, c->S->d_hits.p, c->S->d_totals.p, 0, dfi, dfl);
+  else launch_merge<false>(c, stream, nq, k, dmp, seg->doc_base, c->S->d_hits.p, c->S->d_totals.p, 0, dfi, dfl);
+  hipLaunchKernelGGL(k_scatter_rows, dim3((unsigned)nq), dim3(128), 0, stream, c->S->d_hits.p, c->S->d_totals.p, dm, (int)k, hits_dev, totals_dev);
+  HIP_TRY(hipGetLastError());
+  std::vector<int32_t> low((size_t)nq);
+  HIP_TRY(hipMemcpyAsync(low.data(), dfl, (size_t)nq * 4, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipStreamSynchronize(stream));  // staging / scratch buffers are reused by the next group
+  // queries whose top-k reaches below the fixed-point floor: once more, summed in f32 in clause order (their rows are
+  // simply written again)
+  Group redo;
+  redo.op = RGPU_OP_OR;
+  for (int q = 0; q < nq; ++q) {
+    if (!low[(size_t)q]) continue;
+    DevQuery dq2 = G.queries[(size_t)q];
+    dq2.op &= 0xffff;
+    dq2.pad = 0;
+    const int first = dq2.first_term;
+    dq2.first_term = (int32_t)redo.terms.size();
+    for (int i = 0; i < dq2.n_terms; ++i) { redo.terms.push_back(G.terms[(size_t)(first + i)]); redo.postings += G.terms[(size_t)(first + i)].df; }
+    redo.qmap.push_back(G.qmap[(size_t)q]);
+    redo.queries.push_back(dq2);
+  }
+  if (!redo.queries.empty()) {
+    c->or_wide_redone += (int64_t)redo.queries.size();
+    return search_or_group(seg, redo, k, hits_dev, totals_dev, stream);
+  }
+  return RGPU_OK;
+}
+
 static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t n_queries, const rgpu_query_term* terms,
                            int32_t n_terms_total, int32_t k, HitOut* hits_dev, int64_t* totals_dev, hipStream_t stream) {
   rgpu_ctx* c = seg->ctx;
@@ -980,9 +1114,12 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
   // one group per op; OR groups are cut so that a group's scored runs stay below ~24 GiB of HBM scratch (288 GB per GPU; with the
   // dense clauses decoded inside the window kernel only about a third of a Zipfian batch's postings go through a run at all)
   const int64_t or_postings_cap = 3000000000LL;
-  std::vector<Group> groups(3);
+  std::vector<Group> groups(4);
   int cur_group[3] = {0, 1, 2};
   for (int i = 0; i < 3; ++i) groups[(size_t)i].op = i;
+  groups[3].op = RGPU_OP_OR;  // disjunctions the reference sums in heap order (>= 10 sub-scorers): k_or_wide
+  groups[3].or_wide = true;
+  const bool or_wide_ok = c->cfg.or_wide >= 0 && seg->d_norms && seg->n_norm_ranks > 0 && !seg->d_live;
   std::vector<DevTerm> mine, mine_not, mine_opt;
   for (int32_t q = 0; q < n_queries; ++q) {
     const rgpu_query& Q = queries[q];
@@ -1027,12 +1164,17 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
       std::stable_sort(mine.begin(), mine.end(), [](const DevTerm& a, const DevTerm& b) { return a.df < b.df; });
     // a term with prohibited / optional clauses runs as a one-clause conjunction (the lead-driven kernel probes them)
     const int gop = (qop == RGPU_OP_TERM && (!mine_not.empty() || !mine_opt.empty())) ? (int)RGPU_OP_AND : qop;
-    if (gop == RGPU_OP_OR && groups[(size_t)cur_group[2]].postings > or_postings_cap) {
+    // disjunction_scorer.rs:41-45: >= 10 children and min_should_match <= 1 -> the heap; weights must be >= +0 (the
+    // kernel's "untouched" accumulator is -0.0f)
+    bool to_wide = or_wide_ok && gop == RGPU_OP_OR && mine.size() >= 10 && qmsm <= 1 && mine_not.empty();
+    for (size_t i = 0; to_wide && i < mine.size(); ++i)  // scores within [0, weight * (k1 + 1)]: what the fixed-point scale relies on
+      to_wide = !std::signbit(mine[i].weight) && mine[i].weight <= 3.0e38f && c->sim_nonneg[(size_t)mine[i].sim_table];
+    if (gop == RGPU_OP_OR && !to_wide && groups[(size_t)cur_group[2]].postings > or_postings_cap) {
       groups.emplace_back();
       groups.back().op = RGPU_OP_OR;
       cur_group[2] = (int)groups.size() - 1;
     }
-    Group& G = groups[(size_t)cur_group[gop]];
+    Group& G = to_wide ? groups[3] : groups[(size_t)cur_group[gop]];
     DevQuery dq;
     // the window kernel reads min_should_match from the second byte, the conjunction kernel its optional clause count
     // from the third; device clause order: MUST, MUST_NOT, SHOULD
@@ -1060,7 +1202,8 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
     const int nq = (int)G.queries.size();
     if (nq == 0) continue;
     if (op == RGPU_OP_OR) {
-      int32_t rc_or = search_or_group(seg, G, k, hits_dev, totals_dev, stream);
+      int32_t rc_or = G.or_wide ? search_or_wide_group(seg, G, k, hits_dev, totals_dev, stream)
+                                : search_or_group(seg, G, k, hits_dev, totals_dev, stream);
       if (rc_or != RGPU_OK) return rc_or;
       continue;
     }

@@ -323,6 +323,53 @@ def test_work_partitioning_knobs_do_not_change_answers(oracle, knobs):
         ctx2.close()
 
 
+@pytest.mark.parametrize("knobs", [dict(), dict(or_wide_window_docs=2048), dict(or_wide_window_docs=14336), dict(or_wide=-1)])
+def test_wide_disjunctions(oracle, knobs):
+    """>= 10 SHOULD clauses: the order-free workgroup-window kernel (k_or_wide). Hit counts exact, scores within the
+    reference's own 1e-5 (it sums such disjunctions in heap order). Singletons, tail-only lists, lists that hold every
+    doc (more than 64 blocks per wavefront per window), duplicate clauses, absent terms, a last window cut by max_doc."""
+    import rucene_amd
+    from rucene_amd import indexgen
+    max_doc = 41_003
+    rng = np.random.default_rng(4242)
+    dfs = (1, 1, 5, 100, 127, 128, 129, 300, 3000, 20_000, 39_000, max_doc, 35_000, 38_000, 1, 256, 2, 640)
+    lists = [_postings(rng, df, max_doc) for df in dfs]
+    lists[14] = (lists[0][0].copy(), np.array([3], np.int32))  # a second singleton on the same doc as term 0
+    lists.append((np.zeros(0, np.int32), np.zeros(0, np.int32)))  # term 18: absent
+    lists[7] = (lists[7][0], rng.integers(1, 2000, size=300).astype(np.int32))  # freqs beyond the score table, formula clause
+    f12 = lists[12][1].copy()
+    f12[rng.choice(f12.size, size=350, replace=False)] = 57                     # ... and inside a clause that has a table
+    lists[12] = (lists[12][0], f12)
+    norms = rng.integers(90, 130, size=max_doc).astype(np.uint8)
+    seg = indexgen.build_explicit(max_doc, lists, norms=norms)
+    oseg = oracle.Segment(seg.doc_bytes, seg.norms, max_doc, seg.terms, sum_total_term_freq=60 * max_doc)
+    osearcher = oracle.Searcher([oseg])
+    ctx2 = rucene_amd.Context(profile_kernels=True, **knobs)
+    try:
+        leaf = rucene_amd.LeafReader(seg.doc_bytes, seg.norms, max_doc, seg.terms, sum_total_term_freq=60 * max_doc)
+        gsearcher = rucene_amd.GpuIndexSearcher([leaf], ctx=ctx2)
+        if knobs.get("or_wide", 0) == 0:
+            # the fixed-point floor: three rare terms (idf ~ 10) next to a term every doc holds (idf ~ 1e-5) — the top-k
+            # reaches down to docs that only hold the latter, whose totals are a few hundred fixed-point steps; such a query
+            # is summed again in f32 by the clause-order kernel
+            _check_against_oracle(oracle, osearcher, gsearcher, [(oracle.OP_OR, list(range(10)))], 10, exact=False)
+            assert "k_or_wide" in ctx2.kernel_stats() and "k_or_windows" not in ctx2.kernel_stats()
+            _check_against_oracle(oracle, osearcher, gsearcher, [(oracle.OP_OR, [0, 1, 2] + [11] * 7)], 10, exact=False)
+            assert "k_or_windows" in ctx2.kernel_stats()
+        specs = [(oracle.OP_OR, list(range(10))), (oracle.OP_OR, [0, 1, 2] + [11] * 7), (oracle.OP_OR, list(range(2, 18))), (oracle.OP_OR, [11] * 10),
+                 (oracle.OP_OR, [11, 10, 13, 12, 9] * 3), (oracle.OP_OR, [0, 1, 2, 14, 16, 3, 4, 5, 6, 15]),
+                 (oracle.OP_OR, [0, 14, 1, 2, 16, 3, 4, 0, 14, 1, 2, 16]), (oracle.OP_OR, list(range(8, 18)) + [18, 18]),
+                 (oracle.OP_OR, list(range(9)) + [18]),  # nine live clauses: the clause-order kernel, still within tolerance
+                 (oracle.OP_OR, [17, 15, 7, 8, 9, 10, 11, 12, 13, 6, 5, 4, 3])]
+        for k in (10, 100):
+            _check_against_oracle(oracle, osearcher, gsearcher, specs, k, exact=False)
+        # next to other operators in one batch
+        mixed = [(oracle.OP_TERM, [9]), specs[1], (oracle.OP_AND, [9, 10, 11]), specs[3], (oracle.OP_OR, [8, 9, 10])]
+        _check_against_oracle(oracle, osearcher, gsearcher, mixed, 10, exact=False)
+    finally:
+        ctx2.close()
+
+
 def test_cpp_host_mirror(oracle, tmp_path):
     """The C++ host layer (csrc/host/gpu_index_searcher.hpp) over the C ABI, driven like the reference's example."""
     import subprocess
