@@ -88,7 +88,7 @@ WORKLOAD_TEXT = {
     "and3": "1024 x 3-term AND top-10, ranks log-uniform 1..1000 (BASELINE configs[2])",
     "or10": "1024 x 10-term OR top-100, ranks log-uniform 1..10000 (BASELINE configs[3])",
 }
-DOMINANT = {"term": "k_search_term", "and3": "k_search_and", "or10": "k_or_windows"}
+DOMINANT = {"term": "k_search_term", "and3": "k_search_and", "or10": "k_or_wide"}
 PROFILE_TAG = {"term": "r02_term", "and3": "r02_and3", "or10": "r02_or10", "decode": "r02_decode"}
 
 
@@ -398,9 +398,12 @@ def main():
             c["algorithmic_bytes"] = r["algo_bytes"]
             c["kernels_ms_per_step"] = r["kernels_ms_per_step"]
             c["launches_per_step"] = r["launches_per_step"]
-            kms = sum(v for n, v in r["kernels_ms_per_step"].items() if n in ("k_score_terms", "k_or_windows"))
-            c["roofline"] = roofline("k_score_terms + k_or_windows", kms, r["algo_bytes"], PROFILE_TAG[kind])
-            c["roofline"]["note"] = "achieved = scan bytes (all ten lists + norms) / summed duration of the OR kernels per batch"
+            or_kernels = [n for n in ("k_or_wide", "k_score_terms", "k_or_windows") if n in r["kernels_ms_per_step"]]
+            kms = sum(r["kernels_ms_per_step"][n] for n in or_kernels)
+            c["roofline"] = roofline(" + ".join(or_kernels), kms, r["algo_bytes"], PROFILE_TAG[kind])
+            c["roofline"]["note"] = ("achieved = scan bytes (all ten lists + norms) / summed duration of the OR kernels per batch; ten clauses: "
+                                     "k_or_wide (order-free fixed-point accumulation; queries under its precision floor are run again "
+                                     "by k_score_terms + k_or_windows)")
         if not args.no_cpu_baseline:
             base, parity = cpu_baseline_leg(shard, kind, kk, r, 4.0, nq if kind == "and3" else 256)
             c["cpu_baseline"] = base

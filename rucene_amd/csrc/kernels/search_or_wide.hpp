@@ -32,13 +32,22 @@
 
 namespace rgpu {
 
-constexpr int ORX_WAVES = 8;
+#ifndef RGPU_ORX_WAVES
+#define RGPU_ORX_WAVES 8
+#endif
+#ifndef RGPU_ORX_LOOK
+#define RGPU_ORX_LOOK 2
+#endif
+constexpr int ORX_WAVES = RGPU_ORX_WAVES;  // 8: two workgroups per CU; 16: one, with twice the window
 constexpr int ORX_THREADS = 64 * ORX_WAVES;
+constexpr int ORX_OWN = (16 + ORX_WAVES - 1) / ORX_WAVES;  // clauses whose block bounds a wavefront keeps (c = wave + s * ORX_WAVES)
+constexpr int ORX_LOOK = RGPU_ORX_LOOK;    // directory entries looked at per clause per window, in units of 64
+constexpr int ORX_SCAN_STEP = 4 * ORX_THREADS;  // docs per scan step of the workgroup: windows are multiples of it
 constexpr int ORX_TABLES = 4;       // clauses scored through an LDS score table (the longest lists); the rest use the formula
 constexpr int ORX_MAX_TERMS = 16;   // == RGPU_MAX_QUERY_TERMS
 constexpr int ORX_RING = 4;         // payload rows in flight per wavefront
 constexpr int ORX_BOUNDS_RING = 3;  // bounds of windows n, n+1, n+2
-constexpr int ORX_MAX_WINDOW = 126 * 128;  // a window's blocks of one clause must fit the 128 directory entries looked at
+constexpr int ORX_MAX_WINDOW = (64 * ORX_LOOK - 2) * 128;  // a window's blocks of one clause must fit the directory entries looked at
 constexpr uint32_t ORX_FLOOR_PER_CLAUSE = 1u << 17;  // a returned total below n_clauses * this is summed again in f32 (see above)
 #ifndef RGPU_ORX_ABL  // developer ablations (variant builds only; results are wrong)
 #define RGPU_ORX_ABL 0
@@ -55,7 +64,7 @@ __host__ __device__ constexpr size_t orx_lds_bytes(int WS) { return orx_fixed_ld
 // clauses that get a score table, DevQuery::pad = the query's fixed-point exponent e. Every wavefront writes its own
 // top-k list: item (q * items_per_query + g) * 8 + wave.
 template <bool LEGACY, bool WIDE>
-__global__ __launch_bounds__(ORX_THREADS, 4) void k_or_wide(SegView seg, const DevQuery* __restrict__ queries,
+__global__ __launch_bounds__(ORX_THREADS, ORX_WAVES >= 16 ? 4 : 4) void k_or_wide(SegView seg, const DevQuery* __restrict__ queries,
                                                             const DevTerm* __restrict__ terms, int n_queries,
                                                             int windows_per_query, int windows_per_item, int items_per_query,
                                                             int WS, int k, uint64_t* __restrict__ partial_keys,
@@ -127,114 +136,168 @@ __global__ __launch_bounds__(ORX_THREADS, 4) void k_or_wide(SegView seg, const D
 
   // ---- block bounds of a window, per clause: blocks [lo, lo + cnt) hold a doc of [w0, w1). The owner keeps a cursor
   // `cur` (a block at or before lo) and looks at the 128 directory entries from it.
-  const int own_a = wave, own_b = wave + ORX_WAVES;
-  int cur_a = 0, cur_b = 0;
-  int32_t ea0 = 0, ea1 = 0, eb0 = 0, eb1 = 0;
-  auto bounds_issue = [&](int c, int cur, int32_t& e0, int32_t& e1) {
+  int own_cur[ORX_OWN];
+  int32_t own_e[ORX_OWN][ORX_LOOK];
+  auto bounds_issue = [&](int c, int cur, int32_t (&e)[ORX_LOOK]) {
     const uint32_t dir = (uint32_t)readlane((int)c_dir, c);
     const int nbx = readlane(c_nbx, c);
-    const int p = cur + lane;
-    e0 = p < nbx ? seg.dir_last[dir + p] : 0x7fffffff;
-    e1 = p + 64 < nbx ? seg.dir_last[dir + p + 64] : 0x7fffffff;
+#pragma unroll
+    for (int u = 0; u < ORX_LOOK; ++u) {
+      const int p = cur + 64 * u + lane;
+      e[u] = p < nbx ? seg.dir_last[dir + p] : 0x7fffffff;
+    }
   };
-  auto bounds_finish = [&](int c, int& cur, int32_t e0, int32_t e1, int win) {
+  auto bounds_finish = [&](int c, int& cur, const int32_t (&e)[ORX_LOOK], int win) {
     const int nbx = readlane(c_nbx, c);
     const int32_t w0 = win * WS;
     const int32_t w1 = min(seg.max_doc, w0 + WS);
-    int lo = cur + __popcll(__ballot(e0 < w0)) + __popcll(__ballot(e1 < w0));
-    // block b > 0 holds docs in (dir_last[b-1], dir_last[b]]: it reaches into the window iff dir_last[b-1] <= w1 - 2
-    int hi = min(nbx, cur + __popcll(__ballot(e0 <= w1 - 2)) + __popcll(__ballot(e1 <= w1 - 2)) + 1);
+    int before = 0, reach = 0;
+#pragma unroll
+    for (int u = 0; u < ORX_LOOK; ++u) {
+      before += __popcll(__ballot(e[u] < w0));
+      // block b > 0 holds docs in (dir_last[b-1], dir_last[b]]: it reaches into the window iff dir_last[b-1] <= w1 - 2
+      reach += __popcll(__ballot(e[u] <= w1 - 2));
+    }
+    int lo = cur + before;
+    int hi = min(nbx, cur + reach + 1);
     if (win >= win1) { lo = 0; hi = 0; }
     if (lane == 0) bounds[(win % ORX_BOUNDS_RING) * ORX_MAX_TERMS + c] = make_int2(lo, max(0, hi - lo));
     if (win < win1) cur = max(cur, hi - 1);
   };
-  if (own_a < n) cur_a = find_block_wave(seg.dir_last, (uint32_t)readlane((int)c_dir, own_a), 0, readlane(c_nbx, own_a), first_doc, lane);
-  if (own_b < n) cur_b = find_block_wave(seg.dir_last, (uint32_t)readlane((int)c_dir, own_b), 0, readlane(c_nbx, own_b), first_doc, lane);
-  for (int w = win0; w < win0 + 2; ++w) {  // the first two windows' bounds: the only exposed directory reads
-    if (own_a < n) { bounds_issue(own_a, cur_a, ea0, ea1); bounds_finish(own_a, cur_a, ea0, ea1, w); }
-    if (own_b < n) { bounds_issue(own_b, cur_b, eb0, eb1); bounds_finish(own_b, cur_b, eb0, eb1, w); }
+#pragma unroll
+  for (int s = 0; s < ORX_OWN; ++s) {
+    const int c = wave + s * ORX_WAVES;
+    own_cur[s] = 0;
+#pragma unroll
+    for (int u = 0; u < ORX_LOOK; ++u) own_e[s][u] = 0;
+    if (c < n) {
+      own_cur[s] = find_block_wave(seg.dir_last, (uint32_t)readlane((int)c_dir, c), 0, readlane(c_nbx, c), first_doc, lane);
+      for (int w = win0; w < win0 + 2; ++w) {  // the first two windows' bounds: the only exposed directory reads
+        bounds_issue(c, own_cur[s], own_e[s]);
+        bounds_finish(c, own_cur[s], own_e[s], w);
+      }
+      bounds_issue(c, own_cur[s], own_e[s]);  // for window win0 + 2
+    }
   }
-  if (own_a < n) bounds_issue(own_a, cur_a, ea0, ea1);  // for window win0 + 2
-  if (own_b < n) bounds_issue(own_b, cur_b, eb0, eb1);
   __syncthreads();
 
   // ---- a wavefront's share of a window: entries [wave * per, wave * per + per) of the flat list of (clause, block)
-  // pairs, `per` = ceil(total / 8); lane i of a List holds entry page + i with its directory words
+  // pairs, `per` = ceil(total / 8). Lane i of a List holds entry page + i, everything a block needs as two addresses and
+  // one word, so that the per-block code reads five lanes and does no address arithmetic:
+  //   rows   address of the block's first payload row (or of the tail's cells)
+  //   pn     address of the block's posting-order norm ranks
+  //   meta   bits 0-15 the directory header word, 16-21 R = 16-byte rows between the doc and the freq payload (32 for a
+  //          tail: then lane l's row is simply cell l), 22 FullBlock?, 23-26 clause, 27-30 score table + 1 (0: none)
+  //   base   the doc id before the block's first posting
+  // A page holds at most ORX_PAGE entries: the lanes behind them take the first ORX_RING entries of the NEXT window's list
+  // (append_next), so the ring's look-ahead never has to choose between two lists.
+  constexpr int ORX_PAGE = 64 - ORX_RING;
   struct List {
-    int c, b;
-    uint32_t hdr, row;
+    uint64_t rows, pn;
+    uint32_t meta;
     int32_t base;
-    int n;      // entries held (<= 64), wave-uniform
-    int mine;   // this wavefront's entries in the window (> 64: the rest goes through further pages)
+    int n;      // entries held (<= ORX_PAGE), wave-uniform
+    int mine;   // this wavefront's entries in the window (> ORX_PAGE: the rest goes through further pages)
   };
-  auto build_list = [&](int win, int page) -> List {
+  struct Pending {  // a list whose directory words are still in flight
     List L;
+    uint32_t hdr, row;
+    int c;
+    bool full, first;
+  };
+  auto build_list = [&](int win, int page) -> Pending {
+    Pending P;
     const int2 bd = lane < n ? bounds[(win % ORX_BOUNDS_RING) * ORX_MAX_TERMS + lane] : make_int2(0, 0);
     const int incl = wave_incl_scan(bd.y);
     const int total = (RGPU_ORX_ABL == 4 || RGPU_ORX_ABL == 5) ? 0 : readlane(incl, 63);
     const int per = (total + ORX_WAVES - 1) / ORX_WAVES;
     const int j0 = wave * per;
-    L.mine = max(0, min(total, j0 + per) - j0);
-    L.n = max(0, min(64, L.mine - page));
+    P.L.mine = max(0, min(total, j0 + per) - j0);
+    P.L.n = max(0, min(ORX_PAGE, P.L.mine - page));
     const int j = j0 + page + lane;
     int c = 0;
     for (int t = 0; t < n; ++t) c += j >= readlane(incl, t) ? 1 : 0;
-    const bool valid = lane < L.n;
+    const bool valid = lane < P.L.n;
     c = valid ? c : 0;
     const int off = bd.x - (incl - bd.y);  // lane t: lo_t - (entries before clause t)
-    L.c = c;
-    const int lo_rel = __builtin_amdgcn_ds_bpermute(c << 2, off);  // all lanes active: a bpermute reads 0 from disabled lanes
-    L.b = valid ? lo_rel + j : 0;  // (lanes past the list name clause 0's block 0: a safe address)
-    const uint32_t gi = (uint32_t)__builtin_amdgcn_ds_bpermute(c << 2, (int)c_dir) + (uint32_t)L.b;
-    L.hdr = valid ? (uint32_t)seg.dir_hdr[gi] : 0u;
-    L.row = valid ? seg.dir_row[gi] : 0u;
-    L.base = (valid && L.b > 0) ? seg.dir_last[gi - 1] : 0;
+    // (bpermutes with every lane active: they read 0 from disabled lanes)
+    const int lo_rel = __builtin_amdgcn_ds_bpermute(c << 2, off);
+    const int b = valid ? lo_rel + j : 0;  // lanes past the list name clause 0's block 0: a safe address
+    const uint32_t gi = (uint32_t)__builtin_amdgcn_ds_bpermute(c << 2, (int)c_dir) + (uint32_t)b;
+    const uint64_t bs = ((uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute(c << 2, (int)(uint32_t)(c_bs >> 32)) << 32) |
+                        (uint32_t)__builtin_amdgcn_ds_bpermute(c << 2, (int)(uint32_t)c_bs);
+    const uint64_t pnb = ((uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute(c << 2, (int)(uint32_t)(c_pn >> 32)) << 32) |
+                         (uint32_t)__builtin_amdgcn_ds_bpermute(c << 2, (int)(uint32_t)c_pn);
+    P.full = b < __builtin_amdgcn_ds_bpermute(c << 2, c_nb);
+    P.c = c | ((__builtin_amdgcn_ds_bpermute(c << 2, c_tbl) + 1) << 4);
+    P.L.rows = (uint64_t)(uintptr_t)seg.bstore + bs;
+    P.L.pn = (uint64_t)(uintptr_t)seg.pnorm + pnb + 128u * (uint64_t)(uint32_t)b;
+    // unconditional loads (lanes past the list read clause 0's first slot): a load under a lane mask becomes a branch
+    // and the compiler then waits for it on the spot, in front of the scan
+    P.hdr = (uint32_t)seg.dir_hdr[gi];
+    P.row = seg.dir_row[gi];
+    P.L.base = seg.dir_last[gi - (b > 0 ? 1u : 0u)];  // (b == 0: not used as a base, replaced by 0 in finish_list)
+    P.first = b == 0;
+    P.L.meta = 0u;
+    return P;
+  };
+  auto finish_list = [&](const Pending& P) -> List {  // once the directory words are here
+    List L = P.L;
+    L.rows += 16ull * (uint64_t)P.row;
+    if (P.first) L.base = 0;
+    const uint32_t R = P.full ? (uint32_t)store_doc_rows(P.hdr) : 32u;
+    L.meta = (P.hdr & 0xffffu) | (R << 16) | (P.full ? 1u << 22 : 0u) | ((uint32_t)P.c << 23);
     return L;
+  };
+  // lanes [A.n, A.n + ORX_RING) of A take entries 0 .. ORX_RING-1 of B (clamped to B's last entry; B empty: its lane 0
+  // names a safe address)
+  auto append_next = [&](List& A, const List& B) {
+    const int src = max(0, min(lane - A.n, B.n - 1));
+    const bool take = lane >= A.n && lane < A.n + ORX_RING;
+    const uint32_t rl = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)(uint32_t)B.rows);
+    const uint32_t rh = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)(uint32_t)(B.rows >> 32));
+    const uint32_t pl = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)(uint32_t)B.pn);
+    const uint32_t ph = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)(uint32_t)(B.pn >> 32));
+    const uint32_t mt = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)B.meta);
+    const int32_t bs = __builtin_amdgcn_ds_bpermute(src << 2, B.base);
+    if (take) { A.rows = ((uint64_t)rh << 32) | rl; A.pn = ((uint64_t)ph << 32) | pl; A.meta = mt; A.base = bs; }
   };
 
   struct Slot {
     uint4 rows;   // a FullBlock's payload row of this lane — or, for a tail, {doc0, doc1, freq0, freq1}
     uint32_t nn;  // posting-order norm ranks of postings 2*lane, 2*lane+1
   };
-  // The payload request of one list entry, given as scalars. Unconditional and always the same two loads, so that the
-  // compiler's vmcnt bookkeeping keeps the whole ring in flight (a load behind a branch makes every later wait a
-  // vmcnt(0)). A tail cell is 16 bytes per lane like a FullBlock row; its norms follow the FullBlocks' in pnorm.
-  auto fetch_at = [&](int c, int b, uint32_t hdr, uint32_t row) -> Slot {
+  // The payload request of one list entry: unconditional and always the same two loads, so that the compiler's vmcnt
+  // bookkeeping keeps the whole ring in flight (a load behind a branch makes every later wait a vmcnt(0)).
+  const uint32_t voff_lo = 16u * (uint32_t)(lane & 31), voff_hi = 16u * (uint32_t)(lane >> 5);
+  auto fetch = [&](const List& L, int idx) -> Slot {
     Slot s;
-    const uint8_t* rows0 = block_rows_at(seg.bstore + readlane64(c_bs, c), row);
-    const bool full = b < readlane(c_nb, c);
-    const uint32_t voff = full ? 16u * (uint32_t)(lane & 31) + __umul24(16u * (uint32_t)(lane >> 5), (uint32_t)store_doc_rows(hdr)) : 16u * (uint32_t)lane;
-    s.rows = *reinterpret_cast<const uint4*>(rows0 + voff);
-    s.nn = *reinterpret_cast<const uint16_t*>(seg.pnorm + readlane64(c_pn, c) + (128u * (uint32_t)b + 2u * (uint32_t)lane));
+    // addresses rebuilt from integers: say "global" explicitly, or the loads become FLAT ones (which also count as LDS
+    // operations: every lgkmcnt wait of the unpacking code would then wait for the ring's requests)
+    typedef const __attribute__((address_space(1))) uint8_t* gbytes;
+    gbytes rows0 = (gbytes)(uintptr_t)readlane64(L.rows, idx);
+    gbytes pn = (gbytes)(uintptr_t)readlane64(L.pn, idx);
+    const uint32_t R = ((uint32_t)readlane((int)L.meta, idx) >> 16) & 63u;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 r = *(const __attribute__((address_space(1))) u32x4*)(rows0 + (voff_lo + __umul24(voff_hi, R)));
+    s.rows = make_uint4(r.x, r.y, r.z, r.w);
+    s.nn = *(const __attribute__((address_space(1))) uint16_t*)(pn + 2u * (uint32_t)lane);
     return s;
   };
-  auto fetch = [&](const List& L, int idx) -> Slot {
-    return fetch_at(readlane(L.c, idx), readlane(L.b, idx), (uint32_t)readlane((int)L.hdr, idx), (uint32_t)readlane((int)L.row, idx));
-  };
-  // entry `ia` of list A or entry `ib` of list B (wave-uniform choice): scalar selects, one request
-  auto fetch_either = [&](bool use_b, const List& A, int ia, const List& B, int ib) -> Slot {
-    const int c = use_b ? readlane(B.c, ib) : readlane(A.c, ia);
-    const int b = use_b ? readlane(B.b, ib) : readlane(A.b, ia);
-    const uint32_t hdr = (uint32_t)(use_b ? readlane((int)B.hdr, ib) : readlane((int)A.hdr, ia));
-    const uint32_t row = (uint32_t)(use_b ? readlane((int)B.row, ib) : readlane((int)A.row, ia));
-    return fetch_at(c, b, hdr, row);
-  };
   auto process = [&](const Slot& s, const List& L, int idx, int32_t w0, uint32_t wlen) {
-    const int c = readlane(L.c, idx);
-    const int b = readlane(L.b, idx);
-    const uint32_t hdr = (uint32_t)readlane((int)L.hdr, idx);
+    const uint32_t meta = (uint32_t)readlane((int)L.meta, idx);
+    const uint32_t hdr = meta & 0xffffu;
+    const int c = (int)((meta >> 23) & 15u);
+    const int slot = (int)((meta >> 27) & 15u) - 1;
     int32_t e0, e1;
     uint32_t f0, f1;
     const uint32_t nb0 = s.nn & 0xffu, nb1 = s.nn >> 8;
     bool small_freqs;
     if (RGPU_ORX_ABL == 8) {  // payload consumed, nothing decoded: one store keeps the loads alive
-      if (lane == (int)(s.rows.x & 63u) && s.nn == 0x12345u) acc[lane] = __uint_as_float(s.rows.y);
+      if (lane == (int)(s.rows.x & 63u) && s.nn == 0x12345u) acc[lane] = s.rows.y;
       return;
     }
-    if (RGPU_ORX_ABL == 7) {  // no unpacking: docs from the lane id
-      e0 = readlane(L.base, idx) + 1 + 2 * lane; e1 = e0 + 1; f0 = s.rows.x & 7u; f1 = s.rows.y & 7u; small_freqs = true;
-    } else
-    if (b < readlane(c_nb, c)) {
+    if (meta & (1u << 22)) {
       stage_rows(s.rows, slab, lane);
       wave_sync();
       uint32_t x0, x1;
@@ -247,7 +310,6 @@ __global__ __launch_bounds__(ORX_THREADS, 4) void k_or_wide(SegView seg, const D
       e0 = (int32_t)s.rows.x; e1 = (int32_t)s.rows.y; f0 = s.rows.z; f1 = s.rows.w;
       small_freqs = false;
     }
-    const int slot = readlane(c_tbl, c);
     uint32_t s0, s1;
     if (slot >= 0 && (small_freqs || !__ballot((f0 > f1 ? f0 : f1) > (uint32_t)SCORE_TABLE_FREQS))) {
       const uint32_t* tbl = reinterpret_cast<const uint32_t*>(tables + slot * WAVE_CACHE_FLOATS) + 64;
@@ -274,40 +336,39 @@ __global__ __launch_bounds__(ORX_THREADS, 4) void k_or_wide(SegView seg, const D
 
   WaveTopK top;
   uint64_t tau = 0, floor = 0;
-  int hits = 0;  // wave-uniform: touched docs this wavefront scanned
+  int hits_lane = 0;  // touched docs this lane scanned
   SharedTau shared{tau_slots + q};
   shared.fold(shared.peek(), tau, floor);
 
-  List cur_list = build_list(win0, 0);
-  List next_list = build_list(win0 + 1, 0);
+  List cur_list = finish_list(build_list(win0, 0));
+  List next_list = finish_list(build_list(win0 + 1, 0));
+  append_next(cur_list, next_list);
   Slot ring[ORX_RING];
 #pragma unroll
-  for (int j = 0; j < ORX_RING; ++j) ring[j] = Slot{make_uint4(0u, 0u, 0u, 0u), 0u};
-#pragma unroll
-  for (int j = 0; j < ORX_RING; ++j) ring[j] = fetch(cur_list, max(0, min(j, cur_list.n - 1)));
+  for (int j = 0; j < ORX_RING; ++j) ring[j] = fetch(cur_list, j);  // (entries past cur_list.n: the appended ones — harmless)
   __syncthreads();  // accumulators are cleared, tables and caches are built
 
   for (int win = win0; win < win1; ++win) {
     const int32_t w0 = win * WS;
     const uint32_t wlen = (uint32_t)(min(seg.max_doc, w0 + WS) - w0);
     const uint64_t seen = shared.peek();  // folded before the scan
-    // ---- this wavefront's blocks; the ring ends up holding the next window's first blocks
-    // Groups of ORX_RING blocks; after a block is done its ring slot requests the block ORX_RING further on — in the last
-    // group that is block j of the NEXT window (static slot alignment). Entries past a list's end are clamped: a
-    // redundant request instead of a branch.
-    const int padded = max(ORX_RING, (cur_list.n + ORX_RING - 1) / ORX_RING * ORX_RING);
+    // ---- this wavefront's blocks, in groups of ORX_RING; after a block is done its ring slot requests the block
+    // ORX_RING further on — in the last group that is block j of the NEXT window (lanes n + j: static slot alignment).
+    // Entries past the list's end are clamped: a redundant request instead of a branch.
+    const int nb_mine = cur_list.n;
+    const int padded = max(ORX_RING, (nb_mine + ORX_RING - 1) / ORX_RING * ORX_RING);
     for (int i = 0; i < padded; i += ORX_RING) {
       const bool last_group = i + ORX_RING >= padded;
 #pragma unroll
       for (int j = 0; j < ORX_RING; ++j) {
         const int idx = i + j;
-        if (idx < cur_list.n && RGPU_ORX_ABL != 2 && RGPU_ORX_ABL != 3) process(ring[j], cur_list, idx, w0, wlen);
+        if (idx < nb_mine && RGPU_ORX_ABL != 2 && RGPU_ORX_ABL != 3) process(ring[j], cur_list, idx, w0, wlen);
         if (RGPU_ORX_ABL == 3) continue;
-        ring[j] = fetch_either(last_group, cur_list, max(0, min(idx + ORX_RING, cur_list.n - 1)), next_list, max(0, min(j, next_list.n - 1)));
+        ring[j] = fetch(cur_list, last_group ? nb_mine + j : min(idx + ORX_RING, max(0, nb_mine - 1)));
       }
     }
-    for (int page = 64; page < cur_list.mine; page += 64) {  // > 64 blocks for one wavefront in one window: plain loop
-      const List more = build_list(win, page);
+    for (int page = ORX_PAGE; page < cur_list.mine; page += ORX_PAGE) {  // more blocks than a page for one wavefront: plain loop
+      const List more = finish_list(build_list(win, page));
       for (int idx = 0; idx < more.n; ++idx) process(fetch(more, idx), more, idx, w0, wlen);
     }
     if (wave == 0) {  // singletons (one lane per clause; two clauses may name the same doc: the add is atomic)
@@ -316,40 +377,51 @@ __global__ __launch_bounds__(ORX_THREADS, 4) void k_or_wide(SegView seg, const D
     }
     // ---- bounds of window win + 2 from the directory entries requested one window ago; request the next ones
     if (RGPU_ORX_ABL != 5) {
-      if (own_a < n) { bounds_finish(own_a, cur_a, ea0, ea1, win + 2); bounds_issue(own_a, cur_a, ea0, ea1); }
-      if (own_b < n) { bounds_finish(own_b, cur_b, eb0, eb1, win + 2); bounds_issue(own_b, cur_b, eb0, eb1); }
+#pragma unroll
+      for (int s = 0; s < ORX_OWN; ++s) {
+        const int c = wave + s * ORX_WAVES;
+        if (c < n) { bounds_finish(c, own_cur[s], own_e[s], win + 2); bounds_issue(c, own_cur[s], own_e[s]); }
+      }
     }
     __syncthreads();  // every add of this window has landed; bounds of win + 2 are visible
-    const List after = build_list(win + 2, 0);  // its directory words arrive during the scan
+    const Pending after = build_list(win + 2, 0);  // its directory words arrive during the scan
 
     // ---- scan: four docs per lane per step; a touched accumulator is one collected hit (bulk_scorer.rs:114-120)
     shared.fold(seen, tau, floor);
-    for (uint32_t i0 = 0; i0 < (uint32_t)WS && RGPU_ORX_ABL != 1; i0 += 4 * ORX_THREADS) {
-      uint4* cell = reinterpret_cast<uint4*>(acc + i0 + 4 * threadIdx.x);
-      const uint4 v = *cell;
+    // (the next step's cells are requested before this step's are looked at: the LDS round trip hides behind the work)
+    uint4* cell = reinterpret_cast<uint4*>(acc + 4 * threadIdx.x);
+    uint4 v_next = *cell;
+    for (uint32_t i0 = 0; i0 < (uint32_t)WS && RGPU_ORX_ABL != 1; i0 += ORX_SCAN_STEP) {
+      const uint4 v = v_next;
+      uint4* const here = cell;
+      if (i0 + ORX_SCAN_STEP < (uint32_t)WS) cell += ORX_SCAN_STEP / 4;  // wave-uniform
+      v_next = *cell;
       if (__ballot((v.x | v.y | v.z | v.w) != 0u)) {
-        hits += __popcll(__ballot(v.x != 0u)) + __popcll(__ballot(v.y != 0u)) + __popcll(__ballot(v.z != 0u)) + __popcll(__ballot(v.w != 0u));
-        *cell = make_uint4(0u, 0u, 0u, 0u);
+        hits_lane += (int)min(v.x, 1u) + (int)min(v.y, 1u) + (int)min(v.z, 1u) + (int)min(v.w, 1u);
+        *here = make_uint4(0u, 0u, 0u, 0u);
         const uint32_t thr = max(1u, (uint32_t)(tau >> 32));  // a key's high word is the doc's total
-        const bool c0 = v.x >= thr, c1 = v.y >= thr, c2 = v.z >= thr, c3 = v.w >= thr;
-        if (__ballot(c0 || c1 || c2 || c3)) {
+        if (__ballot(max(max(v.x, v.y), max(v.z, v.w)) >= thr)) {
           const uint32_t nd = ~(uint32_t)(w0 + (int32_t)i0 + 4 * (int32_t)threadIdx.x);  // ~doc: smaller doc id = larger key
-          uint64_t key = c0 ? ((uint64_t)v.x << 32) | nd : 0ull;
+          uint64_t key = v.x >= thr ? ((uint64_t)v.x << 32) | nd : 0ull;
           if (__ballot(key > tau)) topk_offer<WIDE>(top, key, tau, k, lane, floor);
-          key = c1 ? ((uint64_t)v.y << 32) | (nd - 1u) : 0ull;
+          key = v.y >= thr ? ((uint64_t)v.y << 32) | (nd - 1u) : 0ull;
           if (__ballot(key > tau)) topk_offer<WIDE>(top, key, tau, k, lane, floor);
-          key = c2 ? ((uint64_t)v.z << 32) | (nd - 2u) : 0ull;
+          key = v.z >= thr ? ((uint64_t)v.z << 32) | (nd - 2u) : 0ull;
           if (__ballot(key > tau)) topk_offer<WIDE>(top, key, tau, k, lane, floor);
-          key = c3 ? ((uint64_t)v.w << 32) | (nd - 3u) : 0ull;
+          key = v.w >= thr ? ((uint64_t)v.w << 32) | (nd - 3u) : 0ull;
           if (__ballot(key > tau)) topk_offer<WIDE>(top, key, tau, k, lane, floor);
         }
       }
     }
     shared.publish<WIDE>(top, k, lane);
     __syncthreads();  // the window is clear again
+    // the window after next's directory words have arrived during the scan: finish it, move up, and give the new
+    // current list its look-ahead entries
     cur_list = next_list;
-    next_list = after;
+    next_list = finish_list(after);
+    append_next(cur_list, next_list);
   }
+  const int hits = wave_reduce_add(hits_lane);
   uint64_t* pk = partial_keys + (size_t)item * (size_t)k;
   if (lane < k) pk[lane] = top.a;
   if (WIDE && lane + 64 < k) pk[lane + 64] = top.b;

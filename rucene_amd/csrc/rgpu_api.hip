@@ -970,9 +970,13 @@ static int32_t search_or_wide_group(rgpu_segment* seg, Group& G, int32_t k, HitO
   const bool legacy = seg->version < 1;
   if (nt == 0) return RGPU_OK;
   HIP_TRY(scratch_take(c));
-  int WS = c->cfg.or_wide_window_docs > 0 ? (c->cfg.or_wide_window_docs + 2047) / 2048 * 2048 : 12288;
-  WS = std::min(14336, std::max(2048, WS));
-  static_assert(14336 <= ORX_MAX_WINDOW, "a window's blocks of one clause fit the directory look-ahead");
+  // a window: a multiple of the workgroup's scan step, small enough for the directory look-ahead and for LDS
+  constexpr int WS_MAX = ORX_MAX_WINDOW / ORX_SCAN_STEP * ORX_SCAN_STEP;
+  constexpr int WS_DEFAULT = ORX_WAVES >= 16 ? 24576 : 12288;
+  static_assert(WS_DEFAULT <= WS_MAX, "a window's blocks of one clause fit the directory look-ahead");
+  int WS = c->cfg.or_wide_window_docs > 0 ? (c->cfg.or_wide_window_docs + ORX_SCAN_STEP - 1) / ORX_SCAN_STEP * ORX_SCAN_STEP : WS_DEFAULT;
+  WS = std::min(WS_MAX, std::max(ORX_SCAN_STEP, WS));
+  while (orx_lds_bytes(WS) > 160u * 1024u && WS > ORX_SCAN_STEP) WS -= ORX_SCAN_STEP;
   // score tables for the (up to) ORX_TABLES longest lists of each query
   for (DevQuery& dq : G.queries) {
     uint32_t mask = 0;
@@ -1006,7 +1010,10 @@ static int32_t search_or_wide_group(rgpu_segment* seg, Group& G, int32_t k, HitO
   }
   // items = (query, group of windows), one per workgroup: enough of them to fill the chip a few times over
   const int wpq = std::max(1, (int)(((int64_t)seg->max_doc + WS - 1) / WS));
-  int ipq = std::min(wpq, std::max(1, (4096 + nq - 1) / nq));
+#ifndef RGPU_ORX_TARGET_WGS
+#define RGPU_ORX_TARGET_WGS 8192
+#endif
+  int ipq = std::min(wpq, std::max(1, (RGPU_ORX_TARGET_WGS + nq - 1) / nq));
   const int wpi = (wpq + ipq - 1) / ipq;
   ipq = (wpq + wpi - 1) / wpi;
   const int64_t lists = (int64_t)nq * ipq * ORX_WAVES;  // one top-k list per wavefront
