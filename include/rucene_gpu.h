@@ -190,8 +190,11 @@ int32_t rgpu_sim_table_upload(rgpu_ctx* ctx, const float cache[256], float k1);
  *   hits_out        n_queries x k, best first; order = score desc, then doc asc (the canonical tie rule of
  *                   SURVEY.md §8(c)); unused slots {-1, 0}
  *   total_hits_out  n_queries, TopDocs::total_hits (every collected live doc)
- * Scores are f32 computed in the reference's operation order: TERM and AND bit-exact with the CPU scorers,
- * OR with >= 10 clauses within 1e-5 relative (heap-order-dependent summation in the reference). ONE exception, by
+ * Scores are f32 computed in the reference's operation order: TERM, AND and OR with < 10 clauses bit-exact with the
+ * CPU scorers. OR with >= 10 clauses: within 1e-5 relative — the reference sums those in heap order
+ * (disjunction_scorer.rs:41-45), so it pins a score no tighter itself; here such a doc's score is the exact sum of its
+ * clause scores in fixed point (2^-e steps, e per query), rounded to f32 once: deterministic, independent of any
+ * order, hit counts exact (kernels/search_or_wide.hpp; rgpu_config.or_wide = -1 sums in f32 in clause order instead). ONE exception, by
  * design: queries carrying RGPU_OP_WITH_SHOULD clauses always add the optional scores, where the reference's
  * ReqOptScorer skips them for low scorers after 100 docs (see the macro above) — doc ids and hit counts equal the
  * reference's, scores are >= its. */
@@ -338,7 +341,7 @@ int32_t rgpu_terms_lookup(const rgpu_terms* terms, int32_t field_number, const u
 /* The rest of BlockTermState for a field indexed with positions (blocktree/mod.rs:33-59; lucene50_decode_term): where the
  * term's positions start in ".pos", its payloads / offsets in ".pay", and the offset of its last (vint) position block.
  * Same lookup as rgpu_terms_lookup plus positions_out[i] (zeros / -1 for an absent term or a field without positions).
- * No search entry point reads positions yet; this is the term-resolution half of that row. */
+ * rgpu_search_phrase_batch takes them beside each term's state. */
 typedef struct rgpu_term_positions {
   int64_t pos_start_fp;
   int64_t pay_start_fp;           /* 0 unless the field stores payloads or offsets */
