@@ -78,7 +78,8 @@ __global__ __launch_bounds__(WG_THREADS) void k_merge_items(const int64_t* __res
                                                             int head_items, HitOut* __restrict__ hits_out,
                                                             int64_t* __restrict__ totals_out,
                                                             const int2* __restrict__ fixed_info = nullptr,
-                                                            int32_t* __restrict__ low_flags = nullptr) {
+                                                            int32_t* __restrict__ low_flags = nullptr,
+                                                            const int32_t* __restrict__ qmap = nullptr) {
   const int lane = lane_id();
   const int q = (int)(blockIdx.x * WG_WAVES) + wave_id();
   if (q >= n_queries) return;
@@ -108,7 +109,10 @@ __global__ __launch_bounds__(WG_THREADS) void k_merge_items(const int64_t* __res
       m &= __ballot(head > tau);
     }
   }
-  HitOut* out = hits_out + (size_t)q * (size_t)k;
+  // qmap: the group's query q is the caller's row qmap[q] (queries are partitioned by op on the host) — the rows are
+  // written in place, no scatter pass
+  const int row = qmap ? qmap[q] : q;
+  HitOut* out = hits_out + (size_t)row * (size_t)k;
   if (fixed_info != nullptr) {
     // k_or_wide's keys: the high word is a fixed-point total (search_or_wide.hpp). score = total * 2^-e, rounded to f32
     // once; a hit whose total is below the query's floor asks for the f32 path (low_flags)
@@ -119,12 +123,12 @@ __global__ __launch_bounds__(WG_THREADS) void k_merge_items(const int64_t* __res
     const bool low = (lane < k && top.a != 0 && (uint32_t)(top.a >> 32) < (uint32_t)info.y) ||
                      (WIDE && lane + 64 < k && top.b != 0 && (uint32_t)(top.b >> 32) < (uint32_t)info.y);
     const uint64_t any_low = __ballot(low);
-    if (lane == 0) { totals_out[q] = total; low_flags[q] = any_low ? 1 : 0; }
+    if (lane == 0) { totals_out[row] = total; low_flags[q] = any_low ? 1 : 0; }
     return;
   }
   if (lane < k) out[lane] = top.a ? HitOut{key_doc(top.a) + doc_base, key_score(top.a)} : HitOut{-1, 0.f};
   if (WIDE && lane + 64 < k) out[lane + 64] = top.b ? HitOut{key_doc(top.b) + doc_base, key_score(top.b)} : HitOut{-1, 0.f};
-  if (lane == 0) totals_out[q] = total;
+  if (lane == 0) totals_out[row] = total;
 }
 
 // TopDocsCollector::finish_parallel across leaves / shards: list l's rows start at hits_in + l * hits_stride
@@ -154,15 +158,6 @@ __global__ __launch_bounds__(WG_THREADS) void k_merge_lists(const HitOut* __rest
   if (lane < k) out[lane] = top.a ? HitOut{key_doc(top.a), key_score(top.a)} : HitOut{-1, 0.f};
   if (WIDE && lane + 64 < k) out[lane + 64] = top.b ? HitOut{key_doc(top.b), key_score(top.b)} : HitOut{-1, 0.f};
   if (lane == 0) totals_out[q] = total;
-}
-
-// group-local result rows -> the caller's rows (queries are partitioned by op on the host)
-__global__ void k_scatter_rows(const HitOut* __restrict__ hits, const int64_t* __restrict__ totals, const int32_t* __restrict__ qmap,
-                               int k, HitOut* __restrict__ hits_out, int64_t* __restrict__ totals_out) {
-  const int q = (int)blockIdx.x;
-  const int dst = qmap[q];
-  for (int i = (int)threadIdx.x; i < k; i += (int)blockDim.x) hits_out[(size_t)dst * k + i] = hits[(size_t)q * k + i];
-  if (threadIdx.x == 0) totals_out[dst] = totals[q];
 }
 
 __global__ void k_init_hits(HitOut* __restrict__ hits, int64_t n) {

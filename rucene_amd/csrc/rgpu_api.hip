@@ -104,15 +104,13 @@ struct Scratch {
   DevVec<uint8_t> d_stage;
   DevVec<uint64_t> d_partial_keys;
   DevVec<int32_t> d_partial_counts;
-  DevVec<HitOut> d_hits;
-  DevVec<int64_t> d_totals;
   DevVec<unsigned long long> d_tau;  // per-query shared top-k thresholds
   DevVec<unsigned long long> d_touched;  // AND: per-query encoded bytes of the blocks the kernel decoded
   hipEvent_t done = nullptr;
   bool busy = false;
   void release() {
-    h_stage.release(); d_stage.release(); d_partial_keys.release(); d_partial_counts.release(); d_hits.release();
-    d_totals.release(); d_tau.release(); d_touched.release();
+    h_stage.release(); d_stage.release(); d_partial_keys.release(); d_partial_counts.release();
+    d_tau.release(); d_touched.release();
     if (done) (void)hipEventDestroy(done);
     done = nullptr;
   }
@@ -822,11 +820,12 @@ struct Group {  // queries of one op, in their original order
 
 template <bool WIDE>
 static void launch_merge(rgpu_ctx* c, hipStream_t s, int n_queries, int k, const int64_t* d_prefix, int32_t doc_base, HitOut* hits,
-                         int64_t* totals, int head_items = 0, const int2* fixed_info = nullptr, int32_t* low_flags = nullptr) {
+                         int64_t* totals, int head_items = 0, const int2* fixed_info = nullptr, int32_t* low_flags = nullptr,
+                         const int32_t* qmap = nullptr) {
   TimedLaunch tl(c, s, "k_merge_items", 0);
   const unsigned grid = (unsigned)((n_queries + WG_WAVES - 1) / WG_WAVES);
   hipLaunchKernelGGL(k_merge_items<WIDE>, dim3(grid), dim3(WG_THREADS), 0, s, d_prefix, n_queries, k, c->S->d_partial_keys.p,
-                     c->S->d_partial_counts.p, doc_base, head_items, hits, totals, fixed_info, low_flags);
+                     c->S->d_partial_counts.p, doc_base, head_items, hits, totals, fixed_info, low_flags, qmap);
 }
 
 // OR: score every clause once into {doc, score} runs, then accumulate per doc-id window (kernels/search_or.hpp)
@@ -913,8 +912,6 @@ static int32_t search_or_group(rgpu_segment* seg, Group& G, int32_t k, HitOut* h
   HIP_TRY(hipMemsetAsync(c->S->d_tau.p, 0, (size_t)nq * 8, stream));
   HIP_TRY(c->S->d_partial_keys.reserve((size_t)items2 * (size_t)k, 0, stream));
   HIP_TRY(c->S->d_partial_counts.reserve((size_t)items2, 0, stream));
-  HIP_TRY(c->S->d_hits.reserve((size_t)nq * (size_t)k, 0, stream));
-  HIP_TRY(c->S->d_totals.reserve((size_t)nq, 0, stream));
   const DevQuery* dq = reinterpret_cast<const DevQuery*>(c->S->d_stage.p + o_q);
   const DevTerm* dt = reinterpret_cast<const DevTerm*>(c->S->d_stage.p + o_t);
   const int64_t* dip = reinterpret_cast<const int64_t*>(c->S->d_stage.p + o_ip);
@@ -952,9 +949,8 @@ static int32_t search_or_group(rgpu_segment* seg, Group& G, int32_t k, HitOut* h
     };
     HIP_TRY(legacy ? pick(std::true_type{}) : pick(std::false_type{}));
   }
-  if (wide) launch_merge<true>(c, stream, nq, k, dmp, seg->doc_base, c->S->d_hits.p, c->S->d_totals.p);
-  else launch_merge<false>(c, stream, nq, k, dmp, seg->doc_base, c->S->d_hits.p, c->S->d_totals.p);
-  hipLaunchKernelGGL(k_scatter_rows, dim3((unsigned)nq), dim3(128), 0, stream, c->S->d_hits.p, c->S->d_totals.p, dm, (int)k, hits_dev, totals_dev);
+  if (wide) launch_merge<true>(c, stream, nq, k, dmp, seg->doc_base, hits_dev, totals_dev, 0, nullptr, nullptr, dm);
+  else launch_merge<false>(c, stream, nq, k, dmp, seg->doc_base, hits_dev, totals_dev, 0, nullptr, nullptr, dm);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(stream));  // staging / scratch buffers are reused by the next group
   return RGPU_OK;
@@ -1040,8 +1036,6 @@ static int32_t search_or_wide_group(rgpu_segment* seg, Group& G, int32_t k, HitO
   HIP_TRY(hipMemsetAsync(c->S->d_tau.p, 0, (size_t)nq * 8, stream));
   HIP_TRY(c->S->d_partial_keys.reserve((size_t)lists * (size_t)k, 0, stream));
   HIP_TRY(c->S->d_partial_counts.reserve((size_t)lists, 0, stream));
-  HIP_TRY(c->S->d_hits.reserve((size_t)nq * (size_t)k, 0, stream));
-  HIP_TRY(c->S->d_totals.reserve((size_t)nq, 0, stream));
   const DevQuery* dq = reinterpret_cast<const DevQuery*>(c->S->d_stage.p + o_q);
   const DevTerm* dt = reinterpret_cast<const DevTerm*>(c->S->d_stage.p + o_t);
   const int64_t* dmp = reinterpret_cast<const int64_t*>(c->S->d_stage.p + o_mp);
@@ -1063,9 +1057,8 @@ static int32_t search_or_wide_group(rgpu_segment* seg, Group& G, int32_t k, HitO
   }
   const int2* dfi = reinterpret_cast<const int2*>(c->S->d_stage.p + o_fi);
   int32_t* dfl = reinterpret_cast<int32_t*>(c->S->d_stage.p + o_fl);
-  if (wide) launch_merge<true>(c, stream, nq, k, dmp, seg->doc_base, c->S->d_hits.p, c->S->d_totals.p, 0, dfi, dfl);
-  else launch_merge<false>(c, stream, nq, k, dmp, seg->doc_base, c->S->d_hits.p, c->S->d_totals.p, 0, dfi, dfl);
-  hipLaunchKernelGGL(k_scatter_rows, dim3((unsigned)nq), dim3(128), 0, stream, c->S->d_hits.p, c->S->d_totals.p, dm, (int)k, hits_dev, totals_dev);
+  if (wide) launch_merge<true>(c, stream, nq, k, dmp, seg->doc_base, hits_dev, totals_dev, 0, dfi, dfl, dm);
+  else launch_merge<false>(c, stream, nq, k, dmp, seg->doc_base, hits_dev, totals_dev, 0, dfi, dfl, dm);
   HIP_TRY(hipGetLastError());
   std::vector<int32_t> low((size_t)nq);
   HIP_TRY(hipMemcpyAsync(low.data(), dfl, (size_t)nq * 4, hipMemcpyDeviceToHost, stream));
@@ -1196,10 +1189,18 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
     G.queries.push_back(dq);
   }
 
-  // defaults for every query (groups overwrite their own rows)
-  HIP_TRY(hipMemsetAsync(totals_dev, 0, (size_t)n_queries * 8, stream));
-  hipLaunchKernelGGL(k_init_hits, dim3((unsigned)(((size_t)n_queries * k + 255) / 256)), dim3(256), 0, stream, hits_dev,
-                     (int64_t)n_queries * k);
+  // defaults for every query (groups overwrite their own rows) — not needed when one group holds the whole batch and
+  // its merge writes every row (the usual serving case: two enqueues less per batch)
+  auto init_rows = [&]() -> int32_t {
+    HIP_TRY(hipMemsetAsync(totals_dev, 0, (size_t)n_queries * 8, stream));
+    hipLaunchKernelGGL(k_init_hits, dim3((unsigned)(((size_t)n_queries * k + 255) / 256)), dim3(256), 0, stream, hits_dev,
+                       (int64_t)n_queries * k);
+    return RGPU_OK;
+  };
+  int busy_groups = 0;
+  for (const Group& G : groups) busy_groups += G.queries.empty() ? 0 : 1;
+  const bool single_group = busy_groups == 1;
+  if (!single_group) { int32_t rc_i = init_rows(); if (rc_i != RGPU_OK) return rc_i; }
 
   const bool wide = k > 64;
   const bool legacy = seg->version < 1;
@@ -1209,6 +1210,7 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
     const int nq = (int)G.queries.size();
     if (nq == 0) continue;
     if (op == RGPU_OP_OR) {
+      if (single_group && G.terms.empty()) { int32_t rc_i = init_rows(); if (rc_i != RGPU_OK) return rc_i; }  // nothing will be merged
       int32_t rc_or = G.or_wide ? search_or_wide_group(seg, G, k, hits_dev, totals_dev, stream)
                                 : search_or_group(seg, G, k, hits_dev, totals_dev, stream);
       if (rc_or != RGPU_OK) return rc_or;
@@ -1244,26 +1246,28 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
       }
       items += head_items;
     }
-    if (items == 0) continue;
-    // group-local outputs, scattered to the caller's rows afterwards
+    if (items == 0) {
+      if (single_group) { int32_t rc_i = init_rows(); if (rc_i != RGPU_OK) return rc_i; }
+      continue;
+    }
+    // plan + thresholds in one staged copy; the merge writes the caller's rows in place (qmap)
     Stager st(c);
     const size_t o_q = st.add((size_t)nq * sizeof(DevQuery));
     const size_t o_t = st.add(std::max<size_t>(1, G.terms.size()) * sizeof(DevTerm));
     const size_t o_p = st.add((size_t)(nq + 1) * 8);
     const size_t o_m = st.add((size_t)nq * 4);
+    const size_t o_tau = st.add((size_t)nq * 8);  // the per-query shared thresholds: zeroed by the same copy that brings the plan
     HIP_TRY(c->S->h_stage.reserve(st.used));
     HIP_TRY(c->S->d_stage.reserve(st.used, 0, stream));
     std::memcpy(c->S->h_stage.p + o_q, G.queries.data(), (size_t)nq * sizeof(DevQuery));
     if (!G.terms.empty()) std::memcpy(c->S->h_stage.p + o_t, G.terms.data(), G.terms.size() * sizeof(DevTerm));
     std::memcpy(c->S->h_stage.p + o_p, G.item_prefix.data(), (size_t)(nq + 1) * 8);
     std::memcpy(c->S->h_stage.p + o_m, G.qmap.data(), (size_t)nq * 4);
+    std::memset(c->S->h_stage.p + o_tau, 0, (size_t)nq * 8);
     HIP_TRY(hipMemcpyAsync(c->S->d_stage.p, c->S->h_stage.p, st.used, hipMemcpyHostToDevice, stream));
     HIP_TRY(c->S->d_partial_keys.reserve((size_t)items * (size_t)k, 0, stream));
     HIP_TRY(c->S->d_partial_counts.reserve((size_t)items, 0, stream));
-    HIP_TRY(c->S->d_hits.reserve((size_t)nq * (size_t)k, 0, stream));
-    HIP_TRY(c->S->d_totals.reserve((size_t)nq, 0, stream));
-    HIP_TRY(c->S->d_tau.reserve((size_t)nq, 0, stream));
-    HIP_TRY(hipMemsetAsync(c->S->d_tau.p, 0, (size_t)nq * 8, stream));
+    unsigned long long* d_tau = reinterpret_cast<unsigned long long*>(c->S->d_stage.p + o_tau);
     const DevQuery* dq = reinterpret_cast<const DevQuery*>(c->S->d_stage.p + o_q);
     const DevTerm* dt = reinterpret_cast<const DevTerm*>(c->S->d_stage.p + o_t);
     const int64_t* dp = reinterpret_cast<const int64_t*>(c->S->d_stage.p + o_p);
@@ -1278,7 +1282,7 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
       const unsigned grid = (unsigned)((items + WG_WAVES - 1) / WG_WAVES);
       auto go = [&](auto kern) {
         hipLaunchKernelGGL(kern, dim3(grid), dim3(WG_THREADS), 0, stream, sv, dq, dt, dp, nq, items, blocks_per_item, (int)k,
-                           c->S->d_partial_keys.p, c->S->d_partial_counts.p, c->S->d_tau.p, c->S->d_touched.p,
+                           c->S->d_partial_keys.p, c->S->d_partial_counts.p, d_tau, c->S->d_touched.p,
                            (const int64_t*)nullptr, (unsigned long long*)nullptr, (int32_t*)nullptr);
       };
       bool has_not = false, has_opt = false;
@@ -1301,7 +1305,7 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(TERM_THREADS), lds, stream, sv, dq, dt, dp, nq, items, blocks_per_item, (int)k,
-                           c->S->d_partial_keys.p, c->S->d_partial_counts.p, c->S->d_tau.p);
+                           c->S->d_partial_keys.p, c->S->d_partial_counts.p, d_tau);
         return hipSuccess;
       };
       hipError_t e;
@@ -1309,10 +1313,9 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
       else e = wide ? go(k_search_term<false, true>) : go(k_search_term<false, false>);
       HIP_TRY(e);
     }
-    if (wide) launch_merge<true>(c, stream, nq, k, dp, seg->doc_base, c->S->d_hits.p, c->S->d_totals.p, head_items);
-    else launch_merge<false>(c, stream, nq, k, dp, seg->doc_base, c->S->d_hits.p, c->S->d_totals.p, head_items);
-    // scatter group rows to the caller's rows
-    hipLaunchKernelGGL(k_scatter_rows, dim3((unsigned)nq), dim3(128), 0, stream, c->S->d_hits.p, c->S->d_totals.p, dm, (int)k, hits_dev, totals_dev);
+    // the group's rows go straight to the caller's (qmap): no scatter pass
+    if (wide) launch_merge<true>(c, stream, nq, k, dp, seg->doc_base, hits_dev, totals_dev, head_items, nullptr, nullptr, dm);
+    else launch_merge<false>(c, stream, nq, k, dp, seg->doc_base, hits_dev, totals_dev, head_items, nullptr, nullptr, dm);
     HIP_TRY(hipGetLastError());
     HIP_TRY(scratch_mark(c, stream));  // no stream sync: the slot is waited for when it is taken again
   }
