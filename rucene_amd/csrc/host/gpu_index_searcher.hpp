@@ -111,6 +111,28 @@ struct BooleanQuery : Query {
   }
 };
 
+// PhraseQuery with slop 0 (query/phrase_query.rs:60-110: PhraseQuery::build numbers the terms' positions 0, 1, 2, ...;
+// explicit positions leave gaps). Needs a positions field (LeafReader::index_options == 3 with pos_bytes).
+struct PhraseQuery : Query {
+  std::vector<TermQuery> terms;
+  std::vector<int32_t> positions;
+  float boost;
+  explicit PhraseQuery(std::vector<TermQuery> t, std::vector<int32_t> pos = {}, float b = 1.0f)
+      : terms(std::move(t)), positions(std::move(pos)), boost(b) {
+    if (positions.empty()) for (size_t i = 0; i < terms.size(); ++i) positions.push_back(static_cast<int32_t>(i));
+    if (terms.size() < 2 || terms.size() != positions.size())
+      throw Error(RGPU_ERR_ILLEGAL_ARGUMENT, "a phrase needs two or more terms, one position each (a one-term phrase is a TermQuery)");
+  }
+};
+
+// RescoreRequest (search/scorer/rescorer.rs:67-116): how a second query's score is folded into the first pass's
+struct RescoreRequest {
+  const Query* query = nullptr;  // TermQuery, or an all-MUST / all-SHOULD BooleanQuery
+  float query_weight = 1.0f, rescore_weight = 1.0f;
+  rgpu_rescore_mode mode = RGPU_RESCORE_TOTAL;
+  int32_t window_size = 0;  // 0: the whole row
+};
+
 // One segment: postings file, norms, live docs, FieldReader statistics, and the terms: a block-tree dictionary
 // (rgpu_terms_open over the segment's .tim/.tip) and/or a flat term table.
 struct LeafReader {
@@ -125,6 +147,10 @@ struct LeafReader {
   int64_t n_terms = 0;
   const rgpu_terms* dictionary = nullptr;  // not owned
   int32_t field_number = 0;
+  // a positions field (index_options == 3): the .pos file and, for a flat term table, each term's position pointers
+  const uint8_t* pos_bytes = nullptr;
+  size_t pos_len = 0;
+  const rgpu_term_positions* term_positions = nullptr;
   rgpu_segment* segment = nullptr;  // filled by the searcher
   // TermIterator::seek_exact + term_state(); false when the term is absent from this leaf
   bool term_state(const TermQuery& q, rgpu_term_state* out) const {
@@ -137,6 +163,19 @@ struct LeafReader {
     }
     if (q.term >= n_terms || terms[q.term].doc_freq <= 0) return false;
     *out = terms[q.term];
+    return true;
+  }
+  // the same plus the position-stream pointers of BlockTermState (lucene50_decode_term, posting_reader.rs:264-306)
+  bool positions_state(const TermQuery& q, rgpu_term_state* out, rgpu_term_positions* pos) const {
+    if (q.by_text()) {
+      if (!dictionary) throw Error(RGPU_ERR_ILLEGAL_ARGUMENT, "this leaf has no term dictionary: query it by term id");
+      const int64_t offs[2] = {0, static_cast<int64_t>(q.text.size())};
+      uint8_t found = 0;
+      check(rgpu_terms_lookup_positions(dictionary, field_number, reinterpret_cast<const uint8_t*>(q.text.data()), offs, 1, out, pos, &found));
+      return found != 0;
+    }
+    if (!term_state(q, out) || !term_positions) return false;
+    *pos = term_positions[q.term];
     return true;
   }
 };
@@ -268,8 +307,10 @@ class GpuIndexSearcher {
     rgpu_config cfg{};
     cfg.abi_version = RGPU_ABI_VERSION;
     check(rgpu_init(device, &cfg, &ctx_));
-    for (auto& l : leaves_)
+    for (auto& l : leaves_) {
       check(rgpu_segment_upload_field(ctx_, l.doc_bytes, l.doc_len, l.norms, l.max_doc, l.doc_base, l.live_docs, l.index_options, &l.segment));
+      if (l.pos_bytes) check(rgpu_segment_attach_positions(l.segment, l.pos_bytes, l.pos_len));
+    }
     // searcher.rs:306-363: the first leaf with the largest max_doc provides the collection statistics
     for (size_t i = 1; i < leaves_.size(); ++i)
       if (leaves_[i].max_doc > leaves_[stats_leaf_].max_doc) stats_leaf_ = i;
@@ -324,7 +365,78 @@ class GpuIndexSearcher {
       check(rgpu_search_batch(leaves_[li].segment, qs.data(), nq, ts.data(), static_cast<int32_t>(ts.size()), static_cast<int32_t>(k),
                               leaf_hits[li].data(), leaf_totals[li].data()));
     }
-    // TopDocsCollector::finish_parallel (top_docs.rs:157-172) over a handful of leaves: canonical order
+    return merge_leaves(leaf_hits, leaf_totals, nq, k);
+  }
+
+  // IndexSearcher::search(PhraseQuery, TopDocsCollector(k)) for a batch of exact phrases. PhraseQuery::create_weight
+  // (phrase_query.rs:136-186): ONE BM25 weight from the statistics of all the phrase's terms.
+  std::vector<TopDocs> search_phrases(const std::vector<const PhraseQuery*>& queries, size_t k) {
+    const int32_t nq = static_cast<int32_t>(queries.size());
+    std::vector<std::vector<rgpu_hit>> leaf_hits(leaves_.size());
+    std::vector<std::vector<int64_t>> leaf_totals(leaves_.size());
+    for (size_t li = 0; li < leaves_.size(); ++li) {
+      const LeafReader& leaf = leaves_[li];
+      if (!leaf.pos_bytes) throw Error(RGPU_ERR_ILLEGAL_ARGUMENT, "phrase search needs a positions field (LeafReader::pos_bytes)");
+      std::vector<rgpu_phrase_query> qs;
+      std::vector<rgpu_phrase_term> ts;
+      for (const PhraseQuery* q : queries) {
+        std::vector<TermStatistics> stats;
+        for (const TermQuery& t : q->terms) stats.push_back(term_statistics(t));
+        const BM25SimWeight w = sim_.compute_weight(stats_, stats.data(), static_cast<int32_t>(stats.size()), q->boost);
+        if (sim_table_ < 0) check(sim_table_ = rgpu_sim_table_upload(ctx_, w.cache.data(), w.k1));
+        qs.push_back(rgpu_phrase_query{static_cast<int32_t>(q->terms.size()), static_cast<int32_t>(ts.size()), w.weight, sim_table_});
+        for (size_t i = 0; i < q->terms.size(); ++i) {
+          rgpu_phrase_term pt{};
+          if (!leaf.positions_state(q->terms[i], &pt.state, &pt.positions)) { pt.state = rgpu_term_state{}; pt.state.skip_offset = -1; pt.state.singleton_doc_id = -1; }
+          pt.position = q->positions[i];
+          ts.push_back(pt);
+        }
+      }
+      leaf_hits[li].assign(static_cast<size_t>(nq) * k, rgpu_hit{-1, 0.f});
+      leaf_totals[li].assign(static_cast<size_t>(nq), 0);
+      check(rgpu_search_phrase_batch(leaf.segment, qs.data(), nq, ts.data(), static_cast<int32_t>(ts.size()), static_cast<int32_t>(k),
+                                     leaf_hits[li].data(), leaf_totals[li].data()));
+    }
+    return merge_leaves(leaf_hits, leaf_totals, nq, k);
+  }
+
+  // QueryRescorer::rescore (search/scorer/rescorer.rs:118-226) for a batch: row i of `first_pass` is re-ranked by
+  // requests[i]. One device call per leaf; the last one sorts the windows and re-weights the tails.
+  std::vector<TopDocs> rescore(const std::vector<TopDocs>& first_pass, const std::vector<RescoreRequest>& requests, size_t k) {
+    const int32_t nq = static_cast<int32_t>(first_pass.size());
+    if (requests.size() != first_pass.size()) throw Error(RGPU_ERR_ILLEGAL_ARGUMENT, "one rescore request per row");
+    std::vector<rgpu_hit> rows(static_cast<size_t>(nq) * k, rgpu_hit{-1, 0.f});
+    std::vector<rgpu_rescore_request> reqs;
+    for (int32_t q = 0; q < nq; ++q) {
+      const std::vector<ScoreDoc>& docs = first_pass[static_cast<size_t>(q)].score_docs();
+      for (size_t i = 0; i < docs.size() && i < k; ++i) rows[static_cast<size_t>(q) * k + i] = rgpu_hit{docs[i].doc, docs[i].score};
+      const RescoreRequest& r = requests[static_cast<size_t>(q)];
+      reqs.push_back(rgpu_rescore_request{r.query_weight, r.rescore_weight, static_cast<int32_t>(r.mode),
+                                          r.window_size > 0 ? r.window_size : static_cast<int32_t>(k)});
+    }
+    for (size_t li = 0; li < leaves_.size(); ++li) {
+      std::vector<rgpu_query> qs;
+      std::vector<rgpu_query_term> ts;
+      for (const RescoreRequest& r : requests) pack(*r.query, leaves_[li], &qs, &ts);
+      check(rgpu_rescore_batch(leaves_[li].segment, qs.data(), nq, ts.data(), static_cast<int32_t>(ts.size()), reqs.data(),
+                               static_cast<int32_t>(k), rows.data(), li + 1 == leaves_.size() ? 1 : 0));
+    }
+    std::vector<TopDocs> out;
+    for (int32_t q = 0; q < nq; ++q) {
+      std::vector<ScoreDoc> docs;
+      for (size_t i = 0; i < k; ++i) {
+        const rgpu_hit& h = rows[static_cast<size_t>(q) * k + i];
+        if (h.doc >= 0) docs.push_back(ScoreDoc{h.doc, h.score});
+      }
+      out.emplace_back(first_pass[static_cast<size_t>(q)].total_hits(), std::move(docs));
+    }
+    return out;
+  }
+
+ private:
+  // TopDocsCollector::finish_parallel (top_docs.rs:157-172) over a handful of leaves: canonical order
+  std::vector<TopDocs> merge_leaves(const std::vector<std::vector<rgpu_hit>>& leaf_hits, const std::vector<std::vector<int64_t>>& leaf_totals,
+                                    int32_t nq, size_t k) const {
     std::vector<TopDocs> out;
     for (int32_t q = 0; q < nq; ++q) {
       std::vector<ScoreDoc> all;
@@ -345,7 +457,6 @@ class GpuIndexSearcher {
     return out;
   }
 
- private:
   std::pair<float, int32_t> weight_of(const TermQuery& tq) {
     // TermQuery::create_weight (term_query.rs:58-95) -> BM25Similarity::compute_weight
     const TermStatistics ts = term_statistics(tq);

@@ -1,7 +1,7 @@
 """BASELINE.json configs[0]: single-term BM25 queries over a 100k-doc synthetic index on the CPU IndexSearcher — here the
-oracle (C++ restatement; the Rust original cannot be built in this image). No GPU involved. usage: config0_cpu.py [threads]"""
+oracle (C++ restatement; the Rust original cannot be built in this image). No GPU involved. usage: tests/analysis/config0_cpu.py [threads]"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from rucene_amd import indexgen
 from oracle import binding as orc

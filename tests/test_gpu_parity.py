@@ -411,6 +411,73 @@ def test_cpp_host_mirror(oracle, tmp_path):
     assert out[2 * len(specs) + 1].endswith(" 1")
 
 
+def test_cpp_host_mirror_phrases_and_rescoring(ctx, oracle, tmp_path):
+    """The C++ host layer's PhraseQuery and QueryRescorer paths (csrc/host/gpu_index_searcher.hpp: search_phrases, rescore)
+    over a positions field handed over as raw files. Phrases: doc ids, hit counts and score bits against the oracle's
+    PhraseWeight + ExactPhraseScorer; rescoring: the same rows as the Python mirror's rescore_batch on the same segment
+    (which test_query_rescorer checks against the oracle's QueryRescorer)."""
+    import subprocess
+    import rucene_amd
+    from rucene_amd import _lib as gpu
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "phrase_rescore_demo")
+    libdir = os.path.join(root, "rucene_amd")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(root, "tests", "cpp", "phrase_rescore_demo.cpp"),
+                           "-L" + libdir, "-lrucene_gpu", "-Wl,-rpath," + libdir, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
+    rng = np.random.default_rng(606)
+    max_doc, vocab = 9000, 10
+    docs = [rng.integers(0, vocab, size=int(rng.integers(1, 50))).tolist() for _ in range(max_doc)]
+    postings = [[] for _ in range(vocab + 1)]  # the last term never occurs
+    for d, toks in enumerate(docs):
+        where = {}
+        for p, t in enumerate(toks):
+            where.setdefault(t, []).append(p)
+        for t, ps in where.items():
+            postings[t].append((d, ps))
+    ix = oracle.PositionsIndex(max_doc, postings, version=1)
+    doc_bytes, pos_bytes = ix.files()
+    n = len(postings)
+    terms = np.zeros(n, dtype=gpu.TERM_STATE_DTYPE)
+    tpos = np.zeros(n, dtype=gpu.TERM_POSITIONS_DTYPE)
+    for t in range(n):
+        st = ix.term_state(t)
+        terms[t] = (st["doc_start_fp"], st["skip_offset"], st["total_term_freq"], st["doc_freq"], st["singleton_doc_id"])
+        tpos[t]["pos_start_fp"], tpos[t]["last_pos_block_offset"] = st["pos_start_fp"], st["last_pos_block_offset"]
+    norms = rng.integers(95, 125, size=max_doc).astype(np.uint8)
+    sum_ttf = sum(len(toks) for toks in docs)
+    for name, blob in (("doc", doc_bytes), ("pos", pos_bytes), ("norms", norms.tobytes()), ("terms", terms.tobytes()), ("tpos", tpos.tobytes())):
+        (tmp_path / (name + ".bin")).write_bytes(bytes(blob))
+    out = subprocess.check_output([exe, str(tmp_path), str(max_doc), str(max_doc), str(sum_ttf)], text=True).strip().splitlines()
+
+    def parse(parts):
+        return [(int(p.split(":")[0]), int(p.split(":")[1], 16)) for p in parts]
+    phrases = [([0, 1], None), ([3, 3], None), ([4, 5, 6], None), ([2, 7], [0, 2]), ([1, n - 1], None)]
+    for i, (tq, offs) in enumerate(phrases):
+        parts = out[i].split()
+        assert parts[0] == "phrase" and int(parts[1]) == i
+        d, s, total = ix.phrase_search(tq, 10, norms, max_doc, max_doc, sum_ttf, offsets=offs if offs else list(range(len(tq))))
+        assert int(parts[2]) == total
+        got = parse(parts[3:])
+        assert [g[0] for g in got] == d.tolist() and [g[1] for g in got] == s.view(np.uint32).tolist(), (i, tq)
+    # rescoring: the Python mirror on the same files
+    leaf = rucene_amd.LeafReader(np.frombuffer(doc_bytes, np.uint8), norms, max_doc, terms, doc_count=max_doc, sum_total_term_freq=sum_ttf,
+                                 index_options=3)
+    gsearcher = rucene_amd.GpuIndexSearcher([leaf], ctx=ctx)
+    T, B = rucene_amd.TermQuery, rucene_amd.BooleanQuery
+    hits, _ = gsearcher.search_batch([T(0), T(1), T(2)], 10)
+    seconds = [B.build([], [T(4), T(5)]), B.build([T(0), T(2)], []), T(9)]
+    settings = [dict(mode=gpu.RESCORE_TOTAL, rescore_weight=2.0), dict(mode=gpu.RESCORE_MAX, window_size=5),
+                dict(mode=gpu.RESCORE_MULTIPLY, query_weight=0.5)]
+    for i in range(3):
+        want = gsearcher.rescore_batch(hits[i:i + 1], [seconds[i]], **settings[i])[0]
+        parts = out[len(phrases) + i].split()
+        assert parts[0] == "rescore" and int(parts[1]) == i
+        got = parse(parts[2:])
+        nn = int((want["doc"] >= 0).sum())
+        assert [g[0] for g in got] == want["doc"][:nn].tolist(), i
+        assert [g[1] for g in got] == want["score"][:nn].view(np.uint32).tolist(), i
+
+
 def test_negative_boost_and_raw_norm_mode(oracle):
     """Negative weights take the generic key path; raw_norms=True disables the LDS score table (256-entry cache)."""
     import rucene_amd
