@@ -43,6 +43,7 @@ constexpr int ORX_THREADS = 64 * ORX_WAVES;
 constexpr int ORX_OWN = (16 + ORX_WAVES - 1) / ORX_WAVES;  // clauses whose block bounds a wavefront keeps (c = wave + s * ORX_WAVES)
 constexpr int ORX_LOOK = RGPU_ORX_LOOK;    // directory entries looked at per clause per window, in units of 64
 constexpr int ORX_SCAN_STEP = 4 * ORX_THREADS;  // docs per scan step of the workgroup: windows are multiples of it
+constexpr int ORX_WAVES_PER_SIMD = ORX_WAVES >= 16 ? 4 : (2 * ORX_WAVES + 3) / 4;  // two workgroups per CU (one of 16 wavefronts)
 #ifndef RGPU_ORX_TABLES
 #define RGPU_ORX_TABLES 4
 #endif
@@ -67,7 +68,7 @@ __host__ __device__ constexpr size_t orx_lds_bytes(int WS) { return orx_fixed_ld
 // clauses that get a score table, DevQuery::pad = the query's fixed-point exponent e. Every wavefront writes its own
 // top-k list: item (q * items_per_query + g) * 8 + wave.
 template <bool LEGACY, bool WIDE>
-__global__ __launch_bounds__(ORX_THREADS, ORX_WAVES >= 16 ? 4 : 4) void k_or_wide(SegView seg, const DevQuery* __restrict__ queries,
+__global__ __launch_bounds__(ORX_THREADS, ORX_WAVES_PER_SIMD) void k_or_wide(SegView seg, const DevQuery* __restrict__ queries,
                                                             const DevTerm* __restrict__ terms, int n_queries,
                                                             int windows_per_query, int windows_per_item, int items_per_query,
                                                             int WS, int k, uint64_t* __restrict__ partial_keys,
