@@ -255,6 +255,9 @@ def test_multi_leaf_statistics_quirk_and_doc_base(ctx, oracle):
     gsearcher = rucene_amd.GpuIndexSearcher(leaves, ctx=ctx)
     specs = [(oracle.OP_TERM, [t]) for t in (0, 3, 50, 700, 4_999)] + [(oracle.OP_AND, [0, 2, 5]), (oracle.OP_OR, [1, 30, 200, 900])]
     _check_against_oracle(oracle, osearcher, gsearcher, specs, 20)
+    # ten and more SHOULD clauses (the order-free kernel, one launch per leaf), some of them absent from the small leaf
+    wide = [(oracle.OP_OR, [0, 1, 2, 7, 30, 200, 900, 2_000, 3_500, 4_999]), (oracle.OP_OR, list(range(5, 17)))]
+    _check_against_oracle(oracle, osearcher, gsearcher, wide, 20, exact=False)
 
 
 def test_search_api_reads_like_the_reference(zipf):
@@ -835,7 +838,8 @@ def test_sharded_search_through_the_c_abi_with_a_world_of_one(zipf, oracle):
     leaf = searcher.leaves[0]
     comm = gpu.Comm(searcher.ctx, 1, 0, gpu.comm_unique_id())
     T, B = rucene_amd.TermQuery, rucene_amd.BooleanQuery
-    queries = [T(3), T(700), B.build([T(1), T(4), T(20)], []), B.build([], [T(2), T(50), T(700), T(9000)]), T(123456789 % seg.terms.size)]
+    queries = [T(3), T(700), B.build([T(1), T(4), T(20)], []), B.build([], [T(2), T(50), T(700), T(9000)]), T(123456789 % seg.terms.size),
+               B.build([], [T(x) for x in (0, 1, 2, 7, 30, 200, 900, 2_000, 3_500, 4_999)])]  # ten clauses: fixed-point sums are deterministic
     packed = searcher.pack(queries, leaf)
     for k in (10, 100):
         want_h, want_t = leaf.segment.search_batch(packed[0], packed[1], k)
