@@ -329,7 +329,10 @@ def main():
     shard = Shard(args.docs, rank, rank * args.docs, world)
     res = measure(shard, args.workload, k, args.steps, args.warmup, two_streams=True)
     dom_name = DOMINANT[args.workload]
-    ms_per_step = res["ms_two_streams"]
+    # the headline is the faster of the two issue modes (both are in `streams`): two alternating streams win on one GPU
+    # (the next step's search kernel runs over this step's merge tail), one stream can win when every step ends in a collective
+    two_wins = res["ms_two_streams"] <= res["ms_one_stream"]
+    ms_per_step = res["ms_two_streams"] if two_wins else res["ms_one_stream"]
     out = {
         "metric": "queries/sec + postings decoded/sec, BM25 10M-doc synthetic",
         "value": world * nq / (ms_per_step * 1e-3),
@@ -344,7 +347,8 @@ def main():
             "docs_per_shard": args.docs, "vocab": args.vocab, "n_queries": nq, "k": k, "doc_format": ".doc v1 (SIMD-BP128)",
             "parallelism": "segment-sharded x%d, RCCL all-gather of per-shard top-k" % world,
             "postings_per_step_per_shard": res["postings"], "index_build_s": round(shard.build_s, 2), "device": ctx.device_name,
-            "issue": "value = two alternating streams (enqueue-only calls; step i+1's search kernel runs over step i's merge tail)",
+            "issue": ("value = two alternating streams (enqueue-only calls; step i+1's search kernel runs over step i's merge tail)" if two_wins
+                      else "value = one stream (enqueue-only calls back to back); the two-stream figure is in `streams`"),
         },
         "streams": {"one_stream_ms_per_step": res["ms_one_stream"], "one_stream_queries_per_sec": world * nq / (res["ms_one_stream"] * 1e-3),
                     "two_streams_ms_per_step": res["ms_two_streams"],

@@ -1653,6 +1653,11 @@ struct rgpu_comm {
   int n_ranks = 1, rank = 0;
   CommSlot slots[N_COMM_SLOTS];
   int next = 0;
+  // collectives of one communicator must not run side by side: when consecutive calls come on different streams, the
+  // later all-gather waits for the earlier one (an event), while the searches in front of them still overlap
+  hipStream_t last_stream = nullptr;
+  hipEvent_t last_collective = nullptr;
+  bool have_last = false;
 };
 #define NCCL_TRY(expr)                                                                                          \
   do {                                                                                                          \
@@ -1696,6 +1701,7 @@ extern "C" void rgpu_comm_destroy(rgpu_comm* comm) {
     sl.send.release();
     sl.recv.release();
   }
+  if (comm->last_collective) (void)hipEventDestroy(comm->last_collective);
   if (comm->nccl) (void)ncclCommDestroy(comm->nccl);
   delete comm;
 }
@@ -1719,7 +1725,12 @@ extern "C" int32_t rgpu_search_batch_sharded(rgpu_comm* comm, rgpu_segment* seg,
   HIP_TRY(sl.recv.reserve(record * (size_t)comm->n_ranks, 0, s));
   int32_t rc = search_impl(seg, queries, n_queries, terms, n_terms_total, k, (HitOut*)sl.send.p, (int64_t*)(sl.send.p + hits_bytes), s);
   if (rc != RGPU_OK) return rc;
+  if (comm->have_last && comm->last_stream != s) HIP_TRY(hipStreamWaitEvent(s, comm->last_collective, 0));
   NCCL_TRY(ncclAllGather(sl.send.p, sl.recv.p, record, ncclInt8, comm->nccl, s));
+  if (!comm->last_collective) HIP_TRY(hipEventCreateWithFlags(&comm->last_collective, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(comm->last_collective, s));
+  comm->last_stream = s;
+  comm->have_last = true;
   {
     TimedLaunch tl(c, s, "k_merge_lists", 0);
     const unsigned grid = (unsigned)((n_queries + WG_WAVES - 1) / WG_WAVES);
