@@ -62,7 +62,10 @@ typedef struct rgpu_config {
   int32_t or_wide;              /* disjunctions of >= 10 SHOULD clauses (where the reference itself sums in heap order) through the
                                    order-free workgroup-window kernel: 0 = yes (default), -1 = no (clause-order kernel for all) */
   int32_t or_wide_window_docs;  /* docs per workgroup window of that kernel (0 = default 12288; 2048..14336, rounded to 2048) */
-  int32_t reserved[7];          /* must be zero */
+  int32_t req_opt_rule;         /* MUST + SHOULD trees: 0 = the reference's ReqOptScorer, skipping rule included (default: exact
+                                   scores, a sequential pass per query); -1 = always add the optional sums (faster, scores >= the
+                                   reference's) */
+  int32_t reserved[6];          /* must be zero */
 } rgpu_config;
 
 /* blocktree/mod.rs:33-59 BlockTermState, as filled by posting_reader.rs:264-306 lucene50_decode_term.
@@ -98,10 +101,12 @@ typedef enum rgpu_query_op {
  * stored between the MUST clauses and the MUST_NOT ones. BooleanWeight::create_scorer builds ReqOptScorer(must,
  * DisjunctionSumScorer(should)) for such a tree (query/boolean_query.rs:217-233, 253-262; scorer/req_opt_scorer.rs): the
  * SHOULD clauses never change which docs match, each one found on a matching doc adds its score (summed on their own in
- * clause order, then added to the MUST sum). DEVIATION, by design: the reference's ReqOptScorer::score skips the optional
- * clauses for a doc whose MUST score is under half the running mean of earlier docs' MUST scores once 100 docs were
- * scored (:46-50) — state carried from doc to doc in iteration order. This library always adds them: doc ids and hit
- * counts equal the reference's, scores are >= the reference's and equal wherever the reference did not skip. */
+ * clause order, then added to the MUST sum). ReqOptScorer::score carries state from doc to doc: once more than 100 docs
+ * took the optional path, a doc whose MUST score is under half the running mean of those docs' MUST scores returns the
+ * MUST score alone (:46-50). That rule is applied (default): the conjunction kernel leaves one record per lead posting and a
+ * second kernel walks a query's matches in doc order (a sequential pass: a few ms per million matches) — scores equal the
+ * reference's bit for bit. rgpu_config.req_opt_rule = -1 always adds the optional sums instead (one pass; doc ids and hit
+ * counts equal the reference's, scores >= its and equal wherever it did not skip). */
 #define RGPU_OP_WITH_SHOULD(op, n_should) ((int32_t)(op) | ((int32_t)(n_should) << 16))
 
 typedef struct rgpu_query {
@@ -194,10 +199,8 @@ int32_t rgpu_sim_table_upload(rgpu_ctx* ctx, const float cache[256], float k1);
  * CPU scorers. OR with >= 10 clauses: within 1e-5 relative — the reference sums those in heap order
  * (disjunction_scorer.rs:41-45), so it pins a score no tighter itself; here such a doc's score is the exact sum of its
  * clause scores in fixed point (2^-e steps, e per query), rounded to f32 once: deterministic, independent of any
- * order, hit counts exact (kernels/search_or_wide.hpp; rgpu_config.or_wide = -1 sums in f32 in clause order instead). ONE exception, by
- * design: queries carrying RGPU_OP_WITH_SHOULD clauses always add the optional scores, where the reference's
- * ReqOptScorer skips them for low scorers after 100 docs (see the macro above) — doc ids and hit counts equal the
- * reference's, scores are >= its. */
+ * order, hit counts exact (kernels/search_or_wide.hpp; rgpu_config.or_wide = -1 sums in f32 in clause order instead). MUST + SHOULD
+ * trees follow the reference's ReqOptScorer including its sequential skipping rule (see RGPU_OP_WITH_SHOULD). */
 int32_t rgpu_search_batch(rgpu_segment* seg, const rgpu_query* queries, int32_t n_queries, const rgpu_query_term* terms,
                           int32_t n_terms_total, int32_t k, rgpu_hit* hits_out, int64_t* total_hits_out);
 /* Same with device-resident outputs (for the RCCL all-gather of per-shard top-k). Enqueue-only for TERM / AND

@@ -67,7 +67,7 @@ class _Config(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("blocks_per_item", C.c_int32), ("and_blocks_per_item", C.c_int32),
                 ("profile_kernels", C.c_int32), ("or_window_docs", C.c_int32), ("or_dense_clauses", C.c_int32),
                 ("raw_norms", C.c_int32), ("or_wide", C.c_int32), ("or_wide_window_docs", C.c_int32),
-                ("reserved", C.c_int32 * 7)]
+                ("req_opt_rule", C.c_int32), ("reserved", C.c_int32 * 6)]
 
 
 class _KernelStat(C.Structure):
@@ -314,7 +314,7 @@ class Context:
     """rgpu_ctx: one per process per GPU."""
 
     def __init__(self, device=0, profile_kernels=False, blocks_per_item=0, and_blocks_per_item=0, or_window_docs=0,
-                 raw_norms=False, or_dense_clauses=0, or_wide=0, or_wide_window_docs=0):
+                 raw_norms=False, or_dense_clauses=0, or_wide=0, or_wide_window_docs=0, req_opt_rule=0):
         cfg = _Config()
         cfg.abi_version = ABI_VERSION
         cfg.blocks_per_item = blocks_per_item
@@ -325,6 +325,7 @@ class Context:
         cfg.raw_norms = int(raw_norms)
         cfg.or_wide = or_wide
         cfg.or_wide_window_docs = or_wide_window_docs
+        cfg.req_opt_rule = req_opt_rule
         h = C.c_void_p()
         _check(lib().rgpu_init(device, C.byref(cfg), C.byref(h)))
         self._h = h

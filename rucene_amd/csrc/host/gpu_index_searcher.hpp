@@ -86,8 +86,8 @@ struct BooleanQuery : Query {
   std::vector<TermQuery> must_queries, should_queries, must_not_queries;
   int32_t min_should_match = 0;
   // boolean_query.rs:40-86 restricted to what the GPU path serves: SHOULD-only term trees, or MUST clauses with optional
-  // SHOULD clauses beside them (ReqOptScorer, scored without the reference's sequential skipping rule: see
-  // RGPU_OP_WITH_SHOULD), each optionally with MUST_NOT term clauses (ReqNotScorer); a single clause without MUST_NOTs
+  // SHOULD clauses beside them (ReqOptScorer, its sequential skipping rule included: see RGPU_OP_WITH_SHOULD), each
+  // optionally with MUST_NOT term clauses (ReqNotScorer); a single clause without MUST_NOTs
   // collapses to that clause
   // FILTER clauses are required clauses that score 0 (create_weight with needs_scores = false -> NonScoringSimilarity,
   // boolean_query.rs:106-108, searcher.rs:158-202): they join the MUST clauses with boost 0, which leaves every sum unchanged

@@ -93,6 +93,15 @@ struct DirWindow {
 
 constexpr int AND_FILTER_WORDS = 64;  // 2048-bit membership filter per wavefront
 
+// What a MUST + SHOULD tree leaves per LEAD posting when the reference's ReqOptScorer rule is applied (k_req_opt_scan):
+// the conjunction's matches in doc order (= lead posting order), each with its required and its optional sum. A lead
+// posting that is no match (or a deleted doc) leaves doc = -1.
+struct SeqRec {
+  int32_t doc;
+  float req, opt;
+  int32_t pad;
+};
+
 // HAS_NOT / HAS_OPT: some query of the launch carries MUST_NOT / optional SHOULD clauses (separate instantiations keep the
 // common kernel lean). Clause order on the device: [MUST x n_terms][MUST_NOT x pad][SHOULD x (op >> 16)].
 template <bool LEGACY, bool WIDE, bool HAS_NOT, bool HAS_OPT>
@@ -106,7 +115,12 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
                                                            unsigned long long* __restrict__ touched_slots,
                                                            const int64_t* __restrict__ emit_prefix,
                                                            unsigned long long* __restrict__ emit_count,
-                                                           int32_t* __restrict__ emit_docs) {
+                                                           void* __restrict__ emit_out) {
+  // emit_out != null: nothing is collected here. Without HAS_OPT (phrases): int32 doc ids appended to the query's list
+  // at emit_prefix[q] in any order, emit_count[q] the cursor. With HAS_OPT (the exact ReqOptScorer rule): one SeqRec per
+  // lead posting at emit_prefix[q] + the posting's ordinal — doc order, no cursor.
+  int32_t* const emit_docs = HAS_OPT ? nullptr : static_cast<int32_t*>(emit_out);
+  SeqRec* const seq_out = HAS_OPT ? static_cast<SeqRec*>(emit_out) : nullptr;
   __shared__ __attribute__((aligned(16))) uint8_t slabs[WG_WAVES][2 * SLAB_STREAM];  // FullBlock staging only: tails arrive decoded
   __shared__ float caches[WG_WAVES][256];
   __shared__ uint32_t filters[WG_WAVES][AND_FILTER_WORDS];
@@ -141,7 +155,7 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
 
   // nn: the candidates' norm bytes — from the lead's posting-order norms for FullBlocks, gathered for
   // its tail; every other clause scores the same docs, so no clause ever gathers norms again
-  auto intersect = [&](int32_t d0, int32_t d1, uint32_t f0, uint32_t f1, uint32_t nn, bool a0, bool a1) {  // nn = norm byte 0 | norm byte 1 << 8
+  auto intersect = [&](int32_t d0, int32_t d1, uint32_t f0, uint32_t f1, uint32_t nn, bool a0, bool a1, int32_t ord0) {  // nn = norm byte 0 | norm byte 1 << 8; ord0 = ordinal of the wave's first lead posting
     a0 = a0 && doc_in_segment(seg, d0) && doc_is_live(seg.live, d0);
     a1 = a1 && doc_in_segment(seg, d1) && doc_is_live(seg.live, d1);
     use_table(L.sim_table);
@@ -327,6 +341,13 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
         }
       }
     }
+    if (HAS_OPT && seq_out != nullptr) {
+      const int32_t ord = ord0 + 2 * lane;  // ordinals below the lead's doc_freq are postings (a tail fills only some lanes)
+      SeqRec* rec = seq_out + emit_prefix[q] + ord;
+      if (ord < L.df) rec[0] = SeqRec{a0 ? d0 : -1, in_opt ? r0 : s0, in_opt ? s0 : 0.f, 0};
+      if (ord + 1 < L.df) rec[1] = SeqRec{a1 ? d1 : -1, in_opt ? r1 : s1, in_opt ? s1 : 0.f, 0};
+      return;
+    }
     if (HAS_OPT && in_opt) { s0 = r0 + s0; s1 = r1 + s1; }
     if (emit_docs != nullptr) {
       // Phrase queries (search_phrase.hpp): the conjunction's matches are not collected but handed on, every one of them,
@@ -379,7 +400,7 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
       if (has_norms && a1) nn |= norm_at(seg, d1) << 8;
     }
     if (RGPU_AND_ABL == 1) { if (a0 && d0 == 12345 && f0 == 77 && nn == 3) count++; continue; }
-    intersect(d0, d1, f0, f1, nn, a0, a1);
+    intersect(d0, d1, f0, f1, nn, a0, a1, blk < L.nblocks ? 128 * blk : (L.df == 1 ? 0 : 128 * L.nblocks));
   }
   shared.publish<WIDE>(top, k, lane);
   uint64_t* pk = partial_keys + (size_t)item * (size_t)k;
@@ -389,6 +410,58 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
     partial_counts[item] = count;
     atomicAdd(touched_slots + q, (unsigned long long)touched);  // ~160 items per query word: no contention to speak of
   }
+}
+
+// ReqOptScorer::score (search/scorer/req_opt_scorer.rs:41-66) over a query's matches in doc order, one wavefront per query.
+// The scorer carries state from doc to doc: the sum and the number of the required scores of the docs that took the
+// optional path; once more than 100 did, a doc whose required score is under half their mean returns the required score
+// alone and leaves the state untouched. An f32 running sum in iteration order cannot be re-associated, so the matches
+// of a query are walked one by one (the 64 records of a step are loaded together, the decisions are scalar: one add,
+// one divide, one compare per match) — a few ms per million matches, the price of the reference's exact scores for
+// MUST + SHOULD trees (rgpu_config.req_opt_rule = -1 adds the optional sums everywhere instead, in the conjunction
+// kernel itself). The collector part is the usual one: every match counts, keys go to the wavefront's top-k.
+constexpr int REQ_OPT_THRESHOLD = 100;  // OPT_SCORE_THRESHOLD (req_opt_scorer.rs:19)
+template <bool WIDE>
+__global__ __launch_bounds__(WG_THREADS) void k_req_opt_scan(const SeqRec* __restrict__ seq, const int64_t* __restrict__ seq_prefix,
+                                                             int n_queries, int k, int32_t doc_base, const int32_t* __restrict__ qmap,
+                                                             HitOut* __restrict__ hits_out, int64_t* __restrict__ totals_out) {
+  const int lane = lane_id();
+  const int q = (int)(blockIdx.x * WG_WAVES) + wave_id();
+  if (q >= n_queries) return;
+  const int64_t i0 = seq_prefix[q], i1 = seq_prefix[q + 1];
+  WaveTopK top;
+  uint64_t tau = 0;
+  int64_t total = 0;
+  float scores_sum = 0.0f;  // wave-uniform
+  int scores_num = 0;
+  for (int64_t at = i0; at < i1; at += 64) {
+    SeqRec r = SeqRec{-1, 0.f, 0.f, 0};
+    if (at + lane < i1) r = seq[at + lane];
+    const bool valid = r.doc >= 0;
+    uint64_t m = __ballot(valid);
+    total += __popcll(m);
+    uint64_t skipped = 0;
+    while (m) {  // in doc order
+      const int l = __builtin_ctzll(m);
+      m &= m - 1;
+      const float score = __int_as_float(readlane(__float_as_int(r.req), l));
+      bool skip = false;
+      if (scores_num > REQ_OPT_THRESHOLD) skip = 2.0f * score < scores_sum / (float)scores_num;
+      if (skip) {
+        skipped |= 1ull << l;
+      } else {
+        scores_sum += score;
+        scores_num += 1;
+      }
+    }
+    const float final_score = ((skipped >> lane) & 1ull) ? r.req : r.req + r.opt;
+    topk_offer<WIDE>(top, valid ? make_key(final_score, r.doc) : 0ull, tau, k, lane);
+  }
+  const int row = qmap ? qmap[q] : q;
+  HitOut* out = hits_out + (size_t)row * (size_t)k;
+  if (lane < k) out[lane] = top.a ? HitOut{key_doc(top.a) + doc_base, key_score(top.a)} : HitOut{-1, 0.f};
+  if (WIDE && lane + 64 < k) out[lane + 64] = top.b ? HitOut{key_doc(top.b) + doc_base, key_score(top.b)} : HitOut{-1, 0.f};
+  if (lane == 0) totals_out[row] = total;
 }
 
 }  // namespace rgpu

@@ -810,6 +810,7 @@ namespace {
 struct Group {  // queries of one op, in their original order
   int op = 0;
   bool or_wide = false;         // OR queries of >= 10 clauses: the order-free workgroup-window kernel
+  bool req_opt = false;         // MUST + SHOULD trees under the reference's ReqOptScorer rule: conjunction records + sequential scan
   std::vector<int32_t> qmap;    // original query index
   std::vector<DevQuery> queries;
   std::vector<DevTerm> terms;
@@ -1119,6 +1120,11 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
   for (int i = 0; i < 3; ++i) groups[(size_t)i].op = i;
   groups[3].op = RGPU_OP_OR;  // disjunctions the reference sums in heap order (>= 10 sub-scorers): k_or_wide
   groups[3].or_wide = true;
+  groups.emplace_back();
+  groups[4].op = RGPU_OP_AND;  // MUST + SHOULD trees scored with ReqOptScorer's sequential rule (k_search_and records + k_req_opt_scan)
+  groups[4].req_opt = true;
+  int cur_req_opt = 4;
+  int64_t req_opt_records = 0;
   const bool or_wide_ok = c->cfg.or_wide >= 0 && seg->d_norms && seg->n_norm_ranks > 0 && !seg->d_live;
   std::vector<DevTerm> mine, mine_not, mine_opt;
   for (int32_t q = 0; q < n_queries; ++q) {
@@ -1174,7 +1180,19 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
       groups.back().op = RGPU_OP_OR;
       cur_group[2] = (int)groups.size() - 1;
     }
-    Group& G = to_wide ? groups[3] : groups[(size_t)cur_group[gop]];
+    const bool to_req_opt = gop == RGPU_OP_AND && !mine_opt.empty() && !mine.empty() && c->cfg.req_opt_rule >= 0;
+    if (to_req_opt) {  // one record per lead posting: keep a group's records under 1 GiB
+      const int64_t lead_df = mine[0].df;
+      if (req_opt_records > 0 && req_opt_records + lead_df > (64ll << 20)) {
+        groups.emplace_back();
+        groups.back().op = RGPU_OP_AND;
+        groups.back().req_opt = true;
+        cur_req_opt = (int)groups.size() - 1;
+        req_opt_records = 0;
+      }
+      req_opt_records += lead_df;
+    }
+    Group& G = to_wide ? groups[3] : (to_req_opt ? groups[(size_t)cur_req_opt] : groups[(size_t)cur_group[gop]]);
     DevQuery dq;
     // the window kernel reads min_should_match from the second byte, the conjunction kernel its optional clause count
     // from the third; device clause order: MUST, MUST_NOT, SHOULD
@@ -1257,6 +1275,16 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
     const size_t o_p = st.add((size_t)(nq + 1) * 8);
     const size_t o_m = st.add((size_t)nq * 4);
     const size_t o_tau = st.add((size_t)nq * 8);  // the per-query shared thresholds: zeroed by the same copy that brings the plan
+    // ReqOptScorer's rule: one record per lead posting, query after query
+    const size_t o_sp = G.req_opt ? st.add((size_t)(nq + 1) * 8) : 0;
+    std::vector<int64_t> seq_prefix;
+    if (G.req_opt) {
+      seq_prefix.assign((size_t)nq + 1, 0);
+      for (int q = 0; q < nq; ++q) {
+        const DevQuery& dq0 = G.queries[(size_t)q];
+        seq_prefix[(size_t)q + 1] = seq_prefix[(size_t)q] + (dq0.n_terms >= 1 ? (int64_t)G.terms[(size_t)dq0.first_term].df : 0);
+      }
+    }
     HIP_TRY(c->S->h_stage.reserve(st.used));
     HIP_TRY(c->S->d_stage.reserve(st.used, 0, stream));
     std::memcpy(c->S->h_stage.p + o_q, G.queries.data(), (size_t)nq * sizeof(DevQuery));
@@ -1264,6 +1292,7 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
     std::memcpy(c->S->h_stage.p + o_p, G.item_prefix.data(), (size_t)(nq + 1) * 8);
     std::memcpy(c->S->h_stage.p + o_m, G.qmap.data(), (size_t)nq * 4);
     std::memset(c->S->h_stage.p + o_tau, 0, (size_t)nq * 8);
+    if (G.req_opt) std::memcpy(c->S->h_stage.p + o_sp, seq_prefix.data(), (size_t)(nq + 1) * 8);
     HIP_TRY(hipMemcpyAsync(c->S->d_stage.p, c->S->h_stage.p, st.used, hipMemcpyHostToDevice, stream));
     HIP_TRY(c->S->d_partial_keys.reserve((size_t)items * (size_t)k, 0, stream));
     HIP_TRY(c->S->d_partial_counts.reserve((size_t)items, 0, stream));
@@ -1280,10 +1309,18 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
       c->last_and_queries = nq;
       TimedLaunch tl(c, stream, "k_search_and", G.postings);
       const unsigned grid = (unsigned)((items + WG_WAVES - 1) / WG_WAVES);
+      const int64_t* d_sp = nullptr;
+      void* d_seq = nullptr;
+      if (G.req_opt) {  // records instead of a collector (the buffer is the context's run scratch: this group ends with a stream sync)
+        static_assert(sizeof(SeqRec) == 2 * sizeof(ScoredPosting), "SeqRec records are laid over the run scratch");
+        HIP_TRY(c->d_runs.reserve((size_t)seq_prefix[(size_t)nq] * 2 + 64, 0, stream));
+        d_sp = reinterpret_cast<const int64_t*>(c->S->d_stage.p + o_sp);
+        d_seq = c->d_runs.p;
+      }
       auto go = [&](auto kern) {
         hipLaunchKernelGGL(kern, dim3(grid), dim3(WG_THREADS), 0, stream, sv, dq, dt, dp, nq, items, blocks_per_item, (int)k,
                            c->S->d_partial_keys.p, c->S->d_partial_counts.p, d_tau, c->S->d_touched.p,
-                           (const int64_t*)nullptr, (unsigned long long*)nullptr, (int32_t*)nullptr);
+                           d_sp, (unsigned long long*)nullptr, d_seq);
       };
       bool has_not = false, has_opt = false;
       for (const DevQuery& q : G.queries) { has_not = has_not || q.pad != 0; has_opt = has_opt || (q.op >> 16) != 0; }
@@ -1312,6 +1349,18 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
       if (legacy) e = wide ? go(k_search_term<true, true>) : go(k_search_term<true, false>);
       else e = wide ? go(k_search_term<false, true>) : go(k_search_term<false, false>);
       HIP_TRY(e);
+    }
+    if (G.req_opt) {  // the scan is the collector: rows written in place
+      TimedLaunch tl(c, stream, "k_req_opt_scan", G.postings);
+      const unsigned grid = (unsigned)((nq + WG_WAVES - 1) / WG_WAVES);
+      const SeqRec* d_seq = reinterpret_cast<const SeqRec*>(c->d_runs.p);
+      const int64_t* d_sp = reinterpret_cast<const int64_t*>(c->S->d_stage.p + o_sp);
+      if (wide) hipLaunchKernelGGL(k_req_opt_scan<true>, dim3(grid), dim3(WG_THREADS), 0, stream, d_seq, d_sp, nq, (int)k, seg->doc_base, dm, hits_dev, totals_dev);
+      else hipLaunchKernelGGL(k_req_opt_scan<false>, dim3(grid), dim3(WG_THREADS), 0, stream, d_seq, d_sp, nq, (int)k, seg->doc_base, dm, hits_dev, totals_dev);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipStreamSynchronize(stream));  // the record buffer is shared scratch
+      HIP_TRY(scratch_mark(c, stream));
+      continue;
     }
     // the group's rows go straight to the caller's (qmap): no scatter pass
     if (wide) launch_merge<true>(c, stream, nq, k, dp, seg->doc_base, hits_dev, totals_dev, head_items, nullptr, nullptr, dm);
@@ -1516,7 +1565,7 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
       auto go = [&](auto kern) {
         hipLaunchKernelGGL(kern, dim3(grid), dim3(WG_THREADS), 0, stream, sv, d_q, d_t, d_ip, (int)n_queries, items, blocks_per_item, (int)k,
                            c->S->d_partial_keys.p, c->S->d_partial_counts.p, c->S->d_tau.p, c->S->d_touched.p, d_ep, c->phrase_count.p,
-                           c->phrase_docs.p);
+                           (void*)c->phrase_docs.p);
       };
       if (legacy) go(k_search_and<true, false, false, false>); else go(k_search_and<false, false, false, false>);
     }

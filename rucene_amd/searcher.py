@@ -237,8 +237,8 @@ class PhraseQuery:
 
 class BooleanQuery:
     """Only the trees the GPU path serves: all-SHOULD with any min_should_match (OR), or MUST clauses (AND) with optional
-    SHOULD clauses beside them (ReqOptScorer, boolean_query.rs:253-262 — scored without the reference's sequential
-    skipping rule, see RGPU_OP_WITH_SHOULD in include/rucene_gpu.h); each optionally with MUST_NOT TermQuery clauses
+    SHOULD clauses beside them (ReqOptScorer, boolean_query.rs:253-262 — its sequential skipping rule included unless the
+    context was opened with req_opt_rule=-1, see RGPU_OP_WITH_SHOULD in include/rucene_gpu.h); each optionally with MUST_NOT TermQuery clauses
     (ReqNotScorer, boolean_query.rs:235-273). FILTER clauses are required clauses that score 0 (create_weight with
     needs_scores = false -> NonScoringSimilarity, boolean_query.rs:106-108, searcher.rs:158-202): they ride as MUST clauses
     of weight 0, which leaves every f32 sum unchanged."""

@@ -731,37 +731,60 @@ def test_index_directory_opened_and_searched(ctx, oracle, tmp_path):
 
 
 def test_must_with_optional_should_clauses(zipf, oracle):
-    """MUST + SHOULD trees (ReqOptScorer, boolean_query.rs:253-262), also under MUST_NOT (ReqNotScorer around it). The GPU
-    always adds the optional clauses' scores; the reference skips them for some low scorers once 100 docs were scored
-    (req_opt_scorer.rs:46-50, sequential state). So: bit-exact against the oracle with that rule switched off, and
-    against the rule-following oracle the same hit counts with every common doc scored >= the reference."""
+    """MUST + SHOULD trees (ReqOptScorer, boolean_query.rs:253-262), also under MUST_NOT (ReqNotScorer around it). The
+    reference's scorer carries state from doc to doc: once more than 100 docs were scored, a doc whose required score is
+    under half the running mean skips the optional clauses (req_opt_scorer.rs:41-66). Default: that rule is applied
+    (k_search_and leaves one record per lead posting, k_req_opt_scan walks them in doc order) — doc ids, score bits and hit
+    counts equal the rule-following oracle's. With req_opt_rule = -1 the optional sums are always added: bit-exact against
+    the oracle with the rule switched off, and >= the rule-following oracle's on every common doc."""
     import rucene_amd
     seg, osearcher, gsearcher = zipf
     T, B = rucene_amd.TermQuery, rucene_amd.BooleanQuery
     specs = [([0, 1], [2, 7], []), ([3], [1], []), ([900, 5], [0, 1, 2], []), ([2000, 2500], [0], []), ([40], [0], [9]),
              ([1, 4], [2], [3, 6]), ([10], [49_999], []), ([6, 2, 30], [1, 0, 3, 4, 5, 7, 8, 9, 11], []), ([0], [1], [2]),
-             ([12, 7], [7, 12], []), ([49_998], [0, 1], []), ([5], [6], [5])]
+             ([12, 7], [7, 12], []), ([49_998], [0, 1], []), ([5], [6], [5]), ([0], [300], []), ([1], [49_999, 2], [])]
     queries = [B.build([T(t) for t in m], [T(t) for t in s], must_nots=[T(t) for t in n]) for m, s, n in specs]
-    skipped_somewhere = 0
+    differs_somewhere = 0
     for k in (10, 100):
         hits, totals = gsearcher.search_batch(queries, k)
         for i, (m, s, n) in enumerate(specs):
-            ed, es, et = osearcher.search_opt(oracle.OP_AND, m, s, k, must_not_ids=n, exact=True)
-            rd, rs, rt = osearcher.search_opt(oracle.OP_AND, m, s, k, must_not_ids=n)
-            cnt = len(ed)
+            rd, rs, rt = osearcher.search_opt(oracle.OP_AND, m, s, k, must_not_ids=n)                 # the reference's rule
+            ed, es, et = osearcher.search_opt(oracle.OP_AND, m, s, k, must_not_ids=n, exact=True)      # rule switched off
+            cnt = len(rd)
             gd, gs = hits[i]["doc"], hits[i]["score"]
-            assert totals[i] == et == rt, (i, specs[i])
+            assert totals[i] == rt == et, (i, specs[i])
             assert (gd[cnt:] == -1).all()
-            assert (gd[:cnt] == ed).all(), (i, specs[i], gd[:cnt], ed)
-            assert (gs[:cnt].view(np.int32) == es.view(np.int32)).all(), (i, specs[i])
-            ref = dict(zip(rd.tolist(), rs.tolist()))
-            for d, sc in zip(gd[:cnt].tolist(), gs[:cnt].tolist()):
-                if d in ref:
-                    assert sc >= ref[d]
-                    skipped_somewhere += sc > ref[d]
+            assert (gd[:cnt] == rd).all(), (i, specs[i], gd[:cnt], rd)
+            assert (gs[:cnt].view(np.int32) == rs.view(np.int32)).all(), (i, specs[i])
+            differs_somewhere += int(len(ed) != len(rd) or (ed != rd).any() or (es.view(np.int32) != rs.view(np.int32)).any())
+    assert differs_somewhere > 0  # the rule really changed some of these results: the test would notice its absence
+    # mixed with other operators in one batch, and through the plain-AND group when nothing optional is present
+    mixed = [T(7), queries[0], B.build([T(1), T(2)], []), queries[5], B.build([], [T(3), T(4)])]
+    mh, mt = gsearcher.search_batch(mixed, 10)
+    assert mh[1].tobytes() == gsearcher.search_batch([queries[0]], 10)[0][0].tobytes()
+    assert mh[3].tobytes() == gsearcher.search_batch([queries[5]], 10)[0][0].tobytes()
     # without SHOULD clauses present in the leaf the tree degenerates to the plain conjunction
     plain, pt = gsearcher.search_batch([B.build([T(0), T(1)], []), B.build([T(0), T(1)], [T(-1)])], 10)
     assert pt[0] == pt[1] and plain[0].tobytes() == plain[1].tobytes()
+    # the always-add mode
+    ctx2 = rucene_amd.Context(req_opt_rule=-1)
+    try:
+        g2 = rucene_amd.GpuIndexSearcher([rucene_amd.LeafReader.from_synthetic(seg)], ctx=ctx2)
+        for k in (10, 100):
+            hits, totals = g2.search_batch(queries, k)
+            for i, (m, s, n) in enumerate(specs):
+                ed, es, et = osearcher.search_opt(oracle.OP_AND, m, s, k, must_not_ids=n, exact=True)
+                rd, rs, rt = osearcher.search_opt(oracle.OP_AND, m, s, k, must_not_ids=n)
+                cnt = len(ed)
+                gd, gs = hits[i]["doc"], hits[i]["score"]
+                assert totals[i] == et == rt and (gd[cnt:] == -1).all()
+                assert (gd[:cnt] == ed).all() and (gs[:cnt].view(np.int32) == es.view(np.int32)).all(), (i, specs[i])
+                ref = dict(zip(rd.tolist(), rs.tolist()))
+                for d, sc in zip(gd[:cnt].tolist(), gs[:cnt].tolist()):
+                    if d in ref:
+                        assert sc >= ref[d]
+    finally:
+        ctx2.close()
 
 
 def test_filter_clauses(zipf, oracle):
