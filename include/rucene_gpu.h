@@ -110,8 +110,11 @@ typedef enum rgpu_query_op {
 #define RGPU_OP_WITH_SHOULD(op, n_should) ((int32_t)(op) | ((int32_t)(n_should) << 16))
 
 typedef struct rgpu_query {
-  int32_t op;          /* rgpu_query_op (OR: optionally RGPU_OP_OR_MSM(msm); TERM / AND: optionally RGPU_OP_WITH_SHOULD(op, n)) */
-  int32_t n_terms;     /* required / scored clauses: 1 for TERM, 1..RGPU_MAX_QUERY_TERMS MUST (AND) / SHOULD (OR) clauses;
+  int32_t op;          /* rgpu_query_op (OR: optionally RGPU_OP_OR_MSM(msm); TERM / AND: optionally RGPU_OP_WITH_SHOULD(op, n) —
+                          a min_should_match in the second byte is accepted there too and, as in the reference, has no effect:
+                          ReqOptScorer only advance()s the optional scorer) */
+  int32_t n_terms;     /* required / scored clauses: 1 for TERM, 1..RGPU_MAX_QUERY_TERMS MUST (AND) / SHOULD (OR) clauses; 0 for an OR
+                          query of MUST_NOT clauses only, which matches nothing (BooleanWeight::create_scorer -> None);
                           the n optional SHOULD clauses of RGPU_OP_WITH_SHOULD follow them and are not counted here */
   int32_t first_term;  /* index of this query's first clause in the `terms` array */
   int32_t n_must_not;  /* MUST_NOT TermQuery clauses, stored right after the positive ones (weight / sim_table unused):

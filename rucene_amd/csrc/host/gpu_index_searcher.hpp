@@ -100,13 +100,14 @@ struct BooleanQuery : Query {
     if (must_nots.empty() && musts.size() + shoulds.size() + filters.size() == 1)  // a lone FILTER: ConstantScoreQuery, boost 0
       return std::unique_ptr<Query>(new TermQuery(!filters.empty() ? filters[0] : (musts.empty() ? shoulds[0] : musts[0])));
     musts.insert(musts.end(), filters.begin(), filters.end());
-    if ((msm > 1 && !musts.empty()) || msm > 255 || (musts.empty() && shoulds.empty()))
-      throw Error(RGPU_ERR_UNSUPPORTED, "only MUST (+SHOULD, +MUST_NOT) and SHOULD (+MUST_NOT, min_should_match) term trees run on the GPU path");
+    if (msm > 255) throw Error(RGPU_ERR_UNSUPPORTED, "min_should_match above 255");
+    // (beside MUST clauses min_should_match has no effect — ReqOptScorer only advances the optional scorer — and a tree of
+    // MUST_NOT clauses only matches nothing: BooleanWeight::create_scorer -> None)
     auto q = std::unique_ptr<BooleanQuery>(new BooleanQuery());
     q->must_queries = std::move(musts);
     q->should_queries = std::move(shoulds);
     q->must_not_queries = std::move(must_nots);
-    q->min_should_match = msm;
+    q->min_should_match = q->must_queries.empty() ? msm : 0;
     return std::unique_ptr<Query>(q.release());
   }
 };

@@ -1096,9 +1096,13 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
     const rgpu_query& Q = queries[q];
     const int qop = Q.op & 0xff, qmsm = (Q.op >> 8) & 0xff, qopt = (Q.op >> 16) & 0xff;
     if (qop < RGPU_OP_TERM || qop > RGPU_OP_OR || (Q.op >> 24) != 0) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "unknown query op");
-    if (qmsm > 1 && qop != RGPU_OP_OR) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "min_should_match applies to SHOULD clauses (op OR) only");
+    // min_should_match beside MUST clauses is legal and has no effect: ReqOptScorer only ever advance()s the optional
+    // DisjunctionSumScorer, and advance() does not look at the count (disjunction_scorer.rs approximate_advance)
+    if (qmsm > 1 && qop != RGPU_OP_OR && qopt == 0) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "min_should_match needs SHOULD clauses");
     if (qopt > 0 && qop == RGPU_OP_OR) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "optional SHOULD clauses go with MUST clauses (op TERM / AND); an OR query's clauses are its n_terms");
-    if (Q.n_terms < 1 || Q.n_terms > RGPU_MAX_QUERY_TERMS || Q.n_must_not < 0 || Q.n_must_not > RGPU_MAX_QUERY_TERMS ||
+    // (an OR query of MUST_NOT clauses only: BooleanWeight::create_scorer -> None, boolean_query.rs:274-276 — it matches nothing)
+    const int min_terms = (qop == RGPU_OP_OR && Q.n_must_not > 0) ? 0 : 1;
+    if (Q.n_terms < min_terms || Q.n_terms > RGPU_MAX_QUERY_TERMS || Q.n_must_not < 0 || Q.n_must_not > RGPU_MAX_QUERY_TERMS ||
         Q.n_terms + qopt + Q.n_must_not > RGPU_MAX_QUERY_TERMS || (qop == RGPU_OP_TERM && Q.n_terms != 1))
       return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "bad clause count");
     if (Q.first_term < 0 || (int64_t)Q.first_term + Q.n_terms + qopt + Q.n_must_not > (int64_t)n_terms_total)
@@ -1196,7 +1200,7 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
     DevQuery dq;
     // the window kernel reads min_should_match from the second byte, the conjunction kernel its optional clause count
     // from the third; device clause order: MUST, MUST_NOT, SHOULD
-    dq.op = gop | (qmsm > 1 ? qmsm << 8 : 0) | ((int32_t)mine_opt.size() << 16);
+    dq.op = gop | ((qmsm > 1 && gop == RGPU_OP_OR) ? qmsm << 8 : 0) | ((int32_t)mine_opt.size() << 16);
     dq.first_term = (int32_t)G.terms.size();
     dq.n_terms = (int32_t)mine.size();
     dq.pad = (int32_t)mine_not.size();

@@ -258,10 +258,10 @@ class BooleanQuery:
             if filters:   # ConstantScoreQuery::with_boost(filter, 0.0) (boolean_query.rs:70-73): every match scores 0
                 return TermQuery(filters[0].term, 0.0)
             return (list(musts) + list(shoulds))[0]
-        if (msm > 1 and (musts or filters)) or msm > 255:
-            raise RgpuError(-5, "only MUST (+SHOULD, +MUST_NOT) and SHOULD (+MUST_NOT, min_should_match) term trees run on the GPU path")
-        if len(musts) + len(shoulds) + len(filters) == 0:
-            raise RgpuError(-5, "a MUST_NOT-only query (MatchAllDocsQuery minus ...) is not served by the GPU path")
+        if msm > 255:
+            raise RgpuError(-5, "min_should_match above 255")
+        if (musts or filters) and not shoulds:
+            msm = 0   # nothing for it to count (beside MUST clauses it has no effect anyway: ReqOptScorer only advances the optional scorer)
         if any(not isinstance(q, TermQuery) for q in list(musts) + list(shoulds) + list(must_nots) + list(filters)):
             raise RgpuError(-5, "nested boolean clauses are not supported on the GPU path")
         return BooleanQuery(list(musts), list(shoulds), msm, list(must_nots), list(filters))

@@ -136,8 +136,14 @@ def test_boolean_query_build_rules():
     assert len(q.extract_terms()) == 3
     q = B.build([], [], filters=[T(7)])                      # a lone FILTER: ConstantScoreQuery with boost 0
     assert isinstance(q, T) and q.term == 7 and q.boost == 0.0
-    for bad in (lambda: B.build([T(1)], [T(2)], min_should_match=2), lambda: B.build([T(1), T(2)], [], min_should_match=2),
-                lambda: B.build([], [], must_nots=[T(3)]), lambda: B.build([], [T(1), T(2)], filters=[T(3)], min_should_match=2)):
+    # min_should_match beside MUST / FILTER clauses is accepted (no effect in the reference: ReqOptScorer only advances the
+    # optional scorer) and dropped when there is nothing for it to count; a MUST_NOT-only tree is a query that matches nothing
+    q = B.build([T(1)], [T(2), T(4)], min_should_match=2)
+    assert q.min_should_match == 2 and len(q.should_queries) == 2
+    assert B.build([T(1), T(2)], [], min_should_match=2).min_should_match == 0
+    q = B.build([], [], must_nots=[T(3)])
+    assert isinstance(q, B) and not q.must_queries and not q.should_queries and len(q.must_not_queries) == 1
+    for bad in (lambda: B.build([T(1)], [B.build([T(2), T(3)], [])]), lambda: B.build([], [T(1), T(2)], min_should_match=300)):
         with pytest.raises(rucene_amd.RgpuError) as e:
             bad()
         assert e.value.status == -5                      # UnsupportedOperation: caller keeps those on the CPU path

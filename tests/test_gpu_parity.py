@@ -758,6 +758,15 @@ def test_must_with_optional_should_clauses(zipf, oracle):
             assert (gs[:cnt].view(np.int32) == rs.view(np.int32)).all(), (i, specs[i])
             differs_somewhere += int(len(ed) != len(rd) or (ed != rd).any() or (es.view(np.int32) != rs.view(np.int32)).any())
     assert differs_somewhere > 0  # the rule really changed some of these results: the test would notice its absence
+    # min_should_match beside MUST clauses: legal, and without effect (ReqOptScorer only ever advances the optional scorer)
+    for msm in (2, 3):
+        q = B.build([T(0), T(1)], [T(2), T(7), T(30)], min_should_match=msm)
+        h, t = gsearcher.search_batch([q], 10)
+        rd, rs, rt = osearcher.search_opt(oracle.OP_AND, [0, 1], [2, 7, 30], 10, min_should_match=msm)
+        assert t[0] == rt and (h[0]["doc"][:len(rd)] == rd).all() and (h[0]["score"][:len(rd)].view(np.int32) == rs.view(np.int32)).all()
+    # a tree of MUST_NOT clauses only matches nothing (BooleanWeight::create_scorer -> None), also next to real queries
+    h, t = gsearcher.search_batch([B.build([], [], must_nots=[T(0), T(5)]), T(3)], 10)
+    assert t[0] == 0 and (h[0]["doc"] == -1).all() and t[1] == int(seg.terms[3]["doc_freq"])
     # mixed with other operators in one batch, and through the plain-AND group when nothing optional is present
     mixed = [T(7), queries[0], B.build([T(1), T(2)], []), queries[5], B.build([], [T(3), T(4)])]
     mh, mt = gsearcher.search_batch(mixed, 10)
