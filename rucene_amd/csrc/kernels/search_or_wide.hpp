@@ -19,7 +19,7 @@
 //     steps, i.e. by < 4e-6 relative whenever the total is >= n * 2^17 steps. k_merge_items flags the (pathological:
 //     a top-k that reaches down to scores a thousand times smaller than the query's largest possible) queries that
 //     return a smaller total, and the host runs those again through k_or_windows;
-//   * the scan of a window (all 512 lanes, four docs per lane per step) counts the touched docs and offers the ones at or
+//   * the scan of a window (all 512 lanes, eight docs per lane per step) counts the touched docs and offers the ones at or
 //     above the threshold to the wavefront's top-k — keys are (total << 32 | ~doc), no float ordering tricks needed.
 // Clauses < 10, MUST_NOT clauses, min_should_match > 1, deleted docs, raw norm bytes, negative or non-finite weights or
 // similarity tables: k_or_windows (search_or.hpp), which sums f32 in clause order, bit-exact.
@@ -42,24 +42,39 @@ constexpr int ORX_WAVES = RGPU_ORX_WAVES;  // 8: two workgroups per CU; 16: one,
 constexpr int ORX_THREADS = 64 * ORX_WAVES;
 constexpr int ORX_OWN = (16 + ORX_WAVES - 1) / ORX_WAVES;  // clauses whose block bounds a wavefront keeps (c = wave + s * ORX_WAVES)
 constexpr int ORX_LOOK = RGPU_ORX_LOOK;    // directory entries looked at per clause per window, in units of 64
-constexpr int ORX_SCAN_STEP = 4 * ORX_THREADS;  // docs per scan step of the workgroup: windows are multiples of it
+constexpr int ORX_SCAN_STEP = 8 * ORX_THREADS;  // docs per scan step of the workgroup (two 16-byte reads per lane): windows are multiples of it
 constexpr int ORX_WAVES_PER_SIMD = ORX_WAVES >= 16 ? 4 : (2 * ORX_WAVES + 3) / 4;  // two workgroups per CU (one of 16 wavefronts)
 #ifndef RGPU_ORX_TABLES
 #define RGPU_ORX_TABLES 4
 #endif
 constexpr int ORX_TABLES = RGPU_ORX_TABLES;  // clauses scored through an LDS score table (the longest lists); the rest use the formula
 constexpr int ORX_MAX_TERMS = 16;   // == RGPU_MAX_QUERY_TERMS
-constexpr int ORX_RING = 4;         // payload rows in flight per wavefront
+#ifndef RGPU_ORX_RING
+#define RGPU_ORX_RING 4
+#endif
+constexpr int ORX_RING = RGPU_ORX_RING;  // payload rows in flight per wavefront
 constexpr int ORX_BOUNDS_RING = 3;  // bounds of windows n, n+1, n+2
 constexpr int ORX_MAX_WINDOW = (64 * ORX_LOOK - 2) * 128;  // a window's blocks of one clause must fit the directory entries looked at
 constexpr uint32_t ORX_FLOOR_PER_CLAUSE = 1u << 17;  // a returned total below n_clauses * this is summed again in f32 (see above)
+#ifndef RGPU_ORX_STRIDED
+#define RGPU_ORX_STRIDED 1
+#endif
 #ifndef RGPU_ORX_ABL  // developer ablations (variant builds only; results are wrong)
 #define RGPU_ORX_ABL 0
 #endif
 
+#ifdef RGPU_ORX_TIME  // developer instrumentation (variant builds only): wave-cycles per phase of the window loop
+__device__ unsigned long long g_orx_dbg[8];  // [0] blocks [1] bounds [2] barrier 1 [3] scan loop [4] barrier 2 [5] list hand-over [6] list request + fold [7] publish
+#define ORX_STAMP(t) const long long t = (long long)__builtin_readcyclecounter()
+#define ORX_ADD(i, v) orx_t[i] += (v)
+#else
+#define ORX_STAMP(t) do {} while (0)
+#define ORX_ADD(i, v) do {} while (0)
+#endif
+
 __host__ __device__ constexpr size_t orx_fixed_lds() {
   return (size_t)ORX_TABLES * WAVE_CACHE_FLOATS * 4 + (size_t)ORX_MAX_TERMS * 64 * 4 + (size_t)ORX_WAVES * 2 * SLAB_STREAM +
-         (size_t)ORX_BOUNDS_RING * ORX_MAX_TERMS * 8;
+         (size_t)ORX_BOUNDS_RING * ORX_MAX_TERMS * 8 + (size_t)ORX_WAVES * 8;
 }
 __host__ __device__ constexpr size_t orx_lds_bytes(int WS) { return orx_fixed_lds() + (size_t)WS * 4 + 256; }  // + 64 spare cells
 
@@ -81,7 +96,8 @@ __global__ __launch_bounds__(ORX_THREADS, ORX_WAVES_PER_SIMD) void k_or_wide(Seg
   float* caches = tables + ORX_TABLES * WAVE_CACHE_FLOATS;  // caches[c][rank] = the clause's norm cache by norm rank
   uint8_t* slab = reinterpret_cast<uint8_t*>(caches + ORX_MAX_TERMS * 64) + wave * 2 * SLAB_STREAM;
   int2* bounds = reinterpret_cast<int2*>(reinterpret_cast<uint8_t*>(caches + ORX_MAX_TERMS * 64) + ORX_WAVES * 2 * SLAB_STREAM);
-  uint32_t* acc = reinterpret_cast<uint32_t*>(bounds + ORX_BOUNDS_RING * ORX_MAX_TERMS);
+  uint32_t* wg_kth = reinterpret_cast<uint32_t*>(bounds + ORX_BOUNDS_RING * ORX_MAX_TERMS);  // per wavefront: its ceil(k/8)-th best total
+  uint32_t* acc = wg_kth + 2 * ORX_WAVES;
 
   const int q = (int)(blockIdx.x % (unsigned)n_queries);
   const int g = (int)(blockIdx.x / (unsigned)n_queries);
@@ -214,11 +230,19 @@ __global__ __launch_bounds__(ORX_THREADS, ORX_WAVES_PER_SIMD) void k_or_wide(Seg
     const int2 bd = lane < n ? bounds[(win % ORX_BOUNDS_RING) * ORX_MAX_TERMS + lane] : make_int2(0, 0);
     const int incl = wave_incl_scan(bd.y);
     const int total = (RGPU_ORX_ABL == 4 || RGPU_ORX_ABL == 5) ? 0 : readlane(incl, 63);
+#if RGPU_ORX_STRIDED
+    // entry j belongs to wavefront j % 8: every wavefront gets a mix of clauses (table and formula blocks, FullBlocks
+    // and tails) instead of a run of one clause's blocks, and their loads differ by at most one block
+    P.L.mine = total > wave ? (total - wave + ORX_WAVES - 1) / ORX_WAVES : 0;
+    P.L.n = max(0, min(ORX_PAGE, P.L.mine - page));
+    const int j = wave + ORX_WAVES * (page + lane);
+#else
     const int per = (total + ORX_WAVES - 1) / ORX_WAVES;
     const int j0 = wave * per;
     P.L.mine = max(0, min(total, j0 + per) - j0);
     P.L.n = max(0, min(ORX_PAGE, P.L.mine - page));
     const int j = j0 + page + lane;
+#endif
     int c = 0;
     for (int t = 0; t < n; ++t) c += j >= readlane(incl, t) ? 1 : 0;
     const bool valid = lane < P.L.n;
@@ -305,8 +329,27 @@ __global__ __launch_bounds__(ORX_THREADS, ORX_WAVES_PER_SIMD) void k_or_wide(Seg
       stage_rows(s.rows, slab, lane);
       wave_sync();
       uint32_t x0, x1;
-      staged_doc_deltas<LEGACY>(slab, s.rows, hdr, lane, x0, x1);
-      staged_freqs<LEGACY>(slab, s.rows, hdr, lane, f0, f1);
+      if constexpr (LEGACY) {
+        staged_doc_deltas<LEGACY>(slab, s.rows, hdr, lane, x0, x1);
+        staged_freqs<LEGACY>(slab, s.rows, hdr, lane, f0, f1);
+      } else {
+        // both streams without a branch: the two LDS reads go out back to back and their round trips overlap. An
+        // all-equal stream (b == 0: one row holding the value) reads row 0 like any other, keeps nothing of it
+        // (mask 0) and takes the value from the row's owner instead.
+        const int bd = hdr_bdoc(hdr), bf = hdr_bfreq(hdr);
+        const int r = lane >> 1;
+        const int pd = r * bd, pf = r * bf;
+        const uint8_t* ad = slab + ((lane & 1) << 3) + 16 * (pd >> 5);
+        const uint8_t* af = slab + SLAB_STREAM + ((lane & 1) << 3) + 16 * (pf >> 5);
+        const uint2 dlo = lds_u2(ad), dhi = lds_u2(ad + 16);
+        const uint2 flo = lds_u2(af), fhi = lds_u2(af + 16);
+        const uint32_t md = bd ? 0xffffffffu >> (32 - bd) : 0u, ud = bd ? 0u : (uint32_t)readlane((int)s.rows.x, 0);
+        const uint32_t mf = bf ? 0xffffffffu >> (32 - bf) : 0u, uf = bf ? 0u : (uint32_t)readlane((int)s.rows.x, 32);
+        x0 = ((uint32_t)((((uint64_t)dhi.x << 32) | dlo.x) >> (pd & 31)) & md) | ud;
+        x1 = ((uint32_t)((((uint64_t)dhi.y << 32) | dlo.y) >> (pd & 31)) & md) | ud;
+        f0 = ((uint32_t)((((uint64_t)fhi.x << 32) | flo.x) >> (pf & 31)) & mf) | uf;
+        f1 = ((uint32_t)((((uint64_t)fhi.y << 32) | flo.y) >> (pf & 31)) & mf) | uf;
+      }
       wave_sync();  // slab is free for the next block
       deltas_to_docs(x0, x1, readlane(L.base, idx), e0, e1);
       small_freqs = hdr_bfreq(hdr) <= 3;
@@ -322,8 +365,11 @@ __global__ __launch_bounds__(ORX_THREADS, ORX_WAVES_PER_SIMD) void k_or_wide(Seg
     } else {
       const float* cache = caches + c * 64;
       const float wk = __int_as_float(readlane(__float_as_int(c_wk), c));
-      s0 = to_fixed(bm25_score(wk, (float)(int32_t)f0, cache[nb0]));
-      s1 = to_fixed(bm25_score(wk, (float)(int32_t)f1, cache[nb1]));
+      // (v_rcp_f32 is good to one ulp; this kernel's scores are pinned to 1e-5 — the header — and rounded to fixed point
+      // next: an IEEE division would be thirteen instructions per posting for nothing)
+      const float q0 = (float)(int32_t)f0, q1 = (float)(int32_t)f1;
+      s0 = to_fixed(wk * q0 * __builtin_amdgcn_rcpf(q0 + cache[nb0]));
+      s1 = to_fixed(wk * q1 * __builtin_amdgcn_rcpf(q1 + cache[nb1]));
     }
     const uint32_t o0 = (uint32_t)(e0 - w0), o1 = (uint32_t)(e1 - w0);
     if (RGPU_ORX_ABL == 6) {  // plain stores instead of atomics
@@ -340,7 +386,9 @@ __global__ __launch_bounds__(ORX_THREADS, ORX_WAVES_PER_SIMD) void k_or_wide(Seg
 
   WaveTopK top;
   uint64_t tau = 0, floor = 0;
-  int hits_lane = 0;  // touched docs this lane scanned
+  int hits_wave = 0;  // touched docs this wavefront scanned (wave-uniform)
+  const int kth_m = (k + ORX_WAVES - 1) / ORX_WAVES;  // <= 16: the m-th best key of a list is lane m - 1 of its first register
+  uint32_t wg_seen = 0;  // lane l: wavefront (l % 8)'s m-th best total as of the previous window
   SharedTau shared{tau_slots + q};
   shared.fold(shared.peek(), tau, floor);
 
@@ -352,7 +400,11 @@ __global__ __launch_bounds__(ORX_THREADS, ORX_WAVES_PER_SIMD) void k_or_wide(Seg
   for (int j = 0; j < ORX_RING; ++j) ring[j] = fetch(cur_list, j);  // (entries past cur_list.n: the appended ones — harmless)
   __syncthreads();  // accumulators are cleared, tables and caches are built
 
+#ifdef RGPU_ORX_TIME
+  long long orx_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
   for (int win = win0; win < win1; ++win) {
+    ORX_STAMP(t0);
     const int32_t w0 = win * WS;
     const uint32_t wlen = (uint32_t)(min(seg.max_doc, w0 + WS) - w0);
     const uint64_t seen = shared.peek();  // folded before the scan
@@ -375,6 +427,7 @@ __global__ __launch_bounds__(ORX_THREADS, ORX_WAVES_PER_SIMD) void k_or_wide(Seg
       const List more = finish_list(build_list(win, page));
       for (int idx = 0; idx < more.n; ++idx) process(fetch(more, idx), more, idx, w0, wlen);
     }
+    ORX_STAMP(t1);
     if (wave == 0) {  // singletons (one lane per clause; two clauses may name the same doc: the add is atomic)
       const uint32_t o = (uint32_t)(c_sdoc - w0);
       if (c_sdoc >= 0 && o < wlen) __hip_atomic_fetch_add(acc + o, c_sfix, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -387,49 +440,97 @@ __global__ __launch_bounds__(ORX_THREADS, ORX_WAVES_PER_SIMD) void k_or_wide(Seg
         if (c < n) { bounds_finish(c, own_cur[s], own_e[s], win + 2); bounds_issue(c, own_cur[s], own_e[s]); }
       }
     }
+    ORX_STAMP(t2);
     __syncthreads();  // every add of this window has landed; bounds of win + 2 are visible
+    ORX_STAMP(t3);
     const Pending after = build_list(win + 2, 0);  // its directory words arrive during the scan
 
-    // ---- scan: four docs per lane per step; a touched accumulator is one collected hit (bulk_scorer.rs:114-120)
+    // ---- scan: eight docs per lane per step; a touched accumulator is one collected hit (bulk_scorer.rs:114-120)
     shared.fold(seen, tau, floor);
+    if (RGPU_ORX_ABL != 14) {  // the workgroup's bound as of the previous window (see below)
+      static_assert((ORX_WAVES & (ORX_WAVES - 1)) == 0 && ORX_WAVES <= 16, "the min below runs inside one 16-lane row");
+      uint32_t v = wg_seen;
+      // lane 15 ends up with the min over lanes 16 - ORX_WAVES .. 15, i.e. over every wavefront's entry (row_shr; a lane
+      // without a source keeps its own value)
+      auto shr_min = [](uint32_t x, auto ctrl) {
+        const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, decltype(ctrl)::value, 0xf, 0xf, false);
+        return o < x ? o : x;
+      };
+      v = shr_min(v, std::integral_constant<int, 0x111>());
+      if (ORX_WAVES > 2) v = shr_min(v, std::integral_constant<int, 0x112>());
+      if (ORX_WAVES > 4) v = shr_min(v, std::integral_constant<int, 0x114>());
+      if (ORX_WAVES > 8) v = shr_min(v, std::integral_constant<int, 0x118>());
+      const uint64_t wg_bound = (uint64_t)(uint32_t)readlane((int)v, 15) << 32;
+      if (wg_bound > floor) {
+        floor = wg_bound;
+        if (floor > tau) tau = floor;
+        shared.publish_key(wg_bound, lane);
+      }
+    }
     // (the next step's cells are requested before this step's are looked at: the LDS round trip hides behind the work)
-    uint4* cell = reinterpret_cast<uint4*>(acc + 4 * threadIdx.x);
-    uint4 v_next = *cell;
+    ORX_STAMP(t3a);
+    uint4* cell = reinterpret_cast<uint4*>(acc + 4 * threadIdx.x);  // this lane's cells of a step: [0, 4) and [4 T, 4 T + 4)
+    uint4 a_next = cell[0], b_next = cell[ORX_THREADS];
     for (uint32_t i0 = 0; i0 < (uint32_t)WS && RGPU_ORX_ABL != 1; i0 += ORX_SCAN_STEP) {
-      const uint4 v = v_next;
+      const uint4 a = a_next, b = b_next;
       uint4* const here = cell;
       if (i0 + ORX_SCAN_STEP < (uint32_t)WS) cell += ORX_SCAN_STEP / 4;  // wave-uniform
-      v_next = *cell;
-      if (__ballot((v.x | v.y | v.z | v.w) != 0u)) {
-        hits_lane += (int)min(v.x, 1u) + (int)min(v.y, 1u) + (int)min(v.z, 1u) + (int)min(v.w, 1u);
-        *here = make_uint4(0u, 0u, 0u, 0u);
+      a_next = cell[0]; b_next = cell[ORX_THREADS];
+      if (__ballot((a.x | a.y | a.z | a.w | b.x | b.y | b.z | b.w) != 0u)) {
+        // touched docs: counted on the scalar side (one compare per cell, popcounts and adds are SALU work)
+        if (RGPU_ORX_ABL != 13) hits_wave += __popcll(__ballot(a.x != 0u)) + __popcll(__ballot(a.y != 0u)) + __popcll(__ballot(a.z != 0u)) +
+                     __popcll(__ballot(a.w != 0u)) + __popcll(__ballot(b.x != 0u)) + __popcll(__ballot(b.y != 0u)) +
+                     __popcll(__ballot(b.z != 0u)) + __popcll(__ballot(b.w != 0u));
+        if (RGPU_ORX_ABL != 12) {
+          here[0] = make_uint4(0u, 0u, 0u, 0u);
+          here[ORX_THREADS] = make_uint4(0u, 0u, 0u, 0u);
+        }
         const uint32_t thr = max(1u, (uint32_t)(tau >> 32));  // a key's high word is the doc's total
-        if (__ballot(max(max(v.x, v.y), max(v.z, v.w)) >= thr)) {
-          const uint32_t nd = ~(uint32_t)(w0 + (int32_t)i0 + 4 * (int32_t)threadIdx.x);  // ~doc: smaller doc id = larger key
-          uint64_t key = v.x >= thr ? ((uint64_t)v.x << 32) | nd : 0ull;
-          if (__ballot(key > tau)) topk_offer<WIDE>(top, key, tau, k, lane, floor);
-          key = v.y >= thr ? ((uint64_t)v.y << 32) | (nd - 1u) : 0ull;
-          if (__ballot(key > tau)) topk_offer<WIDE>(top, key, tau, k, lane, floor);
-          key = v.z >= thr ? ((uint64_t)v.z << 32) | (nd - 2u) : 0ull;
-          if (__ballot(key > tau)) topk_offer<WIDE>(top, key, tau, k, lane, floor);
-          key = v.w >= thr ? ((uint64_t)v.w << 32) | (nd - 3u) : 0ull;
-          if (__ballot(key > tau)) topk_offer<WIDE>(top, key, tau, k, lane, floor);
+        if (RGPU_ORX_ABL != 11 && __ballot(max(max(max(a.x, a.y), max(a.z, a.w)), max(max(b.x, b.y), max(b.z, b.w))) >= thr)) {
+          uint32_t nd = ~(uint32_t)(w0 + (int32_t)i0 + 4 * (int32_t)threadIdx.x);  // ~doc: smaller doc id = larger key
+          auto offer = [&](uint32_t v, uint32_t ndoc) {
+            const uint64_t key = v >= thr ? ((uint64_t)v << 32) | ndoc : 0ull;
+            if (__ballot(key > tau)) topk_offer<WIDE>(top, key, tau, k, lane, floor);
+          };
+          offer(a.x, nd); offer(a.y, nd - 1u); offer(a.z, nd - 2u); offer(a.w, nd - 3u);
+          nd -= (uint32_t)(4 * ORX_THREADS);
+          offer(b.x, nd); offer(b.y, nd - 1u); offer(b.z, nd - 2u); offer(b.w, nd - 3u);
         }
       }
     }
+    ORX_STAMP(t4a);
     shared.publish<WIDE>(top, k, lane);
+    // The workgroup's own bound on the query's k-th best: every doc is scanned by exactly one wavefront, so if each of
+    // the eight lists holds m = ceil(k / 8) keys >= v there are k docs at or above v — the smallest of the eight m-th
+    // best keys is such a v, and it is about the k-th best of everything the WORKGROUP has seen, where a single list's
+    // k-th best is only that of an eighth of it. (Without it a list's threshold is the k-th best of 1/64 of the query's
+    // docs and some 12 000 keys per query are inserted into one list or another: 1.8 of the kernel's 11.1 ms.) Only the
+    // keys' high words — the totals — are exchanged: (total << 32) is a bound as valid as the key itself.
+    if (lane == 0) wg_kth[wave] = (uint32_t)(readlane64(top.a, kth_m - 1) >> 32);  // 0 while the list holds fewer than m keys
+    ORX_STAMP(t4);
     __syncthreads();  // the window is clear again (measured: dropping this barrier would gain 1.6 %)
+    ORX_STAMP(t5);
+    wg_seen = wg_kth[lane & (ORX_WAVES - 1)];  // folded in front of the next scan: the read's round trip hides behind the blocks
     // the window after next's directory words have arrived during the scan: finish it, move up, and give the new
     // current list its look-ahead entries
     cur_list = next_list;
     next_list = finish_list(after);
     append_next(cur_list, next_list);
+#ifdef RGPU_ORX_TIME
+    {
+      const long long t6 = (long long)__builtin_readcyclecounter();
+      orx_t[0] += t1 - t0; orx_t[1] += t2 - t1; orx_t[2] += t3 - t2; orx_t[3] += t4a - t3a; orx_t[6] += t3a - t3; orx_t[7] += t4 - t4a; orx_t[4] += t5 - t4; orx_t[5] += t6 - t5;
+    }
+#endif
   }
-  const int hits = wave_reduce_add(hits_lane);
+#ifdef RGPU_ORX_TIME
+  if (lane == 0)
+    for (int i = 0; i < 8; ++i) atomicAdd(&g_orx_dbg[i], (unsigned long long)orx_t[i]);
+#endif
   uint64_t* pk = partial_keys + (size_t)item * (size_t)k;
   if (lane < k) pk[lane] = top.a;
   if (WIDE && lane + 64 < k) pk[lane + 64] = top.b;
-  if (lane == 0) partial_counts[item] = hits;
+  if (lane == 0) partial_counts[item] = hits_wave;
 }
 
 }  // namespace rgpu

@@ -1976,6 +1976,16 @@ extern "C" uint8_t rgpu_bm25_encode_norm(float boost, int32_t field_length) {
   return rucene::BM25Similarity::encode_norm_value(boost, field_length);
 }
 
+#ifdef RGPU_ORX_TIME
+extern "C" int32_t rgpu_debug_counters(unsigned long long* out8, int32_t reset) {  // k_or_wide wave-cycles per phase (search_or_wide.hpp)
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_orx_dbg), 64) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_orx_dbg), z, 64) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif
 #ifdef RGPU_EXP_COUNT
 extern "C" int32_t rgpu_debug_counters(unsigned long long* out8, int32_t reset) {  // [0..3] TERM, [4..7] AND
   if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_term_dbg), 32) != hipSuccess) return -1;
