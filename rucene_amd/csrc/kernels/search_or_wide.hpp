@@ -312,6 +312,9 @@ __global__ __launch_bounds__(ORX_THREADS, ORX_WAVES_PER_SIMD) void k_or_wide(Seg
     s.nn = *(const __attribute__((address_space(1))) uint16_t*)(pn + 2u * (uint32_t)lane);
     return s;
   };
+  const uint32_t lane_r = (uint32_t)(lane >> 1);                 // BP128: the row of this lane's pair of values
+  const uint8_t* const slab_lane = slab + ((lane & 1) << 3);     // ... and its pair of streams inside a 16-byte stream word
+  const uint32_t spare = (uint32_t)(WS + lane);                  // this lane's spare accumulator cell
   auto process = [&](const Slot& s, const List& L, int idx, int32_t w0, uint32_t wlen) {
     const uint32_t meta = (uint32_t)readlane((int)L.meta, idx);
     const uint32_t hdr = meta & 0xffffu;
@@ -333,25 +336,28 @@ __global__ __launch_bounds__(ORX_THREADS, ORX_WAVES_PER_SIMD) void k_or_wide(Seg
         staged_doc_deltas<LEGACY>(slab, s.rows, hdr, lane, x0, x1);
         staged_freqs<LEGACY>(slab, s.rows, hdr, lane, f0, f1);
       } else {
-        // both streams without a branch: the two LDS reads go out back to back and their round trips overlap. An
-        // all-equal stream (b == 0: one row holding the value) reads row 0 like any other, keeps nothing of it
-        // (mask 0) and takes the value from the row's owner instead.
+        // both streams in one go: the two LDS reads go out back to back and their round trips overlap. An all-equal
+        // stream (b == 0: one row holding the value) reads row 0 like any other and is overwritten afterwards.
         const int bd = hdr_bdoc(hdr), bf = hdr_bfreq(hdr);
-        const int r = lane >> 1;
-        const int pd = r * bd, pf = r * bf;
-        const uint8_t* ad = slab + ((lane & 1) << 3) + 16 * (pd >> 5);
-        const uint8_t* af = slab + SLAB_STREAM + ((lane & 1) << 3) + 16 * (pf >> 5);
+        const uint32_t pd = __umul24(lane_r, (uint32_t)bd), pf = __umul24(lane_r, (uint32_t)bf);
+        const uint8_t* ad = slab_lane + (__builtin_amdgcn_ubfe(pd, 5, 6) << 4);  // 16 * (p / 32): the row of stream word p / 32
+        const uint8_t* af = slab_lane + SLAB_STREAM + (__builtin_amdgcn_ubfe(pf, 5, 6) << 4);
         const uint2 dlo = lds_u2(ad), dhi = lds_u2(ad + 16);
         const uint2 flo = lds_u2(af), fhi = lds_u2(af + 16);
-        const uint32_t md = bd ? 0xffffffffu >> (32 - bd) : 0u, ud = bd ? 0u : (uint32_t)readlane((int)s.rows.x, 0);
-        const uint32_t mf = bf ? 0xffffffffu >> (32 - bf) : 0u, uf = bf ? 0u : (uint32_t)readlane((int)s.rows.x, 32);
-        x0 = ((uint32_t)((((uint64_t)dhi.x << 32) | dlo.x) >> (pd & 31)) & md) | ud;
-        x1 = ((uint32_t)((((uint64_t)dhi.y << 32) | dlo.y) >> (pd & 31)) & md) | ud;
-        f0 = ((uint32_t)((((uint64_t)fhi.x << 32) | flo.x) >> (pf & 31)) & mf) | uf;
-        f1 = ((uint32_t)((((uint64_t)fhi.y << 32) | flo.y) >> (pf & 31)) & mf) | uf;
+        const uint32_t md = 0xffffffffu >> ((32 - bd) & 31), mf = 0xffffffffu >> ((32 - bf) & 31);  // (b == 0: see below)
+        x0 = (uint32_t)((((uint64_t)dhi.x << 32) | dlo.x) >> (pd & 31)) & md;
+        x1 = (uint32_t)((((uint64_t)dhi.y << 32) | dlo.y) >> (pd & 31)) & md;
+        f0 = (uint32_t)((((uint64_t)fhi.x << 32) | flo.x) >> (pf & 31)) & mf;
+        f1 = (uint32_t)((((uint64_t)fhi.y << 32) | flo.y) >> (pf & 31)) & mf;
+        if (bd == 0) x0 = x1 = (uint32_t)readlane((int)s.rows.x, 0);
+        if (bf == 0) f0 = f1 = (uint32_t)readlane((int)s.rows.x, 32);
       }
       wave_sync();  // slab is free for the next block
-      deltas_to_docs(x0, x1, readlane(L.base, idx), e0, e1);
+      {  // deltas -> doc ids: with the inclusive scan of the pair sums, doc1 = base + scan and doc0 = doc1 - delta1
+        const int incl = wave_incl_scan((int)(x0 + x1));
+        e1 = readlane(L.base, idx) + incl;
+        e0 = e1 - (int32_t)x1;
+      }
       small_freqs = hdr_bfreq(hdr) <= 3;
     } else {  // the tail: decoded and validated at prepare time; slots past its end hold doc INT_MAX, freq 0
       e0 = (int32_t)s.rows.x; e1 = (int32_t)s.rows.y; f0 = s.rows.z; f1 = s.rows.w;
@@ -359,9 +365,9 @@ __global__ __launch_bounds__(ORX_THREADS, ORX_WAVES_PER_SIMD) void k_or_wide(Seg
     }
     uint32_t s0, s1;
     if (slot >= 0 && (small_freqs || !__ballot((f0 > f1 ? f0 : f1) > (uint32_t)SCORE_TABLE_FREQS))) {
-      const uint32_t* tbl = reinterpret_cast<const uint32_t*>(tables + slot * WAVE_CACHE_FLOATS) + 64;
-      s0 = tbl[nb0 * SCORE_TABLE_COLS + f0];
-      s1 = tbl[nb1 * SCORE_TABLE_COLS + f1];
+      const uint8_t* tbl = reinterpret_cast<const uint8_t*>(tables + slot * WAVE_CACHE_FLOATS + 64);
+      s0 = lds_u32(tbl + __umul24(nb0, 4u * SCORE_TABLE_COLS) + (f0 << 2));  // (one multiply-add and one shift-add per posting)
+      s1 = lds_u32(tbl + __umul24(nb1, 4u * SCORE_TABLE_COLS) + (f1 << 2));
     } else {
       const float* cache = caches + c * 64;
       const float wk = __int_as_float(readlane(__float_as_int(c_wk), c));
@@ -379,9 +385,11 @@ __global__ __launch_bounds__(ORX_THREADS, ORX_WAVES_PER_SIMD) void k_or_wide(Seg
     }
     // postings outside the window (a block may reach into its neighbours) go to this lane's spare cell behind it:
     // one select instead of an exec-mask branch around the atomic
-    const uint32_t spare = (uint32_t)(WS + lane);
-    __hip_atomic_fetch_add(acc + (o0 < wlen ? o0 : spare), s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    __hip_atomic_fetch_add(acc + (o1 < wlen ? o1 : spare), s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    // (a doc id is below max_doc, so an offset is either inside [0, wlen) or at least WS: one unsigned min does the select;
+    // an offset in [WS, WS + lane) lands in another lane's spare cell, which is as good)
+    (void)wlen;
+    __hip_atomic_fetch_add(acc + min(o0, spare), s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add(acc + min(o1, spare), s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   };
 
   WaveTopK top;
