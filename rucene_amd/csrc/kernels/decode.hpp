@@ -264,10 +264,9 @@ struct DirChunk {
 
 // deltas -> absolute doc ids (the `accum + delta` chain of posting_reader.rs:622-646, as a wave scan)
 __device__ __forceinline__ void deltas_to_docs(uint32_t d0, uint32_t d1, int32_t base, int32_t& doc0, int32_t& doc1) {
-  const int pair = (int)(d0 + d1);
-  const int incl = wave_incl_scan(pair);
-  doc0 = base + (incl - pair) + (int)d0;
-  doc1 = doc0 + (int)d1;
+  const int incl = wave_incl_scan((int)(d0 + d1));  // sum of the deltas up to and including this lane's pair
+  doc1 = base + incl;
+  doc0 = doc1 - (int)d1;
 }
 
 // Streams the FullBlocks [b0, b1) of one term through `body(block_index, doc0, doc1, freq0, freq1)`, keeping

@@ -243,8 +243,9 @@ __global__ __launch_bounds__(ORX_THREADS, ORX_WAVES_PER_SIMD) void k_or_wide(Seg
     P.L.n = max(0, min(ORX_PAGE, P.L.mine - page));
     const int j = j0 + page + lane;
 #endif
-    int c = 0;
-    for (int t = 0; t < n; ++t) c += j >= readlane(incl, t) ? 1 : 0;
+    int c = 0;  // the clause of entry j = the number of clauses whose entries end at or before j
+#pragma unroll
+    for (int t = 0; t < ORX_MAX_TERMS - 1; ++t) c += j >= readlane(incl, t) ? 1 : 0;  // (lanes >= n hold the total: no entry reaches it; straight-line code beats a loop over n here)
     const bool valid = lane < P.L.n;
     c = valid ? c : 0;
     const int off = bd.x - (incl - bd.y);  // lane t: lo_t - (entries before clause t)
