@@ -219,8 +219,15 @@ def main():
                 dist.barrier()
             torch.cuda.synchronize()
             t = time.perf_counter()
+            op = {"term": rucene_amd._lib.OP_TERM, "and3": rucene_amd._lib.OP_AND}.get(kind, rucene_amd._lib.OP_OR)
             for _ in range(steps):
-                step(shard.searcher.pack(qs, shard.leaf) if replan else packed, n_lanes)
+                if replan == "objects":
+                    pk = shard.searcher.pack(qs, shard.leaf)
+                elif replan == "array":
+                    pk = shard.searcher.pack_uniform(op, tids, shard.leaf)
+                else:
+                    pk = packed
+                step(pk, n_lanes)
             torch.cuda.synchronize()
             if dist_mode:
                 dist.barrier()
@@ -235,7 +242,8 @@ def main():
         res = {"tids": tids, "postings": postings, "algo_bytes": algo_bytes}
         res["ms_one_stream"] = timed(1, False)
         res["ms_two_streams"] = timed(2, False) if two_streams else None
-        res["ms_one_stream_with_planning"] = timed(1, True) if with_planning else None
+        res["ms_one_stream_with_planning"] = timed(1, "objects") if with_planning else None
+        res["ms_two_streams_with_array_planning"] = timed(2, "array") if with_planning else None
         # isolated kernel durations: the same steps on ONE stream with HIP events around every launch
         ctx.set_profiling(True)
         ctx.kernel_stats_reset()
@@ -354,7 +362,11 @@ def main():
                     "two_streams_ms_per_step": res["ms_two_streams"],
                     "one_stream_with_planning_ms_per_step": res["ms_one_stream_with_planning"],
                     "one_stream_with_planning_queries_per_sec": world * nq / (res["ms_one_stream_with_planning"] * 1e-3),
-                    "note": "planning = GpuIndexSearcher.pack per step (term resolution, BM25 weights, sim table) on one host thread"},
+                    "two_streams_with_array_planning_ms_per_step": res["ms_two_streams_with_array_planning"],
+                    "two_streams_with_array_planning_queries_per_sec": world * nq / (res["ms_two_streams_with_array_planning"] * 1e-3),
+                    "note": ("planning = term resolution, BM25 weights and sim-table handles redone every step on one host thread: "
+                             "`with_planning` through GpuIndexSearcher.pack (one Python object per query), `with_array_planning` through "
+                             "GpuIndexSearcher.pack_uniform (the batch handed over as an id array; same structs, test_pack.py)")},
         "roofline": roofline(dom_name, res["kernels_ms"].get(dom_name, 0.0), res["algo_bytes"], PROFILE_TAG[args.workload]),
         "kernels_ms_isolated": res["kernels_ms"],
     }

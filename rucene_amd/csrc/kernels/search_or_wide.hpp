@@ -8,8 +8,8 @@
 // result does not depend on that order at all:
 //   * a WORKGROUP (8 wavefronts) owns a window of `WS` doc ids as u32 accumulators in LDS (48 KB at the default 12288);
 //   * every clause's blocks that overlap the window — FullBlocks and the prepared tail alike, found with one coalesced
-//     look at the clause's block directory — form ONE flat list that is cut into eight equal pieces, one per
-//     wavefront: no clause is "sparse" or "dense", nothing is materialised in HBM (no k_score_terms, no runs), and a
+//     look at the clause's block directory — form ONE flat list that is dealt round-robin to the eight
+//     wavefronts: no clause is "sparse" or "dense", nothing is materialised in HBM (no k_score_terms, no runs), and a
 //     wavefront decodes 128 postings per step whatever the clause;
 //   * a posting's score becomes max(1, round(score * 2^e)) — e per query, chosen by the host so that the sum of the
 //     clauses' largest possible scores stays below 2^31 — and is added with ds_add_u32 (8 cycles per wavefront on gfx950;
@@ -20,7 +20,11 @@
 //     a top-k that reaches down to scores a thousand times smaller than the query's largest possible) queries that
 //     return a smaller total, and the host runs those again through k_or_windows;
 //   * the scan of a window (all 512 lanes, eight docs per lane per step) counts the touched docs and offers the ones at or
-//     above the threshold to the wavefront's top-k — keys are (total << 32 | ~doc), no float ordering tricks needed.
+//     above the threshold to the wavefront's top-k — keys are (total << 32 | ~doc), no float ordering tricks needed;
+//   * the eight lists of a workgroup share a bound on the query's k-th best: the smallest of their ceil(k/8)-th best totals
+//     (every doc is scanned by exactly one wavefront, so k docs reach it).
+// The kernel is bound by the NUMBER of instructions a wavefront issues per window (-DRGPU_ORX_TIME sums the
+// wave-cycles of every phase of the window loop): anything added to the per-block path costs more than it looks.
 // Clauses < 10, MUST_NOT clauses, min_should_match > 1, deleted docs, raw norm bytes, negative or non-finite weights or
 // similarity tables: k_or_windows (search_or.hpp), which sums f32 in clause order, bit-exact.
 //

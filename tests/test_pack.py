@@ -89,3 +89,61 @@ def test_byte_terms_go_through_the_dictionary(world, oracle):
     assert t["state"]["doc_freq"][0] == 0
     with pytest.raises(ra.RgpuError):
         s.pack([T(b"t0003")], leaf)                      # a leaf without a dictionary cannot resolve bytes
+
+
+def test_array_path_equals_the_general_path(world):
+    """A batch that names every term by a plain int id with boost 1 is packed by array operations (_pack_ids): the structs
+    must be the ones the clause-by-clause path writes, absent and out-of-table ids included."""
+    ra, seg, leaf, s = world
+    T, B = ra.TermQuery, ra.BooleanQuery
+    rng = np.random.default_rng(5)
+
+    def batch(wrap):
+        qs = []
+        for i in range(300):
+            ids = [wrap(int(x)) for x in rng.integers(-2, seg.terms.size + 3, size=int(rng.integers(1, 7)))]
+            kind = i % 5
+            if kind == 0:
+                qs.append(T(ids[0]))
+            elif kind == 1:
+                qs.append(B.build([T(x) for x in ids], []))
+            elif kind == 2:
+                qs.append(B.build([], [T(x) for x in ids], min_should_match=1 + i % 2))
+            elif kind == 3:
+                qs.append(B.build([T(x) for x in ids[:1]], [T(x) for x in ids[1:3]], must_nots=[T(x) for x in ids[3:]]))
+            else:
+                qs.append(B.build([], [T(x) for x in ids[:2]], must_nots=[T(x) for x in ids[2:]]) if len(ids) > 2 else T(ids[0]))
+        return qs
+
+    rng = np.random.default_rng(5)
+    fast = s.pack(batch(int), leaf)
+    rng = np.random.default_rng(5)
+    general = s.pack(batch(np.int64), leaf)             # numpy scalars are not `int`: the clause-by-clause path
+    assert fast[0].tobytes() == general[0].tobytes()
+    assert fast[1].tobytes() == general[1].tobytes()
+    assert s._w_memo is not None                        # ... and the first batch did take the array path
+
+
+def test_pack_uniform_equals_pack(world):
+    """The array planner writes what pack() writes for the same batch as query objects."""
+    ra, seg, leaf, s = world
+    from rucene_amd._lib import OP_TERM, OP_AND, OP_OR
+    T, B = ra.TermQuery, ra.BooleanQuery
+    rng = np.random.default_rng(9)
+    ids = rng.integers(-1, seg.terms.size + 2, size=(200, 5))
+    for op, nc, msm in ((OP_TERM, 1, 0), (OP_AND, 3, 0), (OP_OR, 5, 0), (OP_OR, 4, 3), (OP_AND, 1, 0), (OP_OR, 1, 2)):
+        sub = ids[:, :nc]
+        if op == OP_TERM:
+            qs = [T(int(r[0])) for r in sub]
+        elif op == OP_AND:
+            qs = [B.build([T(int(x)) for x in r], []) for r in sub]
+        else:
+            qs = [B.build([], [T(int(x)) for x in r], min_should_match=msm) for r in sub]
+        want = s.pack(qs, leaf)
+        got = s.pack_uniform(op, sub, leaf, min_should_match=msm)
+        assert got[0].tobytes() == want[0].tobytes(), (op, nc, msm)
+        assert got[1].tobytes() == want[1].tobytes(), (op, nc, msm)
+    with pytest.raises(ra.RgpuError):
+        s.pack_uniform(OP_TERM, ids[:, :2], leaf)
+    with pytest.raises(ra.RgpuError):
+        s.pack_uniform(OP_OR, np.zeros((3, 17), dtype=np.int64), leaf)
