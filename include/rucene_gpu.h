@@ -251,6 +251,12 @@ int32_t rgpu_search_batch_sharded(rgpu_comm* comm, rgpu_segment* seg, const rgpu
 int32_t rgpu_bm25_compute_weight(float k1, float b, int64_t max_doc, int64_t doc_count, int64_t sum_total_term_freq,
                                  const int64_t* doc_freqs, int32_t n_terms, float boost, float* weight_out, float* idf_out,
                                  float* cache_out /* 256 floats */);
+/* The weights of `n` single-term queries at once: weights_out[i] = idf(doc_freqs[i]) * boost, the arithmetic of
+ * rgpu_bm25_compute_weight with n_terms = 1 (TermWeight::new -> BM25Similarity::compute_weight, term_query.rs:69-95),
+ * for a planner that resolves a whole batch of terms before it packs rgpu_query_term[]. The norm cache of such weights
+ * does not depend on the term: take it once from rgpu_bm25_compute_weight. */
+int32_t rgpu_bm25_term_weights(int64_t max_doc, int64_t doc_count, const int64_t* doc_freqs, int64_t n, float boost,
+                               float* weights_out);
 /* BM25Similarity::encode_norm_value (bm25_similarity.rs:90-92): float_to_byte315(boost / sqrt(field_length)). */
 uint8_t rgpu_bm25_encode_norm(float boost, int32_t field_length);
 /* Lucene53NormsProducer (codec/norms/norms_producer.rs:40-189; format constants codec/norms/norms.rs:23-28): the

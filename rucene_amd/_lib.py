@@ -49,7 +49,7 @@ EXPORTS = [
     "rgpu_segment_upload_field", "rgpu_segment_release_prepared_terms", "rgpu_segment_attach_positions", "rgpu_search_phrase_batch", "rgpu_rescore_batch",
     "rgpu_segment_free", "rgpu_segment_version", "rgpu_segment_prepare_terms", "rgpu_decode_terms",
     "rgpu_decode_terms_device", "rgpu_advance_batch", "rgpu_sim_table_upload", "rgpu_search_batch",
-    "rgpu_search_batch_device", "rgpu_merge_topk_device", "rgpu_bm25_compute_weight", "rgpu_bm25_encode_norm",
+    "rgpu_search_batch_device", "rgpu_merge_topk_device", "rgpu_bm25_compute_weight", "rgpu_bm25_encode_norm", "rgpu_bm25_term_weights",
     "rgpu_norms_from_lucene53", "rgpu_live_docs_from_lucene50", "rgpu_field_infos_from_lucene60", "rgpu_segment_info_from_lucene62", "rgpu_commit_from_segments_file", "rgpu_compound_entries_from_lucene50", "rgpu_terms_open", "rgpu_terms_close", "rgpu_terms_field_stats",
     "rgpu_terms_lookup", "rgpu_terms_lookup_positions", "rgpu_kernel_stats", "rgpu_kernel_stats_reset", "rgpu_synchronize",
     "rgpu_set_profiling", "rgpu_and_touched_bytes", "rgpu_comm_unique_id", "rgpu_comm_init", "rgpu_comm_destroy",
@@ -134,6 +134,7 @@ def lib():
         "rgpu_merge_topk_device": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp]),
         "rgpu_bm25_compute_weight": (i32, [f32, f32, i64, i64, i64, vp, i32, f32, vp, vp, vp]),
         "rgpu_bm25_encode_norm": (C.c_uint8, [f32, i32]),
+        "rgpu_bm25_term_weights": (i32, [i64, i64, vp, i64, f32, vp]),
         "rgpu_norms_from_lucene53": (i32, [vp, C.c_size_t, vp, C.c_size_t, i32, i32, vp]),
         "rgpu_live_docs_from_lucene50": (i32, [vp, C.c_size_t, i32, i32, vp]),
         "rgpu_segment_info_from_lucene62": (i32, [vp, C.c_size_t, vp, vp]),
@@ -176,6 +177,14 @@ def bm25_compute_weight(k1, b, max_doc, doc_count, sum_total_term_freq, doc_freq
     _check(lib().rgpu_bm25_compute_weight(k1, b, max_doc, doc_count, sum_total_term_freq, dfs.ctypes.data, dfs.size, boost,
                                           C.addressof(w), C.addressof(idf), cache.ctypes.data))
     return w.value, idf.value, cache
+
+
+def bm25_term_weights(max_doc, doc_count, doc_freqs, boost=1.0):
+    """idf(df) * boost for a whole array of single-term queries (rgpu_bm25_term_weights)."""
+    dfs = np.ascontiguousarray(np.atleast_1d(doc_freqs), dtype=np.int64)
+    out = np.zeros(dfs.size, dtype=np.float32)
+    _check(lib().rgpu_bm25_term_weights(max_doc, doc_count, dfs.ctypes.data, dfs.size, boost, out.ctypes.data))
+    return out
 
 
 def bm25_encode_norm(boost, field_length):

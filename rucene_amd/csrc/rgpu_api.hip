@@ -1864,6 +1864,20 @@ extern "C" int32_t rgpu_bm25_compute_weight(float k1, float b, int64_t max_doc, 
   return RGPU_OK;
 }
 
+extern "C" int32_t rgpu_bm25_term_weights(int64_t max_doc, int64_t doc_count, const int64_t* doc_freqs, int64_t n, float boost,
+                                          float* weights_out) {
+  if (!doc_freqs || !weights_out || n < 0) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "bad arguments");
+  rucene::CollectionStatistics cs;
+  cs.max_doc = max_doc;
+  cs.doc_count = doc_count;
+  for (int64_t i = 0; i < n; ++i) {
+    rucene::TermStatistics ts;
+    ts.doc_freq = doc_freqs[i];
+    weights_out[i] = rucene::BM25Similarity::idf(&ts, 1, cs) * boost;  // BM25SimWeight::weight = idf * boost
+  }
+  return RGPU_OK;
+}
+
 extern "C" int32_t rgpu_norms_from_lucene53(const uint8_t* nvm, size_t nvm_len, const uint8_t* nvd, size_t nvd_len,
                                             int32_t field_number, int32_t max_doc, uint8_t* norms_out) {
   std::string why;

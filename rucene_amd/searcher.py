@@ -368,9 +368,12 @@ class GpuIndexSearcher:
         safe = np.where(inside, ids, 0)
         w = self._w_memo[safe]
         unknown = np.isnan(w)
-        if unknown.any():
-            for t in np.unique(safe[unknown]).tolist():
-                self._w_memo[t], self._t_memo[t] = self._weight(int(t), 1.0)
+        if unknown.any():   # terms met for the first time: one call for all their weights; the norm cache (and with it the
+            new = np.unique(safe[unknown])   # sim table) of a single-term weight depends on the collection alone
+            dfs = np.fromiter((self.term_statistics(int(t)) for t in new.tolist()), dtype=np.int64, count=new.size)
+            cs = self.collection_statistics
+            self._w_memo[new] = _lib.bm25_term_weights(cs.max_doc, cs.doc_count, dfs, 1.0)
+            self._t_memo[new] = self._weight(int(new[0]), 1.0)[1]
             w = self._w_memo[safe]
         in_leaf = (ids >= 0) & (ids < leaf.terms.size)
         st = leaf.terms[np.where(in_leaf, ids, 0)]

@@ -147,3 +147,14 @@ def test_pack_uniform_equals_pack(world):
         s.pack_uniform(OP_TERM, ids[:, :2], leaf)
     with pytest.raises(ra.RgpuError):
         s.pack_uniform(OP_OR, np.zeros((3, 17), dtype=np.int64), leaf)
+
+
+def test_batch_term_weights_equal_the_single_term_ones(world):
+    """rgpu_bm25_term_weights(dfs) == rgpu_bm25_compute_weight([df]) for every df, bit for bit (idf in f64, rounded once)."""
+    ra, seg, leaf, s = world
+    dfs = np.unique(np.concatenate([seg.terms["doc_freq"].astype(np.int64), [0, 1, 2, seg.max_doc // 2, seg.max_doc]]))
+    for boost in (1.0, 2.5):
+        got = ra._lib.bm25_term_weights(seg.max_doc, seg.doc_count, dfs, boost)
+        want = np.array([ra.bm25_compute_weight(1.2, 0.75, seg.max_doc, seg.doc_count, seg.sum_total_term_freq, [int(d)], boost)[0] for d in dfs],
+                        dtype=np.float32)
+        assert got.view(np.int32).tolist() == want.view(np.int32).tolist()
