@@ -366,6 +366,9 @@ def test_wide_disjunctions(oracle, knobs):
                  (oracle.OP_OR, [17, 15, 7, 8, 9, 10, 11, 12, 13, 6, 5, 4, 3])]
         for k in (10, 100):
             _check_against_oracle(oracle, osearcher, gsearcher, specs, k, exact=False)
+        if not knobs:  # the workgroup's bound is the smallest of its eight lists' ceil(k / 8)-th best totals: the edges of that rank
+            for k in (1, 7, 8, 9, 64, 65, 128):
+                _check_against_oracle(oracle, osearcher, gsearcher, specs[:6], k, exact=False)
         # next to other operators in one batch
         mixed = [(oracle.OP_TERM, [9]), specs[1], (oracle.OP_AND, [9, 10, 11]), specs[3], (oracle.OP_OR, [8, 9, 10])]
         _check_against_oracle(oracle, osearcher, gsearcher, mixed, 10, exact=False)
