@@ -24,6 +24,7 @@
 #include "kernels/search_and.hpp"
 #include "kernels/search_or.hpp"
 #include "kernels/search_or_wide.hpp"
+#include "host/flat_fp_map.hpp"
 #include "kernels/search_phrase.hpp"
 #include "kernels/search_term.hpp"
 
@@ -152,49 +153,8 @@ struct rgpu_ctx {
 
 struct TermInfo { uint32_t dir_base; int32_t nblocks; int32_t df; uint64_t pn_base; uint64_t bs_base; };
 
-// doc_start_fp -> TermInfo of the prepared terms. Every clause of every batch is looked up here twice (is it prepared?
-// where are its structures?): open addressing over one flat array (load <= 1/2, linear probing, one cache line per hit
-// as a rule) instead of a node-based map — ten thousand clauses of a ten-term OR batch cost 2 ms of host time per batch
-// through std::unordered_map, serialised with the GPU because OR groups end in a synchronisation.
-class PreparedMap {
- public:
-  const TermInfo* find(int64_t key) const {
-    if (slots_.empty() || key < 0) return nullptr;
-    for (size_t i = hash(key) & mask_;; i = (i + 1) & mask_) {
-      const Slot& s = slots_[i];
-      if (s.key == key) return &s.info;
-      if (s.key == EMPTY) return nullptr;
-    }
-  }
-  void put(int64_t key, const TermInfo& info) {  // key >= 0 (validate_state)
-    if ((used_ + 1) * 2 > slots_.size()) grow();
-    for (size_t i = hash(key) & mask_;; i = (i + 1) & mask_) {
-      Slot& s = slots_[i];
-      if (s.key == key) { s.info = info; return; }
-      if (s.key == EMPTY) { s.key = key; s.info = info; ++used_; return; }
-    }
-  }
-  void clear() { slots_.clear(); used_ = 0; mask_ = 0; }
-  size_t size() const { return used_; }
-
- private:
-  static constexpr int64_t EMPTY = INT64_MIN;  // (a file pointer is never negative)
-  struct Slot { int64_t key = EMPTY; TermInfo info{}; };
-  static size_t hash(int64_t k) {
-    uint64_t x = (uint64_t)k * 0x9E3779B97F4A7C15ull;
-    return (size_t)(x ^ (x >> 29));
-  }
-  void grow() {
-    std::vector<Slot> old;
-    old.swap(slots_);
-    slots_.assign(old.empty() ? 1024 : old.size() * 2, Slot());
-    mask_ = slots_.size() - 1;
-    used_ = 0;
-    for (const Slot& s : old) if (s.key != EMPTY) put(s.key, s.info);
-  }
-  std::vector<Slot> slots_;
-  size_t used_ = 0, mask_ = 0;
-};
+// doc_start_fp -> TermInfo of the prepared terms (host/flat_fp_map.hpp: two look-ups per clause per batch)
+using PreparedMap = rucene::FlatFpMap<TermInfo>;
 
 struct rgpu_segment {
   rgpu_ctx* ctx = nullptr;

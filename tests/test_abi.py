@@ -181,3 +181,11 @@ def test_comm_entry_points_check_their_arguments(gpu_lib):
     assert L.rgpu_comm_unique_id(None) == -2
     assert L.rgpu_search_batch_sharded(None, None, None, 0, None, 0, 10, None, None, None) == -2
     L.rgpu_comm_destroy(None)
+
+
+def test_flat_fp_map_against_std_unordered_map(tmp_path):
+    """csrc/host/flat_fp_map.hpp (the prepared-term table of a segment) against std::unordered_map: tests/cpp/flat_fp_map_test.cpp."""
+    exe = str(tmp_path / "flat_fp_map_test")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-o", exe, os.path.join(ROOT, "tests", "cpp", "flat_fp_map_test.cpp")])
+    out = subprocess.check_output([exe], text=True)
+    assert out.startswith("ok "), out
