@@ -61,7 +61,7 @@ typedef struct rgpu_config {
                                    per-clause LDS score table and everything built on it; A/B testing) */
   int32_t or_wide;              /* disjunctions of >= 10 SHOULD clauses (where the reference itself sums in heap order) through the
                                    order-free workgroup-window kernel: 0 = yes (default), -1 = no (clause-order kernel for all) */
-  int32_t or_wide_window_docs;  /* docs per workgroup window of that kernel (0 = default 12288; 4096..12288, rounded up to a multiple of 4096) */
+  int32_t or_wide_window_docs;  /* docs per workgroup window of that kernel (0 = default 16384; 4096..16384, rounded up to a multiple of 4096) */
   int32_t req_opt_rule;         /* MUST + SHOULD trees: 0 = the reference's ReqOptScorer, skipping rule included (default: exact
                                    scores, a sequential pass per query); -1 = always add the optional sums (faster, scores >= the
                                    reference's) */

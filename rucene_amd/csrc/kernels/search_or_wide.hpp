@@ -6,7 +6,7 @@
 // score only up to the rounding of a sum of non-negative terms (1e-5 relative). That freedom is what this
 // kernel is built on — the additions happen in whatever order the wavefronts reach them, in FIXED POINT, so that the
 // result does not depend on that order at all:
-//   * a WORKGROUP (8 wavefronts) owns a window of `WS` doc ids as u32 accumulators in LDS (48 KB at the default 12288);
+//   * a WORKGROUP (8 wavefronts) owns a window of `WS` doc ids as u32 accumulators in LDS (64 KB at the default 16384);
 //   * every clause's blocks that overlap the window — FullBlocks and the prepared tail alike, found with one coalesced
 //     look at the clause's block directory — form ONE flat list that is dealt round-robin to the eight
 //     wavefronts: no clause is "sparse" or "dense", nothing is materialised in HBM (no k_score_terms, no runs), and a
@@ -40,7 +40,7 @@ namespace rgpu {
 #define RGPU_ORX_WAVES 8
 #endif
 #ifndef RGPU_ORX_LOOK
-#define RGPU_ORX_LOOK 2
+#define RGPU_ORX_LOOK 3
 #endif
 constexpr int ORX_WAVES = RGPU_ORX_WAVES;  // 8: two workgroups per CU; 16: one, with twice the window
 constexpr int ORX_THREADS = 64 * ORX_WAVES;
@@ -48,9 +48,10 @@ constexpr int ORX_OWN = (16 + ORX_WAVES - 1) / ORX_WAVES;  // clauses whose bloc
 constexpr int ORX_LOOK = RGPU_ORX_LOOK;    // directory entries looked at per clause per window, in units of 64
 constexpr int ORX_SCAN_STEP = 8 * ORX_THREADS;  // docs per scan step of the workgroup (two 16-byte reads per lane): windows are multiples of it
 constexpr int ORX_WAVES_PER_SIMD = ORX_WAVES >= 16 ? 4 : (2 * ORX_WAVES + 3) / 4;  // two workgroups per CU (one of 16 wavefronts)
-#ifndef RGPU_ORX_TABLES
-#define RGPU_ORX_TABLES 4
-#endif
+#ifndef RGPU_ORX_TABLES  // LDS is the budget (two workgroups per CU: 80 KB each): since the formula path takes a reciprocal instead of
+#define RGPU_ORX_TABLES 1  // a division, a score table buys little (measured 2 / 4 / 6 tables: 9.95 / 9.88 / 10.0 ms at 12288-doc windows) and
+#endif                     // 3 KB of window buy more — one table + 16384-doc windows: 8.9 ms
+
 constexpr int ORX_TABLES = RGPU_ORX_TABLES;  // clauses scored through an LDS score table (the longest lists); the rest use the formula
 constexpr int ORX_MAX_TERMS = 16;   // == RGPU_MAX_QUERY_TERMS
 #ifndef RGPU_ORX_RING
