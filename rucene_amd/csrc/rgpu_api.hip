@@ -975,7 +975,10 @@ static int32_t search_or_wide_group(rgpu_segment* seg, Group& G, int32_t k, HitO
 #ifndef RGPU_ORX_WS  // the default window (variant builds sweep it together with RGPU_ORX_TABLES / RGPU_ORX_LOOK: LDS is the budget)
 #define RGPU_ORX_WS 16384
 #endif
-  constexpr int WS_DEFAULT = ORX_WAVES >= 16 ? 24576 : (RGPU_ORX_WS + ORX_SCAN_STEP - 1) / ORX_SCAN_STEP * ORX_SCAN_STEP;
+#ifndef RGPU_ORX_WS16  // ... and of the one-workgroup-per-CU build (RGPU_ORX_WAVES=16)
+#define RGPU_ORX_WS16 24576
+#endif
+  constexpr int WS_DEFAULT = (ORX_WAVES >= 16 ? RGPU_ORX_WS16 : RGPU_ORX_WS + ORX_SCAN_STEP - 1) / ORX_SCAN_STEP * ORX_SCAN_STEP;
   static_assert(WS_DEFAULT <= WS_MAX, "a window's blocks of one clause fit the directory look-ahead");
   int WS = c->cfg.or_wide_window_docs > 0 ? (c->cfg.or_wide_window_docs + ORX_SCAN_STEP - 1) / ORX_SCAN_STEP * ORX_SCAN_STEP : WS_DEFAULT;
   WS = std::min(WS_MAX, std::max(ORX_SCAN_STEP, WS));
