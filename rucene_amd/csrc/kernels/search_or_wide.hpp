@@ -160,7 +160,7 @@ __global__ __launch_bounds__(ORX_THREADS, ORX_WAVES_PER_SIMD) void k_or_wide(Seg
   for (int i = (int)threadIdx.x; i < WS; i += ORX_THREADS) acc[i] = 0u;
 
   // ---- block bounds of a window, per clause: blocks [lo, lo + cnt) hold a doc of [w0, w1). The owner keeps a cursor
-  // `cur` (a block at or before lo) and looks at the 128 directory entries from it.
+  // `cur` (a block at or before lo) and looks at the 64 * ORX_LOOK directory entries from it.
   int own_cur[ORX_OWN];
   int32_t own_e[ORX_OWN][ORX_LOOK];
   auto bounds_issue = [&](int c, int cur, int32_t (&e)[ORX_LOOK]) {
