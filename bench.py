@@ -6,15 +6,25 @@
         bench.py --gpus N --steps K --warmup W
 
 One "step" = one pass of the hot path over one batch: 1024 single-term BM25 queries (BASELINE.json configs[1],
-SURVEY.md §8(d)) evaluated on the GPU against a 10M-doc Zipfian segment that is already resident in HBM
-(decode -> BM25 -> top-10). With N GPUs the index is segment-sharded (one 10M-doc shard per rank, shard = rank),
-the query batch is replicated, every rank evaluates it against its shard, per-shard top-k is all-gathered over
-RCCL and merged on the GPU — weak scaling: the unit is one query evaluated against one 10M-doc segment.
-Rank 0 prints ONE JSON line. At N = 1 the line also carries, under "configs", north_star's other targets measured
-in the same run: 3-term AND (configs[2]), 10-term OR top-100 (configs[3]), the block-decode microbenchmark, and an
-out-of-Infinity-Cache point (a 100M-doc shard, .doc ~ 670 MB) for block decode and the single-term kernel —
-each with its isolated kernel time, algorithmic bytes, roofline fraction, a bounded CPU leg and full-batch parity
-against the oracle. `--configs none` skips them.
+SURVEY.md §8(d)) PLANNED (term ids -> term states, BM25 weights: the native batch planner behind the C ABI) and evaluated
+on the GPU against a 10M-doc Zipfian segment that is already resident in HBM (decode -> BM25 -> top-10). With N GPUs the
+index is segment-sharded (one 10M-doc shard per rank, shard = rank), the query batch is replicated, every rank evaluates
+it against its shard, per-shard top-k is all-gathered over RCCL and merged on the GPU — weak scaling: the unit is one
+query evaluated against one 10M-doc segment. Rank 0 prints ONE JSON line.
+
+What the line claims, and how each claim is kept honest:
+  * `value` (queries/s) has the planning inside the timed region;
+  * `roofline.frac` is a BANDWIDTH fraction: bytes the dominant kernel really touched (counted by the kernel:
+    rgpu_last_search_counters) / its launch duration (HIP events) / 8 TB/s. What an exhaustive scorer would have had to
+    stream for the same answers is `scan_equivalent_gbs` — a rate, not a fraction (the TERM kernel skips, exactly, every
+    block whose score bound cannot reach the top-k);
+  * `postings_decoded_per_sec` counts postings that were unpacked; `postings_covered_per_sec` those the queries span;
+  * every timed batch is compared with the CPU oracle on the full batch (N = 1): bit-exact doc ids and scores for TERM /
+    AND; for the 10-clause OR — which the reference itself sums in heap order — doc ids are judged by the oracle's own
+    score of every returned doc (oracle/parity.py) and `docs_differing` is reported.
+Under "configs" (N = 1: all; N > 1: and3, i.e. BASELINE configs[4]'s workload): 3-term AND (configs[2]), 10-term OR top-100
+(configs[3]), block decode warm (prepared block store) and COLD (.doc bytes -> skip decode -> postings), and the same four
+out of the Infinity Cache on a 100M-doc shard. `--configs none` skips them.
 """
 import argparse
 import glob
@@ -31,6 +41,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 SEED_QUERIES = 0x527563656E65 ^ 0x51  # "Rucene" ^ purpose tag
+ROUND = "r03"
 
 
 def term_encoded_bytes(terms, doc_len_end):
@@ -45,12 +56,23 @@ def term_encoded_bytes(terms, doc_len_end):
     return out.astype(np.int64)
 
 
+def term_file_bytes(terms, doc_len_end):
+    """Bytes of the .doc file a term owns: postings AND skip data (the next term starts right behind them)."""
+    start = terms["doc_start_fp"].astype(np.int64)
+    nxt = np.empty_like(start)
+    nxt[:-1] = start[1:]
+    nxt[-1] = doc_len_end
+    out = nxt - start
+    out[terms["doc_freq"] <= 1] = 0
+    return out.astype(np.int64)
+
+
 def profiled_traffic(kernel, tag):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC summary profiles/<tag>_rocprofv3_summary.txt:
     2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes. The factor 2 is MI355X_MICROARCH.md's gfx950 correction (FETCH_SIZE
     tallies the 128-byte requests of wide 16-byte-per-lane streaming reads at 64 bytes — these kernels' row loads);
     WRITE_SIZE is taken as reported. None when no such profile is committed — bench.py never runs rocprof."""
-    if " + " in kernel:  # several kernels per batch (OR): their per-launch traffic summed
+    if " + " in kernel:  # several kernels per batch: their per-launch traffic summed
         parts = [profiled_traffic(x, tag) for x in kernel.split(" + ")]
         if any(x is None for x in parts):
             return None
@@ -89,7 +111,7 @@ WORKLOAD_TEXT = {
     "or10": "1024 x 10-term OR top-100, ranks log-uniform 1..10000 (BASELINE configs[3])",
 }
 DOMINANT = {"term": "k_search_term", "and3": "k_search_and", "or10": "k_or_wide"}
-PROFILE_TAG = {"term": "r02_term", "and3": "r02_and3", "or10": "r02_or10", "decode": "r02_decode"}
+K_OF = {"term": 10, "and3": 10, "or10": 100}
 
 
 def main():
@@ -102,7 +124,7 @@ def main():
     ap.add_argument("--queries", type=int, default=1024)
     ap.add_argument("--k", type=int, default=0, help="0 = the workload's own (10; 100 for or10)")
     ap.add_argument("--workload", choices=["term", "and3", "or10"], default="term")
-    ap.add_argument("--configs", default="all", help="all | none | comma list of and3,or10,block_decode,out_of_cache (N = 1 only)")
+    ap.add_argument("--configs", default="all", help="all | none | comma list of and3,or10,block_decode,cold,out_of_cache (N > 1: and3 only)")
     ap.add_argument("--big-docs", type=int, default=100_000_000, help="size of the out-of-cache shard")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true",
@@ -118,7 +140,7 @@ def main():
     import torch
     import torch.distributed as dist
     import rucene_amd
-    from rucene_amd import indexgen
+    from rucene_amd import indexgen, _lib
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: rucene_amd has no CPU fallback")
@@ -137,12 +159,12 @@ def main():
         dist.init_process_group("gloo", rank=rank, world_size=world)
     cores = os.cpu_count() or 1
     nq = args.queries
-    T, B = rucene_amd.TermQuery, rucene_amd.BooleanQuery
     ctx = rucene_amd.Context(device=local_rank, profile_kernels=False)
     from rucene_amd import dist as rdist
     # N > 1: the collective lives behind the C ABI (rgpu_comm_*: RCCL linked into librucene_gpu.so); torch.distributed only
     # carries the 128-byte communicator id, the barriers around the timed region and the max-over-ranks of the time
     comm = rdist.create_comm(ctx) if dist_mode else None
+    OPS = {"term": _lib.OP_TERM, "and3": _lib.OP_AND, "or10": _lib.OP_OR}
 
     class Shard:
         """One segment resident in HBM + the searcher over it (statistics of shard 0, the first largest leaf)."""
@@ -152,32 +174,23 @@ def main():
             self.seg = indexgen.build_zipf(docs, args.vocab, shard=shard, doc_base=doc_base)
             self.build_s = time.time() - t0
             self.leaf = rucene_amd.LeafReader.from_synthetic(self.seg)
+            t0 = time.perf_counter()
             self.searcher = rucene_amd.GpuIndexSearcher([self.leaf], ctx=ctx)
+            self.upload_s = time.perf_counter() - t0   # rgpu_segment_upload: header checks + .doc, norms over PCIe
             stats_seg = self.seg if shard == 0 else indexgen.build_zipf(docs, args.vocab, shard=0)
-            self.searcher.collection_statistics = rucene_amd.CollectionStatistics("body", 0, docs * n_shards, stats_seg.doc_count,
-                                                                                  stats_seg.sum_total_term_freq)
-            stats_df = stats_seg.terms["doc_freq"].astype(np.int64)
-            self.searcher.term_statistics = lambda t: int(stats_df[t])
+            self.searcher.override_statistics(rucene_amd.CollectionStatistics("body", 0, docs * n_shards, stats_seg.doc_count,
+                                                                              stats_seg.sum_total_term_freq),
+                                              None if shard == 0 else stats_seg.terms)
             self.enc = term_encoded_bytes(self.seg.terms, self.seg.doc_bytes.size - 16)
 
-        def queries(self, kind):
-            tids = build_queries(nq, kind, SEED_QUERIES)
-            if kind == "term":
-                qs = [T(int(t[0])) for t in tids]
-            elif kind == "and3":
-                qs = [B.build([T(int(x)) for x in t], []) for t in tids]
-            else:
-                qs = [B.build([], [T(int(x)) for x in t]) for t in tids]
-            return tids, qs
-
         def batch(self, kind, k):
-            tids, qs = self.queries(kind)
-            packed = self.searcher.pack(qs, self.leaf)
+            tids = build_queries(nq, kind, SEED_QUERIES)
+            packed = self.searcher.pack_uniform(OPS[kind], tids, self.leaf)   # the native planner (rgpu_plan_uniform_ids)
             flat = tids.reshape(-1)
             postings = int(self.seg.terms["doc_freq"][flat].sum())
             # encoded blocks + tails + 1 B norm per scored posting + 8 k B output per query
             algo_bytes = int(self.enc[flat].sum()) + postings + 8 * k * nq
-            return tids, qs, packed, postings, algo_bytes
+            return tids, packed, postings, algo_bytes
 
     class Lane:
         def __init__(self, k):
@@ -187,20 +200,19 @@ def main():
             self.local_hits = torch.empty((nq, k), dtype=torch.int64, device="cuda")  # this rank's shard alone (parity checks)
             self.local_totals = torch.empty((nq,), dtype=torch.int64, device="cuda")
 
-    def measure(shard, kind, k, steps, warmup, two_streams, with_planning=True):
+    def measure(shard, kind, k, steps, warmup, full):
         """Times `steps` passes of one batch. rgpu_search_batch_device only enqueues (staging copy + kernels): back-to-back
-        steps overlap the host-side planning of batch i+1 with the kernels of batch i; the timed region is bracketed by a
+        steps overlap the host-side work of batch i+1 with the kernels of batch i; every timed region is bracketed by a
         barrier + device-wide synchronize on both sides and runs WITHOUT per-kernel events. N > 1: a step =
-        rgpu_search_batch_sharded: search -> ONE RCCL all-gather of the per-shard {top-k, count} records -> device merge,
-        enqueued in order on one stream without host syncs.
-        Returns wall figures for one stream, for two alternating streams (the small merge / scatter kernels and the tail
-        of step i then run under step i+1's search kernel), for one stream with the query planning (pack: term
-        resolution, BM25 weights, sim table) redone every step, and the isolated per-kernel durations (HIP events on one
-        stream, a separate pass)."""
-        tids, qs, packed, postings, algo_bytes = shard.batch(kind, k)
+        rgpu_search_batch_sharded: search -> ONE RCCL all-gather of the per-shard {top-k, count, status} records -> device
+        merge, enqueued in order on one stream without host syncs.
+        Figures: "planned" = the batch is planned (ids -> rgpu_query_term[]) again in every step, natively; "resident
+        plan" = planned once. `full` adds the one-stream and object-planner variants of the headline table."""
+        tids, packed, postings, algo_bytes = shard.batch(kind, k)
         lanes = [Lane(k), Lane(k)]
         state = {"n": 0}
         merged = {}
+        T, B = rucene_amd.TermQuery, rucene_amd.BooleanQuery
 
         def step(pk, n_lanes):
             lane = lanes[state["n"] % n_lanes]
@@ -211,7 +223,15 @@ def main():
             else:
                 shard.leaf.segment.search_batch_device(pk[0], pk[1], k, lane.hits.data_ptr(), lane.totals.data_ptr(), lane.stream.cuda_stream)
 
-        def timed(n_lanes, replan):
+        def timed(n_lanes, replan, n_steps=steps):
+            qs = None
+            if replan == "objects":
+                if kind == "term":
+                    qs = [T(int(t[0])) for t in tids]
+                elif kind == "and3":
+                    qs = [B.build([T(int(x)) for x in t], []) for t in tids]
+                else:
+                    qs = [B.build([], [T(int(x)) for x in t]) for t in tids]
             for _ in range(warmup):
                 step(packed, n_lanes)
             torch.cuda.synchronize()
@@ -219,12 +239,11 @@ def main():
                 dist.barrier()
             torch.cuda.synchronize()
             t = time.perf_counter()
-            op = {"term": rucene_amd._lib.OP_TERM, "and3": rucene_amd._lib.OP_AND}.get(kind, rucene_amd._lib.OP_OR)
-            for _ in range(steps):
+            for _ in range(n_steps):
                 if replan == "objects":
                     pk = shard.searcher.pack(qs, shard.leaf)
                 elif replan == "array":
-                    pk = shard.searcher.pack_uniform(op, tids, shard.leaf)
+                    pk = shard.searcher.pack_uniform(OPS[kind], tids, shard.leaf)
                 else:
                     pk = packed
                 step(pk, n_lanes)
@@ -237,13 +256,15 @@ def main():
                 tt = torch.tensor([el], dtype=torch.float64)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 el = float(tt.item())
-            return 1e3 * el / steps
+            return 1e3 * el / n_steps
 
         res = {"tids": tids, "postings": postings, "algo_bytes": algo_bytes}
-        res["ms_one_stream"] = timed(1, False)
-        res["ms_two_streams"] = timed(2, False) if two_streams else None
-        res["ms_one_stream_with_planning"] = timed(1, "objects") if with_planning else None
-        res["ms_two_streams_with_array_planning"] = timed(2, "array") if with_planning else None
+        res["ms_planned_two_streams"] = timed(2, "array")
+        res["ms_planned_one_stream"] = timed(1, "array")
+        if full:
+            res["ms_resident_plan_two_streams"] = timed(2, False)
+            res["ms_resident_plan_one_stream"] = timed(1, False)
+            res["ms_object_planner_one_stream"] = timed(1, "objects", max(3, steps // 4))
         # isolated kernel durations: the same steps on ONE stream with HIP events around every launch
         ctx.set_profiling(True)
         ctx.kernel_stats_reset()
@@ -251,9 +272,10 @@ def main():
             step(packed, 1)
         torch.cuda.synchronize()
         stats = ctx.kernel_stats()
-        res["kernels_ms"] = {n: s["total_ms"] / max(1, s["launches"]) for n, s in stats.items()}  # average per launch
-        res["kernels_ms_per_step"] = {n: s["total_ms"] / steps for n, s in stats.items()}
-        res["launches_per_step"] = {n: s["launches"] / steps for n, s in stats.items()}
+        res["kernels_ms"] = {n: s["total_ms"] / max(1, s["launches"]) for n, s in stats.items() if s["total_ms"] > 0}  # average per launch
+        res["kernels_ms_per_step"] = {n: s["total_ms"] / steps for n, s in stats.items() if s["total_ms"] > 0}
+        res["launches_per_step"] = {n: s["launches"] / steps for n, s in stats.items() if s["total_ms"] > 0}
+        res["counters"] = ctx.last_search_counters()   # of the last launch: what it decoded vs what its queries cover
         ctx.set_profiling(False)
         ctx.kernel_stats_reset()
         res["g_hits"] = merged["hits"].cpu().numpy().view(rucene_amd.HIT_DTYPE).reshape(nq, k).copy()
@@ -265,11 +287,12 @@ def main():
             res["force_dist_same"] = bool(torch.equal(merged["hits"], lane.local_hits)) and bool(torch.equal(merged["totals"], lane.local_totals))
         return res
 
-    def cpu_baseline_leg(shard, kind, k, res, budget_s, sample_queries):
+    def cpu_baseline_leg(shard, kind, k, res, budget_s, sample_queries, parity_queries):
         """cpu_baseline: the oracle (C++ restatement of Rucene's CPU IndexSearcher, one query per thread on all host cores): a bounded timing
-        leg on `sample_queries` of the batch, and parity of the GPU's rows against it on the FULL batch (canonical tie
-        rule). A reported baseline, not the target."""
+        leg on `sample_queries` of the batch, and parity of the GPU's rows against it on `parity_queries` of the batch
+        (canonical tie rule). A reported baseline, not the target."""
         from oracle import binding as orc  # the checker: only ever imported here, after the timed regions
+        from oracle import parity
         osearcher = orc.Searcher([orc.Segment(shard.seg.doc_bytes, shard.seg.norms, shard.seg.max_doc, shard.seg.terms,
                                               sum_total_term_freq=shard.seg.sum_total_term_freq)])
         tids = res["tids"]
@@ -285,34 +308,106 @@ def main():
             done_q += ns
             reps += 1
         sample_postings = int(shard.seg.terms["doc_freq"][flat].sum())
-        ops = np.full(nq, op, np.int32)
-        offs = (np.arange(nq + 1) * tids.shape[1]).astype(np.int32)
-        cd, cs, _, ct, _, _ = osearcher.search_batch(ops, offs, tids.reshape(-1), k, tie_mode=orc.TIE_CANONICAL, threads=cores)
-        g_hits, g_totals = res["g_hits"], res["g_totals"]
-        if kind == "or10":  # >= 10 clauses: the reference's own sum order is heap-dependent -> 1e-5 relative (north_star)
-            parity = bool(np.allclose(g_hits["score"], cs, rtol=1e-5, atol=0) and (g_totals == ct).all())
+        npq = min(nq, parity_queries)
+        ops = np.full(npq, op, np.int32)
+        offs = (np.arange(npq + 1) * tids.shape[1]).astype(np.int32)
+        cd, cs, cc, ct, _, secs = osearcher.search_batch(ops, offs, np.ascontiguousarray(tids[:npq]).reshape(-1), k, tie_mode=orc.TIE_CANONICAL, threads=cores)
+        if reps == 0:  # budget 0: the parity pass is the timing sample too (the slow 100M-doc legs: one pass of the oracle, not two)
+            spent, done_q, reps, ns = secs, npq, 1, npq
+            sample_postings = int(shard.seg.terms["doc_freq"][np.ascontiguousarray(tids[:npq]).reshape(-1)].sum())
+        g_hits, g_totals = res["g_hits"][:npq], res["g_totals"][:npq]
+        parity_info = {"queries_checked": npq, "rule": "bit-exact doc ids, score bits and hit counts"}
+        if kind == "or10":
+            # >= 10 clauses: the reference's own sum order is heap-dependent -> scores within 1e-5 relative (north_star), doc
+            # ids judged by the oracle's own score of every returned doc + nothing above the k-th score band missing
+            parity_info["rule"] = ("hit counts equal; every returned doc matches and the ORACLE scores it within 1e-5 of the returned score; every "
+                                   "oracle hit above the k-th score band is returned (oracle/parity.py)")
+            try:
+                parity_info["docs_differing"] = parity.check_heap_order_batch(osearcher, op, tids[:npq], g_hits, g_totals, cd, cs, cc, ct, rtol=1e-5, what=kind)
+                parity_info["docs_returned"] = int(cc.sum())
+                ok = bool(np.allclose(g_hits["score"], cs, rtol=1e-5, atol=0))
+            except parity.HeapOrderParityError as e:
+                parity_info["failure"] = str(e)
+                ok = False
         else:
-            parity = bool((g_hits["doc"] == cd).all() and (g_hits["score"].view(np.int32) == cs.view(np.int32)).all()
-                          and (g_totals == ct).all())
+            ok = bool((g_hits["doc"] == cd).all() and (g_hits["score"].view(np.int32) == cs.view(np.int32)).all() and (g_totals == ct).all())
         base = {"value": done_q / spent, "unit": "queries/s", "cores": cores, "kind": "port",
                 "postings_per_sec": float(sample_postings) * reps / spent,
-                "postings_per_sec_per_core": float(sample_postings) * reps / spent / cores,
                 "sample": "%d of the batch's %d queries x %d repetitions (%.1f s), one query per thread, %d threads; oracle = C++ "
                           "restatement of Rucene's CPU IndexSearcher (the Rust original cannot be built here)" % (ns, nq, reps, spent, cores)}
-        return base, parity
+        return base, ok, parity_info
 
-    def roofline(kernel, kernel_ms, algo_bytes, tag):
-        achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    def roofline(kernel, kernel_ms, touched_bytes, scan_bytes, tag, what):
+        """frac = bytes the kernel really had to touch / its launch duration / peak. `scan_equivalent_gbs`: the rate at which
+        an exhaustive scorer would have had to stream the lists for the same answers (NOT a bandwidth claim)."""
+        achieved = touched_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         traffic = profiled_traffic(kernel, tag) or {}
-        return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic.get("bytes"), "traffic_source": traffic.get("source"), "kernel": kernel, "kernel_ms": kernel_ms,
-                "algorithmic_bytes_per_launch": algo_bytes, "frac_vs_measured_copy_6290": achieved / 6290.0}
+        r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+             "traffic": traffic.get("bytes"), "traffic_source": traffic.get("source"), "kernel": kernel, "kernel_ms": kernel_ms,
+             "bytes_per_launch": touched_bytes, "bytes_are": what, "frac_vs_measured_copy_6290": achieved / 6290.0}
+        if scan_bytes is not None and scan_bytes != touched_bytes:
+            r["scan_bytes_per_launch"] = scan_bytes
+            r["scan_equivalent_gbs"] = scan_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        assert r["frac"] <= 1.0, "a bandwidth fraction above 1: %r" % (r,)
+        return r
 
-    def decode_bench(shard, rep, reps):
-        """Block-decode microbenchmark (north_star: >= 40 % of HBM peak): every term with df >= 128 of the shard, docs +
-        freqs materialised in HBM as i32. SURVEY 8(d): bytes = encoded block + tail bytes in, 8 B per posting out."""
+    def search_config(shard, kind, steps, warmup, full, tag, cpu_budget, cpu_sample, parity_queries):
+        """One search workload on one shard: throughput with planning in the timed region, the dominant kernel's roofline
+        from what it touched, decoded vs covered postings, the CPU leg and parity."""
+        k = args.k if (args.k and kind == args.workload) else K_OF[kind]
+        r = measure(shard, kind, k, steps, warmup, full)
+        two_wins = r["ms_planned_two_streams"] <= r["ms_planned_one_stream"]
+        ms = r["ms_planned_two_streams"] if two_wins else r["ms_planned_one_stream"]
+        dom = DOMINANT[kind]
+        c = r["counters"]
+        kms = r["kernels_ms"].get(dom, 0.0)
+        out = {"workload": WORKLOAD_TEXT[kind], "k": k, "steps": steps, "ms_per_step": ms,
+               "queries_per_sec": nq / (ms * 1e-3),
+               "postings_covered_per_step": r["postings"], "postings_decoded_per_step": c["postings_decoded"],
+               "postings_decoded_per_sec": c["postings_decoded"] / (ms * 1e-3), "postings_covered_per_sec": r["postings"] / (ms * 1e-3),
+               "issue": "two alternating streams" if two_wins else "one stream",
+               "kernels_ms_isolated": r["kernels_ms"]}
+        if kind == "or10":
+            # every posting of every clause is decoded (k_or_wide): touched = scan bytes; flagged queries are run again by the f32 kernels
+            or_kernels = [n for n in ("k_or_wide", "k_score_terms", "k_or_windows") if n in r["kernels_ms_per_step"]]
+            kms = sum(r["kernels_ms_per_step"][n] for n in or_kernels)
+            out["kernels_ms_per_step"] = r["kernels_ms_per_step"]
+            out["roofline"] = roofline(" + ".join(or_kernels), kms, r["algo_bytes"], None, tag,
+                                       "scan bytes: every clause's encoded blocks + tails + 1 B norm per posting + 8 k B out")
+        elif kind == "and3":
+            lead_postings = int(shard.seg.terms["doc_freq"][r["tids"]].min(axis=1).sum())
+            touched = c["touched_bytes"] + lead_postings + 8 * k * nq
+            out["roofline"] = roofline(dom, kms, touched, r["algo_bytes"], tag,
+                                       "touched bytes: encoded bytes of every block the kernel decoded (counted by the kernel) + 1 B norm per lead posting + 8 k B out")
+        else:
+            touched = c["touched_bytes"] + 8 * k * nq
+            out["roofline"] = roofline(dom, kms, touched, r["algo_bytes"], tag,
+                                       "touched bytes: encoded bytes + norms of every block the kernel unpacked (counted by the kernel) + 14 B of "
+                                       "directory (row, header, frontier words) per block it looked at + 8 k B out")
+            out["roofline"]["pruning"] = "%d of %d FullBlocks unpacked" % (c["blocks_decoded"], int((shard.seg.terms["doc_freq"][r["tids"].reshape(-1)] // 128).sum()))
+        # the step cannot have moved its bytes faster than the memory system allows
+        assert out["roofline"]["bytes_per_launch"] / (ms * 1e-3) / 1e9 <= HBM_PEAK_GBS, "bytes / ms_per_step exceeds the HBM peak"
+        if full:
+            out["streams"] = {k2: r[k2] for k2 in ("ms_planned_two_streams", "ms_planned_one_stream", "ms_resident_plan_two_streams",
+                                                   "ms_resident_plan_one_stream", "ms_object_planner_one_stream")}
+            out["streams"]["note"] = ("ms per step. planned = term ids -> rgpu_query_term[] redone in every step by the native planner behind the C ABI "
+                                      "(rgpu_plan_uniform_ids: term states, BM25 weights, sim table) — the headline; resident plan = planned once; "
+                                      "object planner = one Python query object per query flattened first (GpuIndexSearcher.pack), then the native planner")
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            base, ok, info = cpu_baseline_leg(shard, kind, k, r, cpu_budget, cpu_sample, parity_queries)
+            out["cpu_baseline"] = base
+            out["gpu_over_cpu"] = out["queries_per_sec"] / base["value"]
+            out["parity_vs_oracle"] = ok
+            out["parity"] = info
+        out["_res"] = r
+        return out
+
+    def decode_bench(shard, reps, tag):
+        """Block-decode microbenchmark, WARM (north_star: >= 40 % of HBM peak): every term with df >= 128 of the shard from
+        its prepared block store, docs + freqs materialised in HBM as i32. SURVEY 8(d): bytes = encoded block + tail bytes in,
+        8 B per posting out."""
         keep = shard.seg.terms["doc_freq"] >= 128
-        sel = np.tile(shard.seg.terms[keep], rep)
+        sel = shard.seg.terms[keep]
         total = int(sel["doc_freq"].sum())
         d_docs = torch.empty((total,), dtype=torch.int32, device="cuda")
         d_freqs = torch.empty((total,), dtype=torch.int32, device="cuda")
@@ -326,126 +421,130 @@ def main():
         ctx.set_profiling(False)
         ctx.kernel_stats_reset()
         ms = st["total_ms"] / st["launches"]
-        b = int(shard.enc[keep].sum()) * rep + 8 * total
+        b = int(shard.enc[keep].sum()) + 8 * total
         del d_docs, d_freqs
-        return {"postings": total, "list_repeats": rep, "kernel": "k_decode_terms", "kernel_ms": ms, "postings_per_sec": total / (ms * 1e-3),
-                "algorithmic_bytes": b, "working_set_bytes": int(shard.seg.doc_bytes.size) + 8 * total}, b, ms
+        return {"postings": total, "kernel": "k_decode_terms", "kernel_ms": ms, "postings_decoded_per_sec": total / (ms * 1e-3),
+                "working_set_bytes": int(shard.seg.doc_bytes.size) + 8 * total, "source": "prepared block store (16-byte aligned rows, decoded tails)",
+                "roofline": roofline("k_decode_terms", ms, b, None, tag, "encoded block + tail bytes in + 8 B per posting out")}
+
+    def cold_bench(shard, tag):
+        """The reference's own decode path, end to end: a FRESH copy of the segment (nothing prepared) -> skip-list decode +
+        block framing + alignment + tail decode + validation (k_prepare_terms, k_prepare_blocks: what ForUtil::read_block's
+        header parse, read_vint_block and Lucene50SkipReader do per term, for_util.rs:187-243, posting_reader.rs:308-333,
+        skip_reader.rs:315-584) -> k_decode_terms, for every term with df >= 128. Bytes = the terms' .doc bytes (postings AND
+        skip data) in + 8 B per posting out; time = the three kernels' durations summed (HIP events)."""
+        keep = shard.seg.terms["doc_freq"] >= 128
+        sel = shard.seg.terms[keep]
+        total = int(sel["doc_freq"].sum())
+        t0 = time.perf_counter()
+        seg2 = _lib.Segment(ctx, shard.seg.doc_bytes, shard.seg.norms, shard.seg.max_doc, 0, None)
+        upload_s = time.perf_counter() - t0
+        d_docs = torch.empty((total,), dtype=torch.int32, device="cuda")
+        d_freqs = torch.empty((total,), dtype=torch.int32, device="cuda")
+        ctx.set_profiling(True)
+        ctx.kernel_stats_reset()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        seg2.prepare_terms(sel)
+        seg2.decode_terms_device(sel, d_docs.data_ptr(), d_freqs.data_ptr())
+        torch.cuda.synchronize()
+        wall_ms = 1e3 * (time.perf_counter() - t0)
+        st = ctx.kernel_stats()
+        ctx.set_profiling(False)
+        ctx.kernel_stats_reset()
+        kms = {n: st[n]["total_ms"] for n in ("k_prepare_terms", "k_prepare_blocks", "k_decode_terms") if n in st}
+        ms = sum(kms.values())
+        file_bytes = int(term_file_bytes(shard.seg.terms, shard.seg.doc_bytes.size - 16)[keep].sum())
+        b = file_bytes + 8 * total
+        fp = seg2.footprint()
+        held = fp["directory_bytes"] + fp["block_store_bytes"] + fp["posting_norms_bytes"]
+        out = {"postings": total, "terms": int(keep.sum()), "kernels_ms": kms, "kernels_ms_total": ms, "wall_ms_incl_host_planning": wall_ms,
+               "postings_decoded_per_sec": total / (ms * 1e-3),
+               "doc_file_bytes_of_these_terms": file_bytes, "upload_s_pcie": upload_s,
+               "hbm_footprint": fp, "hbm_bytes_held_per_doc_file_byte": (fp["doc_file_bytes"] + held) / max(1, fp["doc_file_bytes"]),
+               "roofline": roofline("k_prepare_terms + k_prepare_blocks + k_decode_terms", ms, b, None, tag,
+                                    "the terms' .doc bytes (postings and skip data) in + 8 B per posting out; kernel_ms = the three kernels summed")}
+        seg2.close()
+        del d_docs, d_freqs
+        return out
+
+    def strip(c):
+        c.pop("_res", None)
+        return c
 
     # ---- headline: BASELINE configs[1] (or --workload), one 10M-doc shard per rank -----------------------------------------
-    k_of = {"term": 10, "and3": 10, "or10": 100}
-    k = args.k or k_of[args.workload]
     shard = Shard(args.docs, rank, rank * args.docs, world)
-    res = measure(shard, args.workload, k, args.steps, args.warmup, two_streams=True)
-    dom_name = DOMINANT[args.workload]
-    # the headline is the faster of the two issue modes (both are in `streams`): two alternating streams win on one GPU
-    # (the next step's search kernel runs over this step's merge tail), one stream can win when every step ends in a collective
-    two_wins = res["ms_two_streams"] <= res["ms_one_stream"]
-    ms_per_step = res["ms_two_streams"] if two_wins else res["ms_one_stream"]
+    head = search_config(shard, args.workload, args.steps, args.warmup, True, "%s_%s" % (ROUND, args.workload), 8.0, nq, nq)
+    res = head["_res"]
+    ms_per_step = head["ms_per_step"]
     out = {
         "metric": "queries/sec + postings decoded/sec, BM25 10M-doc synthetic",
         "value": world * nq / (ms_per_step * 1e-3),
-        "unit": "queries/s (one query evaluated against one %dM-doc segment; x n_gpus shards)" % (args.docs // 1_000_000),
+        "unit": "queries/s (one query planned and evaluated against one %dM-doc segment; x n_gpus shards)" % (args.docs // 1_000_000),
         "queries_per_sec": nq / (ms_per_step * 1e-3),
-        "postings_per_sec": world * res["postings"] / (ms_per_step * 1e-3),
+        "postings_decoded_per_sec": world * head["postings_decoded_per_sec"],
+        "postings_covered_per_sec": world * head["postings_covered_per_sec"],
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 decode + f32 BM25",
         "data": "synthetic",
         "config": {
             "workload": WORKLOAD_TEXT[args.workload],
-            "docs_per_shard": args.docs, "vocab": args.vocab, "n_queries": nq, "k": k, "doc_format": ".doc v1 (SIMD-BP128)",
+            "docs_per_shard": args.docs, "vocab": args.vocab, "n_queries": nq, "k": head["k"], "doc_format": ".doc v1 (SIMD-BP128)",
             "parallelism": "segment-sharded x%d, RCCL all-gather of per-shard top-k" % world,
-            "postings_per_step_per_shard": res["postings"], "index_build_s": round(shard.build_s, 2), "device": ctx.device_name,
-            "issue": ("value = two alternating streams (enqueue-only calls; step i+1's search kernel runs over step i's merge tail)" if two_wins
-                      else "value = one stream (enqueue-only calls back to back); the two-stream figure is in `streams`"),
+            "postings_covered_per_step_per_shard": res["postings"], "postings_decoded_per_step_per_shard": head["postings_decoded_per_step"],
+            "index_build_s": round(shard.build_s, 2), "segment_upload_s": round(shard.upload_s, 3), "device": ctx.device_name,
+            "issue": "value = %s, every step plans its batch (native planner behind the C ABI) and enqueues it; inputs (index) resident in HBM" % head["issue"],
         },
-        "streams": {"one_stream_ms_per_step": res["ms_one_stream"], "one_stream_queries_per_sec": world * nq / (res["ms_one_stream"] * 1e-3),
-                    "two_streams_ms_per_step": res["ms_two_streams"],
-                    "one_stream_with_planning_ms_per_step": res["ms_one_stream_with_planning"],
-                    "one_stream_with_planning_queries_per_sec": world * nq / (res["ms_one_stream_with_planning"] * 1e-3),
-                    "two_streams_with_array_planning_ms_per_step": res["ms_two_streams_with_array_planning"],
-                    "two_streams_with_array_planning_queries_per_sec": world * nq / (res["ms_two_streams_with_array_planning"] * 1e-3),
-                    "note": ("planning = term resolution, BM25 weights and sim-table handles redone every step on one host thread: "
-                             "`with_planning` through GpuIndexSearcher.pack (one Python object per query), `with_array_planning` through "
-                             "GpuIndexSearcher.pack_uniform (the batch handed over as an id array; same structs, test_pack.py)")},
-        "roofline": roofline(dom_name, res["kernels_ms"].get(dom_name, 0.0), res["algo_bytes"], PROFILE_TAG[args.workload]),
-        "kernels_ms_isolated": res["kernels_ms"],
+        "streams": head["streams"],
+        "roofline": head["roofline"],
+        "kernels_ms_isolated": head["kernels_ms_isolated"],
     }
     out["roofline"]["note"] = ("kernel_ms = average launch duration over K steps issued on one stream (HIP events; a separate pass, the timed "
-                               "region carries no events). achieved = ALGORITHMIC bytes / kernel_ms: k_search_term skips blocks whose (freq, "
-                               "norm rank) frontier bounds them under the top-k threshold (exact: every posting is still counted and the "
-                               "top-k equals the oracle's), so the bytes it actually moves are `traffic`, well below the algorithmic bytes")
+                               "region carries no events). frac = bytes_per_launch (see bytes_are) / kernel_ms / peak. The north-star's >= 40 % "
+                               "block-decode target is configs.block_decode / configs.cold / configs.out_of_cache")
+    for key in ("cpu_baseline", "gpu_over_cpu", "parity_vs_oracle", "parity"):
+        if key in head:
+            out[key] = head[key]
+    if "parity_vs_oracle" in out:
+        out["parity_vs_oracle_full_batch"] = out["parity_vs_oracle"]
     if args.force_dist and world == 1:
         print("force-dist: merged == local: %s" % res.get("force_dist_same"), file=sys.stderr)
         if not res.get("force_dist_same"):
             raise SystemExit("force-dist check failed")
 
-    # ---- CPU baseline + parity for the headline, rank 0, N = 1 only ---------------------------------------------------------
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        base, parity = cpu_baseline_leg(shard, args.workload, k, res, 8.0, nq)
-        out["cpu_baseline"] = base
-        out["gpu_over_cpu"] = out["queries_per_sec"] / base["value"]
-        out["parity_vs_oracle_full_batch"] = parity
-
-    # ---- north_star's other targets, same run (N = 1 only) -------------------------------------------------------------------
-    want = set() if args.configs == "none" or world != 1 or dist_mode else \
-        ({"and3", "or10", "block_decode", "out_of_cache"} if args.configs == "all" else set(args.configs.split(",")))
+    # ---- north_star's other targets, same run ---------------------------------------------------------------------------------
+    if args.configs == "none":
+        want = set()
+    elif world != 1 or dist_mode:
+        want = {"and3"} if args.configs == "all" else (set(args.configs.split(",")) & {"and3", "or10"})   # BASELINE configs[4]'s workload on every N
+    else:
+        want = {"and3", "or10", "block_decode", "cold", "out_of_cache"} if args.configs == "all" else set(args.configs.split(","))
     configs = {}
     for kind in ("and3", "or10"):
         if kind not in want or kind == args.workload:
             continue
-        kk = k_of[kind]
         steps = max(3, min(args.steps, 10 if kind == "and3" else 4))
-        r = measure(shard, kind, kk, steps, 1, two_streams=False, with_planning=False)
-        dom = DOMINANT[kind]
-        c = {"workload": WORKLOAD_TEXT[kind], "k": kk, "steps": steps, "ms_per_step": r["ms_one_stream"],
-             "queries_per_sec": nq / (r["ms_one_stream"] * 1e-3), "postings_per_sec": r["postings"] / (r["ms_one_stream"] * 1e-3),
-             "kernels_ms_isolated": r["kernels_ms"]}
-        if kind == "and3":
-            # scan bytes = every clause's list read fully (what a scan-intersect kernel moves); touched bytes =
-            # only the blocks the lead-driven kernel decoded (counted by the kernel itself) + 1 B norm per lead posting
-            touched = ctx.and_touched_bytes()
-            lead_postings = int(shard.seg.terms["doc_freq"][r["tids"]].min(axis=1).sum())
-            c["scan_bytes"] = r["algo_bytes"]
-            c["touched_bytes"] = touched + lead_postings + 8 * kk * nq
-            c["roofline"] = roofline(dom, r["kernels_ms"].get(dom, 0.0), c["touched_bytes"], PROFILE_TAG[kind])
-            c["roofline"]["scan_equivalent_frac"] = r["algo_bytes"] / (r["kernels_ms"].get(dom, 1e9) * 1e-3) / 1e9 / HBM_PEAK_GBS
-            c["roofline"]["note"] = "achieved = touched bytes / kernel_ms; scan_equivalent_frac = scan bytes / kernel_ms"
-        else:
-            c["algorithmic_bytes"] = r["algo_bytes"]
-            c["kernels_ms_per_step"] = r["kernels_ms_per_step"]
-            c["launches_per_step"] = r["launches_per_step"]
-            or_kernels = [n for n in ("k_or_wide", "k_score_terms", "k_or_windows") if n in r["kernels_ms_per_step"]]
-            kms = sum(r["kernels_ms_per_step"][n] for n in or_kernels)
-            c["roofline"] = roofline(" + ".join(or_kernels), kms, r["algo_bytes"], PROFILE_TAG[kind])
-            c["roofline"]["note"] = ("achieved = scan bytes (all ten lists + norms) / summed duration of the OR kernels per batch; ten clauses: "
-                                     "k_or_wide (order-free fixed-point accumulation; queries under its precision floor are run again "
-                                     "by k_score_terms + k_or_windows)")
-        if not args.no_cpu_baseline:
-            base, parity = cpu_baseline_leg(shard, kind, kk, r, 4.0, nq if kind == "and3" else 256)
-            c["cpu_baseline"] = base
-            c["gpu_over_cpu"] = c["queries_per_sec"] / base["value"]
-            c["parity_vs_oracle_full_batch"] = parity
+        c = strip(search_config(shard, kind, steps, 1, False, "%s_%s" % (ROUND, kind), 4.0, nq if kind == "and3" else 256, nq))
+        if world > 1:
+            c["value_all_shards_queries_per_sec"] = world * c["queries_per_sec"]
         configs[kind] = c
     if "block_decode" in want:
-        d, b, ms = decode_bench(shard, 1, 5)
-        d["roofline"] = roofline("k_decode_terms", ms, b, PROFILE_TAG["decode"])
-        d["note"] = "10M-doc shard, list decoded once per launch: the .doc (67 MB) and the 162 MB of output fit the 256 MiB Infinity Cache only in part; the launch is 62 us long"
+        d = decode_bench(shard, 5, "%s_decode" % ROUND)
+        d["note"] = "10M-doc shard: the .doc (67 MB) and the 162 MB of output fit the 256 MiB Infinity Cache only in part; the launch is ~50 us long"
         configs["block_decode"] = d
+    if "cold" in want:
+        configs["cold"] = cold_bench(shard, "%s_cold" % ROUND)
     if "out_of_cache" in want:
         # a shard whose .doc alone exceeds the 256 MiB Infinity Cache: here "fraction of HBM roofline" means HBM
+        del shard
         big = Shard(args.big_docs, 0, 0, 1)
-        oc = {"docs": args.big_docs, "doc_file_bytes": int(big.seg.doc_bytes.size), "index_build_s": round(big.build_s, 2)}
-        d, b, ms = decode_bench(big, 1, 3)
-        d["roofline"] = roofline("k_decode_terms", ms, b, "r02_decode_big")
-        oc["block_decode"] = d
-        r = measure(big, "term", 10, 5, 1, two_streams=False, with_planning=False)
-        oc["term"] = {"workload": WORKLOAD_TEXT["term"], "ms_per_step": r["ms_one_stream"], "queries_per_sec": nq / (r["ms_one_stream"] * 1e-3),
-                      "postings_per_sec": r["postings"] / (r["ms_one_stream"] * 1e-3), "kernels_ms_isolated": r["kernels_ms"],
-                      "roofline": roofline("k_search_term", r["kernels_ms"].get("k_search_term", 0.0), r["algo_bytes"], "r02_term_big")}
-        if not args.no_cpu_baseline:
-            base, parity = cpu_baseline_leg(big, "term", 10, r, 3.0, 256)
-            oc["term"]["cpu_baseline"] = base
-            oc["term"]["parity_vs_oracle_full_batch"] = parity
+        oc = {"docs": args.big_docs, "doc_file_bytes": int(big.seg.doc_bytes.size), "index_build_s": round(big.build_s, 2),
+              "segment_upload_s": round(big.upload_s, 3)}
+        oc["cold"] = cold_bench(big, "%s_cold_big" % ROUND)
+        oc["block_decode"] = decode_bench(big, 3, "%s_decode_big" % ROUND)
+        oc["term"] = strip(search_config(big, "term", 5, 1, False, "%s_term_big" % ROUND, 3.0, 256, 256))
+        oc["and3"] = strip(search_config(big, "and3", 3, 1, False, "%s_and3_big" % ROUND, 0.0, 256, 256))
+        oc["or10"] = strip(search_config(big, "or10", 2, 1, False, "%s_or10_big" % ROUND, 0.0, 32, 32))
         configs["out_of_cache"] = oc
     if configs:
         out["configs"] = configs

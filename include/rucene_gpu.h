@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RGPU_ABI_VERSION 2
+#define RGPU_ABI_VERSION 3
 #define RGPU_NO_MORE_DOCS 0x7fffffff /* search/mod.rs:59 */
 #define RGPU_BLOCK_SIZE 128          /* codec/postings/posting_format.rs:36 */
 #define RGPU_MAX_QUERY_TERMS 16
@@ -39,7 +39,7 @@ typedef enum rgpu_status {
   RGPU_ERR_ILLEGAL_ARGUMENT = -2,  /* ErrorKind::IllegalArgument */
   RGPU_ERR_UNEXPECTED_EOF = -3,    /* ErrorKind::UnexpectedEOF */
   RGPU_ERR_CORRUPT_INDEX = -4,     /* ErrorKind::CorruptIndex */
-  RGPU_ERR_UNSUPPORTED = -5,       /* ErrorKind::UnsupportedOperation (EF/BITSET blocks, k > RGPU_MAX_K ...) */
+  RGPU_ERR_UNSUPPORTED = -5,       /* ErrorKind::UnsupportedOperation (FULL-encoded doc blocks, payload / offset fields, k > RGPU_MAX_K ...) */
   RGPU_ERR_IO = -6,                /* ErrorKind::IOError */
   RGPU_ERR_RUNTIME = -7            /* ErrorKind::RuntimeError (HIP failure, no device, out of HBM) */
 } rgpu_status;
@@ -47,8 +47,13 @@ typedef enum rgpu_status {
 typedef struct rgpu_ctx rgpu_ctx;
 typedef struct rgpu_segment rgpu_segment;
 
-/* Knobs (the reference has plain config structs only: SURVEY.md §5). Zero-initialise for defaults. Results never
- * depend on any of them (tests/test_gpu_parity.py::test_work_partitioning_knobs_do_not_change_answers). */
+/* Knobs (the reference has plain config structs only: SURVEY.md §5). Zero-initialise for defaults.
+ * Work-partitioning knobs — blocks_per_item, and_blocks_per_item, or_window_docs, or_dense_clauses, or_wide_window_docs,
+ * profile_kernels: results never depend on them (tests/test_gpu_parity.py::test_work_partitioning_knobs_do_not_change_answers).
+ * Knobs that select another ARITHMETIC and so may change scores (never doc-id sets beyond the documented tolerance, never
+ * hit counts): or_wide (-1: f32 clause-order sums instead of order-free fixed-point sums for >= 10 SHOULD clauses),
+ * req_opt_rule (-1: scores >= the reference's for MUST + SHOULD trees), raw_norms (1: no score tables; also routes
+ * >= 10-clause disjunctions to the clause-order kernel, as or_wide = -1 does). */
 typedef struct rgpu_config {
   int32_t abi_version;          /* must be RGPU_ABI_VERSION */
   int32_t blocks_per_item;      /* 128-posting blocks per wave work item in the TERM kernel (0 = auto: 8..512 by batch size) */
@@ -61,7 +66,7 @@ typedef struct rgpu_config {
                                    per-clause LDS score table and everything built on it; A/B testing) */
   int32_t or_wide;              /* disjunctions of >= 10 SHOULD clauses (where the reference itself sums in heap order) through the
                                    order-free workgroup-window kernel: 0 = yes (default), -1 = no (clause-order kernel for all) */
-  int32_t or_wide_window_docs;  /* docs per workgroup window of that kernel (0 = default 16384; 4096..16384, rounded up to a multiple of 4096) */
+  int32_t or_wide_window_docs;  /* docs per workgroup window of that kernel (0 = default 16384; 4096..20480, rounded up to a multiple of 4096) */
   int32_t req_opt_rule;         /* MUST + SHOULD trees: 0 = the reference's ReqOptScorer, skipping rule included (default: exact
                                    scores, a sequential pass per query); -1 = always add the optional sums (faster, scores >= the
                                    reference's) */
@@ -170,6 +175,18 @@ int32_t rgpu_segment_prepare_terms(rgpu_segment* seg, const rgpu_term_state* ter
  * RGPU_ERR_RUNTIME from the call that needed the space. This drops them all (after waiting for work in flight); terms
  * are prepared again the next time they are used. */
 int32_t rgpu_segment_release_prepared_terms(rgpu_segment* seg);
+/* What a segment holds in HBM right now, by part (bytes in use). */
+typedef struct rgpu_segment_footprint {
+  int64_t doc_file_bytes;        /* the .doc bytes, verbatim */
+  int64_t norms_bytes;           /* 1 byte per doc */
+  int64_t live_docs_bytes;
+  int64_t positions_file_bytes;  /* the .pos bytes (rgpu_segment_attach_positions) */
+  int64_t directory_bytes;       /* prepared terms: 22 bytes per block (+ 8 for a positions field) */
+  int64_t block_store_bytes;     /* prepared terms: 16-byte aligned payload rows + decoded tails */
+  int64_t posting_norms_bytes;   /* prepared terms: 1 byte per posting */
+  int64_t prepared_terms;        /* how many distinct terms are prepared */
+} rgpu_segment_footprint;
+int32_t rgpu_segment_get_footprint(rgpu_segment* seg, rgpu_segment_footprint* out);
 
 /* BlockDocIterator over whole terms (posting_reader.rs:501-647: refill_docs + next, i.e. ForUtil
  * read_block for docs and freqs, VInt tail, singleton) — decodes every posting of every given term into
@@ -238,10 +255,37 @@ int32_t rgpu_comm_init(rgpu_ctx* ctx, int32_t n_ranks, int32_t rank, const uint8
 void rgpu_comm_destroy(rgpu_comm* comm);
 /* rgpu_search_batch_device on this rank's segment -> all-gather -> merge, all enqueued in that order on hip_stream
  * (NULL = the context's stream); enqueue-only, collective (every rank calls it with the same batch shape).
- * hits_dev / total_hits_dev (device memory, n_queries x k and n_queries) receive the merged result on every rank. */
+ * hits_dev / total_hits_dev (device memory, n_queries x k and n_queries) receive the merged result on every rank.
+ * A rank whose LOCAL search fails (corrupt segment, out of HBM while preparing terms, ...) still takes part in the
+ * collective — with empty rows and its status in the record (see rgpu_record_bytes) — and only then returns its error, so
+ * its peers neither hang in the all-gather nor keep a stale record: they get the merge of the shards that answered and can
+ * ask rgpu_comm_status which did not. (A failure to allocate the record buffers themselves happens before the
+ * collective and leaves the communicator out of step: destroy it.) */
 int32_t rgpu_search_batch_sharded(rgpu_comm* comm, rgpu_segment* seg, const rgpu_query* queries, int32_t n_queries,
                                   const rgpu_query_term* terms, int32_t n_terms_total, int32_t k, void* hits_dev,
                                   void* total_hits_dev, void* hip_stream);
+/* status_out[r], r < n_ranks: rank r's rgpu_status for the most recent sharded batch on this communicator (waits for it). */
+int32_t rgpu_comm_status(rgpu_comm* comm, int32_t* status_out);
+/* One process that owns several GPUs (Rucene itself is one process whose search_parallel hands leaves to threads,
+ * search/searcher.rs:527-630): ctxs[r] = rank r's context, each on its own device. The n ncclCommInitRank calls are issued
+ * inside one ncclGroupStart / ncclGroupEnd (one after the other from one thread they would wait for each other forever). */
+int32_t rgpu_comm_init_all(rgpu_ctx* const* ctxs, int32_t n, rgpu_comm** out_comms);
+/* The one-process form of rgpu_search_batch_sharded: rank r searches segs[r] with terms_per_rank[r] (the same queries; term
+ * states differ per shard, weights do not) — every shard's search is enqueued first, then the n all-gathers as ONE NCCL
+ * group, then the n merges. hip_streams may be NULL (each context's own stream). */
+int32_t rgpu_search_batch_sharded_all(rgpu_comm* const* comms, rgpu_segment* const* segs, int32_t n, const rgpu_query* queries,
+                                      int32_t n_queries, const rgpu_query_term* const* terms_per_rank, int32_t n_terms_total, int32_t k,
+                                      void* const* hits_dev, void* const* total_hits_dev, void* const* hip_streams);
+/* The two halves of a sharded batch without the collective between them — what a host with its own transport (or a test
+ * with one GPU) composes: a shard's record = [n_queries x k rgpu_hit][n_queries x int64 hit count][int64 rgpu_status],
+ * rgpu_record_bytes(n_queries, k) bytes; rgpu_search_batch_record_device fills one (enqueue-only; the status word is the
+ * call's own return value, rows are empty when it failed); rgpu_merge_records_device runs finish_parallel
+ * (collector/top_docs.rs:157-172) over n_ranks records laid out back to back — the all-gather's receive buffer. */
+int64_t rgpu_record_bytes(int32_t n_queries, int32_t k);
+int32_t rgpu_search_batch_record_device(rgpu_segment* seg, const rgpu_query* queries, int32_t n_queries, const rgpu_query_term* terms,
+                                        int32_t n_terms_total, int32_t k, void* record_dev, void* hip_stream);
+int32_t rgpu_merge_records_device(rgpu_ctx* ctx, const void* records_dev, int32_t n_ranks, int32_t n_queries, int32_t k,
+                                  void* hits_out_dev, void* totals_out_dev, void* hip_stream);
 
 /* ---- host helpers (no GPU work) ----------------------------------------------------------------------------- */
 /* BM25Similarity::compute_weight (bm25_similarity.rs:151-177) for one TermQuery (n_terms = 1) or a multi-term
@@ -362,6 +406,49 @@ typedef struct rgpu_term_positions {
 int32_t rgpu_terms_lookup_positions(const rgpu_terms* terms, int32_t field_number, const uint8_t* term_bytes, const int64_t* term_offsets,
                                     int32_t n_terms, rgpu_term_state* states_out, rgpu_term_positions* positions_out, uint8_t* found_out);
 
+/* ---- batch planner (host; no GPU work besides one sim-table upload) ------------------------------------------------------------ */
+/* A whole batch of term / boolean queries, handed over as ARRAYS, -> the rgpu_query[] / rgpu_query_term[] of rgpu_search_batch*.
+ * Replaces, per query per leaf, TermQuery::create_weight + IndexSearcher::term_statistics + BM25Similarity::compute_weight
+ * (search/query/term_query.rs:58-95, search/searcher.rs:732-767, search/similarity/bm25_similarity.rs:99-177) and
+ * TermWeight::create_scorer's seek_exact (term_query.rs:145-163): resolve every clause's term in the searched leaf (state)
+ * and in the STATISTICS leaf (doc_freq: the first leaf with the largest max_doc, searcher.rs:306-363), weight = idf * boost
+ * (f64 log -> f32, memoised by doc_freq), one sim table per planner. One planner per (searcher, leaf); thread-safe. */
+typedef struct rgpu_planner rgpu_planner;
+typedef struct rgpu_plan_stats {   /* CollectionStatistics the weights are computed against + the BM25 parameters */
+  int64_t max_doc;                 /* of the whole reader */
+  int64_t doc_count;               /* Terms::doc_count of the statistics leaf (-1: max_doc) */
+  int64_t sum_total_term_freq;     /* of the statistics leaf */
+  float k1, b;
+} rgpu_plan_stats;
+/* terms named by bytes: leaf_terms = the searched leaf's dictionary, stats_terms = the statistics leaf's (NULL: the same) */
+int32_t rgpu_planner_create(rgpu_ctx* ctx, const rgpu_plan_stats* stats, const rgpu_terms* leaf_terms, const rgpu_terms* stats_terms_or_null,
+                            int32_t field_number, rgpu_planner** out);
+/* terms named by ids into flat tables of term states (synthetic indexes, or a host that keeps its own dictionary);
+ * doc_freq 0 = absent. The tables are copied. */
+int32_t rgpu_planner_create_flat(rgpu_ctx* ctx, const rgpu_plan_stats* stats, const rgpu_term_state* leaf_states, int64_t n_leaf,
+                                 const rgpu_term_state* stats_states_or_null, int64_t n_stats, rgpu_planner** out);
+void rgpu_planner_destroy(rgpu_planner* planner);
+int32_t rgpu_planner_sim_table(const rgpu_planner* planner);   /* the handle its clauses carry */
+/* ctx may be NULL in the two create calls: nothing is uploaded and clauses carry sim_table -1 until the host names the table
+ * it uploaded itself (rgpu_sim_table_upload of BM25SimWeight::cache for this field's statistics). */
+int32_t rgpu_planner_set_sim_table(rgpu_planner* planner, int32_t sim_table);
+/* Every query the same shape: `op` = RGPU_OP_TERM (n_clauses 1), RGPU_OP_AND (all MUST) or RGPU_OP_OR / RGPU_OP_OR_MSM(m)
+ * (all SHOULD), boost 1; term q * n_clauses + c = clause c of query q. A one-clause AND / OR is rewritten to that clause
+ * (BooleanQuery::build, query/boolean_query.rs:66-75). Outputs: n_queries queries, n_queries * n_clauses terms. */
+int32_t rgpu_plan_uniform_ids(rgpu_planner* planner, int32_t op, int32_t n_queries, int32_t n_clauses, const int64_t* term_ids,
+                              rgpu_query* queries_out, rgpu_query_term* terms_out);
+int32_t rgpu_plan_uniform_bytes(rgpu_planner* planner, int32_t op, int32_t n_queries, int32_t n_clauses, const uint8_t* term_bytes,
+                                const int64_t* term_offsets, rgpu_query* queries_out, rgpu_query_term* terms_out);
+/* Any mix: ops[q] as rgpu_query.op (incl. RGPU_OP_OR_MSM / RGPU_OP_WITH_SHOULD), n_terms[q] / n_must_not[q] as in rgpu_query;
+ * a query's terms follow each other in the order scored, optional SHOULD, MUST_NOT; boosts (NULL: all 1) one per term.
+ * terms_cap = room in terms_out. */
+int32_t rgpu_plan_batch_ids(rgpu_planner* planner, int32_t n_queries, const int32_t* ops, const int32_t* n_terms, const int32_t* n_must_not_or_null,
+                            const int64_t* term_ids, const float* boosts_or_null, rgpu_query* queries_out, rgpu_query_term* terms_out,
+                            int64_t terms_cap);
+int32_t rgpu_plan_batch_bytes(rgpu_planner* planner, int32_t n_queries, const int32_t* ops, const int32_t* n_terms, const int32_t* n_must_not_or_null,
+                              const uint8_t* term_bytes, const int64_t* term_offsets, const float* boosts_or_null, rgpu_query* queries_out,
+                              rgpu_query_term* terms_out, int64_t terms_cap);
+
 /* ---- exact phrases (positions fields) ----------------------------------------------------------------------------- */
 /* The ".pos" file of a segment uploaded with index_options = 3 (Lucene50PostingsReader::open, posting_reader.rs:112-158:
  * header "Lucene50PostingsWriterPos", the .doc file's version, segment id and suffix; footer). Needed before
@@ -429,6 +516,19 @@ int32_t rgpu_set_profiling(rgpu_ctx* ctx, int32_t on);
  * doc and freq payload) of every FullBlock the conjunction kernel decoded — lead blocks and the blocks of the other
  * clauses that held a pending candidate. Waits for that launch. */
 int32_t rgpu_and_touched_bytes(rgpu_ctx* ctx, int64_t* bytes_out);
+/* What the most recent TERM / AND / (>= 10-clause) OR launch on this context really did — as opposed to what its queries
+ * cover: the TERM kernel skips every block whose (freq, norm) frontier cannot reach the top-k, the conjunction kernel
+ * only visits blocks that may hold a candidate. Waits for that launch. */
+typedef struct rgpu_search_counters {
+  int32_t op;                /* rgpu_query_op of the launch (-1: none yet) */
+  int32_t reserved;
+  int64_t postings_covered;  /* sum of doc_freq over the launch's clauses: what an exhaustive scorer would iterate */
+  int64_t postings_decoded;  /* 128 per FullBlock actually unpacked + prepared tails / singletons read */
+  int64_t blocks_decoded;
+  int64_t touched_bytes;     /* encoded bytes of those blocks; TERM: + 1 norm byte per posting of them + 14 directory bytes
+                                (row, header, frontier words) per block looked at. 0 for OR launches (everything is read) */
+} rgpu_search_counters;
+int32_t rgpu_last_search_counters(rgpu_ctx* ctx, rgpu_search_counters* out);
 void rgpu_kernel_stats_reset(rgpu_ctx* ctx);
 int32_t rgpu_synchronize(rgpu_ctx* ctx);
 

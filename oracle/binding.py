@@ -126,6 +126,7 @@ def _declare(L):
         "orc_live_docs_write": (C.c_int, [i64p, C.c_int32, C.c_int32, C.c_int32, u8p, C.c_int64, u8p, i64p]),
         "orc_live_docs_read": (C.c_int, [u8p, C.c_int64, C.c_int32, C.c_int32, i64p]),
         "orc_mock_req_opt": (C.c_int, [i32p, i32p, C.c_int, i32p, i32p, C.c_int, i32p, f32p, C.c_int]),
+        "orc_searcher_score_docs": (C.c_int, [vp, C.c_int, i64p, C.c_int, C.c_int, i32p, C.c_int64, f32p, u8p]),
         "orc_search_opt": (C.c_int, [vp, C.c_int, i64p, C.c_int, i64p, C.c_int, i64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, i32p,
                                      f32p, i32p, i64p]),
         "orc_pos_index_build": (vp, [C.c_int32, C.c_int32, C.c_int32, i64p, i32p, i32p, i64p, i32p]),
@@ -366,6 +367,24 @@ class Searcher:
         _check(lib().orc_searcher_rescore(self._h, op, _p(t, C.c_int64), t.size, _p(d, C.c_int32), _p(sc, C.c_float), d.size, int(window_size),
                                           float(query_weight), float(rescore_weight), int(mode)))
         return d, sc
+
+    def score_docs(self, op, term_ids, docs, min_should_match=0):
+        """The oracle's own score of the given docs (global ids, any order) under a TERM / AND / OR term query: per leaf the
+        query's scorer advanced from doc to doc (IndexSearcher::score_docs). Returns (scores, matched) in the order given."""
+        t = np.ascontiguousarray(term_ids, dtype=np.int64)
+        d = np.ascontiguousarray(docs, dtype=np.int32)
+        order = np.argsort(d, kind="stable")
+        ds = np.ascontiguousarray(d[order])
+        sc = np.zeros(ds.size, dtype=np.float32)
+        mt = np.zeros(ds.size, dtype=np.uint8)
+        if ds.size:
+            _check(lib().orc_searcher_score_docs(self._h, op, _p(t, C.c_int64), t.size, int(min_should_match), _p(ds, C.c_int32), ds.size,
+                                                 _p(sc, C.c_float), _p(mt, C.c_uint8)))
+        scores = np.zeros(ds.size, dtype=np.float32)
+        matched = np.zeros(ds.size, dtype=bool)
+        scores[order] = sc
+        matched[order] = mt != 0
+        return scores, matched
 
     def override_statistics(self, stats_segment, total_max_doc):
         """Score with another leaf's statistics (the index-wide largest leaf living on another shard)."""

@@ -911,6 +911,16 @@ int orc_searcher_rescore(orc_searcher* h, int op, const int64_t* term_ids, int n
   ORC_CATCH
 }
 
+// IndexSearcher::score_docs: the oracle's own score of given docs (global ids, strictly ascending) under a TERM / AND / OR
+// term query — the checker for paths whose scores the reference pins only up to summation order (>= 10 SHOULD clauses).
+int orc_searcher_score_docs(orc_searcher* h, int op, const int64_t* term_ids, int n_terms, int msm, const int32_t* docs, int64_t n_docs,
+                            float* scores_out, uint8_t* matched_out) {
+  ORC_TRY
+  h->s.score_docs(make_query(op, term_ids, n_terms, nullptr, msm), docs, (size_t)n_docs, scores_out, matched_out);
+  return 0;
+  ORC_CATCH
+}
+
 // ---- exact PhraseQuery (oracle/phrase.hpp) ---------------------------------------------------------------------------
 // PhraseWeight::create_scorer for term_ids at phrase positions `offsets` (PhraseQuery::build: 0, 1, 2, ...): null when a
 // term is absent. The scorer owns its iterators; `w` must outlive it.

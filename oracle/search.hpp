@@ -798,6 +798,37 @@ struct IndexSearcher {
     return r;
   }
 
+  // The query's own score of GIVEN docs (global ids, ascending): per leaf one scorer, advanced from doc to doc — the walk of
+  // QueryRescorer::iterative_rescore (rescorer.rs:231-277) without the combining step. What a parity check needs where the
+  // reference pins a score only up to summation order (DisjunctionSumScorer over a DisiPriorityQueue,
+  // disjunction_scorer.rs:41-45): "is this doc a match, and what does the reference score it" for docs another
+  // implementation returned. matched[i] = 0 (score 0) for a doc the query does not match or a deleted one.
+  void score_docs(const Query& q, const int32_t* docs, size_t n_docs, float* scores_out, uint8_t* matched_out) const {
+    std::vector<BM25Weight> weights;
+    for (size_t i = 0; i < q.term_ids.size(); i++) weights.push_back(term_weight(q.term_ids[i], q.boosts.empty() ? 1.0f : q.boosts[i]));
+    for (size_t i = 0; i < q.must_not_ids.size(); i++) weights.push_back(term_weight(q.must_not_ids[i], 1.0f));
+    for (size_t i = 0; i < q.opt_ids.size(); i++) weights.push_back(term_weight(q.opt_ids[i], 1.0f));
+    size_t at = 0;
+    for (auto* seg : leaves) {
+      const int32_t end_doc = seg->doc_base + seg->max_doc;
+      if (at >= n_docs) break;
+      if (docs[at] >= end_doc) continue;
+      ScorerBox scorer = create_scorer(seg, q, weights);
+      for (; at < n_docs && docs[at] < end_doc; ++at) {
+        if (at > 0 && docs[at] <= docs[at - 1]) throw OracleError(E_ILLEGAL_ARGUMENT, "score_docs: docs must be strictly ascending");
+        scores_out[at] = 0.0f;
+        matched_out[at] = 0;
+        if (!scorer || docs[at] < seg->doc_base) continue;
+        const int32_t target = docs[at] - seg->doc_base;
+        if (seg->live_docs && !((seg->live_docs[target >> 6] >> (target & 63)) & 1)) continue;
+        int32_t actual = scorer->doc_id();
+        if (actual < target) actual = scorer->advance(target);
+        if (actual == target) { scores_out[at] = scorer->score(); matched_out[at] = 1; }
+      }
+    }
+    for (; at < n_docs; ++at) { scores_out[at] = 0.0f; matched_out[at] = 0; }
+  }
+
   // ---- QueryRescorer (search/scorer/rescorer.rs:129-374) ---------------------------------------------------------------
   // RescoreMode::combine (:97-116): 0 Avg, 1 Max, 2 Min, 3 Total, 4 Multiply
   static float rescore_mode_combine(int mode, float primary, float secondary) {

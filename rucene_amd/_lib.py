@@ -8,7 +8,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_NAME = "librucene_gpu.so"
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 OP_TERM, OP_AND, OP_OR = 0, 1, 2
 MAX_K = 128
 MAX_QUERY_TERMS = 16
@@ -46,14 +46,17 @@ STATUS_NAMES = {0: "OK", -1: "IllegalState", -2: "IllegalArgument", -3: "Unexpec
 # every symbol include/rucene_gpu.h declares (tests/test_abi.py checks the header and this list agree)
 EXPORTS = [
     "rgpu_init", "rgpu_shutdown", "rgpu_last_error", "rgpu_abi_version", "rgpu_device_name", "rgpu_segment_upload",
-    "rgpu_segment_upload_field", "rgpu_segment_release_prepared_terms", "rgpu_segment_attach_positions", "rgpu_search_phrase_batch", "rgpu_rescore_batch",
+    "rgpu_segment_upload_field", "rgpu_segment_release_prepared_terms", "rgpu_segment_get_footprint", "rgpu_segment_attach_positions", "rgpu_search_phrase_batch", "rgpu_rescore_batch",
     "rgpu_segment_free", "rgpu_segment_version", "rgpu_segment_prepare_terms", "rgpu_decode_terms",
     "rgpu_decode_terms_device", "rgpu_advance_batch", "rgpu_sim_table_upload", "rgpu_search_batch",
     "rgpu_search_batch_device", "rgpu_merge_topk_device", "rgpu_bm25_compute_weight", "rgpu_bm25_encode_norm", "rgpu_bm25_term_weights",
     "rgpu_norms_from_lucene53", "rgpu_live_docs_from_lucene50", "rgpu_field_infos_from_lucene60", "rgpu_segment_info_from_lucene62", "rgpu_commit_from_segments_file", "rgpu_compound_entries_from_lucene50", "rgpu_terms_open", "rgpu_terms_close", "rgpu_terms_field_stats",
     "rgpu_terms_lookup", "rgpu_terms_lookup_positions", "rgpu_kernel_stats", "rgpu_kernel_stats_reset", "rgpu_synchronize",
     "rgpu_set_profiling", "rgpu_and_touched_bytes", "rgpu_comm_unique_id", "rgpu_comm_init", "rgpu_comm_destroy",
-    "rgpu_search_batch_sharded",
+    "rgpu_search_batch_sharded", "rgpu_comm_status", "rgpu_comm_init_all", "rgpu_search_batch_sharded_all", "rgpu_record_bytes",
+    "rgpu_search_batch_record_device", "rgpu_merge_records_device", "rgpu_last_search_counters",
+    "rgpu_planner_create", "rgpu_planner_create_flat", "rgpu_planner_destroy", "rgpu_planner_sim_table", "rgpu_planner_set_sim_table", "rgpu_plan_uniform_ids",
+    "rgpu_plan_uniform_bytes", "rgpu_plan_batch_ids", "rgpu_plan_batch_bytes",
 ]
 
 
@@ -68,6 +71,14 @@ class _Config(C.Structure):
                 ("profile_kernels", C.c_int32), ("or_window_docs", C.c_int32), ("or_dense_clauses", C.c_int32),
                 ("raw_norms", C.c_int32), ("or_wide", C.c_int32), ("or_wide_window_docs", C.c_int32),
                 ("req_opt_rule", C.c_int32), ("reserved", C.c_int32 * 6)]
+
+
+SEARCH_COUNTERS_DTYPE = np.dtype([("op", "<i4"), ("reserved", "<i4"), ("postings_covered", "<i8"), ("postings_decoded", "<i8"),
+                                  ("blocks_decoded", "<i8"), ("touched_bytes", "<i8")], align=True)
+FOOTPRINT_DTYPE = np.dtype([(n, "<i8") for n in ("doc_file_bytes", "norms_bytes", "live_docs_bytes", "positions_file_bytes", "directory_bytes",
+                                                 "block_store_bytes", "posting_norms_bytes", "prepared_terms")], align=True)
+PLAN_STATS_DTYPE = np.dtype([("max_doc", "<i8"), ("doc_count", "<i8"), ("sum_total_term_freq", "<i8"), ("k1", "<f4"), ("b", "<f4")], align=True)
+assert SEARCH_COUNTERS_DTYPE.itemsize == 40 and PLAN_STATS_DTYPE.itemsize == 32
 
 
 class _KernelStat(C.Structure):
@@ -122,6 +133,7 @@ def lib():
         "rgpu_segment_version": (i32, [vp]),
         "rgpu_segment_prepare_terms": (i32, [vp, vp, i64]),
         "rgpu_segment_release_prepared_terms": (i32, [vp]),
+        "rgpu_segment_get_footprint": (i32, [vp, vp]),
         "rgpu_segment_attach_positions": (i32, [vp, vp, C.c_size_t]),
         "rgpu_search_phrase_batch": (i32, [vp, vp, i32, vp, i32, i32, vp, vp]),
         "rgpu_rescore_batch": (i32, [vp, vp, i32, vp, i32, vp, i32, vp, i32]),
@@ -155,6 +167,22 @@ def lib():
         "rgpu_comm_init": (i32, [vp, i32, i32, vp, C.POINTER(vp)]),
         "rgpu_comm_destroy": (None, [vp]),
         "rgpu_search_batch_sharded": (i32, [vp, vp, vp, i32, vp, i32, i32, vp, vp, vp]),
+        "rgpu_comm_status": (i32, [vp, vp]),
+        "rgpu_comm_init_all": (i32, [vp, i32, vp]),
+        "rgpu_search_batch_sharded_all": (i32, [vp, vp, i32, vp, i32, vp, i32, i32, vp, vp, vp]),
+        "rgpu_record_bytes": (i64, [i32, i32]),
+        "rgpu_search_batch_record_device": (i32, [vp, vp, i32, vp, i32, i32, vp, vp]),
+        "rgpu_merge_records_device": (i32, [vp, vp, i32, i32, i32, vp, vp, vp]),
+        "rgpu_last_search_counters": (i32, [vp, vp]),
+        "rgpu_planner_create": (i32, [vp, vp, vp, vp, i32, C.POINTER(vp)]),
+        "rgpu_planner_create_flat": (i32, [vp, vp, vp, i64, vp, i64, C.POINTER(vp)]),
+        "rgpu_planner_destroy": (None, [vp]),
+        "rgpu_planner_sim_table": (i32, [vp]),
+        "rgpu_planner_set_sim_table": (i32, [vp, i32]),
+        "rgpu_plan_uniform_ids": (i32, [vp, i32, i32, i32, vp, vp, vp]),
+        "rgpu_plan_uniform_bytes": (i32, [vp, i32, i32, i32, vp, vp, vp, vp]),
+        "rgpu_plan_batch_ids": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, vp, i64]),
+        "rgpu_plan_batch_bytes": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i64]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -366,6 +394,16 @@ class Context:
         _check(lib().rgpu_and_touched_bytes(self._h, C.byref(out)))
         return int(out.value)
 
+    def last_search_counters(self):
+        """rgpu_last_search_counters: what the most recent TERM / AND / wide-OR launch really decoded (waits for it)."""
+        out = np.zeros(1, dtype=SEARCH_COUNTERS_DTYPE)
+        _check(lib().rgpu_last_search_counters(self._h, out.ctypes.data))
+        return {k: int(out[0][k]) for k in SEARCH_COUNTERS_DTYPE.names if k != "reserved"}
+
+    def merge_records_device(self, records_ptr, n_ranks, n_queries, k, out_hits_ptr, out_totals_ptr, stream=0):
+        """finish_parallel over n_ranks shard records laid out back to back (an all-gather's receive buffer)."""
+        _check(lib().rgpu_merge_records_device(self._h, records_ptr, n_ranks, n_queries, k, out_hits_ptr, out_totals_ptr, stream or None))
+
     def kernel_stats(self):
         arr = (_KernelStat * 32)()
         n = _check(lib().rgpu_kernel_stats(self._h, arr, 32))
@@ -387,6 +425,103 @@ class Context:
                     seg.close()
             self._segments = []
             lib().rgpu_shutdown(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def record_bytes(n_queries, k):
+    """Bytes of one shard's record: [n_queries x k hits][n_queries counts][status]."""
+    return int(lib().rgpu_record_bytes(n_queries, k))
+
+
+class Planner:
+    """rgpu_planner: a batch handed over as arrays -> (QUERY_DTYPE[n_queries], QUERY_TERM_DTYPE[sum of clauses]), natively.
+    `leaf_terms` / `stats_terms`: TermDictionary handles (terms named by bytes) or TERM_STATE_DTYPE tables (named by id);
+    stats_terms None = the searched leaf is the statistics leaf."""
+
+    def __init__(self, ctx, max_doc, doc_count, sum_total_term_freq, leaf_terms, stats_terms=None, k1=1.2, b=0.75, field_number=0,
+                 sim_table=None):
+        """ctx None + sim_table: the caller uploaded the field's norm cache itself (nothing here touches a GPU)."""
+        ps = np.zeros(1, dtype=PLAN_STATS_DTYPE)
+        ch = None if ctx is None else ctx._h
+        ps[0]["max_doc"], ps[0]["doc_count"], ps[0]["sum_total_term_freq"], ps[0]["k1"], ps[0]["b"] = max_doc, doc_count, sum_total_term_freq, k1, b
+        h = C.c_void_p()
+        self.flat = not isinstance(leaf_terms, TermDictionary)
+        if self.flat:
+            lt = np.ascontiguousarray(leaf_terms, dtype=TERM_STATE_DTYPE)
+            stt = None if stats_terms is None else np.ascontiguousarray(stats_terms, dtype=TERM_STATE_DTYPE)
+            _check(lib().rgpu_planner_create_flat(ch, ps.ctypes.data, lt.ctypes.data if lt.size else None, lt.size,
+                                                  None if stt is None or not stt.size else stt.ctypes.data, 0 if stt is None else stt.size, C.byref(h)))
+        else:
+            self._keep = (leaf_terms, stats_terms)
+            _check(lib().rgpu_planner_create(ch, ps.ctypes.data, leaf_terms._h, None if stats_terms is None else stats_terms._h,
+                                             int(field_number), C.byref(h)))
+        self._h = h
+        self.ctx = ctx
+        if sim_table is not None:
+            _check(lib().rgpu_planner_set_sim_table(self._h, int(sim_table)))
+
+    @property
+    def sim_table(self):
+        return int(lib().rgpu_planner_sim_table(self._h))
+
+    @staticmethod
+    def _bytes(terms):
+        terms = [bytes(t) for t in terms]
+        offs = np.zeros(len(terms) + 1, dtype=np.int64)
+        np.cumsum([len(t) for t in terms], out=offs[1:])
+        return np.frombuffer(b"".join(terms) or b"\0", dtype=np.uint8), offs
+
+    def plan_uniform(self, op, terms, n_queries=None, n_clauses=None):
+        """`terms`: [n_queries, n_clauses] ids, or (flat bytes planner) a list of n_queries * n_clauses byte strings with
+        n_queries / n_clauses given."""
+        if self.flat:
+            ids = np.ascontiguousarray(terms, dtype=np.int64)
+            if ids.ndim == 1:
+                ids = ids.reshape(-1, 1)
+            nq, nc = ids.shape
+            qs = np.empty(nq, dtype=QUERY_DTYPE)
+            ts = np.empty(nq * nc, dtype=QUERY_TERM_DTYPE)
+            _check(lib().rgpu_plan_uniform_ids(self._h, int(op), nq, nc, ids.ctypes.data, qs.ctypes.data, ts.ctypes.data))
+            return qs, ts
+        flat, offs = self._bytes(terms)
+        nq, nc = int(n_queries), int(n_clauses)
+        if nq * nc != offs.size - 1:
+            raise ValueError("n_queries * n_clauses terms expected")
+        qs = np.empty(nq, dtype=QUERY_DTYPE)
+        ts = np.empty(nq * nc, dtype=QUERY_TERM_DTYPE)
+        _check(lib().rgpu_plan_uniform_bytes(self._h, int(op), nq, nc, flat.ctypes.data, offs.ctypes.data, qs.ctypes.data, ts.ctypes.data))
+        return qs, ts
+
+    def plan_batch(self, ops, n_terms, terms, n_must_not=None, boosts=None):
+        """Any mix of trees: ops[q] as rgpu_query.op, n_terms[q] / n_must_not[q], `terms` in clause order (ids or byte strings)."""
+        ops = np.ascontiguousarray(ops, dtype=np.int32)
+        nt = np.ascontiguousarray(n_terms, dtype=np.int32)
+        nn = None if n_must_not is None else np.ascontiguousarray(n_must_not, dtype=np.int32)
+        bo = None if boosts is None else np.ascontiguousarray(boosts, dtype=np.float32)
+        qs = np.empty(ops.size, dtype=QUERY_DTYPE)
+        if self.flat:
+            ids = np.ascontiguousarray(terms, dtype=np.int64).ravel()
+            ts = np.empty(max(ids.size, 1), dtype=QUERY_TERM_DTYPE)
+            _check(lib().rgpu_plan_batch_ids(self._h, ops.size, ops.ctypes.data, nt.ctypes.data, None if nn is None else nn.ctypes.data,
+                                             ids.ctypes.data, None if bo is None else bo.ctypes.data, qs.ctypes.data, ts.ctypes.data, ids.size))
+            return qs, ts[:ids.size] if ids.size else ts
+        flat, offs = self._bytes(terms)
+        n = offs.size - 1
+        ts = np.empty(max(n, 1), dtype=QUERY_TERM_DTYPE)
+        _check(lib().rgpu_plan_batch_bytes(self._h, ops.size, ops.ctypes.data, nt.ctypes.data, None if nn is None else nn.ctypes.data,
+                                           flat.ctypes.data, offs.ctypes.data, None if bo is None else bo.ctypes.data, qs.ctypes.data,
+                                           ts.ctypes.data, n))
+        return qs, ts[:n] if n else ts
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().rgpu_planner_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -421,6 +556,12 @@ class Comm:
         t = np.ascontiguousarray(terms, dtype=QUERY_TERM_DTYPE)
         _check(lib().rgpu_search_batch_sharded(self._h, segment._h, q.ctypes.data, q.size, t.ctypes.data, t.size, k, hits_ptr, totals_ptr,
                                                stream or None))
+
+    def status(self):
+        """Every rank's rgpu_status for the most recent sharded batch (waits for it)."""
+        out = np.zeros(self.n_ranks, dtype=np.int32)
+        _check(lib().rgpu_comm_status(self._h, out.ctypes.data))
+        return out
 
     def close(self):
         if getattr(self, "_h", None):
@@ -483,6 +624,12 @@ class Segment:
     def release_prepared_terms(self):
         _check(lib().rgpu_segment_release_prepared_terms(self._h))
 
+    def footprint(self):
+        """rgpu_segment_footprint: HBM bytes held for this segment, by part."""
+        out = np.zeros(1, dtype=FOOTPRINT_DTYPE)
+        _check(lib().rgpu_segment_get_footprint(self._h, out.ctypes.data))
+        return {k: int(out[0][k]) for k in FOOTPRINT_DTYPE.names}
+
     def decode_terms(self, states):
         st = np.ascontiguousarray(np.atleast_1d(states), dtype=TERM_STATE_DTYPE)
         total = int(st["doc_freq"].sum())
@@ -510,6 +657,12 @@ class Segment:
         totals = np.zeros(q.size, dtype=np.int64)
         _check(lib().rgpu_search_batch(self._h, q.ctypes.data, q.size, t.ctypes.data, t.size, k, hits.ctypes.data, totals.ctypes.data))
         return hits, totals
+
+    def search_batch_record_device(self, queries, terms, k, record_ptr, stream=0):
+        """This shard's record ([hits][counts][status], record_bytes(n_queries, k) bytes of device memory); enqueue-only."""
+        q = np.ascontiguousarray(queries, dtype=QUERY_DTYPE)
+        t = np.ascontiguousarray(terms, dtype=QUERY_TERM_DTYPE)
+        _check(lib().rgpu_search_batch_record_device(self._h, q.ctypes.data, q.size, t.ctypes.data, t.size, k, record_ptr, stream or None))
 
     def search_batch_device(self, queries, terms, k, hits_ptr, totals_ptr, stream=0):
         q = np.ascontiguousarray(queries, dtype=QUERY_DTYPE)

@@ -323,6 +323,7 @@ class GpuIndexSearcher {
     stats_.sum_doc_freq = s.sum_doc_freq;
   }
   ~GpuIndexSearcher() {
+    for (rgpu_planner* p : planners_) rgpu_planner_destroy(p);
     for (auto& l : leaves_) rgpu_segment_free(l.segment);
     rgpu_shutdown(ctx_);
   }
@@ -360,7 +361,7 @@ class GpuIndexSearcher {
     for (size_t li = 0; li < leaves_.size(); ++li) {
       std::vector<rgpu_query> qs;
       std::vector<rgpu_query_term> ts;
-      for (const Query* q : queries) pack(*q, leaves_[li], &qs, &ts);
+      plan(queries, li, &qs, &ts);
       leaf_hits[li].assign(static_cast<size_t>(nq) * k, rgpu_hit{-1, 0.f});
       leaf_totals[li].assign(static_cast<size_t>(nq), 0);
       check(rgpu_search_batch(leaves_[li].segment, qs.data(), nq, ts.data(), static_cast<int32_t>(ts.size()), static_cast<int32_t>(k),
@@ -465,6 +466,70 @@ class GpuIndexSearcher {
     if (sim_table_ < 0) check(sim_table_ = rgpu_sim_table_upload(ctx_, w.cache.data(), w.k1));  // one field -> one cache
     return {w.weight, sim_table_};
   }
+  // The whole batch at once: the query objects are flattened to op / clause-count / term arrays and handed to the native
+  // batch planner (rgpu_plan_batch_*: term resolution in this leaf and in the statistics leaf, BM25 weights, the sim table)
+  // — one call per leaf instead of one dictionary lookup and one f64 log per clause. A batch that mixes id-named and
+  // byte-named terms (or names terms the leaf cannot resolve that way) goes clause by clause through pack().
+  void plan(const std::vector<const Query*>& queries, size_t li, std::vector<rgpu_query>* qs, std::vector<rgpu_query_term>* ts) {
+    const LeafReader& leaf = leaves_[li];
+    std::vector<int32_t> ops, n_terms, n_not;
+    std::vector<int64_t> ids, offs{0};
+    std::vector<uint8_t> bytes;
+    std::vector<float> boosts;
+    bool any_id = false, any_text = false, any_boost = false;
+    auto clause = [&](const TermQuery& c) {
+      if (c.by_text()) { any_text = true; bytes.insert(bytes.end(), c.text.begin(), c.text.end()); }
+      else { any_id = true; }
+      ids.push_back(c.term);
+      offs.push_back(static_cast<int64_t>(bytes.size()));
+      boosts.push_back(c.boost);
+      any_boost = any_boost || c.boost != 1.0f;
+    };
+    for (const Query* q : queries) {
+      if (auto* t = dynamic_cast<const TermQuery*>(q)) {
+        ops.push_back(RGPU_OP_TERM); n_terms.push_back(1); n_not.push_back(0);
+        clause(*t);
+      } else if (auto* b = dynamic_cast<const BooleanQuery*>(q)) {
+        const bool conj = !b->must_queries.empty();
+        ops.push_back(conj ? RGPU_OP_WITH_SHOULD(RGPU_OP_AND, b->should_queries.size())
+                           : (b->min_should_match > 1 ? RGPU_OP_OR_MSM(b->min_should_match) : (int32_t)RGPU_OP_OR));
+        n_terms.push_back(static_cast<int32_t>(conj ? b->must_queries.size() : b->should_queries.size()));
+        n_not.push_back(static_cast<int32_t>(b->must_not_queries.size()));
+        for (const TermQuery& c : (conj ? b->must_queries : b->should_queries)) clause(c);
+        if (conj) for (const TermQuery& c : b->should_queries) clause(c);
+        for (const TermQuery& c : b->must_not_queries) clause(c);
+      } else {
+        throw Error(RGPU_ERR_UNSUPPORTED, "query type not served by the GPU path");
+      }
+    }
+    const LeafReader& sl = leaves_[stats_leaf_];
+    const bool native = (any_id != any_text) && (any_text ? (leaf.dictionary && sl.dictionary) : (leaf.terms && sl.terms));
+    if (!native) {
+      for (const Query* q : queries) pack(*q, leaf, qs, ts);
+      return;
+    }
+    if (planners_.size() < leaves_.size()) planners_.resize(leaves_.size(), nullptr);
+    if (!planners_[li]) {
+      rgpu_plan_stats ps{stats_.max_doc, stats_.doc_count, stats_.sum_total_term_freq, sim_.k1(), sim_.b()};
+      if (sim_table_ < 0) {  // one field -> one norm cache, shared with the clause-by-clause path
+        const TermStatistics none;
+        check(sim_table_ = rgpu_sim_table_upload(ctx_, sim_.compute_weight(stats_, &none, 1, 1.0f).cache.data(), sim_.k1()));
+      }
+      if (any_text) check(rgpu_planner_create(nullptr, &ps, leaf.dictionary, &sl == &leaf ? nullptr : sl.dictionary, leaf.field_number, &planners_[li]));
+      else check(rgpu_planner_create_flat(nullptr, &ps, leaf.terms, leaf.n_terms, &sl == &leaf ? nullptr : sl.terms, &sl == &leaf ? 0 : sl.n_terms, &planners_[li]));
+      check(rgpu_planner_set_sim_table(planners_[li], sim_table_));
+    }
+    qs->resize(queries.size());
+    ts->resize(std::max<size_t>(1, ids.size()));
+    const int64_t cap = static_cast<int64_t>(ids.size());
+    if (any_text)
+      check(rgpu_plan_batch_bytes(planners_[li], static_cast<int32_t>(queries.size()), ops.data(), n_terms.data(), n_not.data(), bytes.data(), offs.data(),
+                                  any_boost ? boosts.data() : nullptr, qs->data(), ts->data(), cap));
+    else
+      check(rgpu_plan_batch_ids(planners_[li], static_cast<int32_t>(queries.size()), ops.data(), n_terms.data(), n_not.data(), ids.data(),
+                                any_boost ? boosts.data() : nullptr, qs->data(), ts->data(), cap));
+    ts->resize(ids.size());
+  }
   void pack(const Query& q, const LeafReader& leaf, std::vector<rgpu_query>* qs, std::vector<rgpu_query_term>* ts) {
     const std::vector<TermQuery>* clauses = nullptr;
     const std::vector<TermQuery>* opts = nullptr;  // SHOULD clauses beside MUST ones
@@ -505,6 +570,7 @@ class GpuIndexSearcher {
   size_t stats_leaf_ = 0;
   CollectionStatistics stats_;
   int32_t sim_table_ = -1;
+  std::vector<rgpu_planner*> planners_;  // per leaf, created on first use
 };
 
 }  // namespace rucene

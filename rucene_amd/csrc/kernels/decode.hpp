@@ -31,6 +31,11 @@ __device__ __host__ __forceinline__ int hdr_bdoc(uint32_t h) { return (int)(h & 
 __device__ __host__ __forceinline__ int hdr_vlen(uint32_t h) { return (int)((h >> 6) & 7); }
 __device__ __host__ __forceinline__ int hdr_bfreq(uint32_t h) { return (int)((h >> 9) & 63); }
 
+// bytes of a FullBlock as the .doc file frames it: two header bytes + each stream's payload (16 * b, or its VInt)
+__device__ __host__ __forceinline__ uint32_t encoded_block_bytes(uint32_t hdr) {
+  return 2u + (hdr_bdoc(hdr) ? 16u * (uint32_t)hdr_bdoc(hdr) : (uint32_t)hdr_vlen(hdr)) + (hdr_bfreq(hdr) ? 16u * (uint32_t)hdr_bfreq(hdr) : 1u);
+}
+
 struct __attribute__((packed, aligned(1))) UnalignedU4 { uint32_t x, y, z, w; };
 struct __attribute__((packed, aligned(1))) UnalignedU32 { uint32_t v; };
 

@@ -118,9 +118,19 @@ __global__ __launch_bounds__(WG_THREADS) void k_merge_items(const int64_t* __res
     // once; a hit whose total is below the query's floor asks for the f32 path (low_flags)
     const int2 info = fixed_info[q];
     auto score_of = [&](uint64_t key) { return (float)ldexp((double)(uint32_t)(key >> 32), -info.x); };
-    if (lane < k) out[lane] = top.a ? HitOut{key_doc(top.a) + doc_base, score_of(top.a)} : HitOut{-1, 0.f};
-    if (WIDE && lane + 64 < k) out[lane + 64] = top.b ? HitOut{key_doc(top.b) + doc_base, score_of(top.b)} : HitOut{-1, 0.f};
-    const bool low = (lane < k && top.a != 0 && (uint32_t)(top.a >> 32) < (uint32_t)info.y) ||
+    // Totals reach 2^31 and f32 keeps 24 bits: distinct totals may round to ONE f32 score, and the row must still come out
+    // in the canonical TopDocs order of what the caller sees (score desc, doc asc) — so the (at most k) survivors are ranked
+    // once more on (f32 score, doc). Which docs survive was decided on the exact totals; a doc at the boundary may thus
+    // beat one whose ROUNDED score equals its own but whose doc id is smaller — inside the 1e-5 band this path is pinned to.
+    {
+      WaveTopK ranked;
+      uint64_t t2 = 0;
+      topk_offer<WIDE>(ranked, top.a ? make_key(score_of(top.a), key_doc(top.a)) : 0ull, t2, k, lane);
+      if (WIDE) topk_offer<WIDE>(ranked, top.b ? make_key(score_of(top.b), key_doc(top.b)) : 0ull, t2, k, lane);
+      if (lane < k) out[lane] = ranked.a ? HitOut{key_doc(ranked.a) + doc_base, key_score(ranked.a)} : HitOut{-1, 0.f};
+      if (WIDE && lane + 64 < k) out[lane + 64] = ranked.b ? HitOut{key_doc(ranked.b) + doc_base, key_score(ranked.b)} : HitOut{-1, 0.f};
+    }
+    const bool low =(lane < k && top.a != 0 && (uint32_t)(top.a >> 32) < (uint32_t)info.y) ||
                      (WIDE && lane + 64 < k && top.b != 0 && (uint32_t)(top.b >> 32) < (uint32_t)info.y);
     const uint64_t any_low = __ballot(low);
     if (lane == 0) { totals_out[row] = total; low_flags[q] = any_low ? 1 : 0; }

@@ -146,9 +146,8 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
   uint64_t tau = 0, floor = 0;
   int count = 0;
   uint32_t touched = 0;  // encoded bytes of the FullBlocks this item decoded (SURVEY 8(d) "touched bytes"; scalar)
-  auto block_bytes = [](uint32_t hdr) -> uint32_t {
-    return 2u + (hdr_bdoc(hdr) ? 16u * (uint32_t)hdr_bdoc(hdr) : (uint32_t)hdr_vlen(hdr)) + (hdr_bfreq(hdr) ? 16u * (uint32_t)hdr_bfreq(hdr) : 1u);
-  };
+  uint32_t touched_blocks = 0;  // ... and their number
+  auto block_bytes = [&](uint32_t hdr) -> uint32_t { touched_blocks += 1u; return encoded_block_bytes(hdr); };
   int cursor = 0;  // lane ti holds clause ti's directory cursor (a register array indexed by ti would spill)
   SharedTau shared{tau_slots + q};
   shared.fold(shared.peek(), tau, floor);
@@ -409,6 +408,7 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
   if (lane == 0) {
     partial_counts[item] = count;
     atomicAdd(touched_slots + q, (unsigned long long)touched);  // ~160 items per query word: no contention to speak of
+    atomicAdd(touched_slots + n_queries + q, (unsigned long long)touched_blocks);
   }
 }
 

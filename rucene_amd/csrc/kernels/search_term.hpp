@@ -114,7 +114,8 @@ __device__ __forceinline__ void group_offer2(const GroupList& g, uint64_t key0, 
 template <bool LEGACY, bool WIDE>
 __device__ __forceinline__ void term_blocks_fast(const SegView& seg, const DevTerm& T, int b0, int b1, uint8_t* slab,
                                                  const float* cache, float wk, int lane, const GroupList& group,
-                                                 SharedTau& shared, uint64_t& floor, int k, int& count, bool prune) {
+                                                 SharedTau& shared, uint64_t& floor, int k, int& count, bool prune, uint32_t& looked,
+                                                 uint32_t& touched) {
   constexpr int DEPTH = PREFETCH_DEPTH;
   const uint8_t* term_rows = seg.bstore + T.bs_base;
   const uint8_t* pn = seg.pnorm + T.pn_base;
@@ -202,6 +203,8 @@ __device__ __forceinline__ void term_blocks_fast(const SegView& seg, const DevTe
 #ifdef RGPU_EXP_COUNT
       ++dbg_looked;
 #endif
+      looked += 1u;                            // what this launch really decoded (rgpu_last_search_counters): scalar adds
+      touched += encoded_block_bytes(hdr) + 128u;  // both streams' rows are requested together + the posting-order norms
       const uint32_t r0 = __float_as_uint(s0), r1 = __float_as_uint(s1);
       if (__ballot((r0 > r1 ? r0 : r1) >= thr)) {
 #ifdef RGPU_EXP_COUNT
@@ -283,7 +286,10 @@ __global__ __launch_bounds__(TERM_THREADS, 8) void k_search_term(SegView seg, co
                                                               int64_t n_items, int blocks_per_item, int k,
                                                               uint64_t* __restrict__ partial_keys,
                                                               int32_t* __restrict__ partial_counts,
-                                                              unsigned long long* __restrict__ tau_slots) {
+                                                              unsigned long long* __restrict__ tau_slots,
+                                                              unsigned long long* __restrict__ work_slots) {
+  // work_slots (nullable): [0] += encoded bytes of the FullBlocks this launch decoded (+ their norms), [1] += their number —
+  // with block-max pruning that is a small part of the lists ("touched" vs "scan" bytes)
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   constexpr int LIST_N = WIDE ? 128 : 64;
   const int lane = lane_id();
@@ -326,6 +332,7 @@ __global__ __launch_bounds__(TERM_THREADS, 8) void k_search_term(SegView seg, co
   const GroupList group{lists + leader * LIST_N, locks + leader};
   SharedTau shared{tau_slots + q};
   int count = 0;
+  uint32_t looked = 0, touched = 0;
 
   if (queries[q].n_terms >= 1) {  // else: clause absent from this leaf, nothing to collect
     const DevTerm T = terms[queries[q].first_term];
@@ -371,12 +378,14 @@ __global__ __launch_bounds__(TERM_THREADS, 8) void k_search_term(SegView seg, co
     const int b1 = min(T.nblocks, b0 + blocks_per_item);
     int32_t base = b0 == 0 ? 0 : seg.dir_last[T.dir_base + b0 - 1];
     const uint8_t* term_rows = seg.bstore + T.bs_base;
-    auto on_block = [&](int, int32_t d0, int32_t d1, uint32_t f0, uint32_t f1, uint32_t nb0, uint32_t nb1) {
+    auto on_block = [&](int blk, int32_t d0, int32_t d1, uint32_t f0, uint32_t f1, uint32_t nb0, uint32_t nb1) {
+      looked += 1u;  // the general path (deleted docs, raw norms, negative weights) decodes every block
+      touched += encoded_block_bytes((uint32_t)seg.dir_hdr[T.dir_base + blk]) + (has_norms ? 128u : 0u);
       collect(std::true_type{}, d0, d1, f0, f1, nb0, nb1, true, true);
     };
     if (tabled && !has_live && nonneg) {
       term_blocks_fast<LEGACY, WIDE>(seg, T, b0, b1, slab, cache, wk, lane, group, shared, floor, k, count,
-                                     RGPU_TERM_PRUNE && (T.flags & TERM_FLAG_MONOTONE) != 0u);
+                                     RGPU_TERM_PRUNE && (T.flags & TERM_FLAG_MONOTONE) != 0u, looked, touched);
       if (b1 > b0) base = seg.dir_last[T.dir_base + b1 - 1];
     } else if (has_norms) {
       stream_blocks<LEGACY, true>(term_rows, seg.dir_row, seg.dir_hdr, T.dir_base, seg.pnorm + T.pn_base, b0, b1, slab, lane, base, on_block);
@@ -401,6 +410,10 @@ __global__ __launch_bounds__(TERM_THREADS, 8) void k_search_term(SegView seg, co
 
   // the wave of a group that finishes last emits the group's list; the other items emit empty lists
   if (lane == 0) partial_counts[item] = count;
+  if (work_slots != nullptr && lane == 0 && looked != 0u) {
+    atomicAdd(work_slots, (unsigned long long)touched);
+    atomicAdd(work_slots + 1, (unsigned long long)looked);
+  }
   uint32_t done = 0;
   if (lane == 0) done = __hip_atomic_fetch_add(remaining + leader, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
   done = (uint32_t)readfirstlane((int)done) + 1u;

@@ -126,7 +126,7 @@ struct rgpu_ctx {
   DevVec<float> sim_tables;
   int n_sim_tables = 0;
   std::vector<uint8_t> sim_monotone;  // per table: cache[] finite, >= 0 and non-increasing in the norm byte
-  int64_t or_wide_redone = 0;         // queries k_or_wide handed back to the f32 kernel (fixed-point floor); tests read it
+  int64_t or_wide_redone = 0;         // queries k_or_wide handed back to the f32 kernel (fixed-point floor); rgpu_kernel_stats reports it as "or_wide_redo_queries"
   std::vector<float> sim_k1;          // per table: k1
   std::vector<uint8_t> sim_nonneg;    // per table: k1 and every cache[] entry finite and >= 0 (a score is then within [0, weight * (k1 + 1)])
   // Per-call scratch, in rotating slots: a search call only enqueues work (staging copy + kernels) on its stream
@@ -144,6 +144,13 @@ struct rgpu_ctx {
   int* d_err = nullptr;
   Scratch* last_and = nullptr;  // the slot whose d_touched the most recent AND launch filled
   int last_and_queries = 0;
+  // rgpu_last_search_counters: the most recent TERM / AND / wide-OR launch
+  Scratch* last_counted = nullptr;
+  int last_counted_op = -1, last_counted_queries = 0;
+  int64_t last_counted_dir_blocks = 0;   // TERM: blocks whose directory words the launch looked at (all of them)
+  int64_t last_counted_loose = 0;        // postings outside FullBlocks (prepared tails, singletons) of the (lead) clauses
+  int64_t last_counted_postings = 0;     // sum of doc_freq over the launch's clauses
+  int64_t last_counted_algo_bytes = 0;   // wide OR: encoded bytes of every clause + 1 B norm per posting
   // profiling
   std::vector<StatSlot> stats;
   std::vector<PendingEvent> pending;
@@ -560,6 +567,37 @@ extern "C" int32_t rgpu_and_touched_bytes(rgpu_ctx* c, int64_t* bytes_out) {
   return RGPU_OK;
 }
 
+// What the most recent TERM / AND / (>= 10 clause) OR launch on this context really did (waits for it): FullBlocks decoded,
+// their encoded bytes (+ 1 norm byte per posting of a TERM block, + 14 directory bytes per block a pruned TERM launch looked
+// at: row, header and frontier words), postings decoded = 128 per decoded block + the prepared tails / singletons read.
+extern "C" int32_t rgpu_last_search_counters(rgpu_ctx* c, rgpu_search_counters* out) {
+  if (!c || !out) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "null argument");
+  std::lock_guard<std::mutex> g(c->mu);
+  HIP_TRY(hipSetDevice(c->device));
+  std::memset(out, 0, sizeof *out);
+  out->op = c->last_counted_op;
+  out->postings_covered = c->last_counted_postings;
+  if (c->last_counted_op == RGPU_OP_OR) {  // every posting decoded, blocks that straddle windows more than once
+    out->postings_decoded = c->last_counted_postings;
+    return RGPU_OK;
+  }
+  if (!c->last_counted || c->last_counted_queries <= 0) return RGPU_OK;
+  if (c->last_counted->busy) { HIP_TRY(hipEventSynchronize(c->last_counted->done)); c->last_counted->busy = false; }
+  if (c->last_counted_op == RGPU_OP_TERM) {
+    unsigned long long h[2] = {0, 0};
+    HIP_TRY(hipMemcpy(h, c->last_counted->d_touched.p, 16, hipMemcpyDeviceToHost));
+    out->blocks_decoded = (int64_t)h[1];
+    out->touched_bytes = (int64_t)h[0] + 14 * c->last_counted_dir_blocks;
+  } else {
+    const size_t nq = (size_t)c->last_counted_queries;
+    std::vector<unsigned long long> h(nq * 2);
+    HIP_TRY(hipMemcpy(h.data(), c->last_counted->d_touched.p, nq * 16, hipMemcpyDeviceToHost));
+    for (size_t q = 0; q < nq; ++q) { out->touched_bytes += (int64_t)h[q]; out->blocks_decoded += (int64_t)h[nq + q]; }
+  }
+  out->postings_decoded = 128 * out->blocks_decoded + c->last_counted_loose;
+  return RGPU_OK;
+}
+
 extern "C" void rgpu_kernel_stats_reset(rgpu_ctx* c) {
   if (!c) return;
   std::lock_guard<std::mutex> g(c->mu);
@@ -668,6 +706,22 @@ extern "C" void rgpu_segment_free(rgpu_segment* s) {
 }
 
 extern "C" int32_t rgpu_segment_version(const rgpu_segment* s) { return s ? s->version : RGPU_ERR_ILLEGAL_ARGUMENT; }
+
+// HBM held for one segment, by part (used bytes, not capacity)
+extern "C" int32_t rgpu_segment_get_footprint(rgpu_segment* seg, rgpu_segment_footprint* out) {
+  if (!seg || !out) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "null argument");
+  std::lock_guard<std::mutex> g(seg->ctx->mu);
+  std::memset(out, 0, sizeof *out);
+  out->doc_file_bytes = (int64_t)seg->doc_len;
+  out->norms_bytes = seg->d_norms ? (int64_t)seg->max_doc : 0;
+  out->live_docs_bytes = seg->d_live ? (int64_t)(((size_t)seg->max_doc + 63) / 64 * 8) : 0;
+  out->positions_file_bytes = (int64_t)seg->pos_len;
+  out->directory_bytes = (int64_t)seg->dir_used * (4 + 4 + 4 + 2 + 8 + (seg->has_positions ? 8 : 0));
+  out->block_store_bytes = (int64_t)seg->bstore_used;
+  out->posting_norms_bytes = seg->d_norms ? (int64_t)seg->pnorm_used : 0;
+  out->prepared_terms = (int64_t)seg->prepared.size();
+  return RGPU_OK;
+}
 
 extern "C" int32_t rgpu_segment_release_prepared_terms(rgpu_segment* seg) {
   if (!seg) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "seg is null");
@@ -1051,6 +1105,10 @@ static int32_t search_or_wide_group(rgpu_segment* seg, Group& G, int32_t k, HitO
   const int64_t* dmp = reinterpret_cast<const int64_t*>(c->S->d_stage.p + o_mp);
   const int32_t* dm = reinterpret_cast<const int32_t*>(c->S->d_stage.p + o_m);
   const SegView sv = seg_view(seg);
+  c->last_counted = nullptr;  // nothing to read back: the wide kernel decodes every posting of every clause
+  c->last_counted_op = RGPU_OP_OR;
+  c->last_counted_queries = nq;
+  c->last_counted_postings = G.postings;
   {
     TimedLaunch tl(c, stream, "k_or_wide", G.postings);
     const size_t lds = orx_lds_bytes(WS);
@@ -1079,17 +1137,27 @@ static int32_t search_or_wide_group(rgpu_segment* seg, Group& G, int32_t k, HitO
   redo.op = RGPU_OP_OR;
   for (int q = 0; q < nq; ++q) {
     if (!low[(size_t)q]) continue;
-    DevQuery dq2 = G.queries[(size_t)q];
-    dq2.op &= 0xffff;
-    dq2.pad = 0;
-    const int first = dq2.first_term;
+    // a fresh DevQuery (a wide query has no MUST_NOT clauses and min_should_match <= 1: op OR, clause count, nothing else —
+    // the wide kernel's table mask and fixed-point exponent must not leak into the clause-order kernel's fields)
+    const DevQuery& wq = G.queries[(size_t)q];
+    DevQuery dq2;
+    dq2.op = RGPU_OP_OR;
+    dq2.n_terms = wq.n_terms;
     dq2.first_term = (int32_t)redo.terms.size();
-    for (int i = 0; i < dq2.n_terms; ++i) { redo.terms.push_back(G.terms[(size_t)(first + i)]); redo.postings += G.terms[(size_t)(first + i)].df; }
+    dq2.pad = 0;
+    const int first = wq.first_term;
+    for (int i = 0; i < dq2.n_terms; ++i) {
+      DevTerm t = G.terms[(size_t)(first + i)];
+      t.flags &= ~TERM_FLAG_OR_DENSE;
+      redo.terms.push_back(t);
+      redo.postings += t.df;
+    }
     redo.qmap.push_back(G.qmap[(size_t)q]);
     redo.queries.push_back(dq2);
   }
   if (!redo.queries.empty()) {
     c->or_wide_redone += (int64_t)redo.queries.size();
+    c->stats[(size_t)stat_slot(c, "or_wide_redo_queries")].launches += (int64_t)redo.queries.size();  // read by tests through rgpu_kernel_stats
     return search_or_group(seg, redo, k, hits_dev, totals_dev, stream);
   }
   return RGPU_OK;
@@ -1188,6 +1256,15 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
     bool to_wide = or_wide_ok && gop == RGPU_OP_OR && mine.size() >= 10 && qmsm <= 1 && mine_not.empty();
     for (size_t i = 0; to_wide && i < mine.size(); ++i)  // scores within [0, weight * (k1 + 1)]: what the fixed-point scale relies on
       to_wide = !std::signbit(mine[i].weight) && mine[i].weight <= 3.0e38f && c->sim_nonneg[(size_t)mine[i].sim_table];
+    if (to_wide) {
+      // k_or_wide's list builder and payload ring read the directory / block store / posting-order norms WITHOUT lane masks
+      // (lanes past a list fall back to clause 0's block 0): that needs those arrays to exist, i.e. a prepared term. A
+      // disjunction of singletons only (each lives in its term-dictionary entry, nothing is ever prepared for it) has no
+      // block to walk anyway: the clause-order kernel takes it.
+      bool any_blocks = false;
+      for (const DevTerm& m : mine) any_blocks = any_blocks || m.nblocks > 0 || m.tail_n > 0;
+      to_wide = any_blocks && seg->dir_used > 0 && seg->bstore.p != nullptr && seg->pnorm.p != nullptr;
+    }
     if (gop == RGPU_OP_OR && !to_wide && groups[(size_t)cur_group[2]].postings > or_postings_cap) {
       groups.emplace_back();
       groups.back().op = RGPU_OP_OR;
@@ -1316,10 +1393,16 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
     const int32_t* dm = reinterpret_cast<const int32_t*>(c->S->d_stage.p + o_m);
     const SegView sv = seg_view(seg);
     if (op == RGPU_OP_AND) {
-      HIP_TRY(c->S->d_touched.reserve((size_t)nq, 0, stream));
-      HIP_TRY(hipMemsetAsync(c->S->d_touched.p, 0, (size_t)nq * 8, stream));
+      HIP_TRY(c->S->d_touched.reserve((size_t)nq * 2, 0, stream));
+      HIP_TRY(hipMemsetAsync(c->S->d_touched.p, 0, (size_t)nq * 16, stream));
       c->last_and = c->S;
       c->last_and_queries = nq;
+      c->last_counted = c->S;
+      c->last_counted_op = RGPU_OP_AND;
+      c->last_counted_queries = nq;
+      c->last_counted_postings = G.postings;
+      c->last_counted_loose = 0;
+      for (const DevQuery& q0 : G.queries) if (q0.n_terms >= 1) { const DevTerm& t0 = G.terms[(size_t)q0.first_term]; c->last_counted_loose += t0.df == 1 ? 1 : t0.tail_n; }
       TimedLaunch tl(c, stream, "k_search_and", G.postings);
       const unsigned grid = (unsigned)((items + WG_WAVES - 1) / WG_WAVES);
       const int64_t* d_sp = nullptr;
@@ -1348,6 +1431,15 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
         else { if (wide) go(k_search_and<false, true, false, false>); else go(k_search_and<false, false, false, false>); }
       }
     } else if (op == RGPU_OP_TERM) {
+      HIP_TRY(c->S->d_touched.reserve(2, 0, stream));
+      HIP_TRY(hipMemsetAsync(c->S->d_touched.p, 0, 16, stream));
+      c->last_counted = c->S;
+      c->last_counted_op = RGPU_OP_TERM;
+      c->last_counted_queries = nq;
+      c->last_counted_postings = G.postings;
+      c->last_counted_dir_blocks = 0;
+      c->last_counted_loose = 0;
+      for (const DevTerm& t0 : G.terms) { c->last_counted_dir_blocks += t0.nblocks; c->last_counted_loose += t0.df == 1 ? 1 : t0.tail_n; }
       TimedLaunch tl(c, stream, "k_search_term", G.postings);
       const unsigned grid = (unsigned)((items + TERM_WAVES - 1) / TERM_WAVES);
       const size_t lds = term_lds_bytes(wide);
@@ -1355,7 +1447,7 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(TERM_THREADS), lds, stream, sv, dq, dt, dp, nq, items, blocks_per_item, (int)k,
-                           c->S->d_partial_keys.p, c->S->d_partial_counts.p, d_tau);
+                           c->S->d_partial_keys.p, c->S->d_partial_counts.p, d_tau, c->S->d_touched.p);
         return hipSuccess;
       };
       hipError_t e;
@@ -1561,9 +1653,9 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
     HIP_TRY(c->S->d_partial_keys.reserve((size_t)items * (size_t)k, 0, stream));
     HIP_TRY(c->S->d_partial_counts.reserve((size_t)items, 0, stream));
     HIP_TRY(c->S->d_tau.reserve((size_t)n_queries, 0, stream));
-    HIP_TRY(c->S->d_touched.reserve((size_t)n_queries, 0, stream));
+    HIP_TRY(c->S->d_touched.reserve((size_t)n_queries * 2, 0, stream));
     HIP_TRY(hipMemsetAsync(c->S->d_tau.p, 0, (size_t)n_queries * 8, stream));
-    HIP_TRY(hipMemsetAsync(c->S->d_touched.p, 0, (size_t)n_queries * 8, stream));
+    HIP_TRY(hipMemsetAsync(c->S->d_touched.p, 0, (size_t)n_queries * 16, stream));
     HIP_TRY(hipMemsetAsync(c->d_err, 0, sizeof(int), stream));
     const DevQuery* d_q = reinterpret_cast<const DevQuery*>(c->S->d_stage.p + o_q);
     const DevTerm* d_t = reinterpret_cast<const DevTerm*>(c->S->d_stage.p + o_t);
@@ -1705,7 +1797,7 @@ extern "C" int32_t rgpu_rescore_batch(rgpu_segment* seg, const rgpu_query* queri
 // ---- segment-sharded search: RCCL all-gather of per-shard top-k + device merge -------------------------------------------
 constexpr int N_COMM_SLOTS = 4;
 struct CommSlot {
-  DevVec<uint8_t> send, recv;  // send: [n_queries x k hits][n_queries counts]; recv: the same record from every rank
+  DevVec<uint8_t> send, recv;  // send: one record (record_bytes: hits, counts, status word); recv: the same record from every rank
   hipEvent_t done = nullptr;
   bool busy = false;
 };
@@ -1720,6 +1812,8 @@ struct rgpu_comm {
   hipStream_t last_stream = nullptr;
   hipEvent_t last_collective = nullptr;
   bool have_last = false;
+  CommSlot* last_slot = nullptr;  // the most recent batch's records (rgpu_comm_status)
+  int32_t last_queries = 0, last_k = 0;
 };
 #define NCCL_TRY(expr)                                                                                          \
   do {                                                                                                          \
@@ -1754,6 +1848,41 @@ extern "C" int32_t rgpu_comm_init(rgpu_ctx* c, int32_t n_ranks, int32_t rank, co
   return RGPU_OK;
 }
 
+// One process, one thread, n contexts (Rucene itself is one process: search_parallel hands leaves to threads,
+// searcher.rs:527-630): ncclCommInitRank blocks until every rank of the id has joined, so n of them issued one after the
+// other from one thread would never return — they have to sit inside one ncclGroupStart / ncclGroupEnd.
+extern "C" int32_t rgpu_comm_init_all(rgpu_ctx* const* ctxs, int32_t n, rgpu_comm** out_comms) {
+  if (!ctxs || !out_comms || n < 1) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "bad arguments");
+  for (int32_t r = 0; r < n; ++r) {
+    out_comms[r] = nullptr;
+    if (!ctxs[r]) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "null context");
+    for (int32_t j = 0; j < r; ++j)
+      if (ctxs[j] == ctxs[r] || ctxs[j]->device == ctxs[r]->device) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "every rank needs its own context on its own device");
+  }
+  ncclUniqueId id;
+  NCCL_TRY(ncclGetUniqueId(&id));
+  std::vector<std::unique_ptr<rgpu_comm>> comms;
+  for (int32_t r = 0; r < n; ++r) {
+    comms.emplace_back(new rgpu_comm());
+    comms.back()->ctx = ctxs[r];
+    comms.back()->n_ranks = n;
+    comms.back()->rank = r;
+  }
+  ncclResult_t res = ncclGroupStart();
+  for (int32_t r = 0; r < n && res == ncclSuccess; ++r) {
+    if (hipSetDevice(ctxs[r]->device) != hipSuccess) { res = ncclUnhandledCudaError; break; }
+    res = ncclCommInitRank(&comms[(size_t)r]->nccl, n, id, r);
+  }
+  const ncclResult_t end = ncclGroupEnd();
+  if (res == ncclSuccess) res = end;
+  if (res != ncclSuccess) {
+    for (auto& cm : comms) if (cm->nccl) (void)ncclCommAbort(cm->nccl);
+    return fail(RGPU_ERR_RUNTIME, std::string("ncclCommInitRank (grouped): ") + ncclGetErrorString(res));
+  }
+  for (int32_t r = 0; r < n; ++r) out_comms[r] = comms[(size_t)r].release();
+  return RGPU_OK;
+}
+
 extern "C" void rgpu_comm_destroy(rgpu_comm* comm) {
   if (!comm) return;
   (void)hipSetDevice(comm->ctx->device);
@@ -1768,6 +1897,118 @@ extern "C" void rgpu_comm_destroy(rgpu_comm* comm) {
   delete comm;
 }
 
+// ---- a shard's record: what one rank contributes to the all-gather ---------------------------------------------------------
+// [n_queries x k rgpu_hit][n_queries x int64 hit count][int64 status] — the status word is the rank's rgpu_status for the
+// batch: a rank whose local search failed still takes part in the collective (with empty rows), so that the other ranks
+// neither hang in the all-gather nor silently merge a stale record; every rank can read everybody's status afterwards.
+static size_t record_hits_bytes(int32_t n_queries, int32_t k) { return (size_t)n_queries * (size_t)k * sizeof(HitOut); }
+static size_t record_bytes(int32_t n_queries, int32_t k) { return record_hits_bytes(n_queries, k) + (size_t)n_queries * 8 + 8; }
+extern "C" int64_t rgpu_record_bytes(int32_t n_queries, int32_t k) {
+  if (n_queries <= 0 || k <= 0) return 0;
+  return (int64_t)record_bytes(n_queries, k);
+}
+
+__global__ void k_set_i64(int64_t* p, int64_t v) { *p = v; }
+
+// local search of one shard straight into a record (device memory, record_bytes long); enqueue-only. The call's own status
+// is returned AND left in the record's status word; on failure the record holds empty rows.
+static int32_t search_into_record(rgpu_segment* seg, const rgpu_query* queries, int32_t n_queries, const rgpu_query_term* terms,
+                                  int32_t n_terms_total, int32_t k, uint8_t* record, hipStream_t s) {
+  const size_t hits_bytes = record_hits_bytes(n_queries, k);
+  const int32_t rc = search_impl(seg, queries, n_queries, terms, n_terms_total, k, (HitOut*)record, (int64_t*)(record + hits_bytes), s);
+  const std::string why = rc == RGPU_OK ? std::string() : g_last_error;
+  if (rc != RGPU_OK) {  // whatever was enqueued before the failure is overwritten behind it on the same stream
+    HIP_TRY(hipMemsetAsync(record + hits_bytes, 0, (size_t)n_queries * 8, s));
+    hipLaunchKernelGGL(k_init_hits, dim3((unsigned)(((size_t)n_queries * k + 255) / 256)), dim3(256), 0, s, (HitOut*)record, (int64_t)n_queries * k);
+  }
+  hipLaunchKernelGGL(k_set_i64, dim3(1), dim3(1), 0, s, (int64_t*)(record + hits_bytes + (size_t)n_queries * 8), (int64_t)rc);
+  HIP_TRY(hipGetLastError());
+  if (rc != RGPU_OK) return fail(rc, why);
+  return RGPU_OK;
+}
+
+extern "C" int32_t rgpu_search_batch_record_device(rgpu_segment* seg, const rgpu_query* queries, int32_t n_queries,
+                                                   const rgpu_query_term* terms, int32_t n_terms_total, int32_t k, void* record_dev,
+                                                   void* hip_stream) {
+  if (!seg || !queries || n_queries <= 0 || !terms || n_terms_total <= 0 || !record_dev) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "bad arguments");
+  if (k <= 0 || k > RGPU_MAX_K) return fail(k <= 0 ? RGPU_ERR_ILLEGAL_ARGUMENT : RGPU_ERR_UNSUPPORTED, "k must be in 1..RGPU_MAX_K");
+  std::lock_guard<std::mutex> g(seg->ctx->mu);
+  HIP_TRY(hipSetDevice(seg->ctx->device));
+  hipStream_t s = hip_stream ? (hipStream_t)hip_stream : seg->ctx->stream;
+  return search_into_record(seg, queries, n_queries, terms, n_terms_total, k, (uint8_t*)record_dev, s);
+}
+
+// the canonical k-way merge over `n_ranks` gathered records (k_merge_lists reading them in place, with the record stride)
+static int32_t merge_records(rgpu_ctx* c, const uint8_t* records, int32_t n_ranks, int32_t n_queries, int32_t k, HitOut* hits_dev,
+                             int64_t* totals_dev, hipStream_t s) {
+  const size_t hits_bytes = record_hits_bytes(n_queries, k), record = record_bytes(n_queries, k);
+  {
+    TimedLaunch tl(c, s, "k_merge_lists", 0);
+    const unsigned grid = (unsigned)((n_queries + WG_WAVES - 1) / WG_WAVES);
+    auto go = [&](auto kern) {
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(WG_THREADS), 0, s, (const HitOut*)records, (const int64_t*)(records + hits_bytes),
+                         (int64_t)(record / sizeof(HitOut)), (int64_t)(record / 8), n_ranks, n_queries, (int)k, hits_dev, totals_dev);
+    };
+    if (k > 64) go(k_merge_lists<true>); else go(k_merge_lists<false>);
+  }
+  HIP_TRY(hipGetLastError());
+  return RGPU_OK;
+}
+
+extern "C" int32_t rgpu_merge_records_device(rgpu_ctx* c, const void* records_dev, int32_t n_ranks, int32_t n_queries, int32_t k,
+                                             void* hits_out_dev, void* totals_out_dev, void* hip_stream) {
+  if (!c || !records_dev || !hits_out_dev || !totals_out_dev || n_ranks <= 0 || n_queries <= 0) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "bad arguments");
+  if (k <= 0 || k > RGPU_MAX_K) return fail(k <= 0 ? RGPU_ERR_ILLEGAL_ARGUMENT : RGPU_ERR_UNSUPPORTED, "k must be in 1..RGPU_MAX_K");
+  std::lock_guard<std::mutex> g(c->mu);
+  HIP_TRY(hipSetDevice(c->device));
+  return merge_records(c, (const uint8_t*)records_dev, n_ranks, n_queries, k, (HitOut*)hits_out_dev, (int64_t*)totals_out_dev,
+                       hip_stream ? (hipStream_t)hip_stream : c->stream);
+}
+
+// ---- the three phases of a sharded batch (context mutex held by the caller) -------------------------------------------------
+struct ShardedCall {
+  CommSlot* sl = nullptr;
+  size_t record = 0;
+  int32_t local_rc = RGPU_OK;
+  std::string local_why;
+};
+static int32_t sharded_local(rgpu_comm* comm, rgpu_segment* seg, const rgpu_query* queries, int32_t n_queries, const rgpu_query_term* terms,
+                             int32_t n_terms_total, int32_t k, hipStream_t s, ShardedCall* call) {
+  CommSlot& sl = comm->slots[comm->next];
+  if (sl.busy) { HIP_TRY(hipEventSynchronize(sl.done)); sl.busy = false; }
+  const size_t record = record_bytes(n_queries, k);
+  HIP_TRY(sl.send.reserve(record, 0, s));
+  HIP_TRY(sl.recv.reserve(record * (size_t)comm->n_ranks, 0, s));
+  // from here on this rank WILL enqueue the collective (a failure above — out of HBM for the record itself — leaves the
+  // communicator out of step with its peers: ncclCommAbort territory, see rgpu_comm_status)
+  comm->next = (comm->next + 1) % N_COMM_SLOTS;
+  call->sl = &sl;
+  call->record = record;
+  call->local_rc = search_into_record(seg, queries, n_queries, terms, n_terms_total, k, sl.send.p, s);
+  if (call->local_rc != RGPU_OK) call->local_why = g_last_error;
+  return RGPU_OK;
+}
+static int32_t sharded_gather(rgpu_comm* comm, hipStream_t s, const ShardedCall& call) {
+  if (comm->have_last && comm->last_stream != s) HIP_TRY(hipStreamWaitEvent(s, comm->last_collective, 0));
+  NCCL_TRY(ncclAllGather(call.sl->send.p, call.sl->recv.p, call.record, ncclInt8, comm->nccl, s));
+  if (!comm->last_collective) HIP_TRY(hipEventCreateWithFlags(&comm->last_collective, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(comm->last_collective, s));
+  comm->last_stream = s;
+  comm->have_last = true;
+  return RGPU_OK;
+}
+static int32_t sharded_merge(rgpu_comm* comm, int32_t n_queries, int32_t k, void* hits_dev, void* totals_dev, hipStream_t s, const ShardedCall& call) {
+  int32_t rc = merge_records(comm->ctx, call.sl->recv.p, comm->n_ranks, n_queries, k, (HitOut*)hits_dev, (int64_t*)totals_dev, s);
+  if (rc != RGPU_OK) return rc;
+  if (!call.sl->done) HIP_TRY(hipEventCreateWithFlags(&call.sl->done, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(call.sl->done, s));
+  call.sl->busy = true;
+  comm->last_slot = call.sl;
+  comm->last_queries = n_queries;
+  comm->last_k = k;
+  return RGPU_OK;
+}
+
 extern "C" int32_t rgpu_search_batch_sharded(rgpu_comm* comm, rgpu_segment* seg, const rgpu_query* queries, int32_t n_queries,
                                              const rgpu_query_term* terms, int32_t n_terms_total, int32_t k, void* hits_dev,
                                              void* totals_dev, void* hip_stream) {
@@ -1779,34 +2020,82 @@ extern "C" int32_t rgpu_search_batch_sharded(rgpu_comm* comm, rgpu_segment* seg,
   std::lock_guard<std::mutex> g(c->mu);
   HIP_TRY(hipSetDevice(c->device));
   hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
-  CommSlot& sl = comm->slots[comm->next];
-  comm->next = (comm->next + 1) % N_COMM_SLOTS;
-  if (sl.busy) { HIP_TRY(hipEventSynchronize(sl.done)); sl.busy = false; }
-  const size_t hits_bytes = (size_t)n_queries * (size_t)k * sizeof(HitOut), record = hits_bytes + (size_t)n_queries * 8;
-  HIP_TRY(sl.send.reserve(record, 0, s));
-  HIP_TRY(sl.recv.reserve(record * (size_t)comm->n_ranks, 0, s));
-  int32_t rc = search_impl(seg, queries, n_queries, terms, n_terms_total, k, (HitOut*)sl.send.p, (int64_t*)(sl.send.p + hits_bytes), s);
+  ShardedCall call;
+  int32_t rc = sharded_local(comm, seg, queries, n_queries, terms, n_terms_total, k, s, &call);
   if (rc != RGPU_OK) return rc;
-  if (comm->have_last && comm->last_stream != s) HIP_TRY(hipStreamWaitEvent(s, comm->last_collective, 0));
-  NCCL_TRY(ncclAllGather(sl.send.p, sl.recv.p, record, ncclInt8, comm->nccl, s));
-  if (!comm->last_collective) HIP_TRY(hipEventCreateWithFlags(&comm->last_collective, hipEventDisableTiming));
-  HIP_TRY(hipEventRecord(comm->last_collective, s));
-  comm->last_stream = s;
-  comm->have_last = true;
-  {
-    TimedLaunch tl(c, s, "k_merge_lists", 0);
-    const unsigned grid = (unsigned)((n_queries + WG_WAVES - 1) / WG_WAVES);
-    auto go = [&](auto kern) {
-      hipLaunchKernelGGL(kern, dim3(grid), dim3(WG_THREADS), 0, s, (const HitOut*)sl.recv.p, (const int64_t*)(sl.recv.p + hits_bytes),
-                         (int64_t)(record / sizeof(HitOut)), (int64_t)(record / 8), comm->n_ranks, n_queries, (int)k, (HitOut*)hits_dev,
-                         (int64_t*)totals_dev);
-    };
-    if (k > 64) go(k_merge_lists<true>); else go(k_merge_lists<false>);
+  rc = sharded_gather(comm, s, call);
+  if (rc != RGPU_OK) return rc;
+  rc = sharded_merge(comm, n_queries, k, hits_dev, totals_dev, s, call);
+  if (rc != RGPU_OK) return rc;
+  // the collective has been honoured; now this rank's own failure, if any, is reported (its peers see it in the status words)
+  if (call.local_rc != RGPU_OK) return fail(call.local_rc, call.local_why);
+  return RGPU_OK;
+}
+
+// The one-process form: rank r = comms[r] / segs[r] (from rgpu_comm_init_all), one thread issues the whole batch. The n
+// all-gathers sit in one NCCL group (issued one by one from one thread the first would wait for peers that this very
+// thread has not reached yet).
+extern "C" int32_t rgpu_search_batch_sharded_all(rgpu_comm* const* comms, rgpu_segment* const* segs, int32_t n, const rgpu_query* queries,
+                                                 int32_t n_queries, const rgpu_query_term* const* terms_per_rank, int32_t n_terms_total,
+                                                 int32_t k, void* const* hits_dev, void* const* totals_dev, void* const* hip_streams) {
+  if (!comms || !segs || n < 1 || !queries || n_queries <= 0 || !terms_per_rank || n_terms_total <= 0 || !hits_dev || !totals_dev)
+    return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "bad arguments");
+  if (k <= 0 || k > RGPU_MAX_K) return fail(k <= 0 ? RGPU_ERR_ILLEGAL_ARGUMENT : RGPU_ERR_UNSUPPORTED, "k must be in 1..RGPU_MAX_K");
+  for (int32_t r = 0; r < n; ++r) {
+    if (!comms[r] || !segs[r] || !terms_per_rank[r] || !hits_dev[r] || !totals_dev[r]) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "null per-rank argument");
+    if (segs[r]->ctx != comms[r]->ctx || comms[r]->rank != r || comms[r]->n_ranks != n)
+      return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "comms[r] / segs[r] must be rank r of an n-rank rgpu_comm_init_all group");
   }
-  HIP_TRY(hipGetLastError());
-  if (!sl.done) HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
-  HIP_TRY(hipEventRecord(sl.done, s));
-  sl.busy = true;
+  std::vector<ShardedCall> calls((size_t)n);
+  std::vector<hipStream_t> ss((size_t)n);
+  for (int32_t r = 0; r < n; ++r) {  // every shard's search is enqueued before any collective: the GPUs work side by side
+    rgpu_ctx* c = comms[r]->ctx;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    ss[(size_t)r] = (hip_streams && hip_streams[r]) ? (hipStream_t)hip_streams[r] : c->stream;
+    int32_t rc = sharded_local(comms[r], segs[r], queries, n_queries, terms_per_rank[r], n_terms_total, k, ss[(size_t)r], &calls[(size_t)r]);
+    if (rc != RGPU_OK) return rc;
+  }
+  NCCL_TRY(ncclGroupStart());
+  int32_t grc = RGPU_OK;
+  for (int32_t r = 0; r < n && grc == RGPU_OK; ++r) {
+    rgpu_ctx* c = comms[r]->ctx;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (hipSetDevice(c->device) != hipSuccess) { grc = fail(RGPU_ERR_RUNTIME, "hipSetDevice"); break; }
+    grc = sharded_gather(comms[r], ss[(size_t)r], calls[(size_t)r]);
+  }
+  NCCL_TRY(ncclGroupEnd());
+  if (grc != RGPU_OK) return grc;
+  int32_t first_local = RGPU_OK;
+  std::string first_why;
+  for (int32_t r = 0; r < n; ++r) {
+    rgpu_ctx* c = comms[r]->ctx;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    int32_t rc = sharded_merge(comms[r], n_queries, k, hits_dev[r], totals_dev[r], ss[(size_t)r], calls[(size_t)r]);
+    if (rc != RGPU_OK) return rc;
+    if (first_local == RGPU_OK && calls[(size_t)r].local_rc != RGPU_OK) { first_local = calls[(size_t)r].local_rc; first_why = "rank " + std::to_string(r) + ": " + calls[(size_t)r].local_why; }
+  }
+  if (first_local != RGPU_OK) return fail(first_local, first_why);
+  return RGPU_OK;
+}
+
+// Every rank's status word of the most recent sharded batch on this communicator (waits for that batch): 0, or the
+// rgpu_status its local search failed with — the merged rows then lack that shard's hits.
+extern "C" int32_t rgpu_comm_status(rgpu_comm* comm, int32_t* status_out) {
+  if (!comm || !status_out) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "null argument");
+  rgpu_ctx* c = comm->ctx;
+  std::lock_guard<std::mutex> g(c->mu);
+  HIP_TRY(hipSetDevice(c->device));
+  for (int r = 0; r < comm->n_ranks; ++r) status_out[r] = RGPU_OK;
+  if (!comm->last_slot) return RGPU_OK;
+  if (comm->last_slot->busy) { HIP_TRY(hipEventSynchronize(comm->last_slot->done)); comm->last_slot->busy = false; }
+  const size_t record = record_bytes(comm->last_queries, comm->last_k);
+  for (int r = 0; r < comm->n_ranks; ++r) {
+    int64_t v = 0;
+    HIP_TRY(hipMemcpy(&v, comm->last_slot->recv.p + (size_t)r * record + record - 8, 8, hipMemcpyDeviceToHost));
+    status_out[r] = (int32_t)v;
+  }
   return RGPU_OK;
 }
 
@@ -1993,6 +2282,114 @@ extern "C" int32_t rgpu_terms_lookup_positions(const rgpu_terms* terms, int32_t 
                                                rgpu_term_positions* positions_out, uint8_t* found_out) {
   if (n_terms > 0 && !positions_out) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "positions_out is null");
   return terms_lookup_impl(terms, field_number, term_bytes, term_offsets, n_terms, states_out, positions_out, found_out);
+}
+
+// ---- batch planner (host) -----------------------------------------------------------------------------------------------
+#include "host/batch_planner.hpp"
+struct rgpu_planner {
+  std::unique_ptr<rucene::BatchPlanner> p;
+};
+static int32_t planner_sim_table(rgpu_ctx* c, const rgpu_plan_stats* ps, int32_t* table_out) {
+  if (!ps) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "null argument");
+  if (!(ps->k1 >= 0.0f) || !(ps->b >= 0.0f && ps->b <= 1.0f)) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "illegal k1 / b value");  // BM25Similarity::new
+  if (!c) { *table_out = -1; return RGPU_OK; }  // the host uploads the field's norm cache itself: rgpu_planner_set_sim_table
+  rucene::CollectionStatistics cs;
+  cs.max_doc = ps->max_doc;
+  cs.doc_count = ps->doc_count;
+  cs.sum_total_term_freq = ps->sum_total_term_freq;
+  rucene::TermStatistics ts;
+  const rucene::BM25SimWeight w = rucene::BM25Similarity(ps->k1, ps->b).compute_weight(cs, &ts, 1, 1.0f);  // the cache depends on the collection alone
+  const int32_t t = rgpu_sim_table_upload(c, w.cache.data(), ps->k1);
+  if (t < 0) return t;
+  *table_out = t;
+  return RGPU_OK;
+}
+
+extern "C" int32_t rgpu_planner_create_flat(rgpu_ctx* c, const rgpu_plan_stats* ps, const rgpu_term_state* leaf_states, int64_t n_leaf,
+                                            const rgpu_term_state* stats_states_or_null, int64_t n_stats, rgpu_planner** out) {
+  if (!out) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "out is null");
+  *out = nullptr;
+  if (n_leaf < 0 || (n_leaf > 0 && !leaf_states) || n_stats < 0 || (n_stats > 0 && !stats_states_or_null)) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "bad term tables");
+  int32_t table = -1;
+  const int32_t rc = planner_sim_table(c, ps, &table);
+  if (rc != RGPU_OK) return rc;
+  try {
+    auto h = std::make_unique<rgpu_planner>();
+    h->p.reset(new rucene::BatchPlanner(*ps, table, leaf_states, n_leaf, stats_states_or_null, n_stats));
+    *out = h.release();
+  } catch (const std::bad_alloc&) { return fail(RGPU_ERR_RUNTIME, "out of host memory"); }
+  return RGPU_OK;
+}
+
+extern "C" int32_t rgpu_planner_create(rgpu_ctx* c, const rgpu_plan_stats* ps, const rgpu_terms* leaf_terms, const rgpu_terms* stats_terms_or_null,
+                                       int32_t field_number, rgpu_planner** out) {
+  if (!out) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "out is null");
+  *out = nullptr;
+  if (!leaf_terms) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "leaf_terms is null");
+  if (!leaf_terms->dict->field_stats(field_number)) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "no such indexed field in this segment");
+  int32_t table = -1;
+  const int32_t rc = planner_sim_table(c, ps, &table);
+  if (rc != RGPU_OK) return rc;
+  auto h = std::make_unique<rgpu_planner>();
+  h->p.reset(new rucene::BatchPlanner(*ps, table, leaf_terms->dict.get(), stats_terms_or_null ? stats_terms_or_null->dict.get() : nullptr, field_number));
+  *out = h.release();
+  return RGPU_OK;
+}
+
+extern "C" void rgpu_planner_destroy(rgpu_planner* p) { delete p; }
+extern "C" int32_t rgpu_planner_sim_table(const rgpu_planner* p) { return p ? p->p->sim_table() : RGPU_ERR_ILLEGAL_ARGUMENT; }
+extern "C" int32_t rgpu_planner_set_sim_table(rgpu_planner* p, int32_t sim_table) {
+  if (!p || sim_table < 0) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "bad arguments");
+  p->p->set_sim_table(sim_table);
+  return RGPU_OK;
+}
+
+static int32_t plan_checked(rgpu_planner* p, int32_t n_queries, const int32_t* ops, const int32_t* n_terms, const int32_t* n_must_not,
+                            const int64_t* ids, const uint8_t* bytes, const int64_t* offsets, const float* boosts, rgpu_query* queries_out,
+                            rgpu_query_term* terms_out, int64_t terms_cap) {
+  if (!p || n_queries <= 0 || !ops || !n_terms || !queries_out || !terms_out || terms_cap < 0) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "bad arguments");
+  std::string why;
+  const int rc = p->p->plan(n_queries, ops, n_terms, n_must_not, ids, bytes, offsets, boosts, queries_out, terms_out, terms_cap, &why);
+  return rc == RGPU_OK ? RGPU_OK : fail(rc, why);
+}
+
+extern "C" int32_t rgpu_plan_batch_ids(rgpu_planner* p, int32_t n_queries, const int32_t* ops, const int32_t* n_terms, const int32_t* n_must_not_or_null,
+                                       const int64_t* term_ids, const float* boosts_or_null, rgpu_query* queries_out, rgpu_query_term* terms_out,
+                                       int64_t terms_cap) {
+  if (!term_ids) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "term_ids is null");
+  return plan_checked(p, n_queries, ops, n_terms, n_must_not_or_null, term_ids, nullptr, nullptr, boosts_or_null, queries_out, terms_out, terms_cap);
+}
+
+extern "C" int32_t rgpu_plan_batch_bytes(rgpu_planner* p, int32_t n_queries, const int32_t* ops, const int32_t* n_terms, const int32_t* n_must_not_or_null,
+                                         const uint8_t* term_bytes, const int64_t* term_offsets, const float* boosts_or_null, rgpu_query* queries_out,
+                                         rgpu_query_term* terms_out, int64_t terms_cap) {
+  if (!term_offsets) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "term_offsets is null");
+  static const uint8_t kEmpty = 0;
+  return plan_checked(p, n_queries, ops, n_terms, n_must_not_or_null, nullptr, term_bytes ? term_bytes : &kEmpty, term_offsets, boosts_or_null, queries_out,
+                      terms_out, terms_cap);
+}
+
+// every query the same shape: `op` (RGPU_OP_TERM / AND / OR, OR optionally RGPU_OP_OR_MSM) over n_clauses terms, boost 1
+static int32_t plan_uniform(rgpu_planner* p, int32_t op, int32_t n_queries, int32_t n_clauses, const int64_t* ids, const uint8_t* bytes,
+                            const int64_t* offsets, rgpu_query* queries_out, rgpu_query_term* terms_out) {
+  if (n_queries <= 0 || n_clauses <= 0 || n_clauses > RGPU_MAX_QUERY_TERMS) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "bad batch shape");
+  if ((op >> 16) != 0) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "a uniform batch has no optional clauses");
+  thread_local std::vector<int32_t> ops, counts;
+  ops.assign((size_t)n_queries, op);
+  counts.assign((size_t)n_queries, n_clauses);
+  return plan_checked(p, n_queries, ops.data(), counts.data(), nullptr, ids, bytes, offsets, nullptr, queries_out, terms_out,
+                      (int64_t)n_queries * n_clauses);
+}
+extern "C" int32_t rgpu_plan_uniform_ids(rgpu_planner* p, int32_t op, int32_t n_queries, int32_t n_clauses, const int64_t* term_ids,
+                                         rgpu_query* queries_out, rgpu_query_term* terms_out) {
+  if (!term_ids) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "term_ids is null");
+  return plan_uniform(p, op, n_queries, n_clauses, term_ids, nullptr, nullptr, queries_out, terms_out);
+}
+extern "C" int32_t rgpu_plan_uniform_bytes(rgpu_planner* p, int32_t op, int32_t n_queries, int32_t n_clauses, const uint8_t* term_bytes,
+                                           const int64_t* term_offsets, rgpu_query* queries_out, rgpu_query_term* terms_out) {
+  if (!term_offsets) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "term_offsets is null");
+  static const uint8_t kEmpty = 0;
+  return plan_uniform(p, op, n_queries, n_clauses, nullptr, term_bytes ? term_bytes : &kEmpty, term_offsets, queries_out, terms_out);
 }
 
 extern "C" uint8_t rgpu_bm25_encode_norm(float boost, int32_t field_length) {

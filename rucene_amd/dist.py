@@ -7,7 +7,7 @@ Rust host binds); this module only creates the communicator for a torch.distribu
 over the job's own process group) and, for the CPU tests, restates the record layout of that all-gather with gloo.
 
 Each rank evaluates the replicated query batch against its own shard (hits already in global doc ids: doc +
-doc_base) and contributes one record: `n_queries x k` rgpu_hit entries followed by `n_queries` int64 hit counts.
+doc_base) and contributes one record: `n_queries x k` rgpu_hit entries, `n_queries` int64 hit counts and one int64 status word.
 The payload is tiny (1024 queries x k=10 -> 88 KiB per rank), i.e. latency-bound: batch many queries per collective.
 """
 import numpy as np
@@ -16,19 +16,19 @@ import torch.distributed as dist
 
 
 def record_words(n_queries, k):
-    """int64 words of one rank's record: [n_queries x k packed hits][n_queries hit counts]."""
-    return n_queries * k + n_queries
+    """int64 words of one rank's record: [n_queries x k packed hits][n_queries hit counts][status] (rgpu_record_bytes / 8)."""
+    return n_queries * k + n_queries + 1
 
 
-def pack_record(hits_local, totals_local):
+def pack_record(hits_local, totals_local, status=0):
     """hits_local [n_queries, k] int64 (packed {i32 doc, f32 score}), totals_local [n_queries] int64 -> one record."""
-    return torch.cat([hits_local.reshape(-1), totals_local.reshape(-1)]).contiguous()
+    return torch.cat([hits_local.reshape(-1), totals_local.reshape(-1), torch.tensor([status], dtype=torch.int64)]).contiguous()
 
 
 def unpack_records(records, world, n_queries, k):
     """[world * record_words] -> (hits_all [world, n_queries, k], totals_all [world, n_queries]) views."""
     r = records.view(world, record_words(n_queries, k))
-    return r[:, :n_queries * k].reshape(world, n_queries, k), r[:, n_queries * k:]
+    return r[:, :n_queries * k].reshape(world, n_queries, k), r[:, n_queries * k:n_queries * k + n_queries]
 
 
 def all_gather_records(hits_local, totals_local, group=None):

@@ -318,15 +318,22 @@ class GpuIndexSearcher:
         self.collection_statistics = CollectionStatistics(sl.field, sl.doc_base, self.max_doc(), sl.doc_count,
                                                           sl.sum_total_term_freq, sl.sum_doc_freq)
         self._weights = {}
-        self._w_memo = self._t_memo = None   # _pack_ids: weight / sim table by flat term id (boost 1)
+        self._planners = {}       # per leaf: the native batch planner
+        self._stats_terms = None  # override_statistics: another leaf's term table / dictionary
 
     def max_doc(self):
         return sum(leaf.max_doc for leaf in self.leaves)
 
     def term_statistics(self, term_id):
         """searcher.rs:732-767: df of the term in the statistics leaf only (0 when absent there)."""
-        st = self.leaves[self._stats_leaf].term_state(term_id)
-        return 0 if st is None else int(st["doc_freq"])
+        stats = getattr(self, "_stats_terms", None)
+        if stats is None:
+            st = self.leaves[self._stats_leaf].term_state(term_id)
+            return 0 if st is None else int(st["doc_freq"])
+        if isinstance(stats, _lib.TermDictionary):
+            states, found = stats.lookup(self.leaves[self._stats_leaf].field_number, [term_id])
+            return int(states[0]["doc_freq"]) if found[0] else 0
+        return int(stats[term_id]["doc_freq"]) if 0 <= term_id < len(stats) else 0
 
     def _weight(self, term_id, boost):
         key = (term_id, boost)
@@ -351,63 +358,40 @@ class GpuIndexSearcher:
             return (OP_OR | (msm << 8) if msm > 1 else OP_OR), query.should_queries, [], query.must_not_queries
         raise RgpuError(-5, "query type not served by the GPU path: %r" % (query,))
 
-    def _terms_by_id(self, ids, leaf):
-        """rgpu_query_term[] for flat-table term ids with boost 1, by array operations. Weights come from a per-searcher memo
-        indexed by term id; a term seen for the first time goes through `_weight` like any other."""
-        ids = np.asarray(ids, dtype=np.int64).ravel()
-        memo = getattr(self, "_w_memo", None)
-        if memo is None or memo.size < leaf.terms.size or memo.size < self.leaves[self._stats_leaf].terms.size:
-            size = max(leaf.terms.size, self.leaves[self._stats_leaf].terms.size, 1)
-            self._w_memo = np.full(size, np.nan, dtype=np.float32)
-            self._t_memo = np.zeros(size, dtype=np.int32)
-        n = ids.size
-        ts = np.zeros(max(n, 1), dtype=QUERY_TERM_DTYPE)
-        if n == 0:
-            return ts
-        inside = (ids >= 0) & (ids < self._w_memo.size)
-        safe = np.where(inside, ids, 0)
-        w = self._w_memo[safe]
-        unknown = np.isnan(w)
-        if unknown.any():   # terms met for the first time: one call for all their weights; the norm cache (and with it the
-            new = np.unique(safe[unknown])   # sim table) of a single-term weight depends on the collection alone
-            dfs = np.fromiter((self.term_statistics(int(t)) for t in new.tolist()), dtype=np.int64, count=new.size)
-            cs = self.collection_statistics
-            self._w_memo[new] = _lib.bm25_term_weights(cs.max_doc, cs.doc_count, dfs, 1.0)
-            self._t_memo[new] = self._weight(int(new[0]), 1.0)[1]
-            w = self._w_memo[safe]
-        in_leaf = (ids >= 0) & (ids < leaf.terms.size)
-        st = leaf.terms[np.where(in_leaf, ids, 0)]
-        ts["state"][:n] = st
-        absent = ~(in_leaf & (st["doc_freq"] > 0))
-        if absent.any():
-            blank = np.zeros((), dtype=TERM_STATE_DTYPE)
-            blank["skip_offset"], blank["singleton_doc_id"] = -1, -1
-            ts["state"][:n][absent] = blank
-        ts["weight"][:n] = w
-        ts["sim_table"][:n] = self._t_memo[safe]
-        for i in np.flatnonzero(~inside).tolist():   # an id outside every table: the weight of a term with df = 0, as `_weight` computes it
-            ts["weight"][i], ts["sim_table"][i] = self._weight(int(ids[i]), 1.0)
-        return ts
+    def override_statistics(self, collection_statistics, stats_terms=None):
+        """Score with the statistics of a leaf that lives elsewhere (segment-sharded search: every shard takes them from
+        shard 0, the index-wide first largest leaf — SURVEY.md §8(e)): `stats_terms` = that leaf's flat term table
+        (TERM_STATE_DTYPE, indexed by term id) or its TermDictionary; None keeps this searcher's own statistics leaf."""
+        self.collection_statistics = collection_statistics
+        self._stats_terms = stats_terms
+        self._weights, self._planners = {}, {}
 
-    def _pack_ids(self, flat, clauses, leaf):
-        """pack() for a batch whose clauses all name terms by flat-table id with boost 1: the same structs as the
-        clause-by-clause path writes, the per-clause part by array operations."""
-        ts = self._terms_by_id(np.fromiter((c.term for c in clauses), dtype=np.int64, count=len(clauses)), leaf)
-        qs = np.zeros(len(flat), dtype=QUERY_DTYPE)
-        counts = np.fromiter((len(t) + len(o) + len(x) for _, t, o, x in flat), dtype=np.int64, count=len(flat))
-        if counts.size and int(counts.max()) > _lib.MAX_QUERY_TERMS:
-            raise RgpuError(-5, "more than %d clauses" % _lib.MAX_QUERY_TERMS)
-        qs["op"] = np.fromiter((f[0] for f in flat), dtype=np.int64, count=len(flat))
-        qs["n_terms"] = np.fromiter((len(f[1]) for f in flat), dtype=np.int64, count=len(flat))
-        qs["first_term"] = np.cumsum(counts) - counts
-        qs["n_must_not"] = np.fromiter((len(f[3]) for f in flat), dtype=np.int64, count=len(flat))
-        return qs, ts
+    def _planner(self, leaf):
+        """The native batch planner (rgpu_planner, csrc/host/batch_planner.hpp) of one leaf: term resolution in the leaf
+        and in the statistics leaf, BM25 weights, one sim table."""
+        key = id(leaf)
+        p = self._planners.get(key)
+        if p is None:
+            cs = self.collection_statistics
+            stats = self._stats_terms
+            if stats is None:
+                sl = self.leaves[self._stats_leaf]
+                stats = sl.term_dictionary if sl.term_dictionary is not None else sl.terms
+            mine = leaf.term_dictionary if leaf.term_dictionary is not None else leaf.terms
+            if isinstance(mine, _lib.TermDictionary) != isinstance(stats, _lib.TermDictionary):
+                raise RgpuError(-2, "the searched leaf and the statistics leaf must name terms the same way (bytes or ids)")
+            _w, cache = self.similarity.compute_weight(cs, [1], 1.0)   # the norm cache depends on the collection alone
+            table = self.ctx.sim_table(cache, self.similarity.k1)
+            p = _lib.Planner(None, cs.max_doc, cs.doc_count, cs.sum_total_term_freq, mine, None if stats is mine else stats,
+                             self.similarity.k1, self.similarity.b, leaf.field_number, sim_table=table)
+            self._planners[key] = p
+        return p
 
     def pack_uniform(self, op, term_ids, leaf, min_should_match=0):
         """The planner for a batch handed over as an ARRAY: `term_ids[q, c]` = flat-table id of clause c of query q, every
         query the same shape — `op` OP_TERM (one column), OP_AND (all MUST) or OP_OR (all SHOULD, optionally with
-        min_should_match), boost 1. Equals pack([TermQuery / BooleanQuery.build(...) ...]) on the same ids; no per-query
-        interpreter work at all (term resolution, BM25 weights and sim-table handles are three gathers)."""
+        min_should_match), boost 1. Equals pack([TermQuery / BooleanQuery.build(...) ...]) on the same ids; the whole of it
+        runs behind the C ABI (rgpu_plan_uniform_ids)."""
         term_ids = np.asarray(term_ids, dtype=np.int64)
         if term_ids.ndim == 1:
             term_ids = term_ids.reshape(-1, 1)
@@ -416,21 +400,28 @@ class GpuIndexSearcher:
             raise RgpuError(-1, "pack_uniform: op TERM takes one column, AND / OR at least one")
         if nc > _lib.MAX_QUERY_TERMS:
             raise RgpuError(-5, "more than %d clauses" % _lib.MAX_QUERY_TERMS)
-        if nc == 1 and op != OP_TERM:
-            op = OP_TERM   # BooleanQuery::build with a single clause rewrites to that clause (boolean_query.rs:56-68)
-            min_should_match = 0
-        qs = np.zeros(nq, dtype=QUERY_DTYPE)
-        qs["op"] = (op | (min_should_match << 8)) if (op == OP_OR and min_should_match > 1) else op
-        qs["n_terms"] = nc
-        qs["first_term"] = np.arange(nq, dtype=np.int64) * nc
-        return qs, self._terms_by_id(term_ids, leaf)
+        if nc == 1:
+            op, min_should_match = OP_TERM, 0   # BooleanQuery::build with a single clause rewrites to that clause (boolean_query.rs:56-68)
+        return self._planner(leaf).plan_uniform((op | (min_should_match << 8)) if (op == OP_OR and min_should_match > 1) else op, term_ids)
 
     def pack(self, queries, leaf):
         """queries -> (rgpu_query[], rgpu_query_term[]) for one leaf."""
         flat = [self._flatten(q) for q in queries]
         clauses = [c for _, t, o, n in flat for group in (t, o, n) for c in group]
-        if clauses and all(type(c.term) is int and c.boost == 1.0 for c in clauses):
-            return self._pack_ids(flat, clauses, leaf)
+        by_id = [type(c.term) is int for c in clauses]
+        if clauses and (all(by_id) or not any(by_id)) and all(by_id) == (leaf.term_dictionary is None):
+            # one naming scheme throughout (the usual case): the per-clause work — resolution, weights — happens natively
+            if max(len(t) + len(o) + len(n) for _, t, o, n in flat) > _lib.MAX_QUERY_TERMS:
+                raise RgpuError(-5, "more than %d clauses" % _lib.MAX_QUERY_TERMS)
+            boosts = None if all(c.boost == 1.0 for c in clauses) else [c.boost for c in clauses]
+            return self._planner(leaf).plan_batch([f[0] for f in flat], [len(f[1]) for f in flat], [c.term for c in clauses],
+                                                  [len(f[3]) for f in flat], boosts)
+        return self._pack_clause_by_clause(queries, leaf, flat)
+
+    def _pack_clause_by_clause(self, queries, leaf, flat=None):
+        """pack() one clause at a time in Python: mixed naming schemes, numpy-scalar ids; also what tests hold the native
+        planner against."""
+        flat = flat or [self._flatten(q) for q in queries]
         byte_terms = [c.term for _, t, o, n in flat for c in list(t) + list(o) + list(n) if isinstance(c.term, bytes)]
         if byte_terms:
             leaf.resolve(byte_terms)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Variant builds of librucene_gpu.so for A/B runs on the GPU box (scripts/gpu_session_*.sh take their names):
+# Variant builds of librucene_gpu.so for A/B runs on the GPU box (RUCENE_GPU_LIB=build_variants/<name>.so selects one at run time):
 #   scripts/build_variants.sh <name> <-D flags ...>      e.g.  scripts/build_variants.sh orx_w16_32k -DRGPU_ORX_WAVES=16 -DRGPU_ORX_LOOK=5 -DRGPU_ORX_WS16=32768
 # The next steps DESIGN.md §8 names for k_or_wide, ready to build:
 #   orx_w16_32k   one 16-wavefront workgroup per CU, 32768-doc windows (128 KB of accumulators)

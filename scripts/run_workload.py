@@ -1,5 +1,6 @@
 """Minimal driver for profiling: build the 10M-doc shard, run one workload a few times through the C ABI.
-usage: run_workload.py [term|and3|or10|decode] [reps]"""
+usage: run_workload.py [term|and3|or10|decode|cold] [reps]   (DOCS=... sets the shard size; cold = a fresh segment per repetition:
+skip decode + block framing + alignment + tails (k_prepare_terms, k_prepare_blocks), then k_decode_terms, for every df >= 128 term)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -17,7 +18,18 @@ if os.environ.get('NONORMS'):
 s = rucene_amd.GpuIndexSearcher([leaf], ctx=ctx)
 T, B = rucene_amd.TermQuery, rucene_amd.BooleanQuery
 SEED = 0x527563656E65 ^ 0x51
-if kind == "decode":
+if kind == "cold":
+    sel = seg.terms[seg.terms["doc_freq"] >= 128]
+    import torch  # device buffers only
+    total = int(sel["doc_freq"].sum())
+    td = torch.empty(total, dtype=torch.int32, device="cuda")
+    tf = torch.empty(total, dtype=torch.int32, device="cuda")
+    for _ in range(reps):
+        leaf.segment.release_prepared_terms()
+        leaf.segment.prepare_terms(sel)
+        leaf.segment.decode_terms_device(sel, td.data_ptr(), tf.data_ptr())
+    print("footprint", leaf.segment.footprint())
+elif kind == "decode":
     sel = seg.terms[seg.terms["doc_freq"] >= 128]
     import torch  # device buffers only
     total = int(sel["doc_freq"].sum())
@@ -31,14 +43,14 @@ if kind == "decode":
 else:
     if kind == "term":
         tids = indexgen.log_uniform_ranks(1024, 1, 10_000, SEED).reshape(-1, 1) - 1
-        qs, k = [T(int(t[0])) for t in tids], 10
+        k = 10
     elif kind == "and3":
         tids = indexgen.log_uniform_ranks(3 * 1024, 1, 1000, SEED ^ 0xA3).reshape(-1, 3) - 1
-        qs, k = [B.build([T(int(x)) for x in t], []) for t in tids], 10
+        k = 10
     else:
         tids = indexgen.log_uniform_ranks(10 * 1024, 1, 10_000, SEED ^ 0x0A).reshape(-1, 10) - 1
-        qs, k = [B.build([], [T(int(x)) for x in t]) for t in tids], 100
-    packed = s.pack(qs, leaf)
+        k = 100
+    packed = s.pack_uniform({"term": 0, "and3": 1}.get(kind, 2), tids, leaf)
     for _ in range(reps + 2):
         hits, totals = leaf.segment.search_batch(packed[0], packed[1], k)
 import ctypes as _C

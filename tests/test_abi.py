@@ -42,7 +42,9 @@ def test_header_is_plain_c_and_layouts_match_the_bindings(gpu_lib, tmp_path):
     structs = {"rgpu_term_state": gpu_lib.TERM_STATE_DTYPE, "rgpu_query_term": gpu_lib.QUERY_TERM_DTYPE, "rgpu_query": gpu_lib.QUERY_DTYPE,
                "rgpu_hit": gpu_lib.HIT_DTYPE, "rgpu_field_info": gpu_lib.FIELD_INFO_DTYPE, "rgpu_field_stats": gpu_lib.FIELD_STATS_DTYPE,
                "rgpu_term_positions": gpu_lib.TERM_POSITIONS_DTYPE, "rgpu_segment_info": gpu_lib.SEGMENT_INFO_DTYPE,
-               "rgpu_commit_segment": gpu_lib.COMMIT_SEGMENT_DTYPE, "rgpu_compound_entry": gpu_lib.COMPOUND_ENTRY_DTYPE}
+               "rgpu_commit_segment": gpu_lib.COMMIT_SEGMENT_DTYPE, "rgpu_compound_entry": gpu_lib.COMPOUND_ENTRY_DTYPE,
+               "rgpu_search_counters": gpu_lib.SEARCH_COUNTERS_DTYPE, "rgpu_plan_stats": gpu_lib.PLAN_STATS_DTYPE,
+               "rgpu_segment_footprint": gpu_lib.FOOTPRINT_DTYPE}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "%s"' % os.path.join(ROOT, "include", "rucene_gpu.h"), "int main(void) {"]
     for name, dt in structs.items():
         lines.append('  printf("%s %%zu", sizeof(%s));' % (name, name))
@@ -79,7 +81,7 @@ def test_struct_layouts_match_the_header(gpu_lib):
     assert gpu_lib.QUERY_TERM_DTYPE.itemsize == 40 and gpu_lib.QUERY_TERM_DTYPE.fields["weight"][1] == 32
     assert gpu_lib.QUERY_DTYPE.itemsize == 16 and gpu_lib.HIT_DTYPE.itemsize == 8
     assert C.sizeof(gpu_lib._Config) == 64
-    assert gpu_lib.lib().rgpu_abi_version() == 2
+    assert gpu_lib.lib().rgpu_abi_version() == 3 == gpu_lib.ABI_VERSION
 
 
 def test_bm25_host_helper_is_bit_exact_with_the_oracle(gpu_lib, oracle):
@@ -180,7 +182,27 @@ def test_comm_entry_points_check_their_arguments(gpu_lib):
     assert L.rgpu_comm_init(None, 1, 0, uid.ctypes.data, None) == -2
     assert L.rgpu_comm_unique_id(None) == -2
     assert L.rgpu_search_batch_sharded(None, None, None, 0, None, 0, 10, None, None, None) == -2
+    assert L.rgpu_comm_status(None, None) == -2 and L.rgpu_comm_init_all(None, 0, None) == -2
+    assert L.rgpu_search_batch_sharded_all(None, None, 0, None, 0, None, 0, 10, None, None, None) == -2
+    assert L.rgpu_merge_records_device(None, None, 2, 4, 10, None, None, None) == -2
+    assert L.rgpu_search_batch_record_device(None, None, 0, None, 0, 10, None, None) == -2
+    assert L.rgpu_record_bytes(1024, 10) == 1024 * 10 * 8 + 1024 * 8 + 8 and L.rgpu_record_bytes(0, 10) == 0
     L.rgpu_comm_destroy(None)
+
+
+def test_planner_entry_points_check_their_arguments(gpu_lib):
+    L = gpu_lib.lib()
+    out = C.c_void_p()
+    ps = np.zeros(1, gpu_lib.PLAN_STATS_DTYPE)
+    assert L.rgpu_planner_create_flat(None, None, None, 0, None, 0, C.byref(out)) == -2 and not out.value           # no statistics
+    assert L.rgpu_planner_create_flat(None, ps.ctypes.data, None, 4, None, 0, C.byref(out)) == -2 and not out.value  # a table without its pointer
+    ps[0]["k1"] = -1.0
+    assert L.rgpu_planner_create_flat(None, ps.ctypes.data, None, 0, None, 0, C.byref(out)) == -2 and not out.value  # BM25Similarity::new rejects k1 < 0
+    assert L.rgpu_planner_create(None, ps.ctypes.data, None, None, 0, C.byref(out)) == -2
+    assert L.rgpu_plan_uniform_ids(None, 0, 4, 1, None, None, None) == -2
+    assert L.rgpu_plan_batch_bytes(None, 1, None, None, None, None, None, None, None, None, 0) == -2
+    assert L.rgpu_planner_sim_table(None) == -2
+    L.rgpu_planner_destroy(None)
 
 
 def test_flat_fp_map_against_std_unordered_map(tmp_path):

@@ -71,8 +71,11 @@ def _against_oracle(full, oracle, kind, n, k):
     cd, cs, cc, ct, _, _ = osearcher.search_batch(ops, offs, np.ascontiguousarray(tids).reshape(-1), k, tie_mode=oracle.TIE_CANONICAL,
                                                   threads=os.cpu_count() or 1)
     assert (totals == ct).all()
-    if kind == "or10":  # >= 10 clauses: the reference sums in heap order -> 1e-5 relative (north_star's tolerance)
+    if kind == "or10":  # >= 10 clauses: the reference sums in heap order -> scores within 1e-5 relative (north_star's tolerance),
+        from oracle import parity  # doc ids judged by the oracle's own score of every returned doc (oracle/parity.py)
+        differing = parity.check_heap_order_batch(osearcher, op, tids, hits, totals, cd, cs, cc, ct, rtol=1e-5, what="or10")
         np.testing.assert_allclose(hits["score"], cs, rtol=1e-5, atol=0)
+        print("or10 at full size: %d of %d returned docs differ from the oracle's rows (tie band only)" % (differing, int(cc.sum())))
     else:
         assert (hits["doc"] == cd).all()
         assert (hits["score"].view(np.int32) == cs.view(np.int32)).all()
@@ -87,4 +90,4 @@ def test_conjunction_sample_equals_the_oracle_at_full_size(full, oracle):
 
 
 def test_disjunction_sample_matches_the_oracle_at_full_size(full, oracle):
-    _against_oracle(full, oracle, "or10", 16, 100)
+    _against_oracle(full, oracle, "or10", 64, 100)

@@ -135,11 +135,12 @@ def _check_against_oracle(oracle, osearcher, gsearcher, specs, k, exact=True, na
             assert (gd[:n] == cd[i, :n]).all(), (i, specs[i], gd[:n], cd[i, :n])
             assert (gs[:n].view(np.int32) == cs[i, :n].view(np.int32)).all(), (i, specs[i])
         else:
+            # heap-order disjunctions: doc ids are judged too — every returned doc must match the query and carry the score
+            # the ORACLE gives that very doc, and nothing above the k-th score band may be missing (oracle/parity.py)
+            from oracle import parity
+            parity.check_heap_order_row(osearcher, specs[i][0], specs[i][1], gd, gs, totals[i], cd[i], cs[i], n, ct[i],
+                                        rtol=1e-5, what="query %d %s" % (i, specs[i]))
             np.testing.assert_allclose(gs[:n], cs[i, :n], rtol=1e-5, atol=0)
-            # doc ids may only differ where scores tie within the tolerance
-            diff = gd[:n] != cd[i, :n]
-            if diff.any():
-                assert np.allclose(gs[:n][diff], cs[i, :n][diff], rtol=1e-5)
         # SURVEY §8(c) rule against the Rust-heap emulation: same score multiset, same docs above the k-th score,
         # ties at the k-th score drawn from docs that really have that score (here: present in canonical order
         # or not at all — checked via score equality)
@@ -357,8 +358,9 @@ def test_wide_disjunctions(oracle, knobs):
             # is summed again in f32 by the clause-order kernel
             _check_against_oracle(oracle, osearcher, gsearcher, [(oracle.OP_OR, list(range(10)))], 10, exact=False)
             assert "k_or_wide" in ctx2.kernel_stats() and "k_or_windows" not in ctx2.kernel_stats()
+            assert "or_wide_redo_queries" not in ctx2.kernel_stats()
             _check_against_oracle(oracle, osearcher, gsearcher, [(oracle.OP_OR, [0, 1, 2] + [11] * 7)], 10, exact=False)
-            assert "k_or_windows" in ctx2.kernel_stats()
+            assert "k_or_windows" in ctx2.kernel_stats() and ctx2.kernel_stats()["or_wide_redo_queries"]["launches"] == 1
         specs = [(oracle.OP_OR, list(range(10))), (oracle.OP_OR, [0, 1, 2] + [11] * 7), (oracle.OP_OR, list(range(2, 18))), (oracle.OP_OR, [11] * 10),
                  (oracle.OP_OR, [11, 10, 13, 12, 9] * 3), (oracle.OP_OR, [0, 1, 2, 14, 16, 3, 4, 5, 6, 15]),
                  (oracle.OP_OR, [0, 14, 1, 2, 16, 3, 4, 0, 14, 1, 2, 16]), (oracle.OP_OR, list(range(8, 18)) + [18, 18]),
@@ -1092,3 +1094,165 @@ def test_query_rescorer(zipf, oracle):
                 assert (got[i]["doc"][:n] == wd).all(), (mode, window, i)
                 assert (got[i]["score"][:n].view(np.int32) == ws.view(np.int32)).all(), (mode, window, i)
                 assert (got[i]["doc"][n:] == -1).all()
+
+
+def test_wide_disjunction_of_singletons_on_a_fresh_segment(ctx, oracle):
+    """ten SHOULD clauses that are all singletons (df == 1: nothing is ever prepared for them) on a segment no term
+    was prepared on — the order-free kernel reads directory / block-store arrays without lane masks, so such a query must
+    not reach it with those arrays unallocated. Also next to one prepared term, and all ten on one doc."""
+    import rucene_amd
+    from rucene_amd import indexgen
+    max_doc = 5_000
+    rng = np.random.default_rng(99)
+    docs = rng.choice(max_doc, size=12, replace=False).astype(np.int32)
+    lists = [(np.array([d], np.int32), np.array([1 + i % 4], np.int32)) for i, d in enumerate(docs)]
+    lists += [(np.array([docs[0]], np.int32), np.array([7], np.int32)) for _ in range(3)]   # three more singletons on the first one's doc
+    lists.append(_postings(rng, 700, max_doc))                                              # term 15: the only term with blocks
+    norms = rng.integers(95, 125, size=max_doc).astype(np.uint8)
+    seg = indexgen.build_explicit(max_doc, lists, norms=norms)
+    osearcher = oracle.Searcher([oracle.Segment(seg.doc_bytes, seg.norms, max_doc, seg.terms, sum_total_term_freq=50 * max_doc)])
+    leaf = rucene_amd.LeafReader(seg.doc_bytes, seg.norms, max_doc, seg.terms, sum_total_term_freq=50 * max_doc)
+    gsearcher = rucene_amd.GpuIndexSearcher([leaf], ctx=ctx)
+    _check_against_oracle(oracle, osearcher, gsearcher, [(oracle.OP_OR, list(range(10))), (oracle.OP_OR, [0, 12, 13, 14] + list(range(1, 11)))], 10, exact=False)
+    _check_against_oracle(oracle, osearcher, gsearcher, [(oracle.OP_OR, list(range(12)) + [15]), (oracle.OP_OR, list(range(10)))], 10, exact=False)
+
+
+def test_shard_records_merge_like_finish_parallel(ctx, oracle):
+    """the gather -> merge half of rgpu_search_batch_sharded without a second GPU. Two shards of one
+    index are searched one after the other on this device, each straight into its slot of what would be the all-gather's
+    receive buffer (rgpu_search_batch_record_device: [hits][counts][status] records back to back), and
+    rgpu_merge_records_device — the very k_merge_lists launch the collective path ends with, same strides — must give the
+    two-leaf oracle's rows (TopDocsCollector::finish_parallel, top_docs.rs:157-172). Statistics: shard 0's (the first
+    largest leaf), shipped inside the query terms' weights."""
+    import torch
+    import rucene_amd
+    from rucene_amd import indexgen, _lib as gpu
+    docs, vocab = 80_000, 4_000
+    segs = [indexgen.build_zipf(docs, vocab, shard=r, doc_base=r * docs) for r in range(2)]
+    osearcher = oracle.Searcher([oracle.Segment(s.doc_bytes, s.norms, s.max_doc, s.terms, doc_base=r * docs, sum_total_term_freq=s.sum_total_term_freq)
+                                 for r, s in enumerate(segs)])
+    assert oracle.lib().orc_searcher_stats_leaf(osearcher._h) == 0
+    T, B = rucene_amd.TermQuery, rucene_amd.BooleanQuery
+    specs = [(oracle.OP_TERM, [t]) for t in (0, 5, 77, 900, 3_999)] + [(oracle.OP_AND, [0, 3, 9]), (oracle.OP_AND, [4, 40]), (oracle.OP_OR, [1, 30, 200, 900]),
+                                                                         (oracle.OP_OR, list(range(2, 14)))]
+    queries = [T(tids[0]) if op == oracle.OP_TERM else (B.build([T(t) for t in tids], []) if op == oracle.OP_AND else B.build([], [T(t) for t in tids]))
+               for op, tids in specs]
+    nq = len(queries)
+    searchers = []
+    for r, seg in enumerate(segs):
+        leaf = rucene_amd.LeafReader.from_synthetic(seg, doc_base=r * docs)
+        sr = rucene_amd.GpuIndexSearcher([leaf], ctx=ctx)
+        sr.override_statistics(rucene_amd.CollectionStatistics("body", 0, 2 * docs, segs[0].doc_count, segs[0].sum_total_term_freq), segs[0].terms)
+        searchers.append((sr, leaf))
+    for k in (10, 100):
+        rec = gpu.record_bytes(nq, k)
+        assert rec == nq * k * 8 + nq * 8 + 8
+        recv = torch.zeros((2 * rec,), dtype=torch.uint8, device="cuda")
+        for r, (sr, leaf) in enumerate(searchers):
+            qs, ts = sr.pack(queries, leaf)
+            leaf.segment.search_batch_record_device(qs, ts, k, recv.data_ptr() + r * rec)
+        hits = torch.zeros((nq, k), dtype=torch.int64, device="cuda")
+        totals = torch.zeros((nq,), dtype=torch.int64, device="cuda")
+        ctx.merge_records_device(recv.data_ptr(), 2, nq, k, hits.data_ptr(), totals.data_ptr())
+        ctx.synchronize()
+        raw = recv.cpu().numpy()
+        assert raw[rec - 8:rec].view(np.int64)[0] == 0 and raw[2 * rec - 8:].view(np.int64)[0] == 0    # both shards: status OK
+        got = hits.cpu().numpy().view(gpu.HIT_DTYPE).reshape(nq, k)
+        tot = totals.cpu().numpy()
+        cd, cs, cc, ct, _, _ = _oracle_many(osearcher, oracle, specs, k, oracle.TIE_CANONICAL)
+        from oracle import parity
+        for i, (op, tids) in enumerate(specs):
+            n = int(cc[i])
+            if op == oracle.OP_OR and len(tids) >= 10:
+                parity.check_heap_order_row(osearcher, op, tids, got[i]["doc"], got[i]["score"], tot[i], cd[i], cs[i], n, ct[i], what="merged %s" % (specs[i],))
+            else:
+                assert tot[i] == ct[i] and (got[i]["doc"][:n] == cd[i, :n]).all() and (got[i]["doc"][n:] == -1).all(), (k, specs[i])
+                assert (got[i]["score"][:n].view(np.int32) == cs[i, :n].view(np.int32)).all(), (k, specs[i])
+        assert (got["doc"][:, 0] >= docs).any() and (got["doc"][:, 0] < docs).any()   # both shards contribute winners
+
+
+def test_a_failing_shard_still_joins_the_collective(ctx, oracle):
+    """rgpu_search_batch_sharded is collective — a rank whose LOCAL search fails (here: a term state that points
+    into the middle of another term's blocks -> CorruptIndex from the prepare kernels) must still enqueue the all-gather,
+    with empty rows and its status in the record, and only then report its error; the communicator stays usable."""
+    import torch
+    import rucene_amd
+    from rucene_amd import indexgen, _lib as gpu
+    seg = indexgen.build_zipf(60_000, 3_000)
+    leaf = rucene_amd.LeafReader.from_synthetic(seg)
+    searcher = rucene_amd.GpuIndexSearcher([leaf], ctx=ctx)
+    comm = gpu.Comm(ctx, 1, 0, gpu.comm_unique_id())
+    T = rucene_amd.TermQuery
+    qs, ts = searcher.pack([T(0), T(7), T(1)], leaf)
+    bad = ts.copy()
+    bad["state"]["doc_start_fp"][1] += 3          # no longer a block boundary: the framing checks refuse it
+    hits = torch.full((3, 10), 7, dtype=torch.int64, device="cuda")
+    totals = torch.full((3,), 7, dtype=torch.int64, device="cuda")
+    with pytest.raises(rucene_amd.RgpuError) as e:
+        comm.search_batch_sharded(leaf.segment, qs, bad, 10, hits.data_ptr(), totals.data_ptr())
+    assert e.value.status in (-2, -4)
+    st = comm.status()
+    assert st.tolist() == [e.value.status]
+    ctx.synchronize()
+    got = hits.cpu().numpy().view(gpu.HIT_DTYPE).reshape(3, 10)
+    assert (got["doc"] == -1).all() and (totals.cpu().numpy() == 0).all()   # the merge ran over an empty record
+    comm.search_batch_sharded(leaf.segment, qs, ts, 10, hits.data_ptr(), totals.data_ptr())   # ... and the next batch is fine
+    ctx.synchronize()
+    want_h, want_t = leaf.segment.search_batch(qs, ts, 10)
+    got = hits.cpu().numpy().view(gpu.HIT_DTYPE).reshape(3, 10)
+    assert (got["doc"] == want_h["doc"]).all() and (totals.cpu().numpy() == want_t).all() and comm.status().tolist() == [0]
+    comm.close()
+
+
+def test_search_counters_tell_decoded_from_covered(ctx, oracle):
+    """rgpu_last_search_counters: what a launch really decoded. TERM with block-max pruning decodes a fraction of the
+    postings its queries cover (and never more); with deleted docs it runs unpruned and decodes every FullBlock; the
+    conjunction kernel's figures agree with rgpu_and_touched_bytes."""
+    import rucene_amd
+    from rucene_amd import indexgen
+    seg = indexgen.build_zipf(300_000, 5_000)
+    T, B = rucene_amd.TermQuery, rucene_amd.BooleanQuery
+    leaf = rucene_amd.LeafReader.from_synthetic(seg)
+    searcher = rucene_amd.GpuIndexSearcher([leaf], ctx=ctx)
+    terms = [0, 1, 2, 3, 10, 50]
+    covered = int(seg.terms["doc_freq"][terms].sum())
+    full_blocks = int((seg.terms["doc_freq"][terms] // 128).sum())
+    searcher.search_batch([T(t) for t in terms], 10)
+    c = ctx.last_search_counters()
+    assert c["op"] == 0 and c["postings_covered"] == covered
+    assert 0 < c["blocks_decoded"] < full_blocks // 2 and c["postings_decoded"] < covered // 2      # pruned: far fewer than covered
+    assert c["touched_bytes"] >= 14 * full_blocks
+    searcher.search_batch([B.build([T(0), T(1), T(2)], []), B.build([T(3), T(50)], [])], 10)
+    c = ctx.last_search_counters()
+    assert c["op"] == 1 and c["blocks_decoded"] > 0 and c["touched_bytes"] == ctx.and_touched_bytes()
+    assert c["postings_covered"] == int(seg.terms["doc_freq"][[0, 1, 2, 3, 50]].sum()) and c["postings_decoded"] <= c["postings_covered"] + 128 * 5
+    live = np.full((seg.max_doc + 63) // 64, ~np.uint64(0), dtype=np.uint64)
+    live[3] = np.uint64(0)                                                                       # docs 192..255 deleted
+    leaf2 = rucene_amd.LeafReader(seg.doc_bytes, seg.norms, seg.max_doc, seg.terms, live_docs=live, sum_total_term_freq=seg.sum_total_term_freq)
+    rucene_amd.GpuIndexSearcher([leaf2], ctx=ctx).search_batch([T(t) for t in terms], 10)
+    c = ctx.last_search_counters()
+    assert c["blocks_decoded"] == full_blocks and c["postings_decoded"] == covered                # the general path decodes everything
+
+
+def test_native_planner_with_its_own_sim_table(ctx, oracle):
+    """rgpu_planner_create_flat with a context: the planner uploads the field's norm cache itself; a batch planned by it
+    searches like the same batch planned clause by clause."""
+    import rucene_amd
+    from rucene_amd import indexgen, _lib as gpu
+    seg = indexgen.build_zipf(120_000, 4_000)
+    leaf = rucene_amd.LeafReader.from_synthetic(seg)
+    searcher = rucene_amd.GpuIndexSearcher([leaf], ctx=ctx)
+    planner = gpu.Planner(ctx, seg.max_doc, seg.doc_count, seg.sum_total_term_freq, seg.terms)
+    assert planner.sim_table >= 0
+    rng = np.random.default_rng(12)
+    T, B = rucene_amd.TermQuery, rucene_amd.BooleanQuery
+    for op, nc in ((gpu.OP_TERM, 1), (gpu.OP_AND, 3), (gpu.OP_OR, 4), (gpu.OP_OR, 11)):
+        ids = rng.integers(0, 600, size=(64, nc))
+        qs, ts = planner.plan_uniform(op, ids)
+        got_h, got_t = leaf.segment.search_batch(qs, ts, 10)
+        objs = [T(int(r[0])) if op == gpu.OP_TERM else (B.build([T(int(x)) for x in r], []) if op == gpu.OP_AND else B.build([], [T(int(x)) for x in r])) for r in ids]
+        want_q, want_t = searcher._pack_clause_by_clause(objs, leaf)
+        assert (ts["weight"].view(np.int32) == want_t["weight"].view(np.int32)).all() and qs.tobytes() == want_q.tobytes()
+        want_h, want_tot = leaf.segment.search_batch(want_q, want_t, 10)
+        assert (got_h["doc"] == want_h["doc"]).all() and (got_h["score"].view(np.int32) == want_h["score"].view(np.int32)).all() and (got_t == want_tot).all()
+    planner.close()

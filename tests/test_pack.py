@@ -25,6 +25,7 @@ def world(oracle):
     leaf = rucene_amd.LeafReader.from_synthetic(seg)
     s = object.__new__(rucene_amd.GpuIndexSearcher)     # no Context: pack() is host-only
     s.leaves, s.ctx, s.similarity, s._stats_leaf, s._weights = [leaf], _FakeCtx(), rucene_amd.BM25Similarity(), 0, {}
+    s._planners, s._stats_terms = {}, None
     s.collection_statistics = rucene_amd.CollectionStatistics("body", 0, seg.max_doc, seg.doc_count, seg.sum_total_term_freq)
     return rucene_amd, seg, leaf, s
 
@@ -80,11 +81,17 @@ def test_byte_terms_go_through_the_dictionary(world, oracle):
                           term_dictionary=ra.TermDictionary(tim, tip, [(0, 2)], seg.max_doc), field_number=0)
     s2 = object.__new__(ra.GpuIndexSearcher)
     s2.leaves, s2.ctx, s2.similarity, s2._stats_leaf, s2._weights = [dleaf], _FakeCtx(), ra.BM25Similarity(), 0, {}
+    s2._planners, s2._stats_terms = {}, None
     s2.collection_statistics = s.collection_statistics
     T, B = ra.TermQuery, ra.BooleanQuery
     by_id = s.pack([T(3), B.build([T(1), T(2)], [T(9)], must_nots=[T(4)])], leaf)
     by_text = s2.pack([T(b"t0003"), B.build([T(b"t0001"), T(b"t0002")], [T(b"t0009")], must_nots=[T(b"t0004")])], dleaf)
     assert by_id[0].tobytes() == by_text[0].tobytes() and by_id[1].tobytes() == by_text[1].tobytes()
+    assert s2._planners                                  # byte-named batches are planned natively too (rgpu_plan_batch_bytes) ...
+    qs = [T(b"t0003"), B.build([T(b"t0001"), T(b"t0002", 2.0)], [T(b"t0009")], must_nots=[T(b"t0004")]), B.build([], [T(b"zz"), T(b"t0007")])]
+    native = s2.pack(qs, dleaf)                           # ... and write what the clause-by-clause path writes
+    by_hand = s2._pack_clause_by_clause(qs, dleaf)
+    assert native[0].tobytes() == by_hand[0].tobytes() and native[1].tobytes() == by_hand[1].tobytes()
     q, t = s2.pack([T(b"nope")], dleaf)
     assert t["state"]["doc_freq"][0] == 0
     with pytest.raises(ra.RgpuError):
@@ -92,8 +99,8 @@ def test_byte_terms_go_through_the_dictionary(world, oracle):
 
 
 def test_array_path_equals_the_general_path(world):
-    """A batch that names every term by a plain int id with boost 1 is packed by array operations (_pack_ids): the structs
-    must be the ones the clause-by-clause path writes, absent and out-of-table ids included."""
+    """A batch that names every term the same way is planned behind the C ABI (rgpu_plan_batch_ids, csrc/host/batch_planner.hpp):
+    the structs must be the ones the clause-by-clause Python path writes, absent and out-of-table ids and boosts included."""
     ra, seg, leaf, s = world
     T, B = ra.TermQuery, ra.BooleanQuery
     rng = np.random.default_rng(5)
@@ -121,7 +128,10 @@ def test_array_path_equals_the_general_path(world):
     general = s.pack(batch(np.int64), leaf)             # numpy scalars are not `int`: the clause-by-clause path
     assert fast[0].tobytes() == general[0].tobytes()
     assert fast[1].tobytes() == general[1].tobytes()
-    assert s._w_memo is not None                        # ... and the first batch did take the array path
+    assert s._planners                                  # ... and the first batch did take the native planner
+    boosted = lambda wrap: [T(wrap(3), 2.5), B.build([T(wrap(1), 0.5), T(wrap(2))], [T(wrap(9), 3.0)], must_nots=[T(wrap(4))]), B.build([], [T(wrap(5)), T(wrap(499), 1.5)])]
+    a, b = s.pack(boosted(int), leaf), s.pack(boosted(np.int64), leaf)
+    assert a[0].tobytes() == b[0].tobytes() and a[1].tobytes() == b[1].tobytes()
 
 
 def test_pack_uniform_equals_pack(world):
