@@ -508,25 +508,26 @@ class GpuIndexSearcher {
       for (const Query* q : queries) pack(*q, leaf, qs, ts);
       return;
     }
-    if (planners_.size() < leaves_.size()) planners_.resize(leaves_.size(), nullptr);
-    if (!planners_[li]) {
+    if (planners_.size() < 2 * leaves_.size()) planners_.resize(2 * leaves_.size(), nullptr);
+    const size_t pi = 2 * li + (any_text ? 1 : 0);  // a leaf may be queried by id and by bytes: one planner each
+    if (!planners_[pi]) {
       rgpu_plan_stats ps{stats_.max_doc, stats_.doc_count, stats_.sum_total_term_freq, sim_.k1(), sim_.b()};
       if (sim_table_ < 0) {  // one field -> one norm cache, shared with the clause-by-clause path
         const TermStatistics none;
         check(sim_table_ = rgpu_sim_table_upload(ctx_, sim_.compute_weight(stats_, &none, 1, 1.0f).cache.data(), sim_.k1()));
       }
-      if (any_text) check(rgpu_planner_create(nullptr, &ps, leaf.dictionary, &sl == &leaf ? nullptr : sl.dictionary, leaf.field_number, &planners_[li]));
-      else check(rgpu_planner_create_flat(nullptr, &ps, leaf.terms, leaf.n_terms, &sl == &leaf ? nullptr : sl.terms, &sl == &leaf ? 0 : sl.n_terms, &planners_[li]));
-      check(rgpu_planner_set_sim_table(planners_[li], sim_table_));
+      if (any_text) check(rgpu_planner_create(nullptr, &ps, leaf.dictionary, &sl == &leaf ? nullptr : sl.dictionary, leaf.field_number, &planners_[pi]));
+      else check(rgpu_planner_create_flat(nullptr, &ps, leaf.terms, leaf.n_terms, &sl == &leaf ? nullptr : sl.terms, &sl == &leaf ? 0 : sl.n_terms, &planners_[pi]));
+      check(rgpu_planner_set_sim_table(planners_[pi], sim_table_));
     }
     qs->resize(queries.size());
     ts->resize(std::max<size_t>(1, ids.size()));
     const int64_t cap = static_cast<int64_t>(ids.size());
     if (any_text)
-      check(rgpu_plan_batch_bytes(planners_[li], static_cast<int32_t>(queries.size()), ops.data(), n_terms.data(), n_not.data(), bytes.data(), offs.data(),
+      check(rgpu_plan_batch_bytes(planners_[pi], static_cast<int32_t>(queries.size()), ops.data(), n_terms.data(), n_not.data(), bytes.data(), offs.data(),
                                   any_boost ? boosts.data() : nullptr, qs->data(), ts->data(), cap));
     else
-      check(rgpu_plan_batch_ids(planners_[li], static_cast<int32_t>(queries.size()), ops.data(), n_terms.data(), n_not.data(), ids.data(),
+      check(rgpu_plan_batch_ids(planners_[pi], static_cast<int32_t>(queries.size()), ops.data(), n_terms.data(), n_not.data(), ids.data(),
                                 any_boost ? boosts.data() : nullptr, qs->data(), ts->data(), cap));
     ts->resize(ids.size());
   }
@@ -570,7 +571,7 @@ class GpuIndexSearcher {
   size_t stats_leaf_ = 0;
   CollectionStatistics stats_;
   int32_t sim_table_ = -1;
-  std::vector<rgpu_planner*> planners_;  // per leaf, created on first use
+  std::vector<rgpu_planner*> planners_;  // per leaf and naming scheme (2 * leaf + by-bytes), created on first use
 };
 
 }  // namespace rucene

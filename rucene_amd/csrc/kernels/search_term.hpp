@@ -288,8 +288,8 @@ __global__ __launch_bounds__(TERM_THREADS, 8) void k_search_term(SegView seg, co
                                                               int32_t* __restrict__ partial_counts,
                                                               unsigned long long* __restrict__ tau_slots,
                                                               unsigned long long* __restrict__ work_slots) {
-  // work_slots (nullable): [0] += encoded bytes of the FullBlocks this launch decoded (+ their norms), [1] += their number —
-  // with block-max pruning that is a small part of the lists ("touched" vs "scan" bytes)
+  // work_slots (nullable): [q] += encoded bytes of the FullBlocks this launch decoded for query q (+ their norms),
+  // [n_queries + q] += their number — with block-max pruning a small part of the lists ("touched" vs "scan" bytes)
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   constexpr int LIST_N = WIDE ? 128 : 64;
   const int lane = lane_id();
@@ -410,9 +410,9 @@ __global__ __launch_bounds__(TERM_THREADS, 8) void k_search_term(SegView seg, co
 
   // the wave of a group that finishes last emits the group's list; the other items emit empty lists
   if (lane == 0) partial_counts[item] = count;
-  if (work_slots != nullptr && lane == 0 && looked != 0u) {
-    atomicAdd(work_slots, (unsigned long long)touched);
-    atomicAdd(work_slots + 1, (unsigned long long)looked);
+  if (work_slots != nullptr && lane == 0 && looked != 0u) {  // per query: one address for the whole launch would serialise thousands of wavefronts
+    atomicAdd(work_slots + q, (unsigned long long)touched);
+    atomicAdd(work_slots + n_queries + q, (unsigned long long)looked);
   }
   uint32_t done = 0;
   if (lane == 0) done = __hip_atomic_fetch_add(remaining + leader, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);

@@ -583,17 +583,11 @@ extern "C" int32_t rgpu_last_search_counters(rgpu_ctx* c, rgpu_search_counters* 
   }
   if (!c->last_counted || c->last_counted_queries <= 0) return RGPU_OK;
   if (c->last_counted->busy) { HIP_TRY(hipEventSynchronize(c->last_counted->done)); c->last_counted->busy = false; }
-  if (c->last_counted_op == RGPU_OP_TERM) {
-    unsigned long long h[2] = {0, 0};
-    HIP_TRY(hipMemcpy(h, c->last_counted->d_touched.p, 16, hipMemcpyDeviceToHost));
-    out->blocks_decoded = (int64_t)h[1];
-    out->touched_bytes = (int64_t)h[0] + 14 * c->last_counted_dir_blocks;
-  } else {
-    const size_t nq = (size_t)c->last_counted_queries;
-    std::vector<unsigned long long> h(nq * 2);
-    HIP_TRY(hipMemcpy(h.data(), c->last_counted->d_touched.p, nq * 16, hipMemcpyDeviceToHost));
-    for (size_t q = 0; q < nq; ++q) { out->touched_bytes += (int64_t)h[q]; out->blocks_decoded += (int64_t)h[nq + q]; }
-  }
+  const size_t nq = (size_t)c->last_counted_queries;
+  std::vector<unsigned long long> h(nq * 2);
+  HIP_TRY(hipMemcpy(h.data(), c->last_counted->d_touched.p, nq * 16, hipMemcpyDeviceToHost));
+  for (size_t q = 0; q < nq; ++q) { out->touched_bytes += (int64_t)h[q]; out->blocks_decoded += (int64_t)h[nq + q]; }
+  if (c->last_counted_op == RGPU_OP_TERM) out->touched_bytes += 14 * c->last_counted_dir_blocks;
   out->postings_decoded = 128 * out->blocks_decoded + c->last_counted_loose;
   return RGPU_OK;
 }
@@ -1431,8 +1425,8 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
         else { if (wide) go(k_search_and<false, true, false, false>); else go(k_search_and<false, false, false, false>); }
       }
     } else if (op == RGPU_OP_TERM) {
-      HIP_TRY(c->S->d_touched.reserve(2, 0, stream));
-      HIP_TRY(hipMemsetAsync(c->S->d_touched.p, 0, 16, stream));
+      HIP_TRY(c->S->d_touched.reserve((size_t)nq * 2, 0, stream));
+      HIP_TRY(hipMemsetAsync(c->S->d_touched.p, 0, (size_t)nq * 16, stream));
       c->last_counted = c->S;
       c->last_counted_op = RGPU_OP_TERM;
       c->last_counted_queries = nq;

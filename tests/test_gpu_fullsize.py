@@ -21,7 +21,9 @@ def full():
     ctx = rucene_amd.Context()
     leaf = rucene_amd.LeafReader.from_synthetic(seg)
     searcher = rucene_amd.GpuIndexSearcher([leaf], ctx=ctx)
-    yield rucene_amd, seg, (lambda st: leaf.segment.decode_terms(st)), (lambda qs, k: searcher.search_batch(qs, k))
+    search = lambda qs, k: searcher.search_batch(qs, k)
+    search.ctx = ctx
+    yield rucene_amd, seg, (lambda st: leaf.segment.decode_terms(st)), search
     ctx.close()
 
 
@@ -83,6 +85,18 @@ def _against_oracle(full, oracle, kind, n, k):
 
 def test_single_term_batch_equals_the_oracle_at_full_size(full, oracle):
     _against_oracle(full, oracle, "term", 1024, 10)
+
+
+def test_pruned_term_batch_decodes_a_fraction_of_what_it_covers(full):
+    """rgpu_last_search_counters at BASELINE size: the block-max frontier lets k_search_term leave most FullBlocks packed
+    (bench.py's postings_decoded_per_sec is this figure, not the postings the queries cover)."""
+    rucene_amd, seg, decode, search = full
+    tids = _bench_queries("term", 1024)
+    search([rucene_amd.TermQuery(int(t[0])) for t in tids], 10)
+    c = search.ctx.last_search_counters()
+    full_blocks = int((seg.terms["doc_freq"][tids.reshape(-1)] // 128).sum())
+    assert c["postings_covered"] == int(seg.terms["doc_freq"][tids.reshape(-1)].sum())
+    assert 0 < c["blocks_decoded"] < full_blocks // 5 and c["postings_decoded"] < c["postings_covered"] // 5
 
 
 def test_conjunction_sample_equals_the_oracle_at_full_size(full, oracle):
