@@ -166,8 +166,10 @@ int32_t rgpu_segment_version(const rgpu_segment* seg); /* .doc format version (0
 /* Skip-list decode (Lucene50SkipReader::init/load_skip_levels/read_skip_data, skip_reader.rs:315-511):
  * decodes each term's level-0 skip entries on the GPU into a flat per-term block directory
  * {last doc id, file offset, header bytes} cached in HBM for the life of the segment — the GPU analogue
- * of opening a term's skipper. Called implicitly by every entry point below for terms it has not seen;
- * exposed so a caller can pay it at segment-open time. */
+ * of opening a term's skipper — and re-lays the term's blocks as 16-byte aligned rows (stage A: all a decode needs);
+ * then, for scoring, gathers the norm byte of every posting in posting order and bounds every block's best score
+ * (stage B). Called implicitly by every entry point below for terms it has not seen (rgpu_decode_terms* and
+ * rgpu_advance_batch: stage A only); exposed so a caller can pay both stages at segment-open time. */
 int32_t rgpu_segment_prepare_terms(rgpu_segment* seg, const rgpu_term_state* terms, int64_t n_terms);
 /* The per-term structures (directory, 16-byte aligned block copies, posting-order norms: about the term's share of the
  * .doc file again plus 1 byte per posting) are kept for every distinct term ever queried, for the life of the segment;

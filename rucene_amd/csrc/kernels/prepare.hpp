@@ -1,50 +1,48 @@
-// Term preparation on the GPU, two launches: k_prepare_terms — one workgroup per term turns the term's level-0 skip
-// entries into a flat block directory {last doc id, byte offset, header word, store row} in HBM; k_prepare_blocks —
-// one wavefront per chunk of blocks copies the FullBlock payloads into the 16-byte aligned block store and lays the
-// docs' norms out in posting order. GPU counterpart of (paths relative to
-// /root/reference/src/core):
+// Term preparation on the GPU: from the reference's bytes (.doc: level-0 skip entries, block framing, VInt tails) to what
+// the query kernels read (block directory, 16-byte aligned block store, decoded tails) — stage A, everything a DECODE needs
+// — and, only for terms that get scored, posting-order norms + block-max frontier words — stage B. GPU counterpart of
+// (paths relative to /root/reference/src/core):
 //   codec/postings/skip_reader.rs:460-511   load_skip_levels  (vlong length + bytes for levels L-1..1, then level 0)
 //   codec/postings/skip_reader.rs:431-453   read_skip_data    (vint docDelta, vlong docFpDelta per entry)
 //   codec/postings/skip_reader.rs:513-539   load_next_skip    (the running sums skip_doc / doc_pointer)
 //   codec/postings/for_util.rs:196-223      block header byte (encode type, num_bits, all-equal vint)
-// The higher skip levels are subsampled copies of level 0 with child pointers; a flat level-0 directory plus
-// binary search gives the same `advance` answers, so only their byte lengths are parsed (to find level 0).
+//   codec/postings/posting_reader.rs:308-333 read_vint_block  (the tail)
+// The higher skip levels are subsampled copies of level 0 with child pointers; a flat level-0 directory plus binary
+// search gives the same `advance` answers, so only their byte lengths are parsed (to find level 0).
 //
-// VInt streams are decoded data-parallel: each thread inspects 4 bytes, a workgroup scan over terminator
-// counts yields each value's index, and the thread owning a terminator assembles the value by looking back
-// over its continuation bytes.
+// Stage A is four launches, each spread over the whole chip whatever the terms' sizes (round 2 walked a term's skip data
+// and block headers with ONE workgroup: 3.4 ms for the 20 M-posting head term of the 100 M-doc shard, whatever else ran):
+//   k_skip_dir       one wavefront per 1 KB of level-0 bytes: parallel VInt parse; a chunk's position in the value stream
+//                    and the running sums before it come from the chunks in front of it (each publishes {count, sums}; a
+//                    ticket hands chunks out in order, so a chunk only ever waits for wavefronts that are already running)
+//   k_block_headers  one lane per block: header bytes -> directory header word + the block's rows in the store; every skip
+//                    pointer checked against the block sizes
+//   k_scan_*         exclusive prefix sum of the row counts -> each block's place in the store (one dense region per call)
+//   k_prepare_blocks one wavefront per 32 blocks: the block's byte-misaligned span is staged in LDS with ALIGNED 16-byte
+//                    loads (each file byte fetched once; byte-misaligned dwordx4 loads run at a third of the rate and
+//                    over-fetch a KB per block) and leaves as aligned rows; every block is decoded once and validated;
+//                    EF / BITSET blocks are re-packed; the term's VInt tail is decoded into 16-byte cells
+// Stage B (k_prepare_norms) decodes the blocks again from the store and gathers each posting's norm byte — one cache line
+// per posting for a sparse term: 17-35 x the file's size in fetches on the 100 M-doc shard, which is why it no longer
+// rides on every first touch of a term: a materialising decode (rgpu_decode_terms, rgpu_advance_batch) never pays it.
 #pragma once
-#include "decode.hpp"
+#include "decode_terms.hpp"
 #include "types.hpp"
 
 namespace rgpu {
 
 constexpr int PREP_THREADS = 256;
+constexpr int PREP_WAVES = PREP_THREADS / 64;
+constexpr int SKIP_CHUNK_BYTES = 1024;     // level-0 bytes per wavefront (16 per lane)
+constexpr int PREP_BLOCKS_PER_ITEM = 32;
+constexpr int SCAN_TILE = 2048;            // row counts per workgroup of the prefix sum (8 per thread)
 
 // err[0] = the most severe status (rgpu_status, or -101 "plan again with worst-case rows"), err[1] = the highest-numbered
-// check that failed — which of this file's consistency checks it was ends up in the host's error message
+// check that failed — which of this file's consistency checks it was ends up in the host's error message; err[2] = some
+// block of the call is EF / BITSET encoded
 __device__ __forceinline__ void flag_err(int* err, int status, int site) {
   atomicMin(err, status);
   atomicMax(err + 1, site);
-}
-
-// workgroup exclusive scan for PREP_THREADS threads; `total` is uniform on return
-__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* wave_sums, uint32_t& total) {
-  const int lane = lane_id();
-  const int wave = wave_id();
-  const uint32_t incl = (uint32_t)wave_incl_scan((int)v);
-  __syncthreads();  // protect wave_sums reuse
-  if (lane == 63) wave_sums[wave] = incl;
-  __syncthreads();
-  uint32_t off = 0, tot = 0;
-#pragma unroll
-  for (int w = 0; w < PREP_THREADS / 64; ++w) {
-    const uint32_t s = wave_sums[w];
-    if (w < wave) off += s;
-    tot += s;
-  }
-  total = tot;
-  return off + incl - v;
 }
 
 __device__ __forceinline__ uint64_t read_vlong_serial(const uint8_t* p, int* len) {
@@ -65,171 +63,307 @@ __device__ __forceinline__ int vint_len_serial(const uint8_t* p) {
   return i + 1;
 }
 
-template <bool LEGACY>
-__global__ __launch_bounds__(PREP_THREADS) void k_prepare_terms(const uint8_t* __restrict__ doc, int64_t doc_len,
-                                                                 const PrepTerm* __restrict__ terms, int32_t* dir_last,
-                                                                 uint32_t* dir_off, uint32_t* dir_row, uint16_t* dir_hdr,
-                                                                 uint64_t* dir_pos, int has_freqs, int* err) {
-  const PrepTerm t = terms[blockIdx.x];
-  const int tid = (int)threadIdx.x;
-  __shared__ uint32_t s_ws[PREP_THREADS / 64];
-  __shared__ int64_t s_l0;
-  __shared__ int s_nonpf;  // some block of this term is EF / BITSET encoded
-  if (tid == 0) s_nonpf = 0;
-  __syncthreads();
+// ---- A1: level-0 skip entries -> dir_last / dir_off (/ dir_pos) ------------------------------------------------------------
+// What a chunk tells the chunks behind it: how many VInt values END inside it and their sums by LOCAL residue (index inside
+// the chunk modulo the values per entry: 2 = {docDelta, docFpDelta}, 4 with positions: + {posFpDelta, posBufferUpto}). Which
+// field a residue is depends on how many values precede the chunk, known once the chunks in front have published.
+struct SkipAgg {
+  uint32_t count;
+  uint32_t ready;  // written last (release)
+  uint32_t sum[4];
+  uint32_t pad[2];
+};
+static_assert(sizeof(SkipAgg) == 32, "one aggregate per 32 bytes");
 
-  if (t.n_entries > 0) {
-    // ---- where does level 0 start? (skip_reader.rs:481-509)
-    if (tid == 0) {
-      int64_t p = t.skip_fp;
-      for (int lvl = t.n_levels - 1; lvl >= 1; --lvl) {
-        int n;
-        uint64_t len = read_vlong_serial(doc + p, &n);
-        p += n + (int64_t)len;
-        if (p >= doc_len) { flag_err(err, -4, 1); p = t.skip_fp; break; }
-      }
-      s_l0 = p;
+// bytes a level-0 entry can take: vint docDelta <= 5, vlong docFpDelta (a block is < 16 KiB) <= 3; positions: + vlong
+// posFpDelta <= 9, vint posBufferUpto (< 128) 1
+__host__ __device__ constexpr int skip_entry_max_bytes(bool positions) { return positions ? 18 : 8; }
+__host__ __device__ inline int64_t skip_chunks(int32_t n_entries, bool positions) {
+  return n_entries <= 0 ? 1 : ((int64_t)n_entries * skip_entry_max_bytes(positions) + SKIP_CHUNK_BYTES - 1) / SKIP_CHUNK_BYTES;
+}
+
+__device__ __forceinline__ uint32_t pick4(const uint32_t (&v)[4], uint32_t i) {  // v[i & 3] without a register-array index
+  const uint32_t lo = (i & 1u) ? v[1] : v[0], hi = (i & 1u) ? v[3] : v[2];
+  return (i & 2u) ? hi : lo;
+}
+
+__global__ __launch_bounds__(PREP_THREADS) void k_skip_dir(const uint8_t* __restrict__ doc, int64_t doc_len, int64_t doc_cap,
+                                                           const PrepTerm* __restrict__ terms, const int64_t* __restrict__ chunk_prefix,
+                                                           int n_terms, int64_t n_chunks, SkipAgg* aggs, unsigned long long* ticket,
+                                                           int32_t* dir_last, uint32_t* dir_off, uint64_t* dir_pos, int* err) {
+  __shared__ __attribute__((aligned(16))) uint8_t stage[PREP_WAVES][16 + SKIP_CHUNK_BYTES];
+  const int lane = lane_id();
+  const int wave = wave_id();
+  // chunks are handed out in order: whoever holds chunk i knows that every chunk < i is held by a running (or finished) wavefront
+  unsigned long long tk = 0;
+  if (lane == 0) tk = atomicAdd(ticket, 1ull);
+  const int64_t item = (int64_t)(((uint64_t)(uint32_t)readfirstlane((int)(uint32_t)(tk >> 32)) << 32) | (uint32_t)readfirstlane((int)(uint32_t)tk));
+  if (item >= n_chunks) return;
+  const int t = upper_slot(chunk_prefix, n_terms, item);
+  const int c = (int)(item - chunk_prefix[t]);
+  const int n_mine = (int)(chunk_prefix[t + 1] - chunk_prefix[t]);
+  const PrepTerm T = terms[t];
+  const uint32_t vals = dir_pos ? 4u : 2u, vm = vals - 1u;
+  const uint32_t need = vals * (uint32_t)T.n_entries;
+  SkipAgg* const mine = aggs + item;
+  auto publish = [&](uint32_t count, uint32_t s0, uint32_t s1, uint32_t s2, uint32_t s3) {
+    if (lane == 0) {
+      mine->count = count;
+      mine->sum[0] = s0; mine->sum[1] = s1; mine->sum[2] = s2; mine->sum[3] = s3;
+      __hip_atomic_store(&mine->ready, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __syncthreads();
-    const uint8_t* l0 = doc + s_l0;
-    const int64_t l0_room = doc_len - s_l0;  // bytes of the file from level 0 on (the device copy is padded by 8 KiB of zeros)
-    // ---- parallel VInt decode of the level-0 entries: docDelta (vint), docFpDelta (vlong) and, for a positions field
-    // (dir_pos != null; skip_writer.rs:261-289), posFpDelta (vlong), posBufferUpto (vint)
-    const uint32_t vals = dir_pos ? 4u : 2u;
-    const uint32_t need = vals * (uint32_t)t.n_entries;
-    uint32_t done = 0;
-    int64_t chunk = 0;
-    while (done < need) {
-      const int64_t my = chunk + 16 * tid;  // 16 bytes per thread, 4 KiB per round (a 2 M-posting term has ~80 KB of level 0)
-      if (chunk >= l0_room) { if (tid == 0) flag_err(err, -4, 2); break; }  // ran off the file looking for skip entries (uniform)
-      const uint4 w4 = load16_unaligned(l0 + my);
-      const uint32_t ws[4] = {w4.x, w4.y, w4.z, w4.w};
-      uint32_t term = 0;
-#pragma unroll
-      for (int j = 0; j < 16; ++j) term |= (((ws[j >> 2] >> (8 * (j & 3) + 7)) & 1u) ^ 1u) << j;
-      uint32_t total;
-      uint32_t vi = done + block_excl_scan((uint32_t)__popc(term), s_ws, total);
-      while (term) {
-        const int j = __builtin_ctz(term);
-        term &= term - 1;
-        int64_t p = my + j;
-        uint64_t v = l0[p];
-        for (int back = 0; back < 9 && p > 0 && (l0[p - 1] & 0x80); ++back) {
-          --p;
-          v = (v << 7) | (uint64_t)(l0[p] & 0x7f);
-        }
-        if (vi < need) {
-          const uint32_t e = vi / vals, f = vi % vals;
-          if (f == 0) dir_last[t.dir_base + e] = (int32_t)v;
-          else if (f == 1) dir_off[t.dir_base + e + 1] = (uint32_t)v;
-          else reinterpret_cast<uint32_t*>(dir_pos + t.dir_base + e + 1)[f - 2] = (uint32_t)v;  // [0] posFpDelta, [1] upto
-        }
-        ++vi;
-      }
-      if (total == 0) { if (tid == 0) flag_err(err, -4, 3); break; }  // 4 KiB without a terminator: corrupt
-      done += total;
-      chunk += 16 * PREP_THREADS;
-    }
-    __syncthreads();
-    // ---- deltas -> running sums (skip_doc[0] += delta ; doc_pointer[0] += delta, skip_reader.rs:530, 434)
-    uint32_t carry_doc = 0, carry_off = 0, carry_pos = 0;
-    for (int e0 = 0; e0 < t.n_entries; e0 += PREP_THREADS) {
-      const int e = e0 + tid;
-      const bool ok = e < t.n_entries;
-      const uint32_t dd = ok ? (uint32_t)dir_last[t.dir_base + e] : 0u;
-      const uint32_t fo = ok ? dir_off[t.dir_base + e + 1] : 0u;
-      uint32_t tot_d, tot_o;
-      const uint32_t sd = block_excl_scan(dd, s_ws, tot_d) + dd + carry_doc;
-      const uint32_t so = block_excl_scan(fo, s_ws, tot_o) + fo + carry_off;
-      if (ok) {
-        dir_last[t.dir_base + e] = (int32_t)sd;
-        dir_off[t.dir_base + e + 1] = so;
-      }
-      carry_doc += tot_d;
-      carry_off += tot_o;
-      if (dir_pos) {  // uniform: the position pointer is a running sum too, the buffered count is absolute
-        uint32_t* pp = reinterpret_cast<uint32_t*>(dir_pos + t.dir_base + e + 1);
-        const uint32_t po = ok ? pp[0] : 0u;
-        uint32_t tot_p;
-        const uint32_t sp = block_excl_scan(po, s_ws, tot_p) + po + carry_pos;
-        if (ok) { pp[0] = sp; if (pp[1] >= 128u) flag_err(err, -4, 4); }
-        carry_pos += tot_p;
-      }
-    }
+  };
+  if (c == 0 && lane == 0) {
+    dir_off[T.dir_base] = 0;
+    if (dir_pos) dir_pos[T.dir_base] = 0ull;
+    if (T.nblocks > T.n_entries && T.nblocks > 0) dir_last[T.dir_base + T.nblocks - 1] = DIR_SENTINEL_DOC;  // df % 128 == 0
   }
-  if (tid == 0) {
-    if (dir_pos) dir_pos[t.dir_base] = 0ull;
-    dir_off[t.dir_base] = 0;
-    if (t.nblocks > t.n_entries) dir_last[t.dir_base + t.nblocks - 1] = DIR_SENTINEL_DOC;  // df % 128 == 0
+  if (T.n_entries <= 0) { publish(0, 0, 0, 0, 0); return; }
+  // ---- where does level 0 start? (skip_reader.rs:481-509; uniform: every lane reads the same bytes)
+  int64_t l0 = T.skip_fp;
+  bool lost = false;
+  for (int lvl = T.n_levels - 1; lvl >= 1; --lvl) {
+    int n;
+    const uint64_t len = read_vlong_serial(doc + l0, &n);
+    l0 += n + (int64_t)len;
+    if (l0 >= doc_len) { lost = true; break; }
   }
-  __syncthreads();
-  // ---- block headers (for_util.rs:196-223) + consistency of every skip pointer with the block sizes
-  for (int i = tid; i < t.nblocks; i += PREP_THREADS) {
-    const uint32_t off = dir_off[t.dir_base + i];
-    // offsets are running sums of deltas nobody has checked yet: a block (<= 2 + 2 * 512 bytes) must start inside the file
-    if ((uint64_t)t.start_fp + (uint64_t)off + 1030u > (uint64_t)doc_len + 4096u) { flag_err(err, -4, 5); dir_hdr[t.dir_base + i] = 0; continue; }
-    const uint8_t* p = doc + t.start_fp + off;
-    const uint32_t h = p[0];
-    int bd = (int)(h & 63);
-    int vlen = 0;
-    const int etype = (int)(h >> 6);
-    int doc_sz = 16 * bd;
-    uint32_t flag = 0;
-    if (etype != 0) {  // EF / BITSET doc block (decode.hpp): sized here, decoded and re-packed by k_prepare_blocks
-      if (etype == 3 || LEGACY) flag_err(err, -5, 6);  // FULL is unimplemented in the reference; EF + the legacy layout: not served
-      doc_sz = etype == 3 ? 0 : nonpf_doc_bytes(p, etype);
-      if (doc_sz < 0) { flag_err(err, -4, 7); doc_sz = 0; }
-      bd = 32;       // doc rows reserved in the block store
-      vlen = etype;  // the vint-length field is free in a flagged word
-      flag = HDR_NONPF;
-      s_nonpf = 1;
-    } else {
-      if (bd > 32) flag_err(err, -4, 8);
-      if (bd == 0) { vlen = vint_len_serial(p + 1); doc_sz = vlen; }
-    }
-    // the freq block (absent for IndexOptions::Docs: posting_writer.rs:334-351 writes it only when the field has freqs;
-    // the directory then says "all-equal freq stream" and the block store supplies the value 1)
-    int bf = 0;
-    uint32_t end = off + 1u + (uint32_t)doc_sz;
-    if (has_freqs) {
-      const uint32_t h2 = p[1 + doc_sz];
-      bf = (int)(h2 & 63);
-      if (bf > 32) flag_err(err, -4, 9);
-      const int freq_sz = bf ? 16 * bf : vint_len_serial(p + 1 + doc_sz + 1);
-      end += 1u + (uint32_t)freq_sz;
-    }
-    if (i < t.n_entries && end != dir_off[t.dir_base + i + 1]) flag_err(err, -4, 10);
-    if (i > 0 && i < t.n_entries && dir_last[t.dir_base + i] <= dir_last[t.dir_base + i - 1]) flag_err(err, -4, 11);
-    dir_hdr[t.dir_base + i] = (uint16_t)((uint32_t)bd | ((uint32_t)vlen << 6) | ((uint32_t)bf << 9) | flag);
-  }
-  __syncthreads();
-  // ---- block store rows: block i takes max(b_doc,1) + max(b_freq,1) rows; exclusive prefix sum over the blocks
-  uint32_t carry_rows = 0;
-  for (int i0 = 0; i0 < t.nblocks; i0 += PREP_THREADS) {
-    const int i = i0 + tid;
-    const bool ok = i < t.nblocks;
-    const uint32_t h = ok ? (uint32_t)dir_hdr[t.dir_base + i] : 0u;
-    const uint32_t r = ok ? (uint32_t)(store_doc_rows(h) + store_freq_rows(h)) : 0u;
-    uint32_t tot;
-    const uint32_t at = block_excl_scan(r, s_ws, tot) + carry_rows;
-    if (ok) dir_row[t.dir_base + i] = at;
-    carry_rows += tot;
-  }
-  if (tid == 0) dir_row[t.dir_base + t.nblocks] = carry_rows;  // where the term's decoded tail goes (k_prepare_blocks)
-  const uint32_t tail_rows = (t.df > 1 && t.df % 128 != 0) ? (uint32_t)TAIL_STORE_ROWS : 0u;
-  if (carry_rows + tail_rows > t.bs_rows) {
-    // more rows than the framing the host sized the store from: corrupt — unless the term has EF / BITSET blocks, whose
-    // re-packed deltas may outgrow their file bytes: -101 asks the host to plan this call again with worst-case sizes
-    if (tid == 0) flag_err(err, s_nonpf ? -101 : -4, 12);
+  if (lost) {
+    if (lane == 0 && c == 0) flag_err(err, -4, 1);
+    publish(0, 0, 0, 0, 0);
     return;
+  }
+  // ---- this chunk's bytes (and the 16 in front of it: a value may begin there) into LDS
+  const int64_t at = l0 + (int64_t)SKIP_CHUNK_BYTES * c;
+  uint8_t* const st = stage[wave];
+  uint4 w4 = make_uint4(0u, 0u, 0u, 0u);
+  if (at + 16 * lane + 16 <= doc_cap) w4 = load16_unaligned(doc + at + 16 * lane);  // (the device copy is zero-padded past doc_len)
+  *reinterpret_cast<uint4*>(st + 16 + 16 * lane) = w4;
+  if (lane == 0) {
+    uint4 pre = make_uint4(0u, 0u, 0u, 0u);  // chunk 0: level 0 starts here — nothing in front of it continues into it
+    if (c > 0) pre = load16_unaligned(doc + at - 16);
+    *reinterpret_cast<uint4*>(st) = pre;
+  }
+  wave_sync();
+  const uint32_t ws[4] = {w4.x, w4.y, w4.z, w4.w};
+  uint32_t term = 0;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) term |= (((ws[j >> 2] >> (8 * (j & 3) + 7)) & 1u) ^ 1u) << j;
+  const int cnt = __popc(term);
+  const int incl = wave_incl_scan(cnt);
+  const uint32_t total = (uint32_t)readlane(incl, 63);
+  const uint32_t li0 = (uint32_t)(incl - cnt);  // local index of this lane's first value
+  // the value whose terminator is byte j of this lane's 16: look back over its continuation bytes (vlongs: the low 32 bits
+  // are kept, like the reference's `as i32` / u32 pointers of a < 4 GiB term)
+  auto value_at = [&](int j) -> uint32_t {
+    int p = 16 + 16 * lane + j;
+    uint64_t v = st[p];
+    for (int back = 0; back < 9 && p > 0 && (st[p - 1] & 0x80); ++back) {
+      --p;
+      v = (v << 7) | (uint64_t)(st[p] & 0x7f);
+    }
+    return (uint32_t)v;
+  };
+  // ---- pass 1: sums by local residue
+  uint32_t sl[4] = {0u, 0u, 0u, 0u};
+  {
+    uint32_t m = term, li = li0;
+    while (m) {
+      const int j = __builtin_ctz(m);
+      m &= m - 1;
+      const uint32_t v = value_at(j), r = li & vm;
+      sl[0] += r == 0u ? v : 0u; sl[1] += r == 1u ? v : 0u; sl[2] += r == 2u ? v : 0u; sl[3] += r == 3u ? v : 0u;
+      ++li;
+    }
+  }
+  publish(total, (uint32_t)wave_reduce_add((int)sl[0]), (uint32_t)wave_reduce_add((int)sl[1]), (uint32_t)wave_reduce_add((int)sl[2]),
+          (uint32_t)wave_reduce_add((int)sl[3]));
+  // ---- the chunks in front of this one, front to back: values before this chunk (P) and the running sums by field
+  uint32_t P = 0;
+  uint32_t base[4] = {0u, 0u, 0u, 0u};
+  for (int j0 = 0; j0 < c; j0 += 64) {
+    const int j = j0 + lane;
+    uint32_t cj = 0, sj[4] = {0u, 0u, 0u, 0u};
+    if (j < c) {
+      SkipAgg* a = aggs + (item - c + j);
+      while (__hip_atomic_load(&a->ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(2);
+      cj = a->count;
+      sj[0] = a->sum[0]; sj[1] = a->sum[1]; sj[2] = a->sum[2]; sj[3] = a->sum[3];
+    }
+    const uint32_t inc = (uint32_t)wave_incl_scan((int)cj);
+    const uint32_t Pj = P + inc - cj;  // values before chunk j: its local residue r is field (Pj + r) mod vals
+#pragma unroll
+    for (uint32_t f = 0; f < 4; ++f) base[f] += (uint32_t)wave_reduce_add((int)(f < vals ? pick4(sj, (f - Pj) & vm) : 0u));
+    P += (uint32_t)readlane((int)inc, 63);
+  }
+  if (c == n_mine - 1 && P + total < need && lane == 0) flag_err(err, -4, 2);  // ran off the skip data looking for entries
+  // ---- pass 2: every value's running sum -> the directory
+  uint32_t run[4];
+  {
+    // this lane's sums by FIELD, then the lanes in front of it
+    uint32_t lf[4];
+#pragma unroll
+    for (uint32_t f = 0; f < 4; ++f) lf[f] = f < vals ? pick4(sl, (f - P) & vm) : 0u;
+#pragma unroll
+    for (uint32_t f = 0; f < 4; ++f) run[f] = base[f] + (uint32_t)wave_incl_scan((int)lf[f]) - lf[f];
+  }
+  uint32_t m = term, g = P + li0;
+  while (m) {
+    const int j = __builtin_ctz(m);
+    m &= m - 1;
+    const uint32_t v = value_at(j), f = g & vm;
+    run[0] += f == 0u ? v : 0u; run[1] += f == 1u ? v : 0u; run[2] += f == 2u ? v : 0u;
+    if (g < need) {
+      const uint32_t e = g / vals;
+      if (f == 0u) dir_last[T.dir_base + e] = (int32_t)run[0];             // skip_doc += delta (skip_reader.rs:530)
+      else if (f == 1u) dir_off[T.dir_base + e + 1] = run[1];             // doc_pointer += delta (:434)
+      else if (f == 2u) reinterpret_cast<uint32_t*>(dir_pos + T.dir_base + e + 1)[0] = run[2];  // pos_pointer += delta
+      else { reinterpret_cast<uint32_t*>(dir_pos + T.dir_base + e + 1)[1] = v; if (v >= 128u) flag_err(err, -4, 4); }  // posBufferUpto: absolute
+    }
+    ++g;
   }
 }
 
-// Second half of term preparation, spread over the whole GPU (a 2 M-posting term has 15 k blocks: far too many for the
-// four wavefronts of its directory workgroup). Items = (term, chunk of PREP_BLOCKS_PER_ITEM blocks), one wavefront
-// each: copy the payload rows into the block store, then — with norms — decode the block from those rows and gather
-// its docs' norm bytes in posting order (SegView::pnorm).
-constexpr int PREP_BLOCKS_PER_ITEM = 32;
+// ---- A2: block headers (for_util.rs:196-223) + consistency of every skip pointer with the block sizes ------------------------
+// items = (term, chunk of PREP_BLOCKS_PER_ITEM blocks), one wavefront each, lane j < 32 takes block b0 + j; the term's last
+// item also sizes the tail's cells. Leaves the block's ROW COUNT in dir_row (k_scan_* turn counts into positions).
+template <bool LEGACY>
+__global__ __launch_bounds__(PREP_THREADS) void k_block_headers(const uint8_t* __restrict__ doc, int64_t doc_len,
+                                                                const PrepTerm* __restrict__ terms, const int64_t* __restrict__ item_prefix,
+                                                                int n_terms, int64_t n_items, const int32_t* __restrict__ dir_last,
+                                                                const uint32_t* __restrict__ dir_off, uint32_t* dir_row, uint16_t* dir_hdr,
+                                                                int has_freqs, int* err) {
+  const int lane = lane_id();
+  const int64_t item = (int64_t)blockIdx.x * PREP_WAVES + wave_id();
+  if (item >= n_items) return;
+  const int ti = upper_slot(item_prefix, n_terms, item);
+  const PrepTerm t = terms[ti];
+  const int b0 = (int)(item - item_prefix[ti]) * PREP_BLOCKS_PER_ITEM;
+  const int i = b0 + lane;
+  if (lane == 32 && b0 + PREP_BLOCKS_PER_ITEM >= t.nblocks)  // where the term's decoded tail goes
+    dir_row[t.dir_base + t.nblocks] = (t.df > 1 && t.df % 128 != 0) ? (uint32_t)TAIL_STORE_ROWS : 0u;
+  if (lane >= PREP_BLOCKS_PER_ITEM || i >= t.nblocks) return;
+  const uint32_t off = dir_off[t.dir_base + i];
+  // offsets are running sums of deltas nobody has checked yet: a block (<= 2 + 2 * 512 bytes) must start inside the file
+  if ((uint64_t)t.start_fp + (uint64_t)off + 1030u > (uint64_t)doc_len + 4096u) {
+    flag_err(err, -4, 5);
+    dir_hdr[t.dir_base + i] = 0;
+    dir_row[t.dir_base + i] = 2u;
+    return;
+  }
+  const uint8_t* p = doc + t.start_fp + off;
+  const uint32_t h = p[0];
+  int bd = (int)(h & 63);
+  int vlen = 0;
+  const int etype = (int)(h >> 6);
+  int doc_sz = 16 * bd;
+  uint32_t flag = 0;
+  if (etype != 0) {  // EF / BITSET doc block (decode.hpp): sized here, decoded and re-packed by k_prepare_blocks
+    if (etype == 3 || LEGACY) flag_err(err, -5, 6);  // FULL is unimplemented in the reference; EF + the legacy layout: not served
+    doc_sz = etype == 3 ? 0 : nonpf_doc_bytes(p, etype);
+    if (doc_sz < 0) { flag_err(err, -4, 7); doc_sz = 0; }
+    bd = 32;       // doc rows reserved in the block store
+    vlen = etype;  // the vint-length field is free in a flagged word
+    flag = HDR_NONPF;
+    atomicMax(err + 2, 1);
+  } else {
+    if (bd > 32) { flag_err(err, -4, 8); bd = 32; doc_sz = 512; }
+    if (bd == 0) { vlen = vint_len_serial(p + 1); doc_sz = vlen; }
+  }
+  // the freq block (absent for IndexOptions::Docs: posting_writer.rs:334-351 writes it only when the field has freqs;
+  // the directory then says "all-equal freq stream" and the block store supplies the value 1)
+  int bf = 0;
+  uint32_t end = off + 1u + (uint32_t)doc_sz;
+  if (has_freqs) {
+    const uint32_t h2 = p[1 + doc_sz];
+    bf = (int)(h2 & 63);
+    if (bf > 32) { flag_err(err, -4, 9); bf = 32; }
+    const int freq_sz = bf ? 16 * bf : vint_len_serial(p + 1 + doc_sz + 1);
+    end += 1u + (uint32_t)freq_sz;
+  }
+  if (i < t.n_entries && end != dir_off[t.dir_base + i + 1]) flag_err(err, -4, 10);
+  if (i > 0 && i < t.n_entries && dir_last[t.dir_base + i] <= dir_last[t.dir_base + i - 1]) flag_err(err, -4, 11);
+  const uint32_t hdr = (uint32_t)bd | ((uint32_t)vlen << 6) | ((uint32_t)bf << 9) | flag;
+  dir_hdr[t.dir_base + i] = (uint16_t)hdr;
+  dir_row[t.dir_base + i] = (uint32_t)(store_doc_rows(hdr) + store_freq_rows(hdr));
+}
+
+// ---- A3: exclusive prefix sum of the row counts of one call's directory slots -------------------------------------------------
+// (reduce per tile, scan the tile sums in one workgroup, scan inside the tiles) — rows are positions in ONE dense region
+// of the block store per call, relative to its first byte (PrepTerm::bs_base is that byte for every term of the call)
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* wave_sums, uint32_t& total) {
+  const int lane = lane_id();
+  const int wave = wave_id();
+  const uint32_t incl = (uint32_t)wave_incl_scan((int)v);
+  __syncthreads();  // protect wave_sums reuse
+  if (lane == 63) wave_sums[wave] = incl;
+  __syncthreads();
+  uint32_t off = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < PREP_WAVES; ++w) {
+    const uint32_t s = wave_sums[w];
+    if (w < wave) off += s;
+    tot += s;
+  }
+  total = tot;
+  return off + incl - v;
+}
+__global__ __launch_bounds__(PREP_THREADS) void k_scan_reduce(const uint32_t* __restrict__ v, int64_t n, unsigned long long* tile_sums) {
+  __shared__ uint32_t s_ws[PREP_WAVES];
+  const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + 8 * (int64_t)threadIdx.x;
+  uint32_t mine = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) mine += base + j < n ? v[base + j] : 0u;
+  uint32_t tot;
+  (void)block_excl_scan(mine, s_ws, tot);
+  if (threadIdx.x == 0) tile_sums[blockIdx.x] = tot;
+}
+// tile sums -> exclusive; out2[0] = the call's total rows. cap_rows = rows the host reserved: more than that is corrupt
+// framing — or EF / BITSET blocks whose re-packed deltas outgrow their file bytes: -101 asks for a worst-case plan
+__global__ __launch_bounds__(PREP_THREADS) void k_scan_tiles(unsigned long long* tile_sums, int64_t n_tiles, unsigned long long cap_rows,
+                                                             unsigned long long* out2, int* err) {
+  __shared__ uint32_t s_ws[PREP_WAVES];
+  unsigned long long carry = 0;
+  for (int64_t i0 = 0; i0 < n_tiles; i0 += PREP_THREADS) {
+    const int64_t i = i0 + (int64_t)threadIdx.x;
+    const unsigned long long mine = i < n_tiles ? tile_sums[i] : 0ull;  // (< 2^32 per tile: at most 2048 x 64 rows)
+    uint32_t tot;
+    const uint32_t ex = block_excl_scan((uint32_t)mine, s_ws, tot);
+    if (i < n_tiles) tile_sums[i] = carry + ex;
+    carry += tot;
+  }
+  if (threadIdx.x == 0) {
+    out2[0] = carry;
+    if (carry > cap_rows || carry > 0xfffffff0ull) flag_err(err, (err[2] != 0 && carry <= 0xfffffff0ull) ? -101 : -4, 12);
+  }
+}
+__global__ __launch_bounds__(PREP_THREADS) void k_scan_down(uint32_t* v, int64_t n, const unsigned long long* __restrict__ tile_sums) {
+  __shared__ uint32_t s_ws[PREP_WAVES];
+  const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + 8 * (int64_t)threadIdx.x;
+  uint32_t x[8], mine = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { x[j] = base + j < n ? v[base + j] : 0u; mine += x[j]; }
+  uint32_t tot;
+  uint32_t at = block_excl_scan(mine, s_ws, tot) + (uint32_t)tile_sums[blockIdx.x];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { if (base + j < n) v[base + j] = at; at += x[j]; }
+}
+
+// ---- A4: payload rows -> block store, validation, tails -----------------------------------------------------------------------
+// this lane's 16-byte row of its stream out of the block's bytes staged at `slab` (the block starts at byte `mis`): a
+// misaligned 16 bytes = five aligned dwords shifted into place
+__device__ __forceinline__ uint4 staged_file_row(const uint8_t* slab, uint32_t mis, uint32_t hdr, int lane) {
+  const int bd = hdr_bdoc(hdr);
+  const uint32_t doc_sz = bd ? 16u * (uint32_t)bd : (uint32_t)hdr_vlen(hdr);
+  const uint32_t o = mis + 1u + 16u * (uint32_t)(lane & 31) + __umul24((uint32_t)(lane >> 5), doc_sz + 1u);
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(slab + (o & ~3u));
+  const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4];
+  const uint32_t sh = o & 3u;
+  return make_uint4(__builtin_amdgcn_alignbyte(w1, w0, sh), __builtin_amdgcn_alignbyte(w2, w1, sh), __builtin_amdgcn_alignbyte(w3, w2, sh),
+                    __builtin_amdgcn_alignbyte(w4, w3, sh));
+}
+constexpr int PREP_SLAB_BYTES = SLAB_BYTES;  // >= 15 + 1026 + 20 staged block bytes; the tail decoder's scratch
+static_assert(PREP_SLAB_BYTES >= 1104, "a staged block: 66 aligned rows + the over-read of the last misaligned row");
 
 template <bool LEGACY>
 __global__ __launch_bounds__(PREP_THREADS) void k_prepare_blocks(const uint8_t* __restrict__ doc, const PrepTerm* __restrict__ terms,
@@ -238,27 +372,19 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_blocks(const uint8_t* 
                                                                   const uint32_t* __restrict__ dir_off,
                                                                   const uint32_t* __restrict__ dir_row,
                                                                   uint16_t* dir_hdr, uint8_t* bstore,
-                                                                  const uint8_t* __restrict__ norms, uint8_t* pnorm,
-                                                                  uint64_t* __restrict__ dir_bmax, int ranked, int has_freqs,
+                                                                  uint64_t* __restrict__ dir_bmax, int has_freqs,
                                                                   int32_t max_doc, int* err) {
-  __shared__ __attribute__((aligned(16))) uint8_t slabs[PREP_THREADS / 64][SLAB_BYTES];
+  __shared__ __attribute__((aligned(16))) uint8_t slabs[PREP_WAVES][PREP_SLAB_BYTES];
   const int lane = lane_id();
   const int wave = wave_id();
-  const int64_t item = (int64_t)blockIdx.x * (PREP_THREADS / 64) + wave;
+  const int64_t item = (int64_t)blockIdx.x * PREP_WAVES + wave;
   if (item >= n_items || *err != 0) return;  // a term whose framing did not check out must not be walked
-  int ti = 0;
-  {
-    int lo = 0, hi = n_terms;  // largest t with item_prefix[t] <= item
-    while (hi - lo > 1) {
-      const int mid = (lo + hi) >> 1;
-      if (item_prefix[mid] <= item) lo = mid; else hi = mid;
-    }
-    ti = lo;
-  }
+  const int ti = upper_slot(item_prefix, n_terms, item);
   const PrepTerm t = terms[ti];
   const int b0 = (int)(item - item_prefix[ti]) * PREP_BLOCKS_PER_ITEM;
   const int b1 = min(t.nblocks, b0 + PREP_BLOCKS_PER_ITEM);
   uint8_t* term_rows = bstore + t.bs_base;
+  uint8_t* slab = slabs[wave];
   // the term's last item also takes its VInt tail (posting_reader.rs:308-333): decoded here once, checked like the blocks
   // (doc ids strictly increasing from the last FullBlock's last doc, inside the segment) and stored as 16-byte cells (tail_load)
   const int tail_n = t.df > 1 ? t.df % 128 : 0;
@@ -267,7 +393,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_blocks(const uint8_t* 
     const int32_t tbase = t.nblocks ? dir_last[t.dir_base + t.nblocks - 1] : 0;
     int32_t d0, d1;
     uint32_t f0, f1;
-    decode_tail(doc + t.start_fp + toff, tail_n, tbase, slabs[wave], lane, d0, d1, f0, f1, has_freqs != 0);
+    decode_tail(doc + t.start_fp + toff, tail_n, tbase, slab, lane, d0, d1, f0, f1, has_freqs != 0);
     const bool v0 = 2 * lane < tail_n, v1 = 2 * lane + 1 < tail_n;
     const int32_t prev = __builtin_amdgcn_update_dpp(tbase, d1, 0x138, 0xf, 0xf, false);  // wave_shr:1; lane 0 <- the base doc
     const bool first_ok = (t.nblocks == 0 && lane == 0) ? d0 >= 0 : d0 > prev;  // a term's very first doc may be doc 0
@@ -277,25 +403,54 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_blocks(const uint8_t* 
     *reinterpret_cast<uint4*>(tp + 16 * lane) = make_uint4(v0 ? (uint32_t)d0 : 0x7fffffffu, v1 ? (uint32_t)d1 : 0x7fffffffu, v0 ? f0 : 0u, v1 ? f1 : 0u);
     // the tail's directory slot gets its last doc, like a FullBlock's: the wide OR kernel walks tails as one more block
     const int32_t tail_last = readlane(((tail_n - 1) & 1) ? d1 : d0, (tail_n - 1) >> 1);
-    if (lane == 0) dir_last[t.dir_base + t.nblocks] = tail_last;
-    if (norms != nullptr) {  // ... and its posting-order norms continue the FullBlocks'
-      const uint32_t n0 = v0 ? norms[d0] : 0u, n1 = v1 ? norms[d1] : 0u;
-      *reinterpret_cast<uint16_t*>(pnorm + t.pn_base + 128 * (uint64_t)t.nblocks + 2 * lane) = (uint16_t)(n0 | (n1 << 8));
-    }
+    if (lane == 0) { dir_last[t.dir_base + t.nblocks] = tail_last; dir_bmax[t.dir_base + t.nblocks] = 15ull; }
   }
-  for (int blk = b0; blk < b1; ++blk) {
-    uint32_t hdr = dir_hdr[t.dir_base + blk];
-    const uint32_t row0 = dir_row[t.dir_base + blk];
+  if (b1 <= b0) return;
+  // lane j: block b0 + j's directory words (one coalesced look instead of dependent loads per block)
+  const int nb = b1 - b0;
+  const bool mine = lane < nb;
+  const uint32_t my_off = mine ? dir_off[t.dir_base + b0 + lane] : 0u;
+  const uint32_t my_hdr = mine ? (uint32_t)dir_hdr[t.dir_base + b0 + lane] : 0u;
+  const uint32_t my_row = mine ? dir_row[t.dir_base + b0 + lane] : 0u;
+  int32_t base = b0 == 0 ? 0 : dir_last[t.dir_base + b0 - 1];
+  // a block's aligned rows: [a, a + 16 * n16) covers its bytes; lane l takes row l (rows 64, 65 — a 1026-byte block that
+  // starts late in its first row — ride on lanes 0, 1)
+  struct Staged { uint4 r0, r1; };
+  auto request = [&](int j) -> Staged {
+    const uint32_t hdr = (uint32_t)readlane((int)my_hdr, j);
+    const uint64_t p = t.start_fp + (uint64_t)(uint32_t)readlane((int)my_off, j);
+    const uint32_t mis = (uint32_t)(p & 15u);
+    const uint32_t bytes = hdr_nonpf(hdr) ? 0u : mis + encoded_block_bytes(hdr) + 3u;  // (+3: the last row's fifth dword)
+    const uint8_t* a = doc + (p - mis);
+    Staged s;
+    s.r0 = make_uint4(0u, 0u, 0u, 0u);
+    s.r1 = s.r0;
+    if (16u * (uint32_t)lane < bytes) s.r0 = *reinterpret_cast<const uint4*>(a + 16 * lane);
+    if (1024u + 16u * (uint32_t)lane < bytes) s.r1 = *reinterpret_cast<const uint4*>(a + 1024 + 16 * lane);
+    return s;
+  };
+  Staged cur = request(0);
+  for (int j = 0; j < nb; ++j) {
+    const int blk = b0 + j;
+    uint32_t hdr = (uint32_t)readlane((int)my_hdr, j);
+    const uint32_t row0 = (uint32_t)readlane((int)my_row, j);
+    const uint32_t off = (uint32_t)readlane((int)my_off, j);
+    const Staged nxt = request(min(j + 1, nb - 1));  // the next block's bytes are in flight while this one is re-laid
     uint4 rows;
     if (!hdr_nonpf(hdr)) {
-      rows = store_rows_from_file(file_rows_load(doc + t.start_fp + dir_off[t.dir_base + blk], hdr, lane), hdr, lane, has_freqs != 0);
+      const uint32_t mis = (uint32_t)((t.start_fp + off) & 15u);
+      *reinterpret_cast<uint4*>(slab + 16 * lane) = cur.r0;
+      if (lane < 5) *reinterpret_cast<uint4*>(slab + 1024 + 16 * lane) = cur.r1;
+      wave_sync();
+      rows = store_rows_from_file(staged_file_row(slab, mis, hdr, lane), hdr, lane, has_freqs != 0);
+      wave_sync();
     } else {
       // ---- an EF / BITSET doc block: 128 doc ids -> deltas -> BP128 rows (decode.hpp; for_util.rs:337-372,
       // posting_reader.rs:622-637, elias_fano_decoder.rs:95-169, util/bit_set.rs:351-376)
-      const uint8_t* p = doc + t.start_fp + dir_off[t.dir_base + blk];
+      const uint8_t* p = doc + t.start_fp + off;
       const int etype = hdr_vlen(hdr);
-      int32_t* ids = reinterpret_cast<int32_t*>(slabs[wave]);            // 128 doc ids
-      uint32_t* pack = reinterpret_cast<uint32_t*>(slabs[wave] + 512);   // 132 dwords of BP128 rows
+      int32_t* ids = reinterpret_cast<int32_t*>(slab);            // 128 doc ids
+      uint32_t* pack = reinterpret_cast<uint32_t*>(slab + 512);   // 132 dwords of BP128 rows
       const int32_t pf_base = blk == 0 ? 0 : dir_last[t.dir_base + blk - 1];
       int doc_sz, total;
       if (etype == 2) {
@@ -368,6 +523,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_blocks(const uint8_t* 
       rows = store_rows_from_file(rows, hdr, lane, has_freqs != 0);
       wave_sync();
     }
+    cur = nxt;
     const int half = lane >> 5, row = lane & 31;
     const int rd = store_doc_rows(hdr);
     if (row < (half ? store_freq_rows(hdr) : rd))
@@ -375,11 +531,10 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_blocks(const uint8_t* 
     // Every FullBlock is decoded and validated here, once: doc ids inside the segment and strictly increasing (a zero
     // delta or a 32-bit wrap shows up as d1 <= d0 or d0 <= the previous lane's d1), and the block ending on the doc its
     // skip entry names. The query kernels then gather norms / live bits and index windows with these docs unchecked.
-    const int32_t base = blk == 0 ? 0 : dir_last[t.dir_base + blk - 1];
-    const BlockPair bp = block_rows_decode<LEGACY>(rows, hdr, slabs[wave], lane);
+    const BlockPair bp = block_rows_decode<LEGACY>(rows, hdr, slab, lane);
     int32_t d0, d1;
     deltas_to_docs(bp.d0, bp.d1, base, d0, d1);
-    // df % 128 == 0: no skip entry names the final block's last doc (k_prepare_terms left a sentinel there); the
+    // df % 128 == 0: no skip entry names the final block's last doc (k_skip_dir left a sentinel there); the
     // decode does — windowed consumers (the OR kernel) can then tell that the term has ended
     if (blk == t.nblocks - 1 && t.nblocks > t.n_entries && lane == 63) dir_last[t.dir_base + blk] = d1;
     const int32_t prev = __builtin_amdgcn_update_dpp(base, d1, 0x138, 0xf, 0xf, false);  // wave_shr:1; lane 0 <- the block's base doc
@@ -388,25 +543,54 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_blocks(const uint8_t* 
     const bool bad = bad_first || d1 <= d0 || d1 >= max_doc;
     const bool bad_last = blk < t.n_entries && lane == 63 && d1 != dir_last[t.dir_base + blk];
     if (__ballot(bad || bad_last)) { if (lane == 0) flag_err(err, -4, 15); return; }
-    if (norms != nullptr) {
-      const uint32_t n0 = norms[d0], n1 = norms[d1];
-      *reinterpret_cast<uint16_t*>(pnorm + t.pn_base + 128 * (uint64_t)blk + 2 * lane) = (uint16_t)(n0 | (n1 << 8));
-      // the block's (freq, norm rank) frontier word (SegView::dir_bmax)
-      uint64_t w = 15ull;
-      const uint32_t fmax = wave_reduce_max_u32(bp.f0 > bp.f1 ? bp.f0 : bp.f1);
-      if (ranked && fmax <= 10u) {
-        w = fmax;
-#pragma unroll
-        for (uint32_t f = 1; f <= 10; ++f) {
-          const uint32_t r0 = bp.f0 == f ? n0 : 0u, r1 = bp.f1 == f ? n1 : 0u;
-          w |= (uint64_t)(wave_reduce_max_u32(r0 > r1 ? r0 : r1) & 63u) << (4 + 6 * (f - 1));
-        }
-      }
-      if (lane == 0) dir_bmax[t.dir_base + blk] = w;
-    } else if (lane == 0) {
-      dir_bmax[t.dir_base + blk] = 15ull;
-    }
+    base = readlane(d1, 63);
+    if (lane == 0) dir_bmax[t.dir_base + blk] = 15ull;  // "no bound" until (unless) stage B learns the block's norms
   }
+}
+
+// ---- B: posting-order norms + the (freq, norm rank) frontier of every block, for terms that get scored ------------------------
+// items as in k_prepare_blocks; `pn_base` of a term = where its posting-order norms go (PrepTerm::pn_base)
+template <bool LEGACY>
+__global__ __launch_bounds__(PREP_THREADS) void k_prepare_norms(SegView seg, const PrepTerm* __restrict__ terms,
+                                                                const int64_t* __restrict__ item_prefix, int n_terms, int64_t n_items,
+                                                                uint8_t* pnorm, uint64_t* __restrict__ dir_bmax, int ranked) {
+  __shared__ __attribute__((aligned(16))) uint8_t slabs[PREP_WAVES][2 * SLAB_STREAM];
+  const int lane = lane_id();
+  const int wave = wave_id();
+  const int64_t item = (int64_t)blockIdx.x * PREP_WAVES + wave;
+  if (item >= n_items) return;
+  const int ti = upper_slot(item_prefix, n_terms, item);
+  const PrepTerm t = terms[ti];
+  const int b0 = (int)(item - item_prefix[ti]) * PREP_BLOCKS_PER_ITEM;
+  const int b1 = min(t.nblocks, b0 + PREP_BLOCKS_PER_ITEM);
+  const uint8_t* term_rows = seg.bstore + t.bs_base;
+  uint8_t* pn = pnorm + t.pn_base;
+  const int tail_n = t.df > 1 ? t.df % 128 : 0;
+  if (tail_n > 0 && b0 + PREP_BLOCKS_PER_ITEM >= t.nblocks) {  // the tail's norms continue the FullBlocks'
+    int32_t d0, d1;
+    uint32_t f0, f1;
+    tail_load(term_rows, seg.dir_row[t.dir_base + t.nblocks], lane, d0, d1, f0, f1);
+    const uint32_t n0 = 2 * lane < tail_n ? seg.norms[d0] : 0u, n1 = 2 * lane + 1 < tail_n ? seg.norms[d1] : 0u;
+    *reinterpret_cast<uint16_t*>(pn + 128 * (uint64_t)t.nblocks + 2 * lane) = (uint16_t)(n0 | (n1 << 8));
+  }
+  int32_t base = b0 == 0 ? 0 : seg.dir_last[t.dir_base + b0 - 1];
+  stream_blocks<LEGACY, false>(term_rows, seg.dir_row, seg.dir_hdr, t.dir_base, nullptr, b0, b1, slabs[wave], lane, base,
+                               [&](int blk, int32_t d0, int32_t d1, uint32_t f0, uint32_t f1, uint32_t, uint32_t) {
+    const uint32_t n0 = seg.norms[d0], n1 = seg.norms[d1];
+    *reinterpret_cast<uint16_t*>(pn + 128 * (uint64_t)blk + 2 * lane) = (uint16_t)(n0 | (n1 << 8));
+    // the block's (freq, norm rank) frontier word (SegView::dir_bmax)
+    uint64_t w = 15ull;
+    const uint32_t fmax = wave_reduce_max_u32(f0 > f1 ? f0 : f1);
+    if (ranked && fmax <= 10u) {
+      w = fmax;
+#pragma unroll
+      for (uint32_t f = 1; f <= 10; ++f) {
+        const uint32_t r0 = f0 == f ? n0 : 0u, r1 = f1 == f ? n1 : 0u;
+        w |= (uint64_t)(wave_reduce_max_u32(r0 > r1 ? r0 : r1) & 63u) << (4 + 6 * (f - 1));
+      }
+    }
+    if (lane == 0) dir_bmax[t.dir_base + blk] = w;
+  });
 }
 
 }  // namespace rgpu

@@ -158,7 +158,7 @@ struct rgpu_ctx {
   char name[128] = {0};
 };
 
-struct TermInfo { uint32_t dir_base; int32_t nblocks; int32_t df; uint64_t pn_base; uint64_t bs_base; };
+struct TermInfo { uint32_t dir_base; int32_t nblocks; int32_t df; uint64_t pn_base; uint64_t bs_base; bool norms; };
 
 // doc_start_fp -> TermInfo of the prepared terms (host/flat_fp_map.hpp: two look-ups per clause per batch)
 using PreparedMap = rucene::FlatFpMap<TermInfo>;
@@ -188,6 +188,7 @@ struct rgpu_segment {
   DevVec<uint8_t> pnorm;  // posting-order norms of every prepared term's FullBlocks and tail
   size_t pnorm_used = 0;
   PreparedMap prepared;
+  DevVec<uint8_t> prep_scratch;  // k_skip_dir's chunk aggregates + ticket, the prefix sum's tile sums
 };
 
 // ---- profiling helpers -----------------------------------------------------------------------------------------
@@ -315,34 +316,53 @@ static int32_t validate_state(const rgpu_segment* seg, const rgpu_term_state& st
   return RGPU_OK;
 }
 
-// Build block directories for every not-yet-seen term with df >= 128 (ctx mutex held by the caller).
+// Stage A of term preparation (kernels/prepare.hpp) for every not-yet-seen term with df >= 2 (ctx mutex held by the caller):
+// block directory, aligned block store, decoded tail — what a decode needs. `with_norms` adds stage B (posting-order norms +
+// block-max frontier words: what scoring needs) for every named term that lacks it.
 static int32_t prepare_terms_attempt(rgpu_segment* seg, const rgpu_term_state* const* sts, size_t n, bool wide);
+static int32_t prepare_norms_locked(rgpu_segment* seg, const rgpu_term_state* const* sts, size_t n);
 // -101 from the device: a term holds EF / BITSET doc blocks whose re-packed deltas need more block-store rows than its
 // file bytes suggest — plan the same call again with worst-case rows (64 per block). Nothing was committed.
-static int32_t prepare_terms_locked(rgpu_segment* seg, const rgpu_term_state* const* sts, size_t n) {
+static int32_t prepare_terms_locked(rgpu_segment* seg, const rgpu_term_state* const* sts, size_t n, bool with_norms = true) {
   int32_t rc = prepare_terms_attempt(seg, sts, n, false);
   if (rc == -101) rc = prepare_terms_attempt(seg, sts, n, true);
+  if (rc == -101) rc = fail(RGPU_ERR_CORRUPT_INDEX, "corrupt block framing in .doc (prepare.hpp check #12)");
+  if (rc == RGPU_OK && with_norms) rc = prepare_norms_locked(seg, sts, n);
   return rc;
+}
+static void prep_items(const std::vector<PrepTerm>& work, std::vector<int64_t>* item_prefix, int64_t* n_items, int64_t* postings) {
+  item_prefix->assign(work.size() + 1, 0);
+  *n_items = 0;
+  *postings = 0;
+  for (size_t i = 0; i < work.size(); ++i) {
+    (*item_prefix)[i] = *n_items;
+    *n_items += std::max(1, (work[i].nblocks + PREP_BLOCKS_PER_ITEM - 1) / PREP_BLOCKS_PER_ITEM);  // the last item takes the tail
+    *postings += work[i].df;
+  }
+  (*item_prefix)[work.size()] = *n_items;
 }
 static int32_t prepare_terms_attempt(rgpu_segment* seg, const rgpu_term_state* const* sts, size_t n, bool wide) {
   rgpu_ctx* c = seg->ctx;
   std::vector<PrepTerm> work;
   size_t need_slots = seg->dir_used;
-  size_t need_pn = seg->pnorm_used;
-  size_t need_bs = seg->bstore_used;
+  const size_t batch_bs = (seg->bstore_used + 15) & ~size_t(15);  // this call's rows form one dense region from here
+  uint64_t cap_rows = 0;
   std::vector<std::pair<int64_t, TermInfo>> added;
-  std::unordered_map<int64_t, int> in_batch;
+  rucene::FlatFpMap<int> in_batch;
   for (size_t i = 0; i < n; ++i) {
     const rgpu_term_state& st = *sts[i];
-    int32_t rc = validate_state(seg, st);
-    if (rc != RGPU_OK) return rc;
-    if (st.doc_freq < 2) continue;  // a singleton lives in the term dictionary; everything else has blocks and / or a tail
+    if (st.doc_freq < 2) {  // a singleton lives in the term dictionary; everything else has blocks and / or a tail
+      if (st.doc_freq < 0) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "negative doc_freq");
+      continue;
+    }
     if (const TermInfo* known = seg->prepared.find(st.doc_start_fp)) {
       if (known->df != st.doc_freq) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "term state changed doc_freq for a known doc_start_fp");
       continue;
     }
-    if (in_batch.count(st.doc_start_fp)) continue;
-    in_batch[st.doc_start_fp] = 1;
+    int32_t rc = validate_state(seg, st);
+    if (rc != RGPU_OK) return rc;
+    if (in_batch.find(st.doc_start_fp)) continue;
+    in_batch.put(st.doc_start_fp, 1);
     PrepTerm p;
     p.start_fp = (uint64_t)st.doc_start_fp;
     p.df = st.doc_freq;
@@ -351,7 +371,7 @@ static int32_t prepare_terms_attempt(rgpu_segment* seg, const rgpu_term_state* c
     p.n_levels = ilog8_levels(st.doc_freq);
     p.skip_fp = st.doc_freq > 128 ? st.doc_start_fp + st.skip_offset : -1;
     p.dir_base = (uint32_t)need_slots;
-    p.pn_base = (uint64_t)need_pn;
+    p.pn_base = 0;  // assigned when (if) the term's norms are prepared
     // block store rows: a block's aligned copy is at most 28 bytes longer than its framing in the file (two
     // header bytes dropped, each all-equal VInt padded to a 16-byte row); the FullBlocks end before the skip data
     const uint64_t span = st.doc_freq > 128 ? (uint64_t)st.skip_offset : (p.nblocks ? 1026u : 0u);
@@ -360,86 +380,166 @@ static int32_t prepare_terms_attempt(rgpu_segment* seg, const rgpu_term_state* c
     const uint64_t rows = (wide ? 64u * (uint64_t)p.nblocks : (span + (seg->has_freqs ? 28u : 32u) * (uint64_t)p.nblocks + 15u) / 16u) +
                           ((st.doc_freq % 128) ? (uint64_t)TAIL_STORE_ROWS : 0u);
     if (rows > 0xffffffffull) return fail(RGPU_ERR_UNSUPPORTED, "a single term's postings exceed 64 GiB");
-    p.bs_base = (uint64_t)need_bs;
+    p.bs_base = (uint64_t)batch_bs;  // dir_row counts from the call's first row for every one of its terms
     p.bs_rows = (uint32_t)rows;
+    cap_rows += rows;
     need_slots += (size_t)p.nblocks + 1;
-    need_pn += ((size_t)p.nblocks + ((st.doc_freq % 128) ? 1u : 0u)) * 128;  // the tail's norms follow the FullBlocks' 
-    need_bs += (size_t)rows * 16;
     if (need_slots > 0xfffffff0ull) return fail(RGPU_ERR_UNSUPPORTED, "block directory exceeds 2^32 slots");
     work.push_back(p);
-    added.push_back({st.doc_start_fp, TermInfo{p.dir_base, p.nblocks, p.df, p.pn_base, p.bs_base}});
+    added.push_back({st.doc_start_fp, TermInfo{p.dir_base, p.nblocks, p.df, 0, p.bs_base, seg->d_norms == nullptr}});
   }
   if (work.empty()) return RGPU_OK;
+  if (cap_rows > 0xfffffff0ull) return fail(RGPU_ERR_UNSUPPORTED, "one call prepares more than 64 GiB of block store: split the term list");
   HIP_TRY(scratch_take(c));  // staging below; this function ends with a stream sync, so the slot is free again on return
   HIP_TRY(seg->dir_last.reserve(need_slots, seg->dir_used, c->stream));
   HIP_TRY(seg->dir_off.reserve(need_slots, seg->dir_used, c->stream));
   HIP_TRY(seg->dir_row.reserve(need_slots, seg->dir_used, c->stream));
-  HIP_TRY(seg->bstore.reserve(need_bs + 1024, seg->bstore_used, c->stream));  // + over-read padding of the row loads
+  HIP_TRY(seg->bstore.reserve(batch_bs + (size_t)cap_rows * 16 + 1024, seg->bstore_used, c->stream));  // + over-read padding of the row loads
   HIP_TRY(seg->dir_hdr.reserve(need_slots, seg->dir_used, c->stream));
   HIP_TRY(seg->dir_bmax.reserve(need_slots, seg->dir_used, c->stream));
   if (seg->has_positions) HIP_TRY(seg->dir_pos.reserve(need_slots, seg->dir_used, c->stream));
-  if (seg->d_norms) HIP_TRY(seg->pnorm.reserve(need_pn + 64, seg->pnorm_used, c->stream));
-  // staging: the PrepTerm records + the (term, chunk of blocks) item prefix of the second launch
-  std::vector<int64_t> item_prefix(work.size() + 1);
-  int64_t n_items = 0, postings = 0;
-  for (size_t i = 0; i < work.size(); ++i) {
-    item_prefix[i] = n_items;
-    n_items += std::max(1, (work[i].nblocks + PREP_BLOCKS_PER_ITEM - 1) / PREP_BLOCKS_PER_ITEM);  // the last item takes the tail
-    postings += work[i].df;
-  }
-  item_prefix[work.size()] = n_items;
-  const size_t bytes = work.size() * sizeof(PrepTerm);
-  const size_t o_items = (bytes + 255) & ~size_t(255);
-  const size_t staged = o_items + item_prefix.size() * 8;
-  HIP_TRY(c->S->h_stage.reserve(staged));
-  HIP_TRY(c->S->d_stage.reserve(staged, 0, c->stream));
-  std::memcpy(c->S->h_stage.p, work.data(), bytes);
+  // plans: (term, 1 KB chunk of level-0 skip bytes) for k_skip_dir; (term, chunk of blocks) for the block kernels
+  std::vector<int64_t> item_prefix, chunk_prefix(work.size() + 1);
+  int64_t n_items = 0, postings = 0, n_chunks = 0;
+  prep_items(work, &item_prefix, &n_items, &postings);
+  for (size_t i = 0; i < work.size(); ++i) { chunk_prefix[i] = n_chunks; n_chunks += skip_chunks(work[i].n_entries, seg->has_positions); }
+  chunk_prefix[work.size()] = n_chunks;
+  const size_t n_slots = need_slots - seg->dir_used;
+  const int64_t n_tiles = (int64_t)((n_slots + SCAN_TILE - 1) / SCAN_TILE);
+  Stager st(c);
+  const size_t o_work = st.add(work.size() * sizeof(PrepTerm));
+  const size_t o_items = st.add(item_prefix.size() * 8);
+  const size_t o_chunks = st.add(chunk_prefix.size() * 8);
+  HIP_TRY(c->S->h_stage.reserve(st.used));
+  HIP_TRY(c->S->d_stage.reserve(st.used, 0, c->stream));
+  std::memcpy(c->S->h_stage.p + o_work, work.data(), work.size() * sizeof(PrepTerm));
   std::memcpy(c->S->h_stage.p + o_items, item_prefix.data(), item_prefix.size() * 8);
-  HIP_TRY(hipMemcpyAsync(c->S->d_stage.p, c->S->h_stage.p, staged, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(hipMemsetAsync(c->d_err, 0, 2 * sizeof(int), c->stream));
-  const PrepTerm* d_work = reinterpret_cast<const PrepTerm*>(c->S->d_stage.p);
+  std::memcpy(c->S->h_stage.p + o_chunks, chunk_prefix.data(), chunk_prefix.size() * 8);
+  HIP_TRY(hipMemcpyAsync(c->S->d_stage.p, c->S->h_stage.p, st.used, hipMemcpyHostToDevice, c->stream));
+  // device scratch: [ticket, total rows][chunk aggregates][tile sums]
+  const size_t o_aggs = 64, o_tiles = o_aggs + (size_t)n_chunks * sizeof(SkipAgg);
+  HIP_TRY(seg->prep_scratch.reserve(o_tiles + (size_t)n_tiles * 8 + 64, 0, c->stream));
+  HIP_TRY(hipMemsetAsync(seg->prep_scratch.p, 0, o_tiles, c->stream));
+  HIP_TRY(hipMemsetAsync(c->d_err, 0, 4 * sizeof(int), c->stream));
+  unsigned long long* d_ticket = reinterpret_cast<unsigned long long*>(seg->prep_scratch.p);
+  unsigned long long* d_total = d_ticket + 1;
+  SkipAgg* d_aggs = reinterpret_cast<SkipAgg*>(seg->prep_scratch.p + o_aggs);
+  unsigned long long* d_tiles = reinterpret_cast<unsigned long long*>(seg->prep_scratch.p + o_tiles);
+  const PrepTerm* d_work = reinterpret_cast<const PrepTerm*>(c->S->d_stage.p + o_work);
   const int64_t* d_items = reinterpret_cast<const int64_t*>(c->S->d_stage.p + o_items);
+  const int64_t* d_chunks = reinterpret_cast<const int64_t*>(c->S->d_stage.p + o_chunks);
+  const bool legacy = seg->version < 1;
+  const unsigned item_grid = (unsigned)((n_items + PREP_WAVES - 1) / PREP_WAVES);
   {
-    TimedLaunch tl(c, c->stream, "k_prepare_terms", postings);
-    if (seg->version >= 1)
-      hipLaunchKernelGGL(k_prepare_terms<false>, dim3((unsigned)work.size()), dim3(PREP_THREADS), 0, c->stream, seg->d_doc,
-                         (int64_t)seg->doc_len, d_work, seg->dir_last.p, seg->dir_off.p, seg->dir_row.p, seg->dir_hdr.p, seg->has_positions ? seg->dir_pos.p : nullptr,
-                         seg->has_freqs ? 1 : 0, c->d_err);
-    else
-      hipLaunchKernelGGL(k_prepare_terms<true>, dim3((unsigned)work.size()), dim3(PREP_THREADS), 0, c->stream, seg->d_doc,
-                         (int64_t)seg->doc_len, d_work, seg->dir_last.p, seg->dir_off.p, seg->dir_row.p, seg->dir_hdr.p, seg->has_positions ? seg->dir_pos.p : nullptr,
-                         seg->has_freqs ? 1 : 0, c->d_err);
+    TimedLaunch tl(c, c->stream, "k_skip_dir", postings);
+    hipLaunchKernelGGL(k_skip_dir, dim3((unsigned)((n_chunks + PREP_WAVES - 1) / PREP_WAVES)), dim3(PREP_THREADS), 0, c->stream, seg->d_doc,
+                       (int64_t)seg->doc_len, (int64_t)seg->doc_len + 8192, d_work, d_chunks, (int)work.size(), n_chunks, d_aggs, d_ticket,
+                       seg->dir_last.p, seg->dir_off.p, seg->has_positions ? seg->dir_pos.p : nullptr, c->d_err);
   }
-  if (n_items > 0) {
+  {
+    TimedLaunch tl(c, c->stream, "k_block_headers", postings);
+    auto go = [&](auto kern) {
+      hipLaunchKernelGGL(kern, dim3(item_grid), dim3(PREP_THREADS), 0, c->stream, seg->d_doc, (int64_t)seg->doc_len, d_work, d_items,
+                         (int)work.size(), n_items, seg->dir_last.p, seg->dir_off.p, seg->dir_row.p, seg->dir_hdr.p, seg->has_freqs ? 1 : 0, c->d_err);
+    };
+    if (legacy) go(k_block_headers<true>); else go(k_block_headers<false>);
+  }
+  {
+    TimedLaunch tl(c, c->stream, "k_scan_rows", 0);
+    uint32_t* rows = seg->dir_row.p + seg->dir_used;
+    hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)n_tiles), dim3(PREP_THREADS), 0, c->stream, rows, (int64_t)n_slots, d_tiles);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(PREP_THREADS), 0, c->stream, d_tiles, n_tiles, (unsigned long long)cap_rows, d_total, c->d_err);
+    hipLaunchKernelGGL(k_scan_down, dim3((unsigned)n_tiles), dim3(PREP_THREADS), 0, c->stream, rows, (int64_t)n_slots, d_tiles);
+  }
+  {
     TimedLaunch tl(c, c->stream, "k_prepare_blocks", postings);
-    const unsigned grid = (unsigned)((n_items + PREP_THREADS / 64 - 1) / (PREP_THREADS / 64));
-    if (seg->version >= 1)
-      hipLaunchKernelGGL(k_prepare_blocks<false>, dim3(grid), dim3(PREP_THREADS), 0, c->stream, seg->d_doc, d_work, d_items,
-                         (int)work.size(), n_items, seg->dir_last.p, seg->dir_off.p, seg->dir_row.p, seg->dir_hdr.p, seg->bstore.p,
-                         seg->d_norms, seg->pnorm.p, seg->dir_bmax.p, seg->n_norm_ranks > 0 ? 1 : 0, seg->has_freqs ? 1 : 0, seg->max_doc, c->d_err);
-    else
-      hipLaunchKernelGGL(k_prepare_blocks<true>, dim3(grid), dim3(PREP_THREADS), 0, c->stream, seg->d_doc, d_work, d_items,
-                         (int)work.size(), n_items, seg->dir_last.p, seg->dir_off.p, seg->dir_row.p, seg->dir_hdr.p, seg->bstore.p,
-                         seg->d_norms, seg->pnorm.p, seg->dir_bmax.p, seg->n_norm_ranks > 0 ? 1 : 0, seg->has_freqs ? 1 : 0, seg->max_doc, c->d_err);
+    auto go = [&](auto kern) {
+      hipLaunchKernelGGL(kern, dim3(item_grid), dim3(PREP_THREADS), 0, c->stream, seg->d_doc, d_work, d_items, (int)work.size(), n_items,
+                         seg->dir_last.p, seg->dir_off.p, seg->dir_row.p, seg->dir_hdr.p, seg->bstore.p, seg->dir_bmax.p, seg->has_freqs ? 1 : 0,
+                         seg->max_doc, c->d_err);
+    };
+    if (legacy) go(k_prepare_blocks<true>); else go(k_prepare_blocks<false>);
   }
-  int err2[2] = {0, 0};
-  HIP_TRY(hipMemcpyAsync(err2, c->d_err, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  int err4[4] = {0, 0, 0, 0};
+  unsigned long long total_rows = 0;
+  HIP_TRY(hipMemcpyAsync(err4, c->d_err, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(&total_rows, d_total, 8, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   HIP_TRY(hipGetLastError());
-  const int err = err2[0];
+  const int err = err4[0];
   if (err == -101) return -101;  // see prepare_terms_locked
   if (err != 0) {
     return fail(err, err == RGPU_ERR_UNSUPPORTED ? std::string("FULL-encoded doc block (unimplemented in Rucene itself), or an EF / BITSET block in a legacy (.doc version 0) file")
-                                                 : "corrupt skip data or block framing in .doc (prepare.hpp check #" + std::to_string(err2[1]) + ")");
+                                                 : "corrupt skip data or block framing in .doc (prepare.hpp check #" + std::to_string(err4[1]) + ")");
   }
   seg->dir_used = need_slots;
-  seg->pnorm_used = need_pn;
-  seg->bstore_used = need_bs;
+  seg->bstore_used = batch_bs + (size_t)total_rows * 16;
   for (auto& a : added) seg->prepared.put(a.first, a.second);
   return RGPU_OK;
 }
 
-static int32_t make_dev_term(const rgpu_segment* seg, const rgpu_term_state& st, float weight, int32_t sim_table, DevTerm* out) {
+// Stage B for the named terms that are prepared but have no posting-order norms yet (segments without norms have none to prepare)
+static int32_t prepare_norms_locked(rgpu_segment* seg, const rgpu_term_state* const* sts, size_t n) {
+  rgpu_ctx* c = seg->ctx;
+  if (!seg->d_norms) return RGPU_OK;
+  std::vector<PrepTerm> work;
+  std::vector<int64_t> fps;
+  size_t need_pn = seg->pnorm_used;
+  rucene::FlatFpMap<int> in_batch;
+  for (size_t i = 0; i < n; ++i) {
+    const rgpu_term_state& st = *sts[i];
+    if (st.doc_freq < 2) continue;
+    const TermInfo* info = seg->prepared.find(st.doc_start_fp);
+    if (!info || info->norms || in_batch.find(st.doc_start_fp)) continue;
+    in_batch.put(st.doc_start_fp, 1);
+    PrepTerm p{};
+    p.start_fp = (uint64_t)st.doc_start_fp;
+    p.df = info->df;
+    p.nblocks = info->nblocks;
+    p.dir_base = info->dir_base;
+    p.bs_base = info->bs_base;
+    p.pn_base = (uint64_t)need_pn;
+    need_pn += ((size_t)p.nblocks + ((p.df % 128) ? 1u : 0u)) * 128;  // the tail's norms follow the FullBlocks'
+    work.push_back(p);
+    fps.push_back(st.doc_start_fp);
+  }
+  if (work.empty()) return RGPU_OK;
+  HIP_TRY(scratch_take(c));
+  HIP_TRY(seg->pnorm.reserve(need_pn + 64, seg->pnorm_used, c->stream));
+  std::vector<int64_t> item_prefix;
+  int64_t n_items = 0, postings = 0;
+  prep_items(work, &item_prefix, &n_items, &postings);
+  Stager st(c);
+  const size_t o_work = st.add(work.size() * sizeof(PrepTerm));
+  const size_t o_items = st.add(item_prefix.size() * 8);
+  HIP_TRY(c->S->h_stage.reserve(st.used));
+  HIP_TRY(c->S->d_stage.reserve(st.used, 0, c->stream));
+  std::memcpy(c->S->h_stage.p + o_work, work.data(), work.size() * sizeof(PrepTerm));
+  std::memcpy(c->S->h_stage.p + o_items, item_prefix.data(), item_prefix.size() * 8);
+  HIP_TRY(hipMemcpyAsync(c->S->d_stage.p, c->S->h_stage.p, st.used, hipMemcpyHostToDevice, c->stream));
+  {
+    TimedLaunch tl(c, c->stream, "k_prepare_norms", postings);
+    const unsigned grid = (unsigned)((n_items + PREP_WAVES - 1) / PREP_WAVES);
+    auto go = [&](auto kern) {
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(PREP_THREADS), 0, c->stream, seg_view(seg), reinterpret_cast<const PrepTerm*>(c->S->d_stage.p + o_work),
+                         reinterpret_cast<const int64_t*>(c->S->d_stage.p + o_items), (int)work.size(), n_items, seg->pnorm.p, seg->dir_bmax.p,
+                         seg->n_norm_ranks > 0 ? 1 : 0);
+    };
+    if (seg->version < 1) go(k_prepare_norms<true>); else go(k_prepare_norms<false>);
+  }
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(hipGetLastError());
+  seg->pnorm_used = need_pn;
+  for (size_t i = 0; i < work.size(); ++i) {
+    TermInfo info = *seg->prepared.find(fps[i]);
+    info.pn_base = work[i].pn_base;
+    info.norms = true;
+    seg->prepared.put(fps[i], info);
+  }
+  return RGPU_OK;
+}
+
+static int32_t make_dev_term(const rgpu_segment* seg, const rgpu_term_state& st, float weight, int32_t sim_table, DevTerm* out, bool need_norms = true) {
   DevTerm t;
   std::memset(&t, 0, sizeof t);
   t.start_fp = (uint64_t)std::max<int64_t>(0, st.doc_start_fp);
@@ -454,6 +554,7 @@ static int32_t make_dev_term(const rgpu_segment* seg, const rgpu_term_state& st,
   if (st.doc_freq >= 2) {
     const TermInfo* info = seg->prepared.find(st.doc_start_fp);
     if (!info) return fail(RGPU_ERR_ILLEGAL_STATE, "term not prepared");
+    if (need_norms && !info->norms) return fail(RGPU_ERR_ILLEGAL_STATE, "term's posting-order norms not prepared");
     t.dir_base = info->dir_base;
     t.nblocks = info->nblocks;
     t.pn_base = info->pn_base;
@@ -490,7 +591,7 @@ extern "C" int32_t rgpu_init(int32_t device_ordinal, const rgpu_config* cfg, rgp
   if (c->cfg.blocks_per_item <= 0) { c->cfg.blocks_per_item = 32; c->blocks_per_item_auto = true; }
   if (c->cfg.and_blocks_per_item <= 0) c->cfg.and_blocks_per_item = 4;  // measured 3-5 % over 2 (fewer items, cursors reused longer)
   std::snprintf(c->name, sizeof c->name, "%s (%s)", prop.name, prop.gcnArchName);
-  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipMalloc(&c->d_err, 2 * sizeof(int)) != hipSuccess) {
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipMalloc(&c->d_err, 4 * sizeof(int)) != hipSuccess) {
     delete c;
     return fail(RGPU_ERR_RUNTIME, "failed to create stream / error word");
   }
@@ -695,7 +796,7 @@ extern "C" void rgpu_segment_free(rgpu_segment* s) {
   if (s->d_rank_to_norm) (void)hipFree(s->d_rank_to_norm);
   if (s->d_live) (void)hipFree(s->d_live);
   if (s->d_pos) (void)hipFree(s->d_pos);
-  s->dir_last.release(); s->dir_off.release(); s->dir_row.release(); s->dir_hdr.release(); s->dir_bmax.release(); s->dir_pos.release(); s->pnorm.release(); s->bstore.release();
+  s->dir_last.release(); s->dir_off.release(); s->dir_row.release(); s->dir_hdr.release(); s->dir_bmax.release(); s->dir_pos.release(); s->pnorm.release(); s->bstore.release(); s->prep_scratch.release();
   delete s;
 }
 
@@ -744,7 +845,7 @@ static int32_t decode_terms_impl(rgpu_segment* seg, const rgpu_term_state* terms
   rgpu_ctx* c = seg->ctx;
   std::vector<const rgpu_term_state*> ptrs((size_t)n_terms);
   for (int64_t i = 0; i < n_terms; ++i) ptrs[(size_t)i] = &terms[i];
-  int32_t rc = prepare_terms_locked(seg, ptrs.data(), ptrs.size());
+  int32_t rc = prepare_terms_locked(seg, ptrs.data(), ptrs.size(), false);  // a decode needs no norms: stage A only
   if (rc != RGPU_OK) return rc;
   HIP_TRY(scratch_take(c));  // callers synchronize the stream before they return
   Stager st(c);
@@ -759,7 +860,7 @@ static int32_t decode_terms_impl(rgpu_segment* seg, const rgpu_term_state* terms
   int64_t items = 0, out = 0;
   const int dec_blocks_per_item = 16;
   for (int64_t i = 0; i < n_terms; ++i) {
-    rc = make_dev_term(seg, terms[i], 0.f, 0, &ht[i]);
+    rc = make_dev_term(seg, terms[i], 0.f, 0, &ht[i], false);
     if (rc != RGPU_OK) return rc;
     hitems[i] = items;
     hout[i] = out;
@@ -832,10 +933,10 @@ extern "C" int32_t rgpu_advance_batch(rgpu_segment* seg, const rgpu_term_state* 
   HIP_TRY(hipSetDevice(c->device));
   if (term->doc_freq <= 0) { for (int64_t i = 0; i < n; ++i) { out_docs[i] = RGPU_NO_MORE_DOCS; out_freqs[i] = 0; } return RGPU_OK; }
   const rgpu_term_state* p = term;
-  int32_t rc = prepare_terms_locked(seg, &p, 1);
+  int32_t rc = prepare_terms_locked(seg, &p, 1, false);
   if (rc != RGPU_OK) return rc;
   DevTerm T;
-  rc = make_dev_term(seg, *term, 0.f, 0, &T);
+  rc = make_dev_term(seg, *term, 0.f, 0, &T, false);
   if (rc != RGPU_OK) return rc;
   int32_t* d = nullptr;
   HIP_TRY(hipMalloc(&d, (size_t)n * 12));

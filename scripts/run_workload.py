@@ -26,8 +26,8 @@ if kind == "cold":
     tf = torch.empty(total, dtype=torch.int32, device="cuda")
     for _ in range(reps):
         leaf.segment.release_prepared_terms()
-        leaf.segment.prepare_terms(sel)
-        leaf.segment.decode_terms_device(sel, td.data_ptr(), tf.data_ptr())
+        leaf.segment.decode_terms_device(sel, td.data_ptr(), tf.data_ptr())   # stage A of the preparation + the decode
+        leaf.segment.prepare_terms(sel)                                       # + stage B (norms), what a search adds
     print("footprint", leaf.segment.footprint())
 elif kind == "decode":
     sel = seg.terms[seg.terms["doc_freq"] >= 128]
