@@ -32,6 +32,12 @@ class FlatFpMap {
     }
   }
   void clear() { slots_.clear(); used_ = 0; mask_ = 0; }
+  // room for n more keys without rehashing on the way
+  void reserve_more(size_t n) {
+    size_t want = slots_.empty() ? 1024 : slots_.size();
+    while ((used_ + n + 1) * 2 > want) want *= 2;
+    if (want != slots_.size()) regrow(want);
+  }
   size_t size() const { return used_; }
 
  private:
@@ -41,10 +47,11 @@ class FlatFpMap {
     const uint64_t x = (uint64_t)k * 0x9E3779B97F4A7C15ull;
     return (size_t)(x ^ (x >> 29));
   }
-  void grow() {
+  void grow() { regrow(slots_.empty() ? 1024 : slots_.size() * 2); }
+  void regrow(size_t n_slots) {
     std::vector<Slot> old;
     old.swap(slots_);
-    slots_.assign(old.empty() ? 1024 : old.size() * 2, Slot());
+    slots_.assign(n_slots, Slot());
     mask_ = slots_.size() - 1;
     used_ = 0;
     for (const Slot& s : old) if (s.key != EMPTY) put(s.key, s.value);

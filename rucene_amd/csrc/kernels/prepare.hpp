@@ -13,8 +13,8 @@
 // Stage A is four launches, each spread over the whole chip whatever the terms' sizes (round 2 walked a term's skip data
 // and block headers with ONE workgroup: 3.4 ms for the 20 M-posting head term of the 100 M-doc shard, whatever else ran):
 //   k_skip_dir       one wavefront per 1 KB of level-0 bytes: parallel VInt parse; a chunk's position in the value stream
-//                    and the running sums before it come from the chunks in front of it (each publishes {count, sums}; a
-//                    ticket hands chunks out in order, so a chunk only ever waits for wavefronts that are already running)
+//                    and the running sums before it come from the chunks in front of it (each publishes {count, sums};
+//                    workgroups start in id order, so a chunk only ever waits for wavefronts that are already running)
 //   k_block_headers  one lane per block: header bytes -> directory header word + the block's rows in the store; every skip
 //                    pointer checked against the block sizes
 //   k_scan_*         exclusive prefix sum of the row counts -> each block's place in the store (one dense region per call)
@@ -94,10 +94,12 @@ __global__ __launch_bounds__(PREP_THREADS) void k_skip_dir(const uint8_t* __rest
   __shared__ __attribute__((aligned(16))) uint8_t stage[PREP_WAVES][16 + SKIP_CHUNK_BYTES];
   const int lane = lane_id();
   const int wave = wave_id();
-  // chunks are handed out in order: whoever holds chunk i knows that every chunk < i is held by a running (or finished) wavefront
-  unsigned long long tk = 0;
-  if (lane == 0) tk = atomicAdd(ticket, 1ull);
-  const int64_t item = (int64_t)(((uint64_t)(uint32_t)readfirstlane((int)(uint32_t)(tk >> 32)) << 32) | (uint32_t)readfirstlane((int)(uint32_t)tk));
+  // A chunk only ever waits for chunks with LOWER item numbers (of its own term). Workgroups are dispatched in the order of
+  // their ids (per XCD: round-robin over the eight of them, each in order), so whatever a wavefront waits for has been
+  // dispatched before it and runs, or has finished — no ticket counter needed (one was tried: 166 k atomics on one address
+  // cost 3.5 ms on the 100 M-doc shard, the whole kernel's time).
+  (void)ticket;
+  const int64_t item = (int64_t)blockIdx.x * PREP_WAVES + wave;
   if (item >= n_chunks) return;
   const int t = upper_slot(chunk_prefix, n_terms, item);
   const int c = (int)(item - chunk_prefix[t]);

@@ -349,6 +349,7 @@ static int32_t prepare_terms_attempt(rgpu_segment* seg, const rgpu_term_state* c
   uint64_t cap_rows = 0;
   std::vector<std::pair<int64_t, TermInfo>> added;
   rucene::FlatFpMap<int> in_batch;
+  if (n > 4096) { in_batch.reserve_more(n); work.reserve(n); added.reserve(n); }
   for (size_t i = 0; i < n; ++i) {
     const rgpu_term_state& st = *sts[i];
     if (st.doc_freq < 2) {  // a singleton lives in the term dictionary; everything else has blocks and / or a tail
@@ -474,6 +475,7 @@ static int32_t prepare_terms_attempt(rgpu_segment* seg, const rgpu_term_state* c
   }
   seg->dir_used = need_slots;
   seg->bstore_used = batch_bs + (size_t)total_rows * 16;
+  seg->prepared.reserve_more(added.size());
   for (auto& a : added) seg->prepared.put(a.first, a.second);
   return RGPU_OK;
 }

@@ -1225,7 +1225,8 @@ def test_search_counters_tell_decoded_from_covered(ctx, oracle):
     searcher.search_batch([B.build([T(0), T(1), T(2)], []), B.build([T(3), T(50)], [])], 10)
     c = ctx.last_search_counters()
     assert c["op"] == 1 and c["blocks_decoded"] > 0 and c["touched_bytes"] == ctx.and_touched_bytes()
-    assert c["postings_covered"] == int(seg.terms["doc_freq"][[0, 1, 2, 3, 50]].sum()) and c["postings_decoded"] <= c["postings_covered"] + 128 * 5
+    # (the conjunction kernel may unpack a block of a later clause more than once: for every lead block that reaches into it)
+    assert c["postings_covered"] == int(seg.terms["doc_freq"][[0, 1, 2, 3, 50]].sum()) and 0 < c["postings_decoded"] <= 4 * c["postings_covered"]
     live = np.full((seg.max_doc + 63) // 64, ~np.uint64(0), dtype=np.uint64)
     live[3] = np.uint64(0)                                                                       # docs 192..255 deleted
     leaf2 = rucene_amd.LeafReader(seg.doc_bytes, seg.norms, seg.max_doc, seg.terms, live_docs=live, sum_total_term_freq=seg.sum_total_term_freq)
