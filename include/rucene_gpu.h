@@ -464,18 +464,25 @@ typedef struct rgpu_phrase_term {
   int32_t position;
   int32_t reserved;
 } rgpu_phrase_term;
-/* PhraseQuery with slop 0. `weight` = idf summed over the phrase's terms x boost (PhraseQuery::create_weight,
- * phrase_query.rs:136-186 -> rgpu_bm25_compute_weight with every term's doc_freq), `sim_table` as for rgpu_query_term. */
+/* PhraseQuery. `weight` = idf summed over the phrase's terms x boost (PhraseQuery::create_weight,
+ * phrase_query.rs:136-186 -> rgpu_bm25_compute_weight with every term's doc_freq), `sim_table` as for rgpu_query_term.
+ * `terms` of a query are in the QUERY's own order (PhraseQuery::new's terms / positions vectors): a sloppy phrase's scorer
+ * breaks ties by that order. */
 typedef struct rgpu_phrase_query {
   int32_t n_terms;     /* 2..RGPU_MAX_QUERY_TERMS (the reference turns a one-term phrase into a TermQuery) */
   int32_t first_term;  /* index of the query's first term in `terms` */
   float weight;
   int32_t sim_table;
+  int32_t slop;        /* PhraseQuery::slop: 0 = ExactPhraseScorer, > 0 = SloppyPhraseScorer (phrase_query.rs:312-331) */
+  int32_t reserved;    /* must be zero */
 } rgpu_phrase_query;
 /* One leaf of IndexSearcher::search(PhraseQuery, TopDocsCollector(k)): PhraseWeight::create_scorer (None when a term is
- * absent from the leaf) -> ExactPhraseScorer (scorer/phrase_scorer.rs:122-294) — a doc matches when the terms occur at
- * their phrase offsets, its score is BM25(phrase frequency, norm). Outputs as rgpu_search_batch; scores are bit-exact
- * with the CPU scorer. A doc holding one of the phrase's terms more than 1024 times -> RGPU_ERR_UNSUPPORTED. */
+ * absent from the leaf) -> slop 0: ExactPhraseScorer (scorer/phrase_scorer.rs:122-294) — a doc matches when the terms occur
+ * at their phrase offsets, its score is BM25(phrase frequency, norm); slop > 0: SloppyPhraseScorer (:432-1071) — the
+ * reference's walk of the terms' positions through a priority queue, repeated terms and their collision handling
+ * included, sloppy frequency = sum of 1 / (span + 1) over the spans within the slop, score BM25(sloppy frequency, norm).
+ * Outputs as rgpu_search_batch; scores are bit-exact with the CPU scorers. A doc holding one of an exact phrase's terms more
+ * than 1024 times, or a sloppy phrase's terms more than 2048 times in all -> RGPU_ERR_UNSUPPORTED. */
 int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase_query* queries, int32_t n_queries,
                                  const rgpu_phrase_term* terms, int32_t n_terms_total, int32_t k, rgpu_hit* hits_out,
                                  int64_t* total_hits_out);

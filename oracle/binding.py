@@ -138,6 +138,9 @@ def _declare(L):
         "orc_pos_phrase_freqs": (C.c_int64, [vp, i32p, i32p, C.c_int, i32p, i32p, C.c_int64]),
         "orc_pos_phrase_search": (C.c_int, [vp, i32p, i32p, C.c_int, u8p, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, i32p, f32p,
                                             i32p, i64p]),
+        "orc_pos_sloppy_freqs": (C.c_int64, [vp, i32p, i32p, C.c_int, C.c_int, i32p, f32p, C.c_int64]),
+        "orc_pos_phrase_search_slop": (C.c_int, [vp, i32p, i32p, C.c_int, C.c_int, u8p, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, i32p, f32p,
+                                                 i32p, i64p]),
         "orc_compound_write": (C.c_int, [C.c_int32, u8p, u8p, i64p, u8p, u8p, i64p, u8p, i64p]),
         "orc_compound_read": (C.c_int, [u8p, C.c_int64, u8p, C.c_int64, u8p, C.c_int32, u8p, C.c_int64, i64p, i64p, i64p]),
         "orc_segment_info_write": (C.c_int, [u8p, u8p, i32p, C.c_int32, C.c_int, u8p, i64p]),
@@ -922,13 +925,26 @@ class PositionsIndex:
         n = _check(lib().orc_pos_phrase_freqs(self._h, _p(t, C.c_int32), _p(o, C.c_int32), t.size, _p(docs, C.c_int32), _p(freqs, C.c_int32), cap))
         return list(zip(docs[:n].tolist(), freqs[:n].tolist()))
 
-    def phrase_search(self, term_ids, k, norms, max_doc, doc_count, sum_total_term_freq, offsets=None, tie_mode=TIE_CANONICAL):
-        """IndexSearcher::search(PhraseQuery(slop 0), TopDocsCollector(k)) -> (docs, scores, total_hits)."""
+    def sloppy_freqs(self, term_ids, slop, offsets=None, cap=1 << 20):
+        """SloppyPhraseScorer over the phrase term_ids (query order; positions 0, 1, 2, ... unless `offsets`): [(doc, sloppy freq f32)]."""
+        t = np.ascontiguousarray(term_ids, dtype=np.int32)
+        o = np.ascontiguousarray(range(t.size) if offsets is None else offsets, dtype=np.int32)
+        docs, freqs = np.zeros(cap, np.int32), np.zeros(cap, np.float32)
+        n = _check(lib().orc_pos_sloppy_freqs(self._h, _p(t, C.c_int32), _p(o, C.c_int32), t.size, int(slop), _p(docs, C.c_int32), _p(freqs, C.c_float), cap))
+        return docs[:n].copy(), freqs[:n].copy()
+
+    def phrase_search(self, term_ids, k, norms, max_doc, doc_count, sum_total_term_freq, offsets=None, tie_mode=TIE_CANONICAL, slop=0):
+        """IndexSearcher::search(PhraseQuery(slop), TopDocsCollector(k)) -> (docs, scores, total_hits)."""
         t = np.ascontiguousarray(term_ids, dtype=np.int32)
         o = np.ascontiguousarray(range(t.size) if offsets is None else offsets, dtype=np.int32)
         nm = None if norms is None else np.ascontiguousarray(norms, dtype=np.uint8)
         docs, scores = np.zeros(max(k, 1), np.int32), np.zeros(max(k, 1), np.float32)
         n, total = C.c_int32(), C.c_int64()
+        if slop:
+            _check(lib().orc_pos_phrase_search_slop(self._h, _p(t, C.c_int32), _p(o, C.c_int32), t.size, int(slop), _p(nm, C.c_uint8), int(max_doc),
+                                                    int(doc_count), int(sum_total_term_freq), k, tie_mode, _p(docs, C.c_int32), _p(scores, C.c_float),
+                                                    C.byref(n), C.byref(total)))
+            return docs[:n.value].copy(), scores[:n.value].copy(), total.value
         _check(lib().orc_pos_phrase_search(self._h, _p(t, C.c_int32), _p(o, C.c_int32), t.size, _p(nm, C.c_uint8), int(max_doc), int(doc_count),
                                            int(sum_total_term_freq), k, tie_mode, _p(docs, C.c_int32), _p(scores, C.c_float), C.byref(n),
                                            C.byref(total)))

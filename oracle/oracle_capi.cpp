@@ -17,6 +17,7 @@
 #include "segment_infos.hpp"
 #include "positions.hpp"
 #include "phrase.hpp"
+#include "sloppy_phrase.hpp"
 #include "compound.hpp"
 #include "store.hpp"
 
@@ -977,6 +978,70 @@ int orc_pos_phrase_search(orc_pos_index* h, const int32_t* term_ids, const int32
   TopDocsCollector collector((size_t)k, tie_mode);
   auto sc = make_phrase_scorer(h, term_ids, offsets, n, &w, norms, true);
   if (sc) bulk_score(sc.get(), &collector, nullptr, 0, NO_MORE_DOCS, 0);
+  std::vector<ScoreDoc> r = collector.top_docs();
+  *out_n = (int32_t)r.size();
+  *out_total = (int64_t)collector.total_hits;
+  for (size_t i = 0; i < r.size(); i++) { out_docs[i] = r[i].doc; out_scores[i] = r[i].score; }
+  return 0;
+  ORC_CATCH
+}
+
+// PhraseWeight::create_scorer with slop > 0 (phrase_query.rs:324-331): SloppyPhraseScorer over the postings in QUERY order
+static std::unique_ptr<SloppyPhraseScorer> make_sloppy_scorer(orc_pos_index* h, const int32_t* term_ids, const int32_t* offsets, int n, int slop,
+                                                              const BM25Weight* w, const uint8_t* norms, bool needs_scores) {
+  if (n < 2) throw OracleError(E_ILLEGAL_ARGUMENT, "PhraseWeight does not support less than 2 terms");
+  if (offsets[0] != 0) throw OracleError(E_ILLEGAL_ARGUMENT, "PhraseWeight requires that the first position is 0");
+  if (slop < 0) throw OracleError(E_ILLEGAL_ARGUMENT, "Slop must be >= 0");
+  std::vector<std::unique_ptr<BlockPostingIterator>> its;
+  std::vector<int32_t> offs;
+  std::vector<int64_t> terms;
+  for (int i = 0; i < n; i++) {
+    const PosTermState& st = h->terms.at((size_t)term_ids[i]);
+    if (st.base.doc_freq <= 0) return nullptr;
+    its.emplace_back(new BlockPostingIterator(h->reader.get(), h->pos_file.get(), st));
+    offs.push_back(offsets[i]);
+    terms.push_back(term_ids[i]);
+  }
+  return std::make_unique<SloppyPhraseScorer>(std::move(its), offs, terms, slop, w, norms, needs_scores);
+}
+// every matching doc with its sloppy frequency (scorer.next() to exhaustion, needs_scores = true)
+int64_t orc_pos_sloppy_freqs(orc_pos_index* h, const int32_t* term_ids, const int32_t* offsets, int n, int slop, int32_t* out_docs,
+                             float* out_freqs, int64_t cap) {
+  ORC_TRY
+  BM25Weight w{};
+  auto sc = make_sloppy_scorer(h, term_ids, offsets, n, slop, &w, nullptr, true);
+  if (!sc) return 0;
+  int64_t m = 0;
+  for (int32_t d = sc->next(); d != NO_MORE_DOCS; d = sc->next()) {
+    if (m >= cap) throw OracleError(E_ILLEGAL_ARGUMENT, "capacity exceeded");
+    out_docs[m] = d;
+    out_freqs[m++] = sc->sloppy_freq();
+  }
+  return m;
+  ORC_CATCH
+}
+// IndexSearcher::search(PhraseQuery(slop), TopDocsCollector(k)) over this one segment; slop 0 = the exact scorer
+int orc_pos_phrase_search_slop(orc_pos_index* h, const int32_t* term_ids, const int32_t* offsets, int n, int slop, const uint8_t* norms,
+                               int64_t max_doc, int64_t doc_count, int64_t sum_total_term_freq, int k, int tie_mode, int32_t* out_docs,
+                               float* out_scores, int32_t* out_n, int64_t* out_total) {
+  ORC_TRY
+  CollectionStatistics cs;
+  cs.max_doc = max_doc; cs.doc_count = doc_count; cs.sum_total_term_freq = sum_total_term_freq;
+  std::vector<TermStatistics> ts((size_t)n);
+  for (int i = 0; i < n; i++) {
+    const PosTermState& st = h->terms.at((size_t)term_ids[i]);
+    ts[(size_t)i].doc_freq = st.base.doc_freq;
+    ts[(size_t)i].total_term_freq = st.base.total_term_freq;
+  }
+  BM25Weight w = bm25_compute_weight(1.2f, 0.75f, cs, ts.data(), n, 1.0f);
+  TopDocsCollector collector((size_t)k, tie_mode);
+  if (slop == 0) {
+    auto sc = make_phrase_scorer(h, term_ids, offsets, n, &w, norms, true);
+    if (sc) bulk_score(sc.get(), &collector, nullptr, 0, NO_MORE_DOCS, 0);
+  } else {
+    auto sc = make_sloppy_scorer(h, term_ids, offsets, n, slop, &w, norms, true);
+    if (sc) bulk_score(sc.get(), &collector, nullptr, 0, NO_MORE_DOCS, 0);
+  }
   std::vector<ScoreDoc> r = collector.top_docs();
   *out_n = (int32_t)r.size();
   *out_total = (int64_t)collector.total_hits;

@@ -24,8 +24,9 @@ TERM_POSITIONS_DTYPE_ = np.dtype([("pos_start_fp", "<i8"), ("pay_start_fp", "<i8
 PHRASE_TERM_DTYPE = np.dtype([("state", TERM_STATE_DTYPE), ("positions", TERM_POSITIONS_DTYPE_), ("position", "<i4"), ("reserved", "<i4")], align=True)
 RESCORE_REQUEST_DTYPE = np.dtype([("query_weight", "<f4"), ("rescore_weight", "<f4"), ("mode", "<i4"), ("window_size", "<i4")], align=True)
 RESCORE_AVG, RESCORE_MAX, RESCORE_MIN, RESCORE_TOTAL, RESCORE_MULTIPLY = range(5)
-PHRASE_QUERY_DTYPE = np.dtype([("n_terms", "<i4"), ("first_term", "<i4"), ("weight", "<f4"), ("sim_table", "<i4")], align=True)
-assert PHRASE_TERM_DTYPE.itemsize == 64 and PHRASE_QUERY_DTYPE.itemsize == 16
+PHRASE_QUERY_DTYPE = np.dtype([("n_terms", "<i4"), ("first_term", "<i4"), ("weight", "<f4"), ("sim_table", "<i4"), ("slop", "<i4"), ("reserved", "<i4")],
+                              align=True)
+assert PHRASE_TERM_DTYPE.itemsize == 64 and PHRASE_QUERY_DTYPE.itemsize == 24
 FIELD_INFO_DTYPE = np.dtype([("number", "<i4"), ("index_options", "<i4"), ("has_payloads", "<i4"), ("flags", "<i4")], align=True)
 FIELD_STATS_DTYPE = np.dtype([("num_terms", "<i8"), ("sum_total_term_freq", "<i8"), ("sum_doc_freq", "<i8"), ("doc_count", "<i4"),
                               ("longs_size", "<i4")], align=True)

@@ -112,14 +112,16 @@ struct BooleanQuery : Query {
   }
 };
 
-// PhraseQuery with slop 0 (query/phrase_query.rs:60-110: PhraseQuery::build numbers the terms' positions 0, 1, 2, ...;
+// PhraseQuery (query/phrase_query.rs:60-130: PhraseQuery::build numbers the terms' positions 0, 1, 2, ...;
 // explicit positions leave gaps). Needs a positions field (LeafReader::index_options == 3 with pos_bytes).
 struct PhraseQuery : Query {
   std::vector<TermQuery> terms;
   std::vector<int32_t> positions;
   float boost;
-  explicit PhraseQuery(std::vector<TermQuery> t, std::vector<int32_t> pos = {}, float b = 1.0f)
-      : terms(std::move(t)), positions(std::move(pos)), boost(b) {
+  int32_t slop;  // 0: ExactPhraseScorer; > 0: SloppyPhraseScorer (phrase_query.rs:312-331)
+  explicit PhraseQuery(std::vector<TermQuery> t, std::vector<int32_t> pos = {}, float b = 1.0f, int32_t slop_ = 0)
+      : terms(std::move(t)), positions(std::move(pos)), boost(b), slop(slop_) {
+    if (slop < 0) throw Error(RGPU_ERR_ILLEGAL_ARGUMENT, "Slop must be >= 0");
     if (positions.empty()) for (size_t i = 0; i < terms.size(); ++i) positions.push_back(static_cast<int32_t>(i));
     if (terms.size() < 2 || terms.size() != positions.size())
       throw Error(RGPU_ERR_ILLEGAL_ARGUMENT, "a phrase needs two or more terms, one position each (a one-term phrase is a TermQuery)");
@@ -386,7 +388,7 @@ class GpuIndexSearcher {
         for (const TermQuery& t : q->terms) stats.push_back(term_statistics(t));
         const BM25SimWeight w = sim_.compute_weight(stats_, stats.data(), static_cast<int32_t>(stats.size()), q->boost);
         if (sim_table_ < 0) check(sim_table_ = rgpu_sim_table_upload(ctx_, w.cache.data(), w.k1));
-        qs.push_back(rgpu_phrase_query{static_cast<int32_t>(q->terms.size()), static_cast<int32_t>(ts.size()), w.weight, sim_table_});
+        qs.push_back(rgpu_phrase_query{static_cast<int32_t>(q->terms.size()), static_cast<int32_t>(ts.size()), w.weight, sim_table_, q->slop, 0});
         for (size_t i = 0; i < q->terms.size(); ++i) {
           rgpu_phrase_term pt{};
           if (!leaf.positions_state(q->terms[i], &pt.state, &pt.positions)) { pt.state = rgpu_term_state{}; pt.state.skip_offset = -1; pt.state.singleton_doc_id = -1; }

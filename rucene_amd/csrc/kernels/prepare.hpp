@@ -10,11 +10,11 @@
 // The higher skip levels are subsampled copies of level 0 with child pointers; a flat level-0 directory plus binary
 // search gives the same `advance` answers, so only their byte lengths are parsed (to find level 0).
 //
-// Stage A is four launches, each spread over the whole chip whatever the terms' sizes (round 2 walked a term's skip data
+// Stage A is a handful of launches, each spread over the whole chip whatever the terms' sizes (round 2 walked a term's skip data
 // and block headers with ONE workgroup: 3.4 ms for the 20 M-posting head term of the 100 M-doc shard, whatever else ran):
-//   k_skip_dir       one wavefront per 1 KB of level-0 bytes: parallel VInt parse; a chunk's position in the value stream
-//                    and the running sums before it come from the chunks in front of it (each publishes {count, sums};
-//                    workgroups start in id order, so a chunk only ever waits for wavefronts that are already running)
+//   k_skip_dir<1,2>  one wavefront per 1 KB of level-0 bytes: parallel VInt parse; a chunk's position in the value stream
+//                    and the running sums before it come from the chunks in front of it: pass 1 leaves every chunk's
+//                    {count, sums}, pass 2 adds up the ones in front and writes the directory
 //   k_block_headers  one lane per block: header bytes -> directory header word + the block's rows in the store; every skip
 //                    pointer checked against the block sizes
 //   k_scan_*         exclusive prefix sum of the row counts -> each block's place in the store (one dense region per call)
@@ -69,7 +69,7 @@ __device__ __forceinline__ int vint_len_serial(const uint8_t* p) {
 // field a residue is depends on how many values precede the chunk, known once the chunks in front have published.
 struct SkipAgg {
   uint32_t count;
-  uint32_t ready;  // written last (release)
+  uint32_t pad0;
   uint32_t sum[4];
   uint32_t pad[2];
 };
@@ -87,21 +87,21 @@ __device__ __forceinline__ uint32_t pick4(const uint32_t (&v)[4], uint32_t i) { 
   return (i & 2u) ? hi : lo;
 }
 
+// PASS selects the half of the job: 1 = parse this chunk and leave its aggregate; 2 = parse it again (cheaper than keeping
+// the values anywhere), take the aggregates of the chunks in front of it — complete: they were written by the launch
+// before — and write the directory. (One launch with the chunks waiting for each other was tried first: the wavefronts of a
+// 20 M-posting term's 1220 chunks spinning on acquire loads cost 1 - 4 ms, varying from run to run.)
+template <int PASS>
 __global__ __launch_bounds__(PREP_THREADS) void k_skip_dir(const uint8_t* __restrict__ doc, int64_t doc_len, int64_t doc_cap,
                                                            const PrepTerm* __restrict__ terms, const int64_t* __restrict__ chunk_prefix,
-                                                           int n_terms, int64_t n_chunks, SkipAgg* aggs, unsigned long long* ticket,
+                                                           int n_terms, int64_t n_chunks, SkipAgg* aggs,
                                                            int32_t* dir_last, uint32_t* dir_off, uint64_t* dir_pos, int* err) {
   __shared__ __attribute__((aligned(16))) uint8_t stage[PREP_WAVES][16 + SKIP_CHUNK_BYTES];
   const int lane = lane_id();
   const int wave = wave_id();
-  // A chunk only ever waits for chunks with LOWER item numbers (of its own term). Workgroups are dispatched in the order of
-  // their ids (per XCD: round-robin over the eight of them, each in order), so whatever a wavefront waits for has been
-  // dispatched before it and runs, or has finished — no ticket counter needed (one was tried: 166 k atomics on one address
-  // cost 3.5 ms on the 100 M-doc shard, the whole kernel's time).
-  (void)ticket;
   const int64_t item = (int64_t)blockIdx.x * PREP_WAVES + wave;
   if (item >= n_chunks) return;
-  const int t = upper_slot(chunk_prefix, n_terms, item);
+  const int t = upper_slot_wave(chunk_prefix, n_terms, item, lane);
   const int c = (int)(item - chunk_prefix[t]);
   const int n_mine = (int)(chunk_prefix[t + 1] - chunk_prefix[t]);
   const PrepTerm T = terms[t];
@@ -109,13 +109,12 @@ __global__ __launch_bounds__(PREP_THREADS) void k_skip_dir(const uint8_t* __rest
   const uint32_t need = vals * (uint32_t)T.n_entries;
   SkipAgg* const mine = aggs + item;
   auto publish = [&](uint32_t count, uint32_t s0, uint32_t s1, uint32_t s2, uint32_t s3) {
-    if (lane == 0) {
+    if (PASS == 1 && lane == 0) {
       mine->count = count;
       mine->sum[0] = s0; mine->sum[1] = s1; mine->sum[2] = s2; mine->sum[3] = s3;
-      __hip_atomic_store(&mine->ready, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
   };
-  if (c == 0 && lane == 0) {
+  if (PASS == 2 && c == 0 && lane == 0) {
     dir_off[T.dir_base] = 0;
     if (dir_pos) dir_pos[T.dir_base] = 0ull;
     if (T.nblocks > T.n_entries && T.nblocks > 0) dir_last[T.dir_base + T.nblocks - 1] = DIR_SENTINEL_DOC;  // df % 128 == 0
@@ -131,7 +130,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_skip_dir(const uint8_t* __rest
     if (l0 >= doc_len) { lost = true; break; }
   }
   if (lost) {
-    if (lane == 0 && c == 0) flag_err(err, -4, 1);
+    if (PASS == 2 && lane == 0 && c == 0) flag_err(err, -4, 1);
     publish(0, 0, 0, 0, 0);
     return;
   }
@@ -166,7 +165,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_skip_dir(const uint8_t* __rest
     }
     return (uint32_t)v;
   };
-  // ---- pass 1: sums by local residue
+  // ---- sums by local residue
   uint32_t sl[4] = {0u, 0u, 0u, 0u};
   {
     uint32_t m = term, li = li0;
@@ -178,8 +177,11 @@ __global__ __launch_bounds__(PREP_THREADS) void k_skip_dir(const uint8_t* __rest
       ++li;
     }
   }
-  publish(total, (uint32_t)wave_reduce_add((int)sl[0]), (uint32_t)wave_reduce_add((int)sl[1]), (uint32_t)wave_reduce_add((int)sl[2]),
-          (uint32_t)wave_reduce_add((int)sl[3]));
+  if (PASS == 1) {
+    publish(total, (uint32_t)wave_reduce_add((int)sl[0]), (uint32_t)wave_reduce_add((int)sl[1]), (uint32_t)wave_reduce_add((int)sl[2]),
+            (uint32_t)wave_reduce_add((int)sl[3]));
+    return;
+  }
   // ---- the chunks in front of this one, front to back: values before this chunk (P) and the running sums by field
   uint32_t P = 0;
   uint32_t base[4] = {0u, 0u, 0u, 0u};
@@ -187,8 +189,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_skip_dir(const uint8_t* __rest
     const int j = j0 + lane;
     uint32_t cj = 0, sj[4] = {0u, 0u, 0u, 0u};
     if (j < c) {
-      SkipAgg* a = aggs + (item - c + j);
-      while (__hip_atomic_load(&a->ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(2);
+      const SkipAgg* a = aggs + (item - c + j);
       cj = a->count;
       sj[0] = a->sum[0]; sj[1] = a->sum[1]; sj[2] = a->sum[2]; sj[3] = a->sum[3];
     }
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_skip_dir(const uint8_t* __rest
     P += (uint32_t)readlane((int)inc, 63);
   }
   if (c == n_mine - 1 && P + total < need && lane == 0) flag_err(err, -4, 2);  // ran off the skip data looking for entries
-  // ---- pass 2: every value's running sum -> the directory
+  // ---- every value's running sum -> the directory
   uint32_t run[4];
   {
     // this lane's sums by FIELD, then the lanes in front of it
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_block_headers(const uint8_t* _
   const int lane = lane_id();
   const int64_t item = (int64_t)blockIdx.x * PREP_WAVES + wave_id();
   if (item >= n_items) return;
-  const int ti = upper_slot(item_prefix, n_terms, item);
+  const int ti = upper_slot_wave(item_prefix, n_terms, item, lane);
   const PrepTerm t = terms[ti];
   const int b0 = (int)(item - item_prefix[ti]) * PREP_BLOCKS_PER_ITEM;
   const int i = b0 + lane;
@@ -381,7 +382,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_blocks(const uint8_t* 
   const int wave = wave_id();
   const int64_t item = (int64_t)blockIdx.x * PREP_WAVES + wave;
   if (item >= n_items || *err != 0) return;  // a term whose framing did not check out must not be walked
-  const int ti = upper_slot(item_prefix, n_terms, item);
+  const int ti = upper_slot_wave(item_prefix, n_terms, item, lane);
   const PrepTerm t = terms[ti];
   const int b0 = (int)(item - item_prefix[ti]) * PREP_BLOCKS_PER_ITEM;
   const int b1 = min(t.nblocks, b0 + PREP_BLOCKS_PER_ITEM);
@@ -561,7 +562,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_norms(SegView seg, con
   const int wave = wave_id();
   const int64_t item = (int64_t)blockIdx.x * PREP_WAVES + wave;
   if (item >= n_items) return;
-  const int ti = upper_slot(item_prefix, n_terms, item);
+  const int ti = upper_slot_wave(item_prefix, n_terms, item, lane);
   const PrepTerm t = terms[ti];
   const int b0 = (int)(item - item_prefix[ti]) * PREP_BLOCKS_PER_ITEM;
   const int b1 = min(t.nblocks, b0 + PREP_BLOCKS_PER_ITEM);

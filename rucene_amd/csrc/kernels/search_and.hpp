@@ -20,7 +20,7 @@
 namespace rgpu {
 
 #ifdef RGPU_EXP_COUNT  // developer instrumentation (variant builds only): [0] lead blocks, [1] other-clause block decodes,
-__device__ unsigned long long g_and_dbg[4];  // [2] probed candidates, [3] (lead block, clause) visits
+__device__ unsigned long long g_and_dbg[4];  // [2] of those in dense mode, [3] (lead block, clause) visits
 #define AND_DBG(i, n) do { const unsigned long long n_ = (unsigned long long)(n); if (lane == 0) atomicAdd(&g_and_dbg[i], n_); } while (0)
 #else
 #define AND_DBG(i, n) do {} while (0)
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
   const int wave = wave_id();
   const int64_t item = (int64_t)blockIdx.x * WG_WAVES + wave;
   if (item >= n_items) return;
-  const int q = upper_slot(item_prefix, n_queries, item);
+  const int q = upper_slot_wave(item_prefix, n_queries, item, lane);
   const int chunk = (int)(item - item_prefix[q]);
   const DevQuery Q = queries[q];
   const DevTerm L = terms[Q.first_term];
@@ -226,7 +226,6 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
       // Membership of the candidates c0 / c1 in the 128 (or, for a tail, `ev`-flagged) sorted docs e0 / e1 held two per
       // lane. `freqs()` yields the lanes' freqs and is called only when the filter reports a hit.
       auto probe = [&](int32_t e0, int32_t e1, bool ev0, bool ev1, bool c0, bool c1, auto freqs) {
-        AND_DBG(2, __popcll(__ballot(c0)) + __popcll(__ballot(c1)));
         filt[lane] = 0u;
         wave_sync();
         if (ev0) atomicOr(&filt[((uint32_t)e0 >> 5) & (AND_FILTER_WORDS - 1)], 1u << (e0 & 31));
@@ -360,6 +359,7 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
               wave_sync();
               touched += block_bytes(F.hdr);
               AND_DBG(1, 1);
+              AND_DBG(2, 1);
               uint32_t x0, x1;
               staged_doc_deltas<LEGACY>(slab, F.rows, F.hdr, lane, x0, x1);
               int32_t e0, e1;

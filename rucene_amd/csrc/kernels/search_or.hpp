@@ -38,7 +38,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_score_terms(SegView seg, const D
   const int wave = wave_id();
   const int64_t item = (int64_t)blockIdx.x * WG_WAVES + wave;
   if (item >= n_items) return;
-  const int t = upper_slot(item_prefix, n_terms, item);
+  const int t = upper_slot_wave(item_prefix, n_terms, item, lane);
   const int chunk = (int)(item - item_prefix[t]);
   const DevTerm T = terms[t];
   uint8_t* slab = slabs[wave];

@@ -1,4 +1,4 @@
-// Exact PhraseQuery (slop 0) on the GPU, three launches:
+// PhraseQuery on the GPU. Exact phrases (slop 0), three launches:
 //   1. k_search_and in "emit" mode    the conjunction of the phrase's terms (PhraseWeight::create_scorer drives an
 //                                     ExactPhraseScorer through a ConjunctionScorer over the terms' postings,
 //                                     query/phrase_query.rs:262-330, scorer/phrase_scorer.rs:131-160): every doc that
@@ -15,7 +15,8 @@
 //                                     intersection of sorted lists of (position - phrase offset); the score is
 //                                     BM25(phrase freq, norm) with the phrase's summed-idf weight (:246-251);
 //   3. k_phrase_collect               TopDocsCollector over the candidates with phrase freq > 0.
-// Fields with payloads or offsets (a third file, .pay) are refused at upload; sloppy phrases (slop > 0) are not served.
+// Sloppy phrases (slop > 0): k_sloppy_groups + k_sloppy_match below instead of k_phrase_match.
+// Fields with payloads or offsets (a third file, .pay) are refused at upload.
 #pragma once
 #include "search_and.hpp"
 
@@ -25,13 +26,113 @@ constexpr int RGPU_MAX_K_DEV = 128;  // = RGPU_MAX_K: the widest list a wavefron
 constexpr int PHRASE_LIST_CAP = 1024;  // positions of one term inside one doc that the LDS lists hold
 constexpr int32_t PHRASE_DEAD = (int32_t)0x80000000;
 
+// The positions of `doc` in term T (its clause's PosTerm P), as (position - phrase offset), ascending, into L[0 .. freq):
+// steps 1-3 of k_phrase_match's header comment. Returns freq (>= 1), or a negative code: -1 the doc is not in the term's
+// postings (the conjunction said it is: internal error), -4 corrupt position data, -5 more than `cap` positions.
+template <bool LEGACY>
+__device__ __forceinline__ int phrase_doc_positions(const SegView& seg, const DevTerm& T, const PosTerm& P, int32_t doc, int64_t pos_len,
+                                                    uint8_t* slab, int32_t* L, int cap, int lane) {
+  // ---- 1. the doc's posting in this term: where its positions start in the term's position stream
+  int64_t fp = (int64_t)P.pos_start_fp;
+  int skip = 0, freq = 0;
+  if (T.df == 1) {
+    freq = T.singleton_freq;
+  } else {
+    const int blk = find_block(seg.dir_last, T.dir_base, T.nblocks, doc);
+    int32_t e0, e1;
+    uint32_t g0, g1;
+    bool v0 = true, v1 = true;
+    if (blk < T.nblocks) {
+      const int32_t base = blk == 0 ? 0 : seg.dir_last[T.dir_base + blk - 1];
+      const BlockPair bp = decode_block<LEGACY>(seg.bstore + T.bs_base, seg.dir_row[T.dir_base + blk], seg.dir_hdr[T.dir_base + blk], slab, lane);
+      deltas_to_docs(bp.d0, bp.d1, base, e0, e1);
+      g0 = bp.f0; g1 = bp.f1;
+    } else {
+      tail_load(seg.bstore + T.bs_base, seg.dir_row[T.dir_base + T.nblocks], lane, e0, e1, g0, g1);
+      v0 = 2 * lane < T.tail_n; v1 = 2 * lane + 1 < T.tail_n;
+    }
+    const uint64_t m0 = __ballot(v0 && e0 == doc), m1 = __ballot(v1 && e1 == doc);
+    if (!(m0 | m1)) return -1;  // the conjunction said the doc is here
+    const int pair = (int)((v0 ? g0 : 0u) + (v1 ? g1 : 0u));
+    const int excl = wave_incl_scan(pair) - pair;  // freqs of the block's docs in the lanes before this one
+    int before;
+    if (m0) {
+      const int src = (int)__builtin_ctzll(m0);
+      before = readlane(excl, src);
+      freq = readlane((int)g0, src);
+    } else {
+      const int src = (int)__builtin_ctzll(m1);
+      before = readlane(excl, src) + readlane((int)g0, src);
+      freq = readlane((int)g1, src);
+    }
+    const uint64_t st = seg.dir_pos[T.dir_base + blk];
+    fp += (int64_t)(uint32_t)st;
+    skip = (int)(st >> 32) + before;
+  }
+  if (freq <= 0) return -4;
+  if (freq > cap) return -5;
+  // ---- 2. whole position blocks that hold only earlier docs' positions (ForUtil::skip_block, for_util.rs:263-272)
+  while (skip >= 128) {
+    if (fp == P.last_pos_block_fp || fp + 2 > pos_len) return -4;
+    const uint32_t b = seg.pos[fp];
+    if (b > 32u) return -4;
+    int vlen = 0;
+    if (b == 0) (void)read_vint_uniform(seg.pos + fp + 1, &vlen);
+    fp += 1 + (b ? 16 * (int64_t)b : (int64_t)vlen);
+    skip -= 128;
+  }
+  // ---- 3. this doc's `freq` positions: deltas from the stream, a running sum from 0 (posting_reader.rs:1357-1380)
+  int got = 0;
+  int32_t carry = 0;
+  while (got < freq) {
+    uint32_t x0, x1;
+    int nvals = 128;
+    if (fp < 0 || fp + 2 > pos_len) return -4;
+    if (fp == P.last_pos_block_fp) {
+      decode_vint_block(seg.pos + fp, slab, lane, x0, x1);
+      nvals = (int)(P.total_term_freq % 128);
+      fp = -2;  // nothing follows the trailing block
+    } else {
+      const uint32_t b = seg.pos[fp];
+      if (b > 32u) return -4;
+      if (b == 0) {
+        int vlen;
+        x0 = x1 = read_vint_uniform(seg.pos + fp + 1, &vlen);
+        fp += 1 + vlen;
+      } else {
+        if (lane < 32) *reinterpret_cast<uint4*>(slab + 16 * lane) = load16_unaligned(seg.pos + fp + 1 + 16 * lane);
+        wave_sync();
+        extract_pair<LEGACY>(slab, (int)b, lane, x0, x1);
+        wave_sync();
+        fp += 1 + 16 * (int64_t)b;
+      }
+    }
+    const int take = min(nvals - skip, freq - got);
+    if (take <= 0) return -4;  // the stream ends before the doc's positions do
+    const int i0 = 2 * lane, i1 = 2 * lane + 1;
+    const bool in0 = i0 >= skip && i0 < skip + take, in1 = i1 >= skip && i1 < skip + take;
+    const int d0 = in0 ? (int)x0 : 0, d1 = in1 ? (int)x1 : 0;
+    const int pr = d0 + d1;
+    const int incl = wave_incl_scan(pr);
+    const int32_t p0 = carry + incl - pr + d0, p1 = carry + incl;
+    if (in0) L[got + i0 - skip] = p0 - P.phrase_pos;
+    if (in1) L[got + i1 - skip] = p1 - P.phrase_pos;
+    carry += readlane(incl, 63);
+    got += take;
+    skip = 0;
+  }
+  wave_sync();
+  return freq;
+}
+
+// slops (nullable): per query PhraseQuery::slop; this kernel serves the queries with slop 0 (the others: k_sloppy_match)
 template <bool LEGACY>
 __global__ __launch_bounds__(WG_THREADS) void k_phrase_match(SegView seg, const DevQuery* __restrict__ queries,
                                                              const DevTerm* __restrict__ terms, const PosTerm* __restrict__ pterms,
                                                              const int64_t* __restrict__ emit_prefix,
                                                              const unsigned long long* __restrict__ emit_count,
-                                                             const int32_t* __restrict__ emit_docs, int n_queries, int64_t n_slots,
-                                                             int64_t pos_len, uint64_t* __restrict__ keys_out, int* err) {
+                                                             const int32_t* __restrict__ emit_docs, const int32_t* __restrict__ slops, int n_queries,
+                                                             int64_t n_slots, int64_t pos_len, uint64_t* __restrict__ keys_out, int* err) {
   __shared__ __attribute__((aligned(16))) uint8_t slabs[WG_WAVES][SLAB_BYTES];
   __shared__ int32_t lists_a[WG_WAVES][PHRASE_LIST_CAP];
   __shared__ int32_t lists_c[WG_WAVES][PHRASE_LIST_CAP];
@@ -40,7 +141,8 @@ __global__ __launch_bounds__(WG_THREADS) void k_phrase_match(SegView seg, const 
   const int wave = wave_id();
   const int64_t slot = (int64_t)blockIdx.x * WG_WAVES + wave;
   if (slot >= n_slots) return;
-  const int q = upper_slot(emit_prefix, n_queries, slot);
+  const int q = upper_slot_wave(emit_prefix, n_queries, slot, lane);
+  if (slops != nullptr && slops[q] > 0) return;
   const int64_t idx = slot - emit_prefix[q];
   if ((unsigned long long)idx >= emit_count[q]) {  // the conjunction produced fewer matches than the lead term has docs
     if (lane == 0) keys_out[slot] = 0ull;
@@ -58,96 +160,8 @@ __global__ __launch_bounds__(WG_THREADS) void k_phrase_match(SegView seg, const 
   for (int c = 0; c < Q.n_terms; ++c) {
     const DevTerm T = terms[Q.first_term + c];
     const PosTerm P = pterms[Q.first_term + c];
-    // ---- 1. the doc's posting in this term: where its positions start in the term's position stream
-    int64_t fp = (int64_t)P.pos_start_fp;
-    int skip = 0, freq = 0;
-    if (T.df == 1) {
-      freq = T.singleton_freq;
-    } else {
-      const int blk = find_block(seg.dir_last, T.dir_base, T.nblocks, doc);
-      int32_t e0, e1;
-      uint32_t g0, g1;
-      bool v0 = true, v1 = true;
-      if (blk < T.nblocks) {
-        const int32_t base = blk == 0 ? 0 : seg.dir_last[T.dir_base + blk - 1];
-        const BlockPair bp = decode_block<LEGACY>(seg.bstore + T.bs_base, seg.dir_row[T.dir_base + blk], seg.dir_hdr[T.dir_base + blk], slab, lane);
-        deltas_to_docs(bp.d0, bp.d1, base, e0, e1);
-        g0 = bp.f0; g1 = bp.f1;
-      } else {
-        tail_load(seg.bstore + T.bs_base, seg.dir_row[T.dir_base + T.nblocks], lane, e0, e1, g0, g1);
-        v0 = 2 * lane < T.tail_n; v1 = 2 * lane + 1 < T.tail_n;
-      }
-      const uint64_t m0 = __ballot(v0 && e0 == doc), m1 = __ballot(v1 && e1 == doc);
-      if (!(m0 | m1)) { give_up(-1); return; }  // the conjunction said the doc is here
-      const int pair = (int)((v0 ? g0 : 0u) + (v1 ? g1 : 0u));
-      const int excl = wave_incl_scan(pair) - pair;  // freqs of the block's docs in the lanes before this one
-      int before;
-      if (m0) {
-        const int src = (int)__builtin_ctzll(m0);
-        before = readlane(excl, src);
-        freq = readlane((int)g0, src);
-      } else {
-        const int src = (int)__builtin_ctzll(m1);
-        before = readlane(excl, src) + readlane((int)g0, src);
-        freq = readlane((int)g1, src);
-      }
-      const uint64_t st = seg.dir_pos[T.dir_base + blk];
-      fp += (int64_t)(uint32_t)st;
-      skip = (int)(st >> 32) + before;
-    }
-    if (freq <= 0 || freq > PHRASE_LIST_CAP) { give_up(freq <= 0 ? -4 : -5); return; }
-    // ---- 2. whole position blocks that hold only earlier docs' positions (ForUtil::skip_block, for_util.rs:263-272)
-    while (skip >= 128) {
-      if (fp == P.last_pos_block_fp || fp + 2 > pos_len) { give_up(-4); return; }
-      const uint32_t b = seg.pos[fp];
-      if (b > 32u) { give_up(-4); return; }
-      int vlen = 0;
-      if (b == 0) (void)read_vint_uniform(seg.pos + fp + 1, &vlen);
-      fp += 1 + (b ? 16 * (int64_t)b : (int64_t)vlen);
-      skip -= 128;
-    }
-    // ---- 3. this doc's `freq` positions: deltas from the stream, a running sum from 0 (posting_reader.rs:1357-1380)
-    int32_t* L = c == 0 ? A : C;
-    int got = 0;
-    int32_t carry = 0;
-    while (got < freq) {
-      uint32_t x0, x1;
-      int nvals = 128;
-      if (fp < 0 || fp + 2 > pos_len) { give_up(-4); return; }
-      if (fp == P.last_pos_block_fp) {
-        decode_vint_block(seg.pos + fp, slab, lane, x0, x1);
-        nvals = (int)(P.total_term_freq % 128);
-        fp = -2;  // nothing follows the trailing block
-      } else {
-        const uint32_t b = seg.pos[fp];
-        if (b > 32u) { give_up(-4); return; }
-        if (b == 0) {
-          int vlen;
-          x0 = x1 = read_vint_uniform(seg.pos + fp + 1, &vlen);
-          fp += 1 + vlen;
-        } else {
-          if (lane < 32) *reinterpret_cast<uint4*>(slab + 16 * lane) = load16_unaligned(seg.pos + fp + 1 + 16 * lane);
-          wave_sync();
-          extract_pair<LEGACY>(slab, (int)b, lane, x0, x1);
-          wave_sync();
-          fp += 1 + 16 * (int64_t)b;
-        }
-      }
-      const int take = min(nvals - skip, freq - got);
-      if (take <= 0) { give_up(-4); return; }  // the stream ends before the doc's positions do
-      const int i0 = 2 * lane, i1 = 2 * lane + 1;
-      const bool in0 = i0 >= skip && i0 < skip + take, in1 = i1 >= skip && i1 < skip + take;
-      const int d0 = in0 ? (int)x0 : 0, d1 = in1 ? (int)x1 : 0;
-      const int pr = d0 + d1;
-      const int incl = wave_incl_scan(pr);
-      const int32_t p0 = carry + incl - pr + d0, p1 = carry + incl;
-      if (in0) L[got + i0 - skip] = p0 - P.phrase_pos;
-      if (in1) L[got + i1 - skip] = p1 - P.phrase_pos;
-      carry += readlane(incl, 63);
-      got += take;
-      skip = 0;
-    }
-    wave_sync();
+    const int freq = phrase_doc_positions<LEGACY>(seg, T, P, doc, pos_len, slab, c == 0 ? A : C, PHRASE_LIST_CAP, lane);
+    if (freq < 0) { give_up(freq); return; }
     // ---- 4. keep the first term's positions that line up with this term's
     if (c == 0) {
       n_a = freq;
@@ -177,6 +191,328 @@ __global__ __launch_bounds__(WG_THREADS) void k_phrase_match(SegView seg, const 
     const float wk = T0.weight * (k1 + 1.0f);
     const float nrm = seg.norms != nullptr ? caches[wave][seg.norms[doc]] : k1;
     key = make_key(bm25_score(wk, (float)phrase_freq, nrm), doc);
+  }
+  if (lane == 0) keys_out[slot] = key;
+}
+
+// ---- SloppyPhraseScorer (scorer/phrase_scorer.rs:432-1071; PhraseQuery with slop > 0) ------------------------------------------
+// The reference scores a candidate doc by walking its PhrasePositions (one per phrase term, position = term position -
+// phrase offset) through a priority queue on (position, offset, ord): the least one is advanced, and every time it passes
+// the next one the span end - position of that moment counts 1 / (span + 1) if it is within the slop (phrase_freq,
+// :537-577). It is sequential and stateful: a wavefront takes ONE candidate doc and runs it with the whole state in
+// registers — lane i = PhrasePositions i (QUERY order: the order decides ties in the queue), the queue's array in the
+// lanes too — so that every step is scalar control flow over readlane / writelane; the positions of all terms sit in one
+// LDS pool. Repeated terms ("a b a") go through the reference's collision machinery (advance_rpts, :651-701), which moves
+// PhrasePositions that are INSIDE the queue: what a pop then returns depends on the ARRAY Rust's BinaryHeap keeps, so the
+// heap is emulated operation by operation (push = sift_up, pop = last element into the root, sift_down_to_bottom, sift_up:
+// util/external/binary_heap.rs:121-210), not replaced by "take the minimum".
+// The repetition groups are what the reference finds on the FIRST candidate doc of the leaf (init_first_time, :805-871:
+// repeating pps whose first positions coincide there): k_sloppy_groups does exactly that, once per query, on the query's
+// smallest candidate doc.
+constexpr int SLOPPY_POOL = 2048;  // positions of all the phrase's terms inside one doc that the LDS pool holds
+constexpr int SLOPPY_MAX_TERMS = 16;
+
+struct SloppyGroups {  // per query: PhrasePositions::{rpt_group, rpt_ind} by query-order index; -1 = not a repeater
+  int8_t grp[SLOPPY_MAX_TERMS];
+  int8_t ind[SLOPPY_MAX_TERMS];
+};
+
+template <bool LEGACY>
+__global__ __launch_bounds__(WG_THREADS) void k_sloppy_groups(SegView seg, const DevQuery* __restrict__ queries, const DevTerm* __restrict__ terms,
+                                                              const PosTerm* __restrict__ pterms, const int64_t* __restrict__ emit_prefix,
+                                                              const unsigned long long* __restrict__ emit_count,
+                                                              const int32_t* __restrict__ emit_docs, const int32_t* __restrict__ slops,
+                                                              int n_queries, int64_t pos_len, SloppyGroups* __restrict__ groups, int* err) {
+  __shared__ __attribute__((aligned(16))) uint8_t slabs[WG_WAVES][SLAB_BYTES];
+  __shared__ int32_t lists[WG_WAVES][PHRASE_LIST_CAP];
+  const int lane = lane_id();
+  const int wave = wave_id();
+  const int q = (int)(blockIdx.x * WG_WAVES) + wave;
+  if (q >= n_queries) return;
+  SloppyGroups G;
+#pragma unroll
+  for (int i = 0; i < SLOPPY_MAX_TERMS; ++i) { G.grp[i] = -1; G.ind[i] = 0; }
+  const DevQuery Q = queries[q];
+  const int64_t n_cand = (int64_t)emit_count[q];
+  const int n = Q.n_terms;
+  // lane i: pp i (query order): its offset, which earlier pp names the same term, its device clause
+  int32_t off = 0, same_as = lane, clause = 0;
+  for (int c = 0; c < n; ++c) {
+    const PosTerm P = pterms[Q.first_term + c];
+    if (lane == P.query_ord) { off = P.phrase_pos; same_as = P.same_as; clause = c; }
+  }
+  bool repeats = false;  // this pp's term occurs more than once in the phrase (repeating_terms / repeating_pps)
+  for (int i = 0; i < n; ++i) {
+    const int s_i = readlane(same_as, i);
+    repeats = repeats || (lane < n && lane != i && same_as == s_i);
+  }
+  const uint64_t rpp = __ballot(repeats);
+  if (slops[q] > 0 && rpp != 0ull && n_cand > 0) {
+    // the first candidate doc of the leaf: the conjunction's smallest match
+    int32_t dmin = 0x7fffffff;
+    for (int64_t i = lane; i < n_cand; i += 64) dmin = min(dmin, emit_docs[emit_prefix[q] + i]);
+    dmin = 0x7fffffff - (int32_t)wave_reduce_max_u32((uint32_t)(0x7fffffff - dmin));  // min over the lanes (doc ids are >= 0)
+    // tp_pos of every repeating pp there = the term's first position in that doc
+    int32_t tp = 0;
+    uint64_t m = rpp;
+    while (m) {
+      const int i = (int)__builtin_ctzll(m);
+      m &= m - 1;
+      const int c = readlane(clause, i);
+      const int freq = phrase_doc_positions<LEGACY>(seg, terms[Q.first_term + c], pterms[Q.first_term + c], dmin, pos_len, slabs[wave], lists[wave],
+                                                    PHRASE_LIST_CAP, lane);
+      if (freq < 0) { if (lane == 0) atomicMin(err, freq == -1 ? -1 : freq); break; }
+      const int32_t first = lists[wave][0] + readlane(off, i);  // (the loader stores position - offset)
+      tp = lane == i ? first : tp;
+      wave_sync();
+    }
+    // gather_rpt_groups, the arm without multi-term postings (:841-871), then sort_rpt_groups (:826-838)
+    int32_t grp = -1;
+    int n_groups = 0;
+    uint64_t m1 = rpp;
+    while (m1) {
+      const int i1 = (int)__builtin_ctzll(m1);
+      m1 &= m1 - 1;
+      if (readlane(grp, i1) >= 0) continue;  // already marked as a repetition
+      const int32_t tp1 = readlane(tp, i1), off1 = readlane(off, i1);
+      const uint64_t joins = __ballot(repeats && lane > i1 && grp < 0 && off != off1 && tp == tp1);
+      if (joins) {
+        grp = (lane == i1 || ((joins >> lane) & 1ull)) ? n_groups : grp;
+        ++n_groups;
+      }
+    }
+    // a member's index in its group: members ordered by (offset, pp index) — a stable sort of the discovery order by offset
+    int32_t ind = 0;
+    for (int j = 0; j < n; ++j) {
+      const int32_t gj = readlane(grp, j), oj = readlane(off, j);
+      ind += (grp >= 0 && gj == grp && (oj < off || (oj == off && j < lane))) ? 1 : 0;
+    }
+    for (int i = 0; i < n; ++i) { G.grp[i] = (int8_t)readlane(grp, i); G.ind[i] = (int8_t)readlane(ind, i); }
+  }
+  if (lane == 0) groups[q] = G;
+}
+
+template <bool LEGACY>
+__global__ __launch_bounds__(WG_THREADS) void k_sloppy_match(SegView seg, const DevQuery* __restrict__ queries,
+                                                             const DevTerm* __restrict__ terms, const PosTerm* __restrict__ pterms,
+                                                             const int64_t* __restrict__ emit_prefix,
+                                                             const unsigned long long* __restrict__ emit_count,
+                                                             const int32_t* __restrict__ emit_docs, const int32_t* __restrict__ slops,
+                                                             const SloppyGroups* __restrict__ groups, int n_queries, int64_t n_slots,
+                                                             int64_t pos_len, uint64_t* __restrict__ keys_out, int* err) {
+  __shared__ __attribute__((aligned(16))) uint8_t slabs[WG_WAVES][SLAB_BYTES];
+  __shared__ int32_t pools[WG_WAVES][SLOPPY_POOL];
+  __shared__ float caches[WG_WAVES][256];
+  const int lane = lane_id();
+  const int wave = wave_id();
+  const int64_t slot = (int64_t)blockIdx.x * WG_WAVES + wave;
+  if (slot >= n_slots) return;
+  const int q = upper_slot_wave(emit_prefix, n_queries, slot, lane);
+  const int slop = slops[q];
+  if (slop <= 0) return;  // an exact phrase: k_phrase_match's
+  const int64_t idx = slot - emit_prefix[q];
+  if ((unsigned long long)idx >= emit_count[q]) {
+    if (lane == 0) keys_out[slot] = 0ull;
+    return;
+  }
+  const int32_t doc = emit_docs[slot];
+  const DevQuery Q = queries[q];
+  const int n = Q.n_terms;
+  int32_t* pool = pools[wave];
+  auto give_up = [&](int code) {
+    if (lane == 0) { atomicMin(err, code); keys_out[slot] = 0ull; }
+  };
+  // ---- every term's positions in this doc; lane i keeps PhrasePositions i (query order)
+  int32_t s_pos = 0, s_cnt = 0, s_at = 0, s_off = 0, s_start = 0, s_n = 0;
+  int used = 0;
+  for (int c = 0; c < n; ++c) {
+    const DevTerm T = terms[Q.first_term + c];
+    const PosTerm P = pterms[Q.first_term + c];
+    const int freq = phrase_doc_positions<LEGACY>(seg, T, P, doc, pos_len, slabs[wave], pool + used, SLOPPY_POOL - used, lane);
+    if (freq < 0) { give_up(freq); return; }
+    if (lane == P.query_ord) { s_off = P.phrase_pos; s_start = used; s_n = freq; }
+    used += freq;
+  }
+  const SloppyGroups G = groups[q];
+  int32_t s_grp = -1, s_ind = 0;
+#pragma unroll
+  for (int i = 0; i < SLOPPY_MAX_TERMS; ++i) { s_grp = lane == i ? (int32_t)G.grp[i] : s_grp; s_ind = lane == i ? (int32_t)G.ind[i] : s_ind; }
+  const bool has_rpts = __ballot(lane < n && s_grp >= 0) != 0ull;  // (a phrase whose repeated terms found no group behaves like one without)
+  bool any_rpt_terms = false;
+  {  // has_rpts of the reference = "some term repeats" (repeating_terms), whatever the groups turned out to be
+    int32_t same_as = lane;
+    for (int c = 0; c < n; ++c) { const PosTerm P = pterms[Q.first_term + c]; if (lane == P.query_ord) same_as = P.same_as; }
+    for (int i = 0; i < n; ++i) any_rpt_terms = any_rpt_terms || (__ballot(lane < n && lane != i && same_as == readlane(same_as, i)) != 0ull);
+  }
+  (void)has_rpts;
+  // ---- scalar helpers over the lanes' state (every index is wave-uniform)
+  auto next_position = [&](int i) -> bool {  // PhrasePositions::next_position (:363-373)
+    const int c = readlane(s_cnt, i);
+    if (c <= 0) return false;
+    const int a = readlane(s_at, i);
+    const int32_t p = pool[readlane(s_start, i) + a];  // (position - offset already)
+    s_cnt = lane == i ? c - 1 : s_cnt;
+    s_at = lane == i ? a + 1 : s_at;
+    s_pos = lane == i ? p : s_pos;
+    return true;
+  };
+  auto first_position = [&](int i) {  // :356-360
+    s_cnt = lane == i ? s_n : s_cnt;
+    s_at = lane == i ? 0 : s_at;
+    (void)next_position(i);
+  };
+  int32_t end = (int32_t)0x80000000;
+  auto advance_pp = [&](int i) -> bool {  // :638-646
+    if (!next_position(i)) return false;
+    const int32_t p = readlane(s_pos, i);
+    end = p > end ? p : end;
+    return true;
+  };
+  // std BinaryHeap<PPElement>: lane j = data[j]; PPElement's reversed order: a <= b  <=>  key(a) >= key(b)
+  int32_t heap = 0;
+  int hn = 0;
+  auto key_less = [&](int a, int b) -> bool {
+    const int32_t pa = readlane(s_pos, a), pb = readlane(s_pos, b);
+    if (pa != pb) return pa < pb;
+    const int32_t oa = readlane(s_off, a), ob = readlane(s_off, b);
+    if (oa != ob) return oa < ob;
+    return a < b;
+  };
+  auto sift_up = [&](int start, int pos) {
+    const int elt = readlane(heap, pos);
+    while (pos > start) {
+      const int parent = (pos - 1) / 2;
+      const int pe = readlane(heap, parent);
+      if (!key_less(elt, pe)) break;  // elt <= parent
+      heap = lane == pos ? pe : heap;
+      pos = parent;
+    }
+    heap = lane == pos ? elt : heap;
+  };
+  auto heap_push = [&](int i) {
+    heap = lane == hn ? i : heap;
+    ++hn;
+    sift_up(0, hn - 1);
+  };
+  auto heap_pop = [&]() -> int {
+    --hn;
+    int item = readlane(heap, hn);
+    if (hn > 0) {
+      const int root = readlane(heap, 0);
+      heap = lane == 0 ? item : heap;
+      item = root;
+      int pos = 0;
+      const int elt = readlane(heap, 0);
+      int child = 1;
+      while (child < hn) {
+        const int right = child + 1;
+        if (right < hn && !key_less(readlane(heap, child), readlane(heap, right))) child = right;  // the greater of the two children
+        const int ce = readlane(heap, child);
+        heap = lane == pos ? ce : heap;
+        pos = child;
+        child = 2 * pos + 1;
+      }
+      heap = lane == pos ? elt : heap;
+      sift_up(0, pos);
+    }
+    return item;
+  };
+  auto tp_pos = [&](int i) -> int32_t { return readlane(s_pos, i) + readlane(s_off, i); };
+  auto member = [&](int g, int k) -> int {  // rpt_group[g][k]
+    return (int)__builtin_ctzll(__ballot(lane < n && s_grp == g && s_ind == k) | (1ull << 63));
+  };
+  auto collide = [&](int i) -> int {  // :716-726: the group index of a pp of i's group standing on the same term position, or -1
+    const int g = readlane(s_grp, i);
+    const int len = __popcll(__ballot(lane < n && s_grp == g));
+    const int32_t tp = tp_pos(i);
+    for (int k = 0; k < len; ++k) {
+      const int j = member(g, k);
+      if (j != i && tp_pos(j) == tp) return k;
+    }
+    return -1;
+  };
+  auto lesser = [&](int a, int b) -> int {  // :704-713
+    const int32_t pa = readlane(s_pos, a), pb = readlane(s_pos, b);
+    return (pa < pb || (pa == pb && readlane(s_off, a) < readlane(s_off, b))) ? a : b;
+  };
+  auto advance_rpts = [&](int pp) -> bool {  // :651-701
+    const int g = readlane(s_grp, pp);
+    if (g < 0) return true;  // not a repeater
+    const int len = __popcll(__ballot(lane < n && s_grp == g));
+    uint32_t bits = 0;
+    const int k0 = readlane(s_ind, pp);
+    int cur = pp;
+    while (true) {
+      const int k = collide(cur);
+      if (k < 0) break;
+      cur = lesser(cur, member(g, k));  // always advance the lesser of the (only) two colliding pps
+      if (!advance_pp(cur)) return false;
+      if (k != k0) bits |= 1u << k;  // mark only those currently in the queue
+    }
+    // collisions resolved, now re-queue: pop until every marked pp has come out, then push them all back
+    int32_t stack = 0;
+    int ns = 0;
+    while (bits && hn > 0) {  // (the reference would panic on an empty queue; it cannot get there: a marked pp is in the queue)
+      const int p2 = heap_pop();
+      stack = lane == ns ? p2 : stack;
+      ++ns;
+      const int g2 = readlane(s_grp, p2), k2 = readlane(s_ind, p2);
+      if (g2 >= 0 && k2 < len && ((bits >> k2) & 1u)) bits &= ~(1u << k2);
+    }
+    for (int i = 0; i < ns; ++i) heap_push(readlane(stack, ns - 1 - i));
+    return true;
+  };
+  // ---- init_phrase_positions (:590-627, 733-790): every doc starts the same way once the groups are known
+  bool alive = true;
+  for (int i = 0; i < n; ++i) first_position(i);  // place_first_positions
+  if (any_rpt_terms) {  // advance_repeat_groups, single-term arm: the j-th pp of a group (by offset) advances j times
+    const uint64_t grouped = __ballot(lane < n && s_grp >= 0);
+    uint64_t m = grouped;
+    // (group by group in the order the groups were found, members by index in the group: the order only matters for which
+    // positions are consumed, and each pp's count of advances is fixed: its index in its group)
+    while (m && alive) {
+      const int i = (int)__builtin_ctzll(m);
+      m &= m - 1;
+      const int times = readlane(s_ind, i);
+      for (int t = 0; t < times && alive; ++t) alive = next_position(i);
+    }
+  }
+  float freq = 0.0f;
+  if (alive) {
+    // fill_queue (init_simple pushes in the same order)
+    for (int i = 0; i < n; ++i) {
+      const int32_t p = readlane(s_pos, i);
+      end = p > end ? p : end;
+      heap_push(i);
+    }
+    // ---- phrase_freq (:537-577)
+    int pp = heap_pop();
+    int32_t match_length = end - readlane(s_pos, pp);
+    int32_t next = readlane(s_pos, readlane(heap, 0));
+    while (advance_pp(pp)) {
+      if (any_rpt_terms && !advance_rpts(pp)) break;  // pps exhausted
+      const int32_t p = readlane(s_pos, pp);
+      if (p > next) {  // done minimizing current match-length
+        if (match_length <= slop) freq += 1.0f / ((float)match_length + 1.0f);  // compute_slop_factor (bm25_similarity.rs:65-67)
+        heap_push(pp);
+        pp = heap_pop();
+        next = readlane(s_pos, readlane(heap, 0));
+        match_length = end - readlane(s_pos, pp);
+      } else {
+        const int32_t ml2 = end - p;
+        match_length = ml2 < match_length ? ml2 : match_length;
+      }
+    }
+    if (match_length <= slop) freq += 1.0f / ((float)match_length + 1.0f);
+  }
+  uint64_t key = 0ull;
+  if (freq > 1.1920929e-07f) {  // matches(): sloppy_freq > f32::EPSILON (:1041-1045)
+    const DevTerm T0 = terms[Q.first_term];
+    float k1;
+    load_sim_table(seg, T0.sim_table, caches[wave], lane, k1);
+    const float wk = T0.weight * (k1 + 1.0f);
+    const float nrm = seg.norms != nullptr ? caches[wave][seg.norms[doc]] : k1;
+    key = make_key(bm25_score(wk, freq, nrm), doc);
   }
   if (lane == 0) keys_out[slot] = key;
 }

@@ -39,21 +39,6 @@ __host__ __device__ constexpr size_t term_lds_bytes(bool wide) {
   return (size_t)TERM_WAVES * TERM_WAVE_LDS + (size_t)TERM_WAVES * (wide ? 128 : 64) * 8 + (size_t)TERM_WAVES * 12;
 }
 
-// largest t in [0, n) with prefix[t] <= x, searched by the whole wavefront: 64 probes per step (two dependent
-// loads for 1024 queries instead of ten)
-__device__ __forceinline__ int upper_slot_wave(const int64_t* __restrict__ prefix, int n, int64_t x, int lane) {
-  int lo = 0, hi = n;
-  while (hi - lo > 1) {
-    const int step = (hi - lo + 63) >> 6;
-    const int idx = lo + lane * step;
-    const bool ok = idx < hi && prefix[idx] <= x;  // true on a prefix of the lanes, lane 0 included
-    const int cnt = __popcll(__ballot(ok));
-    lo += (cnt - 1) * step;
-    hi = min(hi, lo + step);
-  }
-  return lo;
-}
-
 // ---- a top-k list shared by the wavefronts of one group -------------------------------------------------------
 struct GroupList {
   uint64_t* keys;  // LDS: 64 (128 when WIDE) keys, sorted descending, 0 == empty — WaveTopK's registers at rest

@@ -89,6 +89,8 @@ struct PosTerm {
   int64_t last_pos_block_fp;   // absolute fp of the trailing VInt block; -1: none (total_term_freq == 128)
   int64_t total_term_freq;
   int32_t phrase_pos;          // the term's position inside the phrase (PhraseQuery::build: 0, 1, 2, ...)
+  int32_t query_ord;           // the term's index in the QUERY's term list (device clauses are in cost order): PhrasePositions::ord
+  int32_t same_as;             // query-order index of the first term of the phrase that is this very term (itself when none before)
   int32_t pad;
 };
 

@@ -417,10 +417,10 @@ static int32_t prepare_terms_attempt(rgpu_segment* seg, const rgpu_term_state* c
   std::memcpy(c->S->h_stage.p + o_items, item_prefix.data(), item_prefix.size() * 8);
   std::memcpy(c->S->h_stage.p + o_chunks, chunk_prefix.data(), chunk_prefix.size() * 8);
   HIP_TRY(hipMemcpyAsync(c->S->d_stage.p, c->S->h_stage.p, st.used, hipMemcpyHostToDevice, c->stream));
-  // device scratch: [ticket, total rows][chunk aggregates][tile sums]
+  // device scratch: [-, total rows][chunk aggregates][tile sums]
   const size_t o_aggs = 64, o_tiles = o_aggs + (size_t)n_chunks * sizeof(SkipAgg);
   HIP_TRY(seg->prep_scratch.reserve(o_tiles + (size_t)n_tiles * 8 + 64, 0, c->stream));
-  HIP_TRY(hipMemsetAsync(seg->prep_scratch.p, 0, o_tiles, c->stream));
+  HIP_TRY(hipMemsetAsync(seg->prep_scratch.p, 0, 64, c->stream));
   HIP_TRY(hipMemsetAsync(c->d_err, 0, 4 * sizeof(int), c->stream));
   unsigned long long* d_ticket = reinterpret_cast<unsigned long long*>(seg->prep_scratch.p);
   unsigned long long* d_total = d_ticket + 1;
@@ -433,9 +433,13 @@ static int32_t prepare_terms_attempt(rgpu_segment* seg, const rgpu_term_state* c
   const unsigned item_grid = (unsigned)((n_items + PREP_WAVES - 1) / PREP_WAVES);
   {
     TimedLaunch tl(c, c->stream, "k_skip_dir", postings);
-    hipLaunchKernelGGL(k_skip_dir, dim3((unsigned)((n_chunks + PREP_WAVES - 1) / PREP_WAVES)), dim3(PREP_THREADS), 0, c->stream, seg->d_doc,
-                       (int64_t)seg->doc_len, (int64_t)seg->doc_len + 8192, d_work, d_chunks, (int)work.size(), n_chunks, d_aggs, d_ticket,
-                       seg->dir_last.p, seg->dir_off.p, seg->has_positions ? seg->dir_pos.p : nullptr, c->d_err);
+    const dim3 grid((unsigned)((n_chunks + PREP_WAVES - 1) / PREP_WAVES));
+    hipLaunchKernelGGL(k_skip_dir<1>, grid, dim3(PREP_THREADS), 0, c->stream, seg->d_doc, (int64_t)seg->doc_len, (int64_t)seg->doc_len + 8192,
+                       d_work, d_chunks, (int)work.size(), n_chunks, d_aggs, seg->dir_last.p, seg->dir_off.p,
+                       seg->has_positions ? seg->dir_pos.p : nullptr, c->d_err);
+    hipLaunchKernelGGL(k_skip_dir<2>, grid, dim3(PREP_THREADS), 0, c->stream, seg->d_doc, (int64_t)seg->doc_len, (int64_t)seg->doc_len + 8192,
+                       d_work, d_chunks, (int)work.size(), n_chunks, d_aggs, seg->dir_last.p, seg->dir_off.p,
+                       seg->has_positions ? seg->dir_pos.p : nullptr, c->d_err);
   }
   {
     TimedLaunch tl(c, c->stream, "k_block_headers", postings);
@@ -1671,6 +1675,8 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
   for (int32_t q = 0; q < n_queries; ++q) {
     const rgpu_phrase_query& Q = queries[q];
     if (Q.n_terms < 2 || Q.n_terms > RGPU_MAX_QUERY_TERMS) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "a phrase has 2..RGPU_MAX_QUERY_TERMS terms");
+    if (Q.slop < 0) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "Slop must be >= 0");  // PhraseQuery::new (phrase_query.rs:77)
+    if (Q.reserved != 0) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "rgpu_phrase_query.reserved must be zero");
     if (Q.first_term < 0 || (int64_t)Q.first_term + Q.n_terms > (int64_t)n_terms_total) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "term range outside terms[]");
     if (Q.sim_table < 0 || Q.sim_table >= c->n_sim_tables) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "unknown sim_table handle");
     for (int i = 0; i < Q.n_terms; ++i) {
@@ -1688,6 +1694,8 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
   std::vector<DevTerm> dt;
   std::vector<PosTerm> pt;
   std::vector<int64_t> item_prefix((size_t)n_queries + 1), emit_prefix((size_t)n_queries + 1);
+  std::vector<int32_t> slops((size_t)n_queries, 0);
+  bool any_sloppy = false, any_exact = false;
   const int blocks_per_item = c->cfg.and_blocks_per_item;
   int64_t items = 0, slots = 0;
   for (int32_t q = 0; q < n_queries; ++q) {
@@ -1714,8 +1722,17 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
       p.last_pos_block_fp = t.state.total_term_freq < 128 ? t.positions.pos_start_fp
                             : (t.state.total_term_freq == 128 ? -1 : t.positions.pos_start_fp + t.positions.last_pos_block_offset);
       p.phrase_pos = t.position;
+      p.query_ord = i;  // PhrasePositions::ord: the sloppy scorer keeps the query's order (phrase_query.rs:324-331 does not sort)
+      p.same_as = i;    // ... and tells repeated terms by Term equality (repeating_terms, phrase_scorer.rs:909-931)
+      for (int j = 0; j < i; ++j) {
+        const rgpu_term_state& o = terms[Q.first_term + j].state;
+        if (o.doc_start_fp == t.state.doc_start_fp && o.doc_freq == t.state.doc_freq && o.singleton_doc_id == t.state.singleton_doc_id &&
+            o.total_term_freq == t.state.total_term_freq) { p.same_as = j; break; }
+      }
       pt.push_back(p);
     }
+    slops[(size_t)q] = Q.slop;
+    (Q.slop > 0 ? any_sloppy : any_exact) = true;
     dq[(size_t)q].n_terms = Q.n_terms;
     const DevTerm& lead = dt[(size_t)dq[(size_t)q].first_term];
     items += lead.nblocks == 0 ? 1 : (lead.nblocks + blocks_per_item - 1) / blocks_per_item;
@@ -1735,11 +1752,14 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
     const size_t o_pt = st.add(pt.size() * sizeof(PosTerm));
     const size_t o_ip = st.add((size_t)(n_queries + 1) * 8);
     const size_t o_ep = st.add((size_t)(n_queries + 1) * 8);
+    const size_t o_sl = st.add((size_t)n_queries * 4);
+    const size_t o_gr = st.add((size_t)n_queries * sizeof(SloppyGroups));  // written by k_sloppy_groups
     HIP_TRY(c->S->h_stage.reserve(st.used));
     HIP_TRY(c->S->d_stage.reserve(st.used, 0, stream));
     std::memcpy(c->S->h_stage.p + o_q, dq.data(), (size_t)n_queries * sizeof(DevQuery));
     std::memcpy(c->S->h_stage.p + o_t, dt.data(), dt.size() * sizeof(DevTerm));
     std::memcpy(c->S->h_stage.p + o_pt, pt.data(), pt.size() * sizeof(PosTerm));
+    std::memcpy(c->S->h_stage.p + o_sl, slops.data(), (size_t)n_queries * 4);
     std::memcpy(c->S->h_stage.p + o_ip, item_prefix.data(), (size_t)(n_queries + 1) * 8);
     std::memcpy(c->S->h_stage.p + o_ep, emit_prefix.data(), (size_t)(n_queries + 1) * 8);
     HIP_TRY(hipMemcpyAsync(c->S->d_stage.p, c->S->h_stage.p, st.used, hipMemcpyHostToDevice, stream));
@@ -1771,15 +1791,35 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
       };
       if (legacy) go(k_search_and<true, false, false, false>); else go(k_search_and<false, false, false, false>);
     }
-    if (slots > 0) {
+    const int32_t* d_sl = reinterpret_cast<const int32_t*>(c->S->d_stage.p + o_sl);
+    SloppyGroups* d_gr = reinterpret_cast<SloppyGroups*>(c->S->d_stage.p + o_gr);
+    if (slots > 0 && any_exact) {
       TimedLaunch tl(c, stream, "k_phrase_match", 0);
       const unsigned grid = (unsigned)((slots + WG_WAVES - 1) / WG_WAVES);
       if (legacy)
         hipLaunchKernelGGL(k_phrase_match<true>, dim3(grid), dim3(WG_THREADS), 0, stream, sv, d_q, d_t, d_pt, d_ep, c->phrase_count.p,
-                           c->phrase_docs.p, (int)n_queries, slots, (int64_t)seg->pos_len, c->phrase_keys.p, c->d_err);
+                           c->phrase_docs.p, d_sl, (int)n_queries, slots, (int64_t)seg->pos_len, c->phrase_keys.p, c->d_err);
       else
         hipLaunchKernelGGL(k_phrase_match<false>, dim3(grid), dim3(WG_THREADS), 0, stream, sv, d_q, d_t, d_pt, d_ep, c->phrase_count.p,
-                           c->phrase_docs.p, (int)n_queries, slots, (int64_t)seg->pos_len, c->phrase_keys.p, c->d_err);
+                           c->phrase_docs.p, d_sl, (int)n_queries, slots, (int64_t)seg->pos_len, c->phrase_keys.p, c->d_err);
+    }
+    if (slots > 0 && any_sloppy) {  // SloppyPhraseScorer: the repetition groups of each query's first candidate doc, then one wavefront per candidate
+      {
+        TimedLaunch tl(c, stream, "k_sloppy_groups", 0);
+        const unsigned grid = (unsigned)((n_queries + WG_WAVES - 1) / WG_WAVES);
+        auto go = [&](auto kern) {
+          hipLaunchKernelGGL(kern, dim3(grid), dim3(WG_THREADS), 0, stream, sv, d_q, d_t, d_pt, d_ep, c->phrase_count.p, c->phrase_docs.p, d_sl,
+                             (int)n_queries, (int64_t)seg->pos_len, d_gr, c->d_err);
+        };
+        if (legacy) go(k_sloppy_groups<true>); else go(k_sloppy_groups<false>);
+      }
+      TimedLaunch tl(c, stream, "k_sloppy_match", 0);
+      const unsigned grid = (unsigned)((slots + WG_WAVES - 1) / WG_WAVES);
+      auto go = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(WG_THREADS), 0, stream, sv, d_q, d_t, d_pt, d_ep, c->phrase_count.p, c->phrase_docs.p, d_sl, d_gr,
+                           (int)n_queries, slots, (int64_t)seg->pos_len, c->phrase_keys.p, c->d_err);
+      };
+      if (legacy) go(k_sloppy_match<true>); else go(k_sloppy_match<false>);
     }
     {
       TimedLaunch tl(c, stream, "k_phrase_collect", 0);
@@ -1800,7 +1840,7 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
   hipError_t e3 = hipStreamSynchronize(stream);
   if (e0 != hipSuccess || e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return fail(RGPU_ERR_RUNTIME, "device to host copy failed");
   if (err != 0)
-    return fail(err, err == RGPU_ERR_UNSUPPORTED ? "a doc holds one of the phrase's terms more than 1024 times"
+    return fail(err, err == RGPU_ERR_UNSUPPORTED ? "a doc holds one of an exact phrase's terms more than 1024 times (a sloppy phrase's terms: more than 2048 times in all)"
                                                  : (err == RGPU_ERR_ILLEGAL_STATE ? "internal: a conjunction match was not found again" : "corrupt position data in .pos"));
   return RGPU_OK;
 }

@@ -223,12 +223,16 @@ class TermQuery:
 
 
 class PhraseQuery:
-    """PhraseQuery::build (query/phrase_query.rs:60-110) with slop 0: terms at positions 0, 1, 2, ... (or `positions`)."""
+    """PhraseQuery::build / ::new (query/phrase_query.rs:60-130): terms at positions 0, 1, 2, ... (or `positions`); slop 0 = an
+    exact phrase, slop > 0 = the reference's SloppyPhraseScorer."""
 
-    def __init__(self, terms, positions=None, boost=1.0):
+    def __init__(self, terms, positions=None, boost=1.0, slop=0):
         self.terms = [bytes(t) if isinstance(t, (bytes, bytearray, memoryview)) else int(t) for t in terms]
         self.positions = list(range(len(self.terms))) if positions is None else [int(p) for p in positions]
         self.boost = float(boost)
+        self.slop = int(slop)
+        if self.slop < 0:
+            raise RgpuError(-2, "Slop must be >= 0, got %d" % self.slop)
         if len(self.terms) < 2:
             raise RgpuError(-2, "PhraseWeight does not support less than 2 terms, call rewrite first")
         if len(self.positions) != len(self.terms):
@@ -463,7 +467,7 @@ class GpuIndexSearcher:
             at = 0
             for i, q in enumerate(queries):
                 w, cache = self.similarity.compute_weight(self.collection_statistics, [self.term_statistics(t) for t in q.terms], q.boost)
-                qs[i] = (len(q.terms), at, w, self.ctx.sim_table(cache, self.similarity.k1))
+                qs[i] = (len(q.terms), at, w, self.ctx.sim_table(cache, self.similarity.k1), q.slop, 0)
                 for t, p in zip(q.terms, q.positions):
                     sp = leaf.positions_state(t)
                     if sp is not None:

@@ -44,7 +44,8 @@ def test_header_is_plain_c_and_layouts_match_the_bindings(gpu_lib, tmp_path):
                "rgpu_term_positions": gpu_lib.TERM_POSITIONS_DTYPE, "rgpu_segment_info": gpu_lib.SEGMENT_INFO_DTYPE,
                "rgpu_commit_segment": gpu_lib.COMMIT_SEGMENT_DTYPE, "rgpu_compound_entry": gpu_lib.COMPOUND_ENTRY_DTYPE,
                "rgpu_search_counters": gpu_lib.SEARCH_COUNTERS_DTYPE, "rgpu_plan_stats": gpu_lib.PLAN_STATS_DTYPE,
-               "rgpu_segment_footprint": gpu_lib.FOOTPRINT_DTYPE}
+               "rgpu_segment_footprint": gpu_lib.FOOTPRINT_DTYPE,
+               "rgpu_phrase_query": gpu_lib.PHRASE_QUERY_DTYPE, "rgpu_phrase_term": gpu_lib.PHRASE_TERM_DTYPE}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "%s"' % os.path.join(ROOT, "include", "rucene_gpu.h"), "int main(void) {"]
     for name, dt in structs.items():
         lines.append('  printf("%s %%zu", sizeof(%s));' % (name, name))

@@ -1023,6 +1023,29 @@ def test_exact_phrases(ctx, oracle, version, max_doc):
             assert totals[i] == total, (i, q.terms, totals[i], total)
             assert (hits[i]["doc"][:d.size] == d).all() and (hits[i]["doc"][d.size:] == -1).all(), (i, q.terms)
             assert (hits[i]["score"][:d.size].view(np.int32) == s.view(np.int32)).all(), (i, q.terms)
+    # ---- sloppy phrases (the other half): SloppyPhraseScorer — the priority-queue walk over the terms' positions,
+    # repeated terms with the reference's collision handling (and its BinaryHeap's array order), groups found on the first
+    # candidate doc — against oracle/sloppy_phrase.hpp: doc ids, hit counts, BM25(sloppy freq) score bits. Exact and sloppy
+    # queries share a batch.
+    sloppy = [([0, 1], None, 1), ([0, 1], None, 2), ([1, 0], None, 5), ([4, 5, 6], None, 2), ([0, 1, 2, 3], None, 5), ([3, 3], None, 1), ([2, 2, 2], None, 5),
+              ([7, 7, 8, 7], None, 2), ([0, 1, 0], None, 1), ([0, 1, 0, 1], None, 5), ([5, 6, 5], [0, 1, 4], 2), ([9, 10, 11, 0, 1], None, 12),
+              ([5, vocab + 2], None, 3), ([vocab, 3], None, 2), ([vocab + 1, 0], None, 1), ([1, 0, 1, 2, 1], None, 5), ([3, 4, 5], [0, 1, 3], 1)]
+    sloppy += [(rng.integers(0, vocab, size=int(rng.integers(2, 5))).tolist(), None, int(rng.integers(1, 7))) for _ in range(30)]
+    sloppy += [(rng.integers(0, 4, size=int(rng.integers(2, 6))).tolist(), None, int(rng.integers(1, 9))) for _ in range(30)]   # few distinct terms: repeats galore
+    squeries = [rucene_amd.PhraseQuery(t, o, slop=sl) for t, o, sl in sloppy]
+    mixed = squeries + queries[:8]
+    matched = 0
+    for k in (10, 100):
+        hits, totals = searcher.search_phrase_batch(mixed, k)
+        for i, q in enumerate(mixed):
+            d, s, total = ix.phrase_search(q.terms, k, norms, max_doc, doc_count, sum_ttf, offsets=q.positions, slop=q.slop)
+            assert totals[i] == total, (i, q.terms, q.positions, q.slop, totals[i], total)
+            assert (hits[i]["doc"][:d.size] == d).all() and (hits[i]["doc"][d.size:] == -1).all(), (i, q.terms, q.slop)
+            assert (hits[i]["score"][:d.size].view(np.int32) == s.view(np.int32)).all(), (i, q.terms, q.slop)
+            matched += total
+    assert matched > 1000
+    with pytest.raises(rucene_amd.RgpuError):
+        rucene_amd.PhraseQuery([0, 1], slop=-1)
     # the same field answers plain term / boolean queries (its .doc skip entries carry position pointers)
     T, B = rucene_amd.TermQuery, rucene_amd.BooleanQuery
     hits, totals = searcher.search_batch([T(0), B.build([T(1), T(2)], []), B.build([], [T(3), T(vocab + 1)])], 10)
