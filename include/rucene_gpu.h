@@ -30,7 +30,7 @@ extern "C" {
 #define RGPU_NO_MORE_DOCS 0x7fffffff /* search/mod.rs:59 */
 #define RGPU_BLOCK_SIZE 128          /* codec/postings/posting_format.rs:36 */
 #define RGPU_MAX_QUERY_TERMS 16
-#define RGPU_MAX_K 128
+#define RGPU_MAX_K 1024   /* k above 128 costs ceil(k / 128) passes of the search; phrase search and rescoring: k <= 128 */
 
 /* error.rs:24-91 ErrorKind */
 typedef enum rgpu_status {

@@ -415,6 +415,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_blocks(const uint8_t* 
   const uint32_t my_off = mine ? dir_off[t.dir_base + b0 + lane] : 0u;
   const uint32_t my_hdr = mine ? (uint32_t)dir_hdr[t.dir_base + b0 + lane] : 0u;
   const uint32_t my_row = mine ? dir_row[t.dir_base + b0 + lane] : 0u;
+  const int32_t my_last = mine ? dir_last[t.dir_base + b0 + lane] : 0;  // (a dependent load per block would be ~1.5 us of nothing else to do)
   int32_t base = b0 == 0 ? 0 : dir_last[t.dir_base + b0 - 1];
   // a block's aligned rows: [a, a + 16 * n16) covers its bytes; lane l takes row l (rows 64, 65 — a 1026-byte block that
   // starts late in its first row — ride on lanes 0, 1)
@@ -454,7 +455,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_blocks(const uint8_t* 
       const int etype = hdr_vlen(hdr);
       int32_t* ids = reinterpret_cast<int32_t*>(slab);            // 128 doc ids
       uint32_t* pack = reinterpret_cast<uint32_t*>(slab + 512);   // 132 dwords of BP128 rows
-      const int32_t pf_base = blk == 0 ? 0 : dir_last[t.dir_base + blk - 1];
+      const int32_t pf_base = base;  // the last doc of the block before this one (0 for a term's first block)
       int doc_sz, total;
       if (etype == 2) {
         int v = 1;
@@ -544,7 +545,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_blocks(const uint8_t* 
     // (a term's very first delta is relative to doc 0 and may be 0: posting_writer.rs:298)
     const bool bad_first = (blk == 0 && lane == 0) ? d0 < 0 : d0 <= prev;
     const bool bad = bad_first || d1 <= d0 || d1 >= max_doc;
-    const bool bad_last = blk < t.n_entries && lane == 63 && d1 != dir_last[t.dir_base + blk];
+    const bool bad_last = blk < t.n_entries && lane == 63 && d1 != readlane(my_last, j);
     if (__ballot(bad || bad_last)) { if (lane == 0) flag_err(err, -4, 15); return; }
     base = readlane(d1, 63);
     if (lane == 0) dir_bmax[t.dir_base + blk] = 15ull;  // "no bound" until (unless) stage B learns the block's norms

@@ -79,7 +79,10 @@ __global__ __launch_bounds__(WG_THREADS) void k_merge_items(const int64_t* __res
                                                             int64_t* __restrict__ totals_out,
                                                             const int2* __restrict__ fixed_info = nullptr,
                                                             int32_t* __restrict__ low_flags = nullptr,
-                                                            const int32_t* __restrict__ qmap = nullptr) {
+                                                            const int32_t* __restrict__ qmap = nullptr, int out_stride = 0, int col0 = 0,
+                                                            unsigned long long* __restrict__ ceil_out = nullptr) {
+  // out_stride / col0: the caller's rows are out_stride hits long and this pass fills columns [col0, col0 + k) (0 = k, 0);
+  // ceil_out[row] = this pass's worst key when it filled all k slots, else 0 ("nothing left below") — the next pass's ceiling
   const int lane = lane_id();
   const int q = (int)(blockIdx.x * WG_WAVES) + wave_id();
   if (q >= n_queries) return;
@@ -112,7 +115,11 @@ __global__ __launch_bounds__(WG_THREADS) void k_merge_items(const int64_t* __res
   // qmap: the group's query q is the caller's row qmap[q] (queries are partitioned by op on the host) — the rows are
   // written in place, no scatter pass
   const int row = qmap ? qmap[q] : q;
-  HitOut* out = hits_out + (size_t)row * (size_t)k;
+  HitOut* out = hits_out + (size_t)row * (size_t)(out_stride > 0 ? out_stride : k) + col0;
+  if (ceil_out != nullptr) {
+    const uint64_t kth = topk_threshold<WIDE>(top, k);
+    if (lane == 0) ceil_out[row] = kth;
+  }
   if (fixed_info != nullptr) {
     // k_or_wide's keys: the high word is a fixed-point total (search_or_wide.hpp). score = total * 2^-e, rounded to f32
     // once; a hit whose total is below the query's floor asks for the f32 path (low_flags)
@@ -143,7 +150,8 @@ __global__ __launch_bounds__(WG_THREADS) void k_merge_items(const int64_t* __res
 
 // TopDocsCollector::finish_parallel across leaves / shards: list l's rows start at hits_in + l * hits_stride
 // ([query][k], already in global doc ids) and its hit counts at totals_in + l * totals_stride — [list][query][k] and
-// [list][query] arrays, or the records of one all-gather ([list][hits | totals]). One wavefront per query.
+// [list][query] arrays, or the records of one all-gather ([list][hits | totals | status]). One wavefront per query; k > 128 in
+// passes of 128 inside the kernel (each pass re-reads the lists and keeps what lies below the previous pass's worst key).
 template <bool WIDE>
 __global__ __launch_bounds__(WG_THREADS) void k_merge_lists(const HitOut* __restrict__ hits_in, const int64_t* __restrict__ totals_in,
                                                             int64_t hits_stride, int64_t totals_stride,
@@ -152,27 +160,33 @@ __global__ __launch_bounds__(WG_THREADS) void k_merge_lists(const HitOut* __rest
   const int lane = lane_id();
   const int q = (int)(blockIdx.x * WG_WAVES) + wave_id();
   if (q >= n_queries) return;
-  WaveTopK top;
-  uint64_t tau = 0;
   int64_t total = 0;
-  for (int l = 0; l < n_lists; ++l) {
-    const HitOut* in = hits_in + (size_t)l * (size_t)hits_stride + (size_t)q * (size_t)k;
-    for (int r = 0; r < k; r += 64) {
-      uint64_t key = 0;
-      if (r + lane < k) { const HitOut h = in[r + lane]; if (h.doc >= 0) key = make_key(h.score, h.doc); }
-      topk_offer<WIDE>(top, key, tau, k, lane);
-    }
-    total += totals_in[(size_t)l * (size_t)totals_stride + q];
-  }
+  for (int l = 0; l < n_lists; ++l) total += totals_in[(size_t)l * (size_t)totals_stride + q];
   HitOut* out = hits_out + (size_t)q * (size_t)k;
-  if (lane < k) out[lane] = top.a ? HitOut{key_doc(top.a), key_score(top.a)} : HitOut{-1, 0.f};
-  if (WIDE && lane + 64 < k) out[lane + 64] = top.b ? HitOut{key_doc(top.b), key_score(top.b)} : HitOut{-1, 0.f};
+  uint64_t ceil = ~0ull;
+  for (int col0 = 0; col0 < k; col0 += 128) {
+    const int kp = min(128, k - col0);
+    WaveTopK top;
+    uint64_t tau = 0;
+    for (int l = 0; l < n_lists; ++l) {
+      const HitOut* in = hits_in + (size_t)l * (size_t)hits_stride + (size_t)q * (size_t)k;
+      for (int r = 0; r < k; r += 64) {
+        uint64_t key = 0;
+        if (r + lane < k) { const HitOut h = in[r + lane]; if (h.doc >= 0) key = below(make_key(h.score, h.doc), ceil); }
+        if (__ballot(key > tau)) topk_offer<WIDE>(top, key, tau, kp, lane);
+      }
+    }
+    if (lane < kp) out[col0 + lane] = top.a ? HitOut{key_doc(top.a), key_score(top.a)} : HitOut{-1, 0.f};
+    if (WIDE && lane + 64 < kp) out[col0 + lane + 64] = top.b ? HitOut{key_doc(top.b), key_score(top.b)} : HitOut{-1, 0.f};
+    ceil = topk_threshold<WIDE>(top, kp);  // 0 when this pass did not fill up: nothing is left for the next one
+  }
   if (lane == 0) totals_out[q] = total;
 }
 
-__global__ void k_init_hits(HitOut* __restrict__ hits, int64_t n) {
+// rows of `stride` hits, columns [col0, col0 + k) set to "no hit"
+__global__ void k_init_hits(HitOut* __restrict__ hits, int64_t n_rows, int k, int stride, int col0) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) hits[i] = HitOut{-1, 0.f};
+  if (i < n_rows * k) hits[(i / k) * stride + col0 + (i % k)] = HitOut{-1, 0.f};
 }
 
 }  // namespace rgpu

@@ -20,7 +20,7 @@
 namespace rgpu {
 
 #ifdef RGPU_EXP_COUNT  // developer instrumentation (variant builds only): [0] lead blocks, [1] other-clause block decodes,
-__device__ unsigned long long g_and_dbg[4];  // [2] of those in dense mode, [3] (lead block, clause) visits
+__device__ unsigned long long g_and_dbg[4];  // [2] probed candidates, [3] (lead block, clause) visits
 #define AND_DBG(i, n) do { const unsigned long long n_ = (unsigned long long)(n); if (lane == 0) atomicAdd(&g_and_dbg[i], n_); } while (0)
 #else
 #define AND_DBG(i, n) do {} while (0)
@@ -38,6 +38,16 @@ constexpr int AND_WAVES_PER_SIMD = RGPU_AND_WAVES;
 #ifndef RGPU_AND_PREFETCH  // 1: the next block's rows are requested before the current one is unpacked (five more VGPRs)
 #define RGPU_AND_PREFETCH 1
 #endif
+// Tried in round 3, measured on the 1024 x 3-term batch (1.51-1.53 ms before and after, every time), not kept:
+//   * a "dense mode": when a directory window's pending candidates are about as many as the blocks they span, stream those
+//     blocks in order and probe ONE 32768-bit filter of the candidates (built once per lead block and clause) with each
+//     block's docs, confirmed hits leaving their freq in the candidate's LDS cell — 62 % of the block decodes went that
+//     way, the kernel's time did not move (1.52 ms);
+//   * clause descriptors in LDS, the next clause's directory window and the next lead block's rows requested a step early,
+//     cursors parked at the LAST visited block: 103-123 VGPRs, four wavefronts per SIMD instead of five, 1.57-1.72 ms.
+// Per (other-clause) block the kernel spends ~1000 SIMD cycles whichever way the block is chosen and probed; the ablation
+// builds put 0.20 ms on the lead decode, 0.08 ms on clause set-up + directory windows, 0.77 ms on decoding the other
+// clauses' blocks and 0.47 ms on the membership probe.
 #ifndef RGPU_AND_ABL  // developer ablations (variant builds only; results are wrong): 1 lead decode only, 2 + clause setup
 #define RGPU_AND_ABL 0  // and directory window, 3 + block decodes without the membership probe
 #endif
@@ -92,12 +102,6 @@ struct DirWindow {
 };
 
 constexpr int AND_FILTER_WORDS = 64;  // 2048-bit membership filter per wavefront
-// Dense mode (below): a 32768-bit filter of the PENDING CANDIDATES, built once per (lead block, clause)
-constexpr int AND_CFILT_WORDS = 1024;
-#ifndef RGPU_AND_DENSE  // 0: variant builds without the dense mode
-#define RGPU_AND_DENSE 1
-#endif
-constexpr int AND_DENSE_RING = 3;
 
 // What a MUST + SHOULD tree leaves per LEAD posting when the reference's ReqOptScorer rule is applied (k_req_opt_scan):
 // the conjunction's matches in doc order (= lead posting order), each with its required and its optional sum. A lead
@@ -121,7 +125,9 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
                                                            unsigned long long* __restrict__ touched_slots,
                                                            const int64_t* __restrict__ emit_prefix,
                                                            unsigned long long* __restrict__ emit_count,
-                                                           void* __restrict__ emit_out) {
+                                                           void* __restrict__ emit_out,
+                                                           const unsigned long long* __restrict__ ceil_slots = nullptr,
+                                                           const int32_t* __restrict__ qmap = nullptr) {
   // emit_out != null: nothing is collected here. Without HAS_OPT (phrases): int32 doc ids appended to the query's list
   // at emit_prefix[q] in any order, emit_count[q] the cursor. With HAS_OPT (the exact ReqOptScorer rule): one SeqRec per
   // lead posting at emit_prefix[q] + the posting's ordinal — doc order, no cursor.
@@ -130,9 +136,6 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
   __shared__ __attribute__((aligned(16))) uint8_t slabs[WG_WAVES][2 * SLAB_STREAM];  // FullBlock staging only: tails arrive decoded
   __shared__ float caches[WG_WAVES][256];
   __shared__ uint32_t filters[WG_WAVES][AND_FILTER_WORDS];
-  __shared__ __attribute__((aligned(16))) uint32_t cfilters[WG_WAVES][AND_CFILT_WORDS];
-  __shared__ int32_t cand_docs[WG_WAVES][128];   // the lead block's 128 candidates, sorted (posting 2 * lane, 2 * lane + 1)
-  __shared__ uint32_t cand_freq[WG_WAVES][128];  // dense mode's answers: the freq a clause holds for candidate i (0: not found)
   const int lane = lane_id();
   const int wave = wave_id();
   const int64_t item = (int64_t)blockIdx.x * WG_WAVES + wave;
@@ -144,9 +147,6 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
   uint8_t* slab = slabs[wave];
   float* cache = caches[wave];
   uint32_t* filt = filters[wave];
-  uint32_t* cfilt = cfilters[wave];
-  int32_t* cdocs = cand_docs[wave];
-  uint32_t* cfreq = cand_freq[wave];
   const bool has_norms = seg.norms != nullptr;
   int cur_table = -1;
   float k1 = 0.f;
@@ -163,6 +163,7 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
   int cursor = 0;  // lane ti holds clause ti's directory cursor (a register array indexed by ti would spill)
   SharedTau shared{tau_slots + q};
   shared.fold(shared.peek(), tau, floor);
+  const uint64_t ceil = ceil_slots != nullptr ? ceil_slots[qmap[q]] : ~0ull;  // k > 128: this pass's hits stay below it (wave.hpp)
 
   // nn: the candidates' norm bytes — from the lead's posting-order norms for FullBlocks, gathered for
   // its tail; every other clause scores the same docs, so no clause ever gathers norms again
@@ -183,7 +184,6 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
     const int n_clauses = HAS_OPT ? n_req_not + ((Q.op >> 16) & 0xff) : n_req_not;
     float r0 = 0.f, r1 = 0.f;  // required sums, parked while s0 / s1 collect the optional sum
     bool in_opt = false;
-    bool cands_staged = false;  // cdocs holds this lead block's candidates
     for (int ti = 1; ti < n_clauses; ++ti) {
       if (!(__ballot(a0) | __ballot(a1))) break;
       const bool excl = HAS_NOT && ti >= Q.n_terms && ti < n_req_not;  // wave-uniform
@@ -226,6 +226,7 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
       // Membership of the candidates c0 / c1 in the 128 (or, for a tail, `ev`-flagged) sorted docs e0 / e1 held two per
       // lane. `freqs()` yields the lanes' freqs and is called only when the filter reports a hit.
       auto probe = [&](int32_t e0, int32_t e1, bool ev0, bool ev1, bool c0, bool c1, auto freqs) {
+        AND_DBG(2, __popcll(__ballot(c0)) + __popcll(__ballot(c1)));
         filt[lane] = 0u;
         wave_sync();
         if (ev0) atomicOr(&filt[((uint32_t)e0 >> 5) & (AND_FILTER_WORDS - 1)], 1u << (e0 & 31));
@@ -283,7 +284,6 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
         }
       };
       bool first_visit = true;
-      bool dense_ready = false;  // cfilt / cfreq are set up for this clause
       while (true) {
         int j = locate();
         if (j < 0) break;
@@ -312,92 +312,6 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
           f.rows = block_rows_load(block_rows_at(term_rows, (uint32_t)readlane((int)W.row, slot)), f.hdr, lane);
           return f;
         };
-#if RGPU_AND_DENSE
-        // ---- Dense mode. When the pending candidates that fall into this directory window are about as many as the blocks
-        // they span, nearly every one of those blocks holds a candidate — the usual case for the second clause of a
-        // conjunction (a rare lead against a list a few times longer: the lead's candidates hit every block of it). Then
-        // the blocks are simply streamed in order, like a scan: no search for "the next block with a candidate", no
-        // per-block filter to zero and fill. Roles are swapped instead: ONE filter of the pending candidates (32768 bits,
-        // built once per lead block and clause) is probed with each block's 128 docs; the rare filter hits are confirmed by
-        // a binary search over the sorted candidates, a confirmed hit leaves its freq in the candidate's cell, and the
-        // candidates collect their answers once the window's stretch is done. The same answers as the visit-by-visit path.
-        {
-          const int jfull = min(63, T.nblocks - from);  // window slots 1 .. jfull are FullBlocks (slot s = block from + s - 1)
-          const int32_t wmax = readlane(W.last, jfull);
-          const uint64_t q0 = __ballot(p0 && d0 <= wmax), q1 = __ballot(p1 && d1 <= wmax);
-          const int cw = __popcll(q0) + __popcll(q1);
-          int jend = j;
-          if (cw >= 4) {
-            const int32_t dl0 = q0 ? readlane(d0, 63 - __builtin_clzll(q0)) : (int32_t)0x80000000;
-            const int32_t dl1 = q1 ? readlane(d1, 63 - __builtin_clzll(q1)) : (int32_t)0x80000000;
-            const int32_t dlast = dl0 > dl1 ? dl0 : dl1;
-            const uint64_t mb = __ballot(W.last >= dlast) & ~1ull;
-            jend = (int)__builtin_ctzll(mb);  // <= jfull: dlast <= wmax
-          }
-          const int span = jend - j + 1;
-          if (span >= 4 && 4 * span <= 5 * cw) {
-            if (!dense_ready) {
-#pragma unroll
-              for (int i = 0; i < AND_CFILT_WORDS / 256; ++i) reinterpret_cast<uint4*>(cfilt)[lane + 64 * i] = make_uint4(0u, 0u, 0u, 0u);
-              cfreq[lane] = 0u;
-              cfreq[64 + lane] = 0u;
-              if (!cands_staged) { cdocs[2 * lane] = d0; cdocs[2 * lane + 1] = d1; cands_staged = true; }
-              wave_sync();
-              if (p0) atomicOr(&cfilt[((uint32_t)d0 >> 5) & (AND_CFILT_WORDS - 1)], 1u << (d0 & 31));
-              if (p1) atomicOr(&cfilt[((uint32_t)d1 >> 5) & (AND_CFILT_WORDS - 1)], 1u << (d1 & 31));
-              wave_sync();
-              dense_ready = true;
-            }
-            auto rank_of = [&](int32_t e) -> int {  // index of e among the 128 sorted candidates, -1 if it is none of them
-              int lo = 0;
-#pragma unroll
-              for (int step = 64; step >= 1; step >>= 1) lo += cdocs[lo + step - 1] < e ? step : 0;
-              return cdocs[lo] == e ? lo : -1;
-            };
-            auto visit = [&](int slot, const Fetched& F) {
-              stage_rows(F.rows, slab, lane);
-              wave_sync();
-              touched += block_bytes(F.hdr);
-              AND_DBG(1, 1);
-              AND_DBG(2, 1);
-              uint32_t x0, x1;
-              staged_doc_deltas<LEGACY>(slab, F.rows, F.hdr, lane, x0, x1);
-              int32_t e0, e1;
-              deltas_to_docs(x0, x1, readlane(W.last, slot - 1), e0, e1);
-              const bool h0 = (cfilt[((uint32_t)e0 >> 5) & (AND_CFILT_WORDS - 1)] >> (e0 & 31)) & 1u;
-              const bool h1 = (cfilt[((uint32_t)e1 >> 5) & (AND_CFILT_WORDS - 1)] >> (e1 & 31)) & 1u;
-              if (__ballot(h0 || h1)) {
-                const int i0 = h0 ? rank_of(e0) : -1, i1 = h1 ? rank_of(e1) : -1;
-                if (__ballot(i0 >= 0 || i1 >= 0)) {
-                  uint32_t g0, g1;
-                  staged_freqs<LEGACY>(slab, F.rows, F.hdr, lane, g0, g1);
-                  if (i0 >= 0) cfreq[i0] = g0;  // (a freq is >= 1: a cell left at 0 says "not in this clause")
-                  if (i1 >= 0) cfreq[i1] = g1;
-                }
-              }
-              wave_sync();  // the slab is free for the next block; the answers are visible to the candidates' lanes
-            };
-            Fetched ring[AND_DENSE_RING];
-#pragma unroll
-            for (int r = 0; r < AND_DENSE_RING; ++r) ring[r] = fetch(min(j + r, jend));
-            for (int sl = j; sl <= jend; sl += AND_DENSE_RING) {
-#pragma unroll
-              for (int r = 0; r < AND_DENSE_RING; ++r) {  // static ring slot r <-> block slot sl + r; prefetch indices clamped, not guarded
-                const Fetched F = ring[r];
-                ring[r] = fetch(min(sl + r + AND_DENSE_RING, jend));
-                if (sl + r <= jend) visit(sl + r, F);
-              }
-            }
-            const int32_t vend = readlane(W.last, jend);
-            const bool c0 = p0 && d0 <= vend, c1 = p1 && d1 <= vend;  // every pending candidate up to the stretch's last doc has its answer
-            if (c0) { const uint32_t f = cfreq[2 * lane]; if (f != 0u) found(a0, s0, f, n0); else missed(a0); }
-            if (c1) { const uint32_t f = cfreq[2 * lane + 1]; if (f != 0u) found(a1, s1, f, n1); else missed(a1); }
-            p0 = p0 && !c0;
-            p1 = p1 && !c1;
-            continue;
-          }
-        }
-#endif
         Fetched A = fetch(j);
         while (true) {
           const int32_t vlast = readlane(W.last, j), vbase = readlane(W.last, j - 1);
@@ -462,8 +376,8 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
       return;
     }
     count += __popcll(__ballot(a0)) + __popcll(__ballot(a1));
-    topk_offer<WIDE>(top, a0 ? make_key(s0, d0) : 0ull, tau, k, lane, floor);
-    topk_offer<WIDE>(top, a1 ? make_key(s1, d1) : 0ull, tau, k, lane, floor);
+    topk_offer<WIDE>(top, a0 ? below(make_key(s0, d0), ceil) : 0ull, tau, k, lane, floor);
+    topk_offer<WIDE>(top, a1 ? below(make_key(s1, d1), ceil) : 0ull, tau, k, lane, floor);
   };
 
   // One call site for the three shapes a lead "block" can take (FullBlock, VInt tail, singleton): the candidate loop
@@ -523,11 +437,15 @@ constexpr int REQ_OPT_THRESHOLD = 100;  // OPT_SCORE_THRESHOLD (req_opt_scorer.r
 template <bool WIDE>
 __global__ __launch_bounds__(WG_THREADS) void k_req_opt_scan(const SeqRec* __restrict__ seq, const int64_t* __restrict__ seq_prefix,
                                                              int n_queries, int k, int32_t doc_base, const int32_t* __restrict__ qmap,
-                                                             HitOut* __restrict__ hits_out, int64_t* __restrict__ totals_out) {
+                                                             HitOut* __restrict__ hits_out, int64_t* __restrict__ totals_out, int out_stride = 0,
+                                                             int col0 = 0, const unsigned long long* __restrict__ ceil_slots = nullptr,
+                                                             unsigned long long* __restrict__ ceil_out = nullptr) {
   const int lane = lane_id();
   const int q = (int)(blockIdx.x * WG_WAVES) + wave_id();
   if (q >= n_queries) return;
   const int64_t i0 = seq_prefix[q], i1 = seq_prefix[q + 1];
+  const int row = qmap ? qmap[q] : q;
+  const uint64_t ceil = ceil_slots != nullptr ? ceil_slots[row] : ~0ull;
   WaveTopK top;
   uint64_t tau = 0;
   int64_t total = 0;
@@ -554,10 +472,13 @@ __global__ __launch_bounds__(WG_THREADS) void k_req_opt_scan(const SeqRec* __res
       }
     }
     const float final_score = ((skipped >> lane) & 1ull) ? r.req : r.req + r.opt;
-    topk_offer<WIDE>(top, valid ? make_key(final_score, r.doc) : 0ull, tau, k, lane);
+    topk_offer<WIDE>(top, valid ? below(make_key(final_score, r.doc), ceil) : 0ull, tau, k, lane);
   }
-  const int row = qmap ? qmap[q] : q;
-  HitOut* out = hits_out + (size_t)row * (size_t)k;
+  HitOut* out = hits_out + (size_t)row * (size_t)(out_stride > 0 ? out_stride : k) + col0;
+  if (ceil_out != nullptr) {
+    const uint64_t kth = topk_threshold<WIDE>(top, k);
+    if (lane == 0) ceil_out[row] = kth;
+  }
   if (lane < k) out[lane] = top.a ? HitOut{key_doc(top.a) + doc_base, key_score(top.a)} : HitOut{-1, 0.f};
   if (WIDE && lane + 64 < k) out[lane + 64] = top.b ? HitOut{key_doc(top.b) + doc_base, key_score(top.b)} : HitOut{-1, 0.f};
   if (lane == 0) totals_out[row] = total;

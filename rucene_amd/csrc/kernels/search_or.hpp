@@ -132,7 +132,9 @@ __global__ __launch_bounds__(OR_THREADS, 6) void k_or_windows(SegView seg, const
                                                               int items_per_query, int W, int k,
                                                               uint64_t* __restrict__ partial_keys,
                                                               int32_t* __restrict__ partial_counts,
-                                                              unsigned long long* __restrict__ tau_slots) {
+                                                              unsigned long long* __restrict__ tau_slots,
+                                                              const unsigned long long* __restrict__ ceil_slots = nullptr,
+                                                              const int32_t* __restrict__ qmap = nullptr) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int lane = lane_id();
   const int wave = wave_id();
@@ -174,6 +176,7 @@ __global__ __launch_bounds__(OR_THREADS, 6) void k_or_windows(SegView seg, const
   int hits_lane = 0;  // collected docs this lane saw (summed over the wave at the end: TopDocs::total_hits)
   SharedTau shared{tau_slots + q};
   shared.fold(shared.peek(), tau, floor);
+  const uint64_t ceil = ceil_slots != nullptr ? ceil_slots[qmap[q]] : ~0ull;  // k > 128: this pass's hits stay below it (wave.hpp)
   const int win0 = g * windows_per_item;
   const int win1 = Q.n_terms > 0 ? min(windows_per_query, win0 + windows_per_item) : win0;
   const int32_t first_doc = win0 * W;
@@ -352,13 +355,13 @@ __global__ __launch_bounds__(OR_THREADS, 6) void k_or_windows(SegView seg, const
           const bool c0 = h0 && o0 >= thi, c1 = h1 && o1 >= thi, c2 = h2 && o2 >= thi, c3 = h3 && o3 >= thi;
           if (RGPU_OR_ABL != 1 && __ballot(c0 || c1 || c2 || c3)) {
             const int32_t d = w0 + (int32_t)i0 + 4 * lane;
-            uint64_t key = c0 ? make_key(v.x, d) : 0ull;
+            uint64_t key = c0 ? below(make_key(v.x, d), ceil) : 0ull;
             if (__ballot(key > tau)) topk_offer<WIDE>(top, key, tau, k, lane, floor);
-            key = c1 ? make_key(v.y, d + 1) : 0ull;
+            key = c1 ? below(make_key(v.y, d + 1), ceil) : 0ull;
             if (__ballot(key > tau)) topk_offer<WIDE>(top, key, tau, k, lane, floor);
-            key = c2 ? make_key(v.z, d + 2) : 0ull;
+            key = c2 ? below(make_key(v.z, d + 2), ceil) : 0ull;
             if (__ballot(key > tau)) topk_offer<WIDE>(top, key, tau, k, lane, floor);
-            key = c3 ? make_key(v.w, d + 3) : 0ull;
+            key = c3 ? below(make_key(v.w, d + 3), ceil) : 0ull;
             if (__ballot(key > tau)) topk_offer<WIDE>(top, key, tau, k, lane, floor);
           }
         }

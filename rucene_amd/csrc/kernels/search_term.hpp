@@ -100,7 +100,7 @@ template <bool LEGACY, bool WIDE>
 __device__ __forceinline__ void term_blocks_fast(const SegView& seg, const DevTerm& T, int b0, int b1, uint8_t* slab,
                                                  const float* cache, float wk, int lane, const GroupList& group,
                                                  SharedTau& shared, uint64_t& floor, int k, int& count, bool prune, uint32_t& looked,
-                                                 uint32_t& touched) {
+                                                 uint32_t& touched, uint64_t ceil) {
   constexpr int DEPTH = PREFETCH_DEPTH;
   const uint8_t* term_rows = seg.bstore + T.bs_base;
   const uint8_t* pn = seg.pnorm + T.pn_base;
@@ -201,7 +201,7 @@ __device__ __forceinline__ void term_blocks_fast(const SegView& seg, const DevTe
         const int32_t base = blk == 0 ? 0 : seg.dir_last[T.dir_base + blk - 1];
         int32_t d0, d1;
         deltas_to_docs(e0, e1, base, d0, d1);
-        const uint64_t key0 = make_key(s0, d0), key1 = make_key(s1, d1);
+        const uint64_t key0 = below(make_key(s0, d0), ceil), key1 = below(make_key(s1, d1), ceil);
         // most blocks that get here only tie with the threshold or trail a fresher one: look at the group's
         // current k-th best (one LDS read) before paying for the lock and the list check-out
         tau = fresh_tau();
@@ -272,7 +272,10 @@ __global__ __launch_bounds__(TERM_THREADS, 8) void k_search_term(SegView seg, co
                                                               uint64_t* __restrict__ partial_keys,
                                                               int32_t* __restrict__ partial_counts,
                                                               unsigned long long* __restrict__ tau_slots,
-                                                              unsigned long long* __restrict__ work_slots) {
+                                                              unsigned long long* __restrict__ work_slots,
+                                                              const unsigned long long* __restrict__ ceil_slots,
+                                                              const int32_t* __restrict__ qmap) {
+  // ceil_slots (nullable): per CALLER row (qmap[q]) the key this pass's hits must stay below (wave.hpp `below`)
   // work_slots (nullable): [q] += encoded bytes of the FullBlocks this launch decoded for query q (+ their norms),
   // [n_queries + q] += their number — with block-max pruning a small part of the lists ("touched" vs "scan" bytes)
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -318,6 +321,7 @@ __global__ __launch_bounds__(TERM_THREADS, 8) void k_search_term(SegView seg, co
   SharedTau shared{tau_slots + q};
   int count = 0;
   uint32_t looked = 0, touched = 0;
+  const uint64_t ceil = ceil_slots != nullptr ? ceil_slots[qmap[q]] : ~0ull;
 
   if (queries[q].n_terms >= 1) {  // else: clause absent from this leaf, nothing to collect
     const DevTerm T = terms[queries[q].first_term];
@@ -354,7 +358,7 @@ __global__ __launch_bounds__(TERM_THREADS, 8) void k_search_term(SegView seg, co
         s1 = bm25_score(wk, (float)(int32_t)f1, has_norms ? cache[nb1] : k1);
       }
       count += __popcll(__ballot(v0)) + __popcll(__ballot(v1));
-      const uint64_t key0 = v0 ? make_key(s0, d0) : 0ull, key1 = v1 ? make_key(s1, d1) : 0ull;
+      const uint64_t key0 = v0 ? below(make_key(s0, d0), ceil) : 0ull, key1 = v1 ? below(make_key(s1, d1), ceil) : 0ull;
       // `tau` may lag behind the group's list: a stale threshold only lets more keys through to the locked offer
       if (__ballot((key0 > key1 ? key0 : key1) > tau)) group_offer2<WIDE>(group, key0, key1, tau, k, lane, floor);
     };
@@ -370,7 +374,7 @@ __global__ __launch_bounds__(TERM_THREADS, 8) void k_search_term(SegView seg, co
     };
     if (tabled && !has_live && nonneg) {
       term_blocks_fast<LEGACY, WIDE>(seg, T, b0, b1, slab, cache, wk, lane, group, shared, floor, k, count,
-                                     RGPU_TERM_PRUNE && (T.flags & TERM_FLAG_MONOTONE) != 0u, looked, touched);
+                                     RGPU_TERM_PRUNE && (T.flags & TERM_FLAG_MONOTONE) != 0u, looked, touched, ceil);
       if (b1 > b0) base = seg.dir_last[T.dir_base + b1 - 1];
     } else if (has_norms) {
       stream_blocks<LEGACY, true>(term_rows, seg.dir_row, seg.dir_hdr, T.dir_base, seg.pnorm + T.pn_base, b0, b1, slab, lane, base, on_block);

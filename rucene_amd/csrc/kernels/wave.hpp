@@ -89,6 +89,10 @@ __device__ __forceinline__ uint64_t make_key(float score, int32_t doc) {
   return ((uint64_t)float_order_bits(score) << 32) | (uint32_t)(~(uint32_t)doc);
 }
 __device__ __forceinline__ int32_t key_doc(uint64_t k) { return (int32_t)(~(uint32_t)k); }
+// k > 128 is served in passes of up to 128 hits (the widest list a wavefront's registers hold): pass p collects the best
+// keys strictly BELOW the worst key of pass p - 1 (keys are unique per doc and totally ordered, so the passes partition the
+// ranking exactly). `ceil` = that key (~0 in the first pass, 0 when the previous pass ran out of hits).
+__device__ __forceinline__ uint64_t below(uint64_t key, uint64_t ceil) { return key < ceil ? key : 0ull; }
 __device__ __forceinline__ float key_score(uint64_t k) { return order_bits_float((uint32_t)(k >> 32)); }
 
 // ---- wave-resident top-k (k <= 128): rank r lives in lane r of `a` (r < 64) or lane r-64 of `b` ----------------

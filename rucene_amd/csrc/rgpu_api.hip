@@ -31,6 +31,7 @@
 using namespace rgpu;
 
 static_assert(sizeof(HitOut) == sizeof(rgpu_hit), "hit layout");
+constexpr int32_t RGPU_PASS_K = 128;  // hits per pass: the widest list a wavefront's registers hold (kernels/wave.hpp WaveTopK)
 static_assert(OR_MAX_TERMS >= RGPU_MAX_QUERY_TERMS, "k_or_windows keeps one cursor per clause in a lane / register slot");
 
 static thread_local std::string g_last_error;
@@ -142,6 +143,10 @@ struct rgpu_ctx {
   DevVec<HitOut> host_api_hits;  // rgpu_search_batch (blocking, host outputs): device-side result rows
   DevVec<int64_t> host_api_totals;
   int* d_err = nullptr;
+  // k > 128: the search runs in passes of up to 128 hits; a pass writes columns [col0, col0 + k_pass) of rows `stride` hits
+  // long and keeps below the previous pass's worst key per caller row (d_ceil; null in the first pass)
+  struct Pass { int stride = 0, col0 = 0; const unsigned long long* ceil_in = nullptr; unsigned long long* ceil_out = nullptr; } pass;
+  DevVec<unsigned long long> d_ceil;
   Scratch* last_and = nullptr;  // the slot whose d_touched the most recent AND launch filled
   int last_and_queries = 0;
   // rgpu_last_search_counters: the most recent TERM / AND / wide-OR launch
@@ -611,7 +616,7 @@ extern "C" void rgpu_shutdown(rgpu_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   drain_events(c);
   for (auto e : c->free_events) (void)hipEventDestroy(e);
-  c->sim_tables.release(); c->d_runs.release(); c->phrase_docs.release(); c->phrase_keys.release(); c->phrase_count.release(); c->host_api_hits.release(); c->host_api_totals.release();
+  c->sim_tables.release(); c->d_ceil.release(); c->d_runs.release(); c->phrase_docs.release(); c->phrase_keys.release(); c->phrase_count.release(); c->host_api_hits.release(); c->host_api_totals.release();
   for (auto& sc : c->scr) sc.release();
   if (c->d_err) (void)hipFree(c->d_err);
   (void)hipStreamDestroy(c->stream);
@@ -984,7 +989,8 @@ static void launch_merge(rgpu_ctx* c, hipStream_t s, int n_queries, int k, const
   TimedLaunch tl(c, s, "k_merge_items", 0);
   const unsigned grid = (unsigned)((n_queries + WG_WAVES - 1) / WG_WAVES);
   hipLaunchKernelGGL(k_merge_items<WIDE>, dim3(grid), dim3(WG_THREADS), 0, s, d_prefix, n_queries, k, c->S->d_partial_keys.p,
-                     c->S->d_partial_counts.p, doc_base, head_items, hits, totals, fixed_info, low_flags, qmap);
+                     c->S->d_partial_counts.p, doc_base, head_items, hits, totals, fixed_info, low_flags, qmap, c->pass.stride, c->pass.col0,
+                     c->pass.ceil_out);
 }
 
 // OR: score every clause once into {doc, score} runs, then accumulate per doc-id window (kernels/search_or.hpp)
@@ -1096,7 +1102,7 @@ static int32_t search_or_group(rgpu_segment* seg, Group& G, int32_t k, HitOut* h
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
       hipLaunchKernelGGL(kern, dim3(grid), dim3(OR_THREADS), lds, stream, sv, dq, dt, drp, c->d_runs.p, nq, wpq, wpi, ipq, W, (int)k,
-                         c->S->d_partial_keys.p, c->S->d_partial_counts.p, c->S->d_tau.p);
+                         c->S->d_partial_keys.p, c->S->d_partial_counts.p, c->S->d_tau.p, c->pass.ceil_in, dm);
       return hipSuccess;
     };
     auto pick = [&](auto legacy_tag) -> hipError_t {
@@ -1264,10 +1270,34 @@ static int32_t search_or_wide_group(rgpu_segment* seg, Group& G, int32_t k, HitO
   return RGPU_OK;
 }
 
+static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t n_queries, const rgpu_query_term* terms,
+                           int32_t n_terms_total, int32_t k, int32_t k_total, HitOut* hits_dev, int64_t* totals_dev, hipStream_t stream);
+// TopDocsCollector takes any k (collector/top_docs.rs:28-95). A wavefront's registers hold a 128-key list, so k > 128 runs as
+// ceil(k / 128) passes of the whole search: pass p collects the best hits strictly below the worst hit of pass p - 1 (keys —
+// score, then doc id — are unique and totally ordered: the passes partition the ranking exactly) and writes columns
+// [128 p, 128 p + 128) of the caller's rows. Page 2 of a 100-per-page result list costs two passes, k = 1024 eight.
 static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t n_queries, const rgpu_query_term* terms,
                            int32_t n_terms_total, int32_t k, HitOut* hits_dev, int64_t* totals_dev, hipStream_t stream) {
   rgpu_ctx* c = seg->ctx;
   if (k <= 0 || k > RGPU_MAX_K) return fail(k <= 0 ? RGPU_ERR_ILLEGAL_ARGUMENT : RGPU_ERR_UNSUPPORTED, "k must be in 1..RGPU_MAX_K");
+  c->pass = rgpu_ctx::Pass{};
+  if (k <= RGPU_PASS_K) return search_pass(seg, queries, n_queries, terms, n_terms_total, k, k, hits_dev, totals_dev, stream);
+  HIP_TRY(c->d_ceil.reserve((size_t)n_queries, 0, stream));
+  int32_t rc = RGPU_OK;
+  for (int32_t col0 = 0; col0 < k && rc == RGPU_OK; col0 += RGPU_PASS_K) {
+    c->pass.stride = k;
+    c->pass.col0 = col0;
+    c->pass.ceil_in = col0 == 0 ? nullptr : c->d_ceil.p;
+    c->pass.ceil_out = c->d_ceil.p;
+    rc = search_pass(seg, queries, n_queries, terms, n_terms_total, std::min<int32_t>(RGPU_PASS_K, k - col0), k, hits_dev, totals_dev, stream);
+  }
+  c->pass = rgpu_ctx::Pass{};
+  if (rc == RGPU_OK) HIP_TRY(hipStreamSynchronize(stream));  // d_ceil belongs to the context: the next call may start over on another stream
+  return rc;
+}
+static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t n_queries, const rgpu_query_term* terms,
+                           int32_t n_terms_total, int32_t k, int32_t k_total, HitOut* hits_dev, int64_t* totals_dev, hipStream_t stream) {
+  rgpu_ctx* c = seg->ctx;
   // validate + prepare
   std::vector<const rgpu_term_state*> ptrs;
   for (int32_t q = 0; q < n_queries; ++q) {
@@ -1307,7 +1337,9 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
   groups[4].req_opt = true;
   int cur_req_opt = 4;
   int64_t req_opt_records = 0;
-  const bool or_wide_ok = c->cfg.or_wide >= 0 && seg->d_norms && seg->n_norm_ranks > 0 && !seg->d_live;
+  // (the fixed-point kernel ranks by exact totals and rounds to f32 afterwards: across passes that would need a ceiling in
+  // its own key space — deep result pages of a >= 10-clause disjunction go through the clause-order kernel instead)
+  const bool or_wide_ok = c->cfg.or_wide >= 0 && seg->d_norms && seg->n_norm_ranks > 0 && !seg->d_live && k_total <= RGPU_PASS_K;
   std::vector<DevTerm> mine, mine_not, mine_opt;
   for (int32_t q = 0; q < n_queries; ++q) {
     const rgpu_query& Q = queries[q];
@@ -1403,7 +1435,8 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
   auto init_rows = [&]() -> int32_t {
     HIP_TRY(hipMemsetAsync(totals_dev, 0, (size_t)n_queries * 8, stream));
     hipLaunchKernelGGL(k_init_hits, dim3((unsigned)(((size_t)n_queries * k + 255) / 256)), dim3(256), 0, stream, hits_dev,
-                       (int64_t)n_queries * k);
+                       (int64_t)n_queries, (int)k, c->pass.stride > 0 ? c->pass.stride : (int)k, c->pass.col0);
+    if (c->pass.ceil_out) HIP_TRY(hipMemsetAsync(c->pass.ceil_out, 0, (size_t)n_queries * 8, stream));  // rows no group writes have nothing below
     return RGPU_OK;
   };
   int busy_groups = 0;
@@ -1517,7 +1550,7 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
       auto go = [&](auto kern) {
         hipLaunchKernelGGL(kern, dim3(grid), dim3(WG_THREADS), 0, stream, sv, dq, dt, dp, nq, items, blocks_per_item, (int)k,
                            c->S->d_partial_keys.p, c->S->d_partial_counts.p, d_tau, c->S->d_touched.p,
-                           d_sp, (unsigned long long*)nullptr, d_seq);
+                           d_sp, (unsigned long long*)nullptr, d_seq, c->pass.ceil_in, dm);
       };
       bool has_not = false, has_opt = false;
       for (const DevQuery& q : G.queries) { has_not = has_not || q.pad != 0; has_opt = has_opt || (q.op >> 16) != 0; }
@@ -1548,7 +1581,7 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(TERM_THREADS), lds, stream, sv, dq, dt, dp, nq, items, blocks_per_item, (int)k,
-                           c->S->d_partial_keys.p, c->S->d_partial_counts.p, d_tau, c->S->d_touched.p);
+                           c->S->d_partial_keys.p, c->S->d_partial_counts.p, d_tau, c->S->d_touched.p, c->pass.ceil_in, dm);
         return hipSuccess;
       };
       hipError_t e;
@@ -1561,8 +1594,10 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
       const unsigned grid = (unsigned)((nq + WG_WAVES - 1) / WG_WAVES);
       const SeqRec* d_seq = reinterpret_cast<const SeqRec*>(c->d_runs.p);
       const int64_t* d_sp = reinterpret_cast<const int64_t*>(c->S->d_stage.p + o_sp);
-      if (wide) hipLaunchKernelGGL(k_req_opt_scan<true>, dim3(grid), dim3(WG_THREADS), 0, stream, d_seq, d_sp, nq, (int)k, seg->doc_base, dm, hits_dev, totals_dev);
-      else hipLaunchKernelGGL(k_req_opt_scan<false>, dim3(grid), dim3(WG_THREADS), 0, stream, d_seq, d_sp, nq, (int)k, seg->doc_base, dm, hits_dev, totals_dev);
+      if (wide) hipLaunchKernelGGL(k_req_opt_scan<true>, dim3(grid), dim3(WG_THREADS), 0, stream, d_seq, d_sp, nq, (int)k, seg->doc_base, dm, hits_dev, totals_dev,
+                                   c->pass.stride, c->pass.col0, c->pass.ceil_in, c->pass.ceil_out);
+      else hipLaunchKernelGGL(k_req_opt_scan<false>, dim3(grid), dim3(WG_THREADS), 0, stream, d_seq, d_sp, nq, (int)k, seg->doc_base, dm, hits_dev, totals_dev,
+                              c->pass.stride, c->pass.col0, c->pass.ceil_in, c->pass.ceil_out);
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipStreamSynchronize(stream));  // the record buffer is shared scratch
       HIP_TRY(scratch_mark(c, stream));
@@ -1664,7 +1699,7 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
                                             int64_t* total_hits_out) {
   if (!seg || !queries || n_queries <= 0 || !terms || n_terms_total <= 0 || !hits_out || !total_hits_out)
     return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "bad arguments");
-  if (k <= 0 || k > RGPU_MAX_K) return fail(k <= 0 ? RGPU_ERR_ILLEGAL_ARGUMENT : RGPU_ERR_UNSUPPORTED, "k must be in 1..RGPU_MAX_K");
+  if (k <= 0 || k > RGPU_PASS_K) return fail(k <= 0 ? RGPU_ERR_ILLEGAL_ARGUMENT : RGPU_ERR_UNSUPPORTED, "phrase search: k must be in 1..128");
   if (!seg->has_positions || !seg->d_pos) return fail(RGPU_ERR_ILLEGAL_STATE, "phrase search needs a positions field with its .pos file attached");
   rgpu_ctx* c = seg->ctx;
   std::lock_guard<std::mutex> g(c->mu);
@@ -1743,7 +1778,7 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
   HIP_TRY(c->host_api_hits.reserve((size_t)n_queries * (size_t)k, 0, stream));
   HIP_TRY(c->host_api_totals.reserve((size_t)n_queries, 0, stream));
   HIP_TRY(hipMemsetAsync(c->host_api_totals.p, 0, (size_t)n_queries * 8, stream));
-  hipLaunchKernelGGL(k_init_hits, dim3((unsigned)(((size_t)n_queries * k + 255) / 256)), dim3(256), 0, stream, c->host_api_hits.p, (int64_t)n_queries * k);
+  hipLaunchKernelGGL(k_init_hits, dim3((unsigned)(((size_t)n_queries * k + 255) / 256)), dim3(256), 0, stream, c->host_api_hits.p, (int64_t)n_queries, (int)k, (int)k, 0);
   if (items > 0) {
     HIP_TRY(scratch_take(c));
     Stager st(c);
@@ -1787,7 +1822,7 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
       auto go = [&](auto kern) {
         hipLaunchKernelGGL(kern, dim3(grid), dim3(WG_THREADS), 0, stream, sv, d_q, d_t, d_ip, (int)n_queries, items, blocks_per_item, (int)k,
                            c->S->d_partial_keys.p, c->S->d_partial_counts.p, c->S->d_tau.p, c->S->d_touched.p, d_ep, c->phrase_count.p,
-                           (void*)c->phrase_docs.p);
+                           (void*)c->phrase_docs.p, (const unsigned long long*)nullptr, (const int32_t*)nullptr);
       };
       if (legacy) go(k_search_and<true, false, false, false>); else go(k_search_and<false, false, false, false>);
     }
@@ -1852,7 +1887,7 @@ extern "C" int32_t rgpu_rescore_batch(rgpu_segment* seg, const rgpu_query* queri
                                       int32_t finish) {
   if (!seg || !queries || n_queries <= 0 || !terms || n_terms_total <= 0 || !requests || !hits_inout)
     return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "bad arguments");
-  if (k <= 0 || k > RGPU_MAX_K) return fail(k <= 0 ? RGPU_ERR_ILLEGAL_ARGUMENT : RGPU_ERR_UNSUPPORTED, "k must be in 1..RGPU_MAX_K");
+  if (k <= 0 || k > RGPU_PASS_K) return fail(k <= 0 ? RGPU_ERR_ILLEGAL_ARGUMENT : RGPU_ERR_UNSUPPORTED, "rescoring: k must be in 1..128");
   rgpu_ctx* c = seg->ctx;
   std::lock_guard<std::mutex> g(c->mu);
   HIP_TRY(hipSetDevice(c->device));
@@ -1868,7 +1903,7 @@ extern "C" int32_t rgpu_rescore_batch(rgpu_segment* seg, const rgpu_query* queri
     if (Q.first_term < 0 || (int64_t)Q.first_term + Q.n_terms > (int64_t)n_terms_total) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "clause range outside terms[]");
     const rgpu_rescore_request& r = requests[q];
     if (r.mode < RGPU_RESCORE_AVG || r.mode > RGPU_RESCORE_MULTIPLY || r.window_size < 0) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "bad rescore request");
-    rp[(size_t)q] = RescoreParams{r.query_weight, r.rescore_weight, r.mode, std::min(std::min(r.window_size, k), RGPU_MAX_K)};
+    rp[(size_t)q] = RescoreParams{r.query_weight, r.rescore_weight, r.mode, std::min(std::min(r.window_size, k), RGPU_PASS_K)};
     for (int i = 0; i < Q.n_terms; ++i) {
       const rgpu_query_term& t = terms[Q.first_term + i];
       if (t.sim_table < 0 || t.sim_table >= c->n_sim_tables) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "unknown sim_table handle");
@@ -2056,7 +2091,7 @@ static int32_t search_into_record(rgpu_segment* seg, const rgpu_query* queries, 
   const std::string why = rc == RGPU_OK ? std::string() : g_last_error;
   if (rc != RGPU_OK) {  // whatever was enqueued before the failure is overwritten behind it on the same stream
     HIP_TRY(hipMemsetAsync(record + hits_bytes, 0, (size_t)n_queries * 8, s));
-    hipLaunchKernelGGL(k_init_hits, dim3((unsigned)(((size_t)n_queries * k + 255) / 256)), dim3(256), 0, s, (HitOut*)record, (int64_t)n_queries * k);
+    hipLaunchKernelGGL(k_init_hits, dim3((unsigned)(((size_t)n_queries * k + 255) / 256)), dim3(256), 0, s, (HitOut*)record, (int64_t)n_queries, (int)k, (int)k, 0);
   }
   hipLaunchKernelGGL(k_set_i64, dim3(1), dim3(1), 0, s, (int64_t*)(record + hits_bytes + (size_t)n_queries * 8), (int64_t)rc);
   HIP_TRY(hipGetLastError());

@@ -1167,7 +1167,7 @@ def test_shard_records_merge_like_finish_parallel(ctx, oracle):
         sr = rucene_amd.GpuIndexSearcher([leaf], ctx=ctx)
         sr.override_statistics(rucene_amd.CollectionStatistics("body", 0, 2 * docs, segs[0].doc_count, segs[0].sum_total_term_freq), segs[0].terms)
         searchers.append((sr, leaf))
-    for k in (10, 100):
+    for k in (10, 100, 300):   # 300: three passes per shard, and the merge's own passes over the gathered lists
         rec = gpu.record_bytes(nq, k)
         assert rec == nq * k * 8 + nq * 8 + 8
         recv = torch.zeros((2 * rec,), dtype=torch.uint8, device="cuda")
@@ -1280,3 +1280,30 @@ def test_native_planner_with_its_own_sim_table(ctx, oracle):
         want_h, want_tot = leaf.segment.search_batch(want_q, want_t, 10)
         assert (got_h["doc"] == want_h["doc"]).all() and (got_h["score"].view(np.int32) == want_h["score"].view(np.int32)).all() and (got_t == want_tot).all()
     planner.close()
+
+
+@pytest.mark.parametrize("k", [129, 300, 1000])
+def test_k_above_128_runs_in_passes(zipf, oracle, k):
+    """TopDocsCollector takes any k (collector/top_docs.rs:28-95); a wavefront's registers hold 128 keys, so k > 128 runs as
+    ceil(k / 128) passes, each collecting what lies strictly below the previous pass's worst hit. Doc ids, score bits and
+    hit counts against the oracle for every operator, lists shorter than k included; >= 10 SHOULD clauses go through the
+    clause-order kernel here (judged like every heap-order disjunction)."""
+    seg, osearcher, gsearcher = zipf
+    specs = [(oracle.OP_TERM, [t]) for t in (0, 3, 40, 700, 5_000, 45_000)]            # df from 60 k down to a handful
+    specs += [(oracle.OP_AND, [0, 1, 2]), (oracle.OP_AND, [5, 60]), (oracle.OP_AND, [2, 300, 4_000])]
+    specs += [(oracle.OP_OR, [1, 30, 400]), (oracle.OP_OR, [7, 90, 2_000, 15_000, 30_000]), (oracle.OP_OR, [40_000, 49_999, 70_000])]
+    _check_against_oracle(oracle, osearcher, gsearcher, specs, k)
+    wide = [(oracle.OP_OR, [0, 1, 2, 7, 30, 200, 900, 2_000, 3_500, 4_999]), (oracle.OP_OR, list(range(20, 32)))]
+    _check_against_oracle(oracle, osearcher, gsearcher, wide, k, exact=False)
+    import rucene_amd
+    T, B = rucene_amd.TermQuery, rucene_amd.BooleanQuery
+    # MUST + SHOULD (the ReqOptScorer scan writes its rows itself) and MUST_NOT trees
+    hits, totals = gsearcher.search_batch([B.build([T(3)], [T(9), T(40)]), B.build([T(1), T(6)], [], must_nots=[T(2)])], k)
+    d, s, total = osearcher.search_opt(oracle.OP_TERM, [3], [9, 40], k)
+    assert totals[0] == total and (hits[0]["doc"][:d.size] == d).all() and (hits[0]["score"][:d.size].view(np.int32) == s.view(np.int32)).all()
+    assert (hits[0]["doc"][d.size:] == -1).all()
+    d, s, total = osearcher.search_not(oracle.OP_AND, [1, 6], [2], k)
+    assert totals[1] == total and (hits[1]["doc"][:d.size] == d).all() and (hits[1]["score"][:d.size].view(np.int32) == s.view(np.int32)).all()
+    with pytest.raises(rucene_amd.RgpuError) as e:
+        gsearcher.search_batch([T(3)], 1025)
+    assert e.value.status == -5
