@@ -376,7 +376,10 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_blocks(const uint8_t* 
                                                                   const uint32_t* __restrict__ dir_row,
                                                                   uint16_t* dir_hdr, uint8_t* bstore,
                                                                   uint64_t* __restrict__ dir_bmax, int has_freqs,
-                                                                  int32_t max_doc, int* err) {
+                                                                  int32_t max_doc, int* err, int32_t* __restrict__ docs_out,
+                                                                  int32_t* __restrict__ freqs_out) {
+  // docs_out / freqs_out (nullable): the materialising decode that triggered this preparation (PrepTerm::out_base) — a
+  // first-touch decode then costs no second pass over the block store (k_decode_terms serves terms prepared earlier)
   __shared__ __attribute__((aligned(16))) uint8_t slabs[PREP_WAVES][PREP_SLAB_BYTES];
   const int lane = lane_id();
   const int wave = wave_id();
@@ -407,6 +410,11 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_blocks(const uint8_t* 
     // the tail's directory slot gets its last doc, like a FullBlock's: the wide OR kernel walks tails as one more block
     const int32_t tail_last = readlane(((tail_n - 1) & 1) ? d1 : d0, (tail_n - 1) >> 1);
     if (lane == 0) { dir_last[t.dir_base + t.nblocks] = tail_last; dir_bmax[t.dir_base + t.nblocks] = 15ull; }
+    if (docs_out != nullptr && t.out_base >= 0) {
+      const int64_t o = t.out_base + 128 * (int64_t)t.nblocks + 2 * lane;
+      if (v0) { docs_out[o] = d0; freqs_out[o] = (int32_t)f0; }
+      if (v1) { docs_out[o + 1] = d1; freqs_out[o + 1] = (int32_t)f1; }
+    }
   }
   if (b1 <= b0) return;
   // lane j: block b0 + j's directory words (one coalesced look instead of dependent loads per block)
@@ -549,6 +557,13 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_blocks(const uint8_t* 
     if (__ballot(bad || bad_last)) { if (lane == 0) flag_err(err, -4, 15); return; }
     base = readlane(d1, 63);
     if (lane == 0) dir_bmax[t.dir_base + blk] = 15ull;  // "no bound" until (unless) stage B learns the block's norms
+    if (docs_out != nullptr && t.out_base >= 0) {  // wave-uniform
+      const int64_t o = t.out_base + 128 * (int64_t)blk + 2 * lane;
+      __builtin_nontemporal_store(d0, docs_out + o);
+      __builtin_nontemporal_store(d1, docs_out + o + 1);
+      __builtin_nontemporal_store((int32_t)bp.f0, freqs_out + o);
+      __builtin_nontemporal_store((int32_t)bp.f1, freqs_out + o + 1);
+    }
   }
 }
 

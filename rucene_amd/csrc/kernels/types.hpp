@@ -81,6 +81,8 @@ struct PrepTerm {
   int32_t n_levels;    // 1 + floor(log8(trim(df) / 128)), capped at 10
   int32_t df;
   uint32_t bs_rows;    // rows reserved for this term in the block store
+  int64_t out_base;    // >= 0: a decode is waiting for this term — k_prepare_blocks, which unpacks every block once anyway (to
+                       // validate it), also leaves the postings at docs_out / freqs_out + out_base; -1: nobody is
 };
 
 // One phrase clause's position-stream pointers (parallel to the DevTerm array of a phrase launch).

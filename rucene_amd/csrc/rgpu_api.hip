@@ -324,13 +324,22 @@ static int32_t validate_state(const rgpu_segment* seg, const rgpu_term_state& st
 // Stage A of term preparation (kernels/prepare.hpp) for every not-yet-seen term with df >= 2 (ctx mutex held by the caller):
 // block directory, aligned block store, decoded tail — what a decode needs. `with_norms` adds stage B (posting-order norms +
 // block-max frontier words: what scoring needs) for every named term that lacks it.
-static int32_t prepare_terms_attempt(rgpu_segment* seg, const rgpu_term_state* const* sts, size_t n, bool wide);
+// A materialising decode that is waiting for (some of) the terms: term i of the call goes to docs / freqs + out_base[i];
+// fused[i] = 1 on return for the terms whose postings the preparation itself wrote there (first occurrences of terms that
+// were not prepared before)
+struct DecodeSink {
+  const int64_t* out_base;
+  int32_t *docs, *freqs;
+  std::vector<uint8_t>* fused;
+};
+static int32_t prepare_terms_attempt(rgpu_segment* seg, const rgpu_term_state* const* sts, size_t n, bool wide, const DecodeSink* sink);
 static int32_t prepare_norms_locked(rgpu_segment* seg, const rgpu_term_state* const* sts, size_t n);
 // -101 from the device: a term holds EF / BITSET doc blocks whose re-packed deltas need more block-store rows than its
 // file bytes suggest — plan the same call again with worst-case rows (64 per block). Nothing was committed.
-static int32_t prepare_terms_locked(rgpu_segment* seg, const rgpu_term_state* const* sts, size_t n, bool with_norms = true) {
-  int32_t rc = prepare_terms_attempt(seg, sts, n, false);
-  if (rc == -101) rc = prepare_terms_attempt(seg, sts, n, true);
+static int32_t prepare_terms_locked(rgpu_segment* seg, const rgpu_term_state* const* sts, size_t n, bool with_norms = true,
+                                    const DecodeSink* sink = nullptr) {
+  int32_t rc = prepare_terms_attempt(seg, sts, n, false, sink);
+  if (rc == -101) rc = prepare_terms_attempt(seg, sts, n, true, sink);
   if (rc == -101) rc = fail(RGPU_ERR_CORRUPT_INDEX, "corrupt block framing in .doc (prepare.hpp check #12)");
   if (rc == RGPU_OK && with_norms) rc = prepare_norms_locked(seg, sts, n);
   return rc;
@@ -346,9 +355,10 @@ static void prep_items(const std::vector<PrepTerm>& work, std::vector<int64_t>* 
   }
   (*item_prefix)[work.size()] = *n_items;
 }
-static int32_t prepare_terms_attempt(rgpu_segment* seg, const rgpu_term_state* const* sts, size_t n, bool wide) {
+static int32_t prepare_terms_attempt(rgpu_segment* seg, const rgpu_term_state* const* sts, size_t n, bool wide, const DecodeSink* sink) {
   rgpu_ctx* c = seg->ctx;
   std::vector<PrepTerm> work;
+  if (sink) sink->fused->assign(n, 0);
   size_t need_slots = seg->dir_used;
   const size_t batch_bs = (seg->bstore_used + 15) & ~size_t(15);  // this call's rows form one dense region from here
   uint64_t cap_rows = 0;
@@ -388,6 +398,8 @@ static int32_t prepare_terms_attempt(rgpu_segment* seg, const rgpu_term_state* c
     if (rows > 0xffffffffull) return fail(RGPU_ERR_UNSUPPORTED, "a single term's postings exceed 64 GiB");
     p.bs_base = (uint64_t)batch_bs;  // dir_row counts from the call's first row for every one of its terms
     p.bs_rows = (uint32_t)rows;
+    p.out_base = sink ? sink->out_base[i] : -1;
+    if (sink) (*sink->fused)[i] = 1;
     cap_rows += rows;
     need_slots += (size_t)p.nblocks + 1;
     if (need_slots > 0xfffffff0ull) return fail(RGPU_ERR_UNSUPPORTED, "block directory exceeds 2^32 slots");
@@ -466,7 +478,7 @@ static int32_t prepare_terms_attempt(rgpu_segment* seg, const rgpu_term_state* c
     auto go = [&](auto kern) {
       hipLaunchKernelGGL(kern, dim3(item_grid), dim3(PREP_THREADS), 0, c->stream, seg->d_doc, d_work, d_items, (int)work.size(), n_items,
                          seg->dir_last.p, seg->dir_off.p, seg->dir_row.p, seg->dir_hdr.p, seg->bstore.p, seg->dir_bmax.p, seg->has_freqs ? 1 : 0,
-                         seg->max_doc, c->d_err);
+                         seg->max_doc, c->d_err, sink ? sink->docs : (int32_t*)nullptr, sink ? sink->freqs : (int32_t*)nullptr);
     };
     if (legacy) go(k_prepare_blocks<true>); else go(k_prepare_blocks<false>);
   }
@@ -479,6 +491,7 @@ static int32_t prepare_terms_attempt(rgpu_segment* seg, const rgpu_term_state* c
   const int err = err4[0];
   if (err == -101) return -101;  // see prepare_terms_locked
   if (err != 0) {
+    if (sink) sink->fused->assign(n, 0);
     return fail(err, err == RGPU_ERR_UNSUPPORTED ? std::string("FULL-encoded doc block (unimplemented in Rucene itself), or an EF / BITSET block in a legacy (.doc version 0) file")
                                                  : "corrupt skip data or block framing in .doc (prepare.hpp check #" + std::to_string(err4[1]) + ")");
   }
@@ -855,42 +868,59 @@ static int32_t decode_terms_impl(rgpu_segment* seg, const rgpu_term_state* terms
                                  int32_t* freqs_dev, hipStream_t stream, int64_t* total_out) {
   rgpu_ctx* c = seg->ctx;
   std::vector<const rgpu_term_state*> ptrs((size_t)n_terms);
-  for (int64_t i = 0; i < n_terms; ++i) ptrs[(size_t)i] = &terms[i];
-  int32_t rc = prepare_terms_locked(seg, ptrs.data(), ptrs.size(), false);  // a decode needs no norms: stage A only
+  std::vector<int64_t> out_of((size_t)n_terms + 1);
+  int64_t out = 0;
+  for (int64_t i = 0; i < n_terms; ++i) {
+    ptrs[(size_t)i] = &terms[i];
+    if (terms[i].doc_freq < 0) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "negative doc_freq");
+    out_of[(size_t)i] = out;
+    out += terms[i].doc_freq;
+  }
+  out_of[(size_t)n_terms] = out;
+  if (total_out) *total_out = out;
+  // A decode needs no norms: stage A only. Terms met for the first time are unpacked by the preparation anyway (every block
+  // is validated once): it writes their postings straight to the caller's arrays; k_decode_terms serves the rest.
+  std::vector<uint8_t> fused;
+  const DecodeSink sink{out_of.data(), docs_dev, freqs_dev, &fused};
+  int32_t rc = prepare_terms_locked(seg, ptrs.data(), ptrs.size(), false, &sink);
   if (rc != RGPU_OK) return rc;
+  std::vector<int64_t> rest;
+  for (int64_t i = 0; i < n_terms; ++i)
+    if (terms[i].doc_freq > 0 && !(i < (int64_t)fused.size() && fused[(size_t)i])) rest.push_back(i);
+  if (rest.empty()) return RGPU_OK;
+  const int64_t nr = (int64_t)rest.size();
   HIP_TRY(scratch_take(c));  // callers synchronize the stream before they return
   Stager st(c);
-  const size_t o_terms = st.add((size_t)n_terms * sizeof(DevTerm));
-  const size_t o_items = st.add((size_t)(n_terms + 1) * 8);
-  const size_t o_out = st.add((size_t)(n_terms + 1) * 8);
+  const size_t o_terms = st.add((size_t)nr * sizeof(DevTerm));
+  const size_t o_items = st.add((size_t)(nr + 1) * 8);
+  const size_t o_out = st.add((size_t)(nr + 1) * 8);
   HIP_TRY(c->S->h_stage.reserve(st.used));
   HIP_TRY(c->S->d_stage.reserve(st.used, 0, c->stream));
   DevTerm* ht = reinterpret_cast<DevTerm*>(c->S->h_stage.p + o_terms);
   int64_t* hitems = reinterpret_cast<int64_t*>(c->S->h_stage.p + o_items);
   int64_t* hout = reinterpret_cast<int64_t*>(c->S->h_stage.p + o_out);
-  int64_t items = 0, out = 0;
+  int64_t items = 0, postings = 0;
   const int dec_blocks_per_item = 16;
-  for (int64_t i = 0; i < n_terms; ++i) {
-    rc = make_dev_term(seg, terms[i], 0.f, 0, &ht[i], false);
+  for (int64_t j = 0; j < nr; ++j) {
+    const int64_t i = rest[(size_t)j];
+    rc = make_dev_term(seg, terms[i], 0.f, 0, &ht[j], false);
     if (rc != RGPU_OK) return rc;
-    hitems[i] = items;
-    hout[i] = out;
-    if (ht[i].df > 0) items += ht[i].nblocks == 0 ? 1 : (ht[i].nblocks + dec_blocks_per_item - 1) / dec_blocks_per_item;
-    out += terms[i].doc_freq;
+    hitems[j] = items;
+    hout[j] = out_of[(size_t)i];
+    items += ht[j].nblocks == 0 ? 1 : (ht[j].nblocks + dec_blocks_per_item - 1) / dec_blocks_per_item;
+    postings += terms[i].doc_freq;
   }
-  hitems[n_terms] = items;
-  hout[n_terms] = out;
-  if (total_out) *total_out = out;
-  if (items == 0) return RGPU_OK;
+  hitems[nr] = items;
+  hout[nr] = out;
   HIP_TRY(hipMemcpyAsync(c->S->d_stage.p, c->S->h_stage.p, st.used, hipMemcpyHostToDevice, stream));
   const unsigned grid = (unsigned)((items + WG_WAVES - 1) / WG_WAVES);
   {
-    TimedLaunch tl(c, stream, "k_decode_terms", out);
+    TimedLaunch tl(c, stream, "k_decode_terms", postings);
     auto args = [&](auto kern) {
       hipLaunchKernelGGL(kern, dim3(grid), dim3(WG_THREADS), 0, stream, seg_view(seg),
                          reinterpret_cast<const DevTerm*>(c->S->d_stage.p + o_terms),
                          reinterpret_cast<const int64_t*>(c->S->d_stage.p + o_items),
-                         reinterpret_cast<const int64_t*>(c->S->d_stage.p + o_out), (int)n_terms, items, dec_blocks_per_item, docs_dev,
+                         reinterpret_cast<const int64_t*>(c->S->d_stage.p + o_out), (int)nr, items, dec_blocks_per_item, docs_dev,
                          freqs_dev);
     };
     if (seg->version >= 1) args(k_decode_terms<false>); else args(k_decode_terms<true>);

@@ -290,9 +290,10 @@ def test_error_codes(ctx):
     with pytest.raises(rucene_amd.RgpuError) as e:
         g.search_batch(qs, ts, 10)  # unknown sim_table handle
     assert e.value.status == -2  # IllegalArgument
+    ts[0]["sim_table"] = 0
     with pytest.raises(rucene_amd.RgpuError) as e:
-        g.search_batch(qs, ts, 1000)
-    assert e.value.status == -5  # k > RGPU_MAX_K -> UnsupportedOperation
+        g.search_batch(qs, ts, 1025)
+    assert e.value.status == -5  # k > RGPU_MAX_K (1024) -> UnsupportedOperation
     # corrupt skip pointer -> CorruptIndex from the skip-decode kernel
     corrupt = seg.doc_bytes.copy()
     st = seg.terms[0]
