@@ -1312,13 +1312,14 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
   if (k <= 0 || k > RGPU_MAX_K) return fail(k <= 0 ? RGPU_ERR_ILLEGAL_ARGUMENT : RGPU_ERR_UNSUPPORTED, "k must be in 1..RGPU_MAX_K");
   c->pass = rgpu_ctx::Pass{};
   if (k <= RGPU_PASS_K) return search_pass(seg, queries, n_queries, terms, n_terms_total, k, k, hits_dev, totals_dev, stream);
-  HIP_TRY(c->d_ceil.reserve((size_t)n_queries, 0, stream));
+  HIP_TRY(c->d_ceil.reserve((size_t)n_queries * 2, 0, stream));  // two sets, alternating: a pass reads the previous pass's, writes its own
   int32_t rc = RGPU_OK;
-  for (int32_t col0 = 0; col0 < k && rc == RGPU_OK; col0 += RGPU_PASS_K) {
+  int flip = 0;
+  for (int32_t col0 = 0; col0 < k && rc == RGPU_OK; col0 += RGPU_PASS_K, flip ^= 1) {
     c->pass.stride = k;
     c->pass.col0 = col0;
-    c->pass.ceil_in = col0 == 0 ? nullptr : c->d_ceil.p;
-    c->pass.ceil_out = c->d_ceil.p;
+    c->pass.ceil_in = col0 == 0 ? nullptr : c->d_ceil.p + (size_t)(flip ^ 1) * (size_t)n_queries;
+    c->pass.ceil_out = c->d_ceil.p + (size_t)flip * (size_t)n_queries;
     rc = search_pass(seg, queries, n_queries, terms, n_terms_total, std::min<int32_t>(RGPU_PASS_K, k - col0), k, hits_dev, totals_dev, stream);
   }
   c->pass = rgpu_ctx::Pass{};
