@@ -70,7 +70,11 @@ typedef struct rgpu_config {
   int32_t req_opt_rule;         /* MUST + SHOULD trees: 0 = the reference's ReqOptScorer, skipping rule included (default: exact
                                    scores, a sequential pass per query); -1 = always add the optional sums (faster, scores >= the
                                    reference's) */
-  int32_t reserved[6];          /* must be zero */
+  int32_t or_bitmaps;           /* doc bitmaps for dense terms + k_or_lazy for the >= 10-clause disjunctions that name one
+                                   (kernels/search_or_lazy.hpp): 0 = terms holding >= 1 doc in 64 (default), n > 0 = >= 1 doc in n,
+                                   -1 = off (k_or_wide walks every clause). A bitmap costs max_doc / 4 + doc_freq bytes of HBM */
+  int32_t or_lazy_cells;        /* accumulator cells (touched docs) per window of k_or_lazy (0 = default 512; 512..4096) */
+  int32_t reserved[4];          /* must be zero */
 } rgpu_config;
 
 /* blocktree/mod.rs:33-59 BlockTermState, as filled by posting_reader.rs:264-306 lucene50_decode_term.
@@ -187,6 +191,8 @@ typedef struct rgpu_segment_footprint {
   int64_t block_store_bytes;     /* prepared terms: 16-byte aligned payload rows + decoded tails */
   int64_t posting_norms_bytes;   /* prepared terms: 1 byte per posting */
   int64_t prepared_terms;        /* how many distinct terms are prepared */
+  int64_t doc_bitmap_bytes;      /* doc bitmaps of the dense terms (rgpu_config.or_bitmaps): words + ranks + freq bytes */
+  int64_t doc_bitmap_terms;
 } rgpu_segment_footprint;
 int32_t rgpu_segment_get_footprint(rgpu_segment* seg, rgpu_segment_footprint* out);
 

@@ -71,13 +71,13 @@ class _Config(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("blocks_per_item", C.c_int32), ("and_blocks_per_item", C.c_int32),
                 ("profile_kernels", C.c_int32), ("or_window_docs", C.c_int32), ("or_dense_clauses", C.c_int32),
                 ("raw_norms", C.c_int32), ("or_wide", C.c_int32), ("or_wide_window_docs", C.c_int32),
-                ("req_opt_rule", C.c_int32), ("reserved", C.c_int32 * 6)]
+                ("req_opt_rule", C.c_int32), ("or_bitmaps", C.c_int32), ("or_lazy_cells", C.c_int32), ("reserved", C.c_int32 * 4)]
 
 
 SEARCH_COUNTERS_DTYPE = np.dtype([("op", "<i4"), ("reserved", "<i4"), ("postings_covered", "<i8"), ("postings_decoded", "<i8"),
                                   ("blocks_decoded", "<i8"), ("touched_bytes", "<i8")], align=True)
 FOOTPRINT_DTYPE = np.dtype([(n, "<i8") for n in ("doc_file_bytes", "norms_bytes", "live_docs_bytes", "positions_file_bytes", "directory_bytes",
-                                                 "block_store_bytes", "posting_norms_bytes", "prepared_terms")], align=True)
+                                                 "block_store_bytes", "posting_norms_bytes", "prepared_terms", "doc_bitmap_bytes", "doc_bitmap_terms")], align=True)
 PLAN_STATS_DTYPE = np.dtype([("max_doc", "<i8"), ("doc_count", "<i8"), ("sum_total_term_freq", "<i8"), ("k1", "<f4"), ("b", "<f4")], align=True)
 assert SEARCH_COUNTERS_DTYPE.itemsize == 40 and PLAN_STATS_DTYPE.itemsize == 32
 
@@ -352,7 +352,7 @@ class Context:
     """rgpu_ctx: one per process per GPU."""
 
     def __init__(self, device=0, profile_kernels=False, blocks_per_item=0, and_blocks_per_item=0, or_window_docs=0,
-                 raw_norms=False, or_dense_clauses=0, or_wide=0, or_wide_window_docs=0, req_opt_rule=0):
+                 raw_norms=False, or_dense_clauses=0, or_wide=0, or_wide_window_docs=0, req_opt_rule=0, or_bitmaps=0, or_lazy_cells=0):
         cfg = _Config()
         cfg.abi_version = ABI_VERSION
         cfg.blocks_per_item = blocks_per_item
@@ -364,6 +364,8 @@ class Context:
         cfg.or_wide = or_wide
         cfg.or_wide_window_docs = or_wide_window_docs
         cfg.req_opt_rule = req_opt_rule
+        cfg.or_bitmaps = or_bitmaps
+        cfg.or_lazy_cells = or_lazy_cells
         h = C.c_void_p()
         _check(lib().rgpu_init(device, C.byref(cfg), C.byref(h)))
         self._h = h

@@ -1,0 +1,77 @@
+// Doc bitmaps of a segment's densest terms — the prepared structure behind k_or_lazy (search_or_lazy.hpp).
+//
+// A term that holds at least one doc in `rgpu_config.or_bitmap_density` (default 64) gets, once, next to its block
+// directory:
+//   words[2 * (ceil(max_doc / 32) + pad)]   pairs {any, hi} per 32 docs: bit d & 31 of any = "the term's list holds doc d", of
+//                                     hi = "... and its posting's freq / (freq + cache[norm]) is >= BITMAP_HI_CUT" under the
+//                                     similarity table the bitmap was built with — a one-bit sketch of the posting's score:
+//                                     a posting outside `hi` scores below weight * (k1 + 1) * BITMAP_HI_CUT whatever the weight
+//                                     (zero padded: a window kernel reads whole windows past max_doc without a bounds test)
+//   ranks[same length]                postings of the list before word w (exclusive prefix popcount): the posting index of
+//                                     doc d is ranks[d >> 5] + popcount(words[d >> 5] below bit d & 31)
+//   freqs[doc_freq + pad]             min(freq, 255) by posting index
+//   ovf[2 * n_ovf]                    {posting index, freq} of the postings whose freq is >= 255 (Rucene clamps term freqs
+//                                     to 10 when it writes an index; a Lucene-written one may hold such a posting)
+// (the sketch only sharpens a bound: a clause that names the term under another similarity table treats every posting as hi)
+// i.e. a random-access view of (doc -> freq) for the lists that hold ~90 % of a Zipfian disjunction's postings: "is doc d
+// in the list" is one bit, and a whole window's membership is one coalesced read of 4 bytes per 32 docs.
+// The reference has no such structure (its DisjunctionSumScorer walks every sub-scorer posting by posting,
+// search/scorer/disjunction_scorer.rs:24-104); results are unchanged by it — see search_or_lazy.hpp for the argument.
+#pragma once
+#include "wave.hpp"
+
+namespace rgpu {
+
+constexpr int BITMAP_OVF_CAP = 4096;   // more postings with freq >= 255 than this: the term gets no bitmap
+constexpr float BITMAP_HI_CUT = 0.72f;  // ~ the top fifth of a BM25 list (k1 1.2, b 0.75): freq >= 3 in a doc of average length
+constexpr int BITMAP_PAD_WORDS = 2048;  // zero words behind the last real one (>= the widest window of k_or_lazy in words)
+
+struct BitmapStats {
+  unsigned int n_ovf;     // postings with freq >= 255
+  unsigned int max_freq;  // the list's largest freq
+  unsigned int bad_docs;  // doc ids outside [0, max_doc): a corrupt list (FullBlocks are validated at prepare time: 0)
+  unsigned int pad;
+};
+
+// one thread per posting of the decoded list. norms: the segment's norm bytes as the kernels see them (ranks or raw bytes);
+// cache: the similarity table's 256 norm-cache floats; rank_to_norm: null when the segment holds raw norm bytes
+__global__ __launch_bounds__(256) void k_bitmap_fill(const int32_t* __restrict__ docs, const int32_t* __restrict__ freqs, int64_t df,
+                                                     int32_t max_doc, const uint8_t* __restrict__ norms, const float* __restrict__ cache,
+                                                     const uint8_t* __restrict__ rank_to_norm, uint2* __restrict__ words,
+                                                     uint8_t* __restrict__ freq8, uint32_t* __restrict__ ovf, BitmapStats* __restrict__ stats) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool ok = i < df;
+  const int32_t d = ok ? docs[i] : 0;
+  const uint32_t f = ok ? (uint32_t)freqs[i] : 0u;
+  const bool in = ok && (uint32_t)d < (uint32_t)max_doc;
+  if (in) {
+    atomicOr(&words[d >> 5].x, 1u << (d & 31));
+    bool hi = true;  // no norms: every posting scores weight * (k1 + 1) * freq / (freq + k1) — no sketch, everything is "hi"
+    if (norms != nullptr) {
+      const uint32_t nb = norms[d];
+      const float cv = cache[rank_to_norm != nullptr ? rank_to_norm[nb] : nb];
+      const float qf = (float)(int32_t)f;
+      hi = !(qf / (qf + cv) < BITMAP_HI_CUT);  // (a NaN — 0 / 0 — counts as hi: never under-estimate)
+    }
+    if (hi) atomicOr(&words[d >> 5].y, 1u << (d & 31));
+  }
+  if (ok) freq8[i] = (uint8_t)(f < 255u ? f : 255u);
+  if (ok && f >= 255u) {
+    const unsigned int at = atomicAdd(&stats->n_ovf, 1u);
+    if (at < (unsigned)BITMAP_OVF_CAP) { ovf[2 * at] = (uint32_t)i; ovf[2 * at + 1] = f; }
+  }
+  // one atomic per wavefront, not per posting (same-address atomics serialise)
+  const uint32_t fmax = wave_reduce_max_u32(f);
+  const uint64_t bad = __ballot(ok && !in);
+  if (lane_id() == 0) {
+    atomicMax(&stats->max_freq, fmax);
+    if (bad) atomicAdd(&stats->bad_docs, (unsigned)__popcll(bad));
+  }
+}
+
+__global__ __launch_bounds__(256) void k_bitmap_popc(const uint2* __restrict__ words, int64_t n_words, uint32_t* __restrict__ ranks) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_words) ranks[i] = (uint32_t)__popc(words[i].x);
+}
+
+}  // namespace rgpu

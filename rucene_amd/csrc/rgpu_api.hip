@@ -24,6 +24,7 @@
 #include "kernels/search_and.hpp"
 #include "kernels/search_or.hpp"
 #include "kernels/search_or_wide.hpp"
+#include "kernels/search_or_lazy.hpp"
 #include "host/flat_fp_map.hpp"
 #include "kernels/search_phrase.hpp"
 #include "kernels/search_term.hpp"
@@ -130,6 +131,8 @@ struct rgpu_ctx {
   int64_t or_wide_redone = 0;         // queries k_or_wide handed back to the f32 kernel (fixed-point floor); rgpu_kernel_stats reports it as "or_wide_redo_queries"
   std::vector<float> sim_k1;          // per table: k1
   std::vector<uint8_t> sim_nonneg;    // per table: k1 and every cache[] entry finite and >= 0 (a score is then within [0, weight * (k1 + 1)])
+  std::vector<float> sim_cache_min;   // per table: the smallest cache[] entry (freq / (freq + cache) is largest there: k_or_lazy's score bounds)
+  int64_t or_lazy_evals = 0, or_lazy_only = 0;  // k_or_lazy: candidates evaluated / of them docs held by lazy lists only (last launch)
   // Per-call scratch, in rotating slots: a search call only enqueues work (staging copy + kernels) on its stream
   // and marks its slot with an event; the slot is waited for when its turn comes again, so the host prepares batch
   // i+1 while the GPU runs batch i and a caller synchronizes the stream once, when it wants the results.
@@ -156,6 +159,8 @@ struct rgpu_ctx {
   int64_t last_counted_loose = 0;        // postings outside FullBlocks (prepared tails, singletons) of the (lead) clauses
   int64_t last_counted_postings = 0;     // sum of doc_freq over the launch's clauses
   int64_t last_counted_algo_bytes = 0;   // wide OR: encoded bytes of every clause + 1 B norm per posting
+  int64_t last_counted_or_decoded = -1;  // k_or_lazy: postings of the walked clauses (-1: the launch walked every clause)
+  int64_t last_counted_or_bytes = 0;     // k_or_lazy: encoded bytes + norms of the walked clauses + the lazy clauses' bitmap words
   // profiling
   std::vector<StatSlot> stats;
   std::vector<PendingEvent> pending;
@@ -164,6 +169,8 @@ struct rgpu_ctx {
 };
 
 struct TermInfo { uint32_t dir_base; int32_t nblocks; int32_t df; uint64_t pn_base; uint64_t bs_base; bool norms; };
+// a term's doc bitmap (kernels/doc_bitmap.hpp): one allocation [words | ranks | ovf | stats | freqs]
+struct BitmapInfo { uint2* words; uint32_t* ranks; uint8_t* freqs; uint32_t* ovf; int32_t n_ovf; int32_t max_freq; int32_t df; int32_t sim_table; bool usable; };
 
 // doc_start_fp -> TermInfo of the prepared terms (host/flat_fp_map.hpp: two look-ups per clause per batch)
 using PreparedMap = rucene::FlatFpMap<TermInfo>;
@@ -193,6 +200,9 @@ struct rgpu_segment {
   DevVec<uint8_t> pnorm;  // posting-order norms of every prepared term's FullBlocks and tail
   size_t pnorm_used = 0;
   PreparedMap prepared;
+  rucene::FlatFpMap<BitmapInfo> bitmaps;  // doc_start_fp -> the term's doc bitmap (terms holding >= 1 doc in cfg.or_bitmaps)
+  std::vector<void*> bitmap_allocs;
+  size_t bitmap_bytes = 0;
   DevVec<uint8_t> prep_scratch;  // k_skip_dir's chunk aggregates + ticket, the prefix sum's tile sums
 };
 
@@ -702,8 +712,9 @@ extern "C" int32_t rgpu_last_search_counters(rgpu_ctx* c, rgpu_search_counters* 
   std::memset(out, 0, sizeof *out);
   out->op = c->last_counted_op;
   out->postings_covered = c->last_counted_postings;
-  if (c->last_counted_op == RGPU_OP_OR) {  // every posting decoded, blocks that straddle windows more than once
-    out->postings_decoded = c->last_counted_postings;
+  if (c->last_counted_op == RGPU_OP_OR) {  // k_or_wide: every posting decoded (blocks that straddle windows more than once)
+    out->postings_decoded = c->last_counted_or_decoded >= 0 ? c->last_counted_or_decoded : c->last_counted_postings;
+    if (c->last_counted_or_decoded >= 0) out->touched_bytes = c->last_counted_or_bytes;  // k_or_lazy: walked clauses + bitmap words
     return RGPU_OK;
   }
   if (!c->last_counted || c->last_counted_queries <= 0) return RGPU_OK;
@@ -745,6 +756,9 @@ extern "C" int32_t rgpu_sim_table_upload(rgpu_ctx* c, const float cache[256], fl
   for (int i = 0; i < 256 && nonneg; ++i) nonneg = cache[i] >= 0.0f && cache[i] <= 3.0e38f;
   c->sim_k1.push_back(k1);
   c->sim_nonneg.push_back(nonneg ? 1 : 0);
+  float cmin = cache[0];
+  for (int i = 1; i < 256; ++i) cmin = std::min(cmin, cache[i]);
+  c->sim_cache_min.push_back(cmin);
   return c->n_sim_tables++;
 }
 
@@ -821,6 +835,7 @@ extern "C" void rgpu_segment_free(rgpu_segment* s) {
   if (s->d_live) (void)hipFree(s->d_live);
   if (s->d_pos) (void)hipFree(s->d_pos);
   s->dir_last.release(); s->dir_off.release(); s->dir_row.release(); s->dir_hdr.release(); s->dir_bmax.release(); s->dir_pos.release(); s->pnorm.release(); s->bstore.release(); s->prep_scratch.release();
+  for (void* b : s->bitmap_allocs) (void)hipFree(b);
   delete s;
 }
 
@@ -839,6 +854,8 @@ extern "C" int32_t rgpu_segment_get_footprint(rgpu_segment* seg, rgpu_segment_fo
   out->block_store_bytes = (int64_t)seg->bstore_used;
   out->posting_norms_bytes = seg->d_norms ? (int64_t)seg->pnorm_used : 0;
   out->prepared_terms = (int64_t)seg->prepared.size();
+  out->doc_bitmap_bytes = (int64_t)seg->bitmap_bytes;
+  out->doc_bitmap_terms = (int64_t)seg->bitmaps.size();
   return RGPU_OK;
 }
 
@@ -851,6 +868,10 @@ extern "C" int32_t rgpu_segment_release_prepared_terms(rgpu_segment* seg) {
   for (auto& sc : c->scr) sc.busy = false;
   seg->prepared.clear();
   seg->dir_used = seg->bstore_used = seg->pnorm_used = 0;  // the arrays keep their capacity and are refilled from the start
+  for (void* b : seg->bitmap_allocs) (void)hipFree(b);
+  seg->bitmap_allocs.clear();
+  seg->bitmaps.clear();
+  seg->bitmap_bytes = 0;
   return RGPU_OK;
 }
 
@@ -998,11 +1019,86 @@ extern "C" int32_t rgpu_advance_batch(rgpu_segment* seg, const rgpu_term_state* 
   return RGPU_OK;
 }
 
+
+// ---- doc bitmaps (kernels/doc_bitmap.hpp) --------------------------------------------------------------------------
+static int32_t decode_terms_impl(rgpu_segment* seg, const rgpu_term_state* terms, int64_t n_terms, int32_t* docs_dev,
+                                 int32_t* freqs_dev, hipStream_t stream, int64_t* total_out);
+// `or_bitmaps`: a term holding at least one doc in this many gets a bitmap (0 = default 64, < 0: none)
+static int64_t bitmap_min_df(const rgpu_segment* seg) {
+  const int32_t d = seg->ctx->cfg.or_bitmaps;
+  if (d < 0) return INT64_MAX;
+  const int64_t den = d == 0 ? 64 : d;
+  return std::max<int64_t>(1024, ((int64_t)seg->max_doc + den - 1) / den);
+}
+// builds the bitmaps of the given terms that lack one (ctx mutex held; ends synchronised). One decode of the list into scratch
+// (the context's run buffer), one thread per posting, a prefix popcount: a one-off per term, ~1 ms for a 2 M-posting list.
+static int32_t ensure_bitmaps_locked(rgpu_segment* seg, const rgpu_term_state* const* sts, const int32_t* sim_tables, size_t n) {
+  rgpu_ctx* c = seg->ctx;
+  const int64_t n_words = ((int64_t)seg->max_doc + 31) / 32;
+  const size_t nw_pad = ((size_t)n_words + 1 + BITMAP_PAD_WORDS + 63) & ~size_t(63);
+  for (size_t i = 0; i < n; ++i) {
+    const rgpu_term_state& st = *sts[i];
+    if (st.doc_freq < 2 || seg->bitmaps.find(st.doc_start_fp)) continue;
+    const size_t df = (size_t)st.doc_freq;
+    const size_t o_ranks = nw_pad * 8, o_ovf = o_ranks + nw_pad * 4, o_stats = o_ovf + (size_t)BITMAP_OVF_CAP * 8;
+    const size_t o_freqs = o_stats + 64, total = o_freqs + ((df + 127) & ~size_t(63));
+    uint8_t* block = nullptr;
+    HIP_TRY(hipMalloc(&block, total));
+    seg->bitmap_allocs.push_back(block);
+    seg->bitmap_bytes += total;
+    BitmapInfo info{};
+    info.words = reinterpret_cast<uint2*>(block);
+    info.sim_table = sim_tables[i];
+    info.ranks = reinterpret_cast<uint32_t*>(block + o_ranks);
+    info.ovf = reinterpret_cast<uint32_t*>(block + o_ovf);
+    info.freqs = block + o_freqs;
+    info.df = st.doc_freq;
+    BitmapStats* d_stats = reinterpret_cast<BitmapStats*>(block + o_stats);
+    HIP_TRY(hipMemsetAsync(block, 0, total, c->stream));
+    static_assert(sizeof(ScoredPosting) == 8, "the run buffer doubles as {docs, freqs} scratch");
+    HIP_TRY(c->d_runs.reserve(df + 64, 0, c->stream));
+    int32_t* docs = reinterpret_cast<int32_t*>(c->d_runs.p);
+    int32_t* freqs = docs + df;
+    int32_t rc = decode_terms_impl(seg, &st, 1, docs, freqs, c->stream, nullptr);
+    if (rc != RGPU_OK) return rc;
+    {
+      TimedLaunch tl(c, c->stream, "k_bitmap_build", (int64_t)df);
+      hipLaunchKernelGGL(k_bitmap_fill, dim3((unsigned)((df + 255) / 256)), dim3(256), 0, c->stream, docs, freqs, (int64_t)df, seg->max_doc,
+                         (const uint8_t*)seg->d_norms, (const float*)(c->sim_tables.p + (size_t)sim_tables[i] * 257),
+                         seg->n_norm_ranks > 0 ? (const uint8_t*)seg->d_rank_to_norm : (const uint8_t*)nullptr, info.words, info.freqs, info.ovf, d_stats);
+      const int64_t n_scan = n_words + 1;  // ranks[n_words] = the list's size
+      hipLaunchKernelGGL(k_bitmap_popc, dim3((unsigned)((n_scan + 255) / 256)), dim3(256), 0, c->stream, info.words, n_scan, info.ranks);
+      const int64_t n_tiles = (n_scan + SCAN_TILE - 1) / SCAN_TILE;
+      HIP_TRY(seg->prep_scratch.reserve(64 + (size_t)n_tiles * 8 + 64, 0, c->stream));
+      unsigned long long* d_total = reinterpret_cast<unsigned long long*>(seg->prep_scratch.p);
+      unsigned long long* d_tiles = d_total + 8;
+      hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)n_tiles), dim3(PREP_THREADS), 0, c->stream, info.ranks, n_scan, d_tiles);
+      hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(PREP_THREADS), 0, c->stream, d_tiles, n_tiles, 0xfffffff0ull, d_total, c->d_err);
+      hipLaunchKernelGGL(k_scan_down, dim3((unsigned)n_tiles), dim3(PREP_THREADS), 0, c->stream, info.ranks, n_scan, d_tiles);
+    }
+    BitmapStats hs{};
+    uint32_t listed = 0;
+    HIP_TRY(hipMemcpyAsync(&hs, d_stats, sizeof hs, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&listed, info.ranks + n_words, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipGetLastError());
+    info.n_ovf = (int32_t)std::min<unsigned>(hs.n_ovf, (unsigned)BITMAP_OVF_CAP);
+    info.max_freq = (int32_t)std::min<unsigned>(hs.max_freq, 0x7fffffffu);
+    // (a list with a repeated or out-of-range doc id — a corrupt tail — or too many huge freqs simply stays a walked clause)
+    info.usable = hs.n_ovf <= (unsigned)BITMAP_OVF_CAP && hs.bad_docs == 0 && listed == (uint32_t)st.doc_freq && hs.max_freq >= 1;
+    seg->bitmaps.put(st.doc_start_fp, info);
+  }
+  return RGPU_OK;
+}
+
 // ---- search ----------------------------------------------------------------------------------------------------
 namespace {
 struct Group {  // queries of one op, in their original order
   int op = 0;
   bool or_wide = false;         // OR queries of >= 10 clauses: the order-free workgroup-window kernel
+  bool no_lazy = false;         // ... that k_or_lazy already declined (no bitmap clause) or handed back
+  bool after_lazy = false;      // ... following a k_or_lazy launch of the same call (rgpu_last_search_counters adds them up)
+  std::vector<int64_t> term_bytes;  // or_wide: per clause, the encoded bytes of its postings (rgpu_last_search_counters)
   bool req_opt = false;         // MUST + SHOULD trees under the reference's ReqOptScorer rule: conjunction records + sequential scan
   std::vector<int32_t> qmap;    // original query index
   std::vector<DevQuery> queries;
@@ -1151,6 +1247,312 @@ static int32_t search_or_group(rgpu_segment* seg, Group& G, int32_t k, HitOut* h
   return RGPU_OK;
 }
 
+
+static int32_t search_or_wide_group(rgpu_segment* seg, Group& G, int32_t k, HitOut* hits_dev, int64_t* totals_dev, hipStream_t stream);
+
+// OR with >= 10 SHOULD clauses of which at least one has a doc bitmap: k_or_lazy (kernels/search_or_lazy.hpp). The bitmap
+// clauses are not walked at all; the others are decoded and scored once per distinct (term, weight) of the batch by
+// k_score_terms into {doc, score} runs. Queries without a bitmap clause, and queries the kernel hands back, go through k_or_wide.
+static int32_t search_or_lazy_group(rgpu_segment* seg, Group& G, int32_t k, HitOut* hits_dev, int64_t* totals_dev, hipStream_t stream) {
+  rgpu_ctx* c = seg->ctx;
+  const bool wide = k > 64;
+  const bool legacy = seg->version < 1;
+  const int64_t min_df = bitmap_min_df(seg);
+  constexpr int STEPS = 8;
+  constexpr int W = STEPS * LZ_STEP_DOCS;
+  // (at least one cell per 32 docs of a window: between the passes the cells double as the window's candidate words)
+  int C = c->cfg.or_lazy_cells > 0 ? std::min(4096, std::max(W / 32, (c->cfg.or_lazy_cells + 63) / 64 * 64)) : 512;
+  while (lz_lds_bytes(W, C) > 160u * 1024u && C > W / 32) C -= 64;
+
+  Group rest;  // queries without a bitmap clause
+  rest.op = RGPU_OP_OR;
+  rest.or_wide = true;
+  rest.no_lazy = true;
+  auto hand_over = [&](Group& to, int q) {
+    const DevQuery& wq = G.queries[(size_t)q];
+    DevQuery dq = wq;
+    dq.first_term = (int32_t)to.terms.size();
+    for (int i = 0; i < wq.n_terms; ++i) {
+      to.terms.push_back(G.terms[(size_t)(wq.first_term + i)]);
+      if (!G.term_bytes.empty()) to.term_bytes.push_back(G.term_bytes[(size_t)(wq.first_term + i)]);
+      to.postings += G.terms[(size_t)(wq.first_term + i)].df;
+    }
+    to.qmap.push_back(G.qmap[(size_t)q]);
+    to.queries.push_back(dq);
+  };
+  std::vector<LazyQuery> lq;
+  std::vector<LazyRun> run_of;       // per walked clause instance
+  std::vector<DevTerm> uniq;         // the distinct (term, weight, similarity) among them: one run each
+  std::vector<int64_t> uniq_bytes;
+  std::vector<int32_t> uniq_of;      // walked clause instance -> uniq
+  rucene::FlatFpMap<int> uniq_at;    // doc_start_fp -> first uniq entry of that term
+  std::vector<LazyClause> lz;
+  std::vector<int32_t> lq_of;        // lazy query -> index in G
+  std::vector<int32_t> fixed_info;
+  int64_t walked_postings = 0, touched_bytes = 0, all_postings = 0;
+  uniq_at.reserve_more(G.terms.size());
+  for (int q = 0; q < (int)G.queries.size(); ++q) {
+    const DevQuery& wq = G.queries[(size_t)q];
+    // the (up to LZ_MAX_LAZY) densest clauses that have a usable bitmap
+    struct Cand { int i; int32_t df; const BitmapInfo* bm; };
+    Cand cands[RGPU_MAX_QUERY_TERMS];
+    int n_cands = 0;
+    for (int i = 0; i < wq.n_terms; ++i) {
+      const DevTerm& t = G.terms[(size_t)(wq.first_term + i)];
+      if (t.df < min_df) continue;
+      const BitmapInfo* bm = seg->bitmaps.find((int64_t)t.start_fp);
+      if (bm && bm->usable && bm->df == t.df) cands[n_cands++] = Cand{i, t.df, bm};
+    }
+    if (n_cands == 0) { hand_over(rest, q); continue; }
+    std::stable_sort(cands, cands + n_cands, [](const Cand& a, const Cand& b) { return a.df > b.df; });
+    n_cands = std::min(n_cands, LZ_MAX_LAZY);
+    uint32_t lazy_mask = 0;
+    for (int j = 0; j < n_cands; ++j) lazy_mask |= 1u << cands[j].i;
+    // the fixed-point exponent of k_or_wide: over ALL clauses
+    double bound = 0.0;
+    for (int i = 0; i < wq.n_terms; ++i) {
+      const DevTerm& t = G.terms[(size_t)(wq.first_term + i)];
+      bound += (double)t.weight * ((double)c->sim_k1[(size_t)t.sim_table] + 1.0) * 1.000001;
+    }
+    int e = 100;
+    if (bound > 0.0) e = std::min(100, (int)std::floor(std::log2((2147483648.0 - 64.0) / bound)));
+    LazyQuery Q{};
+    Q.first_run = (int32_t)run_of.size();
+    Q.first_lazy = (int32_t)lz.size();
+    Q.e = e;
+    for (int i = 0; i < wq.n_terms; ++i) {
+      const DevTerm& t = G.terms[(size_t)(wq.first_term + i)];
+      all_postings += t.df;
+      if ((lazy_mask >> i) & 1u) continue;
+      int u = -1;
+      if (const int* at = uniq_at.find((int64_t)t.start_fp)) {
+        const DevTerm& o = uniq[(size_t)*at];
+        if (o.df == t.df && o.sim_table == t.sim_table && std::memcmp(&o.weight, &t.weight, 4) == 0 && o.singleton_doc == t.singleton_doc) u = *at;
+      }
+      if (u < 0) {  // (the same term under another boost or similarity in one batch: its own run, not registered)
+        u = (int)uniq.size();
+        DevTerm ut = t;
+        ut.flags &= ~TERM_FLAG_OR_DENSE;
+        uniq.push_back(ut);
+        uniq_bytes.push_back(G.term_bytes.empty() ? 2 * (int64_t)t.df : G.term_bytes[(size_t)(wq.first_term + i)]);
+        if (t.df > 1 && !uniq_at.find((int64_t)t.start_fp)) uniq_at.put((int64_t)t.start_fp, u);
+      }
+      uniq_of.push_back(u);
+      run_of.push_back(LazyRun{0, t.df, 0});
+    }
+    Q.n_runs = (int32_t)run_of.size() - Q.first_run;
+    LazyClause mine[LZ_MAX_LAZY];
+    for (int j = 0; j < n_cands; ++j) {
+      const DevTerm& t = G.terms[(size_t)(wq.first_term + cands[j].i)];
+      LazyClause L{};
+      L.words = cands[j].bm->words; L.ranks = cands[j].bm->ranks; L.freqs = cands[j].bm->freqs; L.ovf = cands[j].bm->ovf;
+      L.n_ovf = cands[j].bm->n_ovf;
+      L.sim_table = t.sim_table;
+      const double k1 = (double)c->sim_k1[(size_t)t.sim_table];
+      L.wk = t.weight * (c->sim_k1[(size_t)t.sim_table] + 1.0f);
+      // no posting of the list scores above wk * fmax / (fmax + the smallest cache entry) (the score grows with the freq and
+      // falls with the cache value; only non-negative tables reach this kernel); + slack for the device's rcp and rounding
+      const double fmax = (double)std::max(1, cands[j].bm->max_freq);
+      const double cmin = std::max(0.0, (double)c->sim_cache_min[(size_t)t.sim_table]);
+      const double ub = (double)t.weight * (k1 + 1.0) * (fmax + cmin > 0.0 ? fmax / (fmax + cmin) : 1.0) * 1.00001;
+      const double ubf = std::ceil(std::ldexp(ub, e)) + 2.0;
+      L.ub = (uint32_t)std::min(2147483647.0, std::max(1.0, ubf));
+      // a posting outside the bitmap's `hi` half scores below wk * BITMAP_HI_CUT — under the table the bitmap was built with
+      const double ub_lo = (double)t.weight * (k1 + 1.0) * (double)BITMAP_HI_CUT * 1.00002;
+      L.ub_lo = cands[j].bm->sim_table == t.sim_table ? std::min(L.ub, (uint32_t)std::min(2147483647.0, std::ceil(std::ldexp(ub_lo, e)) + 2.0)) : L.ub;
+      mine[j] = L;
+      touched_bytes += (int64_t)(((int64_t)seg->max_doc + 7) / 8);
+    }
+    std::stable_sort(mine, mine + n_cands, [](const LazyClause& a, const LazyClause& b) { return a.ub > b.ub; });
+    // the kernel reads "the h largest (ub - ub_lo)" off a prefix sum in this order: if the order does not hold (a clause whose
+    // sketch does not apply next to ones where it does), the query runs without sketches
+    for (int j = 1; j < n_cands; ++j)
+      if (mine[j].ub - mine[j].ub_lo > mine[j - 1].ub - mine[j - 1].ub_lo) { for (int i = 0; i < n_cands; ++i) mine[i].ub_lo = mine[i].ub; break; }
+    uint64_t ub_sum = 0, ub_lo_sum = 0;
+    for (int j = 0; j < n_cands; ++j) { ub_sum += mine[j].ub; ub_lo_sum += mine[j].ub_lo; lz.push_back(mine[j]); }
+    Q.n_lazy = n_cands;
+    Q.ub_sum = (uint32_t)std::min<uint64_t>(ub_sum, 0x7fffffffull);
+    Q.ub_lo_sum = (uint32_t)std::min<uint64_t>(ub_lo_sum, 0x7fffffffull);
+    lq.push_back(Q);
+    lq_of.push_back(q);
+    fixed_info.push_back(e);
+    fixed_info.push_back((int32_t)(wq.n_terms * (int)ORX_FLOOR_PER_CLAUSE));
+  }
+  const int nq = (int)lq.size();
+  if (nq > 0) {
+    HIP_TRY(scratch_take(c));
+    // phase 1 plan (k_score_terms): items = (distinct walked term, chunk of blocks); runs end in OR_RUN_PAD sentinels
+    const int nu = (int)uniq.size();
+    int blocks_per_item = 32;
+    std::vector<int64_t> item_prefix((size_t)nu + 1), run_prefix((size_t)nu + 1);
+    int64_t items1 = 0, run_slots = 0;
+    while (true) {
+      items1 = 0;
+      for (int j = 0; j < nu; ++j) {
+        item_prefix[(size_t)j] = items1;
+        items1 += uniq[(size_t)j].nblocks == 0 ? 1 : (uniq[(size_t)j].nblocks + blocks_per_item - 1) / blocks_per_item;
+      }
+      item_prefix[(size_t)nu] = items1;
+      if (items1 <= 1048576 || blocks_per_item >= (1 << 17)) break;
+      blocks_per_item *= 2;
+    }
+    for (int j = 0; j < nu; ++j) {
+      run_prefix[(size_t)j] = run_slots;
+      run_slots += (int64_t)uniq[(size_t)j].df + OR_RUN_PAD;
+      walked_postings += uniq[(size_t)j].df;
+      touched_bytes += uniq_bytes[(size_t)j] + uniq[(size_t)j].df;
+    }
+    run_prefix[(size_t)nu] = run_slots;
+    for (size_t i = 0; i < run_of.size(); ++i) run_of[i].base = run_prefix[(size_t)uniq_of[i]];
+    touched_bytes += 8 * (int64_t)run_of.size() * 0;  // (the runs themselves are scratch: written and read once, 16 B per walked posting)
+    // phase 2 plan: items = (query, group of windows), one per wavefront
+    const int wpq = std::max(1, (int)(((int64_t)seg->max_doc + W - 1) / W));
+#ifndef RGPU_LZ_TARGET_WAVES
+#define RGPU_LZ_TARGET_WAVES 32768
+#endif
+    int ipq = std::min(wpq, std::max(1, (RGPU_LZ_TARGET_WAVES + nq - 1) / nq));
+    const int wpi = (wpq + ipq - 1) / ipq;
+    ipq = ((wpq + wpi - 1) / wpi + LZ_WAVES - 1) / LZ_WAVES * LZ_WAVES;
+    const int64_t lists = (int64_t)nq * ipq;
+    std::vector<int64_t> merge_prefix((size_t)nq + 1);
+    for (int q = 0; q <= nq; ++q) merge_prefix[(size_t)q] = (int64_t)q * ipq;
+    std::vector<int32_t> qmap((size_t)nq);
+    for (int q = 0; q < nq; ++q) qmap[(size_t)q] = G.qmap[(size_t)lq_of[(size_t)q]];
+    Stager st(c);
+    const size_t o_q = st.add((size_t)nq * sizeof(LazyQuery));
+    const size_t o_r = st.add(std::max<size_t>(1, run_of.size()) * sizeof(LazyRun));
+    const size_t o_t = st.add(std::max<size_t>(1, uniq.size()) * sizeof(DevTerm));
+    const size_t o_ip = st.add((size_t)(nu + 1) * 8);
+    const size_t o_rp = st.add((size_t)(nu + 1) * 8);
+    const size_t o_l = st.add(lz.size() * sizeof(LazyClause));
+    const size_t o_mp = st.add((size_t)(nq + 1) * 8);
+    const size_t o_m = st.add((size_t)nq * 4);
+    const size_t o_fi = st.add((size_t)nq * 8);
+    const size_t o_fl = st.add((size_t)nq * 4);   // low flags (k_merge_items)
+    const size_t o_bl = st.add((size_t)nq * 4);   // bail flags (k_or_lazy)
+    const size_t o_ct = st.add(16 + (size_t)nq * 16);  // (+ per query, variant builds: evaluated docs, lazy-only docs)
+    HIP_TRY(c->S->h_stage.reserve(st.used));
+    HIP_TRY(c->S->d_stage.reserve(st.used, 0, stream));
+    std::memset(c->S->h_stage.p + o_fl, 0, st.used - o_fl);
+    std::memcpy(c->S->h_stage.p + o_q, lq.data(), (size_t)nq * sizeof(LazyQuery));
+    if (!run_of.empty()) std::memcpy(c->S->h_stage.p + o_r, run_of.data(), run_of.size() * sizeof(LazyRun));
+    if (!uniq.empty()) std::memcpy(c->S->h_stage.p + o_t, uniq.data(), uniq.size() * sizeof(DevTerm));
+    std::memcpy(c->S->h_stage.p + o_ip, item_prefix.data(), (size_t)(nu + 1) * 8);
+    std::memcpy(c->S->h_stage.p + o_rp, run_prefix.data(), (size_t)(nu + 1) * 8);
+    std::memcpy(c->S->h_stage.p + o_l, lz.data(), lz.size() * sizeof(LazyClause));
+    std::memcpy(c->S->h_stage.p + o_mp, merge_prefix.data(), (size_t)(nq + 1) * 8);
+    std::memcpy(c->S->h_stage.p + o_m, qmap.data(), (size_t)nq * 4);
+    std::memcpy(c->S->h_stage.p + o_fi, fixed_info.data(), (size_t)nq * 8);
+    HIP_TRY(hipMemcpyAsync(c->S->d_stage.p, c->S->h_stage.p, st.used, hipMemcpyHostToDevice, stream));
+    HIP_TRY(c->d_runs.reserve((size_t)run_slots + 128, 0, stream));
+    // per query: the shared threshold slot, then the histogram of finished totals (LZ_HIST u32 counters)
+    HIP_TRY(c->S->d_tau.reserve((size_t)nq * (1 + LZ_HIST / 2), 0, stream));
+    HIP_TRY(hipMemsetAsync(c->S->d_tau.p, 0, (size_t)nq * (1 + LZ_HIST / 2) * 8, stream));
+    uint32_t* d_hist = reinterpret_cast<uint32_t*>(c->S->d_tau.p + nq);
+    HIP_TRY(c->S->d_partial_keys.reserve((size_t)lists * (size_t)k, 0, stream));
+    HIP_TRY(c->S->d_partial_counts.reserve((size_t)lists, 0, stream));
+    const int64_t* dmp = reinterpret_cast<const int64_t*>(c->S->d_stage.p + o_mp);
+    const int32_t* dm = reinterpret_cast<const int32_t*>(c->S->d_stage.p + o_m);
+    int32_t* dbl = reinterpret_cast<int32_t*>(c->S->d_stage.p + o_bl);
+    unsigned long long* dct = reinterpret_cast<unsigned long long*>(c->S->d_stage.p + o_ct);
+    const SegView sv = seg_view(seg);
+    c->last_counted = nullptr;
+    c->last_counted_op = RGPU_OP_OR;
+    c->last_counted_queries = nq;
+    c->last_counted_postings = all_postings;
+    c->last_counted_or_decoded = walked_postings;
+    c->last_counted_or_bytes = touched_bytes;
+    if (nu > 0) {
+      TimedLaunch tl(c, stream, "k_score_terms", walked_postings);
+      const unsigned grid = (unsigned)((items1 + WG_WAVES - 1) / WG_WAVES);
+      const DevTerm* dt = reinterpret_cast<const DevTerm*>(c->S->d_stage.p + o_t);
+      const int64_t* dip = reinterpret_cast<const int64_t*>(c->S->d_stage.p + o_ip);
+      const int64_t* drp = reinterpret_cast<const int64_t*>(c->S->d_stage.p + o_rp);
+      if (legacy)
+        hipLaunchKernelGGL(k_score_terms<true>, dim3(grid), dim3(WG_THREADS), 0, stream, sv, dt, dip, drp, nu, items1, blocks_per_item, c->d_runs.p);
+      else
+        hipLaunchKernelGGL(k_score_terms<false>, dim3(grid), dim3(WG_THREADS), 0, stream, sv, dt, dip, drp, nu, items1, blocks_per_item, c->d_runs.p);
+    }
+    {
+      TimedLaunch tl(c, stream, "k_or_lazy", all_postings);
+      const size_t lds = lz_lds_bytes(W, C);
+      const unsigned grid = (unsigned)(lists / LZ_WAVES);
+      auto go = [&](auto kern) -> hipError_t {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(LZ_THREADS), lds, stream, sv, reinterpret_cast<const LazyQuery*>(c->S->d_stage.p + o_q),
+                           reinterpret_cast<const LazyRun*>(c->S->d_stage.p + o_r), c->d_runs.p, reinterpret_cast<const LazyClause*>(c->S->d_stage.p + o_l),
+                           nq, wpq, wpi, ipq, C, (int)k, c->S->d_partial_keys.p, c->S->d_partial_counts.p, c->S->d_tau.p, dbl, dct, d_hist);
+        return hipSuccess;
+      };
+      HIP_TRY(wide ? go(k_or_lazy<true, STEPS>) : go(k_or_lazy<false, STEPS>));
+    }
+    const int2* dfi = reinterpret_cast<const int2*>(c->S->d_stage.p + o_fi);
+    int32_t* dfl = reinterpret_cast<int32_t*>(c->S->d_stage.p + o_fl);
+    if (wide) launch_merge<true>(c, stream, nq, k, dmp, seg->doc_base, hits_dev, totals_dev, 0, dfi, dfl, dm);
+    else launch_merge<false>(c, stream, nq, k, dmp, seg->doc_base, hits_dev, totals_dev, 0, dfi, dfl, dm);
+    HIP_TRY(hipGetLastError());
+    std::vector<int32_t> low((size_t)nq), bailed((size_t)nq);
+    unsigned long long counts[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(low.data(), dfl, (size_t)nq * 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(bailed.data(), dbl, (size_t)nq * 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(counts, dct, 16, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));  // staging / scratch buffers are reused by the next group
+#ifdef RGPU_LZ_TIME
+    {  // developer output: how the evaluated docs spread over the queries
+      std::vector<unsigned long long> pq((size_t)nq * 2);
+      HIP_TRY(hipMemcpy(pq.data(), dct + 2, (size_t)nq * 16, hipMemcpyDeviceToHost));
+      std::vector<unsigned long long> ev((size_t)nq), lo((size_t)nq);
+      for (int q = 0; q < nq; ++q) { ev[(size_t)q] = pq[(size_t)2 * q]; lo[(size_t)q] = pq[(size_t)2 * q + 1]; }
+      std::sort(ev.begin(), ev.end());
+      std::sort(lo.begin(), lo.end());
+      auto at = [&](const std::vector<unsigned long long>& v, double f) { return v[(size_t)std::min<double>(v.size() - 1, f * v.size())]; };
+      unsigned long long top5 = 0, top5lo = 0;
+      for (size_t i = (size_t)(0.95 * nq); i < (size_t)nq; ++i) { top5 += ev[i]; top5lo += lo[i]; }
+      std::fprintf(stderr, "[lz] per query evaluated docs: p50 %llu p90 %llu p95 %llu p99 %llu max %llu; the top 5%% hold %llu of %llu | lazy-only: p50 %llu p90 %llu p99 %llu max %llu, top 5%% %llu of %llu\n",
+                   at(ev, .5), at(ev, .9), at(ev, .95), at(ev, .99), ev.back(), top5, counts[0], at(lo, .5), at(lo, .9), at(lo, .99), lo.back(), top5lo, counts[1]);
+    }
+#endif
+    c->or_lazy_evals = (int64_t)counts[0];
+    c->or_lazy_only = (int64_t)counts[1];
+    c->stats[(size_t)stat_slot(c, "or_lazy_evaluated_docs")].launches += (int64_t)counts[0];
+    c->stats[(size_t)stat_slot(c, "or_lazy_only_docs")].launches += (int64_t)counts[1];
+    // a window that did not fit: the query goes through k_or_wide with the rest (its row is simply written again); a top-k
+    // that reaches below the fixed-point floor: the clause-order kernel, as after k_or_wide
+    Group redo;
+    redo.op = RGPU_OP_OR;
+    int64_t n_bailed = 0;
+    for (int q = 0; q < nq; ++q) {
+      if (bailed[(size_t)q]) { hand_over(rest, lq_of[(size_t)q]); ++n_bailed; continue; }
+      if (!low[(size_t)q]) continue;
+      const DevQuery& wq = G.queries[(size_t)lq_of[(size_t)q]];
+      DevQuery dq2;
+      dq2.op = RGPU_OP_OR;
+      dq2.n_terms = wq.n_terms;
+      dq2.first_term = (int32_t)redo.terms.size();
+      dq2.pad = 0;
+      for (int i = 0; i < wq.n_terms; ++i) {
+        DevTerm t = G.terms[(size_t)(wq.first_term + i)];
+        t.flags &= ~TERM_FLAG_OR_DENSE;
+        redo.terms.push_back(t);
+        redo.postings += t.df;
+      }
+      redo.qmap.push_back(G.qmap[(size_t)lq_of[(size_t)q]]);
+      redo.queries.push_back(dq2);
+    }
+    if (n_bailed) c->stats[(size_t)stat_slot(c, "or_lazy_bail_queries")].launches += n_bailed;
+    if (!redo.queries.empty()) {
+      c->or_wide_redone += (int64_t)redo.queries.size();
+      c->stats[(size_t)stat_slot(c, "or_wide_redo_queries")].launches += (int64_t)redo.queries.size();
+      int32_t rc = search_or_group(seg, redo, k, hits_dev, totals_dev, stream);
+      if (rc != RGPU_OK) return rc;
+    }
+  }
+  rest.after_lazy = nq > 0;
+  if (!rest.queries.empty()) return search_or_wide_group(seg, rest, k, hits_dev, totals_dev, stream);
+  return RGPU_OK;
+}
+
 // OR with >= 10 SHOULD clauses (the reference sums those in heap order: any order is within its own spec): one launch of
 // k_or_wide (kernels/search_or_wide.hpp), nothing materialised in HBM
 static int32_t search_or_wide_group(rgpu_segment* seg, Group& G, int32_t k, HitOut* hits_dev, int64_t* totals_dev, hipStream_t stream) {
@@ -1160,6 +1562,7 @@ static int32_t search_or_wide_group(rgpu_segment* seg, Group& G, int32_t k, HitO
   const bool wide = k > 64;
   const bool legacy = seg->version < 1;
   if (nt == 0) return RGPU_OK;
+  if (!G.no_lazy && c->cfg.or_bitmaps >= 0 && seg->bitmaps.size() > 0) return search_or_lazy_group(seg, G, k, hits_dev, totals_dev, stream);
   HIP_TRY(scratch_take(c));
   // a window: a multiple of the workgroup's scan step, small enough for the directory look-ahead and for LDS
   constexpr int WS_MAX = ORX_MAX_WINDOW / ORX_SCAN_STEP * ORX_SCAN_STEP;
@@ -1244,8 +1647,18 @@ static int32_t search_or_wide_group(rgpu_segment* seg, Group& G, int32_t k, HitO
   const SegView sv = seg_view(seg);
   c->last_counted = nullptr;  // nothing to read back: the wide kernel decodes every posting of every clause
   c->last_counted_op = RGPU_OP_OR;
-  c->last_counted_queries = nq;
-  c->last_counted_postings = G.postings;
+  if (G.after_lazy) {  // the rest of a batch whose other queries k_or_lazy took: one set of counters for the call
+    c->last_counted_queries += nq;
+    c->last_counted_postings += G.postings;
+    c->last_counted_or_decoded += G.postings;
+    int64_t bytes = G.postings;  // 1 norm byte per posting + the encoded bytes
+    for (int64_t b : G.term_bytes) bytes += b;
+    c->last_counted_or_bytes += bytes;
+  } else {
+    c->last_counted_queries = nq;
+    c->last_counted_postings = G.postings;
+    c->last_counted_or_decoded = -1;
+  }
   {
     TimedLaunch tl(c, stream, "k_or_wide", G.postings);
     const size_t lds = orx_lds_bytes(WS);
@@ -1354,6 +1767,23 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
   }
   int32_t rc = prepare_terms_locked(seg, ptrs.data(), ptrs.size());
   if (rc != RGPU_OK) return rc;
+  // (the fixed-point kernels rank by exact totals and round to f32 afterwards: across passes that would need a ceiling in
+  // their own key space — deep result pages of a >= 10-clause disjunction go through the clause-order kernel instead)
+  const bool or_wide_ok = c->cfg.or_wide >= 0 && seg->d_norms && seg->n_norm_ranks > 0 && !seg->d_live && k_total <= RGPU_PASS_K;
+  if (or_wide_ok && c->cfg.or_bitmaps >= 0) {  // doc bitmaps for the dense terms of the disjunctions k_or_lazy can take
+    const int64_t min_df = bitmap_min_df(seg);
+    std::vector<const rgpu_term_state*> dense;
+    std::vector<int32_t> dense_sim;
+    for (int32_t q = 0; q < n_queries; ++q) {
+      const rgpu_query& Q = queries[q];
+      if ((Q.op & 0xff) != RGPU_OP_OR || ((Q.op >> 8) & 0xff) > 1 || Q.n_terms < 10 || Q.n_must_not != 0) continue;
+      for (int i = 0; i < Q.n_terms; ++i) {
+        const rgpu_term_state& st = terms[Q.first_term + i].state;
+        if (st.doc_freq >= min_df && !seg->bitmaps.find(st.doc_start_fp)) { dense.push_back(&st); dense_sim.push_back(terms[Q.first_term + i].sim_table); }
+      }
+    }
+    if (!dense.empty()) { rc = ensure_bitmaps_locked(seg, dense.data(), dense_sim.data(), dense.size()); if (rc != RGPU_OK) return rc; }
+  }
 
   // one group per op; OR groups are cut so that a group's scored runs stay below ~24 GiB of HBM scratch (288 GB per GPU; with the
   // dense clauses decoded inside the window kernel only about a third of a Zipfian batch's postings go through a run at all)
@@ -1368,10 +1798,8 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
   groups[4].req_opt = true;
   int cur_req_opt = 4;
   int64_t req_opt_records = 0;
-  // (the fixed-point kernel ranks by exact totals and rounds to f32 afterwards: across passes that would need a ceiling in
-  // its own key space — deep result pages of a >= 10-clause disjunction go through the clause-order kernel instead)
-  const bool or_wide_ok = c->cfg.or_wide >= 0 && seg->d_norms && seg->n_norm_ranks > 0 && !seg->d_live && k_total <= RGPU_PASS_K;
   std::vector<DevTerm> mine, mine_not, mine_opt;
+  std::vector<int64_t> mine_bytes;
   for (int32_t q = 0; q < n_queries; ++q) {
     const rgpu_query& Q = queries[q];
     // low byte: rgpu_query_op; next byte: min_should_match (OR); third byte: optional SHOULD clauses (TERM / AND)
@@ -1379,6 +1807,7 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
     mine.clear();
     mine_not.clear();
     mine_opt.clear();
+    mine_bytes.clear();
     bool dead = false;
     for (int i = 0; i < Q.n_terms; ++i) {
       const rgpu_query_term& t = terms[Q.first_term + i];
@@ -1390,6 +1819,8 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
       rc = make_dev_term(seg, t.state, t.weight, t.sim_table, &dt);
       if (rc != RGPU_OK) return rc;
       mine.push_back(dt);
+      // the postings' bytes in .doc: FullBlocks end where the skip data starts; a short list is its VInt tail (~2 B a posting)
+      mine_bytes.push_back(t.state.doc_freq > 128 && t.state.skip_offset > 0 ? t.state.skip_offset : 2 * (int64_t)t.state.doc_freq);
     }
     if (dead) mine.clear();
     // MUST_NOT clauses (boolean_query.rs:235-252): absent terms drop out; without a positive scorer there is none
@@ -1455,6 +1886,7 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
     dq.n_terms = (int32_t)mine.size();
     dq.pad = (int32_t)mine_not.size();
     for (auto& m : mine) { G.terms.push_back(m); G.postings += m.df; }
+    if (to_wide) G.term_bytes.insert(G.term_bytes.end(), mine_bytes.begin(), mine_bytes.end());
     for (auto& m : mine_not) { G.terms.push_back(m); G.postings += m.df; }
     for (auto& m : mine_opt) { G.terms.push_back(m); G.postings += m.df; }
     G.qmap.push_back(q);
@@ -2605,6 +3037,16 @@ extern "C" int32_t rgpu_debug_counters(unsigned long long* out8, int32_t reset) 
   if (reset) {
     unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_orx_dbg), z, 64) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif
+#ifdef RGPU_LZ_TIME
+extern "C" int32_t rgpu_debug_counters(unsigned long long* out8, int32_t reset) {  // k_or_lazy wave-cycles per phase (search_or_lazy.hpp)
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_lz_dbg), 64) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_lz_dbg), z, 64) != hipSuccess) return -1;
   }
   return 0;
 }

@@ -11,7 +11,8 @@ reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 docs = int(os.environ.get("DOCS", "10000000"))
 seg = indexgen.build_zipf(docs, 1_000_000)
 ctx = rucene_amd.Context(profile_kernels=True, blocks_per_item=int(os.environ.get('BPI', '0')), and_blocks_per_item=int(os.environ.get('ABPI', '0')), or_window_docs=int(os.environ.get("ORW", "0")), or_dense_clauses=int(os.environ.get("ORD", "0")),
-                         or_wide=int(os.environ.get("ORWIDE", "0")), or_wide_window_docs=int(os.environ.get("ORWW", "0")))
+                         or_wide=int(os.environ.get("ORWIDE", "0")), or_wide_window_docs=int(os.environ.get("ORWW", "0")),
+                         or_bitmaps=int(os.environ.get("ORBM", "0")), or_lazy_cells=int(os.environ.get("ORCELLS", "0")))
 leaf = rucene_amd.LeafReader.from_synthetic(seg)
 if os.environ.get('NONORMS'):
     leaf.norms = None
@@ -59,5 +60,5 @@ if hasattr(_L, "rgpu_debug_counters"):
     _o = (_C.c_ulonglong * 8)()
     _L.rgpu_debug_counters(_o, 0)
     print("dbg counters (whole run, %d launches)" % (reps + 2), list(_o))
-print({n: (v["launches"], round(v["total_ms"] / v["launches"], 4)) for n, v in ctx.kernel_stats().items()})
+print({n: (v["launches"], round(v["total_ms"] / max(1, v["launches"]), 4)) for n, v in ctx.kernel_stats().items()})
 ctx.close()

@@ -328,7 +328,8 @@ def test_work_partitioning_knobs_do_not_change_answers(oracle, knobs):
         ctx2.close()
 
 
-@pytest.mark.parametrize("knobs", [dict(), dict(or_wide_window_docs=2048), dict(or_wide_window_docs=14336), dict(or_wide=-1)])
+@pytest.mark.parametrize("knobs", [dict(or_bitmaps=-1), dict(or_bitmaps=-1, or_wide_window_docs=2048), dict(or_bitmaps=-1, or_wide_window_docs=14336), dict(or_wide=-1),
+                                   dict(), dict(or_lazy_cells=1024), dict(or_bitmaps=4)])
 def test_wide_disjunctions(oracle, knobs):
     """>= 10 SHOULD clauses: the order-free workgroup-window kernel (k_or_wide). Hit counts exact, scores within the
     reference's own 1e-5 (it sums such disjunctions in heap order). Singletons, tail-only lists, lists that hold every
@@ -353,7 +354,14 @@ def test_wide_disjunctions(oracle, knobs):
     try:
         leaf = rucene_amd.LeafReader(seg.doc_bytes, seg.norms, max_doc, seg.terms, sum_total_term_freq=60 * max_doc)
         gsearcher = rucene_amd.GpuIndexSearcher([leaf], ctx=ctx2)
-        if knobs.get("or_wide", 0) == 0:
+        lazy = knobs.get("or_wide", 0) == 0 and knobs.get("or_bitmaps", 0) >= 0  # dense clauses met through their doc bitmaps (k_or_lazy)
+        if lazy:
+            _check_against_oracle(oracle, osearcher, gsearcher, [(oracle.OP_OR, list(range(10)))], 10, exact=False)
+            assert "k_or_lazy" in ctx2.kernel_stats() and "k_or_wide" not in ctx2.kernel_stats() and "k_or_windows" not in ctx2.kernel_stats()
+            assert leaf.segment.footprint()["doc_bitmap_terms"] == (2 if knobs.get("or_bitmaps", 0) == 0 else 1)
+            _check_against_oracle(oracle, osearcher, gsearcher, [(oracle.OP_OR, [0, 1, 2] + [11] * 7)], 10, exact=False)  # the floor, see below
+            assert "k_or_windows" in ctx2.kernel_stats() and ctx2.kernel_stats()["or_wide_redo_queries"]["launches"] == 1
+        elif knobs.get("or_wide", 0) == 0:
             # the fixed-point floor: three rare terms (idf ~ 10) next to a term every doc holds (idf ~ 1e-5) — the top-k
             # reaches down to docs that only hold the latter, whose totals are a few hundred fixed-point steps; such a query
             # is summed again in f32 by the clause-order kernel
@@ -369,12 +377,72 @@ def test_wide_disjunctions(oracle, knobs):
                  (oracle.OP_OR, [17, 15, 7, 8, 9, 10, 11, 12, 13, 6, 5, 4, 3])]
         for k in (10, 100):
             _check_against_oracle(oracle, osearcher, gsearcher, specs, k, exact=False)
-        if not knobs:  # the workgroup's bound is the smallest of its eight lists' ceil(k / 8)-th best totals: the edges of that rank
+        if lazy:  # a list that holds every doc, walked (ten copies: eight go through the bitmap): more touched docs than cells -> k_or_wide
+            assert ctx2.kernel_stats()["or_lazy_bail_queries"]["launches"] >= 1 and "k_or_wide" in ctx2.kernel_stats()
+        if knobs in (dict(), dict(or_bitmaps=-1)):  # the workgroup's bound is the smallest of its eight lists' ceil(k / 8)-th best totals: the edges of that rank
             for k in (1, 7, 8, 9, 64, 65, 128):
                 _check_against_oracle(oracle, osearcher, gsearcher, specs[:6], k, exact=False)
         # next to other operators in one batch
         mixed = [(oracle.OP_TERM, [9]), specs[1], (oracle.OP_AND, [9, 10, 11]), specs[3], (oracle.OP_OR, [8, 9, 10])]
         _check_against_oracle(oracle, osearcher, gsearcher, mixed, 10, exact=False)
+    finally:
+        ctx2.close()
+
+
+@pytest.mark.parametrize("knobs", [dict(), dict(or_lazy_cells=1024), dict(or_bitmaps=16)])
+def test_lazy_disjunctions(oracle, knobs):
+    """k_or_lazy (>= 10 SHOULD clauses, the dense ones met through their doc bitmaps) over ten windows: hit counts exact, docs and
+    scores under the heap-order rule. Freqs beyond a byte inside a bitmap clause, more than four and more than eight bitmap
+    clauses, queries of dense terms only, duplicate clauses, singletons / tails next to one bitmap clause, a clustered walked
+    list (more blocks in one window than a look shows) and a walked list that holds every doc (both handed to k_or_wide)."""
+    import rucene_amd
+    from rucene_amd import indexgen
+    max_doc = 150_001
+    rng = np.random.default_rng(777)
+    dfs = [1, 3, 70, 128, 200, 700, 1500, 2300, 2340, 5000, 9000, 20_000, 40_000, 75_000, 120_000, max_doc, 30_000, 2400, 60_000, 100_000]
+    lists = [_postings(rng, df, max_doc) for df in dfs]
+    f = lists[12][1].copy()
+    at = rng.choice(f.size, 300, replace=False)
+    f[at] = rng.integers(255, 5000, 300)
+    f[at[:5]] = 255
+    lists[12] = (lists[12][0], f)
+    lists[7] = (np.arange(50_000, 52_300, dtype=np.int32), lists[7][1])  # 18 blocks inside one 16384-doc window
+    norms = rng.integers(90, 130, size=max_doc).astype(np.uint8)
+    seg = indexgen.build_explicit(max_doc, lists, norms=norms)
+    oseg = oracle.Segment(seg.doc_bytes, seg.norms, max_doc, seg.terms, sum_total_term_freq=60 * max_doc)
+    osearcher = oracle.Searcher([oseg])
+    ctx2 = rucene_amd.Context(profile_kernels=True, **knobs)
+    try:
+        leaf = rucene_amd.LeafReader(seg.doc_bytes, seg.norms, max_doc, seg.terms, sum_total_term_freq=60 * max_doc)
+        gsearcher = rucene_amd.GpuIndexSearcher([leaf], ctx=ctx2)
+        specs = [(oracle.OP_OR, [0, 1, 2, 3, 4, 5, 6, 9, 10, 11]),            # three bitmap clauses
+                 (oracle.OP_OR, [3, 4, 5, 6, 11, 12, 13, 14, 16, 18]),         # six (two rounds of four), one with freqs >= 255
+                 (oracle.OP_OR, [11, 12, 13, 14, 15, 16, 18, 19, 9, 10]),      # ten dense terms: six bitmaps, four walked (too dense: handed back)
+                 (oracle.OP_OR, [13] * 5 + [5] * 5),                           # duplicates
+                 (oracle.OP_OR, [0, 1, 2, 0, 1, 2, 0, 1, 2, 14]),              # singletons and a tail next to one bitmap
+                 (oracle.OP_OR, [17, 8, 6, 5, 4, 3, 2, 1, 0, 9, 10, 11, 12, 13, 14, 16]),  # sixteen clauses
+                 (oracle.OP_OR, [12] * 10),                                    # the same dense term ten times: lazy lists only
+                 (oracle.OP_OR, [0, 1, 2, 3, 4, 5, 6, 8, 17, 19])]
+        for k in (10, 100):
+            _check_against_oracle(oracle, osearcher, gsearcher, specs, k, exact=False)
+        stats = ctx2.kernel_stats()
+        assert "k_or_lazy" in stats
+        # (the ten copies of a list that holds a doc in four — two of them walked — do not fit the default 512 cells per 2048 doc ids)
+        assert stats.get("or_lazy_bail_queries", {"launches": 0})["launches"] <= 2 * 2 and stats["k_or_lazy"]["launches"] >= 2, sorted(stats)
+        assert stats["or_lazy_evaluated_docs"]["launches"] > 0
+        if not knobs:
+            for k in (1, 64, 65, 128):
+                _check_against_oracle(oracle, osearcher, gsearcher, specs[:4], k, exact=False)
+        handed_back = [(oracle.OP_OR, [0, 1, 2, 3, 4, 5, 7, 9, 10, 11]),   # the clustered list
+                       (oracle.OP_OR, [15] * 10)]                           # every doc, ten times: two copies are walked
+        _check_against_oracle(oracle, osearcher, gsearcher, handed_back + specs[:2], 10, exact=False)
+        stats = ctx2.kernel_stats()
+        assert stats["or_lazy_bail_queries"]["launches"] >= 2 and "k_or_wide" in stats, sorted(stats)
+        fp = leaf.segment.footprint()
+        assert fp["doc_bitmap_terms"] >= 8 and fp["doc_bitmap_bytes"] > fp["doc_bitmap_terms"] * max_doc // 4
+        leaf.segment.release_prepared_terms()
+        assert leaf.segment.footprint()["doc_bitmap_terms"] == 0
+        _check_against_oracle(oracle, osearcher, gsearcher, specs[:2], 10, exact=False)
     finally:
         ctx2.close()
 
@@ -1257,6 +1325,15 @@ def test_search_counters_tell_decoded_from_covered(ctx, oracle):
     rucene_amd.GpuIndexSearcher([leaf2], ctx=ctx).search_batch([T(t) for t in terms], 10)
     c = ctx.last_search_counters()
     assert c["blocks_decoded"] == full_blocks and c["postings_decoded"] == covered                # the general path decodes everything
+    # a >= 10-clause disjunction: the clauses with a doc bitmap (df >= max_doc / 64) are not walked
+    wide = [0, 1, 2, 3, 10, 50, 200, 900, 2000, 4000, 4999]
+    searcher.search_batch([B.build([], [T(t) for t in wide])], 10)
+    c = ctx.last_search_counters()
+    dfs = seg.terms["doc_freq"][wide].astype(np.int64)
+    lazy = dfs >= max(1024, (seg.max_doc + 63) // 64)
+    assert 1 <= lazy.sum() <= 6
+    assert c["op"] == 2 and c["postings_covered"] == int(dfs.sum()) and c["postings_decoded"] == int(dfs[~lazy].sum())
+    assert c["touched_bytes"] >= int(lazy.sum()) * (seg.max_doc // 8) + int(dfs[~lazy].sum())
 
 
 def test_native_planner_with_its_own_sim_table(ctx, oracle):
