@@ -48,11 +48,14 @@ constexpr int LZ_STEP_DOCS = 2048;  // one bitmap word per lane
 constexpr int LZ_HIST = 128;      // buckets of the per-query histogram of finished totals (bucket = total >> 24)
 constexpr int LZ_FLAG_BAIL = 2;   // a window did not fit (-> k_or_wide)
 
+#ifndef RGPU_LZ_MIN_WAVES  // wavefronts per SIMD the register allocation aims at (LDS: 12 KB per wavefront at 16384-doc windows -> 3)
+#define RGPU_LZ_MIN_WAVES 3
+#endif
 #ifndef RGPU_LZ_ABL  // developer ablations (variant builds only; results are wrong): 1 no lazy-only docs, 2 no candidate evaluation, 3 neither
 #define RGPU_LZ_ABL 0
 #endif
 #ifdef RGPU_LZ_TIME  // developer instrumentation (variant builds only): wave-cycles per phase, summed over wavefronts
-__device__ unsigned long long g_lz_dbg[8];  // [0] run heads + pass 1 [1] numbering [2] bitmap words, hits, lazy-only docs [3] pass 2 [4] cell scan [5] candidate evaluation (inside 2 and 4) [6] set-up [7] windows
+__device__ unsigned long long g_lz_dbg[16];  // [8] steps with the lazy-only test on [9] ... that had a doc in enough lists [10] per-doc bound iterations [11] steps [12] sum of `need` [13] sum of need_hi  // [0] run heads + pass 1 [1] numbering [2] bitmap words, hits, lazy-only docs [3] pass 2 [4] cell scan [5] candidate evaluation (inside 2 and 4) [6] set-up [7] windows
 #define LZ_STAMP(t) const long long t = (long long)__builtin_readcyclecounter()
 #define LZ_ADD(i, v) lz_t[i] += (v)
 #else
@@ -98,10 +101,10 @@ __host__ __device__ constexpr size_t lz_lds_bytes(int W, int C) { return (size_t
 // (k_or_windows: later workgroups start from the thresholds the earlier ones published). counters[0] += candidates
 // evaluated, [1] += of them docs held by lazy lists only.
 template <bool WIDE, int STEPS>
-__global__ __launch_bounds__(LZ_THREADS, 3) void k_or_lazy(SegView seg, const LazyQuery* __restrict__ queries, const LazyRun* __restrict__ run_of,
+__global__ __launch_bounds__(LZ_THREADS, RGPU_LZ_MIN_WAVES) void k_or_lazy(SegView seg, const LazyQuery* __restrict__ queries, const LazyRun* __restrict__ run_of,
                                                         const ScoredPosting* __restrict__ runs, const LazyClause* __restrict__ lazies,
-                                                        int n_queries, int windows_per_query, int windows_per_item, int items_per_query,
-                                                        int C, int k, uint64_t* __restrict__ partial_keys,
+                                                        int64_t sentinel_at, int n_queries, int windows_per_query, int windows_per_item,
+                                                        int items_per_query, int C, int k, uint64_t* __restrict__ partial_keys,
                                                         int32_t* __restrict__ partial_counts, unsigned long long* __restrict__ tau_slots,
                                                         int32_t* __restrict__ flags, unsigned long long* __restrict__ counters,
                                                         uint32_t* __restrict__ hist) {
@@ -166,7 +169,7 @@ __global__ __launch_bounds__(LZ_THREADS, 3) void k_or_lazy(SegView seg, const La
   // ---- walked clauses: lane t owns clause t's cursor — run base, length, the first entry with doc >= this item's first
   // window (one lane-parallel binary search over all clauses at once)
   const bool mine_run = lane < n;
-  int64_t my_at = 0;
+  int64_t my_at = sentinel_at;  // (lanes without a clause: 64 sentinel entries — the head loads are unconditional)
   int my_len = 0;
   if (mine_run) { const LazyRun R = run_of[Q.first_run + lane]; my_at = R.base; my_len = R.len; }
   {
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(LZ_THREADS, 3) void k_or_lazy(SegView seg, const La
   };
   auto threshold = [&]() -> uint32_t { return max(1u, (uint32_t)(tau >> 32)); };
 #ifdef RGPU_LZ_TIME
-  long long lz_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long lz_t[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
 
   // ---- evaluate up to 64 queued candidates: which lazy clauses hold the doc (the bound tightens), their freqs, the total
@@ -313,6 +316,7 @@ __global__ __launch_bounds__(LZ_THREADS, 3) void k_or_lazy(SegView seg, const La
   LZ_STAMP(ts1);
   LZ_ADD(6, ts1 - ts0);
 
+  u32x2 wq[4][4];  // the lazy clauses' {any, hi} words: [slot = step & 3][clause 0 .. 3]
   for (int win = win0; win < win1; ++win) {
     LZ_STAMP(t0);
     const int32_t w0 = win * W;
@@ -325,14 +329,17 @@ __global__ __launch_bounds__(LZ_THREADS, 3) void k_or_lazy(SegView seg, const La
     // of the step four further on as soon as the step is done
     const uint64_t active0 = __ballot(my_next < w1);
     const uint32_t word0 = (uint32_t)(w0 >> 5) + (uint32_t)lane;
-    u32x2 wq[4][4];
     auto words_issue = [&](int slot, int step) __attribute__((always_inline)) {
 #pragma unroll
       for (int c = 0; c < 4; ++c)  // (clamped: OR and the counts below ignore duplicates)
         wq[slot][c] = ((gpairs)(uintptr_t)readlane64(l_words, min(c, nl - 1)))[word0 + 64u * (uint32_t)step];
     };
+    // (a window of four steps: all of its words fit the slots, and they were requested right after the previous window's steps)
+    constexpr bool WORDS_AHEAD = STEPS <= 4;
+    if (!WORDS_AHEAD || win == win0) {
 #pragma unroll
-    for (int i = 0; i < 4 && i < STEPS; ++i) words_issue(i, i);
+      for (int i = 0; i < 4 && i < STEPS; ++i) words_issue(i, i);
+    }
 
     // One clause's entries inside the window. PASS 1 sets their touched bits and leaves the clause's advance (lane t); PASS 2
     // adds the entries whose docs lie in [d_lo, d_lo + d_len) to their cells. The clause loops are unrolled over the prefetched
@@ -366,6 +373,9 @@ __global__ __launch_bounds__(LZ_THREADS, 3) void k_or_lazy(SegView seg, const La
         }
       }
     };
+    // (tried: the eight heads straight-line and predicated — spare cells for the postings outside the window, no exec-mask
+    // branch, eight LDS operations in flight: 3.91 ms against 3.77 for the branches below, which skip the clauses without a
+    // posting in the window)
     auto walk_all = [&](auto pass_tag, int32_t d_lo, uint32_t d_len, uint32_t r0) __attribute__((always_inline)) {
       constexpr bool SECOND = decltype(pass_tag)::value;
       uint64_t more = active0 >> LZ_PREFETCH << LZ_PREFETCH;  // clauses that go on past their 64 prefetched entries (or have none)
@@ -435,13 +445,16 @@ __global__ __launch_bounds__(LZ_THREADS, 3) void k_or_lazy(SegView seg, const La
       const uint32_t t = tw[w].x;
       uw[w] = make_uint2(un_a, un_b);
       hits_lane += __popc(t | un);
+      LZ_ADD(11, 1);
       if ((RGPU_LZ_ABL & 1) || ub_sum < threshold()) return;
+      LZ_ADD(8, 1);
       const uint32_t thr = threshold();
       // lists a doc must be in at best: the smallest m whose m largest bounds reach the threshold (bounds are sorted: l_ubpre
       // ascends over lanes 0 .. nl-1); `hi` postings it must have at best: with every clause present at ub_lo, the h largest
       // (ub - ub_lo) — the host keeps those in the same order — must close the gap (more than there are clauses: nobody)
       const int need = __popcll(__ballot(lane < nl && l_ubpre < thr)) + 1;
       const int need_hi = ub_lo_sum >= thr ? 0 : __popcll(__ballot(lane < nl && ub_lo_sum + l_dpre < thr)) + 1;
+      LZ_ADD(12, need); LZ_ADD(13, need_hi);
       if (need > nl || need_hi > nl) return;
       // docs held by at least `m` of the clauses (x = their words; clamped duplicates of the last clause are harmless to an OR
       // and an AND): an OR, an AND, or a bit-sliced count
@@ -474,12 +487,14 @@ __global__ __launch_bounds__(LZ_THREADS, 3) void k_or_lazy(SegView seg, const La
       };
       uint32_t cand = at_least(cur, need) & ~t;
       if (!__ballot(cand != 0u)) return;  // (six steps in ten end here when a doc has to be in every list)
+      LZ_ADD(9, 1);
       cand &= at_least(chi, need_hi);
       // the docs that get this far are checked one by one — do the bounds of the clauses that hold the doc (ub_lo outside the
       // `hi` halves) reach the threshold? — and the survivors' bits wait in the accumulator cells (idle until pass 2): they are
       // queued after the steps, by one copy of that code instead of one per step
       uint32_t keep = 0u;
       while (__ballot(cand != 0u)) {
+        LZ_ADD(10, 1);
         const bool on = cand != 0u;
         const uint32_t b = on ? (uint32_t)__builtin_ctz(cand) : 0u;
         cand &= cand - 1u;
@@ -503,6 +518,16 @@ __global__ __launch_bounds__(LZ_THREADS, 3) void k_or_lazy(SegView seg, const La
     if (nl <= 4) steps_all(std::integral_constant<int, 4>{});
     else steps_all(std::integral_constant<int, LZ_MAX_LAZY>{});
     wave_sync();
+    if (WORDS_AHEAD) {  // the next window's words (past the item's last window: the bitmaps' zero padding, or another window's words)
+      const uint32_t keep_word0 = word0;
+      (void)keep_word0;
+#pragma unroll
+      for (int i = 0; i < STEPS && i < 4; ++i) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          wq[i][c] = ((gpairs)(uintptr_t)readlane64(l_words, min(c, nl - 1)))[word0 + (uint32_t)(W / 32) + 64u * (uint32_t)i];
+      }
+    }
     for (; lazy_steps; lazy_steps &= lazy_steps - 1u) {
       const int i = (int)__builtin_ctz(lazy_steps);
       const int w = 64 * i + lane;
@@ -582,7 +607,7 @@ __global__ __launch_bounds__(LZ_THREADS, 3) void k_or_lazy(SegView seg, const La
   const int count = wave_reduce_add(hits_lane);
 #ifdef RGPU_LZ_TIME
   if (lane == 0)
-    for (int i = 0; i < 8; ++i) atomicAdd(&g_lz_dbg[i], (unsigned long long)lz_t[i]);
+    for (int i = 0; i < 16; ++i) atomicAdd(&g_lz_dbg[i], (unsigned long long)lz_t[i]);
 #endif
   if (lane == 0) {
     partial_counts[item] = count;

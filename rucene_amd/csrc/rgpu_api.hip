@@ -132,7 +132,12 @@ struct rgpu_ctx {
   std::vector<float> sim_k1;          // per table: k1
   std::vector<uint8_t> sim_nonneg;    // per table: k1 and every cache[] entry finite and >= 0 (a score is then within [0, weight * (k1 + 1)])
   std::vector<float> sim_cache_min;   // per table: the smallest cache[] entry (freq / (freq + cache) is largest there: k_or_lazy's score bounds)
-  int64_t or_lazy_evals = 0, or_lazy_only = 0;  // k_or_lazy: candidates evaluated / of them docs held by lazy lists only (last launch)
+  int64_t or_lazy_evals = 0, or_lazy_only = 0;
+  // search_or_lazy_group: doc_start_fp -> the batch's run of that term. Direct-mapped and stamped with the call's number, so a
+  // call neither allocates nor clears it (a collision costs a second run of the same term, nothing else)
+  struct UniqSlot { int64_t fp; uint32_t stamp; int32_t idx; };
+  std::vector<UniqSlot> lazy_uniq;
+  uint32_t lazy_stamp = 0;  // k_or_lazy: candidates evaluated / of them docs held by lazy lists only (last launch)
   // Per-call scratch, in rotating slots: a search call only enqueues work (staging copy + kernels) on its stream
   // and marks its slot with an event; the slot is waited for when its turn comes again, so the host prepares batch
   // i+1 while the GPU runs batch i and a caller synchronizes the stream once, when it wants the results.
@@ -203,6 +208,7 @@ struct rgpu_segment {
   rucene::FlatFpMap<BitmapInfo> bitmaps;  // doc_start_fp -> the term's doc bitmap (terms holding >= 1 doc in cfg.or_bitmaps)
   std::vector<void*> bitmap_allocs;
   size_t bitmap_bytes = 0;
+  uint8_t* empty_bitmap = nullptr;  // all-zero {any, hi} words + ranks: the one lazy clause of a query that has no dense term (k_or_lazy wants one)
   DevVec<uint8_t> prep_scratch;  // k_skip_dir's chunk aggregates + ticket, the prefix sum's tile sums
 };
 
@@ -836,6 +842,7 @@ extern "C" void rgpu_segment_free(rgpu_segment* s) {
   if (s->d_pos) (void)hipFree(s->d_pos);
   s->dir_last.release(); s->dir_off.release(); s->dir_row.release(); s->dir_hdr.release(); s->dir_bmax.release(); s->dir_pos.release(); s->pnorm.release(); s->bstore.release(); s->prep_scratch.release();
   for (void* b : s->bitmap_allocs) (void)hipFree(b);
+  if (s->empty_bitmap) (void)hipFree(s->empty_bitmap);
   delete s;
 }
 
@@ -1253,18 +1260,34 @@ static int32_t search_or_wide_group(rgpu_segment* seg, Group& G, int32_t k, HitO
 // OR with >= 10 SHOULD clauses of which at least one has a doc bitmap: k_or_lazy (kernels/search_or_lazy.hpp). The bitmap
 // clauses are not walked at all; the others are decoded and scored once per distinct (term, weight) of the batch by
 // k_score_terms into {doc, score} runs. Queries without a bitmap clause, and queries the kernel hands back, go through k_or_wide.
+#ifdef RGPU_LZ_TIME
+#include <chrono>
+#define HOST_STAMP(t) const auto t = std::chrono::steady_clock::now()
+#define HOST_US(a, b) (long long)std::chrono::duration_cast<std::chrono::microseconds>((b) - (a)).count()
+#else
+#define HOST_STAMP(t) do {} while (0)
+#endif
 static int32_t search_or_lazy_group(rgpu_segment* seg, Group& G, int32_t k, HitOut* hits_dev, int64_t* totals_dev, hipStream_t stream) {
   rgpu_ctx* c = seg->ctx;
+  HOST_STAMP(h0);
   const bool wide = k > 64;
   const bool legacy = seg->version < 1;
   const int64_t min_df = bitmap_min_df(seg);
-  constexpr int STEPS = 8;
+#ifndef RGPU_LZ_STEPS
+#define RGPU_LZ_STEPS 8
+#endif
+  constexpr int STEPS = RGPU_LZ_STEPS;  // 2048-doc steps per window (4 or 8)
   constexpr int W = STEPS * LZ_STEP_DOCS;
   // (at least one cell per 32 docs of a window: between the passes the cells double as the window's candidate words)
   int C = c->cfg.or_lazy_cells > 0 ? std::min(4096, std::max(W / 32, (c->cfg.or_lazy_cells + 63) / 64 * 64)) : 512;
   while (lz_lds_bytes(W, C) > 160u * 1024u && C > W / 32) C -= 64;
 
-  Group rest;  // queries without a bitmap clause
+  if (!seg->empty_bitmap) {
+    const size_t bytes = ((((size_t)seg->max_doc + 31) / 32 + 1 + BITMAP_PAD_WORDS + 63) & ~size_t(63)) * 8;
+    HIP_TRY(hipMalloc(&seg->empty_bitmap, bytes));
+    HIP_TRY(hipMemsetAsync(seg->empty_bitmap, 0, bytes, stream));
+  }
+  Group rest;  // queries k_or_lazy hands back
   rest.op = RGPU_OP_OR;
   rest.or_wide = true;
   rest.no_lazy = true;
@@ -1285,12 +1308,15 @@ static int32_t search_or_lazy_group(rgpu_segment* seg, Group& G, int32_t k, HitO
   std::vector<DevTerm> uniq;         // the distinct (term, weight, similarity) among them: one run each
   std::vector<int64_t> uniq_bytes;
   std::vector<int32_t> uniq_of;      // walked clause instance -> uniq
-  rucene::FlatFpMap<int> uniq_at;    // doc_start_fp -> first uniq entry of that term
   std::vector<LazyClause> lz;
   std::vector<int32_t> lq_of;        // lazy query -> index in G
   std::vector<int32_t> fixed_info;
   int64_t walked_postings = 0, touched_bytes = 0, all_postings = 0;
-  uniq_at.reserve_more(G.terms.size());
+  if (c->lazy_uniq.empty()) c->lazy_uniq.assign(65536, rgpu_ctx::UniqSlot{-1, 0u, 0});
+  if (++c->lazy_stamp == 0) { for (auto& u : c->lazy_uniq) u.stamp = 0; c->lazy_stamp = 1; }
+  const uint32_t stamp = c->lazy_stamp;
+  lq.reserve(G.queries.size()); lq_of.reserve(G.queries.size()); fixed_info.reserve(2 * G.queries.size());
+  run_of.reserve(G.terms.size()); uniq_of.reserve(G.terms.size()); lz.reserve(G.terms.size() / 2);
   for (int q = 0; q < (int)G.queries.size(); ++q) {
     const DevQuery& wq = G.queries[(size_t)q];
     // the (up to LZ_MAX_LAZY) densest clauses that have a usable bitmap
@@ -1303,7 +1329,10 @@ static int32_t search_or_lazy_group(rgpu_segment* seg, Group& G, int32_t k, HitO
       const BitmapInfo* bm = seg->bitmaps.find((int64_t)t.start_fp);
       if (bm && bm->usable && bm->df == t.df) cands[n_cands++] = Cand{i, t.df, bm};
     }
-    if (n_cands == 0) { hand_over(rest, q); continue; }
+    // (no dense term: every clause is walked, next to one lazy clause over the segment's empty bitmap — it holds no doc, its
+    // bounds are zero. k_or_wide would decode the same postings inside 16384-doc workgroup windows that these short lists
+    // leave almost empty: 0.5 ms for the 40 such queries of a 1024-query batch)
+    const bool none_dense = n_cands == 0;
     std::stable_sort(cands, cands + n_cands, [](const Cand& a, const Cand& b) { return a.df > b.df; });
     n_cands = std::min(n_cands, LZ_MAX_LAZY);
     uint32_t lazy_mask = 0;
@@ -1315,7 +1344,7 @@ static int32_t search_or_lazy_group(rgpu_segment* seg, Group& G, int32_t k, HitO
       bound += (double)t.weight * ((double)c->sim_k1[(size_t)t.sim_table] + 1.0) * 1.000001;
     }
     int e = 100;
-    if (bound > 0.0) e = std::min(100, (int)std::floor(std::log2((2147483648.0 - 64.0) / bound)));
+    if (bound > 0.0) e = std::min(100, std::ilogb((2147483648.0 - 64.0) / bound));  // floor(log2(.))
     LazyQuery Q{};
     Q.first_run = (int32_t)run_of.size();
     Q.first_lazy = (int32_t)lz.size();
@@ -1325,24 +1354,35 @@ static int32_t search_or_lazy_group(rgpu_segment* seg, Group& G, int32_t k, HitO
       all_postings += t.df;
       if ((lazy_mask >> i) & 1u) continue;
       int u = -1;
-      if (const int* at = uniq_at.find((int64_t)t.start_fp)) {
-        const DevTerm& o = uniq[(size_t)*at];
-        if (o.df == t.df && o.sim_table == t.sim_table && std::memcmp(&o.weight, &t.weight, 4) == 0 && o.singleton_doc == t.singleton_doc) u = *at;
+      rgpu_ctx::UniqSlot& slot = c->lazy_uniq[(size_t)(((uint64_t)t.start_fp * 0x9E3779B97F4A7C15ull) >> 48)];
+      if (slot.stamp == stamp && slot.fp == (int64_t)t.start_fp && t.df > 1) {
+        const DevTerm& o = uniq[(size_t)slot.idx];
+        if (o.df == t.df && o.sim_table == t.sim_table && std::memcmp(&o.weight, &t.weight, 4) == 0) u = slot.idx;
       }
-      if (u < 0) {  // (the same term under another boost or similarity in one batch: its own run, not registered)
+      if (u < 0) {  // (the same term under another boost or similarity, or a colliding term: its own run)
         u = (int)uniq.size();
         DevTerm ut = t;
         ut.flags &= ~TERM_FLAG_OR_DENSE;
         uniq.push_back(ut);
         uniq_bytes.push_back(G.term_bytes.empty() ? 2 * (int64_t)t.df : G.term_bytes[(size_t)(wq.first_term + i)]);
-        if (t.df > 1 && !uniq_at.find((int64_t)t.start_fp)) uniq_at.put((int64_t)t.start_fp, u);
+        if (t.df > 1) slot = rgpu_ctx::UniqSlot{(int64_t)t.start_fp, stamp, u};
       }
       uniq_of.push_back(u);
       run_of.push_back(LazyRun{0, t.df, 0});
     }
     Q.n_runs = (int32_t)run_of.size() - Q.first_run;
     LazyClause mine[LZ_MAX_LAZY];
-    for (int j = 0; j < n_cands; ++j) {
+    if (none_dense) {
+      LazyClause L{};
+      L.words = reinterpret_cast<const uint2*>(seg->empty_bitmap);
+      L.ranks = reinterpret_cast<const uint32_t*>(seg->empty_bitmap);
+      L.freqs = seg->empty_bitmap;
+      L.ovf = reinterpret_cast<const uint32_t*>(seg->empty_bitmap);
+      L.sim_table = G.terms[(size_t)wq.first_term].sim_table;
+      mine[0] = L;
+      n_cands = 1;
+    }
+    for (int j = 0; j < (none_dense ? 0 : n_cands); ++j) {
       const DevTerm& t = G.terms[(size_t)(wq.first_term + cands[j].i)];
       LazyClause L{};
       L.words = cands[j].bm->words; L.ranks = cands[j].bm->ranks; L.freqs = cands[j].bm->freqs; L.ovf = cands[j].bm->ovf;
@@ -1379,6 +1419,7 @@ static int32_t search_or_lazy_group(rgpu_segment* seg, Group& G, int32_t k, HitO
     fixed_info.push_back((int32_t)(wq.n_terms * (int)ORX_FLOOR_PER_CLAUSE));
   }
   const int nq = (int)lq.size();
+  HOST_STAMP(h1);
   if (nq > 0) {
     HIP_TRY(scratch_take(c));
     // phase 1 plan (k_score_terms): items = (distinct walked term, chunk of blocks); runs end in OR_RUN_PAD sentinels
@@ -1408,7 +1449,7 @@ static int32_t search_or_lazy_group(rgpu_segment* seg, Group& G, int32_t k, HitO
     // phase 2 plan: items = (query, group of windows), one per wavefront
     const int wpq = std::max(1, (int)(((int64_t)seg->max_doc + W - 1) / W));
 #ifndef RGPU_LZ_TARGET_WAVES
-#define RGPU_LZ_TARGET_WAVES 32768
+#define RGPU_LZ_TARGET_WAVES 65536  // (measured on the 1024 x 10-term batch: 16 k 4.15 ms, 32 k 3.95, 64 k 3.77, 128 k 3.88)
 #endif
     int ipq = std::min(wpq, std::max(1, (RGPU_LZ_TARGET_WAVES + nq - 1) / nq));
     const int wpi = (wpq + ipq - 1) / ipq;
@@ -1431,6 +1472,7 @@ static int32_t search_or_lazy_group(rgpu_segment* seg, Group& G, int32_t k, HitO
     const size_t o_fl = st.add((size_t)nq * 4);   // low flags (k_merge_items)
     const size_t o_bl = st.add((size_t)nq * 4);   // bail flags (k_or_lazy)
     const size_t o_ct = st.add(16 + (size_t)nq * 16);  // (+ per query, variant builds: evaluated docs, lazy-only docs)
+    const size_t o_sn = st.add(64 * sizeof(ScoredPosting));
     HIP_TRY(c->S->h_stage.reserve(st.used));
     HIP_TRY(c->S->d_stage.reserve(st.used, 0, stream));
     std::memset(c->S->h_stage.p + o_fl, 0, st.used - o_fl);
@@ -1443,8 +1485,12 @@ static int32_t search_or_lazy_group(rgpu_segment* seg, Group& G, int32_t k, HitO
     std::memcpy(c->S->h_stage.p + o_mp, merge_prefix.data(), (size_t)(nq + 1) * 8);
     std::memcpy(c->S->h_stage.p + o_m, qmap.data(), (size_t)nq * 4);
     std::memcpy(c->S->h_stage.p + o_fi, fixed_info.data(), (size_t)nq * 8);
+    for (int i = 0; i < 64; ++i) reinterpret_cast<ScoredPosting*>(c->S->h_stage.p + o_sn)[i] = ScoredPosting{0x7fffffff, 0.0f};
+    HOST_STAMP(h2);
     HIP_TRY(hipMemcpyAsync(c->S->d_stage.p, c->S->h_stage.p, st.used, hipMemcpyHostToDevice, stream));
     HIP_TRY(c->d_runs.reserve((size_t)run_slots + 128, 0, stream));
+    // 64 sentinel entries behind the runs: what a clause slot without a clause looks at
+    HIP_TRY(hipMemcpyAsync(c->d_runs.p + run_slots, c->S->d_stage.p + o_sn, 64 * sizeof(ScoredPosting), hipMemcpyDeviceToDevice, stream));
     // per query: the shared threshold slot, then the histogram of finished totals (LZ_HIST u32 counters)
     HIP_TRY(c->S->d_tau.reserve((size_t)nq * (1 + LZ_HIST / 2), 0, stream));
     HIP_TRY(hipMemsetAsync(c->S->d_tau.p, 0, (size_t)nq * (1 + LZ_HIST / 2) * 8, stream));
@@ -1482,7 +1528,7 @@ static int32_t search_or_lazy_group(rgpu_segment* seg, Group& G, int32_t k, HitO
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(LZ_THREADS), lds, stream, sv, reinterpret_cast<const LazyQuery*>(c->S->d_stage.p + o_q),
                            reinterpret_cast<const LazyRun*>(c->S->d_stage.p + o_r), c->d_runs.p, reinterpret_cast<const LazyClause*>(c->S->d_stage.p + o_l),
-                           nq, wpq, wpi, ipq, C, (int)k, c->S->d_partial_keys.p, c->S->d_partial_counts.p, c->S->d_tau.p, dbl, dct, d_hist);
+                           (int64_t)run_slots, nq, wpq, wpi, ipq, C, (int)k, c->S->d_partial_keys.p, c->S->d_partial_counts.p, c->S->d_tau.p, dbl, dct, d_hist);
         return hipSuccess;
       };
       HIP_TRY(wide ? go(k_or_lazy<true, STEPS>) : go(k_or_lazy<false, STEPS>));
@@ -1494,11 +1540,16 @@ static int32_t search_or_lazy_group(rgpu_segment* seg, Group& G, int32_t k, HitO
     HIP_TRY(hipGetLastError());
     std::vector<int32_t> low((size_t)nq), bailed((size_t)nq);
     unsigned long long counts[2] = {0, 0};
+    HOST_STAMP(h3);
     HIP_TRY(hipMemcpyAsync(low.data(), dfl, (size_t)nq * 4, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipMemcpyAsync(bailed.data(), dbl, (size_t)nq * 4, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipMemcpyAsync(counts, dct, 16, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));  // staging / scratch buffers are reused by the next group
 #ifdef RGPU_LZ_TIME
+    {
+      HOST_STAMP(h4);
+      std::fprintf(stderr, "[lz host] partition %lld us, plan + stage %lld us, enqueue %lld us, copies + sync %lld us\n", HOST_US(h0, h1), HOST_US(h1, h2), HOST_US(h2, h3), HOST_US(h3, h4));
+    }
     {  // developer output: how the evaluated docs spread over the queries
       std::vector<unsigned long long> pq((size_t)nq * 2);
       HIP_TRY(hipMemcpy(pq.data(), dct + 2, (size_t)nq * 16, hipMemcpyDeviceToHost));
@@ -1742,6 +1793,7 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
 static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t n_queries, const rgpu_query_term* terms,
                            int32_t n_terms_total, int32_t k, int32_t k_total, HitOut* hits_dev, int64_t* totals_dev, hipStream_t stream) {
   rgpu_ctx* c = seg->ctx;
+  HOST_STAMP(p0);
   // validate + prepare
   std::vector<const rgpu_term_state*> ptrs;
   for (int32_t q = 0; q < n_queries; ++q) {
@@ -1785,6 +1837,7 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
     if (!dense.empty()) { rc = ensure_bitmaps_locked(seg, dense.data(), dense_sim.data(), dense.size()); if (rc != RGPU_OK) return rc; }
   }
 
+  HOST_STAMP(p1);
   // one group per op; OR groups are cut so that a group's scored runs stay below ~24 GiB of HBM scratch (288 GB per GPU; with the
   // dense clauses decoded inside the window kernel only about a third of a Zipfian batch's postings go through a run at all)
   const int64_t or_postings_cap = 3000000000LL;
@@ -1893,6 +1946,9 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
     G.queries.push_back(dq);
   }
 
+#ifdef RGPU_LZ_TIME
+  { HOST_STAMP(p2); std::fprintf(stderr, "[search_pass host] validate + prepare + bitmaps %lld us, grouping %lld us\n", HOST_US(p0, p1), HOST_US(p1, p2)); }
+#endif
   // defaults for every query (groups overwrite their own rows) — not needed when one group holds the whole batch and
   // its merge writes every row (the usual serving case: two enqueues less per batch)
   auto init_rows = [&]() -> int32_t {
@@ -3044,9 +3100,13 @@ extern "C" int32_t rgpu_debug_counters(unsigned long long* out8, int32_t reset) 
 #ifdef RGPU_LZ_TIME
 extern "C" int32_t rgpu_debug_counters(unsigned long long* out8, int32_t reset) {  // k_or_lazy wave-cycles per phase (search_or_lazy.hpp)
   if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_lz_dbg), 64) != hipSuccess) return -1;
+  unsigned long long more[8];
+  if (hipMemcpyFromSymbol(more, HIP_SYMBOL(g_lz_dbg), 64, 64) != hipSuccess) return -1;
+  std::fprintf(stderr, "[lz steps] lazy-only test on in %llu of %llu steps; a doc in enough lists in %llu; bound iterations %llu; mean need %.2f, need_hi %.2f\n", more[0], more[3],
+               more[1], more[2], more[0] ? (double)more[4] / (double)more[0] : 0.0, more[0] ? (double)more[5] / (double)more[0] : 0.0);
   if (reset) {
-    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (hipMemcpyToSymbol(HIP_SYMBOL(g_lz_dbg), z, 64) != hipSuccess) return -1;
+    unsigned long long z[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_lz_dbg), z, 128) != hipSuccess) return -1;
   }
   return 0;
 }
