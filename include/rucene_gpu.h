@@ -29,7 +29,10 @@ extern "C" {
 #define RGPU_ABI_VERSION 3
 #define RGPU_NO_MORE_DOCS 0x7fffffff /* search/mod.rs:59 */
 #define RGPU_BLOCK_SIZE 128          /* codec/postings/posting_format.rs:36 */
-#define RGPU_MAX_QUERY_TERMS 16
+#define RGPU_MAX_QUERY_TERMS 64  /* clauses of one query, MUST + SHOULD + MUST_NOT together: a clause's cursor lives in a lane of the
+                                   wavefront. Disjunctions of 10..16 SHOULD clauses take the fixed-point kernels, longer ones the
+                                   clause-order kernel */
+#define RGPU_MAX_PHRASE_TERMS 16 /* terms of one phrase */
 #define RGPU_MAX_K 1024   /* k above 128 costs ceil(k / 128) passes of the search; phrase search and rescoring: k <= 128 */
 
 /* error.rs:24-91 ErrorKind */
@@ -475,7 +478,7 @@ typedef struct rgpu_phrase_term {
  * `terms` of a query are in the QUERY's own order (PhraseQuery::new's terms / positions vectors): a sloppy phrase's scorer
  * breaks ties by that order. */
 typedef struct rgpu_phrase_query {
-  int32_t n_terms;     /* 2..RGPU_MAX_QUERY_TERMS (the reference turns a one-term phrase into a TermQuery) */
+  int32_t n_terms;     /* 2..RGPU_MAX_PHRASE_TERMS (the reference turns a one-term phrase into a TermQuery) */
   int32_t first_term;  /* index of the query's first term in `terms` */
   float weight;
   int32_t sim_table;

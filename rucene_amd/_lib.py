@@ -11,7 +11,8 @@ _LIB_NAME = "librucene_gpu.so"
 ABI_VERSION = 3
 OP_TERM, OP_AND, OP_OR = 0, 1, 2
 MAX_K = 1024
-MAX_QUERY_TERMS = 16
+MAX_QUERY_TERMS = 64
+MAX_PHRASE_TERMS = 16
 NO_MORE_DOCS = 0x7FFFFFFF
 
 TERM_STATE_DTYPE = np.dtype(

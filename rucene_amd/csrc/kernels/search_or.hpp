@@ -98,7 +98,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_score_terms(SegView seg, const D
   }
 }
 
-constexpr int OR_MAX_TERMS = 16;
+constexpr int OR_MAX_TERMS = 64;  // one cursor per clause position (SHOULD + MUST_NOT) in a lane
 constexpr int OR_RUN_PAD = 64;  // sentinel entries {doc = INT_MAX} after every clause's run (written by k_score_terms)
 constexpr int OR_DENSE_MAX = 4;  // clauses per query decoded inside the window kernel (score tables: one per wave of a workgroup)
 // The window walk is a chain of dependent steps per clause (LDS read-modify-write of the accumulator, cursor hand-over),
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(OR_THREADS, 6) void k_or_windows(SegView seg, const
   const int n_pos = Q.n_terms + n_not;  // clause positions of a window, in summation order
   const bool mine = lane < n_pos;
   const int my_clause = lane < n_not ? Q.n_terms + lane : lane - n_not;
-  const bool my_dense = mine && lane >= n_not && ((dense_mask >> my_clause) & 1u);
+  const bool my_dense = mine && lane >= n_not && my_clause < 16 && ((dense_mask >> my_clause) & 1u);  // (a dense clause is one of the first 16)
   const int64_t my_base = mine ? run_prefix[Q.first_term + my_clause] : 0;
   int my_len = 0;
   if (mine) { const DevTerm* Tm = terms + Q.first_term + my_clause; my_len = my_dense ? Tm->tail_n : Tm->df; }
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(OR_THREADS, 6) void k_or_windows(SegView seg, const
       }
       // ---- the clause's FullBlocks, when it is a dense one
       const int ci = t - n_not;
-      if (ci >= 0 && ((dense_mask >> ci) & 1u)) {
+      if (ci >= 0 && ci < 16 && ((dense_mask >> ci) & 1u)) {
         const int s = __popc(dense_mask & ((1u << ci) - 1u));
         int cb = readlane(d_cb, s);
         const int nb = readlane(d_nb, s);

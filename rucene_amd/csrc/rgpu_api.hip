@@ -1147,7 +1147,7 @@ static int32_t search_or_group(rgpu_segment* seg, Group& G, int32_t k, HitOut* h
       uint32_t mask = 0;
       for (int pick = 0; pick < dense_max; ++pick) {
         int best = -1;
-        for (int i = 0; i < dq.n_terms; ++i) {
+        for (int i = 0; i < std::min(dq.n_terms, 16); ++i) {  // (the mask travels in 16 bits of DevQuery::op)
           const DevTerm& t = G.terms[(size_t)(dq.first_term + i)];
           if (((mask >> i) & 1u) || t.nblocks < 1 || (int64_t)t.df * W < 64 * (int64_t)seg->max_doc) continue;
           if (best < 0 || t.df > G.terms[(size_t)(dq.first_term + best)].df) best = i;
@@ -1901,7 +1901,8 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
     const int gop = (qop == RGPU_OP_TERM && (!mine_not.empty() || !mine_opt.empty())) ? (int)RGPU_OP_AND : qop;
     // disjunction_scorer.rs:41-45: >= 10 children and min_should_match <= 1 -> the heap; weights must be >= +0 (the
     // kernel's "untouched" accumulator is -0.0f)
-    bool to_wide = or_wide_ok && gop == RGPU_OP_OR && mine.size() >= 10 && qmsm <= 1 && mine_not.empty();
+    // (the fixed-point kernels keep per-clause state for up to 16 clauses; a longer disjunction takes the clause-order kernel)
+    bool to_wide = or_wide_ok && gop == RGPU_OP_OR && mine.size() >= 10 && mine.size() <= (size_t)ORX_MAX_TERMS && qmsm <= 1 && mine_not.empty();
     for (size_t i = 0; to_wide && i < mine.size(); ++i)  // scores within [0, weight * (k1 + 1)]: what the fixed-point scale relies on
       to_wide = !std::signbit(mine[i].weight) && mine[i].weight <= 3.0e38f && c->sim_nonneg[(size_t)mine[i].sim_table];
     if (to_wide) {
@@ -2228,7 +2229,7 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
   std::vector<const rgpu_term_state*> ptrs;
   for (int32_t q = 0; q < n_queries; ++q) {
     const rgpu_phrase_query& Q = queries[q];
-    if (Q.n_terms < 2 || Q.n_terms > RGPU_MAX_QUERY_TERMS) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "a phrase has 2..RGPU_MAX_QUERY_TERMS terms");
+    if (Q.n_terms < 2 || Q.n_terms > RGPU_MAX_PHRASE_TERMS) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "a phrase has 2..RGPU_MAX_PHRASE_TERMS terms");
     if (Q.slop < 0) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "Slop must be >= 0");  // PhraseQuery::new (phrase_query.rs:77)
     if (Q.reserved != 0) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "rgpu_phrase_query.reserved must be zero");
     if (Q.first_term < 0 || (int64_t)Q.first_term + Q.n_terms > (int64_t)n_terms_total) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "term range outside terms[]");

@@ -447,6 +447,36 @@ def test_lazy_disjunctions(oracle, knobs):
         ctx2.close()
 
 
+def test_long_clause_lists(zipf, oracle):
+    """Up to RGPU_MAX_QUERY_TERMS = 64 clauses per query (a clause's cursor lives in a lane): conjunctions bit-exact, disjunctions
+    of more than 16 clauses through the clause-order kernel (heap-order rule), MUST_NOT and min_should_match next to them,
+    65 clauses refused."""
+    import rucene_amd
+    seg, osearcher, gsearcher = zipf
+    rng = np.random.default_rng(99)
+    T, B = rucene_amd.TermQuery, rucene_amd.BooleanQuery
+    head = [int(x) for x in rng.permutation(40)[:24]]                    # 24 frequent terms: a conjunction that still matches
+    specs = [(oracle.OP_AND, head[:17]), (oracle.OP_AND, head), (oracle.OP_AND, head[:3] + head[:3] * 7)]
+    _check_against_oracle(oracle, osearcher, gsearcher, specs, 10)
+    for n in (17, 33, 64):
+        tids = [int(x) for x in np.unique(rng.integers(0, 45_000, size=2 * n))[:n]]
+        rng.shuffle(tids)
+        _check_against_oracle(oracle, osearcher, gsearcher, [(oracle.OP_OR, tids), (oracle.OP_OR, tids[: n // 2] + [0, 1, 2, 3])], 100, exact=False)
+    # 40 SHOULD + 24 MUST_NOT clauses, and min_should_match over 20 clauses (clause-order sums: bit-exact)
+    should = [int(x) for x in np.unique(rng.integers(50, 30_000, size=90))[:40]]
+    nots = [int(x) for x in range(24)]
+    hits, totals = gsearcher.search_batch([B.build([], [T(t) for t in should], must_nots=[T(t) for t in nots]),
+                                           B.build([], [T(t) for t in should[:20]], min_should_match=2)], 10)
+    d, s, total = osearcher.search_not(oracle.OP_OR, should, nots, 10)
+    assert totals[0] == total   # (40 sub-scorers: the reference sums in heap order — scores to 1e-5, docs up to near-ties)
+    np.testing.assert_allclose(hits[0]["score"][:d.size], s, rtol=1e-5)
+    assert len(set(hits[0]["doc"][:d.size].tolist()) & set(d.tolist())) >= d.size - 2
+    d, s, total = osearcher.search(oracle.OP_OR, should[:20], 10, min_should_match=2)
+    assert totals[1] == total and (hits[1]["doc"][:d.size] == d).all() and (hits[1]["score"][:d.size].view(np.int32) == s.view(np.int32)).all()
+    with pytest.raises(rucene_amd.RgpuError):
+        gsearcher.search_batch([B.build([], [T(t) for t in range(65)])], 10)
+
+
 def test_cpp_host_mirror(oracle, tmp_path):
     """The C++ host layer (csrc/host/gpu_index_searcher.hpp) over the C ABI, driven like the reference's example."""
     import subprocess

@@ -65,7 +65,9 @@ def test_clause_limit_and_unsupported_trees(world):
     ra, seg, leaf, s = world
     T, B = ra.TermQuery, ra.BooleanQuery
     with pytest.raises(ra.RgpuError) as e:
-        s.pack([B.build([T(i) for i in range(9)], [T(i) for i in range(9, 17)])], leaf)     # 17 clauses > RGPU_MAX_QUERY_TERMS
+        s.pack([B.build([T(i) for i in range(30)], [T(i) for i in range(30, 65)])], leaf)     # 65 clauses > RGPU_MAX_QUERY_TERMS
+    q, t = s.pack([B.build([T(i) for i in range(30)], [T(i) for i in range(30, 64)])], leaf)    # 64: fine
+    assert q["n_terms"][0] == 30 and (q["op"][0] >> 16) == 34 and len(t) == 64
     assert e.value.status == -5
     with pytest.raises(ra.RgpuError):
         s.pack(["not a query"], leaf)
@@ -156,7 +158,7 @@ def test_pack_uniform_equals_pack(world):
     with pytest.raises(ra.RgpuError):
         s.pack_uniform(OP_TERM, ids[:, :2], leaf)
     with pytest.raises(ra.RgpuError):
-        s.pack_uniform(OP_OR, np.zeros((3, 17), dtype=np.int64), leaf)
+        s.pack_uniform(OP_OR, np.zeros((3, 65), dtype=np.int64), leaf)
 
 
 def test_batch_term_weights_equal_the_single_term_ones(world):
