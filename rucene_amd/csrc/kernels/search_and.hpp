@@ -127,7 +127,11 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
                                                            unsigned long long* __restrict__ emit_count,
                                                            void* __restrict__ emit_out,
                                                            const unsigned long long* __restrict__ ceil_slots = nullptr,
-                                                           const int32_t* __restrict__ qmap = nullptr) {
+                                                           const int32_t* __restrict__ qmap = nullptr,
+                                                           const TermBitmap* __restrict__ bitmaps = nullptr) {
+  // bitmaps (nullable, parallel to `terms`): a clause other than the lead whose term has a doc bitmap answers every candidate
+  // with one bit of it (and, for a hit, the posting's rank and freq byte) instead of a walk through its blocks — a list
+  // that holds a doc in five puts a candidate into nearly every one of its blocks between two lead postings.
   // emit_out != null: nothing is collected here. Without HAS_OPT (phrases): int32 doc ids appended to the query's list
   // at emit_prefix[q] in any order, emit_count[q] the cursor. With HAS_OPT (the exact ReqOptScorer rule): one SeqRec per
   // lead posting at emit_prefix[q] + the posting's ordinal — doc order, no cursor.
@@ -204,6 +208,33 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
       if (T.df == 1) {
         if (a0) { if (d0 == T.singleton_doc) found(a0, s0, (uint32_t)T.singleton_freq, n0); else missed(a0); }
         if (a1) { if (d1 == T.singleton_doc) found(a1, s1, (uint32_t)T.singleton_freq, n1); else missed(a1); }
+        continue;
+      }
+      if (bitmaps != nullptr && bitmaps[Q.first_term + ti].words != nullptr) {
+        const TermBitmap Bm = bitmaps[Q.first_term + ti];
+        typedef const __attribute__((address_space(1))) uint32_t* gwords;
+        typedef const __attribute__((address_space(1))) uint8_t* gbytes1;
+        gwords words = (gwords)(uintptr_t)Bm.words;
+        gwords ranks = (gwords)(uintptr_t)Bm.ranks;
+        gbytes1 freqs = (gbytes1)(uintptr_t)Bm.freqs;
+        // (dead candidates look at word 0: unconditional loads, six in flight)
+        const uint32_t i0 = a0 ? (uint32_t)d0 >> 5 : 0u, i1 = a1 ? (uint32_t)d1 >> 5 : 0u;
+        const uint32_t w0 = words[2u * i0], w1 = words[2u * i1];
+        const uint32_t r0w = ranks[i0], r1w = ranks[i1];
+        const bool h0 = a0 && ((w0 >> (d0 & 31)) & 1u), h1 = a1 && ((w1 >> (d1 & 31)) & 1u);
+        const uint32_t p0i = h0 ? r0w + (uint32_t)__popc(w0 & ((1u << (d0 & 31)) - 1u)) : 0u;
+        const uint32_t p1i = h1 ? r1w + (uint32_t)__popc(w1 & ((1u << (d1 & 31)) - 1u)) : 0u;
+        uint32_t fq0 = freqs[p0i], fq1 = freqs[p1i];
+        if (__ballot((h0 && fq0 == 255u) || (h1 && fq1 == 255u))) {  // a clamped freq byte: the freq is in the overflow list
+          for (int i = 0; i < Bm.n_ovf; ++i) {
+            const uint32_t at = Bm.ovf[2 * i], f = Bm.ovf[2 * i + 1];
+            if (h0 && fq0 == 255u && at == p0i) fq0 = f;
+            if (h1 && fq1 == 255u && at == p1i) fq1 = f;
+          }
+        }
+        touched += 8u * (uint32_t)(__popcll(__ballot(a0)) + __popcll(__ballot(a1))) + (uint32_t)(__popcll(__ballot(h0)) + __popcll(__ballot(h1)));
+        if (a0) { if (h0) found(a0, s0, fq0, n0); else missed(a0); }
+        if (a1) { if (h1) found(a1, s1, fq1, n1); else missed(a1); }
         continue;
       }
       AND_DBG(3, 1);

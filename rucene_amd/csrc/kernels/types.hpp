@@ -1,6 +1,7 @@
 // Device-visible plain structs shared by the host side of the C ABI and the kernels.
 #pragma once
 #include <stdint.h>
+#include <hip/hip_runtime.h>
 
 namespace rgpu {
 
@@ -93,6 +94,17 @@ struct PosTerm {
   int32_t phrase_pos;          // the term's position inside the phrase (PhraseQuery::build: 0, 1, 2, ...)
   int32_t query_ord;           // the term's index in the QUERY's term list (device clauses are in cost order): PhrasePositions::ord
   int32_t same_as;             // query-order index of the first term of the phrase that is this very term (itself when none before)
+  int32_t pad;
+};
+
+// A clause's doc bitmap (doc_bitmap.hpp), parallel to the DevTerm array of a conjunction launch: words == null = the clause is
+// walked through its block directory
+struct TermBitmap {
+  const uint2* words;     // {any, hi} per 32 docs
+  const uint32_t* ranks;  // postings before each word
+  const uint8_t* freqs;   // min(freq, 255) by posting index
+  const uint32_t* ovf;    // {posting index, freq} of the freqs >= 255
+  int32_t n_ovf;
   int32_t pad;
 };
 

@@ -1822,16 +1822,24 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
   // (the fixed-point kernels rank by exact totals and round to f32 afterwards: across passes that would need a ceiling in
   // their own key space — deep result pages of a >= 10-clause disjunction go through the clause-order kernel instead)
   const bool or_wide_ok = c->cfg.or_wide >= 0 && seg->d_norms && seg->n_norm_ranks > 0 && !seg->d_live && k_total <= RGPU_PASS_K;
-  if (or_wide_ok && c->cfg.or_bitmaps >= 0) {  // doc bitmaps for the dense terms of the disjunctions k_or_lazy can take
+  if (c->cfg.or_bitmaps >= 0 && c->n_sim_tables > 0) {
+    // doc bitmaps for the dense terms of the disjunctions k_or_lazy can take, and of conjunctions (k_search_and answers a
+    // candidate of such a clause with one bit instead of walking the list's blocks)
     const int64_t min_df = bitmap_min_df(seg);
     std::vector<const rgpu_term_state*> dense;
     std::vector<int32_t> dense_sim;
     for (int32_t q = 0; q < n_queries; ++q) {
       const rgpu_query& Q = queries[q];
-      if ((Q.op & 0xff) != RGPU_OP_OR || ((Q.op >> 8) & 0xff) > 1 || Q.n_terms < 10 || Q.n_must_not != 0) continue;
-      for (int i = 0; i < Q.n_terms; ++i) {
-        const rgpu_term_state& st = terms[Q.first_term + i].state;
-        if (st.doc_freq >= min_df && !seg->bitmaps.find(st.doc_start_fp)) { dense.push_back(&st); dense_sim.push_back(terms[Q.first_term + i].sim_table); }
+      const int qop = Q.op & 0xff, qopt = (Q.op >> 16) & 0xff;
+      int n_look = 0;
+      if (qop == RGPU_OP_OR) { if (or_wide_ok && ((Q.op >> 8) & 0xff) <= 1 && Q.n_terms >= 10 && Q.n_terms <= ORX_MAX_TERMS && Q.n_must_not == 0) n_look = Q.n_terms; }
+      else if (Q.n_terms + qopt + Q.n_must_not >= 2) n_look = Q.n_terms + qopt + Q.n_must_not;
+      for (int i = 0; i < n_look; ++i) {
+        const rgpu_query_term& t = terms[Q.first_term + i];
+        if (t.state.doc_freq >= min_df && !seg->bitmaps.find(t.state.doc_start_fp)) {
+          dense.push_back(&t.state);
+          dense_sim.push_back(t.sim_table >= 0 && t.sim_table < c->n_sim_tables ? t.sim_table : 0);
+        }
       }
     }
     if (!dense.empty()) { rc = ensure_bitmaps_locked(seg, dense.data(), dense_sim.data(), dense.size()); if (rc != RGPU_OK) return rc; }
@@ -2021,6 +2029,26 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
     const size_t o_tau = st.add((size_t)nq * 8);  // the per-query shared thresholds: zeroed by the same copy that brings the plan
     // ReqOptScorer's rule: one record per lead posting, query after query
     const size_t o_sp = G.req_opt ? st.add((size_t)(nq + 1) * 8) : 0;
+    // conjunctions: the doc bitmaps of the clauses behind the lead (parallel to the DevTerm array)
+    std::vector<TermBitmap> clause_bitmaps;
+    if (op == RGPU_OP_AND && c->cfg.or_bitmaps >= 0 && seg->bitmaps.size() > 0) {
+      const int64_t min_df = bitmap_min_df(seg);
+      bool any = false;
+      clause_bitmaps.assign(G.terms.size(), TermBitmap{nullptr, nullptr, nullptr, nullptr, 0, 0});
+      for (const DevQuery& q0 : G.queries) {
+        const int n_all = q0.n_terms + q0.pad + ((q0.op >> 16) & 0xff);
+        for (int i = 1; i < n_all; ++i) {
+          const DevTerm& t = G.terms[(size_t)(q0.first_term + i)];
+          if (t.df < min_df) continue;
+          const BitmapInfo* bm = seg->bitmaps.find((int64_t)t.start_fp);
+          if (!bm || !bm->usable || bm->df != t.df) continue;
+          clause_bitmaps[(size_t)(q0.first_term + i)] = TermBitmap{bm->words, bm->ranks, bm->freqs, bm->ovf, bm->n_ovf, 0};
+          any = true;
+        }
+      }
+      if (!any) clause_bitmaps.clear();
+    }
+    const size_t o_bm = clause_bitmaps.empty() ? 0 : st.add(clause_bitmaps.size() * sizeof(TermBitmap));
     std::vector<int64_t> seq_prefix;
     if (G.req_opt) {
       seq_prefix.assign((size_t)nq + 1, 0);
@@ -2037,6 +2065,7 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
     std::memcpy(c->S->h_stage.p + o_m, G.qmap.data(), (size_t)nq * 4);
     std::memset(c->S->h_stage.p + o_tau, 0, (size_t)nq * 8);
     if (G.req_opt) std::memcpy(c->S->h_stage.p + o_sp, seq_prefix.data(), (size_t)(nq + 1) * 8);
+    if (!clause_bitmaps.empty()) std::memcpy(c->S->h_stage.p + o_bm, clause_bitmaps.data(), clause_bitmaps.size() * sizeof(TermBitmap));
     HIP_TRY(hipMemcpyAsync(c->S->d_stage.p, c->S->h_stage.p, st.used, hipMemcpyHostToDevice, stream));
     HIP_TRY(c->S->d_partial_keys.reserve((size_t)items * (size_t)k, 0, stream));
     HIP_TRY(c->S->d_partial_counts.reserve((size_t)items, 0, stream));
@@ -2070,7 +2099,8 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
       auto go = [&](auto kern) {
         hipLaunchKernelGGL(kern, dim3(grid), dim3(WG_THREADS), 0, stream, sv, dq, dt, dp, nq, items, blocks_per_item, (int)k,
                            c->S->d_partial_keys.p, c->S->d_partial_counts.p, d_tau, c->S->d_touched.p,
-                           d_sp, (unsigned long long*)nullptr, d_seq, c->pass.ceil_in, dm);
+                           d_sp, (unsigned long long*)nullptr, d_seq, c->pass.ceil_in, dm,
+                           clause_bitmaps.empty() ? (const TermBitmap*)nullptr : reinterpret_cast<const TermBitmap*>(c->S->d_stage.p + o_bm));
       };
       bool has_not = false, has_opt = false;
       for (const DevQuery& q : G.queries) { has_not = has_not || q.pad != 0; has_opt = has_opt || (q.op >> 16) != 0; }
@@ -2342,7 +2372,7 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
       auto go = [&](auto kern) {
         hipLaunchKernelGGL(kern, dim3(grid), dim3(WG_THREADS), 0, stream, sv, d_q, d_t, d_ip, (int)n_queries, items, blocks_per_item, (int)k,
                            c->S->d_partial_keys.p, c->S->d_partial_counts.p, c->S->d_tau.p, c->S->d_touched.p, d_ep, c->phrase_count.p,
-                           (void*)c->phrase_docs.p, (const unsigned long long*)nullptr, (const int32_t*)nullptr);
+                           (void*)c->phrase_docs.p, (const unsigned long long*)nullptr, (const int32_t*)nullptr, (const TermBitmap*)nullptr);
       };
       if (legacy) go(k_search_and<true, false, false, false>); else go(k_search_and<false, false, false, false>);
     }

@@ -438,6 +438,20 @@ def test_lazy_disjunctions(oracle, knobs):
         _check_against_oracle(oracle, osearcher, gsearcher, handed_back + specs[:2], 10, exact=False)
         stats = ctx2.kernel_stats()
         assert stats["or_lazy_bail_queries"]["launches"] >= 2 and "k_or_wide" in stats, sorted(stats)
+        # conjunctions: a clause behind the lead whose term has a bitmap answers its candidates with one bit each (freqs beyond a
+        # byte through the overflow list), MUST_NOT and optional SHOULD clauses too — bit-exact like every conjunction
+        T, B = rucene_amd.TermQuery, rucene_amd.BooleanQuery
+        and_specs = [(oracle.OP_AND, [5, 12, 13]), (oracle.OP_AND, [9, 11, 14, 15]), (oracle.OP_AND, [12, 12, 6]), (oracle.OP_AND, [3, 15]),
+                     (oracle.OP_AND, [0, 13]), (oracle.OP_AND, [12, 13, 14, 15, 16, 18, 19]), (oracle.OP_AND, [7, 12])]
+        for k in (10, 100):
+            _check_against_oracle(oracle, osearcher, gsearcher, and_specs, k)
+        hits, totals = gsearcher.search_batch([B.build([T(9), T(5)], [], must_nots=[T(13), T(12)]), B.build([T(6)], [T(12), T(14), T(2)]),
+                                               B.build([T(10), T(12)], [T(13)], must_nots=[T(11)])], 10)
+        d, sc, total = osearcher.search_not(oracle.OP_AND, [9, 5], [13, 12], 10)
+        assert totals[0] == total and (hits[0]["doc"][:d.size] == d).all() and (hits[0]["score"][:d.size].view(np.int32) == sc.view(np.int32)).all()
+        d, sc, total = osearcher.search_opt(oracle.OP_TERM, [6], [12, 14, 2], 10)
+        assert totals[1] == total and (hits[1]["doc"][:d.size] == d).all() and (hits[1]["score"][:d.size].view(np.int32) == sc.view(np.int32)).all()
+        assert totals[2] > 0
         fp = leaf.segment.footprint()
         assert fp["doc_bitmap_terms"] >= 8 and fp["doc_bitmap_bytes"] > fp["doc_bitmap_terms"] * max_doc // 4
         leaf.segment.release_prepared_terms()
