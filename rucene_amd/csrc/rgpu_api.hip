@@ -1037,6 +1037,13 @@ static int64_t bitmap_min_df(const rgpu_segment* seg) {
   const int64_t den = d == 0 ? 64 : d;
   return std::max<int64_t>(1024, ((int64_t)seg->max_doc + den - 1) / den);
 }
+// ... and for the clauses of a conjunction (`and_bitmaps`: 0 = default 256)
+static int64_t bitmap_min_df_and(const rgpu_segment* seg) {
+  const int32_t d = seg->ctx->cfg.and_bitmaps;
+  if (d < 0) return INT64_MAX;
+  const int64_t den = d == 0 ? 256 : d;
+  return std::max<int64_t>(1024, ((int64_t)seg->max_doc + den - 1) / den);
+}
 // builds the bitmaps of the given terms that lack one (ctx mutex held; ends synchronised). One decode of the list into scratch
 // (the context's run buffer), one thread per posting, a prefix popcount: a one-off per term, ~1 ms for a 2 M-posting list.
 static int32_t ensure_bitmaps_locked(rgpu_segment* seg, const rgpu_term_state* const* sts, const int32_t* sim_tables, size_t n) {
@@ -1822,18 +1829,20 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
   // (the fixed-point kernels rank by exact totals and round to f32 afterwards: across passes that would need a ceiling in
   // their own key space — deep result pages of a >= 10-clause disjunction go through the clause-order kernel instead)
   const bool or_wide_ok = c->cfg.or_wide >= 0 && seg->d_norms && seg->n_norm_ranks > 0 && !seg->d_live && k_total <= RGPU_PASS_K;
-  if (c->cfg.or_bitmaps >= 0 && c->n_sim_tables > 0) {
+  if ((c->cfg.or_bitmaps >= 0 || c->cfg.and_bitmaps >= 0) && c->n_sim_tables > 0) {
     // doc bitmaps for the dense terms of the disjunctions k_or_lazy can take, and of conjunctions (k_search_and answers a
     // candidate of such a clause with one bit instead of walking the list's blocks)
-    const int64_t min_df = bitmap_min_df(seg);
+    const int64_t min_df_or = bitmap_min_df(seg), min_df_and = bitmap_min_df_and(seg);
     std::vector<const rgpu_term_state*> dense;
     std::vector<int32_t> dense_sim;
     for (int32_t q = 0; q < n_queries; ++q) {
       const rgpu_query& Q = queries[q];
       const int qop = Q.op & 0xff, qopt = (Q.op >> 16) & 0xff;
       int n_look = 0;
-      if (qop == RGPU_OP_OR) { if (or_wide_ok && ((Q.op >> 8) & 0xff) <= 1 && Q.n_terms >= 10 && Q.n_terms <= ORX_MAX_TERMS && Q.n_must_not == 0) n_look = Q.n_terms; }
-      else if (Q.n_terms + qopt + Q.n_must_not >= 2) n_look = Q.n_terms + qopt + Q.n_must_not;
+      int64_t min_df = INT64_MAX;
+      if (qop == RGPU_OP_OR) {
+        if (or_wide_ok && ((Q.op >> 8) & 0xff) <= 1 && Q.n_terms >= 10 && Q.n_terms <= ORX_MAX_TERMS && Q.n_must_not == 0) { n_look = Q.n_terms; min_df = min_df_or; }
+      } else if (Q.n_terms + qopt + Q.n_must_not >= 2) { n_look = Q.n_terms + qopt + Q.n_must_not; min_df = min_df_and; }
       for (int i = 0; i < n_look; ++i) {
         const rgpu_query_term& t = terms[Q.first_term + i];
         if (t.state.doc_freq >= min_df && !seg->bitmaps.find(t.state.doc_start_fp)) {
@@ -2031,8 +2040,8 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
     const size_t o_sp = G.req_opt ? st.add((size_t)(nq + 1) * 8) : 0;
     // conjunctions: the doc bitmaps of the clauses behind the lead (parallel to the DevTerm array)
     std::vector<TermBitmap> clause_bitmaps;
-    if (op == RGPU_OP_AND && c->cfg.or_bitmaps >= 0 && seg->bitmaps.size() > 0) {
-      const int64_t min_df = bitmap_min_df(seg);
+    if (op == RGPU_OP_AND && c->cfg.and_bitmaps >= 0 && seg->bitmaps.size() > 0) {
+      const int64_t min_df = bitmap_min_df_and(seg);
       bool any = false;
       clause_bitmaps.assign(G.terms.size(), TermBitmap{nullptr, nullptr, nullptr, nullptr, 0, 0});
       for (const DevQuery& q0 : G.queries) {

@@ -12,7 +12,7 @@ docs = int(os.environ.get("DOCS", "10000000"))
 seg = indexgen.build_zipf(docs, 1_000_000)
 ctx = rucene_amd.Context(profile_kernels=True, blocks_per_item=int(os.environ.get('BPI', '0')), and_blocks_per_item=int(os.environ.get('ABPI', '0')), or_window_docs=int(os.environ.get("ORW", "0")), or_dense_clauses=int(os.environ.get("ORD", "0")),
                          or_wide=int(os.environ.get("ORWIDE", "0")), or_wide_window_docs=int(os.environ.get("ORWW", "0")),
-                         or_bitmaps=int(os.environ.get("ORBM", "0")), or_lazy_cells=int(os.environ.get("ORCELLS", "0")))
+                         or_bitmaps=int(os.environ.get("ORBM", "0")), or_lazy_cells=int(os.environ.get("ORCELLS", "0")), and_bitmaps=int(os.environ.get("ANDBM", "0")))
 leaf = rucene_amd.LeafReader.from_synthetic(seg)
 if os.environ.get('NONORMS'):
     leaf.norms = None
