@@ -17,7 +17,7 @@ fi
 if [ "$WHAT" != "small" ]; then
   # out of the Infinity Cache: the 100M-doc shard
   for w in decode cold term and3 or10; do
-    DOCS=100000000 bash scripts/prof.sh $w prof_${ROUND}_${w}_big > gpurun_out/prof_${ROUND}_${w}_big.log 2>&1
+    PROF_SHORT=1 DOCS=100000000 bash scripts/prof.sh $w prof_${ROUND}_${w}_big > gpurun_out/prof_${ROUND}_${w}_big.log 2>&1
     tail -2 gpurun_out/prof_${ROUND}_${w}_big.log | cut -c1-300
   done
 fi

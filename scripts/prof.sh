@@ -6,8 +6,10 @@ W=${1:-term}; TAG=${2:-prof}
 OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python $R/scripts/run_workload.py $W 5 > $OUT/trace.log 2>&1
+if [ "${PROF_SHORT:-0}" != "1" ]; then  # (the 100 M-doc workloads take the trace and the two HBM passes only: every pass rebuilds the shard)
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $OUT/pmc1 -o p -- python $R/scripts/run_workload.py $W 2 > $OUT/pmc1.log 2>&1
 rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc2 -o p -- python $R/scripts/run_workload.py $W 2 > $OUT/pmc2.log 2>&1
+fi
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc3 -o p -- python $R/scripts/run_workload.py $W 2 > $OUT/pmc3.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc4 -o p -- python $R/scripts/run_workload.py $W 2 > $OUT/pmc4.log 2>&1
 cd $R
