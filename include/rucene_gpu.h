@@ -52,11 +52,15 @@ typedef struct rgpu_segment rgpu_segment;
 
 /* Knobs (the reference has plain config structs only: SURVEY.md §5). Zero-initialise for defaults.
  * Work-partitioning knobs — blocks_per_item, and_blocks_per_item, or_window_docs, or_dense_clauses, or_wide_window_docs,
- * profile_kernels: results never depend on them (tests/test_gpu_parity.py::test_work_partitioning_knobs_do_not_change_answers).
+ * or_lazy_cells, and_bitmaps, profile_kernels: results never depend on them
+ * (tests/test_gpu_parity.py::test_work_partitioning_knobs_do_not_change_answers; a conjunction clause answered through its
+ * doc bitmap yields the same freq and the same f32 score as one walked through its blocks).
  * Knobs that select another ARITHMETIC and so may change scores (never doc-id sets beyond the documented tolerance, never
  * hit counts): or_wide (-1: f32 clause-order sums instead of order-free fixed-point sums for >= 10 SHOULD clauses),
  * req_opt_rule (-1: scores >= the reference's for MUST + SHOULD trees), raw_norms (1: no score tables; also routes
- * >= 10-clause disjunctions to the clause-order kernel, as or_wide = -1 does). */
+ * >= 10-clause disjunctions to the clause-order kernel, as or_wide = -1 does), or_bitmaps (which of the two fixed-point
+ * kernels takes a 10..16-clause disjunction: both sum the same fixed-point steps, but a posting's score is rounded to a step
+ * from a table entry in one and from a reciprocal in the other — totals may differ by a few steps of 2^-e, far inside 1e-5). */
 typedef struct rgpu_config {
   int32_t abi_version;          /* must be RGPU_ABI_VERSION */
   int32_t blocks_per_item;      /* 128-posting blocks per wave work item in the TERM kernel (0 = auto: 8..512 by batch size) */

@@ -307,8 +307,9 @@ def test_error_codes(ctx):
     assert e.value.status == -4
 
 
-@pytest.mark.parametrize("knobs", [dict(blocks_per_item=3, and_blocks_per_item=1, or_window_docs=256),
-                                   dict(blocks_per_item=64, and_blocks_per_item=7, or_window_docs=4096)])
+@pytest.mark.parametrize("knobs", [dict(blocks_per_item=3, and_blocks_per_item=1, or_window_docs=256, and_bitmaps=-1),
+                                   dict(blocks_per_item=64, and_blocks_per_item=7, or_window_docs=4096, and_bitmaps=16),
+                                   dict(and_bitmaps=4096)])
 def test_work_partitioning_knobs_do_not_change_answers(oracle, knobs):
     """Items per query / lead blocks per item / docs per OR window only change how the work is cut up."""
     import rucene_amd
