@@ -12,6 +12,11 @@
 //   freqs[doc_freq + pad]             min(freq, 255) by posting index
 //   ovf[2 * n_ovf]                    {posting index, freq} of the postings whose freq is >= 255 (Rucene clamps term freqs
 //                                     to 10 when it writes an index; a Lucene-written one may hold such a posting)
+//   nib[ceil(max_doc / 8) + pad]      only for a term that holds at least one doc in BITMAP_NIBBLE_DENSITY: four bits per doc —
+//                                     0 = the list does not hold the doc, 1..14 = its freq, 15 = "look the freq up through
+//                                     ranks / freqs". Membership AND freq in one 4-byte gather instead of a word + rank
+//                                     gather followed by a freq gather: the conjunction kernel's two memory round trips per
+//                                     clause become one (max_doc / 2 bytes per term)
 // (the sketch only sharpens a bound: a clause that names the term under another similarity table treats every posting as hi)
 // i.e. a random-access view of (doc -> freq) for the lists that hold ~90 % of a Zipfian disjunction's postings: "is doc d
 // in the list" is one bit, and a whole window's membership is one coalesced read of 4 bytes per 32 docs.
@@ -24,6 +29,10 @@ namespace rgpu {
 
 constexpr int BITMAP_OVF_CAP = 4096;   // more postings with freq >= 255 than this: the term gets no bitmap
 constexpr float BITMAP_HI_CUT = 0.72f;  // ~ the top fifth of a BM25 list (k1 1.2, b 0.75): freq >= 3 in a doc of average length
+#ifndef RGPU_NIBBLE_DENSITY
+#define RGPU_NIBBLE_DENSITY 128  // (3-term batch, k_search_and: 32 -> 0.484 ms, 128 -> 0.474, 512 -> 0.484; without the array 0.505)
+#endif
+constexpr int BITMAP_NIBBLE_DENSITY = RGPU_NIBBLE_DENSITY;  // a term holding >= 1 doc in this many also gets the four-bits-per-doc array
 constexpr int BITMAP_PAD_WORDS = 2048;  // zero words behind the last real one (>= the widest window of k_or_lazy in words)
 
 struct BitmapStats {
@@ -38,7 +47,8 @@ struct BitmapStats {
 __global__ __launch_bounds__(256) void k_bitmap_fill(const int32_t* __restrict__ docs, const int32_t* __restrict__ freqs, int64_t df,
                                                      int32_t max_doc, const uint8_t* __restrict__ norms, const float* __restrict__ cache,
                                                      const uint8_t* __restrict__ rank_to_norm, uint2* __restrict__ words,
-                                                     uint8_t* __restrict__ freq8, uint32_t* __restrict__ ovf, BitmapStats* __restrict__ stats) {
+                                                     uint8_t* __restrict__ freq8, uint32_t* __restrict__ ovf, BitmapStats* __restrict__ stats,
+                                                     uint32_t* __restrict__ nib) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool ok = i < df;
   const int32_t d = ok ? docs[i] : 0;
@@ -54,6 +64,7 @@ __global__ __launch_bounds__(256) void k_bitmap_fill(const int32_t* __restrict__
       hi = !(qf / (qf + cv) < BITMAP_HI_CUT);  // (a NaN — 0 / 0 — counts as hi: never under-estimate)
     }
     if (hi) atomicOr(&words[d >> 5].y, 1u << (d & 31));
+    if (nib != nullptr) atomicOr(&nib[d >> 3], (f >= 1u && f <= 14u ? f : 15u) << (4 * (d & 7)));  // (a freq of 0 — corrupt — goes the long way too)
   }
   if (ok) freq8[i] = (uint8_t)(f < 255u ? f : 255u);
   if (ok && f >= 255u) {

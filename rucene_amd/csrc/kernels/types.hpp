@@ -104,6 +104,7 @@ struct TermBitmap {
   const uint32_t* ranks;  // postings before each word
   const uint8_t* freqs;   // min(freq, 255) by posting index
   const uint32_t* ovf;    // {posting index, freq} of the freqs >= 255
+  const uint32_t* nib;    // four bits per doc (0 absent, 1..14 the freq, 15 look it up), or null
   int32_t n_ovf;
   int32_t pad;
 };

@@ -175,7 +175,7 @@ struct rgpu_ctx {
 
 struct TermInfo { uint32_t dir_base; int32_t nblocks; int32_t df; uint64_t pn_base; uint64_t bs_base; bool norms; };
 // a term's doc bitmap (kernels/doc_bitmap.hpp): one allocation [words | ranks | ovf | stats | freqs]
-struct BitmapInfo { uint2* words; uint32_t* ranks; uint8_t* freqs; uint32_t* ovf; int32_t n_ovf; int32_t max_freq; int32_t df; int32_t sim_table; bool usable; };
+struct BitmapInfo { uint2* words; uint32_t* ranks; uint8_t* freqs; uint32_t* ovf; uint32_t* nib; int32_t n_ovf; int32_t max_freq; int32_t df; int32_t sim_table; bool usable; };
 
 // doc_start_fp -> TermInfo of the prepared terms (host/flat_fp_map.hpp: two look-ups per clause per batch)
 using PreparedMap = rucene::FlatFpMap<TermInfo>;
@@ -1055,7 +1055,10 @@ static int32_t ensure_bitmaps_locked(rgpu_segment* seg, const rgpu_term_state* c
     if (st.doc_freq < 2 || seg->bitmaps.find(st.doc_start_fp)) continue;
     const size_t df = (size_t)st.doc_freq;
     const size_t o_ranks = nw_pad * 8, o_ovf = o_ranks + nw_pad * 4, o_stats = o_ovf + (size_t)BITMAP_OVF_CAP * 8;
-    const size_t o_freqs = o_stats + 64, total = o_freqs + ((df + 127) & ~size_t(63));
+    const size_t o_freqs = o_stats + 64, o_nib = o_freqs + ((df + 127) & ~size_t(63));
+    // (the four-bits-per-doc array of the densest terms: conjunctions answer a candidate with ONE gather from it)
+    const bool with_nib = (int64_t)st.doc_freq * BITMAP_NIBBLE_DENSITY >= (int64_t)seg->max_doc;
+    const size_t total = o_nib + (with_nib ? (nw_pad * 4 + 64) * 4 : 0);
     uint8_t* block = nullptr;
     HIP_TRY(hipMalloc(&block, total));
     seg->bitmap_allocs.push_back(block);
@@ -1066,6 +1069,7 @@ static int32_t ensure_bitmaps_locked(rgpu_segment* seg, const rgpu_term_state* c
     info.ranks = reinterpret_cast<uint32_t*>(block + o_ranks);
     info.ovf = reinterpret_cast<uint32_t*>(block + o_ovf);
     info.freqs = block + o_freqs;
+    info.nib = with_nib ? reinterpret_cast<uint32_t*>(block + o_nib) : nullptr;
     info.df = st.doc_freq;
     BitmapStats* d_stats = reinterpret_cast<BitmapStats*>(block + o_stats);
     HIP_TRY(hipMemsetAsync(block, 0, total, c->stream));
@@ -1079,7 +1083,7 @@ static int32_t ensure_bitmaps_locked(rgpu_segment* seg, const rgpu_term_state* c
       TimedLaunch tl(c, c->stream, "k_bitmap_build", (int64_t)df);
       hipLaunchKernelGGL(k_bitmap_fill, dim3((unsigned)((df + 255) / 256)), dim3(256), 0, c->stream, docs, freqs, (int64_t)df, seg->max_doc,
                          (const uint8_t*)seg->d_norms, (const float*)(c->sim_tables.p + (size_t)sim_tables[i] * 257),
-                         seg->n_norm_ranks > 0 ? (const uint8_t*)seg->d_rank_to_norm : (const uint8_t*)nullptr, info.words, info.freqs, info.ovf, d_stats);
+                         seg->n_norm_ranks > 0 ? (const uint8_t*)seg->d_rank_to_norm : (const uint8_t*)nullptr, info.words, info.freqs, info.ovf, d_stats, info.nib);
       const int64_t n_scan = n_words + 1;  // ranks[n_words] = the list's size
       hipLaunchKernelGGL(k_bitmap_popc, dim3((unsigned)((n_scan + 255) / 256)), dim3(256), 0, c->stream, info.words, n_scan, info.ranks);
       const int64_t n_tiles = (n_scan + SCAN_TILE - 1) / SCAN_TILE;
@@ -2043,7 +2047,7 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
     if (op == RGPU_OP_AND && c->cfg.and_bitmaps >= 0 && seg->bitmaps.size() > 0) {
       const int64_t min_df = bitmap_min_df_and(seg);
       bool any = false;
-      clause_bitmaps.assign(G.terms.size(), TermBitmap{nullptr, nullptr, nullptr, nullptr, 0, 0});
+      clause_bitmaps.assign(G.terms.size(), TermBitmap{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0});
       for (const DevQuery& q0 : G.queries) {
         const int n_all = q0.n_terms + q0.pad + ((q0.op >> 16) & 0xff);
         for (int i = 1; i < n_all; ++i) {
@@ -2051,7 +2055,7 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
           if (t.df < min_df) continue;
           const BitmapInfo* bm = seg->bitmaps.find((int64_t)t.start_fp);
           if (!bm || !bm->usable || bm->df != t.df) continue;
-          clause_bitmaps[(size_t)(q0.first_term + i)] = TermBitmap{bm->words, bm->ranks, bm->freqs, bm->ovf, bm->n_ovf, 0};
+          clause_bitmaps[(size_t)(q0.first_term + i)] = TermBitmap{bm->words, bm->ranks, bm->freqs, bm->ovf, bm->nib, bm->n_ovf, 0};
           any = true;
         }
       }
