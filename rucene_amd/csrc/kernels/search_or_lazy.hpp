@@ -68,12 +68,13 @@ struct LazyClause {
   const uint32_t* ranks;
   const uint8_t* freqs;
   const uint32_t* ovf;   // {posting index, freq} pairs, n_ovf of them
+  const uint32_t* nib;   // four bits per doc (0 absent, 1..14 the freq, 15 look it up), or null
   int32_t n_ovf;
   uint32_t ub;           // fixed-point upper bound of one posting's score
   uint32_t ub_lo;        // ... of a posting outside the bitmap's `hi` half (== ub when the sketch does not apply)
   float wk;              // weight * (k1 + 1)
   int32_t sim_table;
-  int32_t pad;
+  int32_t pad[3];
 };
 
 struct LazyRun {  // one walked clause: its {doc, score} run (k_score_terms), closed by 64 sentinel entries
@@ -139,13 +140,14 @@ __global__ __launch_bounds__(LZ_THREADS, RGPU_LZ_MIN_WAVES) void k_or_lazy(SegVi
   const int32_t first_doc = win0 * W;
 
   // ---- lazy clauses: lane c holds clause c's constants
-  uint64_t l_words = 0, l_ranks = 0, l_freqs = 0;
+  uint64_t l_words = 0, l_ranks = 0, l_freqs = 0, l_nib = 0;
   uint32_t l_ub = 0u, l_ublo = 0u;
   uint32_t l_ubpre = 0u, l_dpre = 0u;  // ub, and ub - ub_lo, of lazy clauses 0 .. lane (sorted by ub descending)
   float l_wk = 0.f;
   if (lane < nl) {
     const LazyClause* L = lazies + Q.first_lazy + lane;
     l_words = (uint64_t)(uintptr_t)L->words; l_ranks = (uint64_t)(uintptr_t)L->ranks; l_freqs = (uint64_t)(uintptr_t)L->freqs;
+    l_nib = (uint64_t)(uintptr_t)L->nib;
     l_ub = L->ub; l_ublo = L->ub_lo; l_wk = L->wk;
   }
   {
@@ -160,6 +162,7 @@ __global__ __launch_bounds__(LZ_THREADS, RGPU_LZ_MIN_WAVES) void k_or_lazy(SegVi
   }
   const uint32_t ub_sum = Q.ub_sum, ub_lo_sum = Q.ub_lo_sum;
   const uint32_t ub_last = (uint32_t)readlane((int)l_ub, max(nl - 1, 0));
+  const bool all_nib = !__ballot(lane < nl && l_nib == 0);  // every lazy clause has the four-bits-per-doc array (wave-uniform)
   for (int c = wave; c < nl; c += LZ_WAVES)
     caches[c * 64 + lane] = seg.sim_tables[(size_t)lazies[Q.first_lazy + c].sim_table * 257 + seg.rank_to_norm[lane]];
   for (int i = lane; i < W / 32; i += 64) { tw[i] = make_uint2(0u, 0u); uw[i] = make_uint2(0u, 0u); }
@@ -241,6 +244,36 @@ __global__ __launch_bounds__(LZ_THREADS, RGPU_LZ_MIN_WAVES) void k_or_lazy(SegVi
     const uint32_t nr = on ? (uint32_t)seg.norms[doc] : 0u;
     const uint32_t thr = threshold();
     bool alive = on;
+    if (all_nib) {
+      // one gather per clause: "absent" or the posting's freq — the exact total after ONE memory round trip. A 15 (freq 15 or
+      // more) sends the whole group of candidates through the general path below.
+      uint32_t exact = total;
+      bool odd = false;
+      for (int c0 = 0; c0 < nl; c0 += 4) {
+        uint32_t v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          v[j] = (((gwords)(uintptr_t)readlane64(l_nib, min(c0 + j, nl - 1)))[on ? doc >> 3 : 0u] >> (4u * (doc & 7u))) & 15u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (c0 + j >= nl) continue;  // wave-uniform
+          const int c = c0 + j;
+          odd = odd || (on && v[j] == 15u);
+          const float qf = (float)(int32_t)v[j];
+          const float wk = __int_as_float(readlane(__float_as_int(l_wk), c));
+          const uint32_t sc = to_fixed(wk * qf * __builtin_amdgcn_rcpf(qf + caches[c * 64 + nr]));
+          if (v[j] != 0u) exact += sc;
+        }
+      }
+      if (!__ballot(odd)) {
+        const uint64_t key = (on && exact >= thr) ? ((uint64_t)exact << 32) | (uint32_t)~doc : 0ull;
+        hist_count(key != 0ull, exact);
+        if (__ballot(key > tau)) topk_offer<WIDE>(top, key, tau, k, lane, floor);
+        LZ_STAMP(td1a);
+        LZ_ADD(5, td1a - td0);
+        return;
+      }
+    }
     for (int c0 = 0; c0 < nl; c0 += 4) {
       uint32_t wd[4], wh[4], rk[4];
 #pragma unroll

@@ -1294,7 +1294,7 @@ static int32_t search_or_lazy_group(rgpu_segment* seg, Group& G, int32_t k, HitO
   while (lz_lds_bytes(W, C) > 160u * 1024u && C > W / 32) C -= 64;
 
   if (!seg->empty_bitmap) {
-    const size_t bytes = ((((size_t)seg->max_doc + 31) / 32 + 1 + BITMAP_PAD_WORDS + 63) & ~size_t(63)) * 8;
+    const size_t bytes = ((((size_t)seg->max_doc + 31) / 32 + 1 + BITMAP_PAD_WORDS + 63) & ~size_t(63)) * 16 + 256;  // (as a four-bits-per-doc array too)
     HIP_TRY(hipMalloc(&seg->empty_bitmap, bytes));
     HIP_TRY(hipMemsetAsync(seg->empty_bitmap, 0, bytes, stream));
   }
@@ -1389,6 +1389,7 @@ static int32_t search_or_lazy_group(rgpu_segment* seg, Group& G, int32_t k, HitO
       L.ranks = reinterpret_cast<const uint32_t*>(seg->empty_bitmap);
       L.freqs = seg->empty_bitmap;
       L.ovf = reinterpret_cast<const uint32_t*>(seg->empty_bitmap);
+      L.nib = reinterpret_cast<const uint32_t*>(seg->empty_bitmap);
       L.sim_table = G.terms[(size_t)wq.first_term].sim_table;
       mine[0] = L;
       n_cands = 1;
@@ -1397,6 +1398,7 @@ static int32_t search_or_lazy_group(rgpu_segment* seg, Group& G, int32_t k, HitO
       const DevTerm& t = G.terms[(size_t)(wq.first_term + cands[j].i)];
       LazyClause L{};
       L.words = cands[j].bm->words; L.ranks = cands[j].bm->ranks; L.freqs = cands[j].bm->freqs; L.ovf = cands[j].bm->ovf;
+      L.nib = cands[j].bm->nib;
       L.n_ovf = cands[j].bm->n_ovf;
       L.sim_table = t.sim_table;
       const double k1 = (double)c->sim_k1[(size_t)t.sim_table];
