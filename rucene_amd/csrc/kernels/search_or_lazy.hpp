@@ -45,7 +45,11 @@ constexpr int LZ_MAX_LAZY = 6;    // bitmap clauses per query (register budget: 
 constexpr int LZ_PREFETCH = 8;   // run heads requested at the start of a window (two VGPRs each)
 constexpr int LZ_QUEUE = 128;     // candidate queue entries (up to 63 waiting + 64 pushed at once)
 constexpr int LZ_STEP_DOCS = 2048;  // one bitmap word per lane
-constexpr int LZ_HIST = 128;      // buckets of the per-query histogram of finished totals (bucket = total >> 24)
+#ifndef RGPU_LZ_HIST_SHIFT
+#define RGPU_LZ_HIST_SHIFT 24
+#endif
+constexpr int LZ_HIST_SHIFT = RGPU_LZ_HIST_SHIFT;  // a bucket of the per-query histogram of finished totals = total >> this
+constexpr int LZ_HIST = 1 << (31 - LZ_HIST_SHIFT);  // 128 buckets (a total is below 2^31)
 constexpr int LZ_FLAG_BAIL = 2;   // a window did not fit (-> k_or_wide)
 
 #ifndef RGPU_LZ_MIN_WAVES  // wavefronts per SIMD the register allocation aims at (LDS: 12 KB per wavefront at 16384-doc windows -> 3)
@@ -198,22 +202,25 @@ __global__ __launch_bounds__(LZ_THREADS, RGPU_LZ_MIN_WAVES) void k_or_lazy(SegVi
   shared.fold(shared.peek(), tau, floor);
   uint32_t* const my_hist = hist + (size_t)q * LZ_HIST;
   // k docs of this query (scored by any wavefront) have totals at or above the lower edge of the highest bucket b whose
-  // suffix count reaches k: (b << 24) bounds the k-th best from below. x1 / x0: the counts of buckets 127 - lane / 63 - lane.
-  auto hist_fold = [&](uint32_t x1, uint32_t x0) __attribute__((always_inline)) {
-    const int s1 = wave_incl_scan((int)x1);
-    const int s0 = wave_incl_scan((int)x0) + readlane(s1, 63);
-    const uint64_t m1 = __ballot(s1 >= k), m0 = __ballot(s0 >= k);
-    int b = -1;
-    if (m1) b = 127 - (int)__builtin_ctzll(m1);
-    else if (m0) b = 63 - (int)__builtin_ctzll(m0);
+  // suffix count reaches k: (b << LZ_HIST_SHIFT) bounds the k-th best from below. x[j]: the count of bucket LZ_HIST - 1 - 64 j - lane.
+  constexpr int HIST_REGS = LZ_HIST / 64;
+  auto hist_fold = [&](const uint32_t (&x)[HIST_REGS]) __attribute__((always_inline)) {
+    int above = 0, b = -1;
+#pragma unroll
+    for (int j = 0; j < HIST_REGS; ++j) {
+      const int sj = wave_incl_scan((int)x[j]) + above;
+      const uint64_t m = __ballot(sj >= k);
+      if (b < 0 && m) b = LZ_HIST - 1 - 64 * j - (int)__builtin_ctzll(m);
+      above = readlane(sj, 63);
+    }
     if (b > 0) {
-      const uint64_t edge = (uint64_t)((uint32_t)b << 24) << 32;
+      const uint64_t edge = (uint64_t)((uint32_t)b << LZ_HIST_SHIFT) << 32;
       if (edge > floor) floor = edge;
       if (floor > tau) tau = floor;
     }
   };
   auto hist_count = [&](bool counted, uint32_t total) __attribute__((always_inline)) {
-    if (counted) atomicAdd(my_hist + (total >> 24), 1u);  // (a total is below 2^31)
+    if (counted) atomicAdd(my_hist + (total >> LZ_HIST_SHIFT), 1u);  // (a total is below 2^31)
   };
   auto threshold = [&]() -> uint32_t { return max(1u, (uint32_t)(tau >> 32)); };
 #ifdef RGPU_LZ_TIME
@@ -355,8 +362,9 @@ __global__ __launch_bounds__(LZ_THREADS, RGPU_LZ_MIN_WAVES) void k_or_lazy(SegVi
     const int32_t w0 = win * W;
     const int32_t w1 = min(seg.max_doc, w0 + W);
     const uint64_t seen = shared.peek();
-    const uint32_t hx1 = __hip_atomic_load(my_hist + (127 - lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t hx0 = __hip_atomic_load(my_hist + (63 - lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t hx[HIST_REGS];
+#pragma unroll
+    for (int j = 0; j < HIST_REGS; ++j) hx[j] = __hip_atomic_load(my_hist + (LZ_HIST - 1 - 64 * j - lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // ---- loads first: the lazy clauses' {any, hi} bitmap words of the window's first four 2048-doc steps (clauses 0 .. 3; a
     // query with more takes the others step by step) — they arrive while pass 1 runs; a step's slot is refilled with the words
     // of the step four further on as soon as the step is done
@@ -449,7 +457,7 @@ __global__ __launch_bounds__(LZ_THREADS, RGPU_LZ_MIN_WAVES) void k_or_lazy(SegVi
       wave_sync();
     }
     shared.fold(seen, tau, floor);
-    hist_fold(hx1, hx0);
+    hist_fold(hx);
     LZ_STAMP(t2);
     // ---- the lazy clauses' bitmap words, 2048 docs at a time: total_hits, the unions for the cell scan, and the docs that lazy
     // lists alone could lift into the top-k
