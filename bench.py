@@ -79,18 +79,19 @@ def profiled_traffic(kernel, tag):
         return {"bytes": sum(x["bytes"] for x in parts), "source": parts[0]["source"]}
     best = None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "%s_rocprofv3_summary.txt" % tag))):
-        fetch = write = None
+        fetch, write = {}, {}   # per kernel line (a name may stand for several instantiations / kernels: k_skip_dir<1>, <2>; k_scan_*): summed
         for line in open(path):
             if kernel not in line:
                 continue
+            name = line.split("  ")[1] if line.startswith("  ") else line
             m = re.search(r"FETCH_SIZE=([0-9.e+]+)", line)
             if m:
-                fetch = float(m.group(1))
+                fetch[name.strip()] = float(m.group(1))
             m = re.search(r"WRITE_SIZE=([0-9.e+]+)", line)
             if m:
-                write = float(m.group(1))
-        if fetch is not None and write is not None:
-            best = {"bytes": (2.0 * fetch + write) * 1024.0, "source": os.path.relpath(path, ROOT)}
+                write[name.strip()] = float(m.group(1))
+        if fetch and write:
+            best = {"bytes": (2.0 * sum(fetch.values()) + sum(write.values())) * 1024.0, "source": os.path.relpath(path, ROOT)}
     return best
 
 
@@ -480,7 +481,7 @@ def main():
                "postings_decoded_per_sec": total / (ms * 1e-3),
                "doc_file_bytes_of_these_terms": file_bytes, "upload_s_pcie": upload_s,
                "hbm_footprint": fp, "hbm_bytes_held_per_doc_file_byte": (fp["doc_file_bytes"] + held) / max(1, fp["doc_file_bytes"]),
-               "roofline": roofline("k_skip_dir + k_block_headers + k_scan_rows + k_prepare_blocks + k_decode_terms", ms, b, None, tag,
+               "roofline": roofline("k_skip_dir + k_block_headers + k_scan_ + k_prepare_blocks", ms, b, None, tag,
                                     "the terms' .doc bytes (postings and skip data) in + 8 B per posting out; kernel_ms = the kernels summed")}
         seg2.close()
         del d_docs, d_freqs
