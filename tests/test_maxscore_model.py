@@ -1,4 +1,6 @@
-"""Executable specification of the MaxScore pruning planned for the OR path — a numpy model, no GPU code.
+"""Executable specification of MaxScore pruning for the OR path — a numpy model, no GPU code. (The GPU kernel built on the idea is
+k_or_lazy, csrc/kernels/search_or_lazy.hpp: its non-essential clauses are the ones with doc bitmaps, and its candidate test uses the
+bounds of the clauses a doc is actually in; this model keeps the textbook form.)
 
   1. theta0 = a LOWER bound of the final k-th best score: the k-th best partial score over the docs of one clause (any k docs'
      full scores are at least their partial scores when weights are non-negative).
