@@ -79,7 +79,8 @@ typedef struct rgpu_config {
                                    reference's) */
   int32_t or_bitmaps;           /* doc bitmaps for dense terms + k_or_lazy for the >= 10-clause disjunctions that name one
                                    (kernels/search_or_lazy.hpp): 0 = terms holding >= 1 doc in 64 (default), n > 0 = >= 1 doc in n,
-                                   -1 = off (k_or_wide walks every clause). A bitmap costs 3 max_doc / 8 + doc_freq bytes of HBM */
+                                   -1 = off (k_or_wide walks every clause). A bitmap costs 3 max_doc / 8 + doc_freq bytes of HBM (+ max_doc / 2
+                                   for a term that holds a doc in 128 or more: four bits per doc — absent / the freq) */
   int32_t or_lazy_cells;        /* accumulator cells (touched docs) per window of k_or_lazy (0 = default 512; 512..4096) */
   int32_t and_bitmaps;          /* conjunctions: a clause behind the lead whose term has a doc bitmap answers a candidate with one bit
                                    instead of a walk through its blocks. 0 = terms holding >= 1 doc in 256 get a bitmap (default;
