@@ -14,7 +14,9 @@
 // and block headers with ONE workgroup: 3.4 ms for the 20 M-posting head term of the 100 M-doc shard, whatever else ran):
 //   k_skip_dir<1,2>  one wavefront per 1 KB of level-0 bytes: parallel VInt parse; a chunk's position in the value stream
 //                    and the running sums before it come from the chunks in front of it: pass 1 leaves every chunk's
-//                    {count, sums}, pass 2 adds up the ones in front and writes the directory
+//                    {count, sums}, pass 2 adds up the ones in front and writes the directory; for a term of more than 64
+//                    chunks k_skip_groups runs in between: 64 chunks' aggregates become one, so that a chunk of the longest
+//                    term looks back over n / 64 / 64 + 1 wavefront-wide rounds instead of n / 64
 //   k_block_headers  one lane per block: header bytes -> directory header word + the block's rows in the store; every skip
 //                    pointer checked against the block sizes
 //   k_scan_*         exclusive prefix sum of the row counts -> each block's place in the store (one dense region per call)
@@ -34,6 +36,11 @@ namespace rgpu {
 constexpr int PREP_THREADS = 256;
 constexpr int PREP_WAVES = PREP_THREADS / 64;
 constexpr int SKIP_CHUNK_BYTES = 1024;     // level-0 bytes per wavefront (16 per lane)
+#ifndef RGPU_SKIP_GROUP
+#define RGPU_SKIP_GROUP 64  // (a build with 1 or 2 here walks the grouped look-back on test-sized terms)
+#endif
+constexpr int SKIP_GROUP = RGPU_SKIP_GROUP;  // chunks per group aggregate; a term of at most this many chunks looks back directly
+static_assert(SKIP_GROUP >= 1 && SKIP_GROUP <= 64, "a group is scanned by one wavefront");
 constexpr int PREP_BLOCKS_PER_ITEM = 32;
 constexpr int SCAN_TILE = 2048;            // row counts per workgroup of the prefix sum (8 per thread)
 
@@ -78,8 +85,15 @@ static_assert(sizeof(SkipAgg) == 32, "one aggregate per 32 bytes");
 // bytes a level-0 entry can take: vint docDelta <= 5, vlong docFpDelta (a block is < 16 KiB) <= 3; positions: + vlong
 // posFpDelta <= 9, vint posBufferUpto (< 128) 1
 __host__ __device__ constexpr int skip_entry_max_bytes(bool positions) { return positions ? 18 : 8; }
+// A term whose level 0 fits SKIP_SMALL_BYTES (16 entries; 7 with positions: df < 2176 / 1024 — nine terms in ten of a Zipf
+// vocabulary) is parsed by ONE LANE of k_skip_terms and takes no chunk: a wavefront per term for a few dozen bytes made
+// k_skip_dir a launch of 330 k two-microsecond wavefronts on the 100 M-doc shard, most of its time spent starting them.
+constexpr int SKIP_SMALL_BYTES = 128;
+__host__ __device__ inline bool skip_is_small(int32_t n_entries, bool positions) {
+  return n_entries * skip_entry_max_bytes(positions) <= SKIP_SMALL_BYTES;
+}
 __host__ __device__ inline int64_t skip_chunks(int32_t n_entries, bool positions) {
-  return n_entries <= 0 ? 1 : ((int64_t)n_entries * skip_entry_max_bytes(positions) + SKIP_CHUNK_BYTES - 1) / SKIP_CHUNK_BYTES;
+  return skip_is_small(n_entries, positions) ? 0 : ((int64_t)n_entries * skip_entry_max_bytes(positions) + SKIP_CHUNK_BYTES - 1) / SKIP_CHUNK_BYTES;
 }
 
 __device__ __forceinline__ uint32_t pick4(const uint32_t (&v)[4], uint32_t i) {  // v[i & 3] without a register-array index
@@ -87,14 +101,139 @@ __device__ __forceinline__ uint32_t pick4(const uint32_t (&v)[4], uint32_t i) { 
   return (i & 2u) ? hi : lo;
 }
 
+__host__ __device__ inline int64_t skip_groups(int64_t n_chunks_of_term) { return (n_chunks_of_term + SKIP_GROUP - 1) / SKIP_GROUP; }
+
+// One lane per term: where its level 0 starts (skip_reader.rs:481-509: a vlong byte length in front of each of the levels
+// L-1 .. 1; -1 when the lengths lead out of the file) — up to six dependent loads which every chunk of the term used to walk
+// again in both passes of k_skip_dir —, the directory words no skip entry writes, and, for a SMALL term, its whole level 0:
+// the lane copies SKIP_SMALL_BYTES into LDS (dword-interleaved across the lanes: lane L's dword i is word 64 i + L, so the
+// lanes' serial walks do not collide on banks) and reads entry after entry (skip_reader.rs:431-453, 513-539).
+__global__ __launch_bounds__(PREP_THREADS) void k_skip_terms(const uint8_t* __restrict__ doc, int64_t doc_len, const PrepTerm* __restrict__ terms,
+                                                             int n_terms, int64_t* __restrict__ l0s, int32_t* dir_last, uint32_t* dir_off,
+                                                             uint64_t* dir_pos, int* err) {
+  __shared__ uint32_t slab[PREP_WAVES][(SKIP_SMALL_BYTES / 4) * 64];
+  const int i = (int)(blockIdx.x * PREP_THREADS + threadIdx.x);
+  if (i >= n_terms) return;
+  const int lane = lane_id();
+  const PrepTerm T = terms[i];
+  int64_t l0 = T.n_entries > 0 ? T.skip_fp : -1;
+  for (int lvl = T.n_levels - 1; lvl >= 1 && l0 >= 0; --lvl) {
+    int n;
+    const uint64_t len = read_vlong_serial(doc + l0, &n);
+    l0 += n + (int64_t)len;
+    if (l0 >= doc_len) l0 = -1;
+  }
+  l0s[i] = l0;
+  dir_off[T.dir_base] = 0;
+  if (dir_pos) dir_pos[T.dir_base] = 0ull;
+  if (T.nblocks > T.n_entries && T.nblocks > 0) dir_last[T.dir_base + T.nblocks - 1] = DIR_SENTINEL_DOC;  // df % 128 == 0
+  if (T.n_entries <= 0 || !skip_is_small(T.n_entries, dir_pos != nullptr)) return;
+  if (l0 < 0) { flag_err(err, -4, 1); return; }
+  uint32_t* const my = slab[wave_id()] + lane;
+#pragma unroll
+  for (int k = 0; k < SKIP_SMALL_BYTES / 16; ++k) {  // (the device copy of .doc is zero-padded for 8 KB past doc_len)
+    const uint4 w = load16_unaligned(doc + l0 + 16 * k);
+    my[64 * (4 * k)] = w.x; my[64 * (4 * k + 1)] = w.y; my[64 * (4 * k + 2)] = w.z; my[64 * (4 * k + 3)] = w.w;
+  }
+  int p = 0;
+  bool over = false;
+  auto vnum = [&](int max_bytes) -> uint32_t {  // VInt / the low 32 bits of a VLong (pointers of a < 4 GiB term, like k_skip_dir)
+    uint64_t v = 0;
+    for (int k = 0; k < max_bytes; ++k) {
+      if (p >= SKIP_SMALL_BYTES) { over = true; break; }
+      const uint32_t b = (my[64 * (p >> 2)] >> (8 * (p & 3))) & 0xffu;
+      ++p;
+      v |= (uint64_t)(b & 0x7fu) << (7 * k);
+      if (!(b & 0x80u)) break;
+    }
+    return (uint32_t)v;
+  };
+  uint32_t run_doc = 0, run_fp = 0, run_pos = 0;
+  for (int e = 0; e < T.n_entries; ++e) {
+    run_doc += vnum(5);                                               // skip_doc += delta (skip_reader.rs:530)
+    run_fp += vnum(9);                                                // doc_pointer += delta (:434)
+    dir_last[T.dir_base + e] = (int32_t)run_doc;
+    dir_off[T.dir_base + e + 1] = run_fp;
+    if (dir_pos) {
+      run_pos += vnum(9);                                             // pos_pointer += delta
+      const uint32_t upto = vnum(5);                                  // posBufferUpto: absolute
+      if (upto >= 128u) flag_err(err, -4, 4);
+      dir_pos[T.dir_base + e + 1] = (uint64_t)run_pos | ((uint64_t)upto << 32);
+    }
+  }
+  if (over) flag_err(err, -4, 2);  // an entry longer than any the writer produces: ran off the bytes taken
+}
+
+// A run of aggregates, front to back, folded into (values before, running sums by FIELD): aggregate j holds its sums by
+// residue relative to ITS first value, which is field (values before j) mod vals.
+__device__ __forceinline__ void fold_aggs(const SkipAgg* a, int n, uint32_t vals, int lane, uint32_t& P, uint32_t (&base)[4]) {
+  const uint32_t vm = vals - 1u;
+  for (int j0 = 0; j0 < n; j0 += 64) {
+    const int j = j0 + lane;
+    uint32_t cj = 0, sj[4] = {0u, 0u, 0u, 0u};
+    if (j < n) {
+      cj = a[j].count;
+      sj[0] = a[j].sum[0]; sj[1] = a[j].sum[1]; sj[2] = a[j].sum[2]; sj[3] = a[j].sum[3];
+    }
+    const uint32_t inc = (uint32_t)wave_incl_scan((int)cj);
+    const uint32_t Pj = P + inc - cj;  // values before aggregate j: its local residue r is field (Pj + r) mod vals
+#pragma unroll
+    for (uint32_t f = 0; f < 4; ++f) base[f] += (uint32_t)wave_reduce_add((int)(f < vals ? pick4(sj, (f - Pj) & vm) : 0u));
+    P += (uint32_t)readlane((int)inc, 63);
+  }
+}
+
+// Between the passes, for the terms of more than SKIP_GROUP chunks (`group_prefix` counts groups for those terms only): one
+// wavefront per SKIP_GROUP consecutive chunks of a term. Each chunk's aggregate is REPLACED by what precedes it inside its group (count and sums by residue relative to the
+// group's first value), and the group's own aggregate goes to `gaggs`: pass 2 then folds the groups in front of its chunk's
+// group and adds one slot. Without it the last chunk of a 20 M-posting term folds 1220 aggregates in 20 dependent rounds —
+// and a 2 G-posting term's would take 1900: the look-back of a term is quadratic in its length, this makes it n^2 / 64.
+__global__ __launch_bounds__(PREP_THREADS) void k_skip_groups(const int64_t* __restrict__ chunk_prefix, const int64_t* __restrict__ group_prefix,
+                                                              int n_terms, int64_t n_groups, uint32_t vals, SkipAgg* aggs, SkipAgg* gaggs) {
+  const int lane = lane_id();
+  const int64_t s = (int64_t)blockIdx.x * PREP_WAVES + wave_id();
+  if (s >= n_groups) return;
+  const int t = upper_slot_wave(group_prefix, n_terms, s, lane);
+  const int n_mine = (int)(chunk_prefix[t + 1] - chunk_prefix[t]);
+  const int j = (int)(s - group_prefix[t]) * SKIP_GROUP + lane;
+  const bool have = lane < SKIP_GROUP && j < n_mine;
+  SkipAgg* const a = aggs + chunk_prefix[t] + j;
+  const uint32_t vm = vals - 1u;
+  uint32_t cj = 0, sj[4] = {0u, 0u, 0u, 0u};
+  if (have) {
+    cj = a->count;
+    sj[0] = a->sum[0]; sj[1] = a->sum[1]; sj[2] = a->sum[2]; sj[3] = a->sum[3];
+  }
+  const uint32_t inc = (uint32_t)wave_incl_scan((int)cj);
+  const uint32_t Pj = inc - cj;
+  uint32_t ex[4], tot[4];
+#pragma unroll
+  for (uint32_t f = 0; f < 4; ++f) {
+    const uint32_t r = f < vals ? pick4(sj, (f - Pj) & vm) : 0u;  // this chunk's sum for residue f of the GROUP
+    const uint32_t in = (uint32_t)wave_incl_scan((int)r);
+    ex[f] = in - r;
+    tot[f] = (uint32_t)readlane((int)in, 63);
+  }
+  if (have) {
+    a->count = Pj;
+    a->sum[0] = ex[0]; a->sum[1] = ex[1]; a->sum[2] = ex[2]; a->sum[3] = ex[3];
+  }
+  if (lane == 0) {
+    SkipAgg* const g = gaggs + s;
+    g->count = (uint32_t)readlane((int)inc, 63);
+    g->sum[0] = tot[0]; g->sum[1] = tot[1]; g->sum[2] = tot[2]; g->sum[3] = tot[3];
+  }
+}
+
 // PASS selects the half of the job: 1 = parse this chunk and leave its aggregate; 2 = parse it again (cheaper than keeping
-// the values anywhere), take the aggregates of the chunks in front of it — complete: they were written by the launch
+// the values anywhere), take the aggregates of the chunks in front of it — complete: they were written by the launches
 // before — and write the directory. (One launch with the chunks waiting for each other was tried first: the wavefronts of a
 // 20 M-posting term's 1220 chunks spinning on acquire loads cost 1 - 4 ms, varying from run to run.)
 template <int PASS>
 __global__ __launch_bounds__(PREP_THREADS) void k_skip_dir(const uint8_t* __restrict__ doc, int64_t doc_len, int64_t doc_cap,
                                                            const PrepTerm* __restrict__ terms, const int64_t* __restrict__ chunk_prefix,
-                                                           int n_terms, int64_t n_chunks, SkipAgg* aggs,
+                                                           const int64_t* __restrict__ l0s, int n_terms, int64_t n_chunks, SkipAgg* aggs,
+                                                           const int64_t* __restrict__ group_prefix, const SkipAgg* __restrict__ gaggs,
                                                            int32_t* dir_last, uint32_t* dir_off, uint64_t* dir_pos, int* err) {
   __shared__ __attribute__((aligned(16))) uint8_t stage[PREP_WAVES][16 + SKIP_CHUNK_BYTES];
   const int lane = lane_id();
@@ -114,22 +253,9 @@ __global__ __launch_bounds__(PREP_THREADS) void k_skip_dir(const uint8_t* __rest
       mine->sum[0] = s0; mine->sum[1] = s1; mine->sum[2] = s2; mine->sum[3] = s3;
     }
   };
-  if (PASS == 2 && c == 0 && lane == 0) {
-    dir_off[T.dir_base] = 0;
-    if (dir_pos) dir_pos[T.dir_base] = 0ull;
-    if (T.nblocks > T.n_entries && T.nblocks > 0) dir_last[T.dir_base + T.nblocks - 1] = DIR_SENTINEL_DOC;  // df % 128 == 0
-  }
-  if (T.n_entries <= 0) { publish(0, 0, 0, 0, 0); return; }
-  // ---- where does level 0 start? (skip_reader.rs:481-509; uniform: every lane reads the same bytes)
-  int64_t l0 = T.skip_fp;
-  bool lost = false;
-  for (int lvl = T.n_levels - 1; lvl >= 1; --lvl) {
-    int n;
-    const uint64_t len = read_vlong_serial(doc + l0, &n);
-    l0 += n + (int64_t)len;
-    if (l0 >= doc_len) { lost = true; break; }
-  }
-  if (lost) {
+  // ---- where level 0 starts: k_skip_terms walked the level headers once per term (and wrote the term's first directory words)
+  const int64_t l0 = l0s[t];
+  if (l0 < 0) {
     if (PASS == 2 && lane == 0 && c == 0) flag_err(err, -4, 1);
     publish(0, 0, 0, 0, 0);
     return;
@@ -185,19 +311,17 @@ __global__ __launch_bounds__(PREP_THREADS) void k_skip_dir(const uint8_t* __rest
   // ---- the chunks in front of this one, front to back: values before this chunk (P) and the running sums by field
   uint32_t P = 0;
   uint32_t base[4] = {0u, 0u, 0u, 0u};
-  for (int j0 = 0; j0 < c; j0 += 64) {
-    const int j = j0 + lane;
-    uint32_t cj = 0, sj[4] = {0u, 0u, 0u, 0u};
-    if (j < c) {
-      const SkipAgg* a = aggs + (item - c + j);
-      cj = a->count;
-      sj[0] = a->sum[0]; sj[1] = a->sum[1]; sj[2] = a->sum[2]; sj[3] = a->sum[3];
-    }
-    const uint32_t inc = (uint32_t)wave_incl_scan((int)cj);
-    const uint32_t Pj = P + inc - cj;  // values before chunk j: its local residue r is field (Pj + r) mod vals
+  if (n_mine <= SKIP_GROUP) {
+    fold_aggs(aggs + (item - c), c, vals, lane, P, base);
+  } else {
+    // the groups in front of this chunk's group, then what k_skip_groups left in this chunk's own slot: the chunks in
+    // front of it inside its group, by residue relative to the group's first value = field (P + residue) mod vals
+    fold_aggs(gaggs + group_prefix[t], c / SKIP_GROUP, vals, lane, P, base);
+    const SkipAgg* a = aggs + item;
+    const uint32_t in[4] = {a->sum[0], a->sum[1], a->sum[2], a->sum[3]};
 #pragma unroll
-    for (uint32_t f = 0; f < 4; ++f) base[f] += (uint32_t)wave_reduce_add((int)(f < vals ? pick4(sj, (f - Pj) & vm) : 0u));
-    P += (uint32_t)readlane((int)inc, 63);
+    for (uint32_t f = 0; f < 4; ++f) base[f] += f < vals ? pick4(in, (f - P) & vm) : 0u;
+    P += a->count;
   }
   if (c == n_mine - 1 && P + total < need && lane == 0) flag_err(err, -4, 2);  // ran off the skip data looking for entries
   // ---- every value's running sum -> the directory
@@ -447,7 +571,9 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_blocks(const uint8_t* 
     uint32_t hdr = (uint32_t)readlane((int)my_hdr, j);
     const uint32_t row0 = (uint32_t)readlane((int)my_row, j);
     const uint32_t off = (uint32_t)readlane((int)my_off, j);
-    const Staged nxt = request(min(j + 1, nb - 1));  // the next block's bytes are in flight while this one is re-laid
+    // the next block's bytes are in flight while this one is re-laid (two blocks ahead: 78 VGPRs, 6 wavefronts per SIMD
+    // instead of 7, and 8 % slower on both the 10 M- and the 50 M-doc shard)
+    const Staged nxt = request(min(j + 1, nb - 1));
     uint4 rows;
     if (!hdr_nonpf(hdr)) {
       const uint32_t mis = (uint32_t)((t.start_fp + off) & 15u);

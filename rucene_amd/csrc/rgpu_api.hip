@@ -433,46 +433,68 @@ static int32_t prepare_terms_attempt(rgpu_segment* seg, const rgpu_term_state* c
   HIP_TRY(seg->dir_bmax.reserve(need_slots, seg->dir_used, c->stream));
   if (seg->has_positions) HIP_TRY(seg->dir_pos.reserve(need_slots, seg->dir_used, c->stream));
   // plans: (term, 1 KB chunk of level-0 skip bytes) for k_skip_dir; (term, chunk of blocks) for the block kernels
-  std::vector<int64_t> item_prefix, chunk_prefix(work.size() + 1);
-  int64_t n_items = 0, postings = 0, n_chunks = 0;
+  // (+ (term, SKIP_GROUP chunks) for k_skip_groups: terms of more than SKIP_GROUP chunks only, the others are zero-width in group_prefix)
+  std::vector<int64_t> item_prefix, chunk_prefix(work.size() + 1), group_prefix(work.size() + 1);
+  int64_t n_items = 0, postings = 0, n_chunks = 0, n_groups = 0;
   prep_items(work, &item_prefix, &n_items, &postings);
-  for (size_t i = 0; i < work.size(); ++i) { chunk_prefix[i] = n_chunks; n_chunks += skip_chunks(work[i].n_entries, seg->has_positions); }
+  for (size_t i = 0; i < work.size(); ++i) {
+    const int64_t mine = skip_chunks(work[i].n_entries, seg->has_positions);
+    chunk_prefix[i] = n_chunks;
+    group_prefix[i] = n_groups;
+    n_chunks += mine;
+    if (mine > SKIP_GROUP) n_groups += skip_groups(mine);
+  }
   chunk_prefix[work.size()] = n_chunks;
+  group_prefix[work.size()] = n_groups;
   const size_t n_slots = need_slots - seg->dir_used;
   const int64_t n_tiles = (int64_t)((n_slots + SCAN_TILE - 1) / SCAN_TILE);
   Stager st(c);
   const size_t o_work = st.add(work.size() * sizeof(PrepTerm));
   const size_t o_items = st.add(item_prefix.size() * 8);
   const size_t o_chunks = st.add(chunk_prefix.size() * 8);
+  const size_t o_groups = st.add(group_prefix.size() * 8);
   HIP_TRY(c->S->h_stage.reserve(st.used));
   HIP_TRY(c->S->d_stage.reserve(st.used, 0, c->stream));
   std::memcpy(c->S->h_stage.p + o_work, work.data(), work.size() * sizeof(PrepTerm));
   std::memcpy(c->S->h_stage.p + o_items, item_prefix.data(), item_prefix.size() * 8);
   std::memcpy(c->S->h_stage.p + o_chunks, chunk_prefix.data(), chunk_prefix.size() * 8);
+  std::memcpy(c->S->h_stage.p + o_groups, group_prefix.data(), group_prefix.size() * 8);
   HIP_TRY(hipMemcpyAsync(c->S->d_stage.p, c->S->h_stage.p, st.used, hipMemcpyHostToDevice, c->stream));
-  // device scratch: [-, total rows][chunk aggregates][tile sums]
-  const size_t o_aggs = 64, o_tiles = o_aggs + (size_t)n_chunks * sizeof(SkipAgg);
+  // device scratch: [-, total rows][chunk aggregates][group aggregates][level-0 starts][tile sums]
+  const size_t o_aggs = 64, o_gaggs = o_aggs + (size_t)n_chunks * sizeof(SkipAgg), o_l0 = o_gaggs + (size_t)n_groups * sizeof(SkipAgg),
+               o_tiles = o_l0 + work.size() * 8;
   HIP_TRY(seg->prep_scratch.reserve(o_tiles + (size_t)n_tiles * 8 + 64, 0, c->stream));
   HIP_TRY(hipMemsetAsync(seg->prep_scratch.p, 0, 64, c->stream));
   HIP_TRY(hipMemsetAsync(c->d_err, 0, 4 * sizeof(int), c->stream));
   unsigned long long* d_ticket = reinterpret_cast<unsigned long long*>(seg->prep_scratch.p);
   unsigned long long* d_total = d_ticket + 1;
   SkipAgg* d_aggs = reinterpret_cast<SkipAgg*>(seg->prep_scratch.p + o_aggs);
+  SkipAgg* d_gaggs = reinterpret_cast<SkipAgg*>(seg->prep_scratch.p + o_gaggs);
+  int64_t* d_l0 = reinterpret_cast<int64_t*>(seg->prep_scratch.p + o_l0);
   unsigned long long* d_tiles = reinterpret_cast<unsigned long long*>(seg->prep_scratch.p + o_tiles);
   const PrepTerm* d_work = reinterpret_cast<const PrepTerm*>(c->S->d_stage.p + o_work);
   const int64_t* d_items = reinterpret_cast<const int64_t*>(c->S->d_stage.p + o_items);
   const int64_t* d_chunks = reinterpret_cast<const int64_t*>(c->S->d_stage.p + o_chunks);
+  const int64_t* d_groups = reinterpret_cast<const int64_t*>(c->S->d_stage.p + o_groups);
   const bool legacy = seg->version < 1;
   const unsigned item_grid = (unsigned)((n_items + PREP_WAVES - 1) / PREP_WAVES);
   {
     TimedLaunch tl(c, c->stream, "k_skip_dir", postings);
     const dim3 grid((unsigned)((n_chunks + PREP_WAVES - 1) / PREP_WAVES));
-    hipLaunchKernelGGL(k_skip_dir<1>, grid, dim3(PREP_THREADS), 0, c->stream, seg->d_doc, (int64_t)seg->doc_len, (int64_t)seg->doc_len + 8192,
-                       d_work, d_chunks, (int)work.size(), n_chunks, d_aggs, seg->dir_last.p, seg->dir_off.p,
+    hipLaunchKernelGGL(k_skip_terms, dim3((unsigned)((work.size() + PREP_THREADS - 1) / PREP_THREADS)), dim3(PREP_THREADS), 0, c->stream, seg->d_doc,
+                       (int64_t)seg->doc_len, d_work, (int)work.size(), d_l0, seg->dir_last.p, seg->dir_off.p,
                        seg->has_positions ? seg->dir_pos.p : nullptr, c->d_err);
-    hipLaunchKernelGGL(k_skip_dir<2>, grid, dim3(PREP_THREADS), 0, c->stream, seg->d_doc, (int64_t)seg->doc_len, (int64_t)seg->doc_len + 8192,
-                       d_work, d_chunks, (int)work.size(), n_chunks, d_aggs, seg->dir_last.p, seg->dir_off.p,
-                       seg->has_positions ? seg->dir_pos.p : nullptr, c->d_err);
+    if (n_chunks > 0) {  // the terms whose level 0 one lane does not finish
+      hipLaunchKernelGGL(k_skip_dir<1>, grid, dim3(PREP_THREADS), 0, c->stream, seg->d_doc, (int64_t)seg->doc_len, (int64_t)seg->doc_len + 8192,
+                         d_work, d_chunks, d_l0, (int)work.size(), n_chunks, d_aggs, d_groups, d_gaggs, seg->dir_last.p, seg->dir_off.p,
+                         seg->has_positions ? seg->dir_pos.p : nullptr, c->d_err);
+      if (n_groups > 0)
+        hipLaunchKernelGGL(k_skip_groups, dim3((unsigned)((n_groups + PREP_WAVES - 1) / PREP_WAVES)), dim3(PREP_THREADS), 0, c->stream, d_chunks,
+                           d_groups, (int)work.size(), n_groups, seg->has_positions ? 4u : 2u, d_aggs, d_gaggs);
+      hipLaunchKernelGGL(k_skip_dir<2>, grid, dim3(PREP_THREADS), 0, c->stream, seg->d_doc, (int64_t)seg->doc_len, (int64_t)seg->doc_len + 8192,
+                         d_work, d_chunks, d_l0, (int)work.size(), n_chunks, d_aggs, d_groups, d_gaggs, seg->dir_last.p, seg->dir_off.p,
+                         seg->has_positions ? seg->dir_pos.p : nullptr, c->d_err);
+    }
   }
   {
     TimedLaunch tl(c, c->stream, "k_block_headers", postings);
@@ -1458,7 +1480,7 @@ static int32_t search_or_lazy_group(rgpu_segment* seg, Group& G, int32_t k, HitO
     }
     run_prefix[(size_t)nu] = run_slots;
     for (size_t i = 0; i < run_of.size(); ++i) run_of[i].base = run_prefix[(size_t)uniq_of[i]];
-    touched_bytes += 8 * (int64_t)run_of.size() * 0;  // (the runs themselves are scratch: written and read once, 16 B per walked posting)
+    // (touched_bytes counts index bytes only: the scored runs are scratch, written once and read once at 16 B per walked posting)
     // phase 2 plan: items = (query, group of windows), one per wavefront
     const int wpq = std::max(1, (int)(((int64_t)seg->max_doc + W - 1) / W));
 #ifndef RGPU_LZ_TARGET_WAVES
