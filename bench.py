@@ -79,7 +79,7 @@ def profiled_traffic(kernel, tag):
         return {"bytes": sum(x["bytes"] for x in parts), "source": parts[0]["source"]}
     best = None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "%s_rocprofv3_summary.txt" % tag))):
-        fetch, write = {}, {}   # per kernel line (a name may stand for several instantiations / kernels: k_skip_dir<1>, <2>; k_scan_*): summed
+        fetch, write = {}, {}   # per kernel line (a name may stand for several instantiations / kernels: k_skip_ = k_skip_terms, k_skip_dir<1>, <2>, k_skip_groups; k_scan_*): summed
         for line in open(path):
             if kernel not in line:
                 continue
@@ -481,7 +481,7 @@ def main():
                "postings_decoded_per_sec": total / (ms * 1e-3),
                "doc_file_bytes_of_these_terms": file_bytes, "upload_s_pcie": upload_s,
                "hbm_footprint": fp, "hbm_bytes_held_per_doc_file_byte": (fp["doc_file_bytes"] + held) / max(1, fp["doc_file_bytes"]),
-               "roofline": roofline("k_skip_dir + k_block_headers + k_scan_ + k_prepare_blocks", ms, b, None, tag,
+               "roofline": roofline("k_skip_ + k_block_headers + k_scan_ + k_prepare_blocks", ms, b, None, tag,
                                     "the terms' .doc bytes (postings and skip data) in + 8 B per posting out; kernel_ms = the kernels summed")}
         seg2.close()
         del d_docs, d_freqs

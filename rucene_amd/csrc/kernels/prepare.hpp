@@ -352,24 +352,50 @@ __global__ __launch_bounds__(PREP_THREADS) void k_skip_dir(const uint8_t* __rest
 }
 
 // ---- A2: block headers (for_util.rs:196-223) + consistency of every skip pointer with the block sizes ------------------------
-// items = (term, chunk of PREP_BLOCKS_PER_ITEM blocks), one wavefront each, lane j < 32 takes block b0 + j; the term's last
-// item also sizes the tail's cells. Leaves the block's ROW COUNT in dir_row (k_scan_* turn counts into positions).
+// One LANE per directory slot of the call (a term's slots are consecutive: its FullBlocks, then the slot of its tail), whatever
+// the terms' sizes: a wavefront per (term, 32 blocks) was 200 k wavefronts for the 1.9 M blocks of the 100 M-doc shard, nine in
+// ten of them with a handful of busy lanes (0.145 ms; slot-major: 0.079 — the header bytes of 355-byte blocks are a cache line
+// each, 0.43 GB fetched for 4 MB read). Leaves the block's ROW COUNT in dir_row
+// (k_scan_* turn counts into positions).
+// largest t in [0, n) with terms[t].dir_base <= slot, searched by the whole wavefront (upper_slot_wave over PrepTerm::dir_base)
+__device__ __forceinline__ int upper_term_wave(const PrepTerm* __restrict__ terms, int n, uint32_t slot, int lane) {
+  int lo = 0, hi = n;
+  while (hi - lo > 1) {
+    const int step = (hi - lo + 63) >> 6;
+    const int idx = lo + lane * step;
+    const bool ok = idx < hi && terms[idx].dir_base <= slot;  // true on a prefix of the lanes, lane 0 included
+    const int cnt = __popcll(__ballot(ok));
+    lo += (cnt - 1) * step;
+    hi = min(hi, lo + step);
+  }
+  return lo;
+}
 template <bool LEGACY>
 __global__ __launch_bounds__(PREP_THREADS) void k_block_headers(const uint8_t* __restrict__ doc, int64_t doc_len,
-                                                                const PrepTerm* __restrict__ terms, const int64_t* __restrict__ item_prefix,
-                                                                int n_terms, int64_t n_items, const int32_t* __restrict__ dir_last,
+                                                                const PrepTerm* __restrict__ terms, int n_terms, uint32_t slot0,
+                                                                int64_t n_slots, const int32_t* __restrict__ dir_last,
                                                                 const uint32_t* __restrict__ dir_off, uint32_t* dir_row, uint16_t* dir_hdr,
                                                                 int has_freqs, int* err) {
   const int lane = lane_id();
-  const int64_t item = (int64_t)blockIdx.x * PREP_WAVES + wave_id();
-  if (item >= n_items) return;
-  const int ti = upper_slot_wave(item_prefix, n_terms, item, lane);
-  const PrepTerm t = terms[ti];
-  const int b0 = (int)(item - item_prefix[ti]) * PREP_BLOCKS_PER_ITEM;
-  const int i = b0 + lane;
-  if (lane == 32 && b0 + PREP_BLOCKS_PER_ITEM >= t.nblocks)  // where the term's decoded tail goes
-    dir_row[t.dir_base + t.nblocks] = (t.df > 1 && t.df % 128 != 0) ? (uint32_t)TAIL_STORE_ROWS : 0u;
-  if (lane >= PREP_BLOCKS_PER_ITEM || i >= t.nblocks) return;
+  const int64_t w0 = ((int64_t)blockIdx.x * PREP_WAVES + wave_id()) * 64;
+  if (w0 >= n_slots) return;
+  const uint32_t first = slot0 + (uint32_t)w0, slot = first + (uint32_t)lane;
+  // the term of the wavefront's first slot, then this lane's: a term has at least one slot, so the terms that begin inside
+  // these 64 slots are among the 63 behind the first one
+  const int t0 = upper_term_wave(terms, n_terms, first, lane);
+  const uint32_t begins = t0 + lane < n_terms ? terms[t0 + lane].dir_base : 0xffffffffu;
+  int ti = t0;
+#pragma unroll
+  for (int j = 1; j < 64; ++j) ti += (uint32_t)readlane((int)begins, j) <= slot ? 1 : 0;
+  if (w0 + lane >= n_slots) return;
+  struct { uint64_t start_fp; uint32_t dir_base; int32_t nblocks, n_entries, df; } t;
+  t.start_fp = terms[ti].start_fp; t.dir_base = terms[ti].dir_base; t.nblocks = terms[ti].nblocks; t.n_entries = terms[ti].n_entries;
+  t.df = terms[ti].df;
+  const int i = (int)(slot - t.dir_base);
+  if (i >= t.nblocks) {  // where the term's decoded tail goes
+    dir_row[slot] = (t.df > 1 && t.df % 128 != 0) ? (uint32_t)TAIL_STORE_ROWS : 0u;
+    return;
+  }
   const uint32_t off = dir_off[t.dir_base + i];
   // offsets are running sums of deltas nobody has checked yet: a block (<= 2 + 2 * 512 bytes) must start inside the file
   if ((uint64_t)t.start_fp + (uint64_t)off + 1030u > (uint64_t)doc_len + 4096u) {

@@ -499,8 +499,9 @@ static int32_t prepare_terms_attempt(rgpu_segment* seg, const rgpu_term_state* c
   {
     TimedLaunch tl(c, c->stream, "k_block_headers", postings);
     auto go = [&](auto kern) {
-      hipLaunchKernelGGL(kern, dim3(item_grid), dim3(PREP_THREADS), 0, c->stream, seg->d_doc, (int64_t)seg->doc_len, d_work, d_items,
-                         (int)work.size(), n_items, seg->dir_last.p, seg->dir_off.p, seg->dir_row.p, seg->dir_hdr.p, seg->has_freqs ? 1 : 0, c->d_err);
+      hipLaunchKernelGGL(kern, dim3((unsigned)((n_slots + PREP_THREADS - 1) / PREP_THREADS)), dim3(PREP_THREADS), 0, c->stream, seg->d_doc,
+                         (int64_t)seg->doc_len, d_work, (int)work.size(), (uint32_t)seg->dir_used, (int64_t)n_slots, seg->dir_last.p, seg->dir_off.p,
+                         seg->dir_row.p, seg->dir_hdr.p, seg->has_freqs ? 1 : 0, c->d_err);
     };
     if (legacy) go(k_block_headers<true>); else go(k_block_headers<false>);
   }
