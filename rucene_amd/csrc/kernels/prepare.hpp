@@ -567,7 +567,9 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_blocks(const uint8_t* 
     }
   }
   if (b1 <= b0) return;
-  // lane j: block b0 + j's directory words (one coalesced look instead of dependent loads per block)
+  // lane j: block b0 + j's directory words (one coalesced look instead of dependent loads per block). (Asking for them and
+  // for the first block's bytes BEFORE the tail above is decoded — nine items in ten are a small term's only one — changed
+  // nothing: 1.09 ms against 1.02 - 1.10 on the 100 M-doc shard. The kernel moves 3.5 GB, most of it written, in that time.)
   const int nb = b1 - b0;
   const bool mine = lane < nb;
   const uint32_t my_off = mine ? dir_off[t.dir_base + b0 + lane] : 0u;
