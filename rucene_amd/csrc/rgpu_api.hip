@@ -652,7 +652,11 @@ extern "C" int32_t rgpu_init(int32_t device_ordinal, const rgpu_config* cfg, rgp
   if (cfg) c->cfg = *cfg;
   c->cfg.abi_version = RGPU_ABI_VERSION;
   if (c->cfg.blocks_per_item <= 0) { c->cfg.blocks_per_item = 32; c->blocks_per_item_auto = true; }
-  if (c->cfg.and_blocks_per_item <= 0) c->cfg.and_blocks_per_item = 4;  // measured 3-5 % over 2 (fewer items, cursors reused longer)
+  // lead blocks per item. With the dense clauses answered through bitmaps a lead block costs a fraction of what it did when
+  // every clause was walked, and an item's fixed cost (descriptors, directory windows, one more list for the merge) weighs
+  // more: on the 1024 x 3-term batch k_search_and + k_merge_items take 0.73 + 0.09 ms at 2, 0.475 + 0.053 at 4 (round 2's
+  // choice), 0.412 + 0.040 at 6, 0.390 + 0.034 at 8, 0.398 + 0.028 at 12, 0.436 + 0.024 at 16, 0.60 + 0.02 at 32
+  if (c->cfg.and_blocks_per_item <= 0) c->cfg.and_blocks_per_item = 8;
   std::snprintf(c->name, sizeof c->name, "%s (%s)", prop.name, prop.gcnArchName);
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipMalloc(&c->d_err, 4 * sizeof(int)) != hipSuccess) {
     delete c;
@@ -951,7 +955,10 @@ static int32_t decode_terms_impl(rgpu_segment* seg, const rgpu_term_state* terms
   int64_t* hitems = reinterpret_cast<int64_t*>(c->S->h_stage.p + o_items);
   int64_t* hout = reinterpret_cast<int64_t*>(c->S->h_stage.p + o_out);
   int64_t items = 0, postings = 0;
-  const int dec_blocks_per_item = 16;
+#ifndef RGPU_DEC_BPI
+#define RGPU_DEC_BPI 16
+#endif
+  const int dec_blocks_per_item = RGPU_DEC_BPI;
   for (int64_t j = 0; j < nr; ++j) {
     const int64_t i = rest[(size_t)j];
     rc = make_dev_term(seg, terms[i], 0.f, 0, &ht[j], false);
