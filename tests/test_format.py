@@ -7,7 +7,7 @@ import pytest
 
 from rucene_amd import indexgen
 
-EDGE_DFS = [1, 2, 3, 127, 128, 129, 255, 256, 257, 383, 384, 1023, 1024, 1025, 1152, 1153, 8192, 8193, 9000]
+EDGE_DFS = [1, 2, 3, 127, 128, 129, 255, 256, 257, 383, 384, 1023, 1024, 1025, 1152, 1153, 2176, 2177, 2304, 8192, 8193, 9000]
 
 
 def random_postings(rng, df, max_doc, max_freq=10):

@@ -27,6 +27,10 @@ def _edge_lists(seed, max_doc):
     out.append((wide, rng.integers(1, 2**20, size=200).astype(np.int32)))                     # wide freq bits + big vints
     big = np.sort(rng.choice(max_doc, size=1300, replace=False)).astype(np.int32)
     out.append((big, rng.integers(1, 2**31 - 1, size=1300).astype(np.int32)))                 # 31-bit freq blocks
+    # either side of "level 0 fits one lane" (prepare.hpp skip_is_small: 16 skip entries = 17 blocks, two skip levels), with
+    # and without a tail / a sentinel slot; appended so that the lists above keep their indices
+    for df in (2175, 2176, 2177, 2304, 2305):
+        out.append(_postings(rng, df, max_doc))
     return out
 
 
@@ -219,7 +223,7 @@ def test_mixed_batch_and_edge_terms(edge_index, ctx, oracle):
     gsearcher = rucene_amd.GpuIndexSearcher([leaf], ctx=ctx)
     n = len(lists)
     specs = [(oracle.OP_TERM, [t]) for t in range(n)]
-    specs += [(oracle.OP_AND, [n - 5, t]) for t in range(n - 6)] + [(oracle.OP_AND, [20, 18, 19]), (oracle.OP_AND, [0, 20])]
+    specs += [(oracle.OP_AND, [20, t]) for t in range(n) if t != 20] + [(oracle.OP_AND, [20, 18, 19]), (oracle.OP_AND, [0, 20])]  # 20: the 70 000-doc list
     specs += [(oracle.OP_OR, [t, (t + 7) % n, (t + 13) % n]) for t in range(n)]
     _check_against_oracle(oracle, osearcher, gsearcher, specs, 10)
     _check_against_oracle(oracle, osearcher, gsearcher, specs[: n + 4], 128)
@@ -1039,9 +1043,10 @@ def test_docs_only_field(ctx, oracle, version):
     gsearcher = rucene_amd.GpuIndexSearcher([leaf], ctx=ctx)
     osearcher = oracle.Searcher([oseg])
     n = len(lists)
+    m = len(EDGE_DFS) + 4  # (the lists behind these are the small-term boundary cases)
     specs = [(oracle.OP_TERM, [t]) for t in range(n)]
-    specs += [(oracle.OP_AND, [n - 5, n - 6]), (oracle.OP_AND, [n - 5, n - 7, n - 8]), (oracle.OP_OR, [0, 3, n - 5, n - 6]),
-              (oracle.OP_OR, list(range(n - 9, n)))]
+    specs += [(oracle.OP_AND, [m - 5, m - 6]), (oracle.OP_AND, [m - 5, m - 7, m - 8]), (oracle.OP_OR, [0, 3, m - 5, m - 6]),
+              (oracle.OP_OR, list(range(m - 9, m))), (oracle.OP_AND, [m - 5, n - 1]), (oracle.OP_OR, list(range(n - 5, n)))]
     for k in (10, 100):
         _check_against_oracle(oracle, osearcher, gsearcher, specs, k)
 
