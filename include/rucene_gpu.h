@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RGPU_ABI_VERSION 3
+#define RGPU_ABI_VERSION 4
 #define RGPU_NO_MORE_DOCS 0x7fffffff /* search/mod.rs:59 */
 #define RGPU_BLOCK_SIZE 128          /* codec/postings/posting_format.rs:36 */
 #define RGPU_MAX_QUERY_TERMS 64  /* clauses of one query, MUST + SHOULD + MUST_NOT together: a clause's cursor lives in a lane of the
@@ -86,7 +86,12 @@ typedef struct rgpu_config {
                                    instead of a walk through its blocks. 0 = terms holding >= 1 doc in 256 get a bitmap (default;
                                    measured on the 3-term batch: 1 in 64 0.59 ms, 256 0.51, 1024 0.54, no bitmaps 1.55),
                                    n > 0 = >= 1 doc in n, -1 = off */
-  int32_t reserved[3];          /* must be zero */
+  int32_t bitmap_budget_mib;    /* HBM the doc bitmaps of ALL segments of this context may hold together, in MiB: 0 = an eighth of
+                                   the device's memory (default), n > 0 = n MiB. Bitmaps are an accelerator, never a requirement: a
+                                   term the budget has no room for (or whose allocation fails) is answered by walking its blocks,
+                                   with the same results; rgpu_segment_footprint.doc_bitmap_refused counts such terms and
+                                   rgpu_segment_release_prepared_terms gives the budget back */
+  int32_t reserved[2];          /* must be zero */
 } rgpu_config;
 
 /* blocktree/mod.rs:33-59 BlockTermState, as filled by posting_reader.rs:264-306 lucene50_decode_term.
@@ -204,7 +209,9 @@ typedef struct rgpu_segment_footprint {
   int64_t posting_norms_bytes;   /* prepared terms: 1 byte per posting */
   int64_t prepared_terms;        /* how many distinct terms are prepared */
   int64_t doc_bitmap_bytes;      /* doc bitmaps of the dense terms (rgpu_config.or_bitmaps): words + ranks + freq bytes */
-  int64_t doc_bitmap_terms;
+  int64_t doc_bitmap_terms;      /* terms that hold one */
+  int64_t doc_bitmap_refused;    /* dense terms that got none (rgpu_config.bitmap_budget_mib spent, allocation failed, or a list a
+                                    bitmap cannot express): their clauses are walked */
 } rgpu_segment_footprint;
 int32_t rgpu_segment_get_footprint(rgpu_segment* seg, rgpu_segment_footprint* out);
 
@@ -247,7 +254,13 @@ int32_t rgpu_search_batch(rgpu_segment* seg, const rgpu_query* queries, int32_t 
  * batches: the call stages its inputs, launches on hip_stream (NULL = the context's own stream) and returns; the
  * outputs are complete when the stream reaches that point (hipStreamSynchronize, or rgpu_synchronize for the
  * context's stream). Back-to-back calls therefore overlap the host-side planning of batch i+1 with the kernels of
- * batch i. `queries` / `terms` are copied before the call returns. */
+ * batch i. `queries` / `terms` are copied before the call returns.
+ * What blocks: an OR group waits for its kernels once (the fixed-point kernels' floor / hand-back flags come back to the
+ * host), and so does a MUST + SHOULD group under the exact ReqOptScorer rule. k > 128 runs ceil(k / 128) passes of the
+ * whole search, each enqueue-only under the same rules (validation and grouping are repeated per pass: host time grows
+ * with the pass count). Arithmetic of deep pages: the fixed-point kernels of the >= 10-clause disjunctions rank by exact
+ * totals and round once, which has no ceiling key across passes — for k > 128 such a disjunction is summed in f32 in
+ * clause order instead (still inside the reference's 1e-5; a score may differ in its last bits between k = 128 and k = 129). */
 int32_t rgpu_search_batch_device(rgpu_segment* seg, const rgpu_query* queries, int32_t n_queries,
                                  const rgpu_query_term* terms, int32_t n_terms_total, int32_t k, void* hits_dev,
                                  void* total_hits_dev, void* hip_stream);
@@ -492,7 +505,12 @@ typedef struct rgpu_phrase_query {
   float weight;
   int32_t sim_table;
   int32_t slop;        /* PhraseQuery::slop: 0 = ExactPhraseScorer, > 0 = SloppyPhraseScorer (phrase_query.rs:312-331) */
-  int32_t reserved;    /* must be zero */
+  int32_t next_limit;  /* sloppy phrases only. SloppyPhraseScorer is two-phase, so BulkScorer drives it through its two-phase loop
+                          (bulk_scorer.rs:97-113): every conjunction match of the phrase's terms — phrase or not, live or deleted —
+                          counts, and a leaf on which more than next_limit of them went by before the first collected doc is
+                          abandoned: the query then has NO hit in this segment. DefaultIndexSearcher::new(reader, next_limit):
+                          0 = its default, DEFAULT_DISMATCH_NEXT_LIMIT = 500 000 (searcher.rs:47, :361); n > 0 = n; -1 = no limit.
+                          (ExactPhraseScorer is not two-phase in the reference — slop 0 ignores this field) */
 } rgpu_phrase_query;
 /* One leaf of IndexSearcher::search(PhraseQuery, TopDocsCollector(k)): PhraseWeight::create_scorer (None when a term is
  * absent from the leaf) -> slop 0: ExactPhraseScorer (scorer/phrase_scorer.rs:122-294) — a doc matches when the terms occur

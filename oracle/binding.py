@@ -139,6 +139,8 @@ def _declare(L):
         "orc_pos_phrase_search": (C.c_int, [vp, i32p, i32p, C.c_int, u8p, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, i32p, f32p,
                                             i32p, i64p]),
         "orc_pos_sloppy_freqs": (C.c_int64, [vp, i32p, i32p, C.c_int, C.c_int, i32p, f32p, C.c_int64]),
+        "orc_pos_phrase_search_ex": (C.c_int, [vp, i32p, i32p, C.c_int, C.c_int, u8p, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int64,
+                                               i32p, f32p, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
         "orc_pos_phrase_search_slop": (C.c_int, [vp, i32p, i32p, C.c_int, C.c_int, u8p, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, i32p, f32p,
                                                  i32p, i64p]),
         "orc_compound_write": (C.c_int, [C.c_int32, u8p, u8p, i64p, u8p, u8p, i64p, u8p, i64p]),
@@ -933,21 +935,21 @@ class PositionsIndex:
         n = _check(lib().orc_pos_sloppy_freqs(self._h, _p(t, C.c_int32), _p(o, C.c_int32), t.size, int(slop), _p(docs, C.c_int32), _p(freqs, C.c_float), cap))
         return docs[:n].copy(), freqs[:n].copy()
 
-    def phrase_search(self, term_ids, k, norms, max_doc, doc_count, sum_total_term_freq, offsets=None, tie_mode=TIE_CANONICAL, slop=0):
-        """IndexSearcher::search(PhraseQuery(slop), TopDocsCollector(k)) -> (docs, scores, total_hits)."""
+    def phrase_search(self, term_ids, k, norms, max_doc, doc_count, sum_total_term_freq, offsets=None, tie_mode=TIE_CANONICAL, slop=0,
+                      live_docs=None, next_limit=None):
+        """IndexSearcher::search(PhraseQuery(slop), TopDocsCollector(k)) -> (docs, scores, total_hits). live_docs: u64 words
+        (FixedBitSet) or None; next_limit: DefaultIndexSearcher::new(reader, next_limit) — None = its default of 500 000 (only the
+        two-phase sloppy scorer is subject to it)."""
         t = np.ascontiguousarray(term_ids, dtype=np.int32)
         o = np.ascontiguousarray(range(t.size) if offsets is None else offsets, dtype=np.int32)
         nm = None if norms is None else np.ascontiguousarray(norms, dtype=np.uint8)
+        lv = None if live_docs is None else np.ascontiguousarray(live_docs, dtype=np.uint64)
         docs, scores = np.zeros(max(k, 1), np.int32), np.zeros(max(k, 1), np.float32)
         n, total = C.c_int32(), C.c_int64()
-        if slop:
-            _check(lib().orc_pos_phrase_search_slop(self._h, _p(t, C.c_int32), _p(o, C.c_int32), t.size, int(slop), _p(nm, C.c_uint8), int(max_doc),
-                                                    int(doc_count), int(sum_total_term_freq), k, tie_mode, _p(docs, C.c_int32), _p(scores, C.c_float),
-                                                    C.byref(n), C.byref(total)))
-            return docs[:n.value].copy(), scores[:n.value].copy(), total.value
-        _check(lib().orc_pos_phrase_search(self._h, _p(t, C.c_int32), _p(o, C.c_int32), t.size, _p(nm, C.c_uint8), int(max_doc), int(doc_count),
-                                           int(sum_total_term_freq), k, tie_mode, _p(docs, C.c_int32), _p(scores, C.c_float), C.byref(n),
-                                           C.byref(total)))
+        _check(lib().orc_pos_phrase_search_ex(self._h, _p(t, C.c_int32), _p(o, C.c_int32), t.size, int(slop), _p(nm, C.c_uint8), int(max_doc),
+                                              int(doc_count), int(sum_total_term_freq), k, tie_mode, None if lv is None else lv.ctypes.data,
+                                              -1 if next_limit is None else int(next_limit), _p(docs, C.c_int32), _p(scores, C.c_float),
+                                              C.byref(n), C.byref(total)))
         return docs[:n.value].copy(), scores[:n.value].copy(), total.value
 
     def close(self):

@@ -1020,10 +1020,12 @@ int64_t orc_pos_sloppy_freqs(orc_pos_index* h, const int32_t* term_ids, const in
   return m;
   ORC_CATCH
 }
-// IndexSearcher::search(PhraseQuery(slop), TopDocsCollector(k)) over this one segment; slop 0 = the exact scorer
-int orc_pos_phrase_search_slop(orc_pos_index* h, const int32_t* term_ids, const int32_t* offsets, int n, int slop, const uint8_t* norms,
-                               int64_t max_doc, int64_t doc_count, int64_t sum_total_term_freq, int k, int tie_mode, int32_t* out_docs,
-                               float* out_scores, int32_t* out_n, int64_t* out_total) {
+// IndexSearcher::search(PhraseQuery(slop), TopDocsCollector(k)) over this one segment; slop 0 = the exact scorer (which is
+// NOT two-phase in the reference: its approximate_next runs do_next), slop > 0 = SloppyPhraseScorer through BulkScorer's
+// two-phase arm. live_docs: FixedBitSet words or null; next_limit < 0: the searcher's default (500 000).
+int orc_pos_phrase_search_ex(orc_pos_index* h, const int32_t* term_ids, const int32_t* offsets, int n, int slop, const uint8_t* norms,
+                             int64_t max_doc, int64_t doc_count, int64_t sum_total_term_freq, int k, int tie_mode, const uint64_t* live_docs,
+                             int64_t next_limit, int32_t* out_docs, float* out_scores, int32_t* out_n, int64_t* out_total) {
   ORC_TRY
   CollectionStatistics cs;
   cs.max_doc = max_doc; cs.doc_count = doc_count; cs.sum_total_term_freq = sum_total_term_freq;
@@ -1035,12 +1037,13 @@ int orc_pos_phrase_search_slop(orc_pos_index* h, const int32_t* term_ids, const 
   }
   BM25Weight w = bm25_compute_weight(1.2f, 0.75f, cs, ts.data(), n, 1.0f);
   TopDocsCollector collector((size_t)k, tie_mode);
+  const size_t limit = next_limit < 0 ? DEFAULT_DISMATCH_NEXT_LIMIT : (size_t)next_limit;
   if (slop == 0) {
     auto sc = make_phrase_scorer(h, term_ids, offsets, n, &w, norms, true);
-    if (sc) bulk_score(sc.get(), &collector, nullptr, 0, NO_MORE_DOCS, 0);
+    if (sc) bulk_score(sc.get(), &collector, live_docs, 0, NO_MORE_DOCS, 0, limit);
   } else {
     auto sc = make_sloppy_scorer(h, term_ids, offsets, n, slop, &w, norms, true);
-    if (sc) bulk_score(sc.get(), &collector, nullptr, 0, NO_MORE_DOCS, 0);
+    if (sc) bulk_score(sc.get(), &collector, live_docs, 0, NO_MORE_DOCS, 0, limit);
   }
   std::vector<ScoreDoc> r = collector.top_docs();
   *out_n = (int32_t)r.size();
@@ -1048,6 +1051,12 @@ int orc_pos_phrase_search_slop(orc_pos_index* h, const int32_t* term_ids, const 
   for (size_t i = 0; i < r.size(); i++) { out_docs[i] = r[i].doc; out_scores[i] = r[i].score; }
   return 0;
   ORC_CATCH
+}
+int orc_pos_phrase_search_slop(orc_pos_index* h, const int32_t* term_ids, const int32_t* offsets, int n, int slop, const uint8_t* norms,
+                               int64_t max_doc, int64_t doc_count, int64_t sum_total_term_freq, int k, int tie_mode, int32_t* out_docs,
+                               float* out_scores, int32_t* out_n, int64_t* out_total) {
+  return orc_pos_phrase_search_ex(h, term_ids, offsets, n, slop, norms, max_doc, doc_count, sum_total_term_freq, k, tie_mode, nullptr, -1, out_docs,
+                                  out_scores, out_n, out_total);
 }
 
 // ---- compound files (oracle/compound.hpp) ------------------------------------------------------------------------------

@@ -156,6 +156,8 @@ struct Scorer {  // search/mod.rs:66-156 (DocIterator) + scorer/mod.rs:85-99 (Sc
   virtual float score() = 0;
   virtual int32_t approximate_next() { return next(); }
   virtual int32_t approximate_advance(int32_t t) { return advance(t); }
+  virtual bool support_two_phase() const { return false; }  // search/mod.rs:141-143
+  virtual bool matches() { return true; }                   // search/mod.rs:128-131
   virtual uint64_t postings_visited() const { return 0; }  // instrumentation only
 };
 typedef std::unique_ptr<Scorer> ScorerBox;
@@ -618,13 +620,32 @@ struct TopDocsCollector {
   }
 };
 
-// bulk_scorer.rs:57-154, non-two-phase arms; live_docs = FixedBitSet i64 words (bit_set.rs:453-460) or null
+// bulk_scorer.rs:57-154; live_docs = FixedBitSet i64 words (bit_set.rs:453-460) or null
 // (MatchAllBits). `max_collect_per_leaf` > 0 emulates EarlyTerminatingSortingCollector raising
 // LeafCollectionTerminated after N docs (collector/early_terminating.rs) — used only by the searcher KAT.
+// A scorer with support_two_phase() (of the scorers restated here: SloppyPhraseScorer, phrase_scorer.rs:1060-1062) takes
+// the two-phase arms (:97-113, :128-146): the live-docs test comes BEFORE matches(), every approximation — matching or not,
+// live or not — counts towards `next`, and a leaf on which `next_limit` + 1 approximations went by without a single collected
+// doc is abandoned (searcher.rs:47 DEFAULT_DISMATCH_NEXT_LIMIT = 500 000; DefaultIndexSearcher::new(reader, next_limit)).
+constexpr size_t DEFAULT_DISMATCH_NEXT_LIMIT = 500000;
 inline int32_t bulk_score(Scorer* scorer, TopDocsCollector* collector, const uint64_t* live_docs, int32_t min,
-                          int32_t max, int max_collect_per_leaf = 0) {
+                          int32_t max, int max_collect_per_leaf = 0, size_t next_limit = DEFAULT_DISMATCH_NEXT_LIMIT) {
   int32_t current_doc = (min == 0 && max == NO_MORE_DOCS) ? scorer->approximate_next() : scorer->approximate_advance(min);
   int collected = 0;
+  if (scorer->support_two_phase()) {
+    size_t next = 0, collect = 0;
+    while (current_doc < max) {
+      const bool live = live_docs == nullptr || ((live_docs[current_doc >> 6] >> (current_doc & 63)) & 1);
+      if (live && scorer->matches()) {
+        collector->collect(current_doc, scorer);
+        collect += 1;
+      }
+      current_doc = scorer->approximate_next();
+      next += 1;
+      if (collect == 0 && next > next_limit) break;
+    }
+    return current_doc;
+  }
   while (current_doc < max) {
     bool live = live_docs == nullptr || ((live_docs[current_doc >> 6] >> (current_doc & 63)) & 1);
     if (live) {

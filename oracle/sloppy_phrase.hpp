@@ -296,10 +296,13 @@ struct SloppyPhraseScorer : Scorer {
   }
 
   // ---- Scorer / DocIterator (phrase_scorer.rs:1008-1071)
-  bool matches() {
+  bool matches() override {
     sloppy_freq_ = phrase_freq();
     return sloppy_freq_ > FLT_EPSILON;
   }
+  bool support_two_phase() const override { return true; }                       // :1060-1062
+  int32_t approximate_next() override { return conjunction->next(); }             // :1064-1066
+  int32_t approximate_advance(int32_t t) override { return conjunction->advance(t); }  // :1068-1070
   int32_t two_phase_next() {  // scorer/mod.rs:158-168
     int32_t doc = conjunction->doc_id();
     while (true) {

@@ -8,7 +8,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_NAME = "librucene_gpu.so"
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 OP_TERM, OP_AND, OP_OR = 0, 1, 2
 MAX_K = 1024
 MAX_QUERY_TERMS = 64
@@ -25,7 +25,7 @@ TERM_POSITIONS_DTYPE_ = np.dtype([("pos_start_fp", "<i8"), ("pay_start_fp", "<i8
 PHRASE_TERM_DTYPE = np.dtype([("state", TERM_STATE_DTYPE), ("positions", TERM_POSITIONS_DTYPE_), ("position", "<i4"), ("reserved", "<i4")], align=True)
 RESCORE_REQUEST_DTYPE = np.dtype([("query_weight", "<f4"), ("rescore_weight", "<f4"), ("mode", "<i4"), ("window_size", "<i4")], align=True)
 RESCORE_AVG, RESCORE_MAX, RESCORE_MIN, RESCORE_TOTAL, RESCORE_MULTIPLY = range(5)
-PHRASE_QUERY_DTYPE = np.dtype([("n_terms", "<i4"), ("first_term", "<i4"), ("weight", "<f4"), ("sim_table", "<i4"), ("slop", "<i4"), ("reserved", "<i4")],
+PHRASE_QUERY_DTYPE = np.dtype([("n_terms", "<i4"), ("first_term", "<i4"), ("weight", "<f4"), ("sim_table", "<i4"), ("slop", "<i4"), ("next_limit", "<i4")],
                               align=True)
 assert PHRASE_TERM_DTYPE.itemsize == 64 and PHRASE_QUERY_DTYPE.itemsize == 24
 FIELD_INFO_DTYPE = np.dtype([("number", "<i4"), ("index_options", "<i4"), ("has_payloads", "<i4"), ("flags", "<i4")], align=True)
@@ -72,13 +72,13 @@ class _Config(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("blocks_per_item", C.c_int32), ("and_blocks_per_item", C.c_int32),
                 ("profile_kernels", C.c_int32), ("or_window_docs", C.c_int32), ("or_dense_clauses", C.c_int32),
                 ("raw_norms", C.c_int32), ("or_wide", C.c_int32), ("or_wide_window_docs", C.c_int32),
-                ("req_opt_rule", C.c_int32), ("or_bitmaps", C.c_int32), ("or_lazy_cells", C.c_int32), ("and_bitmaps", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("req_opt_rule", C.c_int32), ("or_bitmaps", C.c_int32), ("or_lazy_cells", C.c_int32), ("and_bitmaps", C.c_int32), ("bitmap_budget_mib", C.c_int32), ("reserved", C.c_int32 * 2)]
 
 
 SEARCH_COUNTERS_DTYPE = np.dtype([("op", "<i4"), ("reserved", "<i4"), ("postings_covered", "<i8"), ("postings_decoded", "<i8"),
                                   ("blocks_decoded", "<i8"), ("touched_bytes", "<i8")], align=True)
 FOOTPRINT_DTYPE = np.dtype([(n, "<i8") for n in ("doc_file_bytes", "norms_bytes", "live_docs_bytes", "positions_file_bytes", "directory_bytes",
-                                                 "block_store_bytes", "posting_norms_bytes", "prepared_terms", "doc_bitmap_bytes", "doc_bitmap_terms")], align=True)
+                                                 "block_store_bytes", "posting_norms_bytes", "prepared_terms", "doc_bitmap_bytes", "doc_bitmap_terms", "doc_bitmap_refused")], align=True)
 PLAN_STATS_DTYPE = np.dtype([("max_doc", "<i8"), ("doc_count", "<i8"), ("sum_total_term_freq", "<i8"), ("k1", "<f4"), ("b", "<f4")], align=True)
 assert SEARCH_COUNTERS_DTYPE.itemsize == 40 and PLAN_STATS_DTYPE.itemsize == 32
 
@@ -353,7 +353,7 @@ class Context:
     """rgpu_ctx: one per process per GPU."""
 
     def __init__(self, device=0, profile_kernels=False, blocks_per_item=0, and_blocks_per_item=0, or_window_docs=0,
-                 raw_norms=False, or_dense_clauses=0, or_wide=0, or_wide_window_docs=0, req_opt_rule=0, or_bitmaps=0, or_lazy_cells=0, and_bitmaps=0):
+                 raw_norms=False, or_dense_clauses=0, or_wide=0, or_wide_window_docs=0, req_opt_rule=0, or_bitmaps=0, or_lazy_cells=0, and_bitmaps=0, bitmap_budget_mib=0):
         cfg = _Config()
         cfg.abi_version = ABI_VERSION
         cfg.blocks_per_item = blocks_per_item
@@ -368,6 +368,7 @@ class Context:
         cfg.or_bitmaps = or_bitmaps
         cfg.or_lazy_cells = or_lazy_cells
         cfg.and_bitmaps = and_bitmaps
+        cfg.bitmap_budget_mib = bitmap_budget_mib
         h = C.c_void_p()
         _check(lib().rgpu_init(device, C.byref(cfg), C.byref(h)))
         self._h = h

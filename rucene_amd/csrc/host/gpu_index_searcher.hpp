@@ -305,6 +305,9 @@ class IndexDirectory {
 
 class GpuIndexSearcher {
  public:
+  // DefaultIndexSearcher::new(reader, next_limit) (searcher.rs:291-296): approximations a two-phase scorer (a sloppy phrase)
+  // may spend on a leaf without a collected doc before the leaf is abandoned; 0 = the reference's default of 500 000, -1 = none
+  int32_t next_limit = 0;
   GpuIndexSearcher(std::vector<LeafReader> leaves, const BM25Similarity& sim = BM25Similarity(), int device = 0)
       : leaves_(std::move(leaves)), sim_(sim) {
     rgpu_config cfg{};
@@ -388,7 +391,7 @@ class GpuIndexSearcher {
         for (const TermQuery& t : q->terms) stats.push_back(term_statistics(t));
         const BM25SimWeight w = sim_.compute_weight(stats_, stats.data(), static_cast<int32_t>(stats.size()), q->boost);
         if (sim_table_ < 0) check(sim_table_ = rgpu_sim_table_upload(ctx_, w.cache.data(), w.k1));
-        qs.push_back(rgpu_phrase_query{static_cast<int32_t>(q->terms.size()), static_cast<int32_t>(ts.size()), w.weight, sim_table_, q->slop, 0});
+        qs.push_back(rgpu_phrase_query{static_cast<int32_t>(q->terms.size()), static_cast<int32_t>(ts.size()), w.weight, sim_table_, q->slop, next_limit});
         for (size_t i = 0; i < q->terms.size(); ++i) {
           rgpu_phrase_term pt{};
           if (!leaf.positions_state(q->terms[i], &pt.state, &pt.positions)) { pt.state = rgpu_term_state{}; pt.state.skip_offset = -1; pt.state.singleton_doc_id = -1; }

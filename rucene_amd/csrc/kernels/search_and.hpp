@@ -176,8 +176,11 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
   // nn: the candidates' norm bytes — from the lead's posting-order norms for FullBlocks, gathered for
   // its tail; every other clause scores the same docs, so no clause ever gathers norms again
   auto intersect = [&](int32_t d0, int32_t d1, uint32_t f0, uint32_t f1, uint32_t nn, bool a0, bool a1, int32_t ord0) {  // nn = norm byte 0 | norm byte 1 << 8; ord0 = ordinal of the wave's first lead posting
-    a0 = a0 && doc_in_segment(seg, d0) && doc_is_live(seg.live, d0);
-    a1 = a1 && doc_in_segment(seg, d1) && doc_is_live(seg.live, d1);
+    // (phrase candidates keep their deleted docs — marked when they are emitted: the two-phase loop of bulk_scorer.rs counts
+    // every approximation towards next_limit, live or not; the branch is scalar)
+    const uint64_t* const live_here = (!HAS_OPT && emit_out != nullptr) ? nullptr : seg.live;
+    a0 = a0 && doc_in_segment(seg, d0) && doc_is_live(live_here, d0);
+    a1 = a1 && doc_in_segment(seg, d1) && doc_is_live(live_here, d1);
     use_table(L.sim_table);
     float wk = L.weight * (k1 + 1.0f);
     float s0 = bm25_score(wk, (float)(int32_t)f0, has_norms ? cache[nn & 0xffu] : k1);
@@ -418,8 +421,9 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
         unsigned long long at = 0;
         if (lane == 0) at = atomicAdd(emit_count + q, (unsigned long long)nc);
         const int64_t base_at = emit_prefix[q] + (int64_t)readlane64(at, 0);
-        if (a0) emit_docs[base_at + mbcnt(m0)] = d0;
-        if (a1) emit_docs[base_at + n0c + mbcnt(m1)] = d1;
+        // a deleted doc travels with its sign bit set (search_phrase.hpp PHRASE_DEAD): no position check, but it counts as an approximation
+        if (a0) emit_docs[base_at + mbcnt(m0)] = doc_is_live(seg.live, d0) ? d0 : (d0 | (int32_t)0x80000000);
+        if (a1) emit_docs[base_at + n0c + mbcnt(m1)] = doc_is_live(seg.live, d1) ? d1 : (d1 | (int32_t)0x80000000);
       }
       return;
     }

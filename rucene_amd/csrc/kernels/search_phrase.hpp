@@ -149,6 +149,10 @@ __global__ __launch_bounds__(WG_THREADS) void k_phrase_match(SegView seg, const 
     return;
   }
   const int32_t doc = emit_docs[slot];
+  if (doc < 0) {  // a deleted doc (marked by the conjunction): an approximation that is never checked (bulk_scorer.rs:100)
+    if (lane == 0) keys_out[slot] = 0ull;
+    return;
+  }
   const DevQuery Q = queries[q];
   uint8_t* slab = slabs[wave];
   int32_t* A = lists_a[wave];
@@ -248,9 +252,11 @@ __global__ __launch_bounds__(WG_THREADS) void k_sloppy_groups(SegView seg, const
   }
   const uint64_t rpp = __ballot(repeats);
   if (slops[q] > 0 && rpp != 0ull && n_cand > 0) {
-    // the first candidate doc of the leaf: the conjunction's smallest match
+    // the first candidate doc of the leaf: the conjunction's smallest live match
     int32_t dmin = 0x7fffffff;
-    for (int64_t i = lane; i < n_cand; i += 64) dmin = min(dmin, emit_docs[emit_prefix[q] + i]);
+    // (BulkScorer tests live docs before it calls matches() — bulk_scorer.rs:100 — so the scorer's init_first_time runs on the
+    // first LIVE match; deleted candidates carry the sign bit)
+    for (int64_t i = lane; i < n_cand; i += 64) { const int32_t d = emit_docs[emit_prefix[q] + i]; dmin = min(dmin, d < 0 ? 0x7fffffff : d); }
     dmin = 0x7fffffff - (int32_t)wave_reduce_max_u32((uint32_t)(0x7fffffff - dmin));  // min over the lanes (doc ids are >= 0)
     // tp_pos of every repeating pp there = the term's first position in that doc
     int32_t tp = 0;
@@ -316,6 +322,10 @@ __global__ __launch_bounds__(WG_THREADS) void k_sloppy_match(SegView seg, const 
     return;
   }
   const int32_t doc = emit_docs[slot];
+  if (doc < 0) {  // a deleted doc (marked by the conjunction): an approximation that is never checked (bulk_scorer.rs:100)
+    if (lane == 0) keys_out[slot] = 0ull;
+    return;
+  }
   const DevQuery Q = queries[q];
   const int n = Q.n_terms;
   int32_t* pool = pools[wave];
@@ -521,7 +531,9 @@ __global__ __launch_bounds__(WG_THREADS) void k_sloppy_match(SegView seg, const 
 template <bool WIDE>
 __global__ __launch_bounds__(WG_THREADS) void k_phrase_collect(const int64_t* __restrict__ emit_prefix,
                                                                const unsigned long long* __restrict__ emit_count,
-                                                               const uint64_t* __restrict__ keys, int n_queries, int k, int32_t doc_base,
+                                                               const uint64_t* __restrict__ keys, const int32_t* __restrict__ emit_docs,
+                                                               const int32_t* __restrict__ slops, const int32_t* __restrict__ next_limits,
+                                                               int n_queries, int k, int32_t doc_base,
                                                                HitOut* __restrict__ hits_out, int64_t* __restrict__ totals_out) {
   const int lane = lane_id();
   const int q = (int)(blockIdx.x * WG_WAVES) + wave_id();
@@ -530,6 +542,30 @@ __global__ __launch_bounds__(WG_THREADS) void k_phrase_collect(const int64_t* __
   uint64_t tau = 0;
   int64_t total = 0;
   const int64_t base = emit_prefix[q], n = (int64_t)emit_count[q];
+  // SloppyPhraseScorer is two-phase, so BulkScorer runs it through its two-phase loop (bulk_scorer.rs:97-113): every
+  // approximation — a conjunction match, phrase or not, live or deleted — counts, and once more than next_limit of them went by
+  // with nothing collected the leaf is abandoned: the query then has NO hits in this segment. In terms of the candidate list:
+  // the first collected doc F is the smallest doc with a key, and it is reached iff at most next_limit candidates precede it.
+  if (slops[q] > 0 && next_limits[q] >= 0) {
+    int32_t first = 0x7fffffff;
+    for (int64_t i0 = 0; i0 < n; i0 += 64) {
+      const bool hit = i0 + lane < n && keys[base + i0 + lane] != 0ull;
+      if (hit) first = min(first, emit_docs[base + i0 + lane]);
+    }
+    first = 0x7fffffff - (int32_t)wave_reduce_max_u32((uint32_t)(0x7fffffff - first));  // min over the lanes (doc ids are >= 0)
+    int64_t before = 0;
+    for (int64_t i0 = 0; i0 < n; i0 += 64) {
+      const bool earlier = i0 + lane < n && (emit_docs[base + i0 + lane] & 0x7fffffff) < first;
+      before += __popcll(__ballot(earlier));
+    }
+    if (first == 0x7fffffff || before > (int64_t)next_limits[q]) {
+      HitOut* out = hits_out + (size_t)q * (size_t)k;
+      if (lane < k) out[lane] = HitOut{-1, 0.f};
+      if (WIDE && lane + 64 < k) out[lane + 64] = HitOut{-1, 0.f};
+      if (lane == 0) totals_out[q] = 0;
+      return;
+    }
+  }
   for (int64_t i0 = 0; i0 < n; i0 += 64) {
     const uint64_t key = i0 + lane < n ? keys[base + i0 + lane] : 0ull;
     total += __popcll(__ballot(key != 0ull));

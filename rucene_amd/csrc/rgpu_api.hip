@@ -133,6 +133,8 @@ struct rgpu_ctx {
   std::vector<uint8_t> sim_nonneg;    // per table: k1 and every cache[] entry finite and >= 0 (a score is then within [0, weight * (k1 + 1)])
   std::vector<float> sim_cache_min;   // per table: the smallest cache[] entry (freq / (freq + cache) is largest there: k_or_lazy's score bounds)
   int64_t or_lazy_evals = 0, or_lazy_only = 0;
+  size_t bitmap_bytes = 0;    // doc bitmaps of every segment of this context (the budget is the device's, not a segment's)
+  size_t bitmap_budget = 0;   // bytes; rgpu_config.bitmap_budget_mib (0: an eighth of the device's memory)
   // search_or_lazy_group: doc_start_fp -> the batch's run of that term. Direct-mapped and stamped with the call's number, so a
   // call neither allocates nor clears it (a collision costs a second run of the same term, nothing else)
   struct UniqSlot { int64_t fp; uint32_t stamp; int32_t idx; };
@@ -154,7 +156,9 @@ struct rgpu_ctx {
   // k > 128: the search runs in passes of up to 128 hits; a pass writes columns [col0, col0 + k_pass) of rows `stride` hits
   // long and keeps below the previous pass's worst key per caller row (d_ceil; null in the first pass)
   struct Pass { int stride = 0, col0 = 0; const unsigned long long* ceil_in = nullptr; unsigned long long* ceil_out = nullptr; } pass;
-  DevVec<unsigned long long> d_ceil;
+  // (one set of ceiling arrays per call in flight: rotating like the scratch slots, so a deep-page call stays enqueue-only)
+  struct CeilSlot { DevVec<unsigned long long> d; hipEvent_t done = nullptr; bool busy = false; } ceil_slots[N_SCRATCH];
+  int ceil_next = 0;
   Scratch* last_and = nullptr;  // the slot whose d_touched the most recent AND launch filled
   int last_and_queries = 0;
   // rgpu_last_search_counters: the most recent TERM / AND / wide-OR launch
@@ -208,6 +212,7 @@ struct rgpu_segment {
   rucene::FlatFpMap<BitmapInfo> bitmaps;  // doc_start_fp -> the term's doc bitmap (terms holding >= 1 doc in cfg.or_bitmaps)
   std::vector<void*> bitmap_allocs;
   size_t bitmap_bytes = 0;
+  int64_t bitmap_terms = 0, bitmap_refused = 0;  // terms that hold a bitmap / that were filed as "walk it" (budget, allocator, unusable list)
   uint8_t* empty_bitmap = nullptr;  // all-zero {any, hi} words + ranks: the one lazy clause of a query that has no dense term (k_or_lazy wants one)
   DevVec<uint8_t> prep_scratch;  // k_skip_dir's chunk aggregates + ticket, the prefix sum's tile sums
 };
@@ -638,6 +643,7 @@ extern "C" int32_t rgpu_init(int32_t device_ordinal, const rgpu_config* cfg, rgp
   *out_ctx = nullptr;
   if (cfg && cfg->abi_version != RGPU_ABI_VERSION) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "rgpu_config.abi_version mismatch");
   if (cfg) for (int32_t r : cfg->reserved) if (r != 0) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "rgpu_config.reserved must be zero");
+  if (cfg && cfg->bitmap_budget_mib < 0) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "rgpu_config.bitmap_budget_mib must be >= 0 (or_bitmaps / and_bitmaps = -1 turn bitmaps off)");
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
     return fail(RGPU_ERR_RUNTIME, "no HIP device present: this library has no CPU fallback");
@@ -657,6 +663,9 @@ extern "C" int32_t rgpu_init(int32_t device_ordinal, const rgpu_config* cfg, rgp
   // more: on the 1024 x 3-term batch k_search_and + k_merge_items take 0.73 + 0.09 ms at 2, 0.475 + 0.053 at 4 (round 2's
   // choice), 0.412 + 0.040 at 6, 0.390 + 0.034 at 8, 0.398 + 0.028 at 12, 0.436 + 0.024 at 16, 0.60 + 0.02 at 32
   if (c->cfg.and_blocks_per_item <= 0) c->cfg.and_blocks_per_item = 8;
+  // doc bitmaps are an optional accelerator: they get a byte budget (default: an eighth of the device's memory — 36 GB of an
+  // MI355X's 288), and a term past it stays a walked clause (ensure_bitmaps_locked)
+  c->bitmap_budget = c->cfg.bitmap_budget_mib > 0 ? (size_t)c->cfg.bitmap_budget_mib << 20 : (size_t)prop.totalGlobalMem / 8;
   std::snprintf(c->name, sizeof c->name, "%s (%s)", prop.name, prop.gcnArchName);
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipMalloc(&c->d_err, 4 * sizeof(int)) != hipSuccess) {
     delete c;
@@ -672,7 +681,7 @@ extern "C" void rgpu_shutdown(rgpu_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   drain_events(c);
   for (auto e : c->free_events) (void)hipEventDestroy(e);
-  c->sim_tables.release(); c->d_ceil.release(); c->d_runs.release(); c->phrase_docs.release(); c->phrase_keys.release(); c->phrase_count.release(); c->host_api_hits.release(); c->host_api_totals.release();
+  c->sim_tables.release(); for (auto& cs : c->ceil_slots) { cs.d.release(); if (cs.done) (void)hipEventDestroy(cs.done); } c->d_runs.release(); c->phrase_docs.release(); c->phrase_keys.release(); c->phrase_count.release(); c->host_api_hits.release(); c->host_api_totals.release();
   for (auto& sc : c->scr) sc.release();
   if (c->d_err) (void)hipFree(c->d_err);
   (void)hipStreamDestroy(c->stream);
@@ -869,6 +878,7 @@ extern "C" void rgpu_segment_free(rgpu_segment* s) {
   if (s->d_pos) (void)hipFree(s->d_pos);
   s->dir_last.release(); s->dir_off.release(); s->dir_row.release(); s->dir_hdr.release(); s->dir_bmax.release(); s->dir_pos.release(); s->pnorm.release(); s->bstore.release(); s->prep_scratch.release();
   for (void* b : s->bitmap_allocs) (void)hipFree(b);
+  s->ctx->bitmap_bytes -= std::min(s->ctx->bitmap_bytes, s->bitmap_bytes);
   if (s->empty_bitmap) (void)hipFree(s->empty_bitmap);
   delete s;
 }
@@ -889,7 +899,8 @@ extern "C" int32_t rgpu_segment_get_footprint(rgpu_segment* seg, rgpu_segment_fo
   out->posting_norms_bytes = seg->d_norms ? (int64_t)seg->pnorm_used : 0;
   out->prepared_terms = (int64_t)seg->prepared.size();
   out->doc_bitmap_bytes = (int64_t)seg->bitmap_bytes;
-  out->doc_bitmap_terms = (int64_t)seg->bitmaps.size();
+  out->doc_bitmap_terms = seg->bitmap_terms;
+  out->doc_bitmap_refused = seg->bitmap_refused;
   return RGPU_OK;
 }
 
@@ -900,12 +911,15 @@ extern "C" int32_t rgpu_segment_release_prepared_terms(rgpu_segment* seg) {
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipDeviceSynchronize());  // batches in flight on any stream still read the directories
   for (auto& sc : c->scr) sc.busy = false;
+  for (auto& cs : c->ceil_slots) cs.busy = false;
   seg->prepared.clear();
   seg->dir_used = seg->bstore_used = seg->pnorm_used = 0;  // the arrays keep their capacity and are refilled from the start
   for (void* b : seg->bitmap_allocs) (void)hipFree(b);
   seg->bitmap_allocs.clear();
   seg->bitmaps.clear();
+  c->bitmap_bytes -= std::min(c->bitmap_bytes, seg->bitmap_bytes);
   seg->bitmap_bytes = 0;
+  seg->bitmap_terms = seg->bitmap_refused = 0;
   return RGPU_OK;
 }
 
@@ -1080,6 +1094,15 @@ static int32_t ensure_bitmaps_locked(rgpu_segment* seg, const rgpu_term_state* c
   rgpu_ctx* c = seg->ctx;
   const int64_t n_words = ((int64_t)seg->max_doc + 31) / 32;
   const size_t nw_pad = ((size_t)n_words + 1 + BITMAP_PAD_WORDS + 63) & ~size_t(63);
+  // A bitmap is an accelerator, never a requirement: a term the budget has no room for, whose allocation fails or whose build
+  // fails is filed as "no bitmap" (usable = false, nothing held) and its clause is walked — the search itself never fails here.
+  auto refuse = [&](const rgpu_term_state& st) {
+    BitmapInfo none{};
+    none.df = st.doc_freq;
+    none.usable = false;
+    seg->bitmaps.put(st.doc_start_fp, none);
+    seg->bitmap_refused++;
+  };
   for (size_t i = 0; i < n; ++i) {
     const rgpu_term_state& st = *sts[i];
     if (st.doc_freq < 2 || seg->bitmaps.find(st.doc_start_fp)) continue;
@@ -1087,12 +1110,16 @@ static int32_t ensure_bitmaps_locked(rgpu_segment* seg, const rgpu_term_state* c
     const size_t o_ranks = nw_pad * 8, o_ovf = o_ranks + nw_pad * 4, o_stats = o_ovf + (size_t)BITMAP_OVF_CAP * 8;
     const size_t o_freqs = o_stats + 64, o_nib = o_freqs + ((df + 127) & ~size_t(63));
     // (the four-bits-per-doc array of the densest terms: conjunctions answer a candidate with ONE gather from it)
-    const bool with_nib = (int64_t)st.doc_freq * BITMAP_NIBBLE_DENSITY >= (int64_t)seg->max_doc;
-    const size_t total = o_nib + (with_nib ? (nw_pad * 4 + 64) * 4 : 0);
+    bool with_nib = (int64_t)st.doc_freq * BITMAP_NIBBLE_DENSITY >= (int64_t)seg->max_doc;
+    size_t total = o_nib + (with_nib ? (nw_pad * 4 + 64) * 4 : 0);
+    if (with_nib && c->bitmap_bytes + total > c->bitmap_budget) { with_nib = false; total = o_nib; }  // the part a clause can do without goes first
+    if (c->bitmap_bytes + total > c->bitmap_budget) { refuse(st); continue; }
     uint8_t* block = nullptr;
-    HIP_TRY(hipMalloc(&block, total));
-    seg->bitmap_allocs.push_back(block);
-    seg->bitmap_bytes += total;
+    if (hipMalloc(&block, total) != hipSuccess) {
+      (void)hipGetLastError();  // out of memory is not sticky; the clause is walked
+      refuse(st);
+      continue;
+    }
     BitmapInfo info{};
     info.words = reinterpret_cast<uint2*>(block);
     info.sim_table = sim_tables[i];
@@ -1102,38 +1129,62 @@ static int32_t ensure_bitmaps_locked(rgpu_segment* seg, const rgpu_term_state* c
     info.nib = with_nib ? reinterpret_cast<uint32_t*>(block + o_nib) : nullptr;
     info.df = st.doc_freq;
     BitmapStats* d_stats = reinterpret_cast<BitmapStats*>(block + o_stats);
-    HIP_TRY(hipMemsetAsync(block, 0, total, c->stream));
-    static_assert(sizeof(ScoredPosting) == 8, "the run buffer doubles as {docs, freqs} scratch");
-    HIP_TRY(c->d_runs.reserve(df + 64, 0, c->stream));
-    int32_t* docs = reinterpret_cast<int32_t*>(c->d_runs.p);
-    int32_t* freqs = docs + df;
-    int32_t rc = decode_terms_impl(seg, &st, 1, docs, freqs, c->stream, nullptr);
-    if (rc != RGPU_OK) return rc;
-    {
-      TimedLaunch tl(c, c->stream, "k_bitmap_build", (int64_t)df);
-      hipLaunchKernelGGL(k_bitmap_fill, dim3((unsigned)((df + 255) / 256)), dim3(256), 0, c->stream, docs, freqs, (int64_t)df, seg->max_doc,
-                         (const uint8_t*)seg->d_norms, (const float*)(c->sim_tables.p + (size_t)sim_tables[i] * 257),
-                         seg->n_norm_ranks > 0 ? (const uint8_t*)seg->d_rank_to_norm : (const uint8_t*)nullptr, info.words, info.freqs, info.ovf, d_stats, info.nib);
-      const int64_t n_scan = n_words + 1;  // ranks[n_words] = the list's size
-      hipLaunchKernelGGL(k_bitmap_popc, dim3((unsigned)((n_scan + 255) / 256)), dim3(256), 0, c->stream, info.words, n_scan, info.ranks);
-      const int64_t n_tiles = (n_scan + SCAN_TILE - 1) / SCAN_TILE;
-      HIP_TRY(seg->prep_scratch.reserve(64 + (size_t)n_tiles * 8 + 64, 0, c->stream));
-      unsigned long long* d_total = reinterpret_cast<unsigned long long*>(seg->prep_scratch.p);
-      unsigned long long* d_tiles = d_total + 8;
-      hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)n_tiles), dim3(PREP_THREADS), 0, c->stream, info.ranks, n_scan, d_tiles);
-      hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(PREP_THREADS), 0, c->stream, d_tiles, n_tiles, 0xfffffff0ull, d_total, c->d_err);
-      hipLaunchKernelGGL(k_scan_down, dim3((unsigned)n_tiles), dim3(PREP_THREADS), 0, c->stream, info.ranks, n_scan, d_tiles);
-    }
     BitmapStats hs{};
     uint32_t listed = 0;
-    HIP_TRY(hipMemcpyAsync(&hs, d_stats, sizeof hs, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(&listed, info.ranks + n_words, 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipGetLastError());
+    // the build; the block is accounted for only once it succeeded (a failure frees it: no retry leaks a block)
+    auto build = [&]() -> int32_t {
+      HIP_TRY(hipMemsetAsync(block, 0, total, c->stream));
+      static_assert(sizeof(ScoredPosting) == 8, "the run buffer doubles as {docs, freqs} scratch");
+      HIP_TRY(c->d_runs.reserve(df + 64, 0, c->stream));
+      int32_t* docs = reinterpret_cast<int32_t*>(c->d_runs.p);
+      int32_t* freqs = docs + df;
+      int32_t rc = decode_terms_impl(seg, &st, 1, docs, freqs, c->stream, nullptr);
+      if (rc != RGPU_OK) return rc;
+      {
+        TimedLaunch tl(c, c->stream, "k_bitmap_build", (int64_t)df);
+        hipLaunchKernelGGL(k_bitmap_fill, dim3((unsigned)((df + 255) / 256)), dim3(256), 0, c->stream, docs, freqs, (int64_t)df, seg->max_doc,
+                           (const uint8_t*)seg->d_norms, (const float*)(c->sim_tables.p + (size_t)sim_tables[i] * 257),
+                           seg->n_norm_ranks > 0 ? (const uint8_t*)seg->d_rank_to_norm : (const uint8_t*)nullptr, info.words, info.freqs, info.ovf, d_stats, info.nib);
+        const int64_t n_scan = n_words + 1;  // ranks[n_words] = the list's size
+        hipLaunchKernelGGL(k_bitmap_popc, dim3((unsigned)((n_scan + 255) / 256)), dim3(256), 0, c->stream, info.words, n_scan, info.ranks);
+        const int64_t n_tiles = (n_scan + SCAN_TILE - 1) / SCAN_TILE;
+        HIP_TRY(seg->prep_scratch.reserve(64 + (size_t)n_tiles * 8 + 64, 0, c->stream));
+        unsigned long long* d_total = reinterpret_cast<unsigned long long*>(seg->prep_scratch.p);
+        unsigned long long* d_tiles = d_total + 8;
+        hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)n_tiles), dim3(PREP_THREADS), 0, c->stream, info.ranks, n_scan, d_tiles);
+        hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(PREP_THREADS), 0, c->stream, d_tiles, n_tiles, 0xfffffff0ull, d_total, c->d_err);
+        hipLaunchKernelGGL(k_scan_down, dim3((unsigned)n_tiles), dim3(PREP_THREADS), 0, c->stream, info.ranks, n_scan, d_tiles);
+      }
+      HIP_TRY(hipMemcpyAsync(&hs, d_stats, sizeof hs, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipMemcpyAsync(&listed, info.ranks + n_words, 4, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      HIP_TRY(hipGetLastError());
+      return RGPU_OK;
+    };
+    const int32_t rc = build();
+    if (rc != RGPU_OK) {
+      (void)hipStreamSynchronize(c->stream);  // nothing may still write the block
+      (void)hipFree(block);
+      if (rc == RGPU_ERR_RUNTIME) { (void)hipGetLastError(); refuse(st); continue; }  // scratch allocation, launch: a walked clause serves
+      return rc;  // the term itself is bad (corrupt postings): walking it would fail the same way — report it
+    }
+    seg->bitmap_allocs.push_back(block);
+    seg->bitmap_bytes += total;
+    c->bitmap_bytes += total;
     info.n_ovf = (int32_t)std::min<unsigned>(hs.n_ovf, (unsigned)BITMAP_OVF_CAP);
     info.max_freq = (int32_t)std::min<unsigned>(hs.max_freq, 0x7fffffffu);
     // (a list with a repeated or out-of-range doc id — a corrupt tail — or too many huge freqs simply stays a walked clause)
     info.usable = hs.n_ovf <= (unsigned)BITMAP_OVF_CAP && hs.bad_docs == 0 && listed == (uint32_t)st.doc_freq && hs.max_freq >= 1;
+    if (!info.usable) {  // ... and holds no HBM for it
+      (void)hipFree(block);
+      seg->bitmap_allocs.pop_back();
+      seg->bitmap_bytes -= total;
+      c->bitmap_bytes -= total;
+      info.words = nullptr; info.ranks = nullptr; info.ovf = nullptr; info.freqs = nullptr; info.nib = nullptr;
+      seg->bitmap_refused++;
+    } else {
+      seg->bitmap_terms++;
+    }
     seg->bitmaps.put(st.doc_start_fp, info);
   }
   return RGPU_OK;
@@ -1819,18 +1870,24 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
   if (k <= 0 || k > RGPU_MAX_K) return fail(k <= 0 ? RGPU_ERR_ILLEGAL_ARGUMENT : RGPU_ERR_UNSUPPORTED, "k must be in 1..RGPU_MAX_K");
   c->pass = rgpu_ctx::Pass{};
   if (k <= RGPU_PASS_K) return search_pass(seg, queries, n_queries, terms, n_terms_total, k, k, hits_dev, totals_dev, stream);
-  HIP_TRY(c->d_ceil.reserve((size_t)n_queries * 2, 0, stream));  // two sets, alternating: a pass reads the previous pass's, writes its own
+  rgpu_ctx::CeilSlot& cs = c->ceil_slots[c->ceil_next];
+  c->ceil_next = (c->ceil_next + 1) % N_SCRATCH;
+  if (cs.busy) { HIP_TRY(hipEventSynchronize(cs.done)); cs.busy = false; }
+  HIP_TRY(cs.d.reserve((size_t)n_queries * 2, 0, stream));  // two sets, alternating: a pass reads the previous pass's, writes its own
   int32_t rc = RGPU_OK;
   int flip = 0;
   for (int32_t col0 = 0; col0 < k && rc == RGPU_OK; col0 += RGPU_PASS_K, flip ^= 1) {
     c->pass.stride = k;
     c->pass.col0 = col0;
-    c->pass.ceil_in = col0 == 0 ? nullptr : c->d_ceil.p + (size_t)(flip ^ 1) * (size_t)n_queries;
-    c->pass.ceil_out = c->d_ceil.p + (size_t)flip * (size_t)n_queries;
+    c->pass.ceil_in = col0 == 0 ? nullptr : cs.d.p + (size_t)(flip ^ 1) * (size_t)n_queries;
+    c->pass.ceil_out = cs.d.p + (size_t)flip * (size_t)n_queries;
     rc = search_pass(seg, queries, n_queries, terms, n_terms_total, std::min<int32_t>(RGPU_PASS_K, k - col0), k, hits_dev, totals_dev, stream);
   }
   c->pass = rgpu_ctx::Pass{};
-  if (rc == RGPU_OK) HIP_TRY(hipStreamSynchronize(stream));  // d_ceil belongs to the context: the next call may start over on another stream
+  // no stream sync: the ceiling arrays are this call's until the slot comes round again (four calls later), like the scratch slots
+  if (!cs.done) HIP_TRY(hipEventCreateWithFlags(&cs.done, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(cs.done, stream));
+  cs.busy = true;
   return rc;
 }
 static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t n_queries, const rgpu_query_term* terms,
@@ -2306,7 +2363,7 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
     const rgpu_phrase_query& Q = queries[q];
     if (Q.n_terms < 2 || Q.n_terms > RGPU_MAX_PHRASE_TERMS) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "a phrase has 2..RGPU_MAX_PHRASE_TERMS terms");
     if (Q.slop < 0) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "Slop must be >= 0");  // PhraseQuery::new (phrase_query.rs:77)
-    if (Q.reserved != 0) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "rgpu_phrase_query.reserved must be zero");
+    if (Q.next_limit < -1) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "rgpu_phrase_query.next_limit: 0 (the searcher's default), n > 0, or -1 (none)");
     if (Q.first_term < 0 || (int64_t)Q.first_term + Q.n_terms > (int64_t)n_terms_total) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "term range outside terms[]");
     if (Q.sim_table < 0 || Q.sim_table >= c->n_sim_tables) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "unknown sim_table handle");
     for (int i = 0; i < Q.n_terms; ++i) {
@@ -2324,7 +2381,7 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
   std::vector<DevTerm> dt;
   std::vector<PosTerm> pt;
   std::vector<int64_t> item_prefix((size_t)n_queries + 1), emit_prefix((size_t)n_queries + 1);
-  std::vector<int32_t> slops((size_t)n_queries, 0);
+  std::vector<int32_t> slops((size_t)n_queries, 0), limits((size_t)n_queries, -1);
   bool any_sloppy = false, any_exact = false;
   const int blocks_per_item = c->cfg.and_blocks_per_item;
   int64_t items = 0, slots = 0;
@@ -2362,6 +2419,7 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
       pt.push_back(p);
     }
     slops[(size_t)q] = Q.slop;
+    limits[(size_t)q] = Q.next_limit == 0 ? 500000 /* searcher.rs:47 DEFAULT_DISMATCH_NEXT_LIMIT */ : Q.next_limit;
     (Q.slop > 0 ? any_sloppy : any_exact) = true;
     dq[(size_t)q].n_terms = Q.n_terms;
     const DevTerm& lead = dt[(size_t)dq[(size_t)q].first_term];
@@ -2383,6 +2441,7 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
     const size_t o_ip = st.add((size_t)(n_queries + 1) * 8);
     const size_t o_ep = st.add((size_t)(n_queries + 1) * 8);
     const size_t o_sl = st.add((size_t)n_queries * 4);
+    const size_t o_nl = st.add((size_t)n_queries * 4);
     const size_t o_gr = st.add((size_t)n_queries * sizeof(SloppyGroups));  // written by k_sloppy_groups
     HIP_TRY(c->S->h_stage.reserve(st.used));
     HIP_TRY(c->S->d_stage.reserve(st.used, 0, stream));
@@ -2390,6 +2449,7 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
     std::memcpy(c->S->h_stage.p + o_t, dt.data(), dt.size() * sizeof(DevTerm));
     std::memcpy(c->S->h_stage.p + o_pt, pt.data(), pt.size() * sizeof(PosTerm));
     std::memcpy(c->S->h_stage.p + o_sl, slops.data(), (size_t)n_queries * 4);
+    std::memcpy(c->S->h_stage.p + o_nl, limits.data(), (size_t)n_queries * 4);
     std::memcpy(c->S->h_stage.p + o_ip, item_prefix.data(), (size_t)(n_queries + 1) * 8);
     std::memcpy(c->S->h_stage.p + o_ep, emit_prefix.data(), (size_t)(n_queries + 1) * 8);
     HIP_TRY(hipMemcpyAsync(c->S->d_stage.p, c->S->h_stage.p, st.used, hipMemcpyHostToDevice, stream));
@@ -2422,6 +2482,7 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
       if (legacy) go(k_search_and<true, false, false, false>); else go(k_search_and<false, false, false, false>);
     }
     const int32_t* d_sl = reinterpret_cast<const int32_t*>(c->S->d_stage.p + o_sl);
+    const int32_t* d_nl = reinterpret_cast<const int32_t*>(c->S->d_stage.p + o_nl);
     SloppyGroups* d_gr = reinterpret_cast<SloppyGroups*>(c->S->d_stage.p + o_gr);
     if (slots > 0 && any_exact) {
       TimedLaunch tl(c, stream, "k_phrase_match", 0);
@@ -2455,11 +2516,11 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
       TimedLaunch tl(c, stream, "k_phrase_collect", 0);
       const unsigned grid = (unsigned)((n_queries + WG_WAVES - 1) / WG_WAVES);
       if (k > 64)
-        hipLaunchKernelGGL(k_phrase_collect<true>, dim3(grid), dim3(WG_THREADS), 0, stream, d_ep, c->phrase_count.p, c->phrase_keys.p, (int)n_queries,
-                           (int)k, seg->doc_base, c->host_api_hits.p, c->host_api_totals.p);
+        hipLaunchKernelGGL(k_phrase_collect<true>, dim3(grid), dim3(WG_THREADS), 0, stream, d_ep, c->phrase_count.p, c->phrase_keys.p,
+                           (const int32_t*)c->phrase_docs.p, d_sl, d_nl, (int)n_queries, (int)k, seg->doc_base, c->host_api_hits.p, c->host_api_totals.p);
       else
-        hipLaunchKernelGGL(k_phrase_collect<false>, dim3(grid), dim3(WG_THREADS), 0, stream, d_ep, c->phrase_count.p, c->phrase_keys.p, (int)n_queries,
-                           (int)k, seg->doc_base, c->host_api_hits.p, c->host_api_totals.p);
+        hipLaunchKernelGGL(k_phrase_collect<false>, dim3(grid), dim3(WG_THREADS), 0, stream, d_ep, c->phrase_count.p, c->phrase_keys.p,
+                           (const int32_t*)c->phrase_docs.p, d_sl, d_nl, (int)n_queries, (int)k, seg->doc_base, c->host_api_hits.p, c->host_api_totals.p);
     }
     HIP_TRY(hipGetLastError());
   }
@@ -2682,14 +2743,26 @@ __global__ void k_set_i64(int64_t* p, int64_t v) { *p = v; }
 static int32_t search_into_record(rgpu_segment* seg, const rgpu_query* queries, int32_t n_queries, const rgpu_query_term* terms,
                                   int32_t n_terms_total, int32_t k, uint8_t* record, hipStream_t s) {
   const size_t hits_bytes = record_hits_bytes(n_queries, k);
-  const int32_t rc = search_impl(seg, queries, n_queries, terms, n_terms_total, k, (HitOut*)record, (int64_t*)(record + hits_bytes), s);
-  const std::string why = rc == RGPU_OK ? std::string() : g_last_error;
+  int32_t rc = search_impl(seg, queries, n_queries, terms, n_terms_total, k, (HitOut*)record, (int64_t*)(record + hits_bytes), s);
+  std::string why = rc == RGPU_OK ? std::string() : g_last_error;
+  // No early return below: the status word is written whatever else fails (a peer that merged a record without one would
+  // take stale rows for this shard's answer), and the first error is the one reported.
+  auto note = [&](hipError_t e, const char* what) {
+    if (e != hipSuccess && rc == RGPU_OK) { rc = RGPU_ERR_RUNTIME; why = std::string(what) + ": " + hipGetErrorString(e); }
+  };
   if (rc != RGPU_OK) {  // whatever was enqueued before the failure is overwritten behind it on the same stream
-    HIP_TRY(hipMemsetAsync(record + hits_bytes, 0, (size_t)n_queries * 8, s));
+    note(hipMemsetAsync(record + hits_bytes, 0, (size_t)n_queries * 8, s), "hipMemsetAsync(record counts)");
     hipLaunchKernelGGL(k_init_hits, dim3((unsigned)(((size_t)n_queries * k + 255) / 256)), dim3(256), 0, s, (HitOut*)record, (int64_t)n_queries, (int)k, (int)k, 0);
+    note(hipGetLastError(), "k_init_hits");
   }
   hipLaunchKernelGGL(k_set_i64, dim3(1), dim3(1), 0, s, (int64_t*)(record + hits_bytes + (size_t)n_queries * 8), (int64_t)rc);
-  HIP_TRY(hipGetLastError());
+  const hipError_t e_status = hipGetLastError();
+  if (e_status != hipSuccess) {  // the launch itself was refused: put the word there with a copy from the host instead
+    const int64_t word = rc != RGPU_OK ? (int64_t)rc : (int64_t)RGPU_ERR_RUNTIME;
+    (void)hipMemcpyAsync(record + hits_bytes + (size_t)n_queries * 8, &word, 8, hipMemcpyHostToDevice, s);
+    (void)hipStreamSynchronize(s);  // (`word` lives on this frame)
+    note(e_status, "k_set_i64");
+  }
   if (rc != RGPU_OK) return fail(rc, why);
   return RGPU_OK;
 }
@@ -2739,21 +2812,25 @@ struct ShardedCall {
   int32_t local_rc = RGPU_OK;
   std::string local_why;
 };
-static int32_t sharded_local(rgpu_comm* comm, rgpu_segment* seg, const rgpu_query* queries, int32_t n_queries, const rgpu_query_term* terms,
-                             int32_t n_terms_total, int32_t k, hipStream_t s, ShardedCall* call) {
+// phase 0: the slot and its buffers — may fail (out of HBM for the record itself) and then NOTHING has happened: the
+// communicator is still in step with its peers as long as they fail the same call or are told to skip it
+static int32_t sharded_reserve(rgpu_comm* comm, int32_t n_queries, int32_t k, hipStream_t s, ShardedCall* call) {
   CommSlot& sl = comm->slots[comm->next];
   if (sl.busy) { HIP_TRY(hipEventSynchronize(sl.done)); sl.busy = false; }
   const size_t record = record_bytes(n_queries, k);
   HIP_TRY(sl.send.reserve(record, 0, s));
   HIP_TRY(sl.recv.reserve(record * (size_t)comm->n_ranks, 0, s));
-  // from here on this rank WILL enqueue the collective (a failure above — out of HBM for the record itself — leaves the
-  // communicator out of step with its peers: ncclCommAbort territory, see rgpu_comm_status)
-  comm->next = (comm->next + 1) % N_COMM_SLOTS;
   call->sl = &sl;
   call->record = record;
-  call->local_rc = search_into_record(seg, queries, n_queries, terms, n_terms_total, k, sl.send.p, s);
-  if (call->local_rc != RGPU_OK) call->local_why = g_last_error;
   return RGPU_OK;
+}
+// phase 1: from here on this rank WILL enqueue the collective, whatever its local search does (search_into_record leaves the
+// status in the record)
+static void sharded_local(rgpu_comm* comm, rgpu_segment* seg, const rgpu_query* queries, int32_t n_queries, const rgpu_query_term* terms,
+                          int32_t n_terms_total, int32_t k, hipStream_t s, ShardedCall* call) {
+  comm->next = (comm->next + 1) % N_COMM_SLOTS;
+  call->local_rc = search_into_record(seg, queries, n_queries, terms, n_terms_total, k, call->sl->send.p, s);
+  if (call->local_rc != RGPU_OK) call->local_why = g_last_error;
 }
 static int32_t sharded_gather(rgpu_comm* comm, hipStream_t s, const ShardedCall& call) {
   if (comm->have_last && comm->last_stream != s) HIP_TRY(hipStreamWaitEvent(s, comm->last_collective, 0));
@@ -2788,8 +2865,9 @@ extern "C" int32_t rgpu_search_batch_sharded(rgpu_comm* comm, rgpu_segment* seg,
   HIP_TRY(hipSetDevice(c->device));
   hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
   ShardedCall call;
-  int32_t rc = sharded_local(comm, seg, queries, n_queries, terms, n_terms_total, k, s, &call);
+  int32_t rc = sharded_reserve(comm, n_queries, k, s, &call);
   if (rc != RGPU_OK) return rc;
+  sharded_local(comm, seg, queries, n_queries, terms, n_terms_total, k, s, &call);
   rc = sharded_gather(comm, s, call);
   if (rc != RGPU_OK) return rc;
   rc = sharded_merge(comm, n_queries, k, hits_dev, totals_dev, s, call);
@@ -2815,35 +2893,53 @@ extern "C" int32_t rgpu_search_batch_sharded_all(rgpu_comm* const* comms, rgpu_s
   }
   std::vector<ShardedCall> calls((size_t)n);
   std::vector<hipStream_t> ss((size_t)n);
-  for (int32_t r = 0; r < n; ++r) {  // every shard's search is enqueued before any collective: the GPUs work side by side
+  for (int32_t r = 0; r < n; ++r) {  // phase 0 for every rank: a failure here returns before ANY rank has moved on
     rgpu_ctx* c = comms[r]->ctx;
     std::lock_guard<std::mutex> g(c->mu);
     HIP_TRY(hipSetDevice(c->device));
     ss[(size_t)r] = (hip_streams && hip_streams[r]) ? (hipStream_t)hip_streams[r] : c->stream;
-    int32_t rc = sharded_local(comms[r], segs[r], queries, n_queries, terms_per_rank[r], n_terms_total, k, ss[(size_t)r], &calls[(size_t)r]);
+    int32_t rc = sharded_reserve(comms[r], n_queries, k, ss[(size_t)r], &calls[(size_t)r]);
     if (rc != RGPU_OK) return rc;
   }
-  NCCL_TRY(ncclGroupStart());
-  int32_t grc = RGPU_OK;
-  for (int32_t r = 0; r < n && grc == RGPU_OK; ++r) {
+  // From here to ncclGroupEnd nothing returns: every rank advances its slot, searches (a failing shard leaves its status in
+  // its record) and issues its all-gather — a rank left out would leave the others hanging in theirs.
+  int32_t first_rc = RGPU_OK;
+  std::string first_why;
+  auto note = [&](int32_t rc, const std::string& why) { if (rc != RGPU_OK && first_rc == RGPU_OK) { first_rc = rc; first_why = why; } };
+  for (int32_t r = 0; r < n; ++r) {  // every shard's search is enqueued before any collective: the GPUs work side by side
     rgpu_ctx* c = comms[r]->ctx;
     std::lock_guard<std::mutex> g(c->mu);
-    if (hipSetDevice(c->device) != hipSuccess) { grc = fail(RGPU_ERR_RUNTIME, "hipSetDevice"); break; }
-    grc = sharded_gather(comms[r], ss[(size_t)r], calls[(size_t)r]);
+    if (hipSetDevice(c->device) != hipSuccess) {  // the search cannot run: an empty record with a status would need the device too
+      comms[r]->next = (comms[r]->next + 1) % N_COMM_SLOTS;
+      calls[(size_t)r].local_rc = RGPU_ERR_RUNTIME;
+      calls[(size_t)r].local_why = "hipSetDevice";
+      continue;
+    }
+    sharded_local(comms[r], segs[r], queries, n_queries, terms_per_rank[r], n_terms_total, k, ss[(size_t)r], &calls[(size_t)r]);
   }
-  NCCL_TRY(ncclGroupEnd());
-  if (grc != RGPU_OK) return grc;
-  int32_t first_local = RGPU_OK;
-  std::string first_why;
+  {
+    const ncclResult_t gs = ncclGroupStart();
+    if (gs != ncclSuccess) note(RGPU_ERR_RUNTIME, std::string("ncclGroupStart: ") + ncclGetErrorString(gs));
+    for (int32_t r = 0; r < n; ++r) {
+      rgpu_ctx* c = comms[r]->ctx;
+      std::lock_guard<std::mutex> g(c->mu);
+      if (hipSetDevice(c->device) != hipSuccess) { note(RGPU_ERR_RUNTIME, "hipSetDevice"); continue; }
+      const int32_t rc = sharded_gather(comms[r], ss[(size_t)r], calls[(size_t)r]);
+      if (rc != RGPU_OK) note(rc, "rank " + std::to_string(r) + ": " + g_last_error);
+    }
+    const ncclResult_t ge = ncclGroupEnd();
+    if (ge != ncclSuccess) note(RGPU_ERR_RUNTIME, std::string("ncclGroupEnd: ") + ncclGetErrorString(ge));
+  }
+  if (first_rc != RGPU_OK) return fail(first_rc, first_why);  // a collective that could not be issued: rgpu_comm_destroy / a new communicator
   for (int32_t r = 0; r < n; ++r) {
     rgpu_ctx* c = comms[r]->ctx;
     std::lock_guard<std::mutex> g(c->mu);
-    HIP_TRY(hipSetDevice(c->device));
-    int32_t rc = sharded_merge(comms[r], n_queries, k, hits_dev[r], totals_dev[r], ss[(size_t)r], calls[(size_t)r]);
-    if (rc != RGPU_OK) return rc;
-    if (first_local == RGPU_OK && calls[(size_t)r].local_rc != RGPU_OK) { first_local = calls[(size_t)r].local_rc; first_why = "rank " + std::to_string(r) + ": " + calls[(size_t)r].local_why; }
+    if (hipSetDevice(c->device) != hipSuccess) { note(RGPU_ERR_RUNTIME, "hipSetDevice"); continue; }
+    const int32_t rc = sharded_merge(comms[r], n_queries, k, hits_dev[r], totals_dev[r], ss[(size_t)r], calls[(size_t)r]);
+    if (rc != RGPU_OK) note(rc, "rank " + std::to_string(r) + ": " + g_last_error);
+    if (calls[(size_t)r].local_rc != RGPU_OK) note(calls[(size_t)r].local_rc, "rank " + std::to_string(r) + ": " + calls[(size_t)r].local_why);
   }
-  if (first_local != RGPU_OK) return fail(first_local, first_why);
+  if (first_rc != RGPU_OK) return fail(first_rc, first_why);
   return RGPU_OK;
 }
 

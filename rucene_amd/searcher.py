@@ -306,8 +306,13 @@ class GpuIndexSearcher:
     """IndexSearcher over GPU-resident leaves. `search(query, collector)` mirrors searcher.rs:487-525;
     `search_batch` is the batched form the hardware wants (one launch set per leaf for many queries)."""
 
-    def __init__(self, leaves, ctx=None, similarity=None):
+    def __init__(self, leaves, ctx=None, similarity=None, next_limit=None):
         self.leaves = list(leaves)
+        # DefaultIndexSearcher::new(reader, next_limit: Option<usize>) (searcher.rs:291-296, :361): how many approximations of a
+        # two-phase scorer (here: sloppy phrases) may go by on a leaf without a collected doc. None = the default, 500 000
+        if next_limit is not None and int(next_limit) < 1:
+            raise RgpuError(-2, "next_limit must be >= 1 (None: the reference's default of 500 000)")
+        self.next_limit = 0 if next_limit is None else int(next_limit)
         self.ctx = ctx or _lib.Context()
         self.similarity = similarity or BM25Similarity()
         for leaf in self.leaves:
@@ -467,7 +472,7 @@ class GpuIndexSearcher:
             at = 0
             for i, q in enumerate(queries):
                 w, cache = self.similarity.compute_weight(self.collection_statistics, [self.term_statistics(t) for t in q.terms], q.boost)
-                qs[i] = (len(q.terms), at, w, self.ctx.sim_table(cache, self.similarity.k1), q.slop, 0)
+                qs[i] = (len(q.terms), at, w, self.ctx.sim_table(cache, self.similarity.k1), q.slop, self.next_limit)
                 for t, p in zip(q.terms, q.positions):
                     sp = leaf.positions_state(t)
                     if sp is not None:

@@ -466,6 +466,44 @@ def test_lazy_disjunctions(oracle, knobs):
         ctx2.close()
 
 
+def test_doc_bitmaps_stay_inside_their_budget(oracle):
+    """rgpu_config.bitmap_budget_mib: doc bitmaps are an accelerator with a byte budget. Terms the budget has no room for are
+    walked — same answers (disjunctions under the heap-order rule, conjunctions bit-exact), nothing fails, the footprint says
+    how many terms were refused, and releasing the prepared terms gives the budget back."""
+    import rucene_amd
+    from rucene_amd import indexgen
+    max_doc = 150_001
+    rng = np.random.default_rng(778)
+    dfs = [1, 3, 70, 128, 200, 700, 1500, 2300, 5000, 9000, 20_000, 40_000, 75_000, 120_000, 30_000, 60_000, 100_000, 50_000]
+    lists = [_postings(rng, df, max_doc) for df in dfs]
+    norms = rng.integers(90, 130, size=max_doc).astype(np.uint8)
+    seg = indexgen.build_explicit(max_doc, lists, norms=norms)
+    oseg = oracle.Segment(seg.doc_bytes, seg.norms, max_doc, seg.terms, sum_total_term_freq=60 * max_doc)
+    osearcher = oracle.Searcher([oseg])
+    ctx2 = rucene_amd.Context(profile_kernels=True, bitmap_budget_mib=1)
+    try:
+        leaf = rucene_amd.LeafReader(seg.doc_bytes, seg.norms, max_doc, seg.terms, sum_total_term_freq=60 * max_doc)
+        gsearcher = rucene_amd.GpuIndexSearcher([leaf], ctx=ctx2)
+        or_specs = [(oracle.OP_OR, [0, 1, 2, 3, 4, 5, 6, 9, 10, 11]), (oracle.OP_OR, [3, 4, 5, 6, 11, 12, 13, 14, 15, 16]),
+                    (oracle.OP_OR, [8, 9, 10, 11, 12, 13, 14, 15, 16, 17])]
+        and_specs = [(oracle.OP_AND, [5, 12, 13]), (oracle.OP_AND, [9, 11, 14, 15]), (oracle.OP_AND, [10, 16, 17]), (oracle.OP_AND, [12, 13, 14, 15, 16, 17])]
+        for rnd in range(2):
+            _check_against_oracle(oracle, osearcher, gsearcher, or_specs, 10, exact=False)
+            _check_against_oracle(oracle, osearcher, gsearcher, and_specs, 10)
+            fp = leaf.segment.footprint()
+            # eight terms hold a doc in 64 or more; a bitmap here is >= 56 KB + doc_freq (+ 75 KB of nibbles): 1 MiB has no room for all
+            assert 0 < fp["doc_bitmap_bytes"] <= 1 << 20, fp
+            assert fp["doc_bitmap_terms"] >= 2 and fp["doc_bitmap_refused"] >= 1, fp
+            leaf.segment.release_prepared_terms()
+            fp = leaf.segment.footprint()
+            assert fp["doc_bitmap_bytes"] == 0 and fp["doc_bitmap_terms"] == 0 and fp["doc_bitmap_refused"] == 0
+    finally:
+        ctx2.close()
+    with pytest.raises(rucene_amd.RgpuError) as e:
+        rucene_amd.Context(bitmap_budget_mib=-1)
+    assert e.value.status == -2
+
+
 def test_long_clause_lists(zipf, oracle):
     """Up to RGPU_MAX_QUERY_TERMS = 64 clauses per query (a clause's cursor lives in a lane): conjunctions bit-exact, disjunctions
     of more than 16 clauses through the clause-order kernel (heap-order rule), MUST_NOT and min_should_match next to them,
@@ -1170,6 +1208,67 @@ def test_exact_phrases(ctx, oracle, version, max_doc):
     hits, totals = searcher.search_batch([T(0), B.build([T(1), T(2)], []), B.build([], [T(3), T(vocab + 1)])], 10)
     assert totals[0] == len(postings[0]) and totals[1] == len(set(d for d, _ in postings[1]) & set(d for d, _ in postings[2]))
     assert totals[2] == len(set(d for d, _ in postings[3]) | set(d for d, _ in postings[vocab + 1]))
+
+
+@pytest.mark.parametrize("deletions", [False, True], ids=["all-live", "deletions"])
+def test_phrases_two_phase_rule_and_deletions(ctx, oracle, deletions):
+    """Phrases over a segment with deleted docs, and BulkScorer's two-phase loop around the sloppy scorer (bulk_scorer.rs:91-113):
+    live docs are tested before matches() — the scorer's repetition groups come from the first LIVE candidate —, every conjunction
+    match counts as an approximation, and a leaf whose first next_limit + 1 approximations collect nothing yields nothing
+    (DefaultIndexSearcher::new(reader, next_limit), default 500 000). Exact phrases know no such limit."""
+    import rucene_amd
+    from rucene_amd import _lib as gpu
+    rng = np.random.default_rng(33)
+    max_doc, vocab = 6000, 6
+    docs = [rng.integers(0, vocab, size=int(rng.integers(1, 30))).tolist() if rng.random() < 0.9 else [] for _ in range(max_doc)]
+    for d in range(500):  # a front stretch where terms 0 and 1 are 60 positions apart: conjunction matches, no sloppy match
+        docs[d] = [0] + [5] * 59 + [1]
+    postings = [[] for _ in range(vocab)]
+    for d, toks in enumerate(docs):
+        where = {}
+        for p, t in enumerate(toks):
+            where.setdefault(t, []).append(p)
+        for t, ps in where.items():
+            postings[t].append((d, ps))
+    ix = oracle.PositionsIndex(max_doc, postings)
+    doc_bytes, pos_bytes = ix.files()
+    terms = np.zeros(vocab, dtype=gpu.TERM_STATE_DTYPE)
+    tpos = np.zeros(vocab, dtype=gpu.TERM_POSITIONS_DTYPE)
+    for t in range(vocab):
+        st = ix.term_state(t)
+        terms[t] = (st["doc_start_fp"], st["skip_offset"], st["total_term_freq"], st["doc_freq"], st["singleton_doc_id"])
+        tpos[t]["pos_start_fp"], tpos[t]["last_pos_block_offset"] = st["pos_start_fp"], st["last_pos_block_offset"]
+    norms = rng.integers(95, 125, size=max_doc).astype(np.uint8)
+    doc_count = sum(1 for toks in docs if toks)
+    sum_ttf = sum(len(toks) for toks in docs)
+    live = None
+    if deletions:
+        alive = rng.random(max_doc) < 0.7
+        alive[500:520] = False  # the first candidates behind the stretch are deleted: the groups come from a later doc
+        live = np.zeros((max_doc + 63) // 64, dtype=np.uint64)
+        for d in np.nonzero(alive)[0]:
+            live[d >> 6] |= np.uint64(1) << np.uint64(d & 63)
+    phrases = [([0, 1], 1), ([1, 0], 2), ([0, 1, 0], 2), ([0, 1, 2], 3), ([2, 3], 1), ([4, 4], 2), ([0, 1], 0), ([2, 3, 4], 0), ([0, 5, 1], 0)]
+    cut = matched = 0
+    for limit in (None, 1, 100, 499, 500, 3000):
+        leaf = rucene_amd.LeafReader(np.frombuffer(doc_bytes, np.uint8), norms, max_doc, terms, live_docs=live, doc_count=doc_count,
+                                     sum_total_term_freq=sum_ttf, index_options=3)
+        leaf.pos_bytes, leaf.term_positions = np.frombuffer(pos_bytes, np.uint8), tpos
+        searcher = rucene_amd.GpuIndexSearcher([leaf], ctx=ctx, next_limit=limit)
+        queries = [rucene_amd.PhraseQuery(t, slop=sl) for t, sl in phrases]
+        for k in (10, 100):
+            hits, totals = searcher.search_phrase_batch(queries, k)
+            for i, q in enumerate(queries):
+                d, s, total = ix.phrase_search(q.terms, k, norms, max_doc, doc_count, sum_ttf, slop=q.slop, live_docs=live, next_limit=limit)
+                assert totals[i] == total, (limit, q.terms, q.slop, totals[i], total)
+                assert (hits[i]["doc"][:d.size] == d).all() and (hits[i]["doc"][d.size:] == -1).all(), (limit, q.terms, q.slop)
+                assert (hits[i]["score"][:d.size].view(np.int32) == s.view(np.int32)).all(), (limit, q.terms, q.slop)
+                matched += total
+                if q.slop > 0 and total == 0:
+                    cut += 1
+        leaf.segment.close()
+    assert cut >= 4 and matched > 1000  # [0, 1] / [1, 0] / [0, 1, 0] meet the 500-doc stretch first: cut off for the small limits
+    ix.close()
 
 
 @pytest.mark.parametrize("with_pf", [True, False], ids=["ef-where-smaller", "ef-always"])

@@ -303,3 +303,67 @@ def test_sloppy_with_slop_zero_finds_the_exact_scorers_docs(oracle):
         d, f = ix.sloppy_freqs(tids, 0)
         assert d.tolist() == exact and d.size > 0
     ix.close()
+
+
+# ---- BulkScorer's two-phase loop around the sloppy scorer (bulk_scorer.rs:91-113) ----------------------------------------------
+def _python_two_phase(postings, term_ids, offsets, slop, live, next_limit):
+    """score_range_in_docs_set, two-phase arm: the live-docs test comes before matches() (so the scorer's first-doc
+    initialisation happens on the first LIVE candidate), every approximation counts towards `next`, and the leaf is abandoned
+    once more than next_limit approximations went by without a collected doc."""
+    by_term = [dict(postings[t]) for t in term_ids]
+    common = sorted(set.intersection(*[set(b) for b in by_term]))
+    sc = _Sloppy(list(offsets), list(term_ids), slop)
+    out, nxt = [], 0
+    for d in common:
+        if live is None or live[d]:
+            f = sc.phrase_freq([b[d] for b in by_term])
+            if f > np.finfo(np.float32).eps:
+                out.append((d, f))
+        nxt += 1
+        if not out and nxt > next_limit:
+            break
+    return out
+
+
+def _live_words(live):
+    words = np.zeros((live.size + 63) // 64, dtype=np.uint64)
+    for d in np.nonzero(live)[0]:
+        words[d >> 6] |= np.uint64(1) << np.uint64(d & 63)
+    return words
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_two_phase_loop_live_docs_and_next_limit(oracle, seed):
+    """Sloppy phrases go through BulkScorer's two-phase arm: deleted docs are never handed to matches(), and a leaf whose first
+    next_limit + 1 conjunction matches produce no collected doc yields nothing at all (DEFAULT_DISMATCH_NEXT_LIMIT,
+    searcher.rs:47). The exact scorer is not two-phase in the reference: no limit applies to it."""
+    rng = np.random.default_rng(seed)
+    max_doc = 2500
+    postings = _random_positions_index(rng, max_doc, 5, 0.5, 5, 60)
+    # a stretch at the front where terms 0 and 1 sit far apart: conjunction matches, no phrase match for a small slop
+    for t, at in ((0, 0), (1, 50)):
+        postings[t] = [(d, [at]) if d < 400 else (d, ps) for d, ps in postings[t]]
+    ix = oracle.PositionsIndex(max_doc, postings)
+    norms = rng.integers(95, 125, size=max_doc).astype(np.uint8)
+    live = rng.random(max_doc) < 0.8
+    words = _live_words(live)
+    checked = cut = 0
+    for tids, offs in (([0, 1], None), ([1, 0], None), ([0, 1, 2], None), ([0, 1, 0], None), ([3, 4], None), ([2, 2], None)):
+        offs = list(range(len(tids))) if offs is None else offs
+        for slop in (1, 3):
+            for lv, lw in ((None, None), (live, words)):
+                unlimited = _python_two_phase(postings, tids, offs, slop, lv, 1 << 40)
+                for limit in (None, 0, 5, 60, 150, 10_000):
+                    want = _python_two_phase(postings, tids, offs, slop, lv, 500_000 if limit is None else limit)
+                    docs, scores, total = ix.phrase_search(tids, max_doc, norms, max_doc, max_doc, 60 * max_doc, offsets=offs, slop=slop,
+                                                           live_docs=lw, next_limit=limit)
+                    assert total == len(want) and sorted(docs.tolist()) == [d for d, _ in want], (tids, slop, limit, lv is not None)
+                    assert len(want) in (0, len(unlimited))  # all or nothing
+                    cut += 1 if (unlimited and not want) else 0
+                    checked += 1
+    assert checked == 6 * 2 * 2 * 6 and cut >= 8
+    # the exact scorer: live docs filter its matches, next_limit does not exist for it
+    exact = [d for d, _ in ix.phrase_freqs([3, 4])]
+    docs, _, total = ix.phrase_search([3, 4], max_doc, norms, max_doc, max_doc, 60 * max_doc, live_docs=words, next_limit=0)
+    assert total == sum(1 for d in exact if live[d]) > 0 and sorted(docs.tolist()) == [d for d in exact if live[d]]
+    ix.close()
