@@ -15,6 +15,11 @@ constexpr int DECODE_PREFETCH_DEPTH = RGPU_DECODE_DEPTH;
 #ifndef RGPU_DECODE_BURST  // blocks decoded into registers before their stores go out together (0 / 1: block by block). Measured on
 #define RGPU_DECODE_BURST 4  // the 100 M-doc shard, one box, same session: 0.735 ms block by block, 0.656 (2), 0.584 (4), 0.611 (8)
 #endif
+// (Round 4: the burst as 16-byte stores — values transposed through the slab so that every lane holds four consecutive output
+// dwords, the term's misalignment folded into the LDS index — measured SLOWER: 0.057 vs 0.053 ms at 10 M docs, 0.726 vs 0.694
+// at 100 M on one box; the same for k_prepare_blocks' fused output, 1.23 vs 1.14 ms. The compiler already merges a lane's two
+// dwords into one 8-byte store; the stream is not issue-bound, and the LDS round trip costs more than the wider stores save.
+// scripts/experiments/stores_x4.patch.)
 #ifndef RGPU_DECODE_PLAIN_STORES
 #define RGPU_DECODE_PLAIN_STORES 0
 #endif
