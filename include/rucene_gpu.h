@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RGPU_ABI_VERSION 4
+#define RGPU_ABI_VERSION 5
 #define RGPU_NO_MORE_DOCS 0x7fffffff /* search/mod.rs:59 */
 #define RGPU_BLOCK_SIZE 128          /* codec/postings/posting_format.rs:36 */
 #define RGPU_MAX_QUERY_TERMS 64  /* clauses of one query, MUST + SHOULD + MUST_NOT together: a clause's cursor lives in a lane of the
@@ -175,9 +175,15 @@ int32_t rgpu_segment_upload(rgpu_ctx* ctx, const uint8_t* doc_file, size_t doc_l
 /* The same for a field of the given doc::IndexOptions ordinal: 1 = Docs (no freq block follows a doc block, the VInt
  * tail holds plain deltas, every freq reads as 1 and a FREQS-less iterator's skip_block has nothing to skip:
  * posting_reader.rs:532-557, for_util.rs:263-272), 2 = DocsAndFreqs (what rgpu_segment_upload assumes).
- * 3 = DocsAndFreqsAndPositions without payloads (skip entries carry position pointers; see
- * rgpu_segment_attach_positions / rgpu_search_phrase_batch). Offsets (4) -> RGPU_ERR_UNSUPPORTED. For a Docs field
- * rgpu_term_state.total_term_freq is ignored. */
+ * 3 = DocsAndFreqsAndPositions (skip entries carry position pointers; see rgpu_segment_attach_positions /
+ * rgpu_search_phrase_batch), 4 = DocsAndFreqsAndPositionsAndOffsets; a field whose FieldInfo::has_store_payloads is set
+ * passes index_options | RGPU_FIELD_STORES_PAYLOADS (3 or 4). Such fields keep payloads and offsets in a third file
+ * (".pay", rgpu_segment_attach_payloads), their skip entries carry one or two more words (skip_writer.rs:276-286) and the
+ * trailing VInt block of a term's positions carries payload bytes and offset words between the position deltas
+ * (posting_writer.rs:505-560): every search entry point — TERM / AND / OR, exact and sloppy phrases — serves them; what the
+ * reference's scorers never ask for (EverythingIterator's payload() / start_offset() / end_offset(), posting_reader.rs:
+ * 1595-2337) is not decoded on the GPU. For a Docs field rgpu_term_state.total_term_freq is ignored. */
+#define RGPU_FIELD_STORES_PAYLOADS 0x100
 int32_t rgpu_segment_upload_field(rgpu_ctx* ctx, const uint8_t* doc_file, size_t doc_len, const uint8_t* norms_or_null,
                                   int32_t max_doc, int32_t doc_base, const uint64_t* live_docs_or_null, int32_t index_options,
                                   rgpu_segment** out_seg);
@@ -487,6 +493,10 @@ int32_t rgpu_plan_batch_bytes(rgpu_planner* planner, int32_t n_queries, const in
  * header "Lucene50PostingsWriterPos", the .doc file's version, segment id and suffix; footer). Needed before
  * rgpu_search_phrase_batch; TERM / AND / OR search of a positions field works without it. */
 int32_t rgpu_segment_attach_positions(rgpu_segment* seg, const uint8_t* pos_file, size_t pos_len);
+/* The ".pay" file of a segment whose field stores payloads or offsets (posting_reader.rs:131-156: header
+ * "Lucene50PostingsWriterPay", the .doc file's version, segment id and suffix; footer): checked as open() checks it. No
+ * search needs its bytes (see rgpu_segment_upload_field), so none are kept in HBM. */
+int32_t rgpu_segment_attach_payloads(rgpu_segment* seg, const uint8_t* pay_file, size_t pay_len);
 /* One term of a phrase: its postings (BlockTermState), its position-stream pointers (rgpu_terms_lookup_positions) and
  * its position inside the phrase (PhraseQuery::build numbers them 0, 1, 2, ...; query/phrase_query.rs:60-110). */
 typedef struct rgpu_phrase_term {

@@ -130,6 +130,10 @@ def _declare(L):
         "orc_search_opt": (C.c_int, [vp, C.c_int, i64p, C.c_int, i64p, C.c_int, i64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, i32p,
                                      f32p, i32p, i64p]),
         "orc_pos_index_build": (vp, [C.c_int32, C.c_int32, C.c_int32, i64p, i32p, i32p, i64p, i32p]),
+        "orc_pos_index_build_ex": (vp, [C.c_int32, C.c_int32, C.c_int32, i64p, i32p, i32p, i64p, i32p, C.c_int32, i32p, i32p, i64p, u8p]),
+        "orc_pos_index_pay": (C.c_int64, [vp, u8p]),
+        "orc_pos_iterate_everything": (C.c_int64, [vp, C.c_int32, C.c_int32, i32p, C.c_int64, C.c_int32, C.c_int32, i32p, i32p, i32p, C.c_int64,
+                                                   i32p, i32p, i32p, i32p, C.c_int64, u8p, C.c_int64, C.POINTER(C.c_int64)]),
         "orc_pos_index_free": (None, [vp]),
         "orc_pos_index_copy": (None, [vp, u8p, u8p]),
         "orc_pos_index_sizes": (C.c_int64, [vp, i64p, i64p]),
@@ -866,22 +870,39 @@ def segments_file_read(data, generation, max_docs=None):
 # ---- positions (".pos" + BlockPostingIterator) -------------------------------------------------------------------------
 class PositionsIndex:
     """A docs+freqs+positions field written by the restated Lucene50PostingsWriter. postings: per term a list of
-    (doc, [positions...]) in doc order."""
+    (doc, [positions...]) in doc order. offsets / payloads: the field also stores them (IndexOptions::DocsAndFreqsAndPositionsAndOffsets
+    / FieldInfo::has_store_payloads -> a third file, ".pay"); a doc's entry is then (doc, [positions], [(start, end), ...], [payload bytes, ...])
+    — the two extra lists may be None / shorter tuples when their feature is off."""
 
-    def __init__(self, max_doc, postings, version=1):
+    def __init__(self, max_doc, postings, version=1, offsets=False, payloads=False):
         docs, freqs, positions, doc_offs, pos_offs = [], [], [], [0], [0]
+        starts, ends, pay_offs, pay_bytes = [], [], [0], bytearray()
         for plist in postings:
-            for d, ps in plist:
+            for entry in plist:
+                d, ps = entry[0], entry[1]
                 docs.append(d)
                 freqs.append(len(ps))
                 positions.extend(ps)
                 pos_offs.append(len(positions))
+                if offsets:
+                    assert len(entry[2]) == len(ps)
+                    starts.extend(o[0] for o in entry[2])
+                    ends.extend(o[1] for o in entry[2])
+                if payloads:
+                    assert len(entry[3]) == len(ps)
+                    for b in entry[3]:
+                        pay_bytes += bytes(b)
+                        pay_offs.append(len(pay_bytes))
             doc_offs.append(len(docs))
         a = lambda v, t: np.ascontiguousarray(v if len(v) else [0], dtype=t)
-        self._args = (a(doc_offs, np.int64), a(docs, np.int32), a(freqs, np.int32), a(pos_offs, np.int64), a(positions, np.int32))
+        self.offsets, self.payloads = bool(offsets), bool(payloads)
+        self._args = (a(doc_offs, np.int64), a(docs, np.int32), a(freqs, np.int32), a(pos_offs, np.int64), a(positions, np.int32),
+                      a(starts, np.int32), a(ends, np.int32), a(pay_offs, np.int64), a(np.frombuffer(bytes(pay_bytes), np.uint8), np.uint8))
         self.n_terms = len(postings)
-        self._h = lib().orc_pos_index_build(int(max_doc), int(version), self.n_terms, _p(self._args[0], C.c_int64), _p(self._args[1], C.c_int32),
-                                            _p(self._args[2], C.c_int32), _p(self._args[3], C.c_int64), _p(self._args[4], C.c_int32))
+        self._h = lib().orc_pos_index_build_ex(int(max_doc), int(version), self.n_terms, _p(self._args[0], C.c_int64), _p(self._args[1], C.c_int32),
+                                           _p(self._args[2], C.c_int32), _p(self._args[3], C.c_int64), _p(self._args[4], C.c_int32),
+                                           (1 if offsets else 0) | (2 if payloads else 0), _p(self._args[5], C.c_int32), _p(self._args[6], C.c_int32),
+                                           _p(self._args[7], C.c_int64), _p(self._args[8], C.c_uint8))
         if not self._h:
             raise OracleError(lib().orc_last_error().decode())
 
@@ -897,11 +918,42 @@ class PositionsIndex:
         lib().orc_pos_index_copy(self._h, _p(d, C.c_uint8), _p(p, C.c_uint8))
         return d.tobytes(), p.tobytes()
 
+    def pay_file(self):
+        """-> the .pay bytes (b"" when the field stores neither payloads nor offsets)"""
+        n = lib().orc_pos_index_pay(self._h, None)
+        out = np.zeros(max(n, 1), np.uint8)
+        lib().orc_pos_index_pay(self._h, _p(out, C.c_uint8))
+        return out[:n].tobytes()
+
     def term_state(self, term):
-        out = np.zeros(7, dtype=np.int64)
+        out = np.zeros(8, dtype=np.int64)
         _check(lib().orc_pos_term_state(self._h, term, _p(out, C.c_int64)))
         return dict(zip(("doc_start_fp", "skip_offset", "total_term_freq", "doc_freq", "singleton_doc_id", "pos_start_fp",
-                         "last_pos_block_offset"), out.tolist()))
+                         "last_pos_block_offset", "pay_start_fp"), out.tolist()))
+
+    def iterate_everything(self, term, flags=0x78, targets=None, read_every=1, max_positions=-1, cap_visits=1 << 20, cap_positions=1 << 22,
+                           cap_payload_bytes=1 << 24):
+        """EverythingIterator (posting_reader.rs:1595-2337) -> [(doc, freq, [(position, start_offset, end_offset, payload bytes)])].
+        flags: PostingIteratorFlags (0x58 PAYLOADS, 0x38 OFFSETS, 0x78 ALL)."""
+        tg = None if targets is None else np.ascontiguousarray(targets, dtype=np.int32)
+        docs, freqs, npos = (np.zeros(cap_visits, np.int32) for _ in range(3))
+        pos, st, en, pl = (np.zeros(cap_positions, np.int32) for _ in range(4))
+        pb = np.zeros(cap_payload_bytes, np.uint8)
+        total = C.c_int64(0)
+        n = _check(lib().orc_pos_iterate_everything(self._h, term, int(flags), _p(tg, C.c_int32), 0 if tg is None else tg.size, read_every,
+                                                max_positions, _p(docs, C.c_int32), _p(freqs, C.c_int32), _p(npos, C.c_int32), cap_visits,
+                                                _p(pos, C.c_int32), _p(st, C.c_int32), _p(en, C.c_int32), _p(pl, C.c_int32), cap_positions,
+                                                _p(pb, C.c_uint8), cap_payload_bytes, C.byref(total)))
+        out, at, bat = [], 0, 0
+        raw = pb[:total.value].tobytes()
+        for i in range(n):
+            ps = []
+            for j in range(at, at + int(npos[i])):
+                ps.append((int(pos[j]), int(st[j]), int(en[j]), raw[bat:bat + int(pl[j])]))
+                bat += int(pl[j])
+            out.append((int(docs[i]), int(freqs[i]), ps))
+            at += int(npos[i])
+        return out
 
     def iterate(self, term, targets=None, read_every=1, max_positions=-1, cap_visits=1 << 20, cap_positions=1 << 22):
         """-> [(doc, freq, [positions read])]; targets None: next() to the end, else advance(t) for each t."""

@@ -803,20 +803,27 @@ int orc_segments_file_read(const uint8_t* data, int64_t len, int64_t generation,
 
 // ---- positions: .pos file + BlockPostingIterator (oracle/positions.hpp) ---------------------------------------------
 struct orc_pos_index {
-  std::vector<uint8_t> doc, pos;
+  std::vector<uint8_t> doc, pos, pay;
   std::vector<PosTermState> terms;
   std::unique_ptr<PostingsReader> reader;
   std::unique_ptr<PosFile> pos_file;
+  std::unique_ptr<PayFile> pay_file;
+  PosFieldFlags field;
 };
 // Term t owns docs [doc_offs[t], doc_offs[t+1]) with freqs; doc j owns positions [pos_offs[j], pos_offs[j+1]) (pos_offs is
-// indexed by the flat doc slot, so pos_offs[j+1] - pos_offs[j] == freqs[j]).
-orc_pos_index* orc_pos_index_build(int32_t max_doc, int32_t version, int32_t n_terms, const int64_t* doc_offs, const int32_t* docs,
-                                   const int32_t* freqs, const int64_t* pos_offs, const int32_t* positions) {
+// indexed by the flat doc slot, so pos_offs[j+1] - pos_offs[j] == freqs[j]). field_flags: bit 0 = the field stores offsets
+// (start_offsets / end_offsets per position), bit 1 = payloads (position p's payload = payload_bytes[payload_offs[p], payload_offs[p+1])).
+orc_pos_index* orc_pos_index_build_ex(int32_t max_doc, int32_t version, int32_t n_terms, const int64_t* doc_offs, const int32_t* docs,
+                                      const int32_t* freqs, const int64_t* pos_offs, const int32_t* positions, int32_t field_flags,
+                                      const int32_t* start_offsets, const int32_t* end_offsets, const int64_t* payload_offs,
+                                      const uint8_t* payload_bytes) {
   try {
     auto h = std::make_unique<orc_pos_index>();
+    h->field.has_offsets = (field_flags & 1) != 0;
+    h->field.has_payloads = (field_flags & 2) != 0;
     uint8_t id[ID_LENGTH];
     for (int i = 0; i < ID_LENGTH; i++) id[i] = (uint8_t)i;  // the synthetic index writer's default segment id
-    PosPostingsWriter w(max_doc, version, id, "Lucene50_0");
+    PosPostingsWriter w(max_doc, version, id, "Lucene50_0", h->field.has_offsets, h->field.has_payloads);
     for (int32_t t = 0; t < n_terms; t++) {
       PosTermState st;
       w.start_term();
@@ -824,7 +831,11 @@ orc_pos_index* orc_pos_index_build(int32_t max_doc, int32_t version, int32_t n_t
       for (int64_t j = doc_offs[t]; j < doc_offs[t + 1]; j++) {
         if (pos_offs[j + 1] - pos_offs[j] != freqs[j]) throw OracleError(E_ILLEGAL_ARGUMENT, "positions per doc must equal freq");
         w.start_doc(docs[j], freqs[j]);
-        for (int64_t p = pos_offs[j]; p < pos_offs[j + 1]; p++) w.add_position(positions[p]);
+        for (int64_t p = pos_offs[j]; p < pos_offs[j + 1]; p++) {
+          const uint8_t* pl = h->field.has_payloads ? payload_bytes + payload_offs[p] : nullptr;
+          const size_t pn = h->field.has_payloads ? (size_t)(payload_offs[p + 1] - payload_offs[p]) : 0;
+          w.add_position(positions[p], pl, pn, h->field.has_offsets ? start_offsets[p] : 0, h->field.has_offsets ? end_offsets[p] : 0);
+        }
         w.finish_doc();
         ttf += freqs[j];
       }
@@ -836,23 +847,33 @@ orc_pos_index* orc_pos_index_build(int32_t max_doc, int32_t version, int32_t n_t
     w.close();
     h->doc = std::move(w.doc_out.buf);
     h->pos = std::move(w.pos_out.buf);
+    h->pay = std::move(w.pay_out.buf);
     h->reader = std::make_unique<PostingsReader>(h->doc.data(), (int64_t)h->doc.size());
     h->pos_file = std::make_unique<PosFile>(h->pos.data(), (int64_t)h->pos.size(), h->reader->version);
+    if (w.has_pay()) h->pay_file = std::make_unique<PayFile>(h->pay.data(), (int64_t)h->pay.size(), h->reader->version);
     return h.release();
   } catch (const std::exception& e) { g_err = e.what(); return nullptr; }
+}
+orc_pos_index* orc_pos_index_build(int32_t max_doc, int32_t version, int32_t n_terms, const int64_t* doc_offs, const int32_t* docs,
+                                   const int32_t* freqs, const int64_t* pos_offs, const int32_t* positions) {
+  return orc_pos_index_build_ex(max_doc, version, n_terms, doc_offs, docs, freqs, pos_offs, positions, 0, nullptr, nullptr, nullptr, nullptr);
 }
 void orc_pos_index_free(orc_pos_index* h) { delete h; }
 void orc_pos_index_copy(orc_pos_index* h, uint8_t* doc_out, uint8_t* pos_out) {
   std::memcpy(doc_out, h->doc.data(), h->doc.size());
   std::memcpy(pos_out, h->pos.data(), h->pos.size());
 }
+int64_t orc_pos_index_pay(orc_pos_index* h, uint8_t* pay_out_or_null) {  // -> length of the .pay file (0: the field has none)
+  if (pay_out_or_null) std::memcpy(pay_out_or_null, h->pay.data(), h->pay.size());
+  return (int64_t)h->pay.size();
+}
 int64_t orc_pos_index_sizes(orc_pos_index* h, int64_t* doc_len, int64_t* pos_len) { *doc_len = (int64_t)h->doc.size(); *pos_len = (int64_t)h->pos.size(); return (int64_t)h->terms.size(); }
-// out7: doc_start_fp, skip_offset, total_term_freq, doc_freq, singleton_doc_id, pos_start_fp, last_pos_block_offset
-int orc_pos_term_state(orc_pos_index* h, int32_t term, int64_t* out7) {
+// out8: doc_start_fp, skip_offset, total_term_freq, doc_freq, singleton_doc_id, pos_start_fp, last_pos_block_offset, pay_start_fp
+int orc_pos_term_state(orc_pos_index* h, int32_t term, int64_t* out8) {
   ORC_TRY
   const PosTermState& s = h->terms.at((size_t)term);
-  out7[0] = s.base.doc_start_fp; out7[1] = s.base.skip_offset; out7[2] = s.base.total_term_freq; out7[3] = s.base.doc_freq;
-  out7[4] = s.base.singleton_doc_id; out7[5] = s.pos_start_fp; out7[6] = s.last_pos_block_offset;
+  out8[0] = s.base.doc_start_fp; out8[1] = s.base.skip_offset; out8[2] = s.base.total_term_freq; out8[3] = s.base.doc_freq;
+  out8[4] = s.base.singleton_doc_id; out8[5] = s.pos_start_fp; out8[6] = s.last_pos_block_offset; out8[7] = s.pay_start_fp;
   return 0;
   ORC_CATCH
 }
@@ -866,7 +887,7 @@ int64_t orc_pos_iterate(orc_pos_index* h, int32_t term, const int32_t* targets, 
   ORC_TRY
   const PosTermState& st = h->terms.at((size_t)term);
   if (st.base.doc_freq <= 0) return 0;
-  BlockPostingIterator it(h->reader.get(), h->pos_file.get(), st);
+  BlockPostingIterator it(h->reader.get(), h->pos_file.get(), st, h->field);
   if (it.doc_id() != -1) throw OracleError(E_ILLEGAL_STATE, "iterator must start unpositioned");
   int64_t visits = 0, npos_total = 0, ti = 0;
   while (true) {
@@ -893,6 +914,60 @@ int64_t orc_pos_iterate(orc_pos_index* h, int32_t term, const int32_t* targets, 
     out_npos[visits] = np;
     visits++;
   }
+  return visits;
+  ORC_CATCH
+}
+
+// The same drive loop over an EverythingIterator (flags: PostingIteratorFlags — 0x58 PAYLOADS, 0x38 OFFSETS, 0x78 ALL): per
+// position read also start / end offset and the payload (lengths per position, bytes concatenated).
+int64_t orc_pos_iterate_everything(orc_pos_index* h, int32_t term, int32_t flags, const int32_t* targets, int64_t n_targets, int32_t read_every,
+                                   int32_t max_positions, int32_t* out_docs, int32_t* out_freqs, int32_t* out_npos, int64_t cap_visits,
+                                   int32_t* out_positions, int32_t* out_starts, int32_t* out_ends, int32_t* out_payload_lens, int64_t cap_positions,
+                                   uint8_t* out_payload_bytes, int64_t cap_payload_bytes, int64_t* out_payload_total) {
+  ORC_TRY
+  const PosTermState& st = h->terms.at((size_t)term);
+  *out_payload_total = 0;
+  if (st.base.doc_freq <= 0) return 0;
+  if (!h->pay_file) throw OracleError(E_ILLEGAL_STATE, "the field stores neither payloads nor offsets: postings() hands out a BlockPostingIterator");
+  EverythingIterator it(h->reader.get(), h->pos_file.get(), h->pay_file.get(), h->field, st, (uint16_t)flags);
+  if (it.doc_id() != -1) throw OracleError(E_ILLEGAL_STATE, "iterator must start unpositioned");
+  int64_t visits = 0, npos_total = 0, ti = 0, nbytes = 0;
+  while (true) {
+    int32_t d;
+    if (targets) {
+      if (ti >= n_targets) break;
+      d = it.advance(targets[ti++]);
+    } else {
+      d = it.next();
+    }
+    if (d == NO_MORE_DOCS) {
+      if (targets && visits < cap_visits) { out_docs[visits] = d; out_freqs[visits] = 0; out_npos[visits] = 0; visits++; continue; }
+      break;
+    }
+    if (visits >= cap_visits) throw OracleError(E_ILLEGAL_ARGUMENT, "visit capacity exceeded");
+    out_docs[visits] = d;
+    out_freqs[visits] = it.freq();
+    int32_t np = 0;
+    if (read_every > 0 && visits % read_every == 0) {
+      np = max_positions < 0 ? it.freq() : std::min(it.freq(), max_positions);
+      if (npos_total + np > cap_positions) throw OracleError(E_ILLEGAL_ARGUMENT, "position capacity exceeded");
+      for (int32_t i = 0; i < np; i++) {
+        out_positions[npos_total] = it.next_position();
+        out_starts[npos_total] = it.start_offset();
+        out_ends[npos_total] = it.end_offset();
+        // (payload() is only meaningful when PAYLOADS was requested: otherwise the lengths of whole blocks are never loaded)
+        const std::vector<uint8_t> pl = feature_requested((uint16_t)flags, FLAG_PAYLOADS) ? it.payload() : std::vector<uint8_t>();
+        out_payload_lens[npos_total] = (int32_t)pl.size();
+        if (nbytes + (int64_t)pl.size() > cap_payload_bytes) throw OracleError(E_ILLEGAL_ARGUMENT, "payload capacity exceeded");
+        if (!pl.empty()) std::memcpy(out_payload_bytes + nbytes, pl.data(), pl.size());
+        nbytes += (int64_t)pl.size();
+        npos_total++;
+      }
+    }
+    out_npos[visits] = np;
+    visits++;
+  }
+  *out_payload_total = nbytes;
   return visits;
   ORC_CATCH
 }
@@ -940,7 +1015,7 @@ static std::unique_ptr<ExactPhraseScorer> make_phrase_scorer(orc_pos_index* h, c
   for (int i : order) {
     const PosTermState& st = h->terms.at((size_t)term_ids[i]);
     if (st.base.doc_freq <= 0) return nullptr;
-    its.emplace_back(new BlockPostingIterator(h->reader.get(), h->pos_file.get(), st));
+    its.emplace_back(new BlockPostingIterator(h->reader.get(), h->pos_file.get(), st, h->field));
     offs.push_back(offsets[i]);
   }
   return std::make_unique<ExactPhraseScorer>(std::move(its), offs, w, norms, needs_scores);
@@ -998,7 +1073,7 @@ static std::unique_ptr<SloppyPhraseScorer> make_sloppy_scorer(orc_pos_index* h, 
   for (int i = 0; i < n; i++) {
     const PosTermState& st = h->terms.at((size_t)term_ids[i]);
     if (st.base.doc_freq <= 0) return nullptr;
-    its.emplace_back(new BlockPostingIterator(h->reader.get(), h->pos_file.get(), st));
+    its.emplace_back(new BlockPostingIterator(h->reader.get(), h->pos_file.get(), st, h->field));
     offs.push_back(offsets[i]);
     terms.push_back(term_ids[i]);
   }

@@ -8,7 +8,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_NAME = "librucene_gpu.so"
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 OP_TERM, OP_AND, OP_OR = 0, 1, 2
 MAX_K = 1024
 MAX_QUERY_TERMS = 64
@@ -32,6 +32,7 @@ FIELD_INFO_DTYPE = np.dtype([("number", "<i4"), ("index_options", "<i4"), ("has_
 FIELD_STATS_DTYPE = np.dtype([("num_terms", "<i8"), ("sum_total_term_freq", "<i8"), ("sum_doc_freq", "<i8"), ("doc_count", "<i4"),
                               ("longs_size", "<i4")], align=True)
 INDEX_OPTIONS_DOCS, INDEX_OPTIONS_DOCS_AND_FREQS, INDEX_OPTIONS_POSITIONS, INDEX_OPTIONS_OFFSETS = 1, 2, 3, 4
+FIELD_STORES_PAYLOADS = 0x100  # RGPU_FIELD_STORES_PAYLOADS: or-ed into index_options (>= 3) at upload
 TERM_POSITIONS_DTYPE = np.dtype([("pos_start_fp", "<i8"), ("pay_start_fp", "<i8"), ("last_pos_block_offset", "<i8")], align=True)
 SEGMENT_INFO_DTYPE = np.dtype([("max_doc", "<i4"), ("is_compound_file", "<i4"), ("version", "<i4", (3,)), ("n_files", "<i4"),
                                ("n_sort_fields", "<i4"), ("reserved", "<i4"), ("id", "u1", (16,))], align=True)
@@ -48,7 +49,7 @@ STATUS_NAMES = {0: "OK", -1: "IllegalState", -2: "IllegalArgument", -3: "Unexpec
 # every symbol include/rucene_gpu.h declares (tests/test_abi.py checks the header and this list agree)
 EXPORTS = [
     "rgpu_init", "rgpu_shutdown", "rgpu_last_error", "rgpu_abi_version", "rgpu_device_name", "rgpu_segment_upload",
-    "rgpu_segment_upload_field", "rgpu_segment_release_prepared_terms", "rgpu_segment_get_footprint", "rgpu_segment_attach_positions", "rgpu_search_phrase_batch", "rgpu_rescore_batch",
+    "rgpu_segment_upload_field", "rgpu_segment_release_prepared_terms", "rgpu_segment_get_footprint", "rgpu_segment_attach_positions", "rgpu_segment_attach_payloads", "rgpu_search_phrase_batch", "rgpu_rescore_batch",
     "rgpu_segment_free", "rgpu_segment_version", "rgpu_segment_prepare_terms", "rgpu_decode_terms",
     "rgpu_decode_terms_device", "rgpu_advance_batch", "rgpu_sim_table_upload", "rgpu_search_batch",
     "rgpu_search_batch_device", "rgpu_merge_topk_device", "rgpu_bm25_compute_weight", "rgpu_bm25_encode_norm", "rgpu_bm25_term_weights",
@@ -137,6 +138,7 @@ def lib():
         "rgpu_segment_release_prepared_terms": (i32, [vp]),
         "rgpu_segment_get_footprint": (i32, [vp, vp]),
         "rgpu_segment_attach_positions": (i32, [vp, vp, C.c_size_t]),
+        "rgpu_segment_attach_payloads": (i32, [vp, vp, C.c_size_t]),
         "rgpu_search_phrase_batch": (i32, [vp, vp, i32, vp, i32, i32, vp, vp]),
         "rgpu_rescore_batch": (i32, [vp, vp, i32, vp, i32, vp, i32, vp, i32]),
         "rgpu_decode_terms": (i32, [vp, vp, i64, vp, vp]),
@@ -609,6 +611,11 @@ class Segment:
         """The segment's ".pos" file (a field uploaded with index_options = 3)."""
         pos = np.ascontiguousarray(pos_bytes, dtype=np.uint8)
         _check(lib().rgpu_segment_attach_positions(self._h, pos.ctypes.data, pos.size))
+
+    def attach_payloads(self, pay_bytes):
+        """The segment's ".pay" file (a field uploaded with index_options 4 and / or FIELD_STORES_PAYLOADS): validated, not kept."""
+        pay = np.ascontiguousarray(pay_bytes, dtype=np.uint8)
+        _check(lib().rgpu_segment_attach_payloads(self._h, pay.ctypes.data, pay.size))
 
     def search_phrase_batch(self, queries, terms, k):
         q = np.ascontiguousarray(queries, dtype=PHRASE_QUERY_DTYPE)

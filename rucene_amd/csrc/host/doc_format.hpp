@@ -83,31 +83,38 @@ inline int parse_doc_file(const uint8_t* data, size_t len, DocFileInfo* out, std
   return 0;
 }
 
-// The ".pos" file of a positions field (posting_reader.rs:112-158: opened next to .doc with the same version; header
-// "Lucene50PostingsWriterPos", same segment id and suffix as the .doc file, footer magic). No ForUtil table: the .doc
-// file's applies. `doc_file` is the segment's already validated .doc image.
-inline int parse_pos_file(const uint8_t* data, size_t len, const uint8_t* doc_file, int32_t doc_version, int64_t* postings_start,
-                          std::string* why) {
+// The ".pos" file of a positions field, or the ".pay" file of one that stores payloads / offsets (posting_reader.rs:112-158:
+// opened next to .doc with the same version; header "Lucene50PostingsWriterPos" / "...Pay", same segment id and suffix as the
+// .doc file, footer magic). No ForUtil table: the .doc file's applies. `doc_file` is the segment's already validated .doc image.
+inline int parse_side_file(const uint8_t* data, size_t len, const char* codec, const char* ext, const uint8_t* doc_file, int32_t doc_version,
+                           int64_t* postings_start, std::string* why) {
   const int ERR_CORRUPT = -4, ERR_EOF = -3;
-  static const char kCodec[] = "Lucene50PostingsWriterPos";
   static const char kDoc[] = "Lucene50PostingsWriterDoc";
-  if (len < 16 + 4 + 1 + sizeof(kCodec) - 1 + 4 + 16 + 1) { *why = ".pos file too short"; return ERR_EOF; }
+  const size_t codec_len = std::strlen(codec);
+  const std::string x(ext);
+  if (len < 16 + 4 + 1 + codec_len + 4 + 16 + 1) { *why = x + " file too short"; return ERR_EOF; }
   detail::Cursor c{data, len};
-  if (c.be32() != 0x3FD76C17u) { *why = ".pos: codec header mismatch (bad magic)"; return ERR_CORRUPT; }
+  if (c.be32() != 0x3FD76C17u) { *why = x + ": codec header mismatch (bad magic)"; return ERR_CORRUPT; }
   const uint32_t n = c.vint();
-  if (!c.ok || n != sizeof(kCodec) - 1 || std::memcmp(data + c.pos, kCodec, n) != 0) { *why = "codec mismatch: expected Lucene50PostingsWriterPos"; return ERR_CORRUPT; }
+  if (!c.ok || n != codec_len || std::memcmp(data + c.pos, codec, n) != 0) { *why = std::string("codec mismatch: expected ") + codec; return ERR_CORRUPT; }
   c.pos += n;
-  if ((int32_t)c.be32() != doc_version) { *why = ".pos version differs from the .doc file's"; return ERR_CORRUPT; }
+  if ((int32_t)c.be32() != doc_version) { *why = x + " version differs from the .doc file's"; return ERR_CORRUPT; }
   // segment id + suffix must be the .doc file's (check_index_header with the segment's id / suffix)
   const size_t doc_id_at = 4 + 1 + (sizeof(kDoc) - 1) + 4;
   const size_t id_len = 16 + 1 + (size_t)doc_file[doc_id_at + 16];
-  if (c.pos + id_len > len - 16 || std::memcmp(data + c.pos, doc_file + doc_id_at, id_len) != 0) { *why = ".pos belongs to another segment (id / suffix mismatch)"; return ERR_CORRUPT; }
+  if (c.pos + id_len > len - 16 || std::memcmp(data + c.pos, doc_file + doc_id_at, id_len) != 0) { *why = x + " belongs to another segment (id / suffix mismatch)"; return ERR_CORRUPT; }
   c.pos += id_len;
   detail::Cursor f{data, len};
   f.pos = len - 16;
-  if (f.be32() != ~0x3FD76C17u || f.be32() != 0) { *why = ".pos: codec footer mismatch"; return ERR_CORRUPT; }
+  if (f.be32() != ~0x3FD76C17u || f.be32() != 0) { *why = x + ": codec footer mismatch"; return ERR_CORRUPT; }
   *postings_start = (int64_t)c.pos;
   return 0;
+}
+inline int parse_pos_file(const uint8_t* data, size_t len, const uint8_t* doc_file, int32_t doc_version, int64_t* postings_start, std::string* why) {
+  return parse_side_file(data, len, "Lucene50PostingsWriterPos", ".pos", doc_file, doc_version, postings_start, why);
+}
+inline int parse_pay_file(const uint8_t* data, size_t len, const uint8_t* doc_file, int32_t doc_version, int64_t* postings_start, std::string* why) {
+  return parse_side_file(data, len, "Lucene50PostingsWriterPay", ".pay", doc_file, doc_version, postings_start, why);
 }
 
 }  // namespace rucene

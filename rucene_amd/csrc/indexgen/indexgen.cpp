@@ -259,6 +259,11 @@ struct rgen_index {
       pos.be32(0);
       pos.be64((uint64_t)crc32_of(pos.b.data(), pos.size()));
     }
+    if (has_pay()) {
+      pay.be32(~0x3FD76C17u);
+      pay.be32(0);
+      pay.be64((uint64_t)crc32_of(pay.b.data(), pay.size()));
+    }
   }
 
   // ---- positions (IndexOptions::DocsAndFreqsAndPositions, no payloads / offsets) ---------------------------------------
@@ -266,25 +271,40 @@ struct rgen_index {
   // delta restarts at every doc) + (ttf % 128) vints (posting_writer.rs:363-455, 505-560). The ".doc" skip entries of such a
   // field carry two more values: the .pos pointer and the number of buffered positions at the block boundary
   // (skip_writer.rs:261-289). Synthetic data for the positions / phrase row.
-  Bytes pos;
-  bool has_positions = false;
-  std::vector<int64_t> term_pos_start, term_last_pos_block_offset;
+  // A field that also stores OFFSETS (IndexOptions::DocsAndFreqsAndPositionsAndOffsets) and / or PAYLOADS
+  // (FieldInfo::has_store_payloads) gets a third file, ".pay": per 128 positions of a term
+  // [payload-length block][vint byte count][the payload bytes] (payloads) then [offset start-delta block][offset length block]
+  // (offsets) (posting_writer.rs:404-451); the trailing (ttf % 128) positions keep theirs inside ".pos", woven into the VInts
+  // (:505-560); every skip entry grows by the payload bytes buffered at the boundary (payloads) and the .pay pointer
+  // (skip_writer.rs:276-286).
+  Bytes pos, pay;
+  bool has_positions = false, has_offsets = false, has_payloads = false;
+  std::vector<int64_t> term_pos_start, term_last_pos_block_offset, term_pay_start;
+  bool has_pay() const { return has_offsets || has_payloads; }
 
-  void begin_positions(const uint8_t seg_id[16]) {
-    has_positions = true;
-    pos.be32(0x3FD76C17u);
-    const char* name = "Lucene50PostingsWriterPos";
-    pos.vint((uint32_t)std::strlen(name));
-    pos.raw(name, std::strlen(name));
-    pos.be32((uint32_t)version);
-    pos.raw(seg_id, 16);
+  static void index_header(Bytes& out, const char* name, int32_t version, const uint8_t seg_id[16]) {
+    out.be32(0x3FD76C17u);
+    out.vint((uint32_t)std::strlen(name));
+    out.raw(name, std::strlen(name));
+    out.be32((uint32_t)version);
+    out.raw(seg_id, 16);
     const char* suffix = "Lucene50_0";
-    pos.u8((uint8_t)std::strlen(suffix));
-    pos.raw(suffix, std::strlen(suffix));
+    out.u8((uint8_t)std::strlen(suffix));
+    out.raw(suffix, std::strlen(suffix));
+  }
+  void begin_positions(const uint8_t seg_id[16], bool offsets = false, bool payloads = false) {
+    has_positions = true;
+    has_offsets = offsets;
+    has_payloads = payloads;
+    index_header(pos, "Lucene50PostingsWriterPos", version, seg_id);
+    if (has_pay()) index_header(pay, "Lucene50PostingsWriterPay", version, seg_id);
   }
 
-  // positions: flat, doc j of the term owns freqs[j] of them (ascending within a doc)
-  rgpu_term_state add_term_positions(const int32_t* docs, const int32_t* freqs, const int32_t* positions, int64_t df) {
+  // positions: flat, doc j of the term owns freqs[j] of them (ascending within a doc). With offsets: start / end per position
+  // (starts non-decreasing within a doc); with payloads: position q's bytes = payload_bytes[payload_offs[q], payload_offs[q + 1]).
+  rgpu_term_state add_term_positions(const int32_t* docs, const int32_t* freqs, const int32_t* positions, int64_t df,
+                                     const int32_t* starts = nullptr, const int32_t* ends = nullptr, const int64_t* payload_offs = nullptr,
+                                     const uint8_t* payload_bytes = nullptr) {
     rgpu_term_state st;
     st.doc_start_fp = (int64_t)doc.size();
     st.skip_offset = -1;
@@ -305,27 +325,92 @@ struct rgen_index {
         for (int32_t q = 0; q < freqs[j]; q++, at++) { deltas[(size_t)at] = (uint32_t)(positions[at] - last); last = positions[at]; }
       }
     }
+    // per position: payload length, offset start delta (restarts at every doc) and offset length
+    std::vector<uint32_t> plen, odelta, olen;
+    if (has_payloads) {
+      plen.resize((size_t)ttf);
+      for (int64_t i = 0; i < ttf; i++) plen[(size_t)i] = (uint32_t)(payload_offs[i + 1] - payload_offs[i]);
+    }
+    if (has_offsets) {
+      odelta.resize((size_t)ttf);
+      olen.resize((size_t)ttf);
+      int64_t at = 0;
+      for (int64_t j = 0; j < df; j++) {
+        int32_t last = 0;
+        for (int32_t q = 0; q < freqs[j]; q++, at++) {
+          odelta[(size_t)at] = (uint32_t)(starts[at] - last);
+          olen[(size_t)at] = (uint32_t)(ends[at] - starts[at]);
+          last = starts[at];
+        }
+      }
+    }
     const int64_t n_pos_blocks = ttf / 128;
+    const int64_t pay_start = (int64_t)pay.size();
     std::vector<int64_t> pos_fp_after((size_t)n_pos_blocks + 1, pos_start);  // [b] = .pos pointer once b blocks are written
+    std::vector<int64_t> pay_fp_after((size_t)n_pos_blocks + 1, pay_start);  // the same for .pay
     for (int64_t b = 0; b < n_pos_blocks; b++) {
       codec.put_block(deltas.data() + b * 128, pos);
       pos_fp_after[(size_t)b + 1] = (int64_t)pos.size();
+      if (has_payloads) {
+        codec.put_block(plen.data() + b * 128, pay);
+        const int64_t from = payload_offs[b * 128], to = payload_offs[b * 128 + 128];
+        pay.vint((uint32_t)(to - from));
+        pay.raw(payload_bytes + from, (size_t)(to - from));
+      }
+      if (has_offsets) {
+        codec.put_block(odelta.data() + b * 128, pay);
+        codec.put_block(olen.data() + b * 128, pay);
+      }
+      pay_fp_after[(size_t)b + 1] = (int64_t)pay.size();
     }
     term_pos_start.push_back(pos_start);
+    term_pay_start.push_back(has_pay() ? pay_start : 0);
     term_last_pos_block_offset.push_back(ttf > 128 ? (int64_t)pos.size() - pos_start : -1);
-    for (int64_t i = n_pos_blocks * 128; i < ttf; i++) pos.vint(deltas[(size_t)i]);
+    {
+      // the trailing positions: a payload length / an offset length is written only where it differs from the one before
+      int64_t last_plen = -1, last_olen = -1;
+      for (int64_t i = n_pos_blocks * 128; i < ttf; i++) {
+        if (has_payloads) {
+          if ((int64_t)plen[(size_t)i] != last_plen) {
+            last_plen = plen[(size_t)i];
+            pos.vint(deltas[(size_t)i] << 1 | 1u);
+            pos.vint(plen[(size_t)i]);
+          } else {
+            pos.vint(deltas[(size_t)i] << 1);
+          }
+          if (plen[(size_t)i]) pos.raw(payload_bytes + payload_offs[i], plen[(size_t)i]);
+        } else {
+          pos.vint(deltas[(size_t)i]);
+        }
+        if (has_offsets) {
+          if ((int64_t)olen[(size_t)i] == last_olen) {
+            pos.vint(odelta[(size_t)i] << 1);
+          } else {
+            pos.vint(odelta[(size_t)i] << 1 | 1u);
+            pos.vint(olen[(size_t)i]);
+            last_olen = olen[(size_t)i];
+          }
+        }
+      }
+    }
     if (df == 1) { st.singleton_doc_id = docs[0]; return st; }
 
-    struct Level { Bytes buf; int32_t last_doc = 0; int64_t last_fp = 0, last_pos_fp = 0; };
+    struct Level { Bytes buf; int32_t last_doc = 0; int64_t last_fp = 0, last_pos_fp = 0, last_pay_fp = 0; };
     std::vector<Level> levels;
     const int64_t nfull = df / 128;
     int64_t freq_sum = 0;  // positions of the docs written so far
     auto boundary = [&](int64_t blocks_done) {  // the first doc after `blocks_done` full doc blocks is about to be written
-      if (levels.empty()) { levels.resize((size_t)writer_skip_levels); for (auto& L : levels) { L.last_fp = st.doc_start_fp; L.last_pos_fp = pos_start; } }
+      if (levels.empty()) {
+        levels.resize((size_t)writer_skip_levels);
+        for (auto& L : levels) { L.last_fp = st.doc_start_fp; L.last_pos_fp = pos_start; L.last_pay_fp = pay_start; }
+      }
       const int32_t boundary_doc = docs[blocks_done * 128 - 1];
       const int64_t boundary_fp = (int64_t)doc.size();
       const int64_t boundary_pos_fp = pos_fp_after[(size_t)(freq_sum / 128)];
+      const int64_t boundary_pay_fp = pay_fp_after[(size_t)(freq_sum / 128)];
       const uint32_t pos_buffer_upto = (uint32_t)(freq_sum % 128);
+      // payload bytes of the positions buffered since the last full position block
+      const uint32_t payload_byte_upto = has_payloads ? (uint32_t)(payload_offs[freq_sum] - payload_offs[freq_sum - freq_sum % 128]) : 0u;
       int nlev = 1;
       for (int64_t e = blocks_done; e % 8 == 0 && nlev < writer_skip_levels; e /= 8) nlev++;
       int64_t child = 0;
@@ -335,6 +420,8 @@ struct rgen_index {
         L.buf.vlong((uint64_t)(boundary_fp - L.last_fp));
         L.buf.vlong((uint64_t)(boundary_pos_fp - L.last_pos_fp));
         L.buf.vint(pos_buffer_upto);
+        if (has_payloads) L.buf.vint(payload_byte_upto);
+        if (has_pay()) { L.buf.vlong((uint64_t)(boundary_pay_fp - L.last_pay_fp)); L.last_pay_fp = boundary_pay_fp; }
         L.last_doc = boundary_doc;
         L.last_fp = boundary_fp;
         L.last_pos_fp = boundary_pos_fp;
@@ -497,6 +584,7 @@ rgen_index* rgen_build_explicit_positions(int32_t max_doc, int32_t version, int6
       z.singleton_doc_id = -1;
       ix->terms[(size_t)t] = z;
       ix->term_pos_start.push_back((int64_t)ix->pos.size());
+      ix->term_pay_start.push_back(0);
       ix->term_last_pos_block_offset.push_back(-1);
       continue;
     }
@@ -507,6 +595,46 @@ rgen_index* rgen_build_explicit_positions(int32_t max_doc, int32_t version, int6
   ix->finish();
   return ix;
 }
+// The same for a field that also stores offsets (field_flags bit 0: starts / ends per position) and / or payloads (bit 1:
+// position q's payload = payload_bytes[payload_offs[q], payload_offs[q + 1])): ".doc", ".pos" and ".pay".
+rgen_index* rgen_build_explicit_positions_ex(int32_t max_doc, int32_t version, int64_t n_terms, const int64_t* offsets, const int32_t* docs,
+                                             const int32_t* freqs, const int64_t* pos_offsets, const int32_t* positions, int32_t field_flags,
+                                             const int32_t* starts, const int32_t* ends, const int64_t* payload_offs, const uint8_t* payload_bytes,
+                                             const uint8_t* norms_or_null, const uint8_t* seg_id16_or_null) {
+  rgen_index* ix = new rgen_index();
+  uint8_t seg_id[16];
+  for (int i = 0; i < 16; i++) seg_id[i] = seg_id16_or_null ? seg_id16_or_null[i] : (uint8_t)i;
+  const bool offs = (field_flags & 1) != 0, pays = (field_flags & 2) != 0;
+  ix->begin(max_doc, version, seg_id);
+  ix->begin_positions(seg_id, offs, pays);
+  ix->norms.assign((size_t)max_doc, 0);
+  if (norms_or_null) std::memcpy(ix->norms.data(), norms_or_null, (size_t)max_doc);
+  ix->terms.resize((size_t)n_terms);
+  for (int64_t t = 0; t < n_terms; t++) {
+    const int64_t df = offsets[t + 1] - offsets[t];
+    if (df <= 0) {
+      rgpu_term_state z;
+      std::memset(&z, 0, sizeof z);
+      z.skip_offset = -1;
+      z.singleton_doc_id = -1;
+      ix->terms[(size_t)t] = z;
+      ix->term_pos_start.push_back((int64_t)ix->pos.size());
+      ix->term_pay_start.push_back(ix->has_pay() ? (int64_t)ix->pay.size() : 0);
+      ix->term_last_pos_block_offset.push_back(-1);
+      continue;
+    }
+    for (int64_t j = offsets[t]; j < offsets[t + 1]; j++)
+      if (pos_offsets[j + 1] - pos_offsets[j] != freqs[j]) { ix->error = "positions per doc must equal freq"; return ix; }
+    const int64_t p0 = pos_offsets[offsets[t]];
+    ix->terms[(size_t)t] = ix->add_term_positions(docs + offsets[t], freqs + offsets[t], positions + p0, df, offs ? starts + p0 : nullptr,
+                                                  offs ? ends + p0 : nullptr, pays ? payload_offs + p0 : nullptr, payload_bytes);
+  }
+  ix->finish();
+  return ix;
+}
+int64_t rgen_pay_len(const rgen_index* ix) { return (int64_t)ix->pay.size(); }
+const uint8_t* rgen_pay_bytes(const rgen_index* ix) { return ix->pay.b.data(); }
+const int64_t* rgen_pay_start_fps(const rgen_index* ix) { return ix->term_pay_start.data(); }
 int64_t rgen_pos_len(const rgen_index* ix) { return (int64_t)ix->pos.size(); }
 const uint8_t* rgen_pos_bytes(const rgen_index* ix) { return ix->pos.b.data(); }
 const int64_t* rgen_pos_start_fps(const rgen_index* ix) { return ix->term_pos_start.data(); }

@@ -410,6 +410,60 @@ __device__ __forceinline__ void decode_vint_block(const uint8_t* __restrict__ sr
   wave_sync();
 }
 
+// The same block of a field that stores payloads (flags bit 0) and / or offsets (bit 1) — posting_reader.rs:1285-1312: per
+// position  code = vint [payload length = vint when code & 1] [that many payload bytes] [offset code = vint [offset length =
+// vint when code & 1]], position delta = code >>> 1 with payloads, code without. Payload bytes are raw, so where a value
+// starts depends on every length in front of it: the walk is serial. Every lane walks (uniform control flow, LDS broadcast
+// reads) through a 512-byte window of the stream that the lanes refill together whenever the walk is about to leave it — a
+// long payload is jumped over, never read — and keeps the two deltas that are its own. `count` = total_term_freq % 128.
+constexpr int POS_TAIL_PAYLOADS = 1, POS_TAIL_OFFSETS = 2;
+__device__ __forceinline__ void decode_vint_block_everything(const uint8_t* __restrict__ src, int count, int flags, uint8_t* slab, int lane,
+                                                             uint32_t& v0, uint32_t& v1) {
+  constexpr int WIN = 512;
+  int64_t wb = 0, at = 0;  // window base and walk position, bytes from src (wave-uniform)
+  auto refill = [&]() {
+    wave_sync();
+    wb = at;
+    if (lane < WIN / 16) *reinterpret_cast<uint4*>(slab + 16 * lane) = load16_unaligned(src + wb + 16 * lane);
+    wave_sync();
+  };
+  // the four bytes at the walk position (two aligned LDS dwords shifted into place)
+  auto peek = [&]() -> uint32_t {
+    const uint32_t o = (uint32_t)(at - wb);
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(slab + (o & ~3u));
+    return __builtin_amdgcn_alignbyte(w[1], w[0], o & 3u);
+  };
+  auto vint = [&]() -> uint32_t {  // data_input.rs:78-111; at most 5 bytes, the walk stays 12 bytes inside the window
+    uint32_t b = peek(), v = b & 0x7fu;
+    int n = 1;
+    if (b & 0x80u) { v |= ((b >> 8) & 0x7fu) << 7; n = 2;
+      if (b & 0x8000u) { v |= ((b >> 16) & 0x7fu) << 14; n = 3;
+        if (b & 0x800000u) { v |= ((b >> 24) & 0x7fu) << 21; n = 4;
+          if (b & 0x80000000u) { at += 4; v |= (peek() & 0x0fu) << 28; at -= 4; n = 5; } } } }
+    at += n;
+    return v;
+  };
+  refill();
+  uint32_t payload_length = 0;
+  v0 = v1 = 0u;
+  for (int i = 0; i < count; ++i) {
+    if (at - wb > WIN - 24) refill();  // a code and a length: <= 10 bytes (+ the peek's over-read)
+    uint32_t code = vint();
+    if (flags & POS_TAIL_PAYLOADS) {
+      if (code & 1u) payload_length = vint();
+      code >>= 1;
+      at += payload_length;  // posting_reader.rs:1299-1302: seek past the bytes
+    }
+    if (flags & POS_TAIL_OFFSETS) {
+      if (at - wb > WIN - 24 || at < wb) refill();
+      if (vint() & 1u) (void)vint();  // the offset length changed
+    }
+    v0 = i == 2 * lane ? code : v0;
+    v1 = i == 2 * lane + 1 ? code : v1;
+  }
+  wave_sync();
+}
+
 // has_freqs == false (IndexOptions::Docs, posting_reader.rs:326-331): every value is a doc delta, every freq is 1.
 __device__ RGPU_TAIL_INLINE void decode_tail(const uint8_t* __restrict__ tail, int n, int32_t base, uint8_t* slab, int lane,
                                             int32_t& doc0, int32_t& doc1, uint32_t& f0, uint32_t& f1, bool has_freqs = true) {

@@ -71,35 +71,47 @@ __device__ __forceinline__ int vint_len_serial(const uint8_t* p) {
 }
 
 // ---- A1: level-0 skip entries -> dir_last / dir_off (/ dir_pos) ------------------------------------------------------------
+// Values per level-0 entry (skip_writer.rs:261-289), by field: 2 = {docDelta, docFpDelta}; a positions field 4: + {posFpDelta,
+// posBufferUpto}; one that stores offsets but no payloads 5: + {payFpDelta}; one that stores payloads (with or without
+// offsets) 6: + {payloadByteUpto, payFpDelta}. Fields 0 - 2 are deltas (running sums), field 3 is absolute; the .pay words
+// (fields 4, 5) are parsed and dropped — no kernel of this path reads payload bytes or offsets.
 // What a chunk tells the chunks behind it: how many VInt values END inside it and their sums by LOCAL residue (index inside
-// the chunk modulo the values per entry: 2 = {docDelta, docFpDelta}, 4 with positions: + {posFpDelta, posBufferUpto}). Which
-// field a residue is depends on how many values precede the chunk, known once the chunks in front have published.
+// the chunk modulo the values per entry). Which field a residue is depends on how many values precede the chunk, known once
+// the chunks in front have published.
 struct SkipAgg {
   uint32_t count;
-  uint32_t pad0;
-  uint32_t sum[4];
-  uint32_t pad[2];
+  uint32_t sum[6];
+  uint32_t pad;
 };
 static_assert(sizeof(SkipAgg) == 32, "one aggregate per 32 bytes");
 
 // bytes a level-0 entry can take: vint docDelta <= 5, vlong docFpDelta (a block is < 16 KiB) <= 3; positions: + vlong
-// posFpDelta <= 9, vint posBufferUpto (< 128) 1
-__host__ __device__ constexpr int skip_entry_max_bytes(bool positions) { return positions ? 18 : 8; }
+// posFpDelta <= 9, vint posBufferUpto (< 128) 1; payloads: + vint payloadByteUpto <= 5; payloads or offsets: + vlong payFpDelta <= 9
+__host__ __device__ constexpr int skip_entry_max_bytes(int vals) { return vals == 2 ? 8 : vals == 4 ? 18 : vals == 5 ? 27 : 32; }
 // A term whose level 0 fits SKIP_SMALL_BYTES (16 entries; 7 with positions: df < 2176 / 1024 — nine terms in ten of a Zipf
 // vocabulary) is parsed by ONE LANE of k_skip_terms and takes no chunk: a wavefront per term for a few dozen bytes made
 // k_skip_dir a launch of 330 k two-microsecond wavefronts on the 100 M-doc shard, most of its time spent starting them.
 constexpr int SKIP_SMALL_BYTES = 128;
-__host__ __device__ inline bool skip_is_small(int32_t n_entries, bool positions) {
-  return n_entries * skip_entry_max_bytes(positions) <= SKIP_SMALL_BYTES;
+__host__ __device__ inline bool skip_is_small(int32_t n_entries, int vals) {
+  return n_entries * skip_entry_max_bytes(vals) <= SKIP_SMALL_BYTES;
 }
-__host__ __device__ inline int64_t skip_chunks(int32_t n_entries, bool positions) {
-  return skip_is_small(n_entries, positions) ? 0 : ((int64_t)n_entries * skip_entry_max_bytes(positions) + SKIP_CHUNK_BYTES - 1) / SKIP_CHUNK_BYTES;
+__host__ __device__ inline int64_t skip_chunks(int32_t n_entries, int vals) {
+  return skip_is_small(n_entries, vals) ? 0 : ((int64_t)n_entries * skip_entry_max_bytes(vals) + SKIP_CHUNK_BYTES - 1) / SKIP_CHUNK_BYTES;
 }
 
-__device__ __forceinline__ uint32_t pick4(const uint32_t (&v)[4], uint32_t i) {  // v[i & 3] without a register-array index
-  const uint32_t lo = (i & 1u) ? v[1] : v[0], hi = (i & 1u) ? v[3] : v[2];
-  return (i & 2u) ? hi : lo;
+template <uint32_t VALS>
+__device__ __forceinline__ uint32_t pick_res(const uint32_t (&v)[VALS], uint32_t i) {  // v[i], i < VALS, without a register-array index
+  static_assert(VALS >= 2 && VALS <= 8, "a three-level select tree");
+  const uint32_t e0 = v[0], e1 = v[1], e2 = VALS > 2 ? v[VALS > 2 ? 2 : 0] : 0u, e3 = VALS > 3 ? v[VALS > 3 ? 3 : 0] : 0u,
+                 e4 = VALS > 4 ? v[VALS > 4 ? 4 : 0] : 0u, e5 = VALS > 5 ? v[VALS > 5 ? 5 : 0] : 0u, e6 = VALS > 6 ? v[VALS > 6 ? 6 : 0] : 0u,
+                 e7 = VALS > 7 ? v[VALS > 7 ? 7 : 0] : 0u;
+  const uint32_t a = (i & 1u) ? e1 : e0, b = (i & 1u) ? e3 : e2, c = (i & 1u) ? e5 : e4, d = (i & 1u) ? e7 : e6;
+  const uint32_t lo = (i & 2u) ? b : a, hi = (i & 2u) ? d : c;
+  return (i & 4u) ? hi : lo;
 }
+// (a - b) mod VALS for a < VALS and any b (residue arithmetic on value counts)
+template <uint32_t VALS>
+__device__ __forceinline__ uint32_t sub_mod(uint32_t a, uint32_t b) { return (a + VALS - b % VALS) % VALS; }
 
 __host__ __device__ inline int64_t skip_groups(int64_t n_chunks_of_term) { return (n_chunks_of_term + SKIP_GROUP - 1) / SKIP_GROUP; }
 
@@ -110,7 +122,7 @@ __host__ __device__ inline int64_t skip_groups(int64_t n_chunks_of_term) { retur
 // lanes' serial walks do not collide on banks) and reads entry after entry (skip_reader.rs:431-453, 513-539).
 __global__ __launch_bounds__(PREP_THREADS) void k_skip_terms(const uint8_t* __restrict__ doc, int64_t doc_len, const PrepTerm* __restrict__ terms,
                                                              int n_terms, int64_t* __restrict__ l0s, int32_t* dir_last, uint32_t* dir_off,
-                                                             uint64_t* dir_pos, int* err) {
+                                                             uint64_t* dir_pos, int vals, int* err) {
   __shared__ uint32_t slab[PREP_WAVES][(SKIP_SMALL_BYTES / 4) * 64];
   const int i = (int)(blockIdx.x * PREP_THREADS + threadIdx.x);
   if (i >= n_terms) return;
@@ -127,7 +139,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_skip_terms(const uint8_t* __re
   dir_off[T.dir_base] = 0;
   if (dir_pos) dir_pos[T.dir_base] = 0ull;
   if (T.nblocks > T.n_entries && T.nblocks > 0) dir_last[T.dir_base + T.nblocks - 1] = DIR_SENTINEL_DOC;  // df % 128 == 0
-  if (T.n_entries <= 0 || !skip_is_small(T.n_entries, dir_pos != nullptr)) return;
+  if (T.n_entries <= 0 || !skip_is_small(T.n_entries, vals)) return;
   if (l0 < 0) { flag_err(err, -4, 1); return; }
   uint32_t* const my = slab[wave_id()] + lane;
 #pragma unroll
@@ -159,26 +171,32 @@ __global__ __launch_bounds__(PREP_THREADS) void k_skip_terms(const uint8_t* __re
       const uint32_t upto = vnum(5);                                  // posBufferUpto: absolute
       if (upto >= 128u) flag_err(err, -4, 4);
       dir_pos[T.dir_base + e + 1] = (uint64_t)run_pos | ((uint64_t)upto << 32);
+      if (vals == 6) (void)vnum(5);                                   // payloadByteUpto
+      if (vals >= 5) (void)vnum(9);                                   // pay_pointer += delta
     }
   }
   if (over) flag_err(err, -4, 2);  // an entry longer than any the writer produces: ran off the bytes taken
 }
 
-// A run of aggregates, front to back, folded into (values before, running sums by FIELD): aggregate j holds its sums by
-// residue relative to ITS first value, which is field (values before j) mod vals.
-__device__ __forceinline__ void fold_aggs(const SkipAgg* a, int n, uint32_t vals, int lane, uint32_t& P, uint32_t (&base)[4]) {
-  const uint32_t vm = vals - 1u;
+// A run of aggregates, front to back, folded into (values before, running sums by FIELD — the delta fields 0 .. 2): aggregate
+// j holds its sums by residue relative to ITS first value, which is field (values before j) mod VALS.
+template <uint32_t VALS>
+__device__ __forceinline__ void fold_aggs(const SkipAgg* a, int n, int lane, uint32_t& P, uint32_t (&base)[3]) {
+  constexpr uint32_t NF = VALS < 3u ? VALS : 3u;
   for (int j0 = 0; j0 < n; j0 += 64) {
     const int j = j0 + lane;
-    uint32_t cj = 0, sj[4] = {0u, 0u, 0u, 0u};
+    uint32_t cj = 0, sj[VALS];
+#pragma unroll
+    for (uint32_t r = 0; r < VALS; ++r) sj[r] = 0u;
     if (j < n) {
       cj = a[j].count;
-      sj[0] = a[j].sum[0]; sj[1] = a[j].sum[1]; sj[2] = a[j].sum[2]; sj[3] = a[j].sum[3];
+#pragma unroll
+      for (uint32_t r = 0; r < VALS; ++r) sj[r] = a[j].sum[r];
     }
     const uint32_t inc = (uint32_t)wave_incl_scan((int)cj);
-    const uint32_t Pj = P + inc - cj;  // values before aggregate j: its local residue r is field (Pj + r) mod vals
+    const uint32_t Pj = P + inc - cj;  // values before aggregate j: its local residue r is field (Pj + r) mod VALS
 #pragma unroll
-    for (uint32_t f = 0; f < 4; ++f) base[f] += (uint32_t)wave_reduce_add((int)(f < vals ? pick4(sj, (f - Pj) & vm) : 0u));
+    for (uint32_t f = 0; f < NF; ++f) base[f] += (uint32_t)wave_reduce_add((int)pick_res<VALS>(sj, sub_mod<VALS>(f, Pj)));
     P += (uint32_t)readlane((int)inc, 63);
   }
 }
@@ -188,8 +206,9 @@ __device__ __forceinline__ void fold_aggs(const SkipAgg* a, int n, uint32_t vals
 // group's first value), and the group's own aggregate goes to `gaggs`: pass 2 then folds the groups in front of its chunk's
 // group and adds one slot. Without it the last chunk of a 20 M-posting term folds 1220 aggregates in 20 dependent rounds —
 // and a 2 G-posting term's would take 1900: the look-back of a term is quadratic in its length, this makes it n^2 / 64.
+template <uint32_t VALS>
 __global__ __launch_bounds__(PREP_THREADS) void k_skip_groups(const int64_t* __restrict__ chunk_prefix, const int64_t* __restrict__ group_prefix,
-                                                              int n_terms, int64_t n_groups, uint32_t vals, SkipAgg* aggs, SkipAgg* gaggs) {
+                                                              int n_terms, int64_t n_groups, SkipAgg* aggs, SkipAgg* gaggs) {
   const int lane = lane_id();
   const int64_t s = (int64_t)blockIdx.x * PREP_WAVES + wave_id();
   if (s >= n_groups) return;
@@ -198,30 +217,34 @@ __global__ __launch_bounds__(PREP_THREADS) void k_skip_groups(const int64_t* __r
   const int j = (int)(s - group_prefix[t]) * SKIP_GROUP + lane;
   const bool have = lane < SKIP_GROUP && j < n_mine;
   SkipAgg* const a = aggs + chunk_prefix[t] + j;
-  const uint32_t vm = vals - 1u;
-  uint32_t cj = 0, sj[4] = {0u, 0u, 0u, 0u};
+  uint32_t cj = 0, sj[VALS];
+#pragma unroll
+  for (uint32_t r = 0; r < VALS; ++r) sj[r] = 0u;
   if (have) {
     cj = a->count;
-    sj[0] = a->sum[0]; sj[1] = a->sum[1]; sj[2] = a->sum[2]; sj[3] = a->sum[3];
+#pragma unroll
+    for (uint32_t r = 0; r < VALS; ++r) sj[r] = a->sum[r];
   }
   const uint32_t inc = (uint32_t)wave_incl_scan((int)cj);
   const uint32_t Pj = inc - cj;
-  uint32_t ex[4], tot[4];
+  uint32_t ex[VALS], tot[VALS];
 #pragma unroll
-  for (uint32_t f = 0; f < 4; ++f) {
-    const uint32_t r = f < vals ? pick4(sj, (f - Pj) & vm) : 0u;  // this chunk's sum for residue f of the GROUP
+  for (uint32_t f = 0; f < VALS; ++f) {
+    const uint32_t r = pick_res<VALS>(sj, sub_mod<VALS>(f, Pj));  // this chunk's sum for residue f of the GROUP
     const uint32_t in = (uint32_t)wave_incl_scan((int)r);
     ex[f] = in - r;
     tot[f] = (uint32_t)readlane((int)in, 63);
   }
   if (have) {
     a->count = Pj;
-    a->sum[0] = ex[0]; a->sum[1] = ex[1]; a->sum[2] = ex[2]; a->sum[3] = ex[3];
+#pragma unroll
+    for (uint32_t r = 0; r < VALS; ++r) a->sum[r] = ex[r];
   }
   if (lane == 0) {
     SkipAgg* const g = gaggs + s;
     g->count = (uint32_t)readlane((int)inc, 63);
-    g->sum[0] = tot[0]; g->sum[1] = tot[1]; g->sum[2] = tot[2]; g->sum[3] = tot[3];
+#pragma unroll
+    for (uint32_t r = 0; r < VALS; ++r) g->sum[r] = tot[r];
   }
 }
 
@@ -229,13 +252,14 @@ __global__ __launch_bounds__(PREP_THREADS) void k_skip_groups(const int64_t* __r
 // the values anywhere), take the aggregates of the chunks in front of it — complete: they were written by the launches
 // before — and write the directory. (One launch with the chunks waiting for each other was tried first: the wavefronts of a
 // 20 M-posting term's 1220 chunks spinning on acquire loads cost 1 - 4 ms, varying from run to run.)
-template <int PASS>
+template <int PASS, uint32_t VALS>
 __global__ __launch_bounds__(PREP_THREADS) void k_skip_dir(const uint8_t* __restrict__ doc, int64_t doc_len, int64_t doc_cap,
                                                            const PrepTerm* __restrict__ terms, const int64_t* __restrict__ chunk_prefix,
                                                            const int64_t* __restrict__ l0s, int n_terms, int64_t n_chunks, SkipAgg* aggs,
                                                            const int64_t* __restrict__ group_prefix, const SkipAgg* __restrict__ gaggs,
                                                            int32_t* dir_last, uint32_t* dir_off, uint64_t* dir_pos, int* err) {
   __shared__ __attribute__((aligned(16))) uint8_t stage[PREP_WAVES][16 + SKIP_CHUNK_BYTES];
+  constexpr uint32_t NF = VALS < 3u ? VALS : 3u;  // the delta fields: doc, doc pointer, position pointer
   const int lane = lane_id();
   const int wave = wave_id();
   const int64_t item = (int64_t)blockIdx.x * PREP_WAVES + wave;
@@ -244,20 +268,17 @@ __global__ __launch_bounds__(PREP_THREADS) void k_skip_dir(const uint8_t* __rest
   const int c = (int)(item - chunk_prefix[t]);
   const int n_mine = (int)(chunk_prefix[t + 1] - chunk_prefix[t]);
   const PrepTerm T = terms[t];
-  const uint32_t vals = dir_pos ? 4u : 2u, vm = vals - 1u;
-  const uint32_t need = vals * (uint32_t)T.n_entries;
+  const uint32_t need = VALS * (uint32_t)T.n_entries;
   SkipAgg* const mine = aggs + item;
-  auto publish = [&](uint32_t count, uint32_t s0, uint32_t s1, uint32_t s2, uint32_t s3) {
-    if (PASS == 1 && lane == 0) {
-      mine->count = count;
-      mine->sum[0] = s0; mine->sum[1] = s1; mine->sum[2] = s2; mine->sum[3] = s3;
-    }
-  };
   // ---- where level 0 starts: k_skip_terms walked the level headers once per term (and wrote the term's first directory words)
   const int64_t l0 = l0s[t];
   if (l0 < 0) {
     if (PASS == 2 && lane == 0 && c == 0) flag_err(err, -4, 1);
-    publish(0, 0, 0, 0, 0);
+    if (PASS == 1 && lane == 0) {
+      mine->count = 0;
+#pragma unroll
+      for (uint32_t r = 0; r < VALS; ++r) mine->sum[r] = 0u;
+    }
     return;
   }
   // ---- this chunk's bytes (and the 16 in front of it: a value may begin there) into LDS
@@ -292,62 +313,75 @@ __global__ __launch_bounds__(PREP_THREADS) void k_skip_dir(const uint8_t* __rest
     return (uint32_t)v;
   };
   // ---- sums by local residue
-  uint32_t sl[4] = {0u, 0u, 0u, 0u};
+  uint32_t sl[VALS];
+#pragma unroll
+  for (uint32_t r = 0; r < VALS; ++r) sl[r] = 0u;
   {
-    uint32_t m = term, li = li0;
+    uint32_t m = term, res = li0 % VALS;
     while (m) {
       const int j = __builtin_ctz(m);
       m &= m - 1;
-      const uint32_t v = value_at(j), r = li & vm;
-      sl[0] += r == 0u ? v : 0u; sl[1] += r == 1u ? v : 0u; sl[2] += r == 2u ? v : 0u; sl[3] += r == 3u ? v : 0u;
-      ++li;
+      const uint32_t v = value_at(j);
+#pragma unroll
+      for (uint32_t r = 0; r < VALS; ++r) sl[r] += res == r ? v : 0u;
+      res = res + 1u == VALS ? 0u : res + 1u;
     }
   }
   if (PASS == 1) {
-    publish(total, (uint32_t)wave_reduce_add((int)sl[0]), (uint32_t)wave_reduce_add((int)sl[1]), (uint32_t)wave_reduce_add((int)sl[2]),
-            (uint32_t)wave_reduce_add((int)sl[3]));
+    uint32_t red[VALS];
+#pragma unroll
+    for (uint32_t r = 0; r < VALS; ++r) red[r] = (uint32_t)wave_reduce_add((int)sl[r]);
+    if (lane == 0) {
+      mine->count = total;
+#pragma unroll
+      for (uint32_t r = 0; r < VALS; ++r) mine->sum[r] = red[r];
+    }
     return;
   }
   // ---- the chunks in front of this one, front to back: values before this chunk (P) and the running sums by field
   uint32_t P = 0;
-  uint32_t base[4] = {0u, 0u, 0u, 0u};
+  uint32_t base[3] = {0u, 0u, 0u};
   if (n_mine <= SKIP_GROUP) {
-    fold_aggs(aggs + (item - c), c, vals, lane, P, base);
+    fold_aggs<VALS>(aggs + (item - c), c, lane, P, base);
   } else {
     // the groups in front of this chunk's group, then what k_skip_groups left in this chunk's own slot: the chunks in
-    // front of it inside its group, by residue relative to the group's first value = field (P + residue) mod vals
-    fold_aggs(gaggs + group_prefix[t], c / SKIP_GROUP, vals, lane, P, base);
+    // front of it inside its group, by residue relative to the group's first value = field (P + residue) mod VALS
+    fold_aggs<VALS>(gaggs + group_prefix[t], c / SKIP_GROUP, lane, P, base);
     const SkipAgg* a = aggs + item;
-    const uint32_t in[4] = {a->sum[0], a->sum[1], a->sum[2], a->sum[3]};
+    uint32_t in[VALS];
 #pragma unroll
-    for (uint32_t f = 0; f < 4; ++f) base[f] += f < vals ? pick4(in, (f - P) & vm) : 0u;
+    for (uint32_t r = 0; r < VALS; ++r) in[r] = a->sum[r];
+#pragma unroll
+    for (uint32_t f = 0; f < NF; ++f) base[f] += pick_res<VALS>(in, sub_mod<VALS>(f, P));
     P += a->count;
   }
   if (c == n_mine - 1 && P + total < need && lane == 0) flag_err(err, -4, 2);  // ran off the skip data looking for entries
   // ---- every value's running sum -> the directory
-  uint32_t run[4];
+  uint32_t run[3] = {0u, 0u, 0u};
   {
     // this lane's sums by FIELD, then the lanes in front of it
-    uint32_t lf[4];
 #pragma unroll
-    for (uint32_t f = 0; f < 4; ++f) lf[f] = f < vals ? pick4(sl, (f - P) & vm) : 0u;
-#pragma unroll
-    for (uint32_t f = 0; f < 4; ++f) run[f] = base[f] + (uint32_t)wave_incl_scan((int)lf[f]) - lf[f];
+    for (uint32_t f = 0; f < NF; ++f) {
+      const uint32_t lf = pick_res<VALS>(sl, sub_mod<VALS>(f, P));
+      run[f] = base[f] + (uint32_t)wave_incl_scan((int)lf) - lf;
+    }
   }
-  uint32_t m = term, g = P + li0;
+  uint32_t m = term, g = P + li0, fld = g % VALS;
   while (m) {
     const int j = __builtin_ctz(m);
     m &= m - 1;
-    const uint32_t v = value_at(j), f = g & vm;
+    const uint32_t v = value_at(j), f = fld;
     run[0] += f == 0u ? v : 0u; run[1] += f == 1u ? v : 0u; run[2] += f == 2u ? v : 0u;
     if (g < need) {
-      const uint32_t e = g / vals;
+      const uint32_t e = g / VALS;
       if (f == 0u) dir_last[T.dir_base + e] = (int32_t)run[0];             // skip_doc += delta (skip_reader.rs:530)
       else if (f == 1u) dir_off[T.dir_base + e + 1] = run[1];             // doc_pointer += delta (:434)
       else if (f == 2u) reinterpret_cast<uint32_t*>(dir_pos + T.dir_base + e + 1)[0] = run[2];  // pos_pointer += delta
-      else { reinterpret_cast<uint32_t*>(dir_pos + T.dir_base + e + 1)[1] = v; if (v >= 128u) flag_err(err, -4, 4); }  // posBufferUpto: absolute
+      else if (f == 3u) { reinterpret_cast<uint32_t*>(dir_pos + T.dir_base + e + 1)[1] = v; if (v >= 128u) flag_err(err, -4, 4); }  // posBufferUpto: absolute
+      // (fields 4, 5 — payloadByteUpto, the .pay pointer — are read past: see the top of this section)
     }
     ++g;
+    fld = fld + 1u == VALS ? 0u : fld + 1u;
   }
 }
 

@@ -16,7 +16,8 @@
 //                                     BM25(phrase freq, norm) with the phrase's summed-idf weight (:246-251);
 //   3. k_phrase_collect               TopDocsCollector over the candidates with phrase freq > 0.
 // Sloppy phrases (slop > 0): k_sloppy_groups + k_sloppy_match below instead of k_phrase_match.
-// Fields with payloads or offsets (a third file, .pay) are refused at upload.
+// Fields with payloads or offsets (a third file, .pay): the position BLOCKS are the same; the trailing VInt block of a term
+// carries payload bytes / offset words between its deltas (decode_vint_block_everything) and the skip entries two more words.
 #pragma once
 #include "search_and.hpp"
 
@@ -89,8 +90,9 @@ __device__ __forceinline__ int phrase_doc_positions(const SegView& seg, const De
     int nvals = 128;
     if (fp < 0 || fp + 2 > pos_len) return -4;
     if (fp == P.last_pos_block_fp) {
-      decode_vint_block(seg.pos + fp, slab, lane, x0, x1);
       nvals = (int)(P.total_term_freq % 128);
+      if (seg.pos_tail_flags == 0) decode_vint_block(seg.pos + fp, slab, lane, x0, x1);
+      else decode_vint_block_everything(seg.pos + fp, nvals, seg.pos_tail_flags, slab, lane, x0, x1);
       fp = -2;  // nothing follows the trailing block
     } else {
       const uint32_t b = seg.pos[fp];

@@ -49,6 +49,10 @@ struct SegView {
   // buffered in that block (the skip entry's posFP / posBufferUpto, skip_writer.rs:187-205; slot 0 = {0, 0}).
   const uint8_t* pos;
   const uint64_t* dir_pos;
+  // bit 0: the field stores payloads, bit 1: offsets — the trailing VInt position block of a term then carries payload
+  // bytes / offset words between its position deltas (decode.hpp decode_vint_block_everything)
+  int32_t pos_tail_flags;
+  int32_t pad_;
 };
 
 // One term as the kernels see it (built on the host from rgpu_term_state + the directory cache).

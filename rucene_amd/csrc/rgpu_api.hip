@@ -200,6 +200,10 @@ struct rgpu_segment {
   DevVec<uint16_t> dir_hdr;
   DevVec<uint64_t> dir_bmax;  // per block: (freq, norm rank) frontier word (SegView::dir_bmax)
   bool has_positions = false;  // IndexOptions::DocsAndFreqsAndPositions: skip entries carry position pointers
+  bool has_offsets = false;    // ...AndOffsets / FieldInfo::has_store_payloads: the skip entries also carry .pay words, the
+  bool has_payloads = false;   // trailing VInt position block also payload bytes / offset words (kernels: read past)
+  bool pay_checked = false;    // rgpu_segment_attach_payloads went through
+  int skip_vals = 2;           // values per level-0 skip entry: 2, 4 (positions), 5 (+ offsets), 6 (+ payloads) — prepare.hpp A1
   DevVec<uint64_t> dir_pos;    // per block: position-stream state at the block's start (SegView::dir_pos)
   uint8_t* d_pos = nullptr;    // raw .pos bytes (rgpu_segment_attach_positions)
   size_t pos_len = 0;
@@ -314,6 +318,8 @@ static SegView seg_view(const rgpu_segment* s) {
   v.dir_bmax = s->dir_bmax.p;
   v.pos = s->d_pos;
   v.dir_pos = s->has_positions ? s->dir_pos.p : nullptr;
+  v.pos_tail_flags = (s->has_payloads ? POS_TAIL_PAYLOADS : 0) | (s->has_offsets ? POS_TAIL_OFFSETS : 0);
+  v.pad_ = 0;
   v.sim_tables = s->ctx->sim_tables.p;
   v.max_doc = s->max_doc;
   v.doc_base = s->doc_base;
@@ -443,7 +449,7 @@ static int32_t prepare_terms_attempt(rgpu_segment* seg, const rgpu_term_state* c
   int64_t n_items = 0, postings = 0, n_chunks = 0, n_groups = 0;
   prep_items(work, &item_prefix, &n_items, &postings);
   for (size_t i = 0; i < work.size(); ++i) {
-    const int64_t mine = skip_chunks(work[i].n_entries, seg->has_positions);
+    const int64_t mine = skip_chunks(work[i].n_entries, seg->skip_vals);
     chunk_prefix[i] = n_chunks;
     group_prefix[i] = n_groups;
     n_chunks += mine;
@@ -488,17 +494,24 @@ static int32_t prepare_terms_attempt(rgpu_segment* seg, const rgpu_term_state* c
     const dim3 grid((unsigned)((n_chunks + PREP_WAVES - 1) / PREP_WAVES));
     hipLaunchKernelGGL(k_skip_terms, dim3((unsigned)((work.size() + PREP_THREADS - 1) / PREP_THREADS)), dim3(PREP_THREADS), 0, c->stream, seg->d_doc,
                        (int64_t)seg->doc_len, d_work, (int)work.size(), d_l0, seg->dir_last.p, seg->dir_off.p,
-                       seg->has_positions ? seg->dir_pos.p : nullptr, c->d_err);
+                       seg->has_positions ? seg->dir_pos.p : nullptr, seg->skip_vals, c->d_err);
     if (n_chunks > 0) {  // the terms whose level 0 one lane does not finish
-      hipLaunchKernelGGL(k_skip_dir<1>, grid, dim3(PREP_THREADS), 0, c->stream, seg->d_doc, (int64_t)seg->doc_len, (int64_t)seg->doc_len + 8192,
-                         d_work, d_chunks, d_l0, (int)work.size(), n_chunks, d_aggs, d_groups, d_gaggs, seg->dir_last.p, seg->dir_off.p,
-                         seg->has_positions ? seg->dir_pos.p : nullptr, c->d_err);
-      if (n_groups > 0)
-        hipLaunchKernelGGL(k_skip_groups, dim3((unsigned)((n_groups + PREP_WAVES - 1) / PREP_WAVES)), dim3(PREP_THREADS), 0, c->stream, d_chunks,
-                           d_groups, (int)work.size(), n_groups, seg->has_positions ? 4u : 2u, d_aggs, d_gaggs);
-      hipLaunchKernelGGL(k_skip_dir<2>, grid, dim3(PREP_THREADS), 0, c->stream, seg->d_doc, (int64_t)seg->doc_len, (int64_t)seg->doc_len + 8192,
-                         d_work, d_chunks, d_l0, (int)work.size(), n_chunks, d_aggs, d_groups, d_gaggs, seg->dir_last.p, seg->dir_off.p,
-                         seg->has_positions ? seg->dir_pos.p : nullptr, c->d_err);
+      auto pass = [&](auto kern) {
+        hipLaunchKernelGGL(kern, grid, dim3(PREP_THREADS), 0, c->stream, seg->d_doc, (int64_t)seg->doc_len, (int64_t)seg->doc_len + 8192,
+                           d_work, d_chunks, d_l0, (int)work.size(), n_chunks, d_aggs, d_groups, d_gaggs, seg->dir_last.p, seg->dir_off.p,
+                           seg->has_positions ? seg->dir_pos.p : nullptr, c->d_err);
+      };
+      auto groups = [&](auto kern) {
+        if (n_groups > 0)
+          hipLaunchKernelGGL(kern, dim3((unsigned)((n_groups + PREP_WAVES - 1) / PREP_WAVES)), dim3(PREP_THREADS), 0, c->stream, d_chunks,
+                             d_groups, (int)work.size(), n_groups, d_aggs, d_gaggs);
+      };
+      switch (seg->skip_vals) {  // values per level-0 skip entry (prepare.hpp, A1)
+        case 2: pass(k_skip_dir<1, 2>); groups(k_skip_groups<2>); pass(k_skip_dir<2, 2>); break;
+        case 4: pass(k_skip_dir<1, 4>); groups(k_skip_groups<4>); pass(k_skip_dir<2, 4>); break;
+        case 5: pass(k_skip_dir<1, 5>); groups(k_skip_groups<5>); pass(k_skip_dir<2, 5>); break;
+        default: pass(k_skip_dir<1, 6>); groups(k_skip_groups<6>); pass(k_skip_dir<2, 6>); break;
+      }
     }
   }
   {
@@ -815,9 +828,13 @@ extern "C" int32_t rgpu_segment_upload_field(rgpu_ctx* c, const uint8_t* doc_fil
                                              rgpu_segment** out_seg) {
   if (!c || !doc_file || !out_seg) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "bad arguments");
   *out_seg = nullptr;
-  if (index_options < 1 || index_options > 3)
-    return fail(index_options == 4 ? RGPU_ERR_UNSUPPORTED : RGPU_ERR_ILLEGAL_ARGUMENT,
-                "index_options must be 1 (Docs), 2 (DocsAndFreqs) or 3 (DocsAndFreqsAndPositions); offsets / payloads are not supported");
+  const bool payloads = (index_options & RGPU_FIELD_STORES_PAYLOADS) != 0;
+  index_options &= ~RGPU_FIELD_STORES_PAYLOADS;
+  if (index_options < 1 || index_options > 4)
+    return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "index_options must be 1 (Docs), 2 (DocsAndFreqs), 3 (DocsAndFreqsAndPositions) or 4 (...AndOffsets), "
+                                           "optionally | RGPU_FIELD_STORES_PAYLOADS");
+  if (payloads && index_options < 3)  // FieldInfo::check_consistency (field_infos/mod.rs): payloads need positions
+    return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "a field that stores payloads is indexed with positions (index_options >= 3)");
   if (max_doc < 0) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "negative max_doc");
   rucene::DocFileInfo info;
   std::string why;
@@ -833,6 +850,9 @@ extern "C" int32_t rgpu_segment_upload_field(rgpu_ctx* c, const uint8_t* doc_fil
   s->version = info.version;
   s->has_freqs = index_options >= 2;
   s->has_positions = index_options >= 3;
+  s->has_offsets = index_options >= 4;
+  s->has_payloads = payloads;
+  s->skip_vals = !s->has_positions ? 2 : payloads ? 6 : s->has_offsets ? 5 : 4;  // skip_writer.rs:261-289
   const size_t pad = 8192;  // speculative row / tail loads may run past the last posting byte
   auto bail = [&](hipError_t e, const char* what) { rgpu_segment_free(s); return fail(RGPU_ERR_RUNTIME, std::string(what) + ": " + hipGetErrorString(e)); };
   hipError_t e;
@@ -2326,7 +2346,7 @@ extern "C" int32_t rgpu_merge_topk_device(rgpu_ctx* c, const void* hits_dev, con
 // ---- exact phrases -----------------------------------------------------------------------------------------------------------
 extern "C" int32_t rgpu_segment_attach_positions(rgpu_segment* seg, const uint8_t* pos_file, size_t pos_len) {
   if (!seg || !pos_file) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "bad arguments");
-  if (!seg->has_positions) return fail(RGPU_ERR_ILLEGAL_STATE, "the segment was not uploaded as a positions field (index_options 3)");
+  if (!seg->has_positions) return fail(RGPU_ERR_ILLEGAL_STATE, "the segment was not uploaded as a positions field (index_options >= 3)");
   rgpu_ctx* c = seg->ctx;
   std::lock_guard<std::mutex> g(c->mu);
   HIP_TRY(hipSetDevice(c->device));
@@ -2343,6 +2363,27 @@ extern "C" int32_t rgpu_segment_attach_positions(rgpu_segment* seg, const uint8_
   HIP_TRY(hipMemcpy(seg->d_pos, pos_file, pos_len, hipMemcpyHostToDevice));
   HIP_TRY(hipMemset(seg->d_pos + pos_len, 0, pad));
   seg->pos_len = pos_len;
+  return RGPU_OK;
+}
+
+// Lucene50PostingsReader::open's third file (posting_reader.rs:131-156). Nothing on this path reads payload bytes or offsets
+// (phrase scorers ask for positions only and get the iterator that walks past them, :189-212), so the file is checked — header,
+// version, segment id / suffix, footer — as open() checks it, and not kept.
+extern "C" int32_t rgpu_segment_attach_payloads(rgpu_segment* seg, const uint8_t* pay_file, size_t pay_len) {
+  if (!seg || !pay_file) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "bad arguments");
+  if (!seg->has_offsets && !seg->has_payloads)
+    return fail(RGPU_ERR_ILLEGAL_STATE, "the segment's field stores neither payloads nor offsets (index_options 4 / RGPU_FIELD_STORES_PAYLOADS)");
+  rgpu_ctx* c = seg->ctx;
+  std::lock_guard<std::mutex> g(c->mu);
+  HIP_TRY(hipSetDevice(c->device));
+  std::vector<uint8_t> head(128);
+  const size_t head_n = std::min(seg->doc_len, head.size());
+  HIP_TRY(hipMemcpy(head.data(), seg->d_doc, head_n, hipMemcpyDeviceToHost));
+  int64_t start = 0;
+  std::string why;
+  const int rc = rucene::parse_pay_file(pay_file, pay_len, head.data(), seg->version, &start, &why);
+  if (rc != 0) return fail(rc, why);
+  seg->pay_checked = true;
   return RGPU_OK;
 }
 

@@ -53,6 +53,13 @@ def lib():
         for n in ("rgen_pos_bytes", "rgen_pos_start_fps", "rgen_last_pos_block_offsets"):
             getattr(L, n).restype = vp
             getattr(L, n).argtypes = [vp]
+        L.rgen_build_explicit_positions_ex.restype = vp
+        L.rgen_build_explicit_positions_ex.argtypes = [C.c_int32, C.c_int32, C.c_int64, vp, vp, vp, vp, vp, C.c_int32, vp, vp, vp, vp, vp, vp]
+        L.rgen_pay_len.restype = C.c_int64
+        L.rgen_pay_len.argtypes = [vp]
+        for n in ("rgen_pay_bytes", "rgen_pay_start_fps"):
+            getattr(L, n).restype = vp
+            getattr(L, n).argtypes = [vp]
         L.rgen_error.restype = C.c_char_p
         L.rgen_error.argtypes = [vp]
         _lib = L
@@ -85,6 +92,11 @@ class SyntheticSegment:
             self.pos_start_fp = np.ctypeslib.as_array(C.cast(L.rgen_pos_start_fps(handle), C.POINTER(C.c_int64)), shape=(nt,)).copy()
             self.last_pos_block_offset = np.ctypeslib.as_array(C.cast(L.rgen_last_pos_block_offsets(handle), C.POINTER(C.c_int64)),
                                                                shape=(nt,)).copy()
+        npay = L.rgen_pay_len(handle)
+        self.pay_bytes = self.pay_start_fp = None
+        if npay > 0:   # the field stores payloads or offsets: the ".pay" file and each term's pointer into it
+            self.pay_bytes = np.ctypeslib.as_array(C.cast(L.rgen_pay_bytes(handle), C.POINTER(C.c_uint8)), shape=(npay,)).copy()
+            self.pay_start_fp = np.ctypeslib.as_array(C.cast(L.rgen_pay_start_fps(handle), C.POINTER(C.c_int64)), shape=(nt,)).copy()
         err = L.rgen_error(handle).decode()
         L.rgen_free(handle)
         if err:
@@ -115,22 +127,39 @@ def build_explicit(max_doc, postings, norms=None, version=1, segment_id=None, do
     return seg
 
 
-def build_explicit_positions(max_doc, postings, norms=None, version=1, segment_id=None, doc_base=0):
+def build_explicit_positions(max_doc, postings, norms=None, version=1, segment_id=None, doc_base=0, offsets=False, payloads=False):
     """A DocsAndFreqsAndPositions field. postings: per term a list of (doc, [positions ascending]) in doc order (an empty
     list -> absent term). The segment carries .doc bytes (skip entries with position pointers), .pos bytes and, per term,
-    pos_start_fp / last_pos_block_offset next to the usual term states."""
+    pos_start_fp / last_pos_block_offset next to the usual term states. offsets / payloads: the field also stores them
+    (IndexOptions::DocsAndFreqsAndPositionsAndOffsets / FieldInfo::has_store_payloads) — a doc's entry is then
+    (doc, [positions], [(start, end), ...], [payload bytes, ...]) and the segment also carries .pay bytes and pay_start_fp."""
     offs = np.zeros(len(postings) + 1, dtype=np.int64)
     offs[1:] = np.cumsum([len(p) for p in postings])
-    docs = np.ascontiguousarray([d for p in postings for d, _ in p] or [0], dtype=np.int32)
-    freqs = np.ascontiguousarray([len(ps) for p in postings for _, ps in p] or [0], dtype=np.int32)
+    docs = np.ascontiguousarray([e[0] for p in postings for e in p] or [0], dtype=np.int32)
+    freqs = np.ascontiguousarray([len(e[1]) for p in postings for e in p] or [0], dtype=np.int32)
     pos_offs = np.zeros(int(offs[-1]) + 1, dtype=np.int64)
-    pos_offs[1:] = np.cumsum([len(ps) for p in postings for _, ps in p]) if offs[-1] else 0
-    positions = np.ascontiguousarray([x for p in postings for _, ps in p for x in ps] or [0], dtype=np.int32)
+    pos_offs[1:] = np.cumsum([len(e[1]) for p in postings for e in p]) if offs[-1] else 0
+    positions = np.ascontiguousarray([x for p in postings for e in p for x in e[1]] or [0], dtype=np.int32)
     nb = None if norms is None else np.ascontiguousarray(norms, dtype=np.uint8)
     sid = None if segment_id is None else np.frombuffer(segment_id, dtype=np.uint8).copy()
-    h = lib().rgen_build_explicit_positions(max_doc, version, len(postings), offs.ctypes.data, docs.ctypes.data, freqs.ctypes.data,
-                                            pos_offs.ctypes.data, positions.ctypes.data, None if nb is None else nb.ctypes.data,
-                                            None if sid is None else sid.ctypes.data)
+    if not offsets and not payloads:
+        h = lib().rgen_build_explicit_positions(max_doc, version, len(postings), offs.ctypes.data, docs.ctypes.data, freqs.ctypes.data,
+                                                pos_offs.ctypes.data, positions.ctypes.data, None if nb is None else nb.ctypes.data,
+                                                None if sid is None else sid.ctypes.data)
+    else:
+        starts = np.ascontiguousarray([o[0] for p in postings for e in p for o in e[2]] if offsets else [0], dtype=np.int32)
+        ends = np.ascontiguousarray([o[1] for p in postings for e in p for o in e[2]] if offsets else [0], dtype=np.int32)
+        blobs = [bytes(b) for p in postings for e in p for b in e[3]] if payloads else []
+        pay_offs = np.zeros(len(blobs) + 1, dtype=np.int64)
+        if blobs:
+            pay_offs[1:] = np.cumsum([len(b) for b in blobs])
+        pay = np.frombuffer(b"".join(blobs) + b"\0", dtype=np.uint8).copy()
+        assert not offsets or starts.size == positions.size
+        assert not payloads or len(blobs) == positions.size
+        h = lib().rgen_build_explicit_positions_ex(max_doc, version, len(postings), offs.ctypes.data, docs.ctypes.data, freqs.ctypes.data,
+                                                   pos_offs.ctypes.data, positions.ctypes.data, (1 if offsets else 0) | (2 if payloads else 0),
+                                                   starts.ctypes.data, ends.ctypes.data, pay_offs.ctypes.data, pay.ctypes.data,
+                                                   None if nb is None else nb.ctypes.data, None if sid is None else sid.ctypes.data)
     seg = SyntheticSegment(h, doc_base)
     if norms is None:
         seg.norms = None

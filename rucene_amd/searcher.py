@@ -60,15 +60,17 @@ class LeafReader:
 
     def __init__(self, doc_bytes, norms, max_doc, terms, doc_base=0, live_docs=None, doc_count=None,
                  sum_total_term_freq=0, sum_doc_freq=-1, field="body", term_dictionary=None, field_number=0,
-                 index_options=_lib.INDEX_OPTIONS_DOCS_AND_FREQS):
+                 index_options=_lib.INDEX_OPTIONS_DOCS_AND_FREQS, has_payloads=False):
         self.doc_bytes, self.norms, self.max_doc, self.doc_base = doc_bytes, norms, int(max_doc), int(doc_base)
         self.terms = np.ascontiguousarray(terms if terms is not None else [], dtype=TERM_STATE_DTYPE)
         self.live_docs = live_docs
         self.doc_count = int(max_doc if doc_count is None else doc_count)
         self.sum_total_term_freq, self.sum_doc_freq, self.field = int(sum_total_term_freq), int(sum_doc_freq), field
         self.term_dictionary, self.field_number = term_dictionary, int(field_number)
-        self.index_options = int(index_options)  # doc::IndexOptions ordinal: 1 Docs, 2 DocsAndFreqs, 3 DocsAndFreqsAndPositions
+        self.index_options = int(index_options)  # doc::IndexOptions ordinal: 1 Docs, 2 DocsAndFreqs, 3 DocsAndFreqsAndPositions, 4 ...AndOffsets
+        self.has_payloads = bool(has_payloads)   # FieldInfo::has_store_payloads
         self.pos_bytes = None      # the ".pos" file of a positions field
+        self.pay_bytes = None      # the ".pay" file of a field that stores payloads or offsets
         self.term_positions = None  # per flat term id: TERM_POSITIONS_DTYPE records (synthetic segments)
         self._resolved = {}  # term bytes -> state or None
         self.segment = None  # rgpu_segment, created by the searcher
@@ -79,13 +81,18 @@ class LeafReader:
                    seg.live_docs, seg.doc_count, seg.sum_total_term_freq, seg.sum_doc_freq)
 
     @classmethod
-    def from_synthetic_positions(cls, seg, doc_base=None):
-        """A synthetic DocsAndFreqsAndPositions field (indexgen.build_explicit_positions): .doc + .pos + per-term pointers."""
+    def from_synthetic_positions(cls, seg, doc_base=None, offsets=False, payloads=False):
+        """A synthetic DocsAndFreqsAndPositions field (indexgen.build_explicit_positions): .doc + .pos + per-term pointers;
+        offsets / payloads: as the segment was built (+ .pay)."""
         leaf = cls(seg.doc_bytes, seg.norms, seg.max_doc, seg.terms, seg.doc_base if doc_base is None else doc_base,
-                   seg.live_docs, seg.doc_count, seg.sum_total_term_freq, seg.sum_doc_freq, index_options=_lib.INDEX_OPTIONS_POSITIONS)
+                   seg.live_docs, seg.doc_count, seg.sum_total_term_freq, seg.sum_doc_freq,
+                   index_options=_lib.INDEX_OPTIONS_OFFSETS if offsets else _lib.INDEX_OPTIONS_POSITIONS, has_payloads=payloads)
         leaf.pos_bytes = seg.pos_bytes
+        leaf.pay_bytes = seg.pay_bytes
         tp = np.zeros(seg.terms.size, dtype=_lib.TERM_POSITIONS_DTYPE)
         tp["pos_start_fp"], tp["last_pos_block_offset"] = seg.pos_start_fp, seg.last_pos_block_offset
+        if seg.pay_start_fp is not None:
+            tp["pay_start_fp"] = seg.pay_start_fp
         leaf.term_positions = tp
         return leaf
 
@@ -103,31 +110,31 @@ class LeafReader:
 
     @classmethod
     def from_index_files(cls, doc, tim, tip, nvm, nvd, max_doc, field_number=0, index_options=2, liv=None, del_count=-1,
-                         doc_base=0, field="body", other_fields=(), fnm=None):
+                         doc_base=0, field="body", other_fields=(), fnm=None, has_payloads=False):
         """A segment as Rucene wrote it (SegmentReader::open -> the per-format producers): `.doc` postings, `.tim`/`.tip`
         block-tree term dictionary, `.nvm`/`.nvd` norms, optional `.liv` live docs. With `fnm` (the segment's field infos
         file) the searched field is found by its name `field` and every other indexed field is declared from the file;
         otherwise pass `field_number`/`index_options` and `other_fields`: (number, index_options[, has_payloads]) of the
         segment's other indexed fields (the `.tim` summary lists them all).
-        A Docs or a DocsAndFreqs field can be searched (positions fields carry a different skip-entry layout)."""
+        Any indexed field can be searched; for phrases set `pos_bytes` (and, for a field with payloads / offsets, `pay_bytes`)."""
         if fnm is not None:
             infos = _lib.field_infos_from_lucene60(fnm)
             mine = [fi for fi in infos if fi["name"] == field]
             if not mine:
                 raise RgpuError(-2, "no field named %r in this segment" % field)
-            field_number, index_options = mine[0]["number"], mine[0]["index_options"]
+            field_number, index_options, has_payloads = mine[0]["number"], mine[0]["index_options"], bool(mine[0]["has_payloads"])
             other_fields = [(fi["number"], fi["index_options"], int(fi["has_payloads"])) for fi in infos
                             if fi["index_options"] != 0 and fi["name"] != field]
-        if index_options not in (_lib.INDEX_OPTIONS_DOCS, _lib.INDEX_OPTIONS_DOCS_AND_FREQS, _lib.INDEX_OPTIONS_POSITIONS):
-            raise RgpuError(-5, "the searched field must be indexed with IndexOptions::Docs, ::DocsAndFreqs or ::DocsAndFreqsAndPositions")
-        td = _lib.TermDictionary(tim, tip, [(field_number, index_options)] + list(other_fields), max_doc)
+        if index_options not in (_lib.INDEX_OPTIONS_DOCS, _lib.INDEX_OPTIONS_DOCS_AND_FREQS, _lib.INDEX_OPTIONS_POSITIONS, _lib.INDEX_OPTIONS_OFFSETS):
+            raise RgpuError(-5, "the searched field must be indexed (IndexOptions::Docs ... ::DocsAndFreqsAndPositionsAndOffsets)")
+        td = _lib.TermDictionary(tim, tip, [(field_number, index_options, int(has_payloads))] + list(other_fields), max_doc)
         stats = td.field_stats(field_number)
         if stats is None:
             raise RgpuError(-2, "field %d has no postings in this segment" % field_number)
         norms = _lib.norms_from_lucene53(nvm, nvd, field_number, max_doc)
         live = _lib.live_docs_from_lucene50(liv, max_doc, del_count) if liv is not None else None
         return cls(doc, norms, max_doc, None, doc_base, live, stats["doc_count"], stats["sum_total_term_freq"],
-                   stats["sum_doc_freq"], field, td, field_number, index_options)
+                   stats["sum_doc_freq"], field, td, field_number, index_options, has_payloads)
 
     def resolve(self, terms):
         """One batched dictionary lookup for the byte terms not seen before (seek_exact + term_state each)."""
@@ -317,7 +324,10 @@ class GpuIndexSearcher:
         self.similarity = similarity or BM25Similarity()
         for leaf in self.leaves:
             if leaf.segment is None:
-                leaf.segment = _lib.Segment(self.ctx, leaf.doc_bytes, leaf.norms, leaf.max_doc, leaf.doc_base, leaf.live_docs, leaf.index_options)
+                leaf.segment = _lib.Segment(self.ctx, leaf.doc_bytes, leaf.norms, leaf.max_doc, leaf.doc_base, leaf.live_docs,
+                                            leaf.index_options | (_lib.FIELD_STORES_PAYLOADS if getattr(leaf, "has_payloads", False) else 0))
+                if getattr(leaf, "pay_bytes", None) is not None:
+                    leaf.segment.attach_payloads(leaf.pay_bytes)   # Lucene50PostingsReader::open checks the third file too
         # searcher.rs:306-363: statistics of the first leaf with the largest max_doc stand in for the index
         self._stats_leaf = 0
         for i, leaf in enumerate(self.leaves):

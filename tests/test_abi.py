@@ -82,7 +82,7 @@ def test_struct_layouts_match_the_header(gpu_lib):
     assert gpu_lib.QUERY_TERM_DTYPE.itemsize == 40 and gpu_lib.QUERY_TERM_DTYPE.fields["weight"][1] == 32
     assert gpu_lib.QUERY_DTYPE.itemsize == 16 and gpu_lib.HIT_DTYPE.itemsize == 8
     assert C.sizeof(gpu_lib._Config) == 64
-    assert gpu_lib.lib().rgpu_abi_version() == 4 == gpu_lib.ABI_VERSION
+    assert gpu_lib.lib().rgpu_abi_version() == 5 == gpu_lib.ABI_VERSION
 
 
 def test_bm25_host_helper_is_bit_exact_with_the_oracle(gpu_lib, oracle):

@@ -1210,6 +1210,89 @@ def test_exact_phrases(ctx, oracle, version, max_doc):
     assert totals[2] == len(set(d for d, _ in postings[3]) | set(d for d, _ in postings[vocab + 1]))
 
 
+@pytest.mark.parametrize("offsets,payloads,version,max_doc", [(True, True, 1, 6000), (True, False, 1, 6000), (False, True, 1, 6000), (True, True, 0, 6000),
+                                                              (True, True, 1, 90_000), (False, True, 1, 90_000)],
+                         ids=["offsets+payloads", "offsets", "payloads", "legacy", "offsets+payloads-4-skip-levels", "payloads-4-skip-levels"])
+def test_payload_and_offset_fields(ctx, oracle, offsets, payloads, version, max_doc):
+    """SURVEY 8(f)3, the ".pay" half: a field that stores payloads and / or offsets (IndexOptions::...AndOffsets,
+    FieldInfo::has_store_payloads). Its skip entries carry one or two more words (skip_writer.rs:276-286: k_skip_terms /
+    k_skip_dir<., 5 | 6>), the trailing VInt block of a term's positions carries payload bytes — some longer than the walk's
+    LDS window — and offset words between the deltas (posting_writer.rs:505-560: decode_vint_block_everything). Files from the
+    restated writer; exact and sloppy phrases against the oracle's scorers over BlockPostingIterator with the field's flags
+    (doc ids, score bits, hit counts); and the same postings indexed WITHOUT payloads / offsets must give the very same
+    answers — TERM / AND / OR included, whose skip entries differ — (a size-independent property of the path)."""
+    import rucene_amd
+    from rucene_amd import _lib as gpu
+    from test_payloads import make_postings
+    rng = np.random.default_rng(41 + version)
+    vocab = 10 if max_doc <= 6000 else 4
+    postings = make_postings(rng, max_doc, vocab, 40 if max_doc <= 6000 else 12, big_payload_every=173)
+    plain = [[(e[0], e[1]) for e in pl] for pl in postings]
+    n = len(postings)
+    norms = rng.integers(95, 125, size=max_doc).astype(np.uint8)
+    doc_count = len({e[0] for pl in postings for e in pl})
+    sum_ttf = sum(len(e[1]) for pl in postings for e in pl)
+
+    def leaf_of(ix, has_off, has_pay):
+        doc_bytes, pos_bytes = ix.files()
+        terms = np.zeros(n, dtype=gpu.TERM_STATE_DTYPE)
+        tpos = np.zeros(n, dtype=gpu.TERM_POSITIONS_DTYPE)
+        for t in range(n):
+            st = ix.term_state(t)
+            terms[t] = (st["doc_start_fp"], st["skip_offset"], st["total_term_freq"], st["doc_freq"], st["singleton_doc_id"])
+            tpos[t]["pos_start_fp"], tpos[t]["last_pos_block_offset"], tpos[t]["pay_start_fp"] = st["pos_start_fp"], st["last_pos_block_offset"], st["pay_start_fp"]
+        leaf = rucene_amd.LeafReader(np.frombuffer(doc_bytes, np.uint8), norms, max_doc, terms, doc_count=doc_count, sum_total_term_freq=sum_ttf,
+                                     index_options=4 if has_off else 3, has_payloads=has_pay)
+        leaf.pos_bytes, leaf.term_positions = np.frombuffer(pos_bytes, np.uint8), tpos
+        if has_off or has_pay:
+            leaf.pay_bytes = np.frombuffer(ix.pay_file(), np.uint8)
+        return leaf
+
+    ix = oracle.PositionsIndex(max_doc, postings, version=version, offsets=offsets, payloads=payloads)
+    ix_plain = oracle.PositionsIndex(max_doc, plain, version=version)
+    searcher = rucene_amd.GpuIndexSearcher([leaf_of(ix, offsets, payloads)], ctx=ctx)
+    searcher_plain = rucene_amd.GpuIndexSearcher([leaf_of(ix_plain, False, False)], ctx=ctx)
+    phrases = [[0, 1], [1, 0], [2, 2], [3, 3, 3], [0, 1, 2], [0, 1, 2, 3], [1, vocab + 2], [vocab, 3], [vocab + 1, 0], [0, vocab + 1]]
+    phrases += [rng.integers(0, vocab, size=int(rng.integers(2, 5))).tolist() for _ in range(20)]
+    queries = [rucene_amd.PhraseQuery(p) for p in phrases] + [rucene_amd.PhraseQuery(p, slop=int(rng.integers(1, 5))) for p in phrases]
+    matched = 0
+    for k in (10, 100):
+        hits, totals = searcher.search_phrase_batch(queries, k)
+        hits_p, totals_p = searcher_plain.search_phrase_batch(queries, k)
+        assert (totals == totals_p).all() and (hits["doc"] == hits_p["doc"]).all() and (hits["score"].view(np.int32) == hits_p["score"].view(np.int32)).all()
+        for i, q in enumerate(queries):
+            d, s, total = ix.phrase_search(q.terms, k, norms, max_doc, doc_count, sum_ttf, offsets=q.positions, slop=q.slop)
+            assert totals[i] == total, (i, q.terms, q.slop, totals[i], total)
+            assert (hits[i]["doc"][:d.size] == d).all() and (hits[i]["doc"][d.size:] == -1).all(), (i, q.terms, q.slop)
+            assert (hits[i]["score"][:d.size].view(np.int32) == s.view(np.int32)).all(), (i, q.terms, q.slop)
+            matched += total
+    assert matched > 1000
+    # plain term / boolean queries and the materialising decode: the .doc skip entries of the two fields differ, the answers do not
+    T, B = rucene_amd.TermQuery, rucene_amd.BooleanQuery
+    qs = [T(t) for t in range(n)] + [B.build([T(0), T(1)], []), B.build([T(2), T(3), T(1)], []), B.build([], [T(0), T(vocab + 1)]),
+                                     B.build([T(1)], [T(2), T(3)]), B.build([], [T(t % vocab) for t in range(12)])]
+    for k in (10, 100):
+        hits, totals = searcher.search_batch(qs, k)
+        hits_p, totals_p = searcher_plain.search_batch(qs, k)
+        assert (totals == totals_p).all() and (hits["doc"] == hits_p["doc"]).all() and (hits["score"].view(np.int32) == hits_p["score"].view(np.int32)).all()
+    for t in range(n):
+        assert totals[t] == len(postings[t])
+    assert totals[n] == len({e[0] for e in postings[0]} & {e[0] for e in postings[1]})
+    leaf = searcher.leaves[0]
+    for t in (0, vocab, vocab + 1):
+        docs, freqs = leaf.segment.decode_terms(leaf.terms[t])
+        assert docs.tolist() == [e[0] for e in postings[t]] and freqs.tolist() == [len(e[1]) for e in postings[t]]
+    # the third file is checked like Lucene50PostingsReader::open checks it
+    bad = bytearray(ix.pay_file())
+    bad[10] ^= 0x40
+    with pytest.raises(rucene_amd.RgpuError):
+        leaf.segment.attach_payloads(np.frombuffer(bytes(bad), np.uint8))
+    with pytest.raises(rucene_amd.RgpuError):
+        searcher_plain.leaves[0].segment.attach_payloads(np.frombuffer(ix.pay_file(), np.uint8))   # a field without payloads / offsets has none
+    ix.close()
+    ix_plain.close()
+
+
 @pytest.mark.parametrize("deletions", [False, True], ids=["all-live", "deletions"])
 def test_phrases_two_phase_rule_and_deletions(ctx, oracle, deletions):
     """Phrases over a segment with deleted docs, and BulkScorer's two-phase loop around the sloppy scorer (bulk_scorer.rs:91-113):
