@@ -1399,6 +1399,31 @@ static int32_t search_or_lazy_group(rgpu_segment* seg, Group& G, int32_t k, HitO
     HIP_TRY(hipMalloc(&seg->empty_bitmap, bytes));
     HIP_TRY(hipMemsetAsync(seg->empty_bitmap, 0, bytes, stream));
   }
+  if (G.queries.size() > 2) {
+    // Queries that stream the same bitmaps sit next to each other in the launch (workgroup b works on query b % n_queries, one
+    // group of windows after the other): the group's queries are ordered by their two densest terms. Measured on the
+    // 1024 x 10-term batch: k_or_lazy 3.45 ms against 3.66 in the caller's order (26.3 against 28.9 at 100 M docs). Giving
+    // every XCD (b % 8) a contiguous eighth of that order instead — its L2 would hold one neighbourhood's bitmaps — costs
+    // more than it gains: 4.0 ms, the heavy neighbourhoods make their XCD the launch's tail. Rows are found through qmap.
+    const int nq0 = (int)G.queries.size();
+    std::vector<std::pair<uint64_t, int>> keyed((size_t)nq0);
+    for (int i = 0; i < nq0; ++i) {
+      const DevQuery& q0 = G.queries[(size_t)i];
+      int32_t d1 = 0, d2 = 0;
+      uint64_t f1 = 0, f2 = 0;  // the two densest clauses' terms
+      for (int j = 0; j < q0.n_terms; ++j) {
+        const DevTerm& t = G.terms[(size_t)(q0.first_term + j)];
+        if (t.df > d1) { d2 = d1; f2 = f1; d1 = t.df; f1 = t.start_fp; } else if (t.df > d2) { d2 = t.df; f2 = t.start_fp; }
+      }
+      keyed[(size_t)i] = {(f1 & 0xffffffffull) << 32 | (f2 & 0xffffffffull), i};
+    }
+    std::stable_sort(keyed.begin(), keyed.end(), [](const std::pair<uint64_t, int>& a, const std::pair<uint64_t, int>& b) { return a.first < b.first; });
+    std::vector<DevQuery> qs((size_t)nq0);
+    std::vector<int32_t> qm((size_t)nq0);
+    for (int i = 0; i < nq0; ++i) { qs[(size_t)i] = G.queries[(size_t)keyed[(size_t)i].second]; qm[(size_t)i] = G.qmap[(size_t)keyed[(size_t)i].second]; }
+    G.queries.swap(qs);
+    G.qmap.swap(qm);
+  }
   Group rest;  // queries k_or_lazy hands back
   rest.op = RGPU_OP_OR;
   rest.or_wide = true;
@@ -2109,6 +2134,26 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
       continue;
     }
     HIP_TRY(scratch_take(c));
+    if (op == RGPU_OP_AND && !G.req_opt && nq > 2) {
+      // Conjunctions that probe the same list run side by side: the group's queries are ordered by the term of the first clause
+      // behind the lead — the one every lead posting is looked up in (a doc bitmap: one gather per candidate into a 1 - 5 MB
+      // array). Measured on the 1024 x 3-term batch: 0.365 ms against 0.388 in the caller's order; heaviest-lead-first 0.64 and
+      // lightest-first 0.57 (a query's items start all at once, each with an empty top-k list and no published threshold; or
+      // the heavy ones make the tail). The caller's rows are found through qmap, so the order is free.
+      std::vector<int> order((size_t)nq);
+      for (int i = 0; i < nq; ++i) order[(size_t)i] = i;
+      auto key_of = [&](int i) -> uint64_t {
+        const DevQuery& q0 = G.queries[(size_t)i];
+        const int n_all = q0.n_terms + q0.pad + ((q0.op >> 16) & 0xff);
+        return n_all >= 2 && q0.n_terms >= 1 ? G.terms[(size_t)(q0.first_term + 1)].start_fp : 0ull;
+      };
+      std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return key_of(a) > key_of(b); });
+      std::vector<DevQuery> qs((size_t)nq);
+      std::vector<int32_t> qm((size_t)nq);
+      for (int i = 0; i < nq; ++i) { qs[(size_t)i] = G.queries[(size_t)order[(size_t)i]]; qm[(size_t)i] = G.qmap[(size_t)order[(size_t)i]]; }
+      G.queries.swap(qs);
+      G.qmap.swap(qm);
+    }
     int blocks_per_item = op == RGPU_OP_TERM ? c->cfg.blocks_per_item : c->cfg.and_blocks_per_item;
     int64_t items = 0;
     G.item_prefix.assign((size_t)nq + 1, 0);
