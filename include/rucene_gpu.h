@@ -33,7 +33,7 @@ extern "C" {
                                    wavefront. Disjunctions of 10..16 SHOULD clauses take the fixed-point kernels, longer ones the
                                    clause-order kernel */
 #define RGPU_MAX_PHRASE_TERMS 16 /* terms of one phrase */
-#define RGPU_MAX_K 1024   /* k above 128 costs ceil(k / 128) passes of the search; phrase search and rescoring: k <= 128 */
+#define RGPU_MAX_K 1024   /* k above 128 costs ceil(k / 128) passes of the search (phrases: of the collector only); rescoring: k <= 128 */
 
 /* error.rs:24-91 ErrorKind */
 typedef enum rgpu_status {

@@ -530,6 +530,9 @@ __global__ __launch_bounds__(WG_THREADS) void k_sloppy_match(SegView seg, const 
 }
 
 // TopDocsCollector over one query's candidates: a key of 0 = "phrase freq 0" (not a hit). One wavefront per query.
+// Any k up to RGPU_MAX_K (collector/top_docs.rs:28-95): a wavefront's registers hold 128 keys, so k > 128 runs as passes of
+// 128 over the candidates' keys — pass p keeps what lies strictly below pass p - 1's worst key (keys are unique per doc and
+// totally ordered: the passes partition the ranking exactly, as in k_merge_lists). WIDE: k > 64.
 template <bool WIDE>
 __global__ __launch_bounds__(WG_THREADS) void k_phrase_collect(const int64_t* __restrict__ emit_prefix,
                                                                const unsigned long long* __restrict__ emit_count,
@@ -540,10 +543,9 @@ __global__ __launch_bounds__(WG_THREADS) void k_phrase_collect(const int64_t* __
   const int lane = lane_id();
   const int q = (int)(blockIdx.x * WG_WAVES) + wave_id();
   if (q >= n_queries) return;
-  WaveTopK top;
-  uint64_t tau = 0;
   int64_t total = 0;
   const int64_t base = emit_prefix[q], n = (int64_t)emit_count[q];
+  HitOut* out = hits_out + (size_t)q * (size_t)k;
   // SloppyPhraseScorer is two-phase, so BulkScorer runs it through its two-phase loop (bulk_scorer.rs:97-113): every
   // approximation — a conjunction match, phrase or not, live or deleted — counts, and once more than next_limit of them went by
   // with nothing collected the leaf is abandoned: the query then has NO hits in this segment. In terms of the candidate list:
@@ -561,21 +563,26 @@ __global__ __launch_bounds__(WG_THREADS) void k_phrase_collect(const int64_t* __
       before += __popcll(__ballot(earlier));
     }
     if (first == 0x7fffffff || before > (int64_t)next_limits[q]) {
-      HitOut* out = hits_out + (size_t)q * (size_t)k;
-      if (lane < k) out[lane] = HitOut{-1, 0.f};
-      if (WIDE && lane + 64 < k) out[lane + 64] = HitOut{-1, 0.f};
+      for (int i = lane; i < k; i += 64) out[i] = HitOut{-1, 0.f};
       if (lane == 0) totals_out[q] = 0;
       return;
     }
   }
-  for (int64_t i0 = 0; i0 < n; i0 += 64) {
-    const uint64_t key = i0 + lane < n ? keys[base + i0 + lane] : 0ull;
-    total += __popcll(__ballot(key != 0ull));
-    if (__ballot(key > tau)) topk_offer<WIDE>(top, key, tau, k, lane);
+  uint64_t ceil = ~0ull;
+  for (int col0 = 0; col0 < k; col0 += 128) {
+    const int kp = min(128, k - col0);
+    WaveTopK top;
+    uint64_t tau = 0;
+    for (int64_t i0 = 0; i0 < n; i0 += 64) {
+      const uint64_t raw = i0 + lane < n ? keys[base + i0 + lane] : 0ull;
+      if (col0 == 0) total += __popcll(__ballot(raw != 0ull));
+      const uint64_t key = below(raw, ceil);
+      if (__ballot(key > tau)) topk_offer<WIDE>(top, key, tau, kp, lane);
+    }
+    if (lane < kp) out[col0 + lane] = top.a ? HitOut{key_doc(top.a) + doc_base, key_score(top.a)} : HitOut{-1, 0.f};
+    if (WIDE && lane + 64 < kp) out[col0 + lane + 64] = top.b ? HitOut{key_doc(top.b) + doc_base, key_score(top.b)} : HitOut{-1, 0.f};
+    ceil = topk_threshold<WIDE>(top, kp);  // 0 when this pass did not fill up: nothing is left for the next one
   }
-  HitOut* out = hits_out + (size_t)q * (size_t)k;
-  if (lane < k) out[lane] = top.a ? HitOut{key_doc(top.a) + doc_base, key_score(top.a)} : HitOut{-1, 0.f};
-  if (WIDE && lane + 64 < k) out[lane + 64] = top.b ? HitOut{key_doc(top.b) + doc_base, key_score(top.b)} : HitOut{-1, 0.f};
   if (lane == 0) totals_out[q] = total;
 }
 

@@ -335,6 +335,13 @@ static int ilog8_levels(int32_t df) {  // skip_reader.rs:307-313 trim + :461-472
   return std::min(levels, 10);
 }
 
+// developer knob: RGPU_HOST_TIMING=1 prints where the host side of a term preparation / decode call spends its time (stderr)
+struct HostClock {
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  static bool on() { static const bool v = std::getenv("RGPU_HOST_TIMING") != nullptr; return v; }
+  long long lap() { const auto n = std::chrono::steady_clock::now(); const long long us = (long long)std::chrono::duration_cast<std::chrono::microseconds>(n - t).count(); t = n; return us; }
+};
+
 static int32_t validate_state(const rgpu_segment* seg, const rgpu_term_state& st) {
   if (st.doc_freq < 0) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "negative doc_freq");
   if (st.doc_freq <= 1) return RGPU_OK;
@@ -384,6 +391,8 @@ static void prep_items(const std::vector<PrepTerm>& work, std::vector<int64_t>* 
 }
 static int32_t prepare_terms_attempt(rgpu_segment* seg, const rgpu_term_state* const* sts, size_t n, bool wide, const DecodeSink* sink) {
   rgpu_ctx* c = seg->ctx;
+  HostClock hc;
+  long long t_plan = 0, t_reserve = 0, t_stage = 0, t_enqueue = 0, t_sync = 0, t_commit = 0;
   std::vector<PrepTerm> work;
   if (sink) sink->fused->assign(n, 0);
   size_t need_slots = seg->dir_used;
@@ -435,6 +444,7 @@ static int32_t prepare_terms_attempt(rgpu_segment* seg, const rgpu_term_state* c
   }
   if (work.empty()) return RGPU_OK;
   if (cap_rows > 0xfffffff0ull) return fail(RGPU_ERR_UNSUPPORTED, "one call prepares more than 64 GiB of block store: split the term list");
+  t_plan = hc.lap();
   HIP_TRY(scratch_take(c));  // staging below; this function ends with a stream sync, so the slot is free again on return
   HIP_TRY(seg->dir_last.reserve(need_slots, seg->dir_used, c->stream));
   HIP_TRY(seg->dir_off.reserve(need_slots, seg->dir_used, c->stream));
@@ -443,6 +453,7 @@ static int32_t prepare_terms_attempt(rgpu_segment* seg, const rgpu_term_state* c
   HIP_TRY(seg->dir_hdr.reserve(need_slots, seg->dir_used, c->stream));
   HIP_TRY(seg->dir_bmax.reserve(need_slots, seg->dir_used, c->stream));
   if (seg->has_positions) HIP_TRY(seg->dir_pos.reserve(need_slots, seg->dir_used, c->stream));
+  t_reserve = hc.lap();
   // plans: (term, 1 KB chunk of level-0 skip bytes) for k_skip_dir; (term, chunk of blocks) for the block kernels
   // (+ (term, SKIP_GROUP chunks) for k_skip_groups: terms of more than SKIP_GROUP chunks only, the others are zero-width in group_prefix)
   std::vector<int64_t> item_prefix, chunk_prefix(work.size() + 1), group_prefix(work.size() + 1);
@@ -477,6 +488,7 @@ static int32_t prepare_terms_attempt(rgpu_segment* seg, const rgpu_term_state* c
   HIP_TRY(seg->prep_scratch.reserve(o_tiles + (size_t)n_tiles * 8 + 64, 0, c->stream));
   HIP_TRY(hipMemsetAsync(seg->prep_scratch.p, 0, 64, c->stream));
   HIP_TRY(hipMemsetAsync(c->d_err, 0, 4 * sizeof(int), c->stream));
+  t_stage = hc.lap();
   unsigned long long* d_ticket = reinterpret_cast<unsigned long long*>(seg->prep_scratch.p);
   unsigned long long* d_total = d_ticket + 1;
   SkipAgg* d_aggs = reinterpret_cast<SkipAgg*>(seg->prep_scratch.p + o_aggs);
@@ -541,10 +553,12 @@ static int32_t prepare_terms_attempt(rgpu_segment* seg, const rgpu_term_state* c
   }
   int err4[4] = {0, 0, 0, 0};
   unsigned long long total_rows = 0;
+  t_enqueue = hc.lap();
   HIP_TRY(hipMemcpyAsync(err4, c->d_err, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipMemcpyAsync(&total_rows, d_total, 8, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   HIP_TRY(hipGetLastError());
+  t_sync = hc.lap();
   const int err = err4[0];
   if (err == -101) return -101;  // see prepare_terms_locked
   if (err != 0) {
@@ -556,6 +570,10 @@ static int32_t prepare_terms_attempt(rgpu_segment* seg, const rgpu_term_state* c
   seg->bstore_used = batch_bs + (size_t)total_rows * 16;
   seg->prepared.reserve_more(added.size());
   for (auto& a : added) seg->prepared.put(a.first, a.second);
+  t_commit = hc.lap();
+  if (HostClock::on())
+    std::fprintf(stderr, "[prepare host] %zu terms: plan %lld us, reserve (hipMalloc / grow) %lld, plan chunks + stage + H2D %lld, enqueue %lld, kernels + sync %lld, commit %lld\n",
+                 work.size(), t_plan, t_reserve, t_stage, t_enqueue, t_sync, t_commit);
   return RGPU_OK;
 }
 
@@ -2437,7 +2455,7 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
                                             int64_t* total_hits_out) {
   if (!seg || !queries || n_queries <= 0 || !terms || n_terms_total <= 0 || !hits_out || !total_hits_out)
     return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "bad arguments");
-  if (k <= 0 || k > RGPU_PASS_K) return fail(k <= 0 ? RGPU_ERR_ILLEGAL_ARGUMENT : RGPU_ERR_UNSUPPORTED, "phrase search: k must be in 1..128");
+  if (k <= 0 || k > RGPU_MAX_K) return fail(k <= 0 ? RGPU_ERR_ILLEGAL_ARGUMENT : RGPU_ERR_UNSUPPORTED, "phrase search: k must be in 1..RGPU_MAX_K");
   if (!seg->has_positions || !seg->d_pos) return fail(RGPU_ERR_ILLEGAL_STATE, "phrase search needs a positions field with its .pos file attached");
   rgpu_ctx* c = seg->ctx;
   std::lock_guard<std::mutex> g(c->mu);
@@ -2543,7 +2561,8 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
     HIP_TRY(c->phrase_keys.reserve((size_t)slots + 64, 0, stream));
     HIP_TRY(c->phrase_count.reserve((size_t)n_queries, 0, stream));
     HIP_TRY(hipMemsetAsync(c->phrase_count.p, 0, (size_t)n_queries * 8, stream));
-    HIP_TRY(c->S->d_partial_keys.reserve((size_t)items * (size_t)k, 0, stream));
+    const int k_emit = std::min<int>(k, 64);  // the conjunction only emits candidates: its (empty) top-k lists are the narrow kind
+    HIP_TRY(c->S->d_partial_keys.reserve((size_t)items * (size_t)k_emit, 0, stream));
     HIP_TRY(c->S->d_partial_counts.reserve((size_t)items, 0, stream));
     HIP_TRY(c->S->d_tau.reserve((size_t)n_queries, 0, stream));
     HIP_TRY(c->S->d_touched.reserve((size_t)n_queries * 2, 0, stream));
@@ -2561,7 +2580,7 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
       TimedLaunch tl(c, stream, "k_search_and(phrase candidates)", 0);
       const unsigned grid = (unsigned)((items + WG_WAVES - 1) / WG_WAVES);
       auto go = [&](auto kern) {
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(WG_THREADS), 0, stream, sv, d_q, d_t, d_ip, (int)n_queries, items, blocks_per_item, (int)k,
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(WG_THREADS), 0, stream, sv, d_q, d_t, d_ip, (int)n_queries, items, blocks_per_item, k_emit,
                            c->S->d_partial_keys.p, c->S->d_partial_counts.p, c->S->d_tau.p, c->S->d_touched.p, d_ep, c->phrase_count.p,
                            (void*)c->phrase_docs.p, (const unsigned long long*)nullptr, (const int32_t*)nullptr, (const TermBitmap*)nullptr);
       };

@@ -1173,7 +1173,7 @@ def test_exact_phrases(ctx, oracle, version, max_doc):
     phrases += [rng.integers(0, vocab, size=int(rng.integers(2, 5))).tolist() for _ in range(30)]
     gapped = [([0, 1], [0, 2]), ([3, 4, 5], [0, 1, 3]), ([2, 2], [0, 5])]
     queries = [rucene_amd.PhraseQuery(p) for p in phrases] + [rucene_amd.PhraseQuery(t, o) for t, o in gapped]
-    for k in (10, 100):
+    for k in (10, 100, 129, 300):   # (above 128: the collector runs in passes)
         hits, totals = searcher.search_phrase_batch(queries, k)
         for i, q in enumerate(queries):
             d, s, total = ix.phrase_search(q.terms, k, norms, max_doc, doc_count, sum_ttf, offsets=q.positions)
@@ -1192,7 +1192,7 @@ def test_exact_phrases(ctx, oracle, version, max_doc):
     squeries = [rucene_amd.PhraseQuery(t, o, slop=sl) for t, o, sl in sloppy]
     mixed = squeries + queries[:8]
     matched = 0
-    for k in (10, 100):
+    for k in (10, 100, 300):
         hits, totals = searcher.search_phrase_batch(mixed, k)
         for i, q in enumerate(mixed):
             d, s, total = ix.phrase_search(q.terms, k, norms, max_doc, doc_count, sum_ttf, offsets=q.positions, slop=q.slop)
