@@ -21,6 +21,12 @@ class FlatFpMap {
       if (s.key == EMPTY) return nullptr;
     }
   }
+  // Ask for the cache line a later find(key) / put(key) starts at. A table of 150 k prepared terms is 25 MB: a bulk caller (a
+  // first-touch decode of every term of a segment) that looks its keys up one after the other waits ~80 ns of DRAM latency per
+  // key; asking 16 keys ahead makes that ~10 ns.
+  void prefetch(int64_t key) const {
+    if (!slots_.empty() && key >= 0) __builtin_prefetch(&slots_[hash(key) & mask_], 0, 1);
+  }
   // key >= 0; an existing key keeps its slot and takes the new value
   void put(int64_t key, const V& value) {
     if (key < 0) return;

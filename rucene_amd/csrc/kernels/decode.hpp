@@ -417,13 +417,18 @@ __device__ __forceinline__ void decode_vint_block(const uint8_t* __restrict__ sr
 // reads) through a 512-byte window of the stream that the lanes refill together whenever the walk is about to leave it — a
 // long payload is jumped over, never read — and keeps the two deltas that are its own. `count` = total_term_freq % 128.
 constexpr int POS_TAIL_PAYLOADS = 1, POS_TAIL_OFFSETS = 2;
-__device__ __forceinline__ void decode_vint_block_everything(const uint8_t* __restrict__ src, int count, int flags, uint8_t* slab, int lane,
-                                                             uint32_t& v0, uint32_t& v1) {
+// `limit`: bytes of the file from src on (the device copy is zero-padded for 8 KB behind them). A length that leads out of
+// the file — a corrupt payload length is up to 4 GiB — ends the walk: false.
+__device__ __forceinline__ bool decode_vint_block_everything(const uint8_t* __restrict__ src, int64_t limit, int count, int flags, uint8_t* slab,
+                                                             int lane, uint32_t& v0, uint32_t& v1) {
   constexpr int WIN = 512;
   int64_t wb = 0, at = 0;  // window base and walk position, bytes from src (wave-uniform)
+  bool ok = true;
   auto refill = [&]() {
     wave_sync();
-    wb = at;
+    ok = ok && at >= 0 && at <= limit;
+    wb = ok ? at : 0;  // (a walk that left the file reads its first window again: harmless, and reported)
+    at = wb;
     if (lane < WIN / 16) *reinterpret_cast<uint4*>(slab + 16 * lane) = load16_unaligned(src + wb + 16 * lane);
     wave_sync();
   };
@@ -460,8 +465,10 @@ __device__ __forceinline__ void decode_vint_block_everything(const uint8_t* __re
     }
     v0 = i == 2 * lane ? code : v0;
     v1 = i == 2 * lane + 1 ? code : v1;
+    if (!ok) break;
   }
   wave_sync();
+  return ok && at <= limit;
 }
 
 // has_freqs == false (IndexOptions::Docs, posting_reader.rs:326-331): every value is a doc delta, every freq is 1.

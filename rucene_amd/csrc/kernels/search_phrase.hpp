@@ -92,7 +92,7 @@ __device__ __forceinline__ int phrase_doc_positions(const SegView& seg, const De
     if (fp == P.last_pos_block_fp) {
       nvals = (int)(P.total_term_freq % 128);
       if (seg.pos_tail_flags == 0) decode_vint_block(seg.pos + fp, slab, lane, x0, x1);
-      else decode_vint_block_everything(seg.pos + fp, nvals, seg.pos_tail_flags, slab, lane, x0, x1);
+      else if (!decode_vint_block_everything(seg.pos + fp, pos_len - fp, nvals, seg.pos_tail_flags, slab, lane, x0, x1)) return -4;
       fp = -2;  // nothing follows the trailing block
     } else {
       const uint32_t b = seg.pos[fp];

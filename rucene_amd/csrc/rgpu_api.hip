@@ -401,7 +401,9 @@ static int32_t prepare_terms_attempt(rgpu_segment* seg, const rgpu_term_state* c
   std::vector<std::pair<int64_t, TermInfo>> added;
   rucene::FlatFpMap<int> in_batch;
   if (n > 4096) { in_batch.reserve_more(n); work.reserve(n); added.reserve(n); }
+  constexpr size_t AHEAD = 16;  // look-ups of a bulk call are asked for this many terms ahead (flat_fp_map.hpp prefetch)
   for (size_t i = 0; i < n; ++i) {
+    if (i + AHEAD < n) { seg->prepared.prefetch(sts[i + AHEAD]->doc_start_fp); in_batch.prefetch(sts[i + AHEAD]->doc_start_fp); }
     const rgpu_term_state& st = *sts[i];
     if (st.doc_freq < 2) {  // a singleton lives in the term dictionary; everything else has blocks and / or a tail
       if (st.doc_freq < 0) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "negative doc_freq");
@@ -569,7 +571,10 @@ static int32_t prepare_terms_attempt(rgpu_segment* seg, const rgpu_term_state* c
   seg->dir_used = need_slots;
   seg->bstore_used = batch_bs + (size_t)total_rows * 16;
   seg->prepared.reserve_more(added.size());
-  for (auto& a : added) seg->prepared.put(a.first, a.second);
+  for (size_t i = 0; i < added.size(); ++i) {
+    if (i + AHEAD < added.size()) seg->prepared.prefetch(added[i + AHEAD].first);
+    seg->prepared.put(added[i].first, added[i].second);
+  }
   t_commit = hc.lap();
   if (HostClock::on())
     std::fprintf(stderr, "[prepare host] %zu terms: plan %lld us, reserve (hipMalloc / grow) %lld, plan chunks + stage + H2D %lld, enqueue %lld, kernels + sync %lld, commit %lld\n",
@@ -1012,6 +1017,7 @@ static int32_t decode_terms_impl(rgpu_segment* seg, const rgpu_term_state* terms
 #endif
   const int dec_blocks_per_item = RGPU_DEC_BPI;
   for (int64_t j = 0; j < nr; ++j) {
+    if (j + 16 < nr) seg->prepared.prefetch(terms[rest[(size_t)(j + 16)]].doc_start_fp);
     const int64_t i = rest[(size_t)j];
     rc = make_dev_term(seg, terms[i], 0.f, 0, &ht[j], false);
     if (rc != RGPU_OK) return rc;

@@ -1282,6 +1282,21 @@ def test_payload_and_offset_fields(ctx, oracle, offsets, payloads, version, max_
     for t in (0, vocab, vocab + 1):
         docs, freqs = leaf.segment.decode_terms(leaf.terms[t])
         assert docs.tolist() == [e[0] for e in postings[t]] and freqs.tolist() == [len(e[1]) for e in postings[t]]
+    # corrupt payload lengths / position codes in the woven VInt tails: an answer or RGPU_ERR_CORRUPT_INDEX, never a walk out of the file
+    if max_doc <= 6000:
+        _, pos_ok = ix.files()
+        for trial in range(6):
+            bad_pos = bytearray(pos_ok)
+            for at in rng.integers(60, len(bad_pos) - 20, size=40):
+                bad_pos[int(at)] = 0xFF if trial % 2 else int(rng.integers(0, 256))
+            bleaf = leaf_of(ix, offsets, payloads)
+            bleaf.pos_bytes = np.frombuffer(bytes(bad_pos), np.uint8)
+            bsearcher = rucene_amd.GpuIndexSearcher([bleaf], ctx=ctx)
+            try:
+                bsearcher.search_phrase_batch(queries, 10)
+            except rucene_amd.RgpuError:
+                pass
+            bleaf.segment.close()
     # the third file is checked like Lucene50PostingsReader::open checks it
     bad = bytearray(ix.pay_file())
     bad[10] ^= 0x40
