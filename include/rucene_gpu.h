@@ -497,6 +497,16 @@ int32_t rgpu_segment_attach_positions(rgpu_segment* seg, const uint8_t* pos_file
  * "Lucene50PostingsWriterPay", the .doc file's version, segment id and suffix; footer): checked as open() checks it. No
  * search needs its bytes (see rgpu_segment_upload_field), so none are kept in HBM. */
 int32_t rgpu_segment_attach_payloads(rgpu_segment* seg, const uint8_t* pay_file, size_t pay_len);
+/* BlockPostingIterator::{next, next_position} over whole terms (posting_reader.rs:1285-1324 refill_positions, :1357-1380
+ * next_position, :1400-1437 next; for a field with payloads / offsets the same iterator walks past them, :1291-1312): every
+ * position of every doc of every given term into positions_out — terms concatenated in order (total_term_freq entries each), doc
+ * after doc in doc order (rgpu_decode_terms gives the docs and the freqs that delimit them), a doc's positions ascending.
+ * The parity and micro-benchmark surface of the ".pos" stream, as rgpu_decode_terms is of ".doc". At most 2^32 positions per
+ * call. The _device variant leaves them in device memory (hip_stream NULL = the context's stream); both return synchronised. */
+int32_t rgpu_decode_positions(rgpu_segment* seg, const rgpu_term_state* terms, const rgpu_term_positions* positions, int64_t n_terms,
+                              int32_t* positions_out);
+int32_t rgpu_decode_positions_device(rgpu_segment* seg, const rgpu_term_state* terms, const rgpu_term_positions* positions, int64_t n_terms,
+                                     void* positions_dev, void* hip_stream);
 /* One term of a phrase: its postings (BlockTermState), its position-stream pointers (rgpu_terms_lookup_positions) and
  * its position inside the phrase (PhraseQuery::build numbers them 0, 1, 2, ...; query/phrase_query.rs:60-110). */
 typedef struct rgpu_phrase_term {

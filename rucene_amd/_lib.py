@@ -49,7 +49,7 @@ STATUS_NAMES = {0: "OK", -1: "IllegalState", -2: "IllegalArgument", -3: "Unexpec
 # every symbol include/rucene_gpu.h declares (tests/test_abi.py checks the header and this list agree)
 EXPORTS = [
     "rgpu_init", "rgpu_shutdown", "rgpu_last_error", "rgpu_abi_version", "rgpu_device_name", "rgpu_segment_upload",
-    "rgpu_segment_upload_field", "rgpu_segment_release_prepared_terms", "rgpu_segment_get_footprint", "rgpu_segment_attach_positions", "rgpu_segment_attach_payloads", "rgpu_search_phrase_batch", "rgpu_rescore_batch",
+    "rgpu_segment_upload_field", "rgpu_segment_release_prepared_terms", "rgpu_segment_get_footprint", "rgpu_segment_attach_positions", "rgpu_segment_attach_payloads", "rgpu_decode_positions", "rgpu_decode_positions_device", "rgpu_search_phrase_batch", "rgpu_rescore_batch",
     "rgpu_segment_free", "rgpu_segment_version", "rgpu_segment_prepare_terms", "rgpu_decode_terms",
     "rgpu_decode_terms_device", "rgpu_advance_batch", "rgpu_sim_table_upload", "rgpu_search_batch",
     "rgpu_search_batch_device", "rgpu_merge_topk_device", "rgpu_bm25_compute_weight", "rgpu_bm25_encode_norm", "rgpu_bm25_term_weights",
@@ -139,6 +139,8 @@ def lib():
         "rgpu_segment_get_footprint": (i32, [vp, vp]),
         "rgpu_segment_attach_positions": (i32, [vp, vp, C.c_size_t]),
         "rgpu_segment_attach_payloads": (i32, [vp, vp, C.c_size_t]),
+        "rgpu_decode_positions": (i32, [vp, vp, vp, C.c_int64, vp]),
+        "rgpu_decode_positions_device": (i32, [vp, vp, vp, C.c_int64, vp, vp]),
         "rgpu_search_phrase_batch": (i32, [vp, vp, i32, vp, i32, i32, vp, vp]),
         "rgpu_rescore_batch": (i32, [vp, vp, i32, vp, i32, vp, i32, vp, i32]),
         "rgpu_decode_terms": (i32, [vp, vp, i64, vp, vp]),
@@ -616,6 +618,20 @@ class Segment:
         """The segment's ".pay" file (a field uploaded with index_options 4 and / or FIELD_STORES_PAYLOADS): validated, not kept."""
         pay = np.ascontiguousarray(pay_bytes, dtype=np.uint8)
         _check(lib().rgpu_segment_attach_payloads(self._h, pay.ctypes.data, pay.size))
+
+    def decode_positions(self, states, positions):
+        """BlockPostingIterator::next_position to exhaustion: every position of every doc of the given terms (rgpu_decode_positions)."""
+        st = np.ascontiguousarray(np.atleast_1d(states), dtype=TERM_STATE_DTYPE)
+        tp = np.ascontiguousarray(np.atleast_1d(positions), dtype=TERM_POSITIONS_DTYPE)
+        assert st.size == tp.size
+        out = np.zeros(max(1, int(st["total_term_freq"][st["doc_freq"] > 0].sum())), dtype=np.int32)
+        _check(lib().rgpu_decode_positions(self._h, st.ctypes.data, tp.ctypes.data, st.size, out.ctypes.data))
+        return out[:int(st["total_term_freq"][st["doc_freq"] > 0].sum())]
+
+    def decode_positions_device(self, states, positions, positions_ptr, stream=0):
+        st = np.ascontiguousarray(np.atleast_1d(states), dtype=TERM_STATE_DTYPE)
+        tp = np.ascontiguousarray(np.atleast_1d(positions), dtype=TERM_POSITIONS_DTYPE)
+        _check(lib().rgpu_decode_positions_device(self._h, st.ctypes.data, tp.ctypes.data, st.size, positions_ptr, stream or None))
 
     def search_phrase_batch(self, queries, terms, k):
         q = np.ascontiguousarray(queries, dtype=PHRASE_QUERY_DTYPE)

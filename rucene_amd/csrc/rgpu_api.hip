@@ -22,6 +22,7 @@
 #include "kernels/prepare.hpp"
 #include "kernels/search.hpp"
 #include "kernels/search_and.hpp"
+#include "kernels/decode_positions.hpp"
 #include "kernels/search_or.hpp"
 #include "kernels/search_or_wide.hpp"
 #include "kernels/search_or_lazy.hpp"
@@ -147,6 +148,8 @@ struct rgpu_ctx {
   Scratch* S = &scr[0];
   int scr_next = 0;
   DevVec<ScoredPosting> d_runs;  // OR: per-clause {doc, score} runs (one instance: OR groups end with a stream sync)
+  DevVec<uint32_t> pos_counts;             // rgpu_decode_positions: positions per directory slot -> their exclusive prefix sums
+  DevVec<unsigned long long> pos_tiles;    // ... the scan's tile sums (+ [0]: unused, [1]: the call's total)
   DevVec<int32_t> phrase_docs;             // phrase search: the conjunctions' matches (candidates), per query
   DevVec<uint64_t> phrase_keys;            // ... and their keys (0 = phrase freq 0)
   DevVec<unsigned long long> phrase_count;  // ... how many each query's conjunction produced
@@ -717,7 +720,7 @@ extern "C" void rgpu_shutdown(rgpu_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   drain_events(c);
   for (auto e : c->free_events) (void)hipEventDestroy(e);
-  c->sim_tables.release(); for (auto& cs : c->ceil_slots) { cs.d.release(); if (cs.done) (void)hipEventDestroy(cs.done); } c->d_runs.release(); c->phrase_docs.release(); c->phrase_keys.release(); c->phrase_count.release(); c->host_api_hits.release(); c->host_api_totals.release();
+  c->sim_tables.release(); for (auto& cs : c->ceil_slots) { cs.d.release(); if (cs.done) (void)hipEventDestroy(cs.done); } c->d_runs.release(); c->pos_counts.release(); c->pos_tiles.release(); c->phrase_docs.release(); c->phrase_keys.release(); c->phrase_count.release(); c->host_api_hits.release(); c->host_api_totals.release();
   for (auto& sc : c->scr) sc.release();
   if (c->d_err) (void)hipFree(c->d_err);
   (void)hipStreamDestroy(c->stream);
@@ -2454,6 +2457,128 @@ extern "C" int32_t rgpu_segment_attach_payloads(rgpu_segment* seg, const uint8_t
   if (rc != 0) return fail(rc, why);
   seg->pay_checked = true;
   return RGPU_OK;
+}
+
+// BlockPostingIterator::{next, next_position} to exhaustion for every given term (kernels/decode_positions.hpp): ends synchronised
+static int32_t decode_positions_impl(rgpu_segment* seg, const rgpu_term_state* terms, const rgpu_term_positions* positions, int64_t n_terms,
+                                     int32_t* positions_dev, hipStream_t stream) {
+  rgpu_ctx* c = seg->ctx;
+  if (!seg->has_positions || !seg->d_pos) return fail(RGPU_ERR_ILLEGAL_STATE, "a positions decode needs a positions field with its .pos file attached");
+  std::vector<const rgpu_term_state*> ptrs;
+  int64_t expect = 0;
+  for (int64_t i = 0; i < n_terms; ++i) {
+    const rgpu_term_state& st = terms[i];
+    if (st.doc_freq < 0) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "negative doc_freq");
+    if (st.doc_freq == 0) continue;
+    if (st.total_term_freq < st.doc_freq) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "total_term_freq below doc_freq");
+    if (positions[i].pos_start_fp < 0 || (size_t)positions[i].pos_start_fp >= seg->pos_len) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "pos_start_fp outside the .pos file");
+    expect += st.total_term_freq;
+    ptrs.push_back(&st);
+  }
+  if (expect == 0) return RGPU_OK;
+  if (expect > 0xfffffff0ll) return fail(RGPU_ERR_UNSUPPORTED, "one call decodes at most 2^32 positions: split the term list");
+  int32_t rc = prepare_terms_locked(seg, ptrs.data(), ptrs.size(), false);  // stage A: directory (with dir_pos), block store, tails
+  if (rc != RGPU_OK) return rc;
+  std::vector<DevTerm> dt;
+  std::vector<PosTerm> pt;
+  std::vector<int64_t> item_prefix;
+  int64_t items = 0;
+  for (int64_t i = 0; i < n_terms; ++i) {
+    const rgpu_term_state& st = terms[i];
+    if (st.doc_freq == 0) continue;
+    DevTerm d;
+    rc = make_dev_term(seg, st, 0.f, 0, &d, false);
+    if (rc != RGPU_OK) return rc;
+    PosTerm p{};
+    p.pos_start_fp = (uint64_t)positions[i].pos_start_fp;
+    p.total_term_freq = st.total_term_freq;
+    // posting_reader.rs:1195-1203: fewer than 128 positions -> all VInts; exactly 128 -> one packed block, no trailing one
+    p.last_pos_block_fp = st.total_term_freq < 128 ? positions[i].pos_start_fp
+                          : (st.total_term_freq == 128 ? -1 : positions[i].pos_start_fp + positions[i].last_pos_block_offset);
+    dt.push_back(d);
+    pt.push_back(p);
+    item_prefix.push_back(items);
+    items += (int64_t)d.nblocks + ((d.df == 1 || d.tail_n > 0) ? 1 : 0);
+  }
+  item_prefix.push_back(items);
+  const int nt = (int)dt.size();
+  HIP_TRY(scratch_take(c));
+  Stager st(c);
+  const size_t o_t = st.add(dt.size() * sizeof(DevTerm));
+  const size_t o_pt = st.add(pt.size() * sizeof(PosTerm));
+  const size_t o_ip = st.add(item_prefix.size() * 8);
+  HIP_TRY(c->S->h_stage.reserve(st.used));
+  HIP_TRY(c->S->d_stage.reserve(st.used, 0, stream));
+  std::memcpy(c->S->h_stage.p + o_t, dt.data(), dt.size() * sizeof(DevTerm));
+  std::memcpy(c->S->h_stage.p + o_pt, pt.data(), pt.size() * sizeof(PosTerm));
+  std::memcpy(c->S->h_stage.p + o_ip, item_prefix.data(), item_prefix.size() * 8);
+  HIP_TRY(hipMemcpyAsync(c->S->d_stage.p, c->S->h_stage.p, st.used, hipMemcpyHostToDevice, stream));
+  const int64_t n_tiles = (items + SCAN_TILE - 1) / SCAN_TILE;
+  HIP_TRY(c->pos_counts.reserve((size_t)items + 64, 0, stream));
+  HIP_TRY(c->pos_tiles.reserve((size_t)n_tiles + 8, 0, stream));
+  HIP_TRY(hipMemsetAsync(c->d_err, 0, 4 * sizeof(int), stream));
+  const DevTerm* d_t = reinterpret_cast<const DevTerm*>(c->S->d_stage.p + o_t);
+  const PosTerm* d_pt = reinterpret_cast<const PosTerm*>(c->S->d_stage.p + o_pt);
+  const int64_t* d_ip = reinterpret_cast<const int64_t*>(c->S->d_stage.p + o_ip);
+  unsigned long long* d_tiles = c->pos_tiles.p + 8;
+  unsigned long long* d_total = c->pos_tiles.p + 1;
+  const SegView sv = seg_view(seg);
+  const bool legacy = seg->version < 1;
+  const unsigned grid = (unsigned)((items + WG_WAVES - 1) / WG_WAVES);
+  {
+    TimedLaunch tl(c, stream, "k_pos_counts", expect);
+    if (legacy) hipLaunchKernelGGL(k_pos_counts<true>, dim3(grid), dim3(WG_THREADS), 0, stream, sv, d_t, d_ip, nt, items, c->pos_counts.p);
+    else hipLaunchKernelGGL(k_pos_counts<false>, dim3(grid), dim3(WG_THREADS), 0, stream, sv, d_t, d_ip, nt, items, c->pos_counts.p);
+  }
+  {
+    TimedLaunch tl(c, stream, "k_scan_rows", 0);
+    hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)n_tiles), dim3(PREP_THREADS), 0, stream, c->pos_counts.p, items, d_tiles);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(PREP_THREADS), 0, stream, d_tiles, n_tiles, (unsigned long long)expect, d_total, c->d_err);
+    hipLaunchKernelGGL(k_scan_down, dim3((unsigned)n_tiles), dim3(PREP_THREADS), 0, stream, c->pos_counts.p, items, d_tiles);
+  }
+  {
+    TimedLaunch tl(c, stream, "k_decode_positions", expect);
+    if (legacy)
+      hipLaunchKernelGGL(k_decode_positions<true>, dim3(grid), dim3(WG_THREADS), 0, stream, sv, d_t, d_pt, d_ip, nt, items, c->pos_counts.p,
+                         (int64_t)seg->pos_len, positions_dev, c->d_err);
+    else
+      hipLaunchKernelGGL(k_decode_positions<false>, dim3(grid), dim3(WG_THREADS), 0, stream, sv, d_t, d_pt, d_ip, nt, items, c->pos_counts.p,
+                         (int64_t)seg->pos_len, positions_dev, c->d_err);
+  }
+  int err4[4] = {0, 0, 0, 0};
+  unsigned long long total = 0;
+  HIP_TRY(hipMemcpyAsync(err4, c->d_err, 4 * sizeof(int), hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipStreamSynchronize(stream));
+  HIP_TRY(hipGetLastError());
+  if (err4[0] != 0 || total != (unsigned long long)expect)
+    return fail(RGPU_ERR_CORRUPT_INDEX, total != (unsigned long long)expect ? "the postings' freqs do not add up to total_term_freq" : "corrupt position data in .pos");
+  return RGPU_OK;
+}
+
+extern "C" int32_t rgpu_decode_positions_device(rgpu_segment* seg, const rgpu_term_state* terms, const rgpu_term_positions* positions, int64_t n_terms,
+                                                void* positions_dev, void* hip_stream) {
+  if (!seg || !terms || !positions || n_terms <= 0 || !positions_dev) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "bad arguments");
+  std::lock_guard<std::mutex> g(seg->ctx->mu);
+  HIP_TRY(hipSetDevice(seg->ctx->device));
+  return decode_positions_impl(seg, terms, positions, n_terms, (int32_t*)positions_dev, hip_stream ? (hipStream_t)hip_stream : seg->ctx->stream);
+}
+
+extern "C" int32_t rgpu_decode_positions(rgpu_segment* seg, const rgpu_term_state* terms, const rgpu_term_positions* positions, int64_t n_terms,
+                                         int32_t* positions_out) {
+  if (!seg || !terms || !positions || n_terms <= 0 || !positions_out) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "bad arguments");
+  rgpu_ctx* c = seg->ctx;
+  std::lock_guard<std::mutex> g(c->mu);
+  HIP_TRY(hipSetDevice(c->device));
+  int64_t total = 0;
+  for (int64_t i = 0; i < n_terms; ++i) if (terms[i].doc_freq > 0) total += std::max<int64_t>(0, terms[i].total_term_freq);
+  if (total == 0) return RGPU_OK;
+  int32_t* d_pos = nullptr;
+  HIP_TRY(hipMalloc(&d_pos, (size_t)total * 4));
+  int32_t rc = decode_positions_impl(seg, terms, positions, n_terms, d_pos, c->stream);
+  if (rc == RGPU_OK && hipMemcpy(positions_out, d_pos, (size_t)total * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(RGPU_ERR_RUNTIME, "device to host copy failed");
+  (void)hipFree(d_pos);
+  return rc;
 }
 
 extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase_query* queries, int32_t n_queries,

@@ -1208,6 +1208,13 @@ def test_exact_phrases(ctx, oracle, version, max_doc):
     hits, totals = searcher.search_batch([T(0), B.build([T(1), T(2)], []), B.build([], [T(3), T(vocab + 1)])], 10)
     assert totals[0] == len(postings[0]) and totals[1] == len(set(d for d, _ in postings[1]) & set(d for d, _ in postings[2]))
     assert totals[2] == len(set(d for d, _ in postings[3]) | set(d for d, _ in postings[vocab + 1]))
+    # the ".pos" stream materialised (rgpu_decode_positions: BlockPostingIterator::next_position to exhaustion): every position of
+    # every doc of every term, the absent term included in the call — against the input, and the oracle's iterator for one term
+    got = leaf.segment.decode_positions(terms, tpos)
+    want = np.array([p for pl in postings for _, ps in pl for p in ps], dtype=np.int32)
+    assert got.size == want.size and (got == want).all()
+    one = leaf.segment.decode_positions(terms[3], tpos[3])
+    assert one.tolist() == [p for _, _, ps in ix.iterate(3) for p in ps]
 
 
 @pytest.mark.parametrize("offsets,payloads,version,max_doc", [(True, True, 1, 6000), (True, False, 1, 6000), (False, True, 1, 6000), (True, True, 0, 6000),
@@ -1282,6 +1289,12 @@ def test_payload_and_offset_fields(ctx, oracle, offsets, payloads, version, max_
     for t in (0, vocab, vocab + 1):
         docs, freqs = leaf.segment.decode_terms(leaf.terms[t])
         assert docs.tolist() == [e[0] for e in postings[t]] and freqs.tolist() == [len(e[1]) for e in postings[t]]
+    # every position of every term, decoded past the payload bytes / offset words of the woven tails — the plain field gives the same
+    got = leaf.segment.decode_positions(leaf.terms, leaf.term_positions)
+    want = np.array([p for pl in postings for e in pl for p in e[1]], dtype=np.int32)
+    assert got.size == want.size and (got == want).all()
+    pl_leaf = searcher_plain.leaves[0]
+    assert (pl_leaf.segment.decode_positions(pl_leaf.terms, pl_leaf.term_positions) == want).all()
     # corrupt payload lengths / position codes in the woven VInt tails: an answer or RGPU_ERR_CORRUPT_INDEX, never a walk out of the file
     if max_doc <= 6000:
         _, pos_ok = ix.files()
