@@ -23,7 +23,8 @@ What the line claims, and how each claim is kept honest:
     AND; for the 10-clause OR — which the reference itself sums in heap order — doc ids are judged by the oracle's own
     score of every returned doc (oracle/parity.py) and `docs_differing` is reported.
 Under "configs" (N = 1: all; N > 1: and3, i.e. BASELINE configs[4]'s workload): 3-term AND (configs[2]), 10-term OR top-100
-(configs[3]), block decode warm (prepared block store) and COLD (.doc bytes -> skip decode -> postings), and the same four
+(configs[3]), block decode warm (prepared block store) and COLD (.doc bytes -> skip decode -> postings), the positions side (SURVEY
+8(f)3: a materialising .pos decode and two-term exact phrases on the same corpus indexed with positions), and the first four
 out of the Infinity Cache on a 100M-doc shard. `--configs none` skips them.
 """
 import argparse
@@ -41,7 +42,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 SEED_QUERIES = 0x527563656E65 ^ 0x51  # "Rucene" ^ purpose tag
-ROUND = "r03"
+ROUND = "r04"
 
 
 def term_encoded_bytes(terms, doc_len_end):
@@ -125,7 +126,7 @@ def main():
     ap.add_argument("--queries", type=int, default=1024)
     ap.add_argument("--k", type=int, default=0, help="0 = the workload's own (10; 100 for or10)")
     ap.add_argument("--workload", choices=["term", "and3", "or10"], default="term")
-    ap.add_argument("--configs", default="all", help="all | none | comma list of and3,or10,block_decode,cold,out_of_cache (N > 1: and3 only)")
+    ap.add_argument("--configs", default="all", help="all | none | comma list of and3,or10,block_decode,cold,positions,out_of_cache (N > 1: and3 only)")
     ap.add_argument("--big-docs", type=int, default=100_000_000, help="size of the out-of-cache shard")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true",
@@ -487,6 +488,99 @@ def main():
         del d_docs, d_freqs
         return out
 
+    def positions_bench(docs, n_phrases, k, tag):
+        """SURVEY 8(f)3 measured: the same Zipfian postings indexed WITH positions (a posting's `freq` positions start at 0..63 and step
+        by 1..16) — (1) `positions_decode`: every position of every term with df >= 128 materialised (rgpu_decode_positions_device:
+        BlockPostingIterator::next_position to exhaustion), bytes = those terms' .pos bytes + their freq blocks' share of .doc in,
+        4 B per position out; (2) `phrase2`: `n_phrases` two-term exact PhraseQuerys, ranks log-uniform 1..1000, top-k, through
+        rgpu_search_phrase_batch (host outputs, blocking: wall time per batch), checked against the oracle's ExactPhraseScorer on
+        a sample and timed against it on one core."""
+        t0 = time.time()
+        seg = indexgen.build_zipf(docs, args.vocab, positions=True)
+        build_s = time.time() - t0
+        leaf = rucene_amd.LeafReader.from_synthetic_positions(seg)
+        searcher = rucene_amd.GpuIndexSearcher([leaf], ctx=ctx)
+        out = {"docs": docs, "doc_file_bytes": int(seg.doc_bytes.size), "pos_file_bytes": int(seg.pos_bytes.size), "index_build_s": round(build_s, 2)}
+        # ---- (1) positions decode
+        keep = seg.terms["doc_freq"] >= 128
+        sel, selp = seg.terms[keep], leaf.term_positions[keep]
+        total = int(sel["total_term_freq"].sum())
+        leaf.segment.attach_positions(leaf.pos_bytes)
+        leaf._pos_attached = True
+        d_pos = torch.empty((total,), dtype=torch.int32, device="cuda")
+        for _ in range(2):
+            leaf.segment.decode_positions_device(sel, selp, d_pos.data_ptr())
+        ctx.set_profiling(True)
+        ctx.kernel_stats_reset()
+        reps = 5
+        for _ in range(reps):
+            leaf.segment.decode_positions_device(sel, selp, d_pos.data_ptr())
+        st = ctx.kernel_stats()
+        ctx.set_profiling(False)
+        ctx.kernel_stats_reset()
+        kms = {n: st[n]["total_ms"] / reps for n in ("k_pos_counts", "k_scan_rows", "k_decode_positions") if n in st}
+        ms = sum(kms.values())
+        nxt = np.empty(seg.terms.size, dtype=np.int64)
+        nxt[:-1] = seg.pos_start_fp[1:]
+        nxt[-1] = seg.pos_bytes.size - 16
+        pos_bytes_in = int((nxt - seg.pos_start_fp)[keep].sum())
+        doc_bytes_in = int(term_encoded_bytes(seg.terms, seg.doc_bytes.size - 16)[keep].sum())
+        b = pos_bytes_in + 2 * doc_bytes_in + 4 * total   # the freq blocks are unpacked by the count pass and again by the decode pass
+        out["positions_decode"] = {"positions": total, "kernels_ms": kms, "kernels_ms_total": ms, "positions_decoded_per_sec": total / (ms * 1e-3),
+                                   "roofline": roofline("k_pos_counts + k_scan_ + k_decode_positions", ms, b, None, tag + "_posdec",
+                                                        "the terms' .pos bytes + their .doc blocks twice (count pass, decode pass) in + 4 B per position out; kernel_ms = the kernels summed")}
+        got = d_pos.cpu().numpy()
+        del d_pos
+        # ---- (2) two-term exact phrases
+        ranks = indexgen.log_uniform_ranks(2 * n_phrases, 1, 1000, SEED_QUERIES ^ 0xF2).reshape(-1, 2) - 1
+        queries = [rucene_amd.PhraseQuery([int(a), int(b2)]) for a, b2 in ranks]
+        qs, ts = searcher.pack_phrases(queries, leaf)
+        for _ in range(2):
+            hits, totals = leaf.segment.search_phrase_batch(qs, ts, k)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        steps = 5
+        for _ in range(steps):
+            hits, totals = leaf.segment.search_phrase_batch(qs, ts, k)
+        ms_step = 1e3 * (time.perf_counter() - t0) / steps
+        ctx.set_profiling(True)
+        ctx.kernel_stats_reset()
+        leaf.segment.search_phrase_batch(qs, ts, k)
+        st = ctx.kernel_stats()
+        ctx.set_profiling(False)
+        ctx.kernel_stats_reset()
+        ph = {"workload": "%d x two-term exact PhraseQuery top-%d, ranks log-uniform 1..1000, %d M docs with positions" % (n_phrases, k, docs // 1_000_000),
+              "k": k, "ms_per_step": ms_step, "queries_per_sec": n_phrases / (ms_step * 1e-3), "issue": "blocking call, host outputs",
+              "kernels_ms": {n: v["total_ms"] / max(1, v["launches"]) for n, v in st.items() if v["total_ms"] > 0},
+              "conjunction_matches_checked_per_step": int(sum(min(int(seg.terms["doc_freq"][a]), int(seg.terms["doc_freq"][b2])) for a, b2 in ranks)),
+              "phrase_hits_per_step": int(totals.sum())}
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            from oracle import binding as orc   # the checker, after the timed region
+            ix = orc.PositionsIndex.from_files(seg.doc_bytes, seg.pos_bytes, seg.terms, leaf.term_positions)
+            n_chk, ok, spent = min(n_phrases, 96), True, 0.0
+            for i in range(n_chk):
+                t0 = time.perf_counter()
+                d, sc, tot = ix.phrase_search([int(ranks[i, 0]), int(ranks[i, 1])], k, seg.norms, seg.max_doc, seg.doc_count, seg.sum_total_term_freq)
+                spent += time.perf_counter() - t0
+                ok = ok and totals[i] == tot and bool((hits[i]["doc"][:d.size] == d).all()) and bool((hits[i]["score"][:d.size].view(np.int32) == sc.view(np.int32)).all())
+            ph["parity_vs_oracle"] = bool(ok)
+            ph["parity"] = {"queries_checked": n_chk, "rule": "bit-exact doc ids, score bits and hit counts (ExactPhraseScorer)"}
+            ph["cpu_baseline"] = {"value": n_chk / spent, "unit": "queries/s", "cores": 1, "kind": "port",
+                                  "sample": "%d of the batch's queries, one after the other on one core (%.2f s); oracle = C++ restatement of PhraseWeight + ExactPhraseScorer" % (n_chk, spent)}
+            ph["gpu_over_cpu"] = ph["queries_per_sec"] / ph["cpu_baseline"]["value"]
+            # the decoded positions against the oracle's iterator for a handful of terms
+            at, okp = 0, True
+            idx = np.nonzero(keep)[0]
+            offs = np.concatenate([[0], np.cumsum(sel["total_term_freq"])])
+            for j in (4, 40, idx.size // 2, idx.size - 1):   # (lists of <= 500 k docs: the oracle's iterator is driven from Python)
+                want = np.array([p for _, _, ps in ix.iterate(int(idx[j]), cap_visits=1 << 20, cap_positions=1 << 23) for p in ps], dtype=np.int32)
+                okp = okp and bool((got[offs[j]:offs[j + 1]] == want).all())
+            out["positions_decode"]["parity_vs_oracle"] = bool(okp)
+            ix.close()
+        out["phrase2"] = ph
+        leaf.segment.close()
+        return out
+
     def strip(c):
         c.pop("_res", None)
         return c
@@ -537,7 +631,7 @@ def main():
     elif world != 1 or dist_mode:
         want = {"and3"} if args.configs == "all" else (set(args.configs.split(",")) & {"and3", "or10"})   # BASELINE configs[4]'s workload on every N
     else:
-        want = {"and3", "or10", "block_decode", "cold", "out_of_cache"} if args.configs == "all" else set(args.configs.split(","))
+        want = {"and3", "or10", "block_decode", "cold", "positions", "out_of_cache"} if args.configs == "all" else set(args.configs.split(","))
     configs = {}
     for kind in ("and3", "or10"):
         if kind not in want or kind == args.workload:
@@ -553,6 +647,8 @@ def main():
         configs["block_decode"] = d
     if "cold" in want:
         configs["cold"] = cold_bench(shard, "%s_cold" % ROUND)
+    if "positions" in want:
+        configs["positions"] = positions_bench(args.docs, nq, 10, ROUND)
     if "out_of_cache" in want:
         # a shard whose .doc alone exceeds the 256 MiB Infinity Cache: here "fraction of HBM roofline" means HBM
         del shard

@@ -132,6 +132,7 @@ def _declare(L):
         "orc_pos_index_build": (vp, [C.c_int32, C.c_int32, C.c_int32, i64p, i32p, i32p, i64p, i32p]),
         "orc_pos_index_build_ex": (vp, [C.c_int32, C.c_int32, C.c_int32, i64p, i32p, i32p, i64p, i32p, C.c_int32, i32p, i32p, i64p, u8p]),
         "orc_pos_index_pay": (C.c_int64, [vp, u8p]),
+        "orc_pos_index_from_files": (vp, [u8p, C.c_int64, u8p, C.c_int64, u8p, C.c_int64, C.c_int32, i64p, C.c_int32]),
         "orc_pos_iterate_everything": (C.c_int64, [vp, C.c_int32, C.c_int32, i32p, C.c_int64, C.c_int32, C.c_int32, i32p, i32p, i32p, C.c_int64,
                                                    i32p, i32p, i32p, i32p, C.c_int64, u8p, C.c_int64, C.POINTER(C.c_int64)]),
         "orc_pos_index_free": (None, [vp]),
@@ -905,6 +906,27 @@ class PositionsIndex:
                                            _p(self._args[7], C.c_int64), _p(self._args[8], C.c_uint8))
         if not self._h:
             raise OracleError(lib().orc_last_error().decode())
+
+    @classmethod
+    def from_files(cls, doc_bytes, pos_bytes, states, positions, pay_bytes=None, offsets=False, payloads=False):
+        """The readers over files somebody else wrote (the product's writer): states = rgpu_term_state records, positions =
+        rgpu_term_positions records (numpy structured arrays as rucene_amd hands them out)."""
+        self = cls.__new__(cls)
+        n = len(states)
+        s8 = np.zeros((n, 8), dtype=np.int64)
+        for j, k in enumerate(("doc_start_fp", "skip_offset", "total_term_freq", "doc_freq", "singleton_doc_id")):
+            s8[:, j] = states[k]
+        s8[:, 5], s8[:, 6], s8[:, 7] = positions["pos_start_fp"], positions["last_pos_block_offset"], positions["pay_start_fp"]
+        as_u8 = lambda b: np.ascontiguousarray(np.frombuffer(bytes(b), dtype=np.uint8) if isinstance(b, (bytes, bytearray)) else b, dtype=np.uint8)
+        d, p = as_u8(doc_bytes), as_u8(pos_bytes)
+        y = None if pay_bytes is None or len(pay_bytes) == 0 else as_u8(pay_bytes)
+        self.offsets, self.payloads, self.n_terms = bool(offsets), bool(payloads), n
+        self._args = (d, p, y, s8)
+        self._h = lib().orc_pos_index_from_files(_p(d, C.c_uint8), d.size, _p(p, C.c_uint8), p.size, _p(y, C.c_uint8), 0 if y is None else y.size, n,
+                                                 _p(s8, C.c_int64), (1 if offsets else 0) | (2 if payloads else 0))
+        if not self._h:
+            raise OracleError(lib().orc_last_error().decode())
+        return self
 
     def sizes(self):
         d, p = C.c_int64(0), C.c_int64(0)

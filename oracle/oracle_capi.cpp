@@ -858,6 +858,30 @@ orc_pos_index* orc_pos_index_build(int32_t max_doc, int32_t version, int32_t n_t
                                    const int32_t* freqs, const int64_t* pos_offs, const int32_t* positions) {
   return orc_pos_index_build_ex(max_doc, version, n_terms, doc_offs, docs, freqs, pos_offs, positions, 0, nullptr, nullptr, nullptr, nullptr);
 }
+// The same handle over files somebody else wrote (the product's own writer: rucene_amd/csrc/indexgen): states8[t] = doc_start_fp,
+// skip_offset, total_term_freq, doc_freq, singleton_doc_id, pos_start_fp, last_pos_block_offset, pay_start_fp. pay may be empty.
+orc_pos_index* orc_pos_index_from_files(const uint8_t* doc, int64_t doc_len, const uint8_t* pos, int64_t pos_len, const uint8_t* pay, int64_t pay_len,
+                                        int32_t n_terms, const int64_t* states8, int32_t field_flags) {
+  try {
+    auto h = std::make_unique<orc_pos_index>();
+    h->field.has_offsets = (field_flags & 1) != 0;
+    h->field.has_payloads = (field_flags & 2) != 0;
+    h->doc.assign(doc, doc + doc_len);
+    h->pos.assign(pos, pos + pos_len);
+    if (pay && pay_len > 0) h->pay.assign(pay, pay + pay_len);
+    for (int32_t t = 0; t < n_terms; t++) {
+      const int64_t* v = states8 + 8 * (int64_t)t;
+      PosTermState st;
+      st.base.doc_start_fp = v[0]; st.base.skip_offset = v[1]; st.base.total_term_freq = v[2]; st.base.doc_freq = (int32_t)v[3];
+      st.base.singleton_doc_id = (int32_t)v[4]; st.pos_start_fp = v[5]; st.last_pos_block_offset = v[6]; st.pay_start_fp = v[7];
+      h->terms.push_back(st);
+    }
+    h->reader = std::make_unique<PostingsReader>(h->doc.data(), (int64_t)h->doc.size());
+    h->pos_file = std::make_unique<PosFile>(h->pos.data(), (int64_t)h->pos.size(), h->reader->version);
+    if (!h->pay.empty()) h->pay_file = std::make_unique<PayFile>(h->pay.data(), (int64_t)h->pay.size(), h->reader->version);
+    return h.release();
+  } catch (const std::exception& e) { g_err = e.what(); return nullptr; }
+}
 void orc_pos_index_free(orc_pos_index* h) { delete h; }
 void orc_pos_index_copy(orc_pos_index* h, uint8_t* doc_out, uint8_t* pos_out) {
   std::memcpy(doc_out, h->doc.data(), h->doc.size());

@@ -481,7 +481,8 @@ typedef struct rgen_config {
   double zipf_scale;     // df(r) = clamp(round(zipf_scale * N / r), 1, N / 2), r = 1..V
   uint64_t seed;         // 0 -> 0x527563656E65 ("Rucene")
   int32_t shard;         // shard ordinal mixed into every stream (multi-GPU: one segment per shard)
-  int32_t reserved;
+  int32_t positions;     // 1: the field is indexed with positions (IndexOptions::DocsAndFreqsAndPositions): ".pos" + position pointers
+                         // in the skip entries; a posting's `freq` positions start at 0..63 and step by 1..16
 } rgen_config;
 
 // Zipfian corpus of SURVEY.md §8(d).
@@ -492,6 +493,7 @@ rgen_index* rgen_build_zipf(const rgen_config* cfg) {
   uint8_t seg_id[16];
   { SplitMix64 r(seed ^ 0x1D); for (int i = 0; i < 16; i += 8) { uint64_t x = r.next(); std::memcpy(seg_id + i, &x, 8); } }
   ix->begin(N, cfg->version, seg_id);
+  if (cfg->positions) ix->begin_positions(seg_id);
 
   // norms: doc length ~ LogNormal(ln 100, 0.5) clamped to [1, 10000] -> float_to_byte315(1/sqrt(len))
   ix->norms.resize((size_t)N);
@@ -514,7 +516,7 @@ rgen_index* rgen_build_zipf(const rgen_config* cfg) {
   }
 
   ix->terms.resize((size_t)cfg->n_terms);
-  std::vector<int32_t> docs, freqs;
+  std::vector<int32_t> docs, freqs, positions;
   for (int64_t r = 1; r <= cfg->n_terms; r++) {
     double want = std::nearbyint(cfg->zipf_scale * (double)N / (double)r);
     int64_t df_nom = (int64_t)std::min((double)(N / 2), std::max(1.0, want));
@@ -535,7 +537,23 @@ rgen_index* rgen_build_zipf(const rgen_config* cfg) {
       freqs.push_back(std::min(10, f));                  // write-time clamp, postings/mod.rs:82
     }
     if (docs.empty()) { docs.push_back((int32_t)(rng.next() % (uint64_t)N)); freqs.push_back(1); }
-    ix->terms[(size_t)(r - 1)] = ix->add_term(docs.data(), freqs.data(), (int64_t)docs.size());
+    if (cfg->positions) {
+      SplitMix64 prng(seed ^ (0x504F53ULL /* "POS" */ + (uint64_t)r * 0xD6E8FEB86659FD93ULL));
+      positions.clear();
+      for (size_t j = 0; j < docs.size(); j++) {
+        uint64_t bits = prng.next();
+        int32_t at = (int32_t)(bits & 63u);
+        bits >>= 6;
+        for (int32_t q = 0; q < freqs[j]; q++) {
+          positions.push_back(at);
+          at += 1 + (int32_t)(bits & 15u);
+          bits >>= 4;
+        }
+      }
+      ix->terms[(size_t)(r - 1)] = ix->add_term_positions(docs.data(), freqs.data(), positions.data(), (int64_t)docs.size());
+    } else {
+      ix->terms[(size_t)(r - 1)] = ix->add_term(docs.data(), freqs.data(), (int64_t)docs.size());
+    }
   }
   ix->finish();
   return ix;

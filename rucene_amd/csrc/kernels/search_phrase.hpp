@@ -127,22 +127,35 @@ __device__ __forceinline__ int phrase_doc_positions(const SegView& seg, const De
   return freq;
 }
 
+// (Round 4: a fixed launch whose wavefronts stride — or take contiguous stretches — over the CANDIDATES, 41 M of the benchmark
+// batch's 100 M slots, instead of one wavefront per slot: 112 - 117 ms against 48 for this form, same box. A wavefront that
+// works through candidate after candidate pays each one's chain of dependent loads in full; a fresh wavefront per slot lets the
+// dispatcher keep every wavefront slot of the chip on a different candidate, and an empty slot costs a nanosecond.)
 // slops (nullable): per query PhraseQuery::slop; this kernel serves the queries with slop 0 (the others: k_sloppy_match)
-template <bool LEGACY>
+// CAP: positions of one term inside one doc that the wavefront's two LDS lists hold. The kernel waits on chains of dependent loads
+// (directory search, posting block, position blocks, per term) and hides them with wavefronts: two lists of PHRASE_LIST_CAP
+// positions are 32 KB per workgroup — three wavefronts per SIMD. Nearly every doc holds a term a handful of times (Rucene
+// clamps freqs to 10 at write time), so the launch runs with PHRASE_SMALL_CAP-entry lists, eight wavefronts per SIMD; a candidate
+// that does not fit leaves PHRASE_REDO in its key and raises *redo — the host then runs the CAP = PHRASE_LIST_CAP instantiation,
+// which looks at the marked slots only (REDO_ONLY).
+constexpr int PHRASE_SMALL_CAP = 128;
+constexpr uint64_t PHRASE_REDO = 1ull;  // (no real key has a zero high word)
+template <bool LEGACY, int CAP, bool REDO_ONLY>
 __global__ __launch_bounds__(WG_THREADS) void k_phrase_match(SegView seg, const DevQuery* __restrict__ queries,
                                                              const DevTerm* __restrict__ terms, const PosTerm* __restrict__ pterms,
                                                              const int64_t* __restrict__ emit_prefix,
                                                              const unsigned long long* __restrict__ emit_count,
                                                              const int32_t* __restrict__ emit_docs, const int32_t* __restrict__ slops, int n_queries,
-                                                             int64_t n_slots, int64_t pos_len, uint64_t* __restrict__ keys_out, int* err) {
+                                                             int64_t n_slots, int64_t pos_len, uint64_t* __restrict__ keys_out, int* err, int* redo) {
   __shared__ __attribute__((aligned(16))) uint8_t slabs[WG_WAVES][SLAB_BYTES];
-  __shared__ int32_t lists_a[WG_WAVES][PHRASE_LIST_CAP];
-  __shared__ int32_t lists_c[WG_WAVES][PHRASE_LIST_CAP];
+  __shared__ int32_t lists_a[WG_WAVES][CAP];
+  __shared__ int32_t lists_c[WG_WAVES][CAP];
   __shared__ float caches[WG_WAVES][256];
   const int lane = lane_id();
   const int wave = wave_id();
   const int64_t slot = (int64_t)blockIdx.x * WG_WAVES + wave;
   if (slot >= n_slots) return;
+  if (REDO_ONLY && keys_out[slot] != PHRASE_REDO) return;
   const int q = upper_slot_wave(emit_prefix, n_queries, slot, lane);
   if (slops != nullptr && slops[q] > 0) return;
   const int64_t idx = slot - emit_prefix[q];
@@ -166,7 +179,11 @@ __global__ __launch_bounds__(WG_THREADS) void k_phrase_match(SegView seg, const 
   for (int c = 0; c < Q.n_terms; ++c) {
     const DevTerm T = terms[Q.first_term + c];
     const PosTerm P = pterms[Q.first_term + c];
-    const int freq = phrase_doc_positions<LEGACY>(seg, T, P, doc, pos_len, slab, c == 0 ? A : C, PHRASE_LIST_CAP, lane);
+    const int freq = phrase_doc_positions<LEGACY>(seg, T, P, doc, pos_len, slab, c == 0 ? A : C, CAP, lane);
+    if (freq == -5 && CAP < PHRASE_LIST_CAP) {  // does not fit the small lists: the big instantiation takes this candidate
+      if (lane == 0) { keys_out[slot] = PHRASE_REDO; atomicOr(redo, 1); }
+      return;
+    }
     if (freq < 0) { give_up(freq); return; }
     // ---- 4. keep the first term's positions that line up with this term's
     if (c == 0) {
@@ -584,6 +601,60 @@ __global__ __launch_bounds__(WG_THREADS) void k_phrase_collect(const int64_t* __
     ceil = topk_threshold<WIDE>(top, kp);  // 0 when this pass did not fill up: nothing is left for the next one
   }
   if (lane == 0) totals_out[q] = total;
+}
+
+// The same collector for k <= 128 with a query's candidates cut into chunks — one wavefront per (query, PHRASE_COLLECT_CHUNK
+// candidates), partial lists folded by k_merge_items: one wavefront walking the 2 M keys of a common pair of terms was 12 of
+// the 15 ms k_phrase_collect took on the benchmark batch. Items are planned by the host from the lead's doc_freq (an upper bound
+// of the candidates); a chunk past the query's candidate count leaves an empty list. k_phrase_cutoff applies the two-phase rule
+// of the sloppy scorer (see k_phrase_collect) beforehand: abandoned[q] = 1 empties every chunk of the query.
+constexpr int PHRASE_COLLECT_CHUNK = 8192;
+__global__ __launch_bounds__(WG_THREADS) void k_phrase_cutoff(const int64_t* __restrict__ emit_prefix, const unsigned long long* __restrict__ emit_count,
+                                                              const uint64_t* __restrict__ keys, const int32_t* __restrict__ emit_docs,
+                                                              const int32_t* __restrict__ slops, const int32_t* __restrict__ next_limits,
+                                                              int n_queries, int32_t* __restrict__ abandoned) {
+  const int lane = lane_id();
+  const int q = (int)(blockIdx.x * WG_WAVES) + wave_id();
+  if (q >= n_queries) return;
+  if (!(slops[q] > 0 && next_limits[q] >= 0)) return;
+  const int64_t base = emit_prefix[q], n = (int64_t)emit_count[q];
+  int32_t first = 0x7fffffff;
+  for (int64_t i0 = 0; i0 < n; i0 += 64) {
+    const bool hit = i0 + lane < n && keys[base + i0 + lane] != 0ull;
+    if (hit) first = min(first, emit_docs[base + i0 + lane]);
+  }
+  first = 0x7fffffff - (int32_t)wave_reduce_max_u32((uint32_t)(0x7fffffff - first));
+  int64_t before = 0;
+  for (int64_t i0 = 0; i0 < n; i0 += 64) {
+    const bool earlier = i0 + lane < n && (emit_docs[base + i0 + lane] & 0x7fffffff) < first;
+    before += __popcll(__ballot(earlier));
+  }
+  if (lane == 0 && (first == 0x7fffffff || before > (int64_t)next_limits[q])) abandoned[q] = 1;
+}
+template <bool WIDE>
+__global__ __launch_bounds__(WG_THREADS) void k_phrase_collect_items(const int64_t* __restrict__ item_prefix, const int64_t* __restrict__ emit_prefix,
+                                                                     const unsigned long long* __restrict__ emit_count, const uint64_t* __restrict__ keys,
+                                                                     const int32_t* __restrict__ abandoned, int n_queries, int64_t n_items, int k,
+                                                                     uint64_t* __restrict__ partial_keys, int32_t* __restrict__ partial_counts) {
+  const int lane = lane_id();
+  const int64_t item = (int64_t)blockIdx.x * WG_WAVES + wave_id();
+  if (item >= n_items) return;
+  const int q = upper_slot_wave(item_prefix, n_queries, item, lane);
+  const int64_t chunk = item - item_prefix[q];
+  const int64_t base = emit_prefix[q], n = abandoned[q] ? 0 : (int64_t)emit_count[q];
+  const int64_t lo = chunk * PHRASE_COLLECT_CHUNK, hi = min(n, lo + PHRASE_COLLECT_CHUNK);
+  WaveTopK top;
+  uint64_t tau = 0;
+  int count = 0;
+  for (int64_t i0 = lo; i0 < hi; i0 += 64) {
+    const uint64_t key = i0 + lane < hi ? keys[base + i0 + lane] : 0ull;
+    count += __popcll(__ballot(key != 0ull));
+    if (__ballot(key > tau)) topk_offer<WIDE>(top, key, tau, k, lane);
+  }
+  uint64_t* pk = partial_keys + (size_t)item * (size_t)k;
+  if (lane < k) pk[lane] = top.a;
+  if (WIDE && lane + 64 < k) pk[lane + 64] = top.b;
+  if (lane == 0) partial_counts[item] = count;
 }
 
 // ---- QueryRescorer (search/scorer/rescorer.rs:129-374) with a batched second-pass scorer (the BatchScorer hook, :32-36) ----

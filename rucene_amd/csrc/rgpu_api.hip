@@ -2615,8 +2615,10 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
   std::vector<DevQuery> dq((size_t)n_queries);
   std::vector<DevTerm> dt;
   std::vector<PosTerm> pt;
-  std::vector<int64_t> item_prefix((size_t)n_queries + 1), emit_prefix((size_t)n_queries + 1);
+  std::vector<int64_t> item_prefix((size_t)n_queries + 1), emit_prefix((size_t)n_queries + 1), collect_prefix((size_t)n_queries + 1);
   std::vector<int32_t> slops((size_t)n_queries, 0), limits((size_t)n_queries, -1);
+  int64_t collect_items = 0;
+  bool any_cutoff = false;
   bool any_sloppy = false, any_exact = false;
   const int blocks_per_item = c->cfg.and_blocks_per_item;
   int64_t items = 0, slots = 0;
@@ -2624,6 +2626,7 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
     const rgpu_phrase_query& Q = queries[q];
     item_prefix[(size_t)q] = items;
     emit_prefix[(size_t)q] = slots;
+    collect_prefix[(size_t)q] = collect_items;
     dq[(size_t)q] = DevQuery{RGPU_OP_AND, 0, (int32_t)dt.size(), 0};
     bool dead = false;
     for (int i = 0; i < Q.n_terms; ++i) dead = dead || terms[Q.first_term + i].state.doc_freq <= 0;
@@ -2660,9 +2663,12 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
     const DevTerm& lead = dt[(size_t)dq[(size_t)q].first_term];
     items += lead.nblocks == 0 ? 1 : (lead.nblocks + blocks_per_item - 1) / blocks_per_item;
     slots += lead.df;
+    collect_items += ((int64_t)lead.df + PHRASE_COLLECT_CHUNK - 1) / PHRASE_COLLECT_CHUNK;  // the lead's doc_freq bounds the candidates
+    any_cutoff = any_cutoff || (Q.slop > 0 && limits[(size_t)q] >= 0);
   }
   item_prefix[(size_t)n_queries] = items;
   emit_prefix[(size_t)n_queries] = slots;
+  collect_prefix[(size_t)n_queries] = collect_items;
   HIP_TRY(c->host_api_hits.reserve((size_t)n_queries * (size_t)k, 0, stream));
   HIP_TRY(c->host_api_totals.reserve((size_t)n_queries, 0, stream));
   HIP_TRY(hipMemsetAsync(c->host_api_totals.p, 0, (size_t)n_queries * 8, stream));
@@ -2678,6 +2684,8 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
     const size_t o_sl = st.add((size_t)n_queries * 4);
     const size_t o_nl = st.add((size_t)n_queries * 4);
     const size_t o_gr = st.add((size_t)n_queries * sizeof(SloppyGroups));  // written by k_sloppy_groups
+    const size_t o_cp = st.add((size_t)(n_queries + 1) * 8);                // the chunked collector's items
+    const size_t o_ab = st.add((size_t)n_queries * 4);                      // k_phrase_cutoff's flags (zeroed by the copy)
     HIP_TRY(c->S->h_stage.reserve(st.used));
     HIP_TRY(c->S->d_stage.reserve(st.used, 0, stream));
     std::memcpy(c->S->h_stage.p + o_q, dq.data(), (size_t)n_queries * sizeof(DevQuery));
@@ -2687,19 +2695,22 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
     std::memcpy(c->S->h_stage.p + o_nl, limits.data(), (size_t)n_queries * 4);
     std::memcpy(c->S->h_stage.p + o_ip, item_prefix.data(), (size_t)(n_queries + 1) * 8);
     std::memcpy(c->S->h_stage.p + o_ep, emit_prefix.data(), (size_t)(n_queries + 1) * 8);
+    std::memcpy(c->S->h_stage.p + o_cp, collect_prefix.data(), (size_t)(n_queries + 1) * 8);
+    std::memset(c->S->h_stage.p + o_ab, 0, (size_t)n_queries * 4);
     HIP_TRY(hipMemcpyAsync(c->S->d_stage.p, c->S->h_stage.p, st.used, hipMemcpyHostToDevice, stream));
     HIP_TRY(c->phrase_docs.reserve((size_t)slots + 64, 0, stream));
     HIP_TRY(c->phrase_keys.reserve((size_t)slots + 64, 0, stream));
     HIP_TRY(c->phrase_count.reserve((size_t)n_queries, 0, stream));
     HIP_TRY(hipMemsetAsync(c->phrase_count.p, 0, (size_t)n_queries * 8, stream));
     const int k_emit = std::min<int>(k, 64);  // the conjunction only emits candidates: its (empty) top-k lists are the narrow kind
-    HIP_TRY(c->S->d_partial_keys.reserve((size_t)items * (size_t)k_emit, 0, stream));
-    HIP_TRY(c->S->d_partial_counts.reserve((size_t)items, 0, stream));
+    const bool chunked = k <= RGPU_PASS_K && collect_items > 0;  // (deeper pages: the one-wavefront collector's passes)
+    HIP_TRY(c->S->d_partial_keys.reserve(std::max((size_t)items * (size_t)k_emit, chunked ? (size_t)collect_items * (size_t)k : (size_t)0), 0, stream));
+    HIP_TRY(c->S->d_partial_counts.reserve((size_t)std::max(items, chunked ? collect_items : (int64_t)0), 0, stream));
     HIP_TRY(c->S->d_tau.reserve((size_t)n_queries, 0, stream));
     HIP_TRY(c->S->d_touched.reserve((size_t)n_queries * 2, 0, stream));
     HIP_TRY(hipMemsetAsync(c->S->d_tau.p, 0, (size_t)n_queries * 8, stream));
     HIP_TRY(hipMemsetAsync(c->S->d_touched.p, 0, (size_t)n_queries * 16, stream));
-    HIP_TRY(hipMemsetAsync(c->d_err, 0, sizeof(int), stream));
+    HIP_TRY(hipMemsetAsync(c->d_err, 0, 4 * sizeof(int), stream));  // [0]: error code, [3]: "a candidate needs the wide lists"
     const DevQuery* d_q = reinterpret_cast<const DevQuery*>(c->S->d_stage.p + o_q);
     const DevTerm* d_t = reinterpret_cast<const DevTerm*>(c->S->d_stage.p + o_t);
     const PosTerm* d_pt = reinterpret_cast<const PosTerm*>(c->S->d_stage.p + o_pt);
@@ -2721,14 +2732,24 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
     const int32_t* d_nl = reinterpret_cast<const int32_t*>(c->S->d_stage.p + o_nl);
     SloppyGroups* d_gr = reinterpret_cast<SloppyGroups*>(c->S->d_stage.p + o_gr);
     if (slots > 0 && any_exact) {
-      TimedLaunch tl(c, stream, "k_phrase_match", 0);
       const unsigned grid = (unsigned)((slots + WG_WAVES - 1) / WG_WAVES);
-      if (legacy)
-        hipLaunchKernelGGL(k_phrase_match<true>, dim3(grid), dim3(WG_THREADS), 0, stream, sv, d_q, d_t, d_pt, d_ep, c->phrase_count.p,
-                           c->phrase_docs.p, d_sl, (int)n_queries, slots, (int64_t)seg->pos_len, c->phrase_keys.p, c->d_err);
-      else
-        hipLaunchKernelGGL(k_phrase_match<false>, dim3(grid), dim3(WG_THREADS), 0, stream, sv, d_q, d_t, d_pt, d_ep, c->phrase_count.p,
-                           c->phrase_docs.p, d_sl, (int)n_queries, slots, (int64_t)seg->pos_len, c->phrase_keys.p, c->d_err);
+      auto go = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(WG_THREADS), 0, stream, sv, d_q, d_t, d_pt, d_ep, c->phrase_count.p, c->phrase_docs.p, d_sl,
+                           (int)n_queries, slots, (int64_t)seg->pos_len, c->phrase_keys.p, c->d_err, c->d_err + 3);
+      };
+      {
+        TimedLaunch tl(c, stream, "k_phrase_match", 0);
+        if (legacy) go(k_phrase_match<true, PHRASE_SMALL_CAP, false>); else go(k_phrase_match<false, PHRASE_SMALL_CAP, false>);
+      }
+      // a doc that holds a term more often than the small lists hold positions (rare: Rucene clamps freqs to 10): one look at the
+      // flag, then the wide-list instantiation over the marked candidates only
+      int redo = 0;
+      HIP_TRY(hipMemcpyAsync(&redo, c->d_err + 3, sizeof(int), hipMemcpyDeviceToHost, stream));
+      HIP_TRY(hipStreamSynchronize(stream));
+      if (redo) {
+        TimedLaunch tl(c, stream, "k_phrase_match(wide lists)", 0);
+        if (legacy) go(k_phrase_match<true, PHRASE_LIST_CAP, true>); else go(k_phrase_match<false, PHRASE_LIST_CAP, true>);
+      }
     }
     if (slots > 0 && any_sloppy) {  // SloppyPhraseScorer: the repetition groups of each query's first candidate doc, then one wavefront per candidate
       {
@@ -2748,7 +2769,25 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
       };
       if (legacy) go(k_sloppy_match<true>); else go(k_sloppy_match<false>);
     }
-    {
+    if (chunked) {
+      const int64_t* d_cp = reinterpret_cast<const int64_t*>(c->S->d_stage.p + o_cp);
+      int32_t* d_ab = reinterpret_cast<int32_t*>(c->S->d_stage.p + o_ab);
+      {
+      TimedLaunch tl(c, stream, "k_phrase_collect", 0);
+      if (any_cutoff)
+        hipLaunchKernelGGL(k_phrase_cutoff, dim3((unsigned)((n_queries + WG_WAVES - 1) / WG_WAVES)), dim3(WG_THREADS), 0, stream, d_ep, c->phrase_count.p,
+                           c->phrase_keys.p, (const int32_t*)c->phrase_docs.p, d_sl, d_nl, (int)n_queries, d_ab);
+      const unsigned grid = (unsigned)((collect_items + WG_WAVES - 1) / WG_WAVES);
+      if (k > 64)
+        hipLaunchKernelGGL(k_phrase_collect_items<true>, dim3(grid), dim3(WG_THREADS), 0, stream, d_cp, d_ep, c->phrase_count.p, c->phrase_keys.p,
+                           (const int32_t*)d_ab, (int)n_queries, collect_items, (int)k, c->S->d_partial_keys.p, c->S->d_partial_counts.p);
+      else
+        hipLaunchKernelGGL(k_phrase_collect_items<false>, dim3(grid), dim3(WG_THREADS), 0, stream, d_cp, d_ep, c->phrase_count.p, c->phrase_keys.p,
+                           (const int32_t*)d_ab, (int)n_queries, collect_items, (int)k, c->S->d_partial_keys.p, c->S->d_partial_counts.p);
+      }
+      if (k > 64) launch_merge<true>(c, stream, n_queries, k, d_cp, seg->doc_base, c->host_api_hits.p, c->host_api_totals.p);
+      else launch_merge<false>(c, stream, n_queries, k, d_cp, seg->doc_base, c->host_api_hits.p, c->host_api_totals.p);
+    } else {
       TimedLaunch tl(c, stream, "k_phrase_collect", 0);
       const unsigned grid = (unsigned)((n_queries + WG_WAVES - 1) / WG_WAVES);
       if (k > 64)

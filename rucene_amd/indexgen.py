@@ -18,7 +18,7 @@ DEFAULT_SEED = 0x527563656E65  # "Rucene"
 
 class _Config(C.Structure):
     _fields_ = [("max_doc", C.c_int32), ("version", C.c_int32), ("n_terms", C.c_int64), ("zipf_scale", C.c_double),
-                ("seed", C.c_uint64), ("shard", C.c_int32), ("reserved", C.c_int32)]
+                ("seed", C.c_uint64), ("shard", C.c_int32), ("positions", C.c_int32)]
 
 
 _lib = None
@@ -103,8 +103,10 @@ class SyntheticSegment:
             raise ValueError(err)
 
 
-def build_zipf(max_doc, n_terms, zipf_scale=0.2, version=1, seed=DEFAULT_SEED, shard=0, doc_base=0):
-    cfg = _Config(max_doc, version, n_terms, zipf_scale, seed, shard, 0)
+def build_zipf(max_doc, n_terms, zipf_scale=0.2, version=1, seed=DEFAULT_SEED, shard=0, doc_base=0, positions=False):
+    """The Zipfian corpus of SURVEY.md 8(d). positions=True: the same postings as a DocsAndFreqsAndPositions field (".pos", position
+    pointers in the skip entries; a posting's `freq` positions start at 0..63 and step by 1..16)."""
+    cfg = _Config(max_doc, version, n_terms, zipf_scale, seed, shard, 1 if positions else 0)
     h = lib().rgen_build_zipf(C.byref(cfg))
     return SyntheticSegment(h, doc_base)
 

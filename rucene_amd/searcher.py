@@ -472,29 +472,35 @@ class GpuIndexSearcher:
         PhraseQuery::create_weight (phrase_query.rs:136-186): one BM25 weight from the statistics of ALL the phrase's terms."""
         per_leaf = []
         for leaf in self.leaves:
-            if leaf.pos_bytes is None:
-                raise RgpuError(-1, "phrase search needs a positions field (LeafReader.pos_bytes)")
-            if not getattr(leaf, "_pos_attached", False):
-                leaf.segment.attach_positions(leaf.pos_bytes)
-                leaf._pos_attached = True
-            qs = np.zeros(len(queries), dtype=_lib.PHRASE_QUERY_DTYPE)
-            ts = np.zeros(sum(len(q.terms) for q in queries), dtype=_lib.PHRASE_TERM_DTYPE)
-            at = 0
-            for i, q in enumerate(queries):
-                w, cache = self.similarity.compute_weight(self.collection_statistics, [self.term_statistics(t) for t in q.terms], q.boost)
-                qs[i] = (len(q.terms), at, w, self.ctx.sim_table(cache, self.similarity.k1), q.slop, self.next_limit)
-                for t, p in zip(q.terms, q.positions):
-                    sp = leaf.positions_state(t)
-                    if sp is not None:
-                        ts[at]["state"], ts[at]["positions"] = sp
-                    else:
-                        ts[at]["state"]["doc_freq"] = 0
-                    ts[at]["position"] = p
-                    at += 1
+            qs, ts = self.pack_phrases(queries, leaf)
             per_leaf.append(leaf.segment.search_phrase_batch(qs, ts, k))
         if len(per_leaf) == 1:
             return per_leaf[0]
         return self._merge_leaves(per_leaf, len(queries), k)
+
+    def pack_phrases(self, queries, leaf):
+        """PhraseQuery objects -> the rgpu_phrase_query[] / rgpu_phrase_term[] of rgpu_search_phrase_batch for one leaf (attaches the
+        leaf's .pos file on first use)."""
+        if leaf.pos_bytes is None:
+            raise RgpuError(-1, "phrase search needs a positions field (LeafReader.pos_bytes)")
+        if not getattr(leaf, "_pos_attached", False):
+            leaf.segment.attach_positions(leaf.pos_bytes)
+            leaf._pos_attached = True
+        qs = np.zeros(len(queries), dtype=_lib.PHRASE_QUERY_DTYPE)
+        ts = np.zeros(sum(len(q.terms) for q in queries), dtype=_lib.PHRASE_TERM_DTYPE)
+        at = 0
+        for i, q in enumerate(queries):
+            w, cache = self.similarity.compute_weight(self.collection_statistics, [self.term_statistics(t) for t in q.terms], q.boost)
+            qs[i] = (len(q.terms), at, w, self.ctx.sim_table(cache, self.similarity.k1), q.slop, self.next_limit)
+            for t, p in zip(q.terms, q.positions):
+                sp = leaf.positions_state(t)
+                if sp is not None:
+                    ts[at]["state"], ts[at]["positions"] = sp
+                else:
+                    ts[at]["state"]["doc_freq"] = 0
+                ts[at]["position"] = p
+                at += 1
+        return qs, ts
 
     def rescore_batch(self, hits, rescore_queries, query_weight=1.0, rescore_weight=1.0, mode=_lib.RESCORE_TOTAL, window_size=None):
         """QueryRescorer::rescore (search/scorer/rescorer.rs:376-390) for a batch: row i of `hits` (a first pass's output) is

@@ -30,5 +30,11 @@ for k, c in d.get("configs", {}).items():
         for kk in ("cold", "block_decode", "term", "and3", "or10"):
             if kk in c:
                 cfg("  big." + kk, c[kk])
+    elif k == "positions":
+        print("positions", {x: c[x] for x in ("docs", "doc_file_bytes", "pos_file_bytes", "index_build_s")})
+        cfg("  positions_decode", c["positions_decode"])
+        print("   ", {x: c["positions_decode"].get(x) for x in ("positions", "positions_decoded_per_sec", "parity_vs_oracle")})
+        cfg("  phrase2", c["phrase2"])
+        print("   ", {x: c["phrase2"].get(x) for x in ("conjunction_matches_checked_per_step", "phrase_hits_per_step", "cpu_baseline")})
     else:
         cfg(k, c)

@@ -1143,6 +1143,9 @@ def test_exact_phrases(ctx, oracle, version, max_doc):
     rng = np.random.default_rng(21 + version)
     vocab = 12
     docs = [rng.integers(0, vocab, size=int(rng.integers(1, 60))).tolist() if rng.random() < 0.9 else [] for _ in range(max_doc)]
+    # docs that hold a term more often than the phrase kernel's small position lists (128): the wide-list pass takes them
+    docs[5] = [0] * 200 + [1] * 3 + [0, 1] * 150
+    docs[4000] = [2] * 130 + [3, 2] * 70 + [2] * 300
     postings = [[] for _ in range(vocab + 3)]
     for d, toks in enumerate(docs):
         where = {}
