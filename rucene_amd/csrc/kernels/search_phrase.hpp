@@ -39,7 +39,8 @@ __device__ __forceinline__ int phrase_doc_positions(const SegView& seg, const De
   if (T.df == 1) {
     freq = T.singleton_freq;
   } else {
-    const int blk = find_block(seg.dir_last, T.dir_base, T.nblocks, doc);
+    // (a 64-ary search by the whole wavefront: two or three dependent loads where the one-lane binary search took fourteen)
+    const int blk = find_block_wave(seg.dir_last, T.dir_base, 0, T.nblocks, doc, lane);
     int32_t e0, e1;
     uint32_t g0, g1;
     bool v0 = true, v1 = true;
