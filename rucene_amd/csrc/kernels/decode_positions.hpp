@@ -78,7 +78,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_decode_positions(SegView seg, co
   const int lane = lane_id();
   const int wave = wave_id();
   const int64_t item = (int64_t)blockIdx.x * WG_WAVES + wave;
-  if (item >= n_items) return;
+  if (item >= n_items || *err != 0) return;  // (the scan flags freqs that add up to more than total_term_freq: nothing may be written then)
   const int t = upper_slot_wave(item_prefix, n_terms, item, lane);
   const DevTerm T = terms[t];
   const PosTerm P = pterms[t];
