@@ -141,21 +141,28 @@ __device__ __forceinline__ int phrase_doc_positions(const SegView& seg, const De
 // which looks at the marked slots only (REDO_ONLY).
 constexpr int PHRASE_SMALL_CAP = 128;
 constexpr uint64_t PHRASE_REDO = 1ull;  // (no real key has a zero high word)
+// bits of *redo: which later pass some candidate is waiting for
+constexpr int PHRASE_REDO_WIDE = 1;    // k_phrase_match with PHRASE_LIST_CAP lists
+constexpr int PHRASE_REDO_LANES = 2;   // k_phrase_match at all (left by k_phrase_match_lanes)
+constexpr int PHRASE_REDO_SLOPPY = 4;  // k_sloppy_match with the SLOPPY_POOL pool
 template <bool LEGACY, int CAP, bool REDO_ONLY>
 __global__ __launch_bounds__(WG_THREADS) void k_phrase_match(SegView seg, const DevQuery* __restrict__ queries,
                                                              const DevTerm* __restrict__ terms, const PosTerm* __restrict__ pterms,
                                                              const int64_t* __restrict__ emit_prefix,
                                                              const unsigned long long* __restrict__ emit_count,
                                                              const int32_t* __restrict__ emit_docs, const int32_t* __restrict__ slops, int n_queries,
-                                                             int64_t n_slots, int64_t pos_len, uint64_t* __restrict__ keys_out, int* err, int* redo) {
+                                                             int64_t n_slots, int64_t pos_len, uint64_t* __restrict__ keys_out, int* err, int* redo,
+                                                             const int64_t* __restrict__ redo_list = nullptr) {
+  // redo_list (REDO_ONLY; nullable): the n_slots slots to look at, instead of every slot of the launch
   __shared__ __attribute__((aligned(16))) uint8_t slabs[WG_WAVES][SLAB_BYTES];
   __shared__ int32_t lists_a[WG_WAVES][CAP];
   __shared__ int32_t lists_c[WG_WAVES][CAP];
   __shared__ float caches[WG_WAVES][256];
   const int lane = lane_id();
   const int wave = wave_id();
-  const int64_t slot = (int64_t)blockIdx.x * WG_WAVES + wave;
-  if (slot >= n_slots) return;
+  const int64_t work = (int64_t)blockIdx.x * WG_WAVES + wave;
+  if (work >= n_slots) return;
+  const int64_t slot = (REDO_ONLY && redo_list != nullptr) ? redo_list[work] : work;
   if (REDO_ONLY && keys_out[slot] != PHRASE_REDO) return;
   const int q = upper_slot_wave(emit_prefix, n_queries, slot, lane);
   if (slops != nullptr && slops[q] > 0) return;
@@ -182,7 +189,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_phrase_match(SegView seg, const 
     const PosTerm P = pterms[Q.first_term + c];
     const int freq = phrase_doc_positions<LEGACY>(seg, T, P, doc, pos_len, slab, c == 0 ? A : C, CAP, lane);
     if (freq == -5 && CAP < PHRASE_LIST_CAP) {  // does not fit the small lists: the big instantiation takes this candidate
-      if (lane == 0) { keys_out[slot] = PHRASE_REDO; atomicOr(redo, 1); }
+      if (lane == 0) { keys_out[slot] = PHRASE_REDO; atomicOr(redo, PHRASE_REDO_WIDE); }
       return;
     }
     if (freq < 0) { give_up(freq); return; }
@@ -219,6 +226,204 @@ __global__ __launch_bounds__(WG_THREADS) void k_phrase_match(SegView seg, const 
   if (lane == 0) keys_out[slot] = key;
 }
 
+// ---- exact phrases, 64 candidates per wavefront ------------------------------------------------------------------------------------
+// k_phrase_match above spends ~1300 instructions on ONE candidate, two thirds of them scalar (the control flow of the look-ups is
+// wave-uniform): rocprofv3 puts the kernel at the scalar issue rate, not at memory. Here a wavefront takes 64 consecutive slots of
+// one query's candidate list (the host pads every query's slots to a multiple of 64), one candidate per lane, and the scalar work is
+// shared: per term, every lane finds its doc's block by a binary search over the directory (gathers), the DISTINCT blocks among the
+// lanes are decoded once each by the whole wavefront (docs, freqs and the running sum of freqs parked in LDS; each lane of that block
+// finds its doc there), and then every lane reads its own doc's position deltas straight out of the packed position block —
+// value i of a BP128 block of width b sits at bit (i >> 2) * b of 32-bit column i & 3 (packed_simd.rs:126-163), two dword gathers.
+// Each lane keeps its lists in its own LDS column. The kernel only takes what is common: packed (non-legacy) blocks, at most
+// PHRASE_LANE_CAP positions per term and doc (Rucene clamps freqs to 10 when it writes), positions inside packed position blocks.
+// Anything else — a doc in the trailing VInt block of a term's positions, an all-equal block, more positions, a corrupt stream —
+// leaves PHRASE_REDO in the candidate's slot and raises bit 1 of *redo: k_phrase_match<.., REDO_ONLY> takes those candidates (and
+// reports the errors). Results are the same by construction: the same positions, the same intersection, the same score expression.
+constexpr int PHRASE_LANE_CAP = 10;
+constexpr int64_t PHRASE_REDO_LIST_CAP = 1 << 22;  // slots the list of left-over candidates holds (32 MB); beyond: every slot is looked at
+__device__ __forceinline__ uint32_t bp128_value_at(const uint8_t* __restrict__ payload, uint32_t b, int i) {
+  const uint32_t p = (uint32_t)(i >> 2) * b;
+  const uint8_t* at = payload + 4 * (i & 3) + 16 * (p >> 5);
+  const uint64_t win = ((uint64_t)load4_unaligned(at + 16) << 32) | load4_unaligned(at);
+  return (uint32_t)(win >> (p & 31)) & (0xffffffffu >> (32 - b));
+}
+__global__ __launch_bounds__(WG_THREADS) void k_phrase_match_lanes(SegView seg, const DevQuery* __restrict__ queries,
+                                                                   const DevTerm* __restrict__ terms, const PosTerm* __restrict__ pterms,
+                                                                   const int64_t* __restrict__ emit_prefix,
+                                                                   const unsigned long long* __restrict__ emit_count,
+                                                                   const int32_t* __restrict__ emit_docs, const int32_t* __restrict__ slops, int n_queries,
+                                                                   int64_t n_groups, int64_t pos_len, uint64_t* __restrict__ keys_out, int* redo,
+                                                                   int64_t* __restrict__ redo_list, int redo_cap, int* redo_n) {
+  // per wavefront: the block decoder's staging area, reused for the decoded block {doc, freqs before, freq} x 128; two lists
+  __shared__ __attribute__((aligned(16))) int32_t areas[WG_WAVES][384];
+  __shared__ int32_t lists[WG_WAVES][2][PHRASE_LANE_CAP * 64];
+  static_assert(sizeof(int32_t) * 384 >= 2 * SLAB_STREAM, "the staging area holds a block's doc and freq rows");
+  const int lane = lane_id();
+  const int wave = wave_id();
+  const int64_t group = (int64_t)blockIdx.x * WG_WAVES + wave;
+  if (group >= n_groups) return;
+  const int64_t slot = group * 64 + lane;
+  const int q = upper_slot_wave(emit_prefix, n_queries, group * 64, lane);
+  if (slops != nullptr && slops[q] > 0) return;
+  const int64_t idx = slot - emit_prefix[q];
+  const int64_t cnt = (int64_t)emit_count[q];
+  if (idx - lane >= cnt) return;  // nothing in these 64 slots (the collectors read the first emit_count[q] slots only)
+  int32_t doc = idx < cnt ? emit_docs[slot] : -1;
+  bool act = doc >= 0;    // (a deleted doc travels with its sign bit set: an approximation that is never checked, bulk_scorer.rs:100)
+  bool again = false;     // this candidate goes to k_phrase_match
+  const DevQuery Q = queries[q];
+  uint8_t* slab = reinterpret_cast<uint8_t*>(areas[wave]);
+  int32_t* Dd = areas[wave];
+  int32_t* Db = Dd + 128;
+  int32_t* Df = Dd + 256;
+  int32_t* A = lists[wave][0];
+  int32_t* C = lists[wave][1];
+  int n_a = 0;
+  for (int c = 0; c < Q.n_terms; ++c) {
+    if (!__ballot(act && !again)) break;
+    const DevTerm T = terms[Q.first_term + c];
+    const PosTerm P = pterms[Q.first_term + c];
+    int freq = 0, skip = 0;
+    uint32_t pofs = 0;  // of the position block the doc's block starts in, from the term's pos_start_fp
+    if (T.df == 1) {
+      freq = T.singleton_freq;
+      if (act && doc != T.singleton_doc) again = true;  // (the conjunction said the doc is here)
+    } else {
+      // ---- 1. every lane: the first directory slot whose last doc is >= its doc (slot nblocks: the tail)
+      int lo = 0, hi = T.nblocks;
+      while (__ballot(lo < hi)) {
+        const int mid = (lo + hi) >> 1;
+        const int32_t last = seg.dir_last[T.dir_base + min(mid, T.nblocks - 1)];
+        if (lo < hi) { if (last < doc) lo = mid + 1; else hi = mid; }
+      }
+      const int blk = lo;
+      // ---- 2. the distinct blocks among the lanes, decoded once each
+      uint64_t pend = __ballot(act && !again);
+      while (pend) {
+        const int b = readlane(blk, (int)__builtin_ctzll(pend));
+        const uint64_t st = seg.dir_pos[T.dir_base + b];
+        const uint32_t row = seg.dir_row[T.dir_base + b];
+        int32_t e0, e1;
+        uint32_t g0, g1;
+        if (b < T.nblocks) {
+          const uint32_t hdr = (uint32_t)seg.dir_hdr[T.dir_base + b];
+          const int32_t base = b > 0 ? seg.dir_last[T.dir_base + b - 1] : 0;
+          const BlockPair bp = decode_block<false>(seg.bstore + T.bs_base, row, hdr, slab, lane);
+          deltas_to_docs(bp.d0, bp.d1, base, e0, e1);
+          g0 = bp.f0; g1 = bp.f1;
+        } else if (T.tail_n > 0) {
+          tail_load(seg.bstore + T.bs_base, row, lane, e0, e1, g0, g1);  // (INT_MAX / 0 past the tail's end)
+        } else {
+          e0 = e1 = 0x7fffffff; g0 = g1 = 0u;
+        }
+        const int pair = (int)(g0 + g1);
+        const int excl = wave_incl_scan(pair) - pair;
+        Dd[2 * lane] = e0; Dd[2 * lane + 1] = e1;
+        Db[2 * lane] = excl; Db[2 * lane + 1] = excl + (int)g0;
+        Df[2 * lane] = (int32_t)g0; Df[2 * lane + 1] = (int32_t)g1;
+        wave_sync();
+        const bool mine = act && !again && blk == b;
+        if (mine) {
+          int at = 0;  // the first of the block's 128 docs that is >= doc
+#pragma unroll
+          for (int step = 64; step >= 1; step >>= 1) at += Dd[at + step - 1] < doc ? step : 0;
+          if (Dd[at] != doc) {
+            again = true;  // (the conjunction said the doc is here)
+          } else {
+            freq = Df[at];
+            skip = (int)(st >> 32) + Db[at];
+            pofs = (uint32_t)st;
+          }
+        }
+        pend &= ~__ballot(blk == b);
+        wave_sync();  // the area is rewritten by the next block
+      }
+    }
+    bool live = act && !again;
+    if (live && (freq <= 0 || freq > PHRASE_LANE_CAP)) { again = true; live = false; }
+    // ---- 3. the doc's positions: `freq` deltas from value `skip` of the position stream at pofs on
+    int32_t* Lc = c == 0 ? A : C;
+    if (live) {
+      int64_t fp = (int64_t)P.pos_start_fp + (int64_t)pofs;
+      uint32_t b0 = 0, b1 = 0;
+      // a packed position block at `at`: its header byte (1..32); 0 = not one (the trailing VInt block, an all-equal block, the end)
+      auto packed_at = [&](int64_t at) -> uint32_t {
+        if (at < 0 || at + 2 > pos_len || at == P.last_pos_block_fp) return 0u;
+        const uint32_t b = seg.pos[at];
+        return b <= 32u ? b : 0u;
+      };
+      b0 = packed_at(fp);
+      while (b0 != 0u && skip >= 128) {  // whole blocks of earlier docs' positions (ForUtil::skip_block, for_util.rs:263-272)
+        fp += 1 + 16 * (int64_t)b0;
+        skip -= 128;
+        b0 = packed_at(fp);
+      }
+      const int64_t fp1 = fp + 1 + 16 * (int64_t)b0;  // the block behind: a doc's <= 10 positions straddle at most one boundary
+      const bool straddles = skip + freq > 128;
+      if (b0 != 0u && straddles) b1 = packed_at(fp1);
+      if (b0 == 0u || (straddles && b1 == 0u)) {
+        again = true;
+        live = false;
+      } else {
+        uint32_t dl[PHRASE_LANE_CAP];
+#pragma unroll
+        for (int j = 0; j < PHRASE_LANE_CAP; ++j) {
+          const int i = skip + j;
+          dl[j] = 0u;
+          if (j < freq) dl[j] = i < 128 ? bp128_value_at(seg.pos + fp + 1, b0, i) : bp128_value_at(seg.pos + fp1 + 1, b1, i - 128);
+        }
+        int32_t at_pos = -P.phrase_pos;  // (position - phrase offset; the doc's first delta is its first position)
+#pragma unroll
+        for (int j = 0; j < PHRASE_LANE_CAP; ++j) {
+          at_pos += (int32_t)dl[j];
+          if (j < freq) Lc[j * 64 + lane] = at_pos;
+        }
+      }
+    }
+    // ---- 4. keep the first term's positions that line up with this term's (every lane reads and writes its own column only)
+    if (c == 0) {
+      n_a = live ? freq : 0;
+    } else if (live) {
+      int alive = 0;
+      for (int i = 0; i < n_a; ++i) {
+        const int32_t a = A[i * 64 + lane];
+        if (a == PHRASE_DEAD) continue;
+        bool found = false;
+        for (int j = 0; j < freq; ++j) found = found || C[j * 64 + lane] == a;
+        if (found) ++alive; else A[i * 64 + lane] = PHRASE_DEAD;
+      }
+      if (alive == 0) act = false;  // no position of the first term lines up any more: phrase freq 0, key 0
+    }
+  }
+  uint64_t key = 0ull;
+  if (act && !again) {
+    int phrase_freq = 0;
+    for (int i = 0; i < n_a; ++i) phrase_freq += A[i * 64 + lane] != PHRASE_DEAD ? 1 : 0;
+    if (phrase_freq > 0) {
+      const DevTerm T0 = terms[Q.first_term];
+      const float* table = seg.sim_tables + (size_t)T0.sim_table * 257;
+      const float k1 = table[256];
+      float nrm = k1;
+      if (seg.norms != nullptr) {
+        const uint32_t nb = seg.norms[doc];
+        nrm = table[seg.n_norm_ranks > 0 ? (uint32_t)seg.rank_to_norm[nb] : nb];
+      }
+      key = make_key(bm25_score(T0.weight * (k1 + 1.0f), (float)phrase_freq, nrm), doc);
+    }
+  }
+  if (again) key = PHRASE_REDO;
+  keys_out[slot] = key;
+  // the slots left for k_phrase_match, listed (that pass then costs what they cost, not a wavefront per slot of the launch);
+  // a list that overflows is ignored by the host: *redo_n says so
+  const uint64_t m = __ballot(again);
+  if (m) {
+    int at = 0;
+    if (lane == 0) { atomicOr(redo, PHRASE_REDO_LANES); at = atomicAdd(redo_n, (int)__popcll(m)); }
+    at = readlane(at, 0) + (int)mbcnt(m);
+    if (again && at < redo_cap) redo_list[at] = slot;
+  }
+}
+
 // ---- SloppyPhraseScorer (scorer/phrase_scorer.rs:432-1071; PhraseQuery with slop > 0) ------------------------------------------
 // The reference scores a candidate doc by walking its PhrasePositions (one per phrase term, position = term position -
 // phrase offset) through a priority queue on (position, offset, ord): the least one is advanced, and every time it passes
@@ -234,6 +439,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_phrase_match(SegView seg, const 
 // repeating pps whose first positions coincide there): k_sloppy_groups does exactly that, once per query, on the query's
 // smallest candidate doc.
 constexpr int SLOPPY_POOL = 2048;  // positions of all the phrase's terms inside one doc that the LDS pool holds
+constexpr int SLOPPY_SMALL_POOL = 256;  // ... in the first launch (k_sloppy_match<.., POOL, REDO_ONLY>)
 constexpr int SLOPPY_MAX_TERMS = 16;
 
 struct SloppyGroups {  // per query: PhrasePositions::{rpt_group, rpt_ind} by query-order index; -1 = not a repeater
@@ -318,21 +524,24 @@ __global__ __launch_bounds__(WG_THREADS) void k_sloppy_groups(SegView seg, const
   if (lane == 0) groups[q] = G;
 }
 
-template <bool LEGACY>
+// POOL / REDO_ONLY: as k_phrase_match's CAP — the launch runs with SLOPPY_SMALL_POOL positions per wavefront (seven wavefronts per
+// SIMD instead of three); a doc whose terms hold more leaves PHRASE_REDO and the POOL = SLOPPY_POOL instantiation takes it.
+template <bool LEGACY, int POOL, bool REDO_ONLY>
 __global__ __launch_bounds__(WG_THREADS) void k_sloppy_match(SegView seg, const DevQuery* __restrict__ queries,
                                                              const DevTerm* __restrict__ terms, const PosTerm* __restrict__ pterms,
                                                              const int64_t* __restrict__ emit_prefix,
                                                              const unsigned long long* __restrict__ emit_count,
                                                              const int32_t* __restrict__ emit_docs, const int32_t* __restrict__ slops,
                                                              const SloppyGroups* __restrict__ groups, int n_queries, int64_t n_slots,
-                                                             int64_t pos_len, uint64_t* __restrict__ keys_out, int* err) {
+                                                             int64_t pos_len, uint64_t* __restrict__ keys_out, int* err, int* redo) {
   __shared__ __attribute__((aligned(16))) uint8_t slabs[WG_WAVES][SLAB_BYTES];
-  __shared__ int32_t pools[WG_WAVES][SLOPPY_POOL];
+  __shared__ int32_t pools[WG_WAVES][POOL];
   __shared__ float caches[WG_WAVES][256];
   const int lane = lane_id();
   const int wave = wave_id();
   const int64_t slot = (int64_t)blockIdx.x * WG_WAVES + wave;
   if (slot >= n_slots) return;
+  if (REDO_ONLY && keys_out[slot] != PHRASE_REDO) return;
   const int q = upper_slot_wave(emit_prefix, n_queries, slot, lane);
   const int slop = slops[q];
   if (slop <= 0) return;  // an exact phrase: k_phrase_match's
@@ -358,7 +567,11 @@ __global__ __launch_bounds__(WG_THREADS) void k_sloppy_match(SegView seg, const 
   for (int c = 0; c < n; ++c) {
     const DevTerm T = terms[Q.first_term + c];
     const PosTerm P = pterms[Q.first_term + c];
-    const int freq = phrase_doc_positions<LEGACY>(seg, T, P, doc, pos_len, slabs[wave], pool + used, SLOPPY_POOL - used, lane);
+    const int freq = phrase_doc_positions<LEGACY>(seg, T, P, doc, pos_len, slabs[wave], pool + used, POOL - used, lane);
+    if (freq == -5 && POOL < SLOPPY_POOL) {  // does not fit the small pool: the big instantiation takes this candidate
+      if (lane == 0) { keys_out[slot] = PHRASE_REDO; atomicOr(redo, PHRASE_REDO_SLOPPY); }
+      return;
+    }
     if (freq < 0) { give_up(freq); return; }
     if (lane == P.query_ord) { s_off = P.phrase_pos; s_start = used; s_n = freq; }
     used += freq;

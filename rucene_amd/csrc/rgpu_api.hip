@@ -152,6 +152,7 @@ struct rgpu_ctx {
   DevVec<unsigned long long> pos_tiles;    // ... the scan's tile sums (+ [0]: unused, [1]: the call's total)
   DevVec<int32_t> phrase_docs;             // phrase search: the conjunctions' matches (candidates), per query
   DevVec<uint64_t> phrase_keys;            // ... and their keys (0 = phrase freq 0)
+  DevVec<int64_t> phrase_redo;             // ... and the slots the 64-candidate kernel left for the one-candidate kernel (PHRASE_REDO_LIST_CAP)
   DevVec<unsigned long long> phrase_count;  // ... how many each query's conjunction produced
   DevVec<HitOut> host_api_hits;  // rgpu_search_batch (blocking, host outputs): device-side result rows
   DevVec<int64_t> host_api_totals;
@@ -720,7 +721,7 @@ extern "C" void rgpu_shutdown(rgpu_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   drain_events(c);
   for (auto e : c->free_events) (void)hipEventDestroy(e);
-  c->sim_tables.release(); for (auto& cs : c->ceil_slots) { cs.d.release(); if (cs.done) (void)hipEventDestroy(cs.done); } c->d_runs.release(); c->pos_counts.release(); c->pos_tiles.release(); c->phrase_docs.release(); c->phrase_keys.release(); c->phrase_count.release(); c->host_api_hits.release(); c->host_api_totals.release();
+  c->sim_tables.release(); for (auto& cs : c->ceil_slots) { cs.d.release(); if (cs.done) (void)hipEventDestroy(cs.done); } c->d_runs.release(); c->pos_counts.release(); c->pos_tiles.release(); c->phrase_docs.release(); c->phrase_keys.release(); c->phrase_redo.release(); c->phrase_count.release(); c->host_api_hits.release(); c->host_api_totals.release();
   for (auto& sc : c->scr) sc.release();
   if (c->d_err) (void)hipFree(c->d_err);
   (void)hipStreamDestroy(c->stream);
@@ -2662,7 +2663,7 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
     dq[(size_t)q].n_terms = Q.n_terms;
     const DevTerm& lead = dt[(size_t)dq[(size_t)q].first_term];
     items += lead.nblocks == 0 ? 1 : (lead.nblocks + blocks_per_item - 1) / blocks_per_item;
-    slots += lead.df;
+    slots += ((int64_t)lead.df + 63) & ~(int64_t)63;  // (k_phrase_match_lanes: the 64 slots of a wavefront belong to one query)
     collect_items += ((int64_t)lead.df + PHRASE_COLLECT_CHUNK - 1) / PHRASE_COLLECT_CHUNK;  // the lead's doc_freq bounds the candidates
     any_cutoff = any_cutoff || (Q.slop > 0 && limits[(size_t)q] >= 0);
   }
@@ -2700,6 +2701,7 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
     HIP_TRY(hipMemcpyAsync(c->S->d_stage.p, c->S->h_stage.p, st.used, hipMemcpyHostToDevice, stream));
     HIP_TRY(c->phrase_docs.reserve((size_t)slots + 64, 0, stream));
     HIP_TRY(c->phrase_keys.reserve((size_t)slots + 64, 0, stream));
+    HIP_TRY(c->phrase_redo.reserve((size_t)std::min<int64_t>(slots, PHRASE_REDO_LIST_CAP) + 64, 0, stream));
     HIP_TRY(c->phrase_count.reserve((size_t)n_queries, 0, stream));
     HIP_TRY(hipMemsetAsync(c->phrase_count.p, 0, (size_t)n_queries * 8, stream));
     const int k_emit = std::min<int>(k, 64);  // the conjunction only emits candidates: its (empty) top-k lists are the narrow kind
@@ -2731,43 +2733,81 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
     const int32_t* d_sl = reinterpret_cast<const int32_t*>(c->S->d_stage.p + o_sl);
     const int32_t* d_nl = reinterpret_cast<const int32_t*>(c->S->d_stage.p + o_nl);
     SloppyGroups* d_gr = reinterpret_cast<SloppyGroups*>(c->S->d_stage.p + o_gr);
-    if (slots > 0 && any_exact) {
+    if (slots > 0) {
+      // One wavefront per candidate slot, first with the small position lists / pools (seven wavefronts per SIMD). A doc that holds
+      // a term more often than those hold positions (rare: Rucene clamps freqs to 10) leaves PHRASE_REDO in its slot: one look at
+      // the flag, then the wide instantiations over the marked candidates only.
       const unsigned grid = (unsigned)((slots + WG_WAVES - 1) / WG_WAVES);
-      auto go = [&](auto kern) {
+      auto exact = [&](auto kern) {
         hipLaunchKernelGGL(kern, dim3(grid), dim3(WG_THREADS), 0, stream, sv, d_q, d_t, d_pt, d_ep, c->phrase_count.p, c->phrase_docs.p, d_sl,
+                           (int)n_queries, slots, (int64_t)seg->pos_len, c->phrase_keys.p, c->d_err, c->d_err + 3, (const int64_t*)nullptr);
+      };
+      auto sloppy = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(WG_THREADS), 0, stream, sv, d_q, d_t, d_pt, d_ep, c->phrase_count.p, c->phrase_docs.p, d_sl, d_gr,
                            (int)n_queries, slots, (int64_t)seg->pos_len, c->phrase_keys.p, c->d_err, c->d_err + 3);
       };
-      {
-        TimedLaunch tl(c, stream, "k_phrase_match", 0);
-        if (legacy) go(k_phrase_match<true, PHRASE_SMALL_CAP, false>); else go(k_phrase_match<false, PHRASE_SMALL_CAP, false>);
+      if (any_exact) {
+        if (legacy) {  // (.doc version 0: the packed streams of a block are laid out differently — one candidate per wavefront)
+          TimedLaunch tl(c, stream, "k_phrase_match", 0);
+          exact(k_phrase_match<true, PHRASE_SMALL_CAP, false>);
+        } else {
+          TimedLaunch tl(c, stream, "k_phrase_match_lanes", 0);
+          const int64_t groups = slots / 64;
+          hipLaunchKernelGGL(k_phrase_match_lanes, dim3((unsigned)((groups + WG_WAVES - 1) / WG_WAVES)), dim3(WG_THREADS), 0, stream, sv, d_q, d_t, d_pt,
+                             d_ep, c->phrase_count.p, c->phrase_docs.p, d_sl, (int)n_queries, groups, (int64_t)seg->pos_len, c->phrase_keys.p,
+                             c->d_err + 3, c->phrase_redo.p, (int)std::min<int64_t>(slots, PHRASE_REDO_LIST_CAP), c->d_err + 2);
+        }
       }
-      // a doc that holds a term more often than the small lists hold positions (rare: Rucene clamps freqs to 10): one look at the
-      // flag, then the wide-list instantiation over the marked candidates only
-      int redo = 0;
-      HIP_TRY(hipMemcpyAsync(&redo, c->d_err + 3, sizeof(int), hipMemcpyDeviceToHost, stream));
-      HIP_TRY(hipStreamSynchronize(stream));
-      if (redo) {
-        TimedLaunch tl(c, stream, "k_phrase_match(wide lists)", 0);
-        if (legacy) go(k_phrase_match<true, PHRASE_LIST_CAP, true>); else go(k_phrase_match<false, PHRASE_LIST_CAP, true>);
+      if (any_sloppy) {  // SloppyPhraseScorer: the repetition groups of each query's first candidate doc, then the candidates
+        {
+          TimedLaunch tl(c, stream, "k_sloppy_groups", 0);
+          const unsigned ggrid = (unsigned)((n_queries + WG_WAVES - 1) / WG_WAVES);
+          auto go = [&](auto kern) {
+            hipLaunchKernelGGL(kern, dim3(ggrid), dim3(WG_THREADS), 0, stream, sv, d_q, d_t, d_pt, d_ep, c->phrase_count.p, c->phrase_docs.p, d_sl,
+                               (int)n_queries, (int64_t)seg->pos_len, d_gr, c->d_err);
+          };
+          if (legacy) go(k_sloppy_groups<true>); else go(k_sloppy_groups<false>);
+        }
+        TimedLaunch tl(c, stream, "k_sloppy_match", 0);
+        if (legacy) sloppy(k_sloppy_match<true, SLOPPY_SMALL_POOL, false>); else sloppy(k_sloppy_match<false, SLOPPY_SMALL_POOL, false>);
       }
-    }
-    if (slots > 0 && any_sloppy) {  // SloppyPhraseScorer: the repetition groups of each query's first candidate doc, then one wavefront per candidate
-      {
-        TimedLaunch tl(c, stream, "k_sloppy_groups", 0);
-        const unsigned grid = (unsigned)((n_queries + WG_WAVES - 1) / WG_WAVES);
-        auto go = [&](auto kern) {
-          hipLaunchKernelGGL(kern, dim3(grid), dim3(WG_THREADS), 0, stream, sv, d_q, d_t, d_pt, d_ep, c->phrase_count.p, c->phrase_docs.p, d_sl,
-                             (int)n_queries, (int64_t)seg->pos_len, d_gr, c->d_err);
-        };
-        if (legacy) go(k_sloppy_groups<true>); else go(k_sloppy_groups<false>);
-      }
-      TimedLaunch tl(c, stream, "k_sloppy_match", 0);
-      const unsigned grid = (unsigned)((slots + WG_WAVES - 1) / WG_WAVES);
-      auto go = [&](auto kern) {
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(WG_THREADS), 0, stream, sv, d_q, d_t, d_pt, d_ep, c->phrase_count.p, c->phrase_docs.p, d_sl, d_gr,
-                           (int)n_queries, slots, (int64_t)seg->pos_len, c->phrase_keys.p, c->d_err);
+      // which candidates wait for a wider pass (bits PHRASE_REDO_*): one look per stage that can raise one
+      int listed = 0, redo = 0;  // d_err[2]: slots on the redo list, d_err[3]: the bits
+      auto redo_bits = [&]() -> int32_t {
+        int two[2] = {0, 0};
+        HIP_TRY(hipMemcpyAsync(two, c->d_err + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        listed = two[0];
+        redo = two[1];
+        return RGPU_OK;
       };
-      if (legacy) go(k_sloppy_match<true>); else go(k_sloppy_match<false>);
+      rc = redo_bits();
+      if (rc != RGPU_OK) return rc;
+      // the one-candidate kernel over the listed slots (or, should the list have overflowed, over every slot)
+      const bool by_list = (redo & PHRASE_REDO_LANES) && (int64_t)listed <= std::min<int64_t>(slots, PHRASE_REDO_LIST_CAP);
+      auto exact_redo = [&](auto kern) {
+        const int64_t n = by_list ? (int64_t)listed : slots;
+        hipLaunchKernelGGL(kern, dim3((unsigned)((n + WG_WAVES - 1) / WG_WAVES)), dim3(WG_THREADS), 0, stream, sv, d_q, d_t, d_pt, d_ep, c->phrase_count.p,
+                           c->phrase_docs.p, d_sl, (int)n_queries, n, (int64_t)seg->pos_len, c->phrase_keys.p, c->d_err, c->d_err + 3,
+                           by_list ? (const int64_t*)c->phrase_redo.p : (const int64_t*)nullptr);
+      };
+      if (redo & PHRASE_REDO_LANES) {
+        if (HostClock::on()) std::fprintf(stderr, "[phrase] %d of %lld candidate slots left for k_phrase_match\n", listed, (long long)slots);
+        {
+          TimedLaunch tl(c, stream, "k_phrase_match(left by the 64-candidate kernel)", 0);
+          exact_redo(k_phrase_match<false, PHRASE_SMALL_CAP, true>);
+        }
+        rc = redo_bits();
+        if (rc != RGPU_OK) return rc;
+      }
+      if (redo & PHRASE_REDO_WIDE) {
+        TimedLaunch tl(c, stream, "k_phrase_match(wide lists)", 0);
+        if (legacy) exact_redo(k_phrase_match<true, PHRASE_LIST_CAP, true>); else exact_redo(k_phrase_match<false, PHRASE_LIST_CAP, true>);
+      }
+      if (redo & PHRASE_REDO_SLOPPY) {
+        TimedLaunch tl(c, stream, "k_sloppy_match(wide pool)", 0);
+        if (legacy) sloppy(k_sloppy_match<true, SLOPPY_POOL, true>); else sloppy(k_sloppy_match<false, SLOPPY_POOL, true>);
+      }
     }
     if (chunked) {
       const int64_t* d_cp = reinterpret_cast<const int64_t*>(c->S->d_stage.p + o_cp);

@@ -1155,6 +1155,16 @@ def test_exact_phrases(ctx, oracle, version, max_doc):
             postings[t].append((d, ps))
     postings[vocab] = [(17, [3, 4, 900])]                                 # a singleton
     postings[vocab + 1] = [(d, [0]) for d in range(5, 5 + 3 * 100, 3)]     # a short list (VInt tail only), 100 positions in all
+    # two lumpy lists (every doc of the front / back fifth of the segment, one doc in 50 elsewhere): the phrase kernels' first look
+    # for a doc's block — where an evenly spread list would have it — lands far off on either side (find_block_near's two searches)
+    front, back = len(postings), len(postings) + 1
+    postings.append([(d, [d % 7, d % 7 + 3]) for d in range(max_doc) if d < max_doc // 5 or d % 50 == 0])
+    postings.append([(d, [d % 7 + 1]) for d in range(max_doc) if d >= max_doc - max_doc // 5 or d % 50 == 1 or d % 100 == 0])
+    # thirty positions a doc, wide deltas: a posting block's last docs start some thirty position blocks (3 KB of .pos) behind the
+    # place the block's skip entry names — the kernels' window over the position stream (PosWindow, 1 KB) is refilled on the way
+    heavy, heavy2 = len(postings), len(postings) + 1
+    postings.append([(d, [3 * j * j + d % 5 for j in range(30)]) for d in range(2000, 2700)])
+    postings.append([(d, [3 * j * j + d % 5 + 1 for j in range(0, 30, 2)]) for d in range(1990, 2650, 2)])
     ix = oracle.PositionsIndex(max_doc, postings, version=version)      # postings[vocab + 2] never occurs
     doc_bytes, pos_bytes = ix.files()
     n = len(postings)
@@ -1172,7 +1182,8 @@ def test_exact_phrases(ctx, oracle, version, max_doc):
     leaf.pos_bytes, leaf.term_positions = np.frombuffer(pos_bytes, np.uint8), tpos
     searcher = rucene_amd.GpuIndexSearcher([leaf], ctx=ctx)
     phrases = [[0, 1], [1, 0], [3, 3], [2, 2, 2], [4, 5, 6], [7, 7, 8, 7], [0, 1, 2, 3], [9, 10, 11, 0, 1], [5, vocab + 2], [vocab + 2, 5],
-               [vocab, 3], [vocab + 1, 0], [0, vocab + 1]]
+               [vocab, 3], [vocab + 1, 0], [0, vocab + 1], [front, back], [back, front], [front, 0], [1, back], [back, 2, front],
+               [heavy, heavy2], [heavy2, heavy], [heavy, front], [heavy, heavy]]
     phrases += [rng.integers(0, vocab, size=int(rng.integers(2, 5))).tolist() for _ in range(30)]
     gapped = [([0, 1], [0, 2]), ([3, 4, 5], [0, 1, 3]), ([2, 2], [0, 5])]
     queries = [rucene_amd.PhraseQuery(p) for p in phrases] + [rucene_amd.PhraseQuery(t, o) for t, o in gapped]
@@ -1189,7 +1200,8 @@ def test_exact_phrases(ctx, oracle, version, max_doc):
     # queries share a batch.
     sloppy = [([0, 1], None, 1), ([0, 1], None, 2), ([1, 0], None, 5), ([4, 5, 6], None, 2), ([0, 1, 2, 3], None, 5), ([3, 3], None, 1), ([2, 2, 2], None, 5),
               ([7, 7, 8, 7], None, 2), ([0, 1, 0], None, 1), ([0, 1, 0, 1], None, 5), ([5, 6, 5], [0, 1, 4], 2), ([9, 10, 11, 0, 1], None, 12),
-              ([5, vocab + 2], None, 3), ([vocab, 3], None, 2), ([vocab + 1, 0], None, 1), ([1, 0, 1, 2, 1], None, 5), ([3, 4, 5], [0, 1, 3], 1)]
+              ([5, vocab + 2], None, 3), ([vocab, 3], None, 2), ([vocab + 1, 0], None, 1), ([1, 0, 1, 2, 1], None, 5), ([3, 4, 5], [0, 1, 3], 1),
+              ([front, back], None, 2), ([back, front], None, 3), ([back, 2, front], None, 6), ([heavy, heavy2], None, 1), ([heavy2, heavy], None, 4)]
     sloppy += [(rng.integers(0, vocab, size=int(rng.integers(2, 5))).tolist(), None, int(rng.integers(1, 7))) for _ in range(30)]
     sloppy += [(rng.integers(0, 4, size=int(rng.integers(2, 6))).tolist(), None, int(rng.integers(1, 9))) for _ in range(30)]   # few distinct terms: repeats galore
     squeries = [rucene_amd.PhraseQuery(t, o, slop=sl) for t, o, sl in sloppy]
