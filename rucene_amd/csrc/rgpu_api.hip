@@ -2613,6 +2613,21 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
   }
   int32_t rc = prepare_terms_locked(seg, ptrs.data(), ptrs.size());
   if (rc != RGPU_OK) return rc;
+  // the conjunction that finds a phrase's candidates answers a dense clause from its doc bitmap, as a BooleanQuery's does
+  const int64_t bitmap_df = (c->cfg.and_bitmaps >= 0 && c->n_sim_tables > 0) ? bitmap_min_df_and(seg) : INT64_MAX;
+  if (bitmap_df != INT64_MAX) {
+    std::vector<const rgpu_term_state*> dense;
+    std::vector<int32_t> dense_sim;
+    for (int32_t q = 0; q < n_queries; ++q) {
+      const rgpu_phrase_query& Q = queries[q];
+      if (Q.n_terms < 2) continue;
+      for (int i = 0; i < Q.n_terms; ++i) {
+        const rgpu_term_state& st = terms[Q.first_term + i].state;
+        if (st.doc_freq >= bitmap_df && !seg->bitmaps.find(st.doc_start_fp)) { dense.push_back(&st); dense_sim.push_back(Q.sim_table); }
+      }
+    }
+    if (!dense.empty()) { rc = ensure_bitmaps_locked(seg, dense.data(), dense_sim.data(), dense.size()); if (rc != RGPU_OK) return rc; }
+  }
   std::vector<DevQuery> dq((size_t)n_queries);
   std::vector<DevTerm> dt;
   std::vector<PosTerm> pt;
@@ -2687,6 +2702,23 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
     const size_t o_gr = st.add((size_t)n_queries * sizeof(SloppyGroups));  // written by k_sloppy_groups
     const size_t o_cp = st.add((size_t)(n_queries + 1) * 8);                // the chunked collector's items
     const size_t o_ab = st.add((size_t)n_queries * 4);                      // k_phrase_cutoff's flags (zeroed by the copy)
+    std::vector<TermBitmap> clause_bitmaps;  // parallel to dt: the clauses behind a query's lead that have a doc bitmap
+    if (bitmap_df != INT64_MAX && seg->bitmaps.size() > 0) {
+      bool any = false;
+      clause_bitmaps.assign(dt.size(), TermBitmap{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0});
+      for (const DevQuery& q0 : dq) {
+        for (int i = 1; i < q0.n_terms; ++i) {
+          const DevTerm& t = dt[(size_t)(q0.first_term + i)];
+          if (t.df < bitmap_df) continue;
+          const BitmapInfo* bm = seg->bitmaps.find((int64_t)t.start_fp);
+          if (!bm || !bm->usable || bm->df != t.df) continue;
+          clause_bitmaps[(size_t)(q0.first_term + i)] = TermBitmap{bm->words, bm->ranks, bm->freqs, bm->ovf, bm->nib, bm->n_ovf, 0};
+          any = true;
+        }
+      }
+      if (!any) clause_bitmaps.clear();
+    }
+    const size_t o_bm = clause_bitmaps.empty() ? 0 : st.add(clause_bitmaps.size() * sizeof(TermBitmap));
     HIP_TRY(c->S->h_stage.reserve(st.used));
     HIP_TRY(c->S->d_stage.reserve(st.used, 0, stream));
     std::memcpy(c->S->h_stage.p + o_q, dq.data(), (size_t)n_queries * sizeof(DevQuery));
@@ -2698,6 +2730,7 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
     std::memcpy(c->S->h_stage.p + o_ep, emit_prefix.data(), (size_t)(n_queries + 1) * 8);
     std::memcpy(c->S->h_stage.p + o_cp, collect_prefix.data(), (size_t)(n_queries + 1) * 8);
     std::memset(c->S->h_stage.p + o_ab, 0, (size_t)n_queries * 4);
+    if (!clause_bitmaps.empty()) std::memcpy(c->S->h_stage.p + o_bm, clause_bitmaps.data(), clause_bitmaps.size() * sizeof(TermBitmap));
     HIP_TRY(hipMemcpyAsync(c->S->d_stage.p, c->S->h_stage.p, st.used, hipMemcpyHostToDevice, stream));
     HIP_TRY(c->phrase_docs.reserve((size_t)slots + 64, 0, stream));
     HIP_TRY(c->phrase_keys.reserve((size_t)slots + 64, 0, stream));
@@ -2726,7 +2759,8 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
       auto go = [&](auto kern) {
         hipLaunchKernelGGL(kern, dim3(grid), dim3(WG_THREADS), 0, stream, sv, d_q, d_t, d_ip, (int)n_queries, items, blocks_per_item, k_emit,
                            c->S->d_partial_keys.p, c->S->d_partial_counts.p, c->S->d_tau.p, c->S->d_touched.p, d_ep, c->phrase_count.p,
-                           (void*)c->phrase_docs.p, (const unsigned long long*)nullptr, (const int32_t*)nullptr, (const TermBitmap*)nullptr);
+                           (void*)c->phrase_docs.p, (const unsigned long long*)nullptr, (const int32_t*)nullptr,
+                           clause_bitmaps.empty() ? (const TermBitmap*)nullptr : reinterpret_cast<const TermBitmap*>(c->S->d_stage.p + o_bm));
       };
       if (legacy) go(k_search_and<true, false, false, false>); else go(k_search_and<false, false, false, false>);
     }
