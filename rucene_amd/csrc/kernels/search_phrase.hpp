@@ -140,6 +140,7 @@ __device__ __forceinline__ int phrase_doc_positions(const SegView& seg, const De
 // that does not fit leaves PHRASE_REDO in its key and raises *redo — the host then runs the CAP = PHRASE_LIST_CAP instantiation,
 // which looks at the marked slots only (REDO_ONLY).
 constexpr int PHRASE_SMALL_CAP = 128;
+constexpr int64_t PHRASE_LAUNCH_SLOTS = (int64_t)1 << 25;  // slots (wavefronts) per launch of a one-wavefront-per-slot kernel: 2^31 work-items
 constexpr uint64_t PHRASE_REDO = 1ull;  // (no real key has a zero high word)
 // bits of *redo: which later pass some candidate is waiting for
 constexpr int PHRASE_REDO_WIDE = 1;    // k_phrase_match with PHRASE_LIST_CAP lists
@@ -152,15 +153,16 @@ __global__ __launch_bounds__(WG_THREADS) void k_phrase_match(SegView seg, const 
                                                              const unsigned long long* __restrict__ emit_count,
                                                              const int32_t* __restrict__ emit_docs, const int32_t* __restrict__ slops, int n_queries,
                                                              int64_t n_slots, int64_t pos_len, uint64_t* __restrict__ keys_out, int* err, int* redo,
-                                                             const int64_t* __restrict__ redo_list = nullptr) {
-  // redo_list (REDO_ONLY; nullable): the n_slots slots to look at, instead of every slot of the launch
+                                                             const int64_t* __restrict__ redo_list, int64_t first) {
+  // first / n_slots: this launch takes the slots [first, n_slots) — a grid holds at most 2^32 work-items, i.e. 2^26 wavefronts
+  // (PHRASE_LAUNCH_SLOTS); redo_list (REDO_ONLY; nullable): the slots to look at, [first, n_slots) then indexes the list
   __shared__ __attribute__((aligned(16))) uint8_t slabs[WG_WAVES][SLAB_BYTES];
   __shared__ int32_t lists_a[WG_WAVES][CAP];
   __shared__ int32_t lists_c[WG_WAVES][CAP];
   __shared__ float caches[WG_WAVES][256];
   const int lane = lane_id();
   const int wave = wave_id();
-  const int64_t work = (int64_t)blockIdx.x * WG_WAVES + wave;
+  const int64_t work = first + (int64_t)blockIdx.x * WG_WAVES + wave;
   if (work >= n_slots) return;
   const int64_t slot = (REDO_ONLY && redo_list != nullptr) ? redo_list[work] : work;
   if (REDO_ONLY && keys_out[slot] != PHRASE_REDO) return;
@@ -240,6 +242,9 @@ __global__ __launch_bounds__(WG_THREADS) void k_phrase_match(SegView seg, const 
 // leaves PHRASE_REDO in the candidate's slot and raises bit 1 of *redo: k_phrase_match<.., REDO_ONLY> takes those candidates (and
 // reports the errors). Results are the same by construction: the same positions, the same intersection, the same score expression.
 constexpr int PHRASE_LANE_CAP = 10;
+#ifndef RGPU_LANES_ABL  // developer ablations (variant builds only; results are wrong): 1 no positions / intersection, 2 + no block decodes
+#define RGPU_LANES_ABL 0
+#endif
 constexpr int64_t PHRASE_REDO_LIST_CAP = 1 << 22;  // slots the list of left-over candidates holds (32 MB); beyond: every slot is looked at
 __device__ __forceinline__ uint32_t bp128_value_at(const uint8_t* __restrict__ payload, uint32_t b, int i) {
   const uint32_t p = (uint32_t)(i >> 2) * b;
@@ -290,15 +295,26 @@ __global__ __launch_bounds__(WG_THREADS) void k_phrase_match_lanes(SegView seg, 
       if (act && doc != T.singleton_doc) again = true;  // (the conjunction said the doc is here)
     } else {
       // ---- 1. every lane: the first directory slot whose last doc is >= its doc (slot nblocks: the tail)
+      // (four-way: the three probes of a round are in flight together — half the dependent round trips of a binary search)
       int lo = 0, hi = T.nblocks;
       while (__ballot(lo < hi)) {
-        const int mid = (lo + hi) >> 1;
-        const int32_t last = seg.dir_last[T.dir_base + min(mid, T.nblocks - 1)];
-        if (lo < hi) { if (last < doc) lo = mid + 1; else hi = mid; }
+        const int span = hi - lo;
+        const int m1 = lo + (span >> 2), m2 = lo + (span >> 1), m3 = lo + span - (span >> 2) - (span > 3 ? 0 : 1);
+        const int top = T.nblocks - 1;
+        const int32_t l1 = seg.dir_last[T.dir_base + min(max(m1, 0), top)];
+        const int32_t l2 = seg.dir_last[T.dir_base + min(max(m2, 0), top)];
+        const int32_t l3 = seg.dir_last[T.dir_base + min(max(m3, 0), top)];
+        if (lo < hi) {  // lo <= m1 <= m2 <= m3 < hi; slots below lo end before doc, slot hi does not
+          if (l1 >= doc) hi = m1;
+          else if (l2 >= doc) { lo = m1 + 1; hi = m2; }
+          else if (l3 >= doc) { lo = m2 + 1; hi = m3; }
+          else lo = m3 + 1;
+        }
       }
       const int blk = lo;
       // ---- 2. the distinct blocks among the lanes, decoded once each
       uint64_t pend = __ballot(act && !again);
+      if (RGPU_LANES_ABL == 2) { pend = 0; freq = 1 + (blk & 1); }
       while (pend) {
         const int b = readlane(blk, (int)__builtin_ctzll(pend));
         const uint64_t st = seg.dir_pos[T.dir_base + b];
@@ -343,9 +359,12 @@ __global__ __launch_bounds__(WG_THREADS) void k_phrase_match_lanes(SegView seg, 
     if (live && (freq <= 0 || freq > PHRASE_LANE_CAP)) { again = true; live = false; }
     // ---- 3. the doc's positions: `freq` deltas from value `skip` of the position stream at pofs on
     int32_t* Lc = c == 0 ? A : C;
+    if (RGPU_LANES_ABL == 1 || RGPU_LANES_ABL == 2) { if (live && skip == 12345 && freq == 77) keys_out[slot] = 5; continue; }
+    // (a lane without a candidate reads the term's first position block, value 0: the loads below are unconditional)
+    int64_t fp = (int64_t)P.pos_start_fp, fp1 = fp;
+    uint32_t b0 = 1u, b1 = 1u;
     if (live) {
-      int64_t fp = (int64_t)P.pos_start_fp + (int64_t)pofs;
-      uint32_t b0 = 0, b1 = 0;
+      fp += (int64_t)pofs;
       // a packed position block at `at`: its header byte (1..32); 0 = not one (the trailing VInt block, an all-equal block, the end)
       auto packed_at = [&](int64_t at) -> uint32_t {
         if (at < 0 || at + 2 > pos_len || at == P.last_pos_block_fp) return 0u;
@@ -353,44 +372,63 @@ __global__ __launch_bounds__(WG_THREADS) void k_phrase_match_lanes(SegView seg, 
         return b <= 32u ? b : 0u;
       };
       b0 = packed_at(fp);
+      if (RGPU_LANES_ABL == 5) skip &= 127;
       while (b0 != 0u && skip >= 128) {  // whole blocks of earlier docs' positions (ForUtil::skip_block, for_util.rs:263-272)
         fp += 1 + 16 * (int64_t)b0;
         skip -= 128;
         b0 = packed_at(fp);
       }
-      const int64_t fp1 = fp + 1 + 16 * (int64_t)b0;  // the block behind: a doc's <= 10 positions straddle at most one boundary
+      fp1 = fp + 1 + 16 * (int64_t)b0;  // the block behind: a doc's <= 10 positions straddle at most one boundary
       const bool straddles = skip + freq > 128;
       if (b0 != 0u && straddles) b1 = packed_at(fp1);
       if (b0 == 0u || (straddles && b1 == 0u)) {
         again = true;
         live = false;
-      } else {
-        uint32_t dl[PHRASE_LANE_CAP];
-#pragma unroll
-        for (int j = 0; j < PHRASE_LANE_CAP; ++j) {
-          const int i = skip + j;
-          dl[j] = 0u;
-          if (j < freq) dl[j] = i < 128 ? bp128_value_at(seg.pos + fp + 1, b0, i) : bp128_value_at(seg.pos + fp1 + 1, b1, i - 128);
-        }
-        int32_t at_pos = -P.phrase_pos;  // (position - phrase offset; the doc's first delta is its first position)
-#pragma unroll
-        for (int j = 0; j < PHRASE_LANE_CAP; ++j) {
-          at_pos += (int32_t)dl[j];
-          if (j < freq) Lc[j * 64 + lane] = at_pos;
-        }
       }
+    }
+    if (!live) { fp = fp1 = (int64_t)P.pos_start_fp; b0 = b1 = 1u; skip = 0; freq = 1; }
+    // every lane's deltas asked for together (a load behind a per-lane branch waits for the one in front of it: ten round trips
+    // where this takes one); j runs to the largest freq among the lanes, a lane past its own freq reads its last delta again
+    const int maxf = (int)wave_reduce_max_u32(live ? (uint32_t)freq : 0u);
+    // (first every load, then every use: a value unpacked inside the j-th step would make that step wait for its own two loads)
+    uint32_t wlo[PHRASE_LANE_CAP], whi[PHRASE_LANE_CAP];
+#pragma unroll
+    for (int j = 0; j < PHRASE_LANE_CAP; ++j) {
+      wlo[j] = whi[j] = 0u;
+      if (j < maxf && RGPU_LANES_ABL != 4) {  // (wave-uniform)
+        const int i = skip + min(j, freq - 1);
+        const bool behind = i >= 128;
+        const uint32_t p = (uint32_t)((behind ? i - 128 : i) >> 2) * (behind ? b1 : b0);
+        const uint8_t* at = seg.pos + (behind ? fp1 : fp) + 1 + 4 * (i & 3) + 16 * (p >> 5);
+        wlo[j] = load4_unaligned(at);
+        whi[j] = load4_unaligned(at + 16);
+      }
+    }
+    int32_t at_pos = -P.phrase_pos;  // (position - phrase offset; the doc's first delta is its first position)
+#pragma unroll
+    for (int j = 0; j < PHRASE_LANE_CAP; ++j) {
+      if (j >= maxf) break;  // (wave-uniform)
+      const int i = skip + min(j, freq - 1);
+      const bool behind = i >= 128;
+      const uint32_t b = behind ? b1 : b0;
+      const uint32_t p = (uint32_t)((behind ? i - 128 : i) >> 2) * b;
+      const uint32_t v = (uint32_t)((((uint64_t)whi[j] << 32) | wlo[j]) >> (p & 31)) & (0xffffffffu >> (32 - b));
+      at_pos += (int32_t)v;
+      if (live && j < freq) Lc[j * 64 + lane] = at_pos;
     }
     // ---- 4. keep the first term's positions that line up with this term's (every lane reads and writes its own column only)
     if (c == 0) {
       n_a = live ? freq : 0;
-    } else if (live) {
-      int alive = 0;
-      for (int i = 0; i < n_a; ++i) {
+    } else if (live && RGPU_LANES_ABL != 3) {
+      // both lists ascend (a doc's positions do; dead entries of A are skipped): one pass over the two, not a search per entry
+      int alive = 0, i = 0, j = 0;
+      int32_t cv = C[lane];
+      while (i < n_a) {
         const int32_t a = A[i * 64 + lane];
-        if (a == PHRASE_DEAD) continue;
-        bool found = false;
-        for (int j = 0; j < freq; ++j) found = found || C[j * 64 + lane] == a;
-        if (found) ++alive; else A[i * 64 + lane] = PHRASE_DEAD;
+        if (a == PHRASE_DEAD) { ++i; continue; }
+        while (cv < a && j + 1 < freq) { ++j; cv = C[j * 64 + lane]; }
+        if (cv == a) ++alive; else A[i * 64 + lane] = PHRASE_DEAD;
+        ++i;
       }
       if (alive == 0) act = false;  // no position of the first term lines up any more: phrase freq 0, key 0
     }
@@ -533,13 +571,14 @@ __global__ __launch_bounds__(WG_THREADS) void k_sloppy_match(SegView seg, const 
                                                              const unsigned long long* __restrict__ emit_count,
                                                              const int32_t* __restrict__ emit_docs, const int32_t* __restrict__ slops,
                                                              const SloppyGroups* __restrict__ groups, int n_queries, int64_t n_slots,
-                                                             int64_t pos_len, uint64_t* __restrict__ keys_out, int* err, int* redo) {
+                                                             int64_t pos_len, uint64_t* __restrict__ keys_out, int* err, int* redo, int64_t first) {
+  // (first / n_slots: the slots [first, n_slots) — see k_phrase_match)
   __shared__ __attribute__((aligned(16))) uint8_t slabs[WG_WAVES][SLAB_BYTES];
   __shared__ int32_t pools[WG_WAVES][POOL];
   __shared__ float caches[WG_WAVES][256];
   const int lane = lane_id();
   const int wave = wave_id();
-  const int64_t slot = (int64_t)blockIdx.x * WG_WAVES + wave;
+  const int64_t slot = first + (int64_t)blockIdx.x * WG_WAVES + wave;
   if (slot >= n_slots) return;
   if (REDO_ONLY && keys_out[slot] != PHRASE_REDO) return;
   const int q = upper_slot_wave(emit_prefix, n_queries, slot, lane);

@@ -42,6 +42,27 @@ static int32_t fail(int32_t code, const std::string& msg) {
   g_last_error = msg;
   return code;
 }
+// A launch is described to the hardware in WORK-ITEMS, 32 bits per dimension: grid.x * block.x beyond 2^32 - 1 is cut down to
+// its low 32 bits by the runtime without a word (hipGetLastError stays hipSuccess) — the kernel then runs over the first part
+// of its work and nothing says so. (Round 4 found the phrase kernels, one wavefront per candidate slot, doing that from 67 M
+// slots on.) Every launch goes through RGPU_LAUNCH: a grid that does not fit is not launched and the call fails
+// (launch_status(), which the API functions check where they checked hipGetLastError()).
+static thread_local const char* g_refused_launch = nullptr;
+static inline hipError_t launch_status() {
+  if (g_refused_launch != nullptr) {
+    g_last_error = std::string("launch refused: the grid of ") + g_refused_launch + " exceeds 2^32 work-items";
+    g_refused_launch = nullptr;
+    (void)hipGetLastError();
+    return hipErrorInvalidConfiguration;
+  }
+  return hipGetLastError();
+}
+#define RGPU_LAUNCH(kern, grid, block, shmem, stream, ...)                                                  \
+  do {                                                                                                     \
+    const dim3 g_ = (grid), b_ = (block);                                                                  \
+    if ((unsigned long long)g_.x * (unsigned long long)b_.x > 0xffffffffull) g_refused_launch = #kern;     \
+    else hipLaunchKernelGGL(kern, g_, b_, shmem, stream, __VA_ARGS__);                                     \
+  } while (0)
 #define HIP_TRY(expr)                                                                                      \
   do {                                                                                                     \
     hipError_t _e = (expr);                                                                                \
@@ -510,18 +531,18 @@ static int32_t prepare_terms_attempt(rgpu_segment* seg, const rgpu_term_state* c
   {
     TimedLaunch tl(c, c->stream, "k_skip_dir", postings);
     const dim3 grid((unsigned)((n_chunks + PREP_WAVES - 1) / PREP_WAVES));
-    hipLaunchKernelGGL(k_skip_terms, dim3((unsigned)((work.size() + PREP_THREADS - 1) / PREP_THREADS)), dim3(PREP_THREADS), 0, c->stream, seg->d_doc,
+    RGPU_LAUNCH(k_skip_terms, dim3((unsigned)((work.size() + PREP_THREADS - 1) / PREP_THREADS)), dim3(PREP_THREADS), 0, c->stream, seg->d_doc,
                        (int64_t)seg->doc_len, d_work, (int)work.size(), d_l0, seg->dir_last.p, seg->dir_off.p,
                        seg->has_positions ? seg->dir_pos.p : nullptr, seg->skip_vals, c->d_err);
     if (n_chunks > 0) {  // the terms whose level 0 one lane does not finish
       auto pass = [&](auto kern) {
-        hipLaunchKernelGGL(kern, grid, dim3(PREP_THREADS), 0, c->stream, seg->d_doc, (int64_t)seg->doc_len, (int64_t)seg->doc_len + 8192,
+        RGPU_LAUNCH(kern, grid, dim3(PREP_THREADS), 0, c->stream, seg->d_doc, (int64_t)seg->doc_len, (int64_t)seg->doc_len + 8192,
                            d_work, d_chunks, d_l0, (int)work.size(), n_chunks, d_aggs, d_groups, d_gaggs, seg->dir_last.p, seg->dir_off.p,
                            seg->has_positions ? seg->dir_pos.p : nullptr, c->d_err);
       };
       auto groups = [&](auto kern) {
         if (n_groups > 0)
-          hipLaunchKernelGGL(kern, dim3((unsigned)((n_groups + PREP_WAVES - 1) / PREP_WAVES)), dim3(PREP_THREADS), 0, c->stream, d_chunks,
+          RGPU_LAUNCH(kern, dim3((unsigned)((n_groups + PREP_WAVES - 1) / PREP_WAVES)), dim3(PREP_THREADS), 0, c->stream, d_chunks,
                              d_groups, (int)work.size(), n_groups, d_aggs, d_gaggs);
       };
       switch (seg->skip_vals) {  // values per level-0 skip entry (prepare.hpp, A1)
@@ -535,7 +556,7 @@ static int32_t prepare_terms_attempt(rgpu_segment* seg, const rgpu_term_state* c
   {
     TimedLaunch tl(c, c->stream, "k_block_headers", postings);
     auto go = [&](auto kern) {
-      hipLaunchKernelGGL(kern, dim3((unsigned)((n_slots + PREP_THREADS - 1) / PREP_THREADS)), dim3(PREP_THREADS), 0, c->stream, seg->d_doc,
+      RGPU_LAUNCH(kern, dim3((unsigned)((n_slots + PREP_THREADS - 1) / PREP_THREADS)), dim3(PREP_THREADS), 0, c->stream, seg->d_doc,
                          (int64_t)seg->doc_len, d_work, (int)work.size(), (uint32_t)seg->dir_used, (int64_t)n_slots, seg->dir_last.p, seg->dir_off.p,
                          seg->dir_row.p, seg->dir_hdr.p, seg->has_freqs ? 1 : 0, c->d_err);
     };
@@ -544,14 +565,14 @@ static int32_t prepare_terms_attempt(rgpu_segment* seg, const rgpu_term_state* c
   {
     TimedLaunch tl(c, c->stream, "k_scan_rows", 0);
     uint32_t* rows = seg->dir_row.p + seg->dir_used;
-    hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)n_tiles), dim3(PREP_THREADS), 0, c->stream, rows, (int64_t)n_slots, d_tiles);
-    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(PREP_THREADS), 0, c->stream, d_tiles, n_tiles, (unsigned long long)cap_rows, d_total, c->d_err);
-    hipLaunchKernelGGL(k_scan_down, dim3((unsigned)n_tiles), dim3(PREP_THREADS), 0, c->stream, rows, (int64_t)n_slots, d_tiles);
+    RGPU_LAUNCH(k_scan_reduce, dim3((unsigned)n_tiles), dim3(PREP_THREADS), 0, c->stream, rows, (int64_t)n_slots, d_tiles);
+    RGPU_LAUNCH(k_scan_tiles, dim3(1), dim3(PREP_THREADS), 0, c->stream, d_tiles, n_tiles, (unsigned long long)cap_rows, d_total, c->d_err);
+    RGPU_LAUNCH(k_scan_down, dim3((unsigned)n_tiles), dim3(PREP_THREADS), 0, c->stream, rows, (int64_t)n_slots, d_tiles);
   }
   {
     TimedLaunch tl(c, c->stream, "k_prepare_blocks", postings);
     auto go = [&](auto kern) {
-      hipLaunchKernelGGL(kern, dim3(item_grid), dim3(PREP_THREADS), 0, c->stream, seg->d_doc, d_work, d_items, (int)work.size(), n_items,
+      RGPU_LAUNCH(kern, dim3(item_grid), dim3(PREP_THREADS), 0, c->stream, seg->d_doc, d_work, d_items, (int)work.size(), n_items,
                          seg->dir_last.p, seg->dir_off.p, seg->dir_row.p, seg->dir_hdr.p, seg->bstore.p, seg->dir_bmax.p, seg->has_freqs ? 1 : 0,
                          seg->max_doc, c->d_err, sink ? sink->docs : (int32_t*)nullptr, sink ? sink->freqs : (int32_t*)nullptr);
     };
@@ -563,7 +584,7 @@ static int32_t prepare_terms_attempt(rgpu_segment* seg, const rgpu_term_state* c
   HIP_TRY(hipMemcpyAsync(err4, c->d_err, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipMemcpyAsync(&total_rows, d_total, 8, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
-  HIP_TRY(hipGetLastError());
+  HIP_TRY(launch_status());
   t_sync = hc.lap();
   const int err = err4[0];
   if (err == -101) return -101;  // see prepare_terms_locked
@@ -629,14 +650,14 @@ static int32_t prepare_norms_locked(rgpu_segment* seg, const rgpu_term_state* co
     TimedLaunch tl(c, c->stream, "k_prepare_norms", postings);
     const unsigned grid = (unsigned)((n_items + PREP_WAVES - 1) / PREP_WAVES);
     auto go = [&](auto kern) {
-      hipLaunchKernelGGL(kern, dim3(grid), dim3(PREP_THREADS), 0, c->stream, seg_view(seg), reinterpret_cast<const PrepTerm*>(c->S->d_stage.p + o_work),
+      RGPU_LAUNCH(kern, dim3(grid), dim3(PREP_THREADS), 0, c->stream, seg_view(seg), reinterpret_cast<const PrepTerm*>(c->S->d_stage.p + o_work),
                          reinterpret_cast<const int64_t*>(c->S->d_stage.p + o_items), (int)work.size(), n_items, seg->pnorm.p, seg->dir_bmax.p,
                          seg->n_norm_ranks > 0 ? 1 : 0);
     };
     if (seg->version < 1) go(k_prepare_norms<true>); else go(k_prepare_norms<false>);
   }
   HIP_TRY(hipStreamSynchronize(c->stream));
-  HIP_TRY(hipGetLastError());
+  HIP_TRY(launch_status());
   seg->pnorm_used = need_pn;
   for (size_t i = 0; i < work.size(); ++i) {
     TermInfo info = *seg->prepared.find(fps[i]);
@@ -1037,7 +1058,7 @@ static int32_t decode_terms_impl(rgpu_segment* seg, const rgpu_term_state* terms
   {
     TimedLaunch tl(c, stream, "k_decode_terms", postings);
     auto args = [&](auto kern) {
-      hipLaunchKernelGGL(kern, dim3(grid), dim3(WG_THREADS), 0, stream, seg_view(seg),
+      RGPU_LAUNCH(kern, dim3(grid), dim3(WG_THREADS), 0, stream, seg_view(seg),
                          reinterpret_cast<const DevTerm*>(c->S->d_stage.p + o_terms),
                          reinterpret_cast<const int64_t*>(c->S->d_stage.p + o_items),
                          reinterpret_cast<const int64_t*>(c->S->d_stage.p + o_out), (int)nr, items, dec_blocks_per_item, docs_dev,
@@ -1045,7 +1066,7 @@ static int32_t decode_terms_impl(rgpu_segment* seg, const rgpu_term_state* terms
     };
     if (seg->version >= 1) args(k_decode_terms<false>); else args(k_decode_terms<true>);
   }
-  HIP_TRY(hipGetLastError());
+  HIP_TRY(launch_status());
   return RGPU_OK;
 }
 
@@ -1106,9 +1127,9 @@ extern "C" int32_t rgpu_advance_batch(rgpu_segment* seg, const rgpu_term_state* 
     TimedLaunch tl(c, c->stream, "k_advance", n);
     const unsigned grid = (unsigned)((n + WG_WAVES - 1) / WG_WAVES);
     if (seg->version >= 1)
-      hipLaunchKernelGGL(k_advance<false>, dim3(grid), dim3(WG_THREADS), 0, c->stream, seg_view(seg), T, d, n, d + n, d + 2 * n);
+      RGPU_LAUNCH(k_advance<false>, dim3(grid), dim3(WG_THREADS), 0, c->stream, seg_view(seg), T, d, n, d + n, d + 2 * n);
     else
-      hipLaunchKernelGGL(k_advance<true>, dim3(grid), dim3(WG_THREADS), 0, c->stream, seg_view(seg), T, d, n, d + n, d + 2 * n);
+      RGPU_LAUNCH(k_advance<true>, dim3(grid), dim3(WG_THREADS), 0, c->stream, seg_view(seg), T, d, n, d + n, d + 2 * n);
   }
   if (e == hipSuccess) e = hipMemcpyAsync(out_docs, d + n, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(out_freqs, d + 2 * n, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream);
@@ -1190,23 +1211,23 @@ static int32_t ensure_bitmaps_locked(rgpu_segment* seg, const rgpu_term_state* c
       if (rc != RGPU_OK) return rc;
       {
         TimedLaunch tl(c, c->stream, "k_bitmap_build", (int64_t)df);
-        hipLaunchKernelGGL(k_bitmap_fill, dim3((unsigned)((df + 255) / 256)), dim3(256), 0, c->stream, docs, freqs, (int64_t)df, seg->max_doc,
+        RGPU_LAUNCH(k_bitmap_fill, dim3((unsigned)((df + 255) / 256)), dim3(256), 0, c->stream, docs, freqs, (int64_t)df, seg->max_doc,
                            (const uint8_t*)seg->d_norms, (const float*)(c->sim_tables.p + (size_t)sim_tables[i] * 257),
                            seg->n_norm_ranks > 0 ? (const uint8_t*)seg->d_rank_to_norm : (const uint8_t*)nullptr, info.words, info.freqs, info.ovf, d_stats, info.nib);
         const int64_t n_scan = n_words + 1;  // ranks[n_words] = the list's size
-        hipLaunchKernelGGL(k_bitmap_popc, dim3((unsigned)((n_scan + 255) / 256)), dim3(256), 0, c->stream, info.words, n_scan, info.ranks);
+        RGPU_LAUNCH(k_bitmap_popc, dim3((unsigned)((n_scan + 255) / 256)), dim3(256), 0, c->stream, info.words, n_scan, info.ranks);
         const int64_t n_tiles = (n_scan + SCAN_TILE - 1) / SCAN_TILE;
         HIP_TRY(seg->prep_scratch.reserve(64 + (size_t)n_tiles * 8 + 64, 0, c->stream));
         unsigned long long* d_total = reinterpret_cast<unsigned long long*>(seg->prep_scratch.p);
         unsigned long long* d_tiles = d_total + 8;
-        hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)n_tiles), dim3(PREP_THREADS), 0, c->stream, info.ranks, n_scan, d_tiles);
-        hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(PREP_THREADS), 0, c->stream, d_tiles, n_tiles, 0xfffffff0ull, d_total, c->d_err);
-        hipLaunchKernelGGL(k_scan_down, dim3((unsigned)n_tiles), dim3(PREP_THREADS), 0, c->stream, info.ranks, n_scan, d_tiles);
+        RGPU_LAUNCH(k_scan_reduce, dim3((unsigned)n_tiles), dim3(PREP_THREADS), 0, c->stream, info.ranks, n_scan, d_tiles);
+        RGPU_LAUNCH(k_scan_tiles, dim3(1), dim3(PREP_THREADS), 0, c->stream, d_tiles, n_tiles, 0xfffffff0ull, d_total, c->d_err);
+        RGPU_LAUNCH(k_scan_down, dim3((unsigned)n_tiles), dim3(PREP_THREADS), 0, c->stream, info.ranks, n_scan, d_tiles);
       }
       HIP_TRY(hipMemcpyAsync(&hs, d_stats, sizeof hs, hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(hipMemcpyAsync(&listed, info.ranks + n_words, 4, hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(hipStreamSynchronize(c->stream));
-      HIP_TRY(hipGetLastError());
+      HIP_TRY(launch_status());
       return RGPU_OK;
     };
     const int32_t rc = build();
@@ -1261,7 +1282,7 @@ static void launch_merge(rgpu_ctx* c, hipStream_t s, int n_queries, int k, const
                          const int32_t* qmap = nullptr) {
   TimedLaunch tl(c, s, "k_merge_items", 0);
   const unsigned grid = (unsigned)((n_queries + WG_WAVES - 1) / WG_WAVES);
-  hipLaunchKernelGGL(k_merge_items<WIDE>, dim3(grid), dim3(WG_THREADS), 0, s, d_prefix, n_queries, k, c->S->d_partial_keys.p,
+  RGPU_LAUNCH(k_merge_items<WIDE>, dim3(grid), dim3(WG_THREADS), 0, s, d_prefix, n_queries, k, c->S->d_partial_keys.p,
                      c->S->d_partial_counts.p, doc_base, head_items, hits, totals, fixed_info, low_flags, qmap, c->pass.stride, c->pass.col0,
                      c->pass.ceil_out);
 }
@@ -1361,9 +1382,9 @@ static int32_t search_or_group(rgpu_segment* seg, Group& G, int32_t k, HitOut* h
     TimedLaunch tl(c, stream, "k_score_terms", G.postings);
     const unsigned grid = (unsigned)((items1 + WG_WAVES - 1) / WG_WAVES);
     if (legacy)
-      hipLaunchKernelGGL(k_score_terms<true>, dim3(grid), dim3(WG_THREADS), 0, stream, sv, dt, dip, drp, nt, items1, blocks_per_item, c->d_runs.p);
+      RGPU_LAUNCH(k_score_terms<true>, dim3(grid), dim3(WG_THREADS), 0, stream, sv, dt, dip, drp, nt, items1, blocks_per_item, c->d_runs.p);
     else
-      hipLaunchKernelGGL(k_score_terms<false>, dim3(grid), dim3(WG_THREADS), 0, stream, sv, dt, dip, drp, nt, items1, blocks_per_item, c->d_runs.p);
+      RGPU_LAUNCH(k_score_terms<false>, dim3(grid), dim3(WG_THREADS), 0, stream, sv, dt, dip, drp, nt, items1, blocks_per_item, c->d_runs.p);
   }
   {
     TimedLaunch tl(c, stream, "k_or_windows", G.postings);
@@ -1374,7 +1395,7 @@ static int32_t search_or_group(rgpu_segment* seg, Group& G, int32_t k, HitOut* h
     auto go = [&](auto kern) -> hipError_t {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
-      hipLaunchKernelGGL(kern, dim3(grid), dim3(OR_THREADS), lds, stream, sv, dq, dt, drp, c->d_runs.p, nq, wpq, wpi, ipq, W, (int)k,
+      RGPU_LAUNCH(kern, dim3(grid), dim3(OR_THREADS), lds, stream, sv, dq, dt, drp, c->d_runs.p, nq, wpq, wpi, ipq, W, (int)k,
                          c->S->d_partial_keys.p, c->S->d_partial_counts.p, c->S->d_tau.p, c->pass.ceil_in, dm);
       return hipSuccess;
     };
@@ -1389,7 +1410,7 @@ static int32_t search_or_group(rgpu_segment* seg, Group& G, int32_t k, HitOut* h
   }
   if (wide) launch_merge<true>(c, stream, nq, k, dmp, seg->doc_base, hits_dev, totals_dev, 0, nullptr, nullptr, dm);
   else launch_merge<false>(c, stream, nq, k, dmp, seg->doc_base, hits_dev, totals_dev, 0, nullptr, nullptr, dm);
-  HIP_TRY(hipGetLastError());
+  HIP_TRY(launch_status());
   HIP_TRY(hipStreamSynchronize(stream));  // staging / scratch buffers are reused by the next group
   return RGPU_OK;
 }
@@ -1682,9 +1703,9 @@ static int32_t search_or_lazy_group(rgpu_segment* seg, Group& G, int32_t k, HitO
       const int64_t* dip = reinterpret_cast<const int64_t*>(c->S->d_stage.p + o_ip);
       const int64_t* drp = reinterpret_cast<const int64_t*>(c->S->d_stage.p + o_rp);
       if (legacy)
-        hipLaunchKernelGGL(k_score_terms<true>, dim3(grid), dim3(WG_THREADS), 0, stream, sv, dt, dip, drp, nu, items1, blocks_per_item, c->d_runs.p);
+        RGPU_LAUNCH(k_score_terms<true>, dim3(grid), dim3(WG_THREADS), 0, stream, sv, dt, dip, drp, nu, items1, blocks_per_item, c->d_runs.p);
       else
-        hipLaunchKernelGGL(k_score_terms<false>, dim3(grid), dim3(WG_THREADS), 0, stream, sv, dt, dip, drp, nu, items1, blocks_per_item, c->d_runs.p);
+        RGPU_LAUNCH(k_score_terms<false>, dim3(grid), dim3(WG_THREADS), 0, stream, sv, dt, dip, drp, nu, items1, blocks_per_item, c->d_runs.p);
     }
     {
       TimedLaunch tl(c, stream, "k_or_lazy", all_postings);
@@ -1693,7 +1714,7 @@ static int32_t search_or_lazy_group(rgpu_segment* seg, Group& G, int32_t k, HitO
       auto go = [&](auto kern) -> hipError_t {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(LZ_THREADS), lds, stream, sv, reinterpret_cast<const LazyQuery*>(c->S->d_stage.p + o_q),
+        RGPU_LAUNCH(kern, dim3(grid), dim3(LZ_THREADS), lds, stream, sv, reinterpret_cast<const LazyQuery*>(c->S->d_stage.p + o_q),
                            reinterpret_cast<const LazyRun*>(c->S->d_stage.p + o_r), c->d_runs.p, reinterpret_cast<const LazyClause*>(c->S->d_stage.p + o_l),
                            (int64_t)run_slots, nq, wpq, wpi, ipq, C, (int)k, c->S->d_partial_keys.p, c->S->d_partial_counts.p, c->S->d_tau.p, dbl, dct, d_hist);
         return hipSuccess;
@@ -1704,7 +1725,7 @@ static int32_t search_or_lazy_group(rgpu_segment* seg, Group& G, int32_t k, HitO
     int32_t* dfl = reinterpret_cast<int32_t*>(c->S->d_stage.p + o_fl);
     if (wide) launch_merge<true>(c, stream, nq, k, dmp, seg->doc_base, hits_dev, totals_dev, 0, dfi, dfl, dm);
     else launch_merge<false>(c, stream, nq, k, dmp, seg->doc_base, hits_dev, totals_dev, 0, dfi, dfl, dm);
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(launch_status());
     std::vector<int32_t> low((size_t)nq), bailed((size_t)nq);
     unsigned long long counts[2] = {0, 0};
     HOST_STAMP(h3);
@@ -1884,7 +1905,7 @@ static int32_t search_or_wide_group(rgpu_segment* seg, Group& G, int32_t k, HitO
     auto go = [&](auto kern) -> hipError_t {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
-      hipLaunchKernelGGL(kern, dim3(grid), dim3(ORX_THREADS), lds, stream, sv, dq, dt, nq, wpq, wpi, ipq, WS, (int)k,
+      RGPU_LAUNCH(kern, dim3(grid), dim3(ORX_THREADS), lds, stream, sv, dq, dt, nq, wpq, wpi, ipq, WS, (int)k,
                          c->S->d_partial_keys.p, c->S->d_partial_counts.p, c->S->d_tau.p);
       return hipSuccess;
     };
@@ -1895,7 +1916,7 @@ static int32_t search_or_wide_group(rgpu_segment* seg, Group& G, int32_t k, HitO
   int32_t* dfl = reinterpret_cast<int32_t*>(c->S->d_stage.p + o_fl);
   if (wide) launch_merge<true>(c, stream, nq, k, dmp, seg->doc_base, hits_dev, totals_dev, 0, dfi, dfl, dm);
   else launch_merge<false>(c, stream, nq, k, dmp, seg->doc_base, hits_dev, totals_dev, 0, dfi, dfl, dm);
-  HIP_TRY(hipGetLastError());
+  HIP_TRY(launch_status());
   std::vector<int32_t> low((size_t)nq);
   HIP_TRY(hipMemcpyAsync(low.data(), dfl, (size_t)nq * 4, hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipStreamSynchronize(stream));  // staging / scratch buffers are reused by the next group
@@ -2137,7 +2158,7 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
   // its merge writes every row (the usual serving case: two enqueues less per batch)
   auto init_rows = [&]() -> int32_t {
     HIP_TRY(hipMemsetAsync(totals_dev, 0, (size_t)n_queries * 8, stream));
-    hipLaunchKernelGGL(k_init_hits, dim3((unsigned)(((size_t)n_queries * k + 255) / 256)), dim3(256), 0, stream, hits_dev,
+    RGPU_LAUNCH(k_init_hits, dim3((unsigned)(((size_t)n_queries * k + 255) / 256)), dim3(256), 0, stream, hits_dev,
                        (int64_t)n_queries, (int)k, c->pass.stride > 0 ? c->pass.stride : (int)k, c->pass.col0);
     if (c->pass.ceil_out) HIP_TRY(hipMemsetAsync(c->pass.ceil_out, 0, (size_t)n_queries * 8, stream));  // rows no group writes have nothing below
     return RGPU_OK;
@@ -2292,7 +2313,7 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
         d_seq = c->d_runs.p;
       }
       auto go = [&](auto kern) {
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(WG_THREADS), 0, stream, sv, dq, dt, dp, nq, items, blocks_per_item, (int)k,
+        RGPU_LAUNCH(kern, dim3(grid), dim3(WG_THREADS), 0, stream, sv, dq, dt, dp, nq, items, blocks_per_item, (int)k,
                            c->S->d_partial_keys.p, c->S->d_partial_counts.p, d_tau, c->S->d_touched.p,
                            d_sp, (unsigned long long*)nullptr, d_seq, c->pass.ceil_in, dm,
                            clause_bitmaps.empty() ? (const TermBitmap*)nullptr : reinterpret_cast<const TermBitmap*>(c->S->d_stage.p + o_bm));
@@ -2325,7 +2346,7 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
       auto go = [&](auto kern) -> hipError_t {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(TERM_THREADS), lds, stream, sv, dq, dt, dp, nq, items, blocks_per_item, (int)k,
+        RGPU_LAUNCH(kern, dim3(grid), dim3(TERM_THREADS), lds, stream, sv, dq, dt, dp, nq, items, blocks_per_item, (int)k,
                            c->S->d_partial_keys.p, c->S->d_partial_counts.p, d_tau, c->S->d_touched.p, c->pass.ceil_in, dm);
         return hipSuccess;
       };
@@ -2339,11 +2360,11 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
       const unsigned grid = (unsigned)((nq + WG_WAVES - 1) / WG_WAVES);
       const SeqRec* d_seq = reinterpret_cast<const SeqRec*>(c->d_runs.p);
       const int64_t* d_sp = reinterpret_cast<const int64_t*>(c->S->d_stage.p + o_sp);
-      if (wide) hipLaunchKernelGGL(k_req_opt_scan<true>, dim3(grid), dim3(WG_THREADS), 0, stream, d_seq, d_sp, nq, (int)k, seg->doc_base, dm, hits_dev, totals_dev,
+      if (wide) RGPU_LAUNCH(k_req_opt_scan<true>, dim3(grid), dim3(WG_THREADS), 0, stream, d_seq, d_sp, nq, (int)k, seg->doc_base, dm, hits_dev, totals_dev,
                                    c->pass.stride, c->pass.col0, c->pass.ceil_in, c->pass.ceil_out);
-      else hipLaunchKernelGGL(k_req_opt_scan<false>, dim3(grid), dim3(WG_THREADS), 0, stream, d_seq, d_sp, nq, (int)k, seg->doc_base, dm, hits_dev, totals_dev,
+      else RGPU_LAUNCH(k_req_opt_scan<false>, dim3(grid), dim3(WG_THREADS), 0, stream, d_seq, d_sp, nq, (int)k, seg->doc_base, dm, hits_dev, totals_dev,
                               c->pass.stride, c->pass.col0, c->pass.ceil_in, c->pass.ceil_out);
-      HIP_TRY(hipGetLastError());
+      HIP_TRY(launch_status());
       HIP_TRY(hipStreamSynchronize(stream));  // the record buffer is shared scratch
       HIP_TRY(scratch_mark(c, stream));
       continue;
@@ -2351,7 +2372,7 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
     // the group's rows go straight to the caller's (qmap): no scatter pass
     if (wide) launch_merge<true>(c, stream, nq, k, dp, seg->doc_base, hits_dev, totals_dev, head_items, nullptr, nullptr, dm);
     else launch_merge<false>(c, stream, nq, k, dp, seg->doc_base, hits_dev, totals_dev, head_items, nullptr, nullptr, dm);
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(launch_status());
     HIP_TRY(scratch_mark(c, stream));  // no stream sync: the slot is waited for when it is taken again
   }
   return RGPU_OK;
@@ -2406,13 +2427,13 @@ extern "C" int32_t rgpu_merge_topk_device(rgpu_ctx* c, const void* hits_dev, con
     TimedLaunch tl(c, s, "k_merge_lists", 0);
     const unsigned grid = (unsigned)((n_queries + WG_WAVES - 1) / WG_WAVES);
     if (k > 64)
-      hipLaunchKernelGGL(k_merge_lists<true>, dim3(grid), dim3(WG_THREADS), 0, s, (const HitOut*)hits_dev, (const int64_t*)totals_dev,
+      RGPU_LAUNCH(k_merge_lists<true>, dim3(grid), dim3(WG_THREADS), 0, s, (const HitOut*)hits_dev, (const int64_t*)totals_dev,
                          (int64_t)n_queries * k, (int64_t)n_queries, n_lists, n_queries, k, (HitOut*)hits_out_dev, (int64_t*)totals_out_dev);
     else
-      hipLaunchKernelGGL(k_merge_lists<false>, dim3(grid), dim3(WG_THREADS), 0, s, (const HitOut*)hits_dev, (const int64_t*)totals_dev,
+      RGPU_LAUNCH(k_merge_lists<false>, dim3(grid), dim3(WG_THREADS), 0, s, (const HitOut*)hits_dev, (const int64_t*)totals_dev,
                          (int64_t)n_queries * k, (int64_t)n_queries, n_lists, n_queries, k, (HitOut*)hits_out_dev, (int64_t*)totals_out_dev);
   }
-  HIP_TRY(hipGetLastError());
+  HIP_TRY(launch_status());
   return RGPU_OK;  // enqueue only, like rgpu_search_batch_device
 }
 
@@ -2528,22 +2549,22 @@ static int32_t decode_positions_impl(rgpu_segment* seg, const rgpu_term_state* t
   const unsigned grid = (unsigned)((items + WG_WAVES - 1) / WG_WAVES);
   {
     TimedLaunch tl(c, stream, "k_pos_counts", expect);
-    if (legacy) hipLaunchKernelGGL(k_pos_counts<true>, dim3(grid), dim3(WG_THREADS), 0, stream, sv, d_t, d_ip, nt, items, c->pos_counts.p);
-    else hipLaunchKernelGGL(k_pos_counts<false>, dim3(grid), dim3(WG_THREADS), 0, stream, sv, d_t, d_ip, nt, items, c->pos_counts.p);
+    if (legacy) RGPU_LAUNCH(k_pos_counts<true>, dim3(grid), dim3(WG_THREADS), 0, stream, sv, d_t, d_ip, nt, items, c->pos_counts.p);
+    else RGPU_LAUNCH(k_pos_counts<false>, dim3(grid), dim3(WG_THREADS), 0, stream, sv, d_t, d_ip, nt, items, c->pos_counts.p);
   }
   {
     TimedLaunch tl(c, stream, "k_scan_rows", 0);
-    hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)n_tiles), dim3(PREP_THREADS), 0, stream, c->pos_counts.p, items, d_tiles);
-    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(PREP_THREADS), 0, stream, d_tiles, n_tiles, (unsigned long long)expect, d_total, c->d_err);
-    hipLaunchKernelGGL(k_scan_down, dim3((unsigned)n_tiles), dim3(PREP_THREADS), 0, stream, c->pos_counts.p, items, d_tiles);
+    RGPU_LAUNCH(k_scan_reduce, dim3((unsigned)n_tiles), dim3(PREP_THREADS), 0, stream, c->pos_counts.p, items, d_tiles);
+    RGPU_LAUNCH(k_scan_tiles, dim3(1), dim3(PREP_THREADS), 0, stream, d_tiles, n_tiles, (unsigned long long)expect, d_total, c->d_err);
+    RGPU_LAUNCH(k_scan_down, dim3((unsigned)n_tiles), dim3(PREP_THREADS), 0, stream, c->pos_counts.p, items, d_tiles);
   }
   {
     TimedLaunch tl(c, stream, "k_decode_positions", expect);
     if (legacy)
-      hipLaunchKernelGGL(k_decode_positions<true>, dim3(grid), dim3(WG_THREADS), 0, stream, sv, d_t, d_pt, d_ip, nt, items, c->pos_counts.p,
+      RGPU_LAUNCH(k_decode_positions<true>, dim3(grid), dim3(WG_THREADS), 0, stream, sv, d_t, d_pt, d_ip, nt, items, c->pos_counts.p,
                          (int64_t)seg->pos_len, positions_dev, c->d_err);
     else
-      hipLaunchKernelGGL(k_decode_positions<false>, dim3(grid), dim3(WG_THREADS), 0, stream, sv, d_t, d_pt, d_ip, nt, items, c->pos_counts.p,
+      RGPU_LAUNCH(k_decode_positions<false>, dim3(grid), dim3(WG_THREADS), 0, stream, sv, d_t, d_pt, d_ip, nt, items, c->pos_counts.p,
                          (int64_t)seg->pos_len, positions_dev, c->d_err);
   }
   int err4[4] = {0, 0, 0, 0};
@@ -2551,7 +2572,7 @@ static int32_t decode_positions_impl(rgpu_segment* seg, const rgpu_term_state* t
   HIP_TRY(hipMemcpyAsync(err4, c->d_err, 4 * sizeof(int), hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipStreamSynchronize(stream));
-  HIP_TRY(hipGetLastError());
+  HIP_TRY(launch_status());
   if (err4[0] != 0 || total != (unsigned long long)expect)
     return fail(RGPU_ERR_CORRUPT_INDEX, total != (unsigned long long)expect ? "the postings' freqs do not add up to total_term_freq" : "corrupt position data in .pos");
   return RGPU_OK;
@@ -2688,7 +2709,7 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
   HIP_TRY(c->host_api_hits.reserve((size_t)n_queries * (size_t)k, 0, stream));
   HIP_TRY(c->host_api_totals.reserve((size_t)n_queries, 0, stream));
   HIP_TRY(hipMemsetAsync(c->host_api_totals.p, 0, (size_t)n_queries * 8, stream));
-  hipLaunchKernelGGL(k_init_hits, dim3((unsigned)(((size_t)n_queries * k + 255) / 256)), dim3(256), 0, stream, c->host_api_hits.p, (int64_t)n_queries, (int)k, (int)k, 0);
+  RGPU_LAUNCH(k_init_hits, dim3((unsigned)(((size_t)n_queries * k + 255) / 256)), dim3(256), 0, stream, c->host_api_hits.p, (int64_t)n_queries, (int)k, (int)k, 0);
   if (items > 0) {
     HIP_TRY(scratch_take(c));
     Stager st(c);
@@ -2734,7 +2755,11 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
     HIP_TRY(hipMemcpyAsync(c->S->d_stage.p, c->S->h_stage.p, st.used, hipMemcpyHostToDevice, stream));
     HIP_TRY(c->phrase_docs.reserve((size_t)slots + 64, 0, stream));
     HIP_TRY(c->phrase_keys.reserve((size_t)slots + 64, 0, stream));
-    HIP_TRY(c->phrase_redo.reserve((size_t)std::min<int64_t>(slots, PHRASE_REDO_LIST_CAP) + 64, 0, stream));
+    // (developer knob: RGPU_PHRASE_REDO_CAP=<n> shrinks the list of left-over candidates, so that a test reaches the pass that runs without it)
+    int64_t redo_cap = PHRASE_REDO_LIST_CAP;
+    if (const char* e = std::getenv("RGPU_PHRASE_REDO_CAP")) redo_cap = std::max<int64_t>(0, std::min<int64_t>(redo_cap, std::atoll(e)));
+    redo_cap = std::min<int64_t>(slots, redo_cap);
+    HIP_TRY(c->phrase_redo.reserve((size_t)redo_cap + 64, 0, stream));
     HIP_TRY(c->phrase_count.reserve((size_t)n_queries, 0, stream));
     HIP_TRY(hipMemsetAsync(c->phrase_count.p, 0, (size_t)n_queries * 8, stream));
     const int k_emit = std::min<int>(k, 64);  // the conjunction only emits candidates: its (empty) top-k lists are the narrow kind
@@ -2757,7 +2782,7 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
       TimedLaunch tl(c, stream, "k_search_and(phrase candidates)", 0);
       const unsigned grid = (unsigned)((items + WG_WAVES - 1) / WG_WAVES);
       auto go = [&](auto kern) {
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(WG_THREADS), 0, stream, sv, d_q, d_t, d_ip, (int)n_queries, items, blocks_per_item, k_emit,
+        RGPU_LAUNCH(kern, dim3(grid), dim3(WG_THREADS), 0, stream, sv, d_q, d_t, d_ip, (int)n_queries, items, blocks_per_item, k_emit,
                            c->S->d_partial_keys.p, c->S->d_partial_counts.p, c->S->d_tau.p, c->S->d_touched.p, d_ep, c->phrase_count.p,
                            (void*)c->phrase_docs.p, (const unsigned long long*)nullptr, (const int32_t*)nullptr,
                            clause_bitmaps.empty() ? (const TermBitmap*)nullptr : reinterpret_cast<const TermBitmap*>(c->S->d_stage.p + o_bm));
@@ -2771,14 +2796,24 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
       // One wavefront per candidate slot, first with the small position lists / pools (seven wavefronts per SIMD). A doc that holds
       // a term more often than those hold positions (rare: Rucene clamps freqs to 10) leaves PHRASE_REDO in its slot: one look at
       // the flag, then the wide instantiations over the marked candidates only.
-      const unsigned grid = (unsigned)((slots + WG_WAVES - 1) / WG_WAVES);
+      // (one wavefront per slot: at most PHRASE_LAUNCH_SLOTS slots per launch — a grid of more than 2^32 work-items is cut short)
+      auto per_slot = [&](int64_t n, auto launch) {
+        for (int64_t s0 = 0; s0 < n; s0 += PHRASE_LAUNCH_SLOTS) {
+          const int64_t s1 = std::min(n, s0 + PHRASE_LAUNCH_SLOTS);
+          launch(dim3((unsigned)((s1 - s0 + WG_WAVES - 1) / WG_WAVES)), s0, s1);
+        }
+      };
       auto exact = [&](auto kern) {
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(WG_THREADS), 0, stream, sv, d_q, d_t, d_pt, d_ep, c->phrase_count.p, c->phrase_docs.p, d_sl,
-                           (int)n_queries, slots, (int64_t)seg->pos_len, c->phrase_keys.p, c->d_err, c->d_err + 3, (const int64_t*)nullptr);
+        per_slot(slots, [&](dim3 grid, int64_t s0, int64_t s1) {
+          RGPU_LAUNCH(kern, grid, dim3(WG_THREADS), 0, stream, sv, d_q, d_t, d_pt, d_ep, c->phrase_count.p, c->phrase_docs.p, d_sl, (int)n_queries, s1,
+                      (int64_t)seg->pos_len, c->phrase_keys.p, c->d_err, c->d_err + 3, (const int64_t*)nullptr, s0);
+        });
       };
       auto sloppy = [&](auto kern) {
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(WG_THREADS), 0, stream, sv, d_q, d_t, d_pt, d_ep, c->phrase_count.p, c->phrase_docs.p, d_sl, d_gr,
-                           (int)n_queries, slots, (int64_t)seg->pos_len, c->phrase_keys.p, c->d_err, c->d_err + 3);
+        per_slot(slots, [&](dim3 grid, int64_t s0, int64_t s1) {
+          RGPU_LAUNCH(kern, grid, dim3(WG_THREADS), 0, stream, sv, d_q, d_t, d_pt, d_ep, c->phrase_count.p, c->phrase_docs.p, d_sl, d_gr, (int)n_queries, s1,
+                      (int64_t)seg->pos_len, c->phrase_keys.p, c->d_err, c->d_err + 3, s0);
+        });
       };
       if (any_exact) {
         if (legacy) {  // (.doc version 0: the packed streams of a block are laid out differently — one candidate per wavefront)
@@ -2787,9 +2822,9 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
         } else {
           TimedLaunch tl(c, stream, "k_phrase_match_lanes", 0);
           const int64_t groups = slots / 64;
-          hipLaunchKernelGGL(k_phrase_match_lanes, dim3((unsigned)((groups + WG_WAVES - 1) / WG_WAVES)), dim3(WG_THREADS), 0, stream, sv, d_q, d_t, d_pt,
+          RGPU_LAUNCH(k_phrase_match_lanes, dim3((unsigned)((groups + WG_WAVES - 1) / WG_WAVES)), dim3(WG_THREADS), 0, stream, sv, d_q, d_t, d_pt,
                              d_ep, c->phrase_count.p, c->phrase_docs.p, d_sl, (int)n_queries, groups, (int64_t)seg->pos_len, c->phrase_keys.p,
-                             c->d_err + 3, c->phrase_redo.p, (int)std::min<int64_t>(slots, PHRASE_REDO_LIST_CAP), c->d_err + 2);
+                             c->d_err + 3, c->phrase_redo.p, (int)redo_cap, c->d_err + 2);
         }
       }
       if (any_sloppy) {  // SloppyPhraseScorer: the repetition groups of each query's first candidate doc, then the candidates
@@ -2797,7 +2832,7 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
           TimedLaunch tl(c, stream, "k_sloppy_groups", 0);
           const unsigned ggrid = (unsigned)((n_queries + WG_WAVES - 1) / WG_WAVES);
           auto go = [&](auto kern) {
-            hipLaunchKernelGGL(kern, dim3(ggrid), dim3(WG_THREADS), 0, stream, sv, d_q, d_t, d_pt, d_ep, c->phrase_count.p, c->phrase_docs.p, d_sl,
+            RGPU_LAUNCH(kern, dim3(ggrid), dim3(WG_THREADS), 0, stream, sv, d_q, d_t, d_pt, d_ep, c->phrase_count.p, c->phrase_docs.p, d_sl,
                                (int)n_queries, (int64_t)seg->pos_len, d_gr, c->d_err);
           };
           if (legacy) go(k_sloppy_groups<true>); else go(k_sloppy_groups<false>);
@@ -2818,12 +2853,13 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
       rc = redo_bits();
       if (rc != RGPU_OK) return rc;
       // the one-candidate kernel over the listed slots (or, should the list have overflowed, over every slot)
-      const bool by_list = (redo & PHRASE_REDO_LANES) && (int64_t)listed <= std::min<int64_t>(slots, PHRASE_REDO_LIST_CAP);
+      const bool by_list = (redo & PHRASE_REDO_LANES) && (int64_t)listed <= redo_cap;
       auto exact_redo = [&](auto kern) {
-        const int64_t n = by_list ? (int64_t)listed : slots;
-        hipLaunchKernelGGL(kern, dim3((unsigned)((n + WG_WAVES - 1) / WG_WAVES)), dim3(WG_THREADS), 0, stream, sv, d_q, d_t, d_pt, d_ep, c->phrase_count.p,
-                           c->phrase_docs.p, d_sl, (int)n_queries, n, (int64_t)seg->pos_len, c->phrase_keys.p, c->d_err, c->d_err + 3,
-                           by_list ? (const int64_t*)c->phrase_redo.p : (const int64_t*)nullptr);
+        per_slot(by_list ? (int64_t)listed : slots, [&](dim3 grid, int64_t s0, int64_t s1) {
+          RGPU_LAUNCH(kern, grid, dim3(WG_THREADS), 0, stream, sv, d_q, d_t, d_pt, d_ep, c->phrase_count.p, c->phrase_docs.p, d_sl, (int)n_queries, s1,
+                      (int64_t)seg->pos_len, c->phrase_keys.p, c->d_err, c->d_err + 3,
+                      by_list ? (const int64_t*)c->phrase_redo.p : (const int64_t*)nullptr, s0);
+        });
       };
       if (redo & PHRASE_REDO_LANES) {
         if (HostClock::on()) std::fprintf(stderr, "[phrase] %d of %lld candidate slots left for k_phrase_match\n", listed, (long long)slots);
@@ -2849,14 +2885,14 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
       {
       TimedLaunch tl(c, stream, "k_phrase_collect", 0);
       if (any_cutoff)
-        hipLaunchKernelGGL(k_phrase_cutoff, dim3((unsigned)((n_queries + WG_WAVES - 1) / WG_WAVES)), dim3(WG_THREADS), 0, stream, d_ep, c->phrase_count.p,
+        RGPU_LAUNCH(k_phrase_cutoff, dim3((unsigned)((n_queries + WG_WAVES - 1) / WG_WAVES)), dim3(WG_THREADS), 0, stream, d_ep, c->phrase_count.p,
                            c->phrase_keys.p, (const int32_t*)c->phrase_docs.p, d_sl, d_nl, (int)n_queries, d_ab);
       const unsigned grid = (unsigned)((collect_items + WG_WAVES - 1) / WG_WAVES);
       if (k > 64)
-        hipLaunchKernelGGL(k_phrase_collect_items<true>, dim3(grid), dim3(WG_THREADS), 0, stream, d_cp, d_ep, c->phrase_count.p, c->phrase_keys.p,
+        RGPU_LAUNCH(k_phrase_collect_items<true>, dim3(grid), dim3(WG_THREADS), 0, stream, d_cp, d_ep, c->phrase_count.p, c->phrase_keys.p,
                            (const int32_t*)d_ab, (int)n_queries, collect_items, (int)k, c->S->d_partial_keys.p, c->S->d_partial_counts.p);
       else
-        hipLaunchKernelGGL(k_phrase_collect_items<false>, dim3(grid), dim3(WG_THREADS), 0, stream, d_cp, d_ep, c->phrase_count.p, c->phrase_keys.p,
+        RGPU_LAUNCH(k_phrase_collect_items<false>, dim3(grid), dim3(WG_THREADS), 0, stream, d_cp, d_ep, c->phrase_count.p, c->phrase_keys.p,
                            (const int32_t*)d_ab, (int)n_queries, collect_items, (int)k, c->S->d_partial_keys.p, c->S->d_partial_counts.p);
       }
       if (k > 64) launch_merge<true>(c, stream, n_queries, k, d_cp, seg->doc_base, c->host_api_hits.p, c->host_api_totals.p);
@@ -2865,13 +2901,13 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
       TimedLaunch tl(c, stream, "k_phrase_collect", 0);
       const unsigned grid = (unsigned)((n_queries + WG_WAVES - 1) / WG_WAVES);
       if (k > 64)
-        hipLaunchKernelGGL(k_phrase_collect<true>, dim3(grid), dim3(WG_THREADS), 0, stream, d_ep, c->phrase_count.p, c->phrase_keys.p,
+        RGPU_LAUNCH(k_phrase_collect<true>, dim3(grid), dim3(WG_THREADS), 0, stream, d_ep, c->phrase_count.p, c->phrase_keys.p,
                            (const int32_t*)c->phrase_docs.p, d_sl, d_nl, (int)n_queries, (int)k, seg->doc_base, c->host_api_hits.p, c->host_api_totals.p);
       else
-        hipLaunchKernelGGL(k_phrase_collect<false>, dim3(grid), dim3(WG_THREADS), 0, stream, d_ep, c->phrase_count.p, c->phrase_keys.p,
+        RGPU_LAUNCH(k_phrase_collect<false>, dim3(grid), dim3(WG_THREADS), 0, stream, d_ep, c->phrase_count.p, c->phrase_keys.p,
                            (const int32_t*)c->phrase_docs.p, d_sl, d_nl, (int)n_queries, (int)k, seg->doc_base, c->host_api_hits.p, c->host_api_totals.p);
     }
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(launch_status());
   }
   int err = 0;
   hipError_t e0 = items > 0 ? hipMemcpyAsync(&err, c->d_err, sizeof(int), hipMemcpyDeviceToHost, stream) : hipSuccess;
@@ -2958,14 +2994,14 @@ extern "C" int32_t rgpu_rescore_batch(rgpu_segment* seg, const rgpu_query* queri
   {
     TimedLaunch tl(c, stream, "k_rescore", 0);
     const unsigned grid = (unsigned)((n_hits + WG_WAVES - 1) / WG_WAVES);
-    if (seg->version < 1) hipLaunchKernelGGL(k_rescore<true>, dim3(grid), dim3(WG_THREADS), 0, stream, seg_view(seg), d_q, d_t, d_r, (int)n_queries, (int)k, c->host_api_hits.p, finish ? 1 : 0);
-    else hipLaunchKernelGGL(k_rescore<false>, dim3(grid), dim3(WG_THREADS), 0, stream, seg_view(seg), d_q, d_t, d_r, (int)n_queries, (int)k, c->host_api_hits.p, finish ? 1 : 0);
+    if (seg->version < 1) RGPU_LAUNCH(k_rescore<true>, dim3(grid), dim3(WG_THREADS), 0, stream, seg_view(seg), d_q, d_t, d_r, (int)n_queries, (int)k, c->host_api_hits.p, finish ? 1 : 0);
+    else RGPU_LAUNCH(k_rescore<false>, dim3(grid), dim3(WG_THREADS), 0, stream, seg_view(seg), d_q, d_t, d_r, (int)n_queries, (int)k, c->host_api_hits.p, finish ? 1 : 0);
   }
   if (finish) {
     TimedLaunch tl(c, stream, "k_rescore_sort", 0);
-    hipLaunchKernelGGL(k_rescore_sort, dim3((unsigned)((n_queries + WG_WAVES - 1) / WG_WAVES)), dim3(WG_THREADS), 0, stream, d_r, (int)n_queries, (int)k, c->host_api_hits.p);
+    RGPU_LAUNCH(k_rescore_sort, dim3((unsigned)((n_queries + WG_WAVES - 1) / WG_WAVES)), dim3(WG_THREADS), 0, stream, d_r, (int)n_queries, (int)k, c->host_api_hits.p);
   }
-  HIP_TRY(hipGetLastError());
+  HIP_TRY(launch_status());
   HIP_TRY(hipMemcpyAsync(hits_inout, c->host_api_hits.p, n_hits * sizeof(HitOut), hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipStreamSynchronize(stream));
   return RGPU_OK;
@@ -3101,10 +3137,10 @@ static int32_t search_into_record(rgpu_segment* seg, const rgpu_query* queries, 
   };
   if (rc != RGPU_OK) {  // whatever was enqueued before the failure is overwritten behind it on the same stream
     note(hipMemsetAsync(record + hits_bytes, 0, (size_t)n_queries * 8, s), "hipMemsetAsync(record counts)");
-    hipLaunchKernelGGL(k_init_hits, dim3((unsigned)(((size_t)n_queries * k + 255) / 256)), dim3(256), 0, s, (HitOut*)record, (int64_t)n_queries, (int)k, (int)k, 0);
+    RGPU_LAUNCH(k_init_hits, dim3((unsigned)(((size_t)n_queries * k + 255) / 256)), dim3(256), 0, s, (HitOut*)record, (int64_t)n_queries, (int)k, (int)k, 0);
     note(hipGetLastError(), "k_init_hits");
   }
-  hipLaunchKernelGGL(k_set_i64, dim3(1), dim3(1), 0, s, (int64_t*)(record + hits_bytes + (size_t)n_queries * 8), (int64_t)rc);
+  RGPU_LAUNCH(k_set_i64, dim3(1), dim3(1), 0, s, (int64_t*)(record + hits_bytes + (size_t)n_queries * 8), (int64_t)rc);
   const hipError_t e_status = hipGetLastError();
   if (e_status != hipSuccess) {  // the launch itself was refused: put the word there with a copy from the host instead
     const int64_t word = rc != RGPU_OK ? (int64_t)rc : (int64_t)RGPU_ERR_RUNTIME;
@@ -3135,12 +3171,12 @@ static int32_t merge_records(rgpu_ctx* c, const uint8_t* records, int32_t n_rank
     TimedLaunch tl(c, s, "k_merge_lists", 0);
     const unsigned grid = (unsigned)((n_queries + WG_WAVES - 1) / WG_WAVES);
     auto go = [&](auto kern) {
-      hipLaunchKernelGGL(kern, dim3(grid), dim3(WG_THREADS), 0, s, (const HitOut*)records, (const int64_t*)(records + hits_bytes),
+      RGPU_LAUNCH(kern, dim3(grid), dim3(WG_THREADS), 0, s, (const HitOut*)records, (const int64_t*)(records + hits_bytes),
                          (int64_t)(record / sizeof(HitOut)), (int64_t)(record / 8), n_ranks, n_queries, (int)k, hits_dev, totals_dev);
     };
     if (k > 64) go(k_merge_lists<true>); else go(k_merge_lists<false>);
   }
-  HIP_TRY(hipGetLastError());
+  HIP_TRY(launch_status());
   return RGPU_OK;
 }
 

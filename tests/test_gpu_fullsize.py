@@ -105,3 +105,38 @@ def test_conjunction_sample_equals_the_oracle_at_full_size(full, oracle):
 
 def test_disjunction_sample_matches_the_oracle_at_full_size(full, oracle):
     _against_oracle(full, oracle, "or10", 64, 100)
+
+
+# ---- phrases at full size: the whole batch of bench.py's configs.positions.phrase2 ---------------------------------------------------
+def test_phrase_batch_equals_the_oracle_at_full_size(oracle):
+    """1024 two-term exact phrases (bench.py's own batch: ranks log-uniform 1..1000, ~100 M candidate slots) + sloppy ones behind them,
+    over the 10 M-doc corpus indexed with positions, EVERY query against the oracle's ExactPhraseScorer / SloppyPhraseScorer: hit
+    counts, doc ids, score bits. The size matters: a grid is described to the hardware in 32-bit work-item counts, and a kernel
+    that takes one wavefront per candidate slot runs out of them at 67 M slots — round 4 found the exact-phrase kernel silently
+    skipping everything behind that (568 of these 1024 queries answered short) while the first 96, all the bench compared, were fine."""
+    import rucene_amd
+    from rucene_amd import indexgen
+    import bench
+    seg = indexgen.build_zipf(10_000_000, 1_000_000, positions=True)
+    ctx = rucene_amd.Context()
+    try:
+        leaf = rucene_amd.LeafReader.from_synthetic_positions(seg)
+        searcher = rucene_amd.GpuIndexSearcher([leaf], ctx=ctx)
+        ranks = indexgen.log_uniform_ranks(2 * 1024, 1, 1000, bench.SEED_QUERIES ^ 0xF2).reshape(-1, 2) - 1
+        # the sloppy queries come last: their slots lie behind the 2^32 / 64 mark of the batch
+        sloppy = [(int(a), int(b), 1 + i % 3) for i, (a, b) in enumerate(ranks[600:664])]
+        queries = [rucene_amd.PhraseQuery([int(a), int(b)]) for a, b in ranks] + [rucene_amd.PhraseQuery([a, b], slop=sl) for a, b, sl in sloppy]
+        k = 10
+        hits, totals = searcher.search_phrase_batch(queries, k)
+        ix = oracle.PositionsIndex.from_files(seg.doc_bytes, seg.pos_bytes, seg.terms, leaf.term_positions)
+        try:
+            for i, q in enumerate(queries):
+                d, s, total = ix.phrase_search(q.terms, k, seg.norms, seg.max_doc, seg.doc_count, seg.sum_total_term_freq, slop=q.slop)
+                assert totals[i] == total, (i, q.terms, q.slop, int(totals[i]), total)
+                assert (hits[i]["doc"][:d.size] == d).all() and (hits[i]["doc"][d.size:] == -1).all(), (i, q.terms, q.slop)
+                assert (hits[i]["score"][:d.size].view(np.int32) == s.view(np.int32)).all(), (i, q.terms, q.slop)
+        finally:
+            ix.close()
+        assert int(totals[:1024].sum()) > 1_000_000
+    finally:
+        ctx.close()

@@ -1194,6 +1194,17 @@ def test_exact_phrases(ctx, oracle, version, max_doc):
             assert totals[i] == total, (i, q.terms, totals[i], total)
             assert (hits[i]["doc"][:d.size] == d).all() and (hits[i]["doc"][d.size:] == -1).all(), (i, q.terms)
             assert (hits[i]["score"][:d.size].view(np.int32) == s.view(np.int32)).all(), (i, q.terms)
+    # the candidates the 64-per-wavefront kernel leaves for the one-per-wavefront kernel (docs in a term's trailing VInt position
+    # block, docs 5 and 4000 with their hundreds of positions) travel in a list of slots; with the list capped below their number
+    # that pass looks at every slot instead
+    hits1, totals1 = searcher.search_phrase_batch(queries, 10)
+    os.environ["RGPU_PHRASE_REDO_CAP"] = "3"
+    try:
+        hits2, totals2 = searcher.search_phrase_batch(queries, 10)
+    finally:
+        del os.environ["RGPU_PHRASE_REDO_CAP"]
+    assert (totals2 == totals1).all() and (hits2["doc"] == hits1["doc"]).all()
+    assert (hits2["score"].view(np.int32) == hits1["score"].view(np.int32)).all()
     # ---- sloppy phrases (the other half): SloppyPhraseScorer — the priority-queue walk over the terms' positions,
     # repeated terms with the reference's collision handling (and its BinaryHeap's array order), groups found on the first
     # candidate doc — against oracle/sloppy_phrase.hpp: doc ids, hit counts, BM25(sloppy freq) score bits. Exact and sloppy
