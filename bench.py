@@ -552,7 +552,7 @@ def main():
         ph = {"workload": "%d x two-term exact PhraseQuery top-%d, ranks log-uniform 1..1000, %d M docs with positions" % (n_phrases, k, docs // 1_000_000),
               "k": k, "ms_per_step": ms_step, "queries_per_sec": n_phrases / (ms_step * 1e-3), "issue": "blocking call, host outputs",
               "kernels_ms": {n: v["total_ms"] / max(1, v["launches"]) for n, v in st.items() if v["total_ms"] > 0},
-              "conjunction_matches_checked_per_step": int(sum(min(int(seg.terms["doc_freq"][a]), int(seg.terms["doc_freq"][b2])) for a, b2 in ranks)),
+              "lead_postings_per_step": int(sum(min(int(seg.terms["doc_freq"][a]), int(seg.terms["doc_freq"][b2])) for a, b2 in ranks)),
               "phrase_hits_per_step": int(totals.sum())}
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             from oracle import binding as orc   # the checker, after the timed region

@@ -35,6 +35,6 @@ for k, c in d.get("configs", {}).items():
         cfg("  positions_decode", c["positions_decode"])
         print("   ", {x: c["positions_decode"].get(x) for x in ("positions", "positions_decoded_per_sec", "parity_vs_oracle")})
         cfg("  phrase2", c["phrase2"])
-        print("   ", {x: c["phrase2"].get(x) for x in ("conjunction_matches_checked_per_step", "phrase_hits_per_step", "cpu_baseline")})
+        print("   ", {x: c["phrase2"].get(x) for x in ("lead_postings_per_step", "phrase_hits_per_step", "cpu_baseline")})
     else:
         cfg(k, c)
