@@ -57,6 +57,8 @@ static inline hipError_t launch_status() {
   }
   return hipGetLastError();
 }
+// a workgroup count: saturates instead of wrapping (RGPU_LAUNCH then refuses the launch)
+static inline unsigned wg_count(unsigned long long n) { return n > 0xffffffffull ? 0xffffffffu : (unsigned)n; }
 #define RGPU_LAUNCH(kern, grid, block, shmem, stream, ...)                                                  \
   do {                                                                                                     \
     const dim3 g_ = (grid), b_ = (block);                                                                  \
@@ -527,11 +529,11 @@ static int32_t prepare_terms_attempt(rgpu_segment* seg, const rgpu_term_state* c
   const int64_t* d_chunks = reinterpret_cast<const int64_t*>(c->S->d_stage.p + o_chunks);
   const int64_t* d_groups = reinterpret_cast<const int64_t*>(c->S->d_stage.p + o_groups);
   const bool legacy = seg->version < 1;
-  const unsigned item_grid = (unsigned)((n_items + PREP_WAVES - 1) / PREP_WAVES);
+  const unsigned item_grid = wg_count((n_items + PREP_WAVES - 1) / PREP_WAVES);
   {
     TimedLaunch tl(c, c->stream, "k_skip_dir", postings);
-    const dim3 grid((unsigned)((n_chunks + PREP_WAVES - 1) / PREP_WAVES));
-    RGPU_LAUNCH(k_skip_terms, dim3((unsigned)((work.size() + PREP_THREADS - 1) / PREP_THREADS)), dim3(PREP_THREADS), 0, c->stream, seg->d_doc,
+    const dim3 grid(wg_count((n_chunks + PREP_WAVES - 1) / PREP_WAVES));
+    RGPU_LAUNCH(k_skip_terms, dim3(wg_count((work.size() + PREP_THREADS - 1) / PREP_THREADS)), dim3(PREP_THREADS), 0, c->stream, seg->d_doc,
                        (int64_t)seg->doc_len, d_work, (int)work.size(), d_l0, seg->dir_last.p, seg->dir_off.p,
                        seg->has_positions ? seg->dir_pos.p : nullptr, seg->skip_vals, c->d_err);
     if (n_chunks > 0) {  // the terms whose level 0 one lane does not finish
@@ -542,7 +544,7 @@ static int32_t prepare_terms_attempt(rgpu_segment* seg, const rgpu_term_state* c
       };
       auto groups = [&](auto kern) {
         if (n_groups > 0)
-          RGPU_LAUNCH(kern, dim3((unsigned)((n_groups + PREP_WAVES - 1) / PREP_WAVES)), dim3(PREP_THREADS), 0, c->stream, d_chunks,
+          RGPU_LAUNCH(kern, dim3(wg_count((n_groups + PREP_WAVES - 1) / PREP_WAVES)), dim3(PREP_THREADS), 0, c->stream, d_chunks,
                              d_groups, (int)work.size(), n_groups, d_aggs, d_gaggs);
       };
       switch (seg->skip_vals) {  // values per level-0 skip entry (prepare.hpp, A1)
@@ -556,7 +558,7 @@ static int32_t prepare_terms_attempt(rgpu_segment* seg, const rgpu_term_state* c
   {
     TimedLaunch tl(c, c->stream, "k_block_headers", postings);
     auto go = [&](auto kern) {
-      RGPU_LAUNCH(kern, dim3((unsigned)((n_slots + PREP_THREADS - 1) / PREP_THREADS)), dim3(PREP_THREADS), 0, c->stream, seg->d_doc,
+      RGPU_LAUNCH(kern, dim3(wg_count((n_slots + PREP_THREADS - 1) / PREP_THREADS)), dim3(PREP_THREADS), 0, c->stream, seg->d_doc,
                          (int64_t)seg->doc_len, d_work, (int)work.size(), (uint32_t)seg->dir_used, (int64_t)n_slots, seg->dir_last.p, seg->dir_off.p,
                          seg->dir_row.p, seg->dir_hdr.p, seg->has_freqs ? 1 : 0, c->d_err);
     };
@@ -648,7 +650,7 @@ static int32_t prepare_norms_locked(rgpu_segment* seg, const rgpu_term_state* co
   HIP_TRY(hipMemcpyAsync(c->S->d_stage.p, c->S->h_stage.p, st.used, hipMemcpyHostToDevice, c->stream));
   {
     TimedLaunch tl(c, c->stream, "k_prepare_norms", postings);
-    const unsigned grid = (unsigned)((n_items + PREP_WAVES - 1) / PREP_WAVES);
+    const unsigned grid = wg_count((n_items + PREP_WAVES - 1) / PREP_WAVES);
     auto go = [&](auto kern) {
       RGPU_LAUNCH(kern, dim3(grid), dim3(PREP_THREADS), 0, c->stream, seg_view(seg), reinterpret_cast<const PrepTerm*>(c->S->d_stage.p + o_work),
                          reinterpret_cast<const int64_t*>(c->S->d_stage.p + o_items), (int)work.size(), n_items, seg->pnorm.p, seg->dir_bmax.p,
@@ -1054,7 +1056,7 @@ static int32_t decode_terms_impl(rgpu_segment* seg, const rgpu_term_state* terms
   hitems[nr] = items;
   hout[nr] = out;
   HIP_TRY(hipMemcpyAsync(c->S->d_stage.p, c->S->h_stage.p, st.used, hipMemcpyHostToDevice, stream));
-  const unsigned grid = (unsigned)((items + WG_WAVES - 1) / WG_WAVES);
+  const unsigned grid = wg_count((items + WG_WAVES - 1) / WG_WAVES);
   {
     TimedLaunch tl(c, stream, "k_decode_terms", postings);
     auto args = [&](auto kern) {
@@ -1125,7 +1127,7 @@ extern "C" int32_t rgpu_advance_batch(rgpu_segment* seg, const rgpu_term_state* 
   hipError_t e = hipMemcpyAsync(d, targets, (size_t)n * 4, hipMemcpyHostToDevice, c->stream);
   if (e == hipSuccess) {
     TimedLaunch tl(c, c->stream, "k_advance", n);
-    const unsigned grid = (unsigned)((n + WG_WAVES - 1) / WG_WAVES);
+    const unsigned grid = wg_count((n + WG_WAVES - 1) / WG_WAVES);
     if (seg->version >= 1)
       RGPU_LAUNCH(k_advance<false>, dim3(grid), dim3(WG_THREADS), 0, c->stream, seg_view(seg), T, d, n, d + n, d + 2 * n);
     else
@@ -1211,11 +1213,11 @@ static int32_t ensure_bitmaps_locked(rgpu_segment* seg, const rgpu_term_state* c
       if (rc != RGPU_OK) return rc;
       {
         TimedLaunch tl(c, c->stream, "k_bitmap_build", (int64_t)df);
-        RGPU_LAUNCH(k_bitmap_fill, dim3((unsigned)((df + 255) / 256)), dim3(256), 0, c->stream, docs, freqs, (int64_t)df, seg->max_doc,
+        RGPU_LAUNCH(k_bitmap_fill, dim3(wg_count((df + 255) / 256)), dim3(256), 0, c->stream, docs, freqs, (int64_t)df, seg->max_doc,
                            (const uint8_t*)seg->d_norms, (const float*)(c->sim_tables.p + (size_t)sim_tables[i] * 257),
                            seg->n_norm_ranks > 0 ? (const uint8_t*)seg->d_rank_to_norm : (const uint8_t*)nullptr, info.words, info.freqs, info.ovf, d_stats, info.nib);
         const int64_t n_scan = n_words + 1;  // ranks[n_words] = the list's size
-        RGPU_LAUNCH(k_bitmap_popc, dim3((unsigned)((n_scan + 255) / 256)), dim3(256), 0, c->stream, info.words, n_scan, info.ranks);
+        RGPU_LAUNCH(k_bitmap_popc, dim3(wg_count((n_scan + 255) / 256)), dim3(256), 0, c->stream, info.words, n_scan, info.ranks);
         const int64_t n_tiles = (n_scan + SCAN_TILE - 1) / SCAN_TILE;
         HIP_TRY(seg->prep_scratch.reserve(64 + (size_t)n_tiles * 8 + 64, 0, c->stream));
         unsigned long long* d_total = reinterpret_cast<unsigned long long*>(seg->prep_scratch.p);
@@ -1281,7 +1283,7 @@ static void launch_merge(rgpu_ctx* c, hipStream_t s, int n_queries, int k, const
                          int64_t* totals, int head_items = 0, const int2* fixed_info = nullptr, int32_t* low_flags = nullptr,
                          const int32_t* qmap = nullptr) {
   TimedLaunch tl(c, s, "k_merge_items", 0);
-  const unsigned grid = (unsigned)((n_queries + WG_WAVES - 1) / WG_WAVES);
+  const unsigned grid = wg_count((n_queries + WG_WAVES - 1) / WG_WAVES);
   RGPU_LAUNCH(k_merge_items<WIDE>, dim3(grid), dim3(WG_THREADS), 0, s, d_prefix, n_queries, k, c->S->d_partial_keys.p,
                      c->S->d_partial_counts.p, doc_base, head_items, hits, totals, fixed_info, low_flags, qmap, c->pass.stride, c->pass.col0,
                      c->pass.ceil_out);
@@ -1380,7 +1382,7 @@ static int32_t search_or_group(rgpu_segment* seg, Group& G, int32_t k, HitOut* h
   const SegView sv = seg_view(seg);
   {
     TimedLaunch tl(c, stream, "k_score_terms", G.postings);
-    const unsigned grid = (unsigned)((items1 + WG_WAVES - 1) / WG_WAVES);
+    const unsigned grid = wg_count((items1 + WG_WAVES - 1) / WG_WAVES);
     if (legacy)
       RGPU_LAUNCH(k_score_terms<true>, dim3(grid), dim3(WG_THREADS), 0, stream, sv, dt, dip, drp, nt, items1, blocks_per_item, c->d_runs.p);
     else
@@ -1698,7 +1700,7 @@ static int32_t search_or_lazy_group(rgpu_segment* seg, Group& G, int32_t k, HitO
     c->last_counted_or_bytes = touched_bytes;
     if (nu > 0) {
       TimedLaunch tl(c, stream, "k_score_terms", walked_postings);
-      const unsigned grid = (unsigned)((items1 + WG_WAVES - 1) / WG_WAVES);
+      const unsigned grid = wg_count((items1 + WG_WAVES - 1) / WG_WAVES);
       const DevTerm* dt = reinterpret_cast<const DevTerm*>(c->S->d_stage.p + o_t);
       const int64_t* dip = reinterpret_cast<const int64_t*>(c->S->d_stage.p + o_ip);
       const int64_t* drp = reinterpret_cast<const int64_t*>(c->S->d_stage.p + o_rp);
@@ -1901,7 +1903,7 @@ static int32_t search_or_wide_group(rgpu_segment* seg, Group& G, int32_t k, HitO
   {
     TimedLaunch tl(c, stream, "k_or_wide", G.postings);
     const size_t lds = orx_lds_bytes(WS);
-    const unsigned grid = (unsigned)((int64_t)nq * ipq);
+    const unsigned grid = wg_count((int64_t)nq * ipq);
     auto go = [&](auto kern) -> hipError_t {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
@@ -2158,7 +2160,7 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
   // its merge writes every row (the usual serving case: two enqueues less per batch)
   auto init_rows = [&]() -> int32_t {
     HIP_TRY(hipMemsetAsync(totals_dev, 0, (size_t)n_queries * 8, stream));
-    RGPU_LAUNCH(k_init_hits, dim3((unsigned)(((size_t)n_queries * k + 255) / 256)), dim3(256), 0, stream, hits_dev,
+    RGPU_LAUNCH(k_init_hits, dim3(wg_count(((size_t)n_queries * k + 255) / 256)), dim3(256), 0, stream, hits_dev,
                        (int64_t)n_queries, (int)k, c->pass.stride > 0 ? c->pass.stride : (int)k, c->pass.col0);
     if (c->pass.ceil_out) HIP_TRY(hipMemsetAsync(c->pass.ceil_out, 0, (size_t)n_queries * 8, stream));  // rows no group writes have nothing below
     return RGPU_OK;
@@ -2303,7 +2305,7 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
       c->last_counted_loose = 0;
       for (const DevQuery& q0 : G.queries) if (q0.n_terms >= 1) { const DevTerm& t0 = G.terms[(size_t)q0.first_term]; c->last_counted_loose += t0.df == 1 ? 1 : t0.tail_n; }
       TimedLaunch tl(c, stream, "k_search_and", G.postings);
-      const unsigned grid = (unsigned)((items + WG_WAVES - 1) / WG_WAVES);
+      const unsigned grid = wg_count((items + WG_WAVES - 1) / WG_WAVES);
       const int64_t* d_sp = nullptr;
       void* d_seq = nullptr;
       if (G.req_opt) {  // records instead of a collector (the buffer is the context's run scratch: this group ends with a stream sync)
@@ -2341,7 +2343,7 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
       c->last_counted_loose = 0;
       for (const DevTerm& t0 : G.terms) { c->last_counted_dir_blocks += t0.nblocks; c->last_counted_loose += t0.df == 1 ? 1 : t0.tail_n; }
       TimedLaunch tl(c, stream, "k_search_term", G.postings);
-      const unsigned grid = (unsigned)((items + TERM_WAVES - 1) / TERM_WAVES);
+      const unsigned grid = wg_count((items + TERM_WAVES - 1) / TERM_WAVES);
       const size_t lds = term_lds_bytes(wide);
       auto go = [&](auto kern) -> hipError_t {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -2357,7 +2359,7 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
     }
     if (G.req_opt) {  // the scan is the collector: rows written in place
       TimedLaunch tl(c, stream, "k_req_opt_scan", G.postings);
-      const unsigned grid = (unsigned)((nq + WG_WAVES - 1) / WG_WAVES);
+      const unsigned grid = wg_count((nq + WG_WAVES - 1) / WG_WAVES);
       const SeqRec* d_seq = reinterpret_cast<const SeqRec*>(c->d_runs.p);
       const int64_t* d_sp = reinterpret_cast<const int64_t*>(c->S->d_stage.p + o_sp);
       if (wide) RGPU_LAUNCH(k_req_opt_scan<true>, dim3(grid), dim3(WG_THREADS), 0, stream, d_seq, d_sp, nq, (int)k, seg->doc_base, dm, hits_dev, totals_dev,
@@ -2425,7 +2427,7 @@ extern "C" int32_t rgpu_merge_topk_device(rgpu_ctx* c, const void* hits_dev, con
   hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
   {
     TimedLaunch tl(c, s, "k_merge_lists", 0);
-    const unsigned grid = (unsigned)((n_queries + WG_WAVES - 1) / WG_WAVES);
+    const unsigned grid = wg_count((n_queries + WG_WAVES - 1) / WG_WAVES);
     if (k > 64)
       RGPU_LAUNCH(k_merge_lists<true>, dim3(grid), dim3(WG_THREADS), 0, s, (const HitOut*)hits_dev, (const int64_t*)totals_dev,
                          (int64_t)n_queries * k, (int64_t)n_queries, n_lists, n_queries, k, (HitOut*)hits_out_dev, (int64_t*)totals_out_dev);
@@ -2546,7 +2548,7 @@ static int32_t decode_positions_impl(rgpu_segment* seg, const rgpu_term_state* t
   unsigned long long* d_total = c->pos_tiles.p + 1;
   const SegView sv = seg_view(seg);
   const bool legacy = seg->version < 1;
-  const unsigned grid = (unsigned)((items + WG_WAVES - 1) / WG_WAVES);
+  const unsigned grid = wg_count((items + WG_WAVES - 1) / WG_WAVES);
   {
     TimedLaunch tl(c, stream, "k_pos_counts", expect);
     if (legacy) RGPU_LAUNCH(k_pos_counts<true>, dim3(grid), dim3(WG_THREADS), 0, stream, sv, d_t, d_ip, nt, items, c->pos_counts.p);
@@ -2709,7 +2711,7 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
   HIP_TRY(c->host_api_hits.reserve((size_t)n_queries * (size_t)k, 0, stream));
   HIP_TRY(c->host_api_totals.reserve((size_t)n_queries, 0, stream));
   HIP_TRY(hipMemsetAsync(c->host_api_totals.p, 0, (size_t)n_queries * 8, stream));
-  RGPU_LAUNCH(k_init_hits, dim3((unsigned)(((size_t)n_queries * k + 255) / 256)), dim3(256), 0, stream, c->host_api_hits.p, (int64_t)n_queries, (int)k, (int)k, 0);
+  RGPU_LAUNCH(k_init_hits, dim3(wg_count(((size_t)n_queries * k + 255) / 256)), dim3(256), 0, stream, c->host_api_hits.p, (int64_t)n_queries, (int)k, (int)k, 0);
   if (items > 0) {
     HIP_TRY(scratch_take(c));
     Stager st(c);
@@ -2780,7 +2782,7 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
     const bool legacy = seg->version < 1;
     {
       TimedLaunch tl(c, stream, "k_search_and(phrase candidates)", 0);
-      const unsigned grid = (unsigned)((items + WG_WAVES - 1) / WG_WAVES);
+      const unsigned grid = wg_count((items + WG_WAVES - 1) / WG_WAVES);
       auto go = [&](auto kern) {
         RGPU_LAUNCH(kern, dim3(grid), dim3(WG_THREADS), 0, stream, sv, d_q, d_t, d_ip, (int)n_queries, items, blocks_per_item, k_emit,
                            c->S->d_partial_keys.p, c->S->d_partial_counts.p, c->S->d_tau.p, c->S->d_touched.p, d_ep, c->phrase_count.p,
@@ -2800,7 +2802,7 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
       auto per_slot = [&](int64_t n, auto launch) {
         for (int64_t s0 = 0; s0 < n; s0 += PHRASE_LAUNCH_SLOTS) {
           const int64_t s1 = std::min(n, s0 + PHRASE_LAUNCH_SLOTS);
-          launch(dim3((unsigned)((s1 - s0 + WG_WAVES - 1) / WG_WAVES)), s0, s1);
+          launch(dim3(wg_count((s1 - s0 + WG_WAVES - 1) / WG_WAVES)), s0, s1);
         }
       };
       auto exact = [&](auto kern) {
@@ -2822,7 +2824,7 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
         } else {
           TimedLaunch tl(c, stream, "k_phrase_match_lanes", 0);
           const int64_t groups = slots / 64;
-          RGPU_LAUNCH(k_phrase_match_lanes, dim3((unsigned)((groups + WG_WAVES - 1) / WG_WAVES)), dim3(WG_THREADS), 0, stream, sv, d_q, d_t, d_pt,
+          RGPU_LAUNCH(k_phrase_match_lanes, dim3(wg_count((groups + WG_WAVES - 1) / WG_WAVES)), dim3(WG_THREADS), 0, stream, sv, d_q, d_t, d_pt,
                              d_ep, c->phrase_count.p, c->phrase_docs.p, d_sl, (int)n_queries, groups, (int64_t)seg->pos_len, c->phrase_keys.p,
                              c->d_err + 3, c->phrase_redo.p, (int)redo_cap, c->d_err + 2);
         }
@@ -2830,7 +2832,7 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
       if (any_sloppy) {  // SloppyPhraseScorer: the repetition groups of each query's first candidate doc, then the candidates
         {
           TimedLaunch tl(c, stream, "k_sloppy_groups", 0);
-          const unsigned ggrid = (unsigned)((n_queries + WG_WAVES - 1) / WG_WAVES);
+          const unsigned ggrid = wg_count((n_queries + WG_WAVES - 1) / WG_WAVES);
           auto go = [&](auto kern) {
             RGPU_LAUNCH(kern, dim3(ggrid), dim3(WG_THREADS), 0, stream, sv, d_q, d_t, d_pt, d_ep, c->phrase_count.p, c->phrase_docs.p, d_sl,
                                (int)n_queries, (int64_t)seg->pos_len, d_gr, c->d_err);
@@ -2885,9 +2887,9 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
       {
       TimedLaunch tl(c, stream, "k_phrase_collect", 0);
       if (any_cutoff)
-        RGPU_LAUNCH(k_phrase_cutoff, dim3((unsigned)((n_queries + WG_WAVES - 1) / WG_WAVES)), dim3(WG_THREADS), 0, stream, d_ep, c->phrase_count.p,
+        RGPU_LAUNCH(k_phrase_cutoff, dim3(wg_count((n_queries + WG_WAVES - 1) / WG_WAVES)), dim3(WG_THREADS), 0, stream, d_ep, c->phrase_count.p,
                            c->phrase_keys.p, (const int32_t*)c->phrase_docs.p, d_sl, d_nl, (int)n_queries, d_ab);
-      const unsigned grid = (unsigned)((collect_items + WG_WAVES - 1) / WG_WAVES);
+      const unsigned grid = wg_count((collect_items + WG_WAVES - 1) / WG_WAVES);
       if (k > 64)
         RGPU_LAUNCH(k_phrase_collect_items<true>, dim3(grid), dim3(WG_THREADS), 0, stream, d_cp, d_ep, c->phrase_count.p, c->phrase_keys.p,
                            (const int32_t*)d_ab, (int)n_queries, collect_items, (int)k, c->S->d_partial_keys.p, c->S->d_partial_counts.p);
@@ -2899,7 +2901,7 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
       else launch_merge<false>(c, stream, n_queries, k, d_cp, seg->doc_base, c->host_api_hits.p, c->host_api_totals.p);
     } else {
       TimedLaunch tl(c, stream, "k_phrase_collect", 0);
-      const unsigned grid = (unsigned)((n_queries + WG_WAVES - 1) / WG_WAVES);
+      const unsigned grid = wg_count((n_queries + WG_WAVES - 1) / WG_WAVES);
       if (k > 64)
         RGPU_LAUNCH(k_phrase_collect<true>, dim3(grid), dim3(WG_THREADS), 0, stream, d_ep, c->phrase_count.p, c->phrase_keys.p,
                            (const int32_t*)c->phrase_docs.p, d_sl, d_nl, (int)n_queries, (int)k, seg->doc_base, c->host_api_hits.p, c->host_api_totals.p);
@@ -2993,13 +2995,13 @@ extern "C" int32_t rgpu_rescore_batch(rgpu_segment* seg, const rgpu_query* queri
   RescoreParams* d_r = reinterpret_cast<RescoreParams*>(c->S->d_stage.p + o_r);
   {
     TimedLaunch tl(c, stream, "k_rescore", 0);
-    const unsigned grid = (unsigned)((n_hits + WG_WAVES - 1) / WG_WAVES);
+    const unsigned grid = wg_count((n_hits + WG_WAVES - 1) / WG_WAVES);
     if (seg->version < 1) RGPU_LAUNCH(k_rescore<true>, dim3(grid), dim3(WG_THREADS), 0, stream, seg_view(seg), d_q, d_t, d_r, (int)n_queries, (int)k, c->host_api_hits.p, finish ? 1 : 0);
     else RGPU_LAUNCH(k_rescore<false>, dim3(grid), dim3(WG_THREADS), 0, stream, seg_view(seg), d_q, d_t, d_r, (int)n_queries, (int)k, c->host_api_hits.p, finish ? 1 : 0);
   }
   if (finish) {
     TimedLaunch tl(c, stream, "k_rescore_sort", 0);
-    RGPU_LAUNCH(k_rescore_sort, dim3((unsigned)((n_queries + WG_WAVES - 1) / WG_WAVES)), dim3(WG_THREADS), 0, stream, d_r, (int)n_queries, (int)k, c->host_api_hits.p);
+    RGPU_LAUNCH(k_rescore_sort, dim3(wg_count((n_queries + WG_WAVES - 1) / WG_WAVES)), dim3(WG_THREADS), 0, stream, d_r, (int)n_queries, (int)k, c->host_api_hits.p);
   }
   HIP_TRY(launch_status());
   HIP_TRY(hipMemcpyAsync(hits_inout, c->host_api_hits.p, n_hits * sizeof(HitOut), hipMemcpyDeviceToHost, stream));
@@ -3137,7 +3139,7 @@ static int32_t search_into_record(rgpu_segment* seg, const rgpu_query* queries, 
   };
   if (rc != RGPU_OK) {  // whatever was enqueued before the failure is overwritten behind it on the same stream
     note(hipMemsetAsync(record + hits_bytes, 0, (size_t)n_queries * 8, s), "hipMemsetAsync(record counts)");
-    RGPU_LAUNCH(k_init_hits, dim3((unsigned)(((size_t)n_queries * k + 255) / 256)), dim3(256), 0, s, (HitOut*)record, (int64_t)n_queries, (int)k, (int)k, 0);
+    RGPU_LAUNCH(k_init_hits, dim3(wg_count(((size_t)n_queries * k + 255) / 256)), dim3(256), 0, s, (HitOut*)record, (int64_t)n_queries, (int)k, (int)k, 0);
     note(hipGetLastError(), "k_init_hits");
   }
   RGPU_LAUNCH(k_set_i64, dim3(1), dim3(1), 0, s, (int64_t*)(record + hits_bytes + (size_t)n_queries * 8), (int64_t)rc);
@@ -3169,7 +3171,7 @@ static int32_t merge_records(rgpu_ctx* c, const uint8_t* records, int32_t n_rank
   const size_t hits_bytes = record_hits_bytes(n_queries, k), record = record_bytes(n_queries, k);
   {
     TimedLaunch tl(c, s, "k_merge_lists", 0);
-    const unsigned grid = (unsigned)((n_queries + WG_WAVES - 1) / WG_WAVES);
+    const unsigned grid = wg_count((n_queries + WG_WAVES - 1) / WG_WAVES);
     auto go = [&](auto kern) {
       RGPU_LAUNCH(kern, dim3(grid), dim3(WG_THREADS), 0, s, (const HitOut*)records, (const int64_t*)(records + hits_bytes),
                          (int64_t)(record / sizeof(HitOut)), (int64_t)(record / 8), n_ranks, n_queries, (int)k, hits_dev, totals_dev);
