@@ -35,6 +35,8 @@ for k, c in d.get("configs", {}).items():
         cfg("  positions_decode", c["positions_decode"])
         print("   ", {x: c["positions_decode"].get(x) for x in ("positions", "positions_decoded_per_sec", "parity_vs_oracle")})
         cfg("  phrase2", c["phrase2"])
-        print("   ", {x: c["phrase2"].get(x) for x in ("lead_postings_per_step", "phrase_hits_per_step", "cpu_baseline")})
+        ph = c["phrase2"]
+        print("   ", {"lead_postings_per_step": ph.get("lead_postings_per_step", ph.get("conjunction_matches_checked_per_step")),  # (its name before the round's last commits)
+                      "phrase_hits_per_step": ph.get("phrase_hits_per_step"), "cpu_baseline": ph.get("cpu_baseline")})
     else:
         cfg(k, c)
