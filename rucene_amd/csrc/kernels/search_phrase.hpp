@@ -146,6 +146,7 @@ constexpr uint64_t PHRASE_REDO = 1ull;  // (no real key has a zero high word)
 constexpr int PHRASE_REDO_WIDE = 1;    // k_phrase_match with PHRASE_LIST_CAP lists
 constexpr int PHRASE_REDO_LANES = 2;   // k_phrase_match at all (left by k_phrase_match_lanes)
 constexpr int PHRASE_REDO_SLOPPY = 4;  // k_sloppy_match with the SLOPPY_POOL pool
+constexpr int PHRASE_REDO_SLOPPY_LANES = 8;  // k_sloppy_match at all (left by k_sloppy_match_lanes)
 template <bool LEGACY, int CAP, bool REDO_ONLY>
 __global__ __launch_bounds__(WG_THREADS) void k_phrase_match(SegView seg, const DevQuery* __restrict__ queries,
                                                              const DevTerm* __restrict__ terms, const PosTerm* __restrict__ pterms,
@@ -241,17 +242,183 @@ __global__ __launch_bounds__(WG_THREADS) void k_phrase_match(SegView seg, const 
 // Anything else — a doc in the trailing VInt block of a term's positions, an all-equal block, more positions, a corrupt stream —
 // leaves PHRASE_REDO in the candidate's slot and raises bit 1 of *redo: k_phrase_match<.., REDO_ONLY> takes those candidates (and
 // reports the errors). Results are the same by construction: the same positions, the same intersection, the same score expression.
-constexpr int PHRASE_LANE_CAP = 10;
+#ifndef RGPU_PHRASE_LANE_CAP
+#define RGPU_PHRASE_LANE_CAP 10
+#endif
+constexpr int PHRASE_LANE_CAP = RGPU_PHRASE_LANE_CAP;
 #ifndef RGPU_LANES_ABL  // developer ablations (variant builds only; results are wrong): 1 no positions / intersection, 2 + no block decodes
 #define RGPU_LANES_ABL 0
 #endif
-constexpr int64_t PHRASE_REDO_LIST_CAP = 1 << 22;  // slots the list of left-over candidates holds (32 MB); beyond: every slot is looked at
+constexpr int64_t PHRASE_REDO_LIST_CAP = 1 << 25;  // slots the list of left-over candidates holds (at most; 256 MB for a batch of that many slots); beyond: every slot is looked at
 __device__ __forceinline__ uint32_t bp128_value_at(const uint8_t* __restrict__ payload, uint32_t b, int i) {
   const uint32_t p = (uint32_t)(i >> 2) * b;
   const uint8_t* at = payload + 4 * (i & 3) + 16 * (p >> 5);
   const uint64_t win = ((uint64_t)load4_unaligned(at + 16) << 32) | load4_unaligned(at);
   return (uint32_t)(win >> (p & 31)) & (0xffffffffu >> (32 - b));
 }
+// One term of a 64-candidate wavefront (steps 1-3 of the kernels below): the positions of every lane's `doc` in term T, as
+// (position - phrase offset), ascending, into the lane's column of Lc (entry j at Lc[64 j + lane]). `act`: the lane holds a
+// candidate; `again` (in / out): the candidate is handed on to the one-candidate kernel. Returns the lane's freq, 0 for a lane
+// that takes no part (or has just been handed on). `area`: 384 words of LDS (the block decoder's staging area, then the decoded
+// block {doc, freqs before, freq} x 128). ListT = int16_t: a position outside its range hands the candidate on.
+// The end of a 64-candidate kernel: every lane's key goes to its slot; the slots handed on to a one-candidate kernel are marked
+// PHRASE_REDO, `bit` is raised in *redo and the slots are listed (that pass then costs what they cost, not a wavefront per slot
+// of the launch); a list that overflows is ignored by the host: *redo_n says so.
+__device__ __forceinline__ void lanes_finish(bool again, uint64_t key, int64_t slot, uint64_t* __restrict__ keys_out, int* redo, int bit,
+                                             int64_t* __restrict__ redo_list, int redo_cap, int* redo_n, int lane) {
+  keys_out[slot] = again ? PHRASE_REDO : key;
+  const uint64_t m = __ballot(again);
+  if (m) {
+    int at = 0;
+    if (lane == 0) { atomicOr(redo, bit); at = atomicAdd(redo_n, (int)__popcll(m)); }
+    at = readlane(at, 0) + (int)mbcnt(m);
+    if (again && at < redo_cap) redo_list[at] = slot;
+  }
+}
+
+template <typename ListT>
+__device__ __forceinline__ int lanes_doc_positions(const SegView& seg, const DevTerm& T, const PosTerm& P, int32_t doc, bool act, bool& again,
+                                                   int64_t pos_len, int32_t* area, ListT* Lc, int lane) {
+  uint8_t* slab = reinterpret_cast<uint8_t*>(area);
+  int32_t* Dd = area;
+  int32_t* Db = Dd + 128;
+  int32_t* Df = Dd + 256;
+  int freq = 0, skip = 0;
+  uint32_t pofs = 0;  // of the position block the doc's block starts in, from the term's pos_start_fp
+  if (T.df == 1) {
+    freq = T.singleton_freq;
+    if (act && doc != T.singleton_doc) again = true;  // (the conjunction said the doc is here)
+  } else {
+    // ---- 1. every lane: the first directory slot whose last doc is >= its doc (slot nblocks: the tail)
+    // (four-way: the three probes of a round are in flight together — half the dependent round trips of a binary search)
+    int lo = 0, hi = T.nblocks;
+    while (__ballot(lo < hi)) {
+      const int span = hi - lo;
+      const int m1 = lo + (span >> 2), m2 = lo + (span >> 1), m3 = lo + span - (span >> 2) - (span > 3 ? 0 : 1);
+      const int top = T.nblocks - 1;
+      const int32_t l1 = seg.dir_last[T.dir_base + min(max(m1, 0), top)];
+      const int32_t l2 = seg.dir_last[T.dir_base + min(max(m2, 0), top)];
+      const int32_t l3 = seg.dir_last[T.dir_base + min(max(m3, 0), top)];
+      if (lo < hi) {  // lo <= m1 <= m2 <= m3 < hi; slots below lo end before doc, slot hi does not
+        if (l1 >= doc) hi = m1;
+        else if (l2 >= doc) { lo = m1 + 1; hi = m2; }
+        else if (l3 >= doc) { lo = m2 + 1; hi = m3; }
+        else lo = m3 + 1;
+      }
+    }
+    const int blk = lo;
+    // ---- 2. the distinct blocks among the lanes, decoded once each
+    uint64_t pend = __ballot(act && !again);
+    if (RGPU_LANES_ABL == 2) { pend = 0; freq = 1 + (blk & 1); }
+    while (pend) {
+      const int b = readlane(blk, (int)__builtin_ctzll(pend));
+      const uint64_t st = seg.dir_pos[T.dir_base + b];
+      const uint32_t row = seg.dir_row[T.dir_base + b];
+      int32_t e0, e1;
+      uint32_t g0, g1;
+      if (b < T.nblocks) {
+        const uint32_t hdr = (uint32_t)seg.dir_hdr[T.dir_base + b];
+        const int32_t base = b > 0 ? seg.dir_last[T.dir_base + b - 1] : 0;
+        const BlockPair bp = decode_block<false>(seg.bstore + T.bs_base, row, hdr, slab, lane);
+        deltas_to_docs(bp.d0, bp.d1, base, e0, e1);
+        g0 = bp.f0; g1 = bp.f1;
+      } else if (T.tail_n > 0) {
+        tail_load(seg.bstore + T.bs_base, row, lane, e0, e1, g0, g1);  // (INT_MAX / 0 past the tail's end)
+      } else {
+        e0 = e1 = 0x7fffffff; g0 = g1 = 0u;
+      }
+      const int pair = (int)(g0 + g1);
+      const int excl = wave_incl_scan(pair) - pair;
+      Dd[2 * lane] = e0; Dd[2 * lane + 1] = e1;
+      Db[2 * lane] = excl; Db[2 * lane + 1] = excl + (int)g0;
+      Df[2 * lane] = (int32_t)g0; Df[2 * lane + 1] = (int32_t)g1;
+      wave_sync();
+      const bool mine = act && !again && blk == b;
+      if (mine) {
+        int at = 0;  // the first of the block's 128 docs that is >= doc
+#pragma unroll
+        for (int step = 64; step >= 1; step >>= 1) at += Dd[at + step - 1] < doc ? step : 0;
+        if (Dd[at] != doc) {
+          again = true;  // (the conjunction said the doc is here)
+        } else {
+          freq = Df[at];
+          skip = (int)(st >> 32) + Db[at];
+          pofs = (uint32_t)st;
+        }
+      }
+      pend &= ~__ballot(blk == b);
+      wave_sync();  // the area is rewritten by the next block
+    }
+  }
+  bool live = act && !again;
+  if (live && (freq <= 0 || freq > PHRASE_LANE_CAP)) { again = true; live = false; }
+  // ---- 3. the doc's positions: `freq` deltas from value `skip` of the position stream at pofs on
+  if (RGPU_LANES_ABL == 1 || RGPU_LANES_ABL == 2) return live ? freq : 0;
+  // (a lane without a candidate reads the term's first position block, value 0: the loads below are unconditional)
+  int64_t fp = (int64_t)P.pos_start_fp, fp1 = fp;
+  uint32_t b0 = 1u, b1 = 1u;
+  if (live) {
+    fp += (int64_t)pofs;
+    // a packed position block at `at`: its header byte (1..32); 0 = not one (the trailing VInt block, an all-equal block, the end)
+    auto packed_at = [&](int64_t at) -> uint32_t {
+      if (at < 0 || at + 2 > pos_len || at == P.last_pos_block_fp) return 0u;
+      const uint32_t b = seg.pos[at];
+      return b <= 32u ? b : 0u;
+    };
+    b0 = packed_at(fp);
+    if (RGPU_LANES_ABL == 5) skip &= 127;
+    while (b0 != 0u && skip >= 128) {  // whole blocks of earlier docs' positions (ForUtil::skip_block, for_util.rs:263-272)
+      fp += 1 + 16 * (int64_t)b0;
+      skip -= 128;
+      b0 = packed_at(fp);
+    }
+    fp1 = fp + 1 + 16 * (int64_t)b0;  // the block behind: a doc's <= 10 positions straddle at most one boundary
+    const bool straddles = skip + freq > 128;
+    if (b0 != 0u && straddles) b1 = packed_at(fp1);
+    if (b0 == 0u || (straddles && b1 == 0u)) {
+      again = true;
+      live = false;
+    }
+  }
+  if (!live) { fp = fp1 = (int64_t)P.pos_start_fp; b0 = b1 = 1u; skip = 0; freq = 1; }
+  // every lane's deltas asked for together (a load behind a per-lane branch waits for the one in front of it: ten round trips
+  // where this takes one); j runs to the largest freq among the lanes, a lane past its own freq reads its last delta again
+  const int maxf = (int)wave_reduce_max_u32(live ? (uint32_t)freq : 0u);
+  // (first every load, then every use: a value unpacked inside the j-th step would make that step wait for its own two loads)
+  uint32_t wlo[PHRASE_LANE_CAP], whi[PHRASE_LANE_CAP];
+#pragma unroll
+  for (int j = 0; j < PHRASE_LANE_CAP; ++j) {
+    wlo[j] = whi[j] = 0u;
+    if (j < maxf && RGPU_LANES_ABL != 4) {  // (wave-uniform)
+      const int i = skip + min(j, freq - 1);
+      const bool behind = i >= 128;
+      const uint32_t p = (uint32_t)((behind ? i - 128 : i) >> 2) * (behind ? b1 : b0);
+      const uint8_t* at = seg.pos + (behind ? fp1 : fp) + 1 + 4 * (i & 3) + 16 * (p >> 5);
+      wlo[j] = load4_unaligned(at);
+      whi[j] = load4_unaligned(at + 16);
+    }
+  }
+  int32_t at_pos = -P.phrase_pos;  // (position - phrase offset; the doc's first delta is its first position)
+  bool narrow = false;       // some position does not fit the list's element type
+#pragma unroll
+  for (int j = 0; j < PHRASE_LANE_CAP; ++j) {
+    if (j < maxf) {  // (wave-uniform; not a `break`: leaving the unrolled loop early cost 130 registers in copies of wlo / whi)
+      const int i = skip + min(j, freq - 1);
+      const bool behind = i >= 128;
+      const uint32_t b = behind ? b1 : b0;
+      const uint32_t p = (uint32_t)((behind ? i - 128 : i) >> 2) * b;
+      const uint32_t v = (uint32_t)((((uint64_t)whi[j] << 32) | wlo[j]) >> (p & 31)) & (0xffffffffu >> (32 - b));
+      at_pos += (int32_t)v;
+      if (live && j < freq) {
+        Lc[j * 64 + lane] = (ListT)at_pos;
+        narrow = narrow || (int32_t)(ListT)at_pos != at_pos;
+      }
+    }
+  }
+  if (live && narrow) { again = true; live = false; }
+  return live ? freq : 0;
+}
+
 __global__ __launch_bounds__(WG_THREADS) void k_phrase_match_lanes(SegView seg, const DevQuery* __restrict__ queries,
                                                                    const DevTerm* __restrict__ terms, const PosTerm* __restrict__ pterms,
                                                                    const int64_t* __restrict__ emit_prefix,
@@ -259,7 +426,6 @@ __global__ __launch_bounds__(WG_THREADS) void k_phrase_match_lanes(SegView seg, 
                                                                    const int32_t* __restrict__ emit_docs, const int32_t* __restrict__ slops, int n_queries,
                                                                    int64_t n_groups, int64_t pos_len, uint64_t* __restrict__ keys_out, int* redo,
                                                                    int64_t* __restrict__ redo_list, int redo_cap, int* redo_n) {
-  // per wavefront: the block decoder's staging area, reused for the decoded block {doc, freqs before, freq} x 128; two lists
   __shared__ __attribute__((aligned(16))) int32_t areas[WG_WAVES][384];
   __shared__ int32_t lists[WG_WAVES][2][PHRASE_LANE_CAP * 64];
   static_assert(sizeof(int32_t) * 384 >= 2 * SLAB_STREAM, "the staging area holds a block's doc and freq rows");
@@ -277,10 +443,6 @@ __global__ __launch_bounds__(WG_THREADS) void k_phrase_match_lanes(SegView seg, 
   bool act = doc >= 0;    // (a deleted doc travels with its sign bit set: an approximation that is never checked, bulk_scorer.rs:100)
   bool again = false;     // this candidate goes to k_phrase_match
   const DevQuery Q = queries[q];
-  uint8_t* slab = reinterpret_cast<uint8_t*>(areas[wave]);
-  int32_t* Dd = areas[wave];
-  int32_t* Db = Dd + 128;
-  int32_t* Df = Dd + 256;
   int32_t* A = lists[wave][0];
   int32_t* C = lists[wave][1];
   int n_a = 0;
@@ -288,134 +450,9 @@ __global__ __launch_bounds__(WG_THREADS) void k_phrase_match_lanes(SegView seg, 
     if (!__ballot(act && !again)) break;
     const DevTerm T = terms[Q.first_term + c];
     const PosTerm P = pterms[Q.first_term + c];
-    int freq = 0, skip = 0;
-    uint32_t pofs = 0;  // of the position block the doc's block starts in, from the term's pos_start_fp
-    if (T.df == 1) {
-      freq = T.singleton_freq;
-      if (act && doc != T.singleton_doc) again = true;  // (the conjunction said the doc is here)
-    } else {
-      // ---- 1. every lane: the first directory slot whose last doc is >= its doc (slot nblocks: the tail)
-      // (four-way: the three probes of a round are in flight together — half the dependent round trips of a binary search)
-      int lo = 0, hi = T.nblocks;
-      while (__ballot(lo < hi)) {
-        const int span = hi - lo;
-        const int m1 = lo + (span >> 2), m2 = lo + (span >> 1), m3 = lo + span - (span >> 2) - (span > 3 ? 0 : 1);
-        const int top = T.nblocks - 1;
-        const int32_t l1 = seg.dir_last[T.dir_base + min(max(m1, 0), top)];
-        const int32_t l2 = seg.dir_last[T.dir_base + min(max(m2, 0), top)];
-        const int32_t l3 = seg.dir_last[T.dir_base + min(max(m3, 0), top)];
-        if (lo < hi) {  // lo <= m1 <= m2 <= m3 < hi; slots below lo end before doc, slot hi does not
-          if (l1 >= doc) hi = m1;
-          else if (l2 >= doc) { lo = m1 + 1; hi = m2; }
-          else if (l3 >= doc) { lo = m2 + 1; hi = m3; }
-          else lo = m3 + 1;
-        }
-      }
-      const int blk = lo;
-      // ---- 2. the distinct blocks among the lanes, decoded once each
-      uint64_t pend = __ballot(act && !again);
-      if (RGPU_LANES_ABL == 2) { pend = 0; freq = 1 + (blk & 1); }
-      while (pend) {
-        const int b = readlane(blk, (int)__builtin_ctzll(pend));
-        const uint64_t st = seg.dir_pos[T.dir_base + b];
-        const uint32_t row = seg.dir_row[T.dir_base + b];
-        int32_t e0, e1;
-        uint32_t g0, g1;
-        if (b < T.nblocks) {
-          const uint32_t hdr = (uint32_t)seg.dir_hdr[T.dir_base + b];
-          const int32_t base = b > 0 ? seg.dir_last[T.dir_base + b - 1] : 0;
-          const BlockPair bp = decode_block<false>(seg.bstore + T.bs_base, row, hdr, slab, lane);
-          deltas_to_docs(bp.d0, bp.d1, base, e0, e1);
-          g0 = bp.f0; g1 = bp.f1;
-        } else if (T.tail_n > 0) {
-          tail_load(seg.bstore + T.bs_base, row, lane, e0, e1, g0, g1);  // (INT_MAX / 0 past the tail's end)
-        } else {
-          e0 = e1 = 0x7fffffff; g0 = g1 = 0u;
-        }
-        const int pair = (int)(g0 + g1);
-        const int excl = wave_incl_scan(pair) - pair;
-        Dd[2 * lane] = e0; Dd[2 * lane + 1] = e1;
-        Db[2 * lane] = excl; Db[2 * lane + 1] = excl + (int)g0;
-        Df[2 * lane] = (int32_t)g0; Df[2 * lane + 1] = (int32_t)g1;
-        wave_sync();
-        const bool mine = act && !again && blk == b;
-        if (mine) {
-          int at = 0;  // the first of the block's 128 docs that is >= doc
-#pragma unroll
-          for (int step = 64; step >= 1; step >>= 1) at += Dd[at + step - 1] < doc ? step : 0;
-          if (Dd[at] != doc) {
-            again = true;  // (the conjunction said the doc is here)
-          } else {
-            freq = Df[at];
-            skip = (int)(st >> 32) + Db[at];
-            pofs = (uint32_t)st;
-          }
-        }
-        pend &= ~__ballot(blk == b);
-        wave_sync();  // the area is rewritten by the next block
-      }
-    }
-    bool live = act && !again;
-    if (live && (freq <= 0 || freq > PHRASE_LANE_CAP)) { again = true; live = false; }
-    // ---- 3. the doc's positions: `freq` deltas from value `skip` of the position stream at pofs on
-    int32_t* Lc = c == 0 ? A : C;
-    if (RGPU_LANES_ABL == 1 || RGPU_LANES_ABL == 2) { if (live && skip == 12345 && freq == 77) keys_out[slot] = 5; continue; }
-    // (a lane without a candidate reads the term's first position block, value 0: the loads below are unconditional)
-    int64_t fp = (int64_t)P.pos_start_fp, fp1 = fp;
-    uint32_t b0 = 1u, b1 = 1u;
-    if (live) {
-      fp += (int64_t)pofs;
-      // a packed position block at `at`: its header byte (1..32); 0 = not one (the trailing VInt block, an all-equal block, the end)
-      auto packed_at = [&](int64_t at) -> uint32_t {
-        if (at < 0 || at + 2 > pos_len || at == P.last_pos_block_fp) return 0u;
-        const uint32_t b = seg.pos[at];
-        return b <= 32u ? b : 0u;
-      };
-      b0 = packed_at(fp);
-      if (RGPU_LANES_ABL == 5) skip &= 127;
-      while (b0 != 0u && skip >= 128) {  // whole blocks of earlier docs' positions (ForUtil::skip_block, for_util.rs:263-272)
-        fp += 1 + 16 * (int64_t)b0;
-        skip -= 128;
-        b0 = packed_at(fp);
-      }
-      fp1 = fp + 1 + 16 * (int64_t)b0;  // the block behind: a doc's <= 10 positions straddle at most one boundary
-      const bool straddles = skip + freq > 128;
-      if (b0 != 0u && straddles) b1 = packed_at(fp1);
-      if (b0 == 0u || (straddles && b1 == 0u)) {
-        again = true;
-        live = false;
-      }
-    }
-    if (!live) { fp = fp1 = (int64_t)P.pos_start_fp; b0 = b1 = 1u; skip = 0; freq = 1; }
-    // every lane's deltas asked for together (a load behind a per-lane branch waits for the one in front of it: ten round trips
-    // where this takes one); j runs to the largest freq among the lanes, a lane past its own freq reads its last delta again
-    const int maxf = (int)wave_reduce_max_u32(live ? (uint32_t)freq : 0u);
-    // (first every load, then every use: a value unpacked inside the j-th step would make that step wait for its own two loads)
-    uint32_t wlo[PHRASE_LANE_CAP], whi[PHRASE_LANE_CAP];
-#pragma unroll
-    for (int j = 0; j < PHRASE_LANE_CAP; ++j) {
-      wlo[j] = whi[j] = 0u;
-      if (j < maxf && RGPU_LANES_ABL != 4) {  // (wave-uniform)
-        const int i = skip + min(j, freq - 1);
-        const bool behind = i >= 128;
-        const uint32_t p = (uint32_t)((behind ? i - 128 : i) >> 2) * (behind ? b1 : b0);
-        const uint8_t* at = seg.pos + (behind ? fp1 : fp) + 1 + 4 * (i & 3) + 16 * (p >> 5);
-        wlo[j] = load4_unaligned(at);
-        whi[j] = load4_unaligned(at + 16);
-      }
-    }
-    int32_t at_pos = -P.phrase_pos;  // (position - phrase offset; the doc's first delta is its first position)
-#pragma unroll
-    for (int j = 0; j < PHRASE_LANE_CAP; ++j) {
-      if (j >= maxf) break;  // (wave-uniform)
-      const int i = skip + min(j, freq - 1);
-      const bool behind = i >= 128;
-      const uint32_t b = behind ? b1 : b0;
-      const uint32_t p = (uint32_t)((behind ? i - 128 : i) >> 2) * b;
-      const uint32_t v = (uint32_t)((((uint64_t)whi[j] << 32) | wlo[j]) >> (p & 31)) & (0xffffffffu >> (32 - b));
-      at_pos += (int32_t)v;
-      if (live && j < freq) Lc[j * 64 + lane] = at_pos;
-    }
+    const int freq = lanes_doc_positions<int32_t>(seg, T, P, doc, act, again, pos_len, areas[wave], c == 0 ? A : C, lane);
+    const bool live = freq > 0;
+    if (RGPU_LANES_ABL == 1 || RGPU_LANES_ABL == 2) continue;
     // ---- 4. keep the first term's positions that line up with this term's (every lane reads and writes its own column only)
     if (c == 0) {
       n_a = live ? freq : 0;
@@ -449,17 +486,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_phrase_match_lanes(SegView seg, 
       key = make_key(bm25_score(T0.weight * (k1 + 1.0f), (float)phrase_freq, nrm), doc);
     }
   }
-  if (again) key = PHRASE_REDO;
-  keys_out[slot] = key;
-  // the slots left for k_phrase_match, listed (that pass then costs what they cost, not a wavefront per slot of the launch);
-  // a list that overflows is ignored by the host: *redo_n says so
-  const uint64_t m = __ballot(again);
-  if (m) {
-    int at = 0;
-    if (lane == 0) { atomicOr(redo, PHRASE_REDO_LANES); at = atomicAdd(redo_n, (int)__popcll(m)); }
-    at = readlane(at, 0) + (int)mbcnt(m);
-    if (again && at < redo_cap) redo_list[at] = slot;
-  }
+  lanes_finish(again, key, slot, keys_out, redo, PHRASE_REDO_LANES, redo_list, redo_cap, redo_n, lane);
 }
 
 // ---- SloppyPhraseScorer (scorer/phrase_scorer.rs:432-1071; PhraseQuery with slop > 0) ------------------------------------------
@@ -571,15 +598,17 @@ __global__ __launch_bounds__(WG_THREADS) void k_sloppy_match(SegView seg, const 
                                                              const unsigned long long* __restrict__ emit_count,
                                                              const int32_t* __restrict__ emit_docs, const int32_t* __restrict__ slops,
                                                              const SloppyGroups* __restrict__ groups, int n_queries, int64_t n_slots,
-                                                             int64_t pos_len, uint64_t* __restrict__ keys_out, int* err, int* redo, int64_t first) {
-  // (first / n_slots: the slots [first, n_slots) — see k_phrase_match)
+                                                             int64_t pos_len, uint64_t* __restrict__ keys_out, int* err, int* redo,
+                                                             const int64_t* __restrict__ redo_list, int64_t first) {
+  // (first / n_slots / redo_list: as k_phrase_match's)
   __shared__ __attribute__((aligned(16))) uint8_t slabs[WG_WAVES][SLAB_BYTES];
   __shared__ int32_t pools[WG_WAVES][POOL];
   __shared__ float caches[WG_WAVES][256];
   const int lane = lane_id();
   const int wave = wave_id();
-  const int64_t slot = first + (int64_t)blockIdx.x * WG_WAVES + wave;
-  if (slot >= n_slots) return;
+  const int64_t work = first + (int64_t)blockIdx.x * WG_WAVES + wave;
+  if (work >= n_slots) return;
+  const int64_t slot = (REDO_ONLY && redo_list != nullptr) ? redo_list[work] : work;
   if (REDO_ONLY && keys_out[slot] != PHRASE_REDO) return;
   const int q = upper_slot_wave(emit_prefix, n_queries, slot, lane);
   const int slop = slops[q];
@@ -797,6 +826,138 @@ __global__ __launch_bounds__(WG_THREADS) void k_sloppy_match(SegView seg, const 
     key = make_key(bm25_score(wk, freq, nrm), doc);
   }
   if (lane == 0) keys_out[slot] = key;
+}
+
+// ---- sloppy phrases, 64 candidates per wavefront ------------------------------------------------------------------------------------
+// k_sloppy_match is the one-candidate kind (98 ms for 1024 two-term phrases with slop 2 over 10 M docs: scalar issue, as
+// k_phrase_match was). Without repeated terms the scorer's queue never has its keys changed from outside: a pop is the smallest
+// (position, offset, ord), the array order of Rust's BinaryHeap does not show — and the walk (phrase_freq, :537-577) is a few
+// dozen steps over at most n x 10 positions. So each lane runs it for its own candidate: every term's positions in the lane's
+// LDS columns (16-bit: position - offset of a doc longer than 32 k tokens hands the candidate on), the PhrasePositions' state in
+// registers (unrolled over SLOPPY_LANE_TERMS), the f32 sum in the reference's order. Phrases with a repeated term, with one or
+// more than SLOPPY_LANE_TERMS terms, and whatever lanes_doc_positions hands on, go to k_sloppy_match through the list.
+constexpr int SLOPPY_LANE_TERMS = 6;
+__global__ __launch_bounds__(WG_THREADS) void k_sloppy_match_lanes(SegView seg, const DevQuery* __restrict__ queries,
+                                                                   const DevTerm* __restrict__ terms, const PosTerm* __restrict__ pterms,
+                                                                   const int64_t* __restrict__ emit_prefix,
+                                                                   const unsigned long long* __restrict__ emit_count,
+                                                                   const int32_t* __restrict__ emit_docs, const int32_t* __restrict__ slops, int n_queries,
+                                                                   int64_t n_groups, int64_t pos_len, uint64_t* __restrict__ keys_out, int* redo,
+                                                                   int64_t* __restrict__ redo_list, int redo_cap, int* redo_n) {
+  __shared__ __attribute__((aligned(16))) int32_t areas[WG_WAVES][384];
+  __shared__ int16_t lists[WG_WAVES][SLOPPY_LANE_TERMS][PHRASE_LANE_CAP * 64];
+  const int lane = lane_id();
+  const int wave = wave_id();
+  const int64_t group = (int64_t)blockIdx.x * WG_WAVES + wave;
+  if (group >= n_groups) return;
+  const int64_t slot = group * 64 + lane;
+  const int q = upper_slot_wave(emit_prefix, n_queries, group * 64, lane);
+  const int slop = slops[q];
+  if (slop <= 0) return;  // an exact phrase: k_phrase_match_lanes'
+  const int64_t idx = slot - emit_prefix[q];
+  const int64_t cnt = (int64_t)emit_count[q];
+  if (idx - lane >= cnt) return;
+  const int32_t doc = idx < cnt ? emit_docs[slot] : -1;
+  const bool act = doc >= 0;  // (a deleted doc: an approximation that is never checked)
+  bool again = false;
+  const DevQuery Q = queries[q];
+  const int n = Q.n_terms;
+  // the PhrasePositions' fixed parts (wave-uniform), clause by clause: offset, ord; a term that occurs twice sends the phrase away
+  int32_t off[SLOPPY_LANE_TERMS], ord[SLOPPY_LANE_TERMS];
+  bool takes = n >= 2 && n <= SLOPPY_LANE_TERMS;
+#pragma unroll
+  for (int c = 0; c < SLOPPY_LANE_TERMS; ++c) {
+    off[c] = 0; ord[c] = c;
+    if (takes && c < n) {
+      const PosTerm P = pterms[Q.first_term + c];
+      off[c] = P.phrase_pos; ord[c] = P.query_ord;
+      if (P.same_as != P.query_ord) takes = false;
+    }
+  }
+  if (!takes) again = act;
+  // PPElement's order (:393-430) is (position, offset, ord): bit 8 t + u of `ties` = "at equal positions pp t comes before pp u"
+  uint64_t ties = 0ull;
+#pragma unroll
+  for (int t = 0; t < SLOPPY_LANE_TERMS; ++t)
+#pragma unroll
+    for (int u = 0; u < SLOPPY_LANE_TERMS; ++u)
+      if (off[t] < off[u] || (off[t] == off[u] && ord[t] < ord[u])) ties |= 1ull << (8 * t + u);
+  // ---- every term's positions in the lane's doc
+  int32_t fr[SLOPPY_LANE_TERMS];
+#pragma unroll
+  for (int t = 0; t < SLOPPY_LANE_TERMS; ++t) fr[t] = 0;
+  for (int c = 0; takes && c < n; ++c) {
+    if (!__ballot(act && !again)) break;
+    const DevTerm T = terms[Q.first_term + c];
+    const PosTerm P = pterms[Q.first_term + c];
+    const int f = lanes_doc_positions<int16_t>(seg, T, P, doc, act, again, pos_len, areas[wave], lists[wave][c], lane);
+#pragma unroll
+    for (int t = 0; t < SLOPPY_LANE_TERMS; ++t) fr[t] = t == c ? f : fr[t];
+  }
+  const bool live = act && !again;
+  float sfreq = 0.0f;
+  if (live) {
+    const int16_t* L = &lists[wave][0][0];
+    // init_simple (:604-617): every pp on its first position, `end` the largest of them
+    int32_t pos[SLOPPY_LANE_TERMS], nx[SLOPPY_LANE_TERMS];
+    int32_t end = (int32_t)0x80000000;
+#pragma unroll
+    for (int t = 0; t < SLOPPY_LANE_TERMS; ++t) {
+      pos[t] = 0x7fffffff; nx[t] = 1;
+      if (t < n) { pos[t] = (int32_t)L[(t * PHRASE_LANE_CAP) * 64 + lane]; end = pos[t] > end ? pos[t] : end; }
+    }
+    // the pp the queue hands out is the least one
+    auto least = [&](int& cur, int32_t& cur_pos, int32_t& next) {
+      cur = 0; cur_pos = pos[0];
+#pragma unroll
+      for (int t = 1; t < SLOPPY_LANE_TERMS; ++t) {
+        if (t < n) {
+          const bool lt = pos[t] < cur_pos || (pos[t] == cur_pos && ((ties >> (8 * t + cur)) & 1ull) != 0ull);
+          if (lt) { cur = t; cur_pos = pos[t]; }
+        }
+      }
+      next = 0x7fffffff;  // the position on top of the queue once `cur` is out: the least position among the others
+#pragma unroll
+      for (int t = 0; t < SLOPPY_LANE_TERMS; ++t) if (t < n && t != cur) next = pos[t] < next ? pos[t] : next;
+    };
+    int cur;
+    int32_t cur_pos, next;
+    least(cur, cur_pos, next);
+    int32_t match_length = end - cur_pos;
+    // phrase_freq (:537-577)
+    while (true) {
+      int32_t kc = nx[0], fc = fr[0];
+#pragma unroll
+      for (int t = 1; t < SLOPPY_LANE_TERMS; ++t) { kc = cur == t ? nx[t] : kc; fc = cur == t ? fr[t] : fc; }
+      if (kc >= fc) break;  // advance_pp: the pp has no position left
+      const int32_t p = (int32_t)L[(cur * PHRASE_LANE_CAP + kc) * 64 + lane];
+#pragma unroll
+      for (int t = 0; t < SLOPPY_LANE_TERMS; ++t) { nx[t] = cur == t ? kc + 1 : nx[t]; pos[t] = cur == t ? p : pos[t]; }
+      end = p > end ? p : end;
+      if (p > next) {  // done minimizing current match-length
+        if (match_length <= slop) sfreq += 1.0f / ((float)match_length + 1.0f);  // compute_slop_factor (bm25_similarity.rs:65-67)
+        least(cur, cur_pos, next);
+        match_length = end - cur_pos;
+      } else {
+        const int32_t ml2 = end - p;
+        match_length = ml2 < match_length ? ml2 : match_length;
+      }
+    }
+    if (match_length <= slop) sfreq += 1.0f / ((float)match_length + 1.0f);
+  }
+  uint64_t key = 0ull;
+  if (live && sfreq > 1.1920929e-07f) {  // matches(): sloppy_freq > f32::EPSILON (:1041-1045)
+    const DevTerm T0 = terms[Q.first_term];
+    const float* table = seg.sim_tables + (size_t)T0.sim_table * 257;
+    const float k1 = table[256];
+    float nrm = k1;
+    if (seg.norms != nullptr) {
+      const uint32_t nb = seg.norms[doc];
+      nrm = table[seg.n_norm_ranks > 0 ? (uint32_t)seg.rank_to_norm[nb] : nb];
+    }
+    key = make_key(bm25_score(T0.weight * (k1 + 1.0f), sfreq, nrm), doc);
+  }
+  lanes_finish(again, key, slot, keys_out, redo, PHRASE_REDO_SLOPPY_LANES, redo_list, redo_cap, redo_n, lane);
 }
 
 // TopDocsCollector over one query's candidates: a key of 0 = "phrase freq 0" (not a hit). One wavefront per query.

@@ -2659,6 +2659,7 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
   int64_t collect_items = 0;
   bool any_cutoff = false;
   bool any_sloppy = false, any_exact = false;
+  bool sloppy_rpts = false;  // some sloppy phrase names a term twice (SloppyPhraseScorer's repetition groups: k_sloppy_groups)
   const int blocks_per_item = c->cfg.and_blocks_per_item;
   int64_t items = 0, slots = 0;
   for (int32_t q = 0; q < n_queries; ++q) {
@@ -2698,6 +2699,7 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
     slops[(size_t)q] = Q.slop;
     limits[(size_t)q] = Q.next_limit == 0 ? 500000 /* searcher.rs:47 DEFAULT_DISMATCH_NEXT_LIMIT */ : Q.next_limit;
     (Q.slop > 0 ? any_sloppy : any_exact) = true;
+    if (Q.slop > 0) for (size_t i = pt.size() - (size_t)Q.n_terms; i < pt.size(); ++i) sloppy_rpts = sloppy_rpts || pt[i].same_as != pt[i].query_ord;
     dq[(size_t)q].n_terms = Q.n_terms;
     const DevTerm& lead = dt[(size_t)dq[(size_t)q].first_term];
     items += lead.nblocks == 0 ? 1 : (lead.nblocks + blocks_per_item - 1) / blocks_per_item;
@@ -2805,45 +2807,56 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
           launch(dim3(wg_count((s1 - s0 + WG_WAVES - 1) / WG_WAVES)), s0, s1);
         }
       };
-      auto exact = [&](auto kern) {
-        per_slot(slots, [&](dim3 grid, int64_t s0, int64_t s1) {
+      // (list: null = every slot of the launch; else the listed slots — the ones a 64-candidate kernel handed on)
+      auto exact = [&](auto kern, const int64_t* list, int64_t n) {
+        per_slot(n, [&](dim3 grid, int64_t s0, int64_t s1) {
           RGPU_LAUNCH(kern, grid, dim3(WG_THREADS), 0, stream, sv, d_q, d_t, d_pt, d_ep, c->phrase_count.p, c->phrase_docs.p, d_sl, (int)n_queries, s1,
-                      (int64_t)seg->pos_len, c->phrase_keys.p, c->d_err, c->d_err + 3, (const int64_t*)nullptr, s0);
+                      (int64_t)seg->pos_len, c->phrase_keys.p, c->d_err, c->d_err + 3, list, s0);
         });
       };
-      auto sloppy = [&](auto kern) {
-        per_slot(slots, [&](dim3 grid, int64_t s0, int64_t s1) {
+      auto sloppy = [&](auto kern, const int64_t* list, int64_t n) {
+        per_slot(n, [&](dim3 grid, int64_t s0, int64_t s1) {
           RGPU_LAUNCH(kern, grid, dim3(WG_THREADS), 0, stream, sv, d_q, d_t, d_pt, d_ep, c->phrase_count.p, c->phrase_docs.p, d_sl, d_gr, (int)n_queries, s1,
-                      (int64_t)seg->pos_len, c->phrase_keys.p, c->d_err, c->d_err + 3, s0);
+                      (int64_t)seg->pos_len, c->phrase_keys.p, c->d_err, c->d_err + 3, list, s0);
         });
       };
+      auto sloppy_groups = [&]() {  // the repetition groups of each query's first candidate doc (phrases with a repeated term)
+        TimedLaunch tl(c, stream, "k_sloppy_groups", 0);
+        const unsigned ggrid = wg_count((n_queries + WG_WAVES - 1) / WG_WAVES);
+        auto go = [&](auto kern) {
+          RGPU_LAUNCH(kern, dim3(ggrid), dim3(WG_THREADS), 0, stream, sv, d_q, d_t, d_pt, d_ep, c->phrase_count.p, c->phrase_docs.p, d_sl,
+                      (int)n_queries, (int64_t)seg->pos_len, d_gr, c->d_err);
+        };
+        if (legacy) go(k_sloppy_groups<true>); else go(k_sloppy_groups<false>);
+      };
+      const int64_t* const all_slots = nullptr;
+      const int64_t groups = slots / 64;
+      const dim3 lanes_grid(wg_count((groups + WG_WAVES - 1) / WG_WAVES));
+      // ---- first pass. Packed (.doc version 1) segments: 64 candidates per wavefront; what those kernels hand on is listed.
+      // Legacy segments (the packed streams of a block are laid out differently): one candidate per wavefront throughout.
       if (any_exact) {
-        if (legacy) {  // (.doc version 0: the packed streams of a block are laid out differently — one candidate per wavefront)
+        if (legacy) {
           TimedLaunch tl(c, stream, "k_phrase_match", 0);
-          exact(k_phrase_match<true, PHRASE_SMALL_CAP, false>);
+          exact(k_phrase_match<true, PHRASE_SMALL_CAP, false>, all_slots, slots);
         } else {
           TimedLaunch tl(c, stream, "k_phrase_match_lanes", 0);
-          const int64_t groups = slots / 64;
-          RGPU_LAUNCH(k_phrase_match_lanes, dim3(wg_count((groups + WG_WAVES - 1) / WG_WAVES)), dim3(WG_THREADS), 0, stream, sv, d_q, d_t, d_pt,
-                             d_ep, c->phrase_count.p, c->phrase_docs.p, d_sl, (int)n_queries, groups, (int64_t)seg->pos_len, c->phrase_keys.p,
-                             c->d_err + 3, c->phrase_redo.p, (int)redo_cap, c->d_err + 2);
+          RGPU_LAUNCH(k_phrase_match_lanes, lanes_grid, dim3(WG_THREADS), 0, stream, sv, d_q, d_t, d_pt, d_ep, c->phrase_count.p, c->phrase_docs.p, d_sl,
+                      (int)n_queries, groups, (int64_t)seg->pos_len, c->phrase_keys.p, c->d_err + 3, c->phrase_redo.p, (int)redo_cap, c->d_err + 2);
         }
       }
-      if (any_sloppy) {  // SloppyPhraseScorer: the repetition groups of each query's first candidate doc, then the candidates
-        {
-          TimedLaunch tl(c, stream, "k_sloppy_groups", 0);
-          const unsigned ggrid = wg_count((n_queries + WG_WAVES - 1) / WG_WAVES);
-          auto go = [&](auto kern) {
-            RGPU_LAUNCH(kern, dim3(ggrid), dim3(WG_THREADS), 0, stream, sv, d_q, d_t, d_pt, d_ep, c->phrase_count.p, c->phrase_docs.p, d_sl,
-                               (int)n_queries, (int64_t)seg->pos_len, d_gr, c->d_err);
-          };
-          if (legacy) go(k_sloppy_groups<true>); else go(k_sloppy_groups<false>);
+      if (any_sloppy) {
+        if (legacy) {
+          sloppy_groups();
+          TimedLaunch tl(c, stream, "k_sloppy_match", 0);
+          sloppy(k_sloppy_match<true, SLOPPY_SMALL_POOL, false>, all_slots, slots);
+        } else {
+          TimedLaunch tl(c, stream, "k_sloppy_match_lanes", 0);
+          RGPU_LAUNCH(k_sloppy_match_lanes, lanes_grid, dim3(WG_THREADS), 0, stream, sv, d_q, d_t, d_pt, d_ep, c->phrase_count.p, c->phrase_docs.p, d_sl,
+                      (int)n_queries, groups, (int64_t)seg->pos_len, c->phrase_keys.p, c->d_err + 3, c->phrase_redo.p, (int)redo_cap, c->d_err + 2);
         }
-        TimedLaunch tl(c, stream, "k_sloppy_match", 0);
-        if (legacy) sloppy(k_sloppy_match<true, SLOPPY_SMALL_POOL, false>); else sloppy(k_sloppy_match<false, SLOPPY_SMALL_POOL, false>);
       }
-      // which candidates wait for a wider pass (bits PHRASE_REDO_*): one look per stage that can raise one
-      int listed = 0, redo = 0;  // d_err[2]: slots on the redo list, d_err[3]: the bits
+      // ---- which candidates wait for another pass (bits PHRASE_REDO_*): one look per stage that can raise one
+      int listed = 0, redo = 0;  // d_err[2]: slots on the list, d_err[3]: the bits
       auto redo_bits = [&]() -> int32_t {
         int two[2] = {0, 0};
         HIP_TRY(hipMemcpyAsync(two, c->d_err + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
@@ -2854,31 +2867,32 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
       };
       rc = redo_bits();
       if (rc != RGPU_OK) return rc;
-      // the one-candidate kernel over the listed slots (or, should the list have overflowed, over every slot)
-      const bool by_list = (redo & PHRASE_REDO_LANES) && (int64_t)listed <= redo_cap;
-      auto exact_redo = [&](auto kern) {
-        per_slot(by_list ? (int64_t)listed : slots, [&](dim3 grid, int64_t s0, int64_t s1) {
-          RGPU_LAUNCH(kern, grid, dim3(WG_THREADS), 0, stream, sv, d_q, d_t, d_pt, d_ep, c->phrase_count.p, c->phrase_docs.p, d_sl, (int)n_queries, s1,
-                      (int64_t)seg->pos_len, c->phrase_keys.p, c->d_err, c->d_err + 3,
-                      by_list ? (const int64_t*)c->phrase_redo.p : (const int64_t*)nullptr, s0);
-        });
-      };
+      // the one-candidate kernels over the listed slots (or, should the list have overflowed, over every slot)
+      const bool by_list = !legacy && (int64_t)listed <= redo_cap;
+      const int64_t* const left = by_list ? (const int64_t*)c->phrase_redo.p : all_slots;
+      const int64_t n_left = by_list ? (int64_t)listed : slots;
+      if (HostClock::on() && (redo & (PHRASE_REDO_LANES | PHRASE_REDO_SLOPPY_LANES)))
+        std::fprintf(stderr, "[phrase] %d of %lld candidate slots left for the one-candidate kernels\n", listed, (long long)slots);
       if (redo & PHRASE_REDO_LANES) {
-        if (HostClock::on()) std::fprintf(stderr, "[phrase] %d of %lld candidate slots left for k_phrase_match\n", listed, (long long)slots);
-        {
-          TimedLaunch tl(c, stream, "k_phrase_match(left by the 64-candidate kernel)", 0);
-          exact_redo(k_phrase_match<false, PHRASE_SMALL_CAP, true>);
-        }
+        TimedLaunch tl(c, stream, "k_phrase_match(left by the 64-candidate kernel)", 0);
+        exact(k_phrase_match<false, PHRASE_SMALL_CAP, true>, left, n_left);
+      }
+      if (redo & PHRASE_REDO_SLOPPY_LANES) {
+        if (sloppy_rpts) sloppy_groups();
+        TimedLaunch tl(c, stream, "k_sloppy_match(left by the 64-candidate kernel)", 0);
+        sloppy(k_sloppy_match<false, SLOPPY_SMALL_POOL, true>, left, n_left);
+      }
+      if (redo & (PHRASE_REDO_LANES | PHRASE_REDO_SLOPPY_LANES)) {
         rc = redo_bits();
         if (rc != RGPU_OK) return rc;
       }
       if (redo & PHRASE_REDO_WIDE) {
         TimedLaunch tl(c, stream, "k_phrase_match(wide lists)", 0);
-        if (legacy) exact_redo(k_phrase_match<true, PHRASE_LIST_CAP, true>); else exact_redo(k_phrase_match<false, PHRASE_LIST_CAP, true>);
+        if (legacy) exact(k_phrase_match<true, PHRASE_LIST_CAP, true>, left, n_left); else exact(k_phrase_match<false, PHRASE_LIST_CAP, true>, left, n_left);
       }
       if (redo & PHRASE_REDO_SLOPPY) {
         TimedLaunch tl(c, stream, "k_sloppy_match(wide pool)", 0);
-        if (legacy) sloppy(k_sloppy_match<true, SLOPPY_POOL, true>); else sloppy(k_sloppy_match<false, SLOPPY_POOL, true>);
+        if (legacy) sloppy(k_sloppy_match<true, SLOPPY_POOL, true>, left, n_left); else sloppy(k_sloppy_match<false, SLOPPY_POOL, true>, left, n_left);
       }
     }
     if (chunked) {

@@ -1,5 +1,5 @@
 """Minimal driver for profiling: build the 10M-doc shard, run one workload a few times through the C ABI.
-usage: run_workload.py [term|and3|or10|decode|cold|posdec|phrase2] [reps]   (DOCS=... sets the shard size; cold = a fresh segment per repetition:
+usage: run_workload.py [term|and3|or10|decode|cold|posdec|phrase2|sloppy2] [reps]   (DOCS=... sets the shard size; cold = a fresh segment per repetition:
 skip decode + block framing + alignment + tails (k_prepare_terms, k_prepare_blocks), then k_decode_terms, for every df >= 128 term)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -19,7 +19,7 @@ if os.environ.get('NONORMS'):
 s = rucene_amd.GpuIndexSearcher([leaf], ctx=ctx)
 T, B = rucene_amd.TermQuery, rucene_amd.BooleanQuery
 SEED = 0x527563656E65 ^ 0x51
-if kind in ("posdec", "phrase2"):
+if kind in ("posdec", "phrase2", "sloppy2"):
     # the positions side: the same corpus indexed with positions
     seg = indexgen.build_zipf(docs, 1_000_000, positions=True)
     leaf = rucene_amd.LeafReader.from_synthetic_positions(seg)
@@ -35,7 +35,8 @@ if kind in ("posdec", "phrase2"):
             leaf.segment.decode_positions_device(sel, selp, tp.data_ptr())
     else:
         ranks = indexgen.log_uniform_ranks(2 * 1024, 1, 1000, SEED ^ 0xF2).reshape(-1, 2) - 1
-        qs, ts = s.pack_phrases([rucene_amd.PhraseQuery([int(a), int(b)]) for a, b in ranks], leaf)
+        # (sloppy2: the same pairs with slop 2 — SloppyPhraseScorer, one candidate per wavefront)
+        qs, ts = s.pack_phrases([rucene_amd.PhraseQuery([int(a), int(b)], slop=2 if kind == "sloppy2" else 0) for a, b in ranks], leaf)
         for _ in range(reps + 2):
             leaf.segment.search_phrase_batch(qs, ts, 10)
 elif kind == "cold":

@@ -1165,6 +1165,9 @@ def test_exact_phrases(ctx, oracle, version, max_doc):
     heavy, heavy2 = len(postings), len(postings) + 1
     postings.append([(d, [3 * j * j + d % 5 for j in range(30)]) for d in range(2000, 2700)])
     postings.append([(d, [3 * j * j + d % 5 + 1 for j in range(0, 30, 2)]) for d in range(1990, 2650, 2)])
+    # positions beyond the 16-bit lists of the 64-candidate sloppy kernel: those docs go to the one-candidate kernel
+    far = len(postings)
+    postings.append([(d, [5, 40_000 + d % 3] if d % 2 else [7 + d % 4]) for d in range(2100, 2400)])
     ix = oracle.PositionsIndex(max_doc, postings, version=version)      # postings[vocab + 2] never occurs
     doc_bytes, pos_bytes = ix.files()
     n = len(postings)
@@ -1212,7 +1215,8 @@ def test_exact_phrases(ctx, oracle, version, max_doc):
     sloppy = [([0, 1], None, 1), ([0, 1], None, 2), ([1, 0], None, 5), ([4, 5, 6], None, 2), ([0, 1, 2, 3], None, 5), ([3, 3], None, 1), ([2, 2, 2], None, 5),
               ([7, 7, 8, 7], None, 2), ([0, 1, 0], None, 1), ([0, 1, 0, 1], None, 5), ([5, 6, 5], [0, 1, 4], 2), ([9, 10, 11, 0, 1], None, 12),
               ([5, vocab + 2], None, 3), ([vocab, 3], None, 2), ([vocab + 1, 0], None, 1), ([1, 0, 1, 2, 1], None, 5), ([3, 4, 5], [0, 1, 3], 1),
-              ([front, back], None, 2), ([back, front], None, 3), ([back, 2, front], None, 6), ([heavy, heavy2], None, 1), ([heavy2, heavy], None, 4)]
+              ([front, back], None, 2), ([back, front], None, 3), ([back, 2, front], None, 6), ([heavy, heavy2], None, 1), ([heavy2, heavy], None, 4),
+              ([far, 0], None, 3), ([1, far], None, 6), ([0, 1, 2, 3, 4, 5, 6], None, 8), ([6, 5, 4, 3, 2, 1], None, 9), ([2, 4], [0, 3], 2)]
     sloppy += [(rng.integers(0, vocab, size=int(rng.integers(2, 5))).tolist(), None, int(rng.integers(1, 7))) for _ in range(30)]
     sloppy += [(rng.integers(0, 4, size=int(rng.integers(2, 6))).tolist(), None, int(rng.integers(1, 9))) for _ in range(30)]   # few distinct terms: repeats galore
     squeries = [rucene_amd.PhraseQuery(t, o, slop=sl) for t, o, sl in sloppy]
@@ -1227,6 +1231,15 @@ def test_exact_phrases(ctx, oracle, version, max_doc):
             assert (hits[i]["score"][:d.size].view(np.int32) == s.view(np.int32)).all(), (i, q.terms, q.slop)
             matched += total
     assert matched > 1000
+    # a batch without a repeated term anywhere: k_sloppy_groups does not run, the left-over candidates (docs 5 and 4000, the `far`
+    # docs, the seven-term phrase) still reach the one-candidate kernel
+    plain = [q for q in squeries if len(set(q.terms)) == len(q.terms)]
+    assert 20 < len(plain) < len(squeries)
+    hits, totals = searcher.search_phrase_batch(plain, 10)
+    for i, q in enumerate(plain):
+        d, s, total = ix.phrase_search(q.terms, 10, norms, max_doc, doc_count, sum_ttf, offsets=q.positions, slop=q.slop)
+        assert totals[i] == total, (i, q.terms, q.positions, q.slop, totals[i], total)
+        assert (hits[i]["doc"][:d.size] == d).all() and (hits[i]["score"][:d.size].view(np.int32) == s.view(np.int32)).all(), (i, q.terms, q.slop)
     with pytest.raises(rucene_amd.RgpuError):
         rucene_amd.PhraseQuery([0, 1], slop=-1)
     # the same field answers plain term / boolean queries (its .doc skip entries carry position pointers)
