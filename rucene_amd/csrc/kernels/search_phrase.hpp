@@ -3,7 +3,9 @@
 //                                     ExactPhraseScorer through a ConjunctionScorer over the terms' postings,
 //                                     query/phrase_query.rs:262-330, scorer/phrase_scorer.rs:131-160): every doc that
 //                                     holds all terms is appended to the query's candidate list;
-//   2. k_phrase_match                 one wavefront per candidate: for every term find the doc's posting (block
+//   2. k_phrase_match_lanes           (packed segments) 64 candidates per wavefront, one per lane; what it hands on, and every
+//      / k_phrase_match               candidate of a legacy segment, one wavefront per candidate. Either way, per candidate:
+//                                     for every term find the doc's posting (block
 //                                     directory -> block -> index, as BlockPostingIterator::advance does,
 //                                     posting_reader.rs:1439-1587), turn "positions buffered before this block" + the
 //                                     freqs of the block's earlier docs into the doc's place in the term's position
@@ -15,7 +17,7 @@
 //                                     intersection of sorted lists of (position - phrase offset); the score is
 //                                     BM25(phrase freq, norm) with the phrase's summed-idf weight (:246-251);
 //   3. k_phrase_collect               TopDocsCollector over the candidates with phrase freq > 0.
-// Sloppy phrases (slop > 0): k_sloppy_groups + k_sloppy_match below instead of k_phrase_match.
+// Sloppy phrases (slop > 0): k_sloppy_match_lanes (2..6 distinct terms), k_sloppy_groups + k_sloppy_match below instead.
 // Fields with payloads or offsets (a third file, .pay): the position BLOCKS are the same; the trailing VInt block of a term
 // carries payload bytes / offset words between its deltas (decode_vint_block_everything) and the skip entries two more words.
 #pragma once
@@ -128,13 +130,13 @@ __device__ __forceinline__ int phrase_doc_positions(const SegView& seg, const De
   return freq;
 }
 
-// (Round 4: a fixed launch whose wavefronts stride — or take contiguous stretches — over the CANDIDATES, 41 M of the benchmark
-// batch's 100 M slots, instead of one wavefront per slot: 112 - 117 ms against 48 for this form, same box. A wavefront that
-// works through candidate after candidate pays each one's chain of dependent loads in full; a fresh wavefront per slot lets the
-// dispatcher keep every wavefront slot of the chip on a different candidate, and an empty slot costs a nanosecond.)
+// (Round 4: a fixed launch whose wavefronts stride — or take contiguous stretches — over the candidates instead of one wavefront
+// per slot was slower by more than two, same box. Those timings, like every timing of this kernel on the 100 M-slot benchmark
+// batch before the launches were cut into PHRASE_LAUNCH_SLOTS pieces, covered the first 32.6 M slots only: the runtime keeps the
+// low 32 bits of a grid's work-item count. What the kernel is bound by is scalar issue — ~1300 instructions per candidate, two
+// thirds of them scalar — which is why the 64-candidate kernels below exist.)
 // slops (nullable): per query PhraseQuery::slop; this kernel serves the queries with slop 0 (the others: k_sloppy_match)
-// CAP: positions of one term inside one doc that the wavefront's two LDS lists hold. The kernel waits on chains of dependent loads
-// (directory search, posting block, position blocks, per term) and hides them with wavefronts: two lists of PHRASE_LIST_CAP
+// CAP: positions of one term inside one doc that the wavefront's two LDS lists hold: two lists of PHRASE_LIST_CAP
 // positions are 32 KB per workgroup — three wavefronts per SIMD. Nearly every doc holds a term a handful of times (Rucene
 // clamps freqs to 10 at write time), so the launch runs with PHRASE_SMALL_CAP-entry lists, eight wavefronts per SIMD; a candidate
 // that does not fit leaves PHRASE_REDO in its key and raises *redo — the host then runs the CAP = PHRASE_LIST_CAP instantiation,
