@@ -549,7 +549,16 @@ __global__ __launch_bounds__(WG_THREADS) void k_sloppy_groups(SegView seg, const
     int32_t dmin = 0x7fffffff;
     // (BulkScorer tests live docs before it calls matches() — bulk_scorer.rs:100 — so the scorer's init_first_time runs on the
     // first LIVE match; deleted candidates carry the sign bit)
-    for (int64_t i = lane; i < n_cand; i += 64) { const int32_t d = emit_docs[emit_prefix[q] + i]; dmin = min(dmin, d < 0 ? 0x7fffffff : d); }
+    // (eight independent loads per lane and round: one load per round made this walk — 2 M candidates for a pair of the commonest
+    // term — a chain of 31 k round trips, 6 ms; an index past the end reads the last candidate again, which a minimum does not mind)
+    const int64_t e0 = emit_prefix[q];
+    for (int64_t i0 = 0; i0 < n_cand; i0 += 64 * 8) {
+      int32_t d[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) d[u] = emit_docs[e0 + min(i0 + 64 * u + lane, n_cand - 1)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) dmin = min(dmin, d[u] < 0 ? 0x7fffffff : d[u]);
+    }
     dmin = 0x7fffffff - (int32_t)wave_reduce_max_u32((uint32_t)(0x7fffffff - dmin));  // min over the lanes (doc ids are >= 0)
     // tp_pos of every repeating pp there = the term's first position in that doc
     int32_t tp = 0;
@@ -1034,16 +1043,38 @@ __global__ __launch_bounds__(WG_THREADS) void k_phrase_cutoff(const int64_t* __r
   if (q >= n_queries) return;
   if (!(slops[q] > 0 && next_limits[q] >= 0)) return;
   const int64_t base = emit_prefix[q], n = (int64_t)emit_count[q];
+  // Fewer candidates than the limit: the misses in front of the first match cannot exceed it, and a query without any match
+  // collects nothing whether it is marked abandoned or not — nothing to decide (and no walk over the candidates).
+  if (n <= (int64_t)next_limits[q]) return;
+  // (n >= 1 from here on. Eight independent loads per lane and round — see k_sloppy_groups; an index past the end reads the last
+  // candidate again and is masked out of the decision)
   int32_t first = 0x7fffffff;
-  for (int64_t i0 = 0; i0 < n; i0 += 64) {
-    const bool hit = i0 + lane < n && keys[base + i0 + lane] != 0ull;
-    if (hit) first = min(first, emit_docs[base + i0 + lane]);
+  for (int64_t i0 = 0; i0 < n; i0 += 64 * 8) {
+    uint64_t kk[8];
+    int32_t dd[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int64_t at = base + min(i0 + 64 * u + lane, n - 1);
+      kk[u] = keys[at];
+      dd[u] = emit_docs[at];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const bool hit = i0 + 64 * u + lane < n && kk[u] != 0ull;
+      first = hit ? min(first, dd[u]) : first;
+    }
   }
   first = 0x7fffffff - (int32_t)wave_reduce_max_u32((uint32_t)(0x7fffffff - first));
   int64_t before = 0;
-  for (int64_t i0 = 0; i0 < n; i0 += 64) {
-    const bool earlier = i0 + lane < n && (emit_docs[base + i0 + lane] & 0x7fffffff) < first;
-    before += __popcll(__ballot(earlier));
+  for (int64_t i0 = 0; i0 < n; i0 += 64 * 8) {
+    int32_t dd[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) dd[u] = emit_docs[base + min(i0 + 64 * u + lane, n - 1)];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const bool earlier = i0 + 64 * u + lane < n && (dd[u] & 0x7fffffff) < first;
+      before += __popcll(__ballot(earlier));
+    }
   }
   if (lane == 0 && (first == 0x7fffffff || before > (int64_t)next_limits[q])) abandoned[q] = 1;
 }
