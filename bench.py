@@ -557,7 +557,7 @@ def main():
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             from oracle import binding as orc   # the checker, after the timed region
             ix = orc.PositionsIndex.from_files(seg.doc_bytes, seg.pos_bytes, seg.terms, leaf.term_positions)
-            n_chk, ok, spent = min(n_phrases, 96), True, 0.0
+            n_chk, ok, spent = min(n_phrases, 1024), True, 0.0   # (every query of the batch: ~3 s of oracle time; round 4's launch-size bug sat behind query 358)
             for i in range(n_chk):
                 t0 = time.perf_counter()
                 d, sc, tot = ix.phrase_search([int(ranks[i, 0]), int(ranks[i, 1])], k, seg.norms, seg.max_doc, seg.doc_count, seg.sum_total_term_freq)
