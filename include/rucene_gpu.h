@@ -529,9 +529,12 @@ typedef struct rgpu_phrase_query {
                           (bulk_scorer.rs:97-113): every conjunction match of the phrase's terms — phrase or not, live or deleted —
                           counts, and a leaf on which more than next_limit of them went by before the first collected doc is
                           abandoned: the query then has NO hit in this segment. DefaultIndexSearcher::new(reader, next_limit):
-                          0 = its default, DEFAULT_DISMATCH_NEXT_LIMIT = 500 000 (searcher.rs:47, :361); n > 0 = n; -1 = no limit.
+                          0 = its default, DEFAULT_DISMATCH_NEXT_LIMIT = 500 000 (searcher.rs:47, :361); n > 0 = n; -1 = no limit;
+                          RGPU_NEXT_LIMIT_ZERO = Some(0): the leaf is abandoned as soon as one approximation went by uncollected
+                          (a zero-filled struct keeps meaning "the default", as it did when the field was `reserved`).
                           (ExactPhraseScorer is not two-phase in the reference — slop 0 ignores this field) */
 } rgpu_phrase_query;
+#define RGPU_NEXT_LIMIT_ZERO (-2)
 /* One leaf of IndexSearcher::search(PhraseQuery, TopDocsCollector(k)): PhraseWeight::create_scorer (None when a term is
  * absent from the leaf) -> slop 0: ExactPhraseScorer (scorer/phrase_scorer.rs:122-294) — a doc matches when the terms occur
  * at their phrase offsets, its score is BM25(phrase frequency, norm); slop > 0: SloppyPhraseScorer (:432-1071) — the

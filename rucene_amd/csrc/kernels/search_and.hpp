@@ -25,6 +25,16 @@ __device__ unsigned long long g_and_dbg[4];  // [2] probed candidates, [3] (lead
 #else
 #define AND_DBG(i, n) do {} while (0)
 #endif
+#ifdef RGPU_AND_TIME  // developer instrumentation (variant builds only): wave-cycles per phase, summed over the launch's wavefronts
+__device__ unsigned long long g_and_time[16];  // [0] item set-up [1] batched first probe [2] candidate loop on queued survivors
+                                               // [3] candidate loop block by block [4] item epilogue [5] items [6] pops [7] block-by-block vectors
+                                               // [8] queued survivors [9] walked-clause block decodes (popped) [10] ... (block by block)
+#define AND_STAMP(t) const long long t = (long long)__builtin_readcyclecounter()
+#define AND_TADD(i, v) and_t[i] += (long long)(v)
+#else
+#define AND_STAMP(t) do {} while (0)
+#define AND_TADD(i, v) do {} while (0)
+#endif
 
 // Occupancy against registers: at 8 waves/SIMD (64 VGPRs, 80 SGPRs) the kernel spilled 90-120 bytes per lane to
 // scratch (551 MB of writes per launch of the 3-term workload, round 1). With the VInt tail decoder moved to prepare
@@ -32,7 +42,7 @@ __device__ unsigned long long g_and_dbg[4];  // [2] probed candidates, [3] (lead
 // (scripts/kernel_resources.py); measured 1.58-1.61 ms at 5 against 1.52-1.58 ms at 8 with spills (VALU-bound, not
 // latency-bound: 86 % VALU busy).
 #ifndef RGPU_AND_WAVES
-#define RGPU_AND_WAVES 5
+#define RGPU_AND_WAVES 4
 #endif
 constexpr int AND_WAVES_PER_SIMD = RGPU_AND_WAVES;
 #ifndef RGPU_AND_PREFETCH  // 1: the next block's rows are requested before the current one is unpacked (five more VGPRs)
@@ -103,6 +113,28 @@ struct DirWindow {
 
 constexpr int AND_FILTER_WORDS = 64;  // 2048-bit membership filter per wavefront
 
+// Round 5: the batched first probe. The kernel was two to four DEPENDENT round trips per lead block (directory -> rows ->
+// first clause's gather -> second clause's gather) at five wavefronts per SIMD: 65 % of its wave cycles waited. When the first
+// clause behind the lead has a doc bitmap, an item now takes its lead blocks AND_G at a time: all their rows are requested
+// together (row addresses from a register window over the lead's directory), each is unpacked while the next one's rows and the
+// previous one's gathers are in flight, and the first clause is asked about all 128 * AND_G candidates at once — one gather
+// per candidate into the four-bits-per-doc array (membership + freq) or the membership words. What survives (a doc in five at
+// most, usually far fewer) is appended, in doc order, to a wave-private LDS queue of {doc, norm byte | first-clause freq code
+// | lead freq}; whenever 128 survivors have gathered (or the item ends) they are popped two per lane and take the candidate
+// loop below from the second clause on. The later clauses therefore see a tenth of the gathers, the BM25 divisions of the lead
+// and the first clause are only done for survivors, and the top-k list is offered full vectors. Same candidates, same f32 sums
+// in the same order: bit-exact with the block-by-block path (which still serves a walked first clause, the lead's tail /
+// singleton, ReqOptScorer records and lead freqs of 2^20 or more).
+#ifndef RGPU_AND_FAST
+#define RGPU_AND_FAST 1
+#endif
+#ifndef RGPU_AND_G
+#define RGPU_AND_G 4
+#endif
+constexpr int AND_G = RGPU_AND_G;
+constexpr int AND_Q_CAP = 128 + 128 * AND_G;  // fewer than 128 entries wait when a group of AND_G blocks is appended
+constexpr uint32_t AND_Q_FREQ_LIMIT = 1u << 20;  // a lead freq must fit the entry's 20 bits (Rucene clamps freqs to 10 at write time)
+
 // What a MUST + SHOULD tree leaves per LEAD posting when the reference's ReqOptScorer rule is applied (k_req_opt_scan):
 // the conjunction's matches in doc order (= lead posting order), each with its required and its optional sum. A lead
 // posting that is no match (or a deleted doc) leaves doc = -1.
@@ -144,10 +176,18 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
   __shared__ __attribute__((aligned(16))) uint8_t slabs[WG_WAVES][2 * SLAB_STREAM];  // FullBlock staging only: tails arrive decoded
   __shared__ float caches[WG_WAVES][256];
   __shared__ uint32_t filters[WG_WAVES][AND_FILTER_WORDS];
+#if RGPU_AND_FAST
+  __shared__ uint2 queues[WG_WAVES][AND_Q_CAP];  // survivors of the batched first probe: {doc, norm | code << 8 | lead freq << 12}
+#endif
   const int lane = lane_id();
   const int wave = wave_id();
   const int64_t item = (int64_t)blockIdx.x * WG_WAVES + wave;
   if (item >= n_items) return;
+#ifdef RGPU_AND_TIME
+  long long and_t[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  bool and_popped = false;
+#endif
+  AND_STAMP(ts0);
   const int q = upper_slot_wave(item_prefix, n_queries, item, lane);
   const int chunk = (int)(item - item_prefix[q]);
   const DevQuery Q = queries[q];
@@ -175,7 +215,9 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
 
   // nn: the candidates' norm bytes — from the lead's posting-order norms for FullBlocks, gathered for
   // its tail; every other clause scores the same docs, so no clause ever gathers norms again
-  auto intersect = [&](int32_t d0, int32_t d1, uint32_t f0, uint32_t f1, uint32_t nn, bool a0, bool a1, int32_t ord0) {  // nn = norm byte 0 | norm byte 1 << 8; ord0 = ordinal of the wave's first lead posting
+  // ti_start = 2: the candidates come from the survivor queue — they ARE in the first clause, with freqs c1f0 / c1f1
+  auto intersect = [&](int32_t d0, int32_t d1, uint32_t f0, uint32_t f1, uint32_t nn, bool a0, bool a1, int32_t ord0, int ti_start, uint32_t c1f0,
+                       uint32_t c1f1) {  // nn = norm byte 0 | norm byte 1 << 8; ord0 = ordinal of the wave's first lead posting
     // (phrase candidates keep their deleted docs — marked when they are emitted: the two-phase loop of bulk_scorer.rs counts
     // every approximation towards next_limit, live or not; the branch is scalar)
     const uint64_t* const live_here = (!HAS_OPT && emit_out != nullptr) ? nullptr : seg.live;
@@ -195,7 +237,14 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
     const int n_clauses = HAS_OPT ? n_req_not + ((Q.op >> 16) & 0xff) : n_req_not;
     float r0 = 0.f, r1 = 0.f;  // required sums, parked while s0 / s1 collect the optional sum
     bool in_opt = false;
-    for (int ti = 1; ti < n_clauses; ++ti) {
+    if (RGPU_AND_FAST && ti_start == 2) {  // the first clause's score, added where the clause loop would have added it
+      const DevTerm T1 = terms[Q.first_term + 1];
+      use_table(T1.sim_table);
+      wk = T1.weight * (k1 + 1.0f);
+      s0 += bm25_score(wk, (float)(int32_t)c1f0, has_norms ? cache[nn & 0xffu] : k1);
+      s1 += bm25_score(wk, (float)(int32_t)c1f1, has_norms ? cache[nn >> 8] : k1);
+    }
+    for (int ti = RGPU_AND_FAST ? ti_start : 1; ti < n_clauses; ++ti) {
       if (!(__ballot(a0) | __ballot(a1))) break;
       const bool excl = HAS_NOT && ti >= Q.n_terms && ti < n_req_not;  // wave-uniform
       const bool opt = HAS_OPT && ti >= n_req_not;                      // wave-uniform
@@ -387,6 +436,9 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
           wave_sync();
           touched += block_bytes(A.hdr);
           AND_DBG(1, 1);
+#ifdef RGPU_AND_TIME
+          and_t[and_popped ? 9 : 10] += 1;
+#endif
           uint32_t x0, x1;
           staged_doc_deltas<LEGACY>(slab, A.rows, A.hdr, lane, x0, x1);
           int32_t e0, e1;
@@ -432,13 +484,179 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
     topk_offer<WIDE>(top, a1 ? below(make_key(s1, d1), ceil) : 0ull, tau, k, lane, floor);
   };
 
-  // One call site for the three shapes a lead "block" can take (FullBlock, VInt tail, singleton): the candidate loop
-  // above is large, and inlining it three times tripled the kernel's code and its register pressure.
+  // One call site for the shapes a vector of candidates can take (FullBlock, VInt tail, singleton, 128 queued survivors): the
+  // candidate loop above is large, and inlining it three times tripled the kernel's code and its register pressure.
   const int b0 = chunk * blocks_per_item;
   const int b1 = min(L.nblocks, b0 + blocks_per_item);
   const bool with_rest = b1 == L.nblocks && (L.df == 1 || L.tail_n > 0);  // this item also takes the tail / singleton
+  const int b_end = b1 + (with_rest ? 1 : 0);
+#if RGPU_AND_FAST
+  const uint8_t* const lead_rows = seg.bstore + L.bs_base;
+  // posting-order norms of the lead (any readable address when the segment has none: the load is unconditional, its value unused)
+  const uint8_t* const lead_pn = has_norms ? seg.pnorm + L.pn_base : lead_rows;
+  // the batched first probe needs: a doc bitmap for the first clause behind the lead, that clause required (not MUST_NOT / SHOULD),
+  // a collector that takes matches in vectors (not ReqOptScorer's one-record-per-lead-posting form)
+  bool fast = b1 > b0 && bitmaps != nullptr && Q.n_terms >= 2 && !(HAS_OPT && seq_out != nullptr);
+  typedef const __attribute__((address_space(1))) uint32_t* gwords1;
+  gwords1 probe_src = nullptr;
+  int probe_nib = 0;  // 1: four bits per doc {absent, freq 1..14, 15 = look it up}; 0: one membership bit per doc in every other word
+  if (fast) {
+    const TermBitmap B1 = bitmaps[Q.first_term + 1];
+    fast = B1.words != nullptr;
+    probe_nib = B1.nib != nullptr ? 1 : 0;
+    probe_src = (gwords1)(uintptr_t)(B1.nib != nullptr ? (const void*)B1.nib : (const void*)B1.words);
+  }
+  uint2* const queue = queues[wave];
+  int qhead = 0, qtail = 0;
+  int lw0 = b0;  // LW: a register window over the lead's directory — slot j >= 1 = block lw0 + j - 1, its base doc in slot j - 1
+  DirWindow LW;
+  LW.load(seg, L.dir_base, L.nblocks, lw0, lane);
+  int blk = b0;
+  AND_STAMP(ts1);
+  AND_TADD(0, ts1 - ts0);
+  AND_TADD(5, 1);
+  while (true) {
+    AND_STAMP(tl0);
+    if (blk < b1 && blk - lw0 > 63 - AND_G) { lw0 = blk; LW.load(seg, L.dir_base, L.nblocks, lw0, lane); }
+    if (fast && blk < b1 && qtail - qhead < 128) {
+      // ---- AND_G lead blocks: rows requested together, unpacked one after the other, 2 * AND_G gathers per lane in flight ----
+      const int qn = qtail - qhead;
+      if (qhead > 0) {  // what waits moves to the front (fewer than 128 entries)
+        const uint2 m0 = lane < qn ? queue[qhead + lane] : make_uint2(0u, 0u);
+        const uint2 m1 = lane + 64 < qn ? queue[qhead + 64 + lane] : make_uint2(0u, 0u);
+        wave_sync();
+        if (lane < qn) queue[lane] = m0;
+        if (lane + 64 < qn) queue[lane + 64] = m1;
+        wave_sync();
+        qhead = 0;
+        qtail = qn;
+      }
+      const int nb = min(AND_G, b1 - blk);
+      uint4 rows[AND_G];
+      uint32_t nnv[AND_G], hdrs[AND_G];
+#pragma unroll
+      for (int g = 0; g < AND_G; ++g) {  // (indices clamped, not guarded: a repeated block costs less than a load behind a branch)
+        const int bi = min(blk + g, b1 - 1);
+        const int j = bi - lw0 + 1;
+        hdrs[g] = (uint32_t)readlane((int)LW.hdr, j);
+        rows[g] = block_rows_load(block_rows_at(lead_rows, (uint32_t)readlane((int)LW.row, j)), hdrs[g], lane);
+        nnv[g] = *reinterpret_cast<const uint16_t*>(lead_pn + (128u * (uint32_t)bi + 2u * (uint32_t)lane));
+      }
+      int32_t D[2 * AND_G];
+      uint32_t P[2 * AND_G], V[2 * AND_G];
+      bool too_wide = false;
+      const int sh = probe_nib ? 3 : 5, mul = probe_nib ? 1 : 2;
+#pragma unroll
+      for (int g = 0; g < AND_G; ++g) {
+        stage_rows(rows[g], slab, lane);
+        wave_sync();
+        uint32_t x0, x1, y0, y1;
+        staged_doc_deltas<LEGACY>(slab, rows[g], hdrs[g], lane, x0, x1);
+        staged_freqs<LEGACY>(slab, rows[g], hdrs[g], lane, y0, y1);
+        wave_sync();  // the slab is free for the next block
+        const int bi = min(blk + g, b1 - 1);
+        deltas_to_docs(x0, x1, readlane(LW.last, bi - lw0), D[2 * g], D[2 * g + 1]);
+        too_wide = too_wide || __ballot(y0 >= AND_Q_FREQ_LIMIT || y1 >= AND_Q_FREQ_LIMIT) != 0;
+        const uint32_t n2 = has_norms ? nnv[g] : 0u;
+        P[2 * g] = (n2 & 0xffu) | (y0 << 12);
+        P[2 * g + 1] = (n2 >> 8) | (y1 << 12);
+        V[2 * g] = probe_src[((uint32_t)D[2 * g] >> sh) * (uint32_t)mul];
+        V[2 * g + 1] = probe_src[((uint32_t)D[2 * g + 1] >> sh) * (uint32_t)mul];
+      }
+      if (too_wide) {  // a lead freq that does not fit a queue entry: nothing of this group is kept, the rest of the item goes block by block
+        fast = false;
+        continue;
+      }
+#pragma unroll
+      for (int g = 0; g < AND_G; ++g) {
+        if (g < nb) {  // wave-uniform
+          const int32_t e0 = D[2 * g], e1 = D[2 * g + 1];
+          const uint32_t c0 = probe_nib ? (V[2 * g] >> (4 * (e0 & 7))) & 15u : ((V[2 * g] >> (e0 & 31)) & 1u) * 15u;
+          const uint32_t c1 = probe_nib ? (V[2 * g + 1] >> (4 * (e1 & 7))) & 15u : ((V[2 * g + 1] >> (e1 & 31)) & 1u) * 15u;
+          const uint64_t m0 = __ballot(c0 != 0u), m1 = __ballot(c1 != 0u);
+          const int at = qtail + mbcnt(m0) + mbcnt(m1);  // doc order: (lane, slot 0), (lane, slot 1), (lane + 1, slot 0) ...
+          if (c0 != 0u) queue[at] = make_uint2((uint32_t)e0, P[2 * g] | (c0 << 8));
+          if (c1 != 0u) queue[at + (c0 != 0u ? 1 : 0)] = make_uint2((uint32_t)e1, P[2 * g + 1] | (c1 << 8));
+          qtail += __popcll(m0) + __popcll(m1);
+          touched += block_bytes(hdrs[g]) + 4u * 128u;
+          AND_DBG(0, 1);
+        }
+      }
+      wave_sync();
+      blk += nb;
+      {
+        AND_STAMP(tl1);
+        AND_TADD(1, tl1 - tl0);
+      }
+      continue;
+    }
+    int32_t d0, d1;
+    uint32_t f0, f1, nn = 0u, c1f0 = 0u, c1f1 = 0u;
+    bool a0, a1;
+    int ti_start = 1;
+    int32_t ord0 = 0;
+    if (qtail > qhead) {  // up to 128 survivors of the first probe, two per lane in doc order
+      const int n = min(128, qtail - qhead);
+      a0 = 2 * lane < n;
+      a1 = 2 * lane + 1 < n;
+      const uint2 e0 = a0 ? queue[qhead + 2 * lane] : make_uint2(0u, 0u);
+      const uint2 e1 = a1 ? queue[qhead + 2 * lane + 1] : make_uint2(0u, 0u);
+      wave_sync();
+      qhead += n;
+      d0 = (int32_t)e0.x; d1 = (int32_t)e1.x;
+      f0 = e0.y >> 12; f1 = e1.y >> 12;
+      nn = (e0.y & 0xffu) | ((e1.y & 0xffu) << 8);
+      c1f0 = (e0.y >> 8) & 15u; c1f1 = (e1.y >> 8) & 15u;
+      // a code of 15 = "in the list, freq not in the probe's word": the clause loop asks the first clause again (it finds them all)
+      ti_start = __ballot((a0 && c1f0 == 15u) || (a1 && c1f1 == 15u)) ? 1 : 2;
+#ifdef RGPU_AND_TIME
+      and_popped = true;
+      and_t[6] += 1;
+      and_t[8] += n;
+#endif
+    } else if (blk < b_end) {
+#ifdef RGPU_AND_TIME
+      and_popped = false;
+      and_t[7] += 1;
+#endif
+      if (blk < L.nblocks) {
+        const int j = blk - lw0 + 1;
+        const uint32_t lhdr = (uint32_t)readlane((int)LW.hdr, j);
+        if (has_norms) nn = *reinterpret_cast<const uint16_t*>(lead_pn + (128u * (uint32_t)blk + 2u * (uint32_t)lane));
+        const BlockPair bp = decode_block<LEGACY>(lead_rows, (uint32_t)readlane((int)LW.row, j), lhdr, slab, lane);
+        touched += block_bytes(lhdr);
+        deltas_to_docs(bp.d0, bp.d1, readlane(LW.last, j - 1), d0, d1);
+        f0 = bp.f0; f1 = bp.f1;
+        a0 = true; a1 = true;
+        ord0 = 128 * blk;
+        AND_DBG(0, 1);
+      } else if (L.df == 1) {
+        d0 = d1 = L.singleton_doc;
+        f0 = (uint32_t)L.singleton_freq; f1 = 0u;
+        a0 = lane == 0; a1 = false;
+        if (has_norms && a0) nn = norm_at(seg, d0);
+      } else {
+        tail_load(lead_rows, seg.dir_row[L.dir_base + L.nblocks], lane, d0, d1, f0, f1);
+        a0 = 2 * lane < L.tail_n; a1 = 2 * lane + 1 < L.tail_n;
+        if (has_norms && a0) nn = norm_at(seg, d0);
+        if (has_norms && a1) nn |= norm_at(seg, d1) << 8;
+        ord0 = 128 * L.nblocks;
+      }
+      ++blk;
+    } else {
+      break;
+    }
+    intersect(d0, d1, f0, f1, nn, a0, a1, ord0, ti_start, c1f0, c1f1);
+#ifdef RGPU_AND_TIME
+    {
+      AND_STAMP(tl2);
+      and_t[and_popped ? 2 : 3] += tl2 - tl0;
+    }
+#endif
+  }
+#else
   int32_t base = b0 == 0 ? 0 : seg.dir_last[L.dir_base + b0 - 1];
-  for (int blk = b0; blk < b1 + (with_rest ? 1 : 0); ++blk) {
+  for (int blk = b0; blk < b_end; ++blk) {
     int32_t d0, d1;
     uint32_t f0, f1, nn = 0u;
     bool a0, a1;
@@ -464,8 +682,10 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
       if (has_norms && a1) nn |= norm_at(seg, d1) << 8;
     }
     if (RGPU_AND_ABL == 1) { if (a0 && d0 == 12345 && f0 == 77 && nn == 3) count++; continue; }
-    intersect(d0, d1, f0, f1, nn, a0, a1, blk < L.nblocks ? 128 * blk : (L.df == 1 ? 0 : 128 * L.nblocks));
+    intersect(d0, d1, f0, f1, nn, a0, a1, blk < L.nblocks ? 128 * blk : (L.df == 1 ? 0 : 128 * L.nblocks), 1, 0u, 0u);
   }
+#endif
+  AND_STAMP(te0);
   shared.publish<WIDE>(top, k, lane);
   uint64_t* pk = partial_keys + (size_t)item * (size_t)k;
   if (lane < k) pk[lane] = top.a;
@@ -475,6 +695,14 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
     atomicAdd(touched_slots + q, (unsigned long long)touched);  // ~160 items per query word: no contention to speak of
     atomicAdd(touched_slots + n_queries + q, (unsigned long long)touched_blocks);
   }
+#ifdef RGPU_AND_TIME
+  {
+    AND_STAMP(te1);
+    and_t[4] += te1 - te0;
+    if (lane == 0)
+      for (int i = 0; i < 11; ++i) atomicAdd(&g_and_time[i], (unsigned long long)and_t[i]);
+  }
+#endif
 }
 
 // ReqOptScorer::score (search/scorer/req_opt_scorer.rs:41-66) over a query's matches in doc order, one wavefront per query.

@@ -365,7 +365,9 @@ __device__ __forceinline__ int lanes_doc_positions(const SegView& seg, const Dev
     auto packed_at = [&](int64_t at) -> uint32_t {
       if (at < 0 || at + 2 > pos_len || at == P.last_pos_block_fp) return 0u;
       const uint32_t b = seg.pos[at];
-      return b <= 32u ? b : 0u;
+      // the whole block must lie inside the file: a truncated one is handed on to k_phrase_match, which reports it
+      // as RGPU_ERR_CORRUPT_INDEX, instead of being read from the padding behind the file
+      return (b <= 32u && at + 1 + 16 * (int64_t)b <= pos_len) ? b : 0u;
     };
     b0 = packed_at(fp);
     if (RGPU_LANES_ABL == 5) skip &= 127;
@@ -560,9 +562,13 @@ __global__ __launch_bounds__(WG_THREADS) void k_sloppy_groups(SegView seg, const
       for (int u = 0; u < 8; ++u) dmin = min(dmin, d[u] < 0 ? 0x7fffffff : d[u]);
     }
     dmin = 0x7fffffff - (int32_t)wave_reduce_max_u32((uint32_t)(0x7fffffff - dmin));  // min over the lanes (doc ids are >= 0)
+    // Every candidate of the leaf is a deleted doc (the conjunction emits them with the sign bit set, so n_cand > 0
+    // does not promise a live one): matches() is never called in this leaf, init_first_time never runs — the groups stay at
+    // their -1 defaults and no position is looked up (the old code went looking for doc 0x7fffffff and failed the batch).
+    const bool any_live = dmin != 0x7fffffff;
     // tp_pos of every repeating pp there = the term's first position in that doc
     int32_t tp = 0;
-    uint64_t m = rpp;
+    uint64_t m = any_live ? rpp : 0ull;
     while (m) {
       const int i = (int)__builtin_ctzll(m);
       m &= m - 1;
@@ -577,7 +583,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_sloppy_groups(SegView seg, const
     // gather_rpt_groups, the arm without multi-term postings (:841-871), then sort_rpt_groups (:826-838)
     int32_t grp = -1;
     int n_groups = 0;
-    uint64_t m1 = rpp;
+    uint64_t m1 = any_live ? rpp : 0ull;
     while (m1) {
       const int i1 = (int)__builtin_ctzll(m1);
       m1 &= m1 - 1;

@@ -317,9 +317,10 @@ class GpuIndexSearcher:
         self.leaves = list(leaves)
         # DefaultIndexSearcher::new(reader, next_limit: Option<usize>) (searcher.rs:291-296, :361): how many approximations of a
         # two-phase scorer (here: sloppy phrases) may go by on a leaf without a collected doc. None = the default, 500 000
-        if next_limit is not None and int(next_limit) < 1:
-            raise RgpuError(-2, "next_limit must be >= 1 (None: the reference's default of 500 000)")
-        self.next_limit = 0 if next_limit is None else int(next_limit)
+        if next_limit is not None and int(next_limit) < 0:
+            raise RgpuError(-2, "next_limit must be >= 0 (None: the reference's default of 500 000)")
+        # (the C ABI spells Some(0) RGPU_NEXT_LIMIT_ZERO = -2: a zero there keeps meaning "the default")
+        self.next_limit = 0 if next_limit is None else (-2 if int(next_limit) == 0 else int(next_limit))
         self.ctx = ctx or _lib.Context()
         self.similarity = similarity or BM25Similarity()
         for leaf in self.leaves:

@@ -73,6 +73,36 @@ def test_integration_guide_binds_every_entry_point():
     assert not missing, "INTEGRATION.md's FFI block lacks: %s" % missing
 
 
+def test_rust_shim_files_follow_the_header(gpu_lib):
+    """rust/gpu/ffi.rs (the shim's FFI block) is generated from include/rucene_gpu.h: the committed file must be what
+    the generator writes today, bind every symbol the library exports, and give every #[repr(C)] struct the size the header's has."""
+    import re
+    import subprocess
+    import sys
+    gen = os.path.join(ROOT, "scripts", "gen_rust_ffi.py")
+    subprocess.run([sys.executable, gen, "--check"], check=True)
+    ffi = open(os.path.join(ROOT, "rust", "gpu", "ffi.rs")).read()
+    bound = set(re.findall(r"pub fn (rgpu_\w+)\(", ffi))
+    assert bound == set(gpu_lib.EXPORTS) == set(_header_functions())
+    size = {"i32": 4, "f32": 4, "i64": 8, "f64": 8, "u8": 1, "c_char": 1, "u64": 8, "u32": 4}
+
+    def struct_bytes(name):
+        body = re.search(r"pub struct %s \{(.*?)\n\}" % name, ffi, flags=re.S).group(1)
+        total = 0
+        for ty in re.findall(r"pub \w+: ([^,]+),", body):
+            m = re.match(r"\[(\w+); (\d+)\]", ty)
+            total += size[m.group(1)] * int(m.group(2)) if m else (size[ty] if ty in size else struct_bytes(ty))
+        return total
+    for rust_name, dt in (("RgpuTermState", gpu_lib.TERM_STATE_DTYPE), ("RgpuQueryTerm", gpu_lib.QUERY_TERM_DTYPE), ("RgpuQuery", gpu_lib.QUERY_DTYPE),
+                          ("RgpuHit", gpu_lib.HIT_DTYPE), ("RgpuTermPositions", gpu_lib.TERM_POSITIONS_DTYPE), ("RgpuPhraseQuery", gpu_lib.PHRASE_QUERY_DTYPE),
+                          ("RgpuSegmentInfo", gpu_lib.SEGMENT_INFO_DTYPE), ("RgpuCommitSegment", gpu_lib.COMMIT_SEGMENT_DTYPE)):
+        assert struct_bytes(rust_name) == dt.itemsize, rust_name   # (no padding in any of them: fields are naturally aligned)
+    assert struct_bytes("RgpuConfig") == C.sizeof(gpu_lib._Config)
+    searcher = open(os.path.join(ROOT, "rust", "gpu", "searcher.rs")).read()
+    used = set(re.findall(r"\b(rgpu_[a-z_0-9]+)\(", searcher)) - {"rgpu_op_or_msm", "rgpu_op_with_should"}
+    assert used and used <= bound, used - bound   # the seam only calls what ffi.rs declares
+
+
 def test_struct_layouts_match_the_header(gpu_lib):
     assert gpu_lib.TERM_STATE_DTYPE.itemsize == 32
     assert gpu_lib.TERM_POSITIONS_DTYPE.itemsize == 24 and gpu_lib.FIELD_INFO_DTYPE.itemsize == 16 and gpu_lib.FIELD_STATS_DTYPE.itemsize == 32

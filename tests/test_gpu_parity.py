@@ -1400,7 +1400,7 @@ def test_phrases_two_phase_rule_and_deletions(ctx, oracle, deletions):
             live[d >> 6] |= np.uint64(1) << np.uint64(d & 63)
     phrases = [([0, 1], 1), ([1, 0], 2), ([0, 1, 0], 2), ([0, 1, 2], 3), ([2, 3], 1), ([4, 4], 2), ([0, 1], 0), ([2, 3, 4], 0), ([0, 5, 1], 0)]
     cut = matched = 0
-    for limit in (None, 1, 100, 499, 500, 3000):
+    for limit in (None, 0, 1, 100, 499, 500, 3000):  # (0 = DefaultIndexSearcher::new(reader, Some(0)): RGPU_NEXT_LIMIT_ZERO in the C ABI)
         leaf = rucene_amd.LeafReader(np.frombuffer(doc_bytes, np.uint8), norms, max_doc, terms, live_docs=live, doc_count=doc_count,
                                      sum_total_term_freq=sum_ttf, index_options=3)
         leaf.pos_bytes, leaf.term_positions = np.frombuffer(pos_bytes, np.uint8), tpos
@@ -1418,6 +1418,63 @@ def test_phrases_two_phase_rule_and_deletions(ctx, oracle, deletions):
                     cut += 1
         leaf.segment.close()
     assert cut >= 4 and matched > 1000  # [0, 1] / [1, 0] / [0, 1, 0] meet the 500-doc stretch first: cut off for the small limits
+    ix.close()
+
+
+def test_sloppy_repeated_term_when_every_candidate_is_deleted(ctx, oracle):
+    """a sloppy phrase that repeats a term, on a leaf where every conjunction match is a deleted doc. The
+    conjunction hands deleted candidates on (they count as approximations), so 'there are candidates' does not mean a live one
+    exists: the reference never calls matches() there and returns no hit; k_sloppy_groups used to look up positions of doc
+    0x7fffffff and fail the whole batch (or, for a df == 1 term, read another doc's positions)."""
+    import rucene_amd
+    from rucene_amd import _lib as gpu
+    rng = np.random.default_rng(77)
+    max_doc, vocab = 3000, 5
+    docs = [rng.integers(0, 3, size=int(rng.integers(1, 12))).tolist() for _ in range(max_doc)]
+    with_x = [17, 300, 301, 2200]           # the only docs holding term 3 (twice or more each): all of them deleted below
+    for d in with_x:
+        docs[d] = [3, 0, 3, 1, 3]
+    docs[1234] = [4, 2, 4]                  # term 4: df == 1 (a singleton: it lives in the term dictionary entry), deleted too
+    postings = [[] for _ in range(vocab)]
+    for d, toks in enumerate(docs):
+        where = {}
+        for p, t in enumerate(toks):
+            where.setdefault(t, []).append(p)
+        for t, ps in where.items():
+            postings[t].append((d, ps))
+    ix = oracle.PositionsIndex(max_doc, postings)
+    doc_bytes, pos_bytes = ix.files()
+    terms = np.zeros(vocab, dtype=gpu.TERM_STATE_DTYPE)
+    tpos = np.zeros(vocab, dtype=gpu.TERM_POSITIONS_DTYPE)
+    for t in range(vocab):
+        st = ix.term_state(t)
+        terms[t] = (st["doc_start_fp"], st["skip_offset"], st["total_term_freq"], st["doc_freq"], st["singleton_doc_id"])
+        tpos[t]["pos_start_fp"], tpos[t]["last_pos_block_offset"] = st["pos_start_fp"], st["last_pos_block_offset"]
+    norms = rng.integers(95, 125, size=max_doc).astype(np.uint8)
+    doc_count, sum_ttf = max_doc, sum(len(t) for t in docs)
+    alive = np.ones(max_doc, dtype=bool)
+    alive[with_x] = False
+    alive[1234] = False
+    live = np.zeros((max_doc + 63) // 64, dtype=np.uint64)
+    for d in np.nonzero(alive)[0]:
+        live[d >> 6] |= np.uint64(1) << np.uint64(d & 63)
+    leaf = rucene_amd.LeafReader(np.frombuffer(doc_bytes, np.uint8), norms, max_doc, terms, live_docs=live, doc_count=doc_count,
+                                 sum_total_term_freq=sum_ttf, index_options=3)
+    leaf.pos_bytes, leaf.term_positions = np.frombuffer(pos_bytes, np.uint8), tpos
+    searcher = rucene_amd.GpuIndexSearcher([leaf], ctx=ctx)
+    # [3, 3] / [4, 4]: only deleted candidates; [0, 0] / [0, 1, 0]: live ones in the same batch (its groups must not suffer)
+    phrases = [([3, 3], 2), ([4, 4], 2), ([3, 0, 3], 3), ([0, 0], 2), ([0, 1, 0], 2), ([3, 3], 0)]
+    queries = [rucene_amd.PhraseQuery(t, slop=sl) for t, sl in phrases]
+    hits, totals = searcher.search_phrase_batch(queries, 10)
+    found = 0
+    for i, q in enumerate(queries):
+        d, s, total = ix.phrase_search(q.terms, 10, norms, max_doc, doc_count, sum_ttf, slop=q.slop, live_docs=live)
+        assert totals[i] == total, (q.terms, q.slop, totals[i], total)
+        assert (hits[i]["doc"][:d.size] == d).all() and (hits[i]["doc"][d.size:] == -1).all(), (q.terms, q.slop)
+        assert (hits[i]["score"][:d.size].view(np.int32) == s.view(np.int32)).all(), (q.terms, q.slop)
+        found += total
+    assert totals[0] == 0 and totals[1] == 0 and totals[2] == 0 and totals[5] == 0 and found > 0
+    leaf.segment.close()
     ix.close()
 
 
