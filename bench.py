@@ -42,7 +42,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 SEED_QUERIES = 0x527563656E65 ^ 0x51  # "Rucene" ^ purpose tag
-ROUND = "r04"
+ROUND = "r05"
 
 
 def term_encoded_bytes(terms, doc_len_end):
@@ -289,41 +289,94 @@ def main():
             res["force_dist_same"] = bool(torch.equal(merged["hits"], lane.local_hits)) and bool(torch.equal(merged["totals"], lane.local_totals))
         return res
 
+    def physical_cores():
+        """Threads for the CPU leg: one per physical core THIS PROCESS MAY USE — the affinity mask and a cgroup CPU quota count (a
+        GPU box hands a container 256 logical CPUs and a quota of a few dozen: 128 threads then time-slice, and the per-thread
+        rate says nothing about the code)."""
+        try:
+            import psutil
+            n = int(psutil.cpu_count(logical=False) or cores)
+        except Exception:
+            n = cores
+        try:
+            n = min(n, len(os.sched_getaffinity(0)))
+        except Exception:
+            pass
+        quota = None
+        try:
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            if q != "max":
+                quota = float(q) / float(per)
+        except Exception:
+            try:
+                q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    quota = q / per
+            except Exception:
+                pass
+        if quota is not None:
+            n = max(1, min(n, int(quota + 0.5)))
+        return n, quota
+
     def cpu_baseline_leg(shard, kind, k, res, budget_s, sample_queries, parity_queries):
-        """cpu_baseline: the oracle (C++ restatement of Rucene's CPU IndexSearcher, one query per thread on all host cores): a bounded timing
-        leg on `sample_queries` of the batch, and parity of the GPU's rows against it on `parity_queries` of the batch
-        (canonical tie rule). A reported baseline, not the target."""
+        """cpu_baseline: the oracle (C++ restatement of Rucene's CPU IndexSearcher), one query per thread, one thread per PHYSICAL core.
+        The timed sample is ONE call over a long queue — the batch's first `sample_queries` queries replicated until every thread has
+        ~16 of them to pull (dynamic scheduling: the queue is much longer than the thread count, so the makespan is throughput, not the
+        longest query; round 4 timed 1024 queries on 256 threads and measured the Zipf head's tail) — next to a single-thread figure on
+        every 16th query. Parity of the GPU's rows on `parity_queries` of the batch (canonical tie rule); fewer than the batch is
+        reported as "sampled": true. A reported baseline, not the target."""
         from oracle import binding as orc  # the checker: only ever imported here, after the timed regions
         from oracle import parity
         osearcher = orc.Searcher([orc.Segment(shard.seg.doc_bytes, shard.seg.norms, shard.seg.max_doc, shard.seg.terms,
                                               sum_total_term_freq=shard.seg.sum_total_term_freq)])
         tids = res["tids"]
         op = {"term": orc.OP_TERM, "and3": orc.OP_AND, "or10": orc.OP_OR}[kind]
-        ns = min(nq, sample_queries)
-        ops = np.full(ns, op, np.int32)
-        offs = (np.arange(ns + 1) * tids.shape[1]).astype(np.int32)
-        flat = np.ascontiguousarray(tids[:ns]).reshape(-1)
-        spent, done_q, reps = 0.0, 0, 0
-        while spent < budget_s and reps < 50:
-            _, _, _, _, _, secs = osearcher.search_batch(ops, offs, flat, k, tie_mode=orc.TIE_RUST_HEAP, threads=cores)
-            spent += secs
-            done_q += ns
-            reps += 1
-        sample_postings = int(shard.seg.terms["doc_freq"][flat].sum())
+        threads, quota = physical_cores()
         npq = min(nq, parity_queries)
         ops = np.full(npq, op, np.int32)
         offs = (np.arange(npq + 1) * tids.shape[1]).astype(np.int32)
-        cd, cs, cc, ct, _, secs = osearcher.search_batch(ops, offs, np.ascontiguousarray(tids[:npq]).reshape(-1), k, tie_mode=orc.TIE_CANONICAL, threads=cores)
-        if reps == 0:  # budget 0: the parity pass is the timing sample too (the slow 100M-doc legs: one pass of the oracle, not two)
-            spent, done_q, reps, ns = secs, npq, 1, npq
+        cd, cs, cc, ct, _, parity_secs = osearcher.search_batch(ops, offs, np.ascontiguousarray(tids[:npq]).reshape(-1), k, tie_mode=orc.TIE_CANONICAL, threads=cores)
+        ns = min(nq, sample_queries)
+        base_flat = np.ascontiguousarray(tids[:ns]).reshape(-1)
+        sample_postings = int(shard.seg.terms["doc_freq"][base_flat].sum())
+        spent, done_q, reps, single = 0.0, 0, 0, None
+        sweep = None
+        if budget_s > 0:
+            # how many threads this box really gives the process: a short sweep (the whole sample once per width), best width wins
+            sweep = {}
+            ops1 = np.full(ns, op, np.int32)
+            offs1 = (np.arange(ns + 1) * tids.shape[1]).astype(np.int32)
+            for t in sorted({threads, max(1, threads // 2), max(1, threads // 4), min(threads, 32), min(threads, 16)}):
+                _, _, _, _, _, st = osearcher.search_batch(ops1, offs1, base_flat, k, tie_mode=orc.TIE_RUST_HEAP, threads=t)
+                sweep[t] = ns / st
+            threads = max(sweep, key=lambda t: sweep[t])
+            # size the queue from the best width's rate: ~budget_s seconds of work, at least 16 queries per thread
+            parity_secs = ns / sweep[threads] * (npq / ns)
+            rate = npq / max(parity_secs, 1e-6)
+            reps = int(max(1, min(64, max(np.ceil(16.0 * threads / ns), rate * budget_s / ns))))
+            flat = np.tile(base_flat, reps)
+            ops_r = np.full(ns * reps, op, np.int32)
+            offs_r = (np.arange(ns * reps + 1) * tids.shape[1]).astype(np.int32)
+            _, _, _, _, _, spent = osearcher.search_batch(ops_r, offs_r, flat, k, tie_mode=orc.TIE_RUST_HEAP, threads=threads)
+            done_q = ns * reps
+            # one thread, every 16th query of the sample (the same mix of list lengths)
+            sub = np.ascontiguousarray(tids[:ns:16])
+            _, _, _, _, _, s1 = osearcher.search_batch(np.full(sub.shape[0], op, np.int32), (np.arange(sub.shape[0] + 1) * tids.shape[1]).astype(np.int32),
+                                                       sub.reshape(-1), k, tie_mode=orc.TIE_RUST_HEAP, threads=1)
+            single = {"queries_per_sec": sub.shape[0] / s1, "postings_per_sec": float(shard.seg.terms["doc_freq"][sub.reshape(-1)].sum()) / s1,
+                      "sample": "%d queries (every 16th of the sample), %.2f s" % (sub.shape[0], s1)}
+        else:  # budget 0 (the slow 100M-doc legs): the parity pass is the timing sample too — one pass of the oracle, not two
+            spent, done_q, reps, ns, threads = parity_secs, npq, 1, npq, cores
             sample_postings = int(shard.seg.terms["doc_freq"][np.ascontiguousarray(tids[:npq]).reshape(-1)].sum())
         g_hits, g_totals = res["g_hits"][:npq], res["g_totals"][:npq]
-        parity_info = {"queries_checked": npq, "rule": "bit-exact doc ids, score bits and hit counts"}
+        parity_info = {"queries_checked": npq, "queries_in_batch": nq, "sampled": npq < nq, "rule": "bit-exact doc ids, score bits and hit counts"}
         if kind == "or10":
             # >= 10 clauses: the reference's own sum order is heap-dependent -> scores within 1e-5 relative (north_star), doc
             # ids judged by the oracle's own score of every returned doc + nothing above the k-th score band missing
-            parity_info["rule"] = ("hit counts equal; every returned doc matches and the ORACLE scores it within 1e-5 of the returned score; every "
-                                   "oracle hit above the k-th score band is returned (oracle/parity.py)")
+            parity_info["rule"] = ("TIE-BAND RULE, not bit-exact: hit counts equal; every returned doc matches and the ORACLE scores it within 1e-5 of the "
+                                   "returned score; every oracle hit above the k-th score band is returned (oracle/parity.py); docs_differing = "
+                                   "returned docs that are not in the oracle's row")
             try:
                 parity_info["docs_differing"] = parity.check_heap_order_batch(osearcher, op, tids[:npq], g_hits, g_totals, cd, cs, cc, ct, rtol=1e-5, what=kind)
                 parity_info["docs_returned"] = int(cc.sum())
@@ -333,10 +386,21 @@ def main():
                 ok = False
         else:
             ok = bool((g_hits["doc"] == cd).all() and (g_hits["score"].view(np.int32) == cs.view(np.int32)).all() and (g_totals == ct).all())
-        base = {"value": done_q / spent, "unit": "queries/s", "cores": cores, "kind": "port",
-                "postings_per_sec": float(sample_postings) * reps / spent,
-                "sample": "%d of the batch's %d queries x %d repetitions (%.1f s), one query per thread, %d threads; oracle = C++ "
-                          "restatement of Rucene's CPU IndexSearcher (the Rust original cannot be built here)" % (ns, nq, reps, spent, cores)}
+        pps = float(sample_postings) * reps / spent
+        base = {"value": done_q / spent, "unit": "queries/s", "cores": threads, "kind": "port",
+                "postings_per_sec": pps, "postings_per_sec_per_thread": pps / threads, "logical_cpus": cores, "cgroup_cpu_quota": quota,
+                "sample": "%d of the batch's %d queries x %d in ONE queue (%.1f s), one query per thread, %d threads (one per physical core this process may use; %d logical "
+                          "CPUs); oracle = C++ restatement of Rucene's CPU IndexSearcher (the Rust original cannot be built here)" % (ns, nq, reps, spent, threads, cores)}
+        if sweep is not None:
+            base["thread_sweep_queries_per_sec"] = {str(t): v for t, v in sorted(sweep.items())}
+        if single is not None:
+            base["single_thread"] = single
+            ratio = base["postings_per_sec_per_thread"] / single["postings_per_sec"]
+            base["per_thread_vs_single_thread"] = ratio
+            if ratio < 0.5:
+                base["scaling_note"] = ("per-thread throughput at full width is below half the single-thread figure: %d threads share the memory "
+                                        "channels / L3 of a multi-socket box whose index lives on one NUMA node, or the process is held to fewer CPUs than "
+                                        "the affinity mask and cgroup quota let this script see" % threads)
         return base, ok, parity_info
 
     def roofline(kernel, kernel_ms, touched_bytes, scan_bytes, tag, what):
@@ -407,7 +471,8 @@ def main():
             base, ok, info = cpu_baseline_leg(shard, kind, k, r, cpu_budget, cpu_sample, parity_queries)
             out["cpu_baseline"] = base
             out["gpu_over_cpu"] = out["queries_per_sec"] / base["value"]
-            out["parity_vs_oracle"] = ok
+            # (a comparison of fewer queries than the batch holds only counts when it says so: "sampled": true)
+            out["parity_vs_oracle"] = bool(ok and (info["queries_checked"] == info["queries_in_batch"] or info.get("sampled") is True))
             out["parity"] = info
         out["_res"] = r
         return out
@@ -531,45 +596,55 @@ def main():
                                                         "the terms' .pos bytes + their .doc blocks twice (count pass, decode pass) in + 4 B per position out; kernel_ms = the kernels summed")}
         got = d_pos.cpu().numpy()
         del d_pos
-        # ---- (2) two-term exact phrases
+        # ---- (2) two-term phrases: exact (ExactPhraseScorer) and slop 2 (SloppyPhraseScorer) over the same pairs
         ranks = indexgen.log_uniform_ranks(2 * n_phrases, 1, 1000, SEED_QUERIES ^ 0xF2).reshape(-1, 2) - 1
-        queries = [rucene_amd.PhraseQuery([int(a), int(b2)]) for a, b2 in ranks]
-        qs, ts = searcher.pack_phrases(queries, leaf)
-        for _ in range(2):
-            hits, totals = leaf.segment.search_phrase_batch(qs, ts, k)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        steps = 5
-        for _ in range(steps):
-            hits, totals = leaf.segment.search_phrase_batch(qs, ts, k)
-        ms_step = 1e3 * (time.perf_counter() - t0) / steps
-        ctx.set_profiling(True)
-        ctx.kernel_stats_reset()
-        leaf.segment.search_phrase_batch(qs, ts, k)
-        st = ctx.kernel_stats()
-        ctx.set_profiling(False)
-        ctx.kernel_stats_reset()
-        ph = {"workload": "%d x two-term exact PhraseQuery top-%d, ranks log-uniform 1..1000, %d M docs with positions" % (n_phrases, k, docs // 1_000_000),
-              "k": k, "ms_per_step": ms_step, "queries_per_sec": n_phrases / (ms_step * 1e-3), "issue": "blocking call, host outputs",
-              "kernels_ms": {n: v["total_ms"] / max(1, v["launches"]) for n, v in st.items() if v["total_ms"] > 0},
-              "lead_postings_per_step": int(sum(min(int(seg.terms["doc_freq"][a]), int(seg.terms["doc_freq"][b2])) for a, b2 in ranks)),
-              "phrase_hits_per_step": int(totals.sum())}
+        ix = None
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
-            from oracle import binding as orc   # the checker, after the timed region
+            from oracle import binding as orc   # the checker, after the timed regions
             ix = orc.PositionsIndex.from_files(seg.doc_bytes, seg.pos_bytes, seg.terms, leaf.term_positions)
-            n_chk, ok, spent = min(n_phrases, 1024), True, 0.0   # (every query of the batch: ~3 s of oracle time; round 4's launch-size bug sat behind query 358)
-            for i in range(n_chk):
-                t0 = time.perf_counter()
-                d, sc, tot = ix.phrase_search([int(ranks[i, 0]), int(ranks[i, 1])], k, seg.norms, seg.max_doc, seg.doc_count, seg.sum_total_term_freq)
-                spent += time.perf_counter() - t0
-                ok = ok and totals[i] == tot and bool((hits[i]["doc"][:d.size] == d).all()) and bool((hits[i]["score"][:d.size].view(np.int32) == sc.view(np.int32)).all())
-            ph["parity_vs_oracle"] = bool(ok)
-            ph["parity"] = {"queries_checked": n_chk, "rule": "bit-exact doc ids, score bits and hit counts (ExactPhraseScorer)"}
-            ph["cpu_baseline"] = {"value": n_chk / spent, "unit": "queries/s", "cores": 1, "kind": "port",
-                                  "sample": "%d of the batch's queries, one after the other on one core (%.2f s); oracle = C++ restatement of PhraseWeight + ExactPhraseScorer" % (n_chk, spent)}
-            ph["gpu_over_cpu"] = ph["queries_per_sec"] / ph["cpu_baseline"]["value"]
+
+        def phrase_leg(slop, what):
+            queries = [rucene_amd.PhraseQuery([int(a), int(b2)], slop=slop) for a, b2 in ranks]
+            qs, ts = searcher.pack_phrases(queries, leaf)
+            for _ in range(2):
+                hits, totals = leaf.segment.search_phrase_batch(qs, ts, k)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            steps = 5 if slop == 0 else 3
+            for _ in range(steps):
+                hits, totals = leaf.segment.search_phrase_batch(qs, ts, k)
+            ms_step = 1e3 * (time.perf_counter() - t0) / steps
+            ctx.set_profiling(True)
+            ctx.kernel_stats_reset()
+            leaf.segment.search_phrase_batch(qs, ts, k)
+            st = ctx.kernel_stats()
+            ctx.set_profiling(False)
+            ctx.kernel_stats_reset()
+            ph = {"workload": "%d x two-term %s top-%d, ranks log-uniform 1..1000, %d M docs with positions" % (n_phrases, what, k, docs // 1_000_000),
+                  "k": k, "slop": slop, "ms_per_step": ms_step, "queries_per_sec": n_phrases / (ms_step * 1e-3), "issue": "blocking call, host outputs",
+                  "kernels_ms": {n: v["total_ms"] / max(1, v["launches"]) for n, v in st.items() if v["total_ms"] > 0},
+                  "lead_postings_per_step": int(sum(min(int(seg.terms["doc_freq"][a]), int(seg.terms["doc_freq"][b2])) for a, b2 in ranks)),
+                  "phrase_hits_per_step": int(totals.sum())}
+            if ix is not None:
+                # every query of the batch (round 4's launch-size bug sat behind query 358 of a batch whose first 96 were compared)
+                n_chk, ok, spent = n_phrases, True, 0.0
+                for i in range(n_chk):
+                    t0 = time.perf_counter()
+                    d, sc, tot = ix.phrase_search([int(ranks[i, 0]), int(ranks[i, 1])], k, seg.norms, seg.max_doc, seg.doc_count, seg.sum_total_term_freq, slop=slop)
+                    spent += time.perf_counter() - t0
+                    ok = ok and totals[i] == tot and bool((hits[i]["doc"][:d.size] == d).all()) and bool((hits[i]["score"][:d.size].view(np.int32) == sc.view(np.int32)).all())
+                ph["parity_vs_oracle"] = bool(ok)
+                ph["parity"] = {"queries_checked": n_chk, "queries_in_batch": n_phrases, "sampled": False,
+                                "rule": "bit-exact doc ids, score bits and hit counts (%s)" % ("ExactPhraseScorer" if slop == 0 else "SloppyPhraseScorer, two-phase rule with the default next_limit")}
+                ph["cpu_baseline"] = {"value": n_chk / spent, "unit": "queries/s", "cores": 1, "kind": "port",
+                                      "sample": "the batch's %d queries, one after the other on one core (%.2f s); oracle = C++ restatement of PhraseWeight + %s" % (n_chk, spent, "ExactPhraseScorer" if slop == 0 else "SloppyPhraseScorer")}
+                ph["gpu_over_cpu"] = ph["queries_per_sec"] / ph["cpu_baseline"]["value"]
+            return ph
+        ph = phrase_leg(0, "exact PhraseQuery")
+        out["sloppy2"] = phrase_leg(2, "PhraseQuery with slop 2 (SloppyPhraseScorer)")
+        if ix is not None:
             # the decoded positions against the oracle's iterator for a handful of terms
-            at, okp = 0, True
+            okp = True
             idx = np.nonzero(keep)[0]
             offs = np.concatenate([[0], np.cumsum(sel["total_term_freq"])])
             for j in (4, 40, idx.size // 2, idx.size - 1):   # (lists of <= 500 k docs: the oracle's iterator is driven from Python)
@@ -618,12 +693,61 @@ def main():
     for key in ("cpu_baseline", "gpu_over_cpu", "parity_vs_oracle", "parity"):
         if key in head:
             out[key] = head[key]
+    # the fraction at the headline's OPERATING POINT (two launches co-resident on alternating streams): the same bytes over the
+    # step time — next to roofline.frac, which is one isolated launch (kernel_ms may exceed ms_per_step for that reason)
+    out["roofline"]["frac_at_ms_per_step"] = out["roofline"]["bytes_per_launch"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS
+    out["one_stream_ms_per_step"] = head["streams"]["ms_planned_one_stream"]
+    out["one_stream_queries_per_sec"] = nq / (head["streams"]["ms_planned_one_stream"] * 1e-3)
+    # N > 1: the batch is replicated, so the ranks together answer nq queries over an index of world x docs — that rate next to
+    # `value` (whose unit is one query against one segment)
+    out["whole_index_docs"] = world * args.docs
+    out["whole_index_queries_per_sec"] = nq / (ms_per_step * 1e-3)
     if "parity_vs_oracle" in out:
         out["parity_vs_oracle_full_batch"] = out["parity_vs_oracle"]
     if args.force_dist and world == 1:
         print("force-dist: merged == local: %s" % res.get("force_dist_same"), file=sys.stderr)
         if not res.get("force_dist_same"):
             raise SystemExit("force-dist check failed")
+
+    def sharded_overhead(shard, kind, k, steps):
+        """What rgpu_search_batch_sharded adds to a step in a world of ONE rank (search into the rank's own region of the gather
+        buffer, nothing to gather, the record merge) — the path's own overhead, measured on every N = 1 run (VERDICT r4 item 1:
+        0.157 vs 0.093 ms before the in-place record). Planned steps on two alternating streams and on one, local vs sharded."""
+        c1 = _lib.Comm(ctx, 1, 0, _lib.comm_unique_id())
+        tids = build_queries(nq, kind, SEED_QUERIES)
+        lanes = [Lane(k), Lane(k)]
+        res = {}
+        for name in ("local", "sharded"):
+            for n_lanes in (2, 1):
+                def one(i):
+                    pk = shard.searcher.pack_uniform(OPS[kind], tids, shard.leaf)
+                    lane = lanes[i % n_lanes]
+                    if name == "local":
+                        shard.leaf.segment.search_batch_device(pk[0], pk[1], k, lane.hits.data_ptr(), lane.totals.data_ptr(), lane.stream.cuda_stream)
+                    else:
+                        c1.search_batch_sharded(shard.leaf.segment, pk[0], pk[1], k, lane.hits.data_ptr(), lane.totals.data_ptr(), lane.stream.cuda_stream)
+                for i in range(6):
+                    one(i)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(steps):
+                    one(i)
+                torch.cuda.synchronize()
+                res["%s_ms_%s" % (name, "two_streams" if n_lanes == 2 else "one_stream")] = 1e3 * (time.perf_counter() - t0) / steps
+        # the merged rows of a world of one are the local rows
+        pk = shard.searcher.pack_uniform(OPS[kind], tids, shard.leaf)
+        shard.leaf.segment.search_batch_device(pk[0], pk[1], k, lanes[0].hits.data_ptr(), lanes[0].totals.data_ptr(), lanes[0].stream.cuda_stream)
+        c1.search_batch_sharded(shard.leaf.segment, pk[0], pk[1], k, lanes[1].hits.data_ptr(), lanes[1].totals.data_ptr(), lanes[1].stream.cuda_stream)
+        torch.cuda.synchronize()
+        res["same_rows"] = bool(torch.equal(lanes[0].hits, lanes[1].hits)) and bool(torch.equal(lanes[0].totals, lanes[1].totals))
+        res["ratio_two_streams"] = res["sharded_ms_two_streams"] / res["local_ms_two_streams"]
+        res["ratio_one_stream"] = res["sharded_ms_one_stream"] / res["local_ms_one_stream"]
+        res["workload"] = WORKLOAD_TEXT[kind]
+        c1.close()
+        return res
+
+    if world == 1 and not dist_mode:
+        out["sharded_overhead"] = sharded_overhead(shard, args.workload, head["k"], 200)
 
     # ---- north_star's other targets, same run ---------------------------------------------------------------------------------
     if args.configs == "none":
@@ -640,6 +764,7 @@ def main():
         c = strip(search_config(shard, kind, steps, 1, False, "%s_%s" % (ROUND, kind), 4.0, nq if kind == "and3" else 256, nq))
         if world > 1:
             c["value_all_shards_queries_per_sec"] = world * c["queries_per_sec"]
+            c["whole_index_queries_per_sec"] = c["queries_per_sec"]   # the replicated batch answered over world x docs
         configs[kind] = c
     if "block_decode" in want:
         d = decode_bench(shard, 5, "%s_decode" % ROUND)
@@ -657,12 +782,54 @@ def main():
               "segment_upload_s": round(big.upload_s, 3)}
         oc["cold"] = cold_bench(big, "%s_cold_big" % ROUND)
         oc["block_decode"] = decode_bench(big, 3, "%s_decode_big" % ROUND)
-        oc["term"] = strip(search_config(big, "term", 5, 1, False, "%s_term_big" % ROUND, 3.0, 256, 256))
-        oc["and3"] = strip(search_config(big, "and3", 3, 1, False, "%s_and3_big" % ROUND, 0.0, 256, 256))
-        oc["or10"] = strip(search_config(big, "or10", 2, 1, False, "%s_or10_big" % ROUND, 0.0, 32, 32))
+        # parity on the WHOLE batch for TERM and AND (the oracle does 1024 conjunctions over 100 M docs in a couple of seconds on the
+        # GPU box's cores); the 10-clause OR on 256 of its 1024 queries, and says so ("sampled": true)
+        oc["term"] = strip(search_config(big, "term", 5, 1, False, "%s_term_big" % ROUND, 0.0, nq, nq))
+        oc["and3"] = strip(search_config(big, "and3", 3, 1, False, "%s_and3_big" % ROUND, 0.0, nq, nq))
+        oc["or10"] = strip(search_config(big, "or10", 2, 1, False, "%s_or10_big" % ROUND, 0.0, 256, 256))
         configs["out_of_cache"] = oc
     if configs:
         out["configs"] = configs
+    # the north-star's targets as TOP-LEVEL keys (the driver's record keeps those): and3 = BASELINE configs[2] (and configs[4]'s
+    # workload), block decode >= 40 % of HBM, the 10-term OR; the 100 M-doc single-GPU and3 point = the strong-scaling
+    # reference of configs[4] (the same index split 8 x 12.5 M: `bench.py --gpus 8 --docs 12500000 --workload and3`)
+    def hoist(name, path, key):
+        node = configs
+        for part in path:
+            node = node.get(part) if isinstance(node, dict) else None
+            if node is None:
+                return
+        val = node.get(key) if isinstance(node, dict) else None
+        if val is not None:
+            out[name] = val
+    hoist("and3_queries_per_sec", ["and3"], "queries_per_sec")
+    hoist("and3_ms_per_step", ["and3"], "ms_per_step")
+    hoist("and3_gpu_over_cpu", ["and3"], "gpu_over_cpu")
+    hoist("and3_roofline_frac", ["and3", "roofline"], "frac")
+    hoist("and3_kernel_ms", ["and3", "roofline"], "kernel_ms")
+    hoist("and3_parity_vs_oracle", ["and3"], "parity_vs_oracle")
+    hoist("or10_queries_per_sec", ["or10"], "queries_per_sec")
+    hoist("or10_roofline_frac", ["or10", "roofline"], "frac")
+    hoist("or10_parity_vs_oracle", ["or10"], "parity_vs_oracle")
+    hoist("block_decode_frac", ["block_decode", "roofline"], "frac")
+    hoist("cold_frac", ["cold", "roofline"], "frac")
+    hoist("cold_wall_ms", ["cold"], "wall_ms_incl_host_planning")
+    hoist("phrase2_queries_per_sec", ["positions", "phrase2"], "queries_per_sec")
+    hoist("sloppy2_queries_per_sec", ["positions", "sloppy2"], "queries_per_sec")
+    hoist("sloppy2_parity_vs_oracle", ["positions", "sloppy2"], "parity_vs_oracle")
+    hoist("big_block_decode_frac", ["out_of_cache", "block_decode", "roofline"], "frac")
+    hoist("big_cold_frac", ["out_of_cache", "cold", "roofline"], "frac")
+    hoist("big_cold_wall_ms", ["out_of_cache", "cold"], "wall_ms_incl_host_planning")
+    hoist("big_and3_queries_per_sec", ["out_of_cache", "and3"], "queries_per_sec")
+    hoist("big_and3_roofline_frac", ["out_of_cache", "and3", "roofline"], "frac")
+    hoist("big_and3_parity_vs_oracle", ["out_of_cache", "and3"], "parity_vs_oracle")
+    hoist("big_or10_queries_per_sec", ["out_of_cache", "or10"], "queries_per_sec")
+    if args.workload == "and3":
+        out["and3_queries_per_sec"] = out["queries_per_sec"]
+        out["and3_roofline_frac"] = out["roofline"]["frac"]
+    if world > 1 and "and3" in configs:
+        out["and3_whole_index_queries_per_sec"] = configs["and3"]["queries_per_sec"]
+        out["and3_whole_index_docs"] = world * args.docs
 
     sys.stdout.flush()
     os.dup2(stdout_fd, 1)

@@ -45,6 +45,19 @@ class FlatFpMap {
     if (want != slots_.size()) regrow(want);
   }
   size_t size() const { return used_; }
+  // drop the given keys (a rebuild of the table: the rare path of a bulk insert that has to be taken back)
+  void remove_keys(const int64_t* keys, size_t n) {
+    if (n == 0 || slots_.empty()) return;
+    FlatFpMap<char> gone;
+    gone.reserve_more(n);
+    for (size_t i = 0; i < n; ++i) gone.put(keys[i], 1);
+    std::vector<Slot> old;
+    old.swap(slots_);
+    slots_.assign(old.size(), Slot());
+    mask_ = slots_.size() - 1;
+    used_ = 0;
+    for (const Slot& s : old) if (s.key != EMPTY && !gone.find(s.key)) put(s.key, s.value);
+  }
 
  private:
   static constexpr int64_t EMPTY = INT64_MIN;  // (a file pointer is never negative)

@@ -22,6 +22,7 @@
 #include <fstream>
 #include <iterator>
 #include <map>
+#include <functional>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -109,6 +110,46 @@ struct BooleanQuery : Query {
     q->must_not_queries = std::move(must_nots);
     q->min_should_match = q->must_queries.empty() ? msm : 0;
     return std::unique_ptr<Query>(q.release());
+  }
+};
+
+// A BooleanQuery whose MUST / SHOULD clauses may themselves be queries (BooleanQuery::build takes Vec<Box<dyn Query>>,
+// boolean_query.rs:40-86). The GPU path serves flat trees of term clauses; `flattened()` folds ONE level — a MUST clause that is
+// a must-only BooleanQuery, a SHOULD clause that is a should-only one (min_should_match <= 1) — into a flat BooleanQuery, or
+// returns null when the tree is not of that shape. The reference does not rewrite such trees: it sums a + (b + c) where the
+// flat query sums (a + b) + c — the same docs and hit counts, scores equal within 1e-5 relative (north_star's float
+// tolerance), not bit for bit. GpuIndexSearcher folds only when `flatten_nested` is set; everything else goes to `cpu_fallback`
+// ("everything else to the CPU path"; the Rust shim: rust/gpu/searcher.rs).
+struct NestedBooleanQuery : Query {
+  std::vector<std::unique_ptr<Query>> must_queries, should_queries;
+  std::vector<TermQuery> must_not_queries;
+  int32_t min_should_match = 0;
+  std::unique_ptr<Query> flattened() const {
+    auto fold = [](const std::vector<std::unique_ptr<Query>>& clauses, bool want_must, std::vector<TermQuery>* out) -> bool {
+      for (const auto& q : clauses) {
+        if (auto* t = dynamic_cast<const TermQuery*>(q.get())) { out->push_back(*t); continue; }
+        auto* b = dynamic_cast<const BooleanQuery*>(q.get());
+        if (!b || !b->must_not_queries.empty()) return false;
+        if (want_must && !b->must_queries.empty() && b->should_queries.empty()) out->insert(out->end(), b->must_queries.begin(), b->must_queries.end());
+        else if (!want_must && b->must_queries.empty() && !b->should_queries.empty() && b->min_should_match <= 1)
+          out->insert(out->end(), b->should_queries.begin(), b->should_queries.end());
+        else return false;
+      }
+      return true;
+    };
+    std::vector<TermQuery> musts, shoulds;
+    if (!fold(must_queries, true, &musts)) return nullptr;
+    if (!musts.empty()) {  // SHOULD clauses beside MUST ones stay as they are: ReqOptScorer's optional side takes term clauses only
+      for (const auto& q : should_queries) {
+        auto* t = dynamic_cast<const TermQuery*>(q.get());
+        if (!t) return nullptr;
+        shoulds.push_back(*t);
+      }
+    } else {
+      if (!fold(should_queries, false, &shoulds)) return nullptr;
+      if (min_should_match > 1 && shoulds.size() != should_queries.size()) return nullptr;  // it counts the OUTER clauses
+    }
+    return BooleanQuery::build(std::move(musts), std::move(shoulds), min_should_match, must_not_queries);
   }
 };
 
@@ -351,11 +392,28 @@ class GpuIndexSearcher {
   }
   const CollectionStatistics& collection_statistics() const { return stats_; }
 
+  // Trees the GPU path does not serve: fold one level of nesting (same docs, scores within 1e-5 — NestedBooleanQuery), and / or
+  // hand the query to the host's CPU searcher — where rust/gpu/searcher.rs calls DefaultIndexSearcher::search
+  bool flatten_nested = false;
+  std::function<void(const Query&, TopDocsCollector&)> cpu_fallback;
+
   // IndexSearcher::search(query, collector) for a TopDocsCollector
   void search(const Query& query, TopDocsCollector& collector) {
-    std::vector<const Query*> one{&query};
-    std::vector<TopDocs> r = search_many(one, collector.estimated_hits());
-    collector.set_result(std::move(r[0]));
+    try {
+      std::unique_ptr<Query> folded;
+      const Query* q = &query;
+      if (auto* nested = dynamic_cast<const NestedBooleanQuery*>(&query)) {
+        folded = flatten_nested ? nested->flattened() : nullptr;
+        if (!folded) throw Error(RGPU_ERR_UNSUPPORTED, "nested boolean clauses are not served by the GPU path");
+        q = folded.get();
+      }
+      std::vector<const Query*> one{q};
+      std::vector<TopDocs> r = search_many(one, collector.estimated_hits());
+      collector.set_result(std::move(r[0]));
+    } catch (const Error& e) {
+      if (e.kind != RGPU_ERR_UNSUPPORTED || !cpu_fallback) throw;  // ErrorKind::UnsupportedOperation -> the CPU path
+      cpu_fallback(query, collector);
+    }
   }
 
   // the batched form the hardware wants: one launch set per leaf for many queries

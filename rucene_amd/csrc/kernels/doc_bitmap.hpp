@@ -12,6 +12,12 @@
 //   freqs[doc_freq + pad]             min(freq, 255) by posting index
 //   ovf[2 * n_ovf]                    {posting index, freq} of the postings whose freq is >= 255 (Rucene clamps term freqs
 //                                     to 10 when it writes an index; a Lucene-written one may hold such a posting)
+//   memb[ceil(max_doc / 32) + pad]    the `any` bits alone, one per doc: what a conjunction's FIRST probe needs of the list — "is the
+//                                     candidate in it" for every candidate of a lead block. A gather moves a 64-byte sector
+//                                     whatever it needs of it: the sector then covers 512 docs instead of the 128 of `nib`, so a
+//                                     dense lead's neighbouring candidates share it and the probed footprint is max_doc / 8 bytes
+//                                     per list (k_search_and: 0.284 ms probing nib first, 0.274 probing `words`, at 10 M docs;
+//                                     2.27 vs 2.04 ms at 100 M); the survivors (a sixth of the candidates) then ask nib for the freq
 //   nib[ceil(max_doc / 8) + pad]      only for a term that holds at least one doc in BITMAP_NIBBLE_DENSITY: four bits per doc —
 //                                     0 = the list does not hold the doc, 1..14 = its freq, 15 = "look the freq up through
 //                                     ranks / freqs". Membership AND freq in one 4-byte gather instead of a word + rank
@@ -48,7 +54,7 @@ __global__ __launch_bounds__(256) void k_bitmap_fill(const int32_t* __restrict__
                                                      int32_t max_doc, const uint8_t* __restrict__ norms, const float* __restrict__ cache,
                                                      const uint8_t* __restrict__ rank_to_norm, uint2* __restrict__ words,
                                                      uint8_t* __restrict__ freq8, uint32_t* __restrict__ ovf, BitmapStats* __restrict__ stats,
-                                                     uint32_t* __restrict__ nib) {
+                                                     uint32_t* __restrict__ nib, uint32_t* __restrict__ memb) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool ok = i < df;
   const int32_t d = ok ? docs[i] : 0;
@@ -56,6 +62,7 @@ __global__ __launch_bounds__(256) void k_bitmap_fill(const int32_t* __restrict__
   const bool in = ok && (uint32_t)d < (uint32_t)max_doc;
   if (in) {
     atomicOr(&words[d >> 5].x, 1u << (d & 31));
+    atomicOr(&memb[d >> 5], 1u << (d & 31));
     bool hi = true;  // no norms: every posting scores weight * (k1 + 1) * freq / (freq + k1) — no sketch, everything is "hi"
     if (norms != nullptr) {
       const uint32_t nb = norms[d];

@@ -118,11 +118,13 @@ constexpr int AND_FILTER_WORDS = 64;  // 2048-bit membership filter per wavefron
 // clause behind the lead has a doc bitmap, an item now takes its lead blocks AND_G at a time: all their rows are requested
 // together (row addresses from a register window over the lead's directory), each is unpacked while the next one's rows and the
 // previous one's gathers are in flight, and the first clause is asked about all 128 * AND_G candidates at once — one gather
-// per candidate into the four-bits-per-doc array (membership + freq) or the membership words. What survives (a doc in five at
-// most, usually far fewer) is appended, in doc order, to a wave-private LDS queue of {doc, norm byte | first-clause freq code
-// | lead freq}; whenever 128 survivors have gathered (or the item ends) they are popped two per lane and take the candidate
-// loop below from the second clause on. The later clauses therefore see a tenth of the gathers, the BM25 divisions of the lead
-// and the first clause are only done for survivors, and the top-k list is offered full vectors. Same candidates, same f32 sums
+// per candidate into the list's membership bits (doc_bitmap.hpp `memb`: one bit per doc, the smallest footprint a probe can
+// have; RGPU_AND_PROBE = 1 asks the four-bits-per-doc array instead — membership and freq in one gather, four times the bytes).
+// What survives (a doc in five at most, usually far fewer) is appended, in doc order, to a wave-private LDS queue of {doc, norm
+// byte | first-clause freq code | lead freq}; whenever 128 survivors have gathered (or the item ends) they are popped two per
+// lane and take the candidate loop below — from the first clause again when their freqs are still unknown (it finds them all,
+// with their freqs, on a sixth of the candidates), from the second clause on otherwise. The later clauses therefore see a tenth
+// of the gathers, the BM25 divisions are only done for survivors, and the top-k list is offered full vectors. Same candidates, same f32 sums
 // in the same order: bit-exact with the block-by-block path (which still serves a walked first clause, the lead's tail /
 // singleton, ReqOptScorer records and lead freqs of 2^20 or more).
 #ifndef RGPU_AND_FAST
@@ -130,6 +132,15 @@ constexpr int AND_FILTER_WORDS = 64;  // 2048-bit membership filter per wavefron
 #endif
 #ifndef RGPU_AND_G
 #define RGPU_AND_G 4
+#endif
+#ifndef RGPU_AND_GATHER_NT  // 1: the first probe's gathers as nontemporal loads (variant builds)
+#define RGPU_AND_GATHER_NT 0
+#endif
+#ifndef RGPU_AND_PROBE  // what the batched first probe gathers from: 0 the membership bits, 1 the four-bits-per-doc array, 2 the {any, hi} pairs
+#define RGPU_AND_PROBE 0
+#endif
+#ifndef RGPU_AND_PF  // 1: the next group's rows are requested before this group's gathers are waited for (4 * AND_G + AND_G more VGPRs, live across the candidate loop)
+#define RGPU_AND_PF 0
 #endif
 constexpr int AND_G = RGPU_AND_G;
 constexpr int AND_Q_CAP = 128 + 128 * AND_G;  // fewer than 128 entries wait when a group of AND_G blocks is appended
@@ -160,7 +171,7 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
                                                            void* __restrict__ emit_out,
                                                            const unsigned long long* __restrict__ ceil_slots = nullptr,
                                                            const int32_t* __restrict__ qmap = nullptr,
-                                                           const TermBitmap* __restrict__ bitmaps = nullptr) {
+                                                           const TermBitmap* __restrict__ bitmaps = nullptr, int xcd_chunk = 0) {
   // bitmaps (nullable, parallel to `terms`): a clause other than the lead whose term has a doc bitmap answers every candidate
   // with one bit of it (and, for a hit, the posting's rank and freq byte) instead of a walk through its blocks — a list
   // that holds a doc in five puts a candidate into nearly every one of its blocks between two lead postings. (Requesting the
@@ -181,7 +192,20 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
 #endif
   const int lane = lane_id();
   const int wave = wave_id();
-  const int64_t item = (int64_t)blockIdx.x * WG_WAVES + wave;
+  // Workgroups go to the eight XCDs round-robin (workgroup b -> XCD b % 8), each XCD with its own 4 MB L2: with items taken in
+  // launch order every XCD meets every query's bitmaps, and the probes' L2 hit rate is a third (rocprofv3: TCC_HIT 4.5 M of
+  // 14.6 M requests per launch, the L1s stalled on pending misses 69 % of the time). Chunks of `xcd_chunk` consecutive
+  // workgroups — neighbours in the host's order: the same query, or queries that probe the same list — are therefore dealt to the
+  // XCDs whole: chunk c runs on XCD c % 8, so a list's bits are fetched into ONE L2 instead of eight. Measured on the 1024 x
+  // 3-term batch at 10 M docs: 0.284 ms in launch order, 0.272 with chunks of 16, 0.259 with 64, 0.36 with 256 (the chunks'
+  // costs differ: a long tail); at 100 M docs, where a list's bits are 12.5 MB and no L2 holds them: 2.28 / 2.31 / 2.49 / 2.54 —
+  // so the host asks for chunks only while a list's bits fit an L2 (rgpu_api.hip and_xcd_chunk).
+  int64_t wg = (int64_t)blockIdx.x;
+  if (xcd_chunk > 0) {  // (the host launches whole rounds of 8 chunks)
+    const int64_t r = wg >> 3, x = wg & 7;  // the r-th workgroup of XCD x
+    wg = (r / xcd_chunk) * (8 * (int64_t)xcd_chunk) + x * xcd_chunk + (r % xcd_chunk);
+  }
+  const int64_t item = wg * WG_WAVES + wave;
   if (item >= n_items) return;
 #ifdef RGPU_AND_TIME
   long long and_t[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -499,18 +523,28 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
   bool fast = b1 > b0 && bitmaps != nullptr && Q.n_terms >= 2 && !(HAS_OPT && seq_out != nullptr);
   typedef const __attribute__((address_space(1))) uint32_t* gwords1;
   gwords1 probe_src = nullptr;
-  int probe_nib = 0;  // 1: four bits per doc {absent, freq 1..14, 15 = look it up}; 0: one membership bit per doc in every other word
+  int probe_nib = 0;  // 1: four bits per doc {absent, freq 1..14, 15 = look it up}; 0: one membership bit per doc
+  int probe_mul = 1;  // ... in every word (the membership bits) or in every other one (the {any, hi} pairs)
   if (fast) {
     const TermBitmap B1 = bitmaps[Q.first_term + 1];
     fast = B1.words != nullptr;
-    probe_nib = B1.nib != nullptr ? 1 : 0;
-    probe_src = (gwords1)(uintptr_t)(B1.nib != nullptr ? (const void*)B1.nib : (const void*)B1.words);
+    // RGPU_AND_PROBE: 0 = the membership bits (one per doc; a survivor's freq is asked for when it is popped), 1 = the
+    // four-bits-per-doc array where there is one (membership and freq in one gather, four times the footprint), 2 = the {any, hi} pairs
+    probe_nib = (B1.nib != nullptr && RGPU_AND_PROBE == 1) ? 1 : 0;
+    probe_mul = (probe_nib || (RGPU_AND_PROBE == 0 && B1.memb != nullptr)) ? 1 : 2;
+    probe_src = (gwords1)(uintptr_t)(probe_nib ? (const void*)B1.nib : (probe_mul == 1 ? (const void*)B1.memb : (const void*)B1.words));
   }
   uint2* const queue = queues[wave];
   int qhead = 0, qtail = 0;
   int lw0 = b0;  // LW: a register window over the lead's directory — slot j >= 1 = block lw0 + j - 1, its base doc in slot j - 1
   DirWindow LW;
   LW.load(seg, L.dir_base, L.nblocks, lw0, lane);
+#if RGPU_AND_PF
+  // the NEXT group's rows and norms, requested while this group's gathers are in flight (pf_blk: the block they start at, -1: none)
+  uint4 pf_rows[AND_G];
+  uint32_t pf_nn[AND_G];
+  int pf_blk = -1;
+#endif
   int blk = b0;
   AND_STAMP(ts1);
   AND_TADD(0, ts1 - ts0);
@@ -534,18 +568,24 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
       const int nb = min(AND_G, b1 - blk);
       uint4 rows[AND_G];
       uint32_t nnv[AND_G], hdrs[AND_G];
+#if RGPU_AND_PF
+      const bool have_pf = pf_blk == blk;  // wave-uniform
+#endif
 #pragma unroll
       for (int g = 0; g < AND_G; ++g) {  // (indices clamped, not guarded: a repeated block costs less than a load behind a branch)
         const int bi = min(blk + g, b1 - 1);
         const int j = bi - lw0 + 1;
         hdrs[g] = (uint32_t)readlane((int)LW.hdr, j);
+#if RGPU_AND_PF
+        if (have_pf) { rows[g] = pf_rows[g]; nnv[g] = pf_nn[g]; continue; }
+#endif
         rows[g] = block_rows_load(block_rows_at(lead_rows, (uint32_t)readlane((int)LW.row, j)), hdrs[g], lane);
         nnv[g] = *reinterpret_cast<const uint16_t*>(lead_pn + (128u * (uint32_t)bi + 2u * (uint32_t)lane));
       }
       int32_t D[2 * AND_G];
       uint32_t P[2 * AND_G], V[2 * AND_G];
       bool too_wide = false;
-      const int sh = probe_nib ? 3 : 5, mul = probe_nib ? 1 : 2;
+      const int sh = probe_nib ? 3 : 5, mul = probe_mul;
 #pragma unroll
       for (int g = 0; g < AND_G; ++g) {
         stage_rows(rows[g], slab, lane);
@@ -560,13 +600,36 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
         const uint32_t n2 = has_norms ? nnv[g] : 0u;
         P[2 * g] = (n2 & 0xffu) | (y0 << 12);
         P[2 * g + 1] = (n2 >> 8) | (y1 << 12);
-        V[2 * g] = probe_src[((uint32_t)D[2 * g] >> sh) * (uint32_t)mul];
-        V[2 * g + 1] = probe_src[((uint32_t)D[2 * g + 1] >> sh) * (uint32_t)mul];
+        uint32_t ix0 = ((uint32_t)D[2 * g] >> sh) * (uint32_t)mul, ix1 = ((uint32_t)D[2 * g + 1] >> sh) * (uint32_t)mul;
+        if (RGPU_AND_ABL == 7) { ix0 &= 1023u; ix1 &= 1023u; }  // (variant builds: every probe inside one 4 KB window — what the gathers' misses cost)
+#if RGPU_AND_GATHER_NT
+        V[2 * g] = __builtin_nontemporal_load(probe_src + ix0);
+        V[2 * g + 1] = __builtin_nontemporal_load(probe_src + ix1);
+#else
+        V[2 * g] = probe_src[ix0];
+        V[2 * g + 1] = probe_src[ix1];
+#endif
       }
       if (too_wide) {  // a lead freq that does not fit a queue entry: nothing of this group is kept, the rest of the item goes block by block
         fast = false;
         continue;
       }
+#if RGPU_AND_PF
+      {  // the next group's rows: they travel while this group's gathers come back and its survivors are queued (and, when 128
+         // survivors are waiting, while those go through the later clauses). Blocks clamped into the directory window and the item.
+        const int nb0 = blk + nb;
+        const bool ok = nb0 < b1 && nb0 + AND_G - 1 - lw0 + 1 <= 63;
+#pragma unroll
+        for (int g = 0; g < AND_G; ++g) {
+          const int bi = min(min(nb0 + g, b1 - 1), lw0 + 62);
+          const int j = bi - lw0 + 1;
+          const uint32_t h = (uint32_t)readlane((int)LW.hdr, j);
+          pf_rows[g] = block_rows_load(block_rows_at(lead_rows, (uint32_t)readlane((int)LW.row, j)), h, lane);
+          pf_nn[g] = *reinterpret_cast<const uint16_t*>(lead_pn + (128u * (uint32_t)bi + 2u * (uint32_t)lane));
+        }
+        pf_blk = ok ? nb0 : -1;
+      }
+#endif
 #pragma unroll
       for (int g = 0; g < AND_G; ++g) {
         if (g < nb) {  // wave-uniform
@@ -645,6 +708,10 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
       ++blk;
     } else {
       break;
+    }
+    if (RGPU_AND_ABL >= 4) {  // (variant builds: what the vectors of either kind cost — results are wrong)
+      const bool popped_vec = ti_start == 2 || c1f0 != 0u || c1f1 != 0u;
+      if ((RGPU_AND_ABL == 4 && !popped_vec) || (RGPU_AND_ABL == 5 && popped_vec) || RGPU_AND_ABL == 6) { count += (a0 && d0 == 12345) ? 1 : 0; continue; }
     }
     intersect(d0, d1, f0, f1, nn, a0, a1, ord0, ti_start, c1f0, c1f1);
 #ifdef RGPU_AND_TIME

@@ -22,6 +22,9 @@ __device__ unsigned long long g_term_dbg[4];
 #ifndef RGPU_TERM_PRUNE  // 0: variant builds that measure the unpruned kernel
 #define RGPU_TERM_PRUNE 1
 #endif
+#ifndef RGPU_TERM_ORDER
+#define RGPU_TERM_ORDER 1
+#endif
 #ifndef RGPU_TERM_WAVES
 #define RGPU_TERM_WAVES 8
 #endif
@@ -104,36 +107,44 @@ __device__ __forceinline__ void term_blocks_fast(const SegView& seg, const DevTe
   constexpr int DEPTH = PREFETCH_DEPTH;
   const uint8_t* term_rows = seg.bstore + T.bs_base;
   const uint8_t* pn = seg.pnorm + T.pn_base;
-  // Entry test on raw score bits: a posting can enter iff its key exceeds tau = (S, D), i.e. score > S, or
-  // score == S and doc < D. Postings arrive in doc order, so once every remaining doc is known to lie above D
-  // (seen_doc >= D) a tie can no longer win and the test becomes strict — BM25 scores of one term take few
-  // distinct values (freq <= 10 x norm rank), so ties with the threshold are the common case, not the corner.
-  int32_t seen_doc = b0 == 0 ? -1 : seg.dir_last[T.dir_base + b0 - 1];  // every posting from b0 on has doc > seen_doc
-  auto thr_of = [&](uint64_t t) -> uint32_t {
+#if RGPU_TERM_ORDER == 0
+#error "the index-order variant was removed with round 5 (see git history): RGPU_TERM_ORDER must be 1"
+#endif
+  // Entry test on raw score bits: a posting can enter iff its key exceeds tau = (S, D), i.e. score > S, or score == S and
+  // doc < D. BM25 scores of one term take few distinct values (freq <= 10 x norm rank), so ties with the threshold are the common
+  // case, not the corner: a block whose docs all lie above D cannot win a tie, and the test against it is strict. Every doc of
+  // block b is above `lo` = the last doc of block b - 1 (the directory), so "all above D" is lo >= D - 1 — a property of the
+  // block, not of the order the blocks are visited in (round 5: they are visited best bound first, see take()).
+  auto thr_of = [&](uint64_t t, int32_t lo) -> uint32_t {
     const uint32_t thi = (uint32_t)(t >> 32);
     if (!(thi & 0x80000000u)) return 0u;  // no threshold yet (or a negative one): everything is a candidate
     const uint32_t bits = thi & 0x7fffffffu;
-    return key_doc(t) <= seen_doc ? bits + 1u : bits;
+    return key_doc(t) <= lo + 1 ? bits + 1u : bits;  // (key_doc <= lo + 1: no doc of the block is below the threshold's doc)
   };
   auto fresh_tau = [&]() -> uint64_t {
     const uint64_t kth = group_kth<WIDE>(group, k);
     return kth > floor ? kth : floor;
   };
   // `thr` lives in one scalar register between updates (kept opaque: the compiler would otherwise recompute it
-  // from tau / seen_doc — eight scalar instructions — in front of every block's compare)
+  // from tau / lo — eight scalar instructions — in front of every block's compare)
   auto pin = [](uint32_t v) -> uint32_t { asm volatile("" : "+s"(v)); return v; };
   uint64_t tau = fresh_tau();
-  uint32_t thr = pin(thr_of(tau));
 #ifdef RGPU_EXP_COUNT
   int dbg_slow = 0, dbg_looked = 0;
 #endif
-  // a chunk's directory entries (and frontier words) arrive one chunk ahead of their use
-  struct Chunk { DirChunk dir; uint64_t bmax; };
+  // a chunk's directory entries (frontier words, the docs in front of its blocks) arrive one chunk ahead of their use — and with
+  // them a fresh look at what the query's OTHER wavefronts have published meanwhile (round 5: one look per item at its start
+  // left the items of a query warming up side by side, each on its own: 130 k of the headline batch's 2.2 M blocks unpacked
+  // where a threshold known in advance needs a few per query)
+  struct Chunk { DirChunk dir; uint64_t bmax; int32_t lo; uint64_t seen; };
   auto load_chunk = [&](int c0) -> Chunk {
     Chunk c;
     const int nb = min(64, b1 - c0);
     c.dir.load(seg.dir_row, seg.dir_hdr, T.dir_base, c0, nb, lane);
     c.bmax = (prune && lane < nb) ? seg.dir_bmax[T.dir_base + c0 + lane] : 0ull;
+    const int e = c0 + lane - 1;  // the block in front of this lane's
+    c.lo = (lane < nb && e >= 0) ? seg.dir_last[T.dir_base + e] : -1;
+    c.seen = shared.peek();
     return c;
   };
   Chunk next = load_chunk(b0);
@@ -142,9 +153,9 @@ __device__ __forceinline__ void term_blocks_fast(const SegView& seg, const DevTe
     const Chunk cur = next;
     if (c0 + 64 < b1) next = load_chunk(c0 + 64);
     const DirChunk& dir = cur.dir;
-    if (c0 > b0) {  // blocks skipped on the cheap path moved the position too
-      const int32_t upto = seg.dir_last[T.dir_base + c0 - 1];
-      seen_doc = upto > seen_doc ? upto : seen_doc;
+    {
+      uint64_t t0 = 0;
+      shared.fold(cur.seen, t0, floor);
     }
     count += 128 * nb;
     // lane j: the best score any posting of block c0 + j can have (raw bits; scores are >= 0 here)
@@ -161,6 +172,9 @@ __device__ __forceinline__ void term_blocks_fast(const SegView& seg, const DevTe
       best = fmax > (uint32_t)SCORE_TABLE_FREQS ? 0xffffffffu : bb;
     }
     const uint64_t in_chunk = nb == 64 ? ~0ull : ((1ull << nb) - 1ull);
+    // lane j: can block c0 + j still put a posting into the top-k? (its bound against the threshold of the moment, strict when
+    // none of its docs can win a tie)
+    auto may_enter = [&](uint64_t t) -> bool { return best >= thr_of(t, cur.lo); };
     auto step = [&](int idx, const uint4& rows, uint32_t nn) {
       const uint32_t hdr = dir.hdr_at(idx);
       const int bf = hdr_bfreq(hdr);
@@ -190,6 +204,8 @@ __device__ __forceinline__ void term_blocks_fast(const SegView& seg, const DevTe
 #endif
       looked += 1u;                            // what this launch really decoded (rgpu_last_search_counters): scalar adds
       touched += encoded_block_bytes(hdr) + 128u;  // both streams' rows are requested together + the posting-order norms
+      const int32_t base = readlane(cur.lo, idx) < 0 ? 0 : readlane(cur.lo, idx);  // (block 0 of the term: deltas count from doc 0)
+      const uint32_t thr = pin(thr_of(tau, readlane(cur.lo, idx)));
       const uint32_t r0 = __float_as_uint(s0), r1 = __float_as_uint(s1);
       if (__ballot((r0 > r1 ? r0 : r1) >= thr)) {
 #ifdef RGPU_EXP_COUNT
@@ -197,8 +213,6 @@ __device__ __forceinline__ void term_blocks_fast(const SegView& seg, const DevTe
 #endif
         uint32_t e0, e1;
         staged_doc_deltas<LEGACY>(slab, rows, hdr, lane, e0, e1);
-        const int blk = c0 + idx;
-        const int32_t base = blk == 0 ? 0 : seg.dir_last[T.dir_base + blk - 1];
         int32_t d0, d1;
         deltas_to_docs(e0, e1, base, d0, d1);
         const uint64_t key0 = below(make_key(s0, d0), ceil), key1 = below(make_key(s1, d1), ceil);
@@ -206,28 +220,34 @@ __device__ __forceinline__ void term_blocks_fast(const SegView& seg, const DevTe
         // current k-th best (one LDS read) before paying for the lock and the list check-out
         tau = fresh_tau();
         if (__ballot((key0 > key1 ? key0 : key1) > tau)) group_offer2<WIDE>(group, key0, key1, tau, k, lane, floor);
-        seen_doc = readlane(d1, 63);
-        thr = pin(thr_of(tau));
       }
       wave_sync();  // slab is free for the next block
     };
     auto norms_of = [&](int idx) -> uint32_t {
       return *reinterpret_cast<const uint16_t*>(pn + (128u * (uint32_t)(c0 + idx) + 2u * (uint32_t)lane));
     };
-    // Blocks that may still matter, streamed through a DEPTH-deep ring of row (and norm) loads. `todo` is re-filtered
-    // with the threshold of the moment before every round: the threshold only rises, so a stale test is merely
-    // conservative. Ring slots without a block (slot[j] < 0) reload the chunk's first block instead of being guarded:
-    // a redundant load is cheaper than a load behind a branch.
+    // Blocks that may still matter, streamed through a DEPTH-deep ring of row (and norm) loads, the block with the LARGEST bound
+    // first: its postings lift the threshold the most, and every block whose bound the new threshold exceeds is never requested
+    // (in index order a dense term's first chunk unpacked block after block while the threshold crept up). `todo` is re-filtered
+    // with the threshold of the moment before every round: the threshold only rises, so a stale test is merely conservative.
+    // Ring slots without a block (slot[j] < 0) reload the chunk's first block instead of being guarded: a redundant load is
+    // cheaper than a load behind a branch.
     tau = fresh_tau();
-    thr = pin(thr_of(tau));
-    uint64_t todo = in_chunk & __ballot(best >= thr);
+    uint64_t todo = in_chunk & __ballot(may_enter(tau));
     int slot[DEPTH];
     uint4 ring[DEPTH];
     uint32_t nring[DEPTH];
     auto take = [&]() -> int {
       if (!todo) return -1;
-      const int i = (int)__builtin_ctzll(todo);
-      todo &= todo - 1;
+      int i;
+      if (prune) {
+        const uint32_t mine = ((todo >> lane) & 1ull) ? best : 0u;
+        const uint32_t top = wave_reduce_max_u32(mine);
+        i = (int)__builtin_ctzll(todo & __ballot(mine == top));
+      } else {
+        i = (int)__builtin_ctzll(todo);
+      }
+      todo &= ~(1ull << i);
       return i;
     };
 #pragma unroll
@@ -240,8 +260,7 @@ __device__ __forceinline__ void term_blocks_fast(const SegView& seg, const DevTe
     while (slot[0] >= 0) {  // slots fill in order, so an empty slot 0 means an empty ring
       // what the group's other wavefronts achieved meanwhile: one LDS read per DEPTH blocks
       tau = fresh_tau();
-      thr = pin(thr_of(tau));
-      if (prune) todo &= __ballot(best >= thr);
+      if (prune) todo &= __ballot(may_enter(tau));
 #pragma unroll
       for (int j = 0; j < DEPTH; ++j) {  // static ring slot j
         const uint4 rows = ring[j];
@@ -254,6 +273,8 @@ __device__ __forceinline__ void term_blocks_fast(const SegView& seg, const DevTe
         if (idx >= 0) step(idx, rows, nn);
       }
     }
+    // what this chunk achieved, for the query's other wavefronts (an atomic only when the group's k-th best has risen)
+    shared.publish_key(group_kth<WIDE>(group, k), lane);
   }
 #ifdef RGPU_EXP_COUNT
   if (lane == 0) {

@@ -109,6 +109,7 @@ struct TermBitmap {
   const uint8_t* freqs;   // min(freq, 255) by posting index
   const uint32_t* ovf;    // {posting index, freq} of the freqs >= 255
   const uint32_t* nib;    // four bits per doc (0 absent, 1..14 the freq, 15 look it up), or null
+  const uint32_t* memb;   // one bit per doc: membership alone (k_search_and's batched first probe)
   int32_t n_ovf;
   int32_t pad;
 };

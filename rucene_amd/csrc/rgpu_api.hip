@@ -148,6 +148,7 @@ struct rgpu_ctx {
   hipStream_t stream = nullptr;
   rgpu_config cfg{};
   bool blocks_per_item_auto = false;
+  bool and_blocks_per_item_auto = false;
   std::mutex mu;
   DevVec<float> sim_tables;
   int n_sim_tables = 0;
@@ -206,7 +207,7 @@ struct rgpu_ctx {
 
 struct TermInfo { uint32_t dir_base; int32_t nblocks; int32_t df; uint64_t pn_base; uint64_t bs_base; bool norms; };
 // a term's doc bitmap (kernels/doc_bitmap.hpp): one allocation [words | ranks | ovf | stats | freqs]
-struct BitmapInfo { uint2* words; uint32_t* ranks; uint8_t* freqs; uint32_t* ovf; uint32_t* nib; int32_t n_ovf; int32_t max_freq; int32_t df; int32_t sim_table; bool usable; };
+struct BitmapInfo { uint2* words; uint32_t* ranks; uint8_t* freqs; uint32_t* ovf; uint32_t* nib; uint32_t* memb; int32_t n_ovf; int32_t max_freq; int32_t df; int32_t sim_table; bool usable; };
 
 // doc_start_fp -> TermInfo of the prepared terms (host/flat_fp_map.hpp: two look-ups per clause per batch)
 using PreparedMap = rucene::FlatFpMap<TermInfo>;
@@ -426,24 +427,45 @@ static int32_t prepare_terms_attempt(rgpu_segment* seg, const rgpu_term_state* c
   const size_t batch_bs = (seg->bstore_used + 15) & ~size_t(15);  // this call's rows form one dense region from here
   uint64_t cap_rows = 0;
   std::vector<std::pair<int64_t, TermInfo>> added;
+  // Two tables stand between a term and the work list: "prepared already" and "named earlier in this call". A bulk first touch
+  // (152 k terms of a fresh 100 M-doc segment: the cold path) pays two DRAM round trips per term for answers that are known in
+  // advance — nothing is prepared yet, and a term dictionary hands its terms over in file order: while the doc_start_fps of the
+  // call ascend strictly no term can repeat, and the second table is only built (from the work list) once one does not.
   rucene::FlatFpMap<int> in_batch;
-  if (n > 4096) { in_batch.reserve_more(n); work.reserve(n); added.reserve(n); }
+  const bool none_prepared = seg->prepared.size() == 0;
+  bool ascending = true;
+  int64_t last_fp = -1;
+  if (n > 4096) { work.reserve(n); added.reserve(n); }
   constexpr size_t AHEAD = 16;  // look-ups of a bulk call are asked for this many terms ahead (flat_fp_map.hpp prefetch)
   for (size_t i = 0; i < n; ++i) {
-    if (i + AHEAD < n) { seg->prepared.prefetch(sts[i + AHEAD]->doc_start_fp); in_batch.prefetch(sts[i + AHEAD]->doc_start_fp); }
+    if (i + AHEAD < n) {
+      if (!none_prepared) seg->prepared.prefetch(sts[i + AHEAD]->doc_start_fp);
+      if (!ascending) in_batch.prefetch(sts[i + AHEAD]->doc_start_fp);
+    }
     const rgpu_term_state& st = *sts[i];
     if (st.doc_freq < 2) {  // a singleton lives in the term dictionary; everything else has blocks and / or a tail
       if (st.doc_freq < 0) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "negative doc_freq");
       continue;
     }
-    if (const TermInfo* known = seg->prepared.find(st.doc_start_fp)) {
-      if (known->df != st.doc_freq) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "term state changed doc_freq for a known doc_start_fp");
-      continue;
+    if (!none_prepared) {
+      if (const TermInfo* known = seg->prepared.find(st.doc_start_fp)) {
+        if (known->df != st.doc_freq) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "term state changed doc_freq for a known doc_start_fp");
+        continue;
+      }
     }
     int32_t rc = validate_state(seg, st);
     if (rc != RGPU_OK) return rc;
-    if (in_batch.find(st.doc_start_fp)) continue;
-    in_batch.put(st.doc_start_fp, 1);
+    if (ascending && st.doc_start_fp > last_fp) {
+      last_fp = st.doc_start_fp;
+    } else {
+      if (ascending) {  // the order broke: from here on (and for what came before) the table decides
+        ascending = false;
+        in_batch.reserve_more(n);
+        for (const auto& a : added) in_batch.put(a.first, 1);
+      }
+      if (in_batch.find(st.doc_start_fp)) continue;
+      in_batch.put(st.doc_start_fp, 1);
+    }
     PrepTerm p;
     p.start_fp = (uint64_t)st.doc_start_fp;
     p.df = st.doc_freq;
@@ -583,29 +605,43 @@ static int32_t prepare_terms_attempt(rgpu_segment* seg, const rgpu_term_state* c
   int err4[4] = {0, 0, 0, 0};
   unsigned long long total_rows = 0;
   t_enqueue = hc.lap();
-  HIP_TRY(hipMemcpyAsync(err4, c->d_err, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipMemcpyAsync(&total_rows, d_total, 8, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  HIP_TRY(launch_status());
-  t_sync = hc.lap();
-  const int err = err4[0];
-  if (err == -101) return -101;  // see prepare_terms_locked
-  if (err != 0) {
-    if (sink) sink->fused->assign(n, 0);
-    return fail(err, err == RGPU_ERR_UNSUPPORTED ? std::string("FULL-encoded doc block (unimplemented in Rucene itself), or an EF / BITSET block in a legacy (.doc version 0) file")
-                                                 : "corrupt skip data or block framing in .doc (prepare.hpp check #" + std::to_string(err4[1]) + ")");
-  }
-  seg->dir_used = need_slots;
-  seg->bstore_used = batch_bs + (size_t)total_rows * 16;
+  hipError_t e_copy = hipMemcpyAsync(err4, c->d_err, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream);
+  if (e_copy == hipSuccess) e_copy = hipMemcpyAsync(&total_rows, d_total, 8, hipMemcpyDeviceToHost, c->stream);
+  // The terms are filed as prepared WHILE the kernels run (the context's mutex is held: nobody looks before this call returns):
+  // 152 k insertions into a table that is grown and first touched here — 2 to 6 ms of host time that used to follow the
+  // 1.3 ms of kernels instead of hiding behind them. A failing call takes them back (remove_keys: a rebuild, the rare path).
   seg->prepared.reserve_more(added.size());
   for (size_t i = 0; i < added.size(); ++i) {
     if (i + AHEAD < added.size()) seg->prepared.prefetch(added[i + AHEAD].first);
     seg->prepared.put(added[i].first, added[i].second);
   }
   t_commit = hc.lap();
+  auto take_back = [&]() {
+    std::vector<int64_t> keys(added.size());
+    for (size_t i = 0; i < added.size(); ++i) keys[i] = added[i].first;
+    seg->prepared.remove_keys(keys.data(), keys.size());
+    if (sink) sink->fused->assign(n, 0);
+  };
+  hipError_t e_sync = e_copy == hipSuccess ? hipStreamSynchronize(c->stream) : e_copy;
+  if (e_sync == hipSuccess) e_sync = launch_status();
+  if (e_sync != hipSuccess) {
+    (void)hipStreamSynchronize(c->stream);
+    take_back();
+    return fail(RGPU_ERR_RUNTIME, std::string("term preparation: ") + hipGetErrorString(e_sync));
+  }
+  t_sync = hc.lap();
+  const int err = err4[0];
+  if (err == -101) { take_back(); return -101; }  // see prepare_terms_locked
+  if (err != 0) {
+    take_back();
+    return fail(err, err == RGPU_ERR_UNSUPPORTED ? std::string("FULL-encoded doc block (unimplemented in Rucene itself), or an EF / BITSET block in a legacy (.doc version 0) file")
+                                                 : "corrupt skip data or block framing in .doc (prepare.hpp check #" + std::to_string(err4[1]) + ")");
+  }
+  seg->dir_used = need_slots;
+  seg->bstore_used = batch_bs + (size_t)total_rows * 16;
   if (HostClock::on())
-    std::fprintf(stderr, "[prepare host] %zu terms: plan %lld us, reserve (hipMalloc / grow) %lld, plan chunks + stage + H2D %lld, enqueue %lld, kernels + sync %lld, commit %lld\n",
-                 work.size(), t_plan, t_reserve, t_stage, t_enqueue, t_sync, t_commit);
+    std::fprintf(stderr, "[prepare host] %zu terms: plan %lld us, reserve (hipMalloc / grow) %lld, plan chunks + stage + H2D %lld, enqueue %lld, commit (under the kernels) %lld, rest of kernels + sync %lld\n",
+                 work.size(), t_plan, t_reserve, t_stage, t_enqueue, t_commit, t_sync);
   return RGPU_OK;
 }
 
@@ -725,7 +761,10 @@ extern "C" int32_t rgpu_init(int32_t device_ordinal, const rgpu_config* cfg, rgp
   // every clause was walked, and an item's fixed cost (descriptors, directory windows, one more list for the merge) weighs
   // more: on the 1024 x 3-term batch k_search_and + k_merge_items take 0.73 + 0.09 ms at 2, 0.475 + 0.053 at 4 (round 2's
   // choice), 0.412 + 0.040 at 6, 0.390 + 0.034 at 8, 0.398 + 0.028 at 12, 0.436 + 0.024 at 16, 0.60 + 0.02 at 32
-  if (c->cfg.and_blocks_per_item <= 0) c->cfg.and_blocks_per_item = 8;
+  // Round 5 (batched first probe): the items of a launch are sized from its lead blocks — and_item_blocks() — unless the caller
+  // pins them: on one box k_search_and took 0.357 ms at 8, 0.285 at 12, 0.304 at 16, 0.339 at 20, 0.39 at 24 (10 M docs: 320 k
+  // lead blocks) and 2.76 at 32, 2.54 at 48, 2.35 at 60 (100 M docs: 3.2 M lead blocks)
+  if (c->cfg.and_blocks_per_item <= 0) { c->cfg.and_blocks_per_item = 8; c->and_blocks_per_item_auto = true; }
   // doc bitmaps are an optional accelerator: they get a byte budget (default: an eighth of the device's memory — 36 GB of an
   // MI355X's 288), and a term past it stays a walked clause (ensure_bitmaps_locked)
   c->bitmap_budget = c->cfg.bitmap_budget_mib > 0 ? (size_t)c->cfg.bitmap_budget_mib << 20 : (size_t)prop.totalGlobalMem / 8;
@@ -1179,7 +1218,9 @@ static int32_t ensure_bitmaps_locked(rgpu_segment* seg, const rgpu_term_state* c
     if (st.doc_freq < 2 || seg->bitmaps.find(st.doc_start_fp)) continue;
     const size_t df = (size_t)st.doc_freq;
     const size_t o_ranks = nw_pad * 8, o_ovf = o_ranks + nw_pad * 4, o_stats = o_ovf + (size_t)BITMAP_OVF_CAP * 8;
-    const size_t o_freqs = o_stats + 64, o_nib = o_freqs + ((df + 127) & ~size_t(63));
+    // (+ the plain membership bits, one per doc: what the conjunction kernel's batched first probe gathers from — a quarter of
+    // the four-bits-per-doc array's footprint, half of the {any, hi} pairs')
+    const size_t o_freqs = o_stats + 64, o_memb = o_freqs + ((df + 127) & ~size_t(63)), o_nib = o_memb + nw_pad * 4;
     // (the four-bits-per-doc array of the densest terms: conjunctions answer a candidate with ONE gather from it)
     bool with_nib = (int64_t)st.doc_freq * BITMAP_NIBBLE_DENSITY >= (int64_t)seg->max_doc;
     size_t total = o_nib + (with_nib ? (nw_pad * 4 + 64) * 4 : 0);
@@ -1198,6 +1239,7 @@ static int32_t ensure_bitmaps_locked(rgpu_segment* seg, const rgpu_term_state* c
     info.ovf = reinterpret_cast<uint32_t*>(block + o_ovf);
     info.freqs = block + o_freqs;
     info.nib = with_nib ? reinterpret_cast<uint32_t*>(block + o_nib) : nullptr;
+    info.memb = reinterpret_cast<uint32_t*>(block + o_memb);
     info.df = st.doc_freq;
     BitmapStats* d_stats = reinterpret_cast<BitmapStats*>(block + o_stats);
     BitmapStats hs{};
@@ -1215,7 +1257,7 @@ static int32_t ensure_bitmaps_locked(rgpu_segment* seg, const rgpu_term_state* c
         TimedLaunch tl(c, c->stream, "k_bitmap_build", (int64_t)df);
         RGPU_LAUNCH(k_bitmap_fill, dim3(wg_count((df + 255) / 256)), dim3(256), 0, c->stream, docs, freqs, (int64_t)df, seg->max_doc,
                            (const uint8_t*)seg->d_norms, (const float*)(c->sim_tables.p + (size_t)sim_tables[i] * 257),
-                           seg->n_norm_ranks > 0 ? (const uint8_t*)seg->d_rank_to_norm : (const uint8_t*)nullptr, info.words, info.freqs, info.ovf, d_stats, info.nib);
+                           seg->n_norm_ranks > 0 ? (const uint8_t*)seg->d_rank_to_norm : (const uint8_t*)nullptr, info.words, info.freqs, info.ovf, d_stats, info.nib, info.memb);
         const int64_t n_scan = n_words + 1;  // ranks[n_words] = the list's size
         RGPU_LAUNCH(k_bitmap_popc, dim3(wg_count((n_scan + 255) / 256)), dim3(256), 0, c->stream, info.words, n_scan, info.ranks);
         const int64_t n_tiles = (n_scan + SCAN_TILE - 1) / SCAN_TILE;
@@ -1251,7 +1293,7 @@ static int32_t ensure_bitmaps_locked(rgpu_segment* seg, const rgpu_term_state* c
       seg->bitmap_allocs.pop_back();
       seg->bitmap_bytes -= total;
       c->bitmap_bytes -= total;
-      info.words = nullptr; info.ranks = nullptr; info.ovf = nullptr; info.freqs = nullptr; info.nib = nullptr;
+      info.words = nullptr; info.ranks = nullptr; info.ovf = nullptr; info.freqs = nullptr; info.nib = nullptr; info.memb = nullptr;
       seg->bitmap_refused++;
     } else {
       seg->bitmap_terms++;
@@ -1954,6 +1996,33 @@ static int32_t search_or_wide_group(rgpu_segment* seg, Group& G, int32_t k, HitO
   return RGPU_OK;
 }
 
+// Lead blocks per work item of k_search_and when the caller leaves rgpu_config.and_blocks_per_item at 0: about 32 k items per
+// launch. An item's fixed cost (descriptors, directory window, a partial top-k list for the merge) was a sixth of the kernel at 8
+// blocks per item; much longer items leave the chip's 4096 wavefront slots with a ragged tail on a small launch.
+#ifndef RGPU_AND_TARGET_ITEMS
+#define RGPU_AND_TARGET_ITEMS 28672
+#endif
+#ifndef RGPU_AND_MAX_ITEM_BLOCKS  // (100 M docs, 3.2 M lead blocks: 2.76 ms at 32 blocks per item, 2.54 at 48, 2.35 at 60, 2.28 at 78, 2.59 at 112)
+#define RGPU_AND_MAX_ITEM_BLOCKS 72
+#endif
+// k_search_and deals chunks of `chunk` consecutive workgroups to the XCDs (search_and.hpp) when a list's membership bits fit an
+// XCD's L2 with room to spare; the grid then is whole rounds of 8 chunks
+static int and_xcd_chunk(const rgpu_segment* seg) {
+#ifdef RGPU_AND_XCD_CHUNK
+  return RGPU_AND_XCD_CHUNK;
+#else
+  return (int64_t)seg->max_doc / 8 <= (2ll << 20) ? 64 : 0;  // 2 MB of bits per list (max_doc <= 16.7 M) against 4 MB of L2 per XCD
+#endif
+}
+static unsigned long long and_grid(long long wgs, int chunk) {
+  if (chunk <= 0) return (unsigned long long)wgs;
+  const long long round = 8ll * chunk;
+  return (unsigned long long)((wgs + round - 1) / round * round);
+}
+static int and_item_blocks(const rgpu_ctx* c, int64_t lead_blocks) {
+  if (!c->and_blocks_per_item_auto) return c->cfg.and_blocks_per_item;
+  return (int)std::min<int64_t>(RGPU_AND_MAX_ITEM_BLOCKS, std::max<int64_t>(8, (lead_blocks + RGPU_AND_TARGET_ITEMS - 1) / RGPU_AND_TARGET_ITEMS));
+}
 static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t n_queries, const rgpu_query_term* terms,
                            int32_t n_terms_total, int32_t k, int32_t k_total, HitOut* hits_dev, int64_t* totals_dev, hipStream_t stream);
 // TopDocsCollector takes any k (collector/top_docs.rs:28-95). A wavefront's registers hold a 128-key list, so k > 128 runs as
@@ -2205,7 +2274,12 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
       G.queries.swap(qs);
       G.qmap.swap(qm);
     }
-    int blocks_per_item = op == RGPU_OP_TERM ? c->cfg.blocks_per_item : c->cfg.and_blocks_per_item;
+    int blocks_per_item = c->cfg.blocks_per_item;
+    if (op != RGPU_OP_TERM) {
+      int64_t lead_blocks = 0;
+      for (const DevQuery& q0 : G.queries) if (q0.n_terms >= 1) lead_blocks += G.terms[(size_t)q0.first_term].nblocks;
+      blocks_per_item = and_item_blocks(c, lead_blocks);
+    }
     int64_t items = 0;
     G.item_prefix.assign((size_t)nq + 1, 0);
     const int head_items = op == RGPU_OP_TERM ? nq : 0;  // TERM: every query's first chunk is scheduled first
@@ -2252,7 +2326,7 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
     if (op == RGPU_OP_AND && c->cfg.and_bitmaps >= 0 && seg->bitmaps.size() > 0) {
       const int64_t min_df = bitmap_min_df_and(seg);
       bool any = false;
-      clause_bitmaps.assign(G.terms.size(), TermBitmap{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0});
+      clause_bitmaps.assign(G.terms.size(), TermBitmap{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0});
       for (const DevQuery& q0 : G.queries) {
         const int n_all = q0.n_terms + q0.pad + ((q0.op >> 16) & 0xff);
         for (int i = 1; i < n_all; ++i) {
@@ -2260,7 +2334,7 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
           if (t.df < min_df) continue;
           const BitmapInfo* bm = seg->bitmaps.find((int64_t)t.start_fp);
           if (!bm || !bm->usable || bm->df != t.df) continue;
-          clause_bitmaps[(size_t)(q0.first_term + i)] = TermBitmap{bm->words, bm->ranks, bm->freqs, bm->ovf, bm->nib, bm->n_ovf, 0};
+          clause_bitmaps[(size_t)(q0.first_term + i)] = TermBitmap{bm->words, bm->ranks, bm->freqs, bm->ovf, bm->nib, bm->memb, bm->n_ovf, 0};
           any = true;
         }
       }
@@ -2305,7 +2379,9 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
       c->last_counted_loose = 0;
       for (const DevQuery& q0 : G.queries) if (q0.n_terms >= 1) { const DevTerm& t0 = G.terms[(size_t)q0.first_term]; c->last_counted_loose += t0.df == 1 ? 1 : t0.tail_n; }
       TimedLaunch tl(c, stream, "k_search_and", G.postings);
-      const unsigned grid = wg_count((items + WG_WAVES - 1) / WG_WAVES);
+      // (whole rounds of 8 x AND_XCD_CHUNK workgroups: the kernel deals chunks of workgroups to the XCDs, search_and.hpp)
+      const int xcd_chunk = and_xcd_chunk(seg);
+      const unsigned grid = wg_count(and_grid((items + WG_WAVES - 1) / WG_WAVES, xcd_chunk));
       const int64_t* d_sp = nullptr;
       void* d_seq = nullptr;
       if (G.req_opt) {  // records instead of a collector (the buffer is the context's run scratch: this group ends with a stream sync)
@@ -2318,7 +2394,7 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
         RGPU_LAUNCH(kern, dim3(grid), dim3(WG_THREADS), 0, stream, sv, dq, dt, dp, nq, items, blocks_per_item, (int)k,
                            c->S->d_partial_keys.p, c->S->d_partial_counts.p, d_tau, c->S->d_touched.p,
                            d_sp, (unsigned long long*)nullptr, d_seq, c->pass.ceil_in, dm,
-                           clause_bitmaps.empty() ? (const TermBitmap*)nullptr : reinterpret_cast<const TermBitmap*>(c->S->d_stage.p + o_bm));
+                           clause_bitmaps.empty() ? (const TermBitmap*)nullptr : reinterpret_cast<const TermBitmap*>(c->S->d_stage.p + o_bm), xcd_chunk);
       };
       bool has_not = false, has_opt = false;
       for (const DevQuery& q : G.queries) { has_not = has_not || q.pad != 0; has_opt = has_opt || (q.op >> 16) != 0; }
@@ -2660,7 +2736,13 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
   bool any_cutoff = false;
   bool any_sloppy = false, any_exact = false;
   bool sloppy_rpts = false;  // some sloppy phrase names a term twice (SloppyPhraseScorer's repetition groups: k_sloppy_groups)
-  const int blocks_per_item = c->cfg.and_blocks_per_item;
+  int64_t phrase_lead_blocks = 0;  // the conjunctions' lead blocks: every phrase's rarest term
+  for (int32_t q = 0; q < n_queries; ++q) {
+    int64_t least = INT64_MAX;
+    for (int i = 0; i < queries[q].n_terms; ++i) least = std::min<int64_t>(least, std::max<int64_t>(0, terms[queries[q].first_term + i].state.doc_freq));
+    if (least != INT64_MAX) phrase_lead_blocks += least / 128;
+  }
+  const int blocks_per_item = and_item_blocks(c, phrase_lead_blocks);
   int64_t items = 0, slots = 0;
   for (int32_t q = 0; q < n_queries; ++q) {
     const rgpu_phrase_query& Q = queries[q];
@@ -2731,14 +2813,14 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
     std::vector<TermBitmap> clause_bitmaps;  // parallel to dt: the clauses behind a query's lead that have a doc bitmap
     if (bitmap_df != INT64_MAX && seg->bitmaps.size() > 0) {
       bool any = false;
-      clause_bitmaps.assign(dt.size(), TermBitmap{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0});
+      clause_bitmaps.assign(dt.size(), TermBitmap{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0});
       for (const DevQuery& q0 : dq) {
         for (int i = 1; i < q0.n_terms; ++i) {
           const DevTerm& t = dt[(size_t)(q0.first_term + i)];
           if (t.df < bitmap_df) continue;
           const BitmapInfo* bm = seg->bitmaps.find((int64_t)t.start_fp);
           if (!bm || !bm->usable || bm->df != t.df) continue;
-          clause_bitmaps[(size_t)(q0.first_term + i)] = TermBitmap{bm->words, bm->ranks, bm->freqs, bm->ovf, bm->nib, bm->n_ovf, 0};
+          clause_bitmaps[(size_t)(q0.first_term + i)] = TermBitmap{bm->words, bm->ranks, bm->freqs, bm->ovf, bm->nib, bm->memb, bm->n_ovf, 0};
           any = true;
         }
       }
@@ -2788,12 +2870,13 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
     const bool legacy = seg->version < 1;
     {
       TimedLaunch tl(c, stream, "k_search_and(phrase candidates)", 0);
-      const unsigned grid = wg_count((items + WG_WAVES - 1) / WG_WAVES);
+      const int xcd_chunk = and_xcd_chunk(seg);
+      const unsigned grid = wg_count(and_grid((items + WG_WAVES - 1) / WG_WAVES, xcd_chunk));
       auto go = [&](auto kern) {
         RGPU_LAUNCH(kern, dim3(grid), dim3(WG_THREADS), 0, stream, sv, d_q, d_t, d_ip, (int)n_queries, items, blocks_per_item, k_emit,
                            c->S->d_partial_keys.p, c->S->d_partial_counts.p, c->S->d_tau.p, c->S->d_touched.p, d_ep, c->phrase_count.p,
                            (void*)c->phrase_docs.p, (const unsigned long long*)nullptr, (const int32_t*)nullptr,
-                           clause_bitmaps.empty() ? (const TermBitmap*)nullptr : reinterpret_cast<const TermBitmap*>(c->S->d_stage.p + o_bm));
+                           clause_bitmaps.empty() ? (const TermBitmap*)nullptr : reinterpret_cast<const TermBitmap*>(c->S->d_stage.p + o_bm), xcd_chunk);
       };
       if (legacy) go(k_search_and<true, false, false, false>); else go(k_search_and<false, false, false, false>);
     }

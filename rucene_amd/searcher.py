@@ -273,9 +273,50 @@ class BooleanQuery:
             raise RgpuError(-5, "min_should_match above 255")
         if (musts or filters) and not shoulds:
             msm = 0   # nothing for it to count (beside MUST clauses it has no effect anyway: ReqOptScorer only advances the optional scorer)
-        if any(not isinstance(q, TermQuery) for q in list(musts) + list(shoulds) + list(must_nots) + list(filters)):
-            raise RgpuError(-5, "nested boolean clauses are not supported on the GPU path")
+        # (a clause that is itself a BooleanQuery builds, as it does in the reference: whether the GPU path serves the tree is
+        # decided when it is searched — GpuIndexSearcher.flatten_nested / cpu_fallback)
+        if any(not isinstance(q, (TermQuery, BooleanQuery)) for q in list(musts) + list(shoulds) + list(must_nots) + list(filters)):
+            raise RgpuError(-5, "only term and boolean clauses are known to this mirror")
         return BooleanQuery(list(musts), list(shoulds), msm, list(must_nots), list(filters))
+
+    def is_flat(self):
+        return all(isinstance(q, TermQuery) for q in self.must_queries + self.should_queries + self.must_not_queries + self.filter_queries)
+
+    def flattened(self):
+        """ONE level of nesting folded into this query, or None when the tree is not of that shape: a MUST clause that is itself a
+        must-only BooleanQuery of terms, a SHOULD clause that is a should-only one (min_should_match <= 1) — what query builders that
+        AND / OR sub-expressions together produce. The reference does not rewrite such trees (boolean_query.rs:195-279 builds a
+        ConjunctionScorer over [a, ConjunctionScorer(b, c)]): doc ids and hit counts are those of the flat query, but its f32 sums
+        are formed as a + (b + c) where the flat query forms (a + b) + c — equal within 1e-5 relative (north_star's tolerance for
+        floats), NOT bit for bit; a top-k boundary inside such a rounding band may fall differently. Opt-in for that reason."""
+        def fold(clauses, want_must):
+            out = []
+            for q in clauses:
+                if isinstance(q, TermQuery):
+                    out.append(q)
+                    continue
+                if not q.is_flat() or q.must_not_queries or q.filter_queries:
+                    return None
+                if want_must and q.must_queries and not q.should_queries:
+                    out.extend(q.must_queries)
+                elif not want_must and q.should_queries and not q.must_queries and q.min_should_match <= 1:
+                    out.extend(q.should_queries)
+                else:
+                    return None
+            return out
+        if not all(isinstance(q, TermQuery) for q in self.must_not_queries + self.filter_queries):
+            return None
+        musts = fold(self.must_queries, True)
+        if musts is None:
+            return None
+        if musts or self.filter_queries:   # SHOULD clauses beside MUST ones stay as they are (ReqOptScorer's optional side)
+            if not all(isinstance(q, TermQuery) for q in self.should_queries):
+                return None
+            return BooleanQuery(musts, list(self.should_queries), self.min_should_match, self.must_not_queries, self.filter_queries)
+        shoulds = fold(self.should_queries, False)
+        if shoulds is None or (self.min_should_match > 1 and len(shoulds) != len(self.should_queries)):
+            return None   # (min_should_match counts the OUTER clauses: folding would change what it counts)
+        return BooleanQuery([], shoulds, self.min_should_match, self.must_not_queries, [])
 
     def required_clauses(self):
         """MUST clauses followed by the FILTER clauses as zero-weight MUST clauses (BooleanWeight puts both into must_weights)."""
@@ -313,7 +354,13 @@ class GpuIndexSearcher:
     """IndexSearcher over GPU-resident leaves. `search(query, collector)` mirrors searcher.rs:487-525;
     `search_batch` is the batched form the hardware wants (one launch set per leaf for many queries)."""
 
-    def __init__(self, leaves, ctx=None, similarity=None, next_limit=None):
+    def __init__(self, leaves, ctx=None, similarity=None, next_limit=None, flatten_nested=False, cpu_fallback=None):
+        """flatten_nested: fold one level of nested BooleanQuery clauses (BooleanQuery.flattened: same docs and counts, scores
+        within 1e-5 of the reference's — off by default because it is not bit-exact). cpu_fallback(query, collector): what
+        SURVEY 8(f)1 calls "everything else to the CPU path" — search() hands every tree the GPU path does not serve
+        (UnsupportedOperation) to it, as the Rust shim hands them to DefaultIndexSearcher (rust/gpu/searcher.rs); None: raise."""
+        self.flatten_nested = bool(flatten_nested)
+        self.cpu_fallback = cpu_fallback
         self.leaves = list(leaves)
         # DefaultIndexSearcher::new(reader, next_limit: Option<usize>) (searcher.rs:291-296, :361): how many approximations of a
         # two-phase scorer (here: sloppy phrases) may go by on a leaf without a collected doc. None = the default, 500 000
@@ -364,12 +411,16 @@ class GpuIndexSearcher:
             self._weights[key] = (w, self.ctx.sim_table(cache, self.similarity.k1))
         return self._weights[key]
 
-    @staticmethod
-    def _flatten(query):
+    def _flatten(self, query):
         """-> (op, required / scored clauses, optional SHOULD clauses beside MUST ones, MUST_NOT clauses)"""
         if isinstance(query, TermQuery):
             return OP_TERM, [query], [], []
         if isinstance(query, BooleanQuery):
+            if not query.is_flat():
+                folded = query.flattened() if getattr(self, "flatten_nested", False) else None
+                if folded is None:
+                    raise RgpuError(-5, "nested boolean clauses are not served by the GPU path (flatten_nested folds one level of MUST-of-MUSTs / SHOULD-of-SHOULDs)")
+                query = folded
             required = query.required_clauses()
             if required:
                 opts = query.should_queries
@@ -541,9 +592,15 @@ class GpuIndexSearcher:
 
     def search(self, query, collector):
         """IndexSearcher::search(query, collector) for a TopDocsCollector."""
-        if not isinstance(collector, TopDocsCollector):
-            raise RgpuError(-5, "only TopDocsCollector is served by the GPU path")
-        hits, totals = self.search_batch([query], collector.estimated_hits)
+        try:
+            if not isinstance(collector, TopDocsCollector):
+                raise RgpuError(-5, "only TopDocsCollector is served by the GPU path")
+            hits, totals = self.search_batch([query], collector.estimated_hits)
+        except RgpuError as e:
+            # ErrorKind::UnsupportedOperation -> the CPU searcher, exactly where rust/gpu/searcher.rs falls back to DefaultIndexSearcher
+            if e.status == -5 and self.cpu_fallback is not None:
+                return self.cpu_fallback(query, collector)
+            raise
         row = hits[0]
         docs = [(int(d), float(s)) for d, s in zip(row["doc"], row["score"]) if d >= 0]
         collector._result = TopDocs(int(totals[0]), docs)

@@ -20,6 +20,8 @@ def cfg(name, c):
 
 
 print({k: d.get(k) for k in ("value", "ms_per_step", "parity_vs_oracle_full_batch", "gpu_over_cpu", "postings_decoded_per_sec", "postings_covered_per_sec", "n_gpus")})
+print("hoisted", {k: (round(v, 4) if isinstance(v, float) else v) for k, v in d.items() if k.startswith(("and3_", "or10_", "big_", "cold_", "block_decode_", "sloppy2_", "phrase2_", "one_stream", "whole_index"))})
+print("sharded_overhead", d.get("sharded_overhead"))
 print("streams", d.get("streams"))
 print("roofline", rl(d["roofline"]))
 print("parity", d.get("parity"))
@@ -34,6 +36,8 @@ for k, c in d.get("configs", {}).items():
         print("positions", {x: c[x] for x in ("docs", "doc_file_bytes", "pos_file_bytes", "index_build_s")})
         cfg("  positions_decode", c["positions_decode"])
         print("   ", {x: c["positions_decode"].get(x) for x in ("positions", "positions_decoded_per_sec", "parity_vs_oracle")})
+        if "sloppy2" in c:
+            cfg("  sloppy2", c["sloppy2"])
         cfg("  phrase2", c["phrase2"])
         ph = c["phrase2"]
         print("   ", {"lead_postings_per_step": ph.get("lead_postings_per_step", ph.get("conjunction_matches_checked_per_step")),  # (its name before the round's last commits)

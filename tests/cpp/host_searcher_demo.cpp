@@ -112,6 +112,32 @@ int main(int argc, char** argv) {
     bool threw = false;
     try { BooleanQuery::build({}, {}); } catch (const Error& e) { threw = e.kind == RGPU_ERR_ILLEGAL_ARGUMENT; }
     std::printf("empty-boolean-is-illegal-argument %d\n", threw ? 1 : 0);
+    {  // nested trees: refused, folded when asked to, or handed to the host's CPU searcher
+      NestedBooleanQuery nested;  // MUST [ t1, MUST [ t12, t40 ] ]  ==  the flat conjunction of query 2 above
+      nested.must_queries.emplace_back(new TermQuery(1));
+      nested.must_queries.push_back(BooleanQuery::build({TermQuery(12), TermQuery(40)}, {}));
+      NestedBooleanQuery mixed;   // MUST [ t1, SHOULD [ t12, t40 ] ]: not foldable
+      mixed.must_queries.emplace_back(new TermQuery(1));
+      mixed.must_queries.push_back(BooleanQuery::build({}, {TermQuery(12), TermQuery(40)}));
+      bool refused = false;
+      { TopDocsCollector c(10); try { searcher.search(nested, c); } catch (const Error& e) { refused = e.kind == RGPU_ERR_UNSUPPORTED; } }
+      searcher.flatten_nested = true;
+      TopDocsCollector folded(10);
+      searcher.search(nested, folded);
+      TopDocs top = folded.top_docs();
+      std::printf("nested %d %lld", refused ? 1 : 0, (long long)top.total_hits());
+      for (const ScoreDoc& d : top.score_docs()) {
+        uint32_t bits;
+        std::memcpy(&bits, &d.score, 4);
+        std::printf(" %d:%08x", d.doc, bits);
+      }
+      std::printf("\n");
+      int fell_back = 0;
+      searcher.cpu_fallback = [&](const Query& q, TopDocsCollector&) { fell_back += (&q == &mixed) ? 1 : 0; };
+      TopDocsCollector c2(10);
+      searcher.search(mixed, c2);
+      std::printf("fallback %d\n", fell_back);
+    }
     rgpu_terms_close(dict);
     rgen_free(ix);
   } catch (const rucene::Error& e) {

@@ -4,8 +4,8 @@
               is the CPU IndexSearcher: its result against an independent numpy restatement of TermScorer + BM25 + the collector,
               and — `-m gpu` — the same query through the C ABI, bit-exact)
   configs[1]  1024 single-term queries, 10 M docs   -> tests/test_gpu_fullsize.py (the whole batch against the oracle) + bench.py's headline
-  configs[2]  3-term AND, 10 M docs                 -> tests/test_gpu_fullsize.py (256 queries) + bench.py `configs.and3` (all 1024)
-  configs[3]  10-term OR top-100, 10 M docs         -> tests/test_gpu_fullsize.py (64 queries, heap-order rule) + bench.py `configs.or10`
+  configs[2]  3-term AND, 10 M docs                 -> tests/test_gpu_fullsize.py (all 1024 queries) + bench.py `configs.and3` (all 1024)
+  configs[3]  10-term OR top-100, 10 M docs         -> tests/test_gpu_fullsize.py (256 queries, heap-order rule) + bench.py `configs.or10`
   configs[4]  100 M docs in 8 shards, 3-term AND    -> bench.py --gpus 8 (`configs.and3` on every rank's shard); the record /
               merge half on one GPU: tests/test_gpu_parity.py::test_shard_records_merge_like_finish_parallel; world size 2 on CPU:
               tests/test_dist_gloo.py

@@ -197,6 +197,53 @@ def test_conjunctions(zipf, oracle, k):
     _check_against_oracle(oracle, osearcher, gsearcher, specs, k)
 
 
+def test_nested_boolean_trees_through_the_seam(zipf, oracle):
+    """"... everything else to the CPU path". One level of MUST-of-MUSTs / SHOULD-of-SHOULDs folds into the flat
+    query when the searcher is asked to (same docs and counts as the flat query, which the oracle pins; the nested tree's own
+    f32 sums a + (b + c) are restated here and must agree within 1e-5); every other tree reaches cpu_fallback — here the oracle
+    plays the CPU searcher (test infrastructure: the product only ever calls the hook it is given)."""
+    import rucene_amd
+    seg, osearcher, gsearcher = zipf
+    T, B = rucene_amd.TermQuery, rucene_amd.BooleanQuery
+    k = 10
+    g2 = rucene_amd.GpuIndexSearcher(gsearcher.leaves, ctx=gsearcher.ctx, flatten_nested=True)
+    nested = [B.build([T(5), B.build([T(1), T(40)], [])], []), B.build([], [T(300), B.build([], [T(7), T(900)]), T(2)])]
+    flat = [(oracle.OP_AND, [5, 1, 40]), (oracle.OP_OR, [300, 7, 900, 2])]
+    hits, totals = g2.search_batch(nested, k)
+    for i, (op, tids) in enumerate(flat):
+        d, sc, total = osearcher.search(op, tids, k, tie_mode=oracle.TIE_CANONICAL)
+        assert totals[i] == total and (hits[i]["doc"][:d.size] == d).all()
+        assert (hits[i]["score"][:d.size].view(np.int32) == sc.view(np.int32)).all()   # = the flat query, bit for bit
+    # the reference's sums for the nested conjunction: lead-first over [T(5), Conj(1, 40)] sorted by cost, the inner conjunction's
+    # own sum formed first (conjunction_scorer.rs:87-95) — per returned doc, from the oracle's single-term scores
+    per_term = {}
+    for t in (5, 1, 40):
+        scores, matched = osearcher.score_docs(oracle.OP_TERM, [t], hits[0]["doc"][hits[0]["doc"] >= 0])
+        assert matched.all()
+        per_term[t] = np.asarray(scores, dtype=np.float32)
+    inner_order = sorted((1, 40), key=lambda t: int(seg.terms[t]["doc_freq"]))       # ConjunctionScorer::new sorts by cost
+    inner = per_term[inner_order[0]] + per_term[inner_order[1]]                     # f32
+    outer_first_is_inner = min(int(seg.terms[1]["doc_freq"]), int(seg.terms[40]["doc_freq"])) < int(seg.terms[5]["doc_freq"])
+    ref = (inner + per_term[5]) if outer_first_is_inner else (per_term[5] + inner)
+    n = int((hits[0]["doc"] >= 0).sum())
+    np.testing.assert_allclose(hits[0]["score"][:n], ref[:n], rtol=1e-5, atol=0)
+    # everything else -> the hook
+    calls = []
+
+    def cpu(query, collector):
+        calls.append(query)
+        d, sc, total = osearcher.search(oracle.OP_AND, [5, 1], collector.estimated_hits, tie_mode=oracle.TIE_CANONICAL)
+        collector._result = rucene_amd.TopDocs(total, list(zip(d.tolist(), sc.tolist())))
+    g3 = rucene_amd.GpuIndexSearcher(gsearcher.leaves, ctx=gsearcher.ctx, cpu_fallback=cpu)
+    col = rucene_amd.TopDocsCollector(k)
+    mixed = B.build([T(5), B.build([], [T(1), T(40)])], [])
+    g3.search(mixed, col)
+    assert calls == [mixed] and col.top_docs().total_hits() > 0
+    with pytest.raises(rucene_amd.RgpuError) as e:      # no hook, no flattening: UnsupportedOperation, as before
+        gsearcher.search(mixed, rucene_amd.TopDocsCollector(k))
+    assert e.value.status == -5
+
+
 @pytest.mark.parametrize("n_clauses", [2, 5, 9])
 def test_disjunctions_exact_below_ten_clauses(zipf, oracle, n_clauses):
     seg, osearcher, gsearcher = zipf
@@ -573,6 +620,10 @@ def test_cpp_host_mirror(oracle, tmp_path):
         assert out[len(specs) + i] == "text " + out[i]
     assert out[2 * len(specs)] == "text %d 0" % len(specs)      # a term the dictionary does not hold
     assert out[2 * len(specs) + 1].endswith(" 1")
+    # nested trees: refused without flatten_nested (1), then MUST [t1, MUST [t12, t40]] folded = the flat conjunction's line; a
+    # tree that does not fold reaches cpu_fallback exactly once
+    assert out[2 * len(specs) + 2].split()[:2] == ["nested", "1"] and out[2 * len(specs) + 2].split()[2:] == out[2].split()[1:]
+    assert out[2 * len(specs) + 3] == "fallback 1"
 
 
 def test_cpp_host_mirror_phrases_and_rescoring(ctx, oracle, tmp_path):
