@@ -417,6 +417,42 @@ def main():
         assert r["frac"] <= 1.0, "a bandwidth fraction above 1: %r" % (r,)
         return r
 
+    def or_deferred_leg(shard, k, steps, res):
+        """The 10-clause OR batch through a context opened with rgpu_config.or_deferred: rgpu_search_batch_device only enqueues (the
+        fixed-point kernels' hand-back flags are looked at by the next call that needs the scratch slot, or by rgpu_synchronize), so
+        the host's partitioning of batch i + 1 runs under the kernels of batch i. Planned steps on two alternating streams, ONE
+        rgpu_synchronize at the end of the timed region; the rows must be those of the default (blocking-per-group) mode, bit for bit."""
+        ctx_d = rucene_amd.Context(device=local_rank, or_deferred=True)
+        try:
+            leaf = rucene_amd.LeafReader.from_synthetic(shard.seg)
+            sd = rucene_amd.GpuIndexSearcher([leaf], ctx=ctx_d)
+            tids = res["tids"]
+            lanes = [Lane(k), Lane(k)]
+
+            def one(i):
+                pk = sd.pack_uniform(OPS["or10"], tids, leaf)
+                lane = lanes[i % 2]
+                leaf.segment.search_batch_device(pk[0], pk[1], k, lane.hits.data_ptr(), lane.totals.data_ptr(), lane.stream.cuda_stream)
+            for i in range(3):
+                one(i)
+            ctx_d.synchronize()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                one(i)
+            ctx_d.synchronize()
+            torch.cuda.synchronize()
+            ms = 1e3 * (time.perf_counter() - t0) / steps
+            last = lanes[(steps - 1) % 2]
+            g_hits = last.hits.cpu().numpy().view(rucene_amd.HIT_DTYPE).reshape(nq, k)
+            same = bool((g_hits["doc"] == res["g_hits"]["doc"]).all() and (g_hits["score"].view(np.int32) == res["g_hits"]["score"].view(np.int32)).all()
+                        and (last.totals.cpu().numpy() == res["g_totals"]).all())
+            leaf.segment.close()
+            return {"ms_per_step": ms, "queries_per_sec": nq / (ms * 1e-3), "same_rows_as_default_mode": same,
+                    "issue": "rgpu_config.or_deferred = 1: two alternating streams, every step planned, one rgpu_synchronize after the timed steps"}
+        finally:
+            ctx_d.close()
+
     def search_config(shard, kind, steps, warmup, full, tag, cpu_budget, cpu_sample, parity_queries):
         """One search workload on one shard: throughput with planning in the timed region, the dominant kernel's roofline
         from what it touched, decoded vs covered postings, the CPU leg and parity."""
@@ -467,6 +503,8 @@ def main():
             out["streams"]["note"] = ("ms per step. planned = term ids -> rgpu_query_term[] redone in every step by the native planner behind the C ABI "
                                       "(rgpu_plan_uniform_ids: term states, BM25 weights, sim table) — the headline; resident plan = planned once; "
                                       "object planner = one Python query object per query flattened first (GpuIndexSearcher.pack), then the native planner")
+        if kind == "or10" and world == 1 and not dist_mode:
+            out["deferred"] = or_deferred_leg(shard, k, steps, r)
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             base, ok, info = cpu_baseline_leg(shard, kind, k, r, cpu_budget, cpu_sample, parity_queries)
             out["cpu_baseline"] = base
@@ -809,6 +847,8 @@ def main():
     hoist("and3_kernel_ms", ["and3", "roofline"], "kernel_ms")
     hoist("and3_parity_vs_oracle", ["and3"], "parity_vs_oracle")
     hoist("or10_queries_per_sec", ["or10"], "queries_per_sec")
+    hoist("or10_deferred_queries_per_sec", ["or10", "deferred"], "queries_per_sec")
+    hoist("or10_deferred_same_rows", ["or10", "deferred"], "same_rows_as_default_mode")
     hoist("or10_roofline_frac", ["or10", "roofline"], "frac")
     hoist("or10_parity_vs_oracle", ["or10"], "parity_vs_oracle")
     hoist("block_decode_frac", ["block_decode", "roofline"], "frac")

@@ -91,7 +91,21 @@ typedef struct rgpu_config {
                                    term the budget has no room for (or whose allocation fails) is answered by walking its blocks,
                                    with the same results; rgpu_segment_footprint.doc_bitmap_refused counts such terms and
                                    rgpu_segment_release_prepared_terms gives the budget back */
-  int32_t reserved[2];          /* must be zero */
+  int32_t prepared_budget_mib;  /* HBM one segment's prepared-term store (block directory + aligned block store + posting-order norms:
+                                   rgpu_segment_footprint) may hold when a batch arrives, in MiB; 0 = no ceiling (default: every
+                                   term ever queried stays prepared for the life of the segment — 2.1..2.4 HBM bytes per .doc byte
+                                   when the whole vocabulary has been touched). Over the ceiling the store is dropped as a whole
+                                   between two batches and refilled by what the next batches name (the store is one dense region
+                                   per preparing call: keeping the recently used terms means preparing them again, which is what
+                                   their next use does anyway). The reference holds nothing per term (posting_reader.rs:460-500).
+                                   Results never depend on it; doc bitmaps have their own budget (bitmap_budget_mib) and stay */
+  int32_t or_deferred;          /* rgpu_search_batch_device with >= 10-clause disjunctions: 0 (default) = the call returns once the batch's
+                                   hand-back flags have been looked at (a top-k below the fixed-point floor, a window that did not fit:
+                                   those queries run again through another kernel) — one stream synchronisation per OR group; 1 = the
+                                   call only enqueues, like TERM / AND batches: the flags are looked at by the NEXT call that needs the
+                                   scratch slot, or by rgpu_synchronize. The caller must then call rgpu_synchronize(ctx) — not just
+                                   synchronise its stream — before it reads such a batch's rows. The host's planning of batch i + 1
+                                   then runs under the kernels of batch i. Results are the same either way */
 } rgpu_config;
 
 /* blocktree/mod.rs:33-59 BlockTermState, as filled by posting_reader.rs:264-306 lucene50_decode_term.

@@ -73,7 +73,7 @@ class _Config(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("blocks_per_item", C.c_int32), ("and_blocks_per_item", C.c_int32),
                 ("profile_kernels", C.c_int32), ("or_window_docs", C.c_int32), ("or_dense_clauses", C.c_int32),
                 ("raw_norms", C.c_int32), ("or_wide", C.c_int32), ("or_wide_window_docs", C.c_int32),
-                ("req_opt_rule", C.c_int32), ("or_bitmaps", C.c_int32), ("or_lazy_cells", C.c_int32), ("and_bitmaps", C.c_int32), ("bitmap_budget_mib", C.c_int32), ("reserved", C.c_int32 * 2)]
+                ("req_opt_rule", C.c_int32), ("or_bitmaps", C.c_int32), ("or_lazy_cells", C.c_int32), ("and_bitmaps", C.c_int32), ("bitmap_budget_mib", C.c_int32), ("prepared_budget_mib", C.c_int32), ("or_deferred", C.c_int32)]
 
 
 SEARCH_COUNTERS_DTYPE = np.dtype([("op", "<i4"), ("reserved", "<i4"), ("postings_covered", "<i8"), ("postings_decoded", "<i8"),
@@ -357,7 +357,8 @@ class Context:
     """rgpu_ctx: one per process per GPU."""
 
     def __init__(self, device=0, profile_kernels=False, blocks_per_item=0, and_blocks_per_item=0, or_window_docs=0,
-                 raw_norms=False, or_dense_clauses=0, or_wide=0, or_wide_window_docs=0, req_opt_rule=0, or_bitmaps=0, or_lazy_cells=0, and_bitmaps=0, bitmap_budget_mib=0):
+                 raw_norms=False, or_dense_clauses=0, or_wide=0, or_wide_window_docs=0, req_opt_rule=0, or_bitmaps=0, or_lazy_cells=0, and_bitmaps=0, bitmap_budget_mib=0,
+                 prepared_budget_mib=0, or_deferred=False):
         cfg = _Config()
         cfg.abi_version = ABI_VERSION
         cfg.blocks_per_item = blocks_per_item
@@ -373,6 +374,8 @@ class Context:
         cfg.or_lazy_cells = or_lazy_cells
         cfg.and_bitmaps = and_bitmaps
         cfg.bitmap_budget_mib = bitmap_budget_mib
+        cfg.prepared_budget_mib = prepared_budget_mib
+        cfg.or_deferred = int(or_deferred)
         h = C.c_void_p()
         _check(lib().rgpu_init(device, C.byref(cfg), C.byref(h)))
         self._h = h

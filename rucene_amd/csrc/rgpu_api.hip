@@ -7,6 +7,8 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <functional>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -133,11 +135,14 @@ struct Scratch {
   DevVec<int32_t> d_partial_counts;
   DevVec<unsigned long long> d_tau;  // per-query shared top-k thresholds
   DevVec<unsigned long long> d_touched;  // AND: per-query encoded bytes of the blocks the kernel decoded
+  DevVec<ScoredPosting> d_runs;  // OR: per-clause {doc, score} runs; ReqOptScorer records (a slot's own: no sync at the end of the group)
+  HostPinned h_back;             // flags a launch set hands back to the host (fixed-point floor, windows that did not fit)
+  bool settles_later = false;    // ... which the host has not looked at yet (rgpu_ctx::pending_or)
   hipEvent_t done = nullptr;
   bool busy = false;
   void release() {
     h_stage.release(); d_stage.release(); d_partial_keys.release(); d_partial_counts.release();
-    d_tau.release(); d_touched.release();
+    d_tau.release(); d_touched.release(); d_runs.release(); h_back.release();
     if (done) (void)hipEventDestroy(done);
     done = nullptr;
   }
@@ -160,6 +165,7 @@ struct rgpu_ctx {
   int64_t or_lazy_evals = 0, or_lazy_only = 0;
   size_t bitmap_bytes = 0;    // doc bitmaps of every segment of this context (the budget is the device's, not a segment's)
   size_t bitmap_budget = 0;   // bytes; rgpu_config.bitmap_budget_mib (0: an eighth of the device's memory)
+  size_t prepared_budget = 0; // bytes per segment; rgpu_config.prepared_budget_mib (0: no ceiling)
   // search_or_lazy_group: doc_start_fp -> the batch's run of that term. Direct-mapped and stamped with the call's number, so a
   // call neither allocates nor clears it (a collision costs a second run of the same term, nothing else)
   struct UniqSlot { int64_t fp; uint32_t stamp; int32_t idx; };
@@ -171,7 +177,15 @@ struct rgpu_ctx {
   Scratch scr[N_SCRATCH];
   Scratch* S = &scr[0];
   int scr_next = 0;
-  DevVec<ScoredPosting> d_runs;  // OR: per-clause {doc, score} runs (one instance: OR groups end with a stream sync)
+  DevVec<ScoredPosting> d_runs;  // scratch of calls that end with a stream sync (bitmap builds; OR groups whose runs exceed RUNS_PER_SLOT_MAX)
+  // The fixed-point disjunction kernels hand flags back (a top-k that reaches below the fixed-point floor, a window that did not
+  // fit): the host then runs those queries again through another kernel. Looking at the flags needs the launch set to have
+  // finished — a stream sync at the end of every OR group (rounds 2-4), with the host's 0.5 ms of partitioning for the next batch
+  // waiting behind it. Instead the look can wait (`defer_or`): the group records an event, the flags travel to pinned memory,
+  // and what is left to do is a closure that runs when the NEXT call needs the slot or the results are about to be consumed
+  // (rgpu_synchronize, the collective of a sharded batch, rgpu_search_batch's copy to the host).
+  std::vector<std::function<int32_t()>> pending_or;
+  bool defer_or = false;  // set by the entry point for the duration of one call
   DevVec<uint32_t> pos_counts;             // rgpu_decode_positions: positions per directory slot -> their exclusive prefix sums
   DevVec<unsigned long long> pos_tiles;    // ... the scan's tile sums (+ [0]: unused, [1]: the call's total)
   DevVec<int32_t> phrase_docs;             // phrase search: the conjunctions' matches (candidates), per query
@@ -209,8 +223,52 @@ struct TermInfo { uint32_t dir_base; int32_t nblocks; int32_t df; uint64_t pn_ba
 // a term's doc bitmap (kernels/doc_bitmap.hpp): one allocation [words | ranks | ovf | stats | freqs]
 struct BitmapInfo { uint2* words; uint32_t* ranks; uint8_t* freqs; uint32_t* ovf; uint32_t* nib; uint32_t* memb; int32_t n_ovf; int32_t max_freq; int32_t df; int32_t sim_table; bool usable; };
 
-// doc_start_fp -> TermInfo of the prepared terms (host/flat_fp_map.hpp: two look-ups per clause per batch)
-using PreparedMap = rucene::FlatFpMap<TermInfo>;
+// doc_start_fp -> TermInfo of the prepared terms (host/flat_fp_map.hpp: two look-ups per clause per batch).
+// A bulk first touch (every term of a segment's dictionary: 152 k at 100 M docs) used to end with 152 k insertions into a table
+// that is grown and first touched right there — 4 to 8 ms of page faults and cache misses for 1.3 ms of kernels. Such a call's
+// terms arrive in file order: they are kept as the sorted array the planning loop built anyway (`bulk`), looked up by binary
+// search, and a term moves into the hash table the first time a query names it.
+struct PreparedMap {
+  rucene::FlatFpMap<TermInfo> map;
+  std::vector<std::pair<int64_t, TermInfo>> bulk;  // ascending keys
+  std::vector<uint8_t> moved;                      // bulk[i] lives in `map` now
+  size_t bulk_live = 0;
+  long bulk_at(int64_t key) const {
+    size_t lo = 0, hi = bulk.size();
+    while (lo < hi) { const size_t mid = (lo + hi) >> 1; if (bulk[mid].first < key) lo = mid + 1; else hi = mid; }
+    return (lo < bulk.size() && bulk[lo].first == key && !moved[lo]) ? (long)lo : -1;
+  }
+  const TermInfo* find(int64_t key) {
+    if (const TermInfo* p = map.find(key)) return p;
+    if (bulk_live == 0) return nullptr;
+    const long i = bulk_at(key);
+    if (i < 0) return nullptr;
+    map.put(key, bulk[(size_t)i].second);
+    moved[(size_t)i] = 1;
+    if (--bulk_live == 0) { bulk.clear(); bulk.shrink_to_fit(); moved.clear(); }
+    return map.find(key);
+  }
+  void put(int64_t key, const TermInfo& v) {
+    if (bulk_live != 0) { const long i = bulk_at(key); if (i >= 0) { moved[(size_t)i] = 1; --bulk_live; } }
+    map.put(key, v);
+  }
+  void prefetch(int64_t key) const { map.prefetch(key); }
+  void reserve_more(size_t n) { map.reserve_more(n); }
+  size_t size() const { return map.size() + bulk_live; }
+  void clear() { map.clear(); bulk.clear(); moved.clear(); bulk_live = 0; }
+  // `sorted`: ascending keys none of which is in the table. An earlier bulk that is still (partly) pending moves into the table first.
+  void adopt_sorted(std::vector<std::pair<int64_t, TermInfo>>&& sorted) {
+    if (bulk_live != 0) {
+      map.reserve_more(bulk_live);
+      for (size_t i = 0; i < bulk.size(); ++i) if (!moved[i]) map.put(bulk[i].first, bulk[i].second);
+    }
+    bulk = std::move(sorted);
+    moved.assign(bulk.size(), 0);
+    bulk_live = bulk.size();
+  }
+  void drop_bulk() { bulk.clear(); moved.clear(); bulk_live = 0; }
+  void remove_keys(const int64_t* keys, size_t n) { map.remove_keys(keys, n); }
+};
 
 struct rgpu_segment {
   rgpu_ctx* ctx = nullptr;
@@ -240,7 +298,7 @@ struct rgpu_segment {
   size_t bstore_used = 0;
   DevVec<uint8_t> pnorm;  // posting-order norms of every prepared term's FullBlocks and tail
   size_t pnorm_used = 0;
-  PreparedMap prepared;
+  mutable PreparedMap prepared;  // (a look-up may move a term from the bulk array into the table)
   rucene::FlatFpMap<BitmapInfo> bitmaps;  // doc_start_fp -> the term's doc bitmap (terms holding >= 1 doc in cfg.or_bitmaps)
   std::vector<void*> bitmap_allocs;
   size_t bitmap_bytes = 0;
@@ -291,9 +349,31 @@ static void drain_events(rgpu_ctx* c) {
   c->pending.clear();
 }
 
+// ---- launch sets whose hand-back flags are still to be looked at (rgpu_ctx::pending_or) ------------------------------------
+constexpr size_t RUNS_PER_SLOT_MAX = (size_t)1 << 28;  // ScoredPostings (2 GiB): a group with longer runs uses the context's buffer and syncs
+static int32_t settle_pending(rgpu_ctx* c) {
+  int32_t first = RGPU_OK;
+  std::string why;
+  while (!c->pending_or.empty()) {
+    std::function<int32_t()> fin = std::move(c->pending_or.front());
+    c->pending_or.erase(c->pending_or.begin());
+    const bool was = c->defer_or;
+    c->defer_or = false;  // what a settle launches (clause-order redo) finishes inside it
+    const int32_t rc = fin();
+    c->defer_or = was;
+    if (rc != RGPU_OK && first == RGPU_OK) { first = rc; why = g_last_error; }
+  }
+  if (first != RGPU_OK) return fail(first, why);
+  return RGPU_OK;
+}
+
 // ---- scratch slots -------------------------------------------------------------------------------------------------
 // take the next slot (waiting for the work that used it N_SCRATCH calls ago) ...
 static hipError_t scratch_take(rgpu_ctx* c) {
+  // a slot whose flags (pinned read-back, event) are still to be looked at: that happens before it is reused (what the look
+  // launches takes slots itself: the next slot is chosen afterwards)
+  while (c->scr[c->scr_next].settles_later)
+    if (settle_pending(c) != RGPU_OK) return hipErrorUnknown;
   Scratch* sc = &c->scr[c->scr_next];
   c->scr_next = (c->scr_next + 1) % N_SCRATCH;
   if (sc->busy) {
@@ -398,9 +478,34 @@ static int32_t prepare_terms_attempt(rgpu_segment* seg, const rgpu_term_state* c
 static int32_t prepare_norms_locked(rgpu_segment* seg, const rgpu_term_state* const* sts, size_t n);
 // -101 from the device: a term holds EF / BITSET doc blocks whose re-packed deltas need more block-store rows than its
 // file bytes suggest — plan the same call again with worst-case rows (64 per block). Nothing was committed.
+// bytes of HBM the prepared-term store of a segment holds (what rgpu_segment_get_footprint reports as directory + block store +
+// posting-order norms)
+static size_t prepared_store_bytes(const rgpu_segment* seg) {
+  const size_t per_slot = 4 + 4 + 4 + 2 + 8 + (seg->has_positions ? 8 : 0);  // dir_last, dir_off, dir_row, dir_hdr, dir_bmax (, dir_pos)
+  return seg->dir_used * per_slot + seg->bstore_used + seg->pnorm_used;
+}
+// rgpu_config.prepared_budget_mib: a store over its ceiling is dropped as a whole BEFORE the arriving batch is planned — the
+// batch then prepares what it names, like a first touch (a few hundred microseconds per thousand terms; k_prepare_blocks moves
+// ~3 TB/s). Everything enqueued earlier may still read the store: the device is drained first, so this is the one place where
+// an otherwise enqueue-only call waits — once per refill of the budget, not per batch. Doc bitmaps keep their own budget.
+static int32_t enforce_prepared_budget(rgpu_segment* seg) {
+  rgpu_ctx* c = seg->ctx;
+  if (c->prepared_budget == 0 || prepared_store_bytes(seg) <= c->prepared_budget) return RGPU_OK;
+  const int32_t rc_settle = settle_pending(c);  // (what an earlier batch still has to run again reads the store)
+  if (rc_settle != RGPU_OK) return rc_settle;
+  HIP_TRY(hipDeviceSynchronize());
+  for (auto& sc : c->scr) sc.busy = false;
+  for (auto& cs : c->ceil_slots) cs.busy = false;
+  seg->prepared.clear();
+  seg->dir_used = seg->bstore_used = seg->pnorm_used = 0;  // the arrays keep their capacity and are refilled from the start
+  c->stats[(size_t)stat_slot(c, "prepared_store_evictions")].launches += 1;  // (read by tests / callers through rgpu_kernel_stats)
+  return RGPU_OK;
+}
 static int32_t prepare_terms_locked(rgpu_segment* seg, const rgpu_term_state* const* sts, size_t n, bool with_norms = true,
                                     const DecodeSink* sink = nullptr) {
-  int32_t rc = prepare_terms_attempt(seg, sts, n, false, sink);
+  int32_t rc = enforce_prepared_budget(seg);
+  if (rc != RGPU_OK) return rc;
+  rc = prepare_terms_attempt(seg, sts, n, false, sink);
   if (rc == -101) rc = prepare_terms_attempt(seg, sts, n, true, sink);
   if (rc == -101) rc = fail(RGPU_ERR_CORRUPT_INDEX, "corrupt block framing in .doc (prepare.hpp check #12)");
   if (rc == RGPU_OK && with_norms) rc = prepare_norms_locked(seg, sts, n);
@@ -610,16 +715,22 @@ static int32_t prepare_terms_attempt(rgpu_segment* seg, const rgpu_term_state* c
   // The terms are filed as prepared WHILE the kernels run (the context's mutex is held: nobody looks before this call returns):
   // 152 k insertions into a table that is grown and first touched here — 2 to 6 ms of host time that used to follow the
   // 1.3 ms of kernels instead of hiding behind them. A failing call takes them back (remove_keys: a rebuild, the rare path).
-  seg->prepared.reserve_more(added.size());
-  for (size_t i = 0; i < added.size(); ++i) {
-    if (i + AHEAD < added.size()) seg->prepared.prefetch(added[i + AHEAD].first);
-    seg->prepared.put(added[i].first, added[i].second);
+  const bool as_bulk = ascending && added.size() >= 4096;  // file order, no repeats: the array itself is the index (PreparedMap)
+  std::vector<int64_t> added_keys;
+  if (as_bulk) {
+    seg->prepared.adopt_sorted(std::move(added));
+  } else {
+    added_keys.resize(added.size());
+    seg->prepared.reserve_more(added.size());
+    for (size_t i = 0; i < added.size(); ++i) {
+      if (i + AHEAD < added.size()) seg->prepared.prefetch(added[i + AHEAD].first);
+      seg->prepared.put(added[i].first, added[i].second);
+      added_keys[i] = added[i].first;
+    }
   }
   t_commit = hc.lap();
   auto take_back = [&]() {
-    std::vector<int64_t> keys(added.size());
-    for (size_t i = 0; i < added.size(); ++i) keys[i] = added[i].first;
-    seg->prepared.remove_keys(keys.data(), keys.size());
+    if (as_bulk) seg->prepared.drop_bulk(); else seg->prepared.remove_keys(added_keys.data(), added_keys.size());
     if (sink) sink->fused->assign(n, 0);
   };
   hipError_t e_sync = e_copy == hipSuccess ? hipStreamSynchronize(c->stream) : e_copy;
@@ -741,7 +852,7 @@ extern "C" int32_t rgpu_init(int32_t device_ordinal, const rgpu_config* cfg, rgp
   if (!out_ctx) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "out_ctx is null");
   *out_ctx = nullptr;
   if (cfg && cfg->abi_version != RGPU_ABI_VERSION) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "rgpu_config.abi_version mismatch");
-  if (cfg) for (int32_t r : cfg->reserved) if (r != 0) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "rgpu_config.reserved must be zero");
+  if (cfg && (cfg->prepared_budget_mib < 0 || cfg->or_deferred < 0 || cfg->or_deferred > 1)) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "rgpu_config.prepared_budget_mib must be >= 0, or_deferred 0 or 1");
   if (cfg && cfg->bitmap_budget_mib < 0) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "rgpu_config.bitmap_budget_mib must be >= 0 (or_bitmaps / and_bitmaps = -1 turn bitmaps off)");
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
@@ -768,6 +879,7 @@ extern "C" int32_t rgpu_init(int32_t device_ordinal, const rgpu_config* cfg, rgp
   // doc bitmaps are an optional accelerator: they get a byte budget (default: an eighth of the device's memory — 36 GB of an
   // MI355X's 288), and a term past it stays a walked clause (ensure_bitmaps_locked)
   c->bitmap_budget = c->cfg.bitmap_budget_mib > 0 ? (size_t)c->cfg.bitmap_budget_mib << 20 : (size_t)prop.totalGlobalMem / 8;
+  c->prepared_budget = c->cfg.prepared_budget_mib > 0 ? (size_t)c->cfg.prepared_budget_mib << 20 : 0;
   std::snprintf(c->name, sizeof c->name, "%s (%s)", prop.name, prop.gcnArchName);
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipMalloc(&c->d_err, 4 * sizeof(int)) != hipSuccess) {
     delete c;
@@ -780,6 +892,7 @@ extern "C" int32_t rgpu_init(int32_t device_ordinal, const rgpu_config* cfg, rgp
 extern "C" void rgpu_shutdown(rgpu_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
+  c->pending_or.clear();  // (nobody will read those batches any more)
   (void)hipStreamSynchronize(c->stream);
   drain_events(c);
   for (auto e : c->free_events) (void)hipEventDestroy(e);
@@ -800,6 +913,8 @@ extern "C" int32_t rgpu_synchronize(rgpu_ctx* c) {
   if (!c) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "ctx is null");
   std::lock_guard<std::mutex> g(c->mu);
   HIP_TRY(hipSetDevice(c->device));
+  const int32_t rc = settle_pending(c);  // (rgpu_config.or_deferred: flags of OR batches nobody has looked at yet; waits for those batches)
+  if (rc != RGPU_OK) return rc;
   HIP_TRY(hipStreamSynchronize(c->stream));
   return RGPU_OK;
 }
@@ -979,6 +1094,7 @@ extern "C" int32_t rgpu_segment_upload_field(rgpu_ctx* c, const uint8_t* doc_fil
 extern "C" void rgpu_segment_free(rgpu_segment* s) {
   if (!s) return;
   (void)hipSetDevice(s->ctx->device);
+  { std::lock_guard<std::mutex> g(s->ctx->mu); (void)settle_pending(s->ctx); }  // (closures of deferred OR batches name the segment)
   (void)hipStreamSynchronize(s->ctx->stream);
   if (s->d_doc) (void)hipFree(s->d_doc);
   if (s->d_norms) (void)hipFree(s->d_norms);
@@ -1018,6 +1134,7 @@ extern "C" int32_t rgpu_segment_release_prepared_terms(rgpu_segment* seg) {
   rgpu_ctx* c = seg->ctx;
   std::lock_guard<std::mutex> g(c->mu);
   HIP_TRY(hipSetDevice(c->device));
+  (void)settle_pending(c);
   HIP_TRY(hipDeviceSynchronize());  // batches in flight on any stream still read the directories
   for (auto& sc : c->scr) sc.busy = false;
   for (auto& cs : c->ceil_slots) cs.busy = false;
@@ -1410,7 +1527,11 @@ static int32_t search_or_group(rgpu_segment* seg, Group& G, int32_t k, HitOut* h
   std::memcpy(c->S->h_stage.p + o_mp, merge_prefix.data(), (size_t)(nq + 1) * 8);
   std::memcpy(c->S->h_stage.p + o_m, G.qmap.data(), (size_t)nq * 4);
   HIP_TRY(hipMemcpyAsync(c->S->d_stage.p, c->S->h_stage.p, st.used, hipMemcpyHostToDevice, stream));
-  HIP_TRY(c->d_runs.reserve((size_t)postings + 64, 0, stream));
+  // the scored runs: the slot's own buffer (the group then only marks its slot, like a TERM / AND group), or — a group whose runs
+  // would pin gigabytes in every slot — the context's, with a stream sync at the end
+  const bool own_runs = (size_t)postings + 64 <= RUNS_PER_SLOT_MAX;
+  DevVec<ScoredPosting>& runs_buf = own_runs ? c->S->d_runs : c->d_runs;
+  HIP_TRY(runs_buf.reserve((size_t)postings + 64, 0, stream));
   HIP_TRY(c->S->d_tau.reserve((size_t)nq, 0, stream));
   HIP_TRY(hipMemsetAsync(c->S->d_tau.p, 0, (size_t)nq * 8, stream));
   HIP_TRY(c->S->d_partial_keys.reserve((size_t)items2 * (size_t)k, 0, stream));
@@ -1426,9 +1547,9 @@ static int32_t search_or_group(rgpu_segment* seg, Group& G, int32_t k, HitOut* h
     TimedLaunch tl(c, stream, "k_score_terms", G.postings);
     const unsigned grid = wg_count((items1 + WG_WAVES - 1) / WG_WAVES);
     if (legacy)
-      RGPU_LAUNCH(k_score_terms<true>, dim3(grid), dim3(WG_THREADS), 0, stream, sv, dt, dip, drp, nt, items1, blocks_per_item, c->d_runs.p);
+      RGPU_LAUNCH(k_score_terms<true>, dim3(grid), dim3(WG_THREADS), 0, stream, sv, dt, dip, drp, nt, items1, blocks_per_item, runs_buf.p);
     else
-      RGPU_LAUNCH(k_score_terms<false>, dim3(grid), dim3(WG_THREADS), 0, stream, sv, dt, dip, drp, nt, items1, blocks_per_item, c->d_runs.p);
+      RGPU_LAUNCH(k_score_terms<false>, dim3(grid), dim3(WG_THREADS), 0, stream, sv, dt, dip, drp, nt, items1, blocks_per_item, runs_buf.p);
   }
   {
     TimedLaunch tl(c, stream, "k_or_windows", G.postings);
@@ -1439,7 +1560,7 @@ static int32_t search_or_group(rgpu_segment* seg, Group& G, int32_t k, HitOut* h
     auto go = [&](auto kern) -> hipError_t {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
-      RGPU_LAUNCH(kern, dim3(grid), dim3(OR_THREADS), lds, stream, sv, dq, dt, drp, c->d_runs.p, nq, wpq, wpi, ipq, W, (int)k,
+      RGPU_LAUNCH(kern, dim3(grid), dim3(OR_THREADS), lds, stream, sv, dq, dt, drp, runs_buf.p, nq, wpq, wpi, ipq, W, (int)k,
                          c->S->d_partial_keys.p, c->S->d_partial_counts.p, c->S->d_tau.p, c->pass.ceil_in, dm);
       return hipSuccess;
     };
@@ -1455,7 +1576,8 @@ static int32_t search_or_group(rgpu_segment* seg, Group& G, int32_t k, HitOut* h
   if (wide) launch_merge<true>(c, stream, nq, k, dmp, seg->doc_base, hits_dev, totals_dev, 0, nullptr, nullptr, dm);
   else launch_merge<false>(c, stream, nq, k, dmp, seg->doc_base, hits_dev, totals_dev, 0, nullptr, nullptr, dm);
   HIP_TRY(launch_status());
-  HIP_TRY(hipStreamSynchronize(stream));  // staging / scratch buffers are reused by the next group
+  if (own_runs) HIP_TRY(scratch_mark(c, stream));  // no stream sync: the slot is waited for when it is taken again
+  else HIP_TRY(hipStreamSynchronize(stream));      // the context's run buffer is the next group's too
   return RGPU_OK;
 }
 
@@ -1517,22 +1639,6 @@ static int32_t search_or_lazy_group(rgpu_segment* seg, Group& G, int32_t k, HitO
     G.queries.swap(qs);
     G.qmap.swap(qm);
   }
-  Group rest;  // queries k_or_lazy hands back
-  rest.op = RGPU_OP_OR;
-  rest.or_wide = true;
-  rest.no_lazy = true;
-  auto hand_over = [&](Group& to, int q) {
-    const DevQuery& wq = G.queries[(size_t)q];
-    DevQuery dq = wq;
-    dq.first_term = (int32_t)to.terms.size();
-    for (int i = 0; i < wq.n_terms; ++i) {
-      to.terms.push_back(G.terms[(size_t)(wq.first_term + i)]);
-      if (!G.term_bytes.empty()) to.term_bytes.push_back(G.term_bytes[(size_t)(wq.first_term + i)]);
-      to.postings += G.terms[(size_t)(wq.first_term + i)].df;
-    }
-    to.qmap.push_back(G.qmap[(size_t)q]);
-    to.queries.push_back(dq);
-  };
   std::vector<LazyQuery> lq;
   std::vector<LazyRun> run_of;       // per walked clause instance
   std::vector<DevTerm> uniq;         // the distinct (term, weight, similarity) among them: one run each
@@ -1720,9 +1826,11 @@ static int32_t search_or_lazy_group(rgpu_segment* seg, Group& G, int32_t k, HitO
     for (int i = 0; i < 64; ++i) reinterpret_cast<ScoredPosting*>(c->S->h_stage.p + o_sn)[i] = ScoredPosting{0x7fffffff, 0.0f};
     HOST_STAMP(h2);
     HIP_TRY(hipMemcpyAsync(c->S->d_stage.p, c->S->h_stage.p, st.used, hipMemcpyHostToDevice, stream));
-    HIP_TRY(c->d_runs.reserve((size_t)run_slots + 128, 0, stream));
+    const bool own_runs = (size_t)run_slots + 128 <= RUNS_PER_SLOT_MAX;
+    DevVec<ScoredPosting>& runs_buf = own_runs ? c->S->d_runs : c->d_runs;
+    HIP_TRY(runs_buf.reserve((size_t)run_slots + 128, 0, stream));
     // 64 sentinel entries behind the runs: what a clause slot without a clause looks at
-    HIP_TRY(hipMemcpyAsync(c->d_runs.p + run_slots, c->S->d_stage.p + o_sn, 64 * sizeof(ScoredPosting), hipMemcpyDeviceToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(runs_buf.p + run_slots, c->S->d_stage.p + o_sn, 64 * sizeof(ScoredPosting), hipMemcpyDeviceToDevice, stream));
     // per query: the shared threshold slot, then the histogram of finished totals (LZ_HIST u32 counters)
     HIP_TRY(c->S->d_tau.reserve((size_t)nq * (1 + LZ_HIST / 2), 0, stream));
     HIP_TRY(hipMemsetAsync(c->S->d_tau.p, 0, (size_t)nq * (1 + LZ_HIST / 2) * 8, stream));
@@ -1747,9 +1855,9 @@ static int32_t search_or_lazy_group(rgpu_segment* seg, Group& G, int32_t k, HitO
       const int64_t* dip = reinterpret_cast<const int64_t*>(c->S->d_stage.p + o_ip);
       const int64_t* drp = reinterpret_cast<const int64_t*>(c->S->d_stage.p + o_rp);
       if (legacy)
-        RGPU_LAUNCH(k_score_terms<true>, dim3(grid), dim3(WG_THREADS), 0, stream, sv, dt, dip, drp, nu, items1, blocks_per_item, c->d_runs.p);
+        RGPU_LAUNCH(k_score_terms<true>, dim3(grid), dim3(WG_THREADS), 0, stream, sv, dt, dip, drp, nu, items1, blocks_per_item, runs_buf.p);
       else
-        RGPU_LAUNCH(k_score_terms<false>, dim3(grid), dim3(WG_THREADS), 0, stream, sv, dt, dip, drp, nu, items1, blocks_per_item, c->d_runs.p);
+        RGPU_LAUNCH(k_score_terms<false>, dim3(grid), dim3(WG_THREADS), 0, stream, sv, dt, dip, drp, nu, items1, blocks_per_item, runs_buf.p);
     }
     {
       TimedLaunch tl(c, stream, "k_or_lazy", all_postings);
@@ -1759,7 +1867,7 @@ static int32_t search_or_lazy_group(rgpu_segment* seg, Group& G, int32_t k, HitO
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         RGPU_LAUNCH(kern, dim3(grid), dim3(LZ_THREADS), lds, stream, sv, reinterpret_cast<const LazyQuery*>(c->S->d_stage.p + o_q),
-                           reinterpret_cast<const LazyRun*>(c->S->d_stage.p + o_r), c->d_runs.p, reinterpret_cast<const LazyClause*>(c->S->d_stage.p + o_l),
+                           reinterpret_cast<const LazyRun*>(c->S->d_stage.p + o_r), runs_buf.p, reinterpret_cast<const LazyClause*>(c->S->d_stage.p + o_l),
                            (int64_t)run_slots, nq, wpq, wpi, ipq, C, (int)k, c->S->d_partial_keys.p, c->S->d_partial_counts.p, c->S->d_tau.p, dbl, dct, d_hist);
         return hipSuccess;
       };
@@ -1770,19 +1878,91 @@ static int32_t search_or_lazy_group(rgpu_segment* seg, Group& G, int32_t k, HitO
     if (wide) launch_merge<true>(c, stream, nq, k, dmp, seg->doc_base, hits_dev, totals_dev, 0, dfi, dfl, dm);
     else launch_merge<false>(c, stream, nq, k, dmp, seg->doc_base, hits_dev, totals_dev, 0, dfi, dfl, dm);
     HIP_TRY(launch_status());
-    std::vector<int32_t> low((size_t)nq), bailed((size_t)nq);
-    unsigned long long counts[2] = {0, 0};
+    // ---- the flags the launch set hands back: [counts: 2 x u64][low: nq x i32][bailed: nq x i32] into the slot's pinned buffer
+    HIP_TRY(c->S->h_back.reserve(16 + (size_t)nq * 8));
+    unsigned long long* h_counts = reinterpret_cast<unsigned long long*>(c->S->h_back.p);
+    int32_t* h_low = reinterpret_cast<int32_t*>(c->S->h_back.p + 16);
+    int32_t* h_bailed = h_low + nq;
     HOST_STAMP(h3);
-    HIP_TRY(hipMemcpyAsync(low.data(), dfl, (size_t)nq * 4, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipMemcpyAsync(bailed.data(), dbl, (size_t)nq * 4, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipMemcpyAsync(counts, dct, 16, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));  // staging / scratch buffers are reused by the next group
+    HIP_TRY(hipMemcpyAsync(h_low, dfl, (size_t)nq * 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(h_bailed, dbl, (size_t)nq * 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(h_counts, dct, 16, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(scratch_mark(c, stream));
+    Scratch* const slot = c->S;
+    // What is left once the launch set has finished: queries whose window did not fit go through k_or_wide (their rows are simply
+    // written again), queries whose top-k reaches below the fixed-point floor through the clause-order kernels, as after k_or_wide.
+    // Everything it needs is held by value: it may run long after this function returned.
+    auto shared_g = std::make_shared<Group>(std::move(G));
+    auto shared_lq_of = std::make_shared<std::vector<int32_t>>(std::move(lq_of));
+    auto finish = [c, seg, slot, shared_g, shared_lq_of, nq, k, hits_dev, totals_dev, stream, h_counts, h_low, h_bailed, own_runs]() -> int32_t {
+      slot->settles_later = false;
+      HIP_TRY(hipSetDevice(c->device));
+      if (own_runs) HIP_TRY(hipEventSynchronize(slot->done)); else HIP_TRY(hipStreamSynchronize(stream));
+      const Group& G0 = *shared_g;
+      const std::vector<int32_t>& lq0 = *shared_lq_of;
+      c->or_lazy_evals = (int64_t)h_counts[0];
+      c->or_lazy_only = (int64_t)h_counts[1];
+      c->stats[(size_t)stat_slot(c, "or_lazy_evaluated_docs")].launches += (int64_t)h_counts[0];
+      c->stats[(size_t)stat_slot(c, "or_lazy_only_docs")].launches += (int64_t)h_counts[1];
+      Group redo, rest;
+      redo.op = RGPU_OP_OR;
+      rest.op = RGPU_OP_OR;
+      rest.or_wide = true;
+      rest.no_lazy = true;
+      rest.after_lazy = true;
+      int64_t n_bailed = 0;
+      for (int q = 0; q < nq; ++q) {
+        const DevQuery& wq = G0.queries[(size_t)lq0[(size_t)q]];
+        if (h_bailed[q]) {
+          DevQuery dq = wq;
+          dq.first_term = (int32_t)rest.terms.size();
+          for (int i = 0; i < wq.n_terms; ++i) {
+            rest.terms.push_back(G0.terms[(size_t)(wq.first_term + i)]);
+            if (!G0.term_bytes.empty()) rest.term_bytes.push_back(G0.term_bytes[(size_t)(wq.first_term + i)]);
+            rest.postings += G0.terms[(size_t)(wq.first_term + i)].df;
+          }
+          rest.qmap.push_back(G0.qmap[(size_t)lq0[(size_t)q]]);
+          rest.queries.push_back(dq);
+          ++n_bailed;
+          continue;
+        }
+        if (!h_low[q]) continue;
+        DevQuery dq2;
+        dq2.op = RGPU_OP_OR;
+        dq2.n_terms = wq.n_terms;
+        dq2.first_term = (int32_t)redo.terms.size();
+        dq2.pad = 0;
+        for (int i = 0; i < wq.n_terms; ++i) {
+          DevTerm t = G0.terms[(size_t)(wq.first_term + i)];
+          t.flags &= ~TERM_FLAG_OR_DENSE;
+          redo.terms.push_back(t);
+          redo.postings += t.df;
+        }
+        redo.qmap.push_back(G0.qmap[(size_t)lq0[(size_t)q]]);
+        redo.queries.push_back(dq2);
+      }
+      if (n_bailed) c->stats[(size_t)stat_slot(c, "or_lazy_bail_queries")].launches += n_bailed;
+      int32_t rc = RGPU_OK;
+      if (!redo.queries.empty()) {
+        c->or_wide_redone += (int64_t)redo.queries.size();
+        c->stats[(size_t)stat_slot(c, "or_wide_redo_queries")].launches += (int64_t)redo.queries.size();
+        rc = search_or_group(seg, redo, k, hits_dev, totals_dev, stream);
+      }
+      if (rc == RGPU_OK && !rest.queries.empty()) rc = search_or_wide_group(seg, rest, k, hits_dev, totals_dev, stream);
+      if (rc == RGPU_OK && (!redo.queries.empty() || !rest.queries.empty())) HIP_TRY(hipStreamSynchronize(stream));  // (the rare path: the rows are final on return)
+      return rc;
+    };
+    if (c->defer_or && own_runs) {
+      slot->settles_later = true;
+      c->pending_or.push_back(std::move(finish));
+      return RGPU_OK;
+    }
 #ifdef RGPU_LZ_TIME
     {
+      HIP_TRY(hipStreamSynchronize(stream));
       HOST_STAMP(h4);
       std::fprintf(stderr, "[lz host] partition %lld us, plan + stage %lld us, enqueue %lld us, copies + sync %lld us\n", HOST_US(h0, h1), HOST_US(h1, h2), HOST_US(h2, h3), HOST_US(h3, h4));
-    }
-    {  // developer output: how the evaluated docs spread over the queries
+      // developer output: how the evaluated docs spread over the queries
       std::vector<unsigned long long> pq((size_t)nq * 2);
       HIP_TRY(hipMemcpy(pq.data(), dct + 2, (size_t)nq * 16, hipMemcpyDeviceToHost));
       std::vector<unsigned long long> ev((size_t)nq), lo((size_t)nq);
@@ -1792,47 +1972,12 @@ static int32_t search_or_lazy_group(rgpu_segment* seg, Group& G, int32_t k, HitO
       auto at = [&](const std::vector<unsigned long long>& v, double f) { return v[(size_t)std::min<double>(v.size() - 1, f * v.size())]; };
       unsigned long long top5 = 0, top5lo = 0;
       for (size_t i = (size_t)(0.95 * nq); i < (size_t)nq; ++i) { top5 += ev[i]; top5lo += lo[i]; }
-      std::fprintf(stderr, "[lz] per query evaluated docs: p50 %llu p90 %llu p95 %llu p99 %llu max %llu; the top 5%% hold %llu of %llu | lazy-only: p50 %llu p90 %llu p99 %llu max %llu, top 5%% %llu of %llu\n",
-                   at(ev, .5), at(ev, .9), at(ev, .95), at(ev, .99), ev.back(), top5, counts[0], at(lo, .5), at(lo, .9), at(lo, .99), lo.back(), top5lo, counts[1]);
+      std::fprintf(stderr, "[lz] per query evaluated docs: p50 %llu p90 %llu p95 %llu p99 %llu max %llu; the top 5%% hold %llu | lazy-only: p50 %llu p90 %llu p99 %llu max %llu, top 5%% %llu\n",
+                   at(ev, .5), at(ev, .9), at(ev, .95), at(ev, .99), ev.back(), top5, at(lo, .5), at(lo, .9), at(lo, .99), lo.back(), top5lo);
     }
 #endif
-    c->or_lazy_evals = (int64_t)counts[0];
-    c->or_lazy_only = (int64_t)counts[1];
-    c->stats[(size_t)stat_slot(c, "or_lazy_evaluated_docs")].launches += (int64_t)counts[0];
-    c->stats[(size_t)stat_slot(c, "or_lazy_only_docs")].launches += (int64_t)counts[1];
-    // a window that did not fit: the query goes through k_or_wide with the rest (its row is simply written again); a top-k
-    // that reaches below the fixed-point floor: the clause-order kernel, as after k_or_wide
-    Group redo;
-    redo.op = RGPU_OP_OR;
-    int64_t n_bailed = 0;
-    for (int q = 0; q < nq; ++q) {
-      if (bailed[(size_t)q]) { hand_over(rest, lq_of[(size_t)q]); ++n_bailed; continue; }
-      if (!low[(size_t)q]) continue;
-      const DevQuery& wq = G.queries[(size_t)lq_of[(size_t)q]];
-      DevQuery dq2;
-      dq2.op = RGPU_OP_OR;
-      dq2.n_terms = wq.n_terms;
-      dq2.first_term = (int32_t)redo.terms.size();
-      dq2.pad = 0;
-      for (int i = 0; i < wq.n_terms; ++i) {
-        DevTerm t = G.terms[(size_t)(wq.first_term + i)];
-        t.flags &= ~TERM_FLAG_OR_DENSE;
-        redo.terms.push_back(t);
-        redo.postings += t.df;
-      }
-      redo.qmap.push_back(G.qmap[(size_t)lq_of[(size_t)q]]);
-      redo.queries.push_back(dq2);
-    }
-    if (n_bailed) c->stats[(size_t)stat_slot(c, "or_lazy_bail_queries")].launches += n_bailed;
-    if (!redo.queries.empty()) {
-      c->or_wide_redone += (int64_t)redo.queries.size();
-      c->stats[(size_t)stat_slot(c, "or_wide_redo_queries")].launches += (int64_t)redo.queries.size();
-      int32_t rc = search_or_group(seg, redo, k, hits_dev, totals_dev, stream);
-      if (rc != RGPU_OK) return rc;
-    }
+    return finish();
   }
-  rest.after_lazy = nq > 0;
-  if (!rest.queries.empty()) return search_or_wide_group(seg, rest, k, hits_dev, totals_dev, stream);
   return RGPU_OK;
 }
 
@@ -1961,39 +2106,55 @@ static int32_t search_or_wide_group(rgpu_segment* seg, Group& G, int32_t k, HitO
   if (wide) launch_merge<true>(c, stream, nq, k, dmp, seg->doc_base, hits_dev, totals_dev, 0, dfi, dfl, dm);
   else launch_merge<false>(c, stream, nq, k, dmp, seg->doc_base, hits_dev, totals_dev, 0, dfi, dfl, dm);
   HIP_TRY(launch_status());
-  std::vector<int32_t> low((size_t)nq);
-  HIP_TRY(hipMemcpyAsync(low.data(), dfl, (size_t)nq * 4, hipMemcpyDeviceToHost, stream));
-  HIP_TRY(hipStreamSynchronize(stream));  // staging / scratch buffers are reused by the next group
+  HIP_TRY(c->S->h_back.reserve((size_t)nq * 4));
+  int32_t* h_low = reinterpret_cast<int32_t*>(c->S->h_back.p);
+  HIP_TRY(hipMemcpyAsync(h_low, dfl, (size_t)nq * 4, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(scratch_mark(c, stream));
+  Scratch* const slot = c->S;
   // queries whose top-k reaches below the fixed-point floor: once more, summed in f32 in clause order (their rows are
-  // simply written again)
-  Group redo;
-  redo.op = RGPU_OP_OR;
-  for (int q = 0; q < nq; ++q) {
-    if (!low[(size_t)q]) continue;
-    // a fresh DevQuery (a wide query has no MUST_NOT clauses and min_should_match <= 1: op OR, clause count, nothing else —
-    // the wide kernel's table mask and fixed-point exponent must not leak into the clause-order kernel's fields)
-    const DevQuery& wq = G.queries[(size_t)q];
-    DevQuery dq2;
-    dq2.op = RGPU_OP_OR;
-    dq2.n_terms = wq.n_terms;
-    dq2.first_term = (int32_t)redo.terms.size();
-    dq2.pad = 0;
-    const int first = wq.first_term;
-    for (int i = 0; i < dq2.n_terms; ++i) {
-      DevTerm t = G.terms[(size_t)(first + i)];
-      t.flags &= ~TERM_FLAG_OR_DENSE;
-      redo.terms.push_back(t);
-      redo.postings += t.df;
+  // simply written again) — once the launch set has finished: now, or when its flags are looked at (rgpu_ctx::pending_or)
+  auto shared_g = std::make_shared<Group>(std::move(G));
+  auto finish = [c, seg, slot, shared_g, nq, k, hits_dev, totals_dev, stream, h_low]() -> int32_t {
+    slot->settles_later = false;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventSynchronize(slot->done));
+    const Group& G0 = *shared_g;
+    Group redo;
+    redo.op = RGPU_OP_OR;
+    for (int q = 0; q < nq; ++q) {
+      if (!h_low[q]) continue;
+      // a fresh DevQuery (a wide query has no MUST_NOT clauses and min_should_match <= 1: op OR, clause count, nothing else —
+      // the wide kernel's table mask and fixed-point exponent must not leak into the clause-order kernel's fields)
+      const DevQuery& wq = G0.queries[(size_t)q];
+      DevQuery dq2;
+      dq2.op = RGPU_OP_OR;
+      dq2.n_terms = wq.n_terms;
+      dq2.first_term = (int32_t)redo.terms.size();
+      dq2.pad = 0;
+      const int first = wq.first_term;
+      for (int i = 0; i < dq2.n_terms; ++i) {
+        DevTerm t = G0.terms[(size_t)(first + i)];
+        t.flags &= ~TERM_FLAG_OR_DENSE;
+        redo.terms.push_back(t);
+        redo.postings += t.df;
+      }
+      redo.qmap.push_back(G0.qmap[(size_t)q]);
+      redo.queries.push_back(dq2);
     }
-    redo.qmap.push_back(G.qmap[(size_t)q]);
-    redo.queries.push_back(dq2);
-  }
-  if (!redo.queries.empty()) {
+    if (redo.queries.empty()) return RGPU_OK;
     c->or_wide_redone += (int64_t)redo.queries.size();
     c->stats[(size_t)stat_slot(c, "or_wide_redo_queries")].launches += (int64_t)redo.queries.size();  // read by tests through rgpu_kernel_stats
-    return search_or_group(seg, redo, k, hits_dev, totals_dev, stream);
+    const int32_t rc = search_or_group(seg, redo, k, hits_dev, totals_dev, stream);
+    if (rc != RGPU_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(stream));  // (the rare path: the rows are final on return)
+    return RGPU_OK;
+  };
+  if (c->defer_or) {
+    slot->settles_later = true;
+    c->pending_or.push_back(std::move(finish));
+    return RGPU_OK;
   }
-  return RGPU_OK;
+  return finish();
 }
 
 // Lead blocks per work item of k_search_and when the caller leaves rgpu_config.and_blocks_per_item at 0: about 32 k items per
@@ -2384,11 +2545,11 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
       const unsigned grid = wg_count(and_grid((items + WG_WAVES - 1) / WG_WAVES, xcd_chunk));
       const int64_t* d_sp = nullptr;
       void* d_seq = nullptr;
-      if (G.req_opt) {  // records instead of a collector (the buffer is the context's run scratch: this group ends with a stream sync)
+      if (G.req_opt) {  // records instead of a collector (in the slot's own run buffer: the group only marks its slot)
         static_assert(sizeof(SeqRec) == 2 * sizeof(ScoredPosting), "SeqRec records are laid over the run scratch");
-        HIP_TRY(c->d_runs.reserve((size_t)seq_prefix[(size_t)nq] * 2 + 64, 0, stream));
+        HIP_TRY(c->S->d_runs.reserve((size_t)seq_prefix[(size_t)nq] * 2 + 64, 0, stream));  // (a group's records stay under 1 GiB: req_opt_records)
         d_sp = reinterpret_cast<const int64_t*>(c->S->d_stage.p + o_sp);
-        d_seq = c->d_runs.p;
+        d_seq = c->S->d_runs.p;
       }
       auto go = [&](auto kern) {
         RGPU_LAUNCH(kern, dim3(grid), dim3(WG_THREADS), 0, stream, sv, dq, dt, dp, nq, items, blocks_per_item, (int)k,
@@ -2436,15 +2597,14 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
     if (G.req_opt) {  // the scan is the collector: rows written in place
       TimedLaunch tl(c, stream, "k_req_opt_scan", G.postings);
       const unsigned grid = wg_count((nq + WG_WAVES - 1) / WG_WAVES);
-      const SeqRec* d_seq = reinterpret_cast<const SeqRec*>(c->d_runs.p);
+      const SeqRec* d_seq = reinterpret_cast<const SeqRec*>(c->S->d_runs.p);
       const int64_t* d_sp = reinterpret_cast<const int64_t*>(c->S->d_stage.p + o_sp);
       if (wide) RGPU_LAUNCH(k_req_opt_scan<true>, dim3(grid), dim3(WG_THREADS), 0, stream, d_seq, d_sp, nq, (int)k, seg->doc_base, dm, hits_dev, totals_dev,
                                    c->pass.stride, c->pass.col0, c->pass.ceil_in, c->pass.ceil_out);
       else RGPU_LAUNCH(k_req_opt_scan<false>, dim3(grid), dim3(WG_THREADS), 0, stream, d_seq, d_sp, nq, (int)k, seg->doc_base, dm, hits_dev, totals_dev,
                               c->pass.stride, c->pass.col0, c->pass.ceil_in, c->pass.ceil_out);
       HIP_TRY(launch_status());
-      HIP_TRY(hipStreamSynchronize(stream));  // the record buffer is shared scratch
-      HIP_TRY(scratch_mark(c, stream));
+      HIP_TRY(scratch_mark(c, stream));  // no stream sync: the records live in the slot
       continue;
     }
     // the group's rows go straight to the caller's (qmap): no scatter pass
@@ -2465,8 +2625,13 @@ extern "C" int32_t rgpu_search_batch_device(rgpu_segment* seg, const rgpu_query*
   HIP_TRY(hipSetDevice(seg->ctx->device));
   hipStream_t s = hip_stream ? (hipStream_t)hip_stream : seg->ctx->stream;
   // enqueue only: TERM / AND batches return without waiting for the GPU (the caller synchronizes the stream, or
-  // calls rgpu_synchronize for the context's own, before it reads the outputs)
-  return search_impl(seg, queries, n_queries, terms, n_terms_total, k, (HitOut*)hits_dev, (int64_t*)totals_dev, s);
+  // calls rgpu_synchronize for the context's own, before it reads the outputs); >= 10-clause disjunctions too with
+  // rgpu_config.or_deferred (the caller then calls rgpu_synchronize before it reads them)
+  rgpu_ctx* c = seg->ctx;
+  c->defer_or = c->cfg.or_deferred != 0;
+  const int32_t rc = search_impl(seg, queries, n_queries, terms, n_terms_total, k, (HitOut*)hits_dev, (int64_t*)totals_dev, s);
+  c->defer_or = false;
+  return rc;
 }
 
 extern "C" int32_t rgpu_search_batch(rgpu_segment* seg, const rgpu_query* queries, int32_t n_queries, const rgpu_query_term* terms,
@@ -3235,10 +3400,14 @@ __global__ void k_set_i64(int64_t* p, int64_t v) { *p = v; }
 // is returned AND left in the record's status word; on failure the record holds empty rows.
 // `status_zero` (in / out, may be null): the record's status word is known to hold RGPU_OK already — a successful search then
 // leaves it alone (one launch less per batch on the serving path); a failure writes it and clears the flag.
+// `defer`: >= 10-clause disjunctions leave their hand-back flags for settle_pending (the caller runs it before the record is
+// read by anybody: before the collective) — the one-process form enqueues every shard's search before it waits for any.
 static int32_t search_into_record(rgpu_segment* seg, const rgpu_query* queries, int32_t n_queries, const rgpu_query_term* terms,
-                                  int32_t n_terms_total, int32_t k, uint8_t* record, hipStream_t s, bool* status_zero = nullptr) {
+                                  int32_t n_terms_total, int32_t k, uint8_t* record, hipStream_t s, bool* status_zero = nullptr, bool defer = false) {
   const size_t hits_bytes = record_hits_bytes(n_queries, k);
+  seg->ctx->defer_or = defer;
   int32_t rc = search_impl(seg, queries, n_queries, terms, n_terms_total, k, (HitOut*)record, (int64_t*)(record + hits_bytes), s);
+  seg->ctx->defer_or = false;
   std::string why = rc == RGPU_OK ? std::string() : g_last_error;
   // No early return below: the status word is written whatever else fails (a peer that merged a record without one would
   // take stale rows for this shard's answer), and the first error is the one reported.
@@ -3330,11 +3499,26 @@ static int32_t sharded_reserve(rgpu_comm* comm, int32_t n_queries, int32_t k, hi
 // phase 1: from here on this rank WILL enqueue the collective, whatever its local search does (search_into_record leaves the
 // status in the record)
 static void sharded_local(rgpu_comm* comm, rgpu_segment* seg, const rgpu_query* queries, int32_t n_queries, const rgpu_query_term* terms,
-                          int32_t n_terms_total, int32_t k, hipStream_t s, ShardedCall* call) {
+                          int32_t n_terms_total, int32_t k, hipStream_t s, ShardedCall* call, bool defer = false) {
   comm->next = (comm->next + 1) % N_COMM_SLOTS;
   call->local_rc = search_into_record(seg, queries, n_queries, terms, n_terms_total, k, call->sl->recv.p + (size_t)comm->rank * call->record, s,
-                                      &call->sl->status_zero);
+                                      &call->sl->status_zero, defer);
   if (call->local_rc != RGPU_OK) call->local_why = g_last_error;
+}
+// phase 1b (after a deferred sharded_local): whatever the shard's disjunctions still have to run again runs now, before the
+// record is gathered; a failure becomes the shard's status like a failure of the search itself
+static void sharded_settle(rgpu_comm* comm, int32_t n_queries, int32_t k, hipStream_t s, ShardedCall* call) {
+  const int32_t rc = settle_pending(comm->ctx);
+  if (rc == RGPU_OK || call->local_rc != RGPU_OK) return;
+  call->local_rc = rc;
+  call->local_why = g_last_error;
+  uint8_t* record = call->sl->recv.p + (size_t)comm->rank * call->record;
+  const size_t hits_bytes = record_hits_bytes(n_queries, k);
+  call->sl->status_zero = false;
+  (void)hipMemsetAsync(record + hits_bytes, 0, (size_t)n_queries * 8, s);
+  RGPU_LAUNCH(k_init_hits, dim3(wg_count(((size_t)n_queries * k + 255) / 256)), dim3(256), 0, s, (HitOut*)record, (int64_t)n_queries, (int)k, (int)k, 0);
+  RGPU_LAUNCH(k_set_i64, dim3(1), dim3(1), 0, s, (int64_t*)(record + hits_bytes + (size_t)n_queries * 8), (int64_t)rc);
+  (void)launch_status();
 }
 static int32_t sharded_gather(rgpu_comm* comm, hipStream_t s, const ShardedCall& call) {
   // A communicator of one rank has nothing to gather: its record is already where the merge reads it. (Before round 5 this
@@ -3424,7 +3608,15 @@ extern "C" int32_t rgpu_search_batch_sharded_all(rgpu_comm* const* comms, rgpu_s
       calls[(size_t)r].local_why = "hipSetDevice";
       continue;
     }
-    sharded_local(comms[r], segs[r], queries, n_queries, terms_per_rank[r], n_terms_total, k, ss[(size_t)r], &calls[(size_t)r]);
+    sharded_local(comms[r], segs[r], queries, n_queries, terms_per_rank[r], n_terms_total, k, ss[(size_t)r], &calls[(size_t)r], true);
+  }
+  // (round 5: every shard's kernels are enqueued by now — disjunctions included, whose groups used to end in a stream sync and so
+  // ran shard after shard; only here does the thread wait, shard by shard, for flags that are back by then as a rule)
+  for (int32_t r = 0; r < n; ++r) {
+    rgpu_ctx* c = comms[r]->ctx;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (hipSetDevice(c->device) != hipSuccess) continue;
+    sharded_settle(comms[r], n_queries, k, ss[(size_t)r], &calls[(size_t)r]);
   }
   {
     const ncclResult_t gs = ncclGroupStart();

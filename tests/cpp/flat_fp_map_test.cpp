@@ -4,6 +4,7 @@
 #include <cstdlib>
 #include <random>
 #include <unordered_map>
+#include <vector>
 
 #include "../../rucene_amd/csrc/host/flat_fp_map.hpp"
 
@@ -41,6 +42,24 @@ int main() {
       ++checks;
     }
     if (m.find(-1) || m.find(INT64_MIN)) return 5;
+    {  // remove_keys (a bulk insert taken back): every other key goes, the rest keep their values, the size follows
+      std::vector<int64_t> gone;
+      size_t j = 0;
+      for (const auto& kv : ref) if ((j++ & 1) == 0) gone.push_back(kv.first);
+      gone.push_back(-7);                     // a key that was never there (and an illegal one at that)
+      gone.push_back((int64_t)1 << 61);       // ... and a legal one that is absent
+      m.remove_keys(gone.data(), gone.size());
+      for (size_t g = 0; g + 2 < gone.size(); ++g) { if (m.find(gone[g])) return 7; ref.erase(gone[g]); }
+      if (m.size() != ref.size()) return 8;
+      for (const auto& kv : ref) {
+        const Info* f = m.find(kv.first);
+        if (!f || f->a != kv.second.a || f->c != kv.second.c) return 9;
+        ++checks;
+      }
+      m.put(gone[0], Info{1u, 2, 3u});        // a removed key can come back
+      if (!m.find(gone[0]) || m.size() != ref.size() + 1) return 10;
+      ref[gone[0]] = Info{1u, 2, 3u};
+    }
     m.clear();
     if (m.size() != 0 || m.find(ref.begin()->first)) return 6;
   }

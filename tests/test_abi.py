@@ -176,10 +176,14 @@ def test_boolean_query_build_rules():
     assert B.build([T(1), T(2)], [], min_should_match=2).min_should_match == 0
     q = B.build([], [], must_nots=[T(3)])
     assert isinstance(q, B) and not q.must_queries and not q.should_queries and len(q.must_not_queries) == 1
-    for bad in (lambda: B.build([T(1)], [B.build([T(2), T(3)], [])]), lambda: B.build([], [T(1), T(2)], min_should_match=300)):
-        with pytest.raises(rucene_amd.RgpuError) as e:
-            bad()
-        assert e.value.status == -5                      # UnsupportedOperation: caller keeps those on the CPU path
+    with pytest.raises(rucene_amd.RgpuError) as e:
+        B.build([], [T(1), T(2)], min_should_match=300)
+    assert e.value.status == -5                          # UnsupportedOperation: caller keeps those on the CPU path
+    # a clause that is itself a BooleanQuery builds, as in the reference (round 5); whether the GPU path serves the tree is decided
+    # when it is searched: UnsupportedOperation -> cpu_fallback, or one level folded (tests/test_pack.py)
+    nested = B.build([T(1)], [B.build([T(2), T(3)], [])])
+    assert isinstance(nested, B) and not nested.is_flat() and nested.flattened() is None   # a conjunction under SHOULD beside MUST: not foldable
+    assert B.build([T(1), B.build([T(2), T(3)], [])], []).flattened().is_flat()
 
 
 def test_doc_file_validation_needs_no_gpu(gpu_lib):

@@ -441,6 +441,69 @@ def test_wide_disjunctions(oracle, knobs):
         ctx2.close()
 
 
+@pytest.mark.parametrize("knobs", [dict(), dict(or_bitmaps=-1)], ids=["k_or_lazy", "k_or_wide"])
+def test_deferred_disjunction_batches(knobs):
+    """rgpu_config.or_deferred: a batch of >= 10-clause disjunctions only ENQUEUES, like TERM / AND batches —
+    the flags its fixed-point kernels hand back (a top-k below the fixed-point floor -> clause-order kernels; a window that did not
+    fit -> k_or_wide) are looked at when the next call needs the scratch slot, or by rgpu_synchronize. Batches that contain
+    both kinds of hand-back are issued back to back on two alternating streams without any synchronisation in between, mixed with
+    TERM / AND batches that rotate through the scratch slots; after ONE rgpu_synchronize every batch's rows are those of the
+    blocking call (same kernels: bit for bit). The oracle judges those rows elsewhere (test_wide / test_lazy_disjunctions)."""
+    import torch
+    import rucene_amd
+    from rucene_amd import indexgen, _lib as gpu
+    max_doc = 150_001
+    rng = np.random.default_rng(777)
+    dfs = [1, 3, 70, 128, 200, 700, 1500, 2300, 2340, 5000, 9000, 20_000, 40_000, 75_000, 120_000, max_doc, 30_000, 2400, 60_000, 100_000]
+    lists = [_postings(rng, df, max_doc) for df in dfs]
+    lists[7] = (np.arange(50_000, 52_300, dtype=np.int32), lists[7][1])  # 18 blocks inside one 16384-doc window: k_or_lazy hands it back
+    norms = rng.integers(90, 130, size=max_doc).astype(np.uint8)
+    seg = indexgen.build_explicit(max_doc, lists, norms=norms)
+    T, B = rucene_amd.TermQuery, rucene_amd.BooleanQuery
+    OR = lambda ids: B.build([], [T(i) for i in ids])
+    batches = [
+        [OR([0, 1, 2, 3, 4, 5, 6, 9, 10, 11]), OR([0, 1] + [15] * 8), OR([3, 4, 5, 6, 11, 12, 13, 14, 16, 18])],   # the floor: two rare terms (4 docs) next to one every doc holds
+        [OR([0, 1, 2, 3, 4, 5, 7, 9, 10, 11]), OR([15] * 10), OR([11, 12, 13, 14, 15, 16, 18, 19, 9, 10])],         # handed back (clustered list, every doc)
+        [T(9), B.build([T(9), T(10), T(11)], []), OR([13] * 5 + [5] * 5), OR([8, 9, 10])],                          # next to other operators
+        [OR([17, 8, 6, 5, 4, 3, 2, 1, 0, 9, 10, 11, 12, 13, 14, 16]), OR([0, 1] + [15] * 8)],
+    ]
+    k = 10
+    want = []
+    ctx_ref = rucene_amd.Context(**knobs)
+    try:
+        leaf = rucene_amd.LeafReader(seg.doc_bytes, seg.norms, max_doc, seg.terms, sum_total_term_freq=60 * max_doc)
+        ref = rucene_amd.GpuIndexSearcher([leaf], ctx=ctx_ref)
+        for b in batches:
+            want.append(ref.search_batch(b, k))
+    finally:
+        ctx_ref.close()
+    ctx2 = rucene_amd.Context(profile_kernels=True, or_deferred=True, **knobs)
+    try:
+        leaf = rucene_amd.LeafReader(seg.doc_bytes, seg.norms, max_doc, seg.terms, sum_total_term_freq=60 * max_doc)
+        g = rucene_amd.GpuIndexSearcher([leaf], ctx=ctx2)
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        outs = [(i, torch.full((len(b), k), -1, dtype=torch.int64, device="cuda"), torch.full((len(b),), -7, dtype=torch.int64, device="cuda"))
+                for rep in range(3) for i, b in enumerate(batches)]
+        torch.cuda.synchronize()   # (the fills ran on torch's stream)
+        for n, (i, hits, totals) in enumerate(outs):   # twelve batches in flight: every scratch slot is reused with flags pending
+            qs, ts = g.pack(batches[i], leaf)
+            leaf.segment.search_batch_device(qs, ts, k, hits.data_ptr(), totals.data_ptr(), streams[n % 2].cuda_stream)
+        ctx2.synchronize()         # settles what is still pending (and waits for the redo kernels it launches)
+        torch.cuda.synchronize()
+        for i, hits, totals in outs:
+            gh = hits.cpu().numpy().view(gpu.HIT_DTYPE).reshape(len(batches[i]), k)
+            gt = totals.cpu().numpy()
+            wh, wt = want[i]
+            assert (gt == wt).all(), (i, gt, wt)
+            assert (gh["doc"] == wh["doc"]).all() and (gh["score"].view(np.int32) == wh["score"].view(np.int32)).all(), i
+        stats = ctx2.kernel_stats()
+        assert stats["or_wide_redo_queries"]["launches"] >= 3      # the floor queries were run again, in every repetition
+        if not knobs:
+            assert stats["or_lazy_bail_queries"]["launches"] >= 3 and "k_or_wide" in stats
+    finally:
+        ctx2.close()
+
+
 @pytest.mark.parametrize("knobs", [dict(), dict(or_lazy_cells=1024), dict(or_bitmaps=16)])
 def test_lazy_disjunctions(oracle, knobs):
     """k_or_lazy (>= 10 SHOULD clauses, the dense ones met through their doc bitmaps) over ten windows: hit counts exact, docs and
@@ -548,6 +611,62 @@ def test_doc_bitmaps_stay_inside_their_budget(oracle):
         ctx2.close()
     with pytest.raises(rucene_amd.RgpuError) as e:
         rucene_amd.Context(bitmap_budget_mib=-1)
+    assert e.value.status == -2
+
+
+def test_prepared_terms_stay_inside_their_budget(oracle):
+    """rgpu_config.prepared_budget_mib: a shard serves a ROTATING vocabulary under a fixed HBM ceiling. Every
+    term a batch names is prepared on its first use (directory, aligned block store, posting-order norms) and used to stay for the
+    life of the segment; with a budget the store is dropped as a whole once it is over the ceiling when a batch arrives, and
+    refilled by what the batches name. Same answers as without a budget, bit for bit; the store never holds more than the
+    ceiling + one batch; evictions are counted (rgpu_kernel_stats: prepared_store_evictions)."""
+    import rucene_amd
+    from rucene_amd import indexgen
+    seg = indexgen.build_zipf(2_000_000, 100_000)
+    oseg = oracle.Segment(seg.doc_bytes, seg.norms, seg.max_doc, seg.terms, sum_total_term_freq=seg.sum_total_term_freq)
+    osearcher = oracle.Searcher([oseg])
+    budget_mib = 1
+    ctx2 = rucene_amd.Context(profile_kernels=True, prepared_budget_mib=budget_mib)
+    try:
+        leaf = rucene_amd.LeafReader.from_synthetic(seg)
+        gsearcher = rucene_amd.GpuIndexSearcher([leaf], ctx=ctx2)
+        rng = np.random.default_rng(5)
+        biggest_batch = 0
+        for rnd in range(12):   # every round names other terms: ranks rotate through the vocabulary
+            lo = 1 + 300 * rnd
+            ranks = rng.integers(lo, lo + 1500, size=(48, 3))
+            specs = [(oracle.OP_AND, [int(t) for t in row]) for row in ranks[:16]] + [(oracle.OP_OR, [int(t) for t in row]) for row in ranks[16:32]]
+            specs += [(oracle.OP_TERM, [int(row[0])]) for row in ranks[32:]]
+            before = leaf.segment.footprint()
+            held_before = before["directory_bytes"] + before["block_store_bytes"] + before["posting_norms_bytes"]
+            _check_against_oracle(oracle, osearcher, gsearcher, specs, 10)
+            fp = leaf.segment.footprint()
+            held = fp["directory_bytes"] + fp["block_store_bytes"] + fp["posting_norms_bytes"]
+            grew = held - (held_before if held >= held_before else 0)
+            biggest_batch = max(biggest_batch, grew)
+            # a batch arrives to a store at or under the ceiling, or the store is emptied first: never more than ceiling + one batch
+            assert held <= (budget_mib << 20) + biggest_batch, (rnd, held, biggest_batch)
+        evictions = ctx2.kernel_stats().get("prepared_store_evictions", {"launches": 0})["launches"]
+        assert evictions >= 2, evictions   # 12 rounds x ~0.5 MB of fresh terms against 1 MiB
+        # the same batches against a context without a ceiling hold everything
+        ctx3 = rucene_amd.Context()
+        try:
+            leaf3 = rucene_amd.LeafReader.from_synthetic(seg)
+            g3 = rucene_amd.GpuIndexSearcher([leaf3], ctx=ctx3)
+            rng = np.random.default_rng(5)
+            for rnd in range(12):
+                lo = 1 + 300 * rnd
+                ranks = rng.integers(lo, lo + 1500, size=(48, 3))
+                g3.search_batch([rucene_amd.BooleanQuery.build([rucene_amd.TermQuery(int(t)) for t in row], []) for row in ranks[:16]], 10)
+            fp3 = leaf3.segment.footprint()
+            # (a third of every round's queries already hold more than the ceiling when nothing is ever dropped)
+            assert fp3["directory_bytes"] + fp3["block_store_bytes"] + fp3["posting_norms_bytes"] > (budget_mib << 20)
+        finally:
+            ctx3.close()
+    finally:
+        ctx2.close()
+    with pytest.raises(rucene_amd.RgpuError) as e:
+        rucene_amd.Context(prepared_budget_mib=-1)
     assert e.value.status == -2
 
 
