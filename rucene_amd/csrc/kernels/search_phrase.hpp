@@ -511,6 +511,13 @@ constexpr int SLOPPY_POOL = 2048;  // positions of all the phrase's terms inside
 constexpr int SLOPPY_SMALL_POOL = 256;  // ... in the first launch (k_sloppy_match<.., POOL, REDO_ONLY>)
 constexpr int SLOPPY_MAX_TERMS = 16;
 
+// per query, reduced chunk by chunk over its candidates (k_phrase_cutoff_items): the smallest doc with a key, the smallest LIVE
+// candidate (what SloppyPhraseScorer::init_first_time sees: k_sloppy_groups), the candidates in front of the first doc with a key
+struct PhraseCut {
+  int32_t first;
+  int32_t dmin;
+  unsigned long long before;
+};
 struct SloppyGroups {  // per query: PhrasePositions::{rpt_group, rpt_ind} by query-order index; -1 = not a repeater
   int8_t grp[SLOPPY_MAX_TERMS];
   int8_t ind[SLOPPY_MAX_TERMS];
@@ -521,16 +528,16 @@ __global__ __launch_bounds__(WG_THREADS) void k_sloppy_groups(SegView seg, const
                                                               const PosTerm* __restrict__ pterms, const int64_t* __restrict__ emit_prefix,
                                                               const unsigned long long* __restrict__ emit_count,
                                                               const int32_t* __restrict__ emit_docs, const int32_t* __restrict__ slops,
-                                                              int n_queries, int64_t pos_len, SloppyGroups* __restrict__ groups, int* err) {
+                                                              int n_queries, int64_t pos_len, SloppyGroups* __restrict__ groups, int* err,
+                                                              const PhraseCut* __restrict__ cut) {
   __shared__ __attribute__((aligned(16))) uint8_t slabs[WG_WAVES][SLAB_BYTES];
   __shared__ int32_t lists[WG_WAVES][PHRASE_LIST_CAP];
   const int lane = lane_id();
   const int wave = wave_id();
   const int q = (int)(blockIdx.x * WG_WAVES) + wave;
   if (q >= n_queries) return;
-  SloppyGroups G;
-#pragma unroll
-  for (int i = 0; i < SLOPPY_MAX_TERMS; ++i) { G.grp[i] = -1; G.ind[i] = 0; }
+  int32_t out_grp = -1, out_ind = 0;  // lane i: pp i's group and index in it (written by the lanes themselves: a local struct filled
+                                      // through a loop variable lived in scratch, 36 bytes per lane)
   const DevQuery Q = queries[q];
   const int64_t n_cand = (int64_t)emit_count[q];
   const int n = Q.n_terms;
@@ -548,20 +555,11 @@ __global__ __launch_bounds__(WG_THREADS) void k_sloppy_groups(SegView seg, const
   const uint64_t rpp = __ballot(repeats);
   if (slops[q] > 0 && rpp != 0ull && n_cand > 0) {
     // the first candidate doc of the leaf: the conjunction's smallest live match
-    int32_t dmin = 0x7fffffff;
     // (BulkScorer tests live docs before it calls matches() — bulk_scorer.rs:100 — so the scorer's init_first_time runs on the
-    // first LIVE match; deleted candidates carry the sign bit)
-    // (eight independent loads per lane and round: one load per round made this walk — 2 M candidates for a pair of the commonest
-    // term — a chain of 31 k round trips, 6 ms; an index past the end reads the last candidate again, which a minimum does not mind)
-    const int64_t e0 = emit_prefix[q];
-    for (int64_t i0 = 0; i0 < n_cand; i0 += 64 * 8) {
-      int32_t d[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) d[u] = emit_docs[e0 + min(i0 + 64 * u + lane, n_cand - 1)];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) dmin = min(dmin, d[u] < 0 ? 0x7fffffff : d[u]);
-    }
-    dmin = 0x7fffffff - (int32_t)wave_reduce_max_u32((uint32_t)(0x7fffffff - dmin));  // min over the lanes (doc ids are >= 0)
+    // first LIVE match; deleted candidates carry the sign bit. Found chunk by chunk by k_phrase_cutoff_items<2>.)
+    (void)emit_prefix;
+    (void)emit_docs;
+    const int32_t dmin = cut[q].dmin;
     // Every candidate of the leaf is a deleted doc (the conjunction emits them with the sign bit set, so n_cand > 0
     // does not promise a live one): matches() is never called in this leaf, init_first_time never runs — the groups stay at
     // their -1 defaults and no position is looked up (the old code went looking for doc 0x7fffffff and failed the batch).
@@ -601,9 +599,12 @@ __global__ __launch_bounds__(WG_THREADS) void k_sloppy_groups(SegView seg, const
       const int32_t gj = readlane(grp, j), oj = readlane(off, j);
       ind += (grp >= 0 && gj == grp && (oj < off || (oj == off && j < lane))) ? 1 : 0;
     }
-    for (int i = 0; i < n; ++i) { G.grp[i] = (int8_t)readlane(grp, i); G.ind[i] = (int8_t)readlane(ind, i); }
+    if (lane < n) { out_grp = grp; out_ind = ind; }
   }
-  if (lane == 0) groups[q] = G;
+  if (lane < SLOPPY_MAX_TERMS) {
+    groups[q].grp[lane] = (int8_t)out_grp;
+    groups[q].ind[lane] = (int8_t)out_ind;
+  }
 }
 
 // POOL / REDO_ONLY: as k_phrase_match's CAP — the launch runs with SLOPPY_SMALL_POOL positions per wavefront (seven wavefronts per
@@ -860,7 +861,8 @@ __global__ __launch_bounds__(WG_THREADS) void k_sloppy_match_lanes(SegView seg, 
                                                                    const unsigned long long* __restrict__ emit_count,
                                                                    const int32_t* __restrict__ emit_docs, const int32_t* __restrict__ slops, int n_queries,
                                                                    int64_t n_groups, int64_t pos_len, uint64_t* __restrict__ keys_out, int* redo,
-                                                                   int64_t* __restrict__ redo_list, int redo_cap, int* redo_n) {
+                                                                   int64_t* __restrict__ redo_list, int redo_cap, int* redo_n, int rpt_lanes) {
+  // rpt_lanes != 0: k_sloppy_rpt_lanes runs behind this launch and takes the phrases that repeat a term
   __shared__ __attribute__((aligned(16))) int32_t areas[WG_WAVES][384];
   __shared__ int16_t lists[WG_WAVES][SLOPPY_LANE_TERMS][PHRASE_LANE_CAP * 64];
   const int lane = lane_id();
@@ -891,6 +893,8 @@ __global__ __launch_bounds__(WG_THREADS) void k_sloppy_match_lanes(SegView seg, 
       if (P.same_as != P.query_ord) takes = false;
     }
   }
+  // (a phrase that repeats a term is k_sloppy_rpt_lanes' when it has 2..SLOPPY_LANE_TERMS terms — that kernel writes its slots)
+  if (!takes && rpt_lanes && n >= 2 && n <= SLOPPY_LANE_TERMS) return;
   if (!takes) again = act;
   // PPElement's order (:393-430) is (position, offset, ord): bit 8 t + u of `ties` = "at equal positions pp t comes before pp u"
   uint64_t ties = 0ull;
@@ -977,6 +981,254 @@ __global__ __launch_bounds__(WG_THREADS) void k_sloppy_match_lanes(SegView seg, 
   lanes_finish(again, key, slot, keys_out, redo, PHRASE_REDO_SLOPPY_LANES, redo_list, redo_cap, redo_n, lane);
 }
 
+// ---- sloppy phrases that REPEAT a term, 64 candidates per wavefront ---------------------------------------------------------------
+// A phrase like [x, x] made k_sloppy_match — one candidate per wavefront, lane i = PhrasePositions i — the whole cost of a batch:
+// every doc of x is a candidate, two lanes of 64 do the work, 78 ms of the 101 ms that 1024 two-term slop-2 phrases took
+// (~30 of them name one term twice). Here every LANE runs the scorer for its own candidate, the repeats machinery included:
+// advance_repeat_groups, collide / lesser / advance_rpts, and the priority queue as the ARRAY Rust's BinaryHeap keeps
+// (push = sift_up, pop = swap-in the last, sift_down_to_bottom, sift_up: util/external/binary_heap.rs:121-210) — advance_rpts
+// changes the keys of queued PhrasePositions behind the heap's back, so which element a pop hands out depends on that array
+// (phrase_scorer.rs:651-701). The lane's state — position, next index, freq of each pp, the heap array — sits in its own LDS
+// column (16-bit cells: every index is per-lane, so registers would be select chains), the phrase's constants (offsets, groups:
+// SloppyGroups from k_sloppy_groups) in a small table the lanes share. pp i is the phrase's i-th term in QUERY order (the
+// PhrasePositions' ord); statement for statement oracle/sloppy_phrase.hpp, i.e. phrase_scorer.rs:537-790.
+constexpr int SLOPPY_RPT_GROUPS = SLOPPY_LANE_TERMS / 2;  // repetition groups a phrase of <= 6 terms can have
+__global__ __launch_bounds__(WG_THREADS) void k_sloppy_rpt_lanes(SegView seg, const DevQuery* __restrict__ queries,
+                                                                 const DevTerm* __restrict__ terms, const PosTerm* __restrict__ pterms,
+                                                                 const int64_t* __restrict__ emit_prefix,
+                                                                 const unsigned long long* __restrict__ emit_count,
+                                                                 const int32_t* __restrict__ emit_docs, const int32_t* __restrict__ slops,
+                                                                 const SloppyGroups* __restrict__ groups, int n_queries,
+                                                                 int64_t n_groups, int64_t pos_len, uint64_t* __restrict__ keys_out, int* redo,
+                                                                 int64_t* __restrict__ redo_list, int redo_cap, int* redo_n) {
+  constexpr int NT = SLOPPY_LANE_TERMS;
+  __shared__ __attribute__((aligned(16))) int32_t areas[WG_WAVES][384];
+  __shared__ int16_t lists[WG_WAVES][NT][PHRASE_LANE_CAP * 64];
+  __shared__ int16_t states[WG_WAVES][4 * NT][64];                 // rows: position, next index, freq, heap array — one column per lane
+  __shared__ int16_t tables[WG_WAVES][3 * NT + SLOPPY_RPT_GROUPS * (NT + 1)];  // offset, group, index in group; per group: length, members
+  const int lane = lane_id();
+  const int wave = wave_id();
+  const int64_t group = (int64_t)blockIdx.x * WG_WAVES + wave;
+  if (group >= n_groups) return;
+  const int64_t slot = group * 64 + lane;
+  const int q = upper_slot_wave(emit_prefix, n_queries, group * 64, lane);
+  const int slop = slops[q];
+  if (slop <= 0) return;
+  const DevQuery Q = queries[q];
+  const int n = Q.n_terms;
+  if (n < 2 || n > NT) return;  // (k_sloppy_match_lanes handed those on itself)
+  bool repeats = false;
+  for (int c = 0; c < n; ++c) { const PosTerm P = pterms[Q.first_term + c]; repeats = repeats || P.same_as != P.query_ord; }
+  if (!repeats) return;         // k_sloppy_match_lanes' phrase
+  const int64_t idx = slot - emit_prefix[q];
+  const int64_t cnt = (int64_t)emit_count[q];
+  if (idx - lane >= cnt) return;
+  const int32_t doc = idx < cnt ? emit_docs[slot] : -1;
+  const bool act = doc >= 0;  // (a deleted doc: an approximation that is never checked)
+  bool again = false;
+  // ---- the phrase's constants, by pp (query order)
+  int16_t* const T16 = tables[wave];
+  int16_t* const OFFT = T16;
+  int16_t* const GRPT = T16 + NT;
+  int16_t* const INDT = T16 + 2 * NT;
+  int16_t* const GLEN = T16 + 3 * NT;                       // [g]
+  int16_t* const GMEM = T16 + 3 * NT + SLOPPY_RPT_GROUPS;   // [g][k]: the pp with rpt_group g, rpt_ind k
+  const SloppyGroups* const G = groups + q;  // (read in place: a local copy indexed by a loop variable lives in scratch)
+  if (lane < SLOPPY_RPT_GROUPS * (NT + 1)) T16[3 * NT + lane] = lane < SLOPPY_RPT_GROUPS ? 0 : -1;
+  if (lane < NT) { OFFT[lane] = 0; GRPT[lane] = -1; INDT[lane] = 0; }
+  wave_sync();
+  bool fits = true;  // (groups beyond what the table holds cannot come from <= 6 terms; a corrupt SloppyGroups hands the phrase on)
+  for (int c = 0; c < n; ++c) {
+    const PosTerm P = pterms[Q.first_term + c];
+    const int i = P.query_ord;
+    const int g = (i >= 0 && i < SLOPPY_MAX_TERMS) ? (int)G->grp[i] : -1, k = (i >= 0 && i < SLOPPY_MAX_TERMS) ? (int)G->ind[i] : 0;
+    if (i < 0 || i >= NT || g >= SLOPPY_RPT_GROUPS || (g >= 0 && (k < 0 || k >= NT)) || P.phrase_pos > 0x7fff || P.phrase_pos < -0x8000) { fits = false; continue; }
+    if (lane == 0) {
+      OFFT[i] = (int16_t)P.phrase_pos;
+      GRPT[i] = (int16_t)g;
+      INDT[i] = (int16_t)k;
+      if (g >= 0) GMEM[g * NT + k] = (int16_t)i;
+    }
+  }
+  wave_sync();
+  if (lane < SLOPPY_RPT_GROUPS) {  // a group's members are numbered 0 .. len - 1
+    int len = 0;
+    while (len < NT && GMEM[lane * NT + len] >= 0) ++len;
+    GLEN[lane] = (int16_t)len;
+  }
+  wave_sync();
+  if (!fits) again = act;
+  // ---- every pp's positions in the lane's doc: lists[pp], freq in the lane's state column
+  int16_t* const S = &states[wave][0][0];
+  auto POS = [&](int i) -> int16_t& { return S[(0 * NT + i) * 64 + lane]; };
+  auto NXT = [&](int i) -> int16_t& { return S[(1 * NT + i) * 64 + lane]; };
+  auto FRQ = [&](int i) -> int16_t& { return S[(2 * NT + i) * 64 + lane]; };
+  auto HEAP = [&](int j) -> int16_t& { return S[(3 * NT + j) * 64 + lane]; };
+  for (int c = 0; fits && c < n; ++c) {
+    if (!__ballot(act && !again)) break;
+    const DevTerm T = terms[Q.first_term + c];
+    const PosTerm P = pterms[Q.first_term + c];
+    const int f = lanes_doc_positions<int16_t>(seg, T, P, doc, act, again, pos_len, areas[wave], lists[wave][P.query_ord], lane);
+    FRQ(P.query_ord) = (int16_t)f;
+  }
+  wave_sync();
+  const bool live = act && !again;
+  float sfreq = 0.0f;
+  if (live) {
+    const int16_t* const L = &lists[wave][0][0];
+    int32_t end = (int32_t)0x80000000;
+    int hn = 0;
+    auto next_position = [&](int i) -> bool {  // PhrasePositions::next_position (:363-373)
+      const int a = NXT(i);
+      if (a >= (int)FRQ(i)) return false;
+      POS(i) = L[(i * PHRASE_LANE_CAP + a) * 64 + lane];
+      NXT(i) = (int16_t)(a + 1);
+      return true;
+    };
+    auto advance_pp = [&](int i) -> bool {  // :638-646
+      if (!next_position(i)) return false;
+      const int32_t p = POS(i);
+      end = p > end ? p : end;
+      return true;
+    };
+    auto key_less = [&](int a, int b) -> bool {  // PPElement: (position, offset, ord)
+      const int32_t pa = POS(a), pb = POS(b);
+      if (pa != pb) return pa < pb;
+      const int32_t oa = OFFT[a], ob = OFFT[b];
+      if (oa != ob) return oa < ob;
+      return a < b;
+    };
+    auto sift_up = [&](int start, int pos) {
+      const int elt = HEAP(pos);
+      while (pos > start) {
+        const int parent = (pos - 1) / 2;
+        const int pe = HEAP(parent);
+        if (!key_less(elt, pe)) break;  // elt <= parent
+        HEAP(pos) = (int16_t)pe;
+        pos = parent;
+      }
+      HEAP(pos) = (int16_t)elt;
+    };
+    auto heap_push = [&](int i) {
+      HEAP(hn) = (int16_t)i;
+      ++hn;
+      sift_up(0, hn - 1);
+    };
+    auto heap_pop = [&]() -> int {
+      --hn;
+      int item = HEAP(hn);
+      if (hn > 0) {
+        const int root = HEAP(0);
+        HEAP(0) = (int16_t)item;
+        item = root;
+        int pos = 0;
+        const int elt = HEAP(0);
+        int child = 1;
+        while (child < hn) {
+          const int right = child + 1;
+          if (right < hn && !key_less(HEAP(child), HEAP(right))) child = right;  // the greater of the two children
+          HEAP(pos) = HEAP(child);
+          pos = child;
+          child = 2 * pos + 1;
+        }
+        HEAP(pos) = (int16_t)elt;
+        sift_up(0, pos);
+      }
+      return item;
+    };
+    auto tp_pos = [&](int i) -> int32_t { return (int32_t)POS(i) + (int32_t)OFFT[i]; };
+    auto collide = [&](int i) -> int {  // :716-726
+      const int g = GRPT[i];
+      const int len = GLEN[g];
+      const int32_t tp = tp_pos(i);
+      for (int k = 0; k < len; ++k) {
+        const int j = GMEM[g * NT + k];
+        if (j != i && tp_pos(j) == tp) return k;
+      }
+      return -1;
+    };
+    auto lesser = [&](int a, int b) -> int {  // :704-713
+      const int32_t pa = POS(a), pb = POS(b);
+      return (pa < pb || (pa == pb && OFFT[a] < OFFT[b])) ? a : b;
+    };
+    auto advance_rpts = [&](int pp) -> bool {  // :651-701
+      const int g = GRPT[pp];
+      if (g < 0) return true;  // not a repeater
+      const int len = GLEN[g];
+      uint32_t bits = 0;
+      const int k0 = INDT[pp];
+      int cur = pp;
+      while (true) {
+        const int k = collide(cur);
+        if (k < 0) break;
+        cur = lesser(cur, GMEM[g * NT + k]);  // always advance the lesser of the (only) two colliding pps
+        if (!advance_pp(cur)) return false;
+        if (k != k0) bits |= 1u << k;  // mark only those currently in the queue
+      }
+      // collisions resolved, now re-queue: pop until every marked pp has come out, then push them all back
+      uint32_t stack = 0;  // three bits per entry
+      int ns = 0;
+      while (bits && hn > 0) {  // (the reference would panic on an empty queue; it cannot get there: a marked pp is in the queue)
+        const int p2 = heap_pop();
+        stack |= (uint32_t)p2 << (3 * ns);
+        ++ns;
+        const int g2 = GRPT[p2], k2 = INDT[p2];
+        if (g2 >= 0 && k2 < len && ((bits >> k2) & 1u)) bits &= ~(1u << k2);
+      }
+      for (int i = 0; i < ns; ++i) heap_push((int)((stack >> (3 * (ns - 1 - i))) & 7u));
+      return true;
+    };
+    // ---- init_complex (:620-627): place_first_positions, advance_repeat_groups (single-term arm: the j-th pp of a group
+    // advances j times), fill_queue
+    bool alive = true;
+    for (int i = 0; i < n; ++i) { NXT(i) = 0; (void)next_position(i); }
+    for (int i = 0; i < n && alive; ++i) {
+      if (GRPT[i] < 0) continue;
+      const int times = INDT[i];
+      for (int t = 0; t < times && alive; ++t) alive = next_position(i);
+    }
+    if (alive) {
+      for (int i = 0; i < n; ++i) {
+        const int32_t p = POS(i);
+        end = p > end ? p : end;
+        heap_push(i);
+      }
+      // ---- phrase_freq (:537-577)
+      int pp = heap_pop();
+      int32_t match_length = end - (int32_t)POS(pp);
+      int32_t next = POS(HEAP(0));
+      while (advance_pp(pp)) {
+        if (!advance_rpts(pp)) break;  // pps exhausted
+        const int32_t p = POS(pp);
+        if (p > next) {  // done minimizing current match-length
+          if (match_length <= slop) sfreq += 1.0f / ((float)match_length + 1.0f);  // compute_slop_factor (bm25_similarity.rs:65-67)
+          heap_push(pp);
+          pp = heap_pop();
+          next = POS(HEAP(0));
+          match_length = end - (int32_t)POS(pp);
+        } else {
+          const int32_t ml2 = end - p;
+          match_length = ml2 < match_length ? ml2 : match_length;
+        }
+      }
+      if (match_length <= slop) sfreq += 1.0f / ((float)match_length + 1.0f);
+    }
+  }
+  uint64_t key = 0ull;
+  if (live && sfreq > 1.1920929e-07f) {  // matches(): sloppy_freq > f32::EPSILON (:1041-1045)
+    const DevTerm T0 = terms[Q.first_term];
+    const float* table = seg.sim_tables + (size_t)T0.sim_table * 257;
+    const float k1 = table[256];
+    float nrm = k1;
+    if (seg.norms != nullptr) {
+      const uint32_t nb = seg.norms[doc];
+      nrm = table[seg.n_norm_ranks > 0 ? (uint32_t)seg.rank_to_norm[nb] : nb];
+    }
+    key = make_key(bm25_score(T0.weight * (k1 + 1.0f), sfreq, nrm), doc);
+  }
+  lanes_finish(again, key, slot, keys_out, redo, PHRASE_REDO_SLOPPY_LANES, redo_list, redo_cap, redo_n, lane);
+}
+
 // TopDocsCollector over one query's candidates: a key of 0 = "phrase freq 0" (not a hit). One wavefront per query.
 // Any k up to RGPU_MAX_K (collector/top_docs.rs:28-95): a wavefront's registers hold 128 keys, so k > 128 runs as passes of
 // 128 over the candidates' keys — pass p keeps what lies strictly below pass p - 1's worst key (keys are unique per doc and
@@ -1037,52 +1289,84 @@ __global__ __launch_bounds__(WG_THREADS) void k_phrase_collect(const int64_t* __
 // The same collector for k <= 128 with a query's candidates cut into chunks — one wavefront per (query, PHRASE_COLLECT_CHUNK
 // candidates), partial lists folded by k_merge_items: one wavefront walking the 2 M keys of a common pair of terms was 12 of
 // the 15 ms k_phrase_collect took on the benchmark batch. Items are planned by the host from the lead's doc_freq (an upper bound
-// of the candidates); a chunk past the query's candidate count leaves an empty list. k_phrase_cutoff applies the two-phase rule
-// of the sloppy scorer (see k_phrase_collect) beforehand: abandoned[q] = 1 empties every chunk of the query.
+// of the candidates); a chunk past the query's candidate count leaves an empty list. k_phrase_cutoff_items / _decide apply the two-phase
+// rule of the sloppy scorer (see k_phrase_collect) beforehand: abandoned[q] = 1 empties every chunk of the query.
 constexpr int PHRASE_COLLECT_CHUNK = 8192;
-__global__ __launch_bounds__(WG_THREADS) void k_phrase_cutoff(const int64_t* __restrict__ emit_prefix, const unsigned long long* __restrict__ emit_count,
-                                                              const uint64_t* __restrict__ keys, const int32_t* __restrict__ emit_docs,
-                                                              const int32_t* __restrict__ slops, const int32_t* __restrict__ next_limits,
-                                                              int n_queries, int32_t* __restrict__ abandoned) {
+// The two-phase rule's decision with the candidates cut into the collector's chunks (round 5: one wavefront per query walking the
+// 2 M candidates of a common pair of terms twice was 7 ms of the 19 ms a batch of 1024 two-term slop-2 phrases took): PASS 0 — the smallest doc with a
+// key, per query (an atomic min per chunk); PASS 1 — the candidates in front of it (an atomic add per chunk); then one lane per
+// query decides. cut[q] = {first doc, smallest live candidate, candidates before the first doc}: {INT_MAX, INT_MAX, 0} from the host.
+// PASS 2 — run in front of k_sloppy_groups — is the smallest live candidate of every sloppy query (that kernel used to look for it
+// with one wavefront per query: 2 ms for a query with 2 M candidates).
+template <int PASS>
+__global__ __launch_bounds__(WG_THREADS) void k_phrase_cutoff_items(const int64_t* __restrict__ item_prefix, const int64_t* __restrict__ emit_prefix,
+                                                                    const unsigned long long* __restrict__ emit_count, const uint64_t* __restrict__ keys,
+                                                                    const int32_t* __restrict__ emit_docs, const int32_t* __restrict__ slops,
+                                                                    const int32_t* __restrict__ next_limits, int n_queries, int64_t n_items,
+                                                                    PhraseCut* __restrict__ cut) {
   const int lane = lane_id();
-  const int q = (int)(blockIdx.x * WG_WAVES) + wave_id();
-  if (q >= n_queries) return;
+  const int64_t item = (int64_t)blockIdx.x * WG_WAVES + wave_id();
+  if (item >= n_items) return;
+  const int q = upper_slot_wave(item_prefix, n_queries, item, lane);
+  if (PASS == 2) {  // the smallest live candidate of a sloppy query (deleted candidates carry the sign bit)
+    if (slops[q] <= 0) return;
+    const int64_t base2 = emit_prefix[q], n2 = (int64_t)emit_count[q];
+    const int64_t lo2 = (item - item_prefix[q]) * PHRASE_COLLECT_CHUNK, hi2 = min(n2, lo2 + PHRASE_COLLECT_CHUNK);
+    if (lo2 >= hi2) return;
+    int32_t dmin = 0x7fffffff;
+    for (int64_t i0 = lo2; i0 < hi2; i0 += 64 * 8) {
+      int32_t dd[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) dd[u] = emit_docs[base2 + min(i0 + 64 * u + lane, hi2 - 1)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) dmin = min(dmin, dd[u] < 0 ? 0x7fffffff : dd[u]);
+    }
+    dmin = 0x7fffffff - (int32_t)wave_reduce_max_u32((uint32_t)(0x7fffffff - dmin));
+    if (lane == 0 && dmin != 0x7fffffff) atomicMin(&cut[q].dmin, dmin);
+    return;
+  }
   if (!(slops[q] > 0 && next_limits[q] >= 0)) return;
   const int64_t base = emit_prefix[q], n = (int64_t)emit_count[q];
   // Fewer candidates than the limit: the misses in front of the first match cannot exceed it, and a query without any match
   // collects nothing whether it is marked abandoned or not — nothing to decide (and no walk over the candidates).
   if (n <= (int64_t)next_limits[q]) return;
-  // (n >= 1 from here on. Eight independent loads per lane and round — see k_sloppy_groups; an index past the end reads the last
-  // candidate again and is masked out of the decision)
-  int32_t first = 0x7fffffff;
-  for (int64_t i0 = 0; i0 < n; i0 += 64 * 8) {
-    uint64_t kk[8];
-    int32_t dd[8];
+  const int64_t lo = (item - item_prefix[q]) * PHRASE_COLLECT_CHUNK, hi = min(n, lo + PHRASE_COLLECT_CHUNK);
+  if (lo >= hi) return;
+  if (PASS == 0) {
+    int32_t first = 0x7fffffff;
+    for (int64_t i0 = lo; i0 < hi; i0 += 64 * 8) {
+      uint64_t kk[8];
+      int32_t dd[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int64_t at = base + min(i0 + 64 * u + lane, n - 1);
-      kk[u] = keys[at];
-      dd[u] = emit_docs[at];
-    }
+      for (int u = 0; u < 8; ++u) {  // (an index past the chunk reads its last candidate again and is masked out)
+        const int64_t at = base + min(i0 + 64 * u + lane, hi - 1);
+        kk[u] = keys[at];
+        dd[u] = emit_docs[at];
+      }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const bool hit = i0 + 64 * u + lane < n && kk[u] != 0ull;
-      first = hit ? min(first, dd[u]) : first;
+      for (int u = 0; u < 8; ++u) first = (i0 + 64 * u + lane < hi && kk[u] != 0ull) ? min(first, dd[u]) : first;
     }
+    first = 0x7fffffff - (int32_t)wave_reduce_max_u32((uint32_t)(0x7fffffff - first));
+    if (lane == 0 && first != 0x7fffffff) atomicMin(&cut[q].first, first);
+  } else {
+    const int32_t first = cut[q].first;
+    unsigned long long before = 0;
+    for (int64_t i0 = lo; i0 < hi; i0 += 64 * 8) {
+      int32_t dd[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) dd[u] = emit_docs[base + min(i0 + 64 * u + lane, hi - 1)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) before += (unsigned long long)__popcll(__ballot(i0 + 64 * u + lane < hi && (dd[u] & 0x7fffffff) < first));
+    }
+    if (lane == 0 && before != 0ull) atomicAdd(&cut[q].before, before);
   }
-  first = 0x7fffffff - (int32_t)wave_reduce_max_u32((uint32_t)(0x7fffffff - first));
-  int64_t before = 0;
-  for (int64_t i0 = 0; i0 < n; i0 += 64 * 8) {
-    int32_t dd[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) dd[u] = emit_docs[base + min(i0 + 64 * u + lane, n - 1)];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const bool earlier = i0 + 64 * u + lane < n && (dd[u] & 0x7fffffff) < first;
-      before += __popcll(__ballot(earlier));
-    }
-  }
-  if (lane == 0 && (first == 0x7fffffff || before > (int64_t)next_limits[q])) abandoned[q] = 1;
+}
+__global__ void k_phrase_cutoff_decide(const unsigned long long* __restrict__ emit_count, const int32_t* __restrict__ slops,
+                                       const int32_t* __restrict__ next_limits, int n_queries, const PhraseCut* __restrict__ cut,
+                                       int32_t* __restrict__ abandoned) {
+  const int q = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (q >= n_queries || !(slops[q] > 0 && next_limits[q] >= 0) || (int64_t)emit_count[q] <= (int64_t)next_limits[q]) return;
+  if (cut[q].first == 0x7fffffff || cut[q].before > (unsigned long long)next_limits[q]) abandoned[q] = 1;
 }
 template <bool WIDE>
 __global__ __launch_bounds__(WG_THREADS) void k_phrase_collect_items(const int64_t* __restrict__ item_prefix, const int64_t* __restrict__ emit_prefix,

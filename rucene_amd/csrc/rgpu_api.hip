@@ -817,7 +817,11 @@ static int32_t prepare_norms_locked(rgpu_segment* seg, const rgpu_term_state* co
   return RGPU_OK;
 }
 
-static int32_t make_dev_term(const rgpu_segment* seg, const rgpu_term_state& st, float weight, int32_t sim_table, DevTerm* out, bool need_norms = true) {
+// `known`: the term's TermInfo when the caller has looked it up already (search_pass: ONE table look-up per clause and call — the
+// validation, the norms check and this function used to take one each; at 3072 clauses per conjunction batch the host's share of a
+// step was 0.17 ms next to 0.25 ms of kernels)
+static int32_t make_dev_term(const rgpu_segment* seg, const rgpu_term_state& st, float weight, int32_t sim_table, DevTerm* out, bool need_norms = true,
+                             const TermInfo* known = nullptr) {
   DevTerm t;
   std::memset(&t, 0, sizeof t);
   t.start_fp = (uint64_t)std::max<int64_t>(0, st.doc_start_fp);
@@ -830,7 +834,7 @@ static int32_t make_dev_term(const rgpu_segment* seg, const rgpu_term_state& st,
   if (st.doc_freq == 1 && (st.singleton_doc_id < 0 || st.singleton_doc_id >= seg->max_doc))
     return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "singleton_doc_id out of range");
   if (st.doc_freq >= 2) {
-    const TermInfo* info = seg->prepared.find(st.doc_start_fp);
+    const TermInfo* info = known ? known : seg->prepared.find(st.doc_start_fp);
     if (!info) return fail(RGPU_ERR_ILLEGAL_STATE, "term not prepared");
     if (need_norms && !info->norms) return fail(RGPU_ERR_ILLEGAL_STATE, "term's posting-order norms not prepared");
     t.dir_base = info->dir_base;
@@ -2222,6 +2226,8 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
   HOST_STAMP(p0);
   // validate + prepare
   std::vector<const rgpu_term_state*> ptrs;
+  std::vector<TermInfo> tinfo((size_t)n_terms_total);
+  bool need_prepare = false;
   for (int32_t q = 0; q < n_queries; ++q) {
     const rgpu_query& Q = queries[q];
     const int qop = Q.op & 0xff, qmsm = (Q.op >> 8) & 0xff, qopt = (Q.op >> 16) & 0xff;
@@ -2241,10 +2247,30 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
       const rgpu_query_term& t = terms[Q.first_term + i];
       if (i < Q.n_terms + qopt && (t.sim_table < 0 || t.sim_table >= c->n_sim_tables)) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "unknown sim_table handle");
       if (t.state.doc_freq > 0) ptrs.push_back(&t.state);
+      // the term's prepared structures, looked up ONCE per clause and call (by value: a later look-up may grow the table)
+      if (t.state.doc_freq >= 2 && !need_prepare) {
+        const TermInfo* info = seg->prepared.find(t.state.doc_start_fp);
+        if (info && info->df == t.state.doc_freq && (info->norms || !seg->d_norms)) tinfo[(size_t)(Q.first_term + i)] = *info;
+        else need_prepare = true;  // (something is not prepared yet, or a state that must be validated: the full path below)
+      }
     }
   }
-  int32_t rc = prepare_terms_locked(seg, ptrs.data(), ptrs.size());
-  if (rc != RGPU_OK) return rc;
+  int32_t rc = RGPU_OK;
+  if (need_prepare || c->prepared_budget != 0) {
+    rc = prepare_terms_locked(seg, ptrs.data(), ptrs.size());
+    if (rc != RGPU_OK) return rc;
+    for (int32_t q = 0; q < n_queries; ++q) {
+      const rgpu_query& Q = queries[q];
+      const int n_all = Q.n_terms + ((Q.op >> 16) & 0xff) + Q.n_must_not;
+      for (int i = 0; i < n_all; ++i) {
+        const rgpu_query_term& t = terms[Q.first_term + i];
+        if (t.state.doc_freq < 2) continue;
+        const TermInfo* info = seg->prepared.find(t.state.doc_start_fp);
+        if (!info) return fail(RGPU_ERR_ILLEGAL_STATE, "term not prepared");
+        tinfo[(size_t)(Q.first_term + i)] = *info;
+      }
+    }
+  }
   // (the fixed-point kernels rank by exact totals and round to f32 afterwards: across passes that would need a ceiling in
   // their own key space — deep result pages of a >= 10-clause disjunction go through the clause-order kernel instead)
   const bool or_wide_ok = c->cfg.or_wide >= 0 && seg->d_norms && seg->n_norm_ranks > 0 && !seg->d_live && k_total <= RGPU_PASS_K;
@@ -2305,7 +2331,7 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
         continue;
       }
       DevTerm dt;
-      rc = make_dev_term(seg, t.state, t.weight, t.sim_table, &dt);
+      rc = make_dev_term(seg, t.state, t.weight, t.sim_table, &dt, true, &tinfo[(size_t)(Q.first_term + i)]);
       if (rc != RGPU_OK) return rc;
       mine.push_back(dt);
       // the postings' bytes in .doc: FullBlocks end where the skip data starts; a short list is its VInt tail (~2 B a posting)
@@ -2318,7 +2344,7 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
         const rgpu_query_term& t = terms[Q.first_term + Q.n_terms + i];
         if (t.state.doc_freq <= 0) continue;
         DevTerm dt;
-        rc = make_dev_term(seg, t.state, t.weight, t.sim_table, &dt);
+        rc = make_dev_term(seg, t.state, t.weight, t.sim_table, &dt, true, &tinfo[(size_t)(Q.first_term + Q.n_terms + i)]);
         if (rc != RGPU_OK) return rc;
         mine_opt.push_back(dt);
       }
@@ -2326,7 +2352,7 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
         const rgpu_query_term& t = terms[Q.first_term + Q.n_terms + qopt + i];
         if (t.state.doc_freq <= 0) continue;
         DevTerm dt;
-        rc = make_dev_term(seg, t.state, 0.0f, 0, &dt);  // needs_scores = false: weight and table are never read
+        rc = make_dev_term(seg, t.state, 0.0f, 0, &dt, true, &tinfo[(size_t)(Q.first_term + Q.n_terms + qopt + i)]);  // needs_scores = false: weight and table are never read
         if (rc != RGPU_OK) return rc;
         mine_not.push_back(dt);
       }
@@ -2975,6 +3001,7 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
     const size_t o_gr = st.add((size_t)n_queries * sizeof(SloppyGroups));  // written by k_sloppy_groups
     const size_t o_cp = st.add((size_t)(n_queries + 1) * 8);                // the chunked collector's items
     const size_t o_ab = st.add((size_t)n_queries * 4);                      // k_phrase_cutoff's flags (zeroed by the copy)
+    const size_t o_cut = st.add((size_t)n_queries * sizeof(PhraseCut));     // ... and what its chunked form reduces into
     std::vector<TermBitmap> clause_bitmaps;  // parallel to dt: the clauses behind a query's lead that have a doc bitmap
     if (bitmap_df != INT64_MAX && seg->bitmaps.size() > 0) {
       bool any = false;
@@ -3003,6 +3030,7 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
     std::memcpy(c->S->h_stage.p + o_ep, emit_prefix.data(), (size_t)(n_queries + 1) * 8);
     std::memcpy(c->S->h_stage.p + o_cp, collect_prefix.data(), (size_t)(n_queries + 1) * 8);
     std::memset(c->S->h_stage.p + o_ab, 0, (size_t)n_queries * 4);
+    for (int32_t q = 0; q < n_queries; ++q) reinterpret_cast<PhraseCut*>(c->S->h_stage.p + o_cut)[q] = PhraseCut{0x7fffffff, 0x7fffffff, 0ull};
     // "no repetition group" for every query (grp = -1): k_sloppy_groups only runs when some phrase repeats a term, k_sloppy_match
     // reads the region either way (the copy used to carry whatever the pinned buffer held)
     std::memset(c->S->h_stage.p + o_gr, 0xff, (size_t)n_queries * sizeof(SloppyGroups));
@@ -3074,10 +3102,16 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
       };
       auto sloppy_groups = [&]() {  // the repetition groups of each query's first candidate doc (phrases with a repeated term)
         TimedLaunch tl(c, stream, "k_sloppy_groups", 0);
+        PhraseCut* d_cut0 = reinterpret_cast<PhraseCut*>(c->S->d_stage.p + o_cut);
+        const int64_t* d_cp0 = reinterpret_cast<const int64_t*>(c->S->d_stage.p + o_cp);
+        const int32_t* d_nl0 = reinterpret_cast<const int32_t*>(c->S->d_stage.p + o_nl);
+        if (collect_items > 0)  // every sloppy query's smallest live candidate, chunk by chunk
+          RGPU_LAUNCH(k_phrase_cutoff_items<2>, dim3(wg_count((collect_items + WG_WAVES - 1) / WG_WAVES)), dim3(WG_THREADS), 0, stream, d_cp0, d_ep,
+                      c->phrase_count.p, c->phrase_keys.p, (const int32_t*)c->phrase_docs.p, d_sl, d_nl0, (int)n_queries, collect_items, d_cut0);
         const unsigned ggrid = wg_count((n_queries + WG_WAVES - 1) / WG_WAVES);
         auto go = [&](auto kern) {
           RGPU_LAUNCH(kern, dim3(ggrid), dim3(WG_THREADS), 0, stream, sv, d_q, d_t, d_pt, d_ep, c->phrase_count.p, c->phrase_docs.p, d_sl,
-                      (int)n_queries, (int64_t)seg->pos_len, d_gr, c->d_err);
+                      (int)n_queries, (int64_t)seg->pos_len, d_gr, c->d_err, (const PhraseCut*)d_cut0);
         };
         if (legacy) go(k_sloppy_groups<true>); else go(k_sloppy_groups<false>);
       };
@@ -3102,9 +3136,18 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
           TimedLaunch tl(c, stream, "k_sloppy_match", 0);
           sloppy(k_sloppy_match<true, SLOPPY_SMALL_POOL, false>, all_slots, slots);
         } else {
-          TimedLaunch tl(c, stream, "k_sloppy_match_lanes", 0);
-          RGPU_LAUNCH(k_sloppy_match_lanes, lanes_grid, dim3(WG_THREADS), 0, stream, sv, d_q, d_t, d_pt, d_ep, c->phrase_count.p, c->phrase_docs.p, d_sl,
-                      (int)n_queries, groups, (int64_t)seg->pos_len, c->phrase_keys.p, c->d_err + 3, c->phrase_redo.p, (int)redo_cap, c->d_err + 2);
+          if (sloppy_rpts) sloppy_groups();  // the repetition groups: k_sloppy_rpt_lanes (and what it hands on) needs them
+          {
+            TimedLaunch tl(c, stream, "k_sloppy_match_lanes", 0);
+            RGPU_LAUNCH(k_sloppy_match_lanes, lanes_grid, dim3(WG_THREADS), 0, stream, sv, d_q, d_t, d_pt, d_ep, c->phrase_count.p, c->phrase_docs.p, d_sl,
+                        (int)n_queries, groups, (int64_t)seg->pos_len, c->phrase_keys.p, c->d_err + 3, c->phrase_redo.p, (int)redo_cap, c->d_err + 2,
+                        sloppy_rpts ? 1 : 0);
+          }
+          if (sloppy_rpts) {  // phrases that repeat a term: the scorer's repeats machinery per lane
+            TimedLaunch tl(c, stream, "k_sloppy_rpt_lanes", 0);
+            RGPU_LAUNCH(k_sloppy_rpt_lanes, lanes_grid, dim3(WG_THREADS), 0, stream, sv, d_q, d_t, d_pt, d_ep, c->phrase_count.p, c->phrase_docs.p, d_sl,
+                        d_gr, (int)n_queries, groups, (int64_t)seg->pos_len, c->phrase_keys.p, c->d_err + 3, c->phrase_redo.p, (int)redo_cap, c->d_err + 2);
+          }
         }
       }
       // ---- which candidates wait for another pass (bits PHRASE_REDO_*): one look per stage that can raise one
@@ -3130,8 +3173,7 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
         exact(k_phrase_match<false, PHRASE_SMALL_CAP, true>, left, n_left);
       }
       if (redo & PHRASE_REDO_SLOPPY_LANES) {
-        if (sloppy_rpts) sloppy_groups();
-        TimedLaunch tl(c, stream, "k_sloppy_match(left by the 64-candidate kernel)", 0);
+        TimedLaunch tl(c, stream, "k_sloppy_match(left by the 64-candidate kernel)", 0);  // (the groups are there: computed in front of the 64-candidate kernels)
         sloppy(k_sloppy_match<false, SLOPPY_SMALL_POOL, true>, left, n_left);
       }
       if (redo & (PHRASE_REDO_LANES | PHRASE_REDO_SLOPPY_LANES)) {
@@ -3152,10 +3194,16 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
       int32_t* d_ab = reinterpret_cast<int32_t*>(c->S->d_stage.p + o_ab);
       {
       TimedLaunch tl(c, stream, "k_phrase_collect", 0);
-      if (any_cutoff)
-        RGPU_LAUNCH(k_phrase_cutoff, dim3(wg_count((n_queries + WG_WAVES - 1) / WG_WAVES)), dim3(WG_THREADS), 0, stream, d_ep, c->phrase_count.p,
-                           c->phrase_keys.p, (const int32_t*)c->phrase_docs.p, d_sl, d_nl, (int)n_queries, d_ab);
       const unsigned grid = wg_count((collect_items + WG_WAVES - 1) / WG_WAVES);
+      if (any_cutoff) {  // the two-phase rule's cut-off, chunk by chunk: first collected doc, candidates in front of it, the decision
+        PhraseCut* d_cut = reinterpret_cast<PhraseCut*>(c->S->d_stage.p + o_cut);
+        RGPU_LAUNCH(k_phrase_cutoff_items<0>, dim3(grid), dim3(WG_THREADS), 0, stream, d_cp, d_ep, c->phrase_count.p, c->phrase_keys.p,
+                           (const int32_t*)c->phrase_docs.p, d_sl, d_nl, (int)n_queries, collect_items, d_cut);
+        RGPU_LAUNCH(k_phrase_cutoff_items<1>, dim3(grid), dim3(WG_THREADS), 0, stream, d_cp, d_ep, c->phrase_count.p, c->phrase_keys.p,
+                           (const int32_t*)c->phrase_docs.p, d_sl, d_nl, (int)n_queries, collect_items, d_cut);
+        RGPU_LAUNCH(k_phrase_cutoff_decide, dim3(wg_count((n_queries + 255) / 256)), dim3(256), 0, stream, c->phrase_count.p, d_sl, d_nl, (int)n_queries,
+                           d_cut, d_ab);
+      }
       if (k > 64)
         RGPU_LAUNCH(k_phrase_collect_items<true>, dim3(grid), dim3(WG_THREADS), 0, stream, d_cp, d_ep, c->phrase_count.p, c->phrase_keys.p,
                            (const int32_t*)d_ab, (int)n_queries, collect_items, (int)k, c->S->d_partial_keys.p, c->S->d_partial_counts.p);
