@@ -143,7 +143,10 @@ __device__ __forceinline__ void term_blocks_fast(const SegView& seg, const DevTe
   // them a fresh look at what the query's OTHER wavefronts have published meanwhile (round 5: one look per item at its start
   // left the items of a query warming up side by side, each on its own: 130 k of the headline batch's 2.2 M blocks unpacked
   // where a threshold known in advance needs a few per query)
-  struct Chunk { DirChunk dir; uint64_t bmax; int32_t lo; uint64_t seen; };
+  #ifndef RGPU_TERM_SEEN64
+#define RGPU_TERM_SEEN64 0  // 1: carry the whole published key across the chunk (its doc too: strict ties where the doc allows)
+#endif
+  struct Chunk { DirChunk dir; uint64_t bmax; int32_t lo; uint32_t seen_hi; uint32_t seen_lo; };
   auto load_chunk = [&](int c0) -> Chunk {
     Chunk c;
     const int nb = min(64, b1 - c0);
@@ -157,7 +160,17 @@ __device__ __forceinline__ void term_blocks_fast(const SegView& seg, const DevTe
     // 0.085 with a look per chunk; 100 M docs, ~42 items per query (305 for the longest list): 0.217 / 0.68 / 1.56 ms.
     const int ci = (c0 - b0) >> 6;
     const bool look = exchange && (RGPU_TERM_EXCHANGE == 1 || (RGPU_TERM_EXCHANGE == 2 && (ci & (ci - 1)) == 0));
-    c.seen = look ? shared.peek() : 0ull;
+    // (the score half of the published key is enough — and one register instead of two across the chunk. The doc half is then
+    // taken as the LARGEST doc id: (score, INT_MAX) is at or below the published key whatever its doc, so it only ever drops
+    // what the full key would drop, and a tie with it is never read as "lost" — thr_of looks at the threshold's doc)
+#if RGPU_TERM_SEEN64
+    const uint64_t seen = look ? shared.peek() : 0ull;
+    c.seen_hi = (uint32_t)(seen >> 32);
+    c.seen_lo = (uint32_t)seen;
+#else
+    c.seen_hi = look ? __hip_atomic_load(reinterpret_cast<const uint32_t*>(shared.slot) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    c.seen_lo = 0x80000000u;
+#endif
     return c;
   };
   Chunk next = load_chunk(b0);
@@ -168,7 +181,7 @@ __device__ __forceinline__ void term_blocks_fast(const SegView& seg, const DevTe
     const DirChunk& dir = cur.dir;
     {
       uint64_t t0 = 0;
-      shared.fold(cur.seen, t0, floor);
+      shared.fold(cur.seen_hi != 0u ? (((uint64_t)cur.seen_hi << 32) | cur.seen_lo) : 0ull, t0, floor);
     }
     count += 128 * nb;
     // lane j: the best score any posting of block c0 + j can have (raw bits; scores are >= 0 here)

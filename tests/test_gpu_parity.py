@@ -1214,6 +1214,25 @@ def test_sharded_search_through_the_c_abi_with_a_world_of_one(zipf, oracle):
         got = hits.cpu().numpy().view(gpu.HIT_DTYPE).reshape(len(queries), k)
         assert (got["doc"] == want_h["doc"]).all() and (got["score"].view(np.int32) == want_h["score"].view(np.int32)).all()
         assert (totals.cpu().numpy() == want_t).all()
+    # a batch of >= 10-clause disjunctions (fixed-point kernels: hand-back flags, settled before the record is gathered) next to
+    # TERM / AND batches, on two alternating streams, more calls in flight than the communicator and the context have slots
+    rng = np.random.default_rng(8)
+    or_batch = [B.build([], [T(int(x)) for x in rng.integers(0, 5000, size=10)]) for _ in range(6)] + [B.build([], [T(x) for x in (0, 1, 2)] + [T(0)] * 7)]
+    batches = [searcher.pack(or_batch, leaf), packed, searcher.pack([B.build([T(1), T(4), T(20)], [])] * 3, leaf)]
+    sizes = [len(or_batch), len(queries), 3]
+    want = [leaf.segment.search_batch(b[0], b[1], 10) for b in batches]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [(i % 3, torch.zeros((sizes[i % 3], 10), dtype=torch.int64, device="cuda"), torch.zeros((sizes[i % 3],), dtype=torch.int64, device="cuda")) for i in range(9)]
+    torch.cuda.synchronize()
+    for n, (i, hits, totals) in enumerate(outs):
+        comm.search_batch_sharded(leaf.segment, batches[i][0], batches[i][1], 10, hits.data_ptr(), totals.data_ptr(), streams[n % 2].cuda_stream)
+    searcher.ctx.synchronize()
+    torch.cuda.synchronize()
+    assert (comm.status() == 0).all()
+    for i, hits, totals in outs:
+        got = hits.cpu().numpy().view(gpu.HIT_DTYPE).reshape(sizes[i], 10)
+        assert (got["doc"] == want[i][0]["doc"]).all() and (got["score"].view(np.int32) == want[i][0]["score"].view(np.int32)).all(), i
+        assert (totals.cpu().numpy() == want[i][1]).all(), i
     comm.close()
 
 
