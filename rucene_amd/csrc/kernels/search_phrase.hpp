@@ -991,7 +991,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_sloppy_match_lanes(SegView seg, 
 // (phrase_scorer.rs:651-701). The lane's state — position, next index, freq of each pp, the heap array — sits in its own LDS
 // column (16-bit cells: every index is per-lane, so registers would be select chains), the phrase's constants (offsets, groups:
 // SloppyGroups from k_sloppy_groups) in a small table the lanes share. pp i is the phrase's i-th term in QUERY order (the
-// PhrasePositions' ord); statement for statement oracle/sloppy_phrase.hpp, i.e. phrase_scorer.rs:537-790.
+// PhrasePositions' ord); statement for statement phrase_scorer.rs:537-790 (what the tests compare it with restates the same lines).
 constexpr int SLOPPY_RPT_GROUPS = SLOPPY_LANE_TERMS / 2;  // repetition groups a phrase of <= 6 terms can have
 __global__ __launch_bounds__(WG_THREADS) void k_sloppy_rpt_lanes(SegView seg, const DevQuery* __restrict__ queries,
                                                                  const DevTerm* __restrict__ terms, const PosTerm* __restrict__ pterms,

@@ -146,7 +146,11 @@ __device__ __forceinline__ void term_blocks_fast(const SegView& seg, const DevTe
   #ifndef RGPU_TERM_SEEN64
 #define RGPU_TERM_SEEN64 0  // 1: carry the whole published key across the chunk (its doc too: strict ties where the doc allows)
 #endif
+#if RGPU_TERM_SEEN64
   struct Chunk { DirChunk dir; uint64_t bmax; int32_t lo; uint32_t seen_hi; uint32_t seen_lo; };
+#else
+  struct Chunk { DirChunk dir; uint64_t bmax; int32_t lo; uint32_t seen_hi; };
+#endif
   auto load_chunk = [&](int c0) -> Chunk {
     Chunk c;
     const int nb = min(64, b1 - c0);
@@ -169,7 +173,6 @@ __device__ __forceinline__ void term_blocks_fast(const SegView& seg, const DevTe
     c.seen_lo = (uint32_t)seen;
 #else
     c.seen_hi = look ? __hip_atomic_load(reinterpret_cast<const uint32_t*>(shared.slot) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-    c.seen_lo = 0x80000000u;
 #endif
     return c;
   };
@@ -181,7 +184,11 @@ __device__ __forceinline__ void term_blocks_fast(const SegView& seg, const DevTe
     const DirChunk& dir = cur.dir;
     {
       uint64_t t0 = 0;
+#if RGPU_TERM_SEEN64
       shared.fold(cur.seen_hi != 0u ? (((uint64_t)cur.seen_hi << 32) | cur.seen_lo) : 0ull, t0, floor);
+#else
+      shared.fold(cur.seen_hi != 0u ? (((uint64_t)cur.seen_hi << 32) | 0x80000000ull) : 0ull, t0, floor);
+#endif
     }
     count += 128 * nb;
     // lane j: the best score any posting of block c0 + j can have (raw bits; scores are >= 0 here)
@@ -314,8 +321,10 @@ __device__ __forceinline__ void term_blocks_fast(const SegView& seg, const DevTe
 #endif
 }
 
+// (eight wavefronts per SIMD = 64 VGPRs hold the headline instantiation — packed blocks, k <= 64; a second top-k register pair
+// (k > 64) or the legacy decode need a few more: seven wavefronts, 72 VGPRs, instead of 12 B of scratch per lane)
 template <bool LEGACY, bool WIDE>
-__global__ __launch_bounds__(TERM_THREADS, 8) void k_search_term(SegView seg, const DevQuery* __restrict__ queries,
+__global__ __launch_bounds__(TERM_THREADS, (LEGACY || WIDE) ? 7 : 8) void k_search_term(SegView seg, const DevQuery* __restrict__ queries,
                                                               const DevTerm* __restrict__ terms,
                                                               const int64_t* __restrict__ item_prefix, int n_queries,
                                                               int64_t n_items, int blocks_per_item, int k,

@@ -29,6 +29,7 @@
 #include "kernels/search_or_wide.hpp"
 #include "kernels/search_or_lazy.hpp"
 #include "host/flat_fp_map.hpp"
+#include "host/host_threads.hpp"
 #include "kernels/search_phrase.hpp"
 #include "kernels/search_term.hpp"
 
@@ -228,11 +229,21 @@ struct BitmapInfo { uint2* words; uint32_t* ranks; uint8_t* freqs; uint32_t* ovf
 // that is grown and first touched right there — 4 to 8 ms of page faults and cache misses for 1.3 ms of kernels. Such a call's
 // terms arrive in file order: they are kept as the sorted array the planning loop built anyway (`bulk`), looked up by binary
 // search, and a term moves into the hash table the first time a query names it.
+// One term of a bulk call, 16 bytes: what differs from term to term. The rest of its TermInfo is the same for every term of the
+// call (block-store base of the call's region, "has no norms to prepare") or follows (nblocks = df / 128, pn_base = 0 until the
+// norms are prepared — by then the term has moved into the table). 152 k of them are 2.4 MB, first touched by the planner's threads.
+struct PreparedEntry { int64_t first; uint32_t dir_base; int32_t df; };
+using PreparedBulk = std::vector<PreparedEntry, rucene::NoInitAlloc<PreparedEntry>>;
 struct PreparedMap {
   rucene::FlatFpMap<TermInfo> map;
-  std::vector<std::pair<int64_t, TermInfo>> bulk;  // ascending keys
+  PreparedBulk bulk;  // ascending keys
+  uint64_t bulk_bs_base = 0;
+  bool bulk_no_norms = false;
   std::vector<uint8_t> moved;                      // bulk[i] lives in `map` now
   size_t bulk_live = 0;
+  static TermInfo expand(const PreparedEntry& e, uint64_t bs_base, bool no_norms) {
+    return TermInfo{e.dir_base, e.df / 128, e.df, 0, bs_base, no_norms};
+  }
   long bulk_at(int64_t key) const {
     size_t lo = 0, hi = bulk.size();
     while (lo < hi) { const size_t mid = (lo + hi) >> 1; if (bulk[mid].first < key) lo = mid + 1; else hi = mid; }
@@ -243,9 +254,9 @@ struct PreparedMap {
     if (bulk_live == 0) return nullptr;
     const long i = bulk_at(key);
     if (i < 0) return nullptr;
-    map.put(key, bulk[(size_t)i].second);
+    map.put(key, expand(bulk[(size_t)i], bulk_bs_base, bulk_no_norms));
     moved[(size_t)i] = 1;
-    if (--bulk_live == 0) { bulk.clear(); bulk.shrink_to_fit(); moved.clear(); }
+    if (--bulk_live == 0) { bulk.clear(); moved.clear(); }  // (the array keeps its memory: the next bulk call of the segment fills it again)
     return map.find(key);
   }
   void put(int64_t key, const TermInfo& v) {
@@ -256,13 +267,25 @@ struct PreparedMap {
   void reserve_more(size_t n) { map.reserve_more(n); }
   size_t size() const { return map.size() + bulk_live; }
   void clear() { map.clear(); bulk.clear(); moved.clear(); bulk_live = 0; }
-  // `sorted`: ascending keys none of which is in the table. An earlier bulk that is still (partly) pending moves into the table first.
-  void adopt_sorted(std::vector<std::pair<int64_t, TermInfo>>&& sorted) {
+  // An empty array for a bulk call to fill (with whatever memory the last one left), then adopt_sorted(): ascending keys none of
+  // which is in the table. An earlier bulk that is still (partly) pending moves into the table first.
+  PreparedBulk take_array() {
     if (bulk_live != 0) {
       map.reserve_more(bulk_live);
-      for (size_t i = 0; i < bulk.size(); ++i) if (!moved[i]) map.put(bulk[i].first, bulk[i].second);
+      for (size_t i = 0; i < bulk.size(); ++i) if (!moved[i]) map.put(bulk[i].first, expand(bulk[i], bulk_bs_base, bulk_no_norms));
+      bulk_live = 0;
     }
+    PreparedBulk out = std::move(bulk);
+    bulk = PreparedBulk();
+    out.clear();
+    moved.clear();
+    return out;
+  }
+  void adopt_sorted(PreparedBulk&& sorted, uint64_t bs_base, bool no_norms) {
+    if (bulk_live != 0) (void)take_array();
     bulk = std::move(sorted);
+    bulk_bs_base = bs_base;
+    bulk_no_norms = no_norms;
     moved.assign(bulk.size(), 0);
     bulk_live = bulk.size();
   }
@@ -450,17 +473,25 @@ struct HostClock {
   long long lap() { const auto n = std::chrono::steady_clock::now(); const long long us = (long long)std::chrono::duration_cast<std::chrono::microseconds>(n - t).count(); t = n; return us; }
 };
 
-static int32_t validate_state(const rgpu_segment* seg, const rgpu_term_state& st) {
-  if (st.doc_freq < 0) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "negative doc_freq");
-  if (st.doc_freq <= 1) return RGPU_OK;
-  if (st.doc_start_fp < 0 || (size_t)st.doc_start_fp >= seg->doc_len)
-    return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "doc_start_fp outside the .doc file");
+// 0 = a term state the preparation can take (side-effect free: the bulk planner's threads ask it; validate_state words the rest)
+static int state_defect(const rgpu_segment* seg, const rgpu_term_state& st) {
+  if (st.doc_freq < 0) return 1;
+  if (st.doc_freq <= 1) return 0;
+  if (st.doc_start_fp < 0 || (size_t)st.doc_start_fp >= seg->doc_len) return 2;
   if (st.doc_freq > 128) {
-    if (st.skip_offset <= 0 || (size_t)(st.doc_start_fp + st.skip_offset) >= seg->doc_len)
-      return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "skip_offset outside the .doc file");
-    if (st.skip_offset > (int64_t)0xffffffffLL) return fail(RGPU_ERR_UNSUPPORTED, "a single term's postings exceed 4 GiB");
+    if (st.skip_offset <= 0 || (size_t)(st.doc_start_fp + st.skip_offset) >= seg->doc_len) return 3;
+    if (st.skip_offset > (int64_t)0xffffffffLL) return 4;
   }
-  return RGPU_OK;
+  return 0;
+}
+static int32_t validate_state(const rgpu_segment* seg, const rgpu_term_state& st) {
+  switch (state_defect(seg, st)) {
+    case 0: return RGPU_OK;
+    case 1: return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "negative doc_freq");
+    case 2: return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "doc_start_fp outside the .doc file");
+    case 3: return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "skip_offset outside the .doc file");
+    default: return fail(RGPU_ERR_UNSUPPORTED, "a single term's postings exceed 4 GiB");
+  }
 }
 
 // Stage A of term preparation (kernels/prepare.hpp) for every not-yet-seen term with df >= 2 (ctx mutex held by the caller):
@@ -522,6 +553,57 @@ static void prep_items(const std::vector<PrepTerm>& work, std::vector<int64_t>* 
   }
   (*item_prefix)[work.size()] = *n_items;
 }
+// what one new term (df >= 2) adds to a preparation call
+struct PlanOne {
+  int32_t nblocks, n_entries, n_levels;
+  int64_t skip_fp;
+  uint64_t rows;                  // block-store rows reserved for it
+  int64_t items, chunks, groups;  // work items of the block kernels; 1 KB chunks of level-0 skip bytes; groups of SKIP_GROUP chunks
+};
+static inline PlanOne plan_one(const rgpu_segment* seg, const rgpu_term_state& st, bool wide) {
+  PlanOne o;
+  o.nblocks = st.doc_freq / 128;
+  o.n_entries = (st.doc_freq + 127) / 128 - 1;
+  o.n_levels = ilog8_levels(st.doc_freq);
+  o.skip_fp = st.doc_freq > 128 ? st.doc_start_fp + st.skip_offset : -1;
+  // block store rows: a block's aligned copy is at most 28 bytes longer than its framing in the file (two
+  // header bytes dropped, each all-equal VInt padded to a 16-byte row); the FullBlocks end before the skip data
+  const uint64_t span = st.doc_freq > 128 ? (uint64_t)st.skip_offset : (o.nblocks ? 1026u : 0u);
+  // (a docs-only field: one header byte dropped, a synthetic 16-byte freq row added per block);
+  // + the decoded tail: 64 cells {doc, doc, freq, freq} behind the block rows
+  o.rows = (wide ? 64u * (uint64_t)o.nblocks : (span + (seg->has_freqs ? 28u : 32u) * (uint64_t)o.nblocks + 15u) / 16u) +
+           ((st.doc_freq % 128) ? (uint64_t)TAIL_STORE_ROWS : 0u);
+  o.items = std::max(1, (o.nblocks + PREP_BLOCKS_PER_ITEM - 1) / PREP_BLOCKS_PER_ITEM);  // the last item takes the tail
+  o.chunks = skip_chunks(o.n_entries, seg->skip_vals);
+  o.groups = o.chunks > SKIP_GROUP ? skip_groups(o.chunks) : 0;
+  return o;
+}
+static inline PrepTerm prep_term_of(const rgpu_term_state& st, const PlanOne& o, size_t dir_base, size_t batch_bs, int64_t out_base) {
+  PrepTerm p;
+  p.start_fp = (uint64_t)st.doc_start_fp;
+  p.df = st.doc_freq;
+  p.nblocks = o.nblocks;
+  p.n_entries = o.n_entries;
+  p.n_levels = o.n_levels;
+  p.skip_fp = o.skip_fp;
+  p.dir_base = (uint32_t)dir_base;
+  p.pn_base = 0;                   // assigned when (if) the term's norms are prepared
+  p.bs_base = (uint64_t)batch_bs;  // dir_row counts from the call's first row for every one of its terms
+  p.bs_rows = (uint32_t)o.rows;
+  p.out_base = out_base;
+  return p;
+}
+// A bulk first touch planned by several host threads (host/host_threads.hpp): nothing of the segment is prepared yet and the call
+// names a dictionary's worth of terms in file order (strictly ascending doc_start_fp: no repeats, so neither of the sequential
+// loop's tables is needed). Pass 1 counts per contiguous range of the call's terms; the ranges' sums give every range its bases;
+// pass 2 (after the staging buffer is sized) writes descriptors and prefix arrays straight into the pinned staging memory.
+constexpr size_t BULK_PLAN_MIN = 32768;
+struct BulkPart {
+  size_t cnt = 0, slots = 0;
+  uint64_t rows = 0;
+  int64_t items = 0, postings = 0, chunks = 0, groups = 0, first_fp = -1, last_fp = -1;
+  bool odd = false;  // a defect, a repeat or a step back: the sequential loop takes the call (and words the error, if it is one)
+};
 static int32_t prepare_terms_attempt(rgpu_segment* seg, const rgpu_term_state* const* sts, size_t n, bool wide, const DecodeSink* sink) {
   rgpu_ctx* c = seg->ctx;
   HostClock hc;
@@ -531,116 +613,205 @@ static int32_t prepare_terms_attempt(rgpu_segment* seg, const rgpu_term_state* c
   size_t need_slots = seg->dir_used;
   const size_t batch_bs = (seg->bstore_used + 15) & ~size_t(15);  // this call's rows form one dense region from here
   uint64_t cap_rows = 0;
-  std::vector<std::pair<int64_t, TermInfo>> added;
-  // Two tables stand between a term and the work list: "prepared already" and "named earlier in this call". A bulk first touch
-  // (152 k terms of a fresh 100 M-doc segment: the cold path) pays two DRAM round trips per term for answers that are known in
-  // advance — nothing is prepared yet, and a term dictionary hands its terms over in file order: while the doc_start_fps of the
-  // call ascend strictly no term can repeat, and the second table is only built (from the work list) once one does not.
-  rucene::FlatFpMap<int> in_batch;
+  // (empty; with the memory of the segment's last bulk call when none of that call's terms is still waiting in the array)
+  PreparedBulk added = seg->prepared.bulk_live == 0 ? seg->prepared.take_array() : PreparedBulk();
+  size_t n_work = 0;
+  int64_t n_items = 0, postings = 0, n_chunks = 0, n_groups = 0;
+  std::vector<int64_t> item_prefix, chunk_prefix, group_prefix;
   const bool none_prepared = seg->prepared.size() == 0;
   bool ascending = true;
-  int64_t last_fp = -1;
-  if (n > 4096) { work.reserve(n); added.reserve(n); }
   constexpr size_t AHEAD = 16;  // look-ups of a bulk call are asked for this many terms ahead (flat_fp_map.hpp prefetch)
-  for (size_t i = 0; i < n; ++i) {
-    if (i + AHEAD < n) {
-      if (!none_prepared) seg->prepared.prefetch(sts[i + AHEAD]->doc_start_fp);
-      if (!ascending) in_batch.prefetch(sts[i + AHEAD]->doc_start_fp);
+
+  // the step both plans share: the store's arrays grown to what the call adds, the staging buffer sized
+  size_t n_slots = 0, o_work = 0, o_items = 0, o_chunks = 0, o_groups = 0;
+  int64_t n_tiles = 0;
+  Stager st(c);
+  auto size_and_reserve = [&]() -> int32_t {
+    t_plan = hc.lap();
+    HIP_TRY(scratch_take(c));  // staging below; this function ends with a stream sync, so the slot is free again on return
+    HIP_TRY(seg->dir_last.reserve(need_slots, seg->dir_used, c->stream));
+    HIP_TRY(seg->dir_off.reserve(need_slots, seg->dir_used, c->stream));
+    HIP_TRY(seg->dir_row.reserve(need_slots, seg->dir_used, c->stream));
+    HIP_TRY(seg->bstore.reserve(batch_bs + (size_t)cap_rows * 16 + 1024, seg->bstore_used, c->stream));  // + over-read padding of the row loads
+    HIP_TRY(seg->dir_hdr.reserve(need_slots, seg->dir_used, c->stream));
+    HIP_TRY(seg->dir_bmax.reserve(need_slots, seg->dir_used, c->stream));
+    if (seg->has_positions) HIP_TRY(seg->dir_pos.reserve(need_slots, seg->dir_used, c->stream));
+    t_reserve = hc.lap();
+    n_slots = need_slots - seg->dir_used;
+    n_tiles = (int64_t)((n_slots + SCAN_TILE - 1) / SCAN_TILE);
+    o_work = st.add(n_work * sizeof(PrepTerm));
+    o_items = st.add((n_work + 1) * 8);
+    o_chunks = st.add((n_work + 1) * 8);
+    o_groups = st.add((n_work + 1) * 8);
+    HIP_TRY(c->S->h_stage.reserve(st.used));
+    HIP_TRY(c->S->d_stage.reserve(st.used, 0, c->stream));
+    return RGPU_OK;
+  };
+
+  const int n_parts = rucene::host_threads();
+  bool bulk = none_prepared && n >= BULK_PLAN_MIN && n_parts > 1;
+  if (bulk) {
+    std::vector<BulkPart> parts((size_t)n_parts), base((size_t)n_parts);  // a range's sums; what precedes a range
+    PrepTerm* h_work = nullptr;
+    int64_t *h_items = nullptr, *h_chunks = nullptr, *h_groups = nullptr;
+    int32_t rc_mid = RGPU_OK;
+    const size_t dir_used = seg->dir_used;
+    rucene::two_pass_run(n_parts,
+      [&](int t) {  // pass 1: count
+        const auto range = rucene::part_range(n, n_parts, t);
+        BulkPart P;
+        for (size_t i = range.first; i < range.second; ++i) {
+          const rgpu_term_state& ts = *sts[i];
+          if (ts.doc_freq < 2) {
+            if (ts.doc_freq < 0) { P.odd = true; break; }
+            continue;
+          }
+          if (state_defect(seg, ts) != 0 || ts.doc_start_fp <= P.last_fp) { P.odd = true; break; }
+          const PlanOne o = plan_one(seg, ts, wide);
+          if (o.rows > 0xffffffffull) { P.odd = true; break; }
+          if (P.cnt == 0) P.first_fp = ts.doc_start_fp;
+          P.last_fp = ts.doc_start_fp;
+          P.cnt += 1;
+          P.slots += (size_t)o.nblocks + 1;
+          P.rows += o.rows;
+          P.items += o.items;
+          P.postings += ts.doc_freq;
+          P.chunks += o.chunks;
+          P.groups += o.groups;
+        }
+        parts[(size_t)t] = P;
+      },
+      [&]() -> bool {  // between the passes, on this thread: totals, bases, the buffers pass 2 writes into
+        int64_t last = -1;
+        BulkPart acc;
+        for (int t = 0; t < n_parts && bulk; ++t) {
+          const BulkPart& P = parts[(size_t)t];
+          if (P.odd || (P.cnt != 0 && P.first_fp <= last)) { bulk = false; break; }
+          if (P.cnt != 0) last = P.last_fp;
+          base[(size_t)t] = acc;
+          acc.cnt += P.cnt; acc.slots += P.slots; acc.rows += P.rows; acc.items += P.items; acc.postings += P.postings;
+          acc.chunks += P.chunks; acc.groups += P.groups;
+        }
+        // (a defect, a repeat, a step back, a store past its limits, nothing to do: the sequential loop takes the call and words it)
+        if (bulk && (acc.cnt == 0 || seg->dir_used + acc.slots > 0xfffffff0ull || acc.rows > 0xfffffff0ull)) bulk = false;
+        if (!bulk) return false;
+        n_work = acc.cnt; need_slots = seg->dir_used + acc.slots; cap_rows = acc.rows;
+        n_items = acc.items; postings = acc.postings; n_chunks = acc.chunks; n_groups = acc.groups;
+        rc_mid = size_and_reserve();
+        if (rc_mid != RGPU_OK) return false;
+        h_work = reinterpret_cast<PrepTerm*>(c->S->h_stage.p + o_work);
+        h_items = reinterpret_cast<int64_t*>(c->S->h_stage.p + o_items);
+        h_chunks = reinterpret_cast<int64_t*>(c->S->h_stage.p + o_chunks);
+        h_groups = reinterpret_cast<int64_t*>(c->S->h_stage.p + o_groups);
+        added.resize(n_work);  // (left uninitialised: pass 2 writes every entry)
+        return true;
+      },
+      [&](int t) {  // pass 2: fill — descriptors and prefix arrays straight into the pinned staging memory
+        const auto range = rucene::part_range(n, n_parts, t);
+        const BulkPart& B = base[(size_t)t];
+        size_t j = B.cnt, slots = dir_used + B.slots;
+        int64_t items = B.items, chunks = B.chunks, groups = B.groups;
+        for (size_t i = range.first; i < range.second; ++i) {
+          const rgpu_term_state& ts = *sts[i];
+          if (ts.doc_freq < 2) continue;
+          const PlanOne o = plan_one(seg, ts, wide);
+          const PrepTerm p = prep_term_of(ts, o, slots, batch_bs, sink ? sink->out_base[i] : -1);
+          h_work[j] = p;
+          h_items[j] = items;
+          h_chunks[j] = chunks;
+          h_groups[j] = groups;
+          added[j] = PreparedEntry{ts.doc_start_fp, p.dir_base, p.df};
+          if (sink) (*sink->fused)[i] = 1;
+          ++j;
+          slots += (size_t)o.nblocks + 1;
+          items += o.items;
+          chunks += o.chunks;
+          groups += o.groups;
+        }
+      });
+    if (rc_mid != RGPU_OK) return rc_mid;
+    if (bulk) {
+      h_items[n_work] = n_items;
+      h_chunks[n_work] = n_chunks;
+      h_groups[n_work] = n_groups;
+      c->stats[(size_t)stat_slot(c, "prepare_bulk_plans")].launches += 1;  // (tests ask whether this path ran: rgpu_kernel_stats)
     }
-    const rgpu_term_state& st = *sts[i];
-    if (st.doc_freq < 2) {  // a singleton lives in the term dictionary; everything else has blocks and / or a tail
-      if (st.doc_freq < 0) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "negative doc_freq");
-      continue;
-    }
-    if (!none_prepared) {
-      if (const TermInfo* known = seg->prepared.find(st.doc_start_fp)) {
-        if (known->df != st.doc_freq) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "term state changed doc_freq for a known doc_start_fp");
+  }
+  if (!bulk) {
+    // Two tables stand between a term and the work list: "prepared already" and "named earlier in this call". A first touch in
+    // file order pays two DRAM round trips per term for answers that are known in advance — nothing is prepared yet, and while
+    // the doc_start_fps of the call ascend strictly no term can repeat: the second table is only built (from the work list) once
+    // one does not.
+    rucene::FlatFpMap<int> in_batch;
+    int64_t last_fp = -1;
+    if (n > 4096) { work.reserve(n); added.reserve(n); }
+    for (size_t i = 0; i < n; ++i) {
+      if (i + AHEAD < n) {
+        if (!none_prepared) seg->prepared.prefetch(sts[i + AHEAD]->doc_start_fp);
+        if (!ascending) in_batch.prefetch(sts[i + AHEAD]->doc_start_fp);
+      }
+      const rgpu_term_state& st = *sts[i];
+      if (st.doc_freq < 2) {  // a singleton lives in the term dictionary; everything else has blocks and / or a tail
+        if (st.doc_freq < 0) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "negative doc_freq");
         continue;
       }
-    }
-    int32_t rc = validate_state(seg, st);
-    if (rc != RGPU_OK) return rc;
-    if (ascending && st.doc_start_fp > last_fp) {
-      last_fp = st.doc_start_fp;
-    } else {
-      if (ascending) {  // the order broke: from here on (and for what came before) the table decides
-        ascending = false;
-        in_batch.reserve_more(n);
-        for (const auto& a : added) in_batch.put(a.first, 1);
+      if (!none_prepared) {
+        if (const TermInfo* known = seg->prepared.find(st.doc_start_fp)) {
+          if (known->df != st.doc_freq) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "term state changed doc_freq for a known doc_start_fp");
+          continue;
+        }
       }
-      if (in_batch.find(st.doc_start_fp)) continue;
-      in_batch.put(st.doc_start_fp, 1);
+      int32_t rc = validate_state(seg, st);
+      if (rc != RGPU_OK) return rc;
+      if (ascending && st.doc_start_fp > last_fp) {
+        last_fp = st.doc_start_fp;
+      } else {
+        if (ascending) {  // the order broke: from here on (and for what came before) the table decides
+          ascending = false;
+          in_batch.reserve_more(n);
+          for (const auto& a : added) in_batch.put(a.first, 1);
+        }
+        if (in_batch.find(st.doc_start_fp)) continue;
+        in_batch.put(st.doc_start_fp, 1);
+      }
+      const PlanOne o = plan_one(seg, st, wide);
+      if (o.rows > 0xffffffffull) return fail(RGPU_ERR_UNSUPPORTED, "a single term's postings exceed 64 GiB");
+      const PrepTerm p = prep_term_of(st, o, need_slots, batch_bs, sink ? sink->out_base[i] : -1);
+      if (sink) (*sink->fused)[i] = 1;
+      cap_rows += o.rows;
+      need_slots += (size_t)p.nblocks + 1;
+      if (need_slots > 0xfffffff0ull) return fail(RGPU_ERR_UNSUPPORTED, "block directory exceeds 2^32 slots");
+      work.push_back(p);
+      added.push_back(PreparedEntry{st.doc_start_fp, p.dir_base, p.df});
     }
-    PrepTerm p;
-    p.start_fp = (uint64_t)st.doc_start_fp;
-    p.df = st.doc_freq;
-    p.nblocks = st.doc_freq / 128;
-    p.n_entries = (st.doc_freq + 127) / 128 - 1;
-    p.n_levels = ilog8_levels(st.doc_freq);
-    p.skip_fp = st.doc_freq > 128 ? st.doc_start_fp + st.skip_offset : -1;
-    p.dir_base = (uint32_t)need_slots;
-    p.pn_base = 0;  // assigned when (if) the term's norms are prepared
-    // block store rows: a block's aligned copy is at most 28 bytes longer than its framing in the file (two
-    // header bytes dropped, each all-equal VInt padded to a 16-byte row); the FullBlocks end before the skip data
-    const uint64_t span = st.doc_freq > 128 ? (uint64_t)st.skip_offset : (p.nblocks ? 1026u : 0u);
-    // (a docs-only field: one header byte dropped, a synthetic 16-byte freq row added per block);
-    // + the decoded tail: 64 cells {doc, doc, freq, freq} behind the block rows
-    const uint64_t rows = (wide ? 64u * (uint64_t)p.nblocks : (span + (seg->has_freqs ? 28u : 32u) * (uint64_t)p.nblocks + 15u) / 16u) +
-                          ((st.doc_freq % 128) ? (uint64_t)TAIL_STORE_ROWS : 0u);
-    if (rows > 0xffffffffull) return fail(RGPU_ERR_UNSUPPORTED, "a single term's postings exceed 64 GiB");
-    p.bs_base = (uint64_t)batch_bs;  // dir_row counts from the call's first row for every one of its terms
-    p.bs_rows = (uint32_t)rows;
-    p.out_base = sink ? sink->out_base[i] : -1;
-    if (sink) (*sink->fused)[i] = 1;
-    cap_rows += rows;
-    need_slots += (size_t)p.nblocks + 1;
-    if (need_slots > 0xfffffff0ull) return fail(RGPU_ERR_UNSUPPORTED, "block directory exceeds 2^32 slots");
-    work.push_back(p);
-    added.push_back({st.doc_start_fp, TermInfo{p.dir_base, p.nblocks, p.df, 0, p.bs_base, seg->d_norms == nullptr}});
+    if (work.empty()) return RGPU_OK;
+    if (cap_rows > 0xfffffff0ull) return fail(RGPU_ERR_UNSUPPORTED, "one call prepares more than 64 GiB of block store: split the term list");
+    n_work = work.size();
+    // plans: (term, 1 KB chunk of level-0 skip bytes) for k_skip_dir; (term, chunk of blocks) for the block kernels
+    // (+ (term, SKIP_GROUP chunks) for k_skip_groups: terms of more than SKIP_GROUP chunks only, the others are zero-width in group_prefix)
+    chunk_prefix.resize(n_work + 1);
+    group_prefix.resize(n_work + 1);
+    prep_items(work, &item_prefix, &n_items, &postings);
+    for (size_t i = 0; i < n_work; ++i) {
+      const int64_t mine = skip_chunks(work[i].n_entries, seg->skip_vals);
+      chunk_prefix[i] = n_chunks;
+      group_prefix[i] = n_groups;
+      n_chunks += mine;
+      if (mine > SKIP_GROUP) n_groups += skip_groups(mine);
+    }
+    chunk_prefix[n_work] = n_chunks;
+    group_prefix[n_work] = n_groups;
+    const int32_t rc_size = size_and_reserve();
+    if (rc_size != RGPU_OK) return rc_size;
+    std::memcpy(c->S->h_stage.p + o_work, work.data(), n_work * sizeof(PrepTerm));
+    std::memcpy(c->S->h_stage.p + o_items, item_prefix.data(), item_prefix.size() * 8);
+    std::memcpy(c->S->h_stage.p + o_chunks, chunk_prefix.data(), chunk_prefix.size() * 8);
+    std::memcpy(c->S->h_stage.p + o_groups, group_prefix.data(), group_prefix.size() * 8);
   }
-  if (work.empty()) return RGPU_OK;
-  if (cap_rows > 0xfffffff0ull) return fail(RGPU_ERR_UNSUPPORTED, "one call prepares more than 64 GiB of block store: split the term list");
-  t_plan = hc.lap();
-  HIP_TRY(scratch_take(c));  // staging below; this function ends with a stream sync, so the slot is free again on return
-  HIP_TRY(seg->dir_last.reserve(need_slots, seg->dir_used, c->stream));
-  HIP_TRY(seg->dir_off.reserve(need_slots, seg->dir_used, c->stream));
-  HIP_TRY(seg->dir_row.reserve(need_slots, seg->dir_used, c->stream));
-  HIP_TRY(seg->bstore.reserve(batch_bs + (size_t)cap_rows * 16 + 1024, seg->bstore_used, c->stream));  // + over-read padding of the row loads
-  HIP_TRY(seg->dir_hdr.reserve(need_slots, seg->dir_used, c->stream));
-  HIP_TRY(seg->dir_bmax.reserve(need_slots, seg->dir_used, c->stream));
-  if (seg->has_positions) HIP_TRY(seg->dir_pos.reserve(need_slots, seg->dir_used, c->stream));
-  t_reserve = hc.lap();
-  // plans: (term, 1 KB chunk of level-0 skip bytes) for k_skip_dir; (term, chunk of blocks) for the block kernels
-  // (+ (term, SKIP_GROUP chunks) for k_skip_groups: terms of more than SKIP_GROUP chunks only, the others are zero-width in group_prefix)
-  std::vector<int64_t> item_prefix, chunk_prefix(work.size() + 1), group_prefix(work.size() + 1);
-  int64_t n_items = 0, postings = 0, n_chunks = 0, n_groups = 0;
-  prep_items(work, &item_prefix, &n_items, &postings);
-  for (size_t i = 0; i < work.size(); ++i) {
-    const int64_t mine = skip_chunks(work[i].n_entries, seg->skip_vals);
-    chunk_prefix[i] = n_chunks;
-    group_prefix[i] = n_groups;
-    n_chunks += mine;
-    if (mine > SKIP_GROUP) n_groups += skip_groups(mine);
-  }
-  chunk_prefix[work.size()] = n_chunks;
-  group_prefix[work.size()] = n_groups;
-  const size_t n_slots = need_slots - seg->dir_used;
-  const int64_t n_tiles = (int64_t)((n_slots + SCAN_TILE - 1) / SCAN_TILE);
-  Stager st(c);
-  const size_t o_work = st.add(work.size() * sizeof(PrepTerm));
-  const size_t o_items = st.add(item_prefix.size() * 8);
-  const size_t o_chunks = st.add(chunk_prefix.size() * 8);
-  const size_t o_groups = st.add(group_prefix.size() * 8);
-  HIP_TRY(c->S->h_stage.reserve(st.used));
-  HIP_TRY(c->S->d_stage.reserve(st.used, 0, c->stream));
-  std::memcpy(c->S->h_stage.p + o_work, work.data(), work.size() * sizeof(PrepTerm));
-  std::memcpy(c->S->h_stage.p + o_items, item_prefix.data(), item_prefix.size() * 8);
-  std::memcpy(c->S->h_stage.p + o_chunks, chunk_prefix.data(), chunk_prefix.size() * 8);
-  std::memcpy(c->S->h_stage.p + o_groups, group_prefix.data(), group_prefix.size() * 8);
   HIP_TRY(hipMemcpyAsync(c->S->d_stage.p, c->S->h_stage.p, st.used, hipMemcpyHostToDevice, c->stream));
   // device scratch: [-, total rows][chunk aggregates][group aggregates][level-0 starts][tile sums]
   const size_t o_aggs = 64, o_gaggs = o_aggs + (size_t)n_chunks * sizeof(SkipAgg), o_l0 = o_gaggs + (size_t)n_groups * sizeof(SkipAgg),
-               o_tiles = o_l0 + work.size() * 8;
+               o_tiles = o_l0 + n_work * 8;
   HIP_TRY(seg->prep_scratch.reserve(o_tiles + (size_t)n_tiles * 8 + 64, 0, c->stream));
   HIP_TRY(hipMemsetAsync(seg->prep_scratch.p, 0, 64, c->stream));
   HIP_TRY(hipMemsetAsync(c->d_err, 0, 4 * sizeof(int), c->stream));
@@ -660,19 +831,19 @@ static int32_t prepare_terms_attempt(rgpu_segment* seg, const rgpu_term_state* c
   {
     TimedLaunch tl(c, c->stream, "k_skip_dir", postings);
     const dim3 grid(wg_count((n_chunks + PREP_WAVES - 1) / PREP_WAVES));
-    RGPU_LAUNCH(k_skip_terms, dim3(wg_count((work.size() + PREP_THREADS - 1) / PREP_THREADS)), dim3(PREP_THREADS), 0, c->stream, seg->d_doc,
-                       (int64_t)seg->doc_len, d_work, (int)work.size(), d_l0, seg->dir_last.p, seg->dir_off.p,
+    RGPU_LAUNCH(k_skip_terms, dim3(wg_count((n_work + PREP_THREADS - 1) / PREP_THREADS)), dim3(PREP_THREADS), 0, c->stream, seg->d_doc,
+                       (int64_t)seg->doc_len, d_work, (int)n_work, d_l0, seg->dir_last.p, seg->dir_off.p,
                        seg->has_positions ? seg->dir_pos.p : nullptr, seg->skip_vals, c->d_err);
     if (n_chunks > 0) {  // the terms whose level 0 one lane does not finish
       auto pass = [&](auto kern) {
         RGPU_LAUNCH(kern, grid, dim3(PREP_THREADS), 0, c->stream, seg->d_doc, (int64_t)seg->doc_len, (int64_t)seg->doc_len + 8192,
-                           d_work, d_chunks, d_l0, (int)work.size(), n_chunks, d_aggs, d_groups, d_gaggs, seg->dir_last.p, seg->dir_off.p,
+                           d_work, d_chunks, d_l0, (int)n_work, n_chunks, d_aggs, d_groups, d_gaggs, seg->dir_last.p, seg->dir_off.p,
                            seg->has_positions ? seg->dir_pos.p : nullptr, c->d_err);
       };
       auto groups = [&](auto kern) {
         if (n_groups > 0)
           RGPU_LAUNCH(kern, dim3(wg_count((n_groups + PREP_WAVES - 1) / PREP_WAVES)), dim3(PREP_THREADS), 0, c->stream, d_chunks,
-                             d_groups, (int)work.size(), n_groups, d_aggs, d_gaggs);
+                             d_groups, (int)n_work, n_groups, d_aggs, d_gaggs);
       };
       switch (seg->skip_vals) {  // values per level-0 skip entry (prepare.hpp, A1)
         case 2: pass(k_skip_dir<1, 2>); groups(k_skip_groups<2>); pass(k_skip_dir<2, 2>); break;
@@ -686,7 +857,7 @@ static int32_t prepare_terms_attempt(rgpu_segment* seg, const rgpu_term_state* c
     TimedLaunch tl(c, c->stream, "k_block_headers", postings);
     auto go = [&](auto kern) {
       RGPU_LAUNCH(kern, dim3(wg_count((n_slots + PREP_THREADS - 1) / PREP_THREADS)), dim3(PREP_THREADS), 0, c->stream, seg->d_doc,
-                         (int64_t)seg->doc_len, d_work, (int)work.size(), (uint32_t)seg->dir_used, (int64_t)n_slots, seg->dir_last.p, seg->dir_off.p,
+                         (int64_t)seg->doc_len, d_work, (int)n_work, (uint32_t)seg->dir_used, (int64_t)n_slots, seg->dir_last.p, seg->dir_off.p,
                          seg->dir_row.p, seg->dir_hdr.p, seg->has_freqs ? 1 : 0, c->d_err);
     };
     if (legacy) go(k_block_headers<true>); else go(k_block_headers<false>);
@@ -701,7 +872,7 @@ static int32_t prepare_terms_attempt(rgpu_segment* seg, const rgpu_term_state* c
   {
     TimedLaunch tl(c, c->stream, "k_prepare_blocks", postings);
     auto go = [&](auto kern) {
-      RGPU_LAUNCH(kern, dim3(item_grid), dim3(PREP_THREADS), 0, c->stream, seg->d_doc, d_work, d_items, (int)work.size(), n_items,
+      RGPU_LAUNCH(kern, dim3(item_grid), dim3(PREP_THREADS), 0, c->stream, seg->d_doc, d_work, d_items, (int)n_work, n_items,
                          seg->dir_last.p, seg->dir_off.p, seg->dir_row.p, seg->dir_hdr.p, seg->bstore.p, seg->dir_bmax.p, seg->has_freqs ? 1 : 0,
                          seg->max_doc, c->d_err, sink ? sink->docs : (int32_t*)nullptr, sink ? sink->freqs : (int32_t*)nullptr);
     };
@@ -710,25 +881,26 @@ static int32_t prepare_terms_attempt(rgpu_segment* seg, const rgpu_term_state* c
   int err4[4] = {0, 0, 0, 0};
   unsigned long long total_rows = 0;
   t_enqueue = hc.lap();
-  hipError_t e_copy = hipMemcpyAsync(err4, c->d_err, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream);
-  if (e_copy == hipSuccess) e_copy = hipMemcpyAsync(&total_rows, d_total, 8, hipMemcpyDeviceToHost, c->stream);
   // The terms are filed as prepared WHILE the kernels run (the context's mutex is held: nobody looks before this call returns):
   // 152 k insertions into a table that is grown and first touched here — 2 to 6 ms of host time that used to follow the
   // 1.3 ms of kernels instead of hiding behind them. A failing call takes them back (remove_keys: a rebuild, the rare path).
   const bool as_bulk = ascending && added.size() >= 4096;  // file order, no repeats: the array itself is the index (PreparedMap)
   std::vector<int64_t> added_keys;
   if (as_bulk) {
-    seg->prepared.adopt_sorted(std::move(added));
+    seg->prepared.adopt_sorted(std::move(added), (uint64_t)batch_bs, seg->d_norms == nullptr);
   } else {
     added_keys.resize(added.size());
     seg->prepared.reserve_more(added.size());
     for (size_t i = 0; i < added.size(); ++i) {
       if (i + AHEAD < added.size()) seg->prepared.prefetch(added[i + AHEAD].first);
-      seg->prepared.put(added[i].first, added[i].second);
+      seg->prepared.put(added[i].first, PreparedMap::expand(added[i], (uint64_t)batch_bs, seg->d_norms == nullptr));
       added_keys[i] = added[i].first;
     }
   }
   t_commit = hc.lap();
+  // (behind the commit: a copy into pageable host memory returns when it is done, i.e. after the kernels)
+  hipError_t e_copy = hipMemcpyAsync(err4, c->d_err, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream);
+  if (e_copy == hipSuccess) e_copy = hipMemcpyAsync(&total_rows, d_total, 8, hipMemcpyDeviceToHost, c->stream);
   auto take_back = [&]() {
     if (as_bulk) seg->prepared.drop_bulk(); else seg->prepared.remove_keys(added_keys.data(), added_keys.size());
     if (sink) sink->fused->assign(n, 0);
@@ -751,8 +923,8 @@ static int32_t prepare_terms_attempt(rgpu_segment* seg, const rgpu_term_state* c
   seg->dir_used = need_slots;
   seg->bstore_used = batch_bs + (size_t)total_rows * 16;
   if (HostClock::on())
-    std::fprintf(stderr, "[prepare host] %zu terms: plan %lld us, reserve (hipMalloc / grow) %lld, plan chunks + stage + H2D %lld, enqueue %lld, commit (under the kernels) %lld, rest of kernels + sync %lld\n",
-                 work.size(), t_plan, t_reserve, t_stage, t_enqueue, t_commit, t_sync);
+    std::fprintf(stderr, "[prepare host] %zu terms (%s): plan %lld us, reserve (hipMalloc / grow) %lld, plan chunks + stage + H2D %lld, enqueue %lld, commit (under the kernels) %lld, kernels + sync %lld\n",
+                 n_work, bulk ? "bulk plan, host threads" : "one thread", t_plan, t_reserve, t_stage, t_enqueue, t_commit, t_sync);
   return RGPU_OK;
 }
 

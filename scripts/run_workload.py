@@ -49,7 +49,12 @@ elif kind == "cold":
         if r == 1:
             ctx.kernel_stats_reset()   # (the process's first launch carries the code object's load: ~3 ms inside k_skip_dir's events)
         leaf.segment.release_prepared_terms()
+        torch.cuda.synchronize()
+        import time
+        t0 = time.perf_counter()
         leaf.segment.decode_terms_device(sel, td.data_ptr(), tf.data_ptr())   # stage A of the preparation + the decode
+        torch.cuda.synchronize()
+        print("cold wall ms (decode_terms_device on a released store, %d terms): %.3f" % (sel.size, 1e3 * (time.perf_counter() - t0)))
         leaf.segment.prepare_terms(sel)                                       # + stage B (norms), what a search adds
     print("footprint", leaf.segment.footprint())
 elif kind == "decode":

@@ -246,3 +246,16 @@ def test_flat_fp_map_against_std_unordered_map(tmp_path):
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-o", exe, os.path.join(ROOT, "tests", "cpp", "flat_fp_map_test.cpp")])
     out = subprocess.check_output([exe], text=True)
     assert out.startswith("ok "), out
+
+
+def test_host_threads_count_then_fill(tmp_path):
+    """csrc/host/host_threads.hpp (the bulk planner's threads: a first touch of a whole term dictionary): tests/cpp/host_threads_test.cpp."""
+    exe = str(tmp_path / "host_threads_test")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-pthread", "-o", exe,
+                           os.path.join(ROOT, "tests", "cpp", "host_threads_test.cpp")])
+    for threads in ("1", "3", ""):
+        env = dict(os.environ)
+        if threads:
+            env["RGPU_HOST_THREADS"] = threads
+        out = subprocess.check_output([exe], text=True, env=env)
+        assert out.strip() == "host_threads OK", out

@@ -670,6 +670,69 @@ def test_prepared_terms_stay_inside_their_budget(oracle):
     assert e.value.status == -2
 
 
+def test_bulk_first_touch_planned_by_host_threads(oracle, monkeypatch):
+    """A first touch of a whole term dictionary (the cold path: rgpu_decode_terms on a fresh segment) is planned by several host
+    threads when it names >= 32768 new terms in file order (rgpu_api.hip prepare_terms_attempt: a counting pass and a filling pass
+    over contiguous ranges, host/host_threads.hpp). Same postings, same store, same search answers as the one-thread plan; a call
+    whose terms are NOT in file order (or repeat) takes the sequential loop and gives the same postings."""
+    import rucene_amd
+    from rucene_amd import indexgen
+    seg = indexgen.build_zipf(1_500_000, 400_000)
+    assert int((seg.terms["doc_freq"] >= 2).sum()) >= 100_000
+    oseg = oracle.Segment(seg.doc_bytes, seg.norms, seg.max_doc, seg.terms, sum_total_term_freq=seg.sum_total_term_freq)
+    starts = np.zeros(seg.terms.size + 1, np.int64)
+    starts[1:] = np.cumsum(seg.terms["doc_freq"])
+    results = {}
+    ctx2 = rucene_amd.Context(profile_kernels=True)
+    try:
+        for threads in ("1", "5", "8"):
+            monkeypatch.setenv("RGPU_HOST_THREADS", threads)
+            ctx2.kernel_stats_reset()
+            leaf = rucene_amd.LeafReader.from_synthetic(seg)
+            gsearcher = rucene_amd.GpuIndexSearcher([leaf], ctx=ctx2)
+            docs, freqs = leaf.segment.decode_terms(seg.terms)
+            bulk = ctx2.kernel_stats().get("prepare_bulk_plans", {"launches": 0})["launches"]
+            assert bulk == (0 if threads == "1" else 1), (threads, bulk)
+            fp = leaf.segment.footprint()
+            rng = np.random.default_rng(8)
+            ranks = np.concatenate([rng.integers(1, 2000, size=64), rng.integers(2000, 150_000, size=64)])
+            hits, totals = gsearcher.search_batch([rucene_amd.TermQuery(int(r)) for r in ranks] +
+                                                  [rucene_amd.BooleanQuery.build([rucene_amd.TermQuery(int(a)), rucene_amd.TermQuery(int(b))], [])
+                                                   for a, b in zip(ranks[:32], ranks[32:64])], 10)
+            results[threads] = (docs, freqs, {k: fp[k] for k in ("directory_bytes", "block_store_bytes")}, hits, totals)
+            if threads == "5":   # out of file order, with repeats: the sequential loop, whatever the thread count
+                ctx2.kernel_stats_reset()
+                leaf_b = rucene_amd.LeafReader.from_synthetic(seg)
+                rucene_amd.GpuIndexSearcher([leaf_b], ctx=ctx2)   # (creates the leaf's device segment)
+                order = np.random.default_rng(9).permutation(seg.terms.size)[:60_000]
+                order = np.concatenate([order, order[:100]])
+                d2, f2 = leaf_b.segment.decode_terms(seg.terms[order])
+                assert ctx2.kernel_stats().get("prepare_bulk_plans", {"launches": 0})["launches"] == 0
+                o = 0
+                for t in order:
+                    n = int(seg.terms["doc_freq"][t])
+                    if t % 53 == 0 or n > 5000:
+                        assert (d2[o:o + n] == docs[starts[t]:starts[t] + n]).all() and (f2[o:o + n] == freqs[starts[t]:starts[t] + n]).all(), t
+                    o += n
+                assert o == d2.size
+                leaf_b.segment.close()
+            leaf.segment.close()
+    finally:
+        ctx2.close()
+    d1, f1, fp1, h1, t1 = results["1"]
+    for threads in ("5", "8"):
+        d, f, fp, h, t = results[threads]
+        assert (d == d1).all() and (f == f1).all() and fp == fp1, threads
+        assert (h["doc"] == h1["doc"]).all() and (h["score"].view(np.int32) == h1["score"].view(np.int32)).all() and (t == t1).all(), threads
+    # ... and the postings themselves against the oracle's BlockDocIterator: every 211th term and every long one
+    for i in range(seg.terms.size):
+        n = int(seg.terms["doc_freq"][i])
+        if i % 211 == 0 or n > 20_000:
+            d, f = oseg.decode_term(seg.terms[i])
+            assert (d1[starts[i]:starts[i] + n] == d).all() and (f1[starts[i]:starts[i] + n] == f).all(), i
+    assert starts[-1] == d1.size
+
+
 def test_long_clause_lists(zipf, oracle):
     """Up to RGPU_MAX_QUERY_TERMS = 64 clauses per query (a clause's cursor lives in a lane): conjunctions bit-exact, disjunctions
     of more than 16 clauses through the clause-order kernel (heap-order rule), MUST_NOT and min_should_match next to them,
