@@ -9,6 +9,7 @@
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
+#include <exception>
 #include <new>
 #include <thread>
 #include <utility>
@@ -91,16 +92,30 @@ inline void two_pass_run(int n_parts, F1&& pass1, Mid&& mid, F2&& pass2) {
       inline_parts.push_back(t);
     }
   }
-  pass1(0);
-  for (int t : inline_parts) pass1(t);
+  // (whatever the calling thread's share throws — mid() sizes buffers — the workers are released and joined first)
+  std::exception_ptr thrown;
+  bool ok = false;
+  try {
+    pass1(0);
+    for (int t : inline_parts) pass1(t);
+  } catch (...) {
+    thrown = std::current_exception();
+  }
   while (done.load(std::memory_order_acquire) != (int)threads.size()) __builtin_ia32_pause();
-  const bool ok = mid();
+  if (!thrown) {
+    try { ok = mid(); } catch (...) { thrown = std::current_exception(); }
+  }
   go.store(ok ? 1 : -1, std::memory_order_release);
   if (ok) {
-    pass2(0);
-    for (int t : inline_parts) pass2(t);
+    try {
+      pass2(0);
+      for (int t : inline_parts) pass2(t);
+    } catch (...) {
+      thrown = std::current_exception();
+    }
   }
   for (auto& th : threads) th.join();
+  if (thrown) std::rethrow_exception(thrown);
 }
 
 // [begin, end) of part t when n items are dealt to n_parts contiguous ranges

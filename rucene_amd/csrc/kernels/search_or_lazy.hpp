@@ -42,7 +42,10 @@ constexpr int LZ_WAVES = 4;
 constexpr int LZ_THREADS = 64 * LZ_WAVES;
 constexpr int LZ_MAX_TERMS = 16;  // walked clauses (== RGPU_MAX_QUERY_TERMS)
 constexpr int LZ_MAX_LAZY = 6;    // bitmap clauses per query (register budget: two words per clause and step are held)
-constexpr int LZ_PREFETCH = 8;   // run heads requested at the start of a window (two VGPRs each)
+#ifndef RGPU_LZ_PREFETCH
+#define RGPU_LZ_PREFETCH 8
+#endif
+constexpr int LZ_PREFETCH = RGPU_LZ_PREFETCH;   // run heads requested at the start of a window (three VGPRs each: doc, next window's doc, score); 4 or 8
 constexpr int LZ_QUEUE = 128;     // candidate queue entries (up to 63 waiting + 64 pushed at once)
 constexpr int LZ_STEP_DOCS = 2048;  // one bitmap word per lane
 #ifndef RGPU_LZ_HIST_SHIFT

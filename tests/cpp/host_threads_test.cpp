@@ -90,6 +90,15 @@ int main() {
     std::atomic<int> first{0}, second{0};
     rucene::two_pass_run(parts, [&](int) { first++; }, [&]() { return false; }, [&](int) { second++; });
     CHECK(first == parts && second == 0);
+    // a mid() that throws: the workers are released and joined, the exception reaches the caller
+    bool caught = false;
+    std::atomic<int> ran{0};
+    try {
+      rucene::two_pass_run(parts, [&](int) { ran++; }, [&]() -> bool { throw std::bad_alloc(); }, [&](int) { second++; });
+    } catch (const std::bad_alloc&) {
+      caught = true;
+    }
+    CHECK(caught && ran == parts && second == 0);
   }
   if (failures == 0) std::printf("host_threads OK\n");
   return failures ? 1 : 0;
