@@ -68,6 +68,9 @@ __device__ __forceinline__ float table_score(const float* cache, uint32_t rank, 
   return cache[64 + rank * SCORE_TABLE_COLS + freq];
 }
 
+#ifndef RGPU_MERGE_AHEAD
+#define RGPU_MERGE_AHEAD 4  // lists of entering items requested together by k_merge_items (1: one after the other)
+#endif
 // ---- fold the per-item lists of each query: one wavefront per query --------------------------------------------
 // `head_items` > 0 selects the TERM kernel's item layout: item q is query q's first chunk and the query's other
 // chunks are items head_items + [item_prefix[q], item_prefix[q+1]); 0 = plain contiguous ranges.
@@ -104,12 +107,30 @@ __global__ __launch_bounds__(WG_THREADS) void k_merge_items(const int64_t* __res
     total += wave_reduce_add(ok ? partial_counts[mine] : 0);
     uint64_t m = __ballot(head > tau);
     while (m) {
-      const int src = __builtin_ctzll(m);
-      const uint64_t* pk = partial_keys + (size_t)item_at(g0 + src) * (size_t)k;
-      topk_offer<WIDE>(top, lane < k ? pk[lane] : 0ull, tau, k, lane);
-      if (WIDE) topk_offer<WIDE>(top, lane + 64 < k ? pk[lane + 64] : 0ull, tau, k, lane);
-      m &= m - 1;
-      m &= __ballot(head > tau);
+      // the lists of up to MERGE_AHEAD entering items are requested together (one list after the other was a chain of dependent
+      // round trips: 27 us per launch behind a 0.22 ms conjunction kernel); an item whose head has fallen behind the threshold
+      // by the time its turn comes offers keys that all stay outside — same rows either way
+      constexpr int MERGE_AHEAD = RGPU_MERGE_AHEAD;
+      uint64_t ka[MERGE_AHEAD], kb[MERGE_AHEAD];
+      uint64_t rest = m;
+#pragma unroll
+      for (int j = 0; j < MERGE_AHEAD; ++j) {
+        ka[j] = 0ull;
+        kb[j] = 0ull;
+        if (rest) {  // wave-uniform
+          const int src = __builtin_ctzll(rest);
+          rest &= rest - 1;
+          const uint64_t* pk = partial_keys + (size_t)item_at(g0 + src) * (size_t)k;
+          ka[j] = lane < k ? pk[lane] : 0ull;
+          if (WIDE) kb[j] = lane + 64 < k ? pk[lane + 64] : 0ull;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < MERGE_AHEAD; ++j) {
+        if (__ballot(ka[j] > tau)) topk_offer<WIDE>(top, ka[j], tau, k, lane);
+        if (WIDE && __ballot(kb[j] > tau)) topk_offer<WIDE>(top, kb[j], tau, k, lane);
+      }
+      m = rest & __ballot(head > tau);
     }
   }
   // qmap: the group's query q is the caller's row qmap[q] (queries are partitioned by op on the host) — the rows are
