@@ -31,6 +31,23 @@ __device__ unsigned long long g_term_dbg[4];
 #ifndef RGPU_TERM_EXCHANGE_MAX_ITEMS
 #define RGPU_TERM_EXCHANGE_MAX_ITEMS 16
 #endif
+// A query's items start together, each with an empty top-k list. The same batch with every item starting from its query's FINAL
+// threshold (a variant build that keeps the shared thresholds between launches): 0.041 ms against 0.072, 12 k blocks unpacked
+// against 71 k; 0.131 against 0.178 ms at 100 M docs — the price of not knowing the answer. RGPU_TERM_WAIT = 1 was the attempt to
+// buy some of that: the head item (the term's first blocks) publishes its k-th best key after its first 64 blocks and the query's
+// other items wait for that publication before they look at a block (s_sleep between polls of the query's threshold word, at most
+// RGPU_TERM_WAIT_POLLS of them: a bounded wait). Measured: 57.5 k blocks unpacked instead of 70.6 k and the SAME kernel time
+// (0.0722-0.0732 against 0.0711-0.0721 ms; shorter items do not pay either: 128 blocks per item 0.080 against 0.074) — a term's
+// ten best postings are spread over the whole list, the first 8192 postings say little about them. Off.
+#ifndef RGPU_TERM_WAIT
+#define RGPU_TERM_WAIT 0
+#endif
+#ifndef RGPU_TERM_WAIT_POLLS
+#define RGPU_TERM_WAIT_POLLS 48
+#endif
+#ifndef RGPU_TERM_WAIT_SLEEP
+#define RGPU_TERM_WAIT_SLEEP 16  // s_sleep argument: 64 cycles each
+#endif
 constexpr int TERM_EXCHANGE_MAX_ITEMS = RGPU_TERM_EXCHANGE_MAX_ITEMS;
 #ifndef RGPU_TERM_WAVES
 #define RGPU_TERM_WAVES 8
@@ -110,7 +127,7 @@ template <bool LEGACY, bool WIDE>
 __device__ __forceinline__ void term_blocks_fast(const SegView& seg, const DevTerm& T, int b0, int b1, uint8_t* slab,
                                                  const float* cache, float wk, int lane, const GroupList& group,
                                                  SharedTau& shared, uint64_t& floor, int k, int& count, bool prune, uint32_t& looked,
-                                                 uint32_t& touched, uint64_t ceil, bool exchange) {
+                                                 uint32_t& touched, uint64_t ceil, bool exchange, bool head) {
   constexpr int DEPTH = PREFETCH_DEPTH;
   const uint8_t* term_rows = seg.bstore + T.bs_base;
   const uint8_t* pn = seg.pnorm + T.pn_base;
@@ -309,7 +326,10 @@ __device__ __forceinline__ void term_blocks_fast(const SegView& seg, const DevTe
     // what this chunk achieved, for the query's other wavefronts (an atomic only when the group's k-th best has risen)
     {
       const int ci = ((c0 - b0) >> 6) + 1;
-      if (exchange && (RGPU_TERM_EXCHANGE == 1 || (RGPU_TERM_EXCHANGE == 2 && (ci & (ci - 1)) == 0))) shared.publish_key(group_kth<WIDE>(group, k), lane);
+      // (... and the query's head item after its first 64 blocks, whatever the query's size: its other items wait for exactly
+      // that — RGPU_TERM_WAIT in k_search_term)
+      const bool first_of_head = RGPU_TERM_WAIT && head && c0 == b0;
+      if (first_of_head || (exchange && (RGPU_TERM_EXCHANGE == 1 || (RGPU_TERM_EXCHANGE == 2 && (ci & (ci - 1)) == 0)))) shared.publish_key(group_kth<WIDE>(group, k), lane);
     }
   }
 #ifdef RGPU_EXP_COUNT
@@ -434,8 +454,18 @@ __global__ __launch_bounds__(TERM_THREADS, (LEGACY || WIDE) ? 7 : 8) void k_sear
     if (tabled && !has_live && nonneg) {
       // (the query's items: its head + the chunks behind it)
       const int q_items = 1 + (int)(item_prefix[q + 1] - item_prefix[q]);
-      term_blocks_fast<LEGACY, WIDE>(seg, T, b0, b1, slab, cache, wk, lane, group, shared, floor, k, count,
-                                     RGPU_TERM_PRUNE && (T.flags & TERM_FLAG_MONOTONE) != 0u, looked, touched, ceil, q_items <= TERM_EXCHANGE_MAX_ITEMS);
+      const bool prune = RGPU_TERM_PRUNE && (T.flags & TERM_FLAG_MONOTONE) != 0u;
+      if (RGPU_TERM_WAIT && prune && chunk != 0) {  // (wave-uniform) the head's first publication, or the time-out
+        uint64_t s2 = floor;
+        for (int i = 0; i < RGPU_TERM_WAIT_POLLS && s2 == 0ull; ++i) {
+          __builtin_amdgcn_s_sleep(RGPU_TERM_WAIT_SLEEP);
+          const uint64_t g = shared.peek();
+          s2 = ((uint64_t)(uint32_t)readfirstlane((int)(uint32_t)(g >> 32)) << 32) | (uint32_t)readfirstlane((int)(uint32_t)g);
+        }
+        shared.fold(s2, tau, floor);
+      }
+      term_blocks_fast<LEGACY, WIDE>(seg, T, b0, b1, slab, cache, wk, lane, group, shared, floor, k, count, prune, looked, touched, ceil,
+                                     q_items <= TERM_EXCHANGE_MAX_ITEMS, chunk == 0);
       if (b1 > b0) base = seg.dir_last[T.dir_base + b1 - 1];
     } else if (has_norms) {
       stream_blocks<LEGACY, true>(term_rows, seg.dir_row, seg.dir_hdr, T.dir_base, seg.pnorm + T.pn_base, b0, b1, slab, lane, base, on_block);

@@ -2726,6 +2726,13 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
     HIP_TRY(c->S->d_partial_keys.reserve((size_t)items * (size_t)k, 0, stream));
     HIP_TRY(c->S->d_partial_counts.reserve((size_t)items, 0, stream));
     unsigned long long* d_tau = reinterpret_cast<unsigned long long*>(c->S->d_stage.p + o_tau);
+#ifdef RGPU_EXP_KEEP_TAU  // developer experiment (variant builds only): a launch starts from the thresholds the previous launch of
+    {                     // the SAME batch ended with — what the kernel costs when every item knows its query's final k-th key
+      static unsigned long long* keep = nullptr;
+      if (!keep) { HIP_TRY(hipMalloc(&keep, (size_t)1 << 20)); HIP_TRY(hipMemset(keep, 0, (size_t)1 << 20)); }
+      if ((size_t)nq * 8 <= ((size_t)1 << 20)) d_tau = keep;
+    }
+#endif
     const DevQuery* dq = reinterpret_cast<const DevQuery*>(c->S->d_stage.p + o_q);
     const DevTerm* dt = reinterpret_cast<const DevTerm*>(c->S->d_stage.p + o_t);
     const int64_t* dp = reinterpret_cast<const int64_t*>(c->S->d_stage.p + o_p);

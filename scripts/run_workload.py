@@ -81,6 +81,8 @@ else:
     packed = s.pack_uniform({"term": 0, "and3": 1}.get(kind, 2), tids, leaf)
     for _ in range(reps + 2):
         hits, totals = leaf.segment.search_batch(packed[0], packed[1], k)
+    if kind in ("term", "and3"):
+        print("last launch decoded vs covered:", ctx.last_search_counters())
 import ctypes as _C
 _L = _C.CDLL(rucene_amd._lib.lib_path())
 if hasattr(_L, "rgpu_debug_counters"):
