@@ -1263,6 +1263,22 @@ extern "C" int32_t rgpu_segment_upload_field(rgpu_ctx* c, const uint8_t* doc_fil
     if ((e = hipMemcpyAsync(s->d_live, live_docs, words * 8, hipMemcpyHostToDevice, c->stream)) != hipSuccess) return bail(e, "copy live docs");
   }
   if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return bail(e, "sync");
+  // A large segment's prepared-term store is given its room here rather than by the first call that prepares terms: the first
+  // touch of a 100 M-doc segment's whole dictionary reserves ~0.8 GB of block store and seven directory arrays, and those
+  // hipMallocs were measured at 0.3-0.5 ms on most boxes and 15-20 ms on others — inside what a caller sees as the latency of its
+  // first decode. Best effort (a refused allocation is not an error: the arrays grow on demand as before), sized from the file:
+  // the aligned copy of a block is at most 28 bytes longer than its framing (prepare_terms_attempt: ~1.1 x the file in all), a
+  // directory slot per ~330 file bytes on the corpora seen; under a byte budget (prepared_budget_mib) the ceiling bounds it.
+  if (doc_len >= ((size_t)64 << 20)) {
+    size_t rows_bytes = doc_len + doc_len / 4;
+    size_t slots = doc_len / 256;
+    if (c->prepared_budget != 0) { rows_bytes = std::min(rows_bytes, c->prepared_budget); slots = std::min(slots, c->prepared_budget / 32); }
+    const bool roomy = s->bstore.reserve(rows_bytes, 0, c->stream) == hipSuccess && s->dir_last.reserve(slots, 0, c->stream) == hipSuccess &&
+                       s->dir_off.reserve(slots, 0, c->stream) == hipSuccess && s->dir_row.reserve(slots, 0, c->stream) == hipSuccess &&
+                       s->dir_hdr.reserve(slots, 0, c->stream) == hipSuccess && s->dir_bmax.reserve(slots, 0, c->stream) == hipSuccess &&
+                       (!s->has_positions || s->dir_pos.reserve(slots, 0, c->stream) == hipSuccess);
+    if (!roomy) (void)hipGetLastError();  // (out of memory is not sticky)
+  }
   *out_seg = s;
   return RGPU_OK;
 }
