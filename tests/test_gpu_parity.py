@@ -670,15 +670,18 @@ def test_prepared_terms_stay_inside_their_budget(oracle):
     assert e.value.status == -2
 
 
-def test_bulk_first_touch_planned_by_host_threads(oracle, monkeypatch):
+@pytest.mark.parametrize("positions", [False, True], ids=["docs_and_freqs", "positions_field"])
+def test_bulk_first_touch_planned_by_host_threads(oracle, monkeypatch, positions):
     """A first touch of a whole term dictionary (the cold path: rgpu_decode_terms on a fresh segment) is planned by several host
     threads when it names >= 32768 new terms in file order (rgpu_api.hip prepare_terms_attempt: a counting pass and a filling pass
     over contiguous ranges, host/host_threads.hpp). Same postings, same store, same search answers as the one-thread plan; a call
     whose terms are NOT in file order (or repeat) takes the sequential loop and gives the same postings."""
     import rucene_amd
     from rucene_amd import indexgen
-    seg = indexgen.build_zipf(1_500_000, 400_000)
-    assert int((seg.terms["doc_freq"] >= 2).sum()) >= 100_000
+    # (positions_field: the skip entries carry position pointers — four values per entry, a dir_pos word per directory slot)
+    seg = indexgen.build_zipf(600_000, 150_000, positions=True) if positions else indexgen.build_zipf(1_500_000, 400_000)
+    assert int((seg.terms["doc_freq"] >= 2).sum()) >= (40_000 if positions else 100_000)
+    make_leaf = rucene_amd.LeafReader.from_synthetic_positions if positions else rucene_amd.LeafReader.from_synthetic
     oseg = oracle.Segment(seg.doc_bytes, seg.norms, seg.max_doc, seg.terms, sum_total_term_freq=seg.sum_total_term_freq)
     starts = np.zeros(seg.terms.size + 1, np.int64)
     starts[1:] = np.cumsum(seg.terms["doc_freq"])
@@ -688,23 +691,23 @@ def test_bulk_first_touch_planned_by_host_threads(oracle, monkeypatch):
         for threads in ("1", "5", "8"):
             monkeypatch.setenv("RGPU_HOST_THREADS", threads)
             ctx2.kernel_stats_reset()
-            leaf = rucene_amd.LeafReader.from_synthetic(seg)
+            leaf = make_leaf(seg)
             gsearcher = rucene_amd.GpuIndexSearcher([leaf], ctx=ctx2)
             docs, freqs = leaf.segment.decode_terms(seg.terms)
             bulk = ctx2.kernel_stats().get("prepare_bulk_plans", {"launches": 0})["launches"]
             assert bulk == (0 if threads == "1" else 1), (threads, bulk)
             fp = leaf.segment.footprint()
             rng = np.random.default_rng(8)
-            ranks = np.concatenate([rng.integers(1, 2000, size=64), rng.integers(2000, 150_000, size=64)])
+            ranks = np.concatenate([rng.integers(1, 2000, size=64), rng.integers(2000, 50_000 if positions else 150_000, size=64)])
             hits, totals = gsearcher.search_batch([rucene_amd.TermQuery(int(r)) for r in ranks] +
                                                   [rucene_amd.BooleanQuery.build([rucene_amd.TermQuery(int(a)), rucene_amd.TermQuery(int(b))], [])
                                                    for a, b in zip(ranks[:32], ranks[32:64])], 10)
             results[threads] = (docs, freqs, {k: fp[k] for k in ("directory_bytes", "block_store_bytes")}, hits, totals)
             if threads == "5":   # out of file order, with repeats: the sequential loop, whatever the thread count
                 ctx2.kernel_stats_reset()
-                leaf_b = rucene_amd.LeafReader.from_synthetic(seg)
+                leaf_b = make_leaf(seg)
                 rucene_amd.GpuIndexSearcher([leaf_b], ctx=ctx2)   # (creates the leaf's device segment)
-                order = np.random.default_rng(9).permutation(seg.terms.size)[:60_000]
+                order = np.random.default_rng(9).permutation(seg.terms.size)[:40_000 if positions else 60_000]
                 order = np.concatenate([order, order[:100]])
                 d2, f2 = leaf_b.segment.decode_terms(seg.terms[order])
                 assert ctx2.kernel_stats().get("prepare_bulk_plans", {"launches": 0})["launches"] == 0
