@@ -63,8 +63,8 @@ typedef struct rgpu_segment rgpu_segment;
  * from a table entry in one and from a reciprocal in the other — totals may differ by a few steps of 2^-e, far inside 1e-5). */
 typedef struct rgpu_config {
   int32_t abi_version;          /* must be RGPU_ABI_VERSION */
-  int32_t blocks_per_item;      /* 128-posting blocks per wave work item in the TERM kernel (0 = auto: 8..512 by batch size) */
-  int32_t and_blocks_per_item;  /* lead blocks per wave work item of the AND kernel (0 = default 8) */
+  int32_t blocks_per_item;      /* 128-posting blocks per wave work item in the TERM kernel (0 = auto: 8..2048 by the batch's blocks) */
+  int32_t and_blocks_per_item;  /* lead blocks per wave work item of the AND kernel (0 = auto: 8..72, ~28 k items per launch) */
   int32_t profile_kernels;      /* 1 = bracket every kernel with HIP events from the start (see rgpu_set_profiling) */
   int32_t or_window_docs;       /* docs per wave window of the ordered OR kernel (0 = default 1024; 256..4096, rounded to 256) */
   int32_t or_dense_clauses;     /* OR: clauses decoded inside the window kernel instead of through a scored run
