@@ -248,6 +248,15 @@ def test_flat_fp_map_against_std_unordered_map(tmp_path):
     assert out.startswith("ok "), out
 
 
+def test_prepared_map_against_std_map(tmp_path):
+    """csrc/host/prepared_map.hpp (a segment's prepared-term table: flat map + the sorted array a bulk first touch leaves):
+    tests/cpp/prepared_map_test.cpp."""
+    exe = str(tmp_path / "prepared_map_test")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-pthread", "-o", exe,
+                           os.path.join(ROOT, "tests", "cpp", "prepared_map_test.cpp")])
+    assert subprocess.check_output([exe], text=True).strip() == "prepared_map OK"
+
+
 def test_host_threads_count_then_fill(tmp_path):
     """csrc/host/host_threads.hpp (the bulk planner's threads: a first touch of a whole term dictionary): tests/cpp/host_threads_test.cpp."""
     exe = str(tmp_path / "host_threads_test")
