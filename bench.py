@@ -453,6 +453,44 @@ def main():
         finally:
             ctx_d.close()
 
+    def no_sketch_leg(shard, k, steps, res):
+        """The single-term batch through a context opened with RGPU_TERM_SKETCH=0: no block-max sketches (kernels/search_term.hpp) —
+        every item of k_search_term starts without a threshold, as in rounds 2-4. Same planned steps on two alternating streams; the
+        rows must be those of the default context, bit for bit. Reported next to the headline so that what the sketches buy is on
+        the line, not in prose."""
+        os.environ["RGPU_TERM_SKETCH"] = "0"
+        try:
+            ctx_n = rucene_amd.Context(device=local_rank)
+        finally:
+            del os.environ["RGPU_TERM_SKETCH"]
+        try:
+            leaf = rucene_amd.LeafReader.from_synthetic(shard.seg)
+            sn = rucene_amd.GpuIndexSearcher([leaf], ctx=ctx_n)
+            tids = res["tids"]
+            lanes = [Lane(k), Lane(k)]
+
+            def one(i):
+                pk = sn.pack_uniform(OPS["term"], tids, leaf)
+                lane = lanes[i % 2]
+                leaf.segment.search_batch_device(pk[0], pk[1], k, lane.hits.data_ptr(), lane.totals.data_ptr(), lane.stream.cuda_stream)
+            for i in range(6):
+                one(i)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                one(i)
+            torch.cuda.synchronize()
+            ms = 1e3 * (time.perf_counter() - t0) / steps
+            last = lanes[(steps - 1) % 2]
+            g_hits = last.hits.cpu().numpy().view(rucene_amd.HIT_DTYPE).reshape(nq, k)
+            same = bool((g_hits["doc"] == res["g_hits"]["doc"]).all() and (g_hits["score"].view(np.int32) == res["g_hits"]["score"].view(np.int32)).all()
+                        and (last.totals.cpu().numpy() == res["g_totals"]).all())
+            leaf.segment.close()
+            return {"ms_per_step": ms, "queries_per_sec": nq / (ms * 1e-3), "same_rows_as_with_sketches": same,
+                    "issue": "RGPU_TERM_SKETCH=0: two alternating streams, every step planned"}
+        finally:
+            ctx_n.close()
+
     def search_config(shard, kind, steps, warmup, full, tag, cpu_budget, cpu_sample, parity_queries):
         """One search workload on one shard: throughput with planning in the timed region, the dominant kernel's roofline
         from what it touched, decoded vs covered postings, the CPU leg and parity."""
@@ -505,6 +543,8 @@ def main():
                                       "object planner = one Python query object per query flattened first (GpuIndexSearcher.pack), then the native planner")
         if kind == "or10" and world == 1 and not dist_mode:
             out["deferred"] = or_deferred_leg(shard, k, steps, r)
+        if kind == "term" and full and world == 1 and not dist_mode:
+            out["without_sketches"] = no_sketch_leg(shard, k, steps, r)
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             base, ok, info = cpu_baseline_leg(shard, kind, k, r, cpu_budget, cpu_sample, parity_queries)
             out["cpu_baseline"] = base
@@ -736,6 +776,10 @@ def main():
         "roofline": head["roofline"],
         "kernels_ms_isolated": head["kernels_ms_isolated"],
     }
+    if "without_sketches" in head:
+        out["without_sketches"] = head["without_sketches"]
+        out["without_sketches_queries_per_sec"] = head["without_sketches"]["queries_per_sec"]
+        out["without_sketches_same_rows"] = head["without_sketches"]["same_rows_as_with_sketches"]
     out["roofline"]["note"] = ("kernel_ms = average launch duration over K steps issued on one stream (HIP events; a separate pass, the timed "
                                "region carries no events). frac = bytes_per_launch (see bytes_are) / kernel_ms / peak. The north-star's >= 40 % "
                                "block-decode target is configs.block_decode / configs.cold / configs.out_of_cache")

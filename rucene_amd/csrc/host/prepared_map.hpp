@@ -11,7 +11,10 @@
 
 namespace rucene {
 
-struct TermInfo { uint32_t dir_base; int32_t nblocks; int32_t df; uint64_t pn_base; uint64_t bs_base; bool norms; };
+struct TermInfo {
+  uint32_t dir_base; int32_t nblocks; int32_t df; uint64_t pn_base; uint64_t bs_base; bool norms;
+  uint32_t sketch = 0;  // 1 + index of the term's block-max sketch (kernels/search_term.hpp), 0: none
+};
 
 // doc_start_fp -> TermInfo of the prepared terms (host/flat_fp_map.hpp: two look-ups per clause per batch).
 // A bulk first touch (every term of a segment's dictionary: 152 k at 100 M docs) used to end with 152 k insertions into a table

@@ -53,6 +53,10 @@ struct SegView {
   // bytes / offset words between its position deltas (decode.hpp decode_vint_block_everything)
   int32_t pos_tail_flags;
   int32_t pad_;
+  // Block-max sketches of the long terms single-term queries have named (search_term.hpp k_term_sketch): per sketch
+  // TERM_SKETCH_K entries `largest freq | norm rank << 4` — the (freq, rank) of a real posting of each of the term's K best blocks,
+  // best first (0: no such block). DevTerm::sketch points into it.
+  const uint16_t* sketch;
 };
 
 // One term as the kernels see it (built on the host from rgpu_term_state + the directory cache).
@@ -69,7 +73,7 @@ struct DevTerm {
   float weight;           // idf * boost
   int32_t sim_table;
   uint32_t flags;         // bit 0: the sim table's norm cache is non-increasing in the norm byte (block-max bounds hold)
-  uint32_t pad;
+  uint32_t sketch;        // 1 + index of the term's block-max sketch in SegView::sketch (TERM_SKETCH_K entries each); 0: none
 };
 constexpr uint32_t TERM_FLAG_MONOTONE = 1u;
 constexpr uint32_t TERM_FLAG_OR_DENSE = 2u;  // OR: this clause's FullBlocks are decoded inside the window kernel; only its tail runs through k_score_terms

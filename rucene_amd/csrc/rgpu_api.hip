@@ -188,6 +188,7 @@ struct rgpu_ctx {
   // (rgpu_synchronize, the collective of a sharded batch, rgpu_search_batch's copy to the host).
   std::vector<std::function<int32_t()>> pending_or;
   bool defer_or = false;  // set by the entry point for the duration of one call
+  bool term_sketches = true;  // block-max sketches for single-term queries (search_term.hpp); RGPU_TERM_SKETCH=0 in the environment turns them off (A/B, tests)
   DevVec<uint32_t> pos_counts;             // rgpu_decode_positions: positions per directory slot -> their exclusive prefix sums
   DevVec<unsigned long long> pos_tiles;    // ... the scan's tile sums (+ [0]: unused, [1]: the call's total)
   DevVec<int32_t> phrase_docs;             // phrase search: the conjunctions' matches (candidates), per query
@@ -263,6 +264,9 @@ struct rgpu_segment {
   int64_t bitmap_terms = 0, bitmap_refused = 0;  // terms that hold a bitmap / that were filed as "walk it" (budget, allocator, unusable list)
   uint8_t* empty_bitmap = nullptr;  // all-zero {any, hi} words + ranks: the one lazy clause of a query that has no dense term (k_or_lazy wants one)
   DevVec<uint8_t> prep_scratch;  // k_skip_dir's chunk aggregates + ticket, the prefix sum's tile sums
+  DevVec<uint16_t> sketch;       // block-max sketches of long terms (SegView::sketch), TERM_SKETCH_K entries each
+  size_t sketch_used = 0;        // sketches in use (TermInfo::sketch = 1 + index); dropped with the prepared terms
+  DevVec<SketchJob> sketch_jobs;
 };
 
 // ---- profiling helpers -----------------------------------------------------------------------------------------
@@ -384,6 +388,7 @@ static SegView seg_view(const rgpu_segment* s) {
   v.dir_bmax = s->dir_bmax.p;
   v.pos = s->d_pos;
   v.dir_pos = s->has_positions ? s->dir_pos.p : nullptr;
+  v.sketch = s->sketch_used ? s->sketch.p : nullptr;
   v.pos_tail_flags = (s->has_payloads ? POS_TAIL_PAYLOADS : 0) | (s->has_offsets ? POS_TAIL_OFFSETS : 0);
   v.pad_ = 0;
   v.sim_tables = s->ctx->sim_tables.p;
@@ -448,7 +453,7 @@ static int32_t prepare_norms_locked(rgpu_segment* seg, const rgpu_term_state* co
 // posting-order norms)
 static size_t prepared_store_bytes(const rgpu_segment* seg) {
   const size_t per_slot = 4 + 4 + 4 + 2 + 8 + (seg->has_positions ? 8 : 0);  // dir_last, dir_off, dir_row, dir_hdr, dir_bmax (, dir_pos)
-  return seg->dir_used * per_slot + seg->bstore_used + seg->pnorm_used;
+  return seg->dir_used * per_slot + seg->bstore_used + seg->pnorm_used + seg->sketch_used * (size_t)TERM_SKETCH_K * 2;
 }
 // rgpu_config.prepared_budget_mib: a store over its ceiling is dropped as a whole BEFORE the arriving batch is planned — the
 // batch then prepares what it names, like a first touch (a few hundred microseconds per thousand terms; k_prepare_blocks moves
@@ -463,7 +468,7 @@ static int32_t enforce_prepared_budget(rgpu_segment* seg) {
   for (auto& sc : c->scr) sc.busy = false;
   for (auto& cs : c->ceil_slots) cs.busy = false;
   seg->prepared.clear();
-  seg->dir_used = seg->bstore_used = seg->pnorm_used = 0;  // the arrays keep their capacity and are refilled from the start
+  seg->dir_used = seg->bstore_used = seg->pnorm_used = seg->sketch_used = 0;  // the arrays keep their capacity and are refilled from the start
   c->stats[(size_t)stat_slot(c, "prepared_store_evictions")].launches += 1;  // (read by tests / callers through rgpu_kernel_stats)
   return RGPU_OK;
 }
@@ -948,6 +953,7 @@ static int32_t make_dev_term(const rgpu_segment* seg, const rgpu_term_state& st,
     t.nblocks = info->nblocks;
     t.pn_base = info->pn_base;
     t.bs_base = info->bs_base;
+    t.sketch = info->sketch;
   }
   t.tail_n = st.doc_freq > 1 ? st.doc_freq % 128 : 0;
   *out = t;
@@ -991,6 +997,7 @@ extern "C" int32_t rgpu_init(int32_t device_ordinal, const rgpu_config* cfg, rgp
   // MI355X's 288), and a term past it stays a walked clause (ensure_bitmaps_locked)
   c->bitmap_budget = c->cfg.bitmap_budget_mib > 0 ? (size_t)c->cfg.bitmap_budget_mib << 20 : (size_t)prop.totalGlobalMem / 8;
   c->prepared_budget = c->cfg.prepared_budget_mib > 0 ? (size_t)c->cfg.prepared_budget_mib << 20 : 0;
+  if (const char* e = std::getenv("RGPU_TERM_SKETCH")) c->term_sketches = std::atoi(e) != 0;
   std::snprintf(c->name, sizeof c->name, "%s (%s)", prop.name, prop.gcnArchName);
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipMalloc(&c->d_err, 4 * sizeof(int)) != hipSuccess) {
     delete c;
@@ -1228,7 +1235,7 @@ extern "C" void rgpu_segment_free(rgpu_segment* s) {
   if (s->d_rank_to_norm) (void)hipFree(s->d_rank_to_norm);
   if (s->d_live) (void)hipFree(s->d_live);
   if (s->d_pos) (void)hipFree(s->d_pos);
-  s->dir_last.release(); s->dir_off.release(); s->dir_row.release(); s->dir_hdr.release(); s->dir_bmax.release(); s->dir_pos.release(); s->pnorm.release(); s->bstore.release(); s->prep_scratch.release();
+  s->dir_last.release(); s->dir_off.release(); s->dir_row.release(); s->dir_hdr.release(); s->dir_bmax.release(); s->dir_pos.release(); s->pnorm.release(); s->bstore.release(); s->prep_scratch.release(); s->sketch.release(); s->sketch_jobs.release();
   for (void* b : s->bitmap_allocs) (void)hipFree(b);
   s->ctx->bitmap_bytes -= std::min(s->ctx->bitmap_bytes, s->bitmap_bytes);
   if (s->empty_bitmap) (void)hipFree(s->empty_bitmap);
@@ -1246,7 +1253,7 @@ extern "C" int32_t rgpu_segment_get_footprint(rgpu_segment* seg, rgpu_segment_fo
   out->norms_bytes = seg->d_norms ? (int64_t)seg->max_doc : 0;
   out->live_docs_bytes = seg->d_live ? (int64_t)(((size_t)seg->max_doc + 63) / 64 * 8) : 0;
   out->positions_file_bytes = (int64_t)seg->pos_len;
-  out->directory_bytes = (int64_t)seg->dir_used * (4 + 4 + 4 + 2 + 8 + (seg->has_positions ? 8 : 0));
+  out->directory_bytes = (int64_t)seg->dir_used * (4 + 4 + 4 + 2 + 8 + (seg->has_positions ? 8 : 0)) + (int64_t)seg->sketch_used * TERM_SKETCH_K * 2;
   out->block_store_bytes = (int64_t)seg->bstore_used;
   out->posting_norms_bytes = seg->d_norms ? (int64_t)seg->pnorm_used : 0;
   out->prepared_terms = (int64_t)seg->prepared.size();
@@ -1266,7 +1273,7 @@ extern "C" int32_t rgpu_segment_release_prepared_terms(rgpu_segment* seg) {
   for (auto& sc : c->scr) sc.busy = false;
   for (auto& cs : c->ceil_slots) cs.busy = false;
   seg->prepared.clear();
-  seg->dir_used = seg->bstore_used = seg->pnorm_used = 0;  // the arrays keep their capacity and are refilled from the start
+  seg->dir_used = seg->bstore_used = seg->pnorm_used = seg->sketch_used = 0;  // the arrays keep their capacity and are refilled from the start
   for (void* b : seg->bitmap_allocs) (void)hipFree(b);
   seg->bitmap_allocs.clear();
   seg->bitmaps.clear();
@@ -2343,6 +2350,32 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
   cs.busy = true;
   return rc;
 }
+// k_term_sketch for the listed terms (ctx mutex held), on the stream the search itself is about to use; ends synchronised (a
+// one-off per term, ~10 us for a list of 15 k blocks). false: nothing was built (allocation, launch) — the queries do without.
+static bool build_sketches_locked(rgpu_segment* seg, const std::vector<SketchJob>& jobs, const std::vector<int64_t>& fps, hipStream_t stream) {
+  rgpu_ctx* c = seg->ctx;
+  const size_t need = seg->sketch_used + jobs.size();
+  auto gave_up = [&]() { (void)hipGetLastError(); return false; };
+  if (seg->sketch.reserve(std::max<size_t>(need, 4096) * TERM_SKETCH_K, seg->sketch_used * TERM_SKETCH_K, stream) != hipSuccess) return gave_up();
+  if (seg->sketch_jobs.reserve(jobs.size(), 0, stream) != hipSuccess) return gave_up();
+  if (hipMemcpyAsync(seg->sketch_jobs.p, jobs.data(), jobs.size() * sizeof(SketchJob), hipMemcpyHostToDevice, stream) != hipSuccess) return gave_up();
+  const size_t was = seg->sketch_used;
+  seg->sketch_used = need;  // (seg_view hands the array out from here on)
+  {
+    TimedLaunch tl(c, stream, "k_term_sketch", 0);
+    RGPU_LAUNCH(k_term_sketch, dim3(wg_count((jobs.size() + TERM_SKETCH_WAVES - 1) / TERM_SKETCH_WAVES)), dim3(64 * TERM_SKETCH_WAVES), 0, stream,
+                seg_view(seg), seg->sketch_jobs.p, (int)jobs.size(), seg->sketch.p);
+  }
+  if (hipStreamSynchronize(stream) != hipSuccess || launch_status() != hipSuccess) { seg->sketch_used = was; return gave_up(); }
+  for (size_t i = 0; i < jobs.size(); ++i) {
+    const TermInfo* at = seg->prepared.find(fps[i]);
+    if (!at) continue;
+    TermInfo info = *at;
+    info.sketch = jobs[i].out + 1u;
+    seg->prepared.put(fps[i], info);
+  }
+  return true;
+}
 static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t n_queries, const rgpu_query_term* terms,
                            int32_t n_terms_total, int32_t k, int32_t k_total, HitOut* hits_dev, int64_t* totals_dev, hipStream_t stream) {
   rgpu_ctx* c = seg->ctx;
@@ -2420,6 +2453,32 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
       }
     }
     if (!dense.empty()) { rc = ensure_bitmaps_locked(seg, dense.data(), dense_sim.data(), dense.size()); if (rc != RGPU_OK) return rc; }
+  }
+  // block-max sketches (search_term.hpp) for the long lists single-term queries name: built once per term, from the frontier words
+  // stage B left in the directory and the table of the query that names the term first. Like the bitmaps an accelerator, never a
+  // requirement: a failure to build one only means the query starts without a threshold.
+  if (c->term_sketches && seg->d_norms && seg->n_norm_ranks > 0 && !seg->d_live && c->n_sim_tables > 0) {
+    std::vector<SketchJob> jobs;
+    std::vector<int64_t> job_fp;
+    rucene::FlatFpMap<uint32_t> fresh;  // doc_start_fp -> 1 + sketch index, for the clauses of this call
+    for (int32_t q = 0; q < n_queries; ++q) {
+      const rgpu_query& Q = queries[q];
+      if ((Q.op & 0xff) != RGPU_OP_TERM || ((Q.op >> 16) & 0xff) != 0 || Q.n_must_not != 0) continue;
+      const rgpu_query_term& t = terms[Q.first_term];
+      const TermInfo& ti = tinfo[(size_t)Q.first_term];
+      if (t.state.doc_freq < 2 || ti.sketch != 0 || ti.nblocks < TERM_SKETCH_MIN_BLOCKS || fresh.find(t.state.doc_start_fp)) continue;
+      const uint32_t idx = (uint32_t)(seg->sketch_used + jobs.size());
+      jobs.push_back(SketchJob{ti.dir_base, ti.nblocks, t.sim_table, idx});
+      job_fp.push_back(t.state.doc_start_fp);
+      fresh.put(t.state.doc_start_fp, idx + 1u);
+    }
+    if (!jobs.empty() && build_sketches_locked(seg, jobs, job_fp, stream)) {
+      for (int32_t q = 0; q < n_queries; ++q) {
+        const rgpu_query& Q = queries[q];
+        if ((Q.op & 0xff) != RGPU_OP_TERM) continue;
+        if (const uint32_t* at = fresh.find(terms[Q.first_term].state.doc_start_fp)) tinfo[(size_t)Q.first_term].sketch = *at;
+      }
+    }
   }
 
   HOST_STAMP(p1);
@@ -2532,8 +2591,9 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
     G.queries.push_back(dq);
   }
 
+  HOST_STAMP(p2);
 #ifdef RGPU_LZ_TIME
-  { HOST_STAMP(p2); std::fprintf(stderr, "[search_pass host] validate + prepare + bitmaps %lld us, grouping %lld us\n", HOST_US(p0, p1), HOST_US(p1, p2)); }
+  std::fprintf(stderr, "[search_pass host] validate + prepare + bitmaps %lld us, grouping %lld us\n", HOST_US(p0, p1), HOST_US(p1, p2));
 #endif
   // defaults for every query (groups overwrite their own rows) — not needed when one group holds the whole batch and
   // its merge writes every row (the usual serving case: two enqueues less per batch)
@@ -2774,6 +2834,9 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
     HIP_TRY(launch_status());
     HIP_TRY(scratch_mark(c, stream));  // no stream sync: the slot is waited for when it is taken again
   }
+#ifdef RGPU_LZ_TIME
+  { HOST_STAMP(p3); std::fprintf(stderr, "[search_pass host] items + staging + launches %lld us\n", HOST_US(p2, p3)); }
+#endif
   return RGPU_OK;
 }
 

@@ -736,6 +736,65 @@ def test_bulk_first_touch_planned_by_host_threads(oracle, monkeypatch, positions
     assert starts[-1] == d1.size
 
 
+def test_block_max_sketches_give_the_same_rows(oracle, monkeypatch):
+    """Block-max sketches (kernels/search_term.hpp: k_term_sketch): a single-term query over a long list starts from the k-th best
+    of the term's K best blocks' "largest-freq posting" scores — k real postings of k blocks, so a valid threshold before a block
+    is unpacked. Same rows, bit for bit, as a context opened with RGPU_TERM_SKETCH=0 and as the oracle; fewer blocks unpacked; a
+    sketch built under ONE similarity's table is still a valid threshold under another; deep pages (k > 128: passes below a
+    ceiling) and a released store work; the sketches are part of the directory's footprint."""
+    import rucene_amd
+    from rucene_amd import indexgen
+    seg = indexgen.build_zipf(3_000_000, 100_000)
+    oseg = oracle.Segment(seg.doc_bytes, seg.norms, seg.max_doc, seg.terms, sum_total_term_freq=seg.sum_total_term_freq)
+    assert int((seg.terms["doc_freq"] >= 64 * 128).sum()) >= 40   # lists of 64 blocks or more
+    rng = np.random.default_rng(21)
+    ranks = np.concatenate([np.arange(1, 41), rng.integers(41, 3000, size=88)])   # long lists and short ones
+    T = rucene_amd.TermQuery
+    queries = [T(int(r)) for r in ranks]
+    specs = [(oracle.OP_TERM, [int(r)]) for r in ranks]
+    rows = {}
+    for sketches in (True, False):
+        if not sketches:
+            monkeypatch.setenv("RGPU_TERM_SKETCH", "0")
+        ctx2 = rucene_amd.Context(profile_kernels=True)
+        monkeypatch.delenv("RGPU_TERM_SKETCH", raising=False)
+        try:
+            leaf = rucene_amd.LeafReader.from_synthetic(seg)
+            gsearcher = rucene_amd.GpuIndexSearcher([leaf], ctx=ctx2)
+            out = {}
+            for k in (10, 64, 100, 128, 300):
+                out[k] = gsearcher.search_batch(queries, k)
+                if k == 10:
+                    out["blocks"] = ctx2.last_search_counters()["blocks_decoded"]
+                    fp = leaf.segment.footprint()
+                    out["dir_bytes"] = fp["directory_bytes"]
+            built = ctx2.kernel_stats().get("k_term_sketch", {"launches": 0})["launches"]
+            assert (built >= 1) == sketches, (sketches, built)
+            if sketches:
+                # the oracle's rows (canonical ties), k = 10 and a deep page
+                _check_against_oracle(oracle, oracle.Searcher([oseg]), gsearcher, specs, 10)
+                _check_against_oracle(oracle, oracle.Searcher([oseg]), gsearcher, specs[:48], 300)
+                # another similarity: its own sim table, the sketches stay the ones built under the first
+                other = rucene_amd.GpuIndexSearcher([leaf], ctx=ctx2, similarity=rucene_amd.BM25Similarity(k1=2.0, b=0.3))
+                before = ctx2.kernel_stats().get("k_term_sketch", {"launches": 0})["launches"]
+                _check_against_oracle(oracle, oracle.Searcher([oseg], k1=2.0, b=0.3), other, specs, 10)
+                assert ctx2.kernel_stats().get("k_term_sketch", {"launches": 0})["launches"] == before
+                # a released store: the sketches go with the prepared terms and come back with the next batch
+                leaf.segment.release_prepared_terms()
+                again = gsearcher.search_batch(queries, 10)
+                assert (again[0]["doc"] == out[10][0]["doc"]).all() and (again[1] == out[10][1]).all()
+                assert ctx2.kernel_stats()["k_term_sketch"]["launches"] > before
+            rows[sketches] = out
+            leaf.segment.close()
+        finally:
+            ctx2.close()
+    for k in (10, 64, 100, 128, 300):
+        (h1, t1), (h0, t0) = rows[True][k], rows[False][k]
+        assert (h1["doc"] == h0["doc"]).all() and (h1["score"].view(np.int32) == h0["score"].view(np.int32)).all() and (t1 == t0).all(), k
+    assert rows[True]["blocks"] * 2 < rows[False]["blocks"], (rows[True]["blocks"], rows[False]["blocks"])
+    assert rows[True]["dir_bytes"] > rows[False]["dir_bytes"]   # 256 B per sketched term
+
+
 def test_long_clause_lists(zipf, oracle):
     """Up to RGPU_MAX_QUERY_TERMS = 64 clauses per query (a clause's cursor lives in a lane): conjunctions bit-exact, disjunctions
     of more than 16 clauses through the clause-order kernel (heap-order rule), MUST_NOT and min_should_match next to them,
