@@ -30,6 +30,7 @@ out of the Infinity Cache on a 100M-doc shard. `--configs none` skips them.
 import argparse
 import glob
 import json
+import gc
 import os
 import re
 import sys
@@ -240,6 +241,9 @@ def main():
             if dist_mode:
                 dist.barrier()
             torch.cuda.synchronize()
+            # (K = 20 steps of 0.06 ms are a 1.3 ms region: one collection of the interpreter's garbage inside it is a fifth of it)
+            gc.collect()
+            gc.disable()
             t = time.perf_counter()
             for _ in range(n_steps):
                 if replan == "objects":
@@ -254,6 +258,7 @@ def main():
                 dist.barrier()
             torch.cuda.synchronize()
             el = time.perf_counter() - t
+            gc.enable()
             if dist_mode:
                 tt = torch.tensor([el], dtype=torch.float64)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -261,13 +266,13 @@ def main():
             return 1e3 * el / n_steps
 
         res = {"tids": tids, "postings": postings, "algo_bytes": algo_bytes}
-        # untimed, in front of everything: ~20 ms of the workload itself, so that the first timed region (W warmup steps + K steps
+        # untimed, in front of everything: 15-20 ms of the workload itself, so that the first timed region (W warmup steps + K steps
         # can be 2 ms in all) does not start on a GPU that is still raising its clocks — the same batch measured 0.076 ms per step
         # as the first thing a process did and 0.064 a few seconds later
-        t_warm = time.perf_counter()
-        while time.perf_counter() - t_warm < 0.02:
+        # (a fixed number of steps, not a time: with N > 1 every step is a collective, and the ranks must make the same calls)
+        for _ in range({"term": 256, "and3": 64}.get(kind, 4)):
             step(packed, 2)
-            torch.cuda.synchronize()
+        torch.cuda.synchronize()
         res["ms_planned_two_streams"] = timed(2, "array")
         res["ms_planned_one_stream"] = timed(1, "array")
         if full:
