@@ -349,9 +349,13 @@ class GpuIndexSearcher {
   // DefaultIndexSearcher::new(reader, next_limit) (searcher.rs:291-296): approximations a two-phase scorer (a sloppy phrase)
   // may spend on a leaf without a collected doc before the leaf is abandoned; 0 = the reference's default of 500 000, -1 = none
   int32_t next_limit = 0;
-  GpuIndexSearcher(std::vector<LeafReader> leaves, const BM25Similarity& sim = BM25Similarity(), int device = 0)
+  // `config`: the library's knobs (rgpu_config: byte budgets for the doc bitmaps and the prepared-term store, enqueue-only
+  // disjunction batches, work partitioning ...); null = the defaults. abi_version is filled in here.
+  GpuIndexSearcher(std::vector<LeafReader> leaves, const BM25Similarity& sim = BM25Similarity(), int device = 0,
+                   const rgpu_config* config = nullptr)
       : leaves_(std::move(leaves)), sim_(sim) {
     rgpu_config cfg{};
+    if (config) cfg = *config;
     cfg.abi_version = RGPU_ABI_VERSION;
     check(rgpu_init(device, &cfg, &ctx_));
     for (auto& l : leaves_) {
