@@ -43,7 +43,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 SEED_QUERIES = 0x527563656E65 ^ 0x51  # "Rucene" ^ purpose tag
-ROUND = "r05"
+ROUND = "r06"
 
 
 def term_encoded_bytes(terms, doc_len_end):
@@ -117,6 +117,130 @@ DOMINANT = {"term": "k_search_term", "and3": "k_search_and", "or10": "k_or_lazy"
 K_OF = {"term": 10, "and3": 10, "or10": 100}
 
 
+LINE_MAX_BYTES = 8000   # round 5's 25 KB line was not parsed by the driver (round 4's 19 KB one was); the contract keys need < 3 KB
+
+# scalars lifted from the full tree into the ONE stdout line: name -> path in the tree
+HOISTED = [
+    ("and3_queries_per_sec", "configs.and3.queries_per_sec"), ("and3_ms_per_step", "configs.and3.ms_per_step"),
+    ("and3_gpu_over_cpu", "configs.and3.gpu_over_cpu"), ("and3_roofline_frac", "configs.and3.roofline.frac"),
+    ("and3_kernel_ms", "configs.and3.roofline.kernel_ms"), ("and3_kernel_ms_suspect", "configs.and3.roofline.kernel_ms_suspect"),
+    ("and3_traffic_over_touched", "configs.and3.roofline.traffic_over_bytes"),
+    ("and3_parity_vs_oracle", "configs.and3.parity_vs_oracle"),
+    ("or10_queries_per_sec", "configs.or10.queries_per_sec"), ("or10_roofline_frac", "configs.or10.roofline.frac"),
+    ("or10_deferred_queries_per_sec", "configs.or10.deferred.queries_per_sec"),
+    ("or10_parity_vs_oracle", "configs.or10.parity_vs_oracle"), ("or10_docs_differing", "configs.or10.parity.docs_differing"),
+    ("block_decode_frac", "configs.block_decode.roofline.frac"), ("cold_frac", "configs.cold.roofline.frac"),
+    ("cold_scored_frac", "configs.cold.cold_scored.frac"), ("cold_wall_ms", "configs.cold.wall_ms_incl_host_planning"),
+    ("phrase2_queries_per_sec", "configs.positions.phrase2.queries_per_sec"), ("sloppy2_queries_per_sec", "configs.positions.sloppy2.queries_per_sec"),
+    ("phrase2_parity_vs_oracle", "configs.positions.phrase2.parity_vs_oracle"), ("sloppy2_parity_vs_oracle", "configs.positions.sloppy2.parity_vs_oracle"),
+    ("big_block_decode_frac", "configs.out_of_cache.block_decode.roofline.frac"), ("big_cold_frac", "configs.out_of_cache.cold.roofline.frac"),
+    ("big_cold_scored_frac", "configs.out_of_cache.cold.cold_scored.frac"),
+    ("big_term_queries_per_sec", "configs.out_of_cache.term.queries_per_sec"), ("big_term_roofline_frac", "configs.out_of_cache.term.roofline.frac"),
+    ("big_and3_queries_per_sec", "configs.out_of_cache.and3.queries_per_sec"), ("big_and3_roofline_frac", "configs.out_of_cache.and3.roofline.frac"),
+    ("big_and3_kernel_ms", "configs.out_of_cache.and3.roofline.kernel_ms"),
+    ("big_and3_traffic_over_touched", "configs.out_of_cache.and3.roofline.traffic_over_bytes"),
+    ("big_and3_parity_vs_oracle", "configs.out_of_cache.and3.parity_vs_oracle"),
+    ("big_or10_queries_per_sec", "configs.out_of_cache.or10.queries_per_sec"), ("big_or10_roofline_frac", "configs.out_of_cache.or10.roofline.frac"),
+    ("big_or10_parity_vs_oracle", "configs.out_of_cache.or10.parity_vs_oracle"), ("big_or10_parity_queries", "configs.out_of_cache.or10.parity.queries_checked"),
+    ("sharded_ratio_two_streams", "sharded_overhead.ratio_two_streams"), ("sharded_ratio_one_stream", "sharded_overhead.ratio_one_stream"),
+    ("sharded_forced_gather_ratio_two_streams", "sharded_overhead.forced_gather.ratio_two_streams"),
+    ("sharded_forced_gathers_issued", "sharded_overhead.forced_gather.gathers_issued"),
+    ("sharded_forced_gather_same_rows", "sharded_overhead.forced_gather.same_rows"),
+    ("one_stream_ms_per_step", "one_stream_ms_per_step"), ("resident_plan_ms_per_step", "streams.ms_resident_plan_two_streams"),
+    ("kernel_plus_merge_ms", "kernel_plus_merge_ms"), ("step_over_kernels", "step_over_kernels"),
+]
+LINE_REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                 "dtype", "data", "config", "roofline")
+
+
+def _dig(tree, path):
+    node = tree
+    for part in path.split("."):
+        if not isinstance(node, dict) or part not in node:
+            return None
+        node = node[part]
+    return node
+
+
+def _short(text, n):
+    text = str(text)
+    return text if len(text) <= n else text[:n - 3] + "..."
+
+
+def _num(v):
+    """floats at 5 significant digits: the line is read by people and a parser, the full precision lives in the detail file"""
+    if isinstance(v, bool) or not isinstance(v, float):
+        return v
+    return float("%.5g" % v)
+
+
+def final_line(full, detail_path="bench_detail.json"):
+    """The ONE stdout line of the contract, from the full result tree: the contract's keys, `roofline` and `cpu_baseline` as
+    small objects, the north-star's other targets as top-level scalars — and nothing else (the tree itself goes to
+    `detail_path` and to stderr). Guaranteed: strict JSON that round-trips, < LINE_MAX_BYTES."""
+    line = {}
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        line[key] = _num(full.get(key))
+    cfg = full.get("config", {})
+    line["config"] = {k: (_short(v, 160) if isinstance(v, str) else v) for k, v in cfg.items()
+                      if k in ("workload", "docs_per_shard", "vocab", "n_queries", "k", "doc_format", "parallelism", "device", "timed_regions", "issue")}
+    roof = full.get("roofline") or {}
+    line["roofline"] = {k: (_short(roof[k], 200) if isinstance(roof.get(k), str) else _num(roof.get(k)))
+                        for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "kernel_ms_suspect", "bytes_per_launch",
+                                  "bytes_are", "traffic_source") if k in roof}
+    if "cpu_baseline" in full:
+        cb = full["cpu_baseline"]
+        line["cpu_baseline"] = {"value": _num(cb.get("value")), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
+                                "sample": _short(cb.get("sample", ""), 240)}
+    if "parity" in full:
+        par = full["parity"]
+        line["parity"] = {"ok": full.get("parity_vs_oracle"), "queries_checked": par.get("queries_checked"), "queries_in_batch": par.get("queries_in_batch"),
+                          "sampled": par.get("sampled"), "rule": _short(par.get("rule", ""), 120)}
+    for key in ("queries_per_sec", "postings_decoded_per_sec", "postings_covered_per_sec", "gpu_over_cpu", "parity_vs_oracle", "ms_per_step_min_median_max",
+                "whole_index_docs", "whole_index_queries_per_sec", "without_sketches_queries_per_sec", "force_dist_same", "gathers_issued"):
+        if full.get(key) is not None:
+            v = full[key]
+            line[key] = [_num(x) for x in v] if isinstance(v, list) else _num(v)
+    lat = full.get("latency_batch_of_one")
+    if lat:
+        # [p50, p99] in us of rgpu_search_batch(n_queries = 1), host buffers, blocking; then the same with planning inside
+        line["latency_us_p50_p99"] = {kind: [_num(v["p50_us"]), _num(v["p99_us"])] for kind, v in lat.items() if isinstance(v, dict) and "p50_us" in v}
+        line["latency_planned_us_p50_p99"] = {kind: [_num(v["planned_p50_us"]), _num(v["planned_p99_us"])] for kind, v in lat.items() if isinstance(v, dict) and "planned_p50_us" in v}
+        line["latency_same_as_batch"] = all(v.get("same_as_batch", True) for v in lat.values() if isinstance(v, dict))
+    for name, path in HOISTED:
+        v = _dig(full, path)
+        if v is not None:
+            line[name] = _num(v)
+    line["detail"] = detail_path
+    text = json.dumps(line, allow_nan=False)
+    # never over the cap: the hoisted scalars go first (last one first), the contract keys stay
+    names = [n for n, _ in HOISTED if n in line]
+    while len(text.encode()) >= LINE_MAX_BYTES and names:
+        line.pop(names.pop())
+        line["truncated"] = True
+        text = json.dumps(line, allow_nan=False)
+    assert len(text.encode()) < LINE_MAX_BYTES, "the final line does not fit %d bytes" % LINE_MAX_BYTES
+    assert "\n" not in text and json.loads(text) == json.loads(json.dumps(line)), "the final line does not round-trip"
+    missing = [k for k in LINE_REQUIRED if k not in line or (line[k] is None and k != "vs_baseline")]
+    missing += ["roofline." + k for k in ("bound", "achieved", "peak", "unit", "frac", "traffic") if k not in line["roofline"]]
+    assert not missing, "the final line lacks %s" % missing
+    return text
+
+
+def _jsonable(o):
+    if isinstance(o, dict):
+        return {str(k): _jsonable(v) for k, v in o.items() if not str(k).startswith("_")}
+    if isinstance(o, (list, tuple)):
+        return [_jsonable(v) for v in o]
+    if isinstance(o, np.generic):
+        return o.item()
+    if isinstance(o, np.ndarray):
+        return o.tolist()
+    if isinstance(o, float) and (o != o or o in (float("inf"), float("-inf"))):
+        return None
+    return o
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -127,8 +251,10 @@ def main():
     ap.add_argument("--queries", type=int, default=1024)
     ap.add_argument("--k", type=int, default=0, help="0 = the workload's own (10; 100 for or10)")
     ap.add_argument("--workload", choices=["term", "and3", "or10"], default="term")
-    ap.add_argument("--configs", default="all", help="all | none | comma list of and3,or10,block_decode,cold,positions,out_of_cache (N > 1: and3 only)")
+    ap.add_argument("--configs", default="all", help="all | none | comma list of and3,or10,latency,block_decode,cold,positions,out_of_cache (N > 1: and3 only)")
     ap.add_argument("--big-docs", type=int, default=100_000_000, help="size of the out-of-cache shard")
+    ap.add_argument("--regions", type=int, default=5, help="timed regions of --steps steps per figure; the median region is reported")
+    ap.add_argument("--detail", default="", help="where the full result tree goes (default: bench_detail.json next to bench.py, and gpurun_out/ when present)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true",
                     help="developer check: take the N > 1 code path (RCCL all-gather + device merge) with a world of one")
@@ -226,7 +352,16 @@ def main():
             else:
                 shard.leaf.segment.search_batch_device(pk[0], pk[1], k, lane.hits.data_ptr(), lane.totals.data_ptr(), lane.stream.cuda_stream)
 
-        def timed(n_lanes, replan, n_steps=steps):
+        def timed(n_lanes, replan, n_steps=steps, regions=None):
+            """R timed regions of exactly n_steps steps each (every one bracketed by barrier + device synchronize on both
+            sides, warmup in front of the first): {"min", "median", "max"} ms per step. The figure reported is the MEDIAN
+            region — a region of K = 20 steps of 0.06 ms is 1.3 ms long, and one such region is box lottery."""
+            per = [timed_region(n_lanes, replan, n_steps, warmup if r == 0 else 1) for r in range(regions or args.regions)]
+            per.sort()
+            return {"min": per[0], "median": per[len(per) // 2] if len(per) & 1 else 0.5 * (per[len(per) // 2 - 1] + per[len(per) // 2]),
+                    "max": per[-1], "regions": len(per), "steps_per_region": n_steps}
+
+        def timed_region(n_lanes, replan, n_steps, n_warm):
             qs = None
             if replan == "objects":
                 if kind == "term":
@@ -235,7 +370,7 @@ def main():
                     qs = [B.build([T(int(x)) for x in t], []) for t in tids]
                 else:
                     qs = [B.build([], [T(int(x)) for x in t]) for t in tids]
-            for _ in range(warmup):
+            for _ in range(n_warm):
                 step(packed, n_lanes)
             torch.cuda.synchronize()
             if dist_mode:
@@ -273,12 +408,13 @@ def main():
         for _ in range({"term": 256, "and3": 64}.get(kind, 4)):
             step(packed, 2)
         torch.cuda.synchronize()
-        res["ms_planned_two_streams"] = timed(2, "array")
-        res["ms_planned_one_stream"] = timed(1, "array")
+        res["regions"] = {"ms_planned_two_streams": timed(2, "array"), "ms_planned_one_stream": timed(1, "array")}
         if full:
-            res["ms_resident_plan_two_streams"] = timed(2, False)
-            res["ms_resident_plan_one_stream"] = timed(1, False)
-            res["ms_object_planner_one_stream"] = timed(1, "objects", max(3, steps // 4))
+            res["regions"]["ms_resident_plan_two_streams"] = timed(2, False)
+            res["regions"]["ms_resident_plan_one_stream"] = timed(1, False)
+            res["regions"]["ms_object_planner_one_stream"] = timed(1, "objects", max(3, steps // 4), 3)
+        for name, reg in res["regions"].items():
+            res[name] = reg["median"]
         # isolated kernel durations: the same steps on ONE stream with HIP events around every launch
         ctx.set_profiling(True)
         ctx.kernel_stats_reset()
@@ -286,9 +422,12 @@ def main():
             step(packed, 1)
         torch.cuda.synchronize()
         stats = ctx.kernel_stats()
-        res["kernels_ms"] = {n: s["total_ms"] / max(1, s["launches"]) for n, s in stats.items() if s["total_ms"] > 0}  # average per launch
-        res["kernels_ms_per_step"] = {n: s["total_ms"] / steps for n, s in stats.items() if s["total_ms"] > 0}
-        res["launches_per_step"] = {n: s["launches"] / steps for n, s in stats.items() if s["total_ms"] > 0}
+        # MEDIAN launch duration (rgpu_kernel_stat.median_ms): round 5's mean over K launches read 1.775 ms on the driver's box for a
+        # kernel rocprofv3 times at 0.228 ms — one stalled launch multiplies a mean
+        res["kernels_ms"] = {n: s["median_ms"] for n, s in stats.items() if s["timed_launches"] > 0}
+        res["kernels_ms_min_max_mean"] = {n: [s["min_ms"], s["max_ms"], s["total_ms"] / max(1, s["timed_launches"])] for n, s in stats.items() if s["timed_launches"] > 0}
+        res["launches_per_step"] = {n: s["launches"] / steps for n, s in stats.items() if s["timed_launches"] > 0}
+        res["kernels_ms_per_step"] = {n: s["median_ms"] * s["launches"] / steps for n, s in stats.items() if s["timed_launches"] > 0}
         res["counters"] = ctx.last_search_counters()   # of the last launch: what it decoded vs what its queries cover
         ctx.set_profiling(False)
         ctx.kernel_stats_reset()
@@ -423,6 +562,8 @@ def main():
         r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
              "traffic": traffic.get("bytes"), "traffic_source": traffic.get("source"), "kernel": kernel, "kernel_ms": kernel_ms,
              "bytes_per_launch": touched_bytes, "bytes_are": what, "frac_vs_measured_copy_6290": achieved / 6290.0}
+        if traffic.get("bytes") and touched_bytes > 0:
+            r["traffic_over_bytes"] = traffic["bytes"] / touched_bytes   # well above 1 = wasted re-reads
         if scan_bytes is not None and scan_bytes != touched_bytes:
             r["scan_bytes_per_launch"] = scan_bytes
             r["scan_equivalent_gbs"] = scan_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
@@ -513,7 +654,7 @@ def main():
                 leaf.segment.search_batch_device(pk[0], pk[1], k, lanes[0].hits.data_ptr(), lanes[0].totals.data_ptr(), lanes[0].stream.cuda_stream)
             torch.cuda.synchronize()
             st = ctx_n.kernel_stats()
-            kernel_ms = st["k_search_term"]["total_ms"] / max(1, st["k_search_term"]["launches"])
+            kernel_ms = st["k_search_term"]["median_ms"]
             blocks = ctx_n.last_search_counters()["blocks_decoded"]
             leaf.segment.close()
             return {"ms_per_step": ms, "queries_per_sec": nq / (ms * 1e-3), "same_rows_as_with_sketches": same,
@@ -532,7 +673,9 @@ def main():
         dom = DOMINANT[kind]
         c = r["counters"]
         kms = r["kernels_ms"].get(dom, 0.0)
+        reg = r["regions"]["ms_planned_two_streams" if two_wins else "ms_planned_one_stream"]
         out = {"workload": WORKLOAD_TEXT[kind], "k": k, "steps": steps, "ms_per_step": ms,
+               "ms_per_step_min_median_max": [reg["min"], reg["median"], reg["max"]], "timed_regions": reg["regions"],
                "queries_per_sec": nq / (ms * 1e-3),
                "postings_covered_per_step": r["postings"], "postings_decoded_per_step": c["postings_decoded"],
                "postings_decoded_per_sec": c["postings_decoded"] / (ms * 1e-3), "postings_covered_per_sec": r["postings"] / (ms * 1e-3),
@@ -564,11 +707,16 @@ def main():
                                        "touched bytes: encoded bytes + norms of every block the kernel unpacked (counted by the kernel) + 14 B of "
                                        "directory (row, header, frontier words) per block it looked at + 8 k B out")
             out["roofline"]["pruning"] = "%d of %d FullBlocks unpacked" % (c["blocks_decoded"], int((shard.seg.terms["doc_freq"][r["tids"].reshape(-1)] // 128).sum()))
+        # one isolated launch of the dominant kernel cannot take longer than a whole one-stream step that contains it (+ 20 % for the
+        # events' own cost): when it does, the event timing is off and the roofline says so instead of being believed
+        out["roofline"]["kernel_ms_min_max_mean"] = r["kernels_ms_min_max_mean"].get(dom)
+        out["roofline"]["kernel_ms_suspect"] = bool(kind != "or10" and kms > 1.2 * r["ms_planned_one_stream"])
         # the step cannot have moved its bytes faster than the memory system allows
         assert out["roofline"]["bytes_per_launch"] / (ms * 1e-3) / 1e9 <= HBM_PEAK_GBS, "bytes / ms_per_step exceeds the HBM peak"
         if full:
             out["streams"] = {k2: r[k2] for k2 in ("ms_planned_two_streams", "ms_planned_one_stream", "ms_resident_plan_two_streams",
                                                    "ms_resident_plan_one_stream", "ms_object_planner_one_stream")}
+            out["streams"]["min_median_max"] = {k2: [v["min"], v["median"], v["max"]] for k2, v in r["regions"].items()}
             out["streams"]["note"] = ("ms per step. planned = term ids -> rgpu_query_term[] redone in every step by the native planner behind the C ABI "
                                       "(rgpu_plan_uniform_ids: term states, BM25 weights, sim table) — the headline; resident plan = planned once; "
                                       "object planner = one Python query object per query flattened first (GpuIndexSearcher.pack), then the native planner")
@@ -604,7 +752,7 @@ def main():
         st = ctx.kernel_stats()["k_decode_terms"]
         ctx.set_profiling(False)
         ctx.kernel_stats_reset()
-        ms = st["total_ms"] / st["launches"]
+        ms = st["median_ms"]
         b = int(shard.enc[keep].sum()) + 8 * total
         del d_docs, d_freqs
         return {"postings": total, "kernel": "k_decode_terms", "kernel_ms": ms, "postings_decoded_per_sec": total / (ms * 1e-3),
@@ -776,6 +924,68 @@ def main():
         leaf.segment.close()
         return out
 
+    def latency_leg(shard, kinds, n_sample):
+        """IndexSearcher::search(query, collector) is ONE query per call (search/searcher.rs:487-525): what rust/gpu/searcher.rs
+        try_gpu maps to rgpu_search_batch(n_queries = 1) with host buffers, blocking. Per workload: the first `n_sample` queries
+        of the bench batch, each as its own call, one after the other on an otherwise idle GPU — p50 / p99 / mean latency of the
+        call alone (plan resident) and of plan + call (rgpu_plan_uniform_ids for one query, then the search), and the q/s a
+        single caller thread gets that way. The rows of every call are compared with the same query's row of the 1024-query
+        batch (bit for bit; >= 10-clause OR: hit counts equal and scores within 1e-5 — the batch and the single call may take
+        different fixed-point kernels)."""
+        L = _lib.lib()
+        out = {}
+        for kind in kinds:
+            k = K_OF[kind]
+            tids = build_queries(nq, kind, SEED_QUERIES)[:n_sample]
+            plans = [shard.searcher.pack_uniform(OPS[kind], tids[i:i + 1], shard.leaf) for i in range(tids.shape[0])]
+            plans = [(np.ascontiguousarray(q, dtype=_lib.QUERY_DTYPE), np.ascontiguousarray(t, dtype=_lib.QUERY_TERM_DTYPE)) for q, t in plans]
+            hits = np.zeros((1, k), dtype=_lib.HIT_DTYPE)
+            totals = np.zeros(1, dtype=np.int64)
+            rows, tot = np.zeros((tids.shape[0], k), dtype=_lib.HIT_DTYPE), np.zeros(tids.shape[0], dtype=np.int64)
+            seg_h = shard.leaf.segment._h
+
+            def call(q, t):
+                rc = L.rgpu_search_batch(seg_h, q.ctypes.data, 1, t.ctypes.data, t.size, k, hits.ctypes.data, totals.ctypes.data)
+                if rc != 0:
+                    raise SystemExit("rgpu_search_batch(n_queries = 1) failed: %d" % rc)
+            for q, t in plans:   # untimed: every term of the sample prepared, every kernel variant loaded
+                call(q, t)
+            gc.collect()
+            gc.disable()
+            lat = np.empty(len(plans))
+            for i, (q, t) in enumerate(plans):
+                t0 = time.perf_counter()
+                call(q, t)
+                lat[i] = time.perf_counter() - t0
+                rows[i], tot[i] = hits[0], totals[0]
+            lat_p = np.empty(len(plans))
+            for i in range(len(plans)):
+                t0 = time.perf_counter()
+                q, t = shard.searcher.pack_uniform(OPS[kind], tids[i:i + 1], shard.leaf)
+                call(np.ascontiguousarray(q, dtype=_lib.QUERY_DTYPE), np.ascontiguousarray(t, dtype=_lib.QUERY_TERM_DTYPE))
+                lat_p[i] = time.perf_counter() - t0
+            gc.enable()
+            us = lambda a, pct: float(np.percentile(a, pct) * 1e6)
+            out[kind] = {"calls": int(lat.size), "k": k, "p50_us": us(lat, 50), "p99_us": us(lat, 99), "mean_us": float(lat.mean() * 1e6),
+                         "queries_per_sec_one_caller": float(1.0 / lat.mean()),
+                         "planned_p50_us": us(lat_p, 50), "planned_p99_us": us(lat_p, 99), "planned_mean_us": float(lat_p.mean() * 1e6),
+                         "_rows": rows, "_totals": tot}
+        return out
+
+    def latency_parity(lat, kind, batch_hits, batch_totals):
+        """a single-query call must answer what the same query answered inside the 1024-query batch"""
+        rows, tot = lat.pop("_rows"), lat.pop("_totals")
+        n = rows.shape[0]
+        same_tot = bool((tot == batch_totals[:n]).all())
+        if kind == "or10":
+            ok = same_tot and bool(np.allclose(rows["score"], batch_hits["score"][:n], rtol=1e-5, atol=0))
+            lat["same_as_batch_rule"] = "hit counts equal, scores within 1e-5 (fixed-point kernels)"
+        else:
+            ok = same_tot and bool((rows["doc"] == batch_hits["doc"][:n]).all()) and bool((rows["score"].view(np.int32) == batch_hits["score"][:n].view(np.int32)).all())
+            lat["same_as_batch_rule"] = "bit-exact doc ids, score bits, hit counts"
+        lat["same_as_batch"] = ok
+        return lat
+
     def strip(c):
         c.pop("_res", None)
         return c
@@ -801,8 +1011,10 @@ def main():
             "parallelism": "segment-sharded x%d, RCCL all-gather of per-shard top-k" % world,
             "postings_covered_per_step_per_shard": res["postings"], "postings_decoded_per_step_per_shard": head["postings_decoded_per_step"],
             "index_build_s": round(shard.build_s, 2), "segment_upload_s": round(shard.upload_s, 3), "device": ctx.device_name,
+            "timed_regions": "%d regions of %d steps, median region reported (min / median / max in ms_per_step_min_median_max)" % (head["timed_regions"], args.steps),
             "issue": "value = %s, every step plans its batch (native planner behind the C ABI) and enqueues it; inputs (index) resident in HBM" % head["issue"],
         },
+        "ms_per_step_min_median_max": head["ms_per_step_min_median_max"],
         "streams": head["streams"],
         "roofline": head["roofline"],
         "kernels_ms_isolated": head["kernels_ms_isolated"],
@@ -820,6 +1032,11 @@ def main():
     # the fraction at the headline's OPERATING POINT (two launches co-resident on alternating streams): the same bytes over the
     # step time — next to roofline.frac, which is one isolated launch (kernel_ms may exceed ms_per_step for that reason)
     out["roofline"]["frac_at_ms_per_step"] = out["roofline"]["bytes_per_launch"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS
+    # how far the step is from its kernels: dominant kernel + item merge (median launches) vs the planned step
+    kp = sum(v for n, v in head["kernels_ms_isolated"].items() if n in (DOMINANT[args.workload], "k_merge_items", "k_merge_lists"))
+    out["kernel_plus_merge_ms"] = kp
+    out["step_over_kernels"] = ms_per_step / kp if kp > 0 else None
+    out["step_over_kernels_one_stream"] = head["streams"]["ms_planned_one_stream"] / kp if kp > 0 else None
     out["one_stream_ms_per_step"] = head["streams"]["ms_planned_one_stream"]
     out["one_stream_queries_per_sec"] = nq / (head["streams"]["ms_planned_one_stream"] * 1e-3)
     # N > 1: the batch is replicated, so the ranks together answer nq queries over an index of world x docs — that rate next to
@@ -838,9 +1055,33 @@ def main():
         buffer, nothing to gather, the record merge) — the path's own overhead, measured on every N = 1 run (VERDICT r4 item 1:
         0.157 vs 0.093 ms before the in-place record). Planned steps on two alternating streams and on one, local vs sharded."""
         c1 = _lib.Comm(ctx, 1, 0, _lib.comm_unique_id())
+        # ... and with the collective REALLY issued (rgpu_config.comm_force_gather: the in-place ncclAllGather of a one-rank
+        # communicator + the cross-stream ordering around it) — a second context, since the knob is the context's
+        ctx_f = rucene_amd.Context(device=local_rank, comm_force_gather=True)
+        leaf_f = rucene_amd.LeafReader.from_synthetic(shard.seg)
+        sf = rucene_amd.GpuIndexSearcher([leaf_f], ctx=ctx_f)
+        sf.override_statistics(shard.searcher.collection_statistics, None)
+        cf = _lib.Comm(ctx_f, 1, 0, _lib.comm_unique_id())
+        cf.reserve(nq, k)
         tids = build_queries(nq, kind, SEED_QUERIES)
         lanes = [Lane(k), Lane(k)]
         res = {}
+        forced = {}
+        for n_lanes in (2, 1):
+            def onef(i):
+                pk = sf.pack_uniform(OPS[kind], tids, leaf_f)
+                lane = lanes[i % n_lanes]
+                cf.search_batch_sharded(leaf_f.segment, pk[0], pk[1], k, lane.hits.data_ptr(), lane.totals.data_ptr(), lane.stream.cuda_stream)
+            for i in range(6):
+                onef(i)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                onef(i)
+            torch.cuda.synchronize()
+            forced["sharded_ms_%s" % ("two_streams" if n_lanes == 2 else "one_stream")] = 1e3 * (time.perf_counter() - t0) / steps
+        forced["gathers_issued"] = cf.gathers_issued()
+        forced_rows = (lanes[(steps - 1) % 1].hits.clone(), lanes[(steps - 1) % 1].totals.clone())
         for name in ("local", "sharded"):
             for n_lanes in (2, 1):
                 def one(i):
@@ -867,7 +1108,16 @@ def main():
         res["ratio_two_streams"] = res["sharded_ms_two_streams"] / res["local_ms_two_streams"]
         res["ratio_one_stream"] = res["sharded_ms_one_stream"] / res["local_ms_one_stream"]
         res["workload"] = WORKLOAD_TEXT[kind]
+        forced["same_rows"] = bool(torch.equal(forced_rows[0], lanes[0].hits)) and bool(torch.equal(forced_rows[1], lanes[0].totals))
+        forced["ratio_two_streams"] = forced["sharded_ms_two_streams"] / res["local_ms_two_streams"]
+        forced["ratio_one_stream"] = forced["sharded_ms_one_stream"] / res["local_ms_one_stream"]
+        forced["note"] = "rgpu_config.comm_force_gather = 1: ncclAllGather (in place, one rank) issued in every step; must have run steps + warmup times"
+        assert forced["gathers_issued"] >= 2 * (steps + 6), "the forced all-gather did not run"
+        res["forced_gather"] = forced
         c1.close()
+        cf.close()
+        leaf_f.segment.close()
+        ctx_f.close()
         return res
 
     if world == 1 and not dist_mode:
@@ -879,17 +1129,35 @@ def main():
     elif world != 1 or dist_mode:
         want = {"and3"} if args.configs == "all" else (set(args.configs.split(",")) & {"and3", "or10"})   # BASELINE configs[4]'s workload on every N
     else:
-        want = {"and3", "or10", "block_decode", "cold", "positions", "out_of_cache"} if args.configs == "all" else set(args.configs.split(","))
+        want = {"and3", "or10", "latency", "block_decode", "cold", "positions", "out_of_cache"} if args.configs == "all" else set(args.configs.split(","))
     configs = {}
+    batch_rows_extra = {}
     for kind in ("and3", "or10"):
         if kind not in want or kind == args.workload:
             continue
         steps = max(3, min(args.steps, 10 if kind == "and3" else 4))
-        c = strip(search_config(shard, kind, steps, 1, False, "%s_%s" % (ROUND, kind), 4.0, nq if kind == "and3" else 256, nq))
+        c = search_config(shard, kind, steps, 1, False, "%s_%s" % (ROUND, kind), 4.0, nq if kind == "and3" else 256, nq)
+        batch_rows_extra[kind] = (c["_res"]["g_hits"], c["_res"]["g_totals"])
+        c = strip(c)
         if world > 1:
             c["value_all_shards_queries_per_sec"] = world * c["queries_per_sec"]
             c["whole_index_queries_per_sec"] = c["queries_per_sec"]   # the replicated batch answered over world x docs
         configs[kind] = c
+    if "latency" in want:
+        # batch of ONE (what IndexSearcher::search maps to): after the batch legs, so that the legs' rows are there to compare with
+        lat = latency_leg(shard, ("term", "and3", "or10"), 256)
+        batch_rows = {args.workload: (res["g_hits"], res["g_totals"])}
+        for kind in ("and3", "or10"):
+            if kind in batch_rows_extra:
+                batch_rows[kind] = batch_rows_extra[kind]
+        for kind in list(lat):
+            if kind in batch_rows:
+                latency_parity(lat[kind], kind, *batch_rows[kind])
+            else:
+                lat[kind].pop("_rows"); lat[kind].pop("_totals")
+        lat["note"] = ("rgpu_search_batch(n_queries = 1), host buffers, blocking, one call after the other from one thread: p50 / p99 / mean in us "
+                       "(plan resident) and planned_* (rgpu_plan_uniform_ids for the one query + the call); 256 calls = the first 256 queries of each batch")
+        out["latency_batch_of_one"] = lat
     if "block_decode" in want:
         d = decode_bench(shard, 5, "%s_decode" % ROUND)
         d["note"] = "10M-doc shard: the .doc (67 MB) and the 162 MB of output fit the 256 MiB Infinity Cache only in part; the launch is ~50 us long"
@@ -907,63 +1175,41 @@ def main():
         oc["cold"] = cold_bench(big, "%s_cold_big" % ROUND)
         oc["block_decode"] = decode_bench(big, 3, "%s_decode_big" % ROUND)
         # parity on the WHOLE batch for TERM and AND (the oracle does 1024 conjunctions over 100 M docs in a couple of seconds on the
-        # GPU box's cores); the 10-clause OR on 256 of its 1024 queries, and says so ("sampled": true)
+        # GPU box's cores; the 10-clause OR over 100 M docs takes the oracle ~8 ms of one core per query: the whole batch fits too)
         oc["term"] = strip(search_config(big, "term", 5, 1, False, "%s_term_big" % ROUND, 0.0, nq, nq))
         oc["and3"] = strip(search_config(big, "and3", 3, 1, False, "%s_and3_big" % ROUND, 0.0, nq, nq))
-        oc["or10"] = strip(search_config(big, "or10", 2, 1, False, "%s_or10_big" % ROUND, 0.0, 256, 256))
+        oc["or10"] = strip(search_config(big, "or10", 2, 1, False, "%s_or10_big" % ROUND, 0.0, nq, nq))
         configs["out_of_cache"] = oc
     if configs:
         out["configs"] = configs
-    # the north-star's targets as TOP-LEVEL keys (the driver's record keeps those): and3 = BASELINE configs[2] (and configs[4]'s
-    # workload), block decode >= 40 % of HBM, the 10-term OR; the 100 M-doc single-GPU and3 point = the strong-scaling
-    # reference of configs[4] (the same index split 8 x 12.5 M: `bench.py --gpus 8 --docs 12500000 --workload and3`)
-    def hoist(name, path, key):
-        node = configs
-        for part in path:
-            node = node.get(part) if isinstance(node, dict) else None
-            if node is None:
-                return
-        val = node.get(key) if isinstance(node, dict) else None
-        if val is not None:
-            out[name] = val
-    hoist("and3_queries_per_sec", ["and3"], "queries_per_sec")
-    hoist("and3_ms_per_step", ["and3"], "ms_per_step")
-    hoist("and3_gpu_over_cpu", ["and3"], "gpu_over_cpu")
-    hoist("and3_roofline_frac", ["and3", "roofline"], "frac")
-    hoist("and3_kernel_ms", ["and3", "roofline"], "kernel_ms")
-    hoist("and3_parity_vs_oracle", ["and3"], "parity_vs_oracle")
-    hoist("or10_queries_per_sec", ["or10"], "queries_per_sec")
-    hoist("or10_deferred_queries_per_sec", ["or10", "deferred"], "queries_per_sec")
-    hoist("or10_deferred_same_rows", ["or10", "deferred"], "same_rows_as_default_mode")
-    hoist("or10_roofline_frac", ["or10", "roofline"], "frac")
-    hoist("or10_parity_vs_oracle", ["or10"], "parity_vs_oracle")
-    hoist("block_decode_frac", ["block_decode", "roofline"], "frac")
-    hoist("cold_frac", ["cold", "roofline"], "frac")
-    hoist("cold_wall_ms", ["cold"], "wall_ms_incl_host_planning")
-    hoist("cold_wall_released_store_ms", ["cold"], "wall_ms_released_store")
-    hoist("phrase2_queries_per_sec", ["positions", "phrase2"], "queries_per_sec")
-    hoist("sloppy2_queries_per_sec", ["positions", "sloppy2"], "queries_per_sec")
-    hoist("sloppy2_parity_vs_oracle", ["positions", "sloppy2"], "parity_vs_oracle")
-    hoist("big_block_decode_frac", ["out_of_cache", "block_decode", "roofline"], "frac")
-    hoist("big_cold_frac", ["out_of_cache", "cold", "roofline"], "frac")
-    hoist("big_cold_wall_ms", ["out_of_cache", "cold"], "wall_ms_incl_host_planning")
-    hoist("big_cold_wall_released_store_ms", ["out_of_cache", "cold"], "wall_ms_released_store")
-    hoist("big_and3_queries_per_sec", ["out_of_cache", "and3"], "queries_per_sec")
-    hoist("big_and3_roofline_frac", ["out_of_cache", "and3", "roofline"], "frac")
-    hoist("big_and3_parity_vs_oracle", ["out_of_cache", "and3"], "parity_vs_oracle")
-    hoist("big_or10_queries_per_sec", ["out_of_cache", "or10"], "queries_per_sec")
     if args.workload == "and3":
         out["and3_queries_per_sec"] = out["queries_per_sec"]
         out["and3_roofline_frac"] = out["roofline"]["frac"]
     if world > 1 and "and3" in configs:
         out["and3_whole_index_queries_per_sec"] = configs["and3"]["queries_per_sec"]
         out["and3_whole_index_docs"] = world * args.docs
+    if dist_mode:
+        out["gathers_issued"] = comm.gathers_issued()
 
+    # ---- the full tree -> a file + stderr; the ONE stdout line = the contract's keys + the north-star's scalars (final_line) ------
+    full = _jsonable(out)
+    detail_paths = [args.detail] if args.detail else [os.path.join(ROOT, "bench_detail.json")]
+    if not args.detail and os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+        detail_paths.append(os.path.join(ROOT, "gpurun_out", "bench_detail.json"))
+    text = final_line(full, os.path.basename(detail_paths[0])) if rank == 0 else ""
+    if rank == 0:
+        for path in detail_paths:
+            try:
+                with open(path, "w") as f:
+                    json.dump(full, f, indent=1)
+            except OSError as e:
+                print("could not write %s: %s" % (path, e), file=sys.stderr)
+        print("bench detail (full tree; the contract line follows on stdout): " + json.dumps(full), file=sys.stderr, flush=True)
     sys.stdout.flush()
     os.dup2(stdout_fd, 1)
     os.close(stdout_fd)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        print(text, flush=True)
     os.dup2(2, 1)  # anything native libraries print while shutting down stays off stdout too
     if dist_mode:
         dist.barrier()

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RGPU_ABI_VERSION 5
+#define RGPU_ABI_VERSION 6
 #define RGPU_NO_MORE_DOCS 0x7fffffff /* search/mod.rs:59 */
 #define RGPU_BLOCK_SIZE 128          /* codec/postings/posting_format.rs:36 */
 #define RGPU_MAX_QUERY_TERMS 64  /* clauses of one query, MUST + SHOULD + MUST_NOT together: a clause's cursor lives in a lane of the
@@ -106,6 +106,10 @@ typedef struct rgpu_config {
                                    scratch slot, or by rgpu_synchronize. The caller must then call rgpu_synchronize(ctx) — not just
                                    synchronise its stream — before it reads such a batch's rows. The host's planning of batch i + 1
                                    then runs under the kernels of batch i. Results are the same either way */
+  int32_t comm_force_gather;    /* communicators of ONE rank: 0 (default) = nothing to gather, the record is merged where the search
+                                   left it; 1 = issue the in-place ncclAllGather all the same (and the cross-stream ordering around
+                                   it) — the N > 1 data path end to end on a box with one GPU: tests and `bench.py --force-dist`
+                                   (the environment variable RGPU_COMM_FORCE_GATHER=1 does the same). Results never depend on it */
 } rgpu_config;
 
 /* blocktree/mod.rs:33-59 BlockTermState, as filled by posting_reader.rs:264-306 lucene50_decode_term.
@@ -312,11 +316,19 @@ void rgpu_comm_destroy(rgpu_comm* comm);
  * A rank whose LOCAL search fails (corrupt segment, out of HBM while preparing terms, ...) still takes part in the
  * collective — with empty rows and its status in the record (see rgpu_record_bytes) — and only then returns its error, so
  * its peers neither hang in the all-gather nor keep a stale record: they get the merge of the shards that answered and can
- * ask rgpu_comm_status which did not. (A failure to allocate the record buffers themselves happens before the
- * collective and leaves the communicator out of step: destroy it.) */
+ * ask rgpu_comm_status which did not. Nothing between the buffer reservation and the collective returns early: a failed
+ * wait or status-word memset is reported after the all-gather has been joined. The one exception is the allocation of the
+ * gather buffer itself (nowhere to receive into — the communicator is then out of step: destroy it); rgpu_comm_reserve
+ * moves that allocation to start-up. */
 int32_t rgpu_search_batch_sharded(rgpu_comm* comm, rgpu_segment* seg, const rgpu_query* queries, int32_t n_queries,
                                   const rgpu_query_term* terms, int32_t n_terms_total, int32_t k, void* hits_dev,
                                   void* total_hits_dev, void* hip_stream);
+/* Start-up sizing (not a collective): allocates every slot's gather buffer for batches of up to n_queries x k now, so that
+ * the data path never allocates. */
+int32_t rgpu_comm_reserve(rgpu_comm* comm, int32_t n_queries, int32_t k);
+/* ncclAllGather calls enqueued on this communicator so far (a communicator of one rank issues none unless
+ * rgpu_config.comm_force_gather = 1); -1 for a null communicator. */
+int64_t rgpu_comm_gathers_issued(rgpu_comm* comm);
 /* status_out[r], r < n_ranks: rank r's rgpu_status for the most recent sharded batch on this communicator (waits for it). */
 int32_t rgpu_comm_status(rgpu_comm* comm, int32_t* status_out);
 /* One process that owns several GPUs (Rucene itself is one process whose search_parallel hands leaves to threads,
@@ -589,6 +601,9 @@ typedef struct rgpu_kernel_stat {
   int64_t launches;
   double total_ms;          /* HIP-event time summed over launches (needs cfg.profile_kernels = 1) */
   int64_t postings;          /* sum of doc_freq over the terms the launches covered */
+  int64_t timed_launches;    /* launches whose own HIP-event duration was kept (the first 8192 per name) */
+  double min_ms, median_ms, max_ms; /* over those launches: price a roofline on the MEDIAN — total_ms / launches is
+                                multiplied by one stalled launch (a first-use allocation, a clock dip) */
 } rgpu_kernel_stat;
 int32_t rgpu_kernel_stats(rgpu_ctx* ctx, rgpu_kernel_stat* out, int32_t max_out); /* returns count */
 /* Switch the HIP-event bracketing of kernels on / off (rgpu_config.profile_kernels sets the initial state): a timed

@@ -8,7 +8,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_NAME = "librucene_gpu.so"
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 OP_TERM, OP_AND, OP_OR = 0, 1, 2
 MAX_K = 1024
 MAX_QUERY_TERMS = 64
@@ -56,7 +56,7 @@ EXPORTS = [
     "rgpu_norms_from_lucene53", "rgpu_live_docs_from_lucene50", "rgpu_field_infos_from_lucene60", "rgpu_segment_info_from_lucene62", "rgpu_commit_from_segments_file", "rgpu_compound_entries_from_lucene50", "rgpu_terms_open", "rgpu_terms_close", "rgpu_terms_field_stats",
     "rgpu_terms_lookup", "rgpu_terms_lookup_positions", "rgpu_kernel_stats", "rgpu_kernel_stats_reset", "rgpu_synchronize",
     "rgpu_set_profiling", "rgpu_and_touched_bytes", "rgpu_comm_unique_id", "rgpu_comm_init", "rgpu_comm_destroy",
-    "rgpu_search_batch_sharded", "rgpu_comm_status", "rgpu_comm_init_all", "rgpu_search_batch_sharded_all", "rgpu_record_bytes",
+    "rgpu_search_batch_sharded", "rgpu_comm_status", "rgpu_comm_reserve", "rgpu_comm_gathers_issued", "rgpu_comm_init_all", "rgpu_search_batch_sharded_all", "rgpu_record_bytes",
     "rgpu_search_batch_record_device", "rgpu_merge_records_device", "rgpu_last_search_counters",
     "rgpu_planner_create", "rgpu_planner_create_flat", "rgpu_planner_destroy", "rgpu_planner_sim_table", "rgpu_planner_set_sim_table", "rgpu_plan_uniform_ids",
     "rgpu_plan_uniform_bytes", "rgpu_plan_batch_ids", "rgpu_plan_batch_bytes",
@@ -73,7 +73,8 @@ class _Config(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("blocks_per_item", C.c_int32), ("and_blocks_per_item", C.c_int32),
                 ("profile_kernels", C.c_int32), ("or_window_docs", C.c_int32), ("or_dense_clauses", C.c_int32),
                 ("raw_norms", C.c_int32), ("or_wide", C.c_int32), ("or_wide_window_docs", C.c_int32),
-                ("req_opt_rule", C.c_int32), ("or_bitmaps", C.c_int32), ("or_lazy_cells", C.c_int32), ("and_bitmaps", C.c_int32), ("bitmap_budget_mib", C.c_int32), ("prepared_budget_mib", C.c_int32), ("or_deferred", C.c_int32)]
+                ("req_opt_rule", C.c_int32), ("or_bitmaps", C.c_int32), ("or_lazy_cells", C.c_int32), ("and_bitmaps", C.c_int32), ("bitmap_budget_mib", C.c_int32), ("prepared_budget_mib", C.c_int32), ("or_deferred", C.c_int32),
+                ("comm_force_gather", C.c_int32)]
 
 
 SEARCH_COUNTERS_DTYPE = np.dtype([("op", "<i4"), ("reserved", "<i4"), ("postings_covered", "<i8"), ("postings_decoded", "<i8"),
@@ -85,7 +86,8 @@ assert SEARCH_COUNTERS_DTYPE.itemsize == 40 and PLAN_STATS_DTYPE.itemsize == 32
 
 
 class _KernelStat(C.Structure):
-    _fields_ = [("name", C.c_char * 48), ("launches", C.c_int64), ("total_ms", C.c_double), ("postings", C.c_int64)]
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_int64), ("total_ms", C.c_double), ("postings", C.c_int64),
+                ("timed_launches", C.c_int64), ("min_ms", C.c_double), ("median_ms", C.c_double), ("max_ms", C.c_double)]
 
 
 def lib_path():
@@ -174,6 +176,8 @@ def lib():
         "rgpu_comm_destroy": (None, [vp]),
         "rgpu_search_batch_sharded": (i32, [vp, vp, vp, i32, vp, i32, i32, vp, vp, vp]),
         "rgpu_comm_status": (i32, [vp, vp]),
+        "rgpu_comm_reserve": (i32, [vp, i32, i32]),
+        "rgpu_comm_gathers_issued": (i64, [vp]),
         "rgpu_comm_init_all": (i32, [vp, i32, vp]),
         "rgpu_search_batch_sharded_all": (i32, [vp, vp, i32, vp, i32, vp, i32, i32, vp, vp, vp]),
         "rgpu_record_bytes": (i64, [i32, i32]),
@@ -358,7 +362,7 @@ class Context:
 
     def __init__(self, device=0, profile_kernels=False, blocks_per_item=0, and_blocks_per_item=0, or_window_docs=0,
                  raw_norms=False, or_dense_clauses=0, or_wide=0, or_wide_window_docs=0, req_opt_rule=0, or_bitmaps=0, or_lazy_cells=0, and_bitmaps=0, bitmap_budget_mib=0,
-                 prepared_budget_mib=0, or_deferred=False):
+                 prepared_budget_mib=0, or_deferred=False, comm_force_gather=False):
         cfg = _Config()
         cfg.abi_version = ABI_VERSION
         cfg.blocks_per_item = blocks_per_item
@@ -376,6 +380,7 @@ class Context:
         cfg.bitmap_budget_mib = bitmap_budget_mib
         cfg.prepared_budget_mib = prepared_budget_mib
         cfg.or_deferred = int(or_deferred)
+        cfg.comm_force_gather = int(comm_force_gather)
         h = C.c_void_p()
         _check(lib().rgpu_init(device, C.byref(cfg), C.byref(h)))
         self._h = h
@@ -420,7 +425,9 @@ class Context:
     def kernel_stats(self):
         arr = (_KernelStat * 32)()
         n = _check(lib().rgpu_kernel_stats(self._h, arr, 32))
-        return {arr[i].name.decode(): {"launches": arr[i].launches, "total_ms": arr[i].total_ms, "postings": arr[i].postings}
+        return {arr[i].name.decode(): {"launches": arr[i].launches, "total_ms": arr[i].total_ms, "postings": arr[i].postings,
+                                       "timed_launches": arr[i].timed_launches, "min_ms": arr[i].min_ms, "median_ms": arr[i].median_ms,
+                                       "max_ms": arr[i].max_ms}
                 for i in range(n)}
 
     def kernel_stats_reset(self):
@@ -569,6 +576,14 @@ class Comm:
         t = np.ascontiguousarray(terms, dtype=QUERY_TERM_DTYPE)
         _check(lib().rgpu_search_batch_sharded(self._h, segment._h, q.ctypes.data, q.size, t.ctypes.data, t.size, k, hits_ptr, totals_ptr,
                                                stream or None))
+
+    def reserve(self, n_queries, k):
+        """Start-up sizing: every slot's gather buffer for batches of up to n_queries x k (the data path then never allocates)."""
+        _check(lib().rgpu_comm_reserve(self._h, n_queries, k))
+
+    def gathers_issued(self):
+        """ncclAllGather calls enqueued on this communicator so far."""
+        return int(lib().rgpu_comm_gathers_issued(self._h))
 
     def status(self):
         """Every rank's rgpu_status for the most recent sharded batch (waits for it)."""

@@ -124,7 +124,12 @@ struct StatSlot {
   int64_t launches = 0;
   double total_ms = 0;
   int64_t postings = 0;
+  // every event-timed launch's own duration (at most STAT_SAMPLES_MAX: a bench pass is tens of launches): the median is what a
+  // roofline is priced on — a mean over 20 launches is multiplied by one stalled launch (round 5's driver run read 1.775 ms for a
+  // 0.23 ms kernel that way)
+  std::vector<float> samples;
 };
+constexpr size_t STAT_SAMPLES_MAX = 8192;
 struct PendingEvent { int slot; hipEvent_t start, stop; };
 
 }  // namespace
@@ -272,7 +277,7 @@ struct rgpu_segment {
 // ---- profiling helpers -----------------------------------------------------------------------------------------
 static int stat_slot(rgpu_ctx* c, const char* name) {
   for (size_t i = 0; i < c->stats.size(); ++i) if (c->stats[i].name == name) return (int)i;
-  c->stats.push_back(StatSlot{name, 0, 0.0, 0});
+  c->stats.push_back(StatSlot{name, 0, 0.0, 0, {}});
   return (int)c->stats.size() - 1;
 }
 static hipEvent_t take_event(rgpu_ctx* c) {
@@ -304,12 +309,26 @@ static void drain_events(rgpu_ctx* c) {
   for (auto& pe : c->pending) {
     (void)hipEventSynchronize(pe.stop);
     float ms = 0;
-    if (hipEventElapsedTime(&ms, pe.start, pe.stop) == hipSuccess) c->stats[(size_t)pe.slot].total_ms += ms;
+    if (hipEventElapsedTime(&ms, pe.start, pe.stop) == hipSuccess) {
+      StatSlot& st = c->stats[(size_t)pe.slot];
+      st.total_ms += ms;
+      if (st.samples.size() < STAT_SAMPLES_MAX) st.samples.push_back(ms);
+    }
     c->free_events.push_back(pe.start);
     c->free_events.push_back(pe.stop);
   }
   c->pending.clear();
 }
+
+// A deferred group's closure runs under the multi-pass state (rgpu_ctx::pass: row stride, first column, ceiling arrays) of the
+// call that ENQUEUED it, whatever call happens to be running when the flags are finally looked at (a later k > 128 search whose
+// scratch_take settles the earlier batch would otherwise lend the redo its own stride and ceilings: ADVICE r5, medium).
+struct PassScope {
+  rgpu_ctx* c;
+  rgpu_ctx::Pass saved;
+  PassScope(rgpu_ctx* c_, const rgpu_ctx::Pass& at_enqueue) : c(c_), saved(c_->pass) { c->pass = at_enqueue; }
+  ~PassScope() { c->pass = saved; }
+};
 
 // ---- launch sets whose hand-back flags are still to be looked at (rgpu_ctx::pending_or) ------------------------------------
 constexpr size_t RUNS_PER_SLOT_MAX = (size_t)1 << 28;  // ScoredPostings (2 GiB): a group with longer runs uses the context's buffer and syncs
@@ -970,6 +989,7 @@ extern "C" int32_t rgpu_init(int32_t device_ordinal, const rgpu_config* cfg, rgp
   *out_ctx = nullptr;
   if (cfg && cfg->abi_version != RGPU_ABI_VERSION) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "rgpu_config.abi_version mismatch");
   if (cfg && (cfg->prepared_budget_mib < 0 || cfg->or_deferred < 0 || cfg->or_deferred > 1)) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "rgpu_config.prepared_budget_mib must be >= 0, or_deferred 0 or 1");
+  if (cfg && (cfg->comm_force_gather < 0 || cfg->comm_force_gather > 1)) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "rgpu_config.comm_force_gather must be 0 or 1");
   if (cfg && cfg->bitmap_budget_mib < 0) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "rgpu_config.bitmap_budget_mib must be >= 0 (or_bitmaps / and_bitmaps = -1 turn bitmaps off)");
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
@@ -998,6 +1018,7 @@ extern "C" int32_t rgpu_init(int32_t device_ordinal, const rgpu_config* cfg, rgp
   c->bitmap_budget = c->cfg.bitmap_budget_mib > 0 ? (size_t)c->cfg.bitmap_budget_mib << 20 : (size_t)prop.totalGlobalMem / 8;
   c->prepared_budget = c->cfg.prepared_budget_mib > 0 ? (size_t)c->cfg.prepared_budget_mib << 20 : 0;
   if (const char* e = std::getenv("RGPU_TERM_SKETCH")) c->term_sketches = std::atoi(e) != 0;
+  if (const char* e = std::getenv("RGPU_COMM_FORCE_GATHER")) { if (std::atoi(e) != 0) c->cfg.comm_force_gather = 1; }
   std::snprintf(c->name, sizeof c->name, "%s (%s)", prop.name, prop.gcnArchName);
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipMalloc(&c->d_err, 4 * sizeof(int)) != hipSuccess) {
     delete c;
@@ -1050,6 +1071,14 @@ extern "C" int32_t rgpu_kernel_stats(rgpu_ctx* c, rgpu_kernel_stat* out, int32_t
     out[n].launches = s.launches;
     out[n].total_ms = s.total_ms;
     out[n].postings = s.postings;
+    out[n].timed_launches = (int64_t)s.samples.size();
+    if (!s.samples.empty()) {
+      std::vector<float> v(s.samples);
+      std::sort(v.begin(), v.end());
+      out[n].min_ms = v.front();
+      out[n].max_ms = v.back();
+      out[n].median_ms = (v.size() & 1) ? v[v.size() / 2] : 0.5 * ((double)v[v.size() / 2 - 1] + (double)v[v.size() / 2]);
+    }
     ++n;
   }
   return n;
@@ -2028,7 +2057,8 @@ static int32_t search_or_lazy_group(rgpu_segment* seg, Group& G, int32_t k, HitO
     // Everything it needs is held by value: it may run long after this function returned.
     auto shared_g = std::make_shared<Group>(std::move(G));
     auto shared_lq_of = std::make_shared<std::vector<int32_t>>(std::move(lq_of));
-    auto finish = [c, seg, slot, shared_g, shared_lq_of, nq, k, hits_dev, totals_dev, stream, h_counts, h_low, h_bailed, own_runs]() -> int32_t {
+    auto finish = [c, seg, slot, shared_g, shared_lq_of, nq, k, hits_dev, totals_dev, stream, h_counts, h_low, h_bailed, own_runs, pass_at_enqueue = c->pass]() -> int32_t {
+      PassScope scope(c, pass_at_enqueue);
       slot->settles_later = false;
       HIP_TRY(hipSetDevice(c->device));
       if (own_runs) HIP_TRY(hipEventSynchronize(slot->done)); else HIP_TRY(hipStreamSynchronize(stream));
@@ -2248,7 +2278,8 @@ static int32_t search_or_wide_group(rgpu_segment* seg, Group& G, int32_t k, HitO
   // queries whose top-k reaches below the fixed-point floor: once more, summed in f32 in clause order (their rows are
   // simply written again) — once the launch set has finished: now, or when its flags are looked at (rgpu_ctx::pending_or)
   auto shared_g = std::make_shared<Group>(std::move(G));
-  auto finish = [c, seg, slot, shared_g, nq, k, hits_dev, totals_dev, stream, h_low]() -> int32_t {
+  auto finish = [c, seg, slot, shared_g, nq, k, hits_dev, totals_dev, stream, h_low, pass_at_enqueue = c->pass]() -> int32_t {
+    PassScope scope(c, pass_at_enqueue);
     slot->settles_later = false;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipEventSynchronize(slot->done));
@@ -2336,6 +2367,10 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
   HIP_TRY(cs.d.reserve((size_t)n_queries * 2, 0, stream));  // two sets, alternating: a pass reads the previous pass's, writes its own
   int32_t rc = RGPU_OK;
   int flip = 0;
+  // pass p + 1 reads the ceilings pass p wrote: a group of pass p whose redo ran later would change rows and ceilings behind
+  // the next pass's back — inside a multi-pass call every group settles before it returns
+  const bool defer_was = c->defer_or;
+  c->defer_or = false;
   for (int32_t col0 = 0; col0 < k && rc == RGPU_OK; col0 += RGPU_PASS_K, flip ^= 1) {
     c->pass.stride = k;
     c->pass.col0 = col0;
@@ -2344,6 +2379,7 @@ static int32_t search_impl(rgpu_segment* seg, const rgpu_query* queries, int32_t
     rc = search_pass(seg, queries, n_queries, terms, n_terms_total, std::min<int32_t>(RGPU_PASS_K, k - col0), k, hits_dev, totals_dev, stream);
   }
   c->pass = rgpu_ctx::Pass{};
+  c->defer_or = defer_was;
   // no stream sync: the ceiling arrays are this call's until the slot comes round again (four calls later), like the scratch slots
   if (!cs.done) HIP_TRY(hipEventCreateWithFlags(&cs.done, hipEventDisableTiming));
   HIP_TRY(hipEventRecord(cs.done, stream));
@@ -3547,6 +3583,7 @@ struct rgpu_comm {
   bool have_last = false;
   CommSlot* last_slot = nullptr;  // the most recent batch's records (rgpu_comm_status)
   int32_t last_queries = 0, last_k = 0;
+  int64_t gathers_issued = 0;     // ncclAllGather calls enqueued on this communicator (rgpu_comm_gathers_issued)
 };
 #define NCCL_TRY(expr)                                                                                          \
   do {                                                                                                          \
@@ -3723,20 +3760,27 @@ struct ShardedCall {
   size_t record = 0;
   int32_t local_rc = RGPU_OK;
   std::string local_why;
+  int32_t pre_rc = RGPU_OK;  // a failure in front of the collective that did not keep this rank from joining it
+  std::string pre_why;
 };
-// phase 0: the slot and its buffers — may fail (out of HBM for the record itself) and then NOTHING has happened: the
-// communicator is still in step with its peers as long as they fail the same call or are told to skip it
+// phase 0: the slot and its buffers. The ONE thing that can fail here and leave the communicator out of step with its peers
+// is the allocation of the record buffer itself (nowhere to gather into): rgpu_comm_reserve does it at start-up, so a serving
+// host never allocates on the data path. Everything else that goes wrong (a wait on the slot's previous batch, the status
+// word's memset) is remembered in call->pre_rc and reported AFTER the collective has been joined.
 static int32_t sharded_reserve(rgpu_comm* comm, int32_t n_queries, int32_t k, hipStream_t s, ShardedCall* call) {
   CommSlot& sl = comm->slots[comm->next];
-  if (sl.busy) { HIP_TRY(hipEventSynchronize(sl.done)); sl.busy = false; }
+  auto note = [&](hipError_t e, const char* what) {
+    if (e != hipSuccess && call->pre_rc == RGPU_OK) { call->pre_rc = RGPU_ERR_RUNTIME; call->pre_why = std::string(what) + ": " + hipGetErrorString(e); }
+  };
+  if (sl.busy) { note(hipEventSynchronize(sl.done), "hipEventSynchronize(slot)"); sl.busy = false; }
   const size_t record = record_bytes(n_queries, k);
   const uint8_t* before = sl.recv.p;
   HIP_TRY(sl.recv.reserve(record * (size_t)comm->n_ranks, 0, s));
   if (sl.recv.p != before || sl.record != record || !sl.status_zero) {
     // this rank's status word, zeroed once per (buffer, record size): a batch that succeeds never touches it again
-    HIP_TRY(hipMemsetAsync(sl.recv.p + (size_t)comm->rank * record + record - 8, 0, 8, s));
+    const hipError_t e = hipMemsetAsync(sl.recv.p + (size_t)comm->rank * record + record - 8, 0, 8, s);
     sl.record = record;
-    sl.status_zero = true;
+    sl.status_zero = e == hipSuccess;  // not zeroed: search_into_record writes the word with a launch instead
   }
   call->sl = &sl;
   call->record = record;
@@ -3766,18 +3810,33 @@ static void sharded_settle(rgpu_comm* comm, int32_t n_queries, int32_t k, hipStr
   RGPU_LAUNCH(k_set_i64, dim3(1), dim3(1), 0, s, (int64_t*)(record + hits_bytes + (size_t)n_queries * 8), (int64_t)rc);
   (void)launch_status();
 }
-static int32_t sharded_gather(rgpu_comm* comm, hipStream_t s, const ShardedCall& call) {
+static int32_t sharded_gather(rgpu_comm* comm, hipStream_t s, ShardedCall& call) {
   // A communicator of one rank has nothing to gather: its record is already where the merge reads it. (Before round 5 this
   // path cost a device copy of the record, a one-thread launch for the status word and an event wait between consecutive
   // batches on different streams: 0.157 ms per 1024-query TERM step against 0.093 for the local search.)
-  if (comm->n_ranks == 1) return RGPU_OK;
-  if (comm->have_last && comm->last_stream != s) HIP_TRY(hipStreamWaitEvent(s, comm->last_collective, 0));
+  // rgpu_config.comm_force_gather issues the in-place all-gather all the same: the N > 1 path on a one-GPU box.
+  if (comm->n_ranks == 1 && comm->ctx->cfg.comm_force_gather == 0) return RGPU_OK;
+  auto note = [&](hipError_t e, const char* what) {
+    if (e != hipSuccess && call.pre_rc == RGPU_OK) { call.pre_rc = RGPU_ERR_RUNTIME; call.pre_why = std::string(what) + ": " + hipGetErrorString(e); }
+    return e;
+  };
+  // collectives of one communicator run one after the other; when the stream changed, the later one waits for the earlier
+  // one's event. If that wait cannot be enqueued the host waits instead — this rank still joins the collective (its peers
+  // are in it already): nothing between sharded_reserve and ncclAllGather returns
+  if (comm->have_last && comm->last_stream != s)
+    if (note(hipStreamWaitEvent(s, comm->last_collective, 0), "hipStreamWaitEvent(last collective)") != hipSuccess)
+      (void)hipEventSynchronize(comm->last_collective);
   uint8_t* const mine = call.sl->recv.p + (size_t)comm->rank * call.record;  // in place: sendbuff == recvbuff + rank * count
   NCCL_TRY(ncclAllGather(mine, call.sl->recv.p, call.record, ncclInt8, comm->nccl, s));
-  if (!comm->last_collective) HIP_TRY(hipEventCreateWithFlags(&comm->last_collective, hipEventDisableTiming));
-  HIP_TRY(hipEventRecord(comm->last_collective, s));
-  comm->last_stream = s;
-  comm->have_last = true;
+  comm->gathers_issued++;
+  if (!comm->last_collective) note(hipEventCreateWithFlags(&comm->last_collective, hipEventDisableTiming), "hipEventCreate(last collective)");
+  if (comm->last_collective && note(hipEventRecord(comm->last_collective, s), "hipEventRecord(last collective)") == hipSuccess) {
+    comm->last_stream = s;
+    comm->have_last = true;
+  } else {  // no event to order the next collective behind this one: the host waits for this one now
+    (void)hipStreamSynchronize(s);
+    comm->have_last = false;
+  }
   return RGPU_OK;
 }
 static int32_t sharded_merge(rgpu_comm* comm, int32_t n_queries, int32_t k, void* hits_dev, void* totals_dev, hipStream_t s, const ShardedCall& call) {
@@ -3813,7 +3872,38 @@ extern "C" int32_t rgpu_search_batch_sharded(rgpu_comm* comm, rgpu_segment* seg,
   if (rc != RGPU_OK) return rc;
   // the collective has been honoured; now this rank's own failure, if any, is reported (its peers see it in the status words)
   if (call.local_rc != RGPU_OK) return fail(call.local_rc, call.local_why);
+  if (call.pre_rc != RGPU_OK) return fail(call.pre_rc, call.pre_why);
   return RGPU_OK;
+}
+
+// Start-up sizing: every slot's gather buffer for batches of up to n_queries x k, allocated now — the data path then never
+// allocates, and the one failure that would leave a rank out of a collective (no buffer to gather into) cannot happen there.
+// Not a collective; every rank calls it with the shapes it will serve.
+extern "C" int32_t rgpu_comm_reserve(rgpu_comm* comm, int32_t n_queries, int32_t k) {
+  if (!comm || n_queries <= 0) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "bad arguments");
+  if (k <= 0 || k > RGPU_MAX_K) return fail(k <= 0 ? RGPU_ERR_ILLEGAL_ARGUMENT : RGPU_ERR_UNSUPPORTED, "k must be in 1..RGPU_MAX_K");
+  rgpu_ctx* c = comm->ctx;
+  std::lock_guard<std::mutex> g(c->mu);
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t bytes = record_bytes(n_queries, k) * (size_t)comm->n_ranks;
+  for (auto& sl : comm->slots) {
+    if (sl.busy) { HIP_TRY(hipEventSynchronize(sl.done)); sl.busy = false; }
+    const uint8_t* before = sl.recv.p;
+    HIP_TRY(sl.recv.reserve(bytes, 0, c->stream));
+    if (sl.recv.p != before) sl.status_zero = false;
+    if (!sl.done) HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+  }
+  if (!comm->last_collective) HIP_TRY(hipEventCreateWithFlags(&comm->last_collective, hipEventDisableTiming));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return RGPU_OK;
+}
+
+// ncclAllGather calls this communicator has enqueued so far (a communicator of one rank issues none unless
+// rgpu_config.comm_force_gather is set): tests and bench.py assert that the collective really ran.
+extern "C" int64_t rgpu_comm_gathers_issued(rgpu_comm* comm) {
+  if (!comm) return -1;
+  std::lock_guard<std::mutex> g(comm->ctx->mu);
+  return comm->gathers_issued;
 }
 
 // The one-process form: rank r = comms[r] / segs[r] (from rgpu_comm_init_all), one thread issues the whole batch. The n
@@ -3885,6 +3975,7 @@ extern "C" int32_t rgpu_search_batch_sharded_all(rgpu_comm* const* comms, rgpu_s
     const int32_t rc = sharded_merge(comms[r], n_queries, k, hits_dev[r], totals_dev[r], ss[(size_t)r], calls[(size_t)r]);
     if (rc != RGPU_OK) note(rc, "rank " + std::to_string(r) + ": " + g_last_error);
     if (calls[(size_t)r].local_rc != RGPU_OK) note(calls[(size_t)r].local_rc, "rank " + std::to_string(r) + ": " + calls[(size_t)r].local_why);
+    if (calls[(size_t)r].pre_rc != RGPU_OK) note(calls[(size_t)r].pre_rc, "rank " + std::to_string(r) + ": " + calls[(size_t)r].pre_why);
   }
   if (first_rc != RGPU_OK) return fail(first_rc, first_why);
   return RGPU_OK;

@@ -2,33 +2,42 @@
 // src/core/search/gpu/searcher.rs (next to ffi.rs, which scripts/gen_rust_ffi.py writes from include/rucene_gpu.h).
 //
 // NOT COMPILED IN THIS REPOSITORY: the image has no rustc, the reference needs nightly-2020-03-12 and 24 un-vendored crates.
-// The file is written against the reference's own items (paths relative to src/core/) and kept deliberately thin: every
-// decision that affects results lives behind the C ABI and is tested there (tests/, through ctypes and C++). What this file
-// adds is pattern-matching of query trees, term resolution through Rucene's own term dictionary, BM25 weights through Rucene's
-// own BM25Similarity, and the hand-over of hits to the caller's collector. The same logic exists, compiled and tested, as the
-// C++ mirror rucene_amd/csrc/host/gpu_index_searcher.hpp and the Python mirror rucene_amd/searcher.py.
+// The file is written against the reference's own PUBLIC items (paths relative to src/core/) plus the four small accessors of
+// rust/rucene_accessors.patch, and kept deliberately thin: every decision that affects results lives behind the C ABI and
+// is tested there (tests/, through ctypes and C++). What this file adds is pattern-matching of query trees, term resolution
+// through Rucene's own term dictionary, BM25 weights from Rucene's own statistics (the arithmetic itself is the library's
+// rgpu_bm25_compute_weight, bit-exact with bm25_similarity.rs:99-177 — BM25Similarity keeps idf / avg_field_length private),
+// and the hand-over of hits to the caller's collector. The same logic exists, compiled and tested, as the C++ mirror
+// rucene_amd/csrc/host/gpu_index_searcher.hpp and the Python mirror rucene_amd/searcher.py.
 //
-// Three crate-side hooks the shim needs (each a few lines; the fields exist, they are only private today):
-//   * search/query/boolean_query.rs:30-36   pub(crate) fn clauses(&self) -> (&[Box<dyn Query<C>>; must], should, filter, must_not, i32)
-//   * search/query/phrase_query.rs:48-55    pub(crate) fn parts(&self) -> (&str, &[Term], &[i32], i32)
-//   * search/collector/top_docs.rs:107-124  pub(crate) fn add_leaf_result(&mut self, hits: &[(DocId, f32)], total_hits: usize)
+// Crate-side hooks (rust/rucene_accessors.patch; the fields exist, they are only private today):
+//   * search/query/boolean_query.rs   pub(crate) fn clauses(&self) -> (&[Box<dyn Query<C>>], &[..should], &[..filter], &[..must_not], i32)
+//   * search/query/phrase_query.rs    pub(crate) fn parts(&self) -> (&str, &[Term], &[i32], i32)
+//   * search/collector/top_docs.rs    pub(crate) fn estimated_hits(&self) -> usize
+//                                     pub(crate) fn add_leaf_result(&mut self, hits: &[(DocId, f32)], total_hits: usize)
 //       = what finish_parallel does with one LeafTopDocs (top_docs.rs:157-172): total_hits += n; add_doc(doc, score) per hit.
 use std::collections::HashMap;
 use std::ops::Deref;
 use std::sync::Mutex;
 
-use core::codec::{Codec, TermIterator, Terms};
 use core::codec::postings::blocktree::BlockTermState;
+use core::codec::{Codec, TermIterator, Terms};
+use core::doc::Term;
 use core::index::reader::{IndexReader, LeafReaderContext};
 use core::search::collector::{SearchCollector, TopDocsCollector};
 use core::search::query::{BooleanQuery, PhraseQuery, Query, TermQuery};
 use core::search::searcher::{DefaultIndexSearcher, IndexSearcher, SearchPlanBuilder};
-use core::search::similarity::{BM25Similarity, SimilarityProducer};
+use core::search::similarity::SimilarityProducer;
 use core::search::statistics::{CollectionStatistics, TermStatistics};
 use core::util::DocId;
 use error::{Error, ErrorKind, Result};
 
 use super::ffi::*;
+
+/// BM25Similarity::default() (bm25_similarity.rs:55-59) — what DefaultSimilarityProducer hands every field. A searcher built
+/// with another SimilarityProducer must not be wrapped by this shim (open() cannot see the producer's parameters).
+const BM25_K1: f32 = 1.2;
+const BM25_B: f32 = 0.75;
 
 /// status -> error.rs ErrorKind (error.rs:24-91); nothing panics across the boundary
 pub fn check(rc: i32, ctx: *mut RgpuCtx) -> Result<()> {
@@ -61,13 +70,23 @@ struct FlatQuery<'q> {
     must_not: Vec<&'q TermQuery>,
 }
 
+impl<'q> FlatQuery<'q> {
+    fn n_clauses(&self) -> usize { self.positive.len() + self.optional.len() + self.must_not.len() }
+    fn clauses(&self) -> impl Iterator<Item = &'q TermQuery> + '_ {
+        self.positive.iter().map(|(t, _)| *t).chain(self.optional.iter().cloned()).chain(self.must_not.iter().cloned())
+    }
+}
+
 pub struct GpuIndexSearcher<C: Codec, R: IndexReader<Codec = C> + ?Sized, IR: Deref<Target = R>, SP: SimilarityProducer<C>> {
     cpu: DefaultIndexSearcher<C, R, IR, SP>, // statistics (searcher.rs:306-363, :732-767) and the fallback for everything else
     ctx: *mut RgpuCtx,
     field: String,                            // the uploaded field (one rgpu_segment per (leaf, field); more fields: a map)
     leaves: Vec<GpuLeaf>,                     // by LeafReaderContext::ord
-    sim_tables: Mutex<HashMap<(u32, u32, u32), i32>>, // (k1, b, avgdl) bits -> rgpu_sim_table_upload handle
+    sim_tables: Mutex<HashMap<u32, i32>>,     // avgdl bits -> rgpu_sim_table_upload handle (k1, b fixed above)
     next_limit: i32,                          // DefaultIndexSearcher::next_limit (searcher.rs:285): None -> 0, Some(0) -> RGPU_NEXT_LIMIT_ZERO
+    /// Fold ONE level of nested BooleanQuery into its parent (see flatten). Off by default, as in the C++ and Python mirrors
+    /// (flatten_nested = false): the folded f32 sum is within 1e-5 of the CPU's, not bit-equal.
+    allow_flatten: bool,
 }
 
 unsafe impl<C: Codec, R: IndexReader<Codec = C> + ?Sized, IR: Deref<Target = R>, SP: SimilarityProducer<C>> Send for GpuIndexSearcher<C, R, IR, SP> {}
@@ -77,7 +96,8 @@ impl<C: Codec, R: IndexReader<Codec = C> + ?Sized, IR: Deref<Target = R>, SP: Si
     /// `files(leaf)` hands over what SegmentReadState already names for the leaf: the mmapped `.doc` bytes, the field's norms as
     /// one byte per doc (or the `.nvm` / `.nvd` bytes through rgpu_norms_from_lucene53), the live-docs words
     /// (FixedBitSet::bits, util/bit_set.rs:117-124) and, for a positions field, the `.pos` bytes.
-    pub fn open<F>(cpu: DefaultIndexSearcher<C, R, IR, SP>, device: i32, field: &str, index_options: i32, next_limit: Option<usize>, files: F) -> Result<Self>
+    pub fn open<F>(cpu: DefaultIndexSearcher<C, R, IR, SP>, device: i32, field: &str, index_options: i32, next_limit: Option<usize>, allow_flatten: bool,
+                   files: F) -> Result<Self>
     where
         F: Fn(&LeafReaderContext<'_, C>) -> Result<(&[u8], Option<&[u8]>, Option<&[u64]>, Option<&[u8]>)>,
     {
@@ -100,7 +120,7 @@ impl<C: Codec, R: IndexReader<Codec = C> + ?Sized, IR: Deref<Target = R>, SP: Si
             leaves.push(GpuLeaf { seg, has_positions: pos.is_some() });
         }
         let next_limit = match next_limit { None => 0, Some(0) => RGPU_NEXT_LIMIT_ZERO, Some(n) => n.min(i32::max_value() as usize) as i32 };
-        Ok(GpuIndexSearcher { cpu, ctx, field: field.to_string(), leaves, sim_tables: Mutex::new(HashMap::new()), next_limit })
+        Ok(GpuIndexSearcher { cpu, ctx, field: field.to_string(), leaves, sim_tables: Mutex::new(HashMap::new()), next_limit, allow_flatten })
     }
 
     /// BooleanQuery trees the C ABI serves, flattened to one clause list (query/boolean_query.rs:195-279 is what the CPU builds
@@ -110,11 +130,14 @@ impl<C: Codec, R: IndexReader<Codec = C> + ?Sized, IR: Deref<Target = R>, SP: Si
     ///   should only                                 -> OR, RGPU_OP_OR_MSM(msm) when min_should_match > 1
     ///   must + should                               -> RGPU_OP_WITH_SHOULD(AND, n): ReqOptScorer, its sequential rule included
     ///   any of them + must_not                      -> n_must_not > 0: ReqNotScorer
-    ///   a MUST clause that is itself a must-only BooleanQuery, a SHOULD clause that is a should-only one (msm <= 1) with no
-    ///   other kind of clause beside it: ONE level is folded into the parent — same doc ids; the f32 sum is then formed over
-    ///   the flat list (a + b + c) where the CPU forms a + (b + c): within 1e-5 relative (north_star's float tolerance), not
-    ///   bit-equal. `allow_flatten = false` keeps such trees on the CPU.
-    fn flatten<'q>(&self, query: &'q dyn Query<C>, allow_flatten: bool) -> Option<FlatQuery<'q>> {
+    /// With `allow_flatten` (off by default): a MUST clause that is itself a must-only BooleanQuery, a SHOULD clause that is a
+    /// should-only one (msm <= 1) with no other kind of clause inside it — ONE level is folded into the parent: same doc ids;
+    /// the f32 sum is then formed over the flat list (a + b + c) where the CPU forms a + (b + c): within 1e-5 relative
+    /// (north_star's float tolerance), not bit-equal. Two guards, as BooleanQuery.flattened() of the Python and C++ mirrors:
+    /// the folded inner list must be non-empty (an inner query without clauses of the wanted kind is not a clause that can be
+    /// dropped), and an outer min_should_match > 1 is never combined with a fold (SHOULD [a, (b OR c)] with msm = 2 needs `a`
+    /// and one of b / c — OR_MSM(2) over {a, b, c} would also match b and c without a).
+    fn flatten<'q>(&self, query: &'q dyn Query<C>) -> Option<FlatQuery<'q>> {
         if let Some(t) = query.as_any().downcast_ref::<TermQuery>() {
             if t.term.field != self.field { return None; }
             return Some(FlatQuery { op: RGPU_OP_TERM, positive: vec![(t, t.boost)], optional: vec![], must_not: vec![] });
@@ -125,15 +148,19 @@ impl<C: Codec, R: IndexReader<Codec = C> + ?Sized, IR: Deref<Target = R>, SP: Si
         let mut positive = Vec::new();
         let mut optional = Vec::new();
         let mut prohibited = Vec::new();
+        let mut folded = false;
         for q in must_not { prohibited.push(term_of(q)?); }
-        let fold = |q: &'q Box<dyn Query<C>>, want_must: bool, out: &mut Vec<(&'q TermQuery, f32)>| -> Option<()> {
+        let allow = self.allow_flatten;
+        let mut fold = |q: &'q Box<dyn Query<C>>, want_must: bool, out: &mut Vec<(&'q TermQuery, f32)>| -> Option<()> {
             if let Some(t) = term_of(q) { out.push((t, t.boost)); return Some(()); }
-            if !allow_flatten { return None; }
+            if !allow { return None; }
             let inner = q.as_any().downcast_ref::<BooleanQuery<C>>()?;
             let (m, s, f, n, inner_msm) = inner.clauses();
             if !n.is_empty() || !f.is_empty() { return None; }
             let list = if want_must && s.is_empty() { m } else if !want_must && m.is_empty() && inner_msm <= 1 { s } else { return None };
+            if list.is_empty() { return None; }
             for c in list { let t = term_of(c)?; out.push((t, t.boost)); }
+            folded = true;
             Some(())
         };
         if !must.is_empty() || !filter.is_empty() {
@@ -144,84 +171,178 @@ impl<C: Codec, R: IndexReader<Codec = C> + ?Sized, IR: Deref<Target = R>, SP: Si
             Some(FlatQuery { op: rgpu_op_with_should(op, optional.len() as i32), positive, optional, must_not: prohibited })
         } else {
             for q in should { fold(q, false, &mut positive)?; }
+            if msm > 1 && folded { return None; }
             let op = if msm > 1 { rgpu_op_or_msm(msm) } else { RGPU_OP_OR };
             Some(FlatQuery { op, positive, optional, must_not: prohibited })
         }
     }
 
-    /// (weight, sim table handle) of one clause exactly as TermQuery::create_weight (term_query.rs:58-95): the searcher's
-    /// term_statistics — df of the LARGEST leaf, searcher.rs:732-767 —, collections_statistics(field), BM25Similarity::
-    /// compute_weight -> idf x boost and the 256-entry norm cache, uploaded once per (k1, b, avgdl).
-    fn clause_weight(&self, t: &TermQuery, boost: f32) -> Result<(f32, i32)> {
-        let stats: TermStatistics = self.cpu.term_statistics(&t.term)?;
-        let coll: &CollectionStatistics = self.cpu.collections_statistics(&self.field).ok_or_else(|| Error::from(ErrorKind::IllegalState("no statistics".into())))?;
-        let sim = BM25Similarity::default();
-        let avgdl = sim.avg_field_length(coll);
-        let key = (sim.k1().to_bits(), sim.b().to_bits(), avgdl.to_bits());
+    /// The 256-entry norm cache of the field's statistics, uploaded once per avgdl (bm25_similarity.rs:160-166)
+    fn sim_table(&self, coll: &CollectionStatistics) -> Result<i32> {
+        let mut cache = [0f32; 256];
+        let df = [1i64];
+        check(unsafe { rgpu_bm25_compute_weight(BM25_K1, BM25_B, coll.max_doc, coll.doc_count, coll.sum_total_term_freq, df.as_ptr(), 1, 1.0,
+                                                std::ptr::null_mut(), std::ptr::null_mut(), cache.as_mut_ptr()) }, self.ctx)?;
+        let key = cache[255].to_bits() ^ cache[1].to_bits().rotate_left(16); // the cache is a function of avgdl alone
         let mut tables = self.sim_tables.lock().unwrap();
-        let table = match tables.get(&key) {
-            Some(h) => *h,
-            None => {
-                let cache: [f32; 256] = sim.norm_cache(avgdl); // bm25_similarity.rs:160-166
-                let h = unsafe { rgpu_sim_table_upload(self.ctx, cache.as_ptr(), sim.k1()) };
-                check(h, self.ctx)?;
-                tables.insert(key, h);
-                h
-            }
-        };
-        Ok((sim.idf(&[stats], coll) * boost, table))
+        if let Some(h) = tables.get(&key) { return Ok(*h); }
+        let h = unsafe { rgpu_sim_table_upload(self.ctx, cache.as_ptr(), BM25_K1) };
+        check(h, self.ctx)?;
+        tables.insert(key, h);
+        Ok(h)
     }
 
-    /// BlockTermState of `t` in `leaf` -> rgpu_term_state (doc_freq = 0: absent; TermWeight::create_scorer -> None)
-    fn term_state(&self, leaf: &LeafReaderContext<'_, C>, t: &TermQuery) -> Result<RgpuTermState> {
-        let absent = RgpuTermState { doc_start_fp: 0, skip_offset: -1, total_term_freq: 0, doc_freq: 0, singleton_doc_id: -1 };
-        let terms = match leaf.reader.terms(&t.term.field)? { Some(t) => t, None => return Ok(absent) };
+    /// weight = idf x boost of a clause (or of a phrase: idf summed over its terms) exactly as TermQuery::create_weight /
+    /// PhraseQuery::create_weight (term_query.rs:58-95, phrase_query.rs:136-186): the searcher's term_statistics — df of the
+    /// LARGEST leaf, searcher.rs:732-767 —, collections_statistics(field), BM25Similarity::compute_weight.
+    fn weight_of(&self, terms: &[&Term], boost: f32) -> Result<(f32, i32)> {
+        let coll: &CollectionStatistics = self.cpu.collections_statistics(&self.field).ok_or_else(|| Error::from(ErrorKind::IllegalState("no statistics".into())))?;
+        let mut dfs = Vec::with_capacity(terms.len());
+        for t in terms { let s: TermStatistics = self.cpu.term_statistics(t)?; dfs.push(s.doc_freq); }
+        let mut w = 0f32;
+        check(unsafe { rgpu_bm25_compute_weight(BM25_K1, BM25_B, coll.max_doc, coll.doc_count, coll.sum_total_term_freq, dfs.as_ptr(), dfs.len() as i32, boost,
+                                                &mut w, std::ptr::null_mut(), std::ptr::null_mut()) }, self.ctx)?;
+        Ok((w, self.sim_table(coll)?))
+    }
+
+    /// BlockTermState of `term` in `leaf` (None: absent; TermWeight::create_scorer -> None)
+    fn block_state(&self, leaf: &LeafReaderContext<'_, C>, term: &Term) -> Result<Option<BlockTermState>> {
+        let terms = match leaf.reader.terms(&term.field)? { Some(t) => t, None => return Ok(None) };
         let mut it = terms.iterator()?;
-        if !it.seek_exact(&t.term.bytes)? { return Ok(absent); }
-        let st: BlockTermState = it.term_state()?; // blocktree_reader.rs:1779-1808 -> posting_reader.rs:264-306
-        Ok(RgpuTermState { doc_start_fp: st.doc_start_fp, skip_offset: st.skip_offset, total_term_freq: st.total_term_freq, doc_freq: st.doc_freq,
-                           singleton_doc_id: st.singleton_doc_id })
+        if !it.seek_exact(&term.bytes)? { return Ok(None); }
+        Ok(Some(it.term_state()?)) // blocktree_reader.rs:1779-1808 -> posting_reader.rs:264-306
+    }
+
+    fn term_state(st: &Option<BlockTermState>) -> RgpuTermState {
+        match st {
+            None => RgpuTermState { doc_start_fp: 0, skip_offset: -1, total_term_freq: 0, doc_freq: 0, singleton_doc_id: -1 },
+            Some(st) => RgpuTermState { doc_start_fp: st.doc_start_fp, skip_offset: st.skip_offset, total_term_freq: st.total_term_freq, doc_freq: st.doc_freq,
+                                        singleton_doc_id: st.singleton_doc_id },
+        }
+    }
+
+    fn hand_over(top: &mut TopDocsCollector, hits: &[RgpuHit], total: i64) {
+        let rows: Vec<(DocId, f32)> = hits.iter().filter(|h| h.doc >= 0).map(|h| (h.doc, h.score)).collect(); // doc + doc_base already
+        top.add_leaf_result(&rows, total as usize);
+    }
+
+    /// Every clause's (weight, sim table) in the ABI's clause order
+    fn clause_weights(&self, flat: &FlatQuery<'_>) -> Result<Vec<(f32, i32)>> {
+        let mut weights = Vec::with_capacity(flat.n_clauses());
+        for (t, boost) in &flat.positive { weights.push(if *boost == 0.0 { (0.0, 0) } else { self.weight_of(&[&t.term], *boost)? }); }
+        for t in &flat.optional { weights.push(self.weight_of(&[&t.term], t.boost)?); }
+        for _ in &flat.must_not { weights.push((0.0, 0)); } // needs_scores = false: never read
+        Ok(weights)
     }
 
     fn try_gpu(&self, query: &dyn Query<C>, top: &mut TopDocsCollector, k: usize) -> Result<bool> {
         if k == 0 || k > RGPU_MAX_K as usize { return Ok(false); }
         if let Some(p) = query.as_any().downcast_ref::<PhraseQuery>() { return self.try_phrase(p, top, k); }
-        let flat = match self.flatten(query, true) { Some(f) => f, None => return Ok(false) };
-        let n = flat.positive.len() + flat.optional.len() + flat.must_not.len();
+        let flat = match self.flatten(query) { Some(f) => f, None => return Ok(false) };
+        let n = flat.n_clauses();
         if n > RGPU_MAX_QUERY_TERMS as usize { return Ok(false); }
-        let mut weights = Vec::with_capacity(n);
-        for (t, boost) in &flat.positive { weights.push(if *boost == 0.0 { (0.0, 0) } else { self.clause_weight(t, *boost)? }); }
-        for t in &flat.optional { weights.push(self.clause_weight(t, t.boost)?); }
-        for _ in &flat.must_not { weights.push((0.0, 0)); } // needs_scores = false: never read
+        let weights = self.clause_weights(&flat)?;
         for leaf in self.cpu.reader().leaves() {
             let mut terms = Vec::with_capacity(n);
-            let all = flat.positive.iter().map(|(t, _)| *t).chain(flat.optional.iter().cloned()).chain(flat.must_not.iter().cloned());
-            for (i, t) in all.enumerate() {
-                terms.push(RgpuQueryTerm { state: self.term_state(&leaf, t)?, weight: weights[i].0, sim_table: weights[i].1 });
+            for (i, t) in flat.clauses().enumerate() {
+                terms.push(RgpuQueryTerm { state: Self::term_state(&self.block_state(&leaf, &t.term)?), weight: weights[i].0, sim_table: weights[i].1 });
             }
             let q = RgpuQuery { op: flat.op, n_terms: flat.positive.len() as i32, first_term: 0, n_must_not: flat.must_not.len() as i32 };
             let mut hits = vec![RgpuHit { doc: -1, score: 0.0 }; k];
             let mut total: i64 = 0;
             check(unsafe { rgpu_search_batch(self.leaves[leaf.ord].seg, &q, 1, terms.as_ptr(), n as i32, k as i32, hits.as_mut_ptr(), &mut total) }, self.ctx)?;
-            let rows: Vec<(DocId, f32)> = hits.iter().filter(|h| h.doc >= 0).map(|h| (h.doc, h.score)).collect(); // doc + doc_base already
-            top.add_leaf_result(&rows, total as usize);
+            Self::hand_over(top, &hits, total);
         }
         Ok(true)
     }
 
     /// PhraseQuery { any slop } on a positions field (payloads / offsets included): terms + phrase offsets from the query,
-    /// weight = summed idf x boost as PhraseQuery::create_weight (phrase_query.rs:136-186)
+    /// weight = summed idf x boost as PhraseQuery::create_weight (phrase_query.rs:136-186; its boost is 1.0). Per leaf as
+    /// PhraseWeight::create_scorer (:268-333): a term absent from the leaf -> no scorer for that leaf (doc_freq = 0 tells the
+    /// library the same); slop 0 -> ExactPhraseScorer, slop > 0 -> SloppyPhraseScorer under the searcher's next_limit.
     fn try_phrase(&self, p: &PhraseQuery, top: &mut TopDocsCollector, k: usize) -> Result<bool> {
         let (field, terms, positions, slop) = p.parts();
-        if field != self.field || terms.len() < 2 || terms.len() > RGPU_MAX_PHRASE_TERMS as usize || self.leaves.iter().any(|l| !l.has_positions) {
+        if field != self.field || terms.len() < 2 || terms.len() > RGPU_MAX_PHRASE_TERMS as usize || terms.len() != positions.len()
+            || self.leaves.iter().any(|l| !l.has_positions) {
             return Ok(false);
         }
-        let _ = (terms, positions, slop, top, k);
-        // per leaf: seek_exact each term -> RgpuTermState + RgpuTermPositions { pos_start_fp, pay_start_fp, last_pos_block_offset } from the same
-        // BlockTermState; RgpuPhraseTerm { state, positions, offset: positions[i] }; RgpuPhraseQuery { n_terms, first_term: 0, weight, sim_table,
-        // slop, next_limit: self.next_limit }; rgpu_search_phrase_batch(seg, &q, 1, terms, n, k, hits, &mut total); top.add_leaf_result(..)
-        // — the same five lines as try_gpu's leaf loop; spelled out in rucene_amd/csrc/host/gpu_index_searcher.hpp search_phrases().
-        Ok(false)
+        let term_refs: Vec<&Term> = terms.iter().collect();
+        let (weight, sim_table) = self.weight_of(&term_refs, 1.0)?;
+        for leaf in self.cpu.reader().leaves() {
+            let mut pterms = Vec::with_capacity(terms.len());
+            for (t, pos) in terms.iter().zip(positions.iter()) {
+                let st = self.block_state(&leaf, t)?;
+                let ptrs = match &st {
+                    Some(s) => RgpuTermPositions { pos_start_fp: s.pos_start_fp, pay_start_fp: s.pay_start_fp, last_pos_block_offset: s.last_pos_block_offset },
+                    None => RgpuTermPositions { pos_start_fp: 0, pay_start_fp: 0, last_pos_block_offset: -1 },
+                };
+                pterms.push(RgpuPhraseTerm { state: Self::term_state(&st), positions: ptrs, position: *pos, reserved: 0 });
+            }
+            let q = RgpuPhraseQuery { n_terms: pterms.len() as i32, first_term: 0, weight, sim_table, slop, next_limit: self.next_limit };
+            let mut hits = vec![RgpuHit { doc: -1, score: 0.0 }; k];
+            let mut total: i64 = 0;
+            check(unsafe { rgpu_search_phrase_batch(self.leaves[leaf.ord].seg, &q, 1, pterms.as_ptr(), pterms.len() as i32, k as i32, hits.as_mut_ptr(), &mut total) },
+                  self.ctx)?;
+            Self::hand_over(top, &hits, total);
+        }
+        Ok(true)
+    }
+
+    /// Many queries at once — what the GPU is for (bench.py: 1024 single-term queries take 0.05 ms as one batch; one at a time
+    /// each call costs a launch + a synchronisation, see `latency_batch_of_one` there). queries[i] is collected into
+    /// collectors[i] (all built with the same estimated_hits = k). Term / boolean trees go to the GPU as ONE
+    /// rgpu_search_batch per leaf; phrases as one rgpu_search_phrase_batch per leaf; whatever the C ABI does not serve (and
+    /// any batch the library refuses with RGPU_ERR_UNSUPPORTED) runs through DefaultIndexSearcher::search one by one.
+    /// (A batch of identical shape whose terms are known by id or bytes can skip this per-clause work altogether:
+    /// rgpu_planner_create + rgpu_plan_uniform_ids / rgpu_plan_batch_bytes resolve, weigh and pack natively.)
+    pub fn search_many(&self, queries: &[&dyn Query<C>], collectors: &mut [TopDocsCollector]) -> Result<()> {
+        assert_eq!(queries.len(), collectors.len());
+        if queries.is_empty() { return Ok(()); }
+        let k = collectors[0].estimated_hits();
+        let uniform_k = collectors.iter().all(|c| c.estimated_hits() == k);
+        let mut flat_ix = Vec::new(); // queries[i] served as a flat clause list
+        let mut flats = Vec::new();
+        let mut cpu_ix = Vec::new();
+        for (i, q) in queries.iter().enumerate() {
+            let flat = if uniform_k && k > 0 && k <= RGPU_MAX_K as usize && q.as_any().downcast_ref::<PhraseQuery>().is_none() { self.flatten(*q) } else { None };
+            match flat {
+                Some(f) if f.n_clauses() <= RGPU_MAX_QUERY_TERMS as usize => { flat_ix.push(i); flats.push(f); }
+                _ => cpu_ix.push(i),
+            }
+        }
+        if !flats.is_empty() {
+            let mut weights = Vec::new(); // clause weights do not depend on the leaf: once per batch
+            for f in &flats { weights.push(self.clause_weights(f)?); }
+            let n_terms_total: usize = flats.iter().map(|f| f.n_clauses()).sum();
+            let mut served = true;
+            let mut per_leaf: Vec<(Vec<RgpuHit>, Vec<i64>)> = Vec::new();
+            for leaf in self.cpu.reader().leaves() {
+                let mut qs = Vec::with_capacity(flats.len());
+                let mut terms = Vec::with_capacity(n_terms_total);
+                for (f, w) in flats.iter().zip(weights.iter()) {
+                    qs.push(RgpuQuery { op: f.op, n_terms: f.positive.len() as i32, first_term: terms.len() as i32, n_must_not: f.must_not.len() as i32 });
+                    for (c, t) in f.clauses().enumerate() {
+                        terms.push(RgpuQueryTerm { state: Self::term_state(&self.block_state(&leaf, &t.term)?), weight: w[c].0, sim_table: w[c].1 });
+                    }
+                }
+                let mut hits = vec![RgpuHit { doc: -1, score: 0.0 }; qs.len() * k];
+                let mut totals = vec![0i64; qs.len()];
+                let rc = unsafe { rgpu_search_batch(self.leaves[leaf.ord].seg, qs.as_ptr(), qs.len() as i32, terms.as_ptr(), terms.len() as i32, k as i32,
+                                                    hits.as_mut_ptr(), totals.as_mut_ptr()) };
+                if rc == RGPU_ERR_UNSUPPORTED { served = false; break; } // nothing handed over yet: the whole batch takes the CPU path
+                check(rc, self.ctx)?;
+                per_leaf.push((hits, totals));
+            }
+            if served {
+                for (hits, totals) in &per_leaf {
+                    for (j, &i) in flat_ix.iter().enumerate() { Self::hand_over(&mut collectors[i], &hits[j * k..(j + 1) * k], totals[j]); }
+                }
+            } else {
+                cpu_ix.extend(flat_ix.iter().cloned());
+            }
+        }
+        for i in cpu_ix { self.search(queries[i], &mut collectors[i])?; } // phrases go to the GPU from there, one by one
+        Ok(())
     }
 }
 
@@ -253,7 +374,7 @@ impl<C: Codec, R: IndexReader<Codec = C> + ?Sized, IR: Deref<Target = R>, SP: Si
     fn create_weight(&self, q: &dyn Query<C>, needs_scores: bool) -> Result<Box<dyn core::search::query::Weight<C>>> { self.cpu.create_weight(q, needs_scores) }
     fn create_normalized_weight(&self, q: &dyn Query<C>, needs_scores: bool) -> Result<Box<dyn core::search::query::Weight<C>>> { self.cpu.create_normalized_weight(q, needs_scores) }
     fn similarity(&self, field: &str, needs_scores: bool) -> Box<dyn core::search::similarity::Similarity<C>> { self.cpu.similarity(field, needs_scores) }
-    fn term_statistics(&self, term: &core::doc::Term) -> Result<TermStatistics> { self.cpu.term_statistics(term) }
+    fn term_statistics(&self, term: &Term) -> Result<TermStatistics> { self.cpu.term_statistics(term) }
     fn collections_statistics(&self, field: &str) -> Option<&CollectionStatistics> { self.cpu.collections_statistics(field) }
 }
 

@@ -103,6 +103,84 @@ def test_rust_shim_files_follow_the_header(gpu_lib):
     assert used and used <= bound, used - bound   # the seam only calls what ffi.rs declares
 
 
+def _rust_fn_bodies(text):
+    """(name, body) of every `fn` in a Rust source, by brace matching (strings / comments in this file hold no braces that matter)"""
+    import re
+    out = []
+    for m in re.finditer(r"\bfn (\w+)", text):
+        i = text.find("{", m.end())
+        semi = text.find(";", m.end())
+        if i < 0 or (0 <= semi < i):
+            continue   # a declaration without a body
+        depth, j = 0, i
+        while j < len(text):
+            if text[j] == "{":
+                depth += 1
+            elif text[j] == "}":
+                depth -= 1
+                if depth == 0:
+                    break
+            j += 1
+        out.append((m.group(1), text[i + 1:j]))
+    return out
+
+
+def test_rust_shim_has_no_stub_bodies():
+    """VERDICT r5 missing 4: `try_phrase` bound its arguments to `_` and returned Ok(false). No fn of the shim may END in an
+    unconditional Ok(false) (an early `return Ok(false)` behind a condition is the fallback rule and fine), bind its work away
+    with `let _ = (...)`, or be shorter than a real body; try_phrase / search_many must make the calls they are there for."""
+    import re
+    text = open(os.path.join(ROOT, "rust", "gpu", "searcher.rs")).read()
+    code = re.sub(r"//[^\n]*", "", text)
+    bodies = dict(_rust_fn_bodies(code))
+    for name in ("open", "flatten", "try_gpu", "try_phrase", "search_many", "search", "weight_of", "block_state"):
+        assert name in bodies, name
+    for name, body in bodies.items():
+        tail = body.strip().rstrip(";").strip()
+        assert not re.search(r"(^|[;}\s])Ok\(false\)$", tail), "fn %s ends in an unconditional Ok(false)" % name
+        assert "let _ = (" not in body, "fn %s binds its arguments away" % name
+        assert "unimplemented!" not in body and "todo!" not in body, name
+    assert "rgpu_search_phrase_batch(" in bodies["try_phrase"] and "add_leaf_result" in code and "hand_over" in bodies["try_phrase"]
+    assert "rgpu_search_batch(" in bodies["search_many"] and "hand_over" in bodies["search_many"]
+    # ADVICE r5: nested folding is opt-in and never meets an outer min_should_match > 1; an empty folded list is refused
+    assert "allow_flatten: bool" in code and "if msm > 1 && folded { return None; }" in code and "if list.is_empty() { return None; }" in code
+    assert "self.flatten(query, true)" not in code
+
+
+def test_rust_accessor_patch_applies():
+    """rust/rucene_accessors.patch: zero-context hunks anchored on `impl` lines. Here (where /root/reference exists) the anchors are
+    checked against the crate and `patch --dry-run` must accept the file on a scratch copy; on a box without the reference only
+    the patch's own arithmetic is checked (hunk lengths = the '+' lines that follow)."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    path = os.path.join(ROOT, "rust", "rucene_accessors.patch")
+    lines = open(path).read().split("\n")
+    files, cur = {}, None
+    for i, line in enumerate(lines):
+        if line.startswith("+++ b/"):
+            cur = line[6:].strip()
+        m = re.match(r"@@ -(\d+),0 \+(\d+),(\d+) @@ (.*)", line)
+        if m:
+            n = 0
+            while i + 1 + n < len(lines) and lines[i + 1 + n].startswith("+") and not lines[i + 1 + n].startswith("+++"):
+                n += 1
+            assert n == int(m.group(3)) and int(m.group(2)) == int(m.group(1)) + 1, line
+            files[cur] = (int(m.group(1)), m.group(4).strip())
+    assert len(files) == 3
+    ref = "/root/reference"
+    if not os.path.isdir(ref) or shutil.which("patch") is None:
+        return
+    with tempfile.TemporaryDirectory() as tmp:
+        for rel, (n, anchor) in files.items():
+            src = open(os.path.join(ref, rel)).read().split("\n")
+            assert src[n - 1].strip() == anchor, (rel, n, src[n - 1])
+            os.makedirs(os.path.dirname(os.path.join(tmp, rel)), exist_ok=True)
+            shutil.copy(os.path.join(ref, rel), os.path.join(tmp, rel))
+        subprocess.run(["patch", "-p1", "--dry-run", "-s", "-i", path], cwd=tmp, check=True)
+
+
 def test_struct_layouts_match_the_header(gpu_lib):
     assert gpu_lib.TERM_STATE_DTYPE.itemsize == 32
     assert gpu_lib.TERM_POSITIONS_DTYPE.itemsize == 24 and gpu_lib.FIELD_INFO_DTYPE.itemsize == 16 and gpu_lib.FIELD_STATS_DTYPE.itemsize == 32
@@ -111,8 +189,8 @@ def test_struct_layouts_match_the_header(gpu_lib):
     assert gpu_lib.TERM_STATE_DTYPE.fields["doc_freq"][1] == 24 and gpu_lib.TERM_STATE_DTYPE.fields["singleton_doc_id"][1] == 28
     assert gpu_lib.QUERY_TERM_DTYPE.itemsize == 40 and gpu_lib.QUERY_TERM_DTYPE.fields["weight"][1] == 32
     assert gpu_lib.QUERY_DTYPE.itemsize == 16 and gpu_lib.HIT_DTYPE.itemsize == 8
-    assert C.sizeof(gpu_lib._Config) == 64
-    assert gpu_lib.lib().rgpu_abi_version() == 5 == gpu_lib.ABI_VERSION
+    assert C.sizeof(gpu_lib._Config) == 68
+    assert gpu_lib.lib().rgpu_abi_version() == 6 == gpu_lib.ABI_VERSION
 
 
 def test_bm25_host_helper_is_bit_exact_with_the_oracle(gpu_lib, oracle):
