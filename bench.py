@@ -146,7 +146,8 @@ HOISTED = [
     ("sharded_forced_gather_ratio_two_streams", "sharded_overhead.forced_gather.ratio_two_streams"),
     ("sharded_forced_gathers_issued", "sharded_overhead.forced_gather.gathers_issued"),
     ("sharded_forced_gather_same_rows", "sharded_overhead.forced_gather.same_rows"),
-    ("one_stream_ms_per_step", "one_stream_ms_per_step"), ("resident_plan_ms_per_step", "streams.ms_resident_plan_two_streams"),
+    ("one_stream_ms_per_step", "one_stream_ms_per_step"), ("two_calls_ms_per_step", "streams.ms_two_calls_two_streams"),
+    ("fused_same_rows_as_two_calls", "fused_same_rows_as_two_calls"), ("resident_plan_ms_per_step", "streams.ms_resident_plan_two_streams"),
     ("kernel_plus_merge_ms", "kernel_plus_merge_ms"), ("step_over_kernels", "step_over_kernels"),
 ]
 LINE_REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
@@ -343,6 +344,14 @@ def main():
         merged = {}
         T, B = rucene_amd.TermQuery, rucene_amd.BooleanQuery
 
+        def step_fused(n_lanes):
+            """the serving step: term ids -> rows, ONE call behind the C ABI (rgpu_planner_search_uniform_ids_device / _sharded)"""
+            lane = lanes[state["n"] % n_lanes]
+            state["n"] += 1
+            merged["hits"], merged["totals"] = lane.hits, lane.totals
+            shard.searcher.search_uniform_device(OPS[kind], tids, shard.leaf, k, lane.hits.data_ptr(), lane.totals.data_ptr(), lane.stream.cuda_stream,
+                                                 comm=comm if dist_mode else None)
+
         def step(pk, n_lanes):
             lane = lanes[state["n"] % n_lanes]
             state["n"] += 1
@@ -381,6 +390,9 @@ def main():
             gc.disable()
             t = time.perf_counter()
             for _ in range(n_steps):
+                if replan == "fused":
+                    step_fused(n_lanes)
+                    continue
                 if replan == "objects":
                     pk = shard.searcher.pack(qs, shard.leaf)
                 elif replan == "array":
@@ -407,9 +419,21 @@ def main():
         # (a fixed number of steps, not a time: with N > 1 every step is a collective, and the ranks must make the same calls)
         for _ in range({"term": 256, "and3": 64}.get(kind, 4)):
             step(packed, 2)
+        step_fused(2)
         torch.cuda.synchronize()
-        res["regions"] = {"ms_planned_two_streams": timed(2, "array"), "ms_planned_one_stream": timed(1, "array")}
+        fused_same = True
+        if not dist_mode:   # the fused call's rows are the two calls' rows
+            a, b = lanes[0], lanes[1]
+            shard.leaf.segment.search_batch_device(packed[0], packed[1], k, a.hits.data_ptr(), a.totals.data_ptr(), a.stream.cuda_stream)
+            shard.searcher.search_uniform_device(OPS[kind], tids, shard.leaf, k, b.hits.data_ptr(), b.totals.data_ptr(), b.stream.cuda_stream)
+            ctx.synchronize()
+            torch.cuda.synchronize()
+            fused_same = bool(torch.equal(a.hits, b.hits)) and bool(torch.equal(a.totals, b.totals))
+        res["fused_same_rows_as_two_calls"] = fused_same
+        res["regions"] = {"ms_planned_two_streams": timed(2, "fused"), "ms_planned_one_stream": timed(1, "fused")}
         if full:
+            res["regions"]["ms_two_calls_two_streams"] = timed(2, "array")
+            res["regions"]["ms_two_calls_one_stream"] = timed(1, "array")
             res["regions"]["ms_resident_plan_two_streams"] = timed(2, False)
             res["regions"]["ms_resident_plan_one_stream"] = timed(1, False)
             res["regions"]["ms_object_planner_one_stream"] = timed(1, "objects", max(3, steps // 4), 3)
@@ -623,9 +647,8 @@ def main():
             lanes = [Lane(k), Lane(k)]
 
             def one(i):
-                pk = sn.pack_uniform(OPS["term"], tids, leaf)
                 lane = lanes[i % 2]
-                leaf.segment.search_batch_device(pk[0], pk[1], k, lane.hits.data_ptr(), lane.totals.data_ptr(), lane.stream.cuda_stream)
+                sn.search_uniform_device(OPS["term"], tids, leaf, k, lane.hits.data_ptr(), lane.totals.data_ptr(), lane.stream.cuda_stream)
             for i in range(6):
                 one(i)
             torch.cuda.synchronize()
@@ -659,7 +682,7 @@ def main():
             leaf.segment.close()
             return {"ms_per_step": ms, "queries_per_sec": nq / (ms * 1e-3), "same_rows_as_with_sketches": same,
                     "ms_resident_plan_two_streams": ms_resident, "k_search_term_ms": kernel_ms, "blocks_unpacked": blocks,
-                    "issue": "RGPU_TERM_SKETCH=0: two alternating streams, every step planned"}
+                    "issue": "RGPU_TERM_SKETCH=0: two alternating streams, every step planned (the fused call)"}
         finally:
             ctx_n.close()
 
@@ -679,7 +702,7 @@ def main():
                "queries_per_sec": nq / (ms * 1e-3),
                "postings_covered_per_step": r["postings"], "postings_decoded_per_step": c["postings_decoded"],
                "postings_decoded_per_sec": c["postings_decoded"] / (ms * 1e-3), "postings_covered_per_sec": r["postings"] / (ms * 1e-3),
-               "issue": "two alternating streams" if two_wins else "one stream",
+               "issue": "two alternating streams" if two_wins else "one stream", "fused_same_rows_as_two_calls": r["fused_same_rows_as_two_calls"],
                "kernels_ms_isolated": r["kernels_ms"]}
         if kind == "or10":
             # k_or_lazy walks the clauses without a doc bitmap (k_score_terms decodes them) and reads the others' bitmap words;
@@ -714,11 +737,12 @@ def main():
         # the step cannot have moved its bytes faster than the memory system allows
         assert out["roofline"]["bytes_per_launch"] / (ms * 1e-3) / 1e9 <= HBM_PEAK_GBS, "bytes / ms_per_step exceeds the HBM peak"
         if full:
-            out["streams"] = {k2: r[k2] for k2 in ("ms_planned_two_streams", "ms_planned_one_stream", "ms_resident_plan_two_streams",
-                                                   "ms_resident_plan_one_stream", "ms_object_planner_one_stream")}
+            out["streams"] = {k2: r[k2] for k2 in ("ms_planned_two_streams", "ms_planned_one_stream", "ms_two_calls_two_streams", "ms_two_calls_one_stream",
+                                                   "ms_resident_plan_two_streams", "ms_resident_plan_one_stream", "ms_object_planner_one_stream")}
             out["streams"]["min_median_max"] = {k2: [v["min"], v["median"], v["max"]] for k2, v in r["regions"].items()}
-            out["streams"]["note"] = ("ms per step. planned = term ids -> rgpu_query_term[] redone in every step by the native planner behind the C ABI "
-                                      "(rgpu_plan_uniform_ids: term states, BM25 weights, sim table) — the headline; resident plan = planned once; "
+            out["streams"]["note"] = ("ms per step. planned = term ids -> rows in ONE call per step (rgpu_planner_search_uniform_ids_device: term states, BM25 "
+                                      "weights, device descriptors, three enqueues) — the headline; two calls = rgpu_plan_uniform_ids then "
+                                      "rgpu_search_batch_device (rounds 3-5's headline); resident plan = planned once, searched every step; "
                                       "object planner = one Python query object per query flattened first (GpuIndexSearcher.pack), then the native planner")
         if kind == "or10" and world == 1 and not dist_mode:
             out["deferred"] = or_deferred_leg(shard, k, steps, r)
@@ -1012,7 +1036,7 @@ def main():
             "postings_covered_per_step_per_shard": res["postings"], "postings_decoded_per_step_per_shard": head["postings_decoded_per_step"],
             "index_build_s": round(shard.build_s, 2), "segment_upload_s": round(shard.upload_s, 3), "device": ctx.device_name,
             "timed_regions": "%d regions of %d steps, median region reported (min / median / max in ms_per_step_min_median_max)" % (head["timed_regions"], args.steps),
-            "issue": "value = %s, every step plans its batch (native planner behind the C ABI) and enqueues it; inputs (index) resident in HBM" % head["issue"],
+            "issue": "value = %s, every step plans its batch from term ids and enqueues it (one C-ABI call: rgpu_planner_search_uniform_ids_device); inputs (index) resident in HBM" % head["issue"],
         },
         "ms_per_step_min_median_max": head["ms_per_step_min_median_max"],
         "streams": head["streams"],
@@ -1037,6 +1061,7 @@ def main():
     out["kernel_plus_merge_ms"] = kp
     out["step_over_kernels"] = ms_per_step / kp if kp > 0 else None
     out["step_over_kernels_one_stream"] = head["streams"]["ms_planned_one_stream"] / kp if kp > 0 else None
+    out["fused_same_rows_as_two_calls"] = head["fused_same_rows_as_two_calls"]
     out["one_stream_ms_per_step"] = head["streams"]["ms_planned_one_stream"]
     out["one_stream_queries_per_sec"] = nq / (head["streams"]["ms_planned_one_stream"] * 1e-3)
     # N > 1: the batch is replicated, so the ranks together answer nq queries over an index of world x docs — that rate next to
@@ -1069,9 +1094,8 @@ def main():
         forced = {}
         for n_lanes in (2, 1):
             def onef(i):
-                pk = sf.pack_uniform(OPS[kind], tids, leaf_f)
                 lane = lanes[i % n_lanes]
-                cf.search_batch_sharded(leaf_f.segment, pk[0], pk[1], k, lane.hits.data_ptr(), lane.totals.data_ptr(), lane.stream.cuda_stream)
+                sf.search_uniform_device(OPS[kind], tids, leaf_f, k, lane.hits.data_ptr(), lane.totals.data_ptr(), lane.stream.cuda_stream, comm=cf)
             for i in range(6):
                 onef(i)
             torch.cuda.synchronize()
@@ -1085,12 +1109,9 @@ def main():
         for name in ("local", "sharded"):
             for n_lanes in (2, 1):
                 def one(i):
-                    pk = shard.searcher.pack_uniform(OPS[kind], tids, shard.leaf)
                     lane = lanes[i % n_lanes]
-                    if name == "local":
-                        shard.leaf.segment.search_batch_device(pk[0], pk[1], k, lane.hits.data_ptr(), lane.totals.data_ptr(), lane.stream.cuda_stream)
-                    else:
-                        c1.search_batch_sharded(shard.leaf.segment, pk[0], pk[1], k, lane.hits.data_ptr(), lane.totals.data_ptr(), lane.stream.cuda_stream)
+                    shard.searcher.search_uniform_device(OPS[kind], tids, shard.leaf, k, lane.hits.data_ptr(), lane.totals.data_ptr(), lane.stream.cuda_stream,
+                                                         comm=None if name == "local" else c1)
                 for i in range(6):
                     one(i)
                 torch.cuda.synchronize()

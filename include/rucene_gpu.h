@@ -504,6 +504,19 @@ int32_t rgpu_plan_uniform_ids(rgpu_planner* planner, int32_t op, int32_t n_queri
                               rgpu_query* queries_out, rgpu_query_term* terms_out);
 int32_t rgpu_plan_uniform_bytes(rgpu_planner* planner, int32_t op, int32_t n_queries, int32_t n_clauses, const uint8_t* term_bytes,
                                 const int64_t* term_offsets, rgpu_query* queries_out, rgpu_query_term* terms_out);
+/* Plan + search in ONE call: rgpu_plan_uniform_ids followed by rgpu_search_batch_device on `seg` (the leaf the planner's
+ * flat table belongs to), without the rgpu_query[] / rgpu_query_term[] arrays in between — per query what IndexSearcher::search
+ * does from the top (search/searcher.rs:487-525: create_normalized_weight -> TermQuery::create_weight, term_query.rs:58-95;
+ * then per leaf TermWeight::create_scorer, :145-163, and the collector loop). Same rows as the two calls, bit for bit; enqueue-
+ * only like rgpu_search_batch_device (rgpu_config.or_deferred applies). Single-term batches whose terms are all prepared take
+ * a one-pass path (planner entry -> device descriptor, three enqueues: the host's share of a 1024-query batch drops from ~63
+ * to ~30 us); every other batch is planned and searched as the two calls would. Flat-table planners only. */
+int32_t rgpu_planner_search_uniform_ids_device(rgpu_planner* planner, rgpu_segment* seg, int32_t op, int32_t n_queries, int32_t n_clauses,
+                                               const int64_t* term_ids, int32_t k, void* hits_dev, void* total_hits_dev, void* hip_stream);
+/* ... and as rgpu_search_batch_sharded: this rank's plan + search -> the all-gather of the shards' records -> the merge. */
+int32_t rgpu_planner_search_uniform_ids_sharded(rgpu_comm* comm, rgpu_planner* planner, rgpu_segment* seg, int32_t op, int32_t n_queries,
+                                                int32_t n_clauses, const int64_t* term_ids, int32_t k, void* hits_dev, void* total_hits_dev,
+                                                void* hip_stream);
 /* Any mix: ops[q] as rgpu_query.op (incl. RGPU_OP_OR_MSM / RGPU_OP_WITH_SHOULD), n_terms[q] / n_must_not[q] as in rgpu_query;
  * a query's terms follow each other in the order scored, optional SHOULD, MUST_NOT; boosts (NULL: all 1) one per term.
  * terms_cap = room in terms_out. */

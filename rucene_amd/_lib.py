@@ -59,7 +59,7 @@ EXPORTS = [
     "rgpu_search_batch_sharded", "rgpu_comm_status", "rgpu_comm_reserve", "rgpu_comm_gathers_issued", "rgpu_comm_init_all", "rgpu_search_batch_sharded_all", "rgpu_record_bytes",
     "rgpu_search_batch_record_device", "rgpu_merge_records_device", "rgpu_last_search_counters",
     "rgpu_planner_create", "rgpu_planner_create_flat", "rgpu_planner_destroy", "rgpu_planner_sim_table", "rgpu_planner_set_sim_table", "rgpu_plan_uniform_ids",
-    "rgpu_plan_uniform_bytes", "rgpu_plan_batch_ids", "rgpu_plan_batch_bytes",
+    "rgpu_plan_uniform_bytes", "rgpu_plan_batch_ids", "rgpu_plan_batch_bytes", "rgpu_planner_search_uniform_ids_device", "rgpu_planner_search_uniform_ids_sharded",
 ]
 
 
@@ -191,6 +191,8 @@ def lib():
         "rgpu_planner_set_sim_table": (i32, [vp, i32]),
         "rgpu_plan_uniform_ids": (i32, [vp, i32, i32, i32, vp, vp, vp]),
         "rgpu_plan_uniform_bytes": (i32, [vp, i32, i32, i32, vp, vp, vp, vp]),
+        "rgpu_planner_search_uniform_ids_device": (i32, [vp, vp, i32, i32, i32, vp, i32, vp, vp, vp]),
+        "rgpu_planner_search_uniform_ids_sharded": (i32, [vp, vp, vp, i32, i32, i32, vp, i32, vp, vp, vp]),
         "rgpu_plan_batch_ids": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, vp, i64]),
         "rgpu_plan_batch_bytes": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i64]),
     }
@@ -517,6 +519,19 @@ class Planner:
         ts = np.empty(nq * nc, dtype=QUERY_TERM_DTYPE)
         _check(lib().rgpu_plan_uniform_bytes(self._h, int(op), nq, nc, flat.ctypes.data, offs.ctypes.data, qs.ctypes.data, ts.ctypes.data))
         return qs, ts
+
+    def search_uniform_device(self, segment, op, term_ids, k, hits_ptr, totals_ptr, stream=0, comm=None):
+        """rgpu_planner_search_uniform_ids_device (comm: ..._sharded): plan + search in one call, enqueue-only. `term_ids`
+        [n_queries, n_clauses] flat-table ids (int64, C-contiguous: handed over as they are)."""
+        ids = term_ids if (isinstance(term_ids, np.ndarray) and term_ids.dtype == np.int64 and term_ids.flags.c_contiguous) else np.ascontiguousarray(term_ids, dtype=np.int64)
+        if ids.ndim == 1:
+            ids = ids.reshape(-1, 1)
+        nq, nc = ids.shape
+        if comm is None:
+            _check(lib().rgpu_planner_search_uniform_ids_device(self._h, segment._h, int(op), nq, nc, ids.ctypes.data, int(k), hits_ptr, totals_ptr, stream or None))
+        else:
+            _check(lib().rgpu_planner_search_uniform_ids_sharded(comm._h, self._h, segment._h, int(op), nq, nc, ids.ctypes.data, int(k), hits_ptr, totals_ptr,
+                                                                 stream or None))
 
     def plan_batch(self, ops, n_terms, terms, n_must_not=None, boosts=None):
         """Any mix of trees: ops[q] as rgpu_query.op, n_terms[q] / n_must_not[q], `terms` in clause order (ids or byte strings)."""

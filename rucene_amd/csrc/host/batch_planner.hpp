@@ -112,6 +112,24 @@ class BatchPlanner {
     return RGPU_OK;
   }
 
+  // The flat-table planner's per-clause work WITHOUT the arrays in between (the fused plan + search entry points write device
+  // descriptors straight from it): f(i, state, weight) for every id, boost 1, under the planner's lock. An id outside the
+  // table, or a term the leaf does not hold, arrives with doc_freq = 0 (TermWeight::create_scorer -> None).
+  template <class F>
+  void for_each_flat(const int64_t* ids, int64_t n, F&& f) {
+    std::lock_guard<std::mutex> g(mu_);
+    const int64_t n_leaf = (int64_t)leaf_states_.size();
+    const int64_t n_stats = own_stats_ ? (int64_t)stats_df_.size() : n_leaf;
+    const rgpu_term_state none = absent();
+    for (int64_t i = 0; i < n; ++i) {
+      const int64_t id = ids[i];
+      const rgpu_term_state& st = (id >= 0 && id < n_leaf && leaf_states_[(size_t)id].doc_freq > 0) ? leaf_states_[(size_t)id] : none;
+      int32_t df = 0;
+      if (id >= 0 && id < n_stats) df = own_stats_ ? stats_df_[(size_t)id] : leaf_states_[(size_t)id].doc_freq;
+      f(i, st, idf_of(df > 0 ? df : 0));
+    }
+  }
+
  private:
   static rgpu_term_state absent() { return rgpu_term_state{0, -1, 0, 0, -1}; }
   void init() {

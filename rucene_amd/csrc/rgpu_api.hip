@@ -213,6 +213,7 @@ struct rgpu_ctx {
   int last_and_queries = 0;
   // rgpu_last_search_counters: the most recent TERM / AND / wide-OR launch
   Scratch* last_counted = nullptr;
+  const unsigned long long* last_counted_words = nullptr;  // [touched bytes per query][blocks per query] of that launch (the slot's d_touched, or inside its stage)
   int last_counted_op = -1, last_counted_queries = 0;
   int64_t last_counted_dir_blocks = 0;   // TERM: blocks whose directory words the launch looked at (all of them)
   int64_t last_counted_loose = 0;        // postings outside FullBlocks (prepared tails, singletons) of the (lead) clauses
@@ -363,6 +364,7 @@ static hipError_t scratch_take(rgpu_ctx* c) {
     sc->busy = false;
   }
   c->S = sc;
+  if (c->last_counted == sc) { c->last_counted = nullptr; c->last_counted_words = nullptr; }  // (its counters may live in the slot's stage: gone with the reuse)
   return hipSuccess;
 }
 // ... and mark it in flight once everything that reads it has been enqueued on `s`
@@ -1127,7 +1129,7 @@ extern "C" int32_t rgpu_last_search_counters(rgpu_ctx* c, rgpu_search_counters* 
   if (c->last_counted->busy) { HIP_TRY(hipEventSynchronize(c->last_counted->done)); c->last_counted->busy = false; }
   const size_t nq = (size_t)c->last_counted_queries;
   std::vector<unsigned long long> h(nq * 2);
-  HIP_TRY(hipMemcpy(h.data(), c->last_counted->d_touched.p, nq * 16, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(h.data(), c->last_counted_words ? c->last_counted_words : c->last_counted->d_touched.p, nq * 16, hipMemcpyDeviceToHost));
   for (size_t q = 0; q < nq; ++q) { out->touched_bytes += (int64_t)h[q]; out->blocks_decoded += (int64_t)h[nq + q]; }
   if (c->last_counted_op == RGPU_OP_TERM) out->touched_bytes += 14 * c->last_counted_dir_blocks;
   out->postings_decoded = 128 * out->blocks_decoded + c->last_counted_loose;
@@ -2791,6 +2793,7 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
       c->last_and = c->S;
       c->last_and_queries = nq;
       c->last_counted = c->S;
+      c->last_counted_words = c->S->d_touched.p;
       c->last_counted_op = RGPU_OP_AND;
       c->last_counted_queries = nq;
       c->last_counted_postings = G.postings;
@@ -2830,6 +2833,7 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
       HIP_TRY(c->S->d_touched.reserve((size_t)nq * 2, 0, stream));
       HIP_TRY(hipMemsetAsync(c->S->d_touched.p, 0, (size_t)nq * 16, stream));
       c->last_counted = c->S;
+      c->last_counted_words = c->S->d_touched.p;
       c->last_counted_op = RGPU_OP_TERM;
       c->last_counted_queries = nq;
       c->last_counted_postings = G.postings;
@@ -3685,11 +3689,21 @@ __global__ void k_set_i64(int64_t* p, int64_t v) { *p = v; }
 // leaves it alone (one launch less per batch on the serving path); a failure writes it and clears the flag.
 // `defer`: >= 10-clause disjunctions leave their hand-back flags for settle_pending (the caller runs it before the record is
 // read by anybody: before the collective) — the one-process form enqueues every shard's search before it waits for any.
+// A uniform batch that is still to be planned (the fused plan + search entry points): n_queries x n_clauses flat-table ids
+struct UniformBatch {
+  rgpu_planner* planner;
+  int32_t op, n_clauses;
+  const int64_t* ids;
+};
+static int32_t search_uniform_locked(rgpu_segment* seg, const UniformBatch& ub, int32_t n_queries, int32_t k, HitOut* hits_dev, int64_t* totals_dev,
+                                     hipStream_t stream);
 static int32_t search_into_record(rgpu_segment* seg, const rgpu_query* queries, int32_t n_queries, const rgpu_query_term* terms,
-                                  int32_t n_terms_total, int32_t k, uint8_t* record, hipStream_t s, bool* status_zero = nullptr, bool defer = false) {
+                                  int32_t n_terms_total, int32_t k, uint8_t* record, hipStream_t s, bool* status_zero = nullptr, bool defer = false,
+                                  const UniformBatch* uniform = nullptr) {
   const size_t hits_bytes = record_hits_bytes(n_queries, k);
   seg->ctx->defer_or = defer;
-  int32_t rc = search_impl(seg, queries, n_queries, terms, n_terms_total, k, (HitOut*)record, (int64_t*)(record + hits_bytes), s);
+  int32_t rc = uniform ? search_uniform_locked(seg, *uniform, n_queries, k, (HitOut*)record, (int64_t*)(record + hits_bytes), s)
+                       : search_impl(seg, queries, n_queries, terms, n_terms_total, k, (HitOut*)record, (int64_t*)(record + hits_bytes), s);
   seg->ctx->defer_or = false;
   std::string why = rc == RGPU_OK ? std::string() : g_last_error;
   // No early return below: the status word is written whatever else fails (a peer that merged a record without one would
@@ -3789,10 +3803,10 @@ static int32_t sharded_reserve(rgpu_comm* comm, int32_t n_queries, int32_t k, hi
 // phase 1: from here on this rank WILL enqueue the collective, whatever its local search does (search_into_record leaves the
 // status in the record)
 static void sharded_local(rgpu_comm* comm, rgpu_segment* seg, const rgpu_query* queries, int32_t n_queries, const rgpu_query_term* terms,
-                          int32_t n_terms_total, int32_t k, hipStream_t s, ShardedCall* call, bool defer = false) {
+                          int32_t n_terms_total, int32_t k, hipStream_t s, ShardedCall* call, bool defer = false, const UniformBatch* uniform = nullptr) {
   comm->next = (comm->next + 1) % N_COMM_SLOTS;
   call->local_rc = search_into_record(seg, queries, n_queries, terms, n_terms_total, k, call->sl->recv.p + (size_t)comm->rank * call->record, s,
-                                      &call->sl->status_zero, defer);
+                                      &call->sl->status_zero, defer, uniform);
   if (call->local_rc != RGPU_OK) call->local_why = g_last_error;
 }
 // phase 1b (after a deferred sharded_local): whatever the shard's disjunctions still have to run again runs now, before the
@@ -3829,7 +3843,7 @@ static int32_t sharded_gather(rgpu_comm* comm, hipStream_t s, ShardedCall& call)
   uint8_t* const mine = call.sl->recv.p + (size_t)comm->rank * call.record;  // in place: sendbuff == recvbuff + rank * count
   NCCL_TRY(ncclAllGather(mine, call.sl->recv.p, call.record, ncclInt8, comm->nccl, s));
   comm->gathers_issued++;
-  if (!comm->last_collective) note(hipEventCreateWithFlags(&comm->last_collective, hipEventDisableTiming), "hipEventCreate(last collective)");
+  if (!comm->last_collective) (void)note(hipEventCreateWithFlags(&comm->last_collective, hipEventDisableTiming), "hipEventCreate(last collective)");
   if (comm->last_collective && note(hipEventRecord(comm->last_collective, s), "hipEventRecord(last collective)") == hipSuccess) {
     comm->last_stream = s;
     comm->have_last = true;
@@ -4291,6 +4305,221 @@ extern "C" int32_t rgpu_plan_uniform_bytes(rgpu_planner* p, int32_t op, int32_t 
   if (!term_offsets) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "term_offsets is null");
   static const uint8_t kEmpty = 0;
   return plan_uniform(p, op, n_queries, n_clauses, nullptr, term_bytes ? term_bytes : &kEmpty, term_offsets, queries_out, terms_out);
+}
+
+// ---- plan + search in ONE call ------------------------------------------------------------------------------------------------
+// A serving host's steady state is "a batch of term ids arrives -> rows": rgpu_plan_uniform_ids writes rgpu_query[] /
+// rgpu_query_term[] (40 B a clause), rgpu_search_batch_device reads them back, validates them as foreign input, looks every
+// clause's prepared structures up, sorts the queries into groups and only then builds the device descriptors — 63 us of one
+// host thread per 1024-query TERM batch against 47 us of GPU time (round 5). The fused form keeps the ids inside the library:
+// for single-term batches the planner's per-clause result (term state, idf) and the prepared-term table entry go straight
+// into the staged DevQuery / DevTerm arrays — one pass, no intermediate arrays, nothing to validate (the planner's own
+// tables are trusted; an id outside them is an absent term) — and the zeroed per-query counters travel with the same staged
+// copy (three enqueues per batch: copy, k_search_term, k_merge_items). Anything the fast pass does not handle — another op,
+// a term that is not prepared yet or lacks its block-max sketch, k > 128, a prepared-term budget, a dictionary planner — goes
+// through plan() + search_impl() inside the same call: same rows either way (tests/test_gpu_parity.py).
+static int32_t term_batch_fast(rgpu_segment* seg, rucene::BatchPlanner* P, int32_t nq, const int64_t* ids, int32_t k, HitOut* hits_dev,
+                               int64_t* totals_dev, hipStream_t stream, bool* taken) {
+  rgpu_ctx* c = seg->ctx;
+  *taken = false;
+  const int32_t sim_table = P->sim_table();
+  if (!P->flat() || k > RGPU_PASS_K || c->prepared_budget != 0 || sim_table < 0 || sim_table >= c->n_sim_tables || seg->dir_used == 0) return RGPU_OK;
+  const bool want_sketch = c->term_sketches && seg->d_norms && seg->n_norm_ranks > 0 && !seg->d_live;
+  const bool need_norms = seg->d_norms != nullptr;
+  const uint32_t flags = c->sim_monotone[(size_t)sim_table] ? TERM_FLAG_MONOTONE : 0u;
+  c->pass = rgpu_ctx::Pass{};
+  HIP_TRY(scratch_take(c));
+  Stager st(c);
+  const size_t o_q = st.add((size_t)nq * sizeof(DevQuery));
+  const size_t o_t = st.add((size_t)nq * sizeof(DevTerm));
+  const size_t o_p = st.add((size_t)(nq + 1) * 8);
+  const size_t o_m = st.add((size_t)nq * 4);
+  const size_t o_tau = st.add((size_t)nq * 8);       // per-query shared thresholds ...
+  const size_t o_w = st.add((size_t)nq * 16);        // ... and the launch's counters: zeroed by the copy that brings the plan
+  HIP_TRY(c->S->h_stage.reserve(st.used));
+  HIP_TRY(c->S->d_stage.reserve(st.used, 0, stream));
+  DevQuery* hq = reinterpret_cast<DevQuery*>(c->S->h_stage.p + o_q);
+  DevTerm* ht = reinterpret_cast<DevTerm*>(c->S->h_stage.p + o_t);
+  int64_t* hp = reinterpret_cast<int64_t*>(c->S->h_stage.p + o_p);
+  int32_t* hm = reinterpret_cast<int32_t*>(c->S->h_stage.p + o_m);
+  int32_t nt = 0;
+  int64_t postings = 0, total_blocks = 0, loose = 0;
+  bool bail = false;
+  const int32_t max_doc = seg->max_doc;
+  const bool has_freqs = seg->has_freqs;
+  P->for_each_flat(ids, nq, [&](int64_t q, const rgpu_term_state& s0, float idf) {
+    hm[q] = (int32_t)q;
+    if (s0.doc_freq <= 0) { hq[q] = DevQuery{RGPU_OP_TERM, 0, nt, 0}; return; }  // TermWeight::create_scorer -> None for this leaf
+    DevTerm t;
+    t.start_fp = (uint64_t)std::max<int64_t>(0, s0.doc_start_fp);
+    t.pn_base = 0;
+    t.bs_base = 0;
+    t.dir_base = 0;
+    t.nblocks = 0;
+    t.df = s0.doc_freq;
+    t.tail_n = s0.doc_freq > 1 ? s0.doc_freq % 128 : 0;
+    t.singleton_doc = s0.singleton_doc_id;
+    t.singleton_freq = has_freqs ? (int32_t)s0.total_term_freq : 1;
+    t.weight = idf;
+    t.sim_table = sim_table;
+    t.flags = flags;
+    t.sketch = 0;
+    if (s0.doc_freq == 1) {
+      if (s0.singleton_doc_id < 0 || s0.singleton_doc_id >= max_doc) { bail = true; return; }  // (the full path names the error)
+    } else {
+      const TermInfo* info = seg->prepared.find(s0.doc_start_fp);
+      if (!info || info->df != s0.doc_freq || (need_norms && !info->norms) ||
+          (want_sketch && info->sketch == 0 && info->nblocks >= TERM_SKETCH_MIN_BLOCKS)) { bail = true; return; }
+      t.dir_base = info->dir_base;
+      t.nblocks = info->nblocks;
+      t.pn_base = info->pn_base;
+      t.bs_base = info->bs_base;
+      t.sketch = info->sketch;
+    }
+    hq[q] = DevQuery{RGPU_OP_TERM, 1, nt, 0};
+    ht[nt++] = t;
+    postings += t.df;
+    total_blocks += t.nblocks;
+    loose += t.df == 1 ? 1 : t.tail_n;
+  });
+  if (bail) return RGPU_OK;  // (the slot was taken and not marked: it is simply free again)
+  // items: chunks of a term's blocks; every query's first chunk is scheduled first (search_pass's rule, to the letter)
+  int blocks_per_item = c->cfg.blocks_per_item;
+  if (c->blocks_per_item_auto) {
+    blocks_per_item = 8;
+    while (blocks_per_item < 512 && total_blocks / blocks_per_item > 6000) blocks_per_item *= 2;
+    while (blocks_per_item < 2048 && total_blocks / blocks_per_item > 30000) blocks_per_item *= 2;
+  }
+  int64_t items = 0;
+  while (true) {
+    items = 0;
+    for (int q = 0; q < nq; ++q) {
+      hp[q] = items;
+      if (hq[q].n_terms >= 1) {
+        const int32_t nb = ht[hq[q].first_term].nblocks;
+        items += (nb == 0 ? 1 : (nb + blocks_per_item - 1) / blocks_per_item) - 1;
+      }
+    }
+    hp[nq] = items;
+    if (items <= 262144 || blocks_per_item >= (1 << 17)) break;
+    blocks_per_item *= 2;
+  }
+  items += nq;
+  std::memset(c->S->h_stage.p + o_tau, 0, (size_t)nq * 8);
+  std::memset(c->S->h_stage.p + o_w, 0, (size_t)nq * 16);
+  HIP_TRY(hipMemcpyAsync(c->S->d_stage.p, c->S->h_stage.p, st.used, hipMemcpyHostToDevice, stream));
+  HIP_TRY(c->S->d_partial_keys.reserve((size_t)items * (size_t)k, 0, stream));
+  HIP_TRY(c->S->d_partial_counts.reserve((size_t)items, 0, stream));
+  unsigned long long* d_tau = reinterpret_cast<unsigned long long*>(c->S->d_stage.p + o_tau);
+  unsigned long long* d_work = reinterpret_cast<unsigned long long*>(c->S->d_stage.p + o_w);
+  const DevQuery* dq = reinterpret_cast<const DevQuery*>(c->S->d_stage.p + o_q);
+  const DevTerm* dt = reinterpret_cast<const DevTerm*>(c->S->d_stage.p + o_t);
+  const int64_t* dp = reinterpret_cast<const int64_t*>(c->S->d_stage.p + o_p);
+  const int32_t* dm = reinterpret_cast<const int32_t*>(c->S->d_stage.p + o_m);
+  c->last_counted = c->S;
+  c->last_counted_words = d_work;
+  c->last_counted_op = RGPU_OP_TERM;
+  c->last_counted_queries = nq;
+  c->last_counted_postings = postings;
+  c->last_counted_dir_blocks = total_blocks;
+  c->last_counted_loose = loose;
+  const bool wide = k > 64;
+  const bool legacy = seg->version < 1;
+  {
+    TimedLaunch tl(c, stream, "k_search_term", postings);
+    const unsigned grid = wg_count((items + TERM_WAVES - 1) / TERM_WAVES);
+    const size_t lds = term_lds_bytes(wide);
+    const SegView sv = seg_view(seg);
+    auto go = [&](auto kern) -> hipError_t {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      RGPU_LAUNCH(kern, dim3(grid), dim3(TERM_THREADS), lds, stream, sv, dq, dt, dp, nq, items, blocks_per_item, (int)k,
+                         c->S->d_partial_keys.p, c->S->d_partial_counts.p, d_tau, d_work, (const unsigned long long*)nullptr, dm);
+      return hipSuccess;
+    };
+    hipError_t e;
+    if (legacy) e = wide ? go(k_search_term<true, true>) : go(k_search_term<true, false>);
+    else e = wide ? go(k_search_term<false, true>) : go(k_search_term<false, false>);
+    HIP_TRY(e);
+  }
+  if (wide) launch_merge<true>(c, stream, nq, k, dp, seg->doc_base, hits_dev, totals_dev, nq, nullptr, nullptr, dm);
+  else launch_merge<false>(c, stream, nq, k, dp, seg->doc_base, hits_dev, totals_dev, nq, nullptr, nullptr, dm);
+  HIP_TRY(launch_status());
+  HIP_TRY(scratch_mark(c, stream));
+  c->stats[(size_t)stat_slot(c, "fused_term_batches")].launches += 1;  // (tests ask whether this path ran: rgpu_kernel_stats)
+  *taken = true;
+  return RGPU_OK;
+}
+
+// context mutex held by the caller; c->defer_or as the caller set it
+static int32_t search_uniform_locked(rgpu_segment* seg, const UniformBatch& ub, int32_t n_queries, int32_t k, HitOut* hits_dev, int64_t* totals_dev,
+                                     hipStream_t stream) {
+  const int32_t op = ub.op & 0xff;
+  // BooleanQuery::build: a lone clause IS that clause (boolean_query.rs:56-68) — as plan() rewrites it
+  if (ub.n_clauses == 1 && (ub.op >> 8) == 0 && op >= RGPU_OP_TERM && op <= RGPU_OP_OR) {
+    bool taken = false;
+    const int32_t rc = term_batch_fast(seg, ub.planner->p.get(), n_queries, ub.ids, k, hits_dev, totals_dev, stream, &taken);
+    if (rc != RGPU_OK || taken) return rc;
+  }
+  thread_local std::vector<rgpu_query> queries;
+  thread_local std::vector<rgpu_query_term> terms;
+  queries.resize((size_t)n_queries);
+  terms.resize((size_t)n_queries * (size_t)ub.n_clauses);
+  const int32_t rc = plan_uniform(ub.planner, ub.op, n_queries, ub.n_clauses, ub.ids, nullptr, nullptr, queries.data(), terms.data());
+  if (rc != RGPU_OK) return rc;
+  return search_impl(seg, queries.data(), n_queries, terms.data(), (int32_t)terms.size(), k, hits_dev, totals_dev, stream);
+}
+
+static int32_t uniform_args_ok(rgpu_planner* p, rgpu_segment* seg, int32_t op, int32_t n_queries, int32_t n_clauses, const int64_t* ids, int32_t k,
+                               const void* hits_dev, const void* totals_dev) {
+  if (!p || !seg || !ids || !hits_dev || !totals_dev) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "null argument");
+  if (n_queries <= 0 || n_clauses <= 0 || n_clauses > RGPU_MAX_QUERY_TERMS || (int64_t)n_queries * n_clauses > 0x7fffffff) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "bad batch shape");
+  if ((op >> 16) != 0 || (op & 0xff) < RGPU_OP_TERM || (op & 0xff) > RGPU_OP_OR || ((op & 0xff) == RGPU_OP_TERM && n_clauses != 1))
+    return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "a uniform batch is TERM (one clause), AND or OR (optionally RGPU_OP_OR_MSM)");
+  if (k <= 0 || k > RGPU_MAX_K) return fail(k <= 0 ? RGPU_ERR_ILLEGAL_ARGUMENT : RGPU_ERR_UNSUPPORTED, "k must be in 1..RGPU_MAX_K");
+  if (!p->p->flat()) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "this planner names terms by their bytes (rgpu_planner_create): plan with rgpu_plan_uniform_bytes, then rgpu_search_batch_device");
+  return RGPU_OK;
+}
+
+extern "C" int32_t rgpu_planner_search_uniform_ids_device(rgpu_planner* p, rgpu_segment* seg, int32_t op, int32_t n_queries, int32_t n_clauses,
+                                                          const int64_t* term_ids, int32_t k, void* hits_dev, void* totals_dev, void* hip_stream) {
+  const int32_t ok = uniform_args_ok(p, seg, op, n_queries, n_clauses, term_ids, k, hits_dev, totals_dev);
+  if (ok != RGPU_OK) return ok;
+  rgpu_ctx* c = seg->ctx;
+  std::lock_guard<std::mutex> g(c->mu);
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+  const UniformBatch ub{p, op, n_clauses, term_ids};
+  c->defer_or = c->cfg.or_deferred != 0;
+  const int32_t rc = search_uniform_locked(seg, ub, n_queries, k, (HitOut*)hits_dev, (int64_t*)totals_dev, s);
+  c->defer_or = false;
+  return rc;
+}
+
+// ... and its sharded form: rgpu_search_batch_sharded with the batch named by ids (local plan + search -> all-gather -> merge)
+extern "C" int32_t rgpu_planner_search_uniform_ids_sharded(rgpu_comm* comm, rgpu_planner* p, rgpu_segment* seg, int32_t op, int32_t n_queries,
+                                                           int32_t n_clauses, const int64_t* term_ids, int32_t k, void* hits_dev, void* totals_dev,
+                                                           void* hip_stream) {
+  if (!comm) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "null argument");
+  const int32_t ok = uniform_args_ok(p, seg, op, n_queries, n_clauses, term_ids, k, hits_dev, totals_dev);
+  if (ok != RGPU_OK) return ok;
+  if (seg->ctx != comm->ctx) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "segment and communicator belong to different contexts");
+  rgpu_ctx* c = comm->ctx;
+  std::lock_guard<std::mutex> g(c->mu);
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+  const UniformBatch ub{p, op, n_clauses, term_ids};
+  ShardedCall call;
+  int32_t rc = sharded_reserve(comm, n_queries, k, s, &call);
+  if (rc != RGPU_OK) return rc;
+  sharded_local(comm, seg, nullptr, n_queries, nullptr, 0, k, s, &call, false, &ub);
+  rc = sharded_gather(comm, s, call);
+  if (rc != RGPU_OK) return rc;
+  rc = sharded_merge(comm, n_queries, k, hits_dev, totals_dev, s, call);
+  if (rc != RGPU_OK) return rc;
+  if (call.local_rc != RGPU_OK) return fail(call.local_rc, call.local_why);
+  if (call.pre_rc != RGPU_OK) return fail(call.pre_rc, call.pre_why);
+  return RGPU_OK;
 }
 
 extern "C" uint8_t rgpu_bm25_encode_norm(float boost, int32_t field_length) {

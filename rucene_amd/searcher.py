@@ -475,6 +475,23 @@ class GpuIndexSearcher:
             op, min_should_match = OP_TERM, 0   # BooleanQuery::build with a single clause rewrites to that clause (boolean_query.rs:56-68)
         return self._planner(leaf).plan_uniform((op | (min_should_match << 8)) if (op == OP_OR and min_should_match > 1) else op, term_ids)
 
+    def search_uniform_device(self, op, term_ids, leaf, k, hits_ptr, totals_ptr, stream=0, min_should_match=0, comm=None):
+        """pack_uniform + rgpu_search_batch_device (comm: rgpu_search_batch_sharded) as ONE call behind the C ABI
+        (rgpu_planner_search_uniform_ids_device): the serving path of a batch named by term ids. Enqueue-only; same rows as
+        the two calls."""
+        term_ids = np.asarray(term_ids, dtype=np.int64)
+        if term_ids.ndim == 1:
+            term_ids = term_ids.reshape(-1, 1)
+        nc = term_ids.shape[1]
+        if op not in (OP_TERM, OP_AND, OP_OR) or (op == OP_TERM and nc != 1) or nc < 1:
+            raise RgpuError(-1, "search_uniform_device: op TERM takes one column, AND / OR at least one")
+        if nc > _lib.MAX_QUERY_TERMS:
+            raise RgpuError(-5, "more than %d clauses" % _lib.MAX_QUERY_TERMS)
+        if nc == 1:
+            op, min_should_match = OP_TERM, 0
+        full_op = (op | (min_should_match << 8)) if (op == OP_OR and min_should_match > 1) else op
+        self._planner(leaf).search_uniform_device(leaf.segment, full_op, term_ids, k, hits_ptr, totals_ptr, stream, comm=comm)
+
     def pack(self, queries, leaf):
         """queries -> (rgpu_query[], rgpu_query_term[]) for one leaf."""
         flat = [self._flatten(q) for q in queries]

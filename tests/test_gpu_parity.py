@@ -1389,6 +1389,102 @@ def test_min_should_match(zipf, oracle):
             assert (hits[i]["score"][:n].view(np.int32) == cs[i, :n].view(np.int32)).all(), (i, specs[i])
 
 
+def test_plan_and_search_in_one_call(zipf, oracle):
+    """rgpu_planner_search_uniform_ids_device (+ _sharded): plan + search in one call = rgpu_plan_uniform_ids followed by
+    rgpu_search_batch_device, bit for bit — for single-term batches through the one-pass path (planner entry -> device descriptor;
+    `fused_term_batches` counts its launches), for everything else through the same planner and search behind one entry point.
+    Ids outside the table and terms the leaf lacks are absent clauses; a first call on unprepared terms takes the full path
+    (which prepares them and builds the block-max sketches), the next one the fast path; k = 64 / 100 (two top-k registers) and
+    k = 256 (multi-pass: full path) included. The oracle judges the single-term rows once more."""
+    import torch
+    import rucene_amd
+    from rucene_amd import _lib as gpu
+    seg, osearcher, _ = zipf
+    ctx2 = rucene_amd.Context(profile_kernels=True, comm_force_gather=True)
+    try:
+        leaf = rucene_amd.LeafReader.from_synthetic(seg)
+        g = rucene_amd.GpuIndexSearcher([leaf], ctx=ctx2)
+        comm = gpu.Comm(ctx2, 1, 0, gpu.comm_unique_id())
+        rng = np.random.default_rng(61)
+        n_terms = seg.terms.size
+        singles = np.nonzero(seg.terms["doc_freq"] == 1)[0][:8]
+        term_ids = np.concatenate([rng.integers(0, 3000, 300), rng.integers(0, n_terms, 200), singles, [-1, n_terms, n_terms + 7, 0, 0, 1]]).astype(np.int64)
+        and_ids = np.concatenate([rng.integers(0, 400, (60, 3)), [[1, 4, -1], [2, 2, 2]]]).astype(np.int64)
+        or_ids = np.concatenate([rng.integers(0, 5000, (24, 10)), [[0, 1, 2, 3, 4, 5, 6, 7, 8, n_terms + 1]]]).astype(np.int64)
+        fast_before = 0
+
+        def both(op, ids, k, comm_=None):
+            nq = ids.shape[0]
+            outs = []
+            for fused in (False, True):
+                hits = torch.full((nq, k), -3, dtype=torch.int64, device="cuda")
+                totals = torch.full((nq,), -3, dtype=torch.int64, device="cuda")
+                torch.cuda.synchronize()
+                if fused:
+                    g.search_uniform_device(op, ids, leaf, k, hits.data_ptr(), totals.data_ptr(), comm=comm_)
+                else:
+                    qs, ts = g.pack_uniform(op, ids, leaf)
+                    leaf.segment.search_batch_device(qs, ts, k, hits.data_ptr(), totals.data_ptr())
+                ctx2.synchronize()
+                outs.append((hits.cpu().numpy(), totals.cpu().numpy()))
+            assert (outs[0][0] == outs[1][0]).all() and (outs[0][1] == outs[1][1]).all(), (op, k)
+            return outs[1]
+        for k in (10, 64, 100):
+            h, t = both(gpu.OP_TERM, term_ids.reshape(-1, 1), k)
+            fast = ctx2.kernel_stats().get("fused_term_batches", {"launches": 0})["launches"]
+            assert fast > fast_before, "the one-pass path did not run"   # (terms prepared + sketched by the two-call form just before)
+            fast_before = fast
+            rows = h.view(gpu.HIT_DTYPE).reshape(-1, k)
+            for i in (0, 5, 299, 300, 420, 500, 507, 508, 509, 510, 513):
+                tid = int(term_ids[i])
+                if tid < 0 or tid >= n_terms:
+                    assert t[i] == 0 and (rows[i]["doc"] == -1).all()
+                    continue
+                d, sc, total = osearcher.search(oracle.OP_TERM, [tid], k, tie_mode=oracle.TIE_CANONICAL)
+                assert t[i] == total and (rows[i]["doc"][:d.size] == d).all() and (rows[i]["score"][:d.size].view(np.int32) == sc.view(np.int32)).all(), (i, k)
+        both(gpu.OP_TERM, term_ids.reshape(-1, 1), 256)          # multi-pass: the full path inside the same entry point
+        assert ctx2.kernel_stats()["fused_term_batches"]["launches"] == fast_before
+        both(gpu.OP_AND, and_ids, 10)
+        both(gpu.OP_OR, or_ids, 100)
+        both(gpu.OP_OR, or_ids[:, :1], 10)                        # a lone SHOULD clause IS that clause: the TERM path
+        assert ctx2.kernel_stats()["fused_term_batches"]["launches"] == fast_before + 1
+        # a fresh segment: nothing prepared — the fused call itself has to take the full path first, then the fast one
+        leaf2 = rucene_amd.LeafReader.from_synthetic(seg)
+        g2 = rucene_amd.GpuIndexSearcher([leaf2], ctx=ctx2)
+        hits = torch.full((term_ids.size, 10), -3, dtype=torch.int64, device="cuda")
+        totals = torch.full((term_ids.size,), -3, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        want_h, want_t = both(gpu.OP_TERM, term_ids.reshape(-1, 1), 10)
+        n0 = ctx2.kernel_stats()["fused_term_batches"]["launches"]
+        for rep in range(3):
+            g2.search_uniform_device(gpu.OP_TERM, term_ids.reshape(-1, 1), leaf2, 10, hits.data_ptr(), totals.data_ptr())
+            ctx2.synchronize()
+            assert (hits.cpu().numpy() == want_h).all() and (totals.cpu().numpy() == want_t).all(), rep
+        assert ctx2.kernel_stats()["fused_term_batches"]["launches"] == n0 + 2     # the first of the three prepared the terms
+        # the sharded form (world of one, the all-gather forced to run)
+        both(gpu.OP_TERM, term_ids.reshape(-1, 1), 10, comm)
+        both(gpu.OP_AND, and_ids, 10, comm)
+        assert comm.gathers_issued() == 2 and (comm.status() == 0).all()
+        # counters of a fast-path launch (read back from the slot's stage) = those of the two-call launch
+        qs, ts = g.pack_uniform(gpu.OP_TERM, term_ids.reshape(-1, 1), leaf)
+        leaf.segment.search_batch_device(qs, ts, 10, hits.data_ptr(), totals.data_ptr())
+        c_two = ctx2.last_search_counters()
+        g.search_uniform_device(gpu.OP_TERM, term_ids.reshape(-1, 1), leaf, 10, hits.data_ptr(), totals.data_ptr())
+        c_one = ctx2.last_search_counters()
+        assert c_one["postings_covered"] == c_two["postings_covered"] and c_one["op"] == gpu.OP_TERM
+        assert c_one["blocks_decoded"] > 0 and c_one["touched_bytes"] > 0 and c_one["blocks_decoded"] <= 2 * c_two["blocks_decoded"] + 64   # (pruning depends on launch timing)
+        # bad arguments are refused, not planned
+        with pytest.raises(gpu.RgpuError):
+            g.search_uniform_device(gpu.OP_TERM, term_ids.reshape(-1, 1), leaf, 0, hits.data_ptr(), totals.data_ptr())
+        with pytest.raises(gpu.RgpuError):
+            g._planner(leaf).search_uniform_device(leaf.segment, gpu.OP_TERM, and_ids, 10, hits.data_ptr(), totals.data_ptr())
+        comm.close()
+        leaf2.segment.close()
+        leaf.segment.close()
+    finally:
+        ctx2.close()
+
+
 @pytest.mark.parametrize("force_gather", [False, True], ids=["merge_in_place", "forced_all_gather"])
 def test_sharded_search_through_the_c_abi_with_a_world_of_one(zipf, oracle, force_gather):
     """rgpu_comm_* + rgpu_search_batch_sharded (RCCL all-gather of {hits, counts} records + k_merge_lists): with one rank the
