@@ -169,6 +169,48 @@ __global__ __launch_bounds__(WG_THREADS) void k_merge_items(const int64_t* __res
   if (lane == 0) totals_out[row] = total;
 }
 
+// A query with hundreds of item lists (a small batch of >= 10-clause disjunctions: one list per 16384-doc window — 612 for a
+// 10 M-doc segment) folded by ONE wavefront of k_merge_items is a serial chain of insertions (167 us for a single query's 612
+// lists of up to 100 keys, behind 290 us of search). This pass folds groups of `group` consecutive lists in parallel, one
+// wavefront per group: the group's first list receives the merged keys (best first, as every list) and the summed count, the
+// others are emptied (head key 0, count 0) — k_merge_items then meets items / group lists. Plain item ranges only.
+template <bool WIDE>
+__global__ __launch_bounds__(WG_THREADS) void k_premerge_items(const int64_t* __restrict__ item_prefix, int n_queries, int k, int group,
+                                                               int groups_per_query, uint64_t* __restrict__ partial_keys,
+                                                               int32_t* __restrict__ partial_counts) {
+  const int lane = lane_id();
+  const int64_t w = (int64_t)blockIdx.x * WG_WAVES + wave_id();
+  const int q = (int)(w / groups_per_query);
+  if (q >= n_queries) return;
+  const int64_t i0 = item_prefix[q] + (w % groups_per_query) * (int64_t)group;
+  const int64_t i1 = min(item_prefix[q + 1], i0 + group);
+  if (i1 - i0 < 2) return;
+  WaveTopK top;
+  uint64_t tau = 0;
+  int total = 0;
+  for (int64_t g0 = i0; g0 < i1; g0 += 4) {  // four lists requested together
+    uint64_t ka[4], kb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint64_t* pk = partial_keys + (size_t)min(g0 + j, i1 - 1) * (size_t)k;
+      const bool real = g0 + j < i1;  // wave-uniform
+      ka[j] = (real && lane < k) ? pk[lane] : 0ull;
+      kb[j] = (WIDE && real && lane + 64 < k) ? pk[lane + 64] : 0ull;
+      total += real ? partial_counts[min(g0 + j, i1 - 1)] : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (__ballot(ka[j] > tau)) topk_offer<WIDE>(top, ka[j], tau, k, lane);
+      if (WIDE && __ballot(kb[j] > tau)) topk_offer<WIDE>(top, kb[j], tau, k, lane);
+    }
+  }
+  uint64_t* first = partial_keys + (size_t)i0 * (size_t)k;
+  if (lane < k) first[lane] = top.a;
+  if (WIDE && lane + 64 < k) first[lane + 64] = top.b;
+  for (int64_t i = i0 + 1 + lane; i < i1; i += 64) { partial_keys[(size_t)i * (size_t)k] = 0ull; partial_counts[i] = 0; }
+  if (lane == 0) partial_counts[i0] = total;
+}
+
 // TopDocsCollector::finish_parallel across leaves / shards: list l's rows start at hits_in + l * hits_stride
 // ([query][k], already in global doc ids) and its hit counts at totals_in + l * totals_stride — [list][query][k] and
 // [list][query] arrays, or the records of one all-gather ([list][hits | totals | status]). One wavefront per query; k > 128 in

@@ -36,11 +36,11 @@ __device__ unsigned long long g_and_time[16];  // [0] item set-up [1] batched fi
 #define AND_TADD(i, v) do {} while (0)
 #endif
 
-// Occupancy against registers: at 8 waves/SIMD (64 VGPRs, 80 SGPRs) the kernel spilled 90-120 bytes per lane to
-// scratch (551 MB of writes per launch of the 3-term workload, round 1). With the VInt tail decoder moved to prepare
-// time (tail_load) the kernel needs 85-94 VGPRs: 5 waves/SIMD hold every instantiation without scratch
-// (scripts/kernel_resources.py); measured 1.58-1.61 ms at 5 against 1.52-1.58 ms at 8 with spills (VALU-bound, not
-// latency-bound: 86 % VALU busy).
+// Occupancy against registers (history): at 8 waves/SIMD (64 VGPRs, 80 SGPRs) the round-1 kernel spilled 90-120 bytes per lane
+// to scratch; rounds 2-4 ran at 5 waves/SIMD (85-94 VGPRs, no scratch). Since round 5 (batched first probe: AND_G blocks of rows,
+// 2 * AND_G gathers per lane in flight, a survivor queue in LDS) the kernel needs 99-111 VGPRs and 29.8 KB of LDS per workgroup:
+// FOUR waves/SIMD (RGPU_AND_WAVES below), no scratch (scripts/kernel_resources.py). Its 102-121 "SGPR spills" are v_writelane /
+// v_readlane into two VGPRs, not memory: 10-23 reloads per ~1200-instruction candidate loop.
 #ifndef RGPU_AND_WAVES
 #define RGPU_AND_WAVES 4
 #endif

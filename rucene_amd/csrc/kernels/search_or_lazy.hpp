@@ -106,13 +106,13 @@ __host__ __device__ constexpr size_t lz_lds_bytes(int W, int C) { return (size_t
 
 // items = (query, group of `windows_per_item` windows of W = STEPS * 2048 docs), one per wavefront; the four wavefronts of
 // a workgroup work on the same query (they share its lazy clauses' norm caches); workgroup b works on query b % n_queries
-// (k_or_windows: later workgroups start from the thresholds the earlier ones published). counters[0] += candidates
+// (k_or_windows: later workgroups start from the thresholds the earlier ones published; `first_item`: see below). counters[0] += candidates
 // evaluated, [1] += of them docs held by lazy lists only.
 template <bool WIDE, int STEPS>
 __global__ __launch_bounds__(LZ_THREADS, RGPU_LZ_MIN_WAVES) void k_or_lazy(SegView seg, const LazyQuery* __restrict__ queries, const LazyRun* __restrict__ run_of,
                                                         const ScoredPosting* __restrict__ runs, const LazyClause* __restrict__ lazies,
                                                         int64_t sentinel_at, int n_queries, int windows_per_query, int windows_per_item,
-                                                        int items_per_query, int C, int k, uint64_t* __restrict__ partial_keys,
+                                                        int items_per_query, int first_item, int C, int k, uint64_t* __restrict__ partial_keys,
                                                         int32_t* __restrict__ partial_counts, unsigned long long* __restrict__ tau_slots,
                                                         int32_t* __restrict__ flags, unsigned long long* __restrict__ counters,
                                                         uint32_t* __restrict__ hist) {
@@ -133,7 +133,9 @@ __global__ __launch_bounds__(LZ_THREADS, RGPU_LZ_MIN_WAVES) void k_or_lazy(SegVi
   uint16_t* docoff = reinterpret_cast<uint16_t*>(queue + LZ_QUEUE);  // cell r: the doc's offset in the window
 
   const int q = (int)(blockIdx.x % (unsigned)n_queries);
-  const int g = (int)(blockIdx.x / (unsigned)n_queries) * LZ_WAVES + wave;
+  // first_item: this launch covers items [first_item, first_item + gridDim.x / n_queries * LZ_WAVES) of every query (a small
+  // batch runs as a pilot launch over each query's first windows and a second one that starts from the pilot's thresholds)
+  const int g = first_item + (int)(blockIdx.x / (unsigned)n_queries) * LZ_WAVES + wave;
   const int64_t item = (int64_t)q * items_per_query + g;
   const LazyQuery Q = queries[q];
   const int n = Q.n_runs, nl = Q.n_lazy;

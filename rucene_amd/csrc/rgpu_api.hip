@@ -146,18 +146,24 @@ struct Scratch {
   HostPinned h_back;             // flags a launch set hands back to the host (fixed-point floor, windows that did not fit)
   bool settles_later = false;    // ... which the host has not looked at yet (rgpu_ctx::pending_or)
   hipEvent_t done = nullptr;
+  hipEvent_t staged = nullptr;   // the slot's plan has reached d_stage (recorded on the context's upload stream)
   bool busy = false;
   void release() {
     h_stage.release(); d_stage.release(); d_partial_keys.release(); d_partial_counts.release();
     d_tau.release(); d_touched.release(); d_runs.release(); h_back.release();
     if (done) (void)hipEventDestroy(done);
+    if (staged) (void)hipEventDestroy(staged);
     done = nullptr;
+    staged = nullptr;
   }
 };
 
 struct rgpu_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  // (opt-in, see upload_aside) The staged plan of a batch travels on a stream of its own and the caller's stream only waits for the
+  // event behind it: on ONE caller stream the copy of batch i + 1 then runs under the kernels of batch i instead of between them
+  hipStream_t upload = nullptr;
   rgpu_config cfg{};
   bool blocks_per_item_auto = false;
   bool and_blocks_per_item_auto = false;
@@ -193,6 +199,11 @@ struct rgpu_ctx {
   // (rgpu_synchronize, the collective of a sharded batch, rgpu_search_batch's copy to the host).
   std::vector<std::function<int32_t()>> pending_or;
   bool defer_or = false;  // set by the entry point for the duration of one call
+  // staged plans travel on `upload` when RGPU_UPLOAD_ASIDE=1 is in the environment (default: on the caller's stream). Measured in round 6
+  // (1024-query TERM batches): ONE caller stream gains — 0.049 ms per step against 0.059 in a 200-step loop, 0.062 against 0.071 in 20-step
+  // regions — but the cross-stream event wait costs 15-30 us of latency whenever the pipeline is shallow: two alternating streams
+  // 0.063 against 0.047 in 20-step regions, the 3-term AND batch 0.290 against 0.258. Off by default.
+  bool upload_aside = false;
   bool term_sketches = true;  // block-max sketches for single-term queries (search_term.hpp); RGPU_TERM_SKETCH=0 in the environment turns them off (A/B, tests)
   DevVec<uint32_t> pos_counts;             // rgpu_decode_positions: positions per directory slot -> their exclusive prefix sums
   DevVec<unsigned long long> pos_tiles;    // ... the scan's tile sums (+ [0]: unused, [1]: the call's total)
@@ -202,6 +213,7 @@ struct rgpu_ctx {
   DevVec<unsigned long long> phrase_count;  // ... how many each query's conjunction produced
   DevVec<HitOut> host_api_hits;  // rgpu_search_batch (blocking, host outputs): device-side result rows
   DevVec<int64_t> host_api_totals;
+  HostPinned host_api_rows;  // ... of a SMALL batch: pinned host memory the merge kernels write straight into (no copy operations behind them)
   int* d_err = nullptr;
   // k > 128: the search runs in passes of up to 128 hits; a pass writes columns [col0, col0 + k_pass) of rows `stride` hits
   // long and keeps below the previous pass's worst key per caller row (d_ceil; null in the first pass)
@@ -376,6 +388,19 @@ static hipError_t scratch_mark(rgpu_ctx* c, hipStream_t s) {
   }
   hipError_t e = hipEventRecord(sc->done, s);
   if (e == hipSuccess) sc->busy = true;
+  return e;
+}
+
+// the slot's staged plan -> d_stage on the upload stream; `s` (the stream the kernels go to) waits for it
+static hipError_t stage_upload(rgpu_ctx* c, size_t bytes, hipStream_t s) {
+  Scratch* sc = c->S;
+  if (!sc->staged) {
+    hipError_t e = hipEventCreateWithFlags(&sc->staged, hipEventDisableTiming);
+    if (e != hipSuccess) return e;
+  }
+  hipError_t e = hipMemcpyAsync(sc->d_stage.p, sc->h_stage.p, bytes, hipMemcpyHostToDevice, c->upload);
+  if (e == hipSuccess) e = hipEventRecord(sc->staged, c->upload);
+  if (e == hipSuccess) e = hipStreamWaitEvent(s, sc->staged, 0);
   return e;
 }
 
@@ -1020,9 +1045,11 @@ extern "C" int32_t rgpu_init(int32_t device_ordinal, const rgpu_config* cfg, rgp
   c->bitmap_budget = c->cfg.bitmap_budget_mib > 0 ? (size_t)c->cfg.bitmap_budget_mib << 20 : (size_t)prop.totalGlobalMem / 8;
   c->prepared_budget = c->cfg.prepared_budget_mib > 0 ? (size_t)c->cfg.prepared_budget_mib << 20 : 0;
   if (const char* e = std::getenv("RGPU_TERM_SKETCH")) c->term_sketches = std::atoi(e) != 0;
+  if (const char* e = std::getenv("RGPU_UPLOAD_ASIDE")) c->upload_aside = std::atoi(e) != 0;
   if (const char* e = std::getenv("RGPU_COMM_FORCE_GATHER")) { if (std::atoi(e) != 0) c->cfg.comm_force_gather = 1; }
   std::snprintf(c->name, sizeof c->name, "%s (%s)", prop.name, prop.gcnArchName);
-  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipMalloc(&c->d_err, 4 * sizeof(int)) != hipSuccess) {
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&c->upload, hipStreamNonBlocking) != hipSuccess ||
+      hipMalloc(&c->d_err, 4 * sizeof(int)) != hipSuccess) {
     delete c;
     return fail(RGPU_ERR_RUNTIME, "failed to create stream / error word");
   }
@@ -1037,9 +1064,10 @@ extern "C" void rgpu_shutdown(rgpu_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   drain_events(c);
   for (auto e : c->free_events) (void)hipEventDestroy(e);
-  c->sim_tables.release(); for (auto& cs : c->ceil_slots) { cs.d.release(); if (cs.done) (void)hipEventDestroy(cs.done); } c->d_runs.release(); c->pos_counts.release(); c->pos_tiles.release(); c->phrase_docs.release(); c->phrase_keys.release(); c->phrase_redo.release(); c->phrase_count.release(); c->host_api_hits.release(); c->host_api_totals.release();
+  c->sim_tables.release(); for (auto& cs : c->ceil_slots) { cs.d.release(); if (cs.done) (void)hipEventDestroy(cs.done); } c->d_runs.release(); c->pos_counts.release(); c->pos_tiles.release(); c->phrase_docs.release(); c->phrase_keys.release(); c->phrase_redo.release(); c->phrase_count.release(); c->host_api_hits.release(); c->host_api_totals.release(); c->host_api_rows.release();
   for (auto& sc : c->scr) sc.release();
   if (c->d_err) (void)hipFree(c->d_err);
+  if (c->upload) { (void)hipStreamSynchronize(c->upload); (void)hipStreamDestroy(c->upload); }
   (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -2025,21 +2053,46 @@ static int32_t search_or_lazy_group(rgpu_segment* seg, Group& G, int32_t k, HitO
         RGPU_LAUNCH(k_score_terms<false>, dim3(grid), dim3(WG_THREADS), 0, stream, sv, dt, dip, drp, nu, items1, blocks_per_item, runs_buf.p);
     }
     {
-      TimedLaunch tl(c, stream, "k_or_lazy", all_postings);
       const size_t lds = lz_lds_bytes(W, C);
-      const unsigned grid = (unsigned)(lists / LZ_WAVES);
-      auto go = [&](auto kern) -> hipError_t {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        RGPU_LAUNCH(kern, dim3(grid), dim3(LZ_THREADS), lds, stream, sv, reinterpret_cast<const LazyQuery*>(c->S->d_stage.p + o_q),
-                           reinterpret_cast<const LazyRun*>(c->S->d_stage.p + o_r), runs_buf.p, reinterpret_cast<const LazyClause*>(c->S->d_stage.p + o_l),
-                           (int64_t)run_slots, nq, wpq, wpi, ipq, C, (int)k, c->S->d_partial_keys.p, c->S->d_partial_counts.p, c->S->d_tau.p, dbl, dct, d_hist);
-        return hipSuccess;
+      // items [g0, g0 + n_g) of every query (n_g a multiple of LZ_WAVES)
+      auto launch_part = [&](int g0, int n_g) -> hipError_t {
+        TimedLaunch tl(c, stream, "k_or_lazy", all_postings);
+        const unsigned grid = (unsigned)((int64_t)nq * n_g / LZ_WAVES);
+        auto go = [&](auto kern) -> hipError_t {
+          hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+          if (e != hipSuccess) return e;
+          RGPU_LAUNCH(kern, dim3(grid), dim3(LZ_THREADS), lds, stream, sv, reinterpret_cast<const LazyQuery*>(c->S->d_stage.p + o_q),
+                             reinterpret_cast<const LazyRun*>(c->S->d_stage.p + o_r), runs_buf.p, reinterpret_cast<const LazyClause*>(c->S->d_stage.p + o_l),
+                             (int64_t)run_slots, nq, wpq, wpi, ipq, g0, C, (int)k, c->S->d_partial_keys.p, c->S->d_partial_counts.p, c->S->d_tau.p, dbl, dct, d_hist);
+          return hipSuccess;
+        };
+        return wide ? go(k_or_lazy<true, STEPS>) : go(k_or_lazy<false, STEPS>);
       };
-      HIP_TRY(wide ? go(k_or_lazy<true, STEPS>) : go(k_or_lazy<false, STEPS>));
+      // A small batch puts every window of a query into a wavefront of its own (wpi == 1) and the launch starts them all at
+      // once: nobody has a threshold, every doc held by a lazy list is a candidate — a single 10-clause query over 10 M docs
+      // evaluated 1.8 M docs that way (2.3 ms; the same query inside a 1024-query batch: 3.4 us of the batch's kernel). Such a
+      // batch runs as a PILOT launch over the first sixteenth of each query's windows, whose finished totals fill the query's
+      // histogram, and a second launch over the rest that starts from that threshold. The threshold is a lower bound taken from
+      // real docs either way: same rows, fewer evaluations.
+      int pilot = 0;
+      if (wpi == 1 && ipq >= 16 * LZ_WAVES) pilot = ((ipq + 15) / 16 + LZ_WAVES - 1) / LZ_WAVES * LZ_WAVES;
+      if (pilot > 0) {
+        HIP_TRY(launch_part(0, pilot));
+        HIP_TRY(launch_part(pilot, ipq - pilot));
+      } else {
+        HIP_TRY(launch_part(0, ipq));
+      }
     }
     const int2* dfi = reinterpret_cast<const int2*>(c->S->d_stage.p + o_fi);
     int32_t* dfl = reinterpret_cast<int32_t*>(c->S->d_stage.p + o_fl);
+    if (ipq >= 64 && (int64_t)nq * ipq <= 262144) {  // many lists per query, few queries: fold them sixteen at a time first
+      constexpr int GROUP = 16;
+      const int gpq = (ipq + GROUP - 1) / GROUP;
+      TimedLaunch tl(c, stream, "k_premerge_items", 0);
+      const unsigned grid = wg_count(((int64_t)nq * gpq + WG_WAVES - 1) / WG_WAVES);
+      if (wide) RGPU_LAUNCH(k_premerge_items<true>, dim3(grid), dim3(WG_THREADS), 0, stream, dmp, nq, (int)k, GROUP, gpq, c->S->d_partial_keys.p, c->S->d_partial_counts.p);
+      else RGPU_LAUNCH(k_premerge_items<false>, dim3(grid), dim3(WG_THREADS), 0, stream, dmp, nq, (int)k, GROUP, gpq, c->S->d_partial_keys.p, c->S->d_partial_counts.p);
+    }
     if (wide) launch_merge<true>(c, stream, nq, k, dmp, seg->doc_base, hits_dev, totals_dev, 0, dfi, dfl, dm);
     else launch_merge<false>(c, stream, nq, k, dmp, seg->doc_base, hits_dev, totals_dev, 0, dfi, dfl, dm);
     HIP_TRY(launch_status());
@@ -2771,7 +2824,8 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
     std::memset(c->S->h_stage.p + o_tau, 0, (size_t)nq * 8);
     if (G.req_opt) std::memcpy(c->S->h_stage.p + o_sp, seq_prefix.data(), (size_t)(nq + 1) * 8);
     if (!clause_bitmaps.empty()) std::memcpy(c->S->h_stage.p + o_bm, clause_bitmaps.data(), clause_bitmaps.size() * sizeof(TermBitmap));
-    HIP_TRY(hipMemcpyAsync(c->S->d_stage.p, c->S->h_stage.p, st.used, hipMemcpyHostToDevice, stream));
+    if (c->upload_aside) HIP_TRY(stage_upload(c, st.used, stream));
+    else HIP_TRY(hipMemcpyAsync(c->S->d_stage.p, c->S->h_stage.p, st.used, hipMemcpyHostToDevice, stream));
     HIP_TRY(c->S->d_partial_keys.reserve((size_t)items * (size_t)k, 0, stream));
     HIP_TRY(c->S->d_partial_counts.reserve((size_t)items, 0, stream));
     unsigned long long* d_tau = reinterpret_cast<unsigned long long*>(c->S->d_stage.p + o_tau);
@@ -2908,6 +2962,24 @@ extern "C" int32_t rgpu_search_batch(rgpu_segment* seg, const rgpu_query* querie
   HIP_TRY(hipSetDevice(c->device));
   // device-side result rows of the blocking variant live in the context (grow-only): the call ends with a stream
   // sync, so they are free again when it returns
+  // IndexSearcher::search is ONE query per call (search/searcher.rs:487-525): a batch of one is a launch-latency exercise — 66 us
+  // of wall time around 23 us of kernels (round 6's latency leg), two of its six stream operations being the device-to-host
+  // copies of 88 bytes. Rows of up to 256 KiB are therefore written by the kernels straight into pinned host memory
+  // (hipHostMalloc: device-visible, coherent) and copied to the caller's arrays by the CPU after the one stream sync.
+  const size_t hits_bytes = (size_t)n_queries * (size_t)k * sizeof(HitOut), tot_bytes = (size_t)n_queries * 8;
+  if (hits_bytes + tot_bytes <= ((size_t)256 << 10)) {
+    HIP_TRY(c->host_api_rows.reserve(hits_bytes + tot_bytes));
+    HitOut* p_hits = reinterpret_cast<HitOut*>(c->host_api_rows.p);
+    int64_t* p_tot = reinterpret_cast<int64_t*>(c->host_api_rows.p + hits_bytes);
+    int32_t rc = search_impl(seg, queries, n_queries, terms, n_terms_total, k, p_hits, p_tot, c->stream);
+    if (rc != RGPU_OK) return rc;
+    rc = settle_pending(c);  // (nothing is deferred on this path; a closure left by an earlier deferred batch may own the stream's tail)
+    if (rc != RGPU_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    std::memcpy(hits_out, p_hits, hits_bytes);
+    std::memcpy(total_hits_out, p_tot, tot_bytes);
+    return RGPU_OK;
+  }
   HIP_TRY(c->host_api_hits.reserve((size_t)n_queries * (size_t)k, 0, c->stream));
   HIP_TRY(c->host_api_totals.reserve((size_t)n_queries, 0, c->stream));
   HitOut* d_hits = c->host_api_hits.p;
@@ -4407,7 +4479,8 @@ static int32_t term_batch_fast(rgpu_segment* seg, rucene::BatchPlanner* P, int32
   items += nq;
   std::memset(c->S->h_stage.p + o_tau, 0, (size_t)nq * 8);
   std::memset(c->S->h_stage.p + o_w, 0, (size_t)nq * 16);
-  HIP_TRY(hipMemcpyAsync(c->S->d_stage.p, c->S->h_stage.p, st.used, hipMemcpyHostToDevice, stream));
+  if (c->upload_aside) HIP_TRY(stage_upload(c, st.used, stream));
+  else HIP_TRY(hipMemcpyAsync(c->S->d_stage.p, c->S->h_stage.p, st.used, hipMemcpyHostToDevice, stream));
   HIP_TRY(c->S->d_partial_keys.reserve((size_t)items * (size_t)k, 0, stream));
   HIP_TRY(c->S->d_partial_counts.reserve((size_t)items, 0, stream));
   unsigned long long* d_tau = reinterpret_cast<unsigned long long*>(c->S->d_stage.p + o_tau);

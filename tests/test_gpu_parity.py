@@ -578,6 +578,71 @@ def test_deferred_batch_settled_inside_a_later_multi_pass_search(knobs):
         ctx2.close()
 
 
+@pytest.mark.parametrize("knobs", [dict(), dict(or_bitmaps=-1)], ids=["k_or_lazy", "k_or_wide"])
+def test_a_wide_kth_score_band_on_purpose(oracle, knobs):
+    """the tie-band rule where the band is WIDE. Every doc has the same norm and every posting freq 1, so a doc's
+    score depends only on WHICH of the ten clauses hold it: thousands of docs share each total, up to the order in which ten f32
+    terms are added. k = 100 cuts through such a plateau. The reference sums in heap order there; the fixed-point kernels sum
+    order-free — the returned row may name other members of the k-th plateau than the oracle's, and nothing else: hit counts equal,
+    every returned doc scored by the oracle within 1e-5 of what was returned, every oracle hit clearly above the k-th band
+    present, and every doc that differs sits inside the k-th band (asserted here doc by doc, not just by the rule). Below ten
+    clauses the same queries are bit-exact."""
+    import rucene_amd
+    from rucene_amd import indexgen
+    from oracle import parity
+    max_doc = 600_000
+    rng = np.random.default_rng(2024)
+    # twelve terms of 240 000 + i docs each, drawn independently: their idfs differ by a few 1e-6 relative, so a doc's total is
+    # fixed by HOW MANY clauses hold it up to ~5e-6 — and to the order of the ten f32 additions. ~60 docs hold all ten clauses,
+    # ~900 hold nine: k = 100 cuts through the "nine of ten" plateau, whose members differ in the last bits only
+    lists = []
+    for i in range(12):
+        docs = np.sort(rng.permutation(max_doc)[:240_000 + i]).astype(np.int32)
+        lists.append((docs, np.ones(docs.size, dtype=np.int32)))
+    norms = np.full(max_doc, 120, dtype=np.uint8)     # one field length for every doc
+    seg = indexgen.build_explicit(max_doc, lists, norms=norms)
+    oseg = oracle.Segment(seg.doc_bytes, seg.norms, max_doc, seg.terms, sum_total_term_freq=40 * max_doc)
+    osearcher = oracle.Searcher([oseg])
+    ctx2 = rucene_amd.Context(profile_kernels=True, **knobs)
+    try:
+        leaf = rucene_amd.LeafReader(seg.doc_bytes, seg.norms, max_doc, seg.terms, sum_total_term_freq=40 * max_doc)
+        g = rucene_amd.GpuIndexSearcher([leaf], ctx=ctx2)
+        T, B = rucene_amd.TermQuery, rucene_amd.BooleanQuery
+        specs = [list(range(10)), [1, 2, 3, 4, 5, 6, 7, 8, 9, 10], [11, 2, 4, 6, 8, 10, 0, 1, 3, 5], list(range(12))]
+        k = 100
+        hits, totals = g.search_batch([B.build([], [T(i) for i in ids]) for ids in specs], k)
+        differing_total = 0
+        for i, ids in enumerate(specs):
+            d, sc, total = osearcher.search(oracle.OP_OR, ids, k, tie_mode=oracle.TIE_CANONICAL)
+            assert d.size == k
+            differing = parity.check_heap_order_row(osearcher, oracle.OP_OR, ids, hits[i]["doc"], hits[i]["score"], totals[i], d, sc, d.size, total,
+                                                    rtol=1e-5, what="wide band %s" % ids)
+            differing_total += differing
+            # the band really is wide: many oracle hits tie with the k-th score (within the tolerance)
+            kth = float(sc[-1])
+            in_band = np.abs(sc.astype(np.float64) - kth) <= 1e-5 * kth
+            assert in_band.sum() >= 20, (ids, int(in_band.sum()))
+            # docs that differ, either way round, lie INSIDE that band: by the oracle's own score of them
+            ours_only = np.setdiff1d(hits[i]["doc"], d)
+            theirs_only = np.setdiff1d(d, hits[i]["doc"])
+            assert ours_only.size == theirs_only.size == differing
+            if differing:
+                s_ours, m = osearcher.score_docs(oracle.OP_OR, ids, ours_only)
+                assert m.all() and (np.abs(s_ours.astype(np.float64) - kth) <= 1e-5 * kth).all(), (ids, s_ours, kth)
+                s_theirs = sc[np.isin(d, theirs_only)]
+                assert (np.abs(s_theirs.astype(np.float64) - kth) <= 1e-5 * kth).all(), (ids, s_theirs, kth)
+        print("wide k-th band: %d of %d returned docs differ from the oracle's rows, all inside the band" % (differing_total, k * len(specs)))
+        # nine clauses of the same lists: the reference sums in clause order — bit for bit
+        nine = [list(range(9)), [1, 2, 3, 4, 5, 6, 7, 8, 10]]
+        hits, totals = g.search_batch([B.build([], [T(i) for i in ids]) for ids in nine], k)
+        for i, ids in enumerate(nine):
+            d, sc, total = osearcher.search(oracle.OP_OR, ids, k, tie_mode=oracle.TIE_CANONICAL)
+            assert totals[i] == total and (hits[i]["doc"][:d.size] == d).all() and (hits[i]["score"][:d.size].view(np.int32) == sc.view(np.int32)).all(), ids
+        leaf.segment.close()
+    finally:
+        ctx2.close()
+
+
 @pytest.mark.parametrize("knobs", [dict(), dict(or_lazy_cells=1024), dict(or_bitmaps=16)])
 def test_lazy_disjunctions(oracle, knobs):
     """k_or_lazy (>= 10 SHOULD clauses, the dense ones met through their doc bitmaps) over ten windows: hit counts exact, docs and
