@@ -126,10 +126,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_merge_items(const int64_t* __res
         }
       }
 #pragma unroll
-      for (int j = 0; j < MERGE_AHEAD; ++j) {
-        if (__ballot(ka[j] > tau)) topk_offer<WIDE>(top, ka[j], tau, k, lane);
-        if (WIDE && __ballot(kb[j] > tau)) topk_offer<WIDE>(top, kb[j], tau, k, lane);
-      }
+      for (int j = 0; j < MERGE_AHEAD; ++j) topk_offer_sorted<WIDE>(top, ka[j], kb[j], tau, k, lane);  // (lists are sorted: wave.hpp)
       m = rest & __ballot(head > tau);
     }
   }
@@ -199,10 +196,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_premerge_items(const int64_t* __
       total += real ? partial_counts[min(g0 + j, i1 - 1)] : 0;
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (__ballot(ka[j] > tau)) topk_offer<WIDE>(top, ka[j], tau, k, lane);
-      if (WIDE && __ballot(kb[j] > tau)) topk_offer<WIDE>(top, kb[j], tau, k, lane);
-    }
+    for (int j = 0; j < 4; ++j) topk_offer_sorted<WIDE>(top, ka[j], kb[j], tau, k, lane);
   }
   uint64_t* first = partial_keys + (size_t)i0 * (size_t)k;
   if (lane < k) first[lane] = top.a;

@@ -137,6 +137,56 @@ __device__ __forceinline__ void topk_offer(WaveTopK& t, uint64_t key, uint64_t& 
   }
 }
 
+// ---- merging a SORTED list into the wave-resident top-k: a bitonic merge instead of one insertion per key ------------------------
+// Every partial list a search kernel leaves is a WaveTopK at rest: best first, 0 = empty. Offering such a list key by key
+// costs an insertion (ballot, two shifts, a threshold read: ~150 cycles) per ENTERING key — a single 10-clause query's 612 lists
+// of up to 100 keys took one wavefront 167 us. Two sorted n-lists merge in log2(n) + 1 compare-exchange rounds instead:
+// x[i] = max(T[i], L[n - 1 - i]) is a bitonic sequence that holds the n best keys of the union; rounds of "pair i with
+// i ^ d, the lower lane keeps the larger key" for d = n/2 .. 1 sort it (descending). Keys are unique (score, doc) pairs or 0.
+__device__ __forceinline__ uint64_t wave_shfl64(uint64_t v, int src_lane) {
+  const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(uint32_t)v);
+  const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(uint32_t)(v >> 32));
+  return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
+}
+__device__ __forceinline__ uint64_t bitonic_desc64(uint64_t x, int lane) {  // x: a bitonic 64-sequence, one key per lane
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const uint64_t y = wave_shfl64(x, lane ^ d);
+    x = (lane & d) ? (x < y ? x : y) : (x > y ? x : y);
+  }
+  return x;
+}
+// t := the 64 (WIDE: 128) best keys of t and the sorted list {la, lb} (lb: ranks 64..127, unused unless WIDE), sorted.
+// Ranks at and beyond k may then hold keys below the k-th best: nobody reads them (topk_threshold, the list's writers).
+template <bool WIDE>
+__device__ __forceinline__ void topk_merge_sorted(WaveTopK& t, uint64_t la, uint64_t lb, int lane) {
+  if (!WIDE) {
+    const uint64_t r = wave_shfl64(la, 63 - lane);
+    t.a = bitonic_desc64(t.a > r ? t.a : r, lane);
+  } else {
+    const uint64_t ra = wave_shfl64(la, 63 - lane), rb = wave_shfl64(lb, 63 - lane);
+    const uint64_t xa = t.a > rb ? t.a : rb;  // ranks 0..63 against the list's ranks 127..64
+    const uint64_t xb = t.b > ra ? t.b : ra;  // ranks 64..127 against its ranks 63..0
+    t.a = bitonic_desc64(xa > xb ? xa : xb, lane);
+    t.b = bitonic_desc64(xa > xb ? xb : xa, lane);
+  }
+}
+// One sorted list offered to the top-k: the bitonic merge when several of its keys enter, single insertions otherwise
+// (a merge costs ~14 (WIDE: ~28) lane exchanges whatever enters; an insertion ~150 cycles per entering key)
+template <bool WIDE>
+__device__ __forceinline__ void topk_offer_sorted(WaveTopK& t, uint64_t la, uint64_t lb, uint64_t& tau, int k, int lane) {
+  const int entering = __popcll(__ballot(la > tau)) + (WIDE ? __popcll(__ballot(lb > tau)) : 0);
+  if (entering == 0) return;
+  if (entering >= (WIDE ? 10 : 6)) {
+    topk_merge_sorted<WIDE>(t, la, lb, lane);
+    const uint64_t kth = topk_threshold<WIDE>(t, k);
+    if (kth > tau) tau = kth;
+    return;
+  }
+  if (__ballot(la > tau)) topk_offer<WIDE>(t, la, tau, k, lane);
+  if (WIDE && __ballot(lb > tau)) topk_offer<WIDE>(t, lb, tau, k, lane);
+}
+
 // Per-query threshold shared between the wavefronts working on one query (one u64 per query in HBM, zeroed
 // per launch). A wave whose list is full publishes its k-th best with an atomic max; every wave folds the
 // published value into its own entry threshold. Only keys that provably cannot reach the final top-k are
