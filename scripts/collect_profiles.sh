@@ -2,7 +2,7 @@
 # gpurun_out/prof_<round>_<workload>/{summary.txt, trace/*kernel_stats.csv} -> profiles/<round>_<workload>_{rocprofv3_summary.txt, kernel_stats.csv}
 set -u
 R=$(cd "$(dirname "$0")/.." && pwd)
-ROUND=${1:-r05}
+ROUND=${1:-r06}
 for d in $R/gpurun_out/prof_${ROUND}_*; do
   [ -d "$d" ] || continue
   w=$(basename $d | sed "s/^prof_${ROUND}_//")

@@ -1,11 +1,11 @@
 #!/bin/bash
 # rocprofv3 summaries for the round's profiles/ directory: kernel trace + PMC passes per workload (scripts/prof.sh), on the
-# build that is in the tree. usage (on the GPU box): bash scripts/gpu_profiles.sh [round tag, default r05] [small|big|all]
+# build that is in the tree. usage (on the GPU box): bash scripts/gpu_profiles.sh [round tag, default r06] [small|big|all]
 # Afterwards copy gpurun_out/prof_<round>_<workload>/summary.txt to profiles/<round>_<workload>_rocprofv3_summary.txt
 # (scripts/collect_profiles.sh does it).
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
-ROUND=${1:-r05}
+ROUND=${1:-r06}
 WHAT=${2:-all}
 cd $R
 if [ "$WHAT" != "big" ]; then

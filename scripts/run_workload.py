@@ -78,9 +78,14 @@ else:
     else:
         tids = indexgen.log_uniform_ranks(10 * 1024, 1, 10_000, SEED ^ 0x0A).reshape(-1, 10) - 1
         k = 100
-    packed = s.pack_uniform({"term": 0, "and3": 1}.get(kind, 2), tids, leaf)
+    # the bench's own step: term ids -> rows in one C-ABI call, rows left in device memory (rgpu_planner_search_uniform_ids_device)
+    import torch
+    d_hits = torch.empty((tids.shape[0], k), dtype=torch.int64, device="cuda")
+    d_tot = torch.empty((tids.shape[0],), dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
     for _ in range(reps + 2):
-        hits, totals = leaf.segment.search_batch(packed[0], packed[1], k)
+        s.search_uniform_device({"term": 0, "and3": 1}.get(kind, 2), tids, leaf, k, d_hits.data_ptr(), d_tot.data_ptr())
+        ctx.synchronize()
     if kind in ("term", "and3"):
         print("last launch decoded vs covered:", ctx.last_search_counters())
 import ctypes as _C

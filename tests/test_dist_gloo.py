@@ -1,7 +1,16 @@
 """N > 1 path on CPU: world_size-2 gloo run of the segment-sharded search plumbing (rucene_amd/dist.py) — shard
 placement, doc_base, shard-0 statistics, the all-gather layout and the canonical merge. The per-shard search here is
 the CPU oracle (tests may use it) and the merge is a numpy restatement of k_merge_lists' contract; on GPUs the same
-plumbing runs with rgpu_search_batch_device + rgpu_merge_topk_device (bench.py --gpus N)."""
+plumbing runs with rgpu_search_batch_sharded (bench.py --gpus N).
+
+The PRODUCT's half of the same contract is pinned on the GPU side (-m gpu, tests/test_gpu_parity.py):
+  * test_shard_records_merge_like_finish_parallel — two shards with different doc_base are searched on one device, each
+    into its slot of what would be the all-gather's receive buffer (rgpu_search_batch_record_device), and
+    rgpu_merge_records_device (the very k_merge_lists launch, same strides) must give the two-leaf oracle's rows;
+  * test_sharded_search_through_the_c_abi_with_a_world_of_one[forced_all_gather] — the in-place ncclAllGather, the cross-stream
+    ordering between consecutive collectives and rgpu_comm_reserve EXECUTE (rgpu_config.comm_force_gather), counted by
+    rgpu_comm_gathers_issued;
+  * test_a_failing_shard_still_joins_the_collective — a failing local search leaves its status in the record and joins."""
 import os
 import socket
 import sys
