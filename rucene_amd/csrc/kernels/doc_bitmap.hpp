@@ -87,6 +87,22 @@ __global__ __launch_bounds__(256) void k_bitmap_fill(const int32_t* __restrict__
   }
 }
 
+// Membership bits ALONE for a list too sparse for a full bitmap (round 6): the conjunction kernel's batched first probe only asks
+// "is the candidate in the list" (one bit per doc, max_doc / 8 bytes whatever the list's length); the few survivors then find their
+// freq through the list's block directory. stats->bad_docs counts doc ids outside [0, max_doc) AND repeated ones (a bit that was
+// already set): either makes the list unusable for the probe — its clause is simply walked.
+__global__ __launch_bounds__(256) void k_bitmap_memb(const int32_t* __restrict__ docs, int64_t df, int32_t max_doc, uint32_t* __restrict__ memb,
+                                                     BitmapStats* __restrict__ stats) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool ok = i < df;
+  const int32_t d = ok ? docs[i] : 0;
+  const bool in = ok && (uint32_t)d < (uint32_t)max_doc;
+  bool dup = false;
+  if (in) dup = (atomicOr(&memb[d >> 5], 1u << (d & 31)) >> (d & 31)) & 1u;
+  const uint64_t bad = __ballot((ok && !in) || dup);
+  if (lane_id() == 0 && bad) atomicAdd(&stats->bad_docs, (unsigned)__popcll(bad));
+}
+
 __global__ __launch_bounds__(256) void k_bitmap_popc(const uint2* __restrict__ words, int64_t n_words, uint32_t* __restrict__ ranks) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n_words) ranks[i] = (uint32_t)__popc(words[i].x);

@@ -36,6 +36,11 @@ __device__ unsigned long long g_and_time[16];  // [0] item set-up [1] batched fi
 #define AND_TADD(i, v) do {} while (0)
 #endif
 
+#ifdef RGPU_AND_TRACE  // developer instrumentation (variant builds only): every item's {start, end} wall clock (100 MHz), query and
+constexpr int AND_TRACE_CAP = 1 << 17;            // chunk, survivors popped — the launch's timeline, read back by rgpu_debug_trace
+struct AndTraceRec { unsigned long long t0, t1; int32_t q, chunk, lead_blocks, popped; };
+__device__ AndTraceRec g_and_trace[AND_TRACE_CAP];
+#endif
 // Occupancy against registers (history): at 8 waves/SIMD (64 VGPRs, 80 SGPRs) the round-1 kernel spilled 90-120 bytes per lane
 // to scratch; rounds 2-4 ran at 5 waves/SIMD (85-94 VGPRs, no scratch). Since round 5 (batched first probe: AND_G blocks of rows,
 // 2 * AND_G gathers per lane in flight, a survivor queue in LDS) the kernel needs 99-111 VGPRs and 29.8 KB of LDS per workgroup:
@@ -212,6 +217,10 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
   bool and_popped = false;
 #endif
   AND_STAMP(ts0);
+#ifdef RGPU_AND_TRACE
+  const unsigned long long trace_t0 = (unsigned long long)wall_clock64();
+  int trace_popped = 0;
+#endif
   const int q = upper_slot_wave(item_prefix, n_queries, item, lane);
   const int chunk = (int)(item - item_prefix[q]);
   const DevQuery Q = queries[q];
@@ -527,11 +536,13 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
   int probe_mul = 1;  // ... in every word (the membership bits) or in every other one (the {any, hi} pairs)
   if (fast) {
     const TermBitmap B1 = bitmaps[Q.first_term + 1];
-    fast = B1.words != nullptr;
+    // (words == null, memb != null: a list below the full bitmaps' density that carries its membership bits alone — the probe
+    // asks them, the popped survivors find their freq through the clause's block directory in the candidate loop)
+    fast = B1.words != nullptr || B1.memb != nullptr;
     // RGPU_AND_PROBE: 0 = the membership bits (one per doc; a survivor's freq is asked for when it is popped), 1 = the
     // four-bits-per-doc array where there is one (membership and freq in one gather, four times the footprint), 2 = the {any, hi} pairs
     probe_nib = (B1.nib != nullptr && RGPU_AND_PROBE == 1) ? 1 : 0;
-    probe_mul = (probe_nib || (RGPU_AND_PROBE == 0 && B1.memb != nullptr)) ? 1 : 2;
+    probe_mul = (probe_nib || ((RGPU_AND_PROBE == 0 || B1.words == nullptr) && B1.memb != nullptr)) ? 1 : 2;
     probe_src = (gwords1)(uintptr_t)(probe_nib ? (const void*)B1.nib : (probe_mul == 1 ? (const void*)B1.memb : (const void*)B1.words));
   }
   uint2* const queue = queues[wave];
@@ -666,6 +677,9 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
       const uint2 e1 = a1 ? queue[qhead + 2 * lane + 1] : make_uint2(0u, 0u);
       wave_sync();
       qhead += n;
+#ifdef RGPU_AND_TRACE
+      trace_popped += n;
+#endif
       d0 = (int32_t)e0.x; d1 = (int32_t)e1.x;
       f0 = e0.y >> 12; f1 = e1.y >> 12;
       nn = (e0.y & 0xffu) | ((e1.y & 0xffu) << 8);
@@ -757,6 +771,9 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
   uint64_t* pk = partial_keys + (size_t)item * (size_t)k;
   if (lane < k) pk[lane] = top.a;
   if (WIDE && lane + 64 < k) pk[lane + 64] = top.b;
+#ifdef RGPU_AND_TRACE
+  if (lane == 0 && item < AND_TRACE_CAP) g_and_trace[item] = AndTraceRec{trace_t0, (unsigned long long)wall_clock64(), q, chunk, b1 - b0, trace_popped};
+#endif
   if (lane == 0) {
     partial_counts[item] = count;
     atomicAdd(touched_slots + q, (unsigned long long)touched);  // ~160 items per query word: no contention to speak of

@@ -204,6 +204,7 @@ struct rgpu_ctx {
   // regions — but the cross-stream event wait costs 15-30 us of latency whenever the pipeline is shallow: two alternating streams
   // 0.063 against 0.047 in 20-step regions, the 3-term AND batch 0.290 against 0.258. Off by default.
   bool upload_aside = false;
+  bool memb_only_on = true;   // membership-only bits for sparse first clauses of conjunctions (RGPU_AND_MEMB_ONLY=0 in the environment: off; A/B, tests)
   bool term_sketches = true;  // block-max sketches for single-term queries (search_term.hpp); RGPU_TERM_SKETCH=0 in the environment turns them off (A/B, tests)
   DevVec<uint32_t> pos_counts;             // rgpu_decode_positions: positions per directory slot -> their exclusive prefix sums
   DevVec<unsigned long long> pos_tiles;    // ... the scan's tile sums (+ [0]: unused, [1]: the call's total)
@@ -277,6 +278,10 @@ struct rgpu_segment {
   size_t pnorm_used = 0;
   mutable PreparedMap prepared;  // (a look-up may move a term from the bulk array into the table)
   rucene::FlatFpMap<BitmapInfo> bitmaps;  // doc_start_fp -> the term's doc bitmap (terms holding >= 1 doc in cfg.or_bitmaps)
+  // membership bits alone (k_bitmap_memb) of terms below the full bitmaps' density that stand right behind the lead of a
+  // conjunction: doc_start_fp -> {bits, doc_freq}; bits == null: the list was tried and is unusable (its clause is walked)
+  struct MembOnly { uint32_t* memb; int32_t df; };
+  rucene::FlatFpMap<MembOnly> memb_only;
   std::vector<void*> bitmap_allocs;
   size_t bitmap_bytes = 0;
   int64_t bitmap_terms = 0, bitmap_refused = 0;  // terms that hold a bitmap / that were filed as "walk it" (budget, allocator, unusable list)
@@ -1046,6 +1051,7 @@ extern "C" int32_t rgpu_init(int32_t device_ordinal, const rgpu_config* cfg, rgp
   c->prepared_budget = c->cfg.prepared_budget_mib > 0 ? (size_t)c->cfg.prepared_budget_mib << 20 : 0;
   if (const char* e = std::getenv("RGPU_TERM_SKETCH")) c->term_sketches = std::atoi(e) != 0;
   if (const char* e = std::getenv("RGPU_UPLOAD_ASIDE")) c->upload_aside = std::atoi(e) != 0;
+  if (const char* e = std::getenv("RGPU_AND_MEMB_ONLY")) c->memb_only_on = std::atoi(e) != 0;
   if (const char* e = std::getenv("RGPU_COMM_FORCE_GATHER")) { if (std::atoi(e) != 0) c->cfg.comm_force_gather = 1; }
   std::snprintf(c->name, sizeof c->name, "%s (%s)", prop.name, prop.gcnArchName);
   // (the upload stream only exists when it is asked for: HIP multiplexes streams onto four hardware queues, and a fifth stream in the
@@ -1339,6 +1345,7 @@ extern "C" int32_t rgpu_segment_release_prepared_terms(rgpu_segment* seg) {
   for (void* b : seg->bitmap_allocs) (void)hipFree(b);
   seg->bitmap_allocs.clear();
   seg->bitmaps.clear();
+  seg->memb_only.clear();
   c->bitmap_bytes -= std::min(c->bitmap_bytes, seg->bitmap_bytes);
   seg->bitmap_bytes = 0;
   seg->bitmap_terms = seg->bitmap_refused = 0;
@@ -1614,6 +1621,55 @@ static int32_t ensure_bitmaps_locked(rgpu_segment* seg, const rgpu_term_state* c
     seg->bitmaps.put(st.doc_start_fp, info);
   }
   return RGPU_OK;
+}
+
+// Membership bits for conjunction clauses too sparse for a full bitmap (ctx mutex held; ends synchronised): see k_bitmap_memb.
+// Round 6 measured where k_search_and's cycles go on the 1024 x 3-term batch (-DRGPU_AND_TIME): the 6 % of the lead blocks whose
+// first clause behind the lead had NO bitmap (a list below 1 doc in 256: walked through its block directory, ~6 block decodes per
+// lead block) took 29 % of the kernel's wave cycles — 13 x what a lead block costs on the batched-probe path. The probe itself
+// only needs one bit per doc: such a clause now gets the bits alone (max_doc / 8 bytes, no ranks / freqs / nibbles), every lead
+// block takes the batched probe, and only the survivors (docs that ARE in the list) walk its directory for their freq.
+constexpr int64_t MEMB_ONLY_MIN_DF = 512;   // shorter lists: the lead-driven walk meets at most four of their blocks anyway
+static void ensure_memb_only_locked(rgpu_segment* seg, const rgpu_term_state* const* sts, size_t n) {
+  rgpu_ctx* c = seg->ctx;
+  const int64_t n_words = ((int64_t)seg->max_doc + 31) / 32;
+  const size_t nw_pad = ((size_t)n_words + 1 + BITMAP_PAD_WORDS + 63) & ~size_t(63);
+  const size_t total = nw_pad * 4 + 64;
+  for (size_t i = 0; i < n; ++i) {
+    const rgpu_term_state& st = *sts[i];
+    if (seg->memb_only.find(st.doc_start_fp)) continue;
+    auto refuse = [&]() { seg->memb_only.put(st.doc_start_fp, rgpu_segment::MembOnly{nullptr, st.doc_freq}); };
+    if (c->bitmap_bytes + total > c->bitmap_budget) { refuse(); continue; }
+    uint8_t* block = nullptr;
+    if (hipMalloc(&block, total) != hipSuccess) { (void)hipGetLastError(); refuse(); continue; }
+    BitmapStats hs{};
+    auto build = [&]() -> bool {
+      const size_t df = (size_t)st.doc_freq;
+      if (hipMemsetAsync(block, 0, total, c->stream) != hipSuccess) return false;
+      if (c->d_runs.reserve(df + 64, 0, c->stream) != hipSuccess) return false;
+      int32_t* docs = reinterpret_cast<int32_t*>(c->d_runs.p);
+      if (decode_terms_impl(seg, &st, 1, docs, docs + df, c->stream, nullptr) != RGPU_OK) return false;
+      {
+        TimedLaunch tl(c, c->stream, "k_bitmap_memb", (int64_t)df);
+        RGPU_LAUNCH(k_bitmap_memb, dim3(wg_count((df + 255) / 256)), dim3(256), 0, c->stream, docs, (int64_t)df, seg->max_doc,
+                           reinterpret_cast<uint32_t*>(block), reinterpret_cast<BitmapStats*>(block + nw_pad * 4));
+      }
+      if (hipMemcpyAsync(&hs, block + nw_pad * 4, sizeof hs, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return false;
+      if (hipStreamSynchronize(c->stream) != hipSuccess || launch_status() != hipSuccess) return false;
+      return hs.bad_docs == 0;
+    };
+    if (!build()) {  // an accelerator, never a requirement: the clause is walked, and whatever is wrong with the list shows there
+      (void)hipStreamSynchronize(c->stream);
+      (void)hipGetLastError();
+      (void)hipFree(block);
+      refuse();
+      continue;
+    }
+    seg->bitmap_allocs.push_back(block);
+    seg->bitmap_bytes += total;
+    c->bitmap_bytes += total;
+    seg->memb_only.put(st.doc_start_fp, rgpu_segment::MembOnly{reinterpret_cast<uint32_t*>(block), st.doc_freq});
+  }
 }
 
 // ---- search ----------------------------------------------------------------------------------------------------
@@ -2532,6 +2588,7 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
     const int64_t min_df_or = bitmap_min_df(seg), min_df_and = bitmap_min_df_and(seg);
     std::vector<const rgpu_term_state*> dense;
     std::vector<int32_t> dense_sim;
+    std::vector<const rgpu_term_state*> sparse_first;  // conjunctions: the clause right behind the lead, when it is below the bitmaps' density
     for (int32_t q = 0; q < n_queries; ++q) {
       const rgpu_query& Q = queries[q];
       const int qop = Q.op & 0xff, qopt = (Q.op >> 16) & 0xff;
@@ -2540,6 +2597,25 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
       if (qop == RGPU_OP_OR) {
         if (or_wide_ok && ((Q.op >> 8) & 0xff) <= 1 && Q.n_terms >= 10 && Q.n_terms <= ORX_MAX_TERMS && Q.n_must_not == 0) { n_look = Q.n_terms; min_df = min_df_or; }
       } else if (Q.n_terms + qopt + Q.n_must_not >= 2) { n_look = Q.n_terms + qopt + Q.n_must_not; min_df = min_df_and; }
+      // (only while a list's bits stay in an XCD's L2 — max_doc <= 16.7 M, the condition of and_xcd_chunk: measured on the 3-term
+      // batch at 100 M docs, where they are 12.5 MB per list and every probe of a sparse list is an HBM sector, 1.94 ms with them
+      // against 1.71 walking those clauses; at 10 M docs a batch of "rare AND medium" pairs 0.076 against 0.136 ms)
+      if (qop == RGPU_OP_AND && Q.n_terms >= 2 && c->cfg.and_bitmaps >= 0 && c->memb_only_on && (int64_t)seg->max_doc / 8 <= (2ll << 20)) {
+        // the MUST clause with the second smallest doc_freq (ConjunctionScorer's cost order, stable: conjunction_scorer.rs:30)
+        int a = -1, b = -1;
+        for (int i = 0; i < Q.n_terms; ++i) {
+          const int32_t df = terms[Q.first_term + i].state.doc_freq;
+          if (df <= 0) { a = b = -1; break; }  // a missing MUST clause: the conjunction matches nothing
+          if (a < 0 || df < terms[Q.first_term + a].state.doc_freq) { b = a; a = i; }
+          else if (b < 0 || df < terms[Q.first_term + b].state.doc_freq) b = i;
+        }
+        if (b >= 0) {
+          const rgpu_term_state& s1 = terms[Q.first_term + b].state;
+          // (worth it when the lead has blocks of its own to probe with, i.e. >= 128 postings)
+          if (s1.doc_freq >= MEMB_ONLY_MIN_DF && s1.doc_freq < min_df_and && terms[Q.first_term + a].state.doc_freq >= 128 && !seg->memb_only.find(s1.doc_start_fp))
+            sparse_first.push_back(&s1);
+        }
+      }
       for (int i = 0; i < n_look; ++i) {
         const rgpu_query_term& t = terms[Q.first_term + i];
         if (t.state.doc_freq >= min_df && !seg->bitmaps.find(t.state.doc_start_fp)) {
@@ -2549,6 +2625,7 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
       }
     }
     if (!dense.empty()) { rc = ensure_bitmaps_locked(seg, dense.data(), dense_sim.data(), dense.size()); if (rc != RGPU_OK) return rc; }
+    if (!sparse_first.empty()) ensure_memb_only_locked(seg, sparse_first.data(), sparse_first.size());
   }
   // block-max sketches (search_term.hpp) for the long lists single-term queries name: built once per term, from the frontier words
   // stage B left in the directory and the table of the query that names the term first. Like the bitmaps an accelerator, never a
@@ -2794,7 +2871,7 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
     const size_t o_sp = G.req_opt ? st.add((size_t)(nq + 1) * 8) : 0;
     // conjunctions: the doc bitmaps of the clauses behind the lead (parallel to the DevTerm array)
     std::vector<TermBitmap> clause_bitmaps;
-    if (op == RGPU_OP_AND && c->cfg.and_bitmaps >= 0 && seg->bitmaps.size() > 0) {
+    if (op == RGPU_OP_AND && c->cfg.and_bitmaps >= 0 && (seg->bitmaps.size() > 0 || seg->memb_only.size() > 0)) {
       const int64_t min_df = bitmap_min_df_and(seg);
       bool any = false;
       clause_bitmaps.assign(G.terms.size(), TermBitmap{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0});
@@ -2802,7 +2879,18 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
         const int n_all = q0.n_terms + q0.pad + ((q0.op >> 16) & 0xff);
         for (int i = 1; i < n_all; ++i) {
           const DevTerm& t = G.terms[(size_t)(q0.first_term + i)];
-          if (t.df < min_df) continue;
+          if (t.df < min_df) {
+            // the first MUST clause behind the lead may carry its membership bits alone (words == null: the batched probe asks
+            // them, the survivors walk the clause's block directory)
+            if (i == 1 && q0.n_terms >= 2 && !G.req_opt && seg->memb_only.size() > 0) {
+              const rgpu_segment::MembOnly* mo = seg->memb_only.find((int64_t)t.start_fp);
+              if (mo && mo->memb != nullptr && mo->df == t.df) {
+                clause_bitmaps[(size_t)(q0.first_term + 1)] = TermBitmap{nullptr, nullptr, nullptr, nullptr, nullptr, mo->memb, 0, 0};
+                any = true;
+              }
+            }
+            continue;
+          }
           const BitmapInfo* bm = seg->bitmaps.find((int64_t)t.start_fp);
           if (!bm || !bm->usable || bm->df != t.df) continue;
           clause_bitmaps[(size_t)(q0.first_term + i)] = TermBitmap{bm->words, bm->ranks, bm->freqs, bm->ovf, bm->nib, bm->memb, bm->n_ovf, 0};
@@ -4640,6 +4728,14 @@ extern "C" int32_t rgpu_debug_counters(unsigned long long* out8, int32_t reset) 
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_and_time), z, 128) != hipSuccess) return -1;
   }
   return 0;
+}
+#endif
+#ifdef RGPU_AND_TRACE
+// the most recent k_search_and launch's item timeline: n records of {t0, t1 (100 MHz wall clock), q, chunk, lead blocks, survivors popped}
+extern "C" int32_t rgpu_debug_trace(void* out, int32_t n) {
+  if (n > AND_TRACE_CAP) n = AND_TRACE_CAP;
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_and_trace), (size_t)n * sizeof(AndTraceRec)) == hipSuccess ? n : -1;
 }
 #endif
 #ifdef RGPU_EXP_COUNT

@@ -75,6 +75,12 @@ else:
     elif kind == "and3":
         tids = indexgen.log_uniform_ranks(3 * 1024, 1, 1000, SEED ^ 0xA3).reshape(-1, 3) - 1
         k = 10
+    elif kind == "and2sparse":
+        # "rare AND medium": a lead of a few hundred postings, a second clause below the bitmaps' density (round 6: membership bits alone)
+        lead = indexgen.log_uniform_ranks(1024, docs // 2500, docs // 500, SEED ^ 0x51)
+        second = indexgen.log_uniform_ranks(1024, max(2, docs // 160_000), docs // 2600, SEED ^ 0x52)
+        tids = np.stack([lead, second], axis=1) - 1
+        k = 10
     else:
         tids = indexgen.log_uniform_ranks(10 * 1024, 1, 10_000, SEED ^ 0x0A).reshape(-1, 10) - 1
         k = 100
@@ -84,9 +90,9 @@ else:
     d_tot = torch.empty((tids.shape[0],), dtype=torch.int64, device="cuda")
     torch.cuda.synchronize()
     for _ in range(reps + 2):
-        s.search_uniform_device({"term": 0, "and3": 1}.get(kind, 2), tids, leaf, k, d_hits.data_ptr(), d_tot.data_ptr())
+        s.search_uniform_device({"term": 0, "and3": 1, "and2sparse": 1}.get(kind, 2), tids, leaf, k, d_hits.data_ptr(), d_tot.data_ptr())
         ctx.synchronize()
-    if kind in ("term", "and3"):
+    if kind in ("term", "and3", "and2sparse"):
         print("last launch decoded vs covered:", ctx.last_search_counters())
 import ctypes as _C
 _L = _C.CDLL(rucene_amd._lib.lib_path())

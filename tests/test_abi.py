@@ -147,14 +147,12 @@ def test_rust_shim_has_no_stub_bodies():
     assert "self.flatten(query, true)" not in code
 
 
-def test_rust_accessor_patch_applies():
-    """rust/rucene_accessors.patch: zero-context hunks anchored on `impl` lines. Here (where /root/reference exists) the anchors are
-    checked against the crate and `patch --dry-run` must accept the file on a scratch copy; on a box without the reference only
-    the patch's own arithmetic is checked (hunk lengths = the '+' lines that follow)."""
+def test_rust_accessor_patch_is_well_formed():
+    """rust/rucene_accessors.patch: zero-context hunks anchored on `impl` lines — hunk lengths must equal the '+' lines that follow and
+    every hunk inserts right behind its anchor line. (That the anchors sit where the crate has those `impl` lines, and that
+    `patch --dry-run` accepts the file, is checked by scripts/check_accessor_patch.py in the container that holds the reference —
+    tests never read it.)"""
     import re
-    import shutil
-    import subprocess
-    import tempfile
     path = os.path.join(ROOT, "rust", "rucene_accessors.patch")
     lines = open(path).read().split("\n")
     files, cur = {}, None
@@ -167,18 +165,13 @@ def test_rust_accessor_patch_applies():
             while i + 1 + n < len(lines) and lines[i + 1 + n].startswith("+") and not lines[i + 1 + n].startswith("+++"):
                 n += 1
             assert n == int(m.group(3)) and int(m.group(2)) == int(m.group(1)) + 1, line
+            assert m.group(4).strip().startswith("impl"), line
             files[cur] = (int(m.group(1)), m.group(4).strip())
-    assert len(files) == 3
-    ref = "/root/reference"
-    if not os.path.isdir(ref) or shutil.which("patch") is None:
-        return
-    with tempfile.TemporaryDirectory() as tmp:
-        for rel, (n, anchor) in files.items():
-            src = open(os.path.join(ref, rel)).read().split("\n")
-            assert src[n - 1].strip() == anchor, (rel, n, src[n - 1])
-            os.makedirs(os.path.dirname(os.path.join(tmp, rel)), exist_ok=True)
-            shutil.copy(os.path.join(ref, rel), os.path.join(tmp, rel))
-        subprocess.run(["patch", "-p1", "--dry-run", "-s", "-i", path], cwd=tmp, check=True)
+    assert sorted(files) == ["src/core/search/collector/top_docs.rs", "src/core/search/query/boolean_query.rs", "src/core/search/query/phrase_query.rs"]
+    shim = open(os.path.join(ROOT, "rust", "gpu", "searcher.rs")).read()
+    patch = open(path).read()
+    for fn in ("clauses", "parts", "estimated_hits", "add_leaf_result"):   # what the shim calls is what the patch adds
+        assert ("fn %s(" % fn) in patch and ("." + fn + "(") in shim, fn
 
 
 def test_struct_layouts_match_the_header(gpu_lib):

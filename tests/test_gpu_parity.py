@@ -197,6 +197,72 @@ def test_conjunctions(zipf, oracle, k):
     _check_against_oracle(oracle, osearcher, gsearcher, specs, k)
 
 
+def test_conjunctions_whose_first_clause_is_below_the_bitmap_density(oracle):
+    """Round 6: a conjunction's first clause behind the lead gets its MEMBERSHIP BITS ALONE when its list is below the full bitmaps'
+    density (1 doc in 256) — the batched first probe asks one bit per lead posting, the survivors walk the clause's block directory
+    for their freq (rgpu_api.hip ensure_memb_only_locked, k_bitmap_memb). Queries built so that exactly that happens (the clause
+    right behind the lead holds 512 .. max_doc / 256 docs, the lead >= 128), with two to five clauses, MUST_NOT / SHOULD / FILTER
+    clauses beside them, a lead that ends in a tail, a second clause that is also the third, deleted docs — all bit-exact against the
+    oracle, and the same rows with the bits switched off (RGPU_AND_MEMB_ONLY=0: the round-5 walk)."""
+    import rucene_amd
+    from rucene_amd import indexgen
+    docs, vocab = 600_000, 60_000
+    seg = indexgen.build_zipf(docs, vocab)
+    df = seg.terms["doc_freq"]
+    cut = max(1024, (docs + 255) // 256)
+    mid = [int(t) for t in np.nonzero((df >= 512) & (df < cut))[0]]          # candidates for the sparse first clause
+    rare = [int(t) for t in np.nonzero((df >= 128) & (df < 500))[0]]         # leads
+    dense = [int(t) for t in np.nonzero(df >= cut)[0]]
+    assert len(mid) >= 8 and len(rare) >= 8 and len(dense) >= 8
+    rng = np.random.default_rng(66)
+    pick = lambda pool: int(pool[int(rng.integers(0, len(pool)))])
+    specs = []
+    for _ in range(40):
+        shape = int(rng.integers(0, 4))
+        if shape == 0:
+            specs.append((oracle.OP_AND, [pick(rare), pick(mid)]))
+        elif shape == 1:
+            specs.append((oracle.OP_AND, [pick(dense), pick(rare), pick(mid)]))
+        elif shape == 2:
+            specs.append((oracle.OP_AND, [pick(mid), pick(mid), pick(rare), pick(dense), pick(dense)]))
+        else:
+            m = pick(mid)
+            specs.append((oracle.OP_AND, [pick(rare), m, m]))
+    n_words = (docs + 63) // 64
+    live = rng.integers(0, 2**63, size=n_words, dtype=np.uint64) | rng.integers(0, 2**63, size=n_words, dtype=np.uint64) | (np.uint64(1) << np.uint64(63))
+    live &= ~(np.uint64(1) << rng.integers(0, 63, size=n_words).astype(np.uint64))   # (three docs in four stay live)
+    for words in (None, live):
+        oseg = oracle.Segment(seg.doc_bytes, seg.norms, seg.max_doc, seg.terms, sum_total_term_freq=seg.sum_total_term_freq, live_docs=words)
+        osearcher = oracle.Searcher([oseg])
+        rows = {}
+        for on in ("1", "0"):
+            os.environ["RGPU_AND_MEMB_ONLY"] = on
+            try:
+                ctx2 = rucene_amd.Context(profile_kernels=True)
+            finally:
+                del os.environ["RGPU_AND_MEMB_ONLY"]
+            try:
+                leaf = rucene_amd.LeafReader(seg.doc_bytes, seg.norms, seg.max_doc, seg.terms, live_docs=words, doc_count=seg.doc_count,
+                                             sum_total_term_freq=seg.sum_total_term_freq)
+                g = rucene_amd.GpuIndexSearcher([leaf], ctx=ctx2)
+                for k in (10, 100):
+                    _check_against_oracle(oracle, osearcher, g, specs, k)
+                T, B = rucene_amd.TermQuery, rucene_amd.BooleanQuery
+                trees = [B.build([T(rare[0]), T(mid[0])], [T(dense[0])]),                                  # + SHOULD (ReqOptScorer records: no batched probe)
+                         B.build([T(rare[1]), T(mid[1])], [], must_nots=[T(dense[1])]),                    # + MUST_NOT
+                         B.build([T(rare[2])], [], filters=[T(mid[2]), T(dense[2])]),                      # FILTER clauses
+                         B.build([T(rare[3]), T(mid[3]), T(mid[3])], [])]
+                rows[on] = g.search_batch(trees, 10)
+                st = ctx2.kernel_stats()
+                assert ("k_bitmap_memb" in st) == (on == "1"), sorted(st)
+                leaf.segment.close()
+            finally:
+                ctx2.close()
+        assert (rows["1"][1] == rows["0"][1]).all() and (rows["1"][0]["doc"] == rows["0"][0]["doc"]).all()
+        assert (rows["1"][0]["score"].view(np.int32) == rows["0"][0]["score"].view(np.int32)).all()
+        assert rows["1"][1].sum() > 0
+
+
 def test_nested_boolean_trees_through_the_seam(zipf, oracle):
     """"... everything else to the CPU path". One level of MUST-of-MUSTs / SHOULD-of-SHOULDs folds into the flat
     query when the searcher is asked to (same docs and counts as the flat query, which the oracle pins; the nested tree's own
