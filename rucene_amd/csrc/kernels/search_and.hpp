@@ -50,6 +50,15 @@ __device__ AndTraceRec g_and_trace[AND_TRACE_CAP];
 #define RGPU_AND_WAVES 4
 #endif
 constexpr int AND_WAVES_PER_SIMD = RGPU_AND_WAVES;
+// Wavefronts per WORKGROUP of k_search_and. Nothing in the kernel is shared between the wavefronts of a workgroup (every LDS
+// array is indexed by the wavefront, no barrier is met), but a CU gives a workgroup's register and LDS allocation back only when
+// its LAST wavefront ends: with items of 20 us at the median and 67 us at the 99th percentile (round 6's item timeline,
+// scripts/and_timeline.py) three finished wavefronts wait for the fourth — the launch ran at 80 % of its 4096 wavefront slots.
+#ifndef RGPU_AND_WG_WAVES
+#define RGPU_AND_WG_WAVES 4
+#endif
+constexpr int AND_WG_WAVES = RGPU_AND_WG_WAVES;
+constexpr int AND_WG_THREADS = 64 * AND_WG_WAVES;
 #ifndef RGPU_AND_PREFETCH  // 1: the next block's rows are requested before the current one is unpacked (five more VGPRs)
 #define RGPU_AND_PREFETCH 1
 #endif
@@ -163,7 +172,7 @@ struct SeqRec {
 // HAS_NOT / HAS_OPT: some query of the launch carries MUST_NOT / optional SHOULD clauses (separate instantiations keep the
 // common kernel lean). Clause order on the device: [MUST x n_terms][MUST_NOT x pad][SHOULD x (op >> 16)].
 template <bool LEGACY, bool WIDE, bool HAS_NOT, bool HAS_OPT>
-__global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(SegView seg, const DevQuery* __restrict__ queries,
+__global__ __launch_bounds__(AND_WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(SegView seg, const DevQuery* __restrict__ queries,
                                                            const DevTerm* __restrict__ terms,
                                                            const int64_t* __restrict__ item_prefix, int n_queries,
                                                            int64_t n_items, int blocks_per_item, int k,
@@ -189,11 +198,11 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
   // lead posting at emit_prefix[q] + the posting's ordinal — doc order, no cursor.
   int32_t* const emit_docs = HAS_OPT ? nullptr : static_cast<int32_t*>(emit_out);
   SeqRec* const seq_out = HAS_OPT ? static_cast<SeqRec*>(emit_out) : nullptr;
-  __shared__ __attribute__((aligned(16))) uint8_t slabs[WG_WAVES][2 * SLAB_STREAM];  // FullBlock staging only: tails arrive decoded
-  __shared__ float caches[WG_WAVES][256];
-  __shared__ uint32_t filters[WG_WAVES][AND_FILTER_WORDS];
+  __shared__ __attribute__((aligned(16))) uint8_t slabs[AND_WG_WAVES][2 * SLAB_STREAM];  // FullBlock staging only: tails arrive decoded
+  __shared__ float caches[AND_WG_WAVES][256];
+  __shared__ uint32_t filters[AND_WG_WAVES][AND_FILTER_WORDS];
 #if RGPU_AND_FAST
-  __shared__ uint2 queues[WG_WAVES][AND_Q_CAP];  // survivors of the batched first probe: {doc, norm | code << 8 | lead freq << 12}
+  __shared__ uint2 queues[AND_WG_WAVES][AND_Q_CAP];  // survivors of the batched first probe: {doc, norm | code << 8 | lead freq << 12}
 #endif
   const int lane = lane_id();
   const int wave = wave_id();
@@ -210,7 +219,7 @@ __global__ __launch_bounds__(WG_THREADS, AND_WAVES_PER_SIMD) void k_search_and(S
     const int64_t r = wg >> 3, x = wg & 7;  // the r-th workgroup of XCD x
     wg = (r / xcd_chunk) * (8 * (int64_t)xcd_chunk) + x * xcd_chunk + (r % xcd_chunk);
   }
-  const int64_t item = wg * WG_WAVES + wave;
+  const int64_t item = wg * AND_WG_WAVES + wave;
   if (item >= n_items) return;
 #ifdef RGPU_AND_TIME
   long long and_t[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};

@@ -2453,7 +2453,7 @@ static int and_xcd_chunk(const rgpu_segment* seg) {
 #ifdef RGPU_AND_XCD_CHUNK
   return RGPU_AND_XCD_CHUNK;
 #else
-  return (int64_t)seg->max_doc / 8 <= (2ll << 20) ? 64 : 0;  // 2 MB of bits per list (max_doc <= 16.7 M) against 4 MB of L2 per XCD
+  return (int64_t)seg->max_doc / 8 <= (2ll << 20) ? 64 * 4 / AND_WG_WAVES : 0;  // 2 MB of bits per list (max_doc <= 16.7 M) against 4 MB of L2 per XCD; 256 items per chunk
 #endif
 }
 static unsigned long long and_grid(long long wgs, int chunk) {
@@ -2949,7 +2949,7 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
       TimedLaunch tl(c, stream, "k_search_and", G.postings);
       // (whole rounds of 8 x AND_XCD_CHUNK workgroups: the kernel deals chunks of workgroups to the XCDs, search_and.hpp)
       const int xcd_chunk = and_xcd_chunk(seg);
-      const unsigned grid = wg_count(and_grid((items + WG_WAVES - 1) / WG_WAVES, xcd_chunk));
+      const unsigned grid = wg_count(and_grid((items + AND_WG_WAVES - 1) / AND_WG_WAVES, xcd_chunk));
       const int64_t* d_sp = nullptr;
       void* d_seq = nullptr;
       if (G.req_opt) {  // records instead of a collector (in the slot's own run buffer: the group only marks its slot)
@@ -2959,7 +2959,7 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
         d_seq = c->S->d_runs.p;
       }
       auto go = [&](auto kern) {
-        RGPU_LAUNCH(kern, dim3(grid), dim3(WG_THREADS), 0, stream, sv, dq, dt, dp, nq, items, blocks_per_item, (int)k,
+        RGPU_LAUNCH(kern, dim3(grid), dim3(AND_WG_THREADS), 0, stream, sv, dq, dt, dp, nq, items, blocks_per_item, (int)k,
                            c->S->d_partial_keys.p, c->S->d_partial_counts.p, d_tau, c->S->d_touched.p,
                            d_sp, (unsigned long long*)nullptr, d_seq, c->pass.ceil_in, dm,
                            clause_bitmaps.empty() ? (const TermBitmap*)nullptr : reinterpret_cast<const TermBitmap*>(c->S->d_stage.p + o_bm), xcd_chunk);
@@ -3467,9 +3467,9 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
     {
       TimedLaunch tl(c, stream, "k_search_and(phrase candidates)", 0);
       const int xcd_chunk = and_xcd_chunk(seg);
-      const unsigned grid = wg_count(and_grid((items + WG_WAVES - 1) / WG_WAVES, xcd_chunk));
+      const unsigned grid = wg_count(and_grid((items + AND_WG_WAVES - 1) / AND_WG_WAVES, xcd_chunk));
       auto go = [&](auto kern) {
-        RGPU_LAUNCH(kern, dim3(grid), dim3(WG_THREADS), 0, stream, sv, d_q, d_t, d_ip, (int)n_queries, items, blocks_per_item, k_emit,
+        RGPU_LAUNCH(kern, dim3(grid), dim3(AND_WG_THREADS), 0, stream, sv, d_q, d_t, d_ip, (int)n_queries, items, blocks_per_item, k_emit,
                            c->S->d_partial_keys.p, c->S->d_partial_counts.p, c->S->d_tau.p, c->S->d_touched.p, d_ep, c->phrase_count.p,
                            (void*)c->phrase_docs.p, (const unsigned long long*)nullptr, (const int32_t*)nullptr,
                            clause_bitmaps.empty() ? (const TermBitmap*)nullptr : reinterpret_cast<const TermBitmap*>(c->S->d_stage.p + o_bm), xcd_chunk);
