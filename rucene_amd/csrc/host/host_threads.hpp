@@ -17,6 +17,22 @@
 
 namespace rucene {
 
+// One step of a bounded spin: a CPU pause hint while the wait is young (x86 `pause`, aarch64 `yield`), a scheduler yield once it is
+// not — mid() of two_pass_run may hold an hipMalloc (0.3-20 ms): seven cores must not spin through that.
+inline void spin_wait_step(int& spins) {
+  if (++spins < 2048) {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    __asm__ __volatile__("yield");
+#else
+    std::this_thread::yield();
+#endif
+  } else {
+    std::this_thread::yield();
+  }
+}
+
 // How many threads a bulk pass may use: the CPUs this process may run on (affinity mask), the cgroup's CPU quota when there is one
 // (cgroup v2 `cpu.max`: a container with "1600000 100000" has 16 CPUs' worth of time whatever the mask says), at most 8 — the
 // passes are memory-bound and short, more threads only add start-up time. RGPU_HOST_THREADS overrides (1 = everything inline).
@@ -38,6 +54,11 @@ inline int host_threads() {
         if (quota > 0) n = (int)std::min<long long>(n, std::max<long long>(1, quota / period));
       }
       std::fclose(f);
+    } else {  // cgroup v1: cpu.cfs_quota_us / cpu.cfs_period_us (-1: no quota)
+      long long quota = -1, period = 0;
+      if (std::FILE* q = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (std::fscanf(q, "%lld", &quota) != 1) quota = -1; std::fclose(q); }
+      if (std::FILE* pf = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (std::fscanf(pf, "%lld", &period) != 1) period = 0; std::fclose(pf); }
+      if (quota > 0 && period > 0) n = (int)std::min<long long>(n, std::max<long long>(1, quota / period));
     }
     return std::min(n, 8);
   }();
@@ -66,8 +87,8 @@ inline void parallel_run(int n_parts, F&& fn) {
 
 // Two passes over the same parts with the threads kept between them: pass1(t) for every part, then mid() ONCE on the calling
 // thread (all of pass 1 is visible to it), then — if mid() returned true — pass2(t) for every part (mid()'s writes are visible to
-// them). The workers spin for the length of mid(), which is short here (sizing a staging buffer): starting threads twice costs
-// more than the wait, and a core that has just run pass 1 is awake for pass 2. A thread that cannot be started has both passes of
+// them). The workers wait for the length of mid() — a bounded spin (2048 pause hints), then scheduler yields: mid() sizes buffers and may sit in
+// an allocation for milliseconds; starting threads twice costs more than the wait, and a core that has just run pass 1 is awake for pass 2. A thread that cannot be started has both passes of
 // its part run on the calling thread.
 template <class F1, class Mid, class F2>
 inline void two_pass_run(int n_parts, F1&& pass1, Mid&& mid, F2&& pass2) {
@@ -84,8 +105,8 @@ inline void two_pass_run(int n_parts, F1&& pass1, Mid&& mid, F2&& pass2) {
       threads.emplace_back([&, t] {
         pass1(t);
         done.fetch_add(1, std::memory_order_release);
-        int g;
-        while ((g = go.load(std::memory_order_acquire)) == 0) __builtin_ia32_pause();
+        int g, spins = 0;
+        while ((g = go.load(std::memory_order_acquire)) == 0) spin_wait_step(spins);
         if (g > 0) pass2(t);
       });
     } catch (...) {
@@ -101,7 +122,7 @@ inline void two_pass_run(int n_parts, F1&& pass1, Mid&& mid, F2&& pass2) {
   } catch (...) {
     thrown = std::current_exception();
   }
-  while (done.load(std::memory_order_acquire) != (int)threads.size()) __builtin_ia32_pause();
+  { int spins = 0; while (done.load(std::memory_order_acquire) != (int)threads.size()) spin_wait_step(spins); }
   if (!thrown) {
     try { ok = mid(); } catch (...) { thrown = std::current_exception(); }
   }

@@ -427,8 +427,19 @@ __device__ __forceinline__ uint64_t sketch_floor(const uint16_t* __restrict__ sk
 
 // (eight wavefronts per SIMD = 64 VGPRs hold the headline instantiation — packed blocks, k <= 64; a second top-k register pair
 // (k > 64) or the legacy decode need a few more: seven wavefronts, 72 VGPRs, instead of 12 B of scratch per lane)
+// Round 6: the launch bounds ASK for one wavefront less than the kernel gets — 7 for the headline instantiation (63 VGPRs: still
+// eight per SIMD), 6 for the others (65: still seven). What the bound buys is the compiler's SGPR budget: at "8" it is 80 (800 / 8,
+// minus 16 for the trap handler, rounded to 16), at 7 it is 96, at 6 it is 102 — and the headline instantiation's 88 SGPR spills
+// (v_writelane / v_readlane into two VGPRs, 12-24 reloads in each block loop) become 29, the others' 36-44 become 14-23.
+// Measured, same box: k_search_term 0.0405-0.0418 -> 0.0378-0.0382 ms at 10 M docs, 0.139 -> 0.131-0.133 ms at 100 M.
+#ifndef RGPU_TERM_OTHER_WAVES
+#define RGPU_TERM_OTHER_WAVES 6
+#endif
+#ifndef RGPU_TERM_FAST_WAVES
+#define RGPU_TERM_FAST_WAVES 7
+#endif
 template <bool LEGACY, bool WIDE>
-__global__ __launch_bounds__(TERM_THREADS, (LEGACY || WIDE) ? 7 : 8) void k_search_term(SegView seg, const DevQuery* __restrict__ queries,
+__global__ __launch_bounds__(TERM_THREADS, (LEGACY || WIDE) ? RGPU_TERM_OTHER_WAVES : RGPU_TERM_FAST_WAVES) void k_search_term(SegView seg, const DevQuery* __restrict__ queries,
                                                               const DevTerm* __restrict__ terms,
                                                               const int64_t* __restrict__ item_prefix, int n_queries,
                                                               int64_t n_items, int blocks_per_item, int k,

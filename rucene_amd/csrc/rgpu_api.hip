@@ -74,6 +74,23 @@ static inline unsigned wg_count(unsigned long long n) { return n > 0xffffffffull
     hipError_t _e = (expr);                                                                                \
     if (_e != hipSuccess) return fail(RGPU_ERR_RUNTIME, std::string(#expr) + ": " + hipGetErrorString(_e)); \
   } while (0)
+// scratch_take() may have to settle a deferred disjunction batch first (rgpu_config.or_deferred): when THAT fails, the call that
+// happened to need the slot reports the deferred batch's own status and message (it used to become a generic
+// "hipErrorUnknown" attributed to the unrelated later call)
+static thread_local int32_t g_settle_rc = 0;
+static thread_local std::string g_settle_why;
+#define SCRATCH_TAKE(c)                                                                                                   \
+  do {                                                                                                                    \
+    hipError_t _e = scratch_take(c);                                                                                      \
+    if (_e != hipSuccess) {                                                                                               \
+      if (g_settle_rc != 0) {                                                                                             \
+        const int32_t _rc = g_settle_rc;                                                                                  \
+        g_settle_rc = 0;                                                                                                  \
+        return fail(_rc, "a deferred disjunction batch failed when its flags were looked at: " + g_settle_why);          \
+      }                                                                                                                   \
+      return fail(RGPU_ERR_RUNTIME, std::string("scratch_take: ") + hipGetErrorString(_e));                               \
+    }                                                                                                                     \
+  } while (0)
 
 namespace {
 
@@ -371,8 +388,10 @@ static int32_t settle_pending(rgpu_ctx* c) {
 static hipError_t scratch_take(rgpu_ctx* c) {
   // a slot whose flags (pinned read-back, event) are still to be looked at: that happens before it is reused (what the look
   // launches takes slots itself: the next slot is chosen afterwards)
-  while (c->scr[c->scr_next].settles_later)
-    if (settle_pending(c) != RGPU_OK) return hipErrorUnknown;
+  while (c->scr[c->scr_next].settles_later) {
+    const int32_t rc = settle_pending(c);
+    if (rc != RGPU_OK) { g_settle_rc = rc; g_settle_why = g_last_error; return hipErrorUnknown; }
+  }
   Scratch* sc = &c->scr[c->scr_next];
   c->scr_next = (c->scr_next + 1) % N_SCRATCH;
   if (sc->busy) {
@@ -619,7 +638,7 @@ static int32_t prepare_terms_attempt(rgpu_segment* seg, const rgpu_term_state* c
   Stager st(c);
   auto size_and_reserve = [&]() -> int32_t {
     t_plan = hc.lap();
-    HIP_TRY(scratch_take(c));  // staging below; this function ends with a stream sync, so the slot is free again on return
+    SCRATCH_TAKE(c);  // staging below; this function ends with a stream sync, so the slot is free again on return
     HIP_TRY(seg->dir_last.reserve(need_slots, seg->dir_used, c->stream));
     HIP_TRY(seg->dir_off.reserve(need_slots, seg->dir_used, c->stream));
     HIP_TRY(seg->dir_row.reserve(need_slots, seg->dir_used, c->stream));
@@ -892,25 +911,30 @@ static int32_t prepare_terms_attempt(rgpu_segment* seg, const rgpu_term_state* c
   // (behind the commit: a copy into pageable host memory returns when it is done, i.e. after the kernels)
   hipError_t e_copy = hipMemcpyAsync(err4, c->d_err, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream);
   if (e_copy == hipSuccess) e_copy = hipMemcpyAsync(&total_rows, d_total, 8, hipMemcpyDeviceToHost, c->stream);
-  auto take_back = [&]() {
-    if (as_bulk) seg->prepared.drop_bulk(); else seg->prepared.remove_keys(added_keys.data(), added_keys.size());
-    if (sink) sink->fused->assign(n, 0);
-  };
+  // The commit above is provisional until the kernels have been verified: EVERY exit from here on takes the terms back unless it
+  // disarms the guard (the rollback used to be a call each failing branch had to remember).
+  struct Rollback {
+    rgpu_segment* seg; bool as_bulk; const std::vector<int64_t>* keys; const DecodeSink* sink; size_t n; bool armed;
+    ~Rollback() {
+      if (!armed) return;
+      if (as_bulk) seg->prepared.drop_bulk(); else seg->prepared.remove_keys(keys->data(), keys->size());
+      if (sink) sink->fused->assign(n, 0);
+    }
+  } provisional{seg, as_bulk, &added_keys, sink, n, true};
   hipError_t e_sync = e_copy == hipSuccess ? hipStreamSynchronize(c->stream) : e_copy;
   if (e_sync == hipSuccess) e_sync = launch_status();
   if (e_sync != hipSuccess) {
     (void)hipStreamSynchronize(c->stream);
-    take_back();
     return fail(RGPU_ERR_RUNTIME, std::string("term preparation: ") + hipGetErrorString(e_sync));
   }
   t_sync = hc.lap();
   const int err = err4[0];
-  if (err == -101) { take_back(); return -101; }  // see prepare_terms_locked
+  if (err == -101) return -101;  // see prepare_terms_locked
   if (err != 0) {
-    take_back();
     return fail(err, err == RGPU_ERR_UNSUPPORTED ? std::string("FULL-encoded doc block (unimplemented in Rucene itself), or an EF / BITSET block in a legacy (.doc version 0) file")
                                                  : "corrupt skip data or block framing in .doc (prepare.hpp check #" + std::to_string(err4[1]) + ")");
   }
+  provisional.armed = false;  // verified: the terms stay
   seg->dir_used = need_slots;
   seg->bstore_used = batch_bs + (size_t)total_rows * 16;
   if (HostClock::on())
@@ -945,7 +969,7 @@ static int32_t prepare_norms_locked(rgpu_segment* seg, const rgpu_term_state* co
     fps.push_back(st.doc_start_fp);
   }
   if (work.empty()) return RGPU_OK;
-  HIP_TRY(scratch_take(c));
+  SCRATCH_TAKE(c);
   HIP_TRY(seg->pnorm.reserve(need_pn + 64, seg->pnorm_used, c->stream));
   std::vector<int64_t> item_prefix;
   int64_t n_items = 0, postings = 0;
@@ -1336,7 +1360,10 @@ extern "C" int32_t rgpu_segment_release_prepared_terms(rgpu_segment* seg) {
   rgpu_ctx* c = seg->ctx;
   std::lock_guard<std::mutex> g(c->mu);
   HIP_TRY(hipSetDevice(c->device));
-  (void)settle_pending(c);
+  // (a deferred batch whose redo fails here: the store is released all the same — nothing may keep reading it — and the
+  // batch's own status is what this call returns)
+  const int32_t settled = settle_pending(c);
+  const std::string settled_why = settled == RGPU_OK ? std::string() : g_last_error;
   HIP_TRY(hipDeviceSynchronize());  // batches in flight on any stream still read the directories
   for (auto& sc : c->scr) sc.busy = false;
   for (auto& cs : c->ceil_slots) cs.busy = false;
@@ -1349,6 +1376,7 @@ extern "C" int32_t rgpu_segment_release_prepared_terms(rgpu_segment* seg) {
   c->bitmap_bytes -= std::min(c->bitmap_bytes, seg->bitmap_bytes);
   seg->bitmap_bytes = 0;
   seg->bitmap_terms = seg->bitmap_refused = 0;
+  if (settled != RGPU_OK) return fail(settled, "a deferred disjunction batch failed when its flags were looked at: " + settled_why);
   return RGPU_OK;
 }
 
@@ -1387,7 +1415,7 @@ static int32_t decode_terms_impl(rgpu_segment* seg, const rgpu_term_state* terms
     if (terms[i].doc_freq > 0 && !(i < (int64_t)fused.size() && fused[(size_t)i])) rest.push_back(i);
   if (rest.empty()) return RGPU_OK;
   const int64_t nr = (int64_t)rest.size();
-  HIP_TRY(scratch_take(c));  // callers synchronize the stream before they return
+  SCRATCH_TAKE(c);  // callers synchronize the stream before they return
   Stager st(c);
   const size_t o_terms = st.add((size_t)nr * sizeof(DevTerm));
   const size_t o_items = st.add((size_t)(nr + 1) * 8);
@@ -1708,7 +1736,7 @@ static int32_t search_or_group(rgpu_segment* seg, Group& G, int32_t k, HitOut* h
   const bool wide = k > 64;
   const bool legacy = seg->version < 1;
   if (nt == 0) return RGPU_OK;  // every clause absent from this leaf: rows keep their {-1, 0} / 0 defaults
-  HIP_TRY(scratch_take(c));
+  SCRATCH_TAKE(c);
   // Which clauses does the window kernel decode itself? Per query the (up to) `or_dense_clauses` longest SHOULD lists
   // whose 128-posting blocks span at most two windows on average (df * W >= 64 * max_doc): a block is unpacked again
   // in every window it reaches into, so a sparser list is cheaper through a run. On a Zipfian query those few lists
@@ -2011,7 +2039,7 @@ static int32_t search_or_lazy_group(rgpu_segment* seg, Group& G, int32_t k, HitO
   const int nq = (int)lq.size();
   HOST_STAMP(h1);
   if (nq > 0) {
-    HIP_TRY(scratch_take(c));
+    SCRATCH_TAKE(c);
     // phase 1 plan (k_score_terms): items = (distinct walked term, chunk of blocks); runs end in OR_RUN_PAD sentinels
     const int nu = (int)uniq.size();
     int blocks_per_item = 32;
@@ -2271,7 +2299,7 @@ static int32_t search_or_wide_group(rgpu_segment* seg, Group& G, int32_t k, HitO
   const bool legacy = seg->version < 1;
   if (nt == 0) return RGPU_OK;
   if (!G.no_lazy && c->cfg.or_bitmaps >= 0 && seg->bitmaps.size() > 0) return search_or_lazy_group(seg, G, k, hits_dev, totals_dev, stream);
-  HIP_TRY(scratch_take(c));
+  SCRATCH_TAKE(c);
   // a window: a multiple of the workgroup's scan step, small enough for the directory look-ahead and for LDS
   constexpr int WS_MAX = ORX_MAX_WINDOW / ORX_SCAN_STEP * ORX_SCAN_STEP;
 #ifndef RGPU_ORX_WS  // the default window (variant builds sweep it together with RGPU_ORX_TABLES / RGPU_ORX_LOOK: LDS is the budget)
@@ -2796,7 +2824,7 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
       if (rc_or != RGPU_OK) return rc_or;
       continue;
     }
-    HIP_TRY(scratch_take(c));
+    SCRATCH_TAKE(c);
     if (op == RGPU_OP_AND && !G.req_opt && nq > 2) {
       // Conjunctions that probe the same list run side by side: the group's queries are ordered by the term of the first clause
       // behind the lead — the one every lead posting is looked up in (a doc bitmap: one gather per candidate into a 1 - 5 MB
@@ -3196,7 +3224,7 @@ static int32_t decode_positions_impl(rgpu_segment* seg, const rgpu_term_state* t
   }
   item_prefix.push_back(items);
   const int nt = (int)dt.size();
-  HIP_TRY(scratch_take(c));
+  SCRATCH_TAKE(c);
   Stager st(c);
   const size_t o_t = st.add(dt.size() * sizeof(DevTerm));
   const size_t o_pt = st.add(pt.size() * sizeof(PosTerm));
@@ -3392,7 +3420,7 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
   HIP_TRY(hipMemsetAsync(c->host_api_totals.p, 0, (size_t)n_queries * 8, stream));
   RGPU_LAUNCH(k_init_hits, dim3(wg_count(((size_t)n_queries * k + 255) / 256)), dim3(256), 0, stream, c->host_api_hits.p, (int64_t)n_queries, (int)k, (int)k, 0);
   if (items > 0) {
-    HIP_TRY(scratch_take(c));
+    SCRATCH_TAKE(c);
     Stager st(c);
     const size_t o_q = st.add((size_t)n_queries * sizeof(DevQuery));
     const size_t o_t = st.add(dt.size() * sizeof(DevTerm));
@@ -3693,7 +3721,7 @@ extern "C" int32_t rgpu_rescore_batch(rgpu_segment* seg, const rgpu_query* queri
     dq[(size_t)q] = DevQuery{qop, (int32_t)mine.size(), (int32_t)dt.size(), 0};
     for (auto& m : mine) dt.push_back(m);
   }
-  HIP_TRY(scratch_take(c));
+  SCRATCH_TAKE(c);
   Stager st(c);
   const size_t o_q = st.add((size_t)n_queries * sizeof(DevQuery));
   const size_t o_t = st.add(std::max<size_t>(1, dt.size()) * sizeof(DevTerm));
@@ -4493,7 +4521,7 @@ static int32_t term_batch_fast(rgpu_segment* seg, rucene::BatchPlanner* P, int32
   const bool need_norms = seg->d_norms != nullptr;
   const uint32_t flags = c->sim_monotone[(size_t)sim_table] ? TERM_FLAG_MONOTONE : 0u;
   c->pass = rgpu_ctx::Pass{};
-  HIP_TRY(scratch_take(c));
+  SCRATCH_TAKE(c);
   Stager st(c);
   const size_t o_q = st.add((size_t)nq * sizeof(DevQuery));
   const size_t o_t = st.add((size_t)nq * sizeof(DevTerm));
