@@ -432,6 +432,11 @@ __device__ __forceinline__ uint64_t sketch_floor(const uint16_t* __restrict__ sk
 // minus 16 for the trap handler, rounded to 16), at 7 it is 96, at 6 it is 102 — and the headline instantiation's 88 SGPR spills
 // (v_writelane / v_readlane into two VGPRs, 12-24 reloads in each block loop) become 29, the others' 36-44 become 14-23.
 // Measured, same box: k_search_term 0.0405-0.0418 -> 0.0378-0.0382 ms at 10 M docs, 0.139 -> 0.131-0.133 ms at 100 M.
+#ifdef RGPU_TERM_TRACE  // developer instrumentation (variant builds only): every item's {start, end} wall clock (100 MHz), query, chunk,
+constexpr int TERM_TRACE_CAP = 1 << 17;           // blocks looked at / unpacked — the launch's timeline, read back by rgpu_debug_trace
+struct TermTraceRec { unsigned long long t0, t1; int32_t q, chunk, blocks, unpacked; };
+__device__ TermTraceRec g_term_trace[TERM_TRACE_CAP];
+#endif
 #ifndef RGPU_TERM_OTHER_WAVES
 #define RGPU_TERM_OTHER_WAVES 6
 #endif
@@ -441,7 +446,7 @@ __device__ __forceinline__ uint64_t sketch_floor(const uint16_t* __restrict__ sk
 template <bool LEGACY, bool WIDE>
 __global__ __launch_bounds__(TERM_THREADS, (LEGACY || WIDE) ? RGPU_TERM_OTHER_WAVES : RGPU_TERM_FAST_WAVES) void k_search_term(SegView seg, const DevQuery* __restrict__ queries,
                                                               const DevTerm* __restrict__ terms,
-                                                              const int64_t* __restrict__ item_prefix, int n_queries,
+                                                              const int4* __restrict__ item_desc, int n_queries,
                                                               int64_t n_items, int blocks_per_item, int k,
                                                               uint64_t* __restrict__ partial_keys,
                                                               int32_t* __restrict__ partial_counts,
@@ -470,14 +475,21 @@ __global__ __launch_bounds__(TERM_THREADS, (LEGACY || WIDE) ? RGPU_TERM_OTHER_WA
   // start in order, so by the time most chunks begin, their query's first chunk has already published a
   // threshold (SharedTau). Every wave resolves its own item and posts the query in LDS for the others.
   const int64_t item = (int64_t)blockIdx.x * TERM_WAVES + wave;
-  int q = -1, chunk = 0;
+#ifdef RGPU_TERM_TRACE
+  const unsigned long long trace_t0 = (unsigned long long)wall_clock64();
+#endif
+  // item_desc[item] = {query, chunk, the query's term (-1: absent from this leaf), the query's item count}: written by the host next to
+  // the plan. Round 6's item timeline (scripts/term_timeline.py) showed every item of the launch paying ~15 us before it looked at
+  // its first block — a chain of dependent round trips (two for the item -> query search over item_prefix, the query, the term, then
+  // table / sketch / frontier words) on a chip where 5112 wavefronts start at once; the descriptor cuts it to item -> term -> data
+  // (k_search_term 0.0391-0.0399 -> 0.0380-0.0381 ms at 10 M docs and 0.133 -> 0.129 at 100 M on one box, 0.0385-0.0388 -> 0.0384-0.0389
+  // on another: at best 3 %). Requesting the item's first directory
+  // chunk and its sketch entries BEFORE the score table is built, to overlap one more round trip, was measured too: slower
+  // (0.0403-0.0417 ms, whatever the launch bounds: the registers it holds across the table build cost more than the trip).
+  int q = -1, chunk = 0, first_term = -1, q_items = 1;
   if (item < n_items) {
-    if (item < n_queries) {
-      q = (int)item;
-    } else {
-      q = upper_slot_wave(item_prefix, n_queries, item - n_queries, lane);
-      chunk = (int)(item - n_queries - item_prefix[q]) + 1;
-    }
+    const int4 d = item_desc[item];
+    q = d.x; chunk = d.y; first_term = d.z; q_items = d.w;
   }
   lists[wave * LIST_N + lane] = 0ull;
   if (WIDE) lists[wave * LIST_N + 64 + lane] = 0ull;
@@ -497,8 +509,8 @@ __global__ __launch_bounds__(TERM_THREADS, (LEGACY || WIDE) ? RGPU_TERM_OTHER_WA
   uint32_t looked = 0, touched = 0;
   const uint64_t ceil = ceil_slots != nullptr ? ceil_slots[qmap[q]] : ~0ull;
 
-  if (queries[q].n_terms >= 1) {  // else: clause absent from this leaf, nothing to collect
-    const DevTerm T = terms[queries[q].first_term];
+  if (first_term >= 0) {  // else: clause absent from this leaf, nothing to collect
+    const DevTerm T = terms[first_term];
     // one look at what earlier workgroups of this query already achieved (per-block exchanges through HBM cost
     // far more in same-address atomics than they save in insertions), one publication when the group is done
     uint64_t floor = 0, tau = 0;
@@ -548,7 +560,6 @@ __global__ __launch_bounds__(TERM_THREADS, (LEGACY || WIDE) ? RGPU_TERM_OTHER_WA
     };
     if (tabled && !has_live && nonneg) {
       // (the query's items: its head + the chunks behind it)
-      const int q_items = 1 + (int)(item_prefix[q + 1] - item_prefix[q]);
       const bool prune = RGPU_TERM_PRUNE && (T.flags & TERM_FLAG_MONOTONE) != 0u;
       // the term's block-max sketch: k real postings of k blocks, scored with this query's table — a threshold to start from
       // (first pass only: a deeper page collects below a ceiling)
@@ -587,6 +598,9 @@ __global__ __launch_bounds__(TERM_THREADS, (LEGACY || WIDE) ? RGPU_TERM_OTHER_WA
     }
   }
 
+#ifdef RGPU_TERM_TRACE
+  if (lane == 0 && item < TERM_TRACE_CAP) g_term_trace[item] = TermTraceRec{trace_t0, (unsigned long long)wall_clock64(), q, chunk, (int32_t)looked, (int32_t)(touched / 256u)};
+#endif
   // the wave of a group that finishes last emits the group's list; the other items emit empty lists
   if (lane == 0) partial_counts[item] = count;
   if (work_slots != nullptr && lane == 0 && looked != 0u) {  // per query: one address for the whole launch would serialise thousands of wavefronts

@@ -2489,6 +2489,17 @@ static unsigned long long and_grid(long long wgs, int chunk) {
   const long long round = 8ll * chunk;
   return (unsigned long long)((wgs + round - 1) / round * round);
 }
+// k_search_term's item descriptors: items 0 .. nq-1 are every query's first chunk, the other chunks follow query-major
+// (item_prefix[q] = chunks of the queries in front of q beyond their first); {query, chunk, term index or -1, the query's items}
+static void fill_term_item_desc(int4* out, const DevQuery* queries, const int64_t* item_prefix, int nq) {
+  for (int q = 0; q < nq; ++q) {
+    const int n_mine = 1 + (int)(item_prefix[q + 1] - item_prefix[q]);
+    const int ft = queries[q].n_terms >= 1 ? queries[q].first_term : -1;
+    out[q] = make_int4(q, 0, ft, n_mine);
+    int4* rest = out + nq + item_prefix[q];
+    for (int ch = 1; ch < n_mine; ++ch) rest[ch - 1] = make_int4(q, ch, ft, n_mine);
+  }
+}
 static int and_item_blocks(const rgpu_ctx* c, int64_t lead_blocks) {
   if (!c->and_blocks_per_item_auto) return c->cfg.and_blocks_per_item;
   return (int)std::min<int64_t>(RGPU_AND_MAX_ITEM_BLOCKS, std::max<int64_t>(8, (lead_blocks + RGPU_AND_TARGET_ITEMS - 1) / RGPU_AND_TARGET_ITEMS));
@@ -2928,6 +2939,7 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
       if (!any) clause_bitmaps.clear();
     }
     const size_t o_bm = clause_bitmaps.empty() ? 0 : st.add(clause_bitmaps.size() * sizeof(TermBitmap));
+    const size_t o_id = op == RGPU_OP_TERM ? st.add((size_t)items * sizeof(int4)) : 0;  // k_search_term's item descriptors
     std::vector<int64_t> seq_prefix;
     if (G.req_opt) {
       seq_prefix.assign((size_t)nq + 1, 0);
@@ -2945,6 +2957,7 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
     std::memset(c->S->h_stage.p + o_tau, 0, (size_t)nq * 8);
     if (G.req_opt) std::memcpy(c->S->h_stage.p + o_sp, seq_prefix.data(), (size_t)(nq + 1) * 8);
     if (!clause_bitmaps.empty()) std::memcpy(c->S->h_stage.p + o_bm, clause_bitmaps.data(), clause_bitmaps.size() * sizeof(TermBitmap));
+    if (op == RGPU_OP_TERM) fill_term_item_desc(reinterpret_cast<int4*>(c->S->h_stage.p + o_id), G.queries.data(), G.item_prefix.data(), nq);
     if (c->upload_aside) HIP_TRY(stage_upload(c, st.used, stream));
     else HIP_TRY(hipMemcpyAsync(c->S->d_stage.p, c->S->h_stage.p, st.used, hipMemcpyHostToDevice, stream));
     HIP_TRY(c->S->d_partial_keys.reserve((size_t)items * (size_t)k, 0, stream));
@@ -3021,8 +3034,8 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
       auto go = [&](auto kern) -> hipError_t {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        RGPU_LAUNCH(kern, dim3(grid), dim3(TERM_THREADS), lds, stream, sv, dq, dt, dp, nq, items, blocks_per_item, (int)k,
-                           c->S->d_partial_keys.p, c->S->d_partial_counts.p, d_tau, c->S->d_touched.p, c->pass.ceil_in, dm);
+        RGPU_LAUNCH(kern, dim3(grid), dim3(TERM_THREADS), lds, stream, sv, dq, dt, reinterpret_cast<const int4*>(c->S->d_stage.p + o_id), nq, items,
+                           blocks_per_item, (int)k, c->S->d_partial_keys.p, c->S->d_partial_counts.p, d_tau, c->S->d_touched.p, c->pass.ceil_in, dm);
         return hipSuccess;
       };
       hipError_t e;
@@ -4529,6 +4542,9 @@ static int32_t term_batch_fast(rgpu_segment* seg, rucene::BatchPlanner* P, int32
   const size_t o_m = st.add((size_t)nq * 4);
   const size_t o_tau = st.add((size_t)nq * 8);       // per-query shared thresholds ...
   const size_t o_w = st.add((size_t)nq * 16);        // ... and the launch's counters: zeroed by the copy that brings the plan
+  // ... and the item descriptors, LAST: their number is known only once the terms have been read (at most 262144 + nq, the item
+  // loop's cap), the stage has room for the worst case and the copy takes what is used
+  const size_t o_id = st.add(((size_t)262144 + (size_t)nq) * sizeof(int4));
   HIP_TRY(c->S->h_stage.reserve(st.used));
   HIP_TRY(c->S->d_stage.reserve(st.used, 0, stream));
   DevQuery* hq = reinterpret_cast<DevQuery*>(c->S->h_stage.p + o_q);
@@ -4598,10 +4614,13 @@ static int32_t term_batch_fast(rgpu_segment* seg, rucene::BatchPlanner* P, int32
     blocks_per_item *= 2;
   }
   items += nq;
+  if (items > 262144 + (int64_t)nq) return RGPU_OK;  // (blocks_per_item hit its ceiling on an absurd batch: the full path takes it)
   std::memset(c->S->h_stage.p + o_tau, 0, (size_t)nq * 8);
   std::memset(c->S->h_stage.p + o_w, 0, (size_t)nq * 16);
-  if (c->upload_aside) HIP_TRY(stage_upload(c, st.used, stream));
-  else HIP_TRY(hipMemcpyAsync(c->S->d_stage.p, c->S->h_stage.p, st.used, hipMemcpyHostToDevice, stream));
+  fill_term_item_desc(reinterpret_cast<int4*>(c->S->h_stage.p + o_id), hq, hp, nq);
+  const size_t staged = o_id + (size_t)items * sizeof(int4);
+  if (c->upload_aside) HIP_TRY(stage_upload(c, staged, stream));
+  else HIP_TRY(hipMemcpyAsync(c->S->d_stage.p, c->S->h_stage.p, staged, hipMemcpyHostToDevice, stream));
   HIP_TRY(c->S->d_partial_keys.reserve((size_t)items * (size_t)k, 0, stream));
   HIP_TRY(c->S->d_partial_counts.reserve((size_t)items, 0, stream));
   unsigned long long* d_tau = reinterpret_cast<unsigned long long*>(c->S->d_stage.p + o_tau);
@@ -4627,8 +4646,8 @@ static int32_t term_batch_fast(rgpu_segment* seg, rucene::BatchPlanner* P, int32
     auto go = [&](auto kern) -> hipError_t {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
-      RGPU_LAUNCH(kern, dim3(grid), dim3(TERM_THREADS), lds, stream, sv, dq, dt, dp, nq, items, blocks_per_item, (int)k,
-                         c->S->d_partial_keys.p, c->S->d_partial_counts.p, d_tau, d_work, (const unsigned long long*)nullptr, dm);
+      RGPU_LAUNCH(kern, dim3(grid), dim3(TERM_THREADS), lds, stream, sv, dq, dt, reinterpret_cast<const int4*>(c->S->d_stage.p + o_id), nq, items,
+                         blocks_per_item, (int)k, c->S->d_partial_keys.p, c->S->d_partial_counts.p, d_tau, d_work, (const unsigned long long*)nullptr, dm);
       return hipSuccess;
     };
     hipError_t e;
@@ -4756,6 +4775,13 @@ extern "C" int32_t rgpu_debug_counters(unsigned long long* out8, int32_t reset) 
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_and_time), z, 128) != hipSuccess) return -1;
   }
   return 0;
+}
+#endif
+#ifdef RGPU_TERM_TRACE
+extern "C" int32_t rgpu_debug_trace(void* out, int32_t n) {  // the most recent k_search_term launch's item timeline
+  if (n > TERM_TRACE_CAP) n = TERM_TRACE_CAP;
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_term_trace), (size_t)n * sizeof(TermTraceRec)) == hipSuccess ? n : -1;
 }
 #endif
 #ifdef RGPU_AND_TRACE
