@@ -49,6 +49,9 @@ __device__ unsigned long long g_term_dbg[4];
 #define RGPU_TERM_WAIT_SLEEP 16  // s_sleep argument: 64 cycles each
 #endif
 constexpr int TERM_EXCHANGE_MAX_ITEMS = RGPU_TERM_EXCHANGE_MAX_ITEMS;
+#ifndef RGPU_TERM_SKIP_EMPTY_RING
+#define RGPU_TERM_SKIP_EMPTY_RING 1
+#endif
 #ifndef RGPU_TERM_WAVES
 #define RGPU_TERM_WAVES 8
 #endif
@@ -300,6 +303,14 @@ __device__ __forceinline__ void term_blocks_fast(const SegView& seg, const DevTe
       todo &= ~(1ull << i);
       return i;
     };
+#if RGPU_TERM_SKIP_EMPTY_RING
+    // (round 6: a chunk none of whose blocks can enter — seven in ten on the headline batch — used to fill the ring all the same:
+    // DEPTH redundant row + norm loads of its first block, "cheaper than a load behind a branch" inside a chunk, but 64 wasted
+    // kilobyte loads per item across its chunks. The chunk-level test is one scalar branch around the ring — fill AND drain: with the
+    // drain outside it the compiler wanted 71-73 VGPRs. Measured, same box: k_search_term 0.0379-0.0386 -> 0.0366-0.0374 ms at 10 M docs,
+    // 0.1286-0.1303 -> 0.1005-0.1015 ms at 100 M.)
+    if (todo != 0ull) {
+#endif
 #pragma unroll
     for (int j = 0; j < DEPTH; ++j) {
       slot[j] = take();
@@ -323,6 +334,9 @@ __device__ __forceinline__ void term_blocks_fast(const SegView& seg, const DevTe
         if (idx >= 0) step(idx, rows, nn);
       }
     }
+#if RGPU_TERM_SKIP_EMPTY_RING
+    }
+#endif
     // what this chunk achieved, for the query's other wavefronts (an atomic only when the group's k-th best has risen)
     {
       const int ci = ((c0 - b0) >> 6) + 1;
@@ -434,7 +448,7 @@ __device__ __forceinline__ uint64_t sketch_floor(const uint16_t* __restrict__ sk
 // Measured, same box: k_search_term 0.0405-0.0418 -> 0.0378-0.0382 ms at 10 M docs, 0.139 -> 0.131-0.133 ms at 100 M.
 #ifdef RGPU_TERM_TRACE  // developer instrumentation (variant builds only): every item's {start, end} wall clock (100 MHz), query, chunk,
 constexpr int TERM_TRACE_CAP = 1 << 17;           // blocks looked at / unpacked — the launch's timeline, read back by rgpu_debug_trace
-struct TermTraceRec { unsigned long long t0, t1; int32_t q, chunk, blocks, unpacked; };
+struct TermTraceRec { unsigned long long t0, t1; int32_t q, chunk, blocks, unpacked; unsigned int d_term, d_table, d_sketch, d_pad; };  // d_*: 10 ns ticks from t0
 __device__ TermTraceRec g_term_trace[TERM_TRACE_CAP];
 #endif
 #ifndef RGPU_TERM_OTHER_WAVES
@@ -509,8 +523,15 @@ __global__ __launch_bounds__(TERM_THREADS, (LEGACY || WIDE) ? RGPU_TERM_OTHER_WA
   uint32_t looked = 0, touched = 0;
   const uint64_t ceil = ceil_slots != nullptr ? ceil_slots[qmap[q]] : ~0ull;
 
+#ifdef RGPU_TERM_TRACE
+  unsigned int tr_term = 0, tr_table = 0, tr_sketch = 0;
+#define TERM_TR(v, dep) do { asm volatile("" :: "v"(dep)); v = (unsigned int)((unsigned long long)wall_clock64() - trace_t0); } while (0)
+#else
+#define TERM_TR(v, dep) do {} while (0)
+#endif
   if (first_term >= 0) {  // else: clause absent from this leaf, nothing to collect
     const DevTerm T = terms[first_term];
+    TERM_TR(tr_term, T.df);
     // one look at what earlier workgroups of this query already achieved (per-block exchanges through HBM cost
     // far more in same-address atomics than they save in insertions), one publication when the group is done
     uint64_t floor = 0, tau = 0;
@@ -521,6 +542,7 @@ __global__ __launch_bounds__(TERM_THREADS, (LEGACY || WIDE) ? RGPU_TERM_OTHER_WA
     const bool has_norms = seg.norms != nullptr;
     bool tabled = has_norms && seg.n_norm_ranks > 0;
     if (tabled) build_score_table(cache, wk, lane);
+    TERM_TR(tr_table, cache[lane]);
     shared.fold(seen, tau, floor);
     // Norms of FullBlock postings arrive in posting order with the payload rows (SegView::pnorm), so scoring a
     // block needs no gather at all; only the VInt tail / singleton (< 128 postings per term) and the optional
@@ -565,6 +587,7 @@ __global__ __launch_bounds__(TERM_THREADS, (LEGACY || WIDE) ? RGPU_TERM_OTHER_WA
       // (first pass only: a deeper page collects below a ceiling)
       if (T.sketch != 0u && seg.sketch != nullptr && ceil == ~0ull && k <= TERM_SKETCH_K)
         shared.fold(sketch_floor<WIDE>(seg.sketch + (size_t)(T.sketch - 1u) * TERM_SKETCH_K, cache, k, lane), tau, floor);
+      TERM_TR(tr_sketch, (uint32_t)floor);
       if (RGPU_TERM_WAIT && prune && chunk != 0) {  // (wave-uniform) the head's first publication, or the time-out
         uint64_t s2 = floor;
         for (int i = 0; i < RGPU_TERM_WAIT_POLLS && s2 == 0ull; ++i) {
@@ -599,7 +622,7 @@ __global__ __launch_bounds__(TERM_THREADS, (LEGACY || WIDE) ? RGPU_TERM_OTHER_WA
   }
 
 #ifdef RGPU_TERM_TRACE
-  if (lane == 0 && item < TERM_TRACE_CAP) g_term_trace[item] = TermTraceRec{trace_t0, (unsigned long long)wall_clock64(), q, chunk, (int32_t)looked, (int32_t)(touched / 256u)};
+  if (lane == 0 && item < TERM_TRACE_CAP) g_term_trace[item] = TermTraceRec{trace_t0, (unsigned long long)wall_clock64(), q, chunk, (int32_t)looked, (int32_t)(touched / 256u), tr_term, tr_table, tr_sketch, 0u};
 #endif
   // the wave of a group that finishes last emits the group's list; the other items emit empty lists
   if (lane == 0) partial_counts[item] = count;

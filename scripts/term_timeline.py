@@ -26,7 +26,8 @@ for _ in range(6):
     s.search_uniform_device(_lib.OP_TERM, tids, leaf, 10, h.data_ptr(), t.data_ptr())
     ctx.synchronize()
 L = C.CDLL(_lib.lib_path())
-REC = np.dtype([("t0", "<u8"), ("t1", "<u8"), ("q", "<i4"), ("chunk", "<i4"), ("blocks", "<i4"), ("unpacked", "<i4")])
+REC = np.dtype([("t0", "<u8"), ("t1", "<u8"), ("q", "<i4"), ("chunk", "<i4"), ("blocks", "<i4"), ("unpacked", "<i4"),
+                ("d_term", "<u4"), ("d_table", "<u4"), ("d_sketch", "<u4"), ("d_pad", "<u4")])
 buf = np.zeros(1 << 17, dtype=REC)
 n = L.rgpu_debug_trace(C.c_void_p(buf.ctypes.data), C.c_int32(buf.size))
 st = ctx.kernel_stats()["k_search_term"]
@@ -50,6 +51,10 @@ for i in order:
     print("   end %.1f  dur %.1f  start %.1f  q %d (df %d) chunk %d  blocks looked at %d" % (end[i], dur[i], start[i], r["q"], int(df[tids[r["q"], 0]]), r["chunk"], r["blocks"]))
 heads = rec["chunk"] == 0
 print("head items (chunk 0): mean %.1f us, max %.1f; others: mean %.1f, max %.1f" % (dur[heads].mean(), dur[heads].max(), dur[~heads].mean() if (~heads).any() else 0, dur[~heads].max() if (~heads).any() else 0))
+live = rec["d_term"] > 0
+print("phases (us from the item's start; items with a term): term descriptor in registers p50 %.1f / p90 %.1f; score table built %.1f / %.1f; sketch threshold folded %.1f / %.1f; item done %.1f / %.1f" % (
+    *np.percentile(rec["d_term"][live] / 100.0, [50, 90]), *np.percentile(rec["d_table"][live] / 100.0, [50, 90]),
+    *np.percentile(rec["d_sketch"][live & (rec["d_sketch"] > 0)] / 100.0, [50, 90]), *np.percentile(dur[live], [50, 90])))
 A = np.stack([rec["blocks"].astype(np.float64), np.ones(rec.size)], axis=1)
 coef, *_ = np.linalg.lstsq(A, dur, rcond=None)
 print("least squares: item us = %.4f x blocks looked at + %.2f" % tuple(coef))
