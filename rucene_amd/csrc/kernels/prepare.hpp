@@ -803,4 +803,28 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_norms(SegView seg, con
   });
 }
 
+// ---- C: the frontier of every whole chunk of 64 blocks (SegView::dir_sum), from the words stage B has just written ------------
+// items as in k_prepare_norms (PREP_BLOCKS_PER_ITEM = 32 blocks each): the even items of a term take the chunk that starts with them
+static_assert(PREP_BLOCKS_PER_ITEM == 32, "k_chunk_frontiers pairs the items of k_prepare_norms into chunks of 64 blocks");
+__global__ __launch_bounds__(PREP_THREADS) void k_chunk_frontiers(const PrepTerm* __restrict__ terms, const int64_t* __restrict__ item_prefix,
+                                                                  int n_terms, int64_t n_items, const uint64_t* __restrict__ dir_bmax,
+                                                                  uint64_t* __restrict__ dir_sum) {
+  const int lane = lane_id();
+  const int64_t item = (int64_t)blockIdx.x * PREP_WAVES + wave_id();
+  if (item >= n_items) return;
+  const int ti = upper_slot_wave(item_prefix, n_terms, item, lane);
+  const PrepTerm t = terms[ti];
+  const int it = (int)(item - item_prefix[ti]);
+  if (it & 1) return;
+  const int cj = it >> 1;
+  if (64 * cj + 64 > t.nblocks) return;  // the partial chunk at the end has no word
+  const uint64_t w = dir_bmax[t.dir_base + 64u * (uint32_t)cj + (uint32_t)lane];
+  const uint32_t f = (uint32_t)w & 15u;
+  uint64_t sum = wave_reduce_max_u32(f);  // (15 — no bound — wins, as it must)
+#pragma unroll
+  for (int i = 0; i < 10; ++i) sum |= (uint64_t)wave_reduce_max_u32((uint32_t)(w >> (4 + 6 * i)) & 63u) << (4 + 6 * i);
+  if (((uint32_t)sum & 15u) > 10u) sum = 15ull;
+  if (lane == 0) dir_sum[((t.dir_base + 63u) >> 6) + (uint32_t)cj] = sum;
+}
+
 }  // namespace rgpu

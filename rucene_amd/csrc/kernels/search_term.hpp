@@ -163,7 +163,10 @@ __device__ __forceinline__ void term_blocks_fast(const SegView& seg, const DevTe
   // them a fresh look at what the query's OTHER wavefronts have published meanwhile (round 5: one look per item at its start
   // left the items of a query warming up side by side, each on its own: 130 k of the headline batch's 2.2 M blocks unpacked
   // where a threshold known in advance needs a few per query)
-  #ifndef RGPU_TERM_SEEN64
+  #ifndef RGPU_TERM_CHUNK_SUMS
+#define RGPU_TERM_CHUNK_SUMS 1
+#endif
+#ifndef RGPU_TERM_SEEN64
 #define RGPU_TERM_SEEN64 0  // 1: carry the whole published key across the chunk (its doc too: strict ties where the doc allows)
 #endif
 #if RGPU_TERM_SEEN64
@@ -171,18 +174,17 @@ __device__ __forceinline__ void term_blocks_fast(const SegView& seg, const DevTe
 #else
   struct Chunk { DirChunk dir; uint64_t bmax; int32_t lo; uint32_t seen_hi; };
 #endif
-  auto load_chunk = [&](int c0) -> Chunk {
+  auto load_chunk = [&](int c0, int ci) -> Chunk {  // ci: how many chunks this item has visited before this one
     Chunk c;
     const int nb = min(64, b1 - c0);
     c.dir.load(seg.dir_row, seg.dir_hdr, T.dir_base, c0, nb, lane);
     c.bmax = (prune && lane < nb) ? seg.dir_bmax[T.dir_base + c0 + lane] : 0ull;
     const int e = c0 + lane - 1;  // the block in front of this lane's
     c.lo = (lane < nb && e >= 0) ? seg.dir_last[T.dir_base + e] : -1;
-    // A look at what the query's other wavefronts published, with chunks 1, 2, 4, 8 ... of the item — but only for a query of few
+    // A look at what the query's other wavefronts published, with visited chunks 1, 2, 4, 8 ... of the item — but only for a query of few
     // items (`exchange`): every wavefront of a query reads and raises ONE word, and same-address traffic serialises. Measured
     // (k_search_term, the headline batch): 10 M docs, ~5 items per query: 0.077 ms without any exchange, 0.071 with this one,
     // 0.085 with a look per chunk; 100 M docs, ~42 items per query (305 for the longest list): 0.217 / 0.68 / 1.56 ms.
-    const int ci = (c0 - b0) >> 6;
     const bool look = exchange && (RGPU_TERM_EXCHANGE == 1 || (RGPU_TERM_EXCHANGE == 2 && (ci & (ci - 1)) == 0));
     // (the score half of the published key is enough — and one register instead of two across the chunk. The doc half is then
     // taken as the LARGEST doc id: (score, INT_MAX) is at or below the published key whatever its doc, so it only ever drops
@@ -196,11 +198,48 @@ __device__ __forceinline__ void term_blocks_fast(const SegView& seg, const DevTe
 #endif
     return c;
   };
-  Chunk next = load_chunk(b0);
-  for (int c0 = b0; c0 < b1; c0 += 64) {
+  // lane j: the best score any posting behind frontier word w can have (raw bits; scores are >= 0 here)
+  auto bound_of = [&](uint64_t w) -> uint32_t {
+    const uint32_t fmax = (uint32_t)w & 15u;
+    uint32_t bb = 0u;
+#pragma unroll
+    for (int f = 1; f <= SCORE_TABLE_FREQS; ++f) {
+      const uint32_t r = (uint32_t)(w >> (4 + 6 * (f - 1))) & 63u;
+      const uint32_t sc = __float_as_uint(table_score(cache, r, (uint32_t)f));
+      bb = ((uint32_t)f <= fmax && sc > bb) ? sc : bb;
+    }
+    return fmax > (uint32_t)SCORE_TABLE_FREQS ? 0xffffffffu : bb;
+  };
+  // Round 6: the item's chunks of 64 blocks, one LANE each, against the frontier of the chunk's 8192 postings (SegView::dir_sum:
+  // the field-wise maximum of its blocks' words, so its bound IS the largest of their bounds). The per-block test above costs a
+  // wavefront ~80 VALU instructions per chunk — at 100 M docs, 344 k chunks x ~700 cycles over 1024 SIMDs, that WAS the
+  // kernel's 0.097 ms — and seven chunks in ten (more on longer lists) hold no block that can enter. Those are now never
+  // requested at all: not their frontier words, not their directory rows. The chunks that remain are visited in index order, each
+  // requested while the one in front of it is worked on, and the set is re-filtered with the threshold of the moment on the way.
+  const int n_chunks = (b1 - b0 + 63) >> 6;
+  uint64_t cand = n_chunks >= 64 ? ~0ull : ((1ull << n_chunks) - 1ull);
+  const bool summed = RGPU_TERM_CHUNK_SUMS && prune && seg.dir_sum != nullptr && n_chunks >= 2 && n_chunks <= 64 && (b0 & 63) == 0;
+  uint32_t cbest = 0xffffffffu;
+  if (summed) {
+    const int cj = (b0 >> 6) + lane;  // the chunk's index within the term; only whole chunks have a word
+    const bool whole = lane < n_chunks && 64 * cj + 64 <= T.nblocks;
+    cbest = bound_of(whole ? seg.dir_sum[((T.dir_base + 63u) >> 6) + (uint32_t)cj] : 15ull);
+  }
+  auto still = [&](uint64_t t) {  // the non-strict test: thr_of(t, lo) is `bits` or `bits + 1` (cbest is all ones without a word)
+    const uint32_t thi = (uint32_t)(t >> 32);
+    if (thi & 0x80000000u) cand &= __ballot(cbest >= (thi & 0x7fffffffu));
+  };
+  count += 128 * (b1 - b0);
+  still(tau);
+  Chunk next{};
+  if (cand) next = load_chunk(b0 + 64 * (int)__builtin_ctzll(cand), 0);
+  for (int visited = 0; cand != 0ull; ++visited) {
+    const int c0 = b0 + 64 * (int)__builtin_ctzll(cand);
+    cand &= cand - 1ull;
     const int nb = min(64, b1 - c0);
     const Chunk cur = next;
-    if (c0 + 64 < b1) next = load_chunk(c0 + 64);
+    still(tau);  // (what the chunk before this one achieved)
+    if (cand) next = load_chunk(b0 + 64 * (int)__builtin_ctzll(cand), visited + 1);
     const DirChunk& dir = cur.dir;
     {
       uint64_t t0 = 0;
@@ -210,20 +249,8 @@ __device__ __forceinline__ void term_blocks_fast(const SegView& seg, const DevTe
       shared.fold(cur.seen_hi != 0u ? (((uint64_t)cur.seen_hi << 32) | 0x80000000ull) : 0ull, t0, floor);
 #endif
     }
-    count += 128 * nb;
-    // lane j: the best score any posting of block c0 + j can have (raw bits; scores are >= 0 here)
-    uint32_t best = 0xffffffffu;
-    if (prune) {
-      const uint32_t fmax = (uint32_t)cur.bmax & 15u;
-      uint32_t bb = 0u;
-#pragma unroll
-      for (int f = 1; f <= SCORE_TABLE_FREQS; ++f) {
-        const uint32_t r = (uint32_t)(cur.bmax >> (4 + 6 * (f - 1))) & 63u;
-        const uint32_t sc = __float_as_uint(table_score(cache, r, (uint32_t)f));
-        bb = ((uint32_t)f <= fmax && sc > bb) ? sc : bb;
-      }
-      best = fmax > (uint32_t)SCORE_TABLE_FREQS ? 0xffffffffu : bb;
-    }
+    // lane j: the best score any posting of block c0 + j can have
+    const uint32_t best = prune ? bound_of(cur.bmax) : 0xffffffffu;
     const uint64_t in_chunk = nb == 64 ? ~0ull : ((1ull << nb) - 1ull);
     // lane j: can block c0 + j still put a posting into the top-k? (its bound against the threshold of the moment, strict when
     // none of its docs can win a tie)
@@ -339,7 +366,7 @@ __device__ __forceinline__ void term_blocks_fast(const SegView& seg, const DevTe
 #endif
     // what this chunk achieved, for the query's other wavefronts (an atomic only when the group's k-th best has risen)
     {
-      const int ci = ((c0 - b0) >> 6) + 1;
+      const int ci = visited + 1;
       // (... and the query's head item after its first 64 blocks, whatever the query's size: its other items wait for exactly
       // that — RGPU_TERM_WAIT in k_search_term)
       const bool first_of_head = RGPU_TERM_WAIT && head && c0 == b0;
@@ -455,7 +482,7 @@ __device__ TermTraceRec g_term_trace[TERM_TRACE_CAP];
 #define RGPU_TERM_OTHER_WAVES 6
 #endif
 #ifndef RGPU_TERM_FAST_WAVES
-#define RGPU_TERM_FAST_WAVES 7
+#define RGPU_TERM_FAST_WAVES 6
 #endif
 template <bool LEGACY, bool WIDE>
 __global__ __launch_bounds__(TERM_THREADS, (LEGACY || WIDE) ? RGPU_TERM_OTHER_WAVES : RGPU_TERM_FAST_WAVES) void k_search_term(SegView seg, const DevQuery* __restrict__ queries,

@@ -20,6 +20,12 @@ struct SegView {
   // block's best possible score under ANY clause weight is max over f <= largest freq of table[rank_f][f]: the TERM
   // kernel skips a block outright when that bound cannot enter the top-k (search_term.hpp). Built by k_prepare_blocks.
   const uint64_t* dir_bmax;
+  // One level up (round 6): the same word for every WHOLE chunk of 64 consecutive blocks of a term (blocks 64 j .. 64 j + 63 counted
+  // from the term's first) — the field-wise maximum of the chunk's frontier words, 15 if any of them is. Chunk j of a term whose
+  // directory starts at slot `dir_base` sits at dir_sum[(dir_base + 63) / 64 + j]: a term owns nblocks + 1 consecutive slots, so
+  // these ranges never overlap and no term needs a second base. A term's last, partial chunk has no word. Built by
+  // k_chunk_frontiers right behind k_prepare_norms; read by k_search_term (one lane per chunk).
+  const uint64_t* dir_sum;
   // Block store: the FullBlock payloads of every prepared term, copied once (k_prepare_terms) to 16-byte aligned
   // rows: block i = [max(b_doc,1) doc rows][max(b_freq,1) freq rows]; a row is 16 bytes of the BP128 / packed
   // stream exactly as in the .doc file, an all-equal stream (b == 0) is one row holding its value as a u32.

@@ -280,6 +280,7 @@ struct rgpu_segment {
   DevVec<uint32_t> dir_row;
   DevVec<uint16_t> dir_hdr;
   DevVec<uint64_t> dir_bmax;  // per block: (freq, norm rank) frontier word (SegView::dir_bmax)
+  DevVec<uint64_t> dir_sum;   // per whole chunk of 64 blocks of a term: the chunk's frontier word (SegView::dir_sum)
   bool has_positions = false;  // IndexOptions::DocsAndFreqsAndPositions: skip entries carry position pointers
   bool has_offsets = false;    // ...AndOffsets / FieldInfo::has_store_payloads: the skip entries also carry .pay words, the
   bool has_payloads = false;   // trailing VInt position block also payload bytes / offset words (kernels: read past)
@@ -456,6 +457,7 @@ static SegView seg_view(const rgpu_segment* s) {
   v.bstore = s->bstore.p;
   v.dir_hdr = s->dir_hdr.p;
   v.dir_bmax = s->dir_bmax.p;
+  v.dir_sum = s->dir_sum.p;
   v.pos = s->d_pos;
   v.dir_pos = s->has_positions ? s->dir_pos.p : nullptr;
   v.sketch = s->sketch_used ? s->sketch.p : nullptr;
@@ -645,6 +647,7 @@ static int32_t prepare_terms_attempt(rgpu_segment* seg, const rgpu_term_state* c
     HIP_TRY(seg->bstore.reserve(batch_bs + (size_t)cap_rows * 16 + 1024, seg->bstore_used, c->stream));  // + over-read padding of the row loads
     HIP_TRY(seg->dir_hdr.reserve(need_slots, seg->dir_used, c->stream));
     HIP_TRY(seg->dir_bmax.reserve(need_slots, seg->dir_used, c->stream));
+    HIP_TRY(seg->dir_sum.reserve(need_slots / 64 + 2, seg->dir_used / 64 + 2, c->stream));
     if (seg->has_positions) HIP_TRY(seg->dir_pos.reserve(need_slots, seg->dir_used, c->stream));
     t_reserve = hc.lap();
     n_slots = need_slots - seg->dir_used;
@@ -992,6 +995,12 @@ static int32_t prepare_norms_locked(rgpu_segment* seg, const rgpu_term_state* co
     };
     if (seg->version < 1) go(k_prepare_norms<true>); else go(k_prepare_norms<false>);
   }
+  {  // ... and one level up: the frontier of every whole chunk of 64 blocks (what k_search_term tests first)
+    TimedLaunch tl(c, c->stream, "k_chunk_frontiers", postings / 128);
+    const unsigned grid = wg_count((n_items + PREP_WAVES - 1) / PREP_WAVES);
+    RGPU_LAUNCH(k_chunk_frontiers, dim3(grid), dim3(PREP_THREADS), 0, c->stream, reinterpret_cast<const PrepTerm*>(c->S->d_stage.p + o_work),
+                reinterpret_cast<const int64_t*>(c->S->d_stage.p + o_items), (int)work.size(), n_items, seg->dir_bmax.p, seg->dir_sum.p);
+  }
   HIP_TRY(hipStreamSynchronize(c->stream));
   HIP_TRY(launch_status());
   seg->pnorm_used = need_pn;
@@ -1310,6 +1319,7 @@ extern "C" int32_t rgpu_segment_upload_field(rgpu_ctx* c, const uint8_t* doc_fil
     const bool roomy = s->bstore.reserve(rows_bytes, 0, c->stream) == hipSuccess && s->dir_last.reserve(slots, 0, c->stream) == hipSuccess &&
                        s->dir_off.reserve(slots, 0, c->stream) == hipSuccess && s->dir_row.reserve(slots, 0, c->stream) == hipSuccess &&
                        s->dir_hdr.reserve(slots, 0, c->stream) == hipSuccess && s->dir_bmax.reserve(slots, 0, c->stream) == hipSuccess &&
+                       s->dir_sum.reserve(slots / 64 + 2, 0, c->stream) == hipSuccess &&
                        (!s->has_positions || s->dir_pos.reserve(slots, 0, c->stream) == hipSuccess);
     if (!roomy) (void)hipGetLastError();  // (out of memory is not sticky)
   }
@@ -1327,7 +1337,7 @@ extern "C" void rgpu_segment_free(rgpu_segment* s) {
   if (s->d_rank_to_norm) (void)hipFree(s->d_rank_to_norm);
   if (s->d_live) (void)hipFree(s->d_live);
   if (s->d_pos) (void)hipFree(s->d_pos);
-  s->dir_last.release(); s->dir_off.release(); s->dir_row.release(); s->dir_hdr.release(); s->dir_bmax.release(); s->dir_pos.release(); s->pnorm.release(); s->bstore.release(); s->prep_scratch.release(); s->sketch.release(); s->sketch_jobs.release();
+  s->dir_last.release(); s->dir_off.release(); s->dir_row.release(); s->dir_hdr.release(); s->dir_bmax.release(); s->dir_sum.release(); s->dir_pos.release(); s->pnorm.release(); s->bstore.release(); s->prep_scratch.release(); s->sketch.release(); s->sketch_jobs.release();
   for (void* b : s->bitmap_allocs) (void)hipFree(b);
   s->ctx->bitmap_bytes -= std::min(s->ctx->bitmap_bytes, s->bitmap_bytes);
   if (s->empty_bitmap) (void)hipFree(s->empty_bitmap);
@@ -2489,6 +2499,19 @@ static unsigned long long and_grid(long long wgs, int chunk) {
   const long long round = 8ll * chunk;
   return (unsigned long long)((wgs + round - 1) / round * round);
 }
+// Blocks per work item of k_search_term when the caller leaves rgpu_config.blocks_per_item at 0. With block-max pruning an item's cost
+// is its set-up (term descriptor, score table, sketch threshold) plus the chunks and blocks that can still enter, whatever its length
+// (round 6: the chunk frontiers — SegView::dir_sum — in front of the per-block test): about 12 k items per launch, two rounds of
+// wavefronts over the chip, at either shard size. Measured, k_search_term + k_merge_items on the headline batch: 10 M docs 128 blocks
+// per item 0.043 + 0.009 ms, 256 0.034 + 0.008, 512 0.037 + 0.007, 1024 0.038 + 0.007; 100 M docs 512 0.076 + 0.011, 1024 0.061 +
+// 0.009, 2048 0.054 + 0.008, 4096 0.054 + 0.007. (Rounds 4-5, when every block still cost its directory word: 512 up to 6 k items,
+// then up to 2048 beyond 30 k — 10 M docs 128 0.074 ms, 256 0.076, 512 0.071, 1024 0.082; 100 M docs 256 0.315, 512 0.215, 1024 and
+// 2048 0.178.) At most 4096: an item's chunks of 64 blocks are tested one lane each.
+static int term_item_blocks(int64_t total_blocks) {
+  int blocks_per_item = 8;
+  while (blocks_per_item < 4096 && total_blocks / blocks_per_item > 12000) blocks_per_item *= 2;
+  return blocks_per_item;
+}
 // k_search_term's item descriptors: items 0 .. nq-1 are every query's first chunk, the other chunks follow query-major
 // (item_prefix[q] = chunks of the queries in front of q beyond their first); {query, chunk, term index or -1, the query's items}
 static void fill_term_item_desc(int4* out, const DevQuery* queries, const int64_t* item_prefix, int nq) {
@@ -2869,15 +2892,7 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
       if (op == RGPU_OP_TERM && c->blocks_per_item_auto) {  // fewer, longer items when there are plenty of blocks
         int64_t total_blocks = 0;
         for (auto& t : G.terms) total_blocks += t.nblocks;
-        // with block-max pruning most blocks cost a directory word, so an item's fixed cost (term descriptor, score
-        // table, one threshold look-up) is spread over up to 512 of them while the launch still fills the chip
-        blocks_per_item = 8;
-        while (blocks_per_item < 512 && total_blocks / blocks_per_item > 6000) blocks_per_item *= 2;
-        // (a 100 M-doc shard: 22 M blocks make 43 k items of 512 — five rounds of wavefronts over the chip, each item paying its
-        // set-up and its first, threshold-less chunk. Measured there, k_search_term: 256 blocks per item 0.315 ms, 512 0.215,
-        // 1024 0.178, 2048 0.178; at 10 M docs (2.2 M blocks, 4.3 k items of 512) 512 stays best: 128 0.074, 256 0.076, 512
-        // 0.071, 1024 0.082)
-        while (blocks_per_item < 2048 && total_blocks / blocks_per_item > 30000) blocks_per_item *= 2;
+        blocks_per_item = term_item_blocks(total_blocks);
       }
       while (true) {
         items = 0;
@@ -4595,9 +4610,7 @@ static int32_t term_batch_fast(rgpu_segment* seg, rucene::BatchPlanner* P, int32
   // items: chunks of a term's blocks; every query's first chunk is scheduled first (search_pass's rule, to the letter)
   int blocks_per_item = c->cfg.blocks_per_item;
   if (c->blocks_per_item_auto) {
-    blocks_per_item = 8;
-    while (blocks_per_item < 512 && total_blocks / blocks_per_item > 6000) blocks_per_item *= 2;
-    while (blocks_per_item < 2048 && total_blocks / blocks_per_item > 30000) blocks_per_item *= 2;
+    blocks_per_item = term_item_blocks(total_blocks);
   }
   int64_t items = 0;
   while (true) {
