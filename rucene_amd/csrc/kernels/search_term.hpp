@@ -530,7 +530,8 @@ __global__ __launch_bounds__(TERM_THREADS, (LEGACY || WIDE) ? RGPU_TERM_OTHER_WA
   int q = -1, chunk = 0, first_term = -1, q_items = 1;
   if (item < n_items) {
     const int4 d = item_desc[item];
-    q = d.x; chunk = d.y; first_term = d.z; q_items = d.w;
+    q = d.x; chunk = d.y; first_term = d.z; q_items = d.w & 0xffffff;
+    if (d.w >> 24) blocks_per_item = 1 << (d.w >> 24);  // this query's own item size (the host's term_query_item_blocks)
   }
   lists[wave * LIST_N + lane] = 0ull;
   if (WIDE) lists[wave * LIST_N + 64 + lane] = 0ull;

@@ -221,6 +221,8 @@ struct rgpu_ctx {
   // regions — but the cross-stream event wait costs 15-30 us of latency whenever the pipeline is shallow: two alternating streams
   // 0.063 against 0.047 in 20-step regions, the 3-term AND batch 0.290 against 0.258. Off by default.
   bool upload_aside = false;
+  int term_target_items = 3000;  // single-term launches: items of the launch's size, at most about this many (RGPU_TERM_TARGET_ITEMS in the environment)
+  int term_split = 8;         // single-term queries: at least this many items per query, of 64 blocks or more each (RGPU_TERM_SPLIT in the environment; 1: off)
   bool memb_only_on = true;   // membership-only bits for sparse first clauses of conjunctions (RGPU_AND_MEMB_ONLY=0 in the environment: off; A/B, tests)
   bool term_sketches = true;  // block-max sketches for single-term queries (search_term.hpp); RGPU_TERM_SKETCH=0 in the environment turns them off (A/B, tests)
   DevVec<uint32_t> pos_counts;             // rgpu_decode_positions: positions per directory slot -> their exclusive prefix sums
@@ -1085,6 +1087,8 @@ extern "C" int32_t rgpu_init(int32_t device_ordinal, const rgpu_config* cfg, rgp
   if (const char* e = std::getenv("RGPU_TERM_SKETCH")) c->term_sketches = std::atoi(e) != 0;
   if (const char* e = std::getenv("RGPU_UPLOAD_ASIDE")) c->upload_aside = std::atoi(e) != 0;
   if (const char* e = std::getenv("RGPU_AND_MEMB_ONLY")) c->memb_only_on = std::atoi(e) != 0;
+  if (const char* e = std::getenv("RGPU_TERM_TARGET_ITEMS")) c->term_target_items = std::max(256, std::atoi(e));
+  if (const char* e = std::getenv("RGPU_TERM_SPLIT")) c->term_split = std::max(1, std::min(64, std::atoi(e)));
   if (const char* e = std::getenv("RGPU_COMM_FORCE_GATHER")) { if (std::atoi(e) != 0) c->cfg.comm_force_gather = 1; }
   std::snprintf(c->name, sizeof c->name, "%s (%s)", prop.name, prop.gcnArchName);
   // (the upload stream only exists when it is asked for: HIP multiplexes streams onto four hardware queues, and a fifth stream in the
@@ -2499,28 +2503,52 @@ static unsigned long long and_grid(long long wgs, int chunk) {
   const long long round = 8ll * chunk;
   return (unsigned long long)((wgs + round - 1) / round * round);
 }
-// Blocks per work item of k_search_term when the caller leaves rgpu_config.blocks_per_item at 0. With block-max pruning an item's cost
-// is its set-up (term descriptor, score table, sketch threshold) plus the chunks and blocks that can still enter, whatever its length
-// (round 6: the chunk frontiers — SegView::dir_sum — in front of the per-block test): about 12 k items per launch, two rounds of
-// wavefronts over the chip, at either shard size. Measured, k_search_term + k_merge_items on the headline batch: 10 M docs 128 blocks
-// per item 0.043 + 0.009 ms, 256 0.034 + 0.008, 512 0.037 + 0.007, 1024 0.038 + 0.007; 100 M docs 512 0.076 + 0.011, 1024 0.061 +
-// 0.009, 2048 0.054 + 0.008, 4096 0.054 + 0.007. (Rounds 4-5, when every block still cost its directory word: 512 up to 6 k items,
-// then up to 2048 beyond 30 k — 10 M docs 128 0.074 ms, 256 0.076, 512 0.071, 1024 0.082; 100 M docs 256 0.315, 512 0.215, 1024 and
-// 2048 0.178.) At most 4096: an item's chunks of 64 blocks are tested one lane each.
-static int term_item_blocks(int64_t total_blocks) {
+// Blocks per work item of k_search_term when the caller leaves rgpu_config.blocks_per_item at 0 — two rules, measured together (round 6,
+// scripts/split_sweep.sh, k_search_term + k_merge_items on the headline batch, one box per table):
+//   * the launch's size (here): with the chunk frontiers (SegView::dir_sum) in front of the per-block test, an item's cost is its
+//     set-up (term descriptor, score table, sketch threshold: ~5 us) plus 1.4 us per block that can still enter, whatever its length;
+//     a long list is mostly pruned, so its items are long: the smallest power of two that leaves at most `target_items` (3000) such items,
+//     at most 4096 blocks (an item's chunks of 64 blocks are tested one lane each);
+//   * a query's own size (term_query_item_blocks below): at least `split` (8) items for every list of 512 blocks or more, fewer down to
+//     64 blocks per item.
+//   10 M docs:  target 12000 / split 1: 0.034 + 0.008 ms   3000 / 1: 0.037 + 0.007   3000 / 4: 0.031 + 0.007   3000 / 8: 0.031 + 0.007
+//               3000 / 16: 0.032 + 0.007   3000 / 32: 0.043 + 0.008   1500 / 8: 0.031 + 0.007   6000 / 8: 0.032 + 0.007
+//   100 M docs: 12000 / 1: 0.053 + 0.008   3000 / 1: 0.053 + 0.007   3000 / 4: 0.045 + 0.007   3000 / 8: 0.042 + 0.007   3000 / 16: 0.045 + 0.007
+//   (Rounds 4-5, when every block still cost its directory word, one size for all: 512 up to 6 k items, then up to 2048 beyond 30 k —
+//   10 M docs 128 0.074 ms, 256 0.076, 512 0.071, 1024 0.082; 100 M docs 256 0.315, 512 0.215, 1024 and 2048 0.178.)
+static int term_item_blocks(int64_t total_blocks, int64_t target_items) {
   int blocks_per_item = 8;
-  while (blocks_per_item < 4096 && total_blocks / blocks_per_item > 12000) blocks_per_item *= 2;
+  while (blocks_per_item < 4096 && total_blocks / blocks_per_item > target_items) blocks_per_item *= 2;
   return blocks_per_item;
+}
+// ... and for ONE query of the launch: the ~13-20 blocks of a list that can enter the top-k would otherwise be unpacked one after the
+// other by ONE wavefront, 1.4 us each — the launch's critical path (round 6's item timeline, scripts/term_timeline.py: the last items
+// to finish were single-item queries of 150-250 blocks, 26-28 us of a 29.5 us launch, while the chip stood two thirds idle). Halving
+// keeps the sizes powers of two and every item on a chunk boundary; each item starts from the term's sketch threshold, so the items of a
+// query do not wait for one another.
+static int term_query_item_blocks(int nblocks, int base, int split) {
+  int b = base;
+  if (split > 1 && b > 0 && (b & (b - 1)) == 0) while (b > 64 && (nblocks + b - 1) / b < split) b >>= 1;
+  return b;
+}
+static int term_item_shift(int b) {  // log2 of a power-of-two item size for the item descriptor; 0: the launch's size
+  if (b <= 0 || (b & (b - 1)) != 0) return 0;
+  int sh = 0;
+  while ((1 << sh) < b) ++sh;
+  return sh;
 }
 // k_search_term's item descriptors: items 0 .. nq-1 are every query's first chunk, the other chunks follow query-major
 // (item_prefix[q] = chunks of the queries in front of q beyond their first); {query, chunk, term index or -1, the query's items}
-static void fill_term_item_desc(int4* out, const DevQuery* queries, const int64_t* item_prefix, int nq) {
+// (the query's items in the low 24 bits of .w, log2 of ITS item size above them — 0: the launch's blocks_per_item)
+static void fill_term_item_desc(int4* out, const DevQuery* queries, const DevTerm* terms, const int64_t* item_prefix, int nq, int base, int split) {
   for (int q = 0; q < nq; ++q) {
     const int n_mine = 1 + (int)(item_prefix[q + 1] - item_prefix[q]);
     const int ft = queries[q].n_terms >= 1 ? queries[q].first_term : -1;
-    out[q] = make_int4(q, 0, ft, n_mine);
+    const int sh = ft >= 0 ? term_item_shift(term_query_item_blocks(terms[ft].nblocks, base, split)) : 0;
+    const int w = n_mine | (sh << 24);
+    out[q] = make_int4(q, 0, ft, w);
     int4* rest = out + nq + item_prefix[q];
-    for (int ch = 1; ch < n_mine; ++ch) rest[ch - 1] = make_int4(q, ch, ft, n_mine);
+    for (int ch = 1; ch < n_mine; ++ch) rest[ch - 1] = make_int4(q, ch, ft, w);
   }
 }
 static int and_item_blocks(const rgpu_ctx* c, int64_t lead_blocks) {
@@ -2880,6 +2908,7 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
       G.qmap.swap(qm);
     }
     int blocks_per_item = c->cfg.blocks_per_item;
+    int term_split = 1;  // TERM: items per query of a few chunks (term_query_item_blocks), when the library sizes the items
     if (op != RGPU_OP_TERM) {
       int64_t lead_blocks = 0;
       for (const DevQuery& q0 : G.queries) if (q0.n_terms >= 1) lead_blocks += G.terms[(size_t)q0.first_term].nblocks;
@@ -2892,7 +2921,8 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
       if (op == RGPU_OP_TERM && c->blocks_per_item_auto) {  // fewer, longer items when there are plenty of blocks
         int64_t total_blocks = 0;
         for (auto& t : G.terms) total_blocks += t.nblocks;
-        blocks_per_item = term_item_blocks(total_blocks);
+        blocks_per_item = term_item_blocks(total_blocks, c->term_target_items);
+        term_split = c->term_split;
       }
       while (true) {
         items = 0;
@@ -2900,7 +2930,8 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
           G.item_prefix[(size_t)q] = items;
           if (G.queries[(size_t)q].n_terms >= 1) {
             const DevTerm& t = G.terms[(size_t)G.queries[(size_t)q].first_term];
-            const int64_t mine = t.nblocks == 0 ? 1 : (t.nblocks + blocks_per_item - 1) / blocks_per_item;
+            const int mine_blocks = op == RGPU_OP_TERM ? term_query_item_blocks(t.nblocks, blocks_per_item, term_split) : blocks_per_item;
+            const int64_t mine = t.nblocks == 0 ? 1 : (t.nblocks + mine_blocks - 1) / mine_blocks;
             items += head_items ? mine - 1 : mine;
           }
         }
@@ -2972,7 +3003,7 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
     std::memset(c->S->h_stage.p + o_tau, 0, (size_t)nq * 8);
     if (G.req_opt) std::memcpy(c->S->h_stage.p + o_sp, seq_prefix.data(), (size_t)(nq + 1) * 8);
     if (!clause_bitmaps.empty()) std::memcpy(c->S->h_stage.p + o_bm, clause_bitmaps.data(), clause_bitmaps.size() * sizeof(TermBitmap));
-    if (op == RGPU_OP_TERM) fill_term_item_desc(reinterpret_cast<int4*>(c->S->h_stage.p + o_id), G.queries.data(), G.item_prefix.data(), nq);
+    if (op == RGPU_OP_TERM) fill_term_item_desc(reinterpret_cast<int4*>(c->S->h_stage.p + o_id), G.queries.data(), G.terms.data(), G.item_prefix.data(), nq, blocks_per_item, term_split);
     if (c->upload_aside) HIP_TRY(stage_upload(c, st.used, stream));
     else HIP_TRY(hipMemcpyAsync(c->S->d_stage.p, c->S->h_stage.p, st.used, hipMemcpyHostToDevice, stream));
     HIP_TRY(c->S->d_partial_keys.reserve((size_t)items * (size_t)k, 0, stream));
@@ -4609,8 +4640,10 @@ static int32_t term_batch_fast(rgpu_segment* seg, rucene::BatchPlanner* P, int32
   if (bail) return RGPU_OK;  // (the slot was taken and not marked: it is simply free again)
   // items: chunks of a term's blocks; every query's first chunk is scheduled first (search_pass's rule, to the letter)
   int blocks_per_item = c->cfg.blocks_per_item;
+  int term_split = 1;
   if (c->blocks_per_item_auto) {
-    blocks_per_item = term_item_blocks(total_blocks);
+    blocks_per_item = term_item_blocks(total_blocks, c->term_target_items);
+    term_split = c->term_split;
   }
   int64_t items = 0;
   while (true) {
@@ -4619,7 +4652,8 @@ static int32_t term_batch_fast(rgpu_segment* seg, rucene::BatchPlanner* P, int32
       hp[q] = items;
       if (hq[q].n_terms >= 1) {
         const int32_t nb = ht[hq[q].first_term].nblocks;
-        items += (nb == 0 ? 1 : (nb + blocks_per_item - 1) / blocks_per_item) - 1;
+        const int mine_blocks = term_query_item_blocks(nb, blocks_per_item, term_split);
+        items += (nb == 0 ? 1 : (nb + mine_blocks - 1) / mine_blocks) - 1;
       }
     }
     hp[nq] = items;
@@ -4630,7 +4664,7 @@ static int32_t term_batch_fast(rgpu_segment* seg, rucene::BatchPlanner* P, int32
   if (items > 262144 + (int64_t)nq) return RGPU_OK;  // (blocks_per_item hit its ceiling on an absurd batch: the full path takes it)
   std::memset(c->S->h_stage.p + o_tau, 0, (size_t)nq * 8);
   std::memset(c->S->h_stage.p + o_w, 0, (size_t)nq * 16);
-  fill_term_item_desc(reinterpret_cast<int4*>(c->S->h_stage.p + o_id), hq, hp, nq);
+  fill_term_item_desc(reinterpret_cast<int4*>(c->S->h_stage.p + o_id), hq, ht, hp, nq, blocks_per_item, term_split);
   const size_t staged = o_id + (size_t)items * sizeof(int4);
   if (c->upload_aside) HIP_TRY(stage_upload(c, staged, stream));
   else HIP_TRY(hipMemcpyAsync(c->S->d_stage.p, c->S->h_stage.p, staged, hipMemcpyHostToDevice, stream));
