@@ -370,7 +370,7 @@ def main():
             """R timed regions of exactly n_steps steps each (every one bracketed by barrier + device synchronize on both
             sides, warmup in front of the first): {"min", "median", "max"} ms per step. The figure reported is the MEDIAN
             region — a region of K = 20 steps of 0.06 ms is 1.3 ms long, and one such region is box lottery."""
-            per = [timed_region(n_lanes, replan, n_steps, warmup if r == 0 else 1) for r in range(regions or args.regions)]
+            per = [timed_region(n_lanes, replan, n_steps, warmup) for r in range(regions or args.regions)]
             per.sort()
             return {"min": per[0], "median": per[len(per) // 2] if len(per) & 1 else 0.5 * (per[len(per) // 2 - 1] + per[len(per) // 2]),
                     "max": per[-1], "regions": len(per), "steps_per_region": n_steps}
@@ -384,15 +384,22 @@ def main():
                     qs = [B.build([T(int(x)) for x in t], []) for t in tids]
                 else:
                     qs = [B.build([], [T(int(x)) for x in t]) for t in tids]
+            # (K = 20 steps of 0.04 ms are a 0.8 ms region: one collection of the interpreter's garbage inside it is a third of it.
+            # The collection happens IN FRONT of the warm-up steps: until round 6 it sat between them and the timed region, and the
+            # tens of milliseconds it takes are long enough for an idle MI355X to drop its clocks — the same 20 calls measured 48-51 us
+            # per step behind a collection and 36-37 us behind the warm-up steps, scripts/host_call_probe.py. The warm-up steps are
+            # the step being timed.)
+            gc.collect()
+            gc.disable()
             for _ in range(n_warm):
-                step(packed, n_lanes)
+                if replan == "fused":
+                    step_fused(n_lanes)
+                else:
+                    step(packed, n_lanes)
             torch.cuda.synchronize()
             if dist_mode:
                 dist.barrier()
             torch.cuda.synchronize()
-            # (K = 20 steps of 0.06 ms are a 1.3 ms region: one collection of the interpreter's garbage inside it is a fifth of it)
-            gc.collect()
-            gc.disable()
             t = time.perf_counter()
             for _ in range(n_steps):
                 if replan == "fused":
@@ -734,8 +741,8 @@ def main():
         else:
             touched = c["touched_bytes"] + 8 * k * nq
             out["roofline"] = roofline(dom, kms, touched, r["algo_bytes"], tag,
-                                       "touched bytes: encoded bytes + norms of every block the kernel unpacked (counted by the kernel) + 14 B of "
-                                       "directory (row, header, frontier words) per block it looked at + 8 k B out")
+                                       "touched bytes, counted by the kernel: encoded bytes + norms of every block it unpacked + the directory entries it "
+                                       "requested (18 B per block of every 64-block chunk it visited, 8 B per chunk frontier, 2 B per sketch entry) + 8 k B out")
             out["roofline"]["pruning"] = "%d of %d FullBlocks unpacked" % (c["blocks_decoded"], int((shard.seg.terms["doc_freq"][r["tids"].reshape(-1)] // 128).sum()))
         # one isolated launch of the dominant kernel cannot take longer than a whole one-stream step that contains it (+ 20 % for the
         # events' own cost): when it does, the event timing is off and the roofline says so instead of being believed

@@ -635,8 +635,9 @@ typedef struct rgpu_search_counters {
   int64_t postings_covered;  /* sum of doc_freq over the launch's clauses: what an exhaustive scorer would iterate */
   int64_t postings_decoded;  /* 128 per FullBlock actually unpacked + prepared tails / singletons read */
   int64_t blocks_decoded;
-  int64_t touched_bytes;     /* encoded bytes of those blocks; TERM: + 1 norm byte per posting of them + 14 directory bytes
-                                (row, header, frontier words) per block looked at. 0 for OR launches (everything is read) */
+  int64_t touched_bytes;     /* encoded bytes of those blocks; TERM: + 1 norm byte per posting of them + what the launch read of the
+                                block directory (18 bytes per block of every chunk of 64 it visited, 8 per chunk frontier, 2 per sketch
+                                entry), counted by the kernel. 0 for OR launches (everything is read) */
 } rgpu_search_counters;
 int32_t rgpu_last_search_counters(rgpu_ctx* ctx, rgpu_search_counters* out);
 void rgpu_kernel_stats_reset(rgpu_ctx* ctx);

@@ -74,26 +74,11 @@ __device__ __forceinline__ float table_score(const float* cache, uint32_t rank, 
 // ---- fold the per-item lists of each query: one wavefront per query --------------------------------------------
 // `head_items` > 0 selects the TERM kernel's item layout: item q is query q's first chunk and the query's other
 // chunks are items head_items + [item_prefix[q], item_prefix[q+1]); 0 = plain contiguous ranges.
+// The fold itself — also run by the wavefront of k_search_term that finishes a query last (search_term.hpp, TermMerge):
 template <bool WIDE>
-__global__ __launch_bounds__(WG_THREADS) void k_merge_items(const int64_t* __restrict__ item_prefix, int n_queries, int k,
-                                                            const uint64_t* __restrict__ partial_keys,
-                                                            const int32_t* __restrict__ partial_counts, int32_t doc_base,
-                                                            int head_items, HitOut* __restrict__ hits_out,
-                                                            int64_t* __restrict__ totals_out,
-                                                            const int2* __restrict__ fixed_info = nullptr,
-                                                            int32_t* __restrict__ low_flags = nullptr,
-                                                            const int32_t* __restrict__ qmap = nullptr, int out_stride = 0, int col0 = 0,
-                                                            unsigned long long* __restrict__ ceil_out = nullptr) {
-  // out_stride / col0: the caller's rows are out_stride hits long and this pass fills columns [col0, col0 + k) (0 = k, 0);
-  // ceil_out[row] = this pass's worst key when it filled all k slots, else 0 ("nothing left below") — the next pass's ceiling
-  const int lane = lane_id();
-  const int q = (int)(blockIdx.x * WG_WAVES) + wave_id();
-  if (q >= n_queries) return;
-  WaveTopK top;
+__device__ __forceinline__ void merge_query_items(int q, int64_t i0, int64_t n_mine, int head_items, int k, const uint64_t* __restrict__ partial_keys,
+                                                  const int32_t* __restrict__ partial_counts, WaveTopK& top, int64_t& total, int lane) {
   uint64_t tau = 0;
-  int64_t total = 0;
-  const int64_t i0 = item_prefix[q], i1 = item_prefix[q + 1];
-  const int64_t n_mine = (i1 - i0) + (head_items > 0 ? 1 : 0);
   auto item_at = [&](int64_t j) -> int64_t {  // j-th item of this query
     if (head_items > 0) return j == 0 ? (int64_t)q : (int64_t)head_items + i0 + j - 1;
     return i0 + j;
@@ -130,6 +115,26 @@ __global__ __launch_bounds__(WG_THREADS) void k_merge_items(const int64_t* __res
       m = rest & __ballot(head > tau);
     }
   }
+}
+template <bool WIDE>
+__global__ __launch_bounds__(WG_THREADS) void k_merge_items(const int64_t* __restrict__ item_prefix, int n_queries, int k,
+                                                            const uint64_t* __restrict__ partial_keys,
+                                                            const int32_t* __restrict__ partial_counts, int32_t doc_base,
+                                                            int head_items, HitOut* __restrict__ hits_out,
+                                                            int64_t* __restrict__ totals_out,
+                                                            const int2* __restrict__ fixed_info = nullptr,
+                                                            int32_t* __restrict__ low_flags = nullptr,
+                                                            const int32_t* __restrict__ qmap = nullptr, int out_stride = 0, int col0 = 0,
+                                                            unsigned long long* __restrict__ ceil_out = nullptr) {
+  // out_stride / col0: the caller's rows are out_stride hits long and this pass fills columns [col0, col0 + k) (0 = k, 0);
+  // ceil_out[row] = this pass's worst key when it filled all k slots, else 0 ("nothing left below") — the next pass's ceiling
+  const int lane = lane_id();
+  const int q = (int)(blockIdx.x * WG_WAVES) + wave_id();
+  if (q >= n_queries) return;
+  WaveTopK top;
+  int64_t total = 0;
+  const int64_t i0 = item_prefix[q], i1 = item_prefix[q + 1];
+  merge_query_items<WIDE>(q, i0, (i1 - i0) + (head_items > 0 ? 1 : 0), head_items, k, partial_keys, partial_counts, top, total, lane);
   // qmap: the group's query q is the caller's row qmap[q] (queries are partitioned by op on the host) — the rows are
   // written in place, no scatter pass
   const int row = qmap ? qmap[q] : q;

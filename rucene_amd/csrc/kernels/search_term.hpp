@@ -70,6 +70,12 @@ __host__ __device__ constexpr size_t term_lds_bytes(bool wide) {
 }
 
 // ---- a top-k list shared by the wavefronts of one group -------------------------------------------------------
+// (Round 6's phase counters — scripts/term_timeline.py on a -DRGPU_TERM_TRACE build — put 26 % of term_blocks_fast's cycles, 40-45 % in
+// the launch's longest items, into the offer below: ~1450 cycles per offered block. Two alternatives were measured and dropped:
+// every wavefront keeping its OWN list in registers, the group sharing only the largest k-th best (ds_max_u64) and merging the lists
+// at the end — ~1160 cycles per offer, so the lock is ~300 of them, but the looser threshold unpacks more blocks: k_search_term 0.0315
+// against 0.0310 ms at 10 M docs, 0.048 against 0.043 at 100 M; and inserting the best candidate first (one or two wave maxima per
+// insertion) instead of in lane order — as many cycles per offer, 0.0303 against 0.0308 ms. What an offer costs is its ~5-7 insertions.)
 struct GroupList {
   uint64_t* keys;  // LDS: 64 (128 when WIDE) keys, sorted descending, 0 == empty — WaveTopK's registers at rest
   uint32_t* lock;  // LDS
@@ -126,12 +132,22 @@ __device__ __forceinline__ void group_offer2(const GroupList& g, uint64_t key0, 
 // TERM_FLAG_MONOTONE) and the weight is >= 0 — x / y with x >= 0 fixed and y = f + cache[r] > 0 shrinking, correctly
 // rounded. Absent freqs carry rank 0, whose entry the bound of the block's largest freq dominates up to rounding;
 // either way the maximum is taken over a superset of the block's (rank, freq) pairs.
+#ifdef RGPU_TERM_TRACE  // shader-clock cycles per phase of term_blocks_fast, summed over the item (developer instrumentation)
+#define TERM_PH_PARAM , uint32_t (&ph)[8]
+#define TERM_PH_NOW(v) const uint64_t v = (uint64_t)clock64()
+#define TERM_PH_ADD(i, since) ph[i] += (uint32_t)((uint64_t)clock64() - (since))
+#else
+#define TERM_PH_PARAM
+#define TERM_PH_NOW(v) do {} while (0)
+#define TERM_PH_ADD(i, since) do {} while (0)
+#endif
 template <bool LEGACY, bool WIDE>
 __device__ __forceinline__ void term_blocks_fast(const SegView& seg, const DevTerm& T, int b0, int b1, uint8_t* slab,
                                                  const float* cache, float wk, int lane, const GroupList& group,
                                                  SharedTau& shared, uint64_t& floor, int k, int& count, bool prune, uint32_t& looked,
-                                                 uint32_t& touched, uint64_t ceil, bool exchange, bool head) {
+                                                 uint32_t& touched, uint64_t ceil, bool exchange, bool head TERM_PH_PARAM) {
   constexpr int DEPTH = PREFETCH_DEPTH;
+  TERM_PH_NOW(ph_enter);
   const uint8_t* term_rows = seg.bstore + T.bs_base;
   const uint8_t* pn = seg.pnorm + T.pn_base;
 #if RGPU_TERM_ORDER == 0
@@ -224,6 +240,7 @@ __device__ __forceinline__ void term_blocks_fast(const SegView& seg, const DevTe
     const int cj = (b0 >> 6) + lane;  // the chunk's index within the term; only whole chunks have a word
     const bool whole = lane < n_chunks && 64 * cj + 64 <= T.nblocks;
     cbest = bound_of(whole ? seg.dir_sum[((T.dir_base + 63u) >> 6) + (uint32_t)cj] : 15ull);
+    touched += 8u * (uint32_t)n_chunks;  // (what this item reads of the directory is counted where it is requested)
   }
   auto still = [&](uint64_t t) {  // the non-strict test: thr_of(t, lo) is `bits` or `bits + 1` (cbest is all ones without a word)
     const uint32_t thi = (uint32_t)(t >> 32);
@@ -233,11 +250,14 @@ __device__ __forceinline__ void term_blocks_fast(const SegView& seg, const DevTe
   still(tau);
   Chunk next{};
   if (cand) next = load_chunk(b0 + 64 * (int)__builtin_ctzll(cand), 0);
+  TERM_PH_ADD(0, ph_enter);
   for (int visited = 0; cand != 0ull; ++visited) {
+    TERM_PH_NOW(ph_chunk);
     const int c0 = b0 + 64 * (int)__builtin_ctzll(cand);
     cand &= cand - 1ull;
     const int nb = min(64, b1 - c0);
     const Chunk cur = next;
+    touched += 18u * (uint32_t)nb;  // frontier word, store row, header, the doc in front: the directory entries of a visited chunk
     still(tau);  // (what the chunk before this one achieved)
     if (cand) next = load_chunk(b0 + 64 * (int)__builtin_ctzll(cand), visited + 1);
     const DirChunk& dir = cur.dir;
@@ -258,8 +278,11 @@ __device__ __forceinline__ void term_blocks_fast(const SegView& seg, const DevTe
     auto step = [&](int idx, const uint4& rows, uint32_t nn) {
       const uint32_t hdr = dir.hdr_at(idx);
       const int bf = hdr_bfreq(hdr);
+      TERM_PH_NOW(ph_s0);
       stage_rows(rows, slab, lane);
       wave_sync();
+      TERM_PH_ADD(2, ph_s0);
+      TERM_PH_NOW(ph_s1);
       uint32_t f0, f1;
       bool in_table = true;  // wave-uniform: every freq of the block has a table column
       if (bf) {
@@ -287,7 +310,9 @@ __device__ __forceinline__ void term_blocks_fast(const SegView& seg, const DevTe
       const int32_t base = readlane(cur.lo, idx) < 0 ? 0 : readlane(cur.lo, idx);  // (block 0 of the term: deltas count from doc 0)
       const uint32_t thr = pin(thr_of(tau, readlane(cur.lo, idx)));
       const uint32_t r0 = __float_as_uint(s0), r1 = __float_as_uint(s1);
+      TERM_PH_ADD(3, ph_s1);
       if (__ballot((r0 > r1 ? r0 : r1) >= thr)) {
+        TERM_PH_NOW(ph_s2);
 #ifdef RGPU_EXP_COUNT
         ++dbg_slow;
 #endif
@@ -299,7 +324,15 @@ __device__ __forceinline__ void term_blocks_fast(const SegView& seg, const DevTe
         // most blocks that get here only tie with the threshold or trail a fresher one: look at the group's
         // current k-th best (one LDS read) before paying for the lock and the list check-out
         tau = fresh_tau();
-        if (__ballot((key0 > key1 ? key0 : key1) > tau)) group_offer2<WIDE>(group, key0, key1, tau, k, lane, floor);
+        TERM_PH_ADD(4, ph_s2);
+        TERM_PH_NOW(ph_s3);
+        if (__ballot((key0 > key1 ? key0 : key1) > tau)) {
+          group_offer2<WIDE>(group, key0, key1, tau, k, lane, floor);
+#ifdef RGPU_TERM_TRACE
+          ph[7] += 1u;
+#endif
+        }
+        TERM_PH_ADD(5, ph_s3);
       }
       wave_sync();  // slab is free for the next block
     };
@@ -314,6 +347,7 @@ __device__ __forceinline__ void term_blocks_fast(const SegView& seg, const DevTe
     // cheaper than a load behind a branch.
     tau = fresh_tau();
     uint64_t todo = in_chunk & __ballot(may_enter(tau));
+    TERM_PH_ADD(1, ph_chunk);
     int slot[DEPTH];
     uint4 ring[DEPTH];
     uint32_t nring[DEPTH];
@@ -373,6 +407,7 @@ __device__ __forceinline__ void term_blocks_fast(const SegView& seg, const DevTe
       if (first_of_head || (exchange && (RGPU_TERM_EXCHANGE == 1 || (RGPU_TERM_EXCHANGE == 2 && (ci & (ci - 1)) == 0)))) shared.publish_key(group_kth<WIDE>(group, k), lane);
     }
   }
+  TERM_PH_ADD(6, ph_enter);
 #ifdef RGPU_EXP_COUNT
   if (lane == 0) {
     atomicAdd(&g_term_dbg[0], (unsigned long long)(b1 - b0));
@@ -397,7 +432,13 @@ __device__ __forceinline__ void term_blocks_fast(const SegView& seg, const DevTe
 // them into scores with ITS query's table: k table reads and a wave minimum. Under another table the k pairs are still k real
 // postings of k blocks — the threshold stays valid, it is just not the tightest.
 constexpr int TERM_SKETCH_K = 128;          // entries per sketch = the largest k one pass serves (RGPU_PASS_K)
-constexpr int TERM_SKETCH_MIN_BLOCKS = 64;  // shorter lists are one item's work either way
+#ifndef RGPU_TERM_SKETCH_MIN_BLOCKS
+#define RGPU_TERM_SKETCH_MIN_BLOCKS 16
+#endif
+// (64 until round 6, "shorter lists are one item's work either way": they were the launch's LONGEST items — 40-60 blocks, 16 of them
+// unpacked one after the other while the threshold crept up, 25 us of a 26 us launch. With a sketch from 16 blocks up: k_search_term
+// 0.0306 -> 0.0278 ms at 10 M docs, 0.0424 -> 0.0421 at 100 M; cutting such lists into items of 32 or 16 blocks on top: 0.031 / 0.032.)
+constexpr int TERM_SKETCH_MIN_BLOCKS = RGPU_TERM_SKETCH_MIN_BLOCKS;  // 256 bytes of sketch per term of this many blocks or more
 constexpr int TERM_SKETCH_WAVES = 4;
 struct SketchJob {
   uint32_t dir_base;  // the term's first directory slot
@@ -475,7 +516,7 @@ __device__ __forceinline__ uint64_t sketch_floor(const uint16_t* __restrict__ sk
 // Measured, same box: k_search_term 0.0405-0.0418 -> 0.0378-0.0382 ms at 10 M docs, 0.139 -> 0.131-0.133 ms at 100 M.
 #ifdef RGPU_TERM_TRACE  // developer instrumentation (variant builds only): every item's {start, end} wall clock (100 MHz), query, chunk,
 constexpr int TERM_TRACE_CAP = 1 << 17;           // blocks looked at / unpacked — the launch's timeline, read back by rgpu_debug_trace
-struct TermTraceRec { unsigned long long t0, t1; int32_t q, chunk, blocks, unpacked; unsigned int d_term, d_table, d_sketch, d_pad; };  // d_*: 10 ns ticks from t0
+struct TermTraceRec { unsigned long long t0, t1; int32_t q, chunk, blocks, unpacked; unsigned int d_term, d_table, d_sketch, d_pad; unsigned int ph[8]; };  // d_*: 10 ns ticks from t0; ph: shader cycles (TERM_PH_ADD)
 __device__ TermTraceRec g_term_trace[TERM_TRACE_CAP];
 #endif
 #ifndef RGPU_TERM_OTHER_WAVES
@@ -484,6 +525,20 @@ __device__ TermTraceRec g_term_trace[TERM_TRACE_CAP];
 #ifndef RGPU_TERM_FAST_WAVES
 #define RGPU_TERM_FAST_WAVES 6
 #endif
+// The launch's last step inside the launch (round 6): the wavefront that finishes a query's LAST item folds the query's item lists and
+// writes the caller's row — what k_merge_items did in a launch of its own (7 us of kernel behind a 30 us one, plus the gap between
+// two launches, on the headline batch). Every item writes its list and count, makes them visible to the device (release fence at agent
+// scope: the lists sit in the L2 of whichever XCD ran the item) and counts itself at done[q]; the one that reads q_items - 1 there has
+// seen every other item's release, takes an acquire fence and runs merge_query_items. done == nullptr: no fold, k_merge_items follows.
+struct TermMerge {
+  unsigned int* done = nullptr;  // per query, zeroed with the plan: items that have written their list
+  const int64_t* item_prefix;   // the host's item layout (k_merge_items' head_items form)
+  HitOut* hits;                 // the caller's rows, k hits each, and ...
+  int64_t* totals;              // ... hit counts, row qmap[q]
+  unsigned long long* ceil_out; // (nullable) per row: this pass's worst key when it filled all k slots, else 0 — as k_merge_items
+  int32_t doc_base;
+  int32_t out_stride, col0;     // the caller's rows are out_stride hits long and this pass fills columns [col0, col0 + k) (0, 0: k-long rows)
+};
 template <bool LEGACY, bool WIDE>
 __global__ __launch_bounds__(TERM_THREADS, (LEGACY || WIDE) ? RGPU_TERM_OTHER_WAVES : RGPU_TERM_FAST_WAVES) void k_search_term(SegView seg, const DevQuery* __restrict__ queries,
                                                               const DevTerm* __restrict__ terms,
@@ -494,7 +549,7 @@ __global__ __launch_bounds__(TERM_THREADS, (LEGACY || WIDE) ? RGPU_TERM_OTHER_WA
                                                               unsigned long long* __restrict__ tau_slots,
                                                               unsigned long long* __restrict__ work_slots,
                                                               const unsigned long long* __restrict__ ceil_slots,
-                                                              const int32_t* __restrict__ qmap) {
+                                                              const int32_t* __restrict__ qmap, TermMerge fold) {
   // ceil_slots (nullable): per CALLER row (qmap[q]) the key this pass's hits must stay below (wave.hpp `below`)
   // work_slots (nullable): [q] += encoded bytes of the FullBlocks this launch decoded for query q (+ their norms),
   // [n_queries + q] += their number — with block-max pruning a small part of the lists ("touched" vs "scan" bytes)
@@ -553,9 +608,12 @@ __global__ __launch_bounds__(TERM_THREADS, (LEGACY || WIDE) ? RGPU_TERM_OTHER_WA
 
 #ifdef RGPU_TERM_TRACE
   unsigned int tr_term = 0, tr_table = 0, tr_sketch = 0;
+  uint32_t ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define TERM_PH_PASS , ph
 #define TERM_TR(v, dep) do { asm volatile("" :: "v"(dep)); v = (unsigned int)((unsigned long long)wall_clock64() - trace_t0); } while (0)
 #else
 #define TERM_TR(v, dep) do {} while (0)
+#define TERM_PH_PASS
 #endif
   if (first_term >= 0) {  // else: clause absent from this leaf, nothing to collect
     const DevTerm T = terms[first_term];
@@ -613,8 +671,10 @@ __global__ __launch_bounds__(TERM_THREADS, (LEGACY || WIDE) ? RGPU_TERM_OTHER_WA
       const bool prune = RGPU_TERM_PRUNE && (T.flags & TERM_FLAG_MONOTONE) != 0u;
       // the term's block-max sketch: k real postings of k blocks, scored with this query's table — a threshold to start from
       // (first pass only: a deeper page collects below a ceiling)
-      if (T.sketch != 0u && seg.sketch != nullptr && ceil == ~0ull && k <= TERM_SKETCH_K)
+      if (T.sketch != 0u && seg.sketch != nullptr && ceil == ~0ull && k <= TERM_SKETCH_K) {
         shared.fold(sketch_floor<WIDE>(seg.sketch + (size_t)(T.sketch - 1u) * TERM_SKETCH_K, cache, k, lane), tau, floor);
+        touched += 2u * (uint32_t)k;
+      }
       TERM_TR(tr_sketch, (uint32_t)floor);
       if (RGPU_TERM_WAIT && prune && chunk != 0) {  // (wave-uniform) the head's first publication, or the time-out
         uint64_t s2 = floor;
@@ -626,7 +686,7 @@ __global__ __launch_bounds__(TERM_THREADS, (LEGACY || WIDE) ? RGPU_TERM_OTHER_WA
         shared.fold(s2, tau, floor);
       }
       term_blocks_fast<LEGACY, WIDE>(seg, T, b0, b1, slab, cache, wk, lane, group, shared, floor, k, count, prune, looked, touched, ceil,
-                                     q_items <= TERM_EXCHANGE_MAX_ITEMS, chunk == 0);
+                                     q_items <= TERM_EXCHANGE_MAX_ITEMS, chunk == 0 TERM_PH_PASS);
       if (b1 > b0) base = seg.dir_last[T.dir_base + b1 - 1];
     } else if (has_norms) {
       stream_blocks<LEGACY, true>(term_rows, seg.dir_row, seg.dir_hdr, T.dir_base, seg.pnorm + T.pn_base, b0, b1, slab, lane, base, on_block);
@@ -650,11 +710,14 @@ __global__ __launch_bounds__(TERM_THREADS, (LEGACY || WIDE) ? RGPU_TERM_OTHER_WA
   }
 
 #ifdef RGPU_TERM_TRACE
-  if (lane == 0 && item < TERM_TRACE_CAP) g_term_trace[item] = TermTraceRec{trace_t0, (unsigned long long)wall_clock64(), q, chunk, (int32_t)looked, (int32_t)(touched / 256u), tr_term, tr_table, tr_sketch, 0u};
+  if (lane == 0 && item < TERM_TRACE_CAP) g_term_trace[item] = TermTraceRec{trace_t0, (unsigned long long)wall_clock64(), q, chunk, (int32_t)looked, (int32_t)(touched / 256u), tr_term, tr_table, tr_sketch, 0u, {ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[6], ph[7]}};
 #endif
   // the wave of a group that finishes last emits the group's list; the other items emit empty lists
-  if (lane == 0) partial_counts[item] = count;
-  if (work_slots != nullptr && lane == 0 && looked != 0u) {  // per query: one address for the whole launch would serialise thousands of wavefronts
+  if (lane == 0) {
+    if (fold.done != nullptr) __hip_atomic_store(partial_counts + item, count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else partial_counts[item] = count;
+  }
+  if (work_slots != nullptr && lane == 0 && (looked | touched) != 0u) {  // per query: one address for the whole launch would serialise thousands of wavefronts
     atomicAdd(work_slots + q, (unsigned long long)touched);
     atomicAdd(work_slots + n_queries + q, (unsigned long long)looked);
   }
@@ -669,8 +732,34 @@ __global__ __launch_bounds__(TERM_THREADS, (LEGACY || WIDE) ? RGPU_TERM_OTHER_WA
     shared.publish<WIDE>(top, k, lane);
   }
   uint64_t* pk = partial_keys + (size_t)item * (size_t)k;
-  if (lane < k) pk[lane] = top.a;
-  if (WIDE && lane + 64 < k) pk[lane + 64] = top.b;
+  if (fold.done == nullptr) {
+    if (lane < k) pk[lane] = top.a;
+    if (WIDE && lane + 64 < k) pk[lane + 64] = top.b;
+    return;
+  }
+  // (a release fence at agent scope here — buffer_wbl2: the whole L2's dirty lines, once per item — was measured: k_search_term 0.028 ->
+  // 0.085 ms. The list and the count go out as agent-scope stores instead, which write through the XCD's L2 on their own; the
+  // workgroup-scope fence is the wait for their acknowledgement, and only then the item counts itself.)
+  if (lane < k) __hip_atomic_store(pk + lane, top.a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (WIDE && lane + 64 < k) __hip_atomic_store(pk + lane + 64, top.b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  uint32_t finished = 0;
+  if (lane == 0) finished = __hip_atomic_fetch_add(fold.done + q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  finished = (uint32_t)readfirstlane((int)finished) + 1u;
+  if (finished != (uint32_t)q_items) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  WaveTopK all;
+  int64_t total = 0;
+  merge_query_items<WIDE>(q, fold.item_prefix[q], (int64_t)q_items, n_queries, k, partial_keys, partial_counts, all, total, lane);
+  const int row = qmap ? qmap[q] : q;
+  HitOut* out = fold.hits + (size_t)row * (size_t)(fold.out_stride > 0 ? fold.out_stride : k) + fold.col0;
+  if (fold.ceil_out != nullptr) {
+    const uint64_t kth = topk_threshold<WIDE>(all, k);
+    if (lane == 0) fold.ceil_out[row] = kth;
+  }
+  if (lane < k) out[lane] = all.a ? HitOut{key_doc(all.a) + fold.doc_base, key_score(all.a)} : HitOut{-1, 0.f};
+  if (WIDE && lane + 64 < k) out[lane + 64] = all.b ? HitOut{key_doc(all.b) + fold.doc_base, key_score(all.b)} : HitOut{-1, 0.f};
+  if (lane == 0) fold.totals[row] = total;
 }
 
 }  // namespace rgpu

@@ -221,6 +221,9 @@ struct rgpu_ctx {
   // regions — but the cross-stream event wait costs 15-30 us of latency whenever the pipeline is shallow: two alternating streams
   // 0.063 against 0.047 in 20-step regions, the 3-term AND batch 0.290 against 0.258. Off by default.
   bool upload_aside = false;
+  bool stage_by_kernel = true;    // staged plans reach the device through k_stage_copy (RGPU_STAGE_COPY=dma: hipMemcpyAsync)
+  bool term_fold = true;          // plan + search in one call, single-term batches: k_search_term folds the item lists itself (RGPU_TERM_FOLD=0: k_merge_items)
+  int term_min_item_blocks = 64;  // ... and none of its items shorter than this (RGPU_TERM_MIN_ITEM_BLOCKS)
   int term_target_items = 3000;  // single-term launches: items of the launch's size, at most about this many (RGPU_TERM_TARGET_ITEMS in the environment)
   int term_split = 8;         // single-term queries: at least this many items per query, of 64 blocks or more each (RGPU_TERM_SPLIT in the environment; 1: off)
   bool memb_only_on = true;   // membership-only bits for sparse first clauses of conjunctions (RGPU_AND_MEMB_ONLY=0 in the environment: off; A/B, tests)
@@ -247,7 +250,7 @@ struct rgpu_ctx {
   Scratch* last_counted = nullptr;
   const unsigned long long* last_counted_words = nullptr;  // [touched bytes per query][blocks per query] of that launch (the slot's d_touched, or inside its stage)
   int last_counted_op = -1, last_counted_queries = 0;
-  int64_t last_counted_dir_blocks = 0;   // TERM: blocks whose directory words the launch looked at (all of them)
+  int64_t last_counted_dir_blocks = 0;   // TERM: blocks of the launch's lists (what it READ of their directory the kernel counts itself, since round 6)
   int64_t last_counted_loose = 0;        // postings outside FullBlocks (prepared tails, singletons) of the (lead) clauses
   int64_t last_counted_postings = 0;     // sum of doc_freq over the launch's clauses
   int64_t last_counted_algo_bytes = 0;   // wide OR: encoded bytes of every clause + 1 B norm per posting
@@ -429,6 +432,26 @@ static hipError_t stage_upload(rgpu_ctx* c, size_t bytes, hipStream_t s) {
   if (e == hipSuccess) e = hipEventRecord(sc->staged, c->upload);
   if (e == hipSuccess) e = hipStreamWaitEvent(s, sc->staged, 0);
   return e;
+}
+
+// The slot's staged plan -> d_stage, ordered on `s`. Round 6: a copy KERNEL reading the pinned buffer over PCIe, not hipMemcpyAsync: the
+// DMA engine's copy of the headline TERM batch's ~210 KB plan took 11 us, and handing over from the DMA queue to the compute queue and
+// back cost 8-10 us each way (rocprofv3 --kernel-trace --memory-copy-trace, scripts/step_timeline.sh: copy 11.2 | gap 8.5 | k_search_term
+// 28.5 | gap 9.5 us per step on one stream) — 29 us of a 58 us step in which the kernel ran for 28.5. A kernel behind a kernel on one
+// queue starts within 1-2 us. RGPU_STAGE_COPY=dma in the environment: hipMemcpyAsync as before; plans beyond 8 MB take it too.
+__global__ __launch_bounds__(256) void k_stage_copy(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+static hipError_t stage_h2d(rgpu_ctx* c, size_t bytes, hipStream_t s) {
+  Scratch* sc = c->S;
+  if (c->upload_aside) return stage_upload(c, bytes, s);
+  const size_t n16 = (bytes + 15) / 16;
+  if (!c->stage_by_kernel || bytes > ((size_t)8 << 20) || n16 * 16 > sc->h_stage.cap || n16 * 16 > sc->d_stage.cap)
+    return hipMemcpyAsync(sc->d_stage.p, sc->h_stage.p, bytes, hipMemcpyHostToDevice, s);
+  TimedLaunch tl(c, s, "k_stage_copy", 0);
+  const unsigned grid = (unsigned)std::min<size_t>(1024, (n16 + 255) / 256);
+  RGPU_LAUNCH(k_stage_copy, dim3(grid), dim3(256), 0, s, reinterpret_cast<const uint4*>(sc->h_stage.p), reinterpret_cast<uint4*>(sc->d_stage.p), n16);
+  return hipSuccess;
 }
 
 // ---- staging: pack several host arrays into one pinned buffer, one H2D copy ---------------------------------
@@ -1088,6 +1111,9 @@ extern "C" int32_t rgpu_init(int32_t device_ordinal, const rgpu_config* cfg, rgp
   if (const char* e = std::getenv("RGPU_UPLOAD_ASIDE")) c->upload_aside = std::atoi(e) != 0;
   if (const char* e = std::getenv("RGPU_AND_MEMB_ONLY")) c->memb_only_on = std::atoi(e) != 0;
   if (const char* e = std::getenv("RGPU_TERM_TARGET_ITEMS")) c->term_target_items = std::max(256, std::atoi(e));
+  if (const char* e = std::getenv("RGPU_STAGE_COPY")) c->stage_by_kernel = std::strcmp(e, "dma") != 0;
+  if (const char* e = std::getenv("RGPU_TERM_FOLD")) c->term_fold = std::atoi(e) != 0;
+  if (const char* e = std::getenv("RGPU_TERM_MIN_ITEM_BLOCKS")) c->term_min_item_blocks = std::max(8, std::min(4096, std::atoi(e)));
   if (const char* e = std::getenv("RGPU_TERM_SPLIT")) c->term_split = std::max(1, std::min(64, std::atoi(e)));
   if (const char* e = std::getenv("RGPU_COMM_FORCE_GATHER")) { if (std::atoi(e) != 0) c->cfg.comm_force_gather = 1; }
   std::snprintf(c->name, sizeof c->name, "%s (%s)", prop.name, prop.gcnArchName);
@@ -1205,7 +1231,6 @@ extern "C" int32_t rgpu_last_search_counters(rgpu_ctx* c, rgpu_search_counters* 
   std::vector<unsigned long long> h(nq * 2);
   HIP_TRY(hipMemcpy(h.data(), c->last_counted_words ? c->last_counted_words : c->last_counted->d_touched.p, nq * 16, hipMemcpyDeviceToHost));
   for (size_t q = 0; q < nq; ++q) { out->touched_bytes += (int64_t)h[q]; out->blocks_decoded += (int64_t)h[nq + q]; }
-  if (c->last_counted_op == RGPU_OP_TERM) out->touched_bytes += 14 * c->last_counted_dir_blocks;
   out->postings_decoded = 128 * out->blocks_decoded + c->last_counted_loose;
   return RGPU_OK;
 }
@@ -1456,7 +1481,7 @@ static int32_t decode_terms_impl(rgpu_segment* seg, const rgpu_term_state* terms
   }
   hitems[nr] = items;
   hout[nr] = out;
-  HIP_TRY(hipMemcpyAsync(c->S->d_stage.p, c->S->h_stage.p, st.used, hipMemcpyHostToDevice, stream));
+  HIP_TRY(stage_h2d(c, st.used, stream));
   const unsigned grid = wg_count((items + WG_WAVES - 1) / WG_WAVES);
   {
     TimedLaunch tl(c, stream, "k_decode_terms", postings);
@@ -1820,7 +1845,7 @@ static int32_t search_or_group(rgpu_segment* seg, Group& G, int32_t k, HitOut* h
   std::memcpy(c->S->h_stage.p + o_rp, run_prefix.data(), (size_t)(nt + 1) * 8);
   std::memcpy(c->S->h_stage.p + o_mp, merge_prefix.data(), (size_t)(nq + 1) * 8);
   std::memcpy(c->S->h_stage.p + o_m, G.qmap.data(), (size_t)nq * 4);
-  HIP_TRY(hipMemcpyAsync(c->S->d_stage.p, c->S->h_stage.p, st.used, hipMemcpyHostToDevice, stream));
+  HIP_TRY(stage_h2d(c, st.used, stream));
   // the scored runs: the slot's own buffer (the group then only marks its slot, like a TERM / AND group), or — a group whose runs
   // would pin gigabytes in every slot — the context's, with a stream sync at the end
   const bool own_runs = (size_t)postings + 64 <= RUNS_PER_SLOT_MAX;
@@ -2119,7 +2144,7 @@ static int32_t search_or_lazy_group(rgpu_segment* seg, Group& G, int32_t k, HitO
     std::memcpy(c->S->h_stage.p + o_fi, fixed_info.data(), (size_t)nq * 8);
     for (int i = 0; i < 64; ++i) reinterpret_cast<ScoredPosting*>(c->S->h_stage.p + o_sn)[i] = ScoredPosting{0x7fffffff, 0.0f};
     HOST_STAMP(h2);
-    HIP_TRY(hipMemcpyAsync(c->S->d_stage.p, c->S->h_stage.p, st.used, hipMemcpyHostToDevice, stream));
+    HIP_TRY(stage_h2d(c, st.used, stream));
     const bool own_runs = (size_t)run_slots + 128 <= RUNS_PER_SLOT_MAX;
     DevVec<ScoredPosting>& runs_buf = own_runs ? c->S->d_runs : c->d_runs;
     HIP_TRY(runs_buf.reserve((size_t)run_slots + 128, 0, stream));
@@ -2385,7 +2410,7 @@ static int32_t search_or_wide_group(rgpu_segment* seg, Group& G, int32_t k, HitO
   std::memcpy(c->S->h_stage.p + o_m, G.qmap.data(), (size_t)nq * 4);
   std::memcpy(c->S->h_stage.p + o_fi, fixed_info.data(), (size_t)nq * 8);
   std::memset(c->S->h_stage.p + o_fl, 0, (size_t)nq * 4);
-  HIP_TRY(hipMemcpyAsync(c->S->d_stage.p, c->S->h_stage.p, st.used, hipMemcpyHostToDevice, stream));
+  HIP_TRY(stage_h2d(c, st.used, stream));
   HIP_TRY(c->S->d_tau.reserve((size_t)nq, 0, stream));
   HIP_TRY(hipMemsetAsync(c->S->d_tau.p, 0, (size_t)nq * 8, stream));
   HIP_TRY(c->S->d_partial_keys.reserve((size_t)lists * (size_t)k, 0, stream));
@@ -2526,9 +2551,9 @@ static int term_item_blocks(int64_t total_blocks, int64_t target_items) {
 // to finish were single-item queries of 150-250 blocks, 26-28 us of a 29.5 us launch, while the chip stood two thirds idle). Halving
 // keeps the sizes powers of two and every item on a chunk boundary; each item starts from the term's sketch threshold, so the items of a
 // query do not wait for one another.
-static int term_query_item_blocks(int nblocks, int base, int split) {
+static int term_query_item_blocks(int nblocks, int base, int split, int floor_blocks = 64) {
   int b = base;
-  if (split > 1 && b > 0 && (b & (b - 1)) == 0) while (b > 64 && (nblocks + b - 1) / b < split) b >>= 1;
+  if (split > 1 && b > 0 && (b & (b - 1)) == 0) while (b > floor_blocks && (nblocks + b - 1) / b < split) b >>= 1;
   return b;
 }
 static int term_item_shift(int b) {  // log2 of a power-of-two item size for the item descriptor; 0: the launch's size
@@ -2540,11 +2565,11 @@ static int term_item_shift(int b) {  // log2 of a power-of-two item size for the
 // k_search_term's item descriptors: items 0 .. nq-1 are every query's first chunk, the other chunks follow query-major
 // (item_prefix[q] = chunks of the queries in front of q beyond their first); {query, chunk, term index or -1, the query's items}
 // (the query's items in the low 24 bits of .w, log2 of ITS item size above them — 0: the launch's blocks_per_item)
-static void fill_term_item_desc(int4* out, const DevQuery* queries, const DevTerm* terms, const int64_t* item_prefix, int nq, int base, int split) {
+static void fill_term_item_desc(int4* out, const DevQuery* queries, const DevTerm* terms, const int64_t* item_prefix, int nq, int base, int split, int floor_blocks) {
   for (int q = 0; q < nq; ++q) {
     const int n_mine = 1 + (int)(item_prefix[q + 1] - item_prefix[q]);
     const int ft = queries[q].n_terms >= 1 ? queries[q].first_term : -1;
-    const int sh = ft >= 0 ? term_item_shift(term_query_item_blocks(terms[ft].nblocks, base, split)) : 0;
+    const int sh = ft >= 0 ? term_item_shift(term_query_item_blocks(terms[ft].nblocks, base, split, floor_blocks)) : 0;
     const int w = n_mine | (sh << 24);
     out[q] = make_int4(q, 0, ft, w);
     int4* rest = out + nq + item_prefix[q];
@@ -2930,7 +2955,7 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
           G.item_prefix[(size_t)q] = items;
           if (G.queries[(size_t)q].n_terms >= 1) {
             const DevTerm& t = G.terms[(size_t)G.queries[(size_t)q].first_term];
-            const int mine_blocks = op == RGPU_OP_TERM ? term_query_item_blocks(t.nblocks, blocks_per_item, term_split) : blocks_per_item;
+            const int mine_blocks = op == RGPU_OP_TERM ? term_query_item_blocks(t.nblocks, blocks_per_item, term_split, c->term_min_item_blocks) : blocks_per_item;
             const int64_t mine = t.nblocks == 0 ? 1 : (t.nblocks + mine_blocks - 1) / mine_blocks;
             items += head_items ? mine - 1 : mine;
           }
@@ -2952,6 +2977,8 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
     const size_t o_p = st.add((size_t)(nq + 1) * 8);
     const size_t o_m = st.add((size_t)nq * 4);
     const size_t o_tau = st.add((size_t)nq * 8);  // the per-query shared thresholds: zeroed by the same copy that brings the plan
+    const bool term_fold = op == RGPU_OP_TERM && c->term_fold && !G.req_opt;  // k_search_term folds the item lists itself (TermMerge)
+    const size_t o_done = term_fold ? st.add((size_t)nq * 4) : 0;             // ... counting every query's finished items here
     // ReqOptScorer's rule: one record per lead posting, query after query
     const size_t o_sp = G.req_opt ? st.add((size_t)(nq + 1) * 8) : 0;
     // conjunctions: the doc bitmaps of the clauses behind the lead (parallel to the DevTerm array)
@@ -3001,11 +3028,11 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
     std::memcpy(c->S->h_stage.p + o_p, G.item_prefix.data(), (size_t)(nq + 1) * 8);
     std::memcpy(c->S->h_stage.p + o_m, G.qmap.data(), (size_t)nq * 4);
     std::memset(c->S->h_stage.p + o_tau, 0, (size_t)nq * 8);
+    if (term_fold) std::memset(c->S->h_stage.p + o_done, 0, (size_t)nq * 4);
     if (G.req_opt) std::memcpy(c->S->h_stage.p + o_sp, seq_prefix.data(), (size_t)(nq + 1) * 8);
     if (!clause_bitmaps.empty()) std::memcpy(c->S->h_stage.p + o_bm, clause_bitmaps.data(), clause_bitmaps.size() * sizeof(TermBitmap));
-    if (op == RGPU_OP_TERM) fill_term_item_desc(reinterpret_cast<int4*>(c->S->h_stage.p + o_id), G.queries.data(), G.terms.data(), G.item_prefix.data(), nq, blocks_per_item, term_split);
-    if (c->upload_aside) HIP_TRY(stage_upload(c, st.used, stream));
-    else HIP_TRY(hipMemcpyAsync(c->S->d_stage.p, c->S->h_stage.p, st.used, hipMemcpyHostToDevice, stream));
+    if (op == RGPU_OP_TERM) fill_term_item_desc(reinterpret_cast<int4*>(c->S->h_stage.p + o_id), G.queries.data(), G.terms.data(), G.item_prefix.data(), nq, blocks_per_item, term_split, c->term_min_item_blocks);
+    HIP_TRY(stage_h2d(c, st.used, stream));
     HIP_TRY(c->S->d_partial_keys.reserve((size_t)items * (size_t)k, 0, stream));
     HIP_TRY(c->S->d_partial_counts.reserve((size_t)items, 0, stream));
     unsigned long long* d_tau = reinterpret_cast<unsigned long long*>(c->S->d_stage.p + o_tau);
@@ -3074,6 +3101,9 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
       c->last_counted_dir_blocks = 0;
       c->last_counted_loose = 0;
       for (const DevTerm& t0 : G.terms) { c->last_counted_dir_blocks += t0.nblocks; c->last_counted_loose += t0.df == 1 ? 1 : t0.tail_n; }
+      const TermMerge fold = term_fold ? TermMerge{reinterpret_cast<unsigned int*>(c->S->d_stage.p + o_done), dp, hits_dev, totals_dev, c->pass.ceil_out,
+                                                   seg->doc_base, c->pass.stride, c->pass.col0}
+                                       : TermMerge{};
       TimedLaunch tl(c, stream, "k_search_term", G.postings);
       const unsigned grid = wg_count((items + TERM_WAVES - 1) / TERM_WAVES);
       const size_t lds = term_lds_bytes(wide);
@@ -3081,7 +3111,7 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         RGPU_LAUNCH(kern, dim3(grid), dim3(TERM_THREADS), lds, stream, sv, dq, dt, reinterpret_cast<const int4*>(c->S->d_stage.p + o_id), nq, items,
-                           blocks_per_item, (int)k, c->S->d_partial_keys.p, c->S->d_partial_counts.p, d_tau, c->S->d_touched.p, c->pass.ceil_in, dm);
+                           blocks_per_item, (int)k, c->S->d_partial_keys.p, c->S->d_partial_counts.p, d_tau, c->S->d_touched.p, c->pass.ceil_in, dm, fold);
         return hipSuccess;
       };
       hipError_t e;
@@ -3103,7 +3133,8 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
       continue;
     }
     // the group's rows go straight to the caller's (qmap): no scatter pass
-    if (wide) launch_merge<true>(c, stream, nq, k, dp, seg->doc_base, hits_dev, totals_dev, head_items, nullptr, nullptr, dm);
+    if (term_fold) {}  // (written by k_search_term's last wavefront per query)
+    else if (wide) launch_merge<true>(c, stream, nq, k, dp, seg->doc_base, hits_dev, totals_dev, head_items, nullptr, nullptr, dm);
     else launch_merge<false>(c, stream, nq, k, dp, seg->doc_base, hits_dev, totals_dev, head_items, nullptr, nullptr, dm);
     HIP_TRY(launch_status());
     HIP_TRY(scratch_mark(c, stream));  // no stream sync: the slot is waited for when it is taken again
@@ -3293,7 +3324,7 @@ static int32_t decode_positions_impl(rgpu_segment* seg, const rgpu_term_state* t
   std::memcpy(c->S->h_stage.p + o_t, dt.data(), dt.size() * sizeof(DevTerm));
   std::memcpy(c->S->h_stage.p + o_pt, pt.data(), pt.size() * sizeof(PosTerm));
   std::memcpy(c->S->h_stage.p + o_ip, item_prefix.data(), item_prefix.size() * 8);
-  HIP_TRY(hipMemcpyAsync(c->S->d_stage.p, c->S->h_stage.p, st.used, hipMemcpyHostToDevice, stream));
+  HIP_TRY(stage_h2d(c, st.used, stream));
   const int64_t n_tiles = (items + SCAN_TILE - 1) / SCAN_TILE;
   HIP_TRY(c->pos_counts.reserve((size_t)items + 64, 0, stream));
   HIP_TRY(c->pos_tiles.reserve((size_t)n_tiles + 8, 0, stream));
@@ -3525,7 +3556,7 @@ extern "C" int32_t rgpu_search_phrase_batch(rgpu_segment* seg, const rgpu_phrase
     // reads the region either way (the copy used to carry whatever the pinned buffer held)
     std::memset(c->S->h_stage.p + o_gr, 0xff, (size_t)n_queries * sizeof(SloppyGroups));
     if (!clause_bitmaps.empty()) std::memcpy(c->S->h_stage.p + o_bm, clause_bitmaps.data(), clause_bitmaps.size() * sizeof(TermBitmap));
-    HIP_TRY(hipMemcpyAsync(c->S->d_stage.p, c->S->h_stage.p, st.used, hipMemcpyHostToDevice, stream));
+    HIP_TRY(stage_h2d(c, st.used, stream));
     HIP_TRY(c->phrase_docs.reserve((size_t)slots + 64, 0, stream));
     HIP_TRY(c->phrase_keys.reserve((size_t)slots + 64, 0, stream));
     // (developer knob: RGPU_PHRASE_REDO_CAP=<n> shrinks the list of left-over candidates, so that a test reaches the pass that runs without it)
@@ -3790,7 +3821,7 @@ extern "C" int32_t rgpu_rescore_batch(rgpu_segment* seg, const rgpu_query* queri
   std::memcpy(c->S->h_stage.p + o_q, dq.data(), (size_t)n_queries * sizeof(DevQuery));
   if (!dt.empty()) std::memcpy(c->S->h_stage.p + o_t, dt.data(), dt.size() * sizeof(DevTerm));
   std::memcpy(c->S->h_stage.p + o_r, rp.data(), (size_t)n_queries * sizeof(RescoreParams));
-  HIP_TRY(hipMemcpyAsync(c->S->d_stage.p, c->S->h_stage.p, st.used, hipMemcpyHostToDevice, stream));
+  HIP_TRY(stage_h2d(c, st.used, stream));
   const size_t n_hits = (size_t)n_queries * (size_t)k;
   HIP_TRY(c->host_api_hits.reserve(n_hits, 0, stream));
   HIP_TRY(hipMemcpyAsync(c->host_api_hits.p, hits_inout, n_hits * sizeof(HitOut), hipMemcpyHostToDevice, stream));
@@ -4588,6 +4619,7 @@ static int32_t term_batch_fast(rgpu_segment* seg, rucene::BatchPlanner* P, int32
   const size_t o_m = st.add((size_t)nq * 4);
   const size_t o_tau = st.add((size_t)nq * 8);       // per-query shared thresholds ...
   const size_t o_w = st.add((size_t)nq * 16);        // ... and the launch's counters: zeroed by the copy that brings the plan
+  const size_t o_done = st.add((size_t)nq * 4);      // ... and the per-query counts of finished items (TermMerge::done)
   // ... and the item descriptors, LAST: their number is known only once the terms have been read (at most 262144 + nq, the item
   // loop's cap), the stage has room for the worst case and the copy takes what is used
   const size_t o_id = st.add(((size_t)262144 + (size_t)nq) * sizeof(int4));
@@ -4652,7 +4684,7 @@ static int32_t term_batch_fast(rgpu_segment* seg, rucene::BatchPlanner* P, int32
       hp[q] = items;
       if (hq[q].n_terms >= 1) {
         const int32_t nb = ht[hq[q].first_term].nblocks;
-        const int mine_blocks = term_query_item_blocks(nb, blocks_per_item, term_split);
+        const int mine_blocks = term_query_item_blocks(nb, blocks_per_item, term_split, c->term_min_item_blocks);
         items += (nb == 0 ? 1 : (nb + mine_blocks - 1) / mine_blocks) - 1;
       }
     }
@@ -4664,10 +4696,10 @@ static int32_t term_batch_fast(rgpu_segment* seg, rucene::BatchPlanner* P, int32
   if (items > 262144 + (int64_t)nq) return RGPU_OK;  // (blocks_per_item hit its ceiling on an absurd batch: the full path takes it)
   std::memset(c->S->h_stage.p + o_tau, 0, (size_t)nq * 8);
   std::memset(c->S->h_stage.p + o_w, 0, (size_t)nq * 16);
-  fill_term_item_desc(reinterpret_cast<int4*>(c->S->h_stage.p + o_id), hq, ht, hp, nq, blocks_per_item, term_split);
+  std::memset(c->S->h_stage.p + o_done, 0, (size_t)nq * 4);
+  fill_term_item_desc(reinterpret_cast<int4*>(c->S->h_stage.p + o_id), hq, ht, hp, nq, blocks_per_item, term_split, c->term_min_item_blocks);
   const size_t staged = o_id + (size_t)items * sizeof(int4);
-  if (c->upload_aside) HIP_TRY(stage_upload(c, staged, stream));
-  else HIP_TRY(hipMemcpyAsync(c->S->d_stage.p, c->S->h_stage.p, staged, hipMemcpyHostToDevice, stream));
+  HIP_TRY(stage_h2d(c, staged, stream));
   HIP_TRY(c->S->d_partial_keys.reserve((size_t)items * (size_t)k, 0, stream));
   HIP_TRY(c->S->d_partial_counts.reserve((size_t)items, 0, stream));
   unsigned long long* d_tau = reinterpret_cast<unsigned long long*>(c->S->d_stage.p + o_tau);
@@ -4685,6 +4717,9 @@ static int32_t term_batch_fast(rgpu_segment* seg, rucene::BatchPlanner* P, int32
   c->last_counted_loose = loose;
   const bool wide = k > 64;
   const bool legacy = seg->version < 1;
+  // the fold of every query's item lists happens inside k_search_term (TermMerge), unless RGPU_TERM_FOLD=0 asks for k_merge_items
+  const TermMerge fold = c->term_fold ? TermMerge{reinterpret_cast<unsigned int*>(c->S->d_stage.p + o_done), dp, hits_dev, totals_dev, nullptr, seg->doc_base, 0, 0}
+                                      : TermMerge{};
   {
     TimedLaunch tl(c, stream, "k_search_term", postings);
     const unsigned grid = wg_count((items + TERM_WAVES - 1) / TERM_WAVES);
@@ -4694,7 +4729,7 @@ static int32_t term_batch_fast(rgpu_segment* seg, rucene::BatchPlanner* P, int32
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
       RGPU_LAUNCH(kern, dim3(grid), dim3(TERM_THREADS), lds, stream, sv, dq, dt, reinterpret_cast<const int4*>(c->S->d_stage.p + o_id), nq, items,
-                         blocks_per_item, (int)k, c->S->d_partial_keys.p, c->S->d_partial_counts.p, d_tau, d_work, (const unsigned long long*)nullptr, dm);
+                         blocks_per_item, (int)k, c->S->d_partial_keys.p, c->S->d_partial_counts.p, d_tau, d_work, (const unsigned long long*)nullptr, dm, fold);
       return hipSuccess;
     };
     hipError_t e;
@@ -4702,8 +4737,10 @@ static int32_t term_batch_fast(rgpu_segment* seg, rucene::BatchPlanner* P, int32
     else e = wide ? go(k_search_term<false, true>) : go(k_search_term<false, false>);
     HIP_TRY(e);
   }
-  if (wide) launch_merge<true>(c, stream, nq, k, dp, seg->doc_base, hits_dev, totals_dev, nq, nullptr, nullptr, dm);
-  else launch_merge<false>(c, stream, nq, k, dp, seg->doc_base, hits_dev, totals_dev, nq, nullptr, nullptr, dm);
+  if (!c->term_fold) {
+    if (wide) launch_merge<true>(c, stream, nq, k, dp, seg->doc_base, hits_dev, totals_dev, nq, nullptr, nullptr, dm);
+    else launch_merge<false>(c, stream, nq, k, dp, seg->doc_base, hits_dev, totals_dev, nq, nullptr, nullptr, dm);
+  }
   HIP_TRY(launch_status());
   HIP_TRY(scratch_mark(c, stream));
   c->stats[(size_t)stat_slot(c, "fused_term_batches")].launches += 1;  // (tests ask whether this path ran: rgpu_kernel_stats)

@@ -13,7 +13,7 @@ for w in $WORK; do
     for lib in $LIBS; do
       if [ "$lib" = "default" ]; then unset RUCENE_GPU_LIB; else export RUCENE_GPU_LIB=$R/$lib; fi
       echo "== $kind docs=$docs lib=$lib rep=$rep" | tee -a $OUT/ab.log
-      DOCS=$docs timeout 600 python scripts/run_workload.py $kind ${REPS:-8} 2>&1 | tail -2 | cut -c1-1500 | tee -a $OUT/ab.log
+      DOCS=$docs timeout 600 python scripts/run_workload.py $kind ${REPS:-8} 2>&1 | tail -3 | cut -c1-1500 | tee -a $OUT/ab.log
     done
   done
 done

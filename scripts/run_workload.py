@@ -1,7 +1,7 @@
 """Minimal driver for profiling: build the 10M-doc shard, run one workload a few times through the C ABI.
 usage: run_workload.py [term|and3|or10|decode|cold|posdec|phrase2|sloppy2] [reps]   (DOCS=... sets the shard size; cold = a fresh segment per repetition:
 skip decode + block framing + alignment + tails (k_prepare_terms, k_prepare_blocks), then k_decode_terms, for every df >= 128 term)"""
-import os, sys
+import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import rucene_amd
@@ -92,6 +92,23 @@ else:
     for _ in range(reps + 2):
         s.search_uniform_device({"term": 0, "and3": 1, "and2sparse": 1}.get(kind, 2), tids, leaf, k, d_hits.data_ptr(), d_tot.data_ptr())
         ctx.synchronize()
+    # ... and the same step without the profiler's events and without a sync per call: wall time per step, one stream
+    plain = rucene_amd.Context()
+    leaf2 = rucene_amd.LeafReader.from_synthetic(seg)
+    if os.environ.get("WALL", "1") != "0":
+        s2 = rucene_amd.GpuIndexSearcher([leaf2], ctx=plain)
+        op = {"term": 0, "and3": 1, "and2sparse": 1}.get(kind, 2)
+        for _ in range(3):
+            s2.search_uniform_device(op, tids, leaf2, k, d_hits.data_ptr(), d_tot.data_ptr())
+        plain.synchronize()
+        walls = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            for _ in range(20):
+                s2.search_uniform_device(op, tids, leaf2, k, d_hits.data_ptr(), d_tot.data_ptr())
+            plain.synchronize()
+            walls.append((time.perf_counter() - t0) / 20)
+        print("wall per step, one stream, no profiling: median %.4f ms (min %.4f)" % (1e3 * sorted(walls)[2], 1e3 * min(walls)))
     if kind in ("term", "and3", "and2sparse"):
         print("last launch decoded vs covered:", ctx.last_search_counters())
 import ctypes as _C

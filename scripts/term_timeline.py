@@ -27,7 +27,7 @@ for _ in range(6):
     ctx.synchronize()
 L = C.CDLL(_lib.lib_path())
 REC = np.dtype([("t0", "<u8"), ("t1", "<u8"), ("q", "<i4"), ("chunk", "<i4"), ("blocks", "<i4"), ("unpacked", "<i4"),
-                ("d_term", "<u4"), ("d_table", "<u4"), ("d_sketch", "<u4"), ("d_pad", "<u4")])
+                ("d_term", "<u4"), ("d_table", "<u4"), ("d_sketch", "<u4"), ("d_pad", "<u4"), ("ph", "<u4", (8,))])
 buf = np.zeros(1 << 17, dtype=REC)
 n = L.rgpu_debug_trace(C.c_void_p(buf.ctypes.data), C.c_int32(buf.size))
 st = ctx.kernel_stats()["k_search_term"]
@@ -59,3 +59,20 @@ A = np.stack([rec["blocks"].astype(np.float64), np.ones(rec.size)], axis=1)
 coef, *_ = np.linalg.lstsq(A, dur, rcond=None)
 print("least squares: item us = %.4f x blocks looked at + %.2f" % tuple(coef))
 ctx.close()
+
+# shader-clock cycles per phase of term_blocks_fast (TERM_PH_ADD), for the items that unpacked something
+busy = rec["blocks"] > 0
+ph = rec["ph"][busy].astype(np.float64)
+nb = rec["blocks"][busy].astype(np.float64)
+names = ["chunk frontiers + first request", "per chunk: wait for its directory + bounds + todo", "per block: rows arrive + staged", "per block: freqs, scores, compare",
+         "per entering block: doc ids + keys", "per entering block: the group's list (offer)", "term_blocks_fast in all", "offers"]
+tot = ph[:, 6].sum()
+cyc_per_us = tot / np.maximum(1e-9, (dur[busy] - rec["d_sketch"][busy] / 100.0)).sum()
+print("phases of term_blocks_fast over %d items that unpacked blocks (%.0f blocks; ~%.0f shader cycles per us):" % (busy.sum(), nb.sum(), cyc_per_us))
+for i in range(6):
+    print("   %-52s %5.1f %% of its cycles, %7.0f cycles per unpacked block" % (names[i], 100.0 * ph[:, i].sum() / tot, ph[:, i].sum() / nb.sum()))
+print("   offers per unpacked block: %.2f; unaccounted (take(), ring bookkeeping, loop): %.1f %%" % (ph[:, 7].sum() / nb.sum(), 100.0 * (1 - ph[:, :6].sum() / tot)))
+slow = np.argsort(-dur)[:200]
+sl = rec[slow]
+phs = sl["ph"].astype(np.float64)
+print("the 200 longest items: %.1f blocks each;" % sl["blocks"].mean(), " ".join("%s %.0f %%" % (n.split(":")[0][:14], 100 * phs[:, i].sum() / phs[:, 6].sum()) for i, n in enumerate(names[:6])))

@@ -2300,7 +2300,8 @@ def test_search_counters_tell_decoded_from_covered(ctx, oracle):
     c = ctx.last_search_counters()
     assert c["op"] == 0 and c["postings_covered"] == covered
     assert 0 < c["blocks_decoded"] <= full_blocks and c["postings_decoded"] <= covered             # never more than covered (how much less
-    assert c["touched_bytes"] >= 14 * full_blocks                                                   # depends on the lists: test_gpu_fullsize.py)
+    assert c["touched_bytes"] >= (128 + 18) * c["blocks_decoded"]                                   # depends on the lists: test_gpu_fullsize.py);
+    # (an unpacked block: its norms, its directory entry — the kernel counts what it requested, chunk by chunk — and its encoded bytes)
     searcher.search_batch([B.build([T(0), T(1), T(2)], []), B.build([T(3), T(50)], [])], 10)
     c = ctx.last_search_counters()
     assert c["op"] == 1 and c["blocks_decoded"] > 0 and c["touched_bytes"] == ctx.and_touched_bytes()
