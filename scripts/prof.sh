@@ -4,7 +4,7 @@ set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 W=${1:-term}; TAG=${2:-prof}
 OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
-cd /tmp && export TMPDIR=/tmp
+cd /tmp && export TMPDIR=/tmp WALL=0  # (WALL=0: run_workload.py without its untraced wall-clock leg)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python $R/scripts/run_workload.py $W 5 > $OUT/trace.log 2>&1
 if [ "${PROF_SHORT:-0}" != "1" ]; then  # (the 100 M-doc workloads take the trace and the two HBM passes only: every pass rebuilds the shard)
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $OUT/pmc1 -o p -- python $R/scripts/run_workload.py $W 2 > $OUT/pmc1.log 2>&1
