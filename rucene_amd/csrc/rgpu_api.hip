@@ -12,6 +12,7 @@
 #include <mutex>
 #include <string>
 #include <unordered_map>
+#include <tuple>
 #include <vector>
 
 #include "../../include/rucene_gpu.h"
@@ -221,6 +222,7 @@ struct rgpu_ctx {
   // regions — but the cross-stream event wait costs 15-30 us of latency whenever the pipeline is shallow: two alternating streams
   // 0.063 against 0.047 in 20-step regions, the 3-term AND batch 0.290 against 0.258. Off by default.
   bool upload_aside = false;
+  bool host_time = false;         // RGPU_HOST_TIME=1: term_batch_fast prints where the calling thread's time goes
   bool stage_by_kernel = true;    // staged plans reach the device through k_stage_copy (RGPU_STAGE_COPY=dma: hipMemcpyAsync)
   bool term_fold = true;          // plan + search in one call, single-term batches: k_search_term folds the item lists itself (RGPU_TERM_FOLD=0: k_merge_items)
   int term_min_item_blocks = 64;  // ... and none of its items shorter than this (RGPU_TERM_MIN_ITEM_BLOCKS)
@@ -441,6 +443,49 @@ static hipError_t stage_upload(rgpu_ctx* c, size_t bytes, hipStream_t s) {
 // queue starts within 1-2 us. RGPU_STAGE_COPY=dma in the environment: hipMemcpyAsync as before; plans beyond 8 MB take it too.
 __global__ __launch_bounds__(256) void k_stage_copy(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device, size) instead of in front of every launch: it is a
+// runtime call of ~1 us on the calling thread of a 30 us step
+static hipError_t set_dynamic_lds_once(rgpu_ctx* c, const void* kern, size_t lds) {
+  static std::mutex mu;
+  static std::vector<std::tuple<const void*, int, size_t>> seen;
+  std::lock_guard<std::mutex> g(mu);
+  for (const auto& t : seen) if (std::get<0>(t) == kern && std::get<1>(t) == c->device && std::get<2>(t) >= lds) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e == hipSuccess) seen.emplace_back(kern, c->device, lds);
+  return e;
+}
+// ... and for the fused single-term call the same kernel finishes the plan on the way: the per-query thresholds / counters / finished-item
+// counts are ZEROED in place (not read over PCIe), and k_search_term's item descriptors — 16 bytes per item, 5.8 k of them on the headline
+// batch: 93 KB the host used to write and the copy to carry — are written by one thread per query from the query, its item range and its
+// item size (fill_term_item_desc's loop, on the device; it reads the HOST copy of the plan, so it does not wait for the copy next to it).
+// The calling thread's share of a headline step, RGPU_HOST_TIME=1: item loop 5.5 + descriptors and zeroes 6.8 us -> 1.4 + 0.3.
+struct TermPlanLayout {
+  uint32_t o_q, o_p, o_sh, o_id;   // DevQuery[nq], item_prefix[nq + 1], log2 item size per query (bytes), int4 descriptors out
+  uint32_t zero_from, zero_to;     // [from, to): zero-filled in d_stage instead of copied
+  int32_t nq;
+};
+__global__ __launch_bounds__(256) void k_stage_term_plan(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, size_t n16, TermPlanLayout L) {
+  const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
+  const uint4* s16 = reinterpret_cast<const uint4*>(src);
+  uint4* d16 = reinterpret_cast<uint4*>(dst);
+  for (size_t i = tid; i < n16; i += stride) {
+    const size_t off = i * 16;
+    d16[i] = (off >= L.zero_from && off < L.zero_to) ? make_uint4(0u, 0u, 0u, 0u) : s16[i];
+  }
+  const DevQuery* hq = reinterpret_cast<const DevQuery*>(src + L.o_q);
+  const int64_t* hp = reinterpret_cast<const int64_t*>(src + L.o_p);
+  int4* out = reinterpret_cast<int4*>(dst + L.o_id);
+  for (size_t q = tid; q < (size_t)L.nq; q += stride) {
+    const DevQuery Q = hq[q];
+    const int64_t p0 = hp[q];
+    const int n_mine = 1 + (int)(hp[q + 1] - p0);
+    const int ft = Q.n_terms >= 1 ? Q.first_term : -1;
+    const int w = n_mine | ((int)src[L.o_sh + q] << 24);
+    out[q] = make_int4((int)q, 0, ft, w);
+    int4* rest = out + L.nq + p0;
+    for (int ch = 1; ch < n_mine; ++ch) rest[ch - 1] = make_int4((int)q, ch, ft, w);
+  }
 }
 static hipError_t stage_h2d(rgpu_ctx* c, size_t bytes, hipStream_t s) {
   Scratch* sc = c->S;
@@ -1111,6 +1156,7 @@ extern "C" int32_t rgpu_init(int32_t device_ordinal, const rgpu_config* cfg, rgp
   if (const char* e = std::getenv("RGPU_UPLOAD_ASIDE")) c->upload_aside = std::atoi(e) != 0;
   if (const char* e = std::getenv("RGPU_AND_MEMB_ONLY")) c->memb_only_on = std::atoi(e) != 0;
   if (const char* e = std::getenv("RGPU_TERM_TARGET_ITEMS")) c->term_target_items = std::max(256, std::atoi(e));
+  if (const char* e = std::getenv("RGPU_HOST_TIME")) c->host_time = std::atoi(e) != 0;
   if (const char* e = std::getenv("RGPU_STAGE_COPY")) c->stage_by_kernel = std::strcmp(e, "dma") != 0;
   if (const char* e = std::getenv("RGPU_TERM_FOLD")) c->term_fold = std::atoi(e) != 0;
   if (const char* e = std::getenv("RGPU_TERM_MIN_ITEM_BLOCKS")) c->term_min_item_blocks = std::max(8, std::min(4096, std::atoi(e)));
@@ -1877,7 +1923,7 @@ static int32_t search_or_group(rgpu_segment* seg, Group& G, int32_t k, HitOut* h
     const size_t lds = or_lds_bytes(W, has_msm);
     const unsigned grid = (unsigned)(items2 / OR_WAVES);  // exact: items_per_query is a multiple of OR_WAVES
     auto go = [&](auto kern) -> hipError_t {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipError_t e = set_dynamic_lds_once(c, reinterpret_cast<const void*>(kern), lds);
       if (e != hipSuccess) return e;
       RGPU_LAUNCH(kern, dim3(grid), dim3(OR_THREADS), lds, stream, sv, dq, dt, drp, runs_buf.p, nq, wpq, wpi, ipq, W, (int)k,
                          c->S->d_partial_keys.p, c->S->d_partial_counts.p, c->S->d_tau.p, c->pass.ceil_in, dm);
@@ -2185,7 +2231,7 @@ static int32_t search_or_lazy_group(rgpu_segment* seg, Group& G, int32_t k, HitO
         TimedLaunch tl(c, stream, "k_or_lazy", all_postings);
         const unsigned grid = (unsigned)((int64_t)nq * n_g / LZ_WAVES);
         auto go = [&](auto kern) -> hipError_t {
-          hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+          hipError_t e = set_dynamic_lds_once(c, reinterpret_cast<const void*>(kern), lds);
           if (e != hipSuccess) return e;
           RGPU_LAUNCH(kern, dim3(grid), dim3(LZ_THREADS), lds, stream, sv, reinterpret_cast<const LazyQuery*>(c->S->d_stage.p + o_q),
                              reinterpret_cast<const LazyRun*>(c->S->d_stage.p + o_r), runs_buf.p, reinterpret_cast<const LazyClause*>(c->S->d_stage.p + o_l),
@@ -2439,7 +2485,7 @@ static int32_t search_or_wide_group(rgpu_segment* seg, Group& G, int32_t k, HitO
     const size_t lds = orx_lds_bytes(WS);
     const unsigned grid = wg_count((int64_t)nq * ipq);
     auto go = [&](auto kern) -> hipError_t {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipError_t e = set_dynamic_lds_once(c, reinterpret_cast<const void*>(kern), lds);
       if (e != hipSuccess) return e;
       RGPU_LAUNCH(kern, dim3(grid), dim3(ORX_THREADS), lds, stream, sv, dq, dt, nq, wpq, wpi, ipq, WS, (int)k,
                          c->S->d_partial_keys.p, c->S->d_partial_counts.p, c->S->d_tau.p);
@@ -3108,7 +3154,7 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
       const unsigned grid = wg_count((items + TERM_WAVES - 1) / TERM_WAVES);
       const size_t lds = term_lds_bytes(wide);
       auto go = [&](auto kern) -> hipError_t {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = set_dynamic_lds_once(c, reinterpret_cast<const void*>(kern), lds);
         if (e != hipSuccess) return e;
         RGPU_LAUNCH(kern, dim3(grid), dim3(TERM_THREADS), lds, stream, sv, dq, dt, reinterpret_cast<const int4*>(c->S->d_stage.p + o_id), nq, items,
                            blocks_per_item, (int)k, c->S->d_partial_keys.p, c->S->d_partial_counts.p, d_tau, c->S->d_touched.p, c->pass.ceil_in, dm, fold);
@@ -4601,10 +4647,29 @@ extern "C" int32_t rgpu_plan_uniform_bytes(rgpu_planner* p, int32_t op, int32_t 
 // copy (three enqueues per batch: copy, k_search_term, k_merge_items). Anything the fast pass does not handle — another op,
 // a term that is not prepared yet or lacks its block-max sketch, k > 128, a prepared-term budget, a dictionary planner — goes
 // through plan() + search_impl() inside the same call: same rows either way (tests/test_gpu_parity.py).
+// RGPU_HOST_TIME=1 in the environment: where the calling thread's time goes inside term_batch_fast, averaged over 256 calls (stderr)
+struct HostLaps {
+  static constexpr int N = 7;
+  long long ns[N] = {0, 0, 0, 0, 0, 0, 0};
+  int calls = 0;
+  std::chrono::steady_clock::time_point last;
+  void start() { last = std::chrono::steady_clock::now(); }
+  void lap(int i) { const auto t = std::chrono::steady_clock::now(); ns[i] += std::chrono::duration_cast<std::chrono::nanoseconds>(t - last).count(); last = t; }
+  void done() {
+    if (++calls < 256) return;
+    std::fprintf(stderr, "[term_batch_fast host, us per call] slot + stage room %.2f | term states -> descriptors %.2f | items %.2f | item descriptors + zeroes %.2f | "
+                         "stage copy enqueue %.2f | reserve + kernel enqueue %.2f | status + mark %.2f\n",
+                 ns[0] / 256e3, ns[1] / 256e3, ns[2] / 256e3, ns[3] / 256e3, ns[4] / 256e3, ns[5] / 256e3, ns[6] / 256e3);
+    *this = HostLaps{};
+  }
+};
 static int32_t term_batch_fast(rgpu_segment* seg, rucene::BatchPlanner* P, int32_t nq, const int64_t* ids, int32_t k, HitOut* hits_dev,
                                int64_t* totals_dev, hipStream_t stream, bool* taken) {
   rgpu_ctx* c = seg->ctx;
   *taken = false;
+  static thread_local HostLaps laps;
+  const bool timed = c->host_time;
+  if (timed) laps.start();
   const int32_t sim_table = P->sim_table();
   if (!P->flat() || k > RGPU_PASS_K || c->prepared_budget != 0 || sim_table < 0 || sim_table >= c->n_sim_tables || seg->dir_used == 0) return RGPU_OK;
   const bool want_sketch = c->term_sketches && seg->d_norms && seg->n_norm_ranks > 0 && !seg->d_live;
@@ -4617,14 +4682,17 @@ static int32_t term_batch_fast(rgpu_segment* seg, rucene::BatchPlanner* P, int32
   const size_t o_t = st.add((size_t)nq * sizeof(DevTerm));
   const size_t o_p = st.add((size_t)(nq + 1) * 8);
   const size_t o_m = st.add((size_t)nq * 4);
+  const size_t o_sh = st.add((size_t)nq);            // log2 of every query's own item size (0: the launch's)
   const size_t o_tau = st.add((size_t)nq * 8);       // per-query shared thresholds ...
   const size_t o_w = st.add((size_t)nq * 16);        // ... and the launch's counters: zeroed by the copy that brings the plan
   const size_t o_done = st.add((size_t)nq * 4);      // ... and the per-query counts of finished items (TermMerge::done)
+  const size_t o_zero_end = st.add(0);               // (the three above are one range: [o_tau, o_zero_end))
   // ... and the item descriptors, LAST: their number is known only once the terms have been read (at most 262144 + nq, the item
   // loop's cap), the stage has room for the worst case and the copy takes what is used
   const size_t o_id = st.add(((size_t)262144 + (size_t)nq) * sizeof(int4));
   HIP_TRY(c->S->h_stage.reserve(st.used));
   HIP_TRY(c->S->d_stage.reserve(st.used, 0, stream));
+  if (timed) laps.lap(0);
   DevQuery* hq = reinterpret_cast<DevQuery*>(c->S->h_stage.p + o_q);
   DevTerm* ht = reinterpret_cast<DevTerm*>(c->S->h_stage.p + o_t);
   int64_t* hp = reinterpret_cast<int64_t*>(c->S->h_stage.p + o_p);
@@ -4670,6 +4738,7 @@ static int32_t term_batch_fast(rgpu_segment* seg, rucene::BatchPlanner* P, int32
     loose += t.df == 1 ? 1 : t.tail_n;
   });
   if (bail) return RGPU_OK;  // (the slot was taken and not marked: it is simply free again)
+  if (timed) laps.lap(1);
   // items: chunks of a term's blocks; every query's first chunk is scheduled first (search_pass's rule, to the letter)
   int blocks_per_item = c->cfg.blocks_per_item;
   int term_split = 1;
@@ -4678,14 +4747,24 @@ static int32_t term_batch_fast(rgpu_segment* seg, rucene::BatchPlanner* P, int32
     term_split = c->term_split;
   }
   int64_t items = 0;
+  uint8_t* hsh = c->S->h_stage.p + o_sh;
   while (true) {
     items = 0;
+    const int base_sh = term_item_shift(blocks_per_item);  // 0: not a power of two (a caller's own size) — no per-query sizes then
+    const int floor_sh = std::max(1, term_item_shift(c->term_min_item_blocks));
     for (int q = 0; q < nq; ++q) {
       hp[q] = items;
+      hsh[q] = 0;
       if (hq[q].n_terms >= 1) {
         const int32_t nb = ht[hq[q].first_term].nblocks;
-        const int mine_blocks = term_query_item_blocks(nb, blocks_per_item, term_split, c->term_min_item_blocks);
-        items += (nb == 0 ? 1 : (nb + mine_blocks - 1) / mine_blocks) - 1;
+        if (base_sh > 0) {  // term_query_item_blocks in shifts: halve while the query has fewer than `split` items
+          int sh = base_sh;
+          if (term_split > 1) while (sh > floor_sh && ((nb + (1 << sh) - 1) >> sh) < term_split) --sh;
+          hsh[q] = (uint8_t)sh;
+          items += (nb == 0 ? 1 : (nb + (1 << sh) - 1) >> sh) - 1;
+        } else {
+          items += (nb == 0 ? 1 : (nb + blocks_per_item - 1) / blocks_per_item) - 1;
+        }
       }
     }
     hp[nq] = items;
@@ -4693,13 +4772,33 @@ static int32_t term_batch_fast(rgpu_segment* seg, rucene::BatchPlanner* P, int32
     blocks_per_item *= 2;
   }
   items += nq;
+  if (timed) laps.lap(2);
   if (items > 262144 + (int64_t)nq) return RGPU_OK;  // (blocks_per_item hit its ceiling on an absurd batch: the full path takes it)
-  std::memset(c->S->h_stage.p + o_tau, 0, (size_t)nq * 8);
-  std::memset(c->S->h_stage.p + o_w, 0, (size_t)nq * 16);
-  std::memset(c->S->h_stage.p + o_done, 0, (size_t)nq * 4);
-  fill_term_item_desc(reinterpret_cast<int4*>(c->S->h_stage.p + o_id), hq, ht, hp, nq, blocks_per_item, term_split, c->term_min_item_blocks);
-  const size_t staged = o_id + (size_t)items * sizeof(int4);
-  HIP_TRY(stage_h2d(c, staged, stream));
+  const bool plan_on_device = c->stage_by_kernel && !c->upload_aside && o_id + (size_t)items * sizeof(int4) <= 0xffffffffull;
+  if (plan_on_device) {
+    // zeroes and item descriptors are the copy kernel's work (k_stage_term_plan)
+    if (timed) laps.lap(3);
+    const size_t n16 = (o_id + 15) / 16;  // (o_id is 256-aligned: everything in front of the descriptors)
+    const TermPlanLayout L{(uint32_t)o_q, (uint32_t)o_p, (uint32_t)o_sh, (uint32_t)o_id, (uint32_t)o_tau, (uint32_t)o_zero_end, nq};
+    TimedLaunch tl(c, stream, "k_stage_term_plan", 0);
+    const unsigned grid = (unsigned)std::min<size_t>(1024, std::max<size_t>((n16 + 255) / 256, ((size_t)nq + 255) / 256));
+    RGPU_LAUNCH(k_stage_term_plan, dim3(grid), dim3(256), 0, stream, c->S->h_stage.p, c->S->d_stage.p, n16, L);
+  } else {
+    std::memset(c->S->h_stage.p + o_tau, 0, o_zero_end - o_tau);
+    int4* hd = reinterpret_cast<int4*>(c->S->h_stage.p + o_id);
+    for (int q = 0; q < nq; ++q) {  // fill_term_item_desc with the sizes the item loop chose
+      const int n_mine = 1 + (int)(hp[q + 1] - hp[q]);
+      const int ft = hq[q].n_terms >= 1 ? hq[q].first_term : -1;
+      const int w = n_mine | ((int)hsh[q] << 24);
+      hd[q] = make_int4(q, 0, ft, w);
+      int4* rest = hd + nq + hp[q];
+      for (int ch = 1; ch < n_mine; ++ch) rest[ch - 1] = make_int4(q, ch, ft, w);
+    }
+    const size_t staged = o_id + (size_t)items * sizeof(int4);
+    if (timed) laps.lap(3);
+    HIP_TRY(stage_h2d(c, staged, stream));
+  }
+  if (timed) laps.lap(4);
   HIP_TRY(c->S->d_partial_keys.reserve((size_t)items * (size_t)k, 0, stream));
   HIP_TRY(c->S->d_partial_counts.reserve((size_t)items, 0, stream));
   unsigned long long* d_tau = reinterpret_cast<unsigned long long*>(c->S->d_stage.p + o_tau);
@@ -4726,7 +4825,7 @@ static int32_t term_batch_fast(rgpu_segment* seg, rucene::BatchPlanner* P, int32
     const size_t lds = term_lds_bytes(wide);
     const SegView sv = seg_view(seg);
     auto go = [&](auto kern) -> hipError_t {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipError_t e = set_dynamic_lds_once(c, reinterpret_cast<const void*>(kern), lds);
       if (e != hipSuccess) return e;
       RGPU_LAUNCH(kern, dim3(grid), dim3(TERM_THREADS), lds, stream, sv, dq, dt, reinterpret_cast<const int4*>(c->S->d_stage.p + o_id), nq, items,
                          blocks_per_item, (int)k, c->S->d_partial_keys.p, c->S->d_partial_counts.p, d_tau, d_work, (const unsigned long long*)nullptr, dm, fold);
@@ -4741,9 +4840,11 @@ static int32_t term_batch_fast(rgpu_segment* seg, rucene::BatchPlanner* P, int32
     if (wide) launch_merge<true>(c, stream, nq, k, dp, seg->doc_base, hits_dev, totals_dev, nq, nullptr, nullptr, dm);
     else launch_merge<false>(c, stream, nq, k, dp, seg->doc_base, hits_dev, totals_dev, nq, nullptr, nullptr, dm);
   }
+  if (timed) laps.lap(5);
   HIP_TRY(launch_status());
   HIP_TRY(scratch_mark(c, stream));
   c->stats[(size_t)stat_slot(c, "fused_term_batches")].launches += 1;  // (tests ask whether this path ran: rgpu_kernel_stats)
+  if (timed) { laps.lap(6); laps.done(); }
   *taken = true;
   return RGPU_OK;
 }
