@@ -228,7 +228,7 @@ typedef struct rgpu_segment_footprint {
   int64_t norms_bytes;           /* 1 byte per doc */
   int64_t live_docs_bytes;
   int64_t positions_file_bytes;  /* the .pos bytes (rgpu_segment_attach_positions) */
-  int64_t directory_bytes;       /* prepared terms: 22 bytes per block (+ 8 for a positions field) */
+  int64_t directory_bytes;       /* prepared terms: 22 bytes per block (+ 8 for a positions field), + 8 per 64 blocks (chunk frontiers) */
   int64_t block_store_bytes;     /* prepared terms: 16-byte aligned payload rows + decoded tails */
   int64_t posting_norms_bytes;   /* prepared terms: 1 byte per posting */
   int64_t prepared_terms;        /* how many distinct terms are prepared */

@@ -595,7 +595,7 @@ static int32_t prepare_norms_locked(rgpu_segment* seg, const rgpu_term_state* co
 // posting-order norms)
 static size_t prepared_store_bytes(const rgpu_segment* seg) {
   const size_t per_slot = 4 + 4 + 4 + 2 + 8 + (seg->has_positions ? 8 : 0);  // dir_last, dir_off, dir_row, dir_hdr, dir_bmax (, dir_pos)
-  return seg->dir_used * per_slot + seg->bstore_used + seg->pnorm_used + seg->sketch_used * (size_t)TERM_SKETCH_K * 2;
+  return seg->dir_used * per_slot + seg->bstore_used + seg->pnorm_used + seg->sketch_used * (size_t)TERM_SKETCH_K * 2 + (seg->dir_used ? (seg->dir_used / 64 + 2) * 8 : 0);
 }
 // rgpu_config.prepared_budget_mib: a store over its ceiling is dropped as a whole BEFORE the arriving batch is planned — the
 // batch then prepares what it names, like a first touch (a few hundred microseconds per thousand terms; k_prepare_blocks moves
@@ -1430,7 +1430,8 @@ extern "C" int32_t rgpu_segment_get_footprint(rgpu_segment* seg, rgpu_segment_fo
   out->norms_bytes = seg->d_norms ? (int64_t)seg->max_doc : 0;
   out->live_docs_bytes = seg->d_live ? (int64_t)(((size_t)seg->max_doc + 63) / 64 * 8) : 0;
   out->positions_file_bytes = (int64_t)seg->pos_len;
-  out->directory_bytes = (int64_t)seg->dir_used * (4 + 4 + 4 + 2 + 8 + (seg->has_positions ? 8 : 0)) + (int64_t)seg->sketch_used * TERM_SKETCH_K * 2;
+  out->directory_bytes = (int64_t)seg->dir_used * (4 + 4 + 4 + 2 + 8 + (seg->has_positions ? 8 : 0)) + (int64_t)seg->sketch_used * TERM_SKETCH_K * 2 +
+                         (int64_t)(seg->dir_used ? seg->dir_used / 64 + 2 : 0) * 8;
   out->block_store_bytes = (int64_t)seg->bstore_used;
   out->posting_norms_bytes = seg->d_norms ? (int64_t)seg->pnorm_used : 0;
   out->prepared_terms = (int64_t)seg->prepared.size();
