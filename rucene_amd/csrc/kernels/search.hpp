@@ -75,9 +75,23 @@ __device__ __forceinline__ float table_score(const float* cache, uint32_t rank, 
 // `head_items` > 0 selects the TERM kernel's item layout: item q is query q's first chunk and the query's other
 // chunks are items head_items + [item_prefix[q], item_prefix[q+1]); 0 = plain contiguous ranges.
 // The fold itself — also run by the wavefront of k_search_term that finishes a query last (search_term.hpp, TermMerge):
-template <bool WIDE>
-__device__ __forceinline__ void merge_query_items(int q, int64_t i0, int64_t n_mine, int head_items, int k, const uint64_t* __restrict__ partial_keys,
-                                                  const int32_t* __restrict__ partial_counts, WaveTopK& top, int64_t& total, int lane) {
+// COHERENT: the lists were written by other wavefronts of THIS launch, through other XCDs' L2s, which are not coherent with this one's
+// inside a launch. The one mechanism that is: read-modify-write atomics at agent scope, performed at the memory side. The writers
+// EXCHANGE their keys and counts in (search_term.hpp), this reader fetches them with an OR of zero. (Measured first, round 6: agent-scope
+// atomic STORES + a wait for their acknowledgement on the writer's side, an acquire fence + plain loads — or agent-scope atomic LOADS —
+// on the reader's: scripts/fold_race_probe.py, batches of alternating item layouts, found a stale count or list in 5 of 3000
+// launches either way: an acknowledged store has reached the writer's L2, not the memory behind it.) false: a finished launch's lists.
+template <bool WIDE, bool COHERENT = false>
+__device__ __forceinline__ void merge_query_items(int q, int64_t i0, int64_t n_mine, int head_items, int k, const uint64_t* partial_keys,
+                                                  const int32_t* partial_counts, WaveTopK& top, int64_t& total, int lane) {
+  auto key_at = [&](const uint64_t* p) -> uint64_t {
+    if (!COHERENT) return *p;
+    return (uint64_t)__hip_atomic_fetch_or(reinterpret_cast<unsigned long long*>(const_cast<uint64_t*>(p)), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  auto count_at = [&](const int32_t* p) -> int32_t {
+    if (!COHERENT) return *p;
+    return __hip_atomic_fetch_or(const_cast<int32_t*>(p), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
   uint64_t tau = 0;
   auto item_at = [&](int64_t j) -> int64_t {  // j-th item of this query
     if (head_items > 0) return j == 0 ? (int64_t)q : (int64_t)head_items + i0 + j - 1;
@@ -88,8 +102,8 @@ __device__ __forceinline__ void merge_query_items(int q, int64_t i0, int64_t n_m
     // enter the current top-k is skipped without reading the rest of its list
     const bool ok = g0 + lane < n_mine;
     const int64_t mine = ok ? item_at(g0 + lane) : 0;
-    const uint64_t head = ok ? partial_keys[(size_t)mine * (size_t)k] : 0ull;
-    total += wave_reduce_add(ok ? partial_counts[mine] : 0);
+    const uint64_t head = ok ? key_at(partial_keys + (size_t)mine * (size_t)k) : 0ull;
+    total += wave_reduce_add(ok ? count_at(partial_counts + mine) : 0);
     uint64_t m = __ballot(head > tau);
     while (m) {
       // the lists of up to MERGE_AHEAD entering items are requested together (one list after the other was a chain of dependent
@@ -106,8 +120,8 @@ __device__ __forceinline__ void merge_query_items(int q, int64_t i0, int64_t n_m
           const int src = __builtin_ctzll(rest);
           rest &= rest - 1;
           const uint64_t* pk = partial_keys + (size_t)item_at(g0 + src) * (size_t)k;
-          ka[j] = lane < k ? pk[lane] : 0ull;
-          if (WIDE) kb[j] = lane + 64 < k ? pk[lane + 64] : 0ull;
+          ka[j] = lane < k ? key_at(pk + lane) : 0ull;
+          if (WIDE) kb[j] = lane + 64 < k ? key_at(pk + lane + 64) : 0ull;
         }
       }
 #pragma unroll

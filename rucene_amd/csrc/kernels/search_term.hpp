@@ -713,8 +713,9 @@ __global__ __launch_bounds__(TERM_THREADS, (LEGACY || WIDE) ? RGPU_TERM_OTHER_WA
   if (lane == 0 && item < TERM_TRACE_CAP) g_term_trace[item] = TermTraceRec{trace_t0, (unsigned long long)wall_clock64(), q, chunk, (int32_t)looked, (int32_t)(touched / 256u), tr_term, tr_table, tr_sketch, 0u, {ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[6], ph[7]}};
 #endif
   // the wave of a group that finishes last emits the group's list; the other items emit empty lists
+  int32_t count_seen = 0;
   if (lane == 0) {
-    if (fold.done != nullptr) __hip_atomic_store(partial_counts + item, count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (fold.done != nullptr) count_seen = __hip_atomic_exchange(partial_counts + item, count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else partial_counts[item] = count;
   }
   if (work_slots != nullptr && lane == 0 && (looked | touched) != 0u) {  // per query: one address for the whole launch would serialise thousands of wavefronts
@@ -738,19 +739,22 @@ __global__ __launch_bounds__(TERM_THREADS, (LEGACY || WIDE) ? RGPU_TERM_OTHER_WA
     return;
   }
   // (a release fence at agent scope here — buffer_wbl2: the whole L2's dirty lines, once per item — was measured: k_search_term 0.028 ->
-  // 0.085 ms. The list and the count go out as agent-scope stores instead, which write through the XCD's L2 on their own; the
-  // workgroup-scope fence is the wait for their acknowledgement, and only then the item counts itself.)
-  if (lane < k) __hip_atomic_store(pk + lane, top.a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (WIDE && lane + 64 < k) __hip_atomic_store(pk + lane + 64, top.b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  // 0.085 ms; agent-scope atomic STORES and a wait for their acknowledgement were built next and are not enough: the XCDs' L2s are
+  // not coherent with one another inside a launch, and 5 launches in 3000 folded a stale list or count — scripts/fold_race_probe.py.
+  // The list and the count are EXCHANGED in: read-modify-write atomics at agent scope are performed at the memory side, like the
+  // counter below. Their returned values are waited for before the item counts itself.)
+  unsigned long long seen_a = 0ull, seen_b = 0ull;
+  if (lane < k) seen_a = __hip_atomic_exchange(reinterpret_cast<unsigned long long*>(pk) + lane, (unsigned long long)top.a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (WIDE && lane + 64 < k) seen_b = __hip_atomic_exchange(reinterpret_cast<unsigned long long*>(pk) + lane + 64, (unsigned long long)top.b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("" :: "v"(seen_a), "v"(seen_b), "v"(count_seen) : "memory");  // (the exchanges have returned: they are performed)
   uint32_t finished = 0;
   if (lane == 0) finished = __hip_atomic_fetch_add(fold.done + q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   finished = (uint32_t)readfirstlane((int)finished) + 1u;
   if (finished != (uint32_t)q_items) return;
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");  // (ordering only: every read below is itself performed at the memory side)
   WaveTopK all;
   int64_t total = 0;
-  merge_query_items<WIDE>(q, fold.item_prefix[q], (int64_t)q_items, n_queries, k, partial_keys, partial_counts, all, total, lane);
+  merge_query_items<WIDE, true>(q, fold.item_prefix[q], (int64_t)q_items, n_queries, k, partial_keys, partial_counts, all, total, lane);
   const int row = qmap ? qmap[q] : q;
   HitOut* out = fold.hits + (size_t)row * (size_t)(fold.out_stride > 0 ? fold.out_stride : k) + fold.col0;
   if (fold.ceil_out != nullptr) {

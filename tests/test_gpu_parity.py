@@ -2373,3 +2373,156 @@ def test_k_above_128_runs_in_passes(zipf, oracle, k):
     with pytest.raises(rucene_amd.RgpuError) as e:
         gsearcher.search_batch([T(3)], 1025)
     assert e.value.status == -5
+
+
+@pytest.mark.gpu
+def test_single_term_lists_around_every_chunk_and_item_boundary(oracle):
+    """Round 6's k_search_term: chunk frontiers (one word per WHOLE chunk of 64 blocks, SegView::dir_sum), items sized per query
+    (powers of two, >= 64 blocks, a list cut into >= 8 of them), sketches from 16 blocks up, the fold of a query's item lists by
+    its last item, the plan expanded on the device (k_stage_term_plan). Lists of 15 .. 4200 FullBlocks whose lengths sit ON, one
+    below and one above the boundaries those rules have (16, 64, 128, 512, 1024, 4096 blocks; with and without a tail), all in one
+    batch — so that the launch's own item size is large and every list takes its own — and again one list at a time (the launch
+    size is then small: items below 64 blocks, no frontiers). Every row against the oracle, bit for bit, through the two-call path,
+    the fused call, and the fused call under each of the environment's A/B switches; a caller's own blocks_per_item (not a power
+    of two) on top. Scores tie heavily on purpose (three field lengths, freqs 1..3): the strict / non-strict side of the bound
+    tests is what a wrong frontier would break."""
+    import os
+    import torch
+    import rucene_amd
+    from rucene_amd import indexgen
+    from rucene_amd import _lib as gpu
+    max_doc = 700_000
+    rng = np.random.default_rng(606)
+    blocks = [15, 16, 17, 63, 64, 65, 127, 128, 129, 511, 512, 513, 1023, 1024, 1025, 2047, 2048, 4095, 4096, 4200]
+    lists = []
+    for i, nb in enumerate(blocks):
+        df = 128 * nb + (0 if i % 3 == 0 else int(rng.integers(1, 128)))
+        docs = np.sort(rng.permutation(max_doc)[:df]).astype(np.int32)
+        freqs = rng.integers(1, 4, size=df).astype(np.int32)
+        # a few postings that beat everything else, far apart: whole chunks in between can be skipped
+        freqs[rng.integers(0, df, size=5)] = 9
+        lists.append((docs, freqs))
+    norms = rng.choice(np.array([100, 110, 124], dtype=np.uint8), size=max_doc)
+    seg = indexgen.build_explicit(max_doc, lists, norms=norms)
+    oseg = oracle.Segment(seg.doc_bytes, seg.norms, max_doc, seg.terms, sum_total_term_freq=30 * max_doc)
+    osearcher = oracle.Searcher([oseg])
+    ids = np.arange(len(blocks), dtype=np.int64).reshape(-1, 1)
+    want = {}
+    for k in (10, 100):
+        want[k] = [osearcher.search(oracle.OP_TERM, [int(t)], k, tie_mode=oracle.TIE_CANONICAL) for t in ids[:, 0]]
+
+    def check(rows, totals, k, picked, what):
+        for j, t in enumerate(picked):
+            d, sc, total = want[k][int(t)]
+            assert totals[j] == total, (what, k, int(t))
+            assert (rows[j]["doc"][:d.size] == d).all() and (rows[j]["doc"][d.size:] == -1).all(), (what, k, int(t), blocks[int(t)])
+            assert (rows[j]["score"][:d.size].view(np.int32) == sc.view(np.int32)).all(), (what, k, int(t))
+
+    def run(env, cfg, what):
+        saved = {n: os.environ.get(n) for n in env}
+        os.environ.update(env)
+        try:
+            ctx2 = rucene_amd.Context(profile_kernels=True, **cfg)
+        finally:
+            for n, v in saved.items():
+                if v is None:
+                    os.environ.pop(n, None)
+                else:
+                    os.environ[n] = v
+        try:
+            leaf = rucene_amd.LeafReader(seg.doc_bytes, seg.norms, max_doc, seg.terms, sum_total_term_freq=30 * max_doc)
+            g = rucene_amd.GpuIndexSearcher([leaf], ctx=ctx2)
+            for k in (10, 100):
+                for picked in (ids[:, 0], ids[4:5, 0], ids[12:14, 0], ids[::-1, 0].copy()):
+                    sel = picked.reshape(-1, 1)
+                    nq = sel.shape[0]
+                    # the two-call path first (it prepares the terms and builds their sketches), then the fused call
+                    qs, ts = g.pack_uniform(gpu.OP_TERM, sel, leaf)
+                    for fused in (False, True):
+                        hits = torch.full((nq, k), -3, dtype=torch.int64, device="cuda")
+                        totals = torch.full((nq,), -3, dtype=torch.int64, device="cuda")
+                        torch.cuda.synchronize()
+                        if fused:
+                            g.search_uniform_device(gpu.OP_TERM, sel, leaf, k, hits.data_ptr(), totals.data_ptr())
+                        else:
+                            leaf.segment.search_batch_device(qs, ts, k, hits.data_ptr(), totals.data_ptr())
+                        ctx2.synchronize()
+                        rows = hits.cpu().numpy().view(gpu.HIT_DTYPE).reshape(nq, k)
+                        check(rows, totals.cpu().numpy(), k, picked, "%s, %s" % (what, "fused" if fused else "two calls"))
+            st = ctx2.kernel_stats()
+            assert st.get("fused_term_batches", {"launches": 0})["launches"] >= 8, what
+            return st
+        finally:
+            ctx2.close()
+
+    st = run({}, {}, "defaults")
+    assert "k_chunk_frontiers" in st and "k_stage_term_plan" in st          # the frontiers were built; the plan was expanded on the device
+    assert st.get("k_merge_items", {"launches": 0})["launches"] == 0        # ... and every fold happened inside k_search_term
+    st = run({"RGPU_TERM_FOLD": "0"}, {}, "k_merge_items in a launch of its own")
+    assert st["k_merge_items"]["launches"] > 0
+    st = run({"RGPU_STAGE_COPY": "dma"}, {}, "plans by hipMemcpyAsync, descriptors written by the host")
+    assert "k_stage_term_plan" not in st and "k_stage_copy" not in st
+    run({"RGPU_TERM_SPLIT": "1", "RGPU_TERM_TARGET_ITEMS": "256"}, {}, "one item size for all, few long items")
+    run({"RGPU_TERM_SPLIT": "32", "RGPU_TERM_MIN_ITEM_BLOCKS": "16"}, {}, "many short items, below a chunk")
+    run({"RGPU_TERM_SKETCH": "0"}, {}, "no sketches: every item starts without a threshold")
+    run({}, {"blocks_per_item": 96}, "a caller's own item size, not a power of two")
+    run({}, {"blocks_per_item": 8192}, "items of more than 64 chunks: no frontiers")
+
+
+@pytest.mark.gpu
+def test_the_fold_inside_the_launch_reads_no_stale_list(oracle):
+    """k_search_term's last item of a query folds the query's item lists (TermMerge) — lists and counts that OTHER wavefronts of the
+    same launch wrote through other XCDs' L2s. Batches of different item layouts alternate, so that a list or count left over from
+    the launch before (in memory, or in a stale line of the reader's L2) shows as a wrong total or row; the same batch over and
+    over would hide it (stale = fresh). Round 6's first protocol — agent-scope atomic stores + a wait, acquire fence + loads —
+    failed this in ~2 launches per 1000 (scripts/fold_race_probe.py); exchanges and fetch-ORs performed at the memory side do not."""
+    import torch
+    import rucene_amd
+    from rucene_amd import indexgen
+    from rucene_amd import _lib as gpu
+    max_doc = 400_000
+    rng = np.random.default_rng(77)
+    blocks = [15, 16, 17, 63, 64, 65, 127, 128, 129, 511, 512, 513, 1023, 1024, 1025, 2047, 2048, 2500]
+    lists = []
+    for i, nb in enumerate(blocks):
+        df = 128 * nb + (0 if i % 3 == 0 else int(rng.integers(1, 128)))
+        docs = np.sort(rng.permutation(max_doc)[:df]).astype(np.int32)
+        lists.append((docs, rng.integers(1, 4, size=df).astype(np.int32)))
+    norms = rng.choice(np.array([100, 110, 124], dtype=np.uint8), size=max_doc)
+    seg = indexgen.build_explicit(max_doc, lists, norms=norms)
+    dfs = np.array([l[0].size for l in lists])
+    oseg = oracle.Segment(seg.doc_bytes, seg.norms, max_doc, seg.terms, sum_total_term_freq=30 * max_doc)
+    osearcher = oracle.Searcher([oseg])
+    n = len(blocks)
+    batches = [np.arange(n)[::-1].copy(), np.arange(12, 14), np.arange(n), np.arange(4, 5), np.array([17, 0, 16, 1, 15, 2, 6, 6, 6, 9]), np.arange(6, n)]
+    batches = [b.astype(np.int64).reshape(-1, 1) for b in batches]
+    k = 10
+    ctx2 = rucene_amd.Context()
+    try:
+        leaf = rucene_amd.LeafReader(seg.doc_bytes, seg.norms, max_doc, seg.terms, sum_total_term_freq=30 * max_doc)
+        g = rucene_amd.GpuIndexSearcher([leaf], ctx=ctx2)
+        packed = [g.pack_uniform(gpu.OP_TERM, b, leaf) for b in batches]
+        want = []
+        for b in batches:
+            rows = np.zeros((b.shape[0], k), dtype=gpu.HIT_DTYPE)
+            for j, t in enumerate(b[:, 0]):
+                d, sc, total = osearcher.search(oracle.OP_TERM, [int(t)], k, tie_mode=oracle.TIE_CANONICAL)
+                assert total == dfs[int(t)] and d.size == k
+                rows[j]["doc"], rows[j]["score"] = d, sc
+            want.append(rows.view(np.int64).reshape(b.shape[0], k))
+        pick = np.random.default_rng(1)
+        for it in range(500):
+            bi = int(pick.integers(0, len(batches)))
+            ids = batches[bi]
+            for fused in (False, True):
+                hits = torch.full((ids.shape[0], k), -3, dtype=torch.int64, device="cuda")
+                totals = torch.full((ids.shape[0],), -3, dtype=torch.int64, device="cuda")
+                if fused:
+                    g.search_uniform_device(gpu.OP_TERM, ids, leaf, k, hits.data_ptr(), totals.data_ptr())
+                else:
+                    leaf.segment.search_batch_device(packed[bi][0], packed[bi][1], k, hits.data_ptr(), totals.data_ptr())
+                ctx2.synchronize()
+                assert (totals.cpu().numpy() == dfs[ids[:, 0]]).all(), (it, bi, fused)
+                assert (hits.cpu().numpy() == want[bi]).all(), (it, bi, fused)
+    finally:
+        ctx2.close()
