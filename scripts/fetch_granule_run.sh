@@ -1,7 +1,9 @@
 #!/bin/bash
+# The FETCH_SIZE calibration of profiles/r06_fetch_granule.txt (scripts/microbench/fetch_granule.hip under rocprofv3 --pmc FETCH_SIZE), behind the GPU suite
+# and the batch-of-one probe. usage (GPU box): bash scripts/fetch_granule_run.sh [tag]
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$R/gpurun_out/r6e; mkdir -p $OUT
+OUT=$R/gpurun_out/${1:-fetch_granule}; mkdir -p $OUT
 cd $R
 timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1; echo "pytest rc=$?"
 tail -3 $OUT/pytest.log | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl"

@@ -40,8 +40,8 @@ ctx.synchronize()
 print("wall per call, 400 back to back + one sync: %.1f us" % (1e6 * (time.perf_counter() - t0) / 400))
 
 # regions of K calls, synchronized on both sides (the bench's timed region), one stream and two alternating ones
-st = [torch.cuda.Stream(), torch.cuda.Stream()]
-bufs = [(h, t), (torch.empty_like(h), torch.empty_like(t))]
+st = [torch.cuda.Stream() for _ in range(4)]
+bufs = [(h, t)] + [(torch.empty_like(h), torch.empty_like(t)) for _ in range(3)]
 def region(K, n_streams):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -51,7 +51,7 @@ def region(K, n_streams):
     torch.cuda.synchronize()
     return 1e6 * (time.perf_counter() - t0) / K
 for K in (20, 100, 400):
-    for ns in (1, 2):
+    for ns in (1, 2, 3, 4):
         r = sorted(region(K, ns) for _ in range(9))
         print("regions of %3d calls on %d caller stream(s): %.1f us per call (median of 9; min %.1f)" % (K, ns, r[4], r[0]))
 
