@@ -152,6 +152,18 @@ typedef enum rgpu_query_op {
  * reference's bit for bit. rgpu_config.req_opt_rule = -1 always adds the optional sums instead (one pass; doc ids and hit
  * counts equal the reference's, scores >= its and equal wherever it did not skip). */
 #define RGPU_OP_WITH_SHOULD(op, n_should) ((int32_t)(op) | ((int32_t)(n_should) << 16))
+/* RGPU_OP_SHOULD_REQUIRED on top of RGPU_OP_WITH_SHOULD: the n SHOULD clauses are a MUST clause of their own — the tree
+ * "+a +(b c)", a should-only BooleanQuery (min_should_match <= 1) nested under MUST, which BooleanWeight::create_scorer turns into
+ * ConjunctionScorer([TermScorer(a) ..., DisjunctionSumScorer(b, c)]) (query/boolean_query.rs:200-215, 217-233;
+ * scorer/conjunction_scorer.rs:27-43). A doc matches when every MUST clause AND at least one of the n SHOULD clauses hold it; its
+ * score is the MUST sum (cost order) plus the disjunction's own sum (clause order) — ConjunctionScorer::score (:87-95) with the
+ * disjunction as its LAST child, which is where the stable sort by cost puts it when the SHOULD clauses' doc freqs add up to more
+ * than any MUST clause's doc freq (with a single MUST clause the f32 add commutes and any order is exact). The host mirrors send a
+ * tree here only then; otherwise the sums agree within 1e-5 relative, not bit for bit. ReqOptScorer's doc-to-doc rule does not
+ * apply (there is no ReqOptScorer in this tree), rgpu_config.req_opt_rule is not consulted. 1 <= n <= 9 (ten or more children
+ * sum in heap order: disjunction_scorer.rs:41-45); every SHOULD clause absent from the leaf = the nested weight has no scorer =
+ * the query matches nothing there (boolean_query.rs:203-207). */
+#define RGPU_OP_SHOULD_REQUIRED ((int32_t)1 << 24)
 
 typedef struct rgpu_query {
   int32_t op;          /* rgpu_query_op (OR: optionally RGPU_OP_OR_MSM(msm); TERM / AND: optionally RGPU_OP_WITH_SHOULD(op, n) —

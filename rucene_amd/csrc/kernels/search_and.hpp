@@ -279,6 +279,10 @@ __global__ __launch_bounds__(AND_WG_THREADS, AND_WAVES_PER_SIMD) void k_search_a
     const int n_clauses = HAS_OPT ? n_req_not + ((Q.op >> 16) & 0xff) : n_req_not;
     float r0 = 0.f, r1 = 0.f;  // required sums, parked while s0 / s1 collect the optional sum
     bool in_opt = false;
+    // RGPU_OP_SHOULD_REQUIRED ("+a +(b c)": the SHOULD clauses are a DisjunctionSumScorer among the ConjunctionScorer's children,
+    // boolean_query.rs:200-215): a candidate that none of them holds is no match. Bit 0 / 1: candidate 0 / 1 was found in one.
+    const bool need_any = HAS_OPT && (Q.op & (1 << 24)) != 0;  // wave-uniform
+    uint32_t any_opt = 0u;
     if (RGPU_AND_FAST && ti_start == 2) {  // the first clause's score, added where the clause loop would have added it
       const DevTerm T1 = terms[Q.first_term + 1];
       use_table(T1.sim_table);
@@ -298,14 +302,15 @@ __global__ __launch_bounds__(AND_WG_THREADS, AND_WAVES_PER_SIMD) void k_search_a
       }
       // what finding / missing a candidate in this clause means (the norm is looked up on the spot: finds are rare, and
       // two more registers held across the block loop are not)
-      auto found = [&](bool& alive, float& s, uint32_t fq, uint32_t nb) {
+      auto found = [&](uint32_t which, bool& alive, float& s, uint32_t fq, uint32_t nb) {
         if (excl) alive = false; else s += bm25_score(wk, (float)(int32_t)fq, has_norms ? cache[nb] : k1);
+        if (HAS_OPT && opt) any_opt |= which;
       };
       const uint32_t n0 = nn & 0xffu, n1 = nn >> 8;
       auto missed = [&](bool& alive) { if (!excl && !opt) alive = false; };
       if (T.df == 1) {
-        if (a0) { if (d0 == T.singleton_doc) found(a0, s0, (uint32_t)T.singleton_freq, n0); else missed(a0); }
-        if (a1) { if (d1 == T.singleton_doc) found(a1, s1, (uint32_t)T.singleton_freq, n1); else missed(a1); }
+        if (a0) { if (d0 == T.singleton_doc) found(1u, a0, s0, (uint32_t)T.singleton_freq, n0); else missed(a0); }
+        if (a1) { if (d1 == T.singleton_doc) found(2u, a1, s1, (uint32_t)T.singleton_freq, n1); else missed(a1); }
         continue;
       }
       if (bitmaps != nullptr && bitmaps[Q.first_term + ti].words != nullptr) {
@@ -322,8 +327,8 @@ __global__ __launch_bounds__(AND_WG_THREADS, AND_WAVES_PER_SIMD) void k_search_a
           const bool g0 = a0 && v0 != 0u, g1 = a1 && v1 != 0u;
           touched += 4u * (uint32_t)(__popcll(__ballot(a0)) + __popcll(__ballot(a1)));
           if (!__ballot((g0 && v0 == 15u) || (g1 && v1 == 15u))) {
-            if (a0) { if (g0) found(a0, s0, v0, n0); else missed(a0); }
-            if (a1) { if (g1) found(a1, s1, v1, n1); else missed(a1); }
+            if (a0) { if (g0) found(1u, a0, s0, v0, n0); else missed(a0); }
+            if (a1) { if (g1) found(2u, a1, s1, v1, n1); else missed(a1); }
             continue;
           }
           // (some freq is 15 or more: the general probe below answers this clause for all of the lanes)
@@ -344,8 +349,8 @@ __global__ __launch_bounds__(AND_WG_THREADS, AND_WAVES_PER_SIMD) void k_search_a
           }
         }
         touched += 8u * (uint32_t)(__popcll(__ballot(a0)) + __popcll(__ballot(a1))) + (uint32_t)(__popcll(__ballot(h0)) + __popcll(__ballot(h1)));
-        if (a0) { if (h0) found(a0, s0, fq0, n0); else missed(a0); }
-        if (a1) { if (h1) found(a1, s1, fq1, n1); else missed(a1); }
+        if (a0) { if (h0) found(1u, a0, s0, fq0, n0); else missed(a0); }
+        if (a1) { if (h1) found(2u, a1, s1, fq1, n1); else missed(a1); }
         continue;
       }
       AND_DBG(3, 1);
@@ -402,8 +407,8 @@ __global__ __launch_bounds__(AND_WG_THREADS, AND_WAVES_PER_SIMD) void k_search_a
             return got;
           };
           const uint64_t got0 = collect(k0, d0, fq0), got1 = collect(k1m, d1, fq1);
-          if (h0) { if ((got0 >> lane) & 1ull) found(a0, s0, fq0, n0); else missed(a0); }
-          if (h1) { if ((got1 >> lane) & 1ull) found(a1, s1, fq1, n1); else missed(a1); }
+          if (h0) { if ((got0 >> lane) & 1ull) found(1u, a0, s0, fq0, n0); else missed(a0); }
+          if (h1) { if ((got1 >> lane) & 1ull) found(2u, a1, s1, fq1, n1); else missed(a1); }
         }
         wave_sync();  // the filter is rewritten by the next block
       };
@@ -497,6 +502,10 @@ __global__ __launch_bounds__(AND_WG_THREADS, AND_WAVES_PER_SIMD) void k_search_a
 #endif
         }
       }
+    }
+    if (HAS_OPT && need_any) {
+      a0 = a0 && (any_opt & 1u) != 0u;
+      a1 = a1 && (any_opt & 2u) != 0u;
     }
     if (HAS_OPT && seq_out != nullptr) {
       const int32_t ord = ord0 + 2 * lane;  // ordinals below the lead's doc_freq are postings (a tail fills only some lanes)

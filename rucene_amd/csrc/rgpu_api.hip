@@ -2701,7 +2701,12 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
   for (int32_t q = 0; q < n_queries; ++q) {
     const rgpu_query& Q = queries[q];
     const int qop = Q.op & 0xff, qmsm = (Q.op >> 8) & 0xff, qopt = (Q.op >> 16) & 0xff;
-    if (qop < RGPU_OP_TERM || qop > RGPU_OP_OR || (Q.op >> 24) != 0) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "unknown query op");
+    if (qop < RGPU_OP_TERM || qop > RGPU_OP_OR || (Q.op & ~(0xffffff | RGPU_OP_SHOULD_REQUIRED)) != 0) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "unknown query op");
+    // "+a +(b c)": the SHOULD clauses as a nested disjunction under MUST (ConjunctionScorer over the MUST clauses and one
+    // DisjunctionSumScorer). Ten or more children would sum in heap order (disjunction_scorer.rs:41-45): not served here.
+    if ((Q.op & RGPU_OP_SHOULD_REQUIRED) && (qop == RGPU_OP_OR || qopt < 1))
+      return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "RGPU_OP_SHOULD_REQUIRED goes with RGPU_OP_WITH_SHOULD(TERM / AND, n >= 1)");
+    if ((Q.op & RGPU_OP_SHOULD_REQUIRED) && qopt >= 10) return fail(RGPU_ERR_UNSUPPORTED, "a required disjunction of ten or more clauses sums in heap order");
     // min_should_match beside MUST clauses is legal and has no effect: ReqOptScorer only ever advance()s the optional
     // DisjunctionSumScorer, and advance() does not look at the count (disjunction_scorer.rs approximate_advance)
     if (qmsm > 1 && qop != RGPU_OP_OR && qopt == 0) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "min_should_match needs SHOULD clauses");
@@ -2855,6 +2860,7 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
       mine_bytes.push_back(t.state.doc_freq > 128 && t.state.skip_offset > 0 ? t.state.skip_offset : 2 * (int64_t)t.state.doc_freq);
     }
     if (dead) mine.clear();
+    const bool should_required = (Q.op & RGPU_OP_SHOULD_REQUIRED) != 0;
     // MUST_NOT clauses (boolean_query.rs:235-252): absent terms drop out; without a positive scorer there is none
     if (!mine.empty()) {
       for (int i = 0; i < qopt; ++i) {  // SHOULD next to MUST (boolean_query.rs:217-233): absent terms drop out
@@ -2865,7 +2871,9 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
         if (rc != RGPU_OK) return rc;
         mine_opt.push_back(dt);
       }
-      for (int i = 0; i < Q.n_must_not; ++i) {
+      // the nested disjunction has no scorer in this leaf = a MUST weight without a scorer: nothing matches (boolean_query.rs:203-207)
+      if (should_required && mine_opt.empty()) mine.clear();
+      for (int i = 0; i < Q.n_must_not && !mine.empty(); ++i) {
         const rgpu_query_term& t = terms[Q.first_term + Q.n_terms + qopt + i];
         if (t.state.doc_freq <= 0) continue;
         DevTerm dt;
@@ -2898,7 +2906,8 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
       groups.back().op = RGPU_OP_OR;
       cur_group[2] = (int)groups.size() - 1;
     }
-    const bool to_req_opt = gop == RGPU_OP_AND && !mine_opt.empty() && !mine.empty() && c->cfg.req_opt_rule >= 0;
+    // (a required disjunction is a child of the ConjunctionScorer: plain f32 sums, no ReqOptScorer in that tree)
+    const bool to_req_opt = gop == RGPU_OP_AND && !mine_opt.empty() && !mine.empty() && c->cfg.req_opt_rule >= 0 && !should_required;
     if (to_req_opt) {  // one record per lead posting: keep a group's records under 1 GiB
       const int64_t lead_df = mine[0].df;
       if (req_opt_records > 0 && req_opt_records + lead_df > (64ll << 20)) {
@@ -2914,7 +2923,8 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
     DevQuery dq;
     // the window kernel reads min_should_match from the second byte, the conjunction kernel its optional clause count
     // from the third; device clause order: MUST, MUST_NOT, SHOULD
-    dq.op = gop | ((qmsm > 1 && gop == RGPU_OP_OR) ? qmsm << 8 : 0) | ((int32_t)mine_opt.size() << 16);
+    dq.op = gop | ((qmsm > 1 && gop == RGPU_OP_OR) ? qmsm << 8 : 0) | ((int32_t)mine_opt.size() << 16) |
+            ((should_required && !mine.empty()) ? RGPU_OP_SHOULD_REQUIRED : 0);
     dq.first_term = (int32_t)G.terms.size();
     dq.n_terms = (int32_t)mine.size();
     dq.pad = (int32_t)mine_not.size();

@@ -18,7 +18,7 @@ resolves terms, computes BM25 weights (via the C ABI's host helper) and packs qu
 import numpy as np
 
 from . import _lib
-from ._lib import OP_AND, OP_OR, OP_TERM, QUERY_DTYPE, QUERY_TERM_DTYPE, TERM_STATE_DTYPE, RgpuError
+from ._lib import OP_AND, OP_OR, OP_SHOULD_REQUIRED, OP_TERM, QUERY_DTYPE, QUERY_TERM_DTYPE, TERM_STATE_DTYPE, RgpuError
 
 
 class CollectionStatistics:
@@ -318,6 +318,22 @@ class BooleanQuery:
             return None   # (min_should_match counts the OUTER clauses: folding would change what it counts)
         return BooleanQuery([], shoulds, self.min_should_match, self.must_not_queries, [])
 
+    def required_disjunction(self):
+        """"+a +(b c)": MUST TermQuery clauses and exactly ONE MUST clause that is a should-only BooleanQuery of 1..9 terms
+        (min_should_match <= 1), no SHOULD clause of its own -> (that nested query) else None. BooleanWeight::create_scorer builds
+        ConjunctionScorer([TermScorer ..., DisjunctionSumScorer]) for it (boolean_query.rs:200-215); the C ABI takes it as
+        RGPU_OP_WITH_SHOULD(AND, n) | RGPU_OP_SHOULD_REQUIRED."""
+        if self.should_queries or not all(isinstance(q, TermQuery) for q in self.must_not_queries + self.filter_queries):
+            return None
+        nested = [q for q in self.must_queries if not isinstance(q, TermQuery)]
+        if len(nested) != 1:
+            return None
+        d = nested[0]
+        if (not d.is_flat() or d.must_queries or d.must_not_queries or d.filter_queries or d.min_should_match > 1
+                or not 1 <= len(d.should_queries) <= 9):
+            return None
+        return d
+
     def required_clauses(self):
         """MUST clauses followed by the FILTER clauses as zero-weight MUST clauses (BooleanWeight puts both into must_weights)."""
         return list(self.must_queries) + [TermQuery(f.term, 0.0) for f in self.filter_queries]
@@ -417,6 +433,16 @@ class GpuIndexSearcher:
             return OP_TERM, [query], [], []
         if isinstance(query, BooleanQuery):
             if not query.is_flat():
+                d = query.required_disjunction()
+                if d is not None:
+                    musts = [q for q in query.must_queries if q is not d]
+                    if not (musts or query.filter_queries):
+                        # (a lone nested MUST clause: BooleanQuery::build has already rewritten such a tree to the clause itself)
+                        raise RgpuError(-5, "a nested disjunction with no clause beside it is that disjunction")
+                    if self.flatten_nested or self._disjunction_sums_last(musts, d.should_queries):
+                        required = musts + [TermQuery(f.term, 0.0) for f in query.filter_queries]
+                        return (OP_AND | (len(d.should_queries) << 16) | OP_SHOULD_REQUIRED, required, list(d.should_queries),
+                                query.must_not_queries)
                 folded = query.flattened() if getattr(self, "flatten_nested", False) else None
                 if folded is None:
                     raise RgpuError(-5, "nested boolean clauses are not served by the GPU path (flatten_nested folds one level of MUST-of-MUSTs / SHOULD-of-SHOULDs)")
@@ -428,6 +454,24 @@ class GpuIndexSearcher:
             msm = query.min_should_match
             return (OP_OR | (msm << 8) if msm > 1 else OP_OR), query.should_queries, [], query.must_not_queries
         raise RgpuError(-5, "query type not served by the GPU path: %r" % (query,))
+
+    def _disjunction_sums_last(self, musts, shoulds):
+        """Is ConjunctionScorer::score's f32 sum over [musts ..., DisjunctionSumScorer(shoulds)] the MUST sum plus the disjunction's
+        sum — what the kernel forms — in EVERY leaf? The children are sorted by cost() (stable, conjunction_scorer.rs:30): a term's
+        doc_freq in the leaf, the disjunction's = the sum of its clauses' (disjunction_scorer.rs cost). With one scoring MUST
+        clause the add commutes; otherwise the disjunction has to be the costliest child (strictly: ties keep clause order)."""
+        scoring = [m for m in musts if m.boost != 0.0]
+        if len(scoring) <= 1:
+            return True
+        for leaf in self.leaves:
+            def df(t):
+                st = leaf.term_state(t.term)
+                return 0 if st is None else int(st["doc_freq"])
+            if any(df(m) == 0 for m in musts):
+                continue   # a MUST clause without a scorer: nothing matches in this leaf
+            if sum(df(s) for s in shoulds) <= max(df(m) for m in scoring):
+                return False
+        return True
 
     def override_statistics(self, collection_statistics, stats_terms=None):
         """Score with the statistics of a leaf that lives elsewhere (segment-sharded search: every shard takes them from
