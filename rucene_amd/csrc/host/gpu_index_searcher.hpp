@@ -86,6 +86,9 @@ struct TermQuery : Query {
 struct BooleanQuery : Query {
   std::vector<TermQuery> must_queries, should_queries, must_not_queries;
   int32_t min_should_match = 0;
+  // RGPU_OP_SHOULD_REQUIRED: the SHOULD clauses are a should-only BooleanQuery nested under MUST ("+a +(b c)") — set by
+  // NestedBooleanQuery::required_disjunction, never by build()
+  bool should_required = false;
   // boolean_query.rs:40-86 restricted to what the GPU path serves: SHOULD-only term trees, or MUST clauses with optional
   // SHOULD clauses beside them (ReqOptScorer, its sequential skipping rule included: see RGPU_OP_WITH_SHOULD), each
   // optionally with MUST_NOT term clauses (ReqNotScorer); a single clause without MUST_NOTs
@@ -150,6 +153,29 @@ struct NestedBooleanQuery : Query {
       if (min_should_match > 1 && shoulds.size() != should_queries.size()) return nullptr;  // it counts the OUTER clauses
     }
     return BooleanQuery::build(std::move(musts), std::move(shoulds), min_should_match, must_not_queries);
+  }
+  // "+a +(b c)": MUST term clauses and exactly ONE MUST clause that is a should-only BooleanQuery of 1..9 terms
+  // (min_should_match <= 1), no SHOULD clause of its own -> the tree as MUST clauses + required SHOULD clauses
+  // (RGPU_OP_WITH_SHOULD(AND, n) | RGPU_OP_SHOULD_REQUIRED), else null. BooleanWeight::create_scorer builds
+  // ConjunctionScorer([TermScorer ..., DisjunctionSumScorer]) for it (boolean_query.rs:200-215). Whether the kernel's sum — MUST
+  // sum + disjunction sum — is the reference's, bit for bit, depends on the children's costs: GpuIndexSearcher::disjunction_sums_last.
+  std::unique_ptr<BooleanQuery> required_disjunction() const {
+    if (!should_queries.empty()) return nullptr;
+    std::unique_ptr<BooleanQuery> out(new BooleanQuery());
+    const BooleanQuery* nested = nullptr;
+    for (const auto& q : must_queries) {
+      if (auto* t = dynamic_cast<const TermQuery*>(q.get())) { out->must_queries.push_back(*t); continue; }
+      auto* b = dynamic_cast<const BooleanQuery*>(q.get());
+      if (!b || nested) return nullptr;
+      nested = b;
+    }
+    if (!nested || out->must_queries.empty() || !nested->must_queries.empty() || !nested->must_not_queries.empty() || nested->should_required ||
+        nested->min_should_match > 1 || nested->should_queries.empty() || nested->should_queries.size() > 9)
+      return nullptr;
+    out->should_queries = nested->should_queries;
+    out->must_not_queries = must_not_queries;
+    out->should_required = true;
+    return out;
   }
 };
 
@@ -407,7 +433,9 @@ class GpuIndexSearcher {
       std::unique_ptr<Query> folded;
       const Query* q = &query;
       if (auto* nested = dynamic_cast<const NestedBooleanQuery*>(&query)) {
-        folded = flatten_nested ? nested->flattened() : nullptr;
+        std::unique_ptr<BooleanQuery> req = nested->required_disjunction();
+        if (req && (flatten_nested || disjunction_sums_last(*req))) folded = std::move(req);
+        else folded = flatten_nested ? nested->flattened() : nullptr;
         if (!folded) throw Error(RGPU_ERR_UNSUPPORTED, "nested boolean clauses are not served by the GPU path");
         q = folded.get();
       }
@@ -418,6 +446,26 @@ class GpuIndexSearcher {
       if (e.kind != RGPU_ERR_UNSUPPORTED || !cpu_fallback) throw;  // ErrorKind::UnsupportedOperation -> the CPU path
       cpu_fallback(query, collector);
     }
+  }
+
+  // Is ConjunctionScorer::score's f32 sum over [MUST terms ..., DisjunctionSumScorer(required SHOULD terms)] the MUST sum plus the
+  // disjunction's sum — what the kernel forms — in EVERY leaf? The children are sorted by cost() (stable, conjunction_scorer.rs:30):
+  // a term's doc_freq in the leaf, the disjunction's = the sum of its clauses'. With one scoring MUST clause the add commutes;
+  // otherwise the disjunction has to be the costliest child (strictly: ties keep clause order).
+  bool disjunction_sums_last(const BooleanQuery& q) const {
+    size_t scoring = 0;
+    for (const TermQuery& m : q.must_queries) scoring += m.boost != 0.0f ? 1 : 0;
+    if (scoring <= 1) return true;
+    for (const LeafReader& leaf : leaves_) {
+      auto df = [&](const TermQuery& t) -> int64_t { rgpu_term_state st{}; return leaf.term_state(t, &st) ? st.doc_freq : 0; };
+      int64_t must_max = 0, should_sum = 0;
+      bool dead = false;
+      for (const TermQuery& m : q.must_queries) { const int64_t d = df(m); dead = dead || d == 0; if (m.boost != 0.0f) must_max = std::max(must_max, d); }
+      if (dead) continue;  // a MUST clause without a scorer: nothing matches in this leaf
+      for (const TermQuery& c : q.should_queries) should_sum += df(c);
+      if (should_sum <= must_max) return false;
+    }
+    return true;
   }
 
   // the batched form the hardware wants: one launch set per leaf for many queries
@@ -558,7 +606,7 @@ class GpuIndexSearcher {
         clause(*t);
       } else if (auto* b = dynamic_cast<const BooleanQuery*>(q)) {
         const bool conj = !b->must_queries.empty();
-        ops.push_back(conj ? RGPU_OP_WITH_SHOULD(RGPU_OP_AND, b->should_queries.size())
+        ops.push_back(conj ? (RGPU_OP_WITH_SHOULD(RGPU_OP_AND, b->should_queries.size()) | (b->should_required ? RGPU_OP_SHOULD_REQUIRED : 0))
                            : (b->min_should_match > 1 ? RGPU_OP_OR_MSM(b->min_should_match) : (int32_t)RGPU_OP_OR));
         n_terms.push_back(static_cast<int32_t>(conj ? b->must_queries.size() : b->should_queries.size()));
         n_not.push_back(static_cast<int32_t>(b->must_not_queries.size()));
@@ -609,7 +657,7 @@ class GpuIndexSearcher {
       clauses = &single;
     } else if (auto* b = dynamic_cast<const BooleanQuery*>(&q)) {
       op = b->must_queries.empty() ? (b->min_should_match > 1 ? RGPU_OP_OR_MSM(b->min_should_match) : (int32_t)RGPU_OP_OR)
-                                   : RGPU_OP_WITH_SHOULD(RGPU_OP_AND, b->should_queries.size());
+                                   : (RGPU_OP_WITH_SHOULD(RGPU_OP_AND, b->should_queries.size()) | (b->should_required ? RGPU_OP_SHOULD_REQUIRED : 0));
       clauses = b->must_queries.empty() ? &b->should_queries : &b->must_queries;
       if (!b->must_queries.empty()) opts = &b->should_queries;
       nots = &b->must_not_queries;

@@ -1,5 +1,5 @@
 """Minimal driver for profiling: build the 10M-doc shard, run one workload a few times through the C ABI.
-usage: run_workload.py [term|and3|or10|decode|cold|posdec|phrase2|sloppy2] [reps]   (DOCS=... sets the shard size; cold = a fresh segment per repetition:
+usage: run_workload.py [term|and3|and2sparse|mustor|or10|decode|cold|posdec|phrase2|sloppy2] [reps]   (DOCS=... sets the shard size; cold = a fresh segment per repetition:
 skip decode + block framing + alignment + tails (k_prepare_terms, k_prepare_blocks), then k_decode_terms, for every df >= 128 term)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -68,6 +68,23 @@ elif kind == "decode":
     pd, pf = _P(td.data_ptr()), _P(tf.data_ptr())
     for _ in range(reps + 2):
         leaf.segment.decode_terms_device(sel, pd.value, pf.value)
+elif kind == "mustor":
+    # "+a +(b c)" (RGPU_OP_SHOULD_REQUIRED): the and3 batch's term triples, the first as the MUST clause, the other two as the nested
+    # disjunction. Hit counts are cross-checked by inclusion-exclusion over three conjunction batches: |a(b+c)| = |ab| + |ac| - |abc|
+    tids = indexgen.log_uniform_ranks(3 * 1024, 1, 1000, SEED ^ 0xA3).reshape(-1, 3) - 1
+    tids = np.array([r for r in tids if len(set(r.tolist())) == 3])
+    qs, ts = s.pack([B.build([T(int(a)), B.build([], [T(int(b)), T(int(c))])], []) for a, b, c in tids], leaf)
+    for _ in range(reps + 2):
+        hits, totals = leaf.segment.search_batch(qs, ts, 10)
+    t0 = time.perf_counter()
+    for _ in range(10):
+        leaf.segment.search_batch(qs, ts, 10)
+    print("mustor: %d queries, wall per host-buffer batch %.3f ms" % (len(tids), 1e2 * (time.perf_counter() - t0)))
+    def count(cols):
+        q2, t2 = s.pack([B.build([T(int(r[c])) for c in cols], []) for r in tids], leaf)
+        return leaf.segment.search_batch(q2, t2, 10)[1]
+    want = count((0, 1)) + count((0, 2)) - count((0, 1, 2))
+    print("mustor: hit counts equal |ab| + |ac| - |abc| on %d of %d queries; matches in all: %d" % (int((totals == want).sum()), len(tids), int(totals.sum())))
 else:
     if kind == "term":
         tids = indexgen.log_uniform_ranks(1024, 1, 10_000, SEED).reshape(-1, 1) - 1

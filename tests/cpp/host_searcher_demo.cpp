@@ -116,8 +116,11 @@ int main(int argc, char** argv) {
       NestedBooleanQuery nested;  // MUST [ t1, MUST [ t12, t40 ] ]  ==  the flat conjunction of query 2 above
       nested.must_queries.emplace_back(new TermQuery(1));
       nested.must_queries.push_back(BooleanQuery::build({TermQuery(12), TermQuery(40)}, {}));
-      NestedBooleanQuery mixed;   // MUST [ t1, SHOULD [ t12, t40 ] ]: not foldable
-      mixed.must_queries.emplace_back(new TermQuery(1));
+      NestedBooleanQuery required;  // MUST [ t1, SHOULD [ t12, t40 ] ], "+t1 +(t12 t40)": served as it is (RGPU_OP_SHOULD_REQUIRED), bit-exact
+      required.must_queries.emplace_back(new TermQuery(1));
+      required.must_queries.push_back(BooleanQuery::build({}, {TermQuery(12), TermQuery(40)}));
+      NestedBooleanQuery mixed;   // MUST [ SHOULD [ t1, t2 ], SHOULD [ t12, t40 ] ]: two disjunctions under MUST — not served
+      mixed.must_queries.push_back(BooleanQuery::build({}, {TermQuery(1), TermQuery(2)}));
       mixed.must_queries.push_back(BooleanQuery::build({}, {TermQuery(12), TermQuery(40)}));
       bool refused = false;
       { TopDocsCollector c(10); try { searcher.search(nested, c); } catch (const Error& e) { refused = e.kind == RGPU_ERR_UNSUPPORTED; } }
@@ -126,6 +129,17 @@ int main(int argc, char** argv) {
       searcher.search(nested, folded);
       TopDocs top = folded.top_docs();
       std::printf("nested %d %lld", refused ? 1 : 0, (long long)top.total_hits());
+      for (const ScoreDoc& d : top.score_docs()) {
+        uint32_t bits;
+        std::memcpy(&bits, &d.score, 4);
+        std::printf(" %d:%08x", d.doc, bits);
+      }
+      std::printf("\n");
+      searcher.flatten_nested = false;
+      TopDocsCollector req(10);
+      searcher.search(required, req);
+      top = req.top_docs();
+      std::printf("required %lld", (long long)top.total_hits());
       for (const ScoreDoc& d : top.score_docs()) {
         uint32_t bits;
         std::memcpy(&bits, &d.score, 4);

@@ -1144,7 +1144,19 @@ def test_cpp_host_mirror(oracle, tmp_path):
     # nested trees: refused without flatten_nested (1), then MUST [t1, MUST [t12, t40]] folded = the flat conjunction's line; a
     # tree that does not fold reaches cpu_fallback exactly once
     assert out[2 * len(specs) + 2].split()[:2] == ["nested", "1"] and out[2 * len(specs) + 2].split()[2:] == out[2].split()[1:]
-    assert out[2 * len(specs) + 3] == "fallback 1"
+    # "+t1 +(t12 t40)": a disjunction under MUST is served as it is — ConjunctionScorer over [TermScorer(t1), DisjunctionSumScorer(t12, t40)],
+    # expected from the oracle's own scorers on the docs of t1 (one MUST clause: the f32 add commutes)
+    cand = np.asarray(oseg.decode_term(seg.terms[1])[0], dtype=np.int32)
+    ms, mm = osr.score_docs(oracle.OP_TERM, [1], cand)
+    ds, dm = osr.score_docs(oracle.OP_OR, [12, 40], cand)
+    ok = mm & dm
+    sc = (ms + ds).astype(np.float32)[ok]
+    order = np.lexsort((cand[ok], -sc.astype(np.float64)))[:10]
+    parts = out[2 * len(specs) + 3].split()
+    assert parts[0] == "required" and int(parts[1]) == int(ok.sum())
+    assert [int(p.split(":")[0]) for p in parts[2:]] == cand[ok][order].tolist()
+    assert [int(p.split(":")[1], 16) for p in parts[2:]] == sc[order].view(np.uint32).tolist()
+    assert out[2 * len(specs) + 4] == "fallback 1"
 
 
 def test_cpp_host_mirror_phrases_and_rescoring(ctx, oracle, tmp_path):
