@@ -164,6 +164,16 @@ typedef enum rgpu_query_op {
  * sum in heap order: disjunction_scorer.rs:41-45); every SHOULD clause absent from the leaf = the nested weight has no scorer =
  * the query matches nothing there (boolean_query.rs:203-207). */
 #define RGPU_OP_SHOULD_REQUIRED ((int32_t)1 << 24)
+/* RGPU_OP_NESTED_MUST on top of RGPU_OP_WITH_SHOULD: the n clauses behind the MUST clauses are a must-only BooleanQuery nested
+ * under MUST — "+a +(+b +c)", ConjunctionScorer([TermScorer(a) ..., ConjunctionScorer(b, c)]). A doc matches when every MUST clause
+ * and every one of the n nested clauses hold it (the same docs and hit count as the flat conjunction); its score is the MUST sum
+ * (cost order) plus the nested conjunction's own sum — lead1 + lead2 + others over the n clauses in THEIR cost order, formed first
+ * (conjunction_scorer.rs:27-43, 87-95; the library sorts them by doc_freq per leaf, stable). That is ConjunctionScorer::score with
+ * the nested conjunction as the LAST child: its cost is its cheapest clause's doc_freq, so it is last when that exceeds every MUST
+ * clause's doc freq; with a single MUST clause the f32 add commutes. The host mirrors send a tree here only then. n >= 2 (a nested
+ * query of one clause is that clause: boolean_query.rs:56-68); a nested clause absent from the leaf = no scorer = nothing matches.
+ * Not combined with RGPU_OP_SHOULD_REQUIRED. */
+#define RGPU_OP_NESTED_MUST ((int32_t)1 << 25)
 
 typedef struct rgpu_query {
   int32_t op;          /* rgpu_query_op (OR: optionally RGPU_OP_OR_MSM(msm); TERM / AND: optionally RGPU_OP_WITH_SHOULD(op, n) —

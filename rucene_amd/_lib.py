@@ -11,6 +11,7 @@ _LIB_NAME = "librucene_gpu.so"
 ABI_VERSION = 6
 OP_TERM, OP_AND, OP_OR = 0, 1, 2
 OP_SHOULD_REQUIRED = 1 << 24   # RGPU_OP_SHOULD_REQUIRED: the optional SHOULD clauses are a nested disjunction under MUST
+OP_NESTED_MUST = 1 << 25       # RGPU_OP_NESTED_MUST: ... are a nested conjunction under MUST (its own sum, formed first)
 MAX_K = 1024
 MAX_QUERY_TERMS = 64
 MAX_PHRASE_TERMS = 16

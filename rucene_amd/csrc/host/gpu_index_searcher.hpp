@@ -89,6 +89,9 @@ struct BooleanQuery : Query {
   // RGPU_OP_SHOULD_REQUIRED: the SHOULD clauses are a should-only BooleanQuery nested under MUST ("+a +(b c)") — set by
   // NestedBooleanQuery::required_disjunction, never by build()
   bool should_required = false;
+  // RGPU_OP_NESTED_MUST: the SHOULD slots hold a must-only BooleanQuery nested under MUST ("+a +(+b +c)") — set by
+  // NestedBooleanQuery::nested_conjunction
+  bool nested_must = false;
   // boolean_query.rs:40-86 restricted to what the GPU path serves: SHOULD-only term trees, or MUST clauses with optional
   // SHOULD clauses beside them (ReqOptScorer, its sequential skipping rule included: see RGPU_OP_WITH_SHOULD), each
   // optionally with MUST_NOT term clauses (ReqNotScorer); a single clause without MUST_NOTs
@@ -175,6 +178,28 @@ struct NestedBooleanQuery : Query {
     out->should_queries = nested->should_queries;
     out->must_not_queries = must_not_queries;
     out->should_required = true;
+    return out;
+  }
+  // "+a +(+b +c)": MUST term clauses and exactly ONE MUST clause that is a must-only BooleanQuery of >= 2 terms, no SHOULD clause of
+  // its own -> MUST clauses + the nested clauses in the SHOULD slots with nested_must set (RGPU_OP_WITH_SHOULD(AND, n) |
+  // RGPU_OP_NESTED_MUST), else null. The reference sums the nested conjunction first (conjunction_scorer.rs:87-95): bit-exact under
+  // GpuIndexSearcher::nested_child_sums_last, where the flat fold (flattened()) is within 1e-5.
+  std::unique_ptr<BooleanQuery> nested_conjunction() const {
+    if (!should_queries.empty()) return nullptr;
+    std::unique_ptr<BooleanQuery> out(new BooleanQuery());
+    const BooleanQuery* nested = nullptr;
+    for (const auto& q : must_queries) {
+      if (auto* t = dynamic_cast<const TermQuery*>(q.get())) { out->must_queries.push_back(*t); continue; }
+      auto* b = dynamic_cast<const BooleanQuery*>(q.get());
+      if (!b || nested) return nullptr;
+      nested = b;
+    }
+    if (!nested || out->must_queries.empty() || !nested->should_queries.empty() || !nested->must_not_queries.empty() || nested->should_required ||
+        nested->nested_must || nested->must_queries.size() < 2)
+      return nullptr;
+    out->should_queries = nested->must_queries;
+    out->must_not_queries = must_not_queries;
+    out->nested_must = true;
     return out;
   }
 };
@@ -434,8 +459,9 @@ class GpuIndexSearcher {
       const Query* q = &query;
       if (auto* nested = dynamic_cast<const NestedBooleanQuery*>(&query)) {
         std::unique_ptr<BooleanQuery> req = nested->required_disjunction();
-        if (req && (flatten_nested || disjunction_sums_last(*req))) folded = std::move(req);
-        else folded = flatten_nested ? nested->flattened() : nullptr;
+        if (req && (flatten_nested || nested_child_sums_last(*req))) folded = std::move(req);
+        else if (flatten_nested) folded = nested->flattened();  // (the flat fold leads with the tree's rarest clause: within 1e-5)
+        else if ((req = nested->nested_conjunction()) && nested_child_sums_last(*req)) folded = std::move(req);
         if (!folded) throw Error(RGPU_ERR_UNSUPPORTED, "nested boolean clauses are not served by the GPU path");
         q = folded.get();
       }
@@ -448,11 +474,12 @@ class GpuIndexSearcher {
     }
   }
 
-  // Is ConjunctionScorer::score's f32 sum over [MUST terms ..., DisjunctionSumScorer(required SHOULD terms)] the MUST sum plus the
-  // disjunction's sum — what the kernel forms — in EVERY leaf? The children are sorted by cost() (stable, conjunction_scorer.rs:30):
-  // a term's doc_freq in the leaf, the disjunction's = the sum of its clauses'. With one scoring MUST clause the add commutes;
-  // otherwise the disjunction has to be the costliest child (strictly: ties keep clause order).
-  bool disjunction_sums_last(const BooleanQuery& q) const {
+  // Is ConjunctionScorer::score's f32 sum over [MUST terms ..., nested scorer] the MUST sum plus the nested scorer's sum — what the
+  // kernel forms — in EVERY leaf? The children are sorted by cost() (stable, conjunction_scorer.rs:30): a term's doc_freq in the
+  // leaf, a DisjunctionSumScorer's = the sum of its clauses' (should_required), a nested ConjunctionScorer's = its cheapest
+  // clause's (nested_must, conjunction_scorer.rs:111-113). With one scoring MUST clause the add commutes; otherwise the nested
+  // scorer has to be the costliest child (strictly: ties keep clause order).
+  bool nested_child_sums_last(const BooleanQuery& q) const {
     size_t scoring = 0;
     for (const TermQuery& m : q.must_queries) scoring += m.boost != 0.0f ? 1 : 0;
     if (scoring <= 1) return true;
@@ -462,8 +489,10 @@ class GpuIndexSearcher {
       bool dead = false;
       for (const TermQuery& m : q.must_queries) { const int64_t d = df(m); dead = dead || d == 0; if (m.boost != 0.0f) must_max = std::max(must_max, d); }
       if (dead) continue;  // a MUST clause without a scorer: nothing matches in this leaf
-      for (const TermQuery& c : q.should_queries) should_sum += df(c);
-      if (should_sum <= must_max) return false;
+      int64_t should_min = INT64_MAX;
+      for (const TermQuery& c : q.should_queries) { const int64_t d = df(c); should_sum += d; should_min = std::min(should_min, d); }
+      if (q.nested_must && should_min == 0) continue;  // (the nested conjunction has no scorer here either)
+      if ((q.nested_must ? should_min : should_sum) <= must_max) return false;
     }
     return true;
   }
@@ -606,7 +635,7 @@ class GpuIndexSearcher {
         clause(*t);
       } else if (auto* b = dynamic_cast<const BooleanQuery*>(q)) {
         const bool conj = !b->must_queries.empty();
-        ops.push_back(conj ? (RGPU_OP_WITH_SHOULD(RGPU_OP_AND, b->should_queries.size()) | (b->should_required ? RGPU_OP_SHOULD_REQUIRED : 0))
+        ops.push_back(conj ? (RGPU_OP_WITH_SHOULD(RGPU_OP_AND, b->should_queries.size()) | (b->should_required ? RGPU_OP_SHOULD_REQUIRED : 0) | (b->nested_must ? RGPU_OP_NESTED_MUST : 0))
                            : (b->min_should_match > 1 ? RGPU_OP_OR_MSM(b->min_should_match) : (int32_t)RGPU_OP_OR));
         n_terms.push_back(static_cast<int32_t>(conj ? b->must_queries.size() : b->should_queries.size()));
         n_not.push_back(static_cast<int32_t>(b->must_not_queries.size()));
@@ -657,7 +686,7 @@ class GpuIndexSearcher {
       clauses = &single;
     } else if (auto* b = dynamic_cast<const BooleanQuery*>(&q)) {
       op = b->must_queries.empty() ? (b->min_should_match > 1 ? RGPU_OP_OR_MSM(b->min_should_match) : (int32_t)RGPU_OP_OR)
-                                   : (RGPU_OP_WITH_SHOULD(RGPU_OP_AND, b->should_queries.size()) | (b->should_required ? RGPU_OP_SHOULD_REQUIRED : 0));
+                                   : (RGPU_OP_WITH_SHOULD(RGPU_OP_AND, b->should_queries.size()) | (b->should_required ? RGPU_OP_SHOULD_REQUIRED : 0) | (b->nested_must ? RGPU_OP_NESTED_MUST : 0));
       clauses = b->must_queries.empty() ? &b->should_queries : &b->must_queries;
       if (!b->must_queries.empty()) opts = &b->should_queries;
       nots = &b->must_not_queries;

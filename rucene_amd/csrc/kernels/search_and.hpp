@@ -282,6 +282,9 @@ __global__ __launch_bounds__(AND_WG_THREADS, AND_WAVES_PER_SIMD) void k_search_a
     // RGPU_OP_SHOULD_REQUIRED ("+a +(b c)": the SHOULD clauses are a DisjunctionSumScorer among the ConjunctionScorer's children,
     // boolean_query.rs:200-215): a candidate that none of them holds is no match. Bit 0 / 1: candidate 0 / 1 was found in one.
     const bool need_any = HAS_OPT && (Q.op & (1 << 24)) != 0;  // wave-uniform
+    // RGPU_OP_NESTED_MUST ("+a +(+b +c)": the clauses behind the MUST clauses are a ConjunctionScorer of their own): a candidate that
+    // one of them does not hold is no match; their sum is formed on its own, like the optional sum, and added last
+    const bool need_all = HAS_OPT && (Q.op & (1 << 25)) != 0;  // wave-uniform
     uint32_t any_opt = 0u;
     if (RGPU_AND_FAST && ti_start == 2) {  // the first clause's score, added where the clause loop would have added it
       const DevTerm T1 = terms[Q.first_term + 1];
@@ -307,7 +310,7 @@ __global__ __launch_bounds__(AND_WG_THREADS, AND_WAVES_PER_SIMD) void k_search_a
         if (HAS_OPT && opt) any_opt |= which;
       };
       const uint32_t n0 = nn & 0xffu, n1 = nn >> 8;
-      auto missed = [&](bool& alive) { if (!excl && !opt) alive = false; };
+      auto missed = [&](bool& alive) { if (!excl && (!opt || need_all)) alive = false; };
       if (T.df == 1) {
         if (a0) { if (d0 == T.singleton_doc) found(1u, a0, s0, (uint32_t)T.singleton_freq, n0); else missed(a0); }
         if (a1) { if (d1 == T.singleton_doc) found(2u, a1, s1, (uint32_t)T.singleton_freq, n1); else missed(a1); }

@@ -2701,11 +2701,14 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
   for (int32_t q = 0; q < n_queries; ++q) {
     const rgpu_query& Q = queries[q];
     const int qop = Q.op & 0xff, qmsm = (Q.op >> 8) & 0xff, qopt = (Q.op >> 16) & 0xff;
-    if (qop < RGPU_OP_TERM || qop > RGPU_OP_OR || (Q.op & ~(0xffffff | RGPU_OP_SHOULD_REQUIRED)) != 0) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "unknown query op");
+    if (qop < RGPU_OP_TERM || qop > RGPU_OP_OR || (Q.op & ~(0xffffff | RGPU_OP_SHOULD_REQUIRED | RGPU_OP_NESTED_MUST)) != 0) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "unknown query op");
     // "+a +(b c)": the SHOULD clauses as a nested disjunction under MUST (ConjunctionScorer over the MUST clauses and one
     // DisjunctionSumScorer). Ten or more children would sum in heap order (disjunction_scorer.rs:41-45): not served here.
     if ((Q.op & RGPU_OP_SHOULD_REQUIRED) && (qop == RGPU_OP_OR || qopt < 1))
       return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "RGPU_OP_SHOULD_REQUIRED goes with RGPU_OP_WITH_SHOULD(TERM / AND, n >= 1)");
+    // "+a +(+b +c)": the clauses behind the MUST clauses are a nested conjunction (its own f32 sum, formed first)
+    if ((Q.op & RGPU_OP_NESTED_MUST) && (qop == RGPU_OP_OR || qopt < 2 || (Q.op & RGPU_OP_SHOULD_REQUIRED)))
+      return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "RGPU_OP_NESTED_MUST goes with RGPU_OP_WITH_SHOULD(TERM / AND, n >= 2) and without RGPU_OP_SHOULD_REQUIRED");
     if ((Q.op & RGPU_OP_SHOULD_REQUIRED) && qopt >= 10) return fail(RGPU_ERR_UNSUPPORTED, "a required disjunction of ten or more clauses sums in heap order");
     // min_should_match beside MUST clauses is legal and has no effect: ReqOptScorer only ever advance()s the optional
     // DisjunctionSumScorer, and advance() does not look at the count (disjunction_scorer.rs approximate_advance)
@@ -2860,17 +2863,22 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
       mine_bytes.push_back(t.state.doc_freq > 128 && t.state.skip_offset > 0 ? t.state.skip_offset : 2 * (int64_t)t.state.doc_freq);
     }
     if (dead) mine.clear();
-    const bool should_required = (Q.op & RGPU_OP_SHOULD_REQUIRED) != 0;
+    const bool should_required = (Q.op & RGPU_OP_SHOULD_REQUIRED) != 0, nested_must = (Q.op & RGPU_OP_NESTED_MUST) != 0;
     // MUST_NOT clauses (boolean_query.rs:235-252): absent terms drop out; without a positive scorer there is none
     if (!mine.empty()) {
       for (int i = 0; i < qopt; ++i) {  // SHOULD next to MUST (boolean_query.rs:217-233): absent terms drop out
         const rgpu_query_term& t = terms[Q.first_term + Q.n_terms + i];
-        if (t.state.doc_freq <= 0) continue;
+        if (t.state.doc_freq <= 0) {
+          if (nested_must) { mine.clear(); mine_opt.clear(); break; }  // the nested conjunction has no scorer in this leaf (boolean_query.rs:201-207)
+          continue;
+        }
         DevTerm dt;
         rc = make_dev_term(seg, t.state, t.weight, t.sim_table, &dt, true, &tinfo[(size_t)(Q.first_term + Q.n_terms + i)]);
         if (rc != RGPU_OK) return rc;
         mine_opt.push_back(dt);
       }
+      if (nested_must)  // the nested ConjunctionScorer::new: stable sort by cost() (conjunction_scorer.rs:30) — its sum is lead1 + lead2 + others
+        std::stable_sort(mine_opt.begin(), mine_opt.end(), [](const DevTerm& a, const DevTerm& b) { return a.df < b.df; });
       // the nested disjunction has no scorer in this leaf = a MUST weight without a scorer: nothing matches (boolean_query.rs:203-207)
       if (should_required && mine_opt.empty()) mine.clear();
       for (int i = 0; i < Q.n_must_not && !mine.empty(); ++i) {
@@ -2907,7 +2915,7 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
       cur_group[2] = (int)groups.size() - 1;
     }
     // (a required disjunction is a child of the ConjunctionScorer: plain f32 sums, no ReqOptScorer in that tree)
-    const bool to_req_opt = gop == RGPU_OP_AND && !mine_opt.empty() && !mine.empty() && c->cfg.req_opt_rule >= 0 && !should_required;
+    const bool to_req_opt = gop == RGPU_OP_AND && !mine_opt.empty() && !mine.empty() && c->cfg.req_opt_rule >= 0 && !should_required && !nested_must;
     if (to_req_opt) {  // one record per lead posting: keep a group's records under 1 GiB
       const int64_t lead_df = mine[0].df;
       if (req_opt_records > 0 && req_opt_records + lead_df > (64ll << 20)) {
@@ -2924,7 +2932,7 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
     // the window kernel reads min_should_match from the second byte, the conjunction kernel its optional clause count
     // from the third; device clause order: MUST, MUST_NOT, SHOULD
     dq.op = gop | ((qmsm > 1 && gop == RGPU_OP_OR) ? qmsm << 8 : 0) | ((int32_t)mine_opt.size() << 16) |
-            ((should_required && !mine.empty()) ? RGPU_OP_SHOULD_REQUIRED : 0);
+            ((should_required && !mine.empty()) ? RGPU_OP_SHOULD_REQUIRED : 0) | ((nested_must && !mine.empty()) ? RGPU_OP_NESTED_MUST : 0);
     dq.first_term = (int32_t)G.terms.size();
     dq.n_terms = (int32_t)mine.size();
     dq.pad = (int32_t)mine_not.size();

@@ -18,7 +18,7 @@ resolves terms, computes BM25 weights (via the C ABI's host helper) and packs qu
 import numpy as np
 
 from . import _lib
-from ._lib import OP_AND, OP_OR, OP_SHOULD_REQUIRED, OP_TERM, QUERY_DTYPE, QUERY_TERM_DTYPE, TERM_STATE_DTYPE, RgpuError
+from ._lib import OP_AND, OP_NESTED_MUST, OP_OR, OP_SHOULD_REQUIRED, OP_TERM, QUERY_DTYPE, QUERY_TERM_DTYPE, TERM_STATE_DTYPE, RgpuError
 
 
 class CollectionStatistics:
@@ -334,6 +334,21 @@ class BooleanQuery:
             return None
         return d
 
+    def nested_conjunction(self):
+        """"+a +(+b +c)": MUST TermQuery clauses and exactly ONE MUST clause that is a must-only BooleanQuery of >= 2 terms, no SHOULD
+        clause of its own -> (that nested query) else None. The reference builds ConjunctionScorer([TermScorer ...,
+        ConjunctionScorer(b, c)]) (boolean_query.rs:200-215): the nested sum is formed first. The C ABI takes it as
+        RGPU_OP_WITH_SHOULD(AND, n) | RGPU_OP_NESTED_MUST."""
+        if self.should_queries or not all(isinstance(q, TermQuery) for q in self.must_not_queries + self.filter_queries):
+            return None
+        nested = [q for q in self.must_queries if not isinstance(q, TermQuery)]
+        if len(nested) != 1:
+            return None
+        c = nested[0]
+        if not c.is_flat() or c.should_queries or c.must_not_queries or c.filter_queries or len(c.must_queries) < 2:
+            return None
+        return c
+
     def required_clauses(self):
         """MUST clauses followed by the FILTER clauses as zero-weight MUST clauses (BooleanWeight puts both into must_weights)."""
         return list(self.must_queries) + [TermQuery(f.term, 0.0) for f in self.filter_queries]
@@ -439,10 +454,17 @@ class GpuIndexSearcher:
                     if not (musts or query.filter_queries):
                         # (a lone nested MUST clause: BooleanQuery::build has already rewritten such a tree to the clause itself)
                         raise RgpuError(-5, "a nested disjunction with no clause beside it is that disjunction")
-                    if self.flatten_nested or self._disjunction_sums_last(musts, d.should_queries):
+                    if self.flatten_nested or self._nested_child_sums_last(musts, d.should_queries, sum):
                         required = musts + [TermQuery(f.term, 0.0) for f in query.filter_queries]
                         return (OP_AND | (len(d.should_queries) << 16) | OP_SHOULD_REQUIRED, required, list(d.should_queries),
                                 query.must_not_queries)
+                c = None if self.flatten_nested else query.nested_conjunction()
+                if c is not None:
+                    musts = [q for q in query.must_queries if q is not c]
+                    if (musts or query.filter_queries) and self._nested_child_sums_last(musts, c.must_queries, min):
+                        # (without flatten_nested only: the flat fold below serves every such tree within 1e-5 and leads with its rarest clause)
+                        required = musts + [TermQuery(f.term, 0.0) for f in query.filter_queries]
+                        return (OP_AND | (len(c.must_queries) << 16) | OP_NESTED_MUST, required, list(c.must_queries), query.must_not_queries)
                 folded = query.flattened() if getattr(self, "flatten_nested", False) else None
                 if folded is None:
                     raise RgpuError(-5, "nested boolean clauses are not served by the GPU path (flatten_nested folds one level of MUST-of-MUSTs / SHOULD-of-SHOULDs)")
@@ -455,11 +477,12 @@ class GpuIndexSearcher:
             return (OP_OR | (msm << 8) if msm > 1 else OP_OR), query.should_queries, [], query.must_not_queries
         raise RgpuError(-5, "query type not served by the GPU path: %r" % (query,))
 
-    def _disjunction_sums_last(self, musts, shoulds):
-        """Is ConjunctionScorer::score's f32 sum over [musts ..., DisjunctionSumScorer(shoulds)] the MUST sum plus the disjunction's
-        sum — what the kernel forms — in EVERY leaf? The children are sorted by cost() (stable, conjunction_scorer.rs:30): a term's
-        doc_freq in the leaf, the disjunction's = the sum of its clauses' (disjunction_scorer.rs cost). With one scoring MUST
-        clause the add commutes; otherwise the disjunction has to be the costliest child (strictly: ties keep clause order)."""
+    def _nested_child_sums_last(self, musts, inner, cost):
+        """Is ConjunctionScorer::score's f32 sum over [musts ..., nested scorer(inner)] the MUST sum plus the nested scorer's sum —
+        what the kernel forms — in EVERY leaf? The children are sorted by cost() (stable, conjunction_scorer.rs:30): a term's
+        doc_freq in the leaf; a DisjunctionSumScorer's = the sum of its clauses' (`cost` = sum), a nested ConjunctionScorer's = its
+        cheapest clause's (`cost` = min, conjunction_scorer.rs:111-113). With one scoring MUST clause the add commutes; otherwise
+        the nested scorer has to be the costliest child (strictly: ties keep clause order)."""
         scoring = [m for m in musts if m.boost != 0.0]
         if len(scoring) <= 1:
             return True
@@ -469,7 +492,9 @@ class GpuIndexSearcher:
                 return 0 if st is None else int(st["doc_freq"])
             if any(df(m) == 0 for m in musts):
                 continue   # a MUST clause without a scorer: nothing matches in this leaf
-            if sum(df(s) for s in shoulds) <= max(df(m) for m in scoring):
+            if cost == min and any(df(c) == 0 for c in inner):
+                continue   # (the nested conjunction has no scorer here either)
+            if cost([df(c) for c in inner]) <= max(df(m) for m in scoring):
                 return False
         return True
 

@@ -122,8 +122,21 @@ int main(int argc, char** argv) {
       NestedBooleanQuery mixed;   // MUST [ SHOULD [ t1, t2 ], SHOULD [ t12, t40 ] ]: two disjunctions under MUST — not served
       mixed.must_queries.push_back(BooleanQuery::build({}, {TermQuery(1), TermQuery(2)}));
       mixed.must_queries.push_back(BooleanQuery::build({}, {TermQuery(12), TermQuery(40)}));
+      // without flatten_nested the tree is served as it is (RGPU_OP_NESTED_MUST: the nested sum formed first, bit-exact) ...
       bool refused = false;
-      { TopDocsCollector c(10); try { searcher.search(nested, c); } catch (const Error& e) { refused = e.kind == RGPU_ERR_UNSUPPORTED; } }
+      TopDocsCollector exact(10);
+      try { searcher.search(nested, exact); } catch (const Error& e) { refused = e.kind == RGPU_ERR_UNSUPPORTED; }
+      {
+        TopDocs et = exact.top_docs();
+        std::printf("nested-exact %lld", (long long)et.total_hits());
+        for (const ScoreDoc& d : et.score_docs()) {
+          uint32_t bits;
+          std::memcpy(&bits, &d.score, 4);
+          std::printf(" %d:%08x", d.doc, bits);
+        }
+        std::printf("\n");
+      }
+      // ... and with it folded into the flat conjunction (within 1e-5, led by the rarest clause)
       searcher.flatten_nested = true;
       TopDocsCollector folded(10);
       searcher.search(nested, folded);

@@ -382,6 +382,55 @@ def test_a_disjunction_under_must(zipf, oracle, ctx, k):
         assert e.value.status == status
 
 
+@pytest.mark.parametrize("k", [10, 100])
+def test_a_conjunction_under_must(zipf, oracle, k):
+    """"+a +(+b +c)" as it is, bit for bit: ConjunctionScorer([TermScorer(a) ..., ConjunctionScorer(b, c)]) sums the nested
+    conjunction first (conjunction_scorer.rs:87-95) — a + (b + c) where the flat query forms (a + b) + c in cost order. Same docs
+    and hit count as the flat conjunction (the oracle's), scores = the oracle's score of the outer MUST clauses + its score of the
+    nested conjunction, one f32 add (RGPU_OP_NESTED_MUST: one outer MUST clause, or a nested conjunction whose cheapest clause
+    costs more than every outer one)."""
+    import rucene_amd
+    seg, osearcher, gsearcher = zipf
+    T, B = rucene_amd.TermQuery, rucene_amd.BooleanQuery
+    df = lambda t: int(seg.terms[t]["doc_freq"])   # noqa: E731
+    cases = [([5], [1, 40], []), ([1], [12, 40], []), ([300], [7, 2, 0], []), ([0], [1, 2], []), ([900, 4000], [0, 1], []), ([40], [3, 1, 0, 2], []),
+             ([2], [49_999, 0], []), ([5], [1, 40], [3]), ([700, 2500], [2, 1, 0], [7, 11]), ([100], [10, 9, 8, 7, 6, 5], [])]
+    queries, expect, n_diff = [], [], 0
+    for musts, inner, nots in cases:
+        assert len(musts) == 1 or min(df(t) for t in inner) > max(df(t) for t in musts)
+        queries.append(B.build([T(t) for t in musts] + [B.build([T(t) for t in inner], [])], [], must_nots=[T(t) for t in nots]))
+        d, sc, total = (osearcher.search_not(oracle.OP_AND, musts + inner, nots, seg.max_doc, tie_mode=oracle.TIE_CANONICAL) if nots
+                        else osearcher.search(oracle.OP_AND, musts + inner, seg.max_doc, tie_mode=oracle.TIE_CANONICAL))
+        d = np.asarray(d, dtype=np.int32)
+        ms, mm = osearcher.score_docs(oracle.OP_AND if len(musts) > 1 else oracle.OP_TERM, musts, d)
+        cs, cm = osearcher.score_docs(oracle.OP_AND, inner, d)
+        assert mm.all() and cm.all()
+        nested = (ms + cs).astype(np.float32)
+        n_diff += int((nested.view(np.int32) != np.asarray(sc, dtype=np.float32).view(np.int32)).sum())
+        order = np.lexsort((d, -nested.astype(np.float64)))[:k]
+        expect.append((int(total), d[order], nested[order]))
+    assert n_diff > 0   # (the nested sums do differ from the flat ones somewhere: the test can tell the two apart)
+    hits, totals = gsearcher.search_batch(queries, k)
+    for i, (n_hits, d, sc) in enumerate(expect):
+        assert totals[i] == n_hits, (cases[i], totals[i], n_hits)
+        assert (hits[i]["doc"][:d.size] == d).all() and (hits[i]["doc"][d.size:] == -1).all(), cases[i]
+        assert (hits[i]["score"][:d.size].view(np.int32) == sc.view(np.int32)).all(), cases[i]
+    # a nested conjunction that holds a clause cheaper than an outer MUST clause (two scoring outer clauses): not exact -> declined
+    with pytest.raises(rucene_amd.RgpuError) as e:
+        gsearcher.search_batch([B.build([T(0), T(1), B.build([T(4000), T(2)], [])], [])], k)
+    assert e.value.status == -5
+    # through the C ABI: the flag needs two or more nested clauses and excludes RGPU_OP_SHOULD_REQUIRED
+    leaf = gsearcher.leaves[0]
+    qs, ts = gsearcher.pack([queries[0]], leaf)
+    assert qs[0]["op"] == rucene_amd.OP_AND | (2 << 16) | (1 << 25)
+    for bad_op in (rucene_amd.OP_AND | (1 << 16) | (1 << 25), rucene_amd.OP_AND | (2 << 16) | (3 << 24), rucene_amd.OP_OR | (1 << 25)):
+        q2 = qs.copy()
+        q2[0]["op"] = bad_op
+        with pytest.raises(rucene_amd.RgpuError) as e:
+            leaf.segment.search_batch(q2, ts, k)
+        assert e.value.status == -2
+
+
 @pytest.mark.parametrize("n_clauses", [2, 5, 9])
 def test_disjunctions_exact_below_ten_clauses(zipf, oracle, n_clauses):
     seg, osearcher, gsearcher = zipf
@@ -1141,9 +1190,21 @@ def test_cpp_host_mirror(oracle, tmp_path):
         assert out[len(specs) + i] == "text " + out[i]
     assert out[2 * len(specs)] == "text %d 0" % len(specs)      # a term the dictionary does not hold
     assert out[2 * len(specs) + 1].endswith(" 1")
-    # nested trees: refused without flatten_nested (1), then MUST [t1, MUST [t12, t40]] folded = the flat conjunction's line; a
-    # tree that does not fold reaches cpu_fallback exactly once
-    assert out[2 * len(specs) + 2].split()[:2] == ["nested", "1"] and out[2 * len(specs) + 2].split()[2:] == out[2].split()[1:]
+    # nested trees: MUST [t1, MUST [t12, t40]] is served as it is without flatten_nested — the nested sum formed first: the flat
+    # conjunction's docs and count, scores t1 + (t12 + t40) from the oracle's scorers — and folded = the flat conjunction's line with
+    # it; a tree that neither form serves reaches cpu_fallback exactly once
+    d, _, total = osr.search(oracle.OP_AND, [1, 12, 40], seg.max_doc, tie_mode=oracle.TIE_CANONICAL)
+    d = np.asarray(d, dtype=np.int32)
+    ms, _ = osr.score_docs(oracle.OP_TERM, [1], d)
+    cs, _ = osr.score_docs(oracle.OP_AND, [12, 40], d)
+    nested = (ms + cs).astype(np.float32)
+    order = np.lexsort((d, -nested.astype(np.float64)))[:10]
+    parts = out[2 * len(specs) + 2].split()
+    assert parts[0] == "nested-exact" and int(parts[1]) == total
+    assert [int(p.split(":")[0]) for p in parts[2:]] == d[order].tolist()
+    assert [int(p.split(":")[1], 16) for p in parts[2:]] == nested[order].view(np.uint32).tolist()
+    out = out[:2 * len(specs) + 2] + out[2 * len(specs) + 3:]
+    assert out[2 * len(specs) + 2].split()[:2] == ["nested", "0"] and out[2 * len(specs) + 2].split()[2:] == out[2].split()[1:]
     # "+t1 +(t12 t40)": a disjunction under MUST is served as it is — ConjunctionScorer over [TermScorer(t1), DisjunctionSumScorer(t12, t40)],
     # expected from the oracle's own scorers on the docs of t1 (one MUST clause: the f32 add commutes)
     cand = np.asarray(oseg.decode_term(seg.terms[1])[0], dtype=np.int32)

@@ -225,10 +225,15 @@ def test_nested_boolean_trees_fold_one_level_or_fall_back(world):
     deep = B.build([T(1), B.build([T(2), B.build([T(3), T(4)], [])], [])], [])      # two levels: not foldable
     assert not nested_and.is_flat() and B.build([T(1), T(2)], []).is_flat()
     s.flatten_nested, s.cpu_fallback = False, None
-    for q in (nested_and, nested_or, mixed):
+    for q in (nested_or, mixed):
         with pytest.raises(ra.RgpuError) as e:
             s.pack([q], leaf)
         assert e.value.status == -5   # ErrorKind::UnsupportedOperation
+    # MUST [t1, MUST [t2, t3]] with ONE outer MUST clause is served as it is, bit-exact: the nested conjunction's sum is formed
+    # first (RGPU_OP_NESTED_MUST, test_a_conjunction_under_must) — the same clauses as the flat query, another op
+    q, t = s.pack([nested_and], leaf)
+    flat_q, flat_t = s.pack([B.build([T(1), T(2), T(3)], [])], leaf)
+    assert q[0]["op"] == (ra.OP_AND | (2 << 16) | ra._lib.OP_NESTED_MUST) and q[0]["n_terms"] == 1 and t.tobytes() == flat_t.tobytes()
     s.flatten_nested = True
     q, t = s.pack([nested_and, nested_or], leaf)
     flat_q, flat_t = s.pack([B.build([T(1), T(2), T(3)], []), B.build([], [T(4), T(5), T(6), T(7)])], leaf)
