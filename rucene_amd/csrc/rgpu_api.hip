@@ -2892,6 +2892,10 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
     }
     if (qop == RGPU_OP_AND)  // ConjunctionScorer::new: stable sort by cost() = doc_freq (conjunction_scorer.rs:30)
       std::stable_sort(mine.begin(), mine.end(), [](const DevTerm& a, const DevTerm& b) { return a.df < b.df; });
+    // A nested conjunction: the kernel forms sum(first group, lead first) + sum(second group), and that last add commutes — so the
+    // group that holds the rarer clause leads, as lead1 does in the reference's flat iteration (conjunction_scorer.rs:30-43): the
+    // nested tree then costs what the flat conjunction costs. (Each group is already in its own cost order.)
+    if (nested_must && !mine.empty() && !mine_opt.empty() && mine_opt[0].df < mine[0].df) mine.swap(mine_opt);
     // a term with prohibited / optional clauses runs as a one-clause conjunction (the lead-driven kernel probes them)
     const int gop = (qop == RGPU_OP_TERM && (!mine_not.empty() || !mine_opt.empty())) ? (int)RGPU_OP_AND : qop;
     // disjunction_scorer.rs:41-45: >= 10 children and min_should_match <= 1 -> the heap; weights must be >= +0 (the

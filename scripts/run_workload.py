@@ -1,5 +1,5 @@
 """Minimal driver for profiling: build the 10M-doc shard, run one workload a few times through the C ABI.
-usage: run_workload.py [term|and3|and2sparse|mustor|or10|decode|cold|posdec|phrase2|sloppy2] [reps]   (DOCS=... sets the shard size; cold = a fresh segment per repetition:
+usage: run_workload.py [term|and3|and2sparse|mustor|mustand|or10|decode|cold|posdec|phrase2|sloppy2] [reps]   (DOCS=... sets the shard size; cold = a fresh segment per repetition:
 skip decode + block framing + alignment + tails (k_prepare_terms, k_prepare_blocks), then k_decode_terms, for every df >= 128 term)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -85,6 +85,29 @@ elif kind == "mustor":
         return leaf.segment.search_batch(q2, t2, 10)[1]
     want = count((0, 1)) + count((0, 2)) - count((0, 1, 2))
     print("mustor: hit counts equal |ab| + |ac| - |abc| on %d of %d queries; matches in all: %d" % (int((totals == want).sum()), len(tids), int(totals.sum())))
+elif kind == "mustand":
+    # "+a +(+b +c)" (RGPU_OP_NESTED_MUST): the and3 batch's triples as nested trees; rows against the flat conjunctions' (same docs and
+    # counts; scores a + (b + c) against (x + y) + z in cost order: equal within 1e-5, and not always bit for bit)
+    tids = indexgen.log_uniform_ranks(3 * 1024, 1, 1000, SEED ^ 0xA3).reshape(-1, 3) - 1
+    tids = np.array([r for r in tids if len(set(r.tolist())) == 3])
+    qs, ts = s.pack([B.build([T(int(a)), B.build([T(int(b)), T(int(c))], [])], []) for a, b, c in tids], leaf)
+    assert all(q["op"] == (1 | (2 << 16) | (1 << 25)) for q in qs)
+    for _ in range(reps + 2):
+        hits, totals = leaf.segment.search_batch(qs, ts, 10)
+    t0 = time.perf_counter()
+    for _ in range(10):
+        leaf.segment.search_batch(qs, ts, 10)
+    print("mustand: %d queries, wall per host-buffer batch %.3f ms" % (len(tids), 1e2 * (time.perf_counter() - t0)))
+    q2, t2 = s.pack([B.build([T(int(x)) for x in r], []) for r in tids], leaf)
+    fh, ft = leaf.segment.search_batch(q2, t2, 10)
+    t0 = time.perf_counter()
+    for _ in range(10):
+        leaf.segment.search_batch(q2, t2, 10)
+    print("flat conjunctions: wall per host-buffer batch %.3f ms" % (1e2 * (time.perf_counter() - t0)))
+    same_bits = int((hits["score"].view(np.int32) == fh["score"].view(np.int32)).all(axis=1).sum())
+    close = np.allclose(np.sort(hits["score"], axis=1), np.sort(fh["score"], axis=1), rtol=1e-5, atol=0)
+    print("mustand: hit counts equal the flat conjunctions' on %d of %d queries; rows with the same score bits %d; all scores within 1e-5: %s"
+          % (int((totals == ft).sum()), len(tids), same_bits, close))
 else:
     if kind == "term":
         tids = indexgen.log_uniform_ranks(1024, 1, 10_000, SEED).reshape(-1, 1) - 1
