@@ -157,6 +157,26 @@ struct NestedBooleanQuery : Query {
     }
     return BooleanQuery::build(std::move(musts), std::move(shoulds), min_should_match, must_not_queries);
   }
+  // "(b c) a d" / "a (b c) d": a should-only query whose FIRST or SECOND clause is itself a should-only BooleanQuery of terms -> the
+  // flat disjunction with the nested clauses moved to the front, else null. DisjunctionSumScorer sums its children in clause order
+  // from 0.0 (SimpleQueue, below ten children: disjunction_scorer.rs:41-45, 211-225), the nested scorer's own sum formed first:
+  // (a + (b + c)) + d; the flat [b, c, a, d] forms ((b + c) + a) + d — the same f32: the one add that differs has two operands
+  // and commutes. Same docs, counts and score bits: no tolerance, no flag. Fewer than ten clauses in all (the clause-order kernel).
+  std::unique_ptr<Query> nested_disjunction_first() const {
+    if (!must_queries.empty() || min_should_match > 1) return nullptr;
+    std::vector<TermQuery> inner, rest;
+    for (size_t i = 0; i < should_queries.size(); ++i) {
+      if (auto* t = dynamic_cast<const TermQuery*>(should_queries[i].get())) { rest.push_back(*t); continue; }
+      auto* b = dynamic_cast<const BooleanQuery*>(should_queries[i].get());
+      if (!b || !inner.empty() || i > 1 || !b->must_queries.empty() || !b->must_not_queries.empty() || b->min_should_match > 1 ||
+          b->should_queries.empty())
+        return nullptr;
+      inner = b->should_queries;
+    }
+    if (inner.empty() || inner.size() + rest.size() >= 10) return nullptr;
+    inner.insert(inner.end(), rest.begin(), rest.end());
+    return BooleanQuery::build({}, std::move(inner), min_should_match, must_not_queries);
+  }
   // "+a +(b c)": MUST term clauses and exactly ONE MUST clause that is a should-only BooleanQuery of 1..9 terms
   // (min_should_match <= 1), no SHOULD clause of its own -> the tree as MUST clauses + required SHOULD clauses
   // (RGPU_OP_WITH_SHOULD(AND, n) | RGPU_OP_SHOULD_REQUIRED), else null. BooleanWeight::create_scorer builds
@@ -459,7 +479,8 @@ class GpuIndexSearcher {
       const Query* q = &query;
       if (auto* nested = dynamic_cast<const NestedBooleanQuery*>(&query)) {
         std::unique_ptr<BooleanQuery> req = nested->required_disjunction();
-        if (req && (flatten_nested || nested_child_sums_last(*req))) folded = std::move(req);
+        if ((folded = nested->nested_disjunction_first())) {}  // exact as a flat disjunction in another clause order
+        else if (req && (flatten_nested || nested_child_sums_last(*req))) folded = std::move(req);
         else if (flatten_nested) folded = nested->flattened();  // (the flat fold leads with the tree's rarest clause: within 1e-5)
         else if ((req = nested->nested_conjunction()) && nested_child_sums_last(*req)) folded = std::move(req);
         if (!folded) throw Error(RGPU_ERR_UNSUPPORTED, "nested boolean clauses are not served by the GPU path");

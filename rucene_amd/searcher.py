@@ -334,6 +334,28 @@ class BooleanQuery:
             return None
         return d
 
+    def nested_disjunction_first(self):
+        """"(b c) a d" / "a (b c) d": a should-only query whose FIRST or SECOND clause is itself a should-only BooleanQuery of terms ->
+        the flat disjunction with the nested clauses moved to the front, else None. DisjunctionSumScorer sums its children in
+        clause order from 0.0 (SimpleQueue, below ten children: disjunction_scorer.rs:41-45, 211-225), the nested scorer's own sum
+        formed first: (a + (b + c)) + d. The flat query [b, c, a, d] forms ((b + c) + a) + d — the same f32, because the one add
+        that differs has two operands and commutes (a doc without a, or without b / c, drops the absent terms from both sums alike).
+        Same docs, same hit count, same score bits: no tolerance, no flag. Fewer than ten clauses in all (the clause-order kernel)."""
+        if self.must_queries or self.filter_queries or self.min_should_match > 1:
+            return None
+        if not all(isinstance(q, TermQuery) for q in self.must_not_queries):
+            return None
+        nested = [i for i, q in enumerate(self.should_queries) if not isinstance(q, TermQuery)]
+        if len(nested) != 1 or nested[0] > 1:
+            return None
+        d = self.should_queries[nested[0]]
+        if not d.is_flat() or d.must_queries or d.must_not_queries or d.filter_queries or d.min_should_match > 1 or not d.should_queries:
+            return None
+        rest = [q for q in self.should_queries if q is not d]
+        if len(d.should_queries) + len(rest) >= 10:
+            return None
+        return BooleanQuery([], list(d.should_queries) + rest, self.min_should_match, self.must_not_queries, [])
+
     def nested_conjunction(self):
         """"+a +(+b +c)": MUST TermQuery clauses and exactly ONE MUST clause that is a must-only BooleanQuery of >= 2 terms, no SHOULD
         clause of its own -> (that nested query) else None. The reference builds ConjunctionScorer([TermScorer ...,
@@ -458,6 +480,9 @@ class GpuIndexSearcher:
                         required = musts + [TermQuery(f.term, 0.0) for f in query.filter_queries]
                         return (OP_AND | (len(d.should_queries) << 16) | OP_SHOULD_REQUIRED, required, list(d.should_queries),
                                 query.must_not_queries)
+                first = query.nested_disjunction_first()
+                if first is not None:
+                    return self._flatten(first)
                 c = None if self.flatten_nested else query.nested_conjunction()
                 if c is not None:
                     musts = [q for q in query.must_queries if q is not c]

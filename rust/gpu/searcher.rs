@@ -182,6 +182,21 @@ impl<C: Codec, R: IndexReader<Codec = C> + ?Sized, IR: Deref<Target = R>, SP: Si
             let op = if positive.len() == 1 { RGPU_OP_TERM } else { RGPU_OP_AND };
             Some(FlatQuery { op: rgpu_op_with_should(op, optional.len() as i32), positive, optional, must_not: prohibited })
         } else {
+            // "a (b c) d": a nested should-only query (msm <= 1) as FIRST or SECOND clause -> the flat disjunction [b, c, a, d], bit-equal:
+            // DisjunctionSumScorer adds its children in clause order from 0.0 (SimpleQueue below ten children, disjunction_scorer.rs:
+            // 211-225), (a + (b + c)) + d, and the flat query's ((b + c) + a) + d differs in one two-operand add, which commutes.
+            if msm <= 1 && should.iter().filter(|q| term_of(q).is_none()).count() == 1 {
+                let at = should.iter().position(|q| term_of(q).is_none())?;
+                if let Some(inner) = should[at].as_any().downcast_ref::<BooleanQuery<C>>() {
+                    let (m, s, f, n, inner_msm) = inner.clauses();
+                    if at <= 1 && m.is_empty() && f.is_empty() && n.is_empty() && inner_msm <= 1 && !s.is_empty() && s.len() + should.len() - 1 < 10 {
+                        let mut exact = Vec::new();
+                        for c in s { let t = term_of(c)?; exact.push((t, t.boost)); }
+                        for (i, q) in should.iter().enumerate() { if i != at { let t = term_of(q)?; exact.push((t, t.boost)); } }
+                        return Some(FlatQuery { op: RGPU_OP_OR, positive: exact, optional: vec![], must_not: prohibited });
+                    }
+                }
+            }
             for q in should { fold(q, false, &mut positive)?; }
             if msm > 1 && folded { return None; }
             let op = if msm > 1 { rgpu_op_or_msm(msm) } else { RGPU_OP_OR };

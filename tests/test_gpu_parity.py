@@ -273,8 +273,8 @@ def test_nested_boolean_trees_through_the_seam(zipf, oracle):
     T, B = rucene_amd.TermQuery, rucene_amd.BooleanQuery
     k = 10
     g2 = rucene_amd.GpuIndexSearcher(gsearcher.leaves, ctx=gsearcher.ctx, flatten_nested=True)
-    nested = [B.build([T(5), B.build([T(1), T(40)], [])], []), B.build([], [T(300), B.build([], [T(7), T(900)]), T(2)])]
-    flat = [(oracle.OP_AND, [5, 1, 40]), (oracle.OP_OR, [300, 7, 900, 2])]
+    nested = [B.build([T(5), B.build([T(1), T(40)], [])], []), B.build([], [T(300), T(2), B.build([], [T(7), T(900)])])]
+    flat = [(oracle.OP_AND, [5, 1, 40]), (oracle.OP_OR, [300, 2, 7, 900])]
     hits, totals = g2.search_batch(nested, k)
     for i, (op, tids) in enumerate(flat):
         d, sc, total = osearcher.search(op, tids, k, tie_mode=oracle.TIE_CANONICAL)
@@ -380,6 +380,38 @@ def test_a_disjunction_under_must(zipf, oracle, ctx, k):
         with pytest.raises(rucene_amd.RgpuError) as e:
             leaf.segment.search_batch(q2, ts, k)
         assert e.value.status == status
+
+
+def test_a_disjunction_as_first_or_second_should_clause(zipf, oracle):
+    """"a (b c) d": DisjunctionSumScorer over [TermScorer(a), DisjunctionSumScorer(b, c), TermScorer(d)] adds its children in clause
+    order from 0.0, each child's own sum formed first (disjunction_scorer.rs:211-225). The mirrors send the flat disjunction
+    [b, c, a, d]: the nested sums restated here child by child from the oracle's scorers must equal the rows bit for bit."""
+    import rucene_amd
+    seg, osearcher, gsearcher = zipf
+    T, B = rucene_amd.TermQuery, rucene_amd.BooleanQuery
+    oseg = oracle.Segment(seg.doc_bytes, seg.norms, seg.max_doc, seg.terms, sum_total_term_freq=seg.sum_total_term_freq)
+    k = 50
+    cases = [([300], [7, 900], [2]), ([], [40, 1], [5, 12]), ([4000], [5000, 6000, 7000], [8000, 9000, 30]), ([1], [0, 2], [3]),
+             ([49_999], [100, 200], []), ([30], [31, 32, 33, 34, 35], [36, 37])]
+    queries, expect = [], []
+    for before, inner, after in cases:
+        queries.append(B.build([], [T(t) for t in before] + [B.build([], [T(t) for t in inner])] + [T(t) for t in after]))
+        cand = np.unique(np.concatenate([np.asarray(oseg.decode_term(seg.terms[t])[0], dtype=np.int32) for t in before + inner + after]))
+        children = [(oracle.OP_TERM, [t]) for t in before] + [(oracle.OP_OR, inner)] + [(oracle.OP_TERM, [t]) for t in after]
+        total = np.zeros(cand.size, dtype=np.float32)
+        for op, tids in children:   # score = 0.0; for each child on the doc, in clause order: score += child.score()
+            sc, m = osearcher.score_docs(op, tids, cand)
+            total = np.where(m, (total + sc.astype(np.float32)).astype(np.float32), total)
+        order = np.lexsort((cand, -total.astype(np.float64)))[:k]
+        expect.append((cand.size, cand[order], total[order]))
+    hits, totals = gsearcher.search_batch(queries, k)
+    for i, (n_hits, d, sc) in enumerate(expect):
+        assert totals[i] == n_hits, cases[i]
+        assert (hits[i]["doc"][:d.size] == d).all(), cases[i]
+        assert (hits[i]["score"][:d.size].view(np.int32) == sc.view(np.int32)).all(), cases[i]
+    with pytest.raises(rucene_amd.RgpuError) as e:   # the nested disjunction as THIRD clause: two adds precede it, nothing commutes
+        gsearcher.search_batch([B.build([], [T(1), T(2), B.build([], [T(3), T(4)])])], k)
+    assert e.value.status == -5
 
 
 @pytest.mark.parametrize("k", [10, 100])

@@ -219,7 +219,8 @@ def test_nested_boolean_trees_fold_one_level_or_fall_back(world):
     ra, seg, leaf, s = world
     T, B = ra.TermQuery, ra.BooleanQuery
     nested_and = B.build([T(1), B.build([T(2), T(3)], [])], [])
-    nested_or = B.build([], [T(4), B.build([], [T(5), T(6)]), T(7)])
+    nested_or = B.build([], [T(4), T(7), B.build([], [T(5), T(6)])])              # the nested disjunction as THIRD clause: foldable only
+    nested_or_2nd = B.build([], [T(4), B.build([], [T(5), T(6)]), T(7)])          # ... as first or second clause: exact as [5, 6, 4, 7]
     mixed = B.build([B.build([], [T(2), T(3)]), B.build([], [T(4), T(5)])], [])   # two disjunctions under MUST: not served
     with_msm = B.build([], [T(4), B.build([], [T(5), T(6)])], min_should_match=2)   # msm counts the OUTER clauses: not foldable
     deep = B.build([T(1), B.build([T(2), B.build([T(3), T(4)], [])], [])], [])      # two levels: not foldable
@@ -234,9 +235,19 @@ def test_nested_boolean_trees_fold_one_level_or_fall_back(world):
     q, t = s.pack([nested_and], leaf)
     flat_q, flat_t = s.pack([B.build([T(1), T(2), T(3)], [])], leaf)
     assert q[0]["op"] == (ra.OP_AND | (2 << 16) | ra._lib.OP_NESTED_MUST) and q[0]["n_terms"] == 1 and t.tobytes() == flat_t.tobytes()
+    # SHOULD [t4, SHOULD [t5, t6], t7]: DisjunctionSumScorer adds its children in clause order from 0.0, (t4 + (t5 + t6)) + t7 — the
+    # flat disjunction with the nested clauses in FRONT forms ((t5 + t6) + t4) + t7: the one add that differs commutes. No flag.
+    for fl in (False, True):
+        s.flatten_nested = fl
+        q, t = s.pack([nested_or_2nd, B.build([], [B.build([], [T(5), T(6)]), T(4), T(7)], must_nots=[T(9)])], leaf)
+        flat_q, flat_t = s.pack([B.build([], [T(5), T(6), T(4), T(7)]), B.build([], [T(5), T(6), T(4), T(7)], must_nots=[T(9)])], leaf)
+        assert (q == flat_q).all() and (t == flat_t).all()
+    s.flatten_nested = False
+    with pytest.raises(ra.RgpuError):   # ten clauses in all: the heap-order kernels would take the flat query
+        s.pack([B.build([], [T(1), B.build([], [T(i) for i in range(2, 9)]), T(10), T(11)])], leaf)
     s.flatten_nested = True
     q, t = s.pack([nested_and, nested_or], leaf)
-    flat_q, flat_t = s.pack([B.build([T(1), T(2), T(3)], []), B.build([], [T(4), T(5), T(6), T(7)])], leaf)
+    flat_q, flat_t = s.pack([B.build([T(1), T(2), T(3)], []), B.build([], [T(4), T(7), T(5), T(6)])], leaf)
     assert (q == flat_q).all() and (t == flat_t).all()               # the folded tree IS the flat query
     for q in (mixed, with_msm, deep):
         with pytest.raises(ra.RgpuError) as e:
