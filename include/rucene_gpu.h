@@ -156,10 +156,8 @@ typedef enum rgpu_query_op {
  * "+a +(b c)", a should-only BooleanQuery (min_should_match <= 1) nested under MUST, which BooleanWeight::create_scorer turns into
  * ConjunctionScorer([TermScorer(a) ..., DisjunctionSumScorer(b, c)]) (query/boolean_query.rs:200-215, 217-233;
  * scorer/conjunction_scorer.rs:27-43). A doc matches when every MUST clause AND at least one of the n SHOULD clauses hold it; its
- * score is the MUST sum (cost order) plus the disjunction's own sum (clause order) — ConjunctionScorer::score (:87-95) with the
- * disjunction as its LAST child, which is where the stable sort by cost puts it when the SHOULD clauses' doc freqs add up to more
- * than any MUST clause's doc freq (with a single MUST clause the f32 add commutes and any order is exact). The host mirrors send a
- * tree here only then; otherwise the sums agree within 1e-5 relative, not bit for bit. ReqOptScorer's doc-to-doc rule does not
+ * score is ConjunctionScorer::score (:87-95) over the children in their stable cost order, the disjunction contributing its own
+ * sum (clause order) at its place — see RGPU_OP_NESTED_AT: bit-equal to the reference. ReqOptScorer's doc-to-doc rule does not
  * apply (there is no ReqOptScorer in this tree), rgpu_config.req_opt_rule is not consulted. 1 <= n <= 9 (ten or more children
  * sum in heap order: disjunction_scorer.rs:41-45); every SHOULD clause absent from the leaf = the nested weight has no scorer =
  * the query matches nothing there (boolean_query.rs:203-207). */
@@ -168,12 +166,19 @@ typedef enum rgpu_query_op {
  * under MUST — "+a +(+b +c)", ConjunctionScorer([TermScorer(a) ..., ConjunctionScorer(b, c)]). A doc matches when every MUST clause
  * and every one of the n nested clauses hold it (the same docs and hit count as the flat conjunction); its score is the MUST sum
  * (cost order) plus the nested conjunction's own sum — lead1 + lead2 + others over the n clauses in THEIR cost order, formed first
- * (conjunction_scorer.rs:27-43, 87-95; the library sorts them by doc_freq per leaf, stable). That is ConjunctionScorer::score with
- * the nested conjunction as the LAST child: its cost is its cheapest clause's doc_freq, so it is last when that exceeds every MUST
- * clause's doc freq; with a single MUST clause the f32 add commutes. The host mirrors send a tree here only then. n >= 2 (a nested
+ * (conjunction_scorer.rs:27-43, 87-95; the library sorts them by doc_freq per leaf, stable), added at the nested child's place
+ * in the outer cost order — see RGPU_OP_NESTED_AT: bit-equal to the reference. n >= 2 (a nested
  * query of one clause is that clause: boolean_query.rs:56-68); a nested clause absent from the leaf = no scorer = nothing matches.
  * Not combined with RGPU_OP_SHOULD_REQUIRED. */
 #define RGPU_OP_NESTED_MUST ((int32_t)1 << 25)
+/* With either flag, where the nested clause stands among the MUST clauses: RGPU_OP_NESTED_AT(i) = it is the caller's (i + 1)-th
+ * MUST child, i of the n_terms MUST term clauses precede it (0 .. n_terms; 0 when omitted). ConjunctionScorer::new sorts ALL its
+ * children by cost(), stable — a term's doc_freq in the leaf, a nested disjunction's the sum of its clauses' doc freqs, a nested
+ * conjunction's its cheapest clause's (conjunction_scorer.rs:30, 111-113) — and score() adds them in that order (:87-95). The
+ * library does that sort per leaf: the MUST terms that sort before the nested child are summed first, the nested sum is added to
+ * that, the MUST terms behind it are added one by one — the reference's f32 sum for EVERY such tree, bit for bit, whatever the
+ * costs (the index only breaks ties, as the stable sort does). */
+#define RGPU_OP_NESTED_AT(i) ((int32_t)((uint32_t)(i) << 26))
 
 typedef struct rgpu_query {
   int32_t op;          /* rgpu_query_op (OR: optionally RGPU_OP_OR_MSM(msm); TERM / AND: optionally RGPU_OP_WITH_SHOULD(op, n) —

@@ -63,7 +63,7 @@ class BatchPlanner {
     for (int32_t q = 0; q < n_queries; ++q) {
       const int32_t op = ops[q] & 0xff, n_opt = (ops[q] >> 16) & 0xff;
       const int32_t nt = n_terms[q], nn = n_must_not ? n_must_not[q] : 0;
-      if (op < RGPU_OP_TERM || op > RGPU_OP_OR || (ops[q] & ~(0xffffff | RGPU_OP_SHOULD_REQUIRED | RGPU_OP_NESTED_MUST)) != 0) { *why = "unknown query op"; return RGPU_ERR_ILLEGAL_ARGUMENT; }
+      if (op < RGPU_OP_TERM || op > RGPU_OP_OR || (ops[q] & ~(0xffffff | RGPU_OP_SHOULD_REQUIRED | RGPU_OP_NESTED_MUST | RGPU_OP_NESTED_AT(63))) != 0) { *why = "unknown query op"; return RGPU_ERR_ILLEGAL_ARGUMENT; }
       if (nt < 0 || nn < 0 || (op == RGPU_OP_TERM && nt != 1)) { *why = "bad clause count"; return RGPU_ERR_ILLEGAL_ARGUMENT; }
       if (nt + n_opt + nn > RGPU_MAX_QUERY_TERMS) { *why = "more than RGPU_MAX_QUERY_TERMS clauses in one query"; return RGPU_ERR_UNSUPPORTED; }
       int32_t out_op = ops[q];

@@ -92,6 +92,7 @@ struct BooleanQuery : Query {
   // RGPU_OP_NESTED_MUST: the SHOULD slots hold a must-only BooleanQuery nested under MUST ("+a +(+b +c)") — set by
   // NestedBooleanQuery::nested_conjunction
   bool nested_must = false;
+  int32_t nested_at = 0;  // RGPU_OP_NESTED_AT: how many of the MUST term clauses stood before the nested clause in the caller's query
   // boolean_query.rs:40-86 restricted to what the GPU path serves: SHOULD-only term trees, or MUST clauses with optional
   // SHOULD clauses beside them (ReqOptScorer, its sequential skipping rule included: see RGPU_OP_WITH_SHOULD), each
   // optionally with MUST_NOT term clauses (ReqNotScorer); a single clause without MUST_NOTs
@@ -181,7 +182,7 @@ struct NestedBooleanQuery : Query {
   // (min_should_match <= 1), no SHOULD clause of its own -> the tree as MUST clauses + required SHOULD clauses
   // (RGPU_OP_WITH_SHOULD(AND, n) | RGPU_OP_SHOULD_REQUIRED), else null. BooleanWeight::create_scorer builds
   // ConjunctionScorer([TermScorer ..., DisjunctionSumScorer]) for it (boolean_query.rs:200-215). Whether the kernel's sum — MUST
-  // sum + disjunction sum — is the reference's, bit for bit, depends on the children's costs: GpuIndexSearcher::disjunction_sums_last.
+  // sum + disjunction sum — is the reference's, bit for bit, depends on the children's costs: the library's per-leaf sort (RGPU_OP_NESTED_AT).
   std::unique_ptr<BooleanQuery> required_disjunction() const {
     if (!should_queries.empty()) return nullptr;
     std::unique_ptr<BooleanQuery> out(new BooleanQuery());
@@ -191,6 +192,7 @@ struct NestedBooleanQuery : Query {
       auto* b = dynamic_cast<const BooleanQuery*>(q.get());
       if (!b || nested) return nullptr;
       nested = b;
+      out->nested_at = static_cast<int32_t>(out->must_queries.size());
     }
     if (!nested || out->must_queries.empty() || !nested->must_queries.empty() || !nested->must_not_queries.empty() || nested->should_required ||
         nested->min_should_match > 1 || nested->should_queries.empty() || nested->should_queries.size() > 9)
@@ -202,8 +204,8 @@ struct NestedBooleanQuery : Query {
   }
   // "+a +(+b +c)": MUST term clauses and exactly ONE MUST clause that is a must-only BooleanQuery of >= 2 terms, no SHOULD clause of
   // its own -> MUST clauses + the nested clauses in the SHOULD slots with nested_must set (RGPU_OP_WITH_SHOULD(AND, n) |
-  // RGPU_OP_NESTED_MUST), else null. The reference sums the nested conjunction first (conjunction_scorer.rs:87-95): bit-exact under
-  // GpuIndexSearcher::nested_child_sums_last, where the flat fold (flattened()) is within 1e-5.
+  // RGPU_OP_NESTED_MUST), else null. The reference sums the nested conjunction first (conjunction_scorer.rs:87-95): bit for bit
+  // (the library sorts the children per leaf), where the flat fold (flattened()) is within 1e-5.
   std::unique_ptr<BooleanQuery> nested_conjunction() const {
     if (!should_queries.empty()) return nullptr;
     std::unique_ptr<BooleanQuery> out(new BooleanQuery());
@@ -213,6 +215,7 @@ struct NestedBooleanQuery : Query {
       auto* b = dynamic_cast<const BooleanQuery*>(q.get());
       if (!b || nested) return nullptr;
       nested = b;
+      out->nested_at = static_cast<int32_t>(out->must_queries.size());
     }
     if (!nested || out->must_queries.empty() || !nested->should_queries.empty() || !nested->must_not_queries.empty() || nested->should_required ||
         nested->nested_must || nested->must_queries.size() < 2)
@@ -479,10 +482,12 @@ class GpuIndexSearcher {
       const Query* q = &query;
       if (auto* nested = dynamic_cast<const NestedBooleanQuery*>(&query)) {
         std::unique_ptr<BooleanQuery> req = nested->required_disjunction();
+        // (the library sorts a conjunction's children by cost per leaf and adds a nested child's sum where ConjunctionScorer::score
+        // adds it — RGPU_OP_NESTED_AT breaks ties like the stable sort: the reference's f32 sums whatever the costs)
         if ((folded = nested->nested_disjunction_first())) {}  // exact as a flat disjunction in another clause order
-        else if (req && (flatten_nested || nested_child_sums_last(*req))) folded = std::move(req);
-        else if (flatten_nested) folded = nested->flattened();  // (the flat fold leads with the tree's rarest clause: within 1e-5)
-        else if ((req = nested->nested_conjunction()) && nested_child_sums_last(*req)) folded = std::move(req);
+        else if (req) folded = std::move(req);
+        else if ((req = nested->nested_conjunction())) folded = std::move(req);
+        else if (flatten_nested) folded = nested->flattened();  // (what is left — two nested clauses, a disjunction from the third SHOULD clause on — within 1e-5)
         if (!folded) throw Error(RGPU_ERR_UNSUPPORTED, "nested boolean clauses are not served by the GPU path");
         q = folded.get();
       }
@@ -493,29 +498,6 @@ class GpuIndexSearcher {
       if (e.kind != RGPU_ERR_UNSUPPORTED || !cpu_fallback) throw;  // ErrorKind::UnsupportedOperation -> the CPU path
       cpu_fallback(query, collector);
     }
-  }
-
-  // Is ConjunctionScorer::score's f32 sum over [MUST terms ..., nested scorer] the MUST sum plus the nested scorer's sum — what the
-  // kernel forms — in EVERY leaf? The children are sorted by cost() (stable, conjunction_scorer.rs:30): a term's doc_freq in the
-  // leaf, a DisjunctionSumScorer's = the sum of its clauses' (should_required), a nested ConjunctionScorer's = its cheapest
-  // clause's (nested_must, conjunction_scorer.rs:111-113). With one scoring MUST clause the add commutes; otherwise the nested
-  // scorer has to be the costliest child (strictly: ties keep clause order).
-  bool nested_child_sums_last(const BooleanQuery& q) const {
-    size_t scoring = 0;
-    for (const TermQuery& m : q.must_queries) scoring += m.boost != 0.0f ? 1 : 0;
-    if (scoring <= 1) return true;
-    for (const LeafReader& leaf : leaves_) {
-      auto df = [&](const TermQuery& t) -> int64_t { rgpu_term_state st{}; return leaf.term_state(t, &st) ? st.doc_freq : 0; };
-      int64_t must_max = 0, should_sum = 0;
-      bool dead = false;
-      for (const TermQuery& m : q.must_queries) { const int64_t d = df(m); dead = dead || d == 0; if (m.boost != 0.0f) must_max = std::max(must_max, d); }
-      if (dead) continue;  // a MUST clause without a scorer: nothing matches in this leaf
-      int64_t should_min = INT64_MAX;
-      for (const TermQuery& c : q.should_queries) { const int64_t d = df(c); should_sum += d; should_min = std::min(should_min, d); }
-      if (q.nested_must && should_min == 0) continue;  // (the nested conjunction has no scorer here either)
-      if ((q.nested_must ? should_min : should_sum) <= must_max) return false;
-    }
-    return true;
   }
 
   // the batched form the hardware wants: one launch set per leaf for many queries
@@ -656,7 +638,7 @@ class GpuIndexSearcher {
         clause(*t);
       } else if (auto* b = dynamic_cast<const BooleanQuery*>(q)) {
         const bool conj = !b->must_queries.empty();
-        ops.push_back(conj ? (RGPU_OP_WITH_SHOULD(RGPU_OP_AND, b->should_queries.size()) | (b->should_required ? RGPU_OP_SHOULD_REQUIRED : 0) | (b->nested_must ? RGPU_OP_NESTED_MUST : 0))
+        ops.push_back(conj ? (RGPU_OP_WITH_SHOULD(RGPU_OP_AND, b->should_queries.size()) | (b->should_required ? RGPU_OP_SHOULD_REQUIRED : 0) | (b->nested_must ? RGPU_OP_NESTED_MUST : 0) | RGPU_OP_NESTED_AT(b->nested_at))
                            : (b->min_should_match > 1 ? RGPU_OP_OR_MSM(b->min_should_match) : (int32_t)RGPU_OP_OR));
         n_terms.push_back(static_cast<int32_t>(conj ? b->must_queries.size() : b->should_queries.size()));
         n_not.push_back(static_cast<int32_t>(b->must_not_queries.size()));
@@ -707,7 +689,7 @@ class GpuIndexSearcher {
       clauses = &single;
     } else if (auto* b = dynamic_cast<const BooleanQuery*>(&q)) {
       op = b->must_queries.empty() ? (b->min_should_match > 1 ? RGPU_OP_OR_MSM(b->min_should_match) : (int32_t)RGPU_OP_OR)
-                                   : (RGPU_OP_WITH_SHOULD(RGPU_OP_AND, b->should_queries.size()) | (b->should_required ? RGPU_OP_SHOULD_REQUIRED : 0) | (b->nested_must ? RGPU_OP_NESTED_MUST : 0));
+                                   : (RGPU_OP_WITH_SHOULD(RGPU_OP_AND, b->should_queries.size()) | (b->should_required ? RGPU_OP_SHOULD_REQUIRED : 0) | (b->nested_must ? RGPU_OP_NESTED_MUST : 0) | RGPU_OP_NESTED_AT(b->nested_at));
       clauses = b->must_queries.empty() ? &b->should_queries : &b->must_queries;
       if (!b->must_queries.empty()) opts = &b->should_queries;
       nots = &b->must_not_queries;

@@ -276,7 +276,10 @@ __global__ __launch_bounds__(AND_WG_THREADS, AND_WAVES_PER_SIMD) void k_search_a
     // The reference's sequential "skip the optional clause for low scorers after 100 docs" rule is NOT applied:
     // scores are the exact sums, >= the reference's)
     const int n_req_not = HAS_NOT ? Q.n_terms + Q.pad : Q.n_terms;
-    const int n_clauses = HAS_OPT ? n_req_not + ((Q.op >> 16) & 0xff) : n_req_not;
+    // (HAS_OPT) behind the optional / nested group: the MUST clauses that ConjunctionScorer::score adds AFTER the nested child
+    // (rgpu_api.hip search_pass: the children's stable cost order) — required like the first ones, added to (first sum + group sum)
+    const int n_opt_end = HAS_OPT ? n_req_not + ((Q.op >> 16) & 0xff) : n_req_not;
+    const int n_clauses = HAS_OPT ? n_opt_end + (int)((uint32_t)Q.op >> 26) : n_req_not;
     float r0 = 0.f, r1 = 0.f;  // required sums, parked while s0 / s1 collect the optional sum
     bool in_opt = false;
     // RGPU_OP_SHOULD_REQUIRED ("+a +(b c)": the SHOULD clauses are a DisjunctionSumScorer among the ConjunctionScorer's children,
@@ -296,8 +299,12 @@ __global__ __launch_bounds__(AND_WG_THREADS, AND_WAVES_PER_SIMD) void k_search_a
     for (int ti = RGPU_AND_FAST ? ti_start : 1; ti < n_clauses; ++ti) {
       if (!(__ballot(a0) | __ballot(a1))) break;
       const bool excl = HAS_NOT && ti >= Q.n_terms && ti < n_req_not;  // wave-uniform
-      const bool opt = HAS_OPT && ti >= n_req_not;                      // wave-uniform
+      const bool opt = HAS_OPT && ti >= n_req_not && ti < n_opt_end;    // wave-uniform
       if (HAS_OPT && opt && !in_opt) { r0 = s0; r1 = s1; s0 = 0.f; s1 = 0.f; in_opt = true; }
+      if (HAS_OPT && ti >= n_opt_end && in_opt) {  // the group's sum joins; the rest add to it
+        s0 = r0 + s0; s1 = r1 + s1; in_opt = false;
+        if (need_any) { a0 = a0 && (any_opt & 1u) != 0u; a1 = a1 && (any_opt & 2u) != 0u; }
+      }
       const DevTerm T = terms[Q.first_term + ti];
       if (!excl) {
         use_table(T.sim_table);

@@ -2701,7 +2701,9 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
   for (int32_t q = 0; q < n_queries; ++q) {
     const rgpu_query& Q = queries[q];
     const int qop = Q.op & 0xff, qmsm = (Q.op >> 8) & 0xff, qopt = (Q.op >> 16) & 0xff;
-    if (qop < RGPU_OP_TERM || qop > RGPU_OP_OR || (Q.op & ~(0xffffff | RGPU_OP_SHOULD_REQUIRED | RGPU_OP_NESTED_MUST)) != 0) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "unknown query op");
+    if (qop < RGPU_OP_TERM || qop > RGPU_OP_OR || (Q.op & ~(0xffffff | RGPU_OP_SHOULD_REQUIRED | RGPU_OP_NESTED_MUST | RGPU_OP_NESTED_AT(63))) != 0) return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "unknown query op");
+    if (((uint32_t)Q.op >> 26) != 0 && (!(Q.op & (RGPU_OP_SHOULD_REQUIRED | RGPU_OP_NESTED_MUST)) || (int)((uint32_t)Q.op >> 26) > Q.n_terms))
+      return fail(RGPU_ERR_ILLEGAL_ARGUMENT, "RGPU_OP_NESTED_AT: the nested clause's index among the MUST clauses, 0 .. n_terms, with RGPU_OP_SHOULD_REQUIRED / RGPU_OP_NESTED_MUST");
     // "+a +(b c)": the SHOULD clauses as a nested disjunction under MUST (ConjunctionScorer over the MUST clauses and one
     // DisjunctionSumScorer). Ten or more children would sum in heap order (disjunction_scorer.rs:41-45): not served here.
     if ((Q.op & RGPU_OP_SHOULD_REQUIRED) && (qop == RGPU_OP_OR || qopt < 1))
@@ -2838,7 +2840,7 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
   groups[4].req_opt = true;
   int cur_req_opt = 4;
   int64_t req_opt_records = 0;
-  std::vector<DevTerm> mine, mine_not, mine_opt;
+  std::vector<DevTerm> mine, mine_not, mine_opt, mine_suffix;
   std::vector<int64_t> mine_bytes;
   for (int32_t q = 0; q < n_queries; ++q) {
     const rgpu_query& Q = queries[q];
@@ -2847,6 +2849,7 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
     mine.clear();
     mine_not.clear();
     mine_opt.clear();
+    mine_suffix.clear();
     mine_bytes.clear();
     bool dead = false;
     for (int i = 0; i < Q.n_terms; ++i) {
@@ -2890,14 +2893,37 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
         mine_not.push_back(dt);
       }
     }
-    if (qop == RGPU_OP_AND)  // ConjunctionScorer::new: stable sort by cost() = doc_freq (conjunction_scorer.rs:30)
+    // A nested scorer among the MUST children ("+a +b +(c d)", "+a +(+c +d) +b"): ConjunctionScorer::new sorts ALL its children by
+    // cost(), stable (conjunction_scorer.rs:30) — a term's doc_freq, a nested DisjunctionSumScorer's the sum of its clauses', a nested
+    // ConjunctionScorer's its cheapest clause's — and score() adds them in that order (:87-95). The nested child's place p in that
+    // order splits the MUST terms into the ones summed before it and the ones added after it: device clause order [prefix]
+    // [MUST_NOT][nested group][suffix], the kernel forms ((prefix sum) + (group sum)) + suffix clauses one by one. Ties keep the
+    // caller's clause order: RGPU_OP_NESTED_AT names the nested child's index among the MUST clauses.
+    bool nested_flat = false;  // the nested conjunction is the cheapest child: the tree is the flat conjunction [nested clauses][MUST terms]
+    if ((should_required || nested_must) && !mine.empty() && !mine_opt.empty()) {
+      const int at = (int)((uint32_t)Q.op >> 26);
+      int64_t cost = nested_must ? INT64_MAX : 0;
+      for (const DevTerm& m : mine_opt) cost = nested_must ? std::min<int64_t>(cost, m.df) : cost + m.df;
+      size_t p = 0;  // MUST terms that precede the nested child in the stable cost order
+      for (size_t i = 0; i < mine.size(); ++i) p += (mine[i].df < cost || (mine[i].df == cost && (int)i < at)) ? 1 : 0;
       std::stable_sort(mine.begin(), mine.end(), [](const DevTerm& a, const DevTerm& b) { return a.df < b.df; });
-    // A nested conjunction: the kernel forms sum(first group, lead first) + sum(second group), and that last add commutes — so the
-    // group that holds the rarer clause leads, as lead1 does in the reference's flat iteration (conjunction_scorer.rs:30-43): the
-    // nested tree then costs what the flat conjunction costs. (Each group is already in its own cost order.)
-    if (nested_must && !mine.empty() && !mine_opt.empty() && mine_opt[0].df < mine[0].df) mine.swap(mine_opt);
+      if (p == 0 && nested_must) {
+        // lead1 is the nested conjunction: (N + c1) + c2 ... — its own clauses first, in their order, then the MUST terms in theirs:
+        // a flat conjunction in that clause order (and at the flat conjunction's cost: its rarest clause leads)
+        mine_opt.insert(mine_opt.end(), mine.begin(), mine.end());
+        mine.swap(mine_opt);
+        mine_opt.clear();
+        nested_flat = true;
+      } else {
+        if (p == 0) p = 1;  // a disjunction cannot lead here: (N + c1) == (c1 + N), the first add commutes
+        mine_suffix.assign(mine.begin() + (ptrdiff_t)p, mine.end());
+        mine.resize(p);
+      }
+    } else if (qop == RGPU_OP_AND) {  // ConjunctionScorer::new: stable sort by cost() = doc_freq (conjunction_scorer.rs:30)
+      std::stable_sort(mine.begin(), mine.end(), [](const DevTerm& a, const DevTerm& b) { return a.df < b.df; });
+    }
     // a term with prohibited / optional clauses runs as a one-clause conjunction (the lead-driven kernel probes them)
-    const int gop = (qop == RGPU_OP_TERM && (!mine_not.empty() || !mine_opt.empty())) ? (int)RGPU_OP_AND : qop;
+    const int gop = (qop == RGPU_OP_TERM && (!mine_not.empty() || !mine_opt.empty() || nested_flat)) ? (int)RGPU_OP_AND : qop;
     // disjunction_scorer.rs:41-45: >= 10 children and min_should_match <= 1 -> the heap; weights must be >= +0 (the
     // kernel's "untouched" accumulator is -0.0f)
     // (the fixed-point kernels keep per-clause state for up to 16 clauses; a longer disjunction takes the clause-order kernel)
@@ -2936,7 +2962,8 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
     // the window kernel reads min_should_match from the second byte, the conjunction kernel its optional clause count
     // from the third; device clause order: MUST, MUST_NOT, SHOULD
     dq.op = gop | ((qmsm > 1 && gop == RGPU_OP_OR) ? qmsm << 8 : 0) | ((int32_t)mine_opt.size() << 16) |
-            ((should_required && !mine.empty()) ? RGPU_OP_SHOULD_REQUIRED : 0) | ((nested_must && !mine.empty()) ? RGPU_OP_NESTED_MUST : 0);
+            ((should_required && !mine.empty()) ? RGPU_OP_SHOULD_REQUIRED : 0) | ((nested_must && !mine.empty() && !nested_flat) ? RGPU_OP_NESTED_MUST : 0) |
+            (int32_t)((uint32_t)mine_suffix.size() << 26);  // (device side: bits 26.. = MUST clauses added after the nested group)
     dq.first_term = (int32_t)G.terms.size();
     dq.n_terms = (int32_t)mine.size();
     dq.pad = (int32_t)mine_not.size();
@@ -2944,6 +2971,7 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
     if (to_wide) G.term_bytes.insert(G.term_bytes.end(), mine_bytes.begin(), mine_bytes.end());
     for (auto& m : mine_not) { G.terms.push_back(m); G.postings += m.df; }
     for (auto& m : mine_opt) { G.terms.push_back(m); G.postings += m.df; }
+    for (auto& m : mine_suffix) { G.terms.push_back(m); G.postings += m.df; }
     G.qmap.push_back(q);
     G.queries.push_back(dq);
   }
@@ -2991,7 +3019,7 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
       for (int i = 0; i < nq; ++i) order[(size_t)i] = i;
       auto key_of = [&](int i) -> uint64_t {
         const DevQuery& q0 = G.queries[(size_t)i];
-        const int n_all = q0.n_terms + q0.pad + ((q0.op >> 16) & 0xff);
+        const int n_all = q0.n_terms + q0.pad + ((q0.op >> 16) & 0xff) + (int)((uint32_t)q0.op >> 26);
         return n_all >= 2 && q0.n_terms >= 1 ? G.terms[(size_t)(q0.first_term + 1)].start_fp : 0ull;
       };
       std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return key_of(a) > key_of(b); });
@@ -3057,7 +3085,7 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
       bool any = false;
       clause_bitmaps.assign(G.terms.size(), TermBitmap{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0});
       for (const DevQuery& q0 : G.queries) {
-        const int n_all = q0.n_terms + q0.pad + ((q0.op >> 16) & 0xff);
+        const int n_all = q0.n_terms + q0.pad + ((q0.op >> 16) & 0xff) + (int)((uint32_t)q0.op >> 26);
         for (int i = 1; i < n_all; ++i) {
           const DevTerm& t = G.terms[(size_t)(q0.first_term + i)];
           if (t.df < min_df) {
@@ -3148,7 +3176,7 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
                            clause_bitmaps.empty() ? (const TermBitmap*)nullptr : reinterpret_cast<const TermBitmap*>(c->S->d_stage.p + o_bm), xcd_chunk);
       };
       bool has_not = false, has_opt = false;
-      for (const DevQuery& q : G.queries) { has_not = has_not || q.pad != 0; has_opt = has_opt || (q.op >> 16) != 0; }
+      for (const DevQuery& q : G.queries) { has_not = has_not || q.pad != 0; has_opt = has_opt || ((q.op >> 16) & 0xff) != 0; }
       if (has_opt) {  // one instantiation serves MUST_NOT too (rare trees: keep the instantiation count down)
         if (legacy) { if (wide) go(k_search_and<true, true, true, true>); else go(k_search_and<true, false, true, true>); }
         else { if (wide) go(k_search_and<false, true, true, true>); else go(k_search_and<false, false, true, true>); }

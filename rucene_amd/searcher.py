@@ -215,6 +215,11 @@ def open_directory(path, field="body"):
     return leaves
 
 
+def _i32(op):
+    """rgpu_query.op is an int32: RGPU_OP_NESTED_AT(i >= 32) sets its sign bit"""
+    return ((int(op) + (1 << 31)) & 0xFFFFFFFF) - (1 << 31)
+
+
 class TermQuery:
     """term: bytes (resolved through each leaf's term dictionary) or an int term id (synthetic flat term table)."""
 
@@ -470,26 +475,23 @@ class GpuIndexSearcher:
             return OP_TERM, [query], [], []
         if isinstance(query, BooleanQuery):
             if not query.is_flat():
-                d = query.required_disjunction()
-                if d is not None:
-                    musts = [q for q in query.must_queries if q is not d]
-                    if not (musts or query.filter_queries):
-                        # (a lone nested MUST clause: BooleanQuery::build has already rewritten such a tree to the clause itself)
-                        raise RgpuError(-5, "a nested disjunction with no clause beside it is that disjunction")
-                    if self.flatten_nested or self._nested_child_sums_last(musts, d.should_queries, sum):
-                        required = musts + [TermQuery(f.term, 0.0) for f in query.filter_queries]
-                        return (OP_AND | (len(d.should_queries) << 16) | OP_SHOULD_REQUIRED, required, list(d.should_queries),
-                                query.must_not_queries)
                 first = query.nested_disjunction_first()
                 if first is not None:
                     return self._flatten(first)
-                c = None if self.flatten_nested else query.nested_conjunction()
-                if c is not None:
-                    musts = [q for q in query.must_queries if q is not c]
-                    if (musts or query.filter_queries) and self._nested_child_sums_last(musts, c.must_queries, min):
-                        # (without flatten_nested only: the flat fold below serves every such tree within 1e-5 and leads with its rarest clause)
-                        required = musts + [TermQuery(f.term, 0.0) for f in query.filter_queries]
-                        return (OP_AND | (len(c.must_queries) << 16) | OP_NESTED_MUST, required, list(c.must_queries), query.must_not_queries)
+                # "+a +(b c)" / "+a +(+b +c)": ONE nested should-only / must-only query among the MUST clauses. The library sorts the
+                # conjunction's children by cost per leaf as ConjunctionScorer::new does and adds the nested sum where the reference
+                # adds it (RGPU_OP_NESTED_AT breaks ties like the stable sort): the reference's f32 sums, whatever the costs.
+                for nested, flag in ((query.required_disjunction(), OP_SHOULD_REQUIRED), (query.nested_conjunction(), OP_NESTED_MUST)):
+                    if nested is None:
+                        continue
+                    at = [q is nested for q in query.must_queries].index(True)
+                    musts = [q for q in query.must_queries if q is not nested]
+                    if not (musts or query.filter_queries):
+                        # (a lone nested MUST clause: BooleanQuery::build has already rewritten such a tree to the clause itself)
+                        raise RgpuError(-5, "a nested query with no clause beside it is that query")
+                    inner = list(nested.should_queries if flag == OP_SHOULD_REQUIRED else nested.must_queries)
+                    required = musts + [TermQuery(f.term, 0.0) for f in query.filter_queries]
+                    return _i32(OP_AND | (len(inner) << 16) | flag | (at << 26)), required, inner, query.must_not_queries
                 folded = query.flattened() if getattr(self, "flatten_nested", False) else None
                 if folded is None:
                     raise RgpuError(-5, "nested boolean clauses are not served by the GPU path (flatten_nested folds one level of MUST-of-MUSTs / SHOULD-of-SHOULDs)")
@@ -501,27 +503,6 @@ class GpuIndexSearcher:
             msm = query.min_should_match
             return (OP_OR | (msm << 8) if msm > 1 else OP_OR), query.should_queries, [], query.must_not_queries
         raise RgpuError(-5, "query type not served by the GPU path: %r" % (query,))
-
-    def _nested_child_sums_last(self, musts, inner, cost):
-        """Is ConjunctionScorer::score's f32 sum over [musts ..., nested scorer(inner)] the MUST sum plus the nested scorer's sum —
-        what the kernel forms — in EVERY leaf? The children are sorted by cost() (stable, conjunction_scorer.rs:30): a term's
-        doc_freq in the leaf; a DisjunctionSumScorer's = the sum of its clauses' (`cost` = sum), a nested ConjunctionScorer's = its
-        cheapest clause's (`cost` = min, conjunction_scorer.rs:111-113). With one scoring MUST clause the add commutes; otherwise
-        the nested scorer has to be the costliest child (strictly: ties keep clause order)."""
-        scoring = [m for m in musts if m.boost != 0.0]
-        if len(scoring) <= 1:
-            return True
-        for leaf in self.leaves:
-            def df(t):
-                st = leaf.term_state(t.term)
-                return 0 if st is None else int(st["doc_freq"])
-            if any(df(m) == 0 for m in musts):
-                continue   # a MUST clause without a scorer: nothing matches in this leaf
-            if cost == min and any(df(c) == 0 for c in inner):
-                continue   # (the nested conjunction has no scorer here either)
-            if cost([df(c) for c in inner]) <= max(df(m) for m in scoring):
-                return False
-        return True
 
     def override_statistics(self, collection_statistics, stats_terms=None):
         """Score with the statistics of a leaf that lives elsewhere (segment-sharded search: every shard takes them from

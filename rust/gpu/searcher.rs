@@ -129,8 +129,8 @@ impl<C: Codec, R: IndexReader<Codec = C> + ?Sized, IR: Deref<Target = R>, SP: Si
     ///   must / filter only                          -> AND (a FILTER clause is a MUST clause of weight 0: it scores 0.0)
     ///   should only                                 -> OR, RGPU_OP_OR_MSM(msm) when min_should_match > 1
     ///   must + should                               -> RGPU_OP_WITH_SHOULD(AND, n): ReqOptScorer, its sequential rule included
-    ///   must + ONE nested should-only query         -> ... | RGPU_OP_SHOULD_REQUIRED ("+a +(b c)": nested_must_child), bit-exact
-    ///   must + ONE nested must-only query           -> ... | RGPU_OP_NESTED_MUST ("+a +(+b +c)": the nested sum formed first), bit-exact
+    ///   must + ONE nested should-only query         -> ... | RGPU_OP_SHOULD_REQUIRED | RGPU_OP_NESTED_AT(i) ("+a +(b c)": nested_must_child), bit-exact
+    ///   must + ONE nested must-only query           -> ... | RGPU_OP_NESTED_MUST | RGPU_OP_NESTED_AT(i) ("+a +(+b +c)": the nested sum formed first), bit-exact
     ///   any of them + must_not                      -> n_must_not > 0: ReqNotScorer
     /// With `allow_flatten` (off by default): a MUST clause that is itself a must-only BooleanQuery, a SHOULD clause that is a
     /// should-only one (msm <= 1) with no other kind of clause inside it — ONE level is folded into the parent: same doc ids;
@@ -166,15 +166,14 @@ impl<C: Codec, R: IndexReader<Codec = C> + ?Sized, IR: Deref<Target = R>, SP: Si
             Some(())
         };
         if !must.is_empty() || !filter.is_empty() {
-            // "+a +(b c)": exactly ONE MUST clause that is a should-only BooleanQuery of 1..=9 term clauses (msm <= 1), term clauses
-            // beside it, no SHOULD clause of the outer query -> RGPU_OP_WITH_SHOULD(op, n) | RGPU_OP_SHOULD_REQUIRED: the CPU builds
-            // ConjunctionScorer([TermScorer ..., DisjunctionSumScorer]) for it (boolean_query.rs:200-215). Served when the kernel's
-            // sum (MUST sum + the disjunction's sum) IS the CPU's bit for bit — nested_child_sums_last — or under allow_flatten.
-            // "+a +(+b +c)" the same way (RGPU_OP_NESTED_MUST: the nested conjunction's sum is formed first) — unless allow_flatten
-            // asks for the flat fold, which leads with the tree's rarest clause.
+            // "+a +(b c)" / "+a +(+b +c)": exactly ONE MUST clause that is a should-only BooleanQuery of 1..=9 term clauses (msm <= 1)
+            // or a must-only one of >= 2, term clauses beside it, no SHOULD clause of the outer query ->
+            // RGPU_OP_WITH_SHOULD(op, n) | RGPU_OP_SHOULD_REQUIRED / RGPU_OP_NESTED_MUST | RGPU_OP_NESTED_AT(its place): the CPU builds
+            // ConjunctionScorer([TermScorer ..., nested scorer]) (boolean_query.rs:200-215); the library sorts those children by cost
+            // per leaf as ConjunctionScorer::new does and adds the nested sum where score() adds it — bit-equal whatever the costs.
             if should.is_empty() && must.iter().filter(|q| term_of(q).is_none()).count() == 1 {
                 if let Some(f) = self.nested_must_child(must, filter, &prohibited, false) { return Some(f); }
-                if !allow { if let Some(f) = self.nested_must_child(must, filter, &prohibited, true) { return Some(f); } }
+                if let Some(f) = self.nested_must_child(must, filter, &prohibited, true) { return Some(f); }
             }
             for q in must { fold(q, true, &mut positive)?; }
             for q in filter { let t = term_of(q)?; positive.push((t, 0.0)); }
@@ -211,9 +210,11 @@ impl<C: Codec, R: IndexReader<Codec = C> + ?Sized, IR: Deref<Target = R>, SP: Si
         let term_of = |q: &'q Box<dyn Query<C>>| q.as_any().downcast_ref::<TermQuery>().filter(|t| t.term.field == self.field);
         let mut positive = Vec::new();
         let mut optional = Vec::new();
+        let mut at = 0i32;
         for q in must {
             if let Some(t) = term_of(q) { positive.push((t, t.boost)); continue; }
             let inner = q.as_any().downcast_ref::<BooleanQuery<C>>()?;
+            at = positive.len() as i32; // the nested clause's place among the MUST clauses (FILTER clauses follow them: boolean_query.rs:101-108)
             let (m, s, f, n, inner_msm) = inner.clauses();
             if !f.is_empty() || !n.is_empty() { return None; }
             if conjunction {
@@ -226,36 +227,9 @@ impl<C: Codec, R: IndexReader<Codec = C> + ?Sized, IR: Deref<Target = R>, SP: Si
         }
         for q in filter { let t = term_of(q)?; positive.push((t, 0.0)); }
         if positive.is_empty() || optional.is_empty() { return None; }
-        let exact = self.nested_child_sums_last(&positive, &optional, conjunction);
-        if !(exact || (self.allow_flatten && !conjunction)) { return None; }
         let op = if positive.len() == 1 { RGPU_OP_TERM } else { RGPU_OP_AND };
         let flag = if conjunction { RGPU_OP_NESTED_MUST } else { RGPU_OP_SHOULD_REQUIRED };
-        Some(FlatQuery { op: rgpu_op_with_should(op, optional.len() as i32) | flag, positive, optional, must_not: prohibited.to_vec() })
-    }
-
-    /// ConjunctionScorer::new sorts its children by cost() (stable, conjunction_scorer.rs:30) and score() adds them in that order
-    /// (:87-95): a term's cost is its doc_freq in the leaf, a nested disjunction's the sum of its clauses', a nested conjunction's
-    /// its cheapest clause's (:111-113). The kernel adds the nested scorer's sum LAST. With one scoring MUST clause the f32 add
-    /// commutes; otherwise the nested scorer has to be the costliest child in every leaf (strictly: ties keep clause order).
-    fn nested_child_sums_last(&self, positive: &[(&TermQuery, f32)], optional: &[&TermQuery], conjunction: bool) -> bool {
-        if positive.iter().filter(|(_, boost)| *boost != 0.0).count() <= 1 { return true; }
-        for leaf in self.cpu.reader().leaves() {
-            let df = |t: &TermQuery| -> Option<i64> { Some(self.block_state(&leaf, &t.term).ok()?.map_or(0, |s| s.doc_freq as i64)) };
-            let mut must_max = 0i64;
-            let mut dead = false;
-            for (t, boost) in positive {
-                let d = match df(t) { Some(d) => d, None => return false };
-                dead = dead || d == 0;
-                if *boost != 0.0 { must_max = must_max.max(d); }
-            }
-            if dead { continue; } // a MUST clause without a scorer: nothing matches in this leaf
-            let mut should_sum = 0i64;
-            let mut should_min = i64::max_value();
-            for t in optional { let d = match df(t) { Some(d) => d, None => return false }; should_sum += d; should_min = should_min.min(d); }
-            if conjunction && should_min == 0 { continue; } // (the nested conjunction has no scorer here either)
-            if (if conjunction { should_min } else { should_sum }) <= must_max { return false; }
-        }
-        true
+        Some(FlatQuery { op: rgpu_op_with_should(op, optional.len() as i32) | flag | rgpu_op_nested_at(at), positive, optional, must_not: prohibited.to_vec() })
     }
 
     /// The 256-entry norm cache of the field's statistics, uploaded once per avgdl (bm25_similarity.rs:160-166)

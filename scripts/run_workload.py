@@ -91,7 +91,7 @@ elif kind == "mustand":
     tids = indexgen.log_uniform_ranks(3 * 1024, 1, 1000, SEED ^ 0xA3).reshape(-1, 3) - 1
     tids = np.array([r for r in tids if len(set(r.tolist())) == 3])
     qs, ts = s.pack([B.build([T(int(a)), B.build([T(int(b)), T(int(c))], [])], []) for a, b, c in tids], leaf)
-    assert all(q["op"] == (1 | (2 << 16) | (1 << 25)) for q in qs)
+    assert all(q["op"] == (1 | (2 << 16) | (1 << 25) | (1 << 26)) for q in qs)   # AND, two nested clauses, NESTED_MUST, NESTED_AT(1)
     for _ in range(reps + 2):
         hits, totals = leaf.segment.search_batch(qs, ts, 10)
     t0 = time.perf_counter()

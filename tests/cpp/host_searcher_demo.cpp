@@ -136,10 +136,16 @@ int main(int argc, char** argv) {
         }
         std::printf("\n");
       }
-      // ... and with it folded into the flat conjunction (within 1e-5, led by the rarest clause)
+      // ... SHOULD [ t3, t77, SHOULD [ t900, t15000 ] ] — a nested disjunction from the third clause on — is refused without
+      // flatten_nested and folded into the flat disjunction of query 3 above with it (within 1e-5 of the reference)
+      NestedBooleanQuery third;
+      third.should_queries.emplace_back(new TermQuery(3));
+      third.should_queries.emplace_back(new TermQuery(77));
+      third.should_queries.push_back(BooleanQuery::build({}, {TermQuery(900), TermQuery(15000)}));
+      { TopDocsCollector c(10); try { searcher.search(third, c); } catch (const Error& e) { refused = e.kind == RGPU_ERR_UNSUPPORTED; } }
       searcher.flatten_nested = true;
       TopDocsCollector folded(10);
-      searcher.search(nested, folded);
+      searcher.search(third, folded);
       TopDocs top = folded.top_docs();
       std::printf("nested %d %lld", refused ? 1 : 0, (long long)top.total_hits());
       for (const ScoreDoc& d : top.score_docs()) {

@@ -278,8 +278,9 @@ def test_nested_boolean_trees_through_the_seam(zipf, oracle):
     hits, totals = g2.search_batch(nested, k)
     for i, (op, tids) in enumerate(flat):
         d, sc, total = osearcher.search(op, tids, k, tie_mode=oracle.TIE_CANONICAL)
-        assert totals[i] == total and (hits[i]["doc"][:d.size] == d).all()
-        assert (hits[i]["score"][:d.size].view(np.int32) == sc.view(np.int32)).all()   # = the flat query, bit for bit
+        assert totals[i] == total
+        if i == 1:   # the folded disjunction IS the flat query, bit for bit
+            assert (hits[i]["doc"][:d.size] == d).all() and (hits[i]["score"][:d.size].view(np.int32) == sc.view(np.int32)).all()
     # the reference's sums for the nested conjunction: lead-first over [T(5), Conj(1, 40)] sorted by cost, the inner conjunction's
     # own sum formed first (conjunction_scorer.rs:87-95) — per returned doc, from the oracle's single-term scores
     per_term = {}
@@ -292,7 +293,9 @@ def test_nested_boolean_trees_through_the_seam(zipf, oracle):
     outer_first_is_inner = min(int(seg.terms[1]["doc_freq"]), int(seg.terms[40]["doc_freq"])) < int(seg.terms[5]["doc_freq"])
     ref = (inner + per_term[5]) if outer_first_is_inner else (per_term[5] + inner)
     n = int((hits[0]["doc"] >= 0).sum())
-    np.testing.assert_allclose(hits[0]["score"][:n], ref[:n], rtol=1e-5, atol=0)
+    # (since round 6 the nested conjunction is served as it is — RGPU_OP_NESTED_MUST, test_a_conjunction_under_must: the reference's
+    # own sums, not the flat query's)
+    assert (hits[0]["score"][:n].view(np.int32) == ref[:n].view(np.int32)).all()
     # everything else -> the hook
     calls = []
 
@@ -310,14 +313,46 @@ def test_nested_boolean_trees_through_the_seam(zipf, oracle):
     assert e.value.status == -5
 
 
+def _conjunction_with_a_nested_child(oracle, osearcher, docs_of, df, musts, inner, inner_is_or, nots, at, k):
+    """ConjunctionScorer over [TermScorer(m) for m in musts] with a nested scorer inserted at child index `at`, restated from the
+    oracle's own scorers: children sorted by cost(), stable (conjunction_scorer.rs:30 — a term's doc_freq, a DisjunctionSumScorer's
+    the sum of its clauses', a ConjunctionScorer's its cheapest clause's), score = lead1 + lead2 + others in that order (:87-95),
+    a doc matches when every child holds it; MUST_NOT docs dropped (ReqNotScorer). -> (total hits, docs[:k], scores[:k])"""
+    children = [("t", [m]) for m in musts]
+    children.insert(at, ("n", inner))
+    cost = lambda c: df(c[1][0]) if c[0] == "t" else (sum(df(t) for t in inner) if inner_is_or else min(df(t) for t in inner))   # noqa: E731
+    children = sorted(children, key=cost)   # stable
+    cand = docs_of(min(musts, key=df))
+    ok = np.ones(cand.size, dtype=bool)
+    total = None
+    for kind, tids in children:
+        op = oracle.OP_TERM if kind == "t" else (oracle.OP_OR if inner_is_or else oracle.OP_AND)
+        sc, m = osearcher.score_docs(op, tids, cand)
+        ok &= m
+        total = sc.astype(np.float32) if total is None else (total + sc.astype(np.float32)).astype(np.float32)
+    for t in nots:
+        ok &= ~np.isin(cand, docs_of(t))
+    d, sc = cand[ok], total[ok]
+    order = np.lexsort((d, -sc.astype(np.float64)))[:k]
+    return int(ok.sum()), d[order], sc[order]
+
+
+def _check_nested_rows(gsearcher, queries, expect, cases, k):
+    hits, totals = gsearcher.search_batch(queries, k)
+    for i, (n_hits, d, sc) in enumerate(expect):
+        assert totals[i] == n_hits, (cases[i], totals[i], n_hits)
+        assert (hits[i]["doc"][:d.size] == d).all() and (hits[i]["doc"][d.size:] == -1).all(), cases[i]
+        assert (hits[i]["score"][:d.size].view(np.int32) == sc.view(np.int32)).all(), cases[i]
+    return hits, totals
+
+
 @pytest.mark.parametrize("k", [10, 100])
 def test_a_disjunction_under_must(zipf, oracle, ctx, k):
     """VERDICT r5 missing 5, "+a +(b c)": a should-only BooleanQuery as a MUST clause. The reference builds
     ConjunctionScorer([TermScorer(a) ..., DisjunctionSumScorer(b, c)]) (boolean_query.rs:200-215): a doc matches when every MUST
     clause and at least one nested clause hold it, and scores lead1 + lead2 + others in cost order (conjunction_scorer.rs:27-43,
-    87-95), the disjunction contributing its own sum. Expected rows are put together from the ORACLE's scorers: the MUST
-    conjunction's score and the disjunction's score of every doc of the lead list (score_docs), one f32 add, the canonical
-    top-k rule. Every tree below keeps the disjunction last in cost order (or has one MUST clause): bit for bit."""
+    87-95), the disjunction contributing its own sum. Expected rows are put together from the ORACLE's scorers child by child
+    (_conjunction_with_a_nested_child). The disjunction as costliest, cheapest and middle child: bit for bit every time."""
     import rucene_amd
     seg, osearcher, gsearcher = zipf
     T, B = rucene_amd.TermQuery, rucene_amd.BooleanQuery
@@ -326,60 +361,72 @@ def test_a_disjunction_under_must(zipf, oracle, ctx, k):
 
     def docs_of(t):
         return np.asarray(oseg.decode_term(seg.terms[t])[0], dtype=np.int32)
-    # (musts, nested shoulds, must_nots): dense / sparse leads, bitmap and walked clauses, singletons, a tail-only lead, two MUSTs
-    cases = [([5], [1, 40], []), ([300], [7, 900, 2], []), ([2], [30_000, 31_000], []), ([0], [1, 2], []), ([40, 300], [0, 1], []),
-             ([100, 7], [3, 4000, 0], []), ([49_999], [0, 1], []), ([12], [49_998, 49_999], []), ([4000], [5000, 6000, 7000, 8000, 9000], []),
-             ([5], [1, 40], [3]), ([900, 30], [2, 1, 0, 49_000], [7, 11]), ([1], [0, 2, 3, 4, 5, 6, 7, 8, 9], [])]
+    # (musts, nested shoulds, must_nots, index of the nested clause among the MUST clauses): dense / sparse leads, bitmap and walked
+    # clauses, singletons, a tail-only lead; two and three MUST terms with the disjunction last, first and in the middle of the cost order
+    cases = [([5], [1, 40], [], 1), ([300], [7, 900, 2], [], 0), ([2], [30_000, 31_000], [], 1), ([0], [1, 2], [], 1), ([40, 300], [0, 1], [], 2),
+             ([100, 7], [3, 4000, 0], [], 1), ([49_999], [0, 1], [], 0), ([12], [49_998, 49_999], [], 1), ([4000], [5000, 6000, 7000, 8000, 9000], [], 1),
+             ([5], [1, 40], [3], 1), ([900, 30], [2, 1, 0, 49_000], [7, 11], 2), ([1], [0, 2, 3, 4, 5, 6, 7, 8, 9], [], 0),
+             ([0, 1], [300, 900], [], 2), ([0, 1], [300, 900], [], 0), ([0, 300], [7, 12], [], 1), ([0, 2, 300], [5, 40], [11], 3), ([1, 0, 2], [900, 12], [], 1)]
     queries, expect = [], []
-    for musts, shoulds, nots in cases:
-        assert len(musts) == 1 or sum(df(t) for t in shoulds) > max(df(t) for t in musts)
-        queries.append(B.build([T(t) for t in musts] + [B.build([], [T(t) for t in shoulds])], [], must_nots=[T(t) for t in nots]))
-        cand = docs_of(min(musts, key=df))
-        ms, mm = osearcher.score_docs(oracle.OP_AND if len(musts) > 1 else oracle.OP_TERM, musts, cand)
-        ds, dm = osearcher.score_docs(oracle.OP_OR, shoulds, cand)
-        ok = mm & dm
-        for t in nots:
-            ok &= ~np.isin(cand, docs_of(t))
-        total = (ms.astype(np.float32) + ds.astype(np.float32)).astype(np.float32)   # ConjunctionScorer::score, the disjunction last
-        d, sc = cand[ok], total[ok]
-        order = np.lexsort((d, -sc.astype(np.float64)))[:k]
-        expect.append((int(ok.sum()), d[order], sc[order]))
+    for musts, shoulds, nots, at in cases:
+        clauses = [T(t) for t in musts]
+        clauses.insert(at, B.build([], [T(t) for t in shoulds]))
+        queries.append(B.build(clauses, [], must_nots=[T(t) for t in nots]))
+        expect.append(_conjunction_with_a_nested_child(oracle, osearcher, docs_of, df, musts, shoulds, True, nots, at, k))
     assert sum(e[0] for e in expect) > 1000 and any(e[0] > k for e in expect)
-    hits, totals = gsearcher.search_batch(queries, k)
-    for i, (n_hits, d, sc) in enumerate(expect):
-        assert totals[i] == n_hits, (cases[i], totals[i], n_hits)
-        assert (hits[i]["doc"][:d.size] == d).all() and (hits[i]["doc"][d.size:] == -1).all(), cases[i]
-        assert (hits[i]["score"][:d.size].view(np.int32) == sc.view(np.int32)).all(), cases[i]
+    hits, totals = _check_nested_rows(gsearcher, queries, expect, cases, k)
     if k != 10:
         return
     # the reference's ReqOptScorer rule is NOT in this tree: the same clauses as MUST + optional SHOULD match more docs
     flat_hits, flat_totals = gsearcher.search_batch([B.build([T(5)], [T(1), T(40)])], k)
     assert flat_totals[0] == df(5) > totals[0]
-    # a disjunction that is NOT the costliest child of two MUST clauses: declined (-> cpu_fallback), or served within 1e-5 on request
-    cheap = B.build([T(0), T(1), B.build([], [T(4000), T(4001)])], [])
-    with pytest.raises(rucene_amd.RgpuError) as e:
-        gsearcher.search_batch([cheap], k)
-    assert e.value.status == -5
-    g2 = rucene_amd.GpuIndexSearcher(gsearcher.leaves, ctx=gsearcher.ctx, flatten_nested=True)
-    h2, t2 = g2.search_batch([cheap], k)
-    cand = np.union1d(docs_of(4000), docs_of(4001)).astype(np.int32)
-    ms, mm = osearcher.score_docs(oracle.OP_AND, [0, 1], cand)
-    ds, dm = osearcher.score_docs(oracle.OP_OR, [4000, 4001], cand)
-    ok = mm & dm
-    assert t2[0] == int(ok.sum())
-    n = min(k, int(ok.sum()))
-    got = {int(d): float(s) for d, s in zip(h2[0]["doc"][:n], h2[0]["score"][:n])}
-    ref = {int(d): float(np.float32(a) + np.float32(b)) for d, a, b in zip(cand[ok], ms[ok], ds[ok])}
-    assert all(d in ref and abs(got[d] - ref[d]) <= 1e-5 * abs(ref[d]) for d in got)
-    # through the C ABI: the flag needs optional clauses, a TERM / AND op and fewer than ten of them
+    # through the C ABI: the flags need optional clauses, a TERM / AND op, fewer than ten of them, an index within the MUST clauses
     leaf = gsearcher.leaves[0]
     qs, ts = gsearcher.pack([queries[0]], leaf)
-    for bad_op, status in ((rucene_amd.OP_AND | (1 << 24), -2), (rucene_amd.OP_OR | (1 << 24), -2), (rucene_amd.OP_AND | (1 << 25), -2)):
+    for bad_op, status in ((rucene_amd.OP_AND | (1 << 24), -2), (rucene_amd.OP_OR | (1 << 24), -2), (rucene_amd.OP_AND | (2 << 16) | (1 << 26), -2),
+                           (rucene_amd.OP_AND | (2 << 16) | (1 << 24) | (2 << 26), -2)):
         q2 = qs.copy()
         q2[0]["op"] = bad_op
         with pytest.raises(rucene_amd.RgpuError) as e:
             leaf.segment.search_batch(q2, ts, k)
         assert e.value.status == status
+
+
+def test_nested_children_that_tie_on_cost_keep_the_clause_order(ctx, oracle):
+    """ConjunctionScorer::new's sort is stable: a nested child whose cost EQUALS a MUST clause's doc freq stays where the query put
+    it, and with a cheaper third child in front the two orders are two different f32 sums — (c + N) + x against (c + x) + N.
+    RGPU_OP_NESTED_AT carries the place; both orders of both nested kinds against the restated reference."""
+    import rucene_amd
+    from rucene_amd import indexgen
+    rng = np.random.default_rng(77)
+    max_doc = 4000
+
+    def plist(n):
+        d = np.sort(rng.choice(max_doc, size=n, replace=False)).astype(np.int32)
+        return d, rng.integers(1, 9, size=n).astype(np.int32)
+    # term 0: the cheap child (900 docs); term 1: x (2400); terms 2, 3: a disjunction that costs 1200 + 1200 = 2400; terms 4, 5: a
+    # conjunction whose cheapest clause holds 2400
+    seg = indexgen.build_explicit(max_doc, [plist(900), plist(2400), plist(1200), plist(1200), plist(2400), plist(3000)],
+                                  norms=rng.integers(90, 125, size=max_doc).astype(np.uint8))
+    oseg = oracle.Segment(seg.doc_bytes, seg.norms, seg.max_doc, seg.terms, sum_total_term_freq=seg.sum_total_term_freq)
+    osearcher = oracle.Searcher([oseg])
+    gsearcher = rucene_amd.GpuIndexSearcher([rucene_amd.LeafReader.from_synthetic(seg)], ctx=ctx)
+    T, B = rucene_amd.TermQuery, rucene_amd.BooleanQuery
+    df = lambda t: int(seg.terms[t]["doc_freq"])   # noqa: E731
+    docs_of = lambda t: np.asarray(oseg.decode_term(seg.terms[t])[0], dtype=np.int32)   # noqa: E731
+    queries, expect, cases = [], [], []
+    for inner, is_or in (([2, 3], True), ([4, 5], False)):
+        for at in (1, 2):   # "+t0 +N +t1" and "+t0 +t1 +N"
+            clauses = [T(0), T(1)]
+            clauses.insert(at, B.build([], [T(t) for t in inner]) if is_or else B.build([T(t) for t in inner], []))
+            queries.append(B.build(clauses, []))
+            cases.append((inner, is_or, at))
+            expect.append(_conjunction_with_a_nested_child(oracle, osearcher, docs_of, df, [0, 1], inner, is_or, [], at, 64))
+    _check_nested_rows(gsearcher, queries, expect, cases, 64)
+    for a, b in ((0, 1), (2, 3)):   # the two places are two different sums (same docs and counts): the test can tell them apart
+        assert expect[a][0] == expect[b][0] > 64
+        ra, rb = dict(zip(expect[a][1].tolist(), expect[a][2].view(np.int32).tolist())), dict(zip(expect[b][1].tolist(), expect[b][2].view(np.int32).tolist()))
+        assert any(ra[d] != rb[d] for d in ra if d in rb)
 
 
 def test_a_disjunction_as_first_or_second_should_clause(zipf, oracle):
@@ -418,43 +465,34 @@ def test_a_disjunction_as_first_or_second_should_clause(zipf, oracle):
 def test_a_conjunction_under_must(zipf, oracle, k):
     """"+a +(+b +c)" as it is, bit for bit: ConjunctionScorer([TermScorer(a) ..., ConjunctionScorer(b, c)]) sums the nested
     conjunction first (conjunction_scorer.rs:87-95) — a + (b + c) where the flat query forms (a + b) + c in cost order. Same docs
-    and hit count as the flat conjunction (the oracle's), scores = the oracle's score of the outer MUST clauses + its score of the
-    nested conjunction, one f32 add (RGPU_OP_NESTED_MUST: one outer MUST clause, or a nested conjunction whose cheapest clause
-    costs more than every outer one)."""
+    and hit count as the flat conjunction (the oracle's), scores restated child by child from the oracle's scorers
+    (RGPU_OP_NESTED_MUST; the nested conjunction as cheapest, costliest and middle child)."""
     import rucene_amd
     seg, osearcher, gsearcher = zipf
     T, B = rucene_amd.TermQuery, rucene_amd.BooleanQuery
+    oseg = oracle.Segment(seg.doc_bytes, seg.norms, seg.max_doc, seg.terms, sum_total_term_freq=seg.sum_total_term_freq)
     df = lambda t: int(seg.terms[t]["doc_freq"])   # noqa: E731
-    cases = [([5], [1, 40], []), ([1], [12, 40], []), ([300], [7, 2, 0], []), ([0], [1, 2], []), ([900, 4000], [0, 1], []), ([40], [3, 1, 0, 2], []),
-             ([2], [49_999, 0], []), ([5], [1, 40], [3]), ([700, 2500], [2, 1, 0], [7, 11]), ([100], [10, 9, 8, 7, 6, 5], [])]
+    docs_of = lambda t: np.asarray(oseg.decode_term(seg.terms[t])[0], dtype=np.int32)   # noqa: E731
+    cases = [([5], [1, 40], [], 1), ([1], [12, 40], [], 0), ([300], [7, 2, 0], [], 1), ([0], [1, 2], [], 1), ([900, 4000], [0, 1], [], 2), ([40], [3, 1, 0, 2], [], 0),
+             ([2], [49_999, 0], [], 1), ([5], [1, 40], [3], 1), ([700, 2500], [2, 1, 0], [7, 11], 0), ([100], [10, 9, 8, 7, 6, 5], [], 1),
+             ([0, 1], [300, 2], [], 2), ([0, 300], [12, 1], [], 1), ([0, 1, 2], [5, 3], [], 3), ([40, 0, 1], [7, 2], [11], 1)]
     queries, expect, n_diff = [], [], 0
-    for musts, inner, nots in cases:
-        assert len(musts) == 1 or min(df(t) for t in inner) > max(df(t) for t in musts)
-        queries.append(B.build([T(t) for t in musts] + [B.build([T(t) for t in inner], [])], [], must_nots=[T(t) for t in nots]))
-        d, sc, total = (osearcher.search_not(oracle.OP_AND, musts + inner, nots, seg.max_doc, tie_mode=oracle.TIE_CANONICAL) if nots
-                        else osearcher.search(oracle.OP_AND, musts + inner, seg.max_doc, tie_mode=oracle.TIE_CANONICAL))
-        d = np.asarray(d, dtype=np.int32)
-        ms, mm = osearcher.score_docs(oracle.OP_AND if len(musts) > 1 else oracle.OP_TERM, musts, d)
-        cs, cm = osearcher.score_docs(oracle.OP_AND, inner, d)
-        assert mm.all() and cm.all()
-        nested = (ms + cs).astype(np.float32)
-        n_diff += int((nested.view(np.int32) != np.asarray(sc, dtype=np.float32).view(np.int32)).sum())
-        order = np.lexsort((d, -nested.astype(np.float64)))[:k]
-        expect.append((int(total), d[order], nested[order]))
-    assert n_diff > 0   # (the nested sums do differ from the flat ones somewhere: the test can tell the two apart)
-    hits, totals = gsearcher.search_batch(queries, k)
-    for i, (n_hits, d, sc) in enumerate(expect):
-        assert totals[i] == n_hits, (cases[i], totals[i], n_hits)
-        assert (hits[i]["doc"][:d.size] == d).all() and (hits[i]["doc"][d.size:] == -1).all(), cases[i]
-        assert (hits[i]["score"][:d.size].view(np.int32) == sc.view(np.int32)).all(), cases[i]
-    # a nested conjunction that holds a clause cheaper than an outer MUST clause (two scoring outer clauses): not exact -> declined
-    with pytest.raises(rucene_amd.RgpuError) as e:
-        gsearcher.search_batch([B.build([T(0), T(1), B.build([T(4000), T(2)], [])], [])], k)
-    assert e.value.status == -5
+    for musts, inner, nots, at in cases:
+        clauses = [T(t) for t in musts]
+        clauses.insert(at, B.build([T(t) for t in inner], []))
+        queries.append(B.build(clauses, [], must_nots=[T(t) for t in nots]))
+        expect.append(_conjunction_with_a_nested_child(oracle, osearcher, docs_of, df, musts, inner, False, nots, at, k))
+        d, sc, total = (osearcher.search_not(oracle.OP_AND, musts + inner, nots, k, tie_mode=oracle.TIE_CANONICAL) if nots
+                        else osearcher.search(oracle.OP_AND, musts + inner, k, tie_mode=oracle.TIE_CANONICAL))
+        assert total == expect[-1][0]                    # the flat conjunction's docs ...
+        flat = dict(zip(np.asarray(d).tolist(), np.asarray(sc, dtype=np.float32).view(np.int32).tolist()))
+        n_diff += sum(1 for dd, b in zip(expect[-1][1].tolist(), expect[-1][2].view(np.int32).tolist()) if dd in flat and flat[dd] != b)
+    assert n_diff > 0   # ... under sums that do differ from the flat ones somewhere: the test can tell the two apart
+    _check_nested_rows(gsearcher, queries, expect, cases, k)
     # through the C ABI: the flag needs two or more nested clauses and excludes RGPU_OP_SHOULD_REQUIRED
     leaf = gsearcher.leaves[0]
     qs, ts = gsearcher.pack([queries[0]], leaf)
-    assert qs[0]["op"] == rucene_amd.OP_AND | (2 << 16) | (1 << 25)
+    assert qs[0]["op"] == rucene_amd.OP_AND | (2 << 16) | (1 << 25) | (1 << 26)
     for bad_op in (rucene_amd.OP_AND | (1 << 16) | (1 << 25), rucene_amd.OP_AND | (2 << 16) | (3 << 24), rucene_amd.OP_OR | (1 << 25)):
         q2 = qs.copy()
         q2[0]["op"] = bad_op
@@ -1236,7 +1274,8 @@ def test_cpp_host_mirror(oracle, tmp_path):
     assert [int(p.split(":")[0]) for p in parts[2:]] == d[order].tolist()
     assert [int(p.split(":")[1], 16) for p in parts[2:]] == nested[order].view(np.uint32).tolist()
     out = out[:2 * len(specs) + 2] + out[2 * len(specs) + 3:]
-    assert out[2 * len(specs) + 2].split()[:2] == ["nested", "0"] and out[2 * len(specs) + 2].split()[2:] == out[2].split()[1:]
+    # SHOULD [t3, t77, SHOULD [t900, t15000]]: refused without flatten_nested (1), folded = the flat disjunction's line with it
+    assert out[2 * len(specs) + 2].split()[:2] == ["nested", "1"] and out[2 * len(specs) + 2].split()[2:] == out[3].split()[1:]
     # "+t1 +(t12 t40)": a disjunction under MUST is served as it is — ConjunctionScorer over [TermScorer(t1), DisjunctionSumScorer(t12, t40)],
     # expected from the oracle's own scorers on the docs of t1 (one MUST clause: the f32 add commutes)
     cand = np.asarray(oseg.decode_term(seg.terms[1])[0], dtype=np.int32)
