@@ -290,6 +290,8 @@ __global__ __launch_bounds__(AND_WG_THREADS, AND_WAVES_PER_SIMD) void k_search_a
     const bool need_all = HAS_OPT && (Q.op & (1 << 25)) != 0;  // wave-uniform
     uint32_t any_opt = 0u;
     if (RGPU_AND_FAST && ti_start == 2) {  // the first clause's score, added where the clause loop would have added it
+      // (a one-clause prefix in front of a nested conjunction: clause 1 opens the nested group — its score starts the group's sum)
+      if (HAS_OPT && need_all && n_req_not == 1) { r0 = s0; r1 = s1; s0 = 0.f; s1 = 0.f; in_opt = true; }
       const DevTerm T1 = terms[Q.first_term + 1];
       use_table(T1.sim_table);
       wk = T1.weight * (k1 + 1.0f);
@@ -557,7 +559,9 @@ __global__ __launch_bounds__(AND_WG_THREADS, AND_WAVES_PER_SIMD) void k_search_a
   const uint8_t* const lead_pn = has_norms ? seg.pnorm + L.pn_base : lead_rows;
   // the batched first probe needs: a doc bitmap for the first clause behind the lead, that clause required (not MUST_NOT / SHOULD),
   // a collector that takes matches in vectors (not ReqOptScorer's one-record-per-lead-posting form)
-  bool fast = b1 > b0 && bitmaps != nullptr && Q.n_terms >= 2 && !(HAS_OPT && seq_out != nullptr);
+  // (... or the first clause of a nested conjunction right behind a one-clause prefix: RGPU_OP_NESTED_MUST, no MUST_NOT clause between)
+  const bool c1_nested = HAS_OPT && Q.n_terms == 1 && (!HAS_NOT || Q.pad == 0) && (Q.op & (1 << 25)) != 0;
+  bool fast = b1 > b0 && bitmaps != nullptr && (Q.n_terms >= 2 || c1_nested) && !(HAS_OPT && seq_out != nullptr);
   typedef const __attribute__((address_space(1))) uint32_t* gwords1;
   gwords1 probe_src = nullptr;
   int probe_nib = 0;  // 1: four bits per doc {absent, freq 1..14, 15 = look it up}; 0: one membership bit per doc
