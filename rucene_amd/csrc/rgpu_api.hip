@@ -2788,31 +2788,6 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
             sparse_first.push_back(&s1);
         }
       }
-      // ... and of a conjunction nested under MUST: the clause right behind the lead in the order search_pass lays out below (the
-      // children's stable cost order: nested child first -> its own two cheapest clauses; second -> the cheapest MUST term, then the
-      // nested conjunction's cheapest clause; later -> the two cheapest MUST terms)
-      if ((Q.op & RGPU_OP_NESTED_MUST) && qopt >= 2 && qop != RGPU_OP_OR && c->cfg.and_bitmaps >= 0 && c->memb_only_on && (int64_t)seg->max_doc / 8 <= (2ll << 20)) {
-        std::vector<const rgpu_term_state*> outer, inner;
-        bool absent = false;
-        for (int i = 0; i < Q.n_terms + qopt; ++i) {
-          const rgpu_term_state& st = terms[Q.first_term + i].state;
-          absent = absent || st.doc_freq <= 0;
-          (i < Q.n_terms ? outer : inner).push_back(&st);
-        }
-        if (!absent) {
-          const int at = (int)((uint32_t)Q.op >> 26);
-          auto by_df = [](const rgpu_term_state* x, const rgpu_term_state* y) { return x->doc_freq < y->doc_freq; };
-          std::stable_sort(inner.begin(), inner.end(), by_df);
-          const int64_t cost = inner[0]->doc_freq;
-          size_t p = 0;
-          for (size_t i = 0; i < outer.size(); ++i) p += (outer[i]->doc_freq < cost || (outer[i]->doc_freq == cost && (int)i < at)) ? 1 : 0;
-          std::stable_sort(outer.begin(), outer.end(), by_df);
-          const rgpu_term_state* lead = p == 0 ? inner[0] : outer[0];
-          const rgpu_term_state* second = p == 0 ? inner[1] : (p == 1 ? inner[0] : outer[1]);
-          if (second->doc_freq >= MEMB_ONLY_MIN_DF && second->doc_freq < min_df_and && lead->doc_freq >= 128 && !seg->memb_only.find(second->doc_start_fp))
-            sparse_first.push_back(second);
-        }
-      }
       for (int i = 0; i < n_look; ++i) {
         const rgpu_query_term& t = terms[Q.first_term + i];
         if (t.state.doc_freq >= min_df && !seg->bitmaps.find(t.state.doc_start_fp)) {
@@ -3116,8 +3091,7 @@ static int32_t search_pass(rgpu_segment* seg, const rgpu_query* queries, int32_t
           if (t.df < min_df) {
             // the first MUST clause behind the lead may carry its membership bits alone (words == null: the batched probe asks
             // them, the survivors walk the clause's block directory)
-            const bool c1_nested = q0.n_terms == 1 && q0.pad == 0 && (q0.op & RGPU_OP_NESTED_MUST) != 0;  // (search_and.hpp: the same rule)
-            if (i == 1 && (q0.n_terms >= 2 || c1_nested) && !G.req_opt && seg->memb_only.size() > 0) {
+            if (i == 1 && q0.n_terms >= 2 && !G.req_opt && seg->memb_only.size() > 0) {
               const rgpu_segment::MembOnly* mo = seg->memb_only.find((int64_t)t.start_fp);
               if (mo && mo->memb != nullptr && mo->df == t.df) {
                 clause_bitmaps[(size_t)(q0.first_term + 1)] = TermBitmap{nullptr, nullptr, nullptr, nullptr, nullptr, mo->memb, 0, 0};
