@@ -98,6 +98,9 @@ elif kind == "mustand":
     for _ in range(10):
         leaf.segment.search_batch(qs, ts, 10)
     print("mustand: %d queries, wall per host-buffer batch %.3f ms" % (len(tids), 1e2 * (time.perf_counter() - t0)))
+    ka = ctx.kernel_stats().get("k_search_and")
+    print("mustand: k_search_and %.4f ms over %d launches (first launches included)" % (ka["total_ms"] / ka["launches"], ka["launches"]))
+    ctx.kernel_stats_reset()
     q2, t2 = s.pack([B.build([T(int(x)) for x in r], []) for r in tids], leaf)
     fh, ft = leaf.segment.search_batch(q2, t2, 10)
     t0 = time.perf_counter()
