@@ -193,7 +193,7 @@ def final_line(full, detail_path="bench_detail.json"):
     roof = full.get("roofline") or {}
     line["roofline"] = {k: (_short(roof[k], 200) if isinstance(roof.get(k), str) else _num(roof.get(k)))
                         for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "kernel_ms_suspect", "bytes_per_launch",
-                                  "bytes_are", "traffic_source") if k in roof}
+                                  "bytes_are", "traffic_source", "across_rounds") if k in roof}
     if "cpu_baseline" in full:
         cb = full["cpu_baseline"]
         line["cpu_baseline"] = {"value": _num(cb.get("value")), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
@@ -272,6 +272,7 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N > 1)" % (args.gpus, world))
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for RCCL across processes (before the HSA runtime starts)
     import torch
     import torch.distributed as dist
     import rucene_amd
@@ -1083,6 +1084,8 @@ def main():
             out[key] = head[key]
     # the fraction at the headline's OPERATING POINT (two launches co-resident on alternating streams): the same bytes over the
     # step time — next to roofline.frac, which is one isolated launch (kernel_ms may exceed ms_per_step for that reason)
+    # a pruned top-k search, not a stream: better pruning lowers the touched bytes and with them `frac` while the launch gets shorter
+    out["roofline"]["across_rounds"] = ("pruned search: better pruning lowers touched bytes and frac while the launch gets shorter (r05: 36.0 MB / 0.037 ms = 0.12); compare kernel_ms across rounds; streaming kernel: block_decode_frac")
     out["roofline"]["frac_at_ms_per_step"] = out["roofline"]["bytes_per_launch"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS
     # how far the step is from its kernels: every kernel of one step — the plan's copy kernel (round 6), the dominant kernel, the item
     # merge where it is still a launch of its own — as isolated median launches, vs the planned step (two streams overlap them: < 1)
