@@ -131,6 +131,45 @@ struct NestedBooleanQuery : Query {
   std::vector<std::unique_ptr<Query>> must_queries, should_queries;
   std::vector<TermQuery> must_not_queries;
   int32_t min_should_match = 0;
+  // Nested clauses that do NOT score have exact flat forms (same docs, counts and f32 sums as the reference's scorer tree):
+  //   * a MUST_NOT clause that is a should-only BooleanQuery of terms, "-(b c)": ReqNotScorer excludes what the nested
+  //     DisjunctionSumScorer matches, b or c — the MUST_NOT clauses b, c (boolean_query.rs:236-252 builds one disjunction over the
+  //     MUST_NOT scorers with the OUTER min_should_match: equal only while that is <= 1, so msm > 1 is not expanded);
+  //   * a FILTER clause that is a must-only BooleanQuery of terms, "#(+b +c)": its weights are created with needs_scores = false
+  //     (boolean_query.rs:106-108), every clause scores 0.0 and the conjunction's 0.0 + 0.0 joins the outer sum as one 0.0 — the
+  //     FILTER clauses b, c (MUST clauses of boost 0; x + 0.0 == x wherever the cost order puts them).
+  std::vector<std::unique_ptr<Query>> must_not_nested, filter_nested;
+  // -> MUST_NOT terms (the query's own + the expanded ones) and the zero-boost MUST terms the nested FILTER clauses stand for; false:
+  // a nested non-scoring clause of another shape (the tree goes to cpu_fallback)
+  bool scoring_clauses_are_terms() const {
+    for (const auto* v : {&must_queries, &should_queries})
+      for (const auto& q : *v)
+        if (!dynamic_cast<const TermQuery*>(q.get())) return false;
+    return true;
+  }
+  bool expand_non_scoring(std::vector<TermQuery>* nots, std::vector<TermQuery>* zeros) const {
+    *nots = must_not_queries;
+    zeros->clear();
+    for (const auto& q : must_not_nested) {
+      if (auto* t = dynamic_cast<const TermQuery*>(q.get())) { nots->push_back(*t); continue; }
+      auto* b = dynamic_cast<const BooleanQuery*>(q.get());
+      if (!b || min_should_match > 1 || !b->must_queries.empty() || !b->must_not_queries.empty() || b->should_queries.empty() || b->min_should_match > 1 ||
+          b->should_required || b->nested_must)
+        return false;
+      nots->insert(nots->end(), b->should_queries.begin(), b->should_queries.end());
+    }
+    for (const auto& q : filter_nested) {
+      std::vector<TermQuery> terms;
+      if (auto* t = dynamic_cast<const TermQuery*>(q.get())) terms.push_back(*t);
+      else {
+        auto* b = dynamic_cast<const BooleanQuery*>(q.get());
+        if (!b || b->must_queries.empty() || !b->should_queries.empty() || !b->must_not_queries.empty() || b->should_required || b->nested_must) return false;
+        terms = b->must_queries;
+      }
+      for (TermQuery& t : terms) { t.boost = 0.0f; zeros->push_back(t); }
+    }
+    return true;
+  }
   std::unique_ptr<Query> flattened() const {
     auto fold = [](const std::vector<std::unique_ptr<Query>>& clauses, bool want_must, std::vector<TermQuery>* out) -> bool {
       for (const auto& q : clauses) {
@@ -144,8 +183,10 @@ struct NestedBooleanQuery : Query {
       }
       return true;
     };
-    std::vector<TermQuery> musts, shoulds;
+    std::vector<TermQuery> musts, shoulds, nots, zeros;
+    if (!expand_non_scoring(&nots, &zeros)) return nullptr;
     if (!fold(must_queries, true, &musts)) return nullptr;
+    musts.insert(musts.end(), zeros.begin(), zeros.end());
     if (!musts.empty()) {  // SHOULD clauses beside MUST ones stay as they are: ReqOptScorer's optional side takes term clauses only
       for (const auto& q : should_queries) {
         auto* t = dynamic_cast<const TermQuery*>(q.get());
@@ -156,7 +197,7 @@ struct NestedBooleanQuery : Query {
       if (!fold(should_queries, false, &shoulds)) return nullptr;
       if (min_should_match > 1 && shoulds.size() != should_queries.size()) return nullptr;  // it counts the OUTER clauses
     }
-    return BooleanQuery::build(std::move(musts), std::move(shoulds), min_should_match, must_not_queries);
+    return BooleanQuery::build(std::move(musts), std::move(shoulds), min_should_match, std::move(nots));
   }
   // "(b c) a d" / "a (b c) d": a should-only query whose FIRST or SECOND clause is itself a should-only BooleanQuery of terms -> the
   // flat disjunction with the nested clauses moved to the front, else null. DisjunctionSumScorer sums its children in clause order
@@ -165,7 +206,8 @@ struct NestedBooleanQuery : Query {
   // and commutes. Same docs, counts and score bits: no tolerance, no flag. Fewer than ten clauses in all (the clause-order kernel).
   std::unique_ptr<Query> nested_disjunction_first() const {
     if (!must_queries.empty() || min_should_match > 1) return nullptr;
-    std::vector<TermQuery> inner, rest;
+    std::vector<TermQuery> inner, rest, nots, zeros;
+    if (!expand_non_scoring(&nots, &zeros) || !zeros.empty()) return nullptr;  // (a FILTER clause makes it a conjunction)
     for (size_t i = 0; i < should_queries.size(); ++i) {
       if (auto* t = dynamic_cast<const TermQuery*>(should_queries[i].get())) { rest.push_back(*t); continue; }
       auto* b = dynamic_cast<const BooleanQuery*>(should_queries[i].get());
@@ -176,7 +218,7 @@ struct NestedBooleanQuery : Query {
     }
     if (inner.empty() || inner.size() + rest.size() >= 10) return nullptr;
     inner.insert(inner.end(), rest.begin(), rest.end());
-    return BooleanQuery::build({}, std::move(inner), min_should_match, must_not_queries);
+    return BooleanQuery::build({}, std::move(inner), min_should_match, std::move(nots));
   }
   // "+a +(b c)": MUST term clauses and exactly ONE MUST clause that is a should-only BooleanQuery of 1..9 terms
   // (min_should_match <= 1), no SHOULD clause of its own -> the tree as MUST clauses + required SHOULD clauses
@@ -194,11 +236,13 @@ struct NestedBooleanQuery : Query {
       nested = b;
       out->nested_at = static_cast<int32_t>(out->must_queries.size());
     }
+    std::vector<TermQuery> zeros;
+    if (!expand_non_scoring(&out->must_not_queries, &zeros)) return nullptr;
+    out->must_queries.insert(out->must_queries.end(), zeros.begin(), zeros.end());  // behind every MUST term: nested_at stands
     if (!nested || out->must_queries.empty() || !nested->must_queries.empty() || !nested->must_not_queries.empty() || nested->should_required ||
         nested->min_should_match > 1 || nested->should_queries.empty() || nested->should_queries.size() > 9)
       return nullptr;
     out->should_queries = nested->should_queries;
-    out->must_not_queries = must_not_queries;
     out->should_required = true;
     return out;
   }
@@ -217,11 +261,13 @@ struct NestedBooleanQuery : Query {
       nested = b;
       out->nested_at = static_cast<int32_t>(out->must_queries.size());
     }
+    std::vector<TermQuery> zeros;
+    if (!expand_non_scoring(&out->must_not_queries, &zeros)) return nullptr;
+    out->must_queries.insert(out->must_queries.end(), zeros.begin(), zeros.end());  // behind every MUST term: nested_at stands
     if (!nested || out->must_queries.empty() || !nested->should_queries.empty() || !nested->must_not_queries.empty() || nested->should_required ||
         nested->nested_must || nested->must_queries.size() < 2)
       return nullptr;
     out->should_queries = nested->must_queries;
-    out->must_not_queries = must_not_queries;
     out->nested_must = true;
     return out;
   }
@@ -487,7 +533,7 @@ class GpuIndexSearcher {
         if ((folded = nested->nested_disjunction_first())) {}  // exact as a flat disjunction in another clause order
         else if (req) folded = std::move(req);
         else if ((req = nested->nested_conjunction())) folded = std::move(req);
-        else if (flatten_nested) folded = nested->flattened();  // (what is left — two nested clauses, a disjunction from the third SHOULD clause on — within 1e-5)
+        else if (flatten_nested || nested->scoring_clauses_are_terms()) folded = nested->flattened();  // (only non-scoring clauses nested: exact)  // (what is left — two nested clauses, a disjunction from the third SHOULD clause on — within 1e-5)
         if (!folded) throw Error(RGPU_ERR_UNSUPPORTED, "nested boolean clauses are not served by the GPU path");
         q = folded.get();
       }

@@ -284,6 +284,32 @@ class BooleanQuery:
             raise RgpuError(-5, "only term and boolean clauses are known to this mirror")
         return BooleanQuery(list(musts), list(shoulds), msm, list(must_nots), list(filters))
 
+    def normalized(self):
+        """Nested clauses that do NOT score, in their exact flat forms (same docs, counts and f32 sums as the reference's scorer tree),
+        or self when there is none of that shape:
+          * a MUST_NOT clause that is a should-only BooleanQuery of terms, "-(b c)": ReqNotScorer excludes what the nested
+            DisjunctionSumScorer matches — the MUST_NOT clauses b, c. (boolean_query.rs:236-252 puts ONE disjunction over the MUST_NOT
+            scorers with the OUTER min_should_match: the same exclusion only while that is <= 1; above it the clause stays nested.)
+          * a FILTER clause that is a must- / filter-only BooleanQuery of terms, "#(+b +c)": its weights are created with
+            needs_scores = false (boolean_query.rs:106-108), each clause scores 0.0 and the nested conjunction's 0.0 + 0.0 joins the outer
+            sum as one 0.0 — the FILTER clauses b, c (x + 0.0 == x wherever the cost order puts them)."""
+        must_nots, filters, changed = [], [], False
+        for q in self.must_not_queries:
+            if (isinstance(q, BooleanQuery) and self.min_should_match <= 1 and q.is_flat() and q.should_queries and q.min_should_match <= 1
+                    and not (q.must_queries or q.must_not_queries or q.filter_queries)):
+                must_nots.extend(q.should_queries)
+                changed = True
+            else:
+                must_nots.append(q)
+        for q in self.filter_queries:
+            if (isinstance(q, BooleanQuery) and q.is_flat() and (q.must_queries or q.filter_queries)
+                    and not (q.should_queries or q.must_not_queries)):
+                filters.extend(q.must_queries + q.filter_queries)
+                changed = True
+            else:
+                filters.append(q)
+        return BooleanQuery(list(self.must_queries), list(self.should_queries), self.min_should_match, must_nots, filters) if changed else self
+
     def is_flat(self):
         return all(isinstance(q, TermQuery) for q in self.must_queries + self.should_queries + self.must_not_queries + self.filter_queries)
 
@@ -474,6 +500,7 @@ class GpuIndexSearcher:
         if isinstance(query, TermQuery):
             return OP_TERM, [query], [], []
         if isinstance(query, BooleanQuery):
+            query = query.normalized()
             if not query.is_flat():
                 first = query.nested_disjunction_first()
                 if first is not None:

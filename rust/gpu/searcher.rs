@@ -132,6 +132,7 @@ impl<C: Codec, R: IndexReader<Codec = C> + ?Sized, IR: Deref<Target = R>, SP: Si
     ///   must + ONE nested should-only query         -> ... | RGPU_OP_SHOULD_REQUIRED | RGPU_OP_NESTED_AT(i) ("+a +(b c)": nested_must_child), bit-exact
     ///   must + ONE nested must-only query           -> ... | RGPU_OP_NESTED_MUST | RGPU_OP_NESTED_AT(i) ("+a +(+b +c)": the nested sum formed first), bit-exact
     ///   any of them + must_not                      -> n_must_not > 0: ReqNotScorer
+    ///   a nested should-only MUST_NOT clause, a nested must-only FILTER clause -> their term clauses ("-(b c)" = "-b -c", "#(+b +c)" = "#b #c"), bit-exact
     /// With `allow_flatten` (off by default): a MUST clause that is itself a must-only BooleanQuery, a SHOULD clause that is a
     /// should-only one (msm <= 1) with no other kind of clause inside it — ONE level is folded into the parent: same doc ids;
     /// the f32 sum is then formed over the flat list (a + b + c) where the CPU forms a + (b + c): within 1e-5 relative
@@ -151,7 +152,16 @@ impl<C: Codec, R: IndexReader<Codec = C> + ?Sized, IR: Deref<Target = R>, SP: Si
         let mut optional = Vec::new();
         let mut prohibited = Vec::new();
         let mut folded = false;
-        for q in must_not { prohibited.push(term_of(q)?); }
+        for q in must_not {
+            if let Some(t) = term_of(q) { prohibited.push(t); continue; }
+            // "-(b c)": a should-only BooleanQuery of terms as a MUST_NOT clause is the MUST_NOT clauses b, c — ReqNotScorer excludes
+            // what the nested DisjunctionSumScorer matches (boolean_query.rs:236-273), nothing of it is ever scored: exact. The CPU puts
+            // ONE disjunction with the OUTER min_should_match over the MUST_NOT scorers: expanded only while that is <= 1.
+            let inner = q.as_any().downcast_ref::<BooleanQuery<C>>()?;
+            let (m, s, f, n, inner_msm) = inner.clauses();
+            if msm > 1 || !m.is_empty() || !f.is_empty() || !n.is_empty() || s.is_empty() || inner_msm > 1 { return None; }
+            for c in s { prohibited.push(term_of(c)?); }
+        }
         let allow = self.allow_flatten;
         let mut fold = |q: &'q Box<dyn Query<C>>, want_must: bool, out: &mut Vec<(&'q TermQuery, f32)>| -> Option<()> {
             if let Some(t) = term_of(q) { out.push((t, t.boost)); return Some(()); }
@@ -176,7 +186,7 @@ impl<C: Codec, R: IndexReader<Codec = C> + ?Sized, IR: Deref<Target = R>, SP: Si
                 if let Some(f) = self.nested_must_child(must, filter, &prohibited, true) { return Some(f); }
             }
             for q in must { fold(q, true, &mut positive)?; }
-            for q in filter { let t = term_of(q)?; positive.push((t, 0.0)); }
+            for q in filter { self.filter_terms(q, &mut positive)?; }
             for q in should { optional.push(term_of(q)?); }
             let op = if positive.len() == 1 { RGPU_OP_TERM } else { RGPU_OP_AND };
             Some(FlatQuery { op: rgpu_op_with_should(op, optional.len() as i32), positive, optional, must_not: prohibited })
@@ -203,6 +213,19 @@ impl<C: Codec, R: IndexReader<Codec = C> + ?Sized, IR: Deref<Target = R>, SP: Si
         }
     }
 
+    /// A FILTER clause as MUST clauses of weight 0: a term, or "#(+b +c)" — a must- / filter-only BooleanQuery of terms, whose weights the
+    /// CPU creates with needs_scores = false (boolean_query.rs:106-108): every clause scores 0.0, the nested conjunction's 0.0 + 0.0
+    /// joins the outer sum as one 0.0, and x + 0.0 == x wherever the cost order puts the clauses — the FILTER clauses b, c, exact.
+    fn filter_terms<'q>(&self, q: &'q Box<dyn Query<C>>, out: &mut Vec<(&'q TermQuery, f32)>) -> Option<()> {
+        let term_of = |q: &'q Box<dyn Query<C>>| q.as_any().downcast_ref::<TermQuery>().filter(|t| t.term.field == self.field);
+        if let Some(t) = term_of(q) { out.push((t, 0.0)); return Some(()); }
+        let inner = q.as_any().downcast_ref::<BooleanQuery<C>>()?;
+        let (m, s, f, n, _) = inner.clauses();
+        if !s.is_empty() || !n.is_empty() || (m.is_empty() && f.is_empty()) { return None; }
+        for c in m.iter().chain(f.iter()) { out.push((term_of(c)?, 0.0)); }
+        Some(())
+    }
+
     /// The one nested MUST clause of "+a +(b c)" (conjunction = false: a should-only BooleanQuery of 1..=9 terms, msm <= 1) or
     /// "+a +(+b +c)" (conjunction = true: a must-only one of >= 2 terms) with the term clauses beside it, as the C ABI takes them.
     fn nested_must_child<'q>(&self, must: &'q [Box<dyn Query<C>>], filter: &'q [Box<dyn Query<C>>], prohibited: &[&'q TermQuery], conjunction: bool)
@@ -225,7 +248,7 @@ impl<C: Codec, R: IndexReader<Codec = C> + ?Sized, IR: Deref<Target = R>, SP: Si
                 for c in s { optional.push(term_of(c)?); }
             }
         }
-        for q in filter { let t = term_of(q)?; positive.push((t, 0.0)); }
+        for q in filter { self.filter_terms(q, &mut positive)?; }
         if positive.is_empty() || optional.is_empty() { return None; }
         let op = if positive.len() == 1 { RGPU_OP_TERM } else { RGPU_OP_AND };
         let flag = if conjunction { RGPU_OP_NESTED_MUST } else { RGPU_OP_SHOULD_REQUIRED };

@@ -170,6 +170,29 @@ int main(int argc, char** argv) {
       TopDocsCollector c2(10);
       searcher.search(mixed, c2);
       std::printf("fallback %d\n", fell_back);
+      // nested clauses that do not score are served in their exact flat forms, flatten_nested or not: "+t2 +t9 -(t1 t30)" is query 6
+      // above, "+t1 #(+t12 +t40)" the conjunction of query 3 scored by t1 alone
+      searcher.cpu_fallback = nullptr;
+      NestedBooleanQuery prohibited;
+      prohibited.must_queries.emplace_back(new TermQuery(2));
+      prohibited.must_queries.emplace_back(new TermQuery(9));
+      prohibited.must_not_nested.push_back(BooleanQuery::build({}, {TermQuery(1), TermQuery(30)}));
+      NestedBooleanQuery filtered;
+      filtered.must_queries.emplace_back(new TermQuery(1));
+      filtered.filter_nested.push_back(BooleanQuery::build({TermQuery(12), TermQuery(40)}, {}));
+      const NestedBooleanQuery* both[2] = {&prohibited, &filtered};
+      for (const NestedBooleanQuery* nq : both) {
+        TopDocsCollector c(10);
+        searcher.search(*nq, c);
+        TopDocs t = c.top_docs();
+        std::printf("nonscoring %lld", (long long)t.total_hits());
+        for (const ScoreDoc& d : t.score_docs()) {
+          uint32_t bits;
+          std::memcpy(&bits, &d.score, 4);
+          std::printf(" %d:%08x", d.doc, bits);
+        }
+        std::printf("\n");
+      }
     }
     rgpu_terms_close(dict);
     rgen_free(ix);

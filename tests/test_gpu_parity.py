@@ -1289,6 +1289,13 @@ def test_cpp_host_mirror(oracle, tmp_path):
     assert [int(p.split(":")[0]) for p in parts[2:]] == cand[ok][order].tolist()
     assert [int(p.split(":")[1], 16) for p in parts[2:]] == sc[order].view(np.uint32).tolist()
     assert out[2 * len(specs) + 4] == "fallback 1"
+    # nested clauses that do not score (NestedBooleanQuery::expand_non_scoring): "+t2 +t9 -(t1 t30)" is spec 5's line, "+t1 #(+t12 +t40)"
+    # the conjunction's docs scored by t1 alone
+    assert out[2 * len(specs) + 5].split()[0] == "nonscoring" and out[2 * len(specs) + 5].split()[1:] == out[5].split()[1:]
+    d, s, total = osr.search(oracle.OP_AND, [1, 12, 40], 10, tie_mode=oracle.TIE_CANONICAL, boosts=[1.0, 0.0, 0.0])
+    parts = out[2 * len(specs) + 6].split()
+    assert parts[0] == "nonscoring" and int(parts[1]) == total
+    assert [int(p.split(":")[0]) for p in parts[2:]] == d.tolist() and [int(p.split(":")[1], 16) for p in parts[2:]] == s.view(np.uint32).tolist()
 
 
 def test_cpp_host_mirror_phrases_and_rescoring(ctx, oracle, tmp_path):
@@ -1696,6 +1703,52 @@ def test_filter_clauses(zipf, oracle):
     h, t = gsearcher.search_batch([B.build([], [T(1)], filters=[T(3)])], 10)
     ed, es, et = osearcher.search_opt(oracle.OP_TERM, [3], [1], 10, exact=True)   # weight 1 on the required clause ...
     assert t[0] == et                                                                # ... same docs match; scores differ by design
+
+
+def test_nested_clauses_that_do_not_score(zipf, oracle):
+    """"+a -(b c)" and "+a #(+b +c)": nested clauses that never reach a sum have exact flat forms (BooleanQuery.normalized: ReqNotScorer
+    over the nested DisjunctionSumScorer excludes b or c, boolean_query.rs:236-273; a FILTER's weights are created with needs_scores =
+    false and score 0.0, boolean_query.rs:106-108). Rows against the oracle's scorers for the flat trees; hit counts against set
+    algebra on the decoded lists, which knows nothing of the rewrite."""
+    import rucene_amd
+    seg, osearcher, gsearcher = zipf
+    T, B = rucene_amd.TermQuery, rucene_amd.BooleanQuery
+    oseg = oracle.Segment(seg.doc_bytes, seg.norms, seg.max_doc, seg.terms, sum_total_term_freq=seg.sum_total_term_freq)
+    docs_of = lambda t: np.asarray(oseg.decode_term(seg.terms[t])[0], dtype=np.int32)   # noqa: E731
+    # (MUST terms, nested MUST_NOT disjunction, MUST_NOT terms beside it, nested FILTER conjunction)
+    cases = [([5], [1, 40], [], []), ([0, 3], [2, 900, 30_000], [7], []), ([300], [0], [1], []), ([2], [], [], [0, 1]), ([40, 7], [], [], [0, 300]),
+             ([0], [49_999, 1], [2], []), ([12], [], [], [0, 1, 2])]
+    queries = []
+    for m, nn, n1, f in cases:
+        queries.append(B.build([T(t) for t in m], [], must_nots=([B.build([], [T(t) for t in nn])] if len(nn) > 1 else [T(t) for t in nn]) + [T(t) for t in n1],
+                               filters=[B.build([T(t) for t in f], [])] if f else []))
+    assert sum(not q.is_flat() for q in queries) >= 6   # (a one-clause nested disjunction builds as the clause itself)
+    for k in (10, 100):
+        hits, totals = gsearcher.search_batch(queries, k)
+        for i, (m, nn, n1, f) in enumerate(cases):
+            req = m + f
+            op = oracle.OP_AND if len(req) > 1 else oracle.OP_TERM
+            if nn or n1:
+                assert not f
+                cd, cs, ct = osearcher.search_not(op, req, nn + n1, k)
+            else:
+                cd, cs, ct = osearcher.search(op, req, k, boosts=[1.0] * len(m) + [0.0] * len(f))
+            inter = docs_of(req[0])
+            for t in req[1:]:
+                inter = np.intersect1d(inter, docs_of(t))
+            for t in nn + n1:
+                inter = np.setdiff1d(inter, docs_of(t))
+            n = len(cd)
+            assert totals[i] == ct == inter.size, (i, cases[i])
+            assert (hits[i]["doc"][:n] == cd).all() and (hits[i]["doc"][n:] == -1).all(), (i, cases[i])
+            assert (hits[i]["score"][:n].view(np.int32) == cs.view(np.int32)).all(), (i, cases[i])
+    # MUST_NOT + FILTER nested in one tree: the docs by set algebra, the scores those of the MUST clause alone
+    q = B.build([T(5)], [], must_nots=[B.build([], [T(1), T(40)])], filters=[B.build([T(0), T(2)], [])])
+    h, t = gsearcher.search_batch([q], 10)
+    want = np.setdiff1d(np.setdiff1d(np.intersect1d(np.intersect1d(docs_of(5), docs_of(0)), docs_of(2)), docs_of(1)), docs_of(40))
+    assert t[0] == want.size > 0 and np.isin(h[0]["doc"][:min(10, want.size)], want).all()
+    flat_h, flat_t = gsearcher.search_batch([B.build([T(5)], [], must_nots=[T(1), T(40)], filters=[T(0), T(2)])], 10)
+    assert flat_t[0] == t[0] and h.tobytes() == flat_h.tobytes()
 
 
 def test_min_should_match(zipf, oracle):
