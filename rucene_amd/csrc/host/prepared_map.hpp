@@ -33,6 +33,9 @@ struct PreparedMap {
   bool bulk_no_norms = false;
   std::vector<uint8_t> moved;                      // bulk[i] lives in `map` now
   size_t bulk_live = 0;
+  // bumped by everything that adds, replaces or removes a term's TermInfo (a term moving from `bulk` into `map` keeps its value and
+  // does not count): what a memo of finished descriptors checks (rgpu_api.hip term_batch_fast)
+  uint64_t epoch = 1;
   static TermInfo expand(const PreparedEntry& e, uint64_t bs_base, bool no_norms) {
     return TermInfo{e.dir_base, e.df / 128, e.df, 0, bs_base, no_norms};
   }
@@ -52,16 +55,18 @@ struct PreparedMap {
     return map.find(key);
   }
   void put(int64_t key, const TermInfo& v) {
+    ++epoch;
     if (bulk_live != 0) { const long i = bulk_at(key); if (i >= 0) { moved[(size_t)i] = 1; --bulk_live; } }
     map.put(key, v);
   }
   void prefetch(int64_t key) const { map.prefetch(key); }
   void reserve_more(size_t n) { map.reserve_more(n); }
   size_t size() const { return map.size() + bulk_live; }
-  void clear() { map.clear(); bulk.clear(); moved.clear(); bulk_live = 0; }
+  void clear() { ++epoch; map.clear(); bulk.clear(); moved.clear(); bulk_live = 0; }
   // An empty array for a bulk call to fill (with whatever memory the last one left), then adopt_sorted(): ascending keys none of
   // which is in the table. An earlier bulk that is still (partly) pending moves into the table first.
   PreparedBulk take_array() {
+    ++epoch;
     if (bulk_live != 0) {
       map.reserve_more(bulk_live);
       for (size_t i = 0; i < bulk.size(); ++i) if (!moved[i]) map.put(bulk[i].first, expand(bulk[i], bulk_bs_base, bulk_no_norms));
@@ -74,6 +79,7 @@ struct PreparedMap {
     return out;
   }
   void adopt_sorted(PreparedBulk&& sorted, uint64_t bs_base, bool no_norms) {
+    ++epoch;
     if (bulk_live != 0) (void)take_array();
     bulk = std::move(sorted);
     bulk_bs_base = bs_base;
@@ -81,8 +87,8 @@ struct PreparedMap {
     moved.assign(bulk.size(), 0);
     bulk_live = bulk.size();
   }
-  void drop_bulk() { bulk.clear(); moved.clear(); bulk_live = 0; }
-  void remove_keys(const int64_t* keys, size_t n) { map.remove_keys(keys, n); }
+  void drop_bulk() { ++epoch; bulk.clear(); moved.clear(); bulk_live = 0; }
+  void remove_keys(const int64_t* keys, size_t n) { ++epoch; map.remove_keys(keys, n); }
 };
 
 }  // namespace rucene

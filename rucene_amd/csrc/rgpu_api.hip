@@ -272,8 +272,10 @@ using rucene::PreparedMap;
 // a term's doc bitmap (kernels/doc_bitmap.hpp): one allocation [words | ranks | ovf | stats | freqs]
 struct BitmapInfo { uint2* words; uint32_t* ranks; uint8_t* freqs; uint32_t* ovf; uint32_t* nib; uint32_t* memb; int32_t n_ovf; int32_t max_freq; int32_t df; int32_t sim_table; bool usable; };
 
+static std::atomic<uint64_t> g_segment_uid{1};
 struct rgpu_segment {
   rgpu_ctx* ctx = nullptr;
+  const uint64_t uid = g_segment_uid.fetch_add(1, std::memory_order_relaxed);  // never reused (a freed segment's address may be): memo keys
   uint8_t* d_doc = nullptr;
   size_t doc_len = 0;
   uint8_t* d_norms = nullptr;       // raw norm bytes, or norm ranks when n_norm_ranks > 0
@@ -4753,9 +4755,11 @@ static int32_t term_batch_fast(rgpu_segment* seg, rucene::BatchPlanner* P, int32
   bool bail = false;
   const int32_t max_doc = seg->max_doc;
   const bool has_freqs = seg->has_freqs;
-  P->for_each_flat(ids, nq, [&](int64_t q, const rgpu_term_state& s0, float idf) {
-    hm[q] = (int32_t)q;
-    if (s0.doc_freq <= 0) { hq[q] = DevQuery{RGPU_OP_TERM, 0, nt, 0}; return; }  // TermWeight::create_scorer -> None for this leaf
+  // term id -> finished descriptor through the planner's memo (host/batch_planner.hpp for_each_flat_memo): a descriptor is a function
+  // of the planner's tables (immutable), the segment and what its prepared store holds (uid, epoch), and the flags below
+  const rucene::BatchPlanner::MemoKey memo_key{{seg->uid, seg->prepared.epoch, (uint64_t)(uint32_t)sim_table | ((uint64_t)flags << 32),
+                                                (uint64_t)want_sketch | ((uint64_t)need_norms << 1) | ((uint64_t)has_freqs << 2) | ((uint64_t)(uint32_t)max_doc << 8)}};
+  bail = !P->for_each_flat_memo<DevTerm>(ids, nq, memo_key, [&](const rgpu_term_state& s0, float idf, DevTerm* out) -> int32_t {
     DevTerm t;
     t.start_fp = (uint64_t)std::max<int64_t>(0, s0.doc_start_fp);
     t.pn_base = 0;
@@ -4771,22 +4775,27 @@ static int32_t term_batch_fast(rgpu_segment* seg, rucene::BatchPlanner* P, int32
     t.flags = flags;
     t.sketch = 0;
     if (s0.doc_freq == 1) {
-      if (s0.singleton_doc_id < 0 || s0.singleton_doc_id >= max_doc) { bail = true; return; }  // (the full path names the error)
+      if (s0.singleton_doc_id < 0 || s0.singleton_doc_id >= max_doc) return -1;  // (the full path names the error)
     } else {
       const TermInfo* info = seg->prepared.find(s0.doc_start_fp);
       if (!info || info->df != s0.doc_freq || (need_norms && !info->norms) ||
-          (want_sketch && info->sketch == 0 && info->nblocks >= TERM_SKETCH_MIN_BLOCKS)) { bail = true; return; }
+          (want_sketch && info->sketch == 0 && info->nblocks >= TERM_SKETCH_MIN_BLOCKS)) return -1;  // (the full path prepares it: another epoch)
       t.dir_base = info->dir_base;
       t.nblocks = info->nblocks;
       t.pn_base = info->pn_base;
       t.bs_base = info->bs_base;
       t.sketch = info->sketch;
     }
+    *out = t;
+    return 1;
+  }, [&](int64_t q, const DevTerm* t) {
+    hm[q] = (int32_t)q;
+    if (!t) { hq[q] = DevQuery{RGPU_OP_TERM, 0, nt, 0}; return; }  // TermWeight::create_scorer -> None for this leaf
     hq[q] = DevQuery{RGPU_OP_TERM, 1, nt, 0};
-    ht[nt++] = t;
-    postings += t.df;
-    total_blocks += t.nblocks;
-    loose += t.df == 1 ? 1 : t.tail_n;
+    ht[nt++] = *t;
+    postings += t->df;
+    total_blocks += t->nblocks;
+    loose += t->df == 1 ? 1 : t->tail_n;
   });
   if (bail) return RGPU_OK;  // (the slot was taken and not marked: it is simply free again)
   if (timed) laps.lap(1);

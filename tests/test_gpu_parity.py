@@ -1861,6 +1861,22 @@ def test_plan_and_search_in_one_call(zipf, oracle):
             ctx2.synchronize()
             assert (hits.cpu().numpy() == want_h).all() and (totals.cpu().numpy() == want_t).all(), rep
         assert ctx2.kernel_stats()["fused_term_batches"]["launches"] == n0 + 2     # the first of the three prepared the terms
+        # the planner's memo of finished descriptors (BatchPlanner::for_each_flat_memo) follows the prepared store: released terms are
+        # prepared again — elsewhere in the store — and the rows stay; ids that share a memo slot evict each other and stay right
+        leaf2.segment.release_prepared_terms()
+        for rep in range(3):
+            g2.search_uniform_device(gpu.OP_TERM, term_ids.reshape(-1, 1), leaf2, 10, hits.data_ptr(), totals.data_ptr())
+            ctx2.synchronize()
+            assert (hits.cpu().numpy() == want_h).all() and (totals.cpu().numpy() == want_t).all(), ("after release", rep)
+        slot = (np.arange(n_terms, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(48)
+        order = np.argsort(slot, kind="stable")
+        same = np.nonzero(slot[order][1:] == slot[order][:-1])[0][:200]
+        assert same.size == 200
+        pairs = np.stack([order[same], order[same + 1]], axis=1).astype(np.int64)
+        clash = np.concatenate([pairs.reshape(-1), pairs[:, ::-1].reshape(-1), pairs[:, 0], pairs[:, 1]])
+        for rep in range(2):
+            both(gpu.OP_TERM, clash.reshape(-1, 1), 10)
+        both(gpu.OP_TERM, term_ids.reshape(-1, 1), 10)
         # the sharded form (world of one, the all-gather forced to run)
         both(gpu.OP_TERM, term_ids.reshape(-1, 1), 10, comm)
         both(gpu.OP_AND, and_ids, 10, comm)
