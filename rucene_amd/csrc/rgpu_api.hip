@@ -471,23 +471,30 @@ __global__ __launch_bounds__(256) void k_stage_term_plan(const uint8_t* __restri
   const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
   const uint4* s16 = reinterpret_cast<const uint4*>(src);
   uint4* d16 = reinterpret_cast<uint4*>(dst);
+  const DevQuery* hq = reinterpret_cast<const DevQuery*>(src + L.o_q);
+  const int64_t* hp = reinterpret_cast<const int64_t*>(src + L.o_p);
+  int4* out = reinterpret_cast<int4*>(dst + L.o_id);
+  // a thread's query (the grid has at least one thread per query up to 262144 of them): its words are requested BEFORE the copy loop,
+  // so that the two reads of host memory — a PCIe round trip each — are in flight together instead of one behind the other
+  const bool mine = tid < (size_t)L.nq;
+  const size_t q0 = mine ? tid : 0;
+  const DevQuery Q0 = hq[q0];
+  const int64_t p00 = hp[q0], p01 = hp[q0 + 1];
+  const int sh0 = (int)src[L.o_sh + q0];
   for (size_t i = tid; i < n16; i += stride) {
     const size_t off = i * 16;
     d16[i] = (off >= L.zero_from && off < L.zero_to) ? make_uint4(0u, 0u, 0u, 0u) : s16[i];
   }
-  const DevQuery* hq = reinterpret_cast<const DevQuery*>(src + L.o_q);
-  const int64_t* hp = reinterpret_cast<const int64_t*>(src + L.o_p);
-  int4* out = reinterpret_cast<int4*>(dst + L.o_id);
-  for (size_t q = tid; q < (size_t)L.nq; q += stride) {
-    const DevQuery Q = hq[q];
-    const int64_t p0 = hp[q];
-    const int n_mine = 1 + (int)(hp[q + 1] - p0);
+  auto describe = [&](size_t q, const DevQuery& Q, int64_t p0, int64_t p1, int sh) {
+    const int n_mine = 1 + (int)(p1 - p0);
     const int ft = Q.n_terms >= 1 ? Q.first_term : -1;
-    const int w = n_mine | ((int)src[L.o_sh + q] << 24);
+    const int w = n_mine | (sh << 24);
     out[q] = make_int4((int)q, 0, ft, w);
     int4* rest = out + L.nq + p0;
     for (int ch = 1; ch < n_mine; ++ch) rest[ch - 1] = make_int4((int)q, ch, ft, w);
-  }
+  };
+  if (mine) describe(q0, Q0, p00, p01, sh0);
+  for (size_t q = tid + stride; q < (size_t)L.nq; q += stride) describe(q, hq[q], hp[q], hp[q + 1], (int)src[L.o_sh + q]);
 }
 static hipError_t stage_h2d(rgpu_ctx* c, size_t bytes, hipStream_t s) {
   Scratch* sc = c->S;
