@@ -328,6 +328,15 @@ def test_prepared_map_against_std_map(tmp_path):
     assert subprocess.check_output([exe], text=True).strip() == "prepared_map OK"
 
 
+def test_planner_descriptor_memo_and_prepared_epoch(tmp_path):
+    """csrc/host/batch_planner.hpp for_each_flat_memo (the fused TERM call's term id -> descriptor memo) against for_each_flat, and
+    PreparedMap::epoch (what the memo's key follows): tests/cpp/planner_memo_test.cpp."""
+    exe = str(tmp_path / "planner_memo_test")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-pthread", "-o", exe,
+                           os.path.join(ROOT, "tests", "cpp", "planner_memo_test.cpp")])
+    assert subprocess.check_output([exe], text=True).strip() == "planner_memo OK"
+
+
 def test_host_threads_count_then_fill(tmp_path):
     """csrc/host/host_threads.hpp (the bulk planner's threads: a first touch of a whole term dictionary): tests/cpp/host_threads_test.cpp."""
     exe = str(tmp_path / "host_threads_test")
