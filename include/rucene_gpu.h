@@ -536,8 +536,10 @@ int32_t rgpu_plan_uniform_bytes(rgpu_planner* planner, int32_t op, int32_t n_que
  * does from the top (search/searcher.rs:487-525: create_normalized_weight -> TermQuery::create_weight, term_query.rs:58-95;
  * then per leaf TermWeight::create_scorer, :145-163, and the collector loop). Same rows as the two calls, bit for bit; enqueue-
  * only like rgpu_search_batch_device (rgpu_config.or_deferred applies). Single-term batches whose terms are all prepared take
- * a one-pass path (planner entry -> device descriptor, three enqueues: the host's share of a 1024-query batch drops from ~63
- * to ~30 us); every other batch is planned and searched as the two calls would. Flat-table planners only. */
+ * a one-pass path (planner entry -> device descriptor, two enqueues: the host's share of a 1024-query batch drops from ~63
+ * to ~13 us); every other batch is planned and searched as the two calls would. Flat-table planners only. The planner keeps a
+ * memo of finished descriptors for that path (65536 records, 5 MB of host memory, allocated by the first such call; emptied
+ * whenever the segment's prepared terms change). */
 int32_t rgpu_planner_search_uniform_ids_device(rgpu_planner* planner, rgpu_segment* seg, int32_t op, int32_t n_queries, int32_t n_clauses,
                                                const int64_t* term_ids, int32_t k, void* hits_dev, void* total_hits_dev, void* hip_stream);
 /* ... and as rgpu_search_batch_sharded: this rank's plan + search -> the all-gather of the shards' records -> the merge. */
