@@ -147,7 +147,9 @@ struct NestedBooleanQuery : Query {
         if (!dynamic_cast<const TermQuery*>(q.get())) return false;
     return true;
   }
-  bool expand_non_scoring(std::vector<TermQuery>* nots, std::vector<TermQuery>* zeros) const {
+  // `filter_disjunction` (optional): a FILTER clause that is a should-only BooleanQuery of 1..9 terms, "+a #(b c)" — served by
+  // required_disjunction() as the required disjunction of zero-boost clauses; at most one, and only where the caller asks for it
+  bool expand_non_scoring(std::vector<TermQuery>* nots, std::vector<TermQuery>* zeros, const BooleanQuery** filter_disjunction = nullptr) const {
     *nots = must_not_queries;
     zeros->clear();
     for (const auto& q : must_not_nested) {
@@ -163,7 +165,13 @@ struct NestedBooleanQuery : Query {
       if (auto* t = dynamic_cast<const TermQuery*>(q.get())) terms.push_back(*t);
       else {
         auto* b = dynamic_cast<const BooleanQuery*>(q.get());
-        if (!b || b->must_queries.empty() || !b->should_queries.empty() || !b->must_not_queries.empty() || b->should_required || b->nested_must) return false;
+        if (!b || !b->must_not_queries.empty() || b->should_required || b->nested_must) return false;
+        if (b->must_queries.empty()) {  // should-only: a filter by a disjunction
+          if (!filter_disjunction || *filter_disjunction || b->should_queries.empty() || b->should_queries.size() > 9 || b->min_should_match > 1) return false;
+          *filter_disjunction = b;
+          continue;
+        }
+        if (!b->should_queries.empty()) return false;
         terms = b->must_queries;
       }
       for (TermQuery& t : terms) { t.boost = 0.0f; zeros->push_back(t); }
@@ -237,12 +245,19 @@ struct NestedBooleanQuery : Query {
       out->nested_at = static_cast<int32_t>(out->must_queries.size());
     }
     std::vector<TermQuery> zeros;
-    if (!expand_non_scoring(&out->must_not_queries, &zeros)) return nullptr;
+    const BooleanQuery* by_filter = nullptr;
+    if (!expand_non_scoring(&out->must_not_queries, &zeros, &by_filter)) return nullptr;
+    if (by_filter) {  // "+a #(b c)": the required disjunction of zero-boost clauses (they score 0.0: needs_scores = false), behind the MUST
+      if (nested) return nullptr;  // clauses, where BooleanQuery::create_weight puts the FILTER weights (boolean_query.rs:101-108)
+      nested = by_filter;
+      out->nested_at = static_cast<int32_t>(out->must_queries.size());
+    }
     out->must_queries.insert(out->must_queries.end(), zeros.begin(), zeros.end());  // behind every MUST term: nested_at stands
     if (!nested || out->must_queries.empty() || !nested->must_queries.empty() || !nested->must_not_queries.empty() || nested->should_required ||
         nested->min_should_match > 1 || nested->should_queries.empty() || nested->should_queries.size() > 9)
       return nullptr;
     out->should_queries = nested->should_queries;
+    if (by_filter) for (TermQuery& t : out->should_queries) t.boost = 0.0f;
     out->should_required = true;
     return out;
   }

@@ -292,7 +292,8 @@ class BooleanQuery:
             scorers with the OUTER min_should_match: the same exclusion only while that is <= 1; above it the clause stays nested.)
           * a FILTER clause that is a must- / filter-only BooleanQuery of terms, "#(+b +c)": its weights are created with
             needs_scores = false (boolean_query.rs:106-108), each clause scores 0.0 and the nested conjunction's 0.0 + 0.0 joins the outer
-            sum as one 0.0 — the FILTER clauses b, c (x + 0.0 == x wherever the cost order puts them)."""
+            sum as one 0.0 — the FILTER clauses b, c (x + 0.0 == x wherever the cost order puts them).
+          * a FILTER clause that is a should-only BooleanQuery of terms, "+a #(b c)": the required disjunction of zero-boost clauses."""
         must_nots, filters, changed = [], [], False
         for q in self.must_not_queries:
             if (isinstance(q, BooleanQuery) and self.min_should_match <= 1 and q.is_flat() and q.should_queries and q.min_should_match <= 1
@@ -301,14 +302,24 @@ class BooleanQuery:
                 changed = True
             else:
                 must_nots.append(q)
+        musts = list(self.must_queries)
         for q in self.filter_queries:
             if (isinstance(q, BooleanQuery) and q.is_flat() and (q.must_queries or q.filter_queries)
                     and not (q.should_queries or q.must_not_queries)):
                 filters.extend(q.must_queries + q.filter_queries)
                 changed = True
+            elif (isinstance(q, BooleanQuery) and q.is_flat() and 1 <= len(q.should_queries) <= 9 and q.min_should_match <= 1
+                    and not (q.must_queries or q.filter_queries or q.must_not_queries)
+                    and not self.should_queries and all(isinstance(m, TermQuery) for m in self.must_queries) and not any(isinstance(m, BooleanQuery) for m in musts)):
+                # "+a #(b c)" — a filter by a disjunction ("category is b or c"): the required disjunction "+a +(b c)" whose clauses score
+                # 0.0 (needs_scores = false): ConjunctionScorer([a ..., DisjunctionSumScorer(b, c)]) adds (0.0 + 0.0) somewhere in
+                # the cost order, which leaves the f32 sum of the scoring clauses as it is. Behind the MUST clauses, where
+                # BooleanQuery::create_weight puts the FILTER weights (boolean_query.rs:101-108). One such clause per query.
+                musts.append(BooleanQuery([], [TermQuery(t.term, 0.0) for t in q.should_queries], q.min_should_match))
+                changed = True
             else:
                 filters.append(q)
-        return BooleanQuery(list(self.must_queries), list(self.should_queries), self.min_should_match, must_nots, filters) if changed else self
+        return BooleanQuery(musts, list(self.should_queries), self.min_should_match, must_nots, filters) if changed else self
 
     def is_flat(self):
         return all(isinstance(q, TermQuery) for q in self.must_queries + self.should_queries + self.must_not_queries + self.filter_queries)

@@ -67,6 +67,7 @@ struct FlatQuery<'q> {
     op: i32,
     positive: Vec<(&'q TermQuery, f32 /* boost, 0.0 for FILTER */)>,
     optional: Vec<&'q TermQuery>, // SHOULD beside MUST: ReqOptScorer
+    optional_zero: bool,          // the optional clauses score 0.0 (a FILTER by a disjunction, "+a #(b c)": needs_scores = false)
     must_not: Vec<&'q TermQuery>,
 }
 
@@ -133,6 +134,7 @@ impl<C: Codec, R: IndexReader<Codec = C> + ?Sized, IR: Deref<Target = R>, SP: Si
     ///   must + ONE nested must-only query           -> ... | RGPU_OP_NESTED_MUST | RGPU_OP_NESTED_AT(i) ("+a +(+b +c)": the nested sum formed first), bit-exact
     ///   any of them + must_not                      -> n_must_not > 0: ReqNotScorer
     ///   a nested should-only MUST_NOT clause, a nested must-only FILTER clause -> their term clauses ("-(b c)" = "-b -c", "#(+b +c)" = "#b #c"), bit-exact
+    ///   must / filter + ONE nested should-only FILTER clause -> ... | RGPU_OP_SHOULD_REQUIRED with zero-weight clauses ("+a #(b c)": filter_disjunction), bit-exact
     /// With `allow_flatten` (off by default): a MUST clause that is itself a must-only BooleanQuery, a SHOULD clause that is a
     /// should-only one (msm <= 1) with no other kind of clause inside it — ONE level is folded into the parent: same doc ids;
     /// the f32 sum is then formed over the flat list (a + b + c) where the CPU forms a + (b + c): within 1e-5 relative
@@ -143,7 +145,7 @@ impl<C: Codec, R: IndexReader<Codec = C> + ?Sized, IR: Deref<Target = R>, SP: Si
     fn flatten<'q>(&self, query: &'q dyn Query<C>) -> Option<FlatQuery<'q>> {
         if let Some(t) = query.as_any().downcast_ref::<TermQuery>() {
             if t.term.field != self.field { return None; }
-            return Some(FlatQuery { op: RGPU_OP_TERM, positive: vec![(t, t.boost)], optional: vec![], must_not: vec![] });
+            return Some(FlatQuery { op: RGPU_OP_TERM, positive: vec![(t, t.boost)], optional: vec![], optional_zero: false, must_not: vec![] });
         }
         let b = query.as_any().downcast_ref::<BooleanQuery<C>>()?;
         let (must, should, filter, must_not, msm) = b.clauses();
@@ -185,11 +187,15 @@ impl<C: Codec, R: IndexReader<Codec = C> + ?Sized, IR: Deref<Target = R>, SP: Si
                 if let Some(f) = self.nested_must_child(must, filter, &prohibited, false) { return Some(f); }
                 if let Some(f) = self.nested_must_child(must, filter, &prohibited, true) { return Some(f); }
             }
+            // "+a #(b c)": ONE FILTER clause that is a should-only BooleanQuery of 1..=9 term clauses (msm <= 1), term clauses everywhere else
+            if should.is_empty() && must.iter().all(|q| term_of(q).is_some()) && filter.iter().filter(|q| term_of(q).is_none()).count() == 1 {
+                if let Some(f) = self.filter_disjunction(must, filter, &prohibited) { return Some(f); }
+            }
             for q in must { fold(q, true, &mut positive)?; }
             for q in filter { self.filter_terms(q, &mut positive)?; }
             for q in should { optional.push(term_of(q)?); }
             let op = if positive.len() == 1 { RGPU_OP_TERM } else { RGPU_OP_AND };
-            Some(FlatQuery { op: rgpu_op_with_should(op, optional.len() as i32), positive, optional, must_not: prohibited })
+            Some(FlatQuery { op: rgpu_op_with_should(op, optional.len() as i32), positive, optional, optional_zero: false, must_not: prohibited })
         } else {
             // "a (b c) d": a nested should-only query (msm <= 1) as FIRST or SECOND clause -> the flat disjunction [b, c, a, d], bit-equal:
             // DisjunctionSumScorer adds its children in clause order from 0.0 (SimpleQueue below ten children, disjunction_scorer.rs:
@@ -202,15 +208,37 @@ impl<C: Codec, R: IndexReader<Codec = C> + ?Sized, IR: Deref<Target = R>, SP: Si
                         let mut exact = Vec::new();
                         for c in s { let t = term_of(c)?; exact.push((t, t.boost)); }
                         for (i, q) in should.iter().enumerate() { if i != at { let t = term_of(q)?; exact.push((t, t.boost)); } }
-                        return Some(FlatQuery { op: RGPU_OP_OR, positive: exact, optional: vec![], must_not: prohibited });
+                        return Some(FlatQuery { op: RGPU_OP_OR, positive: exact, optional: vec![], optional_zero: false, must_not: prohibited });
                     }
                 }
             }
             for q in should { fold(q, false, &mut positive)?; }
             if msm > 1 && folded { return None; }
             let op = if msm > 1 { rgpu_op_or_msm(msm) } else { RGPU_OP_OR };
-            Some(FlatQuery { op, positive, optional, must_not: prohibited })
+            Some(FlatQuery { op, positive, optional, optional_zero: false, must_not: prohibited })
         }
+    }
+
+    /// "+a #(b c)" — a filter by a disjunction ("category is b or c") is the required disjunction "+a +(b c)" whose clauses score 0.0: the
+    /// CPU builds ConjunctionScorer([TermScorer(a) ..., DisjunctionSumScorer(b, c)]) with the nested weights created with needs_scores =
+    /// false (boolean_query.rs:101-108, 200-215); its 0.0 + 0.0 leaves the f32 sum of the scoring clauses as it is wherever the cost order
+    /// adds it. RGPU_OP_SHOULD_REQUIRED with zero-weight optional clauses, behind the MUST clauses (RGPU_OP_NESTED_AT(must.len())).
+    fn filter_disjunction<'q>(&self, must: &'q [Box<dyn Query<C>>], filter: &'q [Box<dyn Query<C>>], prohibited: &[&'q TermQuery]) -> Option<FlatQuery<'q>> {
+        let term_of = |q: &'q Box<dyn Query<C>>| q.as_any().downcast_ref::<TermQuery>().filter(|t| t.term.field == self.field);
+        let mut positive = Vec::new();
+        let mut optional = Vec::new();
+        for q in must { let t = term_of(q)?; positive.push((t, t.boost)); }
+        for q in filter {
+            if let Some(t) = term_of(q) { positive.push((t, 0.0)); continue; }
+            let inner = q.as_any().downcast_ref::<BooleanQuery<C>>()?;
+            let (m, s, f, n, inner_msm) = inner.clauses();
+            if !m.is_empty() || !f.is_empty() || !n.is_empty() || inner_msm > 1 || s.is_empty() || s.len() > 9 { return None; }
+            for c in s { optional.push(term_of(c)?); }
+        }
+        if positive.is_empty() || optional.is_empty() { return None; }
+        let op = if positive.len() == 1 { RGPU_OP_TERM } else { RGPU_OP_AND };
+        Some(FlatQuery { op: rgpu_op_with_should(op, optional.len() as i32) | RGPU_OP_SHOULD_REQUIRED | rgpu_op_nested_at(must.len() as i32), positive, optional,
+                         optional_zero: true, must_not: prohibited.to_vec() })
     }
 
     /// A FILTER clause as MUST clauses of weight 0: a term, or "#(+b +c)" — a must- / filter-only BooleanQuery of terms, whose weights the
@@ -252,7 +280,7 @@ impl<C: Codec, R: IndexReader<Codec = C> + ?Sized, IR: Deref<Target = R>, SP: Si
         if positive.is_empty() || optional.is_empty() { return None; }
         let op = if positive.len() == 1 { RGPU_OP_TERM } else { RGPU_OP_AND };
         let flag = if conjunction { RGPU_OP_NESTED_MUST } else { RGPU_OP_SHOULD_REQUIRED };
-        Some(FlatQuery { op: rgpu_op_with_should(op, optional.len() as i32) | flag | rgpu_op_nested_at(at), positive, optional, must_not: prohibited.to_vec() })
+        Some(FlatQuery { op: rgpu_op_with_should(op, optional.len() as i32) | flag | rgpu_op_nested_at(at), positive, optional, optional_zero: false, must_not: prohibited.to_vec() })
     }
 
     /// The 256-entry norm cache of the field's statistics, uploaded once per avgdl (bm25_similarity.rs:160-166)
@@ -308,7 +336,7 @@ impl<C: Codec, R: IndexReader<Codec = C> + ?Sized, IR: Deref<Target = R>, SP: Si
     fn clause_weights(&self, flat: &FlatQuery<'_>) -> Result<Vec<(f32, i32)>> {
         let mut weights = Vec::with_capacity(flat.n_clauses());
         for (t, boost) in &flat.positive { weights.push(if *boost == 0.0 { (0.0, 0) } else { self.weight_of(&[&t.term], *boost)? }); }
-        for t in &flat.optional { weights.push(self.weight_of(&[&t.term], t.boost)?); }
+        for t in &flat.optional { weights.push(if flat.optional_zero { (0.0, 0) } else { self.weight_of(&[&t.term], t.boost)? }); }
         for _ in &flat.must_not { weights.push((0.0, 0)); } // needs_scores = false: never read
         Ok(weights)
     }

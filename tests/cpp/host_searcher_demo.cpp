@@ -180,7 +180,10 @@ int main(int argc, char** argv) {
       NestedBooleanQuery filtered;
       filtered.must_queries.emplace_back(new TermQuery(1));
       filtered.filter_nested.push_back(BooleanQuery::build({TermQuery(12), TermQuery(40)}, {}));
-      const NestedBooleanQuery* both[2] = {&prohibited, &filtered};
+      NestedBooleanQuery by_disjunction;  // "+t1 #(t12 t40)": a filter by a disjunction = the required disjunction of zero-boost clauses
+      by_disjunction.must_queries.emplace_back(new TermQuery(1));
+      by_disjunction.filter_nested.push_back(BooleanQuery::build({}, {TermQuery(12), TermQuery(40)}));
+      const NestedBooleanQuery* both[3] = {&prohibited, &filtered, &by_disjunction};
       for (const NestedBooleanQuery* nq : both) {
         TopDocsCollector c(10);
         searcher.search(*nq, c);

@@ -1296,6 +1296,12 @@ def test_cpp_host_mirror(oracle, tmp_path):
     parts = out[2 * len(specs) + 6].split()
     assert parts[0] == "nonscoring" and int(parts[1]) == total
     assert [int(p.split(":")[0]) for p in parts[2:]] == d.tolist() and [int(p.split(":")[1], 16) for p in parts[2:]] == s.view(np.uint32).tolist()
+    # "+t1 #(t12 t40)": the docs of t1 that t12 or t40 holds, scored by t1 alone (ms, mm, dm: the oracle's scorers on the docs of t1, above)
+    sc = ms[ok].astype(np.float32)
+    order = np.lexsort((cand[ok], -sc.astype(np.float64)))[:10]
+    parts = out[2 * len(specs) + 7].split()
+    assert parts[0] == "nonscoring" and int(parts[1]) == int(ok.sum())
+    assert [int(p.split(":")[0]) for p in parts[2:]] == cand[ok][order].tolist() and [int(p.split(":")[1], 16) for p in parts[2:]] == sc[order].view(np.uint32).tolist()
 
 
 def test_cpp_host_mirror_phrases_and_rescoring(ctx, oracle, tmp_path):
@@ -1742,6 +1748,24 @@ def test_nested_clauses_that_do_not_score(zipf, oracle):
             assert totals[i] == ct == inter.size, (i, cases[i])
             assert (hits[i]["doc"][:n] == cd).all() and (hits[i]["doc"][n:] == -1).all(), (i, cases[i])
             assert (hits[i]["score"][:n].view(np.int32) == cs.view(np.int32)).all(), (i, cases[i])
+    # "+a #(b c)": a filter by a disjunction — the docs of a that b or c holds, a's scores (the oracle's TermScorer on those docs)
+    for m, f, nots in (([5], [1, 40], []), ([300, 7], [2, 900, 30_000], [0]), ([49_999], [0, 1], []), ([2], [30_000, 31_000], [])):
+        q = B.build([T(t) for t in m], [], filters=[B.build([], [T(t) for t in f])], must_nots=[T(t) for t in nots])
+        inter = docs_of(m[0])
+        for t in m[1:]:
+            inter = np.intersect1d(inter, docs_of(t))
+        union = np.unique(np.concatenate([docs_of(t) for t in f]))
+        inter = np.intersect1d(inter, union)
+        for t in nots:
+            inter = np.setdiff1d(inter, docs_of(t))
+        sc, held = osearcher.score_docs(oracle.OP_AND if len(m) > 1 else oracle.OP_TERM, m, inter.astype(np.int32))
+        assert held.all()
+        for k in (10, 100):
+            h, t = gsearcher.search_batch([q], k)
+            order = np.lexsort((inter, -sc.astype(np.float64)))[:k]
+            n = order.size
+            assert t[0] == inter.size and (h[0]["doc"][:n] == inter[order]).all() and (h[0]["doc"][n:] == -1).all(), (m, f, k)
+            assert (h[0]["score"][:n].view(np.int32) == sc[order].view(np.int32)).all(), (m, f, k)
     # MUST_NOT + FILTER nested in one tree: the docs by set algebra, the scores those of the MUST clause alone
     q = B.build([T(5)], [], must_nots=[B.build([], [T(1), T(40)])], filters=[B.build([T(0), T(2)], [])])
     h, t = gsearcher.search_batch([q], 10)

@@ -228,12 +228,19 @@ def test_nested_clauses_that_do_not_score_pack_as_their_flat_forms(world):
     q, t = s.pack([B.build([T(1), B.build([], [T(2), T(3)])], [], must_nots=[B.build([], [T(9), T(11)])], filters=[B.build([T(7), T(8)], [])])], leaf)
     want = s.pack([B.build([T(1), B.build([], [T(2), T(3)])], [], must_nots=[T(9), T(11)], filters=[T(7), T(8)])], leaf)
     assert same((q, t), want) and q[0]["op"] == (ra.OP_AND | (2 << 16) | ra._lib.OP_SHOULD_REQUIRED | (1 << 26)) and q[0]["n_must_not"] == 2
+    # "+a +b #(c d)": a filter by a disjunction is the required disjunction of zero-weight clauses, behind the MUST clauses
+    q, t = s.pack([B.build([T(1), T(2)], [], filters=[B.build([], [T(7), T(8)])], must_nots=[T(9)])], leaf)
+    want = s.pack([B.build([T(1), T(2), B.build([], [T(7), T(8)])], [], must_nots=[T(9)])], leaf)
+    assert q[0]["op"] == want[0][0]["op"] == (ra.OP_AND | (2 << 16) | ra._lib.OP_SHOULD_REQUIRED | (2 << 26)) and q[0]["n_terms"] == 2 and q[0]["n_must_not"] == 1
+    assert (t["weight"][2:4] == 0).all() and (want[1]["weight"][2:4] > 0).all() and (t["weight"][:2] == want[1]["weight"][:2]).all()
+    assert t["state"].tobytes() == want[1]["state"].tobytes()
     # NOT rewritten: the outer min_should_match counts the MUST_NOT disjunction's matches too (one scorer vs two), a MUST_NOT
-    # conjunction, a nested min_should_match, a FILTER disjunction, deeper trees
+    # conjunction, a nested min_should_match, a FILTER disjunction beside SHOULD clauses or beside another nested clause, deeper trees
     for tree in (B.build([], [T(1), T(2), T(3)], must_nots=[B.build([], [T(9), T(11)])], min_should_match=2),
                  B.build([T(1), T(2)], [], must_nots=[B.build([T(9), T(11)], [])]),
                  B.build([T(1), T(2)], [], must_nots=[B.build([], [T(9), T(11), T(12)], min_should_match=2)]),
-                 B.build([T(1), T(2)], [], filters=[B.build([], [T(7), T(8)])]),
+                 B.build([T(1), T(2)], [T(4)], filters=[B.build([], [T(7), T(8)])]),
+                 B.build([T(1), B.build([], [T(2), T(3)])], [], filters=[B.build([], [T(7), T(8)])]),
                  B.build([T(1), T(2)], [], must_nots=[B.build([], [T(9), B.build([], [T(11), T(12)])])])):
         with pytest.raises(ra.RgpuError) as e:
             s.pack([tree], leaf)
