@@ -116,7 +116,7 @@ class BatchPlanner {
   // for_each_flat with a memo of what the caller makes of a term (round 6: the fused TERM call was bound by its calling thread, and half
   // of that was term id -> state -> idf -> prepared-term look-up -> device descriptor, the same answer batch after batch). A direct-
   // mapped table of 65536 records keyed by term id; `key` names everything outside this planner that a record depends on (the caller's:
-  // segment, prepared-store epoch, similarity table, flags) — another key empties the table. make(state, idf, &rec) -> 1: rec is the
+  // segment, prepared-store epoch, similarity table, flags) — another key empties the table (a generation number: O(1)). make(state, idf, &rec) -> 1: rec is the
   // term's record (kept), 0: the leaf does not hold the term (kept), < 0: give up (nothing kept, returns false at once);
   // use(i, rec or null) in id order. Under the planner's lock, like for_each_flat.
   struct MemoKey { uint64_t w[4]; bool operator==(const MemoKey& o) const { return w[0] == o.w[0] && w[1] == o.w[1] && w[2] == o.w[2] && w[3] == o.w[3]; } };
@@ -125,11 +125,16 @@ class BatchPlanner {
     static_assert(std::is_trivially_copyable<Rec>::value && sizeof(Rec) <= FLAT_MEMO_REC, "a plain record of at most FLAT_MEMO_REC bytes");
     std::lock_guard<std::mutex> g(mu_);
     if (flat_memo_.empty() || !(flat_memo_key_ == key) || flat_memo_rec_ != sizeof(Rec)) {
-      flat_memo_.resize(FLAT_MEMO_SLOTS);
-      for (FlatMemoSlot& e : flat_memo_) e.id = -1;
+      // another key: every record is stale. A generation number per slot makes that one increment, not a pass over 5 MB — a
+      // workload whose other batches keep preparing new terms changes the key in front of every call
+      if (flat_memo_.empty() || ++flat_memo_gen_ == 0) {
+        flat_memo_.assign(FLAT_MEMO_SLOTS, FlatMemoSlot{});  // (gen 0 everywhere)
+        flat_memo_gen_ = 1;
+      }
       flat_memo_key_ = key;
       flat_memo_rec_ = sizeof(Rec);
     }
+    const uint32_t gen = flat_memo_gen_;
     const int64_t n_leaf = (int64_t)leaf_states_.size();
     const int64_t n_stats = own_stats_ ? (int64_t)stats_df_.size() : n_leaf;
     for (int64_t i = 0; i < n; ++i) {
@@ -137,16 +142,17 @@ class BatchPlanner {
       if (id < 0 || id >= n_leaf) { use(i, static_cast<const Rec*>(nullptr)); continue; }
       FlatMemoSlot& e = flat_memo_[(size_t)(((uint64_t)id * 0x9E3779B97F4A7C15ull) >> (64 - FLAT_MEMO_BITS))];
       Rec* rec = reinterpret_cast<Rec*>(e.rec);
-      if (e.id != id) {
+      if (e.id != id || e.gen != gen) {
         const rgpu_term_state& st = leaf_states_[(size_t)id];
         int32_t held = 0;
         if (st.doc_freq > 0) {
           int32_t df = 0;
           if (id < n_stats) df = own_stats_ ? stats_df_[(size_t)id] : st.doc_freq;
           held = make(st, idf_of(df > 0 ? df : 0), rec);
-          if (held < 0) { e.id = -1; return false; }
+          if (held < 0) { e.gen = 0; return false; }
         }
         e.id = id;
+        e.gen = gen;
         e.held = held;
       }
       use(i, e.held ? rec : static_cast<const Rec*>(nullptr));
@@ -197,7 +203,8 @@ class BatchPlanner {
   static constexpr int FLAT_MEMO_BITS = 16;
   static constexpr size_t FLAT_MEMO_SLOTS = (size_t)1 << FLAT_MEMO_BITS;
   static constexpr size_t FLAT_MEMO_REC = 64;
-  struct FlatMemoSlot { int64_t id; int32_t held; int32_t pad; alignas(8) unsigned char rec[FLAT_MEMO_REC]; };
+  struct FlatMemoSlot { int64_t id = -1; uint32_t gen = 0; int32_t held = 0; alignas(8) unsigned char rec[FLAT_MEMO_REC] = {}; };
+  uint32_t flat_memo_gen_ = 0;  // the generation the current key's records carry (0: no slot is valid)
   std::vector<FlatMemoSlot> flat_memo_;  // (empty until the first for_each_flat_memo: 5 MB)
   MemoKey flat_memo_key_{{0, 0, 0, 0}};
   size_t flat_memo_rec_ = 0;

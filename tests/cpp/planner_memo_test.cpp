@@ -50,7 +50,7 @@ int main() {
   std::vector<Rec> want(ids.size());
   P.for_each_flat(ids.data(), (int64_t)ids.size(), [&](int64_t i, const rgpu_term_state& s, float idf) { want[(size_t)i] = Rec{s.doc_start_fp, s.doc_freq, idf, 0}; });
 
-  uint64_t stamp = 1;
+  uint64_t stamp = 1, min_stamp = 0;   // every record handed out was made under the current key: its stamp is at least min_stamp
   std::map<int64_t, int> made;  // fp -> how often `make` ran for it under the current key
   auto run = [&](const rucene::BatchPlanner::MemoKey& key, int64_t refuse_fp) {
     size_t seen = 0;
@@ -64,7 +64,7 @@ int main() {
       const Rec& w = want[(size_t)i];
       if (w.df <= 0) { CHECK(r == nullptr); return; }
       CHECK(r != nullptr);
-      if (r) CHECK(r->fp == w.fp && r->df == w.df && r->idf == w.idf && r->stamp <= stamp);
+      if (r) CHECK(r->fp == w.fp && r->df == w.df && r->idf == w.idf && r->stamp <= stamp && r->stamp >= min_stamp);
     });
     if (ok) CHECK(seen == ids.size());
     return ok;
@@ -84,15 +84,24 @@ int main() {
   made.clear();
   ++stamp;
   const uint64_t stamp2 = stamp;
+  min_stamp = stamp;
   CHECK(run(k2, -1));
   CHECK(made.size() == distinct);
   P.for_each_flat_memo<Rec>(ids.data(), 1, k2, [&](const rgpu_term_state&, float, Rec*) -> int32_t { CHECK(false); return 1; },
                             [&](int64_t, const Rec* r) { CHECK(r && r->stamp == stamp2); });
+  // keys that change in front of every call (other batches keep preparing terms): a record of an earlier key never comes back
+  for (uint64_t i = 0; i < 60; ++i) {
+    ++stamp;
+    min_stamp = stamp;
+    CHECK(run(rucene::BatchPlanner::MemoKey{{9, i & 1, 0, 0}}, -1));
+  }
   // a refusal: false at once, and the refused term is not kept (the next pass makes it)
   const int64_t refuse = want[ids.size() - 6].fp;   // (the last hot-set id: held)
   CHECK(want[ids.size() - 6].df > 0);
   made.clear();
   const rucene::BatchPlanner::MemoKey k3{{8, 1, 0, 0}};
+  ++stamp;
+  min_stamp = stamp;
   CHECK(!run(k3, refuse));
   CHECK(made.count(refuse) == 0);
   CHECK(run(k3, -1));
