@@ -154,6 +154,7 @@ HOISTED = [
     ("one_stream_ms_per_step", "one_stream_ms_per_step"), ("two_calls_ms_per_step", "streams.ms_two_calls_two_streams"),
     ("fused_same_rows_as_two_calls", "fused_same_rows_as_two_calls"), ("resident_plan_ms_per_step", "streams.ms_resident_plan_two_streams"),
     ("kernel_plus_merge_ms", "kernel_plus_merge_ms"), ("step_over_kernels", "step_over_kernels"),
+    ("sustained_queries_per_sec", "sustained.queries_per_sec"), ("sustained_ms_per_step", "sustained.ms_per_step"), ("sustained_seconds", "sustained.seconds"),
 ]
 LINE_REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                  "dtype", "data", "config", "roofline")
@@ -452,6 +453,22 @@ def main():
             res["regions"]["ms_object_planner_one_stream"] = timed(1, "objects", max(3, steps // 4), 3)
         for name, reg in res["regions"].items():
             res[name] = reg["median"]
+        if full and not dist_mode:
+            # ... and the same step for about 2.5 s on end (the regions above are 0.5 ms long each: a GPU-busy sampler never sees them, and
+            # clocks / thermals have no time to settle): the sustained rate next to the median region. One process, so the number of
+            # steps may follow this box's step time.
+            n_sus = int(min(400_000, max(1000, 2500.0 / res["ms_planned_two_streams"])))
+            gc.collect()
+            gc.disable()
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(n_sus):
+                step_fused(2)
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t
+            gc.enable()
+            res["sustained"] = {"steps": n_sus, "seconds": el, "ms_per_step": 1e3 * el / n_sus, "queries_per_sec": nq * n_sus / el,
+                                "note": "the headline's planned two-stream step back to back, one timed region of `steps` steps"}
         # isolated kernel durations: the same steps (the call the timed regions make) on ONE stream with HIP events around every launch
         ctx.set_profiling(True)
         ctx.kernel_stats_reset()
@@ -754,6 +771,8 @@ def main():
         if full:
             out["streams"] = {k2: r[k2] for k2 in ("ms_planned_two_streams", "ms_planned_one_stream", "ms_two_calls_two_streams", "ms_two_calls_one_stream",
                                                    "ms_resident_plan_two_streams", "ms_resident_plan_one_stream", "ms_object_planner_one_stream")}
+            if "sustained" in r:
+                out["sustained"] = r["sustained"]
             out["streams"]["min_median_max"] = {k2: [v["min"], v["median"], v["max"]] for k2, v in r["regions"].items()}
             out["streams"]["note"] = ("ms per step. planned = term ids -> rows in ONE call per step (rgpu_planner_search_uniform_ids_device: term states, BM25 "
                                       "weights, device descriptors, three enqueues) — the headline; two calls = rgpu_plan_uniform_ids then "
@@ -1095,6 +1114,8 @@ def main():
     out["step_over_kernels_one_stream"] = head["streams"]["ms_planned_one_stream"] / kp if kp > 0 else None
     out["fused_same_rows_as_two_calls"] = head["fused_same_rows_as_two_calls"]
     out["one_stream_ms_per_step"] = head["streams"]["ms_planned_one_stream"]
+    if "sustained" in head:
+        out["sustained"] = head["sustained"]
     out["one_stream_queries_per_sec"] = nq / (head["streams"]["ms_planned_one_stream"] * 1e-3)
     # N > 1: the batch is replicated, so the ranks together answer nq queries over an index of world x docs — that rate next to
     # `value` (whose unit is one query against one segment)
